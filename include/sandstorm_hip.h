@@ -1,0 +1,222 @@
+/* sandstorm_hip.h — C ABI of libsandstorm_hip.so
+ *
+ * The MI355X (gfx950) proving backend that slots behind Sandstorm's
+ * `sandstorm-cli prove` / ministark prover API.  The reference has no FFI for
+ * this path: its seams are Rust traits.  Each entry point below
+ * is what a `hip` cargo feature of ministark would bind in place of its Metal
+ * `gpu` feature, and cites the reference interface it replaces.  See
+ * INTEGRATION.md for the Rust-side `extern "C"` block.
+ *
+ * Conventions
+ *  - Field element: 4 x u64 little-endian limbs, Montgomery form, R = 2^256,
+ *    p = 2^251 + 17*2^192 + 1 — the in-memory image of the reference's `Fp`
+ *    (crypto/src/utils.rs:8-22).  "felt" below always means this 32-byte image.
+ *  - A matrix is column-major: one contiguous device array per column
+ *    (ministark `Matrix<F>` = Vec<GpuVec<F>>; layouts/src/recursive/trace.rs:652-660).
+ *    `cols` arguments are HOST arrays of DEVICE pointers.
+ *  - Digest: 32 raw bytes.  MixedMerkleDigest (crypto/src/merkle/mixed.rs:34-71)
+ *    additionally carries a tag byte: 0 = HighLevel (Pedersen felt as 32-byte
+ *    big-endian canonical, hash/pedersen.rs:23-28), 1 = LowLevel (Blake2s).
+ *  - Every pointer named d_* is device memory (from ss_dev_alloc, hipMalloc or a
+ *    torch tensor's data_ptr); every other pointer is host memory owned by the
+ *    caller for the duration of the call.
+ *  - Work is enqueued on the context's HIP stream; calls that return host data
+ *    synchronise that stream, the others do not (use ss_ctx_sync).
+ *  - Errors: integer status, never an exception/abort across the ABI; the text
+ *    is in ss_last_error() (thread-local).  The reference panics on any error
+ *    (cli/src/main.rs:201 `unwrap`), so a Rust shim `expect()`s on non-zero.
+ *  - One ctx per host thread and per GPU; no global mutable state.
+ */
+#ifndef SANDSTORM_HIP_H
+#define SANDSTORM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int ss_status;
+enum {
+    SS_OK = 0,
+    SS_ERR_INVALID = 1,     /* bad argument */
+    SS_ERR_HIP = 2,         /* HIP runtime error, see ss_last_error */
+    SS_ERR_NO_DEVICE = 3,   /* no gfx950 device / HIP extension unusable */
+    SS_ERR_UNSUPPORTED = 4
+};
+
+typedef struct ss_ctx ss_ctx;
+
+/* NTT direction / element order */
+enum { SS_NTT_FORWARD = 0, SS_NTT_INVERSE = 1 };
+enum { SS_ORDER_NATURAL = 0, SS_ORDER_BITREV = 1 };
+
+/* HashFn implementations of crypto/src/hash/{keccak,blake2s}.rs */
+enum {
+    SS_HASH_KECCAK = 0,       /* Keccak256HashFn           keccak.rs:13-59  */
+    SS_HASH_KECCAK_M20 = 1,   /* MaskedKeccak256HashFn<20> keccak.rs:61-98  */
+    SS_HASH_BLAKE2S = 2,      /* Blake2sHashFn             blake2s.rs:10-62 */
+    SS_HASH_BLAKE2S_M20 = 3   /* MaskedBlake2sHashFn<20>   blake2s.rs:64-100 */
+};
+/* Merkle tree types chosen by src/claims.rs:12-33 */
+enum {
+    SS_TREE_KECCAK = 0,       /* LeafVariantMerkleTree<Keccak256HashFn>           */
+    SS_TREE_KECCAK_M20 = 1,   /* LeafVariantMerkleTree<MaskedKeccak256HashFn<20>> */
+    SS_TREE_FRIENDLY = 2      /* FriendlyMerkleTree<N, PedersenHashFn>            */
+};
+enum { SS_LEAF_DIGEST = 0, SS_LEAF_FELT = 1 };
+enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
+
+const char *ss_last_error(void);
+/* ABI version of this header; bump on any signature change. */
+uint32_t ss_abi_version(void);
+
+/* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;
+ *      call sites src/lib.rs:27-28, layouts/src/recursive/trace.rs:115-120) */
+ss_status ss_ctx_create(int device, ss_ctx **out);
+void ss_ctx_destroy(ss_ctx *ctx);
+ss_status ss_ctx_set_stream(ss_ctx *ctx, void *hip_stream); /* NULL = ctx-owned stream */
+ss_status ss_ctx_sync(ss_ctx *ctx);
+ss_status ss_dev_alloc(ss_ctx *ctx, size_t bytes, void **d_out);
+ss_status ss_dev_free(ss_ctx *ctx, void *d_ptr);
+ss_status ss_upload(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+ss_status ss_download(ss_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+
+/* ---- N1/N2: ministark Matrix::interpolate / Matrix::evaluate (un-vendored;
+ *      call sites src/lib.rs:17-26; convention pinned by
+ *      builtins/src/pedersen/periodic.rs:1183-1209).
+ * In-place NTT of `ncols` columns of 2^log_n felts over offset*<w>, w =
+ * 3^((p-1)/2^log_n).  FORWARD: coefficients -> evaluations; INVERSE:
+ * evaluations -> coefficients (includes 1/n and offset^-i).  `offset` is a
+ * Montgomery felt (NULL = 1).  in_order/out_order select natural or
+ * bit-reversed indexing of the array on entry/exit. */
+ss_status ss_ntt_fp252(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, uint32_t log_n,
+                       int direction, const uint64_t offset[4], int in_order, int out_order);
+
+/* Low-degree extension of `ncols` columns (pipeline steps 3+4 / 8 / 10 of
+ * SURVEY §3.1): interpolate over <w_n>, evaluate over offset*<w_{n*2^log_blowup}>.
+ * d_evals[c]: 2^(log_n+log_blowup) felts, natural order.
+ * d_coeffs (may be NULL) / d_coeffs[c]: 2^log_n felts, the interpolant's
+ * coefficients in BIT-REVERSED index order (kept for OOD/DEEP). d_in may alias
+ * d_coeffs column-wise, never d_evals. */
+ss_status ss_lde_fp252(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols, uint32_t log_n,
+                       uint32_t log_blowup, const uint64_t offset[4], uint64_t *const *d_evals,
+                       uint64_t *const *d_coeffs);
+
+/* ---- H1: crypto/src/merkle/utils.rs:19-46 hash_rows::<H>.
+ * d_digests[r] = H::hash_elements(row r) for r < nrows; rows are read in
+ * natural index order from the column arrays. */
+ss_status ss_hash_rows(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_cols, uint32_t ncols,
+                       uint64_t nrows, uint8_t *d_digests);
+
+/* ---- H2/H3/H4: MatrixMerkleTree::from_matrix tree build
+ *      (crypto/src/merkle/mod.rs:110-123, 289-304; node rules mixed.rs:106-155,
+ *      mod.rs:419-437; builder ministark MerkleTreeImpl::new, un-vendored).
+ * leaves: n digests (SS_LEAF_DIGEST) or n felts (SS_LEAF_FELT, single-column
+ * matrices).  d_nodes: 2n x 32 bytes, heap layout: node k has children 2k,
+ * 2k+1; root at index 1; leaf i at n+i (felt leaves stored as Montgomery-BE
+ * bytes).  d_tags (SS_TREE_FRIENDLY only, may be NULL): 2n tag bytes.
+ * root_out[0..32) digest, root_out[32] tag. */
+ss_status ss_merkle_build(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_layers, int leaf_kind,
+                          const void *d_leaves, uint64_t n, uint8_t *d_nodes, uint8_t *d_tags,
+                          uint8_t root_out[33]);
+/* MerkleTree::prove: authentication paths for `nidx` leaf indices.
+ * out: nidx * log2(n) sibling digests (leaf level first), 32 bytes each;
+ * out_tags (may be NULL) the matching tag bytes. */
+ss_status ss_merkle_open(ss_ctx *ctx, const uint8_t *d_nodes, const uint8_t *d_tags, uint64_t n,
+                         const uint64_t *idx, uint32_t nidx, uint8_t *out, uint8_t *out_tags);
+/* gather full rows `idx` of a column-major matrix to the host (query phase) */
+ss_status ss_gather_rows(ss_ctx *ctx, const uint64_t *const *d_cols, uint32_t ncols,
+                         const uint64_t *idx, uint32_t nidx, uint64_t *out /* nidx*ncols felts */);
+
+/* ---- Q1: AirConfig::eval_constraint over the LDE domain (ministark default
+ *      body; DAG built by layouts/src/{recursive,starknet}/air.rs).
+ * The Rust side lowers its `Expr` DAG once per (layout, n) into this program
+ * for a 4-accumulator register machine (two-address, one instruction = 2 x u32):
+ *   word0: [7:0] opcode, [11:8] dst accumulator, [15:12] operand kind
+ *   word1: operand payload
+ * The program is executed once per LDE point i (x_i = offset * w_N^i). */
+enum {
+    SS_OP_MOV = 0,   /* acc[d] = src            */
+    SS_OP_ADD = 1,   /* acc[d] = acc[d] + src   */
+    SS_OP_SUB = 2,   /* acc[d] = acc[d] - src   */
+    SS_OP_RSUB = 3,  /* acc[d] = src - acc[d]   */
+    SS_OP_MUL = 4,   /* acc[d] = acc[d] * src   */
+    SS_OP_INV = 5,   /* acc[d] = 1 / acc[d]  (0 -> 0), operand ignored */
+    SS_OP_ST = 6,    /* slot[payload] = acc[d]  */
+    SS_OP_OUT = 7    /* out[i] = acc[d]         */
+};
+enum {
+    SS_SRC_ACC = 0,    /* payload = accumulator index                                  */
+    SS_SRC_SLOT = 1,   /* payload = slot index (per-point scratch)                     */
+    SS_SRC_CONST = 2,  /* payload = index into consts (challenges, hints, alpha^k ...) */
+    SS_SRC_TRACE = 3,  /* payload = col << 24 | row_offset: lde[col][(i + (row_offset << log_blowup)) mod N] */
+    SS_SRC_TABLE = 4,  /* payload = table index: tables[desc.offset + (i mod 2^desc.log_len)]
+                          (periodic columns and X^(n/k) zerofier inverses are periodic in i) */
+    SS_SRC_X = 5       /* x_i */
+};
+#define SS_INSTR(op, dst, kind, payload) ((uint32_t)(op) | ((uint32_t)(dst) << 8) | ((uint32_t)(kind) << 12)), ((uint32_t)(payload))
+typedef struct ss_air_program {
+    const uint32_t *code;        /* 2 * n_instr words (host) */
+    uint32_t n_instr;
+    const uint64_t *consts;      /* n_consts felts (host) */
+    uint32_t n_consts;
+    const uint64_t *d_tables;    /* device: concatenated tables of felts */
+    const uint32_t *table_desc;  /* host: 2 * n_tables words: {offset in felts, log_len} */
+    uint32_t n_tables;
+    uint32_t n_slots;            /* scratch slots used by ST / SS_SRC_SLOT */
+} ss_air_program;
+ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
+                           uint32_t ncols, uint32_t log_n, uint32_t log_blowup,
+                           const uint64_t offset[4], uint64_t *d_out);
+
+/* ---- D1: out-of-domain evaluations + DEEP composition (ministark
+ *      DeepPolyComposer, un-vendored; coefficient rule src/lib.rs:102-116).
+ * ss_ood_eval: out[j] = T_{mask_col[j]}(z * w_n^{mask_off[j]}) from the
+ * bit-reversed coefficient columns kept by ss_lde_fp252. */
+ss_status ss_ood_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t ncols, uint32_t log_n,
+                      const uint32_t *mask_col, const uint32_t *mask_off, uint32_t nmask,
+                      const uint64_t z[4], uint64_t *out /* nmask felts, host */);
+/* ss_poly_eval: out[c] = P_c(x) for bit-reversed coefficient columns. */
+ss_status ss_poly_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t ncols, uint32_t log_n,
+                       const uint64_t x[4], uint64_t *out /* ncols felts, host */);
+/* d_out[i] = sum_j coeff_trace[j] (T_{col_j}(x_i) - ood_trace[j]) / (x_i - z w_n^{off_j})
+ *          + sum_k coeff_comp[k]  (H_k(x_i)      - ood_comp[k])  / (x_i - z^ncomp)
+ * for every x_i = offset * w_N^i of the LDE domain, natural order. */
+ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_t ntrace_cols,
+                          const uint64_t *const *d_comp_lde, uint32_t ncomp, uint32_t log_n,
+                          uint32_t log_blowup, const uint64_t offset[4], const uint32_t *mask_col,
+                          const uint32_t *mask_off, uint32_t nmask, const uint64_t *ood_trace,
+                          const uint64_t *coeff_trace, const uint64_t *ood_comp,
+                          const uint64_t *coeff_comp, const uint64_t z[4], uint64_t *d_out);
+
+/* ---- F1: one FRI layer fold (ministark FriProver::build_layers, un-vendored;
+ *      defaults cli/src/main.rs:57-60).  d_evals: 2^log_len felts on
+ *      domain_offset*<w>, natural order; row j = {evals[j + k*len/fold]};
+ *      d_out[j] = degree<fold interpolant of row j evaluated at alpha.
+ *      fold in {2,4,8,16}.  The next layer's offset is domain_offset^fold.
+ * ss_fri_layer_matrix writes the fold-column matrix whose rows get committed
+ * (column k = evals[k*len/fold ..]) as pointers into d_evals (no copy). */
+ss_status ss_fri_fold(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
+                      const uint64_t alpha[4], const uint64_t domain_offset[4], uint64_t *d_out);
+
+/* ---- C2: PublicCoin::grind_proof_of_work (crypto/src/public_coin/
+ *      solidity.rs:120-141, cairo.rs:133-154).  Returns the SMALLEST nonce >= 1
+ *      (the reference's non-parallel `find` semantics, solidity.rs:138). */
+ss_status ss_pow_grind(ss_ctx *ctx, int coin_kind, const uint8_t digest[32], uint32_t bits,
+                       uint64_t *nonce_out);
+
+/* ---- builtins/src/pedersen/mod.rs:31-36 pedersen_hash, batched on device:
+ *      d_out[i] = pedersen_hash(d_a[i], d_b[i]) (Montgomery felts in and out). */
+ss_status ss_pedersen_hash(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t n,
+                           uint64_t *d_out);
+
+/* ---- micro-benchmark hook: d_out[i] = d_a[i] * d_b[i] repeated `reps` times
+ *      (dependent chain), used by bench.py to report mulmod/s. */
+ss_status ss_fp252_mul_bench(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t n,
+                             uint32_t reps, uint64_t *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,72 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see fp252.h).
+ *
+ * Rows F1 and D1 of SURVEY.md §8(a).  Both live in the un-vendored ministark
+ * (FriProver::build_layers, DeepPolyComposer; git 875fb385) and are called with
+ * the reference's defaults fri_folding_factor = 8, fri_max_remainder_coeffs =
+ * 16 (cli/src/main.rs:57-60) and the DEEP coefficient rule of
+ * src/lib.rs:102-116 (powers of one alpha, degree adjustment (1,0) = none).
+ * PARITY UNPINNED: restated from the mathematical
+ * definition, written as naive O(fold^2) sums on purpose so that the HIP
+ * butterflies are checked against something structurally different.
+ */
+#include "oracle.h"
+#include <stdlib.h>
+
+void or_fri_fold(const fp_t *evals, unsigned log_len, unsigned fold, fp_t alpha, fp_t offset,
+                 fp_t *out) {
+    size_t len = (size_t)1 << log_len, rows = len / fold;
+    unsigned log_fold = 0;
+    while ((1u << log_fold) < fold) ++log_fold;
+    fp_t w = fp_root_of_unity(log_len);
+    fp_t wf_inv = fp_inv(fp_root_of_unity(log_fold));
+    fp_t fold_inv = fp_inv(fp_from_u64(fold));
+    /* table of wf_inv^e, e < fold */
+    fp_t wfp[64];
+    wfp[0] = FP_ONE;
+    for (unsigned e = 1; e < fold; ++e) wfp[e] = fp_mul(wfp[e - 1], wf_inv);
+#pragma omp parallel for schedule(static) if (rows >= 256)
+    for (size_t j = 0; j < rows; ++j) {
+        fp_t xj = fp_mul(offset, fp_pow_u64(w, (uint64_t)j));
+        fp_t t = fp_mul(alpha, fp_inv(xj)); /* alpha / x_j */
+        fp_t acc = {{0, 0, 0, 0}}, tm = FP_ONE;
+        for (unsigned m = 0; m < fold; ++m) {
+            /* c_m * x_j^m = (1/fold) sum_k v_k wf^(-k m) */
+            fp_t s = {{0, 0, 0, 0}};
+            for (unsigned k = 0; k < fold; ++k)
+                s = fp_add(s, fp_mul(evals[j + k * rows], wfp[(k * m) % fold]));
+            acc = fp_add(acc, fp_mul(fp_mul(s, fold_inv), tm));
+            tm = fp_mul(tm, t);
+        }
+        out[j] = acc;
+    }
+}
+
+void or_deep_compose(const fp_t *const *trace_lde, const fp_t *const *comp_lde, unsigned log_n,
+                     unsigned log_blowup, fp_t offset, const uint32_t *mask_col,
+                     const uint32_t *mask_off, size_t nmask, const fp_t *ood_trace,
+                     const fp_t *coeff_trace, size_t ncomp, const fp_t *ood_comp,
+                     const fp_t *coeff_comp, fp_t z, fp_t *out) {
+    unsigned log_N = log_n + log_blowup;
+    size_t N = (size_t)1 << log_N;
+    fp_t wn = fp_root_of_unity(log_n), wN = fp_root_of_unity(log_N);
+    fp_t *zs = (fp_t *)malloc(sizeof(fp_t) * (nmask ? nmask : 1));
+    for (size_t j = 0; j < nmask; ++j) zs[j] = fp_mul(z, fp_pow_u64(wn, mask_off[j]));
+    fp_t zc = fp_pow_u64(z, (uint64_t)ncomp);
+#pragma omp parallel for schedule(static) if (N >= 256)
+    for (size_t i = 0; i < N; ++i) {
+        fp_t x = fp_mul(offset, fp_pow_u64(wN, (uint64_t)i));
+        fp_t acc = {{0, 0, 0, 0}};
+        for (size_t j = 0; j < nmask; ++j) {
+            fp_t num = fp_sub(trace_lde[mask_col[j]][i], ood_trace[j]);
+            fp_t den = fp_inv(fp_sub(x, zs[j]));
+            acc = fp_add(acc, fp_mul(coeff_trace[j], fp_mul(num, den)));
+        }
+        fp_t denc = fp_inv(fp_sub(x, zc));
+        for (size_t k = 0; k < ncomp; ++k) {
+            fp_t num = fp_sub(comp_lde[k][i], ood_comp[k]);
+            acc = fp_add(acc, fp_mul(coeff_comp[k], fp_mul(num, denc)));
+        }
+        out[i] = acc;
+    }
+    free(zs);
+}

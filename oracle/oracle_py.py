@@ -1,0 +1,282 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/_build/liboracle.so (the CPU restatement of the
+reference's hot path, see oracle/oracle.h).  Importable only from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg.  Never imported by
+the sandstorm_amd package.
+
+Field elements cross this boundary as numpy uint64 arrays of shape (..., 4):
+little-endian limbs, Montgomery form (R = 2^256) — the same image the HIP
+library uses.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+
+P = 2**251 + 17 * 2**192 + 1
+R = 2**256
+R_MOD_P = R % P
+R_INV = pow(R, -1, P)
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class _FP(C.Structure):
+    _fields_ = [("l", C.c_uint64 * 4)]
+
+
+class _Coin(C.Structure):
+    _fields_ = [("kind", C.c_int), ("digest", C.c_uint8 * 32), ("counter", C.c_uint64)]
+
+
+class AirProgram(C.Structure):
+    """Mirror of ss_air_program (include/sandstorm_hip.h)."""
+    _fields_ = [("code", C.POINTER(C.c_uint32)), ("n_instr", C.c_uint32),
+                ("consts", C.POINTER(C.c_uint64)), ("n_consts", C.c_uint32),
+                ("d_tables", C.POINTER(C.c_uint64)), ("table_desc", C.POINTER(C.c_uint32)),
+                ("n_tables", C.c_uint32), ("n_slots", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.or_init()
+        _lib.or_pedersen_hash.restype = _FP
+        _lib.or_pedersen_hash.argtypes = [_FP, _FP]
+        _lib.or_pedersen_hash_elements.restype = _FP
+        _lib.or_poly_eval.restype = _FP
+        _lib.or_coin_draw.restype = _FP
+        _lib.or_coin_grind.restype = C.c_uint64
+        _lib.or_coin_grind.argtypes = [C.POINTER(_Coin), C.c_uint]
+        _lib.or_coin_verify_pow.argtypes = [C.POINTER(_Coin), C.c_uint, C.c_uint64]
+    return _lib
+
+
+# ---------------------------------------------------------------- conversions
+def to_mont(v):
+    """python int(s) -> uint64[..., 4] Montgomery limbs."""
+    a = np.asarray(v, dtype=object)
+    flat = [((int(x) % P) * R_MOD_P) % P for x in a.reshape(-1)]
+    out = np.zeros((len(flat), 4), dtype=np.uint64)
+    for i, x in enumerate(flat):
+        for k in range(4):
+            out[i, k] = (x >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return out.reshape(a.shape + (4,))
+
+
+def from_mont(arr):
+    """uint64[..., 4] Montgomery limbs -> object array of python ints (canonical)."""
+    a = np.asarray(arr, dtype=np.uint64)
+    flat = a.reshape(-1, 4)
+    out = np.empty(len(flat), dtype=object)
+    for i, row in enumerate(flat):
+        x = sum(int(row[k]) << (64 * k) for k in range(4))
+        out[i] = (x * R_INV) % P
+    return out.reshape(a.shape[:-1])
+
+
+def _fp(limbs):
+    f = _FP()
+    for k in range(4):
+        f.l[k] = int(limbs[k])
+    return f
+
+
+def _fp_out(f):
+    return np.array([f.l[k] for k in range(4)], dtype=np.uint64)
+
+
+def _ptr(a, ty=C.c_void_p):
+    return a.ctypes.data_as(ty)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+# ------------------------------------------------------------------------ NTT
+def ntt(col, inverse=False, offset=None):
+    """natural-order in/out NTT of one column (n,4) over offset*<w_n>."""
+    a = _c(col).copy()
+    log_n = (a.shape[0]).bit_length() - 1
+    off = _fp(offset) if offset is not None else None
+    fn = lib().or_ntt_inverse if inverse else lib().or_ntt_forward
+    fn(_ptr(a), C.c_uint(log_n), C.byref(off) if off is not None else None)
+    return a
+
+
+def bitrev_permute(col):
+    a = _c(col).copy()
+    lib().or_bitrev_permute(_ptr(a), C.c_uint(a.shape[0].bit_length() - 1))
+    return a
+
+
+def lde(col, log_blowup, offset):
+    a = _c(col)
+    n = a.shape[0]
+    log_n = n.bit_length() - 1
+    ev = np.zeros((n << log_blowup, 4), dtype=np.uint64)
+    co = np.zeros((n, 4), dtype=np.uint64)
+    off = _fp(offset)
+    lib().or_lde(_ptr(a), C.c_uint(log_n), C.c_uint(log_blowup), C.byref(off), _ptr(ev), _ptr(co))
+    return ev, co
+
+
+def poly_eval(coeffs, x):
+    a = _c(coeffs)
+    return _fp_out(lib().or_poly_eval(_ptr(a), C.c_size_t(a.shape[0]), _fp(x)))
+
+
+# --------------------------------------------------------------------- hashes
+def keccak256(data: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().or_keccak256(data, C.c_size_t(len(data)), out)
+    return bytes(out)
+
+
+def blake2s256(data: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().or_blake2s256(data, C.c_size_t(len(data)), out)
+    return bytes(out)
+
+
+def hash_rows(kind, cols):
+    """cols: list of (n,4) arrays -> (n,32) uint8 digests."""
+    cols = [_c(c) for c in cols]
+    n = cols[0].shape[0]
+    ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+    out = np.zeros((n, 32), dtype=np.uint8)
+    lib().or_hash_rows(C.c_int(kind), ptrs, C.c_size_t(len(cols)), C.c_size_t(n), _ptr(out))
+    return out
+
+
+def pedersen_hash(a, b):
+    return _fp_out(lib().or_pedersen_hash(_fp(a), _fp(b)))
+
+
+def pedersen_hash_elements(elems):
+    a = _c(elems)
+    return _fp_out(lib().or_pedersen_hash_elements(_ptr(a), C.c_size_t(a.shape[0])))
+
+
+def pedersen_doublings(k, count):
+    xs = np.zeros((count, 4), dtype=np.uint64)
+    ys = np.zeros((count, 4), dtype=np.uint64)
+    lib().or_pedersen_doublings(C.c_int(k), C.c_size_t(count), _ptr(xs), _ptr(ys))
+    return xs, ys
+
+
+# --------------------------------------------------------------------- merkle
+def merkle_build(tree, n_friendly, leaf_kind, leaves):
+    """leaves: (n,32) uint8 digests or (n,4) uint64 felts -> (nodes (2n,32) u8, tags (2n,) u8)."""
+    lv = np.ascontiguousarray(leaves)
+    n = lv.shape[0]
+    nodes = np.zeros((2 * n, 32), dtype=np.uint8)
+    tags = np.zeros(2 * n, dtype=np.uint8)
+    lib().or_merkle_build(C.c_int(tree), C.c_uint(n_friendly), C.c_int(leaf_kind), _ptr(lv),
+                          C.c_size_t(n), _ptr(nodes), _ptr(tags))
+    return nodes, tags
+
+
+# ----------------------------------------------------------------- FRI / DEEP
+def fri_fold(evals, fold, alpha, offset):
+    a = _c(evals)
+    n = a.shape[0]
+    out = np.zeros((n // fold, 4), dtype=np.uint64)
+    lib().or_fri_fold(_ptr(a), C.c_uint(n.bit_length() - 1), C.c_uint(fold), _fp(alpha),
+                      _fp(offset), _ptr(out))
+    return out
+
+
+def deep_compose(trace_lde, comp_lde, log_n, log_blowup, offset, mask_col, mask_off, ood_trace,
+                 coeff_trace, ood_comp, coeff_comp, z):
+    tl = [_c(c) for c in trace_lde]
+    cl = [_c(c) for c in comp_lde]
+    N = tl[0].shape[0]
+    tp = (C.c_void_p * len(tl))(*[c.ctypes.data for c in tl])
+    cp = (C.c_void_p * max(1, len(cl)))(*[c.ctypes.data for c in cl])
+    mc = np.ascontiguousarray(mask_col, dtype=np.uint32)
+    mo = np.ascontiguousarray(mask_off, dtype=np.uint32)
+    ot, ct, oc, cc = _c(ood_trace), _c(coeff_trace), _c(ood_comp), _c(coeff_comp)
+    out = np.zeros((N, 4), dtype=np.uint64)
+    lib().or_deep_compose(tp, cp, C.c_uint(log_n), C.c_uint(log_blowup), _fp(offset), _ptr(mc),
+                          _ptr(mo), C.c_size_t(len(mc)), _ptr(ot), _ptr(ct), C.c_size_t(len(cl)),
+                          _ptr(oc), _ptr(cc), _fp(z), _ptr(out))
+    return out
+
+
+# ----------------------------------------------------------------------- coin
+class Coin:
+    """kind 0 = SolidityVerifierPublicCoin, 1 = CairoVerifierPublicCoin."""
+
+    def __init__(self, kind, digest: bytes):
+        self.c = _Coin()
+        lib().or_coin_new(C.byref(self.c), C.c_int(kind), digest)
+
+    @property
+    def digest(self):
+        return bytes(self.c.digest)
+
+    @property
+    def counter(self):
+        return int(self.c.counter)
+
+    def reseed_bytes(self, b: bytes):
+        lib().or_coin_reseed_bytes(C.byref(self.c), b, C.c_size_t(len(b)))
+
+    def reseed_felts(self, v):
+        a = _c(v)
+        lib().or_coin_reseed_felts(C.byref(self.c), _ptr(a), C.c_size_t(a.shape[0]))
+
+    def reseed_felt_vector(self, v):
+        a = _c(v)
+        lib().or_coin_reseed_felt_vector(C.byref(self.c), _ptr(a), C.c_size_t(a.shape[0]))
+
+    def reseed_int(self, v):
+        lib().or_coin_reseed_int(C.byref(self.c), C.c_uint64(v))
+
+    def draw(self):
+        return _fp_out(lib().or_coin_draw(C.byref(self.c)))
+
+    def draw_queries(self, max_n, domain_size):
+        out = np.zeros(max_n, dtype=np.uint64)
+        lib().or_coin_draw_queries(C.byref(self.c), C.c_size_t(max_n), C.c_uint64(domain_size), _ptr(out))
+        return sorted(set(int(x) for x in out))
+
+    def grind(self, bits):
+        return int(lib().or_coin_grind(C.byref(self.c), C.c_uint(bits)))
+
+    def verify_pow(self, bits, nonce):
+        return bool(lib().or_coin_verify_pow(C.byref(self.c), C.c_uint(bits), C.c_uint64(nonce)))
+
+
+# ------------------------------------------------------------------- quotient
+def eval_program(code, consts, tables, table_desc, n_slots, lde_cols, log_n, log_blowup, offset):
+    code = np.ascontiguousarray(code, dtype=np.uint32)
+    consts = _c(consts) if len(consts) else np.zeros((1, 4), dtype=np.uint64)
+    tables = _c(tables) if len(tables) else np.zeros((1, 4), dtype=np.uint64)
+    desc = np.ascontiguousarray(table_desc, dtype=np.uint32) if len(table_desc) else np.zeros(2, dtype=np.uint32)
+    cols = [_c(c) for c in lde_cols]
+    N = cols[0].shape[0]
+    prog = AirProgram(code.ctypes.data_as(C.POINTER(C.c_uint32)), len(code) // 2,
+                      consts.ctypes.data_as(C.POINTER(C.c_uint64)), consts.shape[0],
+                      None, desc.ctypes.data_as(C.POINTER(C.c_uint32)), len(desc) // 2, n_slots)
+    cp = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+    out = np.zeros((N, 4), dtype=np.uint64)
+    lib().or_eval_program_ex(C.byref(prog), _ptr(tables), cp, C.c_uint(log_n), C.c_uint(log_blowup),
+                             _fp(offset), _ptr(out))
+    return out

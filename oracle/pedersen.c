@@ -1,0 +1,121 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see fp252.h).
+ *
+ * Pedersen hash over the StarkWare curve y^2 = x^3 + x + beta.  The reference
+ * delegates to the un-vendored starknet-crypto 0.6.1 (Cargo.lock:1565-1566;
+ * builtins/src/pedersen/mod.rs:31-36); this restates the published definition
+ * quoted at mod.rs:25-30:
+ *     H(a,b) = [P0 + a_low*P1 + a_high*P2 + b_low*P3 + b_high*P4].x
+ * with a_low the 248 low bits and a_high the 4 high bits of the canonical
+ * value.  P0..P4 are the StarkWare constants (builtins/src/pedersen/
+ * constants.rs:5-30).  Pinned by hash_example0/1_works (mod.rs:183-211) and
+ * the doubling-chain KAT (constants.rs:2064-2093) — tests/golden/pedersen.json.
+ */
+#include "oracle.h"
+#include <stdlib.h>
+
+typedef struct { fp_t x, y; } aff_t;
+typedef struct { fp_t x, y, z; int inf; } jac_t;
+
+static const uint64_t PED_CANON[5][2][4] = {
+    /* P0 */ {{0x551fde4050ca6804ull, 0x716b0b1022947733ull, 0x00ee1b87eb599f16ull, 0x049ee3eba8c16007ull}, {0xd0405d266e10268aull, 0x4e621062c0e056c1ull, 0xf346d49d06ea0ed3ull, 0x03ca0cfe4b3bc6ddull}},
+    /* P1 */ {{0x1080d17957ebe47bull, 0x8fa8120b6d56eb0cull, 0x969c748655fca9e5ull, 0x0234287dcbaffe7full}, {0x6ed0268ee89e5615ull, 0x940135dd7a6c94ccull, 0x1e889527d41f4e39ull, 0x03b056f100f96fb2ull}},
+    /* P2 */ {{0xb7a6932dba8aa378ull, 0x99099ec1de5e3018ull, 0x3f9dab2656558f33ull, 0x04fa56f376c83db3ull}, {0x5168f4e80ff5b54dull, 0x562761f92a7a23b4ull, 0x8113e0c0e47e4401ull, 0x03fa0984c931c9e3ull}},
+    /* P3 */ {{0x3aa372f0bd2d6997ull, 0x40c690c74709e90full, 0x764910f75b45f74bull, 0x04ba4cc166be8decull}, {0x48151f27b24b219cull, 0xcac5c59a5ce5ae7cull, 0x4b971e46c4ede85full, 0x0040301cf5c1751full}},
+    /* P4 */ {{0xd36ff12c49a58202ull, 0x2ca65048d53fb325ull, 0x6e44cca8f61a63bbull, 0x054302dcb0e6cc1cull}, {0x879dcc77e99c2426ull, 0xce98ad783c25561aull, 0xb348046268d8ae25ull, 0x01b77b3e37d13504ull}},
+};
+
+static aff_t PED_P[5];
+/* doubling tables: DBL[k][i] = 2^i * P_{k+1}, k = 0..3, i < 248 (k even) or 4 (k odd) */
+static aff_t *PED_DBL[4];
+static int ped_ready = 0;
+
+static jac_t jac_from_aff(aff_t p) { jac_t r = {p.x, p.y, FP_ONE, 0}; return r; }
+
+static jac_t jac_double(jac_t p) {
+    if (p.inf || fp_is_zero(p.y)) { jac_t o = {FP_ONE, FP_ONE, {{0,0,0,0}}, 1}; return o; }
+    /* a = 1: M = 3X^2 + Z^4 */
+    fp_t xx = fp_mul(p.x, p.x), yy = fp_mul(p.y, p.y), yyyy = fp_mul(yy, yy), zz = fp_mul(p.z, p.z);
+    fp_t s = fp_mul(p.x, yy); s = fp_add(s, s); s = fp_add(s, s);            /* 4XY^2 */
+    fp_t m = fp_add(fp_add(xx, xx), xx); m = fp_add(m, fp_mul(zz, zz));
+    jac_t r; r.inf = 0;
+    r.x = fp_sub(fp_mul(m, m), fp_add(s, s));
+    fp_t e = fp_add(yyyy, yyyy); e = fp_add(e, e); e = fp_add(e, e);          /* 8Y^4 */
+    r.y = fp_sub(fp_mul(m, fp_sub(s, r.x)), e);
+    r.z = fp_mul(p.y, p.z); r.z = fp_add(r.z, r.z);
+    return r;
+}
+
+static jac_t jac_add_aff(jac_t p, aff_t q) {
+    if (p.inf) return jac_from_aff(q);
+    fp_t zz = fp_mul(p.z, p.z);
+    fp_t u2 = fp_mul(q.x, zz), s2 = fp_mul(q.y, fp_mul(zz, p.z));
+    fp_t h = fp_sub(u2, p.x), rr = fp_sub(s2, p.y);
+    if (fp_is_zero(h)) {
+        if (fp_is_zero(rr)) return jac_double(p);
+        jac_t o = {FP_ONE, FP_ONE, {{0,0,0,0}}, 1}; return o;
+    }
+    fp_t hh = fp_mul(h, h), hhh = fp_mul(hh, h), v = fp_mul(p.x, hh);
+    jac_t r; r.inf = 0;
+    r.x = fp_sub(fp_sub(fp_mul(rr, rr), hhh), fp_add(v, v));
+    r.y = fp_sub(fp_mul(rr, fp_sub(v, r.x)), fp_mul(p.y, hhh));
+    r.z = fp_mul(p.z, h);
+    return r;
+}
+
+static aff_t jac_to_aff(jac_t p) {
+    fp_t zi = fp_inv(p.z), zi2 = fp_mul(zi, zi);
+    aff_t r = {fp_mul(p.x, zi2), fp_mul(p.y, fp_mul(zi2, zi))};
+    return r;
+}
+
+static void ped_init(void) {
+    if (ped_ready) return;
+    fp_init();
+    for (int k = 0; k < 5; ++k) {
+        PED_P[k].x = fp_from_canonical(PED_CANON[k][0]);
+        PED_P[k].y = fp_from_canonical(PED_CANON[k][1]);
+    }
+    for (int k = 0; k < 4; ++k) {
+        int cnt = (k & 1) ? 4 : 248;
+        PED_DBL[k] = (aff_t *)malloc(sizeof(aff_t) * cnt);
+        jac_t acc = jac_from_aff(PED_P[k + 1]);
+        for (int i = 0; i < cnt; ++i) {
+            PED_DBL[k][i] = jac_to_aff(acc);
+            acc = jac_double(acc);
+        }
+    }
+    ped_ready = 1;
+}
+
+void or_pedersen_doublings(int k, size_t count, fp_t *xs, fp_t *ys) {
+    ped_init();
+    jac_t acc = jac_from_aff(PED_P[k]);
+    for (size_t i = 0; i < count; ++i) {
+        aff_t a = jac_to_aff(acc);
+        xs[i] = a.x; ys[i] = a.y;
+        acc = jac_double(acc);
+    }
+}
+
+fp_t or_pedersen_hash(fp_t a, fp_t b) {
+    ped_init();
+    jac_t acc = jac_from_aff(PED_P[0]);
+    fp_t in[2] = {a, b};
+    for (int e = 0; e < 2; ++e) {
+        uint64_t c[4];
+        fp_to_canonical(in[e], c);
+        for (int i = 0; i < 252; ++i) {
+            if ((c[i >> 6] >> (i & 63)) & 1) {
+                aff_t q = i < 248 ? PED_DBL[2 * e][i] : PED_DBL[2 * e + 1][i - 248];
+                acc = jac_add_aff(acc, q);
+            }
+        }
+    }
+    return jac_to_aff(acc).x;
+}
+
+fp_t or_pedersen_hash_elements(const fp_t *e, size_t n) {
+    fp_t cur = {{0, 0, 0, 0}};
+    for (size_t i = 0; i < n; ++i) cur = or_pedersen_hash(cur, e[i]);
+    return or_pedersen_hash(cur, fp_from_u64((uint64_t)n));
+}

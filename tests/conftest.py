@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure): oracle/_build/liboracle.so via ctypes."""
+    from oracle import oracle_py
+    oracle_py.lib()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    gdir = os.path.join(ROOT, "tests", "golden")
+
+    def load(name):
+        with open(os.path.join(gdir, name)) as f:
+            return json.load(f)
+    return load

@@ -1,0 +1,144 @@
+"""Pins the CPU oracle against the reference's own known-answer tests
+(SURVEY.md §4 / §8c).  Runs without a GPU."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from tests.util import P, felt_int, int_limbs, random_column
+
+
+def test_montgomery_constants(oracle, golden):
+    g = golden("montgomery.json")
+    assert int(g["modulus"]) == P
+    one = oracle.to_mont([1])[0]
+    assert felt_int(one) == int(g["R_mod_p"])
+    assert int(g["inv64"]) == 2**64 - 1
+    assert oracle.from_mont(one) == 1
+
+
+def test_field_ops_vs_python(oracle):
+    rng = np.random.default_rng(1)
+    vals = [int.from_bytes(rng.bytes(32), "little") % P for _ in range(64)] + [0, 1, P - 1, P - 2, 2**251]
+    a = oracle.to_mont(vals)
+    # a*b via the Pedersen-free path: poly_eval of degree-1 polynomial c0 + c1*x
+    for i in range(0, len(vals) - 2, 3):
+        c = np.stack([a[i], a[i + 1]])
+        got = oracle.from_mont(oracle.poly_eval(c, a[i + 2]))
+        assert got == (vals[i] + vals[i + 1] * vals[i + 2]) % P
+
+
+@pytest.mark.parametrize("name,n", [("ntt_pedersen512.json", 512), ("ntt_ecdsa256.json", 256)])
+def test_ntt_periodic_column_kat(oracle, golden, name, n):
+    g = golden(name)
+    for axis in ("x", "y"):
+        coeffs = oracle.to_mont([int(v) for v in g["coeffs_" + axis]])
+        want = [int(v) for v in g["evals_" + axis]]
+        assert len(want) == n
+        got = oracle.from_mont(oracle.ntt(coeffs))
+        assert list(got) == want
+        # ... and back: interpolation is the inverse
+        back = oracle.ntt(oracle.to_mont(want), inverse=True)
+        assert np.array_equal(back, coeffs)
+
+
+def test_ntt_coset_matches_definition(oracle):
+    n = 64
+    col = random_column(n, 3)
+    g = oracle.to_mont([3])[0]
+    ev = oracle.ntt(col, offset=g)
+    w = pow(3, (P - 1) // n, P)
+    coeffs = list(oracle.from_mont(col))
+    for k in (0, 1, 7, 63):
+        x = 3 * pow(w, k, P) % P
+        want = sum(c * pow(x, i, P) for i, c in enumerate(coeffs)) % P
+        assert oracle.from_mont(ev[k]) == want
+    assert np.array_equal(oracle.ntt(ev, inverse=True, offset=g), col)
+
+
+def test_lde_matches_definition(oracle):
+    n, lb = 32, 1
+    col = random_column(n, 5)
+    g = oracle.to_mont([3])[0]
+    ev, co = oracle.lde(col, lb, g)
+    # interpolant reproduces the trace on <w_n> ...
+    assert np.array_equal(oracle.ntt(co), col)
+    # ... and the LDE is its evaluation on 3<w_2n>
+    w = pow(3, (P - 1) // (n << lb), P)
+    coeffs = list(oracle.from_mont(co))
+    for k in (0, 1, 2, 33, 63):
+        x = 3 * pow(w, k, P) % P
+        assert oracle.from_mont(ev[k]) == sum(c * pow(x, i, P) for i, c in enumerate(coeffs)) % P
+
+
+def test_keccak_and_blake2s_vectors(oracle):
+    assert oracle.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert oracle.keccak256(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    for ln in (0, 1, 55, 63, 64, 65, 127, 128, 129, 135, 136, 137, 271, 272, 320, 1000):
+        msg = bytes((7 * i + ln) & 0xff for i in range(ln))
+        assert oracle.blake2s256(msg) == hashlib.blake2s(msg).digest(), ln
+    # multi-block Keccak self-consistency against the sponge definition is covered by the coin KAT
+
+
+def test_solidity_coin_kat(oracle, golden):
+    g = golden("coins.json")
+    coin = oracle.Coin(0, bytes(32))
+    for want in g["solidity_zero_seed_draws"]:
+        assert oracle.from_mont(coin.draw()) == int(want)
+    assert coin.counter == 4
+
+
+def test_cairo_coin_kat(oracle, golden):
+    g = golden("coins.json")["cairo_reseed"]
+    coin = oracle.Coin(1, bytes.fromhex(g["seed"]))
+    coin.reseed_bytes(int(g["element"]).to_bytes(32, "big"))
+    assert coin.digest.hex() == g["digest"]
+    assert coin.counter == 0
+
+
+def test_pedersen_kat(oracle, golden):
+    g = golden("pedersen.json")
+    for case in g["hash_examples"] + g["extra"]:
+        a, b = oracle.to_mont([int(case["a"]), int(case["b"])])
+        assert oracle.from_mont(oracle.pedersen_hash(a, b)) == int(case["hash"]), case
+    # doubling chains 2^i P_k against the periodic-column evaluations
+    k = golden("ntt_pedersen512.json")
+    xs, ys = oracle.pedersen_doublings(1, 248)
+    assert list(oracle.from_mont(xs)) == [int(v) for v in k["evals_x"][:248]]
+    assert list(oracle.from_mont(ys)) == [int(v) for v in k["evals_y"][:248]]
+    xs, _ = oracle.pedersen_doublings(4, 4)
+    assert list(oracle.from_mont(xs)) == [int(v) for v in k["evals_x"][504:508]]
+
+
+def test_hash_rows_layout(oracle):
+    """hash_elements absorbs to_montgomery(e).to_be_bytes::<32>() per element
+    (crypto/src/hash/keccak.rs:50-58); masks per hash/mod.rs:5-23."""
+    cols = [random_column(8, c) for c in range(3)]
+    for kind, fn, mask in ((0, oracle.keccak256, None), (1, oracle.keccak256, "k"),
+                           (2, oracle.blake2s256, None), (3, oracle.blake2s256, "b")):
+        got = oracle.hash_rows(kind, cols)
+        for r in range(8):
+            msg = b"".join(felt_int(c[r]).to_bytes(32, "big") for c in cols)
+            d = bytearray(fn(msg))
+            if mask == "k":
+                d[20:] = bytes(12)
+            if mask == "b":
+                d[:12] = bytes(12)
+            assert bytes(got[r]) == bytes(d)
+
+
+def test_pow_grind_and_verify(oracle):
+    for kind in (0, 1):
+        coin = oracle.Coin(kind, bytes(range(32)))
+        nonce = coin.grind(8)
+        assert nonce >= 1 and coin.verify_pow(8, nonce)
+        assert all(not coin.verify_pow(8, k) for k in range(1, nonce))
+
+
+def test_draw_queries(oracle):
+    sol = oracle.Coin(0, bytes(32)).draw_queries(16, 1 << 10)
+    assert len(sol) <= 16 and all(q < 1024 for q in sol)
+    c0, c1 = oracle.Coin(1, bytes(32)), oracle.Coin(1, bytes(32))
+    a, b = c0.draw_queries(5, 1 << 10), c1.draw_queries(8, 1 << 10)
+    assert c0.counter == c1.counter == 2          # batches of 4 (cairo.rs:124-130)
+    assert set(a) <= set(b)
