@@ -211,6 +211,16 @@ ss_status ss_pow_grind(ss_ctx *ctx, int coin_kind, const uint8_t digest[32], uin
 ss_status ss_pedersen_hash(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t n,
                            uint64_t *d_out);
 
+/* ---- per-kernel timing (bench.py's roofline leg): when enabled, every launch of
+ *      the named kernel family on the ctx stream is bracketed by HIP events.
+ *      ss_profile_read synchronises the stream and returns the accumulated device
+ *      time and launch count since the last reset. */
+enum { SS_PROF_NTT_PASS = 0, SS_PROF_HASH_ROWS = 1, SS_PROF_MERKLE = 2, SS_PROF_FRI = 3, SS_PROF_QUOTIENT = 4,
+       SS_PROF_DEEP = 5, SS_PROF_KINDS = 6 };
+ss_status ss_profile_enable(ss_ctx *ctx, int on);
+ss_status ss_profile_reset(ss_ctx *ctx);
+ss_status ss_profile_read(ss_ctx *ctx, int kind, double *total_ms, uint64_t *launches);
+
 /* ---- micro-benchmark hook: d_out[i] = d_a[i] * d_b[i] repeated `reps` times
  *      (dependent chain), used by bench.py to report mulmod/s. */
 ss_status ss_fp252_mul_bench(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t n,

@@ -1,0 +1,99 @@
+"""ctypes loader for libsandstorm_hip.so (the C ABI of include/sandstorm_hip.h).
+
+There is no CPU fallback: if the shared library has not been built, or no
+gfx950 device is usable, every entry point raises.  The oracle under oracle/
+is test infrastructure and is never imported from this package.
+"""
+import ctypes as C
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libsandstorm_hip.so")
+
+SS_OK = 0
+
+
+class SandstormHipError(RuntimeError):
+    pass
+
+
+class AirProgram(C.Structure):
+    """ss_air_program"""
+    _fields_ = [("code", C.POINTER(C.c_uint32)), ("n_instr", C.c_uint32),
+                ("consts", C.POINTER(C.c_uint64)), ("n_consts", C.c_uint32),
+                ("d_tables", C.c_void_p), ("table_desc", C.POINTER(C.c_uint32)),
+                ("n_tables", C.c_uint32), ("n_slots", C.c_uint32)]
+
+
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+_vpp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); every symbol include/sandstorm_hip.h declares
+SIGNATURES = {
+    "ss_last_error": (C.c_char_p, []),
+    "ss_abi_version": (C.c_uint32, []),
+    "ss_ctx_create": (C.c_int, [C.c_int, _vpp]),
+    "ss_ctx_destroy": (None, [C.c_void_p]),
+    "ss_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ss_ctx_sync": (C.c_int, [C.c_void_p]),
+    "ss_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, _vpp]),
+    "ss_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ss_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ss_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ss_ntt_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_int, _u64p, C.c_int, C.c_int]),
+    "ss_lde_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _vpp, _vpp]),
+    "ss_hash_rows": (C.c_int, [C.c_void_p, C.c_int, _vpp, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "ss_merkle_build": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64,
+                                  C.c_void_p, C.c_void_p, _u8p]),
+    "ss_merkle_open": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, _u64p, C.c_uint32,
+                                 C.c_void_p, C.c_void_p]),
+    "ss_gather_rows": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, _u64p, C.c_uint32, C.c_void_p]),
+    "ss_eval_quotient": (C.c_int, [C.c_void_p, C.POINTER(AirProgram), _vpp, C.c_uint32, C.c_uint32,
+                                   C.c_uint32, _u64p, C.c_void_p]),
+    "ss_ood_eval": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, _u32p, _u32p, C.c_uint32, _u64p,
+                              C.c_void_p]),
+    "ss_poly_eval": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, _u64p, C.c_void_p]),
+    "ss_deep_compose": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, _vpp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  _u64p, _u32p, _u32p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, _u64p, C.c_void_p]),
+    "ss_fri_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _u64p, _u64p, C.c_void_p]),
+    "ss_pow_grind": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, _u64p]),
+    "ss_pedersen_hash": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "ss_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "ss_profile_reset": (C.c_int, [C.c_void_p]),
+    "ss_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), _u64p]),
+    "ss_fp252_mul_bench": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library and bind every declared symbol (no compute)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SandstormHipError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    # If torch is part of this process its bundled HIP runtime must be the one that
+    # is loaded (same SONAME libamdhip64.so.7); import it first when it is wanted.
+    if os.environ.get("SANDSTORM_WITH_TORCH") == "1" and "torch" not in sys.modules:
+        import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != SS_OK:
+        msg = load().ss_last_error()
+        raise SandstormHipError("status %d: %s" % (status, msg.decode() if msg else "?"))

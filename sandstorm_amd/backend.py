@@ -1,0 +1,283 @@
+"""Host-side mirror of the reference's prover-facing interface for the hot path,
+on top of the C ABI (include/sandstorm_hip.h).
+
+Names follow the reference / ministark:
+  Matrix                 ministark::Matrix<Fp> (column-major; layouts/src/recursive/trace.rs:652-660)
+    .interpolate()/.evaluate()/.lde()   ministark Matrix::{interpolate, evaluate}
+  hash_rows              crypto/src/merkle/utils.rs:19-46
+  LeafVariantMerkleTree  crypto/src/merkle/mod.rs:240-304
+  FriendlyMerkleTree     crypto/src/merkle/mod.rs:43-123
+    .from_matrix()/.root()/.prove()     MatrixMerkleTree / MerkleTree traits
+  fri_fold, pow_grind, pedersen_hash    see the C ABI header
+
+Field elements are numpy uint64[..., 4] Montgomery limbs on the host and 32-byte
+images on the device.  All arithmetic runs on the GPU; nothing here falls back to
+the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+P = 2**251 + 17 * 2**192 + 1
+R = 2**256
+
+NATURAL, BITREV = 0, 1
+FORWARD, INVERSE = 0, 1
+HASH_KECCAK, HASH_KECCAK_M20, HASH_BLAKE2S, HASH_BLAKE2S_M20 = 0, 1, 2, 3
+TREE_KECCAK, TREE_KECCAK_M20, TREE_FRIENDLY = 0, 1, 2
+LEAF_DIGEST, LEAF_FELT = 0, 1
+COIN_SOLIDITY, COIN_CAIRO = 0, 1
+PROF_NTT_PASS, PROF_HASH_ROWS, PROF_MERKLE, PROF_FRI, PROF_QUOTIENT, PROF_DEEP = range(6)
+
+
+def felt(v):
+    """python int -> Montgomery limbs uint64[4]"""
+    x = (int(v) % P) * R % P
+    return np.array([(x >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)], dtype=np.uint64)
+
+
+def _felt_ptr(limbs):
+    if limbs is None:
+        return None, None
+    a = np.ascontiguousarray(limbs, dtype=np.uint64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+class DeviceBuffer:
+    """A device allocation owned by a Context (ss_dev_alloc / ss_dev_free)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        check(ctx.lib.ss_dev_alloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        check(self.ctx.lib.ss_upload(self.ctx.handle, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(self.ctx.lib.ss_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.ss_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr_of(x):
+    """DeviceBuffer | torch tensor | int -> device address"""
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+def _ptr_array(items):
+    return (C.c_void_p * len(items))(*[_ptr_of(i) for i in items])
+
+
+class Context:
+    """One per GPU and host thread (ss_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.ss_ctx_create(device, C.byref(h)))
+        self.handle = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        check(self.lib.ss_ctx_set_stream(self.handle, C.c_void_p(stream)))
+
+    def sync(self):
+        check(self.lib.ss_ctx_sync(self.handle))
+
+    def close(self):
+        if self.handle:
+            self.lib.ss_ctx_destroy(self.handle)
+            self.handle = None
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def column(self, host_col):
+        a = np.ascontiguousarray(host_col, dtype=np.uint64)
+        return DeviceBuffer(self, a.nbytes).upload(a)
+
+    # ---- raw ops on lists of device columns -------------------------------------------------
+    def ntt(self, cols, log_n, direction=FORWARD, offset=None, in_order=NATURAL, out_order=NATURAL):
+        _keep, off = _felt_ptr(offset)
+        check(self.lib.ss_ntt_fp252(self.handle, _ptr_array(cols), len(cols), log_n, direction, off,
+                                    in_order, out_order))
+
+    def lde(self, cols_in, log_n, log_blowup, offset, evals_out, coeffs_out=None):
+        _keep, off = _felt_ptr(offset)
+        check(self.lib.ss_lde_fp252(self.handle, _ptr_array(cols_in), len(cols_in), log_n, log_blowup, off,
+                                    _ptr_array(evals_out), _ptr_array(coeffs_out) if coeffs_out else None))
+
+    def hash_rows(self, kind, cols, nrows, out):
+        check(self.lib.ss_hash_rows(self.handle, kind, _ptr_array(cols), len(cols), nrows, _ptr_of(out)))
+
+    def merkle_build(self, tree, n_friendly, leaf_kind, leaves, n, nodes, tags=None):
+        root = (C.c_uint8 * 33)()
+        check(self.lib.ss_merkle_build(self.handle, tree, n_friendly, leaf_kind, _ptr_of(leaves), n,
+                                       _ptr_of(nodes), _ptr_of(tags) if tags is not None else None, root))
+        return bytes(root[:32]), int(root[32])
+
+    def merkle_open(self, nodes, tags, n, indices):
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        log_n = int(n).bit_length() - 1
+        out = np.zeros((len(idx), log_n, 32), dtype=np.uint8)
+        otags = np.zeros((len(idx), log_n), dtype=np.uint8)
+        check(self.lib.ss_merkle_open(self.handle, _ptr_of(nodes), _ptr_of(tags) if tags is not None else None,
+                                      n, idx.ctypes.data_as(C.POINTER(C.c_uint64)), len(idx),
+                                      out.ctypes.data, otags.ctypes.data))
+        return out, otags
+
+    def gather_rows(self, cols, indices):
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        out = np.zeros((len(idx), len(cols), 4), dtype=np.uint64)
+        check(self.lib.ss_gather_rows(self.handle, _ptr_array(cols), len(cols),
+                                      idx.ctypes.data_as(C.POINTER(C.c_uint64)), len(idx), out.ctypes.data))
+        return out
+
+    def fri_fold(self, evals, log_len, fold, alpha, offset, out):
+        _k1, a = _felt_ptr(alpha)
+        _k2, o = _felt_ptr(offset)
+        check(self.lib.ss_fri_fold(self.handle, _ptr_of(evals), log_len, fold, a, o, _ptr_of(out)))
+
+    def pow_grind(self, coin_kind, digest, bits):
+        nonce = C.c_uint64()
+        check(self.lib.ss_pow_grind(self.handle, coin_kind, bytes(digest), bits, C.byref(nonce)))
+        return nonce.value
+
+    def pedersen_hash(self, a, b, n, out):
+        check(self.lib.ss_pedersen_hash(self.handle, _ptr_of(a), _ptr_of(b), n, _ptr_of(out)))
+
+    def profile(self, on):
+        check(self.lib.ss_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.lib.ss_profile_reset(self.handle))
+
+    def profile_read(self, kind):
+        ms, cnt = C.c_double(), C.c_uint64()
+        check(self.lib.ss_profile_read(self.handle, kind, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def mul_bench(self, a, b, n, reps, out):
+        check(self.lib.ss_fp252_mul_bench(self.handle, _ptr_of(a), _ptr_of(b), n, reps, _ptr_of(out)))
+
+
+class Matrix:
+    """Column-major matrix of felts resident in HBM (ministark::Matrix<Fp>)."""
+
+    def __init__(self, ctx, cols, nrows):
+        self.ctx, self.cols, self.nrows = ctx, list(cols), int(nrows)
+
+    @classmethod
+    def from_host(cls, ctx, host_cols):
+        host_cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in host_cols]
+        return cls(ctx, [ctx.column(c) for c in host_cols], host_cols[0].shape[0])
+
+    @classmethod
+    def empty(cls, ctx, ncols, nrows):
+        return cls(ctx, [ctx.alloc(32 * nrows) for _ in range(ncols)], nrows)
+
+    @property
+    def num_cols(self):
+        return len(self.cols)
+
+    @property
+    def log_rows(self):
+        return self.nrows.bit_length() - 1
+
+    def to_host(self):
+        return [c.download(np.uint64, (self.nrows, 4)) for c in self.cols]
+
+    def interpolate(self, offset=None, out_order=NATURAL):
+        """in place: evaluations over offset*<w> -> coefficients"""
+        self.ctx.ntt(self.cols, self.log_rows, INVERSE, offset, NATURAL, out_order)
+        return self
+
+    def evaluate(self, offset=None, in_order=NATURAL):
+        """in place: coefficients -> evaluations over offset*<w>"""
+        self.ctx.ntt(self.cols, self.log_rows, FORWARD, offset, in_order, NATURAL)
+        return self
+
+    def lde(self, log_blowup, offset, keep_coeffs=True):
+        """-> (evaluations over offset*<w_{n*blowup}>, bit-reversed coefficient matrix or None)"""
+        ev = Matrix.empty(self.ctx, self.num_cols, self.nrows << log_blowup)
+        co = Matrix.empty(self.ctx, self.num_cols, self.nrows) if keep_coeffs else None
+        self.ctx.lde(self.cols, self.log_rows, log_blowup, offset, ev.cols, co.cols if co else None)
+        return ev, co
+
+    def hash_rows(self, kind):
+        out = self.ctx.alloc(32 * self.nrows)
+        self.ctx.hash_rows(kind, self.cols, self.nrows, out)
+        return out
+
+
+class _MerkleTree:
+    tree_kind = None
+    row_hash = None
+    n_friendly = 0
+
+    def __init__(self, ctx, n, nodes, tags, root, root_tag, leaf_kind):
+        self.ctx, self.n, self.nodes, self.tags = ctx, n, nodes, tags
+        self._root, self._root_tag, self.leaf_kind = root, root_tag, leaf_kind
+
+    @classmethod
+    def from_matrix(cls, matrix):
+        """MatrixMerkleTree::from_matrix (crypto/src/merkle/mod.rs:110-123, 289-304)"""
+        ctx, n = matrix.ctx, matrix.nrows
+        nodes = ctx.alloc(64 * n)
+        tags = ctx.alloc(2 * n) if cls.tree_kind == TREE_FRIENDLY else None
+        if matrix.num_cols == 1:
+            leaf_kind, leaves = LEAF_FELT, matrix.cols[0]
+        else:
+            leaf_kind, leaves = LEAF_DIGEST, matrix.hash_rows(cls.row_hash)
+        root, tag = ctx.merkle_build(cls.tree_kind, cls.n_friendly, leaf_kind, leaves, n, nodes, tags)
+        return cls(ctx, n, nodes, tags, root, tag, leaf_kind)
+
+    def root(self):
+        return self._root
+
+    def root_tag(self):
+        return self._root_tag
+
+    def prove(self, indices):
+        """authentication paths (leaf level first) for the given leaf indices"""
+        return self.ctx.merkle_open(self.nodes, self.tags, self.n, indices)
+
+
+class LeafVariantMerkleTree(_MerkleTree):
+    """LeafVariantMerkleTree<MaskedKeccak256HashFn<20>> (starknet EthVerifierClaim, src/claims.rs:20-21)"""
+    tree_kind, row_hash = TREE_KECCAK_M20, HASH_KECCAK_M20
+
+
+class LeafVariantMerkleTreeUnmasked(_MerkleTree):
+    """LeafVariantMerkleTree<Keccak256HashFn> (recursive EthVerifierClaim, src/claims.rs:29-30)"""
+    tree_kind, row_hash = TREE_KECCAK, HASH_KECCAK
+
+
+class FriendlyMerkleTree(_MerkleTree):
+    """FriendlyMerkleTree<22, PedersenHashFn> (CairoVerifierClaim, src/claims.rs:10,22-23,31-32)"""
+    tree_kind, row_hash, n_friendly = TREE_FRIENDLY, HASH_BLAKE2S_M20, 22

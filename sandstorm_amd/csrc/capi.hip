@@ -1,0 +1,553 @@
+// capi.hip — the C ABI of libsandstorm_hip.so (include/sandstorm_hip.h).
+//
+// Host-side planning only: twiddle plans, pass decomposition, level-by-level
+// Merkle scheduling.  All arithmetic on proof data happens in the gfx950
+// kernels of ntt.hip / hash.hip / pedersen.hip / fri.hip / deep.hip /
+// quotient.hip; there is no CPU fallback — without a usable HIP device every
+// entry point returns SS_ERR_NO_DEVICE / SS_ERR_HIP.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/sandstorm_hip.h"
+#include "fp252.h"
+#include "kernels.h"
+
+using namespace ss;
+
+namespace {
+
+thread_local std::string g_err;
+
+ss_status fail(ss_status code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(SS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct PlanKey {
+    uint32_t log_n;
+    int inverse;
+    uint32_t off[8];
+    bool operator<(const PlanKey &o) const {
+        if (log_n != o.log_n) return log_n < o.log_n;
+        if (inverse != o.inverse) return inverse < o.inverse;
+        return memcmp(off, o.off, sizeof off) < 0;
+    }
+};
+
+Fp fp_from_limbs64(const uint64_t v[4]) {
+    Fp a;
+    for (int i = 0; i < 4; ++i) { a.v[2 * i] = (u32)v[i]; a.v[2 * i + 1] = (u32)(v[i] >> 32); }
+    return a;
+}
+
+// 3^((p-1)/2^log_n), (p-1) = (2^59+17) * 2^192
+Fp root_of_unity(uint32_t log_n) {
+    Fp c = fp_pow_u64(fp_from_u64(3), (1ull << 59) + 17ull);
+    for (uint32_t i = 0; i < 192 - log_n; ++i) c = fp_sqr(c);
+    return c;
+}
+
+}  // namespace
+
+struct ss_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::map<PlanKey, Fp *> plans;          // device twiddle tables
+    PedersenTables *ped = nullptr;
+    void *scratch = nullptr;                // grow-only device scratch
+    size_t scratch_bytes = 0;
+    uint64_t *d_small = nullptr;            // 64 x u64: PoW prefix/best etc.
+    bool prof_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[SS_PROF_KINDS];
+    double prof_ms[SS_PROF_KINDS] = {0};
+    uint64_t prof_launches[SS_PROF_KINDS] = {0};
+
+    // bracket one launch with events (only when profiling is on)
+    struct Scope {
+        ss_ctx *c; int kind; hipEvent_t e1 = nullptr;
+        Scope(ss_ctx *c_, int k) : c(c_), kind(k) {
+            if (!c->prof_on) return;
+            hipEvent_t e0;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e1 = nullptr; return; }
+            (void)hipEventRecord(e0, c->stream);
+            c->prof_events[kind].push_back({e0, e1});
+        }
+        ~Scope() { if (e1) (void)hipEventRecord(e1, c->stream); }
+    };
+    void prof_collect() {
+        for (int k = 0; k < SS_PROF_KINDS; ++k) {
+            for (auto &pr : prof_events[k]) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { prof_ms[k] += ms; prof_launches[k] += 1; }
+                (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+            }
+            prof_events[k].clear();
+        }
+    }
+
+    ss_status ensure_scratch(size_t bytes) {
+        if (bytes <= scratch_bytes) return SS_OK;
+        if (scratch) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(scratch)); scratch = nullptr; scratch_bytes = 0; }
+        HIP_TRY(hipMalloc(&scratch, bytes));
+        scratch_bytes = bytes;
+        return SS_OK;
+    }
+
+    // Twiddle plan for the stage network of size 2^log_n: T_s[k] = h^(n/2^(s+1)) * r^(k n/2^(s+1)),
+    // r = w (forward) or w^-1 (inverse), h = offset or offset^-1.
+    ss_status get_plan(uint32_t log_n, bool inverse, const Fp &offset, const Fp **out) {
+        PlanKey key;
+        key.log_n = log_n; key.inverse = inverse ? 1 : 0;
+        memcpy(key.off, offset.v, sizeof key.off);
+        auto it = plans.find(key);
+        if (it != plans.end()) { *out = it->second; return SS_OK; }
+        const uint64_t n = 1ull << log_n;
+        Fp r = root_of_unity(log_n), h = offset;
+        if (inverse) { r = fp_inv(r); h = fp_inv(h); }
+        const bool h_is_one = fp_eq(h, fp_one());
+        const uint64_t half = n / 2 ? n / 2 : 1;
+        const uint64_t n_lo = half < 4096 ? half : 4096, n_hi = half < 4096 ? 1 : half / 4096;
+        std::vector<Fp> host(n_lo + n_hi + log_n + 1);
+        Fp *lo = host.data(), *hi = lo + n_lo, *hp = hi + n_hi;
+        lo[0] = fp_one();
+        for (uint64_t i = 1; i < n_lo; ++i) lo[i] = fp_mul(lo[i - 1], r);
+        Fp r4096 = n_lo == 4096 ? fp_mul(lo[4095], r) : fp_one();
+        hi[0] = fp_one();
+        for (uint64_t i = 1; i < n_hi; ++i) hi[i] = fp_mul(hi[i - 1], r4096);
+        if (log_n > 0) {
+            hp[log_n - 1] = h;
+            for (uint32_t s = log_n - 1; s-- > 0;) hp[s] = fp_sqr(hp[s + 1]);
+        }
+        Fp *d_tabs = nullptr, *d_tw = nullptr;
+        HIP_TRY(hipMalloc(&d_tabs, host.size() * sizeof(Fp)));
+        HIP_TRY(hipMalloc(&d_tw, (n > 1 ? n - 1 : 1) * sizeof(Fp)));
+        HIP_TRY(hipMemcpyAsync(d_tabs, host.data(), host.size() * sizeof(Fp), hipMemcpyHostToDevice, stream));
+        if (log_n > 0)
+            HIP_TRY(launch_twiddles(stream, d_tw, d_tabs, d_tabs + n_lo, d_tabs + n_lo + n_hi, log_n, h_is_one));
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipFree(d_tabs));
+        plans[key] = d_tw;
+        *out = d_tw;
+        return SS_OK;
+    }
+};
+
+namespace {
+
+// stages -> passes: pass 0 is the contiguous one (up to 2^11 adjacent
+// elements), the rest take <= 7 stages each so a 2048-element tile still holds
+// >= 16 adjacent elements per row (>= 512-byte global runs).
+struct Pass { uint32_t s0, r; };
+std::vector<Pass> plan_passes(uint32_t log_n) {
+    std::vector<Pass> v;
+    const uint32_t lt = (uint32_t)ntt_log_tile_max();
+    const uint32_t r0 = log_n < lt ? log_n : lt;
+    v.push_back({0, r0});
+    uint32_t rem = log_n - r0;
+    if (rem) {
+        const uint32_t k = (rem + 6) / 7;
+        uint32_t s0 = r0;
+        for (uint32_t i = 0; i < k; ++i) {
+            uint32_t r = rem / (k - i) + ((rem % (k - i)) ? 1 : 0);
+            v.push_back({s0, r});
+            s0 += r; rem -= r;
+        }
+    }
+    return v;
+}
+
+// forward: bit-reversed (optionally 2^-log_expand sub-sampled) src -> natural dst
+ss_status run_forward(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t log_n, const Fp *tw,
+                      uint32_t log_expand) {
+    const uint32_t lt = (uint32_t)ntt_log_tile_max();
+    const uint32_t log_tile = log_n < lt ? log_n : lt;
+    std::vector<Pass> passes = plan_passes(log_n);
+    if (log_expand > passes[0].r) return fail(SS_ERR_INVALID, "log_blowup %u too large", log_expand);
+    ColPtrs inplace = cols;
+    for (uint32_t c = 0; c < ncols; ++c) inplace.src[c] = cols.dst[c];
+    for (size_t i = 0; i < passes.size(); ++i) {
+        const bool first = i == 0;
+        ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
+        HIP_TRY(launch_ntt_pass(ctx->stream, false, first ? cols : inplace, ncols, tw, log_n, passes[i].s0,
+                                passes[i].r, log_tile, first ? log_expand : 0, first ? log_expand : 0, 0));
+    }
+    return SS_OK;
+}
+// inverse: natural src -> bit-reversed dst, scaled by 1/n
+ss_status run_inverse(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t log_n, const Fp *tw) {
+    const uint32_t lt = (uint32_t)ntt_log_tile_max();
+    const uint32_t log_tile = log_n < lt ? log_n : lt;
+    std::vector<Pass> passes = plan_passes(log_n);
+    ColPtrs inplace = cols;
+    for (uint32_t c = 0; c < ncols; ++c) inplace.src[c] = cols.dst[c];
+    for (size_t i = passes.size(); i-- > 0;) {
+        const bool first = i == passes.size() - 1;
+        const bool last = i == 0;
+        ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
+        HIP_TRY(launch_ntt_pass(ctx->stream, true, first ? cols : inplace, ncols, tw, log_n, passes[i].s0,
+                                passes[i].r, log_tile, 0, 0, last ? log_n : 0));
+    }
+    return SS_OK;
+}
+
+bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
+
+}  // namespace
+
+extern "C" {
+
+const char *ss_last_error(void) { return g_err.c_str(); }
+uint32_t ss_abi_version(void) { return 1; }
+
+ss_status ss_ctx_create(int device, ss_ctx **out) {
+    if (!out) return fail(SS_ERR_INVALID, "out is NULL");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(SS_ERR_NO_DEVICE, "no HIP device: %s", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(SS_ERR_INVALID, "device %d out of range (%d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SS_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    ss_ctx *ctx = new ss_ctx;
+    ctx->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    HIP_TRY(hipMalloc(&ctx->d_small, 64 * sizeof(uint64_t)));
+    HIP_TRY(ntt_set_func_attributes());
+    *out = ctx;
+    return SS_OK;
+}
+
+void ss_ctx_destroy(ss_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->plans) hipFree(kv.second);
+    pedersen_tables_destroy(ctx->ped);
+    if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->d_small) hipFree(ctx->d_small);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+ss_status ss_ctx_set_stream(ss_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SS_OK;
+}
+ss_status ss_ctx_sync(ss_ctx *ctx) {
+    if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+ss_status ss_dev_alloc(ss_ctx *ctx, size_t bytes, void **d_out) {
+    if (!ctx || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(d_out, bytes ? bytes : 1));
+    return SS_OK;
+}
+ss_status ss_dev_free(ss_ctx *ctx, void *d_ptr) {
+    if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
+    if (d_ptr) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(d_ptr)); }
+    return SS_OK;
+}
+ss_status ss_upload(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes) {
+    if (!ctx || (!d_dst && bytes) || (!src && bytes)) return fail(SS_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+ss_status ss_download(ss_ctx *ctx, void *dst, const void *d_src, size_t bytes) {
+    if (!ctx || (!dst && bytes) || (!d_src && bytes)) return fail(SS_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+ss_status ss_profile_enable(ss_ctx *ctx, int on) {
+    if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
+    ctx->prof_on = on != 0;
+    return SS_OK;
+}
+ss_status ss_profile_reset(ss_ctx *ctx) {
+    if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->prof_collect();
+    for (int k = 0; k < SS_PROF_KINDS; ++k) { ctx->prof_ms[k] = 0; ctx->prof_launches[k] = 0; }
+    return SS_OK;
+}
+ss_status ss_profile_read(ss_ctx *ctx, int kind, double *total_ms, uint64_t *launches) {
+    if (!ctx || kind < 0 || kind >= SS_PROF_KINDS) return fail(SS_ERR_INVALID, "bad argument");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->prof_collect();
+    if (total_ms) *total_ms = ctx->prof_ms[kind];
+    if (launches) *launches = ctx->prof_launches[kind];
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------- NTT
+ss_status ss_ntt_fp252(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, uint32_t log_n, int direction,
+                       const uint64_t offset[4], int in_order, int out_order) {
+    if (!ctx || !d_cols) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!valid_log(log_n)) return fail(SS_ERR_INVALID, "log_n %u out of range [1,30]", log_n);
+    if (direction != SS_NTT_FORWARD && direction != SS_NTT_INVERSE) return fail(SS_ERR_INVALID, "bad direction");
+    const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
+    const bool inverse = direction == SS_NTT_INVERSE;
+    const Fp *tw = nullptr;
+    ss_status st = ctx->get_plan(log_n, inverse, off, &tw);
+    if (st != SS_OK) return st;
+    for (uint32_t base = 0; base < ncols; base += MAX_COLS) {
+        const uint32_t nc = ncols - base < (uint32_t)MAX_COLS ? ncols - base : (uint32_t)MAX_COLS;
+        ColPtrs cols;
+        memset(&cols, 0, sizeof cols);
+        for (uint32_t c = 0; c < nc; ++c) { cols.src[c] = d_cols[base + c]; cols.dst[c] = d_cols[base + c]; }
+        if (!inverse) {
+            if (in_order == SS_ORDER_NATURAL)
+                for (uint32_t c = 0; c < nc; ++c) HIP_TRY(launch_bitrev(ctx->stream, (Fp *)cols.dst[c], log_n));
+            st = run_forward(ctx, cols, nc, log_n, tw, 0);
+            if (st != SS_OK) return st;
+            if (out_order == SS_ORDER_BITREV)
+                for (uint32_t c = 0; c < nc; ++c) HIP_TRY(launch_bitrev(ctx->stream, (Fp *)cols.dst[c], log_n));
+        } else {
+            if (in_order == SS_ORDER_BITREV)
+                for (uint32_t c = 0; c < nc; ++c) HIP_TRY(launch_bitrev(ctx->stream, (Fp *)cols.dst[c], log_n));
+            st = run_inverse(ctx, cols, nc, log_n, tw);
+            if (st != SS_OK) return st;
+            if (out_order == SS_ORDER_NATURAL)
+                for (uint32_t c = 0; c < nc; ++c) HIP_TRY(launch_bitrev(ctx->stream, (Fp *)cols.dst[c], log_n));
+        }
+    }
+    return SS_OK;
+}
+
+ss_status ss_lde_fp252(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols, uint32_t log_n,
+                       uint32_t log_blowup, const uint64_t offset[4], uint64_t *const *d_evals,
+                       uint64_t *const *d_coeffs) {
+    if (!ctx || !d_in || !d_evals) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!valid_log(log_n) || !valid_log(log_n + log_blowup)) return fail(SS_ERR_INVALID, "size out of range");
+    const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
+    const Fp *tw_inv = nullptr, *tw_fwd = nullptr;
+    ss_status st = ctx->get_plan(log_n, true, fp_one(), &tw_inv);
+    if (st != SS_OK) return st;
+    st = ctx->get_plan(log_n + log_blowup, false, off, &tw_fwd);
+    if (st != SS_OK) return st;
+    const size_t col_bytes = sizeof(Fp) << log_n;
+    for (uint32_t base = 0; base < ncols; base += MAX_COLS) {
+        const uint32_t nc = ncols - base < (uint32_t)MAX_COLS ? ncols - base : (uint32_t)MAX_COLS;
+        if (!d_coeffs) { st = ctx->ensure_scratch(col_bytes * nc); if (st != SS_OK) return st; }
+        ColPtrs inv, fwd;
+        memset(&inv, 0, sizeof inv); memset(&fwd, 0, sizeof fwd);
+        for (uint32_t c = 0; c < nc; ++c) {
+            void *co = d_coeffs ? (void *)d_coeffs[base + c] : (void *)((char *)ctx->scratch + col_bytes * c);
+            inv.src[c] = d_in[base + c]; inv.dst[c] = co;
+            fwd.src[c] = co; fwd.dst[c] = d_evals[base + c];
+        }
+        st = run_inverse(ctx, inv, nc, log_n, tw_inv);
+        if (st != SS_OK) return st;
+        st = run_forward(ctx, fwd, nc, log_n + log_blowup, tw_fwd, log_blowup);
+        if (st != SS_OK) return st;
+    }
+    return SS_OK;
+}
+
+// --------------------------------------------------------------- hashing
+ss_status ss_hash_rows(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_cols, uint32_t ncols,
+                       uint64_t nrows, uint8_t *d_digests) {
+    if (!ctx || !d_cols || !d_digests) return fail(SS_ERR_INVALID, "NULL argument");
+    if (hash_kind < 0 || hash_kind > 3) return fail(SS_ERR_INVALID, "bad hash kind %d", hash_kind);
+    if (ncols == 0 || ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u not in [1,%d]", ncols, MAX_COLS);
+    ConstColPtrs cols;
+    memset(&cols, 0, sizeof cols);
+    for (uint32_t c = 0; c < ncols; ++c) cols.p[c] = d_cols[c];
+    ss_ctx::Scope prof(ctx, SS_PROF_HASH_ROWS);
+    HIP_TRY(launch_hash_rows(ctx->stream, hash_kind, cols, ncols, nrows, d_digests));
+    return SS_OK;
+}
+
+ss_status ss_merkle_build(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_layers, int leaf_kind,
+                          const void *d_leaves, uint64_t n, uint8_t *d_nodes, uint8_t *d_tags,
+                          uint8_t root_out[33]) {
+    if (!ctx || !d_leaves || !d_nodes) return fail(SS_ERR_INVALID, "NULL argument");
+    if (n < 2 || (n & (n - 1))) return fail(SS_ERR_INVALID, "n must be a power of two >= 2");
+    if (tree_kind < 0 || tree_kind > 2) return fail(SS_ERR_INVALID, "bad tree kind");
+    uint32_t log_n = 0;
+    while ((1ull << log_n) < n) ++log_n;
+    hipStream_t s = ctx->stream;
+    const int hk = tree_kind == SS_TREE_KECCAK ? SS_HASH_KECCAK : tree_kind == SS_TREE_KECCAK_M20 ? SS_HASH_KECCAK_M20 : SS_HASH_BLAKE2S_M20;
+    if (tree_kind == SS_TREE_FRIENDLY && !ctx->ped) HIP_TRY(pedersen_tables_create(s, &ctx->ped));
+    HIP_TRY(hipMemsetAsync(d_nodes, 0, 64, s));
+    if (d_tags) HIP_TRY(hipMemsetAsync(d_tags, 0, 2 * n, s));
+    // leaf slots
+    if (leaf_kind == SS_LEAF_FELT) {
+        HIP_TRY(launch_felts_to_be(s, (const Fp *)d_leaves, n, d_nodes + 32 * n));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_nodes + 32 * n, d_leaves, 32 * n, hipMemcpyDeviceToDevice, s));
+        if (d_tags && tree_kind == SS_TREE_FRIENDLY) HIP_TRY(hipMemsetAsync(d_tags + n, 1, n, s));
+    }
+    // level d holds nodes [2^d, 2^(d+1)); `depth` of an output node = its level, root = 0
+    ss_ctx::Scope prof(ctx, SS_PROF_MERKLE);
+    for (uint32_t d = log_n; d-- > 0;) {
+        const uint64_t count = 1ull << d;
+        const uint8_t *in = d_nodes + 32 * (2 * count);
+        uint8_t *out = d_nodes + 32 * count;
+        const bool leaf_level = d == log_n - 1;
+        if (tree_kind == SS_TREE_FRIENDLY) {
+            const bool pedersen = leaf_kind == SS_LEAF_FELT || d < n_friendly_layers;
+            if (leaf_level && leaf_kind == SS_LEAF_FELT) {
+                HIP_TRY(launch_pedersen_felt_pairs(s, ctx->ped, (const Fp *)d_leaves, count, out));
+            } else if (pedersen) {
+                HIP_TRY(launch_pedersen_pairs(s, ctx->ped, in, count, out));
+            } else {
+                HIP_TRY(launch_hash_pairs(s, SS_HASH_BLAKE2S_M20, in, count, out));
+                if (d_tags) HIP_TRY(hipMemsetAsync(d_tags + count, 1, count, s));
+            }
+        } else if (leaf_level && leaf_kind == SS_LEAF_FELT) {
+            HIP_TRY(launch_hash_felt_pairs(s, hk, (const Fp *)d_leaves, count, out));
+        } else {
+            HIP_TRY(launch_hash_pairs(s, hk, in, count, out));
+        }
+    }
+    if (root_out) {
+        HIP_TRY(hipMemcpyAsync(root_out, d_nodes + 32, 32, hipMemcpyDeviceToHost, s));
+        root_out[32] = 0;
+        if (d_tags) HIP_TRY(hipMemcpyAsync(root_out + 32, d_tags + 1, 1, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (!d_tags && tree_kind == SS_TREE_FRIENDLY)
+            root_out[32] = (leaf_kind == SS_LEAF_FELT || n_friendly_layers > 0) ? 0 : 1;
+    }
+    return SS_OK;
+}
+
+ss_status ss_merkle_open(ss_ctx *ctx, const uint8_t *d_nodes, const uint8_t *d_tags, uint64_t n,
+                         const uint64_t *idx, uint32_t nidx, uint8_t *out, uint8_t *out_tags) {
+    if (!ctx || !d_nodes || (!idx && nidx) || (!out && nidx)) return fail(SS_ERR_INVALID, "NULL argument");
+    if (n < 2 || (n & (n - 1))) return fail(SS_ERR_INVALID, "n must be a power of two >= 2");
+    uint32_t log_n = 0;
+    while ((1ull << log_n) < n) ++log_n;
+    const uint64_t total = (uint64_t)nidx * log_n;
+    if (total == 0) return SS_OK;
+    std::vector<uint64_t> sib(total);
+    for (uint32_t q = 0; q < nidx; ++q) {
+        if (idx[q] >= n) return fail(SS_ERR_INVALID, "leaf index %llu out of range", (unsigned long long)idx[q]);
+        uint64_t k = n + idx[q];
+        for (uint32_t l = 0; l < log_n; ++l) { sib[(uint64_t)q * log_n + l] = k ^ 1ull; k >>= 1; }
+    }
+    const size_t need = total * 8 + total * 32 + total;
+    ss_status st = ctx->ensure_scratch(need);
+    if (st != SS_OK) return st;
+    uint64_t *d_idx = (uint64_t *)ctx->scratch;
+    uint8_t *d_out = (uint8_t *)ctx->scratch + total * 8;
+    uint8_t *d_otags = d_out + total * 32;
+    HIP_TRY(hipMemcpyAsync(d_idx, sib.data(), total * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_gather32(ctx->stream, d_nodes, d_idx, total, d_out));
+    HIP_TRY(hipMemcpyAsync(out, d_out, total * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_tags) {
+        if (d_tags) {
+            HIP_TRY(launch_gather8(ctx->stream, d_tags, d_idx, total, d_otags));
+            HIP_TRY(hipMemcpyAsync(out_tags, d_otags, total, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            memset(out_tags, 0, total);
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+ss_status ss_gather_rows(ss_ctx *ctx, const uint64_t *const *d_cols, uint32_t ncols, const uint64_t *idx,
+                         uint32_t nidx, uint64_t *out) {
+    if (!ctx || !d_cols || (!idx && nidx) || (!out && nidx)) return fail(SS_ERR_INVALID, "NULL argument");
+    if (nidx == 0 || ncols == 0) return SS_OK;
+    const size_t need = (size_t)nidx * 8 + (size_t)nidx * ncols * 32;
+    ss_status st = ctx->ensure_scratch(need);
+    if (st != SS_OK) return st;
+    uint64_t *d_idx = (uint64_t *)ctx->scratch;
+    uint8_t *d_out = (uint8_t *)ctx->scratch + (size_t)nidx * 8;
+    HIP_TRY(hipMemcpyAsync(d_idx, idx, (size_t)nidx * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (uint32_t c = 0; c < ncols; ++c)
+        HIP_TRY(launch_gather32(ctx->stream, (const uint8_t *)d_cols[c], d_idx, nidx, d_out + (size_t)c * nidx * 32));
+    std::vector<uint64_t> tmp((size_t)nidx * ncols * 4);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), d_out, tmp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (uint32_t q = 0; q < nidx; ++q)
+        for (uint32_t c = 0; c < ncols; ++c)
+            memcpy(out + ((size_t)q * ncols + c) * 4, tmp.data() + ((size_t)c * nidx + q) * 4, 32);
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------- FRI
+ss_status ss_fri_fold(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
+                      const uint64_t alpha[4], const uint64_t domain_offset[4], uint64_t *d_out) {
+    if (!ctx || !d_evals || !alpha || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    uint32_t log_fold = 0;
+    while ((1u << log_fold) < fold) ++log_fold;
+    if ((1u << log_fold) != fold || log_fold < 1 || log_fold > 4) return fail(SS_ERR_INVALID, "fold must be 2, 4, 8 or 16");
+    if (!valid_log(log_len) || log_len < log_fold) return fail(SS_ERR_INVALID, "log_len out of range");
+    const Fp off = domain_offset ? fp_from_limbs64(domain_offset) : fp_one();
+    const Fp w_inv = fp_inv(root_of_unity(log_len));
+    const Fp wf_inv = fp_inv(root_of_unity(log_fold));
+    Fp tw[8];
+    tw[0] = fp_one();
+    for (int k = 1; k < 8; ++k) tw[k] = fp_mul(tw[k - 1], wf_inv);
+    ss_ctx::Scope prof(ctx, SS_PROF_FRI);
+    HIP_TRY(launch_fri_fold(ctx->stream, (const Fp *)d_evals, log_len, log_fold, fp_from_limbs64(alpha),
+                            fp_inv(off), w_inv, tw, (Fp *)d_out));
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------- PoW
+ss_status ss_pow_grind(ss_ctx *ctx, int coin_kind, const uint8_t digest[32], uint32_t bits, uint64_t *nonce_out) {
+    if (!ctx || !digest || !nonce_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (coin_kind != SS_COIN_SOLIDITY && coin_kind != SS_COIN_CAIRO) return fail(SS_ERR_INVALID, "bad coin kind");
+    if (bits > 48) return fail(SS_ERR_UNSUPPORTED, "proof-of-work bits %u > 48", bits);
+    uint64_t *d_prefix = ctx->d_small;
+    unsigned long long *d_best = (unsigned long long *)(ctx->d_small + 8);
+    HIP_TRY(launch_pow_prefix(ctx->stream, coin_kind, digest, bits, d_prefix));
+    const uint64_t window = 1ull << 22;
+    for (uint64_t start = 1;; start += window) {
+        unsigned long long best = ~0ull;
+        HIP_TRY(hipMemcpyAsync(d_best, &best, 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(launch_pow_grind(ctx->stream, coin_kind, d_prefix, bits, start, window, d_best));
+        HIP_TRY(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (best != ~0ull) { *nonce_out = best; return SS_OK; }
+        if (start > (1ull << 62)) return fail(SS_ERR_INVALID, "no nonce found");
+    }
+}
+
+// -------------------------------------------------------------- Pedersen
+ss_status ss_pedersen_hash(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t n, uint64_t *d_out) {
+    if (!ctx || !d_a || !d_b || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!ctx->ped) HIP_TRY(pedersen_tables_create(ctx->stream, &ctx->ped));
+    HIP_TRY(launch_pedersen_felts(ctx->stream, ctx->ped, (const Fp *)d_a, (const Fp *)d_b, n, (Fp *)d_out));
+    return SS_OK;
+}
+
+ss_status ss_fp252_mul_bench(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t n, uint32_t reps,
+                             uint64_t *d_out) {
+    if (!ctx || !d_a || !d_b || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    HIP_TRY(launch_mul_bench(ctx->stream, (const Fp *)d_a, (const Fp *)d_b, (Fp *)d_out, n, reps));
+    return SS_OK;
+}
+
+}  // extern "C"

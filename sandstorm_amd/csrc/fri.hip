@@ -1,0 +1,101 @@
+// fri.hip — one coset-FRI layer fold on gfx950.
+//
+// Replaces the per-layer fold of ministark's FriProver::build_layers
+// (un-vendored; options fri_folding_factor = 8 by default, cli/src/main.rs:57-58;
+// row F1 of SURVEY.md §8a).  For row j of the layer (the `fold` evaluations at
+// x_j * w_fold^k, stored at evals[j + k * len/fold]) the folded value is the
+// degree < fold interpolant evaluated at alpha:
+//     out[j] = (1/fold) * sum_m (alpha / x_j)^m * sum_k evals[j + k*rows] * w_fold^(-k m)
+// i.e. a size-`fold` inverse NTT held in registers followed by Horner.
+// One lane = one row; lane j reads evals[j + k*rows] for each k, so every load
+// instruction of a wave is a contiguous 2 KiB run.
+#include <hip/hip_runtime.h>
+#include "fp252.h"
+#include "kernels.h"
+
+namespace ss {
+
+struct FriConsts {
+    Fp alpha, offset_inv, w_inv;
+    Fp tw_inv[8];  // w_fold^(-k), k < fold/2
+};
+
+__device__ __forceinline__ Fp fri_load(const Fp *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void fri_store(Fp *p, const Fp &x) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    q[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+__host__ __device__ constexpr int brev_c(int m, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((m >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+template <int LOGF, int ST>
+__device__ __forceinline__ void fri_stage(Fp (&v)[1 << LOGF], const FriConsts &c) {
+    if (ST >= LOGF) return;
+    constexpr int STC = ST < LOGF ? ST : 0;
+    constexpr int half = 1 << STC;
+#pragma unroll
+    for (int pr = 0; pr < (1 << LOGF) / 2; ++pr) {
+        const int i = ((pr >> STC) << (STC + 1)) | (pr & (half - 1));
+        const int tw = (pr & (half - 1)) << (LOGF - 1 - STC);   // exponent of w_fold^-1
+        const Fp a = v[i], b = v[i | half];
+        v[i] = fp_add(a, b);
+        const Fp d = fp_sub(a, b);
+        v[i | half] = tw == 0 ? d : fp_mul(d, c.tw_inv[tw]);
+    }
+}
+
+template <int LOGF>
+__global__ __launch_bounds__(128) void fri_fold_kernel(const Fp *__restrict__ evals, uint32_t log_len,
+                                                       FriConsts c, Fp *__restrict__ out) {
+    constexpr int F = 1 << LOGF;
+    const uint64_t rows = (1ull << log_len) >> LOGF;
+    const uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (j >= rows) return;
+    Fp v[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) v[k] = fri_load(evals + j + (uint64_t)k * rows);
+    // unnormalised inverse NTT, DIF: natural in, bit-reversed out
+    if (LOGF >= 4) fri_stage<LOGF, 3>(v, c);
+    if (LOGF >= 3) fri_stage<LOGF, 2>(v, c);
+    if (LOGF >= 2) fri_stage<LOGF, 1>(v, c);
+    fri_stage<LOGF, 0>(v, c);
+    // t = alpha / x_j,  1/x_j = offset^-1 * w^-j
+    const Fp t = fp_mul(c.alpha, fp_mul(c.offset_inv, fp_pow_u64(c.w_inv, j)));
+    // Horner over natural-order coefficients c_m = v[bitrev(m)]
+    Fp acc = v[brev_c(F - 1, LOGF)];
+#pragma unroll
+    for (int m = F - 2; m >= 0; --m) acc = fp_add(fp_mul(acc, t), v[brev_c(m, LOGF)]);
+    fri_store(out + j, fp_div_pow2(acc, LOGF));
+}
+
+hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, uint32_t log_fold,
+                           const Fp &alpha, const Fp &offset_inv, const Fp &w_inv, const Fp *fold_tw_inv,
+                           Fp *out) {
+    FriConsts c;
+    c.alpha = alpha; c.offset_inv = offset_inv; c.w_inv = w_inv;
+    for (int k = 0; k < 8; ++k) c.tw_inv[k] = k < (1 << log_fold) / 2 ? fold_tw_inv[k] : fp_zero();
+    const uint64_t rows = (1ull << log_len) >> log_fold;
+    dim3 grid((uint32_t)((rows + 127) / 128)), block(128);
+    switch (log_fold) {
+    case 1: hipLaunchKernelGGL(fri_fold_kernel<1>, grid, block, 0, st, evals, log_len, c, out); break;
+    case 2: hipLaunchKernelGGL(fri_fold_kernel<2>, grid, block, 0, st, evals, log_len, c, out); break;
+    case 3: hipLaunchKernelGGL(fri_fold_kernel<3>, grid, block, 0, st, evals, log_len, c, out); break;
+    case 4: hipLaunchKernelGGL(fri_fold_kernel<4>, grid, block, 0, st, evals, log_len, c, out); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ss

@@ -1,0 +1,411 @@
+// hash.hip — row / node hashing and proof-of-work grinding for gfx950.
+//
+// Replaces crypto/src/merkle/utils.rs:19-46 (hash_rows), the HashFn impls of
+// crypto/src/hash/keccak.rs:13-98 and blake2s.rs:10-100 as used by the Merkle
+// tree configs (crypto/src/merkle/mod.rs:419-437, mixed.rs:106-125), and the
+// grinding loops of crypto/src/public_coin/solidity.rs:120-141 / cairo.rs:133-154.
+//
+// One lane = one row / one node: the matrix is column-major, so lane i reads
+// element i of every column — consecutive lanes, consecutive 32-byte elements,
+// fully coalesced — and the whole sponge state lives in VGPRs.  The message of a
+// row is the concatenation of each element's Montgomery limbs as 32 big-endian
+// bytes (keccak.rs:50-58), i.e. limbs in reverse order, each byte-swapped.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include "fp252.h"
+#include "kernels.h"
+
+namespace ss {
+
+// ------------------------------------------------------------------ Keccak
+__constant__ uint64_t KECCAK_RC[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
+    0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+    0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+    0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
+    0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+__device__ __forceinline__ void keccak_f1600(uint64_t s[25]) {
+#pragma unroll 1
+    for (int round = 0; round < 24; ++round) {
+        uint64_t c0 = s[0] ^ s[5] ^ s[10] ^ s[15] ^ s[20];
+        uint64_t c1 = s[1] ^ s[6] ^ s[11] ^ s[16] ^ s[21];
+        uint64_t c2 = s[2] ^ s[7] ^ s[12] ^ s[17] ^ s[22];
+        uint64_t c3 = s[3] ^ s[8] ^ s[13] ^ s[18] ^ s[23];
+        uint64_t c4 = s[4] ^ s[9] ^ s[14] ^ s[19] ^ s[24];
+        uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1);
+        uint64_t d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);
+        // theta + rho + pi into b
+        uint64_t b0 = s[0] ^ d0;
+        uint64_t b10 = rotl64(s[1] ^ d1, 1), b20 = rotl64(s[2] ^ d2, 62), b5 = rotl64(s[3] ^ d3, 28);
+        uint64_t b15 = rotl64(s[4] ^ d4, 27), b16 = rotl64(s[5] ^ d0, 36), b1 = rotl64(s[6] ^ d1, 44);
+        uint64_t b11 = rotl64(s[7] ^ d2, 6), b21 = rotl64(s[8] ^ d3, 55), b6 = rotl64(s[9] ^ d4, 20);
+        uint64_t b7 = rotl64(s[10] ^ d0, 3), b17 = rotl64(s[11] ^ d1, 10), b2 = rotl64(s[12] ^ d2, 43);
+        uint64_t b12 = rotl64(s[13] ^ d3, 25), b22 = rotl64(s[14] ^ d4, 39), b23 = rotl64(s[15] ^ d0, 41);
+        uint64_t b8 = rotl64(s[16] ^ d1, 45), b18 = rotl64(s[17] ^ d2, 15), b3 = rotl64(s[18] ^ d3, 21);
+        uint64_t b13 = rotl64(s[19] ^ d4, 8), b14 = rotl64(s[20] ^ d0, 18), b24 = rotl64(s[21] ^ d1, 2);
+        uint64_t b9 = rotl64(s[22] ^ d2, 61), b19 = rotl64(s[23] ^ d3, 56), b4 = rotl64(s[24] ^ d4, 14);
+        // chi
+        s[0] = b0 ^ (~b1 & b2); s[1] = b1 ^ (~b2 & b3); s[2] = b2 ^ (~b3 & b4); s[3] = b3 ^ (~b4 & b0); s[4] = b4 ^ (~b0 & b1);
+        s[5] = b5 ^ (~b6 & b7); s[6] = b6 ^ (~b7 & b8); s[7] = b7 ^ (~b8 & b9); s[8] = b8 ^ (~b9 & b5); s[9] = b9 ^ (~b5 & b6);
+        s[10] = b10 ^ (~b11 & b12); s[11] = b11 ^ (~b12 & b13); s[12] = b12 ^ (~b13 & b14); s[13] = b13 ^ (~b14 & b10); s[14] = b14 ^ (~b10 & b11);
+        s[15] = b15 ^ (~b16 & b17); s[16] = b16 ^ (~b17 & b18); s[17] = b17 ^ (~b18 & b19); s[18] = b18 ^ (~b19 & b15); s[19] = b19 ^ (~b15 & b16);
+        s[20] = b20 ^ (~b21 & b22); s[21] = b21 ^ (~b22 & b23); s[22] = b22 ^ (~b23 & b24); s[23] = b23 ^ (~b24 & b20); s[24] = b24 ^ (~b20 & b21);
+        s[0] ^= KECCAK_RC[round];
+    }
+}
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+__device__ __forceinline__ uint64_t bswap64(uint64_t x) { return __builtin_bswap64(x); }
+
+// message lane k (0..3) of one element: LE u64 of its big-endian byte image
+__device__ __forceinline__ uint64_t felt_msg_lane(const uint64_t *elem, int k) {
+    return bswap64(elem[3 - k]);
+}
+
+__device__ __forceinline__ void keccak_store_digest(const uint64_t s[25], uint8_t *out, bool mask20) {
+    uint64_t o2 = s[2], o3 = s[3];
+    if (mask20) { o2 &= 0xffffffffull; o3 = 0; }      // keep the first 20 bytes (hash/mod.rs:5-13)
+    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(out);
+    q[0] = make_ulonglong2(s[0], s[1]);
+    q[1] = make_ulonglong2(o2, o3);
+}
+
+// Absorb `nelem` felts fetched through `fetch(c)` (pointer to the 4 u64 limbs).
+template <typename Fetch>
+__device__ __forceinline__ void keccak_absorb_felts(uint64_t s[25], uint32_t nelem, Fetch fetch) {
+    const uint32_t data_lanes = 4 * nelem;            // pad byte 0x01 sits in lane `data_lanes`
+    const uint32_t nblocks = data_lanes / 17 + 1;
+    for (uint32_t blk = 0; blk < nblocks; ++blk) {
+#pragma unroll
+        for (int pos = 0; pos < 17; ++pos) {
+            const uint32_t lane = blk * 17 + pos;
+            if (lane < data_lanes) s[pos] ^= felt_msg_lane(fetch(lane >> 2), lane & 3);
+            else if (lane == data_lanes) s[pos] ^= 0x01ull;
+        }
+        if (blk == nblocks - 1) s[16] ^= 0x8000000000000000ull;
+        keccak_f1600(s);
+    }
+}
+
+__global__ __launch_bounds__(256) void keccak_rows_kernel(ConstColPtrs cols, uint32_t ncols, uint64_t nrows,
+                                                          uint8_t *__restrict__ out, int mask20) {
+    for (uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; row < nrows;
+         row += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t s[25];
+#pragma unroll
+        for (int i = 0; i < 25; ++i) s[i] = 0;
+        keccak_absorb_felts(s, ncols, [&](uint32_t c) {
+            return reinterpret_cast<const uint64_t *>(cols.p[c]) + 4 * row;
+        });
+        keccak_store_digest(s, out + 32 * row, mask20 != 0);
+    }
+}
+
+// leaf level of UnhashedLeafConfig: H::hash_elements([l0, l1]) (merkle/mod.rs:426-428)
+__global__ __launch_bounds__(256) void keccak_felt_pairs_kernel(const uint64_t *__restrict__ felts, uint64_t count,
+                                                                uint8_t *__restrict__ out, int mask20) {
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < count;
+         k += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t s[25];
+#pragma unroll
+        for (int i = 0; i < 25; ++i) s[i] = 0;
+        keccak_absorb_felts(s, 2, [&](uint32_t c) { return felts + 4 * (2 * k + c); });
+        keccak_store_digest(s, out + 32 * k, mask20 != 0);
+    }
+}
+
+// inner nodes: H::merge(n0, n1) = H(n0 || n1) (keccak.rs:27-32)
+__global__ __launch_bounds__(256) void keccak_pairs_kernel(const uint8_t *__restrict__ in, uint64_t count,
+                                                           uint8_t *__restrict__ out, int mask20) {
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < count;
+         k += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t s[25];
+        const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(in + 64 * k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ulonglong2 v = q[i]; s[2 * i] = v.x; s[2 * i + 1] = v.y; }
+        s[8] = 0x01ull;
+#pragma unroll
+        for (int i = 9; i < 25; ++i) s[i] = 0;
+        s[16] = 0x8000000000000000ull;
+        keccak_f1600(s);
+        keccak_store_digest(s, out + 32 * k, mask20 != 0);
+    }
+}
+
+// ----------------------------------------------------------------- Blake2s
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
+
+#define B2S_G(a, b, c, d, x, y)                       \
+    a = a + b + (x); d = rotr32(d ^ a, 16);           \
+    c = c + d;       b = rotr32(b ^ c, 12);           \
+    a = a + b + (y); d = rotr32(d ^ a, 8);            \
+    c = c + d;       b = rotr32(b ^ c, 7);
+
+#define B2S_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+    B2S_G(v0, v4, v8, v12, m[s0], m[s1]);   B2S_G(v1, v5, v9, v13, m[s2], m[s3]);       \
+    B2S_G(v2, v6, v10, v14, m[s4], m[s5]);  B2S_G(v3, v7, v11, v15, m[s6], m[s7]);      \
+    B2S_G(v0, v5, v10, v15, m[s8], m[s9]);  B2S_G(v1, v6, v11, v12, m[s10], m[s11]);    \
+    B2S_G(v2, v7, v8, v13, m[s12], m[s13]); B2S_G(v3, v4, v9, v14, m[s14], m[s15]);
+
+__device__ __forceinline__ void blake2s_compress(uint32_t h[8], const uint32_t m[16], uint32_t t, bool last) {
+    uint32_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
+    uint32_t v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
+    uint32_t v12 = 0x510E527Fu ^ t, v13 = 0x9B05688Cu, v14 = last ? ~0x1F83D9ABu : 0x1F83D9ABu, v15 = 0x5BE0CD19u;
+    B2S_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    B2S_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    B2S_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+    B2S_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+    B2S_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+    B2S_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+    B2S_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+    B2S_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+    B2S_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+    B2S_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+    h[0] ^= v0 ^ v8;  h[1] ^= v1 ^ v9;  h[2] ^= v2 ^ v10; h[3] ^= v3 ^ v11;
+    h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
+}
+
+__device__ __forceinline__ void blake2s_init(uint32_t h[8]) {
+    h[0] = 0x6A09E667u ^ 0x01010020u; h[1] = 0xBB67AE85u; h[2] = 0x3C6EF372u; h[3] = 0xA54FF53Au;
+    h[4] = 0x510E527Fu; h[5] = 0x9B05688Cu; h[6] = 0x1F83D9ABu; h[7] = 0x5BE0CD19u;
+}
+
+__device__ __forceinline__ void blake2s_store_digest(const uint32_t h[8], uint8_t *out, bool mask20) {
+    uint4 *q = reinterpret_cast<uint4 *>(out);
+    if (mask20) {  // keep the LAST 20 bytes (hash/mod.rs:15-23)
+        q[0] = make_uint4(0, 0, 0, h[3]);
+    } else {
+        q[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    }
+    q[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+// message words of one element: w-th LE u32 of its big-endian image
+__device__ __forceinline__ void felt_msg_words(const Fp &e, uint32_t *m) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) m[w] = bswap32(e.v[7 - w]);
+}
+__device__ __forceinline__ Fp load_fp(const void *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+
+template <typename Fetch>
+__device__ __forceinline__ void blake2s_hash_felts(uint32_t h[8], uint32_t nelem, Fetch fetch) {
+    blake2s_init(h);
+    const uint32_t nblocks = nelem == 0 ? 1 : (nelem + 1) / 2;
+    for (uint32_t blk = 0; blk < nblocks; ++blk) {
+        uint32_t m[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = 0;
+        if (2 * blk < nelem) felt_msg_words(fetch(2 * blk), m);
+        if (2 * blk + 1 < nelem) felt_msg_words(fetch(2 * blk + 1), m + 8);
+        const bool last = blk == nblocks - 1;
+        const uint32_t t = last ? 32 * nelem : 64 * (blk + 1);
+        blake2s_compress(h, m, t, last);
+    }
+}
+
+__global__ __launch_bounds__(256) void blake2s_rows_kernel(ConstColPtrs cols, uint32_t ncols, uint64_t nrows,
+                                                           uint8_t *__restrict__ out, int mask20) {
+    for (uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; row < nrows;
+         row += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t h[8];
+        blake2s_hash_felts(h, ncols, [&](uint32_t c) {
+            return load_fp(reinterpret_cast<const uint8_t *>(cols.p[c]) + 32 * row);
+        });
+        blake2s_store_digest(h, out + 32 * row, mask20 != 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void blake2s_felt_pairs_kernel(const Fp *__restrict__ felts, uint64_t count,
+                                                                 uint8_t *__restrict__ out, int mask20) {
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < count;
+         k += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t h[8];
+        blake2s_hash_felts(h, 2, [&](uint32_t c) { return load_fp(felts + 2 * k + c); });
+        blake2s_store_digest(h, out + 32 * k, mask20 != 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void blake2s_pairs_kernel(const uint8_t *__restrict__ in, uint64_t count,
+                                                            uint8_t *__restrict__ out, int mask20) {
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < count;
+         k += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t h[8], m[16];
+        const uint4 *q = reinterpret_cast<const uint4 *>(in + 64 * k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { uint4 v = q[i]; m[4 * i] = v.x; m[4 * i + 1] = v.y; m[4 * i + 2] = v.z; m[4 * i + 3] = v.w; }
+        blake2s_init(h);
+        blake2s_compress(h, m, 64, true);
+        blake2s_store_digest(h, out + 32 * k, mask20 != 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void felts_to_be_kernel(const Fp *__restrict__ felts, uint64_t count,
+                                                          uint8_t *__restrict__ out) {
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < count;
+         k += (uint64_t)gridDim.x * blockDim.x) {
+        Fp e = load_fp(felts + k);
+        uint4 *q = reinterpret_cast<uint4 *>(out + 32 * k);
+        q[0] = make_uint4(bswap32(e.v[7]), bswap32(e.v[6]), bswap32(e.v[5]), bswap32(e.v[4]));
+        q[1] = make_uint4(bswap32(e.v[3]), bswap32(e.v[2]), bswap32(e.v[1]), bswap32(e.v[0]));
+    }
+}
+
+// ------------------------------------------------------------ PoW grinding
+// prefix = H(be64(0x0123456789ABCDED) || digest || bits)  (41 bytes)
+// (solidity.rs:121-125 / cairo.rs:134-138), then for each nonce
+// H(prefix || be64(nonce)) must have >= bits leading zero bits; the smallest
+// valid nonce of the window wins (atomicMin).
+struct Digest32 { uint64_t w[4]; };
+
+__global__ void pow_prefix_kernel(int coin_kind, Digest32 digest, uint32_t bits, uint64_t *__restrict__ prefix) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint64_t magic = 0x0123456789ABCDEDull;
+    if (coin_kind == 0) {
+        uint64_t s[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) s[k] = 0;
+        s[0] = bswap64(magic);
+        s[1] = digest.w[0]; s[2] = digest.w[1]; s[3] = digest.w[2]; s[4] = digest.w[3];
+        s[5] = (uint64_t)(bits & 0xffu) | (0x01ull << 8);
+        s[16] = 0x8000000000000000ull;
+        keccak_f1600(s);
+        prefix[0] = s[0]; prefix[1] = s[1]; prefix[2] = s[2]; prefix[3] = s[3];
+    } else {
+        uint32_t h[8], m[16];
+        m[0] = bswap32((uint32_t)(magic >> 32)); m[1] = bswap32((uint32_t)magic);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { m[2 + 2 * k] = (uint32_t)digest.w[k]; m[3 + 2 * k] = (uint32_t)(digest.w[k] >> 32); }
+        m[10] = bits & 0xffu;
+#pragma unroll
+        for (int k = 11; k < 16; ++k) m[k] = 0;
+        blake2s_init(h);
+        blake2s_compress(h, m, 41, true);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) prefix[k] = (uint64_t)h[2 * k] | ((uint64_t)h[2 * k + 1] << 32);
+    }
+}
+
+__global__ __launch_bounds__(256) void pow_grind_kernel(int coin_kind, const uint64_t *__restrict__ prefix,
+                                                        uint32_t bits, uint64_t start, uint64_t count,
+                                                        unsigned long long *__restrict__ best) {
+    const uint64_t p0 = prefix[0], p1 = prefix[1], p2 = prefix[2], p3 = prefix[3];
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t nonce = start + i;
+        uint64_t lead;  // first 8 digest bytes as a big-endian integer
+        if (coin_kind == 0) {
+            uint64_t s[25];
+#pragma unroll
+            for (int k = 0; k < 25; ++k) s[k] = 0;
+            s[0] = p0; s[1] = p1; s[2] = p2; s[3] = p3;
+            s[4] = bswap64(nonce);
+            s[5] = 0x01ull;
+            s[16] = 0x8000000000000000ull;
+            keccak_f1600(s);
+            lead = bswap64(s[0]);
+        } else {
+            uint32_t h[8], m[16];
+            m[0] = (uint32_t)p0; m[1] = (uint32_t)(p0 >> 32); m[2] = (uint32_t)p1; m[3] = (uint32_t)(p1 >> 32);
+            m[4] = (uint32_t)p2; m[5] = (uint32_t)(p2 >> 32); m[6] = (uint32_t)p3; m[7] = (uint32_t)(p3 >> 32);
+            m[8] = bswap32((uint32_t)(nonce >> 32));
+            m[9] = bswap32((uint32_t)nonce);
+#pragma unroll
+            for (int k = 10; k < 16; ++k) m[k] = 0;
+            blake2s_init(h);
+            blake2s_compress(h, m, 40, true);
+            lead = ((uint64_t)bswap32(h[0]) << 32) | bswap32(h[1]);
+        }
+        const bool ok = bits == 0 || (lead >> (64 - bits)) == 0;
+        if (ok) atomicMin(best, (unsigned long long)nonce);
+    }
+}
+
+// generic gathers: out[i] = in[idx[i]] (32-byte digests / 1-byte tags)
+__global__ void gather32_kernel(const uint8_t *__restrict__ in, const uint64_t *__restrict__ idx, uint64_t n,
+                                uint8_t *__restrict__ out) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *q = reinterpret_cast<const uint4 *>(in + 32 * idx[i]);
+    uint4 *o = reinterpret_cast<uint4 *>(out + 32 * i);
+    o[0] = q[0]; o[1] = q[1];
+}
+__global__ void gather8_kernel(const uint8_t *__restrict__ in, const uint64_t *__restrict__ idx, uint64_t n,
+                               uint8_t *__restrict__ out) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+
+// -------------------------------------------------------------- launchers
+static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap) {
+    uint64_t g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g == 0) g = 1;
+    return (uint32_t)g;
+}
+
+hipError_t launch_hash_rows(hipStream_t st, int kind, const ConstColPtrs &cols, uint32_t ncols,
+                            uint64_t nrows, uint8_t *digests) {
+    const uint32_t grid = grid_for(nrows, 256, 1u << 20);
+    if (kind == 0 || kind == 1)
+        hipLaunchKernelGGL(keccak_rows_kernel, dim3(grid), dim3(256), 0, st, cols, ncols, nrows, digests, kind == 1);
+    else
+        hipLaunchKernelGGL(blake2s_rows_kernel, dim3(grid), dim3(256), 0, st, cols, ncols, nrows, digests, kind == 3);
+    return hipGetLastError();
+}
+hipError_t launch_hash_pairs(hipStream_t st, int kind, const uint8_t *in, uint64_t count, uint8_t *out) {
+    const uint32_t grid = grid_for(count, 256, 1u << 20);
+    if (kind == 0 || kind == 1)
+        hipLaunchKernelGGL(keccak_pairs_kernel, dim3(grid), dim3(256), 0, st, in, count, out, kind == 1);
+    else
+        hipLaunchKernelGGL(blake2s_pairs_kernel, dim3(grid), dim3(256), 0, st, in, count, out, kind == 3);
+    return hipGetLastError();
+}
+hipError_t launch_hash_felt_pairs(hipStream_t st, int kind, const Fp *felts, uint64_t count, uint8_t *out) {
+    const uint32_t grid = grid_for(count, 256, 1u << 20);
+    if (kind == 0 || kind == 1)
+        hipLaunchKernelGGL(keccak_felt_pairs_kernel, dim3(grid), dim3(256), 0, st,
+                           reinterpret_cast<const uint64_t *>(felts), count, out, kind == 1);
+    else
+        hipLaunchKernelGGL(blake2s_felt_pairs_kernel, dim3(grid), dim3(256), 0, st, felts, count, out, kind == 3);
+    return hipGetLastError();
+}
+hipError_t launch_felts_to_be(hipStream_t st, const Fp *felts, uint64_t count, uint8_t *out) {
+    hipLaunchKernelGGL(felts_to_be_kernel, dim3(grid_for(count, 256, 1u << 20)), dim3(256), 0, st, felts, count, out);
+    return hipGetLastError();
+}
+hipError_t launch_pow_prefix(hipStream_t st, int coin_kind, const uint8_t digest[32], uint32_t bits,
+                             uint64_t *d_prefix) {
+    Digest32 d;
+    memcpy(d.w, digest, 32);
+    hipLaunchKernelGGL(pow_prefix_kernel, dim3(1), dim3(64), 0, st, coin_kind, d, bits, d_prefix);
+    return hipGetLastError();
+}
+hipError_t launch_pow_grind(hipStream_t st, int coin_kind, const uint64_t *d_prefix, uint32_t bits,
+                            uint64_t start, uint64_t count, unsigned long long *d_best) {
+    hipLaunchKernelGGL(pow_grind_kernel, dim3(grid_for(count, 256, 1u << 16)), dim3(256), 0, st, coin_kind,
+                       d_prefix, bits, start, count, d_best);
+    return hipGetLastError();
+}
+hipError_t launch_gather32(hipStream_t st, const uint8_t *in, const uint64_t *d_idx, uint64_t n, uint8_t *out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather32_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, in, d_idx, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_gather8(hipStream_t st, const uint8_t *in, const uint64_t *d_idx, uint64_t n, uint8_t *out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather8_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, in, d_idx, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace ss

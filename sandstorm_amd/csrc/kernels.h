@@ -1,0 +1,66 @@
+// kernels.h — internal launch interface between the C ABI (capi.hip) and the
+// gfx950 kernels.  Not part of the public boundary (include/sandstorm_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fp252.h"
+
+namespace ss {
+
+static constexpr int MAX_COLS = 16;  // columns per launch (kernarg-resident pointer table)
+
+struct ColPtrs {
+    const void *src[MAX_COLS];
+    void *dst[MAX_COLS];
+};
+struct ConstColPtrs {
+    const void *p[MAX_COLS];
+};
+
+// ---- ntt.hip
+int ntt_log_tile_max();
+hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
+                           uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first,
+                           uint32_t log_expand, uint32_t scale_pow2);
+hipError_t launch_twiddles(hipStream_t st, Fp *tw, const Fp *pow_lo, const Fp *pow_hi, const Fp *hpow,
+                           uint32_t log_n, bool h_is_one);
+hipError_t launch_bitrev(hipStream_t st, Fp *a, uint32_t log_n);
+hipError_t launch_mul_bench(hipStream_t st, const Fp *a, const Fp *b, Fp *out, uint64_t n, uint32_t reps);
+hipError_t ntt_set_func_attributes();
+
+// ---- hash.hip
+hipError_t launch_hash_rows(hipStream_t st, int kind, const ConstColPtrs &cols, uint32_t ncols,
+                            uint64_t nrows, uint8_t *digests);
+// one Merkle level: out[k] = H(in[2k] || in[2k+1]) for k < count (64-byte messages)
+hipError_t launch_hash_pairs(hipStream_t st, int kind, const uint8_t *in, uint64_t count, uint8_t *out);
+// leaf level of single-column trees: out[k] = H::hash_elements([felt[2k], felt[2k+1]])
+hipError_t launch_hash_felt_pairs(hipStream_t st, int kind, const Fp *felts, uint64_t count, uint8_t *out);
+// felt leaves -> Montgomery big-endian bytes (leaf slots of the node array)
+hipError_t launch_felts_to_be(hipStream_t st, const Fp *felts, uint64_t count, uint8_t *out);
+hipError_t launch_pow_prefix(hipStream_t st, int coin_kind, const uint8_t digest[32], uint32_t bits,
+                             uint64_t *d_prefix);
+hipError_t launch_pow_grind(hipStream_t st, int coin_kind, const uint64_t *d_prefix, uint32_t bits,
+                            uint64_t start, uint64_t count, unsigned long long *d_best);
+hipError_t launch_gather32(hipStream_t st, const uint8_t *in, const uint64_t *d_idx, uint64_t n, uint8_t *out);
+hipError_t launch_gather8(hipStream_t st, const uint8_t *in, const uint64_t *d_idx, uint64_t n, uint8_t *out);
+
+// ---- pedersen.hip
+struct PedersenTables;  // device-resident windowed tables, built once per context
+hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out);
+void pedersen_tables_destroy(PedersenTables *t);
+// out[i] = pedersen(a[i], b[i]), Montgomery felts
+hipError_t launch_pedersen_felts(hipStream_t st, const PedersenTables *t, const Fp *a, const Fp *b,
+                                 uint64_t n, Fp *out);
+// Merkle level on 32-byte big-endian digests: out[k] = BE(pedersen(int(in[2k]) mod p, int(in[2k+1]) mod p))
+hipError_t launch_pedersen_pairs(hipStream_t st, const PedersenTables *t, const uint8_t *in, uint64_t count,
+                                 uint8_t *out);
+// single-column leaf level: out[k] = BE(PedersenHashFn::hash_elements([f[2k], f[2k+1]]))
+hipError_t launch_pedersen_felt_pairs(hipStream_t st, const PedersenTables *t, const Fp *felts,
+                                      uint64_t count, uint8_t *out);
+
+// ---- fri.hip
+hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, uint32_t log_fold,
+                           const Fp &alpha, const Fp &offset_inv, const Fp &w_inv, const Fp *fold_tw_inv,
+                           Fp *out);
+
+}  // namespace ss

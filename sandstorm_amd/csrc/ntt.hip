@@ -1,0 +1,320 @@
+// ntt.hip — batched NTT / iNTT / LDE over Fp252 for gfx950.
+//
+// Replaces ministark's Matrix::interpolate / Matrix::evaluate (rows N1/N2 of
+// SURVEY.md §8a; call sites src/lib.rs:17-26).  Convention (pinned by
+// builtins/src/pedersen/periodic.rs:1183-1209): forward = evaluation at
+// offset * w^k in natural order, w = 3^((p-1)/n).
+//
+// Structure
+//   * forward  = radix-2 decimation-in-time   network, bit-reversed in -> natural out
+//   * inverse  = radix-2 decimation-in-frequency network, natural in -> bit-reversed out
+//     (the exact inverse network, stage by stage), so an LDE (iNTT then coset
+//     NTT) never needs a transpose or a bit-reversal pass; the coset offset and
+//     its powers are folded into the per-stage twiddle tables at plan time,
+//     1/n is a 2^-k partial Montgomery step in the last inverse pass, and the
+//     zero-padded half of the LDE input is never materialised (`log_expand`).
+//   * log2(n) stages are grouped into passes; one pass = one kernel launch
+//     that streams every column once (2 * n * 32 B of HBM traffic), keeps a
+//     2048-element tile in LDS, and runs up to 11 stages on it as radix-8
+//     register butterflies (3 stages per LDS round trip).
+//   * pass 0 ("contig") covers the stages whose butterflies span <= 2048
+//     adjacent elements: the tile is one contiguous 64 KiB block.  The other
+//     passes ("strided") take 2^r rows x T adjacent elements; T >= 16 keeps
+//     every global access a >= 512 B contiguous run.
+//   * LDS layout: 16-byte halves of the 32-byte elements in two planes (lane i
+//     and lane i+1 then touch adjacent 16-byte slots: conflict-free
+//     ds_read_b128), one pad slot per 8 so the stride-8/64 patterns of the
+//     radix-8 groups spread over all banks.
+#include <hip/hip_runtime.h>
+#include "fp252.h"
+#include "kernels.h"
+
+namespace ss {
+
+static constexpr int LOG_TILE_MAX = 11;          // 2048 elements
+static constexpr int NTT_THREADS = 256;
+
+__device__ __forceinline__ int lds_slot(int e) { return e + (e >> 3); }
+
+__device__ __forceinline__ Fp lds_load(const uint4 *lo, const uint4 *hi, int e) {
+    int s = lds_slot(e);
+    uint4 a = lo[s], b = hi[s];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void lds_store(uint4 *lo, uint4 *hi, int e, const Fp &x) {
+    int s = lds_slot(e);
+    lo[s] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    hi[s] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+__device__ __forceinline__ Fp gload(const Fp *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void gstore(Fp *p, const Fp &x) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    q[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+struct PassParams {
+    uint32_t log_n;       // transform size
+    uint32_t s0;          // first global stage of this pass
+    uint32_t r;           // stages in this pass
+    uint32_t log_tile;    // elements per workgroup tile (<= LOG_TILE_MAX)
+    uint32_t u_first;     // first local stage actually executed (= log_expand in the expanding pass)
+    uint32_t log_expand;  // source index = element index >> log_expand
+    uint32_t scale_pow2;  // DIF only: multiply outputs by 2^-scale_pow2 (0 = off)
+    uint32_t contig;      // 1: s0 == 0, tile is a contiguous block
+};
+
+// One butterfly stage (local stage u + ST) on the 2^G register-resident elements.
+template <bool DIF, int G, int ST>
+__device__ __forceinline__ void radix_stage(Fp (&x)[1 << G], const Fp *__restrict__ tw, const PassParams &p,
+                                            uint32_t u, uint32_t jlow, uint32_t lbits) {
+    if (ST >= G) return;
+    const uint32_t s = p.s0 + u + ST;               // global stage
+    const Fp *tws = tw + ((1u << s) - 1u);
+#pragma unroll
+    for (int pr = 0; pr < (1 << G) / 2; ++pr) {
+        constexpr int STC = ST < G ? ST : 0;
+        const int m = ((pr >> STC) << (STC + 1)) | (pr & ((1 << STC) - 1));
+        const uint32_t k = ((jlow + ((uint32_t)(m & ((1 << STC) - 1)) << u)) << p.s0) | lbits;
+        const Fp t = gload(tws + k);
+        const Fp a = x[m], b = x[m | (1 << STC)];
+        if (DIF) {
+            x[m] = fp_add(a, b);
+            x[m | (1 << STC)] = fp_mul(fp_sub(a, b), t);
+        } else {
+            const Fp bt = fp_mul(b, t);
+            x[m] = fp_add(a, bt);
+            x[m | (1 << STC)] = fp_sub(a, bt);
+        }
+    }
+}
+
+// One radix-2^G register group on local stages [u, u+G).
+template <bool DIF, int G>
+__device__ __forceinline__ void radix_group(uint4 *lo, uint4 *hi, const Fp *__restrict__ tw,
+                                            const PassParams &p, uint32_t u, uint32_t tile,
+                                            bool last_group) {
+    const uint32_t log_t = p.log_tile - p.r;            // log2(T)
+    const uint32_t eshift = p.contig ? 0u : log_t;
+    const uint32_t items = (1u << p.log_tile) >> G;
+    const uint32_t sh = eshift + u;
+    for (uint32_t tau = threadIdx.x; tau < items; tau += blockDim.x) {
+        const uint32_t low = tau & ((1u << sh) - 1u);
+        const uint32_t high = tau >> sh;
+        const uint32_t ebase = (high << (sh + G)) | low;
+        // J of element 0 and the low global bits L
+        uint32_t jbase, lbits;
+        if (p.contig) {
+            jbase = ebase & ((1u << p.r) - 1u);
+            lbits = 0;
+        } else {
+            jbase = ebase >> log_t;
+            const uint32_t q = (tile << log_t) + (ebase & ((1u << log_t) - 1u));
+            lbits = q & ((1u << p.s0) - 1u);
+        }
+        const uint32_t jlow = jbase & ((1u << u) - 1u);
+        Fp x[1 << G];
+#pragma unroll
+        for (int m = 0; m < (1 << G); ++m) x[m] = lds_load(lo, hi, ebase + ((uint32_t)m << sh));
+        if (DIF) {
+            if (G >= 3) radix_stage<DIF, G, 2>(x, tw, p, u, jlow, lbits);
+            if (G >= 2) radix_stage<DIF, G, 1>(x, tw, p, u, jlow, lbits);
+            radix_stage<DIF, G, 0>(x, tw, p, u, jlow, lbits);
+        } else {
+            radix_stage<DIF, G, 0>(x, tw, p, u, jlow, lbits);
+            if (G >= 2) radix_stage<DIF, G, 1>(x, tw, p, u, jlow, lbits);
+            if (G >= 3) radix_stage<DIF, G, 2>(x, tw, p, u, jlow, lbits);
+        }
+        if (DIF && last_group && p.scale_pow2) {
+#pragma unroll
+            for (int m = 0; m < (1 << G); ++m) x[m] = fp_div_pow2(x[m], p.scale_pow2);
+        }
+#pragma unroll
+        for (int m = 0; m < (1 << G); ++m) lds_store(lo, hi, ebase + ((uint32_t)m << sh), x[m]);
+    }
+}
+
+template <bool DIF>
+__global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw,
+                                                               PassParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tile_elems = 1u << p.log_tile;
+    uint4 *lo = reinterpret_cast<uint4 *>(smem);
+    uint4 *hi = lo + (tile_elems + (tile_elems >> 3));
+    const uint32_t tile = blockIdx.x;
+    // select this block's column with scalar compares: a dynamically indexed by-value
+    // kernarg struct would be copied to scratch
+    const void *src_v = cols.src[0];
+    void *dst_v = cols.dst[0];
+#pragma unroll
+    for (int c = 1; c < MAX_COLS; ++c)
+        if (blockIdx.y == (unsigned)c) { src_v = cols.src[c]; dst_v = cols.dst[c]; }
+    const Fp *__restrict__ src = reinterpret_cast<const Fp *>(src_v);
+    Fp *__restrict__ dst = reinterpret_cast<Fp *>(dst_v);
+    const uint32_t log_t = p.log_tile - p.r;
+
+    // ---- global -> LDS (coalesced: consecutive lanes, consecutive addresses)
+    for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x) {
+        uint64_t gi;
+        if (p.contig) {
+            gi = ((uint64_t)tile << p.log_tile) + x;
+        } else {
+            const uint32_t dq = x & ((1u << log_t) - 1u), j = x >> log_t;
+            const uint64_t q = ((uint64_t)tile << log_t) + dq;
+            gi = ((q >> p.s0) << (p.s0 + p.r)) | ((uint64_t)j << p.s0) | (q & ((1ull << p.s0) - 1ull));
+        }
+        lds_store(lo, hi, x, gload(src + (gi >> p.log_expand)));
+    }
+    __syncthreads();
+
+    // ---- stages, 3 per LDS round trip
+    if (!DIF) {
+        uint32_t u = p.u_first;
+        while (u < p.r) {
+            const uint32_t g = (p.r - u) >= 3 ? 3 : (p.r - u);
+            if (g == 3) radix_group<false, 3>(lo, hi, tw, p, u, tile, false);
+            else if (g == 2) radix_group<false, 2>(lo, hi, tw, p, u, tile, false);
+            else radix_group<false, 1>(lo, hi, tw, p, u, tile, false);
+            u += g;
+            __syncthreads();
+        }
+    } else {
+        uint32_t u = p.r;
+        while (u > 0) {
+            const uint32_t g = u >= 3 ? 3 : u;
+            u -= g;
+            const bool last = (u == 0);
+            if (g == 3) radix_group<true, 3>(lo, hi, tw, p, u, tile, last);
+            else if (g == 2) radix_group<true, 2>(lo, hi, tw, p, u, tile, last);
+            else radix_group<true, 1>(lo, hi, tw, p, u, tile, last);
+            __syncthreads();
+        }
+    }
+
+    // ---- LDS -> global
+    for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x) {
+        uint64_t gi;
+        if (p.contig) {
+            gi = ((uint64_t)tile << p.log_tile) + x;
+        } else {
+            const uint32_t dq = x & ((1u << log_t) - 1u), j = x >> log_t;
+            const uint64_t q = ((uint64_t)tile << log_t) + dq;
+            gi = ((q >> p.s0) << (p.s0 + p.r)) | ((uint64_t)j << p.s0) | (q & ((1ull << p.s0) - 1ull));
+        }
+        gstore(dst + gi, lds_load(lo, hi, x));
+    }
+}
+
+// ---------------------------------------------------------------- twiddles
+// T_s[k] = h^(n / 2^(s+1)) * (r^(n / 2^(s+1)))^k,  k < 2^s, stored at (2^s - 1) + k.
+// r^e comes from two host-computed tables: pow_lo[e & 4095] * pow_hi[e >> 12].
+__global__ void twiddle_kernel(Fp *__restrict__ tw, const Fp *__restrict__ pow_lo,
+                               const Fp *__restrict__ pow_hi, const Fp *__restrict__ hpow,
+                               uint32_t log_n, int h_is_one) {
+    const uint64_t total = (1ull << log_n) - 1ull;
+    for (uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t s = 63u - (uint32_t)__clzll(idx + 1ull);
+        const uint64_t k = idx + 1ull - (1ull << s);
+        const uint64_t e = k << (log_n - 1u - s);          // exponent of the n-th root, < n/2
+        Fp t = fp_mul(gload(pow_lo + (e & 4095ull)), gload(pow_hi + (e >> 12)));
+        if (!h_is_one) t = fp_mul(t, gload(hpow + s));
+        gstore(tw + idx, t);
+    }
+}
+
+// ------------------------------------------------------- bit-reversal swap
+__global__ void bitrev_kernel(Fp *__restrict__ a, uint32_t log_n) {
+    const uint64_t n = 1ull << log_n;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t j = __brevll(i) >> (64u - log_n);
+        if (i < j) {
+            Fp x = gload(a + i), y = gload(a + j);
+            gstore(a + i, y);
+            gstore(a + j, x);
+        }
+    }
+}
+
+// ------------------------------------------------------------- mul bench
+__global__ void mul_bench_kernel(const Fp *__restrict__ a, const Fp *__restrict__ b, Fp *__restrict__ out,
+                                 uint64_t n, uint32_t reps) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        Fp x = gload(a + i);
+        const Fp y = gload(b + i);
+        for (uint32_t k = 0; k < reps; ++k) x = fp_mul(x, y);
+        gstore(out + i, x);
+    }
+}
+
+// ------------------------------------------------------------ host launch
+static inline size_t pass_lds_bytes(uint32_t log_tile) {
+    size_t e = (size_t)1 << log_tile;
+    return 2 * (e + (e >> 3)) * sizeof(uint4);
+}
+
+hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
+                           uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first,
+                           uint32_t log_expand, uint32_t scale_pow2) {
+    PassParams p;
+    p.log_n = log_n; p.s0 = s0; p.r = r; p.log_tile = log_tile; p.u_first = u_first;
+    p.log_expand = log_expand; p.scale_pow2 = scale_pow2; p.contig = (s0 == 0);
+    const uint32_t tiles = 1u << (log_n - log_tile);
+    dim3 grid(tiles, ncols), block(NTT_THREADS);
+    const size_t lds = pass_lds_bytes(log_tile);
+    if (dif) hipLaunchKernelGGL(ntt_pass_kernel<true>, grid, block, lds, st, cols, tw, p);
+    else hipLaunchKernelGGL(ntt_pass_kernel<false>, grid, block, lds, st, cols, tw, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_twiddles(hipStream_t st, Fp *tw, const Fp *pow_lo, const Fp *pow_hi, const Fp *hpow,
+                           uint32_t log_n, bool h_is_one) {
+    const uint64_t total = (1ull << log_n) - 1ull;
+    uint32_t blocks = (uint32_t)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(twiddle_kernel, dim3(blocks), dim3(256), 0, st, tw, pow_lo, pow_hi, hpow, log_n,
+                       h_is_one ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_bitrev(hipStream_t st, Fp *a, uint32_t log_n) {
+    const uint64_t n = 1ull << log_n;
+    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bitrev_kernel, dim3(blocks), dim3(256), 0, st, a, log_n);
+    return hipGetLastError();
+}
+
+hipError_t launch_mul_bench(hipStream_t st, const Fp *a, const Fp *b, Fp *out, uint64_t n, uint32_t reps) {
+    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(mul_bench_kernel, dim3(blocks), dim3(256), 0, st, a, b, out, n, reps);
+    return hipGetLastError();
+}
+
+int ntt_log_tile_max() { return LOG_TILE_MAX; }
+
+// tiles above 64 KiB of dynamic LDS need the per-function opt-in
+hipError_t ntt_set_func_attributes() {
+    const int bytes = (int)pass_lds_bytes(LOG_TILE_MAX);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace ss

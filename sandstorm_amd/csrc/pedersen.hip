@@ -1,0 +1,272 @@
+// pedersen.hip — StarkWare Pedersen hash on gfx950, one lane per hash.
+//
+// Replaces builtins/src/pedersen/mod.rs:31-36 (pedersen_hash, which the
+// reference delegates to starknet-crypto 0.6.1) where it sits on the proving
+// hot path: the top N_FRIENDLY_LAYERS of every FriendlyMerkleTree
+// (crypto/src/merkle/mixed.rs:106-155; src/claims.rs:10) and the single-column
+// leaf rule PedersenHashFn::hash_elements (crypto/src/hash/pedersen.rs:65-76).
+//
+//   H(a, b) = [P0 + a_low*P1 + a_high*P2 + b_low*P3 + b_high*P4].x
+//
+// (a_low = low 248 bits, a_high = top 4 bits of the canonical value;
+// mod.rs:25-30; points from builtins/src/pedersen/constants.rs:5-30.)
+//
+// Fixed-base, 8-bit windows: per input 31 table lookups for the low part and one
+// 4-bit lookup for the high part, each a Jacobian+affine mixed addition
+// (8M + 3S), then one inversion.  The tables (2 x 31 x 255 + 2 x 15 affine
+// points, ~1 MiB) are built once per context on the host and stay L2-resident.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "fp252.h"
+#include "kernels.h"
+
+namespace ss {
+
+struct Aff { Fp x, y; };
+struct Jac { Fp x, y, z; };
+
+static const uint64_t PED_CANON[5][2][4] = {
+    {{0x551fde4050ca6804ull, 0x716b0b1022947733ull, 0x00ee1b87eb599f16ull, 0x049ee3eba8c16007ull},
+     {0xd0405d266e10268aull, 0x4e621062c0e056c1ull, 0xf346d49d06ea0ed3ull, 0x03ca0cfe4b3bc6ddull}},
+    {{0x1080d17957ebe47bull, 0x8fa8120b6d56eb0cull, 0x969c748655fca9e5ull, 0x0234287dcbaffe7full},
+     {0x6ed0268ee89e5615ull, 0x940135dd7a6c94ccull, 0x1e889527d41f4e39ull, 0x03b056f100f96fb2ull}},
+    {{0xb7a6932dba8aa378ull, 0x99099ec1de5e3018ull, 0x3f9dab2656558f33ull, 0x04fa56f376c83db3ull},
+     {0x5168f4e80ff5b54dull, 0x562761f92a7a23b4ull, 0x8113e0c0e47e4401ull, 0x03fa0984c931c9e3ull}},
+    {{0x3aa372f0bd2d6997ull, 0x40c690c74709e90full, 0x764910f75b45f74bull, 0x04ba4cc166be8decull},
+     {0x48151f27b24b219cull, 0xcac5c59a5ce5ae7cull, 0x4b971e46c4ede85full, 0x0040301cf5c1751full}},
+    {{0xd36ff12c49a58202ull, 0x2ca65048d53fb325ull, 0x6e44cca8f61a63bbull, 0x054302dcb0e6cc1cull},
+     {0x879dcc77e99c2426ull, 0xce98ad783c25561aull, 0xb348046268d8ae25ull, 0x01b77b3e37d13504ull}},
+};
+
+static constexpr int PED_WINDOWS = 31;            // 8-bit windows over the low 248 bits
+static constexpr int PED_LOW_ENTRIES = PED_WINDOWS * 255;
+static constexpr int PED_HIGH_ENTRIES = 15;
+static constexpr int PED_PER_INPUT = PED_LOW_ENTRIES + PED_HIGH_ENTRIES;
+
+struct PedersenTables {
+    Aff *d_table;   // [2][PED_PER_INPUT]
+    Aff shift;      // P0
+};
+
+// ------------------------------------------------------------ curve (a = 1)
+SS_HD Jac jac_double(const Jac &p) {
+    Fp xx = fp_sqr(p.x), yy = fp_sqr(p.y), yyyy = fp_sqr(yy), zz = fp_sqr(p.z);
+    Fp s = fp_mul(p.x, yy); s = fp_dbl(fp_dbl(s));
+    Fp m = fp_add(fp_add(fp_dbl(xx), xx), fp_sqr(zz));
+    Jac r;
+    r.x = fp_sub(fp_sqr(m), fp_dbl(s));
+    r.y = fp_sub(fp_mul(m, fp_sub(s, r.x)), fp_dbl(fp_dbl(fp_dbl(yyyy))));
+    r.z = fp_dbl(fp_mul(p.y, p.z));
+    return r;
+}
+// p + q, q affine.  The exceptional cases (p = +-q) are handled: doubling, or
+// the point at infinity encoded as z = 0.
+SS_HD Jac jac_add_aff(const Jac &p, const Aff &q) {
+    if (fp_is_zero(p.z)) { Jac r; r.x = q.x; r.y = q.y; r.z = fp_one(); return r; }
+    Fp zz = fp_sqr(p.z);
+    Fp u2 = fp_mul(q.x, zz), s2 = fp_mul(q.y, fp_mul(zz, p.z));
+    Fp h = fp_sub(u2, p.x), rr = fp_sub(s2, p.y);
+    if (fp_is_zero(h)) {
+        if (fp_is_zero(rr)) return jac_double(p);
+        Jac o; o.x = fp_one(); o.y = fp_one(); o.z = fp_zero(); return o;
+    }
+    Fp hh = fp_sqr(h), hhh = fp_mul(hh, h), v = fp_mul(p.x, hh);
+    Jac r;
+    r.x = fp_sub(fp_sub(fp_sqr(rr), hhh), fp_dbl(v));
+    r.y = fp_sub(fp_mul(rr, fp_sub(v, r.x)), fp_mul(p.y, hhh));
+    r.z = fp_mul(p.z, h);
+    return r;
+}
+
+// --------------------------------------------------------------- host side
+static Fp canon_to_mont(const uint64_t c[4]) {
+    Fp a;
+    for (int i = 0; i < 4; ++i) { a.v[2 * i] = (u32)c[i]; a.v[2 * i + 1] = (u32)(c[i] >> 32); }
+    return fp_to_mont(a);
+}
+
+static void batch_to_affine(std::vector<Jac> &pts, std::vector<Aff> &out) {
+    const size_t n = pts.size();
+    std::vector<Fp> prefix(n);
+    Fp acc = fp_one();
+    for (size_t i = 0; i < n; ++i) { prefix[i] = acc; acc = fp_mul(acc, pts[i].z); }
+    Fp inv = fp_inv(acc);
+    out.resize(n);
+    for (size_t i = n; i-- > 0;) {
+        Fp zi = fp_mul(inv, prefix[i]);
+        inv = fp_mul(inv, pts[i].z);
+        Fp zi2 = fp_sqr(zi);
+        out[i].x = fp_mul(pts[i].x, zi2);
+        out[i].y = fp_mul(pts[i].y, fp_mul(zi2, zi));
+    }
+}
+
+hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
+    Aff pts[5];
+    for (int k = 0; k < 5; ++k) { pts[k].x = canon_to_mont(PED_CANON[k][0]); pts[k].y = canon_to_mont(PED_CANON[k][1]); }
+    std::vector<Jac> jac;
+    jac.reserve(2 * PED_PER_INPUT);
+    for (int e = 0; e < 2; ++e) {
+        // low part: base 2^(8j) * P_{1+2e}
+        Jac base; base.x = pts[1 + 2 * e].x; base.y = pts[1 + 2 * e].y; base.z = fp_one();
+        for (int j = 0; j < PED_WINDOWS; ++j) {
+            std::vector<Jac> one(1, base);
+            std::vector<Aff> ba;
+            batch_to_affine(one, ba);
+            Jac acc = base;
+            jac.push_back(acc);                       // d = 1
+            acc = jac_double(base);
+            jac.push_back(acc);                       // d = 2
+            for (int d = 3; d <= 255; ++d) { acc = jac_add_aff(acc, ba[0]); jac.push_back(acc); }
+            for (int k = 0; k < 8; ++k) base = jac_double(base);
+        }
+        // high part: d * P_{2+2e}, d = 1..15
+        Aff hb = pts[2 + 2 * e];
+        Jac acc; acc.x = hb.x; acc.y = hb.y; acc.z = fp_one();
+        jac.push_back(acc);
+        Jac dbl = jac_double(acc);
+        jac.push_back(dbl);
+        acc = dbl;
+        for (int d = 3; d <= 15; ++d) { acc = jac_add_aff(acc, hb); jac.push_back(acc); }
+    }
+    std::vector<Aff> aff;
+    batch_to_affine(jac, aff);
+    PedersenTables *t = new PedersenTables;
+    t->shift = pts[0];
+    hipError_t e = hipMalloc(&t->d_table, aff.size() * sizeof(Aff));
+    if (e != hipSuccess) { delete t; return e; }
+    e = hipMemcpyAsync(t->d_table, aff.data(), aff.size() * sizeof(Aff), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { hipFree(t->d_table); delete t; return e; }
+    *out = t;
+    return hipSuccess;
+}
+void pedersen_tables_destroy(PedersenTables *t) {
+    if (!t) return;
+    hipFree(t->d_table);
+    delete t;
+}
+
+// ------------------------------------------------------------- device side
+__device__ __forceinline__ Aff load_aff(const Aff *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    Aff r;
+    r.x.v[0] = a.x; r.x.v[1] = a.y; r.x.v[2] = a.z; r.x.v[3] = a.w;
+    r.x.v[4] = b.x; r.x.v[5] = b.y; r.x.v[6] = b.z; r.x.v[7] = b.w;
+    r.y.v[0] = c.x; r.y.v[1] = c.y; r.y.v[2] = c.z; r.y.v[3] = c.w;
+    r.y.v[4] = d.x; r.y.v[5] = d.y; r.y.v[6] = d.z; r.y.v[7] = d.w;
+    return r;
+}
+
+// acc += scalar (canonical integer limbs) over input slot e
+__device__ __forceinline__ void ped_accumulate(Jac &acc, const Fp &canon, const Aff *__restrict__ table, int e) {
+    const Aff *tab = table + e * PED_PER_INPUT;
+#pragma unroll 1
+    for (int j = 0; j < PED_WINDOWS; ++j) {
+        const u32 d = (canon.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
+        if (d) acc = jac_add_aff(acc, load_aff(tab + j * 255 + (d - 1)));
+    }
+    const u32 dh = (canon.v[7] >> 24) & 0xfu;     // bits 248..251
+    if (dh) acc = jac_add_aff(acc, load_aff(tab + PED_LOW_ENTRIES + (dh - 1)));
+}
+
+// both inputs canonical (< p); returns x in Montgomery form
+__device__ __forceinline__ Fp ped_hash_canon(const Fp &a, const Fp &b, const Aff *__restrict__ table, const Aff &shift) {
+    Jac acc; acc.x = shift.x; acc.y = shift.y; acc.z = fp_one();
+    ped_accumulate(acc, a, table, 0);
+    ped_accumulate(acc, b, table, 1);
+    Fp zi = fp_inv(acc.z);
+    return fp_mul(acc.x, fp_sqr(zi));
+}
+
+// 32 big-endian bytes -> canonical integer mod p
+__device__ __forceinline__ Fp be_bytes_to_canon(const uint8_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fp v;
+    v.v[7] = __builtin_bswap32(a.x); v.v[6] = __builtin_bswap32(a.y); v.v[5] = __builtin_bswap32(a.z); v.v[4] = __builtin_bswap32(a.w);
+    v.v[3] = __builtin_bswap32(b.x); v.v[2] = __builtin_bswap32(b.y); v.v[1] = __builtin_bswap32(b.z); v.v[0] = __builtin_bswap32(b.w);
+    // value < 2^256 < 32p: subtract p while >= p (digests entering the tree are < 2^160 or < p already)
+    for (int i = 0; i < 32; ++i) {
+        Fp r = fp_reduce_once(v);
+        if (fp_eq(r, v)) break;
+        v = r;
+    }
+    return v;
+}
+__device__ __forceinline__ void canon_to_be_bytes(const Fp &c, uint8_t *out) {
+    uint4 *q = reinterpret_cast<uint4 *>(out);
+    q[0] = make_uint4(__builtin_bswap32(c.v[7]), __builtin_bswap32(c.v[6]), __builtin_bswap32(c.v[5]), __builtin_bswap32(c.v[4]));
+    q[1] = make_uint4(__builtin_bswap32(c.v[3]), __builtin_bswap32(c.v[2]), __builtin_bswap32(c.v[1]), __builtin_bswap32(c.v[0]));
+}
+__device__ __forceinline__ Fp load_felt(const Fp *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void store_felt(Fp *p, const Fp &x) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    q[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+__global__ __launch_bounds__(64) void pedersen_felts_kernel(const Aff *__restrict__ table, Aff shift,
+                                                            const Fp *__restrict__ a, const Fp *__restrict__ b,
+                                                            uint64_t n, Fp *__restrict__ out) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp ca = fp_from_mont(load_felt(a + i)), cb = fp_from_mont(load_felt(b + i));
+    store_felt(out + i, ped_hash_canon(ca, cb, table, shift));
+}
+
+__global__ __launch_bounds__(64) void pedersen_pairs_kernel(const Aff *__restrict__ table, Aff shift,
+                                                            const uint8_t *__restrict__ in, uint64_t count,
+                                                            uint8_t *__restrict__ out) {
+    const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    Fp ca = be_bytes_to_canon(in + 64 * k), cb = be_bytes_to_canon(in + 64 * k + 32);
+    Fp h = ped_hash_canon(ca, cb, table, shift);
+    canon_to_be_bytes(fp_from_mont(h), out + 32 * k);
+}
+
+// PedersenHashFn::hash_elements([l0, l1]) = H(H(H(0, l0), l1), 2)
+__global__ __launch_bounds__(64) void pedersen_felt_pairs_kernel(const Aff *__restrict__ table, Aff shift,
+                                                                 const Fp *__restrict__ felts, uint64_t count,
+                                                                 uint8_t *__restrict__ out) {
+    const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    Fp l0 = fp_from_mont(load_felt(felts + 2 * k)), l1 = fp_from_mont(load_felt(felts + 2 * k + 1));
+    Fp h = ped_hash_canon(fp_zero(), l0, table, shift);
+    h = ped_hash_canon(fp_from_mont(h), l1, table, shift);
+    Fp two = fp_zero(); two.v[0] = 2;
+    h = ped_hash_canon(fp_from_mont(h), two, table, shift);
+    canon_to_be_bytes(fp_from_mont(h), out + 32 * k);
+}
+
+hipError_t launch_pedersen_felts(hipStream_t st, const PedersenTables *t, const Fp *a, const Fp *b,
+                                 uint64_t n, Fp *out) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pedersen_felts_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, st, t->d_table,
+                       t->shift, a, b, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_pedersen_pairs(hipStream_t st, const PedersenTables *t, const uint8_t *in, uint64_t count,
+                                 uint8_t *out) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(pedersen_pairs_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table,
+                       t->shift, in, count, out);
+    return hipGetLastError();
+}
+hipError_t launch_pedersen_felt_pairs(hipStream_t st, const PedersenTables *t, const Fp *felts,
+                                      uint64_t count, uint8_t *out) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(pedersen_felt_pairs_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st,
+                       t->d_table, t->shift, felts, count, out);
+    return hipGetLastError();
+}
+
+}  // namespace ss

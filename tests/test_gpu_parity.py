@@ -1,0 +1,314 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs, against the committed golden vectors, and — at sizes the
+oracle cannot reach in seconds — through size-independent properties.
+
+Bar: bit-exact (integer / byte work).  Run with `pytest -m gpu` on an MI355X.
+"""
+import numpy as np
+import pytest
+
+from tests.util import P, felt_int, random_column
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sandstorm_amd.backend import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def be():
+    from sandstorm_amd import backend
+    return backend
+
+
+def _up(ctx, cols):
+    return [ctx.column(c) for c in cols]
+
+
+def _down(bufs, n):
+    return [b.download(np.uint64, (n, 4)) for b in bufs]
+
+
+G3 = None
+
+
+def g3(oracle):
+    global G3
+    if G3 is None:
+        G3 = oracle.to_mont([3])[0]
+    return G3
+
+
+# ----------------------------------------------------------------------------- NTT
+@pytest.mark.parametrize("name,n", [("ntt_pedersen512.json", 512), ("ntt_ecdsa256.json", 256)])
+def test_ntt_golden_kat(ctx, be, oracle, golden, name, n):
+    """The reference's own periodic-column NTT known-answer tests, on the GPU."""
+    g = golden(name)
+    for axis in ("x", "y"):
+        coeffs = oracle.to_mont([int(v) for v in g["coeffs_" + axis]])
+        want = oracle.to_mont([int(v) for v in g["evals_" + axis]])
+        d = _up(ctx, [coeffs])
+        ctx.ntt(d, n.bit_length() - 1, be.FORWARD)
+        got = _down(d, n)[0]
+        assert np.array_equal(got, want)
+        ctx.ntt(d, n.bit_length() - 1, be.INVERSE)
+        assert np.array_equal(_down(d, n)[0], coeffs)
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 4, 7, 10, 11, 12, 13, 15, 18])
+@pytest.mark.parametrize("coset", [False, True])
+def test_ntt_vs_oracle(ctx, be, oracle, log_n, coset):
+    n = 1 << log_n
+    cols = [random_column(n, c) for c in range(2)]
+    off = g3(oracle) if coset else None
+    d = _up(ctx, cols)
+    ctx.ntt(d, log_n, be.FORWARD, off)
+    got = _down(d, n)
+    for c in range(2):
+        assert np.array_equal(got[c], oracle.ntt(cols[c], offset=off)), (log_n, c)
+    ctx.ntt(d, log_n, be.INVERSE, off)
+    back = _down(d, n)
+    for c in range(2):
+        assert np.array_equal(back[c], cols[c])
+
+
+def test_ntt_orders(ctx, be, oracle):
+    log_n, n = 12, 4096
+    col = random_column(n, 7)
+    want = oracle.ntt(col)
+    # bit-reversed input
+    d = _up(ctx, [oracle.bitrev_permute(col)])
+    ctx.ntt(d, log_n, be.FORWARD, None, be.BITREV, be.NATURAL)
+    assert np.array_equal(_down(d, n)[0], want)
+    # bit-reversed output
+    d = _up(ctx, [col])
+    ctx.ntt(d, log_n, be.FORWARD, None, be.NATURAL, be.BITREV)
+    assert np.array_equal(_down(d, n)[0], oracle.bitrev_permute(want))
+    # inverse to bit-reversed coefficients, then forward from them
+    d = _up(ctx, [want])
+    ctx.ntt(d, log_n, be.INVERSE, None, be.NATURAL, be.BITREV)
+    assert np.array_equal(_down(d, n)[0], oracle.bitrev_permute(col))
+    ctx.ntt(d, log_n, be.FORWARD, None, be.BITREV, be.NATURAL)
+    assert np.array_equal(_down(d, n)[0], want)
+
+
+def test_ntt_many_columns(ctx, be, oracle):
+    """more columns than one launch's pointer table (16)"""
+    log_n, n = 9, 512
+    cols = [random_column(n, c) for c in range(19)]
+    d = _up(ctx, cols)
+    ctx.ntt(d, log_n, be.FORWARD, g3(oracle))
+    got = _down(d, n)
+    for c in range(19):
+        assert np.array_equal(got[c], oracle.ntt(cols[c], offset=g3(oracle))), c
+
+
+@pytest.mark.parametrize("log_n,log_blowup,ncols", [(4, 1, 2), (10, 1, 3), (11, 1, 1), (12, 2, 2), (14, 1, 10), (16, 1, 2)])
+def test_lde_vs_oracle(ctx, be, oracle, log_n, log_blowup, ncols):
+    n = 1 << log_n
+    cols = [random_column(n, c + 100) for c in range(ncols)]
+    m = be.Matrix.from_host(ctx, cols)
+    ev, co = m.lde(log_blowup, g3(oracle))
+    ev_h, co_h = ev.to_host(), co.to_host()
+    for c in range(ncols):
+        want_ev, want_co = oracle.lde(cols[c], log_blowup, g3(oracle))
+        assert np.array_equal(ev_h[c], want_ev), c
+        assert np.array_equal(co_h[c], oracle.bitrev_permute(want_co)), c
+    # without keeping coefficients
+    ev2, none = m.lde(log_blowup, g3(oracle), keep_coeffs=False)
+    assert none is None
+    assert np.array_equal(ev2.to_host()[0], ev_h[0])
+
+
+def test_ntt_2_20_vs_oracle(ctx, be, oracle):
+    """recursive layout at 2^16 steps: n = 2^20 rows (BASELINE configs[1])"""
+    log_n, n = 20, 1 << 20
+    col = random_column(n, 1)
+    d = _up(ctx, [col])
+    ctx.ntt(d, log_n, be.FORWARD, g3(oracle))
+    assert np.array_equal(_down(d, n)[0], oracle.ntt(col, offset=g3(oracle)))
+
+
+def test_ntt_large_impulse_and_roundtrip(ctx, be, oracle):
+    """2^24 points (starknet layout at 2^20 steps): forward(x + d*e_j) - forward(x) is the
+    impulse response d * (g w^k)^j at sampled k, and inverse(forward(x)) == x."""
+    log_n, n = 24, 1 << 24
+    base = random_column(n, 1)
+    js = [0, 1, 4097, n // 2 + 3, n - 1]
+    delta = 0x1234567
+    cols = [base]
+    for j in js:
+        c = base.copy()
+        c[j] = oracle.to_mont([(int(oracle.from_mont(base[j])) + delta) % P])[0]
+        cols.append(c)
+    d = _up(ctx, cols)
+    ctx.ntt(d, log_n, be.FORWARD, g3(oracle))
+    w = pow(3, (P - 1) >> log_n, P)
+    ks = [0, 1, 2, 2048, 2049, 1 << 18, n // 2, n - 1]
+    idx = np.array(ks, dtype=np.uint64)
+    rows = ctx.gather_rows(d, idx)                       # (len(ks), ncols, 4)
+    for qi, k in enumerate(ks):
+        f0 = int(oracle.from_mont(rows[qi, 0]))
+        x = 3 * pow(w, k, P) % P
+        for ci, j in enumerate(js):
+            fj = int(oracle.from_mont(rows[qi, 1 + ci]))
+            assert (fj - f0) % P == delta * pow(x, j, P) % P, (k, j)
+    ctx.ntt(d[:2], log_n, be.INVERSE, g3(oracle))
+    back = _down(d[:2], n)
+    assert np.array_equal(back[0], cols[0]) and np.array_equal(back[1], cols[1])
+
+
+def test_lde_large_consistency(ctx, be, oracle):
+    """2^20-row trace, blowup 2 (BASELINE config #2): the LDE interpolates back to a
+    degree < n polynomial whose coefficients are the kept ones, and the trace-domain
+    evaluations reappear at the right coset when offset = 1."""
+    log_n, n = 20, 1 << 20
+    col = random_column(n, 42)
+    m = be.Matrix.from_host(ctx, [col])
+    ev, co = m.lde(1, g3(oracle))
+    back = be.Matrix(ctx, [ev.cols[0]], 2 * n)
+    back.interpolate(g3(oracle), out_order=be.BITREV)          # bit-reversed coefficients of length 2n
+    c2 = back.to_host()[0]
+    # bit-reversed layout: position 2q holds coefficient bitrev(q) (< n), odd positions the top half
+    assert not np.any(c2[1::2])
+    assert np.array_equal(c2[0::2], co.to_host()[0])
+    ev1, _ = m.lde(1, oracle.to_mont([1])[0], keep_coeffs=False)
+    assert np.array_equal(ev1.to_host()[0][0::2], col)
+
+
+# ------------------------------------------------------------------------- hashing
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("ncols", [1, 2, 3, 4, 7, 8, 9, 10, 16])
+def test_hash_rows_vs_oracle(ctx, be, oracle, kind, ncols):
+    n = 300 if ncols % 2 else 1024                     # a ragged and a full grid
+    cols = [random_column(n, c + 7 * kind) for c in range(ncols)]
+    m = be.Matrix.from_host(ctx, cols)
+    got = m.hash_rows(kind).download(np.uint8, (n, 32))
+    assert np.array_equal(got, oracle.hash_rows(kind, cols))
+
+
+def test_hash_rows_large_checksum(ctx, be, oracle):
+    """2^20 rows x 7 columns (recursive base trace): spot rows against the oracle and
+    an order-independent XOR checksum against a second GPU run on a permuted copy."""
+    n = 1 << 20
+    cols = [random_column(n, c) for c in range(7)]
+    m = be.Matrix.from_host(ctx, cols)
+    got = m.hash_rows(be.HASH_BLAKE2S_M20).download(np.uint8, (n, 32))
+    sel = np.array([0, 1, 255, 256, 65535, n - 1])
+    want = oracle.hash_rows(be.HASH_BLAKE2S_M20, [c[sel] for c in cols])
+    assert np.array_equal(got[sel], want)
+    perm = np.random.default_rng(0).permutation(n)
+    m2 = be.Matrix.from_host(ctx, [c[perm] for c in cols])
+    got2 = m2.hash_rows(be.HASH_BLAKE2S_M20).download(np.uint8, (n, 32))
+    assert np.array_equal(got2, got[perm])
+
+
+@pytest.mark.parametrize("tree,leaf_kind,nf", [(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0),
+                                              (2, 0, 0), (2, 0, 1), (2, 0, 3), (2, 0, 22), (2, 1, 22)])
+@pytest.mark.parametrize("log_n", [1, 3, 8])
+def test_merkle_vs_oracle(ctx, be, oracle, tree, leaf_kind, nf, log_n):
+    n = 1 << log_n
+    if leaf_kind == 0:
+        kind = tree if tree < 2 else be.HASH_BLAKE2S_M20
+        leaves = oracle.hash_rows(kind, [random_column(n, 0), random_column(n, 1)])
+    else:
+        leaves = random_column(n, 5)
+    want_nodes, want_tags = oracle.merkle_build(tree, nf, leaf_kind, leaves)
+    d_leaves = ctx.alloc(32 * n).upload(leaves)
+    nodes, tags = ctx.alloc(64 * n), ctx.alloc(2 * n)
+    root, root_tag = ctx.merkle_build(tree, nf, leaf_kind, d_leaves, n, nodes, tags)
+    got_nodes = nodes.download(np.uint8, (2 * n, 32))
+    assert np.array_equal(got_nodes[1:], want_nodes[1:])
+    assert root == bytes(want_nodes[1])
+    if tree == 2:
+        assert np.array_equal(tags.download(np.uint8, (2 * n,))[1:], want_tags[1:])
+        assert root_tag == want_tags[1]
+    # openings
+    idx = sorted(set([0, n - 1, n // 2, min(3, n - 1)]))
+    paths, ptags = ctx.merkle_open(nodes, tags, n, idx)
+    for q, i in enumerate(idx):
+        k = n + i
+        for lvl in range(log_n):
+            assert bytes(paths[q, lvl]) == bytes(want_nodes[k ^ 1])
+            k >>= 1
+
+
+def test_merkle_tree_classes(ctx, be, oracle):
+    """from_matrix / root / prove on the reference's 8-row test matrices (merkle/mod.rs:455-634)."""
+    col = oracle.to_mont(list(range(8)))
+    for cls, tree, nf, kind in ((be.LeafVariantMerkleTreeUnmasked, 0, 0, 0), (be.LeafVariantMerkleTree, 1, 0, 1),
+                                (be.FriendlyMerkleTree, 2, 22, 3)):
+        for ncols in (1, 2):
+            m = be.Matrix.from_host(ctx, [col] * ncols)
+            t = cls.from_matrix(m)
+            if ncols == 1:
+                want, _ = oracle.merkle_build(tree, nf, 1, col)
+            else:
+                want, _ = oracle.merkle_build(tree, nf, 0, oracle.hash_rows(kind, [col] * ncols))
+            assert t.root() == bytes(want[1])
+            paths, _ = t.prove([3])
+            assert bytes(paths[0, 0]) == bytes(want[(8 + 3) ^ 1])
+
+
+# ------------------------------------------------------------------------ Pedersen
+def test_pedersen_golden_and_oracle(ctx, be, oracle, golden):
+    g = golden("pedersen.json")
+    cases = g["hash_examples"] + g["extra"]
+    a = oracle.to_mont([int(c["a"]) for c in cases])
+    b = oracle.to_mont([int(c["b"]) for c in cases])
+    ra, rb = random_column(200, 11), random_column(200, 12)
+    A, B = np.concatenate([a, ra]), np.concatenate([b, rb])
+    n = A.shape[0]
+    out = ctx.alloc(32 * n)
+    ctx.pedersen_hash(ctx.column(A), ctx.column(B), n, out)
+    got = out.download(np.uint64, (n, 4))
+    for i, c in enumerate(cases):
+        assert oracle.from_mont(got[i]) == int(c["hash"]), c
+    for i in range(len(cases), n):
+        assert np.array_equal(got[i], oracle.pedersen_hash(A[i], B[i])), i
+
+
+# ----------------------------------------------------------------------------- FRI
+@pytest.mark.parametrize("fold", [2, 4, 8, 16])
+@pytest.mark.parametrize("log_len", [4, 9, 13])
+def test_fri_fold_vs_oracle(ctx, be, oracle, fold, log_len):
+    n = 1 << log_len
+    ev = random_column(n, 3 + fold)
+    alpha = oracle.to_mont([0x1234567890ABCDEF ** 3 % P])[0]
+    off = g3(oracle)
+    out = ctx.alloc(32 * (n // fold))
+    ctx.fri_fold(ctx.column(ev), log_len, fold, alpha, off, out)
+    got = out.download(np.uint64, (n // fold, 4))
+    assert np.array_equal(got, oracle.fri_fold(ev, fold, alpha, off))
+
+
+def test_fri_fold_large_degree_property(ctx, be, oracle):
+    """2^21 evaluations of a degree < 2^18 polynomial fold (x8) to evaluations of a degree < 2^15 one."""
+    log_len, n = 21, 1 << 21
+    coeffs = np.zeros((n, 4), dtype=np.uint64)
+    coeffs[: 1 << 18] = random_column(1 << 18, 9)
+    d = _up(ctx, [coeffs])
+    ctx.ntt(d, log_len, be.FORWARD, g3(oracle))
+    out = ctx.alloc(32 * (n // 8))
+    alpha = oracle.to_mont([77])[0]
+    ctx.fri_fold(d[0], log_len, 8, alpha, g3(oracle), out)
+    ctx.ntt([out], log_len - 3, be.INVERSE, oracle.to_mont([pow(3, 8, P)])[0])
+    c2 = out.download(np.uint64, (n // 8, 4))
+    assert not np.any(c2[1 << 15:])
+    cs = oracle.from_mont(coeffs[:64])
+    for m in range(8):
+        assert oracle.from_mont(c2[m]) == sum(pow(77, k, P) * int(cs[8 * m + k]) for k in range(8)) % P
+
+
+# ----------------------------------------------------------------------------- PoW
+@pytest.mark.parametrize("kind", [0, 1])
+def test_pow_grind_vs_oracle(ctx, be, oracle, kind):
+    digest = bytes((5 * i + kind) & 0xff for i in range(32))
+    coin = oracle.Coin(kind, digest)
+    for bits in (1, 8, 16):
+        assert ctx.pow_grind(kind, digest, bits) == coin.grind(bits), bits
