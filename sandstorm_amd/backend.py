@@ -171,6 +171,57 @@ class Context:
     def pedersen_hash(self, a, b, n, out):
         check(self.lib.ss_pedersen_hash(self.handle, _ptr_of(a), _ptr_of(b), n, _ptr_of(out)))
 
+    # ---- D1 -------------------------------------------------------------------------------
+    def poly_eval(self, coeff_cols, log_n, x):
+        """P_c(x) for bit-reversed coefficient columns -> uint64[ncols, 4]"""
+        _k, xp = _felt_ptr(x)
+        out = np.zeros((len(coeff_cols), 4), dtype=np.uint64)
+        check(self.lib.ss_poly_eval(self.handle, _ptr_array(coeff_cols), len(coeff_cols), log_n, xp,
+                                    out.ctypes.data))
+        return out
+
+    def ood_eval(self, coeff_cols, log_n, mask_col, mask_off, z):
+        """T_{col_j}(z * w_n^{off_j}) -> uint64[nmask, 4]"""
+        mc = np.ascontiguousarray(mask_col, dtype=np.uint32)
+        mo = np.ascontiguousarray(mask_off, dtype=np.uint32)
+        _k, zp = _felt_ptr(z)
+        out = np.zeros((len(mc), 4), dtype=np.uint64)
+        check(self.lib.ss_ood_eval(self.handle, _ptr_array(coeff_cols), len(coeff_cols), log_n,
+                                   mc.ctypes.data_as(C.POINTER(C.c_uint32)), mo.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                   len(mc), zp, out.ctypes.data))
+        return out
+
+    def deep_compose(self, trace_cols, comp_cols, log_n, log_blowup, offset, mask_col, mask_off, ood_trace,
+                     coeff_trace, ood_comp, coeff_comp, z, out):
+        mc = np.ascontiguousarray(mask_col, dtype=np.uint32)
+        mo = np.ascontiguousarray(mask_off, dtype=np.uint32)
+        ot, ct = (np.ascontiguousarray(a, dtype=np.uint64) for a in (ood_trace, coeff_trace))
+        oc, cc = (np.ascontiguousarray(a, dtype=np.uint64) for a in (ood_comp, coeff_comp))
+        _k1, op = _felt_ptr(offset)
+        _k2, zp = _felt_ptr(z)
+        check(self.lib.ss_deep_compose(self.handle, _ptr_array(trace_cols), len(trace_cols),
+                                       _ptr_array(comp_cols) if comp_cols else None, len(comp_cols), log_n,
+                                       log_blowup, op, mc.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       mo.ctypes.data_as(C.POINTER(C.c_uint32)), len(mc), ot.ctypes.data,
+                                       ct.ctypes.data, oc.ctypes.data, cc.ctypes.data, zp, _ptr_of(out)))
+
+    # ---- Q1 -------------------------------------------------------------------------------
+    def eval_quotient(self, program, tables, table_desc, lde_cols, log_n, log_blowup, offset, out):
+        """program: air_program.Program; tables: device buffer of concatenated felts (or None);
+        table_desc: flat [offset, log_len, ...] list"""
+        code = np.ascontiguousarray(program.code, dtype=np.uint32)
+        consts = np.zeros((max(1, len(program.consts)), 4), dtype=np.uint64)
+        for i, v in enumerate(program.consts):
+            consts[i] = felt(v)
+        desc = np.ascontiguousarray(table_desc if len(table_desc) else [0, 0], dtype=np.uint32)
+        prog = _lib.AirProgram(code.ctypes.data_as(C.POINTER(C.c_uint32)), len(code) // 2,
+                               consts.ctypes.data_as(C.POINTER(C.c_uint64)), len(program.consts),
+                               _ptr_of(tables) if tables is not None else None,
+                               desc.ctypes.data_as(C.POINTER(C.c_uint32)), len(table_desc) // 2, program.n_slots)
+        _k, op = _felt_ptr(offset)
+        check(self.lib.ss_eval_quotient(self.handle, C.byref(prog), _ptr_array(lde_cols), len(lde_cols), log_n,
+                                        log_blowup, op, _ptr_of(out)))
+
     def profile(self, on):
         check(self.lib.ss_profile_enable(self.handle, 1 if on else 0))
 

@@ -6,6 +6,7 @@
 // quotient.hip; there is no CPU fallback — without a usable HIP device every
 // entry point returns SS_ERR_NO_DEVICE / SS_ERR_HIP.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -111,13 +112,8 @@ struct ss_ctx {
     }
 
     // Twiddle plan for the stage network of size 2^log_n: T_s[k] = h^(n/2^(s+1)) * r^(k n/2^(s+1)),
-    // r = w (forward) or w^-1 (inverse), h = offset or offset^-1.
-    ss_status get_plan(uint32_t log_n, bool inverse, const Fp &offset, const Fp **out) {
-        PlanKey key;
-        key.log_n = log_n; key.inverse = inverse ? 1 : 0;
-        memcpy(key.off, offset.v, sizeof key.off);
-        auto it = plans.find(key);
-        if (it != plans.end()) { *out = it->second; return SS_OK; }
+    // r = w (forward) or w^-1 (inverse), h = offset or offset^-1.  Written into d_tw (n-1 felts).
+    ss_status build_plan(uint32_t log_n, bool inverse, const Fp &offset, Fp *d_tw) {
         const uint64_t n = 1ull << log_n;
         Fp r = root_of_unity(log_n), h = offset;
         if (inverse) { r = fp_inv(r); h = fp_inv(h); }
@@ -135,16 +131,53 @@ struct ss_ctx {
             hp[log_n - 1] = h;
             for (uint32_t s = log_n - 1; s-- > 0;) hp[s] = fp_sqr(hp[s + 1]);
         }
-        Fp *d_tabs = nullptr, *d_tw = nullptr;
+        Fp *d_tabs = nullptr;
         HIP_TRY(hipMalloc(&d_tabs, host.size() * sizeof(Fp)));
-        HIP_TRY(hipMalloc(&d_tw, (n > 1 ? n - 1 : 1) * sizeof(Fp)));
         HIP_TRY(hipMemcpyAsync(d_tabs, host.data(), host.size() * sizeof(Fp), hipMemcpyHostToDevice, stream));
         if (log_n > 0)
             HIP_TRY(launch_twiddles(stream, d_tw, d_tabs, d_tabs + n_lo, d_tabs + n_lo + n_hi, log_n, h_is_one));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipFree(d_tabs));
+        return SS_OK;
+    }
+    // cached plans: the per-proof-invariant ones (trace / LDE / FRI domains)
+    ss_status get_plan(uint32_t log_n, bool inverse, const Fp &offset, const Fp **out) {
+        PlanKey key;
+        key.log_n = log_n; key.inverse = inverse ? 1 : 0;
+        memcpy(key.off, offset.v, sizeof key.off);
+        auto it = plans.find(key);
+        if (it != plans.end()) { *out = it->second; return SS_OK; }
+        Fp *d_tw = nullptr;
+        HIP_TRY(hipMalloc(&d_tw, ((1ull << log_n) > 1 ? (1ull << log_n) - 1 : 1) * sizeof(Fp)));
+        ss_status st = build_plan(log_n, inverse, offset, d_tw);
+        if (st != SS_OK) { (void)hipFree(d_tw); return st; }
         plans[key] = d_tw;
         *out = d_tw;
+        return SS_OK;
+    }
+    // one reusable slot for plans whose offset changes every proof (the OOD point z)
+    Fp *transient_tw = nullptr;
+    size_t transient_elems = 0;
+    ss_status get_transient_plan(uint32_t log_n, bool inverse, const Fp &offset, const Fp **out) {
+        const size_t need = (size_t)1 << log_n;
+        if (need > transient_elems) {
+            if (transient_tw) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(transient_tw)); transient_tw = nullptr; }
+            HIP_TRY(hipMalloc(&transient_tw, need * sizeof(Fp)));
+            transient_elems = need;
+        }
+        ss_status st = build_plan(log_n, inverse, offset, transient_tw);
+        if (st != SS_OK) return st;
+        *out = transient_tw;
+        return SS_OK;
+    }
+    // second grow-only scratch (tables that must coexist with `scratch`)
+    void *scratch2 = nullptr;
+    size_t scratch2_bytes = 0;
+    ss_status ensure_scratch2(size_t bytes) {
+        if (bytes <= scratch2_bytes) return SS_OK;
+        if (scratch2) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(scratch2)); scratch2 = nullptr; scratch2_bytes = 0; }
+        HIP_TRY(hipMalloc(&scratch2, bytes));
+        scratch2_bytes = bytes;
         return SS_OK;
     }
 };
@@ -245,6 +278,8 @@ void ss_ctx_destroy(ss_ctx *ctx) {
     for (auto &kv : ctx->plans) hipFree(kv.second);
     pedersen_tables_destroy(ctx->ped);
     if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->scratch2) hipFree(ctx->scratch2);
+    if (ctx->transient_tw) hipFree(ctx->transient_tw);
     if (ctx->d_small) hipFree(ctx->d_small);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -547,6 +582,218 @@ ss_status ss_fp252_mul_bench(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d
                              uint64_t *d_out) {
     if (!ctx || !d_a || !d_b || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
     HIP_TRY(launch_mul_bench(ctx->stream, (const Fp *)d_a, (const Fp *)d_b, (Fp *)d_out, n, reps));
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------- D1
+ss_status ss_poly_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t ncols, uint32_t log_n,
+                       const uint64_t x[4], uint64_t *out) {
+    if (!ctx || !d_coeffs || !x || !out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!valid_log(log_n)) return fail(SS_ERR_INVALID, "log_n out of range");
+    if (ncols == 0) return SS_OK;
+    if (ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u > %d", ncols, MAX_COLS);
+    // x^(2^j), j < log_n
+    std::vector<Fp> xp(log_n);
+    xp[0] = fp_from_limbs64(x);
+    for (uint32_t j = 1; j < log_n; ++j) xp[j] = fp_sqr(xp[j - 1]);
+    const uint64_t n = 1ull << log_n;
+    const size_t per_col = (size_t)((n >> 1) + (n >> 2) + 2) * sizeof(Fp);      // two ping-pong regions
+    ss_status st = ctx->ensure_scratch(per_col * ncols);
+    if (st != SS_OK) return st;
+    const void *in[MAX_COLS];
+    void *bufa[MAX_COLS], *bufb[MAX_COLS];
+    for (uint32_t c = 0; c < ncols; ++c) {
+        in[c] = d_coeffs[c];
+        bufa[c] = (char *)ctx->scratch + per_col * c;
+        bufb[c] = (char *)bufa[c] + ((n >> 1) + 1) * sizeof(Fp);
+    }
+    uint32_t lc = log_n;
+    bool to_a = true;
+    const void *const *src = in;
+    while (lc > 0) {
+        const uint32_t lv = lc >= 3 ? 3 : lc;
+        Fp mult[3];
+        for (uint32_t k = 0; k < lv; ++k) mult[k] = xp[lc - 1 - k];
+        void *const *dst = to_a ? bufa : bufb;
+        HIP_TRY(launch_poly_reduce(ctx->stream, src, dst, ncols, 1ull << lc, lv, mult));
+        src = (const void *const *)dst;
+        to_a = !to_a;
+        lc -= lv;
+    }
+    for (uint32_t c = 0; c < ncols; ++c)
+        HIP_TRY(hipMemcpyAsync(out + 4 * c, src[c], sizeof(Fp), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+ss_status ss_ood_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t ncols, uint32_t log_n,
+                      const uint32_t *mask_col, const uint32_t *mask_off, uint32_t nmask, const uint64_t z[4],
+                      uint64_t *out) {
+    if (!ctx || !d_coeffs || !z || (nmask && (!mask_col || !mask_off || !out))) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!valid_log(log_n)) return fail(SS_ERR_INVALID, "log_n out of range");
+    if (ncols == 0 || ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u not in [1,%d]", ncols, MAX_COLS);
+    if (nmask == 0) return SS_OK;
+    for (uint32_t j = 0; j < nmask; ++j)
+        if (mask_col[j] >= ncols) return fail(SS_ERR_INVALID, "mask cell %u names column %u", j, mask_col[j]);
+    // T_c(z w^k) for every k at once: one coset NTT (offset z) of each coefficient column
+    const uint64_t n = 1ull << log_n;
+    const size_t col_bytes = sizeof(Fp) << log_n;
+    const size_t small = (size_t)nmask * (4 + 8 + 32);
+    ss_status st = ctx->ensure_scratch(col_bytes * ncols + small);
+    if (st != SS_OK) return st;
+    const Fp *tw = nullptr;
+    st = ctx->get_transient_plan(log_n, false, fp_from_limbs64(z), &tw);
+    if (st != SS_OK) return st;
+    ColPtrs cols;
+    memset(&cols, 0, sizeof cols);
+    const void *evs[MAX_COLS];
+    for (uint32_t c = 0; c < ncols; ++c) {
+        cols.src[c] = d_coeffs[c];
+        cols.dst[c] = (char *)ctx->scratch + col_bytes * c;
+        evs[c] = cols.dst[c];
+    }
+    st = run_forward(ctx, cols, ncols, log_n, tw, 0);
+    if (st != SS_OK) return st;
+    char *sm = (char *)ctx->scratch + col_bytes * ncols;
+    uint64_t *d_idx = (uint64_t *)sm;
+    Fp *d_out = (Fp *)(sm + (size_t)nmask * 8);
+    uint32_t *d_col = (uint32_t *)(sm + (size_t)nmask * 40);
+    std::vector<uint64_t> idx(nmask);
+    for (uint32_t j = 0; j < nmask; ++j) idx[j] = mask_off[j] & (n - 1);
+    HIP_TRY(hipMemcpyAsync(d_idx, idx.data(), (size_t)nmask * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_col, mask_col, (size_t)nmask * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_gather_cells(ctx->stream, evs, ncols, d_col, d_idx, nmask, d_out));
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)nmask * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_t ntrace_cols,
+                          const uint64_t *const *d_comp_lde, uint32_t ncomp, uint32_t log_n, uint32_t log_blowup,
+                          const uint64_t offset[4], const uint32_t *mask_col, const uint32_t *mask_off,
+                          uint32_t nmask, const uint64_t *ood_trace, const uint64_t *coeff_trace,
+                          const uint64_t *ood_comp, const uint64_t *coeff_comp, const uint64_t z[4],
+                          uint64_t *d_out) {
+    if (!ctx || !d_trace_lde || !z || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (nmask && (!mask_col || !mask_off || !ood_trace || !coeff_trace)) return fail(SS_ERR_INVALID, "NULL mask argument");
+    if (ncomp && (!d_comp_lde || !ood_comp || !coeff_comp)) return fail(SS_ERR_INVALID, "NULL composition argument");
+    const uint32_t log_N = log_n + log_blowup;
+    if (!valid_log(log_n) || !valid_log(log_N)) return fail(SS_ERR_INVALID, "size out of range");
+    if (ntrace_cols > (uint32_t)MAX_COLS || ncomp > 4) return fail(SS_ERR_UNSUPPORTED, "too many columns");
+    const uint64_t N = 1ull << log_N, n = 1ull << log_n;
+    const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
+    const Fp zf = fp_from_limbs64(z);
+    const Fp wN = root_of_unity(log_N), wN_inv = fp_inv(wN);
+    const Fp wn_inv = fp_inv(root_of_unity(log_n));
+    // group mask cells by row offset
+    std::vector<uint32_t> order(nmask);
+    for (uint32_t j = 0; j < nmask; ++j) order[j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (mask_off[a] & (n - 1)) < (mask_off[b] & (n - 1)); });
+    std::vector<uint32_t> cell_col(nmask), gdesc;
+    std::vector<Fp> cell_coef(nmask), group_k;
+    for (uint32_t t = 0; t < nmask;) {
+        const uint32_t offv = mask_off[order[t]] & (uint32_t)(n - 1);
+        const Fp wk = fp_pow_u64(wn_inv, offv);
+        Fp kacc = fp_zero();
+        uint32_t first = t;
+        for (; t < nmask && (mask_off[order[t]] & (n - 1)) == offv; ++t) {
+            const uint32_t j = order[t];
+            if (mask_col[j] >= ntrace_cols) return fail(SS_ERR_INVALID, "mask cell %u names column %u", j, mask_col[j]);
+            cell_col[t] = mask_col[j];
+            cell_coef[t] = fp_mul(fp_from_limbs64(coeff_trace + 4 * j), wk);
+            kacc = fp_add(kacc, fp_mul(cell_coef[t], fp_from_limbs64(ood_trace + 4 * j)));
+        }
+        gdesc.push_back(offv << log_blowup); gdesc.push_back(first); gdesc.push_back(t - first);
+        group_k.push_back(kacc);
+    }
+    const uint32_t ngroups = (uint32_t)group_k.size();
+    std::vector<Fp> comp_coef(ncomp ? ncomp : 1);
+    Fp comp_k = fp_zero(), zc = fp_one();
+    for (uint32_t k = 0; k < ncomp; ++k) {
+        comp_coef[k] = fp_from_limbs64(coeff_comp + 4 * k);
+        comp_k = fp_add(comp_k, fp_mul(comp_coef[k], fp_from_limbs64(ood_comp + 4 * k)));
+        zc = fp_mul(zc, zf);
+    }
+    // device staging: D, Dc in scratch2; small arrays in scratch
+    ss_status st = ctx->ensure_scratch2(2 * N * sizeof(Fp));
+    if (st != SS_OK) return st;
+    const size_t small = (size_t)nmask * (4 + 32) + (size_t)ngroups * (12 + 32) + (size_t)(ncomp + 1) * 32 + 256;
+    st = ctx->ensure_scratch(small);
+    if (st != SS_OK) return st;
+    Fp *D = (Fp *)ctx->scratch2, *Dc = D + N;
+    char *p = (char *)ctx->scratch;
+    Fp *d_cell_coef = (Fp *)p; p += (size_t)(nmask ? nmask : 1) * 32;
+    Fp *d_group_k = (Fp *)p; p += (size_t)(ngroups ? ngroups : 1) * 32;
+    Fp *d_comp_coef = (Fp *)p; p += (size_t)(ncomp + 1) * 32;
+    uint32_t *d_cell_col = (uint32_t *)p; p += (size_t)(nmask ? nmask : 1) * 4;
+    uint32_t *d_gdesc = (uint32_t *)p;
+    hipStream_t s = ctx->stream;
+    if (nmask) {
+        HIP_TRY(hipMemcpyAsync(d_cell_coef, cell_coef.data(), (size_t)nmask * 32, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_cell_col, cell_col.data(), (size_t)nmask * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_group_k, group_k.data(), (size_t)ngroups * 32, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_gdesc, gdesc.data(), (size_t)ngroups * 12, hipMemcpyHostToDevice, s));
+    }
+    if (ncomp) HIP_TRY(hipMemcpyAsync(d_comp_coef, comp_coef.data(), (size_t)ncomp * 32, hipMemcpyHostToDevice, s));
+    ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
+    HIP_TRY(launch_batch_inverse(s, D, log_N, off, wN, wN_inv, zf));
+    if (ncomp) HIP_TRY(launch_batch_inverse(s, Dc, log_N, off, wN, wN_inv, zc));
+    HIP_TRY(launch_deep(s, (const void *const *)d_trace_lde, ntrace_cols, (const void *const *)d_comp_lde, ncomp, D, Dc,
+                        d_cell_col, d_cell_coef, d_gdesc, d_group_k, ngroups, d_comp_coef, comp_k, log_N, (Fp *)d_out));
+    HIP_TRY(hipStreamSynchronize(s));     // host staging vectors go out of scope
+    return SS_OK;
+}
+
+// ------------------------------------------------------------------- Q1
+ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
+                           uint32_t ncols, uint32_t log_n, uint32_t log_blowup, const uint64_t offset[4],
+                           uint64_t *d_out) {
+    if (!ctx || !prog || !d_lde_cols || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!prog->code || prog->n_instr == 0) return fail(SS_ERR_INVALID, "empty program");
+    const uint32_t log_N = log_n + log_blowup;
+    if (!valid_log(log_n) || !valid_log(log_N)) return fail(SS_ERR_INVALID, "size out of range");
+    if (ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u > %d", ncols, MAX_COLS);
+    // validate the program against its own declarations (it is caller-supplied data)
+    for (uint32_t pc = 0; pc < prog->n_instr; ++pc) {
+        const uint32_t w0 = prog->code[2 * pc], w1 = prog->code[2 * pc + 1];
+        const uint32_t op = w0 & 0xff, d = (w0 >> 8) & 0xf, kind = (w0 >> 12) & 0xf;
+        if (op > SS_OP_OUT || d > 3) return fail(SS_ERR_INVALID, "instruction %u: bad opcode/accumulator", pc);
+        if (op == SS_OP_ST && w1 >= prog->n_slots) return fail(SS_ERR_INVALID, "instruction %u: slot %u out of range", pc, w1);
+        if (op <= SS_OP_MUL) {
+            if (kind > SS_SRC_X) return fail(SS_ERR_INVALID, "instruction %u: bad operand kind", pc);
+            if (kind == SS_SRC_ACC && w1 > 3) return fail(SS_ERR_INVALID, "instruction %u: bad accumulator", pc);
+            if (kind == SS_SRC_SLOT && w1 >= prog->n_slots) return fail(SS_ERR_INVALID, "instruction %u: slot %u out of range", pc, w1);
+            if (kind == SS_SRC_CONST && w1 >= prog->n_consts) return fail(SS_ERR_INVALID, "instruction %u: constant %u out of range", pc, w1);
+            if (kind == SS_SRC_TRACE && (w1 >> 24) >= ncols) return fail(SS_ERR_INVALID, "instruction %u: column %u out of range", pc, w1 >> 24);
+            if (kind == SS_SRC_TABLE && (w1 >= prog->n_tables || !prog->d_tables || !prog->table_desc))
+                return fail(SS_ERR_INVALID, "instruction %u: table %u out of range", pc, w1);
+        }
+    }
+    const uint64_t N = 1ull << log_N;
+    uint64_t lanes = 256ull * 256 * 4;                 // 4 workgroups of 256 per CU
+    if (lanes > N) lanes = N < 256 ? 256 : N;
+    const size_t code_b = (size_t)prog->n_instr * 8, const_b = (size_t)(prog->n_consts ? prog->n_consts : 1) * 32;
+    const size_t desc_b = (size_t)(prog->n_tables ? prog->n_tables : 1) * 8;
+    const size_t slots_b = (size_t)(prog->n_slots ? prog->n_slots : 1) * lanes * 32;
+    ss_status st = ctx->ensure_scratch(slots_b + const_b + code_b + desc_b + 256);
+    if (st != SS_OK) return st;
+    char *p = (char *)ctx->scratch;
+    Fp *d_slots = (Fp *)p; p += slots_b;
+    Fp *d_consts = (Fp *)p; p += const_b;
+    uint32_t *d_code = (uint32_t *)p; p += code_b;
+    uint32_t *d_desc = (uint32_t *)p;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(d_code, prog->code, code_b, hipMemcpyHostToDevice, s));
+    if (prog->n_consts) HIP_TRY(hipMemcpyAsync(d_consts, prog->consts, (size_t)prog->n_consts * 32, hipMemcpyHostToDevice, s));
+    if (prog->n_tables) HIP_TRY(hipMemcpyAsync(d_desc, prog->table_desc, (size_t)prog->n_tables * 8, hipMemcpyHostToDevice, s));
+    const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
+    const Fp w = root_of_unity(log_N);
+    const Fp wstep = fp_pow_u64(w, lanes);
+    ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
+    HIP_TRY(launch_quotient_vm(s, (const void *const *)d_lde_cols, ncols, d_code, prog->n_instr, d_consts,
+                               (const Fp *)prog->d_tables, d_desc, d_slots, lanes, off, w, wstep, log_N, log_blowup,
+                               (Fp *)d_out));
+    HIP_TRY(hipStreamSynchronize(s));      // the caller's host arrays may go away after return
     return SS_OK;
 }
 

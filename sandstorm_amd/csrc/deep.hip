@@ -1,16 +1,214 @@
-// deep.hip — out-of-domain evaluation and DEEP composition (row D1 of SURVEY.md §8a).
+// deep.hip — out-of-domain evaluation and DEEP composition on gfx950.
+//
+// Replaces ministark's DeepPolyComposer (un-vendored; coefficient rule
+// src/lib.rs:102-116; row D1 of SURVEY.md §8a).
+//
+//  * poly_reduce_kernel: P(x) for bit-reversed coefficient arrays.  In
+//    bit-reversed order position q holds coefficient bitrev(q), so
+//    P(x) = sum_q c[q] * prod_j (x^(2^(L-1-j)))^(q_j): a pairwise tree whose
+//    level-l multiplier is x^(2^(L-1-l)).  One launch folds 3 levels (8 adjacent
+//    elements per lane -> 1), so evaluating a 2^24-coefficient column streams it
+//    once (1.14 x n x 32 B in total).
+//  * batch_inverse_kernel: D[i] = 1/(x_i - z) over the whole LDE domain with
+//    Montgomery's trick on per-lane chunks (5 mulmods per point + one inversion
+//    per chunk).
+//  * deep_kernel: since 1/(x_i - z w_n^k) = w_n^-k * D[i - k*blowup], every DEEP
+//    denominator is one table D read at a shifted index; the host folds w_n^-k
+//    into the coefficients and groups mask cells by offset:
+//      out[i] = sum_g D[i - off_g b] * (sum_{j in g} c'_j T_{col_j}[i] - K_g)
+//             + Dc[i] * (sum_k cc_k H_k[i] - Kc)
+//    = nmask + ngroups + ncomp + 1 multiplications per LDE point, all operands
+//    coalesced (lane i reads element i, or i - shift, of each array).
 #include <hip/hip_runtime.h>
-#include "../../include/sandstorm_hip.h"
+#include "fp252.h"
+#include "kernels.h"
 
-extern "C" {
-// Kernels land next; until then these fail loudly (no CPU fallback).
-ss_status ss_ood_eval(ss_ctx *, const uint64_t *const *, uint32_t, uint32_t, const uint32_t *, const uint32_t *,
-                      uint32_t, const uint64_t[4], uint64_t *) { return SS_ERR_UNSUPPORTED; }
-ss_status ss_poly_eval(ss_ctx *, const uint64_t *const *, uint32_t, uint32_t, const uint64_t[4], uint64_t *) {
-    return SS_ERR_UNSUPPORTED;
+namespace ss {
+
+__device__ __forceinline__ Fp dload(const Fp *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
 }
-ss_status ss_deep_compose(ss_ctx *, const uint64_t *const *, uint32_t, const uint64_t *const *, uint32_t, uint32_t,
-                          uint32_t, const uint64_t[4], const uint32_t *, const uint32_t *, uint32_t,
-                          const uint64_t *, const uint64_t *, const uint64_t *, const uint64_t *, const uint64_t[4],
-                          uint64_t *) { return SS_ERR_UNSUPPORTED; }
+__device__ __forceinline__ void dstore(Fp *p, const Fp &x) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    q[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
+
+// ---- bit-reversed polynomial evaluation: out[col][m] = fold of in[col][m*2^levels ..] ----
+struct ReduceArgs {
+    const Fp *in[MAX_COLS];
+    Fp *out[MAX_COLS];
+    Fp mult[3];          // multipliers of the 1st, 2nd, 3rd level folded by this launch
+};
+
+template <int LEVELS>
+__global__ __launch_bounds__(256) void poly_reduce_kernel(ReduceArgs a, uint64_t out_len) {
+    const void *in_v = a.in[0];
+    void *out_v = a.out[0];
+#pragma unroll
+    for (int c = 1; c < MAX_COLS; ++c)
+        if (blockIdx.y == (unsigned)c) { in_v = a.in[c]; out_v = a.out[c]; }
+    const Fp *in = reinterpret_cast<const Fp *>(in_v);
+    Fp *out = reinterpret_cast<Fp *>(out_v);
+    for (uint64_t m = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; m < out_len;
+         m += (uint64_t)gridDim.x * blockDim.x) {
+        Fp v[1 << LEVELS];
+#pragma unroll
+        for (int k = 0; k < (1 << LEVELS); ++k) v[k] = dload(in + (m << LEVELS) + k);
+        // level 0 pairs adjacent elements
+#pragma unroll
+        for (int k = 0; k < (1 << LEVELS); k += 2) v[k] = fp_add(v[k], fp_mul(v[k + 1], a.mult[0]));
+        if (LEVELS >= 2) {
+#pragma unroll
+            for (int k = 0; k < (1 << LEVELS); k += 4) v[k] = fp_add(v[k], fp_mul(v[k + 2 < (1 << LEVELS) ? k + 2 : 0], a.mult[1]));
+        }
+        if (LEVELS >= 3) v[0] = fp_add(v[0], fp_mul(v[4 < (1 << LEVELS) ? 4 : 0], a.mult[2]));
+        dstore(out + m, v[0]);
+    }
+}
+
+hipError_t launch_poly_reduce(hipStream_t st, const void *const *in, void *const *out, uint32_t ncols,
+                              uint64_t in_len, uint32_t levels, const Fp *mult) {
+    ReduceArgs a;
+    for (int c = 0; c < MAX_COLS; ++c) { a.in[c] = c < (int)ncols ? (const Fp *)in[c] : nullptr; a.out[c] = c < (int)ncols ? (Fp *)out[c] : nullptr; }
+    for (int k = 0; k < 3; ++k) a.mult[k] = k < (int)levels ? mult[k] : fp_zero();
+    const uint64_t out_len = in_len >> levels;
+    uint32_t gx = (uint32_t)((out_len + 255) / 256);
+    if (gx > 65536) gx = 65536;
+    if (gx == 0) gx = 1;
+    dim3 grid(gx, ncols), block(256);
+    if (levels == 3) hipLaunchKernelGGL(poly_reduce_kernel<3>, grid, block, 0, st, a, out_len);
+    else if (levels == 2) hipLaunchKernelGGL(poly_reduce_kernel<2>, grid, block, 0, st, a, out_len);
+    else hipLaunchKernelGGL(poly_reduce_kernel<1>, grid, block, 0, st, a, out_len);
+    return hipGetLastError();
+}
+
+// ---- D[i] = 1 / (offset * w^i - z), i < 2^log_N ----------------------------------------
+// chunk c of length CH is handled by one lane: forward pass stores prefix products in D,
+// one inversion, backward pass overwrites them with the inverses.
+__global__ __launch_bounds__(128) void batch_inverse_kernel(Fp *__restrict__ D, uint32_t log_N, uint32_t log_chunk,
+                                                            Fp offset, Fp w, Fp w_inv, Fp z) {
+    const uint64_t nchunks = 1ull << (log_N - log_chunk);
+    const uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const uint64_t CH = 1ull << log_chunk, i0 = c << log_chunk;
+    Fp x = fp_mul(offset, fp_pow_u64(w, i0));
+    Fp run = fp_one();
+    for (uint64_t k = 0; k < CH; ++k) {
+        dstore(D + i0 + k, run);                 // prefix product of d_0 .. d_{k-1}
+        run = fp_mul(run, fp_sub(x, z));
+        x = fp_mul(x, w);
+    }
+    Fp inv = fp_inv(run);                        // 1 / (d_0 ... d_{CH-1}); 0 stays 0 if some x_i == z
+    for (uint64_t k = CH; k-- > 0;) {
+        x = fp_mul(x, w_inv);                    // x_{i0+k}
+        const Fp pre = dload(D + i0 + k);
+        dstore(D + i0 + k, fp_mul(inv, pre));
+        inv = fp_mul(inv, fp_sub(x, z));
+    }
+}
+
+hipError_t launch_batch_inverse(hipStream_t st, Fp *D, uint32_t log_N, const Fp &offset, const Fp &w,
+                                const Fp &w_inv, const Fp &z) {
+    // enough lanes to fill the chip, chunks long enough to amortise the inversion
+    uint32_t log_chunk = log_N > 17 ? log_N - 17 : 0;
+    if (log_chunk < 4) log_chunk = log_N < 4 ? log_N : 4;
+    if (log_chunk > 7) log_chunk = 7;
+    const uint64_t nchunks = 1ull << (log_N - log_chunk);
+    hipLaunchKernelGGL(batch_inverse_kernel, dim3((uint32_t)((nchunks + 127) / 128)), dim3(128), 0, st, D, log_N,
+                       log_chunk, offset, w, w_inv, z);
+    return hipGetLastError();
+}
+
+// ---- DEEP composition -----------------------------------------------------------------
+struct DeepArgs {
+    const Fp *trace[MAX_COLS];
+    const Fp *comp[4];
+    const Fp *D;            // 1/(x_i - z)
+    const Fp *Dc;           // 1/(x_i - z^ncomp)
+    const uint32_t *cell_col;    // [nmask] sorted by group
+    const Fp *cell_coef;         // [nmask] coeff_j * w_n^-off_j
+    const uint32_t *group_desc;  // [ngroups][3]: shift (= off * blowup), first cell, cell count
+    const Fp *group_k;           // [ngroups] sum_j c'_j * ood_j
+    const Fp *comp_coef;         // [ncomp]
+    Fp comp_k;                   // sum_k cc_k * ood_comp_k
+    uint32_t ngroups, ncomp, log_N;
+};
+
+__global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ out) {
+    const uint64_t N = 1ull << a.log_N;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < N;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        Fp acc = fp_zero();
+        for (uint32_t g = 0; g < a.ngroups; ++g) {
+            const uint32_t shift = a.group_desc[3 * g], first = a.group_desc[3 * g + 1], cnt = a.group_desc[3 * g + 2];
+            Fp inner = fp_zero();
+            for (uint32_t j = first; j < first + cnt; ++j) {
+                const uint32_t col = a.cell_col[j];
+                const Fp *tp = a.trace[0];
+#pragma unroll
+                for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) tp = a.trace[c];
+                inner = fp_add(inner, fp_mul(dload(tp + i), dload(a.cell_coef + j)));
+            }
+            inner = fp_sub(inner, dload(a.group_k + g));
+            acc = fp_add(acc, fp_mul(inner, dload(a.D + ((i - shift) & (N - 1)))));
+        }
+        if (a.ncomp) {
+            Fp inner = fp_zero();
+            for (uint32_t k = 0; k < a.ncomp; ++k) {
+                const Fp *hp = a.comp[0];
+#pragma unroll
+                for (int c = 1; c < 4; ++c) if (k == (uint32_t)c) hp = a.comp[c];
+                inner = fp_add(inner, fp_mul(dload(hp + i), dload(a.comp_coef + k)));
+            }
+            inner = fp_sub(inner, a.comp_k);
+            acc = fp_add(acc, fp_mul(inner, dload(a.Dc + i)));
+        }
+        dstore(out + i, acc);
+    }
+}
+
+hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace, const void *const *comp,
+                       uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *cell_col, const Fp *cell_coef,
+                       const uint32_t *group_desc, const Fp *group_k, uint32_t ngroups, const Fp *comp_coef,
+                       const Fp &comp_k, uint32_t log_N, Fp *out) {
+    DeepArgs a;
+    for (int c = 0; c < MAX_COLS; ++c) a.trace[c] = c < (int)ntrace ? (const Fp *)trace[c] : nullptr;
+    for (int c = 0; c < 4; ++c) a.comp[c] = c < (int)ncomp ? (const Fp *)comp[c] : nullptr;
+    a.D = D; a.Dc = Dc; a.cell_col = cell_col; a.cell_coef = cell_coef; a.group_desc = group_desc;
+    a.group_k = group_k; a.comp_coef = comp_coef; a.comp_k = comp_k; a.ngroups = ngroups; a.ncomp = ncomp;
+    a.log_N = log_N;
+    const uint64_t N = 1ull << log_N;
+    uint32_t gx = (uint32_t)((N + 255) / 256);
+    if (gx > 256 * 16) gx = 256 * 16;
+    hipLaunchKernelGGL(deep_kernel, dim3(gx), dim3(256), 0, st, a, out);
+    return hipGetLastError();
+}
+
+// gather with a column selector: out[j] = cols[col[j]][idx[j]]
+struct GatherArgs { const Fp *cols[MAX_COLS]; };
+__global__ void gather_cells_kernel(GatherArgs a, const uint32_t *__restrict__ col, const uint64_t *__restrict__ idx,
+                                    uint32_t n, Fp *__restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t cc = col[j];
+    const Fp *p = a.cols[0];
+#pragma unroll
+    for (int c = 1; c < MAX_COLS; ++c) if (cc == (uint32_t)c) p = a.cols[c];
+    dstore(out + j, dload(p + idx[j]));
+}
+hipError_t launch_gather_cells(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *col,
+                               const uint64_t *idx, uint32_t n, Fp *out) {
+    if (n == 0) return hipSuccess;
+    GatherArgs a;
+    for (int c = 0; c < MAX_COLS; ++c) a.cols[c] = c < (int)ncols ? (const Fp *)cols[c] : nullptr;
+    hipLaunchKernelGGL(gather_cells_kernel, dim3((n + 127) / 128), dim3(128), 0, st, a, col, idx, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace ss

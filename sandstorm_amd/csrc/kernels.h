@@ -63,4 +63,22 @@ hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, ui
                            const Fp &alpha, const Fp &offset_inv, const Fp &w_inv, const Fp *fold_tw_inv,
                            Fp *out);
 
+// ---- deep.hip
+hipError_t launch_poly_reduce(hipStream_t st, const void *const *in, void *const *out, uint32_t ncols,
+                              uint64_t in_len, uint32_t levels, const Fp *mult);
+hipError_t launch_batch_inverse(hipStream_t st, Fp *D, uint32_t log_N, const Fp &offset, const Fp &w,
+                                const Fp &w_inv, const Fp &z);
+hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace, const void *const *comp,
+                       uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *cell_col, const Fp *cell_coef,
+                       const uint32_t *group_desc, const Fp *group_k, uint32_t ngroups, const Fp *comp_coef,
+                       const Fp &comp_k, uint32_t log_N, Fp *out);
+hipError_t launch_gather_cells(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *col,
+                               const uint64_t *idx, uint32_t n, Fp *out);
+
+// ---- quotient.hip
+hipError_t launch_quotient_vm(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *d_code,
+                              uint32_t n_instr, const Fp *d_consts, const Fp *d_tables, const uint32_t *d_table_desc,
+                              Fp *d_slots, uint64_t lanes, const Fp &offset, const Fp &w, const Fp &wstep,
+                              uint32_t log_N, uint32_t log_blowup, Fp *out);
+
 }  // namespace ss

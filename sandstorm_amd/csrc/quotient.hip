@@ -1,8 +1,114 @@
-// quotient.hip — constraint-program evaluation over the LDE domain (row Q1 of SURVEY.md §8a).
+// quotient.hip — constraint-program evaluation over the LDE domain on gfx950.
+//
+// Replaces ministark's AirConfig::eval_constraint (un-vendored default body) applied
+// to the composition constraint that layouts/src/{recursive,starknet}/air.rs build
+// (recursive air.rs:61-1200; row Q1 of SURVEY.md §8a).  The host lowers the `Expr`
+// DAG once per (layout, trace length) into the 4-accumulator program described in
+// include/sandstorm_hip.h; this kernel interprets it.
+//
+// One lane = one LDE point; the program counter, opcodes and operand selectors are
+// wave-uniform (scalar loads, scalar branches — no divergence), the four
+// accumulators are VGPR-resident, constants arrive through the scalar cache, trace
+// cells are coalesced (lane i reads element i + shift of a column) and scratch slots
+// are [slot][lane] so a slot access is one contiguous 2 KiB run per wave.
 #include <hip/hip_runtime.h>
 #include "../../include/sandstorm_hip.h"
+#include "fp252.h"
+#include "kernels.h"
 
-extern "C" {
-ss_status ss_eval_quotient(ss_ctx *, const ss_air_program *, const uint64_t *const *, uint32_t, uint32_t, uint32_t,
-                           const uint64_t[4], uint64_t *) { return SS_ERR_UNSUPPORTED; }
+namespace ss {
+
+__device__ __forceinline__ Fp qload(const Fp *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
 }
+__device__ __forceinline__ void qstore(Fp *p, const Fp &x) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    q[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+struct VmArgs {
+    const Fp *cols[MAX_COLS];
+    const uint32_t *code;
+    const Fp *consts;
+    const Fp *tables;
+    const uint32_t *table_desc;
+    Fp *slots;               // [n_slots][total_lanes]
+    Fp *out;
+    Fp offset, w, wstep;     // x_i = offset * w^i; wstep = w^(total lanes)
+    uint32_t n_instr, log_N, log_blowup;
+};
+
+__global__ __launch_bounds__(256) void quotient_vm_kernel(VmArgs a) {
+    const uint64_t N = 1ull << a.log_N;
+    const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    Fp x = fp_mul(a.offset, fp_pow_u64(a.w, lane));
+    for (uint64_t i = lane; i < N; i += lanes) {
+        Fp acc0 = fp_zero(), acc1 = fp_zero(), acc2 = fp_zero(), acc3 = fp_zero();
+        for (uint32_t pc = 0; pc < a.n_instr; ++pc) {
+            const uint32_t w0 = a.code[2 * pc], w1 = a.code[2 * pc + 1];
+            const uint32_t op = w0 & 0xffu, d = (w0 >> 8) & 0xfu, kind = (w0 >> 12) & 0xfu;
+            Fp src = fp_zero();
+            if (op <= SS_OP_MUL) {
+                if (kind == SS_SRC_ACC) {
+                    const uint32_t s = w1 & 3u;
+                    src = s == 0 ? acc0 : s == 1 ? acc1 : s == 2 ? acc2 : acc3;
+                } else if (kind == SS_SRC_SLOT) {
+                    src = qload(a.slots + (uint64_t)w1 * lanes + lane);
+                } else if (kind == SS_SRC_CONST) {
+                    src = qload(a.consts + w1);
+                } else if (kind == SS_SRC_TRACE) {
+                    const uint32_t col = w1 >> 24;
+                    const uint64_t row = (i + ((uint64_t)(w1 & 0xffffffu) << a.log_blowup)) & (N - 1);
+                    const Fp *cp = a.cols[0];
+#pragma unroll
+                    for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) cp = a.cols[c];
+                    src = qload(cp + row);
+                } else if (kind == SS_SRC_TABLE) {
+                    const uint32_t off = a.table_desc[2 * w1], ll = a.table_desc[2 * w1 + 1];
+                    src = qload(a.tables + off + (i & ((1ull << ll) - 1ull)));
+                } else {
+                    src = x;
+                }
+            }
+            Fp v = d == 0 ? acc0 : d == 1 ? acc1 : d == 2 ? acc2 : acc3;
+            bool write = true;
+            switch (op) {
+            case SS_OP_MOV: v = src; break;
+            case SS_OP_ADD: v = fp_add(v, src); break;
+            case SS_OP_SUB: v = fp_sub(v, src); break;
+            case SS_OP_RSUB: v = fp_sub(src, v); break;
+            case SS_OP_MUL: v = fp_mul(v, src); break;
+            case SS_OP_INV: v = fp_inv(v); break;
+            case SS_OP_ST: qstore(a.slots + (uint64_t)w1 * lanes + lane, v); write = false; break;
+            case SS_OP_OUT: qstore(a.out + i, v); write = false; break;
+            default: write = false; break;
+            }
+            if (write) {
+                if (d == 0) acc0 = v; else if (d == 1) acc1 = v; else if (d == 2) acc2 = v; else acc3 = v;
+            }
+        }
+        x = fp_mul(x, a.wstep);
+    }
+}
+
+hipError_t launch_quotient_vm(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *d_code,
+                              uint32_t n_instr, const Fp *d_consts, const Fp *d_tables, const uint32_t *d_table_desc,
+                              Fp *d_slots, uint64_t lanes, const Fp &offset, const Fp &w, const Fp &wstep,
+                              uint32_t log_N, uint32_t log_blowup, Fp *out) {
+    VmArgs a;
+    for (int c = 0; c < MAX_COLS; ++c) a.cols[c] = c < (int)ncols ? (const Fp *)cols[c] : nullptr;
+    a.code = d_code; a.consts = d_consts; a.tables = d_tables; a.table_desc = d_table_desc; a.slots = d_slots;
+    a.out = out; a.offset = offset; a.w = w; a.wstep = wstep; a.n_instr = n_instr; a.log_N = log_N;
+    a.log_blowup = log_blowup;
+    hipLaunchKernelGGL(quotient_vm_kernel, dim3((uint32_t)(lanes / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace ss

@@ -312,3 +312,83 @@ def test_pow_grind_vs_oracle(ctx, be, oracle, kind):
     coin = oracle.Coin(kind, digest)
     for bits in (1, 8, 16):
         assert ctx.pow_grind(kind, digest, bits) == coin.grind(bits), bits
+
+
+# ------------------------------------------------------------------------ D1 / Q1
+@pytest.mark.parametrize("log_n", [1, 3, 6, 7, 12, 16])
+def test_poly_eval_vs_oracle(ctx, be, oracle, log_n):
+    n = 1 << log_n
+    cols = [random_column(n, c + 30) for c in range(3)]
+    x = oracle.to_mont([0xDEADBEEFCAFE ** 4 % P])[0]
+    d = _up(ctx, [oracle.bitrev_permute(c) for c in cols])
+    got = ctx.poly_eval(d, log_n, x)
+    for c in range(3):
+        assert np.array_equal(got[c], oracle.poly_eval(cols[c], x)), (log_n, c)
+
+
+@pytest.mark.parametrize("log_n", [4, 11, 14])
+def test_ood_eval_vs_oracle(ctx, be, oracle, log_n):
+    n = 1 << log_n
+    cols = [random_column(n, c + 40) for c in range(4)]
+    m = be.Matrix.from_host(ctx, cols)
+    _, co = m.lde(1, g3(oracle))
+    coeffs = [oracle.lde(c, 1, g3(oracle))[1] for c in cols]
+    mask = [(0, 0), (0, 1), (1, 0), (2, 3), (3, n - 1), (1, 7 % n), (3, 0)]
+    z = 0xABCDEF0123456789 ** 3 % P
+    got = ctx.ood_eval(co.cols, log_n, [c for c, _ in mask], [o for _, o in mask], oracle.to_mont([z])[0])
+    w = pow(3, (P - 1) >> log_n, P)
+    for j, (c, o) in enumerate(mask):
+        want = oracle.poly_eval(coeffs[c], oracle.to_mont([z * pow(w, o, P) % P])[0])
+        assert np.array_equal(got[j], want), (log_n, j)
+
+
+@pytest.mark.parametrize("log_n", [4, 10, 13])
+def test_deep_compose_vs_oracle(ctx, be, oracle, log_n):
+    lb = 1
+    n, N = 1 << log_n, 1 << (log_n + lb)
+    g = g3(oracle)
+    cols = [random_column(n, c + 70) for c in range(3)]
+    m = be.Matrix.from_host(ctx, cols)
+    ev, co = m.lde(lb, g)
+    comp_coeffs = [random_column(n, 90 + k) for k in range(2)]
+    cm = be.Matrix.from_host(ctx, [np.concatenate([c, np.zeros((N - n, 4), dtype=np.uint64)]) for c in comp_coeffs])
+    cm.evaluate(g)
+    z = 0x1357924680ACE ** 5 % P
+    zm = oracle.to_mont([z])[0]
+    mask = [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 5 % n), (0, n - 1), (2, 1)]
+    mc, mo = [c for c, _ in mask], [o for _, o in mask]
+    ood_t = ctx.ood_eval(co.cols, log_n, mc, mo, zm)
+    ood_c = np.stack([oracle.poly_eval(c, oracle.to_mont([z * z % P])[0]) for c in comp_coeffs])
+    alpha = 987654321987654321
+    ct = oracle.to_mont([pow(alpha, j, P) for j in range(len(mask))])
+    cc = oracle.to_mont([pow(alpha, len(mask) + k, P) for k in range(2)])
+    out = ctx.alloc(32 * N)
+    ctx.deep_compose(ev.cols, cm.cols, log_n, lb, g, mc, mo, ood_t, ct, ood_c, cc, zm, out)
+    got = out.download(np.uint64, (N, 4))
+    want = oracle.deep_compose(ev.to_host(), cm.to_host(), log_n, lb, g, mc, mo, ood_t, ct, ood_c, cc, zm)
+    assert np.array_equal(got, want)
+    # consistent OOD values => the DEEP quotient is a polynomial of degree < n
+    ctx.ntt([out], log_n + lb, be.INVERSE, g)
+    assert not np.any(out.download(np.uint64, (N, 4))[n:])
+
+
+@pytest.mark.parametrize("seed,size,log_n", [(1, 30, 3), (2, 120, 8), (3, 400, 12)])
+def test_eval_quotient_vs_oracle(ctx, be, oracle, seed, size, log_n):
+    import random
+    from sandstorm_amd import air_program as ap
+    from tests.test_air_program import random_dag
+    lb, ncols = 1, 3
+    n, N = 1 << log_n, 1 << (log_n + lb)
+    g = g3(oracle)
+    m = be.Matrix.from_host(ctx, [random_column(n, c + seed) for c in range(ncols)])
+    ev, _ = m.lde(lb, g, keep_coeffs=False)
+    tabs = [random_column(4, 50 + seed), random_column(8, 60 + seed)]
+    tables, desc = np.concatenate(tabs), [0, 2, 4, 3]
+    root = random_dag(random.Random(seed), ncols, 2, 5, size)
+    prog = ap.lower(root, P)
+    out = ctx.alloc(32 * N)
+    ctx.eval_quotient(prog, ctx.column(tables), desc, ev.cols, log_n, lb, g, out)
+    got = out.download(np.uint64, (N, 4))
+    want = oracle.eval_program(prog.code, oracle.to_mont(prog.consts), tables, desc, prog.n_slots, ev.to_host(),
+                               log_n, lb, g)
+    assert np.array_equal(got, want)
