@@ -103,6 +103,13 @@ ss_status ss_lde_fp252(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols,
                        uint32_t log_blowup, const uint64_t offset[4], uint64_t *const *d_evals,
                        uint64_t *const *d_coeffs);
 
+/* Evaluate-only half of the LDE (pipeline step 10: the composition columns, whose
+ * coefficients come from one inverse NTT): d_coeffs[c] holds 2^log_n coefficients
+ * in BIT-REVERSED order; d_evals[c] receives the 2^(log_n+log_blowup) evaluations
+ * over offset*<w>, natural order.  d_coeffs is not modified. */
+ss_status ss_evaluate_fp252(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t ncols, uint32_t log_n,
+                            uint32_t log_blowup, const uint64_t offset[4], uint64_t *const *d_evals);
+
 /* ---- H1: crypto/src/merkle/utils.rs:19-46 hash_rows::<H>.
  * d_digests[r] = H::hash_elements(row r) for r < nrows; rows are read in
  * natural index order from the column arrays. */
@@ -220,6 +227,12 @@ enum { SS_PROF_NTT_PASS = 0, SS_PROF_HASH_ROWS = 1, SS_PROF_MERKLE = 2, SS_PROF_
 ss_status ss_profile_enable(ss_ctx *ctx, int on);
 ss_status ss_profile_reset(ss_ctx *ctx);
 ss_status ss_profile_read(ss_ctx *ctx, int kind, double *total_ms, uint64_t *launches);
+
+/* Host-side pedersen_hash for the Fiat-Shamir coin (CairoVerifierPublicCoin::
+ * reseed_with_field_elements hashes the OOD evaluations with a sequential
+ * Pedersen chain, crypto/src/public_coin/cairo.rs:76-80; the coin stays on the
+ * host).  Montgomery felts in and out; no device involved. */
+ss_status ss_pedersen_hash_host(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 
 /* ---- micro-benchmark hook: d_out[i] = d_a[i] * d_b[i] repeated `reps` times
  *      (dependent chain), used by bench.py to report mulmod/s. */

@@ -45,6 +45,7 @@ SIGNATURES = {
     "ss_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ss_ntt_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_int, _u64p, C.c_int, C.c_int]),
     "ss_lde_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _vpp, _vpp]),
+    "ss_evaluate_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _vpp]),
     "ss_hash_rows": (C.c_int, [C.c_void_p, C.c_int, _vpp, C.c_uint32, C.c_uint64, C.c_void_p]),
     "ss_merkle_build": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64,
                                   C.c_void_p, C.c_void_p, _u8p]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "ss_fri_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _u64p, _u64p, C.c_void_p]),
     "ss_pow_grind": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, _u64p]),
     "ss_pedersen_hash": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "ss_pedersen_hash_host": (C.c_int, [_u64p, _u64p, _u64p]),
     "ss_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ss_profile_reset": (C.c_int, [C.c_void_p]),
     "ss_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), _u64p]),

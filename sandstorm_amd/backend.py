@@ -46,6 +46,17 @@ def _felt_ptr(limbs):
     return a, a.ctypes.data_as(C.POINTER(C.c_uint64))
 
 
+def pedersen_hash_host(a, b):
+    """host-side pedersen_hash (Fiat-Shamir coin only); Montgomery limbs in and out"""
+    lib = _lib.load()
+    x = np.ascontiguousarray(a, dtype=np.uint64)
+    y = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.zeros(4, dtype=np.uint64)
+    p64 = C.POINTER(C.c_uint64)
+    check(lib.ss_pedersen_hash_host(x.ctypes.data_as(p64), y.ctypes.data_as(p64), out.ctypes.data_as(p64)))
+    return out
+
+
 class DeviceBuffer:
     """A device allocation owned by a Context (ss_dev_alloc / ss_dev_free)."""
 
@@ -79,9 +90,25 @@ class DeviceBuffer:
             pass
 
 
+class DeviceView:
+    """A sub-range of a DeviceBuffer (no ownership): e.g. one FRI-layer column, or one
+    half of the composition coefficients."""
+
+    def __init__(self, parent, offset, nbytes):
+        assert offset + nbytes <= parent.nbytes
+        self.parent, self.ctx, self.nbytes = parent, parent.ctx, int(nbytes)
+        self.ptr = parent.ptr + int(offset)
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(self.ctx.lib.ss_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+
 def _ptr_of(x):
     """DeviceBuffer | torch tensor | int -> device address"""
-    if isinstance(x, DeviceBuffer):
+    if isinstance(x, (DeviceBuffer, DeviceView)):
         return x.ptr
     if hasattr(x, "data_ptr"):
         return x.data_ptr()
@@ -131,6 +158,12 @@ class Context:
         _keep, off = _felt_ptr(offset)
         check(self.lib.ss_lde_fp252(self.handle, _ptr_array(cols_in), len(cols_in), log_n, log_blowup, off,
                                     _ptr_array(evals_out), _ptr_array(coeffs_out) if coeffs_out else None))
+
+    def evaluate(self, coeff_cols, log_n, log_blowup, offset, evals_out):
+        """bit-reversed coefficient columns -> evaluations over offset*<w_{n*blowup}>"""
+        _keep, off = _felt_ptr(offset)
+        check(self.lib.ss_evaluate_fp252(self.handle, _ptr_array(coeff_cols), len(coeff_cols), log_n, log_blowup,
+                                         off, _ptr_array(evals_out)))
 
     def hash_rows(self, kind, cols, nrows, out):
         check(self.lib.ss_hash_rows(self.handle, kind, _ptr_array(cols), len(cols), nrows, _ptr_of(out)))

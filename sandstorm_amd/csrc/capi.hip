@@ -406,6 +406,25 @@ ss_status ss_lde_fp252(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols,
     return SS_OK;
 }
 
+ss_status ss_evaluate_fp252(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t ncols, uint32_t log_n,
+                            uint32_t log_blowup, const uint64_t offset[4], uint64_t *const *d_evals) {
+    if (!ctx || !d_coeffs || !d_evals) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!valid_log(log_n) || !valid_log(log_n + log_blowup)) return fail(SS_ERR_INVALID, "size out of range");
+    const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
+    const Fp *tw = nullptr;
+    ss_status st = ctx->get_plan(log_n + log_blowup, false, off, &tw);
+    if (st != SS_OK) return st;
+    for (uint32_t base = 0; base < ncols; base += MAX_COLS) {
+        const uint32_t nc = ncols - base < (uint32_t)MAX_COLS ? ncols - base : (uint32_t)MAX_COLS;
+        ColPtrs fwd;
+        memset(&fwd, 0, sizeof fwd);
+        for (uint32_t c = 0; c < nc; ++c) { fwd.src[c] = d_coeffs[base + c]; fwd.dst[c] = d_evals[base + c]; }
+        st = run_forward(ctx, fwd, nc, log_n + log_blowup, tw, log_blowup);
+        if (st != SS_OK) return st;
+    }
+    return SS_OK;
+}
+
 // --------------------------------------------------------------- hashing
 ss_status ss_hash_rows(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_cols, uint32_t ncols,
                        uint64_t nrows, uint8_t *d_digests) {
@@ -575,6 +594,13 @@ ss_status ss_pedersen_hash(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b
     if (!ctx || !d_a || !d_b || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
     if (!ctx->ped) HIP_TRY(pedersen_tables_create(ctx->stream, &ctx->ped));
     HIP_TRY(launch_pedersen_felts(ctx->stream, ctx->ped, (const Fp *)d_a, (const Fp *)d_b, n, (Fp *)d_out));
+    return SS_OK;
+}
+
+ss_status ss_pedersen_hash_host(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    if (!a || !b || !out) return fail(SS_ERR_INVALID, "NULL argument");
+    const Fp r = pedersen_hash_host(fp_from_limbs64(a), fp_from_limbs64(b));
+    for (int i = 0; i < 4; ++i) out[i] = (uint64_t)r.v[2 * i] | ((uint64_t)r.v[2 * i + 1] << 32);
     return SS_OK;
 }
 

@@ -58,6 +58,9 @@ hipError_t launch_pedersen_pairs(hipStream_t st, const PedersenTables *t, const 
 hipError_t launch_pedersen_felt_pairs(hipStream_t st, const PedersenTables *t, const Fp *felts,
                                       uint64_t count, uint8_t *out);
 
+// host-side hash for the Fiat-Shamir coin (Montgomery felts)
+Fp pedersen_hash_host(const Fp &a, const Fp &b);
+
 // ---- fri.hip
 hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, uint32_t log_fold,
                            const Fp &alpha, const Fp &offset_inv, const Fp &w_inv, const Fp *fold_tw_inv,

@@ -16,6 +16,7 @@
 // (8M + 3S), then one inversion.  The tables (2 x 31 x 255 + 2 x 15 affine
 // points, ~1 MiB) are built once per context on the host and stay L2-resident.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <vector>
 #include "fp252.h"
 #include "kernels.h"
@@ -101,7 +102,8 @@ static void batch_to_affine(std::vector<Jac> &pts, std::vector<Aff> &out) {
     }
 }
 
-hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
+// the windowed table on the host: [2][PED_PER_INPUT] affine points, plus P0
+static void build_host_tables(std::vector<Aff> &aff, Aff &shift) {
     Aff pts[5];
     for (int k = 0; k < 5; ++k) { pts[k].x = canon_to_mont(PED_CANON[k][0]); pts[k].y = canon_to_mont(PED_CANON[k][1]); }
     std::vector<Jac> jac;
@@ -129,18 +131,52 @@ hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
         acc = dbl;
         for (int d = 3; d <= 15; ++d) { acc = jac_add_aff(acc, hb); jac.push_back(acc); }
     }
-    std::vector<Aff> aff;
     batch_to_affine(jac, aff);
+    shift = pts[0];
+}
+
+static const std::vector<Aff> &host_tables(Aff *shift) {
+    static std::vector<Aff> aff;
+    static Aff sh;
+    static std::once_flag once;
+    std::call_once(once, [] { build_host_tables(aff, sh); });
+    if (shift) *shift = sh;
+    return aff;
+}
+
+hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
+    Aff shift;
+    const std::vector<Aff> &aff = host_tables(&shift);
     PedersenTables *t = new PedersenTables;
-    t->shift = pts[0];
+    t->shift = shift;
     hipError_t e = hipMalloc(&t->d_table, aff.size() * sizeof(Aff));
     if (e != hipSuccess) { delete t; return e; }
     e = hipMemcpyAsync(t->d_table, aff.data(), aff.size() * sizeof(Aff), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { hipFree(t->d_table); delete t; return e; }
+    if (e != hipSuccess) { (void)hipFree(t->d_table); delete t; return e; }
     *out = t;
     return hipSuccess;
 }
+
+// pedersen_hash on the host, same windowed tables (used by the Fiat-Shamir coin only)
+Fp pedersen_hash_host(const Fp &a, const Fp &b) {
+    Aff shift;
+    const std::vector<Aff> &tab = host_tables(&shift);
+    Jac acc; acc.x = shift.x; acc.y = shift.y; acc.z = fp_one();
+    const Fp in[2] = {fp_from_mont(a), fp_from_mont(b)};
+    for (int e = 0; e < 2; ++e) {
+        const Aff *t = tab.data() + e * PED_PER_INPUT;
+        for (int j = 0; j < PED_WINDOWS; ++j) {
+            const u32 d = (in[e].v[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            if (d) acc = jac_add_aff(acc, t[j * 255 + (d - 1)]);
+        }
+        const u32 dh = (in[e].v[7] >> 24) & 0xfu;
+        if (dh) acc = jac_add_aff(acc, t[PED_LOW_ENTRIES + (dh - 1)]);
+    }
+    const Fp zi = fp_inv(acc.z);
+    return fp_mul(acc.x, fp_sqr(zi));
+}
+
 void pedersen_tables_destroy(PedersenTables *t) {
     if (!t) return;
     hipFree(t->d_table);
