@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py — the hot path on synthetic traces, one rank per GPU.
+"""bench.py — the proving hot path on a synthetic trace, one rank per GPU.
 
     python bench.py --gpus N --steps K --warmup W [--workload starknet_2p20]
 
-A step = one pass of the GPU hot path over one synthetic trace batch resident
-in HBM (see `config.stages` in the output for exactly which stages are inside
-the timed region).  Prints ONE JSON line on rank 0 (contract in the task
-statement): whole-job Fp field-ops/s of the LDE NTTs, plus `roofline` (dominant
-kernel, HIP-event timed) and `cpu_baseline` (the CPU oracle on a bounded sample,
-timed on this box's host cores — a *port*, not the reference binary).
+A step = ONE PROOF: every GPU stage of SURVEY.md §3.1 steps 2-9 (LDE of base and
+extension columns, row hashing + Merkle trees, composition-constraint evaluation,
+composition LDE, OOD evaluation, DEEP composition, FRI layers, proof-of-work,
+query openings) on a trace that is already resident in HBM.  The host trace
+generation (A1/A2) is outside: base and extension columns are
+synthetic random columns; the AIR is the layout-SHAPED synthetic constraint set of
+sandstorm_amd/synthetic_air.py (said so in `config`).
+
+Prints ONE JSON line on rank 0: prove wall-time (s), plus the Fp NTT rate,
+`roofline` (NTT pass kernel, HIP-event timed inside the same K proofs) and
+`cpu_baseline` (the CPU oracle — a port, not the reference binary — on a bounded
+sample of the same stages, on this box's host cores).
 """
 import argparse
 import json
@@ -25,10 +31,10 @@ import torch  # first: its bundled HIP runtime must be the one the C ABI library
 import torch.distributed as dist
 
 WORKLOADS = {
-    # name: (log2 trace rows n, trace columns, description)        rows n = 16 * steps
-    "starknet_2p20": (24, 10, "starknet layout shape, 2^20 steps: 10 columns x 2^24 rows, LDE blowup 2"),
-    "recursive_2p16": (20, 10, "recursive layout shape, 2^16 steps: 10 columns x 2^20 rows, LDE blowup 2"),
-    "tiny": (12, 10, "plumbing"),
+    # name: (layout, log2 steps).  trace rows n = 16 * steps (CYCLE_HEIGHT, recursive/mod.rs:16)
+    "starknet_2p20": ("starknet", 20),      # BASELINE.json: the size the metric is quoted on
+    "recursive_2p16": ("recursive", 16),    # BASELINE.json configs[1]
+    "recursive_2p10": ("recursive", 10),    # plumbing
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -39,39 +45,57 @@ def ntt_field_ops(log_size):
 
 
 def synth_columns(device, ncols, log_n, seed):
-    """uint64[ncols, n, 4] random Montgomery images < p, generated on the GPU"""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    n = 1 << log_n
-    t = torch.randint(0, 2**63 - 1, (ncols, n, 4), dtype=torch.int64, device=device, generator=g)
-    t[:, :, 3] &= (1 << 59) - 1          # < 2^251 < p
+    t = torch.randint(0, 2**63 - 1, (ncols, 1 << log_n, 4), dtype=torch.int64, device=device, generator=g)
+    t[:, :, 3] &= (1 << 59) - 1          # < 2^251 < p: any such 256-bit image is a valid Montgomery felt
     return t
 
 
-def cpu_baseline(sample_log_n, sample_cols):
-    """The CPU oracle (a port of the reference's algorithm, OpenMP) on a bounded sample."""
+def cpu_baseline(layout, log_n_full, ncols):
+    """The CPU oracle (OpenMP port of the same algorithms) on a bounded sample: the LDE,
+    row-hash, Merkle and FRI-fold stages at 2^16 rows, scaled to the full trace length
+    (n log n for the NTTs, n for the rest).  Quotient + DEEP are NOT included: a lower bound."""
     import numpy as np
     from oracle import oracle_py as oracle
     from tests.util import random_column
+    sl = min(16, log_n_full)
+    n = 1 << sl
     g = oracle.to_mont([3])[0]
-    n = 1 << sample_log_n
-    cols = [random_column(n, c) for c in range(sample_cols)]
-    oracle.lde(cols[0][:1024], 1, g)    # warm: build tables, spin up OpenMP
+    cols = [random_column(n, c) for c in range(ncols)]
+    oracle.lde(cols[0][:256], 1, g)
     t0 = time.perf_counter()
-    for c in cols:
-        oracle.lde(c, 1, g)
-    dt = time.perf_counter() - t0
-    ops = sample_cols * (ntt_field_ops(sample_log_n) + ntt_field_ops(sample_log_n + 1))
-    return {"value": ops / dt / 1e9, "unit": "Gfield-ops/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "oracle LDE (iNTT n + coset NTT 2n, OpenMP) of %d columns x 2^%d rows, %.1f s"
-                      % (sample_cols, sample_log_n, dt)}
+    ldes = [oracle.lde(c, 1, g)[0] for c in cols]
+    t_lde = time.perf_counter() - t0
+    kind = 3 if layout == "recursive" else 1
+    tree = 2 if layout == "recursive" else 1
+    t0 = time.perf_counter()
+    leaves = oracle.hash_rows(kind, ldes)
+    oracle.merkle_build(tree, 22, 0, leaves)
+    comp = oracle.hash_rows(kind, ldes[:2])
+    oracle.merkle_build(tree, 22, 0, comp)
+    t_hash = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ev, off = ldes[0], g
+    for _ in range(2):
+        ev = oracle.fri_fold(ev, 8, g, off)
+    t_fri = time.perf_counter() - t0
+    scale_n = float(1 << (log_n_full - sl))
+    scale_ntt = scale_n * (log_n_full + 0.5) / (sl + 0.5)
+    # the proof has ~1.4x the trace-LDE NTT work (composition, OOD, DEEP-free FRI) and 3 trees
+    est = 1.4 * t_lde * scale_ntt + 1.5 * t_hash * scale_n + 1.2 * t_fri * scale_n
+    ops = ncols * (ntt_field_ops(sl) + ntt_field_ops(sl + 1))
+    return {"value": est, "unit": "s", "cores": os.cpu_count(), "kind": "port",
+            "ntt_gfield_ops_per_s": ops / t_lde / 1e9,
+            "sample": "oracle (C, OpenMP) LDE %dx2^%d %.2fs + row-hash/Merkle %.2fs + FRI %.2fs, scaled to 2^%d rows; "
+                      "omits quotient+DEEP (lower bound on a CPU prove)" % (ncols, sl, t_lde, t_hash, t_fri, log_n_full)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="starknet_2p20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -79,92 +103,104 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     from sandstorm_amd import backend as be
-    log_n, ncols, desc = WORKLOADS[args.workload]
-    log_blowup = 1
-    n, N = 1 << log_n, 1 << (log_n + log_blowup)
+    from sandstorm_amd import synthetic_air
+    from sandstorm_amd.prover import Claim, ProofOptions, Prover
 
+    layout, log_steps = WORKLOADS[args.workload]
+    log_n, lb = log_steps + 4, 1
+    n = 1 << log_n
     ctx = be.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    offset = be.felt(3)
+    air = synthetic_air.make_air(layout, ctx, log_n, lb)
+    if layout == "recursive":       # cli/src/main.rs:95-99 -> CairoVerifierClaim
+        claim = Claim(air, be.FriendlyMerkleTree, be.COIN_CAIRO)
+    else:                           # cli/src/main.rs:90-94 -> EthVerifierClaim
+        claim = Claim(air, be.LeafVariantMerkleTree, be.COIN_SOLIDITY)
+    options = ProofOptions()        # CLI defaults: 65 queries, blowup 2, 16 PoW bits, fold 8, <=16 remainder
+    prover = Prover(ctx, claim, options)
 
-    # inputs resident in HBM before the timed region (every rank: its own trace -> weak scaling)
-    trace = synth_columns(device, ncols, log_n, seed=0x53414E44 + rank)
-    evals = torch.empty((ncols, N, 4), dtype=torch.int64, device=device)
-    coeffs = torch.empty((ncols, n, 4), dtype=torch.int64, device=device)
-    t_cols = [trace[c] for c in range(ncols)]
-    e_cols = [evals[c] for c in range(ncols)]
-    c_cols = [coeffs[c] for c in range(ncols)]
+    # inputs resident in HBM before the timed region; one independent trace per rank (weak scaling)
+    base_t = synth_columns(device, air.num_base_columns, log_n, seed=0x53414E44 + rank)
+    ext_t = synth_columns(device, air.num_extension_columns, log_n, seed=0x7E57 + rank)
+    base = be.Matrix(ctx, [base_t[c] for c in range(air.num_base_columns)], n)
+    ext = be.Matrix(ctx, [ext_t[c] for c in range(air.num_extension_columns)], n)
+    seed = bytes((7 * i + rank) & 0xff for i in range(32))
 
     def step():
-        ctx.lde(t_cols, log_n, log_blowup, offset, e_cols, c_cols)
+        return prover.prove(seed, base, lambda challenges: ext)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):          # also builds the twiddle plans
+    for _ in range(args.warmup):          # also builds the twiddle plans and Pedersen tables
         step()
     barrier()
     ctx.profile(True)
     ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        proof = step()
     barrier()
     dt = time.perf_counter() - t0
-    ntt_ms, ntt_launches = ctx.profile_read(be.PROF_NTT_PASS)
+    kinds = [("ntt_pass", be.PROF_NTT_PASS), ("hash_rows", be.PROF_HASH_ROWS), ("merkle", be.PROF_MERKLE),
+             ("fri_fold", be.PROF_FRI), ("quotient", be.PROF_QUOTIENT), ("deep", be.PROF_DEEP)]
+    prof = {name: ctx.profile_read(k) for name, k in kinds}
     ctx.profile(False)
 
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-
-    ops_per_step = ncols * (ntt_field_ops(log_n) + ntt_field_ops(log_n + log_blowup))
-    value = world * ops_per_step * args.steps / dt / 1e9
+    sec_per_proof = dt / args.steps
 
     if rank == 0:
-        # roofline of the dominant kernel family (ntt_pass_kernel): algorithmic bytes per
-        # launch = SURVEY §8d's 2*N*32 B per transform, shared equally by the passes of that
-        # transform, x columns per launch.  Summed over the timed region:
-        algo_bytes = args.steps * ncols * 32.0 * (2 * n + 2 * N)
-        achieved = algo_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
-        # bytes every pass really streams (each pass reads and writes every column once; the
-        # expanding pass reads n and writes N), for reference
-        def passes(lg):
-            r0 = min(11, lg)
-            return 1 + (0 if lg <= r0 else math.ceil((lg - r0) / 7))
-        streamed = args.steps * ncols * 32.0 * (2 * n * passes(log_n) + (n + N) + 2 * N * (passes(log_n + log_blowup) - 1))
+        ncols = air.num_base_columns + air.num_extension_columns
+        N = n << lb
+        # NTT work inside one proof: trace LDE (iNTT n + NTT N per column), composition (iNTT N, 2 x NTT N),
+        # OOD (NTT n per column), FRI remainder (tiny)
+        ntt_ops = ncols * (ntt_field_ops(log_n) + ntt_field_ops(log_n + lb)) + 3 * ntt_field_ops(log_n + lb) \
+            + ncols * ntt_field_ops(log_n)
+        algo_bytes = 32.0 * (ncols * (2 * n + 2 * N) + 3 * 2 * N + ncols * 2 * n)     # 2*N*32 B per transform
+        ntt_ms, ntt_launches = prof["ntt_pass"]
+        ntt_s = ntt_ms * 1e-3 / args.steps
+        achieved = algo_bytes / ntt_s / 1e9 if ntt_s > 0 else 0.0
         out = {
-            "metric": "fp252_lde_ntt_gfield_ops_per_s", "value": value, "unit": "Gfield-ops/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u256 (Fp252 Montgomery, 8x u32 limbs)", "data": "synthetic",
-            "config": {"workload": args.workload, "description": desc,
-                       "stages": ["iNTT n (x%d cols)" % ncols, "coset NTT 2n, offset 3 (x%d cols)" % ncols],
-                       "trace_rows_log2": log_n, "columns": ncols, "lde_blowup": 2,
-                       "per_gpu": "one full trace per rank"},
-            "roofline": {"bound": "hbm", "kernel": "ss::ntt_pass_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "launches": ntt_launches,
-                         "avg_launch_ms": ntt_ms / max(1, ntt_launches),
-                         "streamed_GBps": streamed / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0,
-                         "mulmod_per_s": args.steps * ncols * ((n // 2) * log_n + (N // 2) * (log_n + log_blowup) - n // 1 * 0) / (ntt_ms * 1e-3) if ntt_ms > 0 else 0.0,
-                         "note": "Fp252 butterflies are integer-ALU bound before HBM bound (DESIGN.md)"},
+            "metric": "prove_wall_time_s", "value": sec_per_proof, "unit": "s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_proof * 1e3,
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u256 (Fp252, Montgomery R=2^256, 8 x u32 limbs)", "data": "synthetic",
+            "proofs_per_s": world / sec_per_proof,
+            "ntt_gfield_ops_per_s": ntt_ops / ntt_s / 1e9 if ntt_s > 0 else 0.0,
+            "config": {"workload": args.workload, "layout_shape": layout, "steps_log2": log_steps,
+                       "trace_rows_log2": log_n, "columns": "%d base + %d extension" % (air.num_base_columns, air.num_extension_columns),
+                       "claim": "CairoVerifierClaim (Blake2s+Pedersen-22 tree, Cairo coin)" if layout == "recursive"
+                                else "EthVerifierClaim (Keccak-masked-20 tree, Solidity coin)",
+                       "air": "SYNTHETIC constraint set with the layout's shape: %d mask cells, see sandstorm_amd/synthetic_air.py" % len(air.mask),
+                       "proof_options": "65 queries, blowup 2, 16 PoW bits, FRI fold 8, <=16 remainder coeffs",
+                       "in_timed_region": "LDE x2, commits x3, quotient, composition LDE, OOD, DEEP, FRI, PoW, openings",
+                       "outside": "host trace generation (A1/A2): columns are resident in HBM",
+                       "per_gpu": "one independent proof per rank",
+                       "fri_layers": len(proof.fri_layers), "pow_nonce": proof.pow_nonce},
+            "stage_ms_per_proof": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
+            "roofline": {"bound": "hbm", "kernel": "ss::ntt_pass_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "launches": ntt_launches, "avg_launch_ms": ntt_ms / max(1, ntt_launches),
+                         "note": "algorithmic bytes = 2*N*32 B per transform (SURVEY 8d), shared by its passes; "
+                                 "Fp252 butterflies are integer-ALU bound before HBM bound (DESIGN.md)"},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(20 if log_n >= 20 else log_n, 4)
+            out["cpu_baseline"] = cpu_baseline(layout, log_n, ncols)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -173,6 +173,13 @@ typedef struct ss_air_program {
     uint32_t n_tables;
     uint32_t n_slots;            /* scratch slots used by ST / SS_SRC_SLOT */
 } ss_air_program;
+/* Table of a single-point zerofier inverse over the whole LDE domain:
+ * d_out[i] = 1 / (offset * w_N^i - c), i < 2^log_N (0 where the denominator is 0),
+ * by Montgomery batch inversion.  The AIRs' first/last-row boundary terms
+ * 1/(X - c) (e.g. layouts/src/recursive/air.rs:295-298) become TABLE operands of
+ * length 2^log_N instead of a per-point field inversion. */
+ss_status ss_inverse_table(ss_ctx *ctx, uint32_t log_N, const uint64_t offset[4], const uint64_t c[4],
+                           uint64_t *d_out);
 ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
                            uint32_t ncols, uint32_t log_n, uint32_t log_blowup,
                            const uint64_t offset[4], uint64_t *d_out);

@@ -239,6 +239,12 @@ class Context:
                                        ct.ctypes.data, oc.ctypes.data, cc.ctypes.data, zp, _ptr_of(out)))
 
     # ---- Q1 -------------------------------------------------------------------------------
+    def inverse_table(self, log_N, offset, c, out):
+        """out[i] = 1 / (offset * w_N^i - c)"""
+        _k1, op = _felt_ptr(offset)
+        _k2, cp = _felt_ptr(c)
+        check(self.lib.ss_inverse_table(self.handle, log_N, op, cp, _ptr_of(out)))
+
     def eval_quotient(self, program, tables, table_desc, lde_cols, log_n, log_blowup, offset, out):
         """program: air_program.Program; tables: device buffer of concatenated felts (or None);
         table_desc: flat [offset, log_len, ...] list"""

@@ -771,6 +771,17 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
 }
 
 // ------------------------------------------------------------------- Q1
+ss_status ss_inverse_table(ss_ctx *ctx, uint32_t log_N, const uint64_t offset[4], const uint64_t cval[4],
+                           uint64_t *d_out) {
+    if (!ctx || !cval || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!valid_log(log_N)) return fail(SS_ERR_INVALID, "log_N out of range");
+    const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
+    const Fp w = root_of_unity(log_N);
+    ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
+    HIP_TRY(launch_batch_inverse(ctx->stream, (Fp *)d_out, log_N, off, w, fp_inv(w), fp_from_limbs64(cval)));
+    return SS_OK;
+}
+
 ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
                            uint32_t ncols, uint32_t log_n, uint32_t log_blowup, const uint64_t offset[4],
                            uint64_t *d_out) {

@@ -160,7 +160,10 @@ class Prover:
         comp_coeff = coin.draw()
         proof.composition_coeff = comp_coeff
         program, tables, table_desc = air.build_program(n, challenges, comp_coeff)
-        d_tables = ctx.column(tables) if tables is not None and len(tables) else None
+        if tables is None or isinstance(tables, (be.DeviceBuffer, be.DeviceView)):
+            d_tables = tables
+        else:
+            d_tables = ctx.column(tables) if len(tables) else None
         comp_evals = ctx.alloc(32 * N)
         ctx.eval_quotient(program, d_tables, table_desc, lde_cols, log_n, lb, g, comp_evals)
         # coefficients of H in bit-reversed order: the first half is H0 (even coefficients),
