@@ -706,10 +706,9 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
     const uint32_t log_N = log_n + log_blowup;
     if (!valid_log(log_n) || !valid_log(log_N)) return fail(SS_ERR_INVALID, "size out of range");
     if (ntrace_cols > (uint32_t)MAX_COLS || ncomp > 4) return fail(SS_ERR_UNSUPPORTED, "too many columns");
-    const uint64_t N = 1ull << log_N, n = 1ull << log_n;
+    const uint64_t n = 1ull << log_n;
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp zf = fp_from_limbs64(z);
-    const Fp wN = root_of_unity(log_N), wN_inv = fp_inv(wN);
     const Fp wn_inv = fp_inv(root_of_unity(log_n));
     // group mask cells by row offset
     std::vector<uint32_t> order(nmask);
@@ -729,7 +728,7 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
             cell_coef[t] = fp_mul(fp_from_limbs64(coeff_trace + 4 * j), wk);
             kacc = fp_add(kacc, fp_mul(cell_coef[t], fp_from_limbs64(ood_trace + 4 * j)));
         }
-        gdesc.push_back(offv << log_blowup); gdesc.push_back(first); gdesc.push_back(t - first);
+        gdesc.push_back(offv); gdesc.push_back(first); gdesc.push_back(t - first);
         group_k.push_back(kacc);
     }
     const uint32_t ngroups = (uint32_t)group_k.size();
@@ -740,13 +739,14 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
         comp_k = fp_add(comp_k, fp_mul(comp_coef[k], fp_from_limbs64(ood_comp + 4 * k)));
         zc = fp_mul(zc, zf);
     }
-    // device staging: D, Dc in scratch2; small arrays in scratch
-    ss_status st = ctx->ensure_scratch2(2 * N * sizeof(Fp));
+    // device staging: D, Dc (sub-coset tables) and the sub-coset DEEP values in scratch2;
+    // small arrays in scratch
+    ss_status st = ctx->ensure_scratch2(3 * n * sizeof(Fp));
     if (st != SS_OK) return st;
     const size_t small = (size_t)nmask * (4 + 32) + (size_t)ngroups * (12 + 32) + (size_t)(ncomp + 1) * 32 + 256;
     st = ctx->ensure_scratch(small);
     if (st != SS_OK) return st;
-    Fp *D = (Fp *)ctx->scratch2, *Dc = D + N;
+    Fp *D = (Fp *)ctx->scratch2, *Dc = D + n, *sub = D + 2 * n;
     char *p = (char *)ctx->scratch;
     Fp *d_cell_coef = (Fp *)p; p += (size_t)(nmask ? nmask : 1) * 32;
     Fp *d_group_k = (Fp *)p; p += (size_t)(ngroups ? ngroups : 1) * 32;
@@ -761,11 +761,29 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
         HIP_TRY(hipMemcpyAsync(d_gdesc, gdesc.data(), (size_t)ngroups * 12, hipMemcpyHostToDevice, s));
     }
     if (ncomp) HIP_TRY(hipMemcpyAsync(d_comp_coef, comp_coef.data(), (size_t)ncomp * 32, hipMemcpyHostToDevice, s));
-    ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
-    HIP_TRY(launch_batch_inverse(s, D, log_N, off, wN, wN_inv, zf));
-    if (ncomp) HIP_TRY(launch_batch_inverse(s, Dc, log_N, off, wN, wN_inv, zc));
-    HIP_TRY(launch_deep(s, (const void *const *)d_trace_lde, ntrace_cols, (const void *const *)d_comp_lde, ncomp, D, Dc,
-                        d_cell_col, d_cell_coef, d_gdesc, d_group_k, ngroups, d_comp_coef, comp_k, log_N, (Fp *)d_out));
+    // the DEEP polynomial has degree < n: compose it on the sub-coset offset*<w_n> (LDE rows
+    // m * blowup), interpolate, and expand back to the LDE domain
+    const Fp wn = root_of_unity(log_n);
+    const Fp *tw_inv = nullptr, *tw_fwd = nullptr;
+    st = ctx->get_plan(log_n, true, off, &tw_inv);
+    if (st != SS_OK) return st;
+    st = ctx->get_plan(log_N, false, off, &tw_fwd);
+    if (st != SS_OK) return st;
+    {
+        ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
+        HIP_TRY(launch_batch_inverse(s, D, log_n, off, wn, fp_inv(wn), zf));
+        if (ncomp) HIP_TRY(launch_batch_inverse(s, Dc, log_n, off, wn, fp_inv(wn), zc));
+        HIP_TRY(launch_deep(s, (const void *const *)d_trace_lde, ntrace_cols, (const void *const *)d_comp_lde, ncomp, D, Dc,
+                            d_cell_col, d_cell_coef, d_gdesc, d_group_k, ngroups, d_comp_coef, comp_k, log_n, log_blowup, sub));
+    }
+    ColPtrs inv, fwd;
+    memset(&inv, 0, sizeof inv); memset(&fwd, 0, sizeof fwd);
+    inv.src[0] = sub; inv.dst[0] = sub;
+    fwd.src[0] = sub; fwd.dst[0] = d_out;
+    st = run_inverse(ctx, inv, 1, log_n, tw_inv);
+    if (st != SS_OK) return st;
+    st = run_forward(ctx, fwd, 1, log_N, tw_fwd, log_blowup);
+    if (st != SS_OK) return st;
     HIP_TRY(hipStreamSynchronize(s));     // host staging vectors go out of scope
     return SS_OK;
 }

@@ -17,10 +17,15 @@
 //    into the coefficients and groups mask cells by offset:
 //      out[i] = sum_g D[i - off_g b] * (sum_{j in g} c'_j T_{col_j}[i] - K_g)
 //             + Dc[i] * (sum_k cc_k H_k[i] - Kc)
-//    = nmask + ngroups + ncomp + 1 multiplications per LDE point, all operands
-//    coalesced (lane i reads element i, or i - shift, of each array).
+//    = nmask + ngroups + ncomp + 1 multiplications per point, all operands
+//    coalesced (lane i reads element i, or i - shift, of each array).  The DEEP
+//    polynomial has degree < n, so it is composed on the n-point sub-coset
+//    offset*<w_n> only (every blowup-th LDE row) and then interpolated and
+//    re-expanded by two NTTs — half the pointwise work for blowup 2.  Products are
+//    accumulated in the lazy 9 x 28-bit form with one weak reduction per 12 terms.
 #include <hip/hip_runtime.h>
 #include "fp252.h"
+#include "fl252.h"
 #include "kernels.h"
 
 namespace ss {
@@ -137,53 +142,62 @@ struct DeepArgs {
     const Fp *group_k;           // [ngroups] sum_j c'_j * ood_j
     const Fp *comp_coef;         // [ncomp]
     Fp comp_k;                   // sum_k cc_k * ood_comp_k
-    uint32_t ngroups, ncomp, log_N;
+    uint32_t ngroups, ncomp, log_N, log_stride;     // log_N: log2 of the number of points evaluated
 };
 
+// Evaluates the DEEP sum at LDE indices i = m * stride, m < 2^log_M: with stride = blowup
+// this is the trace-size sub-coset offset*<w_n>, enough to pin the degree < n DEEP
+// polynomial, which the caller then interpolates and re-expands (halves the pointwise work).
+// D / Dc are tables over that same sub-coset; group shifts are in sub-coset units.
 __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ out) {
-    const uint64_t N = 1ull << a.log_N;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < N;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        Fp acc = fp_zero();
+    const uint64_t M = 1ull << a.log_N;              // points evaluated
+    for (uint64_t m = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; m < M;
+         m += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = m << a.log_stride;        // LDE row of this point
+        Fl acc = fl_zero();                          // lazy sum of normalised products
+        uint32_t acc_terms = 0;
         for (uint32_t g = 0; g < a.ngroups; ++g) {
             const uint32_t shift = a.group_desc[3 * g], first = a.group_desc[3 * g + 1], cnt = a.group_desc[3 * g + 2];
-            Fp inner = fp_zero();
+            Fl inner = fl_zero();
+            uint32_t terms = 0;
             for (uint32_t j = first; j < first + cnt; ++j) {
                 const uint32_t col = a.cell_col[j];
                 const Fp *tp = a.trace[0];
 #pragma unroll
                 for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) tp = a.trace[c];
-                inner = fp_add(inner, fp_mul(dload(tp + i), dload(a.cell_coef + j)));
+                inner = fl_add(inner, fl_mul(fl_from_fp(dload(tp + i)), fl_from_fp(dload(a.cell_coef + j))));
+                if (++terms == 12) { inner = fl_weak_reduce(inner); terms = 1; }      // 12 x 1.13p < 16p
             }
-            inner = fp_sub(inner, dload(a.group_k + g));
-            acc = fp_add(acc, fp_mul(inner, dload(a.D + ((i - shift) & (N - 1)))));
+            inner = fn_sub(fl_weak_reduce(inner), fl_from_fp(dload(a.group_k + g)));
+            acc = fl_add(acc, fl_mul(inner, fl_from_fp(dload(a.D + ((m - shift) & (M - 1))))));
+            if (++acc_terms == 12) { acc = fl_weak_reduce(acc); acc_terms = 1; }
         }
         if (a.ncomp) {
-            Fp inner = fp_zero();
+            Fl inner = fl_zero();
             for (uint32_t k = 0; k < a.ncomp; ++k) {
                 const Fp *hp = a.comp[0];
 #pragma unroll
                 for (int c = 1; c < 4; ++c) if (k == (uint32_t)c) hp = a.comp[c];
-                inner = fp_add(inner, fp_mul(dload(hp + i), dload(a.comp_coef + k)));
+                inner = fl_add(inner, fl_mul(fl_from_fp(dload(hp + i)), fl_from_fp(dload(a.comp_coef + k))));
             }
-            inner = fp_sub(inner, a.comp_k);
-            acc = fp_add(acc, fp_mul(inner, dload(a.Dc + i)));
+            inner = fn_sub(fl_weak_reduce(inner), fl_from_fp(a.comp_k));
+            acc = fl_add(acc, fl_mul(inner, fl_from_fp(dload(a.Dc + m))));
         }
-        dstore(out + i, acc);
+        dstore(out + m, fl_to_fp(acc));
     }
 }
 
 hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace, const void *const *comp,
                        uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *cell_col, const Fp *cell_coef,
                        const uint32_t *group_desc, const Fp *group_k, uint32_t ngroups, const Fp *comp_coef,
-                       const Fp &comp_k, uint32_t log_N, Fp *out) {
+                       const Fp &comp_k, uint32_t log_M, uint32_t log_stride, Fp *out) {
     DeepArgs a;
     for (int c = 0; c < MAX_COLS; ++c) a.trace[c] = c < (int)ntrace ? (const Fp *)trace[c] : nullptr;
     for (int c = 0; c < 4; ++c) a.comp[c] = c < (int)ncomp ? (const Fp *)comp[c] : nullptr;
     a.D = D; a.Dc = Dc; a.cell_col = cell_col; a.cell_coef = cell_coef; a.group_desc = group_desc;
     a.group_k = group_k; a.comp_coef = comp_coef; a.comp_k = comp_k; a.ngroups = ngroups; a.ncomp = ncomp;
-    a.log_N = log_N;
-    const uint64_t N = 1ull << log_N;
+    a.log_N = log_M; a.log_stride = log_stride;
+    const uint64_t N = 1ull << log_M;
     uint32_t gx = (uint32_t)((N + 255) / 256);
     if (gx > 256 * 16) gx = 256 * 16;
     hipLaunchKernelGGL(deep_kernel, dim3(gx), dim3(256), 0, st, a, out);

@@ -74,7 +74,7 @@ hipError_t launch_batch_inverse(hipStream_t st, Fp *D, uint32_t log_N, const Fp 
 hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace, const void *const *comp,
                        uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *cell_col, const Fp *cell_coef,
                        const uint32_t *group_desc, const Fp *group_k, uint32_t ngroups, const Fp *comp_coef,
-                       const Fp &comp_k, uint32_t log_N, Fp *out);
+                       const Fp &comp_k, uint32_t log_M, uint32_t log_stride, Fp *out);
 hipError_t launch_gather_cells(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *col,
                                const uint64_t *idx, uint32_t n, Fp *out);
 

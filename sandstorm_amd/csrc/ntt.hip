@@ -27,6 +27,7 @@
 //     radix-8 groups spread over all banks.
 #include <hip/hip_runtime.h>
 #include "fp252.h"
+#include "fl252.h"
 #include "kernels.h"
 
 namespace ss {
@@ -74,27 +75,37 @@ struct PassParams {
     uint32_t contig;      // 1: s0 == 0, tile is a contiguous block
 };
 
-// One butterfly stage (local stage u + ST) on the 2^G register-resident elements.
+// One butterfly stage (local stage u + ST) on the 2^G register-resident elements, in the
+// lazy 9 x 28-bit form (fl252.h): no carry chains, products are 81 in-place
+// v_mad_u64_u32.  Value/limb bounds through a group of up to 3 stages starting from
+// weakly reduced inputs (< 2^252, limbs < 2^28):
+//   DIT  a' = a + b t,  b' = a - b t + 2p     (b t is a normalised product: <C=2,F=1>)
+//        values grow by <= 2p per stage (< 8p after 3), limbs by <= 2^29
+//   DIF  a' = a + b,    b' = (a - b + C p) t  with C = 2, 8, 16 for the 1st, 2nd, 3rd
+//        stage of the group (b's limbs double each stage); a' < 16p after 3 stages.
 template <bool DIF, int G, int ST>
-__device__ __forceinline__ void radix_stage(Fp (&x)[1 << G], const Fp *__restrict__ tw, const PassParams &p,
+__device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const Fp *__restrict__ tw, const PassParams &p,
                                             uint32_t u, uint32_t jlow, uint32_t lbits) {
     if (ST >= G) return;
     const uint32_t s = p.s0 + u + ST;               // global stage
     const Fp *tws = tw + ((1u << s) - 1u);
+    constexpr int STC = ST < G ? ST : 0;
+    // position of this stage inside the group's execution order (DIF runs ST = G-1 .. 0)
+    constexpr int ORD = DIF ? (G - 1 - STC) : STC;
 #pragma unroll
     for (int pr = 0; pr < (1 << G) / 2; ++pr) {
-        constexpr int STC = ST < G ? ST : 0;
         const int m = ((pr >> STC) << (STC + 1)) | (pr & ((1 << STC) - 1));
         const uint32_t k = ((jlow + ((uint32_t)(m & ((1 << STC) - 1)) << u)) << p.s0) | lbits;
-        const Fp t = gload(tws + k);
-        const Fp a = x[m], b = x[m | (1 << STC)];
+        const Fl t = fl_from_fp(gload(tws + k));
+        const Fl a = x[m], b = x[m | (1 << STC)];
         if (DIF) {
-            x[m] = fp_add(a, b);
-            x[m | (1 << STC)] = fp_mul(fp_sub(a, b), t);
+            x[m] = fl_add(a, b);
+            const Fl d = ORD == 0 ? fl_sub_c<2, 1>(a, b) : ORD == 1 ? fl_sub_c<8, 2>(a, b) : fl_sub_c<16, 4>(a, b);
+            x[m | (1 << STC)] = fl_mul(d, t);
         } else {
-            const Fp bt = fp_mul(b, t);
-            x[m] = fp_add(a, bt);
-            x[m | (1 << STC)] = fp_sub(a, bt);
+            const Fl bt = fl_mul(b, t);
+            x[m] = fl_add(a, bt);
+            x[m | (1 << STC)] = fl_sub_c<2, 1>(a, bt);
         }
     }
 }
@@ -123,9 +134,10 @@ __device__ __forceinline__ void radix_group(uint4 *lo, uint4 *hi, const Fp *__re
             lbits = q & ((1u << p.s0) - 1u);
         }
         const uint32_t jlow = jbase & ((1u << u) - 1u);
-        Fp x[1 << G];
+        // LDS holds 256-bit images of weakly reduced values (< 2^252): unpacking is pure bit slicing
+        Fl x[1 << G];
 #pragma unroll
-        for (int m = 0; m < (1 << G); ++m) x[m] = lds_load(lo, hi, ebase + ((uint32_t)m << sh));
+        for (int m = 0; m < (1 << G); ++m) x[m] = fl_from_fp(lds_load(lo, hi, ebase + ((uint32_t)m << sh)));
         if (DIF) {
             if (G >= 3) radix_stage<DIF, G, 2>(x, tw, p, u, jlow, lbits);
             if (G >= 2) radix_stage<DIF, G, 1>(x, tw, p, u, jlow, lbits);
@@ -135,12 +147,17 @@ __device__ __forceinline__ void radix_group(uint4 *lo, uint4 *hi, const Fp *__re
             if (G >= 2) radix_stage<DIF, G, 1>(x, tw, p, u, jlow, lbits);
             if (G >= 3) radix_stage<DIF, G, 2>(x, tw, p, u, jlow, lbits);
         }
-        if (DIF && last_group && p.scale_pow2) {
 #pragma unroll
-            for (int m = 0; m < (1 << G); ++m) x[m] = fp_div_pow2(x[m], p.scale_pow2);
+        for (int m = 0; m < (1 << G); ++m) {
+            Fp out;
+            if (last_group) {                              // leaving the pass: canonical image (< p)
+                out = fl_to_fp(x[m]);
+                if (DIF && p.scale_pow2) out = fp_div_pow2(out, p.scale_pow2);
+            } else {
+                out = fl_pack(fl_weak_reduce(x[m]));
+            }
+            lds_store(lo, hi, ebase + ((uint32_t)m << sh), out);
         }
-#pragma unroll
-        for (int m = 0; m < (1 << G); ++m) lds_store(lo, hi, ebase + ((uint32_t)m << sh), x[m]);
     }
 }
 
@@ -182,9 +199,10 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(ColPtrs cols, 
         uint32_t u = p.u_first;
         while (u < p.r) {
             const uint32_t g = (p.r - u) >= 3 ? 3 : (p.r - u);
-            if (g == 3) radix_group<false, 3>(lo, hi, tw, p, u, tile, false);
-            else if (g == 2) radix_group<false, 2>(lo, hi, tw, p, u, tile, false);
-            else radix_group<false, 1>(lo, hi, tw, p, u, tile, false);
+            const bool last = (u + g >= p.r);
+            if (g == 3) radix_group<false, 3>(lo, hi, tw, p, u, tile, last);
+            else if (g == 2) radix_group<false, 2>(lo, hi, tw, p, u, tile, last);
+            else radix_group<false, 1>(lo, hi, tw, p, u, tile, last);
             u += g;
             __syncthreads();
         }

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/sandstorm_hip.h"
 #include "fp252.h"
+#include "fl252.h"
 #include "kernels.h"
 
 namespace ss {
@@ -44,57 +45,65 @@ struct VmArgs {
     uint32_t n_instr, log_N, log_blowup;
 };
 
+// Accumulators live in the lazy 9 x 28-bit form (fl252.h) and are kept weakly reduced
+// (< 2^252, limbs < 2^28) after every instruction, so any program is closed under the
+// bounds of fl_mul / fl_sub_c<2,1>.
 __global__ __launch_bounds__(256) void quotient_vm_kernel(VmArgs a) {
     const uint64_t N = 1ull << a.log_N;
     const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    Fp x = fp_mul(a.offset, fp_pow_u64(a.w, lane));
+    Fl x = fl_from_fp(fp_mul(a.offset, fp_pow_u64(a.w, lane)));
+    const Fl wstep = fl_from_fp(a.wstep);
     for (uint64_t i = lane; i < N; i += lanes) {
-        Fp acc0 = fp_zero(), acc1 = fp_zero(), acc2 = fp_zero(), acc3 = fp_zero();
+        Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
         for (uint32_t pc = 0; pc < a.n_instr; ++pc) {
             const uint32_t w0 = a.code[2 * pc], w1 = a.code[2 * pc + 1];
             const uint32_t op = w0 & 0xffu, d = (w0 >> 8) & 0xfu, kind = (w0 >> 12) & 0xfu;
-            Fp src = fp_zero();
+            Fl src = fl_zero();
             if (op <= SS_OP_MUL) {
                 if (kind == SS_SRC_ACC) {
                     const uint32_t s = w1 & 3u;
                     src = s == 0 ? acc0 : s == 1 ? acc1 : s == 2 ? acc2 : acc3;
-                } else if (kind == SS_SRC_SLOT) {
-                    src = qload(a.slots + (uint64_t)w1 * lanes + lane);
-                } else if (kind == SS_SRC_CONST) {
-                    src = qload(a.consts + w1);
-                } else if (kind == SS_SRC_TRACE) {
-                    const uint32_t col = w1 >> 24;
-                    const uint64_t row = (i + ((uint64_t)(w1 & 0xffffffu) << a.log_blowup)) & (N - 1);
-                    const Fp *cp = a.cols[0];
-#pragma unroll
-                    for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) cp = a.cols[c];
-                    src = qload(cp + row);
-                } else if (kind == SS_SRC_TABLE) {
-                    const uint32_t off = a.table_desc[2 * w1], ll = a.table_desc[2 * w1 + 1];
-                    src = qload(a.tables + off + (i & ((1ull << ll) - 1ull)));
-                } else {
+                } else if (kind == SS_SRC_X) {
                     src = x;
+                } else {
+                    const Fp *ptr;
+                    if (kind == SS_SRC_SLOT) {
+                        ptr = a.slots + (uint64_t)w1 * lanes + lane;
+                    } else if (kind == SS_SRC_CONST) {
+                        ptr = a.consts + w1;
+                    } else if (kind == SS_SRC_TRACE) {
+                        const uint32_t col = w1 >> 24;
+                        const uint64_t row = (i + ((uint64_t)(w1 & 0xffffffu) << a.log_blowup)) & (N - 1);
+                        const Fp *cp = a.cols[0];
+#pragma unroll
+                        for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) cp = a.cols[c];
+                        ptr = cp + row;
+                    } else {
+                        const uint32_t off = a.table_desc[2 * w1], ll = a.table_desc[2 * w1 + 1];
+                        ptr = a.tables + off + (i & ((1ull << ll) - 1ull));
+                    }
+                    src = fl_from_fp(qload(ptr));       // canonical or weakly reduced 256-bit image
                 }
             }
-            Fp v = d == 0 ? acc0 : d == 1 ? acc1 : d == 2 ? acc2 : acc3;
+            Fl v = d == 0 ? acc0 : d == 1 ? acc1 : d == 2 ? acc2 : acc3;
             bool write = true;
             switch (op) {
             case SS_OP_MOV: v = src; break;
-            case SS_OP_ADD: v = fp_add(v, src); break;
-            case SS_OP_SUB: v = fp_sub(v, src); break;
-            case SS_OP_RSUB: v = fp_sub(src, v); break;
-            case SS_OP_MUL: v = fp_mul(v, src); break;
-            case SS_OP_INV: v = fp_inv(v); break;
-            case SS_OP_ST: qstore(a.slots + (uint64_t)w1 * lanes + lane, v); write = false; break;
-            case SS_OP_OUT: qstore(a.out + i, v); write = false; break;
+            case SS_OP_ADD: v = fn_add(v, src); break;
+            case SS_OP_SUB: v = fn_sub(v, src); break;
+            case SS_OP_RSUB: v = fn_sub(src, v); break;
+            case SS_OP_MUL: v = fl_mul(v, src); break;
+            case SS_OP_INV: v = fl_from_fp(fp_inv(fl_to_fp(v))); break;
+            case SS_OP_ST: qstore(a.slots + (uint64_t)w1 * lanes + lane, fl_pack(v)); write = false; break;
+            case SS_OP_OUT: qstore(a.out + i, fl_to_fp(v)); write = false; break;
             default: write = false; break;
             }
             if (write) {
                 if (d == 0) acc0 = v; else if (d == 1) acc1 = v; else if (d == 2) acc2 = v; else acc3 = v;
             }
         }
-        x = fp_mul(x, a.wstep);
+        x = fl_mul(x, wstep);
     }
 }
 
