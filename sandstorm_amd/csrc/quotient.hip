@@ -45,10 +45,15 @@ struct VmArgs {
     uint32_t n_instr, log_N, log_blowup;
 };
 
-// Accumulators live in the lazy 9 x 28-bit form (fl252.h) and are kept weakly reduced
-// (< 2^252, limbs < 2^28) after every instruction, so any program is closed under the
-// bounds of fl_mul / fl_sub_c<2,1>.
-__global__ __launch_bounds__(256) void quotient_vm_kernel(VmArgs a) {
+// Accumulators live in the lazy 9 x 28-bit form (fl252.h).  Because the program is
+// wave-uniform, a per-accumulator bound b (value < 2 b p, limbs < b 2^28) is tracked in
+// scalar registers: ADD / SUB are nine carry-less 32-bit adds that bump the bound, and a
+// weak reduction is issued (a uniform branch) only when an operation's precondition
+// needs it:  fl_mul   a-side any b <= 8, b-side b == 1;   fl_sub_c<2,1> subtrahend b == 1;
+// ST / table-free operands from memory are always b == 1.
+static constexpr uint32_t VM_MAX_BOUND = 8;       // 8 * 2p * 2p / 2^256 + p < 2p: products stay < 2^252
+
+__global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
     const uint64_t N = 1ull << a.log_N;
     const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -56,14 +61,17 @@ __global__ __launch_bounds__(256) void quotient_vm_kernel(VmArgs a) {
     const Fl wstep = fl_from_fp(a.wstep);
     for (uint64_t i = lane; i < N; i += lanes) {
         Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
+        uint32_t bnd0 = 1, bnd1 = 1, bnd2 = 1, bnd3 = 1;
         for (uint32_t pc = 0; pc < a.n_instr; ++pc) {
             const uint32_t w0 = a.code[2 * pc], w1 = a.code[2 * pc + 1];
             const uint32_t op = w0 & 0xffu, d = (w0 >> 8) & 0xfu, kind = (w0 >> 12) & 0xfu;
             Fl src = fl_zero();
+            uint32_t sb = 1;                               // bound of src
             if (op <= SS_OP_MUL) {
                 if (kind == SS_SRC_ACC) {
                     const uint32_t s = w1 & 3u;
                     src = s == 0 ? acc0 : s == 1 ? acc1 : s == 2 ? acc2 : acc3;
+                    sb = s == 0 ? bnd0 : s == 1 ? bnd1 : s == 2 ? bnd2 : bnd3;
                 } else if (kind == SS_SRC_X) {
                     src = x;
                 } else {
@@ -87,20 +95,40 @@ __global__ __launch_bounds__(256) void quotient_vm_kernel(VmArgs a) {
                 }
             }
             Fl v = d == 0 ? acc0 : d == 1 ? acc1 : d == 2 ? acc2 : acc3;
+            uint32_t vb = d == 0 ? bnd0 : d == 1 ? bnd1 : d == 2 ? bnd2 : bnd3;
             bool write = true;
             switch (op) {
-            case SS_OP_MOV: v = src; break;
-            case SS_OP_ADD: v = fn_add(v, src); break;
-            case SS_OP_SUB: v = fn_sub(v, src); break;
-            case SS_OP_RSUB: v = fn_sub(src, v); break;
-            case SS_OP_MUL: v = fl_mul(v, src); break;
-            case SS_OP_INV: v = fl_from_fp(fp_inv(fl_to_fp(v))); break;
-            case SS_OP_ST: qstore(a.slots + (uint64_t)w1 * lanes + lane, fl_pack(v)); write = false; break;
+            case SS_OP_MOV: v = src; vb = sb; break;
+            case SS_OP_ADD:
+                if (vb + sb > VM_MAX_BOUND) { v = fl_weak_reduce(v); vb = 1; }
+                if (vb + sb > VM_MAX_BOUND) { src = fl_weak_reduce(src); sb = 1; }
+                v = fl_add(v, src); vb += sb;
+                break;
+            case SS_OP_SUB:
+                if (sb > 1) { src = fl_weak_reduce(src); sb = 1; }
+                if (vb + 1 > VM_MAX_BOUND) { v = fl_weak_reduce(v); vb = 1; }
+                v = fl_sub_c<2, 1>(v, src); vb += 1;
+                break;
+            case SS_OP_RSUB:
+                if (vb > 1) { v = fl_weak_reduce(v); vb = 1; }
+                if (sb + 1 > VM_MAX_BOUND) { src = fl_weak_reduce(src); sb = 1; }
+                v = fl_sub_c<2, 1>(src, v); vb = sb + 1;
+                break;
+            case SS_OP_MUL:
+                if (sb > 1) { src = fl_weak_reduce(src); sb = 1; }
+                v = fl_mul(v, src); vb = 1;                // vb <= VM_MAX_BOUND by construction
+                break;
+            case SS_OP_INV: v = fl_from_fp(fp_inv(fl_to_fp(v))); vb = 1; break;
+            case SS_OP_ST:
+                if (vb > 1) { v = fl_weak_reduce(v); vb = 1; }      // slots hold weakly reduced images
+                qstore(a.slots + (uint64_t)w1 * lanes + lane, fl_pack(v));
+                break;
             case SS_OP_OUT: qstore(a.out + i, fl_to_fp(v)); write = false; break;
             default: write = false; break;
             }
             if (write) {
-                if (d == 0) acc0 = v; else if (d == 1) acc1 = v; else if (d == 2) acc2 = v; else acc3 = v;
+                if (d == 0) { acc0 = v; bnd0 = vb; } else if (d == 1) { acc1 = v; bnd1 = vb; }
+                else if (d == 2) { acc2 = v; bnd2 = vb; } else { acc3 = v; bnd3 = vb; }
             }
         }
         x = fl_mul(x, wstep);
