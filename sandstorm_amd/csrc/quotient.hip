@@ -53,6 +53,42 @@ struct VmArgs {
 // ST / table-free operands from memory are always b == 1.
 static constexpr uint32_t VM_MAX_BOUND = 8;       // 8 * 2p * 2p / 2^256 + p < 2p: products stay < 2^252
 
+// One instruction on a NAMED accumulator (v, vb): the destination index is wave-uniform,
+// so the caller dispatches with a scalar switch to one of four inlined copies of this body
+// instead of selecting registers with v_cndmask chains.
+__device__ __forceinline__ void vm_exec(uint32_t op, Fl &v, uint32_t &vb, Fl src, uint32_t sb, const VmArgs &a,
+                                        uint32_t w1, uint64_t lanes, uint64_t lane, uint64_t i) {
+    switch (op) {
+    case SS_OP_MOV: v = src; vb = sb; break;
+    case SS_OP_ADD:
+        if (vb + sb > VM_MAX_BOUND) { v = fl_weak_reduce(v); vb = 1; }
+        if (vb + sb > VM_MAX_BOUND) { src = fl_weak_reduce(src); sb = 1; }
+        v = fl_add(v, src); vb += sb;
+        break;
+    case SS_OP_SUB:
+        if (sb > 1) { src = fl_weak_reduce(src); sb = 1; }
+        if (vb + 1 > VM_MAX_BOUND) { v = fl_weak_reduce(v); vb = 1; }
+        v = fl_sub_c<2, 1>(v, src); vb += 1;
+        break;
+    case SS_OP_RSUB:
+        if (vb > 1) { v = fl_weak_reduce(v); vb = 1; }
+        if (sb + 1 > VM_MAX_BOUND) { src = fl_weak_reduce(src); sb = 1; }
+        v = fl_sub_c<2, 1>(src, v); vb = sb + 1;
+        break;
+    case SS_OP_MUL:
+        if (sb > 1) { src = fl_weak_reduce(src); sb = 1; }
+        v = fl_mul(v, src); vb = 1;                // vb <= VM_MAX_BOUND by construction
+        break;
+    case SS_OP_INV: v = fl_from_fp(fp_inv(fl_to_fp(v))); vb = 1; break;
+    case SS_OP_ST:
+        if (vb > 1) { v = fl_weak_reduce(v); vb = 1; }      // slots hold weakly reduced images
+        qstore(a.slots + (uint64_t)w1 * lanes + lane, fl_pack(v));
+        break;
+    case SS_OP_OUT: qstore(a.out + i, fl_to_fp(v)); break;
+    default: break;
+    }
+}
+
 __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
     const uint64_t N = 1ull << a.log_N;
     const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;
@@ -69,9 +105,12 @@ __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
             uint32_t sb = 1;                               // bound of src
             if (op <= SS_OP_MUL) {
                 if (kind == SS_SRC_ACC) {
-                    const uint32_t s = w1 & 3u;
-                    src = s == 0 ? acc0 : s == 1 ? acc1 : s == 2 ? acc2 : acc3;
-                    sb = s == 0 ? bnd0 : s == 1 ? bnd1 : s == 2 ? bnd2 : bnd3;
+                    switch (w1 & 3u) {
+                    case 0: src = acc0; sb = bnd0; break;
+                    case 1: src = acc1; sb = bnd1; break;
+                    case 2: src = acc2; sb = bnd2; break;
+                    default: src = acc3; sb = bnd3; break;
+                    }
                 } else if (kind == SS_SRC_X) {
                     src = x;
                 } else {
@@ -94,41 +133,11 @@ __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
                     src = fl_from_fp(qload(ptr));       // canonical or weakly reduced 256-bit image
                 }
             }
-            Fl v = d == 0 ? acc0 : d == 1 ? acc1 : d == 2 ? acc2 : acc3;
-            uint32_t vb = d == 0 ? bnd0 : d == 1 ? bnd1 : d == 2 ? bnd2 : bnd3;
-            bool write = true;
-            switch (op) {
-            case SS_OP_MOV: v = src; vb = sb; break;
-            case SS_OP_ADD:
-                if (vb + sb > VM_MAX_BOUND) { v = fl_weak_reduce(v); vb = 1; }
-                if (vb + sb > VM_MAX_BOUND) { src = fl_weak_reduce(src); sb = 1; }
-                v = fl_add(v, src); vb += sb;
-                break;
-            case SS_OP_SUB:
-                if (sb > 1) { src = fl_weak_reduce(src); sb = 1; }
-                if (vb + 1 > VM_MAX_BOUND) { v = fl_weak_reduce(v); vb = 1; }
-                v = fl_sub_c<2, 1>(v, src); vb += 1;
-                break;
-            case SS_OP_RSUB:
-                if (vb > 1) { v = fl_weak_reduce(v); vb = 1; }
-                if (sb + 1 > VM_MAX_BOUND) { src = fl_weak_reduce(src); sb = 1; }
-                v = fl_sub_c<2, 1>(src, v); vb = sb + 1;
-                break;
-            case SS_OP_MUL:
-                if (sb > 1) { src = fl_weak_reduce(src); sb = 1; }
-                v = fl_mul(v, src); vb = 1;                // vb <= VM_MAX_BOUND by construction
-                break;
-            case SS_OP_INV: v = fl_from_fp(fp_inv(fl_to_fp(v))); vb = 1; break;
-            case SS_OP_ST:
-                if (vb > 1) { v = fl_weak_reduce(v); vb = 1; }      // slots hold weakly reduced images
-                qstore(a.slots + (uint64_t)w1 * lanes + lane, fl_pack(v));
-                break;
-            case SS_OP_OUT: qstore(a.out + i, fl_to_fp(v)); write = false; break;
-            default: write = false; break;
-            }
-            if (write) {
-                if (d == 0) { acc0 = v; bnd0 = vb; } else if (d == 1) { acc1 = v; bnd1 = vb; }
-                else if (d == 2) { acc2 = v; bnd2 = vb; } else { acc3 = v; bnd3 = vb; }
+            switch (d) {
+            case 0: vm_exec(op, acc0, bnd0, src, sb, a, w1, lanes, lane, i); break;
+            case 1: vm_exec(op, acc1, bnd1, src, sb, a, w1, lanes, lane, i); break;
+            case 2: vm_exec(op, acc2, bnd2, src, sb, a, w1, lanes, lane, i); break;
+            default: vm_exec(op, acc3, bnd3, src, sb, a, w1, lanes, lane, i); break;
             }
         }
         x = fl_mul(x, wstep);
