@@ -241,6 +241,11 @@ ss_status ss_profile_read(ss_ctx *ctx, int kind, double *total_ms, uint64_t *lau
  * host).  Montgomery felts in and out; no device involved. */
 ss_status ss_pedersen_hash_host(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 
+/* Host-side Keccak-256 for the SolidityVerifierPublicCoin (crypto/src/public_coin/
+ * solidity.rs:36-53 hashes 32..64-byte messages hundreds of times per proof: one
+ * reseed per out-of-domain evaluation).  No device involved. */
+ss_status ss_keccak256_host(const uint8_t *msg, size_t len, uint8_t out[32]);
+
 /* ---- micro-benchmark hook: d_out[i] = d_a[i] * d_b[i] repeated `reps` times
  *      (dependent chain), used by bench.py to report mulmod/s. */
 ss_status ss_fp252_mul_bench(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t n,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ss_pow_grind": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, _u64p]),
     "ss_pedersen_hash": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "ss_pedersen_hash_host": (C.c_int, [_u64p, _u64p, _u64p]),
+    "ss_keccak256_host": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p]),
     "ss_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ss_profile_reset": (C.c_int, [C.c_void_p]),
     "ss_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), _u64p]),

@@ -17,41 +17,14 @@ P = be.P
 _RINV = pow(2**256, -1, P)
 _MASK64 = (1 << 64) - 1
 
-_KRC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B,
-        0x0000000080000001, 0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088,
-        0x0000000080008009, 0x000000008000000A, 0x000000008000808B, 0x800000000000008B, 0x8000000000008089,
-        0x8000000000008003, 0x8000000000008002, 0x8000000000000080, 0x000000000000800A, 0x800000008000000A,
-        0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
-_KROT = [0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14]
-
-
-def _keccak_f(s):
-    for rc in _KRC:
-        c = [s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20] for x in range(5)]
-        d = [c[(x + 4) % 5] ^ (((c[(x + 1) % 5] << 1) | (c[(x + 1) % 5] >> 63)) & _MASK64) for x in range(5)]
-        s = [s[i] ^ d[i % 5] for i in range(25)]
-        b = [0] * 25
-        for x in range(5):
-            for y in range(5):
-                v, r = s[x + 5 * y], _KROT[x + 5 * y]
-                b[y + 5 * ((2 * x + 3 * y) % 5)] = ((v << r) | (v >> (64 - r))) & _MASK64 if r else v
-        s = [b[i] ^ (~b[(i % 5 + 1) % 5 + 5 * (i // 5)] & _MASK64 & b[(i % 5 + 2) % 5 + 5 * (i // 5)]) for i in range(25)]
-        s[0] ^= rc
-    return s
-
-
 def keccak256(data: bytes) -> bytes:
-    rate = 136
-    msg = bytearray(data)
-    msg.append(0x01)
-    msg.extend(b"\x00" * (-len(msg) % rate))
-    msg[-1] |= 0x80
-    s = [0] * 25
-    for off in range(0, len(msg), rate):
-        for i in range(17):
-            s[i] ^= int.from_bytes(msg[off + 8 * i: off + 8 * i + 8], "little")
-        s = _keccak_f(s)
-    return b"".join(v.to_bytes(8, "little") for v in s[:4])
+    """host Keccak-256 of the library (ss_keccak256_host): the Solidity coin reseeds once per
+    out-of-domain evaluation, a few hundred hashes per proof"""
+    import ctypes
+    from . import _lib
+    out = ctypes.create_string_buffer(32)
+    _lib.check(_lib.load().ss_keccak256_host(bytes(data), len(data), out))
+    return out.raw
 
 
 def blake2s256(data: bytes) -> bytes:

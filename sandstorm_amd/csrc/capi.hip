@@ -597,6 +597,60 @@ ss_status ss_pedersen_hash(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b
     return SS_OK;
 }
 
+// host Keccak-256 (Keccak team padding 0x01), for the Fiat-Shamir coin only
+namespace {
+const uint64_t HOST_KRC[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
+    0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+    0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+    0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
+    0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+const int HOST_KPILN[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+const int HOST_KROTC[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+void host_keccak_f(uint64_t st[25]) {
+    for (int r = 0; r < 24; ++r) {
+        uint64_t bc[5];
+        for (int i = 0; i < 5; ++i) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
+        for (int i = 0; i < 5; ++i) {
+            const uint64_t t = bc[(i + 4) % 5] ^ ((bc[(i + 1) % 5] << 1) | (bc[(i + 1) % 5] >> 63));
+            for (int j = 0; j < 25; j += 5) st[j + i] ^= t;
+        }
+        uint64_t t = st[1];
+        for (int i = 0; i < 24; ++i) {
+            const int j = HOST_KPILN[i];
+            const uint64_t b = st[j];
+            st[j] = (t << HOST_KROTC[i]) | (t >> (64 - HOST_KROTC[i]));
+            t = b;
+        }
+        for (int j = 0; j < 25; j += 5) {
+            for (int i = 0; i < 5; ++i) bc[i] = st[j + i];
+            for (int i = 0; i < 5; ++i) st[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+        }
+        st[0] ^= HOST_KRC[r];
+    }
+}
+}  // namespace
+
+ss_status ss_keccak256_host(const uint8_t *msg, size_t len, uint8_t out[32]) {
+    if ((!msg && len) || !out) return fail(SS_ERR_INVALID, "NULL argument");
+    uint64_t st[25] = {0};
+    const size_t rate = 136;
+    while (len >= rate) {
+        for (int i = 0; i < 17; ++i) { uint64_t w; memcpy(&w, msg + 8 * i, 8); st[i] ^= w; }
+        host_keccak_f(st);
+        msg += rate; len -= rate;
+    }
+    uint8_t blk[136] = {0};
+    if (len) memcpy(blk, msg, len);
+    blk[len] ^= 0x01;
+    blk[135] ^= 0x80;
+    for (int i = 0; i < 17; ++i) { uint64_t w; memcpy(&w, blk + 8 * i, 8); st[i] ^= w; }
+    host_keccak_f(st);
+    memcpy(out, st, 32);
+    return SS_OK;
+}
+
 ss_status ss_pedersen_hash_host(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
     if (!a || !b || !out) return fail(SS_ERR_INVALID, "NULL argument");
     const Fp r = pedersen_hash_host(fp_from_limbs64(a), fp_from_limbs64(b));

@@ -102,19 +102,20 @@ __global__ __launch_bounds__(128) void batch_inverse_kernel(Fp *__restrict__ D, 
     const uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     const uint64_t CH = 1ull << log_chunk, i0 = c << log_chunk;
-    Fp x = fp_mul(offset, fp_pow_u64(w, i0));
-    Fp run = fp_one();
+    const Fl wl = fl_from_fp(w), wil = fl_from_fp(w_inv), zl = fl_from_fp(z);
+    Fl x = fl_from_fp(fp_mul(offset, fp_pow_u64(w, i0)));
+    Fl run = fl_one();
     for (uint64_t k = 0; k < CH; ++k) {
-        dstore(D + i0 + k, run);                 // prefix product of d_0 .. d_{k-1}
-        run = fp_mul(run, fp_sub(x, z));
-        x = fp_mul(x, w);
+        dstore(D + i0 + k, fl_pack(run));        // prefix product of d_0 .. d_{k-1} (weakly reduced image)
+        run = fl_mul(fl_sub_c<2, 1>(x, zl), run);
+        x = fl_mul(x, wl);
     }
-    Fp inv = fp_inv(run);                        // 1 / (d_0 ... d_{CH-1}); 0 stays 0 if some x_i == z
+    Fl inv = fn_inv(run);                        // 1 / (d_0 ... d_{CH-1}); 0 stays 0 if some x_i == z
     for (uint64_t k = CH; k-- > 0;) {
-        x = fp_mul(x, w_inv);                    // x_{i0+k}
-        const Fp pre = dload(D + i0 + k);
-        dstore(D + i0 + k, fp_mul(inv, pre));
-        inv = fp_mul(inv, fp_sub(x, z));
+        x = fl_mul(x, wil);                      // x_{i0+k}
+        const Fl pre = fl_from_fp(dload(D + i0 + k));
+        dstore(D + i0 + k, fl_to_fp(fl_mul(inv, pre)));
+        inv = fl_mul(fl_sub_c<2, 1>(x, zl), inv);
     }
 }
 

@@ -79,7 +79,7 @@ __device__ __forceinline__ void vm_exec(uint32_t op, Fl &v, uint32_t &vb, Fl src
         if (sb > 1) { src = fl_weak_reduce(src); sb = 1; }
         v = fl_mul(v, src); vb = 1;                // vb <= VM_MAX_BOUND by construction
         break;
-    case SS_OP_INV: v = fl_from_fp(fp_inv(fl_to_fp(v))); vb = 1; break;
+    case SS_OP_INV: v = fn_inv(fl_weak_reduce(v)); vb = 1; break;
     case SS_OP_ST:
         if (vb > 1) { v = fl_weak_reduce(v); vb = 1; }      // slots hold weakly reduced images
         qstore(a.slots + (uint64_t)w1 * lanes + lane, fl_pack(v));

@@ -135,6 +135,17 @@ class Prover:
         g = be.felt(conv.lde_offset)
         coin = PublicCoin(self.claim.coin_kind, coin_seed)
         proof = Proof(opt, n)
+        import time
+        trace_stages = bool(self.timings is not None and self.timings.get("enabled"))
+        t_last = [time.perf_counter()]
+
+        def mark(name):
+            """optional per-stage wall clock (synchronises the stream: debugging only)"""
+            if trace_stages:
+                ctx.sync()
+                now = time.perf_counter()
+                self.timings[name] = self.timings.get(name, 0.0) + (now - t_last[0])
+                t_last[0] = now
 
         # 2. base trace: interpolate, extend, commit
         base_lde, base_coeffs = base_trace.lde(lb, g)
@@ -142,6 +153,7 @@ class Prover:
         proof.base_root = base_tree.root()
         coin.reseed_with_digest(proof.base_root)
 
+        mark("base_lde_commit")
         # 3-4. challenges -> extension trace
         challenges = [coin.draw() for _ in range(air.num_challenges)]
         proof.challenges = challenges
@@ -156,6 +168,7 @@ class Prover:
             lde_cols += ext_lde.cols
             coeff_cols += ext_coeffs.cols
 
+        mark("ext_lde_commit")
         # 5. composition constraint over the LDE domain, then its 2-column LDE
         comp_coeff = coin.draw()
         proof.composition_coeff = comp_coeff
@@ -164,8 +177,10 @@ class Prover:
             d_tables = tables
         else:
             d_tables = ctx.column(tables) if len(tables) else None
+        mark("lower_program")
         comp_evals = ctx.alloc(32 * N)
         ctx.eval_quotient(program, d_tables, table_desc, lde_cols, log_n, lb, g, comp_evals)
+        mark("quotient")
         # coefficients of H in bit-reversed order: the first half is H0 (even coefficients),
         # the second half H1 (odd), each again bit-reversed — the split is free
         ctx.ntt([comp_evals], log_N, be.INVERSE, g, be.NATURAL, be.BITREV)
@@ -178,6 +193,7 @@ class Prover:
         proof.composition_root = comp_tree.root()
         coin.reseed_with_digest(proof.composition_root)
 
+        mark("composition_lde_commit")
         # 6. out-of-domain point
         z = coin.draw()
         proof.z = z
@@ -188,6 +204,7 @@ class Prover:
         proof.ood_composition = ctx.poly_eval(comp_coeffs, log_n, zc)
         coin.reseed_with_field_elements(list(proof.ood_trace) + list(proof.ood_composition))
 
+        mark("ood")
         # 7. DEEP composition
         deep_alpha = coin.draw()
         proof.deep_alpha = deep_alpha
@@ -196,6 +213,7 @@ class Prover:
         ctx.deep_compose(lde_cols, comp_lde.cols, log_n, lb, g, mask_col, mask_off, proof.ood_trace,
                          coeffs[:len(air.mask)], proof.ood_composition, coeffs[len(air.mask):], z, deep)
 
+        mark("deep")
         # 8. FRI
         fold = opt.fri_folding_factor
         log_fold = _log2(fold)
@@ -225,8 +243,10 @@ class Prover:
         proof.fri_remainder = rem_host[:max(1, degree_bound)]
         coin.reseed_with_field_element_vector(list(proof.fri_remainder))
 
+        mark("fri")
         # 9. proof of work, queries, openings
         proof.pow_nonce = ctx.pow_grind(self.claim.coin_kind, coin.digest, opt.grinding_factor) if opt.grinding_factor else 0
+        mark("pow")
         coin.reseed_with_int(proof.pow_nonce)
         positions = coin.draw_queries(opt.num_queries, N)
         proof.query_positions = positions
@@ -245,4 +265,5 @@ class Prover:
             layer.rows = ctx.gather_rows(matrix.cols, pos)
             layer.paths, _ = tree.prove(pos)
             proof.fri_layers.append(layer)
+        mark("openings")
         return proof

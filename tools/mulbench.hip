@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_fl_mul0(const Fp *in, Fp *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     Fl x0 = fl_from_fp(in[4 * i]), x1 = fl_from_fp(in[4 * i + 1]), x2 = fl_from_fp(in[4 * i + 2]), x3 = fl_from_fp(in[4 * i + 3]);
     const Fl y = fl_from_fp(in[(4 * i + 5) & 1023]);
-    for (int it = 0; it < ITERS; ++it) { x0 = fl_mul_t<0>(x0, y); x1 = fl_mul_t<0>(x1, y); x2 = fl_mul_t<0>(x2, y); x3 = fl_mul_t<0>(x3, y); }
+    for (int it = 0; it < ITERS; ++it) { x0 = fl_mul(x0, y); x1 = fl_mul(x1, y); x2 = fl_mul(x2, y); x3 = fl_mul(x3, y); }
     out[i] = fp_add(fp_add(fl_to_fp(x0), fl_to_fp(x1)), fp_add(fl_to_fp(x2), fl_to_fp(x3)));
 }
 // radix-4 style: 2 butterflies per iteration on 4 values (DIT: b*w, a+bw, a-bw)
