@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -897,11 +898,14 @@ ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64
     if (prog->n_tables) HIP_TRY(hipMemcpyAsync(d_desc, prog->table_desc, (size_t)prog->n_tables * 8, hipMemcpyHostToDevice, s));
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp w = root_of_unity(log_N);
-    const Fp wstep = fp_pow_u64(w, lanes);
+    // optional XCD-contiguous sweep (measured: no gain, the per-XCD window still exceeds L2)
+    const uint32_t xcd_split = (lanes % (8 * 256) == 0 && (N >> 3) >= (lanes >> 3) && (N >> 3) % (lanes >> 3) == 0 &&
+                                getenv("SS_QUOTIENT_XCD_SPLIT") != nullptr) ? 1u : 0u;
+    const Fp wstep = fp_pow_u64(w, xcd_split ? (lanes >> 3) : lanes);
     ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
     HIP_TRY(launch_quotient_vm(s, (const void *const *)d_lde_cols, ncols, d_code, prog->n_instr, d_consts,
                                (const Fp *)prog->d_tables, d_desc, d_slots, lanes, off, w, wstep, log_N, log_blowup,
-                               (Fp *)d_out));
+                               xcd_split, (Fp *)d_out));
     HIP_TRY(hipStreamSynchronize(s));      // the caller's host arrays may go away after return
     return SS_OK;
 }

@@ -82,6 +82,6 @@ hipError_t launch_gather_cells(hipStream_t st, const void *const *cols, uint32_t
 hipError_t launch_quotient_vm(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *d_code,
                               uint32_t n_instr, const Fp *d_consts, const Fp *d_tables, const uint32_t *d_table_desc,
                               Fp *d_slots, uint64_t lanes, const Fp &offset, const Fp &w, const Fp &wstep,
-                              uint32_t log_N, uint32_t log_blowup, Fp *out);
+                              uint32_t log_N, uint32_t log_blowup, uint32_t xcd_split, Fp *out);
 
 }  // namespace ss

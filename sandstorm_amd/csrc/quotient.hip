@@ -42,7 +42,7 @@ struct VmArgs {
     Fp *slots;               // [n_slots][total_lanes]
     Fp *out;
     Fp offset, w, wstep;     // x_i = offset * w^i; wstep = w^(total lanes)
-    uint32_t n_instr, log_N, log_blowup;
+    uint32_t n_instr, log_N, log_blowup, xcd_split;
 };
 
 // Accumulators live in the lazy 9 x 28-bit form (fl252.h).  Because the program is
@@ -92,10 +92,24 @@ __device__ __forceinline__ void vm_exec(uint32_t op, Fl &v, uint32_t &vb, Fl src
 __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
     const uint64_t N = 1ull << a.log_N;
     const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    Fl x = fl_from_fp(fp_mul(a.offset, fp_pow_u64(a.w, lane)));
-    const Fl wstep = fl_from_fp(a.wstep);
-    for (uint64_t i = lane; i < N; i += lanes) {
+    const uint64_t lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;       // slot-file index
+    // XCD-aware point mapping.  Workgroup b runs on XCD b % 8 (observed dispatch order; used
+    // for speed only): every XCD sweeps its own contiguous 1/8 of the LDE domain, so the rows
+    // that different mask offsets re-read stay inside that XCD's 4 MiB L2 instead of being
+    // spread over all eight.  a.xcd_split == 0 falls back to the plain grid-stride order.
+    uint64_t i0, stride, count;
+    if (a.xcd_split) {
+        const uint64_t per_xcd = N >> 3, lanes_xcd = lanes >> 3;
+        i0 = (blockIdx.x & 7u) * per_xcd + (uint64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x;
+        stride = lanes_xcd;
+        count = per_xcd / lanes_xcd;
+    } else {
+        i0 = lane; stride = lanes; count = (N + lanes - 1 - lane) / lanes;
+    }
+    Fl x = fl_from_fp(fp_mul(a.offset, fp_pow_u64(a.w, i0)));
+    const Fl wstep = fl_from_fp(a.wstep);                                          // w^stride
+    for (uint64_t it = 0; it < count; ++it) {
+        const uint64_t i = i0 + it * stride;
         Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
         uint32_t bnd0 = 1, bnd1 = 1, bnd2 = 1, bnd3 = 1;
         for (uint32_t pc = 0; pc < a.n_instr; ++pc) {
@@ -147,12 +161,12 @@ __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
 hipError_t launch_quotient_vm(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *d_code,
                               uint32_t n_instr, const Fp *d_consts, const Fp *d_tables, const uint32_t *d_table_desc,
                               Fp *d_slots, uint64_t lanes, const Fp &offset, const Fp &w, const Fp &wstep,
-                              uint32_t log_N, uint32_t log_blowup, Fp *out) {
+                              uint32_t log_N, uint32_t log_blowup, uint32_t xcd_split, Fp *out) {
     VmArgs a;
     for (int c = 0; c < MAX_COLS; ++c) a.cols[c] = c < (int)ncols ? (const Fp *)cols[c] : nullptr;
     a.code = d_code; a.consts = d_consts; a.tables = d_tables; a.table_desc = d_table_desc; a.slots = d_slots;
     a.out = out; a.offset = offset; a.w = w; a.wstep = wstep; a.n_instr = n_instr; a.log_N = log_N;
-    a.log_blowup = log_blowup;
+    a.log_blowup = log_blowup; a.xcd_split = xcd_split;
     hipLaunchKernelGGL(quotient_vm_kernel, dim3((uint32_t)(lanes / 256)), dim3(256), 0, st, a);
     return hipGetLastError();
 }

@@ -1,0 +1,58 @@
+// air_program.hpp — Expr DAG and its lowering to the constraint-evaluation program of the
+// C ABI (ss_air_program).  C++ counterpart of the reference's `Expr` tree
+// (layouts/src/recursive/air.rs:61-1200, ministark::expression::Expr) and of what a Rust
+// `hip` feature would do once per (layout, trace length): walk
+// `composition_constraint(..).reuse_shared_nodes()` and emit code for the 4-accumulator machine.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <tuple>
+#include <vector>
+
+#include "coin.hpp"
+
+namespace ssh {
+
+enum class NodeKind { X, Const, Trace, Table, Add, Sub, Mul, Inv };
+
+struct Node {
+    NodeKind kind;
+    int a = -1, b = -1;          // children (node ids)
+    uint32_t p0 = 0, p1 = 0;     // Trace: col, row offset; Table: index; Const: index into the graph's constants
+};
+
+// Hash-consed expression graph: structurally equal nodes are the same node, so shared
+// sub-expressions are shared by construction.
+class Graph {
+public:
+    int x();
+    int constant(const Felt &mont);
+    int constant_u64(uint64_t v) { return constant(felt_from_u64(v)); }
+    int trace(uint32_t col, uint32_t row_offset);
+    int table(uint32_t index);
+    int add(int a, int b);
+    int sub(int a, int b);
+    int mul(int a, int b);
+    int inv(int a);
+    const std::vector<Node> &nodes() const { return nodes_; }
+    const std::vector<Felt> &constants() const { return consts_; }
+private:
+    int intern(NodeKind k, int a, int b, uint32_t p0, uint32_t p1);
+    std::vector<Node> nodes_;
+    std::vector<Felt> consts_;
+    std::map<std::tuple<int, int, int, uint32_t, uint32_t>, int> pool_;
+    std::map<Felt, int> const_ix_;
+};
+
+struct Program {
+    std::vector<uint32_t> code;      // 2 words per instruction
+    std::vector<Felt> consts;
+    uint32_t n_slots = 0;
+    uint32_t n_instr() const { return (uint32_t)(code.size() / 2); }
+};
+
+// code leaving `root` in accumulator 0 followed by OUT
+Program lower(const Graph &g, int root);
+
+}  // namespace ssh

@@ -1,0 +1,109 @@
+// host_capi.cpp — C entry points of libsandstorm_host.so: the C++ prover for callers
+// without C++ (bench.py and the tests reach it through ctypes).
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "prover.hpp"
+
+using namespace ssh;
+
+namespace { thread_local std::string g_err; }
+
+extern "C" {
+
+typedef struct ssh_air ssh_air;
+// build_extension_columns callback: fill d_cols_out[0..next) with device pointers of the
+// extension columns for these challenges; return 0 on success
+typedef int (*ssh_extension_cb)(void *user, const uint64_t *challenges, uint32_t nchallenges, uint64_t **d_cols_out);
+
+const char *ssh_last_error(void) { return g_err.c_str(); }
+
+// kind: 0 = mini, 1 = synthetic recursive, 2 = synthetic starknet
+int ssh_air_create(ss_ctx *ctx, int kind, uint32_t log_n, uint32_t log_blowup, ssh_air **out) {
+    try {
+        std::unique_ptr<Air> a = kind == 0 ? make_mini_air(ctx)
+                                           : make_synthetic_air(ctx, kind == 1 ? "recursive" : "starknet", log_n, log_blowup, 3);
+        *out = reinterpret_cast<ssh_air *>(a.release());
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+void ssh_air_destroy(ssh_air *a) { delete reinterpret_cast<Air *>(a); }
+uint32_t ssh_air_columns(const ssh_air *a, int which) {
+    const Air *air = reinterpret_cast<const Air *>(a);
+    return which == 0 ? air->num_base_columns : which == 1 ? air->num_extension_columns : (uint32_t)air->mask.size();
+}
+
+// options: {num_queries, lde_blowup_factor, grinding_factor, fri_folding_factor, fri_max_remainder_coeffs}
+int ssh_prove(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32],
+              uint64_t *const *d_base, uint32_t nbase, uint32_t log_n, ssh_extension_cb cb, void *user, const uint32_t options[5],
+              uint8_t **proof_bytes, uint64_t *proof_len) {
+    try {
+        Air *air = reinterpret_cast<Air *>(air_h);
+        Claim claim;
+        claim.air = air; claim.tree_kind = tree_kind; claim.n_friendly_layers = n_friendly_layers; claim.coin_kind = coin_kind;
+        ProofOptions opt;
+        if (options) {
+            opt.num_queries = options[0]; opt.lde_blowup_factor = options[1]; opt.grinding_factor = options[2];
+            opt.fri_folding_factor = options[3]; opt.fri_max_remainder_coeffs = options[4];
+        }
+        Matrix base;
+        base.nrows = 1ull << log_n;
+        for (uint32_t c = 0; c < nbase; ++c) base.cols.push_back(d_base[c]);
+        Digest sd;
+        memcpy(sd.data(), seed, 32);
+        Prover prover(ctx, claim, opt);
+        Proof proof = prover.prove(sd, base, [&](const std::vector<Felt> &ch) {
+            Matrix ext;
+            ext.nrows = base.nrows;
+            std::vector<uint64_t> flat(4 * ch.size());
+            for (size_t i = 0; i < ch.size(); ++i) memcpy(flat.data() + 4 * i, ch[i].data(), 32);
+            std::vector<uint64_t *> cols(air->num_extension_columns, nullptr);
+            if (!cb || cb(user, flat.data(), (uint32_t)ch.size(), cols.data()) != 0) throw std::runtime_error("extension callback failed");
+            ext.cols = cols;
+            return ext;
+        });
+        if (proof_bytes && proof_len) {
+            std::vector<uint8_t> b = proof.serialize();
+            *proof_bytes = (uint8_t *)malloc(b.size());
+            memcpy(*proof_bytes, b.data(), b.size());
+            *proof_len = b.size();
+        }
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+void ssh_free(void *p) { free(p); }
+
+// ---- the C++ coin, exposed for the CPU tests (tests/test_host_cpp.py)
+typedef struct ssh_coin ssh_coin;
+ssh_coin *ssh_coin_new(int kind, const uint8_t seed[32]) {
+    Digest d;
+    memcpy(d.data(), seed, 32);
+    return reinterpret_cast<ssh_coin *>(new PublicCoin(kind, d));
+}
+void ssh_coin_free(ssh_coin *c) { delete reinterpret_cast<PublicCoin *>(c); }
+static std::vector<Felt> felts_of(const uint64_t *v, uint32_t n) {
+    std::vector<Felt> o(n);
+    for (uint32_t i = 0; i < n; ++i) memcpy(o[i].data(), v + 4 * i, 32);
+    return o;
+}
+int ssh_coin_op(ssh_coin *ch, int op, const uint8_t *bytes, uint64_t len, const uint64_t *felts, uint32_t nfelts, uint64_t arg,
+                uint64_t *out, uint32_t *nout) {
+    try {
+        PublicCoin *c = reinterpret_cast<PublicCoin *>(ch);
+        switch (op) {
+        case 0: c->reseed_with_bytes(bytes, len); break;
+        case 1: c->reseed_with_field_elements(felts_of(felts, nfelts)); break;
+        case 2: c->reseed_with_field_element_vector(felts_of(felts, nfelts)); break;
+        case 3: c->reseed_with_int(arg); break;
+        case 4: { Felt f = c->draw(); memcpy(out, f.data(), 32); break; }
+        case 5: { auto q = c->draw_queries((size_t)arg, len); memcpy(out, q.data(), 8 * q.size()); *nout = (uint32_t)q.size(); break; }
+        case 6: memcpy(out, c->digest().data(), 32); out[4] = c->counter(); break;
+        default: throw std::runtime_error("bad coin op");
+        }
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+}  // extern "C"

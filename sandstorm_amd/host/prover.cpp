@@ -1,0 +1,256 @@
+#include "prover.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <set>
+#include <stdexcept>
+
+namespace ssh {
+
+static void ok(ss_status s) {
+    if (s != SS_OK) throw std::runtime_error(ss_last_error());
+}
+static uint32_t log2u(uint64_t v) {
+    uint32_t l = 0;
+    while ((1ull << l) < v) ++l;
+    if ((1ull << l) != v) throw std::runtime_error("not a power of two");
+    return l;
+}
+
+// ------------------------------------------------------------------ device objects
+DeviceBuffer::DeviceBuffer(ss_ctx *ctx, size_t bytes) : ctx_(ctx), bytes_(bytes) { ok(ss_dev_alloc(ctx, bytes, &ptr_)); }
+DeviceBuffer::~DeviceBuffer() { if (ptr_) ss_dev_free(ctx_, ptr_); }
+
+Matrix Matrix::alloc(ss_ctx *ctx, uint32_t ncols, uint64_t nrows) {
+    Matrix m;
+    m.nrows = nrows;
+    for (uint32_t c = 0; c < ncols; ++c) {
+        auto b = std::make_shared<DeviceBuffer>(ctx, 32 * nrows);
+        m.cols.push_back(b->u64());
+        m.owned.push_back(b);
+    }
+    return m;
+}
+
+std::unique_ptr<MerkleTree> MerkleTree::from_matrix(ss_ctx *ctx, int tree_kind, uint32_t n_friendly, const Matrix &m) {
+    auto t = std::unique_ptr<MerkleTree>(new MerkleTree);
+    t->ctx_ = ctx; t->tree_kind_ = tree_kind; t->n_ = m.nrows;
+    t->nodes_.reset(new DeviceBuffer(ctx, 64 * m.nrows));
+    if (tree_kind == SS_TREE_FRIENDLY) t->tags_.reset(new DeviceBuffer(ctx, 2 * m.nrows));
+    const int row_hash = tree_kind == SS_TREE_KECCAK ? SS_HASH_KECCAK : tree_kind == SS_TREE_KECCAK_M20 ? SS_HASH_KECCAK_M20 : SS_HASH_BLAKE2S_M20;
+    if (m.num_cols() == 1) {            // single column: the column becomes the leaves (merkle/mod.rs:113-117)
+        ok(ss_merkle_build(ctx, tree_kind, n_friendly, SS_LEAF_FELT, m.cols[0], m.nrows, t->nodes_->u8(),
+                           t->tags_ ? t->tags_->u8() : nullptr, t->root_.data()));
+    } else {
+        t->leaves_.reset(new DeviceBuffer(ctx, 32 * m.nrows));
+        ok(ss_hash_rows(ctx, row_hash, (const uint64_t *const *)m.cols.data(), m.num_cols(), m.nrows, t->leaves_->u8()));
+        ok(ss_merkle_build(ctx, tree_kind, n_friendly, SS_LEAF_DIGEST, t->leaves_->u8(), m.nrows, t->nodes_->u8(),
+                           t->tags_ ? t->tags_->u8() : nullptr, t->root_.data()));
+    }
+    return t;
+}
+std::vector<uint8_t> MerkleTree::prove(const std::vector<uint64_t> &idx) const {
+    std::vector<uint8_t> out(idx.size() * log2u(n_) * 32);
+    ok(ss_merkle_open(ctx_, nodes_->u8(), tags_ ? tags_->u8() : nullptr, n_, idx.data(), (uint32_t)idx.size(), out.data(), nullptr));
+    return out;
+}
+
+static std::vector<uint64_t> gather(ss_ctx *ctx, const std::vector<uint64_t *> &cols, const std::vector<uint64_t> &idx) {
+    std::vector<uint64_t> out(idx.size() * cols.size() * 4);
+    ok(ss_gather_rows(ctx, (const uint64_t *const *)cols.data(), (uint32_t)cols.size(), idx.data(), (uint32_t)idx.size(), out.data()));
+    return out;
+}
+static std::vector<uint64_t> flat(const std::vector<Felt> &v) {
+    std::vector<uint64_t> o(4 * v.size());
+    for (size_t i = 0; i < v.size(); ++i) memcpy(o.data() + 4 * i, v[i].data(), 32);
+    return o;
+}
+
+// ------------------------------------------------------------------------- prove
+Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const ExtensionBuilder &build_extension) {
+    Air &air = *claim_.air;
+    const uint64_t n = base_trace.nrows;
+    const uint32_t log_n = log2u(n), lb = log2u(opt_.lde_blowup_factor), log_N = log_n + lb;
+    const uint64_t N = n << lb;
+    const Felt g = felt_from_u64(conv_.lde_offset);
+    PublicCoin coin(claim_.coin_kind, coin_seed);
+    Proof proof;
+    proof.options = opt_;
+    proof.trace_len = n;
+    auto commit = [&](const Matrix &m) { return MerkleTree::from_matrix(ctx_, claim_.tree_kind, claim_.n_friendly_layers, m); };
+    auto digest_of = [](const std::array<uint8_t, 33> &r) { Digest d; memcpy(d.data(), r.data(), 32); return d; };
+
+    // 2. base trace: interpolate, extend, commit
+    Matrix base_lde = Matrix::alloc(ctx_, base_trace.num_cols(), N), base_co = Matrix::alloc(ctx_, base_trace.num_cols(), n);
+    ok(ss_lde_fp252(ctx_, (const uint64_t *const *)base_trace.cols.data(), base_trace.num_cols(), log_n, lb, g.data(),
+                    base_lde.cols.data(), base_co.cols.data()));
+    auto base_tree = commit(base_lde);
+    proof.base_root = base_tree->root();
+    coin.reseed_with_digest(digest_of(proof.base_root));
+
+    // 3-4. challenges -> extension trace
+    for (uint32_t i = 0; i < air.num_challenges; ++i) proof.challenges.push_back(coin.draw());
+    std::vector<uint64_t *> lde_cols = base_lde.cols, coeff_cols = base_co.cols;
+    Matrix ext_lde, ext_co;
+    std::unique_ptr<MerkleTree> ext_tree;
+    if (air.num_extension_columns) {
+        Matrix ext = build_extension(proof.challenges);
+        ext_lde = Matrix::alloc(ctx_, ext.num_cols(), N);
+        ext_co = Matrix::alloc(ctx_, ext.num_cols(), n);
+        ok(ss_lde_fp252(ctx_, (const uint64_t *const *)ext.cols.data(), ext.num_cols(), log_n, lb, g.data(), ext_lde.cols.data(),
+                        ext_co.cols.data()));
+        ext_tree = commit(ext_lde);
+        proof.has_extension = true;
+        proof.extension_root = ext_tree->root();
+        coin.reseed_with_digest(digest_of(proof.extension_root));
+        lde_cols.insert(lde_cols.end(), ext_lde.cols.begin(), ext_lde.cols.end());
+        coeff_cols.insert(coeff_cols.end(), ext_co.cols.begin(), ext_co.cols.end());
+    }
+
+    // 5. composition constraint on the LDE domain; its coefficients in bit-reversed order split
+    //    for free into H0 (first half) and H1 (second half)
+    proof.composition_coeff = coin.draw();
+    AirProgramData pd = air.build_program(n, proof.challenges, proof.composition_coeff);
+    std::vector<uint64_t> consts = flat(pd.program.consts);
+    ss_air_program prog;
+    prog.code = pd.program.code.data(); prog.n_instr = pd.program.n_instr();
+    prog.consts = consts.data(); prog.n_consts = (uint32_t)pd.program.consts.size();
+    prog.d_tables = pd.d_tables; prog.table_desc = pd.table_desc.data(); prog.n_tables = (uint32_t)(pd.table_desc.size() / 2);
+    prog.n_slots = pd.program.n_slots;
+    DeviceBuffer comp_evals(ctx_, 32 * N);
+    ok(ss_eval_quotient(ctx_, &prog, (const uint64_t *const *)lde_cols.data(), (uint32_t)lde_cols.size(), log_n, lb, g.data(), comp_evals.u64()));
+    uint64_t *ce = comp_evals.u64();
+    ok(ss_ntt_fp252(ctx_, &ce, 1, log_N, SS_NTT_INVERSE, g.data(), SS_ORDER_NATURAL, SS_ORDER_BITREV));
+    const uint32_t ncomp = conv_.composition_columns;
+    if (ncomp != (1u << lb) || ncomp != 2) throw std::runtime_error("composition split implemented for blowup 2");
+    std::vector<uint64_t *> comp_coeffs;
+    for (uint32_t k = 0; k < ncomp; ++k) comp_coeffs.push_back(ce + 4 * n * k);
+    Matrix comp_lde = Matrix::alloc(ctx_, ncomp, N);
+    ok(ss_evaluate_fp252(ctx_, (const uint64_t *const *)comp_coeffs.data(), ncomp, log_n, lb, g.data(), comp_lde.cols.data()));
+    auto comp_tree = commit(comp_lde);
+    proof.composition_root = comp_tree->root();
+    coin.reseed_with_digest(digest_of(proof.composition_root));
+
+    // 6. out-of-domain point
+    proof.z = coin.draw();
+    std::vector<uint32_t> mask_col, mask_off;
+    for (auto &c : air.mask) { mask_col.push_back(c.first); mask_off.push_back(c.second); }
+    const uint32_t nmask = (uint32_t)air.mask.size();
+    std::vector<uint64_t> ood_t(4 * nmask), ood_c(4 * ncomp);
+    ok(ss_ood_eval(ctx_, (const uint64_t *const *)coeff_cols.data(), (uint32_t)coeff_cols.size(), log_n, mask_col.data(), mask_off.data(),
+                   nmask, proof.z.data(), ood_t.data()));
+    const Felt zc = felt_pow(proof.z, ncomp);
+    ok(ss_poly_eval(ctx_, (const uint64_t *const *)comp_coeffs.data(), ncomp, log_n, zc.data(), ood_c.data()));
+    for (uint32_t j = 0; j < nmask; ++j) { Felt f; memcpy(f.data(), ood_t.data() + 4 * j, 32); proof.ood_trace.push_back(f); }
+    for (uint32_t k = 0; k < ncomp; ++k) { Felt f; memcpy(f.data(), ood_c.data() + 4 * k, 32); proof.ood_composition.push_back(f); }
+    {
+        std::vector<Felt> all = proof.ood_trace;
+        all.insert(all.end(), proof.ood_composition.begin(), proof.ood_composition.end());
+        coin.reseed_with_field_elements(all);
+    }
+
+    // 7. DEEP composition: coefficients are powers of one alpha (src/lib.rs:102-116)
+    proof.deep_alpha = coin.draw();
+    std::vector<Felt> coeffs;
+    Felt cur = felt_from_u64(1);
+    for (uint32_t i = 0; i < nmask + ncomp; ++i) { coeffs.push_back(cur); cur = felt_mul(cur, proof.deep_alpha); }
+    std::vector<uint64_t> ct = flat(std::vector<Felt>(coeffs.begin(), coeffs.begin() + nmask));
+    std::vector<uint64_t> cc = flat(std::vector<Felt>(coeffs.begin() + nmask, coeffs.end()));
+    auto deep = std::make_shared<DeviceBuffer>(ctx_, 32 * N);
+    ok(ss_deep_compose(ctx_, (const uint64_t *const *)lde_cols.data(), (uint32_t)lde_cols.size(), (const uint64_t *const *)comp_lde.cols.data(), ncomp,
+                       log_n, lb, g.data(), mask_col.data(), mask_off.data(), nmask, ood_t.data(), ct.data(), ood_c.data(), cc.data(),
+                       proof.z.data(), deep->u64()));
+
+    // 8. FRI
+    const uint32_t fold = opt_.fri_folding_factor, log_fold = log2u(fold);
+    struct Layer { std::unique_ptr<MerkleTree> tree; Matrix matrix; std::shared_ptr<DeviceBuffer> evals; };
+    std::vector<Layer> layers;
+    std::shared_ptr<DeviceBuffer> evals = deep;
+    uint32_t log_len = log_N;
+    Felt offset = g;
+    uint64_t degree_bound = n;
+    while (degree_bound > opt_.fri_max_remainder_coeffs) {
+        const uint64_t rows = 1ull << (log_len - log_fold);
+        Layer L;
+        L.evals = evals;
+        L.matrix.nrows = rows;
+        for (uint32_t k = 0; k < fold; ++k) L.matrix.cols.push_back(evals->u64() + 4 * rows * k);
+        L.tree = commit(L.matrix);
+        FriLayerProof lp;
+        lp.root = L.tree->root();
+        lp.log_len = log_len;
+        proof.fri_layers.push_back(lp);
+        coin.reseed_with_digest(digest_of(lp.root));
+        const Felt alpha = coin.draw();
+        proof.fri_alphas.push_back(alpha);
+        auto next = std::make_shared<DeviceBuffer>(ctx_, 32 * rows);
+        ok(ss_fri_fold(ctx_, evals->u64(), log_len, fold, alpha.data(), offset.data(), next->u64()));
+        layers.push_back(std::move(L));
+        evals = next;
+        log_len -= log_fold;
+        offset = felt_pow(offset, fold);
+        degree_bound /= fold;
+    }
+    {
+        uint64_t *e = evals->u64();
+        ok(ss_ntt_fp252(ctx_, &e, 1, log_len, SS_NTT_INVERSE, offset.data(), SS_ORDER_NATURAL, SS_ORDER_NATURAL));
+        std::vector<uint64_t> rem(4ull << log_len);
+        ok(ss_download(ctx_, rem.data(), e, rem.size() * 8));
+        const uint64_t keep = degree_bound ? degree_bound : 1;
+        for (uint64_t i = 4 * keep; i < rem.size(); ++i) if (rem[i]) throw std::runtime_error("FRI remainder exceeds its degree bound");
+        for (uint64_t i = 0; i < keep; ++i) { Felt f; memcpy(f.data(), rem.data() + 4 * i, 32); proof.fri_remainder.push_back(f); }
+        coin.reseed_with_field_element_vector(proof.fri_remainder);
+    }
+
+    // 9. proof of work, queries, openings
+    if (opt_.grinding_factor) ok(ss_pow_grind(ctx_, claim_.coin_kind, coin.digest().data(), opt_.grinding_factor, &proof.pow_nonce));
+    coin.reseed_with_int(proof.pow_nonce);
+    proof.query_positions = coin.draw_queries(opt_.num_queries, N);
+    const auto &pos = proof.query_positions;
+    proof.base_rows = gather(ctx_, base_lde.cols, pos);
+    proof.base_paths = base_tree->prove(pos);
+    if (ext_tree) { proof.extension_rows = gather(ctx_, ext_lde.cols, pos); proof.extension_paths = ext_tree->prove(pos); }
+    proof.composition_rows = gather(ctx_, comp_lde.cols, pos);
+    proof.composition_paths = comp_tree->prove(pos);
+    std::vector<uint64_t> p = pos;
+    for (size_t li = 0; li < layers.size(); ++li) {
+        const uint64_t rows = 1ull << (proof.fri_layers[li].log_len - log_fold);
+        std::set<uint64_t> s;
+        for (uint64_t q : p) s.insert(q % rows);
+        p.assign(s.begin(), s.end());
+        proof.fri_layers[li].positions = p;
+        proof.fri_layers[li].rows = gather(ctx_, layers[li].matrix.cols, p);
+        proof.fri_layers[li].paths = layers[li].tree->prove(p);
+    }
+    return proof;
+}
+
+// ------------------------------------------------------------------ serialisation
+// A flat little-endian dump for the Python tests (NOT the reference's ark-serialize wire
+// format — that is SURVEY §8f X2).
+namespace {
+struct W {
+    std::vector<uint8_t> b;
+    void u32(uint32_t v) { for (int i = 0; i < 4; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
+    void u64(uint64_t v) { for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
+    void raw(const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); }
+    void felts(const std::vector<Felt> &v) { u32((uint32_t)v.size()); for (auto &f : v) raw(f.data(), 32); }
+    void u64s(const std::vector<uint64_t> &v) { u32((uint32_t)v.size()); raw(v.data(), 8 * v.size()); }
+    void bytes(const std::vector<uint8_t> &v) { u32((uint32_t)v.size()); raw(v.data(), v.size()); }
+};
+}  // namespace
+std::vector<uint8_t> Proof::serialize() const {
+    W w;
+    w.u64(trace_len);
+    w.raw(base_root.data(), 33); w.u32(has_extension ? 1 : 0); w.raw(extension_root.data(), 33); w.raw(composition_root.data(), 33);
+    w.felts(challenges); w.raw(composition_coeff.data(), 32); w.raw(z.data(), 32); w.raw(deep_alpha.data(), 32);
+    w.felts(ood_trace); w.felts(ood_composition); w.felts(fri_alphas); w.felts(fri_remainder);
+    w.u64(pow_nonce); w.u64s(query_positions);
+    w.u64s(base_rows); w.u64s(extension_rows); w.u64s(composition_rows);
+    w.bytes(base_paths); w.bytes(extension_paths); w.bytes(composition_paths);
+    w.u32((uint32_t)fri_layers.size());
+    for (auto &l : fri_layers) { w.raw(l.root.data(), 33); w.u32(l.log_len); w.u64s(l.positions); w.u64s(l.rows); w.bytes(l.paths); }
+    return w.b;
+}
+
+}  // namespace ssh

@@ -1,0 +1,138 @@
+// prover.hpp — the proving pipeline above the C ABI, in C++ (the reference's host side is
+// compiled Rust: ministark `Stark::prove` as driven by src/lib.rs:75-125 and
+// cli/src/main.rs:180-213).  Pure sequencing: every arithmetic step on
+// proof data is a call into libsandstorm_hip.so.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/sandstorm_hip.h"
+#include "air_program.hpp"
+#include "coin.hpp"
+
+namespace ssh {
+
+struct ProofOptions {                   // cli/src/main.rs:51-60 defaults
+    uint32_t num_queries = 65;
+    uint32_t lde_blowup_factor = 2;
+    uint32_t grinding_factor = 16;
+    uint32_t fri_folding_factor = 8;
+    uint32_t fri_max_remainder_coeffs = 16;
+};
+
+struct Conventions {                    // ministark-internal, SURVEY.md Appendix A
+    uint64_t lde_offset = 3;            // M2
+    uint32_t composition_columns = 2;   // M5
+};
+
+// RAII device allocation (ss_dev_alloc / ss_dev_free)
+class DeviceBuffer {
+public:
+    DeviceBuffer(ss_ctx *ctx, size_t bytes);
+    ~DeviceBuffer();
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    uint64_t *u64() const { return (uint64_t *)ptr_; }
+    uint8_t *u8() const { return (uint8_t *)ptr_; }
+    size_t bytes() const { return bytes_; }
+private:
+    ss_ctx *ctx_;
+    void *ptr_ = nullptr;
+    size_t bytes_;
+};
+
+// Column-major matrix resident in HBM (ministark::Matrix<Fp>); columns may be borrowed.
+struct Matrix {
+    std::vector<uint64_t *> cols;
+    uint64_t nrows = 0;
+    std::vector<std::shared_ptr<DeviceBuffer>> owned;
+    static Matrix alloc(ss_ctx *ctx, uint32_t ncols, uint64_t nrows);
+    uint32_t num_cols() const { return (uint32_t)cols.size(); }
+};
+
+// MatrixMerkleTree::from_matrix / MerkleTree::{root, prove} (crypto/src/merkle/mod.rs:72-123, 258-304)
+class MerkleTree {
+public:
+    static std::unique_ptr<MerkleTree> from_matrix(ss_ctx *ctx, int tree_kind, uint32_t n_friendly, const Matrix &m);
+    const std::array<uint8_t, 33> &root() const { return root_; }
+    std::vector<uint8_t> prove(const std::vector<uint64_t> &idx) const;     // nidx * log2(n) * 32 bytes
+    uint64_t n() const { return n_; }
+private:
+    ss_ctx *ctx_ = nullptr;
+    int tree_kind_ = 0;
+    uint64_t n_ = 0;
+    std::unique_ptr<DeviceBuffer> nodes_, tags_, leaves_;
+    std::array<uint8_t, 33> root_{};
+};
+
+struct AirProgramData {
+    Program program;
+    const uint64_t *d_tables = nullptr;
+    std::vector<uint32_t> table_desc;
+};
+
+class Air {                              // what the prover needs from an AirConfig
+public:
+    virtual ~Air() = default;
+    std::string name;
+    uint32_t num_base_columns = 0, num_extension_columns = 0, num_challenges = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> mask;     // trace_arguments(): sorted (column, offset)
+    virtual AirProgramData build_program(uint64_t n, const std::vector<Felt> &challenges, const Felt &composition_coeff) = 0;
+};
+
+struct Claim {                           // src/claims.rs:12-33
+    Air *air = nullptr;
+    int tree_kind = SS_TREE_KECCAK_M20;
+    uint32_t n_friendly_layers = 0;      // 22 for the Cairo-verifier claims
+    int coin_kind = SS_COIN_SOLIDITY;
+};
+
+struct FriLayerProof {
+    std::array<uint8_t, 33> root{};
+    uint32_t log_len = 0;
+    std::vector<uint64_t> positions;
+    std::vector<uint64_t> rows;          // positions x fold felts
+    std::vector<uint8_t> paths;
+};
+
+struct Proof {
+    ProofOptions options;
+    uint64_t trace_len = 0;
+    std::array<uint8_t, 33> base_root{}, extension_root{}, composition_root{};
+    bool has_extension = false;
+    std::vector<Felt> challenges, ood_trace, ood_composition, fri_alphas, fri_remainder;
+    Felt composition_coeff{}, z{}, deep_alpha{};
+    std::vector<FriLayerProof> fri_layers;
+    uint64_t pow_nonce = 0;
+    std::vector<uint64_t> query_positions;
+    std::vector<uint64_t> base_rows, extension_rows, composition_rows;
+    std::vector<uint8_t> base_paths, extension_paths, composition_paths;
+    std::vector<uint8_t> serialize() const;
+};
+
+// build_extension_columns(&challenges) (layouts/src/recursive/trace.rs:699-814): returns the
+// extension columns, resident in HBM
+using ExtensionBuilder = std::function<Matrix(const std::vector<Felt> &challenges)>;
+
+class Prover {
+public:
+    Prover(ss_ctx *ctx, const Claim &claim, const ProofOptions &opt = ProofOptions(), const Conventions &conv = Conventions())
+        : ctx_(ctx), claim_(claim), opt_(opt), conv_(conv) {}
+    Proof prove(const Digest &coin_seed, const Matrix &base_trace, const ExtensionBuilder &build_extension);
+private:
+    ss_ctx *ctx_;
+    Claim claim_;
+    ProofOptions opt_;
+    Conventions conv_;
+};
+
+// built-in AIRs
+std::unique_ptr<Air> make_mini_air(ss_ctx *ctx);                                   // tests/mini_air.py
+std::unique_ptr<Air> make_synthetic_air(ss_ctx *ctx, const std::string &layout, uint32_t log_n, uint32_t log_blowup,
+                                        uint64_t lde_offset);                      // layout-shaped, for bench.py
+
+}  // namespace ssh

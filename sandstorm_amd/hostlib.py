@@ -1,0 +1,197 @@
+"""ctypes binding of libsandstorm_host.so — the C++ host side above the C ABI (coin,
+Expr lowering, prover; sandstorm_amd/host/).  The Python modules coin.py / air_program.py
+/ prover.py are the readable mirror used by the tests; bench.py drives the C++ one."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+from . import _lib, backend as be
+from .prover import FriLayer, Proof, ProofOptions
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libsandstorm_host.so")
+AIR_MINI, AIR_SYNTHETIC_RECURSIVE, AIR_SYNTHETIC_STARKNET = 0, 1, 2
+EXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p))
+
+_host = None
+
+
+def load():
+    global _host
+    if _host is None:
+        _lib.load()                                   # libsandstorm_hip.so first (RTLD_GLOBAL)
+        if not os.path.exists(LIB_PATH):
+            raise _lib.SandstormHipError("%s is missing: run __graft_entry__.build()" % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        h.ssh_last_error.restype = C.c_char_p
+        h.ssh_air_create.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        h.ssh_air_destroy.argtypes = [C.c_void_p]
+        h.ssh_air_columns.argtypes = [C.c_void_p, C.c_int]
+        h.ssh_air_columns.restype = C.c_uint32
+        h.ssh_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p, C.POINTER(C.c_void_p),
+                                C.c_uint32, C.c_uint32, EXT_CB, C.c_void_p, C.POINTER(C.c_uint32),
+                                C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
+        h.ssh_free.argtypes = [C.c_void_p]
+        h.ssh_coin_new.restype = C.c_void_p
+        h.ssh_coin_new.argtypes = [C.c_int, C.c_char_p]
+        h.ssh_coin_free.argtypes = [C.c_void_p]
+        h.ssh_coin_op.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint64,
+                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+        _host = h
+    return _host
+
+
+def _check(rc):
+    if rc != 0:
+        raise _lib.SandstormHipError("host: " + load().ssh_last_error().decode())
+
+
+class HostAir:
+    def __init__(self, ctx, kind, log_n, log_blowup=1):
+        self.ctx, self.h = ctx, C.c_void_p()
+        _check(load().ssh_air_create(ctx.handle, kind, log_n, log_blowup, C.byref(self.h)))
+        self.num_base_columns = load().ssh_air_columns(self.h, 0)
+        self.num_extension_columns = load().ssh_air_columns(self.h, 1)
+        self.mask_size = load().ssh_air_columns(self.h, 2)
+
+    def close(self):
+        if self.h:
+            load().ssh_air_destroy(self.h)
+            self.h = None
+
+
+class _Reader:
+    def __init__(self, b):
+        self.b, self.o = b, 0
+
+    def take(self, n):
+        v = self.b[self.o:self.o + n]
+        self.o += n
+        return v
+
+    def u32(self):
+        return struct.unpack("<I", self.take(4))[0]
+
+    def u64(self):
+        return struct.unpack("<Q", self.take(8))[0]
+
+    def felts(self):
+        n = self.u32()
+        return np.frombuffer(self.take(32 * n), dtype=np.uint64).reshape(n, 4).copy()
+
+    def u64s(self):
+        n = self.u32()
+        return np.frombuffer(self.take(8 * n), dtype=np.uint64).copy()
+
+    def bytes_(self):
+        return self.take(self.u32())
+
+
+def parse_proof(raw, options, ncols_base, ncols_ext, ncomp=2):
+    r = _Reader(raw)
+    p = Proof(options, r.u64())
+    p.base_root = bytes(r.take(33))[:32]
+    has_ext = r.u32()
+    ext = bytes(r.take(33))[:32]
+    p.extension_root = ext if has_ext else None
+    p.composition_root = bytes(r.take(33))[:32]
+    p.challenges = list(r.felts())
+    p.composition_coeff = np.frombuffer(r.take(32), dtype=np.uint64).copy()
+    p.z = np.frombuffer(r.take(32), dtype=np.uint64).copy()
+    p.deep_alpha = np.frombuffer(r.take(32), dtype=np.uint64).copy()
+    p.ood_trace, p.ood_composition = r.felts(), r.felts()
+    p.fri_alphas = list(r.felts())
+    p.fri_remainder = r.felts()
+    p.pow_nonce = r.u64()
+    p.query_positions = [int(q) for q in r.u64s()]
+    nq = len(p.query_positions)
+    log_N = (p.trace_len * options.lde_blowup_factor).bit_length() - 1
+    p.base_rows = r.u64s().reshape(nq, ncols_base, 4)
+    er = r.u64s()
+    p.extension_rows = er.reshape(nq, ncols_ext, 4) if len(er) else None
+    p.composition_rows = r.u64s().reshape(nq, ncomp, 4)
+    p.base_paths = np.frombuffer(r.bytes_(), dtype=np.uint8).reshape(nq, log_N, 32)
+    ep = r.bytes_()
+    p.extension_paths = np.frombuffer(ep, dtype=np.uint8).reshape(nq, log_N, 32) if len(ep) else None
+    p.composition_paths = np.frombuffer(r.bytes_(), dtype=np.uint8).reshape(nq, log_N, 32)
+    fold = options.fri_folding_factor
+    for _ in range(r.u32()):
+        root = bytes(r.take(33))
+        layer = FriLayer(root[:32], root[32], r.u32())
+        layer.positions = [int(q) for q in r.u64s()]
+        layer.rows = r.u64s().reshape(len(layer.positions), fold, 4)
+        rows_log = layer.log_len - (fold.bit_length() - 1)
+        layer.paths = np.frombuffer(r.bytes_(), dtype=np.uint8).reshape(len(layer.positions), rows_log, 32)
+        p.fri_layers.append(layer)
+    assert r.o == len(raw)
+    return p
+
+
+def prove(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, base_cols, log_n, build_extension, options=None,
+          want_proof=True):
+    """build_extension(challenges: list of uint64[4]) -> list of device columns (kept alive by the caller)"""
+    options = options or ProofOptions()
+    keep = []
+
+    def cb(_user, ch_ptr, nch, out_ptr):
+        try:
+            ch = [np.array([ch_ptr[4 * i + k] for k in range(4)], dtype=np.uint64) for i in range(nch)]
+            cols = build_extension(ch)
+            keep.append(cols)
+            for i, col in enumerate(cols):
+                out_ptr[i] = be._ptr_of(col)
+            return 0
+        except Exception:                       # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+    opts = (C.c_uint32 * 5)(options.num_queries, options.lde_blowup_factor, options.grinding_factor,
+                            options.fri_folding_factor, options.fri_max_remainder_coeffs)
+    out, n = C.POINTER(C.c_uint8)(), C.c_uint64()
+    _check(load().ssh_prove(ctx.handle, air.h, tree_kind, n_friendly, coin_kind, bytes(seed), be._ptr_array(base_cols),
+                            len(base_cols), log_n, EXT_CB(cb), None, opts,
+                            C.byref(out) if want_proof else None, C.byref(n) if want_proof else None))
+    if not want_proof:
+        return None
+    raw = bytes(C.cast(out, C.POINTER(C.c_uint8 * n.value)).contents)
+    load().ssh_free(out)
+    return parse_proof(raw, options, air.num_base_columns, air.num_extension_columns)
+
+
+class HostCoin:
+    """the C++ PublicCoin, for cross-checks against the oracle coin"""
+
+    def __init__(self, kind, seed):
+        self.c = load().ssh_coin_new(kind, bytes(seed))
+
+    def _op(self, op, data=b"", felts=None, arg=0, nout=4, length=None):
+        f = np.ascontiguousarray(felts, dtype=np.uint64) if felts is not None else np.zeros((1, 4), dtype=np.uint64)
+        out = np.zeros(max(8, nout), dtype=np.uint64)
+        cnt = C.c_uint32()
+        _check(load().ssh_coin_op(self.c, op, bytes(data), len(data) if length is None else length,
+                                  f.ctypes.data_as(C.POINTER(C.c_uint64)), 0 if felts is None else len(f), arg,
+                                  out.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(cnt)))
+        return out, cnt.value
+
+    def reseed_bytes(self, b): self._op(0, b)
+    def reseed_felts(self, v): self._op(1, felts=v)
+    def reseed_felt_vector(self, v): self._op(2, felts=v)
+    def reseed_int(self, v): self._op(3, arg=v)
+    def draw(self): return self._op(4)[0][:4].copy()
+
+    def draw_queries(self, max_n, domain):
+        out, n = self._op(5, arg=max_n, nout=max_n + 4, length=domain)
+        return [int(v) for v in out[:n]]
+
+    @property
+    def state(self):
+        out, _ = self._op(6, nout=8)
+        return out[:4].tobytes(), int(out[4])
+
+    def __del__(self):
+        try:
+            load().ssh_coin_free(self.c)
+        except Exception:
+            pass

@@ -44,21 +44,16 @@ def row_leaf(oracle, kind, row):
     return bytes(oracle.hash_rows(kind, [r[None, :] for r in row])[0])
 
 
-@pytest.mark.parametrize("flavour", ["eth", "cairo"])
-@pytest.mark.parametrize("log_n", [5, 9])
-def test_prove_and_verify_mini_air(ctx, oracle, flavour, log_n):
+def setup_case(ctx, oracle, flavour, log_n):
     from sandstorm_amd import backend as be
     from sandstorm_amd.coin import canonical
-    from sandstorm_amd.prover import Claim, ProofOptions, Prover
-    from sandstorm_amd import air_program as ap
-
+    from sandstorm_amd.prover import Claim, ProofOptions
     n = 1 << log_n
-    N = 2 * n
     air = mini_air.make_air(oracle.to_mont)
     if flavour == "eth":
-        claim, tree_kind, row_kind, coin_kind, nf = Claim(air, be.LeafVariantMerkleTree, be.COIN_SOLIDITY), 1, 1, 0, 0
+        claim, params = Claim(air, be.LeafVariantMerkleTree, be.COIN_SOLIDITY), (1, 1, 0, 0)
     else:
-        claim, tree_kind, row_kind, coin_kind, nf = Claim(air, be.FriendlyMerkleTree, be.COIN_CAIRO), 2, 3, 1, 22
+        claim, params = Claim(air, be.FriendlyMerkleTree, be.COIN_CAIRO), (2, 3, 1, 22)
     opt = ProofOptions(num_queries=12, grinding_factor=8, fri_max_remainder_coeffs=4)
     seed = bytes(range(32))
     c0, c1 = mini_air.base_trace(n)
@@ -67,9 +62,50 @@ def test_prove_and_verify_mini_air(ctx, oracle, flavour, log_n):
     def build_extension(challenges):
         e0 = mini_air.extension_trace(c0, canonical(challenges[0]))
         return be.Matrix.from_host(ctx, [oracle.to_mont(e0)])
+    return n, claim, params, opt, seed, base, build_extension
 
+
+@pytest.mark.parametrize("flavour", ["eth", "cairo"])
+@pytest.mark.parametrize("log_n", [5, 9])
+def test_prove_and_verify_mini_air(ctx, oracle, flavour, log_n):
+    from sandstorm_amd.prover import Prover
+    n, claim, params, opt, seed, base, build_extension = setup_case(ctx, oracle, flavour, log_n)
     proof = Prover(ctx, claim, opt).prove(seed, base, build_extension)
+    verify_mini_proof(oracle, proof, n, params, opt, seed)
 
+
+@pytest.mark.parametrize("flavour", ["eth", "cairo"])
+@pytest.mark.parametrize("log_n", [5, 10])
+def test_cpp_prover_matches_python_prover_and_verifies(ctx, oracle, flavour, log_n):
+    """The C++ host (libsandstorm_host.so: coin, Expr lowering, prover) drives the same
+    kernels: its proof must verify, and every transcript value must equal the Python mirror's."""
+    from sandstorm_amd import hostlib
+    from sandstorm_amd.prover import Prover
+    n, claim, params, opt, seed, base, build_extension = setup_case(ctx, oracle, flavour, log_n)
+    tree_kind, _, coin_kind, nf = params
+    air = hostlib.HostAir(ctx, hostlib.AIR_MINI, log_n)
+    proof = hostlib.prove(ctx, air, tree_kind, nf, coin_kind, seed, base.cols, log_n,
+                          lambda ch: build_extension(ch).cols, opt)
+    air.close()
+    verify_mini_proof(oracle, proof, n, params, opt, seed)
+    ref = Prover(ctx, claim, opt).prove(seed, base, build_extension)
+    assert proof.base_root == ref.base_root and proof.extension_root == ref.extension_root
+    assert proof.composition_root == ref.composition_root
+    assert np.array_equal(proof.z, ref.z) and np.array_equal(proof.ood_trace, ref.ood_trace)
+    assert np.array_equal(proof.ood_composition, ref.ood_composition)
+    assert [l.root for l in proof.fri_layers] == [l.root for l in ref.fri_layers]
+    assert np.array_equal(proof.fri_remainder, ref.fri_remainder)
+    assert proof.pow_nonce == ref.pow_nonce and proof.query_positions == ref.query_positions
+    assert np.array_equal(proof.base_rows, ref.base_rows) and np.array_equal(proof.base_paths, ref.base_paths)
+    for a, b in zip(proof.fri_layers, ref.fri_layers):
+        assert a.positions == b.positions and np.array_equal(a.rows, b.rows) and np.array_equal(a.paths, b.paths)
+
+
+def verify_mini_proof(oracle, proof, n, params, opt, seed):
+    """independent verifier: oracle coins + big integers"""
+    from sandstorm_amd import air_program as ap
+    tree_kind, row_kind, coin_kind, nf = params
+    N = 2 * n
     # ---- transcript replay with the ORACLE's coin
     coin = oracle.Coin(coin_kind, seed)
     coin.reseed_bytes(proof.base_root)
