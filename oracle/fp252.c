@@ -83,4 +83,5 @@ fp_t fp_from_be_bytes_reduce(const uint8_t in[32]) {
     return fp_from_canonical(c);
 }
 
-void or_init(void) { fp_init(); }
+void or_pedersen_init(void);
+void or_init(void) { fp_init(); or_pedersen_init(); }

@@ -27,6 +27,7 @@ void or_merkle_build(int tree, unsigned n_friendly_layers, int leaf_kind, const 
     while (((size_t)1 << log_n) < n) ++log_n;
     const int hk = tree == OR_TREE_KECCAK ? OR_HASH_KECCAK
                  : tree == OR_TREE_KECCAK_M20 ? OR_HASH_KECCAK_M20 : OR_HASH_BLAKE2S_M20;
+    or_pedersen_init();   /* before the OpenMP regions below */
     memset(nodes, 0, 64);
     if (tags) memset(tags, 0, 2 * n);
     /* leaf slots */

@@ -51,6 +51,7 @@ void or_hash_merge(int kind, const uint8_t a[32], const uint8_t b[32], uint8_t o
 void or_hash_rows(int kind, const fp_t *const *cols, size_t ncols, size_t nrows, uint8_t *out);
 
 /* ---- pedersen.c */
+void or_pedersen_init(void);
 fp_t or_pedersen_hash(fp_t a, fp_t b);
 /* PedersenHashFn::hash_elements chain (crypto/src/hash/pedersen.rs:65-76) */
 fp_t or_pedersen_hash_elements(const fp_t *e, size_t n);

@@ -87,6 +87,9 @@ static void ped_init(void) {
     ped_ready = 1;
 }
 
+/* must run once before any threaded use (the lazy init below is not thread-safe) */
+void or_pedersen_init(void) { ped_init(); }
+
 void or_pedersen_doublings(int k, size_t count, fp_t *xs, fp_t *ys) {
     ped_init();
     jac_t acc = jac_from_aff(PED_P[k]);

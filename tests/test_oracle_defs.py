@@ -177,3 +177,13 @@ def test_program_interpreter(oracle):
         x = 3 * pow(wN, i, P) % P
         a = ((v[0][i] * v[1][(i + 2) % N] - c0) * t[i % 4] + x) % P
         assert oracle.from_mont(out[i]) == (a - pow(a, -1, P)) % P
+
+
+def test_friendly_tree_large_threaded(oracle, pedersen):
+    """2048 leaves: the oracle's OpenMP paths (regression: Pedersen tables must be ready before them)"""
+    n = 2048
+    leaves = oracle.hash_rows(3, [random_column(n, 0), random_column(n, 1)])
+    nodes, tags = oracle.merkle_build(2, 22, 0, leaves)
+    for k in (n // 2, n // 2 + 1, n - 1, 1500):
+        a, b = bytes(nodes[2 * k]), bytes(nodes[2 * k + 1])
+        assert int.from_bytes(bytes(nodes[k]), "big") == pedersen(int.from_bytes(a, "big") % P, int.from_bytes(b, "big") % P)
