@@ -77,8 +77,13 @@ ss_status ss_ctx_create(int device, ss_ctx **out);
 void ss_ctx_destroy(ss_ctx *ctx);
 ss_status ss_ctx_set_stream(ss_ctx *ctx, void *hip_stream); /* NULL = ctx-owned stream */
 ss_status ss_ctx_sync(ss_ctx *ctx);
+/* ss_dev_alloc/ss_dev_free are pooled (the role of GpuAllocator / PageAlignedAllocator,
+ * src/lib.rs:27-28): a freed block is kept for reuse by later allocations of a similar size
+ * on the same context, so steady-state proving makes no hipMalloc/hipFree calls.
+ * ss_ctx_trim returns the cached blocks to the driver. */
 ss_status ss_dev_alloc(ss_ctx *ctx, size_t bytes, void **d_out);
 ss_status ss_dev_free(ss_ctx *ctx, void *d_ptr);
+ss_status ss_ctx_trim(ss_ctx *ctx);
 ss_status ss_upload(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 ss_status ss_download(ss_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 

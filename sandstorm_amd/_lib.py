@@ -41,6 +41,7 @@ SIGNATURES = {
     "ss_ctx_sync": (C.c_int, [C.c_void_p]),
     "ss_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, _vpp]),
     "ss_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ss_ctx_trim": (C.c_int, [C.c_void_p]),
     "ss_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ss_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ss_ntt_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_int, _u64p, C.c_int, C.c_int]),

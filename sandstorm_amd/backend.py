@@ -136,6 +136,10 @@ class Context:
     def sync(self):
         check(self.lib.ss_ctx_sync(self.handle))
 
+    def trim(self):
+        """Return the blocks cached by the ss_dev_alloc pool to the driver."""
+        check(self.lib.ss_ctx_trim(self.handle))
+
     def close(self):
         if self.handle:
             self.lib.ss_ctx_destroy(self.handle)

@@ -76,6 +76,19 @@ struct ss_ctx {
     void *scratch = nullptr;                // grow-only device scratch
     size_t scratch_bytes = 0;
     uint64_t *d_small = nullptr;            // 64 x u64: PoW prefix/best etc.
+    // Device-memory pool behind ss_dev_alloc/ss_dev_free.  A proof allocates and releases the
+    // same multi-GiB LDE matrices every time; hipMalloc/hipFree of blocks that size costs
+    // hundreds of ms (map/unmap) and hipFree synchronises the device.  Freed blocks are kept
+    // (stream-ordered reuse is safe: one stream per context) up to pool_cap bytes.
+    std::multimap<size_t, void *> pool_free;          // block size -> pointer
+    std::map<void *, size_t> pool_live;               // handed-out pointer -> block size
+    size_t pool_cached = 0, pool_cap = (size_t)96 << 30;
+    void pool_trim() {
+        for (auto &kv : pool_free) (void)hipFree(kv.second);
+        pool_free.clear();
+        pool_cached = 0;
+    }
+
     bool prof_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[SS_PROF_KINDS];
     double prof_ms[SS_PROF_KINDS] = {0};
@@ -277,6 +290,8 @@ void ss_ctx_destroy(ss_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->plans) hipFree(kv.second);
+    ctx->pool_trim();
+    for (auto &kv : ctx->pool_live) hipFree(kv.first);     // leaked by the caller
     pedersen_tables_destroy(ctx->ped);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->scratch2) hipFree(ctx->scratch2);
@@ -300,12 +315,47 @@ ss_status ss_ctx_sync(ss_ctx *ctx) {
 ss_status ss_dev_alloc(ss_ctx *ctx, size_t bytes, void **d_out) {
     if (!ctx || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMalloc(d_out, bytes ? bytes : 1));
+    const size_t want = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
+    // best fit among cached blocks, wasting at most a quarter of the block
+    auto it = ctx->pool_free.lower_bound(want);
+    if (it != ctx->pool_free.end() && it->first - want <= it->first / 4) {
+        *d_out = it->second;
+        ctx->pool_live[it->second] = it->first;
+        ctx->pool_cached -= it->first;
+        ctx->pool_free.erase(it);
+        return SS_OK;
+    }
+    hipError_t e = hipMalloc(d_out, want);
+    if (e == hipErrorOutOfMemory && !ctx->pool_free.empty()) {     // give the cache back and retry
+        (void)hipGetLastError();
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->pool_trim();
+        e = hipMalloc(d_out, want);
+    }
+    HIP_TRY(e);
+    ctx->pool_live[*d_out] = want;
     return SS_OK;
 }
 ss_status ss_dev_free(ss_ctx *ctx, void *d_ptr) {
     if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
-    if (d_ptr) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(d_ptr)); }
+    if (!d_ptr) return SS_OK;
+    auto it = ctx->pool_live.find(d_ptr);
+    if (it == ctx->pool_live.end()) return fail(SS_ERR_INVALID, "ss_dev_free: pointer was not returned by ss_dev_alloc");
+    const size_t sz = it->second;
+    ctx->pool_live.erase(it);
+    if (ctx->pool_cached + sz > ctx->pool_cap) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(d_ptr));
+        return SS_OK;
+    }
+    ctx->pool_free.emplace(sz, d_ptr);
+    ctx->pool_cached += sz;
+    return SS_OK;
+}
+ss_status ss_ctx_trim(ss_ctx *ctx) {
+    if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->pool_trim();
     return SS_OK;
 }
 ss_status ss_upload(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes) {

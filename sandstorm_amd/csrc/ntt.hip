@@ -33,22 +33,41 @@
 namespace ss {
 
 static constexpr int LOG_TILE_MAX = 11;          // 2048 elements
-static constexpr int NTT_THREADS = 256;
+#ifndef SS_NTT_GMAX
+#define SS_NTT_GMAX 2
+#endif
+#ifndef SS_NTT_THREADS
+#define SS_NTT_THREADS 512
+#endif
+#ifndef SS_NTT_OCC
+#define SS_NTT_OCC (SS_NTT_THREADS / 128)
+#endif
+static constexpr int NTT_THREADS = SS_NTT_THREADS;   // 2 workgroups of 512 per CU: 4 waves per SIMD
+static constexpr int NTT_GMAX = SS_NTT_GMAX;         // stages per register group (radix 2^GMAX)
 
 __device__ __forceinline__ int lds_slot(int e) { return e + (e >> 3); }
 
-__device__ __forceinline__ Fp lds_load(const uint4 *lo, const uint4 *hi, int e) {
-    int s = lds_slot(e);
-    uint4 a = lo[s], b = hi[s];
-    Fp r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+// LDS tile in the lazy form: limbs 0-3 and 4-7 in two 16-byte planes (one pad slot per 8:
+// conflict-free ds_read_b128 for the stride-1/8/64 patterns of the radix-8 groups), limb 8
+// in a dword plane.  2048 elements = 80 KiB: two workgroups per CU.
+struct Tile {
+    uint4 *lo, *hi;
+    u32 *top;
+};
+__device__ __forceinline__ Fl lds_load(const Tile &t, int e) {
+    const int s = lds_slot(e);
+    const uint4 a = t.lo[s], b = t.hi[s];
+    Fl r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = t.top[e];
     return r;
 }
-__device__ __forceinline__ void lds_store(uint4 *lo, uint4 *hi, int e, const Fp &x) {
-    int s = lds_slot(e);
-    lo[s] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    hi[s] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+__device__ __forceinline__ void lds_store(const Tile &t, int e, const Fl &x) {
+    const int s = lds_slot(e);
+    t.lo[s] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+    t.hi[s] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    t.top[e] = x.l[8];
 }
 __device__ __forceinline__ Fp gload(const Fp *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
@@ -110,11 +129,22 @@ __device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const Fp *__restric
     }
 }
 
-// One radix-2^G register group on local stages [u, u+G).
+// global element index of tile-local element e (see the kernel's load phase)
+__device__ __forceinline__ uint64_t tile_gindex(const PassParams &p, uint32_t tile, uint32_t e) {
+    if (p.contig) return ((uint64_t)tile << p.log_tile) + e;
+    const uint32_t log_t = p.log_tile - p.r;
+    const uint32_t dq = e & ((1u << log_t) - 1u), j = e >> log_t;
+    const uint64_t q = ((uint64_t)tile << log_t) + dq;
+    return ((q >> p.s0) << (p.s0 + p.r)) | ((uint64_t)j << p.s0) | (q & ((1ull << p.s0) - 1ull));
+}
+
+// One radix-2^G register group on local stages [u, u+G).  from_global / to_global fuse the
+// pass's HBM traffic into its first / last group (strided passes: lane <-> adjacent element, so
+// the accesses stay coalesced), saving two LDS round trips and two barriers per pass.
 template <bool DIF, int G>
-__device__ __forceinline__ void radix_group(uint4 *lo, uint4 *hi, const Fp *__restrict__ tw,
-                                            const PassParams &p, uint32_t u, uint32_t tile,
-                                            bool last_group) {
+__device__ __forceinline__ void radix_group(const Tile &t, const Fp *__restrict__ tw, const PassParams &p, uint32_t u,
+                                            uint32_t tile, bool last_group, bool from_global, bool to_global,
+                                            const Fp *__restrict__ src, Fp *__restrict__ dst) {
     const uint32_t log_t = p.log_tile - p.r;            // log2(T)
     const uint32_t eshift = p.contig ? 0u : log_t;
     const uint32_t items = (1u << p.log_tile) >> G;
@@ -134,10 +164,13 @@ __device__ __forceinline__ void radix_group(uint4 *lo, uint4 *hi, const Fp *__re
             lbits = q & ((1u << p.s0) - 1u);
         }
         const uint32_t jlow = jbase & ((1u << u) - 1u);
-        // LDS holds 256-bit images of weakly reduced values (< 2^252): unpacking is pure bit slicing
         Fl x[1 << G];
 #pragma unroll
-        for (int m = 0; m < (1 << G); ++m) x[m] = fl_from_fp(lds_load(lo, hi, ebase + ((uint32_t)m << sh)));
+        for (int m = 0; m < (1 << G); ++m) {
+            const uint32_t e = ebase + ((uint32_t)m << sh);
+            if (from_global) x[m] = fl_from_fp(gload(src + (tile_gindex(p, tile, e) >> p.log_expand)));
+            else x[m] = lds_load(t, e);
+        }
         if (DIF) {
             if (G >= 3) radix_stage<DIF, G, 2>(x, tw, p, u, jlow, lbits);
             if (G >= 2) radix_stage<DIF, G, 1>(x, tw, p, u, jlow, lbits);
@@ -149,25 +182,34 @@ __device__ __forceinline__ void radix_group(uint4 *lo, uint4 *hi, const Fp *__re
         }
 #pragma unroll
         for (int m = 0; m < (1 << G); ++m) {
-            Fp out;
-            if (last_group) {                              // leaving the pass: canonical image (< p)
-                out = fl_to_fp(x[m]);
+            const uint32_t e = ebase + ((uint32_t)m << sh);
+            if (to_global) {                               // leaving the pass: canonical image (< p)
+                Fp out = fl_to_fp(x[m]);
                 if (DIF && p.scale_pow2) out = fp_div_pow2(out, p.scale_pow2);
+                gstore(dst + tile_gindex(p, tile, e), out);
             } else {
-                out = fl_pack(fl_weak_reduce(x[m]));
+                lds_store(t, e, fl_weak_reduce(x[m]));     // < 2^252, limbs < 2^28
             }
-            lds_store(lo, hi, ebase + ((uint32_t)m << sh), out);
         }
     }
 }
 
+template <bool DIF, int G>
+__device__ __forceinline__ void run_group(const Tile &t, const Fp *tw, const PassParams &p, uint32_t u, uint32_t tile,
+                                          bool last, bool fg, bool tg, const Fp *src, Fp *dst) {
+    radix_group<DIF, G>(t, tw, p, u, tile, last, fg, tg, src, dst);
+}
+
 template <bool DIF>
-__global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw,
+__global__ __launch_bounds__(NTT_THREADS, SS_NTT_OCC) void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw,
                                                                PassParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tile_elems = 1u << p.log_tile;
-    uint4 *lo = reinterpret_cast<uint4 *>(smem);
-    uint4 *hi = lo + (tile_elems + (tile_elems >> 3));
+    const uint32_t slots = tile_elems + (tile_elems >> 3);
+    Tile t;
+    t.lo = reinterpret_cast<uint4 *>(smem);
+    t.hi = t.lo + slots;
+    t.top = reinterpret_cast<u32 *>(t.hi + slots);
     const uint32_t tile = blockIdx.x;
     // select this block's column with scalar compares: a dynamically indexed by-value
     // kernarg struct would be copied to scratch
@@ -178,58 +220,52 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void ntt_pass_kernel(ColPtrs cols, 
         if (blockIdx.y == (unsigned)c) { src_v = cols.src[c]; dst_v = cols.dst[c]; }
     const Fp *__restrict__ src = reinterpret_cast<const Fp *>(src_v);
     Fp *__restrict__ dst = reinterpret_cast<Fp *>(dst_v);
-    const uint32_t log_t = p.log_tile - p.r;
 
-    // ---- global -> LDS (coalesced: consecutive lanes, consecutive addresses)
-    for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x) {
-        uint64_t gi;
-        if (p.contig) {
-            gi = ((uint64_t)tile << p.log_tile) + x;
-        } else {
-            const uint32_t dq = x & ((1u << log_t) - 1u), j = x >> log_t;
-            const uint64_t q = ((uint64_t)tile << log_t) + dq;
-            gi = ((q >> p.s0) << (p.s0 + p.r)) | ((uint64_t)j << p.s0) | (q & ((1ull << p.s0) - 1ull));
-        }
-        lds_store(lo, hi, x, gload(src + (gi >> p.log_expand)));
+    // Strided passes read/write HBM from the first/last register group directly; the
+    // contiguous pass (tile = one 64 KiB block, first group of stride 1) stages through LDS.
+    const bool fuse = !p.contig;
+    if (!fuse) {
+        for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x)
+            lds_store(t, x, fl_from_fp(gload(src + (tile_gindex(p, tile, x) >> p.log_expand))));
+        __syncthreads();
     }
-    __syncthreads();
 
-    // ---- stages, 3 per LDS round trip
     if (!DIF) {
         uint32_t u = p.u_first;
+        bool first = true;
         while (u < p.r) {
-            const uint32_t g = (p.r - u) >= 3 ? 3 : (p.r - u);
+            const uint32_t g = (p.r - u) >= (uint32_t)NTT_GMAX ? (uint32_t)NTT_GMAX : (p.r - u);
             const bool last = (u + g >= p.r);
-            if (g == 3) radix_group<false, 3>(lo, hi, tw, p, u, tile, last);
-            else if (g == 2) radix_group<false, 2>(lo, hi, tw, p, u, tile, last);
-            else radix_group<false, 1>(lo, hi, tw, p, u, tile, last);
+            const bool fg = fuse && first, tg = fuse && last;
+            if (NTT_GMAX >= 3 && g == 3) run_group<false, NTT_GMAX >= 3 ? 3 : 1>(t, tw, p, u, tile, last, fg, tg, src, dst);
+            else if (g == 2) run_group<false, 2>(t, tw, p, u, tile, last, fg, tg, src, dst);
+            else run_group<false, 1>(t, tw, p, u, tile, last, fg, tg, src, dst);
             u += g;
-            __syncthreads();
+            first = false;
+            if (!last || !fuse) __syncthreads();
         }
     } else {
         uint32_t u = p.r;
+        bool first = true;
         while (u > 0) {
-            const uint32_t g = u >= 3 ? 3 : u;
+            const uint32_t g = u >= (uint32_t)NTT_GMAX ? (uint32_t)NTT_GMAX : u;
             u -= g;
             const bool last = (u == 0);
-            if (g == 3) radix_group<true, 3>(lo, hi, tw, p, u, tile, last);
-            else if (g == 2) radix_group<true, 2>(lo, hi, tw, p, u, tile, last);
-            else radix_group<true, 1>(lo, hi, tw, p, u, tile, last);
-            __syncthreads();
+            const bool fg = fuse && first, tg = fuse && last;
+            if (NTT_GMAX >= 3 && g == 3) run_group<true, NTT_GMAX >= 3 ? 3 : 1>(t, tw, p, u, tile, last, fg, tg, src, dst);
+            else if (g == 2) run_group<true, 2>(t, tw, p, u, tile, last, fg, tg, src, dst);
+            else run_group<true, 1>(t, tw, p, u, tile, last, fg, tg, src, dst);
+            first = false;
+            if (!last || !fuse) __syncthreads();
         }
     }
 
-    // ---- LDS -> global
-    for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x) {
-        uint64_t gi;
-        if (p.contig) {
-            gi = ((uint64_t)tile << p.log_tile) + x;
-        } else {
-            const uint32_t dq = x & ((1u << log_t) - 1u), j = x >> log_t;
-            const uint64_t q = ((uint64_t)tile << log_t) + dq;
-            gi = ((q >> p.s0) << (p.s0 + p.r)) | ((uint64_t)j << p.s0) | (q & ((1ull << p.s0) - 1ull));
+    if (!fuse) {
+        for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x) {
+            Fp out = fl_to_fp(lds_load(t, x));
+            if (DIF && p.scale_pow2) out = fp_div_pow2(out, p.scale_pow2);
+            gstore(dst + tile_gindex(p, tile, x), out);
         }
-        gstore(dst + gi, lds_load(lo, hi, x));
     }
 }
 
@@ -280,7 +316,7 @@ __global__ void mul_bench_kernel(const Fp *__restrict__ a, const Fp *__restrict_
 // ------------------------------------------------------------ host launch
 static inline size_t pass_lds_bytes(uint32_t log_tile) {
     size_t e = (size_t)1 << log_tile;
-    return 2 * (e + (e >> 3)) * sizeof(uint4);
+    return 2 * (e + (e >> 3)) * sizeof(uint4) + e * sizeof(u32);
 }
 
 hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32_t ncols, const Fp *tw,

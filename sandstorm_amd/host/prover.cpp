@@ -1,6 +1,9 @@
 #include "prover.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <stdexcept>
@@ -77,6 +80,16 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     Proof proof;
     proof.options = opt_;
     proof.trace_len = n;
+    // SSH_TIMING=1: wall clock per stage (with a device sync at each boundary) on stderr
+    const bool timing = getenv("SSH_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *stage) {
+        if (!timing) return;
+        ss_ctx_sync(ctx_);
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ssh timing] %-28s %9.3f ms\n", stage, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     auto commit = [&](const Matrix &m) { return MerkleTree::from_matrix(ctx_, claim_.tree_kind, claim_.n_friendly_layers, m); };
     auto digest_of = [](const std::array<uint8_t, 33> &r) { Digest d; memcpy(d.data(), r.data(), 32); return d; };
 
@@ -84,7 +97,9 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     Matrix base_lde = Matrix::alloc(ctx_, base_trace.num_cols(), N), base_co = Matrix::alloc(ctx_, base_trace.num_cols(), n);
     ok(ss_lde_fp252(ctx_, (const uint64_t *const *)base_trace.cols.data(), base_trace.num_cols(), log_n, lb, g.data(),
                     base_lde.cols.data(), base_co.cols.data()));
+    mark("base lde");
     auto base_tree = commit(base_lde);
+    mark("base commit");
     proof.base_root = base_tree->root();
     coin.reseed_with_digest(digest_of(proof.base_root));
 
@@ -99,7 +114,9 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
         ext_co = Matrix::alloc(ctx_, ext.num_cols(), n);
         ok(ss_lde_fp252(ctx_, (const uint64_t *const *)ext.cols.data(), ext.num_cols(), log_n, lb, g.data(), ext_lde.cols.data(),
                         ext_co.cols.data()));
+        mark("extension lde");
         ext_tree = commit(ext_lde);
+        mark("extension commit");
         proof.has_extension = true;
         proof.extension_root = ext_tree->root();
         coin.reseed_with_digest(digest_of(proof.extension_root));
@@ -117,8 +134,10 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     prog.consts = consts.data(); prog.n_consts = (uint32_t)pd.program.consts.size();
     prog.d_tables = pd.d_tables; prog.table_desc = pd.table_desc.data(); prog.n_tables = (uint32_t)(pd.table_desc.size() / 2);
     prog.n_slots = pd.program.n_slots;
+    mark("program build");
     DeviceBuffer comp_evals(ctx_, 32 * N);
     ok(ss_eval_quotient(ctx_, &prog, (const uint64_t *const *)lde_cols.data(), (uint32_t)lde_cols.size(), log_n, lb, g.data(), comp_evals.u64()));
+    mark("quotient");
     uint64_t *ce = comp_evals.u64();
     ok(ss_ntt_fp252(ctx_, &ce, 1, log_N, SS_NTT_INVERSE, g.data(), SS_ORDER_NATURAL, SS_ORDER_BITREV));
     const uint32_t ncomp = conv_.composition_columns;
@@ -127,7 +146,9 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     for (uint32_t k = 0; k < ncomp; ++k) comp_coeffs.push_back(ce + 4 * n * k);
     Matrix comp_lde = Matrix::alloc(ctx_, ncomp, N);
     ok(ss_evaluate_fp252(ctx_, (const uint64_t *const *)comp_coeffs.data(), ncomp, log_n, lb, g.data(), comp_lde.cols.data()));
+    mark("composition lde");
     auto comp_tree = commit(comp_lde);
+    mark("composition commit");
     proof.composition_root = comp_tree->root();
     coin.reseed_with_digest(digest_of(proof.composition_root));
 
@@ -149,6 +170,7 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
         coin.reseed_with_field_elements(all);
     }
 
+    mark("ood");
     // 7. DEEP composition: coefficients are powers of one alpha (src/lib.rs:102-116)
     proof.deep_alpha = coin.draw();
     std::vector<Felt> coeffs;
@@ -161,6 +183,7 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
                        log_n, lb, g.data(), mask_col.data(), mask_off.data(), nmask, ood_t.data(), ct.data(), ood_c.data(), cc.data(),
                        proof.z.data(), deep->u64()));
 
+    mark("deep");
     // 8. FRI
     const uint32_t fold = opt_.fri_folding_factor, log_fold = log2u(fold);
     struct Layer { std::unique_ptr<MerkleTree> tree; Matrix matrix; std::shared_ptr<DeviceBuffer> evals; };
@@ -202,6 +225,7 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
         coin.reseed_with_field_element_vector(proof.fri_remainder);
     }
 
+    mark("fri");
     // 9. proof of work, queries, openings
     if (opt_.grinding_factor) ok(ss_pow_grind(ctx_, claim_.coin_kind, coin.digest().data(), opt_.grinding_factor, &proof.pow_nonce));
     coin.reseed_with_int(proof.pow_nonce);
@@ -222,6 +246,7 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
         proof.fri_layers[li].rows = gather(ctx_, layers[li].matrix.cols, p);
         proof.fri_layers[li].paths = layers[li].tree->prove(p);
     }
+    mark("pow + openings");
     return proof;
 }
 

@@ -392,3 +392,29 @@ def test_eval_quotient_vs_oracle(ctx, be, oracle, seed, size, log_n):
     want = oracle.eval_program(prog.code, oracle.to_mont(prog.consts), tables, desc, prog.n_slots, ev.to_host(),
                                log_n, lb, g)
     assert np.array_equal(got, want)
+
+
+# ----------------------------------------------------------------------------- memory pool
+def test_dev_pool_reuse_and_trim(ctx):
+    """ss_dev_alloc/ss_dev_free are pooled: a freed block is handed out again for a request of
+    similar size, data written through a recycled block is intact, and trim empties the cache."""
+    a = ctx.alloc(1 << 20)
+    pa = a.ptr
+    a.upload(np.arange(1 << 17, dtype=np.uint64))
+    a.free()
+    b = ctx.alloc((1 << 20) - 4096)           # within the 25 % slack: same block
+    assert b.ptr == pa
+    src = np.arange(7, 7 + (1 << 17) - 512, dtype=np.uint64)
+    b.upload(src)
+    assert np.array_equal(b.download(np.uint64, src.shape), src)
+    c = ctx.alloc(1 << 10)                    # far smaller: must not take a 1 MiB block
+    assert c.ptr != pa
+    b.free(); c.free()
+    ctx.trim()
+    d = ctx.alloc(1 << 20)
+    d.free()
+    # freeing a pointer the pool does not own is an error, not a crash
+    import ctypes as C
+    from sandstorm_amd._lib import SandstormHipError, check
+    with pytest.raises(SandstormHipError):
+        check(ctx.lib.ss_dev_free(ctx.handle, C.c_void_p(0x1000)))
