@@ -932,7 +932,7 @@ ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64
     const uint64_t N = 1ull << log_N;
     uint64_t lanes = 256ull * 256 * 4;                 // 4 workgroups of 256 per CU
     if (lanes > N) lanes = N < 256 ? 256 : N;
-    const size_t code_b = (size_t)prog->n_instr * 8, const_b = (size_t)(prog->n_consts ? prog->n_consts : 1) * 32;
+    const size_t code_b = ((size_t)prog->n_instr + 1) * 16, const_b = (size_t)(prog->n_consts ? prog->n_consts : 1) * 32;
     const size_t desc_b = (size_t)(prog->n_tables ? prog->n_tables : 1) * 8;
     const size_t slots_b = (size_t)(prog->n_slots ? prog->n_slots : 1) * lanes * 32;
     ss_status st = ctx->ensure_scratch(slots_b + const_b + code_b + desc_b + 256);
@@ -943,7 +943,9 @@ ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64
     uint32_t *d_code = (uint32_t *)p; p += code_b;
     uint32_t *d_desc = (uint32_t *)p;
     hipStream_t s = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(d_code, prog->code, code_b, hipMemcpyHostToDevice, s));
+    std::vector<uint32_t> dev_code(((size_t)prog->n_instr + 1) * 4);
+    quotient_build_device_code(prog->code, prog->n_instr, dev_code.data());
+    HIP_TRY(hipMemcpyAsync(d_code, dev_code.data(), code_b, hipMemcpyHostToDevice, s));
     if (prog->n_consts) HIP_TRY(hipMemcpyAsync(d_consts, prog->consts, (size_t)prog->n_consts * 32, hipMemcpyHostToDevice, s));
     if (prog->n_tables) HIP_TRY(hipMemcpyAsync(d_desc, prog->table_desc, (size_t)prog->n_tables * 8, hipMemcpyHostToDevice, s));
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();

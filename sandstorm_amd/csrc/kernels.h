@@ -79,6 +79,8 @@ hipError_t launch_gather_cells(hipStream_t st, const void *const *cols, uint32_t
                                const uint64_t *idx, uint32_t n, Fp *out);
 
 // ---- quotient.hip
+// caller's 2-word program -> (n_instr + 1) x 4-word device stream with operand prefetch hints
+void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, uint32_t *dev);
 hipError_t launch_quotient_vm(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *d_code,
                               uint32_t n_instr, const Fp *d_consts, const Fp *d_tables, const uint32_t *d_table_desc,
                               Fp *d_slots, uint64_t lanes, const Fp &offset, const Fp &w, const Fp &wstep,

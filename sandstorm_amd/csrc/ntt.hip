@@ -115,14 +115,26 @@ __device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const Fp *__restric
     for (int pr = 0; pr < (1 << G) / 2; ++pr) {
         const int m = ((pr >> STC) << (STC + 1)) | (pr & ((1 << STC) - 1));
         const uint32_t k = ((jlow + ((uint32_t)(m & ((1 << STC) - 1)) << u)) << p.s0) | lbits;
+#ifdef SS_NTT_ABL_NOTW      // timing ablation only (wrong results): no twiddle loads
+        Fl t = x[m]; t.l[0] += k;
+#else
         const Fl t = fl_from_fp(gload(tws + k));
+#endif
         const Fl a = x[m], b = x[m | (1 << STC)];
         if (DIF) {
             x[m] = fl_add(a, b);
             const Fl d = ORD == 0 ? fl_sub_c<2, 1>(a, b) : ORD == 1 ? fl_sub_c<8, 2>(a, b) : fl_sub_c<16, 4>(a, b);
+#ifdef SS_NTT_ABL_NOMUL     // timing ablation only: no modular multiplication
+            x[m | (1 << STC)] = fl_add(d, t);
+#else
             x[m | (1 << STC)] = fl_mul(d, t);
+#endif
         } else {
+#ifdef SS_NTT_ABL_NOMUL
+            const Fl bt = fl_add(b, t);
+#else
             const Fl bt = fl_mul(b, t);
+#endif
             x[m] = fl_add(a, bt);
             x[m | (1 << STC)] = fl_sub_c<2, 1>(a, bt);
         }

@@ -89,6 +89,32 @@ __device__ __forceinline__ void vm_exec(uint32_t op, Fl &v, uint32_t &vb, Fl src
     }
 }
 
+// Device instruction stream (built by ss_eval_quotient from the caller's 2-word program):
+// 4 words per entry  { w0 | pk << 16,  w1,  pw,  0 },  entry 0 is a no-op that primes the pipeline.
+// (pk, pw) names the memory operand (kind, payload) that THIS entry starts loading: the operand
+// of the next memory-consuming instruction, so that its L2/HBM round trip overlaps this
+// instruction's arithmetic.  Measured (profiles/r01_quotient_vm_experiments.txt): the kernel is
+// VALU-bound (295 k VALU instructions per 64-point wave-row), so one operand of lead is all
+// that pays; a deeper LDS-DMA operand ring (2 to 8 operands in flight) gave nothing more.
+static constexpr uint32_t VM_PK_NONE = 0xfu;
+static constexpr uint32_t VM_OP_NOP = 0xffu;
+
+__device__ __forceinline__ const Fp *vm_operand_ptr(const VmArgs &a, uint32_t kind, uint32_t w, uint64_t N,
+                                                    uint64_t lanes, uint64_t lane, uint64_t i) {
+    if (kind == SS_SRC_SLOT) return a.slots + (uint64_t)w * lanes + lane;
+    if (kind == SS_SRC_CONST) return a.consts + w;
+    if (kind == SS_SRC_TRACE) {
+        const uint32_t col = w >> 24;
+        const uint64_t row = (i + ((uint64_t)(w & 0xffffffu) << a.log_blowup)) & (N - 1);
+        const Fp *cp = a.cols[0];
+#pragma unroll
+        for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) cp = a.cols[c];
+        return cp + row;
+    }
+    const uint32_t off = a.table_desc[2 * w], ll = a.table_desc[2 * w + 1];
+    return a.tables + off + (i & ((1ull << ll) - 1ull));
+}
+
 __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
     const uint64_t N = 1ull << a.log_N;
     const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;
@@ -108,16 +134,26 @@ __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
     }
     Fl x = fl_from_fp(fp_mul(a.offset, fp_pow_u64(a.w, i0)));
     const Fl wstep = fl_from_fp(a.wstep);                                          // w^stride
+    const uint4 *code = reinterpret_cast<const uint4 *>(a.code);
     for (uint64_t it = 0; it < count; ++it) {
         const uint64_t i = i0 + it * stride;
         Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
         uint32_t bnd0 = 1, bnd1 = 1, bnd2 = 1, bnd3 = 1;
+        Fp pre = fp_zero();                                // the operand in flight
         for (uint32_t pc = 0; pc < a.n_instr; ++pc) {
-            const uint32_t w0 = a.code[2 * pc], w1 = a.code[2 * pc + 1];
-            const uint32_t op = w0 & 0xffu, d = (w0 >> 8) & 0xfu, kind = (w0 >> 12) & 0xfu;
+            const uint4 ins = code[pc];
+            const uint32_t w0 = ins.x, w1 = ins.y, pw = ins.z;
+            const uint32_t op = w0 & 0xffu, d = (w0 >> 8) & 0xfu, kind = (w0 >> 12) & 0xfu, pk = (w0 >> 16) & 0xfu;
+            const bool mem = op <= SS_OP_MUL && kind >= SS_SRC_SLOT && kind <= SS_SRC_TABLE;
+            const Fp cur = pre;
+            // start the next operand before this instruction's arithmetic; after an ST only once
+            // the store has been issued (the operand may be the slot just written)
+            if (pk != VM_PK_NONE && op != SS_OP_ST) pre = qload(vm_operand_ptr(a, pk, pw, N, lanes, lane, i));
             Fl src = fl_zero();
             uint32_t sb = 1;                               // bound of src
-            if (op <= SS_OP_MUL) {
+            if (mem) {
+                src = fl_from_fp(cur);                     // canonical or weakly reduced 256-bit image
+            } else if (op <= SS_OP_MUL) {
                 if (kind == SS_SRC_ACC) {
                     switch (w1 & 3u) {
                     case 0: src = acc0; sb = bnd0; break;
@@ -125,26 +161,8 @@ __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
                     case 2: src = acc2; sb = bnd2; break;
                     default: src = acc3; sb = bnd3; break;
                     }
-                } else if (kind == SS_SRC_X) {
-                    src = x;
                 } else {
-                    const Fp *ptr;
-                    if (kind == SS_SRC_SLOT) {
-                        ptr = a.slots + (uint64_t)w1 * lanes + lane;
-                    } else if (kind == SS_SRC_CONST) {
-                        ptr = a.consts + w1;
-                    } else if (kind == SS_SRC_TRACE) {
-                        const uint32_t col = w1 >> 24;
-                        const uint64_t row = (i + ((uint64_t)(w1 & 0xffffffu) << a.log_blowup)) & (N - 1);
-                        const Fp *cp = a.cols[0];
-#pragma unroll
-                        for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) cp = a.cols[c];
-                        ptr = cp + row;
-                    } else {
-                        const uint32_t off = a.table_desc[2 * w1], ll = a.table_desc[2 * w1 + 1];
-                        ptr = a.tables + off + (i & ((1ull << ll) - 1ull));
-                    }
-                    src = fl_from_fp(qload(ptr));       // canonical or weakly reduced 256-bit image
+                    src = x;
                 }
             }
             switch (d) {
@@ -153,8 +171,33 @@ __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
             case 2: vm_exec(op, acc2, bnd2, src, sb, a, w1, lanes, lane, i); break;
             default: vm_exec(op, acc3, bnd3, src, sb, a, w1, lanes, lane, i); break;
             }
+            if (pk != VM_PK_NONE && op == SS_OP_ST) pre = qload(vm_operand_ptr(a, pk, pw, N, lanes, lane, i));
         }
         x = fl_mul(x, wstep);
+    }
+}
+
+// 2-word caller program -> the 4-word device stream described above (n_instr + 1 entries).
+void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, uint32_t *dev) {
+    auto put = [&](uint32_t idx, uint32_t w0, uint32_t w1) {
+        dev[4 * idx] = w0 | (VM_PK_NONE << 16); dev[4 * idx + 1] = w1; dev[4 * idx + 2] = 0; dev[4 * idx + 3] = 0;
+    };
+    put(0, VM_OP_NOP, 0);
+    uint32_t last_node = 0, last_consumer = 0;     // entry indices; the priming no-op counts as both
+    for (uint32_t pc = 0; pc < n_instr; ++pc) {
+        const uint32_t w0 = code[2 * pc] & 0xffffu, w1 = code[2 * pc + 1], idx = pc + 1;
+        const uint32_t op = w0 & 0xffu, kind = (w0 >> 12) & 0xfu;
+        put(idx, w0, w1);
+        if (op <= SS_OP_MUL && kind >= SS_SRC_SLOT && kind <= SS_SRC_TABLE) {
+            // a slot operand may only be requested after the last ST in front of it; anything
+            // else is requested by the previous memory consumer, across any STs in between
+            const uint32_t issuer = kind == SS_SRC_SLOT ? last_node : last_consumer;
+            dev[4 * issuer] = (dev[4 * issuer] & ~(0xfu << 16)) | (kind << 16);
+            dev[4 * issuer + 2] = w1;
+            last_node = last_consumer = idx;
+        } else if (op == SS_OP_ST) {
+            last_node = idx;
+        }
     }
 }
 
@@ -167,6 +210,7 @@ hipError_t launch_quotient_vm(hipStream_t st, const void *const *cols, uint32_t 
     a.code = d_code; a.consts = d_consts; a.tables = d_tables; a.table_desc = d_table_desc; a.slots = d_slots;
     a.out = out; a.offset = offset; a.w = w; a.wstep = wstep; a.n_instr = n_instr; a.log_N = log_N;
     a.log_blowup = log_blowup; a.xcd_split = xcd_split;
+    a.n_instr = n_instr + 1;                 // d_code is the (n_instr + 1)-entry device stream
     hipLaunchKernelGGL(quotient_vm_kernel, dim3((uint32_t)(lanes / 256)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
