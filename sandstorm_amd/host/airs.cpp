@@ -171,7 +171,10 @@ public:
         for (auto &c : ch) chs.push_back(g.constant(c));
         std::mt19937_64 r(0xC0FFEE);
         auto pick = [&]() { return cells[r() % cells.size()]; };
-        int total = -1;
+        // composition = sum_k alpha^k C_k / Z_k, evaluated as sum_Z (1/Z) * (sum_{k: Z_k = Z} alpha^k C_k):
+        // constraints sharing a zerofier are summed before the ONE multiplication by its inverse table
+        // (195 constraints, 22 distinct zerofiers for starknet) — the same field element, a third fewer muls
+        std::vector<std::pair<int, int>> groups;     // (zerofier-inverse table node, partial sum), first-use order
         Felt ap = felt_from_u64(1);
         for (uint32_t k = 0; k < ncons_; ++k) {
             const int a = pick(), b = pick(), c = pick();
@@ -180,9 +183,16 @@ public:
             else if (k % 11 == 5) body = g.sub(g.mul(a, b), g.mul(c, chs[k % chs.size()]));
             else { Felt rc = {r(), r(), r(), r() & ((1ull << 59) - 1)}; body = g.add(g.sub(g.mul(a, b), c), g.constant(rc)); }
             const int zer = (k % 9 == 8) ? g.table(n_zero_ + n_per_ + (k / 9) % N_POINT_ZEROFIERS) : g.table(k % n_zero_);
-            const int term = g.mul(g.mul(body, zer), g.constant(ap));
-            total = total < 0 ? term : g.add(total, term);
+            const int term = g.mul(body, g.constant(ap));
+            auto it = std::find_if(groups.begin(), groups.end(), [&](const std::pair<int, int> &p) { return p.first == zer; });
+            if (it == groups.end()) groups.push_back({zer, term});
+            else it->second = g.add(it->second, term);
             ap = felt_mul(ap, alpha);
+        }
+        int total = -1;
+        for (auto &gr : groups) {
+            const int term = g.mul(gr.second, gr.first);
+            total = total < 0 ? term : g.add(total, term);
         }
         int sum = cells[0];                          // every mask cell is read at least once
         for (size_t i = 1; i < cells.size(); ++i) sum = g.add(sum, cells[i]);

@@ -6,7 +6,8 @@ its `Expr` DAG; until that restatement lands, the bench drives the same kernels
 with a synthetic composition constraint that has the layout's *shape*: the same
 column counts, the same mask (SURVEY.md §8a "Mask / zerofier note": 133 cells for
 recursive — the exact list — and 269 for starknet with the per-column counts and
-maximum offsets), degree-2 constraints, one alpha power per constraint, periodic
+maximum offsets), degree-2 constraints, one alpha power per constraint (constraints
+that share a zerofier are summed before the single multiplication by its inverse), periodic
 zerofier-inverse tables with the layout's periods and full-length tables for the
 single-point boundary zerofiers.  Timing is data-independent, so the cost profile
 is representative; the VALUES prove nothing about Cairo.
@@ -92,7 +93,9 @@ def make_air(name, ctx, log_n, log_blowup=1, lde_offset=3):
         alpha = canonical(comp_coeff)
         ch = [ap.Const(canonical(c)) for c in challenges]
         r = random.Random(0xC0FFEE)
-        total_expr, apow = None, 1
+        # composition = sum_k alpha^k C_k / Z_k, evaluated as sum_Z (1/Z) * (sum_{k: Z_k = Z} alpha^k C_k):
+        # constraints sharing a zerofier are summed before the ONE multiplication by its inverse table
+        groups, apow = {}, 1                 # zerofier table index -> (table node, partial sum); insertion-ordered
         for k in range(ncons):
             a, b, c = r.choice(cells), r.choice(cells), r.choice(cells)
             if k % 7 == 3:
@@ -102,12 +105,19 @@ def make_air(name, ctx, log_n, log_blowup=1, lde_offset=3):
             else:
                 body = a * b - c + ap.Const(r.randrange(P))
             if k % 9 == 8:
-                zer = ap.Table(n_zero + n_per + (k // 9) % N_POINT_ZEROFIERS)               # boundary constraint
+                zi = n_zero + n_per + (k // 9) % N_POINT_ZEROFIERS                          # boundary constraint
             else:
-                zer = ap.Table(k % n_zero)
-            term = body * zer * ap.Const(apow)
-            total_expr = term if total_expr is None else total_expr + term
+                zi = k % n_zero
+            term = body * ap.Const(apow)
+            if zi in groups:
+                groups[zi] = (groups[zi][0], groups[zi][1] + term)
+            else:
+                groups[zi] = (ap.Table(zi), term)
             apow = apow * alpha % P
+        total_expr = None
+        for zer, partial in groups.values():
+            term = partial * zer
+            total_expr = term if total_expr is None else total_expr + term
         # make sure every mask cell is read (the real AIR reads each of its mask cells)
         used = set()
         return_prog = ap.lower(total_expr + sum_cells(cells, used), P)

@@ -398,6 +398,9 @@ def test_eval_quotient_vs_oracle(ctx, be, oracle, seed, size, log_n):
 def test_dev_pool_reuse_and_trim(ctx):
     """ss_dev_alloc/ss_dev_free are pooled: a freed block is handed out again for a request of
     similar size, data written through a recycled block is intact, and trim empties the cache."""
+    import gc
+    gc.collect()
+    ctx.trim()                                # start from an empty cache (other tests share this context)
     a = ctx.alloc(1 << 20)
     pa = a.ptr
     a.upload(np.arange(1 << 17, dtype=np.uint64))
