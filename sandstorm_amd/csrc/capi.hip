@@ -233,7 +233,7 @@ ss_status run_forward(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t
         const bool first = i == 0;
         ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
         HIP_TRY(launch_ntt_pass(ctx->stream, false, first ? cols : inplace, ncols, tw, log_n, passes[i].s0,
-                                passes[i].r, log_tile, first ? log_expand : 0, first ? log_expand : 0, 0));
+                                passes[i].r, log_tile, first ? log_expand : 0, first ? log_expand : 0, 0, i + 1 == passes.size()));
     }
     return SS_OK;
 }
@@ -249,7 +249,7 @@ ss_status run_inverse(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t
         const bool last = i == 0;
         ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
         HIP_TRY(launch_ntt_pass(ctx->stream, true, first ? cols : inplace, ncols, tw, log_n, passes[i].s0,
-                                passes[i].r, log_tile, 0, 0, last ? log_n : 0));
+                                passes[i].r, log_tile, 0, 0, last ? log_n : 0, last));
     }
     return SS_OK;
 }

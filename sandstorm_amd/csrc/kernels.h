@@ -21,7 +21,7 @@ struct ConstColPtrs {
 int ntt_log_tile_max();
 hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
                            uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first,
-                           uint32_t log_expand, uint32_t scale_pow2);
+                           uint32_t log_expand, uint32_t scale_pow2, bool final_pass);
 hipError_t launch_twiddles(hipStream_t st, Fp *tw, const Fp *pow_lo, const Fp *pow_hi, const Fp *hpow,
                            uint32_t log_n, bool h_is_one);
 hipError_t launch_bitrev(hipStream_t st, Fp *a, uint32_t log_n);

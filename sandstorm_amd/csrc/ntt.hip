@@ -33,6 +33,8 @@
 namespace ss {
 
 static constexpr int LOG_TILE_MAX = 11;          // 2048 elements
+// per direction (forward DIT / inverse DIF): stages per register group (radix 2^G), threads per
+// workgroup and waves per SIMD the kernel is compiled for
 #ifndef SS_NTT_GMAX
 #define SS_NTT_GMAX 2
 #endif
@@ -42,8 +44,15 @@ static constexpr int LOG_TILE_MAX = 11;          // 2048 elements
 #ifndef SS_NTT_OCC
 #define SS_NTT_OCC (SS_NTT_THREADS / 128)
 #endif
-static constexpr int NTT_THREADS = SS_NTT_THREADS;   // 2 workgroups of 512 per CU: 4 waves per SIMD
-static constexpr int NTT_GMAX = SS_NTT_GMAX;         // stages per register group (radix 2^GMAX)
+#ifndef SS_NTT_GMAX_DIF
+#define SS_NTT_GMAX_DIF 3          // fewer group boundaries = fewer weak reductions of the DIF sums
+#endif
+#ifndef SS_NTT_THREADS_DIF
+#define SS_NTT_THREADS_DIF 256
+#endif
+#ifndef SS_NTT_OCC_DIF
+#define SS_NTT_OCC_DIF (SS_NTT_THREADS_DIF / 128)
+#endif
 
 __device__ __forceinline__ int lds_slot(int e) { return e + (e >> 3); }
 
@@ -92,16 +101,22 @@ struct PassParams {
     uint32_t log_expand;  // source index = element index >> log_expand
     uint32_t scale_pow2;  // DIF only: multiply outputs by 2^-scale_pow2 (0 = off)
     uint32_t contig;      // 1: s0 == 0, tile is a contiguous block
+    uint32_t final_pass;  // 1: last pass of the transform, outputs are canonical (< p);
+                          // 0: outputs are weakly reduced 256-bit images (< 2^252) for the next pass
 };
 
 // One butterfly stage (local stage u + ST) on the 2^G register-resident elements, in the
 // lazy 9 x 28-bit form (fl252.h): no carry chains, products are 81 in-place
-// v_mad_u64_u32.  Value/limb bounds through a group of up to 3 stages starting from
-// weakly reduced inputs (< 2^252, limbs < 2^28):
-//   DIT  a' = a + b t,  b' = a - b t + 2p     (b t is a normalised product: <C=2,F=1>)
-//        values grow by <= 2p per stage (< 8p after 3), limbs by <= 2^29
+// v_mad_u64_u32.  Reductions are issued only where a bound needs them:
+//   DIT  a' = a + b t,  b' = a - b t + 2p   (b t is a fresh product: normalised, < 2p).
+//        Values grow by <= 2p and limbs by < 1.13 * 2^28 per stage, and fl_mul takes any
+//        multiplicand with u32 limbs and value < 2^256, so a whole pass (<= 11 stages from
+//        inputs < 2^252: values < 24p < 2^256, limbs < 13.4 * 2^28 < 2^32) runs WITHOUT any
+//        reduction; the LDS tile holds the raw limbs and the pass's store reduces once.
 //   DIF  a' = a + b,    b' = (a - b + C p) t  with C = 2, 8, 16 for the 1st, 2nd, 3rd
-//        stage of the group (b's limbs double each stage); a' < 16p after 3 stages.
+//        stage of a group (the sums' limbs double each stage).  Group inputs are < 2^252 and
+//        normalised; products leave the group as they are (< 1.75p, normalised), only the
+//        sums (the even outputs of the group's last stage) are weakly reduced.
 template <bool DIF, int G, int ST>
 __device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const Fp *__restrict__ tw, const PassParams &p,
                                             uint32_t u, uint32_t jlow, uint32_t lbits) {
@@ -195,12 +210,21 @@ __device__ __forceinline__ void radix_group(const Tile &t, const Fp *__restrict_
 #pragma unroll
         for (int m = 0; m < (1 << G); ++m) {
             const uint32_t e = ebase + ((uint32_t)m << sh);
-            if (to_global) {                               // leaving the pass: canonical image (< p)
-                Fp out = fl_to_fp(x[m]);
-                if (DIF && p.scale_pow2) out = fp_div_pow2(out, p.scale_pow2);
+            // DIF: odd outputs of the group's last stage are fresh products (normalised, < 2^252)
+            const bool product = DIF && (m & 1);
+            if (to_global) {
+                Fp out;
+                if (p.final_pass) {                        // leaving the transform: canonical image (< p)
+                    out = product ? fp_reduce_once(fl_pack(x[m])) : fl_to_fp(x[m]);
+                    if (DIF && p.scale_pow2) out = fp_div_pow2(out, p.scale_pow2);
+                } else {                                   // next pass re-limbs any image < 2^256
+                    out = product ? fl_pack(x[m]) : fl_pack(fl_weak_reduce(x[m]));
+                }
                 gstore(dst + tile_gindex(p, tile, e), out);
+            } else if (DIF) {
+                lds_store(t, e, product ? x[m] : fl_weak_reduce(x[m]));     // < 2^252, limbs < 2^28
             } else {
-                lds_store(t, e, fl_weak_reduce(x[m]));     // < 2^252, limbs < 2^28
+                lds_store(t, e, x[m]);                                      // raw lazy limbs (see radix_stage)
             }
         }
     }
@@ -213,9 +237,10 @@ __device__ __forceinline__ void run_group(const Tile &t, const Fp *tw, const Pas
 }
 
 template <bool DIF>
-__global__ __launch_bounds__(NTT_THREADS, SS_NTT_OCC) void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw,
+__global__ __launch_bounds__(DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, DIF ? SS_NTT_OCC_DIF : SS_NTT_OCC) void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw,
                                                                PassParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NTT_GMAX = DIF ? SS_NTT_GMAX_DIF : SS_NTT_GMAX;
     const uint32_t tile_elems = 1u << p.log_tile;
     const uint32_t slots = tile_elems + (tile_elems >> 3);
     Tile t;
@@ -274,8 +299,13 @@ __global__ __launch_bounds__(NTT_THREADS, SS_NTT_OCC) void ntt_pass_kernel(ColPt
 
     if (!fuse) {
         for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x) {
-            Fp out = fl_to_fp(lds_load(t, x));
-            if (DIF && p.scale_pow2) out = fp_div_pow2(out, p.scale_pow2);
+            Fp out;
+            if (p.final_pass) {
+                out = fl_to_fp(lds_load(t, x));
+                if (DIF && p.scale_pow2) out = fp_div_pow2(out, p.scale_pow2);
+            } else {
+                out = fl_pack(fl_weak_reduce(lds_load(t, x)));
+            }
             gstore(dst + tile_gindex(p, tile, x), out);
         }
     }
@@ -333,12 +363,13 @@ static inline size_t pass_lds_bytes(uint32_t log_tile) {
 
 hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
                            uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first,
-                           uint32_t log_expand, uint32_t scale_pow2) {
+                           uint32_t log_expand, uint32_t scale_pow2, bool final_pass) {
     PassParams p;
+    p.final_pass = final_pass ? 1u : 0u;
     p.log_n = log_n; p.s0 = s0; p.r = r; p.log_tile = log_tile; p.u_first = u_first;
     p.log_expand = log_expand; p.scale_pow2 = scale_pow2; p.contig = (s0 == 0);
     const uint32_t tiles = 1u << (log_n - log_tile);
-    dim3 grid(tiles, ncols), block(NTT_THREADS);
+    dim3 grid(tiles, ncols), block(dif ? SS_NTT_THREADS_DIF : SS_NTT_THREADS);
     const size_t lds = pass_lds_bytes(log_tile);
     if (dif) hipLaunchKernelGGL(ntt_pass_kernel<true>, grid, block, lds, st, cols, tw, p);
     else hipLaunchKernelGGL(ntt_pass_kernel<false>, grid, block, lds, st, cols, tw, p);
