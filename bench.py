@@ -58,9 +58,13 @@ def cpu_baseline(layout, log_n_full, ncols):
     row-hash, Merkle and FRI-fold stages at 2^16 rows, scaled to the full trace length
     (n log n for the NTTs, n for the rest).  Quotient + DEEP are NOT included: a lower bound."""
     import numpy as np
+    # the oracle's loops are short at this sample size: cap the OpenMP team (must precede libgomp's start-up)
+    threads = min(os.cpu_count() or 1, 32)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    threads = int(os.environ["OMP_NUM_THREADS"])
     from oracle import oracle_py as oracle
     from tests.util import random_column
-    sl = min(16, log_n_full)
+    sl = min(17, log_n_full)
     n = 1 << sl
     g = oracle.to_mont([3])[0]
     cols = [random_column(n, c) for c in range(ncols)]
@@ -86,7 +90,7 @@ def cpu_baseline(layout, log_n_full, ncols):
     # the proof has ~1.4x the trace-LDE NTT work (composition, OOD, DEEP-free FRI) and 3 trees
     est = 1.4 * t_lde * scale_ntt + 1.5 * t_hash * scale_n + 1.2 * t_fri * scale_n
     ops = ncols * (ntt_field_ops(sl) + ntt_field_ops(sl + 1))
-    return {"value": est, "unit": "s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": est, "unit": "s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
             "ntt_gfield_ops_per_s": ops / t_lde / 1e9,
             "sample": "oracle (C, OpenMP) LDE %dx2^%d %.2fs + row-hash/Merkle %.2fs + FRI %.2fs, scaled to 2^%d rows; "
                       "omits quotient+DEEP (lower bound on a CPU prove)" % (ncols, sl, t_lde, t_hash, t_fri, log_n_full)}
@@ -177,6 +181,14 @@ def main():
         ntt_ms, ntt_launches = prof["ntt_pass"]
         ntt_s = ntt_ms * 1e-3 / args.steps
         achieved = algo_bytes / ntt_s / 1e9 if ntt_s > 0 else 0.0
+        # HBM bytes per launch from the PMC passes of this workload (FETCH_SIZE / WRITE_SIZE cannot be read
+        # live; tools/profile_round.sh collects them, the committed summary is cited here)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
         out = {
             "metric": "prove_wall_time_s", "value": sec_per_proof, "unit": "s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_proof * 1e3,
@@ -197,7 +209,8 @@ def main():
                        "fri_layers": len(proof.fri_layers), "pow_nonce": proof.pow_nonce},
             "stage_ms_per_proof": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
             "roofline": {"bound": "hbm", "kernel": "ss::ntt_pass_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": algo_bytes / max(1.0, ntt_launches / args.steps),
                          "launches": ntt_launches, "avg_launch_ms": ntt_ms / max(1, ntt_launches),
                          "note": "algorithmic bytes = 2*N*32 B per transform (SURVEY 8d), shared by its passes; "
                                  "Fp252 butterflies are integer-ALU bound before HBM bound (DESIGN.md)"},

@@ -501,6 +501,12 @@ ss_status ss_merkle_build(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_layers
     hipStream_t s = ctx->stream;
     const int hk = tree_kind == SS_TREE_KECCAK ? SS_HASH_KECCAK : tree_kind == SS_TREE_KECCAK_M20 ? SS_HASH_KECCAK_M20 : SS_HASH_BLAKE2S_M20;
     if (tree_kind == SS_TREE_FRIENDLY && !ctx->ped) HIP_TRY(pedersen_tables_create(s, &ctx->ped));
+    Fp *ped_tmp = nullptr;
+    if (tree_kind == SS_TREE_FRIENDLY) {
+        ss_status st = ctx->ensure_scratch(PEDERSEN_TMP_FELTS_PER_HASH * (n / 2) * sizeof(Fp));
+        if (st != SS_OK) return st;
+        ped_tmp = (Fp *)ctx->scratch;
+    }
     HIP_TRY(hipMemsetAsync(d_nodes, 0, 64, s));
     if (d_tags) HIP_TRY(hipMemsetAsync(d_tags, 0, 2 * n, s));
     // leaf slots
@@ -520,9 +526,9 @@ ss_status ss_merkle_build(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_layers
         if (tree_kind == SS_TREE_FRIENDLY) {
             const bool pedersen = leaf_kind == SS_LEAF_FELT || d < n_friendly_layers;
             if (leaf_level && leaf_kind == SS_LEAF_FELT) {
-                HIP_TRY(launch_pedersen_felt_pairs(s, ctx->ped, (const Fp *)d_leaves, count, out));
+                HIP_TRY(launch_pedersen_felt_pairs(s, ctx->ped, (const Fp *)d_leaves, count, out, ped_tmp));
             } else if (pedersen) {
-                HIP_TRY(launch_pedersen_pairs(s, ctx->ped, in, count, out));
+                HIP_TRY(launch_pedersen_pairs(s, ctx->ped, in, count, out, ped_tmp));
             } else {
                 HIP_TRY(launch_hash_pairs(s, SS_HASH_BLAKE2S_M20, in, count, out));
                 if (d_tags) HIP_TRY(hipMemsetAsync(d_tags + count, 1, count, s));
@@ -644,7 +650,9 @@ ss_status ss_pow_grind(ss_ctx *ctx, int coin_kind, const uint8_t digest[32], uin
 ss_status ss_pedersen_hash(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t n, uint64_t *d_out) {
     if (!ctx || !d_a || !d_b || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
     if (!ctx->ped) HIP_TRY(pedersen_tables_create(ctx->stream, &ctx->ped));
-    HIP_TRY(launch_pedersen_felts(ctx->stream, ctx->ped, (const Fp *)d_a, (const Fp *)d_b, n, (Fp *)d_out));
+    ss_status st = ctx->ensure_scratch(PEDERSEN_TMP_FELTS_PER_HASH * n * sizeof(Fp));
+    if (st != SS_OK) return st;
+    HIP_TRY(launch_pedersen_felts(ctx->stream, ctx->ped, (const Fp *)d_a, (const Fp *)d_b, n, (Fp *)d_out, (Fp *)ctx->scratch));
     return SS_OK;
 }
 

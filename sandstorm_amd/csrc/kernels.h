@@ -48,15 +48,18 @@ hipError_t launch_gather8(hipStream_t st, const uint8_t *in, const uint64_t *d_i
 struct PedersenTables;  // device-resident windowed tables, built once per context
 hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out);
 void pedersen_tables_destroy(PedersenTables *t);
+// Every launcher takes `tmp`: PEDERSEN_TMP_FELTS_PER_HASH felts of device scratch per hash (Jacobian X and Z,
+// prefix products of the batched inversion, the chained digest of hash_elements).
+static constexpr uint64_t PEDERSEN_TMP_FELTS_PER_HASH = 4;
 // out[i] = pedersen(a[i], b[i]), Montgomery felts
 hipError_t launch_pedersen_felts(hipStream_t st, const PedersenTables *t, const Fp *a, const Fp *b,
-                                 uint64_t n, Fp *out);
+                                 uint64_t n, Fp *out, Fp *tmp);
 // Merkle level on 32-byte big-endian digests: out[k] = BE(pedersen(int(in[2k]) mod p, int(in[2k+1]) mod p))
 hipError_t launch_pedersen_pairs(hipStream_t st, const PedersenTables *t, const uint8_t *in, uint64_t count,
-                                 uint8_t *out);
+                                 uint8_t *out, Fp *tmp);
 // single-column leaf level: out[k] = BE(PedersenHashFn::hash_elements([f[2k], f[2k+1]]))
 hipError_t launch_pedersen_felt_pairs(hipStream_t st, const PedersenTables *t, const Fp *felts,
-                                      uint64_t count, uint8_t *out);
+                                      uint64_t count, uint8_t *out, Fp *tmp);
 
 // host-side hash for the Fiat-Shamir coin (Montgomery felts)
 Fp pedersen_hash_host(const Fp &a, const Fp &b);

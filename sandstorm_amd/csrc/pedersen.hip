@@ -11,10 +11,15 @@
 // (a_low = low 248 bits, a_high = top 4 bits of the canonical value;
 // mod.rs:25-30; points from builtins/src/pedersen/constants.rs:5-30.)
 //
-// Fixed-base, 8-bit windows: per input 31 table lookups for the low part and one
-// 4-bit lookup for the high part, each a Jacobian+affine mixed addition
-// (8M + 3S), then one inversion.  The tables (2 x 31 x 255 + 2 x 15 affine
-// points, ~1 MiB) are built once per context on the host and stay L2-resident.
+// Fixed-base windows.  Device table, per input: 15 windows of 16 bits over bits 0..239
+// (65535 points each), one 8-bit window over bits 240..247, one 4-bit window for the top
+// bits: 17 Jacobian+affine mixed additions (8M + 3S) per input instead of 32 with 8-bit
+// windows.  The table (2 x 983 295 affine points, 126 MB: Infinity-Cache resident) is
+// built once per context ON THE DEVICE from the 8-bit host table (a 16-bit entry is the sum
+// of two 8-bit entries).  The final Jacobian -> affine inversion (~310 multiplications, a
+// quarter of a hash) is not done per hash: the accumulate kernel leaves (X, Z) in a
+// temporary and a second kernel inverts Z in per-lane chunks with Montgomery's trick
+// (5 multiplications per hash + one inversion per chunk).
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <vector>
@@ -45,8 +50,14 @@ static constexpr int PED_LOW_ENTRIES = PED_WINDOWS * 255;
 static constexpr int PED_HIGH_ENTRIES = 15;
 static constexpr int PED_PER_INPUT = PED_LOW_ENTRIES + PED_HIGH_ENTRIES;
 
+// device table layout per input: [15][65535] 16-bit windows | [255] window over bits 240..247 | [15] top 4 bits
+static constexpr int PED_W16 = 15;
+static constexpr uint32_t PED16_SPAN = 65535;
+static constexpr uint32_t PED16_LOW = PED_W16 * PED16_SPAN;
+static constexpr uint32_t PED16_PER_INPUT = PED16_LOW + 255 + PED_HIGH_ENTRIES;
+
 struct PedersenTables {
-    Aff *d_table;   // [2][PED_PER_INPUT]
+    Aff *d_table;   // [2][PED16_PER_INPUT]
     Aff shift;      // P0
 };
 
@@ -177,16 +188,26 @@ static const std::vector<Aff> &host_tables(Aff *shift) {
     return aff;
 }
 
+__global__ void pedersen_build16_kernel(const Aff *__restrict__ t8, Aff *__restrict__ t16);
+
 hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
     Aff shift;
     const std::vector<Aff> &aff = host_tables(&shift);
     PedersenTables *t = new PedersenTables;
     t->shift = shift;
-    hipError_t e = hipMalloc(&t->d_table, aff.size() * sizeof(Aff));
-    if (e != hipSuccess) { delete t; return e; }
-    e = hipMemcpyAsync(t->d_table, aff.data(), aff.size() * sizeof(Aff), hipMemcpyHostToDevice, st);
+    t->d_table = nullptr;
+    Aff *d_t8 = nullptr;
+    hipError_t e = hipMalloc(&d_t8, aff.size() * sizeof(Aff));
+    if (e == hipSuccess) e = hipMalloc(&t->d_table, 2 * (size_t)PED16_PER_INPUT * sizeof(Aff));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_t8, aff.data(), aff.size() * sizeof(Aff), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const uint32_t total = 2 * PED16_PER_INPUT;
+        hipLaunchKernelGGL(pedersen_build16_kernel, dim3((total + 63) / 64), dim3(64), 0, st, d_t8, t->d_table);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(t->d_table); delete t; return e; }
+    if (d_t8) (void)hipFree(d_t8);
+    if (e != hipSuccess) { if (t->d_table) (void)hipFree(t->d_table); delete t; return e; }
     *out = t;
     return hipSuccess;
 }
@@ -234,25 +255,74 @@ __device__ __forceinline__ AffL load_affl(const Aff *p) {
     return r;
 }
 
-// acc += scalar (canonical integer limbs) over input slot e
-__device__ __forceinline__ void ped_accumulate(JacL &acc, const Fp &canon, const Aff *__restrict__ table, int e) {
-    const Aff *tab = table + e * PED_PER_INPUT;
-#pragma unroll 1
-    for (int j = 0; j < PED_WINDOWS; ++j) {
-        const u32 d = (canon.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
-        if (d) acc = jacl_add_aff(acc, load_affl(tab + j * 255 + (d - 1)));
-    }
-    const u32 dh = (canon.v[7] >> 24) & 0xfu;     // bits 248..251
-    if (dh) acc = jacl_add_aff(acc, load_affl(tab + PED_LOW_ENTRIES + (dh - 1)));
+__device__ __forceinline__ Fp load_felt(const Fp *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void store_felt(Fp *p, const Fp &x) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    q[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
 
-// both inputs canonical (< p); returns x in Montgomery form
-__device__ __forceinline__ Fp ped_hash_canon(const Fp &a, const Fp &b, const Aff *__restrict__ table, const Aff &shift) {
+__device__ __forceinline__ void store_aff(Aff *p, const Aff &a) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(a.x.v[0], a.x.v[1], a.x.v[2], a.x.v[3]);
+    q[1] = make_uint4(a.x.v[4], a.x.v[5], a.x.v[6], a.x.v[7]);
+    q[2] = make_uint4(a.y.v[0], a.y.v[1], a.y.v[2], a.y.v[3]);
+    q[3] = make_uint4(a.y.v[4], a.y.v[5], a.y.v[6], a.y.v[7]);
+}
+
+// 16-bit window entry j = lo + 256 hi of window w:  j * 2^(16w) P = lo * 2^(8 (2w)) P + hi * 2^(8 (2w+1)) P
+__global__ __launch_bounds__(64) void pedersen_build16_kernel(const Aff *__restrict__ t8, Aff *__restrict__ t16) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * PED16_PER_INPUT) return;
+    const uint32_t e = idx / PED16_PER_INPUT, r = idx % PED16_PER_INPUT;
+    const Aff *src = t8 + e * PED_PER_INPUT;
+    if (r >= PED16_LOW) {                                       // the 8-bit window 30 and the 4-bit top window: copied
+        const uint32_t tail = r - PED16_LOW;
+        store_aff(t16 + idx, load_aff(src + (tail < 255 ? 30 * 255 + tail : PED_LOW_ENTRIES + (tail - 255))));
+        return;
+    }
+    const uint32_t w = r / PED16_SPAN, j = r % PED16_SPAN + 1, lo = j & 255u, hi = j >> 8;
+    if (!hi) { store_aff(t16 + idx, load_aff(src + (2 * w) * 255 + (lo - 1))); return; }
+    if (!lo) { store_aff(t16 + idx, load_aff(src + (2 * w + 1) * 255 + (hi - 1))); return; }
+    const AffL a = load_affl(src + (2 * w) * 255 + (lo - 1)), b = load_affl(src + (2 * w + 1) * 255 + (hi - 1));
+    JacL acc; acc.x = a.x; acc.y = a.y; acc.z = fl_one();
+    acc = jacl_add_aff(acc, b);
+    const Fl zi = fn_inv(acc.z), zi2 = fn_sqr(zi);
+    Aff o;
+    o.x = fl_to_fp(fn_mul(acc.x, zi2));
+    o.y = fl_to_fp(fn_mul(acc.y, fn_mul(zi2, zi)));
+    store_aff(t16 + idx, o);
+}
+
+// acc += scalar (canonical integer limbs) over input slot e
+__device__ __forceinline__ void ped_accumulate(JacL &acc, const Fp &canon, const Aff *__restrict__ table, int e) {
+    const Aff *tab = table + (size_t)e * PED16_PER_INPUT;
+#pragma unroll 1
+    for (int w = 0; w < PED_W16; ++w) {
+        const u32 d = (canon.v[w >> 1] >> (16 * (w & 1))) & 0xffffu;
+        if (d) acc = jacl_add_aff(acc, load_affl(tab + (size_t)w * PED16_SPAN + (d - 1)));
+    }
+    const u32 d8 = (canon.v[7] >> 16) & 0xffu;    // bits 240..247
+    if (d8) acc = jacl_add_aff(acc, load_affl(tab + PED16_LOW + (d8 - 1)));
+    const u32 dh = (canon.v[7] >> 24) & 0xfu;     // bits 248..251
+    if (dh) acc = jacl_add_aff(acc, load_affl(tab + PED16_LOW + 255 + (dh - 1)));
+}
+
+// both inputs canonical (< p); leaves the Jacobian (X, Z) of P0 + a-part + b-part as weakly reduced images
+__device__ __forceinline__ void ped_jacobian(const Fp &a, const Fp &b, const Aff *__restrict__ table, const Aff &shift,
+                                             Fp *__restrict__ x_out, Fp *__restrict__ z_out) {
     JacL acc; acc.x = fl_from_fp(shift.x); acc.y = fl_from_fp(shift.y); acc.z = fl_one();
     ped_accumulate(acc, a, table, 0);
     ped_accumulate(acc, b, table, 1);
-    const Fl zi = fn_inv(acc.z);
-    return fl_to_fp(fn_mul(acc.x, fn_sqr(zi)));
+    store_felt(x_out, fl_pack(acc.x));            // fn_* results are normalised and < 2p
+    store_felt(z_out, fl_pack(acc.z));
 }
 
 // 32 big-endian bytes -> canonical integer mod p
@@ -275,73 +345,116 @@ __device__ __forceinline__ void canon_to_be_bytes(const Fp &c, uint8_t *out) {
     q[0] = make_uint4(__builtin_bswap32(c.v[7]), __builtin_bswap32(c.v[6]), __builtin_bswap32(c.v[5]), __builtin_bswap32(c.v[4]));
     q[1] = make_uint4(__builtin_bswap32(c.v[3]), __builtin_bswap32(c.v[2]), __builtin_bswap32(c.v[1]), __builtin_bswap32(c.v[0]));
 }
-__device__ __forceinline__ Fp load_felt(const Fp *p) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    uint4 a = q[0], b = q[1];
-    Fp r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    return r;
-}
-__device__ __forceinline__ void store_felt(Fp *p, const Fp &x) {
-    uint4 *q = reinterpret_cast<uint4 *>(p);
-    q[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    q[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
-}
-
-__global__ __launch_bounds__(64) void pedersen_felts_kernel(const Aff *__restrict__ table, Aff shift,
-                                                            const Fp *__restrict__ a, const Fp *__restrict__ b,
-                                                            uint64_t n, Fp *__restrict__ out) {
-    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fp ca = fp_from_mont(load_felt(a + i)), cb = fp_from_mont(load_felt(b + i));
-    store_felt(out + i, ped_hash_canon(ca, cb, table, shift));
-}
-
-__global__ __launch_bounds__(64) void pedersen_pairs_kernel(const Aff *__restrict__ table, Aff shift,
-                                                            const uint8_t *__restrict__ in, uint64_t count,
-                                                            uint8_t *__restrict__ out) {
+// ---- phase 1: accumulate.  xz[k] = X, xz[count + k] = Z of hash k ---------------------------
+// inputs as Montgomery felts: a[k * a_stride] (or the canonical constant a_const when a == nullptr), same for b
+struct PedFeltArgs {
+    const Fp *a; uint64_t a_stride; Fp a_const;
+    const Fp *b; uint64_t b_stride; Fp b_const;
+};
+__global__ __launch_bounds__(64) void pedersen_acc_felts_kernel(const Aff *__restrict__ table, Aff shift, PedFeltArgs g,
+                                                                uint64_t count, Fp *__restrict__ xz) {
     const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (k >= count) return;
-    Fp ca = be_bytes_to_canon(in + 64 * k), cb = be_bytes_to_canon(in + 64 * k + 32);
-    Fp h = ped_hash_canon(ca, cb, table, shift);
-    canon_to_be_bytes(fp_from_mont(h), out + 32 * k);
+    const Fp ca = g.a ? fp_from_mont(load_felt(g.a + k * g.a_stride)) : g.a_const;
+    const Fp cb = g.b ? fp_from_mont(load_felt(g.b + k * g.b_stride)) : g.b_const;
+    ped_jacobian(ca, cb, table, shift, xz + k, xz + count + k);
 }
-
-// PedersenHashFn::hash_elements([l0, l1]) = H(H(H(0, l0), l1), 2)
-__global__ __launch_bounds__(64) void pedersen_felt_pairs_kernel(const Aff *__restrict__ table, Aff shift,
-                                                                 const Fp *__restrict__ felts, uint64_t count,
-                                                                 uint8_t *__restrict__ out) {
+// inputs as 32-byte big-endian digests: (in[2k], in[2k+1])
+__global__ __launch_bounds__(64) void pedersen_acc_pairs_kernel(const Aff *__restrict__ table, Aff shift,
+                                                                const uint8_t *__restrict__ in, uint64_t count,
+                                                                Fp *__restrict__ xz) {
     const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (k >= count) return;
-    Fp l0 = fp_from_mont(load_felt(felts + 2 * k)), l1 = fp_from_mont(load_felt(felts + 2 * k + 1));
-    Fp h = ped_hash_canon(fp_zero(), l0, table, shift);
-    h = ped_hash_canon(fp_from_mont(h), l1, table, shift);
-    Fp two = fp_zero(); two.v[0] = 2;
-    h = ped_hash_canon(fp_from_mont(h), two, table, shift);
-    canon_to_be_bytes(fp_from_mont(h), out + 32 * k);
+    const Fp ca = be_bytes_to_canon(in + 64 * k), cb = be_bytes_to_canon(in + 64 * k + 32);
+    ped_jacobian(ca, cb, table, shift, xz + k, xz + count + k);
 }
 
-hipError_t launch_pedersen_felts(hipStream_t st, const PedersenTables *t, const Fp *a, const Fp *b,
-                                 uint64_t n, Fp *out) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(pedersen_felts_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, st, t->d_table,
-                       t->shift, a, b, n, out);
+// ---- phase 2: x = X / Z^2, `chunk` hashes per lane (k = j * lanes + lane), one inversion per lane ----
+// Montgomery's trick with the prefix products in tmp[2 count ..).  A point at infinity (Z = 0:
+// unreachable for a hash, kept for totality) yields x = 0 as the per-hash formula did.
+template <bool BYTES>
+__global__ __launch_bounds__(64) void pedersen_finish_kernel(Fp *__restrict__ tmp, uint64_t count, uint64_t lanes,
+                                                             Fp *__restrict__ out_felts, uint8_t *__restrict__ out_bytes) {
+    const uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (c >= lanes) return;
+    const Fp *X = tmp, *Z = tmp + count;
+    Fp *P = tmp + 2 * count;
+    Fl run = fl_one();
+    uint64_t k = c;
+    for (; k < count; k += lanes) {
+        Fl z = fl_from_fp(load_felt(Z + k));
+        if (fn_is_zero(z)) z = fl_one();
+        store_felt(P + k, fl_pack(run));
+        run = fn_mul(run, z);
+    }
+    Fl inv = fn_inv(run);
+    while (k > c) {
+        k -= lanes;
+        Fl z = fl_from_fp(load_felt(Z + k));
+        const bool infinity = fn_is_zero(z);
+        if (infinity) z = fl_one();
+        const Fl zi = fn_mul(inv, fl_from_fp(load_felt(P + k)));
+        inv = fn_mul(inv, z);
+        Fp x = fl_to_fp(fn_mul(fl_from_fp(load_felt(X + k)), fn_sqr(zi)));
+        if (infinity) x = fp_zero();
+        if (BYTES) canon_to_be_bytes(fp_from_mont(x), out_bytes + 32 * k);
+        else store_felt(out_felts + k, x);
+    }
+}
+
+static uint64_t finish_lanes(uint64_t count) {
+    const uint64_t chunk = count >= (1ull << 16) ? 8 : count >= (1ull << 13) ? 4 : 1;
+    return (count + chunk - 1) / chunk;
+}
+static hipError_t launch_finish(hipStream_t st, Fp *tmp, uint64_t count, Fp *out_felts, uint8_t *out_bytes) {
+    const uint64_t lanes = finish_lanes(count);
+    const dim3 grid((uint32_t)((lanes + 63) / 64)), block(64);
+    if (out_bytes) hipLaunchKernelGGL(pedersen_finish_kernel<true>, grid, block, 0, st, tmp, count, lanes, (Fp *)nullptr, out_bytes);
+    else hipLaunchKernelGGL(pedersen_finish_kernel<false>, grid, block, 0, st, tmp, count, lanes, out_felts, (uint8_t *)nullptr);
     return hipGetLastError();
+}
+static hipError_t launch_acc_felts(hipStream_t st, const PedersenTables *t, const PedFeltArgs &g, uint64_t count, Fp *tmp) {
+    hipLaunchKernelGGL(pedersen_acc_felts_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table, t->shift,
+                       g, count, tmp);
+    return hipGetLastError();
+}
+
+// tmp: PEDERSEN_TMP_FELTS_PER_HASH * n felts of device scratch (X, Z, prefix products, chained digest)
+hipError_t launch_pedersen_felts(hipStream_t st, const PedersenTables *t, const Fp *a, const Fp *b,
+                                 uint64_t n, Fp *out, Fp *tmp) {
+    if (n == 0) return hipSuccess;
+    PedFeltArgs g;
+    g.a = a; g.a_stride = 1; g.a_const = fp_zero(); g.b = b; g.b_stride = 1; g.b_const = fp_zero();
+    hipError_t e = launch_acc_felts(st, t, g, n, tmp);
+    if (e != hipSuccess) return e;
+    return launch_finish(st, tmp, n, out, nullptr);
 }
 hipError_t launch_pedersen_pairs(hipStream_t st, const PedersenTables *t, const uint8_t *in, uint64_t count,
-                                 uint8_t *out) {
+                                 uint8_t *out, Fp *tmp) {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(pedersen_pairs_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table,
-                       t->shift, in, count, out);
-    return hipGetLastError();
+    hipLaunchKernelGGL(pedersen_acc_pairs_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table,
+                       t->shift, in, count, tmp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_finish(st, tmp, count, nullptr, out);
 }
+// PedersenHashFn::hash_elements([l0, l1]) = H(H(H(0, l0), l1), 2): three rounds over all pairs
 hipError_t launch_pedersen_felt_pairs(hipStream_t st, const PedersenTables *t, const Fp *felts,
-                                      uint64_t count, uint8_t *out) {
+                                      uint64_t count, uint8_t *out, Fp *tmp) {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(pedersen_felt_pairs_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st,
-                       t->d_table, t->shift, felts, count, out);
-    return hipGetLastError();
+    Fp *h = tmp + 3 * count;
+    Fp two = fp_zero(); two.v[0] = 2;
+    PedFeltArgs g;
+    g.a = nullptr; g.a_stride = 0; g.a_const = fp_zero(); g.b = felts; g.b_stride = 2; g.b_const = fp_zero();
+    hipError_t e = launch_acc_felts(st, t, g, count, tmp);
+    if (e == hipSuccess) e = launch_finish(st, tmp, count, h, nullptr);
+    g.a = h; g.a_stride = 1; g.b = felts + 1;
+    if (e == hipSuccess) e = launch_acc_felts(st, t, g, count, tmp);
+    if (e == hipSuccess) e = launch_finish(st, tmp, count, h, nullptr);
+    g.b = nullptr; g.b_stride = 0; g.b_const = two;
+    if (e == hipSuccess) e = launch_acc_felts(st, t, g, count, tmp);
+    if (e == hipSuccess) e = launch_finish(st, tmp, count, nullptr, out);
+    return e;
 }
 
 }  // namespace ss
