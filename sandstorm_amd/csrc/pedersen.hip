@@ -12,9 +12,10 @@
 // mod.rs:25-30; points from builtins/src/pedersen/constants.rs:5-30.)
 //
 // Fixed-base windows.  Device table, per input: 15 windows of 16 bits over bits 0..239
-// (65535 points each), one 8-bit window over bits 240..247, one 4-bit window for the top
-// bits: 17 Jacobian+affine mixed additions (8M + 3S) per input instead of 32 with 8-bit
-// windows.  The table (2 x 983 295 affine points, 126 MB: Infinity-Cache resident) is
+// (65535 points each) and one 12-bit window over bits 240..251 (the last byte of the low
+// part together with the 4-bit high part, which has its own base point): 16 Jacobian+affine
+// mixed additions (8M + 3S) per input instead of 32 with 8-bit windows.  The table
+// (2 x 987 120 affine points, 126 MB: Infinity-Cache resident) is
 // built once per context ON THE DEVICE from the 8-bit host table (a 16-bit entry is the sum
 // of two 8-bit entries).  The final Jacobian -> affine inversion (~310 multiplications, a
 // quarter of a hash) is not done per hash: the accumulate kernel leaves (X, Z) in a
@@ -50,11 +51,12 @@ static constexpr int PED_LOW_ENTRIES = PED_WINDOWS * 255;
 static constexpr int PED_HIGH_ENTRIES = 15;
 static constexpr int PED_PER_INPUT = PED_LOW_ENTRIES + PED_HIGH_ENTRIES;
 
-// device table layout per input: [15][65535] 16-bit windows | [255] window over bits 240..247 | [15] top 4 bits
+// device table layout per input: [15][65535] 16-bit windows | [4095] 12-bit window over bits 240..251
 static constexpr int PED_W16 = 15;
 static constexpr uint32_t PED16_SPAN = 65535;
 static constexpr uint32_t PED16_LOW = PED_W16 * PED16_SPAN;
-static constexpr uint32_t PED16_PER_INPUT = PED16_LOW + 255 + PED_HIGH_ENTRIES;
+static constexpr uint32_t PED16_TOP = 4095;
+static constexpr uint32_t PED16_PER_INPUT = PED16_LOW + PED16_TOP;
 
 struct PedersenTables {
     Aff *d_table;   // [2][PED16_PER_INPUT]
@@ -120,6 +122,28 @@ SS_HD JacL jacl_add_aff(const JacL &p, const AffL &q) {
     r.x = fn_sub(fn_sub(fn_sqr(rr), hhh), fn_dbl(v));
     r.y = fn_sub(fn_mul(rr, fn_sub(v, r.x)), fn_mul(p.y, hhh));
     r.z = fn_mul(p.z, h);
+    return r;
+}
+
+// p + q, both Jacobian (12M + 4S); infinity is z = 0 on either side.  Used by the lane-split
+// accumulation of small tree levels, where partial sums of one hash meet across lanes.
+SS_HD JacL jacl_add(const JacL &p, const JacL &q) {
+    const bool pinf = fn_is_zero(p.z), qinf = fn_is_zero(q.z);
+    const Fl z1z1 = fn_sqr(p.z), z2z2 = fn_sqr(q.z);
+    const Fl u1 = fn_mul(p.x, z2z2), u2 = fn_mul(q.x, z1z1);
+    const Fl s1 = fn_mul(p.y, fn_mul(q.z, z2z2)), s2 = fn_mul(q.y, fn_mul(p.z, z1z1));
+    const Fl h = fn_sub(u2, u1), rr = fn_sub(s2, s1);
+    if (pinf) return q;
+    if (qinf) return p;
+    if (fn_is_zero(h)) {
+        if (fn_is_zero(rr)) return jacl_double(p);
+        JacL o; o.x = fl_one(); o.y = fl_one(); o.z = fl_zero(); return o;
+    }
+    const Fl hh = fn_sqr(h), hhh = fn_mul(hh, h), v = fn_mul(u1, hh);
+    JacL r;
+    r.x = fn_sub(fn_sub(fn_sqr(rr), hhh), fn_dbl(v));
+    r.y = fn_sub(fn_mul(rr, fn_sub(v, r.x)), fn_mul(s1, hhh));
+    r.z = fn_mul(fn_mul(p.z, q.z), h);
     return r;
 }
 
@@ -277,21 +301,28 @@ __device__ __forceinline__ void store_aff(Aff *p, const Aff &a) {
     q[3] = make_uint4(a.y.v[4], a.y.v[5], a.y.v[6], a.y.v[7]);
 }
 
-// 16-bit window entry j = lo + 256 hi of window w:  j * 2^(16w) P = lo * 2^(8 (2w)) P + hi * 2^(8 (2w+1)) P
+// window entry j = lo + 256 hi:  the sum of the 8-bit-table entries `lo` and `hi` of its two halves
 __global__ __launch_bounds__(64) void pedersen_build16_kernel(const Aff *__restrict__ t8, Aff *__restrict__ t16) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 2 * PED16_PER_INPUT) return;
     const uint32_t e = idx / PED16_PER_INPUT, r = idx % PED16_PER_INPUT;
     const Aff *src = t8 + e * PED_PER_INPUT;
-    if (r >= PED16_LOW) {                                       // the 8-bit window 30 and the 4-bit top window: copied
-        const uint32_t tail = r - PED16_LOW;
-        store_aff(t16 + idx, load_aff(src + (tail < 255 ? 30 * 255 + tail : PED_LOW_ENTRIES + (tail - 255))));
-        return;
+    // source entries of the two halves: a 16-bit window joins 8-bit windows 2w and 2w+1; the top
+    // window joins 8-bit window 30 (bits 240..247) and the 4-bit table of the high base point
+    uint32_t lo, hi;
+    const Aff *src_lo, *src_hi;
+    if (r >= PED16_LOW) {
+        const uint32_t j = r - PED16_LOW + 1;
+        lo = j & 255u; hi = j >> 8;
+        src_lo = src + 30 * 255; src_hi = src + PED_LOW_ENTRIES;
+    } else {
+        const uint32_t w = r / PED16_SPAN, j = r % PED16_SPAN + 1;
+        lo = j & 255u; hi = j >> 8;
+        src_lo = src + (2 * w) * 255; src_hi = src + (2 * w + 1) * 255;
     }
-    const uint32_t w = r / PED16_SPAN, j = r % PED16_SPAN + 1, lo = j & 255u, hi = j >> 8;
-    if (!hi) { store_aff(t16 + idx, load_aff(src + (2 * w) * 255 + (lo - 1))); return; }
-    if (!lo) { store_aff(t16 + idx, load_aff(src + (2 * w + 1) * 255 + (hi - 1))); return; }
-    const AffL a = load_affl(src + (2 * w) * 255 + (lo - 1)), b = load_affl(src + (2 * w + 1) * 255 + (hi - 1));
+    if (!hi) { store_aff(t16 + idx, load_aff(src_lo + (lo - 1))); return; }
+    if (!lo) { store_aff(t16 + idx, load_aff(src_hi + (hi - 1))); return; }
+    const AffL a = load_affl(src_lo + (lo - 1)), b = load_affl(src_hi + (hi - 1));
     JacL acc; acc.x = a.x; acc.y = a.y; acc.z = fl_one();
     acc = jacl_add_aff(acc, b);
     const Fl zi = fn_inv(acc.z), zi2 = fn_sqr(zi);
@@ -309,10 +340,8 @@ __device__ __forceinline__ void ped_accumulate(JacL &acc, const Fp &canon, const
         const u32 d = (canon.v[w >> 1] >> (16 * (w & 1))) & 0xffffu;
         if (d) acc = jacl_add_aff(acc, load_affl(tab + (size_t)w * PED16_SPAN + (d - 1)));
     }
-    const u32 d8 = (canon.v[7] >> 16) & 0xffu;    // bits 240..247
-    if (d8) acc = jacl_add_aff(acc, load_affl(tab + PED16_LOW + (d8 - 1)));
-    const u32 dh = (canon.v[7] >> 24) & 0xfu;     // bits 248..251
-    if (dh) acc = jacl_add_aff(acc, load_affl(tab + PED16_LOW + 255 + (dh - 1)));
+    const u32 dt = (canon.v[7] >> 16) & 0xfffu;   // bits 240..251
+    if (dt) acc = jacl_add_aff(acc, load_affl(tab + PED16_LOW + (dt - 1)));
 }
 
 // both inputs canonical (< p); leaves the Jacobian (X, Z) of P0 + a-part + b-part as weakly reduced images
@@ -368,6 +397,43 @@ __global__ __launch_bounds__(64) void pedersen_acc_pairs_kernel(const Aff *__res
     const Fp ca = be_bytes_to_canon(in + 64 * k), cb = be_bytes_to_canon(in + 64 * k + 32);
     ped_jacobian(ca, cb, table, shift, xz + k, xz + count + k);
 }
+
+// Small levels (the top of every tree: a few thousand hashes or fewer, one level after the
+// other) are latency bound: 32 dependent mixed additions per hash with most of the chip idle.
+// There, 32 lanes share one hash: lane (input e, window w) fetches its window's table point, the
+// 32 partial results meet in a 5-step butterfly of full Jacobian additions (cross-lane
+// shuffles), and lane 0 adds the shift point: 6 dependent additions instead of 32.
+__device__ __forceinline__ Fl fl_shfl_xor(const Fl &a, int mask) {
+    Fl r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (u32)__shfl_xor((int)a.l[i], mask, 64);
+    return r;
+}
+__global__ __launch_bounds__(64) void pedersen_acc_pairs_split_kernel(const Aff *__restrict__ table, Aff shift,
+                                                                      const uint8_t *__restrict__ in, uint64_t count,
+                                                                      Fp *__restrict__ xz) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t k = t >> 5;
+    if (k >= count) return;                                 // whole 32-lane groups leave together
+    const uint32_t sub = (uint32_t)t & 31u, e = sub >> 4, w = sub & 15u;
+    const Fp c = be_bytes_to_canon(in + 64 * k + 32 * e);
+    const u32 d = w < (u32)PED_W16 ? (c.v[w >> 1] >> (16 * (w & 1))) & 0xffffu : (c.v[7] >> 16) & 0xfffu;
+    const Aff *tab = table + (size_t)e * PED16_PER_INPUT + (w < (u32)PED_W16 ? (size_t)w * PED16_SPAN : (size_t)PED16_LOW);
+    JacL pt; pt.x = fl_one(); pt.y = fl_one(); pt.z = fl_zero();
+    if (d) { const AffL q = load_affl(tab + (d - 1)); pt.x = q.x; pt.y = q.y; pt.z = fl_one(); }
+#pragma unroll 1
+    for (int m = 16; m >= 1; m >>= 1) {
+        JacL o; o.x = fl_shfl_xor(pt.x, m); o.y = fl_shfl_xor(pt.y, m); o.z = fl_shfl_xor(pt.z, m);
+        pt = jacl_add(pt, o);
+    }
+    if (sub == 0) {
+        AffL sh; sh.x = fl_from_fp(shift.x); sh.y = fl_from_fp(shift.y);
+        pt = jacl_add_aff(pt, sh);
+        store_felt(xz + k, fl_pack(pt.x));
+        store_felt(xz + count + k, fl_pack(pt.z));
+    }
+}
+static constexpr uint64_t PED_SPLIT_MAX = 4096;             // hashes per level at or below which lanes are split
 
 // ---- phase 2: x = X / Z^2, `chunk` hashes per lane (k = j * lanes + lane), one inversion per lane ----
 // Montgomery's trick with the prefix products in tmp[2 count ..).  A point at infinity (Z = 0:
@@ -432,8 +498,12 @@ hipError_t launch_pedersen_felts(hipStream_t st, const PedersenTables *t, const 
 hipError_t launch_pedersen_pairs(hipStream_t st, const PedersenTables *t, const uint8_t *in, uint64_t count,
                                  uint8_t *out, Fp *tmp) {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(pedersen_acc_pairs_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table,
-                       t->shift, in, count, tmp);
+    if (count <= PED_SPLIT_MAX)
+        hipLaunchKernelGGL(pedersen_acc_pairs_split_kernel, dim3((uint32_t)((count * 32 + 63) / 64)), dim3(64), 0, st,
+                           t->d_table, t->shift, in, count, tmp);
+    else
+        hipLaunchKernelGGL(pedersen_acc_pairs_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table,
+                           t->shift, in, count, tmp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_finish(st, tmp, count, nullptr, out);

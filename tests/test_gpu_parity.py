@@ -238,6 +238,19 @@ def test_merkle_vs_oracle(ctx, be, oracle, tree, leaf_kind, nf, log_n):
             k >>= 1
 
 
+def test_friendly_merkle_large_and_small_levels(ctx, be, oracle):
+    """A 2^14-leaf all-Pedersen tree crosses both Pedersen paths: one lane per hash on the levels
+    above 4096 nodes, 32 lanes per hash (window-split, butterfly of Jacobian additions) below."""
+    n = 1 << 14
+    leaves = oracle.hash_rows(be.HASH_BLAKE2S_M20, [random_column(n, 11), random_column(n, 12)])
+    want_nodes, want_tags = oracle.merkle_build(2, 22, 0, leaves)
+    d_leaves = ctx.alloc(32 * n).upload(leaves)
+    nodes, tags = ctx.alloc(64 * n), ctx.alloc(2 * n)
+    root, _ = ctx.merkle_build(2, 22, 0, d_leaves, n, nodes, tags)
+    assert np.array_equal(nodes.download(np.uint8, (2 * n, 32))[1:], want_nodes[1:])
+    assert root == bytes(want_nodes[1])
+
+
 def test_merkle_tree_classes(ctx, be, oracle):
     """from_matrix / root / prove on the reference's 8-row test matrices (merkle/mod.rs:455-634)."""
     col = oracle.to_mont(list(range(8)))
