@@ -940,22 +940,24 @@ ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64
     const uint64_t N = 1ull << log_N;
     uint64_t lanes = 256ull * 256 * 4;                 // 4 workgroups of 256 per CU
     if (lanes > N) lanes = N < 256 ? 256 : N;
-    const size_t code_b = ((size_t)prog->n_instr + 1) * 16, const_b = (size_t)(prog->n_consts ? prog->n_consts : 1) * 32;
-    const size_t desc_b = (size_t)(prog->n_tables ? prog->n_tables : 1) * 8;
+    const size_t code_b = ((size_t)prog->n_instr + 1) * 32, const_b = (size_t)(prog->n_consts ? prog->n_consts : 1) * 32;
     const size_t slots_b = (size_t)(prog->n_slots ? prog->n_slots : 1) * lanes * 32;
-    ss_status st = ctx->ensure_scratch(slots_b + const_b + code_b + desc_b + 256);
+    ss_status st = ctx->ensure_scratch(slots_b + const_b + code_b + 256);
     if (st != SS_OK) return st;
     char *p = (char *)ctx->scratch;
     Fp *d_slots = (Fp *)p; p += slots_b;
     Fp *d_consts = (Fp *)p; p += const_b;
-    uint32_t *d_code = (uint32_t *)p; p += code_b;
-    uint32_t *d_desc = (uint32_t *)p;
+    uint32_t *d_code = (uint32_t *)p;
     hipStream_t s = ctx->stream;
-    std::vector<uint32_t> dev_code(((size_t)prog->n_instr + 1) * 4);
-    quotient_build_device_code(prog->code, prog->n_instr, dev_code.data());
+    // resolve operands and lazy-form bounds on the host (quotient.hip: "device program")
+    VmResolve rs;
+    for (int c = 0; c < MAX_COLS; ++c) rs.cols[c] = c < (int)ncols ? (const void *)d_lde_cols[c] : nullptr;
+    rs.consts = d_consts; rs.tables = prog->d_tables; rs.slots = d_slots; rs.table_desc = prog->table_desc;
+    rs.lanes = lanes; rs.log_N = log_N; rs.log_blowup = log_blowup;
+    std::vector<uint32_t> dev_code(((size_t)prog->n_instr + 1) * 8);
+    quotient_build_device_code(prog->code, prog->n_instr, rs, dev_code.data());
     HIP_TRY(hipMemcpyAsync(d_code, dev_code.data(), code_b, hipMemcpyHostToDevice, s));
     if (prog->n_consts) HIP_TRY(hipMemcpyAsync(d_consts, prog->consts, (size_t)prog->n_consts * 32, hipMemcpyHostToDevice, s));
-    if (prog->n_tables) HIP_TRY(hipMemcpyAsync(d_desc, prog->table_desc, (size_t)prog->n_tables * 8, hipMemcpyHostToDevice, s));
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp w = root_of_unity(log_N);
     // optional XCD-contiguous sweep (measured: no gain, the per-XCD window still exceeds L2)
@@ -963,9 +965,7 @@ ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64
                                 getenv("SS_QUOTIENT_XCD_SPLIT") != nullptr) ? 1u : 0u;
     const Fp wstep = fp_pow_u64(w, xcd_split ? (lanes >> 3) : lanes);
     ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
-    HIP_TRY(launch_quotient_vm(s, (const void *const *)d_lde_cols, ncols, d_code, prog->n_instr, d_consts,
-                               (const Fp *)prog->d_tables, d_desc, d_slots, lanes, off, w, wstep, log_N, log_blowup,
-                               xcd_split, (Fp *)d_out));
+    HIP_TRY(launch_quotient_vm(s, d_code, prog->n_instr + 1, d_slots, lanes, off, w, wstep, log_N, xcd_split, (Fp *)d_out));
     HIP_TRY(hipStreamSynchronize(s));      // the caller's host arrays may go away after return
     return SS_OK;
 }

@@ -82,11 +82,17 @@ hipError_t launch_gather_cells(hipStream_t st, const void *const *cols, uint32_t
                                const uint64_t *idx, uint32_t n, Fp *out);
 
 // ---- quotient.hip
-// caller's 2-word program -> (n_instr + 1) x 4-word device stream with operand prefetch hints
-void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, uint32_t *dev);
-hipError_t launch_quotient_vm(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *d_code,
-                              uint32_t n_instr, const Fp *d_consts, const Fp *d_tables, const uint32_t *d_table_desc,
-                              Fp *d_slots, uint64_t lanes, const Fp &offset, const Fp &w, const Fp &wstep,
-                              uint32_t log_N, uint32_t log_blowup, uint32_t xcd_split, Fp *out);
+// what ss_eval_quotient knows and the device program needs resolved (device addresses, sizes)
+struct VmResolve {
+    const void *cols[MAX_COLS];
+    const void *consts, *tables, *slots;
+    const uint32_t *table_desc;      // host copy: [n_tables][2] = (offset in felts, log2 length)
+    uint64_t lanes;
+    uint32_t log_N, log_blowup;
+};
+// caller's 2-word program -> resolved device program: (n_instr + 1) entries of 8 words (quotient.hip)
+void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, const VmResolve &r, uint32_t *dev);
+hipError_t launch_quotient_vm(hipStream_t st, const uint32_t *d_code, uint32_t n_entries, Fp *d_slots, uint64_t lanes,
+                              const Fp &offset, const Fp &w, const Fp &wstep, uint32_t log_N, uint32_t xcd_split, Fp *out);
 
 }  // namespace ss

@@ -26,9 +26,16 @@
 //     ds_read_b128), one pad slot per 8 so the stride-8/64 patterns of the
 //     radix-8 groups spread over all banks.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "fp252.h"
 #include "fl252.h"
 #include "kernels.h"
+
+#ifdef SS_NTT_ABL_NOBAR      // timing ablation only: no workgroup barriers
+#define NTT_SYNC() do {} while (0)
+#else
+#define NTT_SYNC() __syncthreads()
+#endif
 
 namespace ss {
 
@@ -64,6 +71,9 @@ struct Tile {
     u32 *top;
 };
 __device__ __forceinline__ Fl lds_load(const Tile &t, int e) {
+#ifdef SS_NTT_ABL_NOLDS
+    { Fl r; for (int i = 0; i < 9; ++i) r.l[i] = (u32)e * 2654435761u + i; r.l[8] &= 0xfffffffu; return r; }
+#endif
     const int s = lds_slot(e);
     const uint4 a = t.lo[s], b = t.hi[s];
     Fl r;
@@ -73,12 +83,19 @@ __device__ __forceinline__ Fl lds_load(const Tile &t, int e) {
     return r;
 }
 __device__ __forceinline__ void lds_store(const Tile &t, int e, const Fl &x) {
+#ifdef SS_NTT_ABL_NOLDS      // timing ablation only: no LDS traffic (keeps one conditional store alive)
+    if (x.l[0] == 0xdeadbeefu && x.l[5] == 77u) t.top[e] = x.l[8];
+    return;
+#endif
     const int s = lds_slot(e);
     t.lo[s] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
     t.hi[s] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
     t.top[e] = x.l[8];
 }
 __device__ __forceinline__ Fp gload(const Fp *p) {
+#ifdef SS_NTT_ABL_NOGL       // timing ablation only: no global loads
+    { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = (u32)(size_t)p * 2246822519u + i; r.v[7] &= 0x7ffffffu; return r; }
+#endif
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
     uint4 a = q[0], b = q[1];
     Fp r;
@@ -87,6 +104,9 @@ __device__ __forceinline__ Fp gload(const Fp *p) {
     return r;
 }
 __device__ __forceinline__ void gstore(Fp *p, const Fp &x) {
+#ifdef SS_NTT_ABL_NOGL       // timing ablation only: (almost) no global stores
+    if (!(x.v[0] == 0xdeadbeefu && x.v[3] == 77u)) return;
+#endif
     uint4 *q = reinterpret_cast<uint4 *>(p);
     q[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
     q[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
@@ -101,6 +121,7 @@ struct PassParams {
     uint32_t log_expand;  // source index = element index >> log_expand
     uint32_t scale_pow2;  // DIF only: multiply outputs by 2^-scale_pow2 (0 = off)
     uint32_t contig;      // 1: s0 == 0, tile is a contiguous block
+    uint32_t stagger;     // start delay (units of s_sleep 127 ~ 3.4 us) of every second resident set of workgroups
     uint32_t final_pass;  // 1: last pass of the transform, outputs are canonical (< p);
                           // 0: outputs are weakly reduced 256-bit images (< 2^252) for the next pass
 };
@@ -260,11 +281,18 @@ __global__ __launch_bounds__(DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, DIF ? SS
 
     // Strided passes read/write HBM from the first/last register group directly; the
     // contiguous pass (tile = one 64 KiB block, first group of stride 1) stages through LDS.
+    // Workgroups of one launch are identical, so without this they stay in lock-step: all load
+    // (HBM saturated, VALU idle), then all multiply (HBM idle).  Delaying the second workgroup
+    // slot of every CU by about half a tile time puts the two slots in anti-phase; later
+    // workgroups inherit the offset because they start when a slot frees.
+    if (p.stagger && ((blockIdx.y * gridDim.x + blockIdx.x) >> 8) == 1u) {      // workgroups 256..511 only
+        for (uint32_t k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+    }
     const bool fuse = !p.contig;
     if (!fuse) {
         for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x)
             lds_store(t, x, fl_from_fp(gload(src + (tile_gindex(p, tile, x) >> p.log_expand))));
-        __syncthreads();
+        NTT_SYNC();
     }
 
     if (!DIF) {
@@ -279,7 +307,7 @@ __global__ __launch_bounds__(DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, DIF ? SS
             else run_group<false, 1>(t, tw, p, u, tile, last, fg, tg, src, dst);
             u += g;
             first = false;
-            if (!last || !fuse) __syncthreads();
+            if (!last || !fuse) NTT_SYNC();
         }
     } else {
         uint32_t u = p.r;
@@ -293,7 +321,7 @@ __global__ __launch_bounds__(DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, DIF ? SS
             else if (g == 2) run_group<true, 2>(t, tw, p, u, tile, last, fg, tg, src, dst);
             else run_group<true, 1>(t, tw, p, u, tile, last, fg, tg, src, dst);
             first = false;
-            if (!last || !fuse) __syncthreads();
+            if (!last || !fuse) NTT_SYNC();
         }
     }
 
@@ -366,6 +394,8 @@ hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32
                            uint32_t log_expand, uint32_t scale_pow2, bool final_pass) {
     PassParams p;
     p.final_pass = final_pass ? 1u : 0u;
+    static const uint32_t stagger = [] { const char *e = getenv("SS_NTT_STAGGER"); return e ? (uint32_t)atoi(e) : 0u; }();
+    p.stagger = stagger;
     p.log_n = log_n; p.s0 = s0; p.r = r; p.log_tile = log_tile; p.u_first = u_first;
     p.log_expand = log_expand; p.scale_pow2 = scale_pow2; p.contig = (s0 == 0);
     const uint32_t tiles = 1u << (log_n - log_tile);

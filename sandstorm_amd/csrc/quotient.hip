@@ -34,85 +34,54 @@ __device__ __forceinline__ void qstore(Fp *p, const Fp &x) {
 }
 
 struct VmArgs {
-    const Fp *cols[MAX_COLS];
-    const uint32_t *code;
-    const Fp *consts;
-    const Fp *tables;
-    const uint32_t *table_desc;
+    const uint32_t *code;    // device program, 8 words per entry (see below)
     Fp *slots;               // [n_slots][total_lanes]
     Fp *out;
     Fp offset, w, wstep;     // x_i = offset * w^i; wstep = w^(total lanes)
-    uint32_t n_instr, log_N, log_blowup, xcd_split;
+    uint32_t n_entries, log_N, xcd_split;
 };
 
-// Accumulators live in the lazy 9 x 28-bit form (fl252.h).  Because the program is
-// wave-uniform, a per-accumulator bound b (value < 2 b p, limbs < b 2^28) is tracked in
-// scalar registers: ADD / SUB are nine carry-less 32-bit adds that bump the bound, and a
-// weak reduction is issued (a uniform branch) only when an operation's precondition
-// needs it:  fl_mul   a-side any b <= 8, b-side b == 1;   fl_sub_c<2,1> subtrahend b == 1;
-// ST / table-free operands from memory are always b == 1.
+// ---- device program -------------------------------------------------------------------------
+// The interpreter's non-multiplying instructions are bound by SCALAR issue, not by the vector
+// ALU (measured, profiles/r01_quotient_vm_experiments.txt: ~90 SALU per instruction = 360 cycles
+// per SIMD against 68 VALU = 272): operand-kind decoding, the 12-way column select, table
+// descriptor loads and the lazy-bound bookkeeping all ran on the one scalar unit a CU has.  The
+// program is static, so ss_eval_quotient does that work once on the host and ships a resolved
+// stream, 8 words per entry:
+//   w0  control: op[0:3] d[4:5] src class[6:7] (0 memory, 1 accumulator, 2 x) src acc[8:9]
+//       RV[10] weakly reduce the destination first   RS[11] weakly reduce the source first
+//       P[12]  start loading the NEXT memory operand  PL[13] its index is the lane (slot file), not the point
+//   w1  slot index (ST)
+//   w2,w3 / w4 / w5   next operand: base pointer / index offset / index mask:
+//       address = base + 32 * ((index + offset) & mask)
+//       trace cell: base = column, offset = row_offset << log_blowup, mask = N - 1
+//       table: base = table start, mask = period - 1     constant: mask = 0     slot: base = slot row, index = lane
+// Entry 0 is a no-op that primes the pipeline.  The lazy-form bounds (value < 2 b p, limbs < b 2^28,
+// b <= VM_MAX_BOUND) are tracked by the host with the rules below, which decide RV / RS:
+//   ADD  needs b_v + b_s <= 8 (reduce v, then s, while it does not hold); b_v += b_s
+//   SUB  subtrahend b_s == 1; b_v + 1 <= 8; b_v += 1        RSUB  b_v == 1; b_s + 1 <= 8; b_v = b_s + 1
+//   MUL  b_s == 1 (the accumulator side takes any b <= 8); b_v = 1
+//   INV  reduced input; ST stores a reduced image (and keeps it); memory operands and x are b = 1
 static constexpr uint32_t VM_MAX_BOUND = 8;       // 8 * 2p * 2p / 2^256 + p < 2p: products stay < 2^252
+static constexpr uint32_t VM_OP_NOP = 8;
+static constexpr uint32_t VM_F_RV = 1u << 10, VM_F_RS = 1u << 11, VM_F_P = 1u << 12, VM_F_PL = 1u << 13;
 
-// One instruction on a NAMED accumulator (v, vb): the destination index is wave-uniform,
-// so the caller dispatches with a scalar switch to one of four inlined copies of this body
-// instead of selecting registers with v_cndmask chains.
-__device__ __forceinline__ void vm_exec(uint32_t op, Fl &v, uint32_t &vb, Fl src, uint32_t sb, const VmArgs &a,
-                                        uint32_t w1, uint64_t lanes, uint64_t lane, uint64_t i) {
-    switch (op) {
-    case SS_OP_MOV: v = src; vb = sb; break;
-    case SS_OP_ADD:
-        if (vb + sb > VM_MAX_BOUND) { v = fl_weak_reduce(v); vb = 1; }
-        if (vb + sb > VM_MAX_BOUND) { src = fl_weak_reduce(src); sb = 1; }
-        v = fl_add(v, src); vb += sb;
-        break;
-    case SS_OP_SUB:
-        if (sb > 1) { src = fl_weak_reduce(src); sb = 1; }
-        if (vb + 1 > VM_MAX_BOUND) { v = fl_weak_reduce(v); vb = 1; }
-        v = fl_sub_c<2, 1>(v, src); vb += 1;
-        break;
-    case SS_OP_RSUB:
-        if (vb > 1) { v = fl_weak_reduce(v); vb = 1; }
-        if (sb + 1 > VM_MAX_BOUND) { src = fl_weak_reduce(src); sb = 1; }
-        v = fl_sub_c<2, 1>(src, v); vb = sb + 1;
-        break;
-    case SS_OP_MUL:
-        if (sb > 1) { src = fl_weak_reduce(src); sb = 1; }
-        v = fl_mul(v, src); vb = 1;                // vb <= VM_MAX_BOUND by construction
-        break;
-    case SS_OP_INV: v = fn_inv(fl_weak_reduce(v)); vb = 1; break;
-    case SS_OP_ST:
-        if (vb > 1) { v = fl_weak_reduce(v); vb = 1; }      // slots hold weakly reduced images
-        qstore(a.slots + (uint64_t)w1 * lanes + lane, fl_pack(v));
-        break;
+// One instruction on a NAMED accumulator: the destination index is wave-uniform, so the caller
+// dispatches with a scalar switch to one of four inlined copies of this body.
+__device__ __forceinline__ void vm_exec(uint32_t w0, Fl &v, const Fl &src, const VmArgs &a, uint32_t w1,
+                                        uint64_t lanes, uint64_t lane, uint64_t i) {
+    if (w0 & VM_F_RV) v = fl_weak_reduce(v);
+    switch (w0 & 0xfu) {
+    case SS_OP_MOV: v = src; break;
+    case SS_OP_ADD: v = fl_add(v, src); break;
+    case SS_OP_SUB: v = fl_sub_c<2, 1>(v, src); break;
+    case SS_OP_RSUB: v = fl_sub_c<2, 1>(src, v); break;
+    case SS_OP_MUL: v = fl_mul(v, src); break;
+    case SS_OP_INV: v = fn_inv(v); break;
+    case SS_OP_ST: qstore(a.slots + (uint64_t)w1 * lanes + lane, fl_pack(v)); break;     // weakly reduced image
     case SS_OP_OUT: qstore(a.out + i, fl_to_fp(v)); break;
     default: break;
     }
-}
-
-// Device instruction stream (built by ss_eval_quotient from the caller's 2-word program):
-// 4 words per entry  { w0 | pk << 16,  w1,  pw,  0 },  entry 0 is a no-op that primes the pipeline.
-// (pk, pw) names the memory operand (kind, payload) that THIS entry starts loading: the operand
-// of the next memory-consuming instruction, so that its L2/HBM round trip overlaps this
-// instruction's arithmetic.  Measured (profiles/r01_quotient_vm_experiments.txt): the kernel is
-// VALU-bound (295 k VALU instructions per 64-point wave-row), so one operand of lead is all
-// that pays; a deeper LDS-DMA operand ring (2 to 8 operands in flight) gave nothing more.
-static constexpr uint32_t VM_PK_NONE = 0xfu;
-static constexpr uint32_t VM_OP_NOP = 0xffu;
-
-__device__ __forceinline__ const Fp *vm_operand_ptr(const VmArgs &a, uint32_t kind, uint32_t w, uint64_t N,
-                                                    uint64_t lanes, uint64_t lane, uint64_t i) {
-    if (kind == SS_SRC_SLOT) return a.slots + (uint64_t)w * lanes + lane;
-    if (kind == SS_SRC_CONST) return a.consts + w;
-    if (kind == SS_SRC_TRACE) {
-        const uint32_t col = w >> 24;
-        const uint64_t row = (i + ((uint64_t)(w & 0xffffffu) << a.log_blowup)) & (N - 1);
-        const Fp *cp = a.cols[0];
-#pragma unroll
-        for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) cp = a.cols[c];
-        return cp + row;
-    }
-    const uint32_t off = a.table_desc[2 * w], ll = a.table_desc[2 * w + 1];
-    return a.tables + off + (i & ((1ull << ll) - 1ull));
 }
 
 __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
@@ -137,63 +106,109 @@ __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
     const uint4 *code = reinterpret_cast<const uint4 *>(a.code);
     for (uint64_t it = 0; it < count; ++it) {
         const uint64_t i = i0 + it * stride;
+        const uint32_t i32 = (uint32_t)i, lane32 = (uint32_t)lane;
         Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
-        uint32_t bnd0 = 1, bnd1 = 1, bnd2 = 1, bnd3 = 1;
         Fp pre = fp_zero();                                // the operand in flight
-        for (uint32_t pc = 0; pc < a.n_instr; ++pc) {
-            const uint4 ins = code[pc];
-            const uint32_t w0 = ins.x, w1 = ins.y, pw = ins.z;
-            const uint32_t op = w0 & 0xffu, d = (w0 >> 8) & 0xfu, kind = (w0 >> 12) & 0xfu, pk = (w0 >> 16) & 0xfu;
-            const bool mem = op <= SS_OP_MUL && kind >= SS_SRC_SLOT && kind <= SS_SRC_TABLE;
+        for (uint32_t pc = 0; pc < a.n_entries; ++pc) {
+            const uint4 c0 = code[2 * pc], c1 = code[2 * pc + 1];
+            const uint32_t w0 = c0.x, w1 = c0.y;
+            const uint32_t op = w0 & 0xfu;
             const Fp cur = pre;
             // start the next operand before this instruction's arithmetic; after an ST only once
             // the store has been issued (the operand may be the slot just written)
-            if (pk != VM_PK_NONE && op != SS_OP_ST) pre = qload(vm_operand_ptr(a, pk, pw, N, lanes, lane, i));
-            Fl src = fl_zero();
-            uint32_t sb = 1;                               // bound of src
-            if (mem) {
-                src = fl_from_fp(cur);                     // canonical or weakly reduced 256-bit image
-            } else if (op <= SS_OP_MUL) {
-                if (kind == SS_SRC_ACC) {
-                    switch (w1 & 3u) {
-                    case 0: src = acc0; sb = bnd0; break;
-                    case 1: src = acc1; sb = bnd1; break;
-                    case 2: src = acc2; sb = bnd2; break;
-                    default: src = acc3; sb = bnd3; break;
-                    }
-                } else {
-                    src = x;
+            const char *nbase = reinterpret_cast<const char *>(((uint64_t)c0.w << 32) | c0.z);
+            const uint32_t nidx = (((w0 & VM_F_PL) ? lane32 : i32) + c1.x) & c1.y;
+            const Fp *nptr = reinterpret_cast<const Fp *>(nbase + ((uint64_t)nidx << 5));
+            if ((w0 & VM_F_P) && op != SS_OP_ST) pre = qload(nptr);
+            Fl src;
+            switch ((w0 >> 6) & 3u) {
+            case 0: src = fl_from_fp(cur); break;          // canonical or weakly reduced 256-bit image
+            case 1:
+                switch ((w0 >> 8) & 3u) {
+                case 0: src = acc0; break;
+                case 1: src = acc1; break;
+                case 2: src = acc2; break;
+                default: src = acc3; break;
                 }
+                break;
+            default: src = x; break;
             }
-            switch (d) {
-            case 0: vm_exec(op, acc0, bnd0, src, sb, a, w1, lanes, lane, i); break;
-            case 1: vm_exec(op, acc1, bnd1, src, sb, a, w1, lanes, lane, i); break;
-            case 2: vm_exec(op, acc2, bnd2, src, sb, a, w1, lanes, lane, i); break;
-            default: vm_exec(op, acc3, bnd3, src, sb, a, w1, lanes, lane, i); break;
+            if (w0 & VM_F_RS) src = fl_weak_reduce(src);
+            switch ((w0 >> 4) & 3u) {
+            case 0: vm_exec(w0, acc0, src, a, w1, lanes, lane, i); break;
+            case 1: vm_exec(w0, acc1, src, a, w1, lanes, lane, i); break;
+            case 2: vm_exec(w0, acc2, src, a, w1, lanes, lane, i); break;
+            default: vm_exec(w0, acc3, src, a, w1, lanes, lane, i); break;
             }
-            if (pk != VM_PK_NONE && op == SS_OP_ST) pre = qload(vm_operand_ptr(a, pk, pw, N, lanes, lane, i));
+            if ((w0 & VM_F_P) && op == SS_OP_ST) pre = qload(nptr);
         }
         x = fl_mul(x, wstep);
     }
 }
 
-// 2-word caller program -> the 4-word device stream described above (n_instr + 1 entries).
-void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, uint32_t *dev) {
-    auto put = [&](uint32_t idx, uint32_t w0, uint32_t w1) {
-        dev[4 * idx] = w0 | (VM_PK_NONE << 16); dev[4 * idx + 1] = w1; dev[4 * idx + 2] = 0; dev[4 * idx + 3] = 0;
-    };
-    put(0, VM_OP_NOP, 0);
+// Caller's 2-word program -> resolved device program (n_instr + 1 entries of 8 words, see above).
+void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, const VmResolve &r, uint32_t *dev) {
+    auto is_mem = [](uint32_t op, uint32_t kind) { return op <= SS_OP_MUL && kind >= SS_SRC_SLOT && kind <= SS_SRC_TABLE; };
+    for (size_t k = 0; k < ((size_t)n_instr + 1) * 8; ++k) dev[k] = 0;
+    dev[0] = VM_OP_NOP;
+    uint32_t bound[4] = {1, 1, 1, 1};
     uint32_t last_node = 0, last_consumer = 0;     // entry indices; the priming no-op counts as both
     for (uint32_t pc = 0; pc < n_instr; ++pc) {
-        const uint32_t w0 = code[2 * pc] & 0xffffu, w1 = code[2 * pc + 1], idx = pc + 1;
-        const uint32_t op = w0 & 0xffu, kind = (w0 >> 12) & 0xfu;
-        put(idx, w0, w1);
-        if (op <= SS_OP_MUL && kind >= SS_SRC_SLOT && kind <= SS_SRC_TABLE) {
+        const uint32_t c0 = code[2 * pc], w1 = code[2 * pc + 1], idx = pc + 1;
+        const uint32_t op = c0 & 0xffu, d = (c0 >> 8) & 0x3u, kind = (c0 >> 12) & 0xfu;
+        const bool mem = is_mem(op, kind);
+        uint32_t w0 = op | (d << 4);
+        uint32_t sb = 1;
+        if (op <= SS_OP_MUL) {
+            if (mem) w0 |= 0u << 6;
+            else if (kind == SS_SRC_ACC) { w0 |= (1u << 6) | ((w1 & 3u) << 8); sb = bound[w1 & 3u]; }
+            else w0 |= 2u << 6;                                                   // x
+        }
+        uint32_t &vb = bound[d];
+        switch (op) {
+        case SS_OP_MOV: vb = sb; break;
+        case SS_OP_ADD:
+            if (vb + sb > VM_MAX_BOUND) { w0 |= VM_F_RV; vb = 1; }
+            if (vb + sb > VM_MAX_BOUND) { w0 |= VM_F_RS; sb = 1; }
+            vb += sb;
+            break;
+        case SS_OP_SUB:
+            if (sb > 1) { w0 |= VM_F_RS; sb = 1; }
+            if (vb + 1 > VM_MAX_BOUND) { w0 |= VM_F_RV; vb = 1; }
+            vb += 1;
+            break;
+        case SS_OP_RSUB:
+            if (vb > 1) { w0 |= VM_F_RV; vb = 1; }
+            if (sb + 1 > VM_MAX_BOUND) { w0 |= VM_F_RS; sb = 1; }
+            vb = sb + 1;
+            break;
+        case SS_OP_MUL:
+            if (sb > 1) { w0 |= VM_F_RS; sb = 1; }
+            vb = 1;
+            break;
+        case SS_OP_INV: w0 |= VM_F_RV; vb = 1; break;
+        case SS_OP_ST: if (vb > 1) { w0 |= VM_F_RV; vb = 1; } break;
+        default: break;                                                           // OUT reduces fully itself
+        }
+        dev[8 * idx] = w0;
+        dev[8 * idx + 1] = w1;
+        if (mem) {
             // a slot operand may only be requested after the last ST in front of it; anything
             // else is requested by the previous memory consumer, across any STs in between
             const uint32_t issuer = kind == SS_SRC_SLOT ? last_node : last_consumer;
-            dev[4 * issuer] = (dev[4 * issuer] & ~(0xfu << 16)) | (kind << 16);
-            dev[4 * issuer + 2] = w1;
+            uint64_t base = 0;
+            uint32_t off = 0, mask = 0, fl = VM_F_P;
+            if (kind == SS_SRC_TRACE) {
+                base = (uint64_t)r.cols[w1 >> 24]; off = (w1 & 0xffffffu) << r.log_blowup; mask = (uint32_t)((1ull << r.log_N) - 1ull);
+            } else if (kind == SS_SRC_TABLE) {
+                base = (uint64_t)r.tables + 32ull * r.table_desc[2 * w1]; mask = (uint32_t)((1ull << r.table_desc[2 * w1 + 1]) - 1ull);
+            } else if (kind == SS_SRC_CONST) {
+                base = (uint64_t)r.consts + 32ull * w1;
+            } else {
+                base = (uint64_t)r.slots + 32ull * w1 * r.lanes; mask = 0xffffffffu; fl |= VM_F_PL;
+            }
+            uint32_t *e = dev + 8 * (size_t)issuer;
+            e[0] |= fl; e[2] = (uint32_t)base; e[3] = (uint32_t)(base >> 32); e[4] = off; e[5] = mask;
             last_node = last_consumer = idx;
         } else if (op == SS_OP_ST) {
             last_node = idx;
@@ -201,16 +216,11 @@ void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, uint32_t
     }
 }
 
-hipError_t launch_quotient_vm(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *d_code,
-                              uint32_t n_instr, const Fp *d_consts, const Fp *d_tables, const uint32_t *d_table_desc,
-                              Fp *d_slots, uint64_t lanes, const Fp &offset, const Fp &w, const Fp &wstep,
-                              uint32_t log_N, uint32_t log_blowup, uint32_t xcd_split, Fp *out) {
+hipError_t launch_quotient_vm(hipStream_t st, const uint32_t *d_code, uint32_t n_entries, Fp *d_slots, uint64_t lanes,
+                              const Fp &offset, const Fp &w, const Fp &wstep, uint32_t log_N, uint32_t xcd_split, Fp *out) {
     VmArgs a;
-    for (int c = 0; c < MAX_COLS; ++c) a.cols[c] = c < (int)ncols ? (const Fp *)cols[c] : nullptr;
-    a.code = d_code; a.consts = d_consts; a.tables = d_tables; a.table_desc = d_table_desc; a.slots = d_slots;
-    a.out = out; a.offset = offset; a.w = w; a.wstep = wstep; a.n_instr = n_instr; a.log_N = log_N;
-    a.log_blowup = log_blowup; a.xcd_split = xcd_split;
-    a.n_instr = n_instr + 1;                 // d_code is the (n_instr + 1)-entry device stream
+    a.code = d_code; a.slots = d_slots; a.out = out; a.offset = offset; a.w = w; a.wstep = wstep;
+    a.n_entries = n_entries; a.log_N = log_N; a.xcd_split = xcd_split;
     hipLaunchKernelGGL(quotient_vm_kernel, dim3((uint32_t)(lanes / 256)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
