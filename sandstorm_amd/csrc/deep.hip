@@ -150,26 +150,42 @@ struct DeepArgs {
 // this is the trace-size sub-coset offset*<w_n>, enough to pin the degree < n DEEP
 // polynomial, which the caller then interpolates and re-expands (halves the pointwise work).
 // D / Dc are tables over that same sub-coset; group shifts are in sub-coset units.
+// Wave-uniform, read-only tables (cell columns, coefficients, group descriptors) are read through the
+// constant address space: scalar loads into SGPRs instead of a broadcast vector load per lane, and the
+// coefficient's re-limbing runs on the scalar unit.
+typedef uint32_t dk_u32x4 __attribute__((ext_vector_type(4)));
+typedef const uint32_t __attribute__((address_space(4))) *dk_const_u32;
+typedef const dk_u32x4 __attribute__((address_space(4))) *dk_const_u32x4;
+__device__ __forceinline__ Fp dload_uniform(const Fp *p) {
+    dk_const_u32x4 q = (dk_const_u32x4)(uintptr_t)p;
+    const dk_u32x4 a = q[0], b = q[1];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+
 __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ out) {
     const uint64_t M = 1ull << a.log_N;              // points evaluated
+    dk_const_u32 group_desc = (dk_const_u32)(uintptr_t)a.group_desc, cell_col = (dk_const_u32)(uintptr_t)a.cell_col;
     for (uint64_t m = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; m < M;
          m += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = m << a.log_stride;        // LDE row of this point
         Fl acc = fl_zero();                          // lazy sum of normalised products
         uint32_t acc_terms = 0;
         for (uint32_t g = 0; g < a.ngroups; ++g) {
-            const uint32_t shift = a.group_desc[3 * g], first = a.group_desc[3 * g + 1], cnt = a.group_desc[3 * g + 2];
+            const uint32_t shift = group_desc[3 * g], first = group_desc[3 * g + 1], cnt = group_desc[3 * g + 2];
             Fl inner = fl_zero();
             uint32_t terms = 0;
             for (uint32_t j = first; j < first + cnt; ++j) {
-                const uint32_t col = a.cell_col[j];
+                const uint32_t col = cell_col[j];
                 const Fp *tp = a.trace[0];
 #pragma unroll
                 for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) tp = a.trace[c];
-                inner = fl_add(inner, fl_mul(fl_from_fp(dload(tp + i)), fl_from_fp(dload(a.cell_coef + j))));
+                inner = fl_add(inner, fl_mul(fl_from_fp(dload(tp + i)), fl_from_fp(dload_uniform(a.cell_coef + j))));
                 if (++terms == 12) { inner = fl_weak_reduce(inner); terms = 1; }      // 12 x 1.13p < 16p
             }
-            inner = fn_sub(fl_weak_reduce(inner), fl_from_fp(dload(a.group_k + g)));
+            inner = fn_sub(fl_weak_reduce(inner), fl_from_fp(dload_uniform(a.group_k + g)));
             acc = fl_add(acc, fl_mul(inner, fl_from_fp(dload(a.D + ((m - shift) & (M - 1))))));
             if (++acc_terms == 12) { acc = fl_weak_reduce(acc); acc_terms = 1; }
         }
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ 
                 const Fp *hp = a.comp[0];
 #pragma unroll
                 for (int c = 1; c < 4; ++c) if (k == (uint32_t)c) hp = a.comp[c];
-                inner = fl_add(inner, fl_mul(fl_from_fp(dload(hp + i)), fl_from_fp(dload(a.comp_coef + k))));
+                inner = fl_add(inner, fl_mul(fl_from_fp(dload(hp + i)), fl_from_fp(dload_uniform(a.comp_coef + k))));
             }
             inner = fn_sub(fl_weak_reduce(inner), fl_from_fp(a.comp_k));
             acc = fl_add(acc, fl_mul(inner, fl_from_fp(dload(a.Dc + m))));

@@ -84,6 +84,17 @@ __device__ __forceinline__ void vm_exec(uint32_t w0, Fl &v, const Fl &src, const
     }
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((address_space(4))) vm_const_u32x4;      // constant address space
+typedef u32x4 __attribute__((address_space(1))) vm_global_u32x4;     // global address space
+__device__ __forceinline__ Fp vm_load(const vm_global_u32x4 *p) {
+    const u32x4 lo = p[0], hi = p[1];
+    Fp r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+
 __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
     const uint64_t N = 1ull << a.log_N;
     const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;
@@ -103,23 +114,25 @@ __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
     }
     Fl x = fl_from_fp(fp_mul(a.offset, fp_pow_u64(a.w, i0)));
     const Fl wstep = fl_from_fp(a.wstep);                                          // w^stride
-    const uint4 *code = reinterpret_cast<const uint4 *>(a.code);
+    // the program is read-only for the kernel's lifetime: constant address space => scalar loads
+    // (s_load_dwordx8 through the scalar cache) instead of a vector load + v_readfirstlane per word
+    const vm_const_u32x4 *code = (const vm_const_u32x4 *)(uintptr_t)a.code;
     for (uint64_t it = 0; it < count; ++it) {
         const uint64_t i = i0 + it * stride;
         const uint32_t i32 = (uint32_t)i, lane32 = (uint32_t)lane;
         Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
         Fp pre = fp_zero();                                // the operand in flight
         for (uint32_t pc = 0; pc < a.n_entries; ++pc) {
-            const uint4 c0 = code[2 * pc], c1 = code[2 * pc + 1];
+            const u32x4 c0 = code[2 * pc], c1 = code[2 * pc + 1];
             const uint32_t w0 = c0.x, w1 = c0.y;
             const uint32_t op = w0 & 0xfu;
             const Fp cur = pre;
             // start the next operand before this instruction's arithmetic; after an ST only once
             // the store has been issued (the operand may be the slot just written)
-            const char *nbase = reinterpret_cast<const char *>(((uint64_t)c0.w << 32) | c0.z);
+            const uint64_t nbase = ((uint64_t)c0.w << 32) | c0.z;
             const uint32_t nidx = (((w0 & VM_F_PL) ? lane32 : i32) + c1.x) & c1.y;
-            const Fp *nptr = reinterpret_cast<const Fp *>(nbase + ((uint64_t)nidx << 5));
-            if ((w0 & VM_F_P) && op != SS_OP_ST) pre = qload(nptr);
+            const vm_global_u32x4 *nptr = (const vm_global_u32x4 *)(uintptr_t)(nbase + ((uint64_t)nidx << 5));   // global, not flat
+            if ((w0 & VM_F_P) && op != SS_OP_ST) pre = vm_load(nptr);
             Fl src;
             switch ((w0 >> 6) & 3u) {
             case 0: src = fl_from_fp(cur); break;          // canonical or weakly reduced 256-bit image
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
             case 2: vm_exec(w0, acc2, src, a, w1, lanes, lane, i); break;
             default: vm_exec(w0, acc3, src, a, w1, lanes, lane, i); break;
             }
-            if ((w0 & VM_F_P) && op == SS_OP_ST) pre = qload(nptr);
+            if ((w0 & VM_F_P) && op == SS_OP_ST) pre = vm_load(nptr);
         }
         x = fl_mul(x, wstep);
     }
