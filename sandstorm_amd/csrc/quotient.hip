@@ -126,16 +126,16 @@ __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
             const u32x4 c0 = code[2 * pc], c1 = code[2 * pc + 1];
             const uint32_t w0 = c0.x, w1 = c0.y;
             const uint32_t op = w0 & 0xfu;
-            const Fp cur = pre;
             // start the next operand before this instruction's arithmetic; after an ST only once
             // the store has been issued (the operand may be the slot just written)
             const uint64_t nbase = ((uint64_t)c0.w << 32) | c0.z;
             const uint32_t nidx = (((w0 & VM_F_PL) ? lane32 : i32) + c1.x) & c1.y;
             const vm_global_u32x4 *nptr = (const vm_global_u32x4 *)(uintptr_t)(nbase + ((uint64_t)nidx << 5));   // global, not flat
-            if ((w0 & VM_F_P) && op != SS_OP_ST) pre = vm_load(nptr);
             Fl src;
             switch ((w0 >> 6) & 3u) {
-            case 0: src = fl_from_fp(cur); break;          // canonical or weakly reduced 256-bit image
+            case 0:                                        // canonical or weakly reduced 256-bit image:
+                src = fl_from_fp(pre);                     // re-limbed BEFORE the register is reloaded
+                break;
             case 1:
                 switch ((w0 >> 8) & 3u) {
                 case 0: src = acc0; break;
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
                 break;
             default: src = x; break;
             }
+            if ((w0 & VM_F_P) && op != SS_OP_ST) pre = vm_load(nptr);
             if (w0 & VM_F_RS) src = fl_weak_reduce(src);
             switch ((w0 >> 4) & 3u) {
             case 0: vm_exec(w0, acc0, src, a, w1, lanes, lane, i); break;
