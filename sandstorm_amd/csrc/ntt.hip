@@ -66,16 +66,22 @@ __device__ __forceinline__ int lds_slot(int e) { return e + (e >> 3); }
 // LDS tile in the lazy form: limbs 0-3 and 4-7 in two 16-byte planes (one pad slot per 8:
 // conflict-free ds_read_b128 for the stride-1/8/64 patterns of the radix-8 groups), limb 8
 // in a dword plane.  2048 elements = 80 KiB: two workgroups per CU.
+// Pointers carry the LDS address space explicitly: through a plain `uint4 *` in a struct the
+// compiler lost it on some paths and emitted flat_load_dword for the top-limb plane (flat accesses
+// count on vmcnt as well as lgkmcnt, so the exchange waited behind outstanding global traffic).
+typedef u32 lds_u32x4_t __attribute__((ext_vector_type(4)));
+typedef lds_u32x4_t __attribute__((address_space(3))) *lds_u32x4_ptr;
+typedef u32 __attribute__((address_space(3))) *lds_u32_ptr;
 struct Tile {
-    uint4 *lo, *hi;
-    u32 *top;
+    lds_u32x4_ptr lo, hi;
+    lds_u32_ptr top;
 };
 __device__ __forceinline__ Fl lds_load(const Tile &t, int e) {
 #ifdef SS_NTT_ABL_NOLDS
     { Fl r; for (int i = 0; i < 9; ++i) r.l[i] = (u32)e * 2654435761u + i; r.l[8] &= 0xfffffffu; return r; }
 #endif
     const int s = lds_slot(e);
-    const uint4 a = t.lo[s], b = t.hi[s];
+    const lds_u32x4_t a = t.lo[s], b = t.hi[s];
     Fl r;
     r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
     r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
@@ -88,8 +94,8 @@ __device__ __forceinline__ void lds_store(const Tile &t, int e, const Fl &x) {
     return;
 #endif
     const int s = lds_slot(e);
-    t.lo[s] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
-    t.hi[s] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    t.lo[s] = lds_u32x4_t{x.l[0], x.l[1], x.l[2], x.l[3]};
+    t.hi[s] = lds_u32x4_t{x.l[4], x.l[5], x.l[6], x.l[7]};
     t.top[e] = x.l[8];
 }
 __device__ __forceinline__ Fp gload(const Fp *p) {
@@ -265,9 +271,9 @@ __global__ __launch_bounds__(DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, DIF ? SS
     const uint32_t tile_elems = 1u << p.log_tile;
     const uint32_t slots = tile_elems + (tile_elems >> 3);
     Tile t;
-    t.lo = reinterpret_cast<uint4 *>(smem);
+    t.lo = (lds_u32x4_ptr)smem;
     t.hi = t.lo + slots;
-    t.top = reinterpret_cast<u32 *>(t.hi + slots);
+    t.top = (lds_u32_ptr)(t.hi + slots);
     const uint32_t tile = blockIdx.x;
     // select this block's column with scalar compares: a dynamically indexed by-value
     // kernarg struct would be copied to scratch
