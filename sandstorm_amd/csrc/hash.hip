@@ -26,36 +26,68 @@ __constant__ uint64_t KECCAK_RC[24] = {
     0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
     0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+// Keccak-f[1600] on 32-bit halves, written for the gfx950 VALU: a 64-bit rotation is two full-rate
+// v_alignbit_b32 (the compiler's 64-bit shift pairs are quarter rate), chi's a ^ (~b & c) and theta's
+// 3-way xors are single v_bitop3_b32 instructions.  ~190 VALU per round instead of ~290.
+struct K64 { uint32_t lo, hi; };
+__device__ __forceinline__ K64 k_split(uint64_t x) { K64 r; r.lo = (uint32_t)x; r.hi = (uint32_t)(x >> 32); return r; }
+__device__ __forceinline__ uint64_t k_join(const K64 &x) { return ((uint64_t)x.hi << 32) | x.lo; }
+template <int N>
+__device__ __forceinline__ K64 k_rotl(const K64 &x) {
+    K64 r;
+    if (N == 0) { r = x; }
+    else if (N == 32) { r.lo = x.hi; r.hi = x.lo; }
+    else if (N < 32) {
+        r.hi = __builtin_amdgcn_alignbit(x.hi, x.lo, 32 - N);       // (hi:lo) >> (32 - N), low word
+        r.lo = __builtin_amdgcn_alignbit(x.lo, x.hi, 32 - N);
+    } else {
+        r.hi = __builtin_amdgcn_alignbit(x.lo, x.hi, 64 - N);
+        r.lo = __builtin_amdgcn_alignbit(x.hi, x.lo, 64 - N);
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t k_xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t k_chi(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xD2); }   // a ^ (~b & c)
+__device__ __forceinline__ K64 k_xor5(const K64 &a, const K64 &b, const K64 &c, const K64 &d, const K64 &e) {
+    K64 r; r.lo = k_xor3(k_xor3(a.lo, b.lo, c.lo), d.lo, e.lo); r.hi = k_xor3(k_xor3(a.hi, b.hi, c.hi), d.hi, e.hi); return r;
+}
+__device__ __forceinline__ K64 k_xor(const K64 &a, const K64 &b) { K64 r; r.lo = a.lo ^ b.lo; r.hi = a.hi ^ b.hi; return r; }
+__device__ __forceinline__ K64 k_chi64(const K64 &a, const K64 &b, const K64 &c) { K64 r; r.lo = k_chi(a.lo, b.lo, c.lo); r.hi = k_chi(a.hi, b.hi, c.hi); return r; }
+template <int N>
+__device__ __forceinline__ K64 k_xrot(const K64 &a, const K64 &d) { return k_rotl<N>(k_xor(a, d)); }
 
-__device__ __forceinline__ void keccak_f1600(uint64_t s[25]) {
+__device__ __forceinline__ void keccak_f1600(uint64_t st[25]) {
+    K64 s[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) s[i] = k_split(st[i]);
 #pragma unroll 1
     for (int round = 0; round < 24; ++round) {
-        uint64_t c0 = s[0] ^ s[5] ^ s[10] ^ s[15] ^ s[20];
-        uint64_t c1 = s[1] ^ s[6] ^ s[11] ^ s[16] ^ s[21];
-        uint64_t c2 = s[2] ^ s[7] ^ s[12] ^ s[17] ^ s[22];
-        uint64_t c3 = s[3] ^ s[8] ^ s[13] ^ s[18] ^ s[23];
-        uint64_t c4 = s[4] ^ s[9] ^ s[14] ^ s[19] ^ s[24];
-        uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1);
-        uint64_t d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);
+        const K64 c0 = k_xor5(s[0], s[5], s[10], s[15], s[20]), c1 = k_xor5(s[1], s[6], s[11], s[16], s[21]);
+        const K64 c2 = k_xor5(s[2], s[7], s[12], s[17], s[22]), c3 = k_xor5(s[3], s[8], s[13], s[18], s[23]);
+        const K64 c4 = k_xor5(s[4], s[9], s[14], s[19], s[24]);
+        const K64 d0 = k_xor(c4, k_rotl<1>(c1)), d1 = k_xor(c0, k_rotl<1>(c2)), d2 = k_xor(c1, k_rotl<1>(c3));
+        const K64 d3 = k_xor(c2, k_rotl<1>(c4)), d4 = k_xor(c3, k_rotl<1>(c0));
         // theta + rho + pi into b
-        uint64_t b0 = s[0] ^ d0;
-        uint64_t b10 = rotl64(s[1] ^ d1, 1), b20 = rotl64(s[2] ^ d2, 62), b5 = rotl64(s[3] ^ d3, 28);
-        uint64_t b15 = rotl64(s[4] ^ d4, 27), b16 = rotl64(s[5] ^ d0, 36), b1 = rotl64(s[6] ^ d1, 44);
-        uint64_t b11 = rotl64(s[7] ^ d2, 6), b21 = rotl64(s[8] ^ d3, 55), b6 = rotl64(s[9] ^ d4, 20);
-        uint64_t b7 = rotl64(s[10] ^ d0, 3), b17 = rotl64(s[11] ^ d1, 10), b2 = rotl64(s[12] ^ d2, 43);
-        uint64_t b12 = rotl64(s[13] ^ d3, 25), b22 = rotl64(s[14] ^ d4, 39), b23 = rotl64(s[15] ^ d0, 41);
-        uint64_t b8 = rotl64(s[16] ^ d1, 45), b18 = rotl64(s[17] ^ d2, 15), b3 = rotl64(s[18] ^ d3, 21);
-        uint64_t b13 = rotl64(s[19] ^ d4, 8), b14 = rotl64(s[20] ^ d0, 18), b24 = rotl64(s[21] ^ d1, 2);
-        uint64_t b9 = rotl64(s[22] ^ d2, 61), b19 = rotl64(s[23] ^ d3, 56), b4 = rotl64(s[24] ^ d4, 14);
+        const K64 b0 = k_xor(s[0], d0);
+        const K64 b10 = k_xrot<1>(s[1], d1), b20 = k_xrot<62>(s[2], d2), b5 = k_xrot<28>(s[3], d3);
+        const K64 b15 = k_xrot<27>(s[4], d4), b16 = k_xrot<36>(s[5], d0), b1 = k_xrot<44>(s[6], d1);
+        const K64 b11 = k_xrot<6>(s[7], d2), b21 = k_xrot<55>(s[8], d3), b6 = k_xrot<20>(s[9], d4);
+        const K64 b7 = k_xrot<3>(s[10], d0), b17 = k_xrot<10>(s[11], d1), b2 = k_xrot<43>(s[12], d2);
+        const K64 b12 = k_xrot<25>(s[13], d3), b22 = k_xrot<39>(s[14], d4), b23 = k_xrot<41>(s[15], d0);
+        const K64 b8 = k_xrot<45>(s[16], d1), b18 = k_xrot<15>(s[17], d2), b3 = k_xrot<21>(s[18], d3);
+        const K64 b13 = k_xrot<8>(s[19], d4), b14 = k_xrot<18>(s[20], d0), b24 = k_xrot<2>(s[21], d1);
+        const K64 b9 = k_xrot<61>(s[22], d2), b19 = k_xrot<56>(s[23], d3), b4 = k_xrot<14>(s[24], d4);
         // chi
-        s[0] = b0 ^ (~b1 & b2); s[1] = b1 ^ (~b2 & b3); s[2] = b2 ^ (~b3 & b4); s[3] = b3 ^ (~b4 & b0); s[4] = b4 ^ (~b0 & b1);
-        s[5] = b5 ^ (~b6 & b7); s[6] = b6 ^ (~b7 & b8); s[7] = b7 ^ (~b8 & b9); s[8] = b8 ^ (~b9 & b5); s[9] = b9 ^ (~b5 & b6);
-        s[10] = b10 ^ (~b11 & b12); s[11] = b11 ^ (~b12 & b13); s[12] = b12 ^ (~b13 & b14); s[13] = b13 ^ (~b14 & b10); s[14] = b14 ^ (~b10 & b11);
-        s[15] = b15 ^ (~b16 & b17); s[16] = b16 ^ (~b17 & b18); s[17] = b17 ^ (~b18 & b19); s[18] = b18 ^ (~b19 & b15); s[19] = b19 ^ (~b15 & b16);
-        s[20] = b20 ^ (~b21 & b22); s[21] = b21 ^ (~b22 & b23); s[22] = b22 ^ (~b23 & b24); s[23] = b23 ^ (~b24 & b20); s[24] = b24 ^ (~b20 & b21);
-        s[0] ^= KECCAK_RC[round];
+        s[0] = k_chi64(b0, b1, b2); s[1] = k_chi64(b1, b2, b3); s[2] = k_chi64(b2, b3, b4); s[3] = k_chi64(b3, b4, b0); s[4] = k_chi64(b4, b0, b1);
+        s[5] = k_chi64(b5, b6, b7); s[6] = k_chi64(b6, b7, b8); s[7] = k_chi64(b7, b8, b9); s[8] = k_chi64(b8, b9, b5); s[9] = k_chi64(b9, b5, b6);
+        s[10] = k_chi64(b10, b11, b12); s[11] = k_chi64(b11, b12, b13); s[12] = k_chi64(b12, b13, b14); s[13] = k_chi64(b13, b14, b10); s[14] = k_chi64(b14, b10, b11);
+        s[15] = k_chi64(b15, b16, b17); s[16] = k_chi64(b16, b17, b18); s[17] = k_chi64(b17, b18, b19); s[18] = k_chi64(b18, b19, b15); s[19] = k_chi64(b19, b15, b16);
+        s[20] = k_chi64(b20, b21, b22); s[21] = k_chi64(b21, b22, b23); s[22] = k_chi64(b22, b23, b24); s[23] = k_chi64(b23, b24, b20); s[24] = k_chi64(b24, b20, b21);
+        const uint64_t rc = KECCAK_RC[round];
+        s[0].lo ^= (uint32_t)rc; s[0].hi ^= (uint32_t)(rc >> 32);
     }
+#pragma unroll
+    for (int i = 0; i < 25; ++i) st[i] = k_join(s[i]);
 }
 
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
