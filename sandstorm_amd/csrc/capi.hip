@@ -162,7 +162,7 @@ struct ss_ctx {
         auto it = plans.find(key);
         if (it != plans.end()) { *out = it->second; return SS_OK; }
         Fp *d_tw = nullptr;
-        HIP_TRY(hipMalloc(&d_tw, ((1ull << log_n) > 1 ? (1ull << log_n) - 1 : 1) * sizeof(Fp)));
+        HIP_TRY(hipMalloc(&d_tw, ((1ull << log_n) > 1 ? (1ull << log_n) - 1 : 1) * NTT_PLAN_ENTRY_BYTES + 64));
         ss_status st = build_plan(log_n, inverse, offset, d_tw);
         if (st != SS_OK) { (void)hipFree(d_tw); return st; }
         plans[key] = d_tw;
@@ -176,7 +176,7 @@ struct ss_ctx {
         const size_t need = (size_t)1 << log_n;
         if (need > transient_elems) {
             if (transient_tw) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(transient_tw)); transient_tw = nullptr; }
-            HIP_TRY(hipMalloc(&transient_tw, need * sizeof(Fp)));
+            HIP_TRY(hipMalloc(&transient_tw, need * NTT_PLAN_ENTRY_BYTES + 64));
             transient_elems = need;
         }
         ss_status st = build_plan(log_n, inverse, offset, transient_tw);
@@ -209,7 +209,8 @@ std::vector<Pass> plan_passes(uint32_t log_n) {
     v.push_back({0, r0});
     uint32_t rem = log_n - r0;
     if (rem) {
-        const uint32_t k = (rem + 6) / 7;
+        const uint32_t rmax = lt - 4;                  // rows of >= 16 adjacent elements (>= 512-byte runs)
+        const uint32_t k = (rem + rmax - 1) / rmax;
         uint32_t s0 = r0;
         for (uint32_t i = 0; i < k; ++i) {
             uint32_t r = rem / (k - i) + ((rem % (k - i)) ? 1 : 0);

@@ -193,6 +193,48 @@ SS_HD Fl fl_mul(const Fl &a, const Fl &b) {
     return fl_mont_reduce(c);
 }
 
+// a * t * 2^-280 mod p for a multiplier t the CALLER controls (twiddles, coefficients, tables):
+// such operands are kept as t * 2^280 mod p in limb form ("R280 form": fl_to_r280), so that
+// a (in the interchange domain, x * 2^256) times t comes out in the interchange domain again.
+// 2^280 = 2^(10 * 28): the reduction is exactly ten 28-bit steps and the result is columns
+// 10..18 as they stand - no 4-bit tail step and no 4-bit shift across columns (that tail is
+// ~50 of fl_mul's 223 VALU instructions), and the operand needs no re-limbing.  Same
+// preconditions as fl_mul (a any u32 limbs with value < 2^256, t normalised and canonical) and a
+// stronger contraction: result normalised and < a t / 2^280 + p < 1.01 p.
+SS_HD Fl fl_mul_r280(const Fl &a, const Fl &t) {
+    u64 c[19];
+#pragma unroll
+    for (int k = 0; k < 19; ++k) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) c[i + j] += (u64)a.l[i] * t.l[j];
+    const u32 k24 = fl_opaque(1u << 24), k27 = fl_opaque(1u << 27), k1 = fl_opaque(1u);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const u32 m = (0u - (u32)c[i]) & FL_MASK;
+        c[i + 1] += ((u64)m * k1 + c[i]) >> 28;       // limb i becomes 0; its carry moves up
+        c[i + 6] += (u64)m * k24;
+        c[i + 7] += (u64)m * k1;
+        c[i + 8] += (u64)m * k27;
+    }
+    Fl r;
+    u64 carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u64 v = c[10 + j] + carry;
+        r.l[j] = (u32)v & FL_MASK;
+        carry = v >> 28;
+    }
+    r.l[8] = (u32)(c[18] + carry);
+    return r;
+}
+// interchange-domain image (x * 2^256, canonical) -> R280 form of x (x * 2^280 mod p, canonical, limbs)
+SS_HD Fl fl_to_r280(const Fp &mont256) {
+    Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
+    return fl_from_fp(fp_mul(mont256, fp_to_mont(two24)));
+}
+
 // Montgomery square of a NORMALISED value: 9 squares + 36 doubled cross products.
 SS_HD Fl fl_sqr(const Fl &a) {
     u64 c[18];

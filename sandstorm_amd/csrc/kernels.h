@@ -19,6 +19,8 @@ struct ConstColPtrs {
 
 // ---- ntt.hip
 int ntt_log_tile_max();
+// bytes per twiddle-plan entry (R252 limb planes, ntt.hip); a plan of a size-2^log_n transform has 2^log_n - 1 entries
+static constexpr size_t NTT_PLAN_ENTRY_BYTES = 36;
 hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
                            uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first,
                            uint32_t log_expand, uint32_t scale_pow2, bool final_pass);

@@ -39,7 +39,10 @@
 
 namespace ss {
 
-static constexpr int LOG_TILE_MAX = 11;          // 2048 elements
+#ifndef SS_NTT_LOG_TILE
+#define SS_NTT_LOG_TILE 11
+#endif
+static constexpr int LOG_TILE_MAX = SS_NTT_LOG_TILE;          // 2048 elements
 // per direction (forward DIT / inverse DIF): stages per register group (radix 2^G), threads per
 // workgroup and waves per SIMD the kernel is compiled for
 #ifndef SS_NTT_GMAX
@@ -61,11 +64,32 @@ static constexpr int LOG_TILE_MAX = 11;          // 2048 elements
 #define SS_NTT_OCC_DIF (SS_NTT_THREADS_DIF / 128)
 #endif
 
-__device__ __forceinline__ int lds_slot(int e) { return e + (e >> 3); }
+// Conflict-free LDS indexing by XOR swizzle (no padding).  A register group at shift sh makes the low
+// lane bits walk element-index bits {sh+G.. } and/or {0..sh-1}; the bank index is a linear map of the
+// element bits chosen so that, for every shift the group schedule produces (0, G, 2G, ... in the
+// contiguous pass, >= 4 in strided passes), the bits the lanes walk map injectively:
+//   16-byte planes (a ds_*_b128 serves 16 lanes per cycle: 4 index bits must be distinct)
+//     G = 2:  s = e ^ (x | x << 2),            x = e[5:4]
+//     G = 3:  s = e ^ (e[4] | e[5] << 1 | e[6] * 0b1100)
+//   dword plane (64 lanes, 64 banks: 6 bits)
+//     G = 2:  s = e ^ (y * 0b010101),          y = e[7:6]
+//     G = 3:  s = e ^ (z | z << 3),            z = e[8:6]
+// the tile layout follows the kernel's register-group size, also in its shorter tail groups
+#define LAYOUT_G(dif) ((dif) ? SS_NTT_GMAX_DIF : SS_NTT_GMAX)
+template <int G>
+__device__ __forceinline__ int lds_slot(int e) {
+    if (G == 2) { const int x = (e >> 4) & 3; return e ^ (x | (x << 2)); }
+    return e ^ (((e >> 4) & 1) | (((e >> 5) & 1) << 1) | (((e >> 6) & 1) * 12));
+}
+template <int G>
+__device__ __forceinline__ int lds_top_slot(int e) {
+    if (G == 2) { const int y = (e >> 6) & 3; return e ^ (y * 21); }
+    const int z = (e >> 6) & 7;
+    return e ^ (z | (z << 3));
+}
 
-// LDS tile in the lazy form: limbs 0-3 and 4-7 in two 16-byte planes (one pad slot per 8:
-// conflict-free ds_read_b128 for the stride-1/8/64 patterns of the radix-8 groups), limb 8
-// in a dword plane.  2048 elements = 80 KiB: two workgroups per CU.
+// LDS tile in the lazy form: limbs 0-3 and 4-7 in two 16-byte planes, limb 8 in a dword plane,
+// XOR-swizzled (above).  2048 elements = 72 KiB: two workgroups per CU.
 // Pointers carry the LDS address space explicitly: through a plain `uint4 *` in a struct the
 // compiler lost it on some paths and emitted flat_load_dword for the top-limb plane (flat accesses
 // count on vmcnt as well as lgkmcnt, so the exchange waited behind outstanding global traffic).
@@ -76,27 +100,29 @@ struct Tile {
     lds_u32x4_ptr lo, hi;
     lds_u32_ptr top;
 };
+template <int LG>
 __device__ __forceinline__ Fl lds_load(const Tile &t, int e) {
 #ifdef SS_NTT_ABL_NOLDS
     { Fl r; for (int i = 0; i < 9; ++i) r.l[i] = (u32)e * 2654435761u + i; r.l[8] &= 0xfffffffu; return r; }
 #endif
-    const int s = lds_slot(e);
+    const int s = lds_slot<LG>(e);
     const lds_u32x4_t a = t.lo[s], b = t.hi[s];
     Fl r;
     r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
     r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    r.l[8] = t.top[e];
+    r.l[8] = t.top[lds_top_slot<LG>(e)];
     return r;
 }
+template <int LG>
 __device__ __forceinline__ void lds_store(const Tile &t, int e, const Fl &x) {
 #ifdef SS_NTT_ABL_NOLDS      // timing ablation only: no LDS traffic (keeps one conditional store alive)
-    if (x.l[0] == 0xdeadbeefu && x.l[5] == 77u) t.top[e] = x.l[8];
+    if (x.l[0] == 0xdeadbeefu && x.l[5] == 77u) t.top[lds_top_slot<LG>(e)] = x.l[8];
     return;
 #endif
-    const int s = lds_slot(e);
+    const int s = lds_slot<LG>(e);
     t.lo[s] = lds_u32x4_t{x.l[0], x.l[1], x.l[2], x.l[3]};
     t.hi[s] = lds_u32x4_t{x.l[4], x.l[5], x.l[6], x.l[7]};
-    t.top[e] = x.l[8];
+    t.top[lds_top_slot<LG>(e)] = x.l[8];
 }
 __device__ __forceinline__ Fp gload(const Fp *p) {
 #ifdef SS_NTT_ABL_NOGL       // timing ablation only: no global loads
@@ -149,7 +175,9 @@ __device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const Fp *__restric
                                             uint32_t u, uint32_t jlow, uint32_t lbits) {
     if (ST >= G) return;
     const uint32_t s = p.s0 + u + ST;               // global stage
-    const Fp *tws = tw + ((1u << s) - 1u);
+    const uint64_t tw_total = (1ull << p.log_n) - 1ull, tw_stage = (1ull << s) - 1ull;
+    const uint4 *tw_lo = reinterpret_cast<const uint4 *>(tw) + tw_stage, *tw_hi = tw_lo + tw_total;
+    const u32 *tw_top = reinterpret_cast<const u32 *>(reinterpret_cast<const uint4 *>(tw) + 2 * tw_total) + tw_stage;
     constexpr int STC = ST < G ? ST : 0;
     // position of this stage inside the group's execution order (DIF runs ST = G-1 .. 0)
     constexpr int ORD = DIF ? (G - 1 - STC) : STC;
@@ -160,7 +188,13 @@ __device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const Fp *__restric
 #ifdef SS_NTT_ABL_NOTW      // timing ablation only (wrong results): no twiddle loads
         Fl t = x[m]; t.l[0] += k;
 #else
-        const Fl t = fl_from_fp(gload(tws + k));
+        Fl t;                                      // R280 form: canonical, normalised limbs
+        {
+            const uint4 a4 = tw_lo[k], b4 = tw_hi[k];
+            t.l[0] = a4.x; t.l[1] = a4.y; t.l[2] = a4.z; t.l[3] = a4.w;
+            t.l[4] = b4.x; t.l[5] = b4.y; t.l[6] = b4.z; t.l[7] = b4.w;
+            t.l[8] = tw_top[k];
+        }
 #endif
         const Fl a = x[m], b = x[m | (1 << STC)];
         if (DIF) {
@@ -169,13 +203,13 @@ __device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const Fp *__restric
 #ifdef SS_NTT_ABL_NOMUL     // timing ablation only: no modular multiplication
             x[m | (1 << STC)] = fl_add(d, t);
 #else
-            x[m | (1 << STC)] = fl_mul(d, t);
+            x[m | (1 << STC)] = fl_mul_r280(d, t);
 #endif
         } else {
 #ifdef SS_NTT_ABL_NOMUL
             const Fl bt = fl_add(b, t);
 #else
-            const Fl bt = fl_mul(b, t);
+            const Fl bt = fl_mul_r280(b, t);
 #endif
             x[m] = fl_add(a, bt);
             x[m | (1 << STC)] = fl_sub_c<2, 1>(a, bt);
@@ -223,7 +257,7 @@ __device__ __forceinline__ void radix_group(const Tile &t, const Fp *__restrict_
         for (int m = 0; m < (1 << G); ++m) {
             const uint32_t e = ebase + ((uint32_t)m << sh);
             if (from_global) x[m] = fl_from_fp(gload(src + (tile_gindex(p, tile, e) >> p.log_expand)));
-            else x[m] = lds_load(t, e);
+            else x[m] = lds_load<LAYOUT_G(DIF)>(t, e);
         }
         if (DIF) {
             if (G >= 3) radix_stage<DIF, G, 2>(x, tw, p, u, jlow, lbits);
@@ -249,9 +283,9 @@ __device__ __forceinline__ void radix_group(const Tile &t, const Fp *__restrict_
                 }
                 gstore(dst + tile_gindex(p, tile, e), out);
             } else if (DIF) {
-                lds_store(t, e, product ? x[m] : fl_weak_reduce(x[m]));     // < 2^252, limbs < 2^28
+                lds_store<LAYOUT_G(DIF)>(t, e, product ? x[m] : fl_weak_reduce(x[m]));     // < 2^252, limbs < 2^28
             } else {
-                lds_store(t, e, x[m]);                                      // raw lazy limbs (see radix_stage)
+                lds_store<LAYOUT_G(DIF)>(t, e, x[m]);                                      // raw lazy limbs (see radix_stage)
             }
         }
     }
@@ -269,7 +303,7 @@ __global__ __launch_bounds__(DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, DIF ? SS
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NTT_GMAX = DIF ? SS_NTT_GMAX_DIF : SS_NTT_GMAX;
     const uint32_t tile_elems = 1u << p.log_tile;
-    const uint32_t slots = tile_elems + (tile_elems >> 3);
+    const uint32_t slots = tile_elems;
     Tile t;
     t.lo = (lds_u32x4_ptr)smem;
     t.hi = t.lo + slots;
@@ -297,7 +331,7 @@ __global__ __launch_bounds__(DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, DIF ? SS
     const bool fuse = !p.contig;
     if (!fuse) {
         for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x)
-            lds_store(t, x, fl_from_fp(gload(src + (tile_gindex(p, tile, x) >> p.log_expand))));
+            lds_store<LAYOUT_G(DIF)>(t, x, fl_from_fp(gload(src + (tile_gindex(p, tile, x) >> p.log_expand))));
         NTT_SYNC();
     }
 
@@ -335,10 +369,10 @@ __global__ __launch_bounds__(DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, DIF ? SS
         for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x) {
             Fp out;
             if (p.final_pass) {
-                out = fl_to_fp(lds_load(t, x));
+                out = fl_to_fp(lds_load<LAYOUT_G(DIF)>(t, x));
                 if (DIF && p.scale_pow2) out = fp_div_pow2(out, p.scale_pow2);
             } else {
-                out = fl_pack(fl_weak_reduce(lds_load(t, x)));
+                out = fl_pack(fl_weak_reduce(lds_load<LAYOUT_G(DIF)>(t, x)));
             }
             gstore(dst + tile_gindex(p, tile, x), out);
         }
@@ -348,10 +382,16 @@ __global__ __launch_bounds__(DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, DIF ? SS
 // ---------------------------------------------------------------- twiddles
 // T_s[k] = h^(n / 2^(s+1)) * (r^(n / 2^(s+1)))^k,  k < 2^s, stored at (2^s - 1) + k.
 // r^e comes from two host-computed tables: pow_lo[e & 4095] * pow_hi[e >> 12].
+// The plan is stored in "R280 form" (fl252.h: t * 2^280 mod p as nine 28-bit limbs) in three planes
+// (limbs 0-3, limbs 4-7 as 16-byte vectors, limb 8 as a dword; NTT_PLAN_ENTRY_BYTES = 36 per entry): the
+// butterfly's fl_mul_r280 then needs neither a re-limbing of the twiddle nor the 4-bit tail of the
+// 2^256 reduction (~185 instead of 223 + 12 VALU instructions per butterfly multiplication).
 __global__ void twiddle_kernel(Fp *__restrict__ tw, const Fp *__restrict__ pow_lo,
                                const Fp *__restrict__ pow_hi, const Fp *__restrict__ hpow,
                                uint32_t log_n, int h_is_one) {
     const uint64_t total = (1ull << log_n) - 1ull;
+    uint4 *plane_lo = reinterpret_cast<uint4 *>(tw), *plane_hi = plane_lo + total;
+    u32 *plane_top = reinterpret_cast<u32 *>(plane_hi + total);
     for (uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t s = 63u - (uint32_t)__clzll(idx + 1ull);
@@ -359,7 +399,10 @@ __global__ void twiddle_kernel(Fp *__restrict__ tw, const Fp *__restrict__ pow_l
         const uint64_t e = k << (log_n - 1u - s);          // exponent of the n-th root, < n/2
         Fp t = fp_mul(gload(pow_lo + (e & 4095ull)), gload(pow_hi + (e >> 12)));
         if (!h_is_one) t = fp_mul(t, gload(hpow + s));
-        gstore(tw + idx, t);
+        const Fl l = fl_to_r280(t);
+        plane_lo[idx] = make_uint4(l.l[0], l.l[1], l.l[2], l.l[3]);
+        plane_hi[idx] = make_uint4(l.l[4], l.l[5], l.l[6], l.l[7]);
+        plane_top[idx] = l.l[8];
     }
 }
 
@@ -392,7 +435,7 @@ __global__ void mul_bench_kernel(const Fp *__restrict__ a, const Fp *__restrict_
 // ------------------------------------------------------------ host launch
 static inline size_t pass_lds_bytes(uint32_t log_tile) {
     size_t e = (size_t)1 << log_tile;
-    return 2 * (e + (e >> 3)) * sizeof(uint4) + e * sizeof(u32);
+    return 2 * e * sizeof(uint4) + e * sizeof(u32);
 }
 
 hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
@@ -406,7 +449,8 @@ hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32
     p.log_expand = log_expand; p.scale_pow2 = scale_pow2; p.contig = (s0 == 0);
     const uint32_t tiles = 1u << (log_n - log_tile);
     dim3 grid(tiles, ncols), block(dif ? SS_NTT_THREADS_DIF : SS_NTT_THREADS);
-    const size_t lds = pass_lds_bytes(log_tile);
+    static const size_t lds_pad = [] { const char *e = getenv("SS_NTT_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
+    const size_t lds = pass_lds_bytes(log_tile) + lds_pad;      // SS_NTT_LDS_PAD: occupancy experiments only
     if (dif) hipLaunchKernelGGL(ntt_pass_kernel<true>, grid, block, lds, st, cols, tw, p);
     else hipLaunchKernelGGL(ntt_pass_kernel<false>, grid, block, lds, st, cols, tw, p);
     return hipGetLastError();
@@ -442,7 +486,7 @@ int ntt_log_tile_max() { return LOG_TILE_MAX; }
 
 // tiles above 64 KiB of dynamic LDS need the per-function opt-in
 hipError_t ntt_set_func_attributes() {
-    const int bytes = (int)pass_lds_bytes(LOG_TILE_MAX);
+    const int bytes = (int)pass_lds_bytes(LOG_TILE_MAX) + 65536;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
