@@ -846,6 +846,10 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
         group_k.push_back(kacc);
     }
     const uint32_t ngroups = (uint32_t)group_k.size();
+    // the kernel multiplies with fl_mul_r280: coefficients go over in R280 form (times 2^24)
+    Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
+    const Fp r280_factor = fp_to_mont(two24);
+    for (uint32_t t = 0; t < nmask; ++t) cell_coef[t] = fp_mul(cell_coef[t], r280_factor);
     std::vector<Fp> comp_coef(ncomp ? ncomp : 1);
     Fp comp_k = fp_zero(), zc = fp_one();
     for (uint32_t k = 0; k < ncomp; ++k) {
@@ -853,6 +857,7 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
         comp_k = fp_add(comp_k, fp_mul(comp_coef[k], fp_from_limbs64(ood_comp + 4 * k)));
         zc = fp_mul(zc, zf);
     }
+    for (uint32_t k = 0; k < ncomp; ++k) comp_coef[k] = fp_mul(comp_coef[k], r280_factor);
     // device staging: D, Dc (sub-coset tables) and the sub-coset DEEP values in scratch2;
     // small arrays in scratch
     ss_status st = ctx->ensure_scratch2(3 * n * sizeof(Fp));
@@ -885,8 +890,8 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
     if (st != SS_OK) return st;
     {
         ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
-        HIP_TRY(launch_batch_inverse(s, D, log_n, off, wn, fp_inv(wn), zf));
-        if (ncomp) HIP_TRY(launch_batch_inverse(s, Dc, log_n, off, wn, fp_inv(wn), zc));
+        HIP_TRY(launch_batch_inverse(s, D, log_n, off, wn, fp_inv(wn), zf, true));
+        if (ncomp) HIP_TRY(launch_batch_inverse(s, Dc, log_n, off, wn, fp_inv(wn), zc, true));
         HIP_TRY(launch_deep(s, (const void *const *)d_trace_lde, ntrace_cols, (const void *const *)d_comp_lde, ncomp, D, Dc,
                             d_cell_col, d_cell_coef, d_gdesc, d_group_k, ngroups, d_comp_coef, comp_k, log_n, log_blowup, sub));
     }
@@ -910,7 +915,7 @@ ss_status ss_inverse_table(ss_ctx *ctx, uint32_t log_N, const uint64_t offset[4]
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp w = root_of_unity(log_N);
     ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
-    HIP_TRY(launch_batch_inverse(ctx->stream, (Fp *)d_out, log_N, off, w, fp_inv(w), fp_from_limbs64(cval)));
+    HIP_TRY(launch_batch_inverse(ctx->stream, (Fp *)d_out, log_N, off, w, fp_inv(w), fp_from_limbs64(cval), false));
     return SS_OK;
 }
 
@@ -943,22 +948,30 @@ ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64
     if (lanes > N) lanes = N < 256 ? 256 : N;
     const size_t code_b = ((size_t)prog->n_instr + 1) * 32, const_b = (size_t)(prog->n_consts ? prog->n_consts : 1) * 32;
     const size_t slots_b = (size_t)(prog->n_slots ? prog->n_slots : 1) * lanes * 32;
-    ss_status st = ctx->ensure_scratch(slots_b + const_b + code_b + 256);
+    ss_status st = ctx->ensure_scratch(slots_b + 2 * const_b + code_b + 256);
     if (st != SS_OK) return st;
     char *p = (char *)ctx->scratch;
     Fp *d_slots = (Fp *)p; p += slots_b;
     Fp *d_consts = (Fp *)p; p += const_b;
+    Fp *d_consts_r280 = (Fp *)p; p += const_b;
     uint32_t *d_code = (uint32_t *)p;
     hipStream_t s = ctx->stream;
     // resolve operands and lazy-form bounds on the host (quotient.hip: "device program")
     VmResolve rs;
     for (int c = 0; c < MAX_COLS; ++c) rs.cols[c] = c < (int)ncols ? (const void *)d_lde_cols[c] : nullptr;
-    rs.consts = d_consts; rs.tables = prog->d_tables; rs.slots = d_slots; rs.table_desc = prog->table_desc;
+    rs.consts = d_consts; rs.consts_r280 = d_consts_r280; rs.tables = prog->d_tables; rs.slots = d_slots; rs.table_desc = prog->table_desc;
     rs.lanes = lanes; rs.log_N = log_N; rs.log_blowup = log_blowup;
     std::vector<uint32_t> dev_code(((size_t)prog->n_instr + 1) * 8);
     quotient_build_device_code(prog->code, prog->n_instr, rs, dev_code.data());
     HIP_TRY(hipMemcpyAsync(d_code, dev_code.data(), code_b, hipMemcpyHostToDevice, s));
-    if (prog->n_consts) HIP_TRY(hipMemcpyAsync(d_consts, prog->consts, (size_t)prog->n_consts * 32, hipMemcpyHostToDevice, s));
+    std::vector<Fp> consts_r280(prog->n_consts);
+    if (prog->n_consts) {
+        HIP_TRY(hipMemcpyAsync(d_consts, prog->consts, (size_t)prog->n_consts * 32, hipMemcpyHostToDevice, s));
+        Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
+        const Fp f = fp_to_mont(two24);
+        for (uint32_t k = 0; k < prog->n_consts; ++k) consts_r280[k] = fp_mul(fp_from_limbs64(prog->consts + 4 * (size_t)k), f);
+        HIP_TRY(hipMemcpyAsync(d_consts_r280, consts_r280.data(), (size_t)prog->n_consts * 32, hipMemcpyHostToDevice, s));
+    }
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp w = root_of_unity(log_N);
     // optional XCD-contiguous sweep (measured: no gain, the per-XCD window still exceeds L2)

@@ -96,8 +96,10 @@ hipError_t launch_poly_reduce(hipStream_t st, const void *const *in, void *const
 // ---- D[i] = 1 / (offset * w^i - z), i < 2^log_N ----------------------------------------
 // chunk c of length CH is handled by one lane: forward pass stores prefix products in D,
 // one inversion, backward pass overwrites them with the inverses.
+// r280 != 0: the table is written in R280 form (fl252.h: entries times 2^24, for fl_mul_r280 consumers);
+// the factor rides on the running inverse, so it costs one multiplication per chunk.
 __global__ __launch_bounds__(128) void batch_inverse_kernel(Fp *__restrict__ D, uint32_t log_N, uint32_t log_chunk,
-                                                            Fp offset, Fp w, Fp w_inv, Fp z) {
+                                                            Fp offset, Fp w, Fp w_inv, Fp z, int r280) {
     const uint64_t nchunks = 1ull << (log_N - log_chunk);
     const uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(128) void batch_inverse_kernel(Fp *__restrict__ D, 
         x = fl_mul(x, wl);
     }
     Fl inv = fn_inv(run);                        // 1 / (d_0 ... d_{CH-1}); 0 stays 0 if some x_i == z
+    if (r280) { Fp two24 = fp_zero(); two24.v[0] = 1u << 24; inv = fl_mul(inv, fl_from_fp(fp_to_mont(two24))); }
     for (uint64_t k = CH; k-- > 0;) {
         x = fl_mul(x, wil);                      // x_{i0+k}
         const Fl pre = fl_from_fp(dload(D + i0 + k));
@@ -120,14 +123,14 @@ __global__ __launch_bounds__(128) void batch_inverse_kernel(Fp *__restrict__ D, 
 }
 
 hipError_t launch_batch_inverse(hipStream_t st, Fp *D, uint32_t log_N, const Fp &offset, const Fp &w,
-                                const Fp &w_inv, const Fp &z) {
+                                const Fp &w_inv, const Fp &z, bool r280) {
     // enough lanes to fill the chip, chunks long enough to amortise the inversion
     uint32_t log_chunk = log_N > 17 ? log_N - 17 : 0;
     if (log_chunk < 4) log_chunk = log_N < 4 ? log_N : 4;
     if (log_chunk > 7) log_chunk = 7;
     const uint64_t nchunks = 1ull << (log_N - log_chunk);
     hipLaunchKernelGGL(batch_inverse_kernel, dim3((uint32_t)((nchunks + 127) / 128)), dim3(128), 0, st, D, log_N,
-                       log_chunk, offset, w, w_inv, z);
+                       log_chunk, offset, w, w_inv, z, r280 ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -135,13 +138,13 @@ hipError_t launch_batch_inverse(hipStream_t st, Fp *D, uint32_t log_N, const Fp 
 struct DeepArgs {
     const Fp *trace[MAX_COLS];
     const Fp *comp[4];
-    const Fp *D;            // 1/(x_i - z)
-    const Fp *Dc;           // 1/(x_i - z^ncomp)
+    const Fp *D;            // 1/(x_i - z), R280 form
+    const Fp *Dc;           // 1/(x_i - z^ncomp), R280 form
     const uint32_t *cell_col;    // [nmask] sorted by group
-    const Fp *cell_coef;         // [nmask] coeff_j * w_n^-off_j
+    const Fp *cell_coef;         // [nmask] coeff_j * w_n^-off_j, R280 form (times 2^24: the multiplier side of fl_mul_r280)
     const uint32_t *group_desc;  // [ngroups][3]: shift (= off * blowup), first cell, cell count
     const Fp *group_k;           // [ngroups] sum_j c'_j * ood_j
-    const Fp *comp_coef;         // [ncomp]
+    const Fp *comp_coef;         // [ncomp], R280 form
     Fp comp_k;                   // sum_k cc_k * ood_comp_k
     uint32_t ngroups, ncomp, log_N, log_stride;     // log_N: log2 of the number of points evaluated
 };
@@ -182,11 +185,11 @@ __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ 
                 const Fp *tp = a.trace[0];
 #pragma unroll
                 for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) tp = a.trace[c];
-                inner = fl_add(inner, fl_mul(fl_from_fp(dload(tp + i)), fl_from_fp(dload_uniform(a.cell_coef + j))));
+                inner = fl_add(inner, fl_mul_r280(fl_from_fp(dload(tp + i)), fl_from_fp(dload_uniform(a.cell_coef + j))));
                 if (++terms == 12) { inner = fl_weak_reduce(inner); terms = 1; }      // 12 x 1.13p < 16p
             }
             inner = fn_sub(fl_weak_reduce(inner), fl_from_fp(dload_uniform(a.group_k + g)));
-            acc = fl_add(acc, fl_mul(inner, fl_from_fp(dload(a.D + ((m - shift) & (M - 1))))));
+            acc = fl_add(acc, fl_mul_r280(inner, fl_from_fp(dload(a.D + ((m - shift) & (M - 1))))));
             if (++acc_terms == 12) { acc = fl_weak_reduce(acc); acc_terms = 1; }
         }
         if (a.ncomp) {
@@ -195,10 +198,10 @@ __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ 
                 const Fp *hp = a.comp[0];
 #pragma unroll
                 for (int c = 1; c < 4; ++c) if (k == (uint32_t)c) hp = a.comp[c];
-                inner = fl_add(inner, fl_mul(fl_from_fp(dload(hp + i)), fl_from_fp(dload_uniform(a.comp_coef + k))));
+                inner = fl_add(inner, fl_mul_r280(fl_from_fp(dload(hp + i)), fl_from_fp(dload_uniform(a.comp_coef + k))));
             }
             inner = fn_sub(fl_weak_reduce(inner), fl_from_fp(a.comp_k));
-            acc = fl_add(acc, fl_mul(inner, fl_from_fp(dload(a.Dc + m))));
+            acc = fl_add(acc, fl_mul_r280(inner, fl_from_fp(dload(a.Dc + m))));
         }
         dstore(out + m, fl_to_fp(acc));
     }

@@ -75,7 +75,7 @@ hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, ui
 hipError_t launch_poly_reduce(hipStream_t st, const void *const *in, void *const *out, uint32_t ncols,
                               uint64_t in_len, uint32_t levels, const Fp *mult);
 hipError_t launch_batch_inverse(hipStream_t st, Fp *D, uint32_t log_N, const Fp &offset, const Fp &w,
-                                const Fp &w_inv, const Fp &z);
+                                const Fp &w_inv, const Fp &z, bool r280);
 hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace, const void *const *comp,
                        uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *cell_col, const Fp *cell_coef,
                        const uint32_t *group_desc, const Fp *group_k, uint32_t ngroups, const Fp *comp_coef,
@@ -87,7 +87,7 @@ hipError_t launch_gather_cells(hipStream_t st, const void *const *cols, uint32_t
 // what ss_eval_quotient knows and the device program needs resolved (device addresses, sizes)
 struct VmResolve {
     const void *cols[MAX_COLS];
-    const void *consts, *tables, *slots;
+    const void *consts, *consts_r280, *tables, *slots;    // consts_r280: the constants times 2^24 (R280 form)
     const uint32_t *table_desc;      // host copy: [n_tables][2] = (offset in felts, log2 length)
     uint64_t lanes;
     uint32_t log_N, log_blowup;

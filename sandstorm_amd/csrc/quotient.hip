@@ -60,10 +60,12 @@ struct VmArgs {
 // b <= VM_MAX_BOUND) are tracked by the host with the rules below, which decide RV / RS:
 //   ADD  needs b_v + b_s <= 8 (reduce v, then s, while it does not hold); b_v += b_s
 //   SUB  subtrahend b_s == 1; b_v + 1 <= 8; b_v += 1        RSUB  b_v == 1; b_s + 1 <= 8; b_v = b_s + 1
-//   MUL  b_s == 1 (the accumulator side takes any b <= 8); b_v = 1
+//   MUL  b_s == 1 (the accumulator side takes any b <= 8); b_v = 1.  A MUL by a constant becomes MULR: the
+//        host keeps a second copy of the constants in R280 form and points the operand there
 //   INV  reduced input; ST stores a reduced image (and keeps it); memory operands and x are b = 1
 static constexpr uint32_t VM_MAX_BOUND = 8;       // 8 * 2p * 2p / 2^256 + p < 2p: products stay < 2^252
 static constexpr uint32_t VM_OP_NOP = 8;
+static constexpr uint32_t VM_OP_MULR = 9;         // MUL by a constant kept in R280 form (fl252.h): the cheaper fl_mul_r280
 static constexpr uint32_t VM_F_RV = 1u << 10, VM_F_RS = 1u << 11, VM_F_P = 1u << 12, VM_F_PL = 1u << 13;
 
 // One instruction on a NAMED accumulator: the destination index is wave-uniform, so the caller
@@ -77,6 +79,7 @@ __device__ __forceinline__ void vm_exec(uint32_t w0, Fl &v, const Fl &src, const
     case SS_OP_SUB: v = fl_sub_c<2, 1>(v, src); break;
     case SS_OP_RSUB: v = fl_sub_c<2, 1>(src, v); break;
     case SS_OP_MUL: v = fl_mul(v, src); break;
+    case VM_OP_MULR: v = fl_mul_r280(v, src); break;
     case SS_OP_INV: v = fn_inv(v); break;
     case SS_OP_ST: qstore(a.slots + (uint64_t)w1 * lanes + lane, fl_pack(v)); break;     // weakly reduced image
     case SS_OP_OUT: qstore(a.out + i, fl_to_fp(v)); break;
@@ -204,6 +207,7 @@ void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, const Vm
         case SS_OP_ST: if (vb > 1) { w0 |= VM_F_RV; vb = 1; } break;
         default: break;                                                           // OUT reduces fully itself
         }
+        if (op == SS_OP_MUL && kind == SS_SRC_CONST) w0 = (w0 & ~0xfu) | VM_OP_MULR;
         dev[8 * idx] = w0;
         dev[8 * idx + 1] = w1;
         if (mem) {
@@ -217,7 +221,7 @@ void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, const Vm
             } else if (kind == SS_SRC_TABLE) {
                 base = (uint64_t)r.tables + 32ull * r.table_desc[2 * w1]; mask = (uint32_t)((1ull << r.table_desc[2 * w1 + 1]) - 1ull);
             } else if (kind == SS_SRC_CONST) {
-                base = (uint64_t)r.consts + 32ull * w1;
+                base = (uint64_t)(op == SS_OP_MUL ? r.consts_r280 : r.consts) + 32ull * w1;
             } else {
                 base = (uint64_t)r.slots + 32ull * w1 * r.lanes; mask = 0xffffffffu; fl |= VM_F_PL;
             }
