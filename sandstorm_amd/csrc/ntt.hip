@@ -153,7 +153,6 @@ struct PassParams {
     uint32_t log_expand;  // source index = element index >> log_expand
     uint32_t scale_pow2;  // DIF only: multiply outputs by 2^-scale_pow2 (0 = off)
     uint32_t contig;      // 1: s0 == 0, tile is a contiguous block
-    uint32_t stagger;     // start delay (units of s_sleep 127 ~ 3.4 us) of every second resident set of workgroups
     uint32_t final_pass;  // 1: last pass of the transform, outputs are canonical (< p);
                           // 0: outputs are weakly reduced 256-bit images (< 2^252) for the next pass
 };
@@ -321,13 +320,6 @@ __global__ __launch_bounds__(DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, DIF ? SS
 
     // Strided passes read/write HBM from the first/last register group directly; the
     // contiguous pass (tile = one 64 KiB block, first group of stride 1) stages through LDS.
-    // Workgroups of one launch are identical, so without this they stay in lock-step: all load
-    // (HBM saturated, VALU idle), then all multiply (HBM idle).  Delaying the second workgroup
-    // slot of every CU by about half a tile time puts the two slots in anti-phase; later
-    // workgroups inherit the offset because they start when a slot frees.
-    if (p.stagger && ((blockIdx.y * gridDim.x + blockIdx.x) >> 8) == 1u) {      // workgroups 256..511 only
-        for (uint32_t k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
-    }
     const bool fuse = !p.contig;
     if (!fuse) {
         for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x)
@@ -443,8 +435,6 @@ hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32
                            uint32_t log_expand, uint32_t scale_pow2, bool final_pass) {
     PassParams p;
     p.final_pass = final_pass ? 1u : 0u;
-    static const uint32_t stagger = [] { const char *e = getenv("SS_NTT_STAGGER"); return e ? (uint32_t)atoi(e) : 0u; }();
-    p.stagger = stagger;
     p.log_n = log_n; p.s0 = s0; p.r = r; p.log_tile = log_tile; p.u_first = u_first;
     p.log_expand = log_expand; p.scale_pow2 = scale_pow2; p.contig = (s0 == 0);
     const uint32_t tiles = 1u << (log_n - log_tile);
