@@ -439,8 +439,7 @@ hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32
     p.log_expand = log_expand; p.scale_pow2 = scale_pow2; p.contig = (s0 == 0);
     const uint32_t tiles = 1u << (log_n - log_tile);
     dim3 grid(tiles, ncols), block(dif ? SS_NTT_THREADS_DIF : SS_NTT_THREADS);
-    static const size_t lds_pad = [] { const char *e = getenv("SS_NTT_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
-    const size_t lds = pass_lds_bytes(log_tile) + lds_pad;      // SS_NTT_LDS_PAD: occupancy experiments only
+    const size_t lds = pass_lds_bytes(log_tile);
     if (dif) hipLaunchKernelGGL(ntt_pass_kernel<true>, grid, block, lds, st, cols, tw, p);
     else hipLaunchKernelGGL(ntt_pass_kernel<false>, grid, block, lds, st, cols, tw, p);
     return hipGetLastError();
@@ -476,7 +475,7 @@ int ntt_log_tile_max() { return LOG_TILE_MAX; }
 
 // tiles above 64 KiB of dynamic LDS need the per-function opt-in
 hipError_t ntt_set_func_attributes() {
-    const int bytes = (int)pass_lds_bytes(LOG_TILE_MAX) + 65536;
+    const int bytes = (int)pass_lds_bytes(LOG_TILE_MAX);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;

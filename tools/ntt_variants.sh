@@ -2,7 +2,7 @@
 # scratch experiment driver (GPU box): NTT occupancy / tile-size experiments
 cd /root/repo
 echo "== default (2 WG/CU)"; python tools/ntt_bench.py 24 9 3 2>&1 | grep -v amdgpu
-echo "== 1 WG/CU (LDS pad 40 KB)"; SS_NTT_LDS_PAD=40960 python tools/ntt_bench.py 24 9 3 2>&1 | grep -v amdgpu
+
 for v in "-DSS_NTT_LOG_TILE=10 -DSS_NTT_THREADS=256 -DSS_NTT_OCC=4 -DSS_NTT_GMAX_DIF=2 -DSS_NTT_THREADS_DIF=256 -DSS_NTT_OCC_DIF=4" "-DSS_NTT_LOG_TILE=10 -DSS_NTT_THREADS=256 -DSS_NTT_OCC=4 -DSS_NTT_GMAX_DIF=3 -DSS_NTT_THREADS_DIF=128 -DSS_NTT_OCC_DIF=2"; do
   rm -f sandstorm_amd/_build/ntt.o sandstorm_amd/_build/capi.o
   make -C sandstorm_amd/csrc EXTRA="$v" >/dev/null 2>&1 || { echo "build fail $v"; continue; }
