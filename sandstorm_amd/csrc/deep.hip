@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include "fp252.h"
 #include "fl252.h"
+#include "inv252.h"
 #include "kernels.h"
 
 namespace ss {
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(128) void batch_inverse_kernel(Fp *__restrict__ D, 
         run = fl_mul(fl_sub_c<2, 1>(x, zl), run);
         x = fl_mul(x, wl);
     }
-    Fl inv = fn_inv(run);                        // 1 / (d_0 ... d_{CH-1}); 0 stays 0 if some x_i == z
+    Fl inv = fl_from_fp(fp_inv_safegcd(fl_to_fp(fl_weak_reduce(run))));   // 1 / (d_0 ... d_{CH-1}); 0 stays 0 if some x_i == z
     if (r280) { Fp two24 = fp_zero(); two24.v[0] = 1u << 24; inv = fl_mul(inv, fl_from_fp(fp_to_mont(two24))); }
     for (uint64_t k = CH; k-- > 0;) {
         x = fl_mul(x, wil);                      // x_{i0+k}

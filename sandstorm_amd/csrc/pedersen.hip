@@ -26,6 +26,7 @@
 #include <vector>
 #include "fp252.h"
 #include "fl252.h"
+#include "inv252.h"
 #include "kernels.h"
 
 namespace ss {
@@ -453,7 +454,8 @@ __global__ __launch_bounds__(64) void pedersen_finish_kernel(Fp *__restrict__ tm
         store_felt(P + k, fl_pack(run));
         run = fn_mul(run, z);
     }
-    Fl inv = fn_inv(run);
+    // safegcd (inv252.h): ~3x less latency than the 251-squaring power - what a small level is bound by
+    Fl inv = fl_from_fp(fp_inv_safegcd(fl_to_fp(run)));
     while (k > c) {
         k -= lanes;
         Fl z = fl_from_fp(load_felt(Z + k));
