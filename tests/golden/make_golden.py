@@ -14,6 +14,12 @@ tests and restates each test's expected side with Python big integers:
   coins.json             crypto/src/public_coin/solidity.rs:172-193,
                          crypto/src/public_coin/cairo.rs:189-208
   montgomery.json        crypto/src/utils.rs:19-20 (the MONTGOMERY_R comment)
+  ntt_poseidon8.json     builtins/src/poseidon/periodic.rs:241-290 (full_round_keys{0,1,2}_match:
+                         fft(FULL_ROUND_KEY_k_COEFFS) == the rotated round-key halves)
+  saved_proofs.json      header + out-of-domain tail of the three proof FILES the reference ships
+                         (example/array-sum.proof.saved, example/bootloader/bootloader-proof.bin,
+                         bootloader-proof.bin): options, trace length, base-trace root, the trace-OOD and
+                         composition-OOD vectors - data for the OOD-identity pin
 
 Every file stores field elements as decimal strings of the canonical value.
 """
@@ -166,6 +172,48 @@ def main():
     assert hashlib.blake2s(d).digest() == expected, "reference KAT does not reproduce"
     dump("coins.json", {"solidity_zero_seed_draws": draws,
                         "cairo_reseed": {"seed": seed.hex(), "element": elem, "digest": expected.hex()}})
+
+    # ---- Poseidon round keys: three 8-point NTT known-answer tests
+    src = open(os.path.join(REF, "builtins/src/poseidon/params.rs")).read()
+
+    def key_table(name):
+        m = re.search(r"pub const %s: \[\[Fp; 3\]; NUM_FULL_ROUNDS / 2\] = \[(.*?)\n\];" % name, src, re.S)
+        vals = [int(v) for v in re.findall(r'Fp!\("(\d+)"\)', m.group(1))]
+        assert len(vals) == 12
+        return [vals[3 * i:3 * i + 3] for i in range(4)]
+    h1, h2 = key_table("FULL_ROUND_KEYS_1ST_HALF"), key_table("FULL_ROUND_KEYS_2ND_HALF")
+    pos = {}
+    for k in range(3):
+        a, b = [r[k] for r in h1], [r[k] for r in h2]
+        a, b = a[1:] + [0], b[1:] + [0]                  # rotate_left(1), last = 0
+        co = const_array("builtins/src/poseidon/periodic.rs", "FULL_ROUND_KEY_%d_COEFFS" % k)
+        assert eval_domain(co) == a + b, "reference KAT does not reproduce"
+        pos["key%d" % k] = {"coeffs": s(co), "evals": s(a + b)}
+    dump("ntt_poseidon8.json", pos)
+
+    # ---- saved proofs: header and OOD tail (ark-serialize compressed)
+    def parse_proof(path):
+        raw = open(os.path.join(REF, path), "rb").read()
+        opts = list(raw[:5])
+        trace_len = int.from_bytes(raw[5:13], "little")
+        assert int.from_bytes(raw[13:21], "little") == 32
+        root = raw[21:53]
+        # tail: Vec<Fp> trace OOD (u64 len, 32-byte LE canonical each) then Vec<Fp> composition OOD (len 2), EOF
+        assert int.from_bytes(raw[-72:-64], "little") == 2
+        comp = [int.from_bytes(raw[-64 + 32 * i:len(raw) - 32 + 32 * i] if i == 0 else raw[-32:], "little") for i in range(2)]
+        for n_ood in (269, 133):
+            off = len(raw) - 72 - 32 * n_ood - 8
+            if off > 0 and int.from_bytes(raw[off:off + 8], "little") == n_ood:
+                break
+        else:
+            raise AssertionError("no OOD vector found in " + path)
+        ood = [int.from_bytes(raw[off + 8 + 32 * i:off + 40 + 32 * i], "little") for i in range(n_ood)]
+        assert all(v < P for v in ood + comp)
+        return {"file": path, "bytes": len(raw), "options": {"num_queries": opts[0], "lde_blowup_factor": opts[1],
+                "grinding_factor": opts[2], "fri_folding_factor": opts[3], "fri_max_remainder_coeffs": opts[4]},
+                "trace_len": trace_len, "base_trace_root": root.hex(), "ood_trace": s(ood), "ood_composition": s(comp)}
+    dump("saved_proofs.json", [parse_proof(f) for f in ("example/array-sum.proof.saved",
+                                                        "example/bootloader/bootloader-proof.bin", "bootloader-proof.bin")])
 
     # ---- Montgomery constants
     src = open(os.path.join(REF, "crypto/src/utils.rs")).read()

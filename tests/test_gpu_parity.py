@@ -60,6 +60,19 @@ def test_ntt_golden_kat(ctx, be, oracle, golden, name, n):
         assert np.array_equal(_down(d, n)[0], coeffs)
 
 
+def test_ntt_poseidon_round_key_kat(ctx, be, oracle, golden):
+    """The reference's 8-point Poseidon round-key NTT known-answer tests, on the GPU."""
+    g = golden("ntt_poseidon8.json")
+    for k in range(3):
+        coeffs = oracle.to_mont([int(v) for v in g["key%d" % k]["coeffs"]])
+        want = oracle.to_mont([int(v) for v in g["key%d" % k]["evals"]])
+        d = _up(ctx, [coeffs])
+        ctx.ntt(d, 3, be.FORWARD)
+        assert np.array_equal(_down(d, 8)[0], want)
+        ctx.ntt(d, 3, be.INVERSE)
+        assert np.array_equal(_down(d, 8)[0], coeffs)
+
+
 @pytest.mark.parametrize("log_n", [1, 2, 3, 4, 7, 10, 11, 12, 13, 15, 18])
 @pytest.mark.parametrize("coset", [False, True])
 def test_ntt_vs_oracle(ctx, be, oracle, log_n, coset):

@@ -42,6 +42,32 @@ def test_ntt_periodic_column_kat(oracle, golden, name, n):
         assert np.array_equal(back, coeffs)
 
 
+def test_ntt_poseidon_round_key_kat(oracle, golden):
+    """full_round_keys{0,1,2}_match (builtins/src/poseidon/periodic.rs:241-290): 8-point NTTs."""
+    g = golden("ntt_poseidon8.json")
+    for k in range(3):
+        coeffs = oracle.to_mont([int(v) for v in g["key%d" % k]["coeffs"]])
+        want = [int(v) for v in g["key%d" % k]["evals"]]
+        assert list(oracle.from_mont(oracle.ntt(coeffs))) == want
+        assert np.array_equal(oracle.ntt(oracle.to_mont(want), inverse=True), coeffs)
+
+
+def test_saved_proof_fixture_shape(golden):
+    """Header and out-of-domain tail of the reference's three saved proofs (data only):
+    mask sizes 269 (starknet) / 133 (recursive) are what the synthetic AIRs of bench.py are shaped to, the
+    values are canonical field elements, and the option bytes are the CLI's.  The OOD identity itself needs the
+    restated constraint sets."""
+    proofs = golden("saved_proofs.json")
+    assert [len(p["ood_trace"]) for p in proofs] == [269, 269, 133]
+    from sandstorm_amd import synthetic_air as sa
+    assert len(sa.layout_mask("starknet")) == 269 and len(sa.layout_mask("recursive")) == 133
+    for p in proofs:
+        assert len(p["ood_composition"]) == 2
+        assert all(0 <= int(v) < P for v in p["ood_trace"] + p["ood_composition"])
+        assert p["options"]["lde_blowup_factor"] == 2 and p["options"]["fri_folding_factor"] == 8
+        assert p["trace_len"] in (1 << 21, 1 << 18)
+
+
 def test_ntt_coset_matches_definition(oracle):
     n = 64
     col = random_column(n, 3)
