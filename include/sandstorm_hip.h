@@ -218,6 +218,19 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
  * (column k = evals[k*len/fold ..]) as pointers into d_evals (no copy). */
 ss_status ss_fri_fold(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
                       const uint64_t alpha[4], const uint64_t domain_offset[4], uint64_t *d_out);
+/* The same fold under the conventions found in the proof files the reference ships (data-only pin:
+ * tests/golden/make_fri_golden.py, tests/golden/fri_saved_proofs.json).  flags = 0 is ss_fri_fold.
+ *   SS_FRI_BITREV_ROWS    d_evals is in bit-reversed order: row r = evals[fold*r .. fold*r + fold), entry j of
+ *                         the row at x_r * w_fold^bitrev(j) with x_r = domain_offset * w^bitrev(r); d_out is the
+ *                         next layer, again in bit-reversed order (row r of this layer -> row r >> log2(fold),
+ *                         slot r & (fold-1) of the next)
+ *   SS_FRI_UNNORMALISED   d_out = fold * interpolant(alpha)  (StarkWare's fold: no 1/2 per halving)
+ * example/array-sum.proof.saved and bootloader-proof.bin (masked-20 digests, the current code path) carry
+ * BITREV_ROWS | UNNORMALISED; example/bootloader/bootloader-proof.bin (older path) carries flags = 0. */
+enum { SS_FRI_BITREV_ROWS = 1, SS_FRI_UNNORMALISED = 2 };
+ss_status ss_fri_fold_ex(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
+                         const uint64_t alpha[4], const uint64_t domain_offset[4], uint32_t flags,
+                         uint64_t *d_out);
 
 /* ---- C2: PublicCoin::grind_proof_of_work (crypto/src/public_coin/
  *      solidity.rs:120-141, cairo.rs:133-154).  Returns the SMALLEST nonce >= 1

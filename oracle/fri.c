@@ -5,40 +5,61 @@
  * the reference's defaults fri_folding_factor = 8, fri_max_remainder_coeffs =
  * 16 (cli/src/main.rs:57-60) and the DEEP coefficient rule of
  * src/lib.rs:102-116 (powers of one alpha, degree adjustment (1,0) = none).
- * PARITY UNPINNED: restated from the mathematical
- * definition, written as naive O(fold^2) sums on purpose so that the HIP
- * butterflies are checked against something structurally different.
+ * The FRI fold (M7/M8) is PINNED by data: the queried rows of consecutive layers in the proof files the
+ * reference ships satisfy or_fri_fold_ex under flags = 3 (current code path) resp. 0 (older path) - see
+ * tests/golden/make_fri_golden.py and fri_saved_proofs.json.  DEEP term order (M6) stays unpinned.
+ * Written as naive O(fold^2) sums on purpose so that the HIP butterflies are checked against something
+ * structurally different.
  */
 #include "oracle.h"
 #include <stdlib.h>
 
-void or_fri_fold(const fp_t *evals, unsigned log_len, unsigned fold, fp_t alpha, fp_t offset,
-                 fp_t *out) {
+/* flags: OR_FRI_BITREV_ROWS (1): the vector is in bit-reversed order - row r = evals[fold r .. fold r + fold),
+ * entry j of the row at x_r w_fold^bitrev(j), x_r = offset w^bitrev(r), output in bit-reversed order too;
+ * OR_FRI_UNNORMALISED (2): out = fold * interpolant(alpha).  The two conventions found in the proof files the
+ * reference ships (tests/golden/make_fri_golden.py): flags = 3 for the current code path, 0 for the older one. */
+static unsigned bitrev_u(unsigned x, unsigned bits) {
+    unsigned r = 0;
+    for (unsigned i = 0; i < bits; ++i) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+void or_fri_fold_ex(const fp_t *evals, unsigned log_len, unsigned fold, fp_t alpha, fp_t offset,
+                    unsigned flags, fp_t *out) {
     size_t len = (size_t)1 << log_len, rows = len / fold;
     unsigned log_fold = 0;
     while ((1u << log_fold) < fold) ++log_fold;
+    const unsigned row_bits = log_len - log_fold;
     fp_t w = fp_root_of_unity(log_len);
     fp_t wf_inv = fp_inv(fp_root_of_unity(log_fold));
-    fp_t fold_inv = fp_inv(fp_from_u64(fold));
+    fp_t fold_inv = (flags & 2u) ? FP_ONE : fp_inv(fp_from_u64(fold));
     /* table of wf_inv^e, e < fold */
     fp_t wfp[64];
     wfp[0] = FP_ONE;
     for (unsigned e = 1; e < fold; ++e) wfp[e] = fp_mul(wfp[e - 1], wf_inv);
 #pragma omp parallel for schedule(static) if (rows >= 256)
     for (size_t j = 0; j < rows; ++j) {
-        fp_t xj = fp_mul(offset, fp_pow_u64(w, (uint64_t)j));
+        const uint64_t e = (flags & 1u) ? bitrev_u((unsigned)j, row_bits) : (uint64_t)j;
+        fp_t xj = fp_mul(offset, fp_pow_u64(w, e));
         fp_t t = fp_mul(alpha, fp_inv(xj)); /* alpha / x_j */
         fp_t acc = {{0, 0, 0, 0}}, tm = FP_ONE;
         for (unsigned m = 0; m < fold; ++m) {
-            /* c_m * x_j^m = (1/fold) sum_k v_k wf^(-k m) */
+            /* c_m * x_j^m = (1/fold) sum_k v_k wf^(-k m),  v_k = f(x_j wf^k) */
             fp_t s = {{0, 0, 0, 0}};
-            for (unsigned k = 0; k < fold; ++k)
-                s = fp_add(s, fp_mul(evals[j + k * rows], wfp[(k * m) % fold]));
+            for (unsigned k = 0; k < fold; ++k) {
+                const fp_t vk = (flags & 1u) ? evals[j * fold + bitrev_u(k, log_fold)] : evals[j + k * rows];
+                s = fp_add(s, fp_mul(vk, wfp[(k * m) % fold]));
+            }
             acc = fp_add(acc, fp_mul(fp_mul(s, fold_inv), tm));
             tm = fp_mul(tm, t);
         }
         out[j] = acc;
     }
+}
+
+void or_fri_fold(const fp_t *evals, unsigned log_len, unsigned fold, fp_t alpha, fp_t offset,
+                 fp_t *out) {
+    or_fri_fold_ex(evals, log_len, fold, alpha, offset, 0, out);
 }
 
 void or_deep_compose(const fp_t *const *trace_lde, const fp_t *const *comp_lde, unsigned log_n,

@@ -73,6 +73,8 @@ void or_merkle_build(int tree, unsigned n_friendly_layers, int leaf_kind, const 
 /* One FRI layer fold: evals of length 2^log_len on
  * offset*<w>, natural order; row j = {evals[j + k*(len/fold)]}; out[j] = value
  * at alpha of the degree<fold interpolant over {offset*w^j * w_fold^k}. */
+void or_fri_fold_ex(const fp_t *evals, unsigned log_len, unsigned fold, fp_t alpha, fp_t offset,
+                    unsigned flags, fp_t *out);
 void or_fri_fold(const fp_t *evals, unsigned log_len, unsigned fold, fp_t alpha, fp_t offset,
                  fp_t *out);
 

@@ -193,12 +193,15 @@ def merkle_build(tree, n_friendly, leaf_kind, leaves):
 
 
 # ----------------------------------------------------------------- FRI / DEEP
-def fri_fold(evals, fold, alpha, offset):
+FRI_BITREV_ROWS, FRI_UNNORMALISED = 1, 2
+
+
+def fri_fold(evals, fold, alpha, offset, flags=0):
     a = _c(evals)
     n = a.shape[0]
     out = np.zeros((n // fold, 4), dtype=np.uint64)
-    lib().or_fri_fold(_ptr(a), C.c_uint(n.bit_length() - 1), C.c_uint(fold), _fp(alpha),
-                      _fp(offset), _ptr(out))
+    lib().or_fri_fold_ex(_ptr(a), C.c_uint(n.bit_length() - 1), C.c_uint(fold), _fp(alpha),
+                         _fp(offset), C.c_uint(flags), _ptr(out))
     return out
 
 

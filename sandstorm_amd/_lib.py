@@ -63,6 +63,7 @@ SIGNATURES = {
                                   _u64p, _u32p, _u32p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, _u64p, C.c_void_p]),
     "ss_fri_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _u64p, _u64p, C.c_void_p]),
+    "ss_fri_fold_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _u64p, _u64p, C.c_uint32, C.c_void_p]),
     "ss_pow_grind": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, _u64p]),
     "ss_pedersen_hash": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "ss_pedersen_hash_host": (C.c_int, [_u64p, _u64p, _u64p]),

@@ -25,6 +25,7 @@ P = 2**251 + 17 * 2**192 + 1
 R = 2**256
 
 NATURAL, BITREV = 0, 1
+FRI_BITREV_ROWS, FRI_UNNORMALISED = 1, 2
 FORWARD, INVERSE = 0, 1
 HASH_KECCAK, HASH_KECCAK_M20, HASH_BLAKE2S, HASH_BLAKE2S_M20 = 0, 1, 2, 3
 TREE_KECCAK, TREE_KECCAK_M20, TREE_FRIENDLY = 0, 1, 2
@@ -195,10 +196,11 @@ class Context:
                                       idx.ctypes.data_as(C.POINTER(C.c_uint64)), len(idx), out.ctypes.data))
         return out
 
-    def fri_fold(self, evals, log_len, fold, alpha, offset, out):
+    def fri_fold(self, evals, log_len, fold, alpha, offset, out, flags=0):
+        """flags: FRI_BITREV_ROWS | FRI_UNNORMALISED (include/sandstorm_hip.h: the conventions of the reference's proofs)"""
         _k1, a = _felt_ptr(alpha)
         _k2, o = _felt_ptr(offset)
-        check(self.lib.ss_fri_fold(self.handle, _ptr_of(evals), log_len, fold, a, o, _ptr_of(out)))
+        check(self.lib.ss_fri_fold_ex(self.handle, _ptr_of(evals), log_len, fold, a, o, flags, _ptr_of(out)))
 
     def pow_grind(self, coin_kind, digest, bits):
         nonce = C.c_uint64()

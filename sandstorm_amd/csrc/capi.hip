@@ -262,7 +262,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return 1; }
+uint32_t ss_abi_version(void) { return 2; }   // 2: ss_ctx_trim, ss_fri_fold_ex
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -610,7 +610,12 @@ ss_status ss_gather_rows(ss_ctx *ctx, const uint64_t *const *d_cols, uint32_t nc
 // ------------------------------------------------------------------- FRI
 ss_status ss_fri_fold(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
                       const uint64_t alpha[4], const uint64_t domain_offset[4], uint64_t *d_out) {
+    return ss_fri_fold_ex(ctx, d_evals, log_len, fold, alpha, domain_offset, 0, d_out);
+}
+ss_status ss_fri_fold_ex(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
+                         const uint64_t alpha[4], const uint64_t domain_offset[4], uint32_t flags, uint64_t *d_out) {
     if (!ctx || !d_evals || !alpha || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (flags & ~(uint32_t)(SS_FRI_BITREV_ROWS | SS_FRI_UNNORMALISED)) return fail(SS_ERR_INVALID, "unknown FRI flags %u", flags);
     uint32_t log_fold = 0;
     while ((1u << log_fold) < fold) ++log_fold;
     if ((1u << log_fold) != fold || log_fold < 1 || log_fold > 4) return fail(SS_ERR_INVALID, "fold must be 2, 4, 8 or 16");
@@ -623,7 +628,7 @@ ss_status ss_fri_fold(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, ui
     for (int k = 1; k < 8; ++k) tw[k] = fp_mul(tw[k - 1], wf_inv);
     ss_ctx::Scope prof(ctx, SS_PROF_FRI);
     HIP_TRY(launch_fri_fold(ctx->stream, (const Fp *)d_evals, log_len, log_fold, fp_from_limbs64(alpha),
-                            fp_inv(off), w_inv, tw, (Fp *)d_out));
+                            fp_inv(off), w_inv, tw, flags, (Fp *)d_out));
     return SS_OK;
 }
 

@@ -9,7 +9,16 @@
 // i.e. a size-`fold` inverse NTT held in registers followed by Horner.
 // One lane = one row; lane j reads evals[j + k*rows] for each k, so every load
 // instruction of a wave is a contiguous 2 KiB run.
+//
+// Two conventions, both pinned by proof files the reference ships (tests/golden/make_fri_golden.py):
+//   flags = 0                    natural order, normalised - the older code path's proofs
+//   SS_FRI_BITREV_ROWS           the vector is in bit-reversed order: row r = evals[fold r .. fold r + fold),
+//                                entry j of a row at x_r w_fold^bitrev(j), x_r = offset w^bitrev(r); the output is
+//                                the next layer in bit-reversed order again
+//   SS_FRI_UNNORMALISED          out = fold * interpolant(alpha): StarkWare's fold, no 1/2 per halving
+// BITREV_ROWS | UNNORMALISED is what the current code path's proofs contain.
 #include <hip/hip_runtime.h>
+#include "../../include/sandstorm_hip.h"
 #include "fp252.h"
 #include "kernels.h"
 
@@ -18,6 +27,7 @@ namespace ss {
 struct FriConsts {
     Fp alpha, offset_inv, w_inv;
     Fp tw_inv[8];  // w_fold^(-k), k < fold/2
+    uint32_t flags;
 };
 
 __device__ __forceinline__ Fp fri_load(const Fp *p) {
@@ -63,27 +73,37 @@ __global__ __launch_bounds__(128) void fri_fold_kernel(const Fp *__restrict__ ev
     const uint64_t rows = (1ull << log_len) >> LOGF;
     const uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (j >= rows) return;
-    Fp v[F];
+    const bool bitrev_rows = (c.flags & SS_FRI_BITREV_ROWS) != 0;
+    Fp v[F];                                         // v[k] = f(x_j w_fold^k)
+    if (bitrev_rows) {
 #pragma unroll
-    for (int k = 0; k < F; ++k) v[k] = fri_load(evals + j + (uint64_t)k * rows);
+        for (int k = 0; k < F; ++k) v[k] = fri_load(evals + j * F + brev_c(k, LOGF));
+    } else {
+#pragma unroll
+        for (int k = 0; k < F; ++k) v[k] = fri_load(evals + j + (uint64_t)k * rows);
+    }
     // unnormalised inverse NTT, DIF: natural in, bit-reversed out
     if (LOGF >= 4) fri_stage<LOGF, 3>(v, c);
     if (LOGF >= 3) fri_stage<LOGF, 2>(v, c);
     if (LOGF >= 2) fri_stage<LOGF, 1>(v, c);
     fri_stage<LOGF, 0>(v, c);
-    // t = alpha / x_j,  1/x_j = offset^-1 * w^-j
-    const Fp t = fp_mul(c.alpha, fp_mul(c.offset_inv, fp_pow_u64(c.w_inv, j)));
+    // t = alpha / x_j,  1/x_j = offset^-1 * w^-e,  e = j (natural) or bitrev(j) over the log2(rows) row bits
+    const uint32_t row_bits = log_len - LOGF;
+    const uint64_t e = bitrev_rows ? (row_bits ? (uint64_t)(__brevll(j) >> (64u - row_bits)) : 0ull) : j;
+    const Fp t = fp_mul(c.alpha, fp_mul(c.offset_inv, fp_pow_u64(c.w_inv, e)));
     // Horner over natural-order coefficients c_m = v[bitrev(m)]
     Fp acc = v[brev_c(F - 1, LOGF)];
 #pragma unroll
     for (int m = F - 2; m >= 0; --m) acc = fp_add(fp_mul(acc, t), v[brev_c(m, LOGF)]);
-    fri_store(out + j, fp_div_pow2(acc, LOGF));
+    // the butterflies above are an unnormalised inverse NTT: acc = fold * interpolant(alpha)
+    fri_store(out + j, (c.flags & SS_FRI_UNNORMALISED) ? acc : fp_div_pow2(acc, LOGF));
 }
 
 hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, uint32_t log_fold,
                            const Fp &alpha, const Fp &offset_inv, const Fp &w_inv, const Fp *fold_tw_inv,
-                           Fp *out) {
+                           uint32_t flags, Fp *out) {
     FriConsts c;
+    c.flags = flags;
     c.alpha = alpha; c.offset_inv = offset_inv; c.w_inv = w_inv;
     for (int k = 0; k < 8; ++k) c.tw_inv[k] = k < (1 << log_fold) / 2 ? fold_tw_inv[k] : fp_zero();
     const uint64_t rows = (1ull << log_len) >> log_fold;

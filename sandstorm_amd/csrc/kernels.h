@@ -69,7 +69,7 @@ Fp pedersen_hash_host(const Fp &a, const Fp &b);
 // ---- fri.hip
 hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, uint32_t log_fold,
                            const Fp &alpha, const Fp &offset_inv, const Fp &w_inv, const Fp *fold_tw_inv,
-                           Fp *out);
+                           uint32_t flags, Fp *out);
 
 // ---- deep.hip
 hipError_t launch_poly_reduce(hipStream_t st, const void *const *in, void *const *out, uint32_t ncols,

@@ -313,6 +313,33 @@ def test_fri_fold_vs_oracle(ctx, be, oracle, fold, log_len):
     assert np.array_equal(got, oracle.fri_fold(ev, fold, alpha, off))
 
 
+@pytest.mark.parametrize("flags", [1, 2, 3])
+@pytest.mark.parametrize("log_len", [3, 9, 13])
+def test_fri_fold_conventions_vs_oracle(ctx, be, oracle, flags, log_len):
+    n = 1 << log_len
+    ev = random_column(n, 41 + flags)
+    alpha = oracle.to_mont([0x1234567890ABCDEF ** 3 % P])[0]
+    off = g3(oracle)
+    out = ctx.alloc(32 * (n // 8))
+    ctx.fri_fold(ctx.column(ev), log_len, 8, alpha, off, out, flags)
+    assert np.array_equal(out.download(np.uint64, (n // 8, 4)), oracle.fri_fold(ev, 8, alpha, off, flags))
+
+
+def test_fri_fold_matches_reference_proofs(ctx, be, oracle, golden):
+    """The fold known-answer vectors recovered from the reference's shipped proof files, on the GPU."""
+    g = golden("fri_saved_proofs.json")
+    one = oracle.to_mont([1])[0]
+    out = ctx.alloc(32)
+    for v in g["vectors"]:
+        conv = g["conventions"][v["convention"]]
+        flags = (be.FRI_BITREV_ROWS if conv["bitrev_rows"] else 0) | (be.FRI_UNNORMALISED if conv["scale"] == 8 else 0)
+        row = oracle.to_mont([int(x, 16) for x in v["values"]])
+        beta = oracle.to_mont([int(v["beta"], 16)])[0]
+        ctx.fri_fold(ctx.column(row), 3, 8, beta, one, out, flags)
+        got = oracle.from_mont(out.download(np.uint64, (1, 4)))
+        assert got[0] == int(v["next"], 16), (v["file"], v["layer"], v["row"])
+
+
 def test_fri_fold_large_degree_property(ctx, be, oracle):
     """2^21 evaluations of a degree < 2^18 polynomial fold (x8) to evaluations of a degree < 2^15 one."""
     log_len, n = 21, 1 << 21

@@ -187,3 +187,19 @@ def test_friendly_tree_large_threaded(oracle, pedersen):
     for k in (n // 2, n // 2 + 1, n - 1, 1500):
         a, b = bytes(nodes[2 * k]), bytes(nodes[2 * k + 1])
         assert int.from_bytes(bytes(nodes[k]), "big") == pedersen(int.from_bytes(a, "big") % P, int.from_bytes(b, "big") % P)
+
+
+def test_fri_fold_conventions_agree(oracle):
+    """BITREV_ROWS is the natural-order fold seen through the bit-reversal permutation of both layers;
+    UNNORMALISED is `fold` times the normalised value."""
+    log_len, fold = 9, 8
+    n = 1 << log_len
+    ev = random_column(n, 31)
+    alpha, off = oracle.to_mont([0xABCDEF12345])[0], oracle.to_mont([3])[0]
+    nat = oracle.fri_fold(ev, fold, alpha, off)
+    br = lambda i, bits: int(format(i, "0%db" % bits)[::-1], 2)
+    ev_br = ev[[br(i, log_len) for i in range(n)]]
+    got = oracle.fri_fold(ev_br, fold, alpha, off, oracle.FRI_BITREV_ROWS)
+    assert np.array_equal(got, nat[[br(i, log_len - 3) for i in range(n // fold)]])
+    un = oracle.from_mont(oracle.fri_fold(ev, fold, alpha, off, oracle.FRI_UNNORMALISED))
+    assert [int(x) for x in un] == [int(x) * fold % P for x in oracle.from_mont(nat)]

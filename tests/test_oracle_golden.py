@@ -52,6 +52,27 @@ def test_ntt_poseidon_round_key_kat(oracle, golden):
         assert np.array_equal(oracle.ntt(oracle.to_mont(want), inverse=True), coeffs)
 
 
+def test_fri_fold_matches_reference_proofs(oracle, golden):
+    """The reference's OWN proofs pin the fold: every queried row of every FRI layer of the three shipped proof
+    files, folded at beta = alpha / x (recovered from the data alone, tests/golden/make_fri_golden.py), gives
+    the matching entry of the next layer - under bit-reversed rows + the unnormalised fold for the two files of
+    the current code path, natural rows + the normalised fold for the older one."""
+    g = golden("fri_saved_proofs.json")
+    one = oracle.to_mont([1])[0]
+    seen = set()
+    for v in g["vectors"]:
+        conv = g["conventions"][v["convention"]]
+        flags = (oracle.FRI_BITREV_ROWS if conv["bitrev_rows"] else 0) | (oracle.FRI_UNNORMALISED if conv["scale"] == 8 else 0)
+        row = oracle.to_mont([int(x, 16) for x in v["values"]])
+        beta = oracle.to_mont([int(v["beta"], 16)])[0]
+        got = oracle.from_mont(oracle.fri_fold(row, 8, beta, one, flags))
+        assert got[0] == int(v["next"], 16), (v["file"], v["layer"], v["row"])
+        # ... and NOT under the other convention (the pin discriminates)
+        assert oracle.from_mont(oracle.fri_fold(row, 8, beta, one, flags ^ 3))[0] != int(v["next"], 16)
+        seen.add((v["file"], v["convention"]))
+    assert len(seen) == 3 and len(g["vectors"]) >= 100
+
+
 def test_saved_proof_fixture_shape(golden):
     """Header and out-of-domain tail of the reference's three saved proofs (data only):
     mask sizes 269 (starknet) / 133 (recursive) are what the synthetic AIRs of bench.py are shaped to, the
