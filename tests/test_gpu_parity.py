@@ -264,6 +264,41 @@ def test_friendly_merkle_large_and_small_levels(ctx, be, oracle):
     assert root == bytes(want_nodes[1])
 
 
+def test_merkle_openings_of_reference_proof(ctx, be, oracle, golden):
+    """The reference's saved proof on the GPU: ss_hash_rows reproduces the leaf digests of the opened rows and
+    ss_merkle_build (two leaves at a time, up each authentication path) reproduces the proof's roots."""
+    g = golden("saved_proof_openings.json")
+    roots = g["roots"]
+
+    def rowhash(vals_hex):
+        m = be.Matrix.from_host(ctx, [oracle.to_mont([int(v, 16)]) for v in vals_hex])
+        return bytes(m.hash_rows(be.HASH_KECCAK_M20).download(np.uint8, (1, 32))[0])
+
+    pair_leaves, nodes = ctx.alloc(64), ctx.alloc(128)
+
+    def climb(cur, path, pos):
+        for lvl, sib in enumerate(path):
+            a, b = (cur, sib) if ((pos >> lvl) & 1) == 0 else (sib, cur)
+            pair_leaves.upload(np.frombuffer(a + b, dtype=np.uint8))
+            root, _ = ctx.merkle_build(be.TREE_KECCAK_M20, 0, 0, pair_leaves, 2, nodes)
+            cur = root
+        return cur
+
+    for q in g["queries"][:2]:
+        p = q["position"]
+        for name in ("base", "composition"):
+            leaf = rowhash(q[name]["row"])
+            assert climb(leaf, [bytes.fromhex(d) for d in q[name]["path"]], p).hex() == roots[name]
+        f = q["fri"][0]
+        assert climb(rowhash(f["row"]), [bytes.fromhex(d) for d in f["path"]], f["position"]).hex() == roots["fri_layers"][0]
+        # single-column tree: the leaf level hashes raw elements (UnhashedLeafConfig)
+        pair = [q["extension"]["leaf"], q["extension"]["sibling"]]
+        pair = pair if (p & 1) == 0 else pair[::-1]
+        felts = ctx.column(oracle.to_mont([int(v, 16) for v in pair]))
+        first, _ = ctx.merkle_build(be.TREE_KECCAK_M20, 0, 1, felts, 2, nodes)
+        assert climb(first, [bytes.fromhex(d) for d in q["extension"]["path"]], p >> 1).hex() == roots["extension"]
+
+
 def test_merkle_tree_classes(ctx, be, oracle):
     """from_matrix / root / prove on the reference's 8-row test matrices (merkle/mod.rs:455-634)."""
     col = oracle.to_mont(list(range(8)))

@@ -73,6 +73,64 @@ def test_fri_fold_matches_reference_proofs(oracle, golden):
     assert len(seen) == 3 and len(g["vectors"]) >= 100
 
 
+def _climb(oracle, cur, path, pos, kind=1):
+    import ctypes as C
+    lib = oracle.lib()
+    for lvl, sib in enumerate(path):
+        a, b = (cur, sib) if ((pos >> lvl) & 1) == 0 else (sib, cur)
+        out = (C.c_uint8 * 32)()
+        lib.or_hash_merge(C.c_int(kind), (C.c_uint8 * 32).from_buffer_copy(a), (C.c_uint8 * 32).from_buffer_copy(b), out)
+        cur = bytes(out)
+    return cur
+
+
+def _rowhash(oracle, vals_hex, kind=1):
+    m = oracle.to_mont([int(v, 16) for v in vals_hex])
+    return bytes(oracle.hash_rows(kind, [m[k:k + 1] for k in range(len(vals_hex))])[0])
+
+
+def test_merkle_openings_of_reference_proof(oracle, golden):
+    """Every Merkle opening of example/array-sum.proof.saved (tests/golden/make_proof_golden.py checked all 16
+    queries; 4 are committed) verifies against the proof's roots with the oracle's row hash (H1), unhashed-leaf
+    first layer (H2), node hash and pairing (H3/H4): the reference's own data pins them.  Position p opens row p
+    of the trace trees and row p >> 3(i+1) of FRI layer i."""
+    g = golden("saved_proof_openings.json")
+    roots = g["roots"]
+    for q in g["queries"]:
+        p = q["position"]
+        for name in ("base", "composition"):
+            leaf = _rowhash(oracle, q[name]["row"])
+            assert _climb(oracle, leaf, [bytes.fromhex(d) for d in q[name]["path"]], p).hex() == roots[name]
+        pair = [q["extension"]["leaf"], q["extension"]["sibling"]]
+        first = _rowhash(oracle, pair if (p & 1) == 0 else pair[::-1])            # hash_elements([l0, l1])
+        assert _climb(oracle, first, [bytes.fromhex(d) for d in q["extension"]["path"]], p >> 1).hex() == roots["extension"]
+        for li, f in enumerate(q["fri"]):
+            assert f["position"] == p >> (3 * (li + 1))
+            leaf = _rowhash(oracle, f["row"])
+            assert _climb(oracle, leaf, [bytes.fromhex(d) for d in f["path"]], f["position"]).hex() == roots["fri_layers"][li]
+        # a wrong sibling order must not verify (the pin discriminates)
+        leaf = _rowhash(oracle, q["base"]["row"])
+        assert _climb(oracle, leaf, [bytes.fromhex(d) for d in q["base"]["path"]], p ^ 1).hex() != roots["base"]
+
+
+def test_committed_order_is_bit_reversed(golden):
+    """beta = alpha / x per queried FRI row (fri_saved_proofs.json) times w_L^bitrev(row position) is ONE constant
+    per layer - and 16 different values under the natural map: index i of a committed vector is the point
+    offset * w_L^bitrev(i), w_L = 3^((p-1)/L)."""
+    g, fri = golden("saved_proof_openings.json"), golden("fri_saved_proofs.json")
+    positions = g["positions"]
+    log_N = (g["trace_len"] * g["options"][1]).bit_length() - 1
+    brev = lambda x, bits: int(format(x, "0%db" % bits)[::-1], 2) if bits else 0
+    for li, want in enumerate(g["alpha_over_offset"]):
+        rows_log = log_N - 3 * (li + 1)
+        w = pow(3, (P - 1) >> (rows_log + 3), P)
+        ps = sorted(set(pp >> (3 * (li + 1)) for pp in positions))
+        betas = {v["row"]: int(v["beta"], 16) for v in fri["vectors"]
+                 if v["file"] == g["file"] and v["layer"] == li}
+        assert {betas[r] * pow(w, brev(ps[r], rows_log), P) % P for r in betas} == {int(want, 16)}
+        assert len({betas[r] * pow(w, ps[r], P) % P for r in betas}) > 1
+
+
 def test_saved_proof_fixture_shape(golden):
     """Header and out-of-domain tail of the reference's three saved proofs (data only):
     mask sizes 269 (starknet) / 133 (recursive) are what the synthetic AIRs of bench.py are shaped to, the
