@@ -10,6 +10,9 @@ of the reference runs.  What holds (all 16 queries; base, extension and composit
   * inner node = masked Keccak(left || right); children of node k are 2k, 2k+1; paths are listed bottom-up;
   * a query position p (22 bits) opens row p of the three trace trees, row p >> 3 of FRI layer 0 (slot p & 7),
     row p >> 6 of layer 1, ... - the trace LDE and the FRI evaluation vectors share one index space;
+  * the remainder polynomial (8 coefficients here) interpolates the fold of the last layer over the UNSHIFTED
+    domain: 8 P_r(alpha) = R(w'^bitrev(r)) has one common alpha/offset for all rows, none when the coset offset is
+    put inside R's argument (so the LDE offset itself cannot be read off the FRI data);
   * that index space is BIT-REVERSED: with beta = alpha / x recovered per row by make_fri_golden.py,
     beta * w_L^bitrev(row) is one constant (alpha / offset) for all 16 rows of a layer, while the natural map
     gives 16 different values: committed index i <-> point offset * w_L^bitrev(i), w_L = 3^((p-1)/L).
@@ -184,6 +187,35 @@ def main():
         consts.append(next(iter(br)))
     print("index i <-> offset * w^bitrev(i) holds on every layer (natural order does not)")
 
+    # remainder: the last layer folds onto a polynomial in the UNSHIFTED variable t = y / offset:
+    #   8 * P_r(alpha) = R(w'^bitrev(r))  has one alpha/offset common to all rows; with the coset offset 3^(8^k)
+    #   inside R's argument there is none.
+    sys.path.insert(0, HERE)
+    import make_fri_golden as G
+    last_vals, _pr, _root = layers[-1]
+    rows_log = (trace_len * opts[1]).bit_length() - 1 - 3 * nl
+    wl = pow(3, (P - 1) >> (rows_log + 3), P)
+    ps = sorted(set(pp >> (3 * nl) for pp in positions))
+
+    def evalp(c, x):
+        a = 0
+        for k in reversed(c):
+            a = (a * x + k) % P
+        return a
+
+    def common_alpha(offset):
+        sets = []
+        for r, pos in enumerate(ps):
+            x = offset * pow(wl, brev(pos, rows_log), P) % P
+            f = [8 * c % P for c in G.fold_poly(last_vals[8 * r:8 * r + 8], True)]
+            f[0] = (f[0] - evalp(remainder, pow(x, 8, P))) % P
+            sets.append({b * x % P for b in G.roots(f)})
+        return set.intersection(*sets)
+    unshifted, shifted = common_alpha(1), common_alpha(pow(3, 8 ** (nl - 1), P))
+    assert len(unshifted) == 1 and len(shifted) == 0
+    rem_const = next(iter(unshifted))
+    print("remainder = interpolant of the folded last layer over the unshifted domain (%d coefficients)" % len(remainder))
+
     hx = lambda b: b.hex()
     hv = lambda v: "%x" % v
     K = 4
@@ -191,7 +223,8 @@ def main():
            "roots": {"base": hx(base_root), "extension": hx(ext_root), "composition": hx(comp_root),
                      "fri_layers": [hx(l[2]) for l in layers]},
            "remainder": [hv(v) for v in remainder], "positions": positions,
-           "alpha_over_offset": [hv(c) for c in consts],
+           "alpha_over_offset": [hv(c) for c in consts], "last_alpha_over_offset": hv(rem_const),
+           "last_layer_rows": [[hv(v) for v in last_vals[8 * r:8 * r + 8]] for r in range(len(last_vals) // 8)],
            "queries": []}
     for q in range(K):
         p = positions[q]

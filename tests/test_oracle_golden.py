@@ -131,6 +131,29 @@ def test_committed_order_is_bit_reversed(golden):
         assert len({betas[r] * pow(w, ps[r], P) % P for r in betas}) > 1
 
 
+def test_remainder_of_reference_proof(oracle, golden):
+    """The last FRI layer of the saved proof folds (bit-reversed rows, unnormalised) onto its remainder polynomial
+    taken in the UNSHIFTED variable: fold(row; alpha/offset as recovered, x = w'^bitrev(pos)) == R(x^8)."""
+    g = golden("saved_proof_openings.json")
+    rem = [int(v, 16) for v in g["remainder"]]
+    c = int(g["last_alpha_over_offset"], 16)
+    nl = len(g["roots"]["fri_layers"])
+    rows_log = (g["trace_len"] * g["options"][1]).bit_length() - 1 - 3 * nl
+    w = pow(3, (P - 1) >> (rows_log + 3), P)
+    ps = sorted(set(pp >> (3 * nl) for pp in g["positions"]))
+    brev = lambda x, bits: int(format(x, "0%db" % bits)[::-1], 2) if bits else 0
+    one = oracle.to_mont([1])[0]
+    for r, pos in enumerate(ps):
+        x = pow(w, brev(pos, rows_log), P)
+        row = oracle.to_mont([int(v, 16) for v in g["last_layer_rows"][r]])
+        beta = oracle.to_mont([c * pow(x, -1, P) % P])[0]
+        got = oracle.from_mont(oracle.fri_fold(row, 8, beta, one, oracle.FRI_BITREV_ROWS | oracle.FRI_UNNORMALISED))[0]
+        y, want = pow(x, 8, P), 0
+        for k in reversed(rem):
+            want = (want * y + k) % P
+        assert got == want, r
+
+
 def test_saved_proof_fixture_shape(golden):
     """Header and out-of-domain tail of the reference's three saved proofs (data only):
     mask sizes 269 (starknet) / 133 (recursive) are what the synthetic AIRs of bench.py are shaped to, the
