@@ -120,6 +120,11 @@ ss_status ss_evaluate_fp252(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32
  * natural index order from the column arrays. */
 ss_status ss_hash_rows(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_cols, uint32_t ncols,
                        uint64_t nrows, uint8_t *d_digests);
+/* The same with the leaf order of the reference's proofs: row_order = SS_ORDER_BITREV makes digest i the hash of
+ * matrix row bitrev(i) (index i of a committed vector is the point offset * w^bitrev(i): pinned by
+ * tests/golden/make_proof_golden.py).  The matrix stays in natural order - nothing is permuted in memory. */
+ss_status ss_hash_rows_ex(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_cols, uint32_t ncols,
+                       uint64_t nrows, int row_order, uint8_t *d_digests);
 
 /* ---- H2/H3/H4: MatrixMerkleTree::from_matrix tree build
  *      (crypto/src/merkle/mod.rs:110-123, 289-304; node rules mixed.rs:106-155,
@@ -131,6 +136,11 @@ ss_status ss_hash_rows(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_cols
  * root_out[0..32) digest, root_out[32] tag. */
 ss_status ss_merkle_build(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_layers, int leaf_kind,
                           const void *d_leaves, uint64_t n, uint8_t *d_nodes, uint8_t *d_tags,
+                          uint8_t root_out[33]);
+/* leaf_order = SS_ORDER_BITREV: for SS_LEAF_FELT the leaf slot i holds element bitrev(i) of the column (digest
+ * leaves are taken as given - order them with ss_hash_rows_ex). */
+ss_status ss_merkle_build_ex(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_layers, int leaf_kind,
+                          const void *d_leaves, uint64_t n, int leaf_order, uint8_t *d_nodes, uint8_t *d_tags,
                           uint8_t root_out[33]);
 /* MerkleTree::prove: authentication paths for `nidx` leaf indices.
  * out: nidx * log2(n) sibling digests (leaf level first), 32 bytes each;

@@ -48,7 +48,10 @@ SIGNATURES = {
     "ss_lde_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _vpp, _vpp]),
     "ss_evaluate_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _vpp]),
     "ss_hash_rows": (C.c_int, [C.c_void_p, C.c_int, _vpp, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "ss_hash_rows_ex": (C.c_int, [C.c_void_p, C.c_int, _vpp, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]),
     "ss_merkle_build": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64,
+                                  C.c_void_p, C.c_void_p, _u8p]),
+    "ss_merkle_build_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64, C.c_int,
                                   C.c_void_p, C.c_void_p, _u8p]),
     "ss_merkle_open": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, _u64p, C.c_uint32,
                                  C.c_void_p, C.c_void_p]),

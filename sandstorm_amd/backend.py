@@ -170,13 +170,14 @@ class Context:
         check(self.lib.ss_evaluate_fp252(self.handle, _ptr_array(coeff_cols), len(coeff_cols), log_n, log_blowup,
                                          off, _ptr_array(evals_out)))
 
-    def hash_rows(self, kind, cols, nrows, out):
-        check(self.lib.ss_hash_rows(self.handle, kind, _ptr_array(cols), len(cols), nrows, _ptr_of(out)))
+    def hash_rows(self, kind, cols, nrows, out, order=NATURAL):
+        """order=BITREV: digest i is the hash of row bitrev(i) - the reference's commitment order"""
+        check(self.lib.ss_hash_rows_ex(self.handle, kind, _ptr_array(cols), len(cols), nrows, order, _ptr_of(out)))
 
-    def merkle_build(self, tree, n_friendly, leaf_kind, leaves, n, nodes, tags=None):
+    def merkle_build(self, tree, n_friendly, leaf_kind, leaves, n, nodes, tags=None, leaf_order=NATURAL):
         root = (C.c_uint8 * 33)()
-        check(self.lib.ss_merkle_build(self.handle, tree, n_friendly, leaf_kind, _ptr_of(leaves), n,
-                                       _ptr_of(nodes), _ptr_of(tags) if tags is not None else None, root))
+        check(self.lib.ss_merkle_build_ex(self.handle, tree, n_friendly, leaf_kind, _ptr_of(leaves), n, leaf_order,
+                                          _ptr_of(nodes), _ptr_of(tags) if tags is not None else None, root))
         return bytes(root[:32]), int(root[32])
 
     def merkle_open(self, nodes, tags, n, indices):
@@ -325,9 +326,9 @@ class Matrix:
         self.ctx.lde(self.cols, self.log_rows, log_blowup, offset, ev.cols, co.cols if co else None)
         return ev, co
 
-    def hash_rows(self, kind):
+    def hash_rows(self, kind, order=NATURAL):
         out = self.ctx.alloc(32 * self.nrows)
-        self.ctx.hash_rows(kind, self.cols, self.nrows, out)
+        self.ctx.hash_rows(kind, self.cols, self.nrows, out, order)
         return out
 
 
@@ -341,16 +342,17 @@ class _MerkleTree:
         self._root, self._root_tag, self.leaf_kind = root, root_tag, leaf_kind
 
     @classmethod
-    def from_matrix(cls, matrix):
-        """MatrixMerkleTree::from_matrix (crypto/src/merkle/mod.rs:110-123, 289-304)"""
+    def from_matrix(cls, matrix, order=NATURAL):
+        """MatrixMerkleTree::from_matrix (crypto/src/merkle/mod.rs:110-123, 289-304).  order=BITREV: leaf i is row
+        bitrev(i) of the (natural-order) matrix - the commitment order of the reference's proofs."""
         ctx, n = matrix.ctx, matrix.nrows
         nodes = ctx.alloc(64 * n)
         tags = ctx.alloc(2 * n) if cls.tree_kind == TREE_FRIENDLY else None
         if matrix.num_cols == 1:
             leaf_kind, leaves = LEAF_FELT, matrix.cols[0]
         else:
-            leaf_kind, leaves = LEAF_DIGEST, matrix.hash_rows(cls.row_hash)
-        root, tag = ctx.merkle_build(cls.tree_kind, cls.n_friendly, leaf_kind, leaves, n, nodes, tags)
+            leaf_kind, leaves = LEAF_DIGEST, matrix.hash_rows(cls.row_hash, order)
+        root, tag = ctx.merkle_build(cls.tree_kind, cls.n_friendly, leaf_kind, leaves, n, nodes, tags, order)
         return cls(ctx, n, nodes, tags, root, tag, leaf_kind)
 
     def root(self):

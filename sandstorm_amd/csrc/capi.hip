@@ -480,25 +480,49 @@ ss_status ss_evaluate_fp252(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32
 // --------------------------------------------------------------- hashing
 ss_status ss_hash_rows(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_cols, uint32_t ncols,
                        uint64_t nrows, uint8_t *d_digests) {
+    return ss_hash_rows_ex(ctx, hash_kind, d_cols, ncols, nrows, SS_ORDER_NATURAL, d_digests);
+}
+ss_status ss_hash_rows_ex(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_cols, uint32_t ncols,
+                          uint64_t nrows, int row_order, uint8_t *d_digests) {
     if (!ctx || !d_cols || !d_digests) return fail(SS_ERR_INVALID, "NULL argument");
+    uint32_t brev_bits = 0;
+    if (row_order == SS_ORDER_BITREV) {
+        if (nrows == 0 || (nrows & (nrows - 1))) return fail(SS_ERR_INVALID, "bit-reversed row order needs a power-of-two row count");
+        while ((1ull << brev_bits) < nrows) ++brev_bits;
+    } else if (row_order != SS_ORDER_NATURAL) {
+        return fail(SS_ERR_INVALID, "bad row order %d", row_order);
+    }
     if (hash_kind < 0 || hash_kind > 3) return fail(SS_ERR_INVALID, "bad hash kind %d", hash_kind);
     if (ncols == 0 || ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u not in [1,%d]", ncols, MAX_COLS);
     ConstColPtrs cols;
     memset(&cols, 0, sizeof cols);
     for (uint32_t c = 0; c < ncols; ++c) cols.p[c] = d_cols[c];
     ss_ctx::Scope prof(ctx, SS_PROF_HASH_ROWS);
-    HIP_TRY(launch_hash_rows(ctx->stream, hash_kind, cols, ncols, nrows, d_digests));
+    HIP_TRY(launch_hash_rows(ctx->stream, hash_kind, cols, ncols, nrows, brev_bits, d_digests));
     return SS_OK;
 }
 
 ss_status ss_merkle_build(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_layers, int leaf_kind,
                           const void *d_leaves, uint64_t n, uint8_t *d_nodes, uint8_t *d_tags,
                           uint8_t root_out[33]) {
+    return ss_merkle_build_ex(ctx, tree_kind, n_friendly_layers, leaf_kind, d_leaves, n, SS_ORDER_NATURAL, d_nodes, d_tags, root_out);
+}
+ss_status ss_merkle_build_ex(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_layers, int leaf_kind,
+                             const void *d_leaves, uint64_t n, int leaf_order, uint8_t *d_nodes, uint8_t *d_tags,
+                             uint8_t root_out[33]) {
     if (!ctx || !d_leaves || !d_nodes) return fail(SS_ERR_INVALID, "NULL argument");
     if (n < 2 || (n & (n - 1))) return fail(SS_ERR_INVALID, "n must be a power of two >= 2");
     if (tree_kind < 0 || tree_kind > 2) return fail(SS_ERR_INVALID, "bad tree kind");
+    if (leaf_order != SS_ORDER_NATURAL && leaf_order != SS_ORDER_BITREV) return fail(SS_ERR_INVALID, "bad leaf order %d", leaf_order);
     uint32_t log_n = 0;
     while ((1ull << log_n) < n) ++log_n;
+    if (leaf_kind == SS_LEAF_FELT && leaf_order == SS_ORDER_BITREV) {
+        // single-column matrix committed in bit-reversed order: its permuted image is the leaf array
+        ss_status pst = ctx->ensure_scratch2(n * sizeof(Fp));
+        if (pst != SS_OK) return pst;
+        HIP_TRY(launch_bitrev_copy(ctx->stream, (const Fp *)d_leaves, log_n, (Fp *)ctx->scratch2));
+        d_leaves = ctx->scratch2;
+    }
     hipStream_t s = ctx->stream;
     const int hk = tree_kind == SS_TREE_KECCAK ? SS_HASH_KECCAK : tree_kind == SS_TREE_KECCAK_M20 ? SS_HASH_KECCAK_M20 : SS_HASH_BLAKE2S_M20;
     if (tree_kind == SS_TREE_FRIENDLY && !ctx->ped) HIP_TRY(pedersen_tables_create(s, &ctx->ped));

@@ -123,15 +123,23 @@ __device__ __forceinline__ void keccak_absorb_felts(uint64_t s[25], uint32_t nel
     }
 }
 
+// brev_bits != 0: digest `row` is that of matrix row bitrev(row) over brev_bits bits - the commitment order of the
+// reference's proofs (index i of a committed vector is the point offset * w^bitrev(i); tests/golden/
+// make_proof_golden.py), read straight out of the natural-order LDE.
+__device__ __forceinline__ uint64_t row_source(uint64_t row, uint32_t brev_bits) {
+    return brev_bits ? (__brevll(row) >> (64u - brev_bits)) : row;
+}
+
 __global__ __launch_bounds__(256) void keccak_rows_kernel(ConstColPtrs cols, uint32_t ncols, uint64_t nrows,
-                                                          uint8_t *__restrict__ out, int mask20) {
+                                                          uint8_t *__restrict__ out, int mask20, uint32_t brev_bits) {
     for (uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; row < nrows;
          row += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t src = row_source(row, brev_bits);
         uint64_t s[25];
 #pragma unroll
         for (int i = 0; i < 25; ++i) s[i] = 0;
         keccak_absorb_felts(s, ncols, [&](uint32_t c) {
-            return reinterpret_cast<const uint64_t *>(cols.p[c]) + 4 * row;
+            return reinterpret_cast<const uint64_t *>(cols.p[c]) + 4 * src;
         });
         keccak_store_digest(s, out + 32 * row, mask20 != 0);
     }
@@ -247,12 +255,13 @@ __device__ __forceinline__ void blake2s_hash_felts(uint32_t h[8], uint32_t nelem
 }
 
 __global__ __launch_bounds__(256) void blake2s_rows_kernel(ConstColPtrs cols, uint32_t ncols, uint64_t nrows,
-                                                           uint8_t *__restrict__ out, int mask20) {
+                                                           uint8_t *__restrict__ out, int mask20, uint32_t brev_bits) {
     for (uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; row < nrows;
          row += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t src = row_source(row, brev_bits);
         uint32_t h[8];
         blake2s_hash_felts(h, ncols, [&](uint32_t c) {
-            return load_fp(reinterpret_cast<const uint8_t *>(cols.p[c]) + 32 * row);
+            return load_fp(reinterpret_cast<const uint8_t *>(cols.p[c]) + 32 * src);
         });
         blake2s_store_digest(h, out + 32 * row, mask20 != 0);
     }
@@ -387,12 +396,27 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap) {
 }
 
 hipError_t launch_hash_rows(hipStream_t st, int kind, const ConstColPtrs &cols, uint32_t ncols,
-                            uint64_t nrows, uint8_t *digests) {
+                            uint64_t nrows, uint32_t brev_bits, uint8_t *digests) {
     const uint32_t grid = grid_for(nrows, 256, 1u << 20);
     if (kind == 0 || kind == 1)
-        hipLaunchKernelGGL(keccak_rows_kernel, dim3(grid), dim3(256), 0, st, cols, ncols, nrows, digests, kind == 1);
+        hipLaunchKernelGGL(keccak_rows_kernel, dim3(grid), dim3(256), 0, st, cols, ncols, nrows, digests, kind == 1, brev_bits);
     else
-        hipLaunchKernelGGL(blake2s_rows_kernel, dim3(grid), dim3(256), 0, st, cols, ncols, nrows, digests, kind == 3);
+        hipLaunchKernelGGL(blake2s_rows_kernel, dim3(grid), dim3(256), 0, st, cols, ncols, nrows, digests, kind == 3, brev_bits);
+    return hipGetLastError();
+}
+// dst[i] = src[bitrev(i)] (32-byte elements): the bit-reversed image of a single-column matrix whose raw
+// elements are the leaves of its tree
+__global__ __launch_bounds__(256) void bitrev_copy_kernel(const Fp *__restrict__ src, uint32_t log_n, Fp *__restrict__ dst) {
+    const uint64_t n = 1ull << log_n;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t j = log_n ? (__brevll(i) >> (64u - log_n)) : 0;
+        const uint4 *q = reinterpret_cast<const uint4 *>(src + j);
+        uint4 *d = reinterpret_cast<uint4 *>(dst + i);
+        d[0] = q[0]; d[1] = q[1];
+    }
+}
+hipError_t launch_bitrev_copy(hipStream_t st, const Fp *src, uint32_t log_n, Fp *dst) {
+    hipLaunchKernelGGL(bitrev_copy_kernel, dim3(grid_for(1ull << log_n, 256, 1u << 20)), dim3(256), 0, st, src, log_n, dst);
     return hipGetLastError();
 }
 hipError_t launch_hash_pairs(hipStream_t st, int kind, const uint8_t *in, uint64_t count, uint8_t *out) {

@@ -32,7 +32,8 @@ hipError_t ntt_set_func_attributes();
 
 // ---- hash.hip
 hipError_t launch_hash_rows(hipStream_t st, int kind, const ConstColPtrs &cols, uint32_t ncols,
-                            uint64_t nrows, uint8_t *digests);
+                            uint64_t nrows, uint32_t brev_bits, uint8_t *digests);
+hipError_t launch_bitrev_copy(hipStream_t st, const Fp *src, uint32_t log_n, Fp *dst);
 // one Merkle level: out[k] = H(in[2k] || in[2k+1]) for k < count (64-byte messages)
 hipError_t launch_hash_pairs(hipStream_t st, int kind, const uint8_t *in, uint64_t count, uint8_t *out);
 // leaf level of single-column trees: out[k] = H::hash_elements([felt[2k], felt[2k+1]])

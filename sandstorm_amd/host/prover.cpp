@@ -35,18 +35,18 @@ Matrix Matrix::alloc(ss_ctx *ctx, uint32_t ncols, uint64_t nrows) {
     return m;
 }
 
-std::unique_ptr<MerkleTree> MerkleTree::from_matrix(ss_ctx *ctx, int tree_kind, uint32_t n_friendly, const Matrix &m) {
+std::unique_ptr<MerkleTree> MerkleTree::from_matrix(ss_ctx *ctx, int tree_kind, uint32_t n_friendly, const Matrix &m, int order) {
     auto t = std::unique_ptr<MerkleTree>(new MerkleTree);
     t->ctx_ = ctx; t->tree_kind_ = tree_kind; t->n_ = m.nrows;
     t->nodes_.reset(new DeviceBuffer(ctx, 64 * m.nrows));
     if (tree_kind == SS_TREE_FRIENDLY) t->tags_.reset(new DeviceBuffer(ctx, 2 * m.nrows));
     const int row_hash = tree_kind == SS_TREE_KECCAK ? SS_HASH_KECCAK : tree_kind == SS_TREE_KECCAK_M20 ? SS_HASH_KECCAK_M20 : SS_HASH_BLAKE2S_M20;
     if (m.num_cols() == 1) {            // single column: the column becomes the leaves (merkle/mod.rs:113-117)
-        ok(ss_merkle_build(ctx, tree_kind, n_friendly, SS_LEAF_FELT, m.cols[0], m.nrows, t->nodes_->u8(),
-                           t->tags_ ? t->tags_->u8() : nullptr, t->root_.data()));
+        ok(ss_merkle_build_ex(ctx, tree_kind, n_friendly, SS_LEAF_FELT, m.cols[0], m.nrows, order, t->nodes_->u8(),
+                              t->tags_ ? t->tags_->u8() : nullptr, t->root_.data()));
     } else {
         t->leaves_.reset(new DeviceBuffer(ctx, 32 * m.nrows));
-        ok(ss_hash_rows(ctx, row_hash, (const uint64_t *const *)m.cols.data(), m.num_cols(), m.nrows, t->leaves_->u8()));
+        ok(ss_hash_rows_ex(ctx, row_hash, (const uint64_t *const *)m.cols.data(), m.num_cols(), m.nrows, order, t->leaves_->u8()));
         ok(ss_merkle_build(ctx, tree_kind, n_friendly, SS_LEAF_DIGEST, t->leaves_->u8(), m.nrows, t->nodes_->u8(),
                            t->tags_ ? t->tags_->u8() : nullptr, t->root_.data()));
     }
@@ -90,7 +90,9 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
         fprintf(stderr, "[ssh timing] %-28s %9.3f ms\n", stage, std::chrono::duration<double, std::milli>(t - t_prev).count());
         t_prev = t;
     };
-    auto commit = [&](const Matrix &m) { return MerkleTree::from_matrix(ctx_, claim_.tree_kind, claim_.n_friendly_layers, m); };
+    const int order = conv_.bitrev_commit ? SS_ORDER_BITREV : SS_ORDER_NATURAL;
+    auto brev = [](uint64_t x, uint32_t bits) { uint64_t r = 0; for (uint32_t i = 0; i < bits; ++i) r |= ((x >> i) & 1ull) << (bits - 1 - i); return r; };
+    auto commit = [&](const Matrix &m) { return MerkleTree::from_matrix(ctx_, claim_.tree_kind, claim_.n_friendly_layers, m, order); };
     auto digest_of = [](const std::array<uint8_t, 33> &r) { Digest d; memcpy(d.data(), r.data(), 32); return d; };
 
     // 2. base trace: interpolate, extend, commit
@@ -197,7 +199,10 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
         Layer L;
         L.evals = evals;
         L.matrix.nrows = rows;
-        for (uint32_t k = 0; k < fold; ++k) L.matrix.cols.push_back(evals->u64() + 4 * rows * k);
+        // committed row r = entries fold*r .. fold*r+fold-1 of the bit-reversed vector = natural row bitrev(r),
+        // its entry j at x_r * w_fold^bitrev(j): the natural stride columns, re-ordered
+        for (uint32_t j = 0; j < fold; ++j)
+            L.matrix.cols.push_back(evals->u64() + 4 * rows * (conv_.bitrev_commit ? brev(j, log_fold) : j));
         L.tree = commit(L.matrix);
         FriLayerProof lp;
         lp.root = L.tree->root();
@@ -207,7 +212,8 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
         const Felt alpha = coin.draw();
         proof.fri_alphas.push_back(alpha);
         auto next = std::make_shared<DeviceBuffer>(ctx_, 32 * rows);
-        ok(ss_fri_fold(ctx_, evals->u64(), log_len, fold, alpha.data(), offset.data(), next->u64()));
+        ok(ss_fri_fold_ex(ctx_, evals->u64(), log_len, fold, alpha.data(), offset.data(),
+                          conv_.fri_unnormalised ? SS_FRI_UNNORMALISED : 0, next->u64()));     // natural order in memory
         layers.push_back(std::move(L));
         evals = next;
         log_len -= log_fold;
@@ -216,7 +222,8 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     }
     {
         uint64_t *e = evals->u64();
-        ok(ss_ntt_fp252(ctx_, &e, 1, log_len, SS_NTT_INVERSE, offset.data(), SS_ORDER_NATURAL, SS_ORDER_NATURAL));
+        const Felt rem_offset = conv_.remainder_unshifted ? felt_from_u64(1) : offset;
+        ok(ss_ntt_fp252(ctx_, &e, 1, log_len, SS_NTT_INVERSE, rem_offset.data(), SS_ORDER_NATURAL, SS_ORDER_NATURAL));
         std::vector<uint64_t> rem(4ull << log_len);
         ok(ss_download(ctx_, rem.data(), e, rem.size() * 8));
         const uint64_t keep = degree_bound ? degree_bound : 1;
@@ -231,19 +238,25 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     coin.reseed_with_int(proof.pow_nonce);
     proof.query_positions = coin.draw_queries(opt_.num_queries, N);
     const auto &pos = proof.query_positions;
-    proof.base_rows = gather(ctx_, base_lde.cols, pos);
+    // a position is an index into the COMMITTED order; the matrices themselves are in natural order
+    std::vector<uint64_t> nat = pos;
+    if (conv_.bitrev_commit) for (auto &q : nat) q = brev(q, log_N);
+    proof.base_rows = gather(ctx_, base_lde.cols, nat);
     proof.base_paths = base_tree->prove(pos);
-    if (ext_tree) { proof.extension_rows = gather(ctx_, ext_lde.cols, pos); proof.extension_paths = ext_tree->prove(pos); }
-    proof.composition_rows = gather(ctx_, comp_lde.cols, pos);
+    if (ext_tree) { proof.extension_rows = gather(ctx_, ext_lde.cols, nat); proof.extension_paths = ext_tree->prove(pos); }
+    proof.composition_rows = gather(ctx_, comp_lde.cols, nat);
     proof.composition_paths = comp_tree->prove(pos);
     std::vector<uint64_t> p = pos;
     for (size_t li = 0; li < layers.size(); ++li) {
-        const uint64_t rows = 1ull << (proof.fri_layers[li].log_len - log_fold);
+        const uint32_t row_bits = proof.fri_layers[li].log_len - log_fold;
+        const uint64_t rows = 1ull << row_bits;
         std::set<uint64_t> s;
-        for (uint64_t q : p) s.insert(q % rows);
+        for (uint64_t q : p) s.insert(conv_.bitrev_commit ? (q >> log_fold) : (q % rows));
         p.assign(s.begin(), s.end());
+        std::vector<uint64_t> nat_rows = p;
+        if (conv_.bitrev_commit) for (auto &r : nat_rows) r = brev(r, row_bits);
         proof.fri_layers[li].positions = p;
-        proof.fri_layers[li].rows = gather(ctx_, layers[li].matrix.cols, p);
+        proof.fri_layers[li].rows = gather(ctx_, layers[li].matrix.cols, nat_rows);
         proof.fri_layers[li].paths = layers[li].tree->prove(p);
     }
     mark("pow + openings");

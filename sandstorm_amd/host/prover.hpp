@@ -27,6 +27,11 @@ struct ProofOptions {                   // cli/src/main.rs:51-60 defaults
 struct Conventions {                    // ministark-internal, SURVEY.md Appendix A
     uint64_t lde_offset = 3;            // M2
     uint32_t composition_columns = 2;   // M5
+    // pinned by the reference's shipped proofs (tests/golden/make_fri_golden.py, make_proof_golden.py);
+    // false reproduces the older code path's proofs
+    bool bitrev_commit = true;          // M3: index i of a committed vector is the point offset * w^bitrev(i)
+    bool fri_unnormalised = true;       // M8: fold = 8 * interpolant(alpha)
+    bool remainder_unshifted = true;    // M9: remainder interpolates the folded last layer over the unshifted domain
 };
 
 // RAII device allocation (ss_dev_alloc / ss_dev_free)
@@ -57,7 +62,9 @@ struct Matrix {
 // MatrixMerkleTree::from_matrix / MerkleTree::{root, prove} (crypto/src/merkle/mod.rs:72-123, 258-304)
 class MerkleTree {
 public:
-    static std::unique_ptr<MerkleTree> from_matrix(ss_ctx *ctx, int tree_kind, uint32_t n_friendly, const Matrix &m);
+    // order = SS_ORDER_BITREV: leaf i is row bitrev(i) of the natural-order matrix
+    static std::unique_ptr<MerkleTree> from_matrix(ss_ctx *ctx, int tree_kind, uint32_t n_friendly, const Matrix &m,
+                                                   int order = SS_ORDER_NATURAL);
     const std::array<uint8_t, 33> &root() const { return root_; }
     std::vector<uint8_t> prove(const std::vector<uint64_t> &idx) const;     // nidx * log2(n) * 32 bytes
     uint64_t n() const { return n_; }

@@ -44,6 +44,15 @@ class Conventions:
     """ministark-internal conventions, SURVEY.md Appendix A"""
     lde_offset: int = 3                 # M2: LDE coset offset = field generator
     composition_columns: int = 2        # M5: ce_blowup_factor, H(x) = H0(x^2) + x H1(x^2), OOD point z^2
+    # The next three are PINNED by the reference's shipped proofs (tests/golden/make_fri_golden.py,
+    # make_proof_golden.py); False reproduces the older code path's proofs.
+    bitrev_commit: bool = True          # M3: index i of a committed vector is the point offset * w^bitrev(i)
+    fri_unnormalised: bool = True       # M8: fold = 8 * interpolant(alpha) (no 1/2 per halving)
+    remainder_unshifted: bool = True    # M9: remainder = interpolant of the folded last layer over the unshifted domain
+
+
+def bitrev(x: int, bits: int) -> int:
+    return int(format(x, "0%db" % bits)[::-1], 2) if bits else 0
 
 
 @dataclass
@@ -149,7 +158,8 @@ class Prover:
 
         # 2. base trace: interpolate, extend, commit
         base_lde, base_coeffs = base_trace.lde(lb, g)
-        base_tree = Tree.from_matrix(base_lde)
+        order = be.BITREV if conv.bitrev_commit else be.NATURAL
+        base_tree = Tree.from_matrix(base_lde, order)
         proof.base_root = base_tree.root()
         coin.reseed_with_digest(proof.base_root)
 
@@ -162,7 +172,7 @@ class Prover:
         ext_lde = ext_tree = None
         if ext_trace is not None:
             ext_lde, ext_coeffs = ext_trace.lde(lb, g)
-            ext_tree = Tree.from_matrix(ext_lde)
+            ext_tree = Tree.from_matrix(ext_lde, order)
             proof.extension_root = ext_tree.root()
             coin.reseed_with_digest(proof.extension_root)
             lde_cols += ext_lde.cols
@@ -189,7 +199,7 @@ class Prover:
         comp_coeffs = [be.DeviceView(comp_evals, 32 * n * k, 32 * n) for k in range(ncomp)]
         comp_lde = be.Matrix.empty(ctx, ncomp, N)
         ctx.evaluate(comp_coeffs, log_n, lb, g, comp_lde.cols)
-        comp_tree = Tree.from_matrix(comp_lde)
+        comp_tree = Tree.from_matrix(comp_lde, order)
         proof.composition_root = comp_tree.root()
         coin.reseed_with_digest(proof.composition_root)
 
@@ -220,24 +230,29 @@ class Prover:
         evals, log_len, offset_int = deep, log_N, conv.lde_offset
         degree_bound = n                       # DEEP polynomial: degree < n
         layers = []
+        fri_flags = be.FRI_UNNORMALISED if conv.fri_unnormalised else 0
         while degree_bound > opt.fri_max_remainder_coeffs:
             rows = 1 << (log_len - log_fold)
             cols = [be.DeviceView(evals, 32 * rows * k, 32 * rows) for k in range(fold)]
+            if conv.bitrev_commit:
+                # committed row r = entries fold*r .. fold*r+fold-1 of the bit-reversed vector = natural row
+                # bitrev(r), its entry j at x_r * w_fold^bitrev(j): the natural stride columns, re-ordered
+                cols = [cols[bitrev(j, log_fold)] for j in range(fold)]
             layer_matrix = be.Matrix(ctx, cols, rows)
-            tree = Tree.from_matrix(layer_matrix)
+            tree = Tree.from_matrix(layer_matrix, order)
             layer = FriLayer(tree.root(), tree.root_tag(), log_len)
             coin.reseed_with_digest(layer.root)
             alpha = coin.draw()
             proof.fri_alphas.append(alpha)
             nxt = ctx.alloc(32 * rows)
-            ctx.fri_fold(evals, log_len, fold, alpha, be.felt(offset_int), nxt)
+            ctx.fri_fold(evals, log_len, fold, alpha, be.felt(offset_int), nxt, fri_flags)     # natural order in memory
             layers.append((layer, tree, layer_matrix, evals))
             evals, log_len = nxt, log_len - log_fold
             offset_int = pow(offset_int, fold, be.P)
             degree_bound //= fold
         # remainder: interpolate the last layer, send its (few) coefficients
         rem = be.Matrix(ctx, [evals], 1 << log_len)
-        rem.interpolate(be.felt(offset_int))
+        rem.interpolate(be.felt(1 if conv.remainder_unshifted else offset_int))
         rem_host = rem.to_host()[0]
         assert not np.any(rem_host[max(1, degree_bound):]), "FRI remainder exceeds its degree bound"
         proof.fri_remainder = rem_host[:max(1, degree_bound)]
@@ -250,19 +265,27 @@ class Prover:
         coin.reseed_with_int(proof.pow_nonce)
         positions = coin.draw_queries(opt.num_queries, N)
         proof.query_positions = positions
-        proof.base_rows = ctx.gather_rows(base_lde.cols, positions)
+        # a position is an index into the COMMITTED order; the matrices themselves are in natural order
+        nat = [bitrev(p, log_N) for p in positions] if conv.bitrev_commit else positions
+        proof.base_rows = ctx.gather_rows(base_lde.cols, nat)
         proof.base_paths, _ = base_tree.prove(positions)
         if ext_lde is not None:
-            proof.extension_rows = ctx.gather_rows(ext_lde.cols, positions)
+            proof.extension_rows = ctx.gather_rows(ext_lde.cols, nat)
             proof.extension_paths, _ = ext_tree.prove(positions)
-        proof.composition_rows = ctx.gather_rows(comp_lde.cols, positions)
+        proof.composition_rows = ctx.gather_rows(comp_lde.cols, nat)
         proof.composition_paths, _ = comp_tree.prove(positions)
         pos = positions
         for layer, tree, matrix, _ in layers:
-            rows = 1 << (layer.log_len - log_fold)
-            pos = sorted(set(p % rows for p in pos))
+            row_bits = layer.log_len - log_fold
+            rows = 1 << row_bits
+            if conv.bitrev_commit:
+                pos = sorted(set(p >> log_fold for p in pos))          # row r holds entries fold*r .. of the vector
+                nat_rows = [bitrev(r, row_bits) for r in pos]
+            else:
+                pos = sorted(set(p % rows for p in pos))
+                nat_rows = pos
             layer.positions = pos
-            layer.rows = ctx.gather_rows(matrix.cols, pos)
+            layer.rows = ctx.gather_rows(matrix.cols, nat_rows)
             layer.paths, _ = tree.prove(pos)
             proof.fri_layers.append(layer)
         mark("openings")

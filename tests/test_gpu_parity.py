@@ -264,6 +264,32 @@ def test_friendly_merkle_large_and_small_levels(ctx, be, oracle):
     assert root == bytes(want_nodes[1])
 
 
+@pytest.mark.parametrize("kind", [1, 3])
+def test_hash_rows_bitrev_order(ctx, be, oracle, kind):
+    """ss_hash_rows_ex(SS_ORDER_BITREV): digest i is the digest of row bitrev(i) - the commitment order pinned by
+    the reference's proof - computed from the natural-order matrix."""
+    log_n, n = 11, 1 << 11
+    cols = [random_column(n, 80 + c) for c in range(3)]
+    m = be.Matrix.from_host(ctx, cols)
+    got = m.hash_rows(kind, be.BITREV).download(np.uint8, (n, 32))
+    nat = oracle.hash_rows(kind, cols)
+    perm = [int(format(i, "0%db" % log_n)[::-1], 2) for i in range(n)]
+    assert np.array_equal(got, nat[perm])
+
+
+@pytest.mark.parametrize("tree", [1, 2])
+def test_single_column_tree_bitrev_order(ctx, be, oracle, tree):
+    """ss_merkle_build_ex(leaf_order = BITREV) on raw-element leaves == the natural build of the permuted column."""
+    log_n, n = 9, 1 << 9
+    col = random_column(n, 91)
+    perm = [int(format(i, "0%db" % log_n)[::-1], 2) for i in range(n)]
+    want_nodes, _ = oracle.merkle_build(tree, 22, 1, col[perm])
+    nodes, tags = ctx.alloc(64 * n), ctx.alloc(2 * n)
+    root, _ = ctx.merkle_build(tree, 22, 1, ctx.column(col), n, nodes, tags, be.BITREV)
+    assert np.array_equal(nodes.download(np.uint8, (2 * n, 32))[1:], want_nodes[1:])
+    assert root == bytes(want_nodes[1])
+
+
 def test_merkle_openings_of_reference_proof(ctx, be, oracle, golden):
     """The reference's saved proof on the GPU: ss_hash_rows reproduces the leaf digests of the opened rows and
     ss_merkle_build (two leaves at a time, up each authentication path) reproduces the proof's roots."""

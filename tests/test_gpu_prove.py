@@ -75,6 +75,17 @@ def test_prove_and_verify_mini_air(ctx, oracle, flavour, log_n):
 
 
 @pytest.mark.parametrize("flavour", ["eth", "cairo"])
+def test_prove_and_verify_older_conventions(ctx, oracle, flavour):
+    """natural commitment order, normalised fold, shifted remainder: the conventions of the reference's older
+    proof file (example/bootloader/bootloader-proof.bin) stay selectable."""
+    from sandstorm_amd.prover import Conventions, Prover
+    n, claim, params, opt, seed, base, build_extension = setup_case(ctx, oracle, flavour, 9)
+    conv = Conventions(bitrev_commit=False, fri_unnormalised=False, remainder_unshifted=False)
+    proof = Prover(ctx, claim, opt, conv).prove(seed, base, build_extension)
+    verify_mini_proof(oracle, proof, n, params, opt, seed, conv)
+
+
+@pytest.mark.parametrize("flavour", ["eth", "cairo"])
 @pytest.mark.parametrize("log_n", [5, 10])
 def test_cpp_prover_matches_python_prover_and_verifies(ctx, oracle, flavour, log_n):
     """The C++ host (libsandstorm_host.so: coin, Expr lowering, prover) drives the same
@@ -101,9 +112,16 @@ def test_cpp_prover_matches_python_prover_and_verifies(ctx, oracle, flavour, log
         assert a.positions == b.positions and np.array_equal(a.rows, b.rows) and np.array_equal(a.paths, b.paths)
 
 
-def verify_mini_proof(oracle, proof, n, params, opt, seed):
-    """independent verifier: oracle coins + big integers"""
+def verify_mini_proof(oracle, proof, n, params, opt, seed, conv=None):
+    """independent verifier: oracle coins + big integers.  conv: prover.Conventions (default: the conventions
+    pinned by the reference's shipped proofs - bit-reversed commitment order, unnormalised fold, unshifted remainder)"""
     from sandstorm_amd import air_program as ap
+    from sandstorm_amd.prover import Conventions, bitrev
+    conv = conv or Conventions()
+    log_N = (2 * n).bit_length() - 1
+    log_fold = opt.fri_folding_factor.bit_length() - 1
+    # exponent of the domain generator at index i of a committed vector of 2^bits entries
+    expo = (lambda i, bits: bitrev(i, bits)) if conv.bitrev_commit else (lambda i, bits: i)
     tree_kind, row_kind, coin_kind, nf = params
     N = 2 * n
     # ---- transcript replay with the ORACLE's coin
@@ -149,7 +167,7 @@ def verify_mini_proof(oracle, proof, n, params, opt, seed):
     rows0 = N // fold
     l0 = proof.fri_layers[0]
     for qi, q in enumerate(positions):
-        x = 3 * pow(wN, q, P) % P
+        x = 3 * pow(wN, expo(q, log_N), P) % P
         for rows, paths, root in ((proof.base_rows, proof.base_paths, proof.base_root),
                                   (proof.composition_rows, proof.composition_paths, proof.composition_root)):
             assert merkle_verify(oracle, tree_kind, nf, row_leaf(oracle, row_kind, rows[qi]), q, paths[qi], N, root)
@@ -166,7 +184,7 @@ def verify_mini_proof(oracle, proof, n, params, opt, seed):
             deep += coef[j] * (int(trow[c]) - ood_t[j]) * pow(x - z_ * pow(wn, o, P), -1, P)
         for k in range(2):
             deep += coef[ncells + k] * (int(crow[k]) - ood_c[k]) * pow(x - z_ * z_, -1, P)
-        r, cidx = q % rows0, q // rows0
+        r, cidx = (q >> log_fold, q & (fold - 1)) if conv.bitrev_commit else (q % rows0, q // rows0)
         li = l0.positions.index(r)
         assert int(oracle.from_mont(l0.rows[li, cidx])) == deep % P
 
@@ -180,16 +198,24 @@ def verify_mini_proof(oracle, proof, n, params, opt, seed):
         leaf_kind = row_kind
         for pi, r in enumerate(layer.positions):
             assert merkle_verify(oracle, tree_kind, nf, row_leaf(oracle, leaf_kind, layer.rows[pi]), r, layer.paths[pi], rows, layer.root)
-            xs = [offset * pow(w, r, P) * pow(wf, k, P) % P for k in range(fold)]
+            row_bits = layer.log_len - log_fold
+            xr0 = offset * pow(w, expo(r, row_bits), P) % P
+            # entry j of a committed row sits at x_r * w_fold^j (natural) or x_r * w_fold^bitrev(j)
+            xs = [xr0 * pow(wf, expo(k, log_fold), P) % P for k in range(fold)]
             ys = [int(v) for v in oracle.from_mont(layer.rows[pi])]
             folded = pyref.interpolate_eval(xs, ys, a)
+            if conv.fri_unnormalised:
+                folded = folded * fold % P
             if li + 1 < len(proof.fri_layers):
                 nxt = proof.fri_layers[li + 1]
                 nrows = (1 << nxt.log_len) // fold
-                ni = nxt.positions.index(r % nrows)
-                assert int(oracle.from_mont(nxt.rows[ni, r // nrows])) == folded
+                nr, slot = (r >> log_fold, r & (fold - 1)) if conv.bitrev_commit else (r % nrows, r // nrows)
+                ni = nxt.positions.index(nr)
+                assert int(oracle.from_mont(nxt.rows[ni, slot])) == folded
             else:
                 rem = [int(v) for v in oracle.from_mont(proof.fri_remainder)]
-                xr = pow(offset, fold, P) * pow(pyref.root_of_unity(rows), r, P) % P
+                xr = pow(pyref.root_of_unity(rows), expo(r, row_bits), P)
+                if not conv.remainder_unshifted:
+                    xr = xr * pow(offset, fold, P) % P
                 assert sum(c * pow(xr, i, P) for i, c in enumerate(rem)) % P == folded
         offset = pow(offset, fold, P)
