@@ -123,10 +123,11 @@ __device__ __forceinline__ void keccak_absorb_felts(uint64_t s[25], uint32_t nel
     }
 }
 
-// brev_bits != 0: digest `row` is that of matrix row bitrev(row) over brev_bits bits - the commitment order of the
+// brev_bits != 0: digest i is that of matrix row bitrev(i) over brev_bits bits - the commitment order of the
 // reference's proofs (index i of a committed vector is the point offset * w^bitrev(i); tests/golden/
-// make_proof_golden.py), read straight out of the natural-order LDE.
-__device__ __forceinline__ uint64_t row_source(uint64_t row, uint32_t brev_bits) {
+// make_proof_golden.py), straight out of the natural-order LDE.  The lane keeps its NATURAL row (coalesced reads
+// of every column) and scatters the one 32-byte digest to slot bitrev(row): bit reversal is an involution.
+__device__ __forceinline__ uint64_t digest_slot(uint64_t row, uint32_t brev_bits) {
     return brev_bits ? (__brevll(row) >> (64u - brev_bits)) : row;
 }
 
@@ -134,14 +135,13 @@ __global__ __launch_bounds__(256) void keccak_rows_kernel(ConstColPtrs cols, uin
                                                           uint8_t *__restrict__ out, int mask20, uint32_t brev_bits) {
     for (uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; row < nrows;
          row += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t src = row_source(row, brev_bits);
         uint64_t s[25];
 #pragma unroll
         for (int i = 0; i < 25; ++i) s[i] = 0;
         keccak_absorb_felts(s, ncols, [&](uint32_t c) {
-            return reinterpret_cast<const uint64_t *>(cols.p[c]) + 4 * src;
+            return reinterpret_cast<const uint64_t *>(cols.p[c]) + 4 * row;
         });
-        keccak_store_digest(s, out + 32 * row, mask20 != 0);
+        keccak_store_digest(s, out + 32 * digest_slot(row, brev_bits), mask20 != 0);
     }
 }
 
@@ -258,12 +258,11 @@ __global__ __launch_bounds__(256) void blake2s_rows_kernel(ConstColPtrs cols, ui
                                                            uint8_t *__restrict__ out, int mask20, uint32_t brev_bits) {
     for (uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; row < nrows;
          row += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t src = row_source(row, brev_bits);
         uint32_t h[8];
         blake2s_hash_felts(h, ncols, [&](uint32_t c) {
-            return load_fp(reinterpret_cast<const uint8_t *>(cols.p[c]) + 32 * src);
+            return load_fp(reinterpret_cast<const uint8_t *>(cols.p[c]) + 32 * row);
         });
-        blake2s_store_digest(h, out + 32 * row, mask20 != 0);
+        blake2s_store_digest(h, out + 32 * digest_slot(row, brev_bits), mask20 != 0);
     }
 }
 
