@@ -219,3 +219,55 @@ def verify_mini_proof(oracle, proof, n, params, opt, seed, conv=None):
                     xr = xr * pow(offset, fold, P) % P
                 assert sum(c * pow(xr, i, P) for i, c in enumerate(rem)) % P == folded
         offset = pow(offset, fold, P)
+
+
+def test_proof_in_reference_wire_format(ctx, oracle):
+    """Our own proof (EthVerifierClaim flavour), serialised in the reference's wire format (sandstorm_amd/wire.py),
+    goes through exactly the data-level checks the reference's saved proof passes in tests/golden/
+    make_proof_golden.py: it parses back to EOF, every opening climbs to its root at the query position with the
+    oracle's hashes, FRI rows chain by position p >> 3(i+1), and serialisation is stable."""
+    from sandstorm_amd import wire
+    from sandstorm_amd.coin import keccak256
+    from sandstorm_amd.prover import Prover
+    n, claim, params, opt, seed, base, build_extension = setup_case(ctx, oracle, "eth", 9)
+    proof = Prover(ctx, claim, opt).prove(seed, base, build_extension)
+
+    def leaf_hash(vals):            # LeafVariantMerkleTree<MaskedKeccak256HashFn<20>>: row hash of the tree
+        m = wire._R
+        data = b"".join((v * m % P).to_bytes(32, "big") for v in vals)
+        return keccak256(data)[:20] + bytes(12)
+    raw = wire.serialize(wire.from_proof(proof, leaf_hash))
+    w = wire.parse(raw)
+    assert wire.serialize(w) == raw
+    assert w.options == [opt.num_queries, 2, opt.grinding_factor, 8, opt.fri_max_remainder_coeffs] and w.trace_len == n
+
+    def climb(cur, path, pos):
+        for lvl, sib in enumerate(path):
+            a, b = (cur, sib) if ((pos >> lvl) & 1) == 0 else (sib, cur)
+            cur = pyref.mask_keccak(oracle.keccak256(a + b))
+        return cur
+
+    def rowhash(vals):
+        mm = oracle.to_mont(vals)
+        return bytes(oracle.hash_rows(1, [mm[k:k + 1] for k in range(len(vals))])[0])
+    positions = proof.query_positions
+    nq = len(positions)
+    ncb = len(w.base_rows) // nq
+    for q, p in enumerate(positions):
+        for rows, ops, root, nc in ((w.base_rows, w.base_openings, w.base_root, ncb),
+                                    (w.composition_rows, w.composition_openings, w.composition_root, 2)):
+            o = ops[q]
+            leaf = rowhash(rows[nc * q:nc * q + nc])
+            assert o.variant == 0 and leaf == o.leaf
+            assert climb(leaf, [o.sibling] + o.path, p) == root
+        o = w.extension_openings[q]                       # single column: raw-element leaves
+        assert o.variant == 1 and o.leaf == w.extension_rows[q]
+        pair = [o.leaf, o.sibling] if (p & 1) == 0 else [o.sibling, o.leaf]
+        assert climb(rowhash(pair), o.path, p >> 1) == w.extension_root
+    for li, layer in enumerate(w.fri_layers):
+        ps = sorted(set(pp >> (3 * (li + 1)) for pp in positions))
+        assert len(ps) == len(layer.openings) == len(layer.rows) // 8
+        for r, pos in enumerate(ps):
+            o = layer.openings[r]
+            leaf = rowhash(layer.rows[8 * r:8 * r + 8])
+            assert leaf == o.leaf and climb(leaf, [o.sibling] + o.path, pos) == layer.root
