@@ -36,15 +36,23 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import oracle_py as oracle      # noqa: E402
 
-REF = "/root/reference/example/array-sum.proof.saved"
+REF_DIR = "/root/reference"
+FILES = [("example/array-sum.proof.saved", "saved_proof_openings.json"),
+         ("bootloader-proof.bin", "saved_proof_openings_recursive.json")]      # starknet shape (9+1 columns); recursive shape (7+3)
 P = 2**251 + 17 * 2**192 + 1
 KECCAK_M20 = 1
 
 
 def main():
-    if not os.path.exists(REF):
+    if not os.path.isdir(REF_DIR):
         sys.exit("reference not mounted; fixtures are already committed")
-    raw = open(REF, "rb").read()
+    for rel, out_name in FILES:
+        one(rel, out_name)
+
+
+def one(rel, out_name):
+    print("====", rel)
+    raw = open(os.path.join(REF_DIR, rel), "rb").read()
     u64 = lambda o: int.from_bytes(raw[o:o + 8], "little")
 
     def vec(o):
@@ -122,13 +130,19 @@ def main():
     oodc, o = vec(o)
     assert o == len(raw), "wire format not consumed to EOF"
     nq = len(base_pr)
-    ncb = len(base_rows) // nq
-    print("parsed to EOF: options", opts, "trace_len", trace_len, "queries", nq, "base cols", ncb, "layers", nl)
-
-    # slots of each layer-i row inside its layer-(i+1) row, from the fold pin
-    gold = json.load(open(os.path.join(HERE, "fri_saved_proofs.json")))
-    nxt = {(v["layer"], v["row"]): (v["next_row"], v["next_slot"], int(v["beta"], 16))
-           for v in gold["vectors"] if v["file"] == "example/array-sum.proof.saved"}
+    ncb, nce = len(base_rows) // nq, len(ext_rows) // nq
+    print("parsed to EOF: options", opts, "trace_len", trace_len, "queries", nq, "base cols", ncb, "ext cols", nce, "layers", nl)
+    # slot of each layer-i row inside its layer-(i+1) row and beta = alpha / x per row: the fold pin, on every row
+    sys.path.insert(0, HERE)
+    import make_fri_golden as G
+    nxt = {}
+    for li in range(nl - 1):
+        m = G.match_pair(layers[li][0], layers[li + 1][0], "bitrev_unnormalised")
+        assert m is not None, "fold convention does not hold on layer %d" % li
+        for r, bi, beta in m:
+            nxt.setdefault((li, r), (bi >> 3, bi & 7, beta))
+    log_rows0 = (trace_len * opts[1]).bit_length() - 1 - 3
+    top_bits = log_rows0 - 3 * (nl - 1)
     positions = []
     for q in range(nq):
         r, sl = q, []
@@ -139,7 +153,7 @@ def main():
         leaf = rowhash(vals[8 * q:8 * q + 8])
         assert leaf == pr[q][3]
         hit = None
-        for top in range(16):             # the 4 position bits above the five recovered slots
+        for top in range(1 << top_bits):  # the position bits above the recovered slots
             r0 = 0
             for s in reversed(sl):
                 r0 = r0 * 8 + s
@@ -162,10 +176,14 @@ def main():
         cleaf = rowhash(comp_rows[2 * q:2 * q + 2])
         assert cleaf == comp_pr[q][3] and climb(cleaf, [comp_pr[q][2]] + comp_pr[q][1], p) == comp_root
         tag, nodes, sib, leaf = ext_pr[q]
-        assert tag == 1 and leaf == ext_rows[q]
-        pair = oracle.to_mont([leaf, sib] if (p & 1) == 0 else [sib, leaf])
-        first = bytes(oracle.hash_rows(KECCAK_M20, [pair[0:1], pair[1:2]])[0])
-        assert climb(first, nodes, p >> 1) == ext_root
+        if nce == 1:                      # single column: raw-element leaves, first layer = hash_elements([l0, l1])
+            assert tag == 1 and leaf == ext_rows[q]
+            pair = oracle.to_mont([leaf, sib] if (p & 1) == 0 else [sib, leaf])
+            first = bytes(oracle.hash_rows(KECCAK_M20, [pair[0:1], pair[1:2]])[0])
+            assert climb(first, nodes, p >> 1) == ext_root
+        else:
+            eleaf = rowhash(ext_rows[nce * q:nce * q + nce])
+            assert tag == 0 and eleaf == leaf and climb(eleaf, [sib] + nodes, p) == ext_root
     for li, (vals, pr, root) in enumerate(layers):
         ps = sorted(set(pp >> (3 * (li + 1)) for pp in positions))
         assert len(ps) == len(vals) // 8
@@ -190,8 +208,6 @@ def main():
     # remainder: the last layer folds onto a polynomial in the UNSHIFTED variable t = y / offset:
     #   8 * P_r(alpha) = R(w'^bitrev(r))  has one alpha/offset common to all rows; with the coset offset 3^(8^k)
     #   inside R's argument there is none.
-    sys.path.insert(0, HERE)
-    import make_fri_golden as G
     last_vals, _pr, _root = layers[-1]
     rows_log = (trace_len * opts[1]).bit_length() - 1 - 3 * nl
     wl = pow(3, (P - 1) >> (rows_log + 3), P)
@@ -211,7 +227,7 @@ def main():
             f[0] = (f[0] - evalp(remainder, pow(x, 8, P))) % P
             sets.append({b * x % P for b in G.roots(f)})
         return set.intersection(*sets)
-    unshifted, shifted = common_alpha(1), common_alpha(pow(3, 8 ** (nl - 1), P))
+    unshifted, shifted = common_alpha(1), common_alpha(pow(3, 8 ** (nl - 1), P))      # layer nl-1 sits on 3^(8^(nl-1)) * <w>
     assert len(unshifted) == 1 and len(shifted) == 0
     rem_const = next(iter(unshifted))
     print("remainder = interpolant of the folded last layer over the unshifted domain (%d coefficients)" % len(remainder))
@@ -219,7 +235,7 @@ def main():
     hx = lambda b: b.hex()
     hv = lambda v: "%x" % v
     K = 4
-    out = {"file": "example/array-sum.proof.saved", "options": opts, "trace_len": trace_len, "pow_nonce": nonce,
+    out = {"file": rel, "options": opts, "trace_len": trace_len, "pow_nonce": nonce,
            "roots": {"base": hx(base_root), "extension": hx(ext_root), "composition": hx(comp_root),
                      "fri_layers": [hx(l[2]) for l in layers]},
            "remainder": [hv(v) for v in remainder], "positions": positions,
@@ -233,7 +249,10 @@ def main():
                       "path": [hx(base_pr[q][2])] + [hx(d) for d in base_pr[q][1]]},
              "composition": {"row": [hv(v) for v in comp_rows[2 * q:2 * q + 2]],
                              "path": [hx(comp_pr[q][2])] + [hx(d) for d in comp_pr[q][1]]},
-             "extension": {"leaf": hv(ext_pr[q][3]), "sibling": hv(ext_pr[q][2]), "path": [hx(d) for d in ext_pr[q][1]]},
+             "extension": ({"leaf": hv(ext_pr[q][3]), "sibling": hv(ext_pr[q][2]), "path": [hx(d) for d in ext_pr[q][1]]}
+                           if nce == 1 else
+                           {"row": [hv(v) for v in ext_rows[nce * q:nce * q + nce]],
+                            "path": [hx(ext_pr[q][2])] + [hx(d) for d in ext_pr[q][1]]}),
              "fri": []}
         for li, (vals, pr, root) in enumerate(layers):
             ps = sorted(set(pp >> (3 * (li + 1)) for pp in positions))
@@ -241,9 +260,9 @@ def main():
             e["fri"].append({"position": ps[r], "row": [hv(v) for v in vals[8 * r:8 * r + 8]],
                              "path": [hx(pr[r][2])] + [hx(d) for d in pr[r][1]]})
         out["queries"].append(e)
-    with open(os.path.join(HERE, "saved_proof_openings.json"), "w") as f:
+    with open(os.path.join(HERE, out_name), "w") as f:
         json.dump(out, f, separators=(",", ":"))
-    print("wrote saved_proof_openings.json", os.path.getsize(os.path.join(HERE, "saved_proof_openings.json")), "bytes")
+    print("wrote", out_name, os.path.getsize(os.path.join(HERE, out_name)), "bytes")
 
 
 if __name__ == "__main__":

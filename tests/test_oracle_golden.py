@@ -89,21 +89,30 @@ def _rowhash(oracle, vals_hex, kind=1):
     return bytes(oracle.hash_rows(kind, [m[k:k + 1] for k in range(len(vals_hex))])[0])
 
 
-def test_merkle_openings_of_reference_proof(oracle, golden):
-    """Every Merkle opening of example/array-sum.proof.saved (tests/golden/make_proof_golden.py checked all 16
-    queries; 4 are committed) verifies against the proof's roots with the oracle's row hash (H1), unhashed-leaf
-    first layer (H2), node hash and pairing (H3/H4): the reference's own data pins them.  Position p opens row p
-    of the trace trees and row p >> 3(i+1) of FRI layer i."""
-    g = golden("saved_proof_openings.json")
+PROOF_FIXTURES = ["saved_proof_openings.json", "saved_proof_openings_recursive.json"]
+
+
+@pytest.mark.parametrize("fixture", PROOF_FIXTURES)
+def test_merkle_openings_of_reference_proof(oracle, golden, fixture):
+    """Every Merkle opening of the reference's shipped proofs - example/array-sum.proof.saved (starknet shape, 9+1
+    columns, 16 queries, 6 FRI layers) and bootloader-proof.bin (recursive shape, 7+3 columns, 40 queries, 4 layers);
+    tests/golden/make_proof_golden.py checked every query, 4 are committed - verifies against the proof's roots with
+    the oracle's row hash (H1), unhashed-leaf first layer (H2), node hash and pairing (H3/H4): the reference's own
+    data pins them.  Position p opens row p of the trace trees and row p >> 3(i+1) of FRI layer i."""
+    g = golden(fixture)
     roots = g["roots"]
     for q in g["queries"]:
         p = q["position"]
         for name in ("base", "composition"):
             leaf = _rowhash(oracle, q[name]["row"])
             assert _climb(oracle, leaf, [bytes.fromhex(d) for d in q[name]["path"]], p).hex() == roots[name]
-        pair = [q["extension"]["leaf"], q["extension"]["sibling"]]
-        first = _rowhash(oracle, pair if (p & 1) == 0 else pair[::-1])            # hash_elements([l0, l1])
-        assert _climb(oracle, first, [bytes.fromhex(d) for d in q["extension"]["path"]], p >> 1).hex() == roots["extension"]
+        if "leaf" in q["extension"]:                                                   # single-column extension trace
+            pair = [q["extension"]["leaf"], q["extension"]["sibling"]]
+            first = _rowhash(oracle, pair if (p & 1) == 0 else pair[::-1])            # hash_elements([l0, l1])
+            assert _climb(oracle, first, [bytes.fromhex(d) for d in q["extension"]["path"]], p >> 1).hex() == roots["extension"]
+        else:
+            leaf = _rowhash(oracle, q["extension"]["row"])
+            assert _climb(oracle, leaf, [bytes.fromhex(d) for d in q["extension"]["path"]], p).hex() == roots["extension"]
         for li, f in enumerate(q["fri"]):
             assert f["position"] == p >> (3 * (li + 1))
             leaf = _rowhash(oracle, f["row"])
@@ -113,11 +122,12 @@ def test_merkle_openings_of_reference_proof(oracle, golden):
         assert _climb(oracle, leaf, [bytes.fromhex(d) for d in q["base"]["path"]], p ^ 1).hex() != roots["base"]
 
 
-def test_committed_order_is_bit_reversed(golden):
+@pytest.mark.parametrize("fixture", PROOF_FIXTURES)
+def test_committed_order_is_bit_reversed(golden, fixture):
     """beta = alpha / x per queried FRI row (fri_saved_proofs.json) times w_L^bitrev(row position) is ONE constant
     per layer - and 16 different values under the natural map: index i of a committed vector is the point
     offset * w_L^bitrev(i), w_L = 3^((p-1)/L)."""
-    g, fri = golden("saved_proof_openings.json"), golden("fri_saved_proofs.json")
+    g, fri = golden(fixture), golden("fri_saved_proofs.json")
     positions = g["positions"]
     log_N = (g["trace_len"] * g["options"][1]).bit_length() - 1
     brev = lambda x, bits: int(format(x, "0%db" % bits)[::-1], 2) if bits else 0
@@ -131,10 +141,11 @@ def test_committed_order_is_bit_reversed(golden):
         assert len({betas[r] * pow(w, ps[r], P) % P for r in betas}) > 1
 
 
-def test_remainder_of_reference_proof(oracle, golden):
+@pytest.mark.parametrize("fixture", PROOF_FIXTURES)
+def test_remainder_of_reference_proof(oracle, golden, fixture):
     """The last FRI layer of the saved proof folds (bit-reversed rows, unnormalised) onto its remainder polynomial
     taken in the UNSHIFTED variable: fold(row; alpha/offset as recovered, x = w'^bitrev(pos)) == R(x^8)."""
-    g = golden("saved_proof_openings.json")
+    g = golden(fixture)
     rem = [int(v, 16) for v in g["remainder"]]
     c = int(g["last_alpha_over_offset"], 16)
     nl = len(g["roots"]["fri_layers"])
