@@ -15,16 +15,20 @@
 //     zero-padded half of the LDE input is never materialised (`log_expand`).
 //   * log2(n) stages are grouped into passes; one pass = one kernel launch
 //     that streams every column once (2 * n * 32 B of HBM traffic), keeps a
-//     2048-element tile in LDS, and runs up to 11 stages on it as radix-8
-//     register butterflies (3 stages per LDS round trip).
+//     2048-element tile in LDS in the lazy 9-limb form, and runs up to 11
+//     stages on it in register groups of 2 (forward) or 3 (inverse) stages per
+//     LDS round trip; strided passes read/write HBM from their first/last group.
+//   * butterflies multiply by twiddles kept in R280 limb form (fl252.h), and
+//     reduce only where a bound needs it (radix_stage).
 //   * pass 0 ("contig") covers the stages whose butterflies span <= 2048
 //     adjacent elements: the tile is one contiguous 64 KiB block.  The other
 //     passes ("strided") take 2^r rows x T adjacent elements; T >= 16 keeps
 //     every global access a >= 512 B contiguous run.
-//   * LDS layout: 16-byte halves of the 32-byte elements in two planes (lane i
-//     and lane i+1 then touch adjacent 16-byte slots: conflict-free
-//     ds_read_b128), one pad slot per 8 so the stride-8/64 patterns of the
-//     radix-8 groups spread over all banks.
+//   * LDS layout: limbs 0-3 and 4-7 in two 16-byte planes, limb 8 in a dword
+//     plane, XOR-swizzled so that every group shift is bank-conflict free
+//     (lds_slot / lds_top_slot).
+// What bounds it (profiles/r01_ntt_ablation.txt): VALU issue - ~300 instructions
+// per butterfly, 185 of them the multiplication.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "fp252.h"

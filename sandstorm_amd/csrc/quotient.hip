@@ -4,7 +4,8 @@
 // to the composition constraint that layouts/src/{recursive,starknet}/air.rs build
 // (recursive air.rs:61-1200; row Q1 of SURVEY.md §8a).  The host lowers the `Expr`
 // DAG once per (layout, trace length) into the 4-accumulator program described in
-// include/sandstorm_hip.h; this kernel interprets it.
+// include/sandstorm_hip.h; ss_eval_quotient resolves it (operand addresses, lazy-form
+// bounds, R280 constants: "device program" below) and this kernel interprets that.
 //
 // One lane = one LDE point; the program counter, opcodes and operand selectors are
 // wave-uniform (scalar loads, scalar branches — no divergence), the four
