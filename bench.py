@@ -64,7 +64,7 @@ def cpu_baseline(layout, log_n_full, ncols):
     threads = int(os.environ["OMP_NUM_THREADS"])
     from oracle import oracle_py as oracle
     from tests.util import random_column
-    sl = min(17, log_n_full)
+    sl = min(18, log_n_full)
     n = 1 << sl
     g = oracle.to_mont([3])[0]
     cols = [random_column(n, c) for c in range(ncols)]
