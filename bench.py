@@ -33,6 +33,7 @@ import torch.distributed as dist
 WORKLOADS = {
     # name: (layout, log2 steps).  trace rows n = 16 * steps (CYCLE_HEIGHT, recursive/mod.rs:16)
     "starknet_2p20": ("starknet", 20),      # BASELINE.json: the size the metric is quoted on
+    "starknet_2p22": ("starknet", 22),      # BASELINE.json configs[3] (8-GPU config) on ONE GPU: ~210 GB of the 288 GB
     "recursive_2p20": ("recursive", 20),    # BASELINE.json north_star target size (2^20-step recursive trace)
     "recursive_2p16": ("recursive", 16),    # BASELINE.json configs[1]
     "recursive_2p10": ("recursive", 10),    # plumbing
