@@ -68,7 +68,9 @@ enum { SS_LEAF_DIGEST = 0, SS_LEAF_FELT = 1 };
 enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
 
 const char *ss_last_error(void);
-/* ABI version of this header; bump on any signature change. */
+/* ABI version of this header; bump on any signature change.  ss_abi_version() of the loaded
+ * library must equal SS_ABI_VERSION of the header the caller was built against. */
+#define SS_ABI_VERSION 2u
 uint32_t ss_abi_version(void);
 
 /* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;

@@ -11,7 +11,19 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libsandstorm_hip.so")
 
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sandstorm_hip.h")
+
 SS_OK = 0
+
+
+def header_abi_version():
+    """SS_ABI_VERSION of include/sandstorm_hip.h (the one definition of the boundary's version)."""
+    import re
+    with open(HEADER_PATH) as f:
+        m = re.search(r"#define\s+SS_ABI_VERSION\s+(\d+)u?", f.read())
+    if not m:
+        raise SandstormHipError("SS_ABI_VERSION not found in %s" % HEADER_PATH)
+    return int(m.group(1))
 
 
 class SandstormHipError(RuntimeError):
@@ -98,6 +110,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    want = header_abi_version()
+    if lib.ss_abi_version() != want:
+        raise SandstormHipError("%s has ABI version %d, include/sandstorm_hip.h declares %d: rebuild"
+                                % (LIB_PATH, lib.ss_abi_version(), want))
     _lib = lib
     return lib
 

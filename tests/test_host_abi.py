@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
-    assert lib.ss_abi_version() == 2
+    from sandstorm_amd import _lib
+    assert lib.ss_abi_version() == _lib.header_abi_version() == 2
 
 
 def test_no_device_fails_loudly():
