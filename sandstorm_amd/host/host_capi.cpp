@@ -35,10 +35,12 @@ uint32_t ssh_air_columns(const ssh_air *a, int which) {
     return which == 0 ? air->num_base_columns : which == 1 ? air->num_extension_columns : (uint32_t)air->mask.size();
 }
 
-// options: {num_queries, lde_blowup_factor, grinding_factor, fri_folding_factor, fri_max_remainder_coeffs}
-int ssh_prove(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32],
-              uint64_t *const *d_base, uint32_t nbase, uint32_t log_n, ssh_extension_cb cb, void *user, const uint32_t options[5],
-              uint8_t **proof_bytes, uint64_t *proof_len) {
+}  // extern "C"
+
+// format 0: the flat test dump (Proof::serialize); 1: the reference's wire format (Proof::serialize_wire)
+static int prove_impl(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32],
+                      uint64_t *const *d_base, uint32_t nbase, uint32_t log_n, ssh_extension_cb cb, void *user,
+                      const uint32_t options[5], int format, uint8_t **proof_bytes, uint64_t *proof_len) {
     try {
         Air *air = reinterpret_cast<Air *>(air_h);
         Claim claim;
@@ -65,13 +67,30 @@ int ssh_prove(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_la
             return ext;
         });
         if (proof_bytes && proof_len) {
-            std::vector<uint8_t> b = proof.serialize();
+            std::vector<uint8_t> b = format == 1 ? proof.serialize_wire() : proof.serialize();
             *proof_bytes = (uint8_t *)malloc(b.size());
             memcpy(*proof_bytes, b.data(), b.size());
             *proof_len = b.size();
         }
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+extern "C" {
+
+// options: {num_queries, lde_blowup_factor, grinding_factor, fri_folding_factor, fri_max_remainder_coeffs}
+int ssh_prove(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32],
+              uint64_t *const *d_base, uint32_t nbase, uint32_t log_n, ssh_extension_cb cb, void *user, const uint32_t options[5],
+              uint8_t **proof_bytes, uint64_t *proof_len) {
+    return prove_impl(ctx, air_h, tree_kind, n_friendly_layers, coin_kind, seed, d_base, nbase, log_n, cb, user, options, 0,
+                      proof_bytes, proof_len);
+}
+// same, with the proof in the reference's wire format (what `sandstorm-cli prove --output` writes: cli/src/main.rs:204-213)
+int ssh_prove_wire(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32],
+                   uint64_t *const *d_base, uint32_t nbase, uint32_t log_n, ssh_extension_cb cb, void *user,
+                   const uint32_t options[5], uint8_t **proof_bytes, uint64_t *proof_len) {
+    return prove_impl(ctx, air_h, tree_kind, n_friendly_layers, coin_kind, seed, d_base, nbase, log_n, cb, user, options, 1,
+                      proof_bytes, proof_len);
 }
 void ssh_free(void *p) { free(p); }
 

@@ -58,6 +58,15 @@ std::vector<uint8_t> MerkleTree::prove(const std::vector<uint64_t> &idx) const {
     return out;
 }
 
+std::vector<uint8_t> MerkleTree::leaf_digests(const std::vector<uint64_t> &idx) const {
+    std::vector<uint8_t> out;
+    if (!leaves_ || idx.empty()) return out;
+    out.resize(idx.size() * 32);
+    const uint64_t *col = leaves_->u64();           // a digest is one 32-byte entry of a single "column"
+    ok(ss_gather_rows(ctx_, &col, 1, idx.data(), (uint32_t)idx.size(), (uint64_t *)out.data()));
+    return out;
+}
+
 static std::vector<uint64_t> gather(ss_ctx *ctx, const std::vector<uint64_t *> &cols, const std::vector<uint64_t> &idx) {
     std::vector<uint64_t> out(idx.size() * cols.size() * 4);
     ok(ss_gather_rows(ctx, (const uint64_t *const *)cols.data(), (uint32_t)cols.size(), idx.data(), (uint32_t)idx.size(), out.data()));
@@ -79,6 +88,7 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     PublicCoin coin(claim_.coin_kind, coin_seed);
     Proof proof;
     proof.options = opt_;
+    proof.tree_kind = claim_.tree_kind;
     proof.trace_len = n;
     // SSH_TIMING=1: wall clock per stage (with a device sync at each boundary) on stderr
     const bool timing = getenv("SSH_TIMING") != nullptr;
@@ -243,9 +253,15 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     if (conv_.bitrev_commit) for (auto &q : nat) q = brev(q, log_N);
     proof.base_rows = gather(ctx_, base_lde.cols, nat);
     proof.base_paths = base_tree->prove(pos);
-    if (ext_tree) { proof.extension_rows = gather(ctx_, ext_lde.cols, nat); proof.extension_paths = ext_tree->prove(pos); }
+    proof.base_leaves = base_tree->leaf_digests(pos);
+    if (ext_tree) {
+        proof.extension_rows = gather(ctx_, ext_lde.cols, nat);
+        proof.extension_paths = ext_tree->prove(pos);
+        proof.extension_leaves = ext_tree->leaf_digests(pos);
+    }
     proof.composition_rows = gather(ctx_, comp_lde.cols, nat);
     proof.composition_paths = comp_tree->prove(pos);
+    proof.composition_leaves = comp_tree->leaf_digests(pos);
     std::vector<uint64_t> p = pos;
     for (size_t li = 0; li < layers.size(); ++li) {
         const uint32_t row_bits = proof.fri_layers[li].log_len - log_fold;
@@ -258,14 +274,15 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
         proof.fri_layers[li].positions = p;
         proof.fri_layers[li].rows = gather(ctx_, layers[li].matrix.cols, nat_rows);
         proof.fri_layers[li].paths = layers[li].tree->prove(p);
+        proof.fri_layers[li].leaves = layers[li].tree->leaf_digests(p);
     }
     mark("pow + openings");
     return proof;
 }
 
 // ------------------------------------------------------------------ serialisation
-// A flat little-endian dump for the Python tests (NOT the reference's ark-serialize wire
-// format — that is SURVEY §8f X2).
+// A flat little-endian dump for the Python tests, transcript values included (the reference's
+// own wire format is serialize_wire below).
 namespace {
 struct W {
     std::vector<uint8_t> b;
@@ -288,6 +305,78 @@ std::vector<uint8_t> Proof::serialize() const {
     w.bytes(base_paths); w.bytes(extension_paths); w.bytes(composition_paths);
     w.u32((uint32_t)fri_layers.size());
     for (auto &l : fri_layers) { w.raw(l.root.data(), 33); w.u32(l.log_len); w.u64s(l.positions); w.u64s(l.rows); w.bytes(l.paths); }
+    return w.b;
+}
+
+// ---- the reference's wire format (layout: sandstorm_amd/wire.py)
+namespace {
+struct Wire {
+    std::vector<uint8_t> b;
+    void u8(uint8_t v) { b.push_back(v); }
+    void u64(uint64_t v) { for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
+    void digest(const uint8_t *d) { u64(32); b.insert(b.end(), d, d + 32); }
+    void fp(const Felt &mont) {                     // 32-byte little-endian canonical value
+        const auto be = canonical_be_bytes(mont);
+        for (int i = 31; i >= 0; --i) b.push_back(be[i]);
+    }
+    void fp_limbs(const uint64_t *limbs) { Felt f; memcpy(f.data(), limbs, 32); fp(f); }
+    void fp_vec(const std::vector<Felt> &v) { u64(v.size()); for (auto &f : v) fp(f); }
+    void fp_vec(const std::vector<uint64_t> &limbs) { u64(limbs.size() / 4); for (size_t i = 0; i < limbs.size(); i += 4) fp_limbs(&limbs[i]); }
+    // openings of `npos` positions: rows (npos x ncols felts), paths (npos x depth x 32, leaf level first),
+    // leaves (npos x 32 row digests; empty for a single-column tree)
+    void openings(const std::vector<uint64_t> &rows, const std::vector<uint8_t> &paths, const std::vector<uint8_t> &leaves, size_t npos) {
+        u64(npos);
+        if (!npos) return;
+        const size_t depth = paths.size() / (32 * npos), ncols = rows.size() / (4 * npos);
+        if (!depth || paths.size() != npos * depth * 32) throw std::runtime_error("wire: malformed authentication paths");
+        const bool single = ncols == 1;
+        if (!single && leaves.size() != 32 * npos) throw std::runtime_error("wire: row digests missing");
+        for (size_t q = 0; q < npos; ++q) {
+            const uint8_t *path = paths.data() + q * depth * 32;
+            u8(single ? 1 : 0);
+            u64(depth - 1);
+            for (size_t l = 1; l < depth; ++l) digest(path + 32 * l);
+            if (single) {
+                // the sibling's leaf slot holds the element as big-endian Montgomery bytes
+                Felt sib{};
+                for (int k = 0; k < 4; ++k)
+                    for (int j = 0; j < 8; ++j) sib[k] |= (uint64_t)path[31 - (8 * k + j)] << (8 * j);
+                fp(sib);
+                fp_limbs(&rows[4 * q]);
+            } else {
+                digest(path);
+                digest(leaves.data() + 32 * q);
+            }
+        }
+    }
+};
+}  // namespace
+std::vector<uint8_t> Proof::serialize_wire() const {
+    if (tree_kind == SS_TREE_FRIENDLY)
+        throw std::runtime_error("wire: MixedMerkleDigest (FriendlyMerkleTree) encoding has no reference sample");
+    const uint32_t o[5] = {options.num_queries, options.lde_blowup_factor, options.grinding_factor, options.fri_folding_factor,
+                           options.fri_max_remainder_coeffs};
+    Wire w;
+    for (uint32_t v : o) { if (v > 255) throw std::runtime_error("wire: proof options are single bytes"); w.u8((uint8_t)v); }
+    w.u64(trace_len);
+    w.digest(base_root.data());
+    w.u8(has_extension ? 1 : 0);
+    if (has_extension) w.digest(extension_root.data());
+    w.digest(composition_root.data());
+    w.u64(fri_layers.size());
+    for (auto &l : fri_layers) {
+        w.fp_vec(l.rows);
+        w.openings(l.rows, l.paths, l.leaves, l.positions.size());
+        w.digest(l.root.data());
+    }
+    w.fp_vec(fri_remainder);
+    w.u64(pow_nonce);
+    w.fp_vec(base_rows); w.fp_vec(extension_rows); w.fp_vec(composition_rows);
+    const size_t nq = query_positions.size();
+    w.openings(base_rows, base_paths, base_leaves, nq);
+    w.openings(extension_rows, extension_paths, extension_leaves, has_extension ? nq : 0);
+    w.openings(composition_rows, composition_paths, composition_leaves, nq);
+    w.fp_vec(ood_trace); w.fp_vec(ood_composition);
     return w.b;
 }
 

@@ -67,6 +67,9 @@ public:
                                                    int order = SS_ORDER_NATURAL);
     const std::array<uint8_t, 33> &root() const { return root_; }
     std::vector<uint8_t> prove(const std::vector<uint64_t> &idx) const;     // nidx * log2(n) * 32 bytes
+    // the row digests at these leaf indices (32 bytes each); empty for a single-column tree, whose leaves are the
+    // elements themselves
+    std::vector<uint8_t> leaf_digests(const std::vector<uint64_t> &idx) const;
     uint64_t n() const { return n_; }
 private:
     ss_ctx *ctx_ = nullptr;
@@ -104,10 +107,12 @@ struct FriLayerProof {
     std::vector<uint64_t> positions;
     std::vector<uint64_t> rows;          // positions x fold felts
     std::vector<uint8_t> paths;
+    std::vector<uint8_t> leaves;         // row digests of the opened rows (the wire format carries them)
 };
 
 struct Proof {
     ProofOptions options;
+    int tree_kind = SS_TREE_KECCAK_M20;  // the claim's commitment scheme (decides the wire encoding of digests)
     uint64_t trace_len = 0;
     std::array<uint8_t, 33> base_root{}, extension_root{}, composition_root{};
     bool has_extension = false;
@@ -118,7 +123,12 @@ struct Proof {
     std::vector<uint64_t> query_positions;
     std::vector<uint64_t> base_rows, extension_rows, composition_rows;
     std::vector<uint8_t> base_paths, extension_paths, composition_paths;
-    std::vector<uint8_t> serialize() const;
+    std::vector<uint8_t> base_leaves, extension_leaves, composition_leaves;
+    std::vector<uint8_t> serialize() const;          // flat dump with the transcript values, for the tests
+    // The reference's proof bytes (ministark `Proof`, ark-serialize compressed) as pinned by its shipped proof files
+    // (sandstorm_amd/wire.py has the layout; tests/golden/make_proof_golden.py the evidence).  Keccak trees only:
+    // throws for FriendlyMerkleTree proofs, whose MixedMerkleDigest encoding has no reference sample.
+    std::vector<uint8_t> serialize_wire() const;
 };
 
 // build_extension_columns(&challenges) (layouts/src/recursive/trace.rs:699-814): returns the

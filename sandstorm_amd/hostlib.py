@@ -33,6 +33,7 @@ def load():
         h.ssh_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p, C.POINTER(C.c_void_p),
                                 C.c_uint32, C.c_uint32, EXT_CB, C.c_void_p, C.POINTER(C.c_uint32),
                                 C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
+        h.ssh_prove_wire.argtypes = h.ssh_prove.argtypes
         h.ssh_free.argtypes = [C.c_void_p]
         h.ssh_coin_new.restype = C.c_void_p
         h.ssh_coin_new.argtypes = [C.c_int, C.c_char_p]
@@ -130,8 +131,10 @@ def parse_proof(raw, options, ncols_base, ncols_ext, ncomp=2):
 
 
 def prove(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, base_cols, log_n, build_extension, options=None,
-          want_proof=True):
-    """build_extension(challenges: list of uint64[4]) -> list of device columns (kept alive by the caller)"""
+          want_proof=True, wire=False):
+    """build_extension(challenges: list of uint64[4]) -> list of device columns (kept alive by the caller).
+    wire=True: return the proof as bytes in the reference's wire format (ssh_prove_wire; sandstorm_amd/wire.py
+    parses them) instead of a parsed Proof."""
     options = options or ProofOptions()
     keep = []
 
@@ -150,13 +153,16 @@ def prove(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, base_cols, 
     opts = (C.c_uint32 * 5)(options.num_queries, options.lde_blowup_factor, options.grinding_factor,
                             options.fri_folding_factor, options.fri_max_remainder_coeffs)
     out, n = C.POINTER(C.c_uint8)(), C.c_uint64()
-    _check(load().ssh_prove(ctx.handle, air.h, tree_kind, n_friendly, coin_kind, bytes(seed), be._ptr_array(base_cols),
-                            len(base_cols), log_n, EXT_CB(cb), None, opts,
-                            C.byref(out) if want_proof else None, C.byref(n) if want_proof else None))
+    entry = load().ssh_prove_wire if wire else load().ssh_prove
+    _check(entry(ctx.handle, air.h, tree_kind, n_friendly, coin_kind, bytes(seed), be._ptr_array(base_cols),
+                 len(base_cols), log_n, EXT_CB(cb), None, opts,
+                 C.byref(out) if want_proof else None, C.byref(n) if want_proof else None))
     if not want_proof:
         return None
     raw = bytes(C.cast(out, C.POINTER(C.c_uint8 * n.value)).contents)
     load().ssh_free(out)
+    if wire:
+        return raw
     return parse_proof(raw, options, air.num_base_columns, air.num_extension_columns)
 
 

@@ -89,6 +89,7 @@ class FriLayer:
 class Proof:
     options: ProofOptions
     trace_len: int
+    tree_kind: Optional[int] = None                 # the claim's commitment scheme (backend tree kind), when known
     base_root: bytes = b""
     extension_root: Optional[bytes] = None
     composition_root: bytes = b""
@@ -143,7 +144,7 @@ class Prover:
         log_N, N = log_n + lb, n << lb
         g = be.felt(conv.lde_offset)
         coin = PublicCoin(self.claim.coin_kind, coin_seed)
-        proof = Proof(opt, n)
+        proof = Proof(opt, n, tree_kind=Tree.tree_kind)
         import time
         trace_stages = bool(self.timings is not None and self.timings.get("enabled"))
         t_last = [time.perf_counter()]

@@ -192,6 +192,8 @@ def from_proof(proof, leaf_hash) -> WireProof:
     leaf_hash(list of canonical ints) -> 32-byte digest of that row (the tree's row hash: the wire format carries
     the leaf digest next to its sibling)."""
     opt = proof.options
+    if getattr(proof, "tree_kind", None) == 2:          # backend.TREE_FRIENDLY
+        raise NotImplementedError("MixedMerkleDigest (FriendlyMerkleTree) proofs: no reference sample of the encoding")
     w = WireProof([opt.num_queries, opt.lde_blowup_factor, opt.grinding_factor, opt.fri_folding_factor,
                    opt.fri_max_remainder_coeffs], proof.trace_len, proof.base_root, proof.extension_root,
                   proof.composition_root)

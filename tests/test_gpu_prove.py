@@ -221,6 +221,38 @@ def verify_mini_proof(oracle, proof, n, params, opt, seed, conv=None):
         offset = pow(offset, fold, P)
 
 
+def _keccak_m20_leaf_hash(vals):
+    """LeafVariantMerkleTree<MaskedKeccak256HashFn<20>>: the tree's row hash, on canonical values"""
+    from sandstorm_amd import wire
+    from sandstorm_amd.coin import keccak256
+    data = b"".join((v * wire._R % P).to_bytes(32, "big") for v in vals)
+    return keccak256(data)[:20] + bytes(12)
+
+
+@pytest.mark.parametrize("log_n", [5, 9])
+def test_cpp_host_emits_the_reference_wire_format(ctx, oracle, log_n):
+    """ssh_prove_wire (C++ Proof::serialize_wire) writes byte for byte what wire.py - whose layout is read off the
+    reference's shipped proofs - writes for the Python mirror's proof of the same statement; a FriendlyMerkleTree
+    proof is refused (no reference sample of its MixedMerkleDigest encoding)."""
+    from sandstorm_amd import hostlib, wire
+    from sandstorm_amd._lib import SandstormHipError
+    from sandstorm_amd.prover import Prover
+    n, claim, params, opt, seed, base, build_extension = setup_case(ctx, oracle, "eth", log_n)
+    tree_kind, _, coin_kind, nf = params
+    air = hostlib.HostAir(ctx, hostlib.AIR_MINI, log_n)
+    raw = hostlib.prove(ctx, air, tree_kind, nf, coin_kind, seed, base.cols, log_n, lambda ch: build_extension(ch).cols, opt,
+                        wire=True)
+    ref = Prover(ctx, claim, opt).prove(seed, base, build_extension)
+    assert raw == wire.serialize(wire.from_proof(ref, _keccak_m20_leaf_hash))
+    w = wire.parse(raw)
+    assert w.trace_len == n and w.pow_nonce == ref.pow_nonce and len(w.base_openings) == len(ref.query_positions)
+    n2, claim2, params2, opt2, seed2, base2, build_extension2 = setup_case(ctx, oracle, "cairo", log_n)
+    with pytest.raises(SandstormHipError, match="MixedMerkleDigest"):
+        hostlib.prove(ctx, air, params2[0], params2[3], params2[2], seed2, base2.cols, log_n,
+                      lambda ch: build_extension2(ch).cols, opt2, wire=True)
+    air.close()
+
+
 def test_proof_in_reference_wire_format(ctx, oracle):
     """Our own proof (EthVerifierClaim flavour), serialised in the reference's wire format (sandstorm_amd/wire.py),
     goes through exactly the data-level checks the reference's saved proof passes in tests/golden/
