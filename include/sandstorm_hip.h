@@ -70,7 +70,7 @@ enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
 const char *ss_last_error(void);
 /* ABI version of this header; bump on any signature change.  ss_abi_version() of the loaded
  * library must equal SS_ABI_VERSION of the header the caller was built against. */
-#define SS_ABI_VERSION 2u
+#define SS_ABI_VERSION 3u
 uint32_t ss_abi_version(void);
 
 /* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;
@@ -88,6 +88,8 @@ ss_status ss_dev_free(ss_ctx *ctx, void *d_ptr);
 ss_status ss_ctx_trim(ss_ctx *ctx);
 ss_status ss_upload(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 ss_status ss_download(ss_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+/* zero-fill on the ctx stream (`Vec::resize(trace_len, Fp::ZERO)`, layouts/src/recursive/trace.rs:741-748) */
+ss_status ss_dev_zero(ss_ctx *ctx, void *d_ptr, size_t bytes);
 
 /* ---- N1/N2: ministark Matrix::interpolate / Matrix::evaluate (un-vendored;
  *      call sites src/lib.rs:17-26; convention pinned by
@@ -254,6 +256,35 @@ ss_status ss_pow_grind(ss_ctx *ctx, int coin_kind, const uint8_t digest[32], uin
  *      d_out[i] = pedersen_hash(d_a[i], d_b[i]) (Montgomery felts in and out). */
 ss_status ss_pedersen_hash(ss_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t n,
                            uint64_t *d_out);
+
+/* ---- A2 / X1: Trace::build_extension_columns (layouts/src/recursive/trace.rs:699-814,
+ *      layouts/src/starknet/trace.rs:997-1100), the sequential host loops between the base-trace and the
+ *      extension-trace commitments ("TODO: multithread", trace.rs:700), as device scans.
+ *
+ * An operand describes `array_chunks::<STEP>()` of one column: item k is the STEP felts at d_data + k*stride.
+ * Its term is   z - (alpha * item[value_offset] + item[addr_offset])    (memory: trace.rs:713-714)
+ * or            z - item[addr_offset]            when value_offset < 0  (range check / diluted check: trace.rs:727-728). */
+typedef struct {
+    const uint64_t *d_data;    /* device column, Montgomery felts */
+    uint64_t stride;           /* felts per item */
+    uint64_t addr_offset;      /* felt index of a_k (or of the single value x_k) inside item k */
+    int64_t value_offset;      /* felt index of v_k inside item k; negative: single-value term */
+} ss_perm_operand;
+/* d_out[out_offset + i*out_stride] = numerator_acc_i * batch_inversion(denominator_acc)_i for i < count, where
+ * *_acc_i is the product of the first i+1 terms of the operand (trace.rs:712-719, 767-769).  Like ark-ff's
+ * batch_inversion a zero denominator product inverts to zero.  last_out (nullable, host): the final value — the
+ * reference asserts it is one for the range-check and diluted-check products (trace.rs:734, 757-760); that check
+ * stays with the caller.  The other cells of d_out are not touched (the memory and range-check products share a
+ * column). */
+ss_status ss_permutation_product(ss_ctx *ctx, const ss_perm_operand *num, const ss_perm_operand *den, uint64_t count,
+                                 const uint64_t z[4], const uint64_t alpha[4], uint64_t *d_out, uint64_t out_stride,
+                                 uint64_t out_offset, uint64_t last_out[4]);
+/* Diluted-check aggregate (trace.rs:787-803): with x_i = d_ordered[i*stride + offset],
+ * d_out[out_offset] = 1 and d_out[out_offset + i*out_stride] = acc_i,
+ * acc_i = acc_{i-1} * (1 + z*u_i) + alpha * u_i^2,  u_i = x_i - x_{i-1},  for 0 < i < count. */
+ss_status ss_diluted_aggregate(ss_ctx *ctx, const uint64_t *d_ordered, uint64_t stride, uint64_t offset, uint64_t count,
+                               const uint64_t z[4], const uint64_t alpha[4], uint64_t *d_out, uint64_t out_stride,
+                               uint64_t out_offset);
 
 /* ---- per-kernel timing (bench.py's roofline leg): when enabled, every launch of
  *      the named kernel family on the ctx stream is bracketed by HIP events.

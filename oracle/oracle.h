@@ -89,6 +89,16 @@ void or_deep_compose(const fp_t *const *trace_lde, const fp_t *const *comp_lde, 
                      const fp_t *coeff_trace, size_t ncomp, const fp_t *ood_comp,
                      const fp_t *coeff_comp, fp_t z, fp_t *out);
 
+/* ---- ext.c: Trace::build_extension_columns (layouts/src/recursive/trace.rs:699-814, starknet/trace.rs:997-1100) */
+/* out[i*out_stride + out_off] = prod_{k<=i} term(num, k) * batch_inversion(prod_{k<=i} term(den, k)), i < count;
+ * term = z - (alpha * item[v] + item[a]) or, with v < 0, z - item[a]; item k = column + k*stride. */
+void or_permutation_product(const fp_t *num, uint64_t num_stride, uint64_t num_a, int64_t num_v,
+                            const fp_t *den, uint64_t den_stride, uint64_t den_a, int64_t den_v,
+                            uint64_t count, fp_t z, fp_t alpha, fp_t *out, uint64_t out_stride, uint64_t out_off);
+/* out[out_off] = 1; out[i*out_stride + out_off] = acc_i = acc_{i-1} (1 + z u_i) + alpha u_i^2, u_i = x_i - x_{i-1} */
+void or_diluted_aggregate(const fp_t *ordered, uint64_t stride, uint64_t off, uint64_t count, fp_t z, fp_t alpha,
+                          fp_t *out, uint64_t out_stride, uint64_t out_off);
+
 /* ---- coin.c: the two Fiat-Shamir coins (crypto/src/public_coin/{solidity,cairo}.rs) */
 typedef struct { int kind; /* 0 = Solidity/Keccak, 1 = Cairo/Blake2s */ uint8_t digest[32]; uint64_t counter; } or_coin;
 void or_coin_new(or_coin *c, int kind, const uint8_t digest[32]);

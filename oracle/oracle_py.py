@@ -205,6 +205,65 @@ def fri_fold(evals, fold, alpha, offset, flags=0):
     return out
 
 
+# ------------------------------------------------------------- extension trace
+def permutation_product(num, den, count, z, alpha, out, out_stride=1, out_off=0):
+    """num / den: (column [len, 4], stride, a_off, v_off or -1).  Writes out[i*out_stride + out_off] in place and
+    returns the last value (layouts/src/recursive/trace.rs:712-720, 766-769)."""
+    ncol, dcol = _c(num[0]), _c(den[0])
+    assert out.dtype == np.uint64 and out.flags["C_CONTIGUOUS"]
+    lib().or_permutation_product(_ptr(ncol), C.c_uint64(num[1]), C.c_uint64(num[2]), C.c_int64(num[3]),
+                                 _ptr(dcol), C.c_uint64(den[1]), C.c_uint64(den[2]), C.c_int64(den[3]),
+                                 C.c_uint64(count), _fp(z), _fp(alpha), _ptr(out), C.c_uint64(out_stride), C.c_uint64(out_off))
+    return out[(count - 1) * out_stride + out_off].copy()
+
+
+def diluted_aggregate(ordered, stride, off, count, z, alpha, out, out_stride=1, out_off=0):
+    """layouts/src/recursive/trace.rs:787-803"""
+    col = _c(ordered)
+    assert out.dtype == np.uint64 and out.flags["C_CONTIGUOUS"]
+    lib().or_diluted_aggregate(_ptr(col), C.c_uint64(stride), C.c_uint64(off), C.c_uint64(count), _fp(z), _fp(alpha),
+                               _ptr(out), C.c_uint64(out_stride), C.c_uint64(out_off))
+
+
+def build_extension_columns(layout, cols, challenges, trace_len):
+    """Trace::build_extension_columns for "recursive" (layouts/src/recursive/trace.rs:699-814; returns
+    [diluted_check_aggregate, diluted_check_permutation, mem_and_rc_permutation]) or "starknet"
+    (layouts/src/starknet/trace.rs:997-1100; returns [permutation_column]).
+    cols: dict of the trace's auxiliary columns ([len, 4] Montgomery limbs): npc, memory, range_check and, for
+    recursive, diluted_unordered / diluted_ordered.  challenges: the 6 verifier challenges (air.rs enums:
+    MemoryPermutation Z=0 A=1, RangeCheckPermutation Z=2, DilutedCheckPermutation Z=3, DilutedCheckAggregation Z=4 A=5).
+    Also returns the final (memory, range check, diluted) products; the reference asserts the last two are one."""
+    z_mem, a_mem, z_rc, z_dc, z_agg, a_agg = challenges
+    zero = np.zeros(4, dtype=np.uint64)
+    MEMORY_STEP, RANGE_CHECK_STEP = 2, 4                     # recursive/mod.rs:18-19, starknet/mod.rs:16-17
+    n_mem = len(cols["npc"]) // MEMORY_STEP
+    n_rc = len(cols["range_check"]) // RANGE_CHECK_STEP
+    if layout == "recursive":
+        agg = np.zeros((trace_len, 4), dtype=np.uint64)
+        dperm = np.zeros((trace_len, 4), dtype=np.uint64)
+        mem_rc = np.zeros((trace_len, 4), dtype=np.uint64)
+        # Permutation::{Memory -> (9, 0), RangeCheck -> (9, 1)} (recursive/air.rs:1705-1711); RangeCheck::{OffDst = 0, Ordered = 2}
+        last_mem = permutation_product((cols["npc"], 2, 0, 1), (cols["memory"], 2, 0, 1), n_mem, z_mem, a_mem, mem_rc, MEMORY_STEP, 0)
+        last_rc = permutation_product((cols["range_check"], 4, 0, -1), (cols["range_check"], 4, 2, -1), n_rc, z_rc, zero, mem_rc,
+                                      RANGE_CHECK_STEP, 1)
+        n_dc = len(cols["diluted_unordered"])                # DILUTED_CHECK_STEP = 1
+        last_dc = permutation_product((cols["diluted_unordered"], 1, 0, -1), (cols["diluted_ordered"], 1, 0, -1), n_dc, z_dc, zero, dperm)
+        diluted_aggregate(cols["diluted_ordered"], 1, 0, n_dc, z_agg, a_agg, agg)
+        return [agg, dperm, mem_rc], (last_mem, last_rc, last_dc)
+    assert layout == "starknet"
+    DILUTED_CHECK_STEP = 8                                   # starknet/mod.rs:18
+    perm = np.zeros((trace_len, 4), dtype=np.uint64)
+    # Permutation::{Memory = 0, RangeCheck = 1, DilutedCheck = 7}; DilutedCheck::{Unordered = 1, Ordered = 5, Aggregate = 3}
+    last_mem = permutation_product((cols["npc"], 2, 0, 1), (cols["memory"], 2, 0, 1), n_mem, z_mem, a_mem, perm, MEMORY_STEP, 0)
+    last_rc = permutation_product((cols["range_check"], 4, 0, -1), (cols["range_check"], 4, 2, -1), n_rc, z_rc, zero, perm,
+                                  RANGE_CHECK_STEP, 1)
+    n_dc = len(cols["range_check"]) // DILUTED_CHECK_STEP
+    last_dc = permutation_product((cols["range_check"], 8, 1, -1), (cols["range_check"], 8, 5, -1), n_dc, z_dc, zero, perm,
+                                  DILUTED_CHECK_STEP, 7)
+    diluted_aggregate(cols["range_check"], 8, 5, n_dc, z_agg, a_agg, perm, DILUTED_CHECK_STEP, 3)
+    return [perm], (last_mem, last_rc, last_dc)
+
+
 def deep_compose(trace_lde, comp_lde, log_n, log_blowup, offset, mask_col, mask_off, ood_trace,
                  coeff_trace, ood_comp, coeff_comp, z):
     tl = [_c(c) for c in trace_lde]

@@ -38,6 +38,11 @@ class AirProgram(C.Structure):
                 ("n_tables", C.c_uint32), ("n_slots", C.c_uint32)]
 
 
+class PermOperand(C.Structure):
+    """ss_perm_operand"""
+    _fields_ = [("d_data", C.c_void_p), ("stride", C.c_uint64), ("addr_offset", C.c_uint64), ("value_offset", C.c_int64)]
+
+
 _u64p = C.POINTER(C.c_uint64)
 _u32p = C.POINTER(C.c_uint32)
 _u8p = C.POINTER(C.c_uint8)
@@ -56,6 +61,11 @@ SIGNATURES = {
     "ss_ctx_trim": (C.c_int, [C.c_void_p]),
     "ss_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ss_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ss_dev_zero": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ss_permutation_product": (C.c_int, [C.c_void_p, C.POINTER(PermOperand), C.POINTER(PermOperand), C.c_uint64, _u64p, _u64p,
+                                         C.c_void_p, C.c_uint64, C.c_uint64, _u64p]),
+    "ss_diluted_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, _u64p, _u64p,
+                                       C.c_void_p, C.c_uint64, C.c_uint64]),
     "ss_ntt_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_int, _u64p, C.c_int, C.c_int]),
     "ss_lde_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _vpp, _vpp]),
     "ss_evaluate_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _vpp]),

@@ -268,6 +268,29 @@ class Context:
         check(self.lib.ss_eval_quotient(self.handle, C.byref(prog), _ptr_array(lde_cols), len(lde_cols), log_n,
                                         log_blowup, op, _ptr_of(out)))
 
+    def zero(self, buf, nbytes=None):
+        check(self.lib.ss_dev_zero(self.handle, _ptr_of(buf), buf.nbytes if nbytes is None else nbytes))
+
+    def permutation_product(self, num, den, count, z, alpha, out, out_stride=1, out_offset=0, want_last=True):
+        """num / den: (device column, stride, addr_offset, value_offset or -1) = array_chunks::<stride>() of the column;
+        writes out[out_offset + i*out_stride] = numerator_acc_i / denominator_acc_i (layouts/src/recursive/trace.rs:
+        704-733, 766-769) and returns the last value (Montgomery limbs) when want_last."""
+        ops = [_lib.PermOperand(_ptr_of(o[0]), o[1], o[2], o[3]) for o in (num, den)]
+        _kz, zp = _felt_ptr(z)
+        _ka, ap = _felt_ptr(alpha)
+        last = np.zeros(4, dtype=np.uint64)
+        check(self.lib.ss_permutation_product(self.handle, C.byref(ops[0]), C.byref(ops[1]), count, zp, ap, _ptr_of(out),
+                                              out_stride, out_offset,
+                                              last.ctypes.data_as(C.POINTER(C.c_uint64)) if want_last else None))
+        return last if want_last else None
+
+    def diluted_aggregate(self, ordered, stride, offset, count, z, alpha, out, out_stride=1, out_offset=0):
+        """layouts/src/recursive/trace.rs:787-803"""
+        _kz, zp = _felt_ptr(z)
+        _ka, ap = _felt_ptr(alpha)
+        check(self.lib.ss_diluted_aggregate(self.handle, _ptr_of(ordered), stride, offset, count, zp, ap, _ptr_of(out),
+                                            out_stride, out_offset))
+
     def profile(self, on):
         check(self.lib.ss_profile_enable(self.handle, 1 if on else 0))
 

@@ -19,6 +19,7 @@
 #include "../../include/sandstorm_hip.h"
 #include "fp252.h"
 #include "kernels.h"
+#include "ext_scan.h"
 
 using namespace ss;
 
@@ -262,7 +263,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, ss_fri_fold_ex
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -363,6 +364,11 @@ ss_status ss_upload(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes) {
     if (!ctx || (!d_dst && bytes) || (!src && bytes)) return fail(SS_ERR_INVALID, "NULL argument");
     HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+ss_status ss_dev_zero(ss_ctx *ctx, void *d_ptr, size_t bytes) {
+    if (!ctx || (!d_ptr && bytes)) return fail(SS_ERR_INVALID, "NULL argument");
+    if (bytes) HIP_TRY(hipMemsetAsync(d_ptr, 0, bytes, ctx->stream));
     return SS_OK;
 }
 ss_status ss_download(ss_ctx *ctx, void *dst, const void *d_src, size_t bytes) {
@@ -674,6 +680,44 @@ ss_status ss_pow_grind(ss_ctx *ctx, int coin_kind, const uint8_t digest[32], uin
         if (best != ~0ull) { *nonce_out = best; return SS_OK; }
         if (start > (1ull << 62)) return fail(SS_ERR_INVALID, "no nonce found");
     }
+}
+
+// ------------------------------------------------- extension-trace scans
+static bool perm_operand_ok(const ss_perm_operand *o) {
+    return o && o->d_data && o->stride && o->addr_offset < o->stride && (o->value_offset < 0 || (uint64_t)o->value_offset < o->stride);
+}
+ss_status ss_permutation_product(ss_ctx *ctx, const ss_perm_operand *num, const ss_perm_operand *den, uint64_t count,
+                                 const uint64_t z[4], const uint64_t alpha[4], uint64_t *d_out, uint64_t out_stride,
+                                 uint64_t out_offset, uint64_t last_out[4]) {
+    if (!ctx || !z || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!perm_operand_ok(num) || !perm_operand_ok(den)) return fail(SS_ERR_INVALID, "bad permutation operand (NULL column, zero stride or offset >= stride)");
+    if ((num->value_offset >= 0 || den->value_offset >= 0) && !alpha) return fail(SS_ERR_INVALID, "alpha is required for (address, value) terms");
+    if (count == 0 || count > (1ull << 32)) return fail(SS_ERR_INVALID, "count out of range");
+    if (!out_stride || out_offset >= out_stride) return fail(SS_ERR_INVALID, "bad output stride/offset");
+    ss_status st = ctx->ensure_scratch(permutation_product_scratch_felts(count) * sizeof(Fp));
+    if (st != SS_OK) return st;
+    const PermOperand n{(const Fp *)num->d_data, num->stride, num->addr_offset, num->value_offset};
+    const PermOperand d{(const Fp *)den->d_data, den->stride, den->addr_offset, den->value_offset};
+    HIP_TRY(launch_permutation_product(ctx->stream, n, d, count, fp_from_limbs64(z), alpha ? fp_from_limbs64(alpha) : fp_zero(),
+                                       (Fp *)d_out, out_stride, out_offset, (Fp *)ctx->scratch));
+    if (last_out) {
+        HIP_TRY(hipMemcpyAsync(last_out, (const Fp *)d_out + (count - 1) * out_stride + out_offset, sizeof(Fp), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return SS_OK;
+}
+
+ss_status ss_diluted_aggregate(ss_ctx *ctx, const uint64_t *d_ordered, uint64_t stride, uint64_t offset, uint64_t count,
+                               const uint64_t z[4], const uint64_t alpha[4], uint64_t *d_out, uint64_t out_stride,
+                               uint64_t out_offset) {
+    if (!ctx || !d_ordered || !z || !alpha || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!stride || offset >= stride || !out_stride || out_offset >= out_stride) return fail(SS_ERR_INVALID, "bad stride/offset");
+    if (count == 0 || count > (1ull << 32)) return fail(SS_ERR_INVALID, "count out of range");
+    ss_status st = ctx->ensure_scratch(diluted_aggregate_scratch_felts(count) * sizeof(Fp));
+    if (st != SS_OK) return st;
+    HIP_TRY(launch_diluted_aggregate(ctx->stream, (const Fp *)d_ordered, stride, offset, count, fp_from_limbs64(z),
+                                     fp_from_limbs64(alpha), (Fp *)d_out, out_stride, out_offset, (Fp *)ctx->scratch));
+    return SS_OK;
 }
 
 // -------------------------------------------------------------- Pedersen

@@ -1,0 +1,106 @@
+// ext.hip — extension-trace scans on gfx950 ("next" row X1).
+//
+// Trace::build_extension_columns (layouts/src/recursive/trace.rs:699-814,
+// layouts/src/starknet/trace.rs:997-1100) is three running permutation products
+//     out_i = prod_{k<=i} (z - (alpha v_k + a_k)) / prod_{k<=i} (z - (alpha v'_k + a'_k))
+// (memory; range check and diluted check have single-value terms z - x_k) and one affine
+// recurrence (diluted-check aggregate)
+//     acc_0 = 1,  acc_i = acc_{i-1} (1 + z u_i) + alpha u_i^2,  u_i = x_i - x_{i-1}.
+// The reference runs them as sequential loops on the host between two device phases
+// ("TODO: multithread", trace.rs:700).  Here both are inclusive scans over a monoid
+// (field multiplication; composition of affine maps), done in three phases per level:
+//   reduce : one lane folds a chunk of 64 consecutive items into its aggregate
+//   (recurse on the aggregates: 2^23 items -> 2^17 -> 2^11 -> 32 -> one lane)
+//   apply  : the lane replays its chunk starting from the scanned aggregate before it
+// and the denominators' prefix products are inverted by Montgomery's trick on the same
+// chunks (one safegcd inversion per 64 items), zero-preserving like ark-ff's
+// batch_inversion (a zero entry stays zero and does not poison its neighbours).
+// The arithmetic is exact, so the order of association does not change a single bit.
+// Cost: ~10 multiplications and ~10 x 32 B of HBM traffic per item — microseconds next
+// to the LDE; the point is that the columns never leave HBM between the two phases.
+#include <hip/hip_runtime.h>
+#include "ext_scan.h"
+#include "kernels.h"
+
+namespace ss {
+
+namespace {
+
+template <class Op>
+__global__ __launch_bounds__(128) void scan_reduce_kernel(const Fp *__restrict__ data, uint64_t n, Fp *__restrict__ agg) {
+    scan_reduce_lane<Op>(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, agg);
+}
+template <class Op>
+__global__ __launch_bounds__(128) void scan_apply_kernel(Fp *__restrict__ data, uint64_t n, const Fp *__restrict__ aggscan) {
+    scan_apply_lane<Op>(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, aggscan);
+}
+__global__ __launch_bounds__(128) void inverse_dense_kernel(Fp *__restrict__ data, uint64_t n, Fp *__restrict__ tmp) {
+    inverse_dense_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, tmp);
+}
+__global__ __launch_bounds__(256) void perm_terms_kernel(PermOperand num, PermOperand den, uint64_t count, Fp z, Fp alpha,
+                                                         Fp *__restrict__ tn, Fp *__restrict__ td) {
+    perm_terms_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, num, den, count, z, alpha, tn, td);
+}
+__global__ __launch_bounds__(256) void perm_finish_kernel(const Fp *__restrict__ pn, const Fp *__restrict__ pd_inv, uint64_t count,
+                                                          Fp *out, uint64_t out_stride, uint64_t out_off) {
+    perm_finish_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, pn, pd_inv, count, out, out_stride, out_off);
+}
+__global__ __launch_bounds__(256) void dil_terms_kernel(const Fp *x, uint64_t stride, uint64_t off, uint64_t count, Fp z, Fp alpha,
+                                                        Fp *__restrict__ mc) {
+    dil_terms_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, x, stride, off, count, z, alpha, mc);
+}
+__global__ __launch_bounds__(256) void dil_finish_kernel(const Fp *__restrict__ mc, uint64_t count, Fp *out, uint64_t out_stride,
+                                                         uint64_t out_off) {
+    dil_finish_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, mc, count, out, out_stride, out_off);
+}
+
+inline dim3 grid_for(uint64_t lanes, uint32_t block) { return dim3((uint32_t)((lanes + block - 1) / block)); }
+
+struct HipExec {                 // a lane body = a kernel launch on the context's stream
+    hipStream_t st;
+    static int done() { return (int)hipGetLastError(); }
+    template <class Op> int reduce(uint64_t lanes, const Fp *data, uint64_t n, Fp *agg) {
+        hipLaunchKernelGGL(scan_reduce_kernel<Op>, grid_for(lanes, 128), dim3(128), 0, st, data, n, agg);
+        return done();
+    }
+    template <class Op> int apply(uint64_t lanes, Fp *data, uint64_t n, const Fp *aggscan) {
+        hipLaunchKernelGGL(scan_apply_kernel<Op>, grid_for(lanes, 128), dim3(128), 0, st, data, n, aggscan);
+        return done();
+    }
+    int inverse_dense(uint64_t lanes, Fp *data, uint64_t n, Fp *tmp) {
+        hipLaunchKernelGGL(inverse_dense_kernel, grid_for(lanes, 128), dim3(128), 0, st, data, n, tmp);
+        return done();
+    }
+    int perm_terms(const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z, const Fp &alpha, Fp *tn, Fp *td) {
+        hipLaunchKernelGGL(perm_terms_kernel, grid_for(count, 256), dim3(256), 0, st, num, den, count, z, alpha, tn, td);
+        return done();
+    }
+    int perm_finish(const Fp *pn, const Fp *pd_inv, uint64_t count, Fp *out, uint64_t out_stride, uint64_t out_off) {
+        hipLaunchKernelGGL(perm_finish_kernel, grid_for(count, 256), dim3(256), 0, st, pn, pd_inv, count, out, out_stride, out_off);
+        return done();
+    }
+    int dil_terms(const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z, const Fp &alpha, Fp *mc) {
+        hipLaunchKernelGGL(dil_terms_kernel, grid_for(count, 256), dim3(256), 0, st, x, stride, off, count, z, alpha, mc);
+        return done();
+    }
+    int dil_finish(const Fp *mc, uint64_t count, Fp *out, uint64_t out_stride, uint64_t out_off) {
+        hipLaunchKernelGGL(dil_finish_kernel, grid_for(count, 256), dim3(256), 0, st, mc, count, out, out_stride, out_off);
+        return done();
+    }
+};
+
+}  // namespace
+
+hipError_t launch_permutation_product(hipStream_t st, const PermOperand &num, const PermOperand &den, uint64_t count,
+                                      const Fp &z, const Fp &alpha, Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch) {
+    HipExec ex{st};
+    return (hipError_t)permutation_product(ex, num, den, count, z, alpha, out, out_stride, out_off, scratch);
+}
+
+hipError_t launch_diluted_aggregate(hipStream_t st, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z,
+                                    const Fp &alpha, Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch) {
+    HipExec ex{st};
+    return (hipError_t)diluted_aggregate(ex, x, stride, off, count, z, alpha, out, out_stride, out_off, scratch);
+}
+
+}  // namespace ss

@@ -1,0 +1,161 @@
+// ext_scan.h — lane bodies and the level driver of the extension-trace scans (ext.hip), host+device so that
+// tests/cpp/ext_scan_test.cpp can run the very same code on the CPU with a loop in place of a launch.
+#pragma once
+#include "fp252.h"
+#include "inv252.h"
+
+namespace ss {
+
+constexpr uint32_t SCAN_LOG_CHUNK = 6;
+constexpr uint64_t SCAN_CHUNK = 1ull << SCAN_LOG_CHUNK;
+
+struct PermOperand {            // ss_perm_operand with device pointers typed
+    const Fp *data;
+    uint64_t stride, a_off;
+    int64_t v_off;              // < 0: single-value term z - a_k
+};
+
+// ---- the two monoids --------------------------------------------------------------------
+struct MulOp {                       // field multiplication
+    typedef Fp T;
+    static constexpr uint32_t FELTS = 1;
+    static SS_HD T identity() { return fp_one(); }
+    static SS_HD T load(const Fp *base, uint64_t i) { return base[i]; }
+    static SS_HD void store(Fp *base, uint64_t i, const T &x) { base[i] = x; }
+    static SS_HD T combine(const T &acc, const T &x) { return fp_mul(acc, x); }
+};
+struct Affine { Fp m, c; };          // t -> m t + c
+struct AffineOp {                    // "then": (acc then x)(t) = x.m (acc.m t + acc.c) + x.c
+    typedef Affine T;
+    static constexpr uint32_t FELTS = 2;
+    static SS_HD T identity() { return Affine{fp_one(), fp_zero()}; }
+    static SS_HD T load(const Fp *base, uint64_t i) { return Affine{base[2 * i], base[2 * i + 1]}; }
+    static SS_HD void store(Fp *base, uint64_t i, const T &x) { base[2 * i] = x.m; base[2 * i + 1] = x.c; }
+    static SS_HD T combine(const T &acc, const T &x) { return Affine{fp_mul(acc.m, x.m), fp_add(fp_mul(acc.c, x.m), x.c)}; }
+};
+
+// ---- lane bodies (c = chunk index = global lane id) -------------------------------------------
+template <class Op>
+SS_HD void scan_reduce_lane(uint64_t c, const Fp *data, uint64_t n, Fp *agg) {
+    const uint64_t i0 = c << SCAN_LOG_CHUNK;
+    if (i0 >= n) return;
+    const uint64_t i1 = i0 + SCAN_CHUNK < n ? i0 + SCAN_CHUNK : n;
+    typename Op::T acc = Op::load(data, i0);
+    for (uint64_t i = i0 + 1; i < i1; ++i) acc = Op::combine(acc, Op::load(data, i));
+    Op::store(agg, c, acc);
+}
+
+// in place: data[i] <- data[0] . data[1] ... data[i]; aggscan = inclusive scan of the chunk aggregates (null: one chunk)
+template <class Op>
+SS_HD void scan_apply_lane(uint64_t c, Fp *data, uint64_t n, const Fp *aggscan) {
+    const uint64_t i0 = c << SCAN_LOG_CHUNK;
+    if (i0 >= n) return;
+    const uint64_t i1 = i0 + SCAN_CHUNK < n ? i0 + SCAN_CHUNK : n;
+    typename Op::T acc = (c && aggscan) ? Op::load(aggscan, c - 1) : Op::identity();
+    for (uint64_t i = i0; i < i1; ++i) {
+        acc = Op::combine(acc, Op::load(data, i));
+        Op::store(data, i, acc);
+    }
+}
+
+// zero-preserving element-wise inversion (ark-ff batch_inversion semantics); tmp: n felts.
+// Prefix products of the non-zero entries of the chunk, one inversion, back-substitution.
+SS_HD void inverse_dense_lane(uint64_t c, Fp *data, uint64_t n, Fp *tmp) {
+    const uint64_t i0 = c << SCAN_LOG_CHUNK;
+    if (i0 >= n) return;
+    const uint64_t i1 = i0 + SCAN_CHUNK < n ? i0 + SCAN_CHUNK : n;
+    Fp run = fp_one();
+    for (uint64_t i = i0; i < i1; ++i) {
+        const Fp v = data[i];
+        tmp[i] = run;
+        if (!fp_is_zero(v)) run = fp_mul(run, v);
+    }
+    Fp inv = fp_inv_safegcd(run);                 // run is a product of non-zero entries (or 1)
+    for (uint64_t i = i1; i-- > i0;) {
+        const Fp v = data[i];
+        if (fp_is_zero(v)) continue;              // stays zero
+        data[i] = fp_mul(inv, tmp[i]);
+        inv = fp_mul(inv, v);
+    }
+}
+
+SS_HD Fp perm_term(const PermOperand &o, uint64_t k, const Fp &z, const Fp &alpha) {
+    const Fp *item = o.data + k * o.stride;
+    const Fp a = item[o.a_off];
+    if (o.v_off < 0) return fp_sub(z, a);                                    // z - x_k           (trace.rs:727-728)
+    return fp_sub(z, fp_add(fp_mul(alpha, item[o.v_off]), a));               // z - (alpha v + a)  (trace.rs:713-714)
+}
+SS_HD void perm_terms_lane(uint64_t k, const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z,
+                           const Fp &alpha, Fp *tn, Fp *td) {
+    if (k >= count) return;
+    tn[k] = perm_term(num, k, z, alpha);
+    td[k] = perm_term(den, k, z, alpha);
+}
+SS_HD void perm_finish_lane(uint64_t k, const Fp *pn, const Fp *pd_inv, uint64_t count, Fp *out, uint64_t out_stride,
+                            uint64_t out_off) {
+    if (k >= count) return;
+    out[k * out_stride + out_off] = fp_mul(pn[k], pd_inv[k]);                // n * d_inv         (trace.rs:767-769)
+}
+
+// item 0 is the constant map t -> 1 (the initial value), item k the map t -> t (1 + z u_k) + alpha u_k^2
+SS_HD void dil_terms_lane(uint64_t k, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z,
+                          const Fp &alpha, Fp *mc) {
+    if (k >= count) return;
+    Affine f;
+    if (k == 0) {
+        f.m = fp_zero(); f.c = fp_one();
+    } else {
+        const Fp u = fp_sub(x[k * stride + off], x[(k - 1) * stride + off]);         // curr - prev   (trace.rs:800)
+        f.m = fp_add(fp_one(), fp_mul(z, u));
+        f.c = fp_mul(alpha, fp_sqr(u));
+    }
+    AffineOp::store(mc, k, f);
+}
+SS_HD void dil_finish_lane(uint64_t k, const Fp *mc, uint64_t count, Fp *out, uint64_t out_stride, uint64_t out_off) {
+    if (k >= count) return;
+    out[k * out_stride + out_off] = mc[2 * k + 1];                           // the map is constant: its value is c
+}
+
+inline uint64_t scan_chunks(uint64_t n) { return (n + SCAN_CHUNK - 1) >> SCAN_LOG_CHUNK; }
+inline uint64_t scan_agg_felts(uint64_t count, uint32_t felts) { return felts * (count / (SCAN_CHUNK - 1) + 64); }
+
+// ---- level driver; Exec runs a lane body for lanes 0 .. nlanes-1 (a kernel launch, or a host loop) ----
+// tmp: room for the aggregates of every level: scan_agg_felts(n, Op::FELTS) felts.  Returns Exec's status (0 = ok).
+template <class Op, class Exec>
+int scan_inclusive(Exec &ex, Fp *data, uint64_t n, Fp *tmp) {
+    if (n <= SCAN_CHUNK) return ex.template apply<Op>(1, data, n, (const Fp *)nullptr);
+    const uint64_t m = scan_chunks(n);
+    int e = ex.template reduce<Op>(m, (const Fp *)data, n, tmp);
+    if (e) return e;
+    if ((e = scan_inclusive<Op>(ex, tmp, m, tmp + Op::FELTS * m))) return e;
+    return ex.template apply<Op>(m, data, n, (const Fp *)tmp);
+}
+
+inline uint64_t permutation_product_scratch_felts(uint64_t count) { return 3 * count + scan_agg_felts(count, 1); }
+inline uint64_t diluted_aggregate_scratch_felts(uint64_t count) { return 2 * count + scan_agg_felts(count, 2); }
+
+// the whole permutation product / aggregate in terms of Exec
+template <class Exec>
+int permutation_product(Exec &ex, const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z, const Fp &alpha,
+                        Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch) {
+    if (count == 0) return 0;
+    Fp *tn = scratch, *td = scratch + count, *tmp = scratch + 2 * count, *aggs = scratch + 3 * count;
+    int e = ex.perm_terms(num, den, count, z, alpha, tn, td);
+    if (e) return e;
+    if ((e = scan_inclusive<MulOp>(ex, tn, count, aggs))) return e;          // numerator_acc
+    if ((e = scan_inclusive<MulOp>(ex, td, count, aggs))) return e;          // denominator_acc
+    if ((e = ex.inverse_dense(scan_chunks(count), td, count, tmp))) return e;     // batch_inversion
+    return ex.perm_finish((const Fp *)tn, (const Fp *)td, count, out, out_stride, out_off);
+}
+template <class Exec>
+int diluted_aggregate(Exec &ex, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z, const Fp &alpha, Fp *out,
+                      uint64_t out_stride, uint64_t out_off, Fp *scratch) {
+    if (count == 0) return 0;
+    Fp *mc = scratch, *aggs = scratch + 2 * count;
+    int e = ex.dil_terms(x, stride, off, count, z, alpha, mc);
+    if (e) return e;
+    if ((e = scan_inclusive<AffineOp>(ex, mc, count, aggs))) return e;
+    return ex.dil_finish((const Fp *)mc, count, out, out_stride, out_off);
+}
+
+}  // namespace ss

@@ -84,6 +84,13 @@ hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace
 hipError_t launch_gather_cells(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *col,
                                const uint64_t *idx, uint32_t n, Fp *out);
 
+// ---- ext.hip (extension-trace scans; PermOperand and the scratch sizes are in ext_scan.h)
+struct PermOperand;
+hipError_t launch_permutation_product(hipStream_t st, const PermOperand &num, const PermOperand &den, uint64_t count,
+                                      const Fp &z, const Fp &alpha, Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch);
+hipError_t launch_diluted_aggregate(hipStream_t st, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z,
+                                    const Fp &alpha, Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch);
+
 // ---- quotient.hip
 // what ss_eval_quotient knows and the device program needs resolved (device addresses, sizes)
 struct VmResolve {
