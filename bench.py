@@ -118,7 +118,7 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
-    from sandstorm_amd import backend as be, hostlib
+    from sandstorm_amd import backend as be, extension, hostlib
     from sandstorm_amd.prover import ProofOptions
 
     layout, log_steps = WORKLOADS[args.workload]
@@ -135,14 +135,22 @@ def main():
 
     # inputs resident in HBM before the timed region; one independent trace per rank (weak scaling)
     base_t = synth_columns(device, air.num_base_columns, log_n, seed=0x53414E44 + rank)
-    ext_t = synth_columns(device, air.num_extension_columns, log_n, seed=0x7E57 + rank)
     base_cols = [base_t[c] for c in range(air.num_base_columns)]
-    ext_cols = [ext_t[c] for c in range(air.num_extension_columns)]
+    # the trace's auxiliary columns (npc, memory, range check [, diluted unordered / ordered]): the extension columns
+    # are built from them ON THE DEVICE inside the timed region, after the challenges are drawn
+    # (Trace::build_extension_columns, sandstorm_amd/extension.py; random data, so the is_one asserts are off)
+    aux_t = synth_columns(device, 5 if layout == "recursive" else 3, log_n, seed=0x7E57 + rank)
+    trace_cols = extension.TraceColumns(aux_t[0], aux_t[1], aux_t[2], n, *(aux_t[3:5] if layout == "recursive" else ()))
     seed = bytes((7 * i + rank) & 0xff for i in range(32))
+
+    def build_extension(challenges):
+        m = extension.build_extension_columns(layout, ctx, trace_cols, challenges, check=False)
+        assert m.num_cols == air.num_extension_columns
+        return m.cols
 
     def step(want_proof=False):
         return hostlib.prove(ctx, air, tree_kind, n_friendly, coin_kind, seed, base_cols, log_n,
-                             lambda challenges: ext_cols, options, want_proof=want_proof)
+                             build_extension, options, want_proof=want_proof)
 
     def barrier():
         if world > 1:
@@ -161,7 +169,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kinds = [("ntt_pass", be.PROF_NTT_PASS), ("hash_rows", be.PROF_HASH_ROWS), ("merkle", be.PROF_MERKLE),
-             ("fri_fold", be.PROF_FRI), ("quotient", be.PROF_QUOTIENT), ("deep", be.PROF_DEEP)]
+             ("fri_fold", be.PROF_FRI), ("quotient", be.PROF_QUOTIENT), ("deep", be.PROF_DEEP),
+             ("extension_scans", be.PROF_EXT)]
     prof = {name: ctx.profile_read(k) for name, k in kinds}
     ctx.profile(False)
 
@@ -203,8 +212,8 @@ def main():
                                 else "EthVerifierClaim (Keccak-masked-20 tree, Solidity coin)",
                        "air": "SYNTHETIC constraint set with the layout's shape: %d mask cells, see sandstorm_amd/synthetic_air.py" % air.mask_size,
                        "proof_options": "65 queries, blowup 2, 16 PoW bits, FRI fold 8, <=16 remainder coeffs",
-                       "in_timed_region": "LDE x2, commits x3, quotient, composition LDE, OOD, DEEP, FRI, PoW, openings",
-                       "outside": "host trace generation (A1/A2): columns are resident in HBM",
+                       "in_timed_region": "LDE x2, extension-column scans (A2), commits x3, quotient, composition LDE, OOD, DEEP, FRI, PoW, openings",
+                       "outside": "host trace generation (A1): base and auxiliary columns are resident in HBM",
                        "per_gpu": "one independent proof per rank",
                        "host": "C++ prover (sandstorm_amd/host, libsandstorm_host.so) through ctypes",
                        "fri_layers": len(proof.fri_layers), "pow_nonce": proof.pow_nonce},

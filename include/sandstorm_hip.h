@@ -291,7 +291,7 @@ ss_status ss_diluted_aggregate(ss_ctx *ctx, const uint64_t *d_ordered, uint64_t 
  *      ss_profile_read synchronises the stream and returns the accumulated device
  *      time and launch count since the last reset. */
 enum { SS_PROF_NTT_PASS = 0, SS_PROF_HASH_ROWS = 1, SS_PROF_MERKLE = 2, SS_PROF_FRI = 3, SS_PROF_QUOTIENT = 4,
-       SS_PROF_DEEP = 5, SS_PROF_KINDS = 6 };
+       SS_PROF_DEEP = 5, SS_PROF_EXT = 6, SS_PROF_KINDS = 7 };
 ss_status ss_profile_enable(ss_ctx *ctx, int on);
 ss_status ss_profile_reset(ss_ctx *ctx);
 ss_status ss_profile_read(ss_ctx *ctx, int kind, double *total_ms, uint64_t *launches);

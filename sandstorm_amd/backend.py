@@ -31,7 +31,7 @@ HASH_KECCAK, HASH_KECCAK_M20, HASH_BLAKE2S, HASH_BLAKE2S_M20 = 0, 1, 2, 3
 TREE_KECCAK, TREE_KECCAK_M20, TREE_FRIENDLY = 0, 1, 2
 LEAF_DIGEST, LEAF_FELT = 0, 1
 COIN_SOLIDITY, COIN_CAIRO = 0, 1
-PROF_NTT_PASS, PROF_HASH_ROWS, PROF_MERKLE, PROF_FRI, PROF_QUOTIENT, PROF_DEEP = range(6)
+PROF_NTT_PASS, PROF_HASH_ROWS, PROF_MERKLE, PROF_FRI, PROF_QUOTIENT, PROF_DEEP, PROF_EXT = range(7)
 
 
 def felt(v):

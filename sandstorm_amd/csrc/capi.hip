@@ -696,6 +696,7 @@ ss_status ss_permutation_product(ss_ctx *ctx, const ss_perm_operand *num, const 
     if (!out_stride || out_offset >= out_stride) return fail(SS_ERR_INVALID, "bad output stride/offset");
     ss_status st = ctx->ensure_scratch(permutation_product_scratch_felts(count) * sizeof(Fp));
     if (st != SS_OK) return st;
+    ss_ctx::Scope prof(ctx, SS_PROF_EXT);
     const PermOperand n{(const Fp *)num->d_data, num->stride, num->addr_offset, num->value_offset};
     const PermOperand d{(const Fp *)den->d_data, den->stride, den->addr_offset, den->value_offset};
     HIP_TRY(launch_permutation_product(ctx->stream, n, d, count, fp_from_limbs64(z), alpha ? fp_from_limbs64(alpha) : fp_zero(),
@@ -715,6 +716,7 @@ ss_status ss_diluted_aggregate(ss_ctx *ctx, const uint64_t *d_ordered, uint64_t 
     if (count == 0 || count > (1ull << 32)) return fail(SS_ERR_INVALID, "count out of range");
     ss_status st = ctx->ensure_scratch(diluted_aggregate_scratch_felts(count) * sizeof(Fp));
     if (st != SS_OK) return st;
+    ss_ctx::Scope prof(ctx, SS_PROF_EXT);
     HIP_TRY(launch_diluted_aggregate(ctx->stream, (const Fp *)d_ordered, stride, offset, count, fp_from_limbs64(z),
                                      fp_from_limbs64(alpha), (Fp *)d_out, out_stride, out_offset, (Fp *)ctx->scratch));
     return SS_OK;

@@ -9,16 +9,17 @@
 // The reference runs them as sequential loops on the host between two device phases
 // ("TODO: multithread", trace.rs:700).  Here both are inclusive scans over a monoid
 // (field multiplication; composition of affine maps), done in three phases per level:
-//   reduce : one lane folds a chunk of 64 consecutive items into its aggregate
-//   (recurse on the aggregates: 2^23 items -> 2^17 -> 2^11 -> 32 -> one lane)
+//   reduce : one lane folds a chunk of 2^k consecutive items into its aggregate
+//   (recurse on the aggregates until one lane holds them all)
 //   apply  : the lane replays its chunk starting from the scanned aggregate before it
 // and the denominators' prefix products are inverted by Montgomery's trick on the same
-// chunks (one safegcd inversion per 64 items), zero-preserving like ark-ff's
+// kind of chunks (one safegcd inversion per chunk), zero-preserving like ark-ff's
 // batch_inversion (a zero entry stays zero and does not poison its neighbours).
 // The arithmetic is exact, so the order of association does not change a single bit.
 // Cost: ~10 multiplications and ~10 x 32 B of HBM traffic per item — microseconds next
 // to the LDE; the point is that the columns never leave HBM between the two phases.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "ext_scan.h"
 #include "kernels.h"
 
@@ -27,15 +28,15 @@ namespace ss {
 namespace {
 
 template <class Op>
-__global__ __launch_bounds__(128) void scan_reduce_kernel(const Fp *__restrict__ data, uint64_t n, Fp *__restrict__ agg) {
-    scan_reduce_lane<Op>(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, agg);
+__global__ __launch_bounds__(128) void scan_reduce_kernel(const Fp *__restrict__ data, uint64_t n, Fp *__restrict__ agg, uint32_t lc) {
+    scan_reduce_lane<Op>(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, agg, lc);
 }
 template <class Op>
-__global__ __launch_bounds__(128) void scan_apply_kernel(Fp *__restrict__ data, uint64_t n, const Fp *__restrict__ aggscan) {
-    scan_apply_lane<Op>(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, aggscan);
+__global__ __launch_bounds__(128) void scan_apply_kernel(Fp *__restrict__ data, uint64_t n, const Fp *__restrict__ aggscan, uint32_t lc) {
+    scan_apply_lane<Op>(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, aggscan, lc);
 }
-__global__ __launch_bounds__(128) void inverse_dense_kernel(Fp *__restrict__ data, uint64_t n, Fp *__restrict__ tmp) {
-    inverse_dense_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, tmp);
+__global__ __launch_bounds__(128) void inverse_dense_kernel(Fp *__restrict__ data, uint64_t n, Fp *__restrict__ tmp, uint32_t lc) {
+    inverse_dense_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, tmp, lc);
 }
 __global__ __launch_bounds__(256) void perm_terms_kernel(PermOperand num, PermOperand den, uint64_t count, Fp z, Fp alpha,
                                                          Fp *__restrict__ tn, Fp *__restrict__ td) {
@@ -56,19 +57,28 @@ __global__ __launch_bounds__(256) void dil_finish_kernel(const Fp *__restrict__ 
 
 inline dim3 grid_for(uint64_t lanes, uint32_t block) { return dim3((uint32_t)((lanes + block - 1) / block)); }
 
+// SS_SCAN_LOG_CHUNK / SS_INV_LOG_CHUNK override the chunk sizes (tuning only)
+ScanShape shape_from_env() {
+    ScanShape s;
+    if (const char *e = getenv("SS_SCAN_LOG_CHUNK")) { const int v = atoi(e); if (v >= (int)SCAN_MIN_LOG_CHUNK && v <= 10) s.log_scan = (uint32_t)v; }
+    if (const char *e = getenv("SS_INV_LOG_CHUNK")) { const int v = atoi(e); if (v >= 1 && v <= 10) s.log_inv = (uint32_t)v; }
+    return s;
+}
+
 struct HipExec {                 // a lane body = a kernel launch on the context's stream
     hipStream_t st;
+    ScanShape shape;
     static int done() { return (int)hipGetLastError(); }
-    template <class Op> int reduce(uint64_t lanes, const Fp *data, uint64_t n, Fp *agg) {
-        hipLaunchKernelGGL(scan_reduce_kernel<Op>, grid_for(lanes, 128), dim3(128), 0, st, data, n, agg);
+    template <class Op> int reduce(uint64_t lanes, const Fp *data, uint64_t n, Fp *agg, uint32_t lc) {
+        hipLaunchKernelGGL(scan_reduce_kernel<Op>, grid_for(lanes, 128), dim3(128), 0, st, data, n, agg, lc);
         return done();
     }
-    template <class Op> int apply(uint64_t lanes, Fp *data, uint64_t n, const Fp *aggscan) {
-        hipLaunchKernelGGL(scan_apply_kernel<Op>, grid_for(lanes, 128), dim3(128), 0, st, data, n, aggscan);
+    template <class Op> int apply(uint64_t lanes, Fp *data, uint64_t n, const Fp *aggscan, uint32_t lc) {
+        hipLaunchKernelGGL(scan_apply_kernel<Op>, grid_for(lanes, 128), dim3(128), 0, st, data, n, aggscan, lc);
         return done();
     }
-    int inverse_dense(uint64_t lanes, Fp *data, uint64_t n, Fp *tmp) {
-        hipLaunchKernelGGL(inverse_dense_kernel, grid_for(lanes, 128), dim3(128), 0, st, data, n, tmp);
+    int inverse_dense(uint64_t lanes, Fp *data, uint64_t n, Fp *tmp, uint32_t lc) {
+        hipLaunchKernelGGL(inverse_dense_kernel, grid_for(lanes, 128), dim3(128), 0, st, data, n, tmp, lc);
         return done();
     }
     int perm_terms(const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z, const Fp &alpha, Fp *tn, Fp *td) {
@@ -93,13 +103,15 @@ struct HipExec {                 // a lane body = a kernel launch on the context
 
 hipError_t launch_permutation_product(hipStream_t st, const PermOperand &num, const PermOperand &den, uint64_t count,
                                       const Fp &z, const Fp &alpha, Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch) {
-    HipExec ex{st};
+    static const ScanShape shape = shape_from_env();
+    HipExec ex{st, shape};
     return (hipError_t)permutation_product(ex, num, den, count, z, alpha, out, out_stride, out_off, scratch);
 }
 
 hipError_t launch_diluted_aggregate(hipStream_t st, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z,
                                     const Fp &alpha, Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch) {
-    HipExec ex{st};
+    static const ScanShape shape = shape_from_env();
+    HipExec ex{st, shape};
     return (hipError_t)diluted_aggregate(ex, x, stride, off, count, z, alpha, out, out_stride, out_off, scratch);
 }
 

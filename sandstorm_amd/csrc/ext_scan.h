@@ -6,8 +6,11 @@
 
 namespace ss {
 
-constexpr uint32_t SCAN_LOG_CHUNK = 6;
-constexpr uint64_t SCAN_CHUNK = 1ull << SCAN_LOG_CHUNK;
+// items per lane: the scans and the inversion are chains of dependent multiplications fed by independent loads, so
+// short chunks (more lanes in flight) hide the load latency; the inversion pays one safegcd per chunk and wants
+// longer ones.  Runtime values so that ext.hip can take them from the environment when tuning.
+struct ScanShape { uint32_t log_scan = 3, log_inv = 5; };   // measured: tools/ext_bench.py, DESIGN.md
+constexpr uint32_t SCAN_MIN_LOG_CHUNK = 2;
 
 struct PermOperand {            // ss_perm_operand with device pointers typed
     const Fp *data;
@@ -36,10 +39,10 @@ struct AffineOp {                    // "then": (acc then x)(t) = x.m (acc.m t +
 
 // ---- lane bodies (c = chunk index = global lane id) -------------------------------------------
 template <class Op>
-SS_HD void scan_reduce_lane(uint64_t c, const Fp *data, uint64_t n, Fp *agg) {
-    const uint64_t i0 = c << SCAN_LOG_CHUNK;
+SS_HD void scan_reduce_lane(uint64_t c, const Fp *data, uint64_t n, Fp *agg, uint32_t lc) {
+    const uint64_t i0 = c << lc;
     if (i0 >= n) return;
-    const uint64_t i1 = i0 + SCAN_CHUNK < n ? i0 + SCAN_CHUNK : n;
+    const uint64_t i1 = i0 + (1ull << lc) < n ? i0 + (1ull << lc) : n;
     typename Op::T acc = Op::load(data, i0);
     for (uint64_t i = i0 + 1; i < i1; ++i) acc = Op::combine(acc, Op::load(data, i));
     Op::store(agg, c, acc);
@@ -47,10 +50,10 @@ SS_HD void scan_reduce_lane(uint64_t c, const Fp *data, uint64_t n, Fp *agg) {
 
 // in place: data[i] <- data[0] . data[1] ... data[i]; aggscan = inclusive scan of the chunk aggregates (null: one chunk)
 template <class Op>
-SS_HD void scan_apply_lane(uint64_t c, Fp *data, uint64_t n, const Fp *aggscan) {
-    const uint64_t i0 = c << SCAN_LOG_CHUNK;
+SS_HD void scan_apply_lane(uint64_t c, Fp *data, uint64_t n, const Fp *aggscan, uint32_t lc) {
+    const uint64_t i0 = c << lc;
     if (i0 >= n) return;
-    const uint64_t i1 = i0 + SCAN_CHUNK < n ? i0 + SCAN_CHUNK : n;
+    const uint64_t i1 = i0 + (1ull << lc) < n ? i0 + (1ull << lc) : n;
     typename Op::T acc = (c && aggscan) ? Op::load(aggscan, c - 1) : Op::identity();
     for (uint64_t i = i0; i < i1; ++i) {
         acc = Op::combine(acc, Op::load(data, i));
@@ -60,10 +63,10 @@ SS_HD void scan_apply_lane(uint64_t c, Fp *data, uint64_t n, const Fp *aggscan) 
 
 // zero-preserving element-wise inversion (ark-ff batch_inversion semantics); tmp: n felts.
 // Prefix products of the non-zero entries of the chunk, one inversion, back-substitution.
-SS_HD void inverse_dense_lane(uint64_t c, Fp *data, uint64_t n, Fp *tmp) {
-    const uint64_t i0 = c << SCAN_LOG_CHUNK;
+SS_HD void inverse_dense_lane(uint64_t c, Fp *data, uint64_t n, Fp *tmp, uint32_t lc) {
+    const uint64_t i0 = c << lc;
     if (i0 >= n) return;
-    const uint64_t i1 = i0 + SCAN_CHUNK < n ? i0 + SCAN_CHUNK : n;
+    const uint64_t i1 = i0 + (1ull << lc) < n ? i0 + (1ull << lc) : n;
     Fp run = fp_one();
     for (uint64_t i = i0; i < i1; ++i) {
         const Fp v = data[i];
@@ -116,19 +119,21 @@ SS_HD void dil_finish_lane(uint64_t k, const Fp *mc, uint64_t count, Fp *out, ui
     out[k * out_stride + out_off] = mc[2 * k + 1];                           // the map is constant: its value is c
 }
 
-inline uint64_t scan_chunks(uint64_t n) { return (n + SCAN_CHUNK - 1) >> SCAN_LOG_CHUNK; }
-inline uint64_t scan_agg_felts(uint64_t count, uint32_t felts) { return felts * (count / (SCAN_CHUNK - 1) + 64); }
+inline uint64_t scan_chunks(uint64_t n, uint32_t lc) { return (n + (1ull << lc) - 1) >> lc; }
+// aggregates of every level, for any chunk size >= 2^SCAN_MIN_LOG_CHUNK: sum_l ceil(n / 4^l) < n/3 + (levels <= 32)
+inline uint64_t scan_agg_felts(uint64_t count, uint32_t felts) { return felts * (count / ((1ull << SCAN_MIN_LOG_CHUNK) - 1) + 64); }
 
 // ---- level driver; Exec runs a lane body for lanes 0 .. nlanes-1 (a kernel launch, or a host loop) ----
 // tmp: room for the aggregates of every level: scan_agg_felts(n, Op::FELTS) felts.  Returns Exec's status (0 = ok).
 template <class Op, class Exec>
 int scan_inclusive(Exec &ex, Fp *data, uint64_t n, Fp *tmp) {
-    if (n <= SCAN_CHUNK) return ex.template apply<Op>(1, data, n, (const Fp *)nullptr);
-    const uint64_t m = scan_chunks(n);
-    int e = ex.template reduce<Op>(m, (const Fp *)data, n, tmp);
+    const uint32_t lc = ex.shape.log_scan;
+    if (n <= (1ull << lc)) return ex.template apply<Op>(1, data, n, (const Fp *)nullptr, lc);
+    const uint64_t m = scan_chunks(n, lc);
+    int e = ex.template reduce<Op>(m, (const Fp *)data, n, tmp, lc);
     if (e) return e;
     if ((e = scan_inclusive<Op>(ex, tmp, m, tmp + Op::FELTS * m))) return e;
-    return ex.template apply<Op>(m, data, n, (const Fp *)tmp);
+    return ex.template apply<Op>(m, data, n, (const Fp *)tmp, lc);
 }
 
 inline uint64_t permutation_product_scratch_felts(uint64_t count) { return 3 * count + scan_agg_felts(count, 1); }
@@ -144,7 +149,7 @@ int permutation_product(Exec &ex, const PermOperand &num, const PermOperand &den
     if (e) return e;
     if ((e = scan_inclusive<MulOp>(ex, tn, count, aggs))) return e;          // numerator_acc
     if ((e = scan_inclusive<MulOp>(ex, td, count, aggs))) return e;          // denominator_acc
-    if ((e = ex.inverse_dense(scan_chunks(count), td, count, tmp))) return e;     // batch_inversion
+    if ((e = ex.inverse_dense(scan_chunks(count, ex.shape.log_inv), td, count, tmp, ex.shape.log_inv))) return e;     // batch_inversion
     return ex.perm_finish((const Fp *)tn, (const Fp *)td, count, out, out_stride, out_off);
 }
 template <class Exec>

@@ -5,6 +5,7 @@
 #include <stdexcept>
 #include <string>
 
+#include "extension.hpp"
 #include "prover.hpp"
 
 using namespace ssh;
@@ -93,6 +94,26 @@ int ssh_prove_wire(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friend
                       proof_bytes, proof_len);
 }
 void ssh_free(void *p) { free(p); }
+
+// Trace::build_extension_columns (extension.hpp).  layout: 1 = recursive, 2 = starknet (the ssh_air_create kinds);
+// d_aux = {npc, memory, range_check [, diluted_unordered, diluted_ordered]}; challenges = 6 felts.  The result is a
+// matrix handle owning its device columns (3 for recursive, 1 for starknet).
+typedef struct ssh_matrix ssh_matrix;
+int ssh_build_extension_columns(ss_ctx *ctx, int layout, const uint64_t *const *d_aux, uint64_t trace_len,
+                                const uint64_t *challenges, int check, ssh_matrix **out) {
+    try {
+        TraceColumns c;
+        c.npc = d_aux[0]; c.memory = d_aux[1]; c.range_check = d_aux[2]; c.trace_len = trace_len;
+        if (layout == 1) { c.diluted_unordered = d_aux[3]; c.diluted_ordered = d_aux[4]; }
+        std::vector<Felt> ch(6);
+        for (int i = 0; i < 6; ++i) memcpy(ch[i].data(), challenges + 4 * i, 32);
+        *out = reinterpret_cast<ssh_matrix *>(new Matrix(build_extension_columns(ctx, layout == 1 ? "recursive" : "starknet", c, ch, check != 0)));
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+uint32_t ssh_matrix_num_cols(const ssh_matrix *m) { return reinterpret_cast<const Matrix *>(m)->num_cols(); }
+uint64_t *ssh_matrix_col(const ssh_matrix *m, uint32_t k) { return reinterpret_cast<const Matrix *>(m)->cols[k]; }
+void ssh_matrix_destroy(ssh_matrix *m) { delete reinterpret_cast<Matrix *>(m); }
 
 // ---- the C++ coin, exposed for the CPU tests (tests/test_host_cpp.py)
 typedef struct ssh_coin ssh_coin;

@@ -35,6 +35,13 @@ def load():
                                 C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
         h.ssh_prove_wire.argtypes = h.ssh_prove.argtypes
         h.ssh_free.argtypes = [C.c_void_p]
+        h.ssh_build_extension_columns.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_uint64, C.POINTER(C.c_uint64),
+                                                  C.c_int, C.POINTER(C.c_void_p)]
+        h.ssh_matrix_num_cols.argtypes = [C.c_void_p]
+        h.ssh_matrix_num_cols.restype = C.c_uint32
+        h.ssh_matrix_col.argtypes = [C.c_void_p, C.c_uint32]
+        h.ssh_matrix_col.restype = C.c_void_p
+        h.ssh_matrix_destroy.argtypes = [C.c_void_p]
         h.ssh_coin_new.restype = C.c_void_p
         h.ssh_coin_new.argtypes = [C.c_int, C.c_char_p]
         h.ssh_coin_free.argtypes = [C.c_void_p]
@@ -164,6 +171,40 @@ def prove(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, base_cols, 
     if wire:
         return raw
     return parse_proof(raw, options, air.num_base_columns, air.num_extension_columns)
+
+
+class HostMatrix:
+    """a device matrix owned by the C++ host (ssh_matrix)"""
+
+    def __init__(self, ctx, handle, nrows):
+        self.ctx, self.h, self.nrows = ctx, handle, nrows
+        self.cols = [load().ssh_matrix_col(handle, k) for k in range(load().ssh_matrix_num_cols(handle))]
+
+    def to_host(self):
+        out = []
+        for ptr in self.cols:
+            a = np.empty((self.nrows, 4), dtype=np.uint64)
+            be.check(self.ctx.lib.ss_download(self.ctx.handle, a.ctypes.data, ptr, a.nbytes))
+            out.append(a)
+        return out
+
+    def close(self):
+        if self.h:
+            load().ssh_matrix_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def build_extension_columns(ctx, layout, aux_cols, trace_len, challenges, check=True):
+    """the C++ host's Trace::build_extension_columns (sandstorm_amd/host/extension.cpp).
+    aux_cols: [npc, memory, range_check] (+ [diluted_unordered, diluted_ordered] for "recursive")."""
+    ch = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint64) for c in challenges[:6]]))
+    h = C.c_void_p()
+    _check(load().ssh_build_extension_columns(ctx.handle, 1 if layout == "recursive" else 2, be._ptr_array(aux_cols), trace_len,
+                                              ch.ctypes.data_as(C.POINTER(C.c_uint64)), 1 if check else 0, C.byref(h)))
+    return HostMatrix(ctx, h, trace_len)
 
 
 class HostCoin:

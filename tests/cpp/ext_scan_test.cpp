@@ -26,16 +26,17 @@ static Fp random_fp() {
 }
 
 struct LoopExec {                               // a "launch" = the lane body for every lane, in any order (here: descending)
-    template <class Op> int reduce(uint64_t lanes, const Fp *data, uint64_t n, Fp *agg) {
-        for (uint64_t c = lanes + 3; c-- > 0;) scan_reduce_lane<Op>(c, data, n, agg);
+    ScanShape shape;
+    template <class Op> int reduce(uint64_t lanes, const Fp *data, uint64_t n, Fp *agg, uint32_t lc) {
+        for (uint64_t c = lanes + 3; c-- > 0;) scan_reduce_lane<Op>(c, data, n, agg, lc);
         return 0;
     }
-    template <class Op> int apply(uint64_t lanes, Fp *data, uint64_t n, const Fp *aggscan) {
-        for (uint64_t c = lanes + 3; c-- > 0;) scan_apply_lane<Op>(c, data, n, aggscan);
+    template <class Op> int apply(uint64_t lanes, Fp *data, uint64_t n, const Fp *aggscan, uint32_t lc) {
+        for (uint64_t c = lanes + 3; c-- > 0;) scan_apply_lane<Op>(c, data, n, aggscan, lc);
         return 0;
     }
-    int inverse_dense(uint64_t lanes, Fp *data, uint64_t n, Fp *tmp) {
-        for (uint64_t c = lanes + 3; c-- > 0;) inverse_dense_lane(c, data, n, tmp);
+    int inverse_dense(uint64_t lanes, Fp *data, uint64_t n, Fp *tmp, uint32_t lc) {
+        for (uint64_t c = lanes + 3; c-- > 0;) inverse_dense_lane(c, data, n, tmp, lc);
         return 0;
     }
     int perm_terms(const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z, const Fp &alpha, Fp *tn, Fp *td) {
@@ -63,10 +64,13 @@ static Fp term(const Fp *col, uint64_t stride, uint64_t a, int64_t v, uint64_t k
 }
 
 int main() {
-    const uint64_t counts[] = {1, 2, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097, 20000};
+    const uint64_t counts[] = {1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 20000};
     int cases = 0;
-    LoopExec ex;
+    const ScanShape shapes[] = {ScanShape{}, ScanShape{2, 1}, ScanShape{6, 6}, ScanShape{3, 7}};
+    for (const ScanShape &shape : shapes)
     for (uint64_t count : counts) {
+        LoopExec ex{shape};
+        if (&shape != &shapes[0] && count > 5000) continue;
         for (int variant = 0; variant < 3; ++variant) {
             // variant 0: (address, value) terms, stride 2, out stride 2 offset 0
             // variant 1: single-value terms out of one column at offsets 0 / 2 of stride 4, out stride 4 offset 1

@@ -101,6 +101,28 @@ def test_build_extension_columns_matches_oracle(ctx, oracle, layout):
     assert ext.build_extension_columns(layout, ctx, cols_bad, ch, check=False).nrows == n
 
 
+@pytest.mark.parametrize("layout", ["recursive", "starknet"])
+def test_cpp_host_build_extension_columns(ctx, oracle, layout):
+    """the C++ host's Trace::build_extension_columns (sandstorm_amd/host/extension.cpp) against the oracle"""
+    from sandstorm_amd import hostlib
+    from sandstorm_amd._lib import SandstormHipError
+    n = 1 << 11
+    host = permuted_trace(oracle, layout, n, seed=9)
+    ch = challenges(oracle)
+    want, _ = oracle.build_extension_columns(layout, host, ch, n)
+    names = ["npc", "memory", "range_check"] + (["diluted_unordered", "diluted_ordered"] if layout == "recursive" else [])
+    dev = [ctx.column(host[k]) for k in names]
+    m = hostlib.build_extension_columns(ctx, layout, dev, n, ch)
+    got = m.to_host()
+    m.close()
+    assert len(got) == len(want) and all(np.array_equal(g, w) for g, w in zip(got, want))
+    rc = host["range_check"].copy()
+    rc[2] = oracle.to_mont([4242])[0]
+    dev[2] = ctx.column(rc)
+    with pytest.raises(SandstormHipError, match="range-check permutation product"):
+        hostlib.build_extension_columns(ctx, layout, dev, n, ch)
+
+
 def test_extension_scans_at_full_size(ctx, oracle):
     """2^22 items (a 2^23-row memory column, the starknet 2^19-step shape): a true permutation closes to one, and
     sampled neighbours satisfy out_{i+1} * den_{i+1} = out_i * num_{i+1} (big integers)."""
