@@ -1,0 +1,70 @@
+"""gpurun_out/final/ (tools/final_round.sh) -> profiles/r01_final_*: bench JSON lines, kernel-trace summaries,
+kernel stats, and the HBM-traffic tables + hbm_traffic_<workload>.json that bench.py reports as roofline.traffic.
+Usage: python tools/collect_final.py [round tag, default r01_final]"""
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "final")
+DST = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+
+
+def parse_pmc(path, counter):
+    """tools/pmc_summary.py output -> {kernel: (dispatches, sum)}"""
+    out, cur = {}, None
+    for line in open(path):
+        m = re.match(r"^(\S.*?)\s+disp=(\d+)\s*$", line)
+        if m:
+            cur = (m.group(1), int(m.group(2)))
+            continue
+        m = re.match(r"^\s+%s\s+mean\s+(\S+)\s+sum\s+(\S+)" % counter, line)
+        if m and cur:
+            out[cur[0]] = (cur[1], float(m.group(2)))
+    return out
+
+
+for name in sorted(os.listdir(SRC)):
+    if name.startswith("bench_") and name.endswith(".json"):
+        shutil.copy(os.path.join(SRC, name), os.path.join(DST, "%s_%s" % (TAG, name)))
+if os.path.exists(os.path.join(SRC, "pytest_gpu.txt")):
+    shutil.copy(os.path.join(SRC, "pytest_gpu.txt"), os.path.join(DST, "%s_pytest_gpu.txt" % TAG))
+
+for d in sorted(os.listdir(SRC)):
+    if not d.startswith("prof_"):
+        continue
+    w = d[len("prof_"):]
+    p = os.path.join(SRC, d)
+    for src, dst in (("kernel_trace_summary.txt", "%s_kernel_trace_summary_%s.txt"), ("kernel_stats.csv", "%s_kernel_stats_%s.csv")):
+        if os.path.exists(os.path.join(p, src)):
+            shutil.copy(os.path.join(p, src), os.path.join(DST, dst % (TAG, w)))
+    fpath, wpath = os.path.join(p, "pmc_fetch.txt"), os.path.join(p, "pmc_write.txt")
+    if not (os.path.exists(fpath) and os.path.exists(wpath)):
+        continue
+    fetch, write = parse_pmc(fpath, "FETCH_SIZE"), parse_pmc(wpath, "WRITE_SIZE")
+    rows = []
+    for k in set(fetch) | set(write):
+        disp = (fetch.get(k) or write.get(k))[0]
+        rd = 2.0 * fetch.get(k, (0, 0.0))[1] * 1024        # MI355X_MICROARCH.md: FETCH_SIZE in KB, x2 on gfx950 for wide coalesced reads
+        wr = write.get(k, (0, 0.0))[1] * 1024
+        rows.append((k, disp, rd, wr))
+    rows.sort(key=lambda r: -(r[2] + r[3]))
+    txt = os.path.join(DST, "%s_hbm_traffic_%s.txt" % (TAG, w))
+    with open(txt, "w") as f:
+        f.write("# HBM-side traffic per kernel, %s bench, 2 proofs per run (python bench.py --workload %s --steps 1 --warmup 0 --no-cpu-baseline)\n" % (w, w))
+        f.write("# separate passes: rocprofv3 --pmc FETCH_SIZE ... ; rocprofv3 --pmc WRITE_SIZE ...  (tools/profile_round.sh)\n")
+        f.write("# bytes: read = 2 * FETCH_SIZE[KB] * 1024 (MI355X_MICROARCH.md gfx950 correction for wide coalesced reads), write = WRITE_SIZE[KB] * 1024 (uncalibrated);\n")
+        f.write("# Infinity-Cache hits are counted (the guide), so re-reads served by the 256 MiB cache show up here\n")
+        f.write("%-64s %5s %14s %14s %16s\n" % ("kernel", "disp", "read_GB", "write_GB", "GB_per_dispatch"))
+        for k, disp, rd, wr in rows:
+            f.write("%-64s %5d %14.3f %14.3f %16.4f\n" % (k[:60], disp, rd / 1e9, wr / 1e9, (rd + wr) / 1e9 / max(1, disp)))
+    ntt = [r for r in rows if "ntt_pass_kernel" in r[0]]
+    disp = sum(r[1] for r in ntt)
+    total = sum(r[2] + r[3] for r in ntt)
+    with open(os.path.join(DST, "hbm_traffic_%s.json" % w), "w") as f:
+        json.dump({"workload": w, "kernel": "ss::ntt_pass_kernel", "dispatches": disp, "bytes_per_launch": total / max(1, disp),
+                   "bytes_per_proof": total / 2, "source": "profiles/%s_hbm_traffic_%s.txt" % (TAG, w)}, f, indent=1)
+    print(w, "ntt dispatches", disp, "GB/launch %.3f" % (total / max(1, disp) / 1e9))
