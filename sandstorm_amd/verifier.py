@@ -1,0 +1,234 @@
+"""Host-side verifier of proofs in the reference's wire format ("verify what we proved").
+
+ministark's `Stark::verify` is un-vendored; this follows the prover's own transcript (prover.py, step for step) and
+the conventions the reference's shipped proofs pin (`prover.Conventions`: bit-reversed commitment order, unnormalised
+fold-8, unshifted remainder — tests/golden/make_fri_golden.py, make_proof_golden.py).  Everything here is host
+arithmetic on a few hundred field elements: Python integers, the host hashes of coin.py, no device.
+
+Checked, in the verifier's order:
+  1. transcript replay (challenges, composition coefficient, z, DEEP alpha, FRI alphas, proof of work, query positions)
+  2. out-of-domain identity: composition constraint at z from the trace OOD values == sum_k z^k H_k(z^m)
+  3. Merkle openings of the base / extension / composition rows at the query positions
+  4. DEEP value recomputed from the opened rows == the first FRI layer's entry at that position
+  5. every FRI layer folds into the next at alpha_i, openings included; the last into the remainder polynomial
+Keccak trees only (the wire format of `FriendlyMerkleTree` proofs has no reference sample: wire.py).
+"""
+from dataclasses import dataclass
+from typing import Callable, List
+
+from . import air_program as ap
+from . import backend as be
+from . import wire
+from .coin import PublicCoin, blake2s256, keccak256
+from .prover import Conventions, bitrev
+
+P = be.P
+
+
+class VerificationError(Exception):
+    pass
+
+
+@dataclass
+class VerifierAir:
+    """What the verifier needs from an AirConfig (src/lib.rs:75-125)."""
+    num_base_columns: int
+    num_extension_columns: int
+    num_challenges: int
+    mask: List[tuple]                   # trace_arguments(): sorted (column, row offset) cells, the order of the OOD vector
+    # (trace_len, challenges: list of int, composition_coeff: int) -> air_program.Expr of the composition constraint
+    composition: Callable = None
+    # (trace_len, x: int, table index) -> value at x of the periodic / zerofier table that Expr refers to
+    table_at: Callable = None
+
+
+def _require(cond, what):
+    if not cond:
+        raise VerificationError(what)
+
+
+def _root_of_unity(n):
+    return pow(3, (P - 1) // n, P)
+
+
+def _mont_be(v):
+    return (v * wire._R % P).to_bytes(32, "big")
+
+
+def _verify_pow(coin_kind, digest, bits, nonce):
+    """PublicCoin::verify_proof_of_work (crypto/src/public_coin/solidity.rs:143-156, cairo.rs:156-169)"""
+    h = keccak256 if coin_kind == be.COIN_SOLIDITY else blake2s256
+    prefix = h((0x0123456789ABCDED).to_bytes(8, "big") + digest + bytes([bits]))
+    out = h(prefix + int(nonce).to_bytes(8, "big"))
+    return int.from_bytes(out, "big") >> (256 - bits) == 0 if bits else True
+
+
+class _KeccakTree:
+    """LeafVariantMerkleTree<Keccak256HashFn | MaskedKeccak256HashFn<20>> (crypto/src/merkle/mod.rs:240-304)"""
+
+    def __init__(self, tree_kind):
+        _require(tree_kind in (be.TREE_KECCAK, be.TREE_KECCAK_M20), "the wire format covers the Keccak trees only")
+        self.masked = tree_kind == be.TREE_KECCAK_M20
+
+    def h(self, data):
+        d = keccak256(data)
+        return d[:20] + bytes(12) if self.masked else d
+
+    def row_leaf(self, row):
+        return self.h(b"".join(_mont_be(v) for v in row))
+
+    def climb(self, node, path, pos):
+        for lvl, sib in enumerate(path):
+            node = self.h(node + sib) if ((pos >> lvl) & 1) == 0 else self.h(sib + node)
+        return node
+
+    def check_opening(self, opening, row, pos, depth, root, what):
+        """row: the opened row (canonical ints); pos: leaf index; depth = log2(number of leaves)"""
+        if len(row) == 1:                                   # single column: raw-element leaves (merkle/mod.rs:113-117)
+            _require(opening.variant == 1 and opening.leaf == row[0], what + ": leaf is not the opened element")
+            _require(len(opening.path) == depth - 1, what + ": path length")
+            pair = (opening.leaf, opening.sibling) if (pos & 1) == 0 else (opening.sibling, opening.leaf)
+            node = self.h(_mont_be(pair[0]) + _mont_be(pair[1]))
+            _require(self.climb(node, opening.path, pos >> 1) == root, what + ": authentication path does not reach the root")
+        else:
+            _require(opening.variant == 0 and opening.leaf == self.row_leaf(row), what + ": leaf is not the hash of the opened row")
+            _require(len(opening.path) == depth - 1, what + ": path length")
+            _require(self.climb(opening.leaf, [opening.sibling] + list(opening.path), pos) == root,
+                     what + ": authentication path does not reach the root")
+
+
+def _interpolate_eval(xs, ys, t):
+    acc = 0
+    for i, (xi, yi) in enumerate(zip(xs, ys)):
+        num = den = 1
+        for j, xj in enumerate(xs):
+            if i != j:
+                num = num * (t - xj) % P
+                den = den * (xi - xj) % P
+        acc = (acc + yi * num * pow(den, -1, P)) % P
+    return acc
+
+
+def verify(proof, air: VerifierAir, tree_kind, coin_kind, coin_seed: bytes, conv: Conventions = None):
+    """proof: bytes in the reference's wire format, or a wire.WireProof.  Raises VerificationError; returns the
+    query positions on success."""
+    conv = conv or Conventions()
+    try:
+        w = wire.parse(bytes(proof)) if isinstance(proof, (bytes, bytearray, memoryview)) else proof
+    except ValueError as e:
+        raise VerificationError("malformed proof: %s" % e)
+    num_queries, blowup, grinding, fold, max_remainder = w.options
+    n = w.trace_len
+    _require(n >= 2 and n & (n - 1) == 0 and blowup >= 2 and blowup & (blowup - 1) == 0, "bad trace length / blowup")
+    _require(fold in (2, 4, 8, 16), "bad FRI folding factor")
+    N = n * blowup
+    log_N, log_fold = N.bit_length() - 1, fold.bit_length() - 1
+    ncomp = conv.composition_columns
+    nmask = len(air.mask)
+    tree = _KeccakTree(tree_kind)
+    expo = (lambda i, bits: bitrev(i, bits)) if conv.bitrev_commit else (lambda i, bits: i)
+
+    # ---- 1. transcript (prover.py steps 2-9)
+    _require(len(w.ood_trace) == nmask and len(w.ood_composition) == ncomp, "out-of-domain vector lengths")
+    _require((w.extension_root is not None) == (air.num_extension_columns > 0), "extension root presence")
+    coin = PublicCoin(coin_kind, coin_seed)
+    coin.reseed_with_digest(w.base_root)
+    challenges = [coin.draw() for _ in range(air.num_challenges)]
+    if w.extension_root is not None:
+        coin.reseed_with_digest(w.extension_root)
+    comp_coeff = coin.draw()
+    coin.reseed_with_digest(w.composition_root)
+    z_l = coin.draw()
+    coin.reseed_with_field_elements([be.felt(v) for v in list(w.ood_trace) + list(w.ood_composition)])
+    deep_alpha = wire._canon(coin.draw())
+    # expected number of layers: fold until the remainder fits (prover.py step 8)
+    degree_bound, nlayers = n, 0
+    while degree_bound > max_remainder:
+        degree_bound //= fold
+        nlayers += 1
+    _require(len(w.fri_layers) == nlayers, "number of FRI layers")
+    _require(len(w.remainder) == max(1, degree_bound), "remainder length")
+    fri_alphas = []
+    for layer in w.fri_layers:
+        coin.reseed_with_digest(layer.root)
+        fri_alphas.append(wire._canon(coin.draw()))
+    coin.reseed_with_field_element_vector([be.felt(v) for v in w.remainder])
+    _require(_verify_pow(coin_kind, coin.digest, grinding, w.pow_nonce), "proof of work")
+    coin.reseed_with_int(w.pow_nonce)
+    positions = coin.draw_queries(num_queries, N)
+    nq = len(positions)
+    z = wire._canon(z_l)
+    ch = [wire._canon(c) for c in challenges]
+
+    # ---- 2. out-of-domain identity: sum_k alpha^k C_k(z) == sum_k z^k H_k(z^ncomp)
+    cell = {m: v for m, v in zip(air.mask, w.ood_trace)}
+    dag = air.composition(n, ch, wire._canon(comp_coeff))
+    lhs = ap.evaluate(dag, P, z, lambda c, o: cell[(c, o)], lambda t: air.table_at(n, z, t))
+    rhs = sum(pow(z, k, P) * h for k, h in enumerate(w.ood_composition)) % P
+    _require(lhs == rhs, "out-of-domain identity: the composition constraint does not match the composition columns at z")
+
+    # ---- 3./4. trace openings and the DEEP value at every query
+    ncb, nce = air.num_base_columns, air.num_extension_columns
+    _require(len(w.base_rows) == nq * ncb and len(w.base_openings) == nq, "base rows / openings count")
+    _require(len(w.extension_rows) == nq * nce and len(w.extension_openings) == (nq if nce else 0), "extension rows / openings count")
+    _require(len(w.composition_rows) == nq * ncomp and len(w.composition_openings) == nq, "composition rows / openings count")
+    wN, wn = _root_of_unity(N), _root_of_unity(n)
+    coef = [pow(deep_alpha, j, P) for j in range(nmask + ncomp)]
+    zc = pow(z, ncomp, P)
+    layer_positions = []
+    p = list(positions)
+    for li, layer in enumerate(w.fri_layers):
+        row_bits = log_N - log_fold * (li + 1)
+        rows = 1 << row_bits
+        p = sorted(set((q >> log_fold) if conv.bitrev_commit else (q % rows) for q in p))
+        layer_positions.append(p)
+        _require(len(layer.openings) == len(p) and len(layer.rows) == fold * len(p), "FRI layer %d rows / openings count" % li)
+    for qi, q in enumerate(positions):
+        x = conv.lde_offset * pow(wN, expo(q, log_N), P) % P
+        brow = w.base_rows[ncb * qi: ncb * qi + ncb]
+        erow = w.extension_rows[nce * qi: nce * qi + nce]
+        crow = w.composition_rows[ncomp * qi: ncomp * qi + ncomp]
+        tree.check_opening(w.base_openings[qi], brow, q, log_N, w.base_root, "base trace, query %d" % qi)
+        if nce:
+            tree.check_opening(w.extension_openings[qi], erow, q, log_N, w.extension_root, "extension trace, query %d" % qi)
+        tree.check_opening(w.composition_openings[qi], crow, q, log_N, w.composition_root, "composition trace, query %d" % qi)
+        if not w.fri_layers:
+            continue
+        trow = list(brow) + list(erow)
+        deep = 0
+        for j, (c, o) in enumerate(air.mask):               # src/lib.rs:102-116: coefficients alpha^j over mask cells, then columns
+            deep += coef[j] * (trow[c] - w.ood_trace[j]) * pow(x - z * pow(wn, o, P), -1, P)
+        for k in range(ncomp):
+            deep += coef[nmask + k] * (crow[k] - w.ood_composition[k]) * pow(x - zc, -1, P)
+        rows0 = N // fold
+        r, slot = (q >> log_fold, q & (fold - 1)) if conv.bitrev_commit else (q % rows0, q // rows0)
+        li0 = layer_positions[0].index(r)
+        _require(w.fri_layers[0].rows[fold * li0 + slot] == deep % P, "DEEP composition value at query %d" % qi)
+
+    # ---- 5. FRI: every opened row folds into the next layer (or the remainder)
+    offset = conv.lde_offset % P
+    for li, layer in enumerate(w.fri_layers):
+        row_bits = log_N - log_fold * (li + 1)
+        L, rows = 1 << (row_bits + log_fold), 1 << row_bits
+        wl, wf = _root_of_unity(L), _root_of_unity(fold)
+        for pi, r in enumerate(layer_positions[li]):
+            ys = layer.rows[fold * pi: fold * pi + fold]
+            tree.check_opening(layer.openings[pi], ys, r, row_bits, layer.root, "FRI layer %d, row %d" % (li, r))
+            xr0 = offset * pow(wl, expo(r, row_bits), P) % P
+            xs = [xr0 * pow(wf, expo(k, log_fold), P) % P for k in range(fold)]
+            folded = _interpolate_eval(xs, ys, fri_alphas[li])
+            if conv.fri_unnormalised:
+                folded = folded * fold % P
+            if li + 1 < len(w.fri_layers):
+                nrows = rows >> log_fold
+                nr, slot = (r >> log_fold, r & (fold - 1)) if conv.bitrev_commit else (r % nrows, r // nrows)
+                ni = layer_positions[li + 1].index(nr)
+                _require(w.fri_layers[li + 1].rows[fold * ni + slot] == folded, "FRI layer %d does not fold into layer %d at row %d" % (li, li + 1, r))
+            else:
+                xr = pow(_root_of_unity(rows), expo(r, row_bits), P)
+                if not conv.remainder_unshifted:
+                    xr = xr * pow(offset, fold, P) % P
+                _require(sum(c * pow(xr, i, P) for i, c in enumerate(w.remainder)) % P == folded,
+                         "last FRI layer does not fold into the remainder at row %d" % r)
+        offset = pow(offset, fold, P)
+    return positions

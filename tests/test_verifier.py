@@ -1,0 +1,110 @@
+"""The host verifier (sandstorm_amd/verifier.py) on proofs in the reference's wire format.
+
+CPU: the committed proofs tests/golden/mini_proof_eth_log{5,9}.bin (made on an MI355X by tests/golden/
+make_mini_proof.py) verify, and do not after any single-section tampering.  GPU: a fresh proof from the C++ host."""
+import json
+import os
+
+import pytest
+
+from tests import mini_air
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def mini_verifier_air():
+    from sandstorm_amd.verifier import VerifierAir
+    return VerifierAir(2, 1, 1, mini_air.MASK,
+                       composition=lambda n, ch, a: mini_air.composition(n, ch[0], a),
+                       table_at=lambda n, x, t: mini_air.table_at(n, x))
+
+
+def load_fixture(log_n):
+    with open(os.path.join(GOLD, "mini_proof_meta.json")) as f:
+        meta = json.load(f)
+    with open(os.path.join(GOLD, "mini_proof_eth_log%d.bin" % log_n), "rb") as f:
+        return f.read(), bytes.fromhex(meta["seed_hex"]), meta
+
+
+@pytest.mark.parametrize("log_n", [5, 9])
+def test_committed_proof_verifies(log_n):
+    from sandstorm_amd import backend as be, verifier, wire
+    raw, seed, meta = load_fixture(log_n)
+    positions = verifier.verify(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+    w = wire.parse(raw)
+    assert w.options == meta["options"] and w.trace_len == 1 << log_n
+    assert len(positions) == len(w.base_openings) and positions == sorted(set(positions))
+    assert wire.serialize(w) == raw
+
+
+def test_tampered_proofs_are_rejected():
+    from sandstorm_amd import backend as be, verifier, wire
+    raw, seed, _ = load_fixture(5)
+    air = mini_verifier_air()
+
+    def rejected(mutate, match=None):
+        w = wire.parse(raw)
+        mutate(w)
+        with pytest.raises(verifier.VerificationError, match=match):
+            verifier.verify(w, air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+
+    def bump(lst, i):
+        lst[i] = (lst[i] + 1) % verifier.P
+
+    rejected(lambda w: setattr(w, "pow_nonce", w.pow_nonce + 1))                        # proof of work / positions
+    rejected(lambda w: bump(w.ood_trace, 2))                                            # transcript diverges
+    rejected(lambda w: bump(w.ood_composition, 1))
+    rejected(lambda w: bump(w.remainder, 0))
+    rejected(lambda w: setattr(w, "base_root", bytes(32)))
+    # data below the transcript: the replay still succeeds, the data checks must catch it
+    rejected(lambda w: bump(w.base_rows, 0), match="base trace")
+    rejected(lambda w: bump(w.extension_rows, 0), match="extension trace")
+    rejected(lambda w: bump(w.composition_rows, 1), match="composition trace")
+    rejected(lambda w: bump(w.fri_layers[0].rows, 3), match="FRI layer 0")
+
+    def swap_path(w):
+        o = w.composition_openings[0]
+        o.path[0] = bytes(32)
+    rejected(swap_path, match="authentication path")
+    with pytest.raises(verifier.VerificationError):
+        verifier.verify(raw, air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, bytes(32))     # wrong public-coin seed
+    with pytest.raises(verifier.VerificationError, match="malformed"):
+        verifier.verify(raw[:-5], air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+    with pytest.raises(verifier.VerificationError):
+        verifier.verify(raw, air, be.TREE_KECCAK, be.COIN_SOLIDITY, seed)              # unmasked tree: other hashes
+
+
+def test_older_conventions_are_a_different_statement():
+    """the same bytes do not verify under the older proof's conventions (natural order, normalised fold)"""
+    from sandstorm_amd import backend as be, verifier
+    from sandstorm_amd.prover import Conventions
+    raw, seed, _ = load_fixture(5)
+    with pytest.raises(verifier.VerificationError):
+        verifier.verify(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed,
+                        Conventions(bitrev_commit=False, fri_unnormalised=False, remainder_unshifted=False))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [6, 10])
+def test_fresh_cpp_host_proof_verifies(oracle, log_n):
+    from sandstorm_amd import backend as be, hostlib, verifier
+    from sandstorm_amd.coin import canonical
+    from sandstorm_amd.prover import ProofOptions
+    ctx = be.Context(0)
+    n = 1 << log_n
+    c0, c1 = mini_air.base_trace(n)
+    base = be.Matrix.from_host(ctx, [oracle.to_mont(c0), oracle.to_mont(c1)])
+    keep = []
+
+    def build_extension(challenges):
+        m = be.Matrix.from_host(ctx, [oracle.to_mont(mini_air.extension_trace(c0, canonical(challenges[0])))])
+        keep.append(m)
+        return m.cols
+    opt = ProofOptions(num_queries=20, grinding_factor=10, fri_max_remainder_coeffs=8)
+    seed = bytes(reversed(range(32)))
+    air = hostlib.HostAir(ctx, hostlib.AIR_MINI, log_n)
+    raw = hostlib.prove(ctx, air, be.TREE_KECCAK_M20, 0, be.COIN_SOLIDITY, seed, base.cols, log_n, build_extension, opt, wire=True)
+    air.close()
+    assert len(verifier.verify(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)) <= 20
+    ctx.close()
