@@ -90,6 +90,7 @@ Felt felt_mul(const Felt &a, const Felt &b) {
 }
 static const Felt R2 = {0xfffffd737e000401ull, 0x00000001330fffffull, 0xffffffffff6f8000ull, 0x07ffd4ab5e008810ull};
 Felt felt_from_u64(uint64_t v) { return felt_mul(Felt{v, 0, 0, 0}, R2); }
+Felt felt_from_canonical(const Felt &value) { return felt_mul(value, R2); }
 Felt felt_pow(const Felt &a, uint64_t e) {
     Felt r = felt_from_u64(1), b = a;
     while (e) { if (e & 1) r = felt_mul(r, b); b = felt_mul(b, b); e >>= 1; }

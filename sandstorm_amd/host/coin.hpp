@@ -18,6 +18,7 @@ Digest keccak256(const uint8_t *msg, size_t len);
 Digest blake2s256(const uint8_t *msg, size_t len);
 std::array<uint8_t, 32> mont_be_bytes(const Felt &f);     // to_montgomery(e).to_be_bytes::<32>()
 Felt felt_from_u64(uint64_t v);
+Felt felt_from_canonical(const Felt &value);              // little-endian limbs of an integer < p -> Montgomery
 Felt felt_mul(const Felt &a, const Felt &b);
 Felt felt_pow(const Felt &a, uint64_t e);
 std::array<uint8_t, 32> canonical_be_bytes(const Felt &f);

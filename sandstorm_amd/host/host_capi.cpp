@@ -7,6 +7,7 @@
 
 #include "extension.hpp"
 #include "prover.hpp"
+#include "public_input.hpp"
 
 using namespace ssh;
 
@@ -114,6 +115,26 @@ int ssh_build_extension_columns(ss_ctx *ctx, int layout, const uint64_t *const *
 uint32_t ssh_matrix_num_cols(const ssh_matrix *m) { return reinterpret_cast<const Matrix *>(m)->num_cols(); }
 uint64_t *ssh_matrix_col(const ssh_matrix *m, uint32_t k) { return reinterpret_cast<const Matrix *>(m)->cols[k]; }
 void ssh_matrix_destroy(ssh_matrix *m) { delete reinterpret_cast<Matrix *>(m); }
+
+// CairoPublicCoin::from_public_input (public_input.hpp).  layout: 1 = recursive, 2 = starknet; segments: 9 x
+// {present, begin_addr, stop_ptr} in the header's order; memory: n x (address, 4 little-endian limbs of the value)
+int ssh_public_coin_seed(int layout, uint32_t rc_min, uint32_t rc_max, uint64_t n_steps, const uint32_t *segments,
+                         const uint32_t *mem_addresses, const uint64_t *mem_values, uint64_t n_mem, int coin_kind,
+                         uint8_t seed_out[32], uint64_t *elements_out, uint32_t *n_elements) {
+    try {
+        AirPublicInput pi;
+        pi.layout = layout == 1 ? "recursive" : layout == 2 ? "starknet" : "unknown";
+        pi.rc_min = (uint16_t)rc_min; pi.rc_max = (uint16_t)rc_max; pi.n_steps = n_steps;
+        for (int k = 0; k < 9; ++k) { pi.segments[k].present = segments[3 * k] != 0; pi.segments[k].begin_addr = segments[3 * k + 1]; pi.segments[k].stop_ptr = segments[3 * k + 2]; }
+        pi.public_memory.resize(n_mem);
+        for (uint64_t i = 0; i < n_mem; ++i) { pi.public_memory[i].address = mem_addresses[i]; memcpy(pi.public_memory[i].value.data(), mem_values + 4 * i, 32); }
+        const auto els = public_input_elements(pi, coin_kind);
+        if (elements_out && n_elements) { for (size_t i = 0; i < els.size(); ++i) memcpy(elements_out + 4 * i, els[i].data(), 32); *n_elements = (uint32_t)els.size(); }
+        const Digest d = public_coin_seed(pi, coin_kind);
+        memcpy(seed_out, d.data(), 32);
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
 
 // ---- the C++ coin, exposed for the CPU tests (tests/test_host_cpp.py)
 typedef struct ssh_coin ssh_coin;

@@ -37,6 +37,9 @@ def load():
         h.ssh_free.argtypes = [C.c_void_p]
         h.ssh_build_extension_columns.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_uint64, C.POINTER(C.c_uint64),
                                                   C.c_int, C.POINTER(C.c_void_p)]
+        h.ssh_public_coin_seed.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_uint64), C.c_uint64, C.c_int, C.c_char_p, C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint32)]
         h.ssh_matrix_num_cols.argtypes = [C.c_void_p]
         h.ssh_matrix_num_cols.restype = C.c_uint32
         h.ssh_matrix_col.argtypes = [C.c_void_p, C.c_uint32]
@@ -205,6 +208,28 @@ def build_extension_columns(ctx, layout, aux_cols, trace_len, challenges, check=
     _check(load().ssh_build_extension_columns(ctx.handle, 1 if layout == "recursive" else 2, be._ptr_array(aux_cols), trace_len,
                                               ch.ctypes.data_as(C.POINTER(C.c_uint64)), 1 if check else 0, C.byref(h)))
     return HostMatrix(ctx, h, trace_len)
+
+
+def public_coin_seed(pi, coin_kind):
+    """the C++ host's CairoPublicCoin::from_public_input (sandstorm_amd/host/public_input.cpp).
+    pi: public_input.AirPublicInput.  -> (seed bytes, public input elements as ints)"""
+    from .public_input import SEGMENTS
+    segs = np.zeros(27, dtype=np.uint32)
+    for k, name in enumerate(SEGMENTS):
+        s = pi.memory_segments.get(name)
+        if s is not None:
+            segs[3 * k: 3 * k + 3] = (1, s[0], s[1])
+    addrs = np.array([e[0] for e in pi.public_memory], dtype=np.uint32)
+    vals = np.array([[(e[1] >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)] for e in pi.public_memory], dtype=np.uint64).reshape(-1, 4)
+    seed = C.create_string_buffer(32)
+    els = np.zeros((64, 4), dtype=np.uint64)
+    n_els = C.c_uint32()
+    layout = {"recursive": 1, "starknet": 2}.get(pi.layout, 0)
+    _check(load().ssh_public_coin_seed(layout, pi.rc_min, pi.rc_max, pi.n_steps, segs.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       addrs.ctypes.data_as(C.POINTER(C.c_uint32)), vals.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       len(addrs), coin_kind, seed, els.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(n_els)))
+    ints = [sum(int(els[i, k]) << (64 * k) for k in range(4)) for i in range(n_els.value)]
+    return seed.raw, ints
 
 
 class HostCoin:
