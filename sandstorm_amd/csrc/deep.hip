@@ -189,7 +189,10 @@ __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ 
                 inner = fl_add(inner, fl_mul_r280(fl_from_fp(dload(tp + i)), fl_from_fp(dload_uniform(a.cell_coef + j))));
                 if (++terms == 12) { inner = fl_weak_reduce(inner); terms = 1; }      // 12 x 1.13p < 16p
             }
-            inner = fn_sub(fl_weak_reduce(inner), fl_from_fp(dload_uniform(a.group_k + g)));
+            // inner: at most 12 units (a reduced value + 11 products, or 12 products): value < 13.2p, limbs < 12 * 2^28.
+            // The lazy subtraction adds 2p and one 2^28 per limb: value < 15.2p < 2^256, limbs < 2^32 - exactly what
+            // the multiplicand side of fl_mul_r280 accepts, so no reduction is needed before the multiplication
+            inner = fl_sub_c<2, 1>(inner, fl_from_fp(dload_uniform(a.group_k + g)));
             acc = fl_add(acc, fl_mul_r280(inner, fl_from_fp(dload(a.D + ((m - shift) & (M - 1))))));
             if (++acc_terms == 12) { acc = fl_weak_reduce(acc); acc_terms = 1; }
         }
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ 
                 for (int c = 1; c < 4; ++c) if (k == (uint32_t)c) hp = a.comp[c];
                 inner = fl_add(inner, fl_mul_r280(fl_from_fp(dload(hp + i)), fl_from_fp(dload_uniform(a.comp_coef + k))));
             }
-            inner = fn_sub(fl_weak_reduce(inner), fl_from_fp(a.comp_k));
+            inner = fl_sub_c<2, 1>(inner, fl_from_fp(a.comp_k));            // ncomp <= 4 products: same bound argument
             acc = fl_add(acc, fl_mul_r280(inner, fl_from_fp(dload(a.Dc + m))));
         }
         dstore(out + m, fl_to_fp(acc));
