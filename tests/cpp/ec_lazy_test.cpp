@@ -1,0 +1,90 @@
+// Host check of the lazy Jacobian formulas (sandstorm_amd/csrc/ec252.h, the code the Pedersen kernels run) against
+// the plain 8 x 32 ones on chains of mixed additions over multiples of the Pedersen base point P1
+// (builtins/src/pedersen/constants.rs:5-30; tests/golden/pedersen.json), exceptional cases included.
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../sandstorm_amd/csrc/ec252.h"
+
+using namespace ss;
+
+static uint64_t rng_state = 0x243F6A8885A308D3ull;
+static uint64_t splitmix() {
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static Fp from_canon64(const uint64_t c[4]) {
+    Fp a;
+    for (int i = 0; i < 4; ++i) { a.v[2 * i] = (u32)c[i]; a.v[2 * i + 1] = (u32)(c[i] >> 32); }
+    return fp_to_mont(a);
+}
+static Aff to_affine(const Jac &p) {
+    const Fp zi = fp_inv(p.z), zi2 = fp_sqr(zi);
+    return Aff{fp_mul(p.x, zi2), fp_mul(p.y, fp_mul(zi2, zi))};
+}
+static Jac lift(const Aff &a) { return Jac{a.x, a.y, fp_one()}; }
+static AffL limb(const Aff &a) { return AffL{fl_from_fp(a.x), fl_from_fp(a.y)}; }
+static bool same(const JacL &l, const Jac &j) {
+    return fp_eq(fl_to_fp(l.x), j.x) && fp_eq(fl_to_fp(l.y), j.y) && fp_eq(fl_to_fp(l.z), j.z);
+}
+
+int main() {
+    const uint64_t P1X[4] = {0x1080d17957ebe47bull, 0x8fa8120b6d56eb0cull, 0x969c748655fca9e5ull, 0x0234287dcbaffe7full};
+    const uint64_t P1Y[4] = {0x6ed0268ee89e5615ull, 0x940135dd7a6c94ccull, 0x1e889527d41f4e39ull, 0x03b056f100f96fb2ull};
+    const Aff g{from_canon64(P1X), from_canon64(P1Y)};
+    // a pool of affine multiples of g
+    std::vector<Aff> pool;
+    Jac run = lift(g);
+    for (int i = 0; i < 300; ++i) {
+        const int steps = 1 + (int)(splitmix() % 5);
+        for (int k = 0; k < steps; ++k) run = (splitmix() & 1) ? jac_double(run) : jac_add_aff(run, g);
+        pool.push_back(to_affine(run));
+    }
+    int checked = 0;
+    for (int chain = 0; chain < 200; ++chain) {
+        Jac acc = lift(pool[splitmix() % pool.size()]);
+        JacL accl{fl_from_fp(acc.x), fl_from_fp(acc.y), fl_from_fp(acc.z)};
+        for (int i = 0; i < 34; ++i) {                      // a hash is 32 mixed additions
+            const Aff &q = pool[splitmix() % pool.size()];
+            acc = jac_add_aff(acc, q);
+            accl = jacl_add_aff(accl, limb(q));
+            if (!same(accl, acc)) { printf("mismatch: chain %d step %d\n", chain, i); return 1; }
+            ++checked;
+        }
+    }
+    // exceptional cases: p = q (doubling), p = -q (infinity), p = infinity
+    for (int i = 0; i < 50; ++i) {
+        const Aff q = pool[splitmix() % pool.size()];
+        const Aff t = pool[splitmix() % pool.size()];
+        // a Jacobian representative of q with z != 1: (q + t) - t
+        Jac p = jac_add_aff(lift(q), t);
+        p = jac_add_aff(p, Aff{t.x, fp_neg(t.y)});
+        JacL pl{fl_from_fp(p.x), fl_from_fp(p.y), fl_from_fp(p.z)};
+        if (!same(jacl_add_aff(pl, limb(q)), jac_add_aff(p, q))) { printf("doubling case mismatch %d\n", i); return 1; }
+        const Aff nq{q.x, fp_neg(q.y)};
+        const JacL inf = jacl_add_aff(pl, limb(nq));
+        if (!fp_is_zero(fl_to_fp(inf.z)) || !fp_is_zero(jac_add_aff(p, nq).z)) { printf("infinity case mismatch %d\n", i); return 1; }
+        const JacL back = jacl_add_aff(inf, limb(t));       // infinity + t = t
+        if (!fp_eq(fl_to_fp(back.x), t.x) || !fp_eq(fl_to_fp(back.y), t.y)) { printf("from-infinity mismatch %d\n", i); return 1; }
+        checked += 3;
+    }
+    // the multiplier at the limb bounds the lazy formulas reach (fl_sub_c<2,1> output: limbs up to 2^29 + 2^25; the
+    // lazy x3: limbs up to 2^30 + 2^27), every limb at its maximum and random patterns near it
+    for (int it = 0; it < 2000; ++it) {
+        Fl a, b;
+        for (int i = 0; i < 9; ++i) {
+            const u32 amax = (1u << 30) + (1u << 27), bmax = (1u << 29) + (1u << 25);
+            a.l[i] = it == 0 ? amax : amax - (u32)(splitmix() % (it & 1 ? 16u : amax));
+            b.l[i] = it == 0 ? bmax : bmax - (u32)(splitmix() % (it & 2 ? 16u : bmax));
+        }
+        a.l[8] &= (1u << 29) - 1; b.l[8] &= (1u << 29) - 1;       // keep the VALUES below 16p / 4p (top limb = value >> 224)
+        const Fp want = fp_mul(fl_to_fp(a), fl_to_fp(b));
+        if (!fp_eq(fl_to_fp(fl_mul(a, b)), want)) { printf("fl_mul at the lazy bounds: mismatch %d\n", it); return 1; }
+        ++checked;
+    }
+    printf("ok %d\n", checked);
+    return 0;
+}

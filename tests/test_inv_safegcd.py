@@ -13,3 +13,12 @@ def test_safegcd_matches_fermat(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "bad = 0" in out.stdout
+
+
+def test_lazy_curve_formulas_match_plain_ones(tmp_path):
+    """sandstorm_amd/csrc/ec252.h: the lazy mixed addition the Pedersen kernels run, against the plain 8 x 32
+    formulas on chains over multiples of P1, the exceptional cases, and the multiplier at the lazy limb bounds"""
+    exe = str(tmp_path / "ec_lazy_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "ec_lazy_test.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
