@@ -37,6 +37,7 @@ WORKLOADS = {
     "recursive_2p20": ("recursive", 20),    # BASELINE.json north_star target size (2^20-step recursive trace)
     "recursive_2p16": ("recursive", 16),    # BASELINE.json configs[1]
     "recursive_2p10": ("recursive", 10),    # plumbing
+    "recursive_2p7": ("recursive", 7),      # 128 steps: the size of the only figure the reference publishes (186 ms)
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -225,6 +226,9 @@ def main():
                          "note": "algorithmic bytes = 2*N*32 B per transform (SURVEY 8d), shared by its passes; "
                                  "Fp252 butterflies are integer-ALU bound before HBM bound (DESIGN.md)"},
         }
+        if args.workload == "recursive_2p7":
+            out["config"]["reference_published"] = ("186 ms for the 128-step array-sum proof on the author's machine "
+                                                    "(BASELINE.md section 1: other hardware, older CLI, the real AIR)")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(layout, log_n, ncols)
         print(json.dumps(out))
