@@ -1,13 +1,15 @@
 """The `recursive` layout (layouts/src/recursive/{mod,air,trace}.rs): base-trace generation from a `cairo-run`
 output and the AIR's constraints as air_program expressions.
 
-STATUS (round 1): the CPU component is restated — the 33 `cpu/*` + initial/final register constraints
-(air.rs:82-443) and the trace cells they read (trace.rs:172-232): flags (column 0), the instruction / operand
-cells of the memory pool (column 3), the offset cells of the range-check column (column 5) and the auxiliary column
-(column 6).  The two restatements validate each other: every constraint vanishes on its domain on the trace
-generated from the reference's own example run (tests/test_layout_recursive.py).  Memory, range-check permutation,
-Pedersen, bitwise and diluted-check constraints (air.rs:444-1200) and their trace cells are NOT restated yet
-(DESIGN.md §8 item 4); `constraints()` lists what exists.
+STATUS (round 1): restated are the CPU component (33 `cpu/*` + initial/final register constraints, air.rs:82-443),
+the memory component (permutation, continuity, single-valuedness, public memory: air.rs:444-497), the 16-bit range
+check (air.rs:499-538) and the range-check builtin (air.rs:899-918), with the trace cells they read (trace.rs:95-300,
+590-660): flags (column 0), the whole memory pool incl. the builtins' memory cells (column 3), the sorted memory
+(column 4), the range-check column (column 5) and the auxiliary column (column 6).  The two restatements validate each
+other: every constraint vanishes on its domain on the trace generated from the reference's own example run
+(tests/test_layout_recursive.py).  NOT restated yet: the Pedersen builtin's partial sums / suffixes / slopes and its
+constraints, the bitwise builtin and the diluted check (air.rs:540-895, 920-1160; columns 1, 2 and the odd cells of
+columns 5, 6) — DESIGN.md §8 item 4; `constraints()` lists what exists.
 
 Column map (air.rs:1324-1729): 0 flags | 1 diluted unordered / bitwise | 2 diluted ordered | 3 memory pool ("npc") |
 4 sorted memory | 5 range check / Pedersen partial sums | 6 auxiliary / Pedersen suffixes, slopes |
@@ -22,7 +24,11 @@ from .. import binary as bn
 P = bn.P
 CYCLE_HEIGHT = 16                   # recursive/mod.rs:16
 PUBLIC_MEMORY_STEP, MEMORY_STEP, RANGE_CHECK_STEP, DILUTED_CHECK_STEP = 16, 2, 4, 1
+PEDERSEN_BUILTIN_RATIO, RANGE_CHECK_BUILTIN_RATIO, RANGE_CHECK_BUILTIN_PARTS, BITWISE_RATIO = 128, 8, 8, 8
 NUM_BASE_COLUMNS, NUM_EXTENSION_COLUMNS = 7, 3
+COL_DILUTED_AGGREGATE, COL_DILUTED_PERMUTATION, COL_MEM_RC_PERMUTATION = 7, 8, 9
+# challenge indices (air.rs:1759-1801)
+MEM_Z, MEM_A, RC_Z, DC_Z, AGG_Z, AGG_A = range(6)
 COL_FLAGS, COL_DILUTED_UNORDERED, COL_DILUTED_ORDERED, COL_NPC, COL_MEMORY, COL_RANGE_CHECK, COL_AUXILIARY = range(7)
 
 
@@ -32,8 +38,18 @@ class Npc:
     MEM_DST_ADDR, MEM_DST, MEM_OP1_ADDR, MEM_OP1, UNUSED_ADDR, UNUSED_VAL = 8, 9, 12, 13, 14, 15
 
 
+    # builtin cells (air.rs:1489-1507): offset inside the builtin's own step
+    PEDERSEN_INPUT0_ADDR, PEDERSEN_INPUT1_ADDR, PEDERSEN_OUTPUT_ADDR = 10, 1034, 522
+    RANGE_CHECK128_ADDR, BITWISE_POOL_ADDR, BITWISE_X_OR_Y_ADDR = 74, 26, 42
+
+
+class Mem:
+    ADDRESS, VALUE = 0, 1
+
+
 class RangeCheck:
     OFF_DST, ORDERED, OFF_OP1, OFF_OP0, UNUSED = 0, 2, 4, 8, 12
+    RC16_COMPONENT = 12             # RangeCheckBuiltin::Rc16Component: one 16-bit part per cycle
 
 
 class Auxiliary:
@@ -84,6 +100,25 @@ LAST_CYCLE = Domain("first row of the last cycle", lambda n: [n - CYCLE_HEIGHT],
                     lambda n, g: (ap.X - pow(g, n - CYCLE_HEIGHT, P)).inverse())
 
 
+def _every(k, name):
+    """rows 0, k, 2k, ...: zerofier X^(n/k) - 1"""
+    return Domain(name, lambda n: range(0, n, k), lambda n, g: (_x_pow(n // k) - 1).inverse())
+
+
+def _every_except_last(k, name):
+    return Domain(name, lambda n: range(0, n - k, k), lambda n, g: (ap.X - pow(g, n - k, P)) * (_x_pow(n // k) - 1).inverse())
+
+
+def _row_from_end(k, name):
+    """the single row n - k"""
+    return Domain(name, lambda n: [n - k], lambda n, g: (ap.X - pow(g, n - k, P)).inverse())
+
+
+EVERY_2ND_EXCEPT_LAST, SECOND_LAST_ROW = _every_except_last(2, "every 2nd row but the last"), _row_from_end(2, "row n-2")
+EVERY_4TH_EXCEPT_LAST, FOURTH_LAST_ROW = _every_except_last(4, "every 4th row but the last"), _row_from_end(4, "row n-4")
+EVERY_128, EVERY_128_EXCEPT_LAST = _every(128, "every 128th row"), _every_except_last(128, "every 128th row but the last")
+
+
 @dataclass
 class Constraint:
     name: str                       # StarkWare's name, as the reference's variable (air.rs)
@@ -98,11 +133,31 @@ class Hints:
     initial_pc: int
     final_ap: int
     final_pc: int
+    range_check_min: int = 0
+    range_check_max: int = 0
+    initial_rc_addr: int = 0
+    memory_quotient: int = 0        # needs the memory challenges: with_challenges()
+    range_check_product: int = 1
 
     @classmethod
-    def from_public_input(cls, pi):
+    def from_public_input(cls, pi, challenges=None, trace_len=None):
         prog, exe = pi.memory_segments["program"], pi.memory_segments["execution"]
-        return cls(initial_ap=exe[0], initial_pc=prog[0], final_ap=exe[1], final_pc=prog[1])
+        h = cls(initial_ap=exe[0], initial_pc=prog[0], final_ap=exe[1], final_pc=prog[1], range_check_min=pi.rc_min,
+                range_check_max=pi.rc_max, initial_rc_addr=pi.memory_segments["range_check"][0])
+        if challenges is not None:
+            h.memory_quotient = public_memory_quotient(challenges[MEM_Z], challenges[MEM_A], trace_len or 16 * pi.n_steps, pi)
+        return h
+
+
+def public_memory_quotient(z, alpha, trace_len, pi):
+    """compute_public_memory_quotient (layouts/src/utils.rs:14-46): z^S / (prod (z - (a_i + alpha v_i)) * padding^(S-N))"""
+    s, count = trace_len // PUBLIC_MEMORY_STEP, len(pi.public_memory)
+    den = 1
+    for a, v in pi.public_memory:
+        den = den * (z - (alpha * v + a)) % P
+    pad_a, pad_v = pi.public_memory_padding()
+    den = den * pow((z - (alpha * pad_v + pad_a)) % P, s - count, P) % P
+    return pow(z, s, P) * pow(den, -1, P) % P
 
 
 def cpu_constraints(hints: Hints) -> List[Constraint]:
@@ -179,9 +234,78 @@ def cpu_constraints(hints: Hints) -> List[Constraint]:
     return c
 
 
-def constraints(hints: Hints) -> List[Constraint]:
-    """what is restated so far (see the module docstring)"""
-    return cpu_constraints(hints)
+def npc_at(offset):
+    return ap.Trace(COL_NPC, offset)
+
+
+def mem(cell, mem_offset=0):
+    return ap.Trace(COL_MEMORY, MEMORY_STEP * mem_offset + cell)
+
+
+def rc_ordered(step_offset=0):
+    return ap.Trace(COL_RANGE_CHECK, RANGE_CHECK_STEP * step_offset + RangeCheck.ORDERED)
+
+
+def perm_memory(step_offset=0):                  # Permutation::Memory -> (9, 0), step MEMORY_STEP
+    return ap.Trace(COL_MEM_RC_PERMUTATION, MEMORY_STEP * step_offset)
+
+
+def perm_range_check(step_offset=0):             # Permutation::RangeCheck -> (9, 1), step 4
+    return ap.Trace(COL_MEM_RC_PERMUTATION, 4 * step_offset + 1)
+
+
+def memory_constraints(hints: Hints, challenges) -> List[Constraint]:
+    """air.rs:444-497"""
+    z, a = ap.Const(challenges[MEM_Z]), ap.Const(challenges[MEM_A])
+    one = ap.Const(1)
+    address_diff = mem(Mem.ADDRESS, 1) - mem(Mem.ADDRESS)
+    return [
+        Constraint("memory/multi_column_perm/perm/init0",
+                   (z - (mem(Mem.ADDRESS) + a * mem(Mem.VALUE))) * perm_memory() + npc(Npc.PC) + a * npc(Npc.INSTRUCTION) - z, FIRST_ROW),
+        # Npc::PubMemAddr.curr() is Trace(3, 2): seen from row 2k it is the NEXT (address, value) pair of the pool
+        Constraint("memory/multi_column_perm/perm/step0",
+                   (z - (mem(Mem.ADDRESS, 1) + a * mem(Mem.VALUE, 1))) * perm_memory(1)
+                   - (z - (npc_at(2) + a * npc_at(3))) * perm_memory(), EVERY_2ND_EXCEPT_LAST),
+        Constraint("memory/multi_column_perm/perm/last", perm_memory() - hints.memory_quotient, SECOND_LAST_ROW),
+        Constraint("memory/diff_is_bit", address_diff * address_diff - address_diff, EVERY_2ND_EXCEPT_LAST),
+        Constraint("memory/is_func", (address_diff - one) * (mem(Mem.VALUE) - mem(Mem.VALUE, 1)), EVERY_2ND_EXCEPT_LAST),
+        Constraint("memory/initial_addr", mem(Mem.ADDRESS) - one, FIRST_ROW),
+        Constraint("public_memory_addr_zero", npc(Npc.PUB_MEM_ADDR), ALL_CYCLES),
+        Constraint("public_memory_value_zero", npc(Npc.PUB_MEM_VAL), ALL_CYCLES),
+    ]
+
+
+def range_check_constraints(hints: Hints, challenges) -> List[Constraint]:
+    """air.rs:499-538 (16-bit range check) and 899-918 (the 128-bit range-check builtin)"""
+    z = ap.Const(challenges[RC_Z])
+    diff = rc_ordered(1) - rc_ordered()
+    offset_size = ap.Const(1 << 16)
+    value = None                                   # rc_builtin_value7_0: the 8 parts, most significant first (air.rs:105-119)
+    for k in range(RANGE_CHECK_BUILTIN_PARTS):
+        part = ap.Trace(COL_RANGE_CHECK, CYCLE_HEIGHT * k + RangeCheck.RC16_COMPONENT)
+        value = part if value is None else value * offset_size + part
+    step = CYCLE_HEIGHT * RANGE_CHECK_BUILTIN_RATIO
+    return [
+        Constraint("rc16/perm/init0", (z - rc_ordered()) * perm_range_check() + rc(RangeCheck.OFF_DST) - z, FIRST_ROW),
+        # RangeCheck::OffOp1.curr() is Trace(5, 4): seen from row 4k it is the NEXT unordered value
+        Constraint("rc16/perm/step0", (z - rc_ordered(1)) * perm_range_check(1) - (z - ap.Trace(COL_RANGE_CHECK, 4)) * perm_range_check(),
+                   EVERY_4TH_EXCEPT_LAST),
+        Constraint("rc16/perm/last", perm_range_check() - hints.range_check_product, FOURTH_LAST_ROW),
+        Constraint("rc16/diff_is_bit", diff * diff - diff, EVERY_4TH_EXCEPT_LAST),
+        Constraint("rc16/minimum", rc_ordered() - hints.range_check_min, FIRST_ROW),
+        Constraint("rc16/maximum", rc_ordered() - hints.range_check_max, FOURTH_LAST_ROW),
+        Constraint("rc_builtin/value", value - npc_at(Npc.RANGE_CHECK128_ADDR + 1), EVERY_128),
+        Constraint("rc_builtin/addr_step", npc_at(step + Npc.RANGE_CHECK128_ADDR) - (npc_at(Npc.RANGE_CHECK128_ADDR) + 1), EVERY_128_EXCEPT_LAST),
+        Constraint("rc_builtin/init_addr", npc_at(Npc.RANGE_CHECK128_ADDR) - hints.initial_rc_addr, FIRST_ROW),
+    ]
+
+
+def constraints(hints: Hints, challenges=None) -> List[Constraint]:
+    """what is restated so far (see the module docstring); the permutation constraints need the 6 challenges (ints)"""
+    out = cpu_constraints(hints)
+    if challenges is not None:
+        out += memory_constraints(hints, challenges) + range_check_constraints(hints, challenges)
+    return out
 
 
 # ---- base trace (trace.rs:95-232), CPU cells ----------------------------------------------------------------------
@@ -222,6 +346,115 @@ def cpu_trace(register_states, memory, public_input):
         aux_col[r + Auxiliary.TMP0], aux_col[r + Auxiliary.TMP1] = tmp0, tmp0 * res % P
         aux_col[r + Auxiliary.AP], aux_col[r + Auxiliary.FP] = ap_, fp
         aux_col[r + Auxiliary.OP0_MUL_OP1], aux_col[r + Auxiliary.RES] = op0 * op1 % P, res
+    return cols
+
+
+def _rc_ordered_with_padding(values):
+    """RangeCheckPool::get_ordered_values_with_padding (layouts/src/utils.rs:357-380)"""
+    ordered = sorted(values)
+    padding = [v for a, b in zip(ordered, ordered[1:]) for v in range(a + 1, b)]
+    return sorted(ordered + padding), padding
+
+
+def base_trace(register_states, memory, public_input, private_input=None):
+    """ExecutionTrace::new (trace.rs:95-660) for the components restated so far: the CPU cells (cpu_trace), the whole
+    memory pool with the builtins' memory cells and the gap fillers, the range-check column and the sorted memory
+    column.  private_input: {"pedersen": [(index, a, b)], "range_check": [(index, value)], "bitwise": [(index, x, y)]}
+    (air-private-input.json); missing instances are the reference's empty dummies.  Columns 1 and 2 and the Pedersen
+    cells of columns 5 and 6 are left zero (not restated yet)."""
+    from .. import backend as be                     # host Pedersen (ss_pedersen_hash_host): no device involved
+    from ..coin import canonical
+    private_input = private_input or {}
+    cols = cpu_trace(register_states, memory, public_input)
+    n = len(cols[0])
+    num_cycles = n // CYCLE_HEIGHT
+    npc_col, rc_col = cols[COL_NPC], cols[COL_RANGE_CHECK]
+    seg = public_input.memory_segments
+
+    # ---- range-check pool (trace.rs:131-160, 236-284)
+    pool = []
+    for st in register_states:
+        w = bn.Word(memory[st.pc])
+        pool += [w.off_dst, w.off_op0, w.off_op1]
+    rc128 = [(int(i), int(v)) for i, v in private_input.get("range_check", [])]
+    parts_of = lambda v: [(v >> (16 * (RANGE_CHECK_BUILTIN_PARTS - 1 - k))) & 0xFFFF for k in range(RANGE_CHECK_BUILTIN_PARTS)]
+    for _, v in rc128:
+        pool += parts_of(v)
+    ordered_vals, padding_vals = _rc_ordered_with_padding(pool)
+    rc_min, rc_max = min(pool), max(pool)
+    padding_iter, ordered_iter = iter(padding_vals), iter(ordered_vals)
+    for index in range(len(rc128), num_cycles // RANGE_CHECK_BUILTIN_RATIO):        # dummies made of padding values
+        value = 0
+        for _ in range(RANGE_CHECK_BUILTIN_PARTS):
+            value = (value << 16) + next(padding_iter, rc_max)
+        rc128.append((index, value))
+    for cycle in range(num_cycles):
+        r = cycle * CYCLE_HEIGHT
+        if cycle % 2 == 1:
+            rc_col[r + RangeCheck.UNUSED] = next(padding_iter, rc_max)
+        for o in range(0, CYCLE_HEIGHT, RANGE_CHECK_STEP):
+            rc_col[r + o + RangeCheck.ORDERED] = next(ordered_iter, rc_max)
+    if next(padding_iter, None) is not None or next(ordered_iter, None) is not None:
+        raise ValueError("range-check values do not fit the trace")
+
+    # ---- builtin memory cells (trace.rs:300-420, 540-570)
+    hash00 = None
+    ped = {int(i): (int(a), int(b)) for i, a, b in private_input.get("pedersen", [])}
+    step = PEDERSEN_BUILTIN_RATIO * CYCLE_HEIGHT
+    ped_begin = seg["pedersen"][0]
+    for i in range(n // step):
+        a, b = ped.get(i, (0, 0))
+        if (a, b) == (0, 0):
+            if hash00 is None:
+                hash00 = canonical(be.pedersen_hash_host(be.felt(0), be.felt(0)))
+            out = hash00
+        else:
+            out = canonical(be.pedersen_hash_host(be.felt(a), be.felt(b)))
+        base, addr = i * step, ped_begin + 3 * i
+        for off, (ad, val) in ((Npc.PEDERSEN_INPUT0_ADDR, (addr, a)), (Npc.PEDERSEN_INPUT1_ADDR, (addr + 1, b)),
+                               (Npc.PEDERSEN_OUTPUT_ADDR, (addr + 2, out))):
+            npc_col[base + off], npc_col[base + off + 1] = ad, val % P
+    step = RANGE_CHECK_BUILTIN_RATIO * CYCLE_HEIGHT
+    rc_begin = seg["range_check"][0]
+    for block, (index, value) in enumerate(rc128):
+        base = block * step
+        for k, part in enumerate(parts_of(value)):
+            rc_col[base + CYCLE_HEIGHT * k + RangeCheck.RC16_COMPONENT] = part
+        npc_col[base + Npc.RANGE_CHECK128_ADDR], npc_col[base + Npc.RANGE_CHECK128_ADDR + 1] = rc_begin + index, value
+    step = BITWISE_RATIO * CYCLE_HEIGHT
+    bw = {int(i): (int(x), int(y)) for i, x, y in private_input.get("bitwise", [])}
+    bw_begin = seg["bitwise"][0]
+    for i in range(n // step):
+        x, y = bw.get(i, (0, 0))
+        base, addr = i * step, bw_begin + 5 * i
+        for k, val in enumerate((x, y, x & y, x ^ y)):
+            o = base + Npc.BITWISE_POOL_ADDR + k * (step // 4)
+            npc_col[o], npc_col[o + 1] = addr + k, val
+        npc_col[base + Npc.BITWISE_X_OR_Y_ADDR], npc_col[base + Npc.BITWISE_X_OR_Y_ADDR + 1] = addr + 4, x | y
+
+    # ---- gap fillers (trace.rs:594-625): every address between two accessed ones gets an (address, 0) access
+    accessed = sorted(set(npc_col[0::2]) | {a for a, _ in public_input.public_memory})
+    gaps = [v for a, b in zip(accessed, accessed[1:]) for v in range(a + 1, b)]
+    if len(gaps) > num_cycles:
+        raise ValueError("more memory gaps than cycles to hold them")
+    for cycle, addr in enumerate(gaps):
+        r = cycle * CYCLE_HEIGHT
+        npc_col[r + Npc.UNUSED_ADDR], npc_col[r + Npc.UNUSED_VAL] = addr, 0
+
+    # ---- sorted memory (get_ordered_memory_accesses, layouts/src/utils.rs:112-152)
+    cells = n // PUBLIC_MEMORY_STEP
+    accesses = list(zip(npc_col[0::2], npc_col[1::2]))
+    accesses += [public_input.public_memory_padding()] * (cells - len(public_input.public_memory)) + list(public_input.public_memory)
+    accesses.sort(key=lambda e: e[0])
+    zeros, ordered = accesses[:cells], accesses[cells:]
+    if any(a != 0 for a, _ in zeros) or ordered[0][0] != 1:
+        raise ValueError("the public-memory cells of the pool must be the only accesses of address 0")
+    for (a0, v0), (a1, v1) in zip(ordered, ordered[1:]):
+        if not ((a0, v0) == (a1, v1) or a0 + 1 == a1):
+            raise ValueError("memory is not continuous and single-valued at address %d" % a0)
+    mem_col = cols[COL_MEMORY]
+    mem_col[0::2] = [a for a, _ in ordered]
+    mem_col[1::2] = [v for _, v in ordered]
     return cols
 
 
