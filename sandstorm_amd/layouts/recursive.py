@@ -1,15 +1,15 @@
 """The `recursive` layout (layouts/src/recursive/{mod,air,trace}.rs): base-trace generation from a `cairo-run`
 output and the AIR's constraints as air_program expressions.
 
-STATUS (round 1): restated are the CPU component (33 `cpu/*` + initial/final register constraints, air.rs:82-443),
-the memory component (permutation, continuity, single-valuedness, public memory: air.rs:444-497), the 16-bit range
-check (air.rs:499-538) and the range-check builtin (air.rs:899-918), with the trace cells they read (trace.rs:95-300,
-590-660): flags (column 0), the whole memory pool incl. the builtins' memory cells (column 3), the sorted memory
-(column 4), the range-check column (column 5) and the auxiliary column (column 6).  The two restatements validate each
-other: every constraint vanishes on its domain on the trace generated from the reference's own example run
-(tests/test_layout_recursive.py).  NOT restated yet: the Pedersen builtin's partial sums / suffixes / slopes and its
-constraints, the bitwise builtin and the diluted check (air.rs:540-895, 920-1160; columns 1, 2 and the odd cells of
-columns 5, 6) — DESIGN.md §8 item 4; `constraints()` lists what exists.
+STATUS (round 1): restated are 68 of the 93 constraints — the CPU component (33: air.rs:82-443), memory and public
+memory (8: air.rs:444-497), the 16-bit range check (6: air.rs:499-538), the diluted check (7: air.rs:540-603), the
+range-check builtin (3: air.rs:899-918) and the bitwise builtin (11: air.rs:920-1081) — with every trace cell they
+read (trace.rs:95-300, 420-660): all of columns 0-4 and the range-check / auxiliary cells of columns 5 and 6.  The two
+restatements validate each other: every constraint vanishes on its domain on the trace generated from the reference's
+own example run, the memory product closes to the public-memory quotient, the range-check and diluted products to one
+and the diluted aggregate to its closed form (tests/test_layout_recursive.py).  NOT restated yet: the Pedersen
+builtin's partial sums / suffixes / slopes and its 25 constraints (air.rs:605-895; the odd cells of columns 5 and 6)
+— DESIGN.md §8 item 4; `constraints()` lists what exists.
 
 Column map (air.rs:1324-1729): 0 flags | 1 diluted unordered / bitwise | 2 diluted ordered | 3 memory pool ("npc") |
 4 sorted memory | 5 range check / Pedersen partial sums | 6 auxiliary / Pedersen suffixes, slopes |
@@ -27,6 +27,7 @@ PUBLIC_MEMORY_STEP, MEMORY_STEP, RANGE_CHECK_STEP, DILUTED_CHECK_STEP = 16, 2, 4
 PEDERSEN_BUILTIN_RATIO, RANGE_CHECK_BUILTIN_RATIO, RANGE_CHECK_BUILTIN_PARTS, BITWISE_RATIO = 128, 8, 8, 8
 NUM_BASE_COLUMNS, NUM_EXTENSION_COLUMNS = 7, 3
 COL_DILUTED_AGGREGATE, COL_DILUTED_PERMUTATION, COL_MEM_RC_PERMUTATION = 7, 8, 9
+DILUTED_CHECK_N_BITS, DILUTED_CHECK_SPACING = 16, 4
 # challenge indices (air.rs:1759-1801)
 MEM_Z, MEM_A, RC_Z, DC_Z, AGG_Z, AGG_A = range(6)
 COL_FLAGS, COL_DILUTED_UNORDERED, COL_DILUTED_ORDERED, COL_NPC, COL_MEMORY, COL_RANGE_CHECK, COL_AUXILIARY = range(7)
@@ -116,6 +117,21 @@ def _row_from_end(k, name):
 
 EVERY_2ND_EXCEPT_LAST, SECOND_LAST_ROW = _every_except_last(2, "every 2nd row but the last"), _row_from_end(2, "row n-2")
 EVERY_4TH_EXCEPT_LAST, FOURTH_LAST_ROW = _every_except_last(4, "every 4th row but the last"), _row_from_end(4, "row n-4")
+EVERY_32 = _every(32, "every 32nd row")
+EVERY_ROW_EXCEPT_LAST, LAST_ROW = _every_except_last(1, "every row but the last"), _row_from_end(1, "last row")
+# (X^(n/32) - 1) / (X^(n/128) - g^(3n/4)): rows 0, 32, 64 (not 96) of every 128 (air.rs:926-928)
+BITWISE_TRANSITION = Domain("rows 0, 32, 64 of every 128", lambda n: (r for r in range(0, n, 32) if r % 128 != 96),
+                            lambda n, g: (_x_pow(n // 128) - pow(g, 3 * n // 4, P)) * (_x_pow(n // 32) - 1).inverse())
+
+
+def _segment_zerofier_inv(n, g):               # air.rs:961-978: prod_{k<16} (X^(n/128) - g^(k n/64))
+    z = _x_pow(n // 128) - 1
+    for k in range(1, 16):
+        z = z * (_x_pow(n // 128) - pow(g, k * n // 64, P))
+    return z.inverse()
+
+
+EVERY_16_BIT_SEGMENT = Domain("rows 0, 2, ..., 30 of every 128", lambda n: (r for r in range(0, n, 2) if r % 128 < 32), _segment_zerofier_inv)
 EVERY_128, EVERY_128_EXCEPT_LAST = _every(128, "every 128th row"), _every_except_last(128, "every 128th row but the last")
 
 
@@ -136,17 +152,38 @@ class Hints:
     range_check_min: int = 0
     range_check_max: int = 0
     initial_rc_addr: int = 0
-    memory_quotient: int = 0        # needs the memory challenges: with_challenges()
+    memory_quotient: int = 0        # needs the challenges
     range_check_product: int = 1
+    diluted_check_product: int = 1
+    diluted_check_first: int = 0
+    diluted_check_cumulative_value: int = 0     # needs the challenges
+    initial_bitwise_addr: int = 0
 
     @classmethod
     def from_public_input(cls, pi, challenges=None, trace_len=None):
         prog, exe = pi.memory_segments["program"], pi.memory_segments["execution"]
         h = cls(initial_ap=exe[0], initial_pc=prog[0], final_ap=exe[1], final_pc=prog[1], range_check_min=pi.rc_min,
-                range_check_max=pi.rc_max, initial_rc_addr=pi.memory_segments["range_check"][0])
+                range_check_max=pi.rc_max, initial_rc_addr=pi.memory_segments["range_check"][0],
+                initial_bitwise_addr=pi.memory_segments["bitwise"][0])
         if challenges is not None:
             h.memory_quotient = public_memory_quotient(challenges[MEM_Z], challenges[MEM_A], trace_len or 16 * pi.n_steps, pi)
+            h.diluted_check_cumulative_value = diluted_cumulative_value(challenges[AGG_Z], challenges[AGG_A])
         return h
+
+
+def diluted_cumulative_value(z, alpha, n_bits=DILUTED_CHECK_N_BITS, spacing=DILUTED_CHECK_SPACING):
+    """compute_diluted_cumulative_value (layouts/src/utils.rs:48-108): the aggregate after running over every diluted
+    n_bits-bit value once, in log steps"""
+    diff_multiplier, diff_x = 1 << spacing, (1 << spacing) - 2
+    p, q, x = (z + 1) % P, 1, 1
+    for _ in range(1, n_bits):
+        x = (x + diff_x) % P
+        diff_x = diff_x * diff_multiplier % P
+        xp = x * p % P
+        y = (p + z * xp) % P
+        q = (q + q * y + x * xp) % P
+        p = p * y % P
+    return (p + q * alpha) % P
 
 
 def public_memory_quotient(z, alpha, trace_len, pi):
@@ -300,12 +337,60 @@ def range_check_constraints(hints: Hints, challenges) -> List[Constraint]:
     ]
 
 
+def diluted_check_constraints(hints: Hints, challenges) -> List[Constraint]:
+    """air.rs:540-603; DILUTED_CHECK_STEP = 1: every row"""
+    z, za, aa = ap.Const(challenges[DC_Z]), ap.Const(challenges[AGG_Z]), ap.Const(challenges[AGG_A])
+    un, od = (lambda o=0: ap.Trace(COL_DILUTED_UNORDERED, o)), (lambda o=0: ap.Trace(COL_DILUTED_ORDERED, o))
+    perm, agg = (lambda o=0: ap.Trace(COL_DILUTED_PERMUTATION, o)), (lambda o=0: ap.Trace(COL_DILUTED_AGGREGATE, o))
+    diff = od(1) - od()
+    return [
+        Constraint("diluted_check/permutation/init0", (z - od()) * perm() + un() - z, FIRST_ROW),
+        Constraint("diluted_check/permutation/step0", (z - od(1)) * perm(1) - (z - un(1)) * perm(), EVERY_ROW_EXCEPT_LAST),
+        Constraint("diluted_check/permutation/last", perm() - hints.diluted_check_product, LAST_ROW),
+        Constraint("diluted_check/init", agg() - 1, FIRST_ROW),
+        Constraint("diluted_check/first_element", od() - hints.diluted_check_first, FIRST_ROW),
+        Constraint("diluted_check/step", agg(1) - (agg() * (1 + za * diff) + aa * diff * diff), EVERY_ROW_EXCEPT_LAST),
+        Constraint("diluted_check/last", agg() - hints.diluted_check_cumulative_value, LAST_ROW),
+    ]
+
+
+def bitwise_constraints(hints: Hints) -> List[Constraint]:
+    """air.rs:920-1081.  A bitwise instance spans 128 rows: four 32-row partitions (x, y, x&y, x^y) of column 1, whose
+    even cells 0..30 hold the 16 diluted 16-bit segments (chunk c, stream s at cell 8c + 2s)."""
+    bw = lambda o: ap.Trace(COL_DILUTED_UNORDERED, o)
+    pool_addr = lambda k: npc_at(32 * k + Npc.BITWISE_POOL_ADDR)
+    pool_val = lambda k: npc_at(32 * k + Npc.BITWISE_POOL_ADDR + 1)
+    two = ap.Const(2)
+    sum_var = None                                   # bitwise_sum_var_0_0 + bitwise_sum_var_8_0 (air.rs:121-138)
+    for chunk in range(4):
+        for stream in range(4):
+            term = bw(8 * chunk + 2 * stream)
+            shift = 64 * chunk + stream
+            term = term * (1 << shift) if shift else term
+            sum_var = term if sum_var is None else sum_var + term
+    out = [
+        Constraint("bitwise/init_var_pool_addr", pool_addr(0) - hints.initial_bitwise_addr, FIRST_ROW),
+        Constraint("bitwise/step_var_pool_addr", pool_addr(1) - (pool_addr(0) + 1), BITWISE_TRANSITION),
+        Constraint("bitwise/x_or_y_addr", npc_at(Npc.BITWISE_X_OR_Y_ADDR) - (pool_addr(3) + 1), EVERY_128),
+        Constraint("bitwise/next_var_pool_addr", pool_addr(4) - (npc_at(Npc.BITWISE_X_OR_Y_ADDR) + 1), EVERY_128_EXCEPT_LAST),
+        Constraint("bitwise/partition", sum_var - pool_val(0), EVERY_32),
+        Constraint("bitwise/or_is_and_plus_xor", npc_at(Npc.BITWISE_X_OR_Y_ADDR + 1) - (pool_val(2) + pool_val(3)), EVERY_128),
+        Constraint("bitwise/addition_is_xor_with_and", bw(0) + bw(32) - (bw(96) + bw(64) + bw(64)), EVERY_16_BIT_SEGMENT),
+    ]
+    # unique unpacking of the top chunk: (and + xor) segments shifted (air.rs:1052-1081); cells 1, 65, 33, 97 hold the results
+    for k, (cell, shift) in enumerate(((1, 4), (65, 4), (33, 4), (97, 8))):
+        seg = 24 + 2 * k
+        out.append(Constraint("bitwise/unique_unpacking%d" % (192 + k), (bw(64 + seg) + bw(96 + seg)) * (1 << shift) - bw(cell), EVERY_128))
+    return out
+
+
 def constraints(hints: Hints, challenges=None) -> List[Constraint]:
     """what is restated so far (see the module docstring); the permutation constraints need the 6 challenges (ints)"""
     out = cpu_constraints(hints)
     if challenges is not None:
         out += memory_constraints(hints, challenges) + range_check_constraints(hints, challenges)
-    return out
+        out += diluted_check_constraints(hints, challenges)
+    return out + bitwise_constraints(hints)
 
 
 # ---- base trace (trace.rs:95-232), CPU cells ----------------------------------------------------------------------
@@ -347,6 +432,35 @@ def cpu_trace(register_states, memory, public_input):
         aux_col[r + Auxiliary.AP], aux_col[r + Auxiliary.FP] = ap_, fp
         aux_col[r + Auxiliary.OP0_MUL_OP1], aux_col[r + Auxiliary.RES] = op0 * op1 % P, res
     return cols
+
+
+def _dilute(v, spacing=DILUTED_CHECK_SPACING):
+    """bit i -> bit i * spacing (builtins/src/bitwise/mod.rs dilute)"""
+    out, i = 0, 0
+    while v:
+        out |= (v & 1) << (i * spacing)
+        v >>= 1
+        i += 1
+    return out
+
+
+def _undilute(v, spacing=DILUTED_CHECK_SPACING, n_bits=DILUTED_CHECK_N_BITS):
+    """DilutedCheckPool::push_diluted (layouts/src/utils.rs:255-271)"""
+    out = 0
+    for i in range(n_bits):
+        out |= ((v >> (i * spacing)) & 1) << i
+    if _dilute(out, spacing) != v:
+        raise ValueError("value %#x is not in diluted form" % v)
+    return out
+
+
+def _partition64(v, spacing=DILUTED_CHECK_SPACING):
+    """Partition64::new (builtins/src/bitwise/mod.rs): stream s = the bits at positions = s mod spacing, left in place"""
+    segs = [0] * spacing
+    for b in range(64 // spacing):
+        for s_ in range(spacing):
+            segs[s_] |= ((v >> (b * spacing + s_)) & 1) << (b * spacing)
+    return segs
 
 
 def _rc_ordered_with_padding(values):
@@ -431,6 +545,51 @@ def base_trace(register_states, memory, public_input, private_input=None):
             o = base + Npc.BITWISE_POOL_ADDR + k * (step // 4)
             npc_col[o], npc_col[o + 1] = addr + k, val
         npc_col[base + Npc.BITWISE_X_OR_Y_ADDR], npc_col[base + Npc.BITWISE_X_OR_Y_ADDR + 1] = addr + 4, x | y
+
+    # ---- bitwise partitions and the diluted check (trace.rs:432-588)
+    un_col, od_col = cols[COL_DILUTED_UNORDERED], cols[COL_DILUTED_ORDERED]
+    mask64 = (1 << 64) - 1
+    diluted_pool = []
+    shifted_cells = (1, 65, 33, 97)                  # Bits16Chunk3Offset{0,1,2,3}ResShifted
+    for i in range(n // step):
+        x, y = bw.get(i, (0, 0))
+        base = i * step
+        parts = [[_partition64((v >> (64 * c)) & mask64) for c in range(4)] for v in (x, y, x & y, x ^ y)]
+        for k in range(4):                           # shifts that make the unpacking unique (trace.rs:447-473)
+            v = parts[2][3][k] + parts[3][3][k]
+            sh = 8 if k == 3 else 4
+            if (v << sh) >> sh != v or (v << sh) >= 1 << 64:
+                raise ValueError("bitwise instance %d: top segment does not fit" % i)
+            un_col[base + shifted_cells[k]] = v << sh
+            diluted_pool.append(_undilute(v << sh))
+        for pidx, part in enumerate(parts):          # x, y, x&y, x^y: 32 rows each
+            for c in range(4):
+                for st_ in range(4):
+                    un_col[base + 32 * pidx + 8 * c + 2 * st_] = part[c][st_]
+                    diluted_pool.append(_undilute(part[c][st_]))
+    lo, hi = 0, (1 << DILUTED_CHECK_N_BITS) - 1
+    ordered = sorted(diluted_pool)
+    if ordered and (ordered[0] < lo or ordered[-1] > hi):
+        raise ValueError("diluted value out of range")
+    present = set(ordered)
+    padding = [v for v in range(lo, hi + 1) if v not in present]    # get_ordered_values_with_padding (utils.rs:296-333)
+    ordered = sorted(ordered + padding)
+    pad_iter = iter(padding)
+    done = False
+    for blk in range(n // step):                     # padding goes to the free odd cells of column 1 (trace.rs:547-571)
+        for off in range(1, step, 2):
+            if off in shifted_cells:
+                continue
+            v = next(pad_iter, None)
+            if v is None:
+                done = True
+                break
+            un_col[blk * step + off] = _dilute(v)
+        if done:
+            break
+    if next(pad_iter, None) is not None or len(ordered) > n:
+        raise ValueError("diluted-check values do not fit the trace")
+    od_col[n - len(ordered):] = [_dilute(v) for v in ordered]
 
     # ---- gap fillers (trace.rs:594-625): every address between two accessed ones gets an (address, 0) access
     accessed = sorted(set(npc_col[0::2]) | {a for a, _ in public_input.public_memory})

@@ -11,32 +11,43 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EX = os.path.join(ROOT, "tests", "golden", "example")
 
 
-@pytest.fixture(scope="module")
-def example():
+def load_run():
     from sandstorm_amd import binary, public_input
-    from sandstorm_amd.layouts import recursive as rec
     with open(os.path.join(EX, "trace.bin"), "rb") as f:
         states = binary.read_register_states(f.read())
     with open(os.path.join(EX, "memory.bin"), "rb") as f:
         memory = binary.read_memory(f.read())
     pi = public_input.AirPublicInput.from_json(os.path.join(ROOT, "tests", "golden", "air_public_input_array_sum.json"))
+    return states, memory, pi
+
+
+def with_extension(rec, cols, challenges):
+    """base columns + the ORACLE's extension columns (the product's device version is compared with the oracle in
+    tests/test_gpu_extension.py) -> (all 10 columns as ints, final products)"""
     import numpy as np
     from oracle import oracle_py as oracle
-    cols = rec.base_trace(states, memory, pi)
     n = len(cols[0])
-    challenges = [pow(7, 11 + 3 * i, rec.P) for i in range(6)]
-    # the extension columns from the ORACLE's build_extension_columns on the generated columns (the product's device
-    # version is compared with it in tests/test_gpu_extension.py)
     aux = {"npc": oracle.to_mont(cols[rec.COL_NPC]), "memory": oracle.to_mont(cols[rec.COL_MEMORY]),
            "range_check": oracle.to_mont(cols[rec.COL_RANGE_CHECK]),
            "diluted_unordered": oracle.to_mont(cols[rec.COL_DILUTED_UNORDERED]),
            "diluted_ordered": oracle.to_mont(cols[rec.COL_DILUTED_ORDERED])}
     ext, lasts = oracle.build_extension_columns("recursive", aux, [oracle.to_mont([c])[0] for c in challenges], n)
-    cols = cols + [[int(v) for v in oracle.from_mont(e)] for e in ext]
-    hints = rec.Hints.from_public_input(pi, challenges, n)
-    last_mem, last_rc, last_dc = (int(v) for v in oracle.from_mont(np.stack(lasts)))
-    assert last_mem == hints.memory_quotient and last_rc == 1 and last_dc == 1     # the reference's own asserts (trace.rs:734, 757)
-    return rec, cols, rec.constraints(hints, challenges)
+    return cols + [[int(v) for v in oracle.from_mont(e)] for e in ext], [int(v) for v in oracle.from_mont(np.stack(lasts))]
+
+
+CHALLENGES = [pow(7, 11 + 3 * i, 2**251 + 17 * 2**192 + 1) for i in range(6)]
+
+
+@pytest.fixture(scope="module")
+def example():
+    from sandstorm_amd.layouts import recursive as rec
+    states, memory, pi = load_run()
+    cols, lasts = with_extension(rec, rec.base_trace(states, memory, pi), CHALLENGES)
+    hints = rec.Hints.from_public_input(pi, CHALLENGES, len(cols[0]))
+    # the reference's own asserts (trace.rs:734, 757) and the two hints that are functions of the challenges
+    assert lasts == [hints.memory_quotient, 1, 1]
+    assert cols[rec.COL_DILUTED_AGGREGATE][-1] == hints.diluted_check_cumulative_value
+    return rec, cols, rec.constraints(hints, CHALLENGES)
 
 
 def sample(domain_rows, k=3000):
@@ -51,7 +62,7 @@ def test_constraints_vanish_on_the_example_trace(example):
     rec, cols, constraints = example
     n = len(cols[0])
     assert n == 16 * 16384 and len(cols) == rec.NUM_BASE_COLUMNS + rec.NUM_EXTENSION_COLUMNS
-    assert len(constraints) >= 50 and len({c.name for c in constraints}) == len(constraints)
+    assert len(constraints) >= 68 and len({c.name for c in constraints}) == len(constraints)
     for c in constraints:
         assert rec.failing_rows(c, cols, sample(c.domain.rows(n))) == [], c.name
 
@@ -80,3 +91,32 @@ def test_a_corrupted_cell_trips_its_constraints(example):
             assert tripped, (col, cell, names)          # which of them fire depends on the instruction at that cycle
         finally:
             cols[col][cycle_row + cell] = old
+
+
+def test_bitwise_and_range_check_builtins_with_real_instances():
+    """the example run uses no builtin, so its instances are all-zero dummies: here random bitwise and 128-bit
+    range-check instances go through the same trace generation, and the builtin + diluted-check + range-check
+    constraints must still vanish (the builtins' memory cells live in their own segments, so the rest is unaffected)"""
+    from sandstorm_amd.layouts import recursive as rec
+    states, memory, pi = load_run()
+    rng = random.Random(11)
+    private = {"bitwise": [(i, rng.getrandbits(251), rng.getrandbits(251)) for i in range(40)],
+               # 16-bit parts close to the instruction offsets: the ordered range-check cells must hold every value
+               # between the extremes (a full-range value would need a longer trace, as in the reference)
+               "range_check": [(i, sum(rng.randrange(32700, 32800) << (16 * k) for k in range(8))) for i in range(25)]}
+    import copy
+    pi2 = copy.deepcopy(pi)
+    cols = rec.base_trace(states, memory, pi2, private)
+    # rc_min / rc_max of the public input must cover the builtin's 16-bit parts now
+    parts = [(v >> (16 * k)) & 0xFFFF for _, v in private["range_check"] for k in range(8)]
+    pi2.rc_min, pi2.rc_max = min(pi2.rc_min, min(parts)), max(pi2.rc_max, max(parts))
+    cols = rec.base_trace(states, memory, pi2, private)
+    cols, lasts = with_extension(rec, cols, CHALLENGES)
+    hints = rec.Hints.from_public_input(pi2, CHALLENGES, len(cols[0]))
+    assert lasts[1:] == [1, 1] and cols[rec.COL_DILUTED_AGGREGATE][-1] == hints.diluted_check_cumulative_value
+    n = len(cols[0])
+    x, y = private["bitwise"][7][1:]
+    assert cols[rec.COL_NPC][7 * 128 + rec.Npc.BITWISE_X_OR_Y_ADDR + 1] == x | y
+    for c in rec.constraints(hints, CHALLENGES):
+        if c.name.split("/")[0] in ("bitwise", "diluted_check", "rc16", "rc_builtin"):
+            assert rec.failing_rows(c, cols, sample(c.domain.rows(n))) == [], c.name
