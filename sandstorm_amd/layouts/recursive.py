@@ -1,15 +1,15 @@
 """The `recursive` layout (layouts/src/recursive/{mod,air,trace}.rs): base-trace generation from a `cairo-run`
 output and the AIR's constraints as air_program expressions.
 
-STATUS (round 1): restated are 68 of the 93 constraints — the CPU component (33: air.rs:82-443), memory and public
-memory (8: air.rs:444-497), the 16-bit range check (6: air.rs:499-538), the diluted check (7: air.rs:540-603), the
-range-check builtin (3: air.rs:899-918) and the bitwise builtin (11: air.rs:920-1081) — with every trace cell they
-read (trace.rs:95-300, 420-660): all of columns 0-4 and the range-check / auxiliary cells of columns 5 and 6.  The two
-restatements validate each other: every constraint vanishes on its domain on the trace generated from the reference's
-own example run, the memory product closes to the public-memory quotient, the range-check and diluted products to one
-and the diluted aggregate to its closed form (tests/test_layout_recursive.py).  NOT restated yet: the Pedersen
-builtin's partial sums / suffixes / slopes and its 25 constraints (air.rs:605-895; the odd cells of columns 5 and 6)
-— DESIGN.md §8 item 4; `constraints()` lists what exists.
+STATUS (round 1): all 93 constraints are restated, in the reference's order (air.rs:1083-1180) — CPU (33), memory and
+public memory (8), 16-bit range check (6), diluted check (7), Pedersen builtin (25), range-check builtin (3), bitwise
+builtin (11) — together with the base-trace generation they are checked against (trace.rs:95-660, builtins/src/
+{pedersen,bitwise,range_check}/mod.rs, layouts/src/utils.rs).  The two restatements validate each other
+(tests/test_layout_recursive.py): every constraint vanishes on its domain on the trace generated from the reference's
+own example run and on traces with real builtin instances; the memory product closes to the public-memory quotient,
+the range-check and diluted products to one, the diluted aggregate to its closed form, every Pedersen partial sum ends
+at the library's Pedersen hash; and the set of trace cells the constraints read is exactly the 133-cell mask whose
+size the reference's shipped proof confirms.
 
 Column map (air.rs:1324-1729): 0 flags | 1 diluted unordered / bitwise | 2 diluted ordered | 3 memory pool ("npc") |
 4 sorted memory | 5 range check / Pedersen partial sums | 6 auxiliary / Pedersen suffixes, slopes |
@@ -158,13 +158,14 @@ class Hints:
     diluted_check_first: int = 0
     diluted_check_cumulative_value: int = 0     # needs the challenges
     initial_bitwise_addr: int = 0
+    initial_pedersen_addr: int = 0
 
     @classmethod
     def from_public_input(cls, pi, challenges=None, trace_len=None):
         prog, exe = pi.memory_segments["program"], pi.memory_segments["execution"]
         h = cls(initial_ap=exe[0], initial_pc=prog[0], final_ap=exe[1], final_pc=prog[1], range_check_min=pi.rc_min,
                 range_check_max=pi.rc_max, initial_rc_addr=pi.memory_segments["range_check"][0],
-                initial_bitwise_addr=pi.memory_segments["bitwise"][0])
+                initial_bitwise_addr=pi.memory_segments["bitwise"][0], initial_pedersen_addr=pi.memory_segments["pedersen"][0])
         if challenges is not None:
             h.memory_quotient = public_memory_quotient(challenges[MEM_Z], challenges[MEM_A], trace_len or 16 * pi.n_steps, pi)
             h.diluted_check_cumulative_value = diluted_cumulative_value(challenges[AGG_Z], challenges[AGG_A])
@@ -384,13 +385,150 @@ def bitwise_constraints(hints: Hints) -> List[Constraint]:
     return out
 
 
+def pedersen_constraints(hints: Hints) -> List[Constraint]:
+    """air.rs:605-895.  A hash spans 2048 rows = 512 steps of 4 rows (256 for each input): suffix at row 4k of column 6,
+    slope at 4k + 2, partial sum x / y at rows 4k + 1 / 4k + 3 of column 5; the two flag cells of an input at rows 7 and
+    1022 of its 1024 rows."""
+    suffix = lambda k=0: ap.Trace(COL_AUXILIARY, 4 * k)
+    slope = lambda k=0: ap.Trace(COL_AUXILIARY, 4 * k + 2)
+    sum_x = lambda k=0: ap.Trace(COL_RANGE_CHECK, 4 * k + 1)
+    sum_y = lambda k=0: ap.Trace(COL_RANGE_CHECK, 4 * k + 3)
+    bit_251_196_192, bit_251_196 = ap.Trace(COL_AUXILIARY, 7), ap.Trace(COL_AUXILIARY, 1022)
+    point_x, point_y = ap.Table(TABLE_PEDERSEN_X), ap.Table(TABLE_PEDERSEN_Y)
+    one = ap.Const(1)
+    bit = lambda k: suffix(k) - (suffix(k + 1) + suffix(k + 1))
+    b0 = bit(0)
+    b0_negate = one - b0
+    every_1024, every_2048, every_2048_except_last = _every(1024, "every 1024th row"), _every(2048, "every 2048th row"), \
+        _every_except_last(2048, "every 2048th row but the last")
+    # (X^(n/4) - 1) / (X^(n/1024) - g^(255 n/256)): every 4th row except step 255 of an input (air.rs:652-654)
+    transition = Domain("steps 0..254 of every input", lambda n: (r for r in range(0, n, 4) if r % 1024 != 1020),
+                        lambda n, g: (_x_pow(n // 1024) - pow(g, 255 * n // 256, P)) * (_x_pow(n // 4) - 1).inverse())
+    step_252 = Domain("step 252 of every input", lambda n: range(1008, n, 1024),
+                      lambda n, g: (_x_pow(n // 1024) - pow(g, 63 * n // 64, P)).inverse())
+    step_255 = Domain("step 255 of every input", lambda n: range(1020, n, 1024),
+                      lambda n, g: (_x_pow(n // 1024) - pow(g, 255 * n // 256, P)).inverse())
+    px, py = PEDERSEN_POINTS[0]
+    H = "pedersen/hash0/ec_subset_sum/"
+    return [
+        Constraint(H + "bit_unpacking/last_one_is_zero", bit_251_196_192 * bit(0), every_1024),
+        Constraint(H + "bit_unpacking/zeroes_between_ones0", bit_251_196_192 * (suffix(1) - suffix(192) * (1 << 191)), every_1024),
+        Constraint(H + "bit_unpacking/cumulative_bit192", bit_251_196_192 - bit_251_196 * bit(192), every_1024),
+        Constraint(H + "bit_unpacking/zeroes_between_ones192", bit_251_196 * (suffix(193) - suffix(196) * (1 << 3)), every_1024),
+        Constraint(H + "bit_unpacking/cumulative_bit196", bit_251_196 - bit(251) * bit(196), every_1024),
+        Constraint(H + "bit_unpacking/zeroes_between_ones196", bit(251) * (suffix(197) - suffix(251) * (1 << 54)), every_1024),
+        Constraint(H + "booleanity_test", b0 * (b0 - one), transition),
+        Constraint(H + "bit_extraction_end", suffix(), step_252),
+        Constraint(H + "zeros_tail", suffix(), step_255),
+        Constraint(H + "add_points/slope", b0 * (sum_y() - point_y) - slope() * (sum_x() - point_x), transition),
+        Constraint(H + "add_points/x", slope() * slope() - b0 * (sum_x() + point_x + sum_x(1)), transition),
+        Constraint(H + "add_points/y", b0 * (sum_y() + sum_y(1)) - slope() * (sum_x() - sum_x(1)), transition),
+        Constraint(H + "copy_point/x", b0_negate * (sum_x(1) - sum_x()), transition),
+        Constraint(H + "copy_point/y", b0_negate * (sum_y(1) - sum_y()), transition),
+        Constraint("pedersen/hash0/copy_point/x", sum_x(256) - sum_x(255), every_2048),
+        Constraint("pedersen/hash0/copy_point/y", sum_y(256) - sum_y(255), every_2048),
+        Constraint("pedersen/hash0/init/x", sum_x() - px, every_2048),
+        Constraint("pedersen/hash0/init/y", sum_y() - py, every_2048),
+        Constraint("pedersen/input0_value0", npc_at(Npc.PEDERSEN_INPUT0_ADDR + 1) - suffix(), every_2048),
+        Constraint("pedersen/input0_addr", npc_at(2048 + Npc.PEDERSEN_INPUT0_ADDR) - (npc_at(Npc.PEDERSEN_OUTPUT_ADDR) + 1), every_2048_except_last),
+        Constraint("pedersen/init_addr", npc_at(Npc.PEDERSEN_INPUT0_ADDR) - hints.initial_pedersen_addr, FIRST_ROW),
+        Constraint("pedersen/input1_value0", npc_at(Npc.PEDERSEN_INPUT1_ADDR + 1) - suffix(256), every_2048),
+        Constraint("pedersen/input1_addr", npc_at(Npc.PEDERSEN_INPUT1_ADDR) - (npc_at(Npc.PEDERSEN_INPUT0_ADDR) + 1), every_2048),
+        Constraint("pedersen/output_value0", npc_at(Npc.PEDERSEN_OUTPUT_ADDR + 1) - sum_x(511), every_2048),
+        Constraint("pedersen/output_addr", npc_at(Npc.PEDERSEN_OUTPUT_ADDR) - (npc_at(Npc.PEDERSEN_INPUT1_ADDR) + 1), every_2048),
+    ]
+
+
+def periodic_value(table, row):
+    """value of a periodic column at a trace row it is read at (rows = 0 mod 4): the Pedersen point of step row / 4"""
+    if table in (TABLE_PEDERSEN_X, TABLE_PEDERSEN_Y):
+        return pedersen_constant_points()[(row // 4) % 512][table]
+    raise ValueError("unknown periodic column %d" % table)
+
+
 def constraints(hints: Hints, challenges=None) -> List[Constraint]:
     """what is restated so far (see the module docstring); the permutation constraints need the 6 challenges (ints)"""
     out = cpu_constraints(hints)
     if challenges is not None:
         out += memory_constraints(hints, challenges) + range_check_constraints(hints, challenges)
         out += diluted_check_constraints(hints, challenges)
-    return out + bitwise_constraints(hints)
+    return out + pedersen_constraints(hints) + bitwise_constraints(hints)
+
+
+# ---- the Pedersen builtin (builtins/src/pedersen/{mod,constants}.rs) ----------------------------------------------
+# P0 (the shift point) and the four base points, builtins/src/pedersen/constants.rs:5-30 (StarkWare's pedersen_params)
+PEDERSEN_POINTS = (
+    (2089986280348253421170679821480865132823066470938446095505822317253594081284, 1713931329540660377023406109199410414810705867260802078187082345529207694986),
+    (996781205833008774514500082376783249102396023663454813447423147977397232763, 1668503676786377725805489344771023921079126552019160156920634619255970485781),
+    (2251563274489750535117886426533222435294046428347329203627021249169616184184, 1798716007562728905295480679789526322175868328062420237419143593021674992973),
+    (2138414695194151160943305727036575959195309218611738193261179310511854807447, 113410276730064486255102093846540133784865286929052426931474106396135072156),
+    (2379962749567351885752724891227938183011949129833673362440656643086021394946, 776496453633298175483985398648758586525933812536653089401905292063708816422),
+)
+TABLE_PEDERSEN_X, TABLE_PEDERSEN_Y = 0, 1      # air_program.Table indices of the periodic columns
+
+
+def _ec_double(pt):
+    x, y = pt
+    lam = (3 * x * x + 1) * pow(2 * y, -1, P) % P            # curve y^2 = x^3 + x + beta
+    x3 = (lam * lam - 2 * x) % P
+    return x3, (lam * (x - x3) - y) % P
+
+
+def _ec_add(p1, p2):
+    (x1, y1), (x2, y2) = p1, p2
+    if x1 == x2:
+        if y1 != y2:
+            raise ValueError("point at infinity in a Pedersen partial sum")
+        return _ec_double(p1)
+    lam = (y2 - y1) * pow(x2 - x1, -1, P) % P
+    x3 = (lam * lam - x1 - x2) % P
+    return x3, (lam * (x1 - x3) - y1) % P
+
+
+_PEDERSEN_CONSTANT_POINTS = None
+
+
+def pedersen_constant_points():
+    """the 512 points of the periodic columns: 2^i P1 (i < 248), 2^i P2 (i < 4), the last one repeated up to 256, then
+    the same for P3, P4 (gen_element_steps' constant_points; builtins/src/pedersen/periodic.rs:1211-1250)"""
+    global _PEDERSEN_CONSTANT_POINTS
+    if _PEDERSEN_CONSTANT_POINTS is None:
+        pts = []
+        for lo, hi in ((PEDERSEN_POINTS[1], PEDERSEN_POINTS[2]), (PEDERSEN_POINTS[3], PEDERSEN_POINTS[4])):
+            half, acc = [], lo
+            for _ in range(248):
+                half.append(acc)
+                acc = _ec_double(acc)
+            acc = hi
+            for _ in range(4):
+                half.append(acc)
+                acc = _ec_double(acc)
+            pts += half + [half[-1]] * 4
+        _PEDERSEN_CONSTANT_POINTS = pts
+    return _PEDERSEN_CONSTANT_POINTS
+
+
+def pedersen_element_steps(x, start, which):
+    """gen_element_steps (builtins/src/pedersen/mod.rs:121-163): 256 steps (partial sum BEFORE bit i is added, suffix
+    x >> i, slope of the addition or 0) and the partial sum after them.  which: 0 for input a (P1, P2), 1 for b (P3, P4)"""
+    consts = pedersen_constant_points()[256 * which: 256 * which + 256]
+    point, steps = start, []
+    for i in range(256):
+        suffix = x >> i
+        slope = 0
+        nxt = point
+        if suffix & 1:
+            cx, cy = consts[i]
+            if cx == point[0]:
+                if cy != point[1]:
+                    raise ValueError("point at infinity in a Pedersen partial sum")
+                slope = (3 * cx * cx + 1) * pow(2 * cy, -1, P) % P           # calculate_slope's tangent case
+            else:
+                slope = (point[1] - cy) * pow(point[0] - cx, -1, P) % P      # calculate_slope(constant_point, partial_point)
+            nxt = _ec_add(point, consts[i])
+        steps.append((point, suffix % P, slope))
+        point = nxt
+    return steps, point
 
 
 # ---- base trace (trace.rs:95-232), CPU cells ----------------------------------------------------------------------
@@ -474,8 +612,7 @@ def base_trace(register_states, memory, public_input, private_input=None):
     """ExecutionTrace::new (trace.rs:95-660) for the components restated so far: the CPU cells (cpu_trace), the whole
     memory pool with the builtins' memory cells and the gap fillers, the range-check column and the sorted memory
     column.  private_input: {"pedersen": [(index, a, b)], "range_check": [(index, value)], "bitwise": [(index, x, y)]}
-    (air-private-input.json); missing instances are the reference's empty dummies.  Columns 1 and 2 and the Pedersen
-    cells of columns 5 and 6 are left zero (not restated yet)."""
+    (air-private-input.json); missing instances are the reference's empty dummies."""
     from .. import backend as be                     # host Pedersen (ss_pedersen_hash_host): no device involved
     from ..coin import canonical
     private_input = private_input or {}
@@ -512,19 +649,29 @@ def base_trace(register_states, memory, public_input, private_input=None):
         raise ValueError("range-check values do not fit the trace")
 
     # ---- builtin memory cells (trace.rs:300-420, 540-570)
-    hash00 = None
     ped = {int(i): (int(a), int(b)) for i, a, b in private_input.get("pedersen", [])}
     step = PEDERSEN_BUILTIN_RATIO * CYCLE_HEIGHT
     ped_begin = seg["pedersen"][0]
+    aux_col = cols[COL_AUXILIARY]
+    cache = {}
     for i in range(n // step):
         a, b = ped.get(i, (0, 0))
-        if (a, b) == (0, 0):
-            if hash00 is None:
-                hash00 = canonical(be.pedersen_hash_host(be.felt(0), be.felt(0)))
-            out = hash00
-        else:
-            out = canonical(be.pedersen_hash_host(be.felt(a), be.felt(b)))
+        if (a, b) not in cache:                      # pedersen::InstanceTrace::new (builtins/src/pedersen/mod.rs:81-118)
+            a_steps, mid = pedersen_element_steps(a % P, PEDERSEN_POINTS[0], 0)
+            b_steps, end = pedersen_element_steps(b % P, mid, 1)
+            if canonical(be.pedersen_hash_host(be.felt(a), be.felt(b))) != b_steps[-1][0][0]:
+                raise ValueError("Pedersen partial sums do not end at the hash")        # the reference's own assert
+            cache[(a, b)] = (a_steps + b_steps, b_steps[-1][0][0])
+        steps, out = cache[(a, b)]
         base, addr = i * step, ped_begin + 3 * i
+        for j, (point, suffix, slope) in enumerate(steps):
+            r = base + 4 * j
+            rc_col[r + 1], rc_col[r + 3] = point
+            aux_col[r], aux_col[r + 2] = suffix, slope
+        for half, v in ((0, a), (1, b)):             # the flags that make the bit decomposition unique (trace.rs:383-392)
+            b251, b196, b192 = (v >> 251) & 1, (v >> 196) & 1, (v >> 192) & 1
+            aux_col[base + 1024 * half + 1022] = b251 & b196
+            aux_col[base + 1024 * half + 7] = b251 & b196 & b192
         for off, (ad, val) in ((Npc.PEDERSEN_INPUT0_ADDR, (addr, a)), (Npc.PEDERSEN_INPUT1_ADDR, (addr + 1, b)),
                                (Npc.PEDERSEN_OUTPUT_ADDR, (addr + 2, out))):
             npc_col[base + off], npc_col[base + off + 1] = ad, val % P
@@ -622,7 +769,7 @@ def failing_rows(constraint: Constraint, cols, rows=None, limit=5):
     n = len(cols[0])
     bad = []
     for r in (constraint.domain.rows(n) if rows is None else rows):
-        v = ap.evaluate(constraint.numerator, P, None, lambda c, o: cols[c][(r + o) % n], lambda t: 0)
+        v = ap.evaluate(constraint.numerator, P, None, lambda c, o: cols[c][(r + o) % n], lambda t: periodic_value(t, r))
         if v:
             bad.append(r)
             if len(bad) >= limit:

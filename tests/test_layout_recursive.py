@@ -62,7 +62,7 @@ def test_constraints_vanish_on_the_example_trace(example):
     rec, cols, constraints = example
     n = len(cols[0])
     assert n == 16 * 16384 and len(cols) == rec.NUM_BASE_COLUMNS + rec.NUM_EXTENSION_COLUMNS
-    assert len(constraints) >= 68 and len({c.name for c in constraints}) == len(constraints)
+    assert len(constraints) == 93                      # the reference's count (air.rs:1083-1180) and len({c.name for c in constraints}) == len(constraints)
     for c in constraints:
         assert rec.failing_rows(c, cols, sample(c.domain.rows(n))) == [], c.name
 
@@ -120,3 +120,44 @@ def test_bitwise_and_range_check_builtins_with_real_instances():
     for c in rec.constraints(hints, CHALLENGES):
         if c.name.split("/")[0] in ("bitwise", "diluted_check", "rc16", "rc_builtin"):
             assert rec.failing_rows(c, cols, sample(c.domain.rows(n))) == [], c.name
+
+
+def test_pedersen_builtin_with_real_instances():
+    """random inputs, the all-flags value p - 1 = 2^251 + 2^196 + 2^192, single-bit and zero inputs"""
+    from sandstorm_amd.layouts import recursive as rec
+    states, memory, pi = load_run()
+    rng = random.Random(5)
+    top = (1 << 251) | (1 << 196) | (1 << 192)
+    assert top == rec.P - 1
+    private = {"pedersen": [(0, rng.getrandbits(250), rng.getrandbits(250)), (1, top, (1 << 251) | (1 << 196)), (2, 0, 5), (3, 1 << 251, 1)]}
+    cols = rec.base_trace(states, memory, pi, private)
+    n = len(cols[0])
+    assert cols[rec.COL_AUXILIARY][2048 + 7] == 1 and cols[rec.COL_AUXILIARY][2048 + 1022] == 1      # instance 1, input a: all three bits
+    assert cols[rec.COL_AUXILIARY][2048 + 1024 + 7] == 0 and cols[rec.COL_AUXILIARY][2048 + 1024 + 1022] == 1
+    for c in rec.constraints(rec.Hints.from_public_input(pi)):
+        if c.name.startswith("pedersen"):
+            rows = list(c.domain.rows(n))
+            rows = rows if len(rows) <= 4000 else rows[:3500] + rows[-500:]
+            assert rec.failing_rows(c, cols, rows) == [], c.name
+
+
+def test_mask_is_the_reference_mask():
+    """the trace cells the restated constraints read = the 133-cell mask extracted from the reference's source
+    (its size is the length of the out-of-domain vector in the reference's shipped recursive proof)"""
+    from sandstorm_amd import synthetic_air
+    from sandstorm_amd.layouts import recursive as rec
+    _, _, pi = load_run()
+    cells, seen = set(), set()
+
+    def walk(e):
+        if e._id in seen:
+            return
+        seen.add(e._id)
+        if e.kind == "trace":
+            cells.add(tuple(e.args))
+        elif e.kind in ("add", "sub", "mul", "inv"):
+            for a in e.args:
+                walk(a)
+    for c in rec.constraints(rec.Hints.from_public_input(pi, CHALLENGES, 1 << 18), CHALLENGES):
+        walk(c.numerator)
+    assert cells == {(c, o) for c, offs in synthetic_air.RECURSIVE_MASK.items() for o in offs} and len(cells) == 133
