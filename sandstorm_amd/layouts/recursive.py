@@ -75,63 +75,59 @@ def aux(cell, cycle_offset=0):
     return ap.Trace(COL_AUXILIARY, CYCLE_HEIGHT * cycle_offset + cell)
 
 
-# ---- domains: where a constraint's numerator must vanish, and the inverse of the zerofier the reference divides by
+# ---- domains: where a constraint's numerator must vanish, and the zerofier quotient the reference multiplies by ----
+# A factor is (p, e): X^p - g^e with g the trace-domain generator; a domain's multiplier is prod(num) / prod(den).
 @dataclass
 class Domain:
     name: str
-    rows: Callable                  # trace length -> iterable of rows
-    zerofier_inv: Callable          # (trace length, g = trace-domain generator) -> Expr in X
+    rows: Callable                  # trace length -> iterable of rows where the numerator must vanish
+    num: Callable                   # trace length -> list of factors (p, e)
+    den: Callable
 
-
-def _x_pow(k):
-    return ap.X ** k if k > 1 else ap.X
-
-
-ALL_CYCLES = Domain("every cycle", lambda n: range(0, n, CYCLE_HEIGHT),
-                    lambda n, g: (_x_pow(n // CYCLE_HEIGHT) - 1).inverse())
-ALL_CYCLES_EXCEPT_LAST = Domain("every cycle but the last", lambda n: range(0, n - CYCLE_HEIGHT, CYCLE_HEIGHT),
-                                lambda n, g: (ap.X - pow(g, n - CYCLE_HEIGHT, P)) * (_x_pow(n // CYCLE_HEIGHT) - 1).inverse())
-# (X^n - 1) / (X^(n/16) - g^(15 n/16)): every row whose index is not 15 mod 16 (air.rs:140-145)
-FLAG_ROWS = Domain("every row holding a flag", lambda n: (r for r in range(n) if r % CYCLE_HEIGHT != 15),
-                   lambda n, g: (_x_pow(n // CYCLE_HEIGHT) - pow(g, 15 * n // CYCLE_HEIGHT, P)) * (_x_pow(n) - 1).inverse())
-FLAG_ZERO_ROWS = Domain("the 16th row of every cycle", lambda n: range(15, n, CYCLE_HEIGHT),
-                        lambda n, g: (_x_pow(n // CYCLE_HEIGHT) - pow(g, 15 * n // CYCLE_HEIGHT, P)).inverse())
-FIRST_ROW = Domain("first row", lambda n: [0], lambda n, g: (ap.X - 1).inverse())
-LAST_CYCLE = Domain("first row of the last cycle", lambda n: [n - CYCLE_HEIGHT],
-                    lambda n, g: (ap.X - pow(g, n - CYCLE_HEIGHT, P)).inverse())
+    def multiplier_at(self, n, x):
+        """prod(num) / prod(den) at an arbitrary point x (the verifier's side of the out-of-domain identity)"""
+        g = pow(3, (P - 1) // n, P)
+        val = 1
+        for p_, e in self.num(n):
+            val = val * (pow(x, p_, P) - pow(g, e, P)) % P
+        d = 1
+        for p_, e in self.den(n):
+            d = d * (pow(x, p_, P) - pow(g, e, P)) % P
+        return val * pow(d, -1, P) % P
 
 
 def _every(k, name):
-    """rows 0, k, 2k, ...: zerofier X^(n/k) - 1"""
-    return Domain(name, lambda n: range(0, n, k), lambda n, g: (_x_pow(n // k) - 1).inverse())
+    """rows 0, k, 2k, ...: 1 / (X^(n/k) - 1)"""
+    return Domain(name, lambda n: range(0, n, k), lambda n: [], lambda n: [(n // k, 0)])
 
 
 def _every_except_last(k, name):
-    return Domain(name, lambda n: range(0, n - k, k), lambda n, g: (ap.X - pow(g, n - k, P)) * (_x_pow(n // k) - 1).inverse())
+    return Domain(name, lambda n: range(0, n - k, k), lambda n: [(1, n - k)], lambda n: [(n // k, 0)])
 
 
 def _row_from_end(k, name):
     """the single row n - k"""
-    return Domain(name, lambda n: [n - k], lambda n, g: (ap.X - pow(g, n - k, P)).inverse())
+    return Domain(name, lambda n: [n - k], lambda n: [], lambda n: [(1, n - k)])
 
 
+ALL_CYCLES, ALL_CYCLES_EXCEPT_LAST = _every(CYCLE_HEIGHT, "every cycle"), _every_except_last(CYCLE_HEIGHT, "every cycle but the last")
+# (X^n - 1) / (X^(n/16) - g^(15 n/16)): every row whose index is not 15 mod 16 (air.rs:140-145)
+FLAG_ROWS = Domain("every row holding a flag", lambda n: (r for r in range(n) if r % CYCLE_HEIGHT != 15),
+                   lambda n: [(n // CYCLE_HEIGHT, 15 * n // CYCLE_HEIGHT)], lambda n: [(n, 0)])
+FLAG_ZERO_ROWS = Domain("the 16th row of every cycle", lambda n: range(15, n, CYCLE_HEIGHT),
+                        lambda n: [], lambda n: [(n // CYCLE_HEIGHT, 15 * n // CYCLE_HEIGHT)])
+FIRST_ROW = Domain("first row", lambda n: [0], lambda n: [], lambda n: [(1, 0)])
+LAST_CYCLE = _row_from_end(CYCLE_HEIGHT, "first row of the last cycle")
 EVERY_2ND_EXCEPT_LAST, SECOND_LAST_ROW = _every_except_last(2, "every 2nd row but the last"), _row_from_end(2, "row n-2")
 EVERY_4TH_EXCEPT_LAST, FOURTH_LAST_ROW = _every_except_last(4, "every 4th row but the last"), _row_from_end(4, "row n-4")
 EVERY_32 = _every(32, "every 32nd row")
 EVERY_ROW_EXCEPT_LAST, LAST_ROW = _every_except_last(1, "every row but the last"), _row_from_end(1, "last row")
 # (X^(n/32) - 1) / (X^(n/128) - g^(3n/4)): rows 0, 32, 64 (not 96) of every 128 (air.rs:926-928)
 BITWISE_TRANSITION = Domain("rows 0, 32, 64 of every 128", lambda n: (r for r in range(0, n, 32) if r % 128 != 96),
-                            lambda n, g: (_x_pow(n // 128) - pow(g, 3 * n // 4, P)) * (_x_pow(n // 32) - 1).inverse())
-
-
-def _segment_zerofier_inv(n, g):               # air.rs:961-978: prod_{k<16} (X^(n/128) - g^(k n/64))
-    z = _x_pow(n // 128) - 1
-    for k in range(1, 16):
-        z = z * (_x_pow(n // 128) - pow(g, k * n // 64, P))
-    return z.inverse()
-
-
-EVERY_16_BIT_SEGMENT = Domain("rows 0, 2, ..., 30 of every 128", lambda n: (r for r in range(0, n, 2) if r % 128 < 32), _segment_zerofier_inv)
+                            lambda n: [(n // 128, 3 * n // 4)], lambda n: [(n // 32, 0)])
+# air.rs:961-978: 1 / prod_{k<16} (X^(n/128) - g^(k n/64))
+EVERY_16_BIT_SEGMENT = Domain("rows 0, 2, ..., 30 of every 128", lambda n: (r for r in range(0, n, 2) if r % 128 < 32),
+                              lambda n: [], lambda n: [(n // 128, k * n // 64) for k in range(16)])
 EVERY_128, EVERY_128_EXCEPT_LAST = _every(128, "every 128th row"), _every_except_last(128, "every 128th row but the last")
 
 
@@ -403,11 +399,9 @@ def pedersen_constraints(hints: Hints) -> List[Constraint]:
         _every_except_last(2048, "every 2048th row but the last")
     # (X^(n/4) - 1) / (X^(n/1024) - g^(255 n/256)): every 4th row except step 255 of an input (air.rs:652-654)
     transition = Domain("steps 0..254 of every input", lambda n: (r for r in range(0, n, 4) if r % 1024 != 1020),
-                        lambda n, g: (_x_pow(n // 1024) - pow(g, 255 * n // 256, P)) * (_x_pow(n // 4) - 1).inverse())
-    step_252 = Domain("step 252 of every input", lambda n: range(1008, n, 1024),
-                      lambda n, g: (_x_pow(n // 1024) - pow(g, 63 * n // 64, P)).inverse())
-    step_255 = Domain("step 255 of every input", lambda n: range(1020, n, 1024),
-                      lambda n, g: (_x_pow(n // 1024) - pow(g, 255 * n // 256, P)).inverse())
+                        lambda n: [(n // 1024, 255 * n // 256)], lambda n: [(n // 4, 0)])
+    step_252 = Domain("step 252 of every input", lambda n: range(1008, n, 1024), lambda n: [], lambda n: [(n // 1024, 63 * n // 64)])
+    step_255 = Domain("step 255 of every input", lambda n: range(1020, n, 1024), lambda n: [], lambda n: [(n // 1024, 255 * n // 256)])
     px, py = PEDERSEN_POINTS[0]
     H = "pedersen/hash0/ec_subset_sum/"
     return [
@@ -775,3 +769,177 @@ def failing_rows(constraint: Constraint, cols, rows=None, limit=5):
             if len(bad) >= limit:
                 break
     return bad
+
+
+# ---- the composition constraint and its tables (composition_constraint, air.rs:1183-1199) ---------------------------
+class Tables:
+    """The wave-uniform data the composition reads besides the trace: the two Pedersen periodic columns and the zerofier
+    multipliers.  On the LDE coset x_i = offset * w_N^i a power X^(n/k) has period blowup * k in i, so every multiplier
+    prod(X^p - c) / prod(X^p - c') with p > 1 is a short periodic table; a denominator X - c (first / last rows) is a
+    full-length table of inverses (ss_inverse_table); a numerator X - c is evaluated in the program."""
+
+    def __init__(self, n, blowup=2, offset=3):
+        self.n, self.N, self.offset = n, n * blowup, offset
+        self.g = pow(3, (P - 1) // n, P)
+        self.w = pow(3, (P - 1) // self.N, P)
+        self.specs = [("pedersen", TABLE_PEDERSEN_X), ("pedersen", TABLE_PEDERSEN_Y)]
+        self._index = {}
+
+    def _table(self, spec):
+        if spec not in self._index:
+            self._index[spec] = len(self.specs)
+            self.specs.append(spec)
+        return ap.Table(self._index[spec])
+
+    def multiplier(self, domain: Domain):
+        num, den = domain.num(self.n), domain.den(self.n)
+        periodic = (tuple(f for f in num if f[0] > 1), tuple(f for f in den if f[0] > 1))
+        expr = self._table(("periodic",) + periodic) if periodic != ((), ()) else None
+        for p_, e in num:
+            if p_ == 1:
+                lin = ap.X - pow(self.g, e, P)
+                expr = lin if expr is None else expr * lin
+        for p_, e in den:
+            if p_ == 1:
+                t = self._table(("inverse", e))
+                expr = t if expr is None else expr * t
+        return expr
+
+    # -- values
+    def length(self, spec):
+        if spec[0] == "pedersen":
+            return 2048 * (self.N // self.n)
+        if spec[0] == "inverse":
+            return self.N
+        return max(self.N // p_ for fs in spec[1:] for p_, _ in fs)
+
+    def value_at(self, spec, x):
+        """the table's underlying function at an arbitrary point (the verifier needs it at z)"""
+        if spec[0] == "pedersen":
+            return _poly_eval(_pedersen_coefficients(spec[1]), pow(x, self.n // 2048, P))
+        if spec[0] == "inverse":
+            return pow(x - pow(self.g, spec[1], P), -1, P)
+        val, d = 1, 1
+        for p_, e in spec[1]:
+            val = val * (pow(x, p_, P) - pow(self.g, e, P)) % P
+        for p_, e in spec[2]:
+            d = d * (pow(x, p_, P) - pow(self.g, e, P)) % P
+        return val * pow(d, -1, P) % P
+
+    def host_values(self, spec):
+        """the table over the LDE coset as python ints (tests, small traces; the device builds the long ones itself)"""
+        length = self.length(spec)
+        if spec[0] == "pedersen":
+            coeffs = _pedersen_coefficients(spec[1])
+            base, step = pow(self.offset, self.n // 2048, P), pow(self.w, self.n // 2048, P)
+            out, x = [], base
+            for _ in range(length):
+                out.append(_poly_eval(coeffs, x))
+                x = x * step % P
+            return out
+        if spec[0] == "inverse":
+            c = pow(self.g, spec[1], P)
+            vals, x = [], self.offset
+            for _ in range(length):
+                vals.append((x - c) % P)
+                x = x * self.w % P
+            return _batch_inverse(vals)
+        out = []
+        for i in range(length):
+            x = self.offset * pow(self.w, i, P) % P
+            out.append(self.value_at(spec, x))
+        return out
+
+
+def _poly_eval(coeffs, x):
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % P
+    return acc
+
+
+_PEDERSEN_COEFFS = {}
+
+
+def _pedersen_coefficients(which):
+    """coefficients of the degree < 512 interpolant with value points[j][which] at w_512^j (the reference stores them as
+    HASH_POINTS_{X,Y}_COEFFS; its periodic_*_evals_match tests pin exactly this relation)"""
+    if which not in _PEDERSEN_COEFFS:
+        vals = [pt[which] for pt in pedersen_constant_points()]
+        m = len(vals)
+        w_inv = pow(pow(3, (P - 1) // m, P), -1, P)
+        m_inv = pow(m, -1, P)
+        # radix-2 inverse transform in plain python (512 points)
+        a = list(vals)
+        rev = [int(format(i, "0%db" % (m.bit_length() - 1))[::-1], 2) for i in range(m)]
+        a = [a[rev[i]] for i in range(m)]
+        length = 2
+        while length <= m:
+            wl = pow(w_inv, m // length, P)
+            for start in range(0, m, length):
+                wcur = 1
+                for k in range(length // 2):
+                    u, v = a[start + k], a[start + k + length // 2] * wcur % P
+                    a[start + k], a[start + k + length // 2] = (u + v) % P, (u - v) % P
+                    wcur = wcur * wl % P
+            length *= 2
+        _PEDERSEN_COEFFS[which] = [v * m_inv % P for v in a]
+    return _PEDERSEN_COEFFS[which]
+
+
+def _batch_inverse(vals):
+    prefix, run = [], 1
+    for v in vals:
+        prefix.append(run)
+        run = run * v % P
+    inv = pow(run, -1, P)
+    out = [0] * len(vals)
+    for i in range(len(vals) - 1, -1, -1):
+        out[i] = inv * prefix[i] % P
+        inv = inv * vals[i] % P
+    return out
+
+
+def composition(n, hints: Hints, challenges, alpha, tables: Tables):
+    """sum_i alpha^i * constraint_i (air.rs:1183-1199), constraint_i = numerator_i * multiplier(domain_i); constraints that
+    share a domain are summed before the one multiplication by its multiplier"""
+    groups, order, apow = {}, [], 1
+    for c in constraints(hints, challenges):
+        term = c.numerator * ap.Const(apow) if apow != 1 else c.numerator
+        key = id(c.domain) if c.domain.name not in _SHARED_DOMAINS else c.domain.name
+        if key not in groups:
+            groups[key] = [c.domain, term]
+            order.append(key)
+        else:
+            groups[key][1] = groups[key][1] + term
+        apow = apow * alpha % P
+    total = None
+    for key in order:
+        domain, partial = groups[key]
+        term = partial * tables.multiplier(domain)
+        total = term if total is None else total + term
+    return total
+
+
+# domains built inside pedersen_constraints() are fresh objects per call: group those by name
+_SHARED_DOMAINS = {"every 1024th row", "every 2048th row", "every 2048th row but the last", "steps 0..254 of every input",
+                   "step 252 of every input", "step 255 of every input"}
+
+
+def mask(hints=None):
+    """trace_arguments(): the sorted (column, row offset) cells the constraints read - the order of the OOD vector"""
+    cells, seen = set(), set()
+
+    def walk(e):
+        if e._id in seen:
+            return
+        seen.add(e._id)
+        if e.kind == "trace":
+            cells.add(tuple(e.args))
+        elif e.kind in ("add", "sub", "mul", "inv"):
+            for a in e.args:
+                walk(a)
+    h = hints or Hints(0, 0, 0, 0)
+    for c in constraints(h, [2, 3, 5, 7, 11, 13]):
+        walk(c.numerator)
+    return sorted(cells)

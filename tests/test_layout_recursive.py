@@ -161,3 +161,77 @@ def test_mask_is_the_reference_mask():
     for c in rec.constraints(rec.Hints.from_public_input(pi, CHALLENGES, 1 << 18), CHALLENGES):
         walk(c.numerator)
     assert cells == {(c, o) for c, offs in synthetic_air.RECURSIVE_MASK.items() for o in offs} and len(cells) == 133
+
+
+def test_domain_rows_are_the_zeros_of_their_zerofiers():
+    """both sides are restated from the reference's zerofier expressions: at a trace point g^r the multiplier
+    prod(num) / prod(den) has a pole exactly on the rows where the constraint is enforced"""
+    from sandstorm_amd.layouts import recursive as rec
+    _, _, pi = load_run()
+    n = 4096
+    g = pow(3, (rec.P - 1) // n, rec.P)
+    doms = {}
+    for c in rec.constraints(rec.Hints.from_public_input(pi, CHALLENGES, n), CHALLENGES):
+        doms[c.domain.name] = c.domain
+    assert len(doms) >= 20
+    xs = [pow(g, r, rec.P) for r in range(n)]
+    for name, d in doms.items():
+        want = set(d.rows(n))
+        got = set()
+        for r, x in enumerate(xs):
+            den = 1
+            for p_, e in d.den(n):
+                den = den * (pow(x, p_, rec.P) - pow(g, e, rec.P)) % rec.P
+            num = 1
+            for p_, e in d.num(n):
+                num = num * (pow(x, p_, rec.P) - pow(g, e, rec.P)) % rec.P
+            if den == 0 and num != 0:
+                got.add(r)
+            assert not (den == 0 and num == 0) or r not in want, name       # a cancelled zero is a row that is NOT enforced
+        assert got == want, name
+
+
+def test_composition_of_the_example_is_a_polynomial(example, oracle):
+    """The whole chain on the CPU with the oracle: LDE of the 10 real columns, the composition constraint
+    sum alpha^i C_i (air.rs:1183-1199) lowered to the constraint VM with its periodic / zerofier tables, evaluated on
+    the LDE coset — it interpolates to a polynomial of degree exactly 2n - 3 (the first-row constraints), i.e. every
+    constraint is divisible by its zerofier; the VM agrees with the big-integer definition at sampled points; one
+    corrupted trace cell destroys the divisibility."""
+    import numpy as np
+    from sandstorm_amd import air_program as ap
+    rec, cols, _ = example
+    _, _, pi = load_run()
+    n = len(cols[0])
+    N, log_n = 2 * n, n.bit_length() - 1
+    hints = rec.Hints.from_public_input(pi, CHALLENGES, n)
+    alpha = pow(5, 77, rec.P)
+    tables = rec.Tables(n)
+    expr = rec.composition(n, hints, CHALLENGES, alpha, tables)
+    prog = ap.lower(expr, rec.P)
+    assert rec.mask() == sorted(rec.mask()) and len(rec.mask()) == 133
+    vals, desc, off = [], [], 0
+    for spec in tables.specs:
+        v = tables.host_values(spec)
+        desc += [off, len(v).bit_length() - 1]
+        off += len(v)
+        vals += v
+    tab, g = oracle.to_mont(vals), oracle.to_mont([3])[0]
+
+    def composition_coefficients(columns):
+        lde = [oracle.lde(oracle.to_mont(c), 1, g)[0] for c in columns]
+        out = oracle.eval_program(prog.code, oracle.to_mont(prog.consts), tab, desc, prog.n_slots, lde, log_n, 1, g)
+        return lde, out, oracle.ntt(out, inverse=True, offset=g)
+
+    lde, out, coeffs = composition_coefficients(cols)
+    nonzero = np.nonzero(coeffs.any(axis=1))[0]
+    assert int(nonzero[-1]) == 2 * n - 3
+    w = pow(3, (rec.P - 1) // N, rec.P)
+    for i in (0, 1, 54321, N - 1):
+        x = 3 * pow(w, i, rec.P) % rec.P
+        want = ap.evaluate(expr, rec.P, x, lambda c, o: int(oracle.from_mont(lde[c][(i + 2 * o) % N][None])[0]),
+                           lambda t: tables.value_at(tables.specs[t], x))
+        assert int(oracle.from_mont(out[i][None])[0]) == want
+    bad = [list(c) for c in cols[:1]] + cols[1:]
+    bad[0][16 * 777 + 3] = (bad[0][16 * 777 + 3] + 1) % rec.P          # one flag cell of one cycle
+    _, _, coeffs_bad = composition_coefficients(bad)
+    assert coeffs_bad[-1].any() and coeffs_bad[-2].any()
