@@ -943,3 +943,76 @@ def mask(hints=None):
     for c in constraints(h, [2, 3, 5, 7, 11, 13]):
         walk(c.numerator)
     return sorted(cells)
+
+
+# ---- the layout as the prover and the verifier see it ------------------------------------------------------------------
+_TABLES = {}
+
+
+def tables_for(n, blowup=2, offset=3):
+    """the table registry of trace length n with every table the composition refers to registered (their set and order
+    do not depend on the challenges)"""
+    key = (n, blowup, offset)
+    if key not in _TABLES:
+        t = Tables(n, blowup, offset)
+        composition(n, Hints(0, 0, 0, 0), [2, 3, 5, 7, 11, 13], 17, t)
+        _TABLES[key] = t
+    return _TABLES[key]
+
+
+def make_air(ctx, public_input, n, log_blowup=1, lde_offset=3):
+    """-> prover.Air for this public input and trace length.  The tables are built once: the periodic ones on the host
+    (a few thousand entries), the five full-length inverse tables on the device (ss_inverse_table)."""
+    from .. import backend as be
+    from ..coin import canonical
+    from ..prover import Air
+    tables = tables_for(n, 1 << log_blowup, lde_offset)
+    lengths = [tables.length(s) for s in tables.specs]
+    desc, off = [], 0
+    for ln in lengths:
+        desc += [off, ln.bit_length() - 1]
+        off += ln
+    buf = ctx.alloc(32 * off)
+    g = be.felt(lde_offset)
+    for spec, ln, start in zip(tables.specs, lengths, desc[0::2]):
+        view = be.DeviceView(buf, 32 * start, 32 * ln)
+        if spec[0] == "inverse":
+            ctx.inverse_table((n << log_blowup).bit_length() - 1, g, be.felt(pow(tables.g, spec[1], P)), view)
+        else:
+            import numpy as np
+            host = np.stack([be.felt(v) for v in tables.host_values(spec)])
+            be.check(ctx.lib.ss_upload(ctx.handle, view.ptr, host.ctypes.data, host.nbytes))
+
+    def build_program(n_, challenges, comp_coeff):
+        if n_ != n:
+            raise ValueError("this Air was built for trace length %d" % n)
+        ch = [canonical(c) for c in challenges]
+        hints = Hints.from_public_input(public_input, ch, n)
+        expr = composition(n, hints, ch, canonical(comp_coeff), tables)
+        return ap.lower(expr, P), buf, desc
+
+    air = Air("recursive", NUM_BASE_COLUMNS, NUM_EXTENSION_COLUMNS, 6, mask(), build_program)
+    air.table_buffer = buf
+    return air
+
+
+def verifier_air(public_input, log_blowup=1, lde_offset=3):
+    """-> verifier.VerifierAir: the same composition, with the tables' underlying functions evaluated at the
+    out-of-domain point"""
+    from ..verifier import VerifierAir
+
+    def comp(n, challenges, alpha):
+        return composition(n, Hints.from_public_input(public_input, challenges, n), challenges, alpha, tables_for(n, 1 << log_blowup, lde_offset))
+
+    def table_at(n, x, t):
+        tables = tables_for(n, 1 << log_blowup, lde_offset)
+        return tables.value_at(tables.specs[t], x)
+    return VerifierAir(NUM_BASE_COLUMNS, NUM_EXTENSION_COLUMNS, 6, mask(), comp, table_at)
+
+
+def trace_columns(ctx, base_cols_device, n):
+    """extension.TraceColumns of a base trace resident in HBM (columns 3, 4, 5, 1, 2: trace.rs:652-660)"""
+    from ..extension import TraceColumns
+    return TraceColumns(npc=base_cols_device[COL_NPC], memory=base_cols_device[COL_MEMORY], range_check=base_cols_device[COL_RANGE_CHECK],
+                        trace_len=n, diluted_unordered=base_cols_device[COL_DILUTED_UNORDERED],
+                        diluted_ordered=base_cols_device[COL_DILUTED_ORDERED])

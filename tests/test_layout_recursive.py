@@ -231,6 +231,20 @@ def test_composition_of_the_example_is_a_polynomial(example, oracle):
         want = ap.evaluate(expr, rec.P, x, lambda c, o: int(oracle.from_mont(lde[c][(i + 2 * o) % N][None])[0]),
                            lambda t: tables.value_at(tables.specs[t], x))
         assert int(oracle.from_mont(out[i][None])[0]) == want
+    # the verifier's side: out-of-domain identity sum alpha^i C_i(z) = H0(z^2) + z H1(z^2) with the OOD values computed
+    # from the polynomials themselves (trace coefficients at z w^k, even / odd halves of the composition at z^2)
+    va = rec.verifier_air(pi)
+    assert va.mask == rec.mask()
+    z = pow(11, 1234567, rec.P)
+    wn = pow(3, (rec.P - 1) // n, rec.P)
+    trace_coeffs = [oracle.ntt(oracle.to_mont(c), inverse=True) for c in cols]
+    ood = {(c, o): int(oracle.from_mont(oracle.poly_eval(trace_coeffs[c], oracle.to_mont([z * pow(wn, o, rec.P) % rec.P])[0])[None])[0])
+           for c, o in va.mask}
+    lhs = ap.evaluate(va.composition(n, CHALLENGES, alpha), rec.P, z, lambda c, o: ood[(c, o)], lambda t: va.table_at(n, z, t))
+    h0, h1 = np.ascontiguousarray(coeffs[0::2]), np.ascontiguousarray(coeffs[1::2])
+    z2 = oracle.to_mont([z * z % rec.P])[0]
+    rhs = (int(oracle.from_mont(oracle.poly_eval(h0, z2)[None])[0]) + z * int(oracle.from_mont(oracle.poly_eval(h1, z2)[None])[0])) % rec.P
+    assert lhs == rhs
     bad = [list(c) for c in cols[:1]] + cols[1:]
     bad[0][16 * 777 + 3] = (bad[0][16 * 777 + 3] + 1) % rec.P          # one flag cell of one cycle
     _, _, coeffs_bad = composition_coefficients(bad)

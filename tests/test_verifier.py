@@ -108,3 +108,26 @@ def test_fresh_cpp_host_proof_verifies(oracle, log_n):
     air.close()
     assert len(verifier.verify(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)) <= 20
     ctx.close()
+
+
+def test_committed_proof_of_the_reference_example_verifies():
+    """tests/golden/array_sum_recursive_eth.proof: the reference's array-sum example (recursive layout, 2^14 steps)
+    proven on an MI355X by tests/test_gpu_real_air.py with the restated 93-constraint AIR, seeded from its
+    air-public-input.json; verified here on the CPU with the same AIR; any other public input is rejected"""
+    import copy
+    from sandstorm_amd import backend as be, public_input, verifier, wire
+    from sandstorm_amd.layouts import recursive as rec
+    pi = public_input.AirPublicInput.from_json(os.path.join(GOLD, "air_public_input_array_sum.json"))
+    with open(os.path.join(GOLD, "array_sum_recursive_eth.proof"), "rb") as f:
+        raw = f.read()
+    seed = public_input.public_coin_seed(pi, be.COIN_SOLIDITY)
+    positions = verifier.verify(raw, rec.verifier_air(pi), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
+    w = wire.parse(raw)
+    assert w.trace_len == 16 * pi.n_steps and len(w.ood_trace) == 133 and len(positions) == len(w.base_openings)
+    pi2 = copy.deepcopy(pi)
+    pi2.rc_max += 1                                           # a different claim: other seed, other hints
+    with pytest.raises(verifier.VerificationError):
+        verifier.verify(raw, rec.verifier_air(pi2), be.TREE_KECCAK, be.COIN_SOLIDITY, public_input.public_coin_seed(pi2, be.COIN_SOLIDITY))
+    # same seed, wrong hint: the transcript replays, the out-of-domain identity must catch it
+    with pytest.raises(verifier.VerificationError, match="out-of-domain identity"):
+        verifier.verify(raw, rec.verifier_air(pi2), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
