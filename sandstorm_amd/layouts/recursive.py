@@ -1016,3 +1016,4 @@ def trace_columns(ctx, base_cols_device, n):
     return TraceColumns(npc=base_cols_device[COL_NPC], memory=base_cols_device[COL_MEMORY], range_check=base_cols_device[COL_RANGE_CHECK],
                         trace_len=n, diluted_unordered=base_cols_device[COL_DILUTED_UNORDERED],
                         diluted_ordered=base_cols_device[COL_DILUTED_ORDERED])
+
