@@ -16,41 +16,6 @@ static void ok(ss_status s) {
     if (s != SS_OK) throw std::runtime_error(ss_last_error());
 }
 
-// Felt helpers on canonical small values
-static Felt felt_inv(const Felt &a) {
-    // a^(p-2): p - 2 = 2^251 + 2^196 + 2^192 - 1 ; plain square-and-multiply on the host (rare)
-    Felt r = a;
-    for (int i = 250; i >= 0; --i) {
-        r = felt_mul(r, r);
-        if (i == 196 || i < 192) r = felt_mul(r, a);
-    }
-    return r;
-}
-static Felt felt_neg(const Felt &a) {
-    static const uint64_t P[4] = {1ull, 0ull, 0ull, 0x0800000000000011ull};
-    if ((a[0] | a[1] | a[2] | a[3]) == 0) return a;
-    Felt r;
-    unsigned __int128 br = 0;
-    for (int i = 0; i < 4; ++i) { unsigned __int128 d = (unsigned __int128)P[i] - a[i] - br; r[i] = (uint64_t)d; br = (d >> 64) & 1; }
-    return r;
-}
-static Felt felt_sub(const Felt &a, const Felt &b) {
-    // a - b = a + (-b) with one conditional subtraction
-    static const uint64_t P[4] = {1ull, 0ull, 0ull, 0x0800000000000011ull};
-    Felt nb = felt_neg(b), r;
-    unsigned __int128 c = 0;
-    for (int i = 0; i < 4; ++i) { c += (unsigned __int128)a[i] + nb[i]; r[i] = (uint64_t)c; c >>= 64; }
-    bool ge = true;
-    for (int i = 3; i >= 0; --i) { if (r[i] > P[i]) break; if (r[i] < P[i]) { ge = false; break; } }
-    if (ge) { unsigned __int128 br = 0; for (int i = 0; i < 4; ++i) { unsigned __int128 d = (unsigned __int128)r[i] - P[i] - br; r[i] = (uint64_t)d; br = (d >> 64) & 1; } }
-    return r;
-}
-static Felt root_of_unity(uint32_t log_n) {
-    Felt c = felt_pow(felt_from_u64(3), (1ull << 59) + 17ull);
-    for (uint32_t i = 0; i < 192 - log_n; ++i) c = felt_mul(c, c);
-    return c;
-}
-
 // ---------------------------------------------------------------------------- mini
 class MiniAir : public Air {
 public:

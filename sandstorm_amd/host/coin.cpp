@@ -96,6 +96,42 @@ Felt felt_pow(const Felt &a, uint64_t e) {
     while (e) { if (e & 1) r = felt_mul(r, b); b = felt_mul(b, b); e >>= 1; }
     return r;
 }
+// more field helpers on transcript-sized data (host AIRs, trace generation)
+Felt felt_inv(const Felt &a) {
+    // a^(p-2): p - 2 = 2^251 + 2^196 + 2^192 - 1 ; plain square-and-multiply on the host (rare)
+    Felt r = a;
+    for (int i = 250; i >= 0; --i) {
+        r = felt_mul(r, r);
+        if (i == 196 || i < 192) r = felt_mul(r, a);
+    }
+    return r;
+}
+Felt felt_neg(const Felt &a) {
+    static const uint64_t P[4] = {1ull, 0ull, 0ull, 0x0800000000000011ull};
+    if ((a[0] | a[1] | a[2] | a[3]) == 0) return a;
+    Felt r;
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 4; ++i) { unsigned __int128 d = (unsigned __int128)P[i] - a[i] - br; r[i] = (uint64_t)d; br = (d >> 64) & 1; }
+    return r;
+}
+Felt felt_sub(const Felt &a, const Felt &b) {
+    // a - b = a + (-b) with one conditional subtraction
+    static const uint64_t P[4] = {1ull, 0ull, 0ull, 0x0800000000000011ull};
+    Felt nb = felt_neg(b), r;
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 4; ++i) { c += (unsigned __int128)a[i] + nb[i]; r[i] = (uint64_t)c; c >>= 64; }
+    bool ge = true;
+    for (int i = 3; i >= 0; --i) { if (r[i] > P[i]) break; if (r[i] < P[i]) { ge = false; break; } }
+    if (ge) { unsigned __int128 br = 0; for (int i = 0; i < 4; ++i) { unsigned __int128 d = (unsigned __int128)r[i] - P[i] - br; r[i] = (uint64_t)d; br = (d >> 64) & 1; } }
+    return r;
+}
+Felt root_of_unity(uint32_t log_n) {
+    Felt c = felt_pow(felt_from_u64(3), (1ull << 59) + 17ull);
+    for (uint32_t i = 0; i < 192 - log_n; ++i) c = felt_mul(c, c);
+    return c;
+}
+
+Felt felt_add(const Felt &a, const Felt &b) { return felt_sub(a, felt_neg(b)); }
 std::array<uint8_t, 32> mont_be_bytes(const Felt &f) {
     std::array<uint8_t, 32> o;
     for (int i = 0; i < 4; ++i) for (int b = 0; b < 8; ++b) o[i * 8 + b] = (uint8_t)(f[3 - i] >> (56 - 8 * b));

@@ -21,6 +21,11 @@ Felt felt_from_u64(uint64_t v);
 Felt felt_from_canonical(const Felt &value);              // little-endian limbs of an integer < p -> Montgomery
 Felt felt_mul(const Felt &a, const Felt &b);
 Felt felt_pow(const Felt &a, uint64_t e);
+Felt felt_add(const Felt &a, const Felt &b);
+Felt felt_sub(const Felt &a, const Felt &b);
+Felt felt_neg(const Felt &a);
+Felt felt_inv(const Felt &a);                            // a^(p-2); 0 -> 0
+Felt root_of_unity(uint32_t log_n);                      // 3^((p-1)/2^log_n)
 std::array<uint8_t, 32> canonical_be_bytes(const Felt &f);
 
 class PublicCoin {

@@ -8,6 +8,7 @@
 #include "extension.hpp"
 #include "prover.hpp"
 #include "public_input.hpp"
+#include "trace_recursive.hpp"
 
 using namespace ssh;
 
@@ -132,6 +133,35 @@ int ssh_public_coin_seed(int layout, uint32_t rc_min, uint32_t rc_max, uint64_t 
         if (elements_out && n_elements) { for (size_t i = 0; i < els.size(); ++i) memcpy(elements_out + 4 * i, els[i].data(), 32); *n_elements = (uint32_t)els.size(); }
         const Digest d = public_coin_seed(pi, coin_kind);
         memcpy(seed_out, d.data(), 32);
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// Base trace of the recursive layout (trace_recursive.hpp) from the raw `cairo-run` files.  Public input as in
+// ssh_public_coin_seed; instances: pedersen n x (index, a[4], b[4]) as 9 u64 each, range_check n x (index, value[4]) as 5,
+// bitwise n x (index, x[4], y[4]) as 9.  columns_out: 7 arrays of 4 * (16 * cycles) u64 (Montgomery limbs).
+int ssh_recursive_base_trace(const uint8_t *trace_bin, uint64_t trace_len, const uint8_t *memory_bin, uint64_t memory_len,
+                             uint32_t rc_min, uint32_t rc_max, uint64_t n_steps, const uint32_t *segments, const uint32_t *mem_addresses,
+                             const uint64_t *mem_values, uint64_t n_mem, const uint64_t *pedersen, uint64_t n_pedersen,
+                             const uint64_t *range_check, uint64_t n_range_check, const uint64_t *bitwise, uint64_t n_bitwise,
+                             uint64_t *const *columns_out) {
+    try {
+        AirPublicInput pi;
+        pi.layout = "recursive";
+        pi.rc_min = (uint16_t)rc_min; pi.rc_max = (uint16_t)rc_max; pi.n_steps = n_steps;
+        for (int k = 0; k < 9; ++k) { pi.segments[k].present = segments[3 * k] != 0; pi.segments[k].begin_addr = segments[3 * k + 1]; pi.segments[k].stop_ptr = segments[3 * k + 2]; }
+        pi.public_memory.resize(n_mem);
+        for (uint64_t i = 0; i < n_mem; ++i) { pi.public_memory[i].address = mem_addresses[i]; memcpy(pi.public_memory[i].value.data(), mem_values + 4 * i, 32); }
+        PrivateInput priv;
+        for (uint64_t i = 0; i < n_pedersen; ++i) { PedersenInstance p; p.index = (uint32_t)pedersen[9 * i]; memcpy(p.a.data(), pedersen + 9 * i + 1, 32); memcpy(p.b.data(), pedersen + 9 * i + 5, 32); priv.pedersen.push_back(p); }
+        for (uint64_t i = 0; i < n_range_check; ++i) { RangeCheckInstance p; p.index = (uint32_t)range_check[5 * i]; memcpy(p.value.data(), range_check + 5 * i + 1, 32); priv.range_check.push_back(p); }
+        for (uint64_t i = 0; i < n_bitwise; ++i) { BitwiseInstance p; p.index = (uint32_t)bitwise[9 * i]; memcpy(p.x.data(), bitwise + 9 * i + 1, 32); memcpy(p.y.data(), bitwise + 9 * i + 5, 32); priv.bitwise.push_back(p); }
+        const auto states = read_register_states(trace_bin, trace_len);
+        std::vector<U256> memory;
+        std::vector<uint8_t> present;
+        read_memory(memory_bin, memory_len, memory, present);
+        const auto cols = recursive_base_trace(states, memory, present, pi, priv);
+        for (size_t c = 0; c < cols.size(); ++c) memcpy(columns_out[c], cols[c].data(), cols[c].size() * 32);
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }

@@ -1,0 +1,407 @@
+#include "trace_recursive.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/sandstorm_hip.h"
+
+namespace ssh {
+
+namespace {
+
+constexpr uint64_t CYCLE_HEIGHT = 16, PUBLIC_MEMORY_STEP = 16, RANGE_CHECK_STEP = 4;
+constexpr uint64_t PEDERSEN_BUILTIN_RATIO = 128, RANGE_CHECK_BUILTIN_RATIO = 8, RANGE_CHECK_BUILTIN_PARTS = 8, BITWISE_RATIO = 8;
+constexpr uint32_t DILUTED_N_BITS = 16, DILUTED_SPACING = 4;
+constexpr uint64_t HALF_OFFSET = 1ull << 15;
+enum { COL_FLAGS, COL_DILUTED_UNORDERED, COL_DILUTED_ORDERED, COL_NPC, COL_MEMORY, COL_RANGE_CHECK, COL_AUXILIARY, NUM_COLS };
+// virtual-column offsets (layouts/src/recursive/air.rs:1324-1695)
+enum { NPC_PC = 0, NPC_INSTRUCTION = 1, NPC_PUB_MEM_ADDR = 2, NPC_MEM_OP0_ADDR = 4, NPC_MEM_DST_ADDR = 8, NPC_MEM_OP1_ADDR = 12, NPC_UNUSED_ADDR = 14,
+       NPC_PEDERSEN_INPUT0_ADDR = 10, NPC_PEDERSEN_INPUT1_ADDR = 1034, NPC_PEDERSEN_OUTPUT_ADDR = 522, NPC_RANGE_CHECK128_ADDR = 74,
+       NPC_BITWISE_POOL_ADDR = 26, NPC_BITWISE_X_OR_Y_ADDR = 42 };
+enum { RC_OFF_DST = 0, RC_ORDERED = 2, RC_OFF_OP1 = 4, RC_OFF_OP0 = 8, RC_UNUSED = 12 };
+enum { AUX_AP = 1, AUX_TMP0 = 3, AUX_OP0_MUL_OP1 = 5, AUX_FP = 9, AUX_TMP1 = 11, AUX_RES = 13 };
+// enum Flag (binary/src/lib.rs:740-772)
+enum { F_DST_REG, F_OP0_REG, F_OP1_IMM, F_OP1_FP, F_OP1_AP, F_RES_ADD, F_RES_MUL, F_PC_JUMP_ABS, F_PC_JUMP_REL, F_PC_JNZ, F_AP_ADD, F_AP_ADD1,
+       F_OPCODE_CALL, F_OPCODE_RET, F_OPCODE_ASSERT_EQ, F_ZERO };
+
+[[noreturn]] void fail(const std::string &m) { throw std::runtime_error("recursive trace: " + m); }
+
+bool felt_is_zero(const Felt &f) { return (f[0] | f[1] | f[2] | f[3]) == 0; }
+bool felt_eq(const Felt &a, const Felt &b) { return a == b; }
+U256 shr(const U256 &v, unsigned k) {
+    U256 r{};
+    const unsigned w = k / 64, b = k % 64;
+    for (unsigned i = 0; i + w < 4; ++i) {
+        r[i] = v[i + w] >> b;
+        if (b && i + w + 1 < 4) r[i] |= v[i + w + 1] << (64 - b);
+    }
+    return r;
+}
+bool bit(const U256 &v, unsigned k) { return (v[k / 64] >> (k % 64)) & 1; }
+
+struct Word {                       // binary/src/lib.rs:565-721 (instruction fields live in the low 63 bits)
+    uint64_t w;
+    bool flag(int f) const { return (w >> (48 + f)) & 1; }
+    uint64_t flag_prefix(int f) const { return f == F_ZERO ? 0 : (w >> (48 + f)) & ((1ull << (15 - f)) - 1); }
+    uint64_t off_dst() const { return w & 0xffff; }
+    uint64_t off_op0() const { return (w >> 16) & 0xffff; }
+    uint64_t off_op1() const { return (w >> 32) & 0xffff; }
+    int op1_src() const { return flag(F_OP1_IMM) + 2 * flag(F_OP1_FP) + 4 * flag(F_OP1_AP); }
+    int res_logic() const { return flag(F_RES_ADD) + 2 * flag(F_RES_MUL); }
+    int pc_update() const { return flag(F_PC_JUMP_ABS) + 2 * flag(F_PC_JUMP_REL) + 4 * flag(F_PC_JNZ); }
+};
+
+struct Mem {
+    const std::vector<U256> &m;
+    const std::vector<uint8_t> &present;
+    const U256 &at(uint64_t a) const {
+        if (a >= m.size() || !present[a]) fail("the run reads memory cell " + std::to_string(a) + " that memory.bin does not hold");
+        return m[a];
+    }
+    uint64_t small(uint64_t a) const {
+        const U256 &v = at(a);
+        if (v[1] | v[2] | v[3]) fail("memory cell " + std::to_string(a) + " is used as an address but is not one");
+        return v[0];
+    }
+};
+
+// ---- curve y^2 = x^3 + x + beta, affine (builtins/src/utils.rs)
+struct Pt { Felt x, y; };
+Pt ec_double(const Pt &p) {
+    const Felt xx = felt_mul(p.x, p.x);
+    const Felt lam = felt_mul(felt_add(felt_add(felt_add(xx, xx), xx), felt_from_u64(1)), felt_inv(felt_add(p.y, p.y)));
+    const Felt x3 = felt_sub(felt_mul(lam, lam), felt_add(p.x, p.x));
+    return Pt{x3, felt_sub(felt_mul(lam, felt_sub(p.x, x3)), p.y)};
+}
+Pt ec_add(const Pt &a, const Pt &b) {
+    if (felt_eq(a.x, b.x)) {
+        if (!felt_eq(a.y, b.y)) fail("point at infinity in a Pedersen partial sum");
+        return ec_double(a);
+    }
+    const Felt lam = felt_mul(felt_sub(b.y, a.y), felt_inv(felt_sub(b.x, a.x)));
+    const Felt x3 = felt_sub(felt_sub(felt_mul(lam, lam), a.x), b.x);
+    return Pt{x3, felt_sub(felt_mul(lam, felt_sub(a.x, x3)), a.y)};
+}
+// builtins/src/pedersen/constants.rs:5-30, canonical little-endian limbs
+const uint64_t PEDERSEN_POINTS[5][2][4] = {
+    {{0x551fde4050ca6804ull, 0x716b0b1022947733ull, 0x00ee1b87eb599f16ull, 0x049ee3eba8c16007ull}, {0xd0405d266e10268aull, 0x4e621062c0e056c1ull, 0xf346d49d06ea0ed3ull, 0x03ca0cfe4b3bc6ddull}},
+    {{0x1080d17957ebe47bull, 0x8fa8120b6d56eb0cull, 0x969c748655fca9e5ull, 0x0234287dcbaffe7full}, {0x6ed0268ee89e5615ull, 0x940135dd7a6c94ccull, 0x1e889527d41f4e39ull, 0x03b056f100f96fb2ull}},
+    {{0xb7a6932dba8aa378ull, 0x99099ec1de5e3018ull, 0x3f9dab2656558f33ull, 0x04fa56f376c83db3ull}, {0x5168f4e80ff5b54dull, 0x562761f92a7a23b4ull, 0x8113e0c0e47e4401ull, 0x03fa0984c931c9e3ull}},
+    {{0x3aa372f0bd2d6997ull, 0x40c690c74709e90full, 0x764910f75b45f74bull, 0x04ba4cc166be8decull}, {0x48151f27b24b219cull, 0xcac5c59a5ce5ae7cull, 0x4b971e46c4ede85full, 0x0040301cf5c1751full}},
+    {{0xd36ff12c49a58202ull, 0x2ca65048d53fb325ull, 0x6e44cca8f61a63bbull, 0x054302dcb0e6cc1cull}, {0x879dcc77e99c2426ull, 0xce98ad783c25561aull, 0xb348046268d8ae25ull, 0x01b77b3e37d13504ull}},
+};
+Pt pedersen_point(int k) {
+    U256 x, y;
+    memcpy(x.data(), PEDERSEN_POINTS[k][0], 32); memcpy(y.data(), PEDERSEN_POINTS[k][1], 32);
+    return Pt{felt_from_canonical(x), felt_from_canonical(y)};
+}
+const std::vector<Pt> &constant_points() {          // gen_element_steps' constant_points for both inputs (512 entries)
+    static std::vector<Pt> pts;
+    if (pts.empty()) {
+        for (int e = 0; e < 2; ++e) {
+            std::vector<Pt> half;
+            Pt acc = pedersen_point(1 + 2 * e);
+            for (int i = 0; i < 248; ++i) { half.push_back(acc); acc = ec_double(acc); }
+            acc = pedersen_point(2 + 2 * e);
+            for (int i = 0; i < 4; ++i) { half.push_back(acc); acc = ec_double(acc); }
+            for (int i = 0; i < 4; ++i) half.push_back(half[251]);
+            pts.insert(pts.end(), half.begin(), half.end());
+        }
+    }
+    return pts;
+}
+struct Step { Pt point; Felt suffix, slope; };
+// gen_element_steps (builtins/src/pedersen/mod.rs:121-163)
+Pt element_steps(const U256 &x, Pt point, int which, std::vector<Step> &out) {
+    const std::vector<Pt> &cp = constant_points();
+    for (unsigned i = 0; i < 256; ++i) {
+        const U256 suffix = shr(x, i);
+        Felt slope = felt_from_u64(0);
+        Pt next = point;
+        if (suffix[0] & 1) {
+            const Pt &c = cp[256 * which + i];
+            if (felt_eq(c.x, point.x)) {
+                if (!felt_eq(c.y, point.y)) fail("point at infinity in a Pedersen partial sum");
+                const Felt xx = felt_mul(c.x, c.x);
+                slope = felt_mul(felt_add(felt_add(felt_add(xx, xx), xx), felt_from_u64(1)), felt_inv(felt_add(c.y, c.y)));
+            } else {
+                slope = felt_mul(felt_sub(point.y, c.y), felt_inv(felt_sub(point.x, c.x)));
+            }
+            next = ec_add(point, c);
+        }
+        out.push_back(Step{point, felt_from_canonical(suffix), slope});
+        point = next;
+    }
+    return point;
+}
+
+uint64_t dilute(uint64_t v) {                       // bit i -> bit 4 i
+    uint64_t out = 0;
+    for (unsigned i = 0; i < 16; ++i) out |= ((v >> i) & 1ull) << (DILUTED_SPACING * i);
+    return out;
+}
+uint32_t undilute(uint64_t v) {                     // DilutedCheckPool::push_diluted
+    uint32_t out = 0;
+    for (unsigned i = 0; i < DILUTED_N_BITS; ++i) out |= (uint32_t)((v >> (DILUTED_SPACING * i)) & 1ull) << i;
+    if (dilute(out) != v) fail("a value is not in diluted form");
+    return out;
+}
+void partition64(uint64_t v, uint64_t segs[4]) {    // Partition64::new
+    for (int s = 0; s < 4; ++s) segs[s] = 0;
+    for (unsigned b = 0; b < 16; ++b)
+        for (unsigned s = 0; s < 4; ++s) segs[s] |= ((v >> (b * 4 + s)) & 1ull) << (b * 4);
+}
+
+}  // namespace
+
+std::vector<RegisterState> read_register_states(const uint8_t *data, size_t len) {
+    if (len % 24) fail("trace file is not a sequence of (ap, fp, pc) u64 triples");
+    std::vector<RegisterState> out(len / 24);
+    for (size_t i = 0; i < out.size(); ++i) { memcpy(&out[i].ap, data + 24 * i, 8); memcpy(&out[i].fp, data + 24 * i + 8, 8); memcpy(&out[i].pc, data + 24 * i + 16, 8); }
+    return out;
+}
+
+void read_memory(const uint8_t *data, size_t len, std::vector<U256> &memory, std::vector<uint8_t> &present) {
+    if (len % 40) fail("memory file is not a sequence of (u64 address, 32-byte word) records");
+    uint64_t max_addr = 0;
+    for (size_t o = 0; o < len; o += 40) { uint64_t a; memcpy(&a, data + o, 8); max_addr = std::max(max_addr, a); }
+    memory.assign(len ? max_addr + 1 : 0, U256{});
+    present.assign(memory.size(), 0);
+    for (size_t o = 0; o < len; o += 40) {
+        uint64_t a;
+        memcpy(&a, data + o, 8);
+        memcpy(memory[a].data(), data + o + 8, 32);
+        present[a] = 1;
+    }
+}
+
+std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+                                                    const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv) {
+    const uint64_t num_cycles = states.size();
+    if (!num_cycles || (num_cycles & (num_cycles - 1))) fail("the number of cycles must be a power of two");
+    const uint64_t n = num_cycles * CYCLE_HEIGHT;
+    const Mem mem{memory, present};
+    const Felt zero = felt_from_u64(0);
+    std::vector<std::vector<Felt>> cols(NUM_COLS, std::vector<Felt>(n, zero));
+    auto &flags = cols[COL_FLAGS], &un_col = cols[COL_DILUTED_UNORDERED], &od_col = cols[COL_DILUTED_ORDERED], &npc = cols[COL_NPC],
+         &mem_col = cols[COL_MEMORY], &rc_col = cols[COL_RANGE_CHECK], &aux = cols[COL_AUXILIARY];
+    std::vector<uint64_t> npc_addr(n / 2, 0);           // the address half of the pool, as integers (sorting, gap search)
+
+    const MemoryEntry *padding = nullptr;
+    for (auto &e : pi.public_memory) if (e.address == 1) { padding = &e; break; }
+    if (!padding) fail("public memory has no entry at address 1");
+    const Felt pad_value = felt_from_canonical(padding->value), pad_addr = felt_from_u64(1);
+    for (uint64_t k = 0; k < n / 2; ++k) { npc[2 * k] = pad_addr; npc[2 * k + 1] = pad_value; npc_addr[k] = 1; }
+    auto set_pair = [&](uint64_t row, uint64_t address, const Felt &value) { npc[row] = felt_from_u64(address); npc[row + 1] = value; npc_addr[row / 2] = address; };
+    const Felt rc_max_f = felt_from_u64(pi.rc_max);
+    for (auto &v : rc_col) v = rc_max_f;
+
+    // ---- CPU cells (trace.rs:172-232) and the range-check pool
+    std::vector<uint32_t> rc_count(1 << 16, 0);
+    for (uint64_t cycle = 0; cycle < num_cycles; ++cycle) {
+        const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
+        const U256 &iw = mem.at(pc);
+        const Word w{iw[0]};
+        if ((iw[1] | iw[2] | iw[3]) || w.flag(F_ZERO)) fail("memory cell " + std::to_string(pc) + " is not an instruction");
+        const uint64_t dst_addr = w.off_dst() + (w.flag(F_DST_REG) ? fp : ap) - HALF_OFFSET;
+        const uint64_t op0_addr = w.off_op0() + (w.flag(F_OP0_REG) ? fp : ap) - HALF_OFFSET;
+        const int src = w.op1_src();
+        if (src != 0 && src != 1 && src != 2 && src != 4) fail("invalid op1 source");
+        const uint64_t base = src == 0 ? mem.small(op0_addr) : src == 1 ? pc : src == 2 ? fp : ap;
+        const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
+        const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
+        Felt res;
+        if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : felt_inv(dst);           // get_res: dst^-1 on a jnz
+        else if (w.res_logic() == 0) res = op1;
+        else if (w.res_logic() == 1) res = felt_add(op0, op1);
+        else if (w.res_logic() == 2) res = felt_mul(op0, op1);
+        else fail("invalid res logic");
+        const Felt tmp0 = w.flag(F_PC_JNZ) ? dst : zero;
+        for (int f = 0; f < 16; ++f) flags[r + f] = felt_from_u64(w.flag_prefix(f));
+        set_pair(r + NPC_PC, pc, felt_from_canonical(iw));
+        set_pair(r + NPC_MEM_OP0_ADDR, op0_addr, op0);
+        set_pair(r + NPC_MEM_DST_ADDR, dst_addr, dst);
+        set_pair(r + NPC_MEM_OP1_ADDR, op1_addr, op1);
+        set_pair(r + NPC_PUB_MEM_ADDR, 0, zero);
+        rc_col[r + RC_OFF_DST] = felt_from_u64(w.off_dst()); rc_col[r + RC_OFF_OP1] = felt_from_u64(w.off_op1()); rc_col[r + RC_OFF_OP0] = felt_from_u64(w.off_op0());
+        aux[r + AUX_TMP0] = tmp0; aux[r + AUX_TMP1] = felt_mul(tmp0, res);
+        aux[r + AUX_AP] = felt_from_u64(ap); aux[r + AUX_FP] = felt_from_u64(fp);
+        aux[r + AUX_OP0_MUL_OP1] = felt_mul(op0, op1); aux[r + AUX_RES] = res;
+        ++rc_count[w.off_dst()]; ++rc_count[w.off_op0()]; ++rc_count[w.off_op1()];
+    }
+
+    // ---- range-check builtin instances, ordered values and padding (trace.rs:131-160, 236-284; utils.rs:357-380)
+    struct Rc128 { uint32_t index; U256 value; };
+    std::vector<Rc128> rc128;
+    auto part_of = [](const U256 &v, unsigned k) { return (uint32_t)(shr(v, 16 * (RANGE_CHECK_BUILTIN_PARTS - 1 - k))[0] & 0xffff); };
+    for (auto &inst : priv.range_check) {
+        if (inst.value[2] | inst.value[3]) fail("range-check value does not fit 128 bits");
+        rc128.push_back(Rc128{inst.index, inst.value});
+        for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) ++rc_count[part_of(inst.value, k)];
+    }
+    uint32_t rc_lo = 0xffff, rc_hi = 0;
+    for (uint32_t v = 0; v < (1u << 16); ++v) if (rc_count[v]) { rc_lo = std::min(rc_lo, v); rc_hi = std::max(rc_hi, v); }
+    std::vector<uint32_t> padding_vals, ordered_vals;
+    for (uint32_t v = rc_lo; v <= rc_hi; ++v) {
+        if (!rc_count[v]) padding_vals.push_back(v);
+        for (uint32_t c = 0; c < std::max(rc_count[v], 1u); ++c) ordered_vals.push_back(v);
+    }
+    size_t pad_i = 0, ord_i = 0;
+    auto next_padding = [&]() { return pad_i < padding_vals.size() ? padding_vals[pad_i++] : rc_hi; };
+    for (uint64_t index = rc128.size(); index < num_cycles / RANGE_CHECK_BUILTIN_RATIO; ++index) {
+        U256 value{};
+        for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) {      // value = (value << 16) + part
+            value[3] = (value[3] << 16) | (value[2] >> 48); value[2] = (value[2] << 16) | (value[1] >> 48);
+            value[1] = (value[1] << 16) | (value[0] >> 48); value[0] = (value[0] << 16) | next_padding();
+        }
+        rc128.push_back(Rc128{(uint32_t)index, value});
+    }
+    for (uint64_t cycle = 0; cycle < num_cycles; ++cycle) {
+        const uint64_t r = cycle * CYCLE_HEIGHT;
+        if (cycle % 2 == 1) rc_col[r + RC_UNUSED] = felt_from_u64(next_padding());
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP)
+            rc_col[r + o + RC_ORDERED] = felt_from_u64(ord_i < ordered_vals.size() ? ordered_vals[ord_i++] : rc_hi);
+    }
+    if (pad_i < padding_vals.size() || ord_i < ordered_vals.size()) fail("range-check values do not fit the trace");
+
+    // ---- Pedersen builtin (trace.rs:300-400; builtins/src/pedersen/mod.rs:81-163)
+    const Segment &ped_seg = pi.segments[3], &rc_seg = pi.segments[4], &bw_seg = pi.segments[6];
+    if (!ped_seg.present || !rc_seg.present || !bw_seg.present) fail("the layout needs the pedersen, range_check and bitwise segments");
+    {
+        const uint64_t step = PEDERSEN_BUILTIN_RATIO * CYCLE_HEIGHT;
+        std::map<uint32_t, const PedersenInstance *> given;
+        for (auto &inst : priv.pedersen) given[inst.index] = &inst;
+        struct Cached { std::vector<Step> steps; Felt out; };
+        std::map<std::pair<U256, U256>, Cached> cache;
+        const Pt p0 = pedersen_point(0);
+        for (uint64_t i = 0; i < n / step; ++i) {
+            U256 a{}, b{};
+            auto it = given.find((uint32_t)i);
+            if (it != given.end()) { a = it->second->a; b = it->second->b; }
+            auto key = std::make_pair(a, b);
+            auto cit = cache.find(key);
+            if (cit == cache.end()) {
+                Cached c;
+                const Pt mid = element_steps(a, p0, 0, c.steps);
+                element_steps(b, mid, 1, c.steps);
+                c.out = c.steps.back().point.x;
+                Felt want;
+                const Felt fa = felt_from_canonical(a), fb = felt_from_canonical(b);
+                if (ss_pedersen_hash_host(fa.data(), fb.data(), want.data()) != SS_OK || !felt_eq(want, c.out))
+                    fail("Pedersen partial sums do not end at the hash");                     // the reference's own assert
+                cit = cache.emplace(key, std::move(c)).first;
+            }
+            const Cached &c = cit->second;
+            const uint64_t base = i * step, addr = ped_seg.begin_addr + 3 * i;
+            for (uint64_t j = 0; j < 512; ++j) {
+                const uint64_t r = base + 4 * j;
+                rc_col[r + 1] = c.steps[j].point.x; rc_col[r + 3] = c.steps[j].point.y;
+                aux[r] = c.steps[j].suffix; aux[r + 2] = c.steps[j].slope;
+            }
+            const U256 *in[2] = {&a, &b};
+            for (int half = 0; half < 2; ++half) {
+                const bool b251 = bit(*in[half], 251), b196 = bit(*in[half], 196), b192 = bit(*in[half], 192);
+                aux[base + 1024 * half + 1022] = felt_from_u64(b251 && b196);
+                aux[base + 1024 * half + 7] = felt_from_u64(b251 && b196 && b192);
+            }
+            set_pair(base + NPC_PEDERSEN_INPUT0_ADDR, addr, felt_from_canonical(a));
+            set_pair(base + NPC_PEDERSEN_INPUT1_ADDR, addr + 1, felt_from_canonical(b));
+            set_pair(base + NPC_PEDERSEN_OUTPUT_ADDR, addr + 2, c.out);
+        }
+    }
+    // ---- range-check builtin cells
+    {
+        const uint64_t step = RANGE_CHECK_BUILTIN_RATIO * CYCLE_HEIGHT;
+        for (uint64_t block = 0; block < rc128.size(); ++block) {
+            const uint64_t base = block * step;
+            for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) rc_col[base + CYCLE_HEIGHT * k + RC_UNUSED] = felt_from_u64(part_of(rc128[block].value, k));
+            set_pair(base + NPC_RANGE_CHECK128_ADDR, rc_seg.begin_addr + rc128[block].index, felt_from_canonical(rc128[block].value));
+        }
+    }
+    // ---- bitwise builtin and the diluted check (trace.rs:420-588)
+    {
+        const uint64_t step = BITWISE_RATIO * CYCLE_HEIGHT;
+        std::map<uint32_t, const BitwiseInstance *> given;
+        for (auto &inst : priv.bitwise) given[inst.index] = &inst;
+        std::vector<uint32_t> dil_count(1u << DILUTED_N_BITS, 0);
+        const uint64_t shifted_cells[4] = {1, 65, 33, 97};
+        for (uint64_t i = 0; i < n / step; ++i) {
+            U256 x{}, y{};
+            auto it = given.find((uint32_t)i);
+            if (it != given.end()) { x = it->second->x; y = it->second->y; }
+            U256 vand, vxor, vor;
+            for (int k = 0; k < 4; ++k) { vand[k] = x[k] & y[k]; vxor[k] = x[k] ^ y[k]; vor[k] = x[k] | y[k]; }
+            const U256 *vals[4] = {&x, &y, &vand, &vxor};
+            uint64_t parts[4][4][4];
+            for (int p = 0; p < 4; ++p) for (int c = 0; c < 4; ++c) partition64((*vals[p])[c], parts[p][c]);
+            const uint64_t base = i * step, addr = bw_seg.begin_addr + 5 * i;
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t v = parts[2][3][k] + parts[3][3][k];
+                const unsigned sh = k == 3 ? 8 : 4;
+                if ((v << sh) >> sh != v) fail("bitwise instance: top segment does not fit");
+                un_col[base + shifted_cells[k]] = felt_from_u64(v << sh);
+                ++dil_count[undilute(v << sh)];
+            }
+            for (int p = 0; p < 4; ++p)
+                for (int c = 0; c < 4; ++c)
+                    for (int s = 0; s < 4; ++s) {
+                        un_col[base + 32 * p + 8 * c + 2 * s] = felt_from_u64(parts[p][c][s]);
+                        ++dil_count[undilute(parts[p][c][s])];
+                    }
+            for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + k * (step / 4), addr + k, felt_from_canonical(*vals[k]));
+            set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, felt_from_canonical(vor));
+        }
+        std::vector<uint32_t> padding;
+        uint64_t total = 0;
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) { if (!dil_count[v]) padding.push_back(v); total += std::max(dil_count[v], 1u); }
+        if (total > n) fail("diluted-check values do not fit the trace");
+        size_t pi_ = 0;
+        for (uint64_t blk = 0; blk < n / step && pi_ < padding.size(); ++blk)
+            for (uint64_t off = 1; off < step && pi_ < padding.size(); off += 2) {
+                if (off == 1 || off == 33 || off == 65 || off == 97) continue;
+                un_col[blk * step + off] = felt_from_u64(dilute(padding[pi_++]));
+            }
+        if (pi_ < padding.size()) fail("diluted-check values do not fit the trace");
+        uint64_t row = n - total;
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)
+            for (uint32_t c = 0; c < std::max(dil_count[v], 1u); ++c) od_col[row++] = felt_from_u64(dilute(v));
+    }
+    // ---- gap fillers (trace.rs:594-625)
+    {
+        std::vector<uint64_t> accessed(npc_addr);
+        for (auto &e : pi.public_memory) accessed.push_back(e.address);
+        std::sort(accessed.begin(), accessed.end());
+        accessed.erase(std::unique(accessed.begin(), accessed.end()), accessed.end());
+        uint64_t cycle = 0;
+        for (size_t k = 0; k + 1 < accessed.size(); ++k)
+            for (uint64_t a = accessed[k] + 1; a < accessed[k + 1]; ++a) {
+                if (cycle >= num_cycles) fail("more memory gaps than cycles to hold them");
+                set_pair(cycle * CYCLE_HEIGHT + NPC_UNUSED_ADDR, a, zero);
+                ++cycle;
+            }
+    }
+    // ---- sorted memory (get_ordered_memory_accesses, utils.rs:112-152)
+    {
+        struct Access { uint64_t address; Felt value; };
+        std::vector<Access> acc;
+        acc.reserve(n / 2 + n / PUBLIC_MEMORY_STEP);
+        for (uint64_t k = 0; k < n / 2; ++k) acc.push_back(Access{npc_addr[k], npc[2 * k + 1]});
+        const uint64_t cells = n / PUBLIC_MEMORY_STEP;
+        if (pi.public_memory.size() > cells) fail("public memory does not fit");
+        for (uint64_t k = pi.public_memory.size(); k < cells; ++k) acc.push_back(Access{1, pad_value});
+        for (auto &e : pi.public_memory) acc.push_back(Access{e.address, felt_from_canonical(e.value)});
+        std::stable_sort(acc.begin(), acc.end(), [](const Access &a, const Access &b) { return a.address < b.address; });
+        for (uint64_t k = 0; k < cells; ++k) if (acc[k].address != 0) fail("the public-memory cells of the pool must be the only accesses of address 0");
+        if (acc[cells].address != 1) fail("memory must start at address 1");
+        for (uint64_t k = cells; k + 1 < acc.size(); ++k)
+            if (!((acc[k].address == acc[k + 1].address && felt_eq(acc[k].value, acc[k + 1].value)) || acc[k].address + 1 == acc[k + 1].address))
+                fail("memory is not continuous and single-valued at address " + std::to_string(acc[k].address));
+        for (uint64_t k = 0; k < n / 2; ++k) { mem_col[2 * k] = felt_from_u64(acc[cells + k].address); mem_col[2 * k + 1] = acc[cells + k].value; }
+    }
+    return cols;
+}
+
+}  // namespace ssh

@@ -1,0 +1,35 @@
+// trace_recursive.hpp — base-trace generation of the `recursive` layout on the host ("next"
+// row X1): ExecutionTrace::new (layouts/src/recursive/trace.rs:95-660) with the builtins' instance traces
+// (builtins/src/{pedersen,bitwise,range_check}/mod.rs) and the pools of layouts/src/utils.rs.
+// Mirror: sandstorm_amd/layouts/recursive.py::base_trace, against which tests/test_layout_recursive.py checks it cell
+// for cell; that module also holds the 93 constraints the trace is validated with.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "public_input.hpp"
+
+namespace ssh {
+
+struct RegisterState { uint64_t ap, fp, pc; };                 // binary/src/lib.rs:50-56
+
+std::vector<RegisterState> read_register_states(const uint8_t *data, size_t len);        // trace.bin
+// memory.bin -> memory[address] (canonical 256-bit words); present[address] = 0 for cells the run never touched
+void read_memory(const uint8_t *data, size_t len, std::vector<U256> &memory, std::vector<uint8_t> &present);
+
+struct PedersenInstance { uint32_t index; U256 a, b; };
+struct RangeCheckInstance { uint32_t index; U256 value; };
+struct BitwiseInstance { uint32_t index; U256 x, y; };
+struct PrivateInput {                                           // air-private-input.json
+    std::vector<PedersenInstance> pedersen;
+    std::vector<RangeCheckInstance> range_check;
+    std::vector<BitwiseInstance> bitwise;
+};
+
+// -> the 7 base columns (Montgomery felts, 16 rows per cycle): flags | diluted unordered / bitwise | diluted ordered |
+// memory pool | sorted memory | range check / Pedersen partial sums | auxiliary / Pedersen suffixes, slopes
+std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+                                                    const std::vector<uint8_t> &present, const AirPublicInput &pi,
+                                                    const PrivateInput &priv);
+
+}  // namespace ssh

@@ -40,6 +40,10 @@ def load():
         h.ssh_public_coin_seed.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint64), C.c_uint64, C.c_int, C.c_char_p, C.POINTER(C.c_uint64),
                                            C.POINTER(C.c_uint32)]
+        h.ssh_recursive_base_trace.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
+                                               C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64,
+                                               C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64,
+                                               C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_void_p)]
         h.ssh_matrix_num_cols.argtypes = [C.c_void_p]
         h.ssh_matrix_num_cols.restype = C.c_uint32
         h.ssh_matrix_col.argtypes = [C.c_void_p, C.c_uint32]
@@ -230,6 +234,50 @@ def public_coin_seed(pi, coin_kind):
                                        len(addrs), coin_kind, seed, els.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(n_els)))
     ints = [sum(int(els[i, k]) << (64 * k) for k in range(4)) for i in range(n_els.value)]
     return seed.raw, ints
+
+
+def _public_input_args(pi):
+    from .public_input import SEGMENTS
+    segs = np.zeros(27, dtype=np.uint32)
+    for k, name in enumerate(SEGMENTS):
+        s = pi.memory_segments.get(name)
+        if s is not None:
+            segs[3 * k: 3 * k + 3] = (1, s[0], s[1])
+    addrs = np.array([e[0] for e in pi.public_memory], dtype=np.uint32)
+    vals = np.array([[(e[1] >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)] for e in pi.public_memory], dtype=np.uint64).reshape(-1, 4)
+    return segs, addrs, vals
+
+
+def _instances(rows, width):
+    """[(index, v0[, v1])] -> uint64 array of `width` words per instance (index, then 4 little-endian limbs per value)"""
+    out = np.zeros((max(1, len(rows)), width), dtype=np.uint64)
+    for i, row in enumerate(rows):
+        out[i, 0] = int(row[0])
+        for j, v in enumerate(row[1:]):
+            for k in range(4):
+                out[i, 1 + 4 * j + k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def recursive_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=None):
+    """the C++ host's ExecutionTrace::new for the recursive layout (sandstorm_amd/host/trace_recursive.cpp) from the raw
+    `cairo-run` files -> 7 columns [16 * cycles, 4] of Montgomery limbs"""
+    private_input = private_input or {}
+    if len(trace_bin) % 24:
+        raise _lib.SandstormHipError("host: trace file is not a sequence of (ap, fp, pc) u64 triples")
+    n = 16 * (len(trace_bin) // 24)
+    segs, addrs, vals = _public_input_args(pi)
+    ped, rc, bw = (_instances(private_input.get("pedersen", []), 9), _instances(private_input.get("range_check", []), 5),
+                   _instances(private_input.get("bitwise", []), 9))
+    cols = [np.zeros((n, 4), dtype=np.uint64) for _ in range(7)]
+    ptrs = (C.c_void_p * 7)(*[c.ctypes.data for c in cols])
+    u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    _check(load().ssh_recursive_base_trace(trace_bin, len(trace_bin), memory_bin, len(memory_bin), pi.rc_min, pi.rc_max, pi.n_steps,
+                                           segs.ctypes.data_as(u32p), addrs.ctypes.data_as(u32p), vals.ctypes.data_as(u64p), len(addrs),
+                                           ped.ctypes.data_as(u64p), len(private_input.get("pedersen", [])),
+                                           rc.ctypes.data_as(u64p), len(private_input.get("range_check", [])),
+                                           bw.ctypes.data_as(u64p), len(private_input.get("bitwise", [])), ptrs))
+    return cols
 
 
 class HostCoin:

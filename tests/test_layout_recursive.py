@@ -249,3 +249,30 @@ def test_composition_of_the_example_is_a_polynomial(example, oracle):
     bad[0][16 * 777 + 3] = (bad[0][16 * 777 + 3] + 1) % rec.P          # one flag cell of one cycle
     _, _, coeffs_bad = composition_coefficients(bad)
     assert coeffs_bad[-1].any() and coeffs_bad[-2].any()
+
+
+def test_cpp_base_trace_equals_the_python_one(oracle):
+    """sandstorm_amd/host/trace_recursive.cpp against layouts/recursive.py::base_trace, cell for cell: the example run,
+    and the same run with real Pedersen / bitwise / range-check instances"""
+    import numpy as np
+    from sandstorm_amd import hostlib
+    from sandstorm_amd.layouts import recursive as rec
+    states, memory, pi = load_run()
+    with open(os.path.join(EX, "trace.bin"), "rb") as f:
+        trace_bin = f.read()
+    with open(os.path.join(EX, "memory.bin"), "rb") as f:
+        memory_bin = f.read()
+    rng = random.Random(21)
+    top = (1 << 251) | (1 << 196) | (1 << 192)
+    private = {"pedersen": [(0, rng.getrandbits(250), rng.getrandbits(250)), (1, top, (1 << 251) | (1 << 196)), (5, 0, 5)],
+               "bitwise": [(i, rng.getrandbits(251), rng.getrandbits(251)) for i in range(9)],
+               "range_check": [(i, sum(rng.randrange(32700, 32800) << (16 * k) for k in range(8))) for i in range(6)]}
+    for priv in (None, private):
+        want = rec.base_trace(states, memory, pi, priv)
+        got = hostlib.recursive_base_trace(trace_bin, memory_bin, pi, priv)
+        assert len(got) == len(want) == 7
+        for c, (g, w) in enumerate(zip(got, want)):
+            assert np.array_equal(g, oracle.to_mont(w)), "column %d" % c
+    from sandstorm_amd._lib import SandstormHipError
+    with pytest.raises(SandstormHipError, match="power of two"):
+        hostlib.recursive_base_trace(trace_bin[:24 * 1000], memory_bin, pi)
