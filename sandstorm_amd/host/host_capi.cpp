@@ -166,6 +166,52 @@ int ssh_recursive_base_trace(const uint8_t *trace_bin, uint64_t trace_len, const
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }
 
+static AirPublicInput public_input_from_args(int layout, uint32_t rc_min, uint32_t rc_max, uint64_t n_steps, const uint32_t *segments,
+                                             const uint32_t *mem_addresses, const uint64_t *mem_values, uint64_t n_mem) {
+    AirPublicInput pi;
+    pi.layout = layout == 1 ? "recursive" : layout == 2 ? "starknet" : "unknown";
+    pi.rc_min = (uint16_t)rc_min; pi.rc_max = (uint16_t)rc_max; pi.n_steps = n_steps;
+    for (int k = 0; k < 9; ++k) { pi.segments[k].present = segments[3 * k] != 0; pi.segments[k].begin_addr = segments[3 * k + 1]; pi.segments[k].stop_ptr = segments[3 * k + 2]; }
+    pi.public_memory.resize(n_mem);
+    for (uint64_t i = 0; i < n_mem; ++i) { pi.public_memory[i].address = mem_addresses[i]; memcpy(pi.public_memory[i].value.data(), mem_values + 4 * i, 32); }
+    return pi;
+}
+
+// The real `recursive` AIR for a public input (air_recursive.cpp).  ctx may be NULL: no device tables are built and the
+// handle only serves ssh_air_dump (host-side checks).
+int ssh_air_create_recursive(ss_ctx *ctx, uint32_t rc_min, uint32_t rc_max, uint64_t n_steps, const uint32_t *segments,
+                             const uint32_t *mem_addresses, const uint64_t *mem_values, uint64_t n_mem, uint32_t log_n, uint32_t log_blowup,
+                             ssh_air **out) {
+    try {
+        const AirPublicInput pi = public_input_from_args(1, rc_min, rc_max, n_steps, segments, mem_addresses, mem_values, n_mem);
+        *out = reinterpret_cast<ssh_air *>(make_recursive_air(ctx, pi, log_n, log_blowup, 3).release());
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+// the lowered composition program for these challenges and its table descriptions, as one u64 blob:
+// n_instr, code words..., n_consts, 4 limbs each..., n_slots, then recursive_air_tables()
+int ssh_air_dump(ssh_air *air_h, uint64_t n, const uint64_t *challenges, uint32_t nchallenges, const uint64_t alpha[4], uint64_t **blob, uint64_t *blob_len) {
+    try {
+        Air *air = reinterpret_cast<Air *>(air_h);
+        std::vector<Felt> ch(nchallenges);
+        for (uint32_t i = 0; i < nchallenges; ++i) memcpy(ch[i].data(), challenges + 4 * i, 32);
+        Felt a;
+        memcpy(a.data(), alpha, 32);
+        const AirProgramData pd = air->build_program(n, ch, a);
+        std::vector<uint64_t> out{pd.program.n_instr()};
+        for (uint32_t w : pd.program.code) out.push_back(w);
+        out.push_back(pd.program.consts.size());
+        for (auto &c : pd.program.consts) for (int k = 0; k < 4; ++k) out.push_back(c[k]);
+        out.push_back(pd.program.n_slots);
+        const std::vector<uint64_t> t = recursive_air_tables(*air);
+        out.insert(out.end(), t.begin(), t.end());
+        *blob = (uint64_t *)malloc(out.size() * 8);
+        memcpy(*blob, out.data(), out.size() * 8);
+        *blob_len = out.size();
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
 // ---- the C++ coin, exposed for the CPU tests (tests/test_host_cpp.py)
 typedef struct ssh_coin ssh_coin;
 ssh_coin *ssh_coin_new(int kind, const uint8_t seed[32]) {

@@ -149,6 +149,10 @@ private:
 
 // built-in AIRs
 std::unique_ptr<Air> make_mini_air(ss_ctx *ctx);                                   // tests/mini_air.py
+struct AirPublicInput;
+// the real `recursive` layout (air_recursive.cpp; mirror of sandstorm_amd/layouts/recursive.py)
+std::unique_ptr<Air> make_recursive_air(ss_ctx *ctx, const AirPublicInput &pi, uint32_t log_n, uint32_t log_blowup, uint64_t lde_offset);
+std::vector<uint64_t> recursive_air_tables(const Air &air);      // table descriptions (host-side checks)
 std::unique_ptr<Air> make_synthetic_air(ss_ctx *ctx, const std::string &layout, uint32_t log_n, uint32_t log_blowup,
                                         uint64_t lde_offset);                      // layout-shaped, for bench.py
 

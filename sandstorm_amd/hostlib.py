@@ -44,6 +44,10 @@ def load():
                                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64,
                                                C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64,
                                                C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_void_p)]
+        h.ssh_air_create_recursive.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                               C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        h.ssh_air_dump.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64),
+                                   C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
         h.ssh_matrix_num_cols.argtypes = [C.c_void_p]
         h.ssh_matrix_num_cols.restype = C.c_uint32
         h.ssh_matrix_col.argtypes = [C.c_void_p, C.c_uint32]
@@ -75,6 +79,45 @@ class HostAir:
         if self.h:
             load().ssh_air_destroy(self.h)
             self.h = None
+
+
+class RecursiveHostAir(HostAir):
+    """the C++ host's real `recursive` AIR for a public input (sandstorm_amd/host/air_recursive.cpp).  ctx=None: no device
+    tables, only dump() works (host-side checks)."""
+
+    def __init__(self, ctx, pi, log_n, log_blowup=1):
+        segs, addrs, vals = _public_input_args(pi)
+        h = C.c_void_p()
+        _check(load().ssh_air_create_recursive(ctx.handle if ctx is not None else None, pi.rc_min, pi.rc_max, pi.n_steps,
+                                               segs.ctypes.data_as(C.POINTER(C.c_uint32)), addrs.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                               vals.ctypes.data_as(C.POINTER(C.c_uint64)), len(addrs), log_n, log_blowup, C.byref(h)))
+        self.ctx, self.h = ctx, h
+        self.num_base_columns = load().ssh_air_columns(h, 0)
+        self.num_extension_columns = load().ssh_air_columns(h, 1)
+        self.mask_size = load().ssh_air_columns(h, 2)
+
+    def dump(self, n, challenges, alpha):
+        """-> (code uint32[], consts uint64[*,4], n_slots, table specs in layouts.recursive.Tables' format)"""
+        ch = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint64) for c in challenges]))
+        al = np.ascontiguousarray(alpha, dtype=np.uint64)
+        blob, ln = C.POINTER(C.c_uint64)(), C.c_uint64()
+        _check(load().ssh_air_dump(self.h, n, ch.ctypes.data_as(C.POINTER(C.c_uint64)), len(challenges), al.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                   C.byref(blob), C.byref(ln)))
+        words = [blob[i] for i in range(ln.value)]
+        load().ssh_free(blob)
+        it = iter(words)
+        n_instr = next(it)
+        code = np.array([next(it) for _ in range(2 * n_instr)], dtype=np.uint32)
+        n_consts = next(it)
+        consts = np.array([[next(it) for _ in range(4)] for _ in range(n_consts)], dtype=np.uint64).reshape(-1, 4)
+        n_slots = next(it)
+        specs = []
+        for _ in range(next(it)):
+            kind, e = next(it), next(it)
+            num = tuple((next(it), next(it)) for _ in range(next(it)))
+            den = tuple((next(it), next(it)) for _ in range(next(it)))
+            specs.append(("pedersen", kind) if kind <= 1 else ("periodic", num, den) if kind == 2 else ("inverse", e))
+        return code, consts, n_slots, specs
 
 
 class _Reader:

@@ -441,12 +441,13 @@ def periodic_value(table, row):
 
 
 def constraints(hints: Hints, challenges=None) -> List[Constraint]:
-    """what is restated so far (see the module docstring); the permutation constraints need the 6 challenges (ints)"""
-    out = cpu_constraints(hints)
-    if challenges is not None:
-        out += memory_constraints(hints, challenges) + range_check_constraints(hints, challenges)
-        out += diluted_check_constraints(hints, challenges)
-    return out + pedersen_constraints(hints) + bitwise_constraints(hints)
+    """the 93 constraints in the reference's order (air.rs:1083-1180) - the order fixes which power of alpha each one gets
+    in the composition; without challenges only the 36 + 36 constraints that do not involve a permutation argument"""
+    if challenges is None:
+        return cpu_constraints(hints) + pedersen_constraints(hints) + range_check_constraints(hints, [0] * 6)[6:] + bitwise_constraints(hints)
+    rc = range_check_constraints(hints, challenges)
+    return (cpu_constraints(hints) + memory_constraints(hints, challenges) + rc[:6] + diluted_check_constraints(hints, challenges)
+            + pedersen_constraints(hints) + rc[6:] + bitwise_constraints(hints))
 
 
 # ---- the Pedersen builtin (builtins/src/pedersen/{mod,constants}.rs) ----------------------------------------------

@@ -58,3 +58,44 @@ def test_prove_and_verify_the_reference_example(oracle):
     with pytest.raises(verifier.VerificationError):
         verifier.verify(raw, rec.verifier_air(pi2), be.TREE_KECCAK, be.COIN_SOLIDITY, public_input.public_coin_seed(pi2, be.COIN_SOLIDITY))
     ctx.close()
+
+
+def test_cpp_host_proves_the_reference_example_from_its_files(oracle):
+    """everything above the C ABI in C++: trace.bin / memory.bin -> base trace (host/trace_recursive.cpp) -> HBM -> the real
+    AIR (host/air_recursive.cpp) -> Prover (host/prover.cpp) with the extension columns from host/extension.cpp -> the
+    reference's wire format.  Byte for byte the proof of the Python mirror, and the verifier accepts it."""
+    from sandstorm_amd import backend as be, extension, hostlib, public_input, verifier, wire
+    from sandstorm_amd.layouts import recursive as rec
+    from sandstorm_amd.prover import Claim, ProofOptions, Prover
+    from tests.test_layout_recursive import EX
+    _, _, pi = load_run()
+    with open(os.path.join(EX, "trace.bin"), "rb") as f:
+        trace_bin = f.read()
+    with open(os.path.join(EX, "memory.bin"), "rb") as f:
+        memory_bin = f.read()
+    cols = hostlib.recursive_base_trace(trace_bin, memory_bin, pi)
+    n = cols[0].shape[0]
+    log_n = n.bit_length() - 1
+    ctx = be.Context(0)
+    base = be.Matrix.from_host(ctx, cols)
+    opt = ProofOptions(num_queries=12, grinding_factor=8)
+    seed = public_input.public_coin_seed(pi, be.COIN_SOLIDITY)
+    air = hostlib.RecursiveHostAir(ctx, pi, log_n)
+    keep = []
+
+    def build_extension(challenges):
+        m = hostlib.build_extension_columns(ctx, "recursive", [base.cols[3], base.cols[4], base.cols[5], base.cols[1], base.cols[2]], n, challenges)
+        keep.append(m)
+        return m.cols
+    raw = hostlib.prove(ctx, air, be.TREE_KECCAK, 0, be.COIN_SOLIDITY, seed, base.cols, log_n, build_extension, opt, wire=True)
+    air.close()
+    verifier.verify(raw, rec.verifier_air(pi), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
+    # the Python mirror on the same statement
+    pair = rec.make_air(ctx, pi, n)
+    tc = rec.trace_columns(ctx, base.cols, n)
+    ref = Prover(ctx, Claim(pair, be.LeafVariantMerkleTreeUnmasked, be.COIN_SOLIDITY), opt).prove(
+        seed, base, lambda ch: extension.build_extension_columns("recursive", ctx, tc, ch))
+    assert raw == wire.serialize(wire.from_proof(ref, keccak_leaf_hash))
+    for m in keep:
+        m.close()
+    ctx.close()

@@ -209,9 +209,10 @@ def test_composition_of_the_example_is_a_polynomial(example, oracle):
     expr = rec.composition(n, hints, CHALLENGES, alpha, tables)
     prog = ap.lower(expr, rec.P)
     assert rec.mask() == sorted(rec.mask()) and len(rec.mask()) == 133
-    vals, desc, off = [], [], 0
+    vals, desc, off, by_spec = [], [], 0, {}
     for spec in tables.specs:
         v = tables.host_values(spec)
+        by_spec[spec] = v
         desc += [off, len(v).bit_length() - 1]
         off += len(v)
         vals += v
@@ -245,6 +246,22 @@ def test_composition_of_the_example_is_a_polynomial(example, oracle):
     z2 = oracle.to_mont([z * z % rec.P])[0]
     rhs = (int(oracle.from_mont(oracle.poly_eval(h0, z2)[None])[0]) + z * int(oracle.from_mont(oracle.poly_eval(h1, z2)[None])[0])) % rec.P
     assert lhs == rhs
+    # the C++ host's mirror of the AIR (host/air_recursive.cpp): its program, with its own table numbering, evaluates to
+    # the same composition on every point of the LDE coset
+    from sandstorm_amd import hostlib
+    cpp = hostlib.RecursiveHostAir(None, pi, log_n)
+    assert cpp.mask_size == 133 and (cpp.num_base_columns, cpp.num_extension_columns) == (7, 3)
+    code, consts, n_slots, specs = cpp.dump(n, [oracle.to_mont([c])[0] for c in CHALLENGES], oracle.to_mont([alpha])[0])
+    assert sorted(map(repr, specs)) == sorted(map(repr, tables.specs))
+    cvals, cdesc, coff = [], [], 0
+    for spec in specs:
+        v = by_spec[spec]
+        cdesc += [coff, len(v).bit_length() - 1]
+        coff += len(v)
+        cvals += v
+    out_cpp = oracle.eval_program(code, consts, oracle.to_mont(cvals), cdesc, n_slots, lde, log_n, 1, g)
+    assert np.array_equal(out_cpp, out)
+    cpp.close()
     bad = [list(c) for c in cols[:1]] + cols[1:]
     bad[0][16 * 777 + 3] = (bad[0][16 * 777 + 3] + 1) % rec.P          # one flag cell of one cycle
     _, _, coeffs_bad = composition_coefficients(bad)
