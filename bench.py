@@ -37,6 +37,9 @@ WORKLOADS = {
     "recursive_2p20": ("recursive", 20),    # BASELINE.json north_star target size (2^20-step recursive trace)
     "recursive_2p16": ("recursive", 16),    # BASELINE.json configs[1]
     "recursive_2p10": ("recursive", 10),    # plumbing
+    # BASELINE.json configs[0]: the reference's own example run (tests/golden/example/: cairo-run output of array-sum, 2^14
+    # steps) with the REAL recursive AIR; C++ host from the raw files (host/trace_recursive.cpp, host/air_recursive.cpp)
+    "array_sum_example": ("recursive-real", 14),
     "recursive_2p7": ("recursive", 7),      # 128 steps: the size of the only figure the reference publishes (186 ms)
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -126,28 +129,56 @@ def main():
     log_n, lb = log_steps + 4, 1
     n = 1 << log_n
     ctx = be.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    # the C++ host side (libsandstorm_host.so): coin, Expr lowering, prover, synthetic AIR
-    air = hostlib.HostAir(ctx, hostlib.AIR_SYNTHETIC_RECURSIVE if layout == "recursive" else hostlib.AIR_SYNTHETIC_STARKNET, log_n, lb)
-    if layout == "recursive":       # cli/src/main.rs:95-99 -> CairoVerifierClaim
+    real = layout == "recursive-real"
+    if real:
+        # the reference's example: raw files -> base trace on the host (C++) -> HBM; the real 93-constraint AIR; the seed
+        # from its air-public-input.json; CairoVerifierClaim as the CLI picks for this layout (cli/src/main.rs:95-99)
+        from sandstorm_amd import public_input
+        layout = "recursive"
+        ex = os.path.join(ROOT, "tests", "golden", "example")
+        pi = public_input.AirPublicInput.from_json(os.path.join(ROOT, "tests", "golden", "air_public_input_array_sum.json"))
+        with open(os.path.join(ex, "trace.bin"), "rb") as fh:
+            trace_bin = fh.read()
+        with open(os.path.join(ex, "memory.bin"), "rb") as fh:
+            memory_bin = fh.read()
+        t0 = time.perf_counter()
+        host_cols = hostlib.recursive_base_trace(trace_bin, memory_bin, pi)
+        trace_gen_s = time.perf_counter() - t0
+        assert host_cols[0].shape[0] == n
+        base_cols = [ctx.column(c) for c in host_cols]
+        air = hostlib.RecursiveHostAir(ctx, pi, log_n, lb)
         tree_kind, n_friendly, coin_kind = be.TREE_FRIENDLY, 22, be.COIN_CAIRO
-    else:                           # cli/src/main.rs:90-94 -> EthVerifierClaim
-        tree_kind, n_friendly, coin_kind = be.TREE_KECCAK_M20, 0, be.COIN_SOLIDITY
+        seed = public_input.public_coin_seed(pi, coin_kind)
+        aux_cols = [base_cols[3], base_cols[4], base_cols[5], base_cols[1], base_cols[2]]     # npc, memory, range check, diluted x2
+        keep = []
+
+        def build_extension(challenges):
+            del keep[:]
+            keep.append(hostlib.build_extension_columns(ctx, "recursive", aux_cols, n, challenges))      # check=True: real permutations
+            return keep[0].cols
+    else:
+        # the C++ host side (libsandstorm_host.so): coin, Expr lowering, prover, synthetic AIR
+        air = hostlib.HostAir(ctx, hostlib.AIR_SYNTHETIC_RECURSIVE if layout == "recursive" else hostlib.AIR_SYNTHETIC_STARKNET, log_n, lb)
+        if layout == "recursive":       # cli/src/main.rs:95-99 -> CairoVerifierClaim
+            tree_kind, n_friendly, coin_kind = be.TREE_FRIENDLY, 22, be.COIN_CAIRO
+        else:                           # cli/src/main.rs:90-94 -> EthVerifierClaim
+            tree_kind, n_friendly, coin_kind = be.TREE_KECCAK_M20, 0, be.COIN_SOLIDITY
+
+        # inputs resident in HBM before the timed region; one independent trace per rank (weak scaling)
+        base_t = synth_columns(device, air.num_base_columns, log_n, seed=0x53414E44 + rank)
+        base_cols = [base_t[c] for c in range(air.num_base_columns)]
+        # the trace's auxiliary columns (npc, memory, range check [, diluted unordered / ordered]): the extension columns
+        # are built from them ON THE DEVICE inside the timed region, after the challenges are drawn
+        # (Trace::build_extension_columns, sandstorm_amd/extension.py; random data, so the is_one asserts are off)
+        aux_t = synth_columns(device, 5 if layout == "recursive" else 3, log_n, seed=0x7E57 + rank)
+        trace_cols = extension.TraceColumns(aux_t[0], aux_t[1], aux_t[2], n, *(aux_t[3:5] if layout == "recursive" else ()))
+        seed = bytes((7 * i + rank) & 0xff for i in range(32))
+
+        def build_extension(challenges):
+            m = extension.build_extension_columns(layout, ctx, trace_cols, challenges, check=False)
+            assert m.num_cols == air.num_extension_columns
+            return m.cols
     options = ProofOptions()        # CLI defaults: 65 queries, blowup 2, 16 PoW bits, fold 8, <=16 remainder
-
-    # inputs resident in HBM before the timed region; one independent trace per rank (weak scaling)
-    base_t = synth_columns(device, air.num_base_columns, log_n, seed=0x53414E44 + rank)
-    base_cols = [base_t[c] for c in range(air.num_base_columns)]
-    # the trace's auxiliary columns (npc, memory, range check [, diluted unordered / ordered]): the extension columns
-    # are built from them ON THE DEVICE inside the timed region, after the challenges are drawn
-    # (Trace::build_extension_columns, sandstorm_amd/extension.py; random data, so the is_one asserts are off)
-    aux_t = synth_columns(device, 5 if layout == "recursive" else 3, log_n, seed=0x7E57 + rank)
-    trace_cols = extension.TraceColumns(aux_t[0], aux_t[1], aux_t[2], n, *(aux_t[3:5] if layout == "recursive" else ()))
-    seed = bytes((7 * i + rank) & 0xff for i in range(32))
-
-    def build_extension(challenges):
-        m = extension.build_extension_columns(layout, ctx, trace_cols, challenges, check=False)
-        assert m.num_cols == air.num_extension_columns
-        return m.cols
 
     def step(want_proof=False):
         return hostlib.prove(ctx, air, tree_kind, n_friendly, coin_kind, seed, base_cols, log_n,
@@ -211,7 +242,10 @@ def main():
                        "trace_rows_log2": log_n, "columns": "%d base + %d extension" % (air.num_base_columns, air.num_extension_columns),
                        "claim": "CairoVerifierClaim (Blake2s+Pedersen-22 tree, Cairo coin)" if layout == "recursive"
                                 else "EthVerifierClaim (Keccak-masked-20 tree, Solidity coin)",
-                       "air": "SYNTHETIC constraint set with the layout's shape: %d mask cells, see sandstorm_amd/synthetic_air.py" % air.mask_size,
+                       "air": ("the REAL recursive AIR (93 constraints, %d mask cells: sandstorm_amd/host/air_recursive.cpp) on the reference's "
+                               "example run; base trace generated by the C++ host in %.3f s (outside the timed region)" % (air.mask_size, trace_gen_s))
+                              if real else
+                              "SYNTHETIC constraint set with the layout's shape: %d mask cells, see sandstorm_amd/synthetic_air.py" % air.mask_size,
                        "proof_options": "65 queries, blowup 2, 16 PoW bits, FRI fold 8, <=16 remainder coeffs",
                        "in_timed_region": "LDE x2, extension-column scans (A2), commits x3, quotient, composition LDE, OOD, DEEP, FRI, PoW, openings",
                        "outside": "host trace generation (A1): base and auxiliary columns are resident in HBM",
