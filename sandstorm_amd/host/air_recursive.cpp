@@ -5,7 +5,6 @@
 // where every piece is documented and validated against the reference's example run; a GPU test
 // proves that both hosts emit the same proof for it.
 #include <algorithm>
-#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -261,11 +260,7 @@ private:
         struct Group { Domain d; int sum; };
         std::vector<std::pair<std::string, Group>> groups;
         Felt apow = felt_from_u64(1);
-        const char *lim_env = getenv("SSH_AIR_MAX_CONSTRAINTS");       // debugging aid: keep only the first k constraints
-        const long limit = lim_env ? atol(lim_env) : -1;
-        long count = 0;
         auto add = [&](const std::string &dom_name, const Domain &d, const E &numerator) {
-            if (limit >= 0 && count++ >= limit) { apow = felt_mul(apow, alpha); return; }
             const E term = numerator * CF(apow);
             auto it = std::find_if(groups.begin(), groups.end(), [&](const std::pair<std::string, Group> &p) { return p.first == dom_name; });
             if (it == groups.end()) groups.push_back({dom_name, Group{d, term.id}});

@@ -907,7 +907,7 @@ def composition(n, hints: Hints, challenges, alpha, tables: Tables):
     groups, order, apow = {}, [], 1
     for c in constraints(hints, challenges):
         term = c.numerator * ap.Const(apow) if apow != 1 else c.numerator
-        key = id(c.domain) if c.domain.name not in _SHARED_DOMAINS else c.domain.name
+        key = c.domain.name                      # a domain's name identifies it
         if key not in groups:
             groups[key] = [c.domain, term]
             order.append(key)
@@ -920,11 +920,6 @@ def composition(n, hints: Hints, challenges, alpha, tables: Tables):
         term = partial * tables.multiplier(domain)
         total = term if total is None else total + term
     return total
-
-
-# domains built inside pedersen_constraints() are fresh objects per call: group those by name
-_SHARED_DOMAINS = {"every 1024th row", "every 2048th row", "every 2048th row but the last", "steps 0..254 of every input",
-                   "step 252 of every input", "step 255 of every input"}
 
 
 def mask(hints=None):
