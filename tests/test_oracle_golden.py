@@ -281,3 +281,32 @@ def test_draw_queries(oracle):
     a, b = c0.draw_queries(5, 1 << 10), c1.draw_queries(8, 1 << 10)
     assert c0.counter == c1.counter == 2          # batches of 4 (cairo.rs:124-130)
     assert set(a) <= set(b)
+
+
+def test_lde_offset_pinned_by_the_reference_proof(oracle, golden):
+    """SURVEY Appendix A, M2 (LDE coset offset), from data alone: the diluted-check columns of a run without bitwise
+    instances do not depend on the program; regenerated (layouts/recursive.py) and extended over 3 * <w_N>, they equal
+    what the reference's shipped recursive proof opens at all 40 of its query positions, position q holding the point
+    3 * w_N^bitrev(q) — and they do not for another offset or the natural order."""
+    from sandstorm_amd.layouts import recursive as rec
+    from sandstorm_amd.prover import bitrev
+    from tests.test_layout_recursive import load_run
+    fx = golden("lde_offset_pin.json")
+    states, memory, pi = load_run()
+    cols = rec.base_trace(states, memory, pi)
+    n = len(cols[0])
+    assert n == fx["trace_len"]
+    log_N = (n * fx["lde_blowup"]).bit_length() - 1
+    want = {1: [int(v, 16) for v in fx["column1"]], 2: [int(v, 16) for v in fx["column2"]]}
+
+    def hits(offset, order):
+        g = oracle.to_mont([offset])[0]
+        total = 0
+        for c in (1, 2):
+            lde = oracle.lde(oracle.to_mont(cols[c]), 1, g)[0]
+            for q, v in zip(fx["positions"], want[c]):
+                idx = bitrev(q, log_N) if order == "bitrev" else q
+                total += int(oracle.from_mont(lde[idx][None])[0]) == v
+        return total
+    assert hits(3, "bitrev") == 2 * len(fx["positions"]) == 80
+    assert hits(3, "natural") == 0 and hits(1, "bitrev") == 0 and hits(9, "bitrev") == 0
