@@ -310,3 +310,46 @@ def test_lde_offset_pinned_by_the_reference_proof(oracle, golden):
         return total
     assert hits(3, "bitrev") == 2 * len(fx["positions"]) == 80
     assert hits(3, "natural") == 0 and hits(1, "bitrev") == 0 and hits(9, "bitrev") == 0
+
+
+def test_deep_composition_pinned_by_the_reference_proof(oracle, golden):
+    """SURVEY Appendix A M5 / M6 and the order of the out-of-domain vector, from the reference's shipped recursive proof
+    alone (tests/golden/make_deep_pin_golden.py recovers z and alpha from its data):
+      * the 33 out-of-domain values of the two program-independent columns equal T_c(z w_n^offset), in sorted
+        (column, offset) order;
+      * at every one of its 40 query points the first FRI layer holds
+          sum_j alpha^j (T_j(x) - ood_j) / (x - z w^o_j) + sum_k alpha^(133+k) (H_k(x) - oodc_k) / (x - z^2)
+        with the mask of sandstorm_amd/layouts/recursive.py in sorted order, then the composition columns;
+    (the same expression is the big-integer definition the oracle's or_deep_compose is held to in tests/test_oracle_defs.py,
+    and the GPU kernel is held to the oracle in tests/test_gpu_parity.py)."""
+    from sandstorm_amd.layouts import recursive as rec
+    from sandstorm_amd.prover import bitrev
+    from tests.test_layout_recursive import load_run
+    fx = golden("deep_pin_recursive.json")
+    h = lambda key: [int(v, 16) for v in fx[key]]
+    z, alpha, n = int(fx["z"], 16), int(fx["deep_alpha"], 16), fx["trace_len"]
+    ood_t, ood_c, base, ext, comp, deep = h("ood_trace"), h("ood_composition"), h("base_rows"), h("extension_rows"), h("composition_rows"), h("deep_values")
+    mask = rec.mask()
+    assert len(mask) == len(ood_t) == 133
+    wn = pow(3, (P - 1) // n, P)
+    states, memory, pi = load_run()
+    cols = rec.base_trace(states, memory, pi)
+    for c in (1, 2):
+        coeffs = oracle.ntt(oracle.to_mont(cols[c]), inverse=True)
+        for j, (cc, o) in enumerate(mask):
+            if cc == c:
+                assert int(oracle.from_mont(oracle.poly_eval(coeffs, oracle.to_mont([z * pow(wn, o, P) % P])[0])[None])[0]) == ood_t[j]
+    N = 2 * n
+    w_N = pow(3, (P - 1) // N, P)
+    for qi, q in enumerate(fx["positions"]):
+        x = 3 * pow(w_N, bitrev(q, N.bit_length() - 1), P) % P
+        t = base[7 * qi: 7 * qi + 7] + ext[3 * qi: 3 * qi + 3]
+        acc = 0
+        for j, (col, o) in enumerate(mask):
+            acc += pow(alpha, j, P) * (t[col] - ood_t[j]) * pow((x - z * pow(wn, o, P)) % P, -1, P)
+        for k in range(2):
+            acc += pow(alpha, 133 + k, P) * (comp[2 * qi + k] - ood_c[k]) * pow((x - z * z) % P, -1, P)
+        assert acc % P == deep[qi]
+        # a perturbed convention fails: composition point z instead of z^2
+        bad = acc - sum(pow(alpha, 133 + k, P) * (comp[2 * qi + k] - ood_c[k]) * (pow((x - z * z) % P, -1, P) - pow((x - z) % P, -1, P)) for k in range(2))
+        assert bad % P != deep[qi]
