@@ -137,4 +137,34 @@ Program lower(const Graph &g, int root) {
     return L.prog;
 }
 
+Felt evaluate(const Graph &g, int root, const Felt &x, const std::function<Felt(uint32_t, uint32_t)> &trace_at,
+              const std::function<Felt(uint32_t)> &table_at) {
+    const auto &nodes = g.nodes();
+    std::vector<Felt> val(nodes.size());
+    std::vector<char> done(nodes.size(), 0);
+    std::vector<int> stack{root};
+    while (!stack.empty()) {                            // iterative post-order: children first
+        const int id = stack.back();
+        if (done[id]) { stack.pop_back(); continue; }
+        const Node &nd = nodes[id];
+        const bool need_a = nd.a >= 0 && !done[nd.a], need_b = nd.b >= 0 && !done[nd.b];
+        if (need_a) stack.push_back(nd.a);
+        if (need_b) stack.push_back(nd.b);
+        if (need_a || need_b) continue;
+        switch (nd.kind) {
+        case NodeKind::X: val[id] = x; break;
+        case NodeKind::Const: val[id] = g.constants()[nd.p0]; break;
+        case NodeKind::Trace: val[id] = trace_at(nd.p0, nd.p1); break;
+        case NodeKind::Table: val[id] = table_at(nd.p0); break;
+        case NodeKind::Add: val[id] = felt_add(val[nd.a], val[nd.b]); break;
+        case NodeKind::Sub: val[id] = felt_sub(val[nd.a], val[nd.b]); break;
+        case NodeKind::Mul: val[id] = felt_mul(val[nd.a], val[nd.b]); break;
+        case NodeKind::Inv: val[id] = felt_inv(val[nd.a]); break;
+        }
+        done[id] = 1;
+        stack.pop_back();
+    }
+    return val[root];
+}
+
 }  // namespace ssh

@@ -5,6 +5,7 @@
 // `composition_constraint(..).reuse_shared_nodes()` and emit code for the 4-accumulator machine.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <tuple>
@@ -54,5 +55,10 @@ struct Program {
 
 // code leaving `root` in accumulator 0 followed by OUT
 Program lower(const Graph &g, int root);
+
+// Direct evaluation of the DAG at one point (the definition the lowered program must reproduce; the verifier's side of
+// the out-of-domain identity).  trace_at(col, row offset) and table_at(index) supply the leaves.
+Felt evaluate(const Graph &g, int root, const Felt &x, const std::function<Felt(uint32_t, uint32_t)> &trace_at,
+              const std::function<Felt(uint32_t)> &table_at);
 
 }  // namespace ssh

@@ -163,6 +163,15 @@ public:
         return pd;
     }
 
+    Felt composition_at(uint64_t n, const std::vector<Felt> &ch, const Felt &alpha, const Felt &z, const std::vector<Felt> &ood) override {
+        if (n != n_) throw std::runtime_error("this recursive AIR was built for another trace length");
+        Graph g;
+        const int root = composition(g, ch, alpha);
+        std::map<std::pair<uint32_t, uint32_t>, Felt> cell;
+        for (size_t j = 0; j < mask.size(); ++j) cell[mask[j]] = ood[j];
+        return evaluate(g, root, z, [&](uint32_t c, uint32_t o) { return cell.at({c, o}); }, [&](uint32_t t) { return table_value_at(specs_.at(t), z); });
+    }
+
     // flat description of the tables for host-side checks: per table kind, e, #num, (p, e)..., #den, (p, e)...
     std::vector<uint64_t> describe_tables() const {
         std::vector<uint64_t> out{specs_.size()};
@@ -444,6 +453,22 @@ private:
         return total;
     }
 
+    // the function a table tabulates, at an arbitrary point
+    Felt table_value_at(const TableSpec &s, const Felt &x) const {
+        if (s.kind <= 1) {
+            if (pedersen_coeffs_[s.kind].empty()) pedersen_coeffs_[s.kind] = interpolate(pedersen_column(s.kind));
+            const Felt arg = felt_pow(x, n_ / 2048);
+            Felt acc = felt_from_u64(0);
+            for (size_t k = pedersen_coeffs_[s.kind].size(); k-- > 0;) acc = felt_add(felt_mul(acc, arg), pedersen_coeffs_[s.kind][k]);
+            return acc;
+        }
+        if (s.kind == 3) return felt_inv(felt_sub(x, felt_pow(g_, s.e)));
+        Felt num = felt_from_u64(1), den = felt_from_u64(1);
+        for (auto &f : s.num) num = felt_mul(num, felt_sub(felt_pow(x, f.p), felt_pow(g_, f.e)));
+        for (auto &f : s.den) den = felt_mul(den, felt_sub(felt_pow(x, f.p), felt_pow(g_, f.e)));
+        return felt_mul(num, felt_inv(den));
+    }
+
     // ---- tables on the device
     void build_tables() {
         const uint64_t N = n_ << lb_;
@@ -505,6 +530,7 @@ private:
     std::map<TableSpec, int> table_ix_;
     std::vector<uint32_t> desc_;
     std::unique_ptr<DeviceBuffer> tables_;
+    mutable std::vector<Felt> pedersen_coeffs_[2];
 };
 
 }  // namespace

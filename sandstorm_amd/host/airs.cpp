@@ -16,6 +16,10 @@ static void ok(ss_status s) {
     if (s != SS_OK) throw std::runtime_error(ss_last_error());
 }
 
+Felt Air::composition_at(uint64_t, const std::vector<Felt> &, const Felt &, const Felt &, const std::vector<Felt> &) {
+    throw std::runtime_error("the " + name + " AIR has no verifier side");
+}
+
 // ---------------------------------------------------------------------------- mini
 class MiniAir : public Air {
 public:
@@ -23,10 +27,10 @@ public:
         name = "mini"; num_base_columns = 2; num_extension_columns = 1; num_challenges = 1;
         mask = {{0, 0}, {0, 1}, {1, 0}, {1, 1}, {2, 0}, {2, 1}};
     }
-    AirProgramData build_program(uint64_t n, const std::vector<Felt> &ch, const Felt &alpha) override {
+    // the composition constraint (mirror of tests/mini_air.py::composition); table 0 = 1 / (X^n - 1)
+    static int graph(Graph &g, uint64_t n, const std::vector<Felt> &ch, const Felt &alpha) {
         uint32_t log_n = 0;
         while ((1ull << log_n) < n) ++log_n;
-        Graph g;
         const Felt w = root_of_unity(log_n);
         const int X = g.x();
         const int last = g.sub(X, g.constant(felt_pow(w, n - 1)));
@@ -47,6 +51,19 @@ public:
             total = total < 0 ? term : g.add(total, term);
             ap = felt_mul(ap, alpha);
         }
+        return total;
+    }
+    Felt composition_at(uint64_t n, const std::vector<Felt> &ch, const Felt &alpha, const Felt &z, const std::vector<Felt> &ood) override {
+        Graph g;
+        const int root = graph(g, n, ch, alpha);
+        return evaluate(g, root, z, [&](uint32_t c, uint32_t o) {
+            for (size_t j = 0; j < mask.size(); ++j) if (mask[j].first == c && mask[j].second == o) return ood[j];
+            throw std::runtime_error("trace cell outside the mask");
+        }, [&](uint32_t) { return felt_inv(felt_sub(felt_pow(z, n), felt_from_u64(1))); });
+    }
+    AirProgramData build_program(uint64_t n, const std::vector<Felt> &ch, const Felt &alpha) override {
+        Graph g;
+        const int total = graph(g, n, ch, alpha);
         AirProgramData pd;
         pd.program = lower(g, total);
         // table 0 = 1/(X^n - 1) on the blowup-2 coset: x_i^n = 3^n * (-1)^i

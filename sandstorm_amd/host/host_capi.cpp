@@ -9,6 +9,7 @@
 #include "prover.hpp"
 #include "public_input.hpp"
 #include "trace_recursive.hpp"
+#include "verifier.hpp"
 
 using namespace ssh;
 
@@ -208,6 +209,24 @@ int ssh_air_dump(ssh_air *air_h, uint64_t n, const uint64_t *challenges, uint32_
         *blob = (uint64_t *)malloc(out.size() * 8);
         memcpy(*blob, out.data(), out.size() * 8);
         *blob_len = out.size();
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// Verify a proof in the reference's wire format (verifier.hpp) against an AIR handle (mini or recursive; the handle may
+// have been created without a device).  conventions: 1 = the shipped proofs' (bit-reversed, unnormalised fold, unshifted
+// remainder), 0 = the older path's.  positions_out (nullable): room for num_queries values; *n_positions is set.
+int ssh_verify(ssh_air *air_h, int tree_kind, int coin_kind, const uint8_t seed[32], const uint8_t *proof, uint64_t proof_len,
+               int conventions, uint64_t *positions_out, uint32_t *n_positions) {
+    try {
+        Air *air = reinterpret_cast<Air *>(air_h);
+        Digest sd;
+        memcpy(sd.data(), seed, 32);
+        Conventions conv;
+        if (!conventions) { conv.bitrev_commit = false; conv.fri_unnormalised = false; conv.remainder_unshifted = false; }
+        const WireProof w = parse_wire(proof, proof_len);
+        const std::vector<uint64_t> pos = verify(w, *air, tree_kind, coin_kind, sd, conv);
+        if (positions_out && n_positions) { memcpy(positions_out, pos.data(), pos.size() * 8); *n_positions = (uint32_t)pos.size(); }
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }

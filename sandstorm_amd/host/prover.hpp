@@ -92,6 +92,10 @@ public:
     uint32_t num_base_columns = 0, num_extension_columns = 0, num_challenges = 0;
     std::vector<std::pair<uint32_t, uint32_t>> mask;     // trace_arguments(): sorted (column, offset)
     virtual AirProgramData build_program(uint64_t n, const std::vector<Felt> &challenges, const Felt &composition_coeff) = 0;
+    // the verifier's side of the out-of-domain identity: the composition constraint at z, its trace cells read from the
+    // out-of-domain vector (in `mask` order), its tables evaluated as the functions they tabulate
+    virtual Felt composition_at(uint64_t n, const std::vector<Felt> &challenges, const Felt &composition_coeff, const Felt &z,
+                                const std::vector<Felt> &ood_trace);
 };
 
 struct Claim {                           // src/claims.rs:12-33

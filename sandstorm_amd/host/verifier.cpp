@@ -1,0 +1,290 @@
+#include "verifier.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <set>
+#include <stdexcept>
+
+namespace ssh {
+
+namespace {
+
+[[noreturn]] void reject(const std::string &what) { throw std::runtime_error(what); }
+void require(bool cond, const std::string &what) { if (!cond) reject(what); }
+
+// ---- wire format (layout: sandstorm_amd/wire.py)
+struct Reader {
+    const uint8_t *p;
+    size_t len, o = 0;
+    void need(size_t k) { if (o + k > len) reject("malformed proof: truncated at offset " + std::to_string(o)); }
+    uint8_t u8() { need(1); return p[o++]; }
+    uint64_t u64() { need(8); uint64_t v; memcpy(&v, p + o, 8); o += 8; return v; }
+    Felt fp() {                             // 32-byte little-endian canonical value -> Montgomery
+        need(32);
+        Felt c;
+        memcpy(c.data(), p + o, 32);
+        o += 32;
+        static const uint64_t P[4] = {1ull, 0ull, 0ull, 0x0800000000000011ull};
+        for (int i = 3; i >= 0; --i) { if (c[i] < P[i]) break; if (c[i] > P[i] || i == 0) reject("malformed proof: non-canonical field element"); }
+        return felt_from_canonical(c);
+    }
+    std::vector<Felt> vec() {
+        const uint64_t n = u64();
+        if (n > len) reject("malformed proof: vector length");
+        std::vector<Felt> v(n);
+        for (auto &x : v) x = fp();
+        return v;
+    }
+    Digest digest() {
+        if (u64() != 32) reject("malformed proof: digest length prefix is not 32");
+        need(32);
+        Digest d;
+        memcpy(d.data(), p + o, 32);
+        o += 32;
+        return d;
+    }
+    std::vector<WireOpening> openings() {
+        const uint64_t n = u64();
+        if (n > len) reject("malformed proof: opening count");
+        std::vector<WireOpening> out(n);
+        for (auto &op : out) {
+            op.variant = u8();
+            if (op.variant != 0 && op.variant != 1) reject("malformed proof: unknown opening variant");
+            const uint64_t depth = u64();
+            if (depth > 64) reject("malformed proof: path length");
+            for (uint64_t k = 0; k < depth; ++k) op.path.push_back(digest());
+            if (op.variant == 0) { op.sibling_digest = digest(); op.leaf_digest = digest(); }
+            else { op.sibling_felt = fp(); op.leaf_felt = fp(); }
+        }
+        return out;
+    }
+};
+
+Digest keccak_of(const std::vector<uint8_t> &m, bool masked) {
+    Digest d = keccak256(m.data(), m.size());
+    if (masked) for (int i = 20; i < 32; ++i) d[i] = 0;
+    return d;
+}
+void append_mont_be(std::vector<uint8_t> &m, const Felt &f) { const auto b = mont_be_bytes(f); m.insert(m.end(), b.begin(), b.end()); }
+
+struct KeccakTree {                         // LeafVariantMerkleTree<Keccak256HashFn | MaskedKeccak256HashFn<20>>
+    bool masked;
+    Digest merge(const Digest &a, const Digest &b) const {
+        std::vector<uint8_t> m(a.begin(), a.end());
+        m.insert(m.end(), b.begin(), b.end());
+        return keccak_of(m, masked);
+    }
+    Digest row_leaf(const Felt *row, size_t n) const {
+        std::vector<uint8_t> m;
+        for (size_t i = 0; i < n; ++i) append_mont_be(m, row[i]);
+        return keccak_of(m, masked);
+    }
+    Digest climb(Digest node, const std::vector<Digest> &path, size_t from, uint64_t pos) const {
+        for (size_t l = from; l < path.size(); ++l, pos >>= 1) node = (pos & 1) ? merge(path[l], node) : merge(node, path[l]);
+        return node;
+    }
+    void check(const WireOpening &op, const Felt *row, size_t ncols, uint64_t pos, uint32_t depth, const Digest &root, const std::string &what) const {
+        require(op.path.size() + 1 == depth, what + ": path length");
+        if (ncols == 1) {                   // raw-element leaves (merkle/mod.rs:113-117)
+            require(op.variant == 1 && op.leaf_felt == row[0], what + ": leaf is not the opened element");
+            std::vector<uint8_t> m;
+            if (pos & 1) { append_mont_be(m, op.sibling_felt); append_mont_be(m, op.leaf_felt); }
+            else { append_mont_be(m, op.leaf_felt); append_mont_be(m, op.sibling_felt); }
+            require(climb(keccak_of(m, masked), op.path, 0, pos >> 1) == root, what + ": authentication path does not reach the root");
+        } else {
+            require(op.variant == 0 && op.leaf_digest == row_leaf(row, ncols), what + ": leaf is not the hash of the opened row");
+            const Digest first = (pos & 1) ? merge(op.sibling_digest, op.leaf_digest) : merge(op.leaf_digest, op.sibling_digest);
+            require(climb(first, op.path, 0, pos >> 1) == root, what + ": authentication path does not reach the root");
+        }
+    }
+};
+
+uint64_t brev(uint64_t x, uint32_t bits) { uint64_t r = 0; for (uint32_t i = 0; i < bits; ++i) r |= ((x >> i) & 1ull) << (bits - 1 - i); return r; }
+uint32_t log2u(uint64_t v) { uint32_t l = 0; while ((1ull << l) < v) ++l; return l; }
+
+bool verify_pow(int coin_kind, const Digest &digest, uint32_t bits, uint64_t nonce) {      // solidity.rs:143-156, cairo.rs:156-169
+    if (!bits) return true;
+    auto h = [&](const std::vector<uint8_t> &m) { return coin_kind == SS_COIN_SOLIDITY ? keccak256(m.data(), m.size()) : blake2s256(m.data(), m.size()); };
+    std::vector<uint8_t> m = {0x01, 0x23, 0x45, 0x67, 0x89, 0xAB, 0xCD, 0xED};
+    m.insert(m.end(), digest.begin(), digest.end());
+    m.push_back((uint8_t)bits);
+    const Digest prefix = h(m);
+    std::vector<uint8_t> m2(prefix.begin(), prefix.end());
+    for (int i = 7; i >= 0; --i) m2.push_back((uint8_t)(nonce >> (8 * i)));
+    const Digest out = h(m2);
+    for (uint32_t b = 0; b < bits; ++b) if ((out[b / 8] >> (7 - b % 8)) & 1) return false;
+    return true;
+}
+
+Felt interpolate_eval(const std::vector<Felt> &xs, const Felt *ys, const Felt &t) {
+    Felt acc = felt_from_u64(0);
+    for (size_t i = 0; i < xs.size(); ++i) {
+        Felt num = felt_from_u64(1), den = felt_from_u64(1);
+        for (size_t j = 0; j < xs.size(); ++j) if (i != j) { num = felt_mul(num, felt_sub(t, xs[j])); den = felt_mul(den, felt_sub(xs[i], xs[j])); }
+        acc = felt_add(acc, felt_mul(ys[i], felt_mul(num, felt_inv(den))));
+    }
+    return acc;
+}
+
+}  // namespace
+
+WireProof parse_wire(const uint8_t *data, size_t len) {
+    Reader r{data, len};
+    WireProof p;
+    for (auto &o : p.options) o = r.u8();
+    p.trace_len = r.u64();
+    p.base_root = r.digest();
+    const uint8_t has_ext = r.u8();
+    if (has_ext > 1) reject("malformed proof: bad Option tag for the extension root");
+    p.has_extension = has_ext == 1;
+    if (p.has_extension) p.extension_root = r.digest();
+    p.composition_root = r.digest();
+    const uint64_t layers = r.u64();
+    if (layers > 64) reject("malformed proof: FRI layer count");
+    for (uint64_t l = 0; l < layers; ++l) {
+        WireFriLayer L;
+        L.rows = r.vec();
+        L.openings = r.openings();
+        L.root = r.digest();
+        p.fri_layers.push_back(std::move(L));
+    }
+    p.remainder = r.vec();
+    p.pow_nonce = r.u64();
+    p.base_rows = r.vec(); p.extension_rows = r.vec(); p.composition_rows = r.vec();
+    p.base_openings = r.openings(); p.extension_openings = r.openings(); p.composition_openings = r.openings();
+    p.ood_trace = r.vec(); p.ood_composition = r.vec();
+    if (r.o != len) reject("malformed proof: " + std::to_string(len - r.o) + " trailing bytes");
+    return p;
+}
+
+std::vector<uint64_t> verify(const WireProof &w, Air &air, int tree_kind, int coin_kind, const Digest &coin_seed, const Conventions &conv) {
+    require(tree_kind == SS_TREE_KECCAK || tree_kind == SS_TREE_KECCAK_M20, "the wire format covers the Keccak trees only");
+    const KeccakTree tree{tree_kind == SS_TREE_KECCAK_M20};
+    const uint32_t num_queries = w.options[0], blowup = w.options[1], grinding = w.options[2], fold = w.options[3], max_remainder = w.options[4];
+    const uint64_t n = w.trace_len;
+    require(n >= 2 && !(n & (n - 1)) && blowup >= 2 && !(blowup & (blowup - 1)), "bad trace length / blowup");
+    require(fold == 2 || fold == 4 || fold == 8 || fold == 16, "bad FRI folding factor");
+    const uint64_t N = n * blowup;
+    const uint32_t log_N = log2u(N), log_fold = log2u(fold), ncomp = conv.composition_columns;
+    const size_t nmask = air.mask.size();
+    auto expo = [&](uint64_t i, uint32_t bits) { return conv.bitrev_commit ? brev(i, bits) : i; };
+
+    // ---- 1. transcript (prover.cpp steps 2-9)
+    require(w.ood_trace.size() == nmask && w.ood_composition.size() == ncomp, "out-of-domain vector lengths");
+    require(w.has_extension == (air.num_extension_columns > 0), "extension root presence");
+    PublicCoin coin(coin_kind, coin_seed);
+    coin.reseed_with_digest(w.base_root);
+    std::vector<Felt> challenges;
+    for (uint32_t i = 0; i < air.num_challenges; ++i) challenges.push_back(coin.draw());
+    if (w.has_extension) coin.reseed_with_digest(w.extension_root);
+    const Felt comp_coeff = coin.draw();
+    coin.reseed_with_digest(w.composition_root);
+    const Felt z = coin.draw();
+    {
+        std::vector<Felt> all = w.ood_trace;
+        all.insert(all.end(), w.ood_composition.begin(), w.ood_composition.end());
+        coin.reseed_with_field_elements(all);
+    }
+    const Felt deep_alpha = coin.draw();
+    uint64_t degree_bound = n, nlayers = 0;
+    while (degree_bound > max_remainder) { degree_bound /= fold; ++nlayers; }
+    require(w.fri_layers.size() == nlayers, "number of FRI layers");
+    require(w.remainder.size() == std::max<uint64_t>(1, degree_bound), "remainder length");
+    std::vector<Felt> fri_alphas;
+    for (auto &layer : w.fri_layers) { coin.reseed_with_digest(layer.root); fri_alphas.push_back(coin.draw()); }
+    coin.reseed_with_field_element_vector(w.remainder);
+    require(verify_pow(coin_kind, coin.digest(), grinding, w.pow_nonce), "proof of work");
+    coin.reseed_with_int(w.pow_nonce);
+    const std::vector<uint64_t> positions = coin.draw_queries(num_queries, N);
+    const size_t nq = positions.size();
+
+    // ---- 2. out-of-domain identity: sum_k alpha^k C_k(z) == sum_k z^k H_k(z^ncomp)
+    {
+        const Felt lhs = air.composition_at(n, challenges, comp_coeff, z, w.ood_trace);
+        Felt rhs = felt_from_u64(0), zk = felt_from_u64(1);
+        for (uint32_t k = 0; k < ncomp; ++k) { rhs = felt_add(rhs, felt_mul(zk, w.ood_composition[k])); zk = felt_mul(zk, z); }
+        require(lhs == rhs, "out-of-domain identity: the composition constraint does not match the composition columns at z");
+    }
+
+    // ---- 3./4. trace openings and the DEEP value at every query
+    const size_t ncb = air.num_base_columns, nce = air.num_extension_columns;
+    require(w.base_rows.size() == nq * ncb && w.base_openings.size() == nq, "base rows / openings count");
+    require(w.extension_rows.size() == nq * nce && w.extension_openings.size() == (nce ? nq : 0), "extension rows / openings count");
+    require(w.composition_rows.size() == nq * ncomp && w.composition_openings.size() == nq, "composition rows / openings count");
+    const Felt offset0 = felt_from_u64(conv.lde_offset), wN = root_of_unity(log_N), wn = root_of_unity(log2u(n));
+    std::vector<Felt> coef{felt_from_u64(1)};
+    for (size_t j = 1; j < nmask + ncomp; ++j) coef.push_back(felt_mul(coef.back(), deep_alpha));
+    const Felt zc = felt_pow(z, ncomp);
+    std::vector<std::vector<uint64_t>> layer_positions;
+    {
+        std::vector<uint64_t> p = positions;
+        for (size_t li = 0; li < w.fri_layers.size(); ++li) {
+            const uint32_t row_bits = log_N - log_fold * (uint32_t)(li + 1);
+            std::set<uint64_t> s;
+            for (uint64_t q : p) s.insert(conv.bitrev_commit ? (q >> log_fold) : (q % (1ull << row_bits)));
+            p.assign(s.begin(), s.end());
+            layer_positions.push_back(p);
+            require(w.fri_layers[li].openings.size() == p.size() && w.fri_layers[li].rows.size() == fold * p.size(),
+                    "FRI layer " + std::to_string(li) + " rows / openings count");
+        }
+    }
+    for (size_t qi = 0; qi < nq; ++qi) {
+        const uint64_t q = positions[qi];
+        const Felt x = felt_mul(offset0, felt_pow(wN, expo(q, log_N)));
+        const std::string tag = ", query " + std::to_string(qi);
+        tree.check(w.base_openings[qi], &w.base_rows[ncb * qi], ncb, q, log_N, w.base_root, "base trace" + tag);
+        if (nce) tree.check(w.extension_openings[qi], &w.extension_rows[nce * qi], nce, q, log_N, w.extension_root, "extension trace" + tag);
+        tree.check(w.composition_openings[qi], &w.composition_rows[ncomp * qi], ncomp, q, log_N, w.composition_root, "composition trace" + tag);
+        if (w.fri_layers.empty()) continue;
+        Felt deep = felt_from_u64(0);
+        for (size_t j = 0; j < nmask; ++j) {                    // src/lib.rs:102-116: alpha^j over the mask cells, then the columns
+            const uint32_t c = air.mask[j].first, o = air.mask[j].second;
+            const Felt &t = c < ncb ? w.base_rows[ncb * qi + c] : w.extension_rows[nce * qi + (c - ncb)];
+            deep = felt_add(deep, felt_mul(coef[j], felt_mul(felt_sub(t, w.ood_trace[j]), felt_inv(felt_sub(x, felt_mul(z, felt_pow(wn, o)))))));
+        }
+        for (uint32_t k = 0; k < ncomp; ++k)
+            deep = felt_add(deep, felt_mul(coef[nmask + k], felt_mul(felt_sub(w.composition_rows[ncomp * qi + k], w.ood_composition[k]), felt_inv(felt_sub(x, zc)))));
+        const uint64_t rows0 = N / fold;
+        const uint64_t r = conv.bitrev_commit ? (q >> log_fold) : (q % rows0), slot = conv.bitrev_commit ? (q & (fold - 1)) : (q / rows0);
+        const auto &lp = layer_positions[0];
+        const size_t li0 = std::lower_bound(lp.begin(), lp.end(), r) - lp.begin();
+        require(w.fri_layers[0].rows[fold * li0 + slot] == deep, "DEEP composition value at query " + std::to_string(qi));
+    }
+
+    // ---- 5. FRI: every opened row folds into the next layer (or the remainder)
+    Felt offset = offset0;
+    for (size_t li = 0; li < w.fri_layers.size(); ++li) {
+        const auto &layer = w.fri_layers[li];
+        const uint32_t row_bits = log_N - log_fold * (uint32_t)(li + 1);
+        const uint64_t rows = 1ull << row_bits;
+        const Felt wl = root_of_unity(row_bits + log_fold), wf = root_of_unity(log_fold);
+        for (size_t pi = 0; pi < layer_positions[li].size(); ++pi) {
+            const uint64_t r = layer_positions[li][pi];
+            const Felt *ys = &layer.rows[fold * pi];
+            tree.check(layer.openings[pi], ys, fold, r, row_bits, layer.root, "FRI layer " + std::to_string(li) + ", row " + std::to_string(r));
+            const Felt xr0 = felt_mul(offset, felt_pow(wl, expo(r, row_bits)));
+            std::vector<Felt> xs;
+            for (uint32_t k = 0; k < fold; ++k) xs.push_back(felt_mul(xr0, felt_pow(wf, expo(k, log_fold))));
+            Felt folded = interpolate_eval(xs, ys, fri_alphas[li]);
+            if (conv.fri_unnormalised) folded = felt_mul(folded, felt_from_u64(fold));
+            if (li + 1 < w.fri_layers.size()) {
+                const uint64_t nrows = rows >> log_fold;
+                const uint64_t nr = conv.bitrev_commit ? (r >> log_fold) : (r % nrows), slot = conv.bitrev_commit ? (r & (fold - 1)) : (r / nrows);
+                const auto &np_ = layer_positions[li + 1];
+                const size_t ni = std::lower_bound(np_.begin(), np_.end(), nr) - np_.begin();
+                require(w.fri_layers[li + 1].rows[fold * ni + slot] == folded,
+                        "FRI layer " + std::to_string(li) + " does not fold into layer " + std::to_string(li + 1) + " at row " + std::to_string(r));
+            } else {
+                Felt xr = felt_pow(root_of_unity(row_bits), expo(r, row_bits));
+                if (!conv.remainder_unshifted) xr = felt_mul(xr, felt_pow(offset, fold));
+                Felt acc = felt_from_u64(0);
+                for (size_t k = w.remainder.size(); k-- > 0;) acc = felt_add(felt_mul(acc, xr), w.remainder[k]);
+                require(acc == folded, "last FRI layer does not fold into the remainder at row " + std::to_string(r));
+            }
+        }
+        offset = felt_pow(offset, fold);
+    }
+    return positions;
+}
+
+}  // namespace ssh

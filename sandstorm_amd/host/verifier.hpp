@@ -1,0 +1,38 @@
+// verifier.hpp — host-side verifier of proofs in the reference's wire format, C++ mirror of
+// sandstorm_amd/verifier.py / wire.py: transcript replay, out-of-domain identity, Merkle openings, DEEP values, FRI
+// chain, remainder, proof of work — under the conventions the reference's shipped proofs pin (prover.hpp Conventions).
+// Keccak trees only (the wire encoding of FriendlyMerkleTree proofs has no reference sample).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "prover.hpp"
+
+namespace ssh {
+
+struct WireOpening {
+    int variant = 0;                        // 0: hashed leaves (digest sibling / leaf), 1: single column (felt sibling / leaf)
+    std::vector<Digest> path;               // above the leaf pair, bottom-up
+    Digest sibling_digest{}, leaf_digest{};
+    Felt sibling_felt{}, leaf_felt{};       // Montgomery
+};
+struct WireFriLayer { std::vector<Felt> rows; std::vector<WireOpening> openings; Digest root{}; };
+struct WireProof {
+    uint32_t options[5] = {0, 0, 0, 0, 0};
+    uint64_t trace_len = 0, pow_nonce = 0;
+    Digest base_root{}, extension_root{}, composition_root{};
+    bool has_extension = false;
+    std::vector<WireFriLayer> fri_layers;
+    std::vector<Felt> remainder, base_rows, extension_rows, composition_rows, ood_trace, ood_composition;
+    std::vector<WireOpening> base_openings, extension_openings, composition_openings;
+};
+
+// throws std::runtime_error("malformed proof: ...") on any structural problem, trailing bytes included
+WireProof parse_wire(const uint8_t *data, size_t len);
+
+// throws std::runtime_error naming the failed check; returns the query positions
+std::vector<uint64_t> verify(const WireProof &proof, Air &air, int tree_kind, int coin_kind, const Digest &coin_seed,
+                             const Conventions &conv = Conventions());
+
+}  // namespace ssh

@@ -48,6 +48,8 @@ def load():
                                                C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         h.ssh_air_dump.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64),
                                    C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
+        h.ssh_verify.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_uint32)]
         h.ssh_matrix_num_cols.argtypes = [C.c_void_p]
         h.ssh_matrix_num_cols.restype = C.c_uint32
         h.ssh_matrix_col.argtypes = [C.c_void_p, C.c_uint32]
@@ -69,8 +71,8 @@ def _check(rc):
 
 class HostAir:
     def __init__(self, ctx, kind, log_n, log_blowup=1):
-        self.ctx, self.h = ctx, C.c_void_p()
-        _check(load().ssh_air_create(ctx.handle, kind, log_n, log_blowup, C.byref(self.h)))
+        self.ctx, self.h = ctx, C.c_void_p()        # ctx=None: host-only handle (verification; no device tables)
+        _check(load().ssh_air_create(ctx.handle if ctx is not None else None, kind, log_n, log_blowup, C.byref(self.h)))
         self.num_base_columns = load().ssh_air_columns(self.h, 0)
         self.num_extension_columns = load().ssh_air_columns(self.h, 1)
         self.mask_size = load().ssh_air_columns(self.h, 2)
@@ -321,6 +323,16 @@ def recursive_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=
                                            rc.ctypes.data_as(u64p), len(private_input.get("range_check", [])),
                                            bw.ctypes.data_as(u64p), len(private_input.get("bitwise", [])), ptrs))
     return cols
+
+
+def verify(air: HostAir, tree_kind, coin_kind, seed, proof: bytes, shipped_conventions=True):
+    """the C++ host's verifier (sandstorm_amd/host/verifier.cpp) on a proof in the reference's wire format; raises
+    SandstormHipError naming the failed check, returns the query positions"""
+    pos = np.zeros(256, dtype=np.uint64)
+    npos = C.c_uint32()
+    _check(load().ssh_verify(air.h, tree_kind, coin_kind, bytes(seed), bytes(proof), len(proof), 1 if shipped_conventions else 0,
+                             pos.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(npos)))
+    return [int(v) for v in pos[:npos.value]]
 
 
 class HostCoin:

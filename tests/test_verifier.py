@@ -131,3 +131,50 @@ def test_committed_proof_of_the_reference_example_verifies():
     # same seed, wrong hint: the transcript replays, the out-of-domain identity must catch it
     with pytest.raises(verifier.VerificationError, match="out-of-domain identity"):
         verifier.verify(raw, rec.verifier_air(pi2), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
+
+
+def test_cpp_verifier_on_the_committed_proofs():
+    """sandstorm_amd/host/verifier.cpp (wire parser, transcript, OOD identity through the C++ AIRs, openings, DEEP, FRI):
+    accepts the three committed proofs with the positions the Python verifier finds, rejects tampered bytes with the
+    same diagnosis, and rejects another public input"""
+    import copy
+    from sandstorm_amd import backend as be, hostlib, public_input, verifier, wire
+    from sandstorm_amd._lib import SandstormHipError
+    from sandstorm_amd.layouts import recursive as rec
+    for log_n in (5, 9):
+        raw, seed, _ = load_fixture(log_n)
+        air = hostlib.HostAir(None, hostlib.AIR_MINI, log_n)
+        assert hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw) == \
+            verifier.verify(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+        if log_n == 5:
+            w = wire.parse(raw)
+            w.base_rows[0] = (w.base_rows[0] + 1) % verifier.P
+            with pytest.raises(SandstormHipError, match="base trace"):
+                hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, wire.serialize(w))
+            w = wire.parse(raw)
+            w.fri_layers[0].rows[3] = (w.fri_layers[0].rows[3] + 1) % verifier.P
+            with pytest.raises(SandstormHipError, match="FRI layer 0"):
+                hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, wire.serialize(w))
+            w = wire.parse(raw)
+            w.ood_composition[1] = (w.ood_composition[1] + 1) % verifier.P
+            with pytest.raises(SandstormHipError):
+                hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, wire.serialize(w))
+            with pytest.raises(SandstormHipError, match="malformed"):
+                hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw[:-3])
+            with pytest.raises(SandstormHipError):
+                hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw, shipped_conventions=False)
+        air.close()
+    pi = public_input.AirPublicInput.from_json(os.path.join(GOLD, "air_public_input_array_sum.json"))
+    with open(os.path.join(GOLD, "array_sum_recursive_eth.proof"), "rb") as f:
+        raw = f.read()
+    seed = public_input.public_coin_seed(pi, be.COIN_SOLIDITY)
+    air = hostlib.RecursiveHostAir(None, pi, 18)
+    assert hostlib.verify(air, be.TREE_KECCAK, be.COIN_SOLIDITY, seed, raw) == \
+        verifier.verify(raw, rec.verifier_air(pi), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
+    air.close()
+    pi2 = copy.deepcopy(pi)
+    pi2.rc_max += 1
+    air2 = hostlib.RecursiveHostAir(None, pi2, 18)
+    with pytest.raises(SandstormHipError, match="out-of-domain identity"):
+        hostlib.verify(air2, be.TREE_KECCAK, be.COIN_SOLIDITY, seed, raw)              # same transcript, wrong hint
+    air2.close()
