@@ -1,7 +1,6 @@
-// airs.cpp — the two AIRs the C++ host ships: the small valid "mini" AIR used by the
-// end-to-end tests (mirror of tests/mini_air.py) and the layout-SHAPED synthetic AIR that
-// bench.py drives (mirror of sandstorm_amd/synthetic_air.py; see its header for why the
-// real recursive/starknet constraint sets are not here yet).
+// airs.cpp — the small valid "mini" AIR used by the end-to-end tests (mirror of tests/mini_air.py)
+// and the layout-SHAPED synthetic AIR that bench.py drives at sizes for which no valid trace exists
+// (mirror of sandstorm_amd/synthetic_air.py).  The real `recursive` layout is in air_recursive.cpp.
 #include <algorithm>
 #include <cstring>
 #include <random>

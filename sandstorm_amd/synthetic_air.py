@@ -2,8 +2,11 @@
 
 The reference's real constraint sets (93 constraints for `recursive`, 195 for
 `starknet`; layouts/src/{recursive,starknet}/air.rs) are lowered by the host from
-its `Expr` DAG; until that restatement lands, the bench drives the same kernels
-with a synthetic composition constraint that has the layout's *shape*: the same
+its `Expr` DAG.  The `recursive` set is restated (sandstorm_amd/layouts/recursive.py) but
+needs a VALID trace, which exists only at the size of the reference's example run; the
+`starknet` set is not restated yet.  For the benchmark sizes (2^16 .. 2^22 steps of
+random columns) the bench therefore drives the same kernels with a synthetic
+composition constraint that has the layout's *shape*: the same
 column counts, the same mask (SURVEY.md §8a "Mask / zerofier note": 133 cells for
 recursive — the exact list — and 269 for starknet with the per-column counts and
 maximum offsets), degree-2 constraints, one alpha power per constraint (constraints
