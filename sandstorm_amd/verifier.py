@@ -167,6 +167,29 @@ def verify(proof, air: VerifierAir, tree_kind, coin_kind, coin_seed: bytes, conv
     rhs = sum(pow(z, k, P) * h for k, h in enumerate(w.ood_composition)) % P
     _require(lhs == rhs, "out-of-domain identity: the composition constraint does not match the composition columns at z")
 
+    check_proof_data(w, air.mask, air.num_base_columns, air.num_extension_columns, tree_kind, z, deep_alpha, fri_alphas, positions, conv)
+    return positions
+
+
+def check_proof_data(w, mask, num_base_columns, num_extension_columns, tree_kind, z, deep_alpha, fri_alphas, positions, conv=None):
+    """Everything below the transcript: Merkle openings of the opened rows, the DEEP value of every query against the
+    first FRI layer, the FRI chain and the remainder — for given out-of-domain point, DEEP coefficient, FRI challenges
+    (canonical ints) and query positions.  `verify` calls it with the values its transcript replay produced; the tests
+    also run it on the reference's own shipped proof with the values recovered from that proof's data
+    (tests/golden/deep_pin_recursive.json), where no transcript is available."""
+    conv = conv or Conventions()
+    num_queries, blowup, grinding, fold, max_remainder = w.options
+    n = w.trace_len
+    N = n * blowup
+    log_N, log_fold = N.bit_length() - 1, fold.bit_length() - 1
+    ncomp, nmask, nq = conv.composition_columns, len(mask), len(positions)
+    tree = _KeccakTree(tree_kind)
+    expo = (lambda i, bits: bitrev(i, bits)) if conv.bitrev_commit else (lambda i, bits: i)
+
+    class _Shape:
+        pass
+    air = _Shape()
+    air.mask, air.num_base_columns, air.num_extension_columns = mask, num_base_columns, num_extension_columns
     # ---- 3./4. trace openings and the DEEP value at every query
     ncb, nce = air.num_base_columns, air.num_extension_columns
     _require(len(w.base_rows) == nq * ncb and len(w.base_openings) == nq, "base rows / openings count")

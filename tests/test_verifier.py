@@ -178,3 +178,36 @@ def test_cpp_verifier_on_the_committed_proofs():
     with pytest.raises(SandstormHipError, match="out-of-domain identity"):
         hostlib.verify(air2, be.TREE_KECCAK, be.COIN_SOLIDITY, seed, raw)              # same transcript, wrong hint
     air2.close()
+
+
+REFERENCE_PROOF = "/root/reference/bootloader-proof.bin"
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_PROOF), reason="the reference checkout is only mounted in the build container")
+def test_reference_proof_passes_every_check_below_the_transcript(golden):
+    """The reference's own shipped recursive-layout proof through this repo's verifier, minus the transcript (its public
+    input is not shipped): with the out-of-domain point and DEEP coefficient recovered from its data
+    (deep_pin_recursive.json) and the FRI challenges recovered from its layers (saved_proof_openings_recursive.json),
+    every Merkle opening, the DEEP value of all 40 queries, the whole FRI chain and the 64-coefficient remainder check out
+    under the mask of layouts/recursive.py and the default conventions; perturbing any recovered value fails."""
+    from sandstorm_amd import backend as be, verifier, wire
+    from sandstorm_amd.layouts import recursive as rec
+    with open(REFERENCE_PROOF, "rb") as f:
+        w = wire.parse(f.read())
+    pin, fri = golden("deep_pin_recursive.json"), golden("saved_proof_openings_recursive.json")
+    z, alpha = int(pin["z"], 16), int(pin["deep_alpha"], 16)
+    consts = [int(c, 16) for c in fri["alpha_over_offset"]] + [int(fri["last_alpha_over_offset"], 16)]
+    fri_alphas = [c * pow(3, 8 ** i, verifier.P) % verifier.P for i, c in enumerate(consts)]       # alpha_i = (alpha_i / offset_i) * 3^(8^i)
+    assert len(fri_alphas) == len(w.fri_layers) == 4 and len(w.remainder) == 64
+    args = (w, rec.mask(), 7, 3, be.TREE_KECCAK_M20)
+    assert verifier.check_proof_data(*args, z, alpha, fri_alphas, pin["positions"]) == pin["positions"]
+    with pytest.raises(verifier.VerificationError, match="DEEP composition value"):
+        verifier.check_proof_data(*args, z, alpha + 1, fri_alphas, pin["positions"])
+    with pytest.raises(verifier.VerificationError, match="DEEP composition value"):
+        verifier.check_proof_data(*args, z + 1, alpha, fri_alphas, pin["positions"])
+    with pytest.raises(verifier.VerificationError, match="FRI layer 1 does not fold"):
+        verifier.check_proof_data(*args, z, alpha, fri_alphas[:1] + [fri_alphas[1] + 1] + fri_alphas[2:], pin["positions"])
+    with pytest.raises(verifier.VerificationError, match="remainder"):
+        verifier.check_proof_data(*args, z, alpha, fri_alphas[:3] + [fri_alphas[3] + 1], pin["positions"])
+    with pytest.raises(verifier.VerificationError):
+        verifier.check_proof_data(w, rec.mask(), 7, 3, be.TREE_KECCAK, z, alpha, fri_alphas, pin["positions"])      # unmasked hashes
