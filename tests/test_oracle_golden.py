@@ -353,3 +353,19 @@ def test_deep_composition_pinned_by_the_reference_proof(oracle, golden):
         # a perturbed convention fails: composition point z instead of z^2
         bad = acc - sum(pow(alpha, 133 + k, P) * (comp[2 * qi + k] - ood_c[k]) * (pow((x - z * z) % P, -1, P) - pow((x - z) % P, -1, P)) for k in range(2))
         assert bad % P != deep[qi]
+
+
+def test_starknet_ood_vector_is_in_column_order(golden):
+    """The starknet-layout proofs' 269 out-of-domain values are grouped by column with the per-column cell counts of
+    SURVEY.md 8a (16, 5, 4, 9, 2, ...): in `example/array-sum.proof.saved`, a run without Pedersen instances, the
+    Pedersen partial-sum columns 1 and 2 are the constants P0.x and P0.y and columns 3 and 4 (suffix, slope) are zero —
+    exactly the 5, 4, 9 and 2 entries that follow the 16 flag cells, and no entry next to them."""
+    from sandstorm_amd.layouts.recursive import PEDERSEN_POINTS
+    entry = next(e for e in golden("saved_proofs.json") if e["file"] == "example/array-sum.proof.saved")
+    ood = [int(v) for v in entry["ood_trace"]]
+    px, py = PEDERSEN_POINTS[0]
+    counts = [16, 5, 4, 9, 2]
+    start = [sum(counts[:c]) for c in range(len(counts) + 1)]
+    assert ood[start[1]:start[2]] == [px] * 5 and ood[start[2]:start[3]] == [py] * 4
+    assert ood[start[3]:start[4]] == [0] * 9 and ood[start[4]:start[5]] == [0] * 2
+    assert ood[start[1] - 1] not in (px, py, 0) and ood[start[5]] != 0
