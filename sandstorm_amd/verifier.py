@@ -111,7 +111,15 @@ def _interpolate_eval(xs, ys, t):
 
 def verify(proof, air: VerifierAir, tree_kind, coin_kind, coin_seed: bytes, conv: Conventions = None):
     """proof: bytes in the reference's wire format, or a wire.WireProof.  Raises VerificationError; returns the
-    query positions on success."""
+    query positions on success.  The bytes are untrusted: any arithmetic or indexing accident they provoke (a zero
+    denominator, a missing position) is a rejection too."""
+    try:
+        return _verify(proof, air, tree_kind, coin_kind, coin_seed, conv)
+    except (ValueError, IndexError, KeyError, ZeroDivisionError, OverflowError) as e:
+        raise VerificationError("malformed proof: %s: %s" % (type(e).__name__, e))
+
+
+def _verify(proof, air, tree_kind, coin_kind, coin_seed, conv):
     conv = conv or Conventions()
     try:
         w = wire.parse(bytes(proof)) if isinstance(proof, (bytes, bytearray, memoryview)) else proof

@@ -82,40 +82,51 @@ class WireProof:
 
 # ------------------------------------------------------------------------------------------- parse
 class _Reader:
+    """bounds-checked cursor: the bytes are untrusted"""
+
     def __init__(self, raw):
         self.raw, self.o = raw, 0
 
+    def _take(self, k):
+        if self.o + k > len(self.raw):
+            raise ValueError("truncated at offset %d" % self.o)
+        self.o += k
+        return self.raw[self.o - k:self.o]
+
     def u8(self):
-        self.o += 1
-        return self.raw[self.o - 1]
+        return self._take(1)[0]
 
     def u64(self):
-        self.o += 8
-        return int.from_bytes(self.raw[self.o - 8:self.o], "little")
+        return int.from_bytes(self._take(8), "little")
+
+    def count(self, unit):
+        """a length prefix of items at least `unit` bytes each"""
+        n = self.u64()
+        if n * unit > len(self.raw) - self.o:
+            raise ValueError("count %d at offset %d exceeds the remaining bytes" % (n, self.o - 8))
+        return n
 
     def fp(self):
-        self.o += 32
-        v = int.from_bytes(self.raw[self.o - 32:self.o], "little")
+        v = int.from_bytes(self._take(32), "little")
         if v >= P:
             raise ValueError("non-canonical field element at offset %d" % (self.o - 32))
         return v
 
     def vec(self):
-        return [self.fp() for _ in range(self.u64())]
+        return [self.fp() for _ in range(self.count(32))]
 
     def digest(self):
         if self.u64() != 32:
             raise ValueError("digest length prefix is not 32 at offset %d" % (self.o - 8))
-        self.o += 32
-        return bytes(self.raw[self.o - 32:self.o])
+        return bytes(self._take(32))
 
     def openings(self):
         out = []
-        for _ in range(self.u64()):
+        for _ in range(self.count(9)):
             variant = self.u8()
             if variant not in (0, 1):
                 raise ValueError("unknown opening variant %d at offset %d" % (variant, self.o - 1))
-            path = [self.digest() for _ in range(self.u64())]
+            path = [self.digest() for _ in range(self.count(40))]
             if variant == 0:
                 out.append(Opening(0, path, self.digest(), self.digest()))
             else:
@@ -133,7 +144,7 @@ def parse(raw: bytes) -> WireProof:
         raise ValueError("bad Option tag for the extension root")
     ext_root = r.digest() if has_ext else None
     p = WireProof(options, trace_len, base_root, ext_root, r.digest())
-    for _ in range(r.u64()):
+    for _ in range(r.count(48)):
         rows = r.vec()
         openings = r.openings()
         p.fri_layers.append(WireFriLayer(rows, openings, r.digest()))

@@ -211,3 +211,49 @@ def test_reference_proof_passes_every_check_below_the_transcript(golden):
         verifier.check_proof_data(*args, z, alpha, fri_alphas[:3] + [fri_alphas[3] + 1], pin["positions"])
     with pytest.raises(verifier.VerificationError):
         verifier.check_proof_data(w, rec.mask(), 7, 3, be.TREE_KECCAK, z, alpha, fri_alphas, pin["positions"])      # unmasked hashes
+
+
+def test_parsers_survive_mutated_proofs():
+    """both wire parsers / verifiers take untrusted bytes: random byte flips, truncations, length-field blow-ups and
+    splices of a valid proof must end in a clean rejection (VerificationError / SandstormHipError), never in a crash or
+    an acceptance"""
+    import random
+    from sandstorm_amd import backend as be, hostlib, verifier
+    from sandstorm_amd._lib import SandstormHipError
+    raw, seed, _ = load_fixture(5)
+    air_py, air_cpp = mini_verifier_air(), hostlib.HostAir(None, hostlib.AIR_MINI, 5)
+    rng = random.Random(2024)
+    accepted = 0
+    for it in range(400):
+        b = bytearray(raw)
+        kind = it % 4
+        if kind == 0:                                   # flip 1..3 random bytes
+            for _ in range(rng.randrange(1, 4)):
+                i = rng.randrange(len(b))
+                b[i] ^= 1 << rng.randrange(8)
+        elif kind == 1:                                 # truncate / extend
+            b = b[:rng.randrange(len(b))] if rng.random() < 0.7 else b + bytes(rng.randrange(1, 40))
+        elif kind == 2:                                 # overwrite an aligned 8-byte field with a huge or odd count
+            i = rng.randrange(0, len(b) - 8)
+            b[i:i + 8] = rng.choice([2**63, 2**32 + 7, 0, 2**64 - 1, len(b) + 1]).to_bytes(8, "little")
+        else:                                           # splice a chunk from elsewhere
+            i, j, ln = rng.randrange(len(b)), rng.randrange(len(b)), rng.randrange(1, 200)
+            b[i:i + ln] = b[j:j + ln]
+        b = bytes(b)
+        if b == raw:
+            continue
+        outcomes = []
+        try:
+            verifier.verify(b, air_py, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+            outcomes.append("ok")
+        except verifier.VerificationError:
+            outcomes.append("rejected")
+        try:
+            hostlib.verify(air_cpp, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, b)
+            outcomes.append("ok")
+        except SandstormHipError:
+            outcomes.append("rejected")
+        assert outcomes[0] == outcomes[1], (it, kind, outcomes)
+        accepted += outcomes[0] == "ok"
+    assert accepted == 0
+    air_cpp.close()
