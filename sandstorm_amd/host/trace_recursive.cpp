@@ -1,6 +1,9 @@
 #include "trace_recursive.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -26,6 +29,13 @@ enum { AUX_AP = 1, AUX_TMP0 = 3, AUX_OP0_MUL_OP1 = 5, AUX_FP = 9, AUX_TMP1 = 11,
 // enum Flag (binary/src/lib.rs:740-772)
 enum { F_DST_REG, F_OP0_REG, F_OP1_IMM, F_OP1_FP, F_OP1_AP, F_RES_ADD, F_RES_MUL, F_PC_JUMP_ABS, F_PC_JUMP_REL, F_PC_JNZ, F_AP_ADD, F_AP_ADD1,
        F_OPCODE_CALL, F_OPCODE_RET, F_OPCODE_ASSERT_EQ, F_ZERO };
+
+// OpenMP only pays above this many cycles (thread start-up is ~50 ms of a 150 ms job at 2^14 cycles).
+// SSH_TRACE_PARALLEL_MIN overrides it (tests force the parallel path on the small example with =1).
+uint64_t parallel_min_cycles() {
+    if (const char *e = getenv("SSH_TRACE_PARALLEL_MIN")) return strtoull(e, nullptr, 10);
+    return 1ull << 16;
+}
 
 [[noreturn]] void fail(const std::string &m) { throw std::runtime_error("recursive trace: " + m); }
 
@@ -180,12 +190,22 @@ void read_memory(const uint8_t *data, size_t len, std::vector<U256> &memory, std
 
 std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
                                                     const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv) {
+    const bool timing = getenv("SSH_TRACE_TIMING") != nullptr;   // diagnostic: per-section wall time on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[trace timing] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     const uint64_t num_cycles = states.size();
     if (!num_cycles || (num_cycles & (num_cycles - 1))) fail("the number of cycles must be a power of two");
     const uint64_t n = num_cycles * CYCLE_HEIGHT;
     const Mem mem{memory, present};
     const Felt zero = felt_from_u64(0);
-    std::vector<std::vector<Felt>> cols(NUM_COLS, std::vector<Felt>(n, zero));
+    const bool par = num_cycles >= parallel_min_cycles();
+    std::vector<std::vector<Felt>> cols(NUM_COLS);
+    for (auto &c : cols) c.resize(n);                   // value-initialised to zero limbs = the field's zero
     auto &flags = cols[COL_FLAGS], &un_col = cols[COL_DILUTED_UNORDERED], &od_col = cols[COL_DILUTED_ORDERED], &npc = cols[COL_NPC],
          &mem_col = cols[COL_MEMORY], &rc_col = cols[COL_RANGE_CHECK], &aux = cols[COL_AUXILIARY];
     std::vector<uint64_t> npc_addr(n / 2, 0);           // the address half of the pool, as integers (sorting, gap search)
@@ -194,14 +214,20 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
     for (auto &e : pi.public_memory) if (e.address == 1) { padding = &e; break; }
     if (!padding) fail("public memory has no entry at address 1");
     const Felt pad_value = felt_from_canonical(padding->value), pad_addr = felt_from_u64(1);
-    for (uint64_t k = 0; k < n / 2; ++k) { npc[2 * k] = pad_addr; npc[2 * k + 1] = pad_value; npc_addr[k] = 1; }
+#pragma omp parallel for schedule(static) if (par)
+    for (int64_t k = 0; k < (int64_t)(n / 2); ++k) { npc[2 * k] = pad_addr; npc[2 * k + 1] = pad_value; npc_addr[k] = 1; }
     auto set_pair = [&](uint64_t row, uint64_t address, const Felt &value) { npc[row] = felt_from_u64(address); npc[row + 1] = value; npc_addr[row / 2] = address; };
     const Felt rc_max_f = felt_from_u64(pi.rc_max);
-    for (auto &v : rc_col) v = rc_max_f;
+#pragma omp parallel for schedule(static) if (par)
+    for (int64_t k = 0; k < (int64_t)n; ++k) rc_col[k] = rc_max_f;
 
+    mark("init");
     // ---- CPU cells (trace.rs:172-232) and the range-check pool
     std::vector<uint32_t> rc_count(1 << 16, 0);
-    for (uint64_t cycle = 0; cycle < num_cycles; ++cycle) {
+    std::string first_error;                            // exceptions must not leave an OpenMP region
+#pragma omp parallel for schedule(static) if (par)
+    for (int64_t cyc = 0; cyc < (int64_t)num_cycles; ++cyc) try {
+        const uint64_t cycle = (uint64_t)cyc;
         const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
         const U256 &iw = mem.at(pc);
         const Word w{iw[0]};
@@ -230,9 +256,17 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
         aux[r + AUX_TMP0] = tmp0; aux[r + AUX_TMP1] = felt_mul(tmp0, res);
         aux[r + AUX_AP] = felt_from_u64(ap); aux[r + AUX_FP] = felt_from_u64(fp);
         aux[r + AUX_OP0_MUL_OP1] = felt_mul(op0, op1); aux[r + AUX_RES] = res;
-        ++rc_count[w.off_dst()]; ++rc_count[w.off_op0()]; ++rc_count[w.off_op1()];
+        for (uint64_t v : {w.off_dst(), w.off_op0(), w.off_op1()}) {
+#pragma omp atomic
+            ++rc_count[v];
+        }
+    } catch (const std::exception &e) {
+#pragma omp critical
+        if (first_error.empty()) first_error = e.what();
     }
+    if (!first_error.empty()) throw std::runtime_error(first_error);
 
+    mark("cpu cells");
     // ---- range-check builtin instances, ordered values and padding (trace.rs:131-160, 236-284; utils.rs:357-380)
     struct Rc128 { uint32_t index; U256 value; };
     std::vector<Rc128> rc128;
@@ -267,6 +301,7 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
     }
     if (pad_i < padding_vals.size() || ord_i < ordered_vals.size()) fail("range-check values do not fit the trace");
 
+    mark("range check");
     // ---- Pedersen builtin (trace.rs:300-400; builtins/src/pedersen/mod.rs:81-163)
     const Segment &ped_seg = pi.segments[3], &rc_seg = pi.segments[4], &bw_seg = pi.segments[6];
     if (!ped_seg.present || !rc_seg.present || !bw_seg.present) fail("the layout needs the pedersen, range_check and bitwise segments");
@@ -277,10 +312,7 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
         struct Cached { std::vector<Step> steps; Felt out; };
         std::map<std::pair<U256, U256>, Cached> cache;
         const Pt p0 = pedersen_point(0);
-        for (uint64_t i = 0; i < n / step; ++i) {
-            U256 a{}, b{};
-            auto it = given.find((uint32_t)i);
-            if (it != given.end()) { a = it->second->a; b = it->second->b; }
+        auto trace_of = [&](const U256 &a, const U256 &b) -> const Cached & {
             auto key = std::make_pair(a, b);
             auto cit = cache.find(key);
             if (cit == cache.end()) {
@@ -294,7 +326,21 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
                     fail("Pedersen partial sums do not end at the hash");                     // the reference's own assert
                 cit = cache.emplace(key, std::move(c)).first;
             }
-            const Cached &c = cit->second;
+            return cit->second;
+        };
+        // the distinct instance traces first (sequential: the map is shared), then the cells in parallel
+        std::vector<const Cached *> of_block(n / step);
+        for (uint64_t i = 0; i < n / step; ++i) {
+            auto it = given.find((uint32_t)i);
+            of_block[i] = it != given.end() ? &trace_of(it->second->a, it->second->b) : &trace_of(U256{}, U256{});
+        }
+#pragma omp parallel for schedule(static) if (par)
+        for (int64_t bi = 0; bi < (int64_t)(n / step); ++bi) {
+            const uint64_t i = (uint64_t)bi;
+            U256 a{}, b{};
+            auto it = given.find((uint32_t)i);
+            if (it != given.end()) { a = it->second->a; b = it->second->b; }
+            const Cached &c = *of_block[i];
             const uint64_t base = i * step, addr = ped_seg.begin_addr + 3 * i;
             for (uint64_t j = 0; j < 512; ++j) {
                 const uint64_t r = base + 4 * j;
@@ -312,6 +358,7 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
             set_pair(base + NPC_PEDERSEN_OUTPUT_ADDR, addr + 2, c.out);
         }
     }
+    mark("pedersen");
     // ---- range-check builtin cells
     {
         const uint64_t step = RANGE_CHECK_BUILTIN_RATIO * CYCLE_HEIGHT;
@@ -321,6 +368,7 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
             set_pair(base + NPC_RANGE_CHECK128_ADDR, rc_seg.begin_addr + rc128[block].index, felt_from_canonical(rc128[block].value));
         }
     }
+    mark("rc builtin");
     // ---- bitwise builtin and the diluted check (trace.rs:420-588)
     {
         const uint64_t step = BITWISE_RATIO * CYCLE_HEIGHT;
@@ -328,7 +376,10 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
         for (auto &inst : priv.bitwise) given[inst.index] = &inst;
         std::vector<uint32_t> dil_count(1u << DILUTED_N_BITS, 0);
         const uint64_t shifted_cells[4] = {1, 65, 33, 97};
-        for (uint64_t i = 0; i < n / step; ++i) {
+        std::string bw_error;
+#pragma omp parallel for schedule(static) if (par)
+        for (int64_t bi = 0; bi < (int64_t)(n / step); ++bi) try {
+            const uint64_t i = (uint64_t)bi;
             U256 x{}, y{};
             auto it = given.find((uint32_t)i);
             if (it != given.end()) { x = it->second->x; y = it->second->y; }
@@ -343,17 +394,25 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
                 const unsigned sh = k == 3 ? 8 : 4;
                 if ((v << sh) >> sh != v) fail("bitwise instance: top segment does not fit");
                 un_col[base + shifted_cells[k]] = felt_from_u64(v << sh);
-                ++dil_count[undilute(v << sh)];
+                const uint32_t reg = undilute(v << sh);
+#pragma omp atomic
+                ++dil_count[reg];
             }
             for (int p = 0; p < 4; ++p)
                 for (int c = 0; c < 4; ++c)
                     for (int s = 0; s < 4; ++s) {
                         un_col[base + 32 * p + 8 * c + 2 * s] = felt_from_u64(parts[p][c][s]);
-                        ++dil_count[undilute(parts[p][c][s])];
+                        const uint32_t reg = undilute(parts[p][c][s]);
+#pragma omp atomic
+                        ++dil_count[reg];
                     }
             for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + k * (step / 4), addr + k, felt_from_canonical(*vals[k]));
             set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, felt_from_canonical(vor));
+        } catch (const std::exception &e) {
+#pragma omp critical
+            if (bw_error.empty()) bw_error = e.what();
         }
+        if (!bw_error.empty()) throw std::runtime_error(bw_error);
         std::vector<uint32_t> padding;
         uint64_t total = 0;
         for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) { if (!dil_count[v]) padding.push_back(v); total += std::max(dil_count[v], 1u); }
@@ -369,6 +428,7 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
         for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)
             for (uint32_t c = 0; c < std::max(dil_count[v], 1u); ++c) od_col[row++] = felt_from_u64(dilute(v));
     }
+    mark("bitwise + diluted");
     // ---- gap fillers (trace.rs:594-625)
     {
         std::vector<uint64_t> accessed(npc_addr);
@@ -383,6 +443,7 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
                 ++cycle;
             }
     }
+    mark("gap fill");
     // ---- sorted memory (get_ordered_memory_accesses, utils.rs:112-152)
     {
         struct Access { uint64_t address; Felt value; };
@@ -401,6 +462,7 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
                 fail("memory is not continuous and single-valued at address " + std::to_string(acc[k].address));
         for (uint64_t k = 0; k < n / 2; ++k) { mem_col[2 * k] = felt_from_u64(acc[cells + k].address); mem_col[2 * k + 1] = acc[cells + k].value; }
     }
+    mark("sorted memory");
     return cols;
 }
 

@@ -290,6 +290,14 @@ def test_cpp_base_trace_equals_the_python_one(oracle):
         assert len(got) == len(want) == 7
         for c, (g, w) in enumerate(zip(got, want)):
             assert np.array_equal(g, oracle.to_mont(w)), "column %d" % c
+        # the OpenMP path (normally only above 2^16 cycles) must give the same cells
+        os.environ["SSH_TRACE_PARALLEL_MIN"] = "1"
+        try:
+            par = hostlib.recursive_base_trace(trace_bin, memory_bin, pi, priv)
+        finally:
+            del os.environ["SSH_TRACE_PARALLEL_MIN"]
+        for c, (g, w) in enumerate(zip(got, par)):
+            assert np.array_equal(g, w), "parallel path, column %d" % c
     from sandstorm_amd._lib import SandstormHipError
     with pytest.raises(SandstormHipError, match="power of two"):
         hostlib.recursive_base_trace(trace_bin[:24 * 1000], memory_bin, pi)
