@@ -183,9 +183,9 @@ def diluted_cumulative_value(z, alpha, n_bits=DILUTED_CHECK_N_BITS, spacing=DILU
     return (p + q * alpha) % P
 
 
-def public_memory_quotient(z, alpha, trace_len, pi):
+def public_memory_quotient(z, alpha, trace_len, pi, public_memory_step=PUBLIC_MEMORY_STEP):
     """compute_public_memory_quotient (layouts/src/utils.rs:14-46): z^S / (prod (z - (a_i + alpha v_i)) * padding^(S-N))"""
-    s, count = trace_len // PUBLIC_MEMORY_STEP, len(pi.public_memory)
+    s, count = trace_len // public_memory_step, len(pi.public_memory)
     den = 1
     for a, v in pi.public_memory:
         den = den * (z - (alpha * v + a)) % P
@@ -194,8 +194,12 @@ def public_memory_quotient(z, alpha, trace_len, pi):
     return pow(z, s, P) * pow(den, -1, P) % P
 
 
-def cpu_constraints(hints: Hints) -> List[Constraint]:
-    """air.rs:82-443, in the reference's order"""
+def cpu_constraints(hints: Hints, L=None) -> List[Constraint]:
+    """air.rs:82-443, in the reference's order.  L: the layout module that supplies the cell helpers (this one by default;
+    layouts/starknet.py passes itself - its CPU constraints are the same expressions over other cells, starknet/air.rs:128-557)"""
+    import sys
+    L = L or sys.modules[__name__]
+    flag, npc, rc, aux, Npc, RangeCheck, Auxiliary, COL_FLAGS = L.flag, L.npc, L.rc, L.aux, L.Npc, L.RangeCheck, L.Auxiliary, L.COL_FLAGS
     F = bn
     one, two, four = ap.Const(1), ap.Const(2), ap.Const(4)
     offset_size, half_offset_size = ap.Const(1 << 16), ap.Const(1 << 15)
@@ -901,11 +905,12 @@ def _batch_inverse(vals):
     return out
 
 
-def composition(n, hints: Hints, challenges, alpha, tables: Tables):
+def composition(n, hints: Hints, challenges, alpha, tables: Tables, constraint_list=None):
     """sum_i alpha^i * constraint_i (air.rs:1183-1199), constraint_i = numerator_i * multiplier(domain_i); constraints that
-    share a domain are summed before the one multiplication by its multiplier"""
+    share a domain are summed before the one multiplication by its multiplier.  constraint_list: another layout's
+    constraints (layouts/starknet.py)"""
     groups, order, apow = {}, [], 1
-    for c in constraints(hints, challenges):
+    for c in (constraints(hints, challenges) if constraint_list is None else constraint_list):
         term = c.numerator * ap.Const(apow) if apow != 1 else c.numerator
         key = c.domain.name                      # a domain's name identifies it
         if key not in groups:
@@ -922,7 +927,7 @@ def composition(n, hints: Hints, challenges, alpha, tables: Tables):
     return total
 
 
-def mask(hints=None):
+def mask(hints=None, constraint_list=None):
     """trace_arguments(): the sorted (column, row offset) cells the constraints read - the order of the OOD vector"""
     cells, seen = set(), set()
 
@@ -936,7 +941,7 @@ def mask(hints=None):
             for a in e.args:
                 walk(a)
     h = hints or Hints(0, 0, 0, 0)
-    for c in constraints(h, [2, 3, 5, 7, 11, 13]):
+    for c in (constraints(h, [2, 3, 5, 7, 11, 13]) if constraint_list is None else constraint_list):
         walk(c.numerator)
     return sorted(cells)
 

@@ -1,0 +1,288 @@
+"""The `starknet` layout restatement (sandstorm_amd/layouts/starknet.py) on the CPU.
+
+What pins it to the reference (layouts/src/starknet/{air,trace}.rs, builtins/src/*):
+  * the constraint count (195), the 269-cell mask with the per-column counts and largest offsets read off the
+    reference's source - 269 is the length of the out-of-domain vector of its shipped starknet proofs;
+  * the nine periodic-column polynomials, DERIVED here (curve-point doublings, Hades round constants) and equal,
+    coefficient for coefficient, to the reference's tables (tests/golden/starknet_periodic_fingerprints.json);
+  * the Poseidon margin keys derived here equal to the literals of air.rs:2052-2160, and StarkWare's zero-input
+    example of the permutation (builtins/src/poseidon/mod.rs tests);
+  * the trace generation and the constraints validate each other: every constraint vanishes on its domain on a trace
+    of the reference's example run (dummy builtin instances and real ones), the three permutation products close and
+    the diluted aggregate ends at its closed form.
+The starknet layout needs 2^17 steps before its diluted check fits (60 free cells per 1024 rows for the 65535 padding
+values), so the example run is extended by its own final state - the `jmp rel 0` the runner pads with."""
+import hashlib
+import json
+import os
+import random
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_layout_recursive import load_run, sample  # noqa: E402
+
+P = 2**251 + 17 * 2**192 + 1
+CHALLENGES = [pow(7, 11 + 3 * i, P) for i in range(6)]
+LOG_STEPS = 17
+
+
+def starknet_example(log_steps=LOG_STEPS):
+    """the reference's example run re-declared for the starknet layout: padded to 2^log_steps steps with its final
+    state, the builtin segments laid out after the execution segment, the program's one heap segment moved behind them"""
+    from sandstorm_amd.layouts import starknet as sk
+    states, memory, pi = load_run()
+    states = list(states) + [states[-1]] * ((1 << log_steps) - len(states))
+    pi.n_steps = 1 << log_steps
+    spi = sk.example_public_input(pi)
+    new_base = spi.memory_segments["poseidon"][0] + 6 * (pi.n_steps // sk.POSEIDON_RATIO)
+    heap = [a for a in range(len(memory)) if memory[a] is not None and a > 1000]
+    mem = list(memory) + [None] * (new_base + 16 - len(memory))
+    for a in heap:
+        mem[new_base + a - heap[0]], mem[a] = memory[a], None
+    for a in range(1000):
+        if a < len(memory) and mem[a] is not None and heap[0] <= mem[a] <= heap[-1] + 1:
+            mem[a] += new_base - heap[0]                                         # the pointers into the heap segment
+    return states, mem, spi
+
+
+def real_instances():
+    from sandstorm_amd.layouts import starknet as sk
+    rng = random.Random(2024)
+    priv, msg = 0x1234567, rng.getrandbits(250)
+    k = 1000
+    while True:                                              # an honest signature (w = s^-1 as the builtin takes it)
+        k += 1
+        r = sk._ec_mul(k, sk.GENERATOR)[0]
+        w = k * pow(msg + r * priv, -1, sk.CURVE_ORDER) % sk.CURVE_ORDER
+        if 0 < r < 1 << 251 and 0 < w < 1 << 251:
+            break
+    pub = sk._ec_mul(priv, sk.GENERATOR)
+    p5, q7, q9 = sk._ec_mul(5, sk.GENERATOR), sk._ec_mul(7, sk.GENERATOR), sk._ec_mul(9, sk.GENERATOR)
+    top = (1 << 251) | (1 << 196) | (1 << 192)
+    return {
+        "pedersen": [(0, rng.getrandbits(250), rng.getrandbits(250)), (1, top, (1 << 251) | (1 << 196)), (7, 0, 5)],
+        "range_check": [(i, sum(rng.randrange(32764, 32771) << (16 * j) for j in range(8))) for i in range(5)],
+        "ecdsa": [(1, pub[0], msg, r, w)],
+        "bitwise": [(i, rng.getrandbits(251), rng.getrandbits(251)) for i in range(6)],
+        "ec_op": [(0, p5[0], p5[1], q7[0], q7[1], rng.getrandbits(250)), (2, p5[0], p5[1], q9[0], q9[1], top),
+                  (3, q7[0], q7[1], p5[0], p5[1], (1 << 251) | (1 << 196) | rng.getrandbits(190))],
+        "poseidon": [(0, 1, 2, 3), (5, rng.getrandbits(251), rng.getrandbits(251), rng.getrandbits(251))],
+    }
+
+
+@pytest.fixture(scope="module")
+def example():
+    import numpy as np
+    from oracle import oracle_py as oracle
+    from sandstorm_amd.layouts import starknet as sk
+    states, memory, spi = starknet_example()
+    cols = sk.base_trace(states, memory, spi, real_instances())
+    n = len(cols[0])
+    aux = {"npc": oracle.to_mont(cols[sk.COL_NPC]), "memory": oracle.to_mont(cols[sk.COL_MEMORY]), "range_check": oracle.to_mont(cols[sk.COL_RANGE_CHECK])}
+    ext, lasts = oracle.build_extension_columns("starknet", aux, [oracle.to_mont([c])[0] for c in CHALLENGES], n)
+    cols.append([int(v) for v in oracle.from_mont(ext[0])])
+    hints = sk.Hints.from_public_input(spi, CHALLENGES, n)
+    assert [int(v) for v in oracle.from_mont(np.stack(lasts))] == [hints.memory_quotient, 1, 1]      # trace.rs:1017, 1035, 1055
+    assert cols[sk.COL_PERMUTATION][n - 8 + sk.DilutedCheck.AGGREGATE] == hints.diluted_check_cumulative_value
+    return sk, cols, sk.constraints(hints, CHALLENGES)
+
+
+def test_constraint_set_and_mask_have_the_reference_shape(golden):
+    from sandstorm_amd import synthetic_air
+    from sandstorm_amd.layouts import starknet as sk
+    cs = sk.constraints(sk.Hints(0, 0, 0, 0), CHALLENGES)
+    assert len(cs) == 195 and len({c.name for c in cs}) == 195
+    assert [c.name for c in cs[:2]] == ["cpu/decode/opcode_rc/bit", "cpu/decode/opcode_rc/zero"]
+    assert cs[-1].name == "poseidon/poseidon/margin_partial_to_full2" and cs[33].name == "memory/multi_column_perm/perm/init0"
+    mask = sk.mask()
+    assert mask == sorted(set(mask)) and len(mask) == 269
+    per_col = [sum(1 for c, _ in mask if c == k) for k in range(10)]
+    assert per_col == synthetic_air.STARKNET_CELLS_PER_COLUMN
+    assert [max(o for c, o in mask if c == k) for k in range(10)] == synthetic_air.STARKNET_MAX_OFFSET
+    assert [len(p["ood_trace"]) for p in golden("saved_proofs.json")][:2] == [269, 269]
+
+
+def test_periodic_columns_are_the_references_polynomials():
+    from sandstorm_amd.layouts import starknet as sk
+    with open(os.path.join(ROOT, "tests", "golden", "starknet_periodic_fingerprints.json")) as f:
+        want = json.load(f)
+    assert len(want) == sk.NUM_PERIODIC
+    for table, key in enumerate(want):
+        coeffs = sk.periodic_coefficients(table)
+        assert len(coeffs) == want[key]["count"], key
+        assert hashlib.sha256(",".join(str(v) for v in coeffs).encode()).hexdigest() == want[key]["sha256"], key
+        values, period = sk.periodic_columns()[table]
+        w = pow(3, (P - 1) // len(values), P)
+        for j in (0, 1, len(values) - 1):
+            acc = 0
+            for c in reversed(coeffs):
+                acc = (acc * pow(w, j, P) + c) % P
+            assert acc == values[j]
+
+
+def test_poseidon_keys():
+    from sandstorm_amd.layouts import starknet as sk
+    # StarkWare's example (builtins/src/poseidon/mod.rs zero_hash_matches_starkware_example)
+    assert sk.poseidon_states((0, 0, 0))[2] == [
+        3446325744004048536138401612021367625846492093718951375866996507163446763827,
+        1590252087433376791875644726012779423683501236913937337746052470473806035332,
+        867921192302518434283879514999422690776342565400001269945778456016268852423]
+    keys = sk.poseidon_air_keys()
+    # the literals of air.rs:2052, 2065, 2123, 2137, 2150
+    assert keys["margin_full_to_partial"][1:] == [
+        2006642341318481906727563724340978325665491359415674592697055778067937914672,
+        427751140904099001132521606468025610873158555767197326325930641757709538586]
+    assert keys["margin_partial_to_full"] == [
+        560279373700919169769089400651532183647886248799764942664266404650165812023,
+        1401754474293352309994371631695783042590401941592571735921592823982231996415,
+        1246177936547655338400308396717835700699368047388302793172818304164989556526]
+    # the keys are identities of the permutation: the same constants come out on any other input
+    full, s, _ = sk.poseidon_states((5, 7, 11))
+    c = [pow(v, 3, P) for v in s]
+    assert [(s[k + 3] - (8 * c[k] + 4 * s[k + 1] + 6 * c[k + 1] + 2 * s[k + 2] - 2 * c[k + 2])) % P for k in range(80)] == keys["partial"]
+    assert (full[4][1] - (4 * c[81] + 2 * s[82] + c[82])) % P == keys["margin_partial_to_full"][1]
+
+
+def test_ecdsa_dummy_instance_and_signature_checks():
+    from sandstorm_amd.layouts import starknet as sk
+    pub_x, msg, r, w = sk.ecdsa_dummy_instance()
+    assert pub_x == sk.GENERATOR[0] and 0 < r < 1 << 251 and 0 < w < 1 << 251
+    t = sk.EcdsaInstanceTrace(pub_x, msg, r, w)
+    assert sk._ec_add(t.wb, sk._ec_neg(sk.SHIFT_POINT))[0] == r and t.pubkey[0] == pub_x
+    with pytest.raises(ValueError, match="signature is invalid"):
+        sk.EcdsaInstanceTrace(pub_x, msg + 1, r, w)
+    x = 2
+    while sk._sqrt((pow(x, 3, P) + x + sk.CURVE_BETA) % P) is not None:
+        x += 1
+    with pytest.raises(ValueError, match="not on the curve"):
+        sk.EcdsaInstanceTrace(x, msg, r, w)
+    assert sk._sqrt(49) in (7, P - 7) and (sk.GENERATOR[1] ** 2 - (sk.GENERATOR[0] ** 3 + sk.GENERATOR[0] + sk.CURVE_BETA)) % P == 0
+    assert sk._ec_mul(sk.CURVE_ORDER - 1, sk.GENERATOR) == sk._ec_neg(sk.GENERATOR)
+
+
+def test_domain_rows_are_the_zeros_of_their_zerofiers():
+    """at a trace point g^r the multiplier prod(num) / prod(den) has a pole exactly on the rows the constraint is
+    enforced on; the compound domains are also stated explicitly"""
+    from sandstorm_amd.layouts import starknet as sk
+    n = 1 << 15
+    g = pow(3, (P - 1) // n, P)
+    doms = {}
+    for c in sk.constraints(sk.Hints(0, 0, 0, 0), CHALLENGES):
+        doms[c.domain.name] = c.domain
+    assert len(doms) == 42
+    explicit = {
+        sk.PEDERSEN_TRANSITION.name: lambda r: r % 256 != 255,
+        sk.PEDERSEN_HASH_START.name: lambda r: r % 512 == 0,
+        sk.EC_OP_TRANSITION.name: lambda r: r % 64 == 0 and (r % 16384) // 64 != 255,
+        sk.ECDSA_TRANSITION.name: lambda r: r % 128 == 0 and (r % 32768) // 128 != 255,
+        sk.ECDSA_STEP_251.name: lambda r: r % 32768 == 128 * 251,
+        sk.EC_OP_STEP_252.name: lambda r: r % 16384 == 64 * 252,
+        sk.BITWISE_TRANSITION.name: lambda r: r % 256 == 0 and r % 1024 != 768,
+        sk.EVERY_16_BIT_SEGMENT.name: lambda r: r % 16 == 0 and r % 1024 < 256,
+        sk.POSEIDON_ADDR_STEP.name: lambda r: r % 64 == 0 and (r % 512) // 64 <= 4,
+        sk.POSEIDON_PARTIAL1_SQUARING.name: lambda r: r % 16 == 0 and (r % 512) // 16 <= 21,
+        sk.POSEIDON_HALF_FULL_ROUND_TRANSITION.name: lambda r: r % 64 == 0 and (r % 256) // 64 != 3,
+        sk.POSEIDON_PARTIAL_ROUND0.name: lambda r: r % 8 == 0 and (r % 512) // 8 <= 60,
+        sk.POSEIDON_PARTIAL_ROUND1.name: lambda r: r % 16 == 0 and (r % 512) // 16 <= 18,
+    }
+    assert set(explicit) <= set(doms)
+    gp = {}
+    for name, d in doms.items():
+        want = set(d.rows(n))
+        if name in explicit:
+            assert want == {r for r in range(n) if explicit[name](r)}, name
+        got = set()
+        factors = [(p_, pow(g, e, P)) for p_, e in d.den(n)], [(p_, pow(g, e, P)) for p_, e in d.num(n)]
+        for p_ in {p_ for fs in factors for p_, _ in fs}:
+            if p_ not in gp:
+                step, acc, vals = pow(g, p_, P), 1, []
+                for _ in range(n):
+                    vals.append(acc)
+                    acc = acc * step % P
+                gp[p_] = vals
+        for r in range(n):
+            den_zero = any(gp[p_][r] == c for p_, c in factors[0])
+            num_zero = any(gp[p_][r] == c for p_, c in factors[1])
+            if den_zero and not num_zero:
+                got.add(r)
+        assert got == want, name
+
+
+def test_multiplier_tables_are_the_zerofier_quotients():
+    """the composition's tables (periodic multipliers, full-length inverses, periodic columns) against the definitions:
+    at a random point, and entry by entry on the LDE coset"""
+    from sandstorm_amd import air_program as ap
+    from sandstorm_amd.layouts import starknet as sk
+    n = 1 << 15
+    tables = sk.Tables(n)
+    rng = random.Random(5)
+    x = rng.randrange(P)
+    for c in sk.constraints(sk.Hints(0, 0, 0, 0), CHALLENGES):
+        got = ap.evaluate(tables.multiplier(c.domain), P, x, None, lambda t: tables.value_at(tables.specs[t], x))
+        assert got == c.domain.multiplier_at(n, x), c.domain.name
+    w = pow(3, (P - 1) // (2 * n), P)
+    for spec in tables.specs:
+        if spec[0] == "inverse" or tables.length(spec) > 4096:
+            continue
+        vals = tables.host_values(spec)
+        assert len(vals) == tables.length(spec)
+        for i in (0, 1, len(vals) - 1):
+            assert vals[i] == tables.value_at(spec, 3 * pow(w, i, P) % P), spec
+        if spec[0] == "column":                                     # on the trace domain a periodic column takes its values
+            values, period = sk.periodic_columns()[spec[1]]
+            gn = pow(3, (P - 1) // n, P)
+            for row in (0, period // len(values), period + 3 * (period // len(values))):
+                assert tables.value_at(spec, pow(gn, row, P)) == sk.periodic_value(spec[1], row)
+
+
+def test_constraints_vanish_on_the_example_trace(example):
+    sk, cols, constraints = example
+    n = len(cols[0])
+    assert n == 1 << 21 and len(cols) == 10
+    for c in constraints:
+        assert sk.failing_rows(c, cols, sample(c.domain.rows(n))) == [], c.name
+
+
+def test_a_corrupted_cell_trips_its_constraints(example):
+    sk, cols, constraints = example
+    n = len(cols[0])
+    by_name = {c.name: c for c in constraints}
+    probes = [  # (column, row, a constraint that must notice, a row of its domain that reads the cell)
+        (sk.COL_PEDERSEN_X, 300, ("pedersen/hash0/ec_subset_sum/add_points/x", "pedersen/hash0/ec_subset_sum/copy_point/x"), 299),
+        (sk.COL_AUXILIARY, 32768 + 64 * 10 + sk.Ecdsa.PUBKEY_DOUBLING_Y, "ecdsa/signature0/doubling_key/y", 32768 + 64 * 10),
+        (sk.COL_AUXILIARY, 32768 + 128 * 3 + sk.Ecdsa.GENERATOR_PARTIAL_SUM_X, "ecdsa/signature0/exponentiate_generator/add_points/x_diff_inv", 32768 + 128 * 3),
+        (sk.COL_AUXILIARY, 32768 + sk.Ecdsa.R_POINT_SLOPE, "ecdsa/signature0/extract_r/x", 32768),
+        (sk.COL_AUXILIARY, 16384 * 2 + 64 * 200 + sk.EcOp.R_PARTIAL_SUM_Y, ("ec_op/ec_subset_sum/add_points/y", "ec_op/ec_subset_sum/copy_point/y"), 16384 * 2 + 64 * 200),
+        (sk.COL_AUXILIARY, 16384 * 2 + sk.EcOp.M_BIT251_AND_BIT196, "ec_op/ec_subset_sum/bit_unpacking/cumulative_bit196", 16384 * 2),
+        (sk.COL_AUXILIARY, 512 * 5 + 64 * 2 + 53, "poseidon/poseidon/full_rounds_state0_squaring", 512 * 5 + 128),
+        (sk.COL_RANGE_CHECK, 512 * 5 + 8 * 30 + 3, "poseidon/poseidon/partial_round0", 512 * 5 + 8 * 27),
+        (sk.COL_AUXILIARY, 512 * 5 + 16 * 21 + 6, "poseidon/poseidon/margin_partial_to_full1", 512 * 5),
+        (sk.COL_NPC, 512 * 5 + 231, "poseidon/poseidon/last_full_round0", 512 * 5),
+        (sk.COL_RANGE_CHECK, 1024 * 2 + 256 + 17, "bitwise/partition", 1024 * 2 + 256),
+        (sk.COL_RANGE_CHECK, 256 * 3 + 32 * 2 + 12, "rc_builtin/value", 256 * 3),
+        (sk.COL_PERMUTATION, 8 * 100 + 3, "diluted_check/step", 8 * 100),
+        (sk.COL_FLAGS, 16 * 9 + 3, "cpu/decode/opcode_rc/bit", 16 * 9 + 3),
+    ]
+    for col, row, names, at in probes:
+        names = (names,) if isinstance(names, str) else names           # which of two fires depends on the bit of the step
+        assert all(sk.failing_rows(by_name[name], cols, [at]) == [] for name in names)
+        old = cols[col][row]
+        cols[col][row] = (old + 2) % P
+        try:
+            assert any(sk.failing_rows(by_name[name], cols, [at]) == [at] for name in names), names
+        finally:
+            cols[col][row] = old
+
+
+def test_trace_generation_refuses_what_the_reference_refuses():
+    from sandstorm_amd.layouts import starknet as sk
+    states, memory, spi = starknet_example(11)
+    with pytest.raises(ValueError, match="do not fit the trace"):
+        sk.base_trace(states, memory, spi)                        # 2^15 rows: the diluted check cannot hold its 65536 values
+    with pytest.raises(ValueError, match="at least"):
+        sk.base_trace(states[:1024], memory, spi)
+    with pytest.raises(ValueError, match="power of two"):
+        sk.base_trace(states[:1000], memory, spi)
