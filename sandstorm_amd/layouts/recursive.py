@@ -950,24 +950,28 @@ def mask(hints=None, constraint_list=None):
 _TABLES = {}
 
 
-def tables_for(n, blowup=2, offset=3):
+def tables_for(n, blowup=2, offset=3, L=None):
     """the table registry of trace length n with every table the composition refers to registered (their set and order
-    do not depend on the challenges)"""
-    key = (n, blowup, offset)
+    do not depend on the challenges).  L: the layout module (this one by default, layouts/starknet.py passes itself)"""
+    import sys
+    L = L or sys.modules[__name__]
+    key = (L.__name__, n, blowup, offset)
     if key not in _TABLES:
-        t = Tables(n, blowup, offset)
-        composition(n, Hints(0, 0, 0, 0), [2, 3, 5, 7, 11, 13], 17, t)
+        t = L.Tables(n, blowup, offset)
+        L.composition(n, L.Hints(0, 0, 0, 0), [2, 3, 5, 7, 11, 13], 17, t)
         _TABLES[key] = t
     return _TABLES[key]
 
 
-def make_air(ctx, public_input, n, log_blowup=1, lde_offset=3):
+def make_air(ctx, public_input, n, log_blowup=1, lde_offset=3, L=None):
     """-> prover.Air for this public input and trace length.  The tables are built once: the periodic ones on the host
-    (a few thousand entries), the five full-length inverse tables on the device (ss_inverse_table)."""
+    (up to 2^16 entries each), the full-length inverse tables on the device (ss_inverse_table)."""
+    import sys
     from .. import backend as be
     from ..coin import canonical
     from ..prover import Air
-    tables = tables_for(n, 1 << log_blowup, lde_offset)
+    L = L or sys.modules[__name__]
+    tables = tables_for(n, 1 << log_blowup, lde_offset, L)
     lengths = [tables.length(s) for s in tables.specs]
     desc, off = [], 0
     for ln in lengths:
@@ -988,27 +992,29 @@ def make_air(ctx, public_input, n, log_blowup=1, lde_offset=3):
         if n_ != n:
             raise ValueError("this Air was built for trace length %d" % n)
         ch = [canonical(c) for c in challenges]
-        hints = Hints.from_public_input(public_input, ch, n)
-        expr = composition(n, hints, ch, canonical(comp_coeff), tables)
+        hints = L.Hints.from_public_input(public_input, ch, n)
+        expr = L.composition(n, hints, ch, canonical(comp_coeff), tables)
         return ap.lower(expr, P), buf, desc
 
-    air = Air("recursive", NUM_BASE_COLUMNS, NUM_EXTENSION_COLUMNS, 6, mask(), build_program)
+    air = Air(L.__name__.rsplit(".", 1)[-1], L.NUM_BASE_COLUMNS, L.NUM_EXTENSION_COLUMNS, 6, L.mask(), build_program)
     air.table_buffer = buf
     return air
 
 
-def verifier_air(public_input, log_blowup=1, lde_offset=3):
+def verifier_air(public_input, log_blowup=1, lde_offset=3, L=None):
     """-> verifier.VerifierAir: the same composition, with the tables' underlying functions evaluated at the
     out-of-domain point"""
+    import sys
     from ..verifier import VerifierAir
+    L = L or sys.modules[__name__]
 
     def comp(n, challenges, alpha):
-        return composition(n, Hints.from_public_input(public_input, challenges, n), challenges, alpha, tables_for(n, 1 << log_blowup, lde_offset))
+        return L.composition(n, L.Hints.from_public_input(public_input, challenges, n), challenges, alpha, tables_for(n, 1 << log_blowup, lde_offset, L))
 
     def table_at(n, x, t):
-        tables = tables_for(n, 1 << log_blowup, lde_offset)
+        tables = tables_for(n, 1 << log_blowup, lde_offset, L)
         return tables.value_at(tables.specs[t], x)
-    return VerifierAir(NUM_BASE_COLUMNS, NUM_EXTENSION_COLUMNS, 6, mask(), comp, table_at)
+    return VerifierAir(L.NUM_BASE_COLUMNS, L.NUM_EXTENSION_COLUMNS, 6, L.mask(), comp, table_at)
 
 
 def trace_columns(ctx, base_cols_device, n):

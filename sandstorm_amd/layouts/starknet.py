@@ -1191,3 +1191,23 @@ def composition(n, hints: Hints, challenges, alpha, tables: Tables):
 def mask(hints=None):
     """the 269 trace cells the constraints read, sorted: the order of the out-of-domain vector"""
     return rec.mask(None, constraints(hints or Hints(0, 0, 0, 0), [2, 3, 5, 7, 11, 13]))
+
+
+# ---- the layout as the prover and the verifier see it -------------------------------------------------------------------
+def make_air(ctx, public_input, n, log_blowup=1, lde_offset=3):
+    """-> prover.Air (the tables: 9 periodic columns and the periodic multipliers from the host, 5 full-length inverse
+    tables built on the device)"""
+    import sys
+    return rec.make_air(ctx, public_input, n, log_blowup, lde_offset, sys.modules[__name__])
+
+
+def verifier_air(public_input, log_blowup=1, lde_offset=3):
+    import sys
+    return rec.verifier_air(public_input, log_blowup, lde_offset, sys.modules[__name__])
+
+
+def trace_columns(ctx, base_cols_device, n):
+    """extension.TraceColumns of a base trace resident in HBM: the diluted check lives in the range-check column
+    (trace.rs:997-1056)"""
+    from ..extension import TraceColumns
+    return TraceColumns(npc=base_cols_device[COL_NPC], memory=base_cols_device[COL_MEMORY], range_check=base_cols_device[COL_RANGE_CHECK], trace_len=n)
