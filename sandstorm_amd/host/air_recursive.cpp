@@ -1,24 +1,16 @@
 // air_recursive.cpp — the `recursive` layout's AIR on the C++ host: the 93 constraints of
 // layouts/src/recursive/air.rs:61-1180 in the reference's order, its composition constraint
-// (air.rs:1183-1199), the hints (air.rs:1216-1260, layouts/src/utils.rs:14-108) and the
-// periodic / zerofier tables the constraint VM reads.  Mirror of sandstorm_amd/layouts/recursive.py,
+// (air.rs:1183-1199) and the hints (air.rs:1216-1260, layouts/src/utils.rs:14-108); the table and
+// lowering machinery is air_layout.{hpp,cpp}.  Mirror of sandstorm_amd/layouts/recursive.py,
 // where every piece is documented and validated against the reference's example run; a GPU test
 // proves that both hosts emit the same proof for it.
-#include <algorithm>
-#include <cstring>
-#include <map>
-#include <stdexcept>
-
-#include "prover.hpp"
-#include "public_input.hpp"
+#include "air_layout.hpp"
 
 namespace ssh {
 
 namespace {
 
-void ok(ss_status s) {
-    if (s != SS_OK) throw std::runtime_error(ss_last_error());
-}
+using namespace layout;
 
 constexpr uint64_t CYCLE_HEIGHT = 16;
 enum { COL_FLAGS, COL_DILUTED_UNORDERED, COL_DILUTED_ORDERED, COL_NPC, COL_MEMORY, COL_RANGE_CHECK, COL_AUXILIARY, COL_DILUTED_AGGREGATE,
@@ -32,158 +24,19 @@ enum { F_DST_REG, F_OP0_REG, F_OP1_IMM, F_OP1_FP, F_OP1_AP, F_RES_ADD, F_RES_MUL
        F_OPCODE_CALL, F_OPCODE_RET, F_OPCODE_ASSERT_EQ };
 enum { MEM_Z, MEM_A, RC_Z, DC_Z, AGG_Z, AGG_A };
 
-// ---- expression wrapper over the hash-consed Graph
-struct E {
-    Graph *g;
-    int id;
-};
-E operator+(const E &a, const E &b) { return E{a.g, a.g->add(a.id, b.id)}; }
-E operator-(const E &a, const E &b) { return E{a.g, a.g->sub(a.id, b.id)}; }
-E operator*(const E &a, const E &b) { return E{a.g, a.g->mul(a.id, b.id)}; }
-
-// ---- domains: multiplier prod(num) / prod(den), factor (p, e) = X^p - g^e
-struct Factor {
-    uint64_t p, e;
-    bool operator<(const Factor &o) const { return p != o.p ? p < o.p : e < o.e; }
-    bool operator==(const Factor &o) const { return p == o.p && e == o.e; }
-};
-struct Domain { std::vector<Factor> num, den; };
-
-struct TableSpec {
-    int kind;                               // 0 pedersen x, 1 pedersen y, 2 periodic multiplier, 3 full-length inverse
-    std::vector<Factor> num, den;           // kind 2
-    uint64_t e = 0;                         // kind 3: 1 / (X - g^e)
-    bool operator<(const TableSpec &o) const {
-        if (kind != o.kind) return kind < o.kind;
-        if (e != o.e) return e < o.e;
-        if (num != o.num) return num < o.num;
-        return den < o.den;
-    }
-};
 struct Hints {
     Felt initial_ap, initial_pc, final_ap, final_pc, range_check_min, range_check_max, initial_rc_addr, initial_bitwise_addr,
         initial_pedersen_addr, memory_quotient, diluted_cumulative_value;
 };
 
-// builtins/src/pedersen/constants.rs:5-30 (canonical little-endian limbs)
-const uint64_t PEDERSEN_POINTS[5][2][4] = {
-    {{0x551fde4050ca6804ull, 0x716b0b1022947733ull, 0x00ee1b87eb599f16ull, 0x049ee3eba8c16007ull}, {0xd0405d266e10268aull, 0x4e621062c0e056c1ull, 0xf346d49d06ea0ed3ull, 0x03ca0cfe4b3bc6ddull}},
-    {{0x1080d17957ebe47bull, 0x8fa8120b6d56eb0cull, 0x969c748655fca9e5ull, 0x0234287dcbaffe7full}, {0x6ed0268ee89e5615ull, 0x940135dd7a6c94ccull, 0x1e889527d41f4e39ull, 0x03b056f100f96fb2ull}},
-    {{0xb7a6932dba8aa378ull, 0x99099ec1de5e3018ull, 0x3f9dab2656558f33ull, 0x04fa56f376c83db3ull}, {0x5168f4e80ff5b54dull, 0x562761f92a7a23b4ull, 0x8113e0c0e47e4401ull, 0x03fa0984c931c9e3ull}},
-    {{0x3aa372f0bd2d6997ull, 0x40c690c74709e90full, 0x764910f75b45f74bull, 0x04ba4cc166be8decull}, {0x48151f27b24b219cull, 0xcac5c59a5ce5ae7cull, 0x4b971e46c4ede85full, 0x0040301cf5c1751full}},
-    {{0xd36ff12c49a58202ull, 0x2ca65048d53fb325ull, 0x6e44cca8f61a63bbull, 0x054302dcb0e6cc1cull}, {0x879dcc77e99c2426ull, 0xce98ad783c25561aull, 0xb348046268d8ae25ull, 0x01b77b3e37d13504ull}},
-};
-Felt pedersen_coord(int point, int which) {
-    Felt c;
-    memcpy(c.data(), PEDERSEN_POINTS[point][which], 32);
-    return felt_from_canonical(c);
-}
-struct Pt { Felt x, y; };
-Pt ec_double(const Pt &p) {
-    const Felt xx = felt_mul(p.x, p.x);
-    const Felt lam = felt_mul(felt_add(felt_add(felt_add(xx, xx), xx), felt_from_u64(1)), felt_inv(felt_add(p.y, p.y)));
-    const Felt x3 = felt_sub(felt_mul(lam, lam), felt_add(p.x, p.x));
-    return Pt{x3, felt_sub(felt_mul(lam, felt_sub(p.x, x3)), p.y)};
-}
-// the 512 values of a Pedersen periodic column (builtins/src/pedersen/periodic.rs:1211-1250)
-std::vector<Felt> pedersen_column(int which) {
-    std::vector<Felt> out;
-    for (int e = 0; e < 2; ++e) {
-        std::vector<Pt> half;
-        Pt acc{pedersen_coord(1 + 2 * e, 0), pedersen_coord(1 + 2 * e, 1)};
-        for (int i = 0; i < 248; ++i) { half.push_back(acc); acc = ec_double(acc); }
-        acc = Pt{pedersen_coord(2 + 2 * e, 0), pedersen_coord(2 + 2 * e, 1)};
-        for (int i = 0; i < 4; ++i) { half.push_back(acc); acc = ec_double(acc); }
-        for (int i = 0; i < 4; ++i) half.push_back(half[251]);
-        for (auto &p : half) out.push_back(which ? p.y : p.x);
-    }
-    return out;
-}
-// coefficients of the interpolant over <w_m> (natural order), m a power of two: plain O(m log m) inverse transform
-std::vector<Felt> interpolate(std::vector<Felt> a) {
-    const size_t m = a.size();
-    uint32_t lg = 0;
-    while ((1ull << lg) < m) ++lg;
-    for (size_t i = 0; i < m; ++i) {
-        size_t r = 0;
-        for (uint32_t b = 0; b < lg; ++b) r |= ((i >> b) & 1) << (lg - 1 - b);
-        if (r > i) std::swap(a[i], a[r]);
-    }
-    const Felt w_inv = felt_inv(root_of_unity(lg));
-    for (size_t len = 2; len <= m; len <<= 1) {
-        const Felt wl = felt_pow(w_inv, m / len);
-        for (size_t s = 0; s < m; s += len) {
-            Felt w = felt_from_u64(1);
-            for (size_t k = 0; k < len / 2; ++k) {
-                const Felt u = a[s + k], v = felt_mul(a[s + k + len / 2], w);
-                a[s + k] = felt_add(u, v); a[s + k + len / 2] = felt_sub(u, v);
-                w = felt_mul(w, wl);
-            }
-        }
-    }
-    const Felt m_inv = felt_inv(felt_from_u64(m));
-    for (auto &v : a) v = felt_mul(v, m_inv);
-    return a;
-}
-
-class RecursiveAir : public Air {
+class RecursiveAir : public LayoutAir {
 public:
-    RecursiveAir(ss_ctx *ctx, const AirPublicInput &pi, uint32_t log_n, uint32_t lb, uint64_t lde_offset)
-        : ctx_(ctx), pi_(pi), log_n_(log_n), lb_(lb), offset_(lde_offset), n_(1ull << log_n), g_(root_of_unity(log_n)) {
+    RecursiveAir(ss_ctx *ctx, const AirPublicInput &pi, uint32_t log_n, uint32_t lb, uint64_t lde_offset) : LayoutAir(ctx, pi, log_n, lb, lde_offset) {
         if (pi.layout != "recursive") throw std::runtime_error("the public input is not of the recursive layout");
         name = "recursive"; num_base_columns = 7; num_extension_columns = 3; num_challenges = 6;
-        // register every table (their set and order do not depend on the challenges) and collect the mask
-        std::vector<Felt> ch(6, felt_from_u64(2));
-        Graph g;
-        const int root = composition(g, ch, felt_from_u64(17));
-        std::set<std::pair<uint32_t, uint32_t>> cells;
-        std::vector<char> seen(g.nodes().size(), 0);
-        std::vector<int> stack{root};
-        while (!stack.empty()) {
-            const int id = stack.back(); stack.pop_back();
-            if (seen[id]) continue;
-            seen[id] = 1;
-            const Node &nd = g.nodes()[id];
-            if (nd.kind == NodeKind::Trace) cells.insert({nd.p0, nd.p1});
-            if (nd.a >= 0) stack.push_back(nd.a);
-            if (nd.b >= 0) stack.push_back(nd.b);
-        }
-        mask.assign(cells.begin(), cells.end());
-        if (ctx_) build_tables();
+        finish_construction();
     }
-
-    AirProgramData build_program(uint64_t n, const std::vector<Felt> &ch, const Felt &alpha) override {
-        if (n != n_) throw std::runtime_error("this recursive AIR was built for another trace length");
-        Graph g;
-        const int root = composition(g, ch, alpha);
-        AirProgramData pd;
-        pd.program = lower(g, root);
-        pd.d_tables = tables_ ? tables_->u64() : nullptr;
-        pd.table_desc = desc_;
-        return pd;
-    }
-
-    Felt composition_at(uint64_t n, const std::vector<Felt> &ch, const Felt &alpha, const Felt &z, const std::vector<Felt> &ood) override {
-        if (n != n_) throw std::runtime_error("this recursive AIR was built for another trace length");
-        Graph g;
-        const int root = composition(g, ch, alpha);
-        std::map<std::pair<uint32_t, uint32_t>, Felt> cell;
-        for (size_t j = 0; j < mask.size(); ++j) cell[mask[j]] = ood[j];
-        return evaluate(g, root, z, [&](uint32_t c, uint32_t o) { return cell.at({c, o}); }, [&](uint32_t t) { return table_value_at(specs_.at(t), z); });
-    }
-
-    // flat description of the tables for host-side checks: per table kind, e, #num, (p, e)..., #den, (p, e)...
-    std::vector<uint64_t> describe_tables() const {
-        std::vector<uint64_t> out{specs_.size()};
-        for (auto &s : specs_) {
-            out.push_back((uint64_t)s.kind); out.push_back(s.e);
-            out.push_back(s.num.size());
-            for (auto &f : s.num) { out.push_back(f.p); out.push_back(f.e); }
-            out.push_back(s.den.size());
-            for (auto &f : s.den) { out.push_back(f.p); out.push_back(f.e); }
-        }
-        return out;
-    }
+    using LayoutAir::describe_tables;
 
 private:
     // ---- hints (air.rs:1216-1260)
@@ -193,68 +46,18 @@ private:
         h.initial_ap = seg(1, false); h.final_ap = seg(1, true); h.initial_pc = seg(0, false); h.final_pc = seg(0, true);
         h.range_check_min = felt_from_u64(pi_.rc_min); h.range_check_max = felt_from_u64(pi_.rc_max);
         h.initial_pedersen_addr = seg(3, false); h.initial_rc_addr = seg(4, false); h.initial_bitwise_addr = seg(6, false);
-        // compute_public_memory_quotient (layouts/src/utils.rs:14-46)
-        const Felt &z = ch[MEM_Z], &a = ch[MEM_A];
-        const uint64_t s = n_ / 16, count = pi_.public_memory.size();
-        Felt den = felt_from_u64(1);
-        const MemoryEntry *pad = nullptr;
-        for (auto &e : pi_.public_memory) {
-            den = felt_mul(den, felt_sub(z, felt_add(felt_mul(a, felt_from_canonical(e.value)), felt_from_u64(e.address))));
-            if (!pad && e.address == 1) pad = &e;
-        }
-        if (!pad) throw std::runtime_error("public memory has no entry at address 1");
-        den = felt_mul(den, felt_pow(felt_sub(z, felt_add(felt_mul(a, felt_from_canonical(pad->value)), felt_from_u64(1))), s - count));
-        h.memory_quotient = felt_mul(felt_pow(z, s), felt_inv(den));
-        // compute_diluted_cumulative_value (layouts/src/utils.rs:48-108), 16 bits, spacing 4
-        const Felt &dz = ch[AGG_Z], &da = ch[AGG_A];
-        const Felt one = felt_from_u64(1), mult = felt_from_u64(16);
-        Felt diff_x = felt_from_u64(14), p = felt_add(dz, one), q = one, x = one;
-        for (int i = 1; i < 16; ++i) {
-            x = felt_add(x, diff_x);
-            diff_x = felt_mul(diff_x, mult);
-            const Felt xp = felt_mul(x, p), y = felt_add(p, felt_mul(dz, xp));
-            q = felt_add(q, felt_add(felt_mul(q, y), felt_mul(x, xp)));
-            p = felt_mul(p, y);
-        }
-        h.diluted_cumulative_value = felt_add(p, felt_mul(q, da));
+        h.memory_quotient = public_memory_quotient(pi_, ch[MEM_Z], ch[MEM_A], n_, 16);
+        h.diluted_cumulative_value = diluted_cumulative_value(ch[AGG_Z], ch[AGG_A]);
         return h;
     }
 
-    // ---- domains (mirror of layouts/recursive.py)
-    Domain every(uint64_t k) const { return Domain{{}, {{n_ / k, 0}}}; }
-    Domain every_except_last(uint64_t k) const { return Domain{{{1, n_ - k}}, {{n_ / k, 0}}}; }
-    Domain row_from_end(uint64_t k) const { return Domain{{}, {{1, n_ - k}}}; }
-
-    int table_index(const TableSpec &s) {
-        auto it = table_ix_.find(s);
-        if (it != table_ix_.end()) return it->second;
-        const int ix = (int)specs_.size();
-        specs_.push_back(s);
-        table_ix_[s] = ix;
-        return ix;
-    }
-    E multiplier(Graph &g, const Domain &d) {
-        TableSpec per; per.kind = 2;
-        for (auto &f : d.num) if (f.p > 1) per.num.push_back(f);
-        for (auto &f : d.den) if (f.p > 1) per.den.push_back(f);
-        bool have = false;
-        E expr{&g, -1};
-        if (!per.num.empty() || !per.den.empty()) { expr = E{&g, g.table((uint32_t)table_index(per))}; have = true; }
-        for (auto &f : d.num) if (f.p == 1) {
-            const E lin = E{&g, g.x()} - E{&g, g.constant(felt_pow(g_, f.e))};
-            expr = have ? expr * lin : lin; have = true;
-        }
-        for (auto &f : d.den) if (f.p == 1) {
-            TableSpec inv; inv.kind = 3; inv.e = f.e;
-            const E t{&g, g.table((uint32_t)table_index(inv))};
-            expr = have ? expr * t : t; have = true;
-        }
-        return expr;
-    }
+    // ---- periodic columns: the Pedersen points, one per 4-row step of a 2048-row hash
+    size_t num_periodic_columns() const override { return 2; }
+    std::vector<Felt> column_values(size_t c) const override { return pedersen_column((int)c); }
+    uint64_t column_period(size_t) const override { return 2048; }
 
     // ---- the composition: sum_i alpha^i numerator_i * multiplier(domain_i), grouped by domain (first-use order)
-    int composition(Graph &g, const std::vector<Felt> &ch, const Felt &alpha) {
-        if (specs_.empty()) { TableSpec px; px.kind = 0; table_index(px); TableSpec py; py.kind = 1; table_index(py); }
+    int composition(Graph &g, const std::vector<Felt> &ch, const Felt &alpha) override {
         const Hints h = hints(ch);
         auto T = [&](uint32_t col, uint64_t off) { return E{&g, g.trace(col, (uint32_t)off)}; };
         auto C = [&](uint64_t v) { return E{&g, g.constant_u64(v)}; };
@@ -266,16 +69,8 @@ private:
         auto aux = [&](uint64_t cell, uint64_t cycle = 0) { return T(COL_AUXILIARY, CYCLE_HEIGHT * cycle + cell); };
         const E one = C(1), two = C(2), four = C(4), offset_size = C(1ull << 16), half_offset_size = C(1ull << 15);
 
-        struct Group { Domain d; int sum; };
-        std::vector<std::pair<std::string, Group>> groups;
-        Felt apow = felt_from_u64(1);
-        auto add = [&](const std::string &dom_name, const Domain &d, const E &numerator) {
-            const E term = numerator * CF(apow);
-            auto it = std::find_if(groups.begin(), groups.end(), [&](const std::pair<std::string, Group> &p) { return p.first == dom_name; });
-            if (it == groups.end()) groups.push_back({dom_name, Group{d, term.id}});
-            else it->second.sum = g.add(it->second.sum, term.id);
-            apow = felt_mul(apow, alpha);
-        };
+        Composer composer(*this, g, alpha);
+        auto add = [&](const std::string &dom_name, const Domain &d, const E &numerator) { composer.add(dom_name, d, numerator); };
         const Domain ALL_CYCLES = every(16), ALL_CYCLES_EXCEPT_LAST = every_except_last(16);
         const Domain FLAG_ROWS{{{n_ / 16, 15 * n_ / 16}}, {{n_, 0}}}, FLAG_ZERO_ROWS{{}, {{n_ / 16, 15 * n_ / 16}}};
         const Domain FIRST_ROW{{}, {{1, 0}}}, LAST_CYCLE = row_from_end(16);
@@ -445,103 +240,15 @@ private:
                 ADD(EVERY_128, (bw(64 + 24 + 2 * k) + bw(96 + 24 + 2 * k)) * pow2(k == 3 ? 8 : 4) - bw(cells[k]));
         }
 #undef ADD
-        int total = -1;
-        for (auto &gr : groups) {
-            const E term = E{&g, gr.second.sum} * multiplier(g, gr.second.d);
-            total = total < 0 ? term.id : g.add(total, term.id);
-        }
-        return total;
+        return composer.total();
     }
 
-    // the function a table tabulates, at an arbitrary point
-    Felt table_value_at(const TableSpec &s, const Felt &x) const {
-        if (s.kind <= 1) {
-            if (pedersen_coeffs_[s.kind].empty()) pedersen_coeffs_[s.kind] = interpolate(pedersen_column(s.kind));
-            const Felt arg = felt_pow(x, n_ / 2048);
-            Felt acc = felt_from_u64(0);
-            for (size_t k = pedersen_coeffs_[s.kind].size(); k-- > 0;) acc = felt_add(felt_mul(acc, arg), pedersen_coeffs_[s.kind][k]);
-            return acc;
-        }
-        if (s.kind == 3) return felt_inv(felt_sub(x, felt_pow(g_, s.e)));
-        Felt num = felt_from_u64(1), den = felt_from_u64(1);
-        for (auto &f : s.num) num = felt_mul(num, felt_sub(felt_pow(x, f.p), felt_pow(g_, f.e)));
-        for (auto &f : s.den) den = felt_mul(den, felt_sub(felt_pow(x, f.p), felt_pow(g_, f.e)));
-        return felt_mul(num, felt_inv(den));
-    }
-
-    // ---- tables on the device
-    void build_tables() {
-        const uint64_t N = n_ << lb_;
-        std::vector<uint64_t> lengths;
-        uint64_t off = 0;
-        for (auto &s : specs_) {
-            uint64_t len = 0;
-            if (s.kind <= 1) len = 2048ull << lb_;
-            else if (s.kind == 3) len = N;
-            else { for (auto &f : s.num) len = std::max(len, N / f.p); for (auto &f : s.den) len = std::max(len, N / f.p); }
-            uint32_t ll = 0;
-            while ((1ull << ll) < len) ++ll;
-            desc_.push_back((uint32_t)off); desc_.push_back(ll);
-            lengths.push_back(len);
-            off += len;
-        }
-        tables_.reset(new DeviceBuffer(ctx_, 32 * off));
-        const Felt offset = felt_from_u64(offset_), w = root_of_unity(log_n_ + lb_);
-        for (size_t t = 0; t < specs_.size(); ++t) {
-            const TableSpec &s = specs_[t];
-            uint64_t *dst = tables_->u64() + 4ull * desc_[2 * t];
-            if (s.kind == 3) {
-                const Felt c = felt_pow(g_, s.e);
-                ok(ss_inverse_table(ctx_, log_n_ + lb_, offset.data(), c.data(), dst));
-                continue;
-            }
-            std::vector<Felt> host(lengths[t]);
-            if (s.kind <= 1) {
-                const std::vector<Felt> coeffs = interpolate(pedersen_column(s.kind));
-                const Felt step = felt_pow(w, n_ / 2048);
-                Felt x = felt_pow(offset, n_ / 2048);
-                for (auto &v : host) {
-                    Felt acc = felt_from_u64(0);
-                    for (size_t k = coeffs.size(); k-- > 0;) acc = felt_add(felt_mul(acc, x), coeffs[k]);
-                    v = acc;
-                    x = felt_mul(x, step);
-                }
-            } else {
-                Felt x = offset;
-                for (auto &v : host) {
-                    Felt num = felt_from_u64(1), den = felt_from_u64(1);
-                    for (auto &f : s.num) num = felt_mul(num, felt_sub(felt_pow(x, f.p), felt_pow(g_, f.e)));
-                    for (auto &f : s.den) den = felt_mul(den, felt_sub(felt_pow(x, f.p), felt_pow(g_, f.e)));
-                    v = felt_mul(num, felt_inv(den));
-                    x = felt_mul(x, w);
-                }
-            }
-            ok(ss_upload(ctx_, dst, host.data(), host.size() * 32));
-        }
-        ok(ss_ctx_sync(ctx_));
-    }
-
-    ss_ctx *ctx_;
-    AirPublicInput pi_;
-    uint32_t log_n_, lb_;
-    uint64_t offset_, n_;
-    Felt g_;
-    std::vector<TableSpec> specs_;
-    std::map<TableSpec, int> table_ix_;
-    std::vector<uint32_t> desc_;
-    std::unique_ptr<DeviceBuffer> tables_;
-    mutable std::vector<Felt> pedersen_coeffs_[2];
 };
 
 }  // namespace
 
 std::unique_ptr<Air> make_recursive_air(ss_ctx *ctx, const AirPublicInput &pi, uint32_t log_n, uint32_t log_blowup, uint64_t lde_offset) {
     return std::unique_ptr<Air>(new RecursiveAir(ctx, pi, log_n, log_blowup, lde_offset));
-}
-std::vector<uint64_t> recursive_air_tables(const Air &air) {
-    const RecursiveAir *r = dynamic_cast<const RecursiveAir *>(&air);
-    if (!r) throw std::runtime_error("not a recursive AIR");
-    return r->describe_tables();
 }
 
 }  // namespace ssh

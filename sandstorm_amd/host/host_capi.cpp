@@ -189,8 +189,18 @@ int ssh_air_create_recursive(ss_ctx *ctx, uint32_t rc_min, uint32_t rc_max, uint
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }
+// The real `starknet` AIR (air_starknet.cpp); same conventions.
+int ssh_air_create_starknet(ss_ctx *ctx, uint32_t rc_min, uint32_t rc_max, uint64_t n_steps, const uint32_t *segments,
+                            const uint32_t *mem_addresses, const uint64_t *mem_values, uint64_t n_mem, uint32_t log_n, uint32_t log_blowup,
+                            ssh_air **out) {
+    try {
+        const AirPublicInput pi = public_input_from_args(2, rc_min, rc_max, n_steps, segments, mem_addresses, mem_values, n_mem);
+        *out = reinterpret_cast<ssh_air *>(make_starknet_air(ctx, pi, log_n, log_blowup, 3).release());
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
 // the lowered composition program for these challenges and its table descriptions, as one u64 blob:
-// n_instr, code words..., n_consts, 4 limbs each..., n_slots, then recursive_air_tables()
+// n_instr, code words..., n_consts, 4 limbs each..., n_slots, then layout_air_tables()
 int ssh_air_dump(ssh_air *air_h, uint64_t n, const uint64_t *challenges, uint32_t nchallenges, const uint64_t alpha[4], uint64_t **blob, uint64_t *blob_len) {
     try {
         Air *air = reinterpret_cast<Air *>(air_h);
@@ -204,7 +214,7 @@ int ssh_air_dump(ssh_air *air_h, uint64_t n, const uint64_t *challenges, uint32_
         out.push_back(pd.program.consts.size());
         for (auto &c : pd.program.consts) for (int k = 0; k < 4; ++k) out.push_back(c[k]);
         out.push_back(pd.program.n_slots);
-        const std::vector<uint64_t> t = recursive_air_tables(*air);
+        const std::vector<uint64_t> t = layout_air_tables(*air);
         out.insert(out.end(), t.begin(), t.end());
         *blob = (uint64_t *)malloc(out.size() * 8);
         memcpy(*blob, out.data(), out.size() * 8);

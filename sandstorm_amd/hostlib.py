@@ -46,6 +46,7 @@ def load():
                                                C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_void_p)]
         h.ssh_air_create_recursive.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                                C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        h.ssh_air_create_starknet.argtypes = h.ssh_air_create_recursive.argtypes
         h.ssh_air_dump.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64),
                                    C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
         h.ssh_verify.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64),
@@ -86,11 +87,13 @@ class HostAir:
 class RecursiveHostAir(HostAir):
     """the C++ host's real `recursive` AIR for a public input (sandstorm_amd/host/air_recursive.cpp).  ctx=None: no device
     tables, only dump() works (host-side checks)."""
+    create = "ssh_air_create_recursive"
+    column_tag = "pedersen"                 # what layouts.recursive.Tables calls its periodic columns
 
     def __init__(self, ctx, pi, log_n, log_blowup=1):
         segs, addrs, vals = _public_input_args(pi)
         h = C.c_void_p()
-        _check(load().ssh_air_create_recursive(ctx.handle if ctx is not None else None, pi.rc_min, pi.rc_max, pi.n_steps,
+        _check(getattr(load(), self.create)(ctx.handle if ctx is not None else None, pi.rc_min, pi.rc_max, pi.n_steps,
                                                segs.ctypes.data_as(C.POINTER(C.c_uint32)), addrs.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                vals.ctypes.data_as(C.POINTER(C.c_uint64)), len(addrs), log_n, log_blowup, C.byref(h)))
         self.ctx, self.h = ctx, h
@@ -118,8 +121,15 @@ class RecursiveHostAir(HostAir):
             kind, e = next(it), next(it)
             num = tuple((next(it), next(it)) for _ in range(next(it)))
             den = tuple((next(it), next(it)) for _ in range(next(it)))
-            specs.append(("pedersen", kind) if kind <= 1 else ("periodic", num, den) if kind == 2 else ("inverse", e))
+            # kind 0: periodic column number e (layouts.recursive calls its two "pedersen", layouts.starknet "column")
+            specs.append((self.column_tag, e) if kind == 0 else ("periodic", num, den) if kind == 2 else ("inverse", e))
         return code, consts, n_slots, specs
+
+
+class StarknetHostAir(RecursiveHostAir):
+    """the C++ host's real `starknet` AIR (sandstorm_amd/host/air_starknet.cpp)"""
+    create = "ssh_air_create_starknet"
+    column_tag = "column"
 
 
 class _Reader:

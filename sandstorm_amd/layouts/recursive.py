@@ -849,11 +849,19 @@ class Tables:
                 vals.append((x - c) % P)
                 x = x * self.w % P
             return _batch_inverse(vals)
-        out = []
-        for i in range(length):
-            x = self.offset * pow(self.w, i, P) % P
-            out.append(self.value_at(spec, x))
-        return out
+        # prod(X^p - c) / prod(X^p - c') along x_i = offset * w^i: every power advances by its own step, one batch inversion
+        def running(factors):
+            state = [[pow(self.offset, p_, P), pow(self.w, p_, P), pow(self.g, e, P)] for p_, e in factors]
+            vals = []
+            for _ in range(length):
+                v = 1
+                for f in state:
+                    v = v * (f[0] - f[2]) % P
+                    f[0] = f[0] * f[1] % P
+                vals.append(v)
+            return vals
+        nums, dens = running(spec[1]), _batch_inverse(running(spec[2]))
+        return [a * b % P for a, b in zip(nums, dens)]
 
 
 def _poly_eval(coeffs, x):

@@ -286,3 +286,47 @@ def test_trace_generation_refuses_what_the_reference_refuses():
         sk.base_trace(states[:1024], memory, spi)
     with pytest.raises(ValueError, match="power of two"):
         sk.base_trace(states[:1000], memory, spi)
+
+
+def test_cpp_air_is_the_python_one(oracle):
+    """sandstorm_amd/host/air_starknet.cpp against layouts/starknet.py: the same mask, the same table set, and - both
+    lowered programs run by the oracle's constraint VM on one random evaluation domain (2^15-row trace, blowup 2) with
+    one random table per table description - the same composition at every point"""
+    import numpy as np
+    from sandstorm_amd import air_program as ap
+    from sandstorm_amd import hostlib
+    from sandstorm_amd.layouts import starknet as sk
+    _, _, spi = starknet_example(11)
+    log_n = 15
+    n, N = 1 << log_n, 2 << log_n
+    alpha = pow(5, 77, P)
+    hints = sk.Hints.from_public_input(spi, CHALLENGES, n)
+    tables = sk.Tables(n)
+    prog = ap.lower(sk.composition(n, hints, CHALLENGES, alpha, tables), P)
+    cpp = hostlib.StarknetHostAir(None, spi, log_n)
+    assert cpp.mask_size == 269 and (cpp.num_base_columns, cpp.num_extension_columns) == (9, 1)
+    code, consts, n_slots, specs = cpp.dump(n, [oracle.to_mont([c])[0] for c in CHALLENGES], oracle.to_mont([alpha])[0])
+    cpp.close()
+    assert sorted(map(repr, specs)) == sorted(map(repr, tables.specs)) and specs[:9] == tables.specs[:9]
+    rng = np.random.default_rng(11)
+    def rand(count):                                              # any limbs with the top one below 2^59 are felts below p
+        v = rng.integers(0, 1 << 63, size=(count, 4), dtype=np.uint64)
+        v[:, 3] &= np.uint64((1 << 59) - 1)
+        return np.ascontiguousarray(v)
+    by_spec = {spec: rand(tables.length(spec)) for spec in tables.specs}
+
+    def packed(order):
+        desc, off = [], 0
+        for spec in order:
+            desc += [off, len(by_spec[spec]).bit_length() - 1]
+            off += len(by_spec[spec])
+        return np.concatenate([by_spec[s] for s in order]), desc
+    lde = [rand(N) for _ in range(10)]
+    g = oracle.to_mont([3])[0]
+    tab, desc = packed(tables.specs)
+    out_py = oracle.eval_program(prog.code, oracle.to_mont(prog.consts), tab, desc, prog.n_slots, lde, log_n, 1, g)
+    tab, desc = packed(specs)
+    out_cpp = oracle.eval_program(code, consts, tab, desc, n_slots, lde, log_n, 1, g)
+    assert out_py.any() and np.array_equal(out_cpp, out_py)
+    with pytest.raises(Exception, match="starknet layout"):
+        hostlib.StarknetHostAir(None, load_run()[2], log_n)
