@@ -7,11 +7,14 @@ What pins it to the reference (layouts/src/starknet/{air,trace}.rs, builtins/src
     coefficient for coefficient, to the reference's tables (tests/golden/starknet_periodic_fingerprints.json);
   * the Poseidon margin keys derived here equal to the literals of air.rs:2052-2160, and StarkWare's zero-input
     example of the permutation (builtins/src/poseidon/mod.rs tests);
-  * the trace generation and the constraints validate each other: every constraint vanishes on its domain on a trace
-    of the reference's example run (dummy builtin instances and real ones), the three permutation products close and
-    the diluted aggregate ends at its closed form.
+  * the trace generation and the constraints validate each other on the reference's own starknet-layout run
+    (example/bootloader: 2^17 steps, its public and private input, two real Pedersen instances; committed compressed
+    under tests/golden/bootloader): every constraint vanishes on its domain, the memory is continuous over the real
+    builtin segments, the three permutation products close and the diluted aggregate ends at its closed form.  Real
+    range-check, ECDSA, bitwise, EC-op and Poseidon instances are added on top (the run itself uses none).
 The starknet layout needs 2^17 steps before its diluted check fits (60 free cells per 1024 rows for the 65535 padding
-values), so the example run is extended by its own final state - the `jmp rel 0` the runner pads with."""
+values): the array-sum example of the other tests only serves the size checks and the C++ comparison here."""
+import gzip
 import hashlib
 import json
 import os
@@ -48,6 +51,21 @@ def starknet_example(log_steps=LOG_STEPS):
     return states, mem, spi
 
 
+def bootloader_run():
+    """example/bootloader of the reference: register states, memory, public input, private input (its Pedersen instances)"""
+    from sandstorm_amd import binary, public_input
+    g = os.path.join(ROOT, "tests", "golden")
+    with gzip.open(os.path.join(g, "bootloader", "trace.bin.gz")) as f:
+        states = binary.read_register_states(f.read())
+    with gzip.open(os.path.join(g, "bootloader", "memory.bin.gz")) as f:
+        memory = binary.read_memory(f.read())
+    pi = public_input.AirPublicInput.from_json(os.path.join(g, "air_public_input_bootloader.json"))
+    with open(os.path.join(g, "bootloader", "air-private-input.json")) as f:
+        priv = json.load(f)
+    assert all(priv[k] == [] for k in ("range_check", "ecdsa", "bitwise", "ec_op", "poseidon"))
+    return states, memory, pi, {"pedersen": [(e["index"], int(e["x"], 16), int(e["y"], 16)) for e in priv["pedersen"]]}
+
+
 def real_instances():
     from sandstorm_amd.layouts import starknet as sk
     rng = random.Random(2024)
@@ -63,8 +81,8 @@ def real_instances():
     p5, q7, q9 = sk._ec_mul(5, sk.GENERATOR), sk._ec_mul(7, sk.GENERATOR), sk._ec_mul(9, sk.GENERATOR)
     top = (1 << 251) | (1 << 196) | (1 << 192)
     return {
-        "pedersen": [(0, rng.getrandbits(250), rng.getrandbits(250)), (1, top, (1 << 251) | (1 << 196)), (7, 0, 5)],
-        "range_check": [(i, sum(rng.randrange(32764, 32771) << (16 * j) for j in range(8))) for i in range(5)],
+        "pedersen": [(2, rng.getrandbits(250), rng.getrandbits(250)), (3, top, (1 << 251) | (1 << 196)), (7, 0, 5)],
+        "range_check": [(i, sum(rng.randrange(32758, 32794) << (16 * j) for j in range(8))) for i in range(5)],
         "ecdsa": [(1, pub[0], msg, r, w)],
         "bitwise": [(i, rng.getrandbits(251), rng.getrandbits(251)) for i in range(6)],
         "ec_op": [(0, p5[0], p5[1], q7[0], q7[1], rng.getrandbits(250)), (2, p5[0], p5[1], q9[0], q9[1], top),
@@ -78,8 +96,12 @@ def example():
     import numpy as np
     from oracle import oracle_py as oracle
     from sandstorm_amd.layouts import starknet as sk
-    states, memory, spi = starknet_example()
-    cols = sk.base_trace(states, memory, spi, real_instances())
+    states, memory, spi, private = bootloader_run()
+    assert spi.layout == "starknet" and len(states) == spi.n_steps == 1 << LOG_STEPS and len(private["pedersen"]) == 2
+    extra = real_instances()
+    private["pedersen"] += extra.pop("pedersen")
+    private.update(extra)
+    cols = sk.base_trace(states, memory, spi, private)
     n = len(cols[0])
     aux = {"npc": oracle.to_mont(cols[sk.COL_NPC]), "memory": oracle.to_mont(cols[sk.COL_MEMORY]), "range_check": oracle.to_mont(cols[sk.COL_RANGE_CHECK])}
     ext, lasts = oracle.build_extension_columns("starknet", aux, [oracle.to_mont([c])[0] for c in CHALLENGES], n)
@@ -251,7 +273,7 @@ def test_a_corrupted_cell_trips_its_constraints(example):
     n = len(cols[0])
     by_name = {c.name: c for c in constraints}
     probes = [  # (column, row, a constraint that must notice, a row of its domain that reads the cell)
-        (sk.COL_PEDERSEN_X, 300, ("pedersen/hash0/ec_subset_sum/add_points/x", "pedersen/hash0/ec_subset_sum/copy_point/x"), 299),
+        (sk.COL_PEDERSEN_X, 512 * 2 + 300, ("pedersen/hash0/ec_subset_sum/add_points/x", "pedersen/hash0/ec_subset_sum/copy_point/x"), 512 * 2 + 299),
         (sk.COL_AUXILIARY, 32768 + 64 * 10 + sk.Ecdsa.PUBKEY_DOUBLING_Y, "ecdsa/signature0/doubling_key/y", 32768 + 64 * 10),
         (sk.COL_AUXILIARY, 32768 + 128 * 3 + sk.Ecdsa.GENERATOR_PARTIAL_SUM_X, "ecdsa/signature0/exponentiate_generator/add_points/x_diff_inv", 32768 + 128 * 3),
         (sk.COL_AUXILIARY, 32768 + sk.Ecdsa.R_POINT_SLOPE, "ecdsa/signature0/extract_r/x", 32768),

@@ -1,5 +1,5 @@
 """One-off CPU check of the whole starknet chain with the oracle (about 5 minutes; the unit tests check the pieces):
-the 10 columns of the 2^21-row example trace (tests/test_layout_starknet.py) are extended to the 2^22-point coset, the
+the 10 columns of the 2^21-row trace of the reference's bootloader run (tests/test_layout_starknet.py, with the extra builtin instances) are extended to the 2^22-point coset, the
 lowered composition program runs over it, and the result interpolates to a polynomial of degree exactly 2n - 3 - every
 one of the 195 constraints is divisible by its zerofier - which satisfies the verifier's out-of-domain identity at a
 random point.  Usage: python tools/starknet_composition_check.py"""
@@ -15,11 +15,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle_py as oracle  # noqa: E402
 from sandstorm_amd import air_program as ap  # noqa: E402
 from sandstorm_amd.layouts import starknet as sk  # noqa: E402
-from test_layout_starknet import CHALLENGES, P, real_instances, starknet_example  # noqa: E402
+from test_layout_starknet import CHALLENGES, P, bootloader_run, real_instances  # noqa: E402
 
 t0 = time.time()
-states, memory, spi = starknet_example()
-cols = sk.base_trace(states, memory, spi, real_instances())
+states, memory, spi, private = bootloader_run()
+extra = real_instances()
+private["pedersen"] += extra.pop("pedersen")
+private.update(extra)
+cols = sk.base_trace(states, memory, spi, private)
 n = len(cols[0])
 log_n, N = n.bit_length() - 1, 2 * n
 mont = [oracle.to_mont(c) for c in cols]
