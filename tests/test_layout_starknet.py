@@ -352,3 +352,29 @@ def test_cpp_air_is_the_python_one(oracle):
     assert out_py.any() and np.array_equal(out_cpp, out_py)
     with pytest.raises(Exception, match="starknet layout"):
         hostlib.StarknetHostAir(None, load_run()[2], log_n)
+
+
+def test_base_trace_is_the_one_the_references_proof_opens(oracle, golden):
+    """`example/bootloader/bootloader-proof.bin` is the reference's own proof of the run shipped beside it.  The 100 rows of the
+    base-trace LDE it opens (tests/golden/make_starknet_rows_golden.py) equal, in all 9 columns, the rows of the trace
+    regenerated here from trace.bin / memory.bin / the public and private input: every value of a column's extension
+    depends on all 2^21 cells of that column, so this pins the whole base-trace generation - CPU cells, the memory pool
+    with gap fillers, sorted memory, the range-check and diluted pools with their padding, the real Pedersen instances
+    and the DUMMY instances of all six builtins - together with the LDE coset (offset 3, blowup 2), against real
+    prover output."""
+    from sandstorm_amd.layouts import starknet as sk
+    g = golden("starknet_opened_rows.json")
+    states, memory, pi, private = bootloader_run()
+    cols = sk.base_trace(states, memory, pi, private)
+    assert len(cols[0]) == g["trace_len"] and len(g["positions"]) == 100 == len(set(g["positions"]))
+    offset = oracle.to_mont([g["lde_offset"]])[0]
+    for c, col in enumerate(cols):
+        lde = oracle.lde(oracle.to_mont(col), 1, offset)[0]
+        got = [int(v) for v in oracle.from_mont(lde[g["positions"]])]
+        assert got == [int(row[c], 16) for row in g["rows"]], "column %d" % c
+    # the pin discriminates: one changed cell anywhere in a column changes (almost) every opened value of it
+    col = list(cols[sk.COL_AUXILIARY])
+    col[123456] = (col[123456] + 1) % P
+    lde = oracle.lde(oracle.to_mont(col), 1, offset)[0]
+    got = [int(v) for v in oracle.from_mont(lde[g["positions"]])]
+    assert sum(a == int(row[sk.COL_AUXILIARY], 16) for a, row in zip(got, g["rows"])) == 0
