@@ -11,12 +11,24 @@
 #include "oracle.h"
 #include <stdlib.h>
 
-/* ark-ff 0.4.2 batch_inversion (fields/mod.rs): every non-zero element is replaced by its inverse, zeros are
- * left untouched.  Element-wise inversion is the definition; the reference's Montgomery trick is an optimisation
- * of exactly this map. */
+/* ark-ff 0.4.2 batch_inversion (fields/mod.rs, serial_batch_inversion_and_mul): every non-zero element is replaced by
+ * its inverse, zeros are left untouched - Montgomery's trick as ark-ff writes it: prefix products of the non-zero
+ * elements, one inversion, a backward pass. */
 static void batch_inversion(fp_t *v, uint64_t n) {
+    fp_t *prod = (fp_t *)malloc((n ? n : 1) * sizeof(fp_t));
+    fp_t tmp = FP_ONE;
+    uint64_t m = 0;
     for (uint64_t i = 0; i < n; ++i)
-        if (!fp_is_zero(v[i])) v[i] = fp_inv(v[i]);
+        if (!fp_is_zero(v[i])) { tmp = fp_mul(tmp, v[i]); prod[m++] = tmp; }
+    tmp = fp_inv(tmp);
+    for (uint64_t i = n; i-- > 0;) {
+        if (fp_is_zero(v[i])) continue;
+        --m;
+        const fp_t new_tmp = fp_mul(tmp, v[i]);
+        v[i] = m ? fp_mul(tmp, prod[m - 1]) : tmp;
+        tmp = new_tmp;
+    }
+    free(prod);
 }
 
 static fp_t perm_term(const fp_t *col, uint64_t stride, uint64_t a_off, int64_t v_off, uint64_t k, fp_t z, fp_t alpha) {
