@@ -4,6 +4,7 @@
 // sandstorm_amd/layouts/starknet.py, where every piece is documented, derived and pinned to the reference; the two
 // are compared on the CPU (tests/test_layout_starknet.py: same tables, same composition on a whole evaluation domain).
 #include "air_layout.hpp"
+#include "trace_starknet.hpp"
 
 namespace ssh {
 
@@ -159,6 +160,16 @@ const PoseidonKeys &poseidon_keys() {
     }();
     return keys;
 }
+
+}  // namespace
+
+const std::vector<std::array<Felt, 3>> &poseidon_round_keys() { return poseidon_keys().round; }
+void starknet_curve(Felt &generator_x, Felt &generator_y, Felt &beta) {
+    const Pt g = curve_generator();
+    generator_x = g.x; generator_y = g.y; beta = curve_beta();
+}
+
+namespace {
 
 class StarknetAir : public LayoutAir {
 public:

@@ -9,6 +9,7 @@
 #include "prover.hpp"
 #include "public_input.hpp"
 #include "trace_recursive.hpp"
+#include "trace_starknet.hpp"
 #include "verifier.hpp"
 
 using namespace ssh;
@@ -162,6 +163,38 @@ int ssh_recursive_base_trace(const uint8_t *trace_bin, uint64_t trace_len, const
         std::vector<uint8_t> present;
         read_memory(memory_bin, memory_len, memory, present);
         const auto cols = recursive_base_trace(states, memory, present, pi, priv);
+        for (size_t c = 0; c < cols.size(); ++c) memcpy(columns_out[c], cols[c].data(), cols[c].size() * 32);
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// Base trace of the starknet layout (trace_starknet.hpp).  A flat instance list per builtin, as 1 + 4 k u64 each (index, then
+// k 256-bit values): pedersen k = 2 (a, b), range_check 1, ecdsa 4 (pubkey x, message, r, w), bitwise 2 (x, y),
+// ec_op 5 (p.x, p.y, q.x, q.y, m), poseidon 3.  counts: the six instance counts in that order.  columns_out: 9 arrays.
+int ssh_starknet_base_trace(const uint8_t *trace_bin, uint64_t trace_len, const uint8_t *memory_bin, uint64_t memory_len,
+                            uint32_t rc_min, uint32_t rc_max, uint64_t n_steps, const uint32_t *segments, const uint32_t *mem_addresses,
+                            const uint64_t *mem_values, uint64_t n_mem, const uint64_t *const *instances, const uint64_t *counts,
+                            uint64_t *const *columns_out) {
+    try {
+        AirPublicInput pi;
+        pi.layout = "starknet";
+        pi.rc_min = (uint16_t)rc_min; pi.rc_max = (uint16_t)rc_max; pi.n_steps = n_steps;
+        for (int k = 0; k < 9; ++k) { pi.segments[k].present = segments[3 * k] != 0; pi.segments[k].begin_addr = segments[3 * k + 1]; pi.segments[k].stop_ptr = segments[3 * k + 2]; }
+        pi.public_memory.resize(n_mem);
+        for (uint64_t i = 0; i < n_mem; ++i) { pi.public_memory[i].address = mem_addresses[i]; memcpy(pi.public_memory[i].value.data(), mem_values + 4 * i, 32); }
+        auto val = [](const uint64_t *rec, int k) { U256 v; memcpy(v.data(), rec + 1 + 4 * k, 32); return v; };
+        StarknetPrivateInput priv;
+        for (uint64_t i = 0; i < counts[0]; ++i) { const uint64_t *r = instances[0] + 9 * i; priv.pedersen.push_back(PedersenInstance{(uint32_t)r[0], val(r, 0), val(r, 1)}); }
+        for (uint64_t i = 0; i < counts[1]; ++i) { const uint64_t *r = instances[1] + 5 * i; priv.range_check.push_back(RangeCheckInstance{(uint32_t)r[0], val(r, 0)}); }
+        for (uint64_t i = 0; i < counts[2]; ++i) { const uint64_t *r = instances[2] + 17 * i; priv.ecdsa.push_back(EcdsaInstance{(uint32_t)r[0], val(r, 0), val(r, 1), val(r, 2), val(r, 3)}); }
+        for (uint64_t i = 0; i < counts[3]; ++i) { const uint64_t *r = instances[3] + 9 * i; priv.bitwise.push_back(BitwiseInstance{(uint32_t)r[0], val(r, 0), val(r, 1)}); }
+        for (uint64_t i = 0; i < counts[4]; ++i) { const uint64_t *r = instances[4] + 21 * i; priv.ec_op.push_back(EcOpInstance{(uint32_t)r[0], val(r, 0), val(r, 1), val(r, 2), val(r, 3), val(r, 4)}); }
+        for (uint64_t i = 0; i < counts[5]; ++i) { const uint64_t *r = instances[5] + 13 * i; priv.poseidon.push_back(PoseidonInstance{(uint32_t)r[0], {val(r, 0), val(r, 1), val(r, 2)}}); }
+        const auto states = read_register_states(trace_bin, trace_len);
+        std::vector<U256> memory;
+        std::vector<uint8_t> present;
+        read_memory(memory_bin, memory_len, memory, present);
+        const auto cols = starknet_base_trace(states, memory, present, pi, priv);
         for (size_t c = 0; c < cols.size(); ++c) memcpy(columns_out[c], cols[c].data(), cols[c].size() * 32);
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }

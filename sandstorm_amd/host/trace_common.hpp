@@ -1,0 +1,153 @@
+// trace_common.hpp — what the layouts' base-trace generators (trace_recursive.cpp, trace_starknet.cpp) share: the
+// instruction word (binary/src/lib.rs:565-721), memory access, the curve, the Pedersen builtin's element steps
+// (builtins/src/pedersen/mod.rs:121-163) and the diluted form of the bitwise builtin (builtins/src/bitwise/mod.rs).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "trace_recursive.hpp"
+
+namespace ssh {
+namespace tracedetail {
+
+constexpr uint32_t DILUTED_N_BITS = 16, DILUTED_SPACING = 4;
+constexpr uint64_t HALF_OFFSET = 1ull << 15;
+// enum Flag (binary/src/lib.rs:740-772)
+enum { F_DST_REG, F_OP0_REG, F_OP1_IMM, F_OP1_FP, F_OP1_AP, F_RES_ADD, F_RES_MUL, F_PC_JUMP_ABS, F_PC_JUMP_REL, F_PC_JNZ, F_AP_ADD, F_AP_ADD1,
+       F_OPCODE_CALL, F_OPCODE_RET, F_OPCODE_ASSERT_EQ, F_ZERO };
+
+
+[[noreturn]] inline void fail(const std::string &m) { throw std::runtime_error("trace: " + m); }
+
+inline bool felt_is_zero(const Felt &f) { return (f[0] | f[1] | f[2] | f[3]) == 0; }
+inline bool felt_eq(const Felt &a, const Felt &b) { return a == b; }
+inline U256 shr(const U256 &v, unsigned k) {
+    U256 r{};
+    const unsigned w = k / 64, b = k % 64;
+    for (unsigned i = 0; i + w < 4; ++i) {
+        r[i] = v[i + w] >> b;
+        if (b && i + w + 1 < 4) r[i] |= v[i + w + 1] << (64 - b);
+    }
+    return r;
+}
+inline bool bit(const U256 &v, unsigned k) { return (v[k / 64] >> (k % 64)) & 1; }
+
+struct Word {                       // binary/src/lib.rs:565-721 (instruction fields live in the low 63 bits)
+    uint64_t w;
+    bool flag(int f) const { return (w >> (48 + f)) & 1; }
+    uint64_t flag_prefix(int f) const { return f == F_ZERO ? 0 : (w >> (48 + f)) & ((1ull << (15 - f)) - 1); }
+    uint64_t off_dst() const { return w & 0xffff; }
+    uint64_t off_op0() const { return (w >> 16) & 0xffff; }
+    uint64_t off_op1() const { return (w >> 32) & 0xffff; }
+    int op1_src() const { return flag(F_OP1_IMM) + 2 * flag(F_OP1_FP) + 4 * flag(F_OP1_AP); }
+    int res_logic() const { return flag(F_RES_ADD) + 2 * flag(F_RES_MUL); }
+    int pc_update() const { return flag(F_PC_JUMP_ABS) + 2 * flag(F_PC_JUMP_REL) + 4 * flag(F_PC_JNZ); }
+};
+
+struct Mem {
+    const std::vector<U256> &m;
+    const std::vector<uint8_t> &present;
+    const U256 &at(uint64_t a) const {
+        if (a >= m.size() || !present[a]) fail("the run reads memory cell " + std::to_string(a) + " that memory.bin does not hold");
+        return m[a];
+    }
+    uint64_t small(uint64_t a) const {
+        const U256 &v = at(a);
+        if (v[1] | v[2] | v[3]) fail("memory cell " + std::to_string(a) + " is used as an address but is not one");
+        return v[0];
+    }
+};
+
+// ---- curve y^2 = x^3 + x + beta, affine (builtins/src/utils.rs)
+struct Pt { Felt x, y; };
+inline Pt ec_double(const Pt &p) {
+    const Felt xx = felt_mul(p.x, p.x);
+    const Felt lam = felt_mul(felt_add(felt_add(felt_add(xx, xx), xx), felt_from_u64(1)), felt_inv(felt_add(p.y, p.y)));
+    const Felt x3 = felt_sub(felt_mul(lam, lam), felt_add(p.x, p.x));
+    return Pt{x3, felt_sub(felt_mul(lam, felt_sub(p.x, x3)), p.y)};
+}
+inline Pt ec_add(const Pt &a, const Pt &b) {
+    if (felt_eq(a.x, b.x)) {
+        if (!felt_eq(a.y, b.y)) fail("point at infinity in a Pedersen partial sum");
+        return ec_double(a);
+    }
+    const Felt lam = felt_mul(felt_sub(b.y, a.y), felt_inv(felt_sub(b.x, a.x)));
+    const Felt x3 = felt_sub(felt_sub(felt_mul(lam, lam), a.x), b.x);
+    return Pt{x3, felt_sub(felt_mul(lam, felt_sub(a.x, x3)), a.y)};
+}
+// builtins/src/pedersen/constants.rs:5-30, canonical little-endian limbs
+inline constexpr uint64_t PEDERSEN_POINTS[5][2][4] = {
+    {{0x551fde4050ca6804ull, 0x716b0b1022947733ull, 0x00ee1b87eb599f16ull, 0x049ee3eba8c16007ull}, {0xd0405d266e10268aull, 0x4e621062c0e056c1ull, 0xf346d49d06ea0ed3ull, 0x03ca0cfe4b3bc6ddull}},
+    {{0x1080d17957ebe47bull, 0x8fa8120b6d56eb0cull, 0x969c748655fca9e5ull, 0x0234287dcbaffe7full}, {0x6ed0268ee89e5615ull, 0x940135dd7a6c94ccull, 0x1e889527d41f4e39ull, 0x03b056f100f96fb2ull}},
+    {{0xb7a6932dba8aa378ull, 0x99099ec1de5e3018ull, 0x3f9dab2656558f33ull, 0x04fa56f376c83db3ull}, {0x5168f4e80ff5b54dull, 0x562761f92a7a23b4ull, 0x8113e0c0e47e4401ull, 0x03fa0984c931c9e3ull}},
+    {{0x3aa372f0bd2d6997ull, 0x40c690c74709e90full, 0x764910f75b45f74bull, 0x04ba4cc166be8decull}, {0x48151f27b24b219cull, 0xcac5c59a5ce5ae7cull, 0x4b971e46c4ede85full, 0x0040301cf5c1751full}},
+    {{0xd36ff12c49a58202ull, 0x2ca65048d53fb325ull, 0x6e44cca8f61a63bbull, 0x054302dcb0e6cc1cull}, {0x879dcc77e99c2426ull, 0xce98ad783c25561aull, 0xb348046268d8ae25ull, 0x01b77b3e37d13504ull}},
+};
+inline Pt pedersen_point(int k) {
+    U256 x, y;
+    memcpy(x.data(), PEDERSEN_POINTS[k][0], 32); memcpy(y.data(), PEDERSEN_POINTS[k][1], 32);
+    return Pt{felt_from_canonical(x), felt_from_canonical(y)};
+}
+inline const std::vector<Pt> &constant_points() {          // gen_element_steps' constant_points for both inputs (512 entries)
+    static std::vector<Pt> pts;
+    if (pts.empty()) {
+        for (int e = 0; e < 2; ++e) {
+            std::vector<Pt> half;
+            Pt acc = pedersen_point(1 + 2 * e);
+            for (int i = 0; i < 248; ++i) { half.push_back(acc); acc = ec_double(acc); }
+            acc = pedersen_point(2 + 2 * e);
+            for (int i = 0; i < 4; ++i) { half.push_back(acc); acc = ec_double(acc); }
+            for (int i = 0; i < 4; ++i) half.push_back(half[251]);
+            pts.insert(pts.end(), half.begin(), half.end());
+        }
+    }
+    return pts;
+}
+struct Step { Pt point; Felt suffix, slope; };
+// gen_element_steps (builtins/src/pedersen/mod.rs:121-163)
+inline Pt element_steps(const U256 &x, Pt point, int which, std::vector<Step> &out) {
+    const std::vector<Pt> &cp = constant_points();
+    for (unsigned i = 0; i < 256; ++i) {
+        const U256 suffix = shr(x, i);
+        Felt slope = felt_from_u64(0);
+        Pt next = point;
+        if (suffix[0] & 1) {
+            const Pt &c = cp[256 * which + i];
+            if (felt_eq(c.x, point.x)) {
+                if (!felt_eq(c.y, point.y)) fail("point at infinity in a Pedersen partial sum");
+                const Felt xx = felt_mul(c.x, c.x);
+                slope = felt_mul(felt_add(felt_add(felt_add(xx, xx), xx), felt_from_u64(1)), felt_inv(felt_add(c.y, c.y)));
+            } else {
+                slope = felt_mul(felt_sub(point.y, c.y), felt_inv(felt_sub(point.x, c.x)));
+            }
+            next = ec_add(point, c);
+        }
+        out.push_back(Step{point, felt_from_canonical(suffix), slope});
+        point = next;
+    }
+    return point;
+}
+
+inline uint64_t dilute(uint64_t v) {                       // bit i -> bit 4 i
+    uint64_t out = 0;
+    for (unsigned i = 0; i < 16; ++i) out |= ((v >> i) & 1ull) << (DILUTED_SPACING * i);
+    return out;
+}
+inline uint32_t undilute(uint64_t v) {                     // DilutedCheckPool::push_diluted
+    uint32_t out = 0;
+    for (unsigned i = 0; i < DILUTED_N_BITS; ++i) out |= (uint32_t)((v >> (DILUTED_SPACING * i)) & 1ull) << i;
+    if (dilute(out) != v) fail("a value is not in diluted form");
+    return out;
+}
+inline void partition64(uint64_t v, uint64_t segs[4]) {    // Partition64::new
+    for (int s = 0; s < 4; ++s) segs[s] = 0;
+    for (unsigned b = 0; b < 16; ++b)
+        for (unsigned s = 0; s < 4; ++s) segs[s] |= ((v >> (b * 4 + s)) & 1ull) << (b * 4);
+}
+
+
+}  // namespace tracedetail
+}  // namespace ssh

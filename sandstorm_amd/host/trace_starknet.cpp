@@ -1,0 +1,589 @@
+// trace_starknet.cpp — see trace_starknet.hpp.  Section by section the mirror of layouts/starknet.py::base_trace.
+#include "trace_starknet.hpp"
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <tuple>
+
+#include "../../include/sandstorm_hip.h"
+#include "trace_common.hpp"
+
+namespace ssh {
+
+using namespace tracedetail;
+
+namespace {
+
+constexpr uint64_t CYCLE_HEIGHT = 16, PUBLIC_MEMORY_STEP = 8, RANGE_CHECK_STEP = 4, DILUTED_CHECK_STEP = 8;
+constexpr uint64_t PEDERSEN_BUILTIN_RATIO = 32, RANGE_CHECK_BUILTIN_RATIO = 16, RANGE_CHECK_BUILTIN_PARTS = 8, BITWISE_RATIO = 64;
+constexpr uint64_t ECDSA_BUILTIN_RATIO = 2048, EC_OP_BUILTIN_RATIO = 1024, POSEIDON_RATIO = 32;
+enum { COL_FLAGS, COL_PEDERSEN_X, COL_PEDERSEN_Y, COL_PEDERSEN_SUFFIX, COL_PEDERSEN_SLOPE, COL_NPC, COL_MEMORY, COL_RANGE_CHECK, COL_AUXILIARY, NUM_COLS };
+enum { NPC_PC = 0, NPC_PUB_MEM_ADDR = 2, NPC_MEM_OP0_ADDR = 4, NPC_MEM_DST_ADDR = 8, NPC_MEM_OP1_ADDR = 12, NPC_UNUSED_ADDR = 14,
+       NPC_PEDERSEN_INPUT0_ADDR = 6, NPC_PEDERSEN_INPUT1_ADDR = 262, NPC_PEDERSEN_OUTPUT_ADDR = 134, NPC_RANGE_CHECK128_ADDR = 70,
+       NPC_ECDSA_PUBKEY_ADDR = 390, NPC_ECDSA_MESSAGE_ADDR = 16774, NPC_BITWISE_POOL_ADDR = 198, NPC_BITWISE_X_OR_Y_ADDR = 902 };
+const uint64_t NPC_EC_OP_ADDRS[7] = {8582, 4486, 12678, 2438, 10630, 6534, 14726};            // p.x, p.y, q.x, q.y, m, r.x, r.y
+const uint64_t NPC_POSEIDON_ADDRS[6] = {38, 102, 166, 230, 294, 358};
+enum { RC_OFF_DST = 0, RC_ORDERED = 2, RC_OFF_OP1 = 4, RC_OFF_OP0 = 8, RC_UNUSED = 12, RC16_COMPONENT = 12 };
+enum { AUX_AP = 0, AUX_TMP0 = 2, AUX_OP0_MUL_OP1 = 4, AUX_FP = 8, AUX_TMP1 = 10, AUX_RES = 12 };
+enum { DC_UNORDERED = 1, DC_ORDERED = 5 };
+enum { EC_PUBKEY_DOUBLING_X = 1, EC_PUBKEY_DOUBLING_Y = 33, EC_PUBKEY_DOUBLING_SLOPE = 35, EC_PUBKEY_PARTIAL_SUM_X = 17, EC_PUBKEY_PARTIAL_SUM_Y = 49,
+       EC_PUBKEY_PARTIAL_SUM_X_DIFF_INV = 51, EC_PUBKEY_PARTIAL_SUM_SLOPE = 19, EC_R_SUFFIX = 9, EC_MESSAGE_SUFFIX = 59, EC_GENERATOR_PARTIAL_SUM_Y = 91,
+       EC_GENERATOR_PARTIAL_SUM_X = 27, EC_GENERATOR_PARTIAL_SUM_X_DIFF_INV = 7, EC_GENERATOR_PARTIAL_SUM_SLOPE = 123, EC_R_POINT_SLOPE = 16331,
+       EC_R_POINT_X_DIFF_INV = 32715, EC_R_INV = 16355, EC_W_INV = 32739, EC_MESSAGE_INV = 16363, EC_PUBKEY_X_SQUARED = 32747, EC_B_SLOPE = 32763,
+       EC_B_X_DIFF_INV = 32647 };
+enum { OP_Q_DOUBLING_X = 41, OP_Q_DOUBLING_Y = 25, OP_Q_DOUBLING_SLOPE = 57, OP_R_PARTIAL_SUM_X = 5, OP_R_PARTIAL_SUM_Y = 37, OP_R_PARTIAL_SUM_SLOPE = 11,
+       OP_R_PARTIAL_SUM_X_DIFF_INV = 43, OP_M_SUFFIX = 21, OP_M_BIT251_AND_BIT196_AND_BIT192 = 16371, OP_M_BIT251_AND_BIT196 = 16339 };
+const uint64_t BITWISE_SHIFTED_CELLS[4] = {9, 521, 265, 777};
+
+// the curve's group order (builtins/src/utils.rs:134)
+const U256 CURVE_ORDER{0x1e66a241adc64d2full, 0xb781126dcae7b232ull, 0xffffffffffffffffull, 0x0800000000000010ull};
+
+bool is_zero(const U256 &v) { return (v[0] | v[1] | v[2] | v[3]) == 0; }
+bool less(const U256 &a, const U256 &b) {
+    for (int k = 3; k >= 0; --k) if (a[k] != b[k]) return a[k] < b[k];
+    return false;
+}
+unsigned bit_length(const U256 &v) {
+    for (int k = 3; k >= 0; --k) if (v[k]) return 64 * k + 64 - (unsigned)__builtin_clzll(v[k]);
+    return 0;
+}
+U256 add_raw(const U256 &a, const U256 &b) {
+    U256 r;
+    unsigned __int128 c = 0;
+    for (int k = 0; k < 4; ++k) { c += (unsigned __int128)a[k] + b[k]; r[k] = (uint64_t)c; c >>= 64; }
+    return r;
+}
+U256 sub_raw(const U256 &a, const U256 &b) {
+    U256 r;
+    unsigned __int128 br = 0;
+    for (int k = 0; k < 4; ++k) { const unsigned __int128 t = (unsigned __int128)a[k] - b[k] - (uint64_t)br; r[k] = (uint64_t)t; br = (t >> 64) & 1; }
+    return r;
+}
+// arithmetic modulo the group order (only the dummy signature needs it): values below 2^252, so sums do not overflow 256 bits
+U256 addmod_n(const U256 &a, const U256 &b) { const U256 s = add_raw(a, b); return less(s, CURVE_ORDER) ? s : sub_raw(s, CURVE_ORDER); }
+U256 mulmod_n(const U256 &a, const U256 &b) {
+    U256 acc{};
+    for (int i = (int)bit_length(b) - 1; i >= 0; --i) { acc = addmod_n(acc, acc); if (bit(b, (unsigned)i)) acc = addmod_n(acc, a); }
+    return acc;
+}
+U256 invmod_n(const U256 &a) {                           // a^(N - 2)
+    const U256 e = sub_raw(CURVE_ORDER, U256{2, 0, 0, 0});
+    U256 acc{1, 0, 0, 0};
+    for (int i = (int)bit_length(e) - 1; i >= 0; --i) { acc = mulmod_n(acc, acc); if (bit(e, (unsigned)i)) acc = mulmod_n(acc, a); }
+    return acc;
+}
+U256 canonical_of(const Felt &f) {
+    const std::array<uint8_t, 32> be = canonical_be_bytes(f);
+    U256 v{};
+    for (int i = 0; i < 32; ++i) v[(31 - i) / 8] |= (uint64_t)be[i] << (8 * ((31 - i) % 8));
+    return v;
+}
+
+Pt ec_neg(const Pt &p) { return Pt{p.x, felt_neg(p.y)}; }
+// calculate_slope (builtins/src/utils.rs:163-181): the chord through two points, the tangent when they coincide
+Felt slope_of(const Pt &p1, const Pt &p2) {
+    if (felt_eq(p1.x, p2.x)) {
+        if (!felt_eq(p1.y, p2.y)) fail("vertical chord");
+        const Felt xx = felt_mul(p1.x, p1.x);
+        return felt_mul(felt_add(felt_add(felt_add(xx, xx), xx), felt_from_u64(1)), felt_inv(felt_add(p1.y, p1.y)));
+    }
+    return felt_mul(felt_sub(p1.y, p2.y), felt_inv(felt_sub(p1.x, p2.x)));
+}
+Pt ec_mul_small(uint64_t k, const Pt &p) {
+    bool have = false;
+    Pt acc = p, addend = p;
+    for (; k; k >>= 1) {
+        if (k & 1) { acc = have ? ec_add(acc, addend) : addend; have = true; }
+        addend = ec_double(addend);
+    }
+    return acc;
+}
+// Tonelli-Shanks: p - 1 = 2^192 * (2^59 + 17); 3 generates the multiplicative group
+bool felt_sqrt(const Felt &a, Felt &root) {
+    if (felt_is_zero(a)) { root = a; return true; }
+    const uint64_t q = (1ull << 59) + 17;
+    const Felt one = felt_from_u64(1);
+    Felt legendre = felt_pow(a, q);
+    for (int i = 0; i < 191; ++i) legendre = felt_mul(legendre, legendre);
+    if (!felt_eq(legendre, one)) return false;
+    unsigned m = 192;
+    Felt c = felt_pow(felt_from_u64(3), q), t = felt_pow(a, q), r = felt_pow(a, (q + 1) / 2);
+    while (!felt_eq(t, one)) {
+        unsigned i = 0;
+        for (Felt t2 = t; !felt_eq(t2, one); t2 = felt_mul(t2, t2)) ++i;
+        Felt b = c;
+        for (unsigned k = 0; k + i + 1 < m; ++k) b = felt_mul(b, b);
+        m = i; c = felt_mul(b, b); t = felt_mul(t, c); r = felt_mul(r, b);
+    }
+    root = r;
+    return true;
+}
+
+struct Doubling { Pt point; Felt slope; };
+std::vector<Doubling> doubling_steps(Pt p) {              // ecdsa/mod.rs:192-206
+    std::vector<Doubling> out;
+    for (int i = 0; i < 256; ++i) { out.push_back(Doubling{p, slope_of(p, p)}); p = ec_double(p); }
+    return out;
+}
+struct MadStep { Pt partial; Felt suffix, slope, x_diff_inv; };
+// gen_ec_mad_steps (ecdsa/mod.rs:157-190, ec_op/mod.rs:98-130)
+std::vector<MadStep> ec_mad_steps(const U256 &x, Pt point, Pt partial, unsigned max_doublings) {
+    std::vector<MadStep> out;
+    for (unsigned i = 0; i < 256; ++i) {
+        const U256 suffix = shr(x, i);
+        Felt slope = felt_from_u64(0);
+        Pt next = partial;
+        if (suffix[0] & 1) { slope = slope_of(point, partial); next = ec_add(partial, point); }
+        if (felt_eq(partial.x, point.x)) fail("a partial sum meets the fixed point");
+        out.push_back(MadStep{partial, felt_from_canonical(suffix), slope, felt_inv(felt_sub(partial.x, point.x))});
+        partial = next;
+        if (i < max_doublings) point = ec_double(point);
+    }
+    return out;
+}
+// mimic_ec_mad_air (ecdsa/mod.rs:278-301)
+bool mimic_ec_mad(U256 m, Pt point, Pt partial, Pt &out) {
+    const unsigned bits = bit_length(m);
+    if (bits < 1 || bits >= 252) return false;
+    while (!is_zero(m)) {
+        if (felt_eq(partial.x, point.x)) return false;
+        if (m[0] & 1) partial = ec_add(partial, point);
+        point = ec_double(point);
+        m = shr(m, 1);
+    }
+    out = partial;
+    return true;
+}
+
+struct Curve { Pt generator; Felt beta; Pt shift; };
+const Curve &curve() {
+    static const Curve c = [] {
+        Curve v;
+        starknet_curve(v.generator.x, v.generator.y, v.beta);
+        v.shift = pedersen_point(0);
+        return v;
+    }();
+    return c;
+}
+
+struct EcdsaTrace {                                       // ecdsa::InstanceTrace::new (ecdsa/mod.rs:61-140)
+    Pt pubkey, b;
+    Felt message, b_slope, b_x_diff_inv, w_inv, r_inv, message_inv, r_point_slope, r_point_x_diff_inv;
+    std::vector<MadStep> zg_steps, rq_steps, wb_steps;
+    std::vector<Doubling> pubkey_doubling, b_doubling;
+};
+EcdsaTrace ecdsa_trace(const U256 &pubkey_x, const U256 &message, const U256 &r, const U256 &w) {
+    const Curve &cv = curve();
+    const Felt px = felt_from_canonical(pubkey_x);
+    Felt y;
+    if (!felt_sqrt(felt_add(felt_add(felt_mul(felt_mul(px, px), px), px), cv.beta), y)) fail("the public key is not on the curve");
+    const Pt neg_shift = ec_neg(cv.shift);
+    const U256 yc = canonical_of(y), ync = canonical_of(felt_neg(y));
+    const Felt first = less(yc, ync) ? felt_neg(y) : y, second = less(yc, ync) ? y : felt_neg(y);      // the larger root first (verify, ecdsa/mod.rs:250-276)
+    EcdsaTrace t;
+    bool found = false;
+    Pt zg, rq, wb;
+    for (const Felt &cand : {first, second}) {
+        const Pt q{px, cand};
+        if (!mimic_ec_mad(message, cv.generator, neg_shift, zg) || !mimic_ec_mad(r, q, cv.shift, rq)) continue;
+        if (!mimic_ec_mad(w, ec_add(zg, rq), cv.shift, wb)) continue;
+        if (canonical_of(ec_add(wb, neg_shift).x) == r) { t.pubkey = q; found = true; break; }
+    }
+    if (!found) fail("signature is invalid");
+    t.b = ec_add(zg, rq);
+    t.b_slope = slope_of(zg, rq);
+    t.b_x_diff_inv = felt_inv(felt_sub(zg.x, rq.x));
+    t.zg_steps = ec_mad_steps(message, cv.generator, neg_shift, 250);
+    t.rq_steps = ec_mad_steps(r, t.pubkey, cv.shift, 255);
+    t.wb_steps = ec_mad_steps(w, t.b, cv.shift, 255);
+    t.pubkey_doubling = doubling_steps(t.pubkey);
+    t.b_doubling = doubling_steps(t.b);
+    t.message = felt_from_canonical(message);
+    t.w_inv = felt_inv(felt_from_canonical(w)); t.r_inv = felt_inv(felt_from_canonical(r)); t.message_inv = felt_inv(t.message);
+    t.r_point_slope = slope_of(wb, neg_shift);
+    t.r_point_x_diff_inv = felt_inv(felt_sub(wb.x, neg_shift.x));
+    return t;
+}
+// gen_dummy_instance (ecdsa/mod.rs:208-248): private key 1, message pedersen(1, 0), the first nonce that gives r, w < 2^251
+void ecdsa_dummy_instance(U256 &pubkey_x, U256 &message, U256 &r, U256 &w) {
+    const Curve &cv = curve();
+    const Felt one = felt_from_u64(1), zero = felt_from_u64(0);
+    Felt h;
+    if (ss_pedersen_hash_host(one.data(), zero.data(), h.data()) != SS_OK) fail("Pedersen hash failed");
+    message = canonical_of(h);
+    pubkey_x = canonical_of(cv.generator.x);
+    for (uint64_t k = 1;; ++k) {
+        r = canonical_of(ec_mul_small(k, cv.generator).x);
+        if (is_zero(r) || bit_length(r) > 251) continue;
+        const U256 s = addmod_n(message, r);              // message + r * private key
+        if (is_zero(s)) continue;
+        w = mulmod_n(U256{k, 0, 0, 0}, invmod_n(s));
+        if (is_zero(w) || bit_length(w) > 251) continue;
+        return;
+    }
+}
+
+struct PoseidonTrace { std::array<Felt, 3> full[8]; std::vector<Felt> partial; Felt out[3]; };
+Felt cube(const Felt &v) { return felt_mul(felt_mul(v, v), v); }
+PoseidonTrace poseidon_trace(const std::array<Felt, 3> &input) {       // poseidon::InstanceTrace::new (poseidon/mod.rs:45-98)
+    const auto &rk = poseidon_round_keys();
+    PoseidonTrace t;
+    std::array<Felt, 3> st = input;
+    unsigned r = 0, nfull = 0;
+    for (int phase = 0; phase < 3; ++phase)
+        for (int i = 0; i < (phase == 1 ? 83 : 4); ++i, ++r) {
+            for (int j = 0; j < 3; ++j) st[j] = felt_add(st[j], rk[r][j]);
+            if (phase == 1) { t.partial.push_back(st[2]); st[2] = cube(st[2]); }
+            else { t.full[nfull++] = st; for (auto &v : st) v = cube(v); }
+            st = {felt_add(felt_add(felt_add(felt_add(st[0], st[0]), st[0]), st[1]), st[2]), felt_add(felt_sub(st[0], st[1]), st[2]),
+                  felt_sub(felt_add(st[0], st[1]), felt_add(st[2], st[2]))};
+        }
+    for (int j = 0; j < 3; ++j) t.out[j] = st[j];
+    return t;
+}
+
+}  // namespace
+
+std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+                                                   const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv) {
+    const uint64_t num_cycles = states.size();
+    if (!num_cycles || (num_cycles & (num_cycles - 1))) fail("the number of cycles must be a power of two");
+    if (num_cycles < ECDSA_BUILTIN_RATIO) fail("the starknet layout needs at least 2048 cycles");
+    for (int k : {3, 4, 5, 6, 7, 8}) if (!pi.segments[k].present) fail("the starknet layout requires every builtin segment");
+    const uint64_t n = num_cycles * CYCLE_HEIGHT;
+    const Mem mem{memory, present};
+    const Felt zero = felt_from_u64(0);
+    std::vector<std::vector<Felt>> cols(NUM_COLS);
+    for (auto &c : cols) c.resize(n);
+    auto &flags = cols[COL_FLAGS], &npc = cols[COL_NPC], &mem_col = cols[COL_MEMORY], &rc_col = cols[COL_RANGE_CHECK], &aux = cols[COL_AUXILIARY];
+    std::vector<uint64_t> npc_addr(n / 2, 1);
+
+    const MemoryEntry *padding = nullptr;
+    for (auto &e : pi.public_memory) if (e.address == 1) { padding = &e; break; }
+    if (!padding) fail("public memory has no entry at address 1");
+    const Felt pad_value = felt_from_canonical(padding->value), pad_addr = felt_from_u64(1);
+    for (uint64_t k = 0; k < n / 2; ++k) { npc[2 * k] = pad_addr; npc[2 * k + 1] = pad_value; }
+    auto set_pair = [&](uint64_t row, uint64_t address, const Felt &value) { npc[row] = felt_from_u64(address); npc[row + 1] = value; npc_addr[row / 2] = address; };
+
+    // ---- CPU cells (trace.rs:177-244) and the range-check pool (trace.rs:142-165)
+    std::vector<uint32_t> rc_count(1 << 16, 0);
+    for (uint64_t cycle = 0; cycle < num_cycles; ++cycle) {
+        const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
+        const U256 &iw = mem.at(pc);
+        const Word w{iw[0]};
+        if ((iw[1] | iw[2] | iw[3]) || w.flag(F_ZERO)) fail("memory cell " + std::to_string(pc) + " is not an instruction");
+        const uint64_t dst_addr = w.off_dst() + (w.flag(F_DST_REG) ? fp : ap) - HALF_OFFSET;
+        const uint64_t op0_addr = w.off_op0() + (w.flag(F_OP0_REG) ? fp : ap) - HALF_OFFSET;
+        const int src = w.op1_src();
+        if (src != 0 && src != 1 && src != 2 && src != 4) fail("invalid op1 source");
+        const uint64_t base = src == 0 ? mem.small(op0_addr) : src == 1 ? pc : src == 2 ? fp : ap;
+        const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
+        const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
+        Felt res;
+        if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : felt_inv(dst);
+        else if (w.res_logic() == 0) res = op1;
+        else if (w.res_logic() == 1) res = felt_add(op0, op1);
+        else if (w.res_logic() == 2) res = felt_mul(op0, op1);
+        else fail("invalid res logic");
+        const Felt tmp0 = w.flag(F_PC_JNZ) ? dst : zero;
+        for (int f = 0; f < 16; ++f) flags[r + f] = felt_from_u64(w.flag_prefix(f));
+        set_pair(r + NPC_PC, pc, felt_from_canonical(iw));
+        set_pair(r + NPC_MEM_OP0_ADDR, op0_addr, op0);
+        set_pair(r + NPC_MEM_DST_ADDR, dst_addr, dst);
+        set_pair(r + NPC_MEM_OP1_ADDR, op1_addr, op1);
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += PUBLIC_MEMORY_STEP) set_pair(r + o + NPC_PUB_MEM_ADDR, 0, zero);
+        aux[r + AUX_TMP0] = tmp0; aux[r + AUX_TMP1] = felt_mul(tmp0, res);
+        aux[r + AUX_AP] = felt_from_u64(ap); aux[r + AUX_FP] = felt_from_u64(fp);
+        aux[r + AUX_OP0_MUL_OP1] = felt_mul(op0, op1); aux[r + AUX_RES] = res;
+        for (uint64_t v : {w.off_dst(), w.off_op0(), w.off_op1()}) ++rc_count[v];
+    }
+    struct Rc128 { uint32_t index; U256 value; };
+    std::vector<Rc128> rc128;
+    auto part_of = [](const U256 &v, unsigned k) { return (uint32_t)(shr(v, 16 * (RANGE_CHECK_BUILTIN_PARTS - 1 - k))[0] & 0xffff); };
+    for (auto &inst : priv.range_check) {
+        if (inst.value[2] | inst.value[3]) fail("range-check value does not fit 128 bits");
+        rc128.push_back(Rc128{inst.index, inst.value});
+        for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) ++rc_count[part_of(inst.value, k)];
+    }
+    uint32_t rc_lo = 0xffff, rc_hi = 0;
+    for (uint32_t v = 0; v < (1u << 16); ++v) if (rc_count[v]) { rc_lo = std::min(rc_lo, v); rc_hi = std::max(rc_hi, v); }
+    std::vector<uint32_t> padding_vals, ordered_vals;
+    for (uint32_t v = rc_lo; v <= rc_hi; ++v) {
+        if (!rc_count[v]) padding_vals.push_back(v);
+        for (uint32_t c = 0; c < std::max(rc_count[v], 1u); ++c) ordered_vals.push_back(v);
+    }
+    // the column starts as the padding value; the CPU's offsets go in afterwards (trace.rs:165-235)
+    const Felt rc_max_f = felt_from_u64(rc_hi);
+    for (uint64_t k = 0; k < n; ++k) rc_col[k] = rc_max_f;
+    for (uint64_t cycle = 0; cycle < num_cycles; ++cycle) {
+        const Word w{mem.at(states[cycle].pc)[0]};
+        const uint64_t r = cycle * CYCLE_HEIGHT;
+        rc_col[r + RC_OFF_DST] = felt_from_u64(w.off_dst()); rc_col[r + RC_OFF_OP1] = felt_from_u64(w.off_op1()); rc_col[r + RC_OFF_OP0] = felt_from_u64(w.off_op0());
+    }
+    size_t pad_i = 0, ord_i = 0;
+    auto next_padding = [&]() { return pad_i < padding_vals.size() ? padding_vals[pad_i++] : rc_hi; };
+    for (uint64_t index = rc128.size(); index < num_cycles / RANGE_CHECK_BUILTIN_RATIO; ++index) {       // trace.rs:246-261
+        U256 value{};
+        for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) {
+            value[3] = (value[3] << 16) | (value[2] >> 48); value[2] = (value[2] << 16) | (value[1] >> 48);
+            value[1] = (value[1] << 16) | (value[0] >> 48); value[0] = (value[0] << 16) | next_padding();
+        }
+        rc128.push_back(Rc128{(uint32_t)index, value});
+    }
+    for (uint64_t cycle = 0; cycle < num_cycles; ++cycle) {
+        const uint64_t r = cycle * CYCLE_HEIGHT;
+        if (cycle % 2 == 1) rc_col[r + RC_UNUSED] = felt_from_u64(next_padding());
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP)
+            rc_col[r + o + RC_ORDERED] = felt_from_u64(ord_i < ordered_vals.size() ? ordered_vals[ord_i++] : rc_hi);
+    }
+    if (pad_i != padding_vals.size() || ord_i != ordered_vals.size()) fail("range-check values do not fit the trace");
+    for (uint64_t k = 0; k < n / DILUTED_CHECK_STEP; ++k) rc_col[8 * k + DC_UNORDERED] = rc_col[8 * k + DC_ORDERED] = zero;      // trace.rs:294-302
+
+    // ---- Pedersen (trace.rs:304-386)
+    {
+        std::map<uint32_t, const PedersenInstance *> given;
+        for (auto &p : priv.pedersen) given[p.index] = &p;
+        struct Cached { std::vector<Step> steps; Felt out; };
+        std::map<std::pair<U256, U256>, Cached> cache;
+        const uint64_t step = PEDERSEN_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[3].begin_addr;
+        const Pt p0 = pedersen_point(0);
+        auto &xs = cols[COL_PEDERSEN_X], &ys = cols[COL_PEDERSEN_Y], &suffixes = cols[COL_PEDERSEN_SUFFIX], &slopes = cols[COL_PEDERSEN_SLOPE];
+        for (uint64_t i = 0; i < n / step; ++i) {
+            U256 a{}, b{};
+            auto it = given.find((uint32_t)i);
+            if (it != given.end()) { a = it->second->a; b = it->second->b; }
+            auto key = std::make_pair(a, b);
+            auto cit = cache.find(key);
+            if (cit == cache.end()) {
+                Cached c;
+                const Pt mid = element_steps(a, p0, 0, c.steps);
+                element_steps(b, mid, 1, c.steps);
+                c.out = c.steps.back().point.x;
+                Felt want;
+                const Felt fa = felt_from_canonical(a), fb = felt_from_canonical(b);
+                if (ss_pedersen_hash_host(fa.data(), fb.data(), want.data()) != SS_OK || !felt_eq(want, c.out)) fail("Pedersen partial sums do not end at the hash");
+                cit = cache.emplace(key, std::move(c)).first;
+            }
+            const Cached &c = cit->second;
+            const uint64_t base = i * step, addr = begin + 3 * i;
+            for (uint64_t j = 0; j < 512; ++j) {
+                xs[base + j] = c.steps[j].point.x; ys[base + j] = c.steps[j].point.y;
+                suffixes[base + j] = c.steps[j].suffix; slopes[base + j] = c.steps[j].slope;
+            }
+            const U256 *in[2] = {&a, &b};
+            for (int half = 0; half < 2; ++half) {
+                const bool b251 = bit(*in[half], 251), b196 = bit(*in[half], 196), b192 = bit(*in[half], 192);
+                slopes[base + 256 * half + 255] = felt_from_u64(b251 && b196);
+                aux[base + 256 * half + 71] = felt_from_u64(b251 && b196 && b192);
+            }
+            set_pair(base + NPC_PEDERSEN_INPUT0_ADDR, addr, felt_from_canonical(a));
+            set_pair(base + NPC_PEDERSEN_INPUT1_ADDR, addr + 1, felt_from_canonical(b));
+            set_pair(base + NPC_PEDERSEN_OUTPUT_ADDR, addr + 2, c.out);
+        }
+    }
+    // ---- range-check builtin (trace.rs:388-426)
+    {
+        const uint64_t step = RANGE_CHECK_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[4].begin_addr;
+        for (size_t blk = 0; blk < rc128.size(); ++blk) {
+            const uint64_t base = blk * step;
+            for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) rc_col[base + 32 * k + RC16_COMPONENT] = felt_from_u64(part_of(rc128[blk].value, k));
+            set_pair(base + NPC_RANGE_CHECK128_ADDR, begin + rc128[blk].index, felt_from_canonical(rc128[blk].value));
+        }
+    }
+    // ---- ECDSA (trace.rs:428-523)
+    {
+        std::map<uint32_t, const EcdsaInstance *> given;
+        for (auto &p : priv.ecdsa) given[p.index] = &p;
+        std::map<std::tuple<U256, U256, U256, U256>, EcdsaTrace> cache;
+        const uint64_t step = ECDSA_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[5].begin_addr;
+        U256 dummy[4];
+        bool have_dummy = false;
+        for (uint64_t i = 0; i < n / step; ++i) {
+            U256 in[4];
+            auto it = given.find((uint32_t)i);
+            if (it != given.end()) { in[0] = it->second->pubkey_x; in[1] = it->second->message; in[2] = it->second->r; in[3] = it->second->w; }
+            else {
+                if (!have_dummy) { ecdsa_dummy_instance(dummy[0], dummy[1], dummy[2], dummy[3]); have_dummy = true; }
+                for (int k = 0; k < 4; ++k) in[k] = dummy[k];
+            }
+            auto key = std::make_tuple(in[0], in[1], in[2], in[3]);
+            auto cit = cache.find(key);
+            if (cit == cache.end()) cit = cache.emplace(key, ecdsa_trace(in[0], in[1], in[2], in[3])).first;
+            const EcdsaTrace &t = cit->second;
+            const uint64_t base = i * step;
+            for (int half = 0; half < 2; ++half) {
+                const std::vector<MadStep> &mad = half ? t.wb_steps : t.rq_steps;
+                const std::vector<Doubling> &dbl = half ? t.b_doubling : t.pubkey_doubling;
+                for (uint64_t j = 0; j < 256; ++j) {
+                    const uint64_t r = base + 64 * (256 * half + j);
+                    aux[r + EC_PUBKEY_DOUBLING_X] = dbl[j].point.x; aux[r + EC_PUBKEY_DOUBLING_Y] = dbl[j].point.y; aux[r + EC_PUBKEY_DOUBLING_SLOPE] = dbl[j].slope;
+                    aux[r + EC_PUBKEY_PARTIAL_SUM_X] = mad[j].partial.x; aux[r + EC_PUBKEY_PARTIAL_SUM_Y] = mad[j].partial.y;
+                    aux[r + EC_PUBKEY_PARTIAL_SUM_SLOPE] = mad[j].slope; aux[r + EC_PUBKEY_PARTIAL_SUM_X_DIFF_INV] = mad[j].x_diff_inv; aux[r + EC_R_SUFFIX] = mad[j].suffix;
+                }
+            }
+            for (uint64_t j = 0; j < 256; ++j) {
+                const uint64_t r = base + 128 * j;
+                const MadStep &s = t.zg_steps[j];
+                aux[r + EC_GENERATOR_PARTIAL_SUM_X] = s.partial.x; aux[r + EC_GENERATOR_PARTIAL_SUM_Y] = s.partial.y;
+                aux[r + EC_GENERATOR_PARTIAL_SUM_SLOPE] = s.slope; aux[r + EC_GENERATOR_PARTIAL_SUM_X_DIFF_INV] = s.x_diff_inv; aux[r + EC_MESSAGE_SUFFIX] = s.suffix;
+            }
+            aux[base + EC_B_SLOPE] = t.b_slope; aux[base + EC_B_X_DIFF_INV] = t.b_x_diff_inv; aux[base + EC_W_INV] = t.w_inv; aux[base + EC_R_INV] = t.r_inv;
+            aux[base + EC_R_POINT_SLOPE] = t.r_point_slope; aux[base + EC_R_POINT_X_DIFF_INV] = t.r_point_x_diff_inv; aux[base + EC_MESSAGE_INV] = t.message_inv;
+            aux[base + EC_PUBKEY_X_SQUARED] = felt_mul(t.pubkey.x, t.pubkey.x);
+            set_pair(base + NPC_ECDSA_PUBKEY_ADDR, begin + 2 * i, t.pubkey.x);
+            set_pair(base + NPC_ECDSA_MESSAGE_ADDR, begin + 2 * i + 1, t.message);
+        }
+    }
+    // ---- bitwise and the diluted check (trace.rs:525-705)
+    {
+        std::map<uint32_t, const BitwiseInstance *> given;
+        for (auto &p : priv.bitwise) given[p.index] = &p;
+        const uint64_t step = BITWISE_RATIO * CYCLE_HEIGHT, begin = pi.segments[6].begin_addr;
+        std::vector<uint32_t> dil_count(1u << DILUTED_N_BITS, 0);
+        for (uint64_t i = 0; i < n / step; ++i) {
+            U256 x{}, y{};
+            auto it = given.find((uint32_t)i);
+            if (it != given.end()) { x = it->second->x; y = it->second->y; }
+            U256 vand, vxor, vor;
+            for (int k = 0; k < 4; ++k) { vand[k] = x[k] & y[k]; vxor[k] = x[k] ^ y[k]; vor[k] = x[k] | y[k]; }
+            const uint64_t base = i * step, addr = begin + 5 * i;
+            const U256 *vals[4] = {&x, &y, &vand, &vxor};
+            uint64_t parts[4][4][4];
+            for (int p = 0; p < 4; ++p) for (int c = 0; c < 4; ++c) partition64((*vals[p])[c], parts[p][c]);
+            for (unsigned k = 0; k < 4; ++k) {
+                const uint64_t v = parts[2][3][k] + parts[3][3][k];
+                const unsigned sh = k == 3 ? 8 : 4;
+                if (((v << sh) >> sh) != v) fail("bitwise instance " + std::to_string(i) + ": top segment does not fit");
+                rc_col[base + BITWISE_SHIFTED_CELLS[k]] = felt_from_u64(v << sh);
+                ++dil_count[undilute(v << sh)];
+            }
+            for (int p = 0; p < 4; ++p)
+                for (int c = 0; c < 4; ++c)
+                    for (int s = 0; s < 4; ++s) {
+                        rc_col[base + 256 * p + 16 * (4 * c + s) + 1] = felt_from_u64(parts[p][c][s]);
+                        ++dil_count[undilute(parts[p][c][s])];
+                    }
+            for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + 256 * k, addr + k, felt_from_canonical(*vals[k]));
+            set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, felt_from_canonical(vor));
+        }
+        std::vector<uint32_t> padding_d;
+        uint64_t total = 0;
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) { if (!dil_count[v]) padding_d.push_back(v); total += std::max(dil_count[v], 1u); }
+        size_t pi_d = 0;
+        for (uint64_t blk = 0; blk < n / 1024 && pi_d < padding_d.size(); ++blk)               // the free cells 8 i + 1, i odd (trace.rs:668-693)
+            for (uint64_t i = 1; i < 1024 / DILUTED_CHECK_STEP && pi_d < padding_d.size(); i += 2) {
+                const uint64_t off = 8 * i + DC_UNORDERED;
+                if (std::find(std::begin(BITWISE_SHIFTED_CELLS), std::end(BITWISE_SHIFTED_CELLS), off) != std::end(BITWISE_SHIFTED_CELLS)) continue;
+                rc_col[blk * 1024 + off] = felt_from_u64(dilute(padding_d[pi_d++]));
+            }
+        const uint64_t slots = n / DILUTED_CHECK_STEP;
+        if (pi_d != padding_d.size() || total > slots) fail("diluted-check values do not fit the trace");
+        uint64_t k = slots - total;
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)
+            for (uint32_t c = 0; c < std::max(dil_count[v], 1u); ++c, ++k) rc_col[8 * k + DC_ORDERED] = felt_from_u64(dilute(v));
+    }
+    // ---- EC op (trace.rs:707-777)
+    {
+        std::map<uint32_t, const EcOpInstance *> given;
+        for (auto &p : priv.ec_op) given[p.index] = &p;
+        const Curve &cv = curve();
+        struct Trace { Pt p, q, r; Felt m; std::vector<Doubling> q_doubling; std::vector<MadStep> r_steps; bool b251_196, b251_196_192; };
+        std::map<std::tuple<U256, U256, U256, U256, U256>, Trace> cache;
+        const uint64_t step = EC_OP_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[7].begin_addr;
+        for (uint64_t i = 0; i < n / step; ++i) {
+            U256 in[5];
+            auto it = given.find((uint32_t)i);
+            if (it != given.end()) { in[0] = it->second->p_x; in[1] = it->second->p_y; in[2] = it->second->q_x; in[3] = it->second->q_y; in[4] = it->second->m; }
+            else {                                                   // gen_dummy_instance (ec_op/mod.rs:84-96): P0 + 1 * G
+                in[0] = canonical_of(cv.shift.x); in[1] = canonical_of(cv.shift.y); in[2] = canonical_of(cv.generator.x); in[3] = canonical_of(cv.generator.y);
+                in[4] = U256{1, 0, 0, 0};
+            }
+            auto key = std::make_tuple(in[0], in[1], in[2], in[3], in[4]);
+            auto cit = cache.find(key);
+            if (cit == cache.end()) {
+                Trace t;
+                t.p = Pt{felt_from_canonical(in[0]), felt_from_canonical(in[1])}; t.q = Pt{felt_from_canonical(in[2]), felt_from_canonical(in[3])};
+                t.m = felt_from_canonical(in[4]);
+                t.q_doubling = doubling_steps(t.q);
+                t.r_steps = ec_mad_steps(in[4], t.q, t.p, 255);
+                t.r = t.r_steps.back().partial;
+                t.b251_196 = bit(in[4], 251) && bit(in[4], 196); t.b251_196_192 = t.b251_196 && bit(in[4], 192);
+                cit = cache.emplace(key, std::move(t)).first;
+            }
+            const Trace &t = cit->second;
+            const uint64_t base = i * step, addr = begin + 7 * i;
+            for (uint64_t j = 0; j < 256; ++j) {
+                const uint64_t r = base + 64 * j;
+                aux[r + OP_Q_DOUBLING_X] = t.q_doubling[j].point.x; aux[r + OP_Q_DOUBLING_Y] = t.q_doubling[j].point.y; aux[r + OP_Q_DOUBLING_SLOPE] = t.q_doubling[j].slope;
+                aux[r + OP_R_PARTIAL_SUM_X] = t.r_steps[j].partial.x; aux[r + OP_R_PARTIAL_SUM_Y] = t.r_steps[j].partial.y; aux[r + OP_M_SUFFIX] = t.r_steps[j].suffix;
+                if (j != 255) { aux[r + OP_R_PARTIAL_SUM_SLOPE] = t.r_steps[j].slope; aux[r + OP_R_PARTIAL_SUM_X_DIFF_INV] = t.r_steps[j].x_diff_inv; }   // the ECDSA builtin owns the last ones
+            }
+            aux[base + OP_M_BIT251_AND_BIT196] = felt_from_u64(t.b251_196); aux[base + OP_M_BIT251_AND_BIT196_AND_BIT192] = felt_from_u64(t.b251_196_192);
+            const Felt values[7] = {t.p.x, t.p.y, t.q.x, t.q.y, t.m, t.r.x, t.r.y};
+            for (int k = 0; k < 7; ++k) set_pair(base + NPC_EC_OP_ADDRS[k], addr + k, values[k]);
+        }
+    }
+    // ---- Poseidon (trace.rs:779-888)
+    {
+        std::map<uint32_t, const PoseidonInstance *> given;
+        for (auto &p : priv.poseidon) given[p.index] = &p;
+        std::map<std::tuple<U256, U256, U256>, PoseidonTrace> cache;
+        const uint64_t step = POSEIDON_RATIO * CYCLE_HEIGHT, begin = pi.segments[8].begin_addr;
+        const uint64_t FULL[3][2] = {{53, 29}, {13, 61}, {45, 3}};
+        for (uint64_t i = 0; i < n / step; ++i) {
+            U256 in[3] = {U256{}, U256{}, U256{}};
+            auto it = given.find((uint32_t)i);
+            if (it != given.end()) for (int k = 0; k < 3; ++k) in[k] = it->second->input[k];
+            auto key = std::make_tuple(in[0], in[1], in[2]);
+            auto cit = cache.find(key);
+            const std::array<Felt, 3> input{felt_from_canonical(in[0]), felt_from_canonical(in[1]), felt_from_canonical(in[2])};
+            if (cit == cache.end()) cit = cache.emplace(key, poseidon_trace(input)).first;
+            const PoseidonTrace &t = cit->second;
+            const uint64_t base = i * step, addr = begin + 6 * i;
+            for (uint64_t rnd = 0; rnd < 8; ++rnd)
+                for (int j = 0; j < 3; ++j) {
+                    aux[base + 64 * rnd + FULL[j][0]] = t.full[rnd][j];
+                    aux[base + 64 * rnd + FULL[j][1]] = felt_mul(t.full[rnd][j], t.full[rnd][j]);
+                }
+            for (uint64_t k = 0; k < 64; ++k) { rc_col[base + 8 * k + 3] = t.partial[k]; rc_col[base + 8 * k + 7] = felt_mul(t.partial[k], t.partial[k]); }
+            for (uint64_t k = 0; k + 61 < t.partial.size(); ++k) { aux[base + 16 * k + 6] = t.partial[61 + k]; aux[base + 16 * k + 14] = felt_mul(t.partial[61 + k], t.partial[61 + k]); }
+            for (int k = 0; k < 3; ++k) { set_pair(base + NPC_POSEIDON_ADDRS[k], addr + k, input[k]); set_pair(base + NPC_POSEIDON_ADDRS[3 + k], addr + 3 + k, t.out[k]); }
+        }
+    }
+    // ---- gap fillers (trace.rs:890-925)
+    {
+        std::vector<uint64_t> accessed(npc_addr);
+        for (auto &e : pi.public_memory) accessed.push_back(e.address);
+        std::sort(accessed.begin(), accessed.end());
+        accessed.erase(std::unique(accessed.begin(), accessed.end()), accessed.end());
+        uint64_t cycle = 0;
+        for (size_t k = 0; k + 1 < accessed.size(); ++k)
+            for (uint64_t a = accessed[k] + 1; a < accessed[k + 1]; ++a) {
+                if (cycle >= num_cycles) fail("more memory gaps than cycles to hold them");
+                set_pair(cycle * CYCLE_HEIGHT + NPC_UNUSED_ADDR, a, zero);
+                ++cycle;
+            }
+    }
+    // ---- sorted memory (get_ordered_memory_accesses, utils.rs:112-152)
+    {
+        struct Access { uint64_t address; Felt value; };
+        std::vector<Access> acc;
+        acc.reserve(n / 2 + n / PUBLIC_MEMORY_STEP);
+        for (uint64_t k = 0; k < n / 2; ++k) acc.push_back(Access{npc_addr[k], npc[2 * k + 1]});
+        const uint64_t cells = n / PUBLIC_MEMORY_STEP;
+        if (pi.public_memory.size() > cells) fail("public memory does not fit");
+        for (uint64_t k = pi.public_memory.size(); k < cells; ++k) acc.push_back(Access{1, pad_value});
+        for (auto &e : pi.public_memory) acc.push_back(Access{e.address, felt_from_canonical(e.value)});
+        std::stable_sort(acc.begin(), acc.end(), [](const Access &a, const Access &b) { return a.address < b.address; });
+        for (uint64_t k = 0; k < cells; ++k) if (acc[k].address != 0) fail("the public-memory cells of the pool must be the only accesses of address 0");
+        if (acc[cells].address != 1) fail("memory must start at address 1");
+        for (uint64_t k = cells; k + 1 < acc.size(); ++k)
+            if (!((acc[k].address == acc[k + 1].address && felt_eq(acc[k].value, acc[k + 1].value)) || acc[k].address + 1 == acc[k + 1].address))
+                fail("memory is not continuous and single-valued at address " + std::to_string(acc[k].address));
+        for (uint64_t k = 0; k < n / 2; ++k) { mem_col[2 * k] = felt_from_u64(acc[cells + k].address); mem_col[2 * k + 1] = acc[cells + k].value; }
+    }
+    return cols;
+}
+
+}  // namespace ssh

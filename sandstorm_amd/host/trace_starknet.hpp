@@ -1,0 +1,30 @@
+// trace_starknet.hpp — base-trace generation of the `starknet` layout on the host: ExecutionTrace::new
+// (layouts/src/starknet/trace.rs:98-987) with the instance traces of its six builtins
+// (builtins/src/{pedersen,range_check,ecdsa,bitwise,ec_op,poseidon}/mod.rs) and the pools of layouts/src/utils.rs.
+// Mirror: sandstorm_amd/layouts/starknet.py::base_trace, which is pinned to the reference's own proof of its bootloader
+// run; tests/test_layout_starknet.py compares the two cell for cell on that run.
+#pragma once
+#include "trace_recursive.hpp"
+
+namespace ssh {
+
+struct EcdsaInstance { uint32_t index; U256 pubkey_x, message, r, w; };
+struct EcOpInstance { uint32_t index; U256 p_x, p_y, q_x, q_y, m; };
+struct PoseidonInstance { uint32_t index; U256 input[3]; };
+struct StarknetPrivateInput : PrivateInput {
+    std::vector<EcdsaInstance> ecdsa;
+    std::vector<EcOpInstance> ec_op;
+    std::vector<PoseidonInstance> poseidon;
+};
+
+// -> the 9 base columns (Montgomery felts): flags | Pedersen partial sum x | y | suffix | slope | memory pool | sorted memory |
+// range check / diluted check / bitwise / Poseidon partial rounds | auxiliary / ECDSA / EC op / Poseidon full rounds
+std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+                                                   const std::vector<uint8_t> &present, const AirPublicInput &pi,
+                                                   const StarknetPrivateInput &priv);
+
+// shared with the AIR (air_starknet.cpp): StarkWare's Hades round constants, the curve's generator and beta
+const std::vector<std::array<Felt, 3>> &poseidon_round_keys();
+void starknet_curve(Felt &generator_x, Felt &generator_y, Felt &beta);
+
+}  // namespace ssh

@@ -335,6 +335,29 @@ def recursive_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=
     return cols
 
 
+def starknet_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=None):
+    """the C++ host's ExecutionTrace::new for the starknet layout (sandstorm_amd/host/trace_starknet.cpp) -> 9 columns
+    [16 * cycles, 4] of Montgomery limbs.  private_input: as layouts.starknet.base_trace takes it"""
+    private_input = private_input or {}
+    if len(trace_bin) % 24:
+        raise _lib.SandstormHipError("host: trace file is not a sequence of (ap, fp, pc) u64 triples")
+    n = 16 * (len(trace_bin) // 24)
+    segs, addrs, vals = _public_input_args(pi)
+    names = (("pedersen", 9), ("range_check", 5), ("ecdsa", 17), ("bitwise", 9), ("ec_op", 21), ("poseidon", 13))
+    arrays = [_instances(private_input.get(name, []), width) for name, width in names]
+    counts = np.array([len(private_input.get(name, [])) for name, _ in names], dtype=np.uint64)
+    inst = (C.c_void_p * 6)(*[a.ctypes.data for a in arrays])
+    cols = [np.zeros((n, 4), dtype=np.uint64) for _ in range(9)]
+    ptrs = (C.c_void_p * 9)(*[c.ctypes.data for c in cols])
+    u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    fn = load().ssh_starknet_base_trace
+    fn.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, u32p, u32p, u64p, C.c_uint64,
+                   C.POINTER(C.c_void_p), u64p, C.POINTER(C.c_void_p)]
+    _check(fn(trace_bin, len(trace_bin), memory_bin, len(memory_bin), pi.rc_min, pi.rc_max, pi.n_steps, segs.ctypes.data_as(u32p),
+              addrs.ctypes.data_as(u32p), vals.ctypes.data_as(u64p), len(addrs), inst, counts.ctypes.data_as(u64p), ptrs))
+    return cols
+
+
 def verify(air: HostAir, tree_kind, coin_kind, seed, proof: bytes, shipped_conventions=True):
     """the C++ host's verifier (sandstorm_amd/host/verifier.cpp) on a proof in the reference's wire format; raises
     SandstormHipError naming the failed check, returns the query positions"""

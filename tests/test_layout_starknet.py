@@ -378,3 +378,33 @@ def test_base_trace_is_the_one_the_references_proof_opens(oracle, golden):
     lde = oracle.lde(oracle.to_mont(col), 1, offset)[0]
     got = [int(v) for v in oracle.from_mont(lde[g["positions"]])]
     assert sum(a == int(row[sk.COL_AUXILIARY], 16) for a, row in zip(got, g["rows"])) == 0
+
+
+def test_cpp_base_trace_equals_the_python_one(oracle):
+    """sandstorm_amd/host/trace_starknet.cpp against layouts/starknet.py::base_trace, cell for cell, on the reference's
+    bootloader run with real instances of every builtin added (the other slots hold the dummies of the trace the
+    reference's proof opens)"""
+    import numpy as np
+    from sandstorm_amd import hostlib
+    from sandstorm_amd.layouts import starknet as sk
+    g = os.path.join(ROOT, "tests", "golden")
+    with gzip.open(os.path.join(g, "bootloader", "trace.bin.gz")) as f:
+        trace_bin = f.read()
+    with gzip.open(os.path.join(g, "bootloader", "memory.bin.gz")) as f:
+        memory_bin = f.read()
+    states, memory, pi, private = bootloader_run()
+    extra = real_instances()
+    both = {"pedersen": private["pedersen"] + extra["pedersen"], **{k: v for k, v in extra.items() if k != "pedersen"}}
+    for priv in (both,):
+        want = sk.base_trace(states, memory, pi, priv)
+        got = hostlib.starknet_base_trace(trace_bin, memory_bin, pi, priv)
+        assert len(got) == len(want) == 9
+        for c, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(a, oracle.to_mont(b)), "column %d" % c
+    from sandstorm_amd._lib import SandstormHipError
+    with pytest.raises(SandstormHipError, match="signature is invalid"):
+        bad = dict(both)
+        bad["ecdsa"] = [(1,) + tuple(both["ecdsa"][0][1:4]) + (both["ecdsa"][0][4] + 1,)]
+        hostlib.starknet_base_trace(trace_bin, memory_bin, pi, bad)
+    with pytest.raises(SandstormHipError, match="at least 2048"):
+        hostlib.starknet_base_trace(trace_bin[:24 * 1024], memory_bin, pi)
