@@ -49,6 +49,12 @@ class Conventions:
     bitrev_commit: bool = True          # M3: index i of a committed vector is the point offset * w^bitrev(i)
     fri_unnormalised: bool = True       # M8: fold = 8 * interpolant(alpha) (no 1/2 per halving)
     remainder_unshifted: bool = True    # M9: remainder = interpolant of the folded last layer over the unshifted domain
+    # M8, second half, pinned by replaying the whole transcript of the reference's `example/array-sum.proof.saved`
+    # (tests/test_verifier.py::test_reference_starknet_proof_verifies): the challenge a layer is folded with is the
+    # coin's draw TIMES that layer's domain offset (lde_offset^(fold^layer)) - the reference folds over the unshifted
+    # domain.  The verifier honours the flag; the provers (this file, host/prover.cpp) still fold with the bare draw and
+    # the committed proof fixtures are theirs, so the default stays False until both are switched on a GPU (round 2).
+    fri_alpha_times_offset: bool = False
 
 
 def bitrev(x: int, bits: int) -> int:

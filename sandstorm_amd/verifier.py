@@ -157,9 +157,10 @@ def _verify(proof, air, tree_kind, coin_kind, coin_seed, conv):
     _require(len(w.fri_layers) == nlayers, "number of FRI layers")
     _require(len(w.remainder) == max(1, degree_bound), "remainder length")
     fri_alphas = []
-    for layer in w.fri_layers:
+    for li, layer in enumerate(w.fri_layers):
         coin.reseed_with_digest(layer.root)
-        fri_alphas.append(wire._canon(coin.draw()))
+        scale = pow(conv.lde_offset, fold ** li, P) if conv.fri_alpha_times_offset else 1
+        fri_alphas.append(wire._canon(coin.draw()) * scale % P)
     coin.reseed_with_field_element_vector([be.felt(v) for v in w.remainder])
     _require(_verify_pow(coin_kind, coin.digest, grinding, w.pow_nonce), "proof of work")
     coin.reseed_with_int(w.pow_nonce)

@@ -408,3 +408,60 @@ def test_cpp_base_trace_equals_the_python_one(oracle):
         hostlib.starknet_base_trace(trace_bin, memory_bin, pi, bad)
     with pytest.raises(SandstormHipError, match="at least 2048"):
         hostlib.starknet_base_trace(trace_bin[:24 * 1024], memory_bin, pi)
+
+
+def test_references_own_starknet_proof_verifies(golden):
+    """`example/array-sum.proof.saved` (committed as tests/golden/reference_array_sum_starknet.proof) is the reference's own
+    proof of its array-sum example under the starknet layout (EthVerifierClaim: masked Keccak trees, Solidity coin), 2^17
+    steps.  This repo's verifier accepts it from nothing but the public input: the seed (public_input.py), the whole
+    Fiat-Shamir transcript in order (M10) down to the proof of work and the 16 query positions, the out-of-domain
+    identity of the restated 195-constraint AIR under the replayed challenges, every Merkle opening, the DEEP value of
+    every query, the six FRI layers and the remainder.  The public input is the array-sum run re-declared for the
+    layout (starknet_example) - the run's trace is also the one the proof opens."""
+    from sandstorm_amd import backend as be, public_input, verifier
+    from sandstorm_amd.layouts import starknet as sk
+    from sandstorm_amd.prover import Conventions
+    with open(os.path.join(ROOT, "tests", "golden", "reference_array_sum_starknet.proof"), "rb") as f:
+        raw = f.read()
+    _, _, spi = starknet_example(17)
+    seed = public_input.public_coin_seed(spi, be.COIN_SOLIDITY)
+    conv = Conventions(fri_alpha_times_offset=True)
+    args = (sk.verifier_air(spi), be.TREE_KECCAK_M20, be.COIN_SOLIDITY)
+    positions = verifier.verify(raw, *args, seed, conv)
+    assert len(positions) == 16 and positions == sorted(positions)
+    assert positions[:4] == golden("saved_proof_openings.json")["positions"][:4]        # the positions the openings golden was cut at
+    # what the acceptance rests on
+    with pytest.raises(verifier.VerificationError, match="proof of work"):
+        verifier.verify(raw, *args, bytes(32), conv)                                       # another seed: another statement
+    with pytest.raises(verifier.VerificationError, match="does not fold"):
+        verifier.verify(raw, *args, seed)                                                  # the bare draw as FRI challenge
+    import copy
+    other = copy.deepcopy(spi)
+    other.rc_max += 1
+    with pytest.raises(verifier.VerificationError, match="proof of work"):
+        verifier.verify(raw, sk.verifier_air(other), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, public_input.public_coin_seed(other, be.COIN_SOLIDITY), conv)
+    with pytest.raises(verifier.VerificationError, match="out-of-domain identity"):       # same seed, one hint of the AIR off by one
+        verifier.verify(raw, sk.verifier_air(other), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, conv)
+    bad = bytearray(raw)
+    bad[len(raw) - 40] ^= 1                                                                # inside the out-of-domain vector
+    with pytest.raises(verifier.VerificationError):
+        verifier.verify(bytes(bad), *args, seed, conv)
+
+
+def test_array_sum_trace_is_the_one_the_references_proof_opens(oracle, golden):
+    """the 16 base-trace rows that proof opens are rows of the LDE of the trace regenerated from example/trace.bin /
+    memory.bin re-declared for the starknet layout (starknet_example): all dummy builtin instances, no Pedersen"""
+    from sandstorm_amd import wire
+    from sandstorm_amd.layouts import starknet as sk
+    from sandstorm_amd.prover import bitrev
+    with open(os.path.join(ROOT, "tests", "golden", "reference_array_sum_starknet.proof"), "rb") as f:
+        w = wire.parse(f.read())
+    positions = golden("saved_proof_openings.json")["positions"]
+    states, memory, spi = starknet_example(17)
+    cols = sk.base_trace(states, memory, spi)
+    offset = oracle.to_mont([3])[0]
+    natural = [bitrev(p, 22) for p in positions]                       # committed index -> exponent of w (M3)
+    for c in (0, 5, 6, 7, 8):                                           # flags, memory pool, sorted memory, range check, auxiliary
+        lde = oracle.lde(oracle.to_mont(cols[c]), 1, offset)[0]
+        got = [int(v) for v in oracle.from_mont(lde[natural])]
+        assert got == [int(w.base_rows[9 * q + c]) for q in range(len(positions))], "column %d" % c
