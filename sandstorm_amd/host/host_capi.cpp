@@ -267,6 +267,7 @@ int ssh_verify(ssh_air *air_h, int tree_kind, int coin_kind, const uint8_t seed[
         memcpy(sd.data(), seed, 32);
         Conventions conv;
         if (!conventions) { conv.bitrev_commit = false; conv.fri_unnormalised = false; conv.remainder_unshifted = false; }
+        conv.fri_alpha_times_offset = conventions == 2;       // 2: the shipped conventions plus the reference's FRI challenge scaling
         const WireProof w = parse_wire(proof, proof_len);
         const std::vector<uint64_t> pos = verify(w, *air, tree_kind, coin_kind, sd, conv);
         if (positions_out && n_positions) { memcpy(positions_out, pos.data(), pos.size() * 8); *n_positions = (uint32_t)pos.size(); }

@@ -32,6 +32,9 @@ struct Conventions {                    // ministark-internal, SURVEY.md Appendi
     bool bitrev_commit = true;          // M3: index i of a committed vector is the point offset * w^bitrev(i)
     bool fri_unnormalised = true;       // M8: fold = 8 * interpolant(alpha)
     bool remainder_unshifted = true;    // M9: remainder interpolates the folded last layer over the unshifted domain
+    // pinned by the reference's own starknet proof (tests/test_layout_starknet.py): a layer is folded with the coin's draw
+    // TIMES its domain offset.  Honoured by the verifier; the prover still folds with the bare draw (see prover.py)
+    bool fri_alpha_times_offset = false;
 };
 
 // RAII device allocation (ss_dev_alloc / ss_dev_free)

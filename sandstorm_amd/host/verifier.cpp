@@ -191,7 +191,15 @@ std::vector<uint64_t> verify(const WireProof &w, Air &air, int tree_kind, int co
     require(w.fri_layers.size() == nlayers, "number of FRI layers");
     require(w.remainder.size() == std::max<uint64_t>(1, degree_bound), "remainder length");
     std::vector<Felt> fri_alphas;
-    for (auto &layer : w.fri_layers) { coin.reseed_with_digest(layer.root); fri_alphas.push_back(coin.draw()); }
+    {
+        Felt layer_offset = felt_from_u64(conv.lde_offset);
+        for (auto &layer : w.fri_layers) {
+            coin.reseed_with_digest(layer.root);
+            const Felt a = coin.draw();
+            fri_alphas.push_back(conv.fri_alpha_times_offset ? felt_mul(a, layer_offset) : a);
+            layer_offset = felt_pow(layer_offset, w.options[3]);
+        }
+    }
     coin.reseed_with_field_element_vector(w.remainder);
     require(verify_pow(coin_kind, coin.digest(), grinding, w.pow_nonce), "proof of work");
     coin.reseed_with_int(w.pow_nonce);

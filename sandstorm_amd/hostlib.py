@@ -358,12 +358,12 @@ def starknet_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=N
     return cols
 
 
-def verify(air: HostAir, tree_kind, coin_kind, seed, proof: bytes, shipped_conventions=True):
+def verify(air: HostAir, tree_kind, coin_kind, seed, proof: bytes, shipped_conventions=True, fri_alpha_times_offset=False):
     """the C++ host's verifier (sandstorm_amd/host/verifier.cpp) on a proof in the reference's wire format; raises
     SandstormHipError naming the failed check, returns the query positions"""
     pos = np.zeros(256, dtype=np.uint64)
     npos = C.c_uint32()
-    _check(load().ssh_verify(air.h, tree_kind, coin_kind, bytes(seed), bytes(proof), len(proof), 1 if shipped_conventions else 0,
+    _check(load().ssh_verify(air.h, tree_kind, coin_kind, bytes(seed), bytes(proof), len(proof), (2 if fri_alpha_times_offset else 1) if shipped_conventions else 0,
                              pos.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(npos)))
     return [int(v) for v in pos[:npos.value]]
 

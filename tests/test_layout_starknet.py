@@ -446,6 +446,17 @@ def test_references_own_starknet_proof_verifies(golden):
     bad[len(raw) - 40] ^= 1                                                                # inside the out-of-domain vector
     with pytest.raises(verifier.VerificationError):
         verifier.verify(bytes(bad), *args, seed, conv)
+    # the C++ host: its verifier (host/verifier.cpp) with its own starknet AIR (host/air_starknet.cpp) and seed accepts it too
+    from sandstorm_amd import hostlib
+    from sandstorm_amd._lib import SandstormHipError
+    assert hostlib.public_coin_seed(spi, be.COIN_SOLIDITY)[0] == seed
+    air = hostlib.StarknetHostAir(None, spi, 21)
+    assert hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw, fri_alpha_times_offset=True) == positions
+    with pytest.raises(SandstormHipError, match="does not fold"):
+        hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw)
+    with pytest.raises(SandstormHipError):
+        hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, bytes(bad), fri_alpha_times_offset=True)
+    air.close()
 
 
 def test_array_sum_trace_is_the_one_the_references_proof_opens(oracle, golden):
