@@ -7,9 +7,12 @@ A step = ONE PROOF: every GPU stage of SURVEY.md §3.1 steps 2-9 (LDE of base an
 extension columns, row hashing + Merkle trees, composition-constraint evaluation,
 composition LDE, OOD evaluation, DEEP composition, FRI layers, proof-of-work,
 query openings) on a trace that is already resident in HBM.  The host trace
-generation (A1/A2) is outside: base and extension columns are
-synthetic random columns; the AIR is the layout-SHAPED synthetic constraint set of
-sandstorm_amd/synthetic_air.py (said so in `config`).
+generation (A1) is outside: base and auxiliary columns are synthetic
+random columns; the AIR is the layout's REAL composition constraint (195 constraints
+/ 269 mask cells for starknet, 93 / 133 for recursive: sandstorm_amd/host/air_*.cpp,
+the program the reference's own proof verifies under) - a constraint program does
+not depend on the trace's contents, and every stage's cost is data-independent.
+`--air synthetic` keeps round 1's layout-shaped stand-in for comparison.
 
 Prints ONE JSON line on rank 0: prove wall-time (s), plus the Fp NTT rate,
 `roofline` (NTT pass kernel, HIP-event timed inside the same K proofs) and
@@ -108,6 +111,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="starknet_2p20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--air", default="real", choices=["real", "synthetic"],
+                    help="real: the layout's own composition constraint (default); synthetic: round 1's layout-shaped stand-in")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,8 +162,20 @@ def main():
             keep.append(hostlib.build_extension_columns(ctx, "recursive", aux_cols, n, challenges))      # check=True: real permutations
             return keep[0].cols
     else:
-        # the C++ host side (libsandstorm_host.so): coin, Expr lowering, prover, synthetic AIR
-        air = hostlib.HostAir(ctx, hostlib.AIR_SYNTHETIC_RECURSIVE if layout == "recursive" else hostlib.AIR_SYNTHETIC_STARKNET, log_n, lb)
+        # the C++ host side (libsandstorm_host.so): coin, Expr lowering, prover, the layout's AIR
+        if args.air == "real":
+            # the statement's public input only feeds constants of the program (hints, public memory product): the
+            # reference's example run re-declared for this layout and step count
+            from sandstorm_amd import public_input
+            pi = public_input.AirPublicInput.from_json(os.path.join(ROOT, "tests", "golden", "air_public_input_array_sum.json"))
+            pi.n_steps = 1 << log_steps
+            if layout == "starknet":
+                from sandstorm_amd.layouts import starknet as sk
+                air = hostlib.StarknetHostAir(ctx, sk.example_public_input(pi), log_n, lb)
+            else:
+                air = hostlib.RecursiveHostAir(ctx, pi, log_n, lb)
+        else:
+            air = hostlib.HostAir(ctx, hostlib.AIR_SYNTHETIC_RECURSIVE if layout == "recursive" else hostlib.AIR_SYNTHETIC_STARKNET, log_n, lb)
         if layout == "recursive":       # cli/src/main.rs:95-99 -> CairoVerifierClaim
             tree_kind, n_friendly, coin_kind = be.TREE_FRIENDLY, 22, be.COIN_CAIRO
         else:                           # cli/src/main.rs:90-94 -> EthVerifierClaim
@@ -245,6 +262,9 @@ def main():
                        "air": ("the REAL recursive AIR (93 constraints, %d mask cells: sandstorm_amd/host/air_recursive.cpp) on the reference's "
                                "example run; base trace generated by the C++ host in %.3f s (outside the timed region)" % (air.mask_size, trace_gen_s))
                               if real else
+                              ("the REAL %s AIR (%s, %d mask cells: sandstorm_amd/host/air_%s.cpp) on synthetic columns" %
+                               (layout, "195 constraints" if layout == "starknet" else "93 constraints", air.mask_size, layout))
+                              if args.air == "real" else
                               "SYNTHETIC constraint set with the layout's shape: %d mask cells, see sandstorm_amd/synthetic_air.py" % air.mask_size,
                        "proof_options": "65 queries, blowup 2, 16 PoW bits, FRI fold 8, <=16 remainder coeffs",
                        "in_timed_region": "LDE x2, extension-column scans (A2), commits x3, quotient, composition LDE, OOD, DEEP, FRI, PoW, openings",

@@ -228,8 +228,8 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
  *      domain_offset*<w>, natural order; row j = {evals[j + k*len/fold]};
  *      d_out[j] = degree<fold interpolant of row j evaluated at alpha.
  *      fold in {2,4,8,16}.  The next layer's offset is domain_offset^fold.
- * ss_fri_layer_matrix writes the fold-column matrix whose rows get committed
- * (column k = evals[k*len/fold ..]) as pointers into d_evals (no copy). */
+ *      The matrix whose rows get committed needs no entry point: its column k
+ *      is the slice d_evals[k*len/fold ..) of the layer itself (no copy). */
 ss_status ss_fri_fold(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
                       const uint64_t alpha[4], const uint64_t domain_offset[4], uint64_t *d_out);
 /* The same fold under the conventions found in the proof files the reference ships (data-only pin:

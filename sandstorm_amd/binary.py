@@ -42,6 +42,16 @@ def read_memory(data: bytes) -> List[Optional[int]]:
     return memory
 
 
+def write_register_states(states) -> bytes:
+    """the inverse of read_register_states (the `trace.bin` cairo-run writes)"""
+    return b"".join(struct.pack("<QQQ", s.ap, s.fp, s.pc) for s in states)
+
+
+def write_memory(memory) -> bytes:
+    """the inverse of read_memory: one record per touched cell, in address order"""
+    return b"".join(struct.pack("<Q", a) + int(w).to_bytes(32, "little") for a, w in enumerate(memory) if w is not None)
+
+
 class Word:
     """One memory word read as an instruction (binary/src/lib.rs:565-721)"""
 

@@ -17,7 +17,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)          /* hipcc: device + host; g++ (tests/cpp, the host library): host only */
 #define SS_HD __host__ __device__ __forceinline__
 #else
 #define SS_HD inline

@@ -210,4 +210,19 @@ std::vector<uint64_t> PublicCoin::draw_queries(size_t max_n, uint64_t domain_siz
     return std::vector<uint64_t>(s.begin(), s.end());
 }
 
+// PublicCoin::verify_proof_of_work (crypto/src/public_coin/solidity.rs:143-156, cairo.rs:156-169)
+bool verify_proof_of_work(int coin_kind, const Digest &digest, uint32_t bits, uint64_t nonce) {
+    if (!bits) return true;
+    auto h = [&](const std::vector<uint8_t> &m) { return coin_kind == SS_COIN_SOLIDITY ? keccak256(m.data(), m.size()) : blake2s256(m.data(), m.size()); };
+    std::vector<uint8_t> m = {0x01, 0x23, 0x45, 0x67, 0x89, 0xAB, 0xCD, 0xED};
+    m.insert(m.end(), digest.begin(), digest.end());
+    m.push_back((uint8_t)bits);
+    const Digest prefix = h(m);
+    std::vector<uint8_t> m2(prefix.begin(), prefix.end());
+    for (int i = 7; i >= 0; --i) m2.push_back((uint8_t)(nonce >> (8 * i)));
+    const Digest out = h(m2);
+    for (uint32_t b = 0; b < bits; ++b) if ((out[b / 8] >> (7 - b % 8)) & 1) return false;
+    return true;
+}
+
 }  // namespace ssh

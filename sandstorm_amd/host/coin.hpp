@@ -16,6 +16,8 @@ using Digest = std::array<uint8_t, 32>;
 
 Digest keccak256(const uint8_t *msg, size_t len);
 Digest blake2s256(const uint8_t *msg, size_t len);
+// PublicCoin::verify_proof_of_work for a coin kind: enough leading zero bits in H(H(magic | digest | bits) | nonce)
+bool verify_proof_of_work(int coin_kind, const Digest &digest, uint32_t bits, uint64_t nonce);
 std::array<uint8_t, 32> mont_be_bytes(const Felt &f);     // to_montgomery(e).to_be_bytes::<32>()
 Felt felt_from_u64(uint64_t v);
 Felt felt_from_canonical(const Felt &value);              // little-endian limbs of an integer < p -> Montgomery

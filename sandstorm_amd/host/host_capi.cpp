@@ -45,7 +45,8 @@ uint32_t ssh_air_columns(const ssh_air *a, int which) {
 // format 0: the flat test dump (Proof::serialize); 1: the reference's wire format (Proof::serialize_wire)
 static int prove_impl(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32],
                       uint64_t *const *d_base, uint32_t nbase, uint32_t log_n, ssh_extension_cb cb, void *user,
-                      const uint32_t options[5], int format, uint8_t **proof_bytes, uint64_t *proof_len) {
+                      const uint32_t options[5], int format, uint8_t **proof_bytes, uint64_t *proof_len,
+                      const uint64_t *pow_nonce = nullptr) {
     try {
         Air *air = reinterpret_cast<Air *>(air_h);
         Claim claim;
@@ -61,6 +62,7 @@ static int prove_impl(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_fri
         Digest sd;
         memcpy(sd.data(), seed, 32);
         Prover prover(ctx, claim, opt);
+        if (pow_nonce) prover.set_pow_nonce(*pow_nonce);
         Proof proof = prover.prove(sd, base, [&](const std::vector<Felt> &ch) {
             Matrix ext;
             ext.nrows = base.nrows;
@@ -96,6 +98,13 @@ int ssh_prove_wire(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friend
                    const uint32_t options[5], uint8_t **proof_bytes, uint64_t *proof_len) {
     return prove_impl(ctx, air_h, tree_kind, n_friendly_layers, coin_kind, seed, d_base, nbase, log_n, cb, user, options, 1,
                       proof_bytes, proof_len);
+}
+// same, with a given proof-of-work nonce instead of grinding (Prover::set_pow_nonce: must be valid for the transcript)
+int ssh_prove_wire_with_nonce(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32],
+                              uint64_t *const *d_base, uint32_t nbase, uint32_t log_n, ssh_extension_cb cb, void *user,
+                              const uint32_t options[5], uint64_t pow_nonce, uint8_t **proof_bytes, uint64_t *proof_len) {
+    return prove_impl(ctx, air_h, tree_kind, n_friendly_layers, coin_kind, seed, d_base, nbase, log_n, cb, user, options, 1,
+                      proof_bytes, proof_len, &pow_nonce);
 }
 void ssh_free(void *p) { free(p); }
 
@@ -258,9 +267,13 @@ int ssh_air_dump(ssh_air *air_h, uint64_t n, const uint64_t *challenges, uint32_
 
 // Verify a proof in the reference's wire format (verifier.hpp) against an AIR handle (mini or recursive; the handle may
 // have been created without a device).  conventions: 1 = the shipped proofs' (bit-reversed, unnormalised fold, unshifted
-// remainder), 0 = the older path's.  positions_out (nullable): room for num_queries values; *n_positions is set.
+// remainder) with the bare draw as FRI challenge (round-1 proofs), 2 = the reference's (the FRI challenge is the draw times
+// the layer offset), 0 = the older path's.  required_security_bits: cli/src/main.rs:66-67 (default 80 there).
+// expected_options (nullable): the five ProofOptions the proof must carry.  positions_out (nullable): room for num_queries
+// values; *n_positions is set.
 int ssh_verify(ssh_air *air_h, int tree_kind, int coin_kind, const uint8_t seed[32], const uint8_t *proof, uint64_t proof_len,
-               int conventions, uint64_t *positions_out, uint32_t *n_positions) {
+               int conventions, uint32_t required_security_bits, const uint32_t *expected_options, uint64_t *positions_out,
+               uint32_t *n_positions) {
     try {
         Air *air = reinterpret_cast<Air *>(air_h);
         Digest sd;
@@ -269,7 +282,12 @@ int ssh_verify(ssh_air *air_h, int tree_kind, int coin_kind, const uint8_t seed[
         if (!conventions) { conv.bitrev_commit = false; conv.fri_unnormalised = false; conv.remainder_unshifted = false; }
         conv.fri_alpha_times_offset = conventions == 2;       // 2: the shipped conventions plus the reference's FRI challenge scaling
         const WireProof w = parse_wire(proof, proof_len);
-        const std::vector<uint64_t> pos = verify(w, *air, tree_kind, coin_kind, sd, conv);
+        ProofOptions exp;
+        if (expected_options) {
+            exp.num_queries = expected_options[0]; exp.lde_blowup_factor = expected_options[1]; exp.grinding_factor = expected_options[2];
+            exp.fri_folding_factor = expected_options[3]; exp.fri_max_remainder_coeffs = expected_options[4];
+        }
+        const std::vector<uint64_t> pos = verify(w, *air, tree_kind, coin_kind, sd, conv, required_security_bits, expected_options ? &exp : nullptr);
         if (positions_out && n_positions) { memcpy(positions_out, pos.data(), pos.size() * 8); *n_positions = (uint32_t)pos.size(); }
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }

@@ -219,7 +219,8 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
         lp.log_len = log_len;
         proof.fri_layers.push_back(lp);
         coin.reseed_with_digest(digest_of(lp.root));
-        const Felt alpha = coin.draw();
+        Felt alpha = coin.draw();
+        if (conv_.fri_alpha_times_offset) alpha = felt_mul(alpha, offset);     // challenge = draw * layer offset
         proof.fri_alphas.push_back(alpha);
         auto next = std::make_shared<DeviceBuffer>(ctx_, 32 * rows);
         ok(ss_fri_fold_ex(ctx_, evals->u64(), log_len, fold, alpha.data(), offset.data(),
@@ -244,7 +245,13 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
 
     mark("fri");
     // 9. proof of work, queries, openings
-    if (opt_.grinding_factor) ok(ss_pow_grind(ctx_, claim_.coin_kind, coin.digest().data(), opt_.grinding_factor, &proof.pow_nonce));
+    if (have_nonce_) {
+        if (!verify_proof_of_work(claim_.coin_kind, coin.digest(), opt_.grinding_factor, nonce_))
+            throw std::runtime_error("the supplied proof-of-work nonce is not valid for this transcript");
+        proof.pow_nonce = nonce_;
+    } else if (opt_.grinding_factor) {
+        ok(ss_pow_grind(ctx_, claim_.coin_kind, coin.digest().data(), opt_.grinding_factor, &proof.pow_nonce));
+    }
     coin.reseed_with_int(proof.pow_nonce);
     proof.query_positions = coin.draw_queries(opt_.num_queries, N);
     const auto &pos = proof.query_positions;

@@ -33,8 +33,8 @@ struct Conventions {                    // ministark-internal, SURVEY.md Appendi
     bool fri_unnormalised = true;       // M8: fold = 8 * interpolant(alpha)
     bool remainder_unshifted = true;    // M9: remainder interpolates the folded last layer over the unshifted domain
     // pinned by the reference's own starknet proof (tests/test_layout_starknet.py): a layer is folded with the coin's draw
-    // TIMES its domain offset.  Honoured by the verifier; the prover still folds with the bare draw (see prover.py)
-    bool fri_alpha_times_offset = false;
+    // TIMES its domain offset (the reference folds over the unshifted domain).  false: the bare draw (round-1 proofs)
+    bool fri_alpha_times_offset = true;
 };
 
 // RAII device allocation (ss_dev_alloc / ss_dev_free)
@@ -147,7 +147,14 @@ public:
     Prover(ss_ctx *ctx, const Claim &claim, const ProofOptions &opt = ProofOptions(), const Conventions &conv = Conventions())
         : ctx_(ctx), claim_(claim), opt_(opt), conv_(conv) {}
     Proof prove(const Digest &coin_seed, const Matrix &base_trace, const ExtensionBuilder &build_extension);
+    // Use this proof-of-work nonce instead of grinding, if it is valid for the transcript (else prove() throws).  Any
+    // nonce with enough leading zeros is a valid proof (the reference's grinder returns whichever its parallel search
+    // finds first - `find_any`, crypto/src/public_coin/solidity.rs:120-141); the GPU grinder returns the smallest.
+    // Supplying the reference's nonce makes the whole proof comparable byte for byte.
+    void set_pow_nonce(uint64_t nonce) { have_nonce_ = true; nonce_ = nonce; }
 private:
+    bool have_nonce_ = false;
+    uint64_t nonce_ = 0;
     ss_ctx *ctx_;
     Claim claim_;
     ProofOptions opt_;

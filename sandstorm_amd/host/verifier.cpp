@@ -102,20 +102,6 @@ struct KeccakTree {                         // LeafVariantMerkleTree<Keccak256Ha
 uint64_t brev(uint64_t x, uint32_t bits) { uint64_t r = 0; for (uint32_t i = 0; i < bits; ++i) r |= ((x >> i) & 1ull) << (bits - 1 - i); return r; }
 uint32_t log2u(uint64_t v) { uint32_t l = 0; while ((1ull << l) < v) ++l; return l; }
 
-bool verify_pow(int coin_kind, const Digest &digest, uint32_t bits, uint64_t nonce) {      // solidity.rs:143-156, cairo.rs:156-169
-    if (!bits) return true;
-    auto h = [&](const std::vector<uint8_t> &m) { return coin_kind == SS_COIN_SOLIDITY ? keccak256(m.data(), m.size()) : blake2s256(m.data(), m.size()); };
-    std::vector<uint8_t> m = {0x01, 0x23, 0x45, 0x67, 0x89, 0xAB, 0xCD, 0xED};
-    m.insert(m.end(), digest.begin(), digest.end());
-    m.push_back((uint8_t)bits);
-    const Digest prefix = h(m);
-    std::vector<uint8_t> m2(prefix.begin(), prefix.end());
-    for (int i = 7; i >= 0; --i) m2.push_back((uint8_t)(nonce >> (8 * i)));
-    const Digest out = h(m2);
-    for (uint32_t b = 0; b < bits; ++b) if ((out[b / 8] >> (7 - b % 8)) & 1) return false;
-    return true;
-}
-
 Felt interpolate_eval(const std::vector<Felt> &xs, const Felt *ys, const Felt &t) {
     Felt acc = felt_from_u64(0);
     for (size_t i = 0; i < xs.size(); ++i) {
@@ -157,13 +143,33 @@ WireProof parse_wire(const uint8_t *data, size_t len) {
     return p;
 }
 
-std::vector<uint64_t> verify(const WireProof &w, Air &air, int tree_kind, int coin_kind, const Digest &coin_seed, const Conventions &conv) {
+uint32_t conjectured_security_bits(const uint32_t options[5], uint64_t trace_len, int tree_kind) {
+    const uint32_t log_N = log2u(trace_len * options[1]);
+    const uint32_t query = options[0] * log2u(options[1]) + options[2];
+    const uint32_t field = log_N < 252 ? 252 - log_N : 0;
+    const uint32_t tree = tree_kind == SS_TREE_KECCAK ? 128 : 80;     // masked-20 Keccak; Blake2s masked-20 below Pedersen's 125
+    return std::min(std::min(query, field), std::min(tree, 128u));
+}
+
+std::vector<uint64_t> verify(const WireProof &w, Air &air, int tree_kind, int coin_kind, const Digest &coin_seed, const Conventions &conv,
+                             uint32_t required_security_bits, const ProofOptions *expected_options) {
     require(tree_kind == SS_TREE_KECCAK || tree_kind == SS_TREE_KECCAK_M20, "the wire format covers the Keccak trees only");
     const KeccakTree tree{tree_kind == SS_TREE_KECCAK_M20};
     const uint32_t num_queries = w.options[0], blowup = w.options[1], grinding = w.options[2], fold = w.options[3], max_remainder = w.options[4];
     const uint64_t n = w.trace_len;
-    require(n >= 2 && !(n & (n - 1)) && blowup >= 2 && !(blowup & (blowup - 1)), "bad trace length / blowup");
+    require(n >= 2 && !(n & (n - 1)) && blowup >= 2 && !(blowup & (blowup - 1)) && n <= (1ull << 40) / blowup, "bad trace length / blowup");
     require(fold == 2 || fold == 4 || fold == 8 || fold == 16, "bad FRI folding factor");
+    require(num_queries >= 1, "proof options: no queries");
+    if (expected_options) {
+        const ProofOptions &e = *expected_options;
+        require(num_queries == e.num_queries && blowup == e.lde_blowup_factor && grinding == e.grinding_factor &&
+                fold == e.fri_folding_factor && max_remainder == e.fri_max_remainder_coeffs, "proof options differ from the expected ones");
+    }
+    {
+        const uint32_t sec = conjectured_security_bits(w.options, n, tree_kind);
+        require(sec >= required_security_bits, "proof options give " + std::to_string(sec) + " bits of conjectured security, " +
+                                                   std::to_string(required_security_bits) + " required");
+    }
     const uint64_t N = n * blowup;
     const uint32_t log_N = log2u(N), log_fold = log2u(fold), ncomp = conv.composition_columns;
     const size_t nmask = air.mask.size();
@@ -186,8 +192,15 @@ std::vector<uint64_t> verify(const WireProof &w, Air &air, int tree_kind, int co
         coin.reseed_with_field_elements(all);
     }
     const Felt deep_alpha = coin.draw();
+    // the layer count as the prover computes it; the options are untrusted, so anything the prover would refuse is a rejection
+    require(max_remainder >= 1 && !(max_remainder & (max_remainder - 1)), "FRI max remainder is not a power of two >= 1");
     uint64_t degree_bound = n, nlayers = 0;
-    while (degree_bound > max_remainder) { degree_bound /= fold; ++nlayers; }
+    while (degree_bound > max_remainder) {
+        require(degree_bound % fold == 0, "trace length is not the remainder bound times a power of the folding factor");
+        degree_bound /= fold;
+        ++nlayers;
+    }
+    require(log_fold * nlayers <= log_N, "FRI layers exceed the evaluation domain");
     require(w.fri_layers.size() == nlayers, "number of FRI layers");
     require(w.remainder.size() == std::max<uint64_t>(1, degree_bound), "remainder length");
     std::vector<Felt> fri_alphas;
@@ -201,7 +214,7 @@ std::vector<uint64_t> verify(const WireProof &w, Air &air, int tree_kind, int co
         }
     }
     coin.reseed_with_field_element_vector(w.remainder);
-    require(verify_pow(coin_kind, coin.digest(), grinding, w.pow_nonce), "proof of work");
+    require(verify_proof_of_work(coin_kind, coin.digest(), grinding, w.pow_nonce), "proof of work");
     coin.reseed_with_int(w.pow_nonce);
     const std::vector<uint64_t> positions = coin.draw_queries(num_queries, N);
     const size_t nq = positions.size();
@@ -243,7 +256,6 @@ std::vector<uint64_t> verify(const WireProof &w, Air &air, int tree_kind, int co
         tree.check(w.base_openings[qi], &w.base_rows[ncb * qi], ncb, q, log_N, w.base_root, "base trace" + tag);
         if (nce) tree.check(w.extension_openings[qi], &w.extension_rows[nce * qi], nce, q, log_N, w.extension_root, "extension trace" + tag);
         tree.check(w.composition_openings[qi], &w.composition_rows[ncomp * qi], ncomp, q, log_N, w.composition_root, "composition trace" + tag);
-        if (w.fri_layers.empty()) continue;
         Felt deep = felt_from_u64(0);
         for (size_t j = 0; j < nmask; ++j) {                    // src/lib.rs:102-116: alpha^j over the mask cells, then the columns
             const uint32_t c = air.mask[j].first, o = air.mask[j].second;
@@ -252,6 +264,15 @@ std::vector<uint64_t> verify(const WireProof &w, Air &air, int tree_kind, int co
         }
         for (uint32_t k = 0; k < ncomp; ++k)
             deep = felt_add(deep, felt_mul(coef[nmask + k], felt_mul(felt_sub(w.composition_rows[ncomp * qi + k], w.ood_composition[k]), felt_inv(felt_sub(x, zc)))));
+        if (w.fri_layers.empty()) {
+            // no layer to fold: the DEEP evaluations themselves were interpolated into the remainder (prover.cpp step 8)
+            Felt xr = felt_pow(wN, expo(q, log_N));
+            if (!conv.remainder_unshifted) xr = felt_mul(xr, offset0);
+            Felt acc = felt_from_u64(0);
+            for (size_t k = w.remainder.size(); k-- > 0;) acc = felt_add(felt_mul(acc, xr), w.remainder[k]);
+            require(acc == deep, "DEEP composition value at query " + std::to_string(qi) + " is not the remainder's");
+            continue;
+        }
         const uint64_t rows0 = N / fold;
         const uint64_t r = conv.bitrev_commit ? (q >> log_fold) : (q % rows0), slot = conv.bitrev_commit ? (q & (fold - 1)) : (q / rows0);
         const auto &lp = layer_positions[0];

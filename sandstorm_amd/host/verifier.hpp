@@ -31,8 +31,16 @@ struct WireProof {
 // throws std::runtime_error("malformed proof: ...") on any structural problem, trailing bytes included
 WireProof parse_wire(const uint8_t *data, size_t len);
 
-// throws std::runtime_error naming the failed check; returns the query positions
+// `Proof::security_level_bits` (cli/src/main.rs:203; conjectured): num_queries * log2(blowup) + grinding bits, capped by the
+// field (252 - log2 of the LDE domain) and by the collision resistance of the claim's hashes (crypto/src/hash/keccak.rs:17,64,
+// blake2s.rs:14,67, pedersen.rs:48; merkle/mod.rs:100-102,283-285,434-436)
+uint32_t conjectured_security_bits(const uint32_t options[5], uint64_t trace_len, int tree_kind);
+
+// throws std::runtime_error naming the failed check; returns the query positions.  The proof's own options are untrusted
+// (`claim.verify(proof, required_security_bits)`, cli/src/main.rs:176, default 80): a proof whose options conjecture less is
+// rejected, and so is one whose options differ from `expected_options` when given.
 std::vector<uint64_t> verify(const WireProof &proof, Air &air, int tree_kind, int coin_kind, const Digest &coin_seed,
-                             const Conventions &conv = Conventions());
+                             const Conventions &conv = Conventions(), uint32_t required_security_bits = 80,
+                             const ProofOptions *expected_options = nullptr);
 
 }  // namespace ssh

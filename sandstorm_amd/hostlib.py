@@ -34,6 +34,7 @@ def load():
                                 C.c_uint32, C.c_uint32, EXT_CB, C.c_void_p, C.POINTER(C.c_uint32),
                                 C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
         h.ssh_prove_wire.argtypes = h.ssh_prove.argtypes
+        h.ssh_prove_wire_with_nonce.argtypes = h.ssh_prove.argtypes[:12] + [C.c_uint64] + h.ssh_prove.argtypes[12:]
         h.ssh_free.argtypes = [C.c_void_p]
         h.ssh_build_extension_columns.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_uint64, C.POINTER(C.c_uint64),
                                                   C.c_int, C.POINTER(C.c_void_p)]
@@ -49,8 +50,8 @@ def load():
         h.ssh_air_create_starknet.argtypes = h.ssh_air_create_recursive.argtypes
         h.ssh_air_dump.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64),
                                    C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
-        h.ssh_verify.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64),
-                                 C.POINTER(C.c_uint32)]
+        h.ssh_verify.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.c_uint32,
+                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         h.ssh_matrix_num_cols.argtypes = [C.c_void_p]
         h.ssh_matrix_num_cols.restype = C.c_uint32
         h.ssh_matrix_col.argtypes = [C.c_void_p, C.c_uint32]
@@ -200,10 +201,11 @@ def parse_proof(raw, options, ncols_base, ncols_ext, ncomp=2):
 
 
 def prove(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, base_cols, log_n, build_extension, options=None,
-          want_proof=True, wire=False):
+          want_proof=True, wire=False, pow_nonce=None):
     """build_extension(challenges: list of uint64[4]) -> list of device columns (kept alive by the caller).
     wire=True: return the proof as bytes in the reference's wire format (ssh_prove_wire; sandstorm_amd/wire.py
-    parses them) instead of a parsed Proof."""
+    parses them) instead of a parsed Proof.  pow_nonce (wire only): use this proof-of-work nonce instead of grinding
+    (it must be valid for the transcript)."""
     options = options or ProofOptions()
     keep = []
 
@@ -223,9 +225,14 @@ def prove(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, base_cols, 
                             options.fri_folding_factor, options.fri_max_remainder_coeffs)
     out, n = C.POINTER(C.c_uint8)(), C.c_uint64()
     entry = load().ssh_prove_wire if wire else load().ssh_prove
-    _check(entry(ctx.handle, air.h, tree_kind, n_friendly, coin_kind, bytes(seed), be._ptr_array(base_cols),
-                 len(base_cols), log_n, EXT_CB(cb), None, opts,
-                 C.byref(out) if want_proof else None, C.byref(n) if want_proof else None))
+    head = (ctx.handle, air.h, tree_kind, n_friendly, coin_kind, bytes(seed), be._ptr_array(base_cols),
+            len(base_cols), log_n, EXT_CB(cb), None, opts)
+    tail = (C.byref(out) if want_proof else None, C.byref(n) if want_proof else None)
+    if pow_nonce is not None:
+        assert wire, "a supplied proof-of-work nonce is a wire-format feature"
+        _check(load().ssh_prove_wire_with_nonce(*head, int(pow_nonce), *tail))
+    else:
+        _check(entry(*head, *tail))
     if not want_proof:
         return None
     raw = bytes(C.cast(out, C.POINTER(C.c_uint8 * n.value)).contents)
@@ -358,13 +365,20 @@ def starknet_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=N
     return cols
 
 
-def verify(air: HostAir, tree_kind, coin_kind, seed, proof: bytes, shipped_conventions=True, fri_alpha_times_offset=False):
+def verify(air: HostAir, tree_kind, coin_kind, seed, proof: bytes, shipped_conventions=True, fri_alpha_times_offset=True,
+           required_security_bits=80, expected_options=None):
     """the C++ host's verifier (sandstorm_amd/host/verifier.cpp) on a proof in the reference's wire format; raises
-    SandstormHipError naming the failed check, returns the query positions"""
+    SandstormHipError naming the failed check, returns the query positions.  required_security_bits / expected_options:
+    as sandstorm_amd.verifier.verify"""
     pos = np.zeros(256, dtype=np.uint64)
     npos = C.c_uint32()
+    exp = None
+    if expected_options is not None:
+        o = expected_options
+        exp = (C.c_uint32 * 5)(*(o if isinstance(o, (list, tuple)) else
+                                 [o.num_queries, o.lde_blowup_factor, o.grinding_factor, o.fri_folding_factor, o.fri_max_remainder_coeffs]))
     _check(load().ssh_verify(air.h, tree_kind, coin_kind, bytes(seed), bytes(proof), len(proof), (2 if fri_alpha_times_offset else 1) if shipped_conventions else 0,
-                             pos.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(npos)))
+                             required_security_bits, exp, pos.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(npos)))
     return [int(v) for v in pos[:npos.value]]
 
 

@@ -52,9 +52,8 @@ class Conventions:
     # M8, second half, pinned by replaying the whole transcript of the reference's `example/array-sum.proof.saved`
     # (tests/test_verifier.py::test_reference_starknet_proof_verifies): the challenge a layer is folded with is the
     # coin's draw TIMES that layer's domain offset (lde_offset^(fold^layer)) - the reference folds over the unshifted
-    # domain.  The verifier honours the flag; the provers (this file, host/prover.cpp) still fold with the bare draw and
-    # the committed proof fixtures are theirs, so the default stays False until both are switched on a GPU (round 2).
-    fri_alpha_times_offset: bool = False
+    # domain.  Provers and verifiers of both hosts honour the flag; False keeps the bare draw (round-1 proofs).
+    fri_alpha_times_offset: bool = True
 
 
 def bitrev(x: int, bits: int) -> int:
@@ -140,6 +139,9 @@ class Prover:
         self.options = options or ProofOptions()
         self.conv = conventions or Conventions()
         self.timings = {}
+        # use this proof-of-work nonce instead of grinding (must be valid for the transcript): any nonce with enough
+        # leading zeros is a proof (the reference returns whichever its parallel search finds, solidity.rs:120-141)
+        self.pow_nonce = None
 
     def prove(self, coin_seed: bytes, base_trace: be.Matrix,
               build_extension: Callable[[List[np.ndarray]], Optional[be.Matrix]]) -> Proof:
@@ -250,6 +252,8 @@ class Prover:
             layer = FriLayer(tree.root(), tree.root_tag(), log_len)
             coin.reseed_with_digest(layer.root)
             alpha = coin.draw()
+            if conv.fri_alpha_times_offset:     # the reference folds over the unshifted domain: challenge = draw * layer offset
+                alpha = be.felt(canonical(alpha) * offset_int % be.P)
             proof.fri_alphas.append(alpha)
             nxt = ctx.alloc(32 * rows)
             ctx.fri_fold(evals, log_len, fold, alpha, be.felt(offset_int), nxt, fri_flags)     # natural order in memory
@@ -267,7 +271,13 @@ class Prover:
 
         mark("fri")
         # 9. proof of work, queries, openings
-        proof.pow_nonce = ctx.pow_grind(self.claim.coin_kind, coin.digest, opt.grinding_factor) if opt.grinding_factor else 0
+        if self.pow_nonce is not None:
+            from .verifier import _verify_pow
+            assert _verify_pow(self.claim.coin_kind, coin.digest, opt.grinding_factor, self.pow_nonce), \
+                "the supplied proof-of-work nonce is not valid for this transcript"
+            proof.pow_nonce = self.pow_nonce
+        else:
+            proof.pow_nonce = ctx.pow_grind(self.claim.coin_kind, coin.digest, opt.grinding_factor) if opt.grinding_factor else 0
         mark("pow")
         coin.reseed_with_int(proof.pow_nonce)
         positions = coin.draw_queries(opt.num_queries, N)

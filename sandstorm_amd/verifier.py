@@ -109,34 +109,43 @@ def _interpolate_eval(xs, ys, t):
     return acc
 
 
-def verify(proof, air: VerifierAir, tree_kind, coin_kind, coin_seed: bytes, conv: Conventions = None):
-    """proof: bytes in the reference's wire format, or a wire.WireProof.  Raises VerificationError; returns the
-    query positions on success.  The bytes are untrusted: any arithmetic or indexing accident they provoke (a zero
-    denominator, a missing position) is a rejection too."""
-    try:
-        return _verify(proof, air, tree_kind, coin_kind, coin_seed, conv)
-    except (ValueError, IndexError, KeyError, ZeroDivisionError, OverflowError) as e:
-        raise VerificationError("malformed proof: %s: %s" % (type(e).__name__, e))
+DEFAULT_REQUIRED_SECURITY_BITS = 80     # cli/src/main.rs:66-67: `verify --required-security-bits`, default 80
 
 
-def _verify(proof, air, tree_kind, coin_kind, coin_seed, conv):
+def conjectured_security_bits(options, trace_len, tree_kind, coin_kind):
+    """`Proof::security_level_bits` (cli/src/main.rs:203; ministark, conjectured): what the query phase buys
+    (num_queries * log2(blowup) + grinding bits), capped by the field (252 bits minus log2 of the LDE domain) and by the
+    collision resistance of the claim's tree hash (crypto/src/merkle/mod.rs:100-102, 283-285, 434-436; mixed.rs:127-129:
+    128 bits for Keccak / Blake2s, 8*20/2 = 80 for the masked-20 variants, 125 for Pedersen - hash/keccak.rs:17,64,
+    blake2s.rs:14,67, pedersen.rs:48) and of the coin's hash (public_coin/solidity.rs:158-160, cairo.rs:171-173)."""
+    num_queries, blowup, grinding = options[0], options[1], options[2]
+    query = num_queries * (blowup.bit_length() - 1) + grinding
+    field = 252 - ((trace_len * blowup).bit_length() - 1)
+    tree = {be.TREE_KECCAK: 128, be.TREE_KECCAK_M20: 80, be.TREE_FRIENDLY: 80}[tree_kind]
+    return max(0, min(query, field, tree, 128))
+
+
+def fri_layer_count(trace_len, fold, max_remainder):
+    """number of FRI layers and the remainder's coefficient bound, as the provers compute them (prover.py step 8);
+    the options are untrusted here: anything the provers would refuse is a rejection"""
+    _require(max_remainder >= 1 and max_remainder & (max_remainder - 1) == 0, "FRI max remainder is not a power of two >= 1")
+    degree_bound, nlayers = trace_len, 0
+    while degree_bound > max_remainder:
+        _require(degree_bound % fold == 0, "trace length is not the remainder bound times a power of the folding factor")
+        degree_bound //= fold
+        nlayers += 1
+    return nlayers, degree_bound
+
+
+def replay_transcript(w, air, coin_kind, coin_seed, conv=None):
+    """The verifier's step 1 on a parsed proof: every reseed and draw of prover.py steps 2-9 in order, the proof of work
+    included.  -> {"challenges", "composition_coeff", "z", "deep_alpha", "fri_alphas", "positions"} (canonical ints)"""
     conv = conv or Conventions()
-    try:
-        w = wire.parse(bytes(proof)) if isinstance(proof, (bytes, bytearray, memoryview)) else proof
-    except ValueError as e:
-        raise VerificationError("malformed proof: %s" % e)
     num_queries, blowup, grinding, fold, max_remainder = w.options
     n = w.trace_len
-    _require(n >= 2 and n & (n - 1) == 0 and blowup >= 2 and blowup & (blowup - 1) == 0, "bad trace length / blowup")
-    _require(fold in (2, 4, 8, 16), "bad FRI folding factor")
     N = n * blowup
     log_N, log_fold = N.bit_length() - 1, fold.bit_length() - 1
-    ncomp = conv.composition_columns
-    nmask = len(air.mask)
-    tree = _KeccakTree(tree_kind)
-    expo = (lambda i, bits: bitrev(i, bits)) if conv.bitrev_commit else (lambda i, bits: i)
-
-    # ---- 1. transcript (prover.py steps 2-9)
+    ncomp, nmask = conv.composition_columns, len(air.mask)
     _require(len(w.ood_trace) == nmask and len(w.ood_composition) == ncomp, "out-of-domain vector lengths")
     _require((w.extension_root is not None) == (air.num_extension_columns > 0), "extension root presence")
     coin = PublicCoin(coin_kind, coin_seed)
@@ -150,10 +159,8 @@ def _verify(proof, air, tree_kind, coin_kind, coin_seed, conv):
     coin.reseed_with_field_elements([be.felt(v) for v in list(w.ood_trace) + list(w.ood_composition)])
     deep_alpha = wire._canon(coin.draw())
     # expected number of layers: fold until the remainder fits (prover.py step 8)
-    degree_bound, nlayers = n, 0
-    while degree_bound > max_remainder:
-        degree_bound //= fold
-        nlayers += 1
+    nlayers, degree_bound = fri_layer_count(n, fold, max_remainder)
+    _require(log_fold * nlayers <= log_N, "FRI layers exceed the evaluation domain")
     _require(len(w.fri_layers) == nlayers, "number of FRI layers")
     _require(len(w.remainder) == max(1, degree_bound), "remainder length")
     fri_alphas = []
@@ -169,9 +176,56 @@ def _verify(proof, air, tree_kind, coin_kind, coin_seed, conv):
     z = wire._canon(z_l)
     ch = [wire._canon(c) for c in challenges]
 
+    return {"challenges": ch, "composition_coeff": wire._canon(comp_coeff), "z": z, "deep_alpha": deep_alpha,
+            "fri_alphas": fri_alphas, "positions": positions}
+
+
+def verify(proof, air: VerifierAir, tree_kind, coin_kind, coin_seed: bytes, conv: Conventions = None,
+           required_security_bits: int = DEFAULT_REQUIRED_SECURITY_BITS, expected_options=None):
+    """proof: bytes in the reference's wire format, or a wire.WireProof.  Raises VerificationError; returns the
+    query positions on success.  The bytes are untrusted: any arithmetic or indexing accident they provoke (a zero
+    denominator, a missing position) is a rejection too.  The proof's own options are untrusted as well
+    (`claim.verify(proof, required_security_bits)`, cli/src/main.rs:176): a proof whose options conjecture fewer than
+    `required_security_bits` is rejected, and so is one whose options differ from `expected_options` when given."""
+    try:
+        return _verify(proof, air, tree_kind, coin_kind, coin_seed, conv, required_security_bits, expected_options)
+    except (ValueError, IndexError, KeyError, ZeroDivisionError, OverflowError) as e:
+        raise VerificationError("malformed proof: %s: %s" % (type(e).__name__, e))
+
+
+def _verify(proof, air, tree_kind, coin_kind, coin_seed, conv, required_security_bits, expected_options):
+    conv = conv or Conventions()
+    try:
+        w = wire.parse(bytes(proof)) if isinstance(proof, (bytes, bytearray, memoryview)) else proof
+    except ValueError as e:
+        raise VerificationError("malformed proof: %s" % e)
+    num_queries, blowup, grinding, fold, max_remainder = w.options
+    n = w.trace_len
+    _require(n >= 2 and n & (n - 1) == 0 and blowup >= 2 and blowup & (blowup - 1) == 0, "bad trace length / blowup")
+    _require(n * blowup <= 1 << 40, "bad trace length / blowup")
+    _require(fold in (2, 4, 8, 16), "bad FRI folding factor")
+    _require(num_queries >= 1, "proof options: no queries")
+    if expected_options is not None:
+        exp = expected_options if isinstance(expected_options, (list, tuple)) else \
+            [expected_options.num_queries, expected_options.lde_blowup_factor, expected_options.grinding_factor,
+             expected_options.fri_folding_factor, expected_options.fri_max_remainder_coeffs]
+        _require(list(w.options) == list(exp), "proof options differ from the expected ones")
+    sec = conjectured_security_bits(w.options, n, tree_kind, coin_kind)
+    _require(sec >= required_security_bits, "proof options give %d bits of conjectured security, %d required" % (sec, required_security_bits))
+    N = n * blowup
+    log_N, log_fold = N.bit_length() - 1, fold.bit_length() - 1
+    ncomp = conv.composition_columns
+    nmask = len(air.mask)
+    tree = _KeccakTree(tree_kind)
+    expo = (lambda i, bits: bitrev(i, bits)) if conv.bitrev_commit else (lambda i, bits: i)
+
+    # ---- 1. transcript (prover.py steps 2-9)
+    t = replay_transcript(w, air, coin_kind, coin_seed, conv)
+    z, deep_alpha, fri_alphas, positions, ch, comp_coeff = t["z"], t["deep_alpha"], t["fri_alphas"], t["positions"], t["challenges"], t["composition_coeff"]
+
     # ---- 2. out-of-domain identity: sum_k alpha^k C_k(z) == sum_k z^k H_k(z^ncomp)
     cell = {m: v for m, v in zip(air.mask, w.ood_trace)}
-    dag = air.composition(n, ch, wire._canon(comp_coeff))
+    dag = air.composition(n, ch, comp_coeff)
     lhs = ap.evaluate(dag, P, z, lambda c, o: cell[(c, o)], lambda t: air.table_at(n, z, t))
     rhs = sum(pow(z, k, P) * h for k, h in enumerate(w.ood_composition)) % P
     _require(lhs == rhs, "out-of-domain identity: the composition constraint does not match the composition columns at z")
@@ -224,14 +278,18 @@ def check_proof_data(w, mask, num_base_columns, num_extension_columns, tree_kind
         if nce:
             tree.check_opening(w.extension_openings[qi], erow, q, log_N, w.extension_root, "extension trace, query %d" % qi)
         tree.check_opening(w.composition_openings[qi], crow, q, log_N, w.composition_root, "composition trace, query %d" % qi)
-        if not w.fri_layers:
-            continue
         trow = list(brow) + list(erow)
         deep = 0
         for j, (c, o) in enumerate(air.mask):               # src/lib.rs:102-116: coefficients alpha^j over mask cells, then columns
             deep += coef[j] * (trow[c] - w.ood_trace[j]) * pow(x - z * pow(wn, o, P), -1, P)
         for k in range(ncomp):
             deep += coef[nmask + k] * (crow[k] - w.ood_composition[k]) * pow(x - zc, -1, P)
+        if not w.fri_layers:
+            # no layer to fold: the DEEP evaluations themselves were interpolated into the remainder (prover.py step 8)
+            xr = pow(wN, expo(q, log_N), P) * (1 if conv.remainder_unshifted else conv.lde_offset) % P
+            _require(sum(c * pow(xr, i, P) for i, c in enumerate(w.remainder)) % P == deep % P,
+                     "DEEP composition value at query %d is not the remainder's" % qi)
+            continue
         rows0 = N // fold
         r, slot = (q >> log_fold, q & (fold - 1)) if conv.bitrev_commit else (q % rows0, q // rows0)
         li0 = layer_positions[0].index(r)

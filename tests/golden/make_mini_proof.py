@@ -23,7 +23,9 @@ opt = ProofOptions(num_queries=12, grinding_factor=8, fri_max_remainder_coeffs=4
 meta = {"seed_hex": seed.hex(), "options": [opt.num_queries, opt.lde_blowup_factor, opt.grinding_factor, opt.fri_folding_factor,
                                             opt.fri_max_remainder_coeffs],
         "claim": "EthVerifierClaim flavour: LeafVariantMerkleTree<MaskedKeccak256HashFn<20>>, SolidityVerifierPublicCoin", "files": {}}
-for log_n in (5, 9):
+# the third proof has NO FRI layer (the trace fits the remainder bound): the DEEP evaluations go straight into the remainder
+for log_n, opt, name in ((5, opt, "mini_proof_eth_log5.bin"), (9, opt, "mini_proof_eth_log9.bin"),
+                         (5, ProofOptions(num_queries=12, grinding_factor=8, fri_max_remainder_coeffs=32), "mini_proof_eth_log5_nolayers.bin")):
     n = 1 << log_n
     c0, c1 = mini_air.base_trace(n)
     base = be.Matrix.from_host(ctx, [oracle.to_mont(c0), oracle.to_mont(c1)])
@@ -37,7 +39,6 @@ for log_n in (5, 9):
     air = hostlib.HostAir(ctx, hostlib.AIR_MINI, log_n)
     raw = hostlib.prove(ctx, air, be.TREE_KECCAK_M20, 0, be.COIN_SOLIDITY, seed, base.cols, log_n, build_extension, opt, wire=True)
     air.close()
-    name = "mini_proof_eth_log%d.bin" % log_n
     with open(os.path.join(out_dir, name), "wb") as f:
         f.write(raw)
     meta["files"][name] = {"trace_len": n, "bytes": len(raw)}

@@ -161,3 +161,37 @@ def test_extension_scan_argument_errors(ctx):
         ctx.permutation_product((buf, 2, 0, -1), (buf, 2, 1, -1), 0, z, None, buf)          # empty
     with pytest.raises(SandstormHipError):
         ctx.diluted_aggregate(buf, 1, 0, 4, z, z, buf, 2, 2)                                # out offset >= out stride
+
+
+def test_extension_column_of_the_reference_proof(ctx, oracle):
+    """A2 pinned by reference OUTPUT, on the device (the CPU twin is tests/test_layout_starknet.py::
+    test_extension_column_is_the_one_the_references_proof_opens): the six challenges replayed from the transcript of
+    `example/array-sum.proof.saved`, the extension column built by the device scans (both hosts'
+    build_extension_columns), its LDE over 3<w> by ss_lde_fp252 - the 16 extension leaves that proof opens."""
+    import os
+    from sandstorm_amd import backend as be, binary, extension, hostlib, public_input, wire
+    from sandstorm_amd.coin import PublicCoin
+    from sandstorm_amd.layouts import starknet as sk
+    from sandstorm_amd.prover import bitrev
+    from tests.test_layout_starknet import ROOT, reference_query_positions, starknet_example
+    with open(os.path.join(ROOT, "tests", "golden", "reference_array_sum_starknet.proof"), "rb") as f:
+        w = wire.parse(f.read())
+    states, memory, spi = starknet_example(17)
+    coin = PublicCoin(be.COIN_SOLIDITY, public_input.public_coin_seed(spi, be.COIN_SOLIDITY))
+    coin.reseed_with_digest(w.base_root)
+    challenges_ = [coin.draw() for _ in range(6)]
+    natural = [bitrev(p, 22) for p in reference_query_positions(w, spi)]
+    cols = hostlib.starknet_base_trace(binary.write_register_states(states), binary.write_memory(memory), spi)
+    n = cols[0].shape[0]
+    base = be.Matrix.from_host(ctx, cols)
+    g = oracle.to_mont([3])[0]
+    want = [wire._mont_limbs(int(v)) for v in w.extension_rows]
+    # Python host mirror
+    m = extension.build_extension_columns("starknet", ctx, sk.trace_columns(ctx, base.cols, n), challenges_)
+    lde, _ = m.lde(1, g)
+    got = ctx.gather_rows(lde.cols, natural)
+    assert [[int(x) for x in r[0]] for r in got] == want
+    # C++ host
+    hm = hostlib.build_extension_columns(ctx, "starknet", [base.cols[sk.COL_NPC], base.cols[sk.COL_MEMORY], base.cols[sk.COL_RANGE_CHECK]], n, challenges_)
+    assert np.array_equal(hm.to_host()[0], m.to_host()[0])
+    hm.close()

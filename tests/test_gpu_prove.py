@@ -80,7 +80,7 @@ def test_prove_and_verify_older_conventions(ctx, oracle, flavour):
     proof file (example/bootloader/bootloader-proof.bin) stay selectable."""
     from sandstorm_amd.prover import Conventions, Prover
     n, claim, params, opt, seed, base, build_extension = setup_case(ctx, oracle, flavour, 9)
-    conv = Conventions(bitrev_commit=False, fri_unnormalised=False, remainder_unshifted=False)
+    conv = Conventions(bitrev_commit=False, fri_unnormalised=False, remainder_unshifted=False, fri_alpha_times_offset=False)
     proof = Prover(ctx, claim, opt, conv).prove(seed, base, build_extension)
     verify_mini_proof(oracle, proof, n, params, opt, seed, conv)
 
@@ -195,6 +195,9 @@ def verify_mini_proof(oracle, proof, n, params, opt, seed, conv=None):
         rows = L // fold
         w, wf = pyref.root_of_unity(L), pyref.root_of_unity(fold)
         a = int(oracle.from_mont(fri_alphas[li]))
+        if conv.fri_alpha_times_offset:                # the reference folds over the unshifted domain: challenge = draw * layer offset
+            a = a * offset % P
+        assert a == int(oracle.from_mont(proof.fri_alphas[li]))
         leaf_kind = row_kind
         for pi, r in enumerate(layer.positions):
             assert merkle_verify(oracle, tree_kind, nf, row_leaf(oracle, leaf_kind, layer.rows[pi]), r, layer.paths[pi], rows, layer.root)

@@ -49,14 +49,14 @@ def test_prove_and_verify_the_reference_example(oracle):
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "array_sum_recursive_eth.proof"), "wb") as f:
         f.write(raw)
-    positions = verifier.verify(raw, rec.verifier_air(pi), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
+    positions = verifier.verify(raw, rec.verifier_air(pi), be.TREE_KECCAK, be.COIN_SOLIDITY, seed, required_security_bits=20)
     assert positions == proof.query_positions
     # a different public input (one more step claimed) is a different statement: seed and hints change
     import copy
     pi2 = copy.deepcopy(pi)
     pi2.memory_segments["execution"] = (pi.memory_segments["execution"][0], pi.memory_segments["execution"][1] + 1)
     with pytest.raises(verifier.VerificationError):
-        verifier.verify(raw, rec.verifier_air(pi2), be.TREE_KECCAK, be.COIN_SOLIDITY, public_input.public_coin_seed(pi2, be.COIN_SOLIDITY))
+        verifier.verify(raw, rec.verifier_air(pi2), be.TREE_KECCAK, be.COIN_SOLIDITY, public_input.public_coin_seed(pi2, be.COIN_SOLIDITY), required_security_bits=20)
     ctx.close()
 
 
@@ -89,7 +89,7 @@ def test_cpp_host_proves_the_reference_example_from_its_files(oracle):
         return m.cols
     raw = hostlib.prove(ctx, air, be.TREE_KECCAK, 0, be.COIN_SOLIDITY, seed, base.cols, log_n, build_extension, opt, wire=True)
     air.close()
-    verifier.verify(raw, rec.verifier_air(pi), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
+    verifier.verify(raw, rec.verifier_air(pi), be.TREE_KECCAK, be.COIN_SOLIDITY, seed, required_security_bits=20)
     # the Python mirror on the same statement
     pair = rec.make_air(ctx, pi, n)
     tc = rec.trace_columns(ctx, base.cols, n)

@@ -1,0 +1,65 @@
+"""Q1 on the REAL programs: the lowered composition constraints of the `starknet` (195 constraints,
+269 mask cells, row offsets up to 33 158: layouts/src/starknet/air.rs:115-2406) and `recursive` (93 constraints, 133
+cells: layouts/src/recursive/air.rs:61-1200) layouts, exactly as the C++ host hands them to ss_eval_quotient, run on
+the device over a whole 2^17-point evaluation domain of random columns and random tables and compared, bit for bit,
+with the oracle's constraint VM.  At 2^16 trace rows the largest offsets wrap around the domain several times less
+than at 2^15, but still wrap (33 158 * 2 > 2^16 LDE rows only once the row is within the last half)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_layout_recursive import load_run
+from tests.test_layout_starknet import CHALLENGES, P, starknet_example
+
+pytestmark = pytest.mark.gpu
+
+
+class _Prog:
+    def __init__(self, code, consts, n_slots):
+        self.code, self.consts, self.n_slots = code, consts, n_slots
+
+
+def _rand(rng, count):                          # any limbs with the top one below 2^59 are felts below p
+    v = rng.integers(0, 1 << 63, size=(count, 4), dtype=np.uint64)
+    v[:, 3] &= np.uint64((1 << 59) - 1)
+    return np.ascontiguousarray(v)
+
+
+@pytest.mark.parametrize("layout,log_n", [("starknet", 16), ("recursive", 16), ("starknet", 12)])
+def test_real_composition_program_vs_oracle(oracle, layout, log_n):
+    from sandstorm_amd import backend as be, hostlib
+    if layout == "starknet":
+        from sandstorm_amd.layouts import starknet as lay
+        _, _, pi = starknet_example(11)
+        cpp, ncols = hostlib.StarknetHostAir(None, pi, log_n), 10
+    else:
+        from sandstorm_amd.layouts import recursive as lay
+        _, _, pi = load_run()
+        cpp, ncols = hostlib.RecursiveHostAir(None, pi, log_n), 10
+    n, N = 1 << log_n, 2 << log_n
+    alpha = pow(5, 77, P)
+    code, consts, n_slots, specs = cpp.dump(n, [oracle.to_mont([c])[0] for c in CHALLENGES], oracle.to_mont([alpha])[0])
+    cpp.close()
+    assert len(code) // 2 > (1000 if layout == "starknet" else 500)
+    tables = lay.Tables(n)
+    rng = np.random.default_rng(17 + log_n)
+    tabs, desc, off = [], [], 0
+    for spec in specs:
+        t = _rand(rng, tables.length(spec))
+        desc += [off, len(t).bit_length() - 1]
+        off += len(t)
+        tabs.append(t)
+    tab = np.concatenate(tabs)
+    lde = [_rand(rng, N) for _ in range(ncols)]
+    g = oracle.to_mont([3])[0]
+    want = oracle.eval_program(code, consts, tab, desc, n_slots, lde, log_n, 1, g)
+    assert want.any()
+    ctx = be.Context(0)
+    m = be.Matrix.from_host(ctx, lde)
+    out = ctx.alloc(32 * N)
+    prog = _Prog(code, [int(v) for v in oracle.from_mont(consts)], n_slots)
+    ctx.eval_quotient(prog, ctx.column(tab), desc, m.cols, log_n, 1, g, out)
+    got = out.download(np.uint64, (N, 4))
+    assert np.array_equal(got, want)
+    ctx.close()

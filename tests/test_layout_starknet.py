@@ -418,44 +418,57 @@ def test_references_own_starknet_proof_verifies(golden):
     identity of the restated 195-constraint AIR under the replayed challenges, every Merkle opening, the DEEP value of
     every query, the six FRI layers and the remainder.  The public input is the array-sum run re-declared for the
     layout (starknet_example) - the run's trace is also the one the proof opens."""
-    from sandstorm_amd import backend as be, public_input, verifier
+    import functools
+    from sandstorm_amd import backend as be, hostlib, public_input, verifier
     from sandstorm_amd.layouts import starknet as sk
     from sandstorm_amd.prover import Conventions
     with open(os.path.join(ROOT, "tests", "golden", "reference_array_sum_starknet.proof"), "rb") as f:
         raw = f.read()
     _, _, spi = starknet_example(17)
     seed = public_input.public_coin_seed(spi, be.COIN_SOLIDITY)
-    conv = Conventions(fri_alpha_times_offset=True)
+    # the proof's own options are 16 queries + 16 grinding bits at blowup 2: 32 conjectured bits (the CLI's default
+    # requirement of 80 rejects it, as the reference's `verify` would)
+    verify = functools.partial(verifier.verify, required_security_bits=32)
+    cverify = functools.partial(hostlib.verify, required_security_bits=32)
     args = (sk.verifier_air(spi), be.TREE_KECCAK_M20, be.COIN_SOLIDITY)
-    positions = verifier.verify(raw, *args, seed, conv)
+    positions = verify(raw, *args, seed)                                                   # default conventions = the reference's
     assert len(positions) == 16 and positions == sorted(positions)
     assert positions[:4] == golden("saved_proof_openings.json")["positions"][:4]        # the positions the openings golden was cut at
+    assert verify(raw, *args, seed, expected_options=[16, 2, 16, 8, 16]) == positions
     # what the acceptance rests on
+    with pytest.raises(verifier.VerificationError, match="32 bits of conjectured security, 80 required"):
+        verifier.verify(raw, *args, seed)
+    with pytest.raises(verifier.VerificationError, match="options differ"):
+        verify(raw, *args, seed, expected_options=[65, 2, 16, 8, 16])
     with pytest.raises(verifier.VerificationError, match="proof of work"):
-        verifier.verify(raw, *args, bytes(32), conv)                                       # another seed: another statement
+        verify(raw, *args, bytes(32))                                                      # another seed: another statement
     with pytest.raises(verifier.VerificationError, match="does not fold"):
-        verifier.verify(raw, *args, seed)                                                  # the bare draw as FRI challenge
+        verify(raw, *args, seed, Conventions(fri_alpha_times_offset=False))               # the bare draw as FRI challenge
     import copy
     other = copy.deepcopy(spi)
     other.rc_max += 1
     with pytest.raises(verifier.VerificationError, match="proof of work"):
-        verifier.verify(raw, sk.verifier_air(other), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, public_input.public_coin_seed(other, be.COIN_SOLIDITY), conv)
+        verify(raw, sk.verifier_air(other), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, public_input.public_coin_seed(other, be.COIN_SOLIDITY))
     with pytest.raises(verifier.VerificationError, match="out-of-domain identity"):       # same seed, one hint of the AIR off by one
-        verifier.verify(raw, sk.verifier_air(other), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, conv)
+        verify(raw, sk.verifier_air(other), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
     bad = bytearray(raw)
     bad[len(raw) - 40] ^= 1                                                                # inside the out-of-domain vector
     with pytest.raises(verifier.VerificationError):
-        verifier.verify(bytes(bad), *args, seed, conv)
+        verify(bytes(bad), *args, seed)
     # the C++ host: its verifier (host/verifier.cpp) with its own starknet AIR (host/air_starknet.cpp) and seed accepts it too
-    from sandstorm_amd import hostlib
     from sandstorm_amd._lib import SandstormHipError
     assert hostlib.public_coin_seed(spi, be.COIN_SOLIDITY)[0] == seed
     air = hostlib.StarknetHostAir(None, spi, 21)
-    assert hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw, fri_alpha_times_offset=True) == positions
-    with pytest.raises(SandstormHipError, match="does not fold"):
+    assert cverify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw) == positions
+    assert cverify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw, expected_options=[16, 2, 16, 8, 16]) == positions
+    with pytest.raises(SandstormHipError, match="32 bits of conjectured security, 80 required"):
         hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw)
+    with pytest.raises(SandstormHipError, match="options differ"):
+        cverify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw, expected_options=[16, 2, 16, 8, 8])
+    with pytest.raises(SandstormHipError, match="does not fold"):
+        cverify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw, fri_alpha_times_offset=False)
     with pytest.raises(SandstormHipError):
-        hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, bytes(bad), fri_alpha_times_offset=True)
+        cverify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, bytes(bad))
     air.close()
 
 
@@ -476,3 +489,53 @@ def test_array_sum_trace_is_the_one_the_references_proof_opens(oracle, golden):
         lde = oracle.lde(oracle.to_mont(cols[c]), 1, offset)[0]
         got = [int(v) for v in oracle.from_mont(lde[natural])]
         assert got == [int(w.base_rows[9 * q + c]) for q in range(len(positions))], "column %d" % c
+
+
+def test_extension_column_is_the_one_the_references_proof_opens(oracle):
+    """A2 pinned by reference OUTPUT: replaying the transcript of `example/array-sum.proof.saved` gives
+    the six challenges its prover drew after the base commitment; the extension column rebuilt from them with the
+    oracle's `build_extension_columns` (memory, range-check and diluted-check products + the diluted aggregate, all in
+    the one permutation column: layouts/src/starknet/trace.rs:997-1100), extended over 3<w>, equals the 16 extension
+    leaves the proof opens.  One wrong challenge, or one changed cell, changes every opened value.  The GPU twin is
+    tests/test_gpu_extension.py::test_extension_column_of_the_reference_proof (and the byte-for-byte proof of
+    tests/test_gpu_reference_proof.py)."""
+    import numpy as np
+    from sandstorm_amd import backend as be, public_input, wire
+    from sandstorm_amd.coin import PublicCoin
+    from sandstorm_amd.layouts import starknet as sk
+    from sandstorm_amd.prover import bitrev
+    with open(os.path.join(ROOT, "tests", "golden", "reference_array_sum_starknet.proof"), "rb") as f:
+        w = wire.parse(f.read())
+    states, memory, spi = starknet_example(17)
+    coin = PublicCoin(be.COIN_SOLIDITY, public_input.public_coin_seed(spi, be.COIN_SOLIDITY))
+    coin.reseed_with_digest(w.base_root)
+    challenges = [coin.draw() for _ in range(6)]
+    positions = reference_query_positions(w, spi)
+    assert len(positions) == 16 == len(w.extension_rows)
+    cols = sk.base_trace(states, memory, spi)
+    n = len(cols[0])
+    aux = {"npc": oracle.to_mont(cols[sk.COL_NPC]), "memory": oracle.to_mont(cols[sk.COL_MEMORY]), "range_check": oracle.to_mont(cols[sk.COL_RANGE_CHECK])}
+    natural = [bitrev(p, 22) for p in positions]
+    offset = oracle.to_mont([3])[0]
+
+    def opened(ch):
+        ext, lasts = oracle.build_extension_columns("starknet", aux, ch, n)
+        lde = oracle.lde(ext[0], 1, offset)[0]
+        return [int(v) for v in oracle.from_mont(lde[natural])], lasts
+    got, lasts = opened(challenges)
+    assert got == [int(v) for v in w.extension_rows]
+    hints = sk.Hints.from_public_input(spi, [wire._canon(c) for c in challenges], n)
+    assert [int(v) for v in oracle.from_mont(np.stack(lasts))] == [hints.memory_quotient, 1, 1]
+    # the pin discriminates
+    wrong = list(challenges)
+    wrong[3] = oracle.to_mont([wire._canon(challenges[3]) + 1])[0]         # the diluted-check permutation challenge
+    bad, _ = opened(wrong)
+    assert sum(a == int(b) for a, b in zip(bad, w.extension_rows)) == 0
+
+
+def reference_query_positions(w, spi):
+    """the query positions of the reference's proof, by replaying its transcript (the verifier's step 1)"""
+    from sandstorm_amd import backend as be, public_input, verifier
+    from sandstorm_amd.layouts import starknet as sk
+    seed = public_input.public_coin_seed(spi, be.COIN_SOLIDITY)
+    return verifier.verify(w, sk.verifier_air(spi), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, required_security_bits=32)

@@ -13,6 +13,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+def pv(*a, **k):
+    """sandstorm_amd.verifier.verify at the fixtures' security level (12 queries + 8 grinding bits; the CLI's default is 80)"""
+    from sandstorm_amd import verifier
+    k.setdefault("required_security_bits", 20)
+    return verifier.verify(*a, **k)
+
+
+def cv(*a, **k):
+    """the C++ host's verifier, likewise"""
+    from sandstorm_amd import hostlib
+    k.setdefault("required_security_bits", 20)
+    return hostlib.verify(*a, **k)
+
+
 def mini_verifier_air():
     from sandstorm_amd.verifier import VerifierAir
     return VerifierAir(2, 1, 1, mini_air.MASK,
@@ -31,7 +45,7 @@ def load_fixture(log_n):
 def test_committed_proof_verifies(log_n):
     from sandstorm_amd import backend as be, verifier, wire
     raw, seed, meta = load_fixture(log_n)
-    positions = verifier.verify(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+    positions = pv(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
     w = wire.parse(raw)
     assert w.options == meta["options"] and w.trace_len == 1 << log_n
     assert len(positions) == len(w.base_openings) and positions == sorted(set(positions))
@@ -47,7 +61,7 @@ def test_tampered_proofs_are_rejected():
         w = wire.parse(raw)
         mutate(w)
         with pytest.raises(verifier.VerificationError, match=match):
-            verifier.verify(w, air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+            pv(w, air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
 
     def bump(lst, i):
         lst[i] = (lst[i] + 1) % verifier.P
@@ -68,11 +82,11 @@ def test_tampered_proofs_are_rejected():
         o.path[0] = bytes(32)
     rejected(swap_path, match="authentication path")
     with pytest.raises(verifier.VerificationError):
-        verifier.verify(raw, air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, bytes(32))     # wrong public-coin seed
+        pv(raw, air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, bytes(32))     # wrong public-coin seed
     with pytest.raises(verifier.VerificationError, match="malformed"):
-        verifier.verify(raw[:-5], air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+        pv(raw[:-5], air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
     with pytest.raises(verifier.VerificationError):
-        verifier.verify(raw, air, be.TREE_KECCAK, be.COIN_SOLIDITY, seed)              # unmasked tree: other hashes
+        pv(raw, air, be.TREE_KECCAK, be.COIN_SOLIDITY, seed)              # unmasked tree: other hashes
 
 
 def test_older_conventions_are_a_different_statement():
@@ -81,8 +95,8 @@ def test_older_conventions_are_a_different_statement():
     from sandstorm_amd.prover import Conventions
     raw, seed, _ = load_fixture(5)
     with pytest.raises(verifier.VerificationError):
-        verifier.verify(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed,
-                        Conventions(bitrev_commit=False, fri_unnormalised=False, remainder_unshifted=False))
+        pv(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed,
+                        Conventions(bitrev_commit=False, fri_unnormalised=False, remainder_unshifted=False, fri_alpha_times_offset=False))
 
 
 @pytest.mark.gpu
@@ -106,7 +120,7 @@ def test_fresh_cpp_host_proof_verifies(oracle, log_n):
     air = hostlib.HostAir(ctx, hostlib.AIR_MINI, log_n)
     raw = hostlib.prove(ctx, air, be.TREE_KECCAK_M20, 0, be.COIN_SOLIDITY, seed, base.cols, log_n, build_extension, opt, wire=True)
     air.close()
-    assert len(verifier.verify(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)) <= 20
+    assert len(pv(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)) <= 20
     ctx.close()
 
 
@@ -121,16 +135,16 @@ def test_committed_proof_of_the_reference_example_verifies():
     with open(os.path.join(GOLD, "array_sum_recursive_eth.proof"), "rb") as f:
         raw = f.read()
     seed = public_input.public_coin_seed(pi, be.COIN_SOLIDITY)
-    positions = verifier.verify(raw, rec.verifier_air(pi), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
+    positions = pv(raw, rec.verifier_air(pi), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
     w = wire.parse(raw)
     assert w.trace_len == 16 * pi.n_steps and len(w.ood_trace) == 133 and len(positions) == len(w.base_openings)
     pi2 = copy.deepcopy(pi)
     pi2.rc_max += 1                                           # a different claim: other seed, other hints
     with pytest.raises(verifier.VerificationError):
-        verifier.verify(raw, rec.verifier_air(pi2), be.TREE_KECCAK, be.COIN_SOLIDITY, public_input.public_coin_seed(pi2, be.COIN_SOLIDITY))
+        pv(raw, rec.verifier_air(pi2), be.TREE_KECCAK, be.COIN_SOLIDITY, public_input.public_coin_seed(pi2, be.COIN_SOLIDITY))
     # same seed, wrong hint: the transcript replays, the out-of-domain identity must catch it
     with pytest.raises(verifier.VerificationError, match="out-of-domain identity"):
-        verifier.verify(raw, rec.verifier_air(pi2), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
+        pv(raw, rec.verifier_air(pi2), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
 
 
 def test_cpp_verifier_on_the_committed_proofs():
@@ -144,39 +158,39 @@ def test_cpp_verifier_on_the_committed_proofs():
     for log_n in (5, 9):
         raw, seed, _ = load_fixture(log_n)
         air = hostlib.HostAir(None, hostlib.AIR_MINI, log_n)
-        assert hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw) == \
-            verifier.verify(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+        assert cv(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw) == \
+            pv(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
         if log_n == 5:
             w = wire.parse(raw)
             w.base_rows[0] = (w.base_rows[0] + 1) % verifier.P
             with pytest.raises(SandstormHipError, match="base trace"):
-                hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, wire.serialize(w))
+                cv(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, wire.serialize(w))
             w = wire.parse(raw)
             w.fri_layers[0].rows[3] = (w.fri_layers[0].rows[3] + 1) % verifier.P
             with pytest.raises(SandstormHipError, match="FRI layer 0"):
-                hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, wire.serialize(w))
+                cv(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, wire.serialize(w))
             w = wire.parse(raw)
             w.ood_composition[1] = (w.ood_composition[1] + 1) % verifier.P
             with pytest.raises(SandstormHipError):
-                hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, wire.serialize(w))
+                cv(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, wire.serialize(w))
             with pytest.raises(SandstormHipError, match="malformed"):
-                hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw[:-3])
+                cv(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw[:-3])
             with pytest.raises(SandstormHipError):
-                hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw, shipped_conventions=False)
+                cv(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw, shipped_conventions=False)
         air.close()
     pi = public_input.AirPublicInput.from_json(os.path.join(GOLD, "air_public_input_array_sum.json"))
     with open(os.path.join(GOLD, "array_sum_recursive_eth.proof"), "rb") as f:
         raw = f.read()
     seed = public_input.public_coin_seed(pi, be.COIN_SOLIDITY)
     air = hostlib.RecursiveHostAir(None, pi, 18)
-    assert hostlib.verify(air, be.TREE_KECCAK, be.COIN_SOLIDITY, seed, raw) == \
-        verifier.verify(raw, rec.verifier_air(pi), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
+    assert cv(air, be.TREE_KECCAK, be.COIN_SOLIDITY, seed, raw) == \
+        pv(raw, rec.verifier_air(pi), be.TREE_KECCAK, be.COIN_SOLIDITY, seed)
     air.close()
     pi2 = copy.deepcopy(pi)
     pi2.rc_max += 1
     air2 = hostlib.RecursiveHostAir(None, pi2, 18)
     with pytest.raises(SandstormHipError, match="out-of-domain identity"):
-        hostlib.verify(air2, be.TREE_KECCAK, be.COIN_SOLIDITY, seed, raw)              # same transcript, wrong hint
+        cv(air2, be.TREE_KECCAK, be.COIN_SOLIDITY, seed, raw)              # same transcript, wrong hint
     air2.close()
 
 
@@ -244,12 +258,12 @@ def test_parsers_survive_mutated_proofs():
             continue
         outcomes = []
         try:
-            verifier.verify(b, air_py, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+            pv(b, air_py, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
             outcomes.append("ok")
         except verifier.VerificationError:
             outcomes.append("rejected")
         try:
-            hostlib.verify(air_cpp, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, b)
+            cv(air_cpp, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, b)
             outcomes.append("ok")
         except SandstormHipError:
             outcomes.append("rejected")
@@ -257,3 +271,125 @@ def test_parsers_survive_mutated_proofs():
         accepted += outcomes[0] == "ok"
     assert accepted == 0
     air_cpp.close()
+
+
+def _forged_mini_proof(options, trace_len=32):
+    """the advisor's forgery: no rows, no openings, arbitrary roots and an arbitrary out-of-domain
+    vector; ood_composition[0] is solved from the out-of-domain identity, so everything the verifier replays from the
+    transcript is consistent.  Only the query phase (absent here) ties such bytes to a trace."""
+    from sandstorm_amd import air_program as ap, backend as be, verifier, wire
+    from sandstorm_amd.coin import PublicCoin
+    P = verifier.P
+    seed = bytes(range(32))
+    n = trace_len
+    w = wire.WireProof(list(options), n, b"\x11" * 32, b"\x22" * 32, b"\x33" * 32)
+    w.ood_trace = [5, 6, 7, 8, 9, 10]
+    coin = PublicCoin(be.COIN_SOLIDITY, seed)
+    coin.reseed_with_digest(w.base_root)
+    gamma = wire._canon(coin.draw())
+    coin.reseed_with_digest(w.extension_root)
+    alpha = wire._canon(coin.draw())
+    coin.reseed_with_digest(w.composition_root)
+    z = wire._canon(coin.draw())
+    cell = dict(zip(mini_air.MASK, w.ood_trace))
+    lhs = ap.evaluate(mini_air.composition(n, gamma, alpha), P, z, lambda c, o: cell[(c, o)], lambda t: mini_air.table_at(n, z))
+    h1 = 12345
+    w.ood_composition = [(lhs - z * h1) % P, h1]
+    nlayers, bound = 0, n
+    while bound > options[4]:
+        bound //= options[3]
+        nlayers += 1
+    assert nlayers == 0
+    w.remainder = [1] * max(1, bound)
+    return wire.serialize(w), seed
+
+
+def test_forged_proof_without_queries_is_rejected():
+    """the proof's options are untrusted.  A proof that declares zero queries and no grinding carries no
+    evidence at all; both verifiers refuse it - by the explicit query-count check and by the security level
+    (`claim.verify(proof, required_security_bits)`, cli/src/main.rs:176) even when asked for 0 bits."""
+    from sandstorm_amd import backend as be, hostlib, verifier
+    from sandstorm_amd._lib import SandstormHipError
+    raw, seed = _forged_mini_proof([0, 2, 0, 8, 32])
+    air = hostlib.HostAir(None, hostlib.AIR_MINI, 5)
+    for bits in (0, 20, 80):
+        with pytest.raises(verifier.VerificationError, match="no queries"):
+            verifier.verify(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, required_security_bits=bits)
+        with pytest.raises(SandstormHipError, match="no queries"):
+            hostlib.verify(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw, required_security_bits=bits)
+    # one query, no grinding: 1 conjectured bit
+    raw, seed = _forged_mini_proof([1, 2, 0, 8, 32])
+    with pytest.raises(verifier.VerificationError, match="1 bits of conjectured security, 20 required"):
+        pv(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+    with pytest.raises(SandstormHipError, match="1 bits of conjectured security, 20 required"):
+        cv(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw)
+    # and with the security requirement waived the (absent) query data is what fails
+    with pytest.raises(verifier.VerificationError, match="rows / openings count"):
+        pv(raw, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, required_security_bits=0)
+    with pytest.raises(SandstormHipError, match="rows / openings count"):
+        cv(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw, required_security_bits=0)
+    air.close()
+
+
+def test_security_level_follows_the_reference_constants():
+    """hash/keccak.rs:17,64, blake2s.rs:14,67, pedersen.rs:48; the CLI defaults (65 queries, blowup 2, 16 bits) give 81
+    query-phase bits, capped at 80 by the masked-20 trees - exactly the CLI's default requirement (main.rs:66-67)"""
+    from sandstorm_amd import backend as be
+    from sandstorm_amd.verifier import conjectured_security_bits as sec
+    assert sec([65, 2, 16, 8, 16], 1 << 21, be.TREE_KECCAK_M20, be.COIN_SOLIDITY) == 80
+    assert sec([65, 2, 16, 8, 16], 1 << 21, be.TREE_KECCAK, be.COIN_SOLIDITY) == 81
+    assert sec([65, 2, 16, 8, 16], 1 << 21, be.TREE_FRIENDLY, be.COIN_CAIRO) == 80
+    assert sec([64, 2, 15, 8, 16], 1 << 21, be.TREE_KECCAK, be.COIN_SOLIDITY) == 79
+    assert sec([200, 4, 30, 8, 16], 1 << 21, be.TREE_KECCAK, be.COIN_SOLIDITY) == 128
+    assert sec([16, 2, 16, 8, 16], 1 << 21, be.TREE_KECCAK_M20, be.COIN_SOLIDITY) == 32
+
+
+def test_malformed_options_are_rejected_before_any_geometry():
+    """max_remainder 0 / not a power of two, a trace length that is not the remainder bound times a power of
+    the folding factor, layer counts beyond the domain - all rejected up front by both verifiers (the C++ one used to
+    compute `1 << (log_N - log_fold * layers)` on them)"""
+    from sandstorm_amd import backend as be, hostlib, verifier, wire
+    from sandstorm_amd._lib import SandstormHipError
+    raw, seed = _forged_mini_proof([12, 2, 8, 8, 32])
+    air = hostlib.HostAir(None, hostlib.AIR_MINI, 5)
+    for opts, n, what in (([12, 2, 8, 8, 0], 8, "max remainder"), ([12, 2, 8, 8, 3], 32, "max remainder"),
+                          ([12, 2, 8, 8, 2], 4, "power of the folding factor"), ([12, 2, 8, 16, 1], 32, "power of the folding factor")):
+        w = wire.parse(raw)
+        w.options, w.trace_len = opts, n
+        b = wire.serialize(w)
+        with pytest.raises(verifier.VerificationError, match=what):
+            pv(b, mini_verifier_air(), be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+        with pytest.raises(SandstormHipError, match=what):
+            cv(air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, b)
+    air.close()
+
+
+def test_proof_without_fri_layers_binds_the_remainder():
+    """when the trace fits the remainder bound there is no FRI layer; the DEEP value of every query
+    must then equal the remainder polynomial at that point - otherwise nothing ties the commitments to a low-degree
+    polynomial.  tests/golden/mini_proof_eth_log5_nolayers.bin (GPU-made) verifies in both hosts; below the transcript
+    (same out-of-domain point, DEEP coefficient and positions) one changed remainder coefficient is caught by that
+    check, and through the front door the changed transcript fails the proof of work."""
+    from sandstorm_amd import backend as be, hostlib, verifier, wire
+    from sandstorm_amd._lib import SandstormHipError
+    with open(os.path.join(GOLD, "mini_proof_eth_log5_nolayers.bin"), "rb") as f:
+        raw = f.read()
+    seed = bytes(range(32))
+    w = wire.parse(raw)
+    assert w.fri_layers == [] and len(w.remainder) == 32 and w.options == [12, 2, 8, 8, 32]
+    air = mini_verifier_air()
+    positions = pv(raw, air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+    cpp = hostlib.HostAir(None, hostlib.AIR_MINI, 5)
+    assert cv(cpp, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, raw) == positions
+    t = verifier.replay_transcript(w, air, be.COIN_SOLIDITY, seed)
+    assert t["positions"] == positions and t["fri_alphas"] == []
+    args = (air.mask, 2, 1, be.TREE_KECCAK_M20, t["z"], t["deep_alpha"], [], positions)
+    assert verifier.check_proof_data(w, *args) == positions
+    w.remainder[1] = (w.remainder[1] + 1) % verifier.P
+    with pytest.raises(verifier.VerificationError, match="is not the remainder's"):
+        verifier.check_proof_data(w, *args)
+    with pytest.raises(verifier.VerificationError, match="proof of work"):
+        pv(w, air, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed)
+    with pytest.raises(SandstormHipError, match="proof of work"):
+        cv(cpp, be.TREE_KECCAK_M20, be.COIN_SOLIDITY, seed, wire.serialize(w))
+    cpp.close()
