@@ -160,7 +160,9 @@ E LayoutAir::multiplier(Graph &g, const Domain &d) {
     E expr{&g, -1};
     if (!per.num.empty() || !per.den.empty()) { expr = E{&g, g.table((uint32_t)table_index(per))}; have = true; }
     for (auto &f : d.num) if (f.p == 1) {
-        const E lin = E{&g, g.x()} - E{&g, g.constant(felt_pow(g_, f.e))};
+        // g^e is a per-size value: symbol by the row it names, counted from whichever end is nearer (n-independent)
+        const uint64_t row_sym = f.e > n_ / 2 ? Graph::sym("row from end", n_ - f.e) : Graph::sym("row", f.e);
+        const E lin = E{&g, g.x()} - E{&g, g.runtime_constant(row_sym, felt_pow(g_, f.e))};
         expr = have ? expr * lin : lin; have = true;
     }
     for (auto &f : d.den) if (f.p == 1) {
@@ -172,7 +174,7 @@ E LayoutAir::multiplier(Graph &g, const Domain &d) {
 }
 
 void LayoutAir::Composer::add(const std::string &domain_name, const Domain &d, const E &numerator) {
-    const E term = numerator * E{&g_, g_.constant(apow_)};
+    const E term = numerator * E{&g_, g_.runtime_constant(Graph::sym("alpha^", count_++), apow_)};
     auto it = std::find_if(groups_.begin(), groups_.end(), [&](const Group &p) { return p.name == domain_name; });
     if (it == groups_.end()) groups_.push_back(Group{domain_name, d, term.id});
     else it->sum = g_.add(it->sum, term.id);

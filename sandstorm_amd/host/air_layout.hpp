@@ -104,6 +104,7 @@ protected:
         LayoutAir &air_;
         Graph &g_;
         Felt alpha_, apow_;
+        uint64_t count_ = 0;
         std::vector<Group> groups_;
     };
 

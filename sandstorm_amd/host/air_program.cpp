@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <stdexcept>
 
 #include "../../include/sandstorm_hip.h"
 
@@ -22,6 +23,13 @@ int Graph::constant(const Felt &m) {
     if (it == const_ix_.end()) { ix = (int)consts_.size(); consts_.push_back(m); const_ix_[m] = ix; } else ix = it->second;
     return intern(NodeKind::Const, -1, -1, (uint32_t)ix, 0);
 }
+int Graph::runtime_constant(uint64_t symbol, const Felt &m) {
+    auto it = const_sym_.find(symbol);
+    int ix;
+    if (it == const_sym_.end()) { ix = (int)consts_.size(); consts_.push_back(m); const_sym_[symbol] = ix; }
+    else { ix = it->second; if (!(consts_[ix] == m)) throw std::runtime_error("runtime constant: one symbol, two values"); }
+    return intern(NodeKind::Const, -1, -1, (uint32_t)ix, 1);
+}
 int Graph::trace(uint32_t col, uint32_t off) { return intern(NodeKind::Trace, -1, -1, col, off); }
 int Graph::table(uint32_t index) { return intern(NodeKind::Table, -1, -1, index, 0); }
 int Graph::add(int a, int b) { if (a > b) std::swap(a, b); return intern(NodeKind::Add, a, b, 0, 0); }
@@ -36,7 +44,7 @@ struct Lowerer {
     std::vector<int> uses;
     std::map<int, uint32_t> slot_of;
     std::vector<uint32_t> free_slots;
-    std::map<Felt, uint32_t> const_ix;
+    std::map<uint32_t, uint32_t> const_ix;          // graph constant index -> program constant index (no merging by value)
 
     explicit Lowerer(const Graph &gr) : g(gr), uses(gr.nodes().size(), 0) {}
 
@@ -55,9 +63,8 @@ struct Lowerer {
         switch (nd.kind) {
         case NodeKind::X: kind = SS_SRC_X; payload = 0; return true;
         case NodeKind::Const: {
-            const Felt &v = g.constants()[nd.p0];
-            auto it = const_ix.find(v);
-            if (it == const_ix.end()) { payload = (uint32_t)prog.consts.size(); prog.consts.push_back(v); const_ix[v] = payload; } else payload = it->second;
+            auto it = const_ix.find(nd.p0);
+            if (it == const_ix.end()) { payload = (uint32_t)prog.consts.size(); prog.consts.push_back(g.constants()[nd.p0]); const_ix[nd.p0] = payload; } else payload = it->second;
             kind = SS_SRC_CONST; return true; }
         case NodeKind::Trace: kind = SS_SRC_TRACE; payload = (nd.p0 << 24) | nd.p1; return true;
         case NodeKind::Table: kind = SS_SRC_TABLE; payload = nd.p0; return true;

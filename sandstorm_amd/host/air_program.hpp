@@ -28,8 +28,19 @@ struct Node {
 class Graph {
 public:
     int x();
-    int constant(const Felt &mont);
+    int constant(const Felt &mont);                                   // a STRUCTURAL constant of the AIR: interned by value
     int constant_u64(uint64_t v) { return constant(felt_from_u64(v)); }
+    // A constant whose value is only known per proof (a challenge, a hint from the public input, a power of the
+    // composition coefficient, a power of the trace generator): interned by SYMBOL, never by value, so that the shape of
+    // the graph - and with it the lowered program - is the same for every statement of a layout even when two such
+    // values (or one of them and a structural constant) happen to coincide.  The compiled constraint kernels
+    // (csrc/quotient_gen_*.hip, generated from the lowered program) rely on that.
+    int runtime_constant(uint64_t symbol, const Felt &mont);
+    static constexpr uint64_t sym(const char *name, uint64_t index = 0) {
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (const char *c = name; *c; ++c) h = (h ^ (uint64_t)(unsigned char)*c) * 0x100000001b3ull;
+        return (h ^ index) * 0x100000001b3ull;
+    }
     int trace(uint32_t col, uint32_t row_offset);
     int table(uint32_t index);
     int add(int a, int b);
@@ -44,6 +55,7 @@ private:
     std::vector<Felt> consts_;
     std::map<std::tuple<int, int, int, uint32_t, uint32_t>, int> pool_;
     std::map<Felt, int> const_ix_;
+    std::map<uint64_t, int> const_sym_;
 };
 
 struct Program {

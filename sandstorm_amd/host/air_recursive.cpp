@@ -61,7 +61,10 @@ private:
         const Hints h = hints(ch);
         auto T = [&](uint32_t col, uint64_t off) { return E{&g, g.trace(col, (uint32_t)off)}; };
         auto C = [&](uint64_t v) { return E{&g, g.constant_u64(v)}; };
-        auto CF = [&](const Felt &f) { return E{&g, g.constant(f)}; };
+        auto CF = [&](const Felt &f) { return E{&g, g.constant(f)}; };                 // structural constants only
+        // per-proof values: interned by symbol, so that the program's shape is the same for every statement (air_program.hpp)
+#define HINT(name) E{&g, g.runtime_constant(Graph::sym("hint." #name), h.name)}
+#define CHAL(index) E{&g, g.runtime_constant(Graph::sym("challenge", index), ch[index])}
         auto pow2 = [&](unsigned k) { return CF(felt_pow(felt_from_u64(2), k)); };
         auto flag = [&](int f) { return T(COL_FLAGS, f) - (T(COL_FLAGS, f + 1) + T(COL_FLAGS, f + 1)); };
         auto npc = [&](uint64_t cell, uint64_t cycle = 0) { return T(COL_NPC, CYCLE_HEIGHT * cycle + cell); };
@@ -111,12 +114,12 @@ private:
         ADD(ALL_CYCLES, flag(F_OPCODE_RET) * (rc(RC_OFF_OP1) + one - half_offset_size));
         ADD(ALL_CYCLES, flag(F_OPCODE_RET) * (flag(F_PC_JUMP_ABS) + flag(F_DST_REG) + flag(F_OP1_FP) + flag_res_op1_0 - four));
         ADD(ALL_CYCLES, flag(F_OPCODE_ASSERT_EQ) * (npc(NPC_MEM_DST) - aux(AUX_RES)));
-        ADD(FIRST_ROW, aux(AUX_AP) - CF(h.initial_ap));
-        ADD(FIRST_ROW, aux(AUX_FP) - CF(h.initial_ap));
-        ADD(FIRST_ROW, npc(NPC_PC) - CF(h.initial_pc));
-        ADD(LAST_CYCLE, aux(AUX_AP) - CF(h.final_ap));
-        ADD(LAST_CYCLE, aux(AUX_FP) - CF(h.initial_ap));
-        ADD(LAST_CYCLE, npc(NPC_PC) - CF(h.final_pc));
+        ADD(FIRST_ROW, aux(AUX_AP) - HINT(initial_ap));
+        ADD(FIRST_ROW, aux(AUX_FP) - HINT(initial_ap));
+        ADD(FIRST_ROW, npc(NPC_PC) - HINT(initial_pc));
+        ADD(LAST_CYCLE, aux(AUX_AP) - HINT(final_ap));
+        ADD(LAST_CYCLE, aux(AUX_FP) - HINT(initial_ap));
+        ADD(LAST_CYCLE, npc(NPC_PC) - HINT(final_pc));
 
         // ---- memory (air.rs:444-497)
         const Domain EVERY_2ND_EXCEPT_LAST = every_except_last(2), SECOND_LAST_ROW = row_from_end(2);
@@ -124,11 +127,11 @@ private:
         auto perm_memory = [&](uint64_t k = 0) { return T(COL_MEM_RC_PERMUTATION, 2 * k); };
         auto perm_rc = [&](uint64_t k = 0) { return T(COL_MEM_RC_PERMUTATION, 4 * k + 1); };
         {
-            const E z = CF(ch[MEM_Z]), a = CF(ch[MEM_A]);
+            const E z = CHAL(MEM_Z), a = CHAL(MEM_A);
             const E address_diff = mem(0, 1) - mem(0);
             ADD(FIRST_ROW, (z - (mem(0) + a * mem(1))) * perm_memory() + npc(NPC_PC) + a * npc(NPC_INSTRUCTION) - z);
             ADD(EVERY_2ND_EXCEPT_LAST, (z - (mem(0, 1) + a * mem(1, 1))) * perm_memory(1) - (z - (T(COL_NPC, 2) + a * T(COL_NPC, 3))) * perm_memory());
-            ADD(SECOND_LAST_ROW, perm_memory() - CF(h.memory_quotient));
+            ADD(SECOND_LAST_ROW, perm_memory() - HINT(memory_quotient));
             ADD(EVERY_2ND_EXCEPT_LAST, address_diff * address_diff - address_diff);
             ADD(EVERY_2ND_EXCEPT_LAST, (address_diff - one) * (mem(1) - mem(1, 1)));
             ADD(FIRST_ROW, mem(0) - one);
@@ -139,19 +142,19 @@ private:
         const Domain EVERY_4TH_EXCEPT_LAST = every_except_last(4), FOURTH_LAST_ROW = row_from_end(4);
         auto rc_ordered = [&](uint64_t k = 0) { return T(COL_RANGE_CHECK, 4 * k + RC_ORDERED); };
         {
-            const E z = CF(ch[RC_Z]);
+            const E z = CHAL(RC_Z);
             const E diff = rc_ordered(1) - rc_ordered();
             ADD(FIRST_ROW, (z - rc_ordered()) * perm_rc() + rc(RC_OFF_DST) - z);
             ADD(EVERY_4TH_EXCEPT_LAST, (z - rc_ordered(1)) * perm_rc(1) - (z - T(COL_RANGE_CHECK, 4)) * perm_rc());
             ADD(FOURTH_LAST_ROW, perm_rc() - one);
             ADD(EVERY_4TH_EXCEPT_LAST, diff * diff - diff);
-            ADD(FIRST_ROW, rc_ordered() - CF(h.range_check_min));
-            ADD(FOURTH_LAST_ROW, rc_ordered() - CF(h.range_check_max));
+            ADD(FIRST_ROW, rc_ordered() - HINT(range_check_min));
+            ADD(FOURTH_LAST_ROW, rc_ordered() - HINT(range_check_max));
         }
         // ---- diluted check (air.rs:540-603)
         const Domain EVERY_ROW_EXCEPT_LAST = every_except_last(1), LAST_ROW = row_from_end(1);
         {
-            const E z = CF(ch[DC_Z]), za = CF(ch[AGG_Z]), aa = CF(ch[AGG_A]);
+            const E z = CHAL(DC_Z), za = CHAL(AGG_Z), aa = CHAL(AGG_A);
             auto un = [&](uint64_t o = 0) { return T(COL_DILUTED_UNORDERED, o); };
             auto od = [&](uint64_t o = 0) { return T(COL_DILUTED_ORDERED, o); };
             auto perm = [&](uint64_t o = 0) { return T(COL_DILUTED_PERMUTATION, o); };
@@ -163,7 +166,7 @@ private:
             ADD(FIRST_ROW, agg() - one);
             ADD(FIRST_ROW, od() - C(0));
             ADD(EVERY_ROW_EXCEPT_LAST, agg(1) - (agg() * (one + za * diff) + aa * diff * diff));
-            ADD(LAST_ROW, agg() - CF(h.diluted_cumulative_value));
+            ADD(LAST_ROW, agg() - HINT(diluted_cumulative_value));
         }
         // ---- Pedersen builtin (air.rs:605-895)
         {
@@ -198,7 +201,7 @@ private:
             ADD(EVERY_2048, sum_y() - CF(pedersen_coord(0, 1)));
             ADD(EVERY_2048, T(COL_NPC, NPC_PEDERSEN_INPUT0_ADDR + 1) - suffix());
             ADD(EVERY_2048_EXCEPT_LAST, T(COL_NPC, 2048 + NPC_PEDERSEN_INPUT0_ADDR) - (T(COL_NPC, NPC_PEDERSEN_OUTPUT_ADDR) + one));
-            ADD(FIRST_ROW, T(COL_NPC, NPC_PEDERSEN_INPUT0_ADDR) - CF(h.initial_pedersen_addr));
+            ADD(FIRST_ROW, T(COL_NPC, NPC_PEDERSEN_INPUT0_ADDR) - HINT(initial_pedersen_addr));
             ADD(EVERY_2048, T(COL_NPC, NPC_PEDERSEN_INPUT1_ADDR + 1) - suffix(256));
             ADD(EVERY_2048, T(COL_NPC, NPC_PEDERSEN_INPUT1_ADDR) - (T(COL_NPC, NPC_PEDERSEN_INPUT0_ADDR) + one));
             ADD(EVERY_2048, T(COL_NPC, NPC_PEDERSEN_OUTPUT_ADDR + 1) - sum_x(511));
@@ -211,7 +214,7 @@ private:
             for (uint64_t k = 1; k < 8; ++k) value = value * offset_size + T(COL_RANGE_CHECK, CYCLE_HEIGHT * k + RC16_COMPONENT);
             ADD(EVERY_128, value - T(COL_NPC, NPC_RANGE_CHECK128_ADDR + 1));
             ADD(EVERY_128_EXCEPT_LAST, T(COL_NPC, 128 + NPC_RANGE_CHECK128_ADDR) - (T(COL_NPC, NPC_RANGE_CHECK128_ADDR) + one));
-            ADD(FIRST_ROW, T(COL_NPC, NPC_RANGE_CHECK128_ADDR) - CF(h.initial_rc_addr));
+            ADD(FIRST_ROW, T(COL_NPC, NPC_RANGE_CHECK128_ADDR) - HINT(initial_rc_addr));
         }
         // ---- bitwise builtin (air.rs:920-1081)
         {
@@ -228,7 +231,7 @@ private:
                     if (chunk == 0 && stream == 0) continue;
                     sum_var = sum_var + bw(8 * chunk + 2 * stream) * pow2(64 * chunk + stream);
                 }
-            ADD(FIRST_ROW, pool_addr(0) - CF(h.initial_bitwise_addr));
+            ADD(FIRST_ROW, pool_addr(0) - HINT(initial_bitwise_addr));
             ADD(BITWISE_TRANSITION, pool_addr(1) - (pool_addr(0) + one));
             ADD(EVERY_128, T(COL_NPC, NPC_BITWISE_X_OR_Y_ADDR) - (pool_addr(3) + one));
             ADD(EVERY_128_EXCEPT_LAST, pool_addr(4) - (T(COL_NPC, NPC_BITWISE_X_OR_Y_ADDR) + one));

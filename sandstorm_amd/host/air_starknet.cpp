@@ -220,7 +220,10 @@ private:
         const Hints h = hints(ch);
         auto T = [&](uint32_t col, uint64_t off) { return E{&g, g.trace(col, (uint32_t)off)}; };
         auto C = [&](uint64_t v) { return E{&g, g.constant_u64(v)}; };
-        auto CF = [&](const Felt &f) { return E{&g, g.constant(f)}; };
+        auto CF = [&](const Felt &f) { return E{&g, g.constant(f)}; };                 // structural constants only
+        // per-proof values: interned by symbol, so that the program's shape is the same for every statement (air_program.hpp)
+#define HINT(name) E{&g, g.runtime_constant(Graph::sym("hint." #name), h.name)}
+#define CHAL(index) E{&g, g.runtime_constant(Graph::sym("challenge", index), ch[index])}
         auto NEG = [&](uint64_t v) { return CF(felt_neg(felt_from_u64(v))); };
         auto pow2 = [&](unsigned k) { return CF(felt_pow(felt_from_u64(2), k)); };
         auto flag = [&](int f) { return T(COL_FLAGS, f) - (T(COL_FLAGS, f + 1) + T(COL_FLAGS, f + 1)); };
@@ -275,23 +278,23 @@ private:
         ADD(ALL_CYCLES, flag(F_OPCODE_RET) * (rc(RC_OFF_OP1) + one - half_offset_size));
         ADD(ALL_CYCLES, flag(F_OPCODE_RET) * (flag(F_PC_JUMP_ABS) + flag(F_DST_REG) + flag(F_OP1_FP) + flag_res_op1_0 - four));
         ADD(ALL_CYCLES, flag(F_OPCODE_ASSERT_EQ) * (npc(NPC_MEM_DST) - aux(AUX_RES)));
-        ADD(FIRST_ROW, aux(AUX_AP) - CF(h.initial_ap));
-        ADD(FIRST_ROW, aux(AUX_FP) - CF(h.initial_ap));
-        ADD(FIRST_ROW, npc(NPC_PC) - CF(h.initial_pc));
-        ADD(LAST_CYCLE, aux(AUX_AP) - CF(h.final_ap));
-        ADD(LAST_CYCLE, aux(AUX_FP) - CF(h.initial_ap));
-        ADD(LAST_CYCLE, npc(NPC_PC) - CF(h.final_pc));
+        ADD(FIRST_ROW, aux(AUX_AP) - HINT(initial_ap));
+        ADD(FIRST_ROW, aux(AUX_FP) - HINT(initial_ap));
+        ADD(FIRST_ROW, npc(NPC_PC) - HINT(initial_pc));
+        ADD(LAST_CYCLE, aux(AUX_AP) - HINT(final_ap));
+        ADD(LAST_CYCLE, aux(AUX_FP) - HINT(initial_ap));
+        ADD(LAST_CYCLE, npc(NPC_PC) - HINT(final_pc));
 
         // ---- memory (air.rs:560-600)
         const Domain EVERY_2ND_EXCEPT_LAST = every_except_last(2), SECOND_LAST_ROW = row_from_end(2), EVERY_8 = every(8);
         {
             auto mem = [&](uint64_t cell, uint64_t k = 0) { return T(COL_MEMORY, 2 * k + cell); };
             auto perm = [&](uint64_t k = 0) { return T(COL_PERMUTATION, 2 * k); };
-            const E z = CF(ch[MEM_Z]), a = CF(ch[MEM_A]);
+            const E z = CHAL(MEM_Z), a = CHAL(MEM_A);
             const E diff = mem(0, 1) - mem(0);
             ADD(FIRST_ROW, (z - (mem(0) + a * mem(1))) * perm() + npc(NPC_PC) + a * npc(NPC_INSTRUCTION) - z);
             ADD(EVERY_2ND_EXCEPT_LAST, (z - (mem(0, 1) + a * mem(1, 1))) * perm(1) - (z - (npc_at(2) + a * npc_at(3))) * perm());
-            ADD(SECOND_LAST_ROW, perm() - CF(h.memory_quotient));
+            ADD(SECOND_LAST_ROW, perm() - HINT(memory_quotient));
             ADD(EVERY_2ND_EXCEPT_LAST, diff * diff - diff);
             ADD(EVERY_2ND_EXCEPT_LAST, (diff - one) * (mem(1) - mem(1, 1)));
             ADD(FIRST_ROW, mem(0) - one);
@@ -303,19 +306,19 @@ private:
         {
             auto ordered = [&](uint64_t k = 0) { return c7(4 * k + RC_ORDERED); };
             auto perm = [&](uint64_t k = 0) { return T(COL_PERMUTATION, 4 * k + 1); };
-            const E z = CF(ch[RC_Z]);
+            const E z = CHAL(RC_Z);
             const E diff = ordered(1) - ordered();
             ADD(FIRST_ROW, (z - ordered()) * perm() + rc(RC_OFF_DST) - z);
             ADD(EVERY_4TH_EXCEPT_LAST, (z - ordered(1)) * perm(1) - (z - c7(4)) * perm());
             ADD(FOURTH_LAST_ROW, perm() - one);
             ADD(EVERY_4TH_EXCEPT_LAST, diff * diff - diff);
-            ADD(FIRST_ROW, ordered() - CF(h.range_check_min));
-            ADD(FOURTH_LAST_ROW, ordered() - CF(h.range_check_max));
+            ADD(FIRST_ROW, ordered() - HINT(range_check_min));
+            ADD(FOURTH_LAST_ROW, ordered() - HINT(range_check_max));
         }
         // ---- diluted check (air.rs:632-690): every 8 rows of columns 7 and 9
         const Domain EVERY_8_EXCEPT_LAST = every_except_last(8), EIGHTH_LAST_ROW = row_from_end(8);
         {
-            const E z = CF(ch[DC_Z]), za = CF(ch[AGG_Z]), aa = CF(ch[AGG_A]);
+            const E z = CHAL(DC_Z), za = CHAL(AGG_Z), aa = CHAL(AGG_A);
             auto un = [&](uint64_t k = 0) { return c7(8 * k + 1); };
             auto od = [&](uint64_t k = 0) { return c7(8 * k + 5); };
             auto perm = [&](uint64_t k = 0) { return T(COL_PERMUTATION, 8 * k + 7); };
@@ -327,7 +330,7 @@ private:
             ADD(FIRST_ROW, agg() - one);
             ADD(FIRST_ROW, od() - C(0));
             ADD(EVERY_8_EXCEPT_LAST, agg(1) - (agg() * (one + za * diff) + aa * diff * diff));
-            ADD(EIGHTH_LAST_ROW, agg() - CF(h.diluted_cumulative_value));
+            ADD(EIGHTH_LAST_ROW, agg() - HINT(diluted_cumulative_value));
         }
 
         // ---- shared shapes (layouts/starknet.py::_bit_unpacking, _subset_sum, _doubling)
@@ -377,7 +380,7 @@ private:
             ADD(EVERY_512, sum_y(0) - CF(pedersen_coord(0, 1)));
             ADD(EVERY_512, npc_at(NPC_PEDERSEN_INPUT0_ADDR + 1) - suffix(0));
             ADD(EVERY_512_EXCEPT_LAST, npc_at(512 + NPC_PEDERSEN_INPUT0_ADDR) - (npc_at(NPC_PEDERSEN_OUTPUT_ADDR) + one));
-            ADD(FIRST_ROW, npc_at(NPC_PEDERSEN_INPUT0_ADDR) - CF(h.initial_pedersen_addr));
+            ADD(FIRST_ROW, npc_at(NPC_PEDERSEN_INPUT0_ADDR) - HINT(initial_pedersen_addr));
             ADD(EVERY_512, npc_at(NPC_PEDERSEN_INPUT1_ADDR + 1) - suffix(256));
             ADD(EVERY_512, npc_at(NPC_PEDERSEN_INPUT1_ADDR) - (npc_at(NPC_PEDERSEN_INPUT0_ADDR) + one));
             ADD(EVERY_512, npc_at(NPC_PEDERSEN_OUTPUT_ADDR + 1) - sum_x(511));
@@ -389,7 +392,7 @@ private:
             for (uint64_t k = 1; k < 8; ++k) value = value * offset_size + c7(32 * k + RC16_COMPONENT);
             ADD(EVERY_256, value - npc_at(NPC_RANGE_CHECK128_ADDR + 1));
             ADD(EVERY_256_EXCEPT_LAST, npc_at(256 + NPC_RANGE_CHECK128_ADDR) - (npc_at(NPC_RANGE_CHECK128_ADDR) + one));
-            ADD(FIRST_ROW, npc_at(NPC_RANGE_CHECK128_ADDR) - CF(h.initial_rc_addr));
+            ADD(FIRST_ROW, npc_at(NPC_RANGE_CHECK128_ADDR) - HINT(initial_rc_addr));
         }
         // ---- ECDSA builtin (air.rs:1042-1503)
         const Domain ALL_ECDSA = every(32768), ALL_ECDSA_EXCEPT_LAST = every_except_last(32768), ALL_EC_OP = every(16384),
@@ -430,7 +433,7 @@ private:
             ADD(ALL_EC_OP, rsuffix(0) * dslope(255) - one);
             ADD(ALL_ECDSA, c8(EC_PUBKEY_X_SQUARED) - dx(0) * dx(0));
             ADD(ALL_ECDSA, dy(0) * dy(0) - (dx(0) * c8(EC_PUBKEY_X_SQUARED) + dx(0) * one + CF(curve_beta())));
-            ADD(FIRST_ROW, npc_at(NPC_ECDSA_PUBKEY_ADDR) - CF(h.initial_ecdsa_addr));
+            ADD(FIRST_ROW, npc_at(NPC_ECDSA_PUBKEY_ADDR) - HINT(initial_ecdsa_addr));
             ADD(ALL_ECDSA, npc_at(NPC_ECDSA_MESSAGE_ADDR) - (npc_at(NPC_ECDSA_PUBKEY_ADDR) + one));
             ADD(ALL_ECDSA_EXCEPT_LAST, npc_at(32768 + NPC_ECDSA_PUBKEY_ADDR) - (npc_at(NPC_ECDSA_MESSAGE_ADDR) + one));
             ADD(ALL_ECDSA, npc_at(NPC_ECDSA_MESSAGE_ADDR + 1) - msuffix(0));
@@ -452,7 +455,7 @@ private:
                     if (chunk == 0 && stream == 0) continue;
                     sum_var = sum_var + c7(cell(chunk, stream)) * pow2(64 * chunk + stream);
                 }
-            ADD(FIRST_ROW, pool_addr(0) - CF(h.initial_bitwise_addr));
+            ADD(FIRST_ROW, pool_addr(0) - HINT(initial_bitwise_addr));
             ADD(BITWISE_TRANSITION, pool_addr(1) - (pool_addr(0) + one));
             ADD(ALL_BITWISE, npc_at(NPC_BITWISE_X_OR_Y_ADDR) - (pool_addr(3) + one));
             ADD(ALL_BITWISE_EXCEPT_LAST, pool_addr(4) - (npc_at(NPC_BITWISE_X_OR_Y_ADDR) + one));
@@ -468,7 +471,7 @@ private:
             const Cell rx = cell8(64, OP_R_PARTIAL_SUM_X), ry = cell8(64, OP_R_PARTIAL_SUM_Y), rslope = cell8(64, OP_R_PARTIAL_SUM_SLOPE),
                        rinv = cell8(64, OP_R_PARTIAL_SUM_X_DIFF_INV), msuffix = cell8(64, OP_M_SUFFIX);
             const E b0 = msuffix(0) - (msuffix(1) + msuffix(1));
-            ADD(FIRST_ROW, npc_at(NPC_EC_OP_P_X_ADDR) - CF(h.initial_ec_op_addr));
+            ADD(FIRST_ROW, npc_at(NPC_EC_OP_P_X_ADDR) - HINT(initial_ec_op_addr));
             ADD(ALL_EC_OP_EXCEPT_LAST, npc_at(16384 + NPC_EC_OP_P_X_ADDR) - (npc_at(NPC_EC_OP_P_X_ADDR) + C(7)));
             ADD(ALL_EC_OP, npc_at(NPC_EC_OP_P_Y_ADDR) - (npc_at(NPC_EC_OP_P_X_ADDR) + one));
             ADD(ALL_EC_OP, npc_at(NPC_EC_OP_Q_X_ADDR) - (npc_at(NPC_EC_OP_P_Y_ADDR) + one));
@@ -513,7 +516,7 @@ private:
             std::vector<Factor> D14_17 = D14; D14_17.insert(D14_17.end(), D17.begin(), D17.end());
             const Domain POSEIDON_ADDR_STEP{D15, {F(64)}}, POSEIDON_PARTIAL1_SQUARING{D14_17, {F(16)}}, POSEIDON_HALF_FULL_ROUND_TRANSITION{{F(256, 3, 4)}, {F(64)}};
             const Domain POSEIDON_PARTIAL_ROUND0{D19, {F(8)}}, POSEIDON_PARTIAL_ROUND1{D20, {F(16)}};
-            ADD(FIRST_ROW, addr(0) - CF(h.initial_poseidon_addr));
+            ADD(FIRST_ROW, addr(0) - HINT(initial_poseidon_addr));
             ADD(POSEIDON_ADDR_STEP, addr(1) - (addr(0) + one));
             ADD(EVERY_512_EXCEPT_LAST, npc_at(512 + NPC_POSEIDON_ADDRS[0]) - (addr(5) + one));
             for (int j = 0; j < 3; ++j) ADD(EVERY_64, full(j) * full(j) - full_sq(j));

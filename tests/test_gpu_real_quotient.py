@@ -26,7 +26,7 @@ def _rand(rng, count):                          # any limbs with the top one bel
     return np.ascontiguousarray(v)
 
 
-@pytest.mark.parametrize("layout,log_n", [("starknet", 16), ("recursive", 16), ("starknet", 12)])
+@pytest.mark.parametrize("layout,log_n", [("starknet", 16), ("recursive", 16), ("starknet", 15)])
 def test_real_composition_program_vs_oracle(oracle, layout, log_n):
     from sandstorm_amd import backend as be, hostlib
     if layout == "starknet":
