@@ -91,3 +91,79 @@ void or_deep_compose(const fp_t *const *trace_lde, const fp_t *const *comp_lde, 
     }
     free(zs);
 }
+
+/* The same DEEP composition with ONE field inversion per point (Montgomery's trick over the point's denominators)
+ * instead of one per (point, cell): the definition above is what the tests hold the GPU kernel to at small sizes; this
+ * is what the whole-pipeline CPU runs use (bench.py's cpu_baseline, the multi-rank gloo tests), checked equal to the
+ * definition in tests/test_oracle_defs.py.  row0 / nrows: only the points [row0, row0 + nrows) of the domain are
+ * computed, into out[0 .. nrows) from trace_lde[c][0 .. nrows) (row-block form of the sharded prover). */
+void or_deep_compose_rows(const fp_t *const *trace_lde, const fp_t *const *comp_lde, unsigned log_n,
+                          unsigned log_blowup, fp_t offset, const uint32_t *mask_col,
+                          const uint32_t *mask_off, size_t nmask, const fp_t *ood_trace,
+                          const fp_t *coeff_trace, size_t ncomp, const fp_t *ood_comp,
+                          const fp_t *coeff_comp, fp_t z, uint64_t row0, uint64_t nrows, fp_t *out) {
+    unsigned log_N = log_n + log_blowup;
+    fp_t wn = fp_root_of_unity(log_n), wN = fp_root_of_unity(log_N);
+    /* distinct denominators: one per distinct row offset, plus the composition point */
+    size_t ndist = 0;
+    uint32_t *dist_off = (uint32_t *)malloc(sizeof(uint32_t) * (nmask + 1));
+    size_t *which = (size_t *)malloc(sizeof(size_t) * (nmask + 1));
+    for (size_t j = 0; j < nmask; ++j) {
+        size_t k = 0;
+        while (k < ndist && dist_off[k] != mask_off[j]) ++k;
+        if (k == ndist) dist_off[ndist++] = mask_off[j];
+        which[j] = k;
+    }
+    fp_t *zs = (fp_t *)malloc(sizeof(fp_t) * (ndist + 1));
+    for (size_t k = 0; k < ndist; ++k) zs[k] = fp_mul(z, fp_pow_u64(wn, dist_off[k]));
+    zs[ndist] = fp_pow_u64(z, (uint64_t)ncomp);
+    const size_t nd = ndist + 1;
+#pragma omp parallel
+    {
+        fp_t *den = (fp_t *)malloc(sizeof(fp_t) * nd), *pre = (fp_t *)malloc(sizeof(fp_t) * nd);
+#pragma omp for schedule(static)
+        for (uint64_t r = 0; r < nrows; ++r) {
+            fp_t x = fp_mul(offset, fp_pow_u64(wN, row0 + r));
+            fp_t run = FP_ONE;
+            for (size_t k = 0; k < nd; ++k) { den[k] = fp_sub(x, zs[k]); pre[k] = run; run = fp_mul(run, den[k]); }
+            fp_t inv = fp_inv(run);
+            for (size_t k = nd; k-- > 0;) { fp_t d = den[k]; den[k] = fp_mul(inv, pre[k]); inv = fp_mul(inv, d); }
+            fp_t acc = {{0, 0, 0, 0}};
+            for (size_t j = 0; j < nmask; ++j) {
+                fp_t num = fp_sub(trace_lde[mask_col[j]][r], ood_trace[j]);
+                acc = fp_add(acc, fp_mul(coeff_trace[j], fp_mul(num, den[which[j]])));
+            }
+            for (size_t k = 0; k < ncomp; ++k) {
+                fp_t num = fp_sub(comp_lde[k][r], ood_comp[k]);
+                acc = fp_add(acc, fp_mul(coeff_comp[k], fp_mul(num, den[ndist])));
+            }
+            out[r] = acc;
+        }
+        free(den); free(pre);
+    }
+    free(zs); free(which); free(dist_off);
+}
+
+/* out[j] = T_{mask_col[j]}(z * w_n^{mask_off[j]}) from natural-order coefficient columns (Horner per cell) */
+void or_ood_eval(const fp_t *const *coeffs, unsigned log_n, const uint32_t *mask_col, const uint32_t *mask_off,
+                 size_t nmask, fp_t z, fp_t *out) {
+    const size_t n = (size_t)1 << log_n;
+    fp_t wn = fp_root_of_unity(log_n);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t j = 0; j < nmask; ++j)
+        out[j] = or_poly_eval(coeffs[mask_col[j]], n, fp_mul(z, fp_pow_u64(wn, mask_off[j])));
+}
+
+/* out[i] = 1 / (offset * w_N^i - c), i < 2^log_N (the full-length zerofier tables); batch inversion per chunk */
+void or_inverse_table(unsigned log_N, fp_t offset, fp_t c, fp_t *out) {
+    const size_t N = (size_t)1 << log_N, chunk = 1024;
+    fp_t w = fp_root_of_unity(log_N);
+#pragma omp parallel for schedule(static)
+    for (size_t b = 0; b < (N + chunk - 1) / chunk; ++b) {
+        const size_t lo = b * chunk, hi = lo + chunk < N ? lo + chunk : N;
+        fp_t pre[1024], x = fp_mul(offset, fp_pow_u64(w, (uint64_t)lo)), run = FP_ONE;
+        for (size_t i = lo; i < hi; ++i) { out[i] = fp_sub(x, c); pre[i - lo] = run; run = fp_mul(run, out[i]); x = fp_mul(x, w); }
+        fp_t inv = fp_inv(run);
+        for (size_t i = hi; i-- > lo;) { fp_t d = out[i]; out[i] = fp_mul(inv, pre[i - lo]); inv = fp_mul(inv, d); }
+    }
+}

@@ -19,6 +19,7 @@
 #include "../../include/sandstorm_hip.h"
 #include "fp252.h"
 #include "kernels.h"
+#include "quotient_gen.h"
 #include "ext_scan.h"
 
 using namespace ss;
@@ -994,6 +995,64 @@ ss_status ss_inverse_table(ss_ctx *ctx, uint32_t log_N, const uint64_t offset[4]
     return SS_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// the compiled kernels, by program
+const QGenKernel *quotient_gen_find(const uint32_t *code, uint32_t n_instr) {
+    uint64_t h = 0xcbf29ce484222325ull;                                  // FNV-1a over the code words (tools/gen_quotient.py)
+    for (size_t k = 0; k < 2 * (size_t)n_instr; ++k)
+        for (int b = 0; b < 4; ++b) h = (h ^ ((code[k] >> (8 * b)) & 0xffu)) * 0x100000001b3ull;
+    const QGenKernel *all[] = {&quotient_gen_starknet(), &quotient_gen_recursive()};
+    for (const QGenKernel *k : all)
+        if (k->code_hash == h && k->n_instr == n_instr) return k;
+    return nullptr;
+}
+
+ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
+                                 uint32_t ncols, uint32_t log_N, uint32_t log_blowup, const uint64_t offset[4], uint64_t *d_out) {
+    const uint64_t N = 1ull << log_N;
+    // constants in limb form: 9 x 28-bit limbs of the interchange image (add / sub / mov) and of the R280 form (fl_mul_r280)
+    const uint32_t nc = prog->n_consts ? prog->n_consts : 1u;
+    std::vector<uint32_t> host((size_t)nc * QG_CONST_STRIDE + 2 * (size_t)(prog->n_tables ? prog->n_tables : 1u), 0u);
+    for (uint32_t k = 0; k < prog->n_consts; ++k) {
+        const Fp c = fp_from_limbs64(prog->consts + 4 * (size_t)k);
+        const Fl a = fl_from_fp(c), r = fl_to_r280(c);
+        for (int j = 0; j < 9; ++j) { host[(size_t)k * QG_CONST_STRIDE + j] = a.l[j]; host[(size_t)k * QG_CONST_STRIDE + 12 + j] = r.l[j]; }
+    }
+    uint32_t *tdesc = host.data() + (size_t)nc * QG_CONST_STRIDE;
+    for (uint32_t t = 0; t < prog->n_tables; ++t) {
+        tdesc[2 * t] = prog->table_desc[2 * t];
+        tdesc[2 * t + 1] = (uint32_t)((1ull << prog->table_desc[2 * t + 1]) - 1ull);
+    }
+    ss_status st = ctx->ensure_scratch(host.size() * 4 + 256);
+    if (st != SS_OK) return st;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->scratch, host.data(), host.size() * 4, hipMemcpyHostToDevice, s));
+    QGenArgs a;
+    for (int c = 0; c < QG_MAX_COLS; ++c) a.cols[c] = c < (int)ncols ? (const Fp *)d_lde_cols[c] : nullptr;
+    a.tables = (const Fp *)prog->d_tables;
+    a.consts = (const uint32_t *)ctx->scratch;
+    a.tdesc = a.consts + (size_t)nc * QG_CONST_STRIDE;
+    a.out = (Fp *)d_out;
+    a.log_N = log_N; a.log_blowup = log_blowup;
+    // one workgroup per CU and SIMD slot the kernel's register budget allows; SS_QG_BLOCKS overrides (experiments)
+    uint64_t blocks = 256;
+    if (const char *e = getenv("SS_QG_BLOCKS")) blocks = strtoull(e, nullptr, 10);
+    if (blocks * QG_THREADS > N) blocks = N / QG_THREADS;
+    if (blocks == 0) blocks = 1;
+    a.offset = offset ? fp_from_limbs64(offset) : fp_one();
+    a.w = root_of_unity(log_N);
+    a.wstep = fp_pow_u64(a.w, blocks * QG_THREADS);
+    ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
+    HIP_TRY(gen.launch(s, a, (uint32_t)blocks));
+    HIP_TRY(hipStreamSynchronize(s));      // the staging vector goes away on return
+    return SS_OK;
+}
+}  // namespace
+
+extern "C" {
+
 ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
                            uint32_t ncols, uint32_t log_n, uint32_t log_blowup, const uint64_t offset[4],
                            uint64_t *d_out) {
@@ -1019,6 +1078,13 @@ ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64
         }
     }
     const uint64_t N = 1ull << log_N;
+    // A layout's composition constraint has a compiled kernel (quotient_gen_<layout>.hip, generated from exactly this
+    // program): recognised by the hash of its code words.  Everything per proof (constants, tables, columns, size) is data.
+    if (!getenv("SS_QUOTIENT_INTERPRET")) {
+        const QGenKernel *gen = quotient_gen_find(prog->code, prog->n_instr);
+        if (gen && gen->n_consts == prog->n_consts && gen->n_tables == prog->n_tables && gen->ncols <= ncols && N >= (uint64_t)QG_THREADS)
+            return eval_quotient_compiled(ctx, *gen, prog, d_lde_cols, ncols, log_N, log_blowup, offset, d_out);
+    }
     uint64_t lanes = 256ull * 256 * 4;                 // 4 workgroups of 256 per CU
     if (lanes > N) lanes = N < 256 ? 256 : N;
     const size_t code_b = ((size_t)prog->n_instr + 1) * 32, const_b = (size_t)(prog->n_consts ? prog->n_consts : 1) * 32;

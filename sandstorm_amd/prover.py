@@ -192,7 +192,7 @@ class Prover:
         comp_coeff = coin.draw()
         proof.composition_coeff = comp_coeff
         program, tables, table_desc = air.build_program(n, challenges, comp_coeff)
-        if tables is None or isinstance(tables, (be.DeviceBuffer, be.DeviceView)):
+        if tables is None or hasattr(tables, "ptr"):           # already resident (a buffer of the context)
             d_tables = tables
         else:
             d_tables = ctx.column(tables) if len(tables) else None

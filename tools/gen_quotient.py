@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Compile a layout's composition constraint into straight-line HIP ("stop interpreting the AIR").
+
+The constraint program of a layout is static: `ssh::lower` (sandstorm_amd/host/air_program.cpp) turns the `Expr` DAG of
+layouts/src/{starknet,recursive}/air.rs into the same instruction sequence for every statement of the layout - per-proof
+values (challenges, hints, powers of the composition coefficient, powers of the trace generator) are interned by symbol,
+not by value, so they only change the CONSTANT TABLE, never the code.  This tool takes that sequence from the C++ host
+(`ssh_air_dump`) and writes sandstorm_amd/csrc/quotient_gen_<layout>.hip: one kernel whose body is the program unrolled,
+with
+
+  * the four accumulators and the scratch slots as register-resident 9 x 28-bit lazy values (no slot file in HBM),
+  * operand kinds, column numbers, row offsets and table numbers as immediates,
+  * constants read through the scalar cache, pre-limbed on the host (R256 limbs for add / sub / mov, R280 limbs for the
+    cheaper fl_mul_r280),
+  * the weak reductions of the lazy form placed here, at generation time, by the bound rules of csrc/quotient.hip.
+
+ss_eval_quotient recognises a program by the hash of its code words and launches the compiled kernel for it; any other
+program (the mini AIR, the random programs of the parity tests, a trace too short for the layout's usual shape) runs on
+the interpreter of csrc/quotient.hip.  Both paths are held to the oracle's constraint VM (tests/test_gpu_real_quotient.py).
+
+Usage (build container, after `make -C sandstorm_amd/host`):  python tools/gen_quotient.py [layout ...]
+The generated sources are committed; the build does not run this tool.
+"""
+import hashlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+OP_MOV, OP_ADD, OP_SUB, OP_RSUB, OP_MUL, OP_INV, OP_ST, OP_OUT = range(8)
+SRC_ACC, SRC_SLOT, SRC_CONST, SRC_TRACE, SRC_TABLE, SRC_X = range(6)
+MAX_BOUND = 8           # csrc/quotient.hip VM_MAX_BOUND: value < 2 b p, limbs < b 2^28
+
+
+def code_hash(code):
+    """FNV-1a over the 32-bit code words: what ss_eval_quotient computes to recognise the program"""
+    h = 0xcbf29ce484222325
+    for w in code:
+        for k in range(4):
+            h = ((h ^ ((int(w) >> (8 * k)) & 0xff)) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def template_program(layout):
+    """the layout's lowered program at a size and statement where it has its usual shape"""
+    import numpy as np
+    from oracle import oracle_py as oracle              # only its to_mont helper
+    from sandstorm_amd import hostlib
+    P = 2**251 + 17 * 2**192 + 1
+    ch = [oracle.to_mont([pow(7, 11 + 3 * i, P)])[0] for i in range(6)]
+    alpha = oracle.to_mont([pow(5, 77, P)])[0]
+    if layout == "starknet":
+        from test_layout_starknet import starknet_example
+        _, _, pi = starknet_example(11)
+        air = hostlib.StarknetHostAir(None, pi, 21)
+        n = 1 << 21
+    else:
+        from test_layout_recursive import load_run
+        _, _, pi = load_run()
+        air = hostlib.RecursiveHostAir(None, pi, 18)
+        n = 1 << 18
+    code, consts, n_slots, specs = air.dump(n, ch, alpha)
+    ncols = air.num_base_columns + air.num_extension_columns
+    air.close()
+    return np.asarray(code, dtype=np.uint32), len(consts), n_slots, len(specs), ncols
+
+
+def generate(layout):
+    code, n_consts, n_slots, n_tables, ncols = template_program(layout)
+    n_instr = len(code) // 2
+    out = []
+    emit = out.append
+    bound = [1, 1, 1, 1]
+    stats = {"mul": 0, "mulr": 0, "reduce": 0, "loads": 0}
+
+    def reduce_acc(d):
+        emit("    acc%d = fl_weak_reduce(acc%d);" % (d, d))
+        bound[d] = 1
+        stats["reduce"] += 1
+
+    for pc in range(n_instr):
+        w0, w1 = int(code[2 * pc]), int(code[2 * pc + 1])
+        op, d, kind = w0 & 0xff, (w0 >> 8) & 0xf, (w0 >> 12) & 0xf
+        assert op <= OP_OUT and d < 4
+        v = "acc%d" % d
+        # ---- the operand: an expression of type Fl and its lazy bound
+        src, sb, src_acc = None, 1, None
+        if op <= OP_MUL:
+            if kind == SRC_ACC:
+                src_acc = w1 & 3
+                src, sb = "acc%d" % src_acc, bound[src_acc]
+            elif kind == SRC_SLOT:
+                assert w1 < n_slots
+                src = "s%d" % w1
+            elif kind == SRC_CONST:
+                assert w1 < n_consts
+                src = ("QG_CONST_R280(%d)" if op == OP_MUL else "QG_CONST(%d)") % w1
+            elif kind == SRC_TRACE:
+                col, off = w1 >> 24, w1 & 0xffffff
+                assert col < ncols
+                src = "QG_TRACE(%d, %du)" % (col, off)
+                stats["loads"] += 1
+            elif kind == SRC_TABLE:
+                assert w1 < n_tables
+                src = "QG_TABLE(%d)" % w1
+                stats["loads"] += 1
+            else:
+                assert kind == SRC_X
+                src = "x"
+
+        def reduce_src():
+            """weakly reduce the operand; an accumulator operand is reduced in place (same value mod p)"""
+            nonlocal sb
+            assert src_acc is not None
+            if src_acc != d:
+                reduce_acc(src_acc)
+            sb = 1
+
+        if op == OP_MOV:
+            emit("    %s = %s;" % (v, src))
+            bound[d] = sb
+        elif op == OP_ADD:
+            if src_acc == d:                                   # v + v
+                if 2 * bound[d] > MAX_BOUND:
+                    reduce_acc(d)
+                emit("    %s = fl_add(%s, %s);" % (v, v, v))
+                bound[d] *= 2
+            else:
+                if bound[d] + sb > MAX_BOUND:
+                    reduce_acc(d)
+                if bound[d] + sb > MAX_BOUND:
+                    reduce_src()
+                emit("    %s = fl_add(%s, %s);" % (v, v, src))
+                bound[d] += sb
+        elif op == OP_SUB:
+            if src_acc == d:                                   # v - v
+                reduce_acc(d)
+                emit("    %s = fl_sub_c<2, 1>(%s, %s);" % (v, v, v))
+                bound[d] = 2
+            else:
+                if sb > 1:
+                    reduce_src()
+                if bound[d] + 1 > MAX_BOUND:
+                    reduce_acc(d)
+                emit("    %s = fl_sub_c<2, 1>(%s, %s);" % (v, v, src))
+                bound[d] += 1
+        elif op == OP_RSUB:
+            assert src_acc != d
+            if bound[d] > 1:
+                reduce_acc(d)
+            if sb + 1 > MAX_BOUND:
+                reduce_src()
+            emit("    %s = fl_sub_c<2, 1>(%s, %s);" % (v, src, v))
+            bound[d] = sb + 1
+        elif op == OP_MUL:
+            if src_acc == d:                                   # v * v: the square routine wants a normalised value
+                if bound[d] > 1:
+                    reduce_acc(d)
+                emit("    %s = fl_sqr(%s);" % (v, v))
+            elif kind == SRC_CONST:
+                emit("    %s = fl_mul_r280(%s, %s);" % (v, v, src))
+                stats["mulr"] += 1
+            elif sb > 1 and bound[d] == 1:                      # the lazy side may be either factor
+                emit("    %s = fl_mul(%s, %s);" % (v, src, v))
+            else:
+                if sb > 1:
+                    reduce_src()
+                emit("    %s = fl_mul(%s, %s);" % (v, v, src))
+            stats["mul"] += 1
+            bound[d] = 1
+        elif op == OP_INV:
+            if bound[d] > 1:
+                reduce_acc(d)
+            else:
+                emit("    %s = fl_weak_reduce(%s);" % (v, v))
+            emit("    %s = fn_inv(%s);" % (v, v))
+            bound[d] = 1
+        elif op == OP_ST:
+            assert w1 < n_slots
+            if bound[d] > 1:
+                reduce_acc(d)
+            emit("    s%d = %s;" % (w1, v))
+        else:
+            emit("    qstore(a.out + i, fl_to_fp(%s));" % v)
+    body = "\n".join(out)
+    h = code_hash(code)
+    slots = "".join("    Fl s%d = fl_zero();\n" % s for s in range(n_slots))
+    src = '''// GENERATED by tools/gen_quotient.py - DO NOT EDIT; regenerate with `python tools/gen_quotient.py %(layout)s`.
+//
+// The composition constraint of the `%(layout)s` layout (layouts/src/%(layout)s/air.rs; lowered by
+// sandstorm_amd/host/air_%(layout)s.cpp + air_program.cpp) as straight-line code for gfx950: %(n_instr)d program
+// instructions, %(mul)d multiplications (%(mulr)d of them by a constant in R280 form), %(loads)d trace / table operand
+// loads, %(reduce)d weak reductions placed at generation time, %(n_slots)d register-resident scratch values.
+// Code hash (FNV-1a of the program's code words) 0x%(hash)016x: ss_eval_quotient launches this kernel for exactly
+// that program and interprets any other.
+#include "quotient_gen.h"
+
+namespace ss {
+namespace {
+
+__global__ __launch_bounds__(QG_THREADS) void quotient_%(layout)s_kernel(QGenArgs a) {
+    QG_PROLOGUE
+    Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
+%(slots)s    QG_POINT_LOOP_BEGIN
+%(body)s
+    QG_POINT_LOOP_END
+}
+
+hipError_t launch_%(layout)s(hipStream_t st, const QGenArgs &a, uint32_t blocks) {
+    hipLaunchKernelGGL(quotient_%(layout)s_kernel, dim3(blocks), dim3(QG_THREADS), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+const QGenKernel &quotient_gen_%(layout)s() {
+    static const QGenKernel k = {"%(layout)s", 0x%(hash)016xull, %(n_instr)du, %(n_consts)du, %(n_tables)du, %(ncols)du, launch_%(layout)s};
+    return k;
+}
+
+}  // namespace ss
+''' % dict(layout=layout, n_instr=n_instr, n_slots=n_slots, n_consts=n_consts, n_tables=n_tables, ncols=ncols, hash=h, slots=slots,
+           body=body, **stats)
+    path = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s.hip" % layout)
+    with open(path, "w") as f:
+        f.write(src)
+    print("%s: %d instructions, %d multiplications (%d by constants), %d loads, %d reductions, hash %016x -> %s"
+          % (layout, n_instr, stats["mul"], stats["mulr"], stats["loads"], stats["reduce"], h, os.path.relpath(path, ROOT)))
+
+
+if __name__ == "__main__":
+    for name in (sys.argv[1:] or ["starknet", "recursive"]):
+        generate(name)
