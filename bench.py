@@ -61,47 +61,72 @@ def synth_columns(device, ncols, log_n, seed):
     return t
 
 
-def cpu_baseline(layout, log_n_full, ncols):
-    """The CPU oracle (OpenMP port of the same algorithms) on a bounded sample: the LDE,
-    row-hash, Merkle and FRI-fold stages at 2^16 rows, scaled to the full trace length
-    (n log n for the NTTs, n for the rest).  Quotient + DEEP are NOT included: a lower bound."""
+def _sample_statement(layout, log_steps):
+    """the public input of the bench statements: the reference's example run re-declared for this layout / step count
+    (it only feeds constants of the constraint program)"""
+    from sandstorm_amd import public_input
+    pi = public_input.AirPublicInput.from_json(os.path.join(ROOT, "tests", "golden", "air_public_input_array_sum.json"))
+    pi.n_steps = 1 << log_steps
+    if layout == "starknet":
+        from sandstorm_amd.layouts import starknet as sk
+        return sk, sk.example_public_input(pi)
+    from sandstorm_amd.layouts import recursive as rec
+    return rec, pi
+
+
+def python_host_proof(ctx, layout, log_steps, proofs=1):
+    """One whole proof of the layout's real AIR on synthetic columns through the Python host (sandstorm_amd/prover.py)
+    on `ctx` - a backend.Context (the HIP kernels) or the oracle's CpuContext (the CPU port): the same host code either
+    way.  -> seconds per proof (the AIR's tables and the input columns are set up outside the timed region, as for the
+    GPU runs)."""
     import numpy as np
-    # the oracle's loops are short at this sample size: cap the OpenMP team (must precede libgomp's start-up)
-    threads = min(os.cpu_count() or 1, 32)
+    from sandstorm_amd import backend as be, extension
+    from sandstorm_amd.prover import Claim, ProofOptions, Prover
+    from tests.util import random_column
+    L, pi = _sample_statement(layout, log_steps)
+    n = 16 << log_steps
+    air = L.make_air(ctx, pi, n)
+    base = be.Matrix.from_host(ctx, [random_column(n, c) for c in range(air.num_base_columns)])
+    aux = [ctx.column(random_column(n, 40 + c)) for c in range(5 if layout == "recursive" else 3)]
+    tc = extension.TraceColumns(aux[0], aux[1], aux[2], n, *(aux[3:5] if layout == "recursive" else ()))
+    if layout == "recursive":
+        tree, coin = be.FriendlyMerkleTree, be.COIN_CAIRO
+    else:
+        tree, coin = be.LeafVariantMerkleTree, be.COIN_SOLIDITY
+    prover = Prover(ctx, Claim(air, tree, coin), ProofOptions())
+    build = lambda ch: extension.build_extension_columns(layout, ctx, tc, ch, check=False)
+    seed = bytes(range(32))
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(proofs):
+        prover.prove(seed, base, build)
+    ctx.sync()
+    return (time.perf_counter() - t0) / proofs
+
+
+def cpu_baseline(layout, log_steps_full, gpu_ctx):
+    """The CPU port timed beside the GPU, MEASURED on a whole proof: the oracle (C + OpenMP restatement of every stage,
+    oracle/cpu_context.py) driven by the same host code, on the layout's real AIR at a reduced step count - LDE, extension
+    scans, row hashing, trees, the constraint program, out-of-domain evaluation, DEEP, FRI, proof of work, openings - and
+    the GPU on exactly that sample.  `value` scales the measured CPU time to the bench workload's size (n log n); the
+    measured pair is reported as it is."""
+    threads = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     threads = int(os.environ["OMP_NUM_THREADS"])
-    from oracle import oracle_py as oracle
-    from tests.util import random_column
-    sl = min(18, log_n_full)
-    n = 1 << sl
-    g = oracle.to_mont([3])[0]
-    cols = [random_column(n, c) for c in range(ncols)]
-    oracle.lde(cols[0][:256], 1, g)
-    t0 = time.perf_counter()
-    ldes = [oracle.lde(c, 1, g)[0] for c in cols]
-    t_lde = time.perf_counter() - t0
-    kind = 3 if layout == "recursive" else 1
-    tree = 2 if layout == "recursive" else 1
-    t0 = time.perf_counter()
-    leaves = oracle.hash_rows(kind, ldes)
-    oracle.merkle_build(tree, 22, 0, leaves)
-    comp = oracle.hash_rows(kind, ldes[:2])
-    oracle.merkle_build(tree, 22, 0, comp)
-    t_hash = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    ev, off = ldes[0], g
-    for _ in range(2):
-        ev = oracle.fri_fold(ev, 8, g, off)
-    t_fri = time.perf_counter() - t0
-    scale_n = float(1 << (log_n_full - sl))
-    scale_ntt = scale_n * (log_n_full + 0.5) / (sl + 0.5)
-    # the proof has ~1.4x the trace-LDE NTT work (composition, OOD, DEEP-free FRI) and 3 trees
-    est = 1.4 * t_lde * scale_ntt + 1.5 * t_hash * scale_n + 1.2 * t_fri * scale_n
-    ops = ncols * (ntt_field_ops(sl) + ntt_field_ops(sl + 1))
-    return {"value": est, "unit": "s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
-            "ntt_gfield_ops_per_s": ops / t_lde / 1e9,
-            "sample": "oracle (C, OpenMP) LDE %dx2^%d %.2fs + row-hash/Merkle %.2fs + FRI %.2fs, scaled to 2^%d rows; "
-                      "omits quotient+DEEP (lower bound on a CPU prove)" % (ncols, sl, t_lde, t_hash, t_fri, log_n_full)}
+    from oracle.cpu_context import CpuContext
+    # starknet needs 2^17 steps before its diluted check fits (its smallest statement); recursive: the example's 2^14
+    sample = min(log_steps_full, 17 if layout == "starknet" else 14)
+    t_cpu = python_host_proof(CpuContext(), layout, sample)
+    python_host_proof(gpu_ctx, layout, sample)                      # warm: plans, tables, pool
+    t_gpu = python_host_proof(gpu_ctx, layout, sample, proofs=3)
+    ls, lf = sample + 4, log_steps_full + 4
+    scale = float(1 << (lf - ls)) * (lf + 1) / (ls + 1)
+    return {"value": t_cpu * scale, "unit": "s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "measured_sample_s": t_cpu, "gpu_same_sample_s": t_gpu, "sample_speedup": t_cpu / t_gpu,
+            "sample": "MEASURED whole proof (every stage incl. constraint program and DEEP) of the %s layout's real AIR at 2^%d steps "
+                      "(2^%d trace rows), CLI-default options, by the oracle (C + OpenMP port, untuned, not the reference binary) "
+                      "through the same Python host as the GPU: %.2f s on %d threads; the GPU on the same sample %.4f s; "
+                      "`value` = that CPU time x %.1f (n log n to 2^%d steps)" % (layout, sample, ls, t_cpu, threads, t_gpu, scale, log_steps_full)}
 
 
 def main():
@@ -284,7 +309,7 @@ def main():
             out["config"]["reference_published"] = ("186 ms for the 128-step array-sum proof on the author's machine "
                                                     "(BASELINE.md section 1: other hardware, older CLI, the real AIR)")
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(layout, log_n, ncols)
+            out["cpu_baseline"] = cpu_baseline(layout, log_steps, ctx)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -63,3 +63,53 @@ def test_real_composition_program_vs_oracle(oracle, layout, log_n):
     got = out.download(np.uint64, (N, 4))
     assert np.array_equal(got, want)
     ctx.close()
+
+
+@pytest.mark.parametrize("layout", ["starknet", "recursive"])
+def test_compiled_kernel_is_the_interpreter(oracle, layout, monkeypatch):
+    """the generated straight-line kernel (csrc/quotient_gen_<layout>.hip, picked by the program's code hash) and the
+    interpreter (csrc/quotient.hip, forced with SS_QUOTIENT_INTERPRET) give the same composition at every point of a
+    2^19-point domain; the program at this size IS the one the kernel was generated from (its hash is checked here
+    against the generator's), so the first run really is the compiled path"""
+    import sys
+    from sandstorm_amd import backend as be, hostlib
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_quotient
+    log_n = 18
+    if layout == "starknet":
+        from sandstorm_amd.layouts import starknet as lay
+        _, _, pi = starknet_example(11)
+        cpp = hostlib.StarknetHostAir(None, pi, log_n)
+    else:
+        from sandstorm_amd.layouts import recursive as lay
+        _, _, pi = load_run()
+        cpp = hostlib.RecursiveHostAir(None, pi, log_n)
+    n, N = 1 << log_n, 2 << log_n
+    code, consts, n_slots, specs = cpp.dump(n, [oracle.to_mont([c])[0] for c in CHALLENGES], oracle.to_mont([pow(3, 99, P)])[0])
+    cpp.close()
+    with open(os.path.join(os.path.dirname(gen_quotient.ROOT + "/x"), "sandstorm_amd", "csrc", "quotient_gen_%s.hip" % layout)) as f:
+        assert ("0x%016x" % gen_quotient.code_hash(code)) in f.read(), "the committed kernel was generated from another program"
+    tables = lay.Tables(n)
+    rng = np.random.default_rng(5)
+    tabs, desc, off = [], [], 0
+    for spec in specs:
+        t = _rand(rng, tables.length(spec))
+        desc += [off, len(t).bit_length() - 1]
+        off += len(t)
+        tabs.append(t)
+    tab = np.concatenate(tabs)
+    lde = [_rand(rng, N) for _ in range(10)]
+    g = oracle.to_mont([3])[0]
+    ctx = be.Context(0)
+    m = be.Matrix.from_host(ctx, lde)
+    d_tab = ctx.column(tab)
+    prog = _Prog(code, [int(v) for v in oracle.from_mont(consts)], n_slots)
+    out = ctx.alloc(32 * N)
+    ctx.eval_quotient(prog, d_tab, desc, m.cols, log_n, 1, g, out)
+    compiled = out.download(np.uint64, (N, 4))
+    monkeypatch.setenv("SS_QUOTIENT_INTERPRET", "1")
+    ctx.zero(out)
+    ctx.eval_quotient(prog, d_tab, desc, m.cols, log_n, 1, g, out)
+    interpreted = out.download(np.uint64, (N, 4))
+    assert compiled.any() and np.array_equal(compiled, interpreted)
+    ctx.close()
