@@ -70,7 +70,7 @@ enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
 const char *ss_last_error(void);
 /* ABI version of this header; bump on any signature change.  ss_abi_version() of the loaded
  * library must equal SS_ABI_VERSION of the header the caller was built against. */
-#define SS_ABI_VERSION 3u
+#define SS_ABI_VERSION 4u
 uint32_t ss_abi_version(void);
 
 /* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;
@@ -202,6 +202,15 @@ ss_status ss_inverse_table(ss_ctx *ctx, uint32_t log_N, const uint64_t offset[4]
 ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
                            uint32_t ncols, uint32_t log_n, uint32_t log_blowup,
                            const uint64_t offset[4], uint64_t *d_out);
+/* Row-block form, for one proof sharded over several GPUs (the reference has only rayon loops over
+ * rows to replace, crypto/src/merkle/utils.rs:30-32).  The evaluation domain is cut into contiguous row blocks; a
+ * rank evaluates points row0 .. row0 + nrows from column BLOCKS: d_col_blocks[c][k] = LDE row (row0 + k) mod N of
+ * column c, k < block_rows, where block_rows >= nrows + (largest row offset of the program << log_blowup) - the rows
+ * behind the block that its constraints reach (wrap-around included) travel with it.  Tables stay whole and are
+ * indexed by the global row.  d_out[k] = what ss_eval_quotient writes at row0 + k, bit for bit. */
+ss_status ss_eval_quotient_rows(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_col_blocks,
+                                uint32_t ncols, uint32_t log_n, uint32_t log_blowup, const uint64_t offset[4],
+                                uint64_t row0, uint64_t nrows, uint64_t block_rows, uint64_t *d_out);
 
 /* ---- D1: out-of-domain evaluations + DEEP composition (ministark
  *      DeepPolyComposer, un-vendored; coefficient rule src/lib.rs:102-116).
@@ -222,6 +231,21 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
                           const uint32_t *mask_off, uint32_t nmask, const uint64_t *ood_trace,
                           const uint64_t *coeff_trace, const uint64_t *ood_comp,
                           const uint64_t *coeff_comp, const uint64_t z[4], uint64_t *d_out);
+/* The two halves of ss_deep_compose, for one proof sharded over several GPUs.  The DEEP polynomial has degree < n, so
+ * it is composed on the sub-coset offset * <w_n> (every blowup-th LDE row) and then interpolated and re-expanded:
+ * ss_deep_compose_rows writes its values at the sub-coset points m0 <= m < m0 + count from column blocks with
+ * d_*_blocks[c][k] = LDE row (m0 << log_blowup) + k (no rows behind the block are needed: DEEP reads one row per
+ * point); ss_deep_extend takes all n sub-coset values (natural order, gathered from the ranks; overwritten) to the N
+ * evaluations.  ss_deep_compose(...) == rows(m0 = 0, count = n) followed by extend, bit for bit. */
+ss_status ss_deep_compose_rows(ss_ctx *ctx, const uint64_t *const *d_trace_blocks, uint32_t ntrace_cols,
+                               const uint64_t *const *d_comp_blocks, uint32_t ncomp, uint32_t log_n,
+                               uint32_t log_blowup, const uint64_t offset[4], const uint32_t *mask_col,
+                               const uint32_t *mask_off, uint32_t nmask, const uint64_t *ood_trace,
+                               const uint64_t *coeff_trace, const uint64_t *ood_comp,
+                               const uint64_t *coeff_comp, const uint64_t z[4], uint64_t m0, uint64_t count,
+                               uint64_t *d_out_subcoset);
+ss_status ss_deep_extend(ss_ctx *ctx, uint64_t *d_subcoset, uint32_t log_n, uint32_t log_blowup,
+                         const uint64_t offset[4], uint64_t *d_out);
 
 /* ---- F1: one FRI layer fold (ministark FriProver::build_layers, un-vendored;
  *      defaults cli/src/main.rs:57-60).  d_evals: 2^log_len felts on

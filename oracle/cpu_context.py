@@ -96,6 +96,7 @@ class CpuContext:
         if getattr(l, "_cpu_context_declared", False):
             return
         l.or_deep_compose_rows.restype = None
+        l.or_eval_program_rows.restype = None
         l.or_ood_eval.restype = None
         l.or_inverse_table.restype = None
         l._cpu_context_declared = True
@@ -212,8 +213,8 @@ class CpuContext:
         return out
 
     def deep_compose(self, trace_cols, comp_cols, log_n, log_blowup, offset, mask_col, mask_off, ood_trace,
-                     coeff_trace, ood_comp, coeff_comp, z, out, row0=0, nrows=None):
-        """row0 / nrows: the row-block form (the columns then hold only those rows)"""
+                     coeff_trace, ood_comp, coeff_comp, z, out, row0=0, nrows=None, stride=1):
+        """row0 / nrows / stride: the row-block form (out[j] = value at LDE row row0 + j * stride, the columns start at row0)"""
         N = 1 << (log_n + log_blowup)
         nrows = N if nrows is None else nrows
         tp = (C.c_void_p * len(trace_cols))(*[_addr(c) for c in trace_cols])
@@ -224,7 +225,20 @@ class CpuContext:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         oracle.lib().or_deep_compose_rows(tp, cp, C.c_uint(log_n), C.c_uint(log_blowup), _fp_arg(offset), p(mc), p(mo),
                                           C.c_size_t(len(mc)), p(ot), p(ct), C.c_size_t(len(comp_cols)), p(oc), p(cc),
-                                          _fp_arg(z), C.c_uint64(row0), C.c_uint64(nrows), C.c_void_p(_addr(out)))
+                                          _fp_arg(z), C.c_uint64(row0), C.c_uint64(nrows), C.c_uint64(stride), C.c_void_p(_addr(out)))
+
+    def deep_compose_rows(self, trace_blocks, comp_blocks, log_n, log_blowup, offset, mask_col, mask_off, ood_trace,
+                          coeff_trace, ood_comp, coeff_comp, z, m0, count, out):
+        """ss_deep_compose_rows: the DEEP polynomial at the sub-coset points m0 .. m0 + count"""
+        self.deep_compose(trace_blocks, comp_blocks, log_n, log_blowup, offset, mask_col, mask_off, ood_trace, coeff_trace,
+                          ood_comp, coeff_comp, z, out, row0=m0 << log_blowup, nrows=count, stride=1 << log_blowup)
+
+    def deep_extend(self, subcoset, log_n, log_blowup, offset, out):
+        """ss_deep_extend: n values on offset * <w_n> of a polynomial of degree < n -> its evaluations on offset * <w_N>"""
+        n, N = 1 << log_n, 1 << (log_n + log_blowup)
+        a = np.zeros((N, 4), dtype=np.uint64)
+        a[:n] = oracle.ntt(_felts(subcoset, n), inverse=True, offset=offset)
+        _felts(out, N)[:] = oracle.ntt(a, offset=offset)
 
     # ---- Q1
     def inverse_table(self, log_N, offset, c, out):
@@ -240,6 +254,18 @@ class CpuContext:
         tab = _felts(tables, ntab) if tables is not None and ntab else np.zeros((0, 4), dtype=np.uint64)
         _felts(out, N)[:] = oracle.eval_program(program.code, consts, tab, list(table_desc), program.n_slots,
                                                 [_felts(c, N) for c in lde_cols], log_n, log_blowup, offset)
+
+    def eval_quotient_rows(self, program, tables, table_desc, col_blocks, log_n, log_blowup, offset, row0, nrows, block_rows, out):
+        from sandstorm_amd.backend import felt
+        consts = np.ascontiguousarray(np.stack([felt(v) for v in program.consts])) if len(program.consts) else np.zeros((1, 4), dtype=np.uint64)
+        code = np.ascontiguousarray(program.code, dtype=np.uint32)
+        desc = np.ascontiguousarray(table_desc, dtype=np.uint32) if len(table_desc) else np.zeros(2, dtype=np.uint32)
+        prog = oracle.AirProgram(code.ctypes.data_as(C.POINTER(C.c_uint32)), len(code) // 2,
+                                 consts.ctypes.data_as(C.POINTER(C.c_uint64)), len(program.consts),
+                                 None, desc.ctypes.data_as(C.POINTER(C.c_uint32)), len(table_desc) // 2, program.n_slots)
+        cp = (C.c_void_p * len(col_blocks))(*[_addr(c) for c in col_blocks])
+        oracle.lib().or_eval_program_rows(C.byref(prog), C.c_void_p(_addr(tables)) if tables is not None else None, cp, C.c_uint(log_n),
+                                          C.c_uint(log_blowup), _fp_arg(offset), C.c_uint64(row0), C.c_uint64(nrows), C.c_void_p(_addr(out)))
 
     # ---- A2
     def permutation_product(self, num, den, count, z, alpha, out, out_stride=1, out_offset=0, want_last=True):

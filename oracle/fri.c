@@ -95,13 +95,13 @@ void or_deep_compose(const fp_t *const *trace_lde, const fp_t *const *comp_lde, 
 /* The same DEEP composition with ONE field inversion per point (Montgomery's trick over the point's denominators)
  * instead of one per (point, cell): the definition above is what the tests hold the GPU kernel to at small sizes; this
  * is what the whole-pipeline CPU runs use (bench.py's cpu_baseline, the multi-rank gloo tests), checked equal to the
- * definition in tests/test_oracle_defs.py.  row0 / nrows: only the points [row0, row0 + nrows) of the domain are
- * computed, into out[0 .. nrows) from trace_lde[c][0 .. nrows) (row-block form of the sharded prover). */
+ * definition in tests/test_oracle_defs.py.  Row-block form: out[j], j < nrows, is the value at LDE row row0 + j * stride,
+ * read from trace_lde[c][j * stride] (columns that start at row row0; stride = blowup gives the sub-coset offset * <w_n>). */
 void or_deep_compose_rows(const fp_t *const *trace_lde, const fp_t *const *comp_lde, unsigned log_n,
                           unsigned log_blowup, fp_t offset, const uint32_t *mask_col,
                           const uint32_t *mask_off, size_t nmask, const fp_t *ood_trace,
                           const fp_t *coeff_trace, size_t ncomp, const fp_t *ood_comp,
-                          const fp_t *coeff_comp, fp_t z, uint64_t row0, uint64_t nrows, fp_t *out) {
+                          const fp_t *coeff_comp, fp_t z, uint64_t row0, uint64_t nrows, uint64_t stride, fp_t *out) {
     unsigned log_N = log_n + log_blowup;
     fp_t wn = fp_root_of_unity(log_n), wN = fp_root_of_unity(log_N);
     /* distinct denominators: one per distinct row offset, plus the composition point */
@@ -123,19 +123,20 @@ void or_deep_compose_rows(const fp_t *const *trace_lde, const fp_t *const *comp_
         fp_t *den = (fp_t *)malloc(sizeof(fp_t) * nd), *pre = (fp_t *)malloc(sizeof(fp_t) * nd);
 #pragma omp for schedule(static)
         for (uint64_t r = 0; r < nrows; ++r) {
-            fp_t x = fp_mul(offset, fp_pow_u64(wN, row0 + r));
+            const uint64_t k = r * stride;
+            fp_t x = fp_mul(offset, fp_pow_u64(wN, row0 + k));
             fp_t run = FP_ONE;
-            for (size_t k = 0; k < nd; ++k) { den[k] = fp_sub(x, zs[k]); pre[k] = run; run = fp_mul(run, den[k]); }
+            for (size_t q = 0; q < nd; ++q) { den[q] = fp_sub(x, zs[q]); pre[q] = run; run = fp_mul(run, den[q]); }
             fp_t inv = fp_inv(run);
-            for (size_t k = nd; k-- > 0;) { fp_t d = den[k]; den[k] = fp_mul(inv, pre[k]); inv = fp_mul(inv, d); }
+            for (size_t q = nd; q-- > 0;) { fp_t d = den[q]; den[q] = fp_mul(inv, pre[q]); inv = fp_mul(inv, d); }
             fp_t acc = {{0, 0, 0, 0}};
             for (size_t j = 0; j < nmask; ++j) {
-                fp_t num = fp_sub(trace_lde[mask_col[j]][r], ood_trace[j]);
+                fp_t num = fp_sub(trace_lde[mask_col[j]][k], ood_trace[j]);
                 acc = fp_add(acc, fp_mul(coeff_trace[j], fp_mul(num, den[which[j]])));
             }
-            for (size_t k = 0; k < ncomp; ++k) {
-                fp_t num = fp_sub(comp_lde[k][r], ood_comp[k]);
-                acc = fp_add(acc, fp_mul(coeff_comp[k], fp_mul(num, den[ndist])));
+            for (size_t kk = 0; kk < ncomp; ++kk) {
+                fp_t num = fp_sub(comp_lde[kk][k], ood_comp[kk]);
+                acc = fp_add(acc, fp_mul(coeff_comp[kk], fp_mul(num, den[ndist])));
             }
             out[r] = acc;
         }

@@ -128,7 +128,9 @@ void or_deep_compose_rows(const fp_t *const *trace_lde, const fp_t *const *comp_
                           unsigned log_blowup, fp_t offset, const uint32_t *mask_col,
                           const uint32_t *mask_off, size_t nmask, const fp_t *ood_trace,
                           const fp_t *coeff_trace, size_t ncomp, const fp_t *ood_comp,
-                          const fp_t *coeff_comp, fp_t z, uint64_t row0, uint64_t nrows, fp_t *out);
+                          const fp_t *coeff_comp, fp_t z, uint64_t row0, uint64_t nrows, uint64_t stride, fp_t *out);
+void or_eval_program_rows(const struct ss_air_program *prog, const fp_t *tables, const fp_t *const *col_blocks,
+                          unsigned log_n, unsigned log_blowup, fp_t offset, uint64_t row0, uint64_t nrows, fp_t *out);
 void or_ood_eval(const fp_t *const *coeffs, unsigned log_n, const uint32_t *mask_col, const uint32_t *mask_off,
                  size_t nmask, fp_t z, fp_t *out);
 void or_inverse_table(unsigned log_N, fp_t offset, fp_t c, fp_t *out);

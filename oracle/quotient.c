@@ -11,10 +11,26 @@
 #include "sandstorm_hip.h"
 #include <stdlib.h>
 
+/* block == 0: the whole domain (row0 = 0, nrows = N; trace cells wrap modulo N).  block != 0: the row-block form of
+ * the sharded prover (ss_eval_quotient_rows): lde_cols[c][k] is LDE row row0 + k and carries the rows behind the block. */
+static void eval_program(const ss_air_program *prog, const fp_t *tables, const fp_t *const *lde_cols,
+                         unsigned log_n, unsigned log_blowup, fp_t offset, uint64_t row0, uint64_t nrows, int block, fp_t *out);
+
 void or_eval_program_ex(const ss_air_program *prog, const fp_t *tables, const fp_t *const *lde_cols,
                         unsigned log_n, unsigned log_blowup, fp_t offset, fp_t *out) {
+    eval_program(prog, tables, lde_cols, log_n, log_blowup, offset, 0, (uint64_t)1 << (log_n + log_blowup), 0, out);
+}
+
+void or_eval_program_rows(const ss_air_program *prog, const fp_t *tables, const fp_t *const *col_blocks,
+                          unsigned log_n, unsigned log_blowup, fp_t offset, uint64_t row0, uint64_t nrows, fp_t *out) {
+    eval_program(prog, tables, col_blocks, log_n, log_blowup, offset, row0, nrows, 1, out);
+}
+
+static void eval_program(const ss_air_program *prog, const fp_t *tables, const fp_t *const *lde_cols,
+                         unsigned log_n, unsigned log_blowup, fp_t offset, uint64_t row0, uint64_t nrows, int block, fp_t *out) {
     unsigned log_N = log_n + log_blowup;
-    size_t N = (size_t)1 << log_N;
+    size_t N = (size_t)nrows;
+    const size_t wrap = block ? ~(size_t)0 : (((size_t)1 << log_N) - 1);
     fp_t wN = fp_root_of_unity(log_N);
     const fp_t *consts = (const fp_t *)prog->consts;
 #pragma omp parallel if (N >= 256)
@@ -24,7 +40,7 @@ void or_eval_program_ex(const ss_air_program *prog, const fp_t *tables, const fp
         for (size_t i = 0; i < N; ++i) {
             fp_t acc[4];
             memset(acc, 0, sizeof acc);
-            fp_t x = fp_mul(offset, fp_pow_u64(wN, (uint64_t)i));
+            fp_t x = fp_mul(offset, fp_pow_u64(wN, row0 + (uint64_t)i));
             for (uint32_t pc = 0; pc < prog->n_instr; ++pc) {
                 uint32_t w0 = prog->code[2 * pc], w1 = prog->code[2 * pc + 1];
                 unsigned op = w0 & 0xff, d = (w0 >> 8) & 0xf, kind = (w0 >> 12) & 0xf;
@@ -37,11 +53,11 @@ void or_eval_program_ex(const ss_air_program *prog, const fp_t *tables, const fp
                     case SS_SRC_CONST: src = consts[w1]; break;
                     case SS_SRC_TRACE: {
                         size_t col = w1 >> 24, ro = w1 & 0xffffff;
-                        src = lde_cols[col][(i + (ro << log_blowup)) & (N - 1)];
+                        src = lde_cols[col][(i + (ro << log_blowup)) & wrap];
                     } break;
                     case SS_SRC_TABLE: {
                         uint32_t off = prog->table_desc[2 * w1], ll = prog->table_desc[2 * w1 + 1];
-                        src = tables[off + (i & (((size_t)1 << ll) - 1))];
+                        src = tables[off + ((row0 + i) & (((size_t)1 << ll) - 1))];
                     } break;
                     case SS_SRC_X: src = x; break;
                     default: break;

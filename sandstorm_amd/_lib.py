@@ -81,6 +81,12 @@ SIGNATURES = {
     "ss_inverse_table": (C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p, C.c_void_p]),
     "ss_eval_quotient": (C.c_int, [C.c_void_p, C.POINTER(AirProgram), _vpp, C.c_uint32, C.c_uint32,
                                    C.c_uint32, _u64p, C.c_void_p]),
+    "ss_eval_quotient_rows": (C.c_int, [C.c_void_p, C.POINTER(AirProgram), _vpp, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, _u64p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "ss_deep_compose_rows": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, _vpp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       _u64p, _u32p, _u32p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, _u64p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "ss_deep_extend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _u64p, C.c_void_p]),
     "ss_ood_eval": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, _u32p, _u32p, C.c_uint32, _u64p,
                               C.c_void_p]),
     "ss_poly_eval": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, _u64p, C.c_void_p]),

@@ -245,6 +245,27 @@ class Context:
                                        mo.ctypes.data_as(C.POINTER(C.c_uint32)), len(mc), ot.ctypes.data,
                                        ct.ctypes.data, oc.ctypes.data, cc.ctypes.data, zp, _ptr_of(out)))
 
+    def deep_compose_rows(self, trace_blocks, comp_blocks, log_n, log_blowup, offset, mask_col, mask_off, ood_trace,
+                          coeff_trace, ood_comp, coeff_comp, z, m0, count, out):
+        """ss_deep_compose_rows: the DEEP polynomial at the sub-coset points m0 .. m0 + count from column blocks whose
+        element k is LDE row (m0 << log_blowup) + k"""
+        mc = np.ascontiguousarray(mask_col, dtype=np.uint32)
+        mo = np.ascontiguousarray(mask_off, dtype=np.uint32)
+        ot, ct = (np.ascontiguousarray(a, dtype=np.uint64) for a in (ood_trace, coeff_trace))
+        oc, cc = (np.ascontiguousarray(a, dtype=np.uint64) for a in (ood_comp, coeff_comp))
+        _k1, op = _felt_ptr(offset)
+        _k2, zp = _felt_ptr(z)
+        check(self.lib.ss_deep_compose_rows(self.handle, _ptr_array(trace_blocks), len(trace_blocks),
+                                            _ptr_array(comp_blocks) if comp_blocks else None, len(comp_blocks), log_n,
+                                            log_blowup, op, mc.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            mo.ctypes.data_as(C.POINTER(C.c_uint32)), len(mc), ot.ctypes.data,
+                                            ct.ctypes.data, oc.ctypes.data, cc.ctypes.data, zp, m0, count, _ptr_of(out)))
+
+    def deep_extend(self, subcoset, log_n, log_blowup, offset, out):
+        """ss_deep_extend: n sub-coset values of a polynomial of degree < n (overwritten) -> its N evaluations"""
+        _k, op = _felt_ptr(offset)
+        check(self.lib.ss_deep_extend(self.handle, _ptr_of(subcoset), log_n, log_blowup, op, _ptr_of(out)))
+
     # ---- Q1 -------------------------------------------------------------------------------
     def inverse_table(self, log_N, offset, c, out):
         """out[i] = 1 / (offset * w_N^i - c)"""
@@ -267,6 +288,21 @@ class Context:
         _k, op = _felt_ptr(offset)
         check(self.lib.ss_eval_quotient(self.handle, C.byref(prog), _ptr_array(lde_cols), len(lde_cols), log_n,
                                         log_blowup, op, _ptr_of(out)))
+
+    def eval_quotient_rows(self, program, tables, table_desc, col_blocks, log_n, log_blowup, offset, row0, nrows, block_rows, out):
+        """ss_eval_quotient_rows: points row0 .. row0 + nrows from column blocks of block_rows rows starting at row0"""
+        code = np.ascontiguousarray(program.code, dtype=np.uint32)
+        consts = np.zeros((max(1, len(program.consts)), 4), dtype=np.uint64)
+        for i, v in enumerate(program.consts):
+            consts[i] = felt(v)
+        desc = np.ascontiguousarray(table_desc if len(table_desc) else [0, 0], dtype=np.uint32)
+        prog = _lib.AirProgram(code.ctypes.data_as(C.POINTER(C.c_uint32)), len(code) // 2,
+                               consts.ctypes.data_as(C.POINTER(C.c_uint64)), len(program.consts),
+                               _ptr_of(tables) if tables is not None else None,
+                               desc.ctypes.data_as(C.POINTER(C.c_uint32)), len(table_desc) // 2, program.n_slots)
+        _k, op = _felt_ptr(offset)
+        check(self.lib.ss_eval_quotient_rows(self.handle, C.byref(prog), _ptr_array(col_blocks), len(col_blocks), log_n,
+                                             log_blowup, op, row0, nrows, block_rows, _ptr_of(out)))
 
     def zero(self, buf, nbytes=None):
         check(self.lib.ss_dev_zero(self.handle, _ptr_of(buf), buf.nbytes if nbytes is None else nbytes))

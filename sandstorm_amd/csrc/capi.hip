@@ -264,7 +264,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -884,18 +884,19 @@ ss_status ss_ood_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t nco
     return SS_OK;
 }
 
-ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_t ntrace_cols,
-                          const uint64_t *const *d_comp_lde, uint32_t ncomp, uint32_t log_n, uint32_t log_blowup,
-                          const uint64_t offset[4], const uint32_t *mask_col, const uint32_t *mask_off,
-                          uint32_t nmask, const uint64_t *ood_trace, const uint64_t *coeff_trace,
-                          const uint64_t *ood_comp, const uint64_t *coeff_comp, const uint64_t z[4],
-                          uint64_t *d_out) {
-    if (!ctx || !d_trace_lde || !z || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
-    if (nmask && (!mask_col || !mask_off || !ood_trace || !coeff_trace)) return fail(SS_ERR_INVALID, "NULL mask argument");
-    if (ncomp && (!d_comp_lde || !ood_comp || !coeff_comp)) return fail(SS_ERR_INVALID, "NULL composition argument");
-    const uint32_t log_N = log_n + log_blowup;
-    if (!valid_log(log_n) || !valid_log(log_N)) return fail(SS_ERR_INVALID, "size out of range");
-    if (ntrace_cols > (uint32_t)MAX_COLS || ncomp > 4) return fail(SS_ERR_UNSUPPORTED, "too many columns");
+}  // extern "C"
+
+namespace {
+// The DEEP polynomial's values at the sub-coset points offset * w_n^m, m0 <= m < m0 + count, into d_sub[0 .. count).
+// The column pointers name LDE row (m0 << log_blowup): whole columns with m0 = 0 (ss_deep_compose) or a rank's row block
+// (ss_deep_compose_rows).  block != 0: the inverse table is built for this range only (with the rows the group shifts
+// reach in front of it) instead of over the whole sub-coset.
+ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_t ntrace_cols,
+                        const uint64_t *const *d_comp_lde, uint32_t ncomp, uint32_t log_n, uint32_t log_blowup,
+                        const uint64_t offset[4], const uint32_t *mask_col, const uint32_t *mask_off,
+                        uint32_t nmask, const uint64_t *ood_trace, const uint64_t *coeff_trace,
+                        const uint64_t *ood_comp, const uint64_t *coeff_comp, const uint64_t z[4],
+                        uint64_t m0, uint64_t count, bool block, Fp *d_sub, Fp *table_space /* 2 n felts when !block */) {
     const uint64_t n = 1ull << log_n;
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp zf = fp_from_limbs64(z);
@@ -906,6 +907,7 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (mask_off[a] & (n - 1)) < (mask_off[b] & (n - 1)); });
     std::vector<uint32_t> cell_col(nmask), gdesc;
     std::vector<Fp> cell_coef(nmask), group_k;
+    uint32_t max_shift = 0;
     for (uint32_t t = 0; t < nmask;) {
         const uint32_t offv = mask_off[order[t]] & (uint32_t)(n - 1);
         const Fp wk = fp_pow_u64(wn_inv, offv);
@@ -920,6 +922,7 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
         }
         gdesc.push_back(offv); gdesc.push_back(first); gdesc.push_back(t - first);
         group_k.push_back(kacc);
+        if (offv > max_shift) max_shift = offv;
     }
     const uint32_t ngroups = (uint32_t)group_k.size();
     // the kernel multiplies with fl_mul_r280: coefficients go over in R280 form (times 2^24)
@@ -934,14 +937,22 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
         zc = fp_mul(zc, zf);
     }
     for (uint32_t k = 0; k < ncomp; ++k) comp_coef[k] = fp_mul(comp_coef[k], r280_factor);
-    // device staging: D, Dc (sub-coset tables) and the sub-coset DEEP values in scratch2;
-    // small arrays in scratch
-    ss_status st = ctx->ensure_scratch2(3 * n * sizeof(Fp));
-    if (st != SS_OK) return st;
+    // inverse tables: the whole sub-coset, or this range with the rows the shifts reach in front of it
+    const uint64_t chunk = 1ull << BATCH_INVERSE_RANGE_LOG_CHUNK;
+    const uint64_t pre = block ? ((uint64_t)max_shift + chunk - 1) / chunk * chunk : 0;
+    const uint64_t d_len = block ? (pre + count + chunk - 1) / chunk * chunk : n, dc_len = block ? (count + chunk - 1) / chunk * chunk : n;
+    ss_status st = SS_OK;
+    Fp *D, *Dc;
+    if (block) {
+        st = ctx->ensure_scratch2((d_len + dc_len) * sizeof(Fp));
+        if (st != SS_OK) return st;
+        D = (Fp *)ctx->scratch2; Dc = D + d_len;
+    } else {
+        D = table_space; Dc = D + n;
+    }
     const size_t small = (size_t)nmask * (4 + 32) + (size_t)ngroups * (12 + 32) + (size_t)(ncomp + 1) * 32 + 256;
     st = ctx->ensure_scratch(small);
     if (st != SS_OK) return st;
-    Fp *D = (Fp *)ctx->scratch2, *Dc = D + n, *sub = D + 2 * n;
     char *p = (char *)ctx->scratch;
     Fp *d_cell_coef = (Fp *)p; p += (size_t)(nmask ? nmask : 1) * 32;
     Fp *d_group_k = (Fp *)p; p += (size_t)(ngroups ? ngroups : 1) * 32;
@@ -956,30 +967,103 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
         HIP_TRY(hipMemcpyAsync(d_gdesc, gdesc.data(), (size_t)ngroups * 12, hipMemcpyHostToDevice, s));
     }
     if (ncomp) HIP_TRY(hipMemcpyAsync(d_comp_coef, comp_coef.data(), (size_t)ncomp * 32, hipMemcpyHostToDevice, s));
-    // the DEEP polynomial has degree < n: compose it on the sub-coset offset*<w_n> (LDE rows
-    // m * blowup), interpolate, and expand back to the LDE domain
     const Fp wn = root_of_unity(log_n);
-    const Fp *tw_inv = nullptr, *tw_fwd = nullptr;
-    st = ctx->get_plan(log_n, true, off, &tw_inv);
-    if (st != SS_OK) return st;
-    st = ctx->get_plan(log_N, false, off, &tw_fwd);
-    if (st != SS_OK) return st;
     {
         ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
-        HIP_TRY(launch_batch_inverse(s, D, log_n, off, wn, fp_inv(wn), zf, true));
-        if (ncomp) HIP_TRY(launch_batch_inverse(s, Dc, log_n, off, wn, fp_inv(wn), zc, true));
+        if (block) {
+            // D[j] <-> sub-coset point m0 - pre + j (indices modulo n: the powers of w_n wrap by themselves)
+            const Fp x_d = fp_mul(off, fp_pow_u64(wn, (m0 + n - pre % n) % n)), x_c = fp_mul(off, fp_pow_u64(wn, m0 % n));
+            HIP_TRY(launch_batch_inverse_range(s, D, d_len, x_d, wn, fp_inv(wn), zf, true));
+            if (ncomp) HIP_TRY(launch_batch_inverse_range(s, Dc, dc_len, x_c, wn, fp_inv(wn), zc, true));
+        } else {
+            HIP_TRY(launch_batch_inverse(s, D, log_n, off, wn, fp_inv(wn), zf, true));
+            if (ncomp) HIP_TRY(launch_batch_inverse(s, Dc, log_n, off, wn, fp_inv(wn), zc, true));
+        }
         HIP_TRY(launch_deep(s, (const void *const *)d_trace_lde, ntrace_cols, (const void *const *)d_comp_lde, ncomp, D, Dc,
-                            d_cell_col, d_cell_coef, d_gdesc, d_group_k, ngroups, d_comp_coef, comp_k, log_n, log_blowup, sub));
+                            d_cell_col, d_cell_coef, d_gdesc, d_group_k, ngroups, d_comp_coef, comp_k, count,
+                            block ? (uint32_t)pre : 0u, block ? 0xffffffffu : (uint32_t)(n - 1), log_blowup, d_sub));
     }
+    HIP_TRY(hipStreamSynchronize(s));     // host staging vectors go out of scope
+    return SS_OK;
+}
+
+// sub-coset values of a polynomial of degree < n (on offset * <w_n>, natural order) -> its evaluations over the LDE domain
+ss_status deep_extend(ss_ctx *ctx, Fp *d_sub, uint32_t log_n, uint32_t log_blowup, const Fp &off, uint64_t *d_out) {
+    const Fp *tw_inv = nullptr, *tw_fwd = nullptr;
+    ss_status st = ctx->get_plan(log_n, true, off, &tw_inv);
+    if (st != SS_OK) return st;
+    st = ctx->get_plan(log_n + log_blowup, false, off, &tw_fwd);
+    if (st != SS_OK) return st;
     ColPtrs inv, fwd;
     memset(&inv, 0, sizeof inv); memset(&fwd, 0, sizeof fwd);
-    inv.src[0] = sub; inv.dst[0] = sub;
-    fwd.src[0] = sub; fwd.dst[0] = d_out;
+    inv.src[0] = d_sub; inv.dst[0] = d_sub;
+    fwd.src[0] = d_sub; fwd.dst[0] = d_out;
     st = run_inverse(ctx, inv, 1, log_n, tw_inv);
     if (st != SS_OK) return st;
-    st = run_forward(ctx, fwd, 1, log_N, tw_fwd, log_blowup);
+    return run_forward(ctx, fwd, 1, log_n + log_blowup, tw_fwd, log_blowup);
+}
+
+ss_status deep_check_args(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_t ntrace_cols, const uint64_t *const *d_comp_lde,
+                          uint32_t ncomp, uint32_t log_n, uint32_t log_blowup, const uint32_t *mask_col, const uint32_t *mask_off,
+                          uint32_t nmask, const uint64_t *ood_trace, const uint64_t *coeff_trace, const uint64_t *ood_comp,
+                          const uint64_t *coeff_comp, const uint64_t z[4], const void *d_out) {
+    if (!ctx || !d_trace_lde || !z || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (nmask && (!mask_col || !mask_off || !ood_trace || !coeff_trace)) return fail(SS_ERR_INVALID, "NULL mask argument");
+    if (ncomp && (!d_comp_lde || !ood_comp || !coeff_comp)) return fail(SS_ERR_INVALID, "NULL composition argument");
+    if (!valid_log(log_n) || !valid_log(log_n + log_blowup)) return fail(SS_ERR_INVALID, "size out of range");
+    if (ntrace_cols > (uint32_t)MAX_COLS || ncomp > 4) return fail(SS_ERR_UNSUPPORTED, "too many columns");
+    return SS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_t ntrace_cols,
+                          const uint64_t *const *d_comp_lde, uint32_t ncomp, uint32_t log_n, uint32_t log_blowup,
+                          const uint64_t offset[4], const uint32_t *mask_col, const uint32_t *mask_off,
+                          uint32_t nmask, const uint64_t *ood_trace, const uint64_t *coeff_trace,
+                          const uint64_t *ood_comp, const uint64_t *coeff_comp, const uint64_t z[4],
+                          uint64_t *d_out) {
+    ss_status st = deep_check_args(ctx, d_trace_lde, ntrace_cols, d_comp_lde, ncomp, log_n, log_blowup, mask_col, mask_off, nmask,
+                                   ood_trace, coeff_trace, ood_comp, coeff_comp, z, d_out);
     if (st != SS_OK) return st;
-    HIP_TRY(hipStreamSynchronize(s));     // host staging vectors go out of scope
+    const uint64_t n = 1ull << log_n;
+    // the DEEP polynomial has degree < n: compose it on the sub-coset offset*<w_n> (LDE rows m * blowup), interpolate,
+    // and expand back to the LDE domain.  D, Dc (sub-coset tables) and the sub-coset values live in scratch2.
+    st = ctx->ensure_scratch2(3 * n * sizeof(Fp));
+    if (st != SS_OK) return st;
+    Fp *tables = (Fp *)ctx->scratch2, *sub = tables + 2 * n;
+    st = deep_subcoset(ctx, d_trace_lde, ntrace_cols, d_comp_lde, ncomp, log_n, log_blowup, offset, mask_col, mask_off, nmask,
+                       ood_trace, coeff_trace, ood_comp, coeff_comp, z, 0, n, false, sub, tables);
+    if (st != SS_OK) return st;
+    st = deep_extend(ctx, sub, log_n, log_blowup, offset ? fp_from_limbs64(offset) : fp_one(), d_out);
+    if (st != SS_OK) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+ss_status ss_deep_compose_rows(ss_ctx *ctx, const uint64_t *const *d_trace_blocks, uint32_t ntrace_cols,
+                               const uint64_t *const *d_comp_blocks, uint32_t ncomp, uint32_t log_n, uint32_t log_blowup,
+                               const uint64_t offset[4], const uint32_t *mask_col, const uint32_t *mask_off,
+                               uint32_t nmask, const uint64_t *ood_trace, const uint64_t *coeff_trace,
+                               const uint64_t *ood_comp, const uint64_t *coeff_comp, const uint64_t z[4],
+                               uint64_t m0, uint64_t count, uint64_t *d_out_subcoset) {
+    ss_status st = deep_check_args(ctx, d_trace_blocks, ntrace_cols, d_comp_blocks, ncomp, log_n, log_blowup, mask_col, mask_off, nmask,
+                                   ood_trace, coeff_trace, ood_comp, coeff_comp, z, d_out_subcoset);
+    if (st != SS_OK) return st;
+    const uint64_t n = 1ull << log_n;
+    if (count == 0 || count > n || m0 >= n) return fail(SS_ERR_INVALID, "sub-coset range out of bounds");
+    return deep_subcoset(ctx, d_trace_blocks, ntrace_cols, d_comp_blocks, ncomp, log_n, log_blowup, offset, mask_col, mask_off, nmask,
+                         ood_trace, coeff_trace, ood_comp, coeff_comp, z, m0, count, true, (Fp *)d_out_subcoset, nullptr);
+}
+
+ss_status ss_deep_extend(ss_ctx *ctx, uint64_t *d_subcoset, uint32_t log_n, uint32_t log_blowup, const uint64_t offset[4],
+                         uint64_t *d_out) {
+    if (!ctx || !d_subcoset || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!valid_log(log_n) || !valid_log(log_n + log_blowup)) return fail(SS_ERR_INVALID, "size out of range");
+    ss_status st = deep_extend(ctx, (Fp *)d_subcoset, log_n, log_blowup, offset ? fp_from_limbs64(offset) : fp_one(), d_out);
+    if (st != SS_OK) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SS_OK;
 }
 
@@ -1009,9 +1093,11 @@ const QGenKernel *quotient_gen_find(const uint32_t *code, uint32_t n_instr) {
     return nullptr;
 }
 
+// row0 / npoints / block: the whole domain (0, N, false) or a row block whose columns carry the rows behind it
 ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
-                                 uint32_t ncols, uint32_t log_N, uint32_t log_blowup, const uint64_t offset[4], uint64_t *d_out) {
-    const uint64_t N = 1ull << log_N;
+                                 uint32_t ncols, uint32_t log_N, uint32_t log_blowup, const uint64_t offset[4], uint64_t *d_out,
+                                 uint64_t row0, uint64_t npoints, bool block) {
+    const uint64_t N = npoints;
     // constants in limb form: 9 x 28-bit limbs of the interchange image (add / sub / mov) and of the R280 form (fl_mul_r280)
     const uint32_t nc = prog->n_consts ? prog->n_consts : 1u;
     std::vector<uint32_t> host((size_t)nc * QG_CONST_STRIDE + 2 * (size_t)(prog->n_tables ? prog->n_tables : 1u), 0u);
@@ -1035,14 +1121,15 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
     a.consts = (const uint32_t *)ctx->scratch;
     a.tdesc = a.consts + (size_t)nc * QG_CONST_STRIDE;
     a.out = (Fp *)d_out;
-    a.log_N = log_N; a.log_blowup = log_blowup;
+    a.npoints = npoints; a.row0 = (uint32_t)row0; a.log_blowup = log_blowup;
+    a.trace_mask = block ? 0xffffffffu : (uint32_t)((1ull << log_N) - 1ull);
     // one workgroup per CU and SIMD slot the kernel's register budget allows; SS_QG_BLOCKS overrides (experiments)
     uint64_t blocks = 256;
     if (const char *e = getenv("SS_QG_BLOCKS")) blocks = strtoull(e, nullptr, 10);
     if (blocks * QG_THREADS > N) blocks = N / QG_THREADS;
     if (blocks == 0) blocks = 1;
-    a.offset = offset ? fp_from_limbs64(offset) : fp_one();
     a.w = root_of_unity(log_N);
+    a.offset = fp_mul(offset ? fp_from_limbs64(offset) : fp_one(), fp_pow_u64(a.w, row0));
     a.wstep = fp_pow_u64(a.w, blocks * QG_THREADS);
     ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
     HIP_TRY(gen.launch(s, a, (uint32_t)blocks));
@@ -1053,14 +1140,18 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
 
 extern "C" {
 
-ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
-                           uint32_t ncols, uint32_t log_n, uint32_t log_blowup, const uint64_t offset[4],
-                           uint64_t *d_out) {
+// whole domain: row0 = 0, npoints = N, block_rows = 0.  Row block: the columns hold LDE rows row0 .. row0 + block_rows.
+static ss_status eval_quotient_impl(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
+                                    uint32_t ncols, uint32_t log_n, uint32_t log_blowup, const uint64_t offset[4],
+                                    uint64_t row0, uint64_t npoints, uint64_t block_rows, uint64_t *d_out) {
     if (!ctx || !prog || !d_lde_cols || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
     if (!prog->code || prog->n_instr == 0) return fail(SS_ERR_INVALID, "empty program");
     const uint32_t log_N = log_n + log_blowup;
     if (!valid_log(log_n) || !valid_log(log_N)) return fail(SS_ERR_INVALID, "size out of range");
     if (ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u > %d", ncols, MAX_COLS);
+    const bool block = block_rows != 0;
+    const uint64_t N = block ? npoints : 1ull << log_N;
+    if (block && (npoints == 0 || row0 + npoints > (1ull << log_N))) return fail(SS_ERR_INVALID, "row block out of the domain");
     // validate the program against its own declarations (it is caller-supplied data)
     for (uint32_t pc = 0; pc < prog->n_instr; ++pc) {
         const uint32_t w0 = prog->code[2 * pc], w1 = prog->code[2 * pc + 1];
@@ -1073,20 +1164,22 @@ ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64
             if (kind == SS_SRC_SLOT && w1 >= prog->n_slots) return fail(SS_ERR_INVALID, "instruction %u: slot %u out of range", pc, w1);
             if (kind == SS_SRC_CONST && w1 >= prog->n_consts) return fail(SS_ERR_INVALID, "instruction %u: constant %u out of range", pc, w1);
             if (kind == SS_SRC_TRACE && (w1 >> 24) >= ncols) return fail(SS_ERR_INVALID, "instruction %u: column %u out of range", pc, w1 >> 24);
+            if (kind == SS_SRC_TRACE && block && npoints + ((uint64_t)(w1 & 0xffffffu) << log_blowup) > block_rows)
+                return fail(SS_ERR_INVALID, "instruction %u: row offset %u reaches beyond the block's %llu rows", pc, w1 & 0xffffffu,
+                            (unsigned long long)block_rows);
             if (kind == SS_SRC_TABLE && (w1 >= prog->n_tables || !prog->d_tables || !prog->table_desc))
                 return fail(SS_ERR_INVALID, "instruction %u: table %u out of range", pc, w1);
         }
     }
-    const uint64_t N = 1ull << log_N;
     // A layout's composition constraint has a compiled kernel (quotient_gen_<layout>.hip, generated from exactly this
     // program): recognised by the hash of its code words.  Everything per proof (constants, tables, columns, size) is data.
     if (!getenv("SS_QUOTIENT_INTERPRET")) {
         const QGenKernel *gen = quotient_gen_find(prog->code, prog->n_instr);
-        if (gen && gen->n_consts == prog->n_consts && gen->n_tables == prog->n_tables && gen->ncols <= ncols && N >= (uint64_t)QG_THREADS)
-            return eval_quotient_compiled(ctx, *gen, prog, d_lde_cols, ncols, log_N, log_blowup, offset, d_out);
+        if (gen && gen->n_consts == prog->n_consts && gen->n_tables == prog->n_tables && gen->ncols <= ncols)
+            return eval_quotient_compiled(ctx, *gen, prog, d_lde_cols, ncols, log_N, log_blowup, offset, d_out, row0, N, block);
     }
     uint64_t lanes = 256ull * 256 * 4;                 // 4 workgroups of 256 per CU
-    if (lanes > N) lanes = N < 256 ? 256 : N;
+    if (lanes > N) lanes = N < 256 ? 256 : (N + 255) / 256 * 256;
     const size_t code_b = ((size_t)prog->n_instr + 1) * 32, const_b = (size_t)(prog->n_consts ? prog->n_consts : 1) * 32;
     const size_t slots_b = (size_t)(prog->n_slots ? prog->n_slots : 1) * lanes * 32;
     ss_status st = ctx->ensure_scratch(slots_b + 2 * const_b + code_b + 256);
@@ -1101,7 +1194,9 @@ ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64
     VmResolve rs;
     for (int c = 0; c < MAX_COLS; ++c) rs.cols[c] = c < (int)ncols ? (const void *)d_lde_cols[c] : nullptr;
     rs.consts = d_consts; rs.consts_r280 = d_consts_r280; rs.tables = prog->d_tables; rs.slots = d_slots; rs.table_desc = prog->table_desc;
-    rs.lanes = lanes; rs.log_N = log_N; rs.log_blowup = log_blowup;
+    rs.lanes = lanes; rs.log_blowup = log_blowup;
+    rs.trace_mask = block ? 0xffffffffu : (uint32_t)((1ull << log_N) - 1ull);
+    rs.row0 = (uint32_t)row0;
     std::vector<uint32_t> dev_code(((size_t)prog->n_instr + 1) * 8);
     quotient_build_device_code(prog->code, prog->n_instr, rs, dev_code.data());
     HIP_TRY(hipMemcpyAsync(d_code, dev_code.data(), code_b, hipMemcpyHostToDevice, s));
@@ -1113,16 +1208,29 @@ ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64
         for (uint32_t k = 0; k < prog->n_consts; ++k) consts_r280[k] = fp_mul(fp_from_limbs64(prog->consts + 4 * (size_t)k), f);
         HIP_TRY(hipMemcpyAsync(d_consts_r280, consts_r280.data(), (size_t)prog->n_consts * 32, hipMemcpyHostToDevice, s));
     }
-    const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp w = root_of_unity(log_N);
+    const Fp off = fp_mul(offset ? fp_from_limbs64(offset) : fp_one(), fp_pow_u64(w, row0));
     // optional XCD-contiguous sweep (measured: no gain, the per-XCD window still exceeds L2)
-    const uint32_t xcd_split = (lanes % (8 * 256) == 0 && (N >> 3) >= (lanes >> 3) && (N >> 3) % (lanes >> 3) == 0 &&
+    const uint32_t xcd_split = (lanes % (8 * 256) == 0 && (N >> 3) >= (lanes >> 3) && (N >> 3) % (lanes >> 3) == 0 && (N & (N - 1)) == 0 &&
                                 getenv("SS_QUOTIENT_XCD_SPLIT") != nullptr) ? 1u : 0u;
     const Fp wstep = fp_pow_u64(w, xcd_split ? (lanes >> 3) : lanes);
     ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
-    HIP_TRY(launch_quotient_vm(s, d_code, prog->n_instr + 1, d_slots, lanes, off, w, wstep, log_N, xcd_split, (Fp *)d_out));
+    HIP_TRY(launch_quotient_vm(s, d_code, prog->n_instr + 1, d_slots, lanes, off, w, wstep, N, xcd_split, (Fp *)d_out));
     HIP_TRY(hipStreamSynchronize(s));      // the caller's host arrays may go away after return
     return SS_OK;
+}
+
+ss_status ss_eval_quotient(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
+                           uint32_t ncols, uint32_t log_n, uint32_t log_blowup, const uint64_t offset[4],
+                           uint64_t *d_out) {
+    return eval_quotient_impl(ctx, prog, d_lde_cols, ncols, log_n, log_blowup, offset, 0, 0, 0, d_out);
+}
+
+ss_status ss_eval_quotient_rows(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_col_blocks,
+                                uint32_t ncols, uint32_t log_n, uint32_t log_blowup, const uint64_t offset[4],
+                                uint64_t row0, uint64_t nrows, uint64_t block_rows, uint64_t *d_out) {
+    if (block_rows == 0 || nrows == 0 || nrows > block_rows) return fail(SS_ERR_INVALID, "empty row block");
+    return eval_quotient_impl(ctx, prog, d_col_blocks, ncols, log_n, log_blowup, offset, row0, nrows, block_rows, d_out);
 }
 
 }  // extern "C"

@@ -99,9 +99,8 @@ hipError_t launch_poly_reduce(hipStream_t st, const void *const *in, void *const
 // one inversion, backward pass overwrites them with the inverses.
 // r280 != 0: the table is written in R280 form (fl252.h: entries times 2^24, for fl_mul_r280 consumers);
 // the factor rides on the running inverse, so it costs one multiplication per chunk.
-__global__ __launch_bounds__(128) void batch_inverse_kernel(Fp *__restrict__ D, uint32_t log_N, uint32_t log_chunk,
+__global__ __launch_bounds__(128) void batch_inverse_kernel(Fp *__restrict__ D, uint64_t nchunks, uint32_t log_chunk,
                                                             Fp offset, Fp w, Fp w_inv, Fp z, int r280) {
-    const uint64_t nchunks = 1ull << (log_N - log_chunk);
     const uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     const uint64_t CH = 1ull << log_chunk, i0 = c << log_chunk;
@@ -130,8 +129,21 @@ hipError_t launch_batch_inverse(hipStream_t st, Fp *D, uint32_t log_N, const Fp 
     if (log_chunk < 4) log_chunk = log_N < 4 ? log_N : 4;
     if (log_chunk > 7) log_chunk = 7;
     const uint64_t nchunks = 1ull << (log_N - log_chunk);
-    hipLaunchKernelGGL(batch_inverse_kernel, dim3((uint32_t)((nchunks + 127) / 128)), dim3(128), 0, st, D, log_N,
+    hipLaunchKernelGGL(batch_inverse_kernel, dim3((uint32_t)((nchunks + 127) / 128)), dim3(128), 0, st, D, nchunks,
                        log_chunk, offset, w, w_inv, z, r280 ? 1 : 0);
+    return hipGetLastError();
+}
+
+// D[j] = 1 / (x0 * w^j - z) for j < len: a RANGE of the domain (the row-block form of the sharded prover).  len must be a
+// multiple of 2^BATCH_INVERSE_RANGE_LOG_CHUNK; the entries are the whole-domain table's, bit for bit (every entry is
+// the fully reduced inverse, whatever the chunking).
+hipError_t launch_batch_inverse_range(hipStream_t st, Fp *D, uint64_t len, const Fp &x0, const Fp &w, const Fp &w_inv,
+                                      const Fp &z, bool r280) {
+    const uint32_t log_chunk = BATCH_INVERSE_RANGE_LOG_CHUNK;
+    const uint64_t nchunks = len >> log_chunk;
+    if (nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(batch_inverse_kernel, dim3((uint32_t)((nchunks + 127) / 128)), dim3(128), 0, st, D, nchunks,
+                       log_chunk, x0, w, w_inv, z, r280 ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -147,8 +159,10 @@ struct DeepArgs {
     const Fp *group_k;           // [ngroups] sum_j c'_j * ood_j
     const Fp *comp_coef;         // [ncomp], R280 form
     Fp comp_k;                   // sum_k cc_k * ood_comp_k
-    uint32_t ngroups, ncomp, log_N, log_stride;     // log_N: log2 of the number of points evaluated
-};
+    uint32_t ngroups, ncomp, log_stride;
+    uint64_t count;              // points evaluated: sub-coset points m0 .. m0 + count (m0 is folded into the pointers)
+    uint32_t d_bias, d_mask;     // D is read at (m + d_bias - shift) & d_mask: whole table (0, M - 1) or a local range with
+};                               // `d_bias` entries in front of the block's first point (d_mask = ~0)
 
 // Evaluates the DEEP sum at LDE indices i = m * stride, m < 2^log_M: with stride = blowup
 // this is the trace-size sub-coset offset*<w_n>, enough to pin the degree < n DEEP
@@ -170,7 +184,7 @@ __device__ __forceinline__ Fp dload_uniform(const Fp *p) {
 }
 
 __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ out) {
-    const uint64_t M = 1ull << a.log_N;              // points evaluated
+    const uint64_t M = a.count;                      // points evaluated
     dk_const_u32 group_desc = (dk_const_u32)(uintptr_t)a.group_desc, cell_col = (dk_const_u32)(uintptr_t)a.cell_col;
     for (uint64_t m = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; m < M;
          m += (uint64_t)gridDim.x * blockDim.x) {
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ 
             // The lazy subtraction adds 2p and one 2^28 per limb: value < 15.2p < 2^256, limbs < 2^32 - exactly what
             // the multiplicand side of fl_mul_r280 accepts, so no reduction is needed before the multiplication
             inner = fl_sub_c<2, 1>(inner, fl_from_fp(dload_uniform(a.group_k + g)));
-            acc = fl_add(acc, fl_mul_r280(inner, fl_from_fp(dload(a.D + ((m - shift) & (M - 1))))));
+            acc = fl_add(acc, fl_mul_r280(inner, fl_from_fp(dload(a.D + (((uint32_t)m + a.d_bias - shift) & a.d_mask)))));
             if (++acc_terms == 12) { acc = fl_weak_reduce(acc); acc_terms = 1; }
         }
         if (a.ncomp) {
@@ -214,14 +228,14 @@ __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ 
 hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace, const void *const *comp,
                        uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *cell_col, const Fp *cell_coef,
                        const uint32_t *group_desc, const Fp *group_k, uint32_t ngroups, const Fp *comp_coef,
-                       const Fp &comp_k, uint32_t log_M, uint32_t log_stride, Fp *out) {
+                       const Fp &comp_k, uint64_t count, uint32_t d_bias, uint32_t d_mask, uint32_t log_stride, Fp *out) {
     DeepArgs a;
     for (int c = 0; c < MAX_COLS; ++c) a.trace[c] = c < (int)ntrace ? (const Fp *)trace[c] : nullptr;
     for (int c = 0; c < 4; ++c) a.comp[c] = c < (int)ncomp ? (const Fp *)comp[c] : nullptr;
     a.D = D; a.Dc = Dc; a.cell_col = cell_col; a.cell_coef = cell_coef; a.group_desc = group_desc;
     a.group_k = group_k; a.comp_coef = comp_coef; a.comp_k = comp_k; a.ngroups = ngroups; a.ncomp = ncomp;
-    a.log_N = log_M; a.log_stride = log_stride;
-    const uint64_t N = 1ull << log_M;
+    a.count = count; a.d_bias = d_bias; a.d_mask = d_mask; a.log_stride = log_stride;
+    const uint64_t N = count;
     uint32_t gx = (uint32_t)((N + 255) / 256);
     if (gx > 256 * 16) gx = 256 * 16;
     hipLaunchKernelGGL(deep_kernel, dim3(gx), dim3(256), 0, st, a, out);

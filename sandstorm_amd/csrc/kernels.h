@@ -80,7 +80,10 @@ hipError_t launch_batch_inverse(hipStream_t st, Fp *D, uint32_t log_N, const Fp 
 hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace, const void *const *comp,
                        uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *cell_col, const Fp *cell_coef,
                        const uint32_t *group_desc, const Fp *group_k, uint32_t ngroups, const Fp *comp_coef,
-                       const Fp &comp_k, uint32_t log_M, uint32_t log_stride, Fp *out);
+                       const Fp &comp_k, uint64_t count, uint32_t d_bias, uint32_t d_mask, uint32_t log_stride, Fp *out);
+static constexpr uint32_t BATCH_INVERSE_RANGE_LOG_CHUNK = 5;
+hipError_t launch_batch_inverse_range(hipStream_t st, Fp *D, uint64_t len, const Fp &x0, const Fp &w, const Fp &w_inv,
+                                      const Fp &z, bool r280);
 hipError_t launch_gather_cells(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *col,
                                const uint64_t *idx, uint32_t n, Fp *out);
 
@@ -98,11 +101,13 @@ struct VmResolve {
     const void *consts, *consts_r280, *tables, *slots;    // consts_r280: the constants times 2^24 (R280 form)
     const uint32_t *table_desc;      // host copy: [n_tables][2] = (offset in felts, log2 length)
     uint64_t lanes;
-    uint32_t log_N, log_blowup;
+    uint32_t log_blowup;
+    uint32_t trace_mask;             // trace cells at (point + shift) & trace_mask: N - 1 (whole columns) or ~0 (row block)
+    uint32_t row0;                   // global row of the first point (tables are indexed by the global row)
 };
 // caller's 2-word program -> resolved device program: (n_instr + 1) entries of 8 words (quotient.hip)
 void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, const VmResolve &r, uint32_t *dev);
 hipError_t launch_quotient_vm(hipStream_t st, const uint32_t *d_code, uint32_t n_entries, Fp *d_slots, uint64_t lanes,
-                              const Fp &offset, const Fp &w, const Fp &wstep, uint32_t log_N, uint32_t xcd_split, Fp *out);
+                              const Fp &offset, const Fp &w, const Fp &wstep, uint64_t npoints, uint32_t xcd_split, Fp *out);
 
 }  // namespace ss

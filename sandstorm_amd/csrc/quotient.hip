@@ -39,7 +39,8 @@ struct VmArgs {
     Fp *slots;               // [n_slots][total_lanes]
     Fp *out;
     Fp offset, w, wstep;     // x_i = offset * w^i; wstep = w^(total lanes)
-    uint32_t n_entries, log_N, xcd_split;
+    uint32_t n_entries, xcd_split;
+    uint64_t npoints;        // points evaluated (the whole domain or a row block of it)
 };
 
 // ---- device program -------------------------------------------------------------------------
@@ -100,7 +101,7 @@ __device__ __forceinline__ Fp vm_load(const vm_global_u32x4 *p) {
 }
 
 __global__ __launch_bounds__(256, 4) void quotient_vm_kernel(VmArgs a) {
-    const uint64_t N = 1ull << a.log_N;
+    const uint64_t N = a.npoints;
     const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;       // slot-file index
     // XCD-aware point mapping.  Workgroup b runs on XCD b % 8 (observed dispatch order; used
@@ -218,9 +219,9 @@ void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, const Vm
             uint64_t base = 0;
             uint32_t off = 0, mask = 0, fl = VM_F_P;
             if (kind == SS_SRC_TRACE) {
-                base = (uint64_t)r.cols[w1 >> 24]; off = (w1 & 0xffffffu) << r.log_blowup; mask = (uint32_t)((1ull << r.log_N) - 1ull);
-            } else if (kind == SS_SRC_TABLE) {
-                base = (uint64_t)r.tables + 32ull * r.table_desc[2 * w1]; mask = (uint32_t)((1ull << r.table_desc[2 * w1 + 1]) - 1ull);
+                base = (uint64_t)r.cols[w1 >> 24]; off = (w1 & 0xffffffu) << r.log_blowup; mask = r.trace_mask;
+            } else if (kind == SS_SRC_TABLE) {           // tables are indexed by the GLOBAL row
+                base = (uint64_t)r.tables + 32ull * r.table_desc[2 * w1]; off = r.row0; mask = (uint32_t)((1ull << r.table_desc[2 * w1 + 1]) - 1ull);
             } else if (kind == SS_SRC_CONST) {
                 base = (uint64_t)(op == SS_OP_MUL ? r.consts_r280 : r.consts) + 32ull * w1;
             } else {
@@ -236,10 +237,10 @@ void quotient_build_device_code(const uint32_t *code, uint32_t n_instr, const Vm
 }
 
 hipError_t launch_quotient_vm(hipStream_t st, const uint32_t *d_code, uint32_t n_entries, Fp *d_slots, uint64_t lanes,
-                              const Fp &offset, const Fp &w, const Fp &wstep, uint32_t log_N, uint32_t xcd_split, Fp *out) {
+                              const Fp &offset, const Fp &w, const Fp &wstep, uint64_t npoints, uint32_t xcd_split, Fp *out) {
     VmArgs a;
     a.code = d_code; a.slots = d_slots; a.out = out; a.offset = offset; a.w = w; a.wstep = wstep;
-    a.n_entries = n_entries; a.log_N = log_N; a.xcd_split = xcd_split;
+    a.n_entries = n_entries; a.npoints = npoints; a.xcd_split = xcd_split;
     hipLaunchKernelGGL(quotient_vm_kernel, dim3((uint32_t)(lanes / 256)), dim3(256), 0, st, a);
     return hipGetLastError();
 }

@@ -234,50 +234,10 @@ class Prover:
 
         mark("deep")
         # 8. FRI
-        fold = opt.fri_folding_factor
-        log_fold = _log2(fold)
-        evals, log_len, offset_int = deep, log_N, conv.lde_offset
-        degree_bound = n                       # DEEP polynomial: degree < n
-        layers = []
-        fri_flags = be.FRI_UNNORMALISED if conv.fri_unnormalised else 0
-        while degree_bound > opt.fri_max_remainder_coeffs:
-            rows = 1 << (log_len - log_fold)
-            cols = [be.DeviceView(evals, 32 * rows * k, 32 * rows) for k in range(fold)]
-            if conv.bitrev_commit:
-                # committed row r = entries fold*r .. fold*r+fold-1 of the bit-reversed vector = natural row
-                # bitrev(r), its entry j at x_r * w_fold^bitrev(j): the natural stride columns, re-ordered
-                cols = [cols[bitrev(j, log_fold)] for j in range(fold)]
-            layer_matrix = be.Matrix(ctx, cols, rows)
-            tree = Tree.from_matrix(layer_matrix, order)
-            layer = FriLayer(tree.root(), tree.root_tag(), log_len)
-            coin.reseed_with_digest(layer.root)
-            alpha = coin.draw()
-            if conv.fri_alpha_times_offset:     # the reference folds over the unshifted domain: challenge = draw * layer offset
-                alpha = be.felt(canonical(alpha) * offset_int % be.P)
-            proof.fri_alphas.append(alpha)
-            nxt = ctx.alloc(32 * rows)
-            ctx.fri_fold(evals, log_len, fold, alpha, be.felt(offset_int), nxt, fri_flags)     # natural order in memory
-            layers.append((layer, tree, layer_matrix, evals))
-            evals, log_len = nxt, log_len - log_fold
-            offset_int = pow(offset_int, fold, be.P)
-            degree_bound //= fold
-        # remainder: interpolate the last layer, send its (few) coefficients
-        rem = be.Matrix(ctx, [evals], 1 << log_len)
-        rem.interpolate(be.felt(1 if conv.remainder_unshifted else offset_int))
-        rem_host = rem.to_host()[0]
-        assert not np.any(rem_host[max(1, degree_bound):]), "FRI remainder exceeds its degree bound"
-        proof.fri_remainder = rem_host[:max(1, degree_bound)]
-        coin.reseed_with_field_element_vector(list(proof.fri_remainder))
-
+        layers = fri_commit_phase(ctx, Tree, conv, opt, coin, proof, deep, log_N, n)
         mark("fri")
         # 9. proof of work, queries, openings
-        if self.pow_nonce is not None:
-            from .verifier import _verify_pow
-            assert _verify_pow(self.claim.coin_kind, coin.digest, opt.grinding_factor, self.pow_nonce), \
-                "the supplied proof-of-work nonce is not valid for this transcript"
-            proof.pow_nonce = self.pow_nonce
-        else:
-            proof.pow_nonce = ctx.pow_grind(self.claim.coin_kind, coin.digest, opt.grinding_factor) if opt.grinding_factor else 0
+        proof.pow_nonce = proof_of_work(ctx, self.claim.coin_kind, coin, opt, self.pow_nonce)
         mark("pow")
         coin.reseed_with_int(proof.pow_nonce)
         positions = coin.draw_queries(opt.num_queries, N)
@@ -291,19 +251,76 @@ class Prover:
             proof.extension_paths, _ = ext_tree.prove(positions)
         proof.composition_rows = ctx.gather_rows(comp_lde.cols, nat)
         proof.composition_paths, _ = comp_tree.prove(positions)
-        pos = positions
-        for layer, tree, matrix, _ in layers:
-            row_bits = layer.log_len - log_fold
-            rows = 1 << row_bits
-            if conv.bitrev_commit:
-                pos = sorted(set(p >> log_fold for p in pos))          # row r holds entries fold*r .. of the vector
-                nat_rows = [bitrev(r, row_bits) for r in pos]
-            else:
-                pos = sorted(set(p % rows for p in pos))
-                nat_rows = pos
-            layer.positions = pos
-            layer.rows = ctx.gather_rows(matrix.cols, nat_rows)
-            layer.paths, _ = tree.prove(pos)
-            proof.fri_layers.append(layer)
+        fri_open(ctx, conv, opt, proof, layers, positions)
         mark("openings")
         return proof
+
+
+def fri_commit_phase(ctx, Tree, conv, opt, coin, proof, deep, log_N, n):
+    """FRI commit phase on one device (prover.py step 8): commit every layer, draw its challenge, fold; interpolate the
+    last layer into the remainder.  Appends to proof.fri_alphas, sets proof.fri_remainder, advances the coin.
+    -> [(FriLayer, tree, committed matrix, evaluations)]"""
+    order = be.BITREV if conv.bitrev_commit else be.NATURAL
+    fold = opt.fri_folding_factor
+    log_fold = _log2(fold)
+    evals, log_len, offset_int = deep, log_N, conv.lde_offset
+    degree_bound = n                       # DEEP polynomial: degree < n
+    layers = []
+    fri_flags = be.FRI_UNNORMALISED if conv.fri_unnormalised else 0
+    while degree_bound > opt.fri_max_remainder_coeffs:
+        rows = 1 << (log_len - log_fold)
+        cols = [be.DeviceView(evals, 32 * rows * k, 32 * rows) for k in range(fold)]
+        if conv.bitrev_commit:
+            # committed row r = entries fold*r .. fold*r+fold-1 of the bit-reversed vector = natural row
+            # bitrev(r), its entry j at x_r * w_fold^bitrev(j): the natural stride columns, re-ordered
+            cols = [cols[bitrev(j, log_fold)] for j in range(fold)]
+        layer_matrix = be.Matrix(ctx, cols, rows)
+        tree = Tree.from_matrix(layer_matrix, order)
+        layer = FriLayer(tree.root(), tree.root_tag(), log_len)
+        coin.reseed_with_digest(layer.root)
+        alpha = coin.draw()
+        if conv.fri_alpha_times_offset:     # the reference folds over the unshifted domain: challenge = draw * layer offset
+            alpha = be.felt(canonical(alpha) * offset_int % be.P)
+        proof.fri_alphas.append(alpha)
+        nxt = ctx.alloc(32 * rows)
+        ctx.fri_fold(evals, log_len, fold, alpha, be.felt(offset_int), nxt, fri_flags)     # natural order in memory
+        layers.append((layer, tree, layer_matrix, evals))
+        evals, log_len = nxt, log_len - log_fold
+        offset_int = pow(offset_int, fold, be.P)
+        degree_bound //= fold
+    # remainder: interpolate the last layer, send its (few) coefficients
+    rem = be.Matrix(ctx, [evals], 1 << log_len)
+    rem.interpolate(be.felt(1 if conv.remainder_unshifted else offset_int))
+    rem_host = rem.to_host()[0]
+    assert not np.any(rem_host[max(1, degree_bound):]), "FRI remainder exceeds its degree bound"
+    proof.fri_remainder = rem_host[:max(1, degree_bound)]
+    coin.reseed_with_field_element_vector(list(proof.fri_remainder))
+    return layers
+
+
+def proof_of_work(ctx, coin_kind, coin, opt, supplied_nonce=None):
+    if supplied_nonce is not None:
+        from .verifier import _verify_pow
+        assert _verify_pow(coin_kind, coin.digest, opt.grinding_factor, supplied_nonce), \
+            "the supplied proof-of-work nonce is not valid for this transcript"
+        return supplied_nonce
+    return ctx.pow_grind(coin_kind, coin.digest, opt.grinding_factor) if opt.grinding_factor else 0
+
+
+def fri_open(ctx, conv, opt, proof, layers, positions):
+    """query phase of FRI: the rows and authentication paths every layer opens for these query positions"""
+    log_fold = _log2(opt.fri_folding_factor)
+    pos = positions
+    for layer, tree, matrix, _ in layers:
+        row_bits = layer.log_len - log_fold
+        rows = 1 << row_bits
+        if conv.bitrev_commit:
+            pos = sorted(set(p >> log_fold for p in pos))          # row r holds entries fold*r .. of the vector
+            nat_rows = [bitrev(r, row_bits) for r in pos]
+        else:
+            pos = sorted(set(p % rows for p in pos))
+            nat_rows = pos
+        layer.positions = pos
+        layer.rows = ctx.gather_rows(matrix.cols, nat_rows)
+        layer.paths, _ = tree.prove(pos)
+        proof.fri_layers.append(layer)

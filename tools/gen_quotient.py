@@ -67,24 +67,77 @@ def template_program(layout):
     return np.asarray(code, dtype=np.uint32), len(consts), n_slots, len(specs), ncols
 
 
+PREFETCH_DEPTH = 6      # memory operands in flight ahead of their use (one wave per SIMD: nothing else hides the latency)
+DOT_MAX_TERMS = 16      # products accumulated in the 64-bit columns before a Montgomery reduction (16 * 9 * 2^56 < 2^64)
+
+
 def generate(layout):
     code, n_consts, n_slots, n_tables, ncols = template_program(layout)
     n_instr = len(code) // 2
+    ins = [(int(code[2 * pc]) & 0xff, (int(code[2 * pc]) >> 8) & 0xf, (int(code[2 * pc]) >> 12) & 0xf, int(code[2 * pc + 1])) for pc in range(n_instr)]
+    # ---- memory operands in program order: loaded PREFETCH_DEPTH operands ahead into a rotating set of registers
+    mem_ops = []                                    # (pc, macro text)
+    for pc, (op, d, kind, w1) in enumerate(ins):
+        if op <= OP_MUL and kind == SRC_TRACE:
+            assert (w1 >> 24) < ncols
+            mem_ops.append((pc, "QG_TRACE_RAW(%d, %du, %%s)" % (w1 >> 24, w1 & 0xffffff)))
+        elif op <= OP_MUL and kind == SRC_TABLE:
+            assert w1 < n_tables
+            mem_ops.append((pc, "QG_TABLE_RAW(%d, %%s)" % w1))
+    D = min(PREFETCH_DEPTH, len(mem_ops))
+    mem_index = {pc: j for j, (pc, _) in enumerate(mem_ops)}
+    # ---- which "MUL acc, alpha^k ; ADD sum, acc" pairs become terms of a fused dot product: the product's accumulator
+    #      must die with the ADD (its next use, if any, is a write)
+    def dies_after(acc, pc):
+        for op, d, kind, w1 in ins[pc + 1:]:
+            reads = (op <= OP_MUL and kind == SRC_ACC and (w1 & 3) == acc) or (d == acc and op in (OP_ADD, OP_SUB, OP_RSUB, OP_MUL, OP_INV, OP_ST, OP_OUT))
+            if reads:
+                return False
+            if d == acc and op == OP_MOV:
+                return True
+        return True
+    fused = {}                                      # pc of the MUL -> accumulator the term is added to
+    for pc in range(n_instr - 1):
+        op, e, kind, w1 = ins[pc]
+        op2, d2, kind2, w2 = ins[pc + 1]
+        if op == OP_MUL and kind == SRC_CONST and op2 == OP_ADD and kind2 == SRC_ACC and (w2 & 3) == e and d2 != e and dies_after(e, pc + 1):
+            fused[pc] = d2
     out = []
     emit = out.append
     bound = [1, 1, 1, 1]
-    stats = {"mul": 0, "mulr": 0, "reduce": 0, "loads": 0}
+    stats = {"mul": 0, "mulr": 0, "reduce": 0, "loads": len(mem_ops), "fused": 0, "flushes": 0}
+    wide = {"acc": None, "terms": 0}               # the one wide (unreduced 64-bit column) accumulator in flight
 
     def reduce_acc(d):
         emit("    acc%d = fl_weak_reduce(acc%d);" % (d, d))
         bound[d] = 1
         stats["reduce"] += 1
 
-    for pc in range(n_instr):
-        w0, w1 = int(code[2 * pc]), int(code[2 * pc + 1])
-        op, d, kind = w0 & 0xff, (w0 >> 8) & 0xf, (w0 >> 12) & 0xf
-        assert op <= OP_OUT and d < 4
+    def flush_wide():
+        """fold the pending dot product into its accumulator: one Montgomery reduction for all its terms"""
+        d = wide["acc"]
+        if d is None:
+            return
+        if bound[d] + 1 > MAX_BOUND:
+            reduce_acc(d)
+        emit("    acc%d = fl_add(acc%d, qg_dot_reduce(wd));" % (d, d))
+        bound[d] += 1
+        wide["acc"], wide["terms"] = None, 0
+        stats["flushes"] += 1
+
+    def issue(j, nxt):
+        """start the load of memory operand j (of this point, or of the next one) into its rotating register"""
+        emit("    m%d = %s;  QG_PIN_LOADS" % (j % D, mem_ops[j][1] % ("inext" if nxt else "i32")))
+
+    skip_add = set()
+    for pc, (op, d, kind, w1) in enumerate(ins):
         v = "acc%d" % d
+        if pc in skip_add:                          # the ADD of a fused pair: already accounted in the wide accumulator
+            continue
+        # any other touch of the accumulator that carries a pending dot product needs its value: flush first
+        touches = {d} | ({w1 & 3} if op <= OP_MUL and kind == SRC_ACC else set())
+        if wide["acc"] is not None and wide["acc"] in touches and not (pc in fused and fused[pc] == wide["acc"] and wide["acc"] != d):
+            flush_wide()
         # ---- the operand: an expression of type Fl and its lazy bound
         src, sb, src_acc = None, 1, None
         if op <= OP_MUL:
@@ -97,15 +150,8 @@ def generate(layout):
             elif kind == SRC_CONST:
                 assert w1 < n_consts
                 src = ("QG_CONST_R280(%d)" if op == OP_MUL else "QG_CONST(%d)") % w1
-            elif kind == SRC_TRACE:
-                col, off = w1 >> 24, w1 & 0xffffff
-                assert col < ncols
-                src = "QG_TRACE(%d, %du)" % (col, off)
-                stats["loads"] += 1
-            elif kind == SRC_TABLE:
-                assert w1 < n_tables
-                src = "QG_TABLE(%d)" % w1
-                stats["loads"] += 1
+            elif kind in (SRC_TRACE, SRC_TABLE):
+                src = "fl_from_fp(m%d)" % (mem_index[pc] % D)
             else:
                 assert kind == SRC_X
                 src = "x"
@@ -155,21 +201,39 @@ def generate(layout):
             emit("    %s = fl_sub_c<2, 1>(%s, %s);" % (v, src, v))
             bound[d] = sb + 1
         elif op == OP_MUL:
-            if src_acc == d:                                   # v * v: the square routine wants a normalised value
+            tgt = fused.get(pc)
+            if tgt is not None and (wide["acc"] in (None, tgt)):
+                # term of a dot product: acc_tgt += v * alpha^k with the reduction deferred (the multiplicand must be
+                # normalised: 9 products of 28-bit limbs per column, DOT_MAX_TERMS of them, stay below 2^64)
+                if bound[d] > 1:
+                    reduce_acc(d)
+                if wide["acc"] is None:
+                    emit("    qg_dot_zero(wd);")
+                    wide["acc"] = tgt
+                emit("    qg_dot_mad(wd, %s, %s);" % (v, src))
+                wide["terms"] += 1
+                stats["fused"] += 1
+                skip_add.add(pc + 1)
+                if wide["terms"] == DOT_MAX_TERMS:
+                    flush_wide()
+            elif src_acc == d:                                 # v * v: the square routine wants a normalised value
                 if bound[d] > 1:
                     reduce_acc(d)
                 emit("    %s = fl_sqr(%s);" % (v, v))
+                bound[d] = 1
             elif kind == SRC_CONST:
                 emit("    %s = fl_mul_r280(%s, %s);" % (v, v, src))
                 stats["mulr"] += 1
+                bound[d] = 1
             elif sb > 1 and bound[d] == 1:                      # the lazy side may be either factor
                 emit("    %s = fl_mul(%s, %s);" % (v, src, v))
+                bound[d] = 1
             else:
                 if sb > 1:
                     reduce_src()
                 emit("    %s = fl_mul(%s, %s);" % (v, v, src))
+                bound[d] = 1
             stats["mul"] += 1
-            bound[d] = 1
         elif op == OP_INV:
             if bound[d] > 1:
                 reduce_acc(d)
@@ -183,16 +247,25 @@ def generate(layout):
                 reduce_acc(d)
             emit("    s%d = %s;" % (w1, v))
         else:
+            flush_wide()
             emit("    qstore(a.out + i, fl_to_fp(%s));" % v)
+        # this instruction consumed memory operand j: start the load of operand j + D (of the next point past the end)
+        if pc in mem_index:
+            j = mem_index[pc] + D
+            issue(j % len(mem_ops), j >= len(mem_ops))
+    assert wide["acc"] is None
     body = "\n".join(out)
     h = code_hash(code)
     slots = "".join("    Fl s%d = fl_zero();\n" % s for s in range(n_slots))
+    regs = "    Fp " + ", ".join("m%d" % k for k in range(D)) + ";\n"
+    prime = "".join("    m%d = %s;\n" % (j, mem_ops[j][1] % "i32") for j in range(D))
     src = '''// GENERATED by tools/gen_quotient.py - DO NOT EDIT; regenerate with `python tools/gen_quotient.py %(layout)s`.
 //
 // The composition constraint of the `%(layout)s` layout (layouts/src/%(layout)s/air.rs; lowered by
 // sandstorm_amd/host/air_%(layout)s.cpp + air_program.cpp) as straight-line code for gfx950: %(n_instr)d program
-// instructions, %(mul)d multiplications (%(mulr)d of them by a constant in R280 form), %(loads)d trace / table operand
-// loads, %(reduce)d weak reductions placed at generation time, %(n_slots)d register-resident scratch values.
+// instructions, %(mul)d multiplications (%(mulr)d by a constant in R280 form, %(fused)d more as terms of %(flushes)d fused
+// dot products with one Montgomery reduction each), %(loads)d trace / table operand loads issued %(depth)d operands ahead
+// of their use, %(reduce)d weak reductions placed at generation time, %(n_slots)d register-resident scratch values.
 // Code hash (FNV-1a of the program's code words) 0x%(hash)016x: ss_eval_quotient launches this kernel for exactly
 // that program and interprets any other.
 #include "quotient_gen.h"
@@ -201,9 +274,11 @@ namespace ss {
 namespace {
 
 __global__ __launch_bounds__(QG_THREADS) void quotient_%(layout)s_kernel(QGenArgs a) {
-    QG_PROLOGUE
+    QG_PROLOGUE(%(n_consts)d)
     Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
-%(slots)s    QG_POINT_LOOP_BEGIN
+    QgWide wd;
+%(slots)s%(regs)s    uint32_t i32 = (uint32_t)lane;
+%(prime)s    QG_POINT_LOOP_BEGIN
 %(body)s
     QG_POINT_LOOP_END
 }
@@ -222,12 +297,13 @@ const QGenKernel &quotient_gen_%(layout)s() {
 
 }  // namespace ss
 ''' % dict(layout=layout, n_instr=n_instr, n_slots=n_slots, n_consts=n_consts, n_tables=n_tables, ncols=ncols, hash=h, slots=slots,
-           body=body, **stats)
+           body=body, regs=regs, prime=prime, depth=D, **stats)
     path = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s.hip" % layout)
     with open(path, "w") as f:
         f.write(src)
-    print("%s: %d instructions, %d multiplications (%d by constants), %d loads, %d reductions, hash %016x -> %s"
-          % (layout, n_instr, stats["mul"], stats["mulr"], stats["loads"], stats["reduce"], h, os.path.relpath(path, ROOT)))
+    print("%s: %d instructions, %d multiplications (%d by constants, %d fused into %d dot products), %d loads, %d reductions, hash %016x -> %s"
+          % (layout, n_instr, stats["mul"], stats["mulr"], stats["fused"], stats["flushes"], stats["loads"], stats["reduce"], h,
+             os.path.relpath(path, ROOT)))
 
 
 if __name__ == "__main__":
