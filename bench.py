@@ -129,6 +129,76 @@ def cpu_baseline(layout, log_steps_full, gpu_ctx):
                       "`value` = that CPU time x %.1f (n log n to 2^%d steps)" % (layout, sample, ls, t_cpu, threads, t_gpu, scale, log_steps_full)}
 
 
+def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
+    """--gpus N > 1: ONE proof over the N GPUs of the node (sandstorm_amd/sharded_prover.py): trace columns extended on
+    their owner (column c on rank c % N), point-to-point re-shards into row blocks over RCCL, row hashing / constraint
+    evaluation / DEEP on row blocks, leaf-block sub-trees + root all-gather, composition and DEEP gathers and FRI on rank 0.
+    A step = one whole proof; the time is the max over ranks between two barriers; strong scaling."""
+    from sandstorm_amd import backend as be, extension
+    from sandstorm_amd.prover import Claim, ProofOptions
+    from sandstorm_amd.sharded_prover import Comm, ShardedProver
+    L, pi = _sample_statement(layout, log_steps)
+    n = 16 << log_steps
+    ctx = be.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    air = L.make_air(ctx, pi, n)
+    nb, ne = air.num_base_columns, air.num_extension_columns
+    if layout == "recursive":
+        tree, coin = be.FriendlyMerkleTree, be.COIN_CAIRO
+    else:
+        tree, coin = be.LeafVariantMerkleTree, be.COIN_SOLIDITY
+    comm = Comm(device=device)
+    prover = ShardedProver(ctx, Claim(air, tree, coin), comm, ProofOptions())
+    mine = {c: synth_columns(device, 1, log_steps + 4, seed=0x53414E44 + c)[0] for c in range(nb) if c % world == rank}
+    my_ext = [c for c in range(nb, nb + ne) if c % world == rank]
+    aux = synth_columns(device, 5 if layout == "recursive" else 3, log_steps + 4, seed=0x7E57) if my_ext else None
+
+    def build_extension(challenges):
+        if not my_ext:
+            return {}
+        # every owner of an extension column runs the layout's scans on the auxiliary columns (resident on it) and keeps its own
+        out = be.Matrix(ctx, [torch.zeros((n, 4), dtype=torch.int64, device=device) for _ in range(ne)], n)
+        tc = extension.TraceColumns(aux[0], aux[1], aux[2], n, *(aux[3:5] if layout == "recursive" else ()))
+        extension.build_extension_columns(layout, ctx, tc, challenges, check=False, out=out)
+        return {c: out.cols[c - nb] for c in my_ext}
+    seed = bytes((7 * i) & 0xff for i in range(32))
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+    proof = prover.prove(seed, mine, build_extension, n)
+    for _ in range(args.warmup):
+        prover.prove(seed, mine, build_extension, n)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        prover.prove(seed, mine, build_extension, n)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    sec = float(tmax.item()) / args.steps
+    if rank == 0:
+        print(json.dumps({
+            "metric": "prove_wall_time_s", "value": sec, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": sec * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u256 (Fp252, Montgomery R=2^256, 8 x u32 limbs)", "data": "synthetic", "proofs_per_s": 1.0 / sec,
+            "config": {"workload": args.workload, "layout_shape": layout, "steps_log2": log_steps, "trace_rows_log2": log_steps + 4,
+                       "columns": "%d base + %d extension" % (nb, ne),
+                       "parallelism": "ONE proof sharded over %d GPUs: LDE by column (column c on rank c %% %d), row hashing / constraint "
+                                      "evaluation / DEEP by row block (point-to-point re-shard over RCCL, wrap-around halo of %d rows), "
+                                      "leaf-block sub-trees + root all-gather, composition interpolation / DEEP extension / FRI on rank 0"
+                                      % (world, world, max(o for _, o in air.mask) << 1),
+                       "air": "the REAL %s AIR (%d mask cells) on synthetic columns" % (layout, len(air.mask)),
+                       "claim": "CairoVerifierClaim (Blake2s+Pedersen-22 tree, Cairo coin)" if layout == "recursive"
+                                else "EthVerifierClaim (Keccak-masked-20 tree, Solidity coin)",
+                       "proof_options": "65 queries, blowup 2, 16 PoW bits, FRI fold 8, <=16 remainder coeffs",
+                       "host": "Python host (sandstorm_amd/sharded_prover.py) over the C ABI + torch.distributed (nccl = RCCL)",
+                       "fri_layers": len(proof.fri_layers) if proof is not None else None,
+                       "note": "python bench.py --gpus N --mode replicas runs N independent proofs instead (weak scaling)"},
+        }))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +206,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="starknet_2p20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="auto", choices=["auto", "shard", "replicas"],
+                    help="N > 1 GPUs: shard = ONE proof over the N GPUs (column-sharded LDE, row-block hashing / constraints / DEEP, "
+                         "RCCL point-to-point re-shards; strong scaling) - the default; replicas = one independent proof per GPU (weak scaling)")
     ap.add_argument("--air", default="real", choices=["real", "synthetic"],
                     help="real: the layout's own composition constraint (default); synthetic: round 1's layout-shaped stand-in")
     args = ap.parse_args()
@@ -156,6 +229,12 @@ def main():
     from sandstorm_amd.prover import ProofOptions
 
     layout, log_steps = WORKLOADS[args.workload]
+    if (world > 1 and args.mode == "auto" or args.mode == "shard") and layout in ("starknet", "recursive"):
+        if world == 1:                      # --mode shard on one GPU: the sharded driver with a group of one (smoke / profiling)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        return bench_sharded(args, layout, log_steps, rank, local_rank, world, device)
     log_n, lb = log_steps + 4, 1
     n = 1 << log_n
     ctx = be.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)

@@ -44,8 +44,8 @@ def _is_one(limbs):
     return canonical(limbs) == 1
 
 
-def build_extension_columns(layout, ctx, cols: TraceColumns, challenges, check=True):
-    """-> backend.Matrix of the extension columns, resident in HBM.
+def build_extension_columns(layout, ctx, cols: TraceColumns, challenges, check=True, out=None):
+    """-> backend.Matrix of the extension columns, resident in HBM (`out`: a Matrix of caller-owned columns to fill).
     recursive: [diluted_check_aggregate (col 7), diluted_check_permutation (col 8), mem_and_rc_permutation (col 9)]
     starknet:  [permutation_column (col 9)]
     check: raise PermutationCheckError where the reference asserts that a product closes to one."""
@@ -55,7 +55,7 @@ def build_extension_columns(layout, ctx, cols: TraceColumns, challenges, check=T
     n_mem, n_rc = n // MEMORY_STEP, n // RANGE_CHECK_STEP
     step = DILUTED_CHECK_STEP[layout]
     if layout == "recursive":
-        out = be.Matrix.empty(ctx, 3, n)
+        out = out or be.Matrix.empty(ctx, 3, n)
         agg, dperm, mem_rc = out.cols
         for c in out.cols:
             ctx.zero(c)
@@ -68,7 +68,7 @@ def build_extension_columns(layout, ctx, cols: TraceColumns, challenges, check=T
         last_dc = ctx.permutation_product((cols.diluted_unordered, 1, 0, -1), (cols.diluted_ordered, 1, 0, -1), n, z_dc, None, dperm)
         ctx.diluted_aggregate(cols.diluted_ordered, 1, 0, n, z_agg, a_agg, agg)
     elif layout == "starknet":
-        out = be.Matrix.empty(ctx, 1, n)
+        out = out or be.Matrix.empty(ctx, 1, n)
         perm = out.cols[0]
         ctx.zero(perm)
         # enum Permutation {Memory = 0, RangeCheck = 1, DilutedCheck = 7}, DilutedCheck {Unordered = 1, Ordered = 5,

@@ -55,15 +55,23 @@ class Comm:
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device                        # torch device of the exchanged tensors
+        self.stage_through_host = dist.get_backend() == "gloo" and device is not None and _torch().device(device).type == "cuda"
 
     def exchange(self, sends, recvs):
         """sends / recvs: [(peer, tensor)] in a fixed, globally agreed order per pair of ranks.  Point-to-point, all
         posted at once: on xGMI every pair of GPUs has its own link, so the R (R-1) transfers of a re-shard run concurrently."""
         dist = self.dist
+        staged = []
+        if self.stage_through_host:                 # gloo moves host memory only (ranks sharing one GPU in the tests)
+            sends = [(p, t.cpu()) for p, t in sends]
+            staged = [(t, t.cpu()) for _, t in recvs]
+            recvs = [(p, h) for (p, _), (_, h) in zip(recvs, staged)]
         ops = [dist.P2POp(dist.isend, t, p) for p, t in sends] + [dist.P2POp(dist.irecv, t, p) for p, t in recvs]
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        for dev, host in staged:
+            dev.copy_(host)
 
     def all_gather_object(self, obj):
         out = [None] * self.world
@@ -71,9 +79,9 @@ class Comm:
         return out
 
     def gather_object(self, obj, dst=0):
-        out = [None] * self.world if self.rank == dst else None
-        self.dist.gather_object(obj, out, dst=dst)
-        return out
+        """(an all-gather underneath: gather_object is not available on every backend, and the objects are small)"""
+        out = self.all_gather_object(obj)
+        return out if self.rank == dst else None
 
     def broadcast_object(self, obj, src=0):
         box = [obj]

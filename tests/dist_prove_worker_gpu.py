@@ -1,0 +1,81 @@
+"""Worker of tests/test_gpu_sharded.py: one rank of a sharded proof with the REAL kernels.  The GPU box has one GPU, so
+the ranks share it (each with its own context) and exchange through gloo, staged through host memory; on a multi-GPU
+node the same driver runs one rank per GPU over RCCL (bench.py --gpus N)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from sandstorm_amd import backend as be, wire               # noqa: E402
+from sandstorm_amd.coin import canonical, keccak256         # noqa: E402
+from sandstorm_amd.prover import Claim, ProofOptions        # noqa: E402
+from sandstorm_amd.sharded_prover import Comm, ShardedProver  # noqa: E402
+
+
+def main():
+    backend = sys.argv[3] if len(sys.argv) > 3 else "gloo"
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    dist.init_process_group(backend=backend, **({"device_id": device} if backend == "nccl" else {}))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    case, out_path = sys.argv[1], sys.argv[2]
+    ctx = be.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+
+    def tensor(limbs):
+        return torch.from_numpy(np.ascontiguousarray(limbs, dtype=np.uint64).view(np.int64).copy()).to(device)
+
+    def mont(values):                                       # canonical ints -> Montgomery limbs (host, R = 2^256)
+        return np.stack([be.felt(v) for v in values])
+    if case == "example":
+        from sandstorm_amd import extension, public_input
+        from sandstorm_amd.layouts import recursive as rec
+        from tests.test_layout_recursive import load_run
+        states, memory, pi = load_run()
+        host = [mont(c) for c in rec.base_trace(states, memory, pi)]
+        n = len(host[0])
+        claim = Claim(rec.make_air(ctx, pi, n), be.LeafVariantMerkleTreeUnmasked, be.COIN_SOLIDITY)
+        opt = ProofOptions(num_queries=12, grinding_factor=8)
+        seed = public_input.public_coin_seed(pi, be.COIN_SOLIDITY)
+        cols = dict(enumerate(host))
+
+        def ext(challenges):
+            full = [ctx.column(c) for c in host]
+            m = extension.build_extension_columns("recursive", ctx, rec.trace_columns(ctx, full, n), challenges)
+            return {7 + k: tensor(m.cols[k].download(np.uint64, (n, 4))) for k in range(3) if (7 + k) % world == rank}
+
+        def leaf_hash(vals):
+            return keccak256(b"".join((v * wire._R % wire.P).to_bytes(32, "big") for v in vals))
+    else:
+        from tests import mini_air
+        log_n, max_remainder = (int(v) for v in case.split(":")[1:])
+        n = 1 << log_n
+        c0, c1 = mini_air.base_trace(n)
+        cols = {0: mont(c0), 1: mont(c1)}
+        claim = Claim(mini_air.make_air(mont), be.LeafVariantMerkleTree, be.COIN_SOLIDITY)
+        opt = ProofOptions(num_queries=12, grinding_factor=8, fri_max_remainder_coeffs=max_remainder)
+        seed = bytes(range(32))
+
+        def ext(challenges):
+            return {2: tensor(mont(mini_air.extension_trace(c0, canonical(challenges[0]))))} if 2 % world == rank else {}
+
+        def leaf_hash(vals):
+            return keccak256(b"".join((v * wire._R % wire.P).to_bytes(32, "big") for v in vals))[:20] + bytes(12)
+    comm = Comm(device=device)
+    prover = ShardedProver(ctx, claim, comm, opt)
+    mine = {c: tensor(v) for c, v in cols.items() if c % world == rank}
+    proof = prover.prove(seed, mine, ext, n)
+    if rank == 0:
+        with open(out_path, "wb") as f:
+            f.write(wire.serialize(wire.from_proof(proof, leaf_hash)))
+        print("SHARDED_PROOF_WRITTEN")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
