@@ -139,7 +139,11 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     from sandstorm_amd.sharded_prover import Comm, ShardedProver
     L, pi = _sample_statement(layout, log_steps)
     n = 16 << log_steps
-    ctx = be.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    # ONE stream for torch's tensor ops, the collectives and the C ABI's kernels (torch's default stream has handle 0, which
+    # ss_ctx_set_stream reads as "the context's own stream")
+    stream = torch.cuda.Stream(device)
+    torch.cuda.set_stream(stream)
+    ctx = be.Context(local_rank, stream=stream.cuda_stream)
     air = L.make_air(ctx, pi, n)
     nb, ne = air.num_base_columns, air.num_extension_columns
     if layout == "recursive":

@@ -189,38 +189,60 @@ __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ 
     for (uint64_t m = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; m < M;
          m += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = m << a.log_stride;        // LDE row of this point
-        Fl acc = fl_zero();                          // lazy sum of normalised products
-        uint32_t acc_terms = 0;
+        // Both levels of the sum are fused dot products (fl252.h FlWide): the inner sum over a group's cells and the outer
+        // sum over the groups accumulate their 81 partial products per term in 64-bit columns and pay ONE Montgomery
+        // reduction per <= 16 terms instead of one per product (a product's reduction is more than half of its instructions).
+        Fl acc = fl_zero();                          // reduced partial sums of the outer level (lazy adds)
+        FlWide wo;                                   // outer: sum_g inner_g * D[i - shift_g]
+        fl_wide_zero(wo);
+        uint32_t outer_terms = 0, acc_terms = 0;
         for (uint32_t g = 0; g < a.ngroups; ++g) {
             const uint32_t shift = group_desc[3 * g], first = group_desc[3 * g + 1], cnt = group_desc[3 * g + 2];
             Fl inner = fl_zero();
+            uint32_t parts = 0;                      // reduced partial sums folded into `inner` so far (each < 1.01 p)
+            FlWide wi;
+            fl_wide_zero(wi);
             uint32_t terms = 0;
             for (uint32_t j = first; j < first + cnt; ++j) {
                 const uint32_t col = cell_col[j];
                 const Fp *tp = a.trace[0];
 #pragma unroll
                 for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) tp = a.trace[c];
-                inner = fl_add(inner, fl_mul_r280(fl_from_fp(dload(tp + i)), fl_from_fp(dload_uniform(a.cell_coef + j))));
-                if (++terms == 12) { inner = fl_weak_reduce(inner); terms = 1; }      // 12 x 1.13p < 16p
+                // both factors are canonical images from memory: normalised limbs
+                fl_wide_mad(wi, fl_from_fp(dload(tp + i)), fl_from_fp(dload_uniform(a.cell_coef + j)));
+                if (++terms == (uint32_t)FL_WIDE_MAX_TERMS) {
+                    inner = fl_add(inner, fl_wide_reduce(wi));
+                    fl_wide_zero(wi);
+                    terms = 0;
+                    if (++parts == 6) { inner = fl_weak_reduce(inner); parts = 1; }
+                }
             }
-            // inner: at most 12 units (a reduced value + 11 products, or 12 products): value < 13.2p, limbs < 12 * 2^28.
-            // The lazy subtraction adds 2p and one 2^28 per limb: value < 15.2p < 2^256, limbs < 2^32 - exactly what
-            // the multiplicand side of fl_mul_r280 accepts, so no reduction is needed before the multiplication
-            inner = fl_sub_c<2, 1>(inner, fl_from_fp(dload_uniform(a.group_k + g)));
-            acc = fl_add(acc, fl_mul_r280(inner, fl_from_fp(dload(a.D + (((uint32_t)m + a.d_bias - shift) & a.d_mask)))));
-            if (++acc_terms == 12) { acc = fl_weak_reduce(acc); acc_terms = 1; }
+            if (terms) { inner = fl_add(inner, fl_wide_reduce(wi)); ++parts; }
+            // inner: <= 7 reduced values: < 7.1 p, limbs < 7 * 2^28; minus K_g (lazy subtraction: + 2p), then normalised
+            // for the outer product
+            inner = fl_weak_reduce(fl_sub_c<2, 1>(inner, fl_from_fp(dload_uniform(a.group_k + g))));
+            fl_wide_mad(wo, inner, fl_from_fp(dload(a.D + (((uint32_t)m + a.d_bias - shift) & a.d_mask))));
+            if (++outer_terms == (uint32_t)FL_WIDE_MAX_TERMS) {
+                acc = fl_add(acc, fl_wide_reduce(wo));
+                fl_wide_zero(wo);
+                outer_terms = 0;
+                if (++acc_terms == 6) { acc = fl_weak_reduce(acc); acc_terms = 1; }
+            }
         }
         if (a.ncomp) {
-            Fl inner = fl_zero();
+            FlWide wi;
+            fl_wide_zero(wi);
             for (uint32_t k = 0; k < a.ncomp; ++k) {
                 const Fp *hp = a.comp[0];
 #pragma unroll
                 for (int c = 1; c < 4; ++c) if (k == (uint32_t)c) hp = a.comp[c];
-                inner = fl_add(inner, fl_mul_r280(fl_from_fp(dload(hp + i)), fl_from_fp(dload_uniform(a.comp_coef + k))));
+                fl_wide_mad(wi, fl_from_fp(dload(hp + i)), fl_from_fp(dload_uniform(a.comp_coef + k)));
             }
-            inner = fl_sub_c<2, 1>(inner, fl_from_fp(a.comp_k));            // ncomp <= 4 products: same bound argument
-            acc = fl_add(acc, fl_mul_r280(inner, fl_from_fp(dload(a.Dc + m))));
+            const Fl inner = fl_weak_reduce(fl_sub_c<2, 1>(fl_wide_reduce(wi), fl_from_fp(a.comp_k)));
+            fl_wide_mad(wo, inner, fl_from_fp(dload(a.Dc + m)));
+            ++outer_terms;
         }
+        if (outer_terms) acc = fl_add(acc, fl_wide_reduce(wo));      // <= 6 + 1 reduced values: < 32 p for fl_to_fp
         dstore(out + m, fl_to_fp(acc));
     }
 }

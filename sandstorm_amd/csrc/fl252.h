@@ -229,6 +229,45 @@ SS_HD Fl fl_mul_r280(const Fl &a, const Fl &t) {
     r.l[8] = (u32)(c[18] + carry);
     return r;
 }
+// ---- fused dot products: sum_k a_k * t_k (t_k in R280 form) with ONE Montgomery reduction.  The 81 partial products of
+// every term go straight into 19 64-bit columns; with normalised 28-bit limbs on both sides a column grows by < 9 * 2^56 per
+// term, so FL_WIDE_MAX_TERMS terms stay below 2^64 with room for the reduction's own terms.  fl_wide_reduce is the ten-step
+// R280 reduction of fl_mul_r280: result normalised, < terms * 2p * p / 2^280 + p < 1.01 p.  A term costs its 81
+// v_mad_u64_u32 and nothing else - the reduction (more than half of a product's instructions) is paid once per sum.
+struct FlWide { u64 c[19]; };
+static constexpr int FL_WIDE_MAX_TERMS = 16;
+SS_HD void fl_wide_zero(FlWide &w) {
+#pragma unroll
+    for (int k = 0; k < 19; ++k) w.c[k] = 0;
+}
+SS_HD void fl_wide_mad(FlWide &w, const Fl &a, const Fl &t) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) w.c[i + j] += (u64)a.l[i] * t.l[j];
+}
+SS_HD Fl fl_wide_reduce(FlWide &w) {
+    const u32 k24 = fl_opaque(1u << 24), k27 = fl_opaque(1u << 27), k1 = fl_opaque(1u);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const u32 m = (0u - (u32)w.c[i]) & FL_MASK;
+        w.c[i + 1] += ((u64)m * k1 + w.c[i]) >> 28;
+        w.c[i + 6] += (u64)m * k24;
+        w.c[i + 7] += (u64)m * k1;
+        w.c[i + 8] += (u64)m * k27;
+    }
+    Fl r;
+    u64 carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u64 v = w.c[10 + j] + carry;
+        r.l[j] = (u32)v & FL_MASK;
+        carry = v >> 28;
+    }
+    r.l[8] = (u32)(w.c[18] + carry);
+    return r;
+}
+
 // interchange-domain image (x * 2^256, canonical) -> R280 form of x (x * 2^280 mod p, canonical, limbs)
 SS_HD Fl fl_to_r280(const Fp &mont256) {
     Fp two24 = fp_zero(); two24.v[0] = 1u << 24;

@@ -59,49 +59,22 @@ __device__ __forceinline__ void qg_store(Fp *p, const Fp &x) {
 // is a broadcast, its latency is short and known to the scheduler - unlike ~25 KB of scalar loads that miss the 16 KB
 // scalar cache in front of every multiplication
 static constexpr int QG_CONST_LDS_STRIDE = 18;
-__device__ __forceinline__ Fl qg_const_lds(const uint32_t *c) {
+// LDS pointers carry their address space (32-bit, ds_* instructions) also through the per-point laundering below
+typedef uint32_t __attribute__((address_space(3))) *qg_lds_u32;
+typedef qg_u32x4 __attribute__((address_space(3))) *qg_lds_u32x4;
+__device__ __forceinline__ Fl qg_const_lds(const qg_lds_u32 c) {
     Fl r;
 #pragma unroll
     for (int k = 0; k < 9; ++k) r.l[k] = c[k];
     return r;
 }
 
-// ---- fused dot products: sum_k a_k * t_k with ONE Montgomery reduction.  The 81 partial products of every term go
-// straight into 19 64-bit columns (normalised 28-bit limbs on both sides: a column grows by < 9 * 2^56 per term, so 16
-// terms stay below 2^64 with room for the reduction's own terms); qg_dot_reduce is the ten-step R280 reduction of
-// fl_mul_r280.  Used for sum_k alpha^k C_k, where it replaces a reduction and an addition per constraint by 1 / 16 of one.
-struct QgWide { u64 c[19]; };
-__device__ __forceinline__ void qg_dot_zero(QgWide &w) {
-#pragma unroll
-    for (int k = 0; k < 19; ++k) w.c[k] = 0;
-}
-__device__ __forceinline__ void qg_dot_mad(QgWide &w, const Fl &a, const Fl &t) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-#pragma unroll
-        for (int j = 0; j < 9; ++j) w.c[i + j] += (u64)a.l[i] * t.l[j];
-}
-__device__ __forceinline__ Fl qg_dot_reduce(QgWide &w) {
-    const u32 k24 = fl_opaque(1u << 24), k27 = fl_opaque(1u << 27), k1 = fl_opaque(1u);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const u32 m = (0u - (u32)w.c[i]) & FL_MASK;
-        w.c[i + 1] += ((u64)m * k1 + w.c[i]) >> 28;
-        w.c[i + 6] += (u64)m * k24;
-        w.c[i + 7] += (u64)m * k1;
-        w.c[i + 8] += (u64)m * k27;
-    }
-    Fl r;
-    u64 carry = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const u64 v = w.c[10 + j] + carry;
-        r.l[j] = (u32)v & FL_MASK;
-        carry = v >> 28;
-    }
-    r.l[8] = (u32)(w.c[18] + carry);
-    return r;
-}
+// fused dot products (fl252.h FlWide): used for sum_k alpha^k C_k, where they replace a reduction and an addition per
+// constraint by 1 / 16 of one
+typedef FlWide QgWide;
+#define qg_dot_zero fl_wide_zero
+#define qg_dot_mad fl_wide_mad
+#define qg_dot_reduce fl_wide_reduce
 
 // operands (the generator writes these with immediates).  `idx` is the point's local index: this point's, or the next
 // point's for the loads issued across the loop edge.
@@ -109,11 +82,34 @@ __device__ __forceinline__ Fl qg_dot_reduce(QgWide &w) {
 #define QG_TABLE_RAW(t, idx) qg_load_raw(a.tables + tdesc[2 * (t)], ((idx) + row0) & tdesc[2 * (t) + 1])
 #define QG_CONST(k) qg_const_lds(lds_consts + QG_CONST_LDS_STRIDE * (k))
 #define QG_CONST_R280(k) qg_const_lds(lds_consts + QG_CONST_LDS_STRIDE * (k) + 9)
-// keep a load where the generator put it: everything but vector-memory instructions may still be scheduled across
-#define QG_PIN_LOADS __builtin_amdgcn_sched_barrier(0x1 | 0x2 | 0x4 | 0x8 | 0x80 | 0x100 | 0x200);
+// keep a load where the generator put it: ALU instructions and LDS writes may still be scheduled across, vector-memory
+// instructions and LDS reads may not (an LDS read of a constant depends on nothing: unpinned, hundreds of them float
+// to the top of the point and sit in registers until used)
+#define QG_PIN_LOADS __builtin_amdgcn_sched_barrier(0x1 | 0x2 | 0x4 | 0x8 | 0x200);
 
-#define QG_PROLOGUE(NCONSTS)                                                                          \
-    __shared__ uint32_t lds_consts[(NCONSTS) * QG_CONST_LDS_STRIDE];                                  \
+// scratch slots of the program: per point, in LDS as 32-byte images in two 16-byte planes [slot][lane] (a lane's 16 bytes
+// next to its neighbour's: conflict-free b128 accesses), so that the registers hold only what is being computed on
+#define QG_SLOT_STORE(k, v) qg_slot_store(lds_slots, (k), fl_pack(v))
+#define QG_SLOT(k) fl_from_fp(qg_slot_load(lds_slots, (k)))
+__device__ __forceinline__ void qg_slot_store(qg_lds_u32x4 slots, int k, const Fp &x) {
+    slots[(2 * k) * QG_THREADS + threadIdx.x] = qg_u32x4{x.v[0], x.v[1], x.v[2], x.v[3]};
+    slots[(2 * k + 1) * QG_THREADS + threadIdx.x] = qg_u32x4{x.v[4], x.v[5], x.v[6], x.v[7]};
+}
+__device__ __forceinline__ Fp qg_slot_load(const qg_lds_u32x4 slots, int k) {
+    const qg_u32x4 lo = slots[(2 * k) * QG_THREADS + threadIdx.x], hi = slots[(2 * k + 1) * QG_THREADS + threadIdx.x];
+    Fp r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+static inline size_t qg_lds_bytes(int nconsts, int nslots) {
+    return (size_t)nslots * 2 * QG_THREADS * 16 + (size_t)nconsts * QG_CONST_LDS_STRIDE * 4;
+}
+
+#define QG_PROLOGUE(NCONSTS, NSLOTS)                                                                  \
+    extern __shared__ __attribute__((aligned(16))) unsigned char qg_smem[];                           \
+    qg_lds_u32x4 lds_slots = (qg_lds_u32x4)qg_smem;                                                   \
+    qg_lds_u32 lds_consts = (qg_lds_u32)(qg_smem + (size_t)(NSLOTS) * 2 * QG_THREADS * 16);           \
     for (uint32_t k = threadIdx.x; k < (uint32_t)(NCONSTS) * QG_CONST_LDS_STRIDE; k += blockDim.x)    \
         lds_consts[k] = a.consts[(k / QG_CONST_LDS_STRIDE) * QG_CONST_STRIDE + (k % QG_CONST_LDS_STRIDE < 9 ? k % QG_CONST_LDS_STRIDE : k % QG_CONST_LDS_STRIDE + 3)]; \
     __syncthreads();                                                                                  \
@@ -129,7 +125,9 @@ __device__ __forceinline__ Fl qg_dot_reduce(QgWide &w) {
 #define QG_POINT_LOOP_BEGIN                                                                           \
     for (uint64_t i = lane; i < N; i += lanes) {                                                      \
         i32 = (uint32_t)i;                                                                            \
-        const uint32_t inext = (uint32_t)(i + lanes < N ? i + lanes : i);
+        const uint32_t inext = (uint32_t)(i + lanes < N ? i + lanes : i);                             \
+        /* the constants do not change, but their loads must not be hoisted out of the loop (thousands of registers) */ \
+        asm volatile("" : "+v"(lds_consts), "+v"(lds_slots));
 
 #define QG_POINT_LOOP_END                                                                             \
         x = fl_mul(x, wstep);                                                                         \

@@ -281,7 +281,7 @@ int ssh_verify(ssh_air *air_h, int tree_kind, int coin_kind, const uint8_t seed[
         Conventions conv;
         if (!conventions) { conv.bitrev_commit = false; conv.fri_unnormalised = false; conv.remainder_unshifted = false; }
         conv.fri_alpha_times_offset = conventions == 2;       // 2: the shipped conventions plus the reference's FRI challenge scaling
-        const WireProof w = parse_wire(proof, proof_len);
+        const WireProof w = parse_wire(proof, proof_len, tree_kind);
         ProofOptions exp;
         if (expected_options) {
             exp.num_queries = expected_options[0]; exp.lde_blowup_factor = expected_options[1]; exp.grinding_factor = expected_options[2];

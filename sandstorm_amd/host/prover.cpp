@@ -52,9 +52,11 @@ std::unique_ptr<MerkleTree> MerkleTree::from_matrix(ss_ctx *ctx, int tree_kind, 
     }
     return t;
 }
-std::vector<uint8_t> MerkleTree::prove(const std::vector<uint64_t> &idx) const {
+std::vector<uint8_t> MerkleTree::prove(const std::vector<uint64_t> &idx, std::vector<uint8_t> *tags) const {
     std::vector<uint8_t> out(idx.size() * log2u(n_) * 32);
-    ok(ss_merkle_open(ctx_, nodes_->u8(), tags_ ? tags_->u8() : nullptr, n_, idx.data(), (uint32_t)idx.size(), out.data(), nullptr));
+    if (tags) tags->assign(idx.size() * log2u(n_), 0);
+    ok(ss_merkle_open(ctx_, nodes_->u8(), tags_ ? tags_->u8() : nullptr, n_, idx.data(), (uint32_t)idx.size(), out.data(),
+                      tags && tags_ ? tags->data() : nullptr));
     return out;
 }
 
@@ -259,15 +261,15 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     std::vector<uint64_t> nat = pos;
     if (conv_.bitrev_commit) for (auto &q : nat) q = brev(q, log_N);
     proof.base_rows = gather(ctx_, base_lde.cols, nat);
-    proof.base_paths = base_tree->prove(pos);
+    proof.base_paths = base_tree->prove(pos, &proof.base_path_tags);
     proof.base_leaves = base_tree->leaf_digests(pos);
     if (ext_tree) {
         proof.extension_rows = gather(ctx_, ext_lde.cols, nat);
-        proof.extension_paths = ext_tree->prove(pos);
+        proof.extension_paths = ext_tree->prove(pos, &proof.extension_path_tags);
         proof.extension_leaves = ext_tree->leaf_digests(pos);
     }
     proof.composition_rows = gather(ctx_, comp_lde.cols, nat);
-    proof.composition_paths = comp_tree->prove(pos);
+    proof.composition_paths = comp_tree->prove(pos, &proof.composition_path_tags);
     proof.composition_leaves = comp_tree->leaf_digests(pos);
     std::vector<uint64_t> p = pos;
     for (size_t li = 0; li < layers.size(); ++li) {
@@ -280,7 +282,7 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
         if (conv_.bitrev_commit) for (auto &r : nat_rows) r = brev(r, row_bits);
         proof.fri_layers[li].positions = p;
         proof.fri_layers[li].rows = gather(ctx_, layers[li].matrix.cols, nat_rows);
-        proof.fri_layers[li].paths = layers[li].tree->prove(p);
+        proof.fri_layers[li].paths = layers[li].tree->prove(p, &proof.fri_layers[li].path_tags);
         proof.fri_layers[li].leaves = layers[li].tree->leaf_digests(p);
     }
     mark("pow + openings");
@@ -321,7 +323,14 @@ struct Wire {
     std::vector<uint8_t> b;
     void u8(uint8_t v) { b.push_back(v); }
     void u64(uint64_t v) { for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
+    bool friendly = false;                          // FriendlyMerkleTree: MixedMerkleDigest / FriendlyMerkleTreeProof encodings
     void digest(const uint8_t *d) { u64(32); b.insert(b.end(), d, d + 32); }
+    void pedersen(const uint8_t *be_bytes) { for (int i = 31; i >= 0; --i) b.push_back(be_bytes[i]); }     // Fp, little-endian canonical
+    void mixed(const uint8_t *d, uint8_t tag) {     // crypto/src/merkle/mixed.rs:46-61
+        u8(tag);
+        if (tag == 0) pedersen(d); else digest(d);
+    }
+    void root(const uint8_t *d33) { if (friendly) mixed(d33, d33[32]); else digest(d33); }
     void fp(const Felt &mont) {                     // 32-byte little-endian canonical value
         const auto be = canonical_be_bytes(mont);
         for (int i = 31; i >= 0; --i) b.push_back(be[i]);
@@ -331,18 +340,24 @@ struct Wire {
     void fp_vec(const std::vector<uint64_t> &limbs) { u64(limbs.size() / 4); for (size_t i = 0; i < limbs.size(); i += 4) fp_limbs(&limbs[i]); }
     // openings of `npos` positions: rows (npos x ncols felts), paths (npos x depth x 32, leaf level first),
     // leaves (npos x 32 row digests; empty for a single-column tree)
-    void openings(const std::vector<uint64_t> &rows, const std::vector<uint8_t> &paths, const std::vector<uint8_t> &leaves, size_t npos) {
+    void openings(const std::vector<uint64_t> &rows, const std::vector<uint8_t> &paths, const std::vector<uint8_t> &leaves, size_t npos,
+                  const std::vector<uint8_t> &tags = std::vector<uint8_t>()) {
         u64(npos);
         if (!npos) return;
         const size_t depth = paths.size() / (32 * npos), ncols = rows.size() / (4 * npos);
         if (!depth || paths.size() != npos * depth * 32) throw std::runtime_error("wire: malformed authentication paths");
         const bool single = ncols == 1;
         if (!single && leaves.size() != 32 * npos) throw std::runtime_error("wire: row digests missing");
+        if (friendly && !single && tags.size() != npos * depth) throw std::runtime_error("wire: path tags missing");
         for (size_t q = 0; q < npos; ++q) {
             const uint8_t *path = paths.data() + q * depth * 32;
             u8(single ? 1 : 0);
             u64(depth - 1);
-            for (size_t l = 1; l < depth; ++l) digest(path + 32 * l);
+            for (size_t l = 1; l < depth; ++l) {
+                if (!friendly) digest(path + 32 * l);
+                else if (single) pedersen(path + 32 * l);                 // MerkleView<PedersenDigest, Fp> (merkle/mod.rs:172)
+                else mixed(path + 32 * l, tags[q * depth + l]);
+            }
             if (single) {
                 // the sibling's leaf slot holds the element as big-endian Montgomery bytes
                 Felt sib{};
@@ -359,30 +374,29 @@ struct Wire {
 };
 }  // namespace
 std::vector<uint8_t> Proof::serialize_wire() const {
-    if (tree_kind == SS_TREE_FRIENDLY)
-        throw std::runtime_error("wire: MixedMerkleDigest (FriendlyMerkleTree) encoding has no reference sample");
     const uint32_t o[5] = {options.num_queries, options.lde_blowup_factor, options.grinding_factor, options.fri_folding_factor,
                            options.fri_max_remainder_coeffs};
     Wire w;
+    w.friendly = tree_kind == SS_TREE_FRIENDLY;
     for (uint32_t v : o) { if (v > 255) throw std::runtime_error("wire: proof options are single bytes"); w.u8((uint8_t)v); }
     w.u64(trace_len);
-    w.digest(base_root.data());
+    w.root(base_root.data());
     w.u8(has_extension ? 1 : 0);
-    if (has_extension) w.digest(extension_root.data());
-    w.digest(composition_root.data());
+    if (has_extension) w.root(extension_root.data());
+    w.root(composition_root.data());
     w.u64(fri_layers.size());
     for (auto &l : fri_layers) {
         w.fp_vec(l.rows);
-        w.openings(l.rows, l.paths, l.leaves, l.positions.size());
-        w.digest(l.root.data());
+        w.openings(l.rows, l.paths, l.leaves, l.positions.size(), l.path_tags);
+        w.root(l.root.data());
     }
     w.fp_vec(fri_remainder);
     w.u64(pow_nonce);
     w.fp_vec(base_rows); w.fp_vec(extension_rows); w.fp_vec(composition_rows);
     const size_t nq = query_positions.size();
-    w.openings(base_rows, base_paths, base_leaves, nq);
-    w.openings(extension_rows, extension_paths, extension_leaves, has_extension ? nq : 0);
-    w.openings(composition_rows, composition_paths, composition_leaves, nq);
+    w.openings(base_rows, base_paths, base_leaves, nq, base_path_tags);
+    w.openings(extension_rows, extension_paths, extension_leaves, has_extension ? nq : 0, extension_path_tags);
+    w.openings(composition_rows, composition_paths, composition_leaves, nq, composition_path_tags);
     w.fp_vec(ood_trace); w.fp_vec(ood_composition);
     return w.b;
 }

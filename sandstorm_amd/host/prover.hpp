@@ -69,7 +69,8 @@ public:
     static std::unique_ptr<MerkleTree> from_matrix(ss_ctx *ctx, int tree_kind, uint32_t n_friendly, const Matrix &m,
                                                    int order = SS_ORDER_NATURAL);
     const std::array<uint8_t, 33> &root() const { return root_; }
-    std::vector<uint8_t> prove(const std::vector<uint64_t> &idx) const;     // nidx * log2(n) * 32 bytes
+    // nidx * log2(n) * 32 bytes; tags (optional): nidx * log2(n) MixedMerkleDigest tags of the path entries (friendly trees)
+    std::vector<uint8_t> prove(const std::vector<uint64_t> &idx, std::vector<uint8_t> *tags = nullptr) const;
     // the row digests at these leaf indices (32 bytes each); empty for a single-column tree, whose leaves are the
     // elements themselves
     std::vector<uint8_t> leaf_digests(const std::vector<uint64_t> &idx) const;
@@ -114,6 +115,7 @@ struct FriLayerProof {
     std::vector<uint64_t> positions;
     std::vector<uint64_t> rows;          // positions x fold felts
     std::vector<uint8_t> paths;
+    std::vector<uint8_t> path_tags;      // FriendlyMerkleTree: MixedMerkleDigest tag of every path entry
     std::vector<uint8_t> leaves;         // row digests of the opened rows (the wire format carries them)
 };
 
@@ -131,10 +133,12 @@ struct Proof {
     std::vector<uint64_t> base_rows, extension_rows, composition_rows;
     std::vector<uint8_t> base_paths, extension_paths, composition_paths;
     std::vector<uint8_t> base_leaves, extension_leaves, composition_leaves;
+    std::vector<uint8_t> base_path_tags, extension_path_tags, composition_path_tags;   // FriendlyMerkleTree only
     std::vector<uint8_t> serialize() const;          // flat dump with the transcript values, for the tests
     // The reference's proof bytes (ministark `Proof`, ark-serialize compressed) as pinned by its shipped proof files
-    // (sandstorm_amd/wire.py has the layout; tests/golden/make_proof_golden.py the evidence).  Keccak trees only:
-    // throws for FriendlyMerkleTree proofs, whose MixedMerkleDigest encoding has no reference sample.
+    // (sandstorm_amd/wire.py has the layout; tests/golden/make_proof_golden.py the evidence).  FriendlyMerkleTree proofs
+    // use the MixedMerkleDigest / FriendlyMerkleTreeProof encodings of crypto/src/merkle/mixed.rs:46-101 and
+    // mod.rs:168-236 (source-pinned: the reference ships no such file).
     std::vector<uint8_t> serialize_wire() const;
 };
 

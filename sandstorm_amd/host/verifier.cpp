@@ -43,6 +43,25 @@ struct Reader {
         o += 32;
         return d;
     }
+    bool friendly = false;
+    Digest pedersen_node() {                // Fp on the wire -> the big-endian canonical bytes the trees hold
+        need(32);
+        static const uint64_t P[4] = {1ull, 0ull, 0ull, 0x0800000000000011ull};
+        uint64_t c[4];
+        memcpy(c, p + o, 32);
+        for (int i = 3; i >= 0; --i) { if (c[i] < P[i]) break; if (c[i] > P[i] || i == 0) reject("malformed proof: non-canonical field element"); }
+        Digest d;
+        for (int i = 0; i < 32; ++i) d[i] = p[o + 31 - i];
+        o += 32;
+        return d;
+    }
+    Digest mixed(uint8_t &tag) {            // MixedMerkleDigest (mixed.rs:88-101)
+        tag = u8();
+        if (tag == 0) return pedersen_node();
+        if (tag == 1) return digest();
+        reject("malformed proof: unknown MixedMerkleDigest tag");
+    }
+    Digest root(uint8_t &tag) { if (friendly) return mixed(tag); tag = 0; return digest(); }
     std::vector<WireOpening> openings() {
         const uint64_t n = u64();
         if (n > len) reject("malformed proof: opening count");
@@ -52,7 +71,13 @@ struct Reader {
             if (op.variant != 0 && op.variant != 1) reject("malformed proof: unknown opening variant");
             const uint64_t depth = u64();
             if (depth > 64) reject("malformed proof: path length");
-            for (uint64_t k = 0; k < depth; ++k) op.path.push_back(digest());
+            for (uint64_t k = 0; k < depth; ++k) {
+                uint8_t tag = 0;
+                if (!friendly) op.path.push_back(digest());
+                else if (op.variant == 0) op.path.push_back(mixed(tag));
+                else op.path.push_back(pedersen_node());
+                op.path_tags.push_back(tag);
+            }
             if (op.variant == 0) { op.sibling_digest = digest(); op.leaf_digest = digest(); }
             else { op.sibling_felt = fp(); op.leaf_felt = fp(); }
         }
@@ -99,6 +124,79 @@ struct KeccakTree {                         // LeafVariantMerkleTree<Keccak256Ha
     }
 };
 
+// FriendlyMerkleTree<N, PedersenHashFn> (crypto/src/merkle/mod.rs:43-123, mixed.rs:106-155); depth of a node: root 0
+struct FriendlyTree {
+    uint32_t n_friendly;
+    static Digest blake(const std::vector<uint8_t> &m) {                  // MaskedBlake2sHashFn<20>: the low 20 bytes
+        Digest d = blake2s256(m.data(), m.size());
+        for (int i = 0; i < 12; ++i) d[i] = 0;
+        return d;
+    }
+    static Felt felt_of_be(const Digest &d) {                             // big-endian integer -> Fp (reduced), Montgomery
+        // value < 2^256 = q p + r with q <= 31: subtract p while it fits (host-side, a few iterations)
+        uint64_t c[4];
+        for (int k = 0; k < 4; ++k) { c[k] = 0; for (int j = 0; j < 8; ++j) c[k] |= (uint64_t)d[31 - (8 * k + j)] << (8 * j); }
+        static const uint64_t P[4] = {1ull, 0ull, 0ull, 0x0800000000000011ull};
+        auto geq = [&]() { for (int i = 3; i >= 0; --i) { if (c[i] != P[i]) return c[i] > P[i]; } return true; };
+        while (geq()) { unsigned __int128 br = 0; for (int i = 0; i < 4; ++i) { unsigned __int128 t = (unsigned __int128)c[i] - P[i] - (uint64_t)br; c[i] = (uint64_t)t; br = (t >> 64) & 1; } }
+        Felt v = {c[0], c[1], c[2], c[3]};
+        return felt_from_canonical(v);
+    }
+    static Felt pedersen(const Felt &a, const Felt &b) {
+        Felt o;
+        if (ss_pedersen_hash_host(a.data(), b.data(), o.data()) != SS_OK) reject("Pedersen hash failed");
+        return o;
+    }
+    static Digest be_of(const Felt &f) { const auto b = canonical_be_bytes(f); Digest d; memcpy(d.data(), b.data(), 32); return d; }
+    Digest row_leaf(const Felt *row, size_t n) const {
+        std::vector<uint8_t> m;
+        for (size_t i = 0; i < n; ++i) append_mont_be(m, row[i]);
+        return blake(m);
+    }
+    Digest merge(uint32_t depth, const Digest &l, const Digest &r) const {      // hash_leaves / hash_nodes (mixed.rs:110-125)
+        if (depth < n_friendly) return be_of(pedersen(felt_of_be(l), felt_of_be(r)));
+        std::vector<uint8_t> m(l.begin(), l.end());
+        m.insert(m.end(), r.begin(), r.end());
+        return blake(m);
+    }
+    static bool canonical_node(const Digest &d) {
+        static const uint8_t PB[32] = {0x08, 0, 0, 0, 0, 0, 0, 0x11, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+        return memcmp(d.data(), PB, 32) < 0;
+    }
+    void check_root(uint8_t tag, const std::string &what) const { require(tag == (n_friendly > 0 ? 0 : 1), what + ": root digest variant"); }
+    void check(const WireOpening &op, const Felt *row, size_t ncols, uint64_t pos, uint32_t depth, const Digest &root, const std::string &what) const {
+        require(op.path.size() + 1 == depth, what + ": path length");
+        if (ncols == 1) {                   // SingleCol: a Pedersen tree over the elements (merkle/mod.rs:113-117)
+            require(op.variant == 1 && op.leaf_felt == row[0], what + ": leaf is not the opened element");
+            const Felt &a = (pos & 1) ? op.sibling_felt : op.leaf_felt, &b = (pos & 1) ? op.leaf_felt : op.sibling_felt;
+            Felt node = pedersen(pedersen(pedersen(felt_from_u64(0), a), b), felt_from_u64(2));    // PedersenHashFn::hash_elements
+            uint64_t p = pos >> 1;
+            for (const Digest &sib : op.path) {
+                require(canonical_node(sib), what + ": non-canonical Pedersen digest");
+                const Felt s = felt_of_be(sib);
+                node = (p & 1) ? pedersen(s, node) : pedersen(node, s);
+                p >>= 1;
+            }
+            require(be_of(node) == root, what + ": authentication path does not reach the root");
+            return;
+        }
+        require(op.variant == 0 && op.leaf_digest == row_leaf(row, ncols), what + ": leaf is not the hash of the opened row");
+        require(op.path_tags.size() == op.path.size(), what + ": path tags");
+        Digest node = op.leaf_digest;
+        uint64_t p = pos;
+        for (uint32_t lvl = 0; lvl < depth; ++lvl) {
+            const uint32_t d = depth - 1 - lvl;                            // depth of the parent computed at this step
+            const Digest &sib = lvl == 0 ? op.sibling_digest : op.path[lvl - 1];
+            const uint8_t tag = lvl == 0 ? 1 : op.path_tags[lvl - 1];
+            require(tag == ((lvl > 0 && d + 1 < n_friendly) ? 0 : 1), what + ": digest variant at level " + std::to_string(lvl));
+            if (tag == 0) require(canonical_node(sib), what + ": non-canonical Pedersen digest");
+            node = (p & 1) ? merge(d, sib, node) : merge(d, node, sib);
+            p >>= 1;
+        }
+        require(node == root, what + ": authentication path does not reach the root");
+    }
+};
+
 uint64_t brev(uint64_t x, uint32_t bits) { uint64_t r = 0; for (uint32_t i = 0; i < bits; ++i) r |= ((x >> i) & 1ull) << (bits - 1 - i); return r; }
 uint32_t log2u(uint64_t v) { uint32_t l = 0; while ((1ull << l) < v) ++l; return l; }
 
@@ -114,24 +212,26 @@ Felt interpolate_eval(const std::vector<Felt> &xs, const Felt *ys, const Felt &t
 
 }  // namespace
 
-WireProof parse_wire(const uint8_t *data, size_t len) {
+WireProof parse_wire(const uint8_t *data, size_t len, int tree_kind) {
     Reader r{data, len};
+    r.friendly = tree_kind == SS_TREE_FRIENDLY;
     WireProof p;
+    p.tree_kind = tree_kind;
     for (auto &o : p.options) o = r.u8();
     p.trace_len = r.u64();
-    p.base_root = r.digest();
+    p.base_root = r.root(p.root_tags[0]);
     const uint8_t has_ext = r.u8();
     if (has_ext > 1) reject("malformed proof: bad Option tag for the extension root");
     p.has_extension = has_ext == 1;
-    if (p.has_extension) p.extension_root = r.digest();
-    p.composition_root = r.digest();
+    if (p.has_extension) p.extension_root = r.root(p.root_tags[1]);
+    p.composition_root = r.root(p.root_tags[2]);
     const uint64_t layers = r.u64();
     if (layers > 64) reject("malformed proof: FRI layer count");
     for (uint64_t l = 0; l < layers; ++l) {
         WireFriLayer L;
         L.rows = r.vec();
         L.openings = r.openings();
-        L.root = r.digest();
+        L.root = r.root(L.root_tag);
         p.fri_layers.push_back(std::move(L));
     }
     p.remainder = r.vec();
@@ -152,9 +252,22 @@ uint32_t conjectured_security_bits(const uint32_t options[5], uint64_t trace_len
 }
 
 std::vector<uint64_t> verify(const WireProof &w, Air &air, int tree_kind, int coin_kind, const Digest &coin_seed, const Conventions &conv,
-                             uint32_t required_security_bits, const ProofOptions *expected_options) {
-    require(tree_kind == SS_TREE_KECCAK || tree_kind == SS_TREE_KECCAK_M20, "the wire format covers the Keccak trees only");
-    const KeccakTree tree{tree_kind == SS_TREE_KECCAK_M20};
+                             uint32_t required_security_bits, const ProofOptions *expected_options, uint32_t n_friendly_layers) {
+    require(tree_kind == SS_TREE_KECCAK || tree_kind == SS_TREE_KECCAK_M20 || tree_kind == SS_TREE_FRIENDLY, "unknown tree kind");
+    require(w.tree_kind == tree_kind || (w.tree_kind != SS_TREE_FRIENDLY && tree_kind != SS_TREE_FRIENDLY), "the proof was parsed for another tree");
+    const KeccakTree ktree{tree_kind == SS_TREE_KECCAK_M20};
+    const FriendlyTree ftree{n_friendly_layers};
+    const bool friendly = tree_kind == SS_TREE_FRIENDLY;
+    struct { const KeccakTree *k; const FriendlyTree *f; bool friendly;
+             void check(const WireOpening &op, const Felt *row, size_t ncols, uint64_t pos, uint32_t depth, const Digest &root, const std::string &what) const {
+                 if (friendly) f->check(op, row, ncols, pos, depth, root, what); else k->check(op, row, ncols, pos, depth, root, what);
+             } } tree{&ktree, &ftree, friendly};
+    if (friendly) {
+        ftree.check_root(w.root_tags[0], "base trace root");
+        if (w.has_extension) ftree.check_root(w.root_tags[1], "extension trace root");
+        ftree.check_root(w.root_tags[2], "composition trace root");
+        for (size_t li = 0; li < w.fri_layers.size(); ++li) ftree.check_root(w.fri_layers[li].root_tag, "FRI layer " + std::to_string(li) + " root");
+    }
     const uint32_t num_queries = w.options[0], blowup = w.options[1], grinding = w.options[2], fold = w.options[3], max_remainder = w.options[4];
     const uint64_t n = w.trace_len;
     require(n >= 2 && !(n & (n - 1)) && blowup >= 2 && !(blowup & (blowup - 1)) && n <= (1ull << 40) / blowup, "bad trace length / blowup");

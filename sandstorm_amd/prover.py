@@ -88,6 +88,7 @@ class FriLayer:
     rows: Optional[np.ndarray] = None       # opened rows [nq, fold, 4]
     paths: Optional[np.ndarray] = None
     positions: List[int] = field(default_factory=list)
+    path_tags: Optional[np.ndarray] = None  # FriendlyMerkleTree: MixedMerkleDigest tag of every path entry
 
 
 @dataclass
@@ -110,6 +111,11 @@ class Proof:
     base_paths: Optional[np.ndarray] = None
     extension_paths: Optional[np.ndarray] = None
     composition_paths: Optional[np.ndarray] = None
+    # FriendlyMerkleTree: MixedMerkleDigest tags (0 Pedersen, 1 Blake2s) of the three roots and of every path entry
+    root_tags: Optional[List[int]] = None
+    base_path_tags: Optional[np.ndarray] = None
+    extension_path_tags: Optional[np.ndarray] = None
+    composition_path_tags: Optional[np.ndarray] = None
     # values the verifier re-derives from the transcript, kept for tests/debugging
     challenges: List[np.ndarray] = field(default_factory=list)
     composition_coeff: Optional[np.ndarray] = None
@@ -245,12 +251,13 @@ class Prover:
         # a position is an index into the COMMITTED order; the matrices themselves are in natural order
         nat = [bitrev(p, log_N) for p in positions] if conv.bitrev_commit else positions
         proof.base_rows = ctx.gather_rows(base_lde.cols, nat)
-        proof.base_paths, _ = base_tree.prove(positions)
+        proof.base_paths, proof.base_path_tags = base_tree.prove(positions)
         if ext_lde is not None:
             proof.extension_rows = ctx.gather_rows(ext_lde.cols, nat)
-            proof.extension_paths, _ = ext_tree.prove(positions)
+            proof.extension_paths, proof.extension_path_tags = ext_tree.prove(positions)
         proof.composition_rows = ctx.gather_rows(comp_lde.cols, nat)
-        proof.composition_paths, _ = comp_tree.prove(positions)
+        proof.composition_paths, proof.composition_path_tags = comp_tree.prove(positions)
+        proof.root_tags = [base_tree.root_tag(), ext_tree.root_tag() if ext_tree is not None else 0, comp_tree.root_tag()]
         fri_open(ctx, conv, opt, proof, layers, positions)
         mark("openings")
         return proof
@@ -322,5 +329,5 @@ def fri_open(ctx, conv, opt, proof, layers, positions):
             nat_rows = pos
         layer.positions = pos
         layer.rows = ctx.gather_rows(matrix.cols, nat_rows)
-        layer.paths, _ = tree.prove(pos)
+        layer.paths, layer.path_tags = tree.prove(pos)
         proof.fri_layers.append(layer)

@@ -27,6 +27,10 @@ Distribution of one proof's data over R ranks (R a power of two), per stage of p
   query openings                      rows on their row-block rank, paths   broadcast of the positions, gather of the
                                       on their leaf-block rank              opened rows / paths to rank 0
 
+Streams: the tensors the ranks exchange are torch tensors and the kernels run behind the C ABI, so both must be on ONE HIP
+stream - make a torch.cuda.Stream current and hand its handle to backend.Context (torch's default stream has handle 0, which
+ss_ctx_set_stream takes to mean "the context's own stream").
+
 Nothing is a sum over ranks: there is no all-reduce.  The Fiat-Shamir coin runs on every rank in lock step up to the
 out-of-domain evaluations (every rank sees the same roots and values); from DEEP on only rank 0 holds the transcript.
 """
@@ -87,6 +91,15 @@ class Comm:
         box = [obj]
         self.dist.broadcast_object_list(box, src=src)
         return box[0]
+
+
+def _dbg(comm, what, t):
+    """SS_SHARD_DEBUG=1: fingerprint of an intermediate on every rank (to diff a run against another backend's)"""
+    import os
+    if os.environ.get("SS_SHARD_DEBUG"):
+        import hashlib
+        b = t if isinstance(t, (bytes, bytearray)) else np.ascontiguousarray(t.cpu().numpy()).tobytes()
+        print("[shard dbg] rank %d %-28s %s" % (comm.rank, what, hashlib.sha256(b).hexdigest()[:16]), flush=True)
 
 
 def _bitrev_tensor(t, bits):
@@ -154,6 +167,8 @@ class ShardedProver:
                 out[c] = self.felts(B + halo)
                 recvs.append((o, out[c]))
         comm.exchange(sends, recvs)
+        for c in range(first_col, first_col + ncols):
+            _dbg(comm, "row block of column %d" % c, out[c])
         return [out[c] for c in range(first_col, first_col + ncols)]
 
     # ---- commitment of a row-block matrix
@@ -170,6 +185,7 @@ class ShardedProver:
             mine = torch.zeros((B, 32), dtype=torch.uint8, device=comm.device)
             ctx.hash_rows(Tree.row_hash, blocks, B, mine, be.NATURAL)       # natural local rows; the blocks' halo is not hashed
             leaves = torch.zeros((B, 32), dtype=torch.uint8, device=comm.device)
+        _dbg(comm, "row digests / leaves (rows)", mine)
         # row i = r B + k is leaf bitrev(i) (or i): send every digest to the rank that owns its leaf
         k = torch.arange(B, dtype=torch.int64, device=comm.device)
 
@@ -193,12 +209,14 @@ class ShardedProver:
         comm.exchange(sends, recvs)
         for p, (pos, buf) in places.items():
             leaves[pos] = buf
+        _dbg(comm, "leaf block", leaves)
         # this rank's sub-tree: its root sits at depth log2 R of the whole tree
         nodes = torch.zeros((2 * B, 32), dtype=torch.uint8, device=comm.device)
         tags = torch.zeros(2 * B, dtype=torch.uint8, device=comm.device) if Tree.tree_kind == be.TREE_FRIENDLY else None
         leaf_kind = be.LEAF_FELT if single else be.LEAF_DIGEST
         sub_root, sub_tag = ctx.merkle_build(Tree.tree_kind, sharding.subtree_friendly_layers(Tree.n_friendly, R), leaf_kind,
                                              leaves, B, nodes, tags, be.NATURAL)
+        _dbg(comm, "sub-tree root", sub_root)
         roots = comm.all_gather_object((sub_root, sub_tag))
         # the top log2 R levels on the host (<= 7 hashes)
         top = [list(roots)]

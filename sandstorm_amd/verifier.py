@@ -11,7 +11,8 @@ Checked, in the verifier's order:
   3. Merkle openings of the base / extension / composition rows at the query positions
   4. DEEP value recomputed from the opened rows == the first FRI layer's entry at that position
   5. every FRI layer folds into the next at alpha_i, openings included; the last into the remainder polynomial
-Keccak trees only (the wire format of `FriendlyMerkleTree` proofs has no reference sample: wire.py).
+Keccak trees as the reference's files pin them; FriendlyMerkleTree (Cairo-verifier claims) as its source has them
+(source-pinned, no sample file: wire.py).
 """
 from dataclasses import dataclass
 from typing import Callable, List
@@ -67,7 +68,7 @@ class _KeccakTree:
     """LeafVariantMerkleTree<Keccak256HashFn | MaskedKeccak256HashFn<20>> (crypto/src/merkle/mod.rs:240-304)"""
 
     def __init__(self, tree_kind):
-        _require(tree_kind in (be.TREE_KECCAK, be.TREE_KECCAK_M20), "the wire format covers the Keccak trees only")
+        _require(tree_kind in (be.TREE_KECCAK, be.TREE_KECCAK_M20), "not a Keccak tree")
         self.masked = tree_kind == be.TREE_KECCAK_M20
 
     def h(self, data):
@@ -82,6 +83,9 @@ class _KeccakTree:
             node = self.h(node + sib) if ((pos >> lvl) & 1) == 0 else self.h(sib + node)
         return node
 
+    def check_root(self, root, tag, what):
+        pass
+
     def check_opening(self, opening, row, pos, depth, root, what):
         """row: the opened row (canonical ints); pos: leaf index; depth = log2(number of leaves)"""
         if len(row) == 1:                                   # single column: raw-element leaves (merkle/mod.rs:113-117)
@@ -95,6 +99,70 @@ class _KeccakTree:
             _require(len(opening.path) == depth - 1, what + ": path length")
             _require(self.climb(opening.leaf, [opening.sibling] + list(opening.path), pos) == root,
                      what + ": authentication path does not reach the root")
+
+
+class _FriendlyTree:
+    """FriendlyMerkleTree<N, PedersenHashFn> (crypto/src/merkle/mod.rs:43-123, mixed.rs:106-155): rows hashed with masked
+    Blake2s, inner nodes at depth < N by Pedersen (Blake2s digests entering that boundary read as big-endian integers),
+    below it by masked Blake2s; a single-column matrix is a Pedersen tree over its elements.  `depth` of a node: root 0.
+    Source-pinned (no reference sample of such a proof exists): the depth numbering is the assumption of oracle/merkle.c."""
+
+    def __init__(self, n_friendly=22):
+        self.n_friendly = n_friendly
+
+    @staticmethod
+    def blake(data):
+        return bytes(12) + blake2s256(data)[12:]            # MaskedBlake2sHashFn<20> (hash/blake2s.rs:63-83): the low 20 bytes
+
+    @staticmethod
+    def pedersen(a: int, b: int) -> int:
+        from .coin import canonical
+        return canonical(be.pedersen_hash_host(be.felt(a), be.felt(b)))
+
+    def row_leaf(self, row):
+        return self.blake(b"".join(_mont_be(v) for v in row))
+
+    def merge(self, depth, left, right):
+        """MixedHashMerkleTreeConfigImpl::{hash_leaves, hash_nodes}: -> (digest, tag) of a node at `depth`"""
+        if depth < self.n_friendly:
+            v = self.pedersen(int.from_bytes(left, "big") % P, int.from_bytes(right, "big") % P)
+            return v.to_bytes(32, "big"), 0
+        return self.blake(left + right), 1
+
+    def check_root(self, root, tag, what):
+        _require(tag == (0 if self.n_friendly > 0 else 1), what + ": root digest variant")
+
+    def check_opening(self, opening, row, pos, depth, root, what):
+        _require(len(opening.path) == depth - 1, what + ": path length")
+        if len(row) == 1:                                   # SingleCol: MerkleTreeImpl<UnhashedLeafConfig<PedersenHashFn>>
+            _require(opening.variant == 1 and opening.leaf == row[0], what + ": leaf is not the opened element")
+            a, b = (opening.leaf, opening.sibling) if (pos & 1) == 0 else (opening.sibling, opening.leaf)
+            node = self.pedersen(self.pedersen(self.pedersen(0, a), b), 2)          # PedersenHashFn::hash_elements([l0, l1])
+            p = pos >> 1
+            for sib in opening.path:
+                s_ = int.from_bytes(sib, "big")
+                _require(s_ < P, what + ": non-canonical Pedersen digest")
+                node = self.pedersen(node, s_) if (p & 1) == 0 else self.pedersen(s_, node)
+                p >>= 1
+            _require(node.to_bytes(32, "big") == root, what + ": authentication path does not reach the root")
+            return
+        _require(opening.variant == 0 and opening.leaf == self.row_leaf(row), what + ": leaf is not the hash of the opened row")
+        _require(opening.tags is not None and len(opening.tags) == len(opening.path), what + ": path tags")
+        node, p = opening.leaf, pos
+        sibs = [(opening.sibling, 1)] + list(zip(opening.path, opening.tags))
+        for lvl, (sib, tag) in enumerate(sibs):
+            d = depth - 1 - lvl                             # depth of the parent computed at this step
+            # the sibling is a node of depth d + 1: a leaf, a Blake2s node, or (above the boundary) a Pedersen node
+            _require(tag == (0 if d + 1 < self.n_friendly and lvl > 0 else 1), what + ": digest variant at level %d" % lvl)
+            if tag == 0:
+                _require(int.from_bytes(sib, "big") < P, what + ": non-canonical Pedersen digest")
+            node, _ = self.merge(d, node, sib) if (p & 1) == 0 else self.merge(d, sib, node)
+            p >>= 1
+        _require(node == root, what + ": authentication path does not reach the root")
+
+
+def _tree_of(tree_kind, n_friendly=22):
+    return _FriendlyTree(n_friendly) if tree_kind == be.TREE_FRIENDLY else _KeccakTree(tree_kind)
 
 
 def _interpolate_eval(xs, ys, t):
@@ -181,22 +249,22 @@ def replay_transcript(w, air, coin_kind, coin_seed, conv=None):
 
 
 def verify(proof, air: VerifierAir, tree_kind, coin_kind, coin_seed: bytes, conv: Conventions = None,
-           required_security_bits: int = DEFAULT_REQUIRED_SECURITY_BITS, expected_options=None):
+           required_security_bits: int = DEFAULT_REQUIRED_SECURITY_BITS, expected_options=None, n_friendly_layers: int = 22):
     """proof: bytes in the reference's wire format, or a wire.WireProof.  Raises VerificationError; returns the
     query positions on success.  The bytes are untrusted: any arithmetic or indexing accident they provoke (a zero
     denominator, a missing position) is a rejection too.  The proof's own options are untrusted as well
     (`claim.verify(proof, required_security_bits)`, cli/src/main.rs:176): a proof whose options conjecture fewer than
     `required_security_bits` is rejected, and so is one whose options differ from `expected_options` when given."""
     try:
-        return _verify(proof, air, tree_kind, coin_kind, coin_seed, conv, required_security_bits, expected_options)
+        return _verify(proof, air, tree_kind, coin_kind, coin_seed, conv, required_security_bits, expected_options, n_friendly_layers)
     except (ValueError, IndexError, KeyError, ZeroDivisionError, OverflowError) as e:
         raise VerificationError("malformed proof: %s: %s" % (type(e).__name__, e))
 
 
-def _verify(proof, air, tree_kind, coin_kind, coin_seed, conv, required_security_bits, expected_options):
+def _verify(proof, air, tree_kind, coin_kind, coin_seed, conv, required_security_bits, expected_options, n_friendly_layers=22):
     conv = conv or Conventions()
     try:
-        w = wire.parse(bytes(proof)) if isinstance(proof, (bytes, bytearray, memoryview)) else proof
+        w = wire.parse(bytes(proof), tree_kind) if isinstance(proof, (bytes, bytearray, memoryview)) else proof
     except ValueError as e:
         raise VerificationError("malformed proof: %s" % e)
     num_queries, blowup, grinding, fold, max_remainder = w.options
@@ -216,7 +284,7 @@ def _verify(proof, air, tree_kind, coin_kind, coin_seed, conv, required_security
     log_N, log_fold = N.bit_length() - 1, fold.bit_length() - 1
     ncomp = conv.composition_columns
     nmask = len(air.mask)
-    tree = _KeccakTree(tree_kind)
+    _require(getattr(w, "tree_kind", tree_kind) == tree_kind or tree_kind != be.TREE_FRIENDLY, "the proof was parsed for another tree")
     expo = (lambda i, bits: bitrev(i, bits)) if conv.bitrev_commit else (lambda i, bits: i)
 
     # ---- 1. transcript (prover.py steps 2-9)
@@ -230,11 +298,13 @@ def _verify(proof, air, tree_kind, coin_kind, coin_seed, conv, required_security
     rhs = sum(pow(z, k, P) * h for k, h in enumerate(w.ood_composition)) % P
     _require(lhs == rhs, "out-of-domain identity: the composition constraint does not match the composition columns at z")
 
-    check_proof_data(w, air.mask, air.num_base_columns, air.num_extension_columns, tree_kind, z, deep_alpha, fri_alphas, positions, conv)
+    check_proof_data(w, air.mask, air.num_base_columns, air.num_extension_columns, tree_kind, z, deep_alpha, fri_alphas, positions, conv,
+                     n_friendly_layers)
     return positions
 
 
-def check_proof_data(w, mask, num_base_columns, num_extension_columns, tree_kind, z, deep_alpha, fri_alphas, positions, conv=None):
+def check_proof_data(w, mask, num_base_columns, num_extension_columns, tree_kind, z, deep_alpha, fri_alphas, positions, conv=None,
+                     n_friendly_layers=22):
     """Everything below the transcript: Merkle openings of the opened rows, the DEEP value of every query against the
     first FRI layer, the FRI chain and the remainder — for given out-of-domain point, DEEP coefficient, FRI challenges
     (canonical ints) and query positions.  `verify` calls it with the values its transcript replay produced; the tests
@@ -246,7 +316,15 @@ def check_proof_data(w, mask, num_base_columns, num_extension_columns, tree_kind
     N = n * blowup
     log_N, log_fold = N.bit_length() - 1, fold.bit_length() - 1
     ncomp, nmask, nq = conv.composition_columns, len(mask), len(positions)
-    tree = _KeccakTree(tree_kind)
+    tree = _tree_of(tree_kind, n_friendly_layers)
+    if tree_kind == be.TREE_FRIENDLY:
+        tags = getattr(w, "root_tags", [0, 0, 0])
+        tree.check_root(w.base_root, tags[0], "base trace root")
+        if w.extension_root is not None:
+            tree.check_root(w.extension_root, tags[1], "extension trace root")
+        tree.check_root(w.composition_root, tags[2], "composition trace root")
+        for li, layer in enumerate(w.fri_layers):
+            tree.check_root(layer.root, layer.root_tag, "FRI layer %d root" % li)
     expo = (lambda i, bits: bitrev(i, bits)) if conv.bitrev_commit else (lambda i, bits: i)
 
     class _Shape:

@@ -24,7 +24,11 @@ def main():
     dist.init_process_group(backend=backend, **({"device_id": device} if backend == "nccl" else {}))
     rank, world = dist.get_rank(), dist.get_world_size()
     case, out_path = sys.argv[1], sys.argv[2]
-    ctx = be.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    # ONE stream for torch's tensor ops, the collectives and the C ABI's kernels: torch's default stream has handle 0,
+    # which ss_ctx_set_stream reads as "the context's own stream" - an explicit stream makes the ordering real
+    stream = torch.cuda.Stream(device)
+    torch.cuda.set_stream(stream)
+    ctx = be.Context(0, stream=stream.cuda_stream)
 
     def tensor(limbs):
         return torch.from_numpy(np.ascontiguousarray(limbs, dtype=np.uint64).view(np.int64).copy()).to(device)

@@ -249,10 +249,22 @@ def test_cpp_host_emits_the_reference_wire_format(ctx, oracle, log_n):
     assert raw == wire.serialize(wire.from_proof(ref, _keccak_m20_leaf_hash))
     w = wire.parse(raw)
     assert w.trace_len == n and w.pow_nonce == ref.pow_nonce and len(w.base_openings) == len(ref.query_positions)
+    # the CairoVerifierClaim flavour (FriendlyMerkleTree, Cairo coin): MixedMerkleDigest / FriendlyMerkleTreeProof encodings
+    # (crypto/src/merkle/mixed.rs:46-101, mod.rs:168-236; source-pinned) - the two hosts write the same bytes, both verifiers accept
+    from sandstorm_amd import verifier
+    from sandstorm_amd.coin import blake2s256
+    from tests.test_verifier import mini_verifier_air
     n2, claim2, params2, opt2, seed2, base2, build_extension2 = setup_case(ctx, oracle, "cairo", log_n)
-    with pytest.raises(SandstormHipError, match="MixedMerkleDigest"):
-        hostlib.prove(ctx, air, params2[0], params2[3], params2[2], seed2, base2.cols, log_n,
-                      lambda ch: build_extension2(ch).cols, opt2, wire=True)
+    raw2 = hostlib.prove(ctx, air, params2[0], params2[3], params2[2], seed2, base2.cols, log_n,
+                         lambda ch: build_extension2(ch).cols, opt2, wire=True)
+    ref2 = Prover(ctx, claim2, opt2).prove(seed2, base2, build_extension2)
+
+    def blake_leaf(vals):
+        return bytes(12) + blake2s256(b"".join((v * wire._R % P).to_bytes(32, "big") for v in vals))[12:]
+    assert raw2 == wire.serialize(wire.from_proof(ref2, blake_leaf))
+    sec = opt2.num_queries + opt2.grinding_factor
+    assert verifier.verify(raw2, mini_verifier_air(), params2[0], params2[2], seed2, required_security_bits=sec) == ref2.query_positions
+    assert hostlib.verify(air, params2[0], params2[2], seed2, raw2, required_security_bits=sec) == ref2.query_positions
     air.close()
 
 

@@ -69,6 +69,11 @@ def template_program(layout):
 
 PREFETCH_DEPTH = 6      # memory operands in flight ahead of their use (one wave per SIMD: nothing else hides the latency)
 DOT_MAX_TERMS = 16      # products accumulated in the 64-bit columns before a Montgomery reduction (16 * 9 * 2^56 < 2^64)
+# Fusing "MUL acc, alpha^k ; ADD sum, acc" chains into dot products with one Montgomery reduction per 16 terms removes ~6 %
+# of the vector instructions, but the 19 x 64-bit column accumulator stays live across the constraints between two terms
+# and costs ~150 registers in practice (profiles/r02_quotient_codegen_experiments.txt): the starknet kernel then spills to
+# scratch and runs 2.7x slower.  Off; the DEEP kernel, whose sums are tight loops, uses the same fusion (fl252.h FlWide).
+FUSE_ALPHA_DOT_PRODUCTS = False
 
 
 def generate(layout):
@@ -100,7 +105,7 @@ def generate(layout):
     for pc in range(n_instr - 1):
         op, e, kind, w1 = ins[pc]
         op2, d2, kind2, w2 = ins[pc + 1]
-        if op == OP_MUL and kind == SRC_CONST and op2 == OP_ADD and kind2 == SRC_ACC and (w2 & 3) == e and d2 != e and dies_after(e, pc + 1):
+        if FUSE_ALPHA_DOT_PRODUCTS and op == OP_MUL and kind == SRC_CONST and op2 == OP_ADD and kind2 == SRC_ACC and (w2 & 3) == e and d2 != e and dies_after(e, pc + 1):
             fused[pc] = d2
     out = []
     emit = out.append
@@ -146,7 +151,7 @@ def generate(layout):
                 src, sb = "acc%d" % src_acc, bound[src_acc]
             elif kind == SRC_SLOT:
                 assert w1 < n_slots
-                src = "s%d" % w1
+                src = "QG_SLOT(%d)" % w1
             elif kind == SRC_CONST:
                 assert w1 < n_consts
                 src = ("QG_CONST_R280(%d)" if op == OP_MUL else "QG_CONST(%d)") % w1
@@ -245,7 +250,7 @@ def generate(layout):
             assert w1 < n_slots
             if bound[d] > 1:
                 reduce_acc(d)
-            emit("    s%d = %s;" % (w1, v))
+            emit("    QG_SLOT_STORE(%d, %s);" % (w1, v))
         else:
             flush_wide()
             emit("    qstore(a.out + i, fl_to_fp(%s));" % v)
@@ -256,7 +261,7 @@ def generate(layout):
     assert wide["acc"] is None
     body = "\n".join(out)
     h = code_hash(code)
-    slots = "".join("    Fl s%d = fl_zero();\n" % s for s in range(n_slots))
+    slots = ""
     regs = "    Fp " + ", ".join("m%d" % k for k in range(D)) + ";\n"
     prime = "".join("    m%d = %s;\n" % (j, mem_ops[j][1] % "i32") for j in range(D))
     src = '''// GENERATED by tools/gen_quotient.py - DO NOT EDIT; regenerate with `python tools/gen_quotient.py %(layout)s`.
@@ -265,7 +270,7 @@ def generate(layout):
 // sandstorm_amd/host/air_%(layout)s.cpp + air_program.cpp) as straight-line code for gfx950: %(n_instr)d program
 // instructions, %(mul)d multiplications (%(mulr)d by a constant in R280 form, %(fused)d more as terms of %(flushes)d fused
 // dot products with one Montgomery reduction each), %(loads)d trace / table operand loads issued %(depth)d operands ahead
-// of their use, %(reduce)d weak reductions placed at generation time, %(n_slots)d register-resident scratch values.
+// of their use, %(reduce)d weak reductions placed at generation time, %(n_slots)d scratch values per point in LDS (accumulators in registers).
 // Code hash (FNV-1a of the program's code words) 0x%(hash)016x: ss_eval_quotient launches this kernel for exactly
 // that program and interprets any other.
 #include "quotient_gen.h"
@@ -274,7 +279,7 @@ namespace ss {
 namespace {
 
 __global__ __launch_bounds__(QG_THREADS) void quotient_%(layout)s_kernel(QGenArgs a) {
-    QG_PROLOGUE(%(n_consts)d)
+    QG_PROLOGUE(%(n_consts)d, %(n_slots)d)
     Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
     QgWide wd;
 %(slots)s%(regs)s    uint32_t i32 = (uint32_t)lane;
@@ -284,7 +289,14 @@ __global__ __launch_bounds__(QG_THREADS) void quotient_%(layout)s_kernel(QGenArg
 }
 
 hipError_t launch_%(layout)s(hipStream_t st, const QGenArgs &a, uint32_t blocks) {
-    hipLaunchKernelGGL(quotient_%(layout)s_kernel, dim3(blocks), dim3(QG_THREADS), 0, st, a);
+    const size_t lds = qg_lds_bytes(%(n_consts)d, %(n_slots)d);
+    static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the per-function opt-in
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quotient_%(layout)s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(quotient_%(layout)s_kernel, dim3(blocks), dim3(QG_THREADS), lds, st, a);
     return hipGetLastError();
 }
 
