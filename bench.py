@@ -134,7 +134,7 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     their owner (column c on rank c % N), point-to-point re-shards into row blocks over RCCL, row hashing / constraint
     evaluation / DEEP on row blocks, leaf-block sub-trees + root all-gather, composition and DEEP gathers and FRI on rank 0.
     A step = one whole proof; the time is the max over ranks between two barriers; strong scaling."""
-    from sandstorm_amd import backend as be, extension
+    from sandstorm_amd import backend as be, extension, hostlib
     from sandstorm_amd.prover import Claim, ProofOptions
     from sandstorm_amd.sharded_prover import Comm, ShardedProver
     L, pi = _sample_statement(layout, log_steps)
@@ -144,7 +144,9 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     stream = torch.cuda.Stream(device)
     torch.cuda.set_stream(stream)
     ctx = be.Context(local_rank, stream=stream.cuda_stream)
-    air = L.make_air(ctx, pi, n)
+    # the C++ host's AIR (tables on the device, program lowered in C++ per proof) behind the Python driver's Air interface
+    host_air = (hostlib.StarknetHostAir if layout == "starknet" else hostlib.RecursiveHostAir)(ctx, pi, log_steps + 4, 1)
+    air = hostlib.prover_air(host_air)
     nb, ne = air.num_base_columns, air.num_extension_columns
     if layout == "recursive":
         tree, coin = be.FriendlyMerkleTree, be.COIN_CAIRO

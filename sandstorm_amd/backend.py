@@ -109,8 +109,8 @@ class DeviceView:
 
 def _ptr_of(x):
     """DeviceBuffer | torch tensor | int -> device address"""
-    if isinstance(x, (DeviceBuffer, DeviceView)):
-        return x.ptr
+    if hasattr(x, "ptr"):                   # DeviceBuffer, DeviceView, and what stands in for them
+        return int(x.ptr)
     if hasattr(x, "data_ptr"):
         return x.data_ptr()
     return int(x)
@@ -276,30 +276,14 @@ class Context:
     def eval_quotient(self, program, tables, table_desc, lde_cols, log_n, log_blowup, offset, out):
         """program: air_program.Program; tables: device buffer of concatenated felts (or None);
         table_desc: flat [offset, log_len, ...] list"""
-        code = np.ascontiguousarray(program.code, dtype=np.uint32)
-        consts = np.zeros((max(1, len(program.consts)), 4), dtype=np.uint64)
-        for i, v in enumerate(program.consts):
-            consts[i] = felt(v)
-        desc = np.ascontiguousarray(table_desc if len(table_desc) else [0, 0], dtype=np.uint32)
-        prog = _lib.AirProgram(code.ctypes.data_as(C.POINTER(C.c_uint32)), len(code) // 2,
-                               consts.ctypes.data_as(C.POINTER(C.c_uint64)), len(program.consts),
-                               _ptr_of(tables) if tables is not None else None,
-                               desc.ctypes.data_as(C.POINTER(C.c_uint32)), len(table_desc) // 2, program.n_slots)
+        prog, _keep = _air_program(program, tables, table_desc)
         _k, op = _felt_ptr(offset)
         check(self.lib.ss_eval_quotient(self.handle, C.byref(prog), _ptr_array(lde_cols), len(lde_cols), log_n,
                                         log_blowup, op, _ptr_of(out)))
 
     def eval_quotient_rows(self, program, tables, table_desc, col_blocks, log_n, log_blowup, offset, row0, nrows, block_rows, out):
         """ss_eval_quotient_rows: points row0 .. row0 + nrows from column blocks of block_rows rows starting at row0"""
-        code = np.ascontiguousarray(program.code, dtype=np.uint32)
-        consts = np.zeros((max(1, len(program.consts)), 4), dtype=np.uint64)
-        for i, v in enumerate(program.consts):
-            consts[i] = felt(v)
-        desc = np.ascontiguousarray(table_desc if len(table_desc) else [0, 0], dtype=np.uint32)
-        prog = _lib.AirProgram(code.ctypes.data_as(C.POINTER(C.c_uint32)), len(code) // 2,
-                               consts.ctypes.data_as(C.POINTER(C.c_uint64)), len(program.consts),
-                               _ptr_of(tables) if tables is not None else None,
-                               desc.ctypes.data_as(C.POINTER(C.c_uint32)), len(table_desc) // 2, program.n_slots)
+        prog, _keep = _air_program(program, tables, table_desc)
         _k, op = _felt_ptr(offset)
         check(self.lib.ss_eval_quotient_rows(self.handle, C.byref(prog), _ptr_array(col_blocks), len(col_blocks), log_n,
                                              log_blowup, op, row0, nrows, block_rows, _ptr_of(out)))
@@ -340,6 +324,26 @@ class Context:
 
     def mul_bench(self, a, b, n, reps, out):
         check(self.lib.ss_fp252_mul_bench(self.handle, _ptr_of(a), _ptr_of(b), n, reps, _ptr_of(out)))
+
+
+def _air_program(program, tables, table_desc):
+    """-> (ss_air_program, the host arrays it points into).  program: air_program.Program (constants as canonical ints) or
+    anything with code / n_slots and `consts_mont` (uint64[n, 4] Montgomery limbs: the C++ host's lowering)."""
+    code = np.ascontiguousarray(program.code, dtype=np.uint32)
+    if getattr(program, "consts_mont", None) is not None:
+        n_consts = len(program.consts_mont)
+        consts = np.ascontiguousarray(program.consts_mont, dtype=np.uint64) if n_consts else np.zeros((1, 4), dtype=np.uint64)
+    else:
+        n_consts = len(program.consts)
+        consts = np.zeros((max(1, n_consts), 4), dtype=np.uint64)
+        for i, v in enumerate(program.consts):
+            consts[i] = felt(v)
+    desc = np.ascontiguousarray(table_desc if len(table_desc) else [0, 0], dtype=np.uint32)
+    prog = _lib.AirProgram(code.ctypes.data_as(C.POINTER(C.c_uint32)), len(code) // 2,
+                           consts.ctypes.data_as(C.POINTER(C.c_uint64)), n_consts,
+                           _ptr_of(tables) if tables is not None else None,
+                           desc.ctypes.data_as(C.POINTER(C.c_uint32)), len(table_desc) // 2, program.n_slots)
+    return prog, (code, consts, desc)
 
 
 class Matrix:

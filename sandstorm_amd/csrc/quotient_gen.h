@@ -53,7 +53,7 @@ __device__ __forceinline__ void qg_store(Fp *p, const Fp &x) {
     q[0] = qg_u32x4{x.v[0], x.v[1], x.v[2], x.v[3]};
     q[1] = qg_u32x4{x.v[4], x.v[5], x.v[6], x.v[7]};
 }
-#define qstore qg_store
+#define QG_OUT(v) qg_store(a.out + i, fl_to_fp(v))
 
 // constants live in LDS for the kernel's lifetime (18 dwords each: 9 R256 limbs, 9 R280 limbs): a wave-uniform LDS read
 // is a broadcast, its latency is short and known to the scheduler - unlike ~25 KB of scalar loads that miss the 16 KB

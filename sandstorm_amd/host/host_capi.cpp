@@ -265,6 +265,41 @@ int ssh_air_dump(ssh_air *air_h, uint64_t n, const uint64_t *challenges, uint32_
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }
 
+// What a prover needs from an AIR handle per proof, for callers that drive the kernels themselves (the sharded prover,
+// sandstorm_amd/sharded_prover.py): the lowered composition program for these challenges, the device address of the tables
+// and their descriptions.  One u64 blob: n_instr, code words..., n_consts, 4 limbs each..., n_slots, n_tables,
+// (offset, log2 length) per table, device address of the tables.
+int ssh_air_program(ssh_air *air_h, uint64_t n, const uint64_t *challenges, uint32_t nchallenges, const uint64_t alpha[4], uint64_t **blob,
+                    uint64_t *blob_len) {
+    try {
+        Air *air = reinterpret_cast<Air *>(air_h);
+        std::vector<Felt> ch(nchallenges);
+        for (uint32_t i = 0; i < nchallenges; ++i) memcpy(ch[i].data(), challenges + 4 * i, 32);
+        Felt a;
+        memcpy(a.data(), alpha, 32);
+        const AirProgramData pd = air->build_program(n, ch, a);
+        std::vector<uint64_t> out{pd.program.n_instr()};
+        for (uint32_t w : pd.program.code) out.push_back(w);
+        out.push_back(pd.program.consts.size());
+        for (auto &c : pd.program.consts) for (int k = 0; k < 4; ++k) out.push_back(c[k]);
+        out.push_back(pd.program.n_slots);
+        out.push_back(pd.table_desc.size() / 2);
+        for (uint32_t v : pd.table_desc) out.push_back(v);
+        out.push_back((uint64_t)(uintptr_t)pd.d_tables);
+        *blob = (uint64_t *)malloc(out.size() * 8);
+        memcpy(*blob, out.data(), out.size() * 8);
+        *blob_len = out.size();
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+// the mask (trace_arguments(): sorted (column, row offset) cells): cols_out / offs_out have room for ssh_air_columns(air, 2) entries
+int ssh_air_mask(ssh_air *air_h, uint32_t *cols_out, uint32_t *offs_out) {
+    Air *air = reinterpret_cast<Air *>(air_h);
+    for (size_t j = 0; j < air->mask.size(); ++j) { cols_out[j] = air->mask[j].first; offs_out[j] = air->mask[j].second; }
+    return 0;
+}
+uint32_t ssh_air_num_challenges(ssh_air *air_h) { return reinterpret_cast<Air *>(air_h)->num_challenges; }
+
 // Verify a proof in the reference's wire format (verifier.hpp) against an AIR handle (mini or recursive; the handle may
 // have been created without a device).  conventions: 1 = the shipped proofs' (bit-reversed, unnormalised fold, unshifted
 // remainder) with the bare draw as FRI challenge (round-1 proofs), 2 = the reference's (the FRI challenge is the draw times

@@ -133,6 +133,58 @@ class StarknetHostAir(RecursiveHostAir):
     column_tag = "column"
 
 
+class _HostProgram:
+    """a lowered program as ss_eval_quotient takes it (air_program.Program's duck type), constants already in limb form"""
+
+    def __init__(self, code, consts_mont, n_slots):
+        self.code, self.consts_mont, self.n_slots = code, consts_mont, n_slots
+        self.consts = range(len(consts_mont))           # only its length is read when consts_mont is there
+
+
+def prover_air(host_air):
+    """the C++ host's AIR behind the prover.Air interface (what sandstorm_amd/prover.py and sharded_prover.py drive): the
+    composition program is built and lowered by the C++ host per proof (sub-millisecond; the Python lowering of the same
+    DAG takes ~0.3 s for the starknet layout), its tables are the ones the handle built on the device"""
+    from .prover import Air
+    h = load()
+    h.ssh_air_program.argtypes = h.ssh_air_dump.argtypes
+    h.ssh_air_mask.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    h.ssh_air_num_challenges.argtypes = [C.c_void_p]
+    h.ssh_air_num_challenges.restype = C.c_uint32
+    nmask = host_air.mask_size
+    mc, mo = (C.c_uint32 * nmask)(), (C.c_uint32 * nmask)()
+    h.ssh_air_mask(host_air.h, mc, mo)
+    mask = [(int(mc[j]), int(mo[j])) for j in range(nmask)]
+
+    def build_program(n, challenges, comp_coeff):
+        ch = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint64) for c in challenges]))
+        al = np.ascontiguousarray(comp_coeff, dtype=np.uint64)
+        blob, ln = C.POINTER(C.c_uint64)(), C.c_uint64()
+        _check(h.ssh_air_program(host_air.h, n, ch.ctypes.data_as(C.POINTER(C.c_uint64)), len(challenges), al.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                 C.byref(blob), C.byref(ln)))
+        words = np.ctypeslib.as_array(blob, shape=(ln.value,)).copy()
+        h.ssh_free(blob)
+        o = 0
+        n_instr = int(words[o]); o += 1
+        code = words[o:o + 2 * n_instr].astype(np.uint32); o += 2 * n_instr
+        n_consts = int(words[o]); o += 1
+        consts = words[o:o + 4 * n_consts].reshape(n_consts, 4).copy(); o += 4 * n_consts
+        n_slots = int(words[o]); o += 1
+        n_tables = int(words[o]); o += 1
+        desc = [int(v) for v in words[o:o + 2 * n_tables]]; o += 2 * n_tables
+        d_tables = int(words[o])
+        return _HostProgram(code, consts, n_slots), (_DevicePointer(d_tables) if d_tables else None), desc
+    return Air(type(host_air).__name__, host_air.num_base_columns, host_air.num_extension_columns, h.ssh_air_num_challenges(host_air.h), mask,
+               build_program)
+
+
+class _DevicePointer:
+    """a device address owned by somebody else (the C++ AIR's tables)"""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+
 class _Reader:
     def __init__(self, b):
         self.b, self.o = b, 0

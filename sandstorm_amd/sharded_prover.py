@@ -296,6 +296,18 @@ class ShardedProver:
         halo = min(halo, N - B)
         coin = PublicCoin(self.claim.coin_kind, coin_seed)
         proof = Proof(opt, n, tree_kind=self.claim.tree.tree_kind)
+        import os
+        import time
+        timing = os.environ.get("SS_SHARD_TIMING") and r == 0
+        t_last = [time.perf_counter()]
+
+        def mark(stage):
+            """SS_SHARD_TIMING=1: wall clock per stage on rank 0 (synchronises the stream: diagnosis only)"""
+            if timing:
+                ctx.sync()
+                now = time.perf_counter()
+                print("[shard timing] %-34s %9.3f ms" % (stage, 1e3 * (now - t_last[0])), flush=True)
+                t_last[0] = now
 
         def extend(owned):
             """LDE of this rank's columns -> ({col: evaluations [N, 4]}, {col: bit-reversed coefficients [n, 4]})"""
@@ -309,9 +321,12 @@ class ShardedProver:
         # 2. base trace
         assert sorted(my_base) == [c for c in range(nb) if self.owner(c) == r], "column c lives on rank c % R"
         base_ev, coeffs = extend(my_base)
+        mark("base lde")
         base_blocks = self.to_row_blocks(base_ev, nb, 0, N, halo)
         del base_ev
+        mark("base re-shard")
         base_com = self.commit(base_blocks, N, order)
+        mark("base commit")
         proof.base_root = base_com.root
         coin.reseed_with_digest(proof.base_root)
         # 3-4. challenges -> extension trace
@@ -325,7 +340,9 @@ class ShardedProver:
             coeffs.update(ext_co)
             ext_blocks = self.to_row_blocks(ext_ev, ne, nb, N, halo)
             del ext_ev
+            mark("extension build + lde + re-shard")
             ext_com = self.commit(ext_blocks, N, order)
+            mark("extension commit")
             proof.extension_root = ext_com.root
             coin.reseed_with_digest(proof.extension_root)
             blocks += ext_blocks
@@ -334,11 +351,13 @@ class ShardedProver:
         proof.composition_coeff = comp_coeff
         program, tables, table_desc = air.build_program(n, challenges, comp_coeff)
         d_tables = tables if tables is None or hasattr(tables, "ptr") else (ctx.column(tables) if len(tables) else None)
+        mark("program")
         q_block = self.felts(B)
         if R == 1:
             ctx.eval_quotient(program, d_tables, table_desc, blocks, log_n, lb, g, q_block)
         else:
             ctx.eval_quotient_rows(program, d_tables, table_desc, blocks, log_n, lb, g, r * B, B, B + halo, q_block)
+        mark("quotient")
         ncomp = conv.composition_columns
         assert ncomp == 1 << lb == 2, "composition split implemented for blowup 2"
         comp_owned, comp_co = {}, {}
@@ -362,9 +381,11 @@ class ShardedProver:
         for k, co in comp_co.items():
             comp_owned[k] = self.felts(N)
             ctx.evaluate([co], log_n, lb, g, [comp_owned[k]])
+        mark("composition gather + ntt + lde")
         comp_blocks = self.to_row_blocks(comp_owned, ncomp, 0, N, 0)
         del comp_owned
         comp_com = self.commit(comp_blocks, N, order)
+        mark("composition re-shard + commit")
         proof.composition_root = comp_com.root
         coin.reseed_with_digest(proof.composition_root)
         # 6. out-of-domain point: every column owner evaluates its cells, everybody learns all of them
@@ -386,6 +407,7 @@ class ShardedProver:
         proof.ood_trace = np.stack([ood_t[j] for j in range(len(air.mask))])
         proof.ood_composition = np.stack([ood_c[k] for k in range(ncomp)])
         coin.reseed_with_field_elements(list(proof.ood_trace) + list(proof.ood_composition))
+        mark("ood")
         # 7. DEEP composition on this rank's part of the trace-size sub-coset; rank 0 interpolates and re-expands
         deep_alpha = coin.draw()
         proof.deep_alpha = deep_alpha
@@ -402,14 +424,17 @@ class ShardedProver:
             sub = self.felts(n)
             sub[:cnt] = sub_block
             comm.exchange([], [(p, sub[p * cnt:(p + 1) * cnt]) for p in range(1, R)])
+            mark("deep rows + gather")
             deep = _TensorBuffer(ctx, self.felts(N))
             ctx.deep_extend(sub, log_n, lb, g, deep)
+            mark("deep extend")
             # 8-9. FRI, proof of work, query positions: on rank 0, as the single-device prover does them
             layers = fri_commit_phase(ctx, self.claim.tree, conv, opt, coin, proof, deep, log_N, n)
             proof.pow_nonce = proof_of_work(ctx, self.claim.coin_kind, coin, opt, self.pow_nonce)
             coin.reseed_with_int(proof.pow_nonce)
             positions = coin.draw_queries(opt.num_queries, N)
             proof.query_positions = positions
+            mark("fri + pow")
             comm.broadcast_object(positions, 0)
         # openings of the three trace commitments: rows from the row-block ranks, paths from the leaf-block ranks
         opened = [self.open(base_com, base_blocks, N, positions, order),
@@ -422,6 +447,7 @@ class ShardedProver:
             proof.extension_rows, proof.extension_paths, proof.extension_leaf_digests = opened[1]
         proof.composition_rows, proof.composition_paths, proof.composition_leaf_digests = opened[2]
         fri_open(ctx, conv, opt, proof, layers, positions)
+        mark("openings")
         return proof
 
 

@@ -1,0 +1,89 @@
+// The generated constraint kernels on the CPU (test infrastructure).  The body of a compiled kernel
+// (sandstorm_amd/csrc/quotient_gen_<layout>.inc, written by tools/gen_quotient.py) is plain C++ over the operand macros
+// of quotient_gen.h; here those macros read host arrays, a "workgroup" is a loop, and the body runs over a whole
+// evaluation domain.  tests/test_quotient_gen_host.py compares the result with the oracle's constraint VM: the generator's
+// decisions (lazy-form bounds and reductions, the rotating prefetch registers across the loop edge, slot traffic, the
+// row-block form) are checked without a GPU and without a six-minute device build.
+//
+// usage: quotient_gen_host_test <input file> <output file>     (format: tests/test_quotient_gen_host.py)
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../sandstorm_amd/csrc/fp252.h"
+#include "../../sandstorm_amd/csrc/fl252.h"
+
+using namespace ss;
+
+struct HostArgs {
+    std::vector<std::vector<Fp>> cols;
+    std::vector<Fp> tables;
+    std::vector<uint32_t> tdesc;          // per table: first element, index mask
+    std::vector<Fl> consts, consts_r280;
+    std::vector<Fp> out;
+    Fp offset, w;
+    uint64_t npoints;
+    uint32_t row0, trace_mask, log_blowup;
+};
+
+#define QG_TRACE_RAW(col, off, idx) a.cols[col][((idx) + ((off) << lb)) & maskN]
+#define QG_TABLE_RAW(t, idx) a.tables[a.tdesc[2 * (t)] + (((idx) + row0) & a.tdesc[2 * (t) + 1])]
+#define QG_CONST(k) a.consts[k]
+#define QG_CONST_R280(k) a.consts_r280[k]
+#define QG_SLOT_STORE(k, v) slots[k] = fl_pack(v)
+#define QG_SLOT(k) fl_from_fp(slots[k])
+#define QG_OUT(v) a.out[i] = fl_to_fp(v)
+#define QG_PIN_LOADS
+typedef FlWide QgWide;
+#define qg_dot_zero fl_wide_zero
+#define qg_dot_mad fl_wide_mad
+#define qg_dot_reduce fl_wide_reduce
+#define QG_POINT_LOOP_BEGIN                                        \
+    for (uint64_t i = lane; i < N; i += lanes) {                   \
+        i32 = (uint32_t)i;                                         \
+        const uint32_t inext = (uint32_t)(i + lanes < N ? i + lanes : i);
+#define QG_POINT_LOOP_END                                          \
+        x = fl_mul(x, wstep);                                      \
+    }
+
+// one "lane" of a grid of `lanes` lanes: exactly the device kernel's per-lane code
+static void run_lane_LAYOUT(HostArgs &a, uint64_t lane, uint64_t lanes) {
+    const uint64_t N = a.npoints;
+    const uint32_t lb = a.log_blowup, maskN = a.trace_mask, row0 = a.row0;
+    Fp slots[64];
+    Fl x = fl_from_fp(fp_mul(a.offset, fp_pow_u64(a.w, lane)));
+    const Fl wstep = fl_from_fp(fp_pow_u64(a.w, lanes));
+#include QG_INC
+}
+
+template <class T>
+static void rd(FILE *f, T *p, size_t n) { if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } }
+
+int main(int argc, char **argv) {
+    if (argc != 3) return 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    uint64_t hdr[10];          // ncols, rows per column, ntables_felts, ntables, nconsts, npoints, row0, trace_mask, log_blowup, lanes
+    rd(f, hdr, 10);
+    HostArgs a;
+    a.cols.resize(hdr[0]);
+    for (auto &c : a.cols) { c.resize(hdr[1]); rd(f, c.data(), c.size()); }
+    a.tables.resize(hdr[2]); rd(f, a.tables.data(), a.tables.size());
+    a.tdesc.resize(2 * hdr[3]); rd(f, a.tdesc.data(), a.tdesc.size());
+    std::vector<Fp> consts(hdr[4]); rd(f, consts.data(), consts.size());
+    rd(f, &a.offset, 1); rd(f, &a.w, 1);
+    fclose(f);
+    for (auto &c : consts) { a.consts.push_back(fl_from_fp(c)); a.consts_r280.push_back(fl_to_r280(c)); }
+    a.npoints = hdr[5]; a.row0 = (uint32_t)hdr[6]; a.trace_mask = (uint32_t)hdr[7]; a.log_blowup = (uint32_t)hdr[8];
+    a.out.assign(a.npoints, fp_zero());
+    a.offset = fp_mul(a.offset, fp_pow_u64(a.w, a.row0));
+    const uint64_t lanes = hdr[9];
+#pragma omp parallel for schedule(dynamic, 16)
+    for (uint64_t lane = 0; lane < lanes; ++lane) run_lane_LAYOUT(a, lane, lanes);
+    f = fopen(argv[2], "wb");
+    fwrite(a.out.data(), sizeof(Fp), a.out.size(), f);
+    fclose(f);
+    return 0;
+}

@@ -1,0 +1,94 @@
+"""The generated constraint kernels, checked without a GPU: the body of csrc/quotient_gen_<layout>.inc (what
+tools/gen_quotient.py writes and the device kernel includes) compiled for the host (tests/cpp/quotient_gen_host_test.cpp)
+and run over a whole evaluation domain of random columns, tables and constants, against the oracle's constraint VM on
+the program it was generated from - bit for bit; also in the row-block form of the sharded prover, and with a "grid"
+that does not divide the domain (the rotating prefetch registers cross the loop edge at every point)."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_real_quotient import _rand
+from tests.test_layout_recursive import load_run
+from tests.test_layout_starknet import CHALLENGES, P, starknet_example
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp", "quotient_gen_host_test.cpp")
+
+
+def build(layout, tmp):
+    exe = os.path.join(tmp, "qg_host_%s" % layout)
+    inc = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s.inc" % layout)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fopenmp", "-DQG_INC=\"%s\"" % inc, "-o", exe, CPP])
+    return exe
+
+
+def program(oracle, layout, log_n):
+    from sandstorm_amd import hostlib
+    if layout == "starknet":
+        from sandstorm_amd.layouts import starknet as lay
+        _, _, pi = starknet_example(11)
+        cpp = hostlib.StarknetHostAir(None, pi, log_n)
+    else:
+        from sandstorm_amd.layouts import recursive as lay
+        _, _, pi = load_run()
+        cpp = hostlib.RecursiveHostAir(None, pi, log_n)
+    n = 1 << log_n
+    code, consts, n_slots, specs = cpp.dump(n, [oracle.to_mont([c])[0] for c in CHALLENGES], oracle.to_mont([pow(5, 77, P)])[0])
+    cpp.close()
+    return lay, code, consts, n_slots, specs
+
+
+def run_host(exe, tmp, cols, tab, desc, consts, npoints, row0, trace_mask, lb, lanes, offset, w):
+    path_in, path_out = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+    with open(path_in, "wb") as f:
+        f.write(struct.pack("<10Q", len(cols), len(cols[0]), len(tab), len(desc) // 2, len(consts), npoints, row0, trace_mask, lb, lanes))
+        for c in cols:
+            f.write(np.ascontiguousarray(c).tobytes())
+        f.write(np.ascontiguousarray(tab).tobytes())
+        td = []
+        for k in range(0, len(desc), 2):
+            td += [desc[k], (1 << desc[k + 1]) - 1]
+        f.write(np.asarray(td, dtype=np.uint32).tobytes())
+        f.write(np.ascontiguousarray(consts).tobytes())
+        f.write(np.ascontiguousarray(offset).tobytes())
+        f.write(np.ascontiguousarray(w).tobytes())
+    subprocess.check_call([exe, path_in, path_out], env=dict(os.environ, OMP_NUM_THREADS=str(min(8, os.cpu_count() or 1))))
+    return np.fromfile(path_out, dtype=np.uint64).reshape(npoints, 4)
+
+
+@pytest.mark.parametrize("layout,log_n", [("recursive", 14), ("starknet", 16)])
+def test_generated_kernel_body_on_the_host(oracle, layout, log_n, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_quotient
+    tmp = str(tmp_path)
+    lay, code, consts, n_slots, specs = program(oracle, layout, log_n)
+    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s.hip" % layout)) as f:
+        assert ("0x%016x" % gen_quotient.code_hash(code)) in f.read(), "the committed kernel was generated from another program"
+    exe = build(layout, tmp)
+    n, N = 1 << log_n, 2 << log_n
+    tables = lay.Tables(n)
+    rng = np.random.default_rng(23)
+    tabs, desc, off = [], [], 0
+    for spec in specs:
+        t = _rand(rng, tables.length(spec))
+        desc += [off, len(t).bit_length() - 1]
+        off += len(t)
+        tabs.append(t)
+    tab = np.concatenate(tabs)
+    lde = [_rand(rng, N) for _ in range(10)]
+    g = oracle.to_mont([3])[0]
+    w = oracle.to_mont([pow(3, (P - 1) // N, P)])[0]
+    want = oracle.eval_program(code, consts, tab, desc, n_slots, lde, log_n, 1, g)
+    # whole domain; 96 lanes do not divide it evenly and make every lane loop many times over the loop edge
+    got = run_host(exe, tmp, lde, tab, desc, consts, N, 0, N - 1, 1, 96, g, w)
+    assert np.array_equal(got, want)
+    # row-block form (ss_eval_quotient_rows): the third quarter of the domain with the rows behind it
+    B = N // 4
+    halo = max((int(c) & 0xffffff) for c in code[1::2][(code[0::2] >> 12) & 0xf == 3]) << 1
+    idx = (2 * B + np.arange(B + halo)) % N
+    got = run_host(exe, tmp, [c[idx] for c in lde], tab, desc, consts, B, 2 * B, 0xffffffff, 1, 64, g, w)
+    assert np.array_equal(got, want[2 * B:3 * B])

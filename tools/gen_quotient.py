@@ -253,11 +253,16 @@ def generate(layout):
             emit("    QG_SLOT_STORE(%d, %s);" % (w1, v))
         else:
             flush_wide()
-            emit("    qstore(a.out + i, fl_to_fp(%s));" % v)
-        # this instruction consumed memory operand j: start the load of operand j + D (of the next point past the end)
+            emit("    QG_OUT(%s);" % v)
+        # this instruction consumed memory operand q and freed register q % D: start the load of operand q + D there - or, in
+        # the last D steps of a point, of the next point's operand whose home register that is (operand j lives in m[j % D];
+        # when D does not divide the operand count the tail fills the registers in rotated order)
         if pc in mem_index:
-            j = mem_index[pc] + D
-            issue(j % len(mem_ops), j >= len(mem_ops))
+            q, L = mem_index[pc], len(mem_ops)
+            if q + D < L:
+                issue(q + D, False)
+            else:
+                issue(q % D, True)
     assert wide["acc"] is None
     body = "\n".join(out)
     h = code_hash(code)
@@ -280,12 +285,7 @@ namespace {
 
 __global__ __launch_bounds__(QG_THREADS) void quotient_%(layout)s_kernel(QGenArgs a) {
     QG_PROLOGUE(%(n_consts)d, %(n_slots)d)
-    Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
-    QgWide wd;
-%(slots)s%(regs)s    uint32_t i32 = (uint32_t)lane;
-%(prime)s    QG_POINT_LOOP_BEGIN
-%(body)s
-    QG_POINT_LOOP_END
+#include "quotient_gen_%(layout)s.inc"
 }
 
 hipError_t launch_%(layout)s(hipStream_t st, const QGenArgs &a, uint32_t blocks) {
@@ -310,6 +310,17 @@ const QGenKernel &quotient_gen_%(layout)s() {
 }  // namespace ss
 ''' % dict(layout=layout, n_instr=n_instr, n_slots=n_slots, n_consts=n_consts, n_tables=n_tables, ncols=ncols, hash=h, slots=slots,
            body=body, regs=regs, prime=prime, depth=D, **stats)
+    inc = '''// GENERATED by tools/gen_quotient.py - DO NOT EDIT.  The body of the `%(layout)s` constraint kernel: the program unrolled over the
+// operand macros of quotient_gen.h.  Included by quotient_gen_%(layout)s.hip (device) and, with host definitions of the same
+// macros, by tests/cpp/quotient_gen_host_test.cpp, which runs it on the CPU against the oracle's constraint VM.
+    Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
+%(wide)s%(regs)s    uint32_t i32 = (uint32_t)lane;
+%(prime)s    QG_POINT_LOOP_BEGIN
+%(body)s
+    QG_POINT_LOOP_END
+''' % dict(layout=layout, regs=regs, prime=prime, body=body, wide="    QgWide wd;\n" if stats["fused"] else "")
+    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s.inc" % layout), "w") as f:
+        f.write(inc)
     path = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s.hip" % layout)
     with open(path, "w") as f:
         f.write(src)
