@@ -70,7 +70,7 @@ enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
 const char *ss_last_error(void);
 /* ABI version of this header; bump on any signature change.  ss_abi_version() of the loaded
  * library must equal SS_ABI_VERSION of the header the caller was built against. */
-#define SS_ABI_VERSION 4u
+#define SS_ABI_VERSION 5u
 uint32_t ss_abi_version(void);
 
 /* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;
@@ -246,6 +246,23 @@ ss_status ss_deep_compose_rows(ss_ctx *ctx, const uint64_t *const *d_trace_block
                                uint64_t *d_out_subcoset);
 ss_status ss_deep_extend(ss_ctx *ctx, uint64_t *d_subcoset, uint32_t log_n, uint32_t log_blowup,
                          const uint64_t offset[4], uint64_t *d_out);
+
+/* ---- X4: the 64-bit field variant, p = 2^64 - 2^32 + 1 ("Goldilocks") with Fq3 = Fp[X]/(X^3 - 2): the pair the
+ *      reference instantiates for its experimental claim (cli/src/main.rs:103-133:
+ *      ministark_gpu::fields::p18446744069414584321::ark::{Fp, Fq3}; BASELINE.json configs[4]).  The same conventions as
+ *      the 252-bit entry points (w = 7^((p-1)/n), evaluation at offset * w^k in natural order).  Elements are 8-byte
+ *      values < p; every operation here is linear in the data, so Montgomery images (arkworks' in-memory Fp64) pass
+ *      through unchanged.  `offset` / `alpha` are plain (canonical) values.  PARITY UNPINNED: the field crate is
+ *      un-vendored and the reference holds no vector for it; the oracle restates the definitions (oracle/goldilocks.c). */
+ss_status ss_ntt_gl64(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, uint32_t log_n, int direction, uint64_t offset,
+                      int in_order, int out_order);
+ss_status ss_lde_gl64(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols, uint32_t log_n, uint32_t log_blowup,
+                      uint64_t offset, uint64_t *const *d_evals, uint64_t *const *d_coeffs /* nullable; bit-reversed */);
+/* one FRI layer over Fq3-valued evaluations (interleaved [2^log_len][3]) on the Fp domain domain_offset * <w>, natural
+ * order: row j = {evals[j + k len/fold]}, d_out[j] = (degree < fold interpolant of row j)(alpha), alpha in Fq3;
+ * flags: SS_FRI_UNNORMALISED multiplies by fold */
+ss_status ss_fri_fold_gl64x3(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold, const uint64_t alpha[3],
+                             uint64_t domain_offset, uint32_t flags, uint64_t *d_out);
 
 /* ---- F1: one FRI layer fold (ministark FriProver::build_layers, un-vendored;
  *      defaults cli/src/main.rs:57-60).  d_evals: 2^log_len felts on

@@ -342,3 +342,40 @@ def eval_program(code, consts, tables, table_desc, n_slots, lde_cols, log_n, log
     lib().or_eval_program_ex(C.byref(prog), _ptr(tables), cp, C.c_uint(log_n), C.c_uint(log_blowup),
                              _fp(offset), _ptr(out))
     return out
+
+
+# ------------------------------------------------------------- the 64-bit field (oracle/goldilocks.c)
+GL_P = 2**64 - 2**32 + 1
+
+
+def gl_root_of_unity(log_n):
+    f = lib().or_gl_root_of_unity
+    f.restype = C.c_uint64
+    return int(f(C.c_uint(log_n)))
+
+
+def gl_ntt(col, inverse=False, offset=1):
+    a = np.ascontiguousarray(col, dtype=np.uint64).copy()
+    fn = lib().or_gl_ntt_inverse if inverse else lib().or_gl_ntt_forward
+    fn.restype = None
+    fn(_ptr(a), C.c_uint(a.shape[0].bit_length() - 1), C.c_uint64(offset))
+    return a
+
+
+def gl_lde(col, log_blowup, offset):
+    a = np.ascontiguousarray(col, dtype=np.uint64)
+    n = a.shape[0]
+    ev, co = np.zeros(n << log_blowup, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    lib().or_gl_lde.restype = None
+    lib().or_gl_lde(_ptr(a), C.c_uint(n.bit_length() - 1), C.c_uint(log_blowup), C.c_uint64(offset), _ptr(ev), _ptr(co))
+    return ev, co
+
+
+def gl3_fri_fold(evals, fold, alpha, offset, unnormalised=False):
+    a = np.ascontiguousarray(evals, dtype=np.uint64)
+    L = a.shape[0]
+    out = np.zeros((L // fold, 3), dtype=np.uint64)
+    al = np.ascontiguousarray(alpha, dtype=np.uint64)
+    lib().or_gl3_fri_fold.restype = None
+    lib().or_gl3_fri_fold(_ptr(a), C.c_uint(L.bit_length() - 1), C.c_uint(fold), _ptr(al), C.c_uint64(offset), C.c_int(1 if unnormalised else 0), _ptr(out))
+    return out

@@ -203,6 +203,19 @@ class Context:
         _k2, o = _felt_ptr(offset)
         check(self.lib.ss_fri_fold_ex(self.handle, _ptr_of(evals), log_len, fold, a, o, flags, _ptr_of(out)))
 
+    # ---- X4: the 64-bit field (p = 2^64 - 2^32 + 1) and its cubic extension
+    def ntt_gl64(self, cols, log_n, direction=FORWARD, offset=1, in_order=NATURAL, out_order=NATURAL):
+        check(self.lib.ss_ntt_gl64(self.handle, _ptr_array(cols), len(cols), log_n, direction, int(offset), in_order, out_order))
+
+    def lde_gl64(self, cols_in, log_n, log_blowup, offset, evals_out, coeffs_out=None):
+        check(self.lib.ss_lde_gl64(self.handle, _ptr_array(cols_in), len(cols_in), log_n, log_blowup, int(offset),
+                                   _ptr_array(evals_out), _ptr_array(coeffs_out) if coeffs_out else None))
+
+    def fri_fold_gl64x3(self, evals, log_len, fold, alpha, offset, out, flags=0):
+        a = np.ascontiguousarray(alpha, dtype=np.uint64)
+        check(self.lib.ss_fri_fold_gl64x3(self.handle, _ptr_of(evals), log_len, fold, a.ctypes.data_as(C.POINTER(C.c_uint64)), int(offset),
+                                          flags, _ptr_of(out)))
+
     def pow_grind(self, coin_kind, digest, bits):
         nonce = C.c_uint64()
         check(self.lib.ss_pow_grind(self.handle, coin_kind, bytes(digest), bits, C.byref(nonce)))

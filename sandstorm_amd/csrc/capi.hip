@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -74,6 +75,7 @@ struct ss_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::map<PlanKey, Fp *> plans;          // device twiddle tables
+    std::map<std::tuple<uint32_t, int, uint64_t>, uint64_t *> gl_plans;     // the 64-bit field's: (log_n, inverse, offset)
     PedersenTables *ped = nullptr;
     void *scratch = nullptr;                // grow-only device scratch
     size_t scratch_bytes = 0;
@@ -264,7 +266,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -284,6 +286,7 @@ ss_status ss_ctx_create(int device, ss_ctx **out) {
     ctx->stream = ctx->own_stream;
     HIP_TRY(hipMalloc(&ctx->d_small, 64 * sizeof(uint64_t)));
     HIP_TRY(ntt_set_func_attributes());
+    HIP_TRY(gl_set_func_attributes());
     *out = ctx;
     return SS_OK;
 }
@@ -1087,9 +1090,12 @@ const QGenKernel *quotient_gen_find(const uint32_t *code, uint32_t n_instr) {
     uint64_t h = 0xcbf29ce484222325ull;                                  // FNV-1a over the code words (tools/gen_quotient.py)
     for (size_t k = 0; k < 2 * (size_t)n_instr; ++k)
         for (int b = 0; b < 4; ++b) h = (h ^ ((code[k] >> (8 * b)) & 0xffu)) * 0x100000001b3ull;
-    const QGenKernel *all[] = {&quotient_gen_starknet(), &quotient_gen_recursive()};
+    const QGenKernel *all[] = {&quotient_gen_starknet(), &quotient_gen_recursive(), &quotient_gen_starknet_v1(), &quotient_gen_recursive_v1(),
+                               &quotient_gen_starknet_v2(), &quotient_gen_recursive_v2()};
+    uint32_t variant = 0;                                                // A/B runs: SS_QG_VARIANT=k (tools/gen_quotient.py VARIANTS)
+    if (const char *e = getenv("SS_QG_VARIANT")) variant = (uint32_t)strtoul(e, nullptr, 10);
     for (const QGenKernel *k : all)
-        if (k->code_hash == h && k->n_instr == n_instr) return k;
+        if (k->code_hash == h && k->n_instr == n_instr && k->variant == variant) return k;
     return nullptr;
 }
 
@@ -1124,7 +1130,7 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
     a.npoints = npoints; a.row0 = (uint32_t)row0; a.log_blowup = log_blowup;
     a.trace_mask = block ? 0xffffffffu : (uint32_t)((1ull << log_N) - 1ull);
     // one workgroup per CU and SIMD slot the kernel's register budget allows; SS_QG_BLOCKS overrides (experiments)
-    uint64_t blocks = 256;
+    uint64_t blocks = 256ull * gen.wgs_per_cu;
     if (const char *e = getenv("SS_QG_BLOCKS")) blocks = strtoull(e, nullptr, 10);
     if (blocks * QG_THREADS > N) blocks = N / QG_THREADS;
     if (blocks == 0) blocks = 1;
@@ -1231,6 +1237,167 @@ ss_status ss_eval_quotient_rows(ss_ctx *ctx, const ss_air_program *prog, const u
                                 uint64_t row0, uint64_t nrows, uint64_t block_rows, uint64_t *d_out) {
     if (block_rows == 0 || nrows == 0 || nrows > block_rows) return fail(SS_ERR_INVALID, "empty row block");
     return eval_quotient_impl(ctx, prog, d_col_blocks, ncols, log_n, log_blowup, offset, row0, nrows, block_rows, d_out);
+}
+
+
+// ------------------------------------------------------------------- the 64-bit field variant (X4)
+}  // extern "C"
+
+namespace {
+constexpr uint64_t GL_P = 0xFFFFFFFF00000001ull;
+uint64_t gl_mulh(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % GL_P); }
+
+ss_status gl_get_plan(ss_ctx *ctx, uint32_t log_n, bool inverse, uint64_t offset, const uint64_t **out) {
+    auto key = std::make_tuple(log_n, inverse ? 1 : 0, offset);
+    auto it = ctx->gl_plans.find(key);
+    if (it != ctx->gl_plans.end()) { *out = it->second; return SS_OK; }
+    const uint64_t n = 1ull << log_n;
+    uint64_t r = gl_root_of_unity_host(log_n), h = offset;
+    if (inverse) { r = gl_inv_host(r); h = gl_inv_host(h); }
+    const uint64_t half = n / 2 ? n / 2 : 1;
+    const uint64_t n_lo = half < 4096 ? half : 4096, n_hi = half < 4096 ? 1 : half / 4096;
+    std::vector<uint64_t> host(n_lo + n_hi + log_n + 1);
+    uint64_t *lo = host.data(), *hi = lo + n_lo, *hp = hi + n_hi;
+    lo[0] = 1;
+    for (uint64_t i = 1; i < n_lo; ++i) lo[i] = gl_mulh(lo[i - 1], r);
+    const uint64_t r4096 = n_lo == 4096 ? gl_mulh(lo[4095], r) : 1;
+    hi[0] = 1;
+    for (uint64_t i = 1; i < n_hi; ++i) hi[i] = gl_mulh(hi[i - 1], r4096);
+    hp[log_n - 1] = h;                                       // T_s carries h^(n / 2^(s+1))
+    for (uint32_t s = log_n - 1; s-- > 0;) hp[s] = gl_mulh(hp[s + 1], hp[s + 1]);
+    uint64_t *d_tabs = nullptr, *d_tw = nullptr;
+    HIP_TRY(hipMalloc(&d_tabs, host.size() * 8));
+    HIP_TRY(hipMalloc(&d_tw, n * 8));
+    HIP_TRY(hipMemcpyAsync(d_tabs, host.data(), host.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_gl_twiddles(ctx->stream, d_tw, d_tabs, d_tabs + n_lo, d_tabs + n_lo + n_hi, log_n));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_tabs));
+    ctx->gl_plans[key] = d_tw;
+    *out = d_tw;
+    return SS_OK;
+}
+
+std::vector<Pass> gl_plan_passes(uint32_t log_n) {
+    std::vector<Pass> v;
+    const uint32_t lt = gl_log_tile_max();
+    const uint32_t r0 = log_n < lt ? log_n : lt;
+    v.push_back({0, r0});
+    uint32_t rem = log_n - r0;
+    if (rem) {
+        const uint32_t rmax = lt - 5;                  // rows of >= 32 adjacent elements (256-byte global runs)
+        const uint32_t k = (rem + rmax - 1) / rmax;
+        uint32_t s0 = r0;
+        for (uint32_t i = 0; i < k; ++i) {
+            uint32_t r = rem / (k - i) + ((rem % (k - i)) ? 1 : 0);
+            v.push_back({s0, r});
+            s0 += r; rem -= r;
+        }
+    }
+    return v;
+}
+// forward: bit-reversed (optionally sub-sampled) src -> natural dst
+ss_status gl_run_forward(ss_ctx *ctx, const void *const *src, void *const *dst, uint32_t ncols, uint32_t log_n, const uint64_t *tw, uint32_t log_expand) {
+    const uint32_t lt = gl_log_tile_max(), log_tile = log_n < lt ? log_n : lt;
+    const std::vector<Pass> passes = gl_plan_passes(log_n);
+    if (log_expand > passes[0].r) return fail(SS_ERR_INVALID, "log_blowup %u too large", log_expand);
+    for (size_t i = 0; i < passes.size(); ++i) {
+        ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
+        HIP_TRY(launch_gl_ntt_pass(ctx->stream, false, i == 0 ? src : (const void *const *)dst, dst, ncols, tw, log_n, passes[i].s0, passes[i].r, log_tile,
+                                   i == 0 ? log_expand : 0, i == 0 ? log_expand : 0, 1));
+    }
+    return SS_OK;
+}
+// inverse: natural src -> bit-reversed dst, scaled by 1/n
+ss_status gl_run_inverse(ss_ctx *ctx, const void *const *src, void *const *dst, uint32_t ncols, uint32_t log_n, const uint64_t *tw) {
+    const uint32_t lt = gl_log_tile_max(), log_tile = log_n < lt ? log_n : lt;
+    const std::vector<Pass> passes = gl_plan_passes(log_n);
+    const uint64_t ninv = gl_inv_host((1ull << log_n) % GL_P);
+    for (size_t i = passes.size(); i-- > 0;) {
+        const bool first = i == passes.size() - 1;
+        ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
+        HIP_TRY(launch_gl_ntt_pass(ctx->stream, true, first ? src : (const void *const *)dst, dst, ncols, tw, log_n, passes[i].s0, passes[i].r, log_tile, 0, 0,
+                                   i == 0 ? ninv : 1));
+    }
+    return SS_OK;
+}
+bool gl_valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
+}  // namespace
+
+extern "C" {
+
+ss_status ss_ntt_gl64(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, uint32_t log_n, int direction, uint64_t offset,
+                      int in_order, int out_order) {
+    if (!ctx || !d_cols) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!gl_valid_log(log_n)) return fail(SS_ERR_INVALID, "log_n out of range");
+    if (ncols == 0 || ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u out of range", ncols);
+    if (offset == 0 || offset >= GL_P) return fail(SS_ERR_INVALID, "the coset offset is not a non-zero field element");
+    const bool inverse = direction == SS_NTT_INVERSE;
+    const uint64_t *tw = nullptr;
+    ss_status st = gl_get_plan(ctx, log_n, inverse, offset, &tw);
+    if (st != SS_OK) return st;
+    const uint64_t n = 1ull << log_n;
+    // the networks want: forward bit-reversed in / natural out, inverse natural in / bit-reversed out; other orders go through a
+    // bit-reversal copy in scratch
+    const bool pre = inverse ? in_order == SS_ORDER_BITREV : in_order == SS_ORDER_NATURAL;
+    const bool post = inverse ? out_order == SS_ORDER_NATURAL : out_order == SS_ORDER_BITREV;
+    if (pre || post) { st = ctx->ensure_scratch(n * 8); if (st != SS_OK) return st; }
+    for (uint32_t c = 0; c < ncols; ++c) {
+        uint64_t *col = d_cols[c];
+        const void *src = col; void *dst = col;
+        if (pre) { HIP_TRY(launch_gl_bitrev_copy(ctx->stream, col, (uint64_t *)ctx->scratch, log_n)); src = ctx->scratch; }
+        st = inverse ? gl_run_inverse(ctx, &src, &dst, 1, log_n, tw) : gl_run_forward(ctx, &src, &dst, 1, log_n, tw, 0);
+        if (st != SS_OK) return st;
+        if (post) {
+            HIP_TRY(launch_gl_bitrev_copy(ctx->stream, col, (uint64_t *)ctx->scratch, log_n));
+            HIP_TRY(hipMemcpyAsync(col, ctx->scratch, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+ss_status ss_lde_gl64(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols, uint32_t log_n, uint32_t log_blowup, uint64_t offset,
+                      uint64_t *const *d_evals, uint64_t *const *d_coeffs) {
+    if (!ctx || !d_in || !d_evals) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!gl_valid_log(log_n) || !gl_valid_log(log_n + log_blowup)) return fail(SS_ERR_INVALID, "size out of range");
+    if (offset == 0 || offset >= GL_P) return fail(SS_ERR_INVALID, "the coset offset is not a non-zero field element");
+    if (ncols == 0) return SS_OK;
+    const uint64_t n = 1ull << log_n;
+    const uint64_t *tw_inv = nullptr, *tw_fwd = nullptr;
+    ss_status st = gl_get_plan(ctx, log_n, true, 1, &tw_inv);
+    if (st != SS_OK) return st;
+    st = gl_get_plan(ctx, log_n + log_blowup, false, offset, &tw_fwd);
+    if (st != SS_OK) return st;
+    for (uint32_t base = 0; base < ncols; base += MAX_COLS) {
+        const uint32_t nc = ncols - base < (uint32_t)MAX_COLS ? ncols - base : (uint32_t)MAX_COLS;
+        if (!d_coeffs) { st = ctx->ensure_scratch(n * 8 * nc); if (st != SS_OK) return st; }
+        const void *src[MAX_COLS]; void *co[MAX_COLS]; void *ev[MAX_COLS];
+        for (uint32_t c = 0; c < nc; ++c) {
+            src[c] = d_in[base + c];
+            co[c] = d_coeffs ? (void *)d_coeffs[base + c] : (void *)((char *)ctx->scratch + n * 8 * c);
+            ev[c] = d_evals[base + c];
+        }
+        st = gl_run_inverse(ctx, src, co, nc, log_n, tw_inv);                     // natural evaluations -> bit-reversed coefficients
+        if (st != SS_OK) return st;
+        st = gl_run_forward(ctx, (const void *const *)co, ev, nc, log_n + log_blowup, tw_fwd, log_blowup);
+        if (st != SS_OK) return st;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+ss_status ss_fri_fold_gl64x3(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold, const uint64_t alpha[3],
+                             uint64_t domain_offset, uint32_t flags, uint64_t *d_out) {
+    if (!ctx || !d_evals || !alpha || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (fold != 2 && fold != 4 && fold != 8 && fold != 16) return fail(SS_ERR_INVALID, "fold must be 2, 4, 8 or 16");
+    uint32_t log_fold = 0;
+    while ((1u << log_fold) < fold) ++log_fold;
+    if (!gl_valid_log(log_len) || log_len < log_fold) return fail(SS_ERR_INVALID, "layer length out of range");
+    if (domain_offset == 0 || domain_offset >= GL_P) return fail(SS_ERR_INVALID, "the domain offset is not a non-zero field element");
+    if (flags & ~(uint32_t)SS_FRI_UNNORMALISED) return fail(SS_ERR_UNSUPPORTED, "only SS_FRI_UNNORMALISED is defined for this field");
+    ss_ctx::Scope prof(ctx, SS_PROF_FRI);
+    HIP_TRY(launch_gl3_fri_fold(ctx->stream, d_evals, log_len, fold, alpha, domain_offset, (flags & SS_FRI_UNNORMALISED) != 0, d_out));
+    return SS_OK;
 }
 
 }  // extern "C"

@@ -94,6 +94,20 @@ hipError_t launch_permutation_product(hipStream_t st, const PermOperand &num, co
 hipError_t launch_diluted_aggregate(hipStream_t st, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z,
                                     const Fp &alpha, Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch);
 
+// ---- goldilocks.hip (the 64-bit field variant)
+uint64_t gl_pow_host(uint64_t a, uint64_t e);
+uint64_t gl_root_of_unity_host(uint32_t log_n);
+uint64_t gl_inv_host(uint64_t a);
+uint32_t gl_log_tile_max();
+hipError_t gl_set_func_attributes();
+hipError_t launch_gl_ntt_pass(hipStream_t st, bool dif, const void *const *src, void *const *dst, uint32_t ncols, const uint64_t *tw,
+                              uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first, uint32_t log_expand,
+                              uint64_t scale);
+hipError_t launch_gl_twiddles(hipStream_t st, uint64_t *tw, const uint64_t *pow_lo, const uint64_t *pow_hi, const uint64_t *hpow, uint32_t log_n);
+hipError_t launch_gl_bitrev_copy(hipStream_t st, const uint64_t *src, uint64_t *dst, uint32_t log_n);
+hipError_t launch_gl3_fri_fold(hipStream_t st, const uint64_t *evals, uint32_t log_len, uint32_t fold, const uint64_t alpha[3], uint64_t offset,
+                               bool unnormalised, uint64_t *out);
+
 // ---- quotient.hip
 // what ss_eval_quotient knows and the device program needs resolved (device addresses, sizes)
 struct VmResolve {

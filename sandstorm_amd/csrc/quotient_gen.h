@@ -31,11 +31,17 @@ struct QGenKernel {
     const char *layout;
     uint64_t code_hash;                          // FNV-1a of the program's code words
     uint32_t n_instr, n_consts, n_tables, ncols;
+    uint32_t variant;                            // tools/gen_quotient.py VARIANTS; ss_eval_quotient takes 0 (SS_QG_VARIANT overrides)
+    uint32_t wgs_per_cu;                         // workgroups per CU its register budget allows: the grid is 256 CUs times this
     hipError_t (*launch)(hipStream_t, const QGenArgs &, uint32_t blocks);
 };
 
 const QGenKernel &quotient_gen_starknet();       // quotient_gen_starknet.hip
+const QGenKernel &quotient_gen_starknet_v1();
+const QGenKernel &quotient_gen_starknet_v2();
 const QGenKernel &quotient_gen_recursive();      // quotient_gen_recursive.hip
+const QGenKernel &quotient_gen_recursive_v1();
+const QGenKernel &quotient_gen_recursive_v2();
 
 typedef uint32_t qg_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -89,8 +95,17 @@ typedef FlWide QgWide;
 
 // scratch slots of the program: per point, in LDS as 32-byte images in two 16-byte planes [slot][lane] (a lane's 16 bytes
 // next to its neighbour's: conflict-free b128 accesses), so that the registers hold only what is being computed on
+#ifdef QG_SLOTS_IN_REGISTERS
+// variant: the slots are plain lazy values the compiler keeps in (or spills from) registers; no LDS slot area
+#define QG_SLOT_STORE(k, v) qg_s##k = (v)
+#define QG_SLOT(k) qg_s##k
+#define QG_DECLARE_SLOTS Fl qg_s0, qg_s1, qg_s2, qg_s3, qg_s4, qg_s5, qg_s6, qg_s7, qg_s8, qg_s9, qg_s10, qg_s11, qg_s12, qg_s13, qg_s14, \
+    qg_s15, qg_s16, qg_s17, qg_s18, qg_s19, qg_s20, qg_s21, qg_s22, qg_s23;
+#else
 #define QG_SLOT_STORE(k, v) qg_slot_store(lds_slots, (k), fl_pack(v))
 #define QG_SLOT(k) fl_from_fp(qg_slot_load(lds_slots, (k)))
+#define QG_DECLARE_SLOTS
+#endif
 __device__ __forceinline__ void qg_slot_store(qg_lds_u32x4 slots, int k, const Fp &x) {
     slots[(2 * k) * QG_THREADS + threadIdx.x] = qg_u32x4{x.v[0], x.v[1], x.v[2], x.v[3]};
     slots[(2 * k + 1) * QG_THREADS + threadIdx.x] = qg_u32x4{x.v[4], x.v[5], x.v[6], x.v[7]};
@@ -119,7 +134,8 @@ static inline size_t qg_lds_bytes(int nconsts, int nslots) {
     const uint32_t lb = a.log_blowup, maskN = a.trace_mask, row0 = a.row0;                            \
     const uint32_t *tdesc = a.tdesc;                                                                  \
     Fl x = fl_from_fp(fp_mul(a.offset, fp_pow_u64(a.w, lane)));                                       \
-    const Fl wstep = fl_from_fp(a.wstep);
+    const Fl wstep = fl_from_fp(a.wstep);                                                             \
+    QG_DECLARE_SLOTS
 
 // lanes past the end (a grid larger than the block of points) still run the loads with a wrapped index, never the store
 #define QG_POINT_LOOP_BEGIN                                                                           \

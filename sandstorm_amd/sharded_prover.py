@@ -186,29 +186,21 @@ class ShardedProver:
             ctx.hash_rows(Tree.row_hash, blocks, B, mine, be.NATURAL)       # natural local rows; the blocks' halo is not hashed
             leaves = torch.zeros((B, 32), dtype=torch.uint8, device=comm.device)
         _dbg(comm, "row digests / leaves (rows)", mine)
-        # row i = r B + k is leaf bitrev(i) (or i): send every digest to the rank that owns its leaf
-        k = torch.arange(B, dtype=torch.int64, device=comm.device)
-
-        def leaf_of(src_rank):
-            i = src_rank * B + k
-            return _bitrev_tensor(i, log_N) if order == be.BITREV else i
-        j = leaf_of(r)
-        dest, sends, recvs, places = j // B, [], [], {}
+        # row i = r B + k is leaf bitrev(i) (or i): send every digest to the rank that owns its leaf.  Who sends which rows
+        # where is a property of (N, R, order) alone: the index tensors are built once and kept.
+        out_sel, in_pos = self._leaf_routes(N, order)
+        sends, recvs, places = [], [], {}
         for p in range(R):
-            sel = (dest == p).nonzero().flatten()
             if p == r:
-                leaves[(j[sel] % B)] = mine[sel]
+                leaves[in_pos[p]] = mine[out_sel[p]]
             else:
-                sends.append((p, mine[sel].contiguous()))
-            if p != r:
-                jp = leaf_of(p)
-                selp = ((jp // B) == r).nonzero().flatten()
-                buf = torch.zeros((len(selp),) + tuple(mine.shape[1:]), dtype=mine.dtype, device=comm.device)
+                sends.append((p, mine[out_sel[p]].contiguous()))
+                buf = torch.zeros((len(in_pos[p]),) + tuple(mine.shape[1:]), dtype=mine.dtype, device=comm.device)
                 recvs.append((p, buf))
-                places[p] = (jp[selp] % B, buf)
+                places[p] = buf
         comm.exchange(sends, recvs)
-        for p, (pos, buf) in places.items():
-            leaves[pos] = buf
+        for p, buf in places.items():
+            leaves[in_pos[p]] = buf
         _dbg(comm, "leaf block", leaves)
         # this rank's sub-tree: its root sits at depth log2 R of the whole tree
         nodes = torch.zeros((2 * B, 32), dtype=torch.uint8, device=comm.device)
@@ -231,6 +223,31 @@ class ShardedProver:
             depth -= 1
         return _Commitment(leaves, leaf_kind, nodes, tags, top, top[0][0][0], top[0][0][1])
 
+    def _leaf_routes(self, N, order):
+        """-> (out_sel, in_pos): out_sel[p] = local rows (ascending) whose leaves rank p owns; in_pos[p] = local leaf slots of
+        what rank p sends here, in the order it sends them"""
+        key = (N, order)
+        cache = self.__dict__.setdefault("_routes", {})
+        if key not in cache:
+            torch, comm = _torch(), self.comm
+            R, r = comm.world, comm.rank
+            B, log_N = N // R, _log2(N)
+            k = torch.arange(B, dtype=torch.int64, device=comm.device)
+
+            def leaf_of(src_rank):
+                i = src_rank * B + k
+                return _bitrev_tensor(i, log_N) if order == be.BITREV else i
+            j = leaf_of(r)
+            dest = j // B
+            out_sel = [(dest == p).nonzero().flatten() for p in range(R)]
+            in_pos = []
+            for p in range(R):
+                jp = leaf_of(p)
+                selp = ((jp // B) == r).nonzero().flatten()
+                in_pos.append(jp[selp] % B)
+            cache[key] = (out_sel, in_pos)
+        return cache[key]
+
     def open(self, com: _Commitment, blocks, N, positions, order):
         """-> on rank 0: (rows [nq, ncols, 4], paths [nq, log N, 32], leaf digests [nq, 32] or None); None elsewhere"""
         comm, ctx = self.comm, self.ctx
@@ -247,11 +264,14 @@ class ShardedProver:
                 part["rows"][q] = row
         if my_leaves:
             paths, _ = ctx.merkle_open(com.nodes, com.tags, B, [k for _, k in my_leaves])
-            lv = com.leaves.cpu().numpy() if com.leaf_kind == be.LEAF_DIGEST else None
-            for (q, k), path in zip(my_leaves, paths):
+            lv = None
+            if com.leaf_kind == be.LEAF_DIGEST:         # only the opened leaves cross to the host
+                idx = _torch().tensor([k for _, k in my_leaves], dtype=_torch().int64, device=com.leaves.device)
+                lv = com.leaves[idx].cpu().numpy()
+            for t, ((q, k), path) in enumerate(zip(my_leaves, paths)):
                 part["paths"][q] = path
                 if lv is not None:
-                    part["digests"][q] = lv[k].copy()
+                    part["digests"][q] = lv[t].copy()
         parts = comm.gather_object(part, 0)
         if r != 0:
             return None

@@ -76,8 +76,22 @@ DOT_MAX_TERMS = 16      # products accumulated in the 64-bit columns before a Mo
 FUSE_ALPHA_DOT_PRODUCTS = False
 
 
+# Kernel variants built side by side (ss_eval_quotient takes variant 0; SS_QG_VARIANT=k selects another for A/B runs):
+#   (name suffix, prefetch depth, slots in registers instead of LDS, workgroups per CU the register budget is set for)
+VARIANTS = [("", 6, False, 1), ("_v1", 3, False, 1), ("_v2", 4, True, 2)]
+
+
 def generate(layout):
-    code, n_consts, n_slots, n_tables, ncols = template_program(layout)
+    program = template_program(layout)
+    bodies = {}
+    for k, (suffix, depth, slots_in_regs, wgs) in enumerate(VARIANTS):
+        if depth not in bodies:
+            bodies[depth] = generate_body(layout, program, depth, "" if not bodies else "_d%d" % depth)
+        write_wrapper(layout, program, k, suffix, bodies[depth], slots_in_regs, wgs)
+
+
+def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix):
+    code, n_consts, n_slots, n_tables, ncols = program
     n_instr = len(code) // 2
     ins = [(int(code[2 * pc]) & 0xff, (int(code[2 * pc]) >> 8) & 0xf, (int(code[2 * pc]) >> 12) & 0xf, int(code[2 * pc + 1])) for pc in range(n_instr)]
     # ---- memory operands in program order: loaded PREFETCH_DEPTH operands ahead into a rotating set of registers
@@ -265,68 +279,76 @@ def generate(layout):
                 issue(q % D, True)
     assert wide["acc"] is None
     body = "\n".join(out)
-    h = code_hash(code)
-    slots = ""
     regs = "    Fp " + ", ".join("m%d" % k for k in range(D)) + ";\n"
     prime = "".join("    m%d = %s;\n" % (j, mem_ops[j][1] % "i32") for j in range(D))
-    src = '''// GENERATED by tools/gen_quotient.py - DO NOT EDIT; regenerate with `python tools/gen_quotient.py %(layout)s`.
-//
-// The composition constraint of the `%(layout)s` layout (layouts/src/%(layout)s/air.rs; lowered by
-// sandstorm_amd/host/air_%(layout)s.cpp + air_program.cpp) as straight-line code for gfx950: %(n_instr)d program
-// instructions, %(mul)d multiplications (%(mulr)d by a constant in R280 form, %(fused)d more as terms of %(flushes)d fused
-// dot products with one Montgomery reduction each), %(loads)d trace / table operand loads issued %(depth)d operands ahead
-// of their use, %(reduce)d weak reductions placed at generation time, %(n_slots)d scratch values per point in LDS (accumulators in registers).
-// Code hash (FNV-1a of the program's code words) 0x%(hash)016x: ss_eval_quotient launches this kernel for exactly
-// that program and interprets any other.
-#include "quotient_gen.h"
-
-namespace ss {
-namespace {
-
-__global__ __launch_bounds__(QG_THREADS) void quotient_%(layout)s_kernel(QGenArgs a) {
-    QG_PROLOGUE(%(n_consts)d, %(n_slots)d)
-#include "quotient_gen_%(layout)s.inc"
-}
-
-hipError_t launch_%(layout)s(hipStream_t st, const QGenArgs &a, uint32_t blocks) {
-    const size_t lds = qg_lds_bytes(%(n_consts)d, %(n_slots)d);
-    static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the per-function opt-in
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quotient_%(layout)s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(quotient_%(layout)s_kernel, dim3(blocks), dim3(QG_THREADS), lds, st, a);
-    return hipGetLastError();
-}
-
-}  // namespace
-
-const QGenKernel &quotient_gen_%(layout)s() {
-    static const QGenKernel k = {"%(layout)s", 0x%(hash)016xull, %(n_instr)du, %(n_consts)du, %(n_tables)du, %(ncols)du, launch_%(layout)s};
-    return k;
-}
-
-}  // namespace ss
-''' % dict(layout=layout, n_instr=n_instr, n_slots=n_slots, n_consts=n_consts, n_tables=n_tables, ncols=ncols, hash=h, slots=slots,
-           body=body, regs=regs, prime=prime, depth=D, **stats)
     inc = '''// GENERATED by tools/gen_quotient.py - DO NOT EDIT.  The body of the `%(layout)s` constraint kernel: the program unrolled over the
-// operand macros of quotient_gen.h.  Included by quotient_gen_%(layout)s.hip (device) and, with host definitions of the same
-// macros, by tests/cpp/quotient_gen_host_test.cpp, which runs it on the CPU against the oracle's constraint VM.
+// operand macros of quotient_gen.h (operand loads issued %(depth)d operands ahead).  Included by the quotient_gen_%(layout)s*.hip
+// wrappers (device) and, with host definitions of the same macros, by tests/cpp/quotient_gen_host_test.cpp, which runs it on
+// the CPU against the oracle's constraint VM.
     Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
 %(wide)s%(regs)s    uint32_t i32 = (uint32_t)lane;
 %(prime)s    QG_POINT_LOOP_BEGIN
 %(body)s
     QG_POINT_LOOP_END
-''' % dict(layout=layout, regs=regs, prime=prime, body=body, wide="    QgWide wd;\n" if stats["fused"] else "")
-    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s.inc" % layout), "w") as f:
+''' % dict(layout=layout, regs=regs, prime=prime, body=body, depth=D, wide="    QgWide wd;\n" if stats["fused"] else "")
+    name = "quotient_gen_%s%s.inc" % (layout, inc_suffix)
+    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", name), "w") as f:
         f.write(inc)
-    path = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s.hip" % layout)
+    print("%s: %d instructions, %d multiplications (%d by constants, %d fused into %d dot products), %d loads %d ahead, %d reductions -> %s"
+          % (layout, n_instr, stats["mul"], stats["mulr"], stats["fused"], stats["flushes"], stats["loads"], D, stats["reduce"], name))
+    return dict(stats, inc=name, depth=D)
+
+
+def write_wrapper(layout, program, variant, suffix, body, slots_in_regs, wgs):
+    code, n_consts, n_slots, n_tables, ncols = program
+    n_instr = len(code) // 2
+    h = code_hash(code)
+    src = '''// GENERATED by tools/gen_quotient.py - DO NOT EDIT; regenerate with `python tools/gen_quotient.py %(layout)s`.
+//
+// The composition constraint of the `%(layout)s` layout (layouts/src/%(layout)s/air.rs; lowered by
+// sandstorm_amd/host/air_%(layout)s.cpp + air_program.cpp) as straight-line code for gfx950, variant %(variant)d: %(n_instr)d
+// program instructions, %(mul)d multiplications (%(mulr)d by a constant in R280 form), %(loads)d trace / table operand loads issued
+// %(depth)d operands ahead of their use, %(reduce)d weak reductions placed at generation time, %(n_slots)d scratch values per point
+// in %(where)s, constants in LDS, register budget for %(wgs)d workgroup(s) per CU.
+// Code hash (FNV-1a of the program's code words) 0x%(hash)016x: ss_eval_quotient launches this kernel for exactly
+// that program and interprets any other.
+%(define)s#include "quotient_gen.h"
+
+namespace ss {
+namespace {
+
+__global__ __launch_bounds__(QG_THREADS, %(wgs)d) void quotient_%(layout)s%(suffix)s_kernel(QGenArgs a) {
+    QG_PROLOGUE(%(n_consts)d, %(lds_slots)d)
+#include "%(inc)s"
+}
+
+hipError_t launch_%(layout)s%(suffix)s(hipStream_t st, const QGenArgs &a, uint32_t blocks) {
+    const size_t lds = qg_lds_bytes(%(n_consts)d, %(lds_slots)d);
+    static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the per-function opt-in
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quotient_%(layout)s%(suffix)s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(quotient_%(layout)s%(suffix)s_kernel, dim3(blocks), dim3(QG_THREADS), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+const QGenKernel &quotient_gen_%(layout)s%(suffix)s() {
+    static const QGenKernel k = {"%(layout)s", 0x%(hash)016xull, %(n_instr)du, %(n_consts)du, %(n_tables)du, %(ncols)du, %(variant)du, %(wgs)du, launch_%(layout)s%(suffix)s};
+    return k;
+}
+
+}  // namespace ss
+''' % dict(layout=layout, suffix=suffix, variant=variant, n_instr=n_instr, n_slots=n_slots, n_consts=n_consts, n_tables=n_tables, ncols=ncols,
+           hash=h, wgs=wgs, lds_slots=0 if slots_in_regs else n_slots, where="registers" if slots_in_regs else "LDS",
+           define="#define QG_SLOTS_IN_REGISTERS\n" if slots_in_regs else "", **body)
+    path = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s%s.hip" % (layout, suffix))
     with open(path, "w") as f:
         f.write(src)
-    print("%s: %d instructions, %d multiplications (%d by constants, %d fused into %d dot products), %d loads, %d reductions, hash %016x -> %s"
-          % (layout, n_instr, stats["mul"], stats["mulr"], stats["fused"], stats["flushes"], stats["loads"], stats["reduce"], h,
-             os.path.relpath(path, ROOT)))
+    print("  variant %d -> %s" % (variant, os.path.relpath(path, ROOT)))
 
 
 if __name__ == "__main__":
