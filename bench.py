@@ -44,6 +44,10 @@ WORKLOADS = {
     # steps) with the REAL recursive AIR; C++ host from the raw files (host/trace_recursive.cpp, host/air_recursive.cpp)
     "array_sum_example": ("recursive-real", 14),
     "recursive_2p7": ("recursive", 7),      # 128 steps: the size of the only figure the reference publishes (186 ms)
+    # BASELINE.json configs[4]: the 64-bit field variant at 2^20 steps.  What exists for that field is the low-degree extension
+    # and the FRI fold (ss_lde_gl64, ss_fri_fold_gl64x3; the experimental `plain` layout's AIR is not built): a step = the LDE of
+    # 10 columns of 2^24 rows, blowup 2 - the NTT work of that configuration's trace commitment
+    "goldilocks_lde_2p20": ("goldilocks", 20),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -127,6 +131,95 @@ def cpu_baseline(layout, log_steps_full, gpu_ctx):
                       "(2^%d trace rows), CLI-default options, by the oracle (C + OpenMP port, untuned, not the reference binary) "
                       "through the same Python host as the GPU: %.2f s on %d threads; the GPU on the same sample %.4f s; "
                       "`value` = that CPU time x %.1f (n log n to 2^%d steps)" % (layout, sample, ls, t_cpu, threads, t_gpu, scale, log_steps_full)}
+
+
+def bench_goldilocks(args, log_steps, rank, local_rank, world, device):
+    """--workload goldilocks_lde_2p20: the low-degree extension of 10 columns x 2^24 rows over p = 2^64 - 2^32 + 1 (blowup 2):
+    per column an inverse transform of size n and a coset transform of size 2n.  8-byte elements: this is the field where
+    the HBM roofline is the binding one.  One independent batch per rank (weak scaling)."""
+    import numpy as np
+    from sandstorm_amd import backend as be
+    log_n, lb, ncols = log_steps + 4, 1, 10
+    n = 1 << log_n
+    ctx = be.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device=device)
+    g.manual_seed(0x474C + rank)
+    cols = torch.randint(0, 2**62, (ncols, n), dtype=torch.int64, device=device, generator=g)       # < 2^62 < p
+    evals = torch.zeros((ncols, n << lb), dtype=torch.int64, device=device)
+    coeffs = torch.zeros((ncols, n), dtype=torch.int64, device=device)
+
+    def step():
+        ctx.lde_gl64([cols[c] for c in range(ncols)], log_n, lb, 7, [evals[c] for c in range(ncols)], [coeffs[c] for c in range(ncols)])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(1, args.warmup)):
+        step()
+    barrier()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ntt_ms, launches = ctx.profile_read(be.PROF_NTT_PASS)
+    ctx.profile(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    sec = dt / args.steps
+    if rank == 0:
+        ops = ncols * (ntt_field_ops(log_n) + ntt_field_ops(log_n + lb))
+        algo = 8.0 * ncols * (2 * n + 2 * (n << lb))                 # SURVEY 8d: 2 N e per transform, e = 8 bytes
+        kern_s = ntt_ms * 1e-3 / args.steps
+        passes = launches / args.steps
+        achieved = algo / kern_s / 1e9
+        out = {"metric": "lde_wall_time_s", "value": sec, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": sec * 1e3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u64 (p = 2^64 - 2^32 + 1)", "data": "synthetic", "ntt_gfield_ops_per_s": world * ops / kern_s / 1e9,
+               "config": {"workload": args.workload, "field": "p = 2^64 - 2^32 + 1 (Goldilocks), 8-byte elements", "columns": ncols,
+                          "trace_rows_log2": log_n, "blowup": 2, "per_gpu": "one independent batch per rank",
+                          "note": "the LDE of BASELINE.json configs[4]'s trace; the rest of that configuration (the `plain` layout's "
+                                  "AIR over Fq3) is not built"},
+               "roofline": {"bound": "hbm", "kernel": "ss::gl_ntt_pass_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "launches": launches, "avg_launch_ms": ntt_ms / max(1, launches),
+                            "algorithmic_bytes_per_launch": algo / max(1.0, passes),
+                            "streamed_bytes_per_s": 8.0 * ncols * sum(2 * (1 << ln) * len(_gl_passes(ln)) for ln in (log_n, log_n + lb)) / kern_s,
+                            "note": "algorithmic bytes = 2 N 8 B per transform (SURVEY 8d); a transform of 2^24 (2^25) points is "
+                                    "%d (%d) passes of 16 B per element, so the kernel's own stream rate is `streamed_bytes_per_s`"
+                                    % (len(_gl_passes(log_n)), len(_gl_passes(log_n + lb)))}}
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle_py as oracle
+            sl = 20
+            col = np.random.default_rng(1).integers(0, 2**62, size=1 << sl, dtype=np.uint64)
+            t0 = time.perf_counter()
+            for _ in range(4):
+                oracle.gl_lde(col, lb, 7)
+            t_cpu = (time.perf_counter() - t0) / 4
+            scale = ncols * float(1 << (log_n - sl)) * (log_n + 0.5) / (sl + 0.5)
+            out["cpu_baseline"] = {"value": t_cpu * scale, "unit": "s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), "kind": "port",
+                                   "sample": "oracle (C + OpenMP) LDE of one 2^%d-row column: %.3f s, scaled n log n to %d columns of 2^%d rows"
+                                             % (sl, t_cpu, ncols, log_n)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _gl_passes(log_n, log_tile=13):
+    """the pass split of csrc/capi.hip gl_plan_passes: 13 stages in the contiguous pass, then <= 8 per strided pass"""
+    r0 = min(log_n, log_tile)
+    rem, out = log_n - r0, [r0]
+    if rem:
+        k = -(-rem // (log_tile - 5))
+        for i in range(k):
+            r = -(-rem // (k - i))
+            out.append(r)
+            rem -= r
+    return out
 
 
 def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
@@ -235,6 +328,8 @@ def main():
     from sandstorm_amd.prover import ProofOptions
 
     layout, log_steps = WORKLOADS[args.workload]
+    if layout == "goldilocks":
+        return bench_goldilocks(args, log_steps, rank, local_rank, world, device)
     if (world > 1 and args.mode == "auto" or args.mode == "shard") and layout in ("starknet", "recursive"):
         if world == 1:                      # --mode shard on one GPU: the sharded driver with a group of one (smoke / profiling)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -22,3 +22,11 @@ def test_lazy_curve_formulas_match_plain_ones(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "ec_lazy_test.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+
+
+def test_fused_dot_product_on_the_host(tmp_path):
+    """fl252.h FlWide (the DEEP kernel's and the generated constraint kernels' accumulation with one Montgomery reduction
+    per <= 16 products) equals the sum of single products, at the limb bounds it is specified for (tests/cpp/fl_wide_test.cpp)"""
+    exe = str(tmp_path / "fl_wide_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "fl_wide_test.cpp")])
+    assert "FL_WIDE_OK" in subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout

@@ -78,13 +78,18 @@ FUSE_ALPHA_DOT_PRODUCTS = False
 
 # Kernel variants built side by side (ss_eval_quotient takes variant 0; SS_QG_VARIANT=k selects another for A/B runs):
 #   (name suffix, prefetch depth, slots in registers instead of LDS, workgroups per CU the register budget is set for)
-VARIANTS = [("", 6, False, 1), ("_v1", 3, False, 1), ("_v2", 4, True, 2)]
+# Measured (profiles/r02_quotient_codegen_experiments.txt): the starknet program is register-bound - LDS slots, one
+# workgroup per CU, a shallow prefetch; the recursive one fits two workgroups per CU with its slots in registers.
+VARIANTS = {
+    "starknet": [("", 3, False, 1), ("_v1", 2, False, 1), ("_v2", 1, False, 1), ("_v3", 4, False, 1)],
+    "recursive": [("", 4, True, 2), ("_v1", 6, True, 2), ("_v2", 2, True, 2), ("_v3", 3, False, 1)],
+}
 
 
 def generate(layout):
     program = template_program(layout)
     bodies = {}
-    for k, (suffix, depth, slots_in_regs, wgs) in enumerate(VARIANTS):
+    for k, (suffix, depth, slots_in_regs, wgs) in enumerate(VARIANTS[layout]):
         if depth not in bodies:
             bodies[depth] = generate_body(layout, program, depth, "" if not bodies else "_d%d" % depth)
         write_wrapper(layout, program, k, suffix, bodies[depth], slots_in_regs, wgs)
