@@ -37,13 +37,7 @@ struct QGenKernel {
 };
 
 const QGenKernel &quotient_gen_starknet();       // quotient_gen_starknet.hip
-const QGenKernel &quotient_gen_starknet_v1();
-const QGenKernel &quotient_gen_starknet_v2();
-const QGenKernel &quotient_gen_starknet_v3();
 const QGenKernel &quotient_gen_recursive();      // quotient_gen_recursive.hip
-const QGenKernel &quotient_gen_recursive_v1();
-const QGenKernel &quotient_gen_recursive_v2();
-const QGenKernel &quotient_gen_recursive_v3();
 
 typedef uint32_t qg_u32x4 __attribute__((ext_vector_type(4)));
 

@@ -78,18 +78,22 @@ FUSE_ALPHA_DOT_PRODUCTS = False
 
 # Kernel variants built side by side (ss_eval_quotient takes variant 0; SS_QG_VARIANT=k selects another for A/B runs):
 #   (name suffix, prefetch depth, slots in registers instead of LDS, workgroups per CU the register budget is set for)
-# Measured (profiles/r02_quotient_codegen_experiments.txt): the starknet program is register-bound - LDS slots, one
-# workgroup per CU, a shallow prefetch; the recursive one fits two workgroups per CU with its slots in registers.
+# Measured on the MI355X (profiles/r02_quotient_codegen_experiments.txt; 2^25 points): the starknet program is register
+# bound - LDS slots, one workgroup per CU, a shallow prefetch (depth 3: 153.7 ms, 2: 154.3, 1: 159.6, 4: 153.7, 6: 171.5;
+# slots in registers at two workgroups per CU: 352, scratch spills); the recursive one fits two workgroups per CU with its
+# slots in registers (depth 4: 65.5 ms, 6: 66.0, 2: 65.1; LDS slots at one workgroup per CU: 76.9).
 VARIANTS = {
     "starknet": [("", 3, False, 1), ("_v1", 2, False, 1), ("_v2", 1, False, 1), ("_v3", 4, False, 1)],
     "recursive": [("", 4, True, 2), ("_v1", 6, True, 2), ("_v2", 2, True, 2), ("_v3", 3, False, 1)],
 }
 
 
-def generate(layout):
+def generate(layout, all_variants=False):
+    """variant 0 is what the library builds; --all-variants also writes the others (add them to csrc/Makefile, quotient_gen.h and
+    the table in capi.hip's quotient_gen_find for an A/B run with SS_QG_VARIANT=k)"""
     program = template_program(layout)
     bodies = {}
-    for k, (suffix, depth, slots_in_regs, wgs) in enumerate(VARIANTS[layout]):
+    for k, (suffix, depth, slots_in_regs, wgs) in enumerate(VARIANTS[layout] if all_variants else VARIANTS[layout][:1]):
         if depth not in bodies:
             bodies[depth] = generate_body(layout, program, depth, "" if not bodies else "_d%d" % depth)
         write_wrapper(layout, program, k, suffix, bodies[depth], slots_in_regs, wgs)
@@ -357,5 +361,6 @@ const QGenKernel &quotient_gen_%(layout)s%(suffix)s() {
 
 
 if __name__ == "__main__":
-    for name in (sys.argv[1:] or ["starknet", "recursive"]):
-        generate(name)
+    names = [a for a in sys.argv[1:] if not a.startswith("--")]
+    for name in (names or ["starknet", "recursive"]):
+        generate(name, "--all-variants" in sys.argv)
