@@ -9,7 +9,8 @@
 //
 // An element is 8 bytes, so unlike the 252-bit kernels this one is bound by HBM, not by the multiplier: a pass streams
 // the vector once (16 B per element) and runs up to 13 stages on an 8192-element tile in LDS (64 KiB; two workgroups per
-// CU), so a 2^25-point transform is 13 + 12 stages = TWO passes.  Multiplication: 64 x 64 -> 128 by four 32-bit
+// CU) in register groups of four stages; a 2^25-point transform is 13 + 8 + 4 stages = three passes (strided passes keep
+// >= 32 adjacent elements per row: 256-byte global runs).  Multiplication: 64 x 64 -> 128 by four 32-bit
 // multiply-adds, then 2^64 = 2^32 - 1 and 2^96 = -1 (mod p) fold the high half back: no division, no Montgomery form.
 // Every operation here is linear in the data (data times coefficients this file owns), so element images in Montgomery
 // form (arkworks' Fp64 in memory) pass through unchanged.
@@ -68,12 +69,76 @@ __device__ __forceinline__ uint64_t gl_tile_gindex(const GlPassParams &p, uint32
     return ((q >> p.s0) << (p.s0 + p.r)) | ((uint64_t)j << p.s0) | (q & ((1ull << p.s0) - 1ull));
 }
 
-// One pass: stages [s0, s0 + r) of the network on a tile held in LDS.  Twiddle plan as in the 252-bit path:
-// T_s[k] at (2^s - 1) + k, k < 2^s, T_s[k] = h^(n / 2^(s+1)) * r^(k n / 2^(s+1)).
+// LDS slot of tile element e: XOR swizzle (no padding).  A register group at shift sh makes 32 consecutive lanes walk
+// either 32 consecutive elements (sh >= 5) or elements 16 apart (sh = 0, 4); e ^ ((e >> 4) & 31) maps both onto 32 distinct
+// 8-byte slots modulo 32, i.e. all 64 banks once per ds_*_b64.
+__device__ __forceinline__ uint32_t gl_slot(uint32_t e) { return e ^ ((e >> 4) & 31u); }
+
+// One radix-2^G register group on local stages [u, u + G): each thread holds 2^G elements (element m at ebase + (m << sh))
+// and runs G butterfly stages on them before the tile is touched again - ceil(13 / 4) = 4 LDS round trips per pass instead
+// of 13.  The first / last group of a pass exchange with HBM directly (from_global / to_global).
+// Twiddle plan as in the 252-bit path: T_s[k] at (2^s - 1) + k, k < 2^s, T_s[k] = h^(n / 2^(s+1)) * r^(k n / 2^(s+1)).
+template <bool DIF, int G>
+__device__ __forceinline__ void gl_group(uint64_t *tile_lds, const uint64_t *__restrict__ tw, const GlPassParams &p, uint32_t u, uint32_t tile,
+                                         bool from_global, bool to_global, const uint64_t *__restrict__ src, uint64_t *__restrict__ dst) {
+    const uint32_t log_t = p.log_tile - p.r, eshift = p.contig ? 0u : log_t;
+    const uint32_t items = (1u << p.log_tile) >> G, sh = eshift + u;
+    for (uint32_t tau = threadIdx.x; tau < items; tau += blockDim.x) {
+        const uint32_t low = tau & ((1u << sh) - 1u), high = tau >> sh;
+        const uint32_t ebase = (high << (sh + G)) | low;
+        uint32_t jbase, lbits;
+        if (p.contig) { jbase = ebase & ((1u << p.r) - 1u); lbits = 0; }
+        else {
+            jbase = ebase >> log_t;
+            const uint32_t q = (tile << log_t) + (ebase & ((1u << log_t) - 1u));
+            lbits = q & ((1u << p.s0) - 1u);
+        }
+        const uint32_t jlow = jbase & ((1u << u) - 1u);
+        uint64_t x[1 << G];
+#pragma unroll
+        for (int m = 0; m < (1 << G); ++m) {
+            const uint32_t e = ebase + ((uint32_t)m << sh);
+            x[m] = from_global ? src[gl_tile_gindex(p, tile, e) >> p.log_expand] : tile_lds[gl_slot(e)];
+        }
+#pragma unroll
+        for (int step = 0; step < G; ++step) {
+            const int ST = DIF ? (G - 1 - step) : step;
+            const uint32_t s = p.s0 + u + ST;
+            const uint64_t *tws = tw + ((1ull << s) - 1ull);
+#pragma unroll
+            for (int pr = 0; pr < (1 << G) / 2; ++pr) {
+                const int m = ((pr >> ST) << (ST + 1)) | (pr & ((1 << ST) - 1));
+                const uint32_t k = ((jlow + ((uint32_t)(m & ((1 << ST) - 1)) << u)) << p.s0) | lbits;
+                const uint64_t w = tws[k];
+                const uint64_t a = x[m], b = x[m | (1 << ST)];
+                if (DIF) {
+                    x[m] = gl_add(a, b);
+                    x[m | (1 << ST)] = gl_mul(gl_sub(a, b), w);
+                } else {
+                    const uint64_t bt = gl_mul(b, w);
+                    x[m] = gl_add(a, bt);
+                    x[m | (1 << ST)] = gl_sub(a, bt);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < (1 << G); ++m) {
+            const uint32_t e = ebase + ((uint32_t)m << sh);
+            if (to_global) {
+                uint64_t v = x[m];
+                if (DIF && p.scale != 1ull) v = gl_mul(v, p.scale);
+                dst[gl_tile_gindex(p, tile, e)] = v;
+            } else {
+                tile_lds[gl_slot(e)] = x[m];
+            }
+        }
+    }
+}
+
 template <bool DIF>
 __global__ __launch_bounds__(256) void gl_ntt_pass_kernel(GlCols cols, const uint64_t *__restrict__ tw, GlPassParams p) {
     extern __shared__ uint64_t gl_tile[];
-    const uint32_t tile_elems = 1u << p.log_tile, tile = blockIdx.x;
+    const uint32_t tile = blockIdx.x;
     const void *src_v = cols.src[0];
     void *dst_v = cols.dst[0];
 #pragma unroll
@@ -81,45 +146,24 @@ __global__ __launch_bounds__(256) void gl_ntt_pass_kernel(GlCols cols, const uin
         if (blockIdx.y == (unsigned)c) { src_v = cols.src[c]; dst_v = cols.dst[c]; }
     const uint64_t *__restrict__ src = reinterpret_cast<const uint64_t *>(src_v);
     uint64_t *__restrict__ dst = reinterpret_cast<uint64_t *>(dst_v);
-    for (uint32_t e = threadIdx.x; e < tile_elems; e += blockDim.x)
-        gl_tile[e] = src[gl_tile_gindex(p, tile, e) >> p.log_expand];
-    __syncthreads();
-    const uint32_t log_t = p.log_tile - p.r, eshift = p.contig ? 0u : log_t;
-    const uint32_t nstages = p.r - (DIF ? 0u : p.u_first);
-    for (uint32_t step = 0; step < nstages; ++step) {
-        const uint32_t u = DIF ? (p.r - 1u - step) : (p.u_first + step);      // local stage
-        const uint32_t s = p.s0 + u, sh = eshift + u;
-        const uint64_t *tws = tw + ((1ull << s) - 1ull);
-        for (uint32_t t = threadIdx.x; t < tile_elems / 2; t += blockDim.x) {
-            const uint32_t low = t & ((1u << sh) - 1u), high = t >> sh;
-            const uint32_t e0 = (high << (sh + 1)) | low, e1 = e0 | (1u << sh);
-            // twiddle index: the butterfly's position inside its 2^(s+1) block of the global vector
-            uint32_t jbase, lbits;
-            if (p.contig) { jbase = e0 & ((1u << p.r) - 1u); lbits = 0; }
-            else {
-                jbase = e0 >> log_t;
-                const uint32_t q = (tile << log_t) + (e0 & ((1u << log_t) - 1u));
-                lbits = q & ((1u << p.s0) - 1u);
-            }
-            const uint32_t k = ((jbase & ((1u << u) - 1u)) << p.s0) | lbits;
-            const uint64_t w = tws[k];
-            const uint64_t a = gl_tile[e0], b = gl_tile[e1];
-            if (DIF) {
-                gl_tile[e0] = gl_add(a, b);
-                gl_tile[e1] = gl_mul(gl_sub(a, b), w);
-            } else {
-                const uint64_t bt = gl_mul(b, w);
-                gl_tile[e0] = gl_add(a, bt);
-                gl_tile[e1] = gl_sub(a, bt);
-            }
+    // local stages [first, p.r) in groups of <= 4, ascending (DIT) or descending (DIF); the first group reads HBM, the last writes it
+    const uint32_t first = DIF ? 0u : p.u_first, total = p.r - first;
+    uint32_t done = 0;
+    while (done < total) {
+        const uint32_t g = (total - done) >= 4 ? 4u : (total - done);
+        const uint32_t u = DIF ? (p.r - done - g) : (first + done);
+        const bool fg = done == 0, tg = done + g == total;
+        switch (g) {
+        case 4: gl_group<DIF, 4>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
+        case 3: gl_group<DIF, 3>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
+        case 2: gl_group<DIF, 2>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
+        default: gl_group<DIF, 1>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
         }
-        __syncthreads();
+        done += g;
+        if (!tg) __syncthreads();
     }
-    for (uint32_t e = threadIdx.x; e < tile_elems; e += blockDim.x) {
-        uint64_t v = gl_tile[e];
-        if (DIF && p.scale != 1ull) v = gl_mul(v, p.scale);
-        dst[gl_tile_gindex(p, tile, e)] = v;
-    }
+    if (total == 0)              // nothing to do in this pass (cannot happen for log_n >= 1): copy through
+        for (uint32_t e = threadIdx.x; e < (1u << p.log_tile); e += blockDim.x) dst[gl_tile_gindex(p, tile, e)] = src[gl_tile_gindex(p, tile, e) >> p.log_expand];
 }
 
 // plan: T_s[k] = hpow[s] * r^(k n / 2^(s+1)) with r^e = pow_lo[e & 4095] * pow_hi[e >> 12]

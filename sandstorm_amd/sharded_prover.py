@@ -60,6 +60,10 @@ class Comm:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device                        # torch device of the exchanged tensors
         self.stage_through_host = dist.get_backend() == "gloo" and device is not None and _torch().device(device).type == "cuda"
+        if self.world > 1 and dist.get_backend() == "nccl":
+            # one collective before the first point-to-point batch: RCCL builds its communicators collectively, and a P2P
+            # batch that only some ranks enter must not be the call that triggers it
+            dist.all_reduce(_torch().zeros(1, device=device))
 
     def exchange(self, sends, recvs):
         """sends / recvs: [(peer, tensor)] in a fixed, globally agreed order per pair of ranks.  Point-to-point, all
