@@ -159,6 +159,8 @@ struct PassParams {
     uint32_t contig;      // 1: s0 == 0, tile is a contiguous block
     uint32_t final_pass;  // 1: last pass of the transform, outputs are canonical (< p);
                           // 0: outputs are weakly reduced 256-bit images (< 2^252) for the next pass
+    uint32_t ncols;       // columns of the batch (grid = tiles * ncols workgroups)
+    uint32_t xcd_map;     // 1: the ncols workgroups of one tile are consecutive on ONE XCD (see the kernel)
 };
 
 // One butterfly stage (local stage u + ST) on the 2^G register-resident elements, in the
@@ -311,14 +313,27 @@ __global__ __launch_bounds__(DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, DIF ? SS
     t.lo = (lds_u32x4_ptr)smem;
     t.hi = t.lo + slots;
     t.top = (lds_u32_ptr)(t.hi + slots);
-    const uint32_t tile = blockIdx.x;
+    // Workgroup -> (tile, column).  A strided pass reads one 36-byte twiddle per butterfly and stage, indexed by the
+    // tile's low bits: the same table slice for every column of that tile.  Workgroup b runs on XCD b % 8 (observed;
+    // speed only), so the columns of a tile are made 8 ids apart and adjacent in time: they share the slice in that
+    // XCD's L2 instead of fetching it once per column through the fabric.
+    uint32_t tile, col;
+    if (p.xcd_map) {
+        const uint32_t per = 8u * p.ncols, grp = blockIdx.x / per, rem = blockIdx.x - grp * per;
+        col = rem >> 3;
+        tile = (grp << 3) | (rem & 7u);
+    } else {
+        const uint32_t tiles = 1u << (p.log_n - p.log_tile);
+        col = blockIdx.x >> (p.log_n - p.log_tile);
+        tile = blockIdx.x & (tiles - 1u);
+    }
     // select this block's column with scalar compares: a dynamically indexed by-value
     // kernarg struct would be copied to scratch
     const void *src_v = cols.src[0];
     void *dst_v = cols.dst[0];
 #pragma unroll
     for (int c = 1; c < MAX_COLS; ++c)
-        if (blockIdx.y == (unsigned)c) { src_v = cols.src[c]; dst_v = cols.dst[c]; }
+        if (col == (unsigned)c) { src_v = cols.src[c]; dst_v = cols.dst[c]; }
     const Fp *__restrict__ src = reinterpret_cast<const Fp *>(src_v);
     Fp *__restrict__ dst = reinterpret_cast<Fp *>(dst_v);
 
@@ -442,7 +457,10 @@ hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32
     p.log_n = log_n; p.s0 = s0; p.r = r; p.log_tile = log_tile; p.u_first = u_first;
     p.log_expand = log_expand; p.scale_pow2 = scale_pow2; p.contig = (s0 == 0);
     const uint32_t tiles = 1u << (log_n - log_tile);
-    dim3 grid(tiles, ncols), block(dif ? SS_NTT_THREADS_DIF : SS_NTT_THREADS);
+    static const bool no_xcd_map = getenv("SS_NTT_NO_XCD_MAP") != nullptr;        // A/B switch for profiling
+    p.ncols = ncols;
+    p.xcd_map = (tiles >= 8 && ncols > 1 && !no_xcd_map) ? 1u : 0u;
+    dim3 grid(tiles * ncols), block(dif ? SS_NTT_THREADS_DIF : SS_NTT_THREADS);
     const size_t lds = pass_lds_bytes(log_tile);
     if (dif) hipLaunchKernelGGL(ntt_pass_kernel<true>, grid, block, lds, st, cols, tw, p);
     else hipLaunchKernelGGL(ntt_pass_kernel<false>, grid, block, lds, st, cols, tw, p);

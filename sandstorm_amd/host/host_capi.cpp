@@ -203,8 +203,9 @@ int ssh_starknet_base_trace(const uint8_t *trace_bin, uint64_t trace_len, const 
         std::vector<U256> memory;
         std::vector<uint8_t> present;
         read_memory(memory_bin, memory_len, memory, present);
-        const auto cols = starknet_base_trace(states, memory, present, pi, priv);
-        for (size_t c = 0; c < cols.size(); ++c) memcpy(columns_out[c], cols[c].data(), cols[c].size() * 32);
+        Felt *out[9];
+        for (int c = 0; c < 9; ++c) out[c] = reinterpret_cast<Felt *>(columns_out[c]);
+        starknet_base_trace_into(out, states, memory, present, pi, priv);
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }

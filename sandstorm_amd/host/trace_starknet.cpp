@@ -2,9 +2,16 @@
 #include "trace_starknet.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
+#include <exception>
 #include <memory>
+#include <parallel/algorithm>
 #include <tuple>
+
+#include <omp.h>
 
 #include "../../include/sandstorm_hip.h"
 #include "trace_common.hpp"
@@ -35,6 +42,19 @@ enum { EC_PUBKEY_DOUBLING_X = 1, EC_PUBKEY_DOUBLING_Y = 33, EC_PUBKEY_DOUBLING_S
 enum { OP_Q_DOUBLING_X = 41, OP_Q_DOUBLING_Y = 25, OP_Q_DOUBLING_SLOPE = 57, OP_R_PARTIAL_SUM_X = 5, OP_R_PARTIAL_SUM_Y = 37, OP_R_PARTIAL_SUM_SLOPE = 11,
        OP_R_PARTIAL_SUM_X_DIFF_INV = 43, OP_M_SUFFIX = 21, OP_M_BIT251_AND_BIT196_AND_BIT192 = 16371, OP_M_BIT251_AND_BIT196 = 16339 };
 const uint64_t BITWISE_SHIFTED_CELLS[4] = {9, 521, 265, 777};
+
+// body(k) for k in [0, count) on all host threads; the first exception a body throws is rethrown on the caller's thread
+template <class Body> void parallel_for(uint64_t count, const Body &body) {
+    std::exception_ptr err;
+#pragma omp parallel for schedule(static)
+    for (uint64_t k = 0; k < count; ++k) {
+        try { body(k); } catch (...) {
+#pragma omp critical(ssh_trace_error)
+            if (!err) err = std::current_exception();
+        }
+    }
+    if (err) std::rethrow_exception(err);
+}
 
 // the curve's group order (builtins/src/utils.rs:134)
 const U256 CURVE_ORDER{0x1e66a241adc64d2full, 0xb781126dcae7b232ull, 0xffffffffffffffffull, 0x0800000000000010ull};
@@ -245,8 +265,8 @@ PoseidonTrace poseidon_trace(const std::array<Felt, 3> &input) {       // poseid
 
 }  // namespace
 
-std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
-                                                   const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv) {
+void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+                              const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv) {
     const uint64_t num_cycles = states.size();
     if (!num_cycles || (num_cycles & (num_cycles - 1))) fail("the number of cycles must be a power of two");
     if (num_cycles < ECDSA_BUILTIN_RATIO) fail("the starknet layout needs at least 2048 cycles");
@@ -254,21 +274,39 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
     const uint64_t n = num_cycles * CYCLE_HEIGHT;
     const Mem mem{memory, present};
     const Felt zero = felt_from_u64(0);
-    std::vector<std::vector<Felt>> cols(NUM_COLS);
-    for (auto &c : cols) c.resize(n);
-    auto &flags = cols[COL_FLAGS], &npc = cols[COL_NPC], &mem_col = cols[COL_MEMORY], &rc_col = cols[COL_RANGE_CHECK], &aux = cols[COL_AUXILIARY];
+    const bool timing = getenv("SSH_TRACE_TIMING") != nullptr;               // stage times on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[starknet trace] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
+    struct Col { Felt *p; Felt &operator[](uint64_t i) const { return p[i]; } };
+    Col cols[NUM_COLS];
+    for (int c = 0; c < NUM_COLS; ++c) cols[c] = Col{out[c]};
+    constexpr uint64_t CHUNK = 1 << 16;
+    parallel_for(NUM_COLS * ((n + CHUNK - 1) / CHUNK), [&](uint64_t k) {       // every cell no section writes is zero
+        const uint64_t c = k % NUM_COLS, at = (k / NUM_COLS) * CHUNK;
+        std::fill(out[c] + at, out[c] + std::min(n, at + CHUNK), zero);
+    });
+    const Col flags = cols[COL_FLAGS], npc = cols[COL_NPC], mem_col = cols[COL_MEMORY], rc_col = cols[COL_RANGE_CHECK], aux = cols[COL_AUXILIARY];
     std::vector<uint64_t> npc_addr(n / 2, 1);
 
     const MemoryEntry *padding = nullptr;
     for (auto &e : pi.public_memory) if (e.address == 1) { padding = &e; break; }
     if (!padding) fail("public memory has no entry at address 1");
     const Felt pad_value = felt_from_canonical(padding->value), pad_addr = felt_from_u64(1);
-    for (uint64_t k = 0; k < n / 2; ++k) { npc[2 * k] = pad_addr; npc[2 * k + 1] = pad_value; }
+    parallel_for(n / 2, [&](uint64_t k) { npc[2 * k] = pad_addr; npc[2 * k + 1] = pad_value; });
     auto set_pair = [&](uint64_t row, uint64_t address, const Felt &value) { npc[row] = felt_from_u64(address); npc[row + 1] = value; npc_addr[row / 2] = address; };
 
+    lap("allocation + npc padding");
     // ---- CPU cells (trace.rs:177-244) and the range-check pool (trace.rs:142-165)
     std::vector<uint32_t> rc_count(1 << 16, 0);
-    for (uint64_t cycle = 0; cycle < num_cycles; ++cycle) {
+    std::vector<std::vector<uint32_t>> rc_count_of((size_t)omp_get_max_threads());
+    parallel_for(num_cycles, [&](uint64_t cycle) {
+        std::vector<uint32_t> &my_count = rc_count_of[(size_t)omp_get_thread_num()];
+        if (my_count.empty()) my_count.assign(1 << 16, 0);
         const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
         const U256 &iw = mem.at(pc);
         const Word w{iw[0]};
@@ -296,8 +334,9 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
         aux[r + AUX_TMP0] = tmp0; aux[r + AUX_TMP1] = felt_mul(tmp0, res);
         aux[r + AUX_AP] = felt_from_u64(ap); aux[r + AUX_FP] = felt_from_u64(fp);
         aux[r + AUX_OP0_MUL_OP1] = felt_mul(op0, op1); aux[r + AUX_RES] = res;
-        for (uint64_t v : {w.off_dst(), w.off_op0(), w.off_op1()}) ++rc_count[v];
-    }
+        for (uint64_t v : {w.off_dst(), w.off_op0(), w.off_op1()}) ++my_count[v];
+    });
+    for (auto &part : rc_count_of) for (size_t v = 0; v < part.size(); ++v) rc_count[v] += part[v];
     struct Rc128 { uint32_t index; U256 value; };
     std::vector<Rc128> rc128;
     auto part_of = [](const U256 &v, unsigned k) { return (uint32_t)(shr(v, 16 * (RANGE_CHECK_BUILTIN_PARTS - 1 - k))[0] & 0xffff); };
@@ -315,12 +354,12 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
     }
     // the column starts as the padding value; the CPU's offsets go in afterwards (trace.rs:165-235)
     const Felt rc_max_f = felt_from_u64(rc_hi);
-    for (uint64_t k = 0; k < n; ++k) rc_col[k] = rc_max_f;
-    for (uint64_t cycle = 0; cycle < num_cycles; ++cycle) {
+    parallel_for(num_cycles, [&](uint64_t cycle) {
         const Word w{mem.at(states[cycle].pc)[0]};
         const uint64_t r = cycle * CYCLE_HEIGHT;
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) rc_col[r + o] = rc_max_f;
         rc_col[r + RC_OFF_DST] = felt_from_u64(w.off_dst()); rc_col[r + RC_OFF_OP1] = felt_from_u64(w.off_op1()); rc_col[r + RC_OFF_OP0] = felt_from_u64(w.off_op0());
-    }
+    });
     size_t pad_i = 0, ord_i = 0;
     auto next_padding = [&]() { return pad_i < padding_vals.size() ? padding_vals[pad_i++] : rc_hi; };
     for (uint64_t index = rc128.size(); index < num_cycles / RANGE_CHECK_BUILTIN_RATIO; ++index) {       // trace.rs:246-261
@@ -340,6 +379,7 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
     if (pad_i != padding_vals.size() || ord_i != ordered_vals.size()) fail("range-check values do not fit the trace");
     for (uint64_t k = 0; k < n / DILUTED_CHECK_STEP; ++k) rc_col[8 * k + DC_UNORDERED] = rc_col[8 * k + DC_ORDERED] = zero;      // trace.rs:294-302
 
+    lap("cpu cells + range-check pool");
     // ---- Pedersen (trace.rs:304-386)
     {
         std::map<uint32_t, const PedersenInstance *> given;
@@ -348,7 +388,7 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
         std::map<std::pair<U256, U256>, Cached> cache;
         const uint64_t step = PEDERSEN_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[3].begin_addr;
         const Pt p0 = pedersen_point(0);
-        auto &xs = cols[COL_PEDERSEN_X], &ys = cols[COL_PEDERSEN_Y], &suffixes = cols[COL_PEDERSEN_SUFFIX], &slopes = cols[COL_PEDERSEN_SLOPE];
+        const Col xs = cols[COL_PEDERSEN_X], ys = cols[COL_PEDERSEN_Y], suffixes = cols[COL_PEDERSEN_SUFFIX], slopes = cols[COL_PEDERSEN_SLOPE];
         for (uint64_t i = 0; i < n / step; ++i) {
             U256 a{}, b{};
             auto it = given.find((uint32_t)i);
@@ -382,6 +422,7 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
             set_pair(base + NPC_PEDERSEN_OUTPUT_ADDR, addr + 2, c.out);
         }
     }
+    lap("pedersen");
     // ---- range-check builtin (trace.rs:388-426)
     {
         const uint64_t step = RANGE_CHECK_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[4].begin_addr;
@@ -391,6 +432,7 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
             set_pair(base + NPC_RANGE_CHECK128_ADDR, begin + rc128[blk].index, felt_from_canonical(rc128[blk].value));
         }
     }
+    lap("range-check builtin");
     // ---- ECDSA (trace.rs:428-523)
     {
         std::map<uint32_t, const EcdsaInstance *> given;
@@ -435,6 +477,7 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
             set_pair(base + NPC_ECDSA_MESSAGE_ADDR, begin + 2 * i + 1, t.message);
         }
     }
+    lap("ecdsa");
     // ---- bitwise and the diluted check (trace.rs:525-705)
     {
         std::map<uint32_t, const BitwiseInstance *> given;
@@ -483,6 +526,7 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
         for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)
             for (uint32_t c = 0; c < std::max(dil_count[v], 1u); ++c, ++k) rc_col[8 * k + DC_ORDERED] = felt_from_u64(dilute(v));
     }
+    lap("bitwise + diluted");
     // ---- EC op (trace.rs:707-777)
     {
         std::map<uint32_t, const EcOpInstance *> given;
@@ -524,6 +568,7 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
             for (int k = 0; k < 7; ++k) set_pair(base + NPC_EC_OP_ADDRS[k], addr + k, values[k]);
         }
     }
+    lap("ec op");
     // ---- Poseidon (trace.rs:779-888)
     {
         std::map<uint32_t, const PoseidonInstance *> given;
@@ -551,6 +596,7 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
             for (int k = 0; k < 3; ++k) { set_pair(base + NPC_POSEIDON_ADDRS[k], addr + k, input[k]); set_pair(base + NPC_POSEIDON_ADDRS[3 + k], addr + 3 + k, t.out[k]); }
         }
     }
+    lap("poseidon");
     // ---- gap fillers (trace.rs:890-925)
     {
         std::vector<uint64_t> accessed(npc_addr);
@@ -565,24 +611,38 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
                 ++cycle;
             }
     }
+    lap("gap fillers");
     // ---- sorted memory (get_ordered_memory_accesses, utils.rs:112-152)
     {
         struct Access { uint64_t address; Felt value; };
         std::vector<Access> acc;
-        acc.reserve(n / 2 + n / PUBLIC_MEMORY_STEP);
-        for (uint64_t k = 0; k < n / 2; ++k) acc.push_back(Access{npc_addr[k], npc[2 * k + 1]});
         const uint64_t cells = n / PUBLIC_MEMORY_STEP;
         if (pi.public_memory.size() > cells) fail("public memory does not fit");
-        for (uint64_t k = pi.public_memory.size(); k < cells; ++k) acc.push_back(Access{1, pad_value});
-        for (auto &e : pi.public_memory) acc.push_back(Access{e.address, felt_from_canonical(e.value)});
-        std::stable_sort(acc.begin(), acc.end(), [](const Access &a, const Access &b) { return a.address < b.address; });
+        acc.resize(n / 2 + cells);
+        parallel_for(n / 2, [&](uint64_t k) { acc[k] = Access{npc_addr[k], npc[2 * k + 1]}; });
+        const uint64_t n_pad = cells - pi.public_memory.size();
+        parallel_for(n_pad, [&](uint64_t k) { acc[n / 2 + k] = Access{1, pad_value}; });
+        for (size_t k = 0; k < pi.public_memory.size(); ++k) acc[n / 2 + n_pad + k] = Access{pi.public_memory[k].address, felt_from_canonical(pi.public_memory[k].value)};
+        __gnu_parallel::stable_sort(acc.begin(), acc.end(), [](const Access &a, const Access &b) { return a.address < b.address; });
         for (uint64_t k = 0; k < cells; ++k) if (acc[k].address != 0) fail("the public-memory cells of the pool must be the only accesses of address 0");
         if (acc[cells].address != 1) fail("memory must start at address 1");
-        for (uint64_t k = cells; k + 1 < acc.size(); ++k)
+        uint64_t first_bad = UINT64_MAX;
+#pragma omp parallel for schedule(static) reduction(min : first_bad)
+        for (uint64_t k = cells; k < acc.size() - 1; ++k)
             if (!((acc[k].address == acc[k + 1].address && felt_eq(acc[k].value, acc[k + 1].value)) || acc[k].address + 1 == acc[k + 1].address))
-                fail("memory is not continuous and single-valued at address " + std::to_string(acc[k].address));
-        for (uint64_t k = 0; k < n / 2; ++k) { mem_col[2 * k] = felt_from_u64(acc[cells + k].address); mem_col[2 * k + 1] = acc[cells + k].value; }
+                first_bad = std::min(first_bad, k);
+        if (first_bad != UINT64_MAX) fail("memory is not continuous and single-valued at address " + std::to_string(acc[first_bad].address));
+        parallel_for(n / 2, [&](uint64_t k) { mem_col[2 * k] = felt_from_u64(acc[cells + k].address); mem_col[2 * k + 1] = acc[cells + k].value; });
     }
+    lap("sorted memory");
+}
+
+std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+                                                   const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv) {
+    std::vector<std::vector<Felt>> cols(NUM_COLS);
+    Felt *out[NUM_COLS];
+    for (int c = 0; c < NUM_COLS; ++c) { cols[c].resize(states.size() * CYCLE_HEIGHT); out[c] = cols[c].data(); }
+    starknet_base_trace_into(out, states, memory, present, pi, priv);
     return cols;
 }
 

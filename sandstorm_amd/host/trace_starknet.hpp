@@ -23,6 +23,10 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
                                                    const std::vector<uint8_t> &present, const AirPublicInput &pi,
                                                    const StarknetPrivateInput &priv);
 
+// the same into caller-owned columns of 16 * states.size() felts each (every cell is written)
+void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+                              const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv);
+
 // shared with the AIR (air_starknet.cpp): StarkWare's Hades round constants, the curve's generator and beta
 const std::vector<std::array<Felt, 3>> &poseidon_round_keys();
 void starknet_curve(Felt &generator_x, Felt &generator_y, Felt &beta);

@@ -54,6 +54,35 @@ def main():
 
         def leaf_hash(vals):
             return keccak256(b"".join((v * wire._R % wire.P).to_bytes(32, "big") for v in vals))
+    elif case.startswith("starknet:"):
+        # the reference's array-sum run re-declared for the starknet layout at 2^k steps: C++ trace generator, the C++
+        # host's lowering of the real 195-constraint AIR behind the Python driver, EthVerifierClaim, CLI-default options
+        from sandstorm_amd import binary, extension, hostlib, public_input
+        from sandstorm_amd.layouts import starknet as sk
+        from tests.test_layout_starknet import starknet_example
+        log_steps = int(case.split(":")[1])
+        states, memory, spi = starknet_example(log_steps)
+        host = hostlib.starknet_base_trace(binary.write_register_states(states), binary.write_memory(memory), spi)
+        del states, memory
+        n = len(host[0])
+        host_air = hostlib.StarknetHostAir(ctx, spi, log_steps + 4, 1)
+        claim = Claim(hostlib.prover_air(host_air), be.LeafVariantMerkleTree, be.COIN_SOLIDITY)
+        opt = ProofOptions()
+        seed = public_input.public_coin_seed(spi, be.COIN_SOLIDITY)
+        cols = {c: v for c, v in enumerate(host) if c % world == rank}
+        aux_host = [host[c] for c in (sk.COL_NPC, sk.COL_MEMORY, sk.COL_RANGE_CHECK)] if 9 % world == rank else None
+        del host
+
+        def ext(challenges):
+            if aux_host is None:
+                return {}
+            aux = [tensor(c) for c in aux_host]
+            out = be.Matrix(ctx, [torch.zeros((n, 4), dtype=torch.int64, device=device)], n)
+            extension.build_extension_columns("starknet", ctx, extension.TraceColumns(aux[0], aux[1], aux[2], n), challenges, check=True, out=out)
+            return {9: out.cols[0]}
+
+        def leaf_hash(vals):
+            return keccak256(b"".join((v * wire._R % wire.P).to_bytes(32, "big") for v in vals))[:20] + bytes(12)
     else:
         from tests import mini_air
         log_n, max_remainder = (int(v) for v in case.split(":")[1:])
