@@ -904,34 +904,43 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp zf = fp_from_limbs64(z);
     const Fp wn_inv = fp_inv(root_of_unity(log_n));
-    // group mask cells by row offset
-    std::vector<uint32_t> order(nmask);
-    for (uint32_t j = 0; j < nmask; ++j) order[j] = j;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (mask_off[a] & (n - 1)) < (mask_off[b] & (n - 1)); });
-    std::vector<uint32_t> cell_col(nmask), gdesc;
-    std::vector<Fp> cell_coef(nmask), group_k;
-    uint32_t max_shift = 0;
-    for (uint32_t t = 0; t < nmask;) {
-        const uint32_t offv = mask_off[order[t]] & (uint32_t)(n - 1);
-        const Fp wk = fp_pow_u64(wn_inv, offv);
-        Fp kacc = fp_zero();
-        uint32_t first = t;
-        for (; t < nmask && (mask_off[order[t]] & (n - 1)) == offv; ++t) {
-            const uint32_t j = order[t];
-            if (mask_col[j] >= ntrace_cols) return fail(SS_ERR_INVALID, "mask cell %u names column %u", j, mask_col[j]);
-            cell_col[t] = mask_col[j];
-            cell_coef[t] = fp_mul(fp_from_limbs64(coeff_trace + 4 * j), wk);
-            kacc = fp_add(kacc, fp_mul(cell_coef[t], fp_from_limbs64(ood_trace + 4 * j)));
-        }
-        gdesc.push_back(offv); gdesc.push_back(first); gdesc.push_back(t - first);
-        group_k.push_back(kacc);
-        if (offv > max_shift) max_shift = offv;
-    }
-    const uint32_t ngroups = (uint32_t)group_k.size();
-    // the kernel multiplies with fl_mul_r280: coefficients go over in R280 form (times 2^24)
+    // Taps of the denominator table, column by column (deep.hip): cell (col, off) reads D at shift `off` with coefficient
+    // c' = coeff * w_n^-off (R280 form: times 2^24); one more "column" of constants carries -K_off = -sum_{cells at off} c' * ood.
     Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
     const Fp r280_factor = fp_to_mont(two24);
-    for (uint32_t t = 0; t < nmask; ++t) cell_coef[t] = fp_mul(cell_coef[t], r280_factor);
+    std::vector<uint32_t> order(nmask);
+    for (uint32_t j = 0; j < nmask; ++j) {
+        if (mask_col[j] >= ntrace_cols) return fail(SS_ERR_INVALID, "mask cell %u names column %u", j, mask_col[j]);
+        order[j] = j;
+    }
+    auto off_of = [&](uint32_t j) { return mask_off[j] & (uint32_t)(n - 1); };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        return mask_col[x] != mask_col[y] ? mask_col[x] < mask_col[y] : off_of(x) < off_of(y);
+    });
+    std::map<uint32_t, Fp> wk_of, k_of;                       // per distinct offset: w_n^-off, K_off
+    std::vector<uint32_t> tap_shift, cdesc;
+    std::vector<Fp> tap_coef;
+    uint32_t max_shift = 0;
+    for (uint32_t t = 0; t < nmask;) {
+        const uint32_t col = mask_col[order[t]], first = (uint32_t)tap_shift.size();
+        for (; t < nmask && mask_col[order[t]] == col; ++t) {
+            const uint32_t j = order[t], offv = off_of(j);
+            auto it = wk_of.find(offv);
+            if (it == wk_of.end()) { it = wk_of.emplace(offv, fp_pow_u64(wn_inv, offv)).first; k_of.emplace(offv, fp_zero()); }
+            const Fp cprime = fp_mul(fp_from_limbs64(coeff_trace + 4 * j), it->second);
+            k_of[offv] = fp_add(k_of[offv], fp_mul(cprime, fp_from_limbs64(ood_trace + 4 * j)));
+            tap_shift.push_back(offv);
+            tap_coef.push_back(fp_mul(cprime, r280_factor));
+            if (offv > max_shift) max_shift = offv;
+        }
+        cdesc.push_back(col); cdesc.push_back(first); cdesc.push_back((uint32_t)tap_shift.size() - first);
+    }
+    if (nmask) {
+        const uint32_t first = (uint32_t)tap_shift.size();
+        for (auto &kv : k_of) { tap_shift.push_back(kv.first); tap_coef.push_back(fp_neg(kv.second)); }
+        cdesc.push_back(0xffffffffu); cdesc.push_back(first); cdesc.push_back((uint32_t)tap_shift.size() - first);
+    }
+    const uint32_t ntaps = (uint32_t)tap_shift.size(), ncoldesc = (uint32_t)(cdesc.size() / 3);
     std::vector<Fp> comp_coef(ncomp ? ncomp : 1);
     Fp comp_k = fp_zero(), zc = fp_one();
     for (uint32_t k = 0; k < ncomp; ++k) {
@@ -953,21 +962,19 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
     } else {
         D = table_space; Dc = D + n;
     }
-    const size_t small = (size_t)nmask * (4 + 32) + (size_t)ngroups * (12 + 32) + (size_t)(ncomp + 1) * 32 + 256;
+    const size_t small = (size_t)(ntaps + 1) * (4 + 32) + (size_t)(ncoldesc + 1) * 12 + (size_t)(ncomp + 1) * 32 + 256;
     st = ctx->ensure_scratch(small);
     if (st != SS_OK) return st;
     char *p = (char *)ctx->scratch;
-    Fp *d_cell_coef = (Fp *)p; p += (size_t)(nmask ? nmask : 1) * 32;
-    Fp *d_group_k = (Fp *)p; p += (size_t)(ngroups ? ngroups : 1) * 32;
+    Fp *d_tap_coef = (Fp *)p; p += (size_t)(ntaps + 1) * 32;
     Fp *d_comp_coef = (Fp *)p; p += (size_t)(ncomp + 1) * 32;
-    uint32_t *d_cell_col = (uint32_t *)p; p += (size_t)(nmask ? nmask : 1) * 4;
-    uint32_t *d_gdesc = (uint32_t *)p;
+    uint32_t *d_tap_shift = (uint32_t *)p; p += (size_t)(ntaps + 1) * 4;
+    uint32_t *d_cdesc = (uint32_t *)p;
     hipStream_t s = ctx->stream;
-    if (nmask) {
-        HIP_TRY(hipMemcpyAsync(d_cell_coef, cell_coef.data(), (size_t)nmask * 32, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_cell_col, cell_col.data(), (size_t)nmask * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_group_k, group_k.data(), (size_t)ngroups * 32, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_gdesc, gdesc.data(), (size_t)ngroups * 12, hipMemcpyHostToDevice, s));
+    if (ntaps) {
+        HIP_TRY(hipMemcpyAsync(d_tap_coef, tap_coef.data(), (size_t)ntaps * 32, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_tap_shift, tap_shift.data(), (size_t)ntaps * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_cdesc, cdesc.data(), (size_t)ncoldesc * 12, hipMemcpyHostToDevice, s));
     }
     if (ncomp) HIP_TRY(hipMemcpyAsync(d_comp_coef, comp_coef.data(), (size_t)ncomp * 32, hipMemcpyHostToDevice, s));
     const Fp wn = root_of_unity(log_n);
@@ -983,7 +990,7 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
             if (ncomp) HIP_TRY(launch_batch_inverse(s, Dc, log_n, off, wn, fp_inv(wn), zc, true));
         }
         HIP_TRY(launch_deep(s, (const void *const *)d_trace_lde, ntrace_cols, (const void *const *)d_comp_lde, ncomp, D, Dc,
-                            d_cell_col, d_cell_coef, d_gdesc, d_group_k, ngroups, d_comp_coef, comp_k, count,
+                            d_tap_shift, d_tap_coef, d_cdesc, ncoldesc, d_comp_coef, comp_k, count,
                             block ? (uint32_t)pre : 0u, block ? 0xffffffffu : (uint32_t)(n - 1), log_blowup, d_sub));
     }
     HIP_TRY(hipStreamSynchronize(s));     // host staging vectors go out of scope

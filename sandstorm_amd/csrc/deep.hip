@@ -24,6 +24,7 @@
 //    re-expanded by two NTTs — half the pointwise work for blowup 2.  Products are
 //    accumulated in the lazy 9 x 28-bit form with one weak reduction per 12 terms.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "fp252.h"
 #include "fl252.h"
 #include "inv252.h"
@@ -153,24 +154,33 @@ struct DeepArgs {
     const Fp *comp[4];
     const Fp *D;            // 1/(x_i - z), R280 form
     const Fp *Dc;           // 1/(x_i - z^ncomp), R280 form
-    const uint32_t *cell_col;    // [nmask] sorted by group
-    const Fp *cell_coef;         // [nmask] coeff_j * w_n^-off_j, R280 form (times 2^24: the multiplier side of fl_mul_r280)
-    const uint32_t *group_desc;  // [ngroups][3]: shift (= off * blowup), first cell, cell count
-    const Fp *group_k;           // [ngroups] sum_j c'_j * ood_j
+    const uint32_t *tap_shift;   // [ntaps] sorted by column, then by shift (= off * blowup / stride: sub-coset units)
+    const Fp *tap_coef;          // [ntaps] coeff_j * w_n^-off_j in R280 form (times 2^24); the constant column: -K_g, Montgomery form
+    const uint32_t *col_desc;    // [ncoldesc][3]: trace column (0xffffffff: the constant column), first tap, tap count
     const Fp *comp_coef;         // [ncomp], R280 form
     Fp comp_k;                   // sum_k cc_k * ood_comp_k
-    uint32_t ngroups, ncomp, log_stride;
+    uint32_t ncoldesc, ncomp, log_stride;
     uint64_t count;              // points evaluated: sub-coset points m0 .. m0 + count (m0 is folded into the pointers)
     uint32_t d_bias, d_mask;     // D is read at (m + d_bias - shift) & d_mask: whole table (0, M - 1) or a local range with
-};                               // `d_bias` entries in front of the block's first point (d_mask = ~0)
+                                 // `d_bias` entries in front of the block's first point (d_mask = ~0)
+    uint32_t xcd_map;            // 1: workgroup b sweeps the (b % 8)-th eighth of the points (see the kernel)
+};
 
-// Evaluates the DEEP sum at LDE indices i = m * stride, m < 2^log_M: with stride = blowup
-// this is the trace-size sub-coset offset*<w_n>, enough to pin the degree < n DEEP
-// polynomial, which the caller then interpolates and re-expands (halves the pointwise work).
-// D / Dc are tables over that same sub-coset; group shifts are in sub-coset units.
-// Wave-uniform, read-only tables (cell columns, coefficients, group descriptors) are read through the
-// constant address space: scalar loads into SGPRs instead of a broadcast vector load per lane, and the
-// coefficient's re-limbing runs on the scalar unit.
+// Evaluates the DEEP sum at LDE indices i = m * stride, m < count: with stride = blowup this is the trace-size sub-coset
+// offset*<w_n>, enough to pin the degree < n DEEP polynomial, which the caller then interpolates and re-expands (halves
+// the pointwise work).  D / Dc are tables over that same sub-coset; shifts are in sub-coset units.
+//
+// A cell's trace value is T_col[i] whatever its offset - only the denominator moves - so the sum is taken column by column:
+//   out[m] = sum_c T_c[i] * S_c[m] + S_K[m] + Dc[m] * (sum_k cc_k H_k[i] - Kc),
+//   S_c[m] = sum_{cells (c, off)} c'_(c,off) D[m - shift_off],     S_K[m] = sum_off (-K_off) D[m - shift_off]
+// (K_off = sum of c' * ood over the cells of that offset).  Every S is ONE fused dot product (fl252.h FlWide: 81 partial
+// products per term into 64-bit columns, one Montgomery reduction per <= 16 terms), and so is the outer sum over the
+// columns.  Grouping by offset instead - one inner sum and one reduction per distinct offset - paid 191 + 12 reductions per
+// point for the starknet mask (269 cells at 191 offsets) against 269 + 191 products; this order pays ~ 40.
+// Wave-uniform, read-only tables (shifts, coefficients, descriptors) are read through the constant address space:
+// scalar loads into SGPRs, and the coefficient's re-limbing runs on the scalar unit.  The denominator table is read
+// at ~ 460 shifted positions per point; workgroup b runs on XCD b % 8 (observed; speed only) and sweeps that XCD's own
+// eighth of the points front to back, so those reads stay in one L2.
 typedef uint32_t dk_u32x4 __attribute__((ext_vector_type(4)));
 typedef const uint32_t __attribute__((address_space(4))) *dk_const_u32;
 typedef const dk_u32x4 __attribute__((address_space(4))) *dk_const_u32x4;
@@ -185,49 +195,63 @@ __device__ __forceinline__ Fp dload_uniform(const Fp *p) {
 
 __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ out) {
     const uint64_t M = a.count;                      // points evaluated
-    dk_const_u32 group_desc = (dk_const_u32)(uintptr_t)a.group_desc, cell_col = (dk_const_u32)(uintptr_t)a.cell_col;
-    for (uint64_t m = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; m < M;
-         m += (uint64_t)gridDim.x * blockDim.x) {
+    dk_const_u32 col_desc = (dk_const_u32)(uintptr_t)a.col_desc, tap_shift = (dk_const_u32)(uintptr_t)a.tap_shift;
+    // point range of this workgroup: XCD-contiguous when the points split evenly over 8 x gridDim/8 workgroups
+    uint64_t m_first, m_end, m_step;
+    if (a.xcd_map) {
+        const uint64_t chunk = M >> 3;
+        m_first = (uint64_t)(blockIdx.x & 7u) * chunk + (uint64_t)(blockIdx.x >> 3) * blockDim.x;
+        m_end = (uint64_t)((blockIdx.x & 7u) + 1u) * chunk;
+        m_step = (uint64_t)(gridDim.x >> 3) * blockDim.x;
+    } else {
+        m_first = blockIdx.x * (uint64_t)blockDim.x;
+        m_end = M;
+        m_step = (uint64_t)gridDim.x * blockDim.x;
+    }
+    for (uint64_t m = m_first + threadIdx.x; m < m_end; m += m_step) {
         const uint64_t i = m << a.log_stride;        // LDE row of this point
-        // Both levels of the sum are fused dot products (fl252.h FlWide): the inner sum over a group's cells and the outer
-        // sum over the groups accumulate their 81 partial products per term in 64-bit columns and pay ONE Montgomery
-        // reduction per <= 16 terms instead of one per product (a product's reduction is more than half of its instructions).
-        Fl acc = fl_zero();                          // reduced partial sums of the outer level (lazy adds)
-        FlWide wo;                                   // outer: sum_g inner_g * D[i - shift_g]
+        const uint32_t dbase = (uint32_t)m + a.d_bias;
+        Fl acc = fl_zero();                          // reduced partial sums (lazy adds): < 32 p at the end for fl_to_fp
+        uint32_t acc_terms = 0;
+        FlWide wo;                                   // outer: sum_c T_c * S_c
         fl_wide_zero(wo);
-        uint32_t outer_terms = 0, acc_terms = 0;
-        for (uint32_t g = 0; g < a.ngroups; ++g) {
-            const uint32_t shift = group_desc[3 * g], first = group_desc[3 * g + 1], cnt = group_desc[3 * g + 2];
-            Fl inner = fl_zero();
-            uint32_t parts = 0;                      // reduced partial sums folded into `inner` so far (each < 1.01 p)
+        uint32_t outer_terms = 0;
+        for (uint32_t k = 0; k < a.ncoldesc; ++k) {
+            const uint32_t col = col_desc[3 * k], first = col_desc[3 * k + 1], cnt = col_desc[3 * k + 2];
+            Fl part = fl_zero();                     // reduced partial sums of S (each < 1.01 p)
+            uint32_t parts = 0, terms = 0;
             FlWide wi;
             fl_wide_zero(wi);
-            uint32_t terms = 0;
+            Fp d = dload(a.D + ((dbase - tap_shift[first]) & a.d_mask));
             for (uint32_t j = first; j < first + cnt; ++j) {
-                const uint32_t col = cell_col[j];
+                const Fl dl = fl_from_fp(d);         // canonical image from memory: normalised limbs
+                if (j + 1 < first + cnt) d = dload(a.D + ((dbase - tap_shift[j + 1]) & a.d_mask));     // next tap in flight
+                fl_wide_mad(wi, dl, fl_from_fp(dload_uniform(a.tap_coef + j)));
+                if (++terms == (uint32_t)FL_WIDE_MAX_TERMS) {
+                    part = fl_add(part, fl_wide_reduce(wi));
+                    fl_wide_zero(wi);
+                    terms = 0;
+                    if (++parts == 6) { part = fl_weak_reduce(part); parts = 1; }
+                }
+            }
+            if (terms) part = fl_add(part, fl_wide_reduce(wi));
+            const Fl S = fl_weak_reduce(part);       // <= 7 reduced values -> < 2p, normalised
+            if (col == 0xffffffffu) {                // the constant column: S_K is a Montgomery image, added as it is
+                acc = fl_add(acc, S);
+                ++acc_terms;
+            } else {
                 const Fp *tp = a.trace[0];
 #pragma unroll
                 for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) tp = a.trace[c];
-                // both factors are canonical images from memory: normalised limbs
-                fl_wide_mad(wi, fl_from_fp(dload(tp + i)), fl_from_fp(dload_uniform(a.cell_coef + j)));
-                if (++terms == (uint32_t)FL_WIDE_MAX_TERMS) {
-                    inner = fl_add(inner, fl_wide_reduce(wi));
-                    fl_wide_zero(wi);
-                    terms = 0;
-                    if (++parts == 6) { inner = fl_weak_reduce(inner); parts = 1; }
+                fl_wide_mad(wo, fl_from_fp(dload(tp + i)), S);
+                if (++outer_terms == (uint32_t)FL_WIDE_MAX_TERMS) {
+                    acc = fl_add(acc, fl_wide_reduce(wo));
+                    fl_wide_zero(wo);
+                    outer_terms = 0;
+                    ++acc_terms;
                 }
             }
-            if (terms) { inner = fl_add(inner, fl_wide_reduce(wi)); ++parts; }
-            // inner: <= 7 reduced values: < 7.1 p, limbs < 7 * 2^28; minus K_g (lazy subtraction: + 2p), then normalised
-            // for the outer product
-            inner = fl_weak_reduce(fl_sub_c<2, 1>(inner, fl_from_fp(dload_uniform(a.group_k + g))));
-            fl_wide_mad(wo, inner, fl_from_fp(dload(a.D + (((uint32_t)m + a.d_bias - shift) & a.d_mask))));
-            if (++outer_terms == (uint32_t)FL_WIDE_MAX_TERMS) {
-                acc = fl_add(acc, fl_wide_reduce(wo));
-                fl_wide_zero(wo);
-                outer_terms = 0;
-                if (++acc_terms == 6) { acc = fl_weak_reduce(acc); acc_terms = 1; }
-            }
+            if (acc_terms >= 6) { acc = fl_weak_reduce(acc); acc_terms = 1; }
         }
         if (a.ncomp) {
             FlWide wi;
@@ -242,24 +266,27 @@ __global__ __launch_bounds__(256) void deep_kernel(DeepArgs a, Fp *__restrict__ 
             fl_wide_mad(wo, inner, fl_from_fp(dload(a.Dc + m)));
             ++outer_terms;
         }
-        if (outer_terms) acc = fl_add(acc, fl_wide_reduce(wo));      // <= 6 + 1 reduced values: < 32 p for fl_to_fp
+        if (outer_terms) acc = fl_add(acc, fl_wide_reduce(wo));      // <= 6 + 1 values < 2p each: < 32 p for fl_to_fp
         dstore(out + m, fl_to_fp(acc));
     }
 }
 
 hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace, const void *const *comp,
-                       uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *cell_col, const Fp *cell_coef,
-                       const uint32_t *group_desc, const Fp *group_k, uint32_t ngroups, const Fp *comp_coef,
+                       uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *tap_shift, const Fp *tap_coef,
+                       const uint32_t *col_desc, uint32_t ncoldesc, const Fp *comp_coef,
                        const Fp &comp_k, uint64_t count, uint32_t d_bias, uint32_t d_mask, uint32_t log_stride, Fp *out) {
     DeepArgs a;
     for (int c = 0; c < MAX_COLS; ++c) a.trace[c] = c < (int)ntrace ? (const Fp *)trace[c] : nullptr;
     for (int c = 0; c < 4; ++c) a.comp[c] = c < (int)ncomp ? (const Fp *)comp[c] : nullptr;
-    a.D = D; a.Dc = Dc; a.cell_col = cell_col; a.cell_coef = cell_coef; a.group_desc = group_desc;
-    a.group_k = group_k; a.comp_coef = comp_coef; a.comp_k = comp_k; a.ngroups = ngroups; a.ncomp = ncomp;
+    a.D = D; a.Dc = Dc; a.tap_shift = tap_shift; a.tap_coef = tap_coef; a.col_desc = col_desc; a.ncoldesc = ncoldesc;
+    a.comp_coef = comp_coef; a.comp_k = comp_k; a.ncomp = ncomp;
     a.count = count; a.d_bias = d_bias; a.d_mask = d_mask; a.log_stride = log_stride;
     const uint64_t N = count;
     uint32_t gx = (uint32_t)((N + 255) / 256);
-    if (gx > 256 * 16) gx = 256 * 16;
+    static const uint32_t wgs = getenv("SS_DEEP_WGS") ? (uint32_t)atoi(getenv("SS_DEEP_WGS")) : 256 * 16;    // measured: 512 -> 44 ms, 1024 -> 36, 4096 -> 32 (starknet_2p20)
+    if (gx > wgs) gx = wgs;
+    static const bool no_xcd_map = getenv("SS_DEEP_NO_XCD_MAP") != nullptr;                                // A/B switch for profiling
+    a.xcd_map = (!no_xcd_map && gx >= 8 && gx % 8 == 0 && N % (8 * 256) == 0) ? 1u : 0u;
     hipLaunchKernelGGL(deep_kernel, dim3(gx), dim3(256), 0, st, a, out);
     return hipGetLastError();
 }

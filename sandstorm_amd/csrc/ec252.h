@@ -72,8 +72,10 @@ SS_HD JacL jacl_add_aff(const JacL &p, const AffL &q) {
         if (fn_is_zero(fl_weak_reduce(rr))) return jacl_double(p);
         JacL o; o.x = fl_one(); o.y = fl_one(); o.z = fl_zero(); return o;
     }
-    const Fl hh = fl_mul(h, h), hhh = fl_mul(h, hh), v = fn_mul(p.x, hh);
-    r.x = fl_weak_reduce(fl_sub_c<8, 2>(fl_sub_c<2, 1>(fl_mul(rr, rr), hhh), fl_add(v, v)));
+    // squares of the lazy h, rr (< 4p, limbs < 2^29 + 2^25): fl_sqr's doubled limbs stay below 2^31 and its 45 products sum
+    // to what fl_mul's 81 would - the same column bounds with 36 multiplications fewer each
+    const Fl hh = fl_sqr(h), hhh = fl_mul(h, hh), v = fn_mul(p.x, hh);
+    r.x = fl_weak_reduce(fl_sub_c<8, 2>(fl_sub_c<2, 1>(fl_sqr(rr), hhh), fl_add(v, v)));
     r.y = fl_weak_reduce(fl_sub_c<2, 1>(fl_mul(rr, fl_sub_c<2, 1>(v, r.x)), fn_mul(p.y, hhh)));
     return r;
 }

@@ -78,8 +78,8 @@ hipError_t launch_poly_reduce(hipStream_t st, const void *const *in, void *const
 hipError_t launch_batch_inverse(hipStream_t st, Fp *D, uint32_t log_N, const Fp &offset, const Fp &w,
                                 const Fp &w_inv, const Fp &z, bool r280);
 hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace, const void *const *comp,
-                       uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *cell_col, const Fp *cell_coef,
-                       const uint32_t *group_desc, const Fp *group_k, uint32_t ngroups, const Fp *comp_coef,
+                       uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *tap_shift, const Fp *tap_coef,
+                       const uint32_t *col_desc, uint32_t ncoldesc, const Fp *comp_coef,
                        const Fp &comp_k, uint64_t count, uint32_t d_bias, uint32_t d_mask, uint32_t log_stride, Fp *out);
 static constexpr uint32_t BATCH_INVERSE_RANGE_LOG_CHUNK = 5;
 hipError_t launch_batch_inverse_range(hipStream_t st, Fp *D, uint64_t len, const Fp &x0, const Fp &w, const Fp &w_inv,
