@@ -1097,7 +1097,12 @@ const QGenKernel *quotient_gen_find(const uint32_t *code, uint32_t n_instr) {
     uint64_t h = 0xcbf29ce484222325ull;                                  // FNV-1a over the code words (tools/gen_quotient.py)
     for (size_t k = 0; k < 2 * (size_t)n_instr; ++k)
         for (int b = 0; b < 4; ++b) h = (h ^ ((code[k] >> (8 * b)) & 0xffu)) * 0x100000001b3ull;
-    const QGenKernel *all[] = {&quotient_gen_starknet(), &quotient_gen_recursive()};    // + the A/B variants when built (tools/gen_quotient.py --all-variants)
+#ifdef SS_QG_AB_VARIANTS                                                  // make QG_AB=1: the A/B variants of tools/gen_quotient.py --all-variants
+    const QGenKernel *all[] = {&quotient_gen_starknet(), &quotient_gen_recursive(), &quotient_gen_starknet_v1(), &quotient_gen_starknet_v2(),
+                               &quotient_gen_starknet_v3(), &quotient_gen_recursive_v1(), &quotient_gen_recursive_v2(), &quotient_gen_recursive_v3()};
+#else
+    const QGenKernel *all[] = {&quotient_gen_starknet(), &quotient_gen_recursive()};
+#endif
     uint32_t variant = 0;                                                // A/B runs: SS_QG_VARIANT=k (tools/gen_quotient.py VARIANTS)
     if (const char *e = getenv("SS_QG_VARIANT")) variant = (uint32_t)strtoul(e, nullptr, 10);
     for (const QGenKernel *k : all)

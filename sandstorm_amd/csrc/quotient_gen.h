@@ -38,6 +38,10 @@ struct QGenKernel {
 
 const QGenKernel &quotient_gen_starknet();       // quotient_gen_starknet.hip
 const QGenKernel &quotient_gen_recursive();      // quotient_gen_recursive.hip
+#ifdef SS_QG_AB_VARIANTS
+const QGenKernel &quotient_gen_starknet_v1(); const QGenKernel &quotient_gen_starknet_v2(); const QGenKernel &quotient_gen_starknet_v3();
+const QGenKernel &quotient_gen_recursive_v1(); const QGenKernel &quotient_gen_recursive_v2(); const QGenKernel &quotient_gen_recursive_v3();
+#endif
 
 typedef uint32_t qg_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -88,6 +92,14 @@ typedef FlWide QgWide;
 // instructions and LDS reads may not (an LDS read of a constant depends on nothing: unpinned, hundreds of them float
 // to the top of the point and sit in registers until used)
 #define QG_PIN_LOADS __builtin_amdgcn_sched_barrier(0x1 | 0x2 | 0x4 | 0x8 | 0x200);
+// between two program instructions.  QG_FENCE_EVERY_INSTRUCTION: nothing is scheduled across, so the machine scheduler works
+// on one program instruction at a time instead of interleaving several multiplications (each 19 64-bit columns) for ILP the
+// 81 independent multiply-adds of ONE product already provide
+#ifdef QG_FENCE_EVERY_INSTRUCTION
+#define QG_FENCE __builtin_amdgcn_sched_barrier(0);
+#else
+#define QG_FENCE
+#endif
 
 // scratch slots of the program: per point, in LDS as 32-byte images in two 16-byte planes [slot][lane] (a lane's 16 bytes
 // next to its neighbour's: conflict-free b128 accesses), so that the registers hold only what is being computed on

@@ -36,6 +36,7 @@ struct HostArgs {
 #define QG_SLOT(k) fl_from_fp(slots[k])
 #define QG_OUT(v) a.out[i] = fl_to_fp(v)
 #define QG_PIN_LOADS
+#define QG_FENCE
 typedef FlWide QgWide;
 #define qg_dot_zero fl_wide_zero
 #define qg_dot_mad fl_wide_mad

@@ -69,22 +69,25 @@ def template_program(layout):
 
 PREFETCH_DEPTH = 6      # memory operands in flight ahead of their use (one wave per SIMD: nothing else hides the latency)
 DOT_MAX_TERMS = 16      # products accumulated in the 64-bit columns before a Montgomery reduction (16 * 9 * 2^56 < 2^64)
-# Fusing "MUL acc, alpha^k ; ADD sum, acc" chains into dot products with one Montgomery reduction per 16 terms removes ~6 %
-# of the vector instructions, but the 19 x 64-bit column accumulator stays live across the constraints between two terms
-# and costs ~150 registers in practice (profiles/r02_quotient_codegen_experiments.txt): the starknet kernel then spills to
-# scratch and runs 2.7x slower.  Off; the DEEP kernel, whose sums are tight loops, uses the same fusion (fl252.h FlWide).
-FUSE_ALPHA_DOT_PRODUCTS = False
+# Fusing "MUL acc, alpha^k ; ADD sum, acc" chains into dot products (one Montgomery reduction per DOT_MAX_TERMS units of bound)
+# removes ~9 % of the vector instructions.  Left to itself the machine scheduler interleaves several program instructions
+# and the 19 x 64-bit column accumulator then costs ~150 registers (scratch spills, 2.7x slower: round-2 v2); with a
+# scheduling fence after every program instruction it costs its own 38 and the starknet kernel gains 9 % (154 -> 140 ms).
+# The recursive kernel lives on two workgroups per CU (256 registers) and has no room for the accumulator: unfused.
 
 
 # Kernel variants built side by side (ss_eval_quotient takes variant 0; SS_QG_VARIANT=k selects another for A/B runs):
 #   (name suffix, prefetch depth, slots in registers instead of LDS, workgroups per CU the register budget is set for)
 # Measured on the MI355X (profiles/r02_quotient_codegen_experiments.txt; 2^25 points): the starknet program is register
-# bound - LDS slots, one workgroup per CU, a shallow prefetch (depth 3: 153.7 ms, 2: 154.3, 1: 159.6, 4: 153.7, 6: 171.5;
-# slots in registers at two workgroups per CU: 352, scratch spills); the recursive one fits two workgroups per CU with its
-# slots in registers (depth 4: 65.5 ms, 6: 66.0, 2: 65.1; LDS slots at one workgroup per CU: 76.9).
+# bound - LDS slots, one workgroup per CU, a shallow prefetch (unfused, depth 3: 153.7 ms, 2: 154.3, 1: 159.6, 4: 153.7,
+# 6: 171.5; slots in registers at two workgroups per CU: 352, scratch spills; fenced + fused, depth 3: 140.2, 2: 140.6,
+# 4: 167.8, slots in registers: 161.6); the recursive one fits two workgroups per CU with its slots in registers (depth 4:
+# 65.5 ms, 6: 66.0, 2: 65.1; LDS slots at one workgroup per CU: 76.9; fenced + fused at one workgroup per CU: 86).
+# (suffix, operand prefetch depth, slots in registers, workgroups per CU, scheduling fence after every program instruction,
+#  "MUL alpha^k; ADD" chains as fused dot products)
 VARIANTS = {
-    "starknet": [("", 3, False, 1), ("_v1", 2, False, 1), ("_v2", 1, False, 1), ("_v3", 4, False, 1)],
-    "recursive": [("", 4, True, 2), ("_v1", 6, True, 2), ("_v2", 2, True, 2), ("_v3", 3, False, 1)],
+    "starknet": [("", 3, False, 1, True, True), ("_v1", 2, False, 1, True, True), ("_v2", 3, True, 1, True, True), ("_v3", 3, False, 1, False, False)],
+    "recursive": [("", 4, True, 2, False, False), ("_v1", 4, True, 1, True, True), ("_v2", 4, True, 2, True, True), ("_v3", 4, False, 1, True, True)],
 }
 
 
@@ -93,13 +96,13 @@ def generate(layout, all_variants=False):
     the table in capi.hip's quotient_gen_find for an A/B run with SS_QG_VARIANT=k)"""
     program = template_program(layout)
     bodies = {}
-    for k, (suffix, depth, slots_in_regs, wgs) in enumerate(VARIANTS[layout] if all_variants else VARIANTS[layout][:1]):
-        if depth not in bodies:
-            bodies[depth] = generate_body(layout, program, depth, "" if not bodies else "_d%d" % depth)
-        write_wrapper(layout, program, k, suffix, bodies[depth], slots_in_regs, wgs)
+    for k, (suffix, depth, slots_in_regs, wgs, fence, fuse) in enumerate(VARIANTS[layout] if all_variants else VARIANTS[layout][:1]):
+        if (depth, fuse) not in bodies:
+            bodies[(depth, fuse)] = generate_body(layout, program, depth, "" if not bodies else "_d%d%s" % (depth, "f" if fuse else ""), fuse)
+        write_wrapper(layout, program, k, suffix, bodies[(depth, fuse)], slots_in_regs, wgs, fence)
 
 
-def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix):
+def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix, FUSE_ALPHA_DOT_PRODUCTS=False):
     code, n_consts, n_slots, n_tables, ncols = program
     n_instr = len(code) // 2
     ins = [(int(code[2 * pc]) & 0xff, (int(code[2 * pc]) >> 8) & 0xf, (int(code[2 * pc]) >> 12) & 0xf, int(code[2 * pc + 1])) for pc in range(n_instr)]
@@ -160,6 +163,8 @@ def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix):
     skip_add = set()
     for pc, (op, d, kind, w1) in enumerate(ins):
         v = "acc%d" % d
+        if pc:
+            emit("    QG_FENCE")
         if pc in skip_add:                          # the ADD of a fused pair: already accounted in the wide accumulator
             continue
         # any other touch of the accumulator that carries a pending dot product needs its value: flush first
@@ -231,19 +236,19 @@ def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix):
         elif op == OP_MUL:
             tgt = fused.get(pc)
             if tgt is not None and (wide["acc"] in (None, tgt)):
-                # term of a dot product: acc_tgt += v * alpha^k with the reduction deferred (the multiplicand must be
-                # normalised: 9 products of 28-bit limbs per column, DOT_MAX_TERMS of them, stay below 2^64)
-                if bound[d] > 1:
+                # term of a dot product: acc_tgt += v * alpha^k with the reduction deferred.  A multiplicand of bound b (limbs
+                # < b 2^28) adds < 9 b 2^56 to a column: the terms' bounds may sum to DOT_MAX_TERMS before the columns near 2^64
+                if bound[d] > 4:
                     reduce_acc(d)
+                if wide["acc"] is not None and wide["terms"] + bound[d] > DOT_MAX_TERMS:
+                    flush_wide()
                 if wide["acc"] is None:
                     emit("    qg_dot_zero(wd);")
                     wide["acc"] = tgt
                 emit("    qg_dot_mad(wd, %s, %s);" % (v, src))
-                wide["terms"] += 1
+                wide["terms"] += bound[d]
                 stats["fused"] += 1
                 skip_add.add(pc + 1)
-                if wide["terms"] == DOT_MAX_TERMS:
-                    flush_wide()
             elif src_acc == d:                                 # v * v: the square routine wants a normalised value
                 if bound[d] > 1:
                     reduce_acc(d)
@@ -308,7 +313,7 @@ def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix):
     return dict(stats, inc=name, depth=D)
 
 
-def write_wrapper(layout, program, variant, suffix, body, slots_in_regs, wgs):
+def write_wrapper(layout, program, variant, suffix, body, slots_in_regs, wgs, fence=False):
     code, n_consts, n_slots, n_tables, ncols = program
     n_instr = len(code) // 2
     h = code_hash(code)
@@ -316,9 +321,9 @@ def write_wrapper(layout, program, variant, suffix, body, slots_in_regs, wgs):
 //
 // The composition constraint of the `%(layout)s` layout (layouts/src/%(layout)s/air.rs; lowered by
 // sandstorm_amd/host/air_%(layout)s.cpp + air_program.cpp) as straight-line code for gfx950, variant %(variant)d: %(n_instr)d
-// program instructions, %(mul)d multiplications (%(mulr)d by a constant in R280 form), %(loads)d trace / table operand loads issued
+// program instructions, %(mul)d multiplications (%(mulr)d by a constant in R280 form, %(fused)d as terms of %(flushes)d fused dot products), %(loads)d trace / table operand loads issued
 // %(depth)d operands ahead of their use, %(reduce)d weak reductions placed at generation time, %(n_slots)d scratch values per point
-// in %(where)s, constants in LDS, register budget for %(wgs)d workgroup(s) per CU.
+// in %(where)s, constants in LDS, register budget for %(wgs)d workgroup(s) per CU%(fence)s.
 // Code hash (FNV-1a of the program's code words) 0x%(hash)016x: ss_eval_quotient launches this kernel for exactly
 // that program and interprets any other.
 %(define)s#include "quotient_gen.h"
@@ -353,7 +358,8 @@ const QGenKernel &quotient_gen_%(layout)s%(suffix)s() {
 }  // namespace ss
 ''' % dict(layout=layout, suffix=suffix, variant=variant, n_instr=n_instr, n_slots=n_slots, n_consts=n_consts, n_tables=n_tables, ncols=ncols,
            hash=h, wgs=wgs, lds_slots=0 if slots_in_regs else n_slots, where="registers" if slots_in_regs else "LDS",
-           define="#define QG_SLOTS_IN_REGISTERS\n" if slots_in_regs else "", **body)
+           define=("#define QG_SLOTS_IN_REGISTERS\n" if slots_in_regs else "") + ("#define QG_FENCE_EVERY_INSTRUCTION\n" if fence else ""),
+           fence=", a scheduling fence after every program instruction" if fence else "", **body)
     path = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s%s.hip" % (layout, suffix))
     with open(path, "w") as f:
         f.write(src)
