@@ -70,7 +70,7 @@ enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
 const char *ss_last_error(void);
 /* ABI version of this header; bump on any signature change.  ss_abi_version() of the loaded
  * library must equal SS_ABI_VERSION of the header the caller was built against. */
-#define SS_ABI_VERSION 5u
+#define SS_ABI_VERSION 6u
 uint32_t ss_abi_version(void);
 
 /* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;
@@ -263,6 +263,25 @@ ss_status ss_lde_gl64(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols, 
  * flags: SS_FRI_UNNORMALISED multiplies by fold */
 ss_status ss_fri_fold_gl64x3(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold, const uint64_t alpha[3],
                              uint64_t domain_offset, uint32_t flags, uint64_t *d_out);
+
+/* D1 over the cubic extension (ministark's DeepPolyComposer with Fq = Fq3: the out-of-domain point and every coefficient
+ * are elements of Fq3 - three values < p each - the trace columns are Fp arrays; an Fq3-valued column (extension trace,
+ * composition) is passed as its three component columns, its cells carrying the coefficients c, c X, c X^2 and the
+ * out-of-domain value on the first of them: the sum is linear).
+ * ss_ood_eval_gl64x3: out[3 j ..) = P_{cell_col[j]}(z * w_n^{cell_off[j]}) for bit-reversed coefficient columns (as
+ *   ss_lde_gl64 writes them); out is HOST memory.
+ * ss_deep_compose_gl64x3: d_out[i] (interleaved [n * blowup][3], the layout ss_fri_fold_gl64x3 reads) =
+ *   sum_j coeff_trace[j] (T_{col_j}(x_i) - ood_trace[j]) / (x_i - z w_n^{off_j})
+ *   + sum_k coeff_comp[k] (H_k(x_i) - ood_comp[k]) / (x_i - z_comp),      x_i = offset * w_{n blowup}^i,
+ *   composed on the n-point sub-coset and extended per component (the polynomial has degree < n). */
+ss_status ss_ood_eval_gl64x3(ss_ctx *ctx, const uint64_t *const *d_coeffs_bitrev, uint32_t ncols, uint32_t log_n,
+                             const uint32_t *cell_col, const uint32_t *cell_off, uint32_t ncells, const uint64_t z[3],
+                             uint64_t *out);
+ss_status ss_deep_compose_gl64x3(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_t ntrace_cols,
+                                 const uint64_t *const *d_comp_lde, uint32_t ncomp, uint32_t log_n, uint32_t log_blowup,
+                                 uint64_t offset, const uint32_t *mask_col, const uint32_t *mask_off, uint32_t nmask,
+                                 const uint64_t *ood_trace, const uint64_t *coeff_trace, const uint64_t *ood_comp,
+                                 const uint64_t *coeff_comp, const uint64_t z[3], const uint64_t z_comp[3], uint64_t *d_out);
 
 /* ---- F1: one FRI layer fold (ministark FriProver::build_layers, un-vendored;
  *      defaults cli/src/main.rs:57-60).  d_evals: 2^log_len felts on

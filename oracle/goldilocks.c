@@ -120,3 +120,80 @@ void or_gl3_fri_fold(const uint64_t *evals, unsigned log_len, unsigned fold, con
         memcpy(out + 3 * j, &acc, 24);
     }
 }
+
+/* ---- DEEP over Fq3: the definitions, term by term -----------------------------------------------------------------------
+ * (the kernels use one shifted inverse table and a norm-based inverse; here every denominator is inverted on its own, by
+ * Fermat in Fq3: a^-1 = a^(p^3 - 2)) */
+static gl3_t gl3_sub(gl3_t a, gl3_t b) { gl3_t r = {{gl_sub(a.c[0], b.c[0]), gl_sub(a.c[1], b.c[1]), gl_sub(a.c[2], b.c[2])}}; return r; }
+static gl3_t gl3_inv(gl3_t a) {
+    /* p^3 - 2 as a 192-bit integer, little-endian 64-bit words */
+    unsigned __int128 p = GL_P;
+    unsigned __int128 p2 = p * p;                                    /* < 2^128 */
+    uint64_t w[3];
+    {   /* p2 * p */
+        const uint64_t lo = (uint64_t)p2, hi = (uint64_t)(p2 >> 64);
+        unsigned __int128 t0 = (unsigned __int128)lo * GL_P, t1 = (unsigned __int128)hi * GL_P + (uint64_t)(t0 >> 64);
+        w[0] = (uint64_t)t0; w[1] = (uint64_t)t1; w[2] = (uint64_t)(t1 >> 64);
+    }
+    /* minus 2 (w[0] = p^3 mod 2^64 = 1: borrow) */
+    if (w[0] >= 2) w[0] -= 2; else { w[0] = w[0] - 2; if (w[1]-- == 0) w[2]--; }
+    gl3_t r = {{1, 0, 0}};
+    for (int k = 191; k >= 0; --k) {
+        r = gl3_mul(r, r);
+        if ((w[k / 64] >> (k % 64)) & 1) r = gl3_mul(r, a);
+    }
+    return r;
+}
+void or_gl3_inv(const uint64_t a[3], uint64_t out[3]) { gl3_t x; memcpy(&x, a, 24); gl3_t r = gl3_inv(x); memcpy(out, &r, 24); }
+
+/* out[3 j ..) = P_{cell_col[j]}(z w_n^{cell_off[j]}) for NATURAL-order coefficient columns (Horner in Fq3) */
+void or_gl3_ood_eval(const uint64_t *const *coeffs, unsigned log_n, const uint32_t *cell_col, const uint32_t *cell_off, unsigned ncells,
+                     const uint64_t z[3], uint64_t *out) {
+    const size_t n = (size_t)1 << log_n;
+    const uint64_t wn = or_gl_root_of_unity(log_n);
+    gl3_t zz; memcpy(&zz, z, 24);
+    for (unsigned j = 0; j < ncells; ++j) {
+        const gl3_t pt = gl3_scale(zz, gl_pow(wn, cell_off[j] & (n - 1)));
+        const uint64_t *c = coeffs[cell_col[j]];
+        gl3_t acc = {{0, 0, 0}};
+        for (size_t k = n; k-- > 0;) { acc = gl3_mul(acc, pt); acc.c[0] = gl_add(acc.c[0], c[k]); }
+        memcpy(out + 3 * (size_t)j, &acc, 24);
+    }
+}
+
+/* out[i] (interleaved [N][3]) = sum_j coeff_t[j] (T_{col_j}[i] - ood_t[j]) / (x_i - z w_n^{off_j}) + sum_k coeff_c[k] (H_k[i] - ood_c[k]) / (x_i - zc),
+ * x_i = offset * w_N^i, N = n << log_blowup */
+void or_gl3_deep_compose(const uint64_t *const *trace, const uint64_t *const *comp, unsigned ncomp, unsigned log_n, unsigned log_blowup,
+                         uint64_t offset, const uint32_t *mask_col, const uint32_t *mask_off, unsigned nmask, const uint64_t *ood_t,
+                         const uint64_t *coeff_t, const uint64_t *ood_c, const uint64_t *coeff_c, const uint64_t z[3], const uint64_t zc[3],
+                         uint64_t *out) {
+    const size_t n = (size_t)1 << log_n, N = n << log_blowup;
+    const uint64_t wn = or_gl_root_of_unity(log_n), wN = or_gl_root_of_unity(log_n + log_blowup);
+    gl3_t zz, zcc = {{0, 0, 0}};
+    memcpy(&zz, z, 24);
+    if (ncomp) memcpy(&zcc, zc, 24);
+#pragma omp parallel for schedule(static) if (N >= 64)
+    for (size_t i = 0; i < N; ++i) {
+        const uint64_t x = gl_mul(offset, gl_pow(wN, i));
+        gl3_t acc = {{0, 0, 0}};
+        for (unsigned j = 0; j < nmask; ++j) {
+            gl3_t den = gl3_scale(zz, gl_pow(wn, mask_off[j] & (n - 1)));
+            den.c[0] = gl_sub(x, den.c[0]); den.c[1] = gl_sub(0, den.c[1]); den.c[2] = gl_sub(0, den.c[2]);
+            gl3_t num, o, c;
+            memcpy(&o, ood_t + 3 * (size_t)j, 24); memcpy(&c, coeff_t + 3 * (size_t)j, 24);
+            num.c[0] = gl_sub(trace[mask_col[j]][i], o.c[0]); num.c[1] = gl_sub(0, o.c[1]); num.c[2] = gl_sub(0, o.c[2]);
+            acc = gl3_add(acc, gl3_mul(gl3_mul(c, num), gl3_inv(den)));
+        }
+        if (ncomp) {
+            gl3_t den = {{gl_sub(x, zcc.c[0]), gl_sub(0, zcc.c[1]), gl_sub(0, zcc.c[2])}};
+            const gl3_t dinv = gl3_inv(den);
+            for (unsigned k = 0; k < ncomp; ++k) {
+                gl3_t num, o, c;
+                memcpy(&o, ood_c + 3 * (size_t)k, 24); memcpy(&c, coeff_c + 3 * (size_t)k, 24);
+                num.c[0] = gl_sub(comp[k][i], o.c[0]); num.c[1] = gl_sub(0, o.c[1]); num.c[2] = gl_sub(0, o.c[2]);
+                acc = gl3_add(acc, gl3_mul(gl3_mul(c, num), dinv));
+            }
+        }
+        memcpy(out + 3 * i, &acc, 24);
+    }
+}

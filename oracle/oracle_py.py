@@ -379,3 +379,41 @@ def gl3_fri_fold(evals, fold, alpha, offset, unnormalised=False):
     lib().or_gl3_fri_fold.restype = None
     lib().or_gl3_fri_fold(_ptr(a), C.c_uint(L.bit_length() - 1), C.c_uint(fold), _ptr(al), C.c_uint64(offset), C.c_int(1 if unnormalised else 0), _ptr(out))
     return out
+
+
+def gl3_inv(a):
+    x = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.zeros(3, dtype=np.uint64)
+    lib().or_gl3_inv.restype = None
+    lib().or_gl3_inv(_ptr(x), _ptr(out))
+    return out
+
+
+def _colptrs(cols):
+    cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in cols]
+    return cols, (C.c_void_p * max(len(cols), 1))(*[c.ctypes.data for c in cols])
+
+
+def gl3_ood_eval(coeff_cols, cell_col, cell_off, z):
+    """P_{col_j}(z w_n^{off_j}), z in Fq3, for natural-order coefficient columns -> uint64[ncells, 3]"""
+    cols, ptrs = _colptrs(coeff_cols)
+    cc, co = np.ascontiguousarray(cell_col, dtype=np.uint32), np.ascontiguousarray(cell_off, dtype=np.uint32)
+    zz = np.ascontiguousarray(z, dtype=np.uint64)
+    out = np.zeros((len(cc), 3), dtype=np.uint64)
+    lib().or_gl3_ood_eval.restype = None
+    lib().or_gl3_ood_eval(ptrs, C.c_uint(len(cols[0]).bit_length() - 1), _ptr(cc), _ptr(co), C.c_uint(len(cc)), _ptr(zz), _ptr(out))
+    return out
+
+
+def gl3_deep_compose(trace_lde, comp_lde, log_n, log_blowup, offset, mask_col, mask_off, ood_t, coeff_t, ood_c, coeff_c, z, zc):
+    """the DEEP composition over Fq3, term by term -> uint64[N, 3]"""
+    tc, tp = _colptrs(trace_lde)
+    hc, hp = _colptrs(comp_lde)
+    mc, mo = np.ascontiguousarray(mask_col, dtype=np.uint32), np.ascontiguousarray(mask_off, dtype=np.uint32)
+    arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in (ood_t, coeff_t, ood_c, coeff_c, z, zc)]
+    N = 1 << (log_n + log_blowup)
+    out = np.zeros((N, 3), dtype=np.uint64)
+    lib().or_gl3_deep_compose.restype = None
+    lib().or_gl3_deep_compose(tp, hp, C.c_uint(len(hc)), C.c_uint(log_n), C.c_uint(log_blowup), C.c_uint64(offset), _ptr(mc), _ptr(mo),
+                              C.c_uint(len(mc)), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]), _ptr(arrs[4]), _ptr(arrs[5]), _ptr(out))
+    return out

@@ -216,6 +216,26 @@ class Context:
         check(self.lib.ss_fri_fold_gl64x3(self.handle, _ptr_of(evals), log_len, fold, a.ctypes.data_as(C.POINTER(C.c_uint64)), int(offset),
                                           flags, _ptr_of(out)))
 
+    def ood_eval_gl64x3(self, coeff_cols, log_n, cell_col, cell_off, z):
+        """P_{col_j}(z * w_n^{off_j}) for bit-reversed coefficient columns, z in Fq3 -> uint64[ncells, 3]"""
+        cc, co = np.ascontiguousarray(cell_col, dtype=np.uint32), np.ascontiguousarray(cell_off, dtype=np.uint32)
+        zz = np.ascontiguousarray(z, dtype=np.uint64)
+        out = np.zeros((len(cc), 3), dtype=np.uint64)
+        u32, u64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+        check(self.lib.ss_ood_eval_gl64x3(self.handle, _ptr_array(coeff_cols), len(coeff_cols), log_n, cc.ctypes.data_as(u32), co.ctypes.data_as(u32),
+                                          len(cc), zz.ctypes.data_as(u64), out.ctypes.data_as(u64)))
+        return out
+
+    def deep_compose_gl64x3(self, trace_cols, comp_cols, log_n, log_blowup, offset, mask_col, mask_off, ood_trace, coeff_trace, ood_comp,
+                            coeff_comp, z, z_comp, out):
+        """the DEEP composition over Fq3 (ss_deep_compose_gl64x3); out: [n * blowup][3] interleaved"""
+        u32, u64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+        mc, mo = np.ascontiguousarray(mask_col, dtype=np.uint32), np.ascontiguousarray(mask_off, dtype=np.uint32)
+        arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in (ood_trace, coeff_trace, ood_comp, coeff_comp, z, z_comp)]
+        check(self.lib.ss_deep_compose_gl64x3(self.handle, _ptr_array(trace_cols), len(trace_cols), _ptr_array(comp_cols) if comp_cols else None,
+                                              len(comp_cols), log_n, log_blowup, int(offset), mc.ctypes.data_as(u32), mo.ctypes.data_as(u32), len(mc),
+                                              *[a.ctypes.data_as(u64) for a in arrs], _ptr_of(out)))
+
     def pow_grind(self, coin_kind, digest, bits):
         nonce = C.c_uint64()
         check(self.lib.ss_pow_grind(self.handle, coin_kind, bytes(digest), bits, C.byref(nonce)))

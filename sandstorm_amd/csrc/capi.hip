@@ -266,7 +266,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -1394,6 +1394,156 @@ ss_status ss_lde_gl64(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols, 
         if (st != SS_OK) return st;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+// Fq3 arithmetic on the host (coefficients, constants): Fp[X] / (X^3 - 2)
+struct HGl3 { uint64_t c[3]; };
+static uint64_t gl_addh(uint64_t a, uint64_t b) { const uint64_t s = a + b; return (s < a || s >= GL_P) ? s - GL_P : s; }
+static uint64_t gl_subh(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (GL_P - b); }
+static HGl3 gl3_mulh(const HGl3 &a, const HGl3 &b) {
+    const uint64_t d0 = gl_mulh(a.c[0], b.c[0]), d1 = gl_addh(gl_mulh(a.c[0], b.c[1]), gl_mulh(a.c[1], b.c[0]));
+    const uint64_t d2 = gl_addh(gl_addh(gl_mulh(a.c[0], b.c[2]), gl_mulh(a.c[1], b.c[1])), gl_mulh(a.c[2], b.c[0]));
+    const uint64_t d3 = gl_addh(gl_mulh(a.c[1], b.c[2]), gl_mulh(a.c[2], b.c[1])), d4 = gl_mulh(a.c[2], b.c[2]);
+    return HGl3{{gl_addh(d0, gl_addh(d3, d3)), gl_addh(d1, gl_addh(d4, d4)), d2}};
+}
+static HGl3 gl3_addh(const HGl3 &a, const HGl3 &b) { return HGl3{{gl_addh(a.c[0], b.c[0]), gl_addh(a.c[1], b.c[1]), gl_addh(a.c[2], b.c[2])}}; }
+static HGl3 gl3_scaleh(const HGl3 &a, uint64_t s) { return HGl3{{gl_mulh(a.c[0], s), gl_mulh(a.c[1], s), gl_mulh(a.c[2], s)}}; }
+static bool gl3_valid(const uint64_t *v) { return v[0] < GL_P && v[1] < GL_P && v[2] < GL_P; }
+
+ss_status ss_ood_eval_gl64x3(ss_ctx *ctx, const uint64_t *const *d_coeffs_bitrev, uint32_t ncols, uint32_t log_n, const uint32_t *cell_col,
+                             const uint32_t *cell_off, uint32_t ncells, const uint64_t z[3], uint64_t *out) {
+    if (!ctx || !d_coeffs_bitrev || !z || (ncells && (!cell_col || !cell_off || !out))) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!gl_valid_log(log_n)) return fail(SS_ERR_INVALID, "log_n out of range");
+    if (!gl3_valid(z)) return fail(SS_ERR_INVALID, "z is not an element of the extension");
+    for (uint32_t j = 0; j < ncells; ++j)
+        if (cell_col[j] >= ncols) return fail(SS_ERR_INVALID, "cell %u names column %u", j, cell_col[j]);
+    if (!ncells) return SS_OK;
+    const uint64_t n = 1ull << log_n;
+    // P(z w^k) = sum_j (c_j z^j) w^(jk): scale the (bit-reversed) coefficients by z^j - three Fp arrays - and transform each; the
+    // k-th output of component t is the t-th coordinate of P(z w^k).  One table of powers serves every column.
+    const uint64_t *tw = nullptr;
+    ss_status st = gl_get_plan(ctx, log_n, false, 1, &tw);
+    if (st != SS_OK) return st;
+    st = ctx->ensure_scratch2(6 * n * 8 + (size_t)ncells * (8 + 24) + 64);
+    if (st != SS_OK) return st;
+    uint64_t *zp = (uint64_t *)ctx->scratch2, *comp = zp + 3 * n, *d_idx = comp + 3 * n, *d_vals = d_idx + ncells;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(launch_gl3_zpow_bitrev(s, zp, zp + n, zp + 2 * n, log_n, z));
+    std::vector<uint64_t> idx(ncells);
+    for (uint32_t col = 0; col < ncols; ++col) {
+        std::vector<uint32_t> mine;
+        for (uint32_t j = 0; j < ncells; ++j) if (cell_col[j] == col) mine.push_back(j);
+        if (mine.empty()) continue;
+        HIP_TRY(launch_gl3_scale_columns(s, d_coeffs_bitrev[col], zp, zp + n, zp + 2 * n, n, comp, comp + n, comp + 2 * n));
+        const void *src[3] = {comp, comp + n, comp + 2 * n};
+        void *dst[3] = {comp, comp + n, comp + 2 * n};
+        st = gl_run_forward(ctx, src, dst, 3, log_n, tw, 0);
+        if (st != SS_OK) return st;
+        for (size_t t = 0; t < mine.size(); ++t) idx[t] = cell_off[mine[t]] & (n - 1);
+        HIP_TRY(hipMemcpyAsync(d_idx, idx.data(), mine.size() * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(launch_gl3_gather(s, comp, comp + n, comp + 2 * n, d_idx, (uint32_t)mine.size(), d_vals));
+        std::vector<uint64_t> vals(3 * mine.size());
+        HIP_TRY(hipMemcpyAsync(vals.data(), d_vals, vals.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (size_t t = 0; t < mine.size(); ++t) memcpy(out + 3 * (size_t)mine[t], vals.data() + 3 * t, 24);
+    }
+    return SS_OK;
+}
+
+ss_status ss_deep_compose_gl64x3(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_t ntrace_cols, const uint64_t *const *d_comp_lde,
+                                 uint32_t ncomp, uint32_t log_n, uint32_t log_blowup, uint64_t offset, const uint32_t *mask_col,
+                                 const uint32_t *mask_off, uint32_t nmask, const uint64_t *ood_trace, const uint64_t *coeff_trace,
+                                 const uint64_t *ood_comp, const uint64_t *coeff_comp, const uint64_t z[3], const uint64_t z_comp[3],
+                                 uint64_t *d_out) {
+    if (!ctx || !d_trace_lde || !z || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (nmask && (!mask_col || !mask_off || !ood_trace || !coeff_trace)) return fail(SS_ERR_INVALID, "NULL mask argument");
+    if (ncomp && (!d_comp_lde || !ood_comp || !coeff_comp || !z_comp)) return fail(SS_ERR_INVALID, "NULL composition argument");
+    if (!gl_valid_log(log_n) || !gl_valid_log(log_n + log_blowup)) return fail(SS_ERR_INVALID, "size out of range");
+    if (ntrace_cols > (uint32_t)MAX_COLS || ncomp > 12) return fail(SS_ERR_UNSUPPORTED, "too many columns");
+    if (offset == 0 || offset >= GL_P) return fail(SS_ERR_INVALID, "the coset offset is not a non-zero field element");
+    if (!gl3_valid(z) || (ncomp && !gl3_valid(z_comp))) return fail(SS_ERR_INVALID, "z is not an element of the extension");
+    const uint64_t n = 1ull << log_n, N = n << log_blowup;
+    const uint64_t wn = gl_root_of_unity_host(log_n), wn_inv = gl_inv_host(wn);
+    // taps of the denominator table, column by column (csrc/deep.hip's layout), plus the column of constants -K_off
+    std::vector<uint32_t> order(nmask);
+    for (uint32_t j = 0; j < nmask; ++j) {
+        if (mask_col[j] >= ntrace_cols) return fail(SS_ERR_INVALID, "mask cell %u names column %u", j, mask_col[j]);
+        if (!gl3_valid(ood_trace + 3 * j) || !gl3_valid(coeff_trace + 3 * j)) return fail(SS_ERR_INVALID, "mask cell %u: value out of range", j);
+        order[j] = j;
+    }
+    auto off_of = [&](uint32_t j) { return mask_off[j] & (uint32_t)(n - 1); };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        return mask_col[x] != mask_col[y] ? mask_col[x] < mask_col[y] : off_of(x) < off_of(y);
+    });
+    std::map<uint32_t, HGl3> k_of;
+    std::vector<uint32_t> tap_shift, cdesc;
+    std::vector<uint64_t> tap_coef;
+    auto load3 = [](const uint64_t *p) { return HGl3{{p[0], p[1], p[2]}}; };
+    for (uint32_t t = 0; t < nmask;) {
+        const uint32_t col = mask_col[order[t]], first = (uint32_t)tap_shift.size();
+        for (; t < nmask && mask_col[order[t]] == col; ++t) {
+            const uint32_t j = order[t], offv = off_of(j);
+            const HGl3 cprime = gl3_scaleh(load3(coeff_trace + 3 * j), gl_pow_host(wn_inv, offv));
+            auto it = k_of.find(offv);
+            if (it == k_of.end()) it = k_of.emplace(offv, HGl3{{0, 0, 0}}).first;
+            it->second = gl3_addh(it->second, gl3_mulh(cprime, load3(ood_trace + 3 * j)));
+            tap_shift.push_back(offv);
+            for (int c = 0; c < 3; ++c) tap_coef.push_back(cprime.c[c]);
+        }
+        cdesc.push_back(col); cdesc.push_back(first); cdesc.push_back((uint32_t)tap_shift.size() - first);
+    }
+    if (nmask) {
+        const uint32_t first = (uint32_t)tap_shift.size();
+        for (auto &kv : k_of) { tap_shift.push_back(kv.first); for (int c = 0; c < 3; ++c) tap_coef.push_back(gl_subh(0, kv.second.c[c])); }
+        cdesc.push_back(0xffffffffu); cdesc.push_back(first); cdesc.push_back((uint32_t)tap_shift.size() - first);
+    }
+    const uint32_t ntaps = (uint32_t)tap_shift.size(), ncoldesc = (uint32_t)(cdesc.size() / 3);
+    HGl3 comp_k{{0, 0, 0}};
+    for (uint32_t k = 0; k < ncomp; ++k) {
+        if (!gl3_valid(ood_comp + 3 * k) || !gl3_valid(coeff_comp + 3 * k)) return fail(SS_ERR_INVALID, "composition cell %u: value out of range", k);
+        comp_k = gl3_addh(comp_k, gl3_mulh(load3(coeff_comp + 3 * k), load3(ood_comp + 3 * k)));
+    }
+    // device: tables D, Dc [n][3], the sub-coset values [3][n], then per component iNTT(n) + coset NTT(N), interleaved into d_out
+    const size_t small = (size_t)(ntaps + 1) * (4 + 24) + (size_t)(ncoldesc + 1) * 12 + (size_t)(ncomp + 1) * 24 + 256;
+    ss_status st = ctx->ensure_scratch(small);
+    if (st != SS_OK) return st;
+    st = ctx->ensure_scratch2((6 * n + 3 * n + 3 * N) * 8);
+    if (st != SS_OK) return st;
+    uint64_t *D = (uint64_t *)ctx->scratch2, *Dc = D + 3 * n, *sub = Dc + 3 * n, *lde = sub + 3 * n;
+    char *p = (char *)ctx->scratch;
+    uint64_t *d_tap_coef = (uint64_t *)p; p += (size_t)(ntaps + 1) * 24;
+    uint64_t *d_comp_coef = (uint64_t *)p; p += (size_t)(ncomp + 1) * 24;
+    uint32_t *d_tap_shift = (uint32_t *)p; p += (size_t)(ntaps + 1) * 4;
+    uint32_t *d_cdesc = (uint32_t *)p;
+    hipStream_t s = ctx->stream;
+    if (ntaps) {
+        HIP_TRY(hipMemcpyAsync(d_tap_coef, tap_coef.data(), (size_t)ntaps * 24, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_tap_shift, tap_shift.data(), (size_t)ntaps * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_cdesc, cdesc.data(), (size_t)ncoldesc * 12, hipMemcpyHostToDevice, s));
+    }
+    if (ncomp) HIP_TRY(hipMemcpyAsync(d_comp_coef, coeff_comp, (size_t)ncomp * 24, hipMemcpyHostToDevice, s));
+    const uint64_t *tw_inv = nullptr, *tw_fwd = nullptr;
+    st = gl_get_plan(ctx, log_n, true, offset, &tw_inv);
+    if (st != SS_OK) return st;
+    st = gl_get_plan(ctx, log_n + log_blowup, false, offset, &tw_fwd);
+    if (st != SS_OK) return st;
+    {
+        ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
+        HIP_TRY(launch_gl3_inverse_table(s, D, n, offset, wn, z));
+        if (ncomp) HIP_TRY(launch_gl3_inverse_table(s, Dc, n, offset, wn, z_comp));
+        HIP_TRY(launch_gl3_deep(s, d_trace_lde, ntrace_cols, d_comp_lde, ncomp, D, Dc, d_tap_shift, d_tap_coef, d_cdesc, ncoldesc, d_comp_coef,
+                                comp_k.c, n, log_blowup, sub, sub + n, sub + 2 * n));
+    }
+    const void *src[3] = {sub, sub + n, sub + 2 * n};
+    void *co[3] = {sub, sub + n, sub + 2 * n};
+    void *ev[3] = {lde, lde + N, lde + 2 * N};
+    st = gl_run_inverse(ctx, src, co, 3, log_n, tw_inv);           // values on offset * <w_n> -> bit-reversed coefficients
+    if (st != SS_OK) return st;
+    st = gl_run_forward(ctx, (const void *const *)co, ev, 3, log_n + log_blowup, tw_fwd, log_blowup);
+    if (st != SS_OK) return st;
+    HIP_TRY(launch_gl3_interleave(s, lde, lde + N, lde + 2 * N, N, d_out));
+    HIP_TRY(hipStreamSynchronize(s));
     return SS_OK;
 }
 

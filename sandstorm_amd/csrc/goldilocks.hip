@@ -310,4 +310,195 @@ hipError_t launch_gl3_fri_fold(hipStream_t st, const uint64_t *evals, uint32_t l
     return hipGetLastError();
 }
 
+
+// ---- DEEP over the cubic extension ------------------------------------------------------------------------------------
+// The out-of-domain point z and every coefficient live in Fq3, the trace in Fp.  Same structure as csrc/deep.hip: since
+// 1/(x - z w_n^k) = w_n^-k / (x w_n^-k - z), every denominator is ONE table D[m] = 1/(x_m - z) over the n-point sub-coset
+// read at a shifted index; a cell's trace value does not depend on its offset, so the sum runs column by column:
+//   out[m] = sum_c T_c[i] * S_c[m] + S_K[m] + Dc[m] * (sum_k cc_k H_k[i] - Kc),    S_c[m] = sum_taps c' * D[m - shift]
+// with Fq3 x Fq3 products inside S and Fp x Fq3 products outside.  An Fq3-valued column (extension trace, composition) is
+// three Fp columns whose cells carry the coefficients c, c X, c X^2 - the caller's expansion, the sum is linear.
+__device__ __forceinline__ Gl3 gl3_add(const Gl3 &a, const Gl3 &b) { return Gl3{{gl_add(a.c[0], b.c[0]), gl_add(a.c[1], b.c[1]), gl_add(a.c[2], b.c[2])}}; }
+__device__ __forceinline__ Gl3 gl3_sub(const Gl3 &a, const Gl3 &b) { return Gl3{{gl_sub(a.c[0], b.c[0]), gl_sub(a.c[1], b.c[1]), gl_sub(a.c[2], b.c[2])}}; }
+__device__ __forceinline__ Gl3 gl3_scale(const Gl3 &a, uint64_t s) { return Gl3{{gl_mul(a.c[0], s), gl_mul(a.c[1], s), gl_mul(a.c[2], s)}}; }
+__device__ __forceinline__ Gl3 gl3_load(const uint64_t *p) { return Gl3{{p[0], p[1], p[2]}}; }
+__device__ __forceinline__ uint64_t gl_pow_dev(uint64_t a, uint64_t e) {
+    uint64_t r = 1;
+    for (; e; e >>= 1) { if (e & 1) r = gl_mul(r, a); a = gl_mul(a, a); }
+    return r;
+}
+
+// D[m] = 1 / (x0 * w^m - z), m < len, interleaved [len][3].  a = (x - z0, -z1, -z2); a^-1 = adj(a) / N(a) with
+// adj = (a0^2 - 2 a1 a2, 2 a2^2 - a0 a1, a1^2 - a0 a2) and N = a0 adj0 + 2 a2 adj1 + 2 a1 adj2 in Fp; the norms of a
+// lane's GL3_INV_CHUNK consecutive entries are inverted together (Montgomery's trick, one Fermat inversion per lane).
+// x = z0 with z1 = z2 = 0 (z on the domain) has no inverse: the entry is 0, as the 252-bit table's is.
+static constexpr int GL3_INV_CHUNK = 8;
+__global__ __launch_bounds__(256) void gl3_inverse_table_kernel(uint64_t *__restrict__ D, uint64_t len, uint64_t x0, uint64_t w, Gl3 z) {
+    const uint64_t lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, m0 = lane * GL3_INV_CHUNK;
+    if (m0 >= len) return;
+    uint64_t x = gl_mul(x0, gl_pow_dev(w, m0));
+    Gl3 adj[GL3_INV_CHUNK];
+    uint64_t norm[GL3_INV_CHUNK], prefix[GL3_INV_CHUNK];
+    uint64_t run = 1;
+#pragma unroll
+    for (int k = 0; k < GL3_INV_CHUNK; ++k) {
+        const uint64_t a0 = gl_sub(x, z.c[0]), a1 = gl_sub(0, z.c[1]), a2 = gl_sub(0, z.c[2]);
+        const uint64_t a12 = gl_mul(a1, a2), a22 = gl_mul(a2, a2);
+        adj[k].c[0] = gl_sub(gl_mul(a0, a0), gl_add(a12, a12));
+        adj[k].c[1] = gl_sub(gl_add(a22, a22), gl_mul(a0, a1));
+        adj[k].c[2] = gl_sub(gl_mul(a1, a1), gl_mul(a0, a2));
+        const uint64_t t1 = gl_mul(a2, adj[k].c[1]), t2 = gl_mul(a1, adj[k].c[2]);
+        norm[k] = gl_add(gl_mul(a0, adj[k].c[0]), gl_add(gl_add(t1, t1), gl_add(t2, t2)));
+        prefix[k] = run;
+        if (norm[k]) run = gl_mul(run, norm[k]);
+        x = gl_mul(x, w);
+    }
+    uint64_t inv = gl_pow_dev(run, GL_P - 2);
+#pragma unroll
+    for (int k = GL3_INV_CHUNK - 1; k >= 0; --k) {
+        const uint64_t ni = norm[k] ? gl_mul(inv, prefix[k]) : 0;
+        if (norm[k]) inv = gl_mul(inv, norm[k]);
+        if (m0 + k < len) {
+            const Gl3 r = gl3_scale(adj[k], ni);
+            D[3 * (m0 + k)] = r.c[0]; D[3 * (m0 + k) + 1] = r.c[1]; D[3 * (m0 + k) + 2] = r.c[2];
+        }
+    }
+}
+
+struct Gl3DeepArgs {
+    const uint64_t *trace[MAX_COLS];
+    const uint64_t *comp[12];
+    const uint64_t *D, *Dc;          // [n][3]
+    const uint32_t *tap_shift;       // [ntaps] by column, then by shift (sub-coset units)
+    const uint64_t *tap_coef;        // [ntaps][3]: coeff * w_n^-off; the constant column: -K_off
+    const uint32_t *col_desc;        // [ncoldesc][3]: trace column (0xffffffff: constants), first tap, count
+    const uint64_t *comp_coef;       // [ncomp][3]
+    Gl3 comp_k;
+    uint32_t ncoldesc, ncomp, log_stride, mask;
+    uint64_t count;
+};
+__global__ __launch_bounds__(256) void gl3_deep_kernel(Gl3DeepArgs a, uint64_t *__restrict__ out0, uint64_t *__restrict__ out1, uint64_t *__restrict__ out2) {
+    for (uint64_t m = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; m < a.count; m += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = m << a.log_stride;
+        Gl3 acc = {{0, 0, 0}};
+        for (uint32_t k = 0; k < a.ncoldesc; ++k) {
+            const uint32_t col = a.col_desc[3 * k], first = a.col_desc[3 * k + 1], cnt = a.col_desc[3 * k + 2];
+            Gl3 S = {{0, 0, 0}};
+            for (uint32_t j = first; j < first + cnt; ++j)
+                S = gl3_add(S, gl3_mul(gl3_load(a.tap_coef + 3 * (size_t)j), gl3_load(a.D + 3 * (size_t)(((uint32_t)m - a.tap_shift[j]) & a.mask))));
+            if (col == 0xffffffffu) acc = gl3_add(acc, S);
+            else {
+                const uint64_t *tp = a.trace[0];
+#pragma unroll
+                for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) tp = a.trace[c];
+                acc = gl3_add(acc, gl3_scale(S, tp[i]));
+            }
+        }
+        if (a.ncomp) {
+            Gl3 inner = {{0, 0, 0}};
+            for (uint32_t k = 0; k < a.ncomp; ++k) {
+                const uint64_t *hp = a.comp[0];
+#pragma unroll
+                for (int c = 1; c < 12; ++c) if (k == (uint32_t)c) hp = a.comp[c];
+                inner = gl3_add(inner, gl3_scale(gl3_load(a.comp_coef + 3 * (size_t)k), hp[i]));
+            }
+            acc = gl3_add(acc, gl3_mul(gl3_sub(inner, a.comp_k), gl3_load(a.Dc + 3 * m)));
+        }
+        out0[m] = acc.c[0]; out1[m] = acc.c[1]; out2[m] = acc.c[2];
+    }
+}
+
+// three planar component columns -> interleaved [len][3]
+__global__ void gl3_interleave_kernel(const uint64_t *__restrict__ c0, const uint64_t *__restrict__ c1, const uint64_t *__restrict__ c2,
+                                      uint64_t len, uint64_t *__restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) {
+        out[3 * i] = c0[i]; out[3 * i + 1] = c1[i]; out[3 * i + 2] = c2[i];
+    }
+}
+
+// zp[q] = z^bitrev(q), q < 2^log_n, planar [3][n]: what a bit-reversed coefficient array is scaled by before the transform
+// that evaluates it on z * <w_n>.  A lane walks 64 consecutive q: bitrev(q) = bitrev6(q & 63) << (log_n - 6) | bitrev(q >> 6),
+// so z^bitrev(q) = z^bitrev(q >> 6) * (z^(2^(log_n - 6)))^bitrev6(q & 63): one square-and-multiply per lane, then a 64-entry table.
+__global__ __launch_bounds__(256) void gl3_zpow_bitrev_kernel(uint64_t *__restrict__ zp0, uint64_t *__restrict__ zp1, uint64_t *__restrict__ zp2,
+                                                              uint32_t log_n, Gl3 z) {
+    __shared__ uint64_t tab[64][3];                       // (z^(2^(log_n - lo)))^e, e < 2^lo
+    const uint32_t lo = log_n < 6 ? log_n : 6;
+    if (threadIdx.x == 0) {
+        Gl3 base = z;
+        for (uint32_t b = 0; b + lo < log_n; ++b) base = gl3_mul(base, base);
+        Gl3 p = {{1, 0, 0}};
+        for (uint32_t e = 0; e < (1u << lo); ++e) { tab[e][0] = p.c[0]; tab[e][1] = p.c[1]; tab[e][2] = p.c[2]; p = gl3_mul(p, base); }
+    }
+    __syncthreads();
+    const uint64_t groups = 1ull << (log_n - lo);
+    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < groups; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e_hi = log_n > lo ? (__brevll(g) >> (64u - (log_n - lo))) : 0;     // bitrev of the high part: the exponent's low bits
+        Gl3 hi = {{1, 0, 0}}, sq = z;
+        for (uint64_t e = e_hi; e; e >>= 1) { if (e & 1) hi = gl3_mul(hi, sq); sq = gl3_mul(sq, sq); }
+        for (uint32_t t = 0; t < (1u << lo); ++t) {
+            const uint32_t e_lo = __brev(t) >> (32u - lo);
+            const Gl3 v = gl3_mul(hi, Gl3{{tab[e_lo][0], tab[e_lo][1], tab[e_lo][2]}});
+            const uint64_t q = (g << lo) | t;
+            zp0[q] = v.c[0]; zp1[q] = v.c[1]; zp2[q] = v.c[2];
+        }
+    }
+}
+// out_k[q] = coef[q] * zp_k[q]
+__global__ void gl3_scale_columns_kernel(const uint64_t *__restrict__ coef, const uint64_t *__restrict__ zp0, const uint64_t *__restrict__ zp1,
+                                         const uint64_t *__restrict__ zp2, uint64_t n, uint64_t *__restrict__ o0, uint64_t *__restrict__ o1, uint64_t *__restrict__ o2) {
+    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t c = coef[q];
+        o0[q] = gl_mul(c, zp0[q]); o1[q] = gl_mul(c, zp1[q]); o2[q] = gl_mul(c, zp2[q]);
+    }
+}
+// out[3 j + k] = comp_k[idx[j]]
+__global__ void gl3_gather_kernel(const uint64_t *__restrict__ c0, const uint64_t *__restrict__ c1, const uint64_t *__restrict__ c2,
+                                  const uint64_t *__restrict__ idx, uint32_t count, uint64_t *__restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    out[3 * j] = c0[idx[j]]; out[3 * j + 1] = c1[idx[j]]; out[3 * j + 2] = c2[idx[j]];
+}
+
+static uint32_t gl_blocks(uint64_t items, uint32_t per_block = 256, uint32_t cap = 16384) {
+    uint64_t b = (items + per_block - 1) / per_block;
+    return (uint32_t)(b == 0 ? 1 : b > cap ? cap : b);
+}
+hipError_t launch_gl3_inverse_table(hipStream_t st, uint64_t *D, uint64_t len, uint64_t x0, uint64_t w, const uint64_t z[3]) {
+    const uint64_t lanes = (len + GL3_INV_CHUNK - 1) / GL3_INV_CHUNK;
+    hipLaunchKernelGGL(gl3_inverse_table_kernel, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, D, len, x0, w, Gl3{{z[0], z[1], z[2]}});
+    return hipGetLastError();
+}
+hipError_t launch_gl3_deep(hipStream_t st, const uint64_t *const *trace, uint32_t ntrace, const uint64_t *const *comp, uint32_t ncomp,
+                           const uint64_t *D, const uint64_t *Dc, const uint32_t *tap_shift, const uint64_t *tap_coef, const uint32_t *col_desc,
+                           uint32_t ncoldesc, const uint64_t *comp_coef, const uint64_t comp_k[3], uint64_t count, uint32_t log_stride,
+                           uint64_t *out0, uint64_t *out1, uint64_t *out2) {
+    Gl3DeepArgs a;
+    for (int c = 0; c < MAX_COLS; ++c) a.trace[c] = c < (int)ntrace ? trace[c] : nullptr;
+    for (int c = 0; c < 12; ++c) a.comp[c] = c < (int)ncomp ? comp[c] : nullptr;
+    a.D = D; a.Dc = Dc; a.tap_shift = tap_shift; a.tap_coef = tap_coef; a.col_desc = col_desc; a.ncoldesc = ncoldesc;
+    a.comp_coef = comp_coef; a.comp_k = Gl3{{comp_k[0], comp_k[1], comp_k[2]}}; a.ncomp = ncomp; a.log_stride = log_stride;
+    a.mask = (uint32_t)(count - 1); a.count = count;
+    hipLaunchKernelGGL(gl3_deep_kernel, dim3(gl_blocks(count, 256, 8192)), dim3(256), 0, st, a, out0, out1, out2);
+    return hipGetLastError();
+}
+hipError_t launch_gl3_interleave(hipStream_t st, const uint64_t *c0, const uint64_t *c1, const uint64_t *c2, uint64_t len, uint64_t *out) {
+    hipLaunchKernelGGL(gl3_interleave_kernel, dim3(gl_blocks(len)), dim3(256), 0, st, c0, c1, c2, len, out);
+    return hipGetLastError();
+}
+hipError_t launch_gl3_zpow_bitrev(hipStream_t st, uint64_t *zp0, uint64_t *zp1, uint64_t *zp2, uint32_t log_n, const uint64_t z[3]) {
+    const uint64_t groups = 1ull << (log_n < 6 ? 0 : log_n - 6);
+    hipLaunchKernelGGL(gl3_zpow_bitrev_kernel, dim3(gl_blocks(groups, 256, 4096)), dim3(256), 0, st, zp0, zp1, zp2, log_n, Gl3{{z[0], z[1], z[2]}});
+    return hipGetLastError();
+}
+hipError_t launch_gl3_scale_columns(hipStream_t st, const uint64_t *coef, const uint64_t *zp0, const uint64_t *zp1, const uint64_t *zp2, uint64_t n,
+                                    uint64_t *o0, uint64_t *o1, uint64_t *o2) {
+    hipLaunchKernelGGL(gl3_scale_columns_kernel, dim3(gl_blocks(n)), dim3(256), 0, st, coef, zp0, zp1, zp2, n, o0, o1, o2);
+    return hipGetLastError();
+}
+hipError_t launch_gl3_gather(hipStream_t st, const uint64_t *c0, const uint64_t *c1, const uint64_t *c2, const uint64_t *idx, uint32_t count, uint64_t *out) {
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(gl3_gather_kernel, dim3((count + 127) / 128), dim3(128), 0, st, c0, c1, c2, idx, count, out);
+    return hipGetLastError();
+}
+
 }  // namespace ss

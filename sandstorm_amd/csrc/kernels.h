@@ -107,6 +107,16 @@ hipError_t launch_gl_twiddles(hipStream_t st, uint64_t *tw, const uint64_t *pow_
 hipError_t launch_gl_bitrev_copy(hipStream_t st, const uint64_t *src, uint64_t *dst, uint32_t log_n);
 hipError_t launch_gl3_fri_fold(hipStream_t st, const uint64_t *evals, uint32_t log_len, uint32_t fold, const uint64_t alpha[3], uint64_t offset,
                                bool unnormalised, uint64_t *out);
+hipError_t launch_gl3_inverse_table(hipStream_t st, uint64_t *D, uint64_t len, uint64_t x0, uint64_t w, const uint64_t z[3]);
+hipError_t launch_gl3_deep(hipStream_t st, const uint64_t *const *trace, uint32_t ntrace, const uint64_t *const *comp, uint32_t ncomp,
+                           const uint64_t *D, const uint64_t *Dc, const uint32_t *tap_shift, const uint64_t *tap_coef, const uint32_t *col_desc,
+                           uint32_t ncoldesc, const uint64_t *comp_coef, const uint64_t comp_k[3], uint64_t count, uint32_t log_stride,
+                           uint64_t *out0, uint64_t *out1, uint64_t *out2);
+hipError_t launch_gl3_interleave(hipStream_t st, const uint64_t *c0, const uint64_t *c1, const uint64_t *c2, uint64_t len, uint64_t *out);
+hipError_t launch_gl3_zpow_bitrev(hipStream_t st, uint64_t *zp0, uint64_t *zp1, uint64_t *zp2, uint32_t log_n, const uint64_t z[3]);
+hipError_t launch_gl3_scale_columns(hipStream_t st, const uint64_t *coef, const uint64_t *zp0, const uint64_t *zp1, const uint64_t *zp2, uint64_t n,
+                                    uint64_t *o0, uint64_t *o1, uint64_t *o2);
+hipError_t launch_gl3_gather(hipStream_t st, const uint64_t *c0, const uint64_t *c1, const uint64_t *c2, const uint64_t *idx, uint32_t count, uint64_t *out);
 
 // ---- quotient.hip
 // what ss_eval_quotient knows and the device program needs resolved (device addresses, sizes)

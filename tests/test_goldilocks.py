@@ -130,3 +130,112 @@ def test_fri_fold_vs_oracle(ctx, oracle, fold, log_len):
         out = ctx.alloc(24 * (L // fold))
         ctx.fri_fold_gl64x3(ctx.column(evals), log_len, fold, alpha, 7, out, flags)
         assert np.array_equal(out.download(np.uint64, (L // fold, 3)), oracle.gl3_fri_fold(evals, fold, alpha, 7, un))
+
+
+# ---- DEEP over the cubic extension ---------------------------------------------------------------------------------------
+def _mul3(x, y):
+    d = [0] * 5
+    for i in range(3):
+        for j in range(3):
+            d[i + j] += int(x[i]) * int(y[j])
+    return [(d[0] + 2 * d[3]) % GL_P, (d[1] + 2 * d[4]) % GL_P, d[2] % GL_P]
+
+
+def _deep_case(rng, oracle, log_n, lb, ncols, ncomp, offsets):
+    """random trace / composition polynomials, a mask over `offsets`, honest out-of-domain values"""
+    n = 1 << log_n
+    trace = [rand_fp(rng, n) for _ in range(ncols)]
+    lde, coeffs = zip(*[oracle.gl_lde(t, lb, 7) for t in trace])
+    comp_coeffs = [rand_fp(rng, n) for _ in range(ncomp)]
+    comp_lde = [oracle.gl_ntt(np.concatenate([c, np.zeros((n << lb) - n, dtype=np.uint64)]), offset=7) for c in comp_coeffs]
+    mask = [(c, o) for c in range(ncols) for o in offsets if (c + o) % 3 != 1] or [(0, 0)]
+    mc, mo = [c for c, _ in mask], [o for _, o in mask]
+    z, zc = rand_fp(rng, 3), rand_fp(rng, 3)
+    ood_t = oracle.gl3_ood_eval(coeffs, mc, mo, z)
+    ood_c = oracle.gl3_ood_eval(comp_coeffs, list(range(ncomp)), [0] * ncomp, zc) if ncomp else np.zeros((0, 3), dtype=np.uint64)
+    ct = np.stack([rand_fp(rng, 3) for _ in mask])
+    cc = np.stack([rand_fp(rng, 3) for _ in range(ncomp)]) if ncomp else np.zeros((0, 3), dtype=np.uint64)
+    return trace, lde, coeffs, comp_coeffs, comp_lde, mc, mo, z, zc, ood_t, ood_c, ct, cc
+
+
+def test_deep_oracle_is_the_definition(oracle):
+    rng = np.random.default_rng(5)
+    a = rand_fp(rng, 3)
+    assert _mul3(a, oracle.gl3_inv(a)) == [1, 0, 0]
+    log_n, lb = 4, 1
+    n, N = 1 << log_n, 2 << log_n
+    trace, lde, coeffs, comp_coeffs, comp_lde, mc, mo, z, zc, ood_t, ood_c, ct, cc = _deep_case(rng, oracle, log_n, lb, 2, 1, [0, 1, 5])
+    w = pow(7, (GL_P - 1) // n, GL_P)
+    for j, (c, o) in enumerate(zip(mc, mo)):                         # Horner in Fq3 == the power sum in Python integers
+        pt = [int(v) * pow(w, o, GL_P) % GL_P for v in z]
+        acc, pw = [0, 0, 0], [1, 0, 0]
+        for k in range(n):
+            acc = [(acc[t] + int(coeffs[c][k]) * pw[t]) % GL_P for t in range(3)]
+            pw = _mul3(pw, pt)
+        assert [int(v) for v in ood_t[j]] == acc
+    # honest out-of-domain values make every DEEP term a polynomial: the composition has degree < n on the LDE domain
+    deep = oracle.gl3_deep_compose(lde, comp_lde, log_n, lb, 7, mc, mo, ood_t, ct, ood_c, cc, z, zc)
+    for t in range(3):
+        back = oracle.gl_ntt(deep[:, t].copy(), inverse=True, offset=7)
+        assert not back[n:].any() and back[:n].any()
+    # ... and a wrong one does not
+    bad = ood_t.copy()
+    bad[0, 0] = (int(bad[0, 0]) + 1) % GL_P
+    deep = oracle.gl3_deep_compose(lde, comp_lde, log_n, lb, 7, mc, mo, bad, ct, ood_c, cc, z, zc)
+    assert oracle.gl_ntt(deep[:, 0].copy(), inverse=True, offset=7)[n:].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,lb,ncols,ncomp,offsets", [(3, 1, 1, 0, [0]), (6, 1, 3, 2, [0, 1, 2, 17]), (10, 2, 5, 3, [0, 1, 4, 15, 16, 513]),
+                                                           (12, 1, 6, 6, [0, 1, 2, 3, 8, 70, 2058])])
+def test_deep_and_ood_vs_oracle(ctx, oracle, log_n, lb, ncols, ncomp, offsets):
+    rng = np.random.default_rng(100 + log_n)
+    n, N = 1 << log_n, (1 << log_n) << lb
+    trace, lde, coeffs, comp_coeffs, comp_lde, mc, mo, z, zc, ood_t, ood_c, ct, cc = _deep_case(rng, oracle, log_n, lb, ncols, ncomp, offsets)
+    rev = np.array([int(format(i, "0%db" % log_n)[::-1], 2) for i in range(n)])
+    d_co = [ctx.column(c[rev]) for c in coeffs]                      # bit-reversed, as ss_lde_gl64 leaves them
+    assert np.array_equal(ctx.ood_eval_gl64x3(d_co, log_n, mc, mo, z), ood_t)
+    out = ctx.alloc(24 * N)
+    ctx.deep_compose_gl64x3([ctx.column(c) for c in lde], [ctx.column(c) for c in comp_lde], log_n, lb, 7, mc, mo, ood_t, ct, ood_c, cc, z, zc, out)
+    assert np.array_equal(out.download(np.uint64, (N, 3)), oracle.gl3_deep_compose(lde, comp_lde, log_n, lb, 7, mc, mo, ood_t, ct, ood_c, cc, z, zc))
+    # dishonest out-of-domain values: still the definition (the quotients are then not polynomials; the sub-coset composition +
+    # extension agrees with the term-by-term values only on the sub-coset rows)
+    bad = ood_t.copy()
+    bad[0, 1] = (int(bad[0, 1]) + 1) % GL_P
+    ctx.deep_compose_gl64x3([ctx.column(c) for c in lde], [ctx.column(c) for c in comp_lde], log_n, lb, 7, mc, mo, bad, ct, ood_c, cc, z, zc, out)
+    want = oracle.gl3_deep_compose(lde, comp_lde, log_n, lb, 7, mc, mo, bad, ct, ood_c, cc, z, zc)
+    assert np.array_equal(out.download(np.uint64, (N, 3))[:: 1 << lb], want[:: 1 << lb])
+
+
+@pytest.mark.gpu
+def test_deep_at_the_benchmark_size_feeds_fri(ctx, oracle):
+    """2^20-row columns (5 trace + 1 extension-field column = 8 Fp columns, blowup 2): the composed evaluations interpolate to
+    degree < n per component, and one FRI fold of them has degree < n / 8"""
+    from sandstorm_amd import backend as be
+    log_n, lb, ncols = 20, 1, 8
+    n, N = 1 << log_n, 2 << log_n
+    rng = np.random.default_rng(77)
+    cols = [ctx.column(rand_fp(rng, n)) for _ in range(ncols)]
+    ev = [ctx.alloc(8 * N) for _ in range(ncols)]
+    co = [ctx.alloc(8 * n) for _ in range(ncols)]
+    ctx.lde_gl64(cols, log_n, lb, 7, ev, co)
+    mask = [(c, o) for c in range(ncols) for o in (0, 1, 2, 16, 33)]
+    mc, mo = [c for c, _ in mask], [o for _, o in mask]
+    z = rand_fp(rng, 3)
+    ood = ctx.ood_eval_gl64x3(co, log_n, mc, mo, z)
+    coef = np.stack([rand_fp(rng, 3) for _ in mask])
+    out = ctx.alloc(24 * N)
+    ctx.deep_compose_gl64x3(ev, [], log_n, lb, 7, mc, mo, ood, coef, np.zeros((0, 3), dtype=np.uint64), np.zeros((0, 3), dtype=np.uint64), z, z, out)
+    deep = out.download(np.uint64, (N, 3))
+    for t in range(3):
+        comp = ctx.column(np.ascontiguousarray(deep[:, t]))
+        ctx.ntt_gl64([comp], log_n + lb, be.INVERSE, 7, be.NATURAL, be.NATURAL)
+        got = comp.download(np.uint64, (N,))
+        assert not got[n:].any() and got[:n].any()
+    folded = ctx.alloc(24 * (N // 8))
+    ctx.fri_fold_gl64x3(out, log_n + lb, 8, rand_fp(rng, 3), 7, folded)
+    f = folded.download(np.uint64, (N // 8, 3))
+    comp = ctx.column(np.ascontiguousarray(f[:, 0]))
+    ctx.ntt_gl64([comp], log_n + lb - 3, be.INVERSE, pow(7, 8, GL_P), be.NATURAL, be.NATURAL)
+    got = comp.download(np.uint64, (N // 8,))
+    assert not got[n // 8:].any() and got[:n // 8].any()
