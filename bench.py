@@ -44,9 +44,10 @@ WORKLOADS = {
     # steps) with the REAL recursive AIR; C++ host from the raw files (host/trace_recursive.cpp, host/air_recursive.cpp)
     "array_sum_example": ("recursive-real", 14),
     "recursive_2p7": ("recursive", 7),      # 128 steps: the size of the only figure the reference publishes (186 ms)
-    # BASELINE.json configs[4]: the 64-bit field variant at 2^20 steps.  What exists for that field is the low-degree extension
-    # and the FRI fold (ss_lde_gl64, ss_fri_fold_gl64x3; the experimental `plain` layout's AIR is not built): a step = the LDE of
-    # 10 columns of 2^24 rows, blowup 2 - the NTT work of that configuration's trace commitment
+    # BASELINE.json configs[4]: the 64-bit field variant at 2^20 steps.  What exists for that field is the low-degree extension,
+    # the out-of-domain evaluation / DEEP composition and the FRI fold over Fq3 (ss_lde_gl64, ss_ood_eval_gl64x3,
+    # ss_deep_compose_gl64x3, ss_fri_fold_gl64x3; the experimental `plain` layout's AIR is not built): a step = the LDE of 10
+    # columns of 2^24 rows, blowup 2 - the NTT work of that configuration's trace commitment; the other kernels are timed beside it
     "goldilocks_lde_2p20": ("goldilocks", 20),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -167,6 +168,40 @@ def bench_goldilocks(args, log_steps, rank, local_rank, world, device):
     dt = time.perf_counter() - t0
     ntt_ms, launches = ctx.profile_read(be.PROF_NTT_PASS)
     ctx.profile(False)
+    # the field's other kernels on the same columns, timed beside the headline (not part of `value`): out-of-domain
+    # evaluation and DEEP composition over Fq3 for a plain-layout-sized mask, then the FRI layers down to <= 16 x blowup points
+    other = {}
+    if rank == 0:
+        def timed(name, fn):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            other[name] = (time.perf_counter() - t) * 1e3
+        rng = np.random.default_rng(3)
+        mask = [(c, o) for c in range(ncols) for o in (0, 1, 2, 3, 16)]
+        mc, mo = [c for c, _ in mask], [o for _, o in mask]
+        felt3 = lambda k: rng.integers(0, 2**62, size=(k, 3), dtype=np.uint64)
+        z = felt3(1)[0]
+        ood = [None]
+        timed("ood_eval_fq3", lambda: ood.__setitem__(0, ctx.ood_eval_gl64x3([coeffs[c] for c in range(ncols)], log_n, mc, mo, z)))
+        deep = torch.zeros(((n << lb), 3), dtype=torch.int64, device=device)
+        coef, none = felt3(len(mask)), np.zeros((0, 3), dtype=np.uint64)
+        timed("deep_compose_fq3", lambda: ctx.deep_compose_gl64x3([evals[c] for c in range(ncols)], [], log_n, lb, 7, mc, mo, ood[0], coef, none, none, z, z, deep))
+        layers = [deep]
+        ll = log_n + lb
+        while (1 << ll) > 16 << lb:
+            layers.append(torch.zeros(((1 << ll) // 8, 3), dtype=torch.int64, device=device))
+            ll -= 3
+
+        def fold_all():
+            ll, off = log_n + lb, 7
+            for k in range(len(layers) - 1):
+                ctx.fri_fold_gl64x3(layers[k], ll, 8, felt3(1)[0], off, layers[k + 1], be.FRI_UNNORMALISED)
+                ll, off = ll - 3, pow(off, 8, 2**64 - 2**32 + 1)
+        timed("fri_fold_fq3_all_layers", fold_all)
+        other["mask_cells"], other["fri_layers"] = len(mask), len(layers) - 1
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -183,8 +218,10 @@ def bench_goldilocks(args, log_steps, rank, local_rank, world, device):
                "dtype": "u64 (p = 2^64 - 2^32 + 1)", "data": "synthetic", "ntt_gfield_ops_per_s": world * ops / kern_s / 1e9,
                "config": {"workload": args.workload, "field": "p = 2^64 - 2^32 + 1 (Goldilocks), 8-byte elements", "columns": ncols,
                           "trace_rows_log2": log_n, "blowup": 2, "per_gpu": "one independent batch per rank",
-                          "note": "the LDE of BASELINE.json configs[4]'s trace; the rest of that configuration (the `plain` layout's "
-                                  "AIR over Fq3) is not built"},
+                          "other_stages_ms": other,
+                          "note": "the LDE of BASELINE.json configs[4]'s trace; out-of-domain evaluation, DEEP composition and the FRI folds "
+                                  "over Fq3 are timed beside it (other_stages_ms); the rest of that configuration (the `plain` layout's "
+                                  "constraints over Fq3, SHA-256 trees, ministark's generic coin) is not built"},
                "roofline": {"bound": "hbm", "kernel": "ss::gl_ntt_pass_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "launches": launches, "avg_launch_ms": ntt_ms / max(1, launches),
                             "algorithmic_bytes_per_launch": algo / max(1.0, passes),
