@@ -274,6 +274,12 @@ ss_status ss_fri_fold_gl64x3(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_
  *   sum_j coeff_trace[j] (T_{col_j}(x_i) - ood_trace[j]) / (x_i - z w_n^{off_j})
  *   + sum_k coeff_comp[k] (H_k(x_i) - ood_comp[k]) / (x_i - z_comp),      x_i = offset * w_{n blowup}^i,
  *   composed on the n-point sub-coset and extended per component (the polynomial has degree < n). */
+/* Q1 over the cubic extension: the program format of ss_eval_quotient (ss_air_program above) with accumulators, scratch
+ * slots and constants in Fq3 - prog->consts holds n_consts x 3 values < p - and trace cells, tables (prog->d_tables: 8-byte
+ * elements) and x in Fp, read into the first coordinate.  d_out: [n * blowup][3] interleaved.  Interpreted (no compiled
+ * kernel for this field's experimental layout). */
+ss_status ss_eval_quotient_gl64x3(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols, uint32_t ncols,
+                                  uint32_t log_n, uint32_t log_blowup, uint64_t offset, uint64_t *d_out);
 ss_status ss_ood_eval_gl64x3(ss_ctx *ctx, const uint64_t *const *d_coeffs_bitrev, uint32_t ncols, uint32_t log_n,
                              const uint32_t *cell_col, const uint32_t *cell_off, uint32_t ncells, const uint64_t z[3],
                              uint64_t *out);

@@ -197,3 +197,49 @@ void or_gl3_deep_compose(const uint64_t *const *trace, const uint64_t *const *co
         memcpy(out + 3 * i, &acc, 24);
     }
 }
+
+/* ---- the constraint program over Fq3 (include/sandstorm_hip.h ss_air_program; ss_eval_quotient_gl64x3): accumulators, slots
+ * and constants in Fq3, trace cells / tables / x in Fp.  One point at a time. */
+void or_gl3_eval_program(const uint32_t *code, uint32_t n_instr, const uint64_t *consts3, uint32_t n_slots, const uint64_t *tables,
+                         const uint32_t *table_desc, const uint64_t *const *lde_cols, unsigned log_n, unsigned log_blowup, uint64_t offset,
+                         uint64_t *out) {
+    const size_t N = (size_t)1 << (log_n + log_blowup);
+    const uint64_t wN = or_gl_root_of_unity(log_n + log_blowup);
+#pragma omp parallel if (N >= 256)
+    {
+        gl3_t *slots = (gl3_t *)calloc(n_slots ? n_slots : 1, sizeof(gl3_t));
+#pragma omp for schedule(static)
+        for (size_t i = 0; i < N; ++i) {
+            gl3_t acc[4];
+            memset(acc, 0, sizeof acc);
+            const uint64_t x = gl_mul(offset, gl_pow(wN, i));
+            for (uint32_t pc = 0; pc < n_instr; ++pc) {
+                const uint32_t w0 = code[2 * pc], w1 = code[2 * pc + 1];
+                const unsigned op = w0 & 0xff, d = (w0 >> 8) & 0xf, kind = (w0 >> 12) & 0xf;
+                gl3_t src = {{0, 0, 0}};
+                if (op <= 4) {
+                    switch (kind) {
+                    case 0: src = acc[w1 & 3]; break;
+                    case 1: src = slots[w1]; break;
+                    case 2: memcpy(&src, consts3 + 3 * (size_t)w1, 24); break;
+                    case 3: src.c[0] = lde_cols[w1 >> 24][(i + ((size_t)(w1 & 0xffffff) << log_blowup)) & (N - 1)]; break;
+                    case 4: src.c[0] = tables[table_desc[2 * w1] + (i & (((size_t)1 << table_desc[2 * w1 + 1]) - 1))]; break;
+                    default: src.c[0] = x; break;
+                    }
+                }
+                switch (op) {
+                case 0: acc[d] = src; break;
+                case 1: acc[d] = gl3_add(acc[d], src); break;
+                case 2: acc[d] = gl3_sub(acc[d], src); break;
+                case 3: acc[d] = gl3_sub(src, acc[d]); break;
+                case 4: acc[d] = gl3_mul(acc[d], src); break;
+                case 5: { const gl3_t z = {{0, 0, 0}}; acc[d] = memcmp(&acc[d], &z, 24) ? gl3_inv(acc[d]) : z; } break;
+                case 6: slots[w1] = acc[d]; break;
+                case 7: memcpy(out + 3 * i, &acc[d], 24); break;
+                default: break;
+                }
+            }
+        }
+        free(slots);
+    }
+}

@@ -417,3 +417,17 @@ def gl3_deep_compose(trace_lde, comp_lde, log_n, log_blowup, offset, mask_col, m
     lib().or_gl3_deep_compose(tp, hp, C.c_uint(len(hc)), C.c_uint(log_n), C.c_uint(log_blowup), C.c_uint64(offset), _ptr(mc), _ptr(mo),
                               C.c_uint(len(mc)), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]), _ptr(arrs[4]), _ptr(arrs[5]), _ptr(out))
     return out
+
+
+def gl3_eval_program(code, consts3, n_slots, tables, table_desc, lde_cols, log_n, log_blowup, offset):
+    """the constraint program over Fq3, one point at a time -> uint64[N, 3]"""
+    code = np.ascontiguousarray(code, dtype=np.uint32)
+    consts = np.ascontiguousarray(consts3, dtype=np.uint64).reshape(-1, 3) if len(consts3) else np.zeros((1, 3), dtype=np.uint64)
+    tabs = np.ascontiguousarray(tables, dtype=np.uint64) if tables is not None and len(tables) else np.zeros(1, dtype=np.uint64)
+    desc = np.ascontiguousarray(table_desc if len(table_desc) else [0, 0], dtype=np.uint32)
+    cols, ptrs = _colptrs(lde_cols)
+    out = np.zeros((1 << (log_n + log_blowup), 3), dtype=np.uint64)
+    lib().or_gl3_eval_program.restype = None
+    lib().or_gl3_eval_program(_ptr(code), C.c_uint32(len(code) // 2), _ptr(consts), C.c_uint32(n_slots), _ptr(tabs), _ptr(desc), ptrs,
+                              C.c_uint(log_n), C.c_uint(log_blowup), C.c_uint64(offset), _ptr(out))
+    return out

@@ -216,6 +216,15 @@ class Context:
         check(self.lib.ss_fri_fold_gl64x3(self.handle, _ptr_of(evals), log_len, fold, a.ctypes.data_as(C.POINTER(C.c_uint64)), int(offset),
                                           flags, _ptr_of(out)))
 
+    def eval_quotient_gl64x3(self, code, consts3, n_slots, tables, table_desc, lde_cols, log_n, log_blowup, offset, out):
+        """the constraint program over Fq3 (ss_eval_quotient_gl64x3): code = the ss_air_program words, consts3 = uint64[n, 3]"""
+        code = np.ascontiguousarray(code, dtype=np.uint32)
+        consts = np.ascontiguousarray(consts3, dtype=np.uint64).reshape(-1, 3) if len(consts3) else np.zeros((1, 3), dtype=np.uint64)
+        desc = np.ascontiguousarray(table_desc if len(table_desc) else [0, 0], dtype=np.uint32)
+        prog = _lib.AirProgram(code.ctypes.data_as(C.POINTER(C.c_uint32)), len(code) // 2, consts.ctypes.data_as(C.POINTER(C.c_uint64)), len(consts3),
+                               _ptr_of(tables) if tables is not None else None, desc.ctypes.data_as(C.POINTER(C.c_uint32)), len(table_desc) // 2, n_slots)
+        check(self.lib.ss_eval_quotient_gl64x3(self.handle, C.byref(prog), _ptr_array(lde_cols), len(lde_cols), log_n, log_blowup, int(offset), _ptr_of(out)))
+
     def ood_eval_gl64x3(self, coeff_cols, log_n, cell_col, cell_off, z):
         """P_{col_j}(z * w_n^{off_j}) for bit-reversed coefficient columns, z in Fq3 -> uint64[ncells, 3]"""
         cc, co = np.ascontiguousarray(cell_col, dtype=np.uint32), np.ascontiguousarray(cell_off, dtype=np.uint32)

@@ -266,7 +266,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP and constraint program: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -1411,6 +1411,56 @@ static HGl3 gl3_addh(const HGl3 &a, const HGl3 &b) { return HGl3{{gl_addh(a.c[0]
 static HGl3 gl3_scaleh(const HGl3 &a, uint64_t s) { return HGl3{{gl_mulh(a.c[0], s), gl_mulh(a.c[1], s), gl_mulh(a.c[2], s)}}; }
 static bool gl3_valid(const uint64_t *v) { return v[0] < GL_P && v[1] < GL_P && v[2] < GL_P; }
 
+ss_status ss_eval_quotient_gl64x3(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols, uint32_t ncols, uint32_t log_n,
+                                  uint32_t log_blowup, uint64_t offset, uint64_t *d_out) {
+    if (!ctx || !prog || !prog->code || !d_lde_cols || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!gl_valid_log(log_n + log_blowup)) return fail(SS_ERR_INVALID, "size out of range");
+    if (ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "too many columns");
+    if (offset == 0 || offset >= GL_P) return fail(SS_ERR_INVALID, "the coset offset is not a non-zero field element");
+    if (prog->n_consts && !prog->consts) return fail(SS_ERR_INVALID, "NULL constants");
+    if (prog->n_tables && (!prog->table_desc || !prog->d_tables)) return fail(SS_ERR_INVALID, "NULL tables");
+    const uint64_t N = 1ull << (log_n + log_blowup);
+    // validate every operand before anything is launched: the kernel trusts the program
+    for (uint32_t pc = 0; pc < prog->n_instr; ++pc) {
+        const uint32_t w0 = prog->code[2 * pc], w1 = prog->code[2 * pc + 1], op = w0 & 0xff, d = (w0 >> 8) & 0xf, kind = (w0 >> 12) & 0xf;
+        if (op > SS_OP_OUT || d > 3) return fail(SS_ERR_INVALID, "instruction %u: bad opcode or accumulator", pc);
+        if (op == SS_OP_ST && w1 >= prog->n_slots) return fail(SS_ERR_INVALID, "instruction %u: slot %u out of range", pc, w1);
+        if (op > SS_OP_MUL) continue;
+        const bool ok = kind == SS_SRC_ACC ? w1 < 4 : kind == SS_SRC_SLOT ? w1 < prog->n_slots : kind == SS_SRC_CONST ? w1 < prog->n_consts
+                      : kind == SS_SRC_TRACE ? (w1 >> 24) < ncols : kind == SS_SRC_TABLE ? w1 < prog->n_tables : kind == SS_SRC_X;
+        if (!ok) return fail(SS_ERR_INVALID, "instruction %u: operand out of range", pc);
+    }
+    for (uint32_t k = 0; k < prog->n_consts; ++k)
+        if (!gl3_valid(prog->consts + 3 * (size_t)k)) return fail(SS_ERR_INVALID, "constant %u is not an element of the extension", k);
+    std::vector<uint32_t> tdesc(2 * (size_t)(prog->n_tables ? prog->n_tables : 1), 0);
+    for (uint32_t t = 0; t < prog->n_tables; ++t) {
+        if (prog->table_desc[2 * t + 1] > 30) return fail(SS_ERR_INVALID, "table %u: length out of range", t);
+        tdesc[2 * t] = prog->table_desc[2 * t];
+        tdesc[2 * t + 1] = (uint32_t)((1ull << prog->table_desc[2 * t + 1]) - 1ull);
+    }
+    const uint64_t lanes = gl3_vm_lanes(N);
+    const size_t code_bytes = (size_t)prog->n_instr * 8, const_bytes = (size_t)(prog->n_consts ? prog->n_consts : 1) * 24;
+    ss_status st = ctx->ensure_scratch(code_bytes + const_bytes + tdesc.size() * 4 + 256);
+    if (st != SS_OK) return st;
+    st = ctx->ensure_scratch2((size_t)(prog->n_slots ? prog->n_slots : 1) * 3 * lanes * 8);
+    if (st != SS_OK) return st;
+    char *p = (char *)ctx->scratch;
+    uint64_t *d_consts = (uint64_t *)p; p += const_bytes;
+    uint32_t *d_code = (uint32_t *)p; p += code_bytes;
+    uint32_t *d_tdesc = (uint32_t *)p;
+    hipStream_t s = ctx->stream;
+    if (prog->n_instr) HIP_TRY(hipMemcpyAsync(d_code, prog->code, code_bytes, hipMemcpyHostToDevice, s));
+    if (prog->n_consts) HIP_TRY(hipMemcpyAsync(d_consts, prog->consts, (size_t)prog->n_consts * 24, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_tdesc, tdesc.data(), tdesc.size() * 4, hipMemcpyHostToDevice, s));
+    {
+        ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
+        HIP_TRY(launch_gl3_vm(s, d_code, prog->n_instr, d_consts, prog->d_tables, d_tdesc, d_lde_cols, ncols, (uint64_t *)ctx->scratch2, d_out, offset,
+                              gl_root_of_unity_host(log_n + log_blowup), log_blowup, N));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return SS_OK;
+}
+
 ss_status ss_ood_eval_gl64x3(ss_ctx *ctx, const uint64_t *const *d_coeffs_bitrev, uint32_t ncols, uint32_t log_n, const uint32_t *cell_col,
                              const uint32_t *cell_off, uint32_t ncells, const uint64_t z[3], uint64_t *out) {
     if (!ctx || !d_coeffs_bitrev || !z || (ncells && (!cell_col || !cell_off || !out))) return fail(SS_ERR_INVALID, "NULL argument");
@@ -1425,28 +1475,38 @@ ss_status ss_ood_eval_gl64x3(ss_ctx *ctx, const uint64_t *const *d_coeffs_bitrev
     const uint64_t *tw = nullptr;
     ss_status st = gl_get_plan(ctx, log_n, false, 1, &tw);
     if (st != SS_OK) return st;
-    st = ctx->ensure_scratch2(6 * n * 8 + (size_t)ncells * (8 + 24) + 64);
+    // columns in batches of five: 15 component arrays per transform launch
+    constexpr uint32_t BATCH = 5;
+    st = ctx->ensure_scratch2((3 + 3 * BATCH) * n * 8 + (size_t)ncells * (8 + 24) + 64);
     if (st != SS_OK) return st;
-    uint64_t *zp = (uint64_t *)ctx->scratch2, *comp = zp + 3 * n, *d_idx = comp + 3 * n, *d_vals = d_idx + ncells;
+    uint64_t *zp = (uint64_t *)ctx->scratch2, *comp = zp + 3 * n, *d_idx = comp + 3 * BATCH * n, *d_vals = d_idx + ncells;
     hipStream_t s = ctx->stream;
     HIP_TRY(launch_gl3_zpow_bitrev(s, zp, zp + n, zp + 2 * n, log_n, z));
-    std::vector<uint64_t> idx(ncells);
-    for (uint32_t col = 0; col < ncols; ++col) {
-        std::vector<uint32_t> mine;
-        for (uint32_t j = 0; j < ncells; ++j) if (cell_col[j] == col) mine.push_back(j);
-        if (mine.empty()) continue;
-        HIP_TRY(launch_gl3_scale_columns(s, d_coeffs_bitrev[col], zp, zp + n, zp + 2 * n, n, comp, comp + n, comp + 2 * n));
-        const void *src[3] = {comp, comp + n, comp + 2 * n};
-        void *dst[3] = {comp, comp + n, comp + 2 * n};
-        st = gl_run_forward(ctx, src, dst, 3, log_n, tw, 0);
+    std::vector<uint32_t> used;                                  // columns some cell names
+    for (uint32_t col = 0; col < ncols; ++col)
+        for (uint32_t j = 0; j < ncells; ++j) if (cell_col[j] == col) { used.push_back(col); break; }
+    std::vector<uint64_t> idx(ncells), vals(3 * (size_t)ncells);
+    for (size_t b0 = 0; b0 < used.size(); b0 += BATCH) {
+        const uint32_t nb = (uint32_t)std::min<size_t>(BATCH, used.size() - b0);
+        const void *src[3 * BATCH]; void *dst[3 * BATCH];
+        for (uint32_t k = 0; k < nb; ++k) {
+            uint64_t *c0 = comp + (size_t)3 * k * n;
+            HIP_TRY(launch_gl3_scale_columns(s, d_coeffs_bitrev[used[b0 + k]], zp, zp + n, zp + 2 * n, n, c0, c0 + n, c0 + 2 * n));
+            for (int t = 0; t < 3; ++t) { src[3 * k + t] = c0 + t * n; dst[3 * k + t] = c0 + t * n; }
+        }
+        st = gl_run_forward(ctx, src, dst, 3 * nb, log_n, tw, 0);
         if (st != SS_OK) return st;
-        for (size_t t = 0; t < mine.size(); ++t) idx[t] = cell_off[mine[t]] & (n - 1);
-        HIP_TRY(hipMemcpyAsync(d_idx, idx.data(), mine.size() * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(launch_gl3_gather(s, comp, comp + n, comp + 2 * n, d_idx, (uint32_t)mine.size(), d_vals));
-        std::vector<uint64_t> vals(3 * mine.size());
-        HIP_TRY(hipMemcpyAsync(vals.data(), d_vals, vals.size() * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        for (size_t t = 0; t < mine.size(); ++t) memcpy(out + 3 * (size_t)mine[t], vals.data() + 3 * t, 24);
+        for (uint32_t k = 0; k < nb; ++k) {
+            std::vector<uint32_t> mine;
+            for (uint32_t j = 0; j < ncells; ++j) if (cell_col[j] == used[b0 + k]) mine.push_back(j);
+            for (size_t t = 0; t < mine.size(); ++t) idx[t] = cell_off[mine[t]] & (n - 1);
+            uint64_t *c0 = comp + (size_t)3 * k * n;
+            HIP_TRY(hipMemcpyAsync(d_idx, idx.data(), mine.size() * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(launch_gl3_gather(s, c0, c0 + n, c0 + 2 * n, d_idx, (uint32_t)mine.size(), d_vals));
+            HIP_TRY(hipMemcpyAsync(vals.data(), d_vals, 3 * mine.size() * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            for (size_t t = 0; t < mine.size(); ++t) memcpy(out + 3 * (size_t)mine[t], vals.data() + 3 * t, 24);
+        }
     }
     return SS_OK;
 }

@@ -501,4 +501,94 @@ hipError_t launch_gl3_gather(hipStream_t st, const uint64_t *c0, const uint64_t 
     return hipGetLastError();
 }
 
+
+// ---- the constraint program over the cubic extension (row Q1 for this field) ---------------------------------------------
+// The same 4-accumulator register machine as csrc/quotient.hip (include/sandstorm_hip.h ss_air_program), interpreted:
+// accumulators, constants (challenges, alpha^k, hints) and scratch slots are elements of Fq3, trace cells / periodic tables /
+// x are elements of Fp read into the first coordinate.  One lane = one LDE point; the program counter and operand selectors are
+// wave-uniform (scalar loads and branches).  Slots live in a file [slot][coordinate][lane] in HBM.
+__device__ __forceinline__ Gl3 gl3_inv_dev(const Gl3 &a) {
+    const uint64_t a12 = gl_mul(a.c[1], a.c[2]), a22 = gl_mul(a.c[2], a.c[2]);
+    Gl3 adj;
+    adj.c[0] = gl_sub(gl_mul(a.c[0], a.c[0]), gl_add(a12, a12));
+    adj.c[1] = gl_sub(gl_add(a22, a22), gl_mul(a.c[0], a.c[1]));
+    adj.c[2] = gl_sub(gl_mul(a.c[1], a.c[1]), gl_mul(a.c[0], a.c[2]));
+    const uint64_t t1 = gl_mul(a.c[2], adj.c[1]), t2 = gl_mul(a.c[1], adj.c[2]);
+    const uint64_t norm = gl_add(gl_mul(a.c[0], adj.c[0]), gl_add(gl_add(t1, t1), gl_add(t2, t2)));
+    return gl3_scale(adj, gl_pow_dev(norm, GL_P - 2));                      // 0 -> 0
+}
+struct Gl3VmArgs {
+    const uint32_t *code;            // 2 words per instruction
+    const uint64_t *consts;          // [n_consts][3]
+    const uint64_t *tables;          // concatenated Fp tables
+    const uint32_t *tdesc;           // [n_tables][2]: offset, length - 1
+    const uint64_t *cols[MAX_COLS];
+    uint64_t *slots;                 // [n_slots][3][lanes]
+    uint64_t *out;                   // [N][3]
+    uint64_t offset, w;
+    uint32_t n_instr, log_blowup;
+    uint64_t N;
+};
+__global__ __launch_bounds__(256) void gl3_vm_kernel(Gl3VmArgs a) {
+    typedef const uint32_t __attribute__((address_space(4))) *const_u32;
+    const_u32 code = (const_u32)(uintptr_t)a.code, tdesc = (const_u32)(uintptr_t)a.tdesc;
+    const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x, lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t wstep = gl_pow_dev(a.w, lanes);
+    uint64_t x = gl_mul(a.offset, gl_pow_dev(a.w, lane));
+    for (uint64_t i = lane; i < a.N; i += lanes, x = gl_mul(x, wstep)) {
+        Gl3 acc0 = {{0, 0, 0}}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        for (uint32_t pc = 0; pc < a.n_instr; ++pc) {
+            const uint32_t w0 = code[2 * pc], w1 = code[2 * pc + 1];
+            const uint32_t op = w0 & 0xffu, d = (w0 >> 8) & 0xfu, kind = (w0 >> 12) & 0xfu;
+            Gl3 src = {{0, 0, 0}};
+            if (op <= 4u) {
+                switch (kind) {
+                case 0: { const uint32_t k = w1 & 3u; src = k == 0 ? acc0 : k == 1 ? acc1 : k == 2 ? acc2 : acc3; } break;
+                case 1: for (int c = 0; c < 3; ++c) src.c[c] = a.slots[((uint64_t)w1 * 3 + c) * lanes + lane]; break;
+                case 2: src = gl3_load(a.consts + 3 * (size_t)w1); break;
+                case 3: {
+                    const uint32_t col = w1 >> 24, ro = w1 & 0xffffffu;
+                    const uint64_t *cp = a.cols[0];
+#pragma unroll
+                    for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) cp = a.cols[c];
+                    src.c[0] = cp[(i + ((uint64_t)ro << a.log_blowup)) & (a.N - 1)];
+                } break;
+                case 4: src.c[0] = a.tables[tdesc[2 * w1] + (i & tdesc[2 * w1 + 1])]; break;
+                default: src.c[0] = x; break;
+                }
+            }
+#define SS_GL3_VM_ON(v)                                                                                          \
+            switch (op) {                                                                                        \
+            case 0: v = src; break;                                                                              \
+            case 1: v = gl3_add(v, src); break;                                                                  \
+            case 2: v = gl3_sub(v, src); break;                                                                  \
+            case 3: v = gl3_sub(src, v); break;                                                                  \
+            case 4: v = (kind == 3 || kind == 4 || kind == 5) ? gl3_scale(v, src.c[0]) : gl3_mul(v, src); break; \
+            case 5: v = gl3_inv_dev(v); break;                                                                   \
+            case 6: for (int c = 0; c < 3; ++c) a.slots[((uint64_t)w1 * 3 + c) * lanes + lane] = v.c[c]; break;  \
+            case 7: a.out[3 * i] = v.c[0]; a.out[3 * i + 1] = v.c[1]; a.out[3 * i + 2] = v.c[2]; break;          \
+            default: break;                                                                                      \
+            }
+            switch (d) {
+            case 0: SS_GL3_VM_ON(acc0) break;
+            case 1: SS_GL3_VM_ON(acc1) break;
+            case 2: SS_GL3_VM_ON(acc2) break;
+            default: SS_GL3_VM_ON(acc3) break;
+            }
+#undef SS_GL3_VM_ON
+        }
+    }
+}
+uint32_t gl3_vm_lanes(uint64_t N) { return gl_blocks(N, 256, 4096) * 256u; }
+hipError_t launch_gl3_vm(hipStream_t st, const uint32_t *d_code, uint32_t n_instr, const uint64_t *d_consts, const uint64_t *d_tables,
+                         const uint32_t *d_tdesc, const uint64_t *const *cols, uint32_t ncols, uint64_t *d_slots, uint64_t *d_out, uint64_t offset,
+                         uint64_t w, uint32_t log_blowup, uint64_t N) {
+    Gl3VmArgs a;
+    a.code = d_code; a.consts = d_consts; a.tables = d_tables; a.tdesc = d_tdesc; a.slots = d_slots; a.out = d_out;
+    for (int c = 0; c < MAX_COLS; ++c) a.cols[c] = c < (int)ncols ? cols[c] : nullptr;
+    a.offset = offset; a.w = w; a.n_instr = n_instr; a.log_blowup = log_blowup; a.N = N;
+    hipLaunchKernelGGL(gl3_vm_kernel, dim3(gl3_vm_lanes(N) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 }  // namespace ss

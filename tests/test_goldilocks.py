@@ -239,3 +239,92 @@ def test_deep_at_the_benchmark_size_feeds_fri(ctx, oracle):
     ctx.ntt_gl64([comp], log_n + lb - 3, be.INVERSE, pow(7, 8, GL_P), be.NATURAL, be.NATURAL)
     got = comp.download(np.uint64, (N // 8,))
     assert not got[n // 8:].any() and got[:n // 8].any()
+
+
+# ---- the constraint program over the cubic extension ---------------------------------------------------------------------
+def _gl_program(seed, size, ncols):
+    """a random expression DAG lowered for this field; every constant gets pseudo-random extension coordinates, and a tail
+    exercises INV and the scratch slots"""
+    import random
+    from sandstorm_amd import air_program as ap
+    from tests.test_air_program import random_dag
+    prog = ap.lower(random_dag(random.Random(seed), ncols, 2, 5, size), GL_P)
+    consts = np.array([[c % GL_P, (c * 0x9E3779B97F4A7C15 + 1) % GL_P, (c * c + 7) % GL_P] for c in prog.consts] + [[3, 1, 4]], dtype=np.uint64)
+    code = [int(w) for w in prog.code]
+    assert code[-2] & 0xff == 7                                     # ... OUT acc_d
+    d = (code[-2] >> 8) & 0xf
+    e = (d + 1) % 4
+    I = lambda op, dst, kind, payload: [op | (dst << 8) | (kind << 12), payload]
+    tail = (I(6, d, 0, prog.n_slots) + I(0, e, 2, len(consts) - 1) + I(1, e, 1, prog.n_slots) + I(5, e, 0, 0) + I(4, e, 5, 0)
+            + I(3, e, 3, 1) + I(4, e, 0, d) + I(7, e, 0, 0))        # st; e = (3,1,4) + slot; e = 1/e; e *= x; e = T0[i+1] - e; e *= d; out e
+    return np.array(code[:-2] + tail, dtype=np.uint32), consts, prog.n_slots + 1
+
+
+def _py_program(code, consts, n_slots, tables, desc, lde, log_N, lb, offset, points):
+    """the program at a few points, in Python integers"""
+    N = 1 << log_N
+    w = pow(7, (GL_P - 1) >> log_N, GL_P)
+    add = lambda a, b: [(x + y) % GL_P for x, y in zip(a, b)]
+    sub = lambda a, b: [(x - y) % GL_P for x, y in zip(a, b)]
+
+    def inv3(a):
+        r, base, e = [1, 0, 0], list(a), GL_P ** 3 - 2
+        while e:
+            if e & 1:
+                r = _mul3(r, base)
+            base, e = _mul3(base, base), e >> 1
+        return r if any(a) else [0, 0, 0]
+    out = {}
+    for i in points:
+        acc, slots, x = [[0, 0, 0] for _ in range(4)], [[0, 0, 0] for _ in range(n_slots)], offset * pow(w, i, GL_P) % GL_P
+        for pc in range(len(code) // 2):
+            w0, w1 = int(code[2 * pc]), int(code[2 * pc + 1])
+            op, d, kind = w0 & 0xff, (w0 >> 8) & 0xf, (w0 >> 12) & 0xf
+            src = [0, 0, 0]
+            if op <= 4:
+                src = (acc[w1 & 3] if kind == 0 else slots[w1] if kind == 1 else [int(v) for v in consts[w1]] if kind == 2
+                       else [int(lde[w1 >> 24][(i + ((w1 & 0xffffff) << lb)) % N]), 0, 0] if kind == 3
+                       else [int(tables[desc[2 * w1] + i % (1 << desc[2 * w1 + 1])]), 0, 0] if kind == 4 else [x, 0, 0])
+            if op == 0: acc[d] = list(src)
+            elif op == 1: acc[d] = add(acc[d], src)
+            elif op == 2: acc[d] = sub(acc[d], src)
+            elif op == 3: acc[d] = sub(src, acc[d])
+            elif op == 4: acc[d] = _mul3(acc[d], src)
+            elif op == 5: acc[d] = inv3(acc[d])
+            elif op == 6: slots[w1] = list(acc[d])
+            else: out[i] = list(acc[d])
+    return out
+
+
+def test_program_oracle_is_the_definition(oracle):
+    rng = np.random.default_rng(21)
+    log_n, lb, ncols = 4, 1, 3
+    N = 2 << log_n
+    code, consts, n_slots = _gl_program(4, 60, ncols)
+    lde = [rand_fp(rng, N) for _ in range(ncols)]
+    tables, desc = np.concatenate([rand_fp(rng, 4), rand_fp(rng, 8)]), [0, 2, 4, 3]
+    got = oracle.gl3_eval_program(code, consts, n_slots, tables, desc, lde, log_n, lb, 7)
+    want = _py_program(code, consts, n_slots, tables, desc, lde, log_n + lb, lb, 7, range(N))
+    assert [[int(v) for v in row] for row in got] == [want[i] for i in range(N)]
+    assert got.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,size,log_n", [(1, 30, 3), (2, 120, 8), (3, 400, 12), (5, 250, 17)])
+def test_program_vs_oracle(ctx, oracle, seed, size, log_n):
+    rng = np.random.default_rng(seed)
+    lb, ncols = 1, 3
+    N = 2 << log_n
+    code, consts, n_slots = _gl_program(seed, size, ncols)
+    lde = [rand_fp(rng, N) for _ in range(ncols)]
+    tables, desc = np.concatenate([rand_fp(rng, 4), rand_fp(rng, 8)]), [0, 2, 4, 3]
+    out = ctx.alloc(24 * N)
+    ctx.eval_quotient_gl64x3(code, consts, n_slots, ctx.column(tables), desc, [ctx.column(c) for c in lde], log_n, lb, 7, out)
+    assert np.array_equal(out.download(np.uint64, (N, 3)), oracle.gl3_eval_program(code, consts, n_slots, tables, desc, lde, log_n, lb, 7))
+    # a program that reaches outside its inputs is refused before any launch
+    from sandstorm_amd._lib import SandstormHipError
+    bad = code.copy()
+    assert int(bad[-16]) & 0xff == 6                                  # the tail's ST
+    bad[-15] = n_slots + 5
+    with pytest.raises(SandstormHipError):
+        ctx.eval_quotient_gl64x3(bad, consts, n_slots, ctx.column(tables), desc, [ctx.column(c) for c in lde], log_n, lb, 7, out)
