@@ -328,3 +328,84 @@ def test_program_vs_oracle(ctx, oracle, seed, size, log_n):
     bad[-15] = n_slots + 5
     with pytest.raises(SandstormHipError):
         ctx.eval_quotient_gl64x3(bad, consts, n_slots, ctx.column(tables), desc, [ctx.column(c) for c in lde], log_n, lb, 7, out)
+
+
+# ---- the kernels compose: a small AIR over this field, end to end up to (not including) the commitments -----------------------
+@pytest.mark.gpu
+def test_the_kernels_compose_into_a_proof_skeleton(ctx, oracle):
+    """A two-column AIR (a' = b, b' = a b + a on every row but the last), challenges in Fq3: LDE -> constraint program ->
+    the composition is a polynomial of degree < n -> out-of-domain values satisfy the AIR identity at z (what a verifier
+    recomputes) -> DEEP composition of trace and composition columns has degree < n -> FRI folds bring it down to a constant.
+    Every arrow is a kernel of this file's entry points; the checks are done in Python integers on the host."""
+    from sandstorm_amd import backend as be
+    log_n, lb = 10, 1
+    n, N = 1 << log_n, 2 << log_n
+    g_n = pow(7, (GL_P - 1) >> log_n, GL_P)
+    a, b = [3], [5]
+    for _ in range(n - 1):
+        a, b = a + [b[-1]], b + [(a[-1] * b[-1] + a[-1]) % GL_P]
+    cols = [ctx.column(np.array(c, dtype=np.uint64)) for c in (a, b)]
+    ev, co = [ctx.alloc(8 * N) for _ in range(2)], [ctx.alloc(8 * n) for _ in range(2)]
+    ctx.lde_gl64(cols, log_n, lb, 7, ev, co)
+    rng = np.random.default_rng(8)
+    alpha = [[int(v) for v in rand_fp(rng, 3)] for _ in range(2)]
+    last = pow(g_n, n - 1, GL_P)
+    # tables: 1 / (x^n - 1) over the LDE domain has period `blowup` (x^n = 7^n w_N^(n i))
+    zi = np.array([pow((pow(7, n, GL_P) * pow(pow(7, (GL_P - 1) >> (log_n + lb), GL_P), n * i, GL_P) - 1) % GL_P, GL_P - 2, GL_P) for i in range(2)], dtype=np.uint64)
+    I = lambda op, d, kind, payload: [op | (d << 8) | (kind << 12), payload]
+    T = lambda col, off: (col << 24) | off
+    consts = np.array(alpha + [[last, 0, 0]], dtype=np.uint64)
+    code = np.array(
+        I(0, 0, 3, T(0, 1)) + I(2, 0, 3, T(1, 0)) + I(0, 3, 2, 0) + I(4, 3, 0, 0)                               # acc3 = alpha0 (a' - b)
+        + I(0, 1, 3, T(0, 0)) + I(4, 1, 3, T(1, 0)) + I(1, 1, 3, T(0, 0)) + I(3, 1, 3, T(1, 1))                  # acc1 = b' - (a b + a)
+        + I(0, 2, 2, 1) + I(4, 2, 0, 1) + I(1, 3, 0, 2)                                                          # acc3 += alpha1 acc1
+        + I(0, 0, 5, 0) + I(2, 0, 2, 2) + I(4, 3, 0, 0) + I(4, 3, 4, 0) + I(7, 3, 0, 0), dtype=np.uint32)        # * (x - last) / (x^n - 1)
+    q = ctx.alloc(24 * N)
+    ctx.eval_quotient_gl64x3(code, consts, 0, ctx.column(zi), [0, 1], ev, log_n, lb, 7, q)
+    qh = q.download(np.uint64, (N, 3))
+    comp_ev = [ctx.column(np.ascontiguousarray(qh[:, t])) for t in range(3)]
+    comp_co = [ctx.column(np.ascontiguousarray(qh[:, t])) for t in range(3)]
+    ctx.ntt_gl64(comp_co, log_n + lb, be.INVERSE, 7, be.NATURAL, be.BITREV)
+    for c in comp_co:                                                                 # degree < n: the odd bit-reversed slots are zero
+        got = c.download(np.uint64, (N,))
+        assert not got[1::2].any() and got[0::2].any()
+    # out-of-domain: the verifier's identity at z
+    z = [int(v) for v in rand_fp(rng, 3)]
+    mask = [(0, 0), (0, 1), (1, 0), (1, 1)]
+    mc, mo = [c for c, _ in mask], [o for _, o in mask]
+    ood_t = ctx.ood_eval_gl64x3(co, log_n, mc, mo, z)
+    ood_q = ctx.ood_eval_gl64x3(comp_co, log_n + lb, [0, 1, 2], [0, 0, 0], z)        # the components, as polynomials over the N-domain
+    add = lambda u, v: [(x + y) % GL_P for x, y in zip(u, v)]
+    sub = lambda u, v: [(x - y) % GL_P for x, y in zip(u, v)]
+    Xk = [[1, 0, 0], [0, 1, 0], [0, 0, 1]]
+    q_at_z = [0, 0, 0]
+    for k in range(3):
+        q_at_z = add(q_at_z, _mul3(Xk[k], ood_q[k]))
+    a0, a1, b0, b1 = ([int(v) for v in row] for row in ood_t)
+    c0, c1 = sub(a1, b0), sub(b1, add(_mul3(a0, b0), a0))
+    num = _mul3(add(_mul3(alpha[0], c0), _mul3(alpha[1], c1)), sub(z, [last, 0, 0]))
+    zn = [1, 0, 0]
+    for _ in range(n):
+        zn = _mul3(zn, z)
+    assert _mul3(q_at_z, sub(zn, [1, 0, 0])) == num
+    # DEEP: trace cells + the composition (three component columns, coefficients c X^k, out-of-domain value on the first)
+    coef_t = rand_fp(rng, 12).reshape(4, 3)
+    cq = [int(v) for v in rand_fp(rng, 3)]
+    coef_c = np.array([_mul3(cq, Xk[k]) for k in range(3)], dtype=np.uint64)
+    ood_c = np.array([q_at_z, [0, 0, 0], [0, 0, 0]], dtype=np.uint64)
+    deep = ctx.alloc(24 * N)
+    ctx.deep_compose_gl64x3(ev, comp_ev, log_n, lb, 7, mc, mo, ood_t, coef_t, ood_c, coef_c, z, z, deep)
+    dh = deep.download(np.uint64, (N, 3))
+    for t in range(3):
+        c = ctx.column(np.ascontiguousarray(dh[:, t]))
+        ctx.ntt_gl64([c], log_n + lb, be.INVERSE, 7, be.NATURAL, be.NATURAL)
+        got = c.download(np.uint64, (N,))
+        assert not got[n:].any() and got[:n].any()
+    # FRI: fold 8, 8, 8, 2 (2^11 -> 2^8 -> 2^5 -> 2^2 -> 2^1 points): the last layer is a constant polynomial
+    layer, ll, off = deep, log_n + lb, 7
+    for fold in (8, 8, 8, 2):
+        nxt = ctx.alloc(24 * ((1 << ll) // fold))
+        ctx.fri_fold_gl64x3(layer, ll, fold, rand_fp(rng, 3), off, nxt)
+        layer, ll, off = nxt, ll - (fold.bit_length() - 1), pow(off, fold, GL_P)
+    fin = layer.download(np.uint64, (2, 3))
+    assert np.array_equal(fin[0], fin[1]) and fin.any()
