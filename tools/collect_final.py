@@ -30,8 +30,9 @@ def parse_pmc(path, counter):
 for name in sorted(os.listdir(SRC)):
     if name.startswith("bench_") and name.endswith(".json"):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, "%s_%s" % (TAG, name)))
-if os.path.exists(os.path.join(SRC, "pytest_gpu.txt")):
-    shutil.copy(os.path.join(SRC, "pytest_gpu.txt"), os.path.join(DST, "%s_pytest_gpu.txt" % TAG))
+for name in ("pytest_gpu.txt", "smoke.txt", "sq_counters_starknet_2p20.txt"):
+    if os.path.exists(os.path.join(SRC, name)):
+        shutil.copy(os.path.join(SRC, name), os.path.join(DST, "%s_%s" % (TAG, name)))
 
 for d in sorted(os.listdir(SRC)):
     if not d.startswith("prof_"):

@@ -1,17 +1,27 @@
 #!/bin/bash
-# GPU box: the round-end evidence in one call -> gpurun_out/final/
+# GPU box: the round-end evidence in one call -> gpurun_out/final/  (collected into profiles/ by tools/collect_final.py <tag>)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/final
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd $R
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $OUT/smoke.txt
-for w in starknet_2p20 recursive_2p20 recursive_2p16; do
+for w in starknet_2p20 recursive_2p20 recursive_2p16 array_sum_example; do
   timeout 600 python bench.py --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err
-  python -c "import json; d=json.load(open('$OUT/bench_$w.json')); print('$w', d['value'], d['stage_ms_per_proof'], d['ntt_gfield_ops_per_s'], d.get('cpu_baseline',{}).get('value'))"
+  python -c "import json; d=json.load(open('$OUT/bench_$w.json')); print('$w', d['value'], d['stage_ms_per_proof'], d['ntt_gfield_ops_per_s'], d.get('cpu_baseline',{}).get('measured_sample_s'))"
 done
+timeout 300 python bench.py --workload starknet_2p20 --mode shard --no-cpu-baseline > $OUT/bench_starknet_2p20_shard_1gpu.json 2> $OUT/bench_shard.err
+timeout 300 python bench.py --workload goldilocks_lde_2p20 --steps 10 --warmup 2 > $OUT/bench_goldilocks_lde_2p20.json 2> $OUT/bench_gl.err
+timeout 300 python bench.py --workload starknet_2p22 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_starknet_2p22.json 2> $OUT/bench_2p22.err
+python -c "
+import json
+for w in ('starknet_2p20_shard_1gpu','goldilocks_lde_2p20','starknet_2p22'):
+    try: d=json.load(open('$OUT/bench_%s.json'%w)); print(w, d['value'])
+    except Exception as e: print(w, 'FAILED', e)"
 bash tools/profile_round.sh > $OUT/profile_round.log 2>&1
 cp -r $R/gpurun_out/prof $OUT/prof_starknet_2p20
 WORKLOAD=recursive_2p20 bash tools/profile_round.sh > $OUT/profile_round_rec.log 2>&1
 cp -r $R/gpurun_out/prof $OUT/prof_recursive_2p20
+# SQ instruction / wait counters of the default workload (own pass: --pmc only)
+bash tools/pmc_run.sh sq_final "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/sq_counters_starknet_2p20.txt 2>&1
 ls $OUT
