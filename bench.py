@@ -52,6 +52,28 @@ WORKLOADS = {
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
+# The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner from C stdio
+# when a communicator comes up): file descriptor 1 is pointed at stderr for the whole run and the JSON line goes to a
+# duplicate of the original stdout.
+_REAL_STDOUT = None
+
+
+def _claim_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = json.dumps(obj)
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        _REAL_STDOUT.write(line + "\n")
+        _REAL_STDOUT.flush()
+
 
 def ntt_field_ops(log_size):
     """1.5 * N * log2 N field operations per size-N transform"""
@@ -241,7 +263,7 @@ def bench_goldilocks(args, log_steps, rank, local_rank, world, device):
             out["cpu_baseline"] = {"value": t_cpu * scale, "unit": "s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), "kind": "port",
                                    "sample": "oracle (C + OpenMP) LDE of one 2^%d-row column: %.3f s, scaled n log n to %d columns of 2^%d rows"
                                              % (sl, t_cpu, ncols, log_n)}
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 
@@ -314,7 +336,7 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     sec = float(tmax.item()) / args.steps
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "prove_wall_time_s", "value": sec, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sec * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "u256 (Fp252, Montgomery R=2^256, 8 x u32 limbs)", "data": "synthetic", "proofs_per_s": 1.0 / sec,
@@ -331,7 +353,7 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
                        "host": "Python host (sandstorm_amd/sharded_prover.py) over the C ABI + torch.distributed (nccl = RCCL)",
                        "fri_layers": len(proof.fri_layers) if proof is not None else None,
                        "note": "python bench.py --gpus N --mode replicas runs N independent proofs instead (weak scaling)"},
-        }))
+        })
     dist.destroy_process_group()
 
 
@@ -348,6 +370,7 @@ def main():
     ap.add_argument("--air", default="real", choices=["real", "synthetic"],
                     help="real: the layout's own composition constraint (default); synthetic: round 1's layout-shaped stand-in")
     args = ap.parse_args()
+    _claim_stdout()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -358,7 +381,9 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        # a rank that fails must not leave the others in a collective for the default ten minutes
+        import datetime
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=300))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     from sandstorm_amd import backend as be, extension, hostlib
@@ -527,7 +552,7 @@ def main():
                                                     "(BASELINE.md section 1: other hardware, older CLI, the real AIR)")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(layout, log_steps, ctx)
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

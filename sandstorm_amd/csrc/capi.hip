@@ -1143,11 +1143,11 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
     // one workgroup per CU and SIMD slot the kernel's register budget allows; SS_QG_BLOCKS overrides (experiments)
     uint64_t blocks = 256ull * gen.wgs_per_cu;
     if (const char *e = getenv("SS_QG_BLOCKS")) blocks = strtoull(e, nullptr, 10);
-    if (blocks * QG_THREADS > N) blocks = N / QG_THREADS;
+    if (blocks * gen.threads > N) blocks = N / gen.threads;
     if (blocks == 0) blocks = 1;
     a.w = root_of_unity(log_N);
     a.offset = fp_mul(offset ? fp_from_limbs64(offset) : fp_one(), fp_pow_u64(a.w, row0));
-    a.wstep = fp_pow_u64(a.w, blocks * QG_THREADS);
+    a.wstep = fp_pow_u64(a.w, blocks * gen.threads);
     ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
     HIP_TRY(gen.launch(s, a, (uint32_t)blocks));
     HIP_TRY(hipStreamSynchronize(s));      // the staging vector goes away on return

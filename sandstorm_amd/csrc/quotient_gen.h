@@ -10,7 +10,11 @@
 
 namespace ss {
 
+#ifdef QG_THREADS_PER_WG                       // a wrapper's own workgroup shape (tools/gen_quotient.py VARIANTS)
+static constexpr int QG_THREADS = QG_THREADS_PER_WG;
+#else
 static constexpr int QG_THREADS = 256;
+#endif
 static constexpr int QG_MAX_COLS = 16;
 static constexpr int QG_CONST_STRIDE = 24;       // dwords per constant: 9 R256 limbs at 0, 9 R280 limbs at 12
 
@@ -33,6 +37,7 @@ struct QGenKernel {
     uint32_t n_instr, n_consts, n_tables, ncols;
     uint32_t variant;                            // tools/gen_quotient.py VARIANTS; ss_eval_quotient takes 0 (SS_QG_VARIANT overrides)
     uint32_t wgs_per_cu;                         // workgroups per CU its register budget allows: the grid is 256 CUs times this
+    uint32_t threads;                            // lanes per workgroup (QG_THREADS of that kernel's translation unit)
     hipError_t (*launch)(hipStream_t, const QGenArgs &, uint32_t blocks);
 };
 

@@ -82,12 +82,15 @@ DOT_MAX_TERMS = 16      # products accumulated in the 64-bit columns before a Mo
 # bound - LDS slots, one workgroup per CU, a shallow prefetch (unfused, depth 3: 153.7 ms, 2: 154.3, 1: 159.6, 4: 153.7,
 # 6: 171.5; slots in registers at two workgroups per CU: 352, scratch spills; fenced + fused, depth 3: 140.2, 2: 140.6,
 # 4: 167.8, slots in registers: 161.6); the recursive one fits two workgroups per CU with its slots in registers (depth 4:
-# 65.5 ms, 6: 66.0, 2: 65.1; LDS slots at one workgroup per CU: 76.9; fenced + fused at one workgroup per CU: 86).
+# 65.5 ms, 6: 66.0, 2: 65.1; LDS slots at one workgroup per CU: 76.9; fenced + fused at one workgroup per CU: 86; one 512-lane
+# workgroup per CU with LDS slots - two waves per SIMD, constants shared - does not fit 256 registers either: 88 B of scratch
+# unfused, 868 B fused, not run).
 # (suffix, operand prefetch depth, slots in registers, workgroups per CU, scheduling fence after every program instruction,
-#  "MUL alpha^k; ADD" chains as fused dot products)
+#  "MUL alpha^k; ADD" chains as fused dot products, lanes per workgroup: 512 = two waves per SIMD in ONE workgroup, which
+#  shares the LDS constants and leaves room for LDS slots)
 VARIANTS = {
-    "starknet": [("", 3, False, 1, True, True), ("_v1", 2, False, 1, True, True), ("_v2", 3, True, 1, True, True), ("_v3", 3, False, 1, False, False)],
-    "recursive": [("", 4, True, 2, False, False), ("_v1", 4, True, 1, True, True), ("_v2", 4, True, 2, True, True), ("_v3", 4, False, 1, True, True)],
+    "starknet": [("", 3, False, 1, True, True, 256), ("_v1", 2, False, 1, True, True, 256), ("_v2", 3, True, 1, True, True, 256), ("_v3", 3, False, 1, False, False, 256)],
+    "recursive": [("", 4, True, 2, False, False, 256), ("_v1", 4, True, 1, True, True, 256), ("_v2", 4, False, 1, True, True, 512), ("_v3", 4, False, 1, False, False, 512)],
 }
 
 
@@ -96,10 +99,10 @@ def generate(layout, all_variants=False):
     the table in capi.hip's quotient_gen_find for an A/B run with SS_QG_VARIANT=k)"""
     program = template_program(layout)
     bodies = {}
-    for k, (suffix, depth, slots_in_regs, wgs, fence, fuse) in enumerate(VARIANTS[layout] if all_variants else VARIANTS[layout][:1]):
+    for k, (suffix, depth, slots_in_regs, wgs, fence, fuse, threads) in enumerate(VARIANTS[layout] if all_variants else VARIANTS[layout][:1]):
         if (depth, fuse) not in bodies:
             bodies[(depth, fuse)] = generate_body(layout, program, depth, "" if not bodies else "_d%d%s" % (depth, "f" if fuse else ""), fuse)
-        write_wrapper(layout, program, k, suffix, bodies[(depth, fuse)], slots_in_regs, wgs, fence)
+        write_wrapper(layout, program, k, suffix, bodies[(depth, fuse)], slots_in_regs, wgs, fence, threads)
 
 
 def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix, FUSE_ALPHA_DOT_PRODUCTS=False):
@@ -313,7 +316,7 @@ def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix, FUSE_ALPHA_DOT_PR
     return dict(stats, inc=name, depth=D)
 
 
-def write_wrapper(layout, program, variant, suffix, body, slots_in_regs, wgs, fence=False):
+def write_wrapper(layout, program, variant, suffix, body, slots_in_regs, wgs, fence=False, threads=256):
     code, n_consts, n_slots, n_tables, ncols = program
     n_instr = len(code) // 2
     h = code_hash(code)
@@ -351,14 +354,15 @@ hipError_t launch_%(layout)s%(suffix)s(hipStream_t st, const QGenArgs &a, uint32
 }  // namespace
 
 const QGenKernel &quotient_gen_%(layout)s%(suffix)s() {
-    static const QGenKernel k = {"%(layout)s", 0x%(hash)016xull, %(n_instr)du, %(n_consts)du, %(n_tables)du, %(ncols)du, %(variant)du, %(wgs)du, launch_%(layout)s%(suffix)s};
+    static const QGenKernel k = {"%(layout)s", 0x%(hash)016xull, %(n_instr)du, %(n_consts)du, %(n_tables)du, %(ncols)du, %(variant)du, %(wgs)du, (uint32_t)QG_THREADS, launch_%(layout)s%(suffix)s};
     return k;
 }
 
 }  // namespace ss
 ''' % dict(layout=layout, suffix=suffix, variant=variant, n_instr=n_instr, n_slots=n_slots, n_consts=n_consts, n_tables=n_tables, ncols=ncols,
            hash=h, wgs=wgs, lds_slots=0 if slots_in_regs else n_slots, where="registers" if slots_in_regs else "LDS",
-           define=("#define QG_SLOTS_IN_REGISTERS\n" if slots_in_regs else "") + ("#define QG_FENCE_EVERY_INSTRUCTION\n" if fence else ""),
+           define=("#define QG_SLOTS_IN_REGISTERS\n" if slots_in_regs else "") + ("#define QG_FENCE_EVERY_INSTRUCTION\n" if fence else "")
+                  + ("#define QG_THREADS_PER_WG %d\n" % threads if threads != 256 else ""),
            fence=", a scheduling fence after every program instruction" if fence else "", **body)
     path = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s%s.hip" % (layout, suffix))
     with open(path, "w") as f:
