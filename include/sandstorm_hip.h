@@ -274,6 +274,16 @@ ss_status ss_fri_fold_gl64x3(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_
  *   sum_j coeff_trace[j] (T_{col_j}(x_i) - ood_trace[j]) / (x_i - z w_n^{off_j})
  *   + sum_k coeff_comp[k] (H_k(x_i) - ood_comp[k]) / (x_i - z_comp),      x_i = offset * w_{n blowup}^i,
  *   composed on the n-point sub-coset and extended per component (the polynomial has degree < n). */
+/* H1 / openings for matrices of 8-byte elements: digest i = Keccak-256 of row i's elements as little-endian bytes, segment by
+ * segment (element e of segment s = d_segments[s][i * seg_len + e]): a trace matrix is nseg columns with seg_len 1, the rows of
+ * an Fq3 FRI layer ([len][3] interleaved, row j = {evals[j + k rows]}) are nseg = fold segments d_evals + 3 k rows of seg_len 3.
+ * The tree over the digests is ss_merkle_build's SS_TREE_KECCAK.  (The reference instantiates this field with ministark's
+ * SHA-256 trees, un-vendored: this is the library's own choice for it.)  ss_gather_rows_gl64: the opened rows, to HOST memory
+ * [nidx][nseg][seg_len]. */
+ss_status ss_hash_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, uint64_t nrows,
+                            uint8_t *d_digests);
+ss_status ss_gather_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, const uint64_t *idx,
+                              uint32_t nidx, uint64_t *out);
 /* Q1 over the cubic extension: the program format of ss_eval_quotient (ss_air_program above) with accumulators, scratch
  * slots and constants in Fq3 - prog->consts holds n_consts x 3 values < p - and trace cells, tables (prog->d_tables: 8-byte
  * elements) and x in Fp, read into the first coordinate.  d_out: [n * blowup][3] interleaved.  Interpreted (no compiled

@@ -52,7 +52,7 @@ class Expr:
 
     @property
     def is_leaf(self):
-        return self.kind in ("x", "const", "trace", "table")
+        return self.kind in ("x", "const", "const3", "trace", "table")
 
     def __add__(self, o): return Expr("add", *sorted((self, _wrap(o)), key=lambda e: e._id))
     __radd__ = __add__
@@ -88,6 +88,11 @@ def Const(value):
     return Expr("const", int(value))
 
 
+def Const3(c0, c1, c2):
+    """A constant of the cubic extension Fp[X]/(X^3 - 2) (the 64-bit field's challenges, hints, alpha^k): lower(.., ext=True)"""
+    return Expr("const3", int(c0), int(c1), int(c2))
+
+
 def Trace(col, row_offset=0):
     return Expr("trace", int(col), int(row_offset))
 
@@ -115,8 +120,9 @@ class Program:
         return ix
 
 
-def lower(root, modulus):
+def lower(root, modulus, ext=False):
     """Expr DAG -> Program whose last instruction OUTs the value of `root`.
+    ext: the program of the cubic-extension machine (ss_eval_quotient_gl64x3): every constant is a triple (an int v is (v, 0, 0)).
 
     Tree-walk code generation with accumulator `dst` as the working register:
     operands that are leaves (or shared nodes already parked in a slot) are used in
@@ -150,7 +156,10 @@ def lower(root, modulus):
         if n.kind == "x":
             return SRC.X, 0
         if n.kind == "const":
-            return SRC.CONST, prog.const_index(n.args[0] % modulus)
+            return SRC.CONST, prog.const_index((n.args[0] % modulus, 0, 0) if ext else n.args[0] % modulus)
+        if n.kind == "const3":
+            assert ext, "extension-field constant in a base-field program"
+            return SRC.CONST, prog.const_index(tuple(v % modulus for v in n.args))
         if n.kind == "trace":
             return SRC.TRACE, trace_payload(*n.args)
         if n.kind == "table":
@@ -248,4 +257,55 @@ def evaluate(root, modulus, x, trace_at, table_at):
 
     import sys
     sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    return ev(root)
+
+
+def evaluate_ext(root, modulus, x, trace_at, table_at, nonresidue=2):
+    """evaluate() over the cubic extension Fp[X]/(X^3 - nonresidue): x, trace_at(col, off), table_at(idx) -> triples; the
+    out-of-domain side of the 64-bit field's AIR identity."""
+    p = modulus
+
+    def mul(a, b):
+        d = [0] * 5
+        for i in range(3):
+            for j in range(3):
+                d[i + j] += a[i] * b[j]
+        return ((d[0] + nonresidue * d[3]) % p, (d[1] + nonresidue * d[4]) % p, d[2] % p)
+
+    def inv(a):
+        if not any(a):
+            return (0, 0, 0)
+        r, base, e = (1, 0, 0), a, p ** 3 - 2
+        while e:
+            if e & 1:
+                r = mul(r, base)
+            base, e = mul(base, base), e >> 1
+        return r
+    memo = {}
+
+    def ev(n):
+        v = memo.get(n._id)
+        if v is not None:
+            return v
+        k = n.kind
+        if k == "x":
+            v = tuple(x)
+        elif k == "const":
+            v = (n.args[0] % p, 0, 0)
+        elif k == "const3":
+            v = tuple(c % p for c in n.args)
+        elif k == "trace":
+            v = tuple(trace_at(*n.args))
+        elif k == "table":
+            v = tuple(table_at(n.args[0]))
+        elif k == "inv":
+            v = inv(ev(n.args[0]))
+        else:
+            a, b = ev(n.args[0]), ev(n.args[1])
+            v = (tuple((s + t) % p for s, t in zip(a, b)) if k == "add" else tuple((s - t) % p for s, t in zip(a, b)) if k == "sub" else mul(a, b))
+        memo[n._id] = v
+        return v
+
+    import sys
+    sys.setrecursionlimit(max(100000, sys.getrecursionlimit()))
     return ev(root)

@@ -216,6 +216,18 @@ class Context:
         check(self.lib.ss_fri_fold_gl64x3(self.handle, _ptr_of(evals), log_len, fold, a.ctypes.data_as(C.POINTER(C.c_uint64)), int(offset),
                                           flags, _ptr_of(out)))
 
+    def hash_rows_gl64(self, segments, seg_len, nrows, out):
+        """Keccak-256 of the rows of a matrix of 8-byte elements (ss_hash_rows_gl64) -> out[nrows][32]"""
+        check(self.lib.ss_hash_rows_gl64(self.handle, _ptr_array(segments), len(segments), seg_len, nrows, _ptr_of(out)))
+
+    def gather_rows_gl64(self, segments, seg_len, idx):
+        """rows idx of such a matrix -> uint64[len(idx), nseg, seg_len]"""
+        ix = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.zeros((len(ix), len(segments), seg_len), dtype=np.uint64)
+        u64 = C.POINTER(C.c_uint64)
+        check(self.lib.ss_gather_rows_gl64(self.handle, _ptr_array(segments), len(segments), seg_len, ix.ctypes.data_as(u64), len(ix), out.ctypes.data_as(u64)))
+        return out
+
     def eval_quotient_gl64x3(self, code, consts3, n_slots, tables, table_desc, lde_cols, log_n, log_blowup, offset, out):
         """the constraint program over Fq3 (ss_eval_quotient_gl64x3): code = the ss_air_program words, consts3 = uint64[n, 3]"""
         code = np.ascontiguousarray(code, dtype=np.uint32)

@@ -266,7 +266,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP and constraint program: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -1410,6 +1410,36 @@ static HGl3 gl3_mulh(const HGl3 &a, const HGl3 &b) {
 static HGl3 gl3_addh(const HGl3 &a, const HGl3 &b) { return HGl3{{gl_addh(a.c[0], b.c[0]), gl_addh(a.c[1], b.c[1]), gl_addh(a.c[2], b.c[2])}}; }
 static HGl3 gl3_scaleh(const HGl3 &a, uint64_t s) { return HGl3{{gl_mulh(a.c[0], s), gl_mulh(a.c[1], s), gl_mulh(a.c[2], s)}}; }
 static bool gl3_valid(const uint64_t *v) { return v[0] < GL_P && v[1] < GL_P && v[2] < GL_P; }
+
+ss_status ss_hash_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, uint64_t nrows, uint8_t *d_digests) {
+    if (!ctx || !d_segments || !d_digests) return fail(SS_ERR_INVALID, "NULL argument");
+    if (nseg == 0 || nseg > (uint32_t)MAX_COLS || seg_len == 0 || seg_len > 64) return fail(SS_ERR_UNSUPPORTED, "row shape %u x %u out of range", nseg, seg_len);
+    ConstColPtrs segs;
+    memset(&segs, 0, sizeof segs);
+    for (uint32_t c = 0; c < nseg; ++c) { if (!d_segments[c]) return fail(SS_ERR_INVALID, "NULL segment"); segs.p[c] = d_segments[c]; }
+    ss_ctx::Scope prof(ctx, SS_PROF_HASH_ROWS);
+    HIP_TRY(launch_hash_rows_u64(ctx->stream, segs, nseg, seg_len, nrows, d_digests));
+    return SS_OK;
+}
+
+ss_status ss_gather_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, const uint64_t *idx, uint32_t nidx,
+                              uint64_t *out) {
+    if (!ctx || !d_segments || (nidx && (!idx || !out))) return fail(SS_ERR_INVALID, "NULL argument");
+    if (nseg == 0 || nseg > (uint32_t)MAX_COLS || seg_len == 0 || seg_len > 64) return fail(SS_ERR_UNSUPPORTED, "row shape %u x %u out of range", nseg, seg_len);
+    if (!nidx) return SS_OK;
+    ConstColPtrs segs;
+    memset(&segs, 0, sizeof segs);
+    for (uint32_t c = 0; c < nseg; ++c) segs.p[c] = d_segments[c];
+    const size_t total = (size_t)nidx * nseg * seg_len;
+    ss_status st = ctx->ensure_scratch((size_t)nidx * 8 + total * 8);
+    if (st != SS_OK) return st;
+    uint64_t *d_idx = (uint64_t *)ctx->scratch, *d_out = d_idx + nidx;
+    HIP_TRY(hipMemcpyAsync(d_idx, idx, (size_t)nidx * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(launch_gather_rows_u64(ctx->stream, segs, nseg, seg_len, d_idx, nidx, d_out));
+    HIP_TRY(hipMemcpyAsync(out, d_out, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
 
 ss_status ss_eval_quotient_gl64x3(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols, uint32_t ncols, uint32_t log_n,
                                   uint32_t log_blowup, uint64_t offset, uint64_t *d_out) {

@@ -145,6 +145,44 @@ __global__ __launch_bounds__(256) void keccak_rows_kernel(ConstColPtrs cols, uin
     }
 }
 
+// Rows of 8-byte elements (the 64-bit field, X4): the message of row i is the little-endian bytes of its elements,
+// segment by segment - element e of segment s is segs.p[s][i * seg_len + e].  A trace matrix is nseg columns of seg_len 1;
+// the row of a FRI layer over Fq3 (interleaved [len][3], row j = {evals[j + k rows]}) is nseg = fold segments of seg_len 3.
+__global__ __launch_bounds__(256) void keccak_rows_u64_kernel(ConstColPtrs segs, uint32_t nseg, uint32_t seg_len, uint64_t nrows,
+                                                              uint8_t *__restrict__ out) {
+    const uint32_t data_lanes = nseg * seg_len, nblocks = data_lanes / 17 + 1;
+    for (uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; row < nrows; row += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t s[25];
+#pragma unroll
+        for (int i = 0; i < 25; ++i) s[i] = 0;
+        uint32_t seg = 0, e = 0;
+        for (uint32_t blk = 0; blk < nblocks; ++blk) {
+#pragma unroll
+            for (int pos = 0; pos < 17; ++pos) {
+                const uint32_t lane = blk * 17 + pos;
+                if (lane < data_lanes) {
+                    const uint64_t *sp = reinterpret_cast<const uint64_t *>(segs.p[0]);
+#pragma unroll
+                    for (int c = 1; c < MAX_COLS; ++c) if (seg == (uint32_t)c) sp = reinterpret_cast<const uint64_t *>(segs.p[c]);
+                    s[pos] ^= sp[row * seg_len + e];
+                    if (++e == seg_len) { e = 0; ++seg; }
+                } else if (lane == data_lanes) s[pos] ^= 0x01ull;
+            }
+            if (blk == nblocks - 1) s[16] ^= 0x8000000000000000ull;
+            keccak_f1600(s);
+        }
+        keccak_store_digest(s, out + 32 * row, false);
+    }
+}
+// out[(j * nseg + s) * seg_len + e] = segs.p[s][idx[j] * seg_len + e]: the opened rows of such a matrix
+__global__ void gather_rows_u64_kernel(ConstColPtrs segs, uint32_t nseg, uint32_t seg_len, const uint64_t *__restrict__ idx, uint32_t nidx,
+                                       uint64_t *__restrict__ out) {
+    const uint32_t per = nseg * seg_len, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nidx * per) return;
+    const uint32_t j = t / per, r = t - j * per, s = r / seg_len, e = r - s * seg_len;
+    out[t] = reinterpret_cast<const uint64_t *>(segs.p[s])[idx[j] * seg_len + e];
+}
+
 // leaf level of UnhashedLeafConfig: H::hash_elements([l0, l1]) (merkle/mod.rs:426-428)
 __global__ __launch_bounds__(256) void keccak_felt_pairs_kernel(const uint64_t *__restrict__ felts, uint64_t count,
                                                                 uint8_t *__restrict__ out, int mask20) {
@@ -394,6 +432,17 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap) {
     return (uint32_t)g;
 }
 
+hipError_t launch_hash_rows_u64(hipStream_t st, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, uint64_t nrows, uint8_t *digests) {
+    hipLaunchKernelGGL(keccak_rows_u64_kernel, dim3(grid_for(nrows, 256, 1u << 20)), dim3(256), 0, st, segs, nseg, seg_len, nrows, digests);
+    return hipGetLastError();
+}
+hipError_t launch_gather_rows_u64(hipStream_t st, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, const uint64_t *d_idx, uint32_t nidx,
+                                  uint64_t *d_out) {
+    const uint32_t total = nidx * nseg * seg_len;
+    if (!total) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_u64_kernel, dim3((total + 255) / 256), dim3(256), 0, st, segs, nseg, seg_len, d_idx, nidx, d_out);
+    return hipGetLastError();
+}
 hipError_t launch_hash_rows(hipStream_t st, int kind, const ConstColPtrs &cols, uint32_t ncols,
                             uint64_t nrows, uint32_t brev_bits, uint8_t *digests) {
     const uint32_t grid = grid_for(nrows, 256, 1u << 20);

@@ -116,6 +116,9 @@ hipError_t launch_gl3_interleave(hipStream_t st, const uint64_t *c0, const uint6
 hipError_t launch_gl3_zpow_bitrev(hipStream_t st, uint64_t *zp0, uint64_t *zp1, uint64_t *zp2, uint32_t log_n, const uint64_t z[3]);
 hipError_t launch_gl3_scale_columns(hipStream_t st, const uint64_t *coef, const uint64_t *zp0, const uint64_t *zp1, const uint64_t *zp2, uint64_t n,
                                     uint64_t *o0, uint64_t *o1, uint64_t *o2);
+hipError_t launch_hash_rows_u64(hipStream_t st, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, uint64_t nrows, uint8_t *digests);
+hipError_t launch_gather_rows_u64(hipStream_t st, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, const uint64_t *d_idx, uint32_t nidx,
+                                  uint64_t *d_out);
 uint32_t gl3_vm_lanes(uint64_t N);
 hipError_t launch_gl3_vm(hipStream_t st, const uint32_t *d_code, uint32_t n_instr, const uint64_t *d_consts, const uint64_t *d_tables,
                          const uint32_t *d_tdesc, const uint64_t *const *cols, uint32_t ncols, uint64_t *d_slots, uint64_t *d_out, uint64_t offset,
