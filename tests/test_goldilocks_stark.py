@@ -1,0 +1,145 @@
+"""BASELINE.json configs[4]: the `plain` layout over p = 2^64 - 2^32 + 1 with Fq3 challenges (layouts/plain.py) and the STARK
+around it (sandstorm_amd/goldilocks.py).  PARITY UNPINNED (the reference's parts for this claim are un-vendored and it ships
+no program, trace or proof for the field): what is held here is
+  * the restated AIR against a run of a minimal Cairo machine over this field - every constraint vanishes on its domain, the
+    permutation products close, and a corrupted cell is caught by the constraint that owns it;
+  * the lowered composition program (oracle VM) against the expression DAG evaluated in Python integers;
+  * on the device: a proof of the true statement verifies, and no tampered proof or statement does."""
+import copy
+
+import numpy as np
+import pytest
+
+from sandstorm_amd import air_program as ap
+from sandstorm_amd.layouts import plain as pl
+
+CH = [(11, 22, 33), (5, 6, 7), (9, 8, 7)]
+
+
+@pytest.fixture(scope="module")
+def run():
+    prog = pl.example_program(10)
+    states, memory = pl.run(prog, 64)
+    pi = pl.public_input_of(prog, states, memory)
+    return prog, states, memory, pi, pl.base_trace(states, memory, pi)
+
+
+def test_the_machine_runs_the_example(run):
+    prog, states, memory, pi, cols = run
+    x = 3
+    for _ in range(10):
+        x = (x * x + 7) % pl.P
+    assert x in memory and states[-1].pc == states[-2].pc               # the loop's result is in memory; the run ends in `jmp rel 0`
+    assert states[-1].fp == states[0].fp and len(cols) == 5 and len(cols[0]) == 16 * 64
+
+
+def test_plain_layout_trace_satisfies_the_constraints(run):
+    prog, states, memory, pi, cols = run
+    n = len(cols[0])
+    ext, last = pl.extension_columns(cols, CH)
+    hints = pl.Hints.from_public_input(pi, CH, n)
+    assert last == hints.memory_quotient                                # the memory product ends at the public-memory quotient
+    cs = pl.constraints(hints, CH)
+    assert len(cs) == 47 and len(pl.mask(cs)) == 56
+    for c in cs:
+        assert not pl.failing_rows(c, cols + ext, n), c.name
+    # a corrupted cell is caught by the constraints that read it
+    bad = [list(c) for c in cols]
+    bad[pl.COL_RANGE_CHECK][16 * 2 + pl.Auxiliary.RES[1]] += 1        # `res` of cycle 2 (the loop's multiplication)
+    names = [c.name for c in cs if pl.failing_rows(c, bad + ext, n)]
+    assert "cpu/operands/res" in names
+    # a value outside the program's offsets breaks the range-check permutation
+    bad = [list(c) for c in cols]
+    bad[pl.COL_RANGE_CHECK][16 * 7 + pl.RangeCheck.OFF_DST] = 5
+    with pytest.raises(ValueError):
+        pl.extension_columns(bad, CH)
+
+
+def test_lowered_composition_is_the_dag(run, oracle):
+    prog, states, memory, pi, cols = run
+    n, lb = len(cols[0]), 1
+    N, log_n = n << lb, n.bit_length() - 1
+    ext, _ = pl.extension_columns(cols, CH)
+    lde = [oracle.gl_lde(np.array(c, dtype=np.uint64), lb, pl.GENERATOR)[0] for c in cols + ext]
+    hints = pl.Hints.from_public_input(pi, CH, n)
+    tables = pl.Tables(n, lb)
+    alpha = (123456789, 987654321, 55555)
+    root = pl.composition(n, hints, CH, alpha, tables)
+    program = ap.lower(root, pl.P, ext=True)
+    tvals, tdesc = tables.device_tables()
+    got = oracle.gl3_eval_program(np.array(program.code, dtype=np.uint32), np.array(program.consts, dtype=np.uint64), program.n_slots, tvals, tdesc,
+                                  lde, log_n, lb, pl.GENERATOR)
+    wN = pl.root_of_unity(log_n + lb)
+    for i in (0, 1, 2, 17, 1000, N - 1):
+        x = pl.GENERATOR * pow(wN, i, pl.P) % pl.P
+        want = ap.evaluate_ext(root, pl.P, (x, 0, 0), lambda c, o: (int(lde[c][(i + (o << lb)) % N]), 0, 0),
+                               lambda t: (tables.host_values(tables.specs[t])[i % tables.length(tables.specs[t])], 0, 0))
+        assert tuple(int(v) for v in got[i]) == tuple(want), i
+    # the trace satisfies the AIR: every quotient is a polynomial, the largest (a quadratic numerator over X - 1) of degree 2 n - 3
+    for t in range(3):
+        co = oracle.gl_ntt(got[:, t].copy(), inverse=True, offset=pl.GENERATOR)
+        assert co.any() and not co[N - 2:].any()
+
+
+@pytest.fixture(scope="module")
+def proved(run):
+    import torch
+    from sandstorm_amd import backend as be, goldilocks as gs
+    prog, states, memory, pi, cols = run
+    dev = torch.device("cuda", 0)
+    ctx = be.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    tensor = lambda c: torch.from_numpy(np.array(c, dtype=np.uint64).view(np.int64)).to(dev)
+    air = gs.plain_air()
+    opt = gs.Options(num_queries=20, grinding=8)
+
+    def prove(columns, options=opt):
+        def build_extension(ch):
+            ext, _ = pl.extension_columns(columns, ch)
+            return [tensor(c) for c in ext]
+        return gs.Prover(ctx, air, options).prove(bytes(range(32)), [tensor(c) for c in columns], build_extension, statement=pi)
+    yield gs, air, pi, cols, prove, opt
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_proof_of_the_example_verifies(proved):
+    gs, air, pi, cols, prove, opt = proved
+    proof = prove(cols)
+    positions = gs.verify(proof, air, bytes(range(32)), statement=pi, expected_options=opt, required_security_bits=28)
+    assert len(positions) >= 15 and len(proof.fri_layers) == 2 and proof.remainder.shape == (32, 3)
+    assert gs.verify(prove(cols), air, bytes(range(32)), statement=pi) == positions      # deterministic
+
+
+@pytest.mark.gpu
+def test_tampered_proofs_and_statements_are_rejected(proved):
+    gs, air, pi, cols, prove, opt = proved
+    proof = prove(cols)
+    seed = bytes(range(32))
+
+    def rejected(mutate, **kw):
+        p = copy.deepcopy(proof)
+        mutate(p)
+        with pytest.raises(gs.VerificationError):
+            gs.verify(p, air, kw.get("seed", seed), statement=kw.get("statement", pi), expected_options=kw.get("expected", None))
+    rejected(lambda p: None, seed=bytes(32))                                               # another transcript
+    other = copy.deepcopy(pi)
+    other.public_memory[3] = (other.public_memory[3][0], other.public_memory[3][1] ^ 1)
+    rejected(lambda p: None, statement=other)                                              # another program
+    other = copy.deepcopy(pi)
+    other.rc_max += 1
+    rejected(lambda p: None, statement=other)
+    rejected(lambda p: p.ood_trace.__setitem__((5, 0), (int(p.ood_trace[5, 0]) + 1) % pl.P))
+    rejected(lambda p: p.ood_comp.__setitem__((2, 1), (int(p.ood_comp[2, 1]) + 1) % pl.P))
+    rejected(lambda p: p.base.rows.__setitem__((0, 1), int(p.base.rows[0, 1]) ^ 1))
+    rejected(lambda p: p.comp.paths.__setitem__((1, 2, 0), int(p.comp.paths[1, 2, 0]) ^ 1))
+    rejected(lambda p: p.fri_layers[1].opening.rows.__setitem__((0, 4), int(p.fri_layers[1].opening.rows[0, 4]) ^ 1))
+    rejected(lambda p: p.remainder.__setitem__((3, 0), (int(p.remainder[3, 0]) + 1) % pl.P))
+    rejected(lambda p: setattr(p, "pow_nonce", p.pow_nonce + 1))
+    rejected(lambda p: setattr(p, "comp_root", bytes(32)))
+    rejected(lambda p: setattr(p.options, "num_queries", 19), expected=opt)
+    rejected(lambda p: setattr(p.options, "grinding", 0))                                  # the transcript's nonce no longer counts
+    # a trace that breaks a constraint yields no proof: the prover sees a remainder of full degree
+    bad = [list(c) for c in cols]
+    bad[pl.COL_AUXILIARY][16 * 9 + pl.Auxiliary.TMP0[1]] += 1
+    with pytest.raises(ValueError):
+        prove(bad)
