@@ -121,7 +121,8 @@ def _powers3(a, count):
 
 # ---- prover ----------------------------------------------------------------------------------------------------------------------
 class Prover:
-    """columns are torch int64 tensors on the device (anything with data_ptr()); ctx: backend.Context"""
+    """columns are torch int64 tensors on the device; ctx: a backend.Context bound to the SAME stream torch works on - an explicit
+    torch.cuda.Stream made current (torch's default stream has handle 0, which the C ABI reads as "the context's own stream")"""
 
     def __init__(self, ctx, air: Air, options: Options = None):
         self.ctx, self.air, self.opt = ctx, air, options or Options()

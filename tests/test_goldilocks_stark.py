@@ -87,7 +87,11 @@ def proved(run):
     from sandstorm_amd import backend as be, goldilocks as gs
     prog, states, memory, pi, cols = run
     dev = torch.device("cuda", 0)
-    ctx = be.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    # ONE stream for torch's tensor ops and the C ABI's kernels (torch's default stream has handle 0, which ss_ctx_set_stream reads
+    # as "the context's own stream": the two would not be ordered)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    ctx = be.Context(0, stream=stream.cuda_stream)
     tensor = lambda c: torch.from_numpy(np.array(c, dtype=np.uint64).view(np.int64)).to(dev)
     air = gs.plain_air()
     opt = gs.Options(num_queries=20, grinding=8)
