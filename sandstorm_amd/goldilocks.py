@@ -100,6 +100,12 @@ class Coin(PublicCoin):
         self.reseed_with_bytes(b"".join(int(c).to_bytes(8, "little") for v in values for c in v))
 
 
+def transcript_seed(seed: bytes, opt: Options, trace_len: int) -> bytes:
+    """the options and the trace length are part of the transcript: a proof does not verify under other options"""
+    return keccak256(bytes(seed) + b"".join(int(v).to_bytes(8, "big") for v in (opt.num_queries, opt.log_blowup, opt.grinding, opt.fold,
+                                                                                 opt.max_remainder, trace_len)))
+
+
 def fri_shape(n_lde, opt: Options):
     """-> number of FRI layers; the remainder is the last layer (len <= max_remainder * blowup)"""
     layers, length = 0, n_lde
@@ -151,7 +157,7 @@ class Prover:
         N = n << lb
         dev = base_cols[0].device
         new = lambda rows, width=None: torch.zeros((rows,) if width is None else (rows, width), dtype=torch.int64, device=dev)
-        coin = Coin(seed)
+        coin = Coin(transcript_seed(seed, opt, n))
         proof = Proof(opt, n)
 
         def extend(cols):
@@ -308,7 +314,7 @@ def verify(proof: Proof, air: Air, seed: bytes, statement=None, expected_options
     N = n << lb
     _need(lb == 1, "the composition split is written for blowup 2")
     ncols = air.num_base + air.num_ext
-    coin = Coin(seed)
+    coin = Coin(transcript_seed(seed, opt, n))
     coin.reseed_with_digest(proof.base_root)
     challenges = [coin.draw_fq3() for _ in range(air.num_challenges)]
     if air.num_ext:
