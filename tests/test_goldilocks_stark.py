@@ -142,8 +142,9 @@ def test_tampered_proofs_and_statements_are_rejected(proved):
     rejected(lambda p: setattr(p, "comp_root", bytes(32)))
     rejected(lambda p: setattr(p.options, "num_queries", 19), expected=opt)
     rejected(lambda p: setattr(p.options, "grinding", 0))                                  # the transcript's nonce no longer counts
-    # a trace that breaks a constraint yields no proof: the prover sees a remainder of full degree
+    # a trace that breaks a constraint: the quotient is then not the polynomial the out-of-domain identity asks for (on a domain
+    # of 2 n points every function interpolates, so the prover cannot tell; the verifier's recomputation at z does)
     bad = [list(c) for c in cols]
     bad[pl.COL_AUXILIARY][16 * 9 + pl.Auxiliary.TMP0[1]] += 1
-    with pytest.raises(ValueError):
-        prove(bad)
+    with pytest.raises(gs.VerificationError, match="do not satisfy the AIR"):
+        gs.verify(prove(bad), air, seed, statement=pi)
