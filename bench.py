@@ -49,6 +49,11 @@ WORKLOADS = {
     # ss_deep_compose_gl64x3, ss_fri_fold_gl64x3; the experimental `plain` layout's AIR is not built): a step = the LDE of 10
     # columns of 2^24 rows, blowup 2 - the NTT work of that configuration's trace commitment; the other kernels are timed beside it
     "goldilocks_lde_2p20": ("goldilocks", 20),
+    # BASELINE.json configs[4] as a whole proof: the `plain` layout's 47-constraint AIR (5 base columns + one Fq3 extension column =
+    # 8 committed coordinate columns) at 2^20 steps through sandstorm_amd/goldilocks.py - this library's own instantiation of the
+    # claim the reference builds from un-vendored parts (parity unpinned); synthetic columns, as for the other workloads
+    "goldilocks_plain_2p20": ("goldilocks-plain", 20),
+    "goldilocks_plain_2p16": ("goldilocks-plain", 16),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -281,6 +286,80 @@ def _gl_passes(log_n, log_tile=13):
     return out
 
 
+def bench_goldilocks_plain(args, log_steps, rank, local_rank, world, device):
+    """--workload goldilocks_plain_2p20: ONE proof of the plain layout's real AIR over p = 2^64 - 2^32 + 1 with Fq3 challenges at
+    2^20 steps (2^24 rows, 8 committed coordinate columns, blowup 2): LDE, row hashing + trees, the constraint program, composition
+    split, out-of-domain evaluation, DEEP over Fq3, FRI (fold 8), proof of work, openings - and the extension column's running
+    products between the two trace commitments.  Base columns are synthetic (a constraint program's cost does not depend on the
+    trace).  One independent proof per rank."""
+    import numpy as np
+    from sandstorm_amd import backend as be, goldilocks as gs
+    from sandstorm_amd.layouts import plain as pl
+    n = 16 << log_steps
+    stream = torch.cuda.Stream(device)            # one stream for torch's tensor ops and the C ABI's kernels
+    torch.cuda.set_stream(stream)
+    ctx = be.Context(local_rank, stream=stream.cuda_stream)
+    prog = pl.example_program(10)
+    states, memory = pl.run(prog, 64)
+    pi = pl.public_input_of(prog, states, memory)
+    pi.n_steps = 1 << log_steps                   # the statement only feeds constants of the program
+    air, opt = gs.plain_air(), gs.Options()
+    g = torch.Generator(device=device)
+    g.manual_seed(0x504C + rank)
+    cols = torch.randint(0, 2**62, (5, n), dtype=torch.int64, device=device, generator=g)
+    prover = gs.Prover(ctx, air, opt)
+    seed = bytes((11 * i) & 0xff for i in range(32))
+    base = [cols[c] for c in range(5)]
+    # the extension column's running products are built on the device inside the timed region (check=False: synthetic columns are
+    # not permutations of each other)
+    step = lambda: prover.prove(seed, base, lambda ch: gs.plain_extension_on_device(ctx, base, ch, check=False)[0], statement=pi)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    proof = step()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kinds = [("ntt_pass", be.PROF_NTT_PASS), ("hash_rows", be.PROF_HASH_ROWS), ("merkle", be.PROF_MERKLE), ("fri_fold", be.PROF_FRI),
+             ("quotient", be.PROF_QUOTIENT), ("deep", be.PROF_DEEP), ("extension_scans", be.PROF_EXT)]
+    prof = {name: ctx.profile_read(k) for name, k in kinds}
+    ctx.profile(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    sec = dt / args.steps
+    if rank == 0:
+        ntt_ms, launches = prof["ntt_pass"]
+        emit({"metric": "prove_wall_time_s", "value": sec, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": sec * 1e3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+              "dtype": "u64 (p = 2^64 - 2^32 + 1), challenges in Fq3", "data": "synthetic", "proofs_per_s": world / sec,
+              "config": {"workload": args.workload, "layout": "plain (47 constraints, %d mask cells over 8 coordinate columns)" % len(air.mask),
+                         "steps_log2": log_steps, "trace_rows_log2": log_steps + 4, "blowup": 2,
+                         "proof_options": "%d queries, blowup 2, %d PoW bits, FRI fold %d, <= %d remainder coefficients"
+                                          % (opt.num_queries, opt.grinding, opt.fold, opt.max_remainder),
+                         "claim": "this library's own instantiation (Keccak trees over the rows' bytes, Keccak coin, Fq3 columns as three "
+                                  "coordinate columns): the reference's parts for this claim are un-vendored - PARITY UNPINNED",
+                         "host": "Python host (sandstorm_amd/goldilocks.py) over the C ABI", "fri_layers": len(proof.fri_layers),
+                         "outside": "host trace generation: base columns resident in HBM",
+                         "per_gpu": "one independent proof per rank"},
+              "stage_ms_per_proof": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
+              "roofline": {"bound": "hbm", "kernel": "ss::gl_ntt_pass_kernel", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
+                           "traffic": None, "launches": launches, "avg_launch_ms": ntt_ms / max(1, launches),
+                           "note": "see --workload goldilocks_lde_2p20 for the transform's own roofline line"}})
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     """--gpus N > 1: ONE proof over the N GPUs of the node (sandstorm_amd/sharded_prover.py): trace columns extended on
     their owner (column c on rank c % N), point-to-point re-shards into row blocks over RCCL, row hashing / constraint
@@ -392,6 +471,8 @@ def main():
     layout, log_steps = WORKLOADS[args.workload]
     if layout == "goldilocks":
         return bench_goldilocks(args, log_steps, rank, local_rank, world, device)
+    if layout == "goldilocks-plain":
+        return bench_goldilocks_plain(args, log_steps, rank, local_rank, world, device)
     if (world > 1 and args.mode == "auto" or args.mode == "shard") and layout in ("starknet", "recursive"):
         if world == 1:                      # --mode shard on one GPU: the sharded driver with a group of one (smoke / profiling)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

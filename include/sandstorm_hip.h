@@ -274,6 +274,13 @@ ss_status ss_fri_fold_gl64x3(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_
  *   sum_j coeff_trace[j] (T_{col_j}(x_i) - ood_trace[j]) / (x_i - z w_n^{off_j})
  *   + sum_k coeff_comp[k] (H_k(x_i) - ood_comp[k]) / (x_i - z_comp),      x_i = offset * w_{n blowup}^i,
  *   composed on the n-point sub-coset and extended per component (the polynomial has degree < n). */
+/* A2 over the cubic extension (plain layout: Trace::build_extension_columns, layouts/src/plain/trace.rs:274-330): the running
+ * quotient of a permutation argument, out[k] = prod_{i<=k} (z - (alpha nv_i + na_i)) / prod_{i<=k} (z - (alpha dv_i + da_i)) in Fq3,
+ * item i reading element i * stride of each input (value pointers NULL: single-column argument, terms z - a_i), written as three
+ * coordinate columns at row out_offset + k * out_stride.  last_out (nullable, host): the final quotient - 1 for a permutation. */
+ss_status ss_running_product_gl64x3(ss_ctx *ctx, const uint64_t *d_num_addr, const uint64_t *d_num_val, const uint64_t *d_den_addr,
+                                    const uint64_t *d_den_val, uint64_t stride, uint64_t count, const uint64_t z[3], const uint64_t alpha[3],
+                                    uint64_t *const d_out[3], uint64_t out_stride, uint64_t out_offset, uint64_t last_out[3]);
 /* H1 / openings for matrices of 8-byte elements: digest i = Keccak-256 of row i's elements as little-endian bytes, segment by
  * segment (element e of segment s = d_segments[s][i * seg_len + e]): a trace matrix is nseg columns with seg_len 1, the rows of
  * an Fq3 FRI layer ([len][3] interleaved, row j = {evals[j + k rows]}) are nseg = fold segments d_evals + 3 k rows of seg_len 3.

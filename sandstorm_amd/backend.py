@@ -216,6 +216,18 @@ class Context:
         check(self.lib.ss_fri_fold_gl64x3(self.handle, _ptr_of(evals), log_len, fold, a.ctypes.data_as(C.POINTER(C.c_uint64)), int(offset),
                                           flags, _ptr_of(out)))
 
+    def running_product_gl64x3(self, num_addr, num_val, den_addr, den_val, stride, count, z, alpha, out_cols, out_stride, out_offset, want_last=True):
+        """ss_running_product_gl64x3: the permutation argument's running quotient over Fq3 into three coordinate columns -> the last value"""
+        u64 = C.POINTER(C.c_uint64)
+        zz = np.ascontiguousarray(z, dtype=np.uint64)
+        aa = np.ascontiguousarray(alpha, dtype=np.uint64) if alpha is not None else None
+        last = np.zeros(3, dtype=np.uint64)
+        check(self.lib.ss_running_product_gl64x3(self.handle, _ptr_of(num_addr), _ptr_of(num_val) if num_val is not None else None, _ptr_of(den_addr),
+                                                 _ptr_of(den_val) if den_val is not None else None, stride, count, zz.ctypes.data_as(u64),
+                                                 aa.ctypes.data_as(u64) if aa is not None else None, _ptr_array(out_cols), out_stride, out_offset,
+                                                 last.ctypes.data_as(u64) if want_last else None))
+        return tuple(int(v) for v in last) if want_last else None
+
     def hash_rows_gl64(self, segments, seg_len, nrows, out):
         """Keccak-256 of the rows of a matrix of 8-byte elements (ss_hash_rows_gl64) -> out[nrows][32]"""
         check(self.lib.ss_hash_rows_gl64(self.handle, _ptr_array(segments), len(segments), seg_len, nrows, _ptr_of(out)))

@@ -266,7 +266,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -1410,6 +1410,27 @@ static HGl3 gl3_mulh(const HGl3 &a, const HGl3 &b) {
 static HGl3 gl3_addh(const HGl3 &a, const HGl3 &b) { return HGl3{{gl_addh(a.c[0], b.c[0]), gl_addh(a.c[1], b.c[1]), gl_addh(a.c[2], b.c[2])}}; }
 static HGl3 gl3_scaleh(const HGl3 &a, uint64_t s) { return HGl3{{gl_mulh(a.c[0], s), gl_mulh(a.c[1], s), gl_mulh(a.c[2], s)}}; }
 static bool gl3_valid(const uint64_t *v) { return v[0] < GL_P && v[1] < GL_P && v[2] < GL_P; }
+
+ss_status ss_running_product_gl64x3(ss_ctx *ctx, const uint64_t *d_num_addr, const uint64_t *d_num_val, const uint64_t *d_den_addr,
+                                    const uint64_t *d_den_val, uint64_t stride, uint64_t count, const uint64_t z[3], const uint64_t alpha[3],
+                                    uint64_t *const d_out[3], uint64_t out_stride, uint64_t out_offset, uint64_t last_out[3]) {
+    if (!ctx || !d_num_addr || !d_den_addr || !z || !d_out || !d_out[0] || !d_out[1] || !d_out[2]) return fail(SS_ERR_INVALID, "NULL argument");
+    if ((d_num_val || d_den_val) && (!d_num_val || !d_den_val || !alpha)) return fail(SS_ERR_INVALID, "value columns and alpha come together");
+    if (count == 0 || stride == 0 || out_stride == 0) return fail(SS_ERR_INVALID, "empty product");
+    if (!gl3_valid(z) || (alpha && !gl3_valid(alpha))) return fail(SS_ERR_INVALID, "challenge is not an element of the extension");
+    const uint64_t zero3[3] = {0, 0, 0};
+    ss_status st = ctx->ensure_scratch2((6 * (count / 7 + 64) + 8) * 8);
+    if (st != SS_OK) return st;
+    uint64_t *scratch = (uint64_t *)ctx->scratch2, *d_last = scratch + 6 * (count / 7 + 64);
+    ss_ctx::Scope prof(ctx, SS_PROF_EXT);
+    HIP_TRY(launch_gl3_running_product(ctx->stream, d_num_addr, d_num_val, d_den_addr, d_den_val, stride, count, z, alpha ? alpha : zero3, scratch,
+                                       d_out[0], d_out[1], d_out[2], out_stride, out_offset, last_out ? d_last : nullptr));
+    if (last_out) {
+        HIP_TRY(hipMemcpyAsync(last_out, d_last, 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return SS_OK;
+}
 
 ss_status ss_hash_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, uint64_t nrows, uint8_t *d_digests) {
     if (!ctx || !d_segments || !d_digests) return fail(SS_ERR_INVALID, "NULL argument");

@@ -591,4 +591,104 @@ hipError_t launch_gl3_vm(hipStream_t st, const uint32_t *d_code, uint32_t n_inst
     return hipGetLastError();
 }
 
+
+// ---- running products over Fq3: the permutation arguments' extension column (plain layout: trace.rs:274-330) ----------------------
+// out[k] = prod_{i <= k} (z - (alpha nv_i + na_i)) / prod_{i <= k} (z - (alpha dv_i + da_i)), written as three coordinate columns at
+// row out_offset + k out_stride.  The state of the scan is the PAIR (numerator product, denominator product) in Fq3; levels of 8
+// items per lane: reduce (8 states -> 1) down to a handful, scan those serially, then apply back up (exclusive prefixes of the
+// groups), and the last apply writes numerator * denominator^-1 (one norm-based inverse per output).
+struct Gl3Pair { Gl3 n, d; };
+__device__ __forceinline__ Gl3Pair gl3p_mul(const Gl3Pair &a, const Gl3Pair &b) { return Gl3Pair{gl3_mul(a.n, b.n), gl3_mul(a.d, b.d)}; }
+__device__ __forceinline__ Gl3Pair gl3p_load(const uint64_t *p) { return Gl3Pair{gl3_load(p), gl3_load(p + 3)}; }
+__device__ __forceinline__ void gl3p_store(uint64_t *p, const Gl3Pair &v) {
+    p[0] = v.n.c[0]; p[1] = v.n.c[1]; p[2] = v.n.c[2]; p[3] = v.d.c[0]; p[4] = v.d.c[1]; p[5] = v.d.c[2];
+}
+struct Gl3PermArgs {
+    const uint64_t *na, *nv, *da, *dv;        // nv / dv may be NULL (single-column argument: terms z - a)
+    uint64_t stride;                          // item i reads element i * stride of each
+    uint64_t count;
+    Gl3 z, alpha;
+};
+__device__ __forceinline__ Gl3Pair gl3_perm_term(const Gl3PermArgs &a, uint64_t i) {
+    Gl3Pair t;
+    Gl3 n = a.nv ? gl3_scale(a.alpha, a.nv[i * a.stride]) : Gl3{{0, 0, 0}};
+    n.c[0] = gl_add(n.c[0], a.na[i * a.stride]);
+    Gl3 d = a.dv ? gl3_scale(a.alpha, a.dv[i * a.stride]) : Gl3{{0, 0, 0}};
+    d.c[0] = gl_add(d.c[0], a.da[i * a.stride]);
+    t.n = gl3_sub(a.z, n);
+    t.d = gl3_sub(a.z, d);
+    return t;
+}
+static constexpr int GL3_SCAN_GROUP = 8;
+// level 0: out[j] = product of the terms of items 8 j .. 8 j + 7
+__global__ void gl3_perm_reduce0_kernel(Gl3PermArgs a, uint64_t groups, uint64_t *__restrict__ out) {
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < groups; j += (uint64_t)gridDim.x * blockDim.x) {
+        Gl3Pair run{{{1, 0, 0}}, {{1, 0, 0}}};
+        for (int i = 0; i < GL3_SCAN_GROUP; ++i) { const uint64_t k = j * GL3_SCAN_GROUP + i; if (k < a.count) run = gl3p_mul(run, gl3_perm_term(a, k)); }
+        gl3p_store(out + 6 * j, run);
+    }
+}
+__global__ void gl3_pair_reduce_kernel(const uint64_t *__restrict__ in, uint64_t m, uint64_t groups, uint64_t *__restrict__ out) {
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < groups; j += (uint64_t)gridDim.x * blockDim.x) {
+        Gl3Pair run{{{1, 0, 0}}, {{1, 0, 0}}};
+        for (int i = 0; i < GL3_SCAN_GROUP; ++i) { const uint64_t k = j * GL3_SCAN_GROUP + i; if (k < m) run = gl3p_mul(run, gl3p_load(in + 6 * k)); }
+        gl3p_store(out + 6 * j, run);
+    }
+}
+// top: exclusive scan of a handful of states by one lane (in place)
+__global__ void gl3_pair_scan_top_kernel(uint64_t *__restrict__ st, uint64_t m) {
+    if (blockIdx.x || threadIdx.x) return;
+    Gl3Pair run{{{1, 0, 0}}, {{1, 0, 0}}};
+    for (uint64_t k = 0; k < m; ++k) { const Gl3Pair v = gl3p_load(st + 6 * k); gl3p_store(st + 6 * k, run); run = gl3p_mul(run, v); }
+}
+// apply: st[k] (the group products of this level) become their exclusive prefixes, seeded by the level above (prefix[j] for group j)
+__global__ void gl3_pair_apply_kernel(uint64_t *__restrict__ st, uint64_t m, const uint64_t *__restrict__ prefix, uint64_t groups) {
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < groups; j += (uint64_t)gridDim.x * blockDim.x) {
+        Gl3Pair run = gl3p_load(prefix + 6 * j);
+        for (int i = 0; i < GL3_SCAN_GROUP; ++i) {
+            const uint64_t k = j * GL3_SCAN_GROUP + i;
+            if (k < m) { const Gl3Pair v = gl3p_load(st + 6 * k); gl3p_store(st + 6 * k, run); run = gl3p_mul(run, v); }
+        }
+    }
+}
+// level 0 apply: the running quotient of every item, into the coordinate columns
+__global__ void gl3_perm_apply0_kernel(Gl3PermArgs a, const uint64_t *__restrict__ prefix, uint64_t groups, uint64_t *__restrict__ o0,
+                                       uint64_t *__restrict__ o1, uint64_t *__restrict__ o2, uint64_t out_stride, uint64_t out_offset,
+                                       uint64_t *__restrict__ last) {
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < groups; j += (uint64_t)gridDim.x * blockDim.x) {
+        Gl3Pair run = gl3p_load(prefix + 6 * j);
+        for (int i = 0; i < GL3_SCAN_GROUP; ++i) {
+            const uint64_t k = j * GL3_SCAN_GROUP + i;
+            if (k >= a.count) break;
+            run = gl3p_mul(run, gl3_perm_term(a, k));
+            const Gl3 q = gl3_mul(run.n, gl3_inv_dev(run.d));
+            const uint64_t row = out_offset + k * out_stride;
+            o0[row] = q.c[0]; o1[row] = q.c[1]; o2[row] = q.c[2];
+            if (k == a.count - 1 && last) { last[0] = q.c[0]; last[1] = q.c[1]; last[2] = q.c[2]; }
+        }
+    }
+}
+hipError_t launch_gl3_running_product(hipStream_t st, const uint64_t *na, const uint64_t *nv, const uint64_t *da, const uint64_t *dv, uint64_t stride,
+                                      uint64_t count, const uint64_t z[3], const uint64_t alpha[3], uint64_t *scratch /* >= 6 * (count / 7 + 64) u64 */,
+                                      uint64_t *o0, uint64_t *o1, uint64_t *o2, uint64_t out_stride, uint64_t out_offset, uint64_t *d_last) {
+    Gl3PermArgs a{na, nv, da, dv, stride, count, Gl3{{z[0], z[1], z[2]}}, Gl3{{alpha[0], alpha[1], alpha[2]}}};
+    // level sizes: m[0] = groups of items, m[l + 1] = groups of m[l]
+    uint64_t m[16], off[16];
+    int levels = 0;
+    uint64_t cur = (count + GL3_SCAN_GROUP - 1) / GL3_SCAN_GROUP, at = 0;
+    m[0] = cur; off[0] = 0; at = 6 * cur; levels = 1;
+    while (cur > 16) {
+        cur = (cur + GL3_SCAN_GROUP - 1) / GL3_SCAN_GROUP;
+        m[levels] = cur; off[levels] = at; at += 6 * cur; ++levels;
+    }
+    hipLaunchKernelGGL(gl3_perm_reduce0_kernel, dim3(gl_blocks(m[0])), dim3(256), 0, st, a, m[0], scratch + off[0]);
+    for (int l = 1; l < levels; ++l)
+        hipLaunchKernelGGL(gl3_pair_reduce_kernel, dim3(gl_blocks(m[l])), dim3(256), 0, st, scratch + off[l - 1], m[l - 1], m[l], scratch + off[l]);
+    hipLaunchKernelGGL(gl3_pair_scan_top_kernel, dim3(1), dim3(64), 0, st, scratch + off[levels - 1], m[levels - 1]);
+    for (int l = levels - 1; l >= 1; --l)
+        hipLaunchKernelGGL(gl3_pair_apply_kernel, dim3(gl_blocks(m[l])), dim3(256), 0, st, scratch + off[l - 1], m[l - 1], scratch + off[l], m[l]);
+    hipLaunchKernelGGL(gl3_perm_apply0_kernel, dim3(gl_blocks(m[0])), dim3(256), 0, st, a, scratch + off[0], m[0], o0, o1, o2, out_stride, out_offset, d_last);
+    return hipGetLastError();
+}
+
 }  // namespace ss

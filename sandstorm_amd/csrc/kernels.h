@@ -119,6 +119,9 @@ hipError_t launch_gl3_scale_columns(hipStream_t st, const uint64_t *coef, const 
 hipError_t launch_hash_rows_u64(hipStream_t st, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, uint64_t nrows, uint8_t *digests);
 hipError_t launch_gather_rows_u64(hipStream_t st, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, const uint64_t *d_idx, uint32_t nidx,
                                   uint64_t *d_out);
+hipError_t launch_gl3_running_product(hipStream_t st, const uint64_t *na, const uint64_t *nv, const uint64_t *da, const uint64_t *dv, uint64_t stride,
+                                      uint64_t count, const uint64_t z[3], const uint64_t alpha[3], uint64_t *scratch, uint64_t *o0, uint64_t *o1,
+                                      uint64_t *o2, uint64_t out_stride, uint64_t out_offset, uint64_t *d_last);
 uint32_t gl3_vm_lanes(uint64_t N);
 hipError_t launch_gl3_vm(hipStream_t st, const uint32_t *d_code, uint32_t n_instr, const uint64_t *d_consts, const uint64_t *d_tables,
                          const uint32_t *d_tdesc, const uint64_t *const *cols, uint32_t ncols, uint64_t *d_slots, uint64_t *d_out, uint64_t offset,

@@ -410,6 +410,23 @@ def verify(proof: Proof, air: Air, seed: bytes, statement=None, expected_options
     return positions
 
 
+def plain_extension_on_device(ctx, base_cols, challenges, check=True):
+    """Trace::build_extension_columns of the plain layout (layouts/src/plain/trace.rs:274-330) on the device: the memory and
+    range-check running quotients interleaved in one Fq3 column -> its three coordinate columns (torch tensors) and the last
+    value of the memory product (the public-memory quotient of a true statement)"""
+    import torch
+    npc, mem, rc = base_cols[F.COL_NPC], base_cols[F.COL_MEMORY], base_cols[F.COL_RANGE_CHECK]
+    n = npc.shape[0]
+    out = [torch.zeros(n, dtype=torch.int64, device=npc.device) for _ in range(3)]
+    last_mem = ctx.running_product_gl64x3(npc, npc[1:], mem, mem[1:], F.MEMORY_STEP, n // F.MEMORY_STEP, challenges[F.MEM_Z], challenges[F.MEM_A], out,
+                                          F.MEMORY_STEP, 0)
+    last_rc = ctx.running_product_gl64x3(rc[F.RangeCheck.OFF_DST:], None, rc[F.RangeCheck.ORDERED:], None, F.RANGE_CHECK_STEP, n // F.RANGE_CHECK_STEP,
+                                         challenges[F.RC_Z], None, out, F.RANGE_CHECK_STEP, 1)
+    if check and last_rc != (1, 0, 0):
+        raise ValueError("the range-check permutation does not close")
+    return out, last_mem
+
+
 # ---- the plain layout as an Air ------------------------------------------------------------------------------------------------
 def plain_air():
     """layouts/plain.py behind the Air interface; `statement` = its PublicInput"""

@@ -97,12 +97,39 @@ def proved(run):
     opt = gs.Options(num_queries=20, grinding=8)
 
     def prove(columns, options=opt):
-        def build_extension(ch):
-            ext, _ = pl.extension_columns(columns, ch)
-            return [tensor(c) for c in ext]
-        return gs.Prover(ctx, air, options).prove(bytes(range(32)), [tensor(c) for c in columns], build_extension, statement=pi)
+        base = [tensor(c) for c in columns]
+        return gs.Prover(ctx, air, options).prove(bytes(range(32)), base, lambda ch: gs.plain_extension_on_device(ctx, base, ch)[0], statement=pi)
+    prove.ctx = ctx
     yield gs, air, pi, cols, prove, opt
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_extension_column_on_the_device(proved, run):
+    import torch
+    gs, air, pi, cols, prove, opt = proved
+    ctx = prove.ctx
+    tensor = lambda c: torch.from_numpy(np.array(c, dtype=np.uint64).view(np.int64)).cuda()
+    dcols = [tensor(c) for c in cols]
+    want, want_last = pl.extension_columns(cols, CH)
+    got, last = gs.plain_extension_on_device(ctx, dcols, CH)
+    assert last == want_last == pl.Hints.from_public_input(pi, CH, len(cols[0])).memory_quotient
+    for g, w in zip(got, want):
+        assert [int(v) for v in g.cpu().numpy().view(np.uint64)] == w
+    # at scale: the quotient of two orderings of the same 2^22 (address, value) pairs closes to one; a changed value does not
+    rng = np.random.default_rng(4)
+    m = 1 << 22
+    pairs = rng.integers(0, 2**62, size=(m, 2), dtype=np.uint64)
+    a = torch.from_numpy(pairs.reshape(-1).view(np.int64).copy()).cuda()
+    b = torch.from_numpy(pairs[rng.permutation(m)].reshape(-1).view(np.int64).copy()).cuda()
+    out = [torch.zeros(2 * m, dtype=torch.int64, device="cuda") for _ in range(3)]
+    assert ctx.running_product_gl64x3(a, a[1:], b, b[1:], 2, m, CH[0], CH[1], out, 2, 0) == (1, 0, 0)
+    b[5] += 1
+    assert ctx.running_product_gl64x3(a, a[1:], b, b[1:], 2, m, CH[0], CH[1], out, 2, 0) != (1, 0, 0)
+    with pytest.raises(ValueError):
+        bad = [list(c) for c in cols]
+        bad[pl.COL_RANGE_CHECK][16 * 7 + pl.RangeCheck.OFF_DST] = 5
+        gs.plain_extension_on_device(ctx, [tensor(c) for c in bad], CH)
 
 
 @pytest.mark.gpu
