@@ -517,6 +517,20 @@ __device__ __forceinline__ Gl3 gl3_inv_dev(const Gl3 &a) {
     const uint64_t norm = gl_add(gl_mul(a.c[0], adj.c[0]), gl_add(gl_add(t1, t1), gl_add(t2, t2)));
     return gl3_scale(adj, gl_pow_dev(norm, GL_P - 2));                      // 0 -> 0
 }
+// Most values of a constraint program are base-field values in extension clothes (trace cells, their sums and products: every
+// CPU constraint before its alpha^k): a factor whose upper coordinates are zero costs one or three multiplications instead of
+// nine.  The test is on the data, per lane; which values are base-field is a property of the program, so the lanes agree.
+__device__ __forceinline__ Gl3 gl3_mul_typed(const Gl3 &a, const Gl3 &b) {
+    const bool a_base = (a.c[1] | a.c[2]) == 0, b_base = (b.c[1] | b.c[2]) == 0;
+    if (a_base && b_base) return Gl3{{gl_mul(a.c[0], b.c[0]), 0, 0}};
+    if (b_base) return gl3_scale(a, b.c[0]);
+    if (a_base) return gl3_scale(b, a.c[0]);
+    return gl3_mul(a, b);
+}
+__device__ __forceinline__ Gl3 gl3_inv_typed(const Gl3 &a) {
+    if ((a.c[1] | a.c[2]) == 0) return Gl3{{gl_pow_dev(a.c[0], GL_P - 2), 0, 0}};
+    return gl3_inv_dev(a);
+}
 struct Gl3VmArgs {
     const uint32_t *code;            // 2 words per instruction
     const uint64_t *consts;          // [n_consts][3]
@@ -563,8 +577,8 @@ __global__ __launch_bounds__(256) void gl3_vm_kernel(Gl3VmArgs a) {
             case 1: v = gl3_add(v, src); break;                                                                  \
             case 2: v = gl3_sub(v, src); break;                                                                  \
             case 3: v = gl3_sub(src, v); break;                                                                  \
-            case 4: v = (kind == 3 || kind == 4 || kind == 5) ? gl3_scale(v, src.c[0]) : gl3_mul(v, src); break; \
-            case 5: v = gl3_inv_dev(v); break;                                                                   \
+            case 4: v = gl3_mul_typed(v, src); break;                                                            \
+            case 5: v = gl3_inv_typed(v); break;                                                                 \
             case 6: for (int c = 0; c < 3; ++c) a.slots[((uint64_t)w1 * 3 + c) * lanes + lane] = v.c[c]; break;  \
             case 7: a.out[3 * i] = v.c[0]; a.out[3 * i + 1] = v.c[1]; a.out[3 * i + 2] = v.c[2]; break;          \
             default: break;                                                                                      \

@@ -210,11 +210,15 @@ class Tables:
     N / gcd(N, p): factors with p > 1 become table operands (a few dozen entries), a factor X - g^e is an expression
     (its inverse a VM INV: four of them per point)."""
 
-    def __init__(self, n, log_blowup=1, offset=GENERATOR):
+    def __init__(self, n, log_blowup=1, offset=GENERATOR, single_rows=None):
+        """single_rows: the rows r whose factor X - g^r appears as a DENOMINATOR (first row, last cycle, ...): their inverses share
+        ONE inversion per point - 1 / prod (X - g^r), times the other factors - instead of one each"""
         self.n, self.lb, self.offset = n, log_blowup, offset
         self.N = n << log_blowup
         self.g = root_of_unity(n.bit_length() - 1)
         self.specs, self._ix = [], {}
+        self.single_rows = sorted(set(r % n for r in (single_rows if single_rows is not None else (0, n - CYCLE_HEIGHT, n - 2, n - 4))))
+        self._single_inv = {}
 
     def _table(self, p_, e, inverse):
         key = (p_, e, inverse)
@@ -226,7 +230,23 @@ class Tables:
     def factor(self, p_, e, inverse=False):
         if p_ == 1:
             f = ap.X - ap.Const(pow(self.g, e, P))
-            return f.inverse() if inverse else f
+            if not inverse:
+                return f
+            if e % self.n not in self.single_rows or len(self.single_rows) < 2:
+                return f.inverse()
+            if not self._single_inv:
+                fs = [ap.X - ap.Const(pow(self.g, r, P)) for r in self.single_rows]
+                prod = fs[0]
+                for g_ in fs[1:]:
+                    prod = prod * g_
+                inv_all = prod.inverse()
+                for k, r in enumerate(self.single_rows):
+                    others = None
+                    for j, g_ in enumerate(fs):
+                        if j != k:
+                            others = g_ if others is None else others * g_
+                    self._single_inv[r] = inv_all * others
+            return self._single_inv[e % self.n]
         return self._table(p_, e, inverse)
 
     def multiplier(self, domain):
