@@ -1533,9 +1533,23 @@ ss_status ss_ood_eval_gl64x3(ss_ctx *ctx, const uint64_t *const *d_coeffs_bitrev
     uint64_t *zp = (uint64_t *)ctx->scratch2, *comp = zp + 3 * n, *d_idx = comp + 3 * BATCH * n, *d_vals = d_idx + ncells;
     hipStream_t s = ctx->stream;
     HIP_TRY(launch_gl3_zpow_bitrev(s, zp, zp + n, zp + 2 * n, log_n, z));
-    std::vector<uint32_t> used;                                  // columns some cell names
-    for (uint32_t col = 0; col < ncols; ++col)
-        for (uint32_t j = 0; j < ncells; ++j) if (cell_col[j] == col) { used.push_back(col); break; }
+    std::vector<uint32_t> used;                                  // columns some cell names at a row offset other than 0
+    for (uint32_t col = 0; col < ncols; ++col) {
+        bool any = false, shifted = false;
+        for (uint32_t j = 0; j < ncells; ++j) if (cell_col[j] == col) { any = true; shifted |= (cell_off[j] & (n - 1)) != 0; }
+        if (any && shifted) { used.push_back(col); continue; }
+        if (!any) continue;
+        // read at z only: P(z) = sum_j c_j z^j is one pass over the coefficients against the power table, not three transforms
+        const uint32_t nb = gl3_dot_blocks(n);
+        uint64_t *d_part = comp;                                 // the component area is free here
+        HIP_TRY(launch_gl3_dot(s, d_coeffs_bitrev[col], zp, zp + n, zp + 2 * n, n, d_part));
+        std::vector<uint64_t> part(3 * (size_t)nb);
+        HIP_TRY(hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        uint64_t sum[3] = {0, 0, 0};
+        for (uint32_t b = 0; b < nb; ++b) for (int t = 0; t < 3; ++t) sum[t] = gl_addh(sum[t], part[3 * (size_t)b + t]);
+        for (uint32_t j = 0; j < ncells; ++j) if (cell_col[j] == col) memcpy(out + 3 * (size_t)j, sum, 24);
+    }
     std::vector<uint64_t> idx(ncells), vals(3 * (size_t)ncells);
     for (size_t b0 = 0; b0 < used.size(); b0 += BATCH) {
         const uint32_t nb = (uint32_t)std::min<size_t>(BATCH, used.size() - b0);

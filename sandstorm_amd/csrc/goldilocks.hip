@@ -459,6 +459,26 @@ __global__ void gl3_gather_kernel(const uint64_t *__restrict__ c0, const uint64_
     out[3 * j] = c0[idx[j]]; out[3 * j + 1] = c1[idx[j]]; out[3 * j + 2] = c2[idx[j]];
 }
 
+// partial[b][t] = sum over block b's share of coef[q] * zp_t[q]: P(z) = sum_j c_j z^j for a bit-reversed coefficient array and the
+// power table z^bitrev(q) - the out-of-domain value of a column that is read at a single point
+__global__ __launch_bounds__(256) void gl3_dot_kernel(const uint64_t *__restrict__ coef, const uint64_t *__restrict__ zp0, const uint64_t *__restrict__ zp1,
+                                                      const uint64_t *__restrict__ zp2, uint64_t n, uint64_t *__restrict__ partial) {
+    __shared__ uint64_t red[3][256];
+    uint64_t a0 = 0, a1 = 0, a2 = 0;
+    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t c = coef[q];
+        a0 = gl_add(a0, gl_mul(c, zp0[q])); a1 = gl_add(a1, gl_mul(c, zp1[q])); a2 = gl_add(a2, gl_mul(c, zp2[q]));
+    }
+    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+            for (int t = 0; t < 3; ++t) red[t][threadIdx.x] = gl_add(red[t][threadIdx.x], red[t][threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) partial[3 * blockIdx.x + threadIdx.x] = red[threadIdx.x][0];
+}
+
 static uint32_t gl_blocks(uint64_t items, uint32_t per_block = 256, uint32_t cap = 16384) {
     uint64_t b = (items + per_block - 1) / per_block;
     return (uint32_t)(b == 0 ? 1 : b > cap ? cap : b);
@@ -493,6 +513,11 @@ hipError_t launch_gl3_zpow_bitrev(hipStream_t st, uint64_t *zp0, uint64_t *zp1, 
 hipError_t launch_gl3_scale_columns(hipStream_t st, const uint64_t *coef, const uint64_t *zp0, const uint64_t *zp1, const uint64_t *zp2, uint64_t n,
                                     uint64_t *o0, uint64_t *o1, uint64_t *o2) {
     hipLaunchKernelGGL(gl3_scale_columns_kernel, dim3(gl_blocks(n)), dim3(256), 0, st, coef, zp0, zp1, zp2, n, o0, o1, o2);
+    return hipGetLastError();
+}
+uint32_t gl3_dot_blocks(uint64_t n) { return gl_blocks(n, 256, 1024); }
+hipError_t launch_gl3_dot(hipStream_t st, const uint64_t *coef, const uint64_t *zp0, const uint64_t *zp1, const uint64_t *zp2, uint64_t n, uint64_t *partial) {
+    hipLaunchKernelGGL(gl3_dot_kernel, dim3(gl3_dot_blocks(n)), dim3(256), 0, st, coef, zp0, zp1, zp2, n, partial);
     return hipGetLastError();
 }
 hipError_t launch_gl3_gather(hipStream_t st, const uint64_t *c0, const uint64_t *c1, const uint64_t *c2, const uint64_t *idx, uint32_t count, uint64_t *out) {

@@ -122,6 +122,8 @@ hipError_t launch_gather_rows_u64(hipStream_t st, const ConstColPtrs &segs, uint
 hipError_t launch_gl3_running_product(hipStream_t st, const uint64_t *na, const uint64_t *nv, const uint64_t *da, const uint64_t *dv, uint64_t stride,
                                       uint64_t count, const uint64_t z[3], const uint64_t alpha[3], uint64_t *scratch, uint64_t *o0, uint64_t *o1,
                                       uint64_t *o2, uint64_t out_stride, uint64_t out_offset, uint64_t *d_last);
+uint32_t gl3_dot_blocks(uint64_t n);
+hipError_t launch_gl3_dot(hipStream_t st, const uint64_t *coef, const uint64_t *zp0, const uint64_t *zp1, const uint64_t *zp2, uint64_t n, uint64_t *partial);
 uint32_t gl3_vm_lanes(uint64_t N);
 hipError_t launch_gl3_vm(hipStream_t st, const uint32_t *d_code, uint32_t n_instr, const uint64_t *d_consts, const uint64_t *d_tables,
                          const uint32_t *d_tdesc, const uint64_t *const *cols, uint32_t ncols, uint64_t *d_slots, uint64_t *d_out, uint64_t offset,

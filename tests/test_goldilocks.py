@@ -195,6 +195,9 @@ def test_deep_and_ood_vs_oracle(ctx, oracle, log_n, lb, ncols, ncomp, offsets):
     rev = np.array([int(format(i, "0%db" % log_n)[::-1], 2) for i in range(n)])
     d_co = [ctx.column(c[rev]) for c in coeffs]                      # bit-reversed, as ss_lde_gl64 leaves them
     assert np.array_equal(ctx.ood_eval_gl64x3(d_co, log_n, mc, mo, z), ood_t)
+    # columns read at z only take the one-pass path (a dot product with the power table) instead of three transforms
+    at_z = list(range(ncols))
+    assert np.array_equal(ctx.ood_eval_gl64x3(d_co, log_n, at_z, [0] * ncols, zc), oracle.gl3_ood_eval(coeffs, at_z, [0] * ncols, zc))
     out = ctx.alloc(24 * N)
     ctx.deep_compose_gl64x3([ctx.column(c) for c in lde], [ctx.column(c) for c in comp_lde], log_n, lb, 7, mc, mo, ood_t, ct, ood_c, cc, z, zc, out)
     assert np.array_equal(out.download(np.uint64, (N, 3)), oracle.gl3_deep_compose(lde, comp_lde, log_n, lb, 7, mc, mo, ood_t, ct, ood_c, cc, z, zc))
