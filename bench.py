@@ -347,7 +347,7 @@ def bench_goldilocks_plain(args, log_steps, rank, local_rank, world, device):
                          "steps_log2": log_steps, "trace_rows_log2": log_steps + 4, "blowup": 2,
                          "proof_options": "%d queries, blowup 2, %d PoW bits, FRI fold %d, <= %d remainder coefficients"
                                           % (opt.num_queries, opt.grinding, opt.fold, opt.max_remainder),
-                         "claim": "this library's own instantiation (Keccak trees over the rows' bytes, Keccak coin, Fq3 columns as three "
+                         "claim": "this library's own instantiation (Blake2s trees over the rows' bytes, Keccak coin, Fq3 columns as three "
                                   "coordinate columns): the reference's parts for this claim are un-vendored - PARITY UNPINNED",
                          "host": "Python host (sandstorm_amd/goldilocks.py) over the C ABI", "fri_layers": len(proof.fri_layers),
                          "outside": "host trace generation: base columns resident in HBM",

@@ -62,7 +62,8 @@ enum {
 enum {
     SS_TREE_KECCAK = 0,       /* LeafVariantMerkleTree<Keccak256HashFn>           */
     SS_TREE_KECCAK_M20 = 1,   /* LeafVariantMerkleTree<MaskedKeccak256HashFn<20>> */
-    SS_TREE_FRIENDLY = 2      /* FriendlyMerkleTree<N, PedersenHashFn>            */
+    SS_TREE_FRIENDLY = 2,     /* FriendlyMerkleTree<N, PedersenHashFn>            */
+    SS_TREE_BLAKE2S = 3       /* MatrixMerkleTree over Blake2sHashFn (blake2s.rs:10-62): the 64-bit field's trees here */
 };
 enum { SS_LEAF_DIGEST = 0, SS_LEAF_FELT = 1 };
 enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
@@ -281,14 +282,14 @@ ss_status ss_fri_fold_gl64x3(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_
 ss_status ss_running_product_gl64x3(ss_ctx *ctx, const uint64_t *d_num_addr, const uint64_t *d_num_val, const uint64_t *d_den_addr,
                                     const uint64_t *d_den_val, uint64_t stride, uint64_t count, const uint64_t z[3], const uint64_t alpha[3],
                                     uint64_t *const d_out[3], uint64_t out_stride, uint64_t out_offset, uint64_t last_out[3]);
-/* H1 / openings for matrices of 8-byte elements: digest i = Keccak-256 of row i's elements as little-endian bytes, segment by
+/* H1 / openings for matrices of 8-byte elements: digest i = Keccak-256 or Blake2s-256 (hash_kind) of row i's elements as little-endian bytes, segment by
  * segment (element e of segment s = d_segments[s][i * seg_len + e]): a trace matrix is nseg columns with seg_len 1, the rows of
  * an Fq3 FRI layer ([len][3] interleaved, row j = {evals[j + k rows]}) are nseg = fold segments d_evals + 3 k rows of seg_len 3.
- * The tree over the digests is ss_merkle_build's SS_TREE_KECCAK.  (The reference instantiates this field with ministark's
+ * The tree over the digests is ss_merkle_build's SS_TREE_KECCAK / SS_TREE_BLAKE2S.  (The reference instantiates this field with ministark's
  * SHA-256 trees, un-vendored: this is the library's own choice for it.)  ss_gather_rows_gl64: the opened rows, to HOST memory
  * [nidx][nseg][seg_len]. */
-ss_status ss_hash_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, uint64_t nrows,
-                            uint8_t *d_digests);
+ss_status ss_hash_rows_gl64(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len,
+                            uint64_t nrows, uint8_t *d_digests);
 ss_status ss_gather_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, const uint64_t *idx,
                               uint32_t nidx, uint64_t *out);
 /* Q1 over the cubic extension: the program format of ss_eval_quotient (ss_air_program above) with accumulators, scratch

@@ -28,7 +28,7 @@ NATURAL, BITREV = 0, 1
 FRI_BITREV_ROWS, FRI_UNNORMALISED = 1, 2
 FORWARD, INVERSE = 0, 1
 HASH_KECCAK, HASH_KECCAK_M20, HASH_BLAKE2S, HASH_BLAKE2S_M20 = 0, 1, 2, 3
-TREE_KECCAK, TREE_KECCAK_M20, TREE_FRIENDLY = 0, 1, 2
+TREE_KECCAK, TREE_KECCAK_M20, TREE_FRIENDLY, TREE_BLAKE2S = 0, 1, 2, 3
 LEAF_DIGEST, LEAF_FELT = 0, 1
 COIN_SOLIDITY, COIN_CAIRO = 0, 1
 PROF_NTT_PASS, PROF_HASH_ROWS, PROF_MERKLE, PROF_FRI, PROF_QUOTIENT, PROF_DEEP, PROF_EXT = range(7)
@@ -228,9 +228,10 @@ class Context:
                                                  last.ctypes.data_as(u64) if want_last else None))
         return tuple(int(v) for v in last) if want_last else None
 
-    def hash_rows_gl64(self, segments, seg_len, nrows, out):
-        """Keccak-256 of the rows of a matrix of 8-byte elements (ss_hash_rows_gl64) -> out[nrows][32]"""
-        check(self.lib.ss_hash_rows_gl64(self.handle, _ptr_array(segments), len(segments), seg_len, nrows, _ptr_of(out)))
+    def hash_rows_gl64(self, segments, seg_len, nrows, out, hash_kind=None):
+        """Keccak-256 / Blake2s-256 of the rows of a matrix of 8-byte elements (ss_hash_rows_gl64) -> out[nrows][32]"""
+        check(self.lib.ss_hash_rows_gl64(self.handle, HASH_BLAKE2S if hash_kind is None else hash_kind, _ptr_array(segments), len(segments), seg_len,
+                                         nrows, _ptr_of(out)))
 
     def gather_rows_gl64(self, segments, seg_len, idx):
         """rows idx of such a matrix -> uint64[len(idx), nseg, seg_len]"""

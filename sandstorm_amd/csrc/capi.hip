@@ -522,7 +522,7 @@ ss_status ss_merkle_build_ex(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_lay
                              uint8_t root_out[33]) {
     if (!ctx || !d_leaves || !d_nodes) return fail(SS_ERR_INVALID, "NULL argument");
     if (n < 2 || (n & (n - 1))) return fail(SS_ERR_INVALID, "n must be a power of two >= 2");
-    if (tree_kind < 0 || tree_kind > 2) return fail(SS_ERR_INVALID, "bad tree kind");
+    if (tree_kind < 0 || tree_kind > 3) return fail(SS_ERR_INVALID, "bad tree kind");
     if (leaf_order != SS_ORDER_NATURAL && leaf_order != SS_ORDER_BITREV) return fail(SS_ERR_INVALID, "bad leaf order %d", leaf_order);
     uint32_t log_n = 0;
     while ((1ull << log_n) < n) ++log_n;
@@ -534,7 +534,8 @@ ss_status ss_merkle_build_ex(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_lay
         d_leaves = ctx->scratch2;
     }
     hipStream_t s = ctx->stream;
-    const int hk = tree_kind == SS_TREE_KECCAK ? SS_HASH_KECCAK : tree_kind == SS_TREE_KECCAK_M20 ? SS_HASH_KECCAK_M20 : SS_HASH_BLAKE2S_M20;
+    const int hk = tree_kind == SS_TREE_KECCAK ? SS_HASH_KECCAK : tree_kind == SS_TREE_KECCAK_M20 ? SS_HASH_KECCAK_M20
+                 : tree_kind == SS_TREE_BLAKE2S ? SS_HASH_BLAKE2S : SS_HASH_BLAKE2S_M20;
     if (tree_kind == SS_TREE_FRIENDLY && !ctx->ped) HIP_TRY(pedersen_tables_create(s, &ctx->ped));
     Fp *ped_tmp = nullptr;
     if (tree_kind == SS_TREE_FRIENDLY) {
@@ -1432,14 +1433,16 @@ ss_status ss_running_product_gl64x3(ss_ctx *ctx, const uint64_t *d_num_addr, con
     return SS_OK;
 }
 
-ss_status ss_hash_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, uint64_t nrows, uint8_t *d_digests) {
+ss_status ss_hash_rows_gl64(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, uint64_t nrows,
+                            uint8_t *d_digests) {
     if (!ctx || !d_segments || !d_digests) return fail(SS_ERR_INVALID, "NULL argument");
+    if (hash_kind != SS_HASH_KECCAK && hash_kind != SS_HASH_BLAKE2S) return fail(SS_ERR_INVALID, "hash kind %d: Keccak-256 or Blake2s-256", hash_kind);
     if (nseg == 0 || nseg > (uint32_t)MAX_COLS || seg_len == 0 || seg_len > 64) return fail(SS_ERR_UNSUPPORTED, "row shape %u x %u out of range", nseg, seg_len);
     ConstColPtrs segs;
     memset(&segs, 0, sizeof segs);
     for (uint32_t c = 0; c < nseg; ++c) { if (!d_segments[c]) return fail(SS_ERR_INVALID, "NULL segment"); segs.p[c] = d_segments[c]; }
     ss_ctx::Scope prof(ctx, SS_PROF_HASH_ROWS);
-    HIP_TRY(launch_hash_rows_u64(ctx->stream, segs, nseg, seg_len, nrows, d_digests));
+    HIP_TRY(launch_hash_rows_u64(ctx->stream, hash_kind == SS_HASH_KECCAK ? 0 : 1, segs, nseg, seg_len, nrows, d_digests));
     return SS_OK;
 }
 

@@ -432,8 +432,38 @@ static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap) {
     return (uint32_t)g;
 }
 
-hipError_t launch_hash_rows_u64(hipStream_t st, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, uint64_t nrows, uint8_t *digests) {
-    hipLaunchKernelGGL(keccak_rows_u64_kernel, dim3(grid_for(nrows, 256, 1u << 20)), dim3(256), 0, st, segs, nseg, seg_len, nrows, digests);
+// the same rows under Blake2s-256 (8 elements per 64-byte block)
+__global__ __launch_bounds__(256) void blake2s_rows_u64_kernel(ConstColPtrs segs, uint32_t nseg, uint32_t seg_len, uint64_t nrows,
+                                                               uint8_t *__restrict__ out) {
+    const uint32_t nelem = nseg * seg_len, nblocks = nelem == 0 ? 1 : (nelem + 7) / 8;
+    for (uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; row < nrows; row += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t h[8];
+        blake2s_init(h);
+        uint32_t seg = 0, e = 0;
+        for (uint32_t blk = 0; blk < nblocks; ++blk) {
+            uint32_t m[16];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint64_t v = 0;
+                if (8 * blk + i < nelem) {
+                    const uint64_t *sp = reinterpret_cast<const uint64_t *>(segs.p[0]);
+#pragma unroll
+                    for (int c = 1; c < MAX_COLS; ++c) if (seg == (uint32_t)c) sp = reinterpret_cast<const uint64_t *>(segs.p[c]);
+                    v = sp[row * seg_len + e];
+                    if (++e == seg_len) { e = 0; ++seg; }
+                }
+                m[2 * i] = (uint32_t)v; m[2 * i + 1] = (uint32_t)(v >> 32);
+            }
+            const bool last = blk == nblocks - 1;
+            blake2s_compress(h, m, last ? 8 * nelem : 64 * (blk + 1), last);
+        }
+        blake2s_store_digest(h, out + 32 * row, false);
+    }
+}
+
+hipError_t launch_hash_rows_u64(hipStream_t st, int kind, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, uint64_t nrows, uint8_t *digests) {
+    if (kind == 0) hipLaunchKernelGGL(keccak_rows_u64_kernel, dim3(grid_for(nrows, 256, 1u << 20)), dim3(256), 0, st, segs, nseg, seg_len, nrows, digests);
+    else hipLaunchKernelGGL(blake2s_rows_u64_kernel, dim3(grid_for(nrows, 256, 1u << 20)), dim3(256), 0, st, segs, nseg, seg_len, nrows, digests);
     return hipGetLastError();
 }
 hipError_t launch_gather_rows_u64(hipStream_t st, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, const uint64_t *d_idx, uint32_t nidx,

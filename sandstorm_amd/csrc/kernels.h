@@ -116,7 +116,7 @@ hipError_t launch_gl3_interleave(hipStream_t st, const uint64_t *c0, const uint6
 hipError_t launch_gl3_zpow_bitrev(hipStream_t st, uint64_t *zp0, uint64_t *zp1, uint64_t *zp2, uint32_t log_n, const uint64_t z[3]);
 hipError_t launch_gl3_scale_columns(hipStream_t st, const uint64_t *coef, const uint64_t *zp0, const uint64_t *zp1, const uint64_t *zp2, uint64_t n,
                                     uint64_t *o0, uint64_t *o1, uint64_t *o2);
-hipError_t launch_hash_rows_u64(hipStream_t st, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, uint64_t nrows, uint8_t *digests);
+hipError_t launch_hash_rows_u64(hipStream_t st, int kind, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, uint64_t nrows, uint8_t *digests);
 hipError_t launch_gather_rows_u64(hipStream_t st, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, const uint64_t *d_idx, uint32_t nidx,
                                   uint64_t *d_out);
 hipError_t launch_gl3_running_product(hipStream_t st, const uint64_t *na, const uint64_t *nv, const uint64_t *da, const uint64_t *dv, uint64_t stride,

@@ -7,8 +7,9 @@ is nothing to be byte-compatible with, and PARITY IS UNPINNED.  The pipeline is 
 src/lib.rs:75-125), with this library's own choices where the reference is silent:
   * an Fq3-valued column (extension trace, composition) is committed as its three Fp coordinate columns; every committed column
     is therefore an Fp polynomial, and the mask / out-of-domain values / DEEP terms are per coordinate column;
-  * trees: Keccak-256 over the rows' little-endian bytes (ss_hash_rows_gl64) and ss_merkle_build's Keccak tree, natural row
-    order; coin: the Keccak coin of the 252-bit path (coin.PublicCoin), a field element = 8 drawn bytes reduced mod p;
+  * trees: Blake2s-256 (the reference's Blake2sHashFn; a quarter of Keccak's cost on this chip) over the rows' little-endian bytes
+    (ss_hash_rows_gl64) and ss_merkle_build's SS_TREE_BLAKE2S, natural row order; coin: the Keccak coin of the 252-bit path
+    (coin.PublicCoin), a field element = 8 drawn bytes below p;
   * composition H(x) = H0(x^2) + x H1(x^2) (two Fq3 columns = six coordinate columns), out-of-domain point z^2 for them;
   * FRI: fold 8, the layer's challenge as drawn, values normalised; remainder = coefficients of the last layer.
 What is checked instead of parity: each kernel against the oracle (tests/test_goldilocks.py), and that proofs of true statements
@@ -139,7 +140,7 @@ class Prover:
         nodes = torch.zeros((2 * n_rows, 32), dtype=torch.uint8, device=cols[0].device)
         # rows of more than 16 columns do not occur here (<= 8 trace, 6 composition coordinate columns)
         self.ctx.hash_rows_gl64(cols, 1, n_rows, dig)
-        root, _ = self.ctx.merkle_build(be.TREE_KECCAK, 0, be.LEAF_DIGEST, dig, n_rows, nodes)
+        root, _ = self.ctx.merkle_build(be.TREE_BLAKE2S, 0, be.LEAF_DIGEST, dig, n_rows, nodes)
         return root, nodes
 
     def _open(self, cols, nodes, n_rows, positions, seg_len=1):
@@ -154,6 +155,8 @@ class Prover:
         ctx, air, opt = self.ctx, self.air, self.opt
         n = base_cols[0].shape[0]
         log_n, lb = n.bit_length() - 1, opt.log_blowup
+        if lb != 1:
+            raise ValueError("the composition split (even / odd coefficients) is written for blowup 2")
         N = n << lb
         dev = base_cols[0].device
         new = lambda rows, width=None: torch.zeros((rows,) if width is None else (rows, width), dtype=torch.int64, device=dev)
@@ -190,10 +193,7 @@ class Prover:
         ctx.ntt_gl64(qc, log_n + lb, be.INVERSE, OFFSET, be.NATURAL, be.BITREV)       # bit-reversed coefficients: even ones first
         for half in range(2):
             for t in range(3):
-                c = qc[t][half * n:(half + 1) * n] if lb == 1 else None
-                if c is None:
-                    raise ValueError("the composition split is written for blowup 2")
-                comp_co.append(c.contiguous())
+                comp_co.append(qc[t][half * n:(half + 1) * n].contiguous())
         for c in comp_co:
             padded = new(N)
             padded[::1 << lb] = c                                                    # zero-padded to N in bit-reversed order
@@ -224,7 +224,7 @@ class Prover:
             dig = torch.zeros((rows, 32), dtype=torch.uint8, device=dev)
             nodes = torch.zeros((2 * rows, 32), dtype=torch.uint8, device=dev)
             ctx.hash_rows_gl64(segs, 3, rows, dig)
-            root_l, _ = ctx.merkle_build(be.TREE_KECCAK, 0, be.LEAF_DIGEST, dig, rows, nodes)
+            root_l, _ = ctx.merkle_build(be.TREE_BLAKE2S, 0, be.LEAF_DIGEST, dig, rows, nodes)
             coin.reseed_with_digest(root_l)
             a = coin.draw_fq3()
             nxt = new(rows, 3)
@@ -245,7 +245,7 @@ class Prover:
                     acc, cur = (acc + v * cur) % P, cur * wk % P
                 rem[k, t] = acc * pow(L, -1, P) % P * pow(oinv, k, P) % P
         if rem[L >> lb:].any():
-            raise ValueError("the FRI remainder is not of low degree: the trace does not satisfy the AIR")
+            raise ValueError("the FRI remainder is not of low degree: the DEEP composition is not the polynomial it must be")
         proof.remainder = rem
         coin.reseed_with_fq3s([tuple(int(v) for v in r) for r in rem])
         # 8. proof of work, queries, openings
@@ -280,18 +280,23 @@ def _need(cond, what):
         raise VerificationError(what)
 
 
+def _tree_hash(data: bytes) -> bytes:
+    import hashlib
+    return hashlib.blake2s(data).digest()
+
+
 def _climb(leaf, path, pos):
     node = leaf
     for lvl in range(path.shape[0]):
         sib = bytes(path[lvl])
-        node = keccak256(node + sib) if ((pos >> lvl) & 1) == 0 else keccak256(sib + node)
+        node = _tree_hash(node + sib) if ((pos >> lvl) & 1) == 0 else _tree_hash(sib + node)
     return node
 
 
 def _check_opening(opening, width, positions, depth, root, what):
     _need(opening is not None and opening.rows.shape == (len(positions), width) and opening.paths.shape == (len(positions), depth, 32), what + ": shape")
     for q, pos in enumerate(positions):
-        leaf = keccak256(b"".join(int(v).to_bytes(8, "little") for v in opening.rows[q]))
+        leaf = _tree_hash(b"".join(int(v).to_bytes(8, "little") for v in opening.rows[q]))
         _need(_climb(leaf, opening.paths[q], pos) == root, what + ": authentication path does not reach the root")
 
 

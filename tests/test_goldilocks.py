@@ -412,3 +412,34 @@ def test_the_kernels_compose_into_a_proof_skeleton(ctx, oracle):
         layer, ll, off = nxt, ll - (fold.bit_length() - 1), pow(off, fold, GL_P)
     fin = layer.download(np.uint64, (2, 3))
     assert np.array_equal(fin[0], fin[1]) and fin.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nseg,seg_len", [(1, 1), (5, 1), (8, 1), (9, 1), (16, 1), (8, 3), (2, 17), (1, 34)])
+def test_row_hashing_and_trees_of_8_byte_elements(ctx, nseg, seg_len):
+    """ss_hash_rows_gl64 (Keccak-256 / Blake2s-256 over the rows' little-endian bytes, block boundaries included), the Blake2s
+    tree over the digests, ss_gather_rows_gl64 - against hashlib and the library's host Keccak"""
+    import hashlib
+    from sandstorm_amd import backend as be
+    from sandstorm_amd.coin import keccak256
+    rng = np.random.default_rng(nseg * 100 + seg_len)
+    nrows = 64
+    segs = [rand_fp(rng, nrows * seg_len) for _ in range(nseg)]
+    d_segs = [ctx.column(s) for s in segs]
+    row_bytes = lambda i: b"".join(int(s[i * seg_len + e]).to_bytes(8, "little") for s in segs for e in range(seg_len))
+    for kind, h in ((be.HASH_KECCAK, keccak256), (be.HASH_BLAKE2S, lambda d: hashlib.blake2s(d).digest())):
+        out = ctx.alloc(32 * nrows)
+        ctx.hash_rows_gl64(d_segs, seg_len, nrows, out, kind)
+        got = out.download(np.uint8, (nrows, 32))
+        assert [bytes(r) for r in got] == [h(row_bytes(i)) for i in range(nrows)]
+    nodes = ctx.alloc(64 * nrows)
+    root, _ = ctx.merkle_build(be.TREE_BLAKE2S, 0, be.LEAF_DIGEST, out, nrows, nodes)
+    level = [hashlib.blake2s(row_bytes(i)).digest() for i in range(nrows)]
+    while len(level) > 1:
+        level = [hashlib.blake2s(level[2 * k] + level[2 * k + 1]).digest() for k in range(len(level) // 2)]
+    assert root == level[0]
+    idx = [0, 5, 63, 17]
+    rows = ctx.gather_rows_gl64(d_segs, seg_len, idx)
+    assert rows.shape == (4, nseg, seg_len)
+    for q, i in enumerate(idx):
+        assert [int(v) for v in rows[q].reshape(-1)] == [int(s[i * seg_len + e]) for s in segs for e in range(seg_len)]
