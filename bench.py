@@ -353,9 +353,14 @@ def bench_goldilocks_plain(args, log_steps, rank, local_rank, world, device):
                          "outside": "host trace generation: base columns resident in HBM",
                          "per_gpu": "one independent proof per rank"},
               "stage_ms_per_proof": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
-              "roofline": {"bound": "hbm", "kernel": "ss::gl_ntt_pass_kernel", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
-                           "traffic": None, "launches": launches, "avg_launch_ms": ntt_ms / max(1, launches),
-                           "note": "see --workload goldilocks_lde_2p20 for the transform's own roofline line"}})
+              "roofline": (lambda algo: {"bound": "hbm", "kernel": "ss::gl_ntt_pass_kernel", "achieved": algo / (ntt_ms * 1e-3 / args.steps) / 1e9,
+                                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": algo / (ntt_ms * 1e-3 / args.steps) / 1e9 / HBM_PEAK_GBPS,
+                                         "traffic": None, "launches": launches, "avg_launch_ms": ntt_ms / max(1, launches),
+                                         "algorithmic_bytes_per_proof": algo,
+                                         "note": "algorithmic bytes = 2 N 8 B per transform (SURVEY 8d) over the proof's transforms: LDE of 8 columns "
+                                                 "(n and 2n), composition (3 of 2n in, 6 of 2n out), out-of-domain (3 per shifted column, n), DEEP "
+                                                 "extension (3 of n, 3 of 2n); the kernel is ALU-bound (a 64-bit modular product is ~20 vector "
+                                                 "instructions): see --workload goldilocks_lde_2p20"})(16.0 * (n * (8 + 24 + 3) + 2 * n * (8 + 9 + 3)))})
     if world > 1:
         dist.destroy_process_group()
 
