@@ -37,28 +37,33 @@ def trace_payload(col, row_offset):
 
 
 class Expr:
-    """Hash-consed expression node.  kind in {x, const, trace, table, add, sub, mul, inv}."""
-    __slots__ = ("kind", "args", "_id")
+    """Hash-consed expression node.  kind in {x, const, const3, trace, table, add, sub, mul, inv}.
+    `_skey` is a hash of the node's STRUCTURE (not of when it was built): commutative operands are ordered by it, so the DAG of
+    an expression - and with it the lowered program, word for word - does not depend on what else the process built before
+    (a compiled kernel recognises its program by the hash of the code words)."""
+    __slots__ = ("kind", "args", "_id", "_skey")
     _pool = {}
 
     def __new__(cls, kind, *args):
         key = (kind,) + tuple(a._id if isinstance(a, Expr) else a for a in args)
         node = cls._pool.get(key)
         if node is None:
+            import zlib
             node = object.__new__(cls)
             node.kind, node.args, node._id = kind, args, len(cls._pool)
+            node._skey = zlib.crc32(repr((kind,) + tuple(("e", a._skey) if isinstance(a, Expr) else a for a in args)).encode())
             cls._pool[key] = node
         return node
 
     @property
     def is_leaf(self):
-        return self.kind in ("x", "const", "const3", "trace", "table")
+        return self.kind in ("x", "const", "const3", "sym", "trace", "table")
 
-    def __add__(self, o): return Expr("add", *sorted((self, _wrap(o)), key=lambda e: e._id))
+    def __add__(self, o): return Expr("add", *sorted((self, _wrap(o)), key=lambda e: (e._skey, e._id)))
     __radd__ = __add__
     def __sub__(self, o): return Expr("sub", self, _wrap(o))
     def __rsub__(self, o): return Expr("sub", _wrap(o), self)
-    def __mul__(self, o): return Expr("mul", *sorted((self, _wrap(o)), key=lambda e: e._id))
+    def __mul__(self, o): return Expr("mul", *sorted((self, _wrap(o)), key=lambda e: (e._skey, e._id)))
     __rmul__ = __mul__
     def __neg__(self): return Expr("sub", Const(0), self)
     def inverse(self): return Expr("inv", self)
@@ -93,6 +98,13 @@ def Const3(c0, c1, c2):
     return Expr("const3", int(c0), int(c1), int(c2))
 
 
+def Sym(name):
+    """A constant known by NAME while the DAG is built (a challenge, a hint, alpha^k, a power of the trace generator): its value
+    arrives with lower(..., symbols=) / evaluate_ext(..., symbols=).  Two statements of a layout then share one DAG, hence one
+    program word for word - only the constant table differs - which is what lets a compiled kernel recognise the program."""
+    return Expr("sym", str(name))
+
+
 def Trace(col, row_offset=0):
     return Expr("trace", int(col), int(row_offset))
 
@@ -112,17 +124,20 @@ class Program:
     def n_instr(self):
         return len(self.code) // 2
 
-    def const_index(self, value):
-        ix = self._const_ix.get(value)
+    def const_index(self, value, key=None):
+        """key: what the constant is interned by (its value unless it is a named one)"""
+        key = value if key is None else key
+        ix = self._const_ix.get(key)
         if ix is None:
-            ix = self._const_ix[value] = len(self.consts)
+            ix = self._const_ix[key] = len(self.consts)
             self.consts.append(value)
         return ix
 
 
-def lower(root, modulus, ext=False):
+def lower(root, modulus, ext=False, symbols=None):
     """Expr DAG -> Program whose last instruction OUTs the value of `root`.
     ext: the program of the cubic-extension machine (ss_eval_quotient_gl64x3): every constant is a triple (an int v is (v, 0, 0)).
+    symbols: {name: value} for the Sym leaves (interned by name: equal values of different names stay different constants).
 
     Tree-walk code generation with accumulator `dst` as the working register:
     operands that are leaves (or shared nodes already parked in a slot) are used in
@@ -160,6 +175,10 @@ def lower(root, modulus, ext=False):
         if n.kind == "const3":
             assert ext, "extension-field constant in a base-field program"
             return SRC.CONST, prog.const_index(tuple(v % modulus for v in n.args))
+        if n.kind == "sym":
+            v = symbols[n.args[0]]
+            v = tuple(c % modulus for c in v) if isinstance(v, tuple) else ((v % modulus, 0, 0) if ext else v % modulus)
+            return SRC.CONST, prog.const_index(v, key=("sym", n.args[0]))
         if n.kind == "trace":
             return SRC.TRACE, trace_payload(*n.args)
         if n.kind == "table":
@@ -178,6 +197,22 @@ def lower(root, modulus, ext=False):
 
     def emit(op, dst, kind=0, payload=0):
         prog.code += instr(op, dst, kind, payload)
+
+    need_of = {}
+
+    def need(n):
+        """accumulators a fresh evaluation of n takes (leaves: 0)"""
+        if n.is_leaf:
+            return 0
+        v = need_of.get(n._id)
+        if v is None:
+            if n.kind == "inv":
+                v = max(1, need(n.args[0]))
+            else:
+                a, b = need(n.args[0]), need(n.args[1])
+                v = max(1, a if n.args[0] is n.args[1] else (a + 1 if a == b else max(a, b)))
+            need_of[n._id] = v
+        return v
 
     def gen(n, dst):
         """code leaving n in acc[dst]; serves one parent reference of n"""
@@ -205,18 +240,23 @@ def lower(root, modulus, ext=False):
                 emit(OP.RSUB if n.kind == "sub" else opc, dst, *operand(l))
                 consume(l)
             else:
-                gen(l, dst)
-                if operand(r) is not None:             # r was a shared sub-node of l
-                    emit(opc, dst, *operand(r))
-                    consume(r)
+                # both operands need code: the one that needs more accumulators goes first (Sethi-Ullman), whatever the
+                # order the DAG holds them in; a subtraction the other way round is an RSUB
+                first, second, swapped = (l, r, False) if need(l) >= need(r) else (r, l, True)
+                rev = OP.RSUB if n.kind == "sub" else opc
+                op_ab = rev if swapped else opc            # acc[dst] = first (op) second, in the DAG's sense
+                gen(first, dst)
+                if operand(second) is not None:        # it was a shared sub-node of the first
+                    emit(op_ab, dst, *operand(second))
+                    consume(second)
                 elif dst + 1 < 4:
-                    gen(r, dst + 1)
-                    emit(opc, dst, SRC.ACC, dst + 1)
+                    gen(second, dst + 1)
+                    emit(op_ab, dst, SRC.ACC, dst + 1)
                 else:
                     s = alloc_slot()
                     emit(OP.ST, dst, 0, s)
-                    gen(r, dst)
-                    emit(OP.RSUB if n.kind == "sub" else opc, dst, SRC.SLOT, s)
+                    gen(second, dst)
+                    emit((opc if swapped else rev), dst, SRC.SLOT, s)      # acc[dst] holds `second` now, the slot `first`
                     free_slots.append(s)
         uses[n._id] -= 1
         if uses[n._id] > 0:                            # more parents: park it
@@ -260,7 +300,7 @@ def evaluate(root, modulus, x, trace_at, table_at):
     return ev(root)
 
 
-def evaluate_ext(root, modulus, x, trace_at, table_at, nonresidue=2):
+def evaluate_ext(root, modulus, x, trace_at, table_at, nonresidue=2, symbols=None):
     """evaluate() over the cubic extension Fp[X]/(X^3 - nonresidue): x, trace_at(col, off), table_at(idx) -> triples; the
     out-of-domain side of the 64-bit field's AIR identity."""
     p = modulus
@@ -294,6 +334,9 @@ def evaluate_ext(root, modulus, x, trace_at, table_at, nonresidue=2):
             v = (n.args[0] % p, 0, 0)
         elif k == "const3":
             v = tuple(c % p for c in n.args)
+        elif k == "sym":
+            sv = symbols[n.args[0]]
+            v = tuple(c % p for c in sv) if isinstance(sv, tuple) else (sv % p, 0, 0)
         elif k == "trace":
             v = tuple(trace_at(*n.args))
         elif k == "table":

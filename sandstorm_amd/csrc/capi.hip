@@ -1496,8 +1496,13 @@ ss_status ss_eval_quotient_gl64x3(ss_ctx *ctx, const ss_air_program *prog, const
     const size_t code_bytes = (size_t)prog->n_instr * 8, const_bytes = (size_t)(prog->n_consts ? prog->n_consts : 1) * 24;
     ss_status st = ctx->ensure_scratch(code_bytes + const_bytes + tdesc.size() * 4 + 256);
     if (st != SS_OK) return st;
-    st = ctx->ensure_scratch2((size_t)(prog->n_slots ? prog->n_slots : 1) * 3 * lanes * 8);
-    if (st != SS_OK) return st;
+    // the plain layout's composition has a compiled kernel (quotient_gen_plain_gl.inc); SS_QUOTIENT_INTERPRET=1 forces the interpreter
+    const bool compiled = !getenv("SS_QUOTIENT_INTERPRET") && ncols <= (uint32_t)MAX_COLS &&
+                          gl3_compiled_matches(prog->code, prog->n_instr, prog->consts, prog->n_consts, prog->n_tables);
+    if (!compiled) {
+        st = ctx->ensure_scratch2((size_t)(prog->n_slots ? prog->n_slots : 1) * 3 * lanes * 8);
+        if (st != SS_OK) return st;
+    }
     char *p = (char *)ctx->scratch;
     uint64_t *d_consts = (uint64_t *)p; p += const_bytes;
     uint32_t *d_code = (uint32_t *)p; p += code_bytes;
@@ -1508,8 +1513,12 @@ ss_status ss_eval_quotient_gl64x3(ss_ctx *ctx, const ss_air_program *prog, const
     HIP_TRY(hipMemcpyAsync(d_tdesc, tdesc.data(), tdesc.size() * 4, hipMemcpyHostToDevice, s));
     {
         ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
-        HIP_TRY(launch_gl3_vm(s, d_code, prog->n_instr, d_consts, prog->d_tables, d_tdesc, d_lde_cols, ncols, (uint64_t *)ctx->scratch2, d_out, offset,
-                              gl_root_of_unity_host(log_n + log_blowup), log_blowup, N));
+        if (compiled)
+            HIP_TRY(launch_gl3_plain(s, d_consts, prog->d_tables, d_tdesc, d_lde_cols, ncols, d_out, offset, gl_root_of_unity_host(log_n + log_blowup),
+                                     log_blowup, N));
+        else
+            HIP_TRY(launch_gl3_vm(s, d_code, prog->n_instr, d_consts, prog->d_tables, d_tdesc, d_lde_cols, ncols, (uint64_t *)ctx->scratch2, d_out, offset,
+                                  gl_root_of_unity_host(log_n + log_blowup), log_blowup, N));
     }
     HIP_TRY(hipStreamSynchronize(s));
     return SS_OK;

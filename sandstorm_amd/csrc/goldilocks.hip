@@ -730,4 +730,30 @@ hipError_t launch_gl3_running_product(hipStream_t st, const uint64_t *na, const 
     return hipGetLastError();
 }
 
+
+// ---- the plain layout's composition, compiled (tools/gen_quotient_gl.py) ---------------------------------------------------------
+#include "quotient_gen_plain_gl.inc"
+
+// the compiled kernel for this program, if it is the plain layout's: the code words hash to the generated kernel's, the shapes agree,
+// and every constant the generator typed base-field is one in this table
+bool gl3_compiled_matches(const uint32_t *code, uint32_t n_instr, const uint64_t *consts3, uint32_t n_consts, uint32_t n_tables) {
+    if (n_instr != GL3_PLAIN_N_INSTR || n_consts != GL3_PLAIN_N_CONSTS || n_tables != GL3_PLAIN_N_TABLES) return false;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t k = 0; k < 2 * (size_t)n_instr; ++k)
+        for (int b = 0; b < 4; ++b) h = (h ^ ((code[k] >> (8 * b)) & 0xffu)) * 0x100000001b3ull;
+    if (h != GL3_PLAIN_CODE_HASH) return false;
+    for (uint16_t k : GL3_PLAIN_BASE_CONSTS)
+        if (consts3[3 * (size_t)k + 1] | consts3[3 * (size_t)k + 2]) return false;
+    return true;
+}
+hipError_t launch_gl3_plain(hipStream_t st, const uint64_t *d_consts, const uint64_t *d_tables, const uint32_t *d_tdesc, const uint64_t *const *cols,
+                            uint32_t ncols, uint64_t *d_out, uint64_t offset, uint64_t w, uint32_t log_blowup, uint64_t N) {
+    Gl3VmArgs a;
+    a.code = nullptr; a.consts = d_consts; a.tables = d_tables; a.tdesc = d_tdesc; a.slots = nullptr; a.out = d_out;
+    for (int c = 0; c < MAX_COLS; ++c) a.cols[c] = c < (int)ncols ? cols[c] : nullptr;
+    a.offset = offset; a.w = w; a.n_instr = 0; a.log_blowup = log_blowup; a.N = N;
+    hipLaunchKernelGGL(gl3_plain_kernel, dim3(gl_blocks(N, 256, 8192)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 }  // namespace ss

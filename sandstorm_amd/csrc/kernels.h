@@ -124,6 +124,9 @@ hipError_t launch_gl3_running_product(hipStream_t st, const uint64_t *na, const 
                                       uint64_t *o2, uint64_t out_stride, uint64_t out_offset, uint64_t *d_last);
 uint32_t gl3_dot_blocks(uint64_t n);
 hipError_t launch_gl3_dot(hipStream_t st, const uint64_t *coef, const uint64_t *zp0, const uint64_t *zp1, const uint64_t *zp2, uint64_t n, uint64_t *partial);
+bool gl3_compiled_matches(const uint32_t *code, uint32_t n_instr, const uint64_t *consts3, uint32_t n_consts, uint32_t n_tables);
+hipError_t launch_gl3_plain(hipStream_t st, const uint64_t *d_consts, const uint64_t *d_tables, const uint32_t *d_tdesc, const uint64_t *const *cols,
+                            uint32_t ncols, uint64_t *d_out, uint64_t offset, uint64_t w, uint32_t log_blowup, uint64_t N);
 uint32_t gl3_vm_lanes(uint64_t N);
 hipError_t launch_gl3_vm(hipStream_t st, const uint32_t *d_code, uint32_t n_instr, const uint64_t *d_consts, const uint64_t *d_tables,
                          const uint32_t *d_tdesc, const uint64_t *const *cols, uint32_t ncols, uint64_t *d_slots, uint64_t *d_out, uint64_t offset,

@@ -136,8 +136,8 @@ class Prover:
 
     def _commit(self, cols, n_rows):
         import torch
-        dig = torch.zeros((n_rows, 32), dtype=torch.uint8, device=cols[0].device)
-        nodes = torch.zeros((2 * n_rows, 32), dtype=torch.uint8, device=cols[0].device)
+        dig = torch.empty((n_rows, 32), dtype=torch.uint8, device=cols[0].device)          # every byte is written by the kernels
+        nodes = torch.empty((2 * n_rows, 32), dtype=torch.uint8, device=cols[0].device)
         # rows of more than 16 columns do not occur here (<= 8 trace, 6 composition coordinate columns)
         self.ctx.hash_rows_gl64(cols, 1, n_rows, dig)
         root, _ = self.ctx.merkle_build(be.TREE_BLAKE2S, 0, be.LEAF_DIGEST, dig, n_rows, nodes)
@@ -159,7 +159,7 @@ class Prover:
             raise ValueError("the composition split (even / odd coefficients) is written for blowup 2")
         N = n << lb
         dev = base_cols[0].device
-        new = lambda rows, width=None: torch.zeros((rows,) if width is None else (rows, width), dtype=torch.int64, device=dev)
+        new = lambda rows, width=None: torch.empty((rows,) if width is None else (rows, width), dtype=torch.int64, device=dev)   # fully written below
         coin = Coin(transcript_seed(seed, opt, n))
         proof = Proof(opt, n)
 
@@ -182,7 +182,7 @@ class Prover:
         alpha = coin.draw_fq3()
         tables = tables or air.make_tables(n, lb)
         root = air.composition(n, challenges, alpha, tables, statement)
-        prog = ap.lower(root, P, ext=True)
+        prog = ap.lower(root, P, ext=True, symbols=tables.symbols)
         tvals, tdesc = tables.device_tables()
         d_tables = torch.from_numpy(tvals.view(np.int64)).to(dev)
         q = new(N, 3)
@@ -195,7 +195,7 @@ class Prover:
             for t in range(3):
                 comp_co.append(qc[t][half * n:(half + 1) * n].contiguous())
         for c in comp_co:
-            padded = new(N)
+            padded = torch.zeros(N, dtype=torch.int64, device=dev)
             padded[::1 << lb] = c                                                    # zero-padded to N in bit-reversed order
             ctx.ntt_gl64([padded], log_n + lb, be.FORWARD, OFFSET, be.BITREV, be.NATURAL)
             comp_ev.append(padded)
@@ -221,8 +221,8 @@ class Prover:
         for _ in range(n_layers):
             rows = (1 << ll) // opt.fold
             segs = [be.DeviceView(_Raw(layer), 24 * k * rows, 24 * rows) for k in range(opt.fold)]
-            dig = torch.zeros((rows, 32), dtype=torch.uint8, device=dev)
-            nodes = torch.zeros((2 * rows, 32), dtype=torch.uint8, device=dev)
+            dig = torch.empty((rows, 32), dtype=torch.uint8, device=dev)
+            nodes = torch.empty((2 * rows, 32), dtype=torch.uint8, device=dev)
             ctx.hash_rows_gl64(segs, 3, rows, dig)
             root_l, _ = ctx.merkle_build(be.TREE_BLAKE2S, 0, be.LEAF_DIGEST, dig, rows, nodes)
             coin.reseed_with_digest(root_l)
@@ -336,7 +336,7 @@ def verify(proof: Proof, air: Air, seed: bytes, statement=None, expected_options
     tables = air.make_tables(n, lb)
     root = air.composition(n, challenges, alpha, tables, statement)
     g = F.root_of_unity(log_n)
-    lhs = ap.evaluate_ext(root, P, z, lambda c, o: ood_t[(c, o)], lambda t: tables.value_at(tables.specs[t], z))
+    lhs = ap.evaluate_ext(root, P, z, lambda c, o: ood_t[(c, o)], lambda t: tables.value_at(tables.specs[t], z), symbols=tables.symbols)
     Xk = [(1, 0, 0), (0, 1, 0), (0, 0, 1)]
     H = [(0, 0, 0), (0, 0, 0)]
     for h in range(2):

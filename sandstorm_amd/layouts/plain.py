@@ -175,7 +175,7 @@ def constraints(hints: Hints, challenges=None) -> List[Constraint]:
     import sys
     me = sys.modules[__name__]
     ch = challenges or [(0, 0, 0)] * NUM_CHALLENGES
-    c3 = lambda t: ap.Const3(*t)
+    c3 = lambda t: t if isinstance(t, ap.Expr) else ap.Const3(*t)          # values, or named constants (composition())
     z, a, zr = c3(ch[MEM_Z]), c3(ch[MEM_A]), c3(ch[RC_Z])
     one = ap.Const(1)
     address_diff = mem(Mem.ADDRESS, 1) - mem(Mem.ADDRESS)
@@ -219,6 +219,16 @@ class Tables:
         self.specs, self._ix = [], {}
         self.single_rows = sorted(set(r % n for r in (single_rows if single_rows is not None else (0, n - CYCLE_HEIGHT, n - 2, n - 4))))
         self._single_inv = {}
+        self.symbols = {}               # named constants of the DAG built with these tables: name -> value (composition() fills it)
+
+    def _row_point(self, r):
+        """g^r as an expression: a literal for row 0, a NAMED constant for a row counted from the end (its value depends on n)"""
+        r %= self.n
+        if r == 0:
+            return ap.Const(1)
+        name = "g^(n-%d)" % (self.n - r)
+        self.symbols[name] = pow(self.g, r, P)
+        return ap.Sym(name)
 
     def _table(self, p_, e, inverse):
         key = (p_, e, inverse)
@@ -229,13 +239,13 @@ class Tables:
 
     def factor(self, p_, e, inverse=False):
         if p_ == 1:
-            f = ap.X - ap.Const(pow(self.g, e, P))
+            f = ap.X - self._row_point(e)
             if not inverse:
                 return f
             if e % self.n not in self.single_rows or len(self.single_rows) < 2:
                 return f.inverse()
             if not self._single_inv:
-                fs = [ap.X - ap.Const(pow(self.g, r, P)) for r in self.single_rows]
+                fs = [ap.X - self._row_point(r) for r in self.single_rows]
                 prod = fs[0]
                 for g_ in fs[1:]:
                     prod = prod * g_
@@ -291,11 +301,21 @@ class Tables:
         return np.array(vals or [0], dtype=np.uint64), desc
 
 
-def composition(n, hints: Hints, challenges, alpha, tables: Tables, constraint_list=None):
-    """sum_k alpha^k * numerator_k * multiplier(domain_k), alpha in Fq3"""
+def composition(n, hints: Hints, challenges, alpha, tables: Tables):
+    """sum_k alpha^k * numerator_k * multiplier(domain_k), alpha in Fq3.  Everything a statement or a transcript decides - hints,
+    challenges, alpha^k, the powers of the trace generator - enters the DAG as a NAMED constant (air_program.Sym) whose value
+    goes into tables.symbols: every statement of the layout lowers to the same program, word for word."""
+    sym = tables.symbols
+    names = ("initial_ap", "initial_pc", "final_ap", "final_pc", "range_check_min", "range_check_max", "memory_quotient", "range_check_product")
+    for name in names:
+        sym["hint:" + name] = getattr(hints, name)
+    for k, c in enumerate(challenges):
+        sym["challenge:%d" % k] = tuple(c)
+    shints = Hints(*[ap.Sym("hint:" + name) for name in names])
     root, coeff = None, (1, 0, 0)
-    for c in (constraint_list or constraints(hints, challenges)):
-        term = ap.Const3(*coeff) * (c.numerator * tables.multiplier(c.domain))
+    for k, c in enumerate(constraints(shints, [ap.Sym("challenge:%d" % j) for j in range(NUM_CHALLENGES)])):
+        sym["alpha^%d" % k] = coeff
+        term = ap.Sym("alpha^%d" % k) * (c.numerator * tables.multiplier(c.domain))
         root = term if root is None else root + term
         coeff = mul3(coeff, alpha)
     return root
@@ -541,7 +561,7 @@ def failing_rows(constraint, cols8, n, limit=5):
     """rows of the constraint's domain where its numerator does not vanish on the trace (cols8: the 8 component columns)"""
     bad = []
     for r in constraint.domain.rows(n):
-        v = ap.evaluate_ext(constraint.numerator, P, (0, 0, 0), lambda c, o: (cols8[c][(r + o) % n], 0, 0), None)
+        v = ap.evaluate_ext(constraint.numerator, P, (0, 0, 0), lambda c, o: (cols8[c][(r + o) % n], 0, 0), None)       # concrete constants
         if any(v):
             bad.append(r)
             if len(bad) >= limit:

@@ -65,7 +65,7 @@ def test_lowered_composition_is_the_dag(run, oracle):
     tables = pl.Tables(n, lb)
     alpha = (123456789, 987654321, 55555)
     root = pl.composition(n, hints, CH, alpha, tables)
-    program = ap.lower(root, pl.P, ext=True)
+    program = ap.lower(root, pl.P, ext=True, symbols=tables.symbols)
     tvals, tdesc = tables.device_tables()
     got = oracle.gl3_eval_program(np.array(program.code, dtype=np.uint32), np.array(program.consts, dtype=np.uint64), program.n_slots, tvals, tdesc,
                                   lde, log_n, lb, pl.GENERATOR)
@@ -73,7 +73,7 @@ def test_lowered_composition_is_the_dag(run, oracle):
     for i in (0, 1, 2, 17, 1000, N - 1):
         x = pl.GENERATOR * pow(wN, i, pl.P) % pl.P
         want = ap.evaluate_ext(root, pl.P, (x, 0, 0), lambda c, o: (int(lde[c][(i + (o << lb)) % N]), 0, 0),
-                               lambda t: (tables.host_values(tables.specs[t])[i % tables.length(tables.specs[t])], 0, 0))
+                               lambda t: (tables.host_values(tables.specs[t])[i % tables.length(tables.specs[t])], 0, 0), symbols=tables.symbols)
         assert tuple(int(v) for v in got[i]) == tuple(want), i
     # the trace satisfies the AIR: every quotient is a polynomial, the largest (a quadratic numerator over X - 1) of degree 2 n - 3
     for t in range(3):
@@ -175,3 +175,61 @@ def test_tampered_proofs_and_statements_are_rejected(proved):
     bad[pl.COL_AUXILIARY][16 * 9 + pl.Auxiliary.TMP0[1]] += 1
     with pytest.raises(gs.VerificationError, match="do not satisfy the AIR"):
         gs.verify(prove(bad), air, seed, statement=pi)
+
+
+@pytest.mark.gpu
+def test_compiled_composition_kernel_is_the_interpreter(proved, run, oracle):
+    """the plain layout's composition runs as generated straight-line code (tools/gen_quotient_gl.py); for other statements,
+    sizes and transcripts it is still the program the library recognises, and its values are the interpreter's and the oracle's"""
+    import os
+    import torch
+    gs, air, pi, cols, prove, opt = proved
+    ctx = prove.ctx
+    rng = np.random.default_rng(6)
+    for log_n, ch, alpha in ((10, CH, (123456789, 987654321, 55555)), (13, [(1, 2, 3), (4, 5, 6), (7, 8, 9)], (5, 0, 1))):
+        n, lb = 1 << log_n, 1
+        N = n << lb
+        tables = pl.Tables(n, lb)
+        stmt = copy.deepcopy(pi)
+        stmt.n_steps = n // 16
+        root = pl.composition(n, pl.Hints.from_public_input(stmt, ch, n), ch, alpha, tables)
+        program = ap.lower(root, pl.P, ext=True, symbols=tables.symbols)
+        code, consts = np.array(program.code, dtype=np.uint32), np.array(program.consts, dtype=np.uint64)
+        tvals, tdesc = tables.device_tables()
+        lde = [(rng.integers(0, 1 << 62, size=N, dtype=np.uint64)) for _ in range(8)]
+        d_lde, d_tab = [torch.from_numpy(c.view(np.int64)).cuda() for c in lde], torch.from_numpy(tvals.view(np.int64)).cuda()
+        outs = []
+        for interpret in (False, True):
+            if interpret:
+                os.environ["SS_QUOTIENT_INTERPRET"] = "1"
+            try:
+                out = torch.zeros((N, 3), dtype=torch.int64, device="cuda")
+                ctx.eval_quotient_gl64x3(code, consts, program.n_slots, d_tab, tdesc, d_lde, log_n, lb, pl.GENERATOR, out)
+                outs.append(out.cpu().numpy().view(np.uint64))
+            finally:
+                os.environ.pop("SS_QUOTIENT_INTERPRET", None)
+        assert np.array_equal(outs[0], outs[1])
+        assert np.array_equal(outs[0], oracle.gl3_eval_program(code, consts, program.n_slots, tvals, tdesc, lde, log_n, lb, pl.GENERATOR))
+    # the library must in fact have taken the compiled kernel for this program: the generated hash is this program's
+    import re
+    inc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sandstorm_amd", "csrc", "quotient_gen_plain_gl.inc")).read()
+    want = int(re.search(r"GL3_PLAIN_CODE_HASH = (0x[0-9a-f]+)ull", inc).group(1), 16)
+    h = 0xcbf29ce484222325
+    for w in program.code:
+        for k in range(4):
+            h = ((h ^ ((int(w) >> (8 * k)) & 0xff)) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    assert h == want, "regenerate csrc/quotient_gen_plain_gl.inc (python tools/gen_quotient_gl.py)"
+
+
+def test_generated_kernel_is_current():
+    """CPU: the committed generated kernel is the one the generator writes for today's layout and lowering"""
+    import os
+    import re
+    import sys
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root_dir, "tools"))
+    import gen_quotient_gl as g
+    code, consts, n_slots, n_tables = g.template_program()
+    inc = open(os.path.join(root_dir, "sandstorm_amd", "csrc", "quotient_gen_plain_gl.inc")).read()
+    assert int(re.search(r"GL3_PLAIN_CODE_HASH = (0x[0-9a-f]+)ull", inc).group(1), 16) == g.code_hash(code)
+    assert "GL3_PLAIN_N_INSTR = %du" % (len(code) // 2) in inc
