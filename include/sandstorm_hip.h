@@ -290,8 +290,8 @@ ss_status ss_running_product_gl64x3(ss_ctx *ctx, const uint64_t *d_num_addr, con
  * [nidx][nseg][seg_len]. */
 ss_status ss_hash_rows_gl64(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len,
                             uint64_t nrows, uint8_t *d_digests);
-ss_status ss_gather_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, const uint64_t *idx,
-                              uint32_t nidx, uint64_t *out);
+ss_status ss_gather_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, uint64_t nrows,
+                              const uint64_t *idx, uint32_t nidx, uint64_t *out);
 /* Q1 over the cubic extension: the program format of ss_eval_quotient (ss_air_program above) with accumulators, scratch
  * slots and constants in Fq3 - prog->consts holds n_consts x 3 values < p - and trace cells, tables (prog->d_tables: 8-byte
  * elements) and x in Fp, read into the first coordinate.  d_out: [n * blowup][3] interleaved.  Interpreted (no compiled

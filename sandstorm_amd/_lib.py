@@ -99,7 +99,7 @@ SIGNATURES = {
     "ss_running_product_gl64x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, _u64p, _u64p, _vpp,
                                             C.c_uint64, C.c_uint64, _u64p]),
     "ss_hash_rows_gl64": (C.c_int, [C.c_void_p, C.c_int, _vpp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
-    "ss_gather_rows_gl64": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, _u64p, C.c_uint32, _u64p]),
+    "ss_gather_rows_gl64": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint64, _u64p, C.c_uint32, _u64p]),
     "ss_eval_quotient_gl64x3": (C.c_int, [C.c_void_p, C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
     "ss_ood_eval_gl64x3": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, _u32p, _u32p, C.c_uint32, _u64p, _u64p]),
     "ss_deep_compose_gl64x3": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, _u32p, _u32p,

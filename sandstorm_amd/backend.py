@@ -233,12 +233,12 @@ class Context:
         check(self.lib.ss_hash_rows_gl64(self.handle, HASH_BLAKE2S if hash_kind is None else hash_kind, _ptr_array(segments), len(segments), seg_len,
                                          nrows, _ptr_of(out)))
 
-    def gather_rows_gl64(self, segments, seg_len, idx):
-        """rows idx of such a matrix -> uint64[len(idx), nseg, seg_len]"""
+    def gather_rows_gl64(self, segments, seg_len, nrows, idx):
+        """rows idx (< nrows) of such a matrix -> uint64[len(idx), nseg, seg_len]"""
         ix = np.ascontiguousarray(idx, dtype=np.uint64)
         out = np.zeros((len(ix), len(segments), seg_len), dtype=np.uint64)
         u64 = C.POINTER(C.c_uint64)
-        check(self.lib.ss_gather_rows_gl64(self.handle, _ptr_array(segments), len(segments), seg_len, ix.ctypes.data_as(u64), len(ix), out.ctypes.data_as(u64)))
+        check(self.lib.ss_gather_rows_gl64(self.handle, _ptr_array(segments), len(segments), seg_len, nrows, ix.ctypes.data_as(u64), len(ix), out.ctypes.data_as(u64)))
         return out
 
     def eval_quotient_gl64x3(self, code, consts3, n_slots, tables, table_desc, lde_cols, log_n, log_blowup, offset, out):

@@ -1446,9 +1446,11 @@ ss_status ss_hash_rows_gl64(ss_ctx *ctx, int hash_kind, const uint64_t *const *d
     return SS_OK;
 }
 
-ss_status ss_gather_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, const uint64_t *idx, uint32_t nidx,
-                              uint64_t *out) {
+ss_status ss_gather_rows_gl64(ss_ctx *ctx, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, uint64_t nrows, const uint64_t *idx,
+                              uint32_t nidx, uint64_t *out) {
     if (!ctx || !d_segments || (nidx && (!idx || !out))) return fail(SS_ERR_INVALID, "NULL argument");
+    for (uint32_t j = 0; j < nidx; ++j)
+        if (idx[j] >= nrows) return fail(SS_ERR_INVALID, "row index %llu out of range", (unsigned long long)idx[j]);
     if (nseg == 0 || nseg > (uint32_t)MAX_COLS || seg_len == 0 || seg_len > 64) return fail(SS_ERR_UNSUPPORTED, "row shape %u x %u out of range", nseg, seg_len);
     if (!nidx) return SS_OK;
     ConstColPtrs segs;

@@ -144,7 +144,7 @@ class Prover:
         return root, nodes
 
     def _open(self, cols, nodes, n_rows, positions, seg_len=1):
-        rows = self.ctx.gather_rows_gl64(cols, seg_len, positions).reshape(len(positions), -1)
+        rows = self.ctx.gather_rows_gl64(cols, seg_len, n_rows, positions).reshape(len(positions), -1)
         paths, _ = self.ctx.merkle_open(nodes, None, n_rows, positions)
         return Opening(rows, paths)
 

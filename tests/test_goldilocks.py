@@ -439,7 +439,10 @@ def test_row_hashing_and_trees_of_8_byte_elements(ctx, nseg, seg_len):
         level = [hashlib.blake2s(level[2 * k] + level[2 * k + 1]).digest() for k in range(len(level) // 2)]
     assert root == level[0]
     idx = [0, 5, 63, 17]
-    rows = ctx.gather_rows_gl64(d_segs, seg_len, idx)
+    rows = ctx.gather_rows_gl64(d_segs, seg_len, nrows, idx)
+    from sandstorm_amd._lib import SandstormHipError
+    with pytest.raises(SandstormHipError):
+        ctx.gather_rows_gl64(d_segs, seg_len, nrows, [nrows])
     assert rows.shape == (4, nseg, seg_len)
     for q, i in enumerate(idx):
         assert [int(v) for v in rows[q].reshape(-1)] == [int(s[i * seg_len + e]) for s in segs for e in range(seg_len)]
