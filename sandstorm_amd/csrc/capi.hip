@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -76,6 +77,7 @@ struct ss_ctx {
     hipStream_t stream = nullptr;
     std::map<PlanKey, Fp *> plans;          // device twiddle tables
     std::map<std::tuple<uint32_t, int, uint64_t>, uint64_t *> gl_plans;     // the 64-bit field's: (log_n, inverse, offset)
+    std::map<uint64_t, int> quotient_choice;      // per compiled constraint kernel (code hash): 0 undecided, 1 compiled, 2 interpreter
     PedersenTables *ped = nullptr;
     void *scratch = nullptr;                // grow-only device scratch
     size_t scratch_bytes = 0;
@@ -1159,6 +1161,9 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
 extern "C" {
 
 // whole domain: row0 = 0, npoints = N, block_rows = 0.  Row block: the columns hold LDE rows row0 .. row0 + block_rows.
+static ss_status eval_quotient_interpreted(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols, uint32_t ncols, uint32_t log_N,
+                                           uint32_t log_blowup, const uint64_t offset[4], uint64_t row0, uint64_t N, bool block, uint64_t *d_out);
+
 static ss_status eval_quotient_impl(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols,
                                     uint32_t ncols, uint32_t log_n, uint32_t log_blowup, const uint64_t offset[4],
                                     uint64_t row0, uint64_t npoints, uint64_t block_rows, uint64_t *d_out) {
@@ -1193,9 +1198,36 @@ static ss_status eval_quotient_impl(ss_ctx *ctx, const ss_air_program *prog, con
     // program): recognised by the hash of its code words.  Everything per proof (constants, tables, columns, size) is data.
     if (!getenv("SS_QUOTIENT_INTERPRET")) {
         const QGenKernel *gen = quotient_gen_find(prog->code, prog->n_instr);
-        if (gen && gen->n_consts == prog->n_consts && gen->n_tables == prog->n_tables && gen->ncols <= ncols)
-            return eval_quotient_compiled(ctx, *gen, prog, d_lde_cols, ncols, log_N, log_blowup, offset, d_out, row0, N, block);
+        if (gen && gen->n_consts == prog->n_consts && gen->n_tables == prog->n_tables && gen->ncols <= ncols) {
+            // The compiled kernels run at one or two waves per SIMD off a megabyte of straight-line code: they live on the memory
+            // system's latency (instruction fetch included), the interpreter at four waves per SIMD does not.  On a healthy MI355X the
+            // compiled kernel wins by 1.4x; a device whose fabric is slow can turn that around (seen once: 5x slower, profiles/
+            // r02_end_outlier_box_*).  So the first evaluation of at least 2^20 points with a given kernel runs BOTH paths, timed,
+            // into the same output - they agree bit for bit - and the context keeps the faster one (SS_QUOTIENT_NO_AUTOTUNE=1: always
+            // the compiled kernel).
+            int &choice = ctx->quotient_choice[gen->code_hash];
+            if (choice == 0 && N >= (1ull << 20) && !getenv("SS_QUOTIENT_NO_AUTOTUNE")) {
+                const auto t0 = std::chrono::steady_clock::now();
+                ss_status st = eval_quotient_compiled(ctx, *gen, prog, d_lde_cols, ncols, log_N, log_blowup, offset, d_out, row0, N, block);
+                if (st != SS_OK) return st;
+                const auto t1 = std::chrono::steady_clock::now();
+                st = eval_quotient_interpreted(ctx, prog, d_lde_cols, ncols, log_N, log_blowup, offset, row0, N, block, d_out);
+                if (st != SS_OK) return st;
+                const double tc = std::chrono::duration<double>(t1 - t0).count(), ti = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+                choice = tc <= ti ? 1 : 2;
+                if (choice == 2)
+                    fprintf(stderr, "[sandstorm_hip] compiled %s constraint kernel %.1f ms vs interpreter %.1f ms on this device: interpreting\n",
+                            gen->layout, tc * 1e3, ti * 1e3);
+                return SS_OK;
+            }
+            if (choice != 2) return eval_quotient_compiled(ctx, *gen, prog, d_lde_cols, ncols, log_N, log_blowup, offset, d_out, row0, N, block);
+        }
     }
+    return eval_quotient_interpreted(ctx, prog, d_lde_cols, ncols, log_N, log_blowup, offset, row0, N, block, d_out);
+}
+
+static ss_status eval_quotient_interpreted(ss_ctx *ctx, const ss_air_program *prog, const uint64_t *const *d_lde_cols, uint32_t ncols, uint32_t log_N,
+                                           uint32_t log_blowup, const uint64_t offset[4], uint64_t row0, uint64_t N, bool block, uint64_t *d_out) {
     uint64_t lanes = 256ull * 256 * 4;                 // 4 workgroups of 256 per CU
     if (lanes > N) lanes = N < 256 ? 256 : (N + 255) / 256 * 256;
     const size_t code_b = ((size_t)prog->n_instr + 1) * 32, const_b = (size_t)(prog->n_consts ? prog->n_consts : 1) * 32;

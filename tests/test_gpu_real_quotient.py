@@ -113,3 +113,39 @@ def test_compiled_kernel_is_the_interpreter(oracle, layout, monkeypatch):
     interpreted = out.download(np.uint64, (N, 4))
     assert compiled.any() and np.array_equal(compiled, interpreted)
     ctx.close()
+
+
+def test_first_large_evaluation_times_both_paths_and_agrees(oracle, monkeypatch):
+    """at 2^20 points and above the first evaluation with a compiled kernel runs the compiled kernel AND the interpreter (timed, into
+    the same output) and the context keeps the faster: the output of that call, of the next one (the kept path) and of the forced
+    interpreter are the same"""
+    from sandstorm_amd import backend as be, hostlib
+    from sandstorm_amd.layouts import recursive as lay
+    log_n = 19
+    _, _, pi = load_run()
+    cpp = hostlib.RecursiveHostAir(None, pi, log_n)
+    n, N = 1 << log_n, 2 << log_n
+    code, consts, n_slots, specs = cpp.dump(n, [oracle.to_mont([c])[0] for c in CHALLENGES], oracle.to_mont([pow(3, 99, P)])[0])
+    cpp.close()
+    tables = lay.Tables(n)
+    rng = np.random.default_rng(8)
+    tabs, desc, off = [], [], 0
+    for spec in specs:
+        t = _rand(rng, tables.length(spec))
+        desc += [off, len(t).bit_length() - 1]
+        off += len(t)
+        tabs.append(t)
+    ctx = be.Context(0)
+    m = be.Matrix.from_host(ctx, [_rand(rng, N) for _ in range(10)])
+    d_tab = ctx.column(np.concatenate(tabs))
+    prog = _Prog(code, [int(v) for v in oracle.from_mont(consts)], n_slots)
+    g = oracle.to_mont([3])[0]
+    outs = []
+    for k in range(3):
+        if k == 2:
+            monkeypatch.setenv("SS_QUOTIENT_INTERPRET", "1")
+        out = ctx.alloc(32 * N)
+        ctx.eval_quotient(prog, d_tab, desc, m.cols, log_n, 1, g, out)
+        outs.append(out.download(np.uint64, (N, 4)))
+    assert outs[0].any() and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    ctx.close()
