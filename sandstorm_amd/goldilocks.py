@@ -270,6 +270,34 @@ class _Raw:
         self.t, self.ptr, self.nbytes, self.ctx = t, t.data_ptr(), t.numel() * t.element_size(), None
 
 
+# ---- a proof as a dictionary of arrays (numpy.savez): fixtures, transport ------------------------------------------------------------
+def proof_to_arrays(p: Proof) -> dict:
+    o = p.options
+    d = {"options": np.array([o.num_queries, o.log_blowup, o.grinding, o.fold, o.max_remainder, p.trace_len, p.pow_nonce], dtype=np.uint64),
+         "roots": np.frombuffer(p.base_root + (p.ext_root or bytes(32)) + p.comp_root, dtype=np.uint8).copy(),
+         "has_ext": np.array([1 if p.ext is not None else 0], dtype=np.uint8),
+         "ood_trace": p.ood_trace, "ood_comp": p.ood_comp, "remainder": p.remainder,
+         "fri_roots": np.frombuffer(b"".join(fl.root for fl in p.fri_layers), dtype=np.uint8).copy(),
+         "fri_log_len": np.array([fl.log_len for fl in p.fri_layers], dtype=np.uint32)}
+    for name, op in [("base", p.base), ("ext", p.ext), ("comp", p.comp)] + [("fri%d" % k, fl.opening) for k, fl in enumerate(p.fri_layers)]:
+        if op is not None:
+            d[name + "_rows"], d[name + "_paths"] = op.rows, op.paths
+    return d
+
+
+def proof_from_arrays(d) -> Proof:
+    o = [int(v) for v in d["options"]]
+    roots = bytes(d["roots"])
+    p = Proof(Options(*o[:5]), o[5], roots[:32], roots[32:64] if int(d["has_ext"][0]) else b"", roots[64:96], np.array(d["ood_trace"]),
+              np.array(d["ood_comp"]), [], np.array(d["remainder"]), o[6])
+    opening = lambda name: Opening(np.array(d[name + "_rows"]), np.array(d[name + "_paths"])) if name + "_rows" in d else None
+    p.base, p.ext, p.comp = opening("base"), opening("ext"), opening("comp")
+    fr = bytes(d["fri_roots"])
+    for k, ll in enumerate(d["fri_log_len"]):
+        p.fri_layers.append(FriLayer(fr[32 * k:32 * k + 32], int(ll), opening("fri%d" % k)))
+    return p
+
+
 # ---- verifier --------------------------------------------------------------------------------------------------------------------
 class VerificationError(Exception):
     pass

@@ -233,3 +233,33 @@ def test_generated_kernel_is_current():
     inc = open(os.path.join(root_dir, "sandstorm_amd", "csrc", "quotient_gen_plain_gl.inc")).read()
     assert int(re.search(r"GL3_PLAIN_CODE_HASH = (0x[0-9a-f]+)ull", inc).group(1), 16) == g.code_hash(code)
     assert "GL3_PLAIN_N_INSTR = %du" % (len(code) // 2) in inc
+
+
+def test_gpu_made_proof_verifies_on_the_cpu(run):
+    """tests/golden/goldilocks_plain_proof.npz was written on the MI355X (tests/golden/make_goldilocks_proof.py); the verifier is host
+    code: the statement is rebuilt here from the example run, the AIR identity is recomputed from the layout's DAG"""
+    import os
+    from sandstorm_amd import goldilocks as gs
+    prog, states, memory, pi, cols = run
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "goldilocks_plain_proof.npz")) as f:
+        arrays = {k: f[k] for k in f.files}
+    proof = gs.proof_from_arrays(arrays)
+    air, opt = gs.plain_air(), gs.Options(num_queries=20, grinding=8)
+    positions = gs.verify(proof, air, bytes(range(32)), statement=pi, expected_options=opt, required_security_bits=28)
+    assert len(positions) >= 15 and proof.trace_len == len(cols[0])
+    # the round trip through arrays is lossless
+    again = gs.proof_to_arrays(proof)
+    assert set(again) == set(arrays) and all(np.array_equal(again[k], arrays[k]) for k in arrays)
+    # and the fixture does not verify as anything else
+    for mutate in (lambda p: p.ood_trace.__setitem__((0, 0), (int(p.ood_trace[0, 0]) + 1) % pl.P),
+                   lambda p: p.base.rows.__setitem__((3, 2), int(p.base.rows[3, 2]) ^ 1),
+                   lambda p: p.fri_layers[0].opening.paths.__setitem__((0, 0, 0), int(p.fri_layers[0].opening.paths[0, 0, 0]) ^ 1),
+                   lambda p: setattr(p, "pow_nonce", p.pow_nonce + 1)):
+        p = gs.proof_from_arrays(arrays)
+        mutate(p)
+        with pytest.raises(gs.VerificationError):
+            gs.verify(p, air, bytes(range(32)), statement=pi)
+    other = copy.deepcopy(pi)
+    other.memory_segments["execution"] = (other.memory_segments["execution"][0], other.memory_segments["execution"][1] + 1)
+    with pytest.raises(gs.VerificationError):
+        gs.verify(gs.proof_from_arrays(arrays), air, bytes(range(32)), statement=other)
