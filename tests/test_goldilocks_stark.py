@@ -263,3 +263,24 @@ def test_gpu_made_proof_verifies_on_the_cpu(run):
     other.memory_segments["execution"] = (other.memory_segments["execution"][0], other.memory_segments["execution"][1] + 1)
     with pytest.raises(gs.VerificationError):
         gs.verify(gs.proof_from_arrays(arrays), air, bytes(range(32)), statement=other)
+
+
+def test_whole_pipeline_on_the_oracle_reproduces_the_gpu_made_proof(run):
+    """the prover of sandstorm_amd/goldilocks.py with the oracle standing in for every kernel (oracle/gl_cpu_context.py) writes the
+    proof the MI355X wrote (tests/golden/goldilocks_plain_proof.npz), array for array: transforms, row hashes and trees, the lowered
+    constraint program, out-of-domain values, DEEP, every FRI layer, the remainder, the smallest proof-of-work nonce, the openings"""
+    import os
+    import torch
+    from oracle.gl_cpu_context import GlCpuContext
+    from sandstorm_amd import goldilocks as gs
+    prog, states, memory, pi, cols = run
+    ctx = GlCpuContext()
+    base = [torch.from_numpy(np.array(c, dtype=np.uint64).view(np.int64)) for c in cols]
+    air, opt = gs.plain_air(), gs.Options(num_queries=20, grinding=8)
+    proof = gs.Prover(ctx, air, opt).prove(bytes(range(32)), base, lambda ch: gs.plain_extension_on_device(ctx, base, ch)[0], statement=pi)
+    got = gs.proof_to_arrays(proof)
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "goldilocks_plain_proof.npz")) as f:
+        want = {k: f[k] for k in f.files}
+    assert set(got) == set(want)
+    for k in sorted(want):
+        assert np.array_equal(np.asarray(got[k]), want[k]), k
