@@ -375,7 +375,10 @@ def verify(proof: Proof, air: Air, seed: bytes, statement=None, expected_options
     gamma = coin.draw_fq3()
     coefs = _powers3(gamma, len(air.mask) + 6)
     # FRI transcript
-    n_layers, rem_len = fri_shape(N, opt)
+    try:
+        n_layers, rem_len = fri_shape(N, opt)
+    except ValueError as e:
+        raise VerificationError("options: %s" % e)
     _need(len(proof.fri_layers) == n_layers, "number of FRI layers")
     fri_alphas, ll = [], log_n + lb
     log_fold = opt.fold.bit_length() - 1
