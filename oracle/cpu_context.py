@@ -245,9 +245,8 @@ class CpuContext:
         oracle.lib().or_inverse_table(C.c_uint(log_N), _fp_arg(offset), _fp_arg(c), C.c_void_p(_addr(out)))
 
     def eval_quotient(self, program, tables, table_desc, lde_cols, log_n, log_blowup, offset, out):
-        from sandstorm_amd.backend import felt
         N = 1 << (log_n + log_blowup)
-        consts = np.stack([felt(v) for v in program.consts]) if len(program.consts) else np.zeros((0, 4), dtype=np.uint64)
+        consts = oracle.to_mont(list(program.consts)) if len(program.consts) else np.zeros((0, 4), dtype=np.uint64)
         ntab = 0
         for k in range(0, len(table_desc), 2):
             ntab = max(ntab, table_desc[k] + (1 << table_desc[k + 1]))
@@ -256,8 +255,7 @@ class CpuContext:
                                                 [_felts(c, N) for c in lde_cols], log_n, log_blowup, offset)
 
     def eval_quotient_rows(self, program, tables, table_desc, col_blocks, log_n, log_blowup, offset, row0, nrows, block_rows, out):
-        from sandstorm_amd.backend import felt
-        consts = np.ascontiguousarray(np.stack([felt(v) for v in program.consts])) if len(program.consts) else np.zeros((1, 4), dtype=np.uint64)
+        consts = np.ascontiguousarray(oracle.to_mont(list(program.consts))) if len(program.consts) else np.zeros((1, 4), dtype=np.uint64)
         code = np.ascontiguousarray(program.code, dtype=np.uint32)
         desc = np.ascontiguousarray(table_desc, dtype=np.uint32) if len(table_desc) else np.zeros(2, dtype=np.uint32)
         prog = oracle.AirProgram(code.ctypes.data_as(C.POINTER(C.c_uint32)), len(code) // 2,

@@ -15,6 +15,38 @@ NATURAL, BITREV = 0, 1
 FORWARD, INVERSE = 0, 1
 
 
+# Fq3 = Fp[X] / (X^3 - 2) on Python integers, from the definition (the oracle's own: nothing of the product's is imported here)
+def f3(a):
+    return (a % GL_P, 0, 0)
+
+
+def add3(a, b):
+    return tuple((x + y) % GL_P for x, y in zip(a, b))
+
+
+def sub3(a, b):
+    return tuple((x - y) % GL_P for x, y in zip(a, b))
+
+
+def scale3(a, k):
+    return tuple(x * k % GL_P for x in a)
+
+
+def mul3(a, b):
+    c = [0] * 5
+    for i in range(3):
+        for j in range(3):
+            c[i + j] += a[i] * b[j]
+    return ((c[0] + 2 * c[3]) % GL_P, (c[1] + 2 * c[4]) % GL_P, c[2] % GL_P)
+
+
+def inv3(a):
+    """the adjugate over the norm: (a0 + a1 X + a2 X^2)(t0 + t1 X + t2 X^2) = a0 t0 + 2 (a1 t2 + a2 t1), the X and X^2 terms cancel"""
+    a0, a1, a2 = a
+    t = (a0 * a0 - 2 * a1 * a2, 2 * a2 * a2 - a0 * a1, a1 * a1 - a0 * a2)
+    return scale3(t, pow((a0 * t[0] + 2 * (a1 * t[2] + a2 * t[1])) % GL_P, -1, GL_P))
+
+
 def _np(t):
     """a numpy uint64 view of a torch CPU tensor (or array) sharing its memory"""
     a = t.numpy() if hasattr(t, "numpy") else np.asarray(t)
@@ -111,7 +143,6 @@ class GlCpuContext:
 
     # ---- the extension column's running quotients, proof of work
     def running_product_gl64x3(self, num_addr, num_val, den_addr, den_val, stride, count, z, alpha, out_cols, out_stride, out_offset, want_last=True):
-        from sandstorm_amd.layouts.plain import add3, f3, inv3, mul3, scale3, sub3      # integer Fq3 helpers (host arithmetic)
         na, da = _np(num_addr), _np(den_addr)
         nv, dv = (_np(num_val), _np(den_val)) if num_val is not None else (None, None)
         z, al = tuple(int(v) for v in z), (tuple(int(v) for v in alpha) if alpha is not None else (0, 0, 0))
@@ -127,7 +158,7 @@ class GlCpuContext:
         return last if want_last else None
 
     def pow_grind(self, coin_kind, digest, bits):
-        from sandstorm_amd.coin import keccak256                                        # the library's host Keccak
+        keccak256 = oracle.keccak256                                                    # oracle/keccak.c
         prefix = keccak256((0x0123456789ABCDED).to_bytes(8, "big") + bytes(digest) + bytes([bits]))
         nonce = 0
         while int.from_bytes(keccak256(prefix + nonce.to_bytes(8, "big"))[:8], "big") >> (64 - bits):
