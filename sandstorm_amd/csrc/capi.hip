@@ -1651,6 +1651,11 @@ ss_status ss_deep_compose_gl64x3(ss_ctx *ctx, const uint64_t *const *d_trace_lde
     std::vector<uint32_t> tap_shift, cdesc;
     std::vector<uint64_t> tap_coef;
     auto load3 = [](const uint64_t *p) { return HGl3{{p[0], p[1], p[2]}}; };
+    // a tap's coefficient as the kernel's right-hand factor (gl64.h Gl3Rhs): c0, c1, c2, 2 c1, 2 c2
+    auto push_tap = [&](const HGl3 &c) {
+        for (int t = 0; t < 3; ++t) tap_coef.push_back(c.c[t]);
+        tap_coef.push_back(gl_addh(c.c[1], c.c[1])); tap_coef.push_back(gl_addh(c.c[2], c.c[2]));
+    };
     for (uint32_t t = 0; t < nmask;) {
         const uint32_t col = mask_col[order[t]], first = (uint32_t)tap_shift.size();
         for (; t < nmask && mask_col[order[t]] == col; ++t) {
@@ -1660,13 +1665,13 @@ ss_status ss_deep_compose_gl64x3(ss_ctx *ctx, const uint64_t *const *d_trace_lde
             if (it == k_of.end()) it = k_of.emplace(offv, HGl3{{0, 0, 0}}).first;
             it->second = gl3_addh(it->second, gl3_mulh(cprime, load3(ood_trace + 3 * j)));
             tap_shift.push_back(offv);
-            for (int c = 0; c < 3; ++c) tap_coef.push_back(cprime.c[c]);
+            push_tap(cprime);
         }
         cdesc.push_back(col); cdesc.push_back(first); cdesc.push_back((uint32_t)tap_shift.size() - first);
     }
     if (nmask) {
         const uint32_t first = (uint32_t)tap_shift.size();
-        for (auto &kv : k_of) { tap_shift.push_back(kv.first); for (int c = 0; c < 3; ++c) tap_coef.push_back(gl_subh(0, kv.second.c[c])); }
+        for (auto &kv : k_of) { tap_shift.push_back(kv.first); push_tap(HGl3{{gl_subh(0, kv.second.c[0]), gl_subh(0, kv.second.c[1]), gl_subh(0, kv.second.c[2])}}); }
         cdesc.push_back(0xffffffffu); cdesc.push_back(first); cdesc.push_back((uint32_t)tap_shift.size() - first);
     }
     const uint32_t ntaps = (uint32_t)tap_shift.size(), ncoldesc = (uint32_t)(cdesc.size() / 3);
@@ -1676,20 +1681,20 @@ ss_status ss_deep_compose_gl64x3(ss_ctx *ctx, const uint64_t *const *d_trace_lde
         comp_k = gl3_addh(comp_k, gl3_mulh(load3(coeff_comp + 3 * k), load3(ood_comp + 3 * k)));
     }
     // device: tables D, Dc [n][3], the sub-coset values [3][n], then per component iNTT(n) + coset NTT(N), interleaved into d_out
-    const size_t small = (size_t)(ntaps + 1) * (4 + 24) + (size_t)(ncoldesc + 1) * 12 + (size_t)(ncomp + 1) * 24 + 256;
+    const size_t small = (size_t)(ntaps + 1) * (4 + 40) + (size_t)(ncoldesc + 1) * 12 + (size_t)(ncomp + 1) * 24 + 256;
     ss_status st = ctx->ensure_scratch(small);
     if (st != SS_OK) return st;
     st = ctx->ensure_scratch2((6 * n + 3 * n + 3 * N) * 8);
     if (st != SS_OK) return st;
     uint64_t *D = (uint64_t *)ctx->scratch2, *Dc = D + 3 * n, *sub = Dc + 3 * n, *lde = sub + 3 * n;
     char *p = (char *)ctx->scratch;
-    uint64_t *d_tap_coef = (uint64_t *)p; p += (size_t)(ntaps + 1) * 24;
+    uint64_t *d_tap_coef = (uint64_t *)p; p += (size_t)(ntaps + 1) * 40;
     uint64_t *d_comp_coef = (uint64_t *)p; p += (size_t)(ncomp + 1) * 24;
     uint32_t *d_tap_shift = (uint32_t *)p; p += (size_t)(ntaps + 1) * 4;
     uint32_t *d_cdesc = (uint32_t *)p;
     hipStream_t s = ctx->stream;
     if (ntaps) {
-        HIP_TRY(hipMemcpyAsync(d_tap_coef, tap_coef.data(), (size_t)ntaps * 24, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_tap_coef, tap_coef.data(), (size_t)ntaps * 40, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_tap_shift, tap_shift.data(), (size_t)ntaps * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_cdesc, cdesc.data(), (size_t)ncoldesc * 12, hipMemcpyHostToDevice, s));
     }

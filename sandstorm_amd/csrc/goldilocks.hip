@@ -16,36 +16,11 @@
 // form (arkworks' Fp64 in memory) pass through unchanged.
 #include <hip/hip_runtime.h>
 #include "kernels.h"
+#include "gl64.h"
 
 namespace ss {
 
-static constexpr uint64_t GL_P = 0xFFFFFFFF00000001ull;
-static constexpr uint64_t GL_EPS = 0xFFFFFFFFull;          // 2^64 mod p
 
-__host__ __device__ __forceinline__ uint64_t gl_add(uint64_t a, uint64_t b) {
-    uint64_t s = a + b;
-    if (s < a) s += GL_EPS;                                  // wrapped: + 2^64 = + EPS (cannot wrap again: a, b < p)
-    return s >= GL_P ? s - GL_P : s;
-}
-__host__ __device__ __forceinline__ uint64_t gl_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (GL_P - b); }
-__host__ __device__ __forceinline__ uint64_t gl_reduce128(uint64_t lo, uint64_t hi) {
-    const uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
-    uint64_t t = lo - hi_hi;                                 // 2^96 = -1
-    if (lo < hi_hi) t -= GL_EPS;                             // borrowed 2^64 = EPS
-    const uint64_t m = hi_lo * GL_EPS;                       // 2^64 = EPS; < 2^64
-    uint64_t r = t + m;
-    if (r < t) r += GL_EPS;
-    return r >= GL_P ? r - GL_P : r;
-}
-__host__ __device__ __forceinline__ uint64_t gl_mul(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint64_t lo = a * b, hi = __umul64hi(a, b);
-#else
-    const unsigned __int128 pr = (unsigned __int128)a * b;
-    const uint64_t lo = (uint64_t)pr, hi = (uint64_t)(pr >> 64);
-#endif
-    return gl_reduce128(lo, hi);
-}
 uint64_t gl_pow_host(uint64_t a, uint64_t e) {
     uint64_t r = 1;
     while (e) { if (e & 1) r = gl_mul(r, a); a = gl_mul(a, a); e >>= 1; }
@@ -111,13 +86,13 @@ __device__ __forceinline__ void gl_group(uint64_t *tile_lds, const uint64_t *__r
                 const uint32_t k = ((jlow + ((uint32_t)(m & ((1 << ST) - 1)) << u)) << p.s0) | lbits;
                 const uint64_t w = tws[k];
                 const uint64_t a = x[m], b = x[m | (1 << ST)];
-                if (DIF) {
+                if (DIF) {                                   // every x canonical: the difference is lazy only on its way into the product
                     x[m] = gl_add(a, b);
-                    x[m | (1 << ST)] = gl_mul(gl_sub(a, b), w);
-                } else {
+                    x[m | (1 << ST)] = gl_mul(gl_sub_lazy(a, b), w);
+                } else {                                     // sums and differences stay lazy (gl64.h) until the pass stores them
                     const uint64_t bt = gl_mul(b, w);
-                    x[m] = gl_add(a, bt);
-                    x[m | (1 << ST)] = gl_sub(a, bt);
+                    x[m] = gl_add_lazy(a, bt);
+                    x[m | (1 << ST)] = gl_sub_lazy(a, bt);
                 }
             }
         }
@@ -125,7 +100,7 @@ __device__ __forceinline__ void gl_group(uint64_t *tile_lds, const uint64_t *__r
         for (int m = 0; m < (1 << G); ++m) {
             const uint32_t e = ebase + ((uint32_t)m << sh);
             if (to_global) {
-                uint64_t v = x[m];
+                uint64_t v = DIF ? x[m] : gl_canon(x[m]);
                 if (DIF && p.scale != 1ull) v = gl_mul(v, p.scale);
                 dst[gl_tile_gindex(p, tile, e)] = v;
             } else {
@@ -185,17 +160,6 @@ __global__ void gl_bitrev_copy_kernel(const uint64_t *__restrict__ src, uint64_t
 }
 
 // ---- Fq3 = Fp[X] / (X^3 - 2) and one FRI layer over Fq3-valued evaluations ------------------------------------------
-struct Gl3 { uint64_t c[3]; };
-__device__ __forceinline__ Gl3 gl3_mul(const Gl3 &a, const Gl3 &b) {
-    const uint64_t d0 = gl_mul(a.c[0], b.c[0]), d1 = gl_add(gl_mul(a.c[0], b.c[1]), gl_mul(a.c[1], b.c[0]));
-    const uint64_t d2 = gl_add(gl_add(gl_mul(a.c[0], b.c[2]), gl_mul(a.c[1], b.c[1])), gl_mul(a.c[2], b.c[0]));
-    const uint64_t d3 = gl_add(gl_mul(a.c[1], b.c[2]), gl_mul(a.c[2], b.c[1])), d4 = gl_mul(a.c[2], b.c[2]);
-    Gl3 r;
-    r.c[0] = gl_add(d0, gl_add(d3, d3));
-    r.c[1] = gl_add(d1, gl_add(d4, d4));
-    r.c[2] = d2;
-    return r;
-}
 struct Gl3FriConsts {
     uint64_t winv[16];           // w_fold^-k
     uint64_t inv_fold;           // 1 / fold (or 1 when unnormalised)
@@ -229,10 +193,10 @@ __global__ __launch_bounds__(256) void gl3_fri_fold_kernel(const uint64_t *__res
             Gl3 coef;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                uint64_t s = 0;
+                GlWide s = glw_zero();                       // one reduction for the FOLD products (gl64.h)
 #pragma unroll
-                for (int m = 0; m < FOLD; ++m) s = gl_add(s, gl_mul(v[c][m], k.winv[(t * m) & (FOLD - 1)]));
-                coef.c[c] = gl_mul(s, xpow[t]);
+                for (int m = 0; m < FOLD; ++m) glw_mac(s, v[c][m], k.winv[(t * m) & (FOLD - 1)]);
+                coef.c[c] = gl_mul(glw_reduce(s), xpow[t]);
             }
             acc = gl3_mul(acc, k.alpha);
 #pragma unroll
@@ -318,15 +282,7 @@ hipError_t launch_gl3_fri_fold(hipStream_t st, const uint64_t *evals, uint32_t l
 //   out[m] = sum_c T_c[i] * S_c[m] + S_K[m] + Dc[m] * (sum_k cc_k H_k[i] - Kc),    S_c[m] = sum_taps c' * D[m - shift]
 // with Fq3 x Fq3 products inside S and Fp x Fq3 products outside.  An Fq3-valued column (extension trace, composition) is
 // three Fp columns whose cells carry the coefficients c, c X, c X^2 - the caller's expansion, the sum is linear.
-__device__ __forceinline__ Gl3 gl3_add(const Gl3 &a, const Gl3 &b) { return Gl3{{gl_add(a.c[0], b.c[0]), gl_add(a.c[1], b.c[1]), gl_add(a.c[2], b.c[2])}}; }
-__device__ __forceinline__ Gl3 gl3_sub(const Gl3 &a, const Gl3 &b) { return Gl3{{gl_sub(a.c[0], b.c[0]), gl_sub(a.c[1], b.c[1]), gl_sub(a.c[2], b.c[2])}}; }
-__device__ __forceinline__ Gl3 gl3_scale(const Gl3 &a, uint64_t s) { return Gl3{{gl_mul(a.c[0], s), gl_mul(a.c[1], s), gl_mul(a.c[2], s)}}; }
-__device__ __forceinline__ Gl3 gl3_load(const uint64_t *p) { return Gl3{{p[0], p[1], p[2]}}; }
-__device__ __forceinline__ uint64_t gl_pow_dev(uint64_t a, uint64_t e) {
-    uint64_t r = 1;
-    for (; e; e >>= 1) { if (e & 1) r = gl_mul(r, a); a = gl_mul(a, a); }
-    return r;
-}
+__device__ __forceinline__ uint64_t gl_pow_dev(uint64_t a, uint64_t e) { return gl_pow(a, e); }
 
 // D[m] = 1 / (x0 * w^m - z), m < len, interleaved [len][3].  a = (x - z0, -z1, -z2); a^-1 = adj(a) / N(a) with
 // adj = (a0^2 - 2 a1 a2, 2 a2^2 - a0 a1, a1^2 - a0 a2) and N = a0 adj0 + 2 a2 adj1 + 2 a1 adj2 in Fp; the norms of a
@@ -370,7 +326,7 @@ struct Gl3DeepArgs {
     const uint64_t *comp[12];
     const uint64_t *D, *Dc;          // [n][3]
     const uint32_t *tap_shift;       // [ntaps] by column, then by shift (sub-coset units)
-    const uint64_t *tap_coef;        // [ntaps][3]: coeff * w_n^-off; the constant column: -K_off
+    const uint64_t *tap_rhs;         // [ntaps][5]: c = coeff * w_n^-off (the constant column: -K_off) as c0, c1, c2, 2 c1, 2 c2
     const uint32_t *col_desc;        // [ncoldesc][3]: trace column (0xffffffff: constants), first tap, count
     const uint64_t *comp_coef;       // [ncomp][3]
     Gl3 comp_k;
@@ -378,33 +334,37 @@ struct Gl3DeepArgs {
     uint64_t count;
 };
 __global__ __launch_bounds__(256) void gl3_deep_kernel(Gl3DeepArgs a, uint64_t *__restrict__ out0, uint64_t *__restrict__ out1, uint64_t *__restrict__ out2) {
+    // every sum below is a wide accumulator (gl64.h): a column's S pays three reductions for all its taps instead of nine per tap,
+    // and the sum over the columns three more
     for (uint64_t m = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; m < a.count; m += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = m << a.log_stride;
-        Gl3 acc = {{0, 0, 0}};
+        Gl3Wide acc = gl3w_zero();
         for (uint32_t k = 0; k < a.ncoldesc; ++k) {
             const uint32_t col = a.col_desc[3 * k], first = a.col_desc[3 * k + 1], cnt = a.col_desc[3 * k + 2];
-            Gl3 S = {{0, 0, 0}};
+            Gl3Wide Sw = gl3w_zero();
             for (uint32_t j = first; j < first + cnt; ++j)
-                S = gl3_add(S, gl3_mul(gl3_load(a.tap_coef + 3 * (size_t)j), gl3_load(a.D + 3 * (size_t)(((uint32_t)m - a.tap_shift[j]) & a.mask))));
-            if (col == 0xffffffffu) acc = gl3_add(acc, S);
+                gl3w_mac(Sw, gl3_load(a.D + 3 * (size_t)(((uint32_t)m - a.tap_shift[j]) & a.mask)), gl3_load_rhs(a.tap_rhs + 5 * (size_t)j));
+            const Gl3 S = gl3w_reduce(Sw);
+            if (col == 0xffffffffu) gl3w_add(acc, S);
             else {
                 const uint64_t *tp = a.trace[0];
 #pragma unroll
                 for (int c = 1; c < MAX_COLS; ++c) if (col == (uint32_t)c) tp = a.trace[c];
-                acc = gl3_add(acc, gl3_scale(S, tp[i]));
+                gl3w_mac_base(acc, S, tp[i]);
             }
         }
         if (a.ncomp) {
-            Gl3 inner = {{0, 0, 0}};
+            Gl3Wide inner = gl3w_zero();
             for (uint32_t k = 0; k < a.ncomp; ++k) {
                 const uint64_t *hp = a.comp[0];
 #pragma unroll
                 for (int c = 1; c < 12; ++c) if (k == (uint32_t)c) hp = a.comp[c];
-                inner = gl3_add(inner, gl3_scale(gl3_load(a.comp_coef + 3 * (size_t)k), hp[i]));
+                gl3w_mac_base(inner, gl3_load(a.comp_coef + 3 * (size_t)k), hp[i]);
             }
-            acc = gl3_add(acc, gl3_mul(gl3_sub(inner, a.comp_k), gl3_load(a.Dc + 3 * m)));
+            gl3w_mac(acc, gl3_sub(gl3w_reduce(inner), a.comp_k), gl3_rhs(gl3_load(a.Dc + 3 * m)));
         }
-        out0[m] = acc.c[0]; out1[m] = acc.c[1]; out2[m] = acc.c[2];
+        const Gl3 r = gl3w_reduce(acc);
+        out0[m] = r.c[0]; out1[m] = r.c[1]; out2[m] = r.c[2];
     }
 }
 
@@ -464,12 +424,12 @@ __global__ void gl3_gather_kernel(const uint64_t *__restrict__ c0, const uint64_
 __global__ __launch_bounds__(256) void gl3_dot_kernel(const uint64_t *__restrict__ coef, const uint64_t *__restrict__ zp0, const uint64_t *__restrict__ zp1,
                                                       const uint64_t *__restrict__ zp2, uint64_t n, uint64_t *__restrict__ partial) {
     __shared__ uint64_t red[3][256];
-    uint64_t a0 = 0, a1 = 0, a2 = 0;
+    GlWide a0 = glw_zero(), a1 = glw_zero(), a2 = glw_zero();     // a lane's share is far below the 2^32 terms a wide sum holds
     for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t c = coef[q];
-        a0 = gl_add(a0, gl_mul(c, zp0[q])); a1 = gl_add(a1, gl_mul(c, zp1[q])); a2 = gl_add(a2, gl_mul(c, zp2[q]));
+        glw_mac(a0, c, zp0[q]); glw_mac(a1, c, zp1[q]); glw_mac(a2, c, zp2[q]);
     }
-    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2;
+    red[0][threadIdx.x] = glw_reduce(a0); red[1][threadIdx.x] = glw_reduce(a1); red[2][threadIdx.x] = glw_reduce(a2);
     __syncthreads();
     for (uint32_t s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s)
@@ -495,7 +455,7 @@ hipError_t launch_gl3_deep(hipStream_t st, const uint64_t *const *trace, uint32_
     Gl3DeepArgs a;
     for (int c = 0; c < MAX_COLS; ++c) a.trace[c] = c < (int)ntrace ? trace[c] : nullptr;
     for (int c = 0; c < 12; ++c) a.comp[c] = c < (int)ncomp ? comp[c] : nullptr;
-    a.D = D; a.Dc = Dc; a.tap_shift = tap_shift; a.tap_coef = tap_coef; a.col_desc = col_desc; a.ncoldesc = ncoldesc;
+    a.D = D; a.Dc = Dc; a.tap_shift = tap_shift; a.tap_rhs = tap_coef; a.col_desc = col_desc; a.ncoldesc = ncoldesc;
     a.comp_coef = comp_coef; a.comp_k = Gl3{{comp_k[0], comp_k[1], comp_k[2]}}; a.ncomp = ncomp; a.log_stride = log_stride;
     a.mask = (uint32_t)(count - 1); a.count = count;
     hipLaunchKernelGGL(gl3_deep_kernel, dim3(gl_blocks(count, 256, 8192)), dim3(256), 0, st, a, out0, out1, out2);
@@ -532,16 +492,7 @@ hipError_t launch_gl3_gather(hipStream_t st, const uint64_t *c0, const uint64_t 
 // accumulators, constants (challenges, alpha^k, hints) and scratch slots are elements of Fq3, trace cells / periodic tables /
 // x are elements of Fp read into the first coordinate.  One lane = one LDE point; the program counter and operand selectors are
 // wave-uniform (scalar loads and branches).  Slots live in a file [slot][coordinate][lane] in HBM.
-__device__ __forceinline__ Gl3 gl3_inv_dev(const Gl3 &a) {
-    const uint64_t a12 = gl_mul(a.c[1], a.c[2]), a22 = gl_mul(a.c[2], a.c[2]);
-    Gl3 adj;
-    adj.c[0] = gl_sub(gl_mul(a.c[0], a.c[0]), gl_add(a12, a12));
-    adj.c[1] = gl_sub(gl_add(a22, a22), gl_mul(a.c[0], a.c[1]));
-    adj.c[2] = gl_sub(gl_mul(a.c[1], a.c[1]), gl_mul(a.c[0], a.c[2]));
-    const uint64_t t1 = gl_mul(a.c[2], adj.c[1]), t2 = gl_mul(a.c[1], adj.c[2]);
-    const uint64_t norm = gl_add(gl_mul(a.c[0], adj.c[0]), gl_add(gl_add(t1, t1), gl_add(t2, t2)));
-    return gl3_scale(adj, gl_pow_dev(norm, GL_P - 2));                      // 0 -> 0
-}
+__device__ __forceinline__ Gl3 gl3_inv_dev(const Gl3 &a) { return gl3_inv(a); }            // gl64.h: adjugate over the norm, 0 -> 0
 // Most values of a constraint program are base-field values in extension clothes (trace cells, their sums and products: every
 // CPU constraint before its alpha^k): a factor whose upper coordinates are zero costs one or three multiplications instead of
 // nine.  The test is on the data, per lane; which values are base-field is a property of the program, so the lanes agree.

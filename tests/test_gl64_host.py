@@ -1,0 +1,66 @@
+"""csrc/gl64.h - the arithmetic every kernel of the 64-bit field runs (products in 32-bit halves, lazy sums, wide accumulators,
+Fq3) - is host/device code: compiled here with g++ and held to 128-bit integer arithmetic on edge words (0, p - 1, p, 2^64 - 1,
+2^32 +- 1 ...) and random ones, long wide sums of extreme products, and a butterfly network run lazily against the same
+network on canonical values (tests/cpp/gl64_host_test.cpp).  The device compiles the same source."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gl64_header_on_the_host(tmp_path):
+    exe = str(tmp_path / "gl64_host_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "sandstorm_amd", "csrc"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "gl64_host_test.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "0", "mismatches: %s" % out.stdout
+
+
+def test_generated_composition_kernel_on_the_host(tmp_path, oracle):
+    """csrc/quotient_gen_plain_gl.inc - the straight-line kernel tools/gen_quotient_gl.py writes for the plain layout's composition -
+    compiled for the host over the same gl64.h and run over whole evaluation domains (a "grid" that does not divide them), for two
+    statements / sizes / transcripts: its values are the oracle's constraint VM's on the program the layout lowers to"""
+    import copy
+    import struct
+
+    import numpy as np
+
+    from sandstorm_amd import air_program as ap
+    from sandstorm_amd.layouts import plain as pl
+    exe = str(tmp_path / "gl3_plain_host_test")
+    inc = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_plain_gl.inc")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wno-attributes", "-I", os.path.join(ROOT, "sandstorm_amd", "csrc"), "-DQG_INC=\"%s\"" % inc,
+                           "-o", exe, os.path.join(ROOT, "tests", "cpp", "gl3_plain_host_test.cpp")])
+    prog = pl.example_program(10)
+    states, memory = pl.run(prog, 64)
+    pi = pl.public_input_of(prog, states, memory)
+    rng = np.random.default_rng(8)
+    for log_n, ch, alpha, grid in ((10, [(11, 22, 33), (5, 6, 7), (9, 8, 7)], (123456789, 987654321, 55555), (3, 5)),
+                                   (12, [(1, 2, 3), (4, 5, 6), (pl.P - 1, pl.P - 2, 9)], (5, 0, pl.P - 1), (7, 64))):
+        n, lb = 1 << log_n, 1
+        N = n << lb
+        tables = pl.Tables(n, lb)
+        stmt = copy.deepcopy(pi)
+        stmt.n_steps = n // 16
+        root = pl.composition(n, pl.Hints.from_public_input(stmt, ch, n), ch, alpha, tables)
+        program = ap.lower(root, pl.P, ext=True, symbols=tables.symbols)
+        code, consts = np.array(program.code, dtype=np.uint32), np.array(program.consts, dtype=np.uint64)
+        tvals, tdesc = tables.device_tables()
+        lde = [rng.integers(0, 1 << 62, size=N, dtype=np.uint64) for _ in range(8)]
+        lde[0][:4] = pl.P - 1
+        want = oracle.gl3_eval_program(code, consts, program.n_slots, tvals, tdesc, lde, log_n, lb, pl.GENERATOR)
+        w = pow(7, (pl.P - 1) >> (log_n + lb), pl.P)
+        td = []
+        for k in range(0, len(tdesc), 2):
+            td += [tdesc[k], (1 << tdesc[k + 1]) - 1]
+        fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<10Q", len(lde), N, len(tvals), len(td) // 2, len(consts), lb, pl.GENERATOR, w, grid[0], grid[1]))
+            for c in lde:
+                f.write(np.ascontiguousarray(c).tobytes())
+            f.write(np.ascontiguousarray(tvals, dtype=np.uint64).tobytes())
+            f.write(np.asarray(td, dtype=np.uint32).tobytes())
+            f.write(np.ascontiguousarray(consts.reshape(-1, 3)).tobytes())
+        subprocess.check_call([exe, fin, fout], timeout=600)
+        got = np.fromfile(fout, dtype=np.uint64).reshape(N, 3)
+        assert np.array_equal(got, np.asarray(want).reshape(N, 3))

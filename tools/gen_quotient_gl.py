@@ -111,7 +111,7 @@ def generate():
                 emit("    %s = gl3_mul(%s, %s);" % (a, a, srcv))
                 stats["mul9"] += 1
         elif op == OP_INV:
-            emit("    %s.c[0] = gl_pow_dev(%s.c[0], GL_P - 2);" % (a, a) if dt == B else "    %s = gl3_inv_dev(%s);" % (a, a))
+            emit("    %s.c[0] = gl_pow(%s.c[0], GL_P - 2);" % (a, a) if dt == B else "    %s = gl3_inv(%s);" % (a, a))
             stats["inv"] += 1
         elif op == OP_ST:
             for t in comps(dt):
@@ -128,7 +128,8 @@ def generate():
 // The composition constraint of the `plain` layout over the 64-bit field (layouts/src/plain/air.rs; sandstorm_amd/layouts/plain.py
 // + air_program.lower) as straight-line code: %(n_instr)d program instructions - %(mul1)d base-field products, %(mul3)d products of
 // an extension value with a base-field one, %(mul9)d extension products, %(inv)d inversion(s) - %(n_slots)d scratch values and the four
-// accumulators in registers, typed base-field / extension at generation time.  Included by goldilocks.hip.
+// accumulators in registers, typed base-field / extension at generation time.  Included by goldilocks.hip; compiled for the host
+// (over csrc/gl64.h, the arithmetic both sides share) and held to the oracle by tests/test_gl64_host.py.
 // Code hash (FNV-1a of the program's code words) 0x%(hash)016x: ss_eval_quotient_gl64x3 launches this kernel for exactly that program
 // (after checking that the constants typed base-field here are base-field in its table) and interprets any other.
 static constexpr uint64_t GL3_PLAIN_CODE_HASH = 0x%(hash)016xull;
@@ -141,9 +142,9 @@ __global__ __launch_bounds__(256) void gl3_plain_kernel(Gl3VmArgs a) {
     const_u32 tdesc = (const_u32)(uintptr_t)a.tdesc;
     const_u64 consts = (const_u64)(uintptr_t)a.consts;
     const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x, lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    const uint64_t wstep = gl_pow_dev(a.w, lanes), maskN = a.N - 1;
+    const uint64_t wstep = gl_pow(a.w, lanes), maskN = a.N - 1;
     const uint32_t lb = a.log_blowup;
-    uint64_t x = gl_mul(a.offset, gl_pow_dev(a.w, lane));
+    uint64_t x = gl_mul(a.offset, gl_pow(a.w, lane));
 #define QG_K(k, t) consts[3 * (k) + (t)]
 #define QG_T(col, off) a.cols[col][(i + ((uint64_t)(off) << lb)) & maskN]
 #define QG_TAB(t) a.tables[tdesc[2 * (t)] + (i & tdesc[2 * (t) + 1])]
