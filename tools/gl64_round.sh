@@ -20,3 +20,6 @@ timeout 90 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_gl --
 f=$(ls /tmp/rp_gl/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv
 f=$(ls /tmp/rp_gl/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$f" ] && python $R/tools/trace_summary.py "$f" > $OUT/kernel_trace_summary.txt
 head -12 $OUT/kernel_trace_summary.txt
+cd $R
+timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $OUT/smoke.txt
+timeout 80 python -m pytest tests/test_gpu_reference_proof.py -m gpu -x -q 2>&1 | tail -3 | tee $OUT/pytest_reference_proof.txt
