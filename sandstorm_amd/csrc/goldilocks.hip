@@ -51,45 +51,62 @@ __device__ __forceinline__ uint32_t gl_slot(uint32_t e) { return e ^ ((e >> 4) &
 
 // One radix-2^G register group on local stages [u, u + G): each thread holds 2^G elements (element m at ebase + (m << sh))
 // and runs G butterfly stages on them before the tile is touched again - ceil(13 / 4) = 4 LDS round trips per pass instead
-// of 13.  The first / last group of a pass exchange with HBM directly (from_global / to_global).
+// of 13.  The first / last group of a pass exchange with HBM directly (FG / TG).
 // Twiddle plan as in the 252-bit path: T_s[k] at (2^s - 1) + k, k < 2^s, T_s[k] = h^(n / 2^(s+1)) * r^(k n / 2^(s+1)).
-template <bool DIF, int G>
+// Everything a group decides per ELEMENT is a template parameter: whether it reads HBM or the tile, writes HBM or the tile, and
+// whether the tile is a contiguous block.  As run-time flags (this file's first form) the compiler addressed both memories through
+// one generic pointer (flat_load / flat_store, which wait on both counters) and branched around every element's address
+// computation; now a group's sixteen loads are sixteen global_load (or ds_read) instructions issued back to back, with its fifteen
+// twiddles: the transforms of a 2^20-step proof went from 31.0 to 24.7 ms (profiles/r02_end2_*).
+// Sums and differences of the decimation-in-time network stay lazy words (gl64.h) and are made canonical where the pass stores them.
+template <bool DIF, int G, bool FG, bool TG, bool CONTIG>
 __device__ __forceinline__ void gl_group(uint64_t *tile_lds, const uint64_t *__restrict__ tw, const GlPassParams &p, uint32_t u, uint32_t tile,
-                                         bool from_global, bool to_global, const uint64_t *__restrict__ src, uint64_t *__restrict__ dst) {
-    const uint32_t log_t = p.log_tile - p.r, eshift = p.contig ? 0u : log_t;
+                                           const uint64_t *__restrict__ src, uint64_t *__restrict__ dst) {
+    const uint32_t log_t = p.log_tile - p.r, eshift = CONTIG ? 0u : log_t;
     const uint32_t items = (1u << p.log_tile) >> G, sh = eshift + u;
+    auto gindex = [&](uint32_t e) -> uint64_t {
+        if (CONTIG) return ((uint64_t)tile << p.log_tile) + e;
+        const uint32_t dq = e & ((1u << log_t) - 1u), j = e >> log_t;
+        const uint64_t q = ((uint64_t)tile << log_t) + dq;
+        return ((q >> p.s0) << (p.s0 + p.r)) | ((uint64_t)j << p.s0) | (q & ((1ull << p.s0) - 1ull));
+    };
     for (uint32_t tau = threadIdx.x; tau < items; tau += blockDim.x) {
         const uint32_t low = tau & ((1u << sh) - 1u), high = tau >> sh;
         const uint32_t ebase = (high << (sh + G)) | low;
         uint32_t jbase, lbits;
-        if (p.contig) { jbase = ebase & ((1u << p.r) - 1u); lbits = 0; }
+        if (CONTIG) { jbase = ebase & ((1u << p.r) - 1u); lbits = 0; }
         else {
             jbase = ebase >> log_t;
             const uint32_t q = (tile << log_t) + (ebase & ((1u << log_t) - 1u));
             lbits = q & ((1u << p.s0) - 1u);
         }
         const uint32_t jlow = jbase & ((1u << u) - 1u);
-        uint64_t x[1 << G];
+        // the group's 2^G - 1 twiddles (2^ST distinct ones in stage ST) and its 2^G elements: all loads issued before the first butterfly
+        uint64_t x[1 << G], wv[1 << G];
+#pragma unroll
+        for (int ST = 0; ST < G; ++ST) {
+            const uint64_t *tws = tw + ((1ull << (p.s0 + u + ST)) - 1ull);
+#pragma unroll
+            for (int ml = 0; ml < (1 << ST); ++ml) wv[(1 << ST) - 1 + ml] = tws[((jlow + ((uint32_t)ml << u)) << p.s0) | lbits];
+        }
 #pragma unroll
         for (int m = 0; m < (1 << G); ++m) {
             const uint32_t e = ebase + ((uint32_t)m << sh);
-            x[m] = from_global ? src[gl_tile_gindex(p, tile, e) >> p.log_expand] : tile_lds[gl_slot(e)];
+            if (FG) x[m] = src[gindex(e) >> p.log_expand];
+            else x[m] = tile_lds[gl_slot(e)];
         }
 #pragma unroll
         for (int step = 0; step < G; ++step) {
             const int ST = DIF ? (G - 1 - step) : step;
-            const uint32_t s = p.s0 + u + ST;
-            const uint64_t *tws = tw + ((1ull << s) - 1ull);
 #pragma unroll
             for (int pr = 0; pr < (1 << G) / 2; ++pr) {
                 const int m = ((pr >> ST) << (ST + 1)) | (pr & ((1 << ST) - 1));
-                const uint32_t k = ((jlow + ((uint32_t)(m & ((1 << ST) - 1)) << u)) << p.s0) | lbits;
-                const uint64_t w = tws[k];
+                const uint64_t w = wv[(1 << ST) - 1 + (m & ((1 << ST) - 1))];
                 const uint64_t a = x[m], b = x[m | (1 << ST)];
-                if (DIF) {                                   // every x canonical: the difference is lazy only on its way into the product
+                if (DIF) {
                     x[m] = gl_add(a, b);
                     x[m | (1 << ST)] = gl_mul(gl_sub_lazy(a, b), w);
-                } else {                                     // sums and differences stay lazy (gl64.h) until the pass stores them
+                } else {
                     const uint64_t bt = gl_mul(b, w);
                     x[m] = gl_add_lazy(a, bt);
                     x[m | (1 << ST)] = gl_sub_lazy(a, bt);
@@ -99,18 +116,25 @@ __device__ __forceinline__ void gl_group(uint64_t *tile_lds, const uint64_t *__r
 #pragma unroll
         for (int m = 0; m < (1 << G); ++m) {
             const uint32_t e = ebase + ((uint32_t)m << sh);
-            if (to_global) {
+            if (TG) {
                 uint64_t v = DIF ? x[m] : gl_canon(x[m]);
                 if (DIF && p.scale != 1ull) v = gl_mul(v, p.scale);
-                dst[gl_tile_gindex(p, tile, e)] = v;
+                dst[gindex(e)] = v;
             } else {
                 tile_lds[gl_slot(e)] = x[m];
             }
         }
     }
 }
-
-template <bool DIF>
+template <bool DIF, int G, bool CONTIG>
+__device__ __forceinline__ void gl_group_dispatch(uint64_t *tile_lds, const uint64_t *__restrict__ tw, const GlPassParams &p, uint32_t u, uint32_t tile,
+                                                  bool fg, bool tg, const uint64_t *__restrict__ src, uint64_t *__restrict__ dst) {
+    if (fg && tg) gl_group<DIF, G, true, true, CONTIG>(tile_lds, tw, p, u, tile, src, dst);
+    else if (fg) gl_group<DIF, G, true, false, CONTIG>(tile_lds, tw, p, u, tile, src, dst);
+    else if (tg) gl_group<DIF, G, false, true, CONTIG>(tile_lds, tw, p, u, tile, src, dst);
+    else gl_group<DIF, G, false, false, CONTIG>(tile_lds, tw, p, u, tile, src, dst);
+}
+template <bool DIF, bool CONTIG>
 __global__ __launch_bounds__(256) void gl_ntt_pass_kernel(GlCols cols, const uint64_t *__restrict__ tw, GlPassParams p) {
     extern __shared__ uint64_t gl_tile[];
     const uint32_t tile = blockIdx.x;
@@ -121,7 +145,6 @@ __global__ __launch_bounds__(256) void gl_ntt_pass_kernel(GlCols cols, const uin
         if (blockIdx.y == (unsigned)c) { src_v = cols.src[c]; dst_v = cols.dst[c]; }
     const uint64_t *__restrict__ src = reinterpret_cast<const uint64_t *>(src_v);
     uint64_t *__restrict__ dst = reinterpret_cast<uint64_t *>(dst_v);
-    // local stages [first, p.r) in groups of <= 4, ascending (DIT) or descending (DIF); the first group reads HBM, the last writes it
     const uint32_t first = DIF ? 0u : p.u_first, total = p.r - first;
     uint32_t done = 0;
     while (done < total) {
@@ -129,15 +152,15 @@ __global__ __launch_bounds__(256) void gl_ntt_pass_kernel(GlCols cols, const uin
         const uint32_t u = DIF ? (p.r - done - g) : (first + done);
         const bool fg = done == 0, tg = done + g == total;
         switch (g) {
-        case 4: gl_group<DIF, 4>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
-        case 3: gl_group<DIF, 3>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
-        case 2: gl_group<DIF, 2>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
-        default: gl_group<DIF, 1>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
+        case 4: gl_group_dispatch<DIF, 4, CONTIG>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
+        case 3: gl_group_dispatch<DIF, 3, CONTIG>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
+        case 2: gl_group_dispatch<DIF, 2, CONTIG>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
+        default: gl_group_dispatch<DIF, 1, CONTIG>(gl_tile, tw, p, u, tile, fg, tg, src, dst); break;
         }
         done += g;
         if (!tg) __syncthreads();
     }
-    if (total == 0)              // nothing to do in this pass (cannot happen for log_n >= 1): copy through
+    if (total == 0)
         for (uint32_t e = threadIdx.x; e < (1u << p.log_tile); e += blockDim.x) dst[gl_tile_gindex(p, tile, e)] = src[gl_tile_gindex(p, tile, e) >> p.log_expand];
 }
 
@@ -213,9 +236,13 @@ uint32_t gl_log_tile_max() { return GL_LOG_TILE_MAX; }
 
 hipError_t gl_set_func_attributes() {
     const int bytes = 8 << GL_LOG_TILE_MAX;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gl_ntt_pass_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&gl_ntt_pass_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    const void *kernels[] = {reinterpret_cast<const void *>(&gl_ntt_pass_kernel<true, true>), reinterpret_cast<const void *>(&gl_ntt_pass_kernel<true, false>),
+                             reinterpret_cast<const void *>(&gl_ntt_pass_kernel<false, true>), reinterpret_cast<const void *>(&gl_ntt_pass_kernel<false, false>)};
+    for (const void *k : kernels) {
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_gl_ntt_pass(hipStream_t st, bool dif, const void *const *src, void *const *dst, uint32_t ncols, const uint64_t *tw,
@@ -227,8 +254,13 @@ hipError_t launch_gl_ntt_pass(hipStream_t st, bool dif, const void *const *src, 
     p.log_n = log_n; p.s0 = s0; p.r = r; p.log_tile = log_tile; p.u_first = u_first; p.log_expand = log_expand; p.contig = (s0 == 0); p.scale = scale;
     dim3 grid(1u << (log_n - log_tile), ncols), block(256);
     const size_t lds = (size_t)8 << log_tile;
-    if (dif) hipLaunchKernelGGL(gl_ntt_pass_kernel<true>, grid, block, lds, st, cols, tw, p);
-    else hipLaunchKernelGGL(gl_ntt_pass_kernel<false>, grid, block, lds, st, cols, tw, p);
+    if (p.contig) {
+        if (dif) hipLaunchKernelGGL((gl_ntt_pass_kernel<true, true>), grid, block, lds, st, cols, tw, p);
+        else hipLaunchKernelGGL((gl_ntt_pass_kernel<false, true>), grid, block, lds, st, cols, tw, p);
+    } else {
+        if (dif) hipLaunchKernelGGL((gl_ntt_pass_kernel<true, false>), grid, block, lds, st, cols, tw, p);
+        else hipLaunchKernelGGL((gl_ntt_pass_kernel<false, false>), grid, block, lds, st, cols, tw, p);
+    }
     return hipGetLastError();
 }
 

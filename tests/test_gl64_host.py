@@ -64,3 +64,83 @@ def test_generated_composition_kernel_on_the_host(tmp_path, oracle):
         subprocess.check_call([exe, fin, fout], timeout=600)
         got = np.fromfile(fout, dtype=np.uint64).reshape(N, 3)
         assert np.array_equal(got, np.asarray(want).reshape(N, 3))
+
+
+def test_generated_kernel_keeps_the_lazy_word_discipline():
+    """The generated kernel leaves products, sums and differences as lazy words (any 64-bit word congruent to the value) and the
+    generator tracks which coordinates are; a wrong track would only show on a value in [p, 2^64) - one random word in 2^32 - so
+    the discipline is re-derived here from the EMITTED text alone, independently of the generator's bookkeeping: the second
+    operand of every gl_add_lazy / gl_sub_lazy, the upper coordinates of gl3_mul's right factor, and everything written out must
+    be canonical at that statement."""
+    import re
+    inc = open(os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_plain_gl.inc")).read()
+    body = inc[inc.index("Gl3 a0, a1, a2, a3;"):inc.index("#undef QG_K")]
+    lazy = {}                                                   # "a1.c[0]" -> bool; anything absent (slots, constants, cells, x, 0) is canonical
+    is_lazy = lambda atom: lazy.get(atom.strip(), False)
+    var = r"[as]\d+\.c\[\d\]"                                  # a coordinate of an accumulator or of a scratch value
+    n_checked = 0
+
+    def split2(args):                                           # the two top-level arguments of a call
+        depth = 0
+        for i, ch in enumerate(args):
+            depth += ch == "(" or ch == "{"
+            depth -= ch == ")" or ch == "}"
+            if ch == "," and depth == 0:
+                return args[:i].strip(), args[i + 1:].strip()
+        raise AssertionError(args)
+
+    def assign(dst, expr):
+        nonlocal n_checked
+        m = re.fullmatch(r"(gl_\w+)\((.*)\)", expr)
+        if not m:
+            lazy[dst] = is_lazy(expr)                           # a copy
+            return
+        fn, args = m.group(1), m.group(2)
+        if fn == "gl_canon":
+            lazy[dst] = False
+        elif fn in ("gl_add_lazy", "gl_sub_lazy"):
+            _, b = split2(args)
+            assert not is_lazy(b), "%s = %s: the second operand is a lazy word" % (dst, expr)
+            n_checked += 1
+            lazy[dst] = True
+        elif fn == "gl_mul_lazy":
+            lazy[dst] = True
+        elif fn == "gl_pow":
+            lazy[dst] = False
+        else:
+            raise AssertionError("unknown form: " + expr)
+
+    for line in body.splitlines()[2:]:
+        line = line.strip()
+        if not line or line == "}":
+            continue
+        m = re.fullmatch(r"\{ const uint64_t f = (.+?); (.*) \}", line)
+        if m:
+            lazy["f"] = is_lazy(m.group(1))
+            for part in m.group(2).split(";"):
+                if part.strip():
+                    dst, expr = part.strip().split(" = ", 1)
+                    assign(dst, expr)
+            continue
+        m = re.fullmatch(r"(a\d) = gl3_mul\(a\d, Gl3\{\{(.+)\}\}\);", line)
+        if m:
+            comps = [c.strip() for c in re.split(r",\s*(?![^()]*\))", m.group(2))]
+            assert len(comps) == 3 and not is_lazy(comps[1]) and not is_lazy(comps[2]), line
+            n_checked += 1
+            for t in range(3):
+                lazy["%s.c[%d]" % (m.group(1), t)] = False
+            continue
+        m = re.fullmatch(r"(a\d) = gl3_inv\(a\d\);", line)
+        if m:
+            for t in range(3):
+                lazy["%s.c[%d]" % (m.group(1), t)] = False
+            continue
+        m = re.fullmatch(r"QG_OUT\(\d, (.+)\);", line)
+        if m:
+            assert not is_lazy(m.group(1)), line
+            n_checked += 1
+            continue
+        m = re.fullmatch(r"(%s) = (.+);" % var, line)
+        assert m, "unrecognised statement: " + line
+        assign(m.group(1), m.group(2))
+    assert n_checked > 300

@@ -54,19 +54,32 @@ def generate():
     n_instr = len(code) // 2
     const_type = [B if (c[1] == 0 and c[2] == 0) else E for c in consts]
     acc_t, slot_t = [B] * 4, [B] * max(1, n_slots)
+    # coordinates of accumulators and scratch values held as lazy words (gl64.h), by variable name; constants, cells, x: canonical
+    lazy = {"a%d" % k: [False] * 3 for k in range(4)}
+    lazy.update({"s%d" % k: [False] * 3 for k in range(max(1, n_slots))})
     out = []
     emit = out.append
-    stats = {"mul1": 0, "mul3": 0, "mul9": 0, "inv": 0}
+    stats = {"mul1": 0, "mul3": 0, "mul9": 0, "inv": 0, "canon": 0}
     comps = lambda t: (0,) if t == B else (0, 1, 2)
+
+    def canon(var, t):
+        """make coordinate t of an accumulator or scratch value canonical, in place"""
+        if var is not None and lazy[var][t]:
+            emit("    %s.c[%d] = gl_canon(%s.c[%d]);" % (var, t, var, t))
+            lazy[var][t] = False
+            stats["canon"] += 1
 
     for pc in range(n_instr):
         w0, w1 = code[2 * pc], code[2 * pc + 1]
         op, d, kind = w0 & 0xff, (w0 >> 8) & 0xf, (w0 >> 12) & 0xf
         a = "a%d" % d
+        src_var = None                                            # the source, when it is a variable that may hold lazy words
         if op <= OP_MUL:
             if kind == SRC_ACC:
+                src_var = "a%d" % (w1 & 3)
                 st, s = acc_t[w1 & 3], lambda t, k=w1 & 3: "a%d.c[%d]" % (k, t)
             elif kind == SRC_SLOT:
+                src_var = "s%d" % w1
                 st, s = slot_t[w1], lambda t, k=w1: "s%d.c[%d]" % (k, t)
             elif kind == SRC_CONST:
                 st, s = const_type[w1], lambda t, k=w1: "QG_K(%d, %d)" % (k, t)
@@ -76,49 +89,88 @@ def generate():
                 st, s = B, lambda t, k=w1: "QG_TAB(%d)" % k
             else:
                 st, s = B, lambda t: "x"
-            srcv = "Gl3{{%s}}" % ", ".join(s(t) if t in comps(st) else "0" for t in range(3))
+        src_lazy = lambda t: src_var is not None and lazy[src_var][t]
         dt = acc_t[d]
         if op == OP_MOV:
-            if not (kind == SRC_ACC and (w1 & 3) == d):
+            if src_var != a:
                 for t in comps(st):
                     emit("    %s.c[%d] = %s;" % (a, t, s(t)))
+                    lazy[a][t] = src_lazy(t)
             acc_t[d] = st
         elif op in (OP_ADD, OP_SUB, OP_RSUB):
+            # gl_add_lazy / gl_sub_lazy (lazy or canonical, CANONICAL) -> lazy: five instructions where the canonical forms take nine / seven
             nt = E if E in (dt, st) else B
             for t in comps(nt):
-                x_ = "%s.c[%d]" % (a, t) if t in comps(dt) else "0"
-                y_ = s(t) if t in comps(st) else "0"
-                l, r = (y_, x_) if op == OP_RSUB else (x_, y_)
+                has_a, has_s = t in comps(dt), t in comps(st)
+                x_, y_ = "%s.c[%d]" % (a, t), (s(t) if has_s else None)
                 if op == OP_ADD:
-                    e = l if r == "0" else r if l == "0" else "gl_add(%s, %s)" % (l, r)
-                else:
-                    e = l if r == "0" else "gl_sub(%s, %s)" % (l, r)
-                emit("    %s.c[%d] = %s;" % (a, t, e))
+                    if not has_s:
+                        continue
+                    if not has_a:
+                        emit("    %s = %s;" % (x_, y_))
+                        lazy[a][t] = src_lazy(t)
+                    elif src_var == a:                               # a + a
+                        canon(a, t)
+                        emit("    %s = gl_add_lazy(%s, %s);" % (x_, x_, x_))
+                        lazy[a][t] = True
+                    elif not src_lazy(t):
+                        emit("    %s = gl_add_lazy(%s, %s);" % (x_, x_, y_))
+                        lazy[a][t] = True
+                    elif not lazy[a][t]:
+                        emit("    %s = gl_add_lazy(%s, %s);" % (x_, y_, x_))
+                        lazy[a][t] = True
+                    else:
+                        canon(src_var, t)
+                        emit("    %s = gl_add_lazy(%s, %s);" % (x_, x_, y_))
+                elif op == OP_SUB:                                   # a - s: s canonical
+                    if not has_s:
+                        continue
+                    canon(src_var, t)
+                    emit("    %s = gl_sub_lazy(%s, %s);" % (x_, x_ if has_a else "0", y_))
+                    lazy[a][t] = True
+                else:                                                # s - a: a canonical
+                    if not has_a:
+                        emit("    %s = %s;" % (x_, y_))
+                        lazy[a][t] = src_lazy(t)
+                        continue
+                    canon(a, t)
+                    emit("    %s = gl_sub_lazy(%s, %s);" % (x_, y_ if has_s else "0", x_))
+                    lazy[a][t] = True
             acc_t[d] = nt
         elif op == OP_MUL:
+            # a product takes any words; its result stays lazy (gl_mul_lazy: no final comparison) until something needs the residue itself
             if dt == B and st == B:
-                emit("    %s.c[0] = gl_mul(%s.c[0], %s);" % (a, a, s(0)))
+                emit("    %s.c[0] = gl_mul_lazy(%s.c[0], %s);" % (a, a, s(0)))
+                lazy[a][0] = True
                 stats["mul1"] += 1
-                acc_t[d] = B
             elif st == B:
-                emit("    %s = gl3_scale(%s, %s);" % (a, a, s(0)))
+                emit("    { const uint64_t f = %s; %s }" % (s(0), " ".join("%s.c[%d] = gl_mul_lazy(%s.c[%d], f);" % (a, t, a, t) for t in range(3))))
+                lazy[a] = [True] * 3
                 stats["mul3"] += 1
             elif dt == B:
-                emit("    %s = gl3_scale(%s, %s.c[0]);" % (a, srcv, a))
+                emit("    { const uint64_t f = %s.c[0]; %s }" % (a, " ".join("%s.c[%d] = gl_mul_lazy(%s, f);" % (a, t, s(t)) for t in range(3))))
+                lazy[a] = [True] * 3
                 stats["mul3"] += 1
                 acc_t[d] = E
             else:
-                emit("    %s = gl3_mul(%s, %s);" % (a, a, srcv))
+                canon(src_var, 1), canon(src_var, 2)                 # gl3_mul doubles its right factor's upper coordinates: canonical
+                emit("    %s = gl3_mul(%s, Gl3{{%s, %s, %s}});" % (a, a, s(0), s(1), s(2)))
+                lazy[a] = [False] * 3
                 stats["mul9"] += 1
         elif op == OP_INV:
             emit("    %s.c[0] = gl_pow(%s.c[0], GL_P - 2);" % (a, a) if dt == B else "    %s = gl3_inv(%s);" % (a, a))
+            for t in comps(dt):
+                lazy[a][t] = False
             stats["inv"] += 1
         elif op == OP_ST:
             for t in comps(dt):
                 emit("    s%d.c[%d] = %s.c[%d];" % (w1, t, a, t))
+                lazy["s%d" % w1][t] = lazy[a][t]
             slot_t[w1] = dt
         else:
             for t in range(3):
+                if t in comps(dt):
+                    canon(a, t)
                 emit("    QG_OUT(%d, %s);" % (t, "%s.c[%d]" % (a, t) if t in comps(dt) else "0"))
     base_consts = [k for k, t in enumerate(const_type) if t == B]
     h = code_hash(code)
@@ -128,7 +180,8 @@ def generate():
 // The composition constraint of the `plain` layout over the 64-bit field (layouts/src/plain/air.rs; sandstorm_amd/layouts/plain.py
 // + air_program.lower) as straight-line code: %(n_instr)d program instructions - %(mul1)d base-field products, %(mul3)d products of
 // an extension value with a base-field one, %(mul9)d extension products, %(inv)d inversion(s) - %(n_slots)d scratch values and the four
-// accumulators in registers, typed base-field / extension at generation time.  Included by goldilocks.hip; compiled for the host
+// accumulators in registers, typed base-field / extension at generation time; products, sums and differences are left as lazy
+// words (csrc/gl64.h) and made canonical only where a residue is needed (%(canon)d places).  Included by goldilocks.hip; compiled for the host
 // (over csrc/gl64.h, the arithmetic both sides share) and held to the oracle by tests/test_gl64_host.py.
 // Code hash (FNV-1a of the program's code words) 0x%(hash)016x: ss_eval_quotient_gl64x3 launches this kernel for exactly that program
 // (after checking that the constants typed base-field here are base-field in its table) and interprets any other.
