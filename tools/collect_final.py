@@ -8,7 +8,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "final")
+SRC = os.path.join(ROOT, os.environ.get("COLLECT_SRC", os.path.join("gpurun_out", "final")))      # COLLECT_SRC: another run's directory
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 
