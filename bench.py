@@ -340,6 +340,12 @@ def bench_goldilocks_plain(args, log_steps, rank, local_rank, world, device):
     sec = dt / args.steps
     if rank == 0:
         ntt_ms, launches = prof["ntt_pass"]
+        # HBM bytes of the transform's launches from the PMC passes of this workload (tools/gl64_pmc.sh; FETCH_SIZE / WRITE_SIZE cannot
+        # be read live): the committed summary is cited
+        traffic, tpath = {}, os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh)
         emit({"metric": "prove_wall_time_s", "value": sec, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": sec * 1e3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
               "dtype": "u64 (p = 2^64 - 2^32 + 1), challenges in Fq3", "data": "synthetic", "proofs_per_s": world / sec,
@@ -355,12 +361,14 @@ def bench_goldilocks_plain(args, log_steps, rank, local_rank, world, device):
               "stage_ms_per_proof": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
               "roofline": (lambda algo: {"bound": "hbm", "kernel": "ss::gl_ntt_pass_kernel", "achieved": algo / (ntt_ms * 1e-3 / args.steps) / 1e9,
                                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": algo / (ntt_ms * 1e-3 / args.steps) / 1e9 / HBM_PEAK_GBPS,
-                                         "traffic": None, "launches": launches, "avg_launch_ms": ntt_ms / max(1, launches),
+                                         "traffic": traffic.get("bytes_per_launch"), "traffic_bytes_per_proof": traffic.get("bytes_per_proof"),
+                                         "traffic_source": traffic.get("source"), "launches": launches, "avg_launch_ms": ntt_ms / max(1, launches),
                                          "algorithmic_bytes_per_proof": algo,
                                          "note": "algorithmic bytes = 2 N 8 B per transform (SURVEY 8d) over the proof's transforms: LDE of 8 columns "
                                                  "(n and 2n), composition (3 of 2n in, 6 of 2n out), out-of-domain (3 per shifted column, n), DEEP "
-                                                 "extension (3 of n, 3 of 2n); the kernel is ALU-bound (a 64-bit modular product is ~20 vector "
-                                                 "instructions): see --workload goldilocks_lde_2p20"})(16.0 * (n * (8 + 24 + 3) + 2 * n * (8 + 9 + 3)))})
+                                                 "extension (3 of n, 3 of 2n); measured traffic is 3.6x that: three passes per transform plus twiddles. "
+                                                 "The kernel is ALU-bound (a butterfly is ~38 vector instructions, five of them quarter-rate; "
+                                                 "profiles/r02_end2_sq_counters_*): see --workload goldilocks_lde_2p20"})(16.0 * (n * (8 + 24 + 3) + 2 * n * (8 + 9 + 3)))})
     if world > 1:
         dist.destroy_process_group()
 
