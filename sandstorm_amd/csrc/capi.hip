@@ -23,6 +23,7 @@
 #include "kernels.h"
 #include "quotient_gen.h"
 #include "ext_scan.h"
+#include "gl_ntt.h"
 
 using namespace ss;
 
@@ -1288,7 +1289,6 @@ ss_status ss_eval_quotient_rows(ss_ctx *ctx, const ss_air_program *prog, const u
 }  // extern "C"
 
 namespace {
-constexpr uint64_t GL_P = 0xFFFFFFFF00000001ull;
 uint64_t gl_mulh(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % GL_P); }
 
 ss_status gl_get_plan(ss_ctx *ctx, uint32_t log_n, bool inverse, uint64_t offset, const uint64_t **out) {
@@ -1321,22 +1321,11 @@ ss_status gl_get_plan(ss_ctx *ctx, uint32_t log_n, bool inverse, uint64_t offset
     return SS_OK;
 }
 
-std::vector<Pass> gl_plan_passes(uint32_t log_n) {
+std::vector<Pass> gl_plan_passes(uint32_t log_n) {          // csrc/gl_ntt.h: the plan the host test of the pass code runs too
+    ss::GlPass passes[8];
+    const int np = ss::gl_plan_passes_into(log_n, gl_log_tile_max(), passes);
     std::vector<Pass> v;
-    const uint32_t lt = gl_log_tile_max();
-    const uint32_t r0 = log_n < lt ? log_n : lt;
-    v.push_back({0, r0});
-    uint32_t rem = log_n - r0;
-    if (rem) {
-        const uint32_t rmax = lt - 5;                  // rows of >= 32 adjacent elements (256-byte global runs)
-        const uint32_t k = (rem + rmax - 1) / rmax;
-        uint32_t s0 = r0;
-        for (uint32_t i = 0; i < k; ++i) {
-            uint32_t r = rem / (k - i) + ((rem % (k - i)) ? 1 : 0);
-            v.push_back({s0, r});
-            s0 += r; rem -= r;
-        }
-    }
+    for (int i = 0; i < np; ++i) v.push_back({passes[i].s0, passes[i].r});
     return v;
 }
 // forward: bit-reversed (optionally sub-sampled) src -> natural dst

@@ -144,3 +144,65 @@ def test_generated_kernel_keeps_the_lazy_word_discipline():
         assert m, "unrecognised statement: " + line
         assign(m.group(1), m.group(2))
     assert n_checked > 300
+
+
+def _gl_twiddles(log_n, inverse, offset):
+    """the plan csrc/capi.hip gl_get_plan uploads, from its definition: T_s[k] = h^(n / 2^(s+1)) r^(k n / 2^(s+1)) at (2^s - 1) + k"""
+    import numpy as np
+    P = 2**64 - 2**32 + 1
+    n = 1 << log_n
+    r, h = pow(7, (P - 1) >> log_n, P), offset
+    if inverse:
+        r, h = pow(r, P - 2, P), pow(h, P - 2, P)
+    tw = np.zeros(max(1, n - 1), dtype=np.uint64)
+    for s in range(log_n):
+        hs, step, v = pow(h, n >> (s + 1), P), pow(r, n >> (s + 1), P), 1
+        for k in range(1 << s):
+            tw[(1 << s) - 1 + k] = hs * v % P
+            v = v * step % P
+    return tw[:n - 1]
+
+
+def test_transform_passes_on_the_host(tmp_path, oracle):
+    """csrc/gl_ntt.h - the pass code the device compiles (tile index arithmetic, register groups of 1-4 stages reading / writing
+    HBM or the tile, twiddle indexing, lazy butterflies) and the plan that splits a transform into passes - compiled for the host:
+    forward, inverse and extension (the zero-padded half never materialised) against the oracle for EVERY size up to 2^17 with the
+    device's 2^13 tiles, and with 2^8 tiles so that small sizes run the multi-pass strided paths too; words at both ends of the
+    field among the inputs."""
+    import struct
+
+    import numpy as np
+    P = 2**64 - 2**32 + 1
+    exe = str(tmp_path / "gl_ntt_host_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "sandstorm_amd", "csrc"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "gl_ntt_host_test.cpp")])
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+
+    def run(log_n, inverse, log_expand, scale, lt, src, tw):
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<6Q", log_n, int(inverse), log_expand, scale, lt, len(src)))
+            f.write(np.ascontiguousarray(src, dtype=np.uint64).tobytes())
+            f.write(np.ascontiguousarray(tw, dtype=np.uint64).tobytes())
+        subprocess.check_call([exe, fin, fout], timeout=600)
+        return np.fromfile(fout, dtype=np.uint64)
+
+    rng = np.random.default_rng(64)
+    for lt, sizes in ((13, list(range(1, 18))), (8, list(range(1, 17)))):
+        for log_n in sizes:
+            n = 1 << log_n
+            rev = np.array([int(format(i, "0%db" % log_n)[::-1], 2) for i in range(n)])
+            x = rng.integers(0, P, size=n, dtype=np.uint64)
+            edge = rng.integers(0, 4, size=n)
+            x = np.where(edge == 0, rng.integers(0, 3, size=n, dtype=np.uint64), np.where(edge == 1, np.uint64(P - 1) - rng.integers(0, 3, size=n, dtype=np.uint64), x))
+            off = 7 if log_n % 2 else 1
+            fwd = run(log_n, False, 0, 1, lt, x[rev], _gl_twiddles(log_n, False, off))          # bit-reversed in, natural out
+            assert np.array_equal(fwd, oracle.gl_ntt(x, offset=off)), (lt, log_n, "forward")
+            inv = run(log_n, True, 0, pow(n, P - 2, P), lt, x, _gl_twiddles(log_n, True, off))   # natural in, bit-reversed out, 1/n on the last pass
+            assert np.array_equal(inv[rev], oracle.gl_ntt(x, inverse=True, offset=off)), (lt, log_n, "inverse")
+            for lb in (1, 2):                                                                    # capi.hip ss_lde_gl64: coefficients, then the expanding forward pass
+                if log_n + lb > 17:
+                    continue
+                co = run(log_n, True, 0, pow(n, P - 2, P), lt, x, _gl_twiddles(log_n, True, 1))
+                ev = run(log_n + lb, False, lb, 1, lt, co, _gl_twiddles(log_n + lb, False, 7))
+                want_ev, want_co = oracle.gl_lde(x, lb, 7)
+                assert np.array_equal(co[rev], want_co) and np.array_equal(ev, want_ev), (lt, log_n, lb, "extension")
