@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("SS_TEST_HIPEMU") == "1":
+        # tests/test_device_code_on_host.py runs selected `gpu` tests in a process of their own against the HOST BUILD OF THE DEVICE
+        # CODE (tests/hipemu: test infrastructure; same C ABI, kernels executed lane by lane on the CPU).  Only this test session
+        # is pointed at it - the product's loader has no such switch.
+        from sandstorm_amd import _lib
+        _lib.LIB_PATH = os.environ.get("SS_TEST_HIPEMU_LIB", os.path.join(ROOT, "tests", "hipemu", "_build", "libsandstorm_hipemu.so"))
 
 
 @pytest.fixture(scope="session")

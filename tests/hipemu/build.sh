@@ -1,0 +1,21 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE ONLY: sandstorm_amd/csrc/*.hip compiled for the HOST over tests/hipemu/hip/hip_runtime.h
+#   -> tests/hipemu/_build/libsandstorm_hipemu.so (same C ABI as the product's library; loaded by tests/test_device_code_on_host.py only)
+set -e
+HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd)
+CXX=${HIPEMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}          # clang: the sources use ext_vector_type / address_space attributes
+OUT=${HIPEMU_OUT:-$HERE/_build}; mkdir -p $OUT
+FLAGS="-x c++ -std=c++17 -O2 -fPIC -w -I $HERE -I $ROOT/include -I $ROOT/sandstorm_amd/csrc"
+SRCS="capi ntt hash pedersen fri deep quotient ext goldilocks quotient_gen_starknet quotient_gen_recursive"
+pids=()
+for f in $SRCS; do
+  src=$ROOT/sandstorm_amd/csrc/$f.hip; obj=$OUT/$f.o
+  if [ ! -f $obj ] || [ -n "$(find $ROOT/sandstorm_amd/csrc $HERE/hip $ROOT/include -newer $obj \( -name '*.hip' -o -name '*.h' -o -name '*.inc' \) | head -1)" ]; then
+    ( O=-O2; case $f in quotient_gen_*) O=-O1;; esac; $CXX $FLAGS $O -c $src -o $obj ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$CXX -std=c++17 -O2 -fPIC -w -I $HERE -c $HERE/hipemu.cpp -o $OUT/hipemu.o
+$CXX -shared -fPIC -pthread -o $OUT/libsandstorm_hipemu.so $OUT/hipemu.o $(for f in $SRCS; do echo $OUT/$f.o; done)
+echo $OUT/libsandstorm_hipemu.so

@@ -1,0 +1,64 @@
+"""The library's DEVICE CODE on the CPU.  tests/hipemu/ compiles sandstorm_amd/csrc/*.hip - every kernel, every launch, the C ABI's
+host side - for the host over a stand-in for <hip/hip_runtime.h> (workgroups one after the other, lanes as fibers that yield at
+barriers), into tests/hipemu/_build/libsandstorm_hipemu.so.  Selected `gpu` parity tests then run in a process of their own with
+that library in place of the product's (tests/conftest.py, SS_TEST_HIPEMU=1) - the same tests, oracle and tolerances (bit-exact) the
+MI355X runs, minus the sizes that only make sense on the hardware.
+
+TEST INFRASTRUCTURE: this is not a fallback.  Nothing under sandstorm_amd/ can load the emulation; the product loads
+sandstorm_amd/_build/libsandstorm_hip.so and fails without an MI355X.  What this buys is that index arithmetic, launch geometry,
+lazy-bound bookkeeping and generated kernels are checked on every CPU run, and that kernel work can be verified before GPU time is
+spent on measuring it.  What it cannot see: anything the gfx950 compiler or hardware does (spills, LDS limits, wave-level timing)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+
+
+@pytest.fixture(scope="module")
+def emulated_library():
+    if not (os.path.exists(CLANG) or shutil.which(CLANG)):
+        pytest.skip("no clang++ to build the host emulation with (%s)" % CLANG)
+    out = subprocess.run(["bash", os.path.join(ROOT, "tests", "hipemu", "build.sh")], capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return out.stdout.strip().splitlines()[-1]
+
+
+def run_gpu_tests_on_host(lib, args, timeout=1500):
+    env = dict(os.environ, SS_TEST_HIPEMU="1", SS_TEST_HIPEMU_LIB=lib)
+    out = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=timeout)
+    tail = out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.returncode == 0, tail
+    assert " passed" in out.stdout and " failed" not in out.stdout and " error" not in out.stdout, tail
+    return out.stdout
+
+
+def test_every_kernel_against_the_oracle(emulated_library):
+    """tests/test_gpu_parity.py: transforms, row hashing, Keccak / Blake2s / Pedersen trees and openings, FRI folds, DEEP, the constraint
+    VM, proof of work - the 252-bit path's parity tests, all but the two that only exist for their size"""
+    out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_parity.py", "-k", "not large_impulse"])
+    assert "148 passed" in out, out[-500:]
+
+
+def test_the_64_bit_field(emulated_library):
+    """tests/test_goldilocks.py below the benchmark sizes, and every transform size (tests/hipemu/extra_gl64_sizes.py)"""
+    run_gpu_tests_on_host(emulated_library, ["tests/test_goldilocks.py", "-k", "not benchmark_size"])
+    out = run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_gl64_sizes.py"])
+    assert "17 passed" in out, out[-500:]
+
+
+def test_extension_columns_and_compiled_constraint_kernels(emulated_library):
+    """tests/test_gpu_extension.py (the scans behind Trace::build_extension_columns) and tests/test_gpu_real_quotient.py (the generated
+    starknet / recursive kernels against the interpreter and the oracle over whole domains)"""
+    run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_extension.py"])
+    run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_real_quotient.py"])
+
+
+def test_whole_proofs(emulated_library):
+    """tests/test_gpu_prove.py: prove -> serialise -> verify on the mini AIR, both hosts, every tree and coin"""
+    run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_prove.py"])
