@@ -45,6 +45,13 @@ def test_every_kernel_against_the_oracle(emulated_library):
     assert "148 passed" in out, out[-500:]
 
 
+def test_sweeps_over_the_sizes_the_gpu_suite_samples(emulated_library):
+    """tests/hipemu/extra_fp252_sweeps.py: every transform size, extension factor, fold factor x layer length, row width x hash,
+    tree size x tree kind, and the small out-of-domain / DEEP sizes - cheap here, so all of them"""
+    out = run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_fp252_sweeps.py"])
+    assert "61 passed" in out, out[-500:]
+
+
 def test_the_64_bit_field(emulated_library):
     """tests/test_goldilocks.py below the benchmark sizes, and every transform size (tests/hipemu/extra_gl64_sizes.py)"""
     run_gpu_tests_on_host(emulated_library, ["tests/test_goldilocks.py", "-k", "not benchmark_size"])
