@@ -53,10 +53,13 @@ def test_sweeps_over_the_sizes_the_gpu_suite_samples(emulated_library):
 
 
 def test_the_64_bit_field(emulated_library):
-    """tests/test_goldilocks.py below the benchmark sizes, and every transform size (tests/hipemu/extra_gl64_sizes.py)"""
+    """tests/test_goldilocks.py below the benchmark sizes, every transform size (tests/hipemu/extra_gl64_sizes.py), and a whole proof
+    of the plain layout equal to the one the MI355X wrote (tests/hipemu/extra_gl64_proof.py)"""
     run_gpu_tests_on_host(emulated_library, ["tests/test_goldilocks.py", "-k", "not benchmark_size"])
     out = run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_gl64_sizes.py"])
     assert "17 passed" in out, out[-500:]
+    # and the whole proof: the Python host over the C ABI with CPU tensors as device buffers writes the MI355X-made fixture
+    run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_gl64_proof.py"])
 
 
 def test_extension_columns_and_compiled_constraint_kernels(emulated_library):
