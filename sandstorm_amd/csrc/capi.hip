@@ -406,12 +406,21 @@ ss_status ss_profile_read(ss_ctx *ctx, int kind, double *total_ms, uint64_t *lau
     return SS_OK;
 }
 
+// every entry of a caller's column-pointer table names memory: a NULL one would only show as a fault inside a kernel
+static bool has_null(const void *const *cols, uint32_t n) {
+    for (uint32_t c = 0; c < n; ++c) if (!cols[c]) return true;
+    return false;
+}
+static bool valid_order(int order) { return order == SS_ORDER_NATURAL || order == SS_ORDER_BITREV; }
+
 // ------------------------------------------------------------------- NTT
 ss_status ss_ntt_fp252(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, uint32_t log_n, int direction,
                        const uint64_t offset[4], int in_order, int out_order) {
     if (!ctx || !d_cols) return fail(SS_ERR_INVALID, "NULL argument");
     if (!valid_log(log_n)) return fail(SS_ERR_INVALID, "log_n %u out of range [1,30]", log_n);
     if (direction != SS_NTT_FORWARD && direction != SS_NTT_INVERSE) return fail(SS_ERR_INVALID, "bad direction");
+    if (!valid_order(in_order) || !valid_order(out_order)) return fail(SS_ERR_INVALID, "bad element order %d / %d", in_order, out_order);
+    if (has_null((const void *const *)d_cols, ncols)) return fail(SS_ERR_INVALID, "NULL column");
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const bool inverse = direction == SS_NTT_INVERSE;
     const Fp *tw = nullptr;
@@ -446,6 +455,8 @@ ss_status ss_lde_fp252(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols,
                        uint64_t *const *d_coeffs) {
     if (!ctx || !d_in || !d_evals) return fail(SS_ERR_INVALID, "NULL argument");
     if (!valid_log(log_n) || !valid_log(log_n + log_blowup)) return fail(SS_ERR_INVALID, "size out of range");
+    if (has_null((const void *const *)d_in, ncols) || has_null((const void *const *)d_evals, ncols) || (d_coeffs && has_null((const void *const *)d_coeffs, ncols)))
+        return fail(SS_ERR_INVALID, "NULL column");
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp *tw_inv = nullptr, *tw_fwd = nullptr;
     ss_status st = ctx->get_plan(log_n, true, fp_one(), &tw_inv);
@@ -475,6 +486,7 @@ ss_status ss_evaluate_fp252(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32
                             uint32_t log_blowup, const uint64_t offset[4], uint64_t *const *d_evals) {
     if (!ctx || !d_coeffs || !d_evals) return fail(SS_ERR_INVALID, "NULL argument");
     if (!valid_log(log_n) || !valid_log(log_n + log_blowup)) return fail(SS_ERR_INVALID, "size out of range");
+    if (has_null((const void *const *)d_coeffs, ncols) || has_null((const void *const *)d_evals, ncols)) return fail(SS_ERR_INVALID, "NULL column");
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp *tw = nullptr;
     ss_status st = ctx->get_plan(log_n + log_blowup, false, off, &tw);
@@ -507,6 +519,7 @@ ss_status ss_hash_rows_ex(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_c
     }
     if (hash_kind < 0 || hash_kind > 3) return fail(SS_ERR_INVALID, "bad hash kind %d", hash_kind);
     if (ncols == 0 || ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u not in [1,%d]", ncols, MAX_COLS);
+    if (has_null((const void *const *)d_cols, ncols)) return fail(SS_ERR_INVALID, "NULL column");
     ConstColPtrs cols;
     memset(&cols, 0, sizeof cols);
     for (uint32_t c = 0; c < ncols; ++c) cols.p[c] = d_cols[c];
@@ -526,6 +539,7 @@ ss_status ss_merkle_build_ex(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_lay
     if (!ctx || !d_leaves || !d_nodes) return fail(SS_ERR_INVALID, "NULL argument");
     if (n < 2 || (n & (n - 1))) return fail(SS_ERR_INVALID, "n must be a power of two >= 2");
     if (tree_kind < 0 || tree_kind > 3) return fail(SS_ERR_INVALID, "bad tree kind");
+    if (leaf_kind != SS_LEAF_DIGEST && leaf_kind != SS_LEAF_FELT) return fail(SS_ERR_INVALID, "bad leaf kind %d", leaf_kind);
     if (leaf_order != SS_ORDER_NATURAL && leaf_order != SS_ORDER_BITREV) return fail(SS_ERR_INVALID, "bad leaf order %d", leaf_order);
     uint32_t log_n = 0;
     while ((1ull << log_n) < n) ++log_n;
@@ -628,6 +642,7 @@ ss_status ss_gather_rows(ss_ctx *ctx, const uint64_t *const *d_cols, uint32_t nc
                          uint32_t nidx, uint64_t *out) {
     if (!ctx || !d_cols || (!idx && nidx) || (!out && nidx)) return fail(SS_ERR_INVALID, "NULL argument");
     if (nidx == 0 || ncols == 0) return SS_OK;
+    if (has_null((const void *const *)d_cols, ncols)) return fail(SS_ERR_INVALID, "NULL column");
     const size_t need = (size_t)nidx * 8 + (size_t)nidx * ncols * 32;
     ss_status st = ctx->ensure_scratch(need);
     if (st != SS_OK) return st;
@@ -815,6 +830,7 @@ ss_status ss_poly_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t nc
     if (!valid_log(log_n)) return fail(SS_ERR_INVALID, "log_n out of range");
     if (ncols == 0) return SS_OK;
     if (ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u > %d", ncols, MAX_COLS);
+    if (has_null((const void *const *)d_coeffs, ncols)) return fail(SS_ERR_INVALID, "NULL column");
     // x^(2^j), j < log_n
     std::vector<Fp> xp(log_n);
     xp[0] = fp_from_limbs64(x);
@@ -856,6 +872,7 @@ ss_status ss_ood_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t nco
     if (!valid_log(log_n)) return fail(SS_ERR_INVALID, "log_n out of range");
     if (ncols == 0 || ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u not in [1,%d]", ncols, MAX_COLS);
     if (nmask == 0) return SS_OK;
+    if (has_null((const void *const *)d_coeffs, ncols)) return fail(SS_ERR_INVALID, "NULL column");
     for (uint32_t j = 0; j < nmask; ++j)
         if (mask_col[j] >= ncols) return fail(SS_ERR_INVALID, "mask cell %u names column %u", j, mask_col[j]);
     // T_c(z w^k) for every k at once: one coset NTT (offset z) of each coefficient column
@@ -1173,6 +1190,7 @@ static ss_status eval_quotient_impl(ss_ctx *ctx, const ss_air_program *prog, con
     const uint32_t log_N = log_n + log_blowup;
     if (!valid_log(log_n) || !valid_log(log_N)) return fail(SS_ERR_INVALID, "size out of range");
     if (ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u > %d", ncols, MAX_COLS);
+    if (has_null((const void *const *)d_lde_cols, ncols)) return fail(SS_ERR_INVALID, "NULL column");
     const bool block = block_rows != 0;
     const uint64_t N = block ? npoints : 1ull << log_N;
     if (block && (npoints == 0 || row0 + npoints > (1ull << log_N))) return fail(SS_ERR_INVALID, "row block out of the domain");
@@ -1364,6 +1382,9 @@ ss_status ss_ntt_gl64(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, uint
     if (!gl_valid_log(log_n)) return fail(SS_ERR_INVALID, "log_n out of range");
     if (ncols == 0 || ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_UNSUPPORTED, "ncols %u out of range", ncols);
     if (offset == 0 || offset >= GL_P) return fail(SS_ERR_INVALID, "the coset offset is not a non-zero field element");
+    if (direction != SS_NTT_FORWARD && direction != SS_NTT_INVERSE) return fail(SS_ERR_INVALID, "bad direction");
+    if (!valid_order(in_order) || !valid_order(out_order)) return fail(SS_ERR_INVALID, "bad element order %d / %d", in_order, out_order);
+    if (has_null((const void *const *)d_cols, ncols)) return fail(SS_ERR_INVALID, "NULL column");
     const bool inverse = direction == SS_NTT_INVERSE;
     const uint64_t *tw = nullptr;
     ss_status st = gl_get_plan(ctx, log_n, inverse, offset, &tw);
@@ -1395,6 +1416,8 @@ ss_status ss_lde_gl64(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols, 
     if (!gl_valid_log(log_n) || !gl_valid_log(log_n + log_blowup)) return fail(SS_ERR_INVALID, "size out of range");
     if (offset == 0 || offset >= GL_P) return fail(SS_ERR_INVALID, "the coset offset is not a non-zero field element");
     if (ncols == 0) return SS_OK;
+    if (has_null((const void *const *)d_in, ncols) || has_null((const void *const *)d_evals, ncols) || (d_coeffs && has_null((const void *const *)d_coeffs, ncols)))
+        return fail(SS_ERR_INVALID, "NULL column");
     const uint64_t n = 1ull << log_n;
     const uint64_t *tw_inv = nullptr, *tw_fwd = nullptr;
     ss_status st = gl_get_plan(ctx, log_n, true, 1, &tw_inv);

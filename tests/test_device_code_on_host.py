@@ -72,3 +72,9 @@ def test_extension_columns_and_compiled_constraint_kernels(emulated_library):
 def test_whole_proofs(emulated_library):
     """tests/test_gpu_prove.py: prove -> serialise -> verify on the mini AIR, both hosts, every tree and coin"""
     run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_prove.py"])
+
+
+def test_entry_points_refuse_what_they_cannot_serve(emulated_library):
+    """tests/hipemu/extra_bad_arguments.py: every entry point with a NULL context, with everything else zero / NULL, with huge sizes and
+    NULL data - an error status each time, no crash (each call in a forked child), nothing launched"""
+    run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_bad_arguments.py"])
