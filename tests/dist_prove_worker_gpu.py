@@ -19,16 +19,26 @@ from sandstorm_amd.sharded_prover import Comm, ShardedProver  # noqa: E402
 
 def main():
     backend = sys.argv[3] if len(sys.argv) > 3 else "gloo"
-    torch.cuda.set_device(0)
-    device = torch.device("cuda", 0)
-    dist.init_process_group(backend=backend, **({"device_id": device} if backend == "nccl" else {}))
-    rank, world = dist.get_rank(), dist.get_world_size()
     case, out_path = sys.argv[1], sys.argv[2]
-    # ONE stream for torch's tensor ops, the collectives and the C ABI's kernels: torch's default stream has handle 0,
-    # which ss_ctx_set_stream reads as "the context's own stream" - an explicit stream makes the ordering real
-    stream = torch.cuda.Stream(device)
-    torch.cuda.set_stream(stream)
-    ctx = be.Context(0, stream=stream.cuda_stream)
+    if os.environ.get("SS_TEST_HIPEMU") == "1":
+        # tests/test_device_code_on_host.py: the same ranks over the HOST BUILD OF THE DEVICE CODE (tests/hipemu, test infrastructure) -
+        # "device" buffers are CPU tensors, gloo moves them as they are
+        from sandstorm_amd import _lib
+        _lib.LIB_PATH = os.environ.get("SS_TEST_HIPEMU_LIB", os.path.join(ROOT, "tests", "hipemu", "_build", "libsandstorm_hipemu.so"))
+        device = torch.device("cpu")
+        dist.init_process_group(backend="gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ctx = be.Context(0)
+    else:
+        torch.cuda.set_device(0)
+        device = torch.device("cuda", 0)
+        dist.init_process_group(backend=backend, **({"device_id": device} if backend == "nccl" else {}))
+        rank, world = dist.get_rank(), dist.get_world_size()
+        # ONE stream for torch's tensor ops, the collectives and the C ABI's kernels: torch's default stream has handle 0,
+        # which ss_ctx_set_stream reads as "the context's own stream" - an explicit stream makes the ordering real
+        stream = torch.cuda.Stream(device)
+        torch.cuda.set_stream(stream)
+        ctx = be.Context(0, stream=stream.cuda_stream)
 
     def tensor(limbs):
         return torch.from_numpy(np.ascontiguousarray(limbs, dtype=np.uint64).view(np.int64).copy()).to(device)

@@ -74,6 +74,13 @@ def test_whole_proofs(emulated_library):
     run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_prove.py"])
 
 
+def test_one_proof_over_several_ranks(emulated_library):
+    """tests/hipemu/extra_sharded.py: the sharded driver (torch.distributed / gloo) with the device code on every rank writes the
+    single-device proof byte for byte - the reference's example with the real recursive AIR on 2 ranks, the mini AIR on 4"""
+    out = run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_sharded.py", "-k", "example-2 or 4-4"])
+    assert "2 passed" in out, out[-500:]
+
+
 def test_entry_points_refuse_what_they_cannot_serve(emulated_library):
     """tests/hipemu/extra_bad_arguments.py: every entry point with a NULL context, with everything else zero / NULL, with huge sizes and
     NULL data - an error status each time, no crash (each call in a forked child), nothing launched"""
