@@ -55,18 +55,17 @@ def test_sweeps_over_the_sizes_the_gpu_suite_samples(emulated_library):
 def test_the_64_bit_field(emulated_library):
     """tests/test_goldilocks.py below the benchmark sizes, every transform size (tests/hipemu/extra_gl64_sizes.py), and a whole proof
     of the plain layout equal to the one the MI355X wrote (tests/hipemu/extra_gl64_proof.py)"""
-    run_gpu_tests_on_host(emulated_library, ["tests/test_goldilocks.py", "-k", "not benchmark_size"])
-    out = run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_gl64_sizes.py"])
-    assert "17 passed" in out, out[-500:]
-    # and the whole proof: the Python host over the C ABI with CPU tensors as device buffers writes the MI355X-made fixture
-    run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_gl64_proof.py"])
+    # (the whole proof: the Python host over the C ABI with CPU tensors as device buffers writes the MI355X-made fixture)
+    out = run_gpu_tests_on_host(emulated_library, ["tests/test_goldilocks.py", "tests/hipemu/extra_gl64_sizes.py", "tests/hipemu/extra_gl64_proof.py",
+                                                   "-k", "not benchmark_size"])
+    assert "48 passed" in out, out[-500:]                     # 30 + 17 sizes + 1 proof
 
 
 def test_extension_columns_and_compiled_constraint_kernels(emulated_library):
     """tests/test_gpu_extension.py (the scans behind Trace::build_extension_columns) and tests/test_gpu_real_quotient.py (the generated
     starknet / recursive kernels against the interpreter and the oracle over whole domains)"""
-    run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_extension.py"])
-    run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_real_quotient.py"])
+    out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_extension.py", "tests/test_gpu_real_quotient.py", "-k", "not first_large_evaluation"])
+    assert "41 passed" in out, out[-500:]                     # 36 + 5 (the sixth times two kernels against each other: hardware only)
 
 
 def test_whole_proofs(emulated_library):
