@@ -36,6 +36,11 @@
 extern "C" {
 #endif
 
+/* Every entry point validates what it is handed before anything is launched - sizes, directions / orders / hash, tree, leaf and coin
+ * kinds, NULL tables and NULL entries of column tables, mask cells and program operands against the column / constant / slot /
+ * table counts of the same call, query indices against the tree - and answers SS_ERR_INVALID / SS_ERR_UNSUPPORTED with a message in
+ * ss_last_error(); a call it cannot serve never reaches a kernel (tests/hipemu/extra_bad_arguments.py sweeps all of them).  What
+ * it cannot check is the SIZE of device memory behind a pointer: buffers must hold what the call's sizes say. */
 typedef int ss_status;
 enum {
     SS_OK = 0,
