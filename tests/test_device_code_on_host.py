@@ -84,3 +84,11 @@ def test_entry_points_refuse_what_they_cannot_serve(emulated_library):
     """tests/hipemu/extra_bad_arguments.py: every entry point with a NULL context, with everything else zero / NULL, with huge sizes and
     NULL data - an error status each time, no crash (each call in a forked child), nothing launched"""
     run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_bad_arguments.py"])
+
+
+def test_the_smoke_invocation(emulated_library):
+    """__graft_entry__.smoke() - what the driver runs on the MI355X before the bench - over the host build: its checks are right"""
+    code = ("import sys; sys.path.insert(0, %r); from sandstorm_amd import _lib; _lib.LIB_PATH = %r; import __graft_entry__ as g; g.smoke()"
+            % (ROOT, emulated_library))
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
