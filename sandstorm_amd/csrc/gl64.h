@@ -5,9 +5,9 @@
 //   canonical   - the residue itself, < p: what is stored in HBM, hashed, compared;
 //   lazy        - ANY 64-bit word congruent to the value (p < 2^64 < 2p: a residue has at most two such words).  The transforms'
 //                 butterflies keep their sums lazy and canonicalise once per pass instead of once per addition;
-//   wide        - a 160-bit accumulator of unreduced 128-bit products (GlWide): a dot product pays ONE reduction for all its
-//                 terms - an Fq3 product three instead of nine, a DEEP column sum three instead of nine per tap.
-// 2^64 = 2^32 - 1 (EPS), 2^96 = -1 and 2^128 = -2^32 modulo p are all the reduction needs.
+//   wide        - unreduced 128-bit products added digit by digit into four 64-bit words (GlWide): a dot product pays ONE
+//                 reduction for all its terms - an Fq3 product three instead of nine, a DEEP column sum three instead of nine per tap.
+// 2^64 = 2^32 - 1 (EPS) and 2^96 = -1 modulo p are all the reductions need.
 //
 // On gfx950 a 64 x 64 -> 128 product is four v_mad_u64_u32 (quarter rate: the cost of sixteen plain instructions); writing the
 // product out in 32-bit halves keeps the compiler from also computing the low word a second time with two v_mul_lo_u32
