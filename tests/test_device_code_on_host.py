@@ -47,9 +47,11 @@ def test_every_kernel_against_the_oracle(emulated_library):
 
 def test_sweeps_over_the_sizes_the_gpu_suite_samples(emulated_library):
     """tests/hipemu/extra_fp252_sweeps.py: every transform size, extension factor, fold factor x layer length, row width x hash,
-    tree size x tree kind, and the small out-of-domain / DEEP sizes - cheap here, so all of them"""
-    out = run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_fp252_sweeps.py"])
-    assert "61 passed" in out, out[-500:]
+    tree size x tree kind, the small out-of-domain / DEEP sizes - cheap here, so all of them; tests/hipemu/extra_boundaries.py: DEEP masks
+    that sit on the kernels' bookkeeping boundaries (15 ... 130 cells in one column, wrapped offsets, doubled cells), forty more random
+    constraint programs"""
+    out = run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_fp252_sweeps.py", "tests/hipemu/extra_boundaries.py"])
+    assert "70 passed" in out, out[-500:]                     # 61 sweeps + DEEP masks on the kernels' bookkeeping boundaries (both fields) + 40 random programs
 
 
 def test_the_64_bit_field(emulated_library):
