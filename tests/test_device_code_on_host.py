@@ -60,7 +60,7 @@ def test_the_64_bit_field(emulated_library):
     # (the whole proof: the Python host over the C ABI with CPU tensors as device buffers writes the MI355X-made fixture)
     out = run_gpu_tests_on_host(emulated_library, ["tests/test_goldilocks.py", "tests/hipemu/extra_gl64_sizes.py", "tests/hipemu/extra_gl64_proof.py",
                                                    "-k", "not benchmark_size"])
-    assert "48 passed" in out, out[-500:]                     # 30 + 17 sizes + 1 proof
+    assert "54 passed" in out, out[-500:]                     # 30 + 17 sizes + folds, row shapes, running products + 1 proof
 
 
 def test_extension_columns_and_compiled_constraint_kernels(emulated_library):
