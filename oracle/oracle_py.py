@@ -70,22 +70,17 @@ def lib():
 def to_mont(v):
     """python int(s) -> uint64[..., 4] Montgomery limbs."""
     a = np.asarray(v, dtype=object)
-    flat = [((int(x) % P) * R_MOD_P) % P for x in a.reshape(-1)]
-    out = np.zeros((len(flat), 4), dtype=np.uint64)
-    for i, x in enumerate(flat):
-        for k in range(4):
-            out[i, k] = (x >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
-    return out.reshape(a.shape + (4,))
+    raw = b"".join((((int(x) % P) * R_MOD_P) % P).to_bytes(32, "little") for x in a.reshape(-1))
+    return np.frombuffer(raw, dtype="<u8").astype(np.uint64).reshape(a.shape + (4,))
 
 
 def from_mont(arr):
     """uint64[..., 4] Montgomery limbs -> object array of python ints (canonical)."""
-    a = np.asarray(arr, dtype=np.uint64)
-    flat = a.reshape(-1, 4)
-    out = np.empty(len(flat), dtype=object)
-    for i, row in enumerate(flat):
-        x = sum(int(row[k]) << (64 * k) for k in range(4))
-        out[i] = (x * R_INV) % P
+    a = np.ascontiguousarray(arr, dtype="<u8")
+    raw = a.tobytes()
+    out = np.empty(a.size // 4, dtype=object)
+    for i in range(len(out)):
+        out[i] = (int.from_bytes(raw[32 * i:32 * i + 32], "little") * R_INV) % P
     return out.reshape(a.shape[:-1])
 
 

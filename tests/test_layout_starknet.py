@@ -91,17 +91,39 @@ def real_instances():
     }
 
 
+_TRACES = {}
+
+
+def bootloader_trace_with_real_instances():
+    """-> (public input, private input, the 9 base columns): the Python generator on the bootloader run with real instances of every
+    builtin added - two million rows take it half a minute, so the tests that need it share one (none of them writes to it)"""
+    if "bootloader" not in _TRACES:
+        from sandstorm_amd.layouts import starknet as sk
+        states, memory, spi, private = bootloader_run()
+        assert spi.layout == "starknet" and len(states) == spi.n_steps == 1 << LOG_STEPS and len(private["pedersen"]) == 2
+        extra = real_instances()
+        private["pedersen"] += extra.pop("pedersen")
+        private.update(extra)
+        _TRACES["bootloader"] = (spi, private, sk.base_trace(states, memory, spi, private))
+    return _TRACES["bootloader"]
+
+
+def array_sum_trace():
+    """-> (public input, the 9 base columns) of starknet_example(17), shared likewise"""
+    if "array_sum" not in _TRACES:
+        from sandstorm_amd.layouts import starknet as sk
+        states, memory, spi = starknet_example(17)
+        _TRACES["array_sum"] = (spi, sk.base_trace(states, memory, spi))
+    return _TRACES["array_sum"]
+
+
 @pytest.fixture(scope="module")
 def example():
     import numpy as np
     from oracle import oracle_py as oracle
     from sandstorm_amd.layouts import starknet as sk
-    states, memory, spi, private = bootloader_run()
-    assert spi.layout == "starknet" and len(states) == spi.n_steps == 1 << LOG_STEPS and len(private["pedersen"]) == 2
-    extra = real_instances()
-    private["pedersen"] += extra.pop("pedersen")
-    private.update(extra)
-    cols = sk.base_trace(states, memory, spi, private)
+    spi, private, base = bootloader_trace_with_real_instances()
+    cols = list(base)
     n = len(cols[0])
     aux = {"npc": oracle.to_mont(cols[sk.COL_NPC]), "memory": oracle.to_mont(cols[sk.COL_MEMORY]), "range_check": oracle.to_mont(cols[sk.COL_RANGE_CHECK])}
     ext, lasts = oracle.build_extension_columns("starknet", aux, [oracle.to_mont([c])[0] for c in CHALLENGES], n)
@@ -392,11 +414,9 @@ def test_cpp_base_trace_equals_the_python_one(oracle):
         trace_bin = f.read()
     with gzip.open(os.path.join(g, "bootloader", "memory.bin.gz")) as f:
         memory_bin = f.read()
-    states, memory, pi, private = bootloader_run()
-    extra = real_instances()
-    both = {"pedersen": private["pedersen"] + extra["pedersen"], **{k: v for k, v in extra.items() if k != "pedersen"}}
+    pi, both, python_cols = bootloader_trace_with_real_instances()
     for priv in (both,):
-        want = sk.base_trace(states, memory, pi, priv)
+        want = python_cols
         got = hostlib.starknet_base_trace(trace_bin, memory_bin, pi, priv)
         assert len(got) == len(want) == 9
         for c, (a, b) in enumerate(zip(got, want)):
@@ -481,8 +501,7 @@ def test_array_sum_trace_is_the_one_the_references_proof_opens(oracle, golden):
     with open(os.path.join(ROOT, "tests", "golden", "reference_array_sum_starknet.proof"), "rb") as f:
         w = wire.parse(f.read())
     positions = golden("saved_proof_openings.json")["positions"]
-    states, memory, spi = starknet_example(17)
-    cols = sk.base_trace(states, memory, spi)
+    spi, cols = array_sum_trace()
     offset = oracle.to_mont([3])[0]
     natural = [bitrev(p, 22) for p in positions]                       # committed index -> exponent of w (M3)
     for c in (0, 5, 6, 7, 8):                                           # flags, memory pool, sorted memory, range check, auxiliary
@@ -506,13 +525,12 @@ def test_extension_column_is_the_one_the_references_proof_opens(oracle):
     from sandstorm_amd.prover import bitrev
     with open(os.path.join(ROOT, "tests", "golden", "reference_array_sum_starknet.proof"), "rb") as f:
         w = wire.parse(f.read())
-    states, memory, spi = starknet_example(17)
+    spi, cols = array_sum_trace()
     coin = PublicCoin(be.COIN_SOLIDITY, public_input.public_coin_seed(spi, be.COIN_SOLIDITY))
     coin.reseed_with_digest(w.base_root)
     challenges = [coin.draw() for _ in range(6)]
     positions = reference_query_positions(w, spi)
     assert len(positions) == 16 == len(w.extension_rows)
-    cols = sk.base_trace(states, memory, spi)
     n = len(cols[0])
     aux = {"npc": oracle.to_mont(cols[sk.COL_NPC]), "memory": oracle.to_mont(cols[sk.COL_MEMORY]), "range_check": oracle.to_mont(cols[sk.COL_RANGE_CHECK])}
     natural = [bitrev(p, 22) for p in positions]
