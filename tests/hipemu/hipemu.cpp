@@ -60,6 +60,7 @@ thread_local void *sched_sp = nullptr;
 thread_local Fiber *current = nullptr;
 thread_local const std::function<void()> *body = nullptr;
 thread_local std::vector<int> exchange;                      // __shfl_xor: one word per lane of the workgroup
+const int lane_order = [] { const char *e = getenv("HIPEMU_ORDER"); return !e ? 0 : e[0] == 'r' ? 1 : e[0] == 's' ? 2 : 0; }();   // forward / reverse / shuffle
 
 void fiber_main() {
     (*body)();
@@ -115,9 +116,14 @@ void run_blocks(dim3 grid, dim3 block, const std::function<void()> &lane_body, u
                     f.done = false;
                     f.tid = {tx, ty, tz};
                 }
-        for (size_t live = lanes; live;) {                   // one pass = every live lane from its barrier to the next (or to its end)
+        for (size_t live = lanes, pass = 0; live; ++pass) {  // one pass = every live lane from its barrier to the next (or to its end)
             live = 0;
-            for (size_t k = 0; k < lanes; ++k) {
+            for (size_t j = 0; j < lanes; ++j) {
+                // HIPEMU_ORDER: between two barriers the lanes of a workgroup may run in any order - forward (default), reverse, or a
+                // different rotation + direction every pass; code that is missing a barrier passes in one order and fails in another
+                size_t k = j;
+                if (lane_order == 1) k = lanes - 1 - j;
+                else if (lane_order == 2) { const size_t rot = (pass * 7919 + b * 104729) % lanes; k = ((pass + b) & 1) ? (lanes - 1 - j + rot) % lanes : (j + rot) % lanes; }
                 Fiber &f = fibers[k];
                 if (f.done) continue;
                 current = &f;

@@ -29,7 +29,9 @@ def emulated_library():
 
 
 def run_gpu_tests_on_host(lib, args, timeout=1500):
-    env = dict(os.environ, SS_TEST_HIPEMU="1", SS_TEST_HIPEMU_LIB=lib)
+    # HIPEMU_ORDER=shuffle: between two barriers the lanes of a workgroup run in an order that changes with every pass and workgroup
+    # (any order is a legal schedule; code that is missing a barrier passes in one and fails in another)
+    env = dict(os.environ, SS_TEST_HIPEMU="1", SS_TEST_HIPEMU_LIB=lib, HIPEMU_ORDER=os.environ.get("HIPEMU_ORDER", "shuffle"))
     out = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=timeout)
     tail = out.stdout[-3000:] + out.stderr[-2000:]
