@@ -5,7 +5,10 @@ set -e
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd)
 CXX=${HIPEMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}          # clang: the sources use ext_vector_type / address_space attributes
 OUT=${HIPEMU_OUT:-$HERE/_build}; mkdir -p $OUT
-FLAGS="-x c++ -std=c++17 -O2 -fPIC -w -I $HERE -I $ROOT/include -I $ROOT/sandstorm_amd/csrc"
+# HIPEMU_SANITIZE=address: an AddressSanitizer build (out-of-bounds reads / writes of "device" buffers and LDS arrays inside kernels);
+# run with LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0
+SAN=${HIPEMU_SANITIZE:+-fsanitize=$HIPEMU_SANITIZE -fno-omit-frame-pointer -g1}
+FLAGS="-x c++ -std=c++17 -O2 -fPIC -w $SAN -I $HERE -I $ROOT/include -I $ROOT/sandstorm_amd/csrc"
 SRCS="capi ntt hash pedersen fri deep quotient ext goldilocks quotient_gen_starknet quotient_gen_recursive"
 pids=()
 for f in $SRCS; do
@@ -16,6 +19,6 @@ for f in $SRCS; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$CXX -std=c++17 -O2 -fPIC -w -I $HERE -c $HERE/hipemu.cpp -o $OUT/hipemu.o
-$CXX -shared -fPIC -pthread -o $OUT/libsandstorm_hipemu.so $OUT/hipemu.o $(for f in $SRCS; do echo $OUT/$f.o; done)
+$CXX -std=c++17 -O2 -fPIC -w $SAN -I $HERE -c $HERE/hipemu.cpp -o $OUT/hipemu.o
+$CXX -shared -fPIC -pthread $SAN ${HIPEMU_SANITIZE:+-shared-libsan} -o $OUT/libsandstorm_hipemu.so $OUT/hipemu.o $(for f in $SRCS; do echo $OUT/$f.o; done)
 echo $OUT/libsandstorm_hipemu.so
