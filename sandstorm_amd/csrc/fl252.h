@@ -98,7 +98,7 @@ SS_HD Fl fl_weak_reduce(const Fl &a) {
     for (int i = 1; i < 6; ++i) { t = (int)n.l[i] + c; r.l[i] = (u32)t & FL_MASK; c = t >> 28; }
     t = (int)n.l[6] - (q << 24) + c; r.l[6] = (u32)t & FL_MASK; c = t >> 28;
     t = (int)n.l[7] - q + c;         r.l[7] = (u32)t & FL_MASK; c = t >> 28;
-    r.l[8] = (u32)((int)n.l[8] - (q << 27) + c);
+    r.l[8] = n.l[8] - ((u32)q << 27) + (u32)c;           // unsigned: the top limb of a value near 2^256 is above 2^31 (wraps are meant)
     return r;
 }
 

@@ -114,7 +114,7 @@ SS_HD Fp sg_inverse_canonical(const Fp &x) {
         int wi = 0;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            acc += (int64_t)d.v[i] << bitpos;       // limbs 0..7 are in [0, 2^30); limb 8 is signed
+            acc += (int64_t)d.v[i] * ((int64_t)1 << bitpos);   // limbs 0..7 are in [0, 2^30); limb 8 is signed (a product: shifting a negative value left is undefined before C++20)
             bitpos += 30;
             if (bitpos >= 32 && wi < 9) {
                 w[wi++] = (uint32_t)acc;
