@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("SS_TEST_HOSTLIB"):
+        # a sanitizer build of the C++ host (sandstorm_amd/host: plain C++) for a session of its own: see tests/hipemu/README.md
+        from sandstorm_amd import hostlib
+        hostlib.LIB_PATH = os.environ["SS_TEST_HOSTLIB"]
     if os.environ.get("SS_TEST_HIPEMU") == "1":
         # tests/test_device_code_on_host.py runs selected `gpu` tests in a process of their own against the HOST BUILD OF THE DEVICE
         # CODE (tests/hipemu: test infrastructure; same C ABI, kernels executed lane by lane on the CPU).  Only this test session
