@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("SS_TEST_ORACLELIB"):                  # likewise a sanitizer build of the oracle's C
+        from oracle import oracle_py
+        oracle_py._SO = os.environ["SS_TEST_ORACLELIB"]
     if os.environ.get("SS_TEST_HOSTLIB"):
         # a sanitizer build of the C++ host (sandstorm_amd/host: plain C++) for a session of its own: see tests/hipemu/README.md
         from sandstorm_amd import hostlib
