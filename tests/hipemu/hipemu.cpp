@@ -60,6 +60,7 @@ thread_local void *sched_sp = nullptr;
 thread_local Fiber *current = nullptr;
 thread_local const std::function<void()> *body = nullptr;
 thread_local std::vector<int> exchange;                      // __shfl_xor: one word per lane of the workgroup
+const int block_order = [] { const char *e = getenv("HIPEMU_BLOCKS"); return e && e[0] == 'r' ? 1 : 0; }();
 const int lane_order = [] { const char *e = getenv("HIPEMU_ORDER"); return !e ? 0 : e[0] == 'r' ? 1 : e[0] == 's' ? 2 : 0; }();   // forward / reverse / shuffle
 
 void fiber_main() {
@@ -105,7 +106,9 @@ void run_blocks(dim3 grid, dim3 block, const std::function<void()> &lane_body, u
     exchange.assign(lanes, 0);
     body = &lane_body;
     gridDim = grid; blockDim = block;
-    for (uint64_t b = first; b < last; ++b) {
+    for (uint64_t bb = first; bb < last; ++bb) {
+        // HIPEMU_BLOCKS=reverse: workgroups in descending order (with HIPEMU_THREADS=1: strictly) - nothing may depend on the order
+        const uint64_t b = block_order ? first + (last - 1 - bb) : bb;
         blockIdx = {(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((uint64_t)grid.x * grid.y))};
         size_t i = 0;
         for (unsigned tz = 0; tz < block.z; ++tz)
