@@ -28,6 +28,12 @@ def emulated_library():
     return out.stdout.strip().splitlines()[-1]
 
 
+def heavy():
+    """the selections that take minutes without a handful of cores (workgroups are spread over OS threads): skipped on small machines"""
+    if (os.cpu_count() or 1) < 4 and os.environ.get("SS_TEST_HIPEMU_ALL") != "1":
+        pytest.skip("fewer than 4 cores: set SS_TEST_HIPEMU_ALL=1 to run this selection anyway")
+
+
 def run_gpu_tests_on_host(lib, args, timeout=1500):
     # HIPEMU_ORDER=shuffle: between two barriers the lanes of a workgroup run in an order that changes with every pass and workgroup
     # (any order is a legal schedule; code that is missing a barrier passes in one and fails in another)
@@ -68,18 +74,21 @@ def test_the_64_bit_field(emulated_library):
 def test_extension_columns_and_compiled_constraint_kernels(emulated_library):
     """tests/test_gpu_extension.py (the scans behind Trace::build_extension_columns) and tests/test_gpu_real_quotient.py (the generated
     starknet / recursive kernels against the interpreter and the oracle over whole domains)"""
+    heavy()
     out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_extension.py", "tests/test_gpu_real_quotient.py", "-k", "not first_large_evaluation"])
     assert "41 passed" in out, out[-500:]                     # 36 + 5 (the sixth times two kernels against each other: hardware only)
 
 
 def test_whole_proofs(emulated_library):
     """tests/test_gpu_prove.py: prove -> serialise -> verify on the mini AIR, both hosts, every tree and coin"""
+    heavy()
     run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_prove.py"])
 
 
 def test_one_proof_over_several_ranks(emulated_library):
     """tests/hipemu/extra_sharded.py: the sharded driver (torch.distributed / gloo) with the device code on every rank writes the
     single-device proof byte for byte - the reference's example with the real recursive AIR on 2 ranks, the mini AIR on 4"""
+    heavy()
     out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_sharded.py", "tests/hipemu/extra_sharded.py", "-k", "row_block_forms or (device_code_on_every_rank and (example-2 or 4-4))"])
     assert "3 passed" in out, out[-500:]                      # + the row-block entry points against the whole-domain ones (halo, refusal, DEEP blocks + extension)
 
