@@ -12,7 +12,11 @@ random columns; the AIR is the layout's REAL composition constraint (195 constra
 / 269 mask cells for starknet, 93 / 133 for recursive: sandstorm_amd/host/air_*.cpp,
 the program the reference's own proof verifies under) - a constraint program does
 not depend on the trace's contents, and every stage's cost is data-independent.
-`--air synthetic` keeps round 1's layout-shaped stand-in for comparison.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks
+(torch.distributed.run, one per GPU) and prints rank 0's line; under an external launcher it runs as one rank.
+The default run (starknet_2p20, one GPU) also times the north-star's own configuration - recursive layout, 2^20 steps,
+CairoVerifierClaim - for a few proofs and reports it as `north_star` in the same line.
 
 Prints ONE JSON line on rank 0: prove wall-time (s), plus the Fp NTT rate,
 `roofline` (NTT pass kernel, HIP-event timed inside the same K proofs) and
@@ -416,17 +420,12 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
         dist.barrier()
         torch.cuda.synchronize()
     proof = prover.prove(seed, mine, build_extension, n)
-    for _ in range(args.warmup):
-        prover.prove(seed, mine, build_extension, n)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        prover.prove(seed, mine, build_extension, n)
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    sec = float(tmax.item()) / args.steps
+
+    def all_max(dt):
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+    sec = timed_steps(lambda: prover.prove(seed, mine, build_extension, n), args.steps, args.warmup, barrier, all_max)
     if rank == 0:
         emit({
             "metric": "prove_wall_time_s", "value": sec, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -449,60 +448,81 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="starknet_2p20", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="auto", choices=["auto", "shard", "replicas"],
-                    help="N > 1 GPUs: shard = ONE proof over the N GPUs (column-sharded LDE, row-block hashing / constraints / DEEP, "
-                         "RCCL point-to-point re-shards; strong scaling) - the default; replicas = one independent proof per GPU (weak scaling)")
-    ap.add_argument("--air", default="real", choices=["real", "synthetic"],
-                    help="real: the layout's own composition constraint (default); synthetic: round 1's layout-shaped stand-in")
-    args = ap.parse_args()
-    _claim_stdout()
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # a rank that fails must not leave the others in a collective for the default ten minutes
-        import datetime
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=300))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
-    from sandstorm_amd import backend as be, extension, hostlib
+def self_launch(args):
+    """`python bench.py --gpus N` as typed (no launcher around it): start the N ranks - one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 - wait for them and pass rank 0's ONE JSON line through (every rank's
+    stdout is this process's; only rank 0 writes to it).  -> the exit code."""
+    import subprocess
+    selftest = os.environ.get("SS_BENCH_SELFTEST") == "1"
+    if not selftest:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write("bench.py --gpus %d: this node has %d GPU(s); one rank per GPU is the only mode\n" % (args.gpus, have))
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def timed_steps(step, steps, warmup, barrier, all_max):
+    """the timing protocol of the contract: `warmup` untimed steps, a barrier + device sync, EXACTLY `steps` steps, a barrier
+    + device sync, the MAX over ranks.  -> seconds per step"""
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return all_max(time.perf_counter() - t0) / steps
+
+
+def stage_algorithmic_bytes(nb, ne, log_n, lb, fri_layers, fold=8):
+    """SURVEY.md 8d's algorithmic HBM bytes per proof and stage (every datum read once, every result written once)"""
+    n, N, C = 1 << log_n, 1 << (log_n + lb), nb + ne
+    out = {"quotient": 32.0 * (C + 1) * N,                                   # every trace cell once + the composition evaluations
+           "deep": 32.0 * ((C + 2) * n + n),                                 # composed on the n-point sub-coset (DESIGN.md section 4)
+           "ntt_pass": 32.0 * (C * (2 * n + 2 * N) + 3 * 2 * N + C * 2 * n)}   # 2 N e per transform: trace LDE, composition, OOD
+    hashed = [(nb, N)] + ([(ne, N)] if ne > 1 else []) + [(2, N)]
+    trees = [N, N, N] if ne else [N, N]
+    fri = 0.0
+    L = N
+    for _ in range(fri_layers):
+        hashed.append((fold, L // fold))
+        trees.append(L // fold)
+        fri += 32.0 * (L + L // fold)
+        L //= fold
+    out["hash_rows"] = float(sum(rows * (c * 32 + 32) for c, rows in hashed))
+    out["merkle"] = float(sum(3 * 32 * (leaves - 1) for leaves in trees))
+    out["fri_fold"] = fri
+    return out
+
+
+def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, cpu_leg):
+    """K whole proofs of one workload through the C++ host on this rank's GPU -> the report (rank 0) or None"""
+    from sandstorm_amd import backend as be, extension, hostlib, public_input
     from sandstorm_amd.prover import ProofOptions
-
-    layout, log_steps = WORKLOADS[args.workload]
-    if layout == "goldilocks":
-        return bench_goldilocks(args, log_steps, rank, local_rank, world, device)
-    if layout == "goldilocks-plain":
-        return bench_goldilocks_plain(args, log_steps, rank, local_rank, world, device)
-    if (world > 1 and args.mode == "auto" or args.mode == "shard") and layout in ("starknet", "recursive"):
-        if world == 1:                      # --mode shard on one GPU: the sharded driver with a group of one (smoke / profiling)
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29512")
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
-        return bench_sharded(args, layout, log_steps, rank, local_rank, world, device)
+    layout, log_steps = WORKLOADS[workload]
     log_n, lb = log_steps + 4, 1
     n = 1 << log_n
     ctx = be.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     real = layout == "recursive-real"
+    pi = public_input.AirPublicInput.from_json(os.path.join(ROOT, "tests", "golden", "air_public_input_array_sum.json"))
     if real:
         # the reference's example: raw files -> base trace on the host (C++) -> HBM; the real 93-constraint AIR; the seed
         # from its air-public-input.json; CairoVerifierClaim as the CLI picks for this layout (cli/src/main.rs:95-99)
-        from sandstorm_amd import public_input
         layout = "recursive"
         ex = os.path.join(ROOT, "tests", "golden", "example")
-        pi = public_input.AirPublicInput.from_json(os.path.join(ROOT, "tests", "golden", "air_public_input_array_sum.json"))
         with open(os.path.join(ex, "trace.bin"), "rb") as fh:
             trace_bin = fh.read()
         with open(os.path.join(ex, "memory.bin"), "rb") as fh:
@@ -523,25 +543,17 @@ def main():
             keep.append(hostlib.build_extension_columns(ctx, "recursive", aux_cols, n, challenges))      # check=True: real permutations
             return keep[0].cols
     else:
-        # the C++ host side (libsandstorm_host.so): coin, Expr lowering, prover, the layout's AIR
-        if args.air == "real":
-            # the statement's public input only feeds constants of the program (hints, public memory product): the
-            # reference's example run re-declared for this layout and step count
-            from sandstorm_amd import public_input
-            pi = public_input.AirPublicInput.from_json(os.path.join(ROOT, "tests", "golden", "air_public_input_array_sum.json"))
-            pi.n_steps = 1 << log_steps
-            if layout == "starknet":
-                from sandstorm_amd.layouts import starknet as sk
-                air = hostlib.StarknetHostAir(ctx, sk.example_public_input(pi), log_n, lb)
-            else:
-                air = hostlib.RecursiveHostAir(ctx, pi, log_n, lb)
+        # the C++ host side (libsandstorm_host.so): coin, Expr lowering, prover, the layout's REAL AIR.  The statement's public
+        # input only feeds constants of the program (hints, public memory product): the reference's example run re-declared
+        # for this layout and step count
+        pi.n_steps = 1 << log_steps
+        if layout == "starknet":
+            from sandstorm_amd.layouts import starknet as sk
+            air = hostlib.StarknetHostAir(ctx, sk.example_public_input(pi), log_n, lb)
+            tree_kind, n_friendly, coin_kind = be.TREE_KECCAK_M20, 0, be.COIN_SOLIDITY        # cli/src/main.rs:90-94 -> EthVerifierClaim
         else:
-            air = hostlib.HostAir(ctx, hostlib.AIR_SYNTHETIC_RECURSIVE if layout == "recursive" else hostlib.AIR_SYNTHETIC_STARKNET, log_n, lb)
-        if layout == "recursive":       # cli/src/main.rs:95-99 -> CairoVerifierClaim
-            tree_kind, n_friendly, coin_kind = be.TREE_FRIENDLY, 22, be.COIN_CAIRO
-        else:                           # cli/src/main.rs:90-94 -> EthVerifierClaim
-            tree_kind, n_friendly, coin_kind = be.TREE_KECCAK_M20, 0, be.COIN_SOLIDITY
-
+            air = hostlib.RecursiveHostAir(ctx, pi, log_n, lb)
+            tree_kind, n_friendly, coin_kind = be.TREE_FRIENDLY, 22, be.COIN_CAIRO           # cli/src/main.rs:95-99 -> CairoVerifierClaim
         # inputs resident in HBM before the timed region; one independent trace per rank (weak scaling)
         base_t = synth_columns(device, air.num_base_columns, log_n, seed=0x53414E44 + rank)
         base_cols = [base_t[c] for c in range(air.num_base_columns)]
@@ -567,85 +579,172 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    proof = step(want_proof=True)         # untimed: metadata for the report (also warms every plan and table)
-    for _ in range(args.warmup):          # also builds the twiddle plans and Pedersen tables
+    def all_max(dt):
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    proof = step(want_proof=True)         # untimed: metadata for the report (also builds every plan and table)
+    for _ in range(warmup):
         step()
     barrier()
     ctx.profile(True)
     ctx.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    sec_per_proof = timed_steps(step, steps, 0, barrier, all_max)
     kinds = [("ntt_pass", be.PROF_NTT_PASS), ("hash_rows", be.PROF_HASH_ROWS), ("merkle", be.PROF_MERKLE),
              ("fri_fold", be.PROF_FRI), ("quotient", be.PROF_QUOTIENT), ("deep", be.PROF_DEEP),
              ("extension_scans", be.PROF_EXT)]
     prof = {name: ctx.profile_read(k) for name, k in kinds}
     ctx.profile(False)
-
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    sec_per_proof = dt / args.steps
-
+    out = None
     if rank == 0:
-        ncols = air.num_base_columns + air.num_extension_columns
+        nb, ne = air.num_base_columns, air.num_extension_columns
+        ncols = nb + ne
         N = n << lb
         # NTT work inside one proof: trace LDE (iNTT n + NTT N per column), composition (iNTT N, 2 x NTT N),
         # OOD (NTT n per column), FRI remainder (tiny)
         ntt_ops = ncols * (ntt_field_ops(log_n) + ntt_field_ops(log_n + lb)) + 3 * ntt_field_ops(log_n + lb) \
             + ncols * ntt_field_ops(log_n)
-        algo_bytes = 32.0 * (ncols * (2 * n + 2 * N) + 3 * 2 * N + ncols * 2 * n)     # 2*N*32 B per transform
+        algo = stage_algorithmic_bytes(nb, ne, log_n, lb, len(proof.fri_layers))
+        stage_ms = {k: v[0] / steps for k, v in prof.items()}
         ntt_ms, ntt_launches = prof["ntt_pass"]
-        ntt_s = ntt_ms * 1e-3 / args.steps
-        achieved = algo_bytes / ntt_s / 1e9 if ntt_s > 0 else 0.0
-        # HBM bytes per launch from the PMC passes of this workload (FETCH_SIZE / WRITE_SIZE cannot be read
-        # live; tools/profile_round.sh collects them, the committed summary is cited here)
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
+        ntt_s = ntt_ms * 1e-3 / steps
+
+        def stage_roofline(name, kernel, note):
+            sec = stage_ms[name] * 1e-3
+            ach = algo[name] / sec / 1e9 if sec > 0 else 0.0
+            # HBM bytes per launch from the PMC passes of this workload (FETCH_SIZE / WRITE_SIZE cannot be read live;
+            # tools/profile_round.sh collects them per kernel, the committed summary is cited here)
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % workload)
+            if os.path.exists(tpath):
+                with open(tpath) as fh:
+                    tj = json.load(fh)
+                ent = tj.get("kernels", {}).get(name) or (tj if name == "ntt_pass" else None)
+                if ent:
+                    traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source", tj.get("source"))
+            launches = prof[name][1]
+            return {"bound": "hbm", "kernel": kernel, "stage": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_proof": algo[name], "algorithmic_bytes_per_launch": algo[name] / max(1.0, launches / steps),
+                    "launches": launches, "avg_launch_ms": prof[name][0] / max(1, launches), "stage_ms_per_proof": stage_ms[name], "note": note}
+        dominant = max(("quotient", "ntt_pass", "deep", "merkle", "hash_rows"), key=lambda k: stage_ms[k])
+        kernel_of = {"quotient": "ss::quotient_%s_kernel" % layout, "ntt_pass": "ss::ntt_pass_kernel", "deep": "ss::deep_kernel",
+                     "merkle": "ss::pedersen_*_kernel + blake2s pairs" if layout == "recursive" else "ss::keccak_pairs_kernel",
+                     "hash_rows": "ss::blake2s_rows_kernel" if layout == "recursive" else "ss::keccak_rows_kernel"}
         out = {
             "metric": "prove_wall_time_s", "value": sec_per_proof, "unit": "s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_proof * 1e3,
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": sec_per_proof * 1e3,
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "u256 (Fp252, Montgomery R=2^256, 8 x u32 limbs)", "data": "synthetic",
             "proofs_per_s": world / sec_per_proof,
             "ntt_gfield_ops_per_s": ntt_ops / ntt_s / 1e9 if ntt_s > 0 else 0.0,
-            "config": {"workload": args.workload, "layout_shape": layout, "steps_log2": log_steps,
-                       "trace_rows_log2": log_n, "columns": "%d base + %d extension" % (air.num_base_columns, air.num_extension_columns),
+            "ntt_gbutterflies_per_s": ntt_ops / 3 / ntt_s / 1e9 if ntt_s > 0 else 0.0,
+            "config": {"workload": workload, "layout_shape": layout, "steps_log2": log_steps,
+                       "trace_rows_log2": log_n, "columns": "%d base + %d extension" % (nb, ne),
                        "claim": "CairoVerifierClaim (Blake2s+Pedersen-22 tree, Cairo coin)" if layout == "recursive"
                                 else "EthVerifierClaim (Keccak-masked-20 tree, Solidity coin)",
                        "air": ("the REAL recursive AIR (93 constraints, %d mask cells: sandstorm_amd/host/air_recursive.cpp) on the reference's "
                                "example run; base trace generated by the C++ host in %.3f s (outside the timed region)" % (air.mask_size, trace_gen_s))
                               if real else
                               ("the REAL %s AIR (%s, %d mask cells: sandstorm_amd/host/air_%s.cpp) on synthetic columns" %
-                               (layout, "195 constraints" if layout == "starknet" else "93 constraints", air.mask_size, layout))
-                              if args.air == "real" else
-                              "SYNTHETIC constraint set with the layout's shape: %d mask cells, see sandstorm_amd/synthetic_air.py" % air.mask_size,
+                               (layout, "195 constraints" if layout == "starknet" else "93 constraints", air.mask_size, layout)),
                        "proof_options": "65 queries, blowup 2, 16 PoW bits, FRI fold 8, <=16 remainder coeffs",
                        "in_timed_region": "LDE x2, extension-column scans (A2), commits x3, quotient, composition LDE, OOD, DEEP, FRI, PoW, openings",
                        "outside": "host trace generation (A1): base and auxiliary columns are resident in HBM",
                        "per_gpu": "one independent proof per rank",
                        "host": "C++ prover (sandstorm_amd/host, libsandstorm_host.so) through ctypes",
                        "fri_layers": len(proof.fri_layers), "pow_nonce": proof.pow_nonce},
-            "stage_ms_per_proof": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
-            "roofline": {"bound": "hbm", "kernel": "ss::ntt_pass_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": algo_bytes / max(1.0, ntt_launches / args.steps),
-                         "launches": ntt_launches, "avg_launch_ms": ntt_ms / max(1, ntt_launches),
-                         "note": "algorithmic bytes = 2*N*32 B per transform (SURVEY 8d), shared by its passes; "
-                                 "Fp252 butterflies are integer-ALU bound before HBM bound (DESIGN.md)"},
+            "stage_ms_per_proof": {k: round(v, 3) for k, v in stage_ms.items()},
+            "roofline": dict(stage_roofline("ntt_pass", "ss::ntt_pass_kernel",
+                                            "the kernel north_star names.  algorithmic bytes = 2*N*32 B per transform (SURVEY 8d), shared by "
+                                            "its passes; Fp252 butterflies are integer-ALU bound before HBM bound (DESIGN.md section 3): "
+                                            "`gbutterflies_per_s` against the 135 G/s of a bare butterfly loop (tools/mulbench.hip)"),
+                             gbutterflies_per_s=ntt_ops / 3 / ntt_s / 1e9 if ntt_s > 0 else 0.0, butterfly_ceiling_g_per_s=135.0),
+            "roofline_dominant": stage_roofline(dominant, kernel_of[dominant],
+                                                "the stage with the largest share of the proof, same computation as `roofline` (SURVEY 8d bytes / "
+                                                "HIP-event time of the stage's launches)"),
         }
-        if args.workload == "recursive_2p7":
+        if workload == "recursive_2p7":
             out["config"]["reference_published"] = ("186 ms for the 128-step array-sum proof on the author's machine "
                                                     "(BASELINE.md section 1: other hardware, older CLI, the real AIR)")
-        if not args.no_cpu_baseline and world == 1:
+        if cpu_leg:
             out["cpu_baseline"] = cpu_baseline(layout, log_steps, ctx)
+    if not real:
+        del base_t, aux_t
+    del base_cols
+    air.close()
+    ctx.close()
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="starknet_2p20", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the recursive_2p20 leg of the default run")
+    ap.add_argument("--mode", default="auto", choices=["auto", "shard", "replicas"],
+                    help="N > 1 GPUs: shard = ONE proof over the N GPUs (column-sharded LDE, row-block hashing / constraints / DEEP, "
+                         "RCCL point-to-point re-shards; strong scaling) - the default; replicas = one independent proof per GPU (weak scaling)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    _claim_stdout()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d inside a group of %d ranks: launch with --nproc-per-node %d (or run it bare and let it "
+                 "launch its own ranks)" % (args.gpus, world, args.gpus))
+    if os.environ.get("SS_BENCH_SELFTEST") == "1":
+        # tests/test_bench_launcher.py: this file's launcher, rendezvous, timing protocol and one-line contract on gloo ranks,
+        # the sharded driver over the CPU oracle (test infrastructure, imported from tests/ only) - never a measurement
+        from tests import bench_selftest
+        return bench_selftest.run(args, rank, world, timed_steps, emit)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a rank that fails must not leave the others in a collective for the default ten minutes
+        import datetime
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=300))
+
+    layout, log_steps = WORKLOADS[args.workload]
+    if layout == "goldilocks":
+        return bench_goldilocks(args, log_steps, rank, local_rank, world, device)
+    if layout == "goldilocks-plain":
+        return bench_goldilocks_plain(args, log_steps, rank, local_rank, world, device)
+    if (world > 1 and args.mode == "auto" or args.mode == "shard") and layout in ("starknet", "recursive"):
+        if world == 1:                      # --mode shard on one GPU: the sharded driver with a group of one (smoke / profiling)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        return bench_sharded(args, layout, log_steps, rank, local_rank, world, device)
+    out = bench_proof(args, args.workload, rank, local_rank, world, device, args.steps, args.warmup,
+                      cpu_leg=not args.no_cpu_baseline and world == 1)
+    if rank == 0 and world == 1 and args.workload == "starknet_2p20" and not args.no_north_star:
+        # north_star's own target beside BASELINE's metric configuration: recursive layout, 2^20 steps, the CLI's claim for it
+        # (cli/src/main.rs:95-99: FriendlyMerkleTree<22> + Cairo coin), the same protocol on fewer proofs, in the same run
+        ns = bench_proof(args, "recursive_2p20", rank, local_rank, world, device, min(3, args.steps), 1,
+                         cpu_leg=not args.no_cpu_baseline)
+        out["north_star"] = {"workload": "recursive_2p20", "value": ns["value"], "unit": "s", "steps": ns["steps"], "warmup": ns["warmup"],
+                             "claim": ns["config"]["claim"], "air": ns["config"]["air"], "stage_ms_per_proof": ns["stage_ms_per_proof"],
+                             "ntt_gfield_ops_per_s": ns["ntt_gfield_ops_per_s"], "roofline": ns["roofline"],
+                             "roofline_dominant": ns["roofline_dominant"], "cpu_baseline": ns.get("cpu_baseline"),
+                             "target": ">= 10x the CPU prover's end-to-end time at 1 GPU (BASELINE.json north_star); cpu_baseline here "
+                                       "is the oracle port, not the reference binary"}
+    if rank == 0:
         emit(out)
     if world > 1:
         dist.destroy_process_group()

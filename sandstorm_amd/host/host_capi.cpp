@@ -25,11 +25,11 @@ typedef int (*ssh_extension_cb)(void *user, const uint64_t *challenges, uint32_t
 
 const char *ssh_last_error(void) { return g_err.c_str(); }
 
-// kind: 0 = mini, 1 = synthetic recursive, 2 = synthetic starknet
+// kind: 0 = the mini AIR of the end-to-end tests (the layouts' AIRs: ssh_air_create_recursive / _starknet)
 int ssh_air_create(ss_ctx *ctx, int kind, uint32_t log_n, uint32_t log_blowup, ssh_air **out) {
     try {
-        std::unique_ptr<Air> a = kind == 0 ? make_mini_air(ctx)
-                                           : make_synthetic_air(ctx, kind == 1 ? "recursive" : "starknet", log_n, log_blowup, 3);
+        if (kind != 0) throw std::runtime_error("ssh_air_create: unknown AIR kind");
+        std::unique_ptr<Air> a = make_mini_air(ctx);
         *out = reinterpret_cast<ssh_air *>(a.release());
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
@@ -306,10 +306,11 @@ uint32_t ssh_air_num_challenges(ssh_air *air_h) { return reinterpret_cast<Air *>
 // remainder) with the bare draw as FRI challenge (round-1 proofs), 2 = the reference's (the FRI challenge is the draw times
 // the layer offset), 0 = the older path's.  required_security_bits: cli/src/main.rs:66-67 (default 80 there).
 // expected_options (nullable): the five ProofOptions the proof must carry.  positions_out (nullable): room for num_queries
-// values; *n_positions is set.
+// values; *n_positions is set.  n_friendly_layers: the N of FriendlyMerkleTree<N, _> (src/claims.rs:10: 22), read for
+// SS_TREE_FRIENDLY only - the value the proof was made with (ssh_prove*'s argument of the same name).
 int ssh_verify(ssh_air *air_h, int tree_kind, int coin_kind, const uint8_t seed[32], const uint8_t *proof, uint64_t proof_len,
                int conventions, uint32_t required_security_bits, const uint32_t *expected_options, uint64_t *positions_out,
-               uint32_t *n_positions) {
+               uint32_t *n_positions, uint32_t n_friendly_layers) {
     try {
         Air *air = reinterpret_cast<Air *>(air_h);
         Digest sd;
@@ -323,7 +324,7 @@ int ssh_verify(ssh_air *air_h, int tree_kind, int coin_kind, const uint8_t seed[
             exp.num_queries = expected_options[0]; exp.lde_blowup_factor = expected_options[1]; exp.grinding_factor = expected_options[2];
             exp.fri_folding_factor = expected_options[3]; exp.fri_max_remainder_coeffs = expected_options[4];
         }
-        const std::vector<uint64_t> pos = verify(w, *air, tree_kind, coin_kind, sd, conv, required_security_bits, expected_options ? &exp : nullptr);
+        const std::vector<uint64_t> pos = verify(w, *air, tree_kind, coin_kind, sd, conv, required_security_bits, expected_options ? &exp : nullptr, n_friendly_layers);
         if (positions_out && n_positions) { memcpy(positions_out, pos.data(), pos.size() * 8); *n_positions = (uint32_t)pos.size(); }
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }

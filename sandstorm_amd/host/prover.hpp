@@ -172,7 +172,5 @@ struct AirPublicInput;
 std::unique_ptr<Air> make_recursive_air(ss_ctx *ctx, const AirPublicInput &pi, uint32_t log_n, uint32_t log_blowup, uint64_t lde_offset);
 std::unique_ptr<Air> make_starknet_air(ss_ctx *ctx, const AirPublicInput &pi, uint32_t log_n, uint32_t log_blowup, uint64_t lde_offset);
 std::vector<uint64_t> layout_air_tables(const Air &air);         // table descriptions of a layout AIR (host-side checks)
-std::unique_ptr<Air> make_synthetic_air(ss_ctx *ctx, const std::string &layout, uint32_t log_n, uint32_t log_blowup,
-                                        uint64_t lde_offset);                      // layout-shaped, for bench.py
 
 }  // namespace ssh

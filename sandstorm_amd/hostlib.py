@@ -12,7 +12,7 @@ from .prover import FriLayer, Proof, ProofOptions
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libsandstorm_host.so")
-AIR_MINI, AIR_SYNTHETIC_RECURSIVE, AIR_SYNTHETIC_STARKNET = 0, 1, 2
+AIR_MINI = 0
 EXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p))
 
 _host = None
@@ -51,7 +51,7 @@ def load():
         h.ssh_air_dump.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64),
                                    C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
         h.ssh_verify.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.c_uint32,
-                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint32]
         h.ssh_matrix_num_cols.argtypes = [C.c_void_p]
         h.ssh_matrix_num_cols.restype = C.c_uint32
         h.ssh_matrix_col.argtypes = [C.c_void_p, C.c_uint32]
@@ -418,7 +418,7 @@ def starknet_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=N
 
 
 def verify(air: HostAir, tree_kind, coin_kind, seed, proof: bytes, shipped_conventions=True, fri_alpha_times_offset=True,
-           required_security_bits=80, expected_options=None):
+           required_security_bits=80, expected_options=None, n_friendly_layers=22):
     """the C++ host's verifier (sandstorm_amd/host/verifier.cpp) on a proof in the reference's wire format; raises
     SandstormHipError naming the failed check, returns the query positions.  required_security_bits / expected_options:
     as sandstorm_amd.verifier.verify"""
@@ -430,7 +430,7 @@ def verify(air: HostAir, tree_kind, coin_kind, seed, proof: bytes, shipped_conve
         exp = (C.c_uint32 * 5)(*(o if isinstance(o, (list, tuple)) else
                                  [o.num_queries, o.lde_blowup_factor, o.grinding_factor, o.fri_folding_factor, o.fri_max_remainder_coeffs]))
     _check(load().ssh_verify(air.h, tree_kind, coin_kind, bytes(seed), bytes(proof), len(proof), (2 if fri_alpha_times_offset else 1) if shipped_conventions else 0,
-                             required_security_bits, exp, pos.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(npos)))
+                             required_security_bits, exp, pos.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(npos), int(n_friendly_layers)))
     return [int(v) for v in pos[:npos.value]]
 
 

@@ -61,25 +61,49 @@ class Comm:
         self.device = device                        # torch device of the exchanged tensors
         self.stage_through_host = dist.get_backend() == "gloo" and device is not None and _torch().device(device).type == "cuda"
         if self.world > 1 and dist.get_backend() == "nccl":
-            # one collective before the first point-to-point batch: RCCL builds its communicators collectively, and a P2P
-            # batch that only some ranks enter must not be the call that triggers it
+            # RCCL builds its communicators at the first collective: outside any timed region
             dist.all_reduce(_torch().zeros(1, device=device))
 
     def exchange(self, sends, recvs):
-        """sends / recvs: [(peer, tensor)] in a fixed, globally agreed order per pair of ranks.  Point-to-point, all
-        posted at once: on xGMI every pair of GPUs has its own link, so the R (R-1) transfers of a re-shard run concurrently."""
-        dist = self.dist
-        staged = []
-        if self.stage_through_host:                 # gloo moves host memory only (ranks sharing one GPU in the tests)
-            sends = [(p, t.cpu()) for p, t in sends]
-            staged = [(t, t.cpu()) for _, t in recvs]
-            recvs = [(p, h) for (p, _), (_, h) in zip(recvs, staged)]
-        ops = [dist.P2POp(dist.isend, t, p) for p, t in sends] + [dist.P2POp(dist.irecv, t, p) for p, t in recvs]
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for dev, host in staged:
-            dev.copy_(host)
+        """sends / recvs: [(peer, tensor)] in a fixed, globally agreed order per pair of ranks.  ONE all-to-all with uneven
+        splits that EVERY rank enters, whatever it has to send or receive (a rank with nothing for a peer contributes a
+        zero-length split): over RCCL an all-to-all is a grouped send/recv per pair - on xGMI every pair of GPUs has its own
+        link, so the R (R-1) transfers run concurrently, nothing is a ring - and a collective all ranks enter cannot
+        dead-lock the way one-sided point-to-point batches can (rank 0 only receiving while the others only send)."""
+        torch, dist, R = _torch(), self.dist, self.world
+        if R == 1:
+            assert not sends and not recvs
+            return
+
+        def words(t):                               # every exchanged buffer is a whole number of 8-byte words (felts, digests)
+            assert t.is_contiguous() and (t.numel() * t.element_size()) % 8 == 0
+            return t.view(torch.int64).reshape(-1) if t.dtype != torch.int64 else t.reshape(-1)
+        out_parts, in_views = [[] for _ in range(R)], [[] for _ in range(R)]
+        for p, t in sends:
+            out_parts[p].append(words(t))
+        for p, t in recvs:
+            in_views[p].append(words(t))
+        in_splits = [sum(v.numel() for v in out_parts[p]) for p in range(R)]        # what this rank puts in, per destination
+        out_splits = [sum(v.numel() for v in in_views[p]) for p in range(R)]        # what it gets out, per source
+        dev = "cpu" if self.stage_through_host else self.device     # gloo moves host memory only (ranks sharing one GPU in the tests)
+        flat_in = [v.to(dev) for p in range(R) for v in out_parts[p]]
+        src = torch.cat(flat_in) if flat_in else torch.zeros(0, dtype=torch.int64, device=dev)
+        dst = torch.zeros(sum(out_splits), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(dst, src, out_splits, in_splits)
+        o = 0
+        for p in range(R):
+            for v in in_views[p]:
+                v.copy_(dst[o:o + v.numel()])
+                o += v.numel()
+
+    def all_to_all_equal(self, dst, src):
+        """equal splits: chunk p of `src` (first dimension cut in R) goes to rank p, chunk s of `dst` comes from rank s"""
+        if self.stage_through_host:
+            h = _torch().zeros_like(src, device="cpu")
+            self.dist.all_to_all_single(h, src.cpu())
+            dst.copy_(h)
+        else:
+            self.dist.all_to_all_single(dst, src)
 
     def all_gather_object(self, obj):
         out = [None] * self.world
@@ -164,7 +188,8 @@ class ShardedProver:
                 for p in range(R):
                     blk = block_of(owned[c], p).contiguous()
                     if p == r:
-                        out[c] = blk.clone()            # not a view: the whole column is released after the re-shard
+                        # not a view: the whole column is released after the re-shard (a group of one keeps the column itself)
+                        out[c] = blk.clone() if R > 1 else blk
                     else:
                         sends.append((p, blk))
             else:
@@ -182,29 +207,30 @@ class ShardedProver:
         B, log_N, log_R = N // R, _log2(N), _log2(comm.world)
         Tree = self.claim.tree
         single = len(blocks) == 1
+        log_B = log_N - log_R
+        # Row i = r B + k of the matrix is leaf bitrev(i) (or i).  Bit-reversed: bitrev_{log N}(i) = bitrev_{log B}(k) << log R
+        # | bitrev_{log R}(r), so with this rank's digests stored at their LOCAL bit-reversed slot bitrev_{log B}(k) - which is
+        # what the row-hash kernel's scatter does for free - the B / R slots of chunk p are exactly the leaves rank p owns:
+        # one equal-split all-to-all (32 B per row), after which the chunk from rank s is the stride-R comb at offset
+        # bitrev_{log R}(s) of the leaf block.  No index tensors, no gather on either side.
         if single:                                  # raw-element leaves (merkle/mod.rs:113-117)
             mine = blocks[0][:B]
-            leaves = self.felts(B)
+            if order == be.BITREV:
+                mine = mine[self._bitrev_index(log_B)]
         else:
             mine = torch.zeros((B, 32), dtype=torch.uint8, device=comm.device)
-            ctx.hash_rows(Tree.row_hash, blocks, B, mine, be.NATURAL)       # natural local rows; the blocks' halo is not hashed
-            leaves = torch.zeros((B, 32), dtype=torch.uint8, device=comm.device)
-        _dbg(comm, "row digests / leaves (rows)", mine)
-        # row i = r B + k is leaf bitrev(i) (or i): send every digest to the rank that owns its leaf.  Who sends which rows
-        # where is a property of (N, R, order) alone: the index tensors are built once and kept.
-        out_sel, in_pos = self._leaf_routes(N, order)
-        sends, recvs, places = [], [], {}
-        for p in range(R):
-            if p == r:
-                leaves[in_pos[p]] = mine[out_sel[p]]
-            else:
-                sends.append((p, mine[out_sel[p]].contiguous()))
-                buf = torch.zeros((len(in_pos[p]),) + tuple(mine.shape[1:]), dtype=mine.dtype, device=comm.device)
-                recvs.append((p, buf))
-                places[p] = buf
-        comm.exchange(sends, recvs)
-        for p, buf in places.items():
-            leaves[in_pos[p]] = buf
+            ctx.hash_rows(Tree.row_hash, blocks, B, mine, order)            # the blocks' halo is not hashed
+        _dbg(comm, "row digests / leaves (local order)", mine)
+        if R == 1 or order != be.BITREV:            # natural order: a rank's rows are its leaves
+            leaves = mine
+        else:
+            got = torch.zeros_like(mine)
+            comm.all_to_all_equal(got, mine.contiguous())
+            W = mine.shape[1]
+            leaves = torch.zeros_like(mine)
+            comb = leaves.view(B // R, R, W)
+            for src in range(R):
+                comb[:, bitrev(src, log_R)] = got[src * (B // R):(src + 1) * (B // R)]
         _dbg(comm, "leaf block", leaves)
         # this rank's sub-tree: its root sits at depth log2 R of the whole tree
         nodes = torch.zeros((2 * B, 32), dtype=torch.uint8, device=comm.device)
@@ -227,33 +253,16 @@ class ShardedProver:
             depth -= 1
         return _Commitment(leaves, leaf_kind, nodes, tags, top, top[0][0][0], top[0][0][1])
 
-    def _leaf_routes(self, N, order):
-        """-> (out_sel, in_pos): out_sel[p] = local rows (ascending) whose leaves rank p owns; in_pos[p] = local leaf slots of
-        what rank p sends here, in the order it sends them"""
-        key = (N, order)
-        cache = self.__dict__.setdefault("_routes", {})
-        if key not in cache:
-            torch, comm = _torch(), self.comm
-            R, r = comm.world, comm.rank
-            B, log_N = N // R, _log2(N)
-            k = torch.arange(B, dtype=torch.int64, device=comm.device)
-
-            def leaf_of(src_rank):
-                i = src_rank * B + k
-                return _bitrev_tensor(i, log_N) if order == be.BITREV else i
-            j = leaf_of(r)
-            dest = j // B
-            out_sel = [(dest == p).nonzero().flatten() for p in range(R)]
-            in_pos = []
-            for p in range(R):
-                jp = leaf_of(p)
-                selp = ((jp // B) == r).nonzero().flatten()
-                in_pos.append(jp[selp] % B)
-            cache[key] = (out_sel, in_pos)
-        return cache[key]
+    def _bitrev_index(self, bits):
+        cache = self.__dict__.setdefault("_bitrev", {})
+        if bits not in cache:
+            torch = _torch()
+            cache[bits] = _bitrev_tensor(torch.arange(1 << bits, dtype=torch.int64, device=self.comm.device), bits)
+        return cache[bits]
 
     def open(self, com: _Commitment, blocks, N, positions, order):
-        """-> on rank 0: (rows [nq, ncols, 4], paths [nq, log N, 32], leaf digests [nq, 32] or None); None elsewhere"""
+        """-> on rank 0: (rows [nq, ncols, 4], paths [nq, log N, 32], leaf digests [nq, 32] or None, MixedMerkleDigest tags
+        [nq, log N] of the path entries (FriendlyMerkleTree; None otherwise)); None elsewhere"""
         comm, ctx = self.comm, self.ctx
         R, r = comm.world, comm.rank
         B, log_N, log_R = N // R, _log2(N), _log2(comm.world)
@@ -261,19 +270,20 @@ class ShardedProver:
         nat = [bitrev(p, log_N) for p in positions] if order == be.BITREV else list(positions)
         my_rows = [(q, i % B) for q, i in enumerate(nat) if i // B == r]
         my_leaves = [(q, p % B) for q, p in enumerate(positions) if p // B == r]
-        part = {"rows": {}, "paths": {}, "digests": {}}
+        part = {"rows": {}, "paths": {}, "digests": {}, "tags": {}}
         if my_rows:
             got = ctx.gather_rows(blocks, [k for _, k in my_rows])
             for (q, _), row in zip(my_rows, got):
                 part["rows"][q] = row
         if my_leaves:
-            paths, _ = ctx.merkle_open(com.nodes, com.tags, B, [k for _, k in my_leaves])
+            paths, ptags = ctx.merkle_open(com.nodes, com.tags, B, [k for _, k in my_leaves])
             lv = None
             if com.leaf_kind == be.LEAF_DIGEST:         # only the opened leaves cross to the host
                 idx = _torch().tensor([k for _, k in my_leaves], dtype=_torch().int64, device=com.leaves.device)
                 lv = com.leaves[idx].cpu().numpy()
             for t, ((q, k), path) in enumerate(zip(my_leaves, paths)):
                 part["paths"][q] = path
+                part["tags"][q] = ptags[t]
                 if lv is not None:
                     part["digests"][q] = lv[t].copy()
         parts = comm.gather_object(part, 0)
@@ -283,6 +293,7 @@ class ShardedProver:
         rows = np.zeros((nq, len(blocks), 4), dtype=np.uint64)
         paths = np.zeros((nq, log_N, 32), dtype=np.uint8)
         digests = np.zeros((nq, 32), dtype=np.uint8) if com.leaf_kind == be.LEAF_DIGEST else None
+        tags = np.zeros((nq, log_N), dtype=np.uint8) if com.tags is not None else None
         for prt in parts:
             for q, row in prt["rows"].items():
                 rows[q] = row
@@ -290,13 +301,18 @@ class ShardedProver:
                 paths[q, :log_B] = path
             for q, d in prt["digests"].items():
                 digests[q] = d
+            if tags is not None:
+                for q, tg in prt["tags"].items():
+                    tags[q, :log_B] = tg
         for q, p in enumerate(positions):           # the top levels: siblings of the sub-tree root's ancestors
             node = p // B
             for lvl in range(log_R):
                 sib = com.top[log_R - lvl][node ^ 1]
                 paths[q, log_B + lvl] = np.frombuffer(sib[0], dtype=np.uint8)
+                if tags is not None:
+                    tags[q, log_B + lvl] = sib[1]
                 node >>= 1
-        return rows, paths, digests
+        return rows, paths, digests, tags
 
     # ---- the proof
     def prove(self, coin_seed: bytes, my_base: Dict[int, object], build_extension: Callable[[List[np.ndarray]], Dict[int, object]],
@@ -385,23 +401,32 @@ class ShardedProver:
         ncomp = conv.composition_columns
         assert ncomp == 1 << lb == 2, "composition split implemented for blowup 2"
         comp_owned, comp_co = {}, {}
-        if r == 0:
+        # gather of the R row blocks to rank 0 (every rank enters the exchange), the inverse transform there, then column
+        # k's coefficients to rank k % R (again one exchange that every rank enters)
+        comp_evals = None
+        if R == 1:
+            comp_evals = q_block
+        elif r == 0:
             comp_evals = self.felts(N)
             comp_evals[:B] = q_block
             comm.exchange([], [(p, comp_evals[p * B:(p + 1) * B]) for p in range(1, R)])
-            ctx.ntt([comp_evals], log_N, be.INVERSE, g, be.NATURAL, be.BITREV)   # H0 | H1, each bit-reversed: the split is free
-            for k in range(ncomp):
-                half = comp_evals[k * n:(k + 1) * n]
-                if self.owner(k) == 0:
-                    comp_co[k] = half
-                else:
-                    comm.exchange([(self.owner(k), half.contiguous())], [])
         else:
             comm.exchange([(0, q_block)], [])
-            for k in range(ncomp):
-                if self.owner(k) == r:
-                    comp_co[k] = self.felts(n)
-                    comm.exchange([], [(0, comp_co[k])])
+        if r == 0:
+            ctx.ntt([comp_evals], log_N, be.INVERSE, g, be.NATURAL, be.BITREV)   # H0 | H1, each bit-reversed: the split is free
+        sends, recvs = [], []
+        for k in range(ncomp):
+            o = self.owner(k)
+            if r == 0:
+                half = comp_evals[k * n:(k + 1) * n]
+                if o == 0:
+                    comp_co[k] = half
+                else:
+                    sends.append((o, half))
+            elif o == r:
+                comp_co[k] = self.felts(n)
+                recvs.append((0, comp_co[k]))
+        comm.exchange(sends, recvs)
         for k, co in comp_co.items():
             comp_owned[k] = self.felts(N)
             ctx.evaluate([co], log_n, lb, g, [comp_owned[k]])
@@ -445,9 +470,12 @@ class ShardedProver:
             comm.exchange([(0, sub_block)], [])
             positions = comm.broadcast_object(None, 0)
         else:
-            sub = self.felts(n)
-            sub[:cnt] = sub_block
-            comm.exchange([], [(p, sub[p * cnt:(p + 1) * cnt]) for p in range(1, R)])
+            if R == 1:
+                sub = sub_block
+            else:
+                sub = self.felts(n)
+                sub[:cnt] = sub_block
+                comm.exchange([], [(p, sub[p * cnt:(p + 1) * cnt]) for p in range(1, R)])
             mark("deep rows + gather")
             deep = _TensorBuffer(ctx, self.felts(N))
             ctx.deep_extend(sub, log_n, lb, g, deep)
@@ -466,10 +494,11 @@ class ShardedProver:
                   self.open(comp_com, comp_blocks, N, positions, order)]
         if r != 0:
             return None
-        proof.base_rows, proof.base_paths, proof.base_leaf_digests = opened[0]
+        proof.base_rows, proof.base_paths, proof.base_leaf_digests, proof.base_path_tags = opened[0]
         if ne:
-            proof.extension_rows, proof.extension_paths, proof.extension_leaf_digests = opened[1]
-        proof.composition_rows, proof.composition_paths, proof.composition_leaf_digests = opened[2]
+            proof.extension_rows, proof.extension_paths, proof.extension_leaf_digests, proof.extension_path_tags = opened[1]
+        proof.composition_rows, proof.composition_paths, proof.composition_leaf_digests, proof.composition_path_tags = opened[2]
+        proof.root_tags = [base_com.root_tag, ext_com.root_tag if ne else 0, comp_com.root_tag]
         fri_open(ctx, conv, opt, proof, layers, positions)
         mark("openings")
         return proof

@@ -23,12 +23,25 @@ def tensor(limbs):
     return torch.from_numpy(np.ascontiguousarray(limbs, dtype=np.uint64).view(np.int64).copy())
 
 
-def mini(log_n, max_remainder):
+def blake2s_m20_leaf_hash(vals):
+    import hashlib
+    return bytes(12) + hashlib.blake2s(b"".join((v * wire._R % wire.P).to_bytes(32, "big") for v in vals)).digest()[12:]
+
+
+def friendly_tree(n_friendly):
+    """FriendlyMerkleTree<n_friendly, _>: a small N puts the Blake2s / Pedersen boundary inside a 2^10-leaf tree"""
+    return type("FriendlyMerkleTree%d" % n_friendly, (be.FriendlyMerkleTree,), {"n_friendly": n_friendly})
+
+
+def mini(log_n, max_remainder, flavour="eth", n_friendly=22):
     from tests import mini_air
     n = 1 << log_n
     c0, c1 = mini_air.base_trace(n)
     cols = {0: oracle.to_mont(c0), 1: oracle.to_mont(c1)}
-    claim = Claim(mini_air.make_air(oracle.to_mont), be.LeafVariantMerkleTree, be.COIN_SOLIDITY)
+    if flavour == "cairo":                          # CairoVerifierClaim's parts (src/claims.rs:31-32) around the mini AIR
+        claim = Claim(mini_air.make_air(oracle.to_mont), friendly_tree(n_friendly), be.COIN_CAIRO)
+    else:
+        claim = Claim(mini_air.make_air(oracle.to_mont), be.LeafVariantMerkleTree, be.COIN_SOLIDITY)
     opt = ProofOptions(num_queries=12, grinding_factor=8, fri_max_remainder_coeffs=max_remainder)
 
     def ext(challenges, owner):
@@ -36,7 +49,7 @@ def mini(log_n, max_remainder):
 
     def leaf_hash(vals):
         return keccak256(b"".join((v * wire._R % wire.P).to_bytes(32, "big") for v in vals))[:20] + bytes(12)
-    return n, cols, claim, opt, ext, bytes(range(32)), leaf_hash
+    return n, cols, claim, opt, ext, bytes(range(32)), blake2s_m20_leaf_hash if flavour == "cairo" else leaf_hash
 
 
 def example():
@@ -70,8 +83,8 @@ def main():
     if case == "example":
         n, cols, claim, opt, ext, seed, leaf_hash = example()
     else:
-        log_n, max_remainder = (int(v) for v in case.split(":")[1:])
-        n, cols, claim, opt, ext, seed, leaf_hash = mini(log_n, max_remainder)
+        f = case.split(":")                         # mini:<log n>:<max remainder>[:cairo:<N of FriendlyMerkleTree<N>>]
+        n, cols, claim, opt, ext, seed, leaf_hash = mini(int(f[1]), int(f[2]), *((f[3], int(f[4])) if len(f) > 3 else ()))
     comm = Comm(device=torch.device("cpu"))
     prover = ShardedProver(CpuContext(), claim, comm, opt)
     mine = {c: tensor(v) for c, v in cols.items() if c % world == rank}

@@ -64,6 +64,38 @@ def main():
 
         def leaf_hash(vals):
             return keccak256(b"".join((v * wire._R % wire.P).to_bytes(32, "big") for v in vals))
+    elif case.startswith("recursive:"):
+        # the north-star's claim (cli/src/main.rs:95-99: recursive layout -> CairoVerifierClaim = FriendlyMerkleTree<22> + the
+        # Cairo coin) on the example run padded to 2^k steps: C++ trace generator, the C++ host's lowering of the real
+        # 93-constraint AIR behind the Python driver, CLI-default options
+        import hashlib
+        from sandstorm_amd import binary, extension, hostlib, public_input
+        from sandstorm_amd.layouts import recursive as rec
+        from tests.test_layout_recursive import recursive_example
+        log_steps = int(case.split(":")[1])
+        states, memory, rpi = recursive_example(log_steps)
+        host = hostlib.recursive_base_trace(binary.write_register_states(states), binary.write_memory(memory), rpi)
+        del states, memory
+        n = len(host[0])
+        host_air = hostlib.RecursiveHostAir(ctx, rpi, log_steps + 4, 1)
+        claim = Claim(hostlib.prover_air(host_air), be.FriendlyMerkleTree, be.COIN_CAIRO)
+        opt = ProofOptions()
+        seed = public_input.public_coin_seed(rpi, be.COIN_CAIRO)
+        cols = {c: v for c, v in enumerate(host) if c % world == rank}
+        my_ext = [c for c in (7, 8, 9) if c % world == rank]
+        aux_host = [host[c] for c in (rec.COL_NPC, rec.COL_MEMORY, rec.COL_RANGE_CHECK, rec.COL_DILUTED_UNORDERED, rec.COL_DILUTED_ORDERED)] if my_ext else None
+        del host
+
+        def ext(challenges):
+            if not my_ext:
+                return {}
+            aux = [tensor(c) for c in aux_host]
+            out = be.Matrix(ctx, [torch.zeros((n, 4), dtype=torch.int64, device=device) for _ in range(3)], n)
+            extension.build_extension_columns("recursive", ctx, extension.TraceColumns(aux[0], aux[1], aux[2], n, aux[3], aux[4]), challenges, check=True, out=out)
+            return {c: out.cols[c - 7] for c in my_ext}
+
+        def leaf_hash(vals):
+            return bytes(12) + hashlib.blake2s(b"".join((v * wire._R % wire.P).to_bytes(32, "big") for v in vals)).digest()[12:]
     elif case.startswith("starknet:"):
         # the reference's array-sum run re-declared for the starknet layout at 2^k steps: C++ trace generator, the C++
         # host's lowering of the real 195-constraint AIR behind the Python driver, EthVerifierClaim, CLI-default options

@@ -21,6 +21,40 @@ def load_run():
     return states, memory, pi
 
 
+def recursive_example(log_steps):
+    """the reference's example run as a 2^log_steps-step statement of the recursive layout: padded with its final state (the
+    program ends in `jmp rel 0`), the builtin segments re-declared for that step count back to back behind the execution
+    segment, the program's one heap segment moved behind them (as tests/test_layout_starknet.py::starknet_example)"""
+    import copy
+    from sandstorm_amd.layouts import recursive as rec
+    states, memory, pi = load_run()
+    if (1 << log_steps) == len(states):
+        return states, memory, pi
+    assert (1 << log_steps) > len(states)
+    states = list(states) + [states[-1]] * ((1 << log_steps) - len(states))
+    pi = copy.deepcopy(pi)
+    pi.n_steps = 1 << log_steps
+    seg = dict(pi.memory_segments)
+    addr = seg["execution"][1]
+    seg["output"] = (addr, addr)
+    for name, ratio, cells in (("pedersen", rec.PEDERSEN_BUILTIN_RATIO, 3), ("range_check", rec.RANGE_CHECK_BUILTIN_RATIO, 1),
+                               ("bitwise", rec.BITWISE_RATIO, 5)):
+        seg[name] = (addr, addr)                     # begin = stop: the program uses nothing of the segment
+        addr += cells * (pi.n_steps // ratio)
+    pi.memory_segments = seg
+    new_base = addr
+    heap = [a for a in range(len(memory)) if memory[a] is not None and a > 1000]
+    mem = list(memory) + [None] * (new_base + 16 - len(memory))
+    for a in heap:
+        mem[a] = None
+    for a in heap:
+        mem[new_base + a - heap[0]] = memory[a]
+    for a in range(1000):
+        if a < len(memory) and mem[a] is not None and heap[0] <= mem[a] <= heap[-1] + 1:
+            mem[a] += new_base - heap[0]                                         # the pointers into the heap segment
+    return states, mem, pi
+
+
 def with_extension(rec, cols, challenges):
     """base columns + the ORACLE's extension columns (the product's device version is compared with the oracle in
     tests/test_gpu_extension.py) -> (all 10 columns as ints, final products)"""
@@ -144,7 +178,7 @@ def test_pedersen_builtin_with_real_instances():
 def test_mask_is_the_reference_mask():
     """the trace cells the restated constraints read = the 133-cell mask extracted from the reference's source
     (its size is the length of the out-of-domain vector in the reference's shipped recursive proof)"""
-    from sandstorm_amd import synthetic_air
+    from tests import survey_masks
     from sandstorm_amd.layouts import recursive as rec
     _, _, pi = load_run()
     cells, seen = set(), set()
@@ -160,7 +194,7 @@ def test_mask_is_the_reference_mask():
                 walk(a)
     for c in rec.constraints(rec.Hints.from_public_input(pi, CHALLENGES, 1 << 18), CHALLENGES):
         walk(c.numerator)
-    assert cells == {(c, o) for c, offs in synthetic_air.RECURSIVE_MASK.items() for o in offs} and len(cells) == 133
+    assert cells == {(c, o) for c, offs in survey_masks.RECURSIVE_MASK.items() for o in offs} and len(cells) == 133
 
 
 def test_domain_rows_are_the_zeros_of_their_zerofiers():

@@ -135,7 +135,7 @@ def example():
 
 
 def test_constraint_set_and_mask_have_the_reference_shape(golden):
-    from sandstorm_amd import synthetic_air
+    from tests import survey_masks
     from sandstorm_amd.layouts import starknet as sk
     cs = sk.constraints(sk.Hints(0, 0, 0, 0), CHALLENGES)
     assert len(cs) == 195 and len({c.name for c in cs}) == 195
@@ -144,8 +144,8 @@ def test_constraint_set_and_mask_have_the_reference_shape(golden):
     mask = sk.mask()
     assert mask == sorted(set(mask)) and len(mask) == 269
     per_col = [sum(1 for c, _ in mask if c == k) for k in range(10)]
-    assert per_col == synthetic_air.STARKNET_CELLS_PER_COLUMN
-    assert [max(o for c, o in mask if c == k) for k in range(10)] == synthetic_air.STARKNET_MAX_OFFSET
+    assert per_col == survey_masks.STARKNET_CELLS_PER_COLUMN
+    assert [max(o for c, o in mask if c == k) for k in range(10)] == survey_masks.STARKNET_MAX_OFFSET
     assert [len(p["ood_trace"]) for p in golden("saved_proofs.json")][:2] == [269, 269]
 
 

@@ -167,13 +167,13 @@ def test_remainder_of_reference_proof(oracle, golden, fixture):
 
 def test_saved_proof_fixture_shape(golden):
     """Header and out-of-domain tail of the reference's three saved proofs (data only):
-    mask sizes 269 (starknet) / 133 (recursive) are what the synthetic AIRs of bench.py are shaped to, the
+    mask sizes 269 (starknet) / 133 (recursive) are the masks of the restated AIRs (tests/survey_masks.py), the
     values are canonical field elements, and the option bytes are the CLI's.  The OOD identity itself needs the
     restated constraint sets."""
     proofs = golden("saved_proofs.json")
     assert [len(p["ood_trace"]) for p in proofs] == [269, 269, 133]
-    from sandstorm_amd import synthetic_air as sa
-    assert len(sa.layout_mask("starknet")) == 269 and len(sa.layout_mask("recursive")) == 133
+    from tests import survey_masks as sm
+    assert sum(sm.STARKNET_CELLS_PER_COLUMN) == 269 and sum(len(v) for v in sm.RECURSIVE_MASK.values()) == 133
     for p in proofs:
         assert len(p["ood_composition"]) == 2
         assert all(0 <= int(v) < P for v in p["ood_trace"] + p["ood_composition"])
