@@ -31,7 +31,8 @@ OFFSET = F.GENERATOR                               # LDE coset offset = the fiel
 
 @dataclass
 class Options:
-    num_queries: int = 30
+    """the CLI's defaults (cli/src/main.rs:51-60): 65 queries x 1 bit (blowup 2) + 16 grinding bits = 81 >= the 80 it requires"""
+    num_queries: int = 65
     log_blowup: int = 1
     grinding: int = 16
     fold: int = 8
@@ -101,10 +102,37 @@ class Coin(PublicCoin):
         self.reseed_with_bytes(b"".join(int(c).to_bytes(8, "little") for v in values for c in v))
 
 
-def transcript_seed(seed: bytes, opt: Options, trace_len: int) -> bytes:
-    """the options and the trace length are part of the transcript: a proof does not verify under other options"""
+def statement_digest(statement) -> bytes:
+    """the public input as the transcript absorbs it (the reference seeds its coin from the public input, src/lib.rs:118-120
+    `P::from_public_input`; ministark's generic coin hashes its serialisation - un-vendored, so the byte image here is this
+    library's own): step count, range-check bounds, the memory segments by name, every public-memory cell"""
+    if statement is None:
+        return bytes(32)
+    u64 = lambda v: int(v).to_bytes(8, "big")
+    segs = sorted((str(k), v) for k, v in statement.memory_segments.items() if v is not None)
+    blob = u64(statement.n_steps) + u64(statement.rc_min) + u64(statement.rc_max) + u64(len(segs))
+    for name, (lo, hi) in segs:
+        blob += u64(len(name)) + name.encode() + u64(lo) + u64(hi)
+    blob += u64(len(statement.public_memory)) + b"".join(u64(a) + u64(v) for a, v in statement.public_memory)
+    return keccak256(blob)
+
+
+def transcript_seed(seed: bytes, opt: Options, trace_len: int, statement=None) -> bytes:
+    """the options, the trace length AND the statement are part of the transcript: every challenge depends on the public memory
+    and segments being claimed (Fiat-Shamir over the whole statement), and a proof does not verify under other options"""
     return keccak256(bytes(seed) + b"".join(int(v).to_bytes(8, "big") for v in (opt.num_queries, opt.log_blowup, opt.grinding, opt.fold,
-                                                                                 opt.max_remainder, trace_len)))
+                                                                                 opt.max_remainder, trace_len)) + statement_digest(statement))
+
+
+DEFAULT_REQUIRED_SECURITY_BITS = 80                # cli/src/main.rs:66-67
+
+
+def conjectured_security_bits(opt: Options, trace_len: int) -> int:
+    """min of the query term (one bit per query and doubling of the blowup, plus the grinding bits), the field term (the
+    challenges live in Fq3: 192 bits less the size of the evaluation domain) and the hash term (256-bit digests: 128) - the
+    shape of verifier.conjectured_security_bits on the 252-bit path"""
+    log_N = max(1, int(trace_len).bit_length() - 1 + opt.log_blowup)
+    return min(opt.num_queries * opt.log_blowup + opt.grinding, 192 - log_N, 128)
 
 
 def fri_shape(n_lde, opt: Options):
@@ -160,7 +188,7 @@ class Prover:
         N = n << lb
         dev = base_cols[0].device
         new = lambda rows, width=None: torch.empty((rows,) if width is None else (rows, width), dtype=torch.int64, device=dev)   # fully written below
-        coin = Coin(transcript_seed(seed, opt, n))
+        coin = Coin(transcript_seed(seed, opt, n, statement))
         proof = Proof(opt, n)
 
         def extend(cols):
@@ -322,7 +350,9 @@ def _climb(leaf, path, pos):
 
 
 def _check_opening(opening, width, positions, depth, root, what):
-    _need(opening is not None and opening.rows.shape == (len(positions), width) and opening.paths.shape == (len(positions), depth, 32), what + ": shape")
+    _need(opening is not None and isinstance(opening.rows, np.ndarray) and isinstance(opening.paths, np.ndarray) and
+          opening.rows.dtype == np.uint64 and opening.paths.dtype == np.uint8, what + ": dtype")
+    _need(opening.rows.shape == (len(positions), width) and opening.paths.shape == (len(positions), depth, 32), what + ": shape")
     for q, pos in enumerate(positions):
         leaf = _tree_hash(b"".join(int(v).to_bytes(8, "little") for v in opening.rows[q]))
         _need(_climb(leaf, opening.paths[q], pos) == root, what + ": authentication path does not reach the root")
@@ -333,21 +363,50 @@ def _verify_pow(digest, bits, nonce):
     return int.from_bytes(keccak256(prefix + int(nonce).to_bytes(8, "big"))[:8], "big") >> (64 - bits) == 0 if bits else True
 
 
-def verify(proof: Proof, air: Air, seed: bytes, statement=None, expected_options: Options = None, required_security_bits=0):
-    """raises VerificationError naming the failed check; -> the query positions"""
+def verify(proof: Proof, air: Air, seed: bytes, statement=None, expected_options: Options = None,
+           required_security_bits=DEFAULT_REQUIRED_SECURITY_BITS):
+    """raises VerificationError naming the failed check; -> the query positions.  The proof is untrusted - its options
+    included: a proof whose options conjecture fewer than `required_security_bits` (the CLI's 80 by default) is rejected, and
+    any arithmetic, conversion or indexing accident a malformed proof provokes is a rejection too, never another exception.
+    `statement` (the public input) is absorbed into the transcript before anything else: the challenges depend on it."""
+    try:
+        return _verify(proof, air, seed, statement, expected_options, required_security_bits)
+    except VerificationError:
+        raise
+    except (ValueError, IndexError, KeyError, OverflowError, TypeError, AttributeError, ZeroDivisionError) as e:
+        raise VerificationError("malformed proof: %s: %s" % (type(e).__name__, e))
+
+
+def _u64_array(a, shape, what):
+    """an array of the proof: dtype uint64 (or uint8 for digests) and exactly this shape (None = any length)"""
+    _need(isinstance(a, np.ndarray) and a.dtype == np.uint64 and a.ndim == len(shape) and
+          all(w is None or w == h for w, h in zip(shape, a.shape)), what + ": not a uint64 array of the expected shape")
+    return a
+
+
+def _verify(proof, air, seed, statement, expected_options, required_security_bits):
     opt = proof.options
+    _need(all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in
+              (opt.num_queries, opt.log_blowup, opt.grinding, opt.fold, opt.max_remainder, proof.trace_len, proof.pow_nonce)), "options: not integers")
     if expected_options is not None:
         _need(opt == expected_options, "options are not the expected ones")
-    _need(opt.num_queries >= 1 and opt.fold in (2, 4, 8, 16) and 1 <= opt.log_blowup <= 4 and opt.max_remainder >= 1 and 0 <= opt.grinding <= 40,
-          "options out of range")
-    _need(opt.num_queries * opt.log_blowup + opt.grinding >= required_security_bits, "security level below the required one")
-    n = proof.trace_len
-    _need(n >= 16 and n & (n - 1) == 0, "trace length")
+    _need(1 <= opt.num_queries <= 256 and opt.fold in (2, 4, 8, 16) and 1 <= opt.log_blowup <= 4 and 1 <= opt.max_remainder <= 1 << 16
+          and 0 <= opt.grinding <= 40, "options out of range")
+    n = int(proof.trace_len)
+    _need(16 <= n <= 1 << (32 - opt.log_blowup) and n & (n - 1) == 0, "trace length")
+    _need(0 <= int(proof.pow_nonce) < 1 << 64, "proof-of-work nonce out of range")
+    sec = conjectured_security_bits(opt, n)
+    _need(sec >= required_security_bits, "the proof's options conjecture %d bits of security, %d required" % (sec, required_security_bits))
     log_n, lb = n.bit_length() - 1, opt.log_blowup
     N = n << lb
     _need(lb == 1, "the composition split is written for blowup 2")
+    _need(all(isinstance(r, (bytes, bytearray)) and len(r) == 32 for r in [proof.base_root, proof.comp_root] + ([proof.ext_root] if air.num_ext else [])),
+          "roots: 32 bytes each")
+    _u64_array(proof.ood_trace, (len(air.mask), 3), "out-of-domain trace values")
+    _u64_array(proof.ood_comp, (6, 3), "out-of-domain composition values")
+    _u64_array(proof.remainder, (None, 3), "FRI remainder")
     ncols = air.num_base + air.num_ext
-    coin = Coin(transcript_seed(seed, opt, n))
+    coin = Coin(transcript_seed(seed, opt, n, statement))
     coin.reseed_with_digest(proof.base_root)
     challenges = [coin.draw_fq3() for _ in range(air.num_challenges)]
     if air.num_ext:

@@ -23,6 +23,6 @@ ctx = be.Context(0, stream=stream.cuda_stream)
 base = [torch.from_numpy(np.array(c, dtype=np.uint64).view(np.int64)).to(dev) for c in cols]
 air, opt = gs.plain_air(), gs.Options(num_queries=20, grinding=8)
 proof = gs.Prover(ctx, air, opt).prove(bytes(range(32)), base, lambda ch: gs.plain_extension_on_device(ctx, base, ch)[0], statement=pi)
-gs.verify(proof, air, bytes(range(32)), statement=pi, expected_options=opt)
+gs.verify(proof, air, bytes(range(32)), statement=pi, expected_options=opt, required_security_bits=28)
 np.savez_compressed(sys.argv[1], **gs.proof_to_arrays(proof))
 print("written", sys.argv[1])

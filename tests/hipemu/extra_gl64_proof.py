@@ -33,6 +33,6 @@ def test_device_code_reproduces_the_gpu_made_proof(oracle):
         assert set(got) == set(want)
         for k in sorted(want):
             assert np.array_equal(np.asarray(got[k]), want[k]), k
-        gs.verify(proof, air, seed, statement=pi, expected_options=opt)
+        gs.verify(proof, air, seed, statement=pi, expected_options=opt, required_security_bits=28)
     finally:
         ctx.close()

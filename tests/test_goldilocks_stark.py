@@ -138,7 +138,7 @@ def test_proof_of_the_example_verifies(proved):
     proof = prove(cols)
     positions = gs.verify(proof, air, bytes(range(32)), statement=pi, expected_options=opt, required_security_bits=28)
     assert len(positions) >= 15 and len(proof.fri_layers) == 2 and proof.remainder.shape == (32, 3)
-    assert gs.verify(prove(cols), air, bytes(range(32)), statement=pi) == positions      # deterministic
+    assert gs.verify(prove(cols), air, bytes(range(32)), statement=pi, required_security_bits=28) == positions      # deterministic
 
 
 @pytest.mark.gpu
@@ -151,7 +151,7 @@ def test_tampered_proofs_and_statements_are_rejected(proved):
         p = copy.deepcopy(proof)
         mutate(p)
         with pytest.raises(gs.VerificationError):
-            gs.verify(p, air, kw.get("seed", seed), statement=kw.get("statement", pi), expected_options=kw.get("expected", None))
+            gs.verify(p, air, kw.get("seed", seed), statement=kw.get("statement", pi), expected_options=kw.get("expected", None), required_security_bits=28)
     rejected(lambda p: None, seed=bytes(32))                                               # another transcript
     other = copy.deepcopy(pi)
     other.public_memory[3] = (other.public_memory[3][0], other.public_memory[3][1] ^ 1)
@@ -174,7 +174,7 @@ def test_tampered_proofs_and_statements_are_rejected(proved):
     bad = [list(c) for c in cols]
     bad[pl.COL_AUXILIARY][16 * 9 + pl.Auxiliary.TMP0[1]] += 1
     with pytest.raises(gs.VerificationError, match="do not satisfy the AIR"):
-        gs.verify(prove(bad), air, seed, statement=pi)
+        gs.verify(prove(bad), air, seed, statement=pi, required_security_bits=28)
 
 
 @pytest.mark.gpu
@@ -258,11 +258,11 @@ def test_gpu_made_proof_verifies_on_the_cpu(run):
         p = gs.proof_from_arrays(arrays)
         mutate(p)
         with pytest.raises(gs.VerificationError):
-            gs.verify(p, air, bytes(range(32)), statement=pi)
+            gs.verify(p, air, bytes(range(32)), statement=pi, required_security_bits=28)
     other = copy.deepcopy(pi)
     other.memory_segments["execution"] = (other.memory_segments["execution"][0], other.memory_segments["execution"][1] + 1)
     with pytest.raises(gs.VerificationError):
-        gs.verify(gs.proof_from_arrays(arrays), air, bytes(range(32)), statement=other)
+        gs.verify(gs.proof_from_arrays(arrays), air, bytes(range(32)), statement=other, required_security_bits=28)
 
 
 def test_whole_pipeline_on_the_oracle_reproduces_the_gpu_made_proof(run):
@@ -284,3 +284,41 @@ def test_whole_pipeline_on_the_oracle_reproduces_the_gpu_made_proof(run):
     assert set(got) == set(want)
     for k in sorted(want):
         assert np.array_equal(np.asarray(got[k]), want[k]), k
+
+
+def test_verifier_defaults_and_malformed_proofs(run):
+    """the proof's own options are untrusted - a default call requires the CLI's 80 conjectured bits (the 20-query
+    fixture carries 28) -, the statement is part of the transcript, and whatever a malformed proof provokes is a VerificationError"""
+    import os
+    from sandstorm_amd import goldilocks as gs
+    prog, states, memory, pi, cols = run
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "goldilocks_plain_proof.npz")) as f:
+        arrays = {k: f[k] for k in f.files}
+    air, seed = gs.plain_air(), bytes(range(32))
+    fresh = lambda: gs.proof_from_arrays(arrays)
+    with pytest.raises(gs.VerificationError, match="bits of security"):
+        gs.verify(fresh(), air, seed, statement=pi)                                         # default: 80 bits
+    assert gs.conjectured_security_bits(gs.Options(), 1 << 24) == 81                        # the CLI's defaults clear it
+    assert gs.conjectured_security_bits(gs.Options(num_queries=200), 1 << 24) == 128        # capped by the hash
+    assert gs.conjectured_security_bits(gs.Options(num_queries=1, grinding=0), 1 << 10) == 1
+    # the statement feeds the seed: the same bytes under another public input draw other challenges from the first one on
+    assert gs.transcript_seed(seed, gs.Options(), 1 << 10, pi) != gs.transcript_seed(seed, gs.Options(), 1 << 10, None)
+    other = copy.deepcopy(pi)
+    other.public_memory[0] = (other.public_memory[0][0], other.public_memory[0][1] ^ 1)
+    assert gs.statement_digest(other) != gs.statement_digest(pi)
+    cases = [lambda p: setattr(p, "ood_comp", None),
+             lambda p: setattr(p, "ood_trace", p.ood_trace.astype(np.int64)),
+             lambda p: setattr(p.base, "rows", -p.base.rows.astype(np.int64)),
+             lambda p: setattr(p, "pow_nonce", 1 << 64),
+             lambda p: setattr(p, "pow_nonce", -1),
+             lambda p: setattr(p.options, "grinding", 8.0),
+             lambda p: setattr(p, "trace_len", 1 << 40),
+             lambda p: setattr(p, "base", None),
+             lambda p: setattr(p, "remainder", p.remainder[:, :2]),
+             lambda p: setattr(p, "base_root", b"short"),
+             lambda p: setattr(p.fri_layers[0], "opening", None)]
+    for k, mutate in enumerate(cases):
+        p = fresh()
+        mutate(p)
+        with pytest.raises(gs.VerificationError):
+            gs.verify(p, air, seed, statement=pi, required_security_bits=28)
