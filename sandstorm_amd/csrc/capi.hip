@@ -78,7 +78,23 @@ struct ss_ctx {
     hipStream_t stream = nullptr;
     std::map<PlanKey, Fp *> plans;          // device twiddle tables
     std::map<std::tuple<uint32_t, int, uint64_t>, uint64_t *> gl_plans;     // the 64-bit field's: (log_n, inverse, offset)
-    std::map<uint64_t, int> quotient_choice;      // per compiled constraint kernel (code hash): 0 undecided, 1 compiled, 2 interpreter
+    // pinned staging for the small per-launch tables that go host -> scratch in front of a kernel (the compiled constraint
+    // kernels' constants): the copy and the launch are queued, the call returns without waiting for the stream
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+    hipEvent_t stage_event = nullptr;       // recorded behind the last copy out of `stage`
+    ss_status stage_acquire(size_t bytes, void **out) {
+        if (stage_event) HIP_TRY(hipEventSynchronize(stage_event));     // the previous copy out of the buffer (long done by now)
+        else HIP_TRY(hipEventCreateWithFlags(&stage_event, hipEventDisableTiming));
+        if (bytes > stage_bytes) {
+            if (stage) HIP_TRY(hipHostFree(stage));
+            stage = nullptr; stage_bytes = 0;
+            HIP_TRY(hipHostMalloc(&stage, bytes, hipHostMallocDefault));
+            stage_bytes = bytes;
+        }
+        *out = stage;
+        return SS_OK;
+    }
     PedersenTables *ped = nullptr;
     void *scratch = nullptr;                // grow-only device scratch
     size_t scratch_bytes = 0;
@@ -306,6 +322,8 @@ void ss_ctx_destroy(ss_ctx *ctx) {
     if (ctx->scratch2) hipFree(ctx->scratch2);
     if (ctx->transient_tw) hipFree(ctx->transient_tw);
     if (ctx->d_small) hipFree(ctx->d_small);
+    if (ctx->stage) hipHostFree(ctx->stage);
+    if (ctx->stage_event) hipEventDestroy(ctx->stage_event);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1114,20 +1132,26 @@ ss_status ss_inverse_table(ss_ctx *ctx, uint32_t log_N, const uint64_t offset[4]
 
 namespace {
 // the compiled kernels, by program
-const QGenKernel *quotient_gen_find(const uint32_t *code, uint32_t n_instr) {
+const QGenKernel *quotient_gen_find(const uint32_t *code, uint32_t n_instr, bool *variant_missing) {
+    *variant_missing = false;
     uint64_t h = 0xcbf29ce484222325ull;                                  // FNV-1a over the code words (tools/gen_quotient.py)
     for (size_t k = 0; k < 2 * (size_t)n_instr; ++k)
         for (int b = 0; b < 4; ++b) h = (h ^ ((code[k] >> (8 * b)) & 0xffu)) * 0x100000001b3ull;
-#ifdef SS_QG_AB_VARIANTS                                                  // make QG_AB=1: the A/B variants of tools/gen_quotient.py --all-variants
-    const QGenKernel *all[] = {&quotient_gen_starknet(), &quotient_gen_recursive(), &quotient_gen_starknet_v1(), &quotient_gen_starknet_v2(),
-                               &quotient_gen_starknet_v3(), &quotient_gen_recursive_v1(), &quotient_gen_recursive_v2(), &quotient_gen_recursive_v3()};
-#else
-    const QGenKernel *all[] = {&quotient_gen_starknet(), &quotient_gen_recursive()};
-#endif
-    uint32_t variant = 0;                                                // A/B runs: SS_QG_VARIANT=k (tools/gen_quotient.py VARIANTS)
-    if (const char *e = getenv("SS_QG_VARIANT")) variant = (uint32_t)strtoul(e, nullptr, 10);
-    for (const QGenKernel *k : all)
-        if (k->code_hash == h && k->n_instr == n_instr && k->variant == variant) return k;
+    // quotient_gen_variants.inc: the default kernels; with make QG_AB=1 also the A/B variants of tools/gen_quotient.py --all-variants
+#define QG_VARIANT(entry) &entry(),
+    const QGenKernel *all[] = {
+#include "quotient_gen_variants.inc"
+    };
+#undef QG_VARIANT
+    // A/B runs: SS_QG_VARIANT=k (tools/gen_quotient.py VARIANTS), or per layout SS_QG_VARIANT_STARKNET / SS_QG_VARIANT_RECURSIVE
+    for (const QGenKernel *k : all) {
+        if (k->code_hash != h || k->n_instr != n_instr) continue;
+        uint32_t variant = 0;
+        if (const char *e = getenv("SS_QG_VARIANT")) variant = (uint32_t)strtoul(e, nullptr, 10);
+        if (const char *e = getenv(strcmp(k->layout, "starknet") == 0 ? "SS_QG_VARIANT_STARKNET" : "SS_QG_VARIANT_RECURSIVE")) variant = (uint32_t)strtoul(e, nullptr, 10);
+        if (k->variant == variant) return k;
+        *variant_missing = true;              // the program has compiled kernels, the variant asked for is not in this build
+    }
     return nullptr;
 }
 
@@ -1152,26 +1176,35 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
     ss_status st = ctx->ensure_scratch(host.size() * 4 + 256);
     if (st != SS_OK) return st;
     hipStream_t s = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(ctx->scratch, host.data(), host.size() * 4, hipMemcpyHostToDevice, s));
+    void *pinned = nullptr;                      // no host round trip: the copy leaves from pinned memory the context owns
+    if ((st = ctx->stage_acquire(host.size() * 4, &pinned)) != SS_OK) return st;
+    memcpy(pinned, host.data(), host.size() * 4);
+    HIP_TRY(hipMemcpyAsync(ctx->scratch, pinned, host.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(ctx->stage_event, s));
     QGenArgs a;
     for (int c = 0; c < QG_MAX_COLS; ++c) a.cols[c] = c < (int)ncols ? (const Fp *)d_lde_cols[c] : nullptr;
     a.tables = (const Fp *)prog->d_tables;
     a.consts = (const uint32_t *)ctx->scratch;
     a.tdesc = a.consts + (size_t)nc * QG_CONST_STRIDE;
     a.out = (Fp *)d_out;
+    a.sink = (Fp *)((char *)ctx->scratch + ((host.size() * 4 + 63) / 64) * 64);      // inside ensure_scratch's 256 spare bytes
     a.npoints = npoints; a.row0 = (uint32_t)row0; a.log_blowup = log_blowup;
     a.trace_mask = block ? 0xffffffffu : (uint32_t)((1ull << log_N) - 1ull);
-    // one workgroup per CU and SIMD slot the kernel's register budget allows; SS_QG_BLOCKS overrides (experiments)
-    uint64_t blocks = 256ull * gen.wgs_per_cu;
-    if (const char *e = getenv("SS_QG_BLOCKS")) blocks = strtoull(e, nullptr, 10);
-    if (blocks * gen.threads > N) blocks = N / gen.threads;
-    if (blocks == 0) blocks = 1;
     a.w = root_of_unity(log_N);
     a.offset = fp_mul(offset ? fp_from_limbs64(offset) : fp_one(), fp_pow_u64(a.w, row0));
-    a.wstep = fp_pow_u64(a.w, blocks * gen.threads);
-    ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
-    HIP_TRY(gen.launch(s, a, (uint32_t)blocks));
-    HIP_TRY(hipStreamSynchronize(s));      // the staging vector goes away on return
+    // the program's parts, one launch each on the context's stream: part 0 stores its sum, the others add theirs (a lane owns the
+    // same points in every part only if the grids agree - they need not: a part reads out[i] written by the PREVIOUS launch)
+    for (uint32_t p = 0; p < gen.n_parts; ++p) {
+        const QGenPart &part = gen.parts[p];
+        // one workgroup per CU and SIMD slot the part's register / LDS budget allows; SS_QG_BLOCKS overrides (experiments)
+        uint64_t blocks = 256ull * part.wgs_per_cu;
+        if (const char *e = getenv("SS_QG_BLOCKS")) blocks = strtoull(e, nullptr, 10);
+        if (blocks * part.threads > N) blocks = N / part.threads;
+        if (blocks == 0) blocks = 1;
+        a.wstep = fp_pow_u64(a.w, blocks * part.threads);
+        ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
+        HIP_TRY(part.launch(s, a, (uint32_t)blocks));
+    }
     return SS_OK;
 }
 }  // namespace
@@ -1216,31 +1249,11 @@ static ss_status eval_quotient_impl(ss_ctx *ctx, const ss_air_program *prog, con
     // A layout's composition constraint has a compiled kernel (quotient_gen_<layout>.hip, generated from exactly this
     // program): recognised by the hash of its code words.  Everything per proof (constants, tables, columns, size) is data.
     if (!getenv("SS_QUOTIENT_INTERPRET")) {
-        const QGenKernel *gen = quotient_gen_find(prog->code, prog->n_instr);
-        if (gen && gen->n_consts == prog->n_consts && gen->n_tables == prog->n_tables && gen->ncols <= ncols) {
-            // The compiled kernels run at one or two waves per SIMD off a megabyte of straight-line code: they live on the memory
-            // system's latency (instruction fetch included), the interpreter at four waves per SIMD does not.  On a healthy MI355X the
-            // compiled kernel wins by 1.4x; a device whose fabric is slow can turn that around (seen once: 5x slower, profiles/
-            // r02_end_outlier_box_*).  So the first evaluation of at least 2^20 points with a given kernel runs BOTH paths, timed,
-            // into the same output - they agree bit for bit - and the context keeps the faster one (SS_QUOTIENT_NO_AUTOTUNE=1: always
-            // the compiled kernel).
-            int &choice = ctx->quotient_choice[gen->code_hash];
-            if (choice == 0 && N >= (1ull << 20) && !getenv("SS_QUOTIENT_NO_AUTOTUNE")) {
-                const auto t0 = std::chrono::steady_clock::now();
-                ss_status st = eval_quotient_compiled(ctx, *gen, prog, d_lde_cols, ncols, log_N, log_blowup, offset, d_out, row0, N, block);
-                if (st != SS_OK) return st;
-                const auto t1 = std::chrono::steady_clock::now();
-                st = eval_quotient_interpreted(ctx, prog, d_lde_cols, ncols, log_N, log_blowup, offset, row0, N, block, d_out);
-                if (st != SS_OK) return st;
-                const double tc = std::chrono::duration<double>(t1 - t0).count(), ti = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-                choice = tc <= ti ? 1 : 2;
-                if (choice == 2)
-                    fprintf(stderr, "[sandstorm_hip] compiled %s constraint kernel %.1f ms vs interpreter %.1f ms on this device: interpreting\n",
-                            gen->layout, tc * 1e3, ti * 1e3);
-                return SS_OK;
-            }
-            if (choice != 2) return eval_quotient_compiled(ctx, *gen, prog, d_lde_cols, ncols, log_N, log_blowup, offset, d_out, row0, N, block);
-        }
+        bool variant_missing = false;
+        const QGenKernel *gen = quotient_gen_find(prog->code, prog->n_instr, &variant_missing);
+        if (!gen && variant_missing) return fail(SS_ERR_UNSUPPORTED, "SS_QG_VARIANT names a kernel variant this build does not hold (make QG_AB=1)");
+        if (gen && gen->n_consts == prog->n_consts && gen->n_tables == prog->n_tables && gen->ncols <= ncols)
+            return eval_quotient_compiled(ctx, *gen, prog, d_lde_cols, ncols, log_N, log_blowup, offset, d_out, row0, N, block);
     }
     return eval_quotient_interpreted(ctx, prog, d_lde_cols, ncols, log_N, log_blowup, offset, row0, N, block, d_out);
 }

@@ -11,13 +11,13 @@
 // (a_low = low 248 bits, a_high = top 4 bits of the canonical value;
 // mod.rs:25-30; points from builtins/src/pedersen/constants.rs:5-30.)
 //
-// Fixed-base windows.  Device table, per input: 15 windows of 16 bits over bits 0..239
-// (65535 points each) and one 12-bit window over bits 240..251 (the last byte of the low
-// part together with the 4-bit high part, which has its own base point): 16 Jacobian+affine
-// mixed additions (8M + 3S) per input instead of 32 with 8-bit windows.  The table
-// (2 x 987 120 affine points, 126 MB: Infinity-Cache resident) is
-// built once per context ON THE DEVICE from the 8-bit host table (a 16-bit entry is the sum
-// of two 8-bit entries).  The final Jacobian -> affine inversion (~310 multiplications, a
+// Fixed-base windows of W bits (16, 18 or 20; SS_PED_WINDOW, default PED_DEFAULT_WINDOW).  The 252 scalar bits of an
+// input are one bit string - bit i < 248 stands for 2^i P_low, bit 248 + i for 2^i P_high (the 4-bit high part has its
+// own base point) - cut into ceil(252 / W) windows; the device table holds, per input and window, the 2^W - 1 non-zero
+// subset sums as affine points: ceil(252 / W) Jacobian+affine mixed additions (8M + 3S) per input - 16 / 14 / 13 - against
+// 32 with 8-bit windows.  Table sizes 2 x 16 x 65535 x 64 B = 134 MB (Infinity-Cache resident) / 470 MB / 1.7 GB (64-byte
+// gathers from HBM).  Built once per context ON THE DEVICE from the 2 x 252 bit points (one lane per entry: its bits'
+// points summed, one inversion).  The final Jacobian -> affine inversion (~310 multiplications, a
 // quarter of a hash) is not done per hash: the accumulate kernel leaves (X, Z) in a
 // temporary and a second kernel inverts Z in per-lane chunks with Montgomery's trick
 // (5 multiplications per hash + one inversion per chunk).
@@ -51,16 +51,16 @@ static constexpr int PED_LOW_ENTRIES = PED_WINDOWS * 255;
 static constexpr int PED_HIGH_ENTRIES = 15;
 static constexpr int PED_PER_INPUT = PED_LOW_ENTRIES + PED_HIGH_ENTRIES;
 
-// device table layout per input: [15][65535] 16-bit windows | [4095] 12-bit window over bits 240..251
-static constexpr int PED_W16 = 15;
-static constexpr uint32_t PED16_SPAN = 65535;
-static constexpr uint32_t PED16_LOW = PED_W16 * PED16_SPAN;
-static constexpr uint32_t PED16_TOP = 4095;
-static constexpr uint32_t PED16_PER_INPUT = PED16_LOW + PED16_TOP;
+// device table layout per input: [nwin][2^W - 1] (window w covers scalar bits W w .. W w + W - 1 of the 252)
+static constexpr int PED_BITS = 252;
+static constexpr int PED_DEFAULT_WINDOW = 16;
+static constexpr int PED_MAX_WINDOWS = 16;        // the lane-split kernel gives a window to each of 16 lanes per input
 
 struct PedersenTables {
-    Aff *d_table;   // [2][PED16_PER_INPUT]
+    Aff *d_table;   // [2][nwin * span]
     Aff shift;      // P0
+    uint32_t W, nwin, span;      // window bits, windows per input, entries per window (2^W - 1)
+    uint64_t per_input;          // nwin * span
 };
 
 // --------------------------------------------------------------- host side
@@ -128,25 +128,46 @@ static const std::vector<Aff> &host_tables(Aff *shift) {
     return aff;
 }
 
-__global__ void pedersen_build16_kernel(const Aff *__restrict__ t8, Aff *__restrict__ t16);
+__global__ void pedersen_build_windows_kernel(const Aff *__restrict__ bit_points, Aff *__restrict__ table, uint32_t W, uint32_t span, uint64_t per_input);
+
+// the 2 x 252 bit points: bit i of input e stands for 2^i P_{1+2e} (i < 248) or 2^(i-248) P_{2+2e}
+static void build_bit_points(std::vector<Aff> &out) {
+    Aff pts[5];
+    for (int k = 0; k < 5; ++k) { pts[k].x = canon_to_mont(PED_CANON[k][0]); pts[k].y = canon_to_mont(PED_CANON[k][1]); }
+    std::vector<Jac> jac;
+    for (int e = 0; e < 2; ++e) {
+        Jac cur; cur.x = pts[1 + 2 * e].x; cur.y = pts[1 + 2 * e].y; cur.z = fp_one();
+        for (int i = 0; i < 248; ++i) { jac.push_back(cur); cur = jac_double(cur); }
+        cur.x = pts[2 + 2 * e].x; cur.y = pts[2 + 2 * e].y; cur.z = fp_one();
+        for (int i = 248; i < PED_BITS; ++i) { jac.push_back(cur); cur = jac_double(cur); }
+    }
+    batch_to_affine(jac, out);
+}
 
 hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
     Aff shift;
-    const std::vector<Aff> &aff = host_tables(&shift);
+    (void)host_tables(&shift);
+    uint32_t W = PED_DEFAULT_WINDOW;
+    if (const char *e = getenv("SS_PED_WINDOW")) W = (uint32_t)strtoul(e, nullptr, 10);
+    if (W != 16 && W != 18 && W != 20) return hipErrorInvalidValue;
+    std::vector<Aff> bits;
+    build_bit_points(bits);
     PedersenTables *t = new PedersenTables;
     t->shift = shift;
     t->d_table = nullptr;
-    Aff *d_t8 = nullptr;
-    hipError_t e = hipMalloc(&d_t8, aff.size() * sizeof(Aff));
-    if (e == hipSuccess) e = hipMalloc(&t->d_table, 2 * (size_t)PED16_PER_INPUT * sizeof(Aff));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_t8, aff.data(), aff.size() * sizeof(Aff), hipMemcpyHostToDevice, st);
+    t->W = W; t->nwin = (PED_BITS + W - 1) / W; t->span = (1u << W) - 1u;
+    t->per_input = (uint64_t)t->nwin * t->span;
+    Aff *d_bits = nullptr;
+    hipError_t e = hipMalloc(&d_bits, bits.size() * sizeof(Aff));
+    if (e == hipSuccess) e = hipMalloc(&t->d_table, 2 * t->per_input * sizeof(Aff));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bits, bits.data(), bits.size() * sizeof(Aff), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        const uint32_t total = 2 * PED16_PER_INPUT;
-        hipLaunchKernelGGL(pedersen_build16_kernel, dim3((total + 63) / 64), dim3(64), 0, st, d_t8, t->d_table);
+        const uint64_t total = 2 * t->per_input;
+        hipLaunchKernelGGL(pedersen_build_windows_kernel, dim3((uint32_t)((total + 63) / 64)), dim3(64), 0, st, d_bits, t->d_table, W, t->span, t->per_input);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (d_t8) (void)hipFree(d_t8);
+    if (d_bits) (void)hipFree(d_bits);
     if (e != hipSuccess) { if (t->d_table) (void)hipFree(t->d_table); delete t; return e; }
     *out = t;
     return hipSuccess;
@@ -217,55 +238,62 @@ __device__ __forceinline__ void store_aff(Aff *p, const Aff &a) {
     q[3] = make_uint4(a.y.v[4], a.y.v[5], a.y.v[6], a.y.v[7]);
 }
 
-// window entry j = lo + 256 hi:  the sum of the 8-bit-table entries `lo` and `hi` of its two halves
-__global__ __launch_bounds__(64) void pedersen_build16_kernel(const Aff *__restrict__ t8, Aff *__restrict__ t16) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 2 * PED16_PER_INPUT) return;
-    const uint32_t e = idx / PED16_PER_INPUT, r = idx % PED16_PER_INPUT;
-    const Aff *src = t8 + e * PED_PER_INPUT;
-    // source entries of the two halves: a 16-bit window joins 8-bit windows 2w and 2w+1; the top
-    // window joins 8-bit window 30 (bits 240..247) and the 4-bit table of the high base point
-    uint32_t lo, hi;
-    const Aff *src_lo, *src_hi;
-    if (r >= PED16_LOW) {
-        const uint32_t j = r - PED16_LOW + 1;
-        lo = j & 255u; hi = j >> 8;
-        src_lo = src + 30 * 255; src_hi = src + PED_LOW_ENTRIES;
-    } else {
-        const uint32_t w = r / PED16_SPAN, j = r % PED16_SPAN + 1;
-        lo = j & 255u; hi = j >> 8;
-        src_lo = src + (2 * w) * 255; src_hi = src + (2 * w + 1) * 255;
-    }
-    if (!hi) { store_aff(t16 + idx, load_aff(src_lo + (lo - 1))); return; }
-    if (!lo) { store_aff(t16 + idx, load_aff(src_hi + (hi - 1))); return; }
-    const AffL a = load_affl(src_lo + (lo - 1)), b = load_affl(src_hi + (hi - 1));
-    JacL acc; acc.x = a.x; acc.y = a.y; acc.z = fl_one();
-    acc = jacl_add_aff(acc, b);
-    const Fl zi = fn_inv(acc.z), zi2 = fn_sqr(zi);
+// entry j (1 .. 2^W - 1) of window w of input e: the sum of the bit points of j's set bits (bits beyond the 252nd do not exist:
+// the top window is narrower and its upper entries are never addressed)
+__global__ __launch_bounds__(64) void pedersen_build_windows_kernel(const Aff *__restrict__ bit_points, Aff *__restrict__ table, uint32_t W,
+                                                                    uint32_t span, uint64_t per_input) {
+    const uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (idx >= 2 * per_input) return;
+    const uint32_t e = (uint32_t)(idx / per_input);
+    const uint64_t r = idx % per_input;
+    const uint32_t w = (uint32_t)(r / span), j = (uint32_t)(r % span) + 1u, pos = w * W;
+    const Aff *bits = bit_points + (size_t)e * PED_BITS;
+    JacL acc; acc.x = fl_one(); acc.y = fl_one(); acc.z = fl_zero();
+    int terms = 0;
+#pragma unroll 1
+    for (uint32_t b = 0; b < W && pos + b < (uint32_t)PED_BITS; ++b)
+        if ((j >> b) & 1u) { acc = jacl_add_aff(acc, load_affl(bits + pos + b)); ++terms; }
     Aff o;
-    o.x = fl_to_fp(fn_mul(acc.x, zi2));
-    o.y = fl_to_fp(fn_mul(acc.y, fn_mul(zi2, zi)));
-    store_aff(t16 + idx, o);
+    if (terms == 0) { o.x = fp_zero(); o.y = fp_zero(); }                     // only bits that do not exist: never addressed
+    else if (terms == 1) { o.x = fl_to_fp(acc.x); o.y = fl_to_fp(acc.y); }    // z = 1
+    else {
+        const Fl zi = fn_inv(acc.z), zi2 = fn_sqr(zi);
+        o.x = fl_to_fp(fn_mul(acc.x, zi2));
+        o.y = fl_to_fp(fn_mul(acc.y, fn_mul(zi2, zi)));
+    }
+    store_aff(table + idx, o);
+}
+
+// the canonical scalar as a shift register: its low W bits are the next window's digit (no dynamically indexed limbs)
+template <int W>
+__device__ __forceinline__ u32 ped_next_digit(Fp &c) {
+    const u32 d = c.v[0] & ((1u << W) - 1u);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) c.v[i] = (c.v[i] >> W) | (c.v[i + 1] << (32 - W));
+    c.v[7] >>= W;
+    return d;
 }
 
 // acc += scalar (canonical integer limbs) over input slot e
-__device__ __forceinline__ void ped_accumulate(JacL &acc, const Fp &canon, const Aff *__restrict__ table, int e) {
-    const Aff *tab = table + (size_t)e * PED16_PER_INPUT;
+template <int W>
+__device__ __forceinline__ void ped_accumulate(JacL &acc, Fp canon, const Aff *__restrict__ table, uint64_t per_input, int e) {
+    constexpr uint32_t span = (1u << W) - 1u;
+    constexpr int nwin = (PED_BITS + W - 1) / W;
+    const Aff *tab = table + (size_t)e * per_input;
 #pragma unroll 1
-    for (int w = 0; w < PED_W16; ++w) {
-        const u32 d = (canon.v[w >> 1] >> (16 * (w & 1))) & 0xffffu;
-        if (d) acc = jacl_add_aff(acc, load_affl(tab + (size_t)w * PED16_SPAN + (d - 1)));
+    for (int w = 0; w < nwin; ++w) {
+        const u32 d = ped_next_digit<W>(canon);
+        if (d) acc = jacl_add_aff(acc, load_affl(tab + (size_t)w * span + (d - 1)));
     }
-    const u32 dt = (canon.v[7] >> 16) & 0xfffu;   // bits 240..251
-    if (dt) acc = jacl_add_aff(acc, load_affl(tab + PED16_LOW + (dt - 1)));
 }
 
 // both inputs canonical (< p); leaves the Jacobian (X, Z) of P0 + a-part + b-part as weakly reduced images
-__device__ __forceinline__ void ped_jacobian(const Fp &a, const Fp &b, const Aff *__restrict__ table, const Aff &shift,
+template <int W>
+__device__ __forceinline__ void ped_jacobian(const Fp &a, const Fp &b, const Aff *__restrict__ table, uint64_t per_input, const Aff &shift,
                                              Fp *__restrict__ x_out, Fp *__restrict__ z_out) {
     JacL acc; acc.x = fl_from_fp(shift.x); acc.y = fl_from_fp(shift.y); acc.z = fl_one();
-    ped_accumulate(acc, a, table, 0);
-    ped_accumulate(acc, b, table, 1);
+    ped_accumulate<W>(acc, a, table, per_input, 0);
+    ped_accumulate<W>(acc, b, table, per_input, 1);
     store_felt(x_out, fl_pack(acc.x));            // fn_* results are normalised and < 2p
     store_felt(z_out, fl_pack(acc.z));
 }
@@ -296,22 +324,24 @@ struct PedFeltArgs {
     const Fp *a; uint64_t a_stride; Fp a_const;
     const Fp *b; uint64_t b_stride; Fp b_const;
 };
-__global__ __launch_bounds__(64) void pedersen_acc_felts_kernel(const Aff *__restrict__ table, Aff shift, PedFeltArgs g,
+template <int W>
+__global__ __launch_bounds__(64) void pedersen_acc_felts_kernel(const Aff *__restrict__ table, uint64_t per_input, Aff shift, PedFeltArgs g,
                                                                 uint64_t count, Fp *__restrict__ xz) {
     const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (k >= count) return;
     const Fp ca = g.a ? fp_from_mont(load_felt(g.a + k * g.a_stride)) : g.a_const;
     const Fp cb = g.b ? fp_from_mont(load_felt(g.b + k * g.b_stride)) : g.b_const;
-    ped_jacobian(ca, cb, table, shift, xz + k, xz + count + k);
+    ped_jacobian<W>(ca, cb, table, per_input, shift, xz + k, xz + count + k);
 }
 // inputs as 32-byte big-endian digests: (in[2k], in[2k+1])
-__global__ __launch_bounds__(64) void pedersen_acc_pairs_kernel(const Aff *__restrict__ table, Aff shift,
+template <int W>
+__global__ __launch_bounds__(64) void pedersen_acc_pairs_kernel(const Aff *__restrict__ table, uint64_t per_input, Aff shift,
                                                                 const uint8_t *__restrict__ in, uint64_t count,
                                                                 Fp *__restrict__ xz) {
     const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (k >= count) return;
     const Fp ca = be_bytes_to_canon(in + 64 * k), cb = be_bytes_to_canon(in + 64 * k + 32);
-    ped_jacobian(ca, cb, table, shift, xz + k, xz + count + k);
+    ped_jacobian<W>(ca, cb, table, per_input, shift, xz + k, xz + count + k);
 }
 
 // Small levels (the top of every tree: a few thousand hashes or fewer, one level after the
@@ -325,16 +355,21 @@ __device__ __forceinline__ Fl fl_shfl_xor(const Fl &a, int mask) {
     for (int i = 0; i < 9; ++i) r.l[i] = (u32)__shfl_xor((int)a.l[i], mask, 64);
     return r;
 }
-__global__ __launch_bounds__(64) void pedersen_acc_pairs_split_kernel(const Aff *__restrict__ table, Aff shift,
+template <int W>
+__global__ __launch_bounds__(64) void pedersen_acc_pairs_split_kernel(const Aff *__restrict__ table, uint64_t per_input, Aff shift,
                                                                       const uint8_t *__restrict__ in, uint64_t count,
                                                                       Fp *__restrict__ xz) {
+    constexpr uint32_t span = (1u << W) - 1u, nwin = (PED_BITS + W - 1) / W;
+    static_assert(nwin <= (uint32_t)PED_MAX_WINDOWS, "one lane per window: at most 16 windows per input");
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t k = t >> 5;
     if (k >= count) return;                                 // whole 32-lane groups leave together
     const uint32_t sub = (uint32_t)t & 31u, e = sub >> 4, w = sub & 15u;
-    const Fp c = be_bytes_to_canon(in + 64 * k + 32 * e);
-    const u32 d = w < (u32)PED_W16 ? (c.v[w >> 1] >> (16 * (w & 1))) & 0xffffu : (c.v[7] >> 16) & 0xfffu;
-    const Aff *tab = table + (size_t)e * PED16_PER_INPUT + (w < (u32)PED_W16 ? (size_t)w * PED16_SPAN : (size_t)PED16_LOW);
+    Fp c = be_bytes_to_canon(in + 64 * k + 32 * e);
+    u32 d = 0;                                              // this lane's digit: window w of the scalar (lanes w >= nwin idle)
+#pragma unroll 1
+    for (uint32_t q = 0; q <= w && q < nwin; ++q) { const u32 dq = ped_next_digit<W>(c); if (q == w) d = dq; }
+    const Aff *tab = table + (size_t)e * per_input + (size_t)(w < nwin ? w : 0u) * span;
     JacL pt; pt.x = fl_one(); pt.y = fl_one(); pt.z = fl_zero();
     if (d) { const AffL q = load_affl(tab + (d - 1)); pt.x = q.x; pt.y = q.y; pt.z = fl_one(); }
 #pragma unroll 1
@@ -396,9 +431,16 @@ static hipError_t launch_finish(hipStream_t st, Fp *tmp, uint64_t count, Fp *out
     else hipLaunchKernelGGL(pedersen_finish_kernel<false>, grid, block, 0, st, tmp, count, lanes, out_felts, (uint8_t *)nullptr);
     return hipGetLastError();
 }
+// the window width is a template parameter of the accumulate kernels (digits by constant shifts, tables by constant strides)
+#define PED_DISPATCH(W_, CALL)                                                 \
+    switch (W_) {                                                              \
+        case 16: { constexpr int W = 16; CALL; } break;                        \
+        case 18: { constexpr int W = 18; CALL; } break;                        \
+        default: { constexpr int W = 20; CALL; } break;                        \
+    }
 static hipError_t launch_acc_felts(hipStream_t st, const PedersenTables *t, const PedFeltArgs &g, uint64_t count, Fp *tmp) {
-    hipLaunchKernelGGL(pedersen_acc_felts_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table, t->shift,
-                       g, count, tmp);
+    PED_DISPATCH(t->W, hipLaunchKernelGGL(pedersen_acc_felts_kernel<W>, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table, t->per_input,
+                                          t->shift, g, count, tmp));
     return hipGetLastError();
 }
 
@@ -415,12 +457,13 @@ hipError_t launch_pedersen_felts(hipStream_t st, const PedersenTables *t, const 
 hipError_t launch_pedersen_pairs(hipStream_t st, const PedersenTables *t, const uint8_t *in, uint64_t count,
                                  uint8_t *out, Fp *tmp) {
     if (count == 0) return hipSuccess;
-    if (count <= PED_SPLIT_MAX)
-        hipLaunchKernelGGL(pedersen_acc_pairs_split_kernel, dim3((uint32_t)((count * 32 + 63) / 64)), dim3(64), 0, st,
-                           t->d_table, t->shift, in, count, tmp);
-    else
-        hipLaunchKernelGGL(pedersen_acc_pairs_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table,
-                           t->shift, in, count, tmp);
+    if (count <= PED_SPLIT_MAX) {
+        PED_DISPATCH(t->W, hipLaunchKernelGGL(pedersen_acc_pairs_split_kernel<W>, dim3((uint32_t)((count * 32 + 63) / 64)), dim3(64), 0, st,
+                                              t->d_table, t->per_input, t->shift, in, count, tmp));
+    } else {
+        PED_DISPATCH(t->W, hipLaunchKernelGGL(pedersen_acc_pairs_kernel<W>, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table,
+                                              t->per_input, t->shift, in, count, tmp));
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_finish(st, tmp, count, nullptr, out);

@@ -24,6 +24,7 @@ struct QGenArgs {
     const uint32_t *tdesc;                       // per table: first element, index mask (period - 1)
     const uint32_t *consts;                      // per constant QG_CONST_STRIDE dwords, limb form
     Fp *out;
+    Fp *sink;                                    // 32 bytes nobody reads: where lanes past the end of the points store
     Fp offset, w, wstep;                         // x of local point k = offset * w^k (offset carries w^row0); wstep = w^(lanes of the grid)
     uint64_t npoints;                            // points evaluated: the whole domain, or one row block of it
     uint32_t row0;                               // global row of local point 0 (tables are indexed by the global row)
@@ -31,22 +32,28 @@ struct QGenArgs {
     uint32_t log_blowup;                         // row block that carries the rows behind it (ss_eval_quotient_rows)
 };
 
-struct QGenKernel {
-    const char *layout;
-    uint64_t code_hash;                          // FNV-1a of the program's code words
-    uint32_t n_instr, n_consts, n_tables, ncols;
-    uint32_t variant;                            // tools/gen_quotient.py VARIANTS; ss_eval_quotient takes 0 (SS_QG_VARIANT overrides)
-    uint32_t wgs_per_cu;                         // workgroups per CU its register budget allows: the grid is 256 CUs times this
+// One compiled program = one or more kernels ("parts", tools/gen_quotient.py split_program) whose outputs sum to the
+// program's: part 0 stores its sum, every further part adds its own into the output.  A part is sized to the registers and
+// LDS of its workgroup shape, so that two workgroups per CU are resident wherever its scratch values allow.
+static constexpr int QG_MAX_PARTS = 8;
+struct QGenPart {
+    uint32_t wgs_per_cu;                         // workgroups per CU its register / LDS budget allows: the grid is 256 CUs times this
     uint32_t threads;                            // lanes per workgroup (QG_THREADS of that kernel's translation unit)
+    uint32_t n_instr;                            // program instructions in this part
     hipError_t (*launch)(hipStream_t, const QGenArgs &, uint32_t blocks);
 };
+struct QGenKernel {
+    const char *layout;
+    uint64_t code_hash;                          // FNV-1a of the (whole) program's code words
+    uint32_t n_instr, n_consts, n_tables, ncols;
+    uint32_t variant;                            // tools/gen_quotient.py VARIANTS; ss_eval_quotient takes 0 (SS_QG_VARIANT overrides)
+    uint32_t n_parts;
+    QGenPart parts[QG_MAX_PARTS];
+};
 
-const QGenKernel &quotient_gen_starknet();       // quotient_gen_starknet.hip
-const QGenKernel &quotient_gen_recursive();      // quotient_gen_recursive.hip
-#ifdef SS_QG_AB_VARIANTS
-const QGenKernel &quotient_gen_starknet_v1(); const QGenKernel &quotient_gen_starknet_v2(); const QGenKernel &quotient_gen_starknet_v3();
-const QGenKernel &quotient_gen_recursive_v1(); const QGenKernel &quotient_gen_recursive_v2(); const QGenKernel &quotient_gen_recursive_v3();
-#endif
+#define QG_VARIANT(entry) const QGenKernel &entry();
+#include "quotient_gen_variants.inc"             // quotient_gen_starknet(), quotient_gen_recursive() [, the A/B variants]
+#undef QG_VARIANT
 
 typedef uint32_t qg_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -64,7 +71,19 @@ __device__ __forceinline__ void qg_store(Fp *p, const Fp &x) {
     q[0] = qg_u32x4{x.v[0], x.v[1], x.v[2], x.v[3]};
     q[1] = qg_u32x4{x.v[4], x.v[5], x.v[6], x.v[7]};
 }
-#define QG_OUT(v) qg_store(a.out + i, fl_to_fp(v))
+// (a lane past the end of the points stores into a.sink instead: a select of the address, not a branch around the store -
+// control flow here costs the register allocator the whole kernel, 6 KB of scratch per lane)
+#define QG_OUT(v) qg_store(qg_live ? a.out + i : a.sink, fl_to_fp(v))
+// parts after the first: out += v (canonical before and after; out[i] was written by the previous part's launch)
+#define QG_OUT_ACC(v) qg_store(qg_live ? a.out + i : a.sink, fl_to_fp(fl_add(fl_weak_reduce(v), fl_from_fp(qg_load_raw(a.out, (uint32_t)i)))))
+// QG_SYNC (between program instructions, where a part's configuration asks for it): the waves of a workgroup run the same
+// straight-line code; kept within a few instructions of each other they share every instruction-cache line they fetch
+// (a part is 100-900 KB of code against 64 KB of instruction cache per two CUs)
+#ifdef QG_SYNC_WAVES
+#define QG_SYNC __syncthreads();
+#else
+#define QG_SYNC
+#endif
 
 // constants live in LDS for the kernel's lifetime (18 dwords each: 9 R256 limbs, 9 R280 limbs): a wave-uniform LDS read
 // is a broadcast, its latency is short and known to the scheduler - unlike ~25 KB of scalar loads that miss the 16 KB
@@ -150,11 +169,16 @@ static inline size_t qg_lds_bytes(int nconsts, int nslots) {
     const Fl wstep = fl_from_fp(a.wstep);                                                             \
     QG_DECLARE_SLOTS
 
-// lanes past the end (a grid larger than the block of points) still run the loads with a wrapped index, never the store
+// Every lane of the grid runs the same number of iterations (the parts may hold workgroup barriers - QG_SYNC - inside a point):
+// a lane past the end of the points works on the last point again and does not store.
 #define QG_POINT_LOOP_BEGIN                                                                           \
-    for (uint64_t i = lane; i < N; i += lanes) {                                                      \
+    const uint64_t qg_iters = (N + lanes - 1) / lanes;                                                \
+    for (uint64_t qg_it = 0; qg_it < qg_iters; ++qg_it) {                                             \
+        const uint64_t qg_raw = lane + qg_it * lanes;                                                 \
+        const bool qg_live = qg_raw < N;                                                              \
+        const uint64_t i = qg_live ? qg_raw : N - 1;                                                  \
         i32 = (uint32_t)i;                                                                            \
-        const uint32_t inext = (uint32_t)(i + lanes < N ? i + lanes : i);                             \
+        const uint32_t inext = (uint32_t)(qg_raw + lanes < N ? qg_raw + lanes : N - 1);               \
         /* the constants do not change, but their loads must not be hoisted out of the loop (thousands of registers) */ \
         asm volatile("" : "+v"(lds_consts), "+v"(lds_slots));
 

@@ -34,7 +34,9 @@ struct HostArgs {
 #define QG_CONST_R280(k) a.consts_r280[k]
 #define QG_SLOT_STORE(k, v) slots[k] = fl_pack(v)
 #define QG_SLOT(k) fl_from_fp(slots[k])
-#define QG_OUT(v) a.out[i] = fl_to_fp(v)
+#define QG_OUT(v) *(qg_live ? &a.out[i] : &sink) = fl_to_fp(v)
+#define QG_OUT_ACC(v) *(qg_live ? &a.out[i] : &sink) = fl_to_fp(fl_add(fl_weak_reduce(v), fl_from_fp(a.out[i])))
+#define QG_SYNC
 #define QG_PIN_LOADS
 #define QG_FENCE
 typedef FlWide QgWide;
@@ -42,22 +44,29 @@ typedef FlWide QgWide;
 #define qg_dot_mad fl_wide_mad
 #define qg_dot_reduce fl_wide_reduce
 #define QG_POINT_LOOP_BEGIN                                        \
-    for (uint64_t i = lane; i < N; i += lanes) {                   \
+    const uint64_t qg_iters = (N + lanes - 1) / lanes;             \
+    for (uint64_t qg_it = 0; qg_it < qg_iters; ++qg_it) {          \
+        const uint64_t qg_raw = lane + qg_it * lanes;              \
+        const bool qg_live = qg_raw < N;                           \
+        const uint64_t i = qg_live ? qg_raw : N - 1;               \
         i32 = (uint32_t)i;                                         \
-        const uint32_t inext = (uint32_t)(i + lanes < N ? i + lanes : i);
+        const uint32_t inext = (uint32_t)(qg_raw + lanes < N ? qg_raw + lanes : N - 1);
 #define QG_POINT_LOOP_END                                          \
         x = fl_mul(x, wstep);                                      \
     }
 
-// one "lane" of a grid of `lanes` lanes: exactly the device kernel's per-lane code
-static void run_lane_LAYOUT(HostArgs &a, uint64_t lane, uint64_t lanes) {
-    const uint64_t N = a.npoints;
-    const uint32_t lb = a.log_blowup, maskN = a.trace_mask, row0 = a.row0;
-    Fp slots[64];
-    Fl x = fl_from_fp(fp_mul(a.offset, fp_pow_u64(a.w, lane)));
+// one "lane" of a grid of `lanes` lanes: exactly the device kernel's per-lane code.  A compiled program is one or more parts
+// (csrc/quotient_gen_<layout>_p<j>.inc) run one after the other over the whole domain, like the device's launches: part 0 stores,
+// the others add.  QG_PARTS_H (written by tests/test_quotient_gen_host.py) defines one function per part with QG_LANE_PRELUDE in
+// front of the included body, and the table PARTS.
+#define QG_LANE_PRELUDE                                                              \
+    const uint64_t N = a.npoints;                                                    \
+    const uint32_t lb = a.log_blowup, maskN = a.trace_mask, row0 = a.row0;           \
+    Fp slots[64], sink;                                                              \
+    Fl x = fl_from_fp(fp_mul(a.offset, fp_pow_u64(a.w, lane)));                      \
     const Fl wstep = fl_from_fp(fp_pow_u64(a.w, lanes));
-#include QG_INC
-}
+typedef void (*part_fn)(HostArgs &, uint64_t, uint64_t);
+#include QG_PARTS_H
 
 template <class T>
 static void rd(FILE *f, T *p, size_t n) { if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } }
@@ -81,8 +90,10 @@ int main(int argc, char **argv) {
     a.out.assign(a.npoints, fp_zero());
     a.offset = fp_mul(a.offset, fp_pow_u64(a.w, a.row0));
     const uint64_t lanes = hdr[9];
+    for (part_fn part : PARTS) {
 #pragma omp parallel for schedule(dynamic, 16)
-    for (uint64_t lane = 0; lane < lanes; ++lane) run_lane_LAYOUT(a, lane, lanes);
+        for (uint64_t lane = 0; lane < lanes; ++lane) part(a, lane, lanes);
+    }
     f = fopen(argv[2], "wb");
     fwrite(a.out.data(), sizeof(Fp), a.out.size(), f);
     fclose(f);

@@ -9,7 +9,9 @@ OUT=${HIPEMU_OUT:-$HERE/_build}; mkdir -p $OUT
 # run with LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0
 SAN=${HIPEMU_SANITIZE:+-fsanitize=$HIPEMU_SANITIZE -fno-omit-frame-pointer -g1}
 FLAGS="-x c++ -std=c++17 -O2 -fPIC -w $SAN -I $HERE -I $ROOT/include -I $ROOT/sandstorm_amd/csrc"
-SRCS="capi ntt hash pedersen fri deep quotient ext goldilocks quotient_gen_starknet quotient_gen_recursive"
+# the generated constraint kernels' translation units: csrc/quotient_gen_sources.mk (tools/gen_quotient.py)
+QG=$(sed -n 's/^QG_SRCS := //p' $ROOT/sandstorm_amd/csrc/quotient_gen_sources.mk | sed 's/\.hip//g')
+SRCS="capi ntt hash pedersen fri deep quotient ext goldilocks $QG"
 pids=()
 for f in $SRCS; do
   src=$ROOT/sandstorm_amd/csrc/$f.hip; obj=$OUT/$f.o

@@ -75,8 +75,8 @@ def test_extension_columns_and_compiled_constraint_kernels(emulated_library):
     """tests/test_gpu_extension.py (the scans behind Trace::build_extension_columns) and tests/test_gpu_real_quotient.py (the generated
     starknet / recursive kernels against the interpreter and the oracle over whole domains)"""
     heavy()
-    out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_extension.py", "tests/test_gpu_real_quotient.py", "-k", "not first_large_evaluation"])
-    assert "41 passed" in out, out[-500:]                     # 36 + 5 (the sixth times two kernels against each other: hardware only)
+    out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_extension.py", "tests/test_gpu_real_quotient.py", "-k", "not back_to_back"])
+    assert "41 passed" in out, out[-500:]                     # 36 + 5 (the sixth queues 2^20-point evaluations back to back: hardware only)
 
 
 def test_whole_proofs(emulated_library):

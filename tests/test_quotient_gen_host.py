@@ -2,7 +2,9 @@
 tools/gen_quotient.py writes and the device kernel includes) compiled for the host (tests/cpp/quotient_gen_host_test.cpp)
 and run over a whole evaluation domain of random columns, tables and constants, against the oracle's constraint VM on
 the program it was generated from - bit for bit; also in the row-block form of the sharded prover, and with a "grid"
-that does not divide the domain (the rotating prefetch registers cross the loop edge at every point)."""
+that does not divide the domain (the rotating prefetch registers cross the loop edge at every point).  A compiled program
+is several kernels (tools/gen_quotient.py split_program): the parts run one after the other, the first storing and the others
+adding into the output, as the device launches them."""
 import os
 import struct
 import subprocess
@@ -19,10 +21,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp", "quotient_gen_host_test.cpp")
 
 
+def part_bodies(layout):
+    """the bodies of the layout's compiled program, in launch order: csrc/quotient_gen_<layout>_p<j>.inc"""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "sandstorm_amd", "csrc")
+    found = {int(re.search(r"_p(\d+)\.inc$", f).group(1)): f for f in glob.glob(os.path.join(csrc, "quotient_gen_%s_p*.inc" % layout))}
+    assert sorted(found) == list(range(len(found))) and found, found
+    return [found[j] for j in range(len(found))]
+
+
 def build(layout, tmp):
     exe = os.path.join(tmp, "qg_host_%s" % layout)
-    inc = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s.inc" % layout)
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fopenmp", "-DQG_INC=\"%s\"" % inc, "-o", exe, CPP])
+    parts = part_bodies(layout)
+    with open(os.path.join(tmp, "qg_parts.h"), "w") as f:
+        for j, inc in enumerate(parts):
+            f.write("static void run_lane_p%d(HostArgs &a, uint64_t lane, uint64_t lanes) {\n    QG_LANE_PRELUDE\n#include \"%s\"\n}\n" % (j, inc))
+        f.write("static const part_fn PARTS[] = {%s};\n" % ", ".join("run_lane_p%d" % j for j in range(len(parts))))
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fopenmp", "-I", tmp, "-DQG_PARTS_H=\"qg_parts.h\"", "-o", exe, CPP])
     return exe
 
 

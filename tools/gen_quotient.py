@@ -67,6 +67,175 @@ def template_program(layout):
     return np.asarray(code, dtype=np.uint32), len(consts), n_slots, len(specs), ncols
 
 
+
+def decode(code):
+    return [(int(code[2 * pc]) & 0xff, (int(code[2 * pc]) >> 8) & 0xf, (int(code[2 * pc]) >> 12) & 0xf, int(code[2 * pc + 1])) for pc in range(len(code) // 2)]
+
+
+def split_program(ins, parts, inner_split=False):
+    """Cut the program into `parts` programs whose outputs SUM to the program's output (several kernels by
+    constraint group, each small enough in registers for two workgroups per CU and in code for the instruction cache).
+
+    The composition is a sum of terms "group of constraints times the inverse of their zerofier" (42 for starknet, hardly a
+    value shared between two of them).  The instruction stream is executed symbolically into a value graph, the output's
+    top-level additions are flattened into those terms, the terms are dealt into `parts` runs of consecutive terms with
+    balanced multiplication counts, and part j keeps - in the original order, with the original accumulators, slots,
+    constants and tables - exactly the instructions its terms depend on; a top-level addition one of whose sides has no
+    term in the part degenerates into a move or disappears.  -> [instruction list] (each ends in OUT)."""
+    nodes = []                                     # (kind, a, b): kind in LEAF / ADD / SUB / MUL / INV
+    def new(kind, a=None, b=None):
+        nodes.append((kind, a, b))
+        return len(nodes) - 1
+    acc, slot, produced, root = [None] * 4, {}, [None] * len(ins), None
+    for pc, (op, d, kind, w1) in enumerate(ins):
+        if op <= OP_MUL:
+            src = acc[w1 & 3] if kind == SRC_ACC else slot[w1] if kind == SRC_SLOT else new("LEAF")
+        if op == OP_MOV:
+            acc[d] = src
+        elif op in (OP_ADD, OP_SUB, OP_MUL):
+            acc[d] = new({OP_ADD: "ADD", OP_SUB: "SUB", OP_MUL: "MUL"}[op], acc[d], src)
+        elif op == OP_RSUB:
+            acc[d] = new("SUB", src, acc[d])
+        elif op == OP_INV:
+            acc[d] = new("INV", acc[d])
+        elif op == OP_ST:
+            slot[w1] = acc[d]
+        else:
+            root = acc[d]
+        produced[pc] = acc[d] if op != OP_ST else slot[w1]
+    assert root is not None and ins[-1][0] == OP_OUT
+    uses = {}
+    for kind, a, b in nodes:
+        for x in (a, b):
+            if x is not None:
+                uses[x] = uses.get(x, 0) + 1
+    terms, inner, scale = [], set(), set()
+    stack = [root]
+    while stack:                                   # the flattened top-level sum: inner additions, leaves = the terms
+        v = stack.pop()
+        kind, a, b = nodes[v]
+        if kind == "ADD" and (v == root or uses.get(v, 0) == 1):
+            inner.add(v)
+            stack += [a, b]
+        elif inner_split and kind == "MUL" and uses.get(v, 0) == 1 and nodes[b][0] == "LEAF" and nodes[a][0] in ("ADD", "MUL"):
+            # "sum of constraints x inverse zerofier" / "constraint x alpha^k": a scaling by a table or constant distributes over
+            # the sum below it, so the split may cut INSIDE a group (each side then pays the scaling once)
+            scale.add(v)
+            stack.append(a)
+        else:
+            terms.append(v)
+    terms.sort()                                   # value numbers grow with the program counter
+    def cone(v, seen):
+        st = [v]
+        while st:
+            x = st.pop()
+            if x in seen:
+                continue
+            seen.add(x)
+            st += [y for y in nodes[x][1:] if y is not None]
+        return seen
+    weight = [sum(1 for x in cone(t, set()) if nodes[x][0] == "MUL") + 1 for t in terms]
+    total, cuts, run = sum(weight), [], 0
+    for k, wgt in enumerate(weight):               # consecutive runs of ~ total / parts multiplications
+        run += wgt
+        if len(cuts) < parts - 1 and run >= total * (len(cuts) + 1) / parts:
+            cuts.append(k + 1)
+    bounds = [0] + cuts + [len(terms)]
+    out = []
+    for j in range(parts):
+        mine = terms[bounds[j]:bounds[j + 1]]
+        assert mine, "more parts than terms"
+        need = set()
+        for t in mine:
+            cone(t, need)
+        # which inner sums are non-empty in this part
+        full = set(mine)
+        def nonempty(v):
+            if v in full:
+                return True
+            if v in scale:
+                r = nonempty(nodes[v][1])
+                if r:
+                    full.add(v)
+                return r
+            if v not in inner:
+                return False
+            _, a, b = nodes[v]
+            r = nonempty(a) | nonempty(b)          # no short circuit: memoise both
+            if r:
+                full.add(v)
+            return r
+        nonempty(root)
+        acc, slot, part = [None] * 4, {}, []
+        for pc, (op, d, kind, w1) in enumerate(ins):   # replay: same symbolic values, filtered emission
+            if op <= OP_MUL:
+                src = acc[w1 & 3] if kind == SRC_ACC else slot[w1] if kind == SRC_SLOT else None
+            v = produced[pc]
+            if op == OP_MOV:
+                val = src if kind in (SRC_ACC, SRC_SLOT) else v
+                if (val in need or val in full) if kind in (SRC_ACC, SRC_SLOT) else (v in need):
+                    part.append(ins[pc])
+                acc[d] = v
+            elif op == OP_ST:
+                if v in need or v in full:
+                    part.append(ins[pc])
+                slot[w1] = v
+            elif op == OP_OUT:
+                part.append(ins[pc])
+            elif v in scale:                       # the scaling of a (partial) sum: only where something is summed
+                if nodes[v][1] in full:
+                    part.append(ins[pc])
+                acc[d] = v
+            elif v in inner:                       # a top-level addition: d = d + src
+                a_, b_ = nodes[v][1], nodes[v][2]
+                ea, eb = a_ in full, b_ in full
+                if ea and eb:
+                    part.append(ins[pc])
+                elif eb:                           # nothing of this part on the accumulator's side yet: the sum starts here
+                    part.append((OP_MOV, d, kind, w1))
+                acc[d] = v
+            else:
+                if v in need:
+                    part.append(ins[pc])
+                acc[d] = v
+        out.append(part)
+    return out, [weight[bounds[j]:bounds[j + 1]] for j in range(parts)]
+
+
+def compact_slots(ins):
+    """rename the scratch slots of a (part) program so that values with disjoint lifetimes share a slot: -> (program, slots).
+    A slot's value lives from its ST to its last read before the next ST of the same slot."""
+    lives, open_ = [], {}                          # [first pc, last pc, [pcs that name it]]
+    for pc, (op, d, kind, w1) in enumerate(ins):
+        if op <= OP_MUL and kind == SRC_SLOT:
+            iv = open_[w1]
+            iv[1] = pc
+            iv[2].append(pc)
+        elif op == OP_ST:
+            open_[w1] = [pc, pc, [pc]]
+            lives.append(open_[w1])
+    out, free_at, n = list(ins), [], 0             # free_at[c] = pc after which colour c is free
+    for first, last, pcs in sorted(lives, key=lambda iv: iv[0]):
+        c = next((c for c in range(n) if free_at[c] < first), None)
+        if c is None:
+            c = n
+            n += 1
+            free_at.append(0)
+        free_at[c] = last
+        for pc in pcs:
+            op, d, kind, _ = out[pc]
+            out[pc] = (op, d, kind, c)
+    return out, n
+
+
+def encode(ins):
+    import numpy as np
+    code = np.zeros(2 * len(ins), dtype=np.uint32)
+    for pc, (op, d, kind, w1) in enumerate(ins):
+        code[2 * pc], code[2 * pc + 1] = op | (d << 8) | (kind << 12), w1
+    return code
+
+
 PREFETCH_DEPTH = 6      # memory operands in flight ahead of their use (one wave per SIMD: nothing else hides the latency)
 DOT_MAX_TERMS = 16      # products accumulated in the 64-bit columns before a Montgomery reduction (16 * 9 * 2^56 < 2^64)
 # Fusing "MUL acc, alpha^k ; ADD sum, acc" chains into dot products (one Montgomery reduction per DOT_MAX_TERMS units of bound)
@@ -76,39 +245,74 @@ DOT_MAX_TERMS = 16      # products accumulated in the 64-bit columns before a Mo
 # The recursive kernel lives on two workgroups per CU (256 registers) and has no room for the accumulator: unfused.
 
 
-# Kernel variants built side by side (ss_eval_quotient takes variant 0; SS_QG_VARIANT=k selects another for A/B runs):
-#   (name suffix, prefetch depth, slots in registers instead of LDS, workgroups per CU the register budget is set for)
-# Measured on the MI355X (profiles/r02_quotient_codegen_experiments.txt; 2^25 points): the starknet program is register
-# bound - LDS slots, one workgroup per CU, a shallow prefetch (unfused, depth 3: 153.7 ms, 2: 154.3, 1: 159.6, 4: 153.7,
-# 6: 171.5; slots in registers at two workgroups per CU: 352, scratch spills; fenced + fused, depth 3: 140.2, 2: 140.6,
-# 4: 167.8, slots in registers: 161.6); the recursive one fits two workgroups per CU with its slots in registers (depth 4:
-# 65.5 ms, 6: 66.0, 2: 65.1; LDS slots at one workgroup per CU: 76.9; fenced + fused at one workgroup per CU: 86; one 512-lane
-# workgroup per CU with LDS slots - two waves per SIMD, constants shared - does not fit 256 registers either: 88 B of scratch
-# unfused, 868 B fused, not run).
-# (suffix, operand prefetch depth, slots in registers, workgroups per CU, scheduling fence after every program instruction,
-#  "MUL alpha^k; ADD" chains as fused dot products, lanes per workgroup: 512 = two waves per SIMD in ONE workgroup, which
-#  shares the LDS constants and leaves room for LDS slots)
+# Kernel variants built side by side (ss_eval_quotient takes variant 0; SS_QG_VARIANT=k selects another for A/B runs, built by
+# `make QG_AB=1`).  A variant = (name suffix, inner split, [one configuration per PART]); a part's configuration =
+#   (operand prefetch depth, slots in registers instead of LDS, workgroups per CU the register budget is set for, scheduling
+#    fence after every program instruction, "MUL alpha^k; ADD" chains as fused dot products, lanes per workgroup)
+# Round 2, one kernel per layout, measured on the MI355X (profiles/r02_quotient_codegen_experiments.txt; 2^25 points): the
+# starknet program is register bound - LDS slots, one workgroup per CU, a shallow prefetch (unfused, depth 3: 153.7 ms, 2:
+# 154.3, 1: 159.6, 4: 153.7, 6: 171.5; slots in registers at two workgroups per CU: 352, scratch spills; fenced + fused, depth
+# 3: 140.2, 2: 140.6, 4: 167.8, slots in registers: 161.6); the recursive one fits two workgroups per CU with its slots in
+# registers (depth 4: 65.5 ms, 6: 66.0, 2: 65.1; LDS slots at one workgroup per CU: 76.9; fenced + fused at one workgroup per
+# CU: 86).  Round 3: the program cut into parts that each fit two workgroups per CU - split_program above.
+ONE_WG = (3, False, 1, True, True, 256)            # round 2's starknet kernel: 17 LDS slots, fused dot products, one wave per SIMD
+TWO_WG = (3, False, 2, True, False, 256)           # <= 7 LDS slots + constants in 80 KB, 256 registers: two waves per SIMD
+TWO_WG_FUSED = (3, False, 2, True, True, 256)
+TWO_WG_REGS = (4, True, 2, False, False, 256)      # round 2's recursive kernel: slots in registers
+BIG_WG = (3, False, 1, True, False, 512)           # ONE 512-lane workgroup per CU: two waves per SIMD behind one barrier, constants shared
+sync = lambda cfg, every=8: cfg + (every,)         # + a workgroup barrier every `every` program instructions
 VARIANTS = {
-    "starknet": [("", 3, False, 1, True, True, 256), ("_v1", 2, False, 1, True, True, 256), ("_v2", 3, True, 1, True, True, 256), ("_v3", 3, False, 1, False, False, 256)],
-    "recursive": [("", 4, True, 2, False, False, 256), ("_v1", 4, True, 1, True, True, 256), ("_v2", 4, False, 1, True, True, 512), ("_v3", 4, False, 1, False, False, 512)],
+    "starknet": [("", True, [sync(ONE_WG)] + [sync(TWO_WG)] * 5),
+                 ("_v1", False, [ONE_WG]),                                 # round 2's kernel
+                 ("_v2", False, [sync(ONE_WG)]),                           # ... its waves in lock step
+                 ("_v3", True, [ONE_WG] + [TWO_WG] * 5),                   # cut into 6, no barriers
+                 ("_v4", True, [sync(ONE_WG)] + [sync(TWO_WG_FUSED)] * 5),
+                 ("_v5", True, [sync(ONE_WG)] + [sync(TWO_WG)] * 3),
+                 ("_v6", True, [sync(ONE_WG)] + [sync(TWO_WG)] * 7),
+                 ("_v7", True, [sync(ONE_WG)] + [sync(BIG_WG)] * 5),
+                 ("_v8", True, [sync(ONE_WG, 32)] + [sync(TWO_WG, 32)] * 5),
+                 ("_v9", False, [ONE_WG, TWO_WG, TWO_WG])],                # cuts between zerofier groups only
+    "recursive": [("", True, [sync(ONE_WG)] + [sync(TWO_WG)] * 2),
+                  ("_v1", False, [TWO_WG_REGS]),                           # round 2's kernel
+                  ("_v2", False, [sync(TWO_WG_REGS)]),
+                  ("_v3", True, [TWO_WG_REGS, TWO_WG, TWO_WG]),
+                  ("_v4", True, [ONE_WG, TWO_WG, TWO_WG]),
+                  ("_v5", True, [sync(ONE_WG)] + [sync(TWO_WG)] * 3),
+                  ("_v6", True, [sync(ONE_WG)] + [sync(TWO_WG_FUSED)] * 2)],
 }
+LDS_BYTES_PER_CU = 160 * 1024
 
 
 def generate(layout, all_variants=False):
-    """variant 0 is what the library builds; --all-variants also writes the others (add them to csrc/Makefile, quotient_gen.h and
-    the table in capi.hip's quotient_gen_find for an A/B run with SS_QG_VARIANT=k)"""
-    program = template_program(layout)
-    bodies = {}
-    for k, (suffix, depth, slots_in_regs, wgs, fence, fuse, threads) in enumerate(VARIANTS[layout] if all_variants else VARIANTS[layout][:1]):
-        if (depth, fuse) not in bodies:
-            bodies[(depth, fuse)] = generate_body(layout, program, depth, "" if not bodies else "_d%d%s" % (depth, "f" if fuse else ""), fuse)
-        write_wrapper(layout, program, k, suffix, bodies[(depth, fuse)], slots_in_regs, wgs, fence, threads)
+    """variant 0 is what the library builds; --all-variants also writes the others (`make QG_AB=1` builds them, SS_QG_VARIANT=k
+    selects one at run time).  -> [(variant, suffix, [part source names])]"""
+    code, n_consts, n_slots, n_tables, ncols = template_program(layout)
+    ins = decode(code)
+    written = []
+    for k, (suffix, inner, cfgs) in enumerate(VARIANTS[layout] if all_variants else VARIANTS[layout][:1]):
+        parts, weights = split_program(ins, len(cfgs), inner) if len(cfgs) > 1 else ([ins], None)
+        names = []
+        for j, (part, cfg) in enumerate(zip(parts, cfgs)):
+            depth, slots_in_regs, wgs, fence, fuse, threads = cfg[:6]
+            sync = cfg[6] if len(cfg) > 6 else 0
+            part, part_slots = compact_slots(part)
+            if not slots_in_regs:
+                lds = part_slots * 2 * threads * 16 + n_consts * 18 * 4
+                assert lds * wgs <= LDS_BYTES_PER_CU, "%s%s part %d: %d slots + constants = %d B of LDS x %d workgroups per CU" % (layout, suffix, j, part_slots, lds, wgs)
+            base = "quotient_gen_%s%s_p%d" % (layout, suffix, j)
+            body = generate_body(layout, part, n_consts, part_slots, n_tables, ncols, depth, base + ".inc", fuse, "QG_OUT" if j == 0 else "QG_OUT_ACC", sync)
+            write_part(layout, suffix, j, len(parts), base, body, len(part), n_consts, part_slots, slots_in_regs, wgs, fence, threads, sync)
+            names.append(base + ".hip")
+        write_kernel_table(layout, suffix, k, code, n_consts, n_tables, ncols, len(parts))
+        names.append("quotient_gen_%s%s.hip" % (layout, suffix))
+        written.append((k, suffix, names))
+    return written
 
 
-def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix, FUSE_ALPHA_DOT_PRODUCTS=False):
-    code, n_consts, n_slots, n_tables, ncols = program
-    n_instr = len(code) // 2
-    ins = [(int(code[2 * pc]) & 0xff, (int(code[2 * pc]) >> 8) & 0xf, (int(code[2 * pc]) >> 12) & 0xf, int(code[2 * pc + 1])) for pc in range(n_instr)]
+def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPTH, inc_name, FUSE_ALPHA_DOT_PRODUCTS=False, out_macro="QG_OUT",
+                  sync_every=0):
+    """the straight-line body of one (part) program -> csrc/<inc_name>"""
+    n_instr = len(ins)
     # ---- memory operands in program order: loaded PREFETCH_DEPTH operands ahead into a rotating set of registers
     mem_ops = []                                    # (pc, macro text)
     for pc, (op, d, kind, w1) in enumerate(ins):
@@ -168,6 +372,8 @@ def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix, FUSE_ALPHA_DOT_PR
         v = "acc%d" % d
         if pc:
             emit("    QG_FENCE")
+        if sync_every and pc and pc % sync_every == 0:
+            emit("    QG_SYNC")
         if pc in skip_add:                          # the ADD of a fused pair: already accounted in the wide accumulator
             continue
         # any other touch of the accumulator that carries a pending dot product needs its value: flush first
@@ -284,7 +490,7 @@ def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix, FUSE_ALPHA_DOT_PR
             emit("    QG_SLOT_STORE(%d, %s);" % (w1, v))
         else:
             flush_wide()
-            emit("    QG_OUT(%s);" % v)
+            emit("    %s(%s);" % (out_macro, v))
         # this instruction consumed memory operand q and freed register q % D: start the load of operand q + D there - or, in
         # the last D steps of a point, of the next point's operand whose home register that is (operand j lives in m[j % D];
         # when D does not divide the operand count the tail fills the registers in rotated order)
@@ -303,12 +509,12 @@ def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix, FUSE_ALPHA_DOT_PR
 // wrappers (device) and, with host definitions of the same macros, by tests/cpp/quotient_gen_host_test.cpp, which runs it on
 // the CPU against the oracle's constraint VM.
     Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
-%(wide)s%(regs)s    uint32_t i32 = (uint32_t)lane;
+%(wide)s%(regs)s    uint32_t i32 = (uint32_t)(lane < N ? lane : N - 1);
 %(prime)s    QG_POINT_LOOP_BEGIN
 %(body)s
     QG_POINT_LOOP_END
 ''' % dict(layout=layout, regs=regs, prime=prime, body=body, depth=D, wide="    QgWide wd;\n" if stats["fused"] else "")
-    name = "quotient_gen_%s%s.inc" % (layout, inc_suffix)
+    name = inc_name
     with open(os.path.join(ROOT, "sandstorm_amd", "csrc", name), "w") as f:
         f.write(inc)
     print("%s: %d instructions, %d multiplications (%d by constants, %d fused into %d dot products), %d loads %d ahead, %d reductions -> %s"
@@ -316,61 +522,102 @@ def generate_body(layout, program, PREFETCH_DEPTH, inc_suffix, FUSE_ALPHA_DOT_PR
     return dict(stats, inc=name, depth=D)
 
 
-def write_wrapper(layout, program, variant, suffix, body, slots_in_regs, wgs, fence=False, threads=256):
-    code, n_consts, n_slots, n_tables, ncols = program
-    n_instr = len(code) // 2
-    h = code_hash(code)
-    src = '''// GENERATED by tools/gen_quotient.py - DO NOT EDIT; regenerate with `python tools/gen_quotient.py %(layout)s`.
+def write_part(layout, suffix, part, n_parts, base, body, n_instr, n_consts, n_slots, slots_in_regs, wgs, fence, threads, sync=0):
+    src = """// GENERATED by tools/gen_quotient.py - DO NOT EDIT; regenerate with `python tools/gen_quotient.py %(layout)s`.
 //
 // The composition constraint of the `%(layout)s` layout (layouts/src/%(layout)s/air.rs; lowered by
-// sandstorm_amd/host/air_%(layout)s.cpp + air_program.cpp) as straight-line code for gfx950, variant %(variant)d: %(n_instr)d
-// program instructions, %(mul)d multiplications (%(mulr)d by a constant in R280 form, %(fused)d as terms of %(flushes)d fused dot products), %(loads)d trace / table operand loads issued
-// %(depth)d operands ahead of their use, %(reduce)d weak reductions placed at generation time, %(n_slots)d scratch values per point
-// in %(where)s, constants in LDS, register budget for %(wgs)d workgroup(s) per CU%(fence)s.
-// Code hash (FNV-1a of the program's code words) 0x%(hash)016x: ss_eval_quotient launches this kernel for exactly
-// that program and interprets any other.
+// sandstorm_amd/host/air_%(layout)s.cpp + air_program.cpp) as straight-line code for gfx950%(variant)s - PART %(part)d OF %(n_parts)d
+// (the parts' outputs sum to the composition; part 0 stores, the others add into the output: tools/gen_quotient.py
+// split_program): %(n_instr)d program instructions, %(mul)d multiplications (%(mulr)d by a constant in R280 form, %(fused)d as terms of
+// %(flushes)d fused dot products), %(loads)d trace / table operand loads issued %(depth)d operands ahead of their use, %(reduce)d weak reductions
+// placed at generation time, %(n_slots)d scratch values per point in %(where)s, constants in LDS, register budget for %(wgs)d
+// workgroup(s) per CU%(fence)s.
 %(define)s#include "quotient_gen.h"
 
 namespace ss {
 namespace {
 
-__global__ __launch_bounds__(QG_THREADS, %(wgs)d) void quotient_%(layout)s%(suffix)s_kernel(QGenArgs a) {
+__global__ __launch_bounds__(QG_THREADS, %(wgs)d) void quotient_%(layout)s%(suffix)s_p%(part)d_kernel(QGenArgs a) {
     QG_PROLOGUE(%(n_consts)d, %(lds_slots)d)
 #include "%(inc)s"
 }
 
-hipError_t launch_%(layout)s%(suffix)s(hipStream_t st, const QGenArgs &a, uint32_t blocks) {
+hipError_t launch(hipStream_t st, const QGenArgs &a, uint32_t blocks) {
     const size_t lds = qg_lds_bytes(%(n_consts)d, %(lds_slots)d);
     static bool attr_set = false;            // > 64 KiB of dynamic LDS needs the per-function opt-in
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quotient_%(layout)s%(suffix)s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quotient_%(layout)s%(suffix)s_p%(part)d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(quotient_%(layout)s%(suffix)s_kernel, dim3(blocks), dim3(QG_THREADS), lds, st, a);
+    hipLaunchKernelGGL(quotient_%(layout)s%(suffix)s_p%(part)d_kernel, dim3(blocks), dim3(QG_THREADS), lds, st, a);
     return hipGetLastError();
 }
 
 }  // namespace
 
+QGenPart quotient_gen_%(layout)s%(suffix)s_p%(part)d() { return QGenPart{%(wgs)du, (uint32_t)QG_THREADS, %(n_instr)du, launch}; }
+
+}  // namespace ss
+""" % dict(layout=layout, suffix=suffix, variant=" (variant `%s`)" % suffix if suffix else "", part=part, n_parts=n_parts, n_instr=n_instr,
+           n_slots=n_slots, n_consts=n_consts, wgs=wgs, lds_slots=0 if slots_in_regs else n_slots,
+           where="registers" if slots_in_regs else "LDS",
+           define=("#define QG_SLOTS_IN_REGISTERS\n" if slots_in_regs else "") + ("#define QG_FENCE_EVERY_INSTRUCTION\n" if fence else "")
+                  + ("#define QG_THREADS_PER_WG %d\n" % threads if threads != 256 else "") + ("#define QG_SYNC_WAVES\n" if sync else ""),
+           fence=(", a scheduling fence after every program instruction" if fence else "")
+                 + (", a workgroup barrier every %d program instructions (the waves share their instruction fetches)" % sync if sync else ""), **body)
+    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", base + ".hip"), "w") as f:
+        f.write(src)
+
+
+def write_kernel_table(layout, suffix, variant, code, n_consts, n_tables, ncols, n_parts):
+    """the host-side entry of one variant: what ss_eval_quotient looks up by the program's hash"""
+    decl = "".join("QGenPart quotient_gen_%s%s_p%d();\n" % (layout, suffix, j) for j in range(n_parts))
+    parts = ", ".join("quotient_gen_%s%s_p%d()" % (layout, suffix, j) for j in range(n_parts))
+    src = """// GENERATED by tools/gen_quotient.py - DO NOT EDIT; regenerate with `python tools/gen_quotient.py %(layout)s`.
+//
+// The compiled composition constraint of the `%(layout)s` layout, variant %(variant)d: %(n_parts)d kernel(s) (quotient_gen_%(layout)s%(suffix)s_p*.hip) whose
+// outputs sum to the program's.  Code hash (FNV-1a of the program's code words) 0x%(hash)016x: ss_eval_quotient launches these
+// kernels for exactly that program and interprets any other.
+#include "quotient_gen.h"
+
+namespace ss {
+
+%(decl)s
 const QGenKernel &quotient_gen_%(layout)s%(suffix)s() {
-    static const QGenKernel k = {"%(layout)s", 0x%(hash)016xull, %(n_instr)du, %(n_consts)du, %(n_tables)du, %(ncols)du, %(variant)du, %(wgs)du, (uint32_t)QG_THREADS, launch_%(layout)s%(suffix)s};
+    static const QGenKernel k = {"%(layout)s", 0x%(hash)016xull, %(n_instr)du, %(n_consts)du, %(n_tables)du, %(ncols)du, %(variant)du, %(n_parts)du, {%(parts)s}};
     return k;
 }
 
 }  // namespace ss
-''' % dict(layout=layout, suffix=suffix, variant=variant, n_instr=n_instr, n_slots=n_slots, n_consts=n_consts, n_tables=n_tables, ncols=ncols,
-           hash=h, wgs=wgs, lds_slots=0 if slots_in_regs else n_slots, where="registers" if slots_in_regs else "LDS",
-           define=("#define QG_SLOTS_IN_REGISTERS\n" if slots_in_regs else "") + ("#define QG_FENCE_EVERY_INSTRUCTION\n" if fence else "")
-                  + ("#define QG_THREADS_PER_WG %d\n" % threads if threads != 256 else ""),
-           fence=", a scheduling fence after every program instruction" if fence else "", **body)
-    path = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s%s.hip" % (layout, suffix))
-    with open(path, "w") as f:
+""" % dict(layout=layout, suffix=suffix, variant=variant, n_parts=n_parts, hash=code_hash(code), n_instr=len(code) // 2, n_consts=n_consts,
+           n_tables=n_tables, ncols=ncols, decl=decl, parts=parts)
+    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s%s.hip" % (layout, suffix)), "w") as f:
         f.write(src)
-    print("  variant %d -> %s" % (variant, os.path.relpath(path, ROOT)))
+
+
+def write_source_lists(written, all_variants):
+    """csrc/quotient_gen_sources.mk (what the Makefile and tests/hipemu/build.sh compile) and csrc/quotient_gen_variants.inc (the
+    X-macro list capi.hip's lookup table is made of)"""
+    csrc = os.path.join(ROOT, "sandstorm_amd", "csrc")
+    default = [n for layout in written for k, _, names in written[layout] if k == 0 for n in names]
+    ab = [n for layout in written for k, _, names in written[layout] if k != 0 for n in names]
+    with open(os.path.join(csrc, "quotient_gen_sources.mk"), "w") as f:
+        f.write("# GENERATED by tools/gen_quotient.py: the generated constraint kernels' translation units\n")
+        f.write("QG_SRCS := %s\n" % " ".join(default))
+        if all_variants:
+            f.write("# make QG_AB=1: the A/B variants (python tools/gen_quotient.py --all-variants), selected with SS_QG_VARIANT=k\n")
+            f.write("QG_AB_SRCS := %s\n" % " ".join(ab))
+    with open(os.path.join(csrc, "quotient_gen_variants.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_quotient.py: QG_VARIANT(entry) per compiled program variant\n")
+        for layout in written:
+            for k, suffix, _ in written[layout]:
+                line = "QG_VARIANT(quotient_gen_%s%s)\n" % (layout, suffix)
+                f.write(line if k == 0 else "#ifdef SS_QG_AB_VARIANTS\n%s#endif\n" % line)
 
 
 if __name__ == "__main__":
-    names = [a for a in sys.argv[1:] if not a.startswith("--")]
-    for name in (names or ["starknet", "recursive"]):
-        generate(name, "--all-variants" in sys.argv)
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["starknet", "recursive"]
+    assert sorted(names) == ["recursive", "starknet"], "the source lists cover both layouts: generate both"
+    everything = "--all-variants" in sys.argv
+    write_source_lists({name: generate(name, everything) for name in names}, everything)
