@@ -672,9 +672,14 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
                                                     "(BASELINE.md section 1: other hardware, older CLI, the real AIR)")
         if cpu_leg:
             out["cpu_baseline"] = cpu_baseline(layout, log_steps, ctx)
-    if not real:
-        del base_t, aux_t
-    del base_cols
+    # everything that lives in the context's pool goes before the context does
+    if real:
+        for m in keep:
+            m.close()
+        del keep[:], aux_cols
+    else:
+        del base_t, aux_t, trace_cols
+    del base_cols, build_extension, step
     air.close()
     ctx.close()
     torch.cuda.empty_cache()

@@ -883,6 +883,9 @@ ss_status ss_poly_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t nc
     return SS_OK;
 }
 
+static ss_status ood_eval_sparse(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t ncols, uint32_t log_n,
+                                 const uint32_t *mask_col, const uint32_t *mask_off, uint32_t nmask, const uint64_t z[4], uint64_t *out);
+
 ss_status ss_ood_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t ncols, uint32_t log_n,
                       const uint32_t *mask_col, const uint32_t *mask_off, uint32_t nmask, const uint64_t z[4],
                       uint64_t *out) {
@@ -893,6 +896,15 @@ ss_status ss_ood_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t nco
     if (has_null((const void *const *)d_coeffs, ncols)) return fail(SS_ERR_INVALID, "NULL column");
     for (uint32_t j = 0; j < nmask; ++j)
         if (mask_col[j] >= ncols) return fail(SS_ERR_INVALID, "mask cell %u names column %u", j, mask_col[j]);
+    // A mask names few points per column (269 cells over 10 columns for starknet): large columns are evaluated point by point
+    // (deep.hip: blocks transformed in registers + fused Horner trees), a fifth of the arithmetic of the transforms below - from
+    // 2^22 coefficients on, where that outweighs the host's share of the point-by-point path (the level multipliers of every
+    // point: ~2 ms of host arithmetic per call, more than ten transforms of 2^18 points take).  SS_OOD_SPARSE_MIN_LOG moves the
+    // threshold (the parity tests run the point-by-point path from 2^12), SS_OOD_TRANSFORM=1 keeps the transforms.
+    uint32_t sparse_min_log = 22;
+    if (const char *e = getenv("SS_OOD_SPARSE_MIN_LOG")) sparse_min_log = (uint32_t)strtoul(e, nullptr, 10);
+    if (sparse_min_log < 12) sparse_min_log = 12;
+    if (log_n >= sparse_min_log && !getenv("SS_OOD_TRANSFORM")) return ood_eval_sparse(ctx, d_coeffs, ncols, log_n, mask_col, mask_off, nmask, z, out);
     // T_c(z w^k) for every k at once: one coset NTT (offset z) of each coefficient column
     const uint64_t n = 1ull << log_n;
     const size_t col_bytes = sizeof(Fp) << log_n;
@@ -923,6 +935,171 @@ ss_status ss_ood_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t nco
     HIP_TRY(launch_gather_cells(ctx->stream, evs, ncols, d_col, d_idx, nmask, d_out));
     HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)nmask * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+
+// T_col(z w_n^k) for the distinct (column, k) of the mask, without a transform of the whole column (deep.hip, "out-of-domain
+// evaluation at FEW points").  Per column S = 0 / 2 / 4 stages of the forward network run on blocks of 2^S coefficients -
+// more cells, more shared work - then every point folds the R = n >> S block values it needs with a bit-reversed Horner tree.
+static ss_status ood_eval_sparse(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t ncols, uint32_t log_n,
+                                 const uint32_t *mask_col, const uint32_t *mask_off, uint32_t nmask, const uint64_t z[4], uint64_t *out) {
+    const uint64_t n = 1ull << log_n;
+    const Fp zf = fp_from_limbs64(z), wn = root_of_unity(log_n);
+    // ---- the distinct points, column by column
+    struct Point { uint32_t col, k, S; Fp x; std::vector<Fp> xpow; Fp *buf[2]; };
+    std::vector<Point> pts;
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> index;
+    std::vector<std::vector<uint32_t>> of_col(ncols);
+    for (uint32_t j = 0; j < nmask; ++j) {
+        const uint32_t k = mask_off[j] & (uint32_t)(n - 1);
+        if (index.emplace(std::make_pair(mask_col[j], k), (uint32_t)pts.size()).second) {
+            Point p;
+            p.col = mask_col[j]; p.k = k; p.S = 0; p.x = fp_mul(zf, fp_pow_u64(wn, k)); p.buf[0] = p.buf[1] = nullptr;
+            of_col[p.col].push_back((uint32_t)pts.size());
+            pts.push_back(p);
+        }
+    }
+    std::vector<uint32_t> S_of(ncols, 0);
+    for (uint32_t c = 0; c < ncols; ++c) {
+        const size_t cnt = of_col[c].size();
+        S_of[c] = cnt <= 3 ? 0u : cnt <= 12 ? 2u : 4u;
+        if (const char *e = getenv("SS_OOD_BLOCK_LOG")) S_of[c] = cnt ? (uint32_t)strtoul(e, nullptr, 10) : 0u;    // A/B: 0 .. 4 for every column
+        if (S_of[c] > 4) S_of[c] = 4;
+        for (uint32_t pi : of_col[c]) pts[pi].S = S_of[c];
+    }
+    for (Point &p : pts) {                       // x^(2^j), j < log_n - S: the Horner tree's level multipliers
+        p.xpow.resize(log_n - p.S);
+        p.xpow[0] = p.x;
+        for (size_t j = 1; j < p.xpow.size(); ++j) p.xpow[j] = fp_sqr(p.xpow[j - 1]);
+    }
+    std::vector<Fp> zsq(log_n);                  // z^(2^i)
+    zsq[0] = zf;
+    for (uint32_t i = 1; i < log_n; ++i) zsq[i] = fp_sqr(zsq[i - 1]);
+    // ---- device memory: block outputs, two fold buffers per point, the final values, the descriptors of every launch
+    size_t felts = pts.size() + 8;
+    std::vector<size_t> y_off(ncols, 0);
+    std::vector<uint32_t> res_mask(ncols, 0);
+    for (uint32_t c = 0; c < ncols; ++c) {
+        if (!S_of[c]) continue;
+        for (uint32_t pi : of_col[c]) res_mask[c] |= 1u << (pts[pi].k & ((1u << S_of[c]) - 1u));
+        y_off[c] = felts;
+        felts += (size_t)__builtin_popcount(res_mask[c]) * (n >> S_of[c]);
+    }
+    auto first_levels = [&](uint32_t lc) { return lc >= 3 ? 3u : lc; };      // 8 values per lane and launch (16 would not fit 256 registers)
+    for (Point &p : pts) {
+        const uint32_t lc = log_n - p.S, g1 = first_levels(lc), g2 = first_levels(lc - g1);
+        const size_t a = (size_t)1 << (lc - g1), b = (size_t)1 << (lc - g1 - g2);
+        p.buf[0] = (Fp *)(uintptr_t)felts; felts += a;                          // (offsets for now: the scratch may move)
+        p.buf[1] = (Fp *)(uintptr_t)felts; felts += b;
+    }
+    const size_t desc_bytes = (size_t)(log_n / 3 + 2) * 3 * (pts.size() * (sizeof(OodFoldPoint) + sizeof(OodFoldArray)) + 64);
+    ss_status st = ctx->ensure_scratch(felts * sizeof(Fp) + desc_bytes + 256);
+    if (st != SS_OK) return st;
+    Fp *base = (Fp *)ctx->scratch, *d_final = base;
+    char *d_desc = (char *)(base + felts);
+    for (Point &p : pts) { p.buf[0] = base + (uintptr_t)p.buf[0]; p.buf[1] = base + (uintptr_t)p.buf[1]; }
+    hipStream_t s = ctx->stream;
+    // ---- (A) the blocks
+    for (uint32_t c = 0; c < ncols; ++c) {
+        const uint32_t S = S_of[c];
+        if (!S || of_col[c].empty()) continue;
+        OodBlockArgs a;
+        memset(&a, 0, sizeof a);
+        a.coeffs = (const Fp *)d_coeffs[c]; a.out = base + y_off[c]; a.blocks = n >> S; a.res_mask = res_mask[c];
+        for (uint32_t u = 0; u < S; ++u) {       // stage u of the size-n forward network: z^(n / 2^(u+1)) w_n^(j n / 2^(u+1)), j < 2^u
+            const Fp h = zsq[log_n - u - 1], r = root_of_unity(u + 1);
+            Fp rj = fp_one();
+            for (uint32_t j = 0; j < (1u << u); ++j) {
+                const Fl t = fl_to_r280(fp_mul(h, rj));
+                for (int i = 0; i < 9; ++i) a.tw[(1u << u) - 1 + j][i] = t.l[i];
+                rj = fp_mul(rj, r);
+            }
+        }
+        ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
+        HIP_TRY(launch_ood_blocks(s, (int)S, a));
+    }
+    // ---- (B) the folds, one group of columns (same S: same lengths) after the other; every launch's descriptors are laid out
+    //      first and uploaded in one copy
+    std::vector<char> host_desc;
+    struct Launch { size_t arrays_at, points_at; uint32_t narrays, max_points; uint64_t in_len; uint32_t levels; bool last; };
+    std::vector<Launch> launches;
+    for (uint32_t S = 0; S <= 4; ++S) {
+        std::vector<uint32_t> group;
+        for (uint32_t pi = 0; pi < pts.size(); ++pi) if (pts[pi].S == S) group.push_back(pi);
+        if (group.empty()) continue;
+        uint32_t lc = log_n - S;
+        int round = 0;
+        while (lc > 0) {
+            const uint32_t g = first_levels(lc);
+            const bool last = lc == g;
+            std::vector<OodFoldArray> arrays;
+            std::vector<OodFoldPoint> points;
+            auto add_point = [&](uint32_t pi) {
+                const Point &p = pts[pi];
+                OodFoldPoint fp_;
+                memset(&fp_, 0, sizeof fp_);
+                fp_.out = last ? d_final + pi : p.buf[round & 1];
+                for (uint32_t t = 0; t < (1u << g); ++t) {       // element t = sum t_i 2^i of a group: weight prod_i (x^(2^(lc-1-i)))^(t_i)
+                    Fp wgt = fp_one();
+                    for (uint32_t i = 0; i < g; ++i) if ((t >> i) & 1u) wgt = fp_mul(wgt, p.xpow[lc - 1 - i]);
+                    const Fl l = fl_to_r280(wgt);
+                    for (int q = 0; q < 9; ++q) fp_.coef[t][q] = l.l[q];
+                }
+                points.push_back(fp_);
+            };
+            if (round == 0) {                    // inputs: the coefficient column (S = 0) or one block-output array per residue
+                for (uint32_t c = 0; c < ncols; ++c) {
+                    if (S_of[c] != S || of_col[c].empty()) continue;
+                    if (S == 0) {
+                        arrays.push_back({(const Fp *)d_coeffs[c], (uint32_t)points.size(), (uint32_t)of_col[c].size()});
+                        for (uint32_t pi : of_col[c]) add_point(pi);
+                        continue;
+                    }
+                    uint32_t slot = 0;
+                    for (uint32_t res = 0; res < (1u << S); ++res) {
+                        if (!((res_mask[c] >> res) & 1u)) continue;
+                        const uint32_t first = (uint32_t)points.size();
+                        for (uint32_t pi : of_col[c]) if ((pts[pi].k & ((1u << S) - 1u)) == res) add_point(pi);
+                        arrays.push_back({base + y_off[c] + (size_t)slot * (n >> S), first, (uint32_t)points.size() - first});
+                        ++slot;
+                    }
+                }
+            } else {
+                for (uint32_t pi : group) {
+                    arrays.push_back({pts[pi].buf[(round - 1) & 1], (uint32_t)points.size(), 1u});
+                    add_point(pi);
+                }
+            }
+            Launch L;
+            L.narrays = (uint32_t)arrays.size(); L.in_len = 1ull << lc; L.levels = g; L.last = last;
+            L.max_points = 1;
+            for (const OodFoldArray &ar : arrays) if (ar.npoints > L.max_points) L.max_points = ar.npoints;
+            host_desc.resize((host_desc.size() + 63) / 64 * 64);
+            L.arrays_at = host_desc.size();
+            host_desc.insert(host_desc.end(), (const char *)arrays.data(), (const char *)(arrays.data() + arrays.size()));
+            host_desc.resize((host_desc.size() + 63) / 64 * 64);
+            L.points_at = host_desc.size();
+            host_desc.insert(host_desc.end(), (const char *)points.data(), (const char *)(points.data() + points.size()));
+            launches.push_back(L);
+            lc -= g;
+            ++round;
+        }
+    }
+    if (host_desc.size() > desc_bytes) return fail(SS_ERR_INVALID, "out-of-domain descriptors: %zu bytes for %zu reserved", host_desc.size(), desc_bytes);
+    HIP_TRY(hipMemcpyAsync(d_desc, host_desc.data(), host_desc.size(), hipMemcpyHostToDevice, s));
+    for (const Launch &L : launches) {
+        ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
+        HIP_TRY(launch_ood_fold(s, (const OodFoldArray *)(d_desc + L.arrays_at), L.narrays, L.max_points, (const OodFoldPoint *)(d_desc + L.points_at), L.in_len,
+                                L.levels, L.last));
+    }
+    std::vector<Fp> vals(pts.size());
+    HIP_TRY(hipMemcpyAsync(vals.data(), d_final, pts.size() * sizeof(Fp), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));            // (also keeps host_desc alive until its copy is done)
+    for (uint32_t j = 0; j < nmask; ++j) {
+        const Fp &v = vals[index[std::make_pair(mask_col[j], mask_off[j] & (uint32_t)(n - 1))]];
+        for (int q = 0; q < 4; ++q) out[4 * j + q] = (uint64_t)v.v[2 * q] | ((uint64_t)v.v[2 * q + 1] << 32);
+    }
     return SS_OK;
 }
 

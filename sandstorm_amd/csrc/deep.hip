@@ -95,6 +95,145 @@ hipError_t launch_poly_reduce(hipStream_t st, const void *const *in, void *const
     return hipGetLastError();
 }
 
+// ---- out-of-domain evaluation at FEW points: T_c(z w^k) for the k of a column's mask cells ------------------------
+// A column's cells need its polynomial at |S| << n points x_k = z w_n^k.  A coset transform (round 2: one size-n transform
+// per column, 12 n butterflies) computes all n of them.  Instead: split P(x) = sum_{r < R} x^r P_r(x^R), R = n / m, m = 2^S.
+// In the bit-reversed coefficient array block b = [b m, (b+1) m) IS P_r for r = bitrev(b) (its coefficients, bit-reversed),
+// and x_k^R = z^R w_m^k only depends on k mod m, so
+//   (A) ood_blocks_kernel: one lane per block runs the first S stages of the forward network on its m coefficients in
+//       registers (the size-m coset transform, offset z^R: S m / 2 butterflies with wave-uniform twiddles) and keeps the
+//       outputs whose residue some cell needs: Y[res][b] = P_bitrev(b)(z^R w_m^res);
+//   (B) ood_fold_kernel: X[k] = sum_b x_k^bitrev(b) Y[k mod m][b] is the bit-reversed Horner tree of poly_reduce_kernel over
+//       the block index, 2^LEVELS elements per lane and launch, as ONE fused dot product per point (fl252.h FlWide: the
+//       2^LEVELS coefficients prod_i mult_i^(t_i) come from the host in R280 form); points that read the same array share
+//       the loads.
+// Work per column: S n / 2 butterflies + 1.07 |S| n / m fused terms, against 12 n butterflies: 5.7x less over the starknet
+// mask (269 cells: |S| = 16, 5, 4, 9, 2, 60, 4, 56, 105, 8 per column), and no per-proof twiddle plan of n entries.
+// butterfly IDX = (stage u, pair pr) of the 2^S-point network, unrolled by recursion: the element indices must be compile-time
+// constants for x[] to live in registers (a `#pragma unroll` loop around 32 inlined multiplications is not unrolled - the array
+// then sits in scratch, 5x slower)
+template <int S, int IDX>
+__device__ __forceinline__ void ood_butterflies(Fl (&x)[1 << S], const OodBlockArgs &a) {
+    constexpr int HALF = (1 << S) / 2;
+    if constexpr (IDX < S * HALF) {
+        constexpr int u = IDX / HALF, pr = IDX % HALF;
+        constexpr int j = pr & ((1 << u) - 1), lo = ((pr >> u) << (u + 1)) | j, hi = lo | (1 << u);
+        Fl t;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t.l[i] = a.tw[(1 << u) - 1 + j][i];
+        const Fl bt = fl_mul_r280(x[hi], t);              // DIT: a' = a + b t, b' = a - b t + 2p (ntt.hip radix_stage: <= 11 stages lazily)
+        const Fl lo_v = x[lo];
+        x[lo] = fl_add(lo_v, bt);
+        x[hi] = fl_sub_c<2, 1>(lo_v, bt);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);                // one multiplication at a time: interleaved, their 19-column accumulators cost 130 registers
+        ood_butterflies<S, IDX + 1>(x, a);
+    }
+}
+template <int S, int J>
+__device__ __forceinline__ void ood_store_residues(const Fl (&x)[1 << S], const OodBlockArgs &a, uint64_t b, uint32_t slot) {
+    if constexpr (J < (1 << S)) {
+        if ((a.res_mask >> J) & 1u) {
+            dstore(a.out + (uint64_t)slot * a.blocks + b, fl_pack(fl_weak_reduce(x[J])));     // < 2^252, what the fold re-limbs
+            ++slot;
+        }
+        ood_store_residues<S, J + 1>(x, a, b, slot);
+    }
+}
+template <int S, int T>
+__device__ __forceinline__ void ood_load_block(Fl (&x)[1 << S], const Fp *p) {
+    if constexpr (T < (1 << S)) {
+        x[T] = fl_from_fp(dload(p + T));
+        ood_load_block<S, T + 1>(x, p);
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(128, 2) void ood_blocks_kernel(OodBlockArgs a) {       // two waves per SIMD: <= 256 registers
+    constexpr int M = 1 << S;
+    const uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (b >= a.blocks) return;
+    Fl x[M];
+    ood_load_block<S, 0>(x, a.coeffs + b * M);
+    ood_butterflies<S, 0>(x, a);
+    ood_store_residues<S, 0>(x, a, b, 0u);
+}
+
+hipError_t launch_ood_blocks(hipStream_t st, int S, const OodBlockArgs &a) {
+    const dim3 grid((uint32_t)((a.blocks + 127) / 128)), block(128);
+    if (S == 4) hipLaunchKernelGGL(ood_blocks_kernel<4>, grid, block, 0, st, a);
+    else if (S == 3) hipLaunchKernelGGL(ood_blocks_kernel<3>, grid, block, 0, st, a);
+    else if (S == 2) hipLaunchKernelGGL(ood_blocks_kernel<2>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(ood_blocks_kernel<1>, grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+// one array (grid.y) folded for each of its points: out_p[q] = sum_{t < 2^LEVELS} in[(q << LEVELS) + t] * coef_p[t].  The points'
+// coefficients sit in LDS (wave-uniform reads: broadcasts) - read from global memory inside the loop every term waited on its
+// own load; the 2^LEVELS values of a lane stay in registers across the array's points.
+template <int LEVELS, int T>
+__device__ __forceinline__ void ood_load_group(Fl (&v)[1 << LEVELS], const Fp *p) {
+    if constexpr (T < (1 << LEVELS)) {
+        v[T] = fl_from_fp(dload(p + T));
+        ood_load_group<LEVELS, T + 1>(v, p);
+    }
+}
+typedef u32 __attribute__((address_space(3))) *ood_lds_u32;
+template <int LEVELS, int T>
+__device__ __forceinline__ void ood_dot(FlWide &w, const Fl (&v)[1 << LEVELS], const ood_lds_u32 coef) {
+    if constexpr (T < (1 << LEVELS)) {
+        Fl c;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c.l[i] = coef[9 * T + i];
+        fl_wide_mad(w, v[T], c);
+        asm volatile("" ::: "memory");                    // keep the coefficient reads next to their use (hoisted, they are 144 registers)
+        __builtin_amdgcn_sched_barrier(0);
+        ood_dot<LEVELS, T + 1>(w, v, coef);
+    }
+}
+template <int LEVELS>
+__global__ __launch_bounds__(128, 2) void ood_fold_kernel(const OodFoldArray *__restrict__ arrays, const OodFoldPoint *__restrict__ points,
+                                                       uint64_t out_len, int canonical) {
+    constexpr int T = 1 << LEVELS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ood_lds_u32 lds = (ood_lds_u32)smem;                                    // [npoints][T][9]
+    const OodFoldArray arr = arrays[blockIdx.y];
+    for (uint32_t idx = threadIdx.x; idx < arr.npoints * (uint32_t)(T * 9); idx += blockDim.x) {
+        const uint32_t k = idx / (uint32_t)(T * 9), rem = idx % (uint32_t)(T * 9);
+        lds[idx] = points[arr.first_point + k].coef[rem / 9u][rem % 9u];
+    }
+    __syncthreads();
+    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < out_len; q += (uint64_t)gridDim.x * blockDim.x) {
+        Fl v[T];
+        ood_load_group<LEVELS, 0>(v, arr.in + (q << LEVELS));
+#pragma unroll 1
+        for (uint32_t k = 0; k < arr.npoints; ++k) {
+            FlWide w;
+            fl_wide_zero(w);
+            ood_dot<LEVELS, 0>(w, v, lds + k * (uint32_t)(T * 9));
+            const Fl r = fl_wide_reduce(w);                  // normalised, < 1.01 p
+            dstore(points[arr.first_point + k].out + q, canonical ? fl_to_fp(r) : fl_pack(r));
+        }
+    }
+}
+
+hipError_t launch_ood_fold(hipStream_t st, const OodFoldArray *d_arrays, uint32_t narrays, uint32_t max_points, const OodFoldPoint *d_points,
+                           uint64_t in_len, uint32_t levels, bool canonical) {
+    const uint64_t out_len = in_len >> levels;
+    uint32_t gx = (uint32_t)((out_len + 127) / 128);
+    if (gx > 16384) gx = 16384;
+    if (gx == 0) gx = 1;
+    const dim3 grid(gx, narrays), block(128);
+    const int cn = canonical ? 1 : 0;
+    const size_t lds = (size_t)max_points * (36u << levels);                          // the coefficients of one array's points
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (levels == 4) hipLaunchKernelGGL(ood_fold_kernel<4>, grid, block, lds, st, d_arrays, d_points, out_len, cn);
+    else if (levels == 3) hipLaunchKernelGGL(ood_fold_kernel<3>, grid, block, lds, st, d_arrays, d_points, out_len, cn);
+    else if (levels == 2) hipLaunchKernelGGL(ood_fold_kernel<2>, grid, block, lds, st, d_arrays, d_points, out_len, cn);
+    else hipLaunchKernelGGL(ood_fold_kernel<1>, grid, block, lds, st, d_arrays, d_points, out_len, cn);
+    return hipGetLastError();
+}
+
 // ---- D[i] = 1 / (offset * w^i - z), i < 2^log_N ----------------------------------------
 // chunk c of length CH is handled by one lane: forward pass stores prefix products in D,
 // one inversion, backward pass overwrites them with the inverses.

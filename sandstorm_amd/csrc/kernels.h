@@ -84,6 +84,19 @@ hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace
 static constexpr uint32_t BATCH_INVERSE_RANGE_LOG_CHUNK = 5;
 hipError_t launch_batch_inverse_range(hipStream_t st, Fp *D, uint64_t len, const Fp &x0, const Fp &w, const Fp &w_inv,
                                       const Fp &z, bool r280);
+// out-of-domain evaluation at few points (deep.hip): blocks of 2^S coefficients transformed in registers, then folded per point
+struct OodBlockArgs {
+    const Fp *coeffs;        // the column: n bit-reversed coefficients
+    Fp *out;                 // [popcount(res_mask)][blocks]
+    uint64_t blocks;         // R = n >> S
+    uint32_t res_mask;       // residues (k mod 2^S) to keep, in ascending order
+    uint32_t tw[15][9];      // twiddles of stages 0 .. S-1 in R280 limb form: stage u at (2^u - 1) + j, j < 2^u
+};
+struct OodFoldArray { const Fp *in; uint32_t first_point, npoints; };           // an input array and the points that read it
+struct OodFoldPoint { Fp *out; uint32_t coef[16][9]; uint32_t pad[2]; };           // coef[t]: R280 limbs of the weight of element t
+hipError_t launch_ood_blocks(hipStream_t st, int S, const OodBlockArgs &a);
+hipError_t launch_ood_fold(hipStream_t st, const OodFoldArray *d_arrays, uint32_t narrays, uint32_t max_points, const OodFoldPoint *d_points,
+                           uint64_t in_len, uint32_t levels, bool canonical);
 hipError_t launch_gather_cells(hipStream_t st, const void *const *cols, uint32_t ncols, const uint32_t *col,
                                const uint64_t *idx, uint32_t n, Fp *out);
 

@@ -11,13 +11,13 @@
 // (a_low = low 248 bits, a_high = top 4 bits of the canonical value;
 // mod.rs:25-30; points from builtins/src/pedersen/constants.rs:5-30.)
 //
-// Fixed-base windows of W bits (16, 18 or 20; SS_PED_WINDOW, default PED_DEFAULT_WINDOW).  The 252 scalar bits of an
+// Fixed-base windows of W bits (16, 18, 20, 22 or 24; SS_PED_WINDOW, default PED_DEFAULT_WINDOW).  The 252 scalar bits of an
 // input are one bit string - bit i < 248 stands for 2^i P_low, bit 248 + i for 2^i P_high (the 4-bit high part has its
 // own base point) - cut into ceil(252 / W) windows; the device table holds, per input and window, the 2^W - 1 non-zero
 // subset sums as affine points: ceil(252 / W) Jacobian+affine mixed additions (8M + 3S) per input - 16 / 14 / 13 - against
-// 32 with 8-bit windows.  Table sizes 2 x 16 x 65535 x 64 B = 134 MB (Infinity-Cache resident) / 470 MB / 1.7 GB (64-byte
-// gathers from HBM).  Built once per context ON THE DEVICE from the 2 x 252 bit points (one lane per entry: its bits'
-// points summed, one inversion).  The final Jacobian -> affine inversion (~310 multiplications, a
+// 32 with 8-bit windows.  Table sizes 134 MB (16 bits: Infinity-Cache resident) / 470 MB / 1.7 GB / 6.4 GB / 23.6 GB (24 bits:
+// 11 additions per input, 64-byte gathers from HBM - 8 % of the 288 GB buy 18 % of the Pedersen layers' time).  Built once per process and device ON THE DEVICE from the 2 x 252 bit points, in two levels (half windows
+// entry by entry, then every entry as one affine addition of its halves with batched inversions).  The final Jacobian -> affine inversion (~310 multiplications, a
 // quarter of a hash) is not done per hash: the accumulate kernel leaves (X, Z) in a
 // temporary and a second kernel inverts Z in per-lane chunks with Montgomery's trick
 // (5 multiplications per hash + one inversion per chunk).
@@ -53,7 +53,7 @@ static constexpr int PED_PER_INPUT = PED_LOW_ENTRIES + PED_HIGH_ENTRIES;
 
 // device table layout per input: [nwin][2^W - 1] (window w covers scalar bits W w .. W w + W - 1 of the 252)
 static constexpr int PED_BITS = 252;
-static constexpr int PED_DEFAULT_WINDOW = 16;
+static constexpr int PED_DEFAULT_WINDOW = 24;       // measured (profiles/r03_pedersen_windows.txt): Merkle stage of recursive_2p20 53.3 / 49.8 / 47.5 / 46.3 / 43.6 ms for 16 .. 24
 static constexpr int PED_MAX_WINDOWS = 16;        // the lane-split kernel gives a window to each of 16 lanes per input
 
 struct PedersenTables {
@@ -61,7 +61,11 @@ struct PedersenTables {
     Aff shift;      // P0
     uint32_t W, nwin, span;      // window bits, windows per input, entries per window (2^W - 1)
     uint64_t per_input;          // nwin * span
+    int device, users;           // the tables are constants: ONE copy per device and process, shared by its contexts
 };
+static std::mutex g_ped_mutex;
+static std::vector<PedersenTables *> g_ped_tables;      // at most one per device: kept while the process lives (a context
+                                                        // that comes later - every test makes its own - finds it built)
 
 // --------------------------------------------------------------- host side
 static Fp canon_to_mont(const uint64_t c[4]) {
@@ -129,6 +133,7 @@ static const std::vector<Aff> &host_tables(Aff *shift) {
 }
 
 __global__ void pedersen_build_windows_kernel(const Aff *__restrict__ bit_points, Aff *__restrict__ table, uint32_t W, uint32_t span, uint64_t per_input);
+__global__ void pedersen_join_halves_kernel(const Aff *__restrict__ half, Aff *__restrict__ table, uint32_t W, uint32_t nwin, uint32_t nhalf);
 
 // the 2 x 252 bit points: bit i of input e stands for 2^i P_{1+2e} (i < 248) or 2^(i-248) P_{2+2e}
 static void build_bit_points(std::vector<Aff> &out) {
@@ -149,26 +154,55 @@ hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
     (void)host_tables(&shift);
     uint32_t W = PED_DEFAULT_WINDOW;
     if (const char *e = getenv("SS_PED_WINDOW")) W = (uint32_t)strtoul(e, nullptr, 10);
-    if (W != 16 && W != 18 && W != 20) return hipErrorInvalidValue;
+    if (W != 16 && W != 18 && W != 20 && W != 22 && W != 24) return hipErrorInvalidValue;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_ped_mutex);
+    for (size_t k = 0; k < g_ped_tables.size(); ++k) {
+        PedersenTables *c = g_ped_tables[k];
+        if (c->device != device) continue;
+        if (c->W == W) { c->users += 1; *out = c; return hipSuccess; }
+        if (c->users == 0) {                     // another width was asked for (SS_PED_WINDOW changed): replace the idle copy
+            (void)hipFree(c->d_table);
+            delete c;
+            g_ped_tables.erase(g_ped_tables.begin() + k);
+        }
+        break;
+    }
     std::vector<Aff> bits;
     build_bit_points(bits);
     PedersenTables *t = new PedersenTables;
+    t->device = device; t->users = 1;
     t->shift = shift;
     t->d_table = nullptr;
     t->W = W; t->nwin = (PED_BITS + W - 1) / W; t->span = (1u << W) - 1u;
     t->per_input = (uint64_t)t->nwin * t->span;
-    Aff *d_bits = nullptr;
+    // Two levels: the windows of W / 2 bits straight from the bit points (2 x ceil(252 / (W/2)) x (2^(W/2) - 1) entries: thousands),
+    // then every W-bit entry as ONE affine + affine addition of its two halves, the slopes' denominators inverted eight at a
+    // time (6 multiplications and an eighth of an inversion per entry: 0.1 s for the 3.7 10^8 entries of W = 24, where summing
+    // an entry's bit points one by one took 1.4 s)
+    const uint32_t h = W / 2, nhalf = (PED_BITS + h - 1) / h, spanh = (1u << h) - 1u;
+    const uint64_t per_input_half = (uint64_t)nhalf * spanh;
+    Aff *d_bits = nullptr, *d_half = nullptr;
     hipError_t e = hipMalloc(&d_bits, bits.size() * sizeof(Aff));
+    if (e == hipSuccess) e = hipMalloc(&d_half, 2 * per_input_half * sizeof(Aff));
     if (e == hipSuccess) e = hipMalloc(&t->d_table, 2 * t->per_input * sizeof(Aff));
     if (e == hipSuccess) e = hipMemcpyAsync(d_bits, bits.data(), bits.size() * sizeof(Aff), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        const uint64_t total = 2 * t->per_input;
-        hipLaunchKernelGGL(pedersen_build_windows_kernel, dim3((uint32_t)((total + 63) / 64)), dim3(64), 0, st, d_bits, t->d_table, W, t->span, t->per_input);
+        const uint64_t total = 2 * per_input_half;
+        hipLaunchKernelGGL(pedersen_build_windows_kernel, dim3((uint32_t)((total + 63) / 64)), dim3(64), 0, st, d_bits, d_half, h, spanh, per_input_half);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        const uint64_t lanes = 2ull * t->nwin * ((1ull << W) / 8);
+        hipLaunchKernelGGL(pedersen_join_halves_kernel, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, d_half, t->d_table, W, t->nwin, nhalf);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (d_bits) (void)hipFree(d_bits);
+    if (d_half) (void)hipFree(d_half);
     if (e != hipSuccess) { if (t->d_table) (void)hipFree(t->d_table); delete t; return e; }
+    g_ped_tables.push_back(t);
     *out = t;
     return hipSuccess;
 }
@@ -192,10 +226,10 @@ Fp pedersen_hash_host(const Fp &a, const Fp &b) {
     return fp_mul(acc.x, fp_sqr(zi));
 }
 
-void pedersen_tables_destroy(PedersenTables *t) {
+void pedersen_tables_destroy(PedersenTables *t) {       // a context lets go of the shared copy (which stays for the next one)
     if (!t) return;
-    hipFree(t->d_table);
-    delete t;
+    std::lock_guard<std::mutex> lock(g_ped_mutex);
+    if (t->users > 0) t->users -= 1;
 }
 
 // ------------------------------------------------------------- device side
@@ -262,6 +296,60 @@ __global__ __launch_bounds__(64) void pedersen_build_windows_kernel(const Aff *_
         o.y = fl_to_fp(fn_mul(acc.y, fn_mul(zi2, zi)));
     }
     store_aff(table + idx, o);
+}
+
+// entry j = lo + 2^(W/2) hi of window w = entry lo of half window 2w + entry hi of half window 2w + 1 (affine points: the chord
+// rule, its denominator x_lo - x_hi inverted together with those of the lane's other seven entries - same hi, consecutive lo)
+__global__ __launch_bounds__(64) void pedersen_join_halves_kernel(const Aff *__restrict__ half, Aff *__restrict__ table, uint32_t W,
+                                                                  uint32_t nwin, uint32_t nhalf) {
+    constexpr int CH = 8;
+    const uint32_t h = W / 2, spanh = (1u << h) - 1u, span = (1u << W) - 1u;
+    const uint64_t per_w = (1ull << W) / CH, c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (c >= 2ull * nwin * per_w) return;
+    const uint32_t e = (uint32_t)(c / ((uint64_t)nwin * per_w)), w = (uint32_t)((c / per_w) % nwin), j0 = (uint32_t)(c % per_w) * CH;
+    const uint32_t hi = j0 >> h;
+    const Aff *lo_tab = half + ((size_t)e * nhalf + 2 * w) * spanh;
+    const bool has_hi_tab = 2 * w + 1 < nhalf;               // the narrower top window may have no upper half: those entries are never addressed
+    const Aff *hi_tab = half + ((size_t)e * nhalf + 2 * w + 1) * spanh;
+    Aff *out = table + ((size_t)e * nwin + w) * span;
+    Aff P; P.x = fp_zero(); P.y = fp_zero();
+    if (hi && has_hi_tab) P = load_aff(hi_tab + (hi - 1));
+    const Fl px = fl_from_fp(P.x), py = fl_from_fp(P.y);
+    Fl prefix[CH], run = fl_one();
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {                           // prefix products of the denominators (1 where there is nothing to add)
+        const uint32_t lo = (j0 + k) & spanh;
+        prefix[k] = run;
+        if (hi && lo && has_hi_tab) {
+            Fl d = fn_sub(fl_from_fp(load_felt(&lo_tab[lo - 1].x)), px);
+            if (fn_is_zero(d)) d = fl_one();                 // equal abscissae (does not happen for these multiples): left as garbage, not as a fault
+            run = fn_mul(run, d);
+        }
+    }
+    Fl inv = fn_inv(run);
+#pragma unroll
+    for (int k = CH - 1; k >= 0; --k) {
+        const uint32_t j = j0 + k, lo = j & spanh;
+        if (j == 0) continue;                                // no entry for the zero digit
+        Aff o;
+        if (!hi || !has_hi_tab) {
+            if (!lo || hi) { o.x = fp_zero(); o.y = fp_zero(); } else o = load_aff(lo_tab + (lo - 1));
+        } else if (!lo) {
+            o = P;
+        } else {
+            const Aff Q = load_aff(lo_tab + (lo - 1));
+            const Fl qx = fl_from_fp(Q.x), qy = fl_from_fp(Q.y);
+            Fl d = fn_sub(qx, px);
+            if (fn_is_zero(d)) d = fl_one();
+            const Fl dinv = fn_mul(inv, prefix[k]);
+            inv = fn_mul(inv, d);
+            const Fl lam = fn_mul(fn_sub(qy, py), dinv);
+            const Fl x3 = fn_sub(fn_sub(fn_sqr(lam), px), qx);
+            const Fl y3 = fn_sub(fn_mul(lam, fn_sub(px, x3)), py);
+            o.x = fl_to_fp(x3); o.y = fl_to_fp(y3);
+        }
+        store_aff(out + (j - 1), o);
+    }
 }
 
 // the canonical scalar as a shift register: its low W bits are the next window's digit (no dynamically indexed limbs)
@@ -436,7 +524,9 @@ static hipError_t launch_finish(hipStream_t st, Fp *tmp, uint64_t count, Fp *out
     switch (W_) {                                                              \
         case 16: { constexpr int W = 16; CALL; } break;                        \
         case 18: { constexpr int W = 18; CALL; } break;                        \
-        default: { constexpr int W = 20; CALL; } break;                        \
+        case 20: { constexpr int W = 20; CALL; } break;                        \
+        case 22: { constexpr int W = 22; CALL; } break;                        \
+        default: { constexpr int W = 24; CALL; } break;                        \
     }
 static hipError_t launch_acc_felts(hipStream_t st, const PedersenTables *t, const PedFeltArgs &g, uint64_t count, Fp *tmp) {
     PED_DISPATCH(t->W, hipLaunchKernelGGL(pedersen_acc_felts_kernel<W>, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table, t->per_input,

@@ -23,6 +23,8 @@ def pytest_configure(config):
         # is pointed at it - the product's loader has no such switch.
         from sandstorm_amd import _lib
         _lib.LIB_PATH = os.environ.get("SS_TEST_HIPEMU_LIB", os.path.join(ROOT, "tests", "hipemu", "_build", "libsandstorm_hipemu.so"))
+        # the product's Pedersen table is sized for HBM (24-bit windows: 23.6 GB); the emulated device's memory is this host's
+        os.environ.setdefault("SS_PED_WINDOW", "16")
 
 
 @pytest.fixture(scope="session")

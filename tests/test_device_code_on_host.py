@@ -50,7 +50,7 @@ def test_every_kernel_against_the_oracle(emulated_library):
     """tests/test_gpu_parity.py: transforms, row hashing, Keccak / Blake2s / Pedersen trees and openings, FRI folds, DEEP, the constraint
     VM, proof of work - the 252-bit path's parity tests, all but the two that only exist for their size"""
     out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_parity.py", "-k", "not large_impulse"])
-    assert "148 passed" in out, out[-500:]
+    assert "155 passed" in out, out[-500:]
 
 
 def test_sweeps_over_the_sizes_the_gpu_suite_samples(emulated_library):

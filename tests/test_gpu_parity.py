@@ -456,6 +456,35 @@ def test_ood_eval_vs_oracle(ctx, be, oracle, log_n):
         assert np.array_equal(got[j], want), (log_n, j)
 
 
+@pytest.mark.parametrize("log_n,block_log", [(12, None), (14, None), (13, 0), (13, 1), (13, 2), (13, 3), (13, 4)])
+def test_ood_eval_of_a_layout_sized_mask(ctx, be, oracle, log_n, block_log, monkeypatch):
+    """ss_ood_eval of large columns evaluates point by point (deep.hip: the first S stages of the forward network on
+    blocks of 2^S coefficients in registers, then one fused Horner tree per point): columns with 2, 7 and 40 distinct offsets take
+    S = 0, 2 and 4; SS_OOD_BLOCK_LOG forces every S; the values are the oracle's and the transform path's (SS_OOD_TRANSFORM=1),
+    duplicated cells and offsets beyond the trace length (taken mod n) included"""
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n * 7 + (block_log or 0))
+    cols = [random_column(n, c + 300) for c in range(4)]
+    m = be.Matrix.from_host(ctx, cols)
+    _, co = m.lde(1, g3(oracle))
+    coeffs = [oracle.lde(c, 1, g3(oracle))[1] for c in cols]
+    offs = [[0, 5], [0, 1, 2, 3, 16, 255, n - 1], sorted({int(v) for v in rng.integers(0, min(n, 40000), size=44)} | {0, 1, n - 1})[:40], [7]]
+    mask = [(c, o) for c in range(4) for o in offs[c]] + [(1, 16), (2, offs[2][3] + n), (0, 5)]
+    z = 0x1F2E3D4C5B6A7988 ** 3 % P
+    zm = oracle.to_mont([z])[0]
+    monkeypatch.setenv("SS_OOD_SPARSE_MIN_LOG", "12")           # the library takes this path from 2^22 coefficients on
+    if block_log is not None:
+        monkeypatch.setenv("SS_OOD_BLOCK_LOG", str(block_log))
+    got = ctx.ood_eval(co.cols, log_n, [c for c, _ in mask], [o for _, o in mask], zm)
+    monkeypatch.setenv("SS_OOD_TRANSFORM", "1")
+    assert np.array_equal(got, ctx.ood_eval(co.cols, log_n, [c for c, _ in mask], [o for _, o in mask], zm))
+    w = pow(3, (P - 1) >> log_n, P)
+    for j, (c, o) in enumerate(mask):
+        if j % 5 == 0 or j >= len(mask) - 3:
+            want = oracle.poly_eval(coeffs[c], oracle.to_mont([z * pow(w, o % n, P) % P])[0])
+            assert np.array_equal(got[j], want), (log_n, j)
+
+
 @pytest.mark.parametrize("log_n", [4, 10, 13])
 def test_deep_compose_vs_oracle(ctx, be, oracle, log_n):
     lb = 1

@@ -260,25 +260,24 @@ TWO_WG = (3, False, 2, True, False, 256)           # <= 7 LDS slots + constants 
 TWO_WG_FUSED = (3, False, 2, True, True, 256)
 TWO_WG_REGS = (4, True, 2, False, False, 256)      # round 2's recursive kernel: slots in registers
 BIG_WG = (3, False, 1, True, False, 512)           # ONE 512-lane workgroup per CU: two waves per SIMD behind one barrier, constants shared
+BIG_WG_FUSED = (3, False, 1, True, True, 512)
 sync = lambda cfg, every=8: cfg + (every,)         # + a workgroup barrier every `every` program instructions
+depth = lambda cfg, d: (d,) + cfg[1:]
+# Round 3, MI355X, 2^25 points (profiles/r03_quotient_parts_ab.txt).  starknet: round 2's kernel 140.3 ms (with barriers 147.8);
+# cut into 6 at two workgroups per CU 131.7 (+ barriers every 8 instructions 136.1, every 32: 133.3; + fused dot products
+# 130.2; 4 parts 136.7, 8 parts 136.0; cuts between zerofier groups only, 3 parts: 134.1); the five light parts as ONE
+# 512-lane workgroup per CU: 133.4 without barriers, 128.9 with (every 16: 127.2, every 4: 132.1; prefetch depth 2 / 4: 129.5 /
+# 129.3; 8 parts 130.1), with fused dot products 122.1 (barriers every 16: 120.3; part 0 without: 120.9; 5 / 7 / 8 parts: 126.5 /
+# 121.3 / 123.3; prefetch depth 2 / 4: 122.5 / 122.8).  recursive: round 2's kernel 63.1 ms stays the best (3 - 4 parts: 63.3 - 68.6).
 VARIANTS = {
-    "starknet": [("", True, [sync(ONE_WG)] + [sync(TWO_WG)] * 5),
+    "starknet": [("", True, [sync(ONE_WG, 16)] + [sync(BIG_WG_FUSED, 16)] * 5),
                  ("_v1", False, [ONE_WG]),                                 # round 2's kernel
-                 ("_v2", False, [sync(ONE_WG)]),                           # ... its waves in lock step
-                 ("_v3", True, [ONE_WG] + [TWO_WG] * 5),                   # cut into 6, no barriers
-                 ("_v4", True, [sync(ONE_WG)] + [sync(TWO_WG_FUSED)] * 5),
-                 ("_v5", True, [sync(ONE_WG)] + [sync(TWO_WG)] * 3),
-                 ("_v6", True, [sync(ONE_WG)] + [sync(TWO_WG)] * 7),
-                 ("_v7", True, [sync(ONE_WG)] + [sync(BIG_WG)] * 5),
-                 ("_v8", True, [sync(ONE_WG, 32)] + [sync(TWO_WG, 32)] * 5),
-                 ("_v9", False, [ONE_WG, TWO_WG, TWO_WG])],                # cuts between zerofier groups only
-    "recursive": [("", True, [sync(ONE_WG)] + [sync(TWO_WG)] * 2),
-                  ("_v1", False, [TWO_WG_REGS]),                           # round 2's kernel
-                  ("_v2", False, [sync(TWO_WG_REGS)]),
-                  ("_v3", True, [TWO_WG_REGS, TWO_WG, TWO_WG]),
-                  ("_v4", True, [ONE_WG, TWO_WG, TWO_WG]),
-                  ("_v5", True, [sync(ONE_WG)] + [sync(TWO_WG)] * 3),
-                  ("_v6", True, [sync(ONE_WG)] + [sync(TWO_WG_FUSED)] * 2)],
+                 ("_v2", True, [ONE_WG] + [sync(BIG_WG_FUSED, 16)] * 5),
+                 ("_v3", True, [sync(ONE_WG)] + [sync(BIG_WG_FUSED)] * 5),
+                 ("_v4", True, [sync(ONE_WG, 16)] + [sync(BIG_WG_FUSED, 16)] * 6),
+                 ("_v5", True, [sync(ONE_WG, 32)] + [sync(BIG_WG_FUSED, 32)] * 5)],
+    "recursive": [("", False, [TWO_WG_REGS]),                              # round 2's kernel
+                  ("_v1", True, [sync(ONE_WG)] + [sync(BIG_WG_FUSED)] * 2)],
 }
 LDS_BYTES_PER_CU = 160 * 1024
 
