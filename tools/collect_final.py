@@ -30,7 +30,7 @@ def parse_pmc(path, counter):
 for name in sorted(os.listdir(SRC)):
     if name.startswith("bench_") and name.endswith(".json"):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, "%s_%s" % (TAG, name)))
-for name in ("pytest_gpu.txt", "smoke.txt", "sq_counters_starknet_2p20.txt"):
+for name in ("pytest_gpu.txt", "smoke.txt", "sq_counters_starknet_2p20.txt", "sq_counters_recursive_2p20.txt"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, "%s_%s" % (TAG, name)))
 
@@ -65,7 +65,16 @@ for d in sorted(os.listdir(SRC)):
     ntt = [r for r in rows if "ntt_pass_kernel" in r[0]]
     disp = sum(r[1] for r in ntt)
     total = sum(r[2] + r[3] for r in ntt)
+    # per bench stage (bench.py stage_roofline reads `kernels`): the kernels whose launches the stage's HIP events bracket
+    stages = {"ntt_pass": ["ntt_pass_kernel"], "quotient": ["quotient_"], "deep": ["deep_kernel", "ood_blocks", "ood_fold", "batch_inverse", "poly_reduce"],
+              "hash_rows": ["keccak_rows", "blake2s_rows"], "merkle": ["_pairs_kernel", "pedersen_", "felt_pairs"], "fri_fold": ["fri_fold_kernel"]}
+    per_stage = {}
+    for stage, keys in stages.items():
+        sel = [r for r in rows if any(k in r[0] for k in keys)]
+        d, t = sum(r[1] for r in sel), sum(r[2] + r[3] for r in sel)
+        if d:
+            per_stage[stage] = {"dispatches": d, "bytes_per_launch": t / d, "bytes_per_proof": t / 2, "source": "profiles/%s_hbm_traffic_%s.txt" % (TAG, w)}
     with open(os.path.join(DST, "hbm_traffic_%s.json" % w), "w") as f:
         json.dump({"workload": w, "kernel": "ss::ntt_pass_kernel", "dispatches": disp, "bytes_per_launch": total / max(1, disp),
-                   "bytes_per_proof": total / 2, "source": "profiles/%s_hbm_traffic_%s.txt" % (TAG, w)}, f, indent=1)
+                   "bytes_per_proof": total / 2, "source": "profiles/%s_hbm_traffic_%s.txt" % (TAG, w), "kernels": per_stage}, f, indent=1)
     print(w, "ntt dispatches", disp, "GB/launch %.3f" % (total / max(1, disp) / 1e9))

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd $R
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -16 > $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $OUT/smoke.txt
 for w in starknet_2p20 recursive_2p20 recursive_2p16 array_sum_example; do
   timeout 600 python bench.py --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err
@@ -25,4 +25,6 @@ WORKLOAD=recursive_2p20 bash tools/profile_round.sh > $OUT/profile_round_rec.log
 cp -r $R/gpurun_out/prof $OUT/prof_recursive_2p20
 # SQ instruction / wait counters of the default workload (own pass: --pmc only)
 bash tools/pmc_run.sh sq_final "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star > $OUT/sq_counters_starknet_2p20.txt 2>&1
+bash tools/pmc_run.sh sq_final_rec "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $R/bench.py --workload recursive_2p20 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/sq_counters_recursive_2p20.txt 2>&1
+bash tools/gl64_pmc.sh > $OUT/gl64_pmc.log 2>&1
 ls $OUT
