@@ -76,7 +76,7 @@ enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
 const char *ss_last_error(void);
 /* ABI version of this header; bump on any signature change.  ss_abi_version() of the loaded
  * library must equal SS_ABI_VERSION of the header the caller was built against. */
-#define SS_ABI_VERSION 6u
+#define SS_ABI_VERSION 7u
 uint32_t ss_abi_version(void);
 
 /* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;
@@ -96,6 +96,31 @@ ss_status ss_upload(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 ss_status ss_download(ss_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 /* zero-fill on the ctx stream (`Vec::resize(trace_len, Fp::ZERO)`, layouts/src/recursive/trace.rs:741-748) */
 ss_status ss_dev_zero(ss_ctx *ctx, void *d_ptr, size_t bytes);
+
+/* ---- data movement of the sharded driver (ABI 7; DESIGN.md section 6: nothing in the reference to replace - its
+ * parallelism is rayon loops in one address space, crypto/src/merkle/utils.rs:30-32).  All on the ctx stream, no host sync. */
+/* device -> device */
+ss_status ss_dev_copy(ss_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+/* `rows` runs of `width` bytes: row r from d_src + r * src_pitch to d_dst + r * dst_pitch (the stride-R comb of a leaf block) */
+ss_status ss_dev_copy_2d(ss_ctx *ctx, void *d_dst, size_t dst_pitch, const void *d_src, size_t src_pitch, size_t width, size_t rows);
+/* 32-byte elements: d_dst[bitrev(i)] = d_src[i], i < 2^log_n (a single column's leaves in the commitment order); not in place */
+ss_status ss_bitrev_permute32(ss_ctx *ctx, const void *d_src, uint32_t log_n, void *d_dst);
+
+/* One communicator per rank over RCCL (loaded with dlopen at the first call: a process that never shards does not need the
+ * library).  Rank 0 makes the 128-byte id (ss_comm_unique_id) and hands it to the other ranks by whatever launched them; every
+ * rank then calls ss_comm_create on its own context.  The exchanges run on the context's stream. */
+typedef struct ss_comm ss_comm;
+ss_status ss_comm_unique_id(uint8_t id_out[128]);
+ss_status ss_comm_create(ss_ctx *ctx, const uint8_t id[128], uint32_t rank, uint32_t world, ss_comm **out);
+void ss_comm_destroy(ss_comm *comm);
+/* One exchange step that EVERY rank enters: message i of this rank goes from d_send[i] (send_bytes[i] bytes) to rank
+ * send_peer[i]; message j arrives from rank recv_peer[j] in d_recv[j].  The messages of one ordered pair of ranks are matched
+ * in list order (messages to the own rank are device copies); either list may be empty.  ONE grouped ncclSend / ncclRecv
+ * batch - on xGMI each pair of GPUs has its own link, so the R (R - 1) transfers of a re-shard run concurrently, no ring. */
+ss_status ss_comm_exchange(ss_comm *comm, uint32_t nsend, const uint32_t *send_peer, const void *const *d_send, const uint64_t *send_bytes,
+                           uint32_t nrecv, const uint32_t *recv_peer, void *const *d_recv, const uint64_t *recv_bytes);
+/* `bytes` bytes of every rank, in rank order, into d_recv (world * bytes) */
+ss_status ss_comm_all_gather(ss_comm *comm, const void *d_send, uint64_t bytes, void *d_recv);
 
 /* ---- N1/N2: ministark Matrix::interpolate / Matrix::evaluate (un-vendored;
  *      call sites src/lib.rs:17-26; convention pinned by

@@ -62,6 +62,14 @@ SIGNATURES = {
     "ss_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ss_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ss_dev_zero": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ss_dev_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ss_dev_copy_2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]),
+    "ss_bitrev_permute32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "ss_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "ss_comm_create": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, _vpp]),
+    "ss_comm_destroy": (None, [C.c_void_p]),
+    "ss_comm_exchange": (C.c_int, [C.c_void_p, C.c_uint32, _u32p, _vpp, _u64p, C.c_uint32, _u32p, _vpp, _u64p]),
+    "ss_comm_all_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "ss_permutation_product": (C.c_int, [C.c_void_p, C.POINTER(PermOperand), C.POINTER(PermOperand), C.c_uint64, _u64p, _u64p,
                                          C.c_void_p, C.c_uint64, C.c_uint64, _u64p]),
     "ss_diluted_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, _u64p, _u64p,

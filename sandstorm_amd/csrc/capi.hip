@@ -6,6 +6,7 @@
 // quotient.hip; there is no CPU fallback — without a usable HIP device every
 // entry point returns SS_ERR_NO_DEVICE / SS_ERR_HIP.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cstdarg>
 #include <chrono>
@@ -285,7 +286,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL)
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -396,10 +397,139 @@ ss_status ss_dev_zero(ss_ctx *ctx, void *d_ptr, size_t bytes) {
     if (bytes) HIP_TRY(hipMemsetAsync(d_ptr, 0, bytes, ctx->stream));
     return SS_OK;
 }
+// ---- data movement of the sharded driver (ABI 7)
+ss_status ss_dev_copy(ss_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !d_src))) return fail(SS_ERR_INVALID, "NULL argument");
+    if (bytes) HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SS_OK;
+}
+ss_status ss_dev_copy_2d(ss_ctx *ctx, void *d_dst, size_t dst_pitch, const void *d_src, size_t src_pitch, size_t width, size_t rows) {
+    if (!ctx || (width && rows && (!d_dst || !d_src))) return fail(SS_ERR_INVALID, "NULL argument");
+    if (dst_pitch < width || src_pitch < width) return fail(SS_ERR_INVALID, "pitch smaller than the row width");
+    if (width && rows) HIP_TRY(hipMemcpy2DAsync(d_dst, dst_pitch, d_src, src_pitch, width, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    return SS_OK;
+}
+ss_status ss_bitrev_permute32(ss_ctx *ctx, const void *d_src, uint32_t log_n, void *d_dst) {
+    if (!ctx || !d_src || !d_dst) return fail(SS_ERR_INVALID, "NULL argument");
+    if (log_n > 40) return fail(SS_ERR_INVALID, "log_n out of range");
+    if (d_src == d_dst) return fail(SS_ERR_INVALID, "ss_bitrev_permute32 is not in place");
+    HIP_TRY(launch_bitrev_copy(ctx->stream, (const Fp *)d_src, log_n, (Fp *)d_dst));
+    return SS_OK;
+}
+
 ss_status ss_download(ss_ctx *ctx, void *dst, const void *d_src, size_t bytes) {
     if (!ctx || (!dst && bytes) || (!d_src && bytes)) return fail(SS_ERR_INVALID, "NULL argument");
     HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+
+// ---- RCCL, loaded at the first use (dlopen: a process that never shards one proof over several GPUs carries no dependency)
+struct ss_comm {
+    ss_ctx *ctx;
+    void *nccl;              // ncclComm_t
+    uint32_t rank, world;
+};
+namespace {
+struct Rccl {
+    struct Id { char b[128]; };                 // ncclUniqueId (passed by value)
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string error;
+    bool load() {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { error = std::string("RCCL not found: ") + dlerror(); return false; }
+        auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) error = std::string("RCCL lacks ") + n; return p; };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        AllGather = (decltype(AllGather))sym("ncclAllGather");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !AllGather) { lib = nullptr; return false; }
+        return true;
+    }
+} g_rccl;
+constexpr int NCCL_INT8 = 0;                    // ncclInt8 / ncclChar
+}  // namespace
+#define RCCL_TRY(expr) do { const int r_ = (expr); if (r_ != 0) return fail(SS_ERR_HIP, "RCCL: %s (%s)", g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "error", #expr); } while (0)
+
+ss_status ss_comm_unique_id(uint8_t id_out[128]) {
+    if (!id_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!g_rccl.load()) return fail(SS_ERR_UNSUPPORTED, "%s", g_rccl.error.c_str());
+    RCCL_TRY(g_rccl.GetUniqueId(id_out));
+    return SS_OK;
+}
+ss_status ss_comm_create(ss_ctx *ctx, const uint8_t id[128], uint32_t rank, uint32_t world, ss_comm **out) {
+    if (!ctx || !id || !out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (world == 0 || rank >= world) return fail(SS_ERR_INVALID, "rank %u of %u", rank, world);
+    if (!g_rccl.load()) return fail(SS_ERR_UNSUPPORTED, "%s", g_rccl.error.c_str());
+    HIP_TRY(hipSetDevice(ctx->device));
+    Rccl::Id uid;
+    memcpy(uid.b, id, 128);
+    void *c = nullptr;
+    RCCL_TRY(g_rccl.CommInitRank(&c, (int)world, uid, (int)rank));
+    ss_comm *cm = new ss_comm;
+    cm->ctx = ctx; cm->nccl = c; cm->rank = rank; cm->world = world;
+    *out = cm;
+    return SS_OK;
+}
+void ss_comm_destroy(ss_comm *comm) {
+    if (!comm) return;
+    if (comm->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm->nccl);
+    delete comm;
+}
+ss_status ss_comm_exchange(ss_comm *comm, uint32_t nsend, const uint32_t *send_peer, const void *const *d_send, const uint64_t *send_bytes,
+                           uint32_t nrecv, const uint32_t *recv_peer, void *const *d_recv, const uint64_t *recv_bytes) {
+    if (!comm || (nsend && (!send_peer || !d_send || !send_bytes)) || (nrecv && (!recv_peer || !d_recv || !recv_bytes)))
+        return fail(SS_ERR_INVALID, "NULL argument");
+    hipStream_t s = comm->ctx->stream;
+    const uint32_t r = comm->rank;
+    for (uint32_t i = 0; i < nsend; ++i)
+        if (send_peer[i] >= comm->world || (send_bytes[i] && !d_send[i])) return fail(SS_ERR_INVALID, "send %u: bad peer or NULL buffer", i);
+    for (uint32_t j = 0; j < nrecv; ++j)
+        if (recv_peer[j] >= comm->world || (recv_bytes[j] && !d_recv[j])) return fail(SS_ERR_INVALID, "receive %u: bad peer or NULL buffer", j);
+    // messages to the own rank: matched in order, device copies
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < nsend; ++i) {
+        if (send_peer[i] != r) continue;
+        while (j < nrecv && recv_peer[j] != r) ++j;
+        if (j == nrecv || recv_bytes[j] != send_bytes[i]) return fail(SS_ERR_INVALID, "a message to the own rank has no matching receive");
+        if (send_bytes[i]) HIP_TRY(hipMemcpyAsync(d_recv[j], d_send[i], send_bytes[i], hipMemcpyDeviceToDevice, s));
+        ++j;
+    }
+    if (comm->world == 1) return SS_OK;
+    RCCL_TRY(g_rccl.GroupStart());
+    for (uint32_t i = 0; i < nsend; ++i)
+        if (send_peer[i] != r && send_bytes[i]) RCCL_TRY(g_rccl.Send(d_send[i], send_bytes[i], NCCL_INT8, (int)send_peer[i], comm->nccl, s));
+    for (uint32_t k = 0; k < nrecv; ++k)
+        if (recv_peer[k] != r && recv_bytes[k]) RCCL_TRY(g_rccl.Recv(d_recv[k], recv_bytes[k], NCCL_INT8, (int)recv_peer[k], comm->nccl, s));
+    RCCL_TRY(g_rccl.GroupEnd());
+    return SS_OK;
+}
+ss_status ss_comm_all_gather(ss_comm *comm, const void *d_send, uint64_t bytes, void *d_recv) {
+    if (!comm || (bytes && (!d_send || !d_recv))) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!bytes) return SS_OK;
+    if (comm->world == 1) {
+        if (d_send != d_recv) HIP_TRY(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, comm->ctx->stream));
+        return SS_OK;
+    }
+    RCCL_TRY(g_rccl.AllGather(d_send, d_recv, bytes, NCCL_INT8, comm->nccl, comm->ctx->stream));
     return SS_OK;
 }
 

@@ -80,6 +80,89 @@ static std::vector<uint64_t> flat(const std::vector<Felt> &v) {
     return o;
 }
 
+// ------------------------------------------------------------- FRI, proof of work
+// (free functions: the single-device prover below and the sharded one of sharded.cpp run the same code on rank 0)
+static uint64_t brev_bits(uint64_t x, uint32_t bits) { uint64_t r = 0; for (uint32_t i = 0; i < bits; ++i) r |= ((x >> i) & 1ull) << (bits - 1 - i); return r; }
+static Digest digest_of_root(const std::array<uint8_t, 33> &r) { Digest d; memcpy(d.data(), r.data(), 32); return d; }
+
+std::vector<FriLayerState> fri_commit_phase(ss_ctx *ctx, const Claim &claim, const Conventions &conv, const ProofOptions &opt, PublicCoin &coin,
+                                            Proof &proof, std::shared_ptr<DeviceBuffer> deep, uint32_t log_N, uint64_t n) {
+    const int order = conv.bitrev_commit ? SS_ORDER_BITREV : SS_ORDER_NATURAL;
+    const uint32_t fold = opt.fri_folding_factor, log_fold = log2u(fold);
+    std::vector<FriLayerState> layers;
+    std::shared_ptr<DeviceBuffer> evals = deep;
+    uint32_t log_len = log_N;
+    Felt offset = felt_from_u64(conv.lde_offset);
+    uint64_t degree_bound = n;
+    while (degree_bound > opt.fri_max_remainder_coeffs) {
+        const uint64_t rows = 1ull << (log_len - log_fold);
+        FriLayerState L;
+        L.evals = evals;
+        L.matrix.nrows = rows;
+        // committed row r = entries fold*r .. fold*r+fold-1 of the bit-reversed vector = natural row bitrev(r),
+        // its entry j at x_r * w_fold^bitrev(j): the natural stride columns, re-ordered
+        for (uint32_t j = 0; j < fold; ++j)
+            L.matrix.cols.push_back(evals->u64() + 4 * rows * (conv.bitrev_commit ? brev_bits(j, log_fold) : j));
+        L.tree = MerkleTree::from_matrix(ctx, claim.tree_kind, claim.n_friendly_layers, L.matrix, order);
+        FriLayerProof lp;
+        lp.root = L.tree->root();
+        lp.log_len = log_len;
+        proof.fri_layers.push_back(lp);
+        coin.reseed_with_digest(digest_of_root(lp.root));
+        Felt alpha = coin.draw();
+        if (conv.fri_alpha_times_offset) alpha = felt_mul(alpha, offset);     // challenge = draw * layer offset
+        proof.fri_alphas.push_back(alpha);
+        auto next = std::make_shared<DeviceBuffer>(ctx, 32 * rows);
+        ok(ss_fri_fold_ex(ctx, evals->u64(), log_len, fold, alpha.data(), offset.data(),
+                          conv.fri_unnormalised ? SS_FRI_UNNORMALISED : 0, next->u64()));     // natural order in memory
+        layers.push_back(std::move(L));
+        evals = next;
+        log_len -= log_fold;
+        offset = felt_pow(offset, fold);
+        degree_bound /= fold;
+    }
+    uint64_t *e = evals->u64();
+    const Felt rem_offset = conv.remainder_unshifted ? felt_from_u64(1) : offset;
+    ok(ss_ntt_fp252(ctx, &e, 1, log_len, SS_NTT_INVERSE, rem_offset.data(), SS_ORDER_NATURAL, SS_ORDER_NATURAL));
+    std::vector<uint64_t> rem(4ull << log_len);
+    ok(ss_download(ctx, rem.data(), e, rem.size() * 8));
+    const uint64_t keep = degree_bound ? degree_bound : 1;
+    for (uint64_t i = 4 * keep; i < rem.size(); ++i) if (rem[i]) throw std::runtime_error("FRI remainder exceeds its degree bound");
+    for (uint64_t i = 0; i < keep; ++i) { Felt f; memcpy(f.data(), rem.data() + 4 * i, 32); proof.fri_remainder.push_back(f); }
+    coin.reseed_with_field_element_vector(proof.fri_remainder);
+    return layers;
+}
+
+uint64_t proof_of_work(ss_ctx *ctx, const Claim &claim, PublicCoin &coin, const ProofOptions &opt, bool have_nonce, uint64_t nonce) {
+    if (have_nonce) {
+        if (!verify_proof_of_work(claim.coin_kind, coin.digest(), opt.grinding_factor, nonce))
+            throw std::runtime_error("the supplied proof-of-work nonce is not valid for this transcript");
+        return nonce;
+    }
+    uint64_t found = 0;
+    if (opt.grinding_factor) ok(ss_pow_grind(ctx, claim.coin_kind, coin.digest().data(), opt.grinding_factor, &found));
+    return found;
+}
+
+void fri_open(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Proof &proof, std::vector<FriLayerState> &layers,
+              const std::vector<uint64_t> &positions) {
+    const uint32_t log_fold = log2u(opt.fri_folding_factor);
+    std::vector<uint64_t> p = positions;
+    for (size_t li = 0; li < layers.size(); ++li) {
+        const uint32_t row_bits = proof.fri_layers[li].log_len - log_fold;
+        const uint64_t rows = 1ull << row_bits;
+        std::set<uint64_t> s;
+        for (uint64_t q : p) s.insert(conv.bitrev_commit ? (q >> log_fold) : (q % rows));
+        p.assign(s.begin(), s.end());
+        std::vector<uint64_t> nat_rows = p;
+        if (conv.bitrev_commit) for (auto &r : nat_rows) r = brev_bits(r, row_bits);
+        proof.fri_layers[li].positions = p;
+        proof.fri_layers[li].rows = gather(ctx, layers[li].matrix.cols, nat_rows);
+        proof.fri_layers[li].paths = layers[li].tree->prove(p, &proof.fri_layers[li].path_tags);
+        proof.fri_layers[li].leaves = layers[li].tree->leaf_digests(p);
+    }
+}
+
 // ------------------------------------------------------------------------- prove
 Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const ExtensionBuilder &build_extension) {
     Air &air = *claim_.air;
@@ -199,61 +282,11 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
 
     mark("deep");
     // 8. FRI
-    const uint32_t fold = opt_.fri_folding_factor, log_fold = log2u(fold);
-    struct Layer { std::unique_ptr<MerkleTree> tree; Matrix matrix; std::shared_ptr<DeviceBuffer> evals; };
-    std::vector<Layer> layers;
-    std::shared_ptr<DeviceBuffer> evals = deep;
-    uint32_t log_len = log_N;
-    Felt offset = g;
-    uint64_t degree_bound = n;
-    while (degree_bound > opt_.fri_max_remainder_coeffs) {
-        const uint64_t rows = 1ull << (log_len - log_fold);
-        Layer L;
-        L.evals = evals;
-        L.matrix.nrows = rows;
-        // committed row r = entries fold*r .. fold*r+fold-1 of the bit-reversed vector = natural row bitrev(r),
-        // its entry j at x_r * w_fold^bitrev(j): the natural stride columns, re-ordered
-        for (uint32_t j = 0; j < fold; ++j)
-            L.matrix.cols.push_back(evals->u64() + 4 * rows * (conv_.bitrev_commit ? brev(j, log_fold) : j));
-        L.tree = commit(L.matrix);
-        FriLayerProof lp;
-        lp.root = L.tree->root();
-        lp.log_len = log_len;
-        proof.fri_layers.push_back(lp);
-        coin.reseed_with_digest(digest_of(lp.root));
-        Felt alpha = coin.draw();
-        if (conv_.fri_alpha_times_offset) alpha = felt_mul(alpha, offset);     // challenge = draw * layer offset
-        proof.fri_alphas.push_back(alpha);
-        auto next = std::make_shared<DeviceBuffer>(ctx_, 32 * rows);
-        ok(ss_fri_fold_ex(ctx_, evals->u64(), log_len, fold, alpha.data(), offset.data(),
-                          conv_.fri_unnormalised ? SS_FRI_UNNORMALISED : 0, next->u64()));     // natural order in memory
-        layers.push_back(std::move(L));
-        evals = next;
-        log_len -= log_fold;
-        offset = felt_pow(offset, fold);
-        degree_bound /= fold;
-    }
-    {
-        uint64_t *e = evals->u64();
-        const Felt rem_offset = conv_.remainder_unshifted ? felt_from_u64(1) : offset;
-        ok(ss_ntt_fp252(ctx_, &e, 1, log_len, SS_NTT_INVERSE, rem_offset.data(), SS_ORDER_NATURAL, SS_ORDER_NATURAL));
-        std::vector<uint64_t> rem(4ull << log_len);
-        ok(ss_download(ctx_, rem.data(), e, rem.size() * 8));
-        const uint64_t keep = degree_bound ? degree_bound : 1;
-        for (uint64_t i = 4 * keep; i < rem.size(); ++i) if (rem[i]) throw std::runtime_error("FRI remainder exceeds its degree bound");
-        for (uint64_t i = 0; i < keep; ++i) { Felt f; memcpy(f.data(), rem.data() + 4 * i, 32); proof.fri_remainder.push_back(f); }
-        coin.reseed_with_field_element_vector(proof.fri_remainder);
-    }
+    std::vector<FriLayerState> layers = fri_commit_phase(ctx_, claim_, conv_, opt_, coin, proof, deep, log_N, n);
 
     mark("fri");
     // 9. proof of work, queries, openings
-    if (have_nonce_) {
-        if (!verify_proof_of_work(claim_.coin_kind, coin.digest(), opt_.grinding_factor, nonce_))
-            throw std::runtime_error("the supplied proof-of-work nonce is not valid for this transcript");
-        proof.pow_nonce = nonce_;
-    } else if (opt_.grinding_factor) {
-        ok(ss_pow_grind(ctx_, claim_.coin_kind, coin.digest().data(), opt_.grinding_factor, &proof.pow_nonce));
-    }
+    proof.pow_nonce = proof_of_work(ctx_, claim_, coin, opt_, have_nonce_, nonce_);
     coin.reseed_with_int(proof.pow_nonce);
     proof.query_positions = coin.draw_queries(opt_.num_queries, N);
     const auto &pos = proof.query_positions;
@@ -271,20 +304,7 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     proof.composition_rows = gather(ctx_, comp_lde.cols, nat);
     proof.composition_paths = comp_tree->prove(pos, &proof.composition_path_tags);
     proof.composition_leaves = comp_tree->leaf_digests(pos);
-    std::vector<uint64_t> p = pos;
-    for (size_t li = 0; li < layers.size(); ++li) {
-        const uint32_t row_bits = proof.fri_layers[li].log_len - log_fold;
-        const uint64_t rows = 1ull << row_bits;
-        std::set<uint64_t> s;
-        for (uint64_t q : p) s.insert(conv_.bitrev_commit ? (q >> log_fold) : (q % rows));
-        p.assign(s.begin(), s.end());
-        std::vector<uint64_t> nat_rows = p;
-        if (conv_.bitrev_commit) for (auto &r : nat_rows) r = brev(r, row_bits);
-        proof.fri_layers[li].positions = p;
-        proof.fri_layers[li].rows = gather(ctx_, layers[li].matrix.cols, nat_rows);
-        proof.fri_layers[li].paths = layers[li].tree->prove(p, &proof.fri_layers[li].path_tags);
-        proof.fri_layers[li].leaves = layers[li].tree->leaf_digests(p);
-    }
+    fri_open(ctx_, conv_, opt_, proof, layers, pos);
     mark("pow + openings");
     return proof;
 }

@@ -142,6 +142,15 @@ struct Proof {
     std::vector<uint8_t> serialize_wire() const;
 };
 
+class PublicCoin;
+// FRI commit phase / proof of work / FRI query phase on one device (steps 8-9 of Prover::prove; the sharded prover runs them on rank 0)
+struct FriLayerState { std::unique_ptr<MerkleTree> tree; Matrix matrix; std::shared_ptr<DeviceBuffer> evals; };
+std::vector<FriLayerState> fri_commit_phase(ss_ctx *ctx, const Claim &claim, const Conventions &conv, const ProofOptions &opt, PublicCoin &coin,
+                                            Proof &proof, std::shared_ptr<DeviceBuffer> deep, uint32_t log_N, uint64_t n);
+uint64_t proof_of_work(ss_ctx *ctx, const Claim &claim, PublicCoin &coin, const ProofOptions &opt, bool have_nonce, uint64_t nonce);
+void fri_open(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Proof &proof, std::vector<FriLayerState> &layers,
+              const std::vector<uint64_t> &positions);
+
 // build_extension_columns(&challenges) (layouts/src/recursive/trace.rs:699-814): returns the
 // extension columns, resident in HBM
 using ExtensionBuilder = std::function<Matrix(const std::vector<Felt> &challenges)>;

@@ -228,6 +228,43 @@ def compact_slots(ins):
     return out, n
 
 
+TEMP_ACC = 4            # a fifth accumulator the generator may use (the program format has four)
+
+
+def rematerialize_cheap_slots(ins, max_recipe=4):
+    """Scratch values that are a few additions of trace cells (the 16 decoded flags of the CPU constraints: cell - 2 x next cell)
+    need not sit in a slot from their definition to their last use - 17 of them at once keep the starknet program's first part
+    at one wave per SIMD (139 KB of LDS per 256 lanes).  Such a value is recomputed where it is read: its defining instructions
+    (a MOV from a trace cell / constant followed by ADD / SUB / RSUB of cells or constants, at most `max_recipe` instructions) are
+    replayed into a fifth accumulator in front of the reading instruction, and its store disappears.  -> program"""
+    leafy = lambda kind: kind in (SRC_TRACE, SRC_CONST)
+    recipe = [None] * 4                            # per accumulator: the instructions that made its value, if they qualify
+    slot_recipe, out = {}, []
+    for op, d, kind, w1 in ins:
+        if op <= OP_MUL and kind == SRC_SLOT and w1 in slot_recipe:
+            for rop, _, rkind, rw1 in slot_recipe[w1]:
+                out.append((rop, TEMP_ACC, rkind, rw1))
+            out.append((op, d, SRC_ACC, TEMP_ACC))
+            if d < 4:
+                recipe[d] = None                   # (a MOV from such a slot is not itself a recipe: keep it simple)
+            continue
+        if op == OP_ST:
+            if recipe[d] is not None and len(recipe[d]) <= max_recipe:
+                slot_recipe[w1] = list(recipe[d])  # no store: every read below recomputes
+                continue
+            slot_recipe.pop(w1, None)
+            out.append((op, d, kind, w1))
+            continue
+        if op == OP_MOV and leafy(kind):
+            recipe[d] = [(op, d, kind, w1)]
+        elif op in (OP_ADD, OP_SUB, OP_RSUB) and leafy(kind) and recipe[d] is not None:
+            recipe[d] = recipe[d] + [(op, d, kind, w1)]
+        elif op != OP_OUT:
+            recipe[d] = None
+        out.append((op, d, kind, w1))
+    return out
+
+
 def encode(ins):
     import numpy as np
     code = np.zeros(2 * len(ins), dtype=np.uint32)
@@ -269,17 +306,19 @@ depth = lambda cfg, d: (d,) + cfg[1:]
 # 512-lane workgroup per CU: 133.4 without barriers, 128.9 with (every 16: 127.2, every 4: 132.1; prefetch depth 2 / 4: 129.5 /
 # 129.3; 8 parts 130.1), with fused dot products 122.1 (barriers every 16: 120.3; part 0 without: 120.9; 5 / 7 / 8 parts: 126.5 /
 # 121.3 / 123.3; prefetch depth 2 / 4: 122.5 / 122.8).  recursive: round 2's kernel 63.1 ms stays the best (3 - 4 parts: 63.3 - 68.6).
+# Then the 16 decoded flags (cell - 2 x next cell) recomputed at their uses instead of parked in scratch slots (17 -> 6 slots: the
+# first part fits a 512-lane workgroup as well): starknet 120.8 -> 117.5 ms (7 parts: 117.5, 5 parts: 121.7); recursive as ONE
+# 512-lane workgroup with fused dot products 63.7 -> 60.1 ms (round 2's shape with the flags recomputed: 67.5).
+# (suffix, cuts inside zerofier groups, [part configurations], recompute cheap scratch values at their uses)
 VARIANTS = {
-    "starknet": [("", True, [sync(ONE_WG, 16)] + [sync(BIG_WG_FUSED, 16)] * 5),
-                 ("_v1", False, [ONE_WG]),                                 # round 2's kernel
-                 ("_v2", True, [ONE_WG] + [sync(BIG_WG_FUSED, 16)] * 5),
-                 ("_v3", True, [sync(ONE_WG)] + [sync(BIG_WG_FUSED)] * 5),
-                 ("_v4", True, [sync(ONE_WG, 16)] + [sync(BIG_WG_FUSED, 16)] * 6),
-                 ("_v5", True, [sync(ONE_WG, 32)] + [sync(BIG_WG_FUSED, 32)] * 5)],
-    "recursive": [("", False, [TWO_WG_REGS]),                              # round 2's kernel
-                  ("_v1", True, [sync(ONE_WG)] + [sync(BIG_WG_FUSED)] * 2)],
+    "starknet": [("", True, [sync(BIG_WG_FUSED, 16)] * 6, True),
+                 ("_v1", False, [ONE_WG], False),                                               # round 2's kernel
+                 ("_v2", True, [sync(ONE_WG, 16)] + [sync(BIG_WG_FUSED, 16)] * 5, False)],     # part 0 with its 17 slots
+    "recursive": [("", False, [sync(BIG_WG_FUSED, 16)], True),
+                  ("_v1", False, [TWO_WG_REGS], False)],                                        # round 2's kernel
 }
 LDS_BYTES_PER_CU = 160 * 1024
+REMAT_ABOVE_SLOTS = 8
 
 
 def generate(layout, all_variants=False):
@@ -288,13 +327,15 @@ def generate(layout, all_variants=False):
     code, n_consts, n_slots, n_tables, ncols = template_program(layout)
     ins = decode(code)
     written = []
-    for k, (suffix, inner, cfgs) in enumerate(VARIANTS[layout] if all_variants else VARIANTS[layout][:1]):
+    for k, (suffix, inner, cfgs, remat) in enumerate(VARIANTS[layout] if all_variants else VARIANTS[layout][:1]):
         parts, weights = split_program(ins, len(cfgs), inner) if len(cfgs) > 1 else ([ins], None)
         names = []
         for j, (part, cfg) in enumerate(zip(parts, cfgs)):
             depth, slots_in_regs, wgs, fence, fuse, threads = cfg[:6]
             sync = cfg[6] if len(cfg) > 6 else 0
             part, part_slots = compact_slots(part)
+            if remat and part_slots > REMAT_ABOVE_SLOTS:     # the decoded flags: recomputed at their uses instead of parked (17 -> 6 slots)
+                part, part_slots = compact_slots(rematerialize_cheap_slots(part))
             if not slots_in_regs:
                 lds = part_slots * 2 * threads * 16 + n_consts * 18 * 4
                 assert lds * wgs <= LDS_BYTES_PER_CU, "%s%s part %d: %d slots + constants = %d B of LDS x %d workgroups per CU" % (layout, suffix, j, part_slots, lds, wgs)
@@ -327,7 +368,7 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
     #      must die with the ADD (its next use, if any, is a write)
     def dies_after(acc, pc):
         for op, d, kind, w1 in ins[pc + 1:]:
-            reads = (op <= OP_MUL and kind == SRC_ACC and (w1 & 3) == acc) or (d == acc and op in (OP_ADD, OP_SUB, OP_RSUB, OP_MUL, OP_INV, OP_ST, OP_OUT))
+            reads = (op <= OP_MUL and kind == SRC_ACC and (w1 & 7) == acc) or (d == acc and op in (OP_ADD, OP_SUB, OP_RSUB, OP_MUL, OP_INV, OP_ST, OP_OUT))
             if reads:
                 return False
             if d == acc and op == OP_MOV:
@@ -337,11 +378,11 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
     for pc in range(n_instr - 1):
         op, e, kind, w1 = ins[pc]
         op2, d2, kind2, w2 = ins[pc + 1]
-        if FUSE_ALPHA_DOT_PRODUCTS and op == OP_MUL and kind == SRC_CONST and op2 == OP_ADD and kind2 == SRC_ACC and (w2 & 3) == e and d2 != e and dies_after(e, pc + 1):
+        if FUSE_ALPHA_DOT_PRODUCTS and op == OP_MUL and kind == SRC_CONST and op2 == OP_ADD and kind2 == SRC_ACC and (w2 & 7) == e and d2 != e and dies_after(e, pc + 1):
             fused[pc] = d2
     out = []
     emit = out.append
-    bound = [1, 1, 1, 1]
+    bound = [1, 1, 1, 1, 1]                        # four accumulators of the program format + the generator's own (TEMP_ACC)
     stats = {"mul": 0, "mulr": 0, "reduce": 0, "loads": len(mem_ops), "fused": 0, "flushes": 0}
     wide = {"acc": None, "terms": 0}               # the one wide (unreduced 64-bit column) accumulator in flight
 
@@ -376,14 +417,14 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
         if pc in skip_add:                          # the ADD of a fused pair: already accounted in the wide accumulator
             continue
         # any other touch of the accumulator that carries a pending dot product needs its value: flush first
-        touches = {d} | ({w1 & 3} if op <= OP_MUL and kind == SRC_ACC else set())
+        touches = {d} | ({w1 & 7} if op <= OP_MUL and kind == SRC_ACC else set())
         if wide["acc"] is not None and wide["acc"] in touches and not (pc in fused and fused[pc] == wide["acc"] and wide["acc"] != d):
             flush_wide()
         # ---- the operand: an expression of type Fl and its lazy bound
         src, sb, src_acc = None, 1, None
         if op <= OP_MUL:
             if kind == SRC_ACC:
-                src_acc = w1 & 3
+                src_acc = w1 & 7
                 src, sb = "acc%d" % src_acc, bound[src_acc]
             elif kind == SRC_SLOT:
                 assert w1 < n_slots
@@ -507,12 +548,13 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
 // operand macros of quotient_gen.h (operand loads issued %(depth)d operands ahead).  Included by the quotient_gen_%(layout)s*.hip
 // wrappers (device) and, with host definitions of the same macros, by tests/cpp/quotient_gen_host_test.cpp, which runs it on
 // the CPU against the oracle's constraint VM.
-    Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero();
+    Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero()%(temp_acc)s;
 %(wide)s%(regs)s    uint32_t i32 = (uint32_t)(lane < N ? lane : N - 1);
 %(prime)s    QG_POINT_LOOP_BEGIN
 %(body)s
     QG_POINT_LOOP_END
-''' % dict(layout=layout, regs=regs, prime=prime, body=body, depth=D, wide="    QgWide wd;\n" if stats["fused"] else "")
+''' % dict(layout=layout, regs=regs, prime=prime, body=body, depth=D, wide="    QgWide wd;\n" if stats["fused"] else "",
+           temp_acc=", acc4 = fl_zero()" if any(d == TEMP_ACC for _, d, _, _ in ins) else "")
     name = inc_name
     with open(os.path.join(ROOT, "sandstorm_amd", "csrc", name), "w") as f:
         f.write(inc)

@@ -22,7 +22,7 @@ from bench import synth_columns                                     # noqa: E402
 def main():
     layout = sys.argv[1]
     log_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    variants = [int(v) for v in sys.argv[3:]] or list(range(11 if layout == "starknet" else 3))
+    variants = [int(v) for v in sys.argv[3:]] or list(range(3 if layout == "starknet" else 2))
     log_n, lb = log_steps + 4, 1
     n, N = 1 << log_n, 2 << log_n
     dev = torch.device("cuda", 0)
