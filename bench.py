@@ -419,13 +419,30 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     def barrier():
         dist.barrier()
         torch.cuda.synchronize()
-    proof = prover.prove(seed, mine, build_extension, n)
+    if args.sharded_host == "cpp":
+        # the C++ host's sharded prover (sandstorm_amd/host/sharded.cpp) over RCCL through the C ABI (ss_comm_*): rank 0 makes the
+        # communicator's id, torch.distributed only hands it out
+        box = [hostlib.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        tree_kind, n_friendly = (be.TREE_FRIENDLY, 22) if layout == "recursive" else (be.TREE_KECCAK_M20, 0)
+        wire_proof = [None]
+
+        def prove_once():
+            wire_proof[0] = hostlib.prove_sharded(ctx, host_air, tree_kind, n_friendly, coin, seed, rank, world, box[0], mine, log_steps + 4,
+                                                  build_extension, ProofOptions())
+            return wire_proof[0]
+    else:
+        prove_once = lambda: prover.prove(seed, mine, build_extension, n)
+    proof = prove_once()
+    if args.sharded_host == "cpp" and rank == 0:
+        from sandstorm_amd import wire as wire_format
+        proof = wire_format.parse(proof, tree_kind)
 
     def all_max(dt):
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item())
-    sec = timed_steps(lambda: prover.prove(seed, mine, build_extension, n), args.steps, args.warmup, barrier, all_max)
+    sec = timed_steps(prove_once, args.steps, args.warmup, barrier, all_max)
     if rank == 0:
         emit({
             "metric": "prove_wall_time_s", "value": sec, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -441,7 +458,8 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
                        "claim": "CairoVerifierClaim (Blake2s+Pedersen-22 tree, Cairo coin)" if layout == "recursive"
                                 else "EthVerifierClaim (Keccak-masked-20 tree, Solidity coin)",
                        "proof_options": "65 queries, blowup 2, 16 PoW bits, FRI fold 8, <=16 remainder coeffs",
-                       "host": "Python host (sandstorm_amd/sharded_prover.py) over the C ABI + torch.distributed (nccl = RCCL)",
+                       "host": "C++ host (sandstorm_amd/host/sharded.cpp) over the C ABI, RCCL through ss_comm_*" if args.sharded_host == "cpp" else
+                               "Python host (sandstorm_amd/sharded_prover.py) over the C ABI + torch.distributed (nccl = RCCL)",
                        "fri_layers": len(proof.fri_layers) if proof is not None else None,
                        "note": "python bench.py --gpus N --mode replicas runs N independent proofs instead (weak scaling)"},
         })
@@ -694,6 +712,9 @@ def main():
     ap.add_argument("--workload", default="starknet_2p20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true", help="skip the recursive_2p20 leg of the default run")
+    ap.add_argument("--sharded-host", default="python", choices=["python", "cpp"],
+                    help="--mode shard: the driver above the C ABI - sandstorm_amd/sharded_prover.py over torch.distributed (default: the "
+                         "one the multi-rank gloo tests run as it is launched here), or the C++ host's sharded.cpp over RCCL (ss_comm_*)")
     ap.add_argument("--mode", default="auto", choices=["auto", "shard", "replicas"],
                     help="N > 1 GPUs: shard = ONE proof over the N GPUs (column-sharded LDE, row-block hashing / constraints / DEEP, "
                          "RCCL point-to-point re-shards; strong scaling) - the default; replicas = one independent proof per GPU (weak scaling)")

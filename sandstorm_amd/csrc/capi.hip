@@ -446,9 +446,14 @@ struct Rccl {
     std::string error;
     bool load() {
         if (lib) return true;
-        for (const char *name : {"librccl.so.1", "librccl.so"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // the copy the process already holds (PyTorch loads the librccl.so it bundles), else the ROCm installation's
+        for (const char *name : {"librccl.so", "librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
             if (lib) break;
+        }
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (lib) break;
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!lib) { error = std::string("RCCL not found: ") + dlerror(); return false; }
         auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) error = std::string("RCCL lacks ") + n; return p; };

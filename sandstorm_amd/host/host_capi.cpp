@@ -7,6 +7,7 @@
 
 #include "extension.hpp"
 #include "prover.hpp"
+#include "sharded.hpp"
 #include "public_input.hpp"
 #include "trace_recursive.hpp"
 #include "trace_starknet.hpp"
@@ -107,6 +108,64 @@ int ssh_prove_wire_with_nonce(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32
                       proof_bytes, proof_len, &pow_nonce);
 }
 void ssh_free(void *p) { free(p); }
+
+// ---- one proof over several ranks (sharded.hpp).  Every rank calls ssh_prove_sharded with its own context and AIR handle; the
+// proof (reference wire format) comes out on rank 0.  Transport: a local group (ranks = threads of this process:
+// ssh_local_group_create) or RCCL (rccl_id = the 128 bytes of ss_comm_unique_id from rank 0).
+typedef struct ssh_local_group ssh_local_group;
+ssh_local_group *ssh_local_group_create(uint32_t world) { return reinterpret_cast<ssh_local_group *>(new std::shared_ptr<LocalGroup>(make_local_group(world))); }
+void ssh_local_group_destroy(ssh_local_group *g) { delete reinterpret_cast<std::shared_ptr<LocalGroup> *>(g); }
+// the rank's extension columns for these challenges: fill cols_out / d_cols_out (<= 16 entries) and *ncols_out; 0 on success
+typedef int (*ssh_sharded_extension_cb)(void *user, const uint64_t *challenges, uint32_t nchallenges, uint32_t *cols_out, uint64_t **d_cols_out,
+                                        uint32_t *ncols_out);
+int ssh_prove_sharded(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32], uint32_t rank,
+                      uint32_t world, ssh_local_group *group, const uint8_t *rccl_id, const uint32_t *base_cols, uint64_t *const *d_base,
+                      uint32_t nbase_mine, uint32_t log_n, ssh_sharded_extension_cb cb, void *user, const uint32_t options[5],
+                      uint8_t **proof_bytes, uint64_t *proof_len) {
+    std::shared_ptr<LocalGroup> *lg = reinterpret_cast<std::shared_ptr<LocalGroup> *>(group);
+    try {
+        if (!ctx || !air_h || !seed || (!group && !rccl_id)) throw std::runtime_error("ssh_prove_sharded: NULL argument");
+        Air *air = reinterpret_cast<Air *>(air_h);
+        Claim claim;
+        claim.air = air; claim.tree_kind = tree_kind; claim.n_friendly_layers = n_friendly_layers; claim.coin_kind = coin_kind;
+        ProofOptions opt;
+        if (options) {
+            opt.num_queries = options[0]; opt.lde_blowup_factor = options[1]; opt.grinding_factor = options[2];
+            opt.fri_folding_factor = options[3]; opt.fri_max_remainder_coeffs = options[4];
+        }
+        std::unique_ptr<Transport> comm = lg ? make_local_transport(*lg, rank) : make_rccl_transport(ctx, rccl_id, rank, world);
+        if (comm->world != world) throw std::runtime_error("ssh_prove_sharded: the group has another number of ranks");
+        std::map<uint32_t, uint64_t *> mine;
+        for (uint32_t k = 0; k < nbase_mine; ++k) mine[base_cols[k]] = d_base[k];
+        Digest sd;
+        memcpy(sd.data(), seed, 32);
+        ShardedProver prover(ctx, claim, *comm, opt);
+        Proof proof;
+        const bool have = prover.prove(sd, mine, [&](const std::vector<Felt> &ch) {
+            std::vector<uint64_t> flat(4 * ch.size());
+            for (size_t i = 0; i < ch.size(); ++i) memcpy(flat.data() + 4 * i, ch[i].data(), 32);
+            uint32_t cols[16], ncols = 0;
+            uint64_t *ptrs[16];
+            if (!cb || cb(user, flat.data(), (uint32_t)ch.size(), cols, ptrs, &ncols) != 0 || ncols > 16) throw std::runtime_error("extension callback failed");
+            std::map<uint32_t, uint64_t *> out;
+            for (uint32_t k = 0; k < ncols; ++k) out[cols[k]] = ptrs[k];
+            return out;
+        }, 1ull << log_n, &proof);
+        if (proof_bytes && proof_len) { *proof_bytes = nullptr; *proof_len = 0; }
+        if (have && proof_bytes && proof_len) {
+            const std::vector<uint8_t> b = proof.serialize_wire();
+            *proof_bytes = (uint8_t *)malloc(b.size());
+            memcpy(*proof_bytes, b.data(), b.size());
+            *proof_len = b.size();
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        if (lg) local_group_fail(**lg);
+        return 1;
+    }
+}
+
 
 // Trace::build_extension_columns (extension.hpp).  layout: 1 = recursive, 2 = starknet (the ssh_air_create kinds);
 // d_aux = {npc, memory, range_check [, diluted_unordered, diluted_ordered]}; challenges = 6 felts.  The result is a

@@ -1,0 +1,75 @@
+// sharded.hpp — ONE proof over the GPUs of a node, in the C++ host.
+//
+// The reference has nothing to match: its parallelism is rayon loops inside one address space
+// (crypto/src/merkle/utils.rs:30-32, layouts/src/starknet/trace.rs:182).  One process (or thread) per GPU, each with its own
+// ss_ctx; the ranks meet in a Transport: RCCL over xGMI on a multi-GPU node (ss_comm_* of the C ABI), or - for ranks that are
+// threads of one process, the way the tests and a single-GPU box run it - a local group that copies between the contexts.
+// The proof is the single-device prover's, byte for byte (tests/test_sharded_host.py; the Python mirror of this driver is
+// sandstorm_amd/sharded_prover.py, whose module text has the distribution table).
+#pragma once
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "prover.hpp"
+
+namespace ssh {
+
+struct Message { uint32_t peer; void *ptr; uint64_t bytes; };       // device memory of this rank's context
+
+class Transport {
+public:
+    virtual ~Transport() = default;
+    uint32_t rank = 0, world = 1;
+    // One exchange step that EVERY rank enters, whatever it has to send or receive; the messages of one ordered pair of ranks
+    // are matched in list order (ss_comm_exchange).  Runs on the context's stream.
+    virtual void exchange(ss_ctx *ctx, const std::vector<Message> &sends, const std::vector<Message> &recvs) = 0;
+    // `mine.size()` host bytes of every rank (the same count everywhere), in rank order
+    virtual std::vector<uint8_t> all_gather(ss_ctx *ctx, const std::vector<uint8_t> &mine) = 0;
+    // any number of bytes per rank -> one vector per rank
+    std::vector<std::vector<uint8_t>> all_gather_var(ss_ctx *ctx, const std::vector<uint8_t> &mine);
+};
+
+// RCCL: `id` = the 128 bytes of ss_comm_unique_id made by rank 0 and handed out by whatever launched the ranks
+std::unique_ptr<Transport> make_rccl_transport(ss_ctx *ctx, const uint8_t id[128], uint32_t rank, uint32_t world);
+// ranks = threads of one process (every thread with its own context, on one device or several)
+class LocalGroup;
+std::shared_ptr<LocalGroup> make_local_group(uint32_t world);
+std::unique_ptr<Transport> make_local_transport(std::shared_ptr<LocalGroup> group, uint32_t rank);
+void local_group_fail(LocalGroup &group);          // a rank gave up: the others leave their barriers with an error
+
+// build_extension_columns on the ranks: -> {global column number: device column of n felts} for the extension columns this
+// rank owns (column c lives on rank c % world)
+using ShardedExtensionBuilder = std::function<std::map<uint32_t, uint64_t *>(const std::vector<Felt> &challenges)>;
+
+class ShardedProver {
+public:
+    ShardedProver(ss_ctx *ctx, const Claim &claim, Transport &comm, const ProofOptions &opt = ProofOptions(), const Conventions &conv = Conventions())
+        : ctx_(ctx), claim_(claim), comm_(comm), opt_(opt), conv_(conv) {}
+    // my_base: {column c: device column of n felts} for the base columns with c % world == rank.  Every rank calls it; the proof
+    // comes out on rank 0 (-> true there, false on the others).
+    bool prove(const Digest &coin_seed, const std::map<uint32_t, uint64_t *> &my_base, const ShardedExtensionBuilder &build_extension,
+               uint64_t n, Proof *out);
+    void set_pow_nonce(uint64_t nonce) { have_nonce_ = true; nonce_ = nonce; }
+private:
+    struct Commitment;
+    using Buf = std::shared_ptr<DeviceBuffer>;
+    uint32_t owner(uint32_t col) const { return col % comm_.world; }
+    std::vector<Buf> to_row_blocks(const std::map<uint32_t, Buf> &owned, uint32_t ncols, uint32_t first_col, uint64_t N, uint64_t halo);
+    std::unique_ptr<Commitment> commit(const std::vector<Buf> &blocks, uint64_t N, int order);
+    void open(const Commitment &com, const std::vector<Buf> &blocks, uint64_t N, const std::vector<uint64_t> &positions, int order,
+              std::vector<uint64_t> *rows, std::vector<uint8_t> *paths, std::vector<uint8_t> *leaves, std::vector<uint8_t> *tags);
+    ss_ctx *ctx_;
+    Claim claim_;
+    Transport &comm_;
+    ProofOptions opt_;
+    Conventions conv_;
+    bool have_nonce_ = false;
+    uint64_t nonce_ = 0;
+};
+
+// MerkleTreeConfig::hash_nodes on the host for the log2(world) levels above the ranks' sub-trees (33 bytes: digest + tag)
+std::array<uint8_t, 33> merge_nodes(int tree_kind, uint32_t n_friendly_layers, uint32_t depth, const std::array<uint8_t, 33> &left,
+                                    const std::array<uint8_t, 33> &right);
+
+}  // namespace ssh

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libsandstorm_host.so")
 AIR_MINI = 0
 EXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p))
+SHARDED_EXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))
 
 _host = None
 
@@ -34,6 +35,13 @@ def load():
                                 C.c_uint32, C.c_uint32, EXT_CB, C.c_void_p, C.POINTER(C.c_uint32),
                                 C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
         h.ssh_prove_wire.argtypes = h.ssh_prove.argtypes
+        h.ssh_local_group_create.argtypes = [C.c_uint32]
+        h.ssh_local_group_create.restype = C.c_void_p
+        h.ssh_local_group_destroy.argtypes = [C.c_void_p]
+        h.ssh_local_group_destroy.restype = None
+        h.ssh_prove_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_char_p,
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, SHARDED_EXT_CB, C.c_void_p,
+                                        C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
         h.ssh_prove_wire_with_nonce.argtypes = h.ssh_prove.argtypes[:12] + [C.c_uint64] + h.ssh_prove.argtypes[12:]
         h.ssh_free.argtypes = [C.c_void_p]
         h.ssh_build_extension_columns.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_uint64, C.POINTER(C.c_uint64),
@@ -432,6 +440,65 @@ def verify(air: HostAir, tree_kind, coin_kind, seed, proof: bytes, shipped_conve
     _check(load().ssh_verify(air.h, tree_kind, coin_kind, bytes(seed), bytes(proof), len(proof), (2 if fri_alpha_times_offset else 1) if shipped_conventions else 0,
                              required_security_bits, exp, pos.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(npos), int(n_friendly_layers)))
     return [int(v) for v in pos[:npos.value]]
+
+
+class LocalGroup:
+    """the meeting point of ranks that are THREADS of this process (host/sharded.cpp LocalTransport): every thread has its own
+    backend.Context - on one device, as the tests and a single-GPU box run it, or on several"""
+
+    def __init__(self, world):
+        self.world, self.h = world, load().ssh_local_group_create(world)
+
+    def close(self):
+        if self.h:
+            load().ssh_local_group_destroy(self.h)
+            self.h = None
+
+
+def rccl_unique_id():
+    """the 128 bytes rank 0 makes and every rank passes to prove_sharded(group=<those bytes>) (ss_comm_unique_id)"""
+    buf = C.create_string_buffer(128)
+    be.check(_lib.load().ss_comm_unique_id(buf))
+    return buf.raw
+
+
+def prove_sharded(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, rank, world, group, my_base, log_n, build_extension, options=None):
+    """ONE proof over `world` ranks by the C++ host (host/sharded.cpp; the Python mirror is sandstorm_amd/sharded_prover.py).  Called
+    by every rank with its own context and AIR handle.  group: a LocalGroup (ranks = threads of this process) or the 128 bytes of
+    rccl_unique_id() (one process per GPU, RCCL).  my_base: {column: device column} of the base columns with column % world ==
+    rank; build_extension(challenges) -> {global column number: device column} of this rank's extension columns (kept alive by
+    the caller).  -> the proof in the reference's wire format on rank 0, None on the others."""
+    options = options or ProofOptions()
+    keep = []
+
+    def cb(_user, ch_ptr, nch, cols_out, ptrs_out, ncols_out):
+        try:
+            ch = [np.array([ch_ptr[4 * i + k] for k in range(4)], dtype=np.uint64) for i in range(nch)]
+            cols = build_extension(ch)
+            keep.append(cols)
+            for i, (c, col) in enumerate(sorted(cols.items())):
+                cols_out[i] = c
+                ptrs_out[i] = be._ptr_of(col)
+            ncols_out[0] = len(cols)
+            return 0
+        except Exception:                       # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+    opts = (C.c_uint32 * 5)(options.num_queries, options.lde_blowup_factor, options.grinding_factor,
+                            options.fri_folding_factor, options.fri_max_remainder_coeffs)
+    cols = sorted(my_base)
+    col_ids = (C.c_uint32 * max(1, len(cols)))(*cols)
+    out, n = C.POINTER(C.c_uint8)(), C.c_uint64()
+    local = isinstance(group, LocalGroup)
+    _check(load().ssh_prove_sharded(ctx.handle, air.h, tree_kind, n_friendly, coin_kind, bytes(seed), rank, world, group.h if local else None,
+                                    None if local else bytes(group), col_ids, be._ptr_array([my_base[c] for c in cols]), len(cols), log_n,
+                                    SHARDED_EXT_CB(cb), None, opts, C.byref(out), C.byref(n)))
+    if not n.value:
+        return None
+    raw = bytes(bytearray(out[:n.value]))
+    load().ssh_free(out)
+    return raw
 
 
 class HostCoin:

@@ -105,3 +105,17 @@ def test_the_smoke_invocation(emulated_library):
             % (ROOT, emulated_library))
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_cpp_sharded_prover_over_ranks_as_threads(emulated_library):
+    """tests/hipemu/extra_sharded_host.py: the C++ host's sharded prover (sandstorm_amd/host/sharded.cpp) on 1, 2, 4 and 8 ranks - threads
+    of one process, each with its own emulated context, meeting in the LocalTransport: the MI355X-made single-device proofs byte for
+    byte (mini AIR; the reference's example with the real recursive AIR under the CairoVerifierClaim), friendly trees with the
+    Blake2s / Pedersen boundary inside"""
+    heavy()
+    os.environ["HIPEMU_THREADS"] = "1"           # the emulator's worker pool serves one launching thread: the ranks are the parallelism
+    try:
+        out = run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_sharded_host.py"])
+    finally:
+        del os.environ["HIPEMU_THREADS"]
+    assert "11 passed" in out, out[-500:]
