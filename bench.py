@@ -422,8 +422,11 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     if args.sharded_host == "cpp":
         # the C++ host's sharded prover (sandstorm_amd/host/sharded.cpp) over RCCL through the C ABI (ss_comm_*): rank 0 makes the
         # communicator's id, torch.distributed only hands it out
-        box = [hostlib.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
+        if world == 1:                              # a group of one needs no communicator
+            box = [hostlib.LocalGroup(1)]
+        else:
+            box = [hostlib.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
         tree_kind, n_friendly = (be.TREE_FRIENDLY, 22) if layout == "recursive" else (be.TREE_KECCAK_M20, 0)
         wire_proof = [None]
 

@@ -446,6 +446,9 @@ struct Rccl {
     std::string error;
     bool load() {
         if (lib) return true;
+        // one node, one process per GPU: the communicator's bootstrap runs over the loopback interface (on a box without any
+        // other interface RCCL otherwise spends minutes probing); a deployment that wants something else sets the variable itself
+        setenv("NCCL_SOCKET_IFNAME", "lo", 0);
         // the copy the process already holds (PyTorch loads the librccl.so it bundles), else the ROCm installation's
         for (const char *name : {"librccl.so", "librccl.so.1"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
