@@ -445,12 +445,38 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item())
-    sec = timed_steps(prove_once, args.steps, args.warmup, barrier, all_max)
+    for _ in range(args.warmup):
+        prove_once()
+    barrier()
+    ctx.profile(True)
+    ctx.profile_reset()
+    sec = timed_steps(prove_once, args.steps, 0, barrier, all_max)
+    kinds = [("ntt_pass", be.PROF_NTT_PASS), ("hash_rows", be.PROF_HASH_ROWS), ("merkle", be.PROF_MERKLE), ("fri_fold", be.PROF_FRI),
+             ("quotient", be.PROF_QUOTIENT), ("deep", be.PROF_DEEP), ("extension_scans", be.PROF_EXT)]
+    prof = {name: ctx.profile_read(k) for name, k in kinds}
+    ctx.profile(False)
+    # every rank's kernel time per stage (HIP events on its own stream), gathered for the report: where the proof's time goes per GPU
+    mine_ms = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
+    by_rank = [None] * world
+    dist.all_gather_object(by_rank, (mine_ms, prof["ntt_pass"][1]))
     if rank == 0:
+        algo = stage_algorithmic_bytes(nb, ne, log_steps + 4, 1, len(proof.fri_layers))["ntt_pass"]
+        slowest = max(range(world), key=lambda r: by_rank[r][0]["ntt_pass"])
+        ntt_ms, ntt_launches = by_rank[slowest][0]["ntt_pass"], by_rank[slowest][1]
+        ach = algo / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
         emit({
             "metric": "prove_wall_time_s", "value": sec, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sec * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "u256 (Fp252, Montgomery R=2^256, 8 x u32 limbs)", "data": "synthetic", "proofs_per_s": 1.0 / sec,
+            "stage_ms_per_proof_by_rank": [r[0] for r in by_rank],
+            "roofline": {"bound": "hbm", "kernel": "ss::ntt_pass_kernel", "stage": "ntt_pass", "achieved": ach, "peak": HBM_PEAK_GBPS * world,
+                         "unit": "GB/s", "frac": ach / (HBM_PEAK_GBPS * world), "traffic": None,
+                         "launches": ntt_launches, "avg_launch_ms": ntt_ms * args.steps / max(1, ntt_launches),
+                         "algorithmic_bytes_per_proof": algo,
+                         "note": "the WHOLE proof's transform bytes (SURVEY 8d: 2 N 32 B per transform) over the transform time of the rank "
+                                 "that spends most in them (rank %d: columns are dealt round-robin, 9-10 columns do not divide by %d), "
+                                 "against %d x the HBM peak; per-launch traffic is the single-device run's (profiles/hbm_traffic_*.json)"
+                                 % (slowest, world, world)},
             "config": {"workload": args.workload, "layout_shape": layout, "steps_log2": log_steps, "trace_rows_log2": log_steps + 4,
                        "columns": "%d base + %d extension" % (nb, ne),
                        "parallelism": "ONE proof sharded over %d GPUs: LDE by column (column c on rank c %% %d), row hashing / constraint "
@@ -461,7 +487,8 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
                        "claim": "CairoVerifierClaim (Blake2s+Pedersen-22 tree, Cairo coin)" if layout == "recursive"
                                 else "EthVerifierClaim (Keccak-masked-20 tree, Solidity coin)",
                        "proof_options": "65 queries, blowup 2, 16 PoW bits, FRI fold 8, <=16 remainder coeffs",
-                       "host": "C++ host (sandstorm_amd/host/sharded.cpp) over the C ABI, RCCL through ss_comm_*" if args.sharded_host == "cpp" else
+                       "host": ("C++ host (sandstorm_amd/host/sharded.cpp) over the C ABI, " + ("a group of one" if world == 1 else "RCCL through ss_comm_*"))
+                               if args.sharded_host == "cpp" else
                                "Python host (sandstorm_amd/sharded_prover.py) over the C ABI + torch.distributed (nccl = RCCL)",
                        "fri_layers": len(proof.fri_layers) if proof is not None else None,
                        "note": "python bench.py --gpus N --mode replicas runs N independent proofs instead (weak scaling)"},
@@ -508,12 +535,20 @@ def timed_steps(step, steps, warmup, barrier, all_max):
     return all_max(time.perf_counter() - t0) / steps
 
 
+def ood_by_transform(log_n):
+    """csrc/capi.hip ss_ood_eval: one coset transform per column below 2^22 coefficients (or SS_OOD_TRANSFORM=1), point by point above"""
+    return os.environ.get("SS_OOD_TRANSFORM") == "1" or log_n < int(os.environ.get("SS_OOD_SPARSE_MIN_LOG", "22"))
+
+
 def stage_algorithmic_bytes(nb, ne, log_n, lb, fri_layers, fold=8):
     """SURVEY.md 8d's algorithmic HBM bytes per proof and stage (every datum read once, every result written once)"""
     n, N, C = 1 << log_n, 1 << (log_n + lb), nb + ne
+    by_transform = ood_by_transform(log_n)
     out = {"quotient": 32.0 * (C + 1) * N,                                   # every trace cell once + the composition evaluations
-           "deep": 32.0 * ((C + 2) * n + n),                                 # composed on the n-point sub-coset (DESIGN.md section 4)
-           "ntt_pass": 32.0 * (C * (2 * n + 2 * N) + 3 * 2 * N + C * 2 * n)}   # 2 N e per transform: trace LDE, composition, OOD
+           # composed on the n-point sub-coset (DESIGN.md section 4); the point-by-point out-of-domain kernels read every coefficient once
+           "deep": 32.0 * ((C + 2) * n + n + (0 if by_transform else (C + 2) * n)),
+           # 2 N e per transform: trace LDE, composition (one inverse, two forward), the DEEP polynomial's extension, OOD if by transform
+           "ntt_pass": 32.0 * (C * (2 * n + 2 * N) + 3 * 2 * N + (2 * n + 2 * N) + (C * 2 * n if by_transform else 0))}
     hashed = [(nb, N)] + ([(ne, N)] if ne > 1 else []) + [(2, N)]
     trees = [N, N, N] if ne else [N, N]
     fri = 0.0
@@ -624,10 +659,10 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
         nb, ne = air.num_base_columns, air.num_extension_columns
         ncols = nb + ne
         N = n << lb
-        # NTT work inside one proof: trace LDE (iNTT n + NTT N per column), composition (iNTT N, 2 x NTT N),
-        # OOD (NTT n per column), FRI remainder (tiny)
+        # NTT work inside one proof: trace LDE (iNTT n + NTT N per column), composition (iNTT N, 2 x NTT N), the DEEP polynomial's
+        # extension (iNTT n + NTT N), OOD where it is one transform per column (NTT n), FRI remainder (tiny)
         ntt_ops = ncols * (ntt_field_ops(log_n) + ntt_field_ops(log_n + lb)) + 3 * ntt_field_ops(log_n + lb) \
-            + ncols * ntt_field_ops(log_n)
+            + ntt_field_ops(log_n) + ntt_field_ops(log_n + lb) + (ncols * ntt_field_ops(log_n) if ood_by_transform(log_n) else 0)
         algo = stage_algorithmic_bytes(nb, ne, log_n, lb, len(proof.fri_layers))
         stage_ms = {k: v[0] / steps for k, v in prof.items()}
         ntt_ms, ntt_launches = prof["ntt_pass"]
