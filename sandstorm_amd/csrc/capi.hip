@@ -21,6 +21,7 @@
 
 #include "../../include/sandstorm_hip.h"
 #include "fp252.h"
+#include "fp252_host.h"
 #include "kernels.h"
 #include "quotient_gen.h"
 #include "ext_scan.h"
@@ -1084,6 +1085,9 @@ static ss_status ood_eval_sparse(ss_ctx *ctx, const uint64_t *const *d_coeffs, u
                                  const uint32_t *mask_col, const uint32_t *mask_off, uint32_t nmask, const uint64_t z[4], uint64_t *out) {
     const uint64_t n = 1ull << log_n;
     const Fp zf = fp_from_limbs64(z), wn = root_of_unity(log_n);
+    // the host's share - level multipliers of every point, ~300 products each - in 64-bit limbs (fp252_host.h)
+    Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
+    const Fp to_r280 = fp_to_mont(two24);                      // x R -> x 2^280: a product with the image of 2^24, as fl_to_r280
     // ---- the distinct points, column by column
     struct Point { uint32_t col, k, S; Fp x; std::vector<Fp> xpow; Fp *buf[2]; };
     std::vector<Point> pts;
@@ -1093,7 +1097,7 @@ static ss_status ood_eval_sparse(ss_ctx *ctx, const uint64_t *const *d_coeffs, u
         const uint32_t k = mask_off[j] & (uint32_t)(n - 1);
         if (index.emplace(std::make_pair(mask_col[j], k), (uint32_t)pts.size()).second) {
             Point p;
-            p.col = mask_col[j]; p.k = k; p.S = 0; p.x = fp_mul(zf, fp_pow_u64(wn, k)); p.buf[0] = p.buf[1] = nullptr;
+            p.col = mask_col[j]; p.k = k; p.S = 0; p.x = fph_mul(zf, fph_pow_u64(wn, k)); p.buf[0] = p.buf[1] = nullptr;
             of_col[p.col].push_back((uint32_t)pts.size());
             pts.push_back(p);
         }
@@ -1109,11 +1113,11 @@ static ss_status ood_eval_sparse(ss_ctx *ctx, const uint64_t *const *d_coeffs, u
     for (Point &p : pts) {                       // x^(2^j), j < log_n - S: the Horner tree's level multipliers
         p.xpow.resize(log_n - p.S);
         p.xpow[0] = p.x;
-        for (size_t j = 1; j < p.xpow.size(); ++j) p.xpow[j] = fp_sqr(p.xpow[j - 1]);
+        for (size_t j = 1; j < p.xpow.size(); ++j) p.xpow[j] = fph_sqr(p.xpow[j - 1]);
     }
     std::vector<Fp> zsq(log_n);                  // z^(2^i)
     zsq[0] = zf;
-    for (uint32_t i = 1; i < log_n; ++i) zsq[i] = fp_sqr(zsq[i - 1]);
+    for (uint32_t i = 1; i < log_n; ++i) zsq[i] = fph_sqr(zsq[i - 1]);
     // ---- device memory: block outputs, two fold buffers per point, the final values, the descriptors of every launch
     size_t felts = pts.size() + 8;
     std::vector<size_t> y_off(ncols, 0);
@@ -1149,9 +1153,9 @@ static ss_status ood_eval_sparse(ss_ctx *ctx, const uint64_t *const *d_coeffs, u
             const Fp h = zsq[log_n - u - 1], r = root_of_unity(u + 1);
             Fp rj = fp_one();
             for (uint32_t j = 0; j < (1u << u); ++j) {
-                const Fl t = fl_to_r280(fp_mul(h, rj));
+                const Fl t = fl_from_fp(fph_mul(fph_mul(h, rj), to_r280));
                 for (int i = 0; i < 9; ++i) a.tw[(1u << u) - 1 + j][i] = t.l[i];
-                rj = fp_mul(rj, r);
+                rj = fph_mul(rj, r);
             }
         }
         ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
@@ -1179,9 +1183,9 @@ static ss_status ood_eval_sparse(ss_ctx *ctx, const uint64_t *const *d_coeffs, u
                 memset(&fp_, 0, sizeof fp_);
                 fp_.out = last ? d_final + pi : p.buf[round & 1];
                 for (uint32_t t = 0; t < (1u << g); ++t) {       // element t = sum t_i 2^i of a group: weight prod_i (x^(2^(lc-1-i)))^(t_i)
-                    Fp wgt = fp_one();
-                    for (uint32_t i = 0; i < g; ++i) if ((t >> i) & 1u) wgt = fp_mul(wgt, p.xpow[lc - 1 - i]);
-                    const Fl l = fl_to_r280(wgt);
+                    Fp wgt = to_r280;                              // weights are multipliers of the fold: R280 form (fl252.h)
+                    for (uint32_t i = 0; i < g; ++i) if ((t >> i) & 1u) wgt = fph_mul(wgt, p.xpow[lc - 1 - i]);
+                    const Fl l = fl_from_fp(wgt);
                     for (int q = 0; q < 9; ++q) fp_.coef[t][q] = l.l[q];
                 }
                 points.push_back(fp_);

@@ -27,6 +27,7 @@
 #include "fp252.h"
 #include "fl252.h"
 #include "inv252.h"
+#include "fp252_host.h"
 #include "ec252.h"
 #include "kernels.h"
 
@@ -207,23 +208,59 @@ hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
     return hipSuccess;
 }
 
-// pedersen_hash on the host, same windowed tables (used by the Fiat-Shamir coin only)
+// pedersen_hash on the host, same windowed tables (used by the Fiat-Shamir coin only: the CairoVerifierPublicCoin chains ~155 of
+// them per proof through reseed_with_field_elements, crypto/src/public_coin/cairo.rs).  The 8 x 32-bit arithmetic of fp252.h is
+// shaped for the GPU; a CPU core does the same Montgomery product in 4 x 64-bit limbs (fp252_host.h) in a tenth of the time, and
+// safegcd replaces the 251-squaring power: 49 -> 3.8 us per hash.
+namespace {
+struct JacH { H4 x, y, z; };
+const H4 H4_ONE = {{0xffffffffffffffe1ull, 0xffffffffffffffffull, 0xffffffffffffffffull, 0x07fffffffffffdf0ull}};    // 2^256 mod p
+JacH jach_double(const JacH &p) {                                     // a = 1 (the curve's coefficient), as jac_double
+    const H4 xx = h4_sqr(p.x), yy = h4_sqr(p.y), yyyy = h4_sqr(yy), zz = h4_sqr(p.z);
+    H4 s = h4_mul(p.x, yy); s = h4_add(s, s); s = h4_add(s, s);
+    const H4 m = h4_add(h4_add(h4_add(xx, xx), xx), h4_sqr(zz));
+    JacH r;
+    r.x = h4_sub(h4_sqr(m), h4_add(s, s));
+    H4 y8 = h4_add(yyyy, yyyy); y8 = h4_add(y8, y8); y8 = h4_add(y8, y8);
+    r.y = h4_sub(h4_mul(m, h4_sub(s, r.x)), y8);
+    const H4 yz = h4_mul(p.y, p.z);
+    r.z = h4_add(yz, yz);
+    return r;
+}
+JacH jach_add_aff(const JacH &p, const H4 &qx, const H4 &qy) {       // the cases of jac_add_aff (ec252.h), in its order
+    if (h4_is_zero(p.z)) { JacH r; r.x = qx; r.y = qy; r.z = H4_ONE; return r; }
+    const H4 zz = h4_sqr(p.z);
+    const H4 u2 = h4_mul(qx, zz), s2 = h4_mul(qy, h4_mul(zz, p.z));
+    const H4 h = h4_sub(u2, p.x), rr = h4_sub(s2, p.y);
+    if (h4_is_zero(h)) {
+        if (h4_is_zero(rr)) return jach_double(p);
+        JacH o; o.x = H4_ONE; o.y = H4_ONE; o.z = H4{{0, 0, 0, 0}}; return o;
+    }
+    const H4 hh = h4_sqr(h), hhh = h4_mul(hh, h), v = h4_mul(p.x, hh);
+    JacH r;
+    r.x = h4_sub(h4_sub(h4_sqr(rr), hhh), h4_add(v, v));
+    r.y = h4_sub(h4_mul(rr, h4_sub(v, r.x)), h4_mul(p.y, hhh));
+    r.z = h4_mul(p.z, h);
+    return r;
+}
+}  // namespace
 Fp pedersen_hash_host(const Fp &a, const Fp &b) {
     Aff shift;
     const std::vector<Aff> &tab = host_tables(&shift);
-    Jac acc; acc.x = shift.x; acc.y = shift.y; acc.z = fp_one();
+    JacH acc; acc.x = h4_from_fp(shift.x); acc.y = h4_from_fp(shift.y); acc.z = H4_ONE;
     const Fp in[2] = {fp_from_mont(a), fp_from_mont(b)};
     for (int e = 0; e < 2; ++e) {
         const Aff *t = tab.data() + e * PED_PER_INPUT;
         for (int j = 0; j < PED_WINDOWS; ++j) {
             const u32 d = (in[e].v[j >> 2] >> (8 * (j & 3))) & 0xffu;
-            if (d) acc = jac_add_aff(acc, t[j * 255 + (d - 1)]);
+            if (d) { const Aff &q = t[j * 255 + (d - 1)]; acc = jach_add_aff(acc, h4_from_fp(q.x), h4_from_fp(q.y)); }
         }
         const u32 dh = (in[e].v[7] >> 24) & 0xfu;
-        if (dh) acc = jac_add_aff(acc, t[PED_LOW_ENTRIES + (dh - 1)]);
+        if (dh) { const Aff &q = t[PED_LOW_ENTRIES + (dh - 1)]; acc = jach_add_aff(acc, h4_from_fp(q.x), h4_from_fp(q.y)); }
     }
-    const Fp zi = fp_inv(acc.z);
-    return fp_mul(acc.x, fp_sqr(zi));
+    if (h4_is_zero(acc.z)) return fp_zero();                           // unreachable for a hash; fp_inv(0) = 0 gave the same
+    const H4 zi = h4_from_fp(fp_inv_safegcd(h4_to_fp(acc.z)));
+    return h4_to_fp(h4_mul(acc.x, h4_sqr(zi)));
 }
 
 void pedersen_tables_destroy(PedersenTables *t) {       // a context lets go of the shared copy (which stays for the next one)
