@@ -102,4 +102,26 @@ SS_HD JacL jacl_add(const JacL &p, const JacL &q) {
     return r;
 }
 
+// p + q, both affine (4M + 2S), either possibly the point at infinity (flagged: an affine point has no room for it) -> Jacobian.
+// The first round of the lane-split accumulation: 32 table points meet pairwise.
+SS_HD JacL jacl_add_affs(const AffL &p, bool pinf, const AffL &q, bool qinf) {
+    JacL r;
+    if (pinf || qinf) {
+        if (pinf && qinf) { r.x = fl_one(); r.y = fl_one(); r.z = fl_zero(); return r; }
+        const AffL &o = pinf ? q : p;
+        r.x = o.x; r.y = o.y; r.z = fl_one();
+        return r;
+    }
+    const Fl h = fn_sub(q.x, p.x), rr = fn_sub(q.y, p.y);
+    if (fn_is_zero(h)) {
+        if (fn_is_zero(rr)) { JacL d; d.x = p.x; d.y = p.y; d.z = fl_one(); return jacl_double(d); }
+        r.x = fl_one(); r.y = fl_one(); r.z = fl_zero(); return r;
+    }
+    const Fl hh = fn_sqr(h), hhh = fn_mul(hh, h), v = fn_mul(p.x, hh);
+    r.x = fn_sub(fn_sub(fn_sqr(rr), hhh), fn_dbl(v));
+    r.y = fn_sub(fn_mul(rr, fn_sub(v, r.x)), fn_mul(p.y, hhh));
+    r.z = h;
+    return r;
+}
+
 }  // namespace ss

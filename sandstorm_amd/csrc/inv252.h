@@ -43,6 +43,36 @@ SS_HD int32_t sg_divsteps_30(int32_t eta, uint32_t f, uint32_t g, int32_t t[4]) 
     return eta;
 }
 
+// The same 30 division steps, variable time: runs of even g are shifted out at once (count trailing zeros) and, while eta >= 0, up to
+// six low bits of g are cancelled with one multiple of f (w = -g / f mod 2^k; for odd f, f (f^2 - 2) = -1/f mod 64).  The same
+// steps in the same order, so the same matrix and eta as sg_divsteps_30 (tests/test_inv_safegcd.py holds one to the other) in a
+// third of the instructions - for the ONE lane per hash that inverts at the top of a tree, where latency is all there is; lanes of
+// a wave that run it diverge, so the batched inversions of large levels keep the branch-free form.
+SS_HD int32_t sg_divsteps_30_var(int32_t eta, uint32_t f, uint32_t g, int32_t t[4]) {
+    uint32_t u = 1, v = 0, q = 0, r = 1;
+    int i = 30;
+    for (;;) {
+        const int zeros = __builtin_ctz(g | (0xffffffffu << i));      // at most i
+        g >>= zeros; u <<= zeros; v <<= zeros;
+        eta -= zeros; i -= zeros;
+        if (i == 0) break;
+        if (eta < 0) {                                                // g odd, eta < 0: (f, g) <- (g, -f); with the step's own
+            uint32_t tmp;                                             // decrement (counted with the zeros) eta -> -eta - 2 as above
+            eta = -eta - 1;
+            tmp = f; f = g; g = 0u - tmp;
+            tmp = u; u = q; q = 0u - tmp;
+            tmp = v; v = r; r = 0u - tmp;
+        }
+        // eta >= 0: cancel low bits of g - no more than i (done by then) and no more than eta + 1 (the sign flips there)
+        const int limit = (eta + 1) > i ? i : (eta + 1);
+        const uint32_t m = (0xffffffffu >> (32 - limit)) & 63u;
+        const uint32_t w = (g * f * (f * f - 2u)) & m;
+        g += f * w; q += u * w; r += v * w;
+    }
+    t[0] = (int32_t)u; t[1] = (int32_t)v; t[2] = (int32_t)q; t[3] = (int32_t)r;
+    return eta;
+}
+
 // (d, e) <- t (d, e) / 2^30 mod p, keeping d, e in (-2p, p)
 SS_HD void sg_update_de(S30 &d, S30 &e, const int32_t t[4]) {
     const int64_t u = t[0], v = t[1], q = t[2], r = t[3];
@@ -78,7 +108,8 @@ SS_HD void sg_update_fg(S30 &f, S30 &g, const int32_t t[4]) {
     f.v[8] = (int32_t)cf; g.v[8] = (int32_t)cg;
 }
 
-// x^-1 mod p for a canonical integer x < p given as 8 x u32 (NOT Montgomery); 0 -> 0.
+// x^-1 mod p for a canonical integer x < p given as 8 x u32 (NOT Montgomery); 0 -> 0.  VAR: the variable-time division steps.
+template <bool VAR = false>
 SS_HD Fp sg_inverse_canonical(const Fp &x) {
     S30 d, e, f, g;
 #pragma unroll
@@ -96,7 +127,8 @@ SS_HD Fp sg_inverse_canonical(const Fp &x) {
 #pragma unroll 1
     for (int it = 0; it < 32; ++it) {                   // 741 division steps suffice for 256-bit inputs: 25 rounds
         int32_t t[4];
-        eta = sg_divsteps_30(eta, (uint32_t)f.v[0] | ((uint32_t)f.v[1] << 30), (uint32_t)g.v[0] | ((uint32_t)g.v[1] << 30), t);
+        const uint32_t f0 = (uint32_t)f.v[0] | ((uint32_t)f.v[1] << 30), g0 = (uint32_t)g.v[0] | ((uint32_t)g.v[1] << 30);
+        eta = VAR ? sg_divsteps_30_var(eta, f0, g0, t) : sg_divsteps_30(eta, f0, g0, t);
         sg_update_de(d, e, t);
         sg_update_fg(f, g, t);
         int32_t nz = 0;
@@ -160,11 +192,12 @@ SS_HD Fp sg_inverse_canonical(const Fp &x) {
 
 // Montgomery in, Montgomery out: a = x R  ->  x^-1 R   (R = 2^256).  sg gives (x R)^-1 = x^-1 R^-1; times R^2 by
 // one Montgomery multiplication with R^3.
+template <bool VAR = false>
 SS_HD Fp fp_inv_safegcd(const Fp &a_mont) {
     Fp r3;
     r3.v[0] = 0x406df18eu; r3.v[1] = 0xcc7177d1u; r3.v[2] = 0x77ffcc06u; r3.v[3] = 0x75457066u;
     r3.v[4] = 0x36300018u; r3.v[5] = 0xf47d84f8u; r3.v[6] = 0x873c0a6du; r3.v[7] = 0x038e5f79u;
-    return fp_mul(sg_inverse_canonical(a_mont), r3);
+    return fp_mul(sg_inverse_canonical<VAR>(a_mont), r3);
 }
 
 }  // namespace ss

@@ -22,6 +22,7 @@
 // temporary and a second kernel inverts Z in per-lane chunks with Montgomery's trick
 // (5 multiplications per hash + one inversion per chunk).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 #include "fp252.h"
@@ -511,6 +512,56 @@ __global__ __launch_bounds__(64) void pedersen_acc_pairs_split_kernel(const Aff 
 }
 static constexpr uint64_t PED_SPLIT_MAX = 4096;             // hashes per level at or below which lanes are split
 
+// The same level in ONE launch, shaped for latency (the top dozen levels of every tree are a chain of launches that each wait
+// for the one before: 32 lanes per hash, most of the chip idle):
+//   - the table points are affine, so the first butterfly round is an affine + affine addition (4M + 2S against 12M + 4S);
+//   - with fewer than 16 windows per input a lane is idle anyway: one of them carries the shift point P0 into the butterfly
+//     instead of a seventh, dependent addition at the end;
+//   - lane 0 of the hash inverts its own Z - variable-time division steps (inv252.h): nothing shares the wave's time with it -
+//     and writes the digest: no second launch, no round trip of (X, Z) through memory.
+template <int W>
+__global__ __launch_bounds__(64) void pedersen_pairs_small_kernel(const Aff *__restrict__ table, uint64_t per_input, Aff shift,
+                                                                  const uint8_t *__restrict__ in, uint64_t count, uint8_t *__restrict__ out) {
+    constexpr uint32_t span = (1u << W) - 1u, nwin = (PED_BITS + W - 1) / W;
+    static_assert(nwin <= (uint32_t)PED_MAX_WINDOWS, "one lane per window: at most 16 windows per input");
+    constexpr bool shift_in_lane = nwin < 16;
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t k = t >> 5;
+    if (k >= count) return;                                 // whole 32-lane groups leave together
+    const uint32_t sub = (uint32_t)t & 31u, e = sub >> 4, w = sub & 15u;
+    Fp c = be_bytes_to_canon(in + 64 * k + 32 * e);
+    u32 d = 0;                                              // this lane's digit: window w of the scalar (lanes w >= nwin have none)
+#pragma unroll 1
+    for (uint32_t q = 0; q <= w && q < nwin; ++q) { const u32 dq = ped_next_digit<W>(c); if (q == w) d = dq; }
+    AffL pt; pt.x = fl_one(); pt.y = fl_one();
+    int inf = 1;
+    if (d) { pt = load_affl(table + (size_t)e * per_input + (size_t)w * span + (d - 1)); inf = 0; }
+    if (shift_in_lane && sub == 15u) { pt.x = fl_from_fp(shift.x); pt.y = fl_from_fp(shift.y); inf = 0; }
+    JacL acc;
+    {
+        AffL o; o.x = fl_shfl_xor(pt.x, 16); o.y = fl_shfl_xor(pt.y, 16);
+        const int oinf = __shfl_xor(inf, 16, 64);
+        acc = jacl_add_affs(pt, inf != 0, o, oinf != 0);
+    }
+#pragma unroll 1
+    for (int m = 8; m >= 1; m >>= 1) {
+        JacL o; o.x = fl_shfl_xor(acc.x, m); o.y = fl_shfl_xor(acc.y, m); o.z = fl_shfl_xor(acc.z, m);
+        acc = jacl_add(acc, o);
+    }
+    if (sub != 0) return;
+    if (!shift_in_lane) {
+        AffL sh; sh.x = fl_from_fp(shift.x); sh.y = fl_from_fp(shift.y);
+        acc = jacl_add_aff(acc, sh);
+    }
+    Fp x = fp_zero();                                       // a point at infinity (unreachable for a hash) -> 0, as pedersen_finish_kernel
+    const Fp z = fl_to_fp(acc.z);
+    if (!fp_is_zero(z)) {
+        const Fl zi = fl_from_fp(fp_inv_safegcd<true>(z));
+        x = fl_to_fp(fn_mul(acc.x, fn_sqr(zi)));            // acc.x: normalised and < 2p from either addition
+    }
+    canon_to_be_bytes(fp_from_mont(x), out + 32 * k);
+}
+
 // ---- phase 2: x = X / Z^2, `chunk` hashes per lane (k = j * lanes + lane), one inversion per lane ----
 // Montgomery's trick with the prefix products in tmp[2 count ..).  A point at infinity (Z = 0:
 // unreachable for a hash, kept for totality) yields x = 0 as the per-hash formula did.
@@ -584,6 +635,12 @@ hipError_t launch_pedersen_felts(hipStream_t st, const PedersenTables *t, const 
 hipError_t launch_pedersen_pairs(hipStream_t st, const PedersenTables *t, const uint8_t *in, uint64_t count,
                                  uint8_t *out, Fp *tmp) {
     if (count == 0) return hipSuccess;
+    static const bool two_launches = getenv("SS_PED_SMALL_TWO_LAUNCHES") != nullptr;        // A/B: round 2's split kernel + finish
+    if (count <= PED_SPLIT_MAX && !two_launches) {
+        PED_DISPATCH(t->W, hipLaunchKernelGGL(pedersen_pairs_small_kernel<W>, dim3((uint32_t)((count * 32 + 63) / 64)), dim3(64), 0, st,
+                                              t->d_table, t->per_input, t->shift, in, count, out));
+        return hipGetLastError();
+    }
     if (count <= PED_SPLIT_MAX) {
         PED_DISPATCH(t->W, hipLaunchKernelGGL(pedersen_acc_pairs_split_kernel<W>, dim3((uint32_t)((count * 32 + 63) / 64)), dim3(64), 0, st,
                                               t->d_table, t->per_input, t->shift, in, count, tmp));

@@ -71,6 +71,17 @@ int main() {
         if (!fp_eq(fl_to_fp(back.x), t.x) || !fp_eq(fl_to_fp(back.y), t.y)) { printf("from-infinity mismatch %d\n", i); return 1; }
         checked += 3;
     }
+    // affine + affine (the first round of the lane-split accumulation) against the plain mixed addition: generic pairs, q + q, q - q,
+    // and the point at infinity on either or both sides
+    for (int i = 0; i < 400; ++i) {
+        const Aff a = pool[splitmix() % pool.size()], b = i % 8 == 0 ? a : i % 8 == 1 ? Aff{a.x, fp_neg(a.y)} : pool[splitmix() % pool.size()];
+        const JacL got = jacl_add_affs(limb(a), false, limb(b), false);
+        const Jac want = jac_add_aff(lift(a), b);
+        if (fp_is_zero(want.z) ? !fp_is_zero(fl_to_fp(got.z)) : !same(got, want)) { printf("affine + affine mismatch %d\n", i); return 1; }
+        const JacL l = jacl_add_affs(limb(a), true, limb(b), false), r = jacl_add_affs(limb(a), false, limb(b), true), n = jacl_add_affs(limb(a), true, limb(b), true);
+        if (!same(l, lift(b)) || !same(r, lift(a)) || !fp_is_zero(fl_to_fp(n.z))) { printf("affine + affine with infinity: mismatch %d\n", i); return 1; }
+        checked += 4;
+    }
     // the multiplier at the limb bounds the lazy formulas reach (fl_sub_c<2,1> output: limbs up to 2^29 + 2^25; the
     // lazy x3: limbs up to 2^30 + 2^27), every limb at its maximum and random patterns near it
     for (int it = 0; it < 2000; ++it) {
