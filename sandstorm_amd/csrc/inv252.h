@@ -108,34 +108,8 @@ SS_HD void sg_update_fg(S30 &f, S30 &g, const int32_t t[4]) {
     f.v[8] = (int32_t)cf; g.v[8] = (int32_t)cg;
 }
 
-// x^-1 mod p for a canonical integer x < p given as 8 x u32 (NOT Montgomery); 0 -> 0.  VAR: the variable-time division steps.
-template <bool VAR = false>
-SS_HD Fp sg_inverse_canonical(const Fp &x) {
-    S30 d, e, f, g;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { d.v[i] = 0; e.v[i] = 0; f.v[i] = sg_modulus(i); }
-    e.v[0] = 1;
-    // 8 x 32 -> 9 x 30
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int bit = 30 * i, w = bit >> 5, s = bit & 31;
-        uint64_t two = x.v[w];
-        if (w + 1 < 8) two |= (uint64_t)x.v[w + 1] << 32;
-        g.v[i] = (int32_t)((uint32_t)(two >> s) & (uint32_t)SG_M30);
-    }
-    int32_t eta = -1;
-#pragma unroll 1
-    for (int it = 0; it < 32; ++it) {                   // 741 division steps suffice for 256-bit inputs: 25 rounds
-        int32_t t[4];
-        const uint32_t f0 = (uint32_t)f.v[0] | ((uint32_t)f.v[1] << 30), g0 = (uint32_t)g.v[0] | ((uint32_t)g.v[1] << 30);
-        eta = VAR ? sg_divsteps_30_var(eta, f0, g0, t) : sg_divsteps_30(eta, f0, g0, t);
-        sg_update_de(d, e, t);
-        sg_update_fg(f, g, t);
-        int32_t nz = 0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) nz |= g.v[i];
-        if (nz == 0) break;
-    }
+// the end of an inversion: d in (-2p, p) as signed limbs, f = +-1 (fneg: the inverse is -d) -> the canonical 8 x u32
+SS_HD Fp sg_finish(const S30 &d, bool fneg) {
     // d in (-2p, p) as signed limbs -> 9 x 32-bit two's complement
     uint32_t w[9];
     {
@@ -157,7 +131,6 @@ SS_HD Fp sg_inverse_canonical(const Fp &x) {
         // remaining words: sign extension
         for (; wi < 9; ++wi) { w[wi] = (uint32_t)acc; acc >>= 32; }
     }
-    const bool fneg = f.v[8] < 0;                       // f = -1: the inverse is -d
     if (fneg) {                                         // two's complement negate (288 bits)
         uint64_t c = 1;
 #pragma unroll
@@ -188,6 +161,37 @@ SS_HD Fp sg_inverse_canonical(const Fp &x) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = w[i];
     return r;
+}
+
+// x^-1 mod p for a canonical integer x < p given as 8 x u32 (NOT Montgomery); 0 -> 0.  VAR: the variable-time division steps.
+template <bool VAR = false>
+SS_HD Fp sg_inverse_canonical(const Fp &x) {
+    S30 d, e, f, g;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { d.v[i] = 0; e.v[i] = 0; f.v[i] = sg_modulus(i); }
+    e.v[0] = 1;
+    // 8 x 32 -> 9 x 30
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 30 * i, w = bit >> 5, s = bit & 31;
+        uint64_t two = x.v[w];
+        if (w + 1 < 8) two |= (uint64_t)x.v[w + 1] << 32;
+        g.v[i] = (int32_t)((uint32_t)(two >> s) & (uint32_t)SG_M30);
+    }
+    int32_t eta = -1;
+#pragma unroll 1
+    for (int it = 0; it < 32; ++it) {                   // 741 division steps suffice for 256-bit inputs: 25 rounds
+        int32_t t[4];
+        const uint32_t f0 = (uint32_t)f.v[0] | ((uint32_t)f.v[1] << 30), g0 = (uint32_t)g.v[0] | ((uint32_t)g.v[1] << 30);
+        eta = VAR ? sg_divsteps_30_var(eta, f0, g0, t) : sg_divsteps_30(eta, f0, g0, t);
+        sg_update_de(d, e, t);
+        sg_update_fg(f, g, t);
+        int32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) nz |= g.v[i];
+        if (nz == 0) break;
+    }
+    return sg_finish(d, f.v[8] < 0);                   // f = -1: the inverse is -d
 }
 
 // Montgomery in, Montgomery out: a = x R  ->  x^-1 R   (R = 2^256).  sg gives (x R)^-1 = x^-1 R^-1; times R^2 by

@@ -519,6 +519,129 @@ static constexpr uint64_t PED_SPLIT_MAX = 4096;             // hashes per level 
 //     instead of a seventh, dependent addition at the end;
 //   - lane 0 of the hash inverts its own Z - variable-time division steps (inv252.h): nothing shares the wave's time with it -
 //     and writes the digest: no second launch, no round trip of (X, Z) through memory.
+// ---- four lanes, one value: the lanes of a QUAD (lanes 4j .. 4j + 3) read each other's registers with DPP quad permutes - full
+// rate, no LDS.  The butterfly below reduces over lane bits 0 and 1 first, so from its second round on the four lanes of a quad
+// hold the same two points, and at its end the same sum: work that is a few independent multiplications deep is dealt out to
+// the quad by ROLE (= lane & 3) and read back.
+template <int K> __device__ __forceinline__ u32 ped_quad(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ u32 ped_quad_perm(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+template <int K> __device__ __forceinline__ Fl fl_quad(const Fl &mine) {      // role K's value
+    Fl r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = ped_quad<K>(mine.l[i]);
+    return r;
+}
+// role's operand of a level, picked with masks: a ternary over the four values invites the compiler to pick an ADDRESS instead - the
+// values parked in scratch, a branchy pointer select and a scratch load per limb (seen in the first version's assembly)
+__device__ __forceinline__ Fl ped_by_role(uint32_t role, const Fl &a0, const Fl &a1, const Fl &a2, const Fl &a3) {
+    const u32 m0 = role == 0u ? ~0u : 0u, m1 = role == 1u ? ~0u : 0u, m2 = role == 2u ? ~0u : 0u, m3 = role == 3u ? ~0u : 0u;
+    Fl r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = (a0.l[i] & m0) | (a1.l[i] & m1) | (a2.l[i] & m2) | (a3.l[i] & m3);
+    return r;
+}
+// A Jacobian addition over a quad: its 16 multiplications are five levels of at most four independent ones, so every lane does
+// ONE multiplication per level - its role's.  Five dependent multiplications instead of sixteen; the lanes agree on (p, q) in this
+// order and all of them end with the same (x3, y3, z3).
+__device__ __forceinline__ JacL jacl_add_quad(const JacL &p, const JacL &q, uint32_t role) {
+    Fl m = fn_mul(ped_by_role(role, p.z, q.z, p.z, p.z), ped_by_role(role, p.z, q.z, q.z, p.z));
+    const Fl z1z1 = fl_quad<0>(m), z2z2 = fl_quad<1>(m), z1z2 = fl_quad<2>(m);
+    m = fn_mul(ped_by_role(role, p.x, q.x, q.z, p.z), ped_by_role(role, z2z2, z1z1, z2z2, z1z1));
+    const Fl u1 = fl_quad<0>(m), u2 = fl_quad<1>(m), t1 = fl_quad<2>(m), t2 = fl_quad<3>(m);
+    const Fl h = fn_sub(u2, u1);
+    m = fn_mul(ped_by_role(role, p.y, q.y, h, z1z2), ped_by_role(role, t1, t2, h, h));
+    const Fl s1 = fl_quad<0>(m), s2 = fl_quad<1>(m), hh = fl_quad<2>(m), z3 = fl_quad<3>(m);
+    const Fl rr = fn_sub(s2, s1);
+    m = fn_mul(ped_by_role(role, h, u1, rr, rr), ped_by_role(role, hh, hh, rr, rr));
+    const Fl hhh = fl_quad<0>(m), v = fl_quad<1>(m), rr2 = fl_quad<2>(m);
+    JacL r;
+    r.x = fn_sub(fn_sub(rr2, hhh), fn_dbl(v));
+    const Fl vx = fn_sub(v, r.x);
+    m = fn_mul(ped_by_role(role, rr, s1, rr, s1), ped_by_role(role, vx, hhh, vx, hhh));
+    r.y = fn_sub(fl_quad<0>(m), fl_quad<1>(m));
+    r.z = z3;
+    // the exceptional cases, as jacl_add decides them (every lane of the quad sees the same p and q, so they agree)
+    if (__builtin_expect(fn_is_zero(p.z) || fn_is_zero(q.z) || fn_is_zero(h), 0)) {
+        if (fn_is_zero(p.z)) return q;
+        if (fn_is_zero(q.z)) return p;
+        if (fn_is_zero(rr)) return jacl_double(p);
+        JacL o; o.x = fl_one(); o.y = fl_one(); o.z = fl_zero(); return o;
+    }
+    return r;
+}
+
+// safegcd (inv252.h) over a quad.  An outer iteration is 30 division steps on the low words - serial, every lane does them - and
+// the update of the four rows d, e, f, g by the steps' matrix: 72 multiply-adds that are a third of the inversion on one lane.
+// Here every lane keeps ONE pair of rows - roles 0, 1: (d, e); roles 2, 3: (f, g) - updates ONE row (role 0: d, 1: e, 2: f, 3: g)
+// and reads its pair's other row back.  20 iterations = 600 steps cover every input (590 suffice, inv252.h); a lane whose g is
+// zero idles through the rest: the quad permutes sit outside every branch.  x canonical (any integer < p) -> x^-1 mod p, 0 -> 0.
+__device__ __forceinline__ Fp sg_inverse_quad(const Fp &x, uint32_t role) {
+    const bool de = role < 2u, second = (role & 1u) != 0u;
+    S30 A, B;                                               // (d, e) = (0, 1) or (f, g) = (p, x)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 30 * i, w = bit >> 5, sft = bit & 31;
+        uint64_t two = x.v[w];
+        if (w + 1 < 8) two |= (uint64_t)x.v[w + 1] << 32;
+        const int32_t gi = (int32_t)((uint32_t)(two >> sft) & (uint32_t)SG_M30);
+        A.v[i] = de ? 0 : sg_modulus(i);
+        B.v[i] = de ? (i == 0 ? 1 : 0) : gi;
+    }
+    int32_t eta = -1;
+    u32 busy = 1;
+#pragma unroll 1
+    for (int it = 0; it < 20; ++it) {
+        // the low words of (f, g) live on roles 2 and 3
+        const u32 f0 = ped_quad<2>((u32)A.v[0] | ((u32)A.v[1] << 30)), g0 = ped_quad<2>((u32)B.v[0] | ((u32)B.v[1] << 30));
+        S30 row = second ? B : A;                           // an idle lane hands its row back unchanged
+        if (busy) {
+            int32_t t[4];
+            eta = sg_divsteps_30_var(eta, f0, g0, t);
+            const int64_t c0 = second ? t[2] : t[0], c1 = second ? t[3] : t[1];
+            // rows of (d, e): + m p with m chosen to clear the low 30 bits and keep the row in (-2p, p) (sg_update_de); rows of
+            // (f, g) divide exactly: m = 0
+            int32_t md = 0;
+            int64_t c = c0 * A.v[0] + c1 * B.v[0];
+            if (de) {
+                const int32_t sa = A.v[8] >> 31, sb = B.v[8] >> 31;
+                md = ((int32_t)c0 & sa) + ((int32_t)c1 & sb);
+                md -= (int32_t)(((uint32_t)c + (uint32_t)md) & (uint32_t)SG_M30);
+                c += (int64_t)sg_modulus(0) * md;
+            }
+            c >>= 30;
+#pragma unroll
+            for (int i = 1; i < 9; ++i) {
+                c += c0 * A.v[i] + c1 * B.v[i];
+                if (sg_modulus(i)) c += (int64_t)sg_modulus(i) * md;
+                row.v[i - 1] = (int32_t)c & SG_M30; c >>= 30;
+            }
+            row.v[8] = (int32_t)c;
+        }
+        int32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            A.v[i] = (int32_t)ped_quad_perm<0xA0>((u32)row.v[i]);       // quad_perm [0, 0, 2, 2]: the pair's first row
+            B.v[i] = (int32_t)ped_quad_perm<0xF5>((u32)row.v[i]);       // quad_perm [1, 1, 3, 3]: the pair's second row
+            nz |= B.v[i];
+        }
+        busy = ped_quad<2>((u32)(nz != 0)) & busy;          // g (roles 2, 3) decides for the quad
+    }
+    // d from role 0, the sign of f from role 2
+    S30 d;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d.v[i] = (int32_t)ped_quad<0>((u32)A.v[i]);
+    const bool fneg = (int32_t)ped_quad<2>((u32)A.v[8]) < 0;
+    return sg_finish(d, fneg);
+}
+
+// The same level in ONE launch, shaped for latency (the top dozen levels of every tree are a chain of launches that each wait
+// for the one before: 32 lanes per hash, most of the chip idle):
+//   - the table points are affine, so the first butterfly round is an affine + affine addition (4M + 2S against 12M + 4S);
+//   - with fewer than 16 windows per input a lane is idle anyway: one of them carries the shift point P0 into the butterfly
+//     instead of a seventh, dependent addition at the end;
+//   - the four Jacobian rounds and the inversion of Z run over quads (above): 5 dependent multiplications per addition instead
+//     of 16, a quarter of the inversion's matrix updates per lane;
+//   - lane 0 of the hash writes the digest: no second launch, no round trip of (X, Z) through memory.
 template <int W>
 __global__ __launch_bounds__(64) void pedersen_pairs_small_kernel(const Aff *__restrict__ table, uint64_t per_input, Aff shift,
                                                                   const uint8_t *__restrict__ in, uint64_t count, uint8_t *__restrict__ out) {
@@ -528,7 +651,7 @@ __global__ __launch_bounds__(64) void pedersen_pairs_small_kernel(const Aff *__r
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t k = t >> 5;
     if (k >= count) return;                                 // whole 32-lane groups leave together
-    const uint32_t sub = (uint32_t)t & 31u, e = sub >> 4, w = sub & 15u;
+    const uint32_t sub = (uint32_t)t & 31u, e = sub >> 4, w = sub & 15u, role = sub & 3u;
     Fp c = be_bytes_to_canon(in + 64 * k + 32 * e);
     u32 d = 0;                                              // this lane's digit: window w of the scalar (lanes w >= nwin have none)
 #pragma unroll 1
@@ -539,27 +662,45 @@ __global__ __launch_bounds__(64) void pedersen_pairs_small_kernel(const Aff *__r
     if (shift_in_lane && sub == 15u) { pt.x = fl_from_fp(shift.x); pt.y = fl_from_fp(shift.y); inf = 0; }
     JacL acc;
     {
-        AffL o; o.x = fl_shfl_xor(pt.x, 16); o.y = fl_shfl_xor(pt.y, 16);
-        const int oinf = __shfl_xor(inf, 16, 64);
-        acc = jacl_add_affs(pt, inf != 0, o, oinf != 0);
+        AffL o; o.x = fl_shfl_xor(pt.x, 1); o.y = fl_shfl_xor(pt.y, 1);
+        const int oinf = __shfl_xor(inf, 1, 64);
+        // both lanes of a pair add in the same order (the even lane's point first): the same representative on both
+        const u32 up = (sub & 1u) ? ~0u : 0u;
+        AffL a, b;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const u32 dx = (o.x.l[i] ^ pt.x.l[i]) & up, dy = (o.y.l[i] ^ pt.y.l[i]) & up;
+            a.x.l[i] = pt.x.l[i] ^ dx; a.y.l[i] = pt.y.l[i] ^ dy;
+            b.x.l[i] = o.x.l[i] ^ dx; b.y.l[i] = o.y.l[i] ^ dy;
+        }
+        const int di = (oinf ^ inf) & (int)up;
+        acc = jacl_add_affs(a, (inf ^ di) != 0, b, (oinf ^ di) != 0);
     }
 #pragma unroll 1
-    for (int m = 8; m >= 1; m >>= 1) {
-        JacL o; o.x = fl_shfl_xor(acc.x, m); o.y = fl_shfl_xor(acc.y, m); o.z = fl_shfl_xor(acc.z, m);
-        acc = jacl_add(acc, o);
+    for (uint32_t m = 2; m <= 16; m <<= 1) {
+        JacL o; o.x = fl_shfl_xor(acc.x, (int)m); o.y = fl_shfl_xor(acc.y, (int)m); o.z = fl_shfl_xor(acc.z, (int)m);
+        const u32 up = (sub & m) ? ~0u : 0u;                  // the lanes of a quad agree on the order: the lower half's sum first
+        JacL a, b;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const u32 dx = (o.x.l[i] ^ acc.x.l[i]) & up, dy = (o.y.l[i] ^ acc.y.l[i]) & up, dz = (o.z.l[i] ^ acc.z.l[i]) & up;
+            a.x.l[i] = acc.x.l[i] ^ dx; a.y.l[i] = acc.y.l[i] ^ dy; a.z.l[i] = acc.z.l[i] ^ dz;
+            b.x.l[i] = o.x.l[i] ^ dx; b.y.l[i] = o.y.l[i] ^ dy; b.z.l[i] = o.z.l[i] ^ dz;
+        }
+        acc = jacl_add_quad(a, b, role);                     // (quad permutes inside: one call, every lane of the wave in it)
     }
-    if (sub != 0) return;
     if (!shift_in_lane) {
         AffL sh; sh.x = fl_from_fp(shift.x); sh.y = fl_from_fp(shift.y);
         acc = jacl_add_aff(acc, sh);
     }
-    Fp x = fp_zero();                                       // a point at infinity (unreachable for a hash) -> 0, as pedersen_finish_kernel
-    const Fp z = fl_to_fp(acc.z);
-    if (!fp_is_zero(z)) {
-        const Fl zi = fl_from_fp(fp_inv_safegcd<true>(z));
-        x = fl_to_fp(fn_mul(acc.x, fn_sqr(zi)));            // acc.x: normalised and < 2p from either addition
-    }
-    canon_to_be_bytes(fp_from_mont(x), out + 32 * k);
+    // x = X / Z^2 on every lane of the hash (they hold the same sum); Z = 0 - a point at infinity, unreachable for a hash - inverts
+    // to 0 and gives x = 0, as pedersen_finish_kernel
+    Fp r3;                                                  // (z R)^-1 -> z^-1 R: a Montgomery product with R^3 (fp_inv_safegcd)
+    r3.v[0] = 0x406df18eu; r3.v[1] = 0xcc7177d1u; r3.v[2] = 0x77ffcc06u; r3.v[3] = 0x75457066u;
+    r3.v[4] = 0x36300018u; r3.v[5] = 0xf47d84f8u; r3.v[6] = 0x873c0a6du; r3.v[7] = 0x038e5f79u;
+    const Fl zi = fl_from_fp(fp_mul(sg_inverse_quad(fl_to_fp(acc.z), role), r3));
+    const Fp x = fl_to_fp(fn_mul(acc.x, fn_sqr(zi)));        // acc.x: normalised and < 2p from either addition
+    if (sub == 0u) canon_to_be_bytes(fp_from_mont(x), out + 32 * k);
 }
 
 // ---- phase 2: x = X / Z^2, `chunk` hashes per lane (k = j * lanes + lane), one inversion per lane ----

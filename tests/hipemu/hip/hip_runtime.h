@@ -49,6 +49,9 @@ void hipemu_barrier();                                       // yield to the wor
 #define __syncthreads() hipemu_barrier()
 int hipemu_shfl_xor(int v, int mask, int width);
 #define __shfl_xor(v, mask, width) hipemu_shfl_xor((v), (mask), (width))
+// DPP quad permutes (ctrl < 0x100: lane 4j + i reads lane 4j + ((ctrl >> 2i) & 3)) - the only DPP form the kernels use
+#define __builtin_amdgcn_mov_dpp(v, ctrl, row_mask, bank_mask, bound_ctrl) \
+    hipemu_shfl_xor((v), (int)((threadIdx.x & 3u) ^ ((((unsigned)(ctrl)) >> (2u * (threadIdx.x & 3u))) & 3u)), 64)
 
 static inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) {      // workgroups may run on several OS threads
     unsigned long long o = __atomic_load_n(p, __ATOMIC_RELAXED);
