@@ -470,47 +470,16 @@ __global__ __launch_bounds__(64) void pedersen_acc_pairs_kernel(const Aff *__res
     ped_jacobian<W>(ca, cb, table, per_input, shift, xz + k, xz + count + k);
 }
 
-// Small levels (the top of every tree: a few thousand hashes or fewer, one level after the
-// other) are latency bound: 32 dependent mixed additions per hash with most of the chip idle.
-// There, 32 lanes share one hash: lane (input e, window w) fetches its window's table point, the
-// 32 partial results meet in a 5-step butterfly of full Jacobian additions (cross-lane
-// shuffles), and lane 0 adds the shift point: 6 dependent additions instead of 32.
+// Small levels (the top of every tree: a few thousand hashes or fewer, one level after the other) are latency bound: 22 - 32
+// dependent mixed additions per hash with most of the chip idle.  There, 32 lanes share one hash (pedersen_pairs_small_kernel below).
 __device__ __forceinline__ Fl fl_shfl_xor(const Fl &a, int mask) {
     Fl r;
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.l[i] = (u32)__shfl_xor((int)a.l[i], mask, 64);
     return r;
 }
-template <int W>
-__global__ __launch_bounds__(64) void pedersen_acc_pairs_split_kernel(const Aff *__restrict__ table, uint64_t per_input, Aff shift,
-                                                                      const uint8_t *__restrict__ in, uint64_t count,
-                                                                      Fp *__restrict__ xz) {
-    constexpr uint32_t span = (1u << W) - 1u, nwin = (PED_BITS + W - 1) / W;
-    static_assert(nwin <= (uint32_t)PED_MAX_WINDOWS, "one lane per window: at most 16 windows per input");
-    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    const uint64_t k = t >> 5;
-    if (k >= count) return;                                 // whole 32-lane groups leave together
-    const uint32_t sub = (uint32_t)t & 31u, e = sub >> 4, w = sub & 15u;
-    Fp c = be_bytes_to_canon(in + 64 * k + 32 * e);
-    u32 d = 0;                                              // this lane's digit: window w of the scalar (lanes w >= nwin idle)
-#pragma unroll 1
-    for (uint32_t q = 0; q <= w && q < nwin; ++q) { const u32 dq = ped_next_digit<W>(c); if (q == w) d = dq; }
-    const Aff *tab = table + (size_t)e * per_input + (size_t)(w < nwin ? w : 0u) * span;
-    JacL pt; pt.x = fl_one(); pt.y = fl_one(); pt.z = fl_zero();
-    if (d) { const AffL q = load_affl(tab + (d - 1)); pt.x = q.x; pt.y = q.y; pt.z = fl_one(); }
-#pragma unroll 1
-    for (int m = 16; m >= 1; m >>= 1) {
-        JacL o; o.x = fl_shfl_xor(pt.x, m); o.y = fl_shfl_xor(pt.y, m); o.z = fl_shfl_xor(pt.z, m);
-        pt = jacl_add(pt, o);
-    }
-    if (sub == 0) {
-        AffL sh; sh.x = fl_from_fp(shift.x); sh.y = fl_from_fp(shift.y);
-        pt = jacl_add_aff(pt, sh);
-        store_felt(xz + k, fl_pack(pt.x));
-        store_felt(xz + count + k, fl_pack(pt.z));
-    }
-}
-static constexpr uint64_t PED_SPLIT_MAX = 4096;             // hashes per level at or below which lanes are split
+static constexpr uint64_t PED_SPLIT_MAX = 8192;             // hashes per level at or below which 32 lanes share a hash (measured: 2048 .. 32768,
+                                                            // profiles/r03_pedersen_small_levels.txt)
 
 // The same level in ONE launch, shaped for latency (the top dozen levels of every tree are a chain of launches that each wait
 // for the one before: 32 lanes per hash, most of the chip idle):
@@ -776,19 +745,14 @@ hipError_t launch_pedersen_felts(hipStream_t st, const PedersenTables *t, const 
 hipError_t launch_pedersen_pairs(hipStream_t st, const PedersenTables *t, const uint8_t *in, uint64_t count,
                                  uint8_t *out, Fp *tmp) {
     if (count == 0) return hipSuccess;
-    static const bool two_launches = getenv("SS_PED_SMALL_TWO_LAUNCHES") != nullptr;        // A/B: round 2's split kernel + finish
-    if (count <= PED_SPLIT_MAX && !two_launches) {
+    static const uint64_t small_max = getenv("SS_PED_SMALL_MAX") ? strtoull(getenv("SS_PED_SMALL_MAX"), nullptr, 10) : PED_SPLIT_MAX;   // A/B
+    if (count <= small_max) {
         PED_DISPATCH(t->W, hipLaunchKernelGGL(pedersen_pairs_small_kernel<W>, dim3((uint32_t)((count * 32 + 63) / 64)), dim3(64), 0, st,
                                               t->d_table, t->per_input, t->shift, in, count, out));
         return hipGetLastError();
     }
-    if (count <= PED_SPLIT_MAX) {
-        PED_DISPATCH(t->W, hipLaunchKernelGGL(pedersen_acc_pairs_split_kernel<W>, dim3((uint32_t)((count * 32 + 63) / 64)), dim3(64), 0, st,
-                                              t->d_table, t->per_input, t->shift, in, count, tmp));
-    } else {
-        PED_DISPATCH(t->W, hipLaunchKernelGGL(pedersen_acc_pairs_kernel<W>, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table,
-                                              t->per_input, t->shift, in, count, tmp));
-    }
+    PED_DISPATCH(t->W, hipLaunchKernelGGL(pedersen_acc_pairs_kernel<W>, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, t->d_table,
+                                          t->per_input, t->shift, in, count, tmp));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_finish(st, tmp, count, nullptr, out);
