@@ -536,8 +536,8 @@ def timed_steps(step, steps, warmup, barrier, all_max):
 
 
 def ood_by_transform(log_n):
-    """csrc/capi.hip ss_ood_eval: one coset transform per column below 2^22 coefficients (or SS_OOD_TRANSFORM=1), point by point above"""
-    return os.environ.get("SS_OOD_TRANSFORM") == "1" or log_n < int(os.environ.get("SS_OOD_SPARSE_MIN_LOG", "22"))
+    """csrc/capi.hip ss_ood_eval: one coset transform per column below 2^20 coefficients (or SS_OOD_TRANSFORM=1), point by point above"""
+    return os.environ.get("SS_OOD_TRANSFORM") == "1" or log_n < int(os.environ.get("SS_OOD_SPARSE_MIN_LOG", "20"))
 
 
 def stage_algorithmic_bytes(nb, ne, log_n, lb, fri_layers, fold=8):

@@ -1037,10 +1037,11 @@ ss_status ss_ood_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t nco
         if (mask_col[j] >= ncols) return fail(SS_ERR_INVALID, "mask cell %u names column %u", j, mask_col[j]);
     // A mask names few points per column (269 cells over 10 columns for starknet): large columns are evaluated point by point
     // (deep.hip: blocks transformed in registers + fused Horner trees), a fifth of the arithmetic of the transforms below - from
-    // 2^22 coefficients on, where that outweighs the host's share of the point-by-point path (the level multipliers of every
-    // point: ~2 ms of host arithmetic per call, more than ten transforms of 2^18 points take).  SS_OOD_SPARSE_MIN_LOG moves the
-    // threshold (the parity tests run the point-by-point path from 2^12), SS_OOD_TRANSFORM=1 keeps the transforms.
-    uint32_t sparse_min_log = 22;
+    // 2^20 coefficients on: below, the descriptors and level multipliers of every point (host work, ~0.3 ms per call in 64-bit
+    // limbs) and the fold launches cost what ten small transforms do (measured at 2^18 and 2^20, gpurun_out/r03_call16).
+    // SS_OOD_SPARSE_MIN_LOG moves the threshold (the parity tests run the point-by-point path from 2^12), SS_OOD_TRANSFORM=1
+    // keeps the transforms.
+    uint32_t sparse_min_log = 20;
     if (const char *e = getenv("SS_OOD_SPARSE_MIN_LOG")) sparse_min_log = (uint32_t)strtoul(e, nullptr, 10);
     if (sparse_min_log < 12) sparse_min_log = 12;
     if (log_n >= sparse_min_log && !getenv("SS_OOD_TRANSFORM")) return ood_eval_sparse(ctx, d_coeffs, ncols, log_n, mask_col, mask_off, nmask, z, out);

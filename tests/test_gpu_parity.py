@@ -472,7 +472,7 @@ def test_ood_eval_of_a_layout_sized_mask(ctx, be, oracle, log_n, block_log, monk
     mask = [(c, o) for c in range(4) for o in offs[c]] + [(1, 16), (2, offs[2][3] + n), (0, 5)]
     z = 0x1F2E3D4C5B6A7988 ** 3 % P
     zm = oracle.to_mont([z])[0]
-    monkeypatch.setenv("SS_OOD_SPARSE_MIN_LOG", "12")           # the library takes this path from 2^22 coefficients on
+    monkeypatch.setenv("SS_OOD_SPARSE_MIN_LOG", "12")           # the library takes this path from 2^20 coefficients on
     if block_log is not None:
         monkeypatch.setenv("SS_OOD_BLOCK_LOG", str(block_log))
     got = ctx.ood_eval(co.cols, log_n, [c for c, _ in mask], [o for _, o in mask], zm)
