@@ -25,6 +25,9 @@ def pytest_configure(config):
         _lib.LIB_PATH = os.environ.get("SS_TEST_HIPEMU_LIB", os.path.join(ROOT, "tests", "hipemu", "_build", "libsandstorm_hipemu.so"))
         # the product's Pedersen table is sized for HBM (24-bit windows: 23.6 GB); the emulated device's memory is this host's
         os.environ.setdefault("SS_PED_WINDOW", "16")
+        # ... and a cross-lane read costs the emulator two workgroup barriers: the 32-lanes-per-hash kernel (a thousand of them per lane)
+        # runs the tree levels of <= 128 hashes here, not <= 8192
+        os.environ.setdefault("SS_PED_SMALL_MAX", "128")
 
 
 @pytest.fixture(scope="session")

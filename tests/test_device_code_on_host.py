@@ -103,7 +103,8 @@ def test_the_smoke_invocation(emulated_library):
     """__graft_entry__.smoke() - what the driver runs on the MI355X before the bench - over the host build: its checks are right"""
     code = ("import sys; sys.path.insert(0, %r); from sandstorm_amd import _lib; _lib.LIB_PATH = %r; import __graft_entry__ as g; g.smoke()"
             % (ROOT, emulated_library))
-    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, SS_PED_WINDOW="16", SS_PED_SMALL_MAX="128")          # the emulated device's sizes (tests/conftest.py)
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
