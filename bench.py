@@ -450,7 +450,16 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     barrier()
     ctx.profile(True)
     ctx.profile_reset()
+    host_profile = None
+    if os.environ.get("SS_BENCH_PROFILE") == "1" and rank == 0:        # diagnosis: where the driver's HOST time goes (-> stderr)
+        import cProfile
+        host_profile = cProfile.Profile()
+        host_profile.enable()
     sec = timed_steps(prove_once, args.steps, 0, barrier, all_max)
+    if host_profile is not None:
+        import pstats
+        host_profile.disable()
+        pstats.Stats(host_profile, stream=sys.stderr).sort_stats("tottime").print_stats(45)
     kinds = [("ntt_pass", be.PROF_NTT_PASS), ("hash_rows", be.PROF_HASH_ROWS), ("merkle", be.PROF_MERKLE), ("fri_fold", be.PROF_FRI),
              ("quotient", be.PROF_QUOTIENT), ("deep", be.PROF_DEEP), ("extension_scans", be.PROF_EXT)]
     prof = {name: ctx.profile_read(k) for name, k in kinds}

@@ -188,6 +188,15 @@ class CpuContext:
                 out[q, k] = _felts(base + 32 * int(i), 1)[0]
         return out
 
+    def bitrev_permute32(self, src, log_n, dst):
+        """dst[i] = src[bitrev(i)] over 32-byte records (ss_bitrev_permute32)"""
+        n = 1 << log_n
+        idx = np.arange(n, dtype=np.uint64)
+        rev = np.zeros(n, dtype=np.uint64)
+        for b in range(log_n):
+            rev |= ((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(log_n - 1 - b)
+        _bytes32(dst, n)[:] = _bytes32(src, n)[rev.astype(np.int64)]
+
     # ---- F1, C2
     def fri_fold(self, evals, log_len, fold, alpha, offset, out, flags=0):
         n = 1 << log_len

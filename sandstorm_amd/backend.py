@@ -190,6 +190,10 @@ class Context:
                                       out.ctypes.data, otags.ctypes.data))
         return out, otags
 
+    def bitrev_permute32(self, src, log_n, dst):
+        """dst[i] = src[bitrev(i)], i < 2^log_n, over 32-byte records (field elements or digests); not in place"""
+        check(self.lib.ss_bitrev_permute32(self.handle, _ptr_of(src), log_n, _ptr_of(dst)))
+
     def gather_rows(self, cols, indices):
         idx = np.ascontiguousarray(indices, dtype=np.uint64)
         out = np.zeros((len(idx), len(cols), 4), dtype=np.uint64)

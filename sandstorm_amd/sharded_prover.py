@@ -130,14 +130,6 @@ def _dbg(comm, what, t):
         print("[shard dbg] rank %d %-28s %s" % (comm.rank, what, hashlib.sha256(b).hexdigest()[:16]), flush=True)
 
 
-def _bitrev_tensor(t, bits):
-    torch = _torch()
-    r = torch.zeros_like(t)
-    for b in range(bits):
-        r |= ((t >> b) & 1) << (bits - 1 - b)
-    return r
-
-
 @dataclass
 class _Commitment:
     """a matrix committed over R ranks: this rank's leaf block and sub-tree, and the replicated top levels"""
@@ -163,7 +155,9 @@ class ShardedProver:
 
     # ---- buffers: torch tensors (what torch.distributed moves); the C ABI takes their data_ptr
     def felts(self, rows):
-        return _torch().zeros((rows, 4), dtype=_torch().int64, device=self.comm.device)
+        """a column of `rows` field elements.  Every caller hands it to a kernel or an exchange that writes all of it: no fill (a zero
+        fill of the ~21 GB a 2^20-step proof allocates is ~7 ms of the GPU's time per proof)"""
+        return _torch().empty((rows, 4), dtype=_torch().int64, device=self.comm.device)
 
     def owner(self, col):
         return col % self.comm.world
@@ -215,19 +209,20 @@ class ShardedProver:
         # bitrev_{log R}(s) of the leaf block.  No index tensors, no gather on either side.
         if single:                                  # raw-element leaves (merkle/mod.rs:113-117)
             mine = blocks[0][:B]
-            if order == be.BITREV:
-                mine = mine[self._bitrev_index(log_B)]
+            if order == be.BITREV:                  # (a torch index gather of 2^25 elements is 2.4 ms; the library's permutation 0.5)
+                src, mine = mine.contiguous(), self.felts(B)
+                ctx.bitrev_permute32(src, log_B, mine)
         else:
-            mine = torch.zeros((B, 32), dtype=torch.uint8, device=comm.device)
+            mine = torch.empty((B, 32), dtype=torch.uint8, device=comm.device)
             ctx.hash_rows(Tree.row_hash, blocks, B, mine, order)            # the blocks' halo is not hashed
         _dbg(comm, "row digests / leaves (local order)", mine)
         if R == 1 or order != be.BITREV:            # natural order: a rank's rows are its leaves
             leaves = mine
         else:
-            got = torch.zeros_like(mine)
+            got = torch.empty_like(mine)
             comm.all_to_all_equal(got, mine.contiguous())
             W = mine.shape[1]
-            leaves = torch.zeros_like(mine)
+            leaves = torch.empty_like(mine)
             comb = leaves.view(B // R, R, W)
             for src in range(R):
                 comb[:, bitrev(src, log_R)] = got[src * (B // R):(src + 1) * (B // R)]
@@ -252,13 +247,6 @@ class ShardedProver:
             top.insert(0, [sharding.merge_nodes(Tree.tree_kind, nf, depth, lvl[2 * q], lvl[2 * q + 1]) for q in range(len(lvl) // 2)])
             depth -= 1
         return _Commitment(leaves, leaf_kind, nodes, tags, top, top[0][0][0], top[0][0][1])
-
-    def _bitrev_index(self, bits):
-        cache = self.__dict__.setdefault("_bitrev", {})
-        if bits not in cache:
-            torch = _torch()
-            cache[bits] = _bitrev_tensor(torch.arange(1 << bits, dtype=torch.int64, device=self.comm.device), bits)
-        return cache[bits]
 
     def open(self, com: _Commitment, blocks, N, positions, order):
         """-> on rank 0: (rows [nq, ncols, 4], paths [nq, log N, 32], leaf digests [nq, 32] or None, MixedMerkleDigest tags
