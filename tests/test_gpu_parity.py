@@ -252,10 +252,35 @@ def test_merkle_vs_oracle(ctx, be, oracle, tree, leaf_kind, nf, log_n):
 
 
 def test_friendly_merkle_large_and_small_levels(ctx, be, oracle):
-    """A 2^14-leaf all-Pedersen tree crosses both Pedersen paths: one lane per hash on the levels
-    above 4096 nodes, 32 lanes per hash (window-split, butterfly of Jacobian additions) below."""
-    n = 1 << 14
+    """A 2^15-leaf all-Pedersen tree crosses both Pedersen paths: one lane per hash (+ the batched inversion) on the level of 16384
+    hashes, 32 lanes per hash (one window each, additions and inversion dealt out to quads of lanes) from 8192 hashes down."""
+    n = 1 << 15
     leaves = oracle.hash_rows(be.HASH_BLAKE2S_M20, [random_column(n, 11), random_column(n, 12)])
+    want_nodes, want_tags = oracle.merkle_build(2, 22, 0, leaves)
+    d_leaves = ctx.alloc(32 * n).upload(leaves)
+    nodes, tags = ctx.alloc(64 * n), ctx.alloc(2 * n)
+    root, _ = ctx.merkle_build(2, 22, 0, d_leaves, n, nodes, tags)
+    assert np.array_equal(nodes.download(np.uint8, (2 * n, 32))[1:], want_nodes[1:])
+    assert root == bytes(want_nodes[1])
+
+
+def test_pedersen_levels_on_sparse_digests(ctx, be, oracle):
+    """The 32-lanes-per-hash kernel gives every lane ONE window of a scalar: a zero digit is a lane that holds the point at infinity,
+    and the butterfly's additions meet it on either side, on both, and all the way up (a scalar of zero).  Leaves with few non-zero
+    windows - 0, 1, single bits at and around the 16 / 18 / 20 / 22 / 24-bit window boundaries, all-ones runs, p - 1 - in every pairing
+    with each other and with full-width digests."""
+    vals = [0, 1, 2, P - 1, P - 2, (1 << 251) - 1, 1 << 251, (1 << 248) - 1]
+    for w in (16, 18, 20, 22, 24):
+        vals += [1 << w, (1 << w) - 1, 1 << (2 * w), (1 << (10 * w)) | 1, ((1 << w) - 1) << (3 * w)]
+    vals += [1 << k for k in (31, 32, 63, 64, 127, 128, 191, 192, 239, 240, 247, 250)]
+    rnd = [int.from_bytes(bytes(r), "big") % P for r in oracle.hash_rows(be.HASH_BLAKE2S_M20, [random_column(16, 77)])]
+    vals += rnd
+    pairs = [(a, b) for a in vals for b in (vals[:6] + rnd[:2])] + [(b, a) for a in vals for b in vals[:4]] + [(a, a) for a in vals]
+    n = 1
+    while n < 2 * len(pairs):
+        n <<= 1
+    flat = [v for ab in pairs for v in ab] + [0] * (n - 2 * len(pairs))
+    leaves = np.frombuffer(b"".join(v.to_bytes(32, "big") for v in flat), dtype=np.uint8).reshape(n, 32).copy()
     want_nodes, want_tags = oracle.merkle_build(2, 22, 0, leaves)
     d_leaves = ctx.alloc(32 * n).upload(leaves)
     nodes, tags = ctx.alloc(64 * n), ctx.alloc(2 * n)
