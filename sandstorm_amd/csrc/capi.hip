@@ -1258,7 +1258,8 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
                         const uint64_t offset[4], const uint32_t *mask_col, const uint32_t *mask_off,
                         uint32_t nmask, const uint64_t *ood_trace, const uint64_t *coeff_trace,
                         const uint64_t *ood_comp, const uint64_t *coeff_comp, const uint64_t z[4],
-                        uint64_t m0, uint64_t count, bool block, Fp *d_sub, Fp *table_space /* 2 n felts when !block */) {
+                        uint64_t m0, uint64_t count, bool block, Fp *d_sub /* block: where the values go */,
+                        Fp **sub_out /* !block: the n sub-coset values, in scratch2 */) {
     const uint64_t n = 1ull << log_n;
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp zf = fp_from_limbs64(z);
@@ -1276,6 +1277,35 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         return mask_col[x] != mask_col[y] ? mask_col[x] < mask_col[y] : off_of(x) < off_of(y);
     });
+    // ---- which cells go the rational way (deep.hip, "the mask's LARGE columns as rational functions"): whole-domain calls from
+    // 2^20 points on (below, five pruned transforms cost more than the taps they replace), the up to DEEP_RATIONAL_MAX_COLS
+    // columns with >= 24 cells, and with them the constants' column; SS_DEEP_RATIONAL_MIN_LOG moves the threshold (the parity
+    // tests run this path from 2^10), SS_DEEP_TAPS=1 keeps every cell a tap.  The row-block form keeps the taps: a rank would
+    // evaluate the polynomials on the whole sub-coset to use an R-th of them.
+    std::vector<uint32_t> cells_of(ntrace_cols, 0);
+    std::map<uint32_t, uint32_t> off_index;                    // distinct offset -> its index (ascending)
+    for (uint32_t j = 0; j < nmask; ++j) { cells_of[mask_col[j]] += 1; off_index.emplace(off_of(j), 0u); }
+    { uint32_t k = 0; for (auto &kv : off_index) kv.second = k++; }
+    uint32_t rat_min_log = 20;
+    if (const char *e = getenv("SS_DEEP_RATIONAL_MIN_LOG")) rat_min_log = (uint32_t)strtoul(e, nullptr, 10);
+    std::vector<int> rat_slot(ntrace_cols, -1);                // column -> its slot among the rational columns
+    std::vector<uint32_t> rat_cols;
+    uint32_t poly_log = 0;                                     // the polynomials' coefficient arrays: 2^poly_log entries
+    bool rational = !block && nmask && log_n >= rat_min_log && !getenv("SS_DEEP_TAPS");
+    if (rational) {
+        std::vector<uint32_t> by_size;
+        for (uint32_t c = 0; c < ntrace_cols; ++c) if (cells_of[c] >= 24) by_size.push_back(c);
+        std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t x, uint32_t y) { return cells_of[x] > cells_of[y]; });
+        if (by_size.size() > DEEP_RATIONAL_MAX_COLS) by_size.resize(DEEP_RATIONAL_MAX_COLS);
+        uint32_t moved = (uint32_t)off_index.size();
+        for (uint32_t c : by_size) moved += cells_of[c];
+        while ((1ull << poly_log) < off_index.size() + 1) ++poly_log;
+        const uint32_t max_expand = plan_passes(log_n)[0].r;
+        if (poly_log + max_expand < log_n) poly_log = log_n - max_expand;      // the first pass expands at most its own stages
+        // worth it when the taps moved outnumber what (columns + 2) transforms and the point-wise pass cost (~ 20 taps each)
+        if (poly_log > log_n || moved < 20u * ((uint32_t)by_size.size() + 3u)) rational = false;
+        else { rat_cols = by_size; std::sort(rat_cols.begin(), rat_cols.end()); for (uint32_t k = 0; k < rat_cols.size(); ++k) rat_slot[rat_cols[k]] = (int)k; }
+    }
     std::map<uint32_t, Fp> wk_of, k_of;                       // per distinct offset: w_n^-off, K_off
     std::vector<uint32_t> tap_shift, cdesc;
     std::vector<Fp> tap_coef;
@@ -1288,16 +1318,63 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
             if (it == wk_of.end()) { it = wk_of.emplace(offv, fp_pow_u64(wn_inv, offv)).first; k_of.emplace(offv, fp_zero()); }
             const Fp cprime = fp_mul(fp_from_limbs64(coeff_trace + 4 * j), it->second);
             k_of[offv] = fp_add(k_of[offv], fp_mul(cprime, fp_from_limbs64(ood_trace + 4 * j)));
+            if (rat_slot[col] >= 0) continue;
             tap_shift.push_back(offv);
             tap_coef.push_back(fp_mul(cprime, r280_factor));
             if (offv > max_shift) max_shift = offv;
         }
+        if ((uint32_t)tap_shift.size() == first) continue;
         cdesc.push_back(col); cdesc.push_back(first); cdesc.push_back((uint32_t)tap_shift.size() - first);
     }
-    if (nmask) {
+    if (nmask && !rational) {
         const uint32_t first = (uint32_t)tap_shift.size();
         for (auto &kv : k_of) { tap_shift.push_back(kv.first); tap_coef.push_back(fp_neg(kv.second)); }
         cdesc.push_back(0xffffffffu); cdesc.push_back(first); cdesc.push_back((uint32_t)tap_shift.size() - first);
+    }
+    // ---- the rational part's polynomials, host arithmetic in 64-bit limbs (fp252_host.h): B = prod_o (x - z_o), z_o = z w_n^o;
+    // Q_o = B / (x - z_o) by synthetic division; A_c = sum_{cells (c, o)} coeff Q_o, A_K = sum_o K_o Q_o with
+    // K_o = sum_{cells at o} coeff * ood (the plain coefficients here: the w_n^-o above belongs to the shifted-table form)
+    const uint32_t npoly = rational ? (uint32_t)rat_cols.size() + 2u : 0u;       // A_c ..., A_K, B
+    std::vector<Fp> poly_coef;
+    if (rational) {
+        const uint32_t d = (uint32_t)off_index.size();
+        const size_t plen = (size_t)1 << poly_log;
+        std::vector<H4> zo(d), B(d + 1), Q(d);
+        std::vector<std::vector<H4>> A(npoly - 1, std::vector<H4>(d, H4{{0, 0, 0, 0}}));
+        const H4 zero = H4{{0, 0, 0, 0}}, one = h4_from_fp(fp_one()), zh = h4_from_fp(zf), wn_h = h4_from_fp(root_of_unity(log_n));
+        for (auto &kv : off_index) zo[kv.second] = h4_mul(zh, h4_from_fp(fph_pow_u64(h4_to_fp(wn_h), kv.first)));
+        B[0] = one;
+        for (uint32_t k = 1; k <= d; ++k) B[k] = zero;
+        for (uint32_t o = 0; o < d; ++o)                       // B <- B (x - z_o), degree o -> o + 1
+            for (uint32_t k = o + 1; k-- > 0;) {
+                B[k + 1] = h4_add(B[k + 1], B[k]);
+                B[k] = h4_sub(zero, h4_mul(zo[o], B[k]));
+            }
+        // per offset: the cells' coefficients by rational slot, and K_o
+        std::vector<std::vector<H4>> coef_at(d, std::vector<H4>(npoly - 1, zero));
+        for (uint32_t j = 0; j < nmask; ++j) {
+            const uint32_t o = off_index[off_of(j)];
+            const H4 cj = h4_from_fp(fp_from_limbs64(coeff_trace + 4 * j));
+            coef_at[o][npoly - 2] = h4_add(coef_at[o][npoly - 2], h4_mul(cj, h4_from_fp(fp_from_limbs64(ood_trace + 4 * j))));
+            if (rat_slot[mask_col[j]] >= 0) coef_at[o][rat_slot[mask_col[j]]] = h4_add(coef_at[o][rat_slot[mask_col[j]]], cj);
+        }
+        for (uint32_t o = 0; o < d; ++o) {
+            Q[d - 1] = B[d];
+            for (uint32_t k = d - 1; k > 0; --k) Q[k - 1] = h4_add(B[k], h4_mul(zo[o], Q[k]));
+            for (uint32_t pidx = 0; pidx + 1 < npoly; ++pidx) {
+                const H4 cf = coef_at[o][pidx];
+                if (h4_is_zero(cf)) continue;
+                for (uint32_t k = 0; k < d; ++k) A[pidx][k] = h4_add(A[pidx][k], h4_mul(cf, Q[k]));
+            }
+        }
+        // multipliers leave the transform / the inversion in R280 form: A_c times 2^24, B times 2^-24 (A_K as it is)
+        const H4 up = h4_from_fp(r280_factor), down = h4_from_fp(fp_inv_safegcd(r280_factor));
+        auto brev = [&](uint32_t k) { uint32_t r = 0; for (uint32_t b = 0; b < poly_log; ++b) r |= ((k >> b) & 1u) << (poly_log - 1 - b); return r; };
+        poly_coef.assign(plen * npoly, fp_zero());
+        for (uint32_t pidx = 0; pidx + 2 < npoly; ++pidx)
+            for (uint32_t k = 0; k < d; ++k) poly_coef[plen * pidx + brev(k)] = h4_to_fp(h4_mul(A[pidx][k], up));
+        for (uint32_t k = 0; k < d; ++k) poly_coef[plen * (npoly - 2) + brev(k)] = h4_to_fp(A[npoly - 2][k]);
+        for (uint32_t k = 0; k <= d; ++k) poly_coef[plen * (npoly - 1) + brev(k)] = h4_to_fp(h4_mul(B[k], down));
     }
     const uint32_t ntaps = (uint32_t)tap_shift.size(), ncoldesc = (uint32_t)(cdesc.size() / 3);
     std::vector<Fp> comp_coef(ncomp ? ncomp : 1);
@@ -1313,23 +1390,29 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
     const uint64_t pre = block ? ((uint64_t)max_shift + chunk - 1) / chunk * chunk : 0;
     const uint64_t d_len = block ? (pre + count + chunk - 1) / chunk * chunk : n, dc_len = block ? (count + chunk - 1) / chunk * chunk : n;
     ss_status st = SS_OK;
-    Fp *D, *Dc;
+    Fp *D, *Dc, *poly_vals = nullptr;                          // poly_vals: npoly columns of n values + n of scratch for the inversion
     if (block) {
         st = ctx->ensure_scratch2((d_len + dc_len) * sizeof(Fp));
         if (st != SS_OK) return st;
         D = (Fp *)ctx->scratch2; Dc = D + d_len;
     } else {
-        D = table_space; Dc = D + n;
+        // D, Dc (sub-coset tables), the sub-coset values and the rational part's polynomial values live in scratch2
+        st = ctx->ensure_scratch2((size_t)(3 + (npoly ? npoly + 1 : 0)) * n * sizeof(Fp));
+        if (st != SS_OK) return st;
+        D = (Fp *)ctx->scratch2; Dc = D + n; d_sub = D + 2 * n; poly_vals = D + 3 * n;
+        if (sub_out) *sub_out = d_sub;
     }
-    const size_t small = (size_t)(ntaps + 1) * (4 + 32) + (size_t)(ncoldesc + 1) * 12 + (size_t)(ncomp + 1) * 32 + 256;
+    const size_t small = (size_t)(ntaps + 1) * (4 + 32) + (size_t)(ncoldesc + 1) * 12 + (size_t)(ncomp + 1) * 32 + 256 + poly_coef.size() * 32;
     st = ctx->ensure_scratch(small);
     if (st != SS_OK) return st;
     char *p = (char *)ctx->scratch;
     Fp *d_tap_coef = (Fp *)p; p += (size_t)(ntaps + 1) * 32;
     Fp *d_comp_coef = (Fp *)p; p += (size_t)(ncomp + 1) * 32;
+    Fp *d_poly_coef = (Fp *)p; p += poly_coef.size() * 32;
     uint32_t *d_tap_shift = (uint32_t *)p; p += (size_t)(ntaps + 1) * 4;
     uint32_t *d_cdesc = (uint32_t *)p;
     hipStream_t s = ctx->stream;
+    if (npoly) HIP_TRY(hipMemcpyAsync(d_poly_coef, poly_coef.data(), poly_coef.size() * 32, hipMemcpyHostToDevice, s));
     if (ntaps) {
         HIP_TRY(hipMemcpyAsync(d_tap_coef, tap_coef.data(), (size_t)ntaps * 32, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_tap_shift, tap_shift.data(), (size_t)ntaps * 4, hipMemcpyHostToDevice, s));
@@ -1351,6 +1434,24 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
         HIP_TRY(launch_deep(s, (const void *const *)d_trace_lde, ntrace_cols, (const void *const *)d_comp_lde, ncomp, D, Dc,
                             d_tap_shift, d_tap_coef, d_cdesc, ncoldesc, d_comp_coef, comp_k, count,
                             block ? (uint32_t)pre : 0u, block ? 0xffffffffu : (uint32_t)(n - 1), log_blowup, d_sub));
+    }
+    if (npoly) {
+        // the polynomials on the sub-coset: one pruned forward transform for all of them (the transforms are booked as transforms)
+        const Fp *tw = nullptr;
+        st = ctx->get_plan(log_n, false, off, &tw);
+        if (st != SS_OK) return st;
+        ColPtrs cols;
+        memset(&cols, 0, sizeof cols);
+        const Fp *a_vals[DEEP_RATIONAL_MAX_COLS];
+        const void *t_cols[DEEP_RATIONAL_MAX_COLS];
+        for (uint32_t k = 0; k < npoly; ++k) { cols.src[k] = d_poly_coef + ((size_t)k << poly_log); cols.dst[k] = poly_vals + (size_t)k * n; }
+        for (uint32_t k = 0; k + 2 < npoly; ++k) { a_vals[k] = poly_vals + (size_t)k * n; t_cols[k] = d_trace_lde[rat_cols[k]]; }
+        st = run_forward(ctx, cols, npoly, log_n, tw, log_n - poly_log);
+        if (st != SS_OK) return st;
+        ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
+        Fp *b_vals = poly_vals + (size_t)(npoly - 1) * n;
+        HIP_TRY(launch_batch_inverse_values(s, b_vals, poly_vals + (size_t)npoly * n, n));
+        HIP_TRY(launch_deep_rational(s, t_cols, a_vals, npoly - 2, poly_vals + (size_t)(npoly - 2) * n, b_vals, count, log_blowup, d_sub));
     }
     HIP_TRY(hipStreamSynchronize(s));     // host staging vectors go out of scope
     return SS_OK;
@@ -1398,12 +1499,10 @@ ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
     if (st != SS_OK) return st;
     const uint64_t n = 1ull << log_n;
     // the DEEP polynomial has degree < n: compose it on the sub-coset offset*<w_n> (LDE rows m * blowup), interpolate,
-    // and expand back to the LDE domain.  D, Dc (sub-coset tables) and the sub-coset values live in scratch2.
-    st = ctx->ensure_scratch2(3 * n * sizeof(Fp));
-    if (st != SS_OK) return st;
-    Fp *tables = (Fp *)ctx->scratch2, *sub = tables + 2 * n;
+    // and expand back to the LDE domain
+    Fp *sub = nullptr;
     st = deep_subcoset(ctx, d_trace_lde, ntrace_cols, d_comp_lde, ncomp, log_n, log_blowup, offset, mask_col, mask_off, nmask,
-                       ood_trace, coeff_trace, ood_comp, coeff_comp, z, 0, n, false, sub, tables);
+                       ood_trace, coeff_trace, ood_comp, coeff_comp, z, 0, n, false, nullptr, &sub);
     if (st != SS_OK) return st;
     st = deep_extend(ctx, sub, log_n, log_blowup, offset ? fp_from_limbs64(offset) : fp_one(), d_out);
     if (st != SS_OK) return st;

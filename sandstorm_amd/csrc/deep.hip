@@ -430,6 +430,83 @@ hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace
     return hipGetLastError();
 }
 
+// ---- the mask's LARGE columns as rational functions ------------------------------------------------------------------------
+// A column with many cells (starknet: 105, 60 and 56 of the 269) and the constants' column (one tap per distinct offset: 191)
+// pay a tap each per point above.  But sum_{cells j of c} c_j / (x - z w^off_j) = A_c(x) / B(x) with B = prod_off (x - z w^off)
+// over the mask's distinct offsets and deg A_c < deg B <= a few hundred: the host builds the coefficients (O(offsets x cells)
+// products), ONE pruned transform evaluates each polynomial on the sub-coset (its first stages see zeros: log_expand), B is
+// inverted in batches, and a point pays ONE product per such column:
+//     out[m] += (sum_c T_c[i] A_c[m] - A_K[m]) / B[m],      A_K = sum_off K_off B / (x - z w^off)
+// A_c comes scaled by 2^24 and B by 2^-24 from the host, so both multipliers are in R280 form as they leave the transform / the
+// inversion.  The field arithmetic is exact: the same values as the tap sums, bit for bit.
+__global__ __launch_bounds__(128) void batch_inverse_values_kernel(Fp *__restrict__ V, Fp *__restrict__ tmp, uint64_t nchunks, uint32_t log_chunk) {
+    const uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    // chunk c = elements c, c + nchunks, c + 2 nchunks, ...: the lanes of a wave read neighbours
+    const uint64_t CH = 1ull << log_chunk;
+    Fl run = fl_one();
+    for (uint64_t k = 0; k < CH; ++k) {
+        const uint64_t i = c + k * nchunks;
+        Fl v = fl_from_fp(dload(V + i));
+        if (fn_is_zero(v)) v = fl_one();
+        dstore(tmp + i, fl_pack(run));
+        run = fn_mul(run, v);
+    }
+    Fl inv = fl_from_fp(fp_inv_safegcd(fl_to_fp(run)));
+    for (uint64_t k = CH; k-- > 0;) {
+        const uint64_t i = c + k * nchunks;
+        Fl v = fl_from_fp(dload(V + i));
+        const bool zero = fn_is_zero(v);
+        if (zero) v = fl_one();
+        const Fl r = fn_mul(inv, fl_from_fp(dload(tmp + i)));
+        inv = fn_mul(inv, v);
+        dstore(V + i, zero ? fp_zero() : fl_to_fp(r));
+    }
+}
+hipError_t launch_batch_inverse_values(hipStream_t st, Fp *V, Fp *tmp, uint64_t len) {
+    uint32_t log_chunk = 5;
+    while (log_chunk > 0 && (len >> log_chunk) < 4096 ) --log_chunk;
+    while ((len & ((1ull << log_chunk) - 1)) != 0) --log_chunk;          // len is a power of two here; any len works with chunk 1
+    const uint64_t nchunks = len >> log_chunk;
+    if (nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(batch_inverse_values_kernel, dim3((uint32_t)((nchunks + 127) / 128)), dim3(128), 0, st, V, tmp, nchunks, log_chunk);
+    return hipGetLastError();
+}
+
+struct DeepRationalArgs {
+    const Fp *trace[DEEP_RATIONAL_MAX_COLS];
+    const Fp *A[DEEP_RATIONAL_MAX_COLS];
+    const Fp *AK, *Binv;
+    uint32_t ncols, log_stride;
+    uint64_t count;
+};
+__global__ __launch_bounds__(256) void deep_rational_kernel(DeepRationalArgs a, Fp *__restrict__ out) {
+    for (uint64_t m = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; m < a.count; m += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = m << a.log_stride;
+        FlWide w;
+        fl_wide_zero(w);
+#pragma unroll
+        for (uint32_t k = 0; k < DEEP_RATIONAL_MAX_COLS; ++k)
+            if (k < a.ncols) fl_wide_mad(w, fl_from_fp(dload(a.trace[k] + i)), fl_from_fp(dload(a.A[k] + m)));
+        const Fl s = fl_wide_reduce(w);                                      // normalised, < 1.01 p (0 for no columns)
+        const Fl d = fl_sub_c<2, 1>(s, fl_from_fp(dload(a.AK + m)));         // lazy: < 4p
+        const Fl v = fl_mul_r280(d, fl_from_fp(dload(a.Binv + m)));         // normalised, < 1.01 p
+        dstore(out + m, fl_to_fp(fl_add(fl_from_fp(dload(out + m)), v)));
+    }
+}
+hipError_t launch_deep_rational(hipStream_t st, const void *const *trace, const Fp *const *A, uint32_t ncols, const Fp *AK, const Fp *Binv,
+                                uint64_t count, uint32_t log_stride, Fp *out) {
+    if (ncols > DEEP_RATIONAL_MAX_COLS) return hipErrorInvalidValue;
+    DeepRationalArgs a;
+    for (uint32_t k = 0; k < DEEP_RATIONAL_MAX_COLS; ++k) { a.trace[k] = k < ncols ? (const Fp *)trace[k] : nullptr; a.A[k] = k < ncols ? A[k] : nullptr; }
+    a.AK = AK; a.Binv = Binv; a.ncols = ncols; a.log_stride = log_stride; a.count = count;
+    uint32_t gx = (uint32_t)((count + 255) / 256);
+    if (gx > 256 * 16) gx = 256 * 16;
+    if (gx == 0) gx = 1;
+    hipLaunchKernelGGL(deep_rational_kernel, dim3(gx), dim3(256), 0, st, a, out);
+    return hipGetLastError();
+}
+
 // gather with a column selector: out[j] = cols[col[j]][idx[j]]
 struct GatherArgs { const Fp *cols[MAX_COLS]; };
 __global__ void gather_cells_kernel(GatherArgs a, const uint32_t *__restrict__ col, const uint64_t *__restrict__ idx,

@@ -81,6 +81,12 @@ hipError_t launch_deep(hipStream_t st, const void *const *trace, uint32_t ntrace
                        uint32_t ncomp, const Fp *D, const Fp *Dc, const uint32_t *tap_shift, const Fp *tap_coef,
                        const uint32_t *col_desc, uint32_t ncoldesc, const Fp *comp_coef,
                        const Fp &comp_k, uint64_t count, uint32_t d_bias, uint32_t d_mask, uint32_t log_stride, Fp *out);
+// the mask's large columns as rational functions (deep.hip): V[m] <- 1 / V[m] (tmp: len felts), and
+// out[m] += (sum_k trace_k[m << log_stride] * A_k[m] - AK[m]) * Binv[m]   (A_k, Binv in R280 form; ncols <= DEEP_RATIONAL_MAX_COLS)
+static constexpr uint32_t DEEP_RATIONAL_MAX_COLS = 8;
+hipError_t launch_batch_inverse_values(hipStream_t st, Fp *V, Fp *tmp, uint64_t len);
+hipError_t launch_deep_rational(hipStream_t st, const void *const *trace, const Fp *const *A, uint32_t ncols, const Fp *AK, const Fp *Binv,
+                                uint64_t count, uint32_t log_stride, Fp *out);
 static constexpr uint32_t BATCH_INVERSE_RANGE_LOG_CHUNK = 5;
 hipError_t launch_batch_inverse_range(hipStream_t st, Fp *D, uint64_t len, const Fp &x0, const Fp &w, const Fp &w_inv,
                                       const Fp &z, bool r280);

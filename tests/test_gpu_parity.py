@@ -540,6 +540,53 @@ def test_deep_compose_vs_oracle(ctx, be, oracle, log_n):
     assert not np.any(out.download(np.uint64, (N, 4))[n:])
 
 
+@pytest.mark.parametrize("log_n,shape", [(10, "two large"), (12, "two large"), (12, "one large"), (13, "all large"), (11, "many offsets")])
+def test_deep_compose_of_a_layout_sized_mask(ctx, be, oracle, log_n, shape, monkeypatch):
+    """A layout's mask has columns with dozens of cells (starknet: 105, 60, 56) and one constant per distinct offset (191): from 2^20
+    points on ss_deep_compose takes those as RATIONAL functions - A_c(x) / B(x), B over the mask's distinct offsets, evaluated by one
+    pruned transform each (deep.hip) - instead of a tap per cell.  The same values as the taps (SS_DEEP_TAPS=1) and the oracle's:
+    columns of 40 / 26 / 3 / 1 cells, one or all of them above the 24-cell bar, offsets up to n - 1 and beyond (taken mod n), a cell
+    named twice, more distinct offsets than a 2^7-entry coefficient array holds."""
+    lb = 1
+    n, N = 1 << log_n, 1 << (log_n + lb)
+    g = g3(oracle)
+    rng = np.random.default_rng(log_n * 11 + len(shape))
+    ncols = 4
+    cols = [random_column(n, c + 700) for c in range(ncols)]
+    m = be.Matrix.from_host(ctx, cols)
+    ev, co = m.lde(lb, g)
+    comp_coeffs = [random_column(n, 790 + k) for k in range(2)]
+    cm = be.Matrix.from_host(ctx, [np.concatenate([c, np.zeros((N - n, 4), dtype=np.uint64)]) for c in comp_coeffs])
+    cm.evaluate(g)
+    pick = lambda k, hi: sorted({int(v) for v in rng.integers(0, hi, size=3 * k)} | {0, 1})[:k]
+    if shape == "two large":
+        offs = [pick(40, n), pick(26, min(n, 600)), [0, 1, n - 1], [5]]
+    elif shape == "one large":
+        offs = [pick(30, n), pick(20, n), [0, 1, 2], [0]]
+    elif shape == "all large":
+        offs = [pick(40, n), pick(30, n), pick(25, n), pick(24, 64)]
+    else:
+        offs = [pick(90, n), pick(80, n), [0], [1]]
+    mask = [(c, o) for c in range(ncols) for o in offs[c]] + [(0, offs[0][3]), (1, offs[1][2] + n)]
+    mc, mo = [c for c, _ in mask], [o for _, o in mask]
+    z = 0x2468ACE13579B ** 5 % P
+    zm = oracle.to_mont([z])[0]
+    ood_t = ctx.ood_eval(co.cols, log_n, mc, mo, zm)
+    ood_c = np.stack([oracle.poly_eval(c, oracle.to_mont([z * z % P])[0]) for c in comp_coeffs])
+    alpha = 192837465564738291
+    ct = oracle.to_mont([pow(alpha, j, P) for j in range(len(mask))])
+    cc = oracle.to_mont([pow(alpha, len(mask) + k, P) for k in range(2)])
+    out, out_taps = ctx.alloc(32 * N), ctx.alloc(32 * N)
+    monkeypatch.setenv("SS_DEEP_RATIONAL_MIN_LOG", "8")           # the library takes this path from 2^20 points on
+    ctx.deep_compose(ev.cols, cm.cols, log_n, lb, g, mc, mo, ood_t, ct, ood_c, cc, zm, out)
+    monkeypatch.setenv("SS_DEEP_TAPS", "1")
+    ctx.deep_compose(ev.cols, cm.cols, log_n, lb, g, mc, mo, ood_t, ct, ood_c, cc, zm, out_taps)
+    got = out.download(np.uint64, (N, 4))
+    assert np.array_equal(got, out_taps.download(np.uint64, (N, 4)))
+    want = oracle.deep_compose(ev.to_host(), cm.to_host(), log_n, lb, g, mc, mo, ood_t, ct, ood_c, cc, zm)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("seed,size,log_n", [(1, 30, 3), (2, 120, 8), (3, 400, 12)])
 def test_eval_quotient_vs_oracle(ctx, be, oracle, seed, size, log_n):
     import random
