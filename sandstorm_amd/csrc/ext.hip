@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void perm_terms_kernel(PermOperand num, PermOp
                                                          Fp *__restrict__ tn, Fp *__restrict__ td) {
     perm_terms_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, num, den, count, z, alpha, tn, td);
 }
-__global__ __launch_bounds__(256) void perm_finish_kernel(const Fp *__restrict__ pn, const Fp *__restrict__ pd_inv, uint64_t count,
+__global__ __launch_bounds__(256) void perm_finish_kernel(const Fp *pn, const Fp *__restrict__ pd_inv, uint64_t count,
                                                           Fp *out, uint64_t out_stride, uint64_t out_off) {
     perm_finish_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, pn, pd_inv, count, out, out_stride, out_off);
 }
