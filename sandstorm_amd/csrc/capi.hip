@@ -252,14 +252,21 @@ ss_status run_forward(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t
     const uint32_t lt = (uint32_t)ntt_log_tile_max();
     const uint32_t log_tile = log_n < lt ? log_n : lt;
     std::vector<Pass> passes = plan_passes(log_n);
-    if (log_expand > passes[0].r) return fail(SS_ERR_INVALID, "log_blowup %u too large", log_expand);
+    if (log_expand >= log_n && log_n > 0) return fail(SS_ERR_INVALID, "log_blowup %u too large", log_expand);
+    // The first log_expand stages of the network see a zero in every second input: they replicate (element i = source
+    // i >> log_expand) and are skipped - whole passes of them too (a polynomial of 2^8 coefficients on 2^24 points: the 11-stage
+    // pass and five stages of the next; the first pass that runs reads the source at the shifted index, whatever its stride).
+    size_t start = 0;
+    uint32_t skip = log_expand;
+    while (start + 1 < passes.size() && skip >= passes[start].r) { skip -= passes[start].r; ++start; }
+    if (skip >= passes[start].r && log_n > 0) return fail(SS_ERR_INVALID, "log_blowup %u too large", log_expand);
     ColPtrs inplace = cols;
     for (uint32_t c = 0; c < ncols; ++c) inplace.src[c] = cols.dst[c];
-    for (size_t i = 0; i < passes.size(); ++i) {
-        const bool first = i == 0;
+    for (size_t i = start; i < passes.size(); ++i) {
+        const bool first = i == start;
         ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
         HIP_TRY(launch_ntt_pass(ctx->stream, false, first ? cols : inplace, ncols, tw, log_n, passes[i].s0,
-                                passes[i].r, log_tile, first ? log_expand : 0, first ? log_expand : 0, 0, i + 1 == passes.size()));
+                                passes[i].r, log_tile, first ? skip : 0, first ? log_expand : 0, 0, i + 1 == passes.size()));
     }
     return SS_OK;
 }
@@ -1300,8 +1307,7 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
         uint32_t moved = (uint32_t)off_index.size();
         for (uint32_t c : by_size) moved += cells_of[c];
         while ((1ull << poly_log) < off_index.size() + 1) ++poly_log;
-        const uint32_t max_expand = plan_passes(log_n)[0].r;
-        if (poly_log + max_expand < log_n) poly_log = log_n - max_expand;      // the first pass expands at most its own stages
+        if (poly_log == 0) poly_log = 1;
         // worth it when the taps moved outnumber what (columns + 2) transforms and the point-wise pass cost (~ 20 taps each)
         if (poly_log > log_n || moved < 20u * ((uint32_t)by_size.size() + 3u)) rational = false;
         else { rat_cols = by_size; std::sort(rat_cols.begin(), rat_cols.end()); for (uint32_t k = 0; k < rat_cols.size(); ++k) rat_slot[rat_cols[k]] = (int)k; }

@@ -540,6 +540,29 @@ def test_deep_compose_vs_oracle(ctx, be, oracle, log_n):
     assert not np.any(out.download(np.uint64, (N, 4))[n:])
 
 
+@pytest.mark.parametrize("log_n,log_blowup", [(5, 1), (3, 9), (6, 11), (5, 12), (4, 14), (1, 16), (8, 10)])
+def test_evaluate_few_coefficients_on_many_points(ctx, be, oracle, log_n, log_blowup):
+    """ss_evaluate_fp252 with a large blow-up (DEEP's rational functions: 2^8 coefficients on 2^24 points): the first log_blowup stages
+    of the network only replicate and are skipped - the first pass whole when they are its 11 stages or more, and stages of the
+    next (a strided pass that reads the source at the shifted index).  Equal to the full transform of the zero-padded column, and
+    to the polynomial at a few points."""
+    n, N = 1 << log_n, 1 << (log_n + log_blowup)
+    g = g3(oracle)
+    coeffs = [random_column(n, 900 + c) for c in range(2)]
+    brev = [int(format(i, "0%db" % log_n)[::-1], 2) for i in range(n)]
+    d_co = _up(ctx, [c[brev] for c in coeffs])
+    outs = [ctx.alloc(32 * N) for _ in coeffs]
+    ctx.evaluate(d_co, log_n, log_blowup, g, outs)
+    full = be.Matrix.from_host(ctx, [np.concatenate([c, np.zeros((N - n, 4), dtype=np.uint64)]) for c in coeffs])
+    full.evaluate(g)
+    w = pow(3, (P - 1) >> (log_n + log_blowup), P)
+    for c in range(2):
+        got = outs[c].download(np.uint64, (N, 4))
+        assert np.array_equal(got, full.to_host()[c])
+        for i in (0, 1, N // 2 + 3, N - 1):
+            assert np.array_equal(got[i], oracle.poly_eval(coeffs[c], oracle.to_mont([3 * pow(w, i, P) % P])[0])), (c, i)
+
+
 @pytest.mark.parametrize("log_n,shape", [(10, "two large"), (12, "two large"), (12, "one large"), (13, "all large"), (11, "many offsets")])
 def test_deep_compose_of_a_layout_sized_mask(ctx, be, oracle, log_n, shape, monkeypatch):
     """A layout's mask has columns with dozens of cells (starknet: 105, 60, 56) and one constant per distinct offset (191): from 2^20
