@@ -1286,9 +1286,10 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
     });
     // ---- which cells go the rational way (deep.hip, "the mask's LARGE columns as rational functions"): whole-domain calls from
     // 2^20 points on (below, five pruned transforms cost more than the taps they replace), the up to DEEP_RATIONAL_MAX_COLS
-    // columns with >= 24 cells, and with them the constants' column; SS_DEEP_RATIONAL_MIN_LOG moves the threshold (the parity
-    // tests run this path from 2^10), SS_DEEP_TAPS=1 keeps every cell a tap.  The row-block form keeps the taps: a rank would
-    // evaluate the polynomials on the whole sub-coset to use an R-th of them.
+    // columns with >= 12 cells, and with them the constants' column; SS_DEEP_RATIONAL_MIN_LOG moves the threshold (the parity
+    // tests run this path from 2^10), SS_DEEP_TAPS=1 keeps every cell a tap.  The row-block form evaluates the polynomials on the
+    // whole sub-coset too (a transform has no cheap R-th) and uses its range of them: five pruned transforms still cost a rank
+    // less than its share of 412 taps, on 8 ranks as on one.
     std::vector<uint32_t> cells_of(ntrace_cols, 0);
     std::map<uint32_t, uint32_t> off_index;                    // distinct offset -> its index (ascending)
     for (uint32_t j = 0; j < nmask; ++j) { cells_of[mask_col[j]] += 1; off_index.emplace(off_of(j), 0u); }
@@ -1298,18 +1299,20 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
     std::vector<int> rat_slot(ntrace_cols, -1);                // column -> its slot among the rational columns
     std::vector<uint32_t> rat_cols;
     uint32_t poly_log = 0;                                     // the polynomials' coefficient arrays: 2^poly_log entries
-    bool rational = !block && nmask && log_n >= rat_min_log && !getenv("SS_DEEP_TAPS");
+    bool rational = nmask && log_n >= rat_min_log && !getenv("SS_DEEP_TAPS");
     if (rational) {
         std::vector<uint32_t> by_size;
-        for (uint32_t c = 0; c < ntrace_cols; ++c) if (cells_of[c] >= 24) by_size.push_back(c);
+        uint32_t min_cells = 12;                              // a polynomial costs what ~ 10 taps do (measured: gpurun_out/r03_call23)
+        if (const char *e = getenv("SS_DEEP_RATIONAL_MIN_CELLS")) min_cells = (uint32_t)strtoul(e, nullptr, 10);
+        for (uint32_t c = 0; c < ntrace_cols; ++c) if (cells_of[c] >= min_cells) by_size.push_back(c);
         std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t x, uint32_t y) { return cells_of[x] > cells_of[y]; });
         if (by_size.size() > DEEP_RATIONAL_MAX_COLS) by_size.resize(DEEP_RATIONAL_MAX_COLS);
         uint32_t moved = (uint32_t)off_index.size();
         for (uint32_t c : by_size) moved += cells_of[c];
         while ((1ull << poly_log) < off_index.size() + 1) ++poly_log;
         if (poly_log == 0) poly_log = 1;
-        // worth it when the taps moved outnumber what (columns + 2) transforms and the point-wise pass cost (~ 20 taps each)
-        if (poly_log > log_n || moved < 20u * ((uint32_t)by_size.size() + 3u)) rational = false;
+        // worth it when the taps moved outnumber what (columns + 2) transforms and the point-wise pass cost
+        if (poly_log >= log_n || moved < min_cells * ((uint32_t)by_size.size() + 3u)) rational = false;
         else { rat_cols = by_size; std::sort(rat_cols.begin(), rat_cols.end()); for (uint32_t k = 0; k < rat_cols.size(); ++k) rat_slot[rat_cols[k]] = (int)k; }
     }
     std::map<uint32_t, Fp> wk_of, k_of;                       // per distinct offset: w_n^-off, K_off
@@ -1398,9 +1401,9 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
     ss_status st = SS_OK;
     Fp *D, *Dc, *poly_vals = nullptr;                          // poly_vals: npoly columns of n values + n of scratch for the inversion
     if (block) {
-        st = ctx->ensure_scratch2((d_len + dc_len) * sizeof(Fp));
+        st = ctx->ensure_scratch2((d_len + dc_len + (npoly ? (size_t)npoly * n + count : 0)) * sizeof(Fp));
         if (st != SS_OK) return st;
-        D = (Fp *)ctx->scratch2; Dc = D + d_len;
+        D = (Fp *)ctx->scratch2; Dc = D + d_len; poly_vals = Dc + dc_len;
     } else {
         // D, Dc (sub-coset tables), the sub-coset values and the rational part's polynomial values live in scratch2
         st = ctx->ensure_scratch2((size_t)(3 + (npoly ? npoly + 1 : 0)) * n * sizeof(Fp));
@@ -1455,9 +1458,11 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
         st = run_forward(ctx, cols, npoly, log_n, tw, log_n - poly_log);
         if (st != SS_OK) return st;
         ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
-        Fp *b_vals = poly_vals + (size_t)(npoly - 1) * n;
-        HIP_TRY(launch_batch_inverse_values(s, b_vals, poly_vals + (size_t)npoly * n, n));
-        HIP_TRY(launch_deep_rational(s, t_cols, a_vals, npoly - 2, poly_vals + (size_t)(npoly - 2) * n, b_vals, count, log_blowup, d_sub));
+        // this call's points m0 .. m0 + count of them (the whole sub-coset, or a rank's range; the trace columns are its blocks)
+        Fp *b_vals = poly_vals + (size_t)(npoly - 1) * n + m0;
+        for (uint32_t k = 0; k + 2 < npoly; ++k) a_vals[k] += m0;
+        HIP_TRY(launch_batch_inverse_values(s, b_vals, poly_vals + (size_t)npoly * n, count));
+        HIP_TRY(launch_deep_rational(s, t_cols, a_vals, npoly - 2, poly_vals + (size_t)(npoly - 2) * n + m0, b_vals, count, log_blowup, d_sub));
     }
     HIP_TRY(hipStreamSynchronize(s));     // host staging vectors go out of scope
     return SS_OK;

@@ -73,15 +73,26 @@ def test_row_block_forms_are_the_whole_domain_forms(oracle):
     whole = ctx.alloc(32 * N)
     ctx.deep_compose(m.cols, cm.cols, log_n, 1, g, mc, mo, ood_t, ct, ood_c, cc, z, whole)
     want = whole.download(np.uint64, (N, 4))
-    sub = ctx.alloc(32 * n)
     cnt = n // R
-    for r in range(R):
-        tb = [ctx.column(c[r * B:(r + 1) * B]) for c in lde]
-        cb = [ctx.column(c[r * B:(r + 1) * B]) for c in comp]
-        ctx.deep_compose_rows(tb, cb, log_n, 1, g, mc, mo, ood_t, ct, ood_c, cc, z, r * cnt, cnt, be.DeviceView(sub, 32 * r * cnt, 32 * cnt))
-    out = ctx.alloc(32 * N)
-    ctx.deep_extend(sub, log_n, 1, g, out)
-    assert np.array_equal(out.download(np.uint64, (N, 4)), want)
+    # a tap per cell (what this size takes by itself), then the large columns as rational functions (the library's choice from 2^20
+    # points on: every rank evaluates the polynomials on the whole sub-coset and uses its range of them)
+    for rational in (False, True):
+        if rational:
+            os.environ["SS_DEEP_RATIONAL_MIN_LOG"] = "8"
+        try:
+            if rational:
+                ctx.deep_compose(m.cols, cm.cols, log_n, 1, g, mc, mo, ood_t, ct, ood_c, cc, z, whole)
+                assert np.array_equal(whole.download(np.uint64, (N, 4)), want)
+            sub = ctx.alloc(32 * n)
+            for r in range(R):
+                tb = [ctx.column(c[r * B:(r + 1) * B]) for c in lde]
+                cb = [ctx.column(c[r * B:(r + 1) * B]) for c in comp]
+                ctx.deep_compose_rows(tb, cb, log_n, 1, g, mc, mo, ood_t, ct, ood_c, cc, z, r * cnt, cnt, be.DeviceView(sub, 32 * r * cnt, 32 * cnt))
+            out = ctx.alloc(32 * N)
+            ctx.deep_extend(sub, log_n, 1, g, out)
+            assert np.array_equal(out.download(np.uint64, (N, 4)), want), rational
+        finally:
+            os.environ.pop("SS_DEEP_RATIONAL_MIN_LOG", None)
     ctx.close()
 
 
