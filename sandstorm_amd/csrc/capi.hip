@@ -1344,8 +1344,8 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
     // Q_o = B / (x - z_o) by synthetic division; A_c = sum_{cells (c, o)} coeff Q_o, A_K = sum_o K_o Q_o with
     // K_o = sum_{cells at o} coeff * ood (the plain coefficients here: the w_n^-o above belongs to the shifted-table form)
     const uint32_t npoly = rational ? (uint32_t)rat_cols.size() + 2u : 0u;       // A_c ..., A_K, B
-    std::vector<Fp> poly_coef;
-    if (rational) {
+    std::vector<Fp> poly_coef((size_t)npoly << poly_log, fp_zero());
+    auto build_polynomials = [&]() {             // (~ 1 ms of host arithmetic: run while the tables and the taps are on the GPU)
         const uint32_t d = (uint32_t)off_index.size();
         const size_t plen = (size_t)1 << poly_log;
         std::vector<H4> zo(d), B(d + 1), Q(d);
@@ -1379,12 +1379,11 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
         // multipliers leave the transform / the inversion in R280 form: A_c times 2^24, B times 2^-24 (A_K as it is)
         const H4 up = h4_from_fp(r280_factor), down = h4_from_fp(fp_inv_safegcd(r280_factor));
         auto brev = [&](uint32_t k) { uint32_t r = 0; for (uint32_t b = 0; b < poly_log; ++b) r |= ((k >> b) & 1u) << (poly_log - 1 - b); return r; };
-        poly_coef.assign(plen * npoly, fp_zero());
         for (uint32_t pidx = 0; pidx + 2 < npoly; ++pidx)
             for (uint32_t k = 0; k < d; ++k) poly_coef[plen * pidx + brev(k)] = h4_to_fp(h4_mul(A[pidx][k], up));
         for (uint32_t k = 0; k < d; ++k) poly_coef[plen * (npoly - 2) + brev(k)] = h4_to_fp(A[npoly - 2][k]);
         for (uint32_t k = 0; k <= d; ++k) poly_coef[plen * (npoly - 1) + brev(k)] = h4_to_fp(h4_mul(B[k], down));
-    }
+    };
     const uint32_t ntaps = (uint32_t)tap_shift.size(), ncoldesc = (uint32_t)(cdesc.size() / 3);
     std::vector<Fp> comp_coef(ncomp ? ncomp : 1);
     Fp comp_k = fp_zero(), zc = fp_one();
@@ -1421,7 +1420,7 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
     uint32_t *d_tap_shift = (uint32_t *)p; p += (size_t)(ntaps + 1) * 4;
     uint32_t *d_cdesc = (uint32_t *)p;
     hipStream_t s = ctx->stream;
-    if (npoly) HIP_TRY(hipMemcpyAsync(d_poly_coef, poly_coef.data(), poly_coef.size() * 32, hipMemcpyHostToDevice, s));
+
     if (ntaps) {
         HIP_TRY(hipMemcpyAsync(d_tap_coef, tap_coef.data(), (size_t)ntaps * 32, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_tap_shift, tap_shift.data(), (size_t)ntaps * 4, hipMemcpyHostToDevice, s));
@@ -1445,6 +1444,8 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
                             block ? (uint32_t)pre : 0u, block ? 0xffffffffu : (uint32_t)(n - 1), log_blowup, d_sub));
     }
     if (npoly) {
+        build_polynomials();
+        HIP_TRY(hipMemcpyAsync(d_poly_coef, poly_coef.data(), poly_coef.size() * 32, hipMemcpyHostToDevice, s));
         // the polynomials on the sub-coset: one pruned forward transform for all of them (the transforms are booked as transforms)
         const Fp *tw = nullptr;
         st = ctx->get_plan(log_n, false, off, &tw);
