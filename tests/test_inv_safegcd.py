@@ -30,3 +30,12 @@ def test_fused_dot_product_on_the_host(tmp_path):
     exe = str(tmp_path / "fl_wide_test")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "fl_wide_test.cpp")])
     assert "FL_WIDE_OK" in subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+
+
+def test_host_arithmetic_in_64_bit_limbs_is_the_32_bit_arithmetic(tmp_path):
+    """csrc/fp252_host.h (what the coin's Pedersen chain and DEEP's polynomials are computed in on the host) against csrc/fp252.h:
+    products, sums, differences and powers of 200 000 pairs with 0, 1, p - 1 and the values around p's middle limbs among them"""
+    exe = str(tmp_path / "fp252_host_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "fp252_host_test.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "bad = 0" in out.stdout, out.stdout + out.stderr
