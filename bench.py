@@ -726,7 +726,9 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
             "roofline": dict(stage_roofline("ntt_pass", "ss::ntt_pass_kernel",
                                             "the kernel north_star names.  algorithmic bytes = 2*N*32 B per transform (SURVEY 8d), shared by "
                                             "its passes; Fp252 butterflies are integer-ALU bound before HBM bound (DESIGN.md section 3): "
-                                            "`gbutterflies_per_s` against the 135 G/s of a bare butterfly loop (tools/mulbench.hip)"),
+                                            "`gbutterflies_per_s` against the 135 G/s of a bare butterfly loop (tools/mulbench.hip); the pruned "
+                                            "transforms of DEEP's rational polynomials (6-7 per proof, ~4 ms) are in the stage's time but in "
+                                            "neither the byte nor the butterfly count"),
                              gbutterflies_per_s=ntt_ops / 3 / ntt_s / 1e9 if ntt_s > 0 else 0.0, butterfly_ceiling_g_per_s=135.0),
             "roofline_dominant": stage_roofline(dominant, kernel_of[dominant],
                                                 "the stage with the largest share of the proof, same computation as `roofline` (SURVEY 8d bytes / "
