@@ -152,7 +152,7 @@ struct ss_ctx {
 
     // Twiddle plan for the stage network of size 2^log_n: T_s[k] = h^(n/2^(s+1)) * r^(k n/2^(s+1)),
     // r = w (forward) or w^-1 (inverse), h = offset or offset^-1.  Written into d_tw (n-1 felts).
-    ss_status build_plan(uint32_t log_n, bool inverse, const Fp &offset, Fp *d_tw) {
+    ss_status build_plan(uint32_t log_n, bool inverse, const Fp &offset, Fp *d_tw, bool bitrev_levels = false) {
         const uint64_t n = 1ull << log_n;
         Fp r = root_of_unity(log_n), h = offset;
         if (inverse) { r = fp_inv(r); h = fp_inv(h); }
@@ -174,21 +174,22 @@ struct ss_ctx {
         HIP_TRY(hipMalloc(&d_tabs, host.size() * sizeof(Fp)));
         HIP_TRY(hipMemcpyAsync(d_tabs, host.data(), host.size() * sizeof(Fp), hipMemcpyHostToDevice, stream));
         if (log_n > 0)
-            HIP_TRY(launch_twiddles(stream, d_tw, d_tabs, d_tabs + n_lo, d_tabs + n_lo + n_hi, log_n, h_is_one));
+            HIP_TRY(launch_twiddles(stream, d_tw, d_tabs, d_tabs + n_lo, d_tabs + n_lo + n_hi, log_n, h_is_one, bitrev_levels));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipFree(d_tabs));
         return SS_OK;
     }
     // cached plans: the per-proof-invariant ones (trace / LDE / FRI domains)
-    ss_status get_plan(uint32_t log_n, bool inverse, const Fp &offset, const Fp **out) {
+    // bitrev_levels: every level's entries in bit-reversed order (PLAN_BITREV: what the CTI network of ntt_pass_kernel reads)
+    ss_status get_plan(uint32_t log_n, bool inverse, const Fp &offset, const Fp **out, bool bitrev_levels = false) {
         PlanKey key;
-        key.log_n = log_n; key.inverse = inverse ? 1 : 0;
+        key.log_n = log_n; key.inverse = (inverse ? 1 : 0) | (bitrev_levels ? 2 : 0);
         memcpy(key.off, offset.v, sizeof key.off);
         auto it = plans.find(key);
         if (it != plans.end()) { *out = it->second; return SS_OK; }
         Fp *d_tw = nullptr;
         HIP_TRY(hipMalloc(&d_tw, ((1ull << log_n) > 1 ? (1ull << log_n) - 1 : 1) * NTT_PLAN_ENTRY_BYTES + 64));
-        ss_status st = build_plan(log_n, inverse, offset, d_tw);
+        ss_status st = build_plan(log_n, inverse, offset, d_tw, bitrev_levels);
         if (st != SS_OK) { (void)hipFree(d_tw); return st; }
         plans[key] = d_tw;
         *out = d_tw;
@@ -265,13 +266,22 @@ ss_status run_forward(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t
     for (size_t i = start; i < passes.size(); ++i) {
         const bool first = i == start;
         ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
-        HIP_TRY(launch_ntt_pass(ctx->stream, false, first ? cols : inplace, ncols, tw, log_n, passes[i].s0,
+        HIP_TRY(launch_ntt_pass(ctx->stream, NTT_MODE_DIT, first ? cols : inplace, ncols, tw, log_n, passes[i].s0,
                                 passes[i].r, log_tile, first ? skip : 0, first ? log_expand : 0, 0, i + 1 == passes.size()));
     }
     return SS_OK;
 }
+// The inverse transform's plan and stage network: over the subgroup itself (offset 1: every trace column) the Cooley-Tukey
+// network on a bit-reversed plan (NTT_MODE_CTI, ntt.hip), over a coset the Gentleman-Sande one (it folds h^-j into its twiddles).
+// SS_NTT_INVERSE_DIF=1: always the latter (A/B, and the parity tests run both).
+ss_status get_inverse_plan(ss_ctx *ctx, uint32_t log_n, const Fp &offset, const Fp **tw, int *mode) {
+    static const bool force_dif = getenv("SS_NTT_INVERSE_DIF") != nullptr;
+    const bool cti = fp_eq(offset, fp_one()) && !force_dif;
+    *mode = cti ? NTT_MODE_CTI : NTT_MODE_DIF;
+    return ctx->get_plan(log_n, true, offset, tw, cti);
+}
 // inverse: natural src -> bit-reversed dst, scaled by 1/n
-ss_status run_inverse(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t log_n, const Fp *tw) {
+ss_status run_inverse(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t log_n, const Fp *tw, int mode) {
     const uint32_t lt = (uint32_t)ntt_log_tile_max();
     const uint32_t log_tile = log_n < lt ? log_n : lt;
     std::vector<Pass> passes = plan_passes(log_n);
@@ -281,7 +291,7 @@ ss_status run_inverse(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t
         const bool first = i == passes.size() - 1;
         const bool last = i == 0;
         ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
-        HIP_TRY(launch_ntt_pass(ctx->stream, true, first ? cols : inplace, ncols, tw, log_n, passes[i].s0,
+        HIP_TRY(launch_ntt_pass(ctx->stream, mode, first ? cols : inplace, ncols, tw, log_n, passes[i].s0,
                                 passes[i].r, log_tile, 0, 0, last ? log_n : 0, last));
     }
     return SS_OK;
@@ -588,7 +598,8 @@ ss_status ss_ntt_fp252(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, uin
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const bool inverse = direction == SS_NTT_INVERSE;
     const Fp *tw = nullptr;
-    ss_status st = ctx->get_plan(log_n, inverse, off, &tw);
+    int inv_mode = NTT_MODE_DIF;
+    ss_status st = inverse ? get_inverse_plan(ctx, log_n, off, &tw, &inv_mode) : ctx->get_plan(log_n, false, off, &tw);
     if (st != SS_OK) return st;
     for (uint32_t base = 0; base < ncols; base += MAX_COLS) {
         const uint32_t nc = ncols - base < (uint32_t)MAX_COLS ? ncols - base : (uint32_t)MAX_COLS;
@@ -605,7 +616,7 @@ ss_status ss_ntt_fp252(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, uin
         } else {
             if (in_order == SS_ORDER_BITREV)
                 for (uint32_t c = 0; c < nc; ++c) HIP_TRY(launch_bitrev(ctx->stream, (Fp *)cols.dst[c], log_n));
-            st = run_inverse(ctx, cols, nc, log_n, tw);
+            st = run_inverse(ctx, cols, nc, log_n, tw, inv_mode);
             if (st != SS_OK) return st;
             if (out_order == SS_ORDER_NATURAL)
                 for (uint32_t c = 0; c < nc; ++c) HIP_TRY(launch_bitrev(ctx->stream, (Fp *)cols.dst[c], log_n));
@@ -623,7 +634,8 @@ ss_status ss_lde_fp252(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols,
         return fail(SS_ERR_INVALID, "NULL column");
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp *tw_inv = nullptr, *tw_fwd = nullptr;
-    ss_status st = ctx->get_plan(log_n, true, fp_one(), &tw_inv);
+    int inv_mode = NTT_MODE_DIF;
+    ss_status st = get_inverse_plan(ctx, log_n, fp_one(), &tw_inv, &inv_mode);
     if (st != SS_OK) return st;
     st = ctx->get_plan(log_n + log_blowup, false, off, &tw_fwd);
     if (st != SS_OK) return st;
@@ -638,7 +650,7 @@ ss_status ss_lde_fp252(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols,
             inv.src[c] = d_in[base + c]; inv.dst[c] = co;
             fwd.src[c] = co; fwd.dst[c] = d_evals[base + c];
         }
-        st = run_inverse(ctx, inv, nc, log_n, tw_inv);
+        st = run_inverse(ctx, inv, nc, log_n, tw_inv, inv_mode);
         if (st != SS_OK) return st;
         st = run_forward(ctx, fwd, nc, log_n + log_blowup, tw_fwd, log_blowup);
         if (st != SS_OK) return st;
@@ -1471,16 +1483,21 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
 
 // sub-coset values of a polynomial of degree < n (on offset * <w_n>, natural order) -> its evaluations over the LDE domain
 ss_status deep_extend(ss_ctx *ctx, Fp *d_sub, uint32_t log_n, uint32_t log_blowup, const Fp &off, uint64_t *d_out) {
+    // The values on off * <w_n> are those of Q(y) = P(off y) on <w_n>, and P(off w_2n^k) = Q(w_2n^k): interpolate and evaluate Q
+    // over the subgroups themselves (offset 1 on both sides - the inverse then runs the cheaper CTI network, and the
+    // coefficients in between, c_j off^j, are nobody else's).
+    (void)off;
     const Fp *tw_inv = nullptr, *tw_fwd = nullptr;
-    ss_status st = ctx->get_plan(log_n, true, off, &tw_inv);
+    int inv_mode = NTT_MODE_DIF;
+    ss_status st = get_inverse_plan(ctx, log_n, fp_one(), &tw_inv, &inv_mode);
     if (st != SS_OK) return st;
-    st = ctx->get_plan(log_n + log_blowup, false, off, &tw_fwd);
+    st = ctx->get_plan(log_n + log_blowup, false, fp_one(), &tw_fwd);
     if (st != SS_OK) return st;
     ColPtrs inv, fwd;
     memset(&inv, 0, sizeof inv); memset(&fwd, 0, sizeof fwd);
     inv.src[0] = d_sub; inv.dst[0] = d_sub;
     fwd.src[0] = d_sub; fwd.dst[0] = d_out;
-    st = run_inverse(ctx, inv, 1, log_n, tw_inv);
+    st = run_inverse(ctx, inv, 1, log_n, tw_inv, inv_mode);
     if (st != SS_OK) return st;
     return run_forward(ctx, fwd, 1, log_n + log_blowup, tw_fwd, log_blowup);
 }

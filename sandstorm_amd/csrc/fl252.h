@@ -102,6 +102,28 @@ SS_HD Fl fl_weak_reduce(const Fl &a) {
     return r;
 }
 
+// The same in ONE carry chain, for a transform pass's store (ntt.hip): any lazy value < 2^256 whose limbs 0..7 are below
+// 15 * 2^28 - 32 -> normalised limbs, value < 2^252 + 2^229 (top limb < 2^28 + 2^5).  The quotient is read off the
+// UN-normalised top limb, q = max(floor(l8 / 2^27) - 1, 0) <= floor(value / p), and value - q p is computed as
+// value - (q + 1) 2^251 + E with E = 2^251 - q (17 2^192 + 1) >= 0 written so that every limb is positive:
+//   e0 = 2^28 - q, e1..e5 = 2^28 - 1, e6 = 2^28 - 1 - (q & 15) 2^24, e7 = 2^28 - 1 - q - (q >> 4), e8 = 2^27 - 1
+// (q 2^192 = (q & 15) 2^24 2^168 + (q >> 4) 2^196), so the chain is unsigned adds, masks and shifts: no borrows, no
+// compares, 37 instead of 54 vector instructions.  The top limb is exact modulo 2^32 and the true result fits it.
+SS_HD Fl fl_weak_reduce1(const Fl &a) {
+    const u32 q0 = a.l[8] >> 27;
+    const u32 q = q0 ? q0 - 1u : 0u;
+    Fl r;
+    u32 t = a.l[0] + ((1u << 28) - q);
+    r.l[0] = t & FL_MASK;
+    u32 c = t >> 28;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) { t = a.l[i] + FL_MASK + c; r.l[i] = t & FL_MASK; c = t >> 28; }
+    t = a.l[6] + (FL_MASK - ((q & 15u) << 24)) + c; r.l[6] = t & FL_MASK; c = t >> 28;
+    t = a.l[7] + (FL_MASK - q - (q >> 4)) + c;      r.l[7] = t & FL_MASK; c = t >> 28;
+    r.l[8] = a.l[8] + ((1u << 27) - 1u) - ((q + 1u) << 27) + c;
+    return r;
+}
+
 // fully reduced 8 x 32 image (< p) of a lazy value < 32 p
 SS_HD Fp fl_to_fp(const Fl &a) {
     Fl w = fl_weak_reduce(a);                 // < 2p, normalised

@@ -21,11 +21,14 @@ struct ConstColPtrs {
 int ntt_log_tile_max();
 // bytes per twiddle-plan entry (R252 limb planes, ntt.hip); a plan of a size-2^log_n transform has 2^log_n - 1 entries
 static constexpr size_t NTT_PLAN_ENTRY_BYTES = 36;
-hipError_t launch_ntt_pass(hipStream_t st, bool dif, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
+// the three stage networks of ntt_pass_kernel: forward (bit-reversed in, natural out), inverse with Gentleman-Sande butterflies
+// (natural in, bit-reversed out; any coset), inverse over the subgroup with Cooley-Tukey butterflies (needs a PLAN_BITREV plan)
+enum { NTT_MODE_DIT = 0, NTT_MODE_DIF = 1, NTT_MODE_CTI = 2 };
+hipError_t launch_ntt_pass(hipStream_t st, int mode, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
                            uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first,
                            uint32_t log_expand, uint32_t scale_pow2, bool final_pass);
 hipError_t launch_twiddles(hipStream_t st, Fp *tw, const Fp *pow_lo, const Fp *pow_hi, const Fp *hpow,
-                           uint32_t log_n, bool h_is_one);
+                           uint32_t log_n, bool h_is_one, bool bitrev_levels);
 hipError_t launch_bitrev(hipStream_t st, Fp *a, uint32_t log_n);
 hipError_t launch_mul_bench(hipStream_t st, const Fp *a, const Fp *b, Fp *out, uint64_t n, uint32_t reps);
 hipError_t ntt_set_func_attributes();
