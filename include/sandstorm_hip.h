@@ -76,7 +76,7 @@ enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
 const char *ss_last_error(void);
 /* ABI version of this header; bump on any signature change.  ss_abi_version() of the loaded
  * library must equal SS_ABI_VERSION of the header the caller was built against. */
-#define SS_ABI_VERSION 7u
+#define SS_ABI_VERSION 8u
 uint32_t ss_abi_version(void);
 
 /* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;
@@ -149,6 +149,23 @@ ss_status ss_lde_fp252(ss_ctx *ctx, const uint64_t *const *d_in, uint32_t ncols,
  * over offset*<w>, natural order.  d_coeffs is not modified. */
 ss_status ss_evaluate_fp252(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t ncols, uint32_t log_n,
                             uint32_t log_blowup, const uint64_t offset[4], uint64_t *const *d_evals);
+
+/* ---- (e) ONE transform spread over R = 2^log_ranks GPUs (nothing in the reference to match: its
+ * Matrix::interpolate / evaluate run in one address space, src/lib.rs:17-26).  A rank holds the contiguous block
+ * [rank n/R, (rank+1) n/R) of the array.  The network's log2(n/R) stages that pair elements less than n/R apart never leave
+ * a block (part LOCAL: on the rank's block, a buffer of n/R felts); its log_ranks stages that pair element x of block b with
+ * element x of another block run after ONE equal-split all-to-all (ss_comm_exchange: chunk m of every block to rank m) has
+ * given rank m the x-range [m n/R^2, (m+1) n/R^2) of EVERY block, block after block in a buffer of n/R felts (part CROSS).
+ *   INVERSE (natural in, bit-reversed out, 1/n and offset^-j included):  CROSS on the exchanged layout, exchange back, LOCAL
+ *   FORWARD (bit-reversed in, natural out):  LOCAL on the block, exchange, CROSS; the caller exchanges back if it wants blocks.
+ * log_n = log2 of the WHOLE transform, n >= R^2.  log_expand (FORWARD LOCAL only): the block's input is the 2^-log_expand
+ * sub-sampled coefficient block (n/R >> log_expand felts in d_cols[c]; d_out[c]: n/R felts) - the zero-padded half of an
+ * LDE is not materialised.  d_out = NULL: in place.  Everything is bit-identical to ss_ntt_fp252 / ss_evaluate_fp252 on the
+ * gathered array (tests/test_gpu_parity.py::test_ntt_spread_over_ranks). */
+enum { SS_NTT_PART_LOCAL = 0, SS_NTT_PART_CROSS = 1 };
+ss_status ss_ntt_shard_fp252(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, uint32_t log_n, uint32_t log_ranks,
+                             uint32_t rank, int direction, const uint64_t offset[4], int part, uint32_t log_expand,
+                             uint64_t *const *d_out);
 
 /* ---- H1: crypto/src/merkle/utils.rs:19-46 hash_rows::<H>.
  * d_digests[r] = H::hash_elements(row r) for r < nrows; rows are read in
@@ -359,6 +376,13 @@ enum { SS_FRI_BITREV_ROWS = 1, SS_FRI_UNNORMALISED = 2 };
 ss_status ss_fri_fold_ex(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
                          const uint64_t alpha[4], const uint64_t domain_offset[4], uint32_t flags,
                          uint64_t *d_out);
+
+/* `count` rows of a layer from row `row0` on (one FRI layer folded by several GPUs): d_evals holds the
+ * rows' `fold` entries column after column, entry k of row row0 + i at d_evals[k * count + i] (= the layer's
+ * evals[row0 + i + k * len/fold]); d_out[i] = the fold of row row0 + i.  Natural order only (no SS_FRI_BITREV_ROWS). */
+ss_status ss_fri_fold_rows(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
+                           const uint64_t alpha[4], const uint64_t domain_offset[4], uint32_t flags,
+                           uint64_t row0, uint64_t count, uint64_t *d_out);
 
 /* ---- C2: PublicCoin::grind_proof_of_work (crypto/src/public_coin/
  *      solidity.rs:120-141, cairo.rs:133-154).  Returns the SMALLEST nonce >= 1

@@ -77,6 +77,7 @@ SIGNATURES = {
     "ss_ntt_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_int, _u64p, C.c_int, C.c_int]),
     "ss_lde_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _vpp, _vpp]),
     "ss_evaluate_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _vpp]),
+    "ss_ntt_shard_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _u64p, C.c_int, C.c_uint32, _vpp]),
     "ss_hash_rows": (C.c_int, [C.c_void_p, C.c_int, _vpp, C.c_uint32, C.c_uint64, C.c_void_p]),
     "ss_hash_rows_ex": (C.c_int, [C.c_void_p, C.c_int, _vpp, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]),
     "ss_merkle_build": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64,
@@ -114,6 +115,7 @@ SIGNATURES = {
                                          C.c_uint32, _u64p, _u64p, _u64p, _u64p, _u64p, _u64p, C.c_void_p]),
     "ss_fri_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _u64p, _u64p, C.c_void_p]),
     "ss_fri_fold_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _u64p, _u64p, C.c_uint32, C.c_void_p]),
+    "ss_fri_fold_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _u64p, _u64p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
     "ss_pow_grind": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_uint32, _u64p]),
     "ss_pedersen_hash": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "ss_pedersen_hash_host": (C.c_int, [_u64p, _u64p, _u64p]),

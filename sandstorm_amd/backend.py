@@ -27,6 +27,7 @@ R = 2**256
 NATURAL, BITREV = 0, 1
 FRI_BITREV_ROWS, FRI_UNNORMALISED = 1, 2
 FORWARD, INVERSE = 0, 1
+NTT_PART_LOCAL, NTT_PART_CROSS = 0, 1
 HASH_KECCAK, HASH_KECCAK_M20, HASH_BLAKE2S, HASH_BLAKE2S_M20 = 0, 1, 2, 3
 TREE_KECCAK, TREE_KECCAK_M20, TREE_FRIENDLY, TREE_BLAKE2S = 0, 1, 2, 3
 LEAF_DIGEST, LEAF_FELT = 0, 1
@@ -170,6 +171,12 @@ class Context:
         check(self.lib.ss_evaluate_fp252(self.handle, _ptr_array(coeff_cols), len(coeff_cols), log_n, log_blowup,
                                          off, _ptr_array(evals_out)))
 
+    def ntt_shard(self, cols, log_n, log_ranks, rank, direction, offset, part, log_expand=0, out=None):
+        """ss_ntt_shard_fp252: this rank's share (part LOCAL / CROSS) of ONE transform of 2^log_n points spread over 2^log_ranks ranks"""
+        _keep, off = _felt_ptr(offset)
+        check(self.lib.ss_ntt_shard_fp252(self.handle, _ptr_array(cols), len(cols), log_n, log_ranks, rank, direction, off, part, log_expand,
+                                          _ptr_array(out) if out else None))
+
     def hash_rows(self, kind, cols, nrows, out, order=NATURAL):
         """order=BITREV: digest i is the hash of row bitrev(i) - the reference's commitment order"""
         check(self.lib.ss_hash_rows_ex(self.handle, kind, _ptr_array(cols), len(cols), nrows, order, _ptr_of(out)))
@@ -206,6 +213,12 @@ class Context:
         _k1, a = _felt_ptr(alpha)
         _k2, o = _felt_ptr(offset)
         check(self.lib.ss_fri_fold_ex(self.handle, _ptr_of(evals), log_len, fold, a, o, flags, _ptr_of(out)))
+
+    def fri_fold_rows(self, evals, log_len, fold, alpha, offset, row0, count, out, flags=0):
+        """ss_fri_fold_rows: rows row0 .. row0 + count of a layer, entry k of row row0 + i at evals[k * count + i]"""
+        _k1, a = _felt_ptr(alpha)
+        _k2, o = _felt_ptr(offset)
+        check(self.lib.ss_fri_fold_rows(self.handle, _ptr_of(evals), log_len, fold, a, o, flags, row0, count, _ptr_of(out)))
 
     # ---- X4: the 64-bit field (p = 2^64 - 2^32 + 1) and its cubic extension
     def ntt_gl64(self, cols, log_n, direction=FORWARD, offset=1, in_order=NATURAL, out_order=NATURAL):

@@ -249,7 +249,7 @@ std::vector<Pass> plan_passes(uint32_t log_n) {
 
 // forward: bit-reversed (optionally 2^-log_expand sub-sampled) src -> natural dst
 ss_status run_forward(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t log_n, const Fp *tw,
-                      uint32_t log_expand) {
+                      uint32_t log_expand, bool canonical_out = true) {
     const uint32_t lt = (uint32_t)ntt_log_tile_max();
     const uint32_t log_tile = log_n < lt ? log_n : lt;
     std::vector<Pass> passes = plan_passes(log_n);
@@ -267,7 +267,7 @@ ss_status run_forward(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t
         const bool first = i == start;
         ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
         HIP_TRY(launch_ntt_pass(ctx->stream, NTT_MODE_DIT, first ? cols : inplace, ncols, tw, log_n, passes[i].s0,
-                                passes[i].r, log_tile, first ? skip : 0, first ? log_expand : 0, 0, i + 1 == passes.size()));
+                                passes[i].r, log_tile, first ? skip : 0, first ? log_expand : 0, 0, canonical_out && i + 1 == passes.size()));
     }
     return SS_OK;
 }
@@ -280,8 +280,11 @@ ss_status get_inverse_plan(ss_ctx *ctx, uint32_t log_n, const Fp &offset, const 
     *mode = cti ? NTT_MODE_CTI : NTT_MODE_DIF;
     return ctx->get_plan(log_n, true, offset, tw, cti);
 }
-// inverse: natural src -> bit-reversed dst, scaled by 1/n
-ss_status run_inverse(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t log_n, const Fp *tw, int mode) {
+// inverse: natural src -> bit-reversed dst, scaled by 1/n (2^-scale_log: the local part of a transform spread over several ranks
+// scales by the whole transform's size); cti_trivial: the CTI plan's offset is one
+ss_status run_inverse(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t log_n, const Fp *tw, int mode,
+                      uint32_t scale_log = ~0u, bool cti_trivial = true) {
+    if (scale_log == ~0u) scale_log = log_n;
     const uint32_t lt = (uint32_t)ntt_log_tile_max();
     const uint32_t log_tile = log_n < lt ? log_n : lt;
     std::vector<Pass> passes = plan_passes(log_n);
@@ -292,7 +295,7 @@ ss_status run_inverse(ss_ctx *ctx, const ColPtrs &cols, uint32_t ncols, uint32_t
         const bool last = i == 0;
         ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
         HIP_TRY(launch_ntt_pass(ctx->stream, mode, first ? cols : inplace, ncols, tw, log_n, passes[i].s0,
-                                passes[i].r, log_tile, 0, 0, last ? log_n : 0, last));
+                                passes[i].r, log_tile, 0, 0, last ? scale_log : 0, last, cti_trivial));
     }
     return SS_OK;
 }
@@ -304,7 +307,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL)
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -678,6 +681,69 @@ ss_status ss_evaluate_fp252(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32
     return SS_OK;
 }
 
+// One rank's share of ONE transform spread over R = 2^log_ranks ranks (include/sandstorm_hip.h; host/sharded.cpp).
+ss_status ss_ntt_shard_fp252(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, uint32_t log_n, uint32_t log_ranks, uint32_t rank,
+                             int direction, const uint64_t offset[4], int part, uint32_t log_expand, uint64_t *const *d_out) {
+    if (!ctx || !d_cols) return fail(SS_ERR_INVALID, "NULL argument");
+    if (direction != SS_NTT_FORWARD && direction != SS_NTT_INVERSE) return fail(SS_ERR_INVALID, "bad direction");
+    if (part != SS_NTT_PART_LOCAL && part != SS_NTT_PART_CROSS) return fail(SS_ERR_INVALID, "bad part");
+    if (!valid_log(log_n) || log_ranks == 0 || 2 * log_ranks > log_n || log_ranks > 7) return fail(SS_ERR_INVALID, "a transform of 2^%u points does not split over 2^%u ranks (needs n >= R^2)", log_n, log_ranks);
+    if (rank >> log_ranks) return fail(SS_ERR_INVALID, "rank %u of %u", rank, 1u << log_ranks);
+    if (ncols == 0 || ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_INVALID, "1..%d columns per call", MAX_COLS);
+    if (has_null((const void *const *)d_cols, ncols) || (d_out && has_null((const void *const *)d_out, ncols))) return fail(SS_ERR_INVALID, "NULL column");
+    const bool inverse = direction == SS_NTT_INVERSE, local = part == SS_NTT_PART_LOCAL;
+    if (log_expand && (inverse || !local)) return fail(SS_ERR_INVALID, "log_expand belongs to the local part of a forward transform");
+    if (log_expand >= log_n - log_ranks && log_expand) return fail(SS_ERR_INVALID, "log_expand %u too large", log_expand);
+    const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
+    const uint32_t log_local = log_n - log_ranks;
+    ColPtrs cols;
+    memset(&cols, 0, sizeof cols);
+    for (uint32_t c = 0; c < ncols; ++c) { cols.src[c] = d_cols[c]; cols.dst[c] = d_out ? d_out[c] : d_cols[c]; }
+    static const bool force_dif = getenv("SS_NTT_INVERSE_DIF") != nullptr;
+    const bool cti = inverse && fp_eq(off, fp_one()) && !force_dif;
+    const Fp *tw = nullptr;
+    if (local) {
+        // Stage s < log_local of the whole network pairs elements of ONE block and its twiddle only reads the index bits below s:
+        // on a block the local stages ARE a whole transform of 2^log_local points - DIT / DIF: over the coset offset^R
+        // (T_s[k] = offset^(n / 2^(s+1)) w_n^(k n / 2^(s+1)) either way); CTI: the remainder tree below node `rank` of level
+        // log_ranks, whose modulus is x^(n/R) - c^(n/R) with c = w_n^-bitrev(rank): the smaller tree's twiddles times c^(2^s),
+        // which is what a bit-reversed plan built for the offset c^-1 holds.
+        if (!inverse) {
+            Fp h = off;
+            for (uint32_t i = 0; i < log_ranks; ++i) h = fp_sqr(h);
+            ss_status st = ctx->get_plan(log_local, false, h, &tw);
+            if (st != SS_OK) return st;
+            return run_forward(ctx, cols, ncols, log_local, tw, log_expand, false);
+        }
+        if (cti) {
+            uint32_t br = 0;
+            for (uint32_t i = 0; i < log_ranks; ++i) br |= ((rank >> i) & 1u) << (log_ranks - 1 - i);
+            const Fp c_inv = fp_pow_u64(root_of_unity(log_n), br);
+            ss_status st = ctx->get_plan(log_local, true, c_inv, &tw, true);
+            if (st != SS_OK) return st;
+            return run_inverse(ctx, cols, ncols, log_local, tw, NTT_MODE_CTI, log_n, br == 0);
+        }
+        Fp h = off;
+        for (uint32_t i = 0; i < log_ranks; ++i) h = fp_sqr(h);
+        ss_status st = ctx->get_plan(log_local, true, h, &tw);
+        if (st != SS_OK) return st;
+        return run_inverse(ctx, cols, ncols, log_local, tw, NTT_MODE_DIF, log_n);
+    }
+    // the top log_ranks stages: one windowed pass over the rank's share of every row (ntt.hip PassParams), twiddles from the
+    // whole transform's plan
+    ss_status st = inverse ? ctx->get_plan(log_n, true, off, &tw, cti) : ctx->get_plan(log_n, false, off, &tw);
+    if (st != SS_OK) return st;
+    NttWindow win;
+    win.log_len = log_local - log_ranks;
+    win.first = rank << win.log_len;
+    const uint32_t lt = (uint32_t)ntt_log_tile_max();
+    const uint32_t log_t = win.log_len < lt - log_ranks ? win.log_len : lt - log_ranks;
+    ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
+    HIP_TRY(launch_ntt_pass(ctx->stream, inverse ? (cti ? NTT_MODE_CTI : NTT_MODE_DIF) : NTT_MODE_DIT, cols, ncols, tw, log_n, log_local, log_ranks,
+                            log_ranks + log_t, 0, 0, 0, !inverse, true, &win));
+    return SS_OK;
+}
+
 // --------------------------------------------------------------- hashing
 ss_status ss_hash_rows(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_cols, uint32_t ncols,
                        uint64_t nrows, uint8_t *d_digests) {
@@ -841,14 +907,21 @@ ss_status ss_fri_fold(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, ui
                       const uint64_t alpha[4], const uint64_t domain_offset[4], uint64_t *d_out) {
     return ss_fri_fold_ex(ctx, d_evals, log_len, fold, alpha, domain_offset, 0, d_out);
 }
-ss_status ss_fri_fold_ex(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
-                         const uint64_t alpha[4], const uint64_t domain_offset[4], uint32_t flags, uint64_t *d_out) {
+static ss_status fri_fold_impl(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold, const uint64_t alpha[4],
+                               const uint64_t domain_offset[4], uint32_t flags, bool whole, uint64_t row0, uint64_t count, uint64_t *d_out) {
     if (!ctx || !d_evals || !alpha || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
     if (flags & ~(uint32_t)(SS_FRI_BITREV_ROWS | SS_FRI_UNNORMALISED)) return fail(SS_ERR_INVALID, "unknown FRI flags %u", flags);
     uint32_t log_fold = 0;
     while ((1u << log_fold) < fold) ++log_fold;
     if ((1u << log_fold) != fold || log_fold < 1 || log_fold > 4) return fail(SS_ERR_INVALID, "fold must be 2, 4, 8 or 16");
     if (!valid_log(log_len) || log_len < log_fold) return fail(SS_ERR_INVALID, "log_len out of range");
+    const uint64_t rows = (1ull << log_len) >> log_fold;
+    if (whole) { row0 = 0; count = rows; }
+    else {
+        if (flags & SS_FRI_BITREV_ROWS) return fail(SS_ERR_UNSUPPORTED, "a row range of a layer in bit-reversed order");
+        if (row0 > rows || count > rows - row0) return fail(SS_ERR_INVALID, "rows %llu .. +%llu of %llu", (unsigned long long)row0, (unsigned long long)count, (unsigned long long)rows);
+        if (!count) return SS_OK;
+    }
     const Fp off = domain_offset ? fp_from_limbs64(domain_offset) : fp_one();
     const Fp w_inv = fp_inv(root_of_unity(log_len));
     const Fp wf_inv = fp_inv(root_of_unity(log_fold));
@@ -857,8 +930,16 @@ ss_status ss_fri_fold_ex(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len,
     for (int k = 1; k < 8; ++k) tw[k] = fp_mul(tw[k - 1], wf_inv);
     ss_ctx::Scope prof(ctx, SS_PROF_FRI);
     HIP_TRY(launch_fri_fold(ctx->stream, (const Fp *)d_evals, log_len, log_fold, fp_from_limbs64(alpha),
-                            fp_inv(off), w_inv, tw, flags, (Fp *)d_out));
+                            fp_inv(off), w_inv, tw, flags, (Fp *)d_out, row0, count));
     return SS_OK;
+}
+ss_status ss_fri_fold_ex(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
+                         const uint64_t alpha[4], const uint64_t domain_offset[4], uint32_t flags, uint64_t *d_out) {
+    return fri_fold_impl(ctx, d_evals, log_len, fold, alpha, domain_offset, flags, true, 0, 0, d_out);
+}
+ss_status ss_fri_fold_rows(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold, const uint64_t alpha[4],
+                           const uint64_t domain_offset[4], uint32_t flags, uint64_t row0, uint64_t count, uint64_t *d_out) {
+    return fri_fold_impl(ctx, d_evals, log_len, fold, alpha, domain_offset, flags, false, row0, count, d_out);
 }
 
 // ------------------------------------------------------------------- PoW

@@ -68,19 +68,20 @@ __device__ __forceinline__ void fri_stage(Fp (&v)[1 << LOGF], const FriConsts &c
 
 template <int LOGF>
 __global__ __launch_bounds__(128) void fri_fold_kernel(const Fp *__restrict__ evals, uint32_t log_len,
-                                                       FriConsts c, Fp *__restrict__ out) {
+                                                       FriConsts c, Fp *__restrict__ out, uint64_t row0, uint64_t rows) {
+    // rows row0 .. row0 + rows of the layer, entry k of row row0 + i at evals[i + k * rows] (the whole layer: row0 = 0, rows = len / fold)
     constexpr int F = 1 << LOGF;
-    const uint64_t rows = (1ull << log_len) >> LOGF;
-    const uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (j >= rows) return;
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const uint64_t j = row0 + i;
     const bool bitrev_rows = (c.flags & SS_FRI_BITREV_ROWS) != 0;
     Fp v[F];                                         // v[k] = f(x_j w_fold^k)
     if (bitrev_rows) {
 #pragma unroll
-        for (int k = 0; k < F; ++k) v[k] = fri_load(evals + j * F + brev_c(k, LOGF));
+        for (int k = 0; k < F; ++k) v[k] = fri_load(evals + i * F + brev_c(k, LOGF));
     } else {
 #pragma unroll
-        for (int k = 0; k < F; ++k) v[k] = fri_load(evals + j + (uint64_t)k * rows);
+        for (int k = 0; k < F; ++k) v[k] = fri_load(evals + i + (uint64_t)k * rows);
     }
     // unnormalised inverse NTT, DIF: natural in, bit-reversed out
     if (LOGF >= 4) fri_stage<LOGF, 3>(v, c);
@@ -96,23 +97,23 @@ __global__ __launch_bounds__(128) void fri_fold_kernel(const Fp *__restrict__ ev
 #pragma unroll
     for (int m = F - 2; m >= 0; --m) acc = fp_add(fp_mul(acc, t), v[brev_c(m, LOGF)]);
     // the butterflies above are an unnormalised inverse NTT: acc = fold * interpolant(alpha)
-    fri_store(out + j, (c.flags & SS_FRI_UNNORMALISED) ? acc : fp_div_pow2(acc, LOGF));
+    fri_store(out + i, (c.flags & SS_FRI_UNNORMALISED) ? acc : fp_div_pow2(acc, LOGF));
 }
 
 hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, uint32_t log_fold,
                            const Fp &alpha, const Fp &offset_inv, const Fp &w_inv, const Fp *fold_tw_inv,
-                           uint32_t flags, Fp *out) {
+                           uint32_t flags, Fp *out, uint64_t row0, uint64_t count) {
     FriConsts c;
     c.flags = flags;
     c.alpha = alpha; c.offset_inv = offset_inv; c.w_inv = w_inv;
     for (int k = 0; k < 8; ++k) c.tw_inv[k] = k < (1 << log_fold) / 2 ? fold_tw_inv[k] : fp_zero();
-    const uint64_t rows = (1ull << log_len) >> log_fold;
+    const uint64_t rows = count;
     dim3 grid((uint32_t)((rows + 127) / 128)), block(128);
     switch (log_fold) {
-    case 1: hipLaunchKernelGGL(fri_fold_kernel<1>, grid, block, 0, st, evals, log_len, c, out); break;
-    case 2: hipLaunchKernelGGL(fri_fold_kernel<2>, grid, block, 0, st, evals, log_len, c, out); break;
-    case 3: hipLaunchKernelGGL(fri_fold_kernel<3>, grid, block, 0, st, evals, log_len, c, out); break;
-    case 4: hipLaunchKernelGGL(fri_fold_kernel<4>, grid, block, 0, st, evals, log_len, c, out); break;
+    case 1: hipLaunchKernelGGL(fri_fold_kernel<1>, grid, block, 0, st, evals, log_len, c, out, row0, rows); break;
+    case 2: hipLaunchKernelGGL(fri_fold_kernel<2>, grid, block, 0, st, evals, log_len, c, out, row0, rows); break;
+    case 3: hipLaunchKernelGGL(fri_fold_kernel<3>, grid, block, 0, st, evals, log_len, c, out, row0, rows); break;
+    case 4: hipLaunchKernelGGL(fri_fold_kernel<4>, grid, block, 0, st, evals, log_len, c, out, row0, rows); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

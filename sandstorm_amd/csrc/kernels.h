@@ -24,9 +24,12 @@ static constexpr size_t NTT_PLAN_ENTRY_BYTES = 36;
 // the three stage networks of ntt_pass_kernel: forward (bit-reversed in, natural out), inverse with Gentleman-Sande butterflies
 // (natural in, bit-reversed out; any coset), inverse over the subgroup with Cooley-Tukey butterflies (needs a PLAN_BITREV plan)
 enum { NTT_MODE_DIT = 0, NTT_MODE_DIF = 1, NTT_MODE_CTI = 2 };
+// a windowed top pass (ntt.hip PassParams): this rank's 2^log_len elements q >= first of every row
+struct NttWindow { uint32_t first, log_len; };
 hipError_t launch_ntt_pass(hipStream_t st, int mode, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
                            uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first,
-                           uint32_t log_expand, uint32_t scale_pow2, bool final_pass);
+                           uint32_t log_expand, uint32_t scale_pow2, bool final_pass, bool cti_trivial = true,
+                           const NttWindow *win = nullptr);
 hipError_t launch_twiddles(hipStream_t st, Fp *tw, const Fp *pow_lo, const Fp *pow_hi, const Fp *hpow,
                            uint32_t log_n, bool h_is_one, bool bitrev_levels);
 hipError_t launch_bitrev(hipStream_t st, Fp *a, uint32_t log_n);
@@ -71,9 +74,10 @@ hipError_t launch_pedersen_felt_pairs(hipStream_t st, const PedersenTables *t, c
 Fp pedersen_hash_host(const Fp &a, const Fp &b);
 
 // ---- fri.hip
+// rows row0 .. row0 + count of the layer, entry k of row row0 + i at evals[i + k * count] (the whole layer: 0, len / fold)
 hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, uint32_t log_fold,
                            const Fp &alpha, const Fp &offset_inv, const Fp &w_inv, const Fp *fold_tw_inv,
-                           uint32_t flags, Fp *out);
+                           uint32_t flags, Fp *out, uint64_t row0, uint64_t count);
 
 // ---- deep.hip
 hipError_t launch_poly_reduce(hipStream_t st, const void *const *in, void *const *out, uint32_t ncols,

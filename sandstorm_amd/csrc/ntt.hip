@@ -179,7 +179,19 @@ struct PassParams {
                           // 0: outputs are weakly reduced 256-bit images (< 2^252) for the next pass
     uint32_t ncols;       // columns of the batch (grid = tiles * ncols workgroups)
     uint32_t xcd_map;     // 1: the ncols workgroups of one tile are consecutive on ONE XCD (see the kernel)
+    uint32_t log_tiles;   // tiles of this launch (2^log_tiles): all of the transform's, or those of a window (below)
+    uint32_t tile0;       // first tile of the launch
+    // A WINDOWED top pass (s0 + r == log_n; one transform spread over several GPUs, sharded.cpp): this rank holds, of every one
+    // of the 2^r rows j, the elements q in [win0, win0 + 2^win_log) - stored row after row: element (j, q) of the transform,
+    // global index (j << s0) | q, lives at (j << win_log) + (q - win0) of the column's buffer.  win_log1 = win_log + 1, 0 = off.
+    uint32_t win_log1, win0;
+    uint32_t cti_trivial; // CTI: the plan's offset is one, so zeta = 1 at the root and the left node of level 1 (radix_stage)
 };
+// where element g of the transform lives in the column's buffer
+__device__ __forceinline__ uint32_t mem_index(const PassParams &p, uint32_t g) {
+    if (!p.win_log1) return g;
+    return ((g >> p.s0) << (p.win_log1 - 1u)) + ((g & ((1u << p.s0) - 1u)) - p.win0);
+}
 
 // the plan's three planes (limbs 0-3, limbs 4-7, limb 8) of n - 1 entries each
 struct TwPlanes {
@@ -240,8 +252,8 @@ __device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const TwPlanes &tw,
     }
     // CTI: the transform's first two levels (the top register group of its first pass) have zeta = 1 at the root and at the
     // left node of level 1; (wave-uniform branch)
-    const bool lvl0 = MODE == MODE_CTI && top_group && s + 1u == p.log_n;
-    const bool lvl1 = MODE == MODE_CTI && top_group && s + 2u == p.log_n;
+    const bool lvl0 = MODE == MODE_CTI && top_group && p.cti_trivial && s + 1u == p.log_n;
+    const bool lvl1 = MODE == MODE_CTI && top_group && p.cti_trivial && s + 2u == p.log_n;
 #pragma unroll
     for (int pr = 0; pr < (1 << G) / 2; ++pr) {
         const int m = ((pr >> STC) << (STC + 1)) | (pr & ((1 << STC) - 1));
@@ -321,7 +333,9 @@ __device__ __forceinline__ void radix_group(const Tile &t, const TwPlanes &tw, c
     LdsAddr am[1 << G];
 #pragma unroll
     for (int m = 0; m < (1 << G); ++m) am[m] = lds_addr<LG>((uint32_t)m << sh);
-    const size_t src_step = ((size_t)1 << gsh) >> p.log_expand, dst_step = (size_t)1 << gsh;
+    // element m of a group: global index g0 + (m << gsh); in the buffer + m * step (a window stores row j = g >> s0 at j << win_log)
+    const size_t dst_step = p.win_log1 ? (size_t)1 << (u + p.win_log1 - 1u) : (size_t)1 << gsh;
+    const size_t src_step = p.win_log1 ? dst_step : ((size_t)1 << gsh) >> p.log_expand;
     for (uint32_t tau = threadIdx.x; tau < items; tau += blockDim.x) {
         const uint32_t low = tau & ((1u << sh) - 1u);
         const uint32_t high = tau >> sh;
@@ -330,7 +344,7 @@ __device__ __forceinline__ void radix_group(const Tile &t, const TwPlanes &tw, c
         const LdsAddr ab = lds_addr<LG>(ebase);
         Fl x[1 << G];
         if (from_global) {
-            const Fp *sp = src + (g0 >> p.log_expand);
+            const Fp *sp = src + (mem_index(p, g0) >> p.log_expand);
 #pragma unroll
             for (int m = 0; m < (1 << G); ++m) x[m] = fl_from_fp(gload(sp + (size_t)m * src_step));
         } else {
@@ -347,7 +361,7 @@ __device__ __forceinline__ void radix_group(const Tile &t, const TwPlanes &tw, c
             if (G >= 3) radix_stage<MODE, G, 2>(x, tw, p, u, g0, top_group);
         }
         if (to_global) {
-            Fp *dp = dst + g0;
+            Fp *dp = dst + mem_index(p, g0);
 #pragma unroll
             for (int m = 0; m < (1 << G); ++m)     // DIF: odd outputs of the group's last stage are fresh products (normalised, < 2^252)
                 gstore(dp + (size_t)m * dst_step, pass_output<MODE>(p, x[m], DIF && (m & 1)));
@@ -385,10 +399,10 @@ void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw_plan, PassParams p)
         col = rem >> 3;
         tile = (grp << 3) | (rem & 7u);
     } else {
-        const uint32_t tiles = 1u << (p.log_n - p.log_tile);
-        col = blockIdx.x >> (p.log_n - p.log_tile);
-        tile = blockIdx.x & (tiles - 1u);
+        col = blockIdx.x >> p.log_tiles;
+        tile = blockIdx.x & ((1u << p.log_tiles) - 1u);
     }
+    tile += p.tile0;
     // select this block's column with scalar compares: a dynamically indexed by-value
     // kernarg struct would be copied to scratch
     const void *src_v = cols.src[0];
@@ -404,7 +418,7 @@ void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw_plan, PassParams p)
     const bool fuse = !p.contig;
     if (!fuse) {
         for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x)
-            lds_store(t, lds_addr<LG>(x), fl_from_fp(gload(src + (tile_gindex(p, tile, x) >> p.log_expand))));
+            lds_store(t, lds_addr<LG>(x), fl_from_fp(gload(src + (mem_index(p, tile_gindex(p, tile, x)) >> p.log_expand))));
         NTT_SYNC();
     }
 
@@ -441,7 +455,7 @@ void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw_plan, PassParams p)
 
     if (!fuse) {
         for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x)
-            gstore(dst + tile_gindex(p, tile, x), pass_output<MODE>(p, lds_load(t, lds_addr<LG>(x)), false));
+            gstore(dst + mem_index(p, tile_gindex(p, tile, x)), pass_output<MODE>(p, lds_load(t, lds_addr<LG>(x)), false));
     }
 }
 
@@ -503,12 +517,22 @@ __global__ void mul_bench_kernel(const Fp *__restrict__ a, const Fp *__restrict_
 // ------------------------------------------------------------ host launch
 hipError_t launch_ntt_pass(hipStream_t st, int mode, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
                            uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first,
-                           uint32_t log_expand, uint32_t scale_pow2, bool final_pass) {
+                           uint32_t log_expand, uint32_t scale_pow2, bool final_pass, bool cti_trivial, const NttWindow *win) {
     PassParams p;
     p.final_pass = final_pass ? 1u : 0u;
     p.log_n = log_n; p.s0 = s0; p.r = r; p.log_tile = log_tile; p.u_first = u_first;
     p.log_expand = log_expand; p.scale_pow2 = scale_pow2; p.contig = (s0 == 0);
-    const uint32_t tiles = 1u << (log_n - log_tile);
+    p.cti_trivial = cti_trivial ? 1u : 0u;
+    p.log_tiles = log_n - log_tile; p.tile0 = 0; p.win_log1 = 0; p.win0 = 0;
+    if (win) {                                   // the tiles of the window only; a tile = 2^r rows x 2^(log_tile - r) adjacent q
+        const uint32_t log_t = log_tile - r;
+        if (s0 + r != log_n || s0 == 0 || log_expand || win->log_len < log_t || (win->first & ((1u << win->log_len) - 1u))) return hipErrorInvalidValue;
+        p.log_tiles = win->log_len - log_t;
+        p.tile0 = win->first >> log_t;
+        p.win_log1 = win->log_len + 1u;
+        p.win0 = win->first;
+    }
+    const uint32_t tiles = 1u << p.log_tiles;
     static const bool no_xcd_map = getenv("SS_NTT_NO_XCD_MAP") != nullptr;        // A/B switch for profiling
     p.ncols = ncols;
     p.xcd_map = (tiles >= 8 && ncols > 1 && !no_xcd_map) ? 1u : 0u;

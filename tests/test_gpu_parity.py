@@ -121,6 +121,69 @@ def test_ntt_many_columns(ctx, be, oracle):
         assert np.array_equal(got[c], oracle.ntt(cols[c], offset=g3(oracle))), c
 
 
+def _exchange(parts, R):
+    """the equal-split all-to-all between the block layout and the exchanged one (its own inverse): chunk m of rank t's buffer
+    becomes chunk t of rank m's"""
+    chunk = parts[0].shape[0] // R
+    return [np.concatenate([parts[t][m * chunk:(m + 1) * chunk] for t in range(R)]) for m in range(R)]
+
+
+@pytest.mark.parametrize("log_n,log_ranks", [(2, 1), (4, 2), (6, 3), (7, 1), (9, 2), (10, 3), (12, 1), (13, 3), (14, 2), (16, 3)])
+@pytest.mark.parametrize("coset", [False, True])
+def test_ntt_spread_over_ranks(ctx, be, oracle, log_n, log_ranks, coset):
+    """ss_ntt_shard_fp252: ONE transform over R ranks - local stages on blocks, the cross stages on the exchanged layout (here the
+    ranks are buffers of one device and the all-to-all is numpy) - is ss_ntt_fp252 on the gathered array, bit for bit: the
+    inverse (natural in, bit-reversed out; the Cooley-Tukey tree over the subgroup, Gentleman-Sande over a coset) and the
+    forward transform from the bit-reversed coefficients, with and without the LDE's zero padding"""
+    n, R = 1 << log_n, 1 << log_ranks
+    off = g3(oracle) if coset else None
+    col = random_column(n, 40 + log_n)
+    evals = oracle.ntt(col, offset=off)                      # natural order
+    # inverse: blocks of evaluations -> blocks of bit-reversed coefficients
+    parts = _exchange(np.split(evals, R), R)
+    bufs = _up(ctx, parts)
+    for m in range(R):
+        ctx.ntt_shard([bufs[m]], log_n, log_ranks, m, be.INVERSE, off, be.NTT_PART_CROSS)
+    parts = _exchange(_down(bufs, n // R), R)
+    bufs = _up(ctx, parts)
+    for r in range(R):
+        ctx.ntt_shard([bufs[r]], log_n, log_ranks, r, be.INVERSE, off, be.NTT_PART_LOCAL)
+    coeff_br = np.concatenate(_down(bufs, n // R))
+    assert np.array_equal(coeff_br, oracle.bitrev_permute(col))
+    # forward from them, and the LDE's forward half (twice the points, the zero padding never stored)
+    for log_expand in (0, 1):
+        N, log_N = n << log_expand, log_n + log_expand
+        want = oracle.ntt(np.concatenate([col, np.zeros_like(col)]), offset=off) if log_expand else evals
+        src = _up(ctx, np.split(coeff_br, R))
+        dst = [ctx.alloc(32 * (N // R)) for _ in range(R)]
+        for r in range(R):
+            ctx.ntt_shard([src[r]], log_N, log_ranks, r, be.FORWARD, off, be.NTT_PART_LOCAL, log_expand, [dst[r]])
+        bufs = _up(ctx, _exchange(_down(dst, N // R), R))
+        for m in range(R):
+            ctx.ntt_shard([bufs[m]], log_N, log_ranks, m, be.FORWARD, off, be.NTT_PART_CROSS)
+        got = np.concatenate(_exchange(_down(bufs, N // R), R))
+        assert np.array_equal(got, want), log_expand
+
+
+def test_fri_fold_rows_of_a_layer(ctx, be, oracle):
+    """ss_fri_fold_rows: a layer folded range by range (each range's entries column after column) is the layer folded whole"""
+    log_len, fold = 12, 8
+    n, rows = 1 << log_len, (1 << log_len) // 8
+    ev = random_column(n, 77)
+    alpha, off = oracle.to_mont([987654321])[0], g3(oracle)
+    for flags in (0, be.FRI_UNNORMALISED):
+        want = oracle.fri_fold(ev, fold, alpha, off, flags)
+        for R in (1, 2, 4, 8):
+            cnt = rows // R
+            got = []
+            for m in range(R):
+                local = np.concatenate([ev[k * rows + m * cnt:k * rows + (m + 1) * cnt] for k in range(fold)])
+                d, out = ctx.column(local), ctx.alloc(32 * cnt)
+                ctx.fri_fold_rows(d, log_len, fold, alpha, off, m * cnt, cnt, out, flags)
+                got.append(out.download(np.uint64, (cnt, 4)))
+            assert np.array_equal(np.concatenate(got), want), (flags, R)
+
+
 @pytest.mark.parametrize("log_n,log_blowup,ncols", [(4, 1, 2), (10, 1, 3), (11, 1, 1), (12, 2, 2), (14, 1, 10), (16, 1, 2)])
 def test_lde_vs_oracle(ctx, be, oracle, log_n, log_blowup, ncols):
     n = 1 << log_n
