@@ -111,20 +111,28 @@ void ssh_free(void *p) { free(p); }
 
 // ---- one proof over several ranks (sharded.hpp).  Every rank calls ssh_prove_sharded with its own context and AIR handle; the
 // proof (reference wire format) comes out on rank 0.  Transport: a local group (ranks = threads of this process:
-// ssh_local_group_create) or RCCL (rccl_id = the 128 bytes of ss_comm_unique_id from rank 0).
+// ssh_local_group_create) or an RCCL communicator (ssh_rccl_group_create: made ONCE from the 128 bytes of ss_comm_unique_id that
+// rank 0 hands out - an id's bootstrap serves one ncclCommInitRank per rank - and kept across proofs).
 typedef struct ssh_local_group ssh_local_group;
 ssh_local_group *ssh_local_group_create(uint32_t world) { return reinterpret_cast<ssh_local_group *>(new std::shared_ptr<LocalGroup>(make_local_group(world))); }
 void ssh_local_group_destroy(ssh_local_group *g) { delete reinterpret_cast<std::shared_ptr<LocalGroup> *>(g); }
-// the rank's extension columns for these challenges: fill cols_out / d_cols_out (<= 16 entries) and *ncols_out; 0 on success
+typedef struct ssh_rccl_group ssh_rccl_group;
+ssh_rccl_group *ssh_rccl_group_create(ss_ctx *ctx, const uint8_t rccl_id[128], uint32_t rank, uint32_t world) {
+    try {
+        if (!ctx || !rccl_id) throw std::runtime_error("ssh_rccl_group_create: NULL argument");
+        return reinterpret_cast<ssh_rccl_group *>(make_rccl_transport(ctx, rccl_id, rank, world).release());
+    } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+void ssh_rccl_group_destroy(ssh_rccl_group *g) { delete reinterpret_cast<Transport *>(g); }
 typedef int (*ssh_sharded_extension_cb)(void *user, const uint64_t *challenges, uint32_t nchallenges, uint32_t *cols_out, uint64_t **d_cols_out,
                                         uint32_t *ncols_out);
 int ssh_prove_sharded(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32], uint32_t rank,
-                      uint32_t world, ssh_local_group *group, const uint8_t *rccl_id, const uint32_t *base_cols, uint64_t *const *d_base,
+                      uint32_t world, ssh_local_group *group, ssh_rccl_group *rccl, const uint32_t *base_cols, uint64_t *const *d_base,
                       uint32_t nbase_mine, uint32_t log_n, ssh_sharded_extension_cb cb, void *user, const uint32_t options[5],
                       uint8_t **proof_bytes, uint64_t *proof_len) {
     std::shared_ptr<LocalGroup> *lg = reinterpret_cast<std::shared_ptr<LocalGroup> *>(group);
     try {
-        if (!ctx || !air_h || !seed || (!group && !rccl_id)) throw std::runtime_error("ssh_prove_sharded: NULL argument");
+        if (!ctx || !air_h || !seed || (!group && !rccl)) throw std::runtime_error("ssh_prove_sharded: NULL argument");
         Air *air = reinterpret_cast<Air *>(air_h);
         Claim claim;
         claim.air = air; claim.tree_kind = tree_kind; claim.n_friendly_layers = n_friendly_layers; claim.coin_kind = coin_kind;
@@ -133,8 +141,9 @@ int ssh_prove_sharded(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_fri
             opt.num_queries = options[0]; opt.lde_blowup_factor = options[1]; opt.grinding_factor = options[2];
             opt.fri_folding_factor = options[3]; opt.fri_max_remainder_coeffs = options[4];
         }
-        std::unique_ptr<Transport> comm = lg ? make_local_transport(*lg, rank) : make_rccl_transport(ctx, rccl_id, rank, world);
-        if (comm->world != world) throw std::runtime_error("ssh_prove_sharded: the group has another number of ranks");
+        std::unique_ptr<Transport> local = lg ? make_local_transport(*lg, rank) : nullptr;
+        Transport *comm = lg ? local.get() : reinterpret_cast<Transport *>(rccl);
+        if (comm->world != world || comm->rank != rank) throw std::runtime_error("ssh_prove_sharded: the group has another number of ranks, or this is another rank of it");
         std::map<uint32_t, uint64_t *> mine;
         for (uint32_t k = 0; k < nbase_mine; ++k) mine[base_cols[k]] = d_base[k];
         Digest sd;

@@ -87,13 +87,15 @@ static Digest digest_of_root(const std::array<uint8_t, 33> &r) { Digest d; memcp
 
 std::vector<FriLayerState> fri_commit_phase(ss_ctx *ctx, const Claim &claim, const Conventions &conv, const ProofOptions &opt, PublicCoin &coin,
                                             Proof &proof, std::shared_ptr<DeviceBuffer> deep, uint32_t log_N, uint64_t n) {
+    return fri_commit_phase_from(ctx, claim, conv, opt, coin, proof, deep, log_N, felt_from_u64(conv.lde_offset), n);
+}
+// the same from a later layer on (the sharded prover folds the first layers on the ranks): `evals` = that layer, 2^log_len values
+// over offset * <w>, of a polynomial of degree < degree_bound
+std::vector<FriLayerState> fri_commit_phase_from(ss_ctx *ctx, const Claim &claim, const Conventions &conv, const ProofOptions &opt, PublicCoin &coin,
+                                                 Proof &proof, std::shared_ptr<DeviceBuffer> evals, uint32_t log_len, Felt offset, uint64_t degree_bound) {
     const int order = conv.bitrev_commit ? SS_ORDER_BITREV : SS_ORDER_NATURAL;
     const uint32_t fold = opt.fri_folding_factor, log_fold = log2u(fold);
     std::vector<FriLayerState> layers;
-    std::shared_ptr<DeviceBuffer> evals = deep;
-    uint32_t log_len = log_N;
-    Felt offset = felt_from_u64(conv.lde_offset);
-    uint64_t degree_bound = n;
     while (degree_bound > opt.fri_max_remainder_coeffs) {
         const uint64_t rows = 1ull << (log_len - log_fold);
         FriLayerState L;
@@ -146,9 +148,15 @@ uint64_t proof_of_work(ss_ctx *ctx, const Claim &claim, PublicCoin &coin, const 
 
 void fri_open(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Proof &proof, std::vector<FriLayerState> &layers,
               const std::vector<uint64_t> &positions) {
+    fri_open_from(ctx, conv, opt, proof, layers, positions, 0);
+}
+// layers[k] is the proof's layer first + k; `positions`: the query positions as folded down to layer `first`'s index space
+void fri_open_from(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Proof &proof, std::vector<FriLayerState> &layers_from,
+                   const std::vector<uint64_t> &positions, size_t first) {
     const uint32_t log_fold = log2u(opt.fri_folding_factor);
     std::vector<uint64_t> p = positions;
-    for (size_t li = 0; li < layers.size(); ++li) {
+    for (size_t li = first; li < first + layers_from.size(); ++li) {
+        FriLayerState &layer = layers_from[li - first];
         const uint32_t row_bits = proof.fri_layers[li].log_len - log_fold;
         const uint64_t rows = 1ull << row_bits;
         std::set<uint64_t> s;
@@ -157,9 +165,9 @@ void fri_open(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Pro
         std::vector<uint64_t> nat_rows = p;
         if (conv.bitrev_commit) for (auto &r : nat_rows) r = brev_bits(r, row_bits);
         proof.fri_layers[li].positions = p;
-        proof.fri_layers[li].rows = gather(ctx, layers[li].matrix.cols, nat_rows);
-        proof.fri_layers[li].paths = layers[li].tree->prove(p, &proof.fri_layers[li].path_tags);
-        proof.fri_layers[li].leaves = layers[li].tree->leaf_digests(p);
+        proof.fri_layers[li].rows = gather(ctx, layer.matrix.cols, nat_rows);
+        proof.fri_layers[li].paths = layer.tree->prove(p, &proof.fri_layers[li].path_tags);
+        proof.fri_layers[li].leaves = layer.tree->leaf_digests(p);
     }
 }
 

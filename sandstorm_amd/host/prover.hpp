@@ -147,7 +147,11 @@ class PublicCoin;
 struct FriLayerState { std::unique_ptr<MerkleTree> tree; Matrix matrix; std::shared_ptr<DeviceBuffer> evals; };
 std::vector<FriLayerState> fri_commit_phase(ss_ctx *ctx, const Claim &claim, const Conventions &conv, const ProofOptions &opt, PublicCoin &coin,
                                             Proof &proof, std::shared_ptr<DeviceBuffer> deep, uint32_t log_N, uint64_t n);
+std::vector<FriLayerState> fri_commit_phase_from(ss_ctx *ctx, const Claim &claim, const Conventions &conv, const ProofOptions &opt, PublicCoin &coin,
+                                                 Proof &proof, std::shared_ptr<DeviceBuffer> evals, uint32_t log_len, Felt offset, uint64_t degree_bound);
 uint64_t proof_of_work(ss_ctx *ctx, const Claim &claim, PublicCoin &coin, const ProofOptions &opt, bool have_nonce, uint64_t nonce);
+void fri_open_from(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Proof &proof, std::vector<FriLayerState> &layers_from,
+                   const std::vector<uint64_t> &positions, size_t first);
 void fri_open(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Proof &proof, std::vector<FriLayerState> &layers,
               const std::vector<uint64_t> &positions);
 

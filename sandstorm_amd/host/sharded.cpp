@@ -7,11 +7,18 @@
 //                                                                                       chunk p of them is rank p's, one equal-split
 //                                                                                       exchange, a stride-R comb on arrival; the R
 //                                                                                       sub-tree roots all-gathered, top levels on hosts
-//   composition polynomial (Q2)           rank 0 interpolates, columns on ranks 0, 1    gather of the row blocks, one column out
-//   DEEP polynomial, FRI (F1), PoW        every rank composes its n / R sub-coset       gather to rank 0, which extends and runs FRI
+//   extension columns, composition        ONE transform over the R ranks                owner scatters n / R blocks; per transform two
+//   polynomial (Q2), DEEP's extension     (ss_ntt_shard_fp252: local stages on blocks,  equal-split all-to-alls (block <-> exchanged
+//                                         the log2 R cross stages on the exchanged      layout); the halo rows from the next ranks
+//                                         layout): every rank 1 / R of every transform
+//   out-of-domain values                  base columns: by column owner; distributed    all-gather of the values / of R partial sums
+//                                         coefficient blocks: P(y) = sum_r y^j(r) P_r(y^R)  per cell, combined on every host
+//   FRI (F1): layers above 2^21 values    rank m holds the fold rows [m rows/R, ...)    block layout -> row layout: one all-to-all of
+//                                         with all `fold` entries: folds and commits     1 / R of the layer; then the layer (<= 2^21)
+//                                         its rows (sub-tree + digest routing as above)  gathered to rank 0, which finishes + grinds
 //   openings                              rows / paths where they live                  gathered to rank 0 (kilobytes)
 //
-// Nothing is a sum over ranks: no all-reduce.  The coin runs on every rank in lock step up to the out-of-domain values.
+// Nothing is a sum over ranks: no all-reduce.  The coin runs on every rank in lock step up to the last distributed FRI layer.
 #include "sharded.hpp"
 
 #include <algorithm>
@@ -270,6 +277,11 @@ std::vector<ShardedProver::Buf> ShardedProver::to_row_blocks(const std::map<uint
 }
 
 std::unique_ptr<ShardedProver::Commitment> ShardedProver::commit(const std::vector<Buf> &blocks, uint64_t N, int order) {
+    std::vector<const uint64_t *> cols;
+    for (const Buf &b : blocks) cols.push_back(b->u64());
+    return commit(cols, N, order);
+}
+std::unique_ptr<ShardedProver::Commitment> ShardedProver::commit(const std::vector<const uint64_t *> &blocks, uint64_t N, int order) {
     const uint32_t R = comm_.world;
     const uint64_t B = N / R;
     const uint32_t log_R = log2u(R), log_B = log2u(B);
@@ -281,14 +293,13 @@ std::unique_ptr<ShardedProver::Commitment> ShardedProver::commit(const std::vect
     // leaves rank p owns: one equal-split exchange (32 B per row), after which the chunk from rank s is the stride-R comb at
     // offset bitrev_{log R}(s) of the leaf block.
     Buf mine = std::make_shared<DeviceBuffer>(ctx_, 32 * B);
+    if (R > 1 && order == SS_ORDER_BITREV && B < R) throw std::runtime_error("a tree of fewer than R^2 leaves over R ranks");
     if (single) {                               // raw-element leaves (merkle/mod.rs:113-117)
-        if (order == SS_ORDER_BITREV) ok(ss_bitrev_permute32(ctx_, blocks[0]->u8(), log_B, mine->u8()));
-        else ok(ss_dev_copy(ctx_, mine->u8(), blocks[0]->u8(), 32 * B));
+        if (order == SS_ORDER_BITREV) ok(ss_bitrev_permute32(ctx_, blocks[0], log_B, mine->u8()));
+        else ok(ss_dev_copy(ctx_, mine->u8(), blocks[0], 32 * B));
     } else {
         const int row_hash = claim_.tree_kind == SS_TREE_KECCAK ? SS_HASH_KECCAK : claim_.tree_kind == SS_TREE_KECCAK_M20 ? SS_HASH_KECCAK_M20 : SS_HASH_BLAKE2S_M20;
-        std::vector<const uint64_t *> cols;
-        for (const Buf &b : blocks) cols.push_back(b->u64());
-        ok(ss_hash_rows_ex(ctx_, row_hash, cols.data(), (uint32_t)cols.size(), B, order, mine->u8()));      // the blocks' halo is not hashed
+        ok(ss_hash_rows_ex(ctx_, row_hash, blocks.data(), (uint32_t)blocks.size(), B, order, mine->u8()));      // the blocks' halo is not hashed
     }
     if (R == 1 || order != SS_ORDER_BITREV) {   // natural order: a rank's rows are its leaves
         com->leaves_own = mine;
@@ -334,6 +345,12 @@ std::unique_ptr<ShardedProver::Commitment> ShardedProver::commit(const std::vect
 // -> on rank 0: rows [nq x ncols felts], paths [nq x log N x 32], leaf digests [nq x 32] (hashed leaves), tags [nq x log N] (friendly trees)
 void ShardedProver::open(const Commitment &com, const std::vector<Buf> &blocks, uint64_t N, const std::vector<uint64_t> &positions, int order,
                          std::vector<uint64_t> *rows, std::vector<uint8_t> *paths, std::vector<uint8_t> *leaves, std::vector<uint8_t> *tags) {
+    std::vector<const uint64_t *> cols;
+    for (const Buf &b : blocks) cols.push_back(b->u64());
+    open(com, cols, N, positions, order, rows, paths, leaves, tags);
+}
+void ShardedProver::open(const Commitment &com, const std::vector<const uint64_t *> &blocks, uint64_t N, const std::vector<uint64_t> &positions, int order,
+                         std::vector<uint64_t> *rows, std::vector<uint8_t> *paths, std::vector<uint8_t> *leaves, std::vector<uint8_t> *tags) {
     const uint32_t R = comm_.world, r = comm_.rank;
     const uint64_t B = N / R;
     const uint32_t log_N = log2u(N), log_R = log2u(R), log_B = log_N - log_R;
@@ -350,10 +367,8 @@ void ShardedProver::open(const Commitment &com, const std::vector<Buf> &blocks, 
         }
         part.u64(q_rows.size());
         if (!q_rows.empty()) {
-            std::vector<const uint64_t *> cols;
-            for (const Buf &b : blocks) cols.push_back(b->u64());
             std::vector<uint64_t> got(q_rows.size() * ncols * 4);
-            ok(ss_gather_rows(ctx_, cols.data(), (uint32_t)ncols, k_rows.data(), (uint32_t)k_rows.size(), got.data()));
+            ok(ss_gather_rows(ctx_, blocks.data(), (uint32_t)ncols, k_rows.data(), (uint32_t)k_rows.size(), got.data()));
             for (size_t t = 0; t < q_rows.size(); ++t) { part.u64(q_rows[t]); part.raw(got.data() + t * ncols * 4, ncols * 32); }
         }
         part.u64(q_leaf.size());
@@ -446,15 +461,36 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
     auto base_com = commit(base_blocks, N, order);
     proof.base_root = base_com->root;
     coin.reseed_with_digest(digest_of(proof.base_root));
-    // 3-4. challenges -> extension trace
+    // 3-4. challenges -> extension trace: its owner deals out blocks of n / R rows, then every transform is ONE transform over
+    // the ranks (each rank 1 / R of its butterflies) that ends in the row blocks; the halo comes from the next ranks
     for (uint32_t i = 0; i < air.num_challenges; ++i) proof.challenges.push_back(coin.draw());
-    std::vector<Buf> blocks = base_blocks, ext_blocks;
+    std::vector<Buf> blocks = base_blocks, ext_blocks, ext_coeff_blocks;
     std::unique_ptr<Commitment> ext_com;
+    const uint64_t nb_rows = n / R;              // rows of a trace-size block
     if (ne) {
         const std::map<uint32_t, uint64_t *> my_ext = build_extension(proof.challenges);
         for (uint32_t c = nb; c < nb + ne; ++c)
             if ((owner(c) == r) != (my_ext.count(c) == 1)) throw std::runtime_error("extension column c lives on rank c % R");
-        ext_blocks = to_row_blocks(extend(my_ext), ne, nb, N, halo);
+        std::vector<Buf> xb;
+        {
+            std::vector<Message> sends, recvs;
+            for (uint32_t c = nb; c < nb + ne; ++c) {
+                Buf mine = std::make_shared<DeviceBuffer>(ctx_, 32 * nb_rows);
+                const uint32_t o = owner(c);
+                if (o == r) {
+                    const uint8_t *col = (const uint8_t *)my_ext.at(c);
+                    for (uint32_t p = 0; p < R; ++p) {
+                        if (p == r) ok(ss_dev_copy(ctx_, mine->u8(), col + 32 * p * nb_rows, 32 * nb_rows));
+                        else sends.push_back({p, (void *)(col + 32 * p * nb_rows), 32 * nb_rows});
+                    }
+                } else recvs.push_back({o, mine->u8(), 32 * nb_rows});
+                xb.push_back(mine);
+            }
+            if (R > 1) comm_.exchange(ctx_, sends, recvs);
+        }
+        ext_coeff_blocks = spread_inverse(xb, log_n, nullptr);
+        xb.clear();
+        ext_blocks = with_halo(spread_forward(ext_coeff_blocks, log_N, lb, &g), B, halo);
         ext_com = commit(ext_blocks, N, order);
         proof.has_extension = true;
         proof.extension_root = ext_com->root;
@@ -463,7 +499,7 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
     }
     std::vector<const uint64_t *> block_ptrs;
     for (const Buf &b : blocks) block_ptrs.push_back(b->u64());
-    // 5. the composition constraint on this rank's rows; interpolation on rank 0; the two column LDEs on ranks 0 and 1 % R
+    // 5. the composition constraint on this rank's rows; its interpolation and the two column extensions over all the ranks
     proof.composition_coeff = coin.draw();
     AirProgramData pd = air.build_program(n, proof.challenges, proof.composition_coeff);
     const std::vector<uint64_t> consts = flat(pd.program.consts);
@@ -477,62 +513,54 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
     else ok(ss_eval_quotient_rows(ctx_, &prog, block_ptrs.data(), (uint32_t)block_ptrs.size(), log_n, lb, g.data(), r * B, B, B + halo, q_block->u64()));
     const uint32_t ncomp = conv_.composition_columns;
     if (ncomp != (1u << lb) || ncomp != 2) throw std::runtime_error("composition split implemented for blowup 2");
-    Buf comp_evals;                              // rank 0: the whole vector, then its bit-reversed coefficients H0 | H1
-    if (R == 1) comp_evals = q_block;
-    else if (r == 0) {
-        comp_evals = std::make_shared<DeviceBuffer>(ctx_, 32 * N);
-        std::vector<Message> recvs;
-        ok(ss_dev_copy(ctx_, comp_evals->u8(), q_block->u8(), 32 * B));
-        for (uint32_t p = 1; p < R; ++p) recvs.push_back({p, comp_evals->u8() + 32 * p * B, 32 * B});
-        comm_.exchange(ctx_, {}, recvs);
-    } else comm_.exchange(ctx_, {{0, q_block->u8(), 32 * B}}, {});
-    if (r == 0) {
-        uint64_t *ce = comp_evals->u64();
-        ok(ss_ntt_fp252(ctx_, &ce, 1, log_N, SS_NTT_INVERSE, g.data(), SS_ORDER_NATURAL, SS_ORDER_BITREV));     // the split is free
-    }
-    std::map<uint32_t, uint64_t *> comp_co;
-    std::vector<Buf> comp_co_own;
+    // the N coefficients in bit-reversed order: positions < n are H0's (in its own bit-reversed order), the rest H1's - the split
+    // is free, and rank r's block of the array is one of the two halves' blocks 2 r', 2 r' + 1: one exchange deals them out
+    std::vector<Buf> comp_coeff_blocks;
     {
-        std::vector<Message> sends, recvs;
-        for (uint32_t k = 0; k < ncomp; ++k) {
-            const uint32_t o = owner(k);
-            if (r == 0) {
-                uint8_t *half = comp_evals->u8() + 32 * n * k;
-                if (o == 0) comp_co[k] = (uint64_t *)half;
-                else sends.push_back({o, half, 32 * n});
-            } else if (o == r) {
+        std::vector<Buf> cb = spread_inverse({q_block}, log_N, &g);
+        q_block.reset();
+        if (R == 1) {
+            for (uint32_t k = 0; k < ncomp; ++k) {
                 Buf b = std::make_shared<DeviceBuffer>(ctx_, 32 * n);
-                comp_co_own.push_back(b);
-                comp_co[k] = b->u64();
-                recvs.push_back({0, b->u8(), 32 * n});
+                ok(ss_dev_copy(ctx_, b->u8(), cb[0]->u8() + 32 * n * k, 32 * n));
+                comp_coeff_blocks.push_back(b);
             }
+        } else {
+            std::vector<Message> sends, recvs;
+            for (uint32_t k = 0; k < ncomp; ++k) comp_coeff_blocks.push_back(std::make_shared<DeviceBuffer>(ctx_, 32 * nb_rows));
+            const uint32_t mine_k = r / (R / 2), r2 = r % (R / 2);         // this rank's block: halves 2 r2, 2 r2 + 1 of H_{mine_k}
+            for (uint32_t h = 0; h < 2; ++h) {
+                const uint32_t dst = 2 * r2 + h;
+                uint8_t *src = cb[0]->u8() + 32 * nb_rows * h;
+                if (dst == r) ok(ss_dev_copy(ctx_, comp_coeff_blocks[mine_k]->u8(), src, 32 * nb_rows));
+                else sends.push_back({dst, src, 32 * nb_rows});
+            }
+            for (uint32_t k = 0; k < ncomp; ++k) {
+                const uint32_t src_rank = k * (R / 2) + r / 2;
+                if (src_rank != r) recvs.push_back({src_rank, comp_coeff_blocks[k]->u8(), 32 * nb_rows});
+            }
+            comm_.exchange(ctx_, sends, recvs);
         }
-        comm_.exchange(ctx_, sends, recvs);
     }
-    std::map<uint32_t, Buf> comp_owned;
-    for (auto &kv : comp_co) {
-        Buf e = std::make_shared<DeviceBuffer>(ctx_, 32 * N);
-        const uint64_t *co = kv.second;
-        uint64_t *ev = e->u64();
-        ok(ss_evaluate_fp252(ctx_, &co, 1, log_n, lb, g.data(), &ev));
-        comp_owned[kv.first] = e;
-    }
-    std::vector<Buf> comp_blocks = to_row_blocks(comp_owned, ncomp, 0, N, 0);
-    comp_owned.clear();
+    std::vector<Buf> comp_blocks = spread_forward(comp_coeff_blocks, log_N, lb, &g);
     auto comp_com = commit(comp_blocks, N, order);
     proof.composition_root = comp_com->root;
     coin.reseed_with_digest(digest_of(proof.composition_root));
-    // 6. out-of-domain point: every column owner evaluates its cells, everybody learns all of them
+    // 6. out-of-domain point.  Base columns: their owner evaluates its cells.  A column whose coefficients are spread over the
+    // ranks: block r of the bit-reversed coefficient array holds the coefficients j = R j' + bitrev(r), in the bit-reversed
+    // order of j' - P(y) = sum_r y^bitrev(r) P_r(y^R), and P_r(y^R) at y = z w_n^off is the out-of-domain evaluation of the
+    // block as a polynomial of n / R coefficients at the point z^R with the same offset.  Everybody learns everything.
     proof.z = coin.draw();
     const uint32_t nmask = (uint32_t)air.mask.size();
     std::vector<uint32_t> mask_col, mask_off;
     for (auto &c : air.mask) { mask_col.push_back(c.first); mask_off.push_back(c.second); }
+    const uint32_t log_R = log2u(R), br_r = (uint32_t)brev(r, log_R);
     {
         Writer part;
         std::vector<uint32_t> cols_mine, cell_j, cell_col, cell_off;
         for (auto &kv : coeffs) cols_mine.push_back(kv.first);                    // ascending (std::map)
         for (uint32_t j = 0; j < nmask; ++j)
-            if (owner(mask_col[j]) == r) {
+            if (mask_col[j] < nb && owner(mask_col[j]) == r) {
                 cell_j.push_back(j);
                 cell_col.push_back((uint32_t)(std::find(cols_mine.begin(), cols_mine.end(), mask_col[j]) - cols_mine.begin()));
                 cell_off.push_back(mask_off[j]);
@@ -545,27 +573,52 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
             ok(ss_ood_eval(ctx_, cp.data(), (uint32_t)cp.size(), log_n, cell_col.data(), cell_off.data(), (uint32_t)cell_j.size(), proof.z.data(), vals.data()));
             for (size_t t = 0; t < cell_j.size(); ++t) { part.u64(cell_j[t]); part.raw(vals.data() + 4 * t, 32); }
         }
-        const Felt zc = felt_pow(proof.z, ncomp);
-        part.u64(comp_co.size());
-        for (auto &kv : comp_co) {
-            const uint64_t *co = kv.second;
-            uint64_t v[4];
-            ok(ss_poly_eval(ctx_, &co, 1, log_n, zc.data(), v));
-            part.u64(kv.first);
-            part.raw(v, 32);
+        // the partial sums of the extension columns' cells and of the composition columns at z^ncomp
+        std::vector<uint32_t> xcell_j, xcell_col, xcell_off;
+        for (uint32_t j = 0; j < nmask; ++j)
+            if (mask_col[j] >= nb) { xcell_j.push_back(j); xcell_col.push_back(mask_col[j] - nb); xcell_off.push_back(mask_off[j]); }
+        const Felt zR = felt_pow(proof.z, R), zc = felt_pow(proof.z, ncomp), zcR = felt_pow(zc, R);
+        std::vector<uint64_t> xvals(4 * xcell_j.size()), cvals(4 * ncomp);
+        if (!xcell_j.empty()) {
+            std::vector<const uint64_t *> cp;
+            for (const Buf &b : ext_coeff_blocks) cp.push_back(b->u64());
+            ok(ss_ood_eval(ctx_, cp.data(), (uint32_t)cp.size(), log_n - log_R, xcell_col.data(), xcell_off.data(), (uint32_t)xcell_j.size(), zR.data(), xvals.data()));
         }
+        {
+            std::vector<const uint64_t *> cp;
+            for (const Buf &b : comp_coeff_blocks) cp.push_back(b->u64());
+            ok(ss_poly_eval(ctx_, cp.data(), ncomp, log_n - log_R, zcR.data(), cvals.data()));
+        }
+        part.raw(xvals.data(), 8 * xvals.size());
+        part.raw(cvals.data(), 8 * cvals.size());
         proof.ood_trace.assign(nmask, Felt{});
         proof.ood_composition.assign(ncomp, Felt{});
-        for (const std::vector<uint8_t> &pb : comm_.all_gather_var(ctx_, part.b)) {
-            Reader rd{pb};
+        const Felt w_n = root_of_unity(log_n);
+        const std::vector<std::vector<uint8_t>> parts = comm_.all_gather_var(ctx_, part.b);
+        for (uint32_t p = 0; p < R; ++p) {
+            Reader rd{parts[p]};
             for (uint64_t cnt = rd.u64(), t = 0; t < cnt; ++t) { const uint64_t j = rd.u64(); memcpy(proof.ood_trace[j].data(), rd.take(32), 32); }
-            for (uint64_t cnt = rd.u64(), t = 0; t < cnt; ++t) { const uint64_t k = rd.u64(); memcpy(proof.ood_composition[k].data(), rd.take(32), 32); }
+            const uint64_t e = brev(p, log_R);                       // rank p's blocks hold the coefficients j = e mod R
+            for (size_t t = 0; t < xcell_j.size(); ++t) {
+                Felt v;
+                memcpy(v.data(), rd.take(32), 32);
+                const Felt y = felt_mul(proof.z, felt_pow(w_n, xcell_off[t]));
+                Felt &acc = proof.ood_trace[xcell_j[t]];
+                acc = felt_add(acc, felt_mul(felt_pow(y, e), v));
+            }
+            for (uint32_t k = 0; k < ncomp; ++k) {
+                Felt v;
+                memcpy(v.data(), rd.take(32), 32);
+                proof.ood_composition[k] = felt_add(proof.ood_composition[k], felt_mul(felt_pow(zc, e), v));
+            }
         }
+        (void)br_r;
         std::vector<Felt> all = proof.ood_trace;
         all.insert(all.end(), proof.ood_composition.begin(), proof.ood_composition.end());
         coin.reseed_with_field_elements(all);
     }
-    // 7. DEEP composition on this rank's part of the trace-size sub-coset; rank 0 interpolates and re-expands
+    // 7. DEEP composition on this rank's part of the trace-size sub-coset, then its extension over all the ranks: the values on
+    // offset * <w_n> are those of Q(y) = P(offset y) on <w_n>, and P(offset w_2n^k) = Q(w_2n^k) (ss_deep_extend's argument)
     proof.deep_alpha = coin.draw();
     std::vector<Felt> dcoef;
     Felt cur = felt_from_u64(1);
@@ -578,28 +631,90 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
     for (const Buf &b : comp_blocks) comp_ptrs.push_back(b->u64());
     ok(ss_deep_compose_rows(ctx_, block_ptrs.data(), (uint32_t)block_ptrs.size(), comp_ptrs.data(), ncomp, log_n, lb, g.data(), mask_col.data(), mask_off.data(),
                             nmask, ood_t.data(), ct.data(), ood_c.data(), cc.data(), proof.z.data(), r * cnt, cnt, sub_block->u64()));
+    Buf layer;                                   // the current FRI layer: this rank's block of it (R == 1: all of it)
+    if (R == 1) {
+        layer = std::make_shared<DeviceBuffer>(ctx_, 32 * N);
+        ok(ss_deep_extend(ctx_, sub_block->u64(), log_n, lb, g.data(), layer->u64()));
+    } else {
+        layer = spread_forward(spread_inverse({sub_block}, log_n, nullptr), log_N, lb, nullptr)[0];
+    }
+    sub_block.reset();
+    // 8. FRI.  A layer above 2^fri_spread_min_log values is folded by all the ranks: rank m takes the fold rows [m rows / R, ...)
+    // - all `fold` entries of a row, which sit len / fold apart: one all-to-all out of the block layout -, commits them (its
+    // leaf block after the digest routing of commit()) and folds them into ITS block of the next layer.  Then the layer is
+    // gathered to rank 0, which finishes as the single-device prover does.
+    struct SpreadLayer { std::unique_ptr<Commitment> com; Buf rows_buf; std::vector<const uint64_t *> cols; uint64_t rows; };
+    std::vector<SpreadLayer> spread_layers;
+    const uint32_t fold = opt_.fri_folding_factor, log_fold = log2u(fold);
+    uint32_t log_len = log_N;
+    Felt fri_offset = g;
+    uint64_t degree_bound = n;
+    const char *min_log_env = getenv("SSH_FRI_SPREAD_MIN_LOG");                  // (a test knob: small proofs spread their layers too)
+    const uint32_t spread_min_log = min_log_env ? (uint32_t)atoi(min_log_env) : 21u;
+    while (R > 1 && degree_bound > opt_.fri_max_remainder_coeffs && log_len > spread_min_log && log_len >= log_fold + 2 * log_R && fold >= R && fold % R == 0) {
+        const uint64_t len = 1ull << log_len, rows = len >> log_fold, rcnt = rows / R, Bl = len / R;
+        SpreadLayer L;
+        L.rows = rows;
+        L.rows_buf = std::make_shared<DeviceBuffer>(ctx_, 32 * fold * rcnt);
+        {   // block layout -> row layout: my block holds fold / R whole columns k of the layer; chunk m of column k goes to rank m's slot k
+            std::vector<Message> sends, recvs;
+            const uint32_t kper = fold / R;
+            for (uint32_t k = 0; k < fold; ++k) {
+                const uint32_t src_rank = k / kper;
+                for (uint32_t m = 0; m < R; ++m) {
+                    if (src_rank == r) {
+                        uint8_t *src = layer->u8() + 32 * ((uint64_t)(k % kper) * rows + (uint64_t)m * rcnt);
+                        if (m == r) ok(ss_dev_copy(ctx_, L.rows_buf->u8() + 32 * (uint64_t)k * rcnt, src, 32 * rcnt));
+                        else sends.push_back({m, src, 32 * rcnt});
+                    }
+                }
+                if (src_rank != r) recvs.push_back({src_rank, L.rows_buf->u8() + 32 * (uint64_t)k * rcnt, 32 * rcnt});
+            }
+            (void)Bl;
+            comm_.exchange(ctx_, sends, recvs);
+        }
+        // committed row = the natural stride columns in bit-reversed column order (fri_commit_phase)
+        for (uint32_t j = 0; j < fold; ++j) L.cols.push_back(L.rows_buf->u64() + 4 * rcnt * (conv_.bitrev_commit ? brev(j, log_fold) : j));
+        L.com = commit(L.cols, rows, order);
+        FriLayerProof lp;
+        lp.root = L.com->root;
+        lp.log_len = log_len;
+        proof.fri_layers.push_back(lp);
+        coin.reseed_with_digest(digest_of(lp.root));
+        Felt alpha = coin.draw();
+        if (conv_.fri_alpha_times_offset) alpha = felt_mul(alpha, fri_offset);
+        proof.fri_alphas.push_back(alpha);
+        Buf next = std::make_shared<DeviceBuffer>(ctx_, 32 * rcnt);
+        ok(ss_fri_fold_rows(ctx_, L.rows_buf->u64(), log_len, fold, alpha.data(), fri_offset.data(), conv_.fri_unnormalised ? SS_FRI_UNNORMALISED : 0,
+                            (uint64_t)r * rcnt, rcnt, next->u64()));
+        spread_layers.push_back(std::move(L));
+        layer = next;
+        log_len -= log_fold;
+        fri_offset = felt_pow(fri_offset, fold);
+        degree_bound /= fold;
+    }
     std::vector<FriLayerState> layers;
     std::vector<uint64_t> positions;
+    const uint64_t len_now = 1ull << log_len, blk_now = len_now / R;
     if (r != 0) {
-        if (R > 1) comm_.exchange(ctx_, {{0, sub_block->u8(), 32 * cnt}}, {});
+        if (R > 1) comm_.exchange(ctx_, {{0, layer->u8(), 32 * blk_now}}, {});
     } else {
-        Buf sub = sub_block;
+        Buf whole = layer;
         if (R > 1) {
-            sub = std::make_shared<DeviceBuffer>(ctx_, 32 * n);
-            ok(ss_dev_copy(ctx_, sub->u8(), sub_block->u8(), 32 * cnt));
+            whole = std::make_shared<DeviceBuffer>(ctx_, 32 * len_now);
+            ok(ss_dev_copy(ctx_, whole->u8(), layer->u8(), 32 * blk_now));
             std::vector<Message> recvs;
-            for (uint32_t p = 1; p < R; ++p) recvs.push_back({p, sub->u8() + 32 * p * cnt, 32 * cnt});
+            for (uint32_t p = 1; p < R; ++p) recvs.push_back({p, whole->u8() + 32 * p * blk_now, 32 * blk_now});
             comm_.exchange(ctx_, {}, recvs);
         }
-        auto deep = std::make_shared<DeviceBuffer>(ctx_, 32 * N);
-        ok(ss_deep_extend(ctx_, sub->u64(), log_n, lb, g.data(), deep->u64()));
-        // 8-9. FRI, proof of work, query positions: on rank 0, as the single-device prover does them
-        layers = fri_commit_phase(ctx_, claim_, conv_, opt_, coin, proof, deep, log_N, n);
+        // 8-9. the rest of FRI, proof of work, query positions: on rank 0, as the single-device prover does them
+        layers = fri_commit_phase_from(ctx_, claim_, conv_, opt_, coin, proof, whole, log_len, fri_offset, degree_bound);
         proof.pow_nonce = proof_of_work(ctx_, claim_, coin, opt_, have_nonce_, nonce_);
         coin.reseed_with_int(proof.pow_nonce);
         positions = coin.draw_queries(opt_.num_queries, N);
         proof.query_positions = positions;
     }
+    layer.reset();
     {                                            // the positions to every rank
         Writer w;
         if (r == 0) for (uint64_t p : positions) w.u64(p);
@@ -613,10 +728,125 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
     open(*base_com, base_blocks, N, positions, order, &proof.base_rows, &proof.base_paths, &proof.base_leaves, &proof.base_path_tags);
     if (ne) open(*ext_com, ext_blocks, N, positions, order, &proof.extension_rows, &proof.extension_paths, &proof.extension_leaves, &proof.extension_path_tags);
     open(*comp_com, comp_blocks, N, positions, order, &proof.composition_rows, &proof.composition_paths, &proof.composition_leaves, &proof.composition_path_tags);
+    // the FRI layers the ranks folded: the same openings over their row matrices; position p of a layer -> row p >> log2 fold of it
+    std::vector<uint64_t> fp = positions;
+    for (size_t li = 0; li < spread_layers.size(); ++li) {
+        SpreadLayer &L = spread_layers[li];
+        std::vector<uint64_t> nxt;
+        for (uint64_t q : fp) nxt.push_back(conv_.bitrev_commit ? (q >> log_fold) : (q % L.rows));
+        std::sort(nxt.begin(), nxt.end());
+        nxt.erase(std::unique(nxt.begin(), nxt.end()), nxt.end());
+        fp = nxt;
+        FriLayerProof lpo;
+        open(*L.com, L.cols, L.rows, fp, order, &lpo.rows, &lpo.paths, &lpo.leaves, &lpo.path_tags);
+        if (r == 0) {
+            FriLayerProof &lp = proof.fri_layers[li];
+            lp.positions = fp;
+            lp.rows = std::move(lpo.rows); lp.paths = std::move(lpo.paths); lp.leaves = std::move(lpo.leaves); lp.path_tags = std::move(lpo.path_tags);
+        }
+    }
     if (r != 0) return false;
-    fri_open(ctx_, conv_, opt_, proof, layers, positions);
+    fri_open_from(ctx_, conv_, opt_, proof, layers, fp, spread_layers.size());
     *out = std::move(proof);
     return true;
+}
+
+// ------------------------------------------------------------------------------------ one transform over the ranks
+// block layout <-> exchanged layout (its own inverse): chunk m of this rank's buffer to rank m, chunk t from rank t
+std::vector<ShardedProver::Buf> ShardedProver::exchange_layout(const std::vector<Buf> &in, uint64_t elems) {
+    const uint32_t R = comm_.world, r = comm_.rank;
+    const uint64_t chunk = elems / R;
+    if (chunk * R != elems || !chunk) throw std::runtime_error("a transform of fewer than R^2 points over R ranks");
+    std::vector<Buf> out;
+    std::vector<Message> sends, recvs;
+    for (const Buf &b : in) {
+        Buf o = std::make_shared<DeviceBuffer>(ctx_, 32 * elems);
+        for (uint32_t p = 0; p < R; ++p) {
+            if (p == r) ok(ss_dev_copy(ctx_, o->u8() + 32 * p * chunk, b->u8() + 32 * p * chunk, 32 * chunk));
+            else {
+                sends.push_back({p, b->u8() + 32 * p * chunk, 32 * chunk});
+                recvs.push_back({p, o->u8() + 32 * p * chunk, 32 * chunk});
+            }
+        }
+        out.push_back(o);
+    }
+    comm_.exchange(ctx_, sends, recvs);
+    return out;
+}
+
+// blocks of 2^log_n / R values over offset * <w_n>, natural order -> blocks of the bit-reversed coefficient array (inputs kept)
+std::vector<ShardedProver::Buf> ShardedProver::spread_inverse(const std::vector<Buf> &blocks, uint32_t log_n, const Felt *offset) {
+    const uint32_t R = comm_.world, r = comm_.rank;
+    const uint64_t elems = (1ull << log_n) / R;
+    std::vector<uint64_t *> ptrs;
+    if (R == 1) {
+        std::vector<Buf> out;
+        for (const Buf &b : blocks) {
+            Buf o = std::make_shared<DeviceBuffer>(ctx_, 32 * elems);
+            ok(ss_dev_copy(ctx_, o->u8(), b->u8(), 32 * elems));
+            out.push_back(o);
+            ptrs.push_back(o->u64());
+        }
+        ok(ss_ntt_fp252(ctx_, ptrs.data(), (uint32_t)ptrs.size(), log_n, SS_NTT_INVERSE, offset ? offset->data() : nullptr, SS_ORDER_NATURAL, SS_ORDER_BITREV));
+        return out;
+    }
+    const uint32_t log_R = log2u(R);
+    std::vector<Buf> t = exchange_layout(blocks, elems);
+    for (const Buf &b : t) ptrs.push_back(b->u64());
+    ok(ss_ntt_shard_fp252(ctx_, ptrs.data(), (uint32_t)ptrs.size(), log_n, log_R, r, SS_NTT_INVERSE, offset ? offset->data() : nullptr, SS_NTT_PART_CROSS, 0, nullptr));
+    std::vector<Buf> out = exchange_layout(t, elems);
+    t.clear();
+    ptrs.clear();
+    for (const Buf &b : out) ptrs.push_back(b->u64());
+    ok(ss_ntt_shard_fp252(ctx_, ptrs.data(), (uint32_t)ptrs.size(), log_n, log_R, r, SS_NTT_INVERSE, offset ? offset->data() : nullptr, SS_NTT_PART_LOCAL, 0, nullptr));
+    return out;
+}
+
+// blocks of the bit-reversed coefficient array (2^(log_n - log_expand) / R coefficients each) -> blocks of the 2^log_n evaluations
+// over offset * <w>
+std::vector<ShardedProver::Buf> ShardedProver::spread_forward(const std::vector<Buf> &coeff_blocks, uint32_t log_n, uint32_t log_expand, const Felt *offset) {
+    const uint32_t R = comm_.world, r = comm_.rank;
+    const uint64_t elems = (1ull << log_n) / R;
+    std::vector<Buf> out;
+    std::vector<uint64_t *> src, dst;
+    for (const Buf &b : coeff_blocks) {
+        out.push_back(std::make_shared<DeviceBuffer>(ctx_, 32 * elems));
+        src.push_back(b->u64());
+        dst.push_back(out.back()->u64());
+    }
+    if (R == 1) {
+        ok(ss_evaluate_fp252(ctx_, (const uint64_t *const *)src.data(), (uint32_t)src.size(), log_n - log_expand, log_expand, offset ? offset->data() : nullptr, dst.data()));
+        return out;
+    }
+    const uint32_t log_R = log2u(R);
+    ok(ss_ntt_shard_fp252(ctx_, src.data(), (uint32_t)src.size(), log_n, log_R, r, SS_NTT_FORWARD, offset ? offset->data() : nullptr, SS_NTT_PART_LOCAL, log_expand, dst.data()));
+    std::vector<Buf> t = exchange_layout(out, elems);
+    out.clear();
+    dst.clear();
+    for (const Buf &b : t) dst.push_back(b->u64());
+    ok(ss_ntt_shard_fp252(ctx_, dst.data(), (uint32_t)dst.size(), log_n, log_R, r, SS_NTT_FORWARD, offset ? offset->data() : nullptr, SS_NTT_PART_CROSS, 0, nullptr));
+    return exchange_layout(t, elems);
+}
+
+// rows [r B, (r + 1) B + halo) mod N of vectors held as blocks of B rows: the rows behind a block come from the next ranks
+std::vector<ShardedProver::Buf> ShardedProver::with_halo(const std::vector<Buf> &blocks, uint64_t B, uint64_t halo) {
+    const uint32_t R = comm_.world, r = comm_.rank;
+    if (R == 1 || !halo) return blocks;
+    std::vector<Buf> out;
+    std::vector<Message> sends, recvs;
+    for (const Buf &b : blocks) {
+        Buf o = std::make_shared<DeviceBuffer>(ctx_, 32 * (B + halo));
+        ok(ss_dev_copy(ctx_, o->u8(), b->u8(), 32 * B));
+        for (uint64_t d = 1, left = halo; left; ++d) {
+            const uint64_t take = std::min(B, left);
+            recvs.push_back({(uint32_t)((r + d) % R), o->u8() + 32 * (B + (d - 1) * B), 32 * take});
+            sends.push_back({(uint32_t)((r + R - d % R) % R), b->u8(), 32 * take});
+            left -= take;
+        }
+        out.push_back(o);
+    }
+    comm_.exchange(ctx_, sends, recvs);
+    return out;
 }
 
 }  // namespace ssh

@@ -57,8 +57,17 @@ private:
     uint32_t owner(uint32_t col) const { return col % comm_.world; }
     std::vector<Buf> to_row_blocks(const std::map<uint32_t, Buf> &owned, uint32_t ncols, uint32_t first_col, uint64_t N, uint64_t halo);
     std::unique_ptr<Commitment> commit(const std::vector<Buf> &blocks, uint64_t N, int order);
+    std::unique_ptr<Commitment> commit(const std::vector<const uint64_t *> &blocks, uint64_t N, int order);
     void open(const Commitment &com, const std::vector<Buf> &blocks, uint64_t N, const std::vector<uint64_t> &positions, int order,
               std::vector<uint64_t> *rows, std::vector<uint8_t> *paths, std::vector<uint8_t> *leaves, std::vector<uint8_t> *tags);
+    void open(const Commitment &com, const std::vector<const uint64_t *> &blocks, uint64_t N, const std::vector<uint64_t> &positions, int order,
+              std::vector<uint64_t> *rows, std::vector<uint8_t> *paths, std::vector<uint8_t> *leaves, std::vector<uint8_t> *tags);
+    // ONE transform over the ranks (ss_ntt_shard_fp252): blocks of n / R values in natural order -> blocks of the bit-reversed
+    // coefficient array, and those (2^-log_expand sub-sampled) -> blocks of the evaluations; several vectors per call
+    std::vector<Buf> exchange_layout(const std::vector<Buf> &in, uint64_t elems);
+    std::vector<Buf> spread_inverse(const std::vector<Buf> &blocks, uint32_t log_n, const Felt *offset);
+    std::vector<Buf> spread_forward(const std::vector<Buf> &coeff_blocks, uint32_t log_n, uint32_t log_expand, const Felt *offset);
+    std::vector<Buf> with_halo(const std::vector<Buf> &blocks, uint64_t B, uint64_t halo);
     ss_ctx *ctx_;
     Claim claim_;
     Transport &comm_;

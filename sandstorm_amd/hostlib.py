@@ -39,7 +39,11 @@ def load():
         h.ssh_local_group_create.restype = C.c_void_p
         h.ssh_local_group_destroy.argtypes = [C.c_void_p]
         h.ssh_local_group_destroy.restype = None
-        h.ssh_prove_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_char_p,
+        h.ssh_rccl_group_create.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32]
+        h.ssh_rccl_group_create.restype = C.c_void_p
+        h.ssh_rccl_group_destroy.argtypes = [C.c_void_p]
+        h.ssh_rccl_group_destroy.restype = None
+        h.ssh_prove_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, SHARDED_EXT_CB, C.c_void_p,
                                         C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
         h.ssh_prove_wire_with_nonce.argtypes = h.ssh_prove.argtypes[:12] + [C.c_uint64] + h.ssh_prove.argtypes[12:]
@@ -456,16 +460,32 @@ class LocalGroup:
 
 
 def rccl_unique_id():
-    """the 128 bytes rank 0 makes and every rank passes to prove_sharded(group=<those bytes>) (ss_comm_unique_id)"""
+    """the 128 bytes rank 0 makes and hands to every rank for ITS RcclGroup (ss_comm_unique_id); an id makes one group"""
     buf = C.create_string_buffer(128)
     be.check(_lib.load().ss_comm_unique_id(buf))
     return buf.raw
 
 
+class RcclGroup:
+    """this rank's end of the RCCL communicator of ranks that are processes, one per GPU (host/sharded.cpp RcclTransport over
+    ss_comm_*): made once from rank 0's rccl_unique_id() and kept across proofs"""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self.world, self.rank = world, rank
+        self.h = load().ssh_rccl_group_create(ctx.handle, bytes(unique_id), rank, world)
+        if not self.h:
+            raise _lib.SandstormHipError("host: " + load().ssh_last_error().decode())
+
+    def close(self):
+        if self.h:
+            load().ssh_rccl_group_destroy(self.h)
+            self.h = None
+
+
 def prove_sharded(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, rank, world, group, my_base, log_n, build_extension, options=None):
     """ONE proof over `world` ranks by the C++ host (host/sharded.cpp; the Python mirror is sandstorm_amd/sharded_prover.py).  Called
-    by every rank with its own context and AIR handle.  group: a LocalGroup (ranks = threads of this process) or the 128 bytes of
-    rccl_unique_id() (one process per GPU, RCCL).  my_base: {column: device column} of the base columns with column % world ==
+    by every rank with its own context and AIR handle.  group: a LocalGroup (ranks = threads of this process) or this rank's
+    RcclGroup (one process per GPU).  my_base: {column: device column} of the base columns with column % world ==
     rank; build_extension(challenges) -> {global column number: device column} of this rank's extension columns (kept alive by
     the caller).  -> the proof in the reference's wire format on rank 0, None on the others."""
     options = options or ProofOptions()
@@ -492,7 +512,7 @@ def prove_sharded(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, ran
     out, n = C.POINTER(C.c_uint8)(), C.c_uint64()
     local = isinstance(group, LocalGroup)
     _check(load().ssh_prove_sharded(ctx.handle, air.h, tree_kind, n_friendly, coin_kind, bytes(seed), rank, world, group.h if local else None,
-                                    None if local else bytes(group), col_ids, be._ptr_array([my_base[c] for c in cols]), len(cols), log_n,
+                                    None if local else group.h, col_ids, be._ptr_array([my_base[c] for c in cols]), len(cols), log_n,
                                     SHARDED_EXT_CB(cb), None, opts, C.byref(out), C.byref(n)))
     if not n.value:
         return None

@@ -12,11 +12,15 @@ from tests.sharded_host_cases import GOLD, mini_case, recursive_case, run_ranks,
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world", [1, 2, 4, 8])
-@pytest.mark.parametrize("name,log_n,max_remainder", [("mini_proof_eth_log9.bin", 9, 4), ("mini_proof_eth_log5_nolayers.bin", 5, 32)])
+@pytest.fixture(autouse=True)
+def spread_small_fri_layers(monkeypatch):
+    """the ranks fold FRI layers above 2^21 values together: make these small proofs do it too (sharded.cpp)"""
+    monkeypatch.setenv("SSH_FRI_SPREAD_MIN_LOG", "6")
+
+
+@pytest.mark.parametrize("world,name,log_n,max_remainder", [(w, "mini_proof_eth_log9.bin", 9, 4) for w in (1, 2, 4, 8)]
+                         + [(w, "mini_proof_eth_log5_nolayers.bin", 5, 32) for w in (1, 2, 4)])     # a transform over R ranks has >= R^2 points
 def test_cpp_sharded_prover_writes_the_single_device_proofs(world, name, log_n, max_remainder):
-    if (1 << log_n) < 4 * world:
-        pytest.skip("fewer trace rows than the ranks' blocks need")
     make, _ = mini_case(log_n, max_remainder)
     with open(os.path.join(GOLD, name), "rb") as f:
         want = f.read()
@@ -35,10 +39,19 @@ def test_cpp_sharded_prover_friendly_tree_and_cairo_coin(world):
     assert run_ranks(world, make(world)) == want
 
 
-def test_cpp_sharded_prover_real_recursive_air_cairo_claim():
-    """the reference's example under the CLI's claim for it, 4 ranks: tests/golden/array_sum_recursive_cairo.proof (written by the
-    single-device C++ host on the MI355X), wrap-around halo of 4116 rows included"""
+@pytest.mark.parametrize("world", [4, 8])
+def test_cpp_sharded_prover_real_recursive_air_cairo_claim(world):
+    """the reference's example under the CLI's claim for it, 4 and 8 ranks: tests/golden/array_sum_recursive_cairo.proof (written by
+    the single-device C++ host on the MI355X), wrap-around halo of 4116 rows included; three extension columns, the composition
+    and DEEP's extension each ONE transform over the ranks, two FRI layers folded by the ranks"""
     make, _ = recursive_case(14)
     with open(os.path.join(GOLD, "array_sum_recursive_cairo.proof"), "rb") as f:
         want = f.read()
-    assert run_ranks(4, make(4)) == want
+    assert run_ranks(world, make(world)) == want
+
+
+def test_too_few_rows_for_the_ranks_is_an_error():
+    """a transform of fewer than R^2 points does not spread over R ranks: a message, not a wrong root"""
+    make, _ = mini_case(5, 32)
+    with pytest.raises(Exception, match="R\\^2|ranks"):
+        run_ranks(8, make(8))

@@ -10,11 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def run_ranks(world, make_rank, group=None):
+def run_ranks(world, make_rank, group=None, repeat=1):
     """make_rank(rank, ctx) -> (air, tree_kind, n_friendly, coin_kind, seed, my_base, log_n, build_extension, options); one
-    thread per rank -> rank 0's proof bytes.  group: a hostlib.LocalGroup (default) or rccl id bytes (world must be 1 per process)"""
+    thread per rank -> rank 0's proof bytes.  group: a hostlib.LocalGroup (default), or "rccl": every rank makes its RcclGroup from one
+    unique id (world must be 1: one process per GPU) and proves `repeat` times over it"""
     from sandstorm_amd import backend as be, hostlib
     own = group is None
+    rccl_id = hostlib.rccl_unique_id() if group == "rccl" else None
     if own:
         group = hostlib.LocalGroup(world)
     out, errs = [None] * world, [None] * world
@@ -24,9 +26,13 @@ def run_ranks(world, make_rank, group=None):
         try:
             ctx = be.Context(0)
             air, tree_kind, nf, coin_kind, seed, mine, log_n, ext, opt = make_rank(rank, ctx)
+            grp = hostlib.RcclGroup(ctx, rccl_id, rank, world) if rccl_id is not None else group
             try:
-                out[rank] = hostlib.prove_sharded(ctx, air, tree_kind, nf, coin_kind, seed, rank, world, group, mine, log_n, ext, opt)
-            finally:                             # everything that lives in the context's pool goes before the context does
+                for _ in range(repeat):          # a communicator outlives a proof (an RCCL unique id serves ONE ncclCommInitRank per rank)
+                    out[rank] = hostlib.prove_sharded(ctx, air, tree_kind, nf, coin_kind, seed, rank, world, grp, mine, log_n, ext, opt)
+            finally:
+                if rccl_id is not None:
+                    grp.close()                             # everything that lives in the context's pool goes before the context does
                 for m in getattr(ext, "matrices", []):
                     m.close()
                 air.close()

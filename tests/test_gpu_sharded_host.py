@@ -13,6 +13,12 @@ from tests.sharded_host_cases import GOLD, mini_case, recursive_case, run_ranks,
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def spread_small_fri_layers(monkeypatch):
+    """the ranks fold FRI layers above 2^21 values together: make these small proofs do it too (sharded.cpp)"""
+    monkeypatch.setenv("SSH_FRI_SPREAD_MIN_LOG", "6")
+
+
 @pytest.mark.parametrize("world", [1, 2, 4])
 @pytest.mark.parametrize("name,log_n,max_remainder", [("mini_proof_eth_log9.bin", 9, 4), ("mini_proof_eth_log5_nolayers.bin", 5, 32)])
 def test_cpp_sharded_prover_writes_the_single_device_proofs(world, name, log_n, max_remainder):
@@ -67,9 +73,9 @@ def test_cpp_sharded_prover_at_2p16_steps_two_ranks():
 
 def test_rccl_transport_with_a_group_of_one():
     """the RCCL path (ss_comm_create from a unique id, grouped send / receive, all-gather) as far as one GPU can take it: a group of
-    one - communicator set-up, the own-rank copies, the host all-gathers through device buffers"""
-    from sandstorm_amd import hostlib
+    one - communicator set-up, the own-rank copies, the host all-gathers through device buffers; the communicator is made once and
+    proves twice (an RCCL unique id serves one ncclCommInitRank per rank: ADVICE r3)"""
     make, _ = mini_case(9, 4)
     with open(os.path.join(GOLD, "mini_proof_eth_log9.bin"), "rb") as f:
         want = f.read()
-    assert run_ranks(1, make(1), group=hostlib.rccl_unique_id()) == want
+    assert run_ranks(1, make(1), group="rccl", repeat=2) == want
