@@ -423,15 +423,28 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
         # the C++ host's sharded prover (sandstorm_amd/host/sharded.cpp) over RCCL through the C ABI (ss_comm_*): rank 0 makes the
         # communicator's id, torch.distributed only hands it out
         if world == 1:                              # a group of one needs no communicator
-            box = [hostlib.LocalGroup(1)]
+            group = hostlib.LocalGroup(1)
         else:
+            # ONE communicator for the whole run, made before the warm-up (an RCCL unique id serves one ncclCommInitRank per
+            # rank; its set-up is not part of a proof).  A watchdog turns a bootstrap that never completes into an error.
+            import threading
             box = [hostlib.rccl_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
+            done = threading.Event()
+
+            def watchdog():
+                if not done.wait(float(os.environ.get("SS_BENCH_RCCL_TIMEOUT_S", "300"))):
+                    sys.stderr.write("bench.py: rank %d: the RCCL communicator of the C++ host did not come up (ss_comm_create)\n" % rank)
+                    sys.stderr.flush()
+                    os._exit(3)
+            threading.Thread(target=watchdog, daemon=True).start()
+            group = hostlib.RcclGroup(ctx, box[0], rank, world)
+            done.set()
         tree_kind, n_friendly = (be.TREE_FRIENDLY, 22) if layout == "recursive" else (be.TREE_KECCAK_M20, 0)
         wire_proof = [None]
 
         def prove_once():
-            wire_proof[0] = hostlib.prove_sharded(ctx, host_air, tree_kind, n_friendly, coin, seed, rank, world, box[0], mine, log_steps + 4,
+            wire_proof[0] = hostlib.prove_sharded(ctx, host_air, tree_kind, n_friendly, coin, seed, rank, world, group, mine, log_steps + 4,
                                                   build_extension, ProofOptions())
             return wire_proof[0]
     else:
@@ -488,10 +501,13 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
                                  % (slowest, world, world)},
             "config": {"workload": args.workload, "layout_shape": layout, "steps_log2": log_steps, "trace_rows_log2": log_steps + 4,
                        "columns": "%d base + %d extension" % (nb, ne),
-                       "parallelism": "ONE proof sharded over %d GPUs: LDE by column (column c on rank c %% %d), row hashing / constraint "
-                                      "evaluation / DEEP by row block (point-to-point re-shard over RCCL, wrap-around halo of %d rows), "
-                                      "leaf-block sub-trees + root all-gather, composition interpolation / DEEP extension / FRI on rank 0"
-                                      % (world, world, max(o for _, o in air.mask) << 1),
+                       "parallelism": ("ONE proof sharded over %d GPUs: base-column LDE by column (column c on rank c %% %d), row hashing / "
+                                       "constraint evaluation / DEEP by row block (point-to-point re-shard over RCCL, wrap-around halo of %d "
+                                       "rows), leaf-block sub-trees + root all-gather, " % (world, world, max(o for _, o in air.mask) << 1))
+                                      + ("extension columns / composition interpolation + extension / DEEP extension each ONE transform over "
+                                         "the ranks (two equal-split all-to-alls per transform), FRI layers above 2^21 values folded and "
+                                         "committed by all ranks, the rest on rank 0" if args.sharded_host == "cpp" else
+                                         "composition interpolation / DEEP extension / FRI on rank 0"),
                        "air": "the REAL %s AIR (%d mask cells) on synthetic columns" % (layout, len(air.mask)),
                        "claim": "CairoVerifierClaim (Blake2s+Pedersen-22 tree, Cairo coin)" if layout == "recursive"
                                 else "EthVerifierClaim (Keccak-masked-20 tree, Solidity coin)",
@@ -761,9 +777,10 @@ def main():
     ap.add_argument("--workload", default="starknet_2p20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true", help="skip the recursive_2p20 leg of the default run")
-    ap.add_argument("--sharded-host", default="python", choices=["python", "cpp"],
-                    help="--mode shard: the driver above the C ABI - sandstorm_amd/sharded_prover.py over torch.distributed (default: the "
-                         "one the multi-rank gloo tests run as it is launched here), or the C++ host's sharded.cpp over RCCL (ss_comm_*)")
+    ap.add_argument("--sharded-host", default="cpp", choices=["python", "cpp"],
+                    help="--mode shard: the driver above the C ABI - the C++ host's sharded.cpp over RCCL (ss_comm_*; default: every "
+                         "single-vector transform and the large FRI layers spread over the ranks), or sandstorm_amd/sharded_prover.py "
+                         "over torch.distributed (the older distribution: composition, DEEP extension and FRI on rank 0)")
     ap.add_argument("--mode", default="auto", choices=["auto", "shard", "replicas"],
                     help="N > 1 GPUs: shard = ONE proof over the N GPUs (column-sharded LDE, row-block hashing / constraints / DEEP, "
                          "RCCL point-to-point re-shards; strong scaling) - the default; replicas = one independent proof per GPU (weak scaling)")

@@ -88,7 +88,11 @@ ss_status ss_ctx_sync(ss_ctx *ctx);
 /* ss_dev_alloc/ss_dev_free are pooled (the role of GpuAllocator / PageAlignedAllocator,
  * src/lib.rs:27-28): a freed block is kept for reuse by later allocations of a similar size
  * on the same context, so steady-state proving makes no hipMalloc/hipFree calls.
- * ss_ctx_trim returns the cached blocks to the driver. */
+ * ss_ctx_trim returns the cached blocks to the driver, and with them the Pedersen window tables that no context of the process
+ * uses any more.  (Memory a process holds besides its buffers: twiddle plans, 36 B per point and (size, direction, offset);
+ * for FriendlyMerkleTree claims ONE fixed-base window table per device and process - 23.6 GB at the default 24-bit windows,
+ * narrower windows (6.4 / 1.75 / 0.47 / 0.13 GB) when the device's free memory does not leave 4 GiB beside it or SS_PED_WINDOW
+ * says so; built at the first friendly tree in ~0.1 s.) */
 ss_status ss_dev_alloc(ss_ctx *ctx, size_t bytes, void **d_out);
 ss_status ss_dev_free(ss_ctx *ctx, void *d_ptr);
 ss_status ss_ctx_trim(ss_ctx *ctx);

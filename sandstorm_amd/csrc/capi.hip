@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <utility>
@@ -405,6 +406,7 @@ ss_status ss_ctx_trim(ss_ctx *ctx) {
     if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->pool_trim();
+    pedersen_tables_trim();                      // the window tables of contexts that are gone (up to 23.6 GB per device)
     return SS_OK;
 }
 ss_status ss_upload(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes) {
@@ -465,8 +467,12 @@ struct Rccl {
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::string error;
-    bool load() {
-        if (lib) return true;
+    std::once_flag once;
+    bool load() {                               // two threads may create their communicators at once: one of them loads
+        std::call_once(once, [this] { load_once(); });
+        return lib != nullptr;
+    }
+    void load_once() {
         // one node, one process per GPU: the communicator's bootstrap runs over the loopback interface (on a box without any
         // other interface RCCL otherwise spends minutes probing); a deployment that wants something else sets the variable itself
         setenv("NCCL_SOCKET_IFNAME", "lo", 0);
@@ -479,7 +485,7 @@ struct Rccl {
             if (lib) break;
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
-        if (!lib) { error = std::string("RCCL not found: ") + dlerror(); return false; }
+        if (!lib) { error = std::string("RCCL not found: ") + dlerror(); return; }
         auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) error = std::string("RCCL lacks ") + n; return p; };
         GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
         CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
@@ -490,8 +496,7 @@ struct Rccl {
         Recv = (decltype(Recv))sym("ncclRecv");
         AllGather = (decltype(AllGather))sym("ncclAllGather");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        if (!GetUniqueId || !CommInitRank || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !AllGather) { lib = nullptr; return false; }
-        return true;
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !AllGather) lib = nullptr;
     }
 } g_rccl;
 constexpr int NCCL_INT8 = 0;                    // ncclInt8 / ncclChar
@@ -543,12 +548,18 @@ ss_status ss_comm_exchange(ss_comm *comm, uint32_t nsend, const uint32_t *send_p
         ++j;
     }
     if (comm->world == 1) return SS_OK;
+    // the group is closed on every path: a Send / Recv that fails inside an open group would leave this thread's later RCCL calls
+    // undefined; the first error is the one reported
     RCCL_TRY(g_rccl.GroupStart());
-    for (uint32_t i = 0; i < nsend; ++i)
-        if (send_peer[i] != r && send_bytes[i]) RCCL_TRY(g_rccl.Send(d_send[i], send_bytes[i], NCCL_INT8, (int)send_peer[i], comm->nccl, s));
-    for (uint32_t k = 0; k < nrecv; ++k)
-        if (recv_peer[k] != r && recv_bytes[k]) RCCL_TRY(g_rccl.Recv(d_recv[k], recv_bytes[k], NCCL_INT8, (int)recv_peer[k], comm->nccl, s));
-    RCCL_TRY(g_rccl.GroupEnd());
+    int first_err = 0;
+    const char *what = "";
+    for (uint32_t i = 0; i < nsend && !first_err; ++i)
+        if (send_peer[i] != r && send_bytes[i]) { first_err = g_rccl.Send(d_send[i], send_bytes[i], NCCL_INT8, (int)send_peer[i], comm->nccl, s); what = "ncclSend"; }
+    for (uint32_t k = 0; k < nrecv && !first_err; ++k)
+        if (recv_peer[k] != r && recv_bytes[k]) { first_err = g_rccl.Recv(d_recv[k], recv_bytes[k], NCCL_INT8, (int)recv_peer[k], comm->nccl, s); what = "ncclRecv"; }
+    const int end_err = g_rccl.GroupEnd();
+    if (first_err) return fail(SS_ERR_HIP, "RCCL: %s (%s)", g_rccl.GetErrorString ? g_rccl.GetErrorString(first_err) : "error", what);
+    if (end_err) return fail(SS_ERR_HIP, "RCCL: %s (ncclGroupEnd)", g_rccl.GetErrorString ? g_rccl.GetErrorString(end_err) : "error");
     return SS_OK;
 }
 ss_status ss_comm_all_gather(ss_comm *comm, const void *d_send, uint64_t bytes, void *d_recv) {

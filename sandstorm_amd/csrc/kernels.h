@@ -57,6 +57,7 @@ hipError_t launch_gather8(hipStream_t st, const uint8_t *in, const uint64_t *d_i
 struct PedersenTables;  // device-resident windowed tables, built once per context
 hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out);
 void pedersen_tables_destroy(PedersenTables *t);
+void pedersen_tables_trim();         // free the tables no context uses (ss_ctx_trim)
 // Every launcher takes `tmp`: PEDERSEN_TMP_FELTS_PER_HASH felts of device scratch per hash (Jacobian X and Z,
 // prefix products of the batched inversion, the chained digest of hash_elements).
 static constexpr uint64_t PEDERSEN_TMP_FELTS_PER_HASH = 4;

@@ -55,7 +55,7 @@ static constexpr int PED_PER_INPUT = PED_LOW_ENTRIES + PED_HIGH_ENTRIES;
 
 // device table layout per input: [nwin][2^W - 1] (window w covers scalar bits W w .. W w + W - 1 of the 252)
 static constexpr int PED_BITS = 252;
-static constexpr int PED_DEFAULT_WINDOW = 24;       // measured (profiles/r03_pedersen_windows.txt): Merkle stage of recursive_2p20 53.3 / 49.8 / 47.5 / 46.3 / 43.6 ms for 16 .. 24
+// the default window: the widest of 24 .. 16 bits that fits (pedersen_tables_create); measured (profiles/r03_pedersen_windows.txt): Merkle stage of recursive_2p20 53.3 / 49.8 / 47.5 / 46.3 / 43.6 ms for 16 .. 24
 static constexpr int PED_MAX_WINDOWS = 16;        // the lane-split kernel gives a window to each of 16 lanes per input
 
 struct PedersenTables {
@@ -151,26 +151,11 @@ static void build_bit_points(std::vector<Aff> &out) {
     batch_to_affine(jac, out);
 }
 
-hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
-    Aff shift;
-    (void)host_tables(&shift);
-    uint32_t W = PED_DEFAULT_WINDOW;
-    if (const char *e = getenv("SS_PED_WINDOW")) W = (uint32_t)strtoul(e, nullptr, 10);
-    if (W != 16 && W != 18 && W != 20 && W != 22 && W != 24) return hipErrorInvalidValue;
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return hipErrorInvalidDevice;
-    std::lock_guard<std::mutex> lock(g_ped_mutex);
-    for (size_t k = 0; k < g_ped_tables.size(); ++k) {
-        PedersenTables *c = g_ped_tables[k];
-        if (c->device != device) continue;
-        if (c->W == W) { c->users += 1; *out = c; return hipSuccess; }
-        if (c->users == 0) {                     // another width was asked for (SS_PED_WINDOW changed): replace the idle copy
-            (void)hipFree(c->d_table);
-            delete c;
-            g_ped_tables.erase(g_ped_tables.begin() + k);
-        }
-        break;
-    }
+static size_t ped_table_bytes(uint32_t W) {
+    const uint64_t nwin = (PED_BITS + W - 1) / W, span = (1ull << W) - 1ull;
+    return (size_t)(2ull * nwin * span * sizeof(Aff));
+}
+static hipError_t pedersen_tables_build(hipStream_t st, uint32_t W, int device, const Aff &shift, PedersenTables **out) {
     std::vector<Aff> bits;
     build_bit_points(bits);
     PedersenTables *t = new PedersenTables;
@@ -203,10 +188,70 @@ hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (d_bits) (void)hipFree(d_bits);
     if (d_half) (void)hipFree(d_half);
-    if (e != hipSuccess) { if (t->d_table) (void)hipFree(t->d_table); delete t; return e; }
+    if (e != hipSuccess) { if (t->d_table) (void)hipFree(t->d_table); delete t; (void)hipGetLastError(); return e; }
+    *out = t;
+    return hipSuccess;
+}
+
+// The window width: SS_PED_WINDOW if set (an error if that table does not fit), else the widest of 24 / 22 / 20 / 18 / 16 bits
+// whose table fits the device's FREE memory with 4 GiB to spare (23.6 / 6.4 / 1.75 / 0.47 / 0.13 GB: ranks that share one GPU, or
+// a GPU with little room, get a smaller table - 10 of the north-star proof's 218 ms - instead of an allocation error), stepping
+// down again if the allocation itself fails.
+hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
+    Aff shift;
+    (void)host_tables(&shift);
+    static const uint32_t widths[] = {24, 22, 20, 18, 16};
+    uint32_t forced = 0;
+    if (const char *e = getenv("SS_PED_WINDOW")) {
+        forced = (uint32_t)strtoul(e, nullptr, 10);
+        if (forced != 16 && forced != 18 && forced != 20 && forced != 22 && forced != 24) return hipErrorInvalidValue;
+    }
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_ped_mutex);
+    for (size_t k = 0; k < g_ped_tables.size(); ++k) {
+        PedersenTables *c = g_ped_tables[k];
+        if (c->device != device) continue;
+        if (!forced || c->W == forced) { c->users += 1; *out = c; return hipSuccess; }     // the copy the process already has
+        if (c->users == 0) {                     // another width was asked for (SS_PED_WINDOW changed): replace the idle copy
+            (void)hipFree(c->d_table);
+            delete c;
+            g_ped_tables.erase(g_ped_tables.begin() + k);
+        }
+        break;
+    }
+    hipError_t e = hipErrorOutOfMemory;
+    PedersenTables *t = nullptr;
+    if (forced) e = pedersen_tables_build(st, forced, device, shift, &t);
+    else {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = ~(size_t)0;
+        for (uint32_t W : widths) {
+            if (W != 16 && ped_table_bytes(W) + ((size_t)4 << 30) > free_b) continue;
+            e = pedersen_tables_build(st, W, device, shift, &t);
+            if (e != hipErrorOutOfMemory) break;
+        }
+    }
+    if (e != hipSuccess) return e;
     g_ped_tables.push_back(t);
     *out = t;
     return hipSuccess;
+}
+
+// ss_ctx_trim: the tables no context of this process uses any more go back to the driver (they are rebuilt in ~0.1 s)
+void pedersen_tables_trim() {
+    std::lock_guard<std::mutex> lock(g_ped_mutex);
+    for (size_t k = 0; k < g_ped_tables.size();) {
+        PedersenTables *c = g_ped_tables[k];
+        if (c->users == 0) {
+            int prev = 0;
+            const bool sw = hipGetDevice(&prev) == hipSuccess && prev != c->device && hipSetDevice(c->device) == hipSuccess;
+            (void)hipFree(c->d_table);
+            if (sw) (void)hipSetDevice(prev);
+            delete c;
+            g_ped_tables.erase(g_ped_tables.begin() + k);
+        } else ++k;
+    }
 }
 
 // pedersen_hash on the host, same windowed tables (used by the Fiat-Shamir coin only: the CairoVerifierPublicCoin chains ~155 of

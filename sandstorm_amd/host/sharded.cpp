@@ -66,7 +66,7 @@ public:
         rank = rank_; world = world_;
         ok(ss_comm_create(ctx, id, rank, world, &comm_));
     }
-    ~RcclTransport() override { ss_comm_destroy(comm_); }
+    ~RcclTransport() override { stage_.reset(); ss_comm_destroy(comm_); }
     void exchange(ss_ctx *, const std::vector<Message> &sends, const std::vector<Message> &recvs) override {
         std::vector<uint32_t> sp, rp;
         std::vector<const void *> sb;
@@ -80,14 +80,18 @@ public:
         const uint64_t n = mine.size();
         std::vector<uint8_t> out(n * world);
         if (!n) return out;
-        DeviceBuffer d_in(ctx, (n + 15) / 16 * 16), d_out(ctx, (n * world + 15) / 16 * 16);
-        ok(ss_upload(ctx, d_in.u8(), mine.data(), n));
-        ok(ss_comm_all_gather(comm_, d_in.u8(), n, d_out.u8()));
-        ok(ss_download(ctx, out.data(), d_out.u8(), n * world));
+        // the host all-gathers are small and many (roots, out-of-domain values, openings): one staging buffer kept by the transport
+        const size_t in_bytes = (n + 255) / 256 * 256, need = in_bytes + n * world;
+        if (!stage_ || stage_->bytes() < need) stage_.reset(new DeviceBuffer(ctx, std::max<size_t>(need, 1 << 16)));
+        uint8_t *d_in = stage_->u8(), *d_out = d_in + in_bytes;
+        ok(ss_upload(ctx, d_in, mine.data(), n));
+        ok(ss_comm_all_gather(comm_, d_in, n, d_out));
+        ok(ss_download(ctx, out.data(), d_out, n * world));
         return out;
     }
 private:
     ss_comm *comm_ = nullptr;
+    std::unique_ptr<DeviceBuffer> stage_;
 };
 }  // namespace
 

@@ -98,6 +98,7 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     p->totalGlobalMem = (size_t)1 << 34;
     return hipSuccess;
 }
+static inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) { *free_b = (size_t)8 << 30; *total_b = (size_t)16 << 30; return hipSuccess; }
 static inline hipError_t hipMalloc(void **p, size_t bytes) { *p = malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <class T>
 static inline hipError_t hipMalloc(T **p, size_t bytes) { return hipMalloc((void **)p, bytes); }

@@ -49,9 +49,8 @@ def run_ranks(world, make_rank, group=None, repeat=1):
         t.join()
     if own:
         group.close()
-    for e in errs:
-        if e is not None:
-            raise e
+    for e in sorted((e for e in errs if e is not None), key=lambda e: "another rank failed" in str(e)):
+        raise e                                  # the rank that failed first, not the ones it released from their barriers
     assert all(o is None for o in out[1:])
     return out[0]
 
@@ -138,3 +137,42 @@ def recursive_case(log_steps, claim="cairo"):
             return air, tree, nf, coin, seed, mine, log_n, ext, opt
         return make_rank
     return make, (tree, nf, coin, opt, host, log_n, pi, seed)
+
+
+def starknet_case(log_steps):
+    """the reference's array-sum run re-declared for the starknet layout and padded to 2^log_steps steps (tests/test_layout_starknet.py
+    starknet_example), the real 195-constraint AIR, C++ trace generator; CLI-default options; the Eth claim's parts (masked Keccak trees,
+    Solidity coin) - the statement tests/test_gpu_full_size.py proves on one device"""
+    from sandstorm_amd import backend as be, binary, hostlib, public_input
+    from sandstorm_amd.layouts import starknet as sk
+    from sandstorm_amd.prover import ProofOptions
+    from tests.test_layout_starknet import starknet_example
+    states, memory, spi = starknet_example(log_steps)
+    host = hostlib.starknet_base_trace(binary.write_register_states(states), binary.write_memory(memory), spi)
+    del states, memory
+    log_n = log_steps + 4
+    n = 1 << log_n
+    tree, nf, coin = be.TREE_KECCAK_M20, 0, be.COIN_SOLIDITY
+    seed = public_input.public_coin_seed(spi, coin)
+    opt = ProofOptions()
+    nb = len(host)
+    aux_cols = (sk.COL_NPC, sk.COL_MEMORY, sk.COL_RANGE_CHECK)
+
+    def make(world):
+        def make_rank(rank, ctx):
+            air = hostlib.StarknetHostAir(ctx, spi, log_n)
+            mine = {c: ctx.column(v) for c, v in enumerate(host) if c % world == rank}
+            keep = []
+
+            def ext(challenges):
+                if nb % world != rank:               # the one extension column is column nb
+                    return {}
+                aux = [mine[c] if c in mine else ctx.column(host[c]) for c in aux_cols]
+                m = hostlib.build_extension_columns(ctx, "starknet", aux, n, challenges)
+                keep.append(aux)
+                ext.matrices.append(m)
+                return {nb: m.cols[0]}
+            ext.matrices = []
+            return air, tree, nf, coin, seed, mine, log_n, ext, opt
+        return make_rank
+    return make, (tree, nf, coin, opt, host, log_n, spi, seed)

@@ -103,11 +103,35 @@ def test_sharded_driver_two_ranks_real_starknet_air(tmp_path):
     assert run_sharded_gpu(2, "starknet:18", tmp_path, "gloo", timeout=1500) == want
 
 
-def test_starknet_2p22_steps_real_statement_proves_and_verifies():
-    """BASELINE configs[3]'s statement size (2^26 rows x 10 columns: 21 GB of base trace, 43 GB of LDE) on ONE device -
-    the capacity check behind DESIGN's "sized for 288 GB"; on the driver's 8-GPU node the same statement size is what
-    `bench.py --gpus 8 --workload starknet_2p22` shards"""
+def test_cpp_sharded_host_two_ranks_at_2p20_steps_real_starknet_air(proof_2p20):
+    """the C++ host's sharded prover (host/sharded.cpp) at BASELINE configs[2]'s size on two ranks - threads of this process, each
+    with its own context on this box's GPU: column-owned base LDE and re-shard with the 66 316-row halo, the extension column, the
+    composition (one 2^25-point inverse, two extensions) and DEEP's extension each ONE transform over the ranks, FRI layers 0 and
+    1 (2^25 and 2^22 values) folded and committed by both ranks - the single-device proof, byte for byte"""
+    from tests.sharded_host_cases import run_ranks, starknet_case
+    make, _ = starknet_case(20)
+    assert run_ranks(2, make(2)) == proof_2p20
+
+
+@pytest.fixture(scope="module")
+def proof_2p22():
     import torch
     if torch.cuda.mem_get_info(0)[1] < 200 << 30:
         pytest.skip("needs an MI355X-sized device")
-    _prove_and_verify(22, python_verifier=False)
+    return _prove_and_verify(22, python_verifier=False)
+
+
+def test_starknet_2p22_steps_real_statement_proves_and_verifies(proof_2p22):
+    """BASELINE configs[3]'s statement size (2^26 rows x 10 columns: 21 GB of base trace, 43 GB of LDE) on ONE device -
+    the capacity check behind DESIGN's "sized for 288 GB"; on the driver's 8-GPU node the same statement size is what
+    `bench.py --gpus 8 --workload starknet_2p22` shards"""
+    assert len(proof_2p22) > 100_000
+
+
+def test_cpp_sharded_host_two_ranks_at_2p22_steps(proof_2p22):
+    """BASELINE configs[3] in its stated form as far as one GPU goes: the 2^22-step statement SHARDED - two ranks (threads, own
+    contexts, this box's GPU, which holds both ranks' 2^27-row working sets; on the driver's node: one process per GPU over RCCL,
+    the same driver) - writes the single-device proof of the same statement, byte for byte"""
+    from tests.sharded_host_cases import run_ranks, starknet_case
+    make, _ = starknet_case(22)
+    assert run_ranks(2, make(2)) == proof_2p22
