@@ -118,7 +118,7 @@ def python_host_proof(ctx, layout, log_steps, proofs=1):
     import numpy as np
     from sandstorm_amd import backend as be, extension
     from sandstorm_amd.prover import Claim, ProofOptions, Prover
-    from tests.util import random_column
+    from sandstorm_amd.examples import random_column
     L, pi = _sample_statement(layout, log_steps)
     n = 16 << log_steps
     air = L.make_air(ctx, pi, n)
@@ -589,6 +589,77 @@ def stage_algorithmic_bytes(nb, ne, log_n, lb, fri_layers, fold=8):
     return out
 
 
+def end_to_end(ctx, layout, log_steps, device, repeats=3):
+    """`files -> proof`: what the reference's "Proof generated in" timer wraps - claim.prove(options, witness) (cli/src/main.rs:200-202)
+    INCLUDES generate_trace (src/lib.rs:94-100).  A REAL statement of the layout at this step count (the reference's example run
+    re-declared and padded with its final state: sandstorm_amd/examples.py; the same statements tests/test_gpu_full_size.py and
+    tests/test_gpu_recursive_claim.py prove and verify); the raw `cairo-run` bytes are the input:
+      trace_gen_s  the C++ host's ExecutionTrace::new (OpenMP over the host's cores) straight into PINNED host columns
+                   (the GpuAllocator seam, layouts/src/recursive/trace.rs:115-120), allocated once like the reference's vectors
+      h2d_s        the columns to HBM (one async copy per column, then a sync)
+      prove_s      the proof by the C++ host: every stage of bench.py's timed region plus the REAL extension columns (check on)
+    -> the means over `repeats` runs after one untimed run (pinned pages touched, plans and tables built)."""
+    from sandstorm_amd import backend as be, binary, examples, hostlib, public_input
+    from sandstorm_amd.prover import ProofOptions
+    log_n = log_steps + 4
+    n = 1 << log_n
+    if layout == "starknet":
+        from sandstorm_amd.layouts import starknet as sk
+        states, memory, xpi = examples.starknet_example(log_steps)
+        gen, nb = hostlib.starknet_base_trace, 9
+        aux_idx = (sk.COL_NPC, sk.COL_MEMORY, sk.COL_RANGE_CHECK)
+        tree_kind, n_friendly, coin_kind = be.TREE_KECCAK_M20, 0, be.COIN_SOLIDITY
+        air = hostlib.StarknetHostAir(ctx, xpi, log_n, 1)
+    else:
+        from sandstorm_amd.layouts import recursive as rec
+        states, memory, xpi = examples.recursive_example(log_steps)
+        gen, nb = hostlib.recursive_base_trace, 7
+        aux_idx = (rec.COL_NPC, rec.COL_MEMORY, rec.COL_RANGE_CHECK, rec.COL_DILUTED_UNORDERED, rec.COL_DILUTED_ORDERED)
+        tree_kind, n_friendly, coin_kind = be.TREE_FRIENDLY, 22, be.COIN_CAIRO
+        air = hostlib.RecursiveHostAir(ctx, xpi, log_n, 1)
+    trace_bin, memory_bin = binary.write_register_states(states), binary.write_memory(memory)
+    del states, memory
+    seed = public_input.public_coin_seed(xpi, coin_kind)
+    pinned = [torch.empty((n, 4), dtype=torch.int64).pin_memory() for _ in range(nb)]
+    views = [t.numpy().view("uint64") for t in pinned]
+    dev = [torch.empty((n, 4), dtype=torch.int64, device=device) for _ in range(nb)]
+    keep = []
+
+    def build_extension(challenges):
+        del keep[:]
+        keep.append(hostlib.build_extension_columns(ctx, layout, [dev[c] for c in aux_idx], n, challenges))
+        return keep[0].cols
+    options = ProofOptions()
+    acc = {"trace_gen_s": 0.0, "h2d_s": 0.0, "prove_s": 0.0}
+    for it in range(repeats + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gen(trace_bin, memory_bin, xpi, out=views)
+        t1 = time.perf_counter()
+        for c in range(nb):
+            dev[c].copy_(pinned[c], non_blocking=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        hostlib.prove(ctx, air, tree_kind, n_friendly, coin_kind, seed, dev, log_n, build_extension, options, want_proof=False)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        if it:
+            acc["trace_gen_s"] += t1 - t0
+            acc["h2d_s"] += t2 - t1
+            acc["prove_s"] += t3 - t2
+    for m in keep:
+        m.close()
+    del keep[:], dev, pinned, views
+    air.close()
+    out = {k: v / repeats for k, v in acc.items()}
+    out["total_s"] = sum(out.values())
+    out["host_threads"] = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    out["statement"] = ("the reference's array-sum run re-declared for the %s layout, padded to 2^%d steps (a real, verifiable statement: "
+                        "%d base columns x 2^%d rows from %.1f MB of trace.bin / memory.bin); upload and proof are not overlapped"
+                        % (layout, log_steps, nb, log_n, (len(trace_bin) + len(memory_bin)) / 1e6))
+    return out
+
+
 def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, cpu_leg):
     """K whole proofs of one workload through the C++ host on this rank's GPU -> the report (rank 0) or None"""
     from sandstorm_amd import backend as be, extension, hostlib, public_input
@@ -755,6 +826,8 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
                                                     "(BASELINE.md section 1: other hardware, older CLI, the real AIR)")
         if cpu_leg:
             out["cpu_baseline"] = cpu_baseline(layout, log_steps, ctx)
+        if world == 1 and not real and not args.no_end_to_end and log_steps >= 17:
+            out["end_to_end"] = end_to_end(ctx, layout, log_steps, device)
     # everything that lives in the context's pool goes before the context does
     if real:
         for m in keep:
@@ -777,6 +850,7 @@ def main():
     ap.add_argument("--workload", default="starknet_2p20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true", help="skip the recursive_2p20 leg of the default run")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the files -> proof leg (trace generation + upload + proof of a real statement)")
     ap.add_argument("--sharded-host", default="cpp", choices=["python", "cpp"],
                     help="--mode shard: the driver above the C ABI - the C++ host's sharded.cpp over RCCL (ss_comm_*; default: every "
                          "single-vector transform and the large FRI layers spread over the ranks), or sandstorm_amd/sharded_prover.py "

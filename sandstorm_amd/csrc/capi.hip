@@ -53,9 +53,12 @@ struct PlanKey {
     uint32_t log_n;
     int inverse;
     uint32_t off[8];
+    uint32_t win_stages = 0, win_first = 0;      // the plan of a windowed top pass (ss_ntt_shard_fp252): its stages, the window's first q
     bool operator<(const PlanKey &o) const {
         if (log_n != o.log_n) return log_n < o.log_n;
         if (inverse != o.inverse) return inverse < o.inverse;
+        if (win_stages != o.win_stages) return win_stages < o.win_stages;
+        if (win_first != o.win_first) return win_first < o.win_first;
         return memcmp(off, o.off, sizeof off) < 0;
     }
 };
@@ -114,6 +117,17 @@ struct ss_ctx {
         pool_free.clear();
         pool_cached = 0;
     }
+    // hipMalloc for what lives outside the pool (plans, scratch): out of memory gives the pool's cache back and tries once more
+    hipError_t malloc_retry(void **p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipErrorOutOfMemory && !pool_free.empty()) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(stream);
+            pool_trim();
+            e = hipMalloc(p, bytes);
+        }
+        return e;
+    }
 
     bool prof_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[SS_PROF_KINDS];
@@ -146,14 +160,15 @@ struct ss_ctx {
     ss_status ensure_scratch(size_t bytes) {
         if (bytes <= scratch_bytes) return SS_OK;
         if (scratch) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(scratch)); scratch = nullptr; scratch_bytes = 0; }
-        HIP_TRY(hipMalloc(&scratch, bytes));
+        HIP_TRY(malloc_retry(&scratch, bytes));
         scratch_bytes = bytes;
         return SS_OK;
     }
 
     // Twiddle plan for the stage network of size 2^log_n: T_s[k] = h^(n/2^(s+1)) * r^(k n/2^(s+1)),
     // r = w (forward) or w^-1 (inverse), h = offset or offset^-1.  Written into d_tw (n-1 felts).
-    ss_status build_plan(uint32_t log_n, bool inverse, const Fp &offset, Fp *d_tw, bool bitrev_levels = false) {
+    ss_status build_plan(uint32_t log_n, bool inverse, const Fp &offset, Fp *d_tw, bool bitrev_levels = false, const NttWindow *win = nullptr,
+                         uint32_t win_stages = 0) {
         const uint64_t n = 1ull << log_n;
         Fp r = root_of_unity(log_n), h = offset;
         if (inverse) { r = fp_inv(r); h = fp_inv(h); }
@@ -175,22 +190,27 @@ struct ss_ctx {
         HIP_TRY(hipMalloc(&d_tabs, host.size() * sizeof(Fp)));
         HIP_TRY(hipMemcpyAsync(d_tabs, host.data(), host.size() * sizeof(Fp), hipMemcpyHostToDevice, stream));
         if (log_n > 0)
-            HIP_TRY(launch_twiddles(stream, d_tw, d_tabs, d_tabs + n_lo, d_tabs + n_lo + n_hi, log_n, h_is_one, bitrev_levels));
+            HIP_TRY(launch_twiddles(stream, d_tw, d_tabs, d_tabs + n_lo, d_tabs + n_lo + n_hi, log_n, h_is_one, bitrev_levels, win, win_stages));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipFree(d_tabs));
         return SS_OK;
     }
     // cached plans: the per-proof-invariant ones (trace / LDE / FRI domains)
     // bitrev_levels: every level's entries in bit-reversed order (PLAN_BITREV: what the CTI network of ntt_pass_kernel reads)
-    ss_status get_plan(uint32_t log_n, bool inverse, const Fp &offset, const Fp **out, bool bitrev_levels = false) {
+    // win: only what the windowed top pass of `win_stages` stages reads (ntt.hip PassParams.tw_entries): a transform spread over
+    // R ranks costs a rank (R - 1) / R^2 of the whole plan's memory, not all of it
+    ss_status get_plan(uint32_t log_n, bool inverse, const Fp &offset, const Fp **out, bool bitrev_levels = false, const NttWindow *win = nullptr,
+                       uint32_t win_stages = 0) {
         PlanKey key;
         key.log_n = log_n; key.inverse = (inverse ? 1 : 0) | (bitrev_levels ? 2 : 0);
+        if (win) { key.win_stages = win_stages; key.win_first = win->first; }
         memcpy(key.off, offset.v, sizeof key.off);
         auto it = plans.find(key);
         if (it != plans.end()) { *out = it->second; return SS_OK; }
         Fp *d_tw = nullptr;
-        HIP_TRY(hipMalloc(&d_tw, ((1ull << log_n) > 1 ? (1ull << log_n) - 1 : 1) * NTT_PLAN_ENTRY_BYTES + 64));
-        ss_status st = build_plan(log_n, inverse, offset, d_tw, bitrev_levels);
+        const uint64_t entries = win ? ntt_window_plan_entries(*win, win_stages) : ((1ull << log_n) > 1 ? (1ull << log_n) - 1 : 1);
+        HIP_TRY(malloc_retry((void **)&d_tw, entries * NTT_PLAN_ENTRY_BYTES + 64));
+        ss_status st = build_plan(log_n, inverse, offset, d_tw, bitrev_levels, win, win_stages);
         if (st != SS_OK) { (void)hipFree(d_tw); return st; }
         plans[key] = d_tw;
         *out = d_tw;
@@ -203,7 +223,7 @@ struct ss_ctx {
         const size_t need = (size_t)1 << log_n;
         if (need > transient_elems) {
             if (transient_tw) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(transient_tw)); transient_tw = nullptr; }
-            HIP_TRY(hipMalloc(&transient_tw, need * NTT_PLAN_ENTRY_BYTES + 64));
+            HIP_TRY(malloc_retry((void **)&transient_tw, need * NTT_PLAN_ENTRY_BYTES + 64));
             transient_elems = need;
         }
         ss_status st = build_plan(log_n, inverse, offset, transient_tw);
@@ -217,7 +237,7 @@ struct ss_ctx {
     ss_status ensure_scratch2(size_t bytes) {
         if (bytes <= scratch2_bytes) return SS_OK;
         if (scratch2) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(scratch2)); scratch2 = nullptr; scratch2_bytes = 0; }
-        HIP_TRY(hipMalloc(&scratch2, bytes));
+        HIP_TRY(malloc_retry(&scratch2, bytes));
         scratch2_bytes = bytes;
         return SS_OK;
     }
@@ -740,18 +760,22 @@ ss_status ss_ntt_shard_fp252(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncol
         if (st != SS_OK) return st;
         return run_inverse(ctx, cols, ncols, log_local, tw, NTT_MODE_DIF, log_n);
     }
-    // the top log_ranks stages: one windowed pass over the rank's share of every row (ntt.hip PassParams), twiddles from the
-    // whole transform's plan
-    ss_status st = inverse ? ctx->get_plan(log_n, true, off, &tw, cti) : ctx->get_plan(log_n, false, off, &tw);
-    if (st != SS_OK) return st;
+    // the top log_ranks stages: one windowed pass over the rank's share of every row (ntt.hip PassParams) with a plan that holds
+    // what this window's butterflies read - DIT / DIF: (2^log_ranks - 1) window lengths of the top stages' entries; CTI: its top
+    // levels ARE the plan of a transform of 2^log_ranks points
     NttWindow win;
     win.log_len = log_local - log_ranks;
     win.first = rank << win.log_len;
+    uint64_t tw_entries;
+    ss_status st;
+    if (cti) { tw_entries = (1ull << log_ranks) - 1ull; st = ctx->get_plan(log_ranks, true, fp_one(), &tw, true); }
+    else { tw_entries = ntt_window_plan_entries(win, log_ranks); st = ctx->get_plan(log_n, inverse, off, &tw, false, &win, log_ranks); }
+    if (st != SS_OK) return st;
     const uint32_t lt = (uint32_t)ntt_log_tile_max();
     const uint32_t log_t = win.log_len < lt - log_ranks ? win.log_len : lt - log_ranks;
     ss_ctx::Scope prof(ctx, SS_PROF_NTT_PASS);
     HIP_TRY(launch_ntt_pass(ctx->stream, inverse ? (cti ? NTT_MODE_CTI : NTT_MODE_DIF) : NTT_MODE_DIT, cols, ncols, tw, log_n, log_local, log_ranks,
-                            log_ranks + log_t, 0, 0, 0, !inverse, true, &win));
+                            log_ranks + log_t, 0, 0, 0, !inverse, true, &win, tw_entries));
     return SS_OK;
 }
 

@@ -29,9 +29,11 @@ struct NttWindow { uint32_t first, log_len; };
 hipError_t launch_ntt_pass(hipStream_t st, int mode, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
                            uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first,
                            uint32_t log_expand, uint32_t scale_pow2, bool final_pass, bool cti_trivial = true,
-                           const NttWindow *win = nullptr);
+                           const NttWindow *win = nullptr, uint64_t tw_entries = 0);      // tw_entries: of a window's plan (0: 2^log_n - 1)
 hipError_t launch_twiddles(hipStream_t st, Fp *tw, const Fp *pow_lo, const Fp *pow_hi, const Fp *hpow,
-                           uint32_t log_n, bool h_is_one, bool bitrev_levels);
+                           uint32_t log_n, bool h_is_one, bool bitrev_levels, const NttWindow *win = nullptr, uint32_t win_stages = 0);
+// entries of the plan of a windowed top pass of `stages` stages (DIT / DIF; ntt.hip PassParams.tw_entries)
+static inline uint64_t ntt_window_plan_entries(const NttWindow &win, uint32_t stages) { return (((uint64_t)1 << stages) - 1ull) << win.log_len; }
 hipError_t launch_bitrev(hipStream_t st, Fp *a, uint32_t log_n);
 hipError_t launch_mul_bench(hipStream_t st, const Fp *a, const Fp *b, Fp *out, uint64_t n, uint32_t reps);
 hipError_t ntt_set_func_attributes();

@@ -186,6 +186,11 @@ struct PassParams {
     // global index (j << s0) | q, lives at (j << win_log) + (q - win0) of the column's buffer.  win_log1 = win_log + 1, 0 = off.
     uint32_t win_log1, win0;
     uint32_t cti_trivial; // CTI: the plan's offset is one, so zeta = 1 at the root and the left node of level 1 (radix_stage)
+    // entries per plane of the plan: 2^log_n - 1, or fewer for the plan of a windowed pass - which only holds what the window's
+    // butterflies read.  DIT / DIF: stage s0 + v (v < r) needs T_s[(jl << s0) | q] for jl < 2^v and the window's q; stored at
+    // ((2^v - 1 + jl) << win_log) + (q - win0) (twiddle_kernel, `window` mode).  CTI: its top r levels are the whole plan of a
+    // transform of 2^r points (T_level[J] = w^-(bitrev(J) n / 2^(level+1)) is the same for every n).
+    uint32_t tw_entries;
 };
 // where element g of the transform lives in the column's buffer
 __device__ __forceinline__ uint32_t mem_index(const PassParams &p, uint32_t g) {
@@ -248,7 +253,9 @@ __device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const TwPlanes &tw,
         const uint32_t level = p.log_n - 1u - s;
         tw_base = ((1u << level) - 1u) + ((g0 >> (gsh + G)) << (G - 1 - STC));
     } else {
-        tw_base = ((1u << s) - 1u) + (g0 & ((1u << gsh) - 1u));
+        const uint32_t klow = g0 & ((1u << gsh) - 1u);
+        if (p.win_log1) tw_base = ((((1u << (s - p.s0)) - 1u) + (klow >> p.s0)) << (p.win_log1 - 1u)) + ((klow & ((1u << p.s0) - 1u)) - p.win0);
+        else tw_base = ((1u << s) - 1u) + klow;
     }
     // CTI: the transform's first two levels (the top register group of its first pass) have zeta = 1 at the root and at the
     // left node of level 1; (wave-uniform branch)
@@ -264,8 +271,9 @@ __device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const TwPlanes &tw,
             x[m | (1 << STC)] = lvl0 ? fl_sub_c<2, 1>(a, b) : fl_sub_c<8, 2>(a, b);
             continue;
         }
+        // the partner index bits of this pair move the row: + (m_low << u) rows, a window-length each in a window's plan
         const uint32_t k = MODE == MODE_CTI ? tw_base + (uint32_t)(pr >> STC)
-                                            : tw_base + ((uint32_t)(m & ((1 << STC) - 1)) << gsh);
+                                            : tw_base + ((uint32_t)(m & ((1 << STC) - 1)) << (p.win_log1 ? u + p.win_log1 - 1u : gsh));
 #ifdef SS_NTT_ABL_NOTW      // timing ablation only (wrong results): no twiddle loads
         Fl t = x[m]; t.l[0] += k;
 #else
@@ -384,7 +392,7 @@ void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw_plan, PassParams p)
     t.base = (lds_bytes_ptr)smem;
     TwPlanes tw;
     {
-        const uint64_t tw_total = (1ull << p.log_n) - 1ull;
+        const uint64_t tw_total = p.tw_entries;
         tw.lo = reinterpret_cast<const uint4 *>(tw_plan);
         tw.hi = tw.lo + tw_total;
         tw.top = reinterpret_cast<const u32 *>(tw.lo + 2 * tw_total);
@@ -468,14 +476,22 @@ void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw_plan, PassParams p)
 // 2^256 reduction (~185 instead of 223 + 12 VALU instructions per butterfly multiplication).
 __global__ void twiddle_kernel(Fp *__restrict__ tw, const Fp *__restrict__ pow_lo,
                                const Fp *__restrict__ pow_hi, const Fp *__restrict__ hpow,
-                               uint32_t log_n, int h_is_one, int bitrev_levels) {
-    const uint64_t total = (1ull << log_n) - 1ull;
+                               uint32_t log_n, int h_is_one, int bitrev_levels, uint32_t win_s0, uint32_t win_log, uint32_t win0,
+                               uint64_t total) {
+    // total = 2^log_n - 1 entries (stage s at 2^s - 1), or - win_s0 != 0 - the plan of a windowed top pass (PassParams.tw_entries):
+    // entry ((2^v - 1 + jl) << win_log) + dq is T_(win_s0 + v)[(jl << win_s0) | (win0 + dq)]
     uint4 *plane_lo = reinterpret_cast<uint4 *>(tw), *plane_hi = plane_lo + total;
     u32 *plane_top = reinterpret_cast<u32 *>(plane_hi + total);
     for (uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t s = 63u - (uint32_t)__clzll(idx + 1ull);
+        uint32_t s = 63u - (uint32_t)__clzll(idx + 1ull);
         uint64_t k = idx + 1ull - (1ull << s);
+        if (win_s0) {
+            const uint64_t t = idx >> win_log;
+            const uint32_t v = 63u - (uint32_t)__clzll(t + 1ull);
+            s = win_s0 + v;
+            k = ((t + 1ull - (1ull << v)) << win_s0) | (win0 + (idx & ((1ull << win_log) - 1ull)));
+        }
         // PLAN_BITREV (the CTI network, ntt_pass_kernel): entry J of level s is the natural plan's entry bitrev_s(J)
         if (bitrev_levels && s) k = __brevll(k) >> (64u - s);
         const uint64_t e = k << (log_n - 1u - s);          // exponent of the n-th root, < n/2
@@ -517,8 +533,10 @@ __global__ void mul_bench_kernel(const Fp *__restrict__ a, const Fp *__restrict_
 // ------------------------------------------------------------ host launch
 hipError_t launch_ntt_pass(hipStream_t st, int mode, const ColPtrs &cols, uint32_t ncols, const Fp *tw,
                            uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first,
-                           uint32_t log_expand, uint32_t scale_pow2, bool final_pass, bool cti_trivial, const NttWindow *win) {
+                           uint32_t log_expand, uint32_t scale_pow2, bool final_pass, bool cti_trivial, const NttWindow *win,
+                           uint64_t tw_entries) {
     PassParams p;
+    p.tw_entries = tw_entries ? (uint32_t)tw_entries : (uint32_t)((1ull << log_n) - 1ull);
     p.final_pass = final_pass ? 1u : 0u;
     p.log_n = log_n; p.s0 = s0; p.r = r; p.log_tile = log_tile; p.u_first = u_first;
     p.log_expand = log_expand; p.scale_pow2 = scale_pow2; p.contig = (s0 == 0);
@@ -544,13 +562,13 @@ hipError_t launch_ntt_pass(hipStream_t st, int mode, const ColPtrs &cols, uint32
 }
 
 hipError_t launch_twiddles(hipStream_t st, Fp *tw, const Fp *pow_lo, const Fp *pow_hi, const Fp *hpow,
-                           uint32_t log_n, bool h_is_one, bool bitrev_levels) {
-    const uint64_t total = (1ull << log_n) - 1ull;
+                           uint32_t log_n, bool h_is_one, bool bitrev_levels, const NttWindow *win, uint32_t win_stages) {
+    const uint64_t total = win ? (((uint64_t)1 << win_stages) - 1ull) << win->log_len : (1ull << log_n) - 1ull;
     uint32_t blocks = (uint32_t)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(twiddle_kernel, dim3(blocks), dim3(256), 0, st, tw, pow_lo, pow_hi, hpow, log_n,
-                       h_is_one ? 1 : 0, bitrev_levels ? 1 : 0);
+                       h_is_one ? 1 : 0, bitrev_levels ? 1 : 0, win ? log_n - win_stages : 0u, win ? win->log_len : 0u, win ? win->first : 0u, total);
     return hipGetLastError();
 }
 

@@ -239,8 +239,7 @@ int ssh_recursive_base_trace(const uint8_t *trace_bin, uint64_t trace_len, const
         std::vector<U256> memory;
         std::vector<uint8_t> present;
         read_memory(memory_bin, memory_len, memory, present);
-        const auto cols = recursive_base_trace(states, memory, present, pi, priv);
-        for (size_t c = 0; c < cols.size(); ++c) memcpy(columns_out[c], cols[c].data(), cols[c].size() * 32);
+        recursive_base_trace_into(reinterpret_cast<Felt *const *>(columns_out), states, memory, present, pi, priv);
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }

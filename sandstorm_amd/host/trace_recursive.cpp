@@ -59,6 +59,17 @@ void read_memory(const uint8_t *data, size_t len, std::vector<U256> &memory, std
 
 std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
                                                     const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv) {
+    std::vector<std::vector<Felt>> cols(NUM_COLS);
+    Felt *out[NUM_COLS];
+    for (int c = 0; c < NUM_COLS; ++c) { cols[c].resize(states.size() * CYCLE_HEIGHT); out[c] = cols[c].data(); }
+    recursive_base_trace_into(out, states, memory, present, pi, priv);
+    return cols;
+}
+
+// the same into the caller's columns (pinned host memory the upload reads straight from: the GpuAllocator seam of
+// layouts/src/recursive/trace.rs:115-120); every cell is written
+void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+                               const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv) {
     const bool timing = getenv("SSH_TRACE_TIMING") != nullptr;   // diagnostic: per-section wall time on stderr
     auto t_prev = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {
@@ -73,10 +84,20 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
     const Mem mem{memory, present};
     const Felt zero = felt_from_u64(0);
     const bool par = num_cycles >= parallel_min_cycles();
-    std::vector<std::vector<Felt>> cols(NUM_COLS);
-    for (auto &c : cols) c.resize(n);                   // value-initialised to zero limbs = the field's zero
-    auto &flags = cols[COL_FLAGS], &un_col = cols[COL_DILUTED_UNORDERED], &od_col = cols[COL_DILUTED_ORDERED], &npc = cols[COL_NPC],
-         &mem_col = cols[COL_MEMORY], &rc_col = cols[COL_RANGE_CHECK], &aux = cols[COL_AUXILIARY];
+    struct Col { Felt *p; Felt &operator[](uint64_t i) const { return p[i]; } };
+    Col cols[NUM_COLS];
+    for (int c = 0; c < NUM_COLS; ++c) cols[c] = Col{out[c]};
+    {                                                   // every cell no section writes is the field's zero
+        constexpr int64_t CHUNK = 1 << 16;
+        const int64_t chunks = (int64_t)((n + CHUNK - 1) / CHUNK);
+#pragma omp parallel for schedule(static) if (par)
+        for (int64_t k = 0; k < chunks * NUM_COLS; ++k) {
+            const int64_t c = k % NUM_COLS, at = (k / NUM_COLS) * CHUNK;
+            std::fill(out[c] + at, out[c] + std::min<int64_t>((int64_t)n, at + CHUNK), zero);
+        }
+    }
+    const Col flags = cols[COL_FLAGS], un_col = cols[COL_DILUTED_UNORDERED], od_col = cols[COL_DILUTED_ORDERED], npc = cols[COL_NPC],
+              mem_col = cols[COL_MEMORY], rc_col = cols[COL_RANGE_CHECK], aux = cols[COL_AUXILIARY];
     std::vector<uint64_t> npc_addr(n / 2, 0);           // the address half of the pool, as integers (sorting, gap search)
 
     const MemoryEntry *padding = nullptr;
@@ -332,7 +353,6 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
         for (uint64_t k = 0; k < n / 2; ++k) { mem_col[2 * k] = felt_from_u64(acc[cells + k].address); mem_col[2 * k + 1] = acc[cells + k].value; }
     }
     mark("sorted memory");
-    return cols;
 }
 
 }  // namespace ssh

@@ -32,4 +32,8 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
                                                     const std::vector<uint8_t> &present, const AirPublicInput &pi,
                                                     const PrivateInput &priv);
 
+// the same into the caller's 7 columns of 16 * cycles felts each (every cell is written)
+void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+                               const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv);
+
 }  // namespace ssh

@@ -385,9 +385,19 @@ def _instances(rows, width):
     return out
 
 
-def recursive_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=None):
+def _trace_out(out, ncols, n):
+    """the generator's destination: fresh arrays, or the caller's (pinned, page-aligned: the GpuAllocator seam of
+    layouts/src/recursive/trace.rs:115-120) - `ncols` C-contiguous arrays of n x 4 64-bit limbs"""
+    if out is None:
+        return [np.zeros((n, 4), dtype=np.uint64) for _ in range(ncols)]
+    if len(out) != ncols or any(a.shape != (n, 4) or a.dtype.itemsize != 8 or not a.flags["C_CONTIGUOUS"] for a in out):
+        raise _lib.SandstormHipError("host: out must be %d C-contiguous arrays of shape (%d, 4) and 8-byte items" % (ncols, n))
+    return list(out)
+
+
+def recursive_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=None, out=None):
     """the C++ host's ExecutionTrace::new for the recursive layout (sandstorm_amd/host/trace_recursive.cpp) from the raw
-    `cairo-run` files -> 7 columns [16 * cycles, 4] of Montgomery limbs"""
+    `cairo-run` files -> 7 columns [16 * cycles, 4] of Montgomery limbs (written into `out` if given)"""
     private_input = private_input or {}
     if len(trace_bin) % 24:
         raise _lib.SandstormHipError("host: trace file is not a sequence of (ap, fp, pc) u64 triples")
@@ -395,7 +405,7 @@ def recursive_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=
     segs, addrs, vals = _public_input_args(pi)
     ped, rc, bw = (_instances(private_input.get("pedersen", []), 9), _instances(private_input.get("range_check", []), 5),
                    _instances(private_input.get("bitwise", []), 9))
-    cols = [np.zeros((n, 4), dtype=np.uint64) for _ in range(7)]
+    cols = _trace_out(out, 7, n)
     ptrs = (C.c_void_p * 7)(*[c.ctypes.data for c in cols])
     u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
     _check(load().ssh_recursive_base_trace(trace_bin, len(trace_bin), memory_bin, len(memory_bin), pi.rc_min, pi.rc_max, pi.n_steps,
@@ -406,9 +416,9 @@ def recursive_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=
     return cols
 
 
-def starknet_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=None):
+def starknet_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=None, out=None):
     """the C++ host's ExecutionTrace::new for the starknet layout (sandstorm_amd/host/trace_starknet.cpp) -> 9 columns
-    [16 * cycles, 4] of Montgomery limbs.  private_input: as layouts.starknet.base_trace takes it"""
+    [16 * cycles, 4] of Montgomery limbs (written into `out` if given).  private_input: as layouts.starknet.base_trace takes it"""
     private_input = private_input or {}
     if len(trace_bin) % 24:
         raise _lib.SandstormHipError("host: trace file is not a sequence of (ap, fp, pc) u64 triples")
@@ -418,7 +428,7 @@ def starknet_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=N
     arrays = [_instances(private_input.get(name, []), width) for name, width in names]
     counts = np.array([len(private_input.get(name, [])) for name, _ in names], dtype=np.uint64)
     inst = (C.c_void_p * 6)(*[a.ctypes.data for a in arrays])
-    cols = [np.zeros((n, 4), dtype=np.uint64) for _ in range(9)]
+    cols = _trace_out(out, 9, n)
     ptrs = (C.c_void_p * 9)(*[c.ctypes.data for c in cols])
     u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
     fn = load().ssh_starknet_base_trace

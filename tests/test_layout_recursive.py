@@ -11,48 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EX = os.path.join(ROOT, "tests", "golden", "example")
 
 
-def load_run():
-    from sandstorm_amd import binary, public_input
-    with open(os.path.join(EX, "trace.bin"), "rb") as f:
-        states = binary.read_register_states(f.read())
-    with open(os.path.join(EX, "memory.bin"), "rb") as f:
-        memory = binary.read_memory(f.read())
-    pi = public_input.AirPublicInput.from_json(os.path.join(ROOT, "tests", "golden", "air_public_input_array_sum.json"))
-    return states, memory, pi
-
-
-def recursive_example(log_steps):
-    """the reference's example run as a 2^log_steps-step statement of the recursive layout: padded with its final state (the
-    program ends in `jmp rel 0`), the builtin segments re-declared for that step count back to back behind the execution
-    segment, the program's one heap segment moved behind them (as tests/test_layout_starknet.py::starknet_example)"""
-    import copy
-    from sandstorm_amd.layouts import recursive as rec
-    states, memory, pi = load_run()
-    if (1 << log_steps) == len(states):
-        return states, memory, pi
-    assert (1 << log_steps) > len(states)
-    states = list(states) + [states[-1]] * ((1 << log_steps) - len(states))
-    pi = copy.deepcopy(pi)
-    pi.n_steps = 1 << log_steps
-    seg = dict(pi.memory_segments)
-    addr = seg["execution"][1]
-    seg["output"] = (addr, addr)
-    for name, ratio, cells in (("pedersen", rec.PEDERSEN_BUILTIN_RATIO, 3), ("range_check", rec.RANGE_CHECK_BUILTIN_RATIO, 1),
-                               ("bitwise", rec.BITWISE_RATIO, 5)):
-        seg[name] = (addr, addr)                     # begin = stop: the program uses nothing of the segment
-        addr += cells * (pi.n_steps // ratio)
-    pi.memory_segments = seg
-    new_base = addr
-    heap = [a for a in range(len(memory)) if memory[a] is not None and a > 1000]
-    mem = list(memory) + [None] * (new_base + 16 - len(memory))
-    for a in heap:
-        mem[a] = None
-    for a in heap:
-        mem[new_base + a - heap[0]] = memory[a]
-    for a in range(1000):
-        if a < len(memory) and mem[a] is not None and heap[0] <= mem[a] <= heap[-1] + 1:
-            mem[a] += new_base - heap[0]                                         # the pointers into the heap segment
-    return states, mem, pi
+from sandstorm_amd.examples import load_run, recursive_example  # noqa: E402,F401  (moved: bench.py proves these statements too)
 
 
 def with_extension(rec, cols, challenges):

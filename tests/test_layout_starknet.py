@@ -32,23 +32,7 @@ CHALLENGES = [pow(7, 11 + 3 * i, P) for i in range(6)]
 LOG_STEPS = 17
 
 
-def starknet_example(log_steps=LOG_STEPS):
-    """the reference's example run re-declared for the starknet layout: padded to 2^log_steps steps with its final
-    state, the builtin segments laid out after the execution segment, the program's one heap segment moved behind them"""
-    from sandstorm_amd.layouts import starknet as sk
-    states, memory, pi = load_run()
-    states = list(states) + [states[-1]] * ((1 << log_steps) - len(states))
-    pi.n_steps = 1 << log_steps
-    spi = sk.example_public_input(pi)
-    new_base = spi.memory_segments["poseidon"][0] + 6 * (pi.n_steps // sk.POSEIDON_RATIO)
-    heap = [a for a in range(len(memory)) if memory[a] is not None and a > 1000]
-    mem = list(memory) + [None] * (new_base + 16 - len(memory))
-    for a in heap:
-        mem[new_base + a - heap[0]], mem[a] = memory[a], None
-    for a in range(1000):
-        if a < len(memory) and mem[a] is not None and heap[0] <= mem[a] <= heap[-1] + 1:
-            mem[a] += new_base - heap[0]                                         # the pointers into the heap segment
-    return states, mem, spi
+from sandstorm_amd.examples import starknet_example  # noqa: E402,F401  (moved: bench.py proves this statement too)
 
 
 def bootloader_run():
