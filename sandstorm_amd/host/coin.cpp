@@ -89,7 +89,14 @@ Felt felt_mul(const Felt &a, const Felt &b) {
     return {r[0], r[1], r[2], r[3]};
 }
 static const Felt R2 = {0xfffffd737e000401ull, 0x00000001330fffffull, 0xffffffffff6f8000ull, 0x07ffd4ab5e008810ull};
-Felt felt_from_u64(uint64_t v) { return felt_mul(Felt{v, 0, 0, 0}, R2); }
+// v 2^256 mod p.  2^256 = 32 2^251 = -(544 2^192 + 32) mod p, so for v < 2^49 (every address, offset, flag and count the trace
+// generators convert by the million) the image is p - (544 v 2^192 + 32 v) - the subtrahend is below p and has two non-zero
+// limbs: a handful of 64-bit operations where the general path is a Montgomery product with 2^512 mod p
+Felt felt_from_u64(uint64_t v) {
+    if (v >> 49) return felt_mul(Felt{v, 0, 0, 0}, R2);
+    if (!v) return Felt{0, 0, 0, 0};
+    return Felt{1ull - 32ull * v, ~0ull, ~0ull, P[3] - 544ull * v - 1ull};      // the low limb borrows (32 v > 1) through limbs 1, 2
+}
 Felt felt_from_canonical(const Felt &value) { return felt_mul(value, R2); }
 Felt felt_pow(const Felt &a, uint64_t e) {
     Felt r = felt_from_u64(1), b = a;

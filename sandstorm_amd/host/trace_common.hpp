@@ -2,6 +2,8 @@
 // instruction word (binary/src/lib.rs:565-721), memory access, the curve, the Pedersen builtin's element steps
 // (builtins/src/pedersen/mod.rs:121-163) and the diluted form of the bitwise builtin (builtins/src/bitwise/mod.rs).
 #pragma once
+#include <algorithm>
+#include <climits>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -148,6 +150,103 @@ inline void partition64(uint64_t v, uint64_t segs[4]) {    // Partition64::new
         for (unsigned s = 0; s < 4; ++s) segs[s] |= ((v >> (b * 4 + s)) & 1ull) << (b * 4);
 }
 
+
+// the addresses between the lowest and the highest accessed one that nothing accesses, ascending (the gap fillers of
+// trace.rs:594-625 / 890-925): a byte map of the accessed addresses instead of a sort of all n / 2 accesses
+inline std::vector<uint64_t> memory_gaps(const std::vector<uint64_t> &npc_addr, const std::vector<MemoryEntry> &public_memory) {
+    uint64_t top = 0, low = UINT64_MAX;
+#pragma omp parallel for schedule(static) reduction(max : top) reduction(min : low)
+    for (uint64_t k = 0; k < npc_addr.size(); ++k) { top = std::max(top, npc_addr[k]); low = std::min(low, npc_addr[k]); }
+    for (auto &e : public_memory) { top = std::max<uint64_t>(top, e.address); low = std::min<uint64_t>(low, e.address); }
+    std::vector<uint64_t> gaps;
+    if (low == UINT64_MAX) return gaps;
+    if (top > (1ull << 34)) fail("memory address out of range");
+    std::vector<uint8_t> seen(top + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (uint64_t k = 0; k < npc_addr.size(); ++k) seen[npc_addr[k]] = 1;       // (every writer writes the same byte)
+    for (auto &e : public_memory) seen[e.address] = 1;
+    for (uint64_t a = low + 1; a < top; ++a) if (!seen[a]) gaps.push_back(a);
+    return gaps;
+}
+
+// get_ordered_memory_accesses (layouts/src/utils.rs:112-152) without a sort.  The accesses - the pool's n / 2 (address, value)
+// pairs and the public memory's `cells` (its entries, padded with (1, pad_value)) - ordered by address are RUNS: memory is
+// single-valued and continuous, so the ordered column is (a, value(a)) repeated count(a) times for a = 1, 2, ...  Counting per
+// address (atomic increments; the pool's zero and padding addresses, which most accesses carry, are counted per thread), a
+// prefix sum and a parallel fill replace the sort of ~n / 2 forty-byte records (0.8 s of the recursive layout's 2.6 s at 2^20
+// steps on 256 host threads), with the reference's checks kept: the pool's address-0 cells are exactly the public-memory
+// cells, memory starts at address 1, has no gaps and one value per address.
+inline void ordered_memory_into(Felt *mem_col, uint64_t n, const std::vector<uint64_t> &npc_addr, const Felt *npc, uint64_t cells,
+                                const std::vector<MemoryEntry> &public_memory, const Felt &pad_value) {
+    if (public_memory.size() > cells) fail("public memory does not fit");
+    const uint64_t half = n / 2;
+    uint64_t top = 1;
+#pragma omp parallel for schedule(static) reduction(max : top)
+    for (uint64_t k = 0; k < half; ++k) top = std::max(top, npc_addr[k]);
+    for (auto &e : public_memory) top = std::max<uint64_t>(top, e.address);
+    if (top > (1ull << 34)) fail("memory address out of range");
+    std::vector<uint32_t> count(top + 2, 0);
+    std::vector<uint64_t> rep(top + 2, UINT64_MAX);           // the first access of an address: pool index, or half + public index
+    uint64_t zeros = 0, ones = 0;
+#pragma omp parallel for schedule(static) reduction(+ : zeros, ones)
+    for (uint64_t k = 0; k < half; ++k) {
+        const uint64_t a = npc_addr[k];
+        if (a == 0) { ++zeros; continue; }
+        if (a == 1) { ++ones; continue; }
+#pragma omp atomic
+        ++count[a];
+        uint64_t seen;
+#pragma omp atomic read
+        seen = rep[a];
+        while (k < seen) {                                    // atomic min
+            uint64_t expect = seen;
+            if (__atomic_compare_exchange_n(&rep[a], &expect, k, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+            seen = expect;
+        }
+    }
+    if (zeros != cells) fail("the public-memory cells of the pool must be the only accesses of address 0");
+    std::vector<Felt> pub_value(public_memory.size());
+    for (size_t k = 0; k < public_memory.size(); ++k) {
+        const uint64_t a = public_memory[k].address;
+        pub_value[k] = felt_from_canonical(public_memory[k].value);
+        if (a == 0) fail("the public-memory cells of the pool must be the only accesses of address 0");
+        if (a == 1) { ++ones; continue; }
+        ++count[a];
+        rep[a] = std::min<uint64_t>(rep[a], half + k);
+    }
+    ones += cells - public_memory.size();                      // the padding entries (1, pad_value)
+    if (!ones) fail("memory must start at address 1");
+    if (ones > UINT32_MAX) fail("too many accesses of address 1");
+    count[1] = (uint32_t)ones;
+    auto value_of = [&](uint64_t idx) -> const Felt & { return idx < half ? npc[2 * idx + 1] : pub_value[idx - half]; };
+    // one value per address (address 1: the padding value), no address skipped
+    uint64_t first_bad = UINT64_MAX;
+#pragma omp parallel for schedule(static) reduction(min : first_bad)
+    for (uint64_t k = 0; k < half; ++k) {
+        const uint64_t a = npc_addr[k];
+        if (a == 0) continue;
+        if (!felt_eq(npc[2 * k + 1], a == 1 ? pad_value : value_of(rep[a]))) first_bad = std::min(first_bad, a);
+    }
+    for (size_t k = 0; k < public_memory.size(); ++k) {
+        const uint64_t a = public_memory[k].address;
+        if (!felt_eq(pub_value[k], a == 1 ? pad_value : value_of(rep[a]))) first_bad = std::min<uint64_t>(first_bad, a);
+    }
+#pragma omp parallel for schedule(static) reduction(min : first_bad)
+    for (uint64_t a = 1; a <= top; ++a) if (!count[a]) first_bad = std::min(first_bad, a - 1);
+    if (first_bad != UINT64_MAX) fail("memory is not continuous and single-valued at address " + std::to_string(first_bad));
+    // rows: address a fills [start(a), start(a) + count(a)); address 1's long run in parallel, the rest address by address
+    std::vector<uint64_t> start(top + 2, 0);
+    for (uint64_t a = 1; a <= top; ++a) start[a + 1] = start[a] + count[a];
+    if (start[top + 1] != half) fail("the ordered memory does not fill its column");
+    const Felt one_f = felt_from_u64(1);
+#pragma omp parallel for schedule(static)
+    for (uint64_t j = 0; j < ones; ++j) { mem_col[2 * j] = one_f; mem_col[2 * j + 1] = pad_value; }
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (uint64_t a = 2; a <= top; ++a) {
+        const Felt af = felt_from_u64(a), &v = value_of(rep[a]);
+        for (uint64_t j = start[a]; j < start[a + 1]; ++j) { mem_col[2 * j] = af; mem_col[2 * j + 1] = v; }
+    }
+}
 
 }  // namespace tracedetail
 }  // namespace ssh

@@ -10,6 +10,7 @@
 #include <string>
 
 #include "../../include/sandstorm_hip.h"
+#include <omp.h>
 #include "trace_common.hpp"
 
 namespace ssh {
@@ -97,7 +98,7 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
         }
     }
     const Col flags = cols[COL_FLAGS], un_col = cols[COL_DILUTED_UNORDERED], od_col = cols[COL_DILUTED_ORDERED], npc = cols[COL_NPC],
-              mem_col = cols[COL_MEMORY], rc_col = cols[COL_RANGE_CHECK], aux = cols[COL_AUXILIARY];
+              rc_col = cols[COL_RANGE_CHECK], aux = cols[COL_AUXILIARY];
     std::vector<uint64_t> npc_addr(n / 2, 0);           // the address half of the pool, as integers (sorting, gap search)
 
     const MemoryEntry *padding = nullptr;
@@ -173,7 +174,7 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
         if (!rc_count[v]) padding_vals.push_back(v);
         for (uint32_t c = 0; c < std::max(rc_count[v], 1u); ++c) ordered_vals.push_back(v);
     }
-    size_t pad_i = 0, ord_i = 0;
+    size_t pad_i = 0;
     auto next_padding = [&]() { return pad_i < padding_vals.size() ? padding_vals[pad_i++] : rc_hi; };
     for (uint64_t index = rc128.size(); index < num_cycles / RANGE_CHECK_BUILTIN_RATIO; ++index) {
         U256 value{};
@@ -183,13 +184,24 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
         }
         rc128.push_back(Rc128{(uint32_t)index, value});
     }
-    for (uint64_t cycle = 0; cycle < num_cycles; ++cycle) {
-        const uint64_t r = cycle * CYCLE_HEIGHT;
-        if (cycle % 2 == 1) rc_col[r + RC_UNUSED] = felt_from_u64(next_padding());
-        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP)
-            rc_col[r + o + RC_ORDERED] = felt_from_u64(ord_i < ordered_vals.size() ? ordered_vals[ord_i++] : rc_hi);
+    {   // the odd cycles take the next padding values in order, every cycle its CYCLE_HEIGHT / RANGE_CHECK_STEP ordered values: both
+        // sequences are indexed by the cycle, so the cycles go in parallel
+        const size_t pad0 = pad_i;
+        const uint64_t per = CYCLE_HEIGHT / RANGE_CHECK_STEP;
+#pragma omp parallel for schedule(static) if (par)
+        for (int64_t cyc = 0; cyc < (int64_t)num_cycles; ++cyc) {
+            const uint64_t cycle = (uint64_t)cyc, r = cycle * CYCLE_HEIGHT;
+            if (cycle % 2 == 1) {
+                const size_t at = pad0 + cycle / 2;
+                rc_col[r + RC_UNUSED] = felt_from_u64(at < padding_vals.size() ? padding_vals[at] : rc_hi);
+            }
+            for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP) {
+                const uint64_t at = cycle * per + o / RANGE_CHECK_STEP;
+                rc_col[r + o + RC_ORDERED] = felt_from_u64(at < ordered_vals.size() ? ordered_vals[at] : rc_hi);
+            }
+        }
+        if (pad0 + num_cycles / 2 < padding_vals.size() || num_cycles * per < ordered_vals.size()) fail("range-check values do not fit the trace");
     }
-    if (pad_i < padding_vals.size() || ord_i < ordered_vals.size()) fail("range-check values do not fit the trace");
 
     mark("range check");
     // ---- Pedersen builtin (trace.rs:300-400; builtins/src/pedersen/mod.rs:81-163)
@@ -252,8 +264,9 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
     // ---- range-check builtin cells
     {
         const uint64_t step = RANGE_CHECK_BUILTIN_RATIO * CYCLE_HEIGHT;
-        for (uint64_t block = 0; block < rc128.size(); ++block) {
-            const uint64_t base = block * step;
+#pragma omp parallel for schedule(static) if (par)
+        for (int64_t blk = 0; blk < (int64_t)rc128.size(); ++blk) {
+            const uint64_t block = (uint64_t)blk, base = block * step;
             for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) rc_col[base + CYCLE_HEIGHT * k + RC_UNUSED] = felt_from_u64(part_of(rc128[block].value, k));
             set_pair(base + NPC_RANGE_CHECK128_ADDR, rc_seg.begin_addr + rc128[block].index, felt_from_canonical(rc128[block].value));
         }
@@ -265,10 +278,14 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
         std::map<uint32_t, const BitwiseInstance *> given;
         for (auto &inst : priv.bitwise) given[inst.index] = &inst;
         std::vector<uint32_t> dil_count(1u << DILUTED_N_BITS, 0);
+        // one histogram per thread (nearly every instance is the dummy one: all threads would hammer the counter of value 0)
+        std::vector<std::vector<uint32_t>> dil_count_of((size_t)omp_get_max_threads());
         const uint64_t shifted_cells[4] = {1, 65, 33, 97};
         std::string bw_error;
 #pragma omp parallel for schedule(static) if (par)
         for (int64_t bi = 0; bi < (int64_t)(n / step); ++bi) try {
+            std::vector<uint32_t> &my_count = dil_count_of[(size_t)omp_get_thread_num()];
+            if (my_count.empty()) my_count.assign(1u << DILUTED_N_BITS, 0);
             const uint64_t i = (uint64_t)bi;
             U256 x{}, y{};
             auto it = given.find((uint32_t)i);
@@ -284,17 +301,13 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
                 const unsigned sh = k == 3 ? 8 : 4;
                 if ((v << sh) >> sh != v) fail("bitwise instance: top segment does not fit");
                 un_col[base + shifted_cells[k]] = felt_from_u64(v << sh);
-                const uint32_t reg = undilute(v << sh);
-#pragma omp atomic
-                ++dil_count[reg];
+                ++my_count[undilute(v << sh)];
             }
             for (int p = 0; p < 4; ++p)
                 for (int c = 0; c < 4; ++c)
                     for (int s = 0; s < 4; ++s) {
                         un_col[base + 32 * p + 8 * c + 2 * s] = felt_from_u64(parts[p][c][s]);
-                        const uint32_t reg = undilute(parts[p][c][s]);
-#pragma omp atomic
-                        ++dil_count[reg];
+                        ++my_count[undilute(parts[p][c][s])];
                     }
             for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + k * (step / 4), addr + k, felt_from_canonical(*vals[k]));
             set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, felt_from_canonical(vor));
@@ -303,6 +316,7 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
             if (bw_error.empty()) bw_error = e.what();
         }
         if (!bw_error.empty()) throw std::runtime_error(bw_error);
+        for (auto &part : dil_count_of) for (size_t v = 0; v < part.size(); ++v) dil_count[v] += part[v];
         std::vector<uint32_t> padding;
         uint64_t total = 0;
         for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) { if (!dil_count[v]) padding.push_back(v); total += std::max(dil_count[v], 1u); }
@@ -314,44 +328,30 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
                 un_col[blk * step + off] = felt_from_u64(dilute(padding[pi_++]));
             }
         if (pi_ < padding.size()) fail("diluted-check values do not fit the trace");
-        uint64_t row = n - total;
-        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)
-            for (uint32_t c = 0; c < std::max(dil_count[v], 1u); ++c) od_col[row++] = felt_from_u64(dilute(v));
+        std::vector<uint64_t> first_row((1u << DILUTED_N_BITS) + 1, n - total);
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) first_row[v + 1] = first_row[v] + std::max(dil_count[v], 1u);
+#pragma omp parallel for schedule(dynamic, 64) if (par)
+        for (int64_t v = 0; v < (int64_t)(1u << DILUTED_N_BITS); ++v) {
+            const Felt f = felt_from_u64(dilute((uint32_t)v));
+            if (first_row[v + 1] - first_row[v] < 4096) { for (uint64_t r2 = first_row[v]; r2 < first_row[v + 1]; ++r2) od_col[r2] = f; }
+        }
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)             // the long runs (value 0 of the dummy instances) by all threads
+            if (first_row[v + 1] - first_row[v] >= 4096) {
+                const Felt f = felt_from_u64(dilute(v));
+#pragma omp parallel for schedule(static) if (par)
+                for (int64_t r2 = (int64_t)first_row[v]; r2 < (int64_t)first_row[v + 1]; ++r2) od_col[r2] = f;
+            }
     }
     mark("bitwise + diluted");
     // ---- gap fillers (trace.rs:594-625)
     {
-        std::vector<uint64_t> accessed(npc_addr);
-        for (auto &e : pi.public_memory) accessed.push_back(e.address);
-        std::sort(accessed.begin(), accessed.end());
-        accessed.erase(std::unique(accessed.begin(), accessed.end()), accessed.end());
-        uint64_t cycle = 0;
-        for (size_t k = 0; k + 1 < accessed.size(); ++k)
-            for (uint64_t a = accessed[k] + 1; a < accessed[k + 1]; ++a) {
-                if (cycle >= num_cycles) fail("more memory gaps than cycles to hold them");
-                set_pair(cycle * CYCLE_HEIGHT + NPC_UNUSED_ADDR, a, zero);
-                ++cycle;
-            }
+        const std::vector<uint64_t> gaps = memory_gaps(npc_addr, pi.public_memory);
+        if (gaps.size() > num_cycles) fail("more memory gaps than cycles to hold them");
+        for (size_t k = 0; k < gaps.size(); ++k) set_pair(k * CYCLE_HEIGHT + NPC_UNUSED_ADDR, gaps[k], zero);
     }
     mark("gap fill");
     // ---- sorted memory (get_ordered_memory_accesses, utils.rs:112-152)
-    {
-        struct Access { uint64_t address; Felt value; };
-        std::vector<Access> acc;
-        acc.reserve(n / 2 + n / PUBLIC_MEMORY_STEP);
-        for (uint64_t k = 0; k < n / 2; ++k) acc.push_back(Access{npc_addr[k], npc[2 * k + 1]});
-        const uint64_t cells = n / PUBLIC_MEMORY_STEP;
-        if (pi.public_memory.size() > cells) fail("public memory does not fit");
-        for (uint64_t k = pi.public_memory.size(); k < cells; ++k) acc.push_back(Access{1, pad_value});
-        for (auto &e : pi.public_memory) acc.push_back(Access{e.address, felt_from_canonical(e.value)});
-        std::stable_sort(acc.begin(), acc.end(), [](const Access &a, const Access &b) { return a.address < b.address; });
-        for (uint64_t k = 0; k < cells; ++k) if (acc[k].address != 0) fail("the public-memory cells of the pool must be the only accesses of address 0");
-        if (acc[cells].address != 1) fail("memory must start at address 1");
-        for (uint64_t k = cells; k + 1 < acc.size(); ++k)
-            if (!((acc[k].address == acc[k + 1].address && felt_eq(acc[k].value, acc[k + 1].value)) || acc[k].address + 1 == acc[k + 1].address))
-                fail("memory is not continuous and single-valued at address " + std::to_string(acc[k].address));
-        for (uint64_t k = 0; k < n / 2; ++k) { mem_col[2 * k] = felt_from_u64(acc[cells + k].address); mem_col[2 * k + 1] = acc[cells + k].value; }
-    }
+    ordered_memory_into(out[COL_MEMORY], n, npc_addr, out[COL_NPC], n / PUBLIC_MEMORY_STEP, pi.public_memory, pad_value);
     mark("sorted memory");
 }
 

@@ -11,6 +11,7 @@
 #include <parallel/algorithm>
 #include <tuple>
 
+#include <mutex>
 #include <omp.h>
 
 #include "../../include/sandstorm_hip.h"
@@ -290,7 +291,7 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         const uint64_t c = k % NUM_COLS, at = (k / NUM_COLS) * CHUNK;
         std::fill(out[c] + at, out[c] + std::min(n, at + CHUNK), zero);
     });
-    const Col flags = cols[COL_FLAGS], npc = cols[COL_NPC], mem_col = cols[COL_MEMORY], rc_col = cols[COL_RANGE_CHECK], aux = cols[COL_AUXILIARY];
+    const Col flags = cols[COL_FLAGS], npc = cols[COL_NPC], rc_col = cols[COL_RANGE_CHECK], aux = cols[COL_AUXILIARY];
     std::vector<uint64_t> npc_addr(n / 2, 1);
 
     const MemoryEntry *padding = nullptr;
@@ -360,7 +361,7 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) rc_col[r + o] = rc_max_f;
         rc_col[r + RC_OFF_DST] = felt_from_u64(w.off_dst()); rc_col[r + RC_OFF_OP1] = felt_from_u64(w.off_op1()); rc_col[r + RC_OFF_OP0] = felt_from_u64(w.off_op0());
     });
-    size_t pad_i = 0, ord_i = 0;
+    size_t pad_i = 0;
     auto next_padding = [&]() { return pad_i < padding_vals.size() ? padding_vals[pad_i++] : rc_hi; };
     for (uint64_t index = rc128.size(); index < num_cycles / RANGE_CHECK_BUILTIN_RATIO; ++index) {       // trace.rs:246-261
         U256 value{};
@@ -370,14 +371,24 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         }
         rc128.push_back(Rc128{(uint32_t)index, value});
     }
-    for (uint64_t cycle = 0; cycle < num_cycles; ++cycle) {
-        const uint64_t r = cycle * CYCLE_HEIGHT;
-        if (cycle % 2 == 1) rc_col[r + RC_UNUSED] = felt_from_u64(next_padding());
-        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP)
-            rc_col[r + o + RC_ORDERED] = felt_from_u64(ord_i < ordered_vals.size() ? ordered_vals[ord_i++] : rc_hi);
+    {   // the odd cycles take the next padding values in order, every cycle its CYCLE_HEIGHT / RANGE_CHECK_STEP ordered values: both
+        // sequences are indexed by the cycle, so the cycles go in parallel
+        const size_t pad0 = pad_i;
+        const uint64_t per = CYCLE_HEIGHT / RANGE_CHECK_STEP;
+        parallel_for(num_cycles, [&](uint64_t cycle) {
+            const uint64_t r = cycle * CYCLE_HEIGHT;
+            if (cycle % 2 == 1) {
+                const size_t at = pad0 + cycle / 2;
+                rc_col[r + RC_UNUSED] = felt_from_u64(at < padding_vals.size() ? padding_vals[at] : rc_hi);
+            }
+            for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP) {
+                const uint64_t at = cycle * per + o / RANGE_CHECK_STEP;
+                rc_col[r + o + RC_ORDERED] = felt_from_u64(at < ordered_vals.size() ? ordered_vals[at] : rc_hi);
+            }
+        });
+        if (pad0 + num_cycles / 2 < padding_vals.size() || num_cycles * per < ordered_vals.size()) fail("range-check values do not fit the trace");
     }
-    if (pad_i != padding_vals.size() || ord_i != ordered_vals.size()) fail("range-check values do not fit the trace");
-    for (uint64_t k = 0; k < n / DILUTED_CHECK_STEP; ++k) rc_col[8 * k + DC_UNORDERED] = rc_col[8 * k + DC_ORDERED] = zero;      // trace.rs:294-302
+    parallel_for(n / DILUTED_CHECK_STEP, [&](uint64_t k) { rc_col[8 * k + DC_UNORDERED] = rc_col[8 * k + DC_ORDERED] = zero; });      // trace.rs:294-302
 
     lap("cpu cells + range-check pool");
     // ---- Pedersen (trace.rs:304-386)
@@ -389,10 +400,17 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         const uint64_t step = PEDERSEN_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[3].begin_addr;
         const Pt p0 = pedersen_point(0);
         const Col xs = cols[COL_PEDERSEN_X], ys = cols[COL_PEDERSEN_Y], suffixes = cols[COL_PEDERSEN_SUFFIX], slopes = cols[COL_PEDERSEN_SLOPE];
-        for (uint64_t i = 0; i < n / step; ++i) {
-            U256 a{}, b{};
+        // the distinct instance traces first (sequential: the map is shared; nearly every instance is the dummy one), then the
+        // cells of all instances in parallel
+        auto inputs_of = [&](uint64_t i, U256 &a, U256 &b) {
+            a = U256{}; b = U256{};
             auto it = given.find((uint32_t)i);
             if (it != given.end()) { a = it->second->a; b = it->second->b; }
+        };
+        std::vector<const Cached *> of_block(n / step);
+        for (uint64_t i = 0; i < n / step; ++i) {
+            U256 a, b;
+            inputs_of(i, a, b);
             auto key = std::make_pair(a, b);
             auto cit = cache.find(key);
             if (cit == cache.end()) {
@@ -405,7 +423,12 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
                 if (ss_pedersen_hash_host(fa.data(), fb.data(), want.data()) != SS_OK || !felt_eq(want, c.out)) fail("Pedersen partial sums do not end at the hash");
                 cit = cache.emplace(key, std::move(c)).first;
             }
-            const Cached &c = cit->second;
+            of_block[i] = &cit->second;
+        }
+        parallel_for(n / step, [&](uint64_t i) {
+            U256 a, b;
+            inputs_of(i, a, b);
+            const Cached &c = *of_block[i];
             const uint64_t base = i * step, addr = begin + 3 * i;
             for (uint64_t j = 0; j < 512; ++j) {
                 xs[base + j] = c.steps[j].point.x; ys[base + j] = c.steps[j].point.y;
@@ -420,17 +443,17 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
             set_pair(base + NPC_PEDERSEN_INPUT0_ADDR, addr, felt_from_canonical(a));
             set_pair(base + NPC_PEDERSEN_INPUT1_ADDR, addr + 1, felt_from_canonical(b));
             set_pair(base + NPC_PEDERSEN_OUTPUT_ADDR, addr + 2, c.out);
-        }
+        });
     }
     lap("pedersen");
     // ---- range-check builtin (trace.rs:388-426)
     {
         const uint64_t step = RANGE_CHECK_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[4].begin_addr;
-        for (size_t blk = 0; blk < rc128.size(); ++blk) {
+        parallel_for(rc128.size(), [&](uint64_t blk) {
             const uint64_t base = blk * step;
             for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) rc_col[base + 32 * k + RC16_COMPONENT] = felt_from_u64(part_of(rc128[blk].value, k));
             set_pair(base + NPC_RANGE_CHECK128_ADDR, begin + rc128[blk].index, felt_from_canonical(rc128[blk].value));
-        }
+        });
     }
     lap("range-check builtin");
     // ---- ECDSA (trace.rs:428-523)
@@ -439,20 +462,26 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         for (auto &p : priv.ecdsa) given[p.index] = &p;
         std::map<std::tuple<U256, U256, U256, U256>, EcdsaTrace> cache;
         const uint64_t step = ECDSA_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[5].begin_addr;
-        U256 dummy[4];
-        bool have_dummy = false;
+        // the dummy instance (a constant: ecdsa/mod.rs gen_dummy_instance) and its trace - three scalar multiplications with their
+        // doubling chains, ~0.15 s - are made once per process
+        static std::once_flag dummy_once;
+        static U256 dummy[4];
+        static EcdsaTrace dummy_trace;
+        if (n / step > given.size())
+            std::call_once(dummy_once, [] { ecdsa_dummy_instance(dummy[0], dummy[1], dummy[2], dummy[3]); dummy_trace = ecdsa_trace(dummy[0], dummy[1], dummy[2], dummy[3]); });
+        std::vector<const EcdsaTrace *> of_block(n / step);
         for (uint64_t i = 0; i < n / step; ++i) {
             U256 in[4];
             auto it = given.find((uint32_t)i);
-            if (it != given.end()) { in[0] = it->second->pubkey_x; in[1] = it->second->message; in[2] = it->second->r; in[3] = it->second->w; }
-            else {
-                if (!have_dummy) { ecdsa_dummy_instance(dummy[0], dummy[1], dummy[2], dummy[3]); have_dummy = true; }
-                for (int k = 0; k < 4; ++k) in[k] = dummy[k];
-            }
+            if (it == given.end()) { of_block[i] = &dummy_trace; continue; }
+            in[0] = it->second->pubkey_x; in[1] = it->second->message; in[2] = it->second->r; in[3] = it->second->w;
             auto key = std::make_tuple(in[0], in[1], in[2], in[3]);
             auto cit = cache.find(key);
             if (cit == cache.end()) cit = cache.emplace(key, ecdsa_trace(in[0], in[1], in[2], in[3])).first;
-            const EcdsaTrace &t = cit->second;
+            of_block[i] = &cit->second;
+        }
+        parallel_for(n / step, [&](uint64_t i) {
+            const EcdsaTrace &t = *of_block[i];
             const uint64_t base = i * step;
             for (int half = 0; half < 2; ++half) {
                 const std::vector<MadStep> &mad = half ? t.wb_steps : t.rq_steps;
@@ -475,7 +504,7 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
             aux[base + EC_PUBKEY_X_SQUARED] = felt_mul(t.pubkey.x, t.pubkey.x);
             set_pair(base + NPC_ECDSA_PUBKEY_ADDR, begin + 2 * i, t.pubkey.x);
             set_pair(base + NPC_ECDSA_MESSAGE_ADDR, begin + 2 * i + 1, t.message);
-        }
+        });
     }
     lap("ecdsa");
     // ---- bitwise and the diluted check (trace.rs:525-705)
@@ -484,7 +513,11 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         for (auto &p : priv.bitwise) given[p.index] = &p;
         const uint64_t step = BITWISE_RATIO * CYCLE_HEIGHT, begin = pi.segments[6].begin_addr;
         std::vector<uint32_t> dil_count(1u << DILUTED_N_BITS, 0);
-        for (uint64_t i = 0; i < n / step; ++i) {
+        // one histogram per thread (nearly every instance is the dummy one: all threads would hammer the counter of value 0)
+        std::vector<std::vector<uint32_t>> dil_count_of((size_t)omp_get_max_threads());
+        parallel_for(n / step, [&](uint64_t i) {
+            std::vector<uint32_t> &my_count = dil_count_of[(size_t)omp_get_thread_num()];
+            if (my_count.empty()) my_count.assign(1u << DILUTED_N_BITS, 0);
             U256 x{}, y{};
             auto it = given.find((uint32_t)i);
             if (it != given.end()) { x = it->second->x; y = it->second->y; }
@@ -499,17 +532,18 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
                 const unsigned sh = k == 3 ? 8 : 4;
                 if (((v << sh) >> sh) != v) fail("bitwise instance " + std::to_string(i) + ": top segment does not fit");
                 rc_col[base + BITWISE_SHIFTED_CELLS[k]] = felt_from_u64(v << sh);
-                ++dil_count[undilute(v << sh)];
+                ++my_count[undilute(v << sh)];
             }
             for (int p = 0; p < 4; ++p)
                 for (int c = 0; c < 4; ++c)
                     for (int s = 0; s < 4; ++s) {
                         rc_col[base + 256 * p + 16 * (4 * c + s) + 1] = felt_from_u64(parts[p][c][s]);
-                        ++dil_count[undilute(parts[p][c][s])];
+                        ++my_count[undilute(parts[p][c][s])];
                     }
             for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + 256 * k, addr + k, felt_from_canonical(*vals[k]));
             set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, felt_from_canonical(vor));
-        }
+        });
+        for (auto &part : dil_count_of) for (size_t v = 0; v < part.size(); ++v) dil_count[v] += part[v];
         std::vector<uint32_t> padding_d;
         uint64_t total = 0;
         for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) { if (!dil_count[v]) padding_d.push_back(v); total += std::max(dil_count[v], 1u); }
@@ -522,9 +556,19 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
             }
         const uint64_t slots = n / DILUTED_CHECK_STEP;
         if (pi_d != padding_d.size() || total > slots) fail("diluted-check values do not fit the trace");
-        uint64_t k = slots - total;
-        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)
-            for (uint32_t c = 0; c < std::max(dil_count[v], 1u); ++c, ++k) rc_col[8 * k + DC_ORDERED] = felt_from_u64(dilute(v));
+        std::vector<uint64_t> first_slot((1u << DILUTED_N_BITS) + 1, slots - total);
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) first_slot[v + 1] = first_slot[v] + std::max(dil_count[v], 1u);
+        parallel_for(1u << DILUTED_N_BITS, [&](uint64_t v) {                // the short runs value by value
+            if (first_slot[v + 1] - first_slot[v] >= 4096) return;
+            const Felt f = felt_from_u64(dilute((uint32_t)v));
+            for (uint64_t k = first_slot[v]; k < first_slot[v + 1]; ++k) rc_col[8 * k + DC_ORDERED] = f;
+        });
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)                 // the long ones (value 0 of the dummy instances) by all threads
+            if (first_slot[v + 1] - first_slot[v] >= 4096) {
+                const Felt f = felt_from_u64(dilute(v));
+                const uint64_t k0 = first_slot[v];
+                parallel_for(first_slot[v + 1] - k0, [&](uint64_t j) { rc_col[8 * (k0 + j) + DC_ORDERED] = f; });
+            }
     }
     lap("bitwise + diluted");
     // ---- EC op (trace.rs:707-777)
@@ -535,6 +579,7 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         struct Trace { Pt p, q, r; Felt m; std::vector<Doubling> q_doubling; std::vector<MadStep> r_steps; bool b251_196, b251_196_192; };
         std::map<std::tuple<U256, U256, U256, U256, U256>, Trace> cache;
         const uint64_t step = EC_OP_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[7].begin_addr;
+        std::vector<const Trace *> of_block(n / step);
         for (uint64_t i = 0; i < n / step; ++i) {
             U256 in[5];
             auto it = given.find((uint32_t)i);
@@ -555,7 +600,10 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
                 t.b251_196 = bit(in[4], 251) && bit(in[4], 196); t.b251_196_192 = t.b251_196 && bit(in[4], 192);
                 cit = cache.emplace(key, std::move(t)).first;
             }
-            const Trace &t = cit->second;
+            of_block[i] = &cit->second;
+        }
+        parallel_for(n / step, [&](uint64_t i) {
+            const Trace &t = *of_block[i];
             const uint64_t base = i * step, addr = begin + 7 * i;
             for (uint64_t j = 0; j < 256; ++j) {
                 const uint64_t r = base + 64 * j;
@@ -566,7 +614,7 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
             aux[base + OP_M_BIT251_AND_BIT196] = felt_from_u64(t.b251_196); aux[base + OP_M_BIT251_AND_BIT196_AND_BIT192] = felt_from_u64(t.b251_196_192);
             const Felt values[7] = {t.p.x, t.p.y, t.q.x, t.q.y, t.m, t.r.x, t.r.y};
             for (int k = 0; k < 7; ++k) set_pair(base + NPC_EC_OP_ADDRS[k], addr + k, values[k]);
-        }
+        });
     }
     lap("ec op");
     // ---- Poseidon (trace.rs:779-888)
@@ -576,15 +624,25 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         std::map<std::tuple<U256, U256, U256>, PoseidonTrace> cache;
         const uint64_t step = POSEIDON_RATIO * CYCLE_HEIGHT, begin = pi.segments[8].begin_addr;
         const uint64_t FULL[3][2] = {{53, 29}, {13, 61}, {45, 3}};
-        for (uint64_t i = 0; i < n / step; ++i) {
-            U256 in[3] = {U256{}, U256{}, U256{}};
+        auto inputs_of = [&](uint64_t i, U256 (&in)[3]) {
+            for (int k = 0; k < 3; ++k) in[k] = U256{};
             auto it = given.find((uint32_t)i);
             if (it != given.end()) for (int k = 0; k < 3; ++k) in[k] = it->second->input[k];
+        };
+        std::vector<const PoseidonTrace *> of_block(n / step);
+        for (uint64_t i = 0; i < n / step; ++i) {
+            U256 in[3];
+            inputs_of(i, in);
             auto key = std::make_tuple(in[0], in[1], in[2]);
             auto cit = cache.find(key);
+            if (cit == cache.end()) cit = cache.emplace(key, poseidon_trace(std::array<Felt, 3>{felt_from_canonical(in[0]), felt_from_canonical(in[1]), felt_from_canonical(in[2])})).first;
+            of_block[i] = &cit->second;
+        }
+        parallel_for(n / step, [&](uint64_t i) {
+            U256 in[3];
+            inputs_of(i, in);
             const std::array<Felt, 3> input{felt_from_canonical(in[0]), felt_from_canonical(in[1]), felt_from_canonical(in[2])};
-            if (cit == cache.end()) cit = cache.emplace(key, poseidon_trace(input)).first;
-            const PoseidonTrace &t = cit->second;
+            const PoseidonTrace &t = *of_block[i];
             const uint64_t base = i * step, addr = begin + 6 * i;
             for (uint64_t rnd = 0; rnd < 8; ++rnd)
                 for (int j = 0; j < 3; ++j) {
@@ -594,46 +652,18 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
             for (uint64_t k = 0; k < 64; ++k) { rc_col[base + 8 * k + 3] = t.partial[k]; rc_col[base + 8 * k + 7] = felt_mul(t.partial[k], t.partial[k]); }
             for (uint64_t k = 0; k + 61 < t.partial.size(); ++k) { aux[base + 16 * k + 6] = t.partial[61 + k]; aux[base + 16 * k + 14] = felt_mul(t.partial[61 + k], t.partial[61 + k]); }
             for (int k = 0; k < 3; ++k) { set_pair(base + NPC_POSEIDON_ADDRS[k], addr + k, input[k]); set_pair(base + NPC_POSEIDON_ADDRS[3 + k], addr + 3 + k, t.out[k]); }
-        }
+        });
     }
     lap("poseidon");
     // ---- gap fillers (trace.rs:890-925)
     {
-        std::vector<uint64_t> accessed(npc_addr);
-        for (auto &e : pi.public_memory) accessed.push_back(e.address);
-        std::sort(accessed.begin(), accessed.end());
-        accessed.erase(std::unique(accessed.begin(), accessed.end()), accessed.end());
-        uint64_t cycle = 0;
-        for (size_t k = 0; k + 1 < accessed.size(); ++k)
-            for (uint64_t a = accessed[k] + 1; a < accessed[k + 1]; ++a) {
-                if (cycle >= num_cycles) fail("more memory gaps than cycles to hold them");
-                set_pair(cycle * CYCLE_HEIGHT + NPC_UNUSED_ADDR, a, zero);
-                ++cycle;
-            }
+        const std::vector<uint64_t> gaps = memory_gaps(npc_addr, pi.public_memory);
+        if (gaps.size() > num_cycles) fail("more memory gaps than cycles to hold them");
+        for (size_t k = 0; k < gaps.size(); ++k) set_pair(k * CYCLE_HEIGHT + NPC_UNUSED_ADDR, gaps[k], zero);
     }
     lap("gap fillers");
     // ---- sorted memory (get_ordered_memory_accesses, utils.rs:112-152)
-    {
-        struct Access { uint64_t address; Felt value; };
-        std::vector<Access> acc;
-        const uint64_t cells = n / PUBLIC_MEMORY_STEP;
-        if (pi.public_memory.size() > cells) fail("public memory does not fit");
-        acc.resize(n / 2 + cells);
-        parallel_for(n / 2, [&](uint64_t k) { acc[k] = Access{npc_addr[k], npc[2 * k + 1]}; });
-        const uint64_t n_pad = cells - pi.public_memory.size();
-        parallel_for(n_pad, [&](uint64_t k) { acc[n / 2 + k] = Access{1, pad_value}; });
-        for (size_t k = 0; k < pi.public_memory.size(); ++k) acc[n / 2 + n_pad + k] = Access{pi.public_memory[k].address, felt_from_canonical(pi.public_memory[k].value)};
-        __gnu_parallel::stable_sort(acc.begin(), acc.end(), [](const Access &a, const Access &b) { return a.address < b.address; });
-        for (uint64_t k = 0; k < cells; ++k) if (acc[k].address != 0) fail("the public-memory cells of the pool must be the only accesses of address 0");
-        if (acc[cells].address != 1) fail("memory must start at address 1");
-        uint64_t first_bad = UINT64_MAX;
-#pragma omp parallel for schedule(static) reduction(min : first_bad)
-        for (uint64_t k = cells; k < acc.size() - 1; ++k)
-            if (!((acc[k].address == acc[k + 1].address && felt_eq(acc[k].value, acc[k + 1].value)) || acc[k].address + 1 == acc[k + 1].address))
-                first_bad = std::min(first_bad, k);
-        if (first_bad != UINT64_MAX) fail("memory is not continuous and single-valued at address " + std::to_string(acc[first_bad].address));
-        parallel_for(n / 2, [&](uint64_t k) { mem_col[2 * k] = felt_from_u64(acc[cells + k].address); mem_col[2 * k + 1] = acc[cells + k].value; });
-    }
+    ordered_memory_into(out[COL_MEMORY], n, npc_addr, out[COL_NPC], n / PUBLIC_MEMORY_STEP, pi.public_memory, pad_value);
     lap("sorted memory");
 }
 

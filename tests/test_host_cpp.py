@@ -25,3 +25,19 @@ def test_cpp_coin_kats_and_oracle(oracle, golden):
         a.reseed_int(777); b.reseed_int(777)
         assert a.draw_queries(9, 1 << 12) == b.draw_queries(9, 1 << 12)
         assert a.state == (b.digest, b.counter)
+
+
+def test_small_integers_to_montgomery_form(tmp_path):
+    """felt_from_u64's short path (host/coin.cpp: v 2^256 mod p = p - (544 v 2^192 + 32 v) below 2^49, what the trace generators
+    call by the million) equals the general Montgomery product (tests/cpp/felt_from_u64_test.cpp, linked against the host library)"""
+    import os
+    import subprocess
+    from sandstorm_amd import hostlib
+    hostlib.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    build = os.path.join(root, "sandstorm_amd", "_build")
+    exe = str(tmp_path / "felt_from_u64")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "felt_from_u64_test.cpp"),
+                           "-L" + build, "-lsandstorm_host", "-Wl,-rpath," + build])
+    out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH=build + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", "")))
+    assert out.returncode == 0 and "FELT_FROM_U64_OK" in out.stdout, out.stdout + out.stderr
