@@ -908,6 +908,7 @@ def main():
                              "claim": ns["config"]["claim"], "air": ns["config"]["air"], "stage_ms_per_proof": ns["stage_ms_per_proof"],
                              "ntt_gfield_ops_per_s": ns["ntt_gfield_ops_per_s"], "roofline": ns["roofline"],
                              "roofline_dominant": ns["roofline_dominant"], "cpu_baseline": ns.get("cpu_baseline"),
+                             "end_to_end": ns.get("end_to_end"),
                              "target": ">= 10x the CPU prover's end-to-end time at 1 GPU (BASELINE.json north_star); cpu_baseline here "
                                        "is the oracle port, not the reference binary"}
     if rank == 0:

@@ -187,22 +187,34 @@ inline void ordered_memory_into(Felt *mem_col, uint64_t n, const std::vector<uin
     if (top > (1ull << 34)) fail("memory address out of range");
     std::vector<uint32_t> count(top + 2, 0);
     std::vector<uint64_t> rep(top + 2, UINT64_MAX);           // the first access of an address: pool index, or half + public index
+    // A run that idles in `jmp rel 0` (every padded one) reads the same handful of cells a million times: each thread counts through
+    // a small direct-mapped table of its own (address -> count, first index) and only touches the shared arrays when an entry
+    // is evicted or at the end - without it the threads of a 256-thread host serialise on a few cache lines (0.6 s at 2^20 steps).
     uint64_t zeros = 0, ones = 0;
-#pragma omp parallel for schedule(static) reduction(+ : zeros, ones)
-    for (uint64_t k = 0; k < half; ++k) {
-        const uint64_t a = npc_addr[k];
-        if (a == 0) { ++zeros; continue; }
-        if (a == 1) { ++ones; continue; }
+#pragma omp parallel reduction(+ : zeros, ones)
+    {
+        constexpr int SLOTS = 256;
+        uint64_t l_addr[SLOTS], l_rep[SLOTS];
+        uint32_t l_cnt[SLOTS];
+        for (int i = 0; i < SLOTS; ++i) { l_addr[i] = UINT64_MAX; l_cnt[i] = 0; l_rep[i] = UINT64_MAX; }
+        auto flush = [&](int i) {
+            if (l_addr[i] == UINT64_MAX) return;
+            const uint64_t a = l_addr[i];
 #pragma omp atomic
-        ++count[a];
-        uint64_t seen;
-#pragma omp atomic read
-        seen = rep[a];
-        while (k < seen) {                                    // atomic min
-            uint64_t expect = seen;
-            if (__atomic_compare_exchange_n(&rep[a], &expect, k, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
-            seen = expect;
+            count[a] += l_cnt[i];
+            uint64_t seen = __atomic_load_n(&rep[a], __ATOMIC_RELAXED);
+            while (l_rep[i] < seen && !__atomic_compare_exchange_n(&rep[a], &seen, l_rep[i], false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        };
+#pragma omp for schedule(static)
+        for (uint64_t k = 0; k < half; ++k) {
+            const uint64_t a = npc_addr[k];
+            if (a == 0) { ++zeros; continue; }
+            if (a == 1) { ++ones; continue; }
+            const int i = (int)(a & (SLOTS - 1));
+            if (l_addr[i] != a) { flush(i); l_addr[i] = a; l_cnt[i] = 0; l_rep[i] = k; }
+            ++l_cnt[i];
         }
+        for (int i = 0; i < SLOTS; ++i) flush(i);
     }
     if (zeros != cells) fail("the public-memory cells of the pool must be the only accesses of address 0");
     std::vector<Felt> pub_value(public_memory.size());

@@ -88,12 +88,15 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
     struct Col { Felt *p; Felt &operator[](uint64_t i) const { return p[i]; } };
     Col cols[NUM_COLS];
     for (int c = 0; c < NUM_COLS; ++c) cols[c] = Col{out[c]};
-    {                                                   // every cell no section writes is the field's zero
+    {   // every cell no section writes is the field's zero: such cells exist in the two diluted-check columns and the auxiliary
+        // one; the flags, the memory pool (padding first), the ordered memory and the range-check column (its maximum first) are
+        // written whole
         constexpr int64_t CHUNK = 1 << 16;
         const int64_t chunks = (int64_t)((n + CHUNK - 1) / CHUNK);
+        const int sparse[3] = {COL_DILUTED_UNORDERED, COL_DILUTED_ORDERED, COL_AUXILIARY};
 #pragma omp parallel for schedule(static) if (par)
-        for (int64_t k = 0; k < chunks * NUM_COLS; ++k) {
-            const int64_t c = k % NUM_COLS, at = (k / NUM_COLS) * CHUNK;
+        for (int64_t k = 0; k < chunks * 3; ++k) {
+            const int64_t c = sparse[k % 3], at = (k / 3) * CHUNK;
             std::fill(out[c] + at, out[c] + std::min<int64_t>((int64_t)n, at + CHUNK), zero);
         }
     }
@@ -116,8 +119,13 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
     // ---- CPU cells (trace.rs:172-232) and the range-check pool
     std::vector<uint32_t> rc_count(1 << 16, 0);
     std::string first_error;                            // exceptions must not leave an OpenMP region
+    // one histogram of the offsets per thread (an idling run has the same three offsets in every cycle: all threads would hammer
+    // three counters)
+    std::vector<std::vector<uint32_t>> rc_count_of((size_t)omp_get_max_threads());
 #pragma omp parallel for schedule(static) if (par)
     for (int64_t cyc = 0; cyc < (int64_t)num_cycles; ++cyc) try {
+        std::vector<uint32_t> &my_count = rc_count_of[(size_t)omp_get_thread_num()];
+        if (my_count.empty()) my_count.assign(1 << 16, 0);
         const uint64_t cycle = (uint64_t)cyc;
         const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
         const U256 &iw = mem.at(pc);
@@ -147,15 +155,13 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
         aux[r + AUX_TMP0] = tmp0; aux[r + AUX_TMP1] = felt_mul(tmp0, res);
         aux[r + AUX_AP] = felt_from_u64(ap); aux[r + AUX_FP] = felt_from_u64(fp);
         aux[r + AUX_OP0_MUL_OP1] = felt_mul(op0, op1); aux[r + AUX_RES] = res;
-        for (uint64_t v : {w.off_dst(), w.off_op0(), w.off_op1()}) {
-#pragma omp atomic
-            ++rc_count[v];
-        }
+        for (uint64_t v : {w.off_dst(), w.off_op0(), w.off_op1()}) ++my_count[v];
     } catch (const std::exception &e) {
 #pragma omp critical
         if (first_error.empty()) first_error = e.what();
     }
     if (!first_error.empty()) throw std::runtime_error(first_error);
+    for (auto &part : rc_count_of) for (size_t v = 0; v < part.size(); ++v) rc_count[v] += part[v];
 
     mark("cpu cells");
     // ---- range-check builtin instances, ordered values and padding (trace.rs:131-160, 236-284; utils.rs:357-380)

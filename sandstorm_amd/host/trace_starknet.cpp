@@ -287,9 +287,12 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
     Col cols[NUM_COLS];
     for (int c = 0; c < NUM_COLS; ++c) cols[c] = Col{out[c]};
     constexpr uint64_t CHUNK = 1 << 16;
-    parallel_for(NUM_COLS * ((n + CHUNK - 1) / CHUNK), [&](uint64_t k) {       // every cell no section writes is zero
-        const uint64_t c = k % NUM_COLS, at = (k / NUM_COLS) * CHUNK;
-        std::fill(out[c] + at, out[c] + std::min(n, at + CHUNK), zero);
+    // every cell no section writes is zero.  Only the auxiliary column has such cells: the flags (16 per cycle), the four Pedersen
+    // columns (512 rows per instance of 512), the memory pool (padding first), the ordered memory and the range-check column
+    // (its maximum first) are written whole - 8 of the 9 columns need no first pass over them (0.5 GB each at 2^20 steps)
+    parallel_for((n + CHUNK - 1) / CHUNK, [&](uint64_t k) {
+        const uint64_t at = k * CHUNK;
+        std::fill(out[COL_AUXILIARY] + at, out[COL_AUXILIARY] + std::min(n, at + CHUNK), zero);
     });
     const Col flags = cols[COL_FLAGS], npc = cols[COL_NPC], rc_col = cols[COL_RANGE_CHECK], aux = cols[COL_AUXILIARY];
     std::vector<uint64_t> npc_addr(n / 2, 1);

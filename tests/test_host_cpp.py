@@ -41,3 +41,26 @@ def test_small_integers_to_montgomery_form(tmp_path):
                            "-L" + build, "-lsandstorm_host", "-Wl,-rpath," + build])
     out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH=build + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", "")))
     assert out.returncode == 0 and "FELT_FROM_U64_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_trace_generators_write_every_cell_of_the_callers_columns():
+    """the C++ base-trace generators fill the caller's (pinned) columns in place and only pre-zero the columns that have cells no
+    section writes (host/trace_recursive.cpp, trace_starknet.cpp): from poisoned columns they must leave the trace a fresh call
+    returns - the padded example of both layouts, and the reference's bootloader run with real instances of every builtin"""
+    from sandstorm_amd import binary, examples, hostlib
+    from tests.test_layout_starknet import bootloader_run, real_instances
+    cases = []
+    for layout, log_steps in (("recursive", 14), ("recursive", 15), ("starknet", 17)):
+        states, memory, pi = (examples.recursive_example if layout == "recursive" else examples.starknet_example)(log_steps)
+        cases.append((layout, binary.write_register_states(states), binary.write_memory(memory), pi, None))
+    states, memory, pi, priv = bootloader_run()
+    more = dict(real_instances())
+    more["pedersen"] = priv["pedersen"] + more["pedersen"]
+    cases.append(("starknet", binary.write_register_states(states), binary.write_memory(memory), pi, more))
+    for layout, trace_bin, memory_bin, pi, priv in cases:
+        gen = hostlib.recursive_base_trace if layout == "recursive" else hostlib.starknet_base_trace
+        want = gen(trace_bin, memory_bin, pi, priv)
+        out = [np.full(c.shape, 0x7777777777777777, dtype=np.uint64) for c in want]
+        gen(trace_bin, memory_bin, pi, priv, out=out)
+        for c, (a, b) in enumerate(zip(out, want)):
+            assert np.array_equal(a, b), (layout, c)
