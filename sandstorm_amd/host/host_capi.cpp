@@ -26,15 +26,8 @@ typedef int (*ssh_extension_cb)(void *user, const uint64_t *challenges, uint32_t
 
 const char *ssh_last_error(void) { return g_err.c_str(); }
 
-// kind: 0 = the mini AIR of the end-to-end tests (the layouts' AIRs: ssh_air_create_recursive / _starknet)
-int ssh_air_create(ss_ctx *ctx, int kind, uint32_t log_n, uint32_t log_blowup, ssh_air **out) {
-    try {
-        if (kind != 0) throw std::runtime_error("ssh_air_create: unknown AIR kind");
-        std::unique_ptr<Air> a = make_mini_air(ctx);
-        *out = reinterpret_cast<ssh_air *>(a.release());
-        return 0;
-    } catch (const std::exception &e) { g_err = e.what(); return 1; }
-}
+// an `ssh_air` handle is an `Air *` (prover.hpp): the layouts' AIRs come from ssh_air_create_recursive / _starknet below; a caller
+// with an AIR of its own (the tests' mini AIR: tests/cpp/mini_air_lib.cpp) hands in its own object
 void ssh_air_destroy(ssh_air *a) { delete reinterpret_cast<Air *>(a); }
 uint32_t ssh_air_columns(const ssh_air *a, int which) {
     const Air *air = reinterpret_cast<const Air *>(a);

@@ -80,6 +80,10 @@ static std::vector<uint64_t> flat(const std::vector<Felt> &v) {
     return o;
 }
 
+Felt Air::composition_at(uint64_t, const std::vector<Felt> &, const Felt &, const Felt &, const std::vector<Felt> &) {
+    throw std::runtime_error("the " + name + " AIR has no verifier side");
+}
+
 // ------------------------------------------------------------- FRI, proof of work
 // (free functions: the single-device prover below and the sharded one of sharded.cpp run the same code on rank 0)
 static uint64_t brev_bits(uint64_t x, uint32_t bits) { uint64_t r = 0; for (uint32_t i = 0; i < bits; ++i) r |= ((x >> i) & 1ull) << (bits - 1 - i); return r; }

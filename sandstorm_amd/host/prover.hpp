@@ -178,8 +178,7 @@ private:
     Conventions conv_;
 };
 
-// built-in AIRs
-std::unique_ptr<Air> make_mini_air(ss_ctx *ctx);                                   // tests/mini_air.py
+// the layouts' AIRs
 struct AirPublicInput;
 // the real `recursive` layout (air_recursive.cpp; mirror of sandstorm_amd/layouts/recursive.py)
 std::unique_ptr<Air> make_recursive_air(ss_ctx *ctx, const AirPublicInput &pi, uint32_t log_n, uint32_t log_blowup, uint64_t lde_offset);

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the tests' mini AIR is test infrastructure (tests/cpp/mini_air_lib.cpp): registered with the host bindings, built at first use
+    from tests import mini_air_host
+    mini_air_host.register()
     if os.environ.get("SS_TEST_ORACLELIB"):                  # likewise a sanitizer build of the oracle's C
         from oracle import oracle_py
         oracle_py._SO = os.environ["SS_TEST_ORACLELIB"]

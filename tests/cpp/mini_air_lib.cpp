@@ -1,21 +1,18 @@
-// airs.cpp — the small valid "mini" AIR used by the end-to-end tests (mirror of tests/mini_air.py).  The real layouts are in
-// air_recursive.cpp and air_starknet.cpp.
+// mini_air_lib.cpp — TEST INFRASTRUCTURE: the small valid "mini" AIR of the end-to-end tests (mirror of tests/mini_air.py) as an `Air` of
+// the C++ host, built into tests/_build/libsandstorm_test_air.so (tests/mini_air_host.py) and handed to the product's prover
+// through the `ssh_air` handle.  The product library holds the layouts' AIRs only (host/air_recursive.cpp, air_starknet.cpp).
 #include <algorithm>
 #include <cstring>
 #include <random>
 #include <set>
 #include <stdexcept>
 
-#include "prover.hpp"
+#include "../../sandstorm_amd/host/prover.hpp"
 
 namespace ssh {
 
 static void ok(ss_status s) {
     if (s != SS_OK) throw std::runtime_error(ss_last_error());
-}
-
-Felt Air::composition_at(uint64_t, const std::vector<Felt> &, const Felt &, const Felt &, const std::vector<Felt> &) {
-    throw std::runtime_error("the " + name + " AIR has no verifier side");
 }
 
 // ---------------------------------------------------------------------------- mini
@@ -79,6 +76,8 @@ private:
     ss_ctx *ctx_;
     std::unique_ptr<DeviceBuffer> tables_;
 };
-std::unique_ptr<Air> make_mini_air(ss_ctx *ctx) { return std::unique_ptr<Air>(new MiniAir(ctx)); }
-
 }  // namespace ssh
+
+extern "C" int sst_mini_air_create(ss_ctx *ctx, void **out) {          // -> an `ssh_air` handle (ssh_air_destroy frees it)
+    try { *out = new ssh::MiniAir(ctx); return 0; } catch (const std::exception &) { return 1; }
+}

@@ -26,7 +26,37 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
     from sandstorm_amd import _lib
-    assert lib.ss_abi_version() == _lib.header_abi_version() == 7
+    assert lib.ss_abi_version() == _lib.header_abi_version() == 8
+
+
+def test_boundary_document_and_bindings_follow_the_header():
+    """INTEGRATION.md's `extern "C"` block is generated from include/sandstorm_hip.h (tools/gen_integration.py) and must not be
+    stale; the ctypes table of sandstorm_amd/_lib.py has every entry point with the header's argument count, a pointer where the
+    header has a pointer and an integer of the header's width elsewhere (a hand-written block had ss_bitrev_permute32
+    in place and ss_comm_all_gather's arguments in another order)"""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_integration as gi
+    from sandstorm_amd import _lib
+    with open(gi.DOC) as f:
+        doc = f.read()
+    assert gi.render(doc) == doc, "INTEGRATION.md section 1 is stale: run python tools/gen_integration.py"
+    protos = gi.prototypes()
+    assert len(protos) == len(_lib.SIGNATURES) >= 60
+    width = {"u64": 8, "u32": 4, "u8": 1, "c_int": 4, "usize": C.sizeof(C.c_size_t), "i64": 8, "f64": 8}
+    for name, ret, params in protos:
+        restype, argtypes = _lib.SIGNATURES[name]
+        assert len(argtypes) == len(params), name
+        for (ctype, pname), at in zip(params, argtypes):
+            rt = gi.rust_type(ctype).split(" /*")[0]
+            if rt.startswith("*"):
+                assert at in (C.c_void_p, C.c_char_p) or hasattr(at, "contents") or issubclass(at, C._Pointer), (name, pname)
+            else:
+                assert C.sizeof(at) == width[rt] and not issubclass(at, C._Pointer) and at not in (C.c_void_p, C.c_char_p), (name, pname, rt)
+    # the two the hand-written block had wrong
+    by_name = {n: [p for _, p in ps] for n, _, ps in protos}
+    assert by_name["ss_bitrev_permute32"] == ["ctx", "d_src", "log_n", "d_dst"]
+    assert by_name["ss_comm_all_gather"] == ["comm", "d_send", "bytes", "d_recv"]
 
 
 def test_no_device_fails_loudly():
