@@ -769,7 +769,7 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
             ach = algo[name] / sec / 1e9 if sec > 0 else 0.0
             # HBM bytes per launch from the PMC passes of this workload (FETCH_SIZE / WRITE_SIZE cannot be read live;
             # tools/profile_round.sh collects them per kernel, the committed summary is cited here)
-            traffic, traffic_src = None, None
+            traffic, traffic_src, tj = None, None, {}
             tpath = os.path.join(ROOT, "profiles", "hbm_traffic_%s.json" % workload)
             if os.path.exists(tpath):
                 with open(tpath) as fh:
@@ -778,8 +778,28 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
                 if ent:
                     traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source", tj.get("source"))
             launches = prof[name][1]
+            # the ALU roofline beside the HBM one (these kernels are bound by vector-instruction issue): the
+            # stage's SQ_INSTS_VALU per proof from the counters' own --pmc pass (profiles/alu_counters_<workload>.json, its commit
+            # inside; tools/final_round.sh + collect_final.py) over THIS run's HIP-event stage time, against 1024 SIMDs issuing
+            # one wave-instruction per `weighted_cycles_per_inst` cycles of 2.4 GHz - the kernels' static instruction mix priced
+            # with the measured cost of each mnemonic (profiles/alu_model.json, tools/alu_model.py, tools/ubench.hip)
+            alu = None
+            apath = os.path.join(ROOT, "profiles", "alu_counters_%s.json" % workload)
+            if os.path.exists(apath) and sec > 0:
+                with open(apath) as fh:
+                    aj = json.load(fh)
+                st = aj.get("stages", {}).get(name)
+                if st and st.get("weighted_cycles_per_inst"):
+                    insts, cyc = st["valu_wave_insts_per_proof"], st["weighted_cycles_per_inst"]
+                    peak_i = 1024 * 2.4e9 / cyc
+                    units = {"ntt_pass": ntt_ops / 3.0, "quotient": float(N), "deep": float(n), "hash_rows": float(3 * N), "merkle": float(3 * N)}.get(name)
+                    alu = {"valu_wave_insts_per_proof": insts, "valu_insts_per_unit": insts * 64.0 / units if units else None,
+                           "unit": {"ntt_pass": "butterfly", "quotient": "LDE point", "deep": "sub-coset point", "hash_rows": "row", "merkle": "leaf"}.get(name),
+                           "weighted_cycles_per_inst": cyc, "peak_wave_insts_per_s": peak_i, "achieved_wave_insts_per_s": insts / sec,
+                           "frac": insts / sec / peak_i, "counters_source": aj.get("source"), "counters_commit": aj.get("commit")}
             return {"bound": "hbm", "kernel": kernel, "stage": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                    "frac": ach / HBM_PEAK_GBPS, "alu": alu, "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_commit": tj.get("commit") if traffic is not None else None,
                     "algorithmic_bytes_per_proof": algo[name], "algorithmic_bytes_per_launch": algo[name] / max(1.0, launches / steps),
                     "launches": launches, "avg_launch_ms": prof[name][0] / max(1, launches), "stage_ms_per_proof": stage_ms[name], "note": note}
         dominant = max(("quotient", "ntt_pass", "deep", "merkle", "hash_rows"), key=lambda k: stage_ms[k])

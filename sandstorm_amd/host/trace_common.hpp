@@ -163,7 +163,10 @@ inline std::vector<uint64_t> memory_gaps(const std::vector<uint64_t> &npc_addr, 
     if (top > (1ull << 34)) fail("memory address out of range");
     std::vector<uint8_t> seen(top + 1, 0);
 #pragma omp parallel for schedule(static)
-    for (uint64_t k = 0; k < npc_addr.size(); ++k) seen[npc_addr[k]] = 1;       // (every writer writes the same byte)
+    for (uint64_t k = 0; k < npc_addr.size(); ++k) {                              // (every writer writes the same byte; an idling run
+        const uint64_t a = npc_addr[k];                                          // hits the same few: look before writing, or 256 threads
+        if (!seen[a]) seen[a] = 1;                                               // pass one cache line around)
+    }
     for (auto &e : public_memory) seen[e.address] = 1;
     for (uint64_t a = low + 1; a < top; ++a) if (!seen[a]) gaps.push_back(a);
     return gaps;

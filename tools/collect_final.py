@@ -7,7 +7,13 @@ import re
 import shutil
 import sys
 
+import subprocess
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+try:
+    COMMIT = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
+except OSError:
+    COMMIT = None
 SRC = os.path.join(ROOT, os.environ.get("COLLECT_SRC", os.path.join("gpurun_out", "final")))      # COLLECT_SRC: another run's directory
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
@@ -76,5 +82,59 @@ for d in sorted(os.listdir(SRC)):
             per_stage[stage] = {"dispatches": d, "bytes_per_launch": t / d, "bytes_per_proof": t / 2, "source": "profiles/%s_hbm_traffic_%s.txt" % (TAG, w)}
     with open(os.path.join(DST, "hbm_traffic_%s.json" % w), "w") as f:
         json.dump({"workload": w, "kernel": "ss::ntt_pass_kernel", "dispatches": disp, "bytes_per_launch": total / max(1, disp),
-                   "bytes_per_proof": total / 2, "source": "profiles/%s_hbm_traffic_%s.txt" % (TAG, w), "kernels": per_stage}, f, indent=1)
+                   "bytes_per_proof": total / 2, "source": "profiles/%s_hbm_traffic_%s.txt" % (TAG, w), "commit": COMMIT, "kernels": per_stage}, f, indent=1)
     print(w, "ntt dispatches", disp, "GB/launch %.3f" % (total / max(1, disp) / 1e9))
+
+
+# ---- the ALU roofline's measured half: SQ_INSTS_VALU per proof and stage (own --pmc pass: tools/final_round.sh), with the
+# instruction-weighted issue cost of the stage's kernels from profiles/alu_model.json (tools/alu_model.py) -> alu_counters_<w>.json
+STAGES = {"ntt_pass": ["ntt_pass_kernel"], "quotient": ["quotient_"], "deep": ["deep_kernel", "deep_rational", "ood_blocks", "ood_fold", "batch_inverse", "poly_reduce"],
+          "hash_rows": ["keccak_rows", "blake2s_rows"], "merkle": ["_pairs_kernel", "pedersen_", "felt_pairs"], "fri_fold": ["fri_fold_kernel"],
+          "extension_scans": ["scan_", "perm_", "dil_", "inverse_dense"]}
+model_path = os.path.join(DST, "alu_model.json")
+model = json.load(open(model_path))["kernels"] if os.path.exists(model_path) else {}
+
+
+def parse_all(path):
+    """tools/pmc_summary.py output -> {kernel: {counter: sum, "disp": n}}"""
+    out, cur = {}, None
+    for line in open(path):
+        m = re.match(r"^(\S.*?)\s+disp=(\d+)\s*$", line)
+        if m:
+            cur = out.setdefault(m.group(1), {"disp": int(m.group(2))})
+            continue
+        m = re.match(r"^\s+(\w+)\s+mean\s+(\S+)\s+sum\s+(\S+)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = float(m.group(3))
+    return out
+
+
+for w in ("starknet_2p20", "recursive_2p20"):
+    src = os.path.join(SRC, "sq_counters_%s.txt" % w)
+    if not os.path.exists(src):
+        continue
+    ks = parse_all(src)
+    stages = {}
+    for stage, keys in STAGES.items():
+        sel = {k: v for k, v in ks.items() if any(key in k for key in keys) and "SQ_INSTS_VALU" in v}
+        if not sel:
+            continue
+        valu = sum(v["SQ_INSTS_VALU"] for v in sel.values())
+        cyc, priced = 0.0, 0.0
+        per_kernel = {}
+        for k, v in sel.items():
+            hit = [m for name, m in model.items() if name[:60].startswith(k[:56]) or k[:56].startswith(name[:56])]
+            c = hit[0]["weighted_cycles_per_inst"] if hit else None
+            per_kernel[k] = {"dispatches": v["disp"], "SQ_INSTS_VALU": v["SQ_INSTS_VALU"], "weighted_cycles_per_inst": c}
+            if c:
+                cyc += c * v["SQ_INSTS_VALU"]
+                priced += v["SQ_INSTS_VALU"]
+        stages[stage] = {"valu_wave_insts_per_proof": valu / 2, "weighted_cycles_per_inst": cyc / priced if priced else None,
+                         "busy_cycles_per_proof": sum(v.get("SQ_BUSY_CYCLES", 0.0) for v in sel.values()) / 2,
+                         "wave_cycles_per_proof": sum(v.get("SQ_WAVE_CYCLES", 0.0) for v in sel.values()) / 2,
+                         "wait_any_per_proof": sum(v.get("SQ_WAIT_ANY", 0.0) for v in sel.values()) / 2, "kernels": per_kernel}
+    with open(os.path.join(DST, "alu_counters_%s.json" % w), "w") as f:
+        json.dump({"workload": w, "commit": COMMIT, "proofs_in_run": 2, "source": "profiles/%s_sq_counters_%s.txt" % (TAG, w),
+                   "model": "profiles/alu_model.json (tools/alu_model.py: static instruction mix x profiles/r04_ubench_instruction_rates.txt)",
+                   "stages": stages}, f, indent=1)
+    print(w, "alu counters:", {k: "%.3g" % v["valu_wave_insts_per_proof"] for k, v in stages.items()})

@@ -73,6 +73,54 @@ __global__ __launch_bounds__(256) void probe(uint64_t *out, uint32_t seed) {
 #define M(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"(da));
             X4(X8(M))
 #undef M
+        } else if (KIND == 12) {        // round 4: the rest of the field kernels' instruction mix (tools/alu_model.py prices them)
+#define M(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(w[i]) : "v"(b));
+            X4(X8(M))
+#undef M
+        } else if (KIND == 13) {
+#define M(i) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(w[i]) : "v"(b));
+            X4(X8(M))
+#undef M
+        } else if (KIND == 14) {
+#define M(i) asm volatile("v_lshrrev_b32 %0, 28, %0" : "+v"(w[i]));
+            X4(X8(M))
+#undef M
+        } else if (KIND == 15) {
+#define M(i) asm volatile("v_lshrrev_b64 %0, 28, %0" : "+v"(q[i]));
+            X4(X8(M))
+#undef M
+        } else if (KIND == 16) {
+#define M(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(w[i]) : "v"(b));
+            X4(X8(M))
+#undef M
+        } else if (KIND == 17) {
+#define M(i) asm volatile("v_lshl_or_b32 %0, %0, 4, %1" : "+v"(w[i]) : "v"(b));
+            X4(X8(M))
+#undef M
+        } else if (KIND == 18) {
+#define M(i) asm volatile("v_bfe_u32 %0, %0, 4, 20" : "+v"(w[i]));
+            X4(X8(M))
+#undef M
+        } else if (KIND == 19) {
+#define M(i) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(w[i]) : "v"(b));
+            X4(X8(M))
+#undef M
+        } else if (KIND == 20) {
+#define M(i) asm volatile("v_mov_b32 %0, %1" : "+v"(w[i]) : "v"(w[(i + 1) & 7]));
+            X4(X8(M))
+#undef M
+        } else if (KIND == 21) {
+#define M(i) asm volatile("v_ashrrev_i32 %0, 28, %0" : "+v"(w[i]));
+            X4(X8(M))
+#undef M
+        } else if (KIND == 22) {
+#define M(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(w[i]) : "v"(b) : "vcc");
+            X4(X8(M))
+#undef M
+        } else if (KIND == 23) {
+#define M(i) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(w[i]) : "v"(b));
+            X4(X8(M))
+#undef M
         }
     }
     uint64_t r = 0;
@@ -118,5 +166,17 @@ int main() {
     run<6>("v_mad_u32_u24", d_out);
     run<7>("v_mul_hi_u32_u24", d_out);
     run<8>("add_co+nop+addc (pair)", d_out);
+    run<12>("v_and_b32", d_out);
+    run<13>("v_sub_u32", d_out);
+    run<14>("v_lshrrev_b32", d_out);
+    run<15>("v_lshrrev_b64", d_out);
+    run<16>("v_xor_b32", d_out);
+    run<17>("v_lshl_or_b32", d_out);
+    run<18>("v_bfe_u32", d_out);
+    run<19>("v_add3_u32", d_out);
+    run<20>("v_mov_b32", d_out);
+    run<21>("v_ashrrev_i32", d_out);
+    run<22>("v_cndmask_b32", d_out);
+    run<23>("v_lshl_add_u32", d_out);
     return 0;
 }
