@@ -64,6 +64,9 @@ static constexpr int LOG_TILE_MAX = SS_NTT_LOG_TILE;          // 2048 elements
 #ifndef SS_NTT_THREADS_DIF
 #define SS_NTT_THREADS_DIF 256
 #endif
+#ifndef SS_NTT_PRELOAD_TW
+#define SS_NTT_PRELOAD_TW 1        // the twiddles of a radix-2 / radix-4 register group loaded at its start (A/B: 0 = where they are used)
+#endif
 #ifndef SS_NTT_OCC_DIF
 #define SS_NTT_OCC_DIF (SS_NTT_THREADS_DIF / 128)
 #endif
@@ -238,25 +241,35 @@ __device__ __forceinline__ Fl tw_load(const TwPlanes &tw, uint32_t idx) {      /
 //        of the DIF mode's 256-lane radix-8 ones, three twiddle loads per group of four butterflies (the two lower-stage
 //        nodes are neighbours in the plan), and the first two levels need one product instead of four: zeta = 1 at the
 //        root and at the left node of level 1.
+// plan index of the twiddle of pair `pr` of stage ST of a register group (see radix_stage)
 template <int MODE, int G, int ST>
-__device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const TwPlanes &tw, const PassParams &p,
-                                            uint32_t u, uint32_t g0, bool top_group) {
-    if (ST >= G) return;
-    constexpr bool DIF = MODE == MODE_DIF;
+__device__ __forceinline__ uint32_t stage_tw_index(const PassParams &p, uint32_t u, uint32_t g0, int pr) {
     constexpr int STC = ST < G ? ST : 0;
     const uint32_t gsh = p.s0 + u;                  // element m of the group has global index g0 + (m << gsh)
     const uint32_t s = gsh + STC;                   // global stage
-    // position of this stage inside the group's execution order (DIF runs ST = G-1 .. 0)
-    constexpr int ORD = DIF ? (G - 1 - STC) : STC;
-    uint32_t tw_base;                               // plan index of pair 0's twiddle
     if (MODE == MODE_CTI) {
         const uint32_t level = p.log_n - 1u - s;
-        tw_base = ((1u << level) - 1u) + ((g0 >> (gsh + G)) << (G - 1 - STC));
-    } else {
-        const uint32_t klow = g0 & ((1u << gsh) - 1u);
-        if (p.win_log1) tw_base = ((((1u << (s - p.s0)) - 1u) + (klow >> p.s0)) << (p.win_log1 - 1u)) + ((klow & ((1u << p.s0) - 1u)) - p.win0);
-        else tw_base = ((1u << s) - 1u) + klow;
+        return ((1u << level) - 1u) + ((g0 >> (gsh + G)) << (G - 1 - STC)) + (uint32_t)(pr >> STC);
     }
+    const uint32_t klow = g0 & ((1u << gsh) - 1u);
+    const int m = ((pr >> STC) << (STC + 1)) | (pr & ((1 << STC) - 1));
+    // the partner index bits of this pair move the row: + (m_low << u) rows, a window-length each in a window's plan
+    if (p.win_log1)
+        return ((((1u << (s - p.s0)) - 1u) + (klow >> p.s0)) << (p.win_log1 - 1u)) + ((klow & ((1u << p.s0) - 1u)) - p.win0)
+               + ((uint32_t)(m & ((1 << STC) - 1)) << (u + p.win_log1 - 1u));
+    return ((1u << s) - 1u) + klow + ((uint32_t)(m & ((1 << STC) - 1)) << gsh);
+}
+
+template <int MODE, int G, int ST, bool PRE>
+__device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const TwPlanes &tw, const PassParams &p,
+                                            uint32_t u, uint32_t g0, bool top_group, const Fl *pre) {
+    if (ST >= G) return;
+    constexpr bool DIF = MODE == MODE_DIF;
+    constexpr int STC = ST < G ? ST : 0;
+    const uint32_t gsh = p.s0 + u;
+    const uint32_t s = gsh + STC;                   // global stage
+    // position of this stage inside the group's execution order (DIF runs ST = G-1 .. 0)
+    constexpr int ORD = DIF ? (G - 1 - STC) : STC;
     // CTI: the transform's first two levels (the top register group of its first pass) have zeta = 1 at the root and at the
     // left node of level 1; (wave-uniform branch)
     const bool lvl0 = MODE == MODE_CTI && top_group && p.cti_trivial && s + 1u == p.log_n;
@@ -271,13 +284,10 @@ __device__ __forceinline__ void radix_stage(Fl (&x)[1 << G], const TwPlanes &tw,
             x[m | (1 << STC)] = lvl0 ? fl_sub_c<2, 1>(a, b) : fl_sub_c<8, 2>(a, b);
             continue;
         }
-        // the partner index bits of this pair move the row: + (m_low << u) rows, a window-length each in a window's plan
-        const uint32_t k = MODE == MODE_CTI ? tw_base + (uint32_t)(pr >> STC)
-                                            : tw_base + ((uint32_t)(m & ((1 << STC) - 1)) << (p.win_log1 ? u + p.win_log1 - 1u : gsh));
 #ifdef SS_NTT_ABL_NOTW      // timing ablation only (wrong results): no twiddle loads
-        Fl t = x[m]; t.l[0] += k;
+        Fl t = x[m]; t.l[0] += stage_tw_index<MODE, G, ST>(p, u, g0, pr);
 #else
-        const Fl t = tw_load(tw, k);
+        const Fl t = PRE ? pre[pr] : tw_load(tw, stage_tw_index<MODE, G, ST>(p, u, g0, pr));
 #endif
         if (DIF) {
             x[m] = fl_add(a, b);
@@ -350,6 +360,18 @@ __device__ __forceinline__ void radix_group(const Tile &t, const TwPlanes &tw, c
         const uint32_t ebase = (high << (sh + G)) | low;
         const uint32_t g0 = tile_gindex(p, tile, ebase);
         const LdsAddr ab = lds_addr<LG>(ebase);
+        // the group's twiddles first (radix 2 and 4: at most three distinct ones, 27 registers): their loads are in flight while
+        // the elements arrive and the first products run - issued where they are used, a wave waited a few hundred cycles on every
+        // second product (the waves of a workgroup move in step from barrier to barrier, so nobody fills the gap)
+        constexpr bool PRE = SS_NTT_PRELOAD_TW && G <= 2 && MODE != MODE_DIF;
+        Fl tw0[PRE ? (1 << G) / 2 : 1], tw1[PRE ? (1 << G) / 2 : 1];
+        if (PRE) {                                   // (the two trivial levels of a CTI transform's top group read theirs for nothing)
+#pragma unroll
+            for (int pr = 0; pr < (1 << G) / 2; ++pr) {
+                tw0[PRE ? pr : 0] = tw_load(tw, stage_tw_index<MODE, G, 0>(p, u, g0, pr));
+                if (G >= 2) tw1[PRE ? pr : 0] = tw_load(tw, stage_tw_index<MODE, G, 1>(p, u, g0, pr));
+            }
+        }
         Fl x[1 << G];
         if (from_global) {
             const Fp *sp = src + (mem_index(p, g0) >> p.log_expand);
@@ -360,13 +382,13 @@ __device__ __forceinline__ void radix_group(const Tile &t, const TwPlanes &tw, c
             for (int m = 0; m < (1 << G); ++m) x[m] = lds_load(t, ab ^ am[m]);
         }
         if (MODE != MODE_DIT) {
-            if (G >= 3) radix_stage<MODE, G, 2>(x, tw, p, u, g0, top_group);
-            if (G >= 2) radix_stage<MODE, G, 1>(x, tw, p, u, g0, top_group);
-            radix_stage<MODE, G, 0>(x, tw, p, u, g0, top_group);
+            if (G >= 3) radix_stage<MODE, G, 2, false>(x, tw, p, u, g0, top_group, nullptr);
+            if (G >= 2) radix_stage<MODE, G, 1, PRE>(x, tw, p, u, g0, top_group, PRE ? tw1 : nullptr);
+            radix_stage<MODE, G, 0, PRE>(x, tw, p, u, g0, top_group, PRE ? tw0 : nullptr);
         } else {
-            radix_stage<MODE, G, 0>(x, tw, p, u, g0, top_group);
-            if (G >= 2) radix_stage<MODE, G, 1>(x, tw, p, u, g0, top_group);
-            if (G >= 3) radix_stage<MODE, G, 2>(x, tw, p, u, g0, top_group);
+            radix_stage<MODE, G, 0, PRE>(x, tw, p, u, g0, top_group, PRE ? tw0 : nullptr);
+            if (G >= 2) radix_stage<MODE, G, 1, PRE>(x, tw, p, u, g0, top_group, PRE ? tw1 : nullptr);
+            if (G >= 3) radix_stage<MODE, G, 2, false>(x, tw, p, u, g0, top_group, nullptr);
         }
         if (to_global) {
             Fp *dp = dst + mem_index(p, g0);
