@@ -516,6 +516,99 @@ def base_trace(states, memory, pi):
     return cols
 
 
+def base_trace_np(states, memory, pi):
+    """base_trace for runs of millions of steps: the same cells as numpy uint64 arrays.  The instruction of a state is decoded once
+    per DISTINCT (pc, ap, fp) - a run that idles in `jmp rel 0` (every padded one) has few - and every column is filled by
+    index arithmetic; the pools are sorted by numpy.  (tests/test_goldilocks_stark.py holds it to base_trace cell for cell.)"""
+    import numpy as np
+    num_cycles = len(states)
+    if num_cycles & (num_cycles - 1):
+        raise ValueError("the number of cycles must be a power of two")
+    n = num_cycles * CYCLE_HEIGHT
+    u64 = np.uint64
+    pad_addr, pad_value = pi.public_memory_padding()
+    st = np.array([(s.pc, s.ap, s.fp) for s in states], dtype=u64)
+    uniq, inv = np.unique(st, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    mult = np.bincount(inv, minlength=len(uniq))
+    U = len(uniq)
+    fl = np.zeros((U, 16), dtype=u64)
+    cell = {k: np.zeros(U, dtype=u64) for k in ("pc", "inst", "op0a", "op0", "dsta", "dst", "op1a", "op1", "offd", "off0", "off1", "ap", "fp", "mul", "res", "tmp0", "tmp1")}
+    touched = {a for a, _ in pi.public_memory}
+    for k, (pc, ap_, fp) in enumerate(uniq.tolist()):
+        w = bn.Word(memory[pc])
+        if w.flag(bn.ZERO):
+            raise ValueError("instruction at pc %d has bit 63 set" % pc)
+        dst_addr, op0_addr, op1_addr = w.dst_addr(ap_, fp), w.op0_addr(ap_, fp), w.op1_addr(pc, ap_, fp, memory)
+        dst, op0, op1 = memory[dst_addr] % P, memory[op0_addr] % P, memory[op1_addr] % P
+        res = _res(w, pc, ap_, fp, memory)
+        tmp0 = dst if w.flag(bn.PC_JNZ) else 0
+        touched |= {pc, dst_addr, op0_addr, op1_addr}
+        for f in range(16):
+            fl[k, f] = w.flag_prefix(f)
+        for name, v in (("pc", pc), ("inst", memory[pc] % P), ("op0a", op0_addr), ("op0", op0), ("dsta", dst_addr), ("dst", dst), ("op1a", op1_addr),
+                        ("op1", op1), ("offd", w.off_dst), ("off0", w.off_op0), ("off1", w.off_op1), ("ap", ap_), ("fp", fp), ("mul", op0 * op1 % P),
+                        ("res", res), ("tmp0", tmp0), ("tmp1", tmp0 * res % P)):
+            cell[name][k] = v
+    cols = [np.zeros(n, dtype=u64) for _ in range(NUM_BASE_COLUMNS)]
+    flags, npc_col, rc_col, aux_col = cols[COL_FLAGS], cols[COL_NPC], cols[COL_RANGE_CHECK], cols[COL_AUXILIARY]
+    npc_col[0::2], npc_col[1::2] = u64(pad_addr), u64(pad_value)
+    holes = [a for a in range(1, max(touched) + 1) if a not in touched]
+    if len(holes) > n // 16:
+        raise ValueError("more memory holes than gap cells")
+    hk = np.arange(len(holes), dtype=np.int64) * 16
+    npc_col[hk + Npc.GAP_ADDR], npc_col[hk + Npc.GAP_VAL] = np.array(holes, dtype=u64), u64(0)
+    # the range-check pool: every cycle's three offsets; ordered with the gaps between the smallest and the largest filled
+    cnt = np.zeros(1 << 16, dtype=np.int64)
+    for name in ("offd", "off0", "off1"):
+        np.add.at(cnt, cell[name].astype(np.int64), mult)
+    present = np.nonzero(cnt)[0]
+    lo, hi = int(present[0]), int(present[-1])
+    rng_vals = np.arange(lo, hi + 1, dtype=np.int64)
+    padding_vals = rng_vals[cnt[lo:hi + 1] == 0].astype(u64)
+    ordered_vals = np.repeat(rng_vals, np.maximum(cnt[lo:hi + 1], 1)).astype(u64)
+    rc_max = u64(hi)
+    rc_col[:] = rc_max
+    r = np.arange(num_cycles, dtype=np.int64) * CYCLE_HEIGHT
+    for f in range(16):
+        flags[r + f] = fl[inv, f]
+    for off, name in ((Npc.PC, "pc"), (Npc.INSTRUCTION, "inst"), (Npc.MEM_OP0_ADDR, "op0a"), (Npc.MEM_OP0, "op0"), (Npc.MEM_DST_ADDR, "dsta"),
+                      (Npc.MEM_DST, "dst"), (Npc.MEM_OP1_ADDR, "op1a"), (Npc.MEM_OP1, "op1")):
+        npc_col[r + off] = cell[name][inv]
+    for o in range(0, CYCLE_HEIGHT, PUBLIC_MEMORY_STEP):
+        npc_col[r + o + Npc.PUB_MEM_ADDR] = npc_col[r + o + Npc.PUB_MEM_VAL] = u64(0)
+    for off, name in ((RangeCheck.OFF_DST, "offd"), (RangeCheck.OFF_OP1, "off1"), (RangeCheck.OFF_OP0, "off0"), (Auxiliary.AP[1], "ap"), (Auxiliary.FP[1], "fp"),
+                      (Auxiliary.OP0_MUL_OP1[1], "mul"), (Auxiliary.RES[1], "res")):
+        rc_col[r + off] = cell[name][inv]
+    aux_col[r + Auxiliary.TMP0[1]], aux_col[r + Auxiliary.TMP1[1]] = cell["tmp0"][inv], cell["tmp1"][inv]
+    if len(padding_vals) > num_cycles or len(ordered_vals) > n // RANGE_CHECK_STEP:
+        raise ValueError("range-check values do not fit the trace")
+    unused = np.full(num_cycles, rc_max, dtype=u64)
+    unused[:len(padding_vals)] = padding_vals
+    rc_col[r + RangeCheck.UNUSED] = unused
+    ordered = np.full(n // RANGE_CHECK_STEP, rc_max, dtype=u64)
+    ordered[:len(ordered_vals)] = ordered_vals
+    rc_col[np.arange(n // RANGE_CHECK_STEP, dtype=np.int64) * RANGE_CHECK_STEP + RangeCheck.ORDERED] = ordered
+    # sorted memory: the pool's accesses with the public-memory cells (address 0 in the pool) replaced by the public memory and its padding
+    cells = n // PUBLIC_MEMORY_STEP
+    if len(pi.public_memory) > cells:
+        raise ValueError("public memory does not fit")
+    extra = cells - len(pi.public_memory)
+    addr = np.concatenate([npc_col[0::2], np.full(extra, pad_addr, dtype=u64), np.array([a for a, _ in pi.public_memory], dtype=u64)])
+    val = np.concatenate([npc_col[1::2], np.full(extra, pad_value, dtype=u64), np.array([v % P for _, v in pi.public_memory], dtype=u64)])
+    order = np.argsort(addr, kind="stable")
+    addr, val = addr[order], val[order]
+    if addr[:cells].any() or addr[cells] != 1:
+        raise ValueError("the public-memory cells must be the only accesses of address 0, and memory starts at 1")
+    a0, a1, v0, v1 = addr[cells:-1], addr[cells + 1:], val[cells:-1], val[cells + 1:]
+    bad = ~(((a0 == a1) & (v0 == v1)) | (a0 + u64(1) == a1))
+    if bad.any():
+        raise ValueError("memory is not continuous and single-valued at address %d" % int(a0[np.nonzero(bad)[0][0]]))
+    mem_col = cols[COL_MEMORY]
+    mem_col[0::2], mem_col[1::2] = addr[cells:], val[cells:]
+    return cols
+
+
 def _batch_inv3(vals):
     pre, run = [], (1, 0, 0)
     for v in vals:

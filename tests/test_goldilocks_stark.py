@@ -55,6 +55,18 @@ def test_plain_layout_trace_satisfies_the_constraints(run):
         pl.extension_columns(bad, CH)
 
 
+@pytest.mark.parametrize("run_steps,total", [(64, 64), (64, 256), (128, 1024)])
+def test_vectorised_trace_generator_is_the_reference_one(run_steps, total):
+    """base_trace_np (numpy columns, one decode per distinct state: what the 2^20-step GPU test below generates its trace with)
+    writes base_trace's cells - a whole run, and runs padded with their final state (`jmp rel 0`)"""
+    prog = pl.example_program(10)
+    states, memory = pl.run(prog, run_steps)
+    states = list(states) + [states[-1]] * (total - len(states))
+    pi = pl.public_input_of(prog, states, memory)
+    for a, b in zip(pl.base_trace(states, memory, pi), pl.base_trace_np(states, memory, pi)):
+        assert np.array_equal(np.array(a, dtype=np.uint64), b)
+
+
 def test_lowered_composition_is_the_dag(run, oracle):
     prog, states, memory, pi, cols = run
     n, lb = len(cols[0]), 1
@@ -322,3 +334,38 @@ def test_verifier_defaults_and_malformed_proofs(run):
         mutate(p)
         with pytest.raises(gs.VerificationError):
             gs.verify(p, air, seed, statement=pi, required_security_bits=28)
+
+
+@pytest.mark.gpu
+def test_plain_layout_at_2p20_steps_proves_and_verifies():
+    """BASELINE.json configs[4] at its size: the example program's run padded with its final state to 2^20 steps (a real statement:
+    2^24 rows x 5 base + 3 extension coordinate columns), CLI-default options (65 queries, 16 grinding bits), every stage a HIP
+    kernel at the size `bench.py --workload goldilocks_plain_2p20` times - the proof verifies (80 conjectured bits), a flipped
+    trace cell makes the prover's permutation check or the verifier fail.  PARITY UNPINNED, as everything about this field."""
+    import torch
+    from sandstorm_amd import backend as be, goldilocks as gs
+    log_steps = 20
+    prog = pl.example_program(10)
+    states, memory = pl.run(prog, 64)
+    states = list(states) + [states[-1]] * ((1 << log_steps) - len(states))
+    pi = pl.public_input_of(prog, states, memory)
+    cols = pl.base_trace_np(states, memory, pi)
+    del states
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    ctx = be.Context(0, stream=stream.cuda_stream)
+    try:
+        air, opt = gs.plain_air(), gs.Options()
+        base = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
+        seed = bytes(range(32))
+        proof = gs.Prover(ctx, air, opt).prove(seed, base, lambda ch: gs.plain_extension_on_device(ctx, base, ch)[0], statement=pi)   # check on: the permutations close
+        positions = gs.verify(proof, air, seed, statement=pi, expected_options=opt)
+        assert len(positions) >= 60 and proof.trace_len == 16 << log_steps if hasattr(proof, "trace_len") else len(positions) >= 60
+        bad = copy.deepcopy(proof)
+        bad.ood_trace[3, 1] = (int(bad.ood_trace[3, 1]) + 1) % pl.P
+        with pytest.raises(gs.VerificationError):
+            gs.verify(bad, air, seed, statement=pi, expected_options=opt)
+    finally:
+        del base
+        ctx.close()

@@ -673,6 +673,52 @@ def test_deep_compose_of_a_layout_sized_mask(ctx, be, oracle, log_n, shape, monk
     assert np.array_equal(got, want)
 
 
+def test_production_paths_at_2p20_without_overrides(ctx, be, oracle, monkeypatch):
+    """the paths `bench.py` times are chosen by thresholds (point-by-point out-of-domain values and DEEP's rational
+    functions from 2^20 points on) that the parity tests above only reach by overriding them at small sizes.  Here at 2^20 rows
+    with NO override: ss_ood_eval and ss_deep_compose as a proof calls them, against the other path forced explicitly
+    (SS_OOD_TRANSFORM=1 / SS_DEEP_TAPS=1: the paths the oracle holds at small sizes) - bit for bit - and sampled cells / points
+    against the oracle's polynomial evaluation."""
+    for v in ("SS_OOD_SPARSE_MIN_LOG", "SS_OOD_TRANSFORM", "SS_OOD_BLOCK_LOG", "SS_DEEP_RATIONAL_MIN_LOG", "SS_DEEP_RATIONAL_MIN_CELLS", "SS_DEEP_TAPS"):
+        monkeypatch.delenv(v, raising=False)
+    log_n, lb = 20, 1
+    n, N = 1 << log_n, 1 << (log_n + lb)
+    g = g3(oracle)
+    rng = np.random.default_rng(2020)
+    cols = [random_column(n, c + 900) for c in range(3)]
+    m = be.Matrix.from_host(ctx, cols)
+    ev, co = m.lde(lb, g)
+    comp_coeffs = [random_column(n, 990 + k) for k in range(2)]
+    cm = be.Matrix.from_host(ctx, [np.concatenate([c, np.zeros((N - n, 4), dtype=np.uint64)]) for c in comp_coeffs])
+    cm.evaluate(g)
+    pick = lambda k, hi: sorted({int(v) for v in rng.integers(0, hi, size=3 * k)} | {0, 1})[:k]
+    offs = [pick(60, 40000), pick(14, n), [0, 1, 33158]]          # a column above both bars (12 / 24 cells), one between, a small one
+    mask = [(c, o) for c in range(3) for o in offs[c]]
+    mc, mo = [c for c, _ in mask], [o for _, o in mask]
+    z = 0x13579BDF02468ACE ** 3 % P
+    zm = oracle.to_mont([z])[0]
+    ood_t = ctx.ood_eval(co.cols, log_n, mc, mo, zm)                               # point by point (the default from 2^20 on)
+    monkeypatch.setenv("SS_OOD_TRANSFORM", "1")
+    assert np.array_equal(ood_t, ctx.ood_eval(co.cols, log_n, mc, mo, zm))          # one coset transform per column
+    monkeypatch.delenv("SS_OOD_TRANSFORM")
+    w = pow(3, (P - 1) >> log_n, P)
+    coeff_h = co.to_host()
+    for j in (0, 17, 59, 60, 73, len(mask) - 1):
+        c, o = mask[j]
+        want = oracle.poly_eval(oracle.bitrev_permute(coeff_h[c]), oracle.to_mont([z * pow(w, o, P) % P])[0])
+        assert np.array_equal(ood_t[j], want), j
+    ood_c = np.stack([oracle.poly_eval(c, oracle.to_mont([z * z % P])[0]) for c in comp_coeffs])
+    alpha = 918273645546372819
+    ct = oracle.to_mont([pow(alpha, j, P) for j in range(len(mask))])
+    cc = oracle.to_mont([pow(alpha, len(mask) + k, P) for k in range(2)])
+    out, out_taps = ctx.alloc(32 * N), ctx.alloc(32 * N)
+    ctx.deep_compose(ev.cols, cm.cols, log_n, lb, g, mc, mo, ood_t, ct, ood_c, cc, zm, out)          # rational functions (default from 2^20 on)
+    monkeypatch.setenv("SS_DEEP_TAPS", "1")
+    ctx.deep_compose(ev.cols, cm.cols, log_n, lb, g, mc, mo, ood_t, ct, ood_c, cc, zm, out_taps)     # a tap per cell
+    got = out.download(np.uint64, (N, 4))
+    assert np.array_equal(got, out_taps.download(np.uint64, (N, 4)))
+
+
 @pytest.mark.parametrize("seed,size,log_n", [(1, 30, 3), (2, 120, 8), (3, 400, 12)])
 def test_eval_quotient_vs_oracle(ctx, be, oracle, seed, size, log_n):
     import random
