@@ -458,43 +458,62 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
         if (!in.empty()) ok(ss_lde_fp252(ctx_, in.data(), (uint32_t)in.size(), log_n, lb, g.data(), evp.data(), cop.data()));
         return ev;
     };
-    // 2. base trace
+    const uint64_t nb_rows = n / R;              // rows of a trace-size block
+    // Whole columns on their owners -> every rank's LDE row block of them, as ONE transform per column over the ranks: the owner
+    // deals out blocks of n / R rows, the inverse and the forward transform run spread (spread_inverse / spread_forward), the
+    // halo comes from the next ranks.  -> the blocks (with halo); the bit-reversed coefficient blocks are appended to `co`.
+    auto spread_lde = [&](const std::map<uint32_t, uint64_t *> &mine, uint32_t first_col, uint32_t ncols, std::vector<Buf> *co) {
+        std::vector<Buf> xb;
+        std::vector<Message> sends, recvs;
+        for (uint32_t c = first_col; c < first_col + ncols; ++c) {
+            Buf blk = std::make_shared<DeviceBuffer>(ctx_, 32 * nb_rows);
+            const uint32_t o = owner(c);
+            if (o == r) {
+                const uint8_t *col = (const uint8_t *)mine.at(c);
+                for (uint32_t p = 0; p < R; ++p) {
+                    if (p == r) ok(ss_dev_copy(ctx_, blk->u8(), col + 32 * p * nb_rows, 32 * nb_rows));
+                    else sends.push_back({p, (void *)(col + 32 * p * nb_rows), 32 * nb_rows});
+                }
+            } else recvs.push_back({o, blk->u8(), 32 * nb_rows});
+            xb.push_back(blk);
+        }
+        if (R > 1) comm_.exchange(ctx_, sends, recvs);
+        std::vector<Buf> cb = spread_inverse(xb, log_n, nullptr);
+        xb.clear();
+        std::vector<Buf> ev = with_halo(spread_forward(cb, log_N, lb, &g), B, halo);
+        co->insert(co->end(), cb.begin(), cb.end());
+        return ev;
+    };
+    // 2. base trace: R columns at a time, one per rank, extended whole on their owners and dealt out as row blocks; a few columns
+    // left over (9 columns on 8 ranks: one) each as one transform over all the ranks - no rank extends two while the others wait
     for (uint32_t c = 0; c < nb; ++c)
         if ((owner(c) == r) != (my_base.count(c) == 1)) throw std::runtime_error("column c lives on rank c % R");
-    std::vector<Buf> base_blocks = to_row_blocks(extend(my_base), nb, 0, N, halo);
+    // (a spread column costs a rank 1 / R of its butterflies and four all-to-alls of ~1 / R of it; a column on its owner a whole
+    // LDE and one re-shard while R - L ranks idle: spread the L left-over columns when they are few, L <= R / 2)
+    const uint32_t nb_owned = (R == 1 || nb % R > R / 2) ? nb : (nb / R) * R;          // columns 0 .. nb_owned: by owner; nb_owned .. nb: spread
+    std::vector<Buf> spread_coeff_blocks;                            // coefficient blocks of the spread columns: nb_owned .. nb, then the extension's
+    std::vector<Buf> base_blocks;
+    {
+        std::map<uint32_t, uint64_t *> owned_part;
+        for (auto &kv : my_base) if (kv.first < nb_owned) owned_part[kv.first] = kv.second;
+        base_blocks = to_row_blocks(extend(owned_part), nb_owned, 0, N, halo);
+        if (nb_owned < nb) {
+            std::vector<Buf> more = spread_lde(my_base, nb_owned, nb - nb_owned, &spread_coeff_blocks);
+            base_blocks.insert(base_blocks.end(), more.begin(), more.end());
+        }
+    }
     auto base_com = commit(base_blocks, N, order);
     proof.base_root = base_com->root;
     coin.reseed_with_digest(digest_of(proof.base_root));
-    // 3-4. challenges -> extension trace: its owner deals out blocks of n / R rows, then every transform is ONE transform over
-    // the ranks (each rank 1 / R of its butterflies) that ends in the row blocks; the halo comes from the next ranks
+    // 3-4. challenges -> extension trace: every column ONE transform over the ranks
     for (uint32_t i = 0; i < air.num_challenges; ++i) proof.challenges.push_back(coin.draw());
-    std::vector<Buf> blocks = base_blocks, ext_blocks, ext_coeff_blocks;
+    std::vector<Buf> blocks = base_blocks, ext_blocks;
     std::unique_ptr<Commitment> ext_com;
-    const uint64_t nb_rows = n / R;              // rows of a trace-size block
     if (ne) {
         const std::map<uint32_t, uint64_t *> my_ext = build_extension(proof.challenges);
         for (uint32_t c = nb; c < nb + ne; ++c)
             if ((owner(c) == r) != (my_ext.count(c) == 1)) throw std::runtime_error("extension column c lives on rank c % R");
-        std::vector<Buf> xb;
-        {
-            std::vector<Message> sends, recvs;
-            for (uint32_t c = nb; c < nb + ne; ++c) {
-                Buf mine = std::make_shared<DeviceBuffer>(ctx_, 32 * nb_rows);
-                const uint32_t o = owner(c);
-                if (o == r) {
-                    const uint8_t *col = (const uint8_t *)my_ext.at(c);
-                    for (uint32_t p = 0; p < R; ++p) {
-                        if (p == r) ok(ss_dev_copy(ctx_, mine->u8(), col + 32 * p * nb_rows, 32 * nb_rows));
-                        else sends.push_back({p, (void *)(col + 32 * p * nb_rows), 32 * nb_rows});
-                    }
-                } else recvs.push_back({o, mine->u8(), 32 * nb_rows});
-                xb.push_back(mine);
-            }
-            if (R > 1) comm_.exchange(ctx_, sends, recvs);
-        }
-        ext_coeff_blocks = spread_inverse(xb, log_n, nullptr);
-        xb.clear();
-        ext_blocks = with_halo(spread_forward(ext_coeff_blocks, log_N, lb, &g), B, halo);
+        ext_blocks = spread_lde(my_ext, nb, ne, &spread_coeff_blocks);
         ext_com = commit(ext_blocks, N, order);
         proof.has_extension = true;
         proof.extension_root = ext_com->root;
@@ -564,7 +583,7 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
         std::vector<uint32_t> cols_mine, cell_j, cell_col, cell_off;
         for (auto &kv : coeffs) cols_mine.push_back(kv.first);                    // ascending (std::map)
         for (uint32_t j = 0; j < nmask; ++j)
-            if (mask_col[j] < nb && owner(mask_col[j]) == r) {
+            if (mask_col[j] < nb_owned && owner(mask_col[j]) == r) {
                 cell_j.push_back(j);
                 cell_col.push_back((uint32_t)(std::find(cols_mine.begin(), cols_mine.end(), mask_col[j]) - cols_mine.begin()));
                 cell_off.push_back(mask_off[j]);
@@ -580,12 +599,12 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
         // the partial sums of the extension columns' cells and of the composition columns at z^ncomp
         std::vector<uint32_t> xcell_j, xcell_col, xcell_off;
         for (uint32_t j = 0; j < nmask; ++j)
-            if (mask_col[j] >= nb) { xcell_j.push_back(j); xcell_col.push_back(mask_col[j] - nb); xcell_off.push_back(mask_off[j]); }
+            if (mask_col[j] >= nb_owned) { xcell_j.push_back(j); xcell_col.push_back(mask_col[j] - nb_owned); xcell_off.push_back(mask_off[j]); }
         const Felt zR = felt_pow(proof.z, R), zc = felt_pow(proof.z, ncomp), zcR = felt_pow(zc, R);
         std::vector<uint64_t> xvals(4 * xcell_j.size()), cvals(4 * ncomp);
         if (!xcell_j.empty()) {
             std::vector<const uint64_t *> cp;
-            for (const Buf &b : ext_coeff_blocks) cp.push_back(b->u64());
+            for (const Buf &b : spread_coeff_blocks) cp.push_back(b->u64());
             ok(ss_ood_eval(ctx_, cp.data(), (uint32_t)cp.size(), log_n - log_R, xcell_col.data(), xcell_off.data(), (uint32_t)xcell_j.size(), zR.data(), xvals.data()));
         }
         {
