@@ -34,6 +34,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def effective_cpus():
+    """the CPUs this process may actually use: os.cpu_count() capped by the scheduler affinity and by the cgroup's CPU quota
+    (cpu.max / cpu.cfs_quota_us).  The GPU boxes SHOW 256 hardware threads under a quota of 16 CPUs: 256 OpenMP threads there are
+    16 CPUs' worth of time sliced 256 ways (trace generation 0.55 s against 0.13 s with 16-32 threads: profiles/r04_end_to_end.txt)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                              # cgroup v2: "<quota|max> <period>"
+            q, period = f.read().split()
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = float(f.read()), float(g.read())
+                if q > 0 and period > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota and quota >= 1:
+        n = min(n, int(math.ceil(quota)))
+    return max(1, n)
+
+
+HOST_CPUS = effective_cpus()
+os.environ.setdefault("OMP_NUM_THREADS", str(HOST_CPUS))       # before any OpenMP runtime starts: the oracle port, the trace generators, torch
+
 import torch  # first: its bundled HIP runtime must be the one the C ABI library binds to
 import torch.distributed as dist
 
@@ -146,9 +178,7 @@ def cpu_baseline(layout, log_steps_full, gpu_ctx):
     scans, row hashing, trees, the constraint program, out-of-domain evaluation, DEEP, FRI, proof of work, openings - and
     the GPU on exactly that sample.  `value` scales the measured CPU time to the bench workload's size (n log n); the
     measured pair is reported as it is."""
-    threads = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
-    threads = int(os.environ["OMP_NUM_THREADS"])
+    threads = int(os.environ.get("OMP_NUM_THREADS", HOST_CPUS))      # set at import: the CPUs the cgroup grants, not the ones it shows
     from oracle.cpu_context import CpuContext
     # starknet needs 2^17 steps before its diluted check fits (its smallest statement); recursive: the example's 2^14
     sample = min(log_steps_full, 17 if layout == "starknet" else 14)
@@ -157,7 +187,7 @@ def cpu_baseline(layout, log_steps_full, gpu_ctx):
     t_gpu = python_host_proof(gpu_ctx, layout, sample, proofs=3)
     ls, lf = sample + 4, log_steps_full + 4
     scale = float(1 << (lf - ls)) * (lf + 1) / (ls + 1)
-    out = {"value": t_cpu * scale, "unit": "s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+    out = {"value": t_cpu * scale, "unit": "s", "cores": threads, "host_cpus": os.cpu_count(), "cpu_quota": HOST_CPUS, "kind": "port",
            "measured_sample_s": t_cpu, "gpu_same_sample_s": t_gpu, "sample_speedup": t_cpu / t_gpu,
            "sample": "MEASURED whole proof (every stage incl. constraint program and DEEP) of the %s layout's real AIR at 2^%d steps "
                      "(2^%d trace rows), CLI-default options, by the oracle (C + OpenMP port, untuned, not the reference binary) "
@@ -279,7 +309,7 @@ def bench_goldilocks(args, log_steps, rank, local_rank, world, device):
                 oracle.gl_lde(col, lb, 7)
             t_cpu = (time.perf_counter() - t0) / 4
             scale = ncols * float(1 << (log_n - sl)) * (log_n + 0.5) / (sl + 0.5)
-            out["cpu_baseline"] = {"value": t_cpu * scale, "unit": "s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), "kind": "port",
+            out["cpu_baseline"] = {"value": t_cpu * scale, "unit": "s", "cores": int(os.environ.get("OMP_NUM_THREADS", HOST_CPUS)), "kind": "port",
                                    "sample": "oracle (C + OpenMP) LDE of one 2^%d-row column: %.3f s, scaled n log n to %d columns of 2^%d rows"
                                              % (sl, t_cpu, ncols, log_n)}
         emit(out)
@@ -663,7 +693,8 @@ def end_to_end(ctx, layout, log_steps, device, repeats=3):
     air.close()
     out = {k: v / repeats for k, v in acc.items()}
     out["total_s"] = sum(out.values())
-    out["host_threads"] = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    out["host_threads"] = int(os.environ.get("OMP_NUM_THREADS", HOST_CPUS))
+    out["host_cpus_visible"], out["host_cpu_quota"] = os.cpu_count(), HOST_CPUS
     out["statement"] = ("the reference's array-sum run re-declared for the %s layout, padded to 2^%d steps (a real, verifiable statement: "
                         "%d base columns x 2^%d rows from %.1f MB of trace.bin / memory.bin); upload and proof are not overlapped"
                         % (layout, log_steps, nb, log_n, (len(trace_bin) + len(memory_bin)) / 1e6))
@@ -770,6 +801,27 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
         ntt_ops = ncols * (ntt_field_ops(log_n) + ntt_field_ops(log_n + lb)) + 3 * ntt_field_ops(log_n + lb) \
             + ntt_field_ops(log_n) + ntt_field_ops(log_n + lb) + (ncols * ntt_field_ops(log_n) if ood_by_transform(log_n) else 0)
         algo = stage_algorithmic_bytes(nb, ne, log_n, lb, len(proof.fri_layers))
+        # ... and the pruned transforms of DEEP's rational functions (csrc/capi.hip deep_compose_impl, from 2^20 points on): the columns
+        # with >= 12 mask cells, the constants' and the denominator polynomial, 2^poly_log coefficients each onto the n sub-coset
+        # points - only poly_log of the log n stages are real, and what they move is the n x 32 B each writes
+        pruned = {"polynomials": 0, "real_stages": 0, "butterflies": 0.0}
+        if log_n >= int(os.environ.get("SS_DEEP_RATIONAL_MIN_LOG", "20")) and os.environ.get("SS_DEEP_TAPS") != "1":
+            try:
+                mask = hostlib.prover_air(air).mask
+                per_col = {}
+                for c, _ in mask:
+                    per_col[c] = per_col.get(c, 0) + 1
+                min_cells = int(os.environ.get("SS_DEEP_RATIONAL_MIN_CELLS", "12"))
+                big = [c for c, k in per_col.items() if k >= min_cells]
+                offs = len({o for _, o in mask})
+                poly_log = max(1, (offs + 1 - 1).bit_length())
+                moved = sum(per_col[c] for c in big) + offs
+                if big and poly_log < log_n and moved >= min_cells * (len(big) + 3):
+                    pruned = {"polynomials": len(big) + 2, "real_stages": poly_log, "butterflies": (len(big) + 2) * poly_log * (n / 2.0)}
+                    ntt_ops += 3.0 * pruned["butterflies"]
+                    algo["ntt_pass"] += 32.0 * n * (len(big) + 2)
+            except Exception:
+                pass
         stage_ms = {k: v[0] / steps for k, v in prof.items()}
         ntt_ms, ntt_launches = prof["ntt_pass"]
         ntt_s = ntt_ms * 1e-3 / steps
@@ -844,9 +896,10 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
                                             "the kernel north_star names.  algorithmic bytes = 2*N*32 B per transform (SURVEY 8d), shared by "
                                             "its passes; Fp252 butterflies are integer-ALU bound before HBM bound (DESIGN.md section 3): "
                                             "`gbutterflies_per_s` against the 135 G/s of a bare butterfly loop (tools/mulbench.hip); the pruned "
-                                            "transforms of DEEP's rational polynomials (6-7 per proof, ~4 ms) are in the stage's time but in "
-                                            "neither the byte nor the butterfly count"),
-                             gbutterflies_per_s=ntt_ops / 3 / ntt_s / 1e9 if ntt_s > 0 else 0.0, butterfly_ceiling_g_per_s=135.0),
+                                            "transforms of DEEP's rational polynomials are counted with their real stages and the bytes they "
+                                            "write (`pruned_deep_transforms`)"),
+                             gbutterflies_per_s=ntt_ops / 3 / ntt_s / 1e9 if ntt_s > 0 else 0.0, butterfly_ceiling_g_per_s=135.0,
+                             pruned_deep_transforms=pruned),
             "roofline_dominant": stage_roofline(dominant, kernel_of[dominant],
                                                 "the stage with the largest share of the proof, same computation as `roofline` (SURVEY 8d bytes / "
                                                 "HIP-event time of the stage's launches)"),

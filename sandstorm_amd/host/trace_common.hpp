@@ -2,7 +2,10 @@
 // instruction word (binary/src/lib.rs:565-721), memory access, the curve, the Pedersen builtin's element steps
 // (builtins/src/pedersen/mod.rs:121-163) and the diluted form of the bitwise builtin (builtins/src/bitwise/mod.rs).
 #pragma once
+#include <omp.h>
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <climits>
 #include <cstdint>
 #include <cstring>
@@ -150,6 +153,35 @@ inline void partition64(uint64_t v, uint64_t segs[4]) {    // Partition64::new
         for (unsigned s = 0; s < 4; ++s) segs[s] |= ((v >> (b * 4 + s)) & 1ull) << (b * 4);
 }
 
+
+// How many OpenMP threads the generators use: SSH_HOST_THREADS if set; else what OpenMP would take, but no more than twice the
+// CPU time the cgroup grants (cpu.max / cpu.cfs_quota_us).  A container that SEES 256 hardware threads under a quota of 16 CPUs runs
+// 256 runnable threads on 16: measured (profiles/r04_end_to_end.txt) 0.53-0.70 s per 2^20-step starknet trace with 128-256
+// threads, 0.12-0.15 s with 16-32.
+inline int host_threads() {
+    if (const char *e = getenv("SSH_HOST_THREADS")) { const int t = atoi(e); if (t > 0) return t; }
+    int want = omp_get_max_threads();
+    double cpus = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                      // cgroup v2: "<quota|max> <period>"
+        char q[32]; long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && period > 0 && strcmp(q, "max") != 0) cpus = atof(q) / (double)period;
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {     // cgroup v1
+        long quota = -1, period = 0;
+        if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &period) != 1) period = 0; fclose(h); }
+        if (quota > 0 && period > 0) cpus = (double)quota / (double)period;
+    }
+    if (cpus >= 1.0) want = std::min(want, std::max(1, (int)(2.0 * cpus + 0.5)));
+    return std::max(1, want);
+}
+// for the span of a generator call: that many threads in its parallel regions, the caller's setting back afterwards
+struct HostThreadsScope {
+    int before;
+    HostThreadsScope() : before(omp_get_max_threads()) { omp_set_num_threads(host_threads()); }
+    ~HostThreadsScope() { omp_set_num_threads(before); }
+};
 
 // the addresses between the lowest and the highest accessed one that nothing accesses, ascending (the gap fillers of
 // trace.rs:594-625 / 890-925): a byte map of the accessed addresses instead of a sort of all n / 2 accesses

@@ -71,6 +71,7 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
 // layouts/src/recursive/trace.rs:115-120); every cell is written
 void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
                                const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv) {
+    const HostThreadsScope host_threads_scope;              // OpenMP threads by the cgroup's CPU quota (trace_common.hpp)
     const bool timing = getenv("SSH_TRACE_TIMING") != nullptr;   // diagnostic: per-section wall time on stderr
     auto t_prev = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {

@@ -268,6 +268,7 @@ PoseidonTrace poseidon_trace(const std::array<Felt, 3> &input) {       // poseid
 
 void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
                               const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv) {
+    const HostThreadsScope host_threads_scope;              // OpenMP threads by the cgroup's CPU quota (trace_common.hpp)
     const uint64_t num_cycles = states.size();
     if (!num_cycles || (num_cycles & (num_cycles - 1))) fail("the number of cycles must be a power of two");
     if (num_cycles < ECDSA_BUILTIN_RATIO) fail("the starknet layout needs at least 2048 cycles");

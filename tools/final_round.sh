@@ -10,8 +10,9 @@ for w in starknet_2p20 recursive_2p20 recursive_2p16 array_sum_example; do
   timeout 600 python bench.py --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err
   python -c "import json; d=json.load(open('$OUT/bench_$w.json')); print('$w', d['value'], d['stage_ms_per_proof'], d['ntt_gfield_ops_per_s'], d.get('cpu_baseline',{}).get('measured_sample_s'))"
 done
-timeout 300 python bench.py --workload starknet_2p20 --mode shard --no-cpu-baseline > $OUT/bench_starknet_2p20_shard_1gpu.json 2> $OUT/bench_shard.err
+timeout 300 python bench.py --workload starknet_2p20 --mode shard --sharded-host python --no-cpu-baseline > $OUT/bench_starknet_2p20_shard_1gpu.json 2> $OUT/bench_shard.err
 timeout 300 python bench.py --workload starknet_2p20 --mode shard --sharded-host cpp --no-cpu-baseline > $OUT/bench_starknet_2p20_shard_cpp_1gpu.json 2> $OUT/bench_shard_cpp.err
+tools/_build/ubench > $OUT/ubench.txt 2>&1
 timeout 300 python bench.py --workload goldilocks_lde_2p20 --steps 10 --warmup 2 > $OUT/bench_goldilocks_lde_2p20.json 2> $OUT/bench_gl.err
 timeout 300 python bench.py --workload goldilocks_plain_2p20 --steps 3 --warmup 1 > $OUT/bench_goldilocks_plain_2p20.json 2> $OUT/bench_glp.err
 timeout 300 python bench.py --workload starknet_2p22 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_starknet_2p22.json 2> $OUT/bench_2p22.err
