@@ -859,6 +859,17 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
                            "unit": {"ntt_pass": "butterfly", "quotient": "LDE point", "deep": "sub-coset point", "hash_rows": "row", "merkle": "leaf"}.get(name),
                            "weighted_cycles_per_inst": cyc, "peak_wave_insts_per_s": peak_i, "achieved_wave_insts_per_s": insts / sec,
                            "frac": insts / sec / peak_i, "counters_source": aj.get("source"), "counters_commit": aj.get("commit")}
+                    # the clock the stage's kernels actually ran at (GRBM_GUI_ACTIVE / traced duration of a --pmc pass, tools/valu_busy.sh
+                    # -> profiles/effective_clock_<workload>.json): the chip clocks to its power budget, these kernels sit at 2.0-2.4 GHz
+                    epath = os.path.join(ROOT, "profiles", "effective_clock_%s.json" % workload)
+                    if os.path.exists(epath):
+                        with open(epath) as fh:
+                            ej = json.load(fh)
+                        est = ej.get("stages", {}).get(name)
+                        if est and est.get("effective_clock_ghz"):
+                            ghz = est["effective_clock_ghz"]
+                            alu.update({"effective_clock_ghz": ghz, "frac_at_effective_clock": alu["frac"] * 2.4 / ghz,
+                                        "effective_clock_source": "profiles/effective_clock_%s.json (commit %s)" % (workload, ej.get("commit"))})
                     if alu["frac"] > 1.05:
                         # c-bar prices the STATIC mix of the stage's kernels; where most of the executed instructions sit in a few
                         # loop bodies (the Pedersen trees: window loops of curve additions around one-off glue) the executed mix is

@@ -40,6 +40,20 @@
 #else
 #define NTT_SYNC() __syncthreads()
 #endif
+// Between two phases of a pass in which every wave only touches ITS OWN chunk of the tile (see chunk_private below) nothing
+// has to wait for another wave: the LDS executes one wave's instructions in order, so the wave's reads see its earlier writes;
+// the fence only keeps the compiler from moving them across.  (The host emulation of the tests has no waves: a barrier there.)
+#ifndef SS_NTT_WAVE_PRIVATE
+#define SS_NTT_WAVE_PRIVATE 1      // A/B: 0 = a workgroup barrier between all phases (rounds 1-3)
+#endif
+#if defined(HIPEMU)
+#define NTT_WAVE_SYNC() __syncthreads()
+#elif defined(SS_NTT_ABL_NOBAR)
+#define NTT_WAVE_SYNC() do {} while (0)
+#else
+#define NTT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 
 namespace ss {
 
@@ -354,7 +368,13 @@ __device__ __forceinline__ void radix_group(const Tile &t, const TwPlanes &tw, c
     // element m of a group: global index g0 + (m << gsh); in the buffer + m * step (a window stores row j = g >> s0 at j << win_log)
     const size_t dst_step = p.win_log1 ? (size_t)1 << (u + p.win_log1 - 1u) : (size_t)1 << gsh;
     const size_t src_step = p.win_log1 ? dst_step : ((size_t)1 << gsh) >> p.log_expand;
-    for (uint32_t tau = threadIdx.x; tau < items; tau += blockDim.x) {
+    // lane -> items: wave w takes the items [w * ipw, (w + 1) * ipw), 64 at a time - the elements of ONE chunk of the tile whenever
+    // the group's stride allows (chunk_private); a group with fewer items than lanes leaves the upper lanes idle
+    const uint32_t nthreads = blockDim.x, ipw = items / (nthreads >> 6);
+    const bool whole = items >= nthreads;
+    const uint32_t tau0 = whole ? (threadIdx.x >> 6) * ipw + (threadIdx.x & 63u) : threadIdx.x;
+    const uint32_t tau_end = whole ? tau0 + ipw : (threadIdx.x < items ? tau0 + 1u : tau0);
+    for (uint32_t tau = tau0; tau < tau_end; tau += 64u) {
         const uint32_t low = tau & ((1u << sh) - 1u);
         const uint32_t high = tau >> sh;
         const uint32_t ebase = (high << (sh + G)) | low;
@@ -446,10 +466,29 @@ void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw_plan, PassParams p)
     // Strided passes read/write HBM from the first/last register group directly; the
     // contiguous pass (tile = one 64 KiB block, first group of stride 1) stages through LDS.
     const bool fuse = !p.contig;
+    // A tile is 2^log_chunk elements per wave.  A phase is chunk-private when wave w touches the elements [w << log_chunk,
+    // (w + 1) << log_chunk) only: the contiguous pass's load and store phases by construction, a register group when its
+    // elements' stride stays inside a chunk (sh + G <= log_chunk; radix_group deals a wave the items of one chunk).  Between two
+    // such phases the waves do not wait for each other: a contiguous pass of 11 stages has 3 workgroup barriers instead of 7, a
+    // strided one of 7 stages 2 instead of 3 - and the waves drift apart, so one's LDS round trip hides behind another's products.
+    const uint32_t log_waves = 31u - (uint32_t)__builtin_clz(blockDim.x >> 6);
+    const uint32_t log_chunk = p.log_tile - log_waves;
+    const bool chunks = SS_NTT_WAVE_PRIVATE && tile_elems >= blockDim.x;
+    auto group_private = [&](uint32_t u, uint32_t g) {
+        return chunks && (tile_elems >> g) >= blockDim.x && (fuse ? p.log_tile - p.r : 0u) + u + g <= log_chunk;
+    };
+    bool prev_private = false;
+    auto phase_sync = [&](bool cur_private) {          // between the previous phase and the one about to start
+        if (prev_private && cur_private) NTT_WAVE_SYNC(); else NTT_SYNC();
+        prev_private = cur_private;
+    };
+    const uint32_t x0 = chunks ? ((threadIdx.x >> 6) << log_chunk) + (threadIdx.x & 63u) : threadIdx.x;
+    const uint32_t x_step = chunks ? 64u : blockDim.x;
+    const uint32_t x_end = chunks ? (((threadIdx.x >> 6) + 1u) << log_chunk) : tile_elems;
     if (!fuse) {
-        for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x)
+        for (uint32_t x = x0; x < x_end; x += x_step)
             lds_store(t, lds_addr<LG>(x), fl_from_fp(gload(src + (mem_index(p, tile_gindex(p, tile, x)) >> p.log_expand))));
-        NTT_SYNC();
+        prev_private = chunks;
     }
 
     if (MODE == MODE_DIT) {
@@ -459,12 +498,12 @@ void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw_plan, PassParams p)
             const uint32_t g = (p.r - u) >= (uint32_t)NTT_GMAX ? (uint32_t)NTT_GMAX : (p.r - u);
             const bool last = (u + g >= p.r);
             const bool fg = fuse && first, tg = fuse && last;
+            if (fg) prev_private = group_private(u, g); else phase_sync(group_private(u, g));
             if (NTT_GMAX >= 3 && g == 3) radix_group<MODE, NTT_GMAX >= 3 ? 3 : 1>(t, tw, p, u, tile, false, fg, tg, src, dst);
             else if (g == 2) radix_group<MODE, 2>(t, tw, p, u, tile, false, fg, tg, src, dst);
             else radix_group<MODE, 1>(t, tw, p, u, tile, false, fg, tg, src, dst);
             u += g;
             first = false;
-            if (!last || !fuse) NTT_SYNC();
         }
     } else {
         uint32_t u = p.r;
@@ -475,16 +514,17 @@ void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw_plan, PassParams p)
             u -= g;
             const bool last = (u == 0);
             const bool fg = fuse && first, tg = fuse && last, top = top_pass && first;
+            if (fg) prev_private = group_private(u, g); else phase_sync(group_private(u, g));
             if (NTT_GMAX >= 3 && g == 3) radix_group<MODE, NTT_GMAX >= 3 ? 3 : 1>(t, tw, p, u, tile, top, fg, tg, src, dst);
             else if (g == 2) radix_group<MODE, 2>(t, tw, p, u, tile, top, fg, tg, src, dst);
             else radix_group<MODE, 1>(t, tw, p, u, tile, top, fg, tg, src, dst);
             first = false;
-            if (!last || !fuse) NTT_SYNC();
         }
     }
 
     if (!fuse) {
-        for (uint32_t x = threadIdx.x; x < tile_elems; x += blockDim.x)
+        phase_sync(chunks);
+        for (uint32_t x = x0; x < x_end; x += x_step)
             gstore(dst + mem_index(p, tile_gindex(p, tile, x)), pass_output<MODE>(p, lds_load(t, lds_addr<LG>(x)), false));
     }
 }

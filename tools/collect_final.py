@@ -138,3 +138,14 @@ for w in ("starknet_2p20", "recursive_2p20"):
                    "model": "profiles/alu_model.json (tools/alu_model.py: static instruction mix x profiles/r04_ubench_instruction_rates.txt)",
                    "stages": stages}, f, indent=1)
     print(w, "alu counters:", {k: "%.3g" % v["valu_wave_insts_per_proof"] for k, v in stages.items()})
+
+
+# ---- the clock each stage's kernels ran at (tools/valu_busy.sh's pass) -> profiles/effective_clock_<w>.json + the per-kernel table
+for w in ("starknet_2p20", "recursive_2p20"):
+    cc, kt = os.path.join(SRC, "valu_busy", "counters_%s.csv" % w), os.path.join(SRC, "valu_busy", "kernel_trace_%s.csv" % w)
+    if os.path.exists(cc) and os.path.exists(kt):
+        import subprocess
+        with open(os.path.join(DST, "%s_valu_busy_%s.txt" % (TAG, w)), "w") as f:
+            subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_busy.py"), cc, kt, os.path.join(DST, "effective_clock_%s.json" % w), w, str(COMMIT)],
+                           stdout=f, check=True)
+        print(w, "effective clocks written")

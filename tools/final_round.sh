@@ -28,5 +28,6 @@ cp -r $R/gpurun_out/prof $OUT/prof_recursive_2p20
 # SQ instruction / wait counters of the default workload (own pass: --pmc only)
 bash tools/pmc_run.sh sq_final "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-end-to-end > $OUT/sq_counters_starknet_2p20.txt 2>&1
 bash tools/pmc_run.sh sq_final_rec "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $R/bench.py --workload recursive_2p20 --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end > $OUT/sq_counters_recursive_2p20.txt 2>&1
+for w in starknet_2p20 recursive_2p20; do bash tools/valu_busy.sh $w $OUT/valu_busy > $OUT/valu_busy_$w.log 2>&1; done
 bash tools/gl64_pmc.sh > $OUT/gl64_pmc.log 2>&1
 ls $OUT
