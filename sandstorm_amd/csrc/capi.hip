@@ -1726,16 +1726,35 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
     const uint64_t N = npoints;
     // constants in limb form: 9 x 28-bit limbs of the interchange image (add / sub / mov) and of the R280 form (fl_mul_r280)
     const uint32_t nc = prog->n_consts ? prog->n_consts : 1u;
-    std::vector<uint32_t> host((size_t)nc * QG_CONST_STRIDE + 2 * (size_t)(prog->n_tables ? prog->n_tables : 1u), 0u);
+    // [constants | table descriptors | one step w^(lanes of the grid) per part, 32-byte aligned]
+    const size_t wstep_at = (((size_t)nc * QG_CONST_STRIDE + 2 * (size_t)(prog->n_tables ? prog->n_tables : 1u)) + 7) / 8 * 8;
+    std::vector<uint32_t> host(wstep_at + 8 * (size_t)QG_MAX_PARTS, 0u);
     for (uint32_t k = 0; k < prog->n_consts; ++k) {
         const Fp c = fp_from_limbs64(prog->consts + 4 * (size_t)k);
-        const Fl a = fl_from_fp(c), r = fl_to_r280(c);
-        for (int j = 0; j < 9; ++j) { host[(size_t)k * QG_CONST_STRIDE + j] = a.l[j]; host[(size_t)k * QG_CONST_STRIDE + 12 + j] = r.l[j]; }
+        Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
+        const Fp up = fp_mul(c, fp_to_mont(two24));              // c 2^24: takes a constraint's own wide sum (g C 2^-24) back, quotient_gen.h
+        const Fl a = fl_from_fp(c), r = fl_to_r280(c), ru = fl_to_r280(up), rn = fl_to_r280(fp_neg(up));
+        for (int j = 0; j < 9; ++j) {
+            uint32_t *e = &host[(size_t)k * QG_CONST_STRIDE];
+            e[j] = a.l[j]; e[12 + j] = r.l[j]; e[24 + j] = ru.l[j]; e[36 + j] = rn.l[j];
+        }
     }
     uint32_t *tdesc = host.data() + (size_t)nc * QG_CONST_STRIDE;
     for (uint32_t t = 0; t < prog->n_tables; ++t) {
         tdesc[2 * t] = prog->table_desc[2 * t];
         tdesc[2 * t + 1] = (uint32_t)((1ull << prog->table_desc[2 * t + 1]) - 1ull);
+    }
+    const Fp w_dom = root_of_unity(log_N);
+    std::vector<uint64_t> part_blocks(gen.n_parts);
+    for (uint32_t p = 0; p < gen.n_parts; ++p) {
+        // one workgroup per CU and SIMD slot the part's register / LDS budget allows; SS_QG_BLOCKS overrides (experiments)
+        uint64_t blocks = 256ull * gen.parts[p].wgs_per_cu;
+        if (const char *e = getenv("SS_QG_BLOCKS")) blocks = strtoull(e, nullptr, 10);
+        if (blocks * gen.parts[p].threads > N) blocks = N / gen.parts[p].threads;
+        if (blocks == 0) blocks = 1;
+        part_blocks[p] = blocks;
+        const Fp ws = fp_pow_u64(w_dom, blocks * gen.parts[p].threads);
+        for (int j = 0; j < 8; ++j) host[wstep_at + 8 * (size_t)p + j] = ws.v[j];
     }
     ss_status st = ctx->ensure_scratch(host.size() * 4 + 256);
     if (st != SS_OK) return st;
@@ -1754,20 +1773,15 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
     a.sink = (Fp *)((char *)ctx->scratch + ((host.size() * 4 + 63) / 64) * 64);      // inside ensure_scratch's 256 spare bytes
     a.npoints = npoints; a.row0 = (uint32_t)row0; a.log_blowup = log_blowup;
     a.trace_mask = block ? 0xffffffffu : (uint32_t)((1ull << log_N) - 1ull);
-    a.w = root_of_unity(log_N);
+    a.w = w_dom;
     a.offset = fp_mul(offset ? fp_from_limbs64(offset) : fp_one(), fp_pow_u64(a.w, row0));
     // the program's parts, one launch each on the context's stream: part 0 stores its sum, the others add theirs (a lane owns the
     // same points in every part only if the grids agree - they need not: a part reads out[i] written by the PREVIOUS launch)
     for (uint32_t p = 0; p < gen.n_parts; ++p) {
         const QGenPart &part = gen.parts[p];
-        // one workgroup per CU and SIMD slot the part's register / LDS budget allows; SS_QG_BLOCKS overrides (experiments)
-        uint64_t blocks = 256ull * part.wgs_per_cu;
-        if (const char *e = getenv("SS_QG_BLOCKS")) blocks = strtoull(e, nullptr, 10);
-        if (blocks * part.threads > N) blocks = N / part.threads;
-        if (blocks == 0) blocks = 1;
-        a.wstep = fp_pow_u64(a.w, blocks * part.threads);
+        a.wstep_ptr = reinterpret_cast<const Fp *>(a.consts + wstep_at + 8 * (size_t)p);
         ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
-        HIP_TRY(part.launch(s, a, (uint32_t)blocks));
+        HIP_TRY(part.launch(s, a, (uint32_t)part_blocks[p]));
     }
     return SS_OK;
 }

@@ -16,7 +16,9 @@ static constexpr int QG_THREADS = QG_THREADS_PER_WG;
 static constexpr int QG_THREADS = 256;
 #endif
 static constexpr int QG_MAX_COLS = 16;
-static constexpr int QG_CONST_STRIDE = 24;       // dwords per constant: 9 R256 limbs at 0, 9 R280 limbs at 12
+static constexpr int QG_CONST_STRIDE = 48;       // dwords per constant, four limb forms of 9 (+ 3 pad): R256 limbs at 0 (add / sub / mov), R280
+                                                 // limbs at 12 (fl_mul_r280), R280 limbs of c 2^24 at 24 and of -c 2^24 at 36 (the alpha powers
+                                                 // that take a constraint's own wide sum g C 2^-24 back: tools/gen_quotient.py plan_wide_constraints)
 
 struct QGenArgs {
     const Fp *cols[QG_MAX_COLS];
@@ -25,7 +27,8 @@ struct QGenArgs {
     const uint32_t *consts;                      // per constant QG_CONST_STRIDE dwords, limb form
     Fp *out;
     Fp *sink;                                    // 32 bytes nobody reads: where lanes past the end of the points store
-    Fp offset, w, wstep;                         // x of local point k = offset * w^k (offset carries w^row0); wstep = w^(lanes of the grid)
+    Fp offset, w;                                // x of local point k = offset * w^k (offset carries w^row0)
+    const Fp *wstep_ptr;                         // -> w^(lanes of this launch's grid), in device memory (read at the end of every point)
     uint64_t npoints;                            // points evaluated: the whole domain, or one row block of it
     uint32_t row0;                               // global row of local point 0 (tables are indexed by the global row)
     uint32_t trace_mask;                         // trace cells are read at (k + shift) & trace_mask: N - 1 on whole columns, ~0 on a
@@ -85,10 +88,10 @@ __device__ __forceinline__ void qg_store(Fp *p, const Fp &x) {
 #define QG_SYNC
 #endif
 
-// constants live in LDS for the kernel's lifetime (18 dwords each: 9 R256 limbs, 9 R280 limbs): a wave-uniform LDS read
+// constants live in LDS for the kernel's lifetime (36 dwords each: the four limb forms of QG_CONST_STRIDE): a wave-uniform LDS read
 // is a broadcast, its latency is short and known to the scheduler - unlike ~25 KB of scalar loads that miss the 16 KB
 // scalar cache in front of every multiplication
-static constexpr int QG_CONST_LDS_STRIDE = 18;
+static constexpr int QG_CONST_LDS_STRIDE = 36;
 // LDS pointers carry their address space (32-bit, ds_* instructions) also through the per-point laundering below
 typedef uint32_t __attribute__((address_space(3))) *qg_lds_u32;
 typedef qg_u32x4 __attribute__((address_space(3))) *qg_lds_u32x4;
@@ -105,6 +108,12 @@ typedef FlWide QgWide;
 #define qg_dot_zero fl_wide_zero
 #define qg_dot_mad fl_wide_mad
 #define qg_dot_reduce fl_wide_reduce
+// + L 2^256 into a wide sum that the ten-step reduction divides by 2^280: 2^256 = 2^4 2^(9 * 28), so limb j goes to column 9 + j
+// shifted by four bits (a lazy limb < 2^32: far below a column's 2^64)
+__device__ __forceinline__ void qg_wide_tail(QgWide &w, const Fl &l) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) w.c[9 + j] += (u64)l.l[j] << 4;
+}
 
 // operands (the generator writes these with immediates).  `idx` is the point's local index: this point's, or the next
 // point's for the loads issued across the loop edge.
@@ -112,6 +121,8 @@ typedef FlWide QgWide;
 #define QG_TABLE_RAW(t, idx) qg_load_raw(a.tables + tdesc[2 * (t)], ((idx) + row0) & tdesc[2 * (t) + 1])
 #define QG_CONST(k) qg_const_lds(lds_consts + QG_CONST_LDS_STRIDE * (k))
 #define QG_CONST_R280(k) qg_const_lds(lds_consts + QG_CONST_LDS_STRIDE * (k) + 9)
+#define QG_CONST_R280_UP(k) qg_const_lds(lds_consts + QG_CONST_LDS_STRIDE * (k) + 18)
+#define QG_CONST_R280_UPN(k) qg_const_lds(lds_consts + QG_CONST_LDS_STRIDE * (k) + 27)
 // keep a load where the generator put it: ALU instructions and LDS writes may still be scheduled across, vector-memory
 // instructions and LDS reads may not (an LDS read of a constant depends on nothing: unpinned, hundreds of them float
 // to the top of the point and sit in registers until used)
@@ -158,7 +169,7 @@ static inline size_t qg_lds_bytes(int nconsts, int nslots) {
     qg_lds_u32x4 lds_slots = (qg_lds_u32x4)qg_smem;                                                   \
     qg_lds_u32 lds_consts = (qg_lds_u32)(qg_smem + (size_t)(NSLOTS) * 2 * QG_THREADS * 16);           \
     for (uint32_t k = threadIdx.x; k < (uint32_t)(NCONSTS) * QG_CONST_LDS_STRIDE; k += blockDim.x)    \
-        lds_consts[k] = a.consts[(k / QG_CONST_LDS_STRIDE) * QG_CONST_STRIDE + (k % QG_CONST_LDS_STRIDE < 9 ? k % QG_CONST_LDS_STRIDE : k % QG_CONST_LDS_STRIDE + 3)]; \
+        lds_consts[k] = a.consts[(k / QG_CONST_LDS_STRIDE) * QG_CONST_STRIDE + ((k % QG_CONST_LDS_STRIDE) / 9) * 12 + (k % QG_CONST_LDS_STRIDE) % 9]; \
     __syncthreads();                                                                                  \
     const uint64_t N = a.npoints;                                                                     \
     const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x;                                          \
@@ -166,7 +177,6 @@ static inline size_t qg_lds_bytes(int nconsts, int nslots) {
     const uint32_t lb = a.log_blowup, maskN = a.trace_mask, row0 = a.row0;                            \
     const uint32_t *tdesc = a.tdesc;                                                                  \
     Fl x = fl_from_fp(fp_mul(a.offset, fp_pow_u64(a.w, lane)));                                       \
-    const Fl wstep = fl_from_fp(a.wstep);                                                             \
     QG_DECLARE_SLOTS
 
 // Every lane of the grid runs the same number of iterations (the parts may hold workgroup barriers - QG_SYNC - inside a point):
@@ -182,8 +192,14 @@ static inline size_t qg_lds_bytes(int nconsts, int nslots) {
         /* the constants do not change, but their loads must not be hoisted out of the loop (thousands of registers) */ \
         asm volatile("" : "+v"(lds_consts), "+v"(lds_slots));
 
+// The step to the lane's next point is read from memory at the end of every point (two 16-byte loads + 16 vector instructions):
+// held in registers across the point it cost nine of the 256 that the straight-line code fights over.
 #define QG_POINT_LOOP_END                                                                             \
-        x = fl_mul(x, wstep);                                                                         \
+        {                                                                                             \
+            const Fp *qg_ws = a.wstep_ptr;                                                            \
+            asm volatile("" : "+v"(qg_ws));                                                           \
+            x = fl_mul(x, fl_from_fp(qg_load_raw(qg_ws, 0)));                                         \
+        }                                                                                             \
     }
 
 }  // namespace ss

@@ -21,7 +21,7 @@ struct HostArgs {
     std::vector<std::vector<Fp>> cols;
     std::vector<Fp> tables;
     std::vector<uint32_t> tdesc;          // per table: first element, index mask
-    std::vector<Fl> consts, consts_r280;
+    std::vector<Fl> consts, consts_r280, consts_up, consts_upn;
     std::vector<Fp> out;
     Fp offset, w;
     uint64_t npoints;
@@ -32,6 +32,8 @@ struct HostArgs {
 #define QG_TABLE_RAW(t, idx) a.tables[a.tdesc[2 * (t)] + (((idx) + row0) & a.tdesc[2 * (t) + 1])]
 #define QG_CONST(k) a.consts[k]
 #define QG_CONST_R280(k) a.consts_r280[k]
+#define QG_CONST_R280_UP(k) a.consts_up[k]
+#define QG_CONST_R280_UPN(k) a.consts_upn[k]
 #define QG_SLOT_STORE(k, v) slots[k] = fl_pack(v)
 #define QG_SLOT(k) fl_from_fp(slots[k])
 #define QG_OUT(v) *(qg_live ? &a.out[i] : &sink) = fl_to_fp(v)
@@ -43,6 +45,9 @@ typedef FlWide QgWide;
 #define qg_dot_zero fl_wide_zero
 #define qg_dot_mad fl_wide_mad
 #define qg_dot_reduce fl_wide_reduce
+static inline void qg_wide_tail(QgWide &w, const Fl &l) {
+    for (int j = 0; j < 9; ++j) w.c[9 + j] += (u64)l.l[j] << 4;
+}
 #define QG_POINT_LOOP_BEGIN                                        \
     const uint64_t qg_iters = (N + lanes - 1) / lanes;             \
     for (uint64_t qg_it = 0; qg_it < qg_iters; ++qg_it) {          \
@@ -85,7 +90,12 @@ int main(int argc, char **argv) {
     std::vector<Fp> consts(hdr[4]); rd(f, consts.data(), consts.size());
     rd(f, &a.offset, 1); rd(f, &a.w, 1);
     fclose(f);
-    for (auto &c : consts) { a.consts.push_back(fl_from_fp(c)); a.consts_r280.push_back(fl_to_r280(c)); }
+    Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
+    for (auto &c : consts) {
+        const Fp up = fp_mul(c, fp_to_mont(two24));
+        a.consts.push_back(fl_from_fp(c)); a.consts_r280.push_back(fl_to_r280(c));
+        a.consts_up.push_back(fl_to_r280(up)); a.consts_upn.push_back(fl_to_r280(fp_neg(up)));
+    }
     a.npoints = hdr[5]; a.row0 = (uint32_t)hdr[6]; a.trace_mask = (uint32_t)hdr[7]; a.log_blowup = (uint32_t)hdr[8];
     a.out.assign(a.npoints, fp_zero());
     a.offset = fp_mul(a.offset, fp_pow_u64(a.w, a.row0));

@@ -274,6 +274,7 @@ def encode(ins):
 
 
 PREFETCH_DEPTH = 6      # memory operands in flight ahead of their use (one wave per SIMD: nothing else hides the latency)
+LAZY_PRODUCT_MAX = int(os.environ.get("QG_LAZY_PRODUCT", "0"))   # bound(a) x bound(b) a plain product takes without reducing a factor first
 DOT_MAX_TERMS = 16      # products accumulated in the 64-bit columns before a Montgomery reduction (16 * 9 * 2^56 < 2^64)
 # Fusing "MUL acc, alpha^k ; ADD sum, acc" chains into dot products (one Montgomery reduction per DOT_MAX_TERMS units of bound)
 # removes ~9 % of the vector instructions.  Left to itself the machine scheduler interleaves several program instructions
@@ -337,10 +338,17 @@ def generate(layout, all_variants=False):
             if remat and part_slots > REMAT_ABOVE_SLOTS:     # the decoded flags: recomputed at their uses instead of parked (17 -> 6 slots)
                 part, part_slots = compact_slots(rematerialize_cheap_slots(part))
             if not slots_in_regs:
-                lds = part_slots * 2 * threads * 16 + n_consts * 18 * 4
+                lds = part_slots * 2 * threads * 16 + n_consts * 36 * 4
                 assert lds * wgs <= LDS_BYTES_PER_CU, "%s%s part %d: %d slots + constants = %d B of LDS x %d workgroups per CU" % (layout, suffix, j, part_slots, lds, wgs)
             base = "quotient_gen_%s%s_p%d" % (layout, suffix, j)
-            body = generate_body(layout, part, n_consts, part_slots, n_tables, ncols, depth, base + ".inc", fuse, "QG_OUT" if j == 0 else "QG_OUT_ACC", sync)
+            wide_here, depth_here, lazy_sub, const_factor = PART_TUNING.get(layout, {}).get((suffix, j), (False, depth, False, False))
+            if "QG_WIDE_PARTS" in os.environ:                 # A/B builds (tools/qg_wide_ab.sh): the same choice for every part
+                wide_here = ("%s:%d" % (layout, j)) in os.environ["QG_WIDE_PARTS"].split(",") or os.environ["QG_WIDE_PARTS"] == "all"
+            depth_here = int(os.environ.get("QG_DEPTH", depth_here))
+            lazy_sub = os.environ["QG_SUB_LAZY2"] != "0" if "QG_SUB_LAZY2" in os.environ else lazy_sub
+            const_factor = os.environ["QG_CONST_FACTOR"] != "0" if "QG_CONST_FACTOR" in os.environ else const_factor
+            body = generate_body(layout, part, n_consts, part_slots, n_tables, ncols, depth_here, base + ".inc", fuse,
+                                 "QG_OUT" if j == 0 else "QG_OUT_ACC", sync, wide_here, lazy_sub, const_factor)
             write_part(layout, suffix, j, len(parts), base, body, len(part), n_consts, part_slots, slots_in_regs, wgs, fence, threads, sync)
             names.append(base + ".hip")
         write_kernel_table(layout, suffix, k, code, n_consts, n_tables, ncols, len(parts))
@@ -349,8 +357,122 @@ def generate(layout, all_variants=False):
     return written
 
 
+
+WIDE_MAX_OTHER_PRODUCTS = int(os.environ.get("QG_WIDE_OTHER", "0"))     # other multiplications allowed while a constraint's wide sum is open
+WIDE_MAX_SPAN = int(os.environ.get("QG_WIDE_SPAN", "1000"))            # program instructions from its first product to its alpha multiplication
+# the parts (variant suffix, part number) whose constraints' top-level products accumulate in a second wide accumulator (see
+# plan_wide_constraints); QG_WIDE_PARTS="starknet:1,starknet:3,..." overrides for A/B builds
+# Chosen per part on the MI355X (profiles/r04_quotient_algebra.txt: every part is its own kernel, 16 builds timed part by part):
+# (variant suffix, part) -> (wide sums, operand prefetch depth, lazy subtrahends).  The instruction counts fall everywhere; the time
+# follows only where the register allocator keeps its spills (a second 38-register accumulator beside the dot product's) - part 4
+# of starknet is faster as it was, with a shallower prefetch.
+PART_TUNING = {"starknet": {("", 0): (True, 3, True, True), ("", 1): (True, 2, True, True), ("", 2): (True, 3, False, False), ("", 3): (True, 3, True, True),
+                            ("", 4): (False, 2, False, False), ("", 5): (True, 3, True, True)},
+               "recursive": {("", 0): (True, 2, True, True)}}
+
+
+class WideViolation(Exception):
+    """the emission met a use of a half-summed constraint it cannot express: that constraint goes back to plain products"""
+    def __init__(self, k, why):
+        Exception.__init__(self, "constraint at pc %d: %s" % (k, why))
+        self.k = k
+
+
+def plan_wide_constraints(ins, fused, banned, const_factor=True):
+    """Round 4.  A constraint C = sum_i s_i A_i B_i + L (A_i, B_i, L: sums of cells, constants and earlier values;
+    most of the program's products sit at this top level) paid a whole Montgomery product per A_i B_i - 81 multiply-adds plus a
+    142-instruction reduction - and, where a product waited for its siblings in a scratch slot, a weak reduction, a store and a
+    load on top.  The products of ONE constraint can share one reduction: their 81 partial products each go into the 19 64-bit
+    columns of a wide accumulator (fl252.h FlWide), L joins as L * 2^256 (its limbs shifted 4 bits into columns 9..17), and one
+    ten-step reduction by 2^280 yields g C 2^-24 (g = +-1, chosen so that most products need no negation) - which the
+    multiplication by the constraint's power of the composition coefficient, already a term of a fused dot product, takes back
+    by using g alpha^k 2^24 as its constant (quotient_gen.h QG_CONST_R280_UP / _UPN).
+
+    This function finds, in the value graph of the instruction stream, for every fused "MUL acc, alpha^k" (pc in `fused`) the
+    flattened signed sum below the multiplied value and its product terms.  -> (wide_mul: pc of a product -> (constraint, sign),
+    close: pc of the alpha multiplication -> (g, number of products), struct: pc of an ADD / SUB / RSUB inside the sum ->
+    constraint).  A constraint is named by the pc of its alpha multiplication."""
+    nodes = []                                     # (kind, a, b)
+
+    def new(kind, a=None, b=None):
+        nodes.append((kind, a, b))
+        return len(nodes) - 1
+    acc, slot = [None] * 8, {}
+    made_at, root_of = {}, {}                      # node -> pc of the instruction that made it; pc of an alpha MUL -> node multiplied
+    for pc, (op, d, kind, w1) in enumerate(ins):
+        src = None
+        if op <= OP_MUL:
+            src = acc[w1 & 7] if kind == SRC_ACC else slot[w1] if kind == SRC_SLOT else new("CONST" if kind == SRC_CONST else "LEAF")
+        if op == OP_MOV:
+            acc[d] = src
+        elif op in (OP_ADD, OP_SUB):
+            acc[d] = new("ADD" if op == OP_ADD else "SUB", acc[d], src)
+            made_at[acc[d]] = pc
+        elif op == OP_RSUB:
+            acc[d] = new("SUB", src, acc[d])
+            made_at[acc[d]] = pc
+        elif op == OP_MUL:
+            if pc in fused:
+                root_of[pc] = acc[d]
+            acc[d] = new("MUL", acc[d], src)
+            made_at[acc[d]] = pc
+        elif op == OP_INV:
+            acc[d] = new("INV", acc[d])
+        elif op == OP_ST:
+            slot[w1] = acc[d]
+        elif op == OP_OUT:
+            new("OUT", acc[d])
+    uses = {}
+    for kind, a, b in nodes:
+        for x in (a, b):
+            if x is not None:
+                uses[x] = uses.get(x, 0) + 1
+    wide_mul, close, struct = {}, {}, {}
+    taken = set()
+    for k in sorted(root_of):
+        if k in banned:
+            continue
+        r = root_of[k]
+        if r is None or uses.get(r, 0) != 1:
+            continue
+        terms, inner, stack = [], [], [(1, r)]
+        while stack:
+            sgn, v = stack.pop()
+            kind, a, b = nodes[v]
+            if kind in ("ADD", "SUB") and (v == r or uses.get(v, 0) == 1):
+                inner.append(v)
+                stack.append((sgn, a))
+                stack.append((sgn if kind == "ADD" else -sgn, b))
+            else:
+                terms.append((sgn, v))
+        prods = [(sgn, v) for sgn, v in terms
+                 if nodes[v][0] == "MUL" and uses.get(v, 0) == 1 and nodes[v][1] != nodes[v][2] and v not in taken
+                 and nodes[nodes[v][2]][0] != "CONST" and (const_factor or nodes[nodes[v][1]][0] != "CONST") and made_at[v] not in fused]
+        # (a constant that was MOVed into the accumulator and multiplied by a cell is a factor like any other: its R256 limbs are the
+        # value c 2^256, so c x cell comes out at the same 2^-24 as the products of two cells - sums of 2^(16 j) x cell_j, fourteen terms
+        # long in the range-check and bit-unpacking constraints, become fourteen 81-multiply-add terms and ONE reduction)
+        if not prods:
+            continue
+        # register pressure: the wide sum (38 registers) lives from the constraint's first product to the alpha multiplication,
+        # beside the alpha dot product's own 38; a plain product in between adds its 36 columns on top (scratch spills: the
+        # recursive kernel ran 14 % SLOWER with every constraint widened) - so only constraints whose products follow each other
+        first = min(made_at[v] for _, v in prods)
+        mine = set(made_at[v] for _, v in prods)
+        between = [pc for pc in range(first, k) if ins[pc][0] in (OP_MUL, OP_INV) and pc not in mine]
+        if len(between) > WIDE_MAX_OTHER_PRODUCTS or k - first > WIDE_MAX_SPAN:
+            continue
+        g = 1 if sum(1 for sgn, _ in prods if sgn > 0) * 2 >= len(prods) else -1
+        for sgn, v in prods:
+            wide_mul[made_at[v]] = (k, sgn * g)
+            taken.add(v)
+        for v in inner:
+            struct[made_at[v]] = k
+        close[k] = (g, len(prods))
+    return wide_mul, close, struct
+
+
 def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPTH, inc_name, FUSE_ALPHA_DOT_PRODUCTS=False, out_macro="QG_OUT",
-                  sync_every=0):
+                  sync_every=0, wide_products=False, lazy_sub=False, const_factor=False):
     """the straight-line body of one (part) program -> csrc/<inc_name>"""
     n_instr = len(ins)
     # ---- memory operands in program order: loaded PREFETCH_DEPTH operands ahead into a rotating set of registers
@@ -380,16 +502,72 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
         op2, d2, kind2, w2 = ins[pc + 1]
         if FUSE_ALPHA_DOT_PRODUCTS and op == OP_MUL and kind == SRC_CONST and op2 == OP_ADD and kind2 == SRC_ACC and (w2 & 7) == e and d2 != e and dies_after(e, pc + 1):
             fused[pc] = d2
+    banned = set()
+    while True:                                     # constraints whose half-summed value is used in a way the emission cannot express
+        try:                                        # go back to plain products, one at a time (plan_wide_constraints)
+            out, stats = _emit_body(ins, n_consts, n_slots, mem_ops, mem_index, D, fused, out_macro, sync_every, lazy_sub, const_factor,
+                                    plan_wide_constraints(ins, fused, banned, const_factor) if wide_products and FUSE_ALPHA_DOT_PRODUCTS else ({}, {}, {}))
+            break
+        except WideViolation as e:
+            banned.add(e.k)
+            if os.environ.get("QG_VERBOSE"):
+                print("   plain again:", e)
+    stats["wide_banned"] = len(banned)
+    body = "\n".join(out)
+    regs = "    Fp " + ", ".join("m%d" % k for k in range(D)) + ";\n"
+    prime = "".join("    m%d = %s;\n" % (j, mem_ops[j][1] % "i32") for j in range(D))
+    inc = _INC_TEMPLATE % dict(layout=layout, regs=regs, prime=prime, body=body, depth=D,
+                               wide=("    QgWide wd;\n" if stats["fused"] else "") + ("    QgWide wq;\n" if stats["wide_terms"] else ""),
+                               temp_acc=", acc4 = fl_zero()" if any(d == TEMP_ACC for _, d, _, _ in ins) else "")
+    name = inc_name
+    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", name), "w") as f:
+        f.write(inc)
+    print("%s: %d instructions, %d multiplications (%d by constants, %d fused into %d dot products, %d as terms of %d constraints' own wide sums - %d "
+          "negated, %d constraints kept plain), %d loads %d ahead, %d reductions -> %s"
+          % (layout, len(ins), stats["mul"], stats["mulr"], stats["fused"], stats["flushes"], stats["wide_terms"], stats["wide_closes"], stats["wide_neg"],
+             stats["wide_banned"], stats["loads"], D, stats["reduce"], name))
+    return dict(stats, inc=name, depth=D)
+
+
+_INC_TEMPLATE = '''// GENERATED by tools/gen_quotient.py - DO NOT EDIT.  The body of the `%(layout)s` constraint kernel: the program unrolled over the
+// operand macros of quotient_gen.h (operand loads issued %(depth)d operands ahead).  Included by the quotient_gen_%(layout)s*.hip
+// wrappers (device) and, with host definitions of the same macros, by tests/cpp/quotient_gen_host_test.cpp, which runs it on
+// the CPU against the oracle's constraint VM.
+    Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero()%(temp_acc)s;
+%(wide)s%(regs)s    uint32_t i32 = (uint32_t)(lane < N ? lane : N - 1);
+%(prime)s    QG_POINT_LOOP_BEGIN
+%(body)s
+    QG_POINT_LOOP_END
+'''
+
+
+def _emit_body(ins, n_consts, n_slots, mem_ops, mem_index, D, fused, out_macro, sync_every, SUB_LAZY2, CONST_FACTOR, plan):
+    """one pass over the (part) program: -> (lines, stats); raises WideViolation"""
+    n_instr = len(ins)
+    wide_mul, wide_close, wide_struct = plan
     out = []
     emit = out.append
     bound = [1, 1, 1, 1, 1]                        # four accumulators of the program format + the generator's own (TEMP_ACC)
-    stats = {"mul": 0, "mulr": 0, "reduce": 0, "loads": len(mem_ops), "fused": 0, "flushes": 0}
-    wide = {"acc": None, "terms": 0}               # the one wide (unreduced 64-bit column) accumulator in flight
+    stats = {"mul": 0, "mulr": 0, "reduce": 0, "loads": len(mem_ops), "fused": 0, "flushes": 0, "wide_terms": 0, "wide_closes": 0, "wide_neg": 0}
+    wide = {"acc": None, "terms": 0}               # the one wide (unreduced 64-bit column) accumulator of the alpha dot products in flight
+    # the constraint whose products are being summed in the second wide accumulator (wq), and which accumulators / slots hold a
+    # part of that constraint's value: k -> the constraint, lin -> whether the register (slot) holds a plain part beside what is in wq
+    wq = {"k": None, "units": 0, "terms": 0}
+    wacc, wslot = [None] * 8, {}
+    acc_const = [None] * 8                         # the constant an accumulator was just loaded with (MOV acc, CONST), if it still holds it
 
     def reduce_acc(d):
         emit("    acc%d = fl_weak_reduce(acc%d);" % (d, d))
         bound[d] = 1
         stats["reduce"] += 1
+
+    def negate_acc(d):
+        """acc = -acc as C p - acc, limb-wise and borrow-free (fl252.h fl_sub_c): the template by the value's bound"""
+        if bound[d] > 4:
+            reduce_acc(d)
+        c, f, nb = {1: (2, 1, 2), 2: (8, 2, 4), 3: (16, 4, 8), 4: (16, 4, 8)}[bound[d]]
+        emit("    acc%d = fl_sub_c<%d, %d>(fl_zero(), acc%d);" % (d, c, f, d))
+        bound[d] = nb
 
     def flush_wide():
         """fold the pending dot product into its accumulator: one Montgomery reduction for all its terms"""
@@ -410,6 +588,9 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
     skip_add = set()
     for pc, (op, d, kind, w1) in enumerate(ins):
         v = "acc%d" % d
+        const_before = acc_const[d] if d < 8 else None
+        if op in (OP_MOV, OP_ADD, OP_SUB, OP_RSUB, OP_MUL, OP_INV) and d < 8:
+            acc_const[d] = w1 if (op == OP_MOV and kind == SRC_CONST) else None
         if pc:
             emit("    QG_FENCE")
         if sync_every and pc and pc % sync_every == 0:
@@ -446,10 +627,117 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
                 reduce_acc(src_acc)
             sb = 1
 
+        # ---- the constraint's own wide sum (plan_wide_constraints): what this instruction does to the PLAIN parts of its operands
+        sm = wacc[src_acc] if src_acc is not None else (wslot.get(w1) if op <= OP_MUL and kind == SRC_SLOT else None)
+        dm = wacc[d] if op != OP_MOV else None
+        op_e = op                                   # None: nothing to compute; "NEG" / "NEGMOV": the plain part changes sign
         if op == OP_MOV:
+            wacc[d] = dict(sm) if sm else None
+            if sm and not sm["lin"]:
+                op_e = None
+        elif op == OP_ST:
+            wslot[w1] = dict(dm) if dm else None
+            if dm and not dm["lin"]:
+                op_e = None
+        elif op in (OP_ADD, OP_SUB, OP_RSUB):
+            if sm or dm:
+                k = (dm or sm)["k"]
+                if sm and dm and sm["k"] != dm["k"]:
+                    raise WideViolation(k, "meets another constraint's sum at pc %d" % pc)
+                if wide_struct.get(pc) != k or src_acc == d:
+                    raise WideViolation(k, "used outside its sum at pc %d" % pc)
+                lin_d, lin_s = (dm["lin"] if dm else True), (sm["lin"] if sm else True)
+                wacc[d] = {"k": k, "lin": lin_d or lin_s}
+                if lin_d and lin_s:
+                    pass
+                elif lin_d:
+                    op_e = "NEG" if op == OP_RSUB else None
+                elif lin_s:
+                    op_e = "NEGMOV" if op == OP_SUB else OP_MOV
+                else:
+                    op_e = None
+        elif op == OP_MUL:
+            if pc in wide_mul:
+                op_e = "WMAD"
+                if sm or dm:
+                    raise WideViolation((sm or dm)["k"], "a factor at pc %d" % pc)
+            elif dm is not None and pc in wide_close and dm["k"] == pc:
+                g, nterms = wide_close[pc]
+                if wq["k"] != pc or wq["terms"] != nterms:
+                    raise WideViolation(pc, "closed with %d of %d products" % (wq["terms"], nterms))
+                if dm["lin"]:                                      # + L 2^256 (g L where the sum is -C)
+                    if g < 0:
+                        negate_acc(d)
+                    emit("    qg_wide_tail(wq, %s);" % v)
+                emit("    %s = qg_dot_reduce(wq);" % v)               # g C 2^-24, normalised
+                bound[d] = 1
+                for r_ in range(8):
+                    if wacc[r_] is not None and wacc[r_]["k"] == pc:
+                        wacc[r_] = None
+                for r_ in list(wslot):
+                    if wslot[r_] is not None and wslot[r_]["k"] == pc:
+                        wslot[r_] = None
+                wq.update(k=None, units=0, terms=0)
+                stats["wide_closes"] += 1
+                src = ("QG_CONST_R280_UP(%d)" if g > 0 else "QG_CONST_R280_UPN(%d)") % w1
+            elif sm or dm:
+                raise WideViolation((sm or dm)["k"], "multiplied at pc %d" % pc)
+        elif op in (OP_INV, OP_OUT) and wacc[d] is not None:
+            raise WideViolation(wacc[d]["k"], "used at pc %d" % pc)
+
+        if op_e is None:
+            pass
+        elif op_e == "NEG":
+            negate_acc(d)
+        elif op_e == "NEGMOV":
+            if sb > 1:
+                reduce_src()
+            emit("    %s = fl_sub_c<2, 1>(fl_zero(), %s);" % (v, src))
+            bound[d] = 2
+        elif op_e == "WMAD":
+            k, sg = wide_mul[pc]
+            if wq["k"] is None:
+                emit("    qg_dot_zero(wq);")
+                wq.update(k=k, units=0, terms=0)
+            elif wq["k"] != k:                                    # the one that stays open across other constraints gives way
+                raise WideViolation(max(k, wq["k"]), "the sums of constraints %d and %d overlap" % (wq["k"], k))
+            # a term of factors bounded a and b puts < 9 a b 2^56 into a column: the sum's terms share DOT_MAX_TERMS units (one kept
+            # for L 2^256; a negation doubles one factor's bound)
+            room = min(DOT_MAX_TERMS - 1 - wq["units"], max(2, (DOT_MAX_TERMS - 1) // wide_close[k][1]))     # (a fair share per term)
+            neg = 2 if sg < 0 else 1
+            if bound[d] * sb * neg > room:
+                if sb >= bound[d] and src_acc is not None:
+                    reduce_src()
+                else:
+                    reduce_acc(d)
+                if bound[d] * sb * neg > room and bound[d] > 1:
+                    reduce_acc(d)
+                if bound[d] * sb * neg > room and sb > 1 and src_acc is not None:
+                    reduce_src()
+                if bound[d] * sb * neg > room:
+                    raise WideViolation(k, "more than a reduction's worth of products")
+            a_expr, a_b, b_expr, b_b = v, bound[d], src, sb
+            if sg < 0:                                             # - A B = A (2p - B): a normalised factor is negated
+                if b_b == 1:
+                    b_expr, b_b = "fl_sub_c<2, 1>(fl_zero(), %s)" % b_expr, 2
+                else:
+                    if a_b > 1:
+                        reduce_acc(d)
+                    a_expr, a_b = "fl_sub_c<2, 1>(fl_zero(), %s)" % a_expr, 2
+                stats["wide_neg"] += 1
+            if wq["units"] + a_b * b_b > DOT_MAX_TERMS - 1:        # (one unit kept for the L 2^256 term)
+                raise WideViolation(k, "more than a reduction's worth of products")
+            emit("    qg_dot_mad(wq, %s, %s);" % (a_expr, b_expr))
+            wq["units"] += a_b * b_b
+            wq["terms"] += 1
+            wacc[d] = {"k": k, "lin": False}
+            bound[d] = 1
+            stats["wide_terms"] += 1
+            stats["mul"] += 1
+        elif op_e == OP_MOV:
             emit("    %s = %s;" % (v, src))
             bound[d] = sb
-        elif op == OP_ADD:
+        elif op_e == OP_ADD:
             if src_acc == d:                                   # v + v
                 if 2 * bound[d] > MAX_BOUND:
                     reduce_acc(d)
@@ -462,27 +750,39 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
                     reduce_src()
                 emit("    %s = fl_add(%s, %s);" % (v, v, src))
                 bound[d] += sb
-        elif op == OP_SUB:
+        elif op_e == OP_SUB:
             if src_acc == d:                                   # v - v
                 reduce_acc(d)
                 emit("    %s = fl_sub_c<2, 1>(%s, %s);" % (v, v, v))
                 bound[d] = 2
             else:
-                if sb > 1:
-                    reduce_src()
-                if bound[d] + 1 > MAX_BOUND:
-                    reduce_acc(d)
-                emit("    %s = fl_sub_c<2, 1>(%s, %s);" % (v, v, src))
-                bound[d] += 1
-        elif op == OP_RSUB:
+                # a subtrahend of bound 2 (a sum of two normalised values, a difference of them) is taken as it is by fl_sub_c<8, 2>
+                # (+ 8p: four units) where the result stays within MAX_BOUND - otherwise it is reduced first (54 instructions)
+                if sb == 2 and SUB_LAZY2 and min(bound[d], 1 if bound[d] + 4 > MAX_BOUND else bound[d]) + 4 <= MAX_BOUND:
+                    if bound[d] + 4 > MAX_BOUND:
+                        reduce_acc(d)
+                    emit("    %s = fl_sub_c<8, 2>(%s, %s);" % (v, v, src))
+                    bound[d] += 4
+                else:
+                    if sb > 1:
+                        reduce_src()
+                    if bound[d] + 1 > MAX_BOUND:
+                        reduce_acc(d)
+                    emit("    %s = fl_sub_c<2, 1>(%s, %s);" % (v, v, src))
+                    bound[d] += 1
+        elif op_e == OP_RSUB:
             assert src_acc != d
-            if bound[d] > 1:
-                reduce_acc(d)
-            if sb + 1 > MAX_BOUND:
-                reduce_src()
-            emit("    %s = fl_sub_c<2, 1>(%s, %s);" % (v, src, v))
-            bound[d] = sb + 1
-        elif op == OP_MUL:
+            if bound[d] == 2 and SUB_LAZY2 and sb + 4 <= MAX_BOUND:      # the flags: cell - 2 x next cell
+                emit("    %s = fl_sub_c<8, 2>(%s, %s);" % (v, src, v))
+                bound[d] = sb + 4
+            else:
+                if bound[d] > 1:
+                    reduce_acc(d)
+                if sb + 1 > MAX_BOUND:
+                    reduce_src()
+                emit("    %s = fl_sub_c<2, 1>(%s, %s);" % (v, src, v))
+                bound[d] = sb + 1
+        elif op_e == OP_MUL:
             tgt = fused.get(pc)
             if tgt is not None and (wide["acc"] in (None, tgt)):
                 # term of a dot product: acc_tgt += v * alpha^k with the reduction deferred.  A multiplicand of bound b (limbs
@@ -507,23 +807,35 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
                 emit("    %s = fl_mul_r280(%s, %s);" % (v, v, src))
                 stats["mulr"] += 1
                 bound[d] = 1
-            elif sb > 1 and bound[d] == 1:                      # the lazy side may be either factor
-                emit("    %s = fl_mul(%s, %s);" % (v, src, v))
+            elif CONST_FACTOR and const_before is not None and src_acc != d:      # MOV acc, c ; MUL acc, value: the constant is the R280 operand
+                emit("    %s = fl_mul_r280(%s, QG_CONST_R280(%d));" % (v, src, const_before))
+                stats["mulr"] += 1
                 bound[d] = 1
             else:
-                if sb > 1:
-                    reduce_src()
+                # both factors may be lazy: limbs < a 2^28 and < b 2^28 put < 9 a b 2^56 into a column (a b <= 16 fits 64 bits beside
+                # the reduction's own terms) and the product / 2^256 + p stays below 2p - a normalised result - for a b <= 8
+                # (round 4; before, one factor was always reduced first: 54 instructions for every product of two differences)
+                if LAZY_PRODUCT_MAX == 0:                       # (rounds 2-3: one factor always normalised)
+                    if sb > 1 and bound[d] > 1:
+                        reduce_src()
+                elif bound[d] * sb > LAZY_PRODUCT_MAX:
+                    if sb >= bound[d] and src_acc is not None:
+                        reduce_src()
+                    else:
+                        reduce_acc(d)
+                    if bound[d] * sb > LAZY_PRODUCT_MAX:
+                        reduce_acc(d) if bound[d] > 1 else reduce_src()
                 emit("    %s = fl_mul(%s, %s);" % (v, v, src))
                 bound[d] = 1
             stats["mul"] += 1
-        elif op == OP_INV:
+        elif op_e == OP_INV:
             if bound[d] > 1:
                 reduce_acc(d)
             else:
                 emit("    %s = fl_weak_reduce(%s);" % (v, v))
             emit("    %s = fn_inv(%s);" % (v, v))
             bound[d] = 1
-        elif op == OP_ST:
+        elif op_e == OP_ST:
             assert w1 < n_slots
             if bound[d] > 1:
                 reduce_acc(d)
@@ -541,26 +853,9 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
             else:
                 issue(q % D, True)
     assert wide["acc"] is None
-    body = "\n".join(out)
-    regs = "    Fp " + ", ".join("m%d" % k for k in range(D)) + ";\n"
-    prime = "".join("    m%d = %s;\n" % (j, mem_ops[j][1] % "i32") for j in range(D))
-    inc = '''// GENERATED by tools/gen_quotient.py - DO NOT EDIT.  The body of the `%(layout)s` constraint kernel: the program unrolled over the
-// operand macros of quotient_gen.h (operand loads issued %(depth)d operands ahead).  Included by the quotient_gen_%(layout)s*.hip
-// wrappers (device) and, with host definitions of the same macros, by tests/cpp/quotient_gen_host_test.cpp, which runs it on
-// the CPU against the oracle's constraint VM.
-    Fl acc0 = fl_zero(), acc1 = fl_zero(), acc2 = fl_zero(), acc3 = fl_zero()%(temp_acc)s;
-%(wide)s%(regs)s    uint32_t i32 = (uint32_t)(lane < N ? lane : N - 1);
-%(prime)s    QG_POINT_LOOP_BEGIN
-%(body)s
-    QG_POINT_LOOP_END
-''' % dict(layout=layout, regs=regs, prime=prime, body=body, depth=D, wide="    QgWide wd;\n" if stats["fused"] else "",
-           temp_acc=", acc4 = fl_zero()" if any(d == TEMP_ACC for _, d, _, _ in ins) else "")
-    name = inc_name
-    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", name), "w") as f:
-        f.write(inc)
-    print("%s: %d instructions, %d multiplications (%d by constants, %d fused into %d dot products), %d loads %d ahead, %d reductions -> %s"
-          % (layout, n_instr, stats["mul"], stats["mulr"], stats["fused"], stats["flushes"], stats["loads"], D, stats["reduce"], name))
-    return dict(stats, inc=name, depth=D)
+    if wq["k"] is not None:
+        raise WideViolation(wq["k"], "never closed")
+    return out, stats
 
 
 def write_part(layout, suffix, part, n_parts, base, body, n_instr, n_consts, n_slots, slots_in_regs, wgs, fence, threads, sync=0):
