@@ -478,8 +478,24 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
                     sys.stderr.flush()
                     os._exit(3)
             threading.Thread(target=watchdog, daemon=True).start()
-            group = hostlib.RcclGroup(ctx, box[0], rank, world)
+            # RCCL between more than one GPU has never run where this was developed (one GPU per box): if the communicator cannot be
+            # made on ANY rank (library not found, ncclCommInitRank refused), every rank falls back to the Python driver over
+            # torch.distributed - same proof bytes, same kernels - and the JSON line says so
+            group, group_err = None, None
+            try:
+                group = hostlib.RcclGroup(ctx, box[0], rank, world)
+            except Exception as e:                  # noqa: BLE001 - reported below, by every rank the same way
+                group_err = "%s: %s" % (type(e).__name__, e)
             done.set()
+            bad = torch.tensor([0 if group is not None else 1], dtype=torch.int32, device=device)
+            dist.all_reduce(bad)
+            if int(bad.item()):
+                if rank == 0 or group_err:
+                    sys.stderr.write("bench.py: rank %d: the C++ host's RCCL group did not come up on %d rank(s) (%s): falling back to "
+                                     "--sharded-host python\n" % (rank, int(bad.item()), group_err))
+                args.sharded_host, args.sharded_host_fallback = "python", group_err or "another rank failed"
+                group = None
+    if args.sharded_host == "cpp":
         tree_kind, n_friendly = (be.TREE_FRIENDLY, 22) if layout == "recursive" else (be.TREE_KECCAK_M20, 0)
         wire_proof = [None]
 
@@ -556,6 +572,7 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
                                if args.sharded_host == "cpp" else
                                "Python host (sandstorm_amd/sharded_prover.py) over the C ABI + torch.distributed (nccl = RCCL)",
                        "fri_layers": len(proof.fri_layers) if proof is not None else None,
+                       "sharded_host_fallback": getattr(args, "sharded_host_fallback", None),
                        "note": "python bench.py --gpus N --mode replicas runs N independent proofs instead (weak scaling)"},
         })
     dist.destroy_process_group()
