@@ -108,3 +108,47 @@ def test_generated_kernel_body_on_the_host(oracle, layout, log_n, tmp_path):
     idx = (2 * B + np.arange(B + halo)) % N
     got = run_host(exe, tmp, [c[idx] for c in lde], tab, desc, consts, B, 2 * B, 0xffffffff, 1, 64, g, w)
     assert np.array_equal(got, want[2 * B:3 * B])
+
+
+def _extreme(rng, count):
+    """canonical 256-bit images at the edges of the lazy limb forms: 0, 1, p - 1, p - 2, 2^251 - 1 (every limb below the top
+    one full), single full 28-bit limbs, and a few random values in between (4 x u64 little endian, like _rand)"""
+    pool = [0, 1, 2, P - 1, P - 2, (1 << 251) - 1, (1 << 251), (1 << 251) + (17 << 192), (P - 1) // 2, (1 << 224) - 1,
+            ((1 << 28) - 1) << 28, ((1 << 28) - 1) << 168, ((1 << 28) - 1) << 196, sum(((1 << 28) - 1) << (56 * k) for k in range(4))]
+    pool += [int(rng.integers(0, 1 << 62)) * int(rng.integers(0, 1 << 62)) * int(rng.integers(0, 1 << 62)) % P for _ in range(6)]
+    table = np.array([[(v >> (64 * k)) & ((1 << 64) - 1) for k in range(4)] for v in pool], dtype=np.uint64)
+    return table[rng.integers(0, len(pool), size=count)]
+
+
+@pytest.mark.parametrize("layout,log_n", [("recursive", 14), ("starknet", 16)])
+def test_generated_kernel_body_on_values_at_the_limb_forms_edges(oracle, layout, log_n, tmp_path):
+    """the generator places lazy-form operations by BOUNDS (sums of two values subtracted unreduced, products of lazy factors, a
+    constraint's own wide sum with its L 2^256 term, negated factors): random columns hardly ever reach those bounds - columns,
+    tables and constants drawn from the values at the limb forms' edges do"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_quotient
+    tmp = str(tmp_path)
+    lay, code, consts, n_slots, specs = program(oracle, layout, log_n)
+    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s.hip" % layout)) as f:
+        assert ("0x%016x" % gen_quotient.code_hash(code)) in f.read(), "the committed kernel was generated from another program"
+    exe = build(layout, tmp)
+    n, N = 1 << log_n, 2 << log_n
+    tables = lay.Tables(n)
+    rng = np.random.default_rng(29)
+    tabs, desc, off = [], [], 0
+    for spec in specs:
+        t = _extreme(rng, tables.length(spec))
+        desc += [off, len(t).bit_length() - 1]
+        off += len(t)
+        tabs.append(t)
+    tab = np.concatenate(tabs)
+    lde = [_extreme(rng, N) for _ in range(10)]
+    consts = np.array(consts, dtype=np.uint64).reshape(-1, 4).copy()
+    edge = _extreme(rng, len(consts))
+    pick = rng.random(len(consts)) < 0.5                      # half of the constants at the edges too
+    consts[pick] = edge[pick]
+    g = oracle.to_mont([3])[0]
+    w = oracle.to_mont([pow(3, (P - 1) // N, P)])[0]
+    want = oracle.eval_program(code, consts, tab, desc, n_slots, lde, log_n, 1, g)
+    got = run_host(exe, tmp, lde, tab, desc, consts, N, 0, N - 1, 1, 96, g, w)
+    assert np.array_equal(got, want)
