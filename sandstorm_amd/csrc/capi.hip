@@ -1932,7 +1932,7 @@ ss_status gl_get_plan(ss_ctx *ctx, uint32_t log_n, bool inverse, uint64_t offset
 
 std::vector<Pass> gl_plan_passes(uint32_t log_n) {          // csrc/gl_ntt.h: the plan the host test of the pass code runs too
     ss::GlPass passes[8];
-    const int np = ss::gl_plan_passes_into(log_n, gl_log_tile_max(), passes);
+    const int np = ss::gl_plan_passes_into(log_n, gl_log_tile_max(), passes, gl_log_min_run());
     std::vector<Pass> v;
     for (int i = 0; i < np; ++i) v.push_back({passes[i].s0, passes[i].r});
     return v;

@@ -12,13 +12,13 @@ namespace ss {
 // ---- the plan: pass i runs global stages [s0, s0 + r).  The first pass is a contiguous tile of up to 2^log_tile_max elements;
 // the others are strided tiles of 2^r rows x >= 32 adjacent elements (256-byte global runs), the remaining stages split evenly.
 struct GlPass { uint32_t s0, r; };
-static inline int gl_plan_passes_into(uint32_t log_n, uint32_t log_tile_max, GlPass out[8]) {
+static inline int gl_plan_passes_into(uint32_t log_n, uint32_t log_tile_max, GlPass out[8], uint32_t log_min_run = 5) {
     int np = 0;
     const uint32_t r0 = log_n < log_tile_max ? log_n : log_tile_max;
     out[np++] = GlPass{0, r0};
     uint32_t rem = log_n - r0;
     if (rem) {
-        const uint32_t rmax = log_tile_max - 5;
+        const uint32_t rmax = log_tile_max - log_min_run;      // rows of a strided tile: 2^log_min_run adjacent elements per global run
         const uint32_t k = (rem + rmax - 1) / rmax;
         uint32_t s0 = r0;
         for (uint32_t i = 0; i < k; ++i) {

@@ -33,7 +33,7 @@ uint64_t gl_inv_host(uint64_t a) { return gl_pow_host(a, GL_P - 2); }
 struct GlCols { const uint64_t *src[MAX_COLS]; uint64_t *dst[MAX_COLS]; };
 
 template <bool DIF, bool CONTIG>
-__global__ __launch_bounds__(256) void gl_ntt_pass_kernel(GlCols cols, const uint64_t *__restrict__ tw, GlPassParams p) {
+__global__ __launch_bounds__(512) void gl_ntt_pass_kernel(GlCols cols, const uint64_t *__restrict__ tw, GlPassParams p) {
     extern __shared__ uint64_t gl_tile[];
     const uint32_t tile = blockIdx.x;
     const void *src_v = cols.src[0];
@@ -130,10 +130,20 @@ __global__ __launch_bounds__(256) void gl3_fri_fold_kernel(const uint64_t *__res
 
 // ------------------------------------------------------------------------------------------------ host launch
 static constexpr uint32_t GL_LOG_TILE_MAX = 13;             // 8192 elements = 64 KiB of LDS: two workgroups per CU
-uint32_t gl_log_tile_max() { return GL_LOG_TILE_MAX; }
+// A/B knobs (read once): SS_GL_LOG_TILE = 14 (128 KiB: one workgroup per CU) with SS_GL_MIN_RUN_LOG = 3 (64-byte runs in the strided
+// pass) makes a 2^24 / 2^25-point transform TWO passes instead of three; SS_GL_THREADS = lanes per workgroup
+static uint32_t gl_env_u32(const char *name, uint32_t dflt, uint32_t lo, uint32_t hi) {
+    const char *e = getenv(name);
+    if (!e) return dflt;
+    const unsigned long v = strtoul(e, nullptr, 10);
+    return v < lo ? lo : v > hi ? hi : (uint32_t)v;
+}
+uint32_t gl_log_tile_max() { static const uint32_t v = gl_env_u32("SS_GL_LOG_TILE", GL_LOG_TILE_MAX, 10, 14); return v; }
+uint32_t gl_log_min_run() { static const uint32_t v = gl_env_u32("SS_GL_MIN_RUN_LOG", 5, 2, 6); return v; }
+static uint32_t gl_threads() { static const uint32_t v = gl_env_u32("SS_GL_THREADS", 256, 64, 512); return v; }
 
 hipError_t gl_set_func_attributes() {
-    const int bytes = 8 << GL_LOG_TILE_MAX;
+    const int bytes = 8 << 14;
     const void *kernels[] = {reinterpret_cast<const void *>(&gl_ntt_pass_kernel<true, true>), reinterpret_cast<const void *>(&gl_ntt_pass_kernel<true, false>),
                              reinterpret_cast<const void *>(&gl_ntt_pass_kernel<false, true>), reinterpret_cast<const void *>(&gl_ntt_pass_kernel<false, false>)};
     for (const void *k : kernels) {
@@ -150,7 +160,7 @@ hipError_t launch_gl_ntt_pass(hipStream_t st, bool dif, const void *const *src, 
     for (int c = 0; c < MAX_COLS; ++c) { cols.src[c] = c < (int)ncols ? (const uint64_t *)src[c] : nullptr; cols.dst[c] = c < (int)ncols ? (uint64_t *)dst[c] : nullptr; }
     GlPassParams p;
     p.log_n = log_n; p.s0 = s0; p.r = r; p.log_tile = log_tile; p.u_first = u_first; p.log_expand = log_expand; p.contig = (s0 == 0); p.scale = scale;
-    dim3 grid(1u << (log_n - log_tile), ncols), block(256);
+    dim3 grid(1u << (log_n - log_tile), ncols), block(gl_threads());
     const size_t lds = (size_t)8 << log_tile;
     if (p.contig) {
         if (dif) hipLaunchKernelGGL((gl_ntt_pass_kernel<true, true>), grid, block, lds, st, cols, tw, p);

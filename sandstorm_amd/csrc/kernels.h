@@ -128,6 +128,7 @@ uint64_t gl_pow_host(uint64_t a, uint64_t e);
 uint64_t gl_root_of_unity_host(uint32_t log_n);
 uint64_t gl_inv_host(uint64_t a);
 uint32_t gl_log_tile_max();
+uint32_t gl_log_min_run();
 hipError_t gl_set_func_attributes();
 hipError_t launch_gl_ntt_pass(hipStream_t st, bool dif, const void *const *src, void *const *dst, uint32_t ncols, const uint64_t *tw,
                               uint32_t log_n, uint32_t s0, uint32_t r, uint32_t log_tile, uint32_t u_first, uint32_t log_expand,
