@@ -333,7 +333,7 @@ def generate(layout, all_variants=False):
         names = []
         for j, (part, cfg) in enumerate(zip(parts, cfgs)):
             depth, slots_in_regs, wgs, fence, fuse, threads = cfg[:6]
-            sync = cfg[6] if len(cfg) > 6 else 0
+            sync = int(os.environ.get("QG_SYNC", cfg[6] if len(cfg) > 6 else 0))
             part, part_slots = compact_slots(part)
             if remat and part_slots > REMAT_ABOVE_SLOTS:     # the decoded flags: recomputed at their uses instead of parked (17 -> 6 slots)
                 part, part_slots = compact_slots(rematerialize_cheap_slots(part))
@@ -341,14 +341,15 @@ def generate(layout, all_variants=False):
                 lds = part_slots * 2 * threads * 16 + n_consts * 36 * 4
                 assert lds * wgs <= LDS_BYTES_PER_CU, "%s%s part %d: %d slots + constants = %d B of LDS x %d workgroups per CU" % (layout, suffix, j, part_slots, lds, wgs)
             base = "quotient_gen_%s%s_p%d" % (layout, suffix, j)
-            wide_here, depth_here, lazy_sub, const_factor = PART_TUNING.get(layout, {}).get((suffix, j), (False, depth, False, False))
+            wide_here, depth_here, lazy_sub, const_factor, min_terms = PART_TUNING.get(layout, {}).get((suffix, j), (False, depth, False, False, 1))
+            min_terms = int(os.environ.get("QG_WIDE_MIN_TERMS", min_terms))
             if "QG_WIDE_PARTS" in os.environ:                 # A/B builds (tools/qg_wide_ab.sh): the same choice for every part
                 wide_here = ("%s:%d" % (layout, j)) in os.environ["QG_WIDE_PARTS"].split(",") or os.environ["QG_WIDE_PARTS"] == "all"
             depth_here = int(os.environ.get("QG_DEPTH", depth_here))
             lazy_sub = os.environ["QG_SUB_LAZY2"] != "0" if "QG_SUB_LAZY2" in os.environ else lazy_sub
             const_factor = os.environ["QG_CONST_FACTOR"] != "0" if "QG_CONST_FACTOR" in os.environ else const_factor
             body = generate_body(layout, part, n_consts, part_slots, n_tables, ncols, depth_here, base + ".inc", fuse,
-                                 "QG_OUT" if j == 0 else "QG_OUT_ACC", sync, wide_here, lazy_sub, const_factor)
+                                 "QG_OUT" if j == 0 else "QG_OUT_ACC", sync, wide_here, lazy_sub, const_factor, min_terms)
             write_part(layout, suffix, j, len(parts), base, body, len(part), n_consts, part_slots, slots_in_regs, wgs, fence, threads, sync)
             names.append(base + ".hip")
         write_kernel_table(layout, suffix, k, code, n_consts, n_tables, ncols, len(parts))
@@ -363,12 +364,13 @@ WIDE_MAX_SPAN = int(os.environ.get("QG_WIDE_SPAN", "1000"))            # program
 # the parts (variant suffix, part number) whose constraints' top-level products accumulate in a second wide accumulator (see
 # plan_wide_constraints); QG_WIDE_PARTS="starknet:1,starknet:3,..." overrides for A/B builds
 # Chosen per part on the MI355X (profiles/r04_quotient_algebra.txt: every part is its own kernel, 16 builds timed part by part):
-# (variant suffix, part) -> (wide sums, operand prefetch depth, lazy subtrahends).  The instruction counts fall everywhere; the time
+# (variant suffix, part) -> (wide sums, operand prefetch depth, lazy subtrahends, constants as factors, products a constraint needs
+# to get a wide sum of its own).  The instruction counts fall everywhere; the time
 # follows only where the register allocator keeps its spills (a second 38-register accumulator beside the dot product's) - part 4
 # of starknet is faster as it was, with a shallower prefetch.
-PART_TUNING = {"starknet": {("", 0): (True, 3, True, True), ("", 1): (True, 2, True, True), ("", 2): (True, 3, False, False), ("", 3): (True, 3, True, True),
-                            ("", 4): (False, 2, False, False), ("", 5): (True, 3, True, True)},
-               "recursive": {("", 0): (True, 2, True, True)}}
+PART_TUNING = {"starknet": {("", 0): (True, 3, True, True, 1), ("", 1): (True, 2, True, True, 1), ("", 2): (True, 3, False, False, 1),
+                            ("", 3): (True, 3, True, True, 2), ("", 4): (True, 2, False, False, 2), ("", 5): (True, 3, True, True, 1)},
+               "recursive": {("", 0): (True, 2, True, True, 1)}}
 
 
 class WideViolation(Exception):
@@ -378,7 +380,7 @@ class WideViolation(Exception):
         self.k = k
 
 
-def plan_wide_constraints(ins, fused, banned, const_factor=True):
+def plan_wide_constraints(ins, fused, banned, const_factor=True, min_terms=1):
     """Round 4.  A constraint C = sum_i s_i A_i B_i + L (A_i, B_i, L: sums of cells, constants and earlier values;
     most of the program's products sit at this top level) paid a whole Montgomery product per A_i B_i - 81 multiply-adds plus a
     142-instruction reduction - and, where a product waited for its siblings in a scratch slot, a weak reduction, a store and a
@@ -451,7 +453,7 @@ def plan_wide_constraints(ins, fused, banned, const_factor=True):
         # (a constant that was MOVed into the accumulator and multiplied by a cell is a factor like any other: its R256 limbs are the
         # value c 2^256, so c x cell comes out at the same 2^-24 as the products of two cells - sums of 2^(16 j) x cell_j, fourteen terms
         # long in the range-check and bit-unpacking constraints, become fourteen 81-multiply-add terms and ONE reduction)
-        if not prods:
+        if len(prods) < min_terms:
             continue
         # register pressure: the wide sum (38 registers) lives from the constraint's first product to the alpha multiplication,
         # beside the alpha dot product's own 38; a plain product in between adds its 36 columns on top (scratch spills: the
@@ -472,7 +474,7 @@ def plan_wide_constraints(ins, fused, banned, const_factor=True):
 
 
 def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPTH, inc_name, FUSE_ALPHA_DOT_PRODUCTS=False, out_macro="QG_OUT",
-                  sync_every=0, wide_products=False, lazy_sub=False, const_factor=False):
+                  sync_every=0, wide_products=False, lazy_sub=False, const_factor=False, min_terms=1):
     """the straight-line body of one (part) program -> csrc/<inc_name>"""
     n_instr = len(ins)
     # ---- memory operands in program order: loaded PREFETCH_DEPTH operands ahead into a rotating set of registers
@@ -506,7 +508,7 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
     while True:                                     # constraints whose half-summed value is used in a way the emission cannot express
         try:                                        # go back to plain products, one at a time (plan_wide_constraints)
             out, stats = _emit_body(ins, n_consts, n_slots, mem_ops, mem_index, D, fused, out_macro, sync_every, lazy_sub, const_factor,
-                                    plan_wide_constraints(ins, fused, banned, const_factor) if wide_products and FUSE_ALPHA_DOT_PRODUCTS else ({}, {}, {}))
+                                    plan_wide_constraints(ins, fused, banned, const_factor, min_terms) if wide_products and FUSE_ALPHA_DOT_PRODUCTS else ({}, {}, {}))
             break
         except WideViolation as e:
             banned.add(e.k)
