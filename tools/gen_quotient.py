@@ -360,6 +360,7 @@ def generate(layout, all_variants=False):
 
 
 WIDE_MAX_OTHER_PRODUCTS = int(os.environ.get("QG_WIDE_OTHER", "0"))     # other multiplications allowed while a constraint's wide sum is open
+WIDE_ANY_CONST_MUL = os.environ.get("QG_WIDE_ANY_CONST", "1") != "0"   # constraints whose alpha power is not a fused dot term close at their constant too
 WIDE_MAX_SPAN = int(os.environ.get("QG_WIDE_SPAN", "1000"))            # program instructions from its first product to its alpha multiplication
 # the parts (variant suffix, part number) whose constraints' top-level products accumulate in a second wide accumulator (see
 # plan_wide_constraints); QG_WIDE_PARTS="starknet:1,starknet:3,..." overrides for A/B builds
@@ -414,7 +415,7 @@ def plan_wide_constraints(ins, fused, banned, const_factor=True, min_terms=1):
             acc[d] = new("SUB", src, acc[d])
             made_at[acc[d]] = pc
         elif op == OP_MUL:
-            if pc in fused:
+            if pc in fused or (WIDE_ANY_CONST_MUL and kind == SRC_CONST):      # any scaling by a constant can take the 2^24 back
                 root_of[pc] = acc[d]
             acc[d] = new("MUL", acc[d], src)
             made_at[acc[d]] = pc
@@ -449,7 +450,7 @@ def plan_wide_constraints(ins, fused, banned, const_factor=True, min_terms=1):
                 terms.append((sgn, v))
         prods = [(sgn, v) for sgn, v in terms
                  if nodes[v][0] == "MUL" and uses.get(v, 0) == 1 and nodes[v][1] != nodes[v][2] and v not in taken
-                 and nodes[nodes[v][2]][0] != "CONST" and (const_factor or nodes[nodes[v][1]][0] != "CONST") and made_at[v] not in fused]
+                 and nodes[nodes[v][2]][0] != "CONST" and (const_factor or nodes[nodes[v][1]][0] != "CONST") and made_at[v] not in root_of]
         # (a constant that was MOVed into the accumulator and multiplied by a cell is a factor like any other: its R256 limbs are the
         # value c 2^256, so c x cell comes out at the same 2^-24 as the products of two cells - sums of 2^(16 j) x cell_j, fourteen terms
         # long in the range-check and bit-unpacking constraints, become fourteen 81-multiply-add terms and ONE reduction)
