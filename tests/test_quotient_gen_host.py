@@ -152,3 +152,18 @@ def test_generated_kernel_body_on_values_at_the_limb_forms_edges(oracle, layout,
     want = oracle.eval_program(code, consts, tab, desc, n_slots, lde, log_n, 1, g)
     got = run_host(exe, tmp, lde, tab, desc, consts, N, 0, N - 1, 1, 96, g, w)
     assert np.array_equal(got, want)
+
+
+def test_committed_kernels_are_what_the_generator_writes(tmp_path):
+    """the library recognises a compiled program by the hash of its code words only: a change to tools/gen_quotient.py (or to its
+    per-part tuning table) that was not followed by a regeneration would ship stale kernels silently"""
+    import filecmp
+    import glob
+    out = str(tmp_path)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("QG_")}
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_quotient.py")], env=dict(env, QG_OUT_DIR=out), stdout=subprocess.DEVNULL)
+    made = sorted(os.path.basename(f) for f in glob.glob(os.path.join(out, "quotient_gen_*")))
+    assert len(made) >= 2 * 7 + 2 + 2, made                    # parts (.hip + .inc), kernel tables, source lists
+    csrc = os.path.join(ROOT, "sandstorm_amd", "csrc")
+    stale = [f for f in made if not filecmp.cmp(os.path.join(out, f), os.path.join(csrc, f), shallow=False)]
+    assert not stale, "regenerate with `python tools/gen_quotient.py`: %s" % stale

@@ -29,6 +29,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+OUT_DIR = os.environ.get("QG_OUT_DIR", os.path.join(ROOT, "sandstorm_amd", "csrc"))     # QG_OUT_DIR: write elsewhere (tests/test_quotient_gen_host.py
+                                                                                          # checks that the committed sources are what this tool writes)
 OP_MOV, OP_ADD, OP_SUB, OP_RSUB, OP_MUL, OP_INV, OP_ST, OP_OUT = range(8)
 SRC_ACC, SRC_SLOT, SRC_CONST, SRC_TRACE, SRC_TABLE, SRC_X = range(6)
 MAX_BOUND = 8           # csrc/quotient.hip VM_MAX_BOUND: value < 2 b p, limbs < b 2^28
@@ -523,7 +525,7 @@ def generate_body(layout, ins, n_consts, n_slots, n_tables, ncols, PREFETCH_DEPT
                                wide=("    QgWide wd;\n" if stats["fused"] else "") + ("    QgWide wq;\n" if stats["wide_terms"] else ""),
                                temp_acc=", acc4 = fl_zero()" if any(d == TEMP_ACC for _, d, _, _ in ins) else "")
     name = inc_name
-    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", name), "w") as f:
+    with open(os.path.join(OUT_DIR, name), "w") as f:
         f.write(inc)
     print("%s: %d instructions, %d multiplications (%d by constants, %d fused into %d dot products, %d as terms of %d constraints' own wide sums - %d "
           "negated, %d constraints kept plain), %d loads %d ahead, %d reductions -> %s"
@@ -905,7 +907,7 @@ QGenPart quotient_gen_%(layout)s%(suffix)s_p%(part)d() { return QGenPart{%(wgs)d
                   + ("#define QG_THREADS_PER_WG %d\n" % threads if threads != 256 else "") + ("#define QG_SYNC_WAVES\n" if sync else ""),
            fence=(", a scheduling fence after every program instruction" if fence else "")
                  + (", a workgroup barrier every %d program instructions (the waves share their instruction fetches)" % sync if sync else ""), **body)
-    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", base + ".hip"), "w") as f:
+    with open(os.path.join(OUT_DIR, base + ".hip"), "w") as f:
         f.write(src)
 
 
@@ -931,14 +933,14 @@ const QGenKernel &quotient_gen_%(layout)s%(suffix)s() {
 }  // namespace ss
 """ % dict(layout=layout, suffix=suffix, variant=variant, n_parts=n_parts, hash=code_hash(code), n_instr=len(code) // 2, n_consts=n_consts,
            n_tables=n_tables, ncols=ncols, decl=decl, parts=parts)
-    with open(os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s%s.hip" % (layout, suffix)), "w") as f:
+    with open(os.path.join(OUT_DIR, "quotient_gen_%s%s.hip" % (layout, suffix)), "w") as f:
         f.write(src)
 
 
 def write_source_lists(written, all_variants):
     """csrc/quotient_gen_sources.mk (what the Makefile and tests/hipemu/build.sh compile) and csrc/quotient_gen_variants.inc (the
     X-macro list capi.hip's lookup table is made of)"""
-    csrc = os.path.join(ROOT, "sandstorm_amd", "csrc")
+    csrc = OUT_DIR
     default = [n for layout in written for k, _, names in written[layout] if k == 0 for n in names]
     ab = [n for layout in written for k, _, names in written[layout] if k != 0 for n in names]
     with open(os.path.join(csrc, "quotient_gen_sources.mk"), "w") as f:
