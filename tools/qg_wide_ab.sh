@@ -15,7 +15,7 @@ if [ "$1" = build ]; then
         -c sandstorm_amd/csrc/$f.hip -o $V/$name/$f.o ) & done; wait
     objs=$(ls sandstorm_amd/_build/*.o | grep -v 'quotient_gen_.*_p[0-9]*\.o$')
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/$name/libsandstorm_hip.so $V/$name/*.o $objs -Wl,-rpath,/opt/rocm/lib
-    [ -f /tmp/cnt_obj.py ] && python /tmp/cnt_obj.py $V/$name/quotient_gen_*.o | sort
+    python tools/count_insts.py $V/$name/quotient_gen_*.o | sort
     rm $V/$name/*.o
     echo "built $name ($@)"
     exit 0
