@@ -459,6 +459,7 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     def barrier():
         dist.barrier()
         torch.cuda.synchronize()
+    comm_check = None
     if args.sharded_host == "cpp":
         # the C++ host's sharded prover (sandstorm_amd/host/sharded.cpp) over RCCL through the C ABI (ss_comm_*): rank 0 makes the
         # communicator's id, torch.distributed only hands it out
@@ -474,7 +475,7 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
 
             def watchdog():
                 if not done.wait(float(os.environ.get("SS_BENCH_RCCL_TIMEOUT_S", "300"))):
-                    sys.stderr.write("bench.py: rank %d: the RCCL communicator of the C++ host did not come up (ss_comm_create)\n" % rank)
+                    sys.stderr.write("bench.py: rank %d: the RCCL communicator of the C++ host did not come up or hung in its self check (ss_comm_*)\n" % rank)
                     sys.stderr.flush()
                     os._exit(3)
             threading.Thread(target=watchdog, daemon=True).start()
@@ -486,14 +487,32 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
                 group = hostlib.RcclGroup(ctx, box[0], rank, world)
             except Exception as e:                  # noqa: BLE001 - reported below, by every rank the same way
                 group_err = "%s: %s" % (type(e).__name__, e)
-            done.set()
             bad = torch.tensor([0 if group is not None else 1], dtype=torch.int32, device=device)
             dist.all_reduce(bad)
+            if not int(bad.item()):
+                # the group's first exchanges are a SELF CHECK, not a proof's (host/sharded.cpp transport_self_check): two messages of
+                # different sizes between every ordered pair of ranks whose bytes name (source, destination, message), an all-gather, a
+                # variable-length all-gather - every rank learns every rank's verdict -, then one timed all-to-all of 64 MiB per pair
+                try:
+                    comm_check = {"ok": True, "exchange_gbps": hostlib.group_self_check(ctx, rank, world, group, 64 << 20)}
+                except Exception as e:              # noqa: BLE001
+                    group_err = "%s: %s" % (type(e).__name__, e)
+                    comm_check = {"ok": False, "error": group_err}
+                bad = torch.tensor([0 if comm_check["ok"] else 1], dtype=torch.int32, device=device)
+                dist.all_reduce(bad)
+                rates = [None] * world
+                dist.all_gather_object(rates, comm_check.get("exchange_gbps"))
+                comm_check["exchange_gbps_by_rank"] = rates
+                comm_check["note"] = ("ss_comm_exchange + ss_comm_all_gather over the run's RCCL group before the warm-up: contents checked on every "
+                                      "rank; exchange_gbps = a rank's send + receive rate in one all-to-all of 64 MiB per ordered pair")
+            done.set()
             if int(bad.item()):
                 if rank == 0 or group_err:
-                    sys.stderr.write("bench.py: rank %d: the C++ host's RCCL group did not come up on %d rank(s) (%s): falling back to "
-                                     "--sharded-host python\n" % (rank, int(bad.item()), group_err))
+                    sys.stderr.write("bench.py: rank %d: the C++ host's RCCL group did not come up or failed its self check on %d rank(s) (%s): "
+                                     "falling back to --sharded-host python\n" % (rank, int(bad.item()), group_err))
                 args.sharded_host, args.sharded_host_fallback = "python", group_err or "another rank failed"
+                if group is not None:
+                    group.close()
                 group = None
     if args.sharded_host == "cpp":
         tree_kind, n_friendly = (be.TREE_FRIENDLY, 22) if layout == "recursive" else (be.TREE_KECCAK_M20, 0)
@@ -573,6 +592,7 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
                                "Python host (sandstorm_amd/sharded_prover.py) over the C ABI + torch.distributed (nccl = RCCL)",
                        "fri_layers": len(proof.fri_layers) if proof is not None else None,
                        "sharded_host_fallback": getattr(args, "sharded_host_fallback", None),
+                       "comm_self_check": comm_check,
                        "note": "python bench.py --gpus N --mode replicas runs N independent proofs instead (weak scaling)"},
         })
     dist.destroy_process_group()

@@ -720,8 +720,13 @@ ss_status ss_ntt_shard_fp252(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncol
     if (part != SS_NTT_PART_LOCAL && part != SS_NTT_PART_CROSS) return fail(SS_ERR_INVALID, "bad part");
     if (!valid_log(log_n) || log_ranks == 0 || 2 * log_ranks > log_n || log_ranks > 7) return fail(SS_ERR_INVALID, "a transform of 2^%u points does not split over 2^%u ranks (needs n >= R^2)", log_n, log_ranks);
     if (rank >> log_ranks) return fail(SS_ERR_INVALID, "rank %u of %u", rank, 1u << log_ranks);
-    if (ncols == 0 || ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_INVALID, "1..%d columns per call", MAX_COLS);
+    if (ncols == 0) return fail(SS_ERR_INVALID, "no columns");
     if (has_null((const void *const *)d_cols, ncols) || (d_out && has_null((const void *const *)d_out, ncols))) return fail(SS_ERR_INVALID, "NULL column");
+    for (uint32_t c0 = 0; ncols > (uint32_t)MAX_COLS && c0 < ncols; c0 += MAX_COLS) {        // any number of columns, MAX_COLS per launch (as ss_ntt_fp252)
+        const uint32_t k = ncols - c0 < (uint32_t)MAX_COLS ? ncols - c0 : (uint32_t)MAX_COLS;
+        const ss_status st = ss_ntt_shard_fp252(ctx, d_cols + c0, k, log_n, log_ranks, rank, direction, offset, part, log_expand, d_out ? d_out + c0 : nullptr);
+        if (st != SS_OK || c0 + k == ncols) return st;
+    }
     const bool inverse = direction == SS_NTT_INVERSE, local = part == SS_NTT_PART_LOCAL;
     if (log_expand && (inverse || !local)) return fail(SS_ERR_INVALID, "log_expand belongs to the local part of a forward transform");
     if (log_expand >= log_n - log_ranks && log_expand) return fail(SS_ERR_INVALID, "log_expand %u too large", log_expand);

@@ -84,6 +84,13 @@ static constexpr int LOG_TILE_MAX = SS_NTT_LOG_TILE;          // 2048 elements
 #ifndef SS_NTT_OCC_DIF
 #define SS_NTT_OCC_DIF (SS_NTT_THREADS_DIF / 128)
 #endif
+// The wave-private phases (NTT_WAVE_SYNC; chunk ownership = threadIdx.x >> 6, log_waves = log2(blockDim.x >> 6)) are written for
+// 64-lane wavefronts and workgroups that are a power-of-two number of them: anything else would corrupt tiles silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIPEMU) && !defined(__GFX9__)
+#error "ntt.hip: the wave-private phases assume the 64-lane wavefronts of gfx9 (gfx950)"
+#endif
+static_assert(SS_NTT_THREADS % 64 == 0 && (SS_NTT_THREADS & (SS_NTT_THREADS - 1)) == 0, "SS_NTT_THREADS: a power-of-two number of 64-lane waves");
+static_assert(SS_NTT_THREADS_DIF % 64 == 0 && (SS_NTT_THREADS_DIF & (SS_NTT_THREADS_DIF - 1)) == 0, "SS_NTT_THREADS_DIF: a power-of-two number of 64-lane waves");
 
 // Conflict-free LDS indexing by XOR swizzle (no padding).  A register group at shift sh makes the low
 // lane bits walk element-index bits {sh+G.. } and/or {0..sh-1}; the bank index is a linear map of the

@@ -25,6 +25,11 @@ typedef struct ssh_air ssh_air;
 typedef int (*ssh_extension_cb)(void *user, const uint64_t *challenges, uint32_t nchallenges, uint64_t **d_cols_out);
 
 const char *ssh_last_error(void) { return g_err.c_str(); }
+// bumped whenever an entry point of this file changes its signature or meaning (hostlib.py checks it at load; ss_abi_version is
+// the device library's).  2: ssh_prove_sharded takes transport handles (ssh_rccl_group_create / ssh_callback_group_create)
+// instead of the raw RCCL id; ssh_air_create left for the callers' own AIR objects.
+#define SSH_HOST_ABI_VERSION 2
+uint32_t ssh_abi_version(void) { return SSH_HOST_ABI_VERSION; }
 
 // an `ssh_air` handle is an `Air *` (prover.hpp): the layouts' AIRs come from ssh_air_create_recursive / _starknet below; a caller
 // with an AIR of its own (the tests' mini AIR: tests/cpp/mini_air_lib.cpp) hands in its own object
@@ -117,6 +122,39 @@ ssh_rccl_group *ssh_rccl_group_create(ss_ctx *ctx, const uint8_t rccl_id[128], u
     } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
 void ssh_rccl_group_destroy(ssh_rccl_group *g) { delete reinterpret_cast<Transport *>(g); }
+// The caller's own collectives instead of RCCL (sharded.hpp TransportCallbacks: an all-to-all and an all-gather of HOST bytes,
+// entered by every rank; MPI_Alltoallv / MPI_Allgather fit as they are): ranks that are processes on a node without RCCL, and how
+// the CPU suite runs this driver as 2 / 4 / 8 processes over gloo.  The handle is passed to ssh_prove_sharded where an
+// ssh_rccl_group goes (both are the driver's `Transport`) and freed by ssh_rccl_group_destroy.
+typedef int (*ssh_all_to_all_cb)(void *user, const uint8_t *send, const uint64_t *send_bytes, uint8_t *recv, const uint64_t *recv_bytes);
+typedef int (*ssh_all_gather_cb)(void *user, const uint8_t *mine, uint64_t bytes, uint8_t *out);
+ssh_rccl_group *ssh_callback_group_create(uint32_t rank, uint32_t world, ssh_all_to_all_cb all_to_all, ssh_all_gather_cb all_gather, void *user) {
+    try {
+        TransportCallbacks cb;
+        cb.user = user; cb.all_to_all = all_to_all; cb.all_gather = all_gather;
+        return reinterpret_cast<ssh_rccl_group *>(make_callback_transport(cb, rank, world).release());
+    } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+// Before the first proof over a group: every rank enters; messages of different sizes between every ordered pair of ranks with
+// contents that name (source, destination, message), an all-gather, a variable-length all-gather (sharded.hpp transport_self_check).
+// -> 0, or 1 with the mismatch in ssh_last_error on the rank that saw it.  bandwidth_bytes > 0: then one timed equal-split
+// all-to-all of that many bytes per pair -> *gbps_out = this rank's send + receive rate.  group / transport: as ssh_prove_sharded.
+int ssh_group_self_check(ss_ctx *ctx, uint32_t rank, uint32_t world, ssh_local_group *group, ssh_rccl_group *transport, uint64_t bandwidth_bytes,
+                         double *gbps_out) {
+    std::shared_ptr<LocalGroup> *lg = reinterpret_cast<std::shared_ptr<LocalGroup> *>(group);
+    try {
+        if (!ctx || (!group && !transport)) throw std::runtime_error("ssh_group_self_check: NULL argument");
+        std::unique_ptr<Transport> local = lg ? make_local_transport(*lg, rank) : nullptr;
+        Transport *comm = lg ? local.get() : reinterpret_cast<Transport *>(transport);
+        if (comm->world != world || comm->rank != rank) throw std::runtime_error("ssh_group_self_check: the group has another number of ranks, or this is another rank of it");
+        transport_self_check(ctx, *comm, bandwidth_bytes, gbps_out);
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        if (lg) local_group_fail(**lg);
+        return 1;
+    }
+}
 typedef int (*ssh_sharded_extension_cb)(void *user, const uint64_t *challenges, uint32_t nchallenges, uint32_t *cols_out, uint64_t **d_cols_out,
                                         uint32_t *ncols_out);
 int ssh_prove_sharded(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32], uint32_t rank,

@@ -22,6 +22,8 @@
 #include "sharded.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <string>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -99,6 +101,57 @@ std::unique_ptr<Transport> make_rccl_transport(ss_ctx *ctx, const uint8_t id[128
     return std::unique_ptr<Transport>(new RcclTransport(ctx, id, rank, world));
 }
 
+namespace {
+// The caller's collectives over host memory (TransportCallbacks): an exchange step is ONE all-to-all of bytes.  The messages for a
+// peer are packed in list order - the order the receiver lists its receives from this rank in -, downloaded into one host buffer,
+// exchanged, and uploaded to where the receives point.  A message to this rank itself is a device copy.
+class CallbackTransport : public Transport {
+public:
+    CallbackTransport(const TransportCallbacks &cb, uint32_t rank_, uint32_t world_) : cb_(cb) {
+        if (!cb.all_to_all || !cb.all_gather) throw std::runtime_error("callback transport: both callbacks are needed");
+        if (!world_ || rank_ >= world_) throw std::runtime_error("callback transport: rank / world");
+        rank = rank_; world = world_;
+    }
+    void exchange(ss_ctx *ctx, const std::vector<Message> &sends, const std::vector<Message> &recvs) override {
+        std::vector<uint64_t> sb(world, 0), rb(world, 0), so(world + 1, 0), ro(world + 1, 0);
+        for (const Message &m : sends) { if (m.peer >= world) throw std::runtime_error("callback transport: peer"); if (m.peer != rank) sb[m.peer] += m.bytes; }
+        for (const Message &m : recvs) { if (m.peer >= world) throw std::runtime_error("callback transport: peer"); if (m.peer != rank) rb[m.peer] += m.bytes; }
+        for (uint32_t p = 0; p < world; ++p) { so[p + 1] = so[p] + sb[p]; ro[p + 1] = ro[p] + rb[p]; }
+        send_.resize(so[world]);
+        recv_.resize(ro[world]);
+        std::vector<uint64_t> at(so.begin(), so.end() - 1);
+        for (const Message &m : sends)
+            if (m.peer != rank && m.bytes) { ok(ss_download(ctx, send_.data() + at[m.peer], m.ptr, m.bytes)); at[m.peer] += m.bytes; }
+        // this rank's messages to itself: matched in list order, copied on the device
+        size_t k = 0;
+        for (const Message &rv : recvs) {
+            if (rv.peer != rank) continue;
+            while (k < sends.size() && sends[k].peer != rank) ++k;
+            if (k == sends.size() || sends[k].bytes != rv.bytes) throw std::runtime_error("callback transport: a receive without its matching send");
+            ok(ss_dev_copy(ctx, rv.ptr, sends[k].ptr, rv.bytes));
+            ++k;
+        }
+        if (cb_.all_to_all(cb_.user, send_.data(), sb.data(), recv_.data(), rb.data()) != 0) throw std::runtime_error("callback transport: all_to_all failed");
+        at.assign(ro.begin(), ro.end() - 1);
+        for (const Message &m : recvs)
+            if (m.peer != rank && m.bytes) { ok(ss_upload(ctx, m.ptr, recv_.data() + at[m.peer], m.bytes)); at[m.peer] += m.bytes; }
+        ok(ss_ctx_sync(ctx));                                        // the staging buffers are reused by the next step
+    }
+    std::vector<uint8_t> all_gather(ss_ctx *, const std::vector<uint8_t> &mine) override {
+        std::vector<uint8_t> out(mine.size() * world);
+        if (mine.empty()) return out;
+        if (cb_.all_gather(cb_.user, mine.data(), mine.size(), out.data()) != 0) throw std::runtime_error("callback transport: all_gather failed");
+        return out;
+    }
+private:
+    TransportCallbacks cb_;
+    std::vector<uint8_t> send_, recv_;
+};
+}  // namespace
+std::unique_ptr<Transport> make_callback_transport(const TransportCallbacks &cb, uint32_t rank, uint32_t world) {
+    return std::unique_ptr<Transport>(new CallbackTransport(cb, rank, world));
+}
+
 // Ranks as threads of one process: a step publishes what a rank offers, a barrier, every rank copies what is addressed to it
 // (device -> device on its own stream: the contexts share an address space), a barrier.
 class LocalGroup {
@@ -167,6 +220,82 @@ private:
 }  // namespace
 std::unique_ptr<Transport> make_local_transport(std::shared_ptr<LocalGroup> group, uint32_t rank) {
     return std::unique_ptr<Transport>(new LocalTransport(std::move(group), rank));
+}
+
+// ------------------------------------------------------------------------------------------------ self check
+void transport_self_check(ss_ctx *ctx, Transport &comm, uint64_t bandwidth_bytes, double *gbps) {
+    const uint32_t R = comm.world, r = comm.rank;
+    auto len = [](uint32_t s, uint32_t d, uint32_t k) -> uint64_t { return 32ull * (1 + (7 * s + 3 * d + 11 * k) % 13) * (k ? 9 : 1); };
+    auto byte = [](uint32_t s, uint32_t d, uint32_t k, uint64_t i) -> uint8_t { return (uint8_t)(131 * s + 17 * d + 5 * k + i + (i >> 8)); };
+    // a rank that sees a wrong byte still enters every step (the others are in them); the verdicts are gathered at the end and
+    // EVERY rank throws the same message
+    std::string bad;
+    auto complain = [&](const std::string &what) { if (bad.empty()) bad = "rank " + std::to_string(r) + " " + what; };
+    uint64_t stot = 0, rtot = 0;
+    for (uint32_t p = 0; p < R; ++p) for (uint32_t k = 0; k < 2; ++k) { stot += len(r, p, k); rtot += len(p, r, k); }
+    std::vector<uint8_t> hs(stot), hr(rtot);
+    DeviceBuffer ds(ctx, stot), dr(ctx, rtot);
+    std::vector<Message> sends, recvs;
+    uint64_t so = 0, ro = 0;
+    for (uint32_t k = 0; k < 2; ++k)                         // message 0 of every pair, then message 1: the lists interleave the peers
+        for (uint32_t p = 0; p < R; ++p) {
+            const uint64_t ls = len(r, p, k), lr = len(p, r, k);
+            for (uint64_t i = 0; i < ls; ++i) hs[so + i] = byte(r, p, k, i);
+            sends.push_back({p, ds.u8() + so, ls});
+            recvs.push_back({p, dr.u8() + ro, lr});
+            so += ls; ro += lr;
+        }
+    ok(ss_upload(ctx, ds.u8(), hs.data(), stot));
+    ok(ss_dev_zero(ctx, dr.u8(), rtot));
+    comm.exchange(ctx, sends, recvs);
+    ok(ss_download(ctx, hr.data(), dr.u8(), rtot));
+    ro = 0;
+    for (uint32_t k = 0; k < 2; ++k)
+        for (uint32_t p = 0; p < R; ++p) {
+            const uint64_t lr = len(p, r, k);
+            for (uint64_t i = 0; i < lr; ++i)
+                if (hr[ro + i] != byte(p, r, k, i)) {
+                    complain("got a wrong byte in message " + std::to_string(k) + " from rank " + std::to_string(p) + " (offset " + std::to_string(i) + " of " +
+                             std::to_string(lr) + ")");
+                    break;
+                }
+            ro += lr;
+        }
+    std::vector<uint8_t> mine(33);
+    for (size_t i = 0; i < mine.size(); ++i) mine[i] = byte(r, 0, 2, i);
+    const std::vector<uint8_t> all = comm.all_gather(ctx, mine);
+    if (all.size() != mine.size() * R) complain("got an all_gather of the wrong size");
+    else
+        for (uint32_t p = 0; p < R; ++p)
+            for (size_t i = 0; i < mine.size(); ++i)
+                if (all[p * mine.size() + i] != byte(p, 0, 2, i)) { complain("got a wrong all_gather slot " + std::to_string(p)); break; }
+    std::vector<uint8_t> var(5 * r);                         // rank 0 contributes nothing
+    for (size_t i = 0; i < var.size(); ++i) var[i] = byte(r, 1, 3, i);
+    const std::vector<std::vector<uint8_t>> parts = comm.all_gather_var(ctx, var);
+    for (uint32_t p = 0; p < R; ++p) {
+        if (parts[p].size() != 5 * p) { complain("got an all_gather_var slot of the wrong length from rank " + std::to_string(p)); continue; }
+        for (size_t i = 0; i < parts[p].size(); ++i) if (parts[p][i] != byte(p, 1, 3, i)) { complain("got wrong all_gather_var bytes from rank " + std::to_string(p)); break; }
+    }
+    std::string verdict;
+    for (const std::vector<uint8_t> &v : comm.all_gather_var(ctx, std::vector<uint8_t>(bad.begin(), bad.end())))
+        if (!v.empty()) verdict += (verdict.empty() ? "" : "; ") + std::string(v.begin(), v.end());
+    if (!verdict.empty()) throw std::runtime_error("transport self check: " + verdict);
+    if (gbps) *gbps = 0.0;
+    if (bandwidth_bytes && R > 1) {
+        const uint64_t per = bandwidth_bytes / 32 * 32;
+        DeviceBuffer bs(ctx, per * R), br(ctx, per * R);
+        ok(ss_dev_zero(ctx, bs.u8(), per * R));
+        std::vector<Message> s2, r2;
+        for (uint32_t p = 0; p < R; ++p) if (p != r) { s2.push_back({p, bs.u8() + per * p, per}); r2.push_back({p, br.u8() + per * p, per}); }
+        comm.exchange(ctx, s2, r2);                          // untimed: connections come up at the first use of a pair
+        ok(ss_ctx_sync(ctx));
+        comm.all_gather(ctx, std::vector<uint8_t>(8, 0));    // every rank starts the timed step together
+        const auto t0 = std::chrono::steady_clock::now();
+        comm.exchange(ctx, s2, r2);
+        ok(ss_ctx_sync(ctx));
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (gbps && dt > 0) *gbps = 2.0 * per * (R - 1) / dt / 1e9;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ top levels on the host

@@ -32,11 +32,29 @@ public:
 
 // RCCL: `id` = the 128 bytes of ss_comm_unique_id made by rank 0 and handed out by whatever launched the ranks
 std::unique_ptr<Transport> make_rccl_transport(ss_ctx *ctx, const uint8_t id[128], uint32_t rank, uint32_t world);
+// The caller's own collectives (MPI, gloo, UCX ...: one process per GPU on a node without RCCL, and how the CPU suite runs this
+// driver as 2 / 4 / 8 PROCESSES over the emulated device code).  Both callbacks are entered by every rank, in the same order on
+// every rank, and return 0 on success.  All buffers are HOST memory the transport stages through (ss_download / ss_upload).
+struct TransportCallbacks {
+    void *user = nullptr;
+    // MPI_Alltoallv on bytes: `send` = the bytes for rank 0, 1, ... back to back (send_bytes[p] of them for rank p), `recv` the
+    // same way with recv_bytes[p] from rank p; this rank's own slot has length 0 (the transport copies on the device)
+    int (*all_to_all)(void *user, const uint8_t *send, const uint64_t *send_bytes, uint8_t *recv, const uint64_t *recv_bytes) = nullptr;
+    // `bytes` of every rank (the same count everywhere) -> out[p * bytes ...), in rank order
+    int (*all_gather)(void *user, const uint8_t *mine, uint64_t bytes, uint8_t *out) = nullptr;
+};
+std::unique_ptr<Transport> make_callback_transport(const TransportCallbacks &cb, uint32_t rank, uint32_t world);
 // ranks = threads of one process (every thread with its own context, on one device or several)
 class LocalGroup;
 std::shared_ptr<LocalGroup> make_local_group(uint32_t world);
 std::unique_ptr<Transport> make_local_transport(std::shared_ptr<LocalGroup> group, uint32_t rank);
 void local_group_fail(LocalGroup &group);          // a rank gave up: the others leave their barriers with an error
+
+// Every rank enters: two messages of different sizes per ordered pair of ranks (list-order matching), one message to itself, an
+// all_gather and an all_gather_var, all with contents that name (source, destination, message); throws on the rank that sees a
+// wrong byte.  bandwidth_bytes > 0: then one timed equal-split all-to-all of that many bytes per pair -> this rank's
+// send + receive rate in GB/s through *gbps (what a re-shard gets out of the links).
+void transport_self_check(ss_ctx *ctx, Transport &comm, uint64_t bandwidth_bytes = 0, double *gbps = nullptr);
 
 // build_extension_columns on the ranks: -> {global column number: device column of n felts} for the extension columns this
 // rank owns (column c lives on rank c % world)

@@ -185,22 +185,29 @@ struct HostThreadsScope {
 
 // the addresses between the lowest and the highest accessed one that nothing accesses, ascending (the gap fillers of
 // trace.rs:594-625 / 890-925): a byte map of the accessed addresses instead of a sort of all n / 2 accesses
-inline std::vector<uint64_t> memory_gaps(const std::vector<uint64_t> &npc_addr, const std::vector<MemoryEntry> &public_memory) {
+inline std::vector<uint64_t> memory_gaps(const std::vector<uint64_t> &npc_addr, const std::vector<MemoryEntry> &public_memory, uint64_t max_gaps) {
     uint64_t top = 0, low = UINT64_MAX;
 #pragma omp parallel for schedule(static) reduction(max : top) reduction(min : low)
     for (uint64_t k = 0; k < npc_addr.size(); ++k) { top = std::max(top, npc_addr[k]); low = std::min(low, npc_addr[k]); }
     for (auto &e : public_memory) { top = std::max<uint64_t>(top, e.address); low = std::min<uint64_t>(low, e.address); }
     std::vector<uint64_t> gaps;
     if (low == UINT64_MAX) return gaps;
-    if (top > (1ull << 34)) fail("memory address out of range");
-    std::vector<uint8_t> seen(top + 1, 0);
+    // The span holds at most one accessed address per access; whatever else is in it is a gap, and the caller has room for max_gaps
+    // of them: a span beyond that fails HERE, with the caller's message, before anything is sized by an address out of a corrupt
+    // memory.bin (the map below is then bounded by the trace, not by the file's largest address)
+    if (top - low > (uint64_t)npc_addr.size() + public_memory.size() + max_gaps) fail("more memory gaps than cycles to hold them");
+    std::vector<uint8_t> seen(top - low + 1, 0);
 #pragma omp parallel for schedule(static)
     for (uint64_t k = 0; k < npc_addr.size(); ++k) {                              // (every writer writes the same byte; an idling run
-        const uint64_t a = npc_addr[k];                                          // hits the same few: look before writing, or 256 threads
-        if (!seen[a]) seen[a] = 1;                                               // pass one cache line around)
+        uint8_t *cell = &seen[npc_addr[k] - low];                                // hits the same few: look before writing, or 256 threads
+        if (!__atomic_load_n(cell, __ATOMIC_RELAXED)) __atomic_store_n(cell, (uint8_t)1, __ATOMIC_RELAXED);   // pass one cache line around)
     }
-    for (auto &e : public_memory) seen[e.address] = 1;
-    for (uint64_t a = low + 1; a < top; ++a) if (!seen[a]) gaps.push_back(a);
+    for (auto &e : public_memory) seen[e.address - low] = 1;
+    for (uint64_t a = low + 1; a < top; ++a)
+        if (!seen[a - low]) {
+            gaps.push_back(a);
+            if (gaps.size() > max_gaps) fail("more memory gaps than cycles to hold them");
+        }
     return gaps;
 }
 
@@ -219,7 +226,10 @@ inline void ordered_memory_into(Felt *mem_col, uint64_t n, const std::vector<uin
 #pragma omp parallel for schedule(static) reduction(max : top)
     for (uint64_t k = 0; k < half; ++k) top = std::max(top, npc_addr[k]);
     for (auto &e : public_memory) top = std::max<uint64_t>(top, e.address);
-    if (top > (1ull << 34)) fail("memory address out of range");
+    // continuous memory has an access per address 1 ... top, and there are n / 2 accesses in all (the checks below): an address
+    // beyond that is the discontinuity itself - said before three arrays are sized by it (a corrupt memory.bin must not cost 20 B
+    // per address up to its largest one)
+    if (top > half) fail("memory is not continuous and single-valued: address " + std::to_string(top) + " with " + std::to_string(half) + " accesses");
     std::vector<uint32_t> count(top + 2, 0);
     std::vector<uint64_t> rep(top + 2, UINT64_MAX);           // the first access of an address: pool index, or half + public index
     // A run that idles in `jmp rel 0` (every padded one) reads the same handful of cells a million times: each thread counts through

@@ -352,7 +352,7 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
     mark("bitwise + diluted");
     // ---- gap fillers (trace.rs:594-625)
     {
-        const std::vector<uint64_t> gaps = memory_gaps(npc_addr, pi.public_memory);
+        const std::vector<uint64_t> gaps = memory_gaps(npc_addr, pi.public_memory, num_cycles);
         if (gaps.size() > num_cycles) fail("more memory gaps than cycles to hold them");
         for (size_t k = 0; k < gaps.size(); ++k) set_pair(k * CYCLE_HEIGHT + NPC_UNUSED_ADDR, gaps[k], zero);
     }

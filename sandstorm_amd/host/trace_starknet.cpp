@@ -661,7 +661,7 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
     lap("poseidon");
     // ---- gap fillers (trace.rs:890-925)
     {
-        const std::vector<uint64_t> gaps = memory_gaps(npc_addr, pi.public_memory);
+        const std::vector<uint64_t> gaps = memory_gaps(npc_addr, pi.public_memory, num_cycles);
         if (gaps.size() > num_cycles) fail("more memory gaps than cycles to hold them");
         for (size_t k = 0; k < gaps.size(); ++k) set_pair(k * CYCLE_HEIGHT + NPC_UNUSED_ADDR, gaps[k], zero);
     }

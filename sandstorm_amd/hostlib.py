@@ -14,6 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libsandstorm_host.so")
 AIR_MINI = 0
 EXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p))
+ALL_TO_ALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint64))
+ALL_GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint8))
+HOST_ABI_VERSION = 2             # host_capi.cpp SSH_HOST_ABI_VERSION
 SHARDED_EXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))
 
 _host = None
@@ -27,6 +30,12 @@ def load():
             raise _lib.SandstormHipError("%s is missing: run __graft_entry__.build()" % LIB_PATH)
         h = C.CDLL(LIB_PATH)
         h.ssh_last_error.restype = C.c_char_p
+        h.ssh_abi_version.restype = C.c_uint32
+        if h.ssh_abi_version() != HOST_ABI_VERSION:
+            raise _lib.SandstormHipError("%s has host ABI %d, these bindings are written for %d: rebuild (__graft_entry__.build())"
+                                         % (LIB_PATH, h.ssh_abi_version(), HOST_ABI_VERSION))
+        h.ssh_callback_group_create.argtypes = [C.c_uint32, C.c_uint32, ALL_TO_ALL_CB, ALL_GATHER_CB, C.c_void_p]
+        h.ssh_callback_group_create.restype = C.c_void_p
         h.ssh_air_destroy.argtypes = [C.c_void_p]
         h.ssh_air_columns.argtypes = [C.c_void_p, C.c_int]
         h.ssh_air_columns.restype = C.c_uint32
@@ -504,10 +513,92 @@ class RcclGroup:
             self.h = None
 
 
+class CallbackGroup:
+    """this rank's end of a group whose collectives are the CALLER's (host/sharded.cpp CallbackTransport): all_to_all(send: bytes-like,
+    send_counts, recv_counts) -> bytes-like of sum(recv_counts) bytes (MPI_Alltoallv on bytes, slots in rank order) and
+    all_gather(mine: bytes-like) -> the ranks' equal-sized contributions in rank order.  The C++ driver stages device memory
+    through the host for them.  Goes where an RcclGroup goes."""
+
+    def __init__(self, rank, world, all_to_all, all_gather):
+        self.world, self.rank = world, rank
+        self._all_to_all, self._all_gather = all_to_all, all_gather
+
+        def a2a(_user, send, send_counts, recv, recv_counts):
+            try:
+                sc = [int(send_counts[p]) for p in range(world)]
+                rc = [int(recv_counts[p]) for p in range(world)]
+                src = np.ctypeslib.as_array(send, shape=(sum(sc),)) if sum(sc) else np.zeros(0, dtype=np.uint8)
+                got = np.frombuffer(self._all_to_all(src, sc, rc), dtype=np.uint8)
+                if got.size != sum(rc):
+                    raise ValueError("all_to_all returned %d bytes, %d expected" % (got.size, sum(rc)))
+                if got.size:
+                    C.memmove(recv, got.ctypes.data, got.size)
+                return 0
+            except Exception:                   # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def gather(_user, mine, nbytes, out):
+            try:
+                got = np.frombuffer(self._all_gather(np.ctypeslib.as_array(mine, shape=(int(nbytes),))), dtype=np.uint8)
+                if got.size != int(nbytes) * world:
+                    raise ValueError("all_gather returned %d bytes, %d expected" % (got.size, int(nbytes) * world))
+                C.memmove(out, got.ctypes.data, got.size)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cbs = (ALL_TO_ALL_CB(a2a), ALL_GATHER_CB(gather))          # kept alive as long as the group
+        self.h = load().ssh_callback_group_create(rank, world, self._cbs[0], self._cbs[1], None)
+        if not self.h:
+            raise _lib.SandstormHipError("host: " + load().ssh_last_error().decode())
+
+    def close(self):
+        if self.h:
+            load().ssh_rccl_group_destroy(self.h)
+            self.h = None
+
+
+def torch_dist_group(pg=None):
+    """a CallbackGroup over a torch.distributed process group with CPU tensors (gloo): the C++ sharded driver between processes
+    without RCCL - host-staged, for nodes where RCCL does not come up and for the CPU suite, not for speed"""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(pg), dist.get_world_size(pg)
+
+    def all_to_all(send, send_counts, recv_counts):
+        out = torch.empty(sum(recv_counts), dtype=torch.uint8)
+        src = torch.from_numpy(np.ascontiguousarray(send)) if len(send) else torch.empty(0, dtype=torch.uint8)
+        dist.all_to_all_single(out, src, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=pg)
+        return out.numpy()
+
+    def all_gather(mine):
+        src = torch.from_numpy(np.array(mine, dtype=np.uint8, copy=True))
+        out = torch.empty(src.numel() * world, dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, src, group=pg)
+        return out.numpy()
+    return CallbackGroup(rank, world, all_to_all, all_gather)
+
+
+def group_self_check(ctx, rank, world, group, bandwidth_bytes=0):
+    """every rank enters, before the first proof over `group` (LocalGroup / RcclGroup / CallbackGroup): messages of different sizes
+    between every ordered pair of ranks whose bytes name (source, destination, message), an all-gather, a variable-length all-gather
+    (host/sharded.cpp transport_self_check); raises SandstormHipError on the rank that saw a wrong byte.  bandwidth_bytes > 0: then
+    one timed equal-split all-to-all of that many bytes per pair.  -> this rank's send + receive rate in GB/s (0.0 if not asked)"""
+    h = load()
+    h.ssh_group_self_check.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
+    gbps = C.c_double(0.0)
+    local = isinstance(group, LocalGroup)
+    _check(h.ssh_group_self_check(ctx.handle, rank, world, group.h if local else None, None if local else group.h, int(bandwidth_bytes), C.byref(gbps)))
+    return gbps.value
+
+
 def prove_sharded(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, rank, world, group, my_base, log_n, build_extension, options=None):
     """ONE proof over `world` ranks by the C++ host (host/sharded.cpp; the Python mirror is sandstorm_amd/sharded_prover.py).  Called
-    by every rank with its own context and AIR handle.  group: a LocalGroup (ranks = threads of this process) or this rank's
-    RcclGroup (one process per GPU).  my_base: {column: device column} of the base columns with column % world ==
+    by every rank with its own context and AIR handle.  group: a LocalGroup (ranks = threads of this process), this rank's
+    RcclGroup (one process per GPU) or a CallbackGroup (one process per GPU, the caller's collectives).  my_base: {column: device column} of the base columns with column % world ==
     rank; build_extension(challenges) -> {global column number: device column} of this rank's extension columns (kept alive by
     the caller).  -> the proof in the reference's wire format on rank 0, None on the others."""
     options = options or ProofOptions()

@@ -18,15 +18,31 @@ def run_bench(argv, env_extra, timeout=600):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("gpus", [2, 4])
-def test_bench_launches_its_own_ranks(gpus):
-    out = run_bench(["--gpus", str(gpus), "--steps", "2", "--warmup", "1"], {"SS_BENCH_SELFTEST": "1", "OMP_NUM_THREADS": "1"})
+@pytest.fixture(scope="module")
+def emulated_library():
+    """the default `--sharded-host cpp` self-test runs the C++ host over the device code on the CPU (tests/hipemu: ~15 s when built)"""
+    out = subprocess.run(["bash", os.path.join(ROOT, "tests", "hipemu", "build.sh")], capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    from tests import mini_air_host
+    mini_air_host.load()                                 # built once here, not by N ranks at the same time
+    return out.stdout.strip().splitlines()[-1]
+
+
+@pytest.mark.parametrize("gpus,host", [(2, "cpp"), (4, "cpp"), (8, "cpp"), (2, "python")])
+def test_bench_launches_its_own_ranks(gpus, host, emulated_library):
+    """the default path of `bench.py --gpus N` - the C++ sharded host, one PROCESS per rank, group self check before the warm-up - and
+    the Python driver behind `--sharded-host python`"""
+    out = run_bench(["--gpus", str(gpus), "--steps", "2", "--warmup", "1"] + (["--sharded-host", host] if host != "cpp" else []),
+                    {"SS_BENCH_SELFTEST": "1", "OMP_NUM_THREADS": "1", "SS_TEST_HIPEMU_LIB": emulated_library})
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout                   # the contract: ONE line on stdout, whatever the ranks and libraries print
     line = json.loads(lines[0])
     assert line["n_gpus"] == gpus and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "strong"
     assert line["selftest"] is True and line["proof_is_the_single_device_proof"] is True
+    assert line["config"]["sharded_host"] == host
+    if host == "cpp":
+        assert line["config"]["comm_self_check"]["ok"] is True and line["config"]["comm_self_check"]["exchange_gbps"] > 0
     assert line["value"] > 0 and abs(line["ms_per_step"] - 1e3 * line["value"]) < 1e-6
 
 

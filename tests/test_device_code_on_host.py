@@ -51,7 +51,7 @@ def test_every_kernel_against_the_oracle(emulated_library):
     VM, proof of work - the 252-bit path's parity tests, all but the two that only exist for their size"""
     # (the trees of this file are small: the 32-lanes-per-hash Pedersen kernel serves their levels as it does on the device)
     out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_parity.py", "-k", "not large_impulse"], SS_PED_SMALL_MAX="1024")
-    assert "190 passed" in out, out[-500:]
+    assert "191 passed" in out, out[-500:]
 
 
 def test_sweeps_over_the_sizes_the_gpu_suite_samples(emulated_library):
@@ -121,3 +121,13 @@ def test_cpp_sharded_prover_over_ranks_as_threads(emulated_library):
     finally:
         del os.environ["HIPEMU_THREADS"]
     assert "12 passed" in out, out[-500:]                     # 7 mini + 2 friendly + 2 real AIR + the too-few-rows error
+
+
+def test_cpp_sharded_prover_over_ranks_as_processes(emulated_library):
+    """tests/hipemu/extra_sharded_host_procs.py: the same driver with the ranks as 2, 4 and 8 PROCESSES under torch.distributed.run - what
+    `bench.py --gpus N` starts -, every process with its own emulated device, coin and columns, meeting in the driver's
+    CallbackTransport over gloo: the single-device proofs byte for byte (mini AIR; friendly trees + Cairo coin; the real recursive
+    AIR with a spread base column)"""
+    heavy()
+    out = run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_sharded_host_procs.py"])
+    assert "9 passed" in out, out[-500:]                      # 3 mini + 2 friendly + 2 real AIR + the group self check on 2 and 8

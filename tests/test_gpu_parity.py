@@ -165,6 +165,31 @@ def test_ntt_spread_over_ranks(ctx, be, oracle, log_n, log_ranks, coset):
         assert np.array_equal(got, want), log_expand
 
 
+def test_ntt_spread_over_ranks_takes_any_number_of_columns(ctx, be, oracle):
+    """ss_ntt_shard_fp252 with 17 vectors in ONE call (it refused more than 16 where ss_ntt_fp252 / ss_lde_fp252 chunk): each
+    column of the call is what a call of its own gives, both parts, both directions"""
+    log_n, log_ranks, rank, ncols = 8, 2, 3, 17
+    B = (1 << log_n) >> log_ranks
+    cols = [random_column(B, 300 + c) for c in range(ncols)]
+    off = g3(oracle)
+    for direction, part, log_expand in ((be.INVERSE, be.NTT_PART_CROSS, 0), (be.INVERSE, be.NTT_PART_LOCAL, 0), (be.FORWARD, be.NTT_PART_CROSS, 0),
+                                        (be.FORWARD, be.NTT_PART_LOCAL, 0), (be.FORWARD, be.NTT_PART_LOCAL, 1)):
+        src = [c[:B >> log_expand] for c in cols]
+        one_by_one = []
+        for c in src:
+            d, out = _up(ctx, [c])[0], ctx.alloc(32 * B)
+            ctx.ntt_shard([d], log_n, log_ranks, rank, direction, off, part, log_expand, [out])
+            one_by_one.append(out.download(np.uint64, (B, 4)))
+        ds, outs = _up(ctx, src), [ctx.alloc(32 * B) for _ in range(ncols)]
+        ctx.ntt_shard(ds, log_n, log_ranks, rank, direction, off, part, log_expand, outs)
+        for c in range(ncols):
+            assert np.array_equal(outs[c].download(np.uint64, (B, 4)), one_by_one[c]), (direction, part, log_expand, c)
+        if not log_expand:                                   # and in place
+            ctx.ntt_shard(ds, log_n, log_ranks, rank, direction, off, part)
+            for c in range(ncols):
+                assert np.array_equal(ds[c].download(np.uint64, (B, 4)), one_by_one[c]), (direction, part, "in place", c)
+
+
 def test_fri_fold_rows_of_a_layer(ctx, be, oracle):
     """ss_fri_fold_rows: a layer folded range by range (each range's entries column after column) is the layer folded whole"""
     log_len, fold = 12, 8

@@ -79,3 +79,48 @@ def test_rccl_transport_with_a_group_of_one():
     with open(os.path.join(GOLD, "mini_proof_eth_log9.bin"), "rb") as f:
         want = f.read()
     assert run_ranks(1, make(1), group="rccl", repeat=2) == want
+
+
+@pytest.mark.parametrize("world,case,gold", [(2, "mini:9:4", "mini_proof_eth_log9.bin"), (4, "mini:9:4", "mini_proof_eth_log9.bin"),
+                                             (2, "recursive:14", "array_sum_recursive_cairo.proof")])
+def test_cpp_sharded_prover_with_ranks_as_processes(world, case, gold, tmp_path):
+    """the ranks as PROCESSES under torch.distributed.run - what `bench.py --gpus N` starts - sharing this box's GPU: every process with
+    its own context, coin and columns, the group self check first, the exchanges through the driver's CallbackTransport over gloo
+    (staged through the host; RCCL refuses two ranks on one device).  The single-device proofs, byte for byte; with 2 ranks the
+    recursive layout's seventh base column is left over and spread.  (The CPU suite runs the same on the emulated device code on
+    2 / 4 / 8 processes: tests/hipemu/extra_sharded_host_procs.py.)"""
+    from tests.hipemu.extra_sharded_host_procs import run_processes
+    with open(os.path.join(GOLD, gold), "rb") as f:
+        want = f.read()
+    assert run_processes(world, case, tmp_path, timeout=900) == want
+
+
+def test_group_self_check_over_rccl_and_over_threads():
+    """hostlib.group_self_check (what bench.py runs over its RCCL group before the warm-up) on the transports one GPU offers: the RCCL
+    group of one rank (own-rank copies, all-gathers through device buffers) and four thread-ranks in a LocalGroup"""
+    import threading
+    from sandstorm_amd import backend as be, hostlib
+    if os.environ.get("SS_TEST_HIPEMU") != "1":              # (the emulated device has no RCCL)
+        ctx = be.Context(0)
+        grp = hostlib.RcclGroup(ctx, hostlib.rccl_unique_id(), 0, 1)
+        assert hostlib.group_self_check(ctx, 0, 1, grp, 1 << 20) == 0.0      # nobody to exchange with: no rate
+        grp.close()
+        ctx.close()
+    world, group, rates, errs = 4, hostlib.LocalGroup(4), [None] * 4, []
+
+    def body(rank):
+        c = be.Context(0)
+        try:
+            rates[rank] = hostlib.group_self_check(c, rank, world, group, 1 << 22)
+        except BaseException as e:          # noqa: BLE001
+            errs.append(e)
+        finally:
+            c.close()
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    group.close()
+    assert not errs, errs
+    assert all(r > 0 for r in rates), rates

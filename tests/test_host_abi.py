@@ -112,3 +112,26 @@ def test_host_coins_match_oracle(oracle, golden):
         a.reseed_with_int(12345); b.reseed_int(12345)
         assert a.draw_queries(9, 1 << 12) == b.draw_queries(9, 1 << 12)
         assert a.digest == b.digest and a.counter == b.counter
+
+
+def test_host_library_document_names_what_the_library_exports():
+    """INTEGRATION.md section 4 against libsandstorm_host.so (the table still listed an entry point that had left the library):
+    every `ssh_*` the document names is exported, every exported `ssh_*` entry point of host_capi.cpp is either named there or one of
+    the test / diagnostic hooks listed here, and the bindings check the host ABI version at load"""
+    import ctypes as C
+    from sandstorm_amd import hostlib
+    lib = hostlib.load()
+    assert lib.ssh_abi_version() == hostlib.HOST_ABI_VERSION == 2
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        doc = f.read()
+    named = set(re.findall(r"\b(ssh_[a-z0-9_]+)\b", doc)) - {"ssh_air", "ssh_matrix", "ssh_coin"}          # handle types
+    for name in sorted(named):
+        C.cast(getattr(lib, name), C.c_void_p)              # AttributeError: the document names something the library lacks
+    src = open(os.path.join(ROOT, "sandstorm_amd", "host", "host_capi.cpp")).read()
+    defined = set(re.findall(r"^[a-z_0-9 \*]*?\b(ssh_[a-z0-9_]+)\(", src, flags=re.M))
+    hooks = {"ssh_last_error", "ssh_free", "ssh_air_destroy", "ssh_air_columns", "ssh_air_dump", "ssh_air_program", "ssh_air_mask",
+             "ssh_air_num_challenges", "ssh_coin_new", "ssh_coin_free", "ssh_coin_op", "ssh_matrix_num_cols", "ssh_matrix_col",
+             "ssh_matrix_destroy", "ssh_local_group_create", "ssh_local_group_destroy", "ssh_rccl_group_destroy", "ssh_prove",
+             "ssh_prove_wire_with_nonce", "ssh_build_extension_columns", "ssh_public_coin_seed"}
+    assert len(defined) >= 25
+    assert defined - named - hooks == set(), defined - named - hooks

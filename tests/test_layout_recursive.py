@@ -294,3 +294,34 @@ def test_cpp_base_trace_equals_the_python_one(oracle):
     from sandstorm_amd._lib import SandstormHipError
     with pytest.raises(SandstormHipError, match="power of two"):
         hostlib.recursive_base_trace(trace_bin[:24 * 1000], memory_bin, pi)
+
+
+def test_cpp_trace_refuses_a_far_away_address_without_sizing_anything_by_it():
+    """one corrupt high address (here a public-memory entry at 2^32 - 16: addresses cross the C boundary as 32-bit) must end in the generator's own message - more gaps
+    than there are cycles to hold them - and not in count / first-access / seen arrays of 20 B per address up to it (86 GB).  The
+    address space limit of the child process is what makes a regression visible here."""
+    import dataclasses
+    import subprocess
+    import sys
+    code = """
+import os, resource, sys
+sys.path.insert(0, %r)
+from sandstorm_amd import hostlib
+from sandstorm_amd._lib import SandstormHipError
+from sandstorm_amd.examples import load_run
+import dataclasses
+states, memory, pi = load_run()
+ex = %r
+trace_bin, memory_bin = open(os.path.join(ex, "trace.bin"), "rb").read(), open(os.path.join(ex, "memory.bin"), "rb").read()
+hostlib.load()
+resource.setrlimit(resource.RLIMIT_AS, (24 << 30, 24 << 30))
+for addr in (0xFFFFFFF0, 1 << 24):
+    bad = dataclasses.replace(pi, public_memory=pi.public_memory + [(addr, 7)])
+    try:
+        hostlib.recursive_base_trace(trace_bin, memory_bin, bad)
+    except SandstormHipError as e:
+        assert "more memory gaps than cycles" in str(e), e
+        print("REFUSED", addr)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), EX)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.count("REFUSED") == 2, out.stdout[-1000:] + out.stderr[-3000:]
