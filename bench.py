@@ -827,6 +827,17 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
              ("fri_fold", be.PROF_FRI), ("quotient", be.PROF_QUOTIENT), ("deep", be.PROF_DEEP),
              ("extension_scans", be.PROF_EXT)]
     prof = {name: ctx.profile_read(k) for name, k in kinds}
+    # one more proof, untimed, with shader-clock stamps around every profiled launch (ss_profile_enable level 2: s_memtime /
+    # s_memrealtime read by one wave per XCD before and after each scope): the clock each stage's kernels are granted IN THIS RUN
+    ctx.profile(2)
+    ctx.profile_reset()
+    step()
+    stage_clock = {}
+    for name, k in kinds:
+        cyc, ref = ctx.profile_read_clock(k)
+        ms2 = ctx.profile_read(k)[0]
+        if ref > 0 and ms2 > 0:
+            stage_clock[name] = {"ghz": cyc / ref * 0.1, "ref_ticks_per_s": ref / (ms2 * 1e-3), "stamped_ms": ms2}
     ctx.profile(False)
     out = None
     if rank == 0:
@@ -878,35 +889,28 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
                     traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source", tj.get("source"))
             launches = prof[name][1]
             # the ALU roofline beside the HBM one (these kernels are bound by vector-instruction issue): the
-            # stage's SQ_INSTS_VALU per proof from the counters' own --pmc pass (profiles/alu_counters_<workload>.json, its commit
-            # inside; tools/final_round.sh + collect_final.py) over THIS run's HIP-event stage time, against 1024 SIMDs issuing
-            # one wave-instruction per `weighted_cycles_per_inst` cycles of 2.4 GHz - the kernels' static instruction mix priced
-            # with the measured cost of each mnemonic (profiles/alu_model.json, tools/alu_model.py, tools/ubench.hip)
+            # stage's SQ_INSTS_VALU per proof (a deterministic count: the counters' own --pmc pass, profiles/alu_counters_<workload>.json)
+            # over THIS run's HIP-event stage time, against 1024 SIMDs issuing one wave-instruction per `weighted_cycles_per_inst`
+            # cycles of the clock THIS run's stamps measured for the stage (ss_profile_read_clock) - the kernels' static instruction
+            # mix priced with the issue cost of each mnemonic in cycles of the probe's own clock (tools/ubench.hip stamps itself)
             alu = None
             apath = os.path.join(ROOT, "profiles", "alu_counters_%s.json" % workload)
-            if os.path.exists(apath) and sec > 0:
+            clk = stage_clock.get(name)
+            if os.path.exists(apath) and sec > 0 and clk:
                 with open(apath) as fh:
                     aj = json.load(fh)
                 st = aj.get("stages", {}).get(name)
                 if st and st.get("weighted_cycles_per_inst"):
                     insts, cyc = st["valu_wave_insts_per_proof"], st["weighted_cycles_per_inst"]
-                    peak_i = 1024 * 2.4e9 / cyc
+                    peak_i = 1024 * clk["ghz"] * 1e9 / cyc
                     units = {"ntt_pass": ntt_ops / 3.0, "quotient": float(N), "deep": float(n), "hash_rows": float(3 * N), "merkle": float(3 * N)}.get(name)
                     alu = {"valu_wave_insts_per_proof": insts, "valu_insts_per_unit": insts * 64.0 / units if units else None,
                            "unit": {"ntt_pass": "butterfly", "quotient": "LDE point", "deep": "sub-coset point", "hash_rows": "row", "merkle": "leaf"}.get(name),
-                           "weighted_cycles_per_inst": cyc, "peak_wave_insts_per_s": peak_i, "achieved_wave_insts_per_s": insts / sec,
+                           "weighted_cycles_per_inst": cyc, "cycles_are": aj.get("cycles_are", "cycles at a nominal 2.4 GHz (round-4 price list)"),
+                           "clock_ghz": clk["ghz"], "clock_source": "this run: s_memtime / s_memrealtime stamps around the stage's launches (ss_profile_read_clock)",
+                           "ref_counter_hz_measured": clk["ref_ticks_per_s"],
+                           "peak_wave_insts_per_s": peak_i, "achieved_wave_insts_per_s": insts / sec,
                            "frac": insts / sec / peak_i, "counters_source": aj.get("source"), "counters_commit": aj.get("commit")}
-                    # the clock the stage's kernels actually ran at (GRBM_GUI_ACTIVE / traced duration of a --pmc pass, tools/valu_busy.sh
-                    # -> profiles/effective_clock_<workload>.json): the chip clocks to its power budget, these kernels sit at 2.0-2.4 GHz
-                    epath = os.path.join(ROOT, "profiles", "effective_clock_%s.json" % workload)
-                    if os.path.exists(epath):
-                        with open(epath) as fh:
-                            ej = json.load(fh)
-                        est = ej.get("stages", {}).get(name)
-                        if est and est.get("effective_clock_ghz"):
-                            ghz = est["effective_clock_ghz"]
-                            alu.update({"effective_clock_ghz": ghz, "frac_at_effective_clock": alu["frac"] * 2.4 / ghz,
-                                        "effective_clock_source": "profiles/effective_clock_%s.json (commit %s)" % (workload, ej.get("commit"))})
                     if alu["frac"] > 1.05:
                         # c-bar prices the STATIC mix of the stage's kernels; where most of the executed instructions sit in a few
                         # loop bodies (the Pedersen trees: window loops of curve additions around one-off glue) the executed mix is

@@ -76,7 +76,7 @@ enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
 const char *ss_last_error(void);
 /* ABI version of this header; bump on any signature change.  ss_abi_version() of the loaded
  * library must equal SS_ABI_VERSION of the header the caller was built against. */
-#define SS_ABI_VERSION 8u
+#define SS_ABI_VERSION 9u
 uint32_t ss_abi_version(void);
 
 /* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;
@@ -437,6 +437,13 @@ enum { SS_PROF_NTT_PASS = 0, SS_PROF_HASH_ROWS = 1, SS_PROF_MERKLE = 2, SS_PROF_
 ss_status ss_profile_enable(ss_ctx *ctx, int on);
 ss_status ss_profile_reset(ss_ctx *ctx);
 ss_status ss_profile_read(ss_ctx *ctx, int kind, double *total_ms, uint64_t *launches);
+/* ss_profile_enable(ctx, 2): besides the events, one wave per XCD stamps the shader-cycle counter (s_memtime) and the
+ * constant-rate reference counter (s_memrealtime) right before and after every profiled scope, on its stream.
+ * ss_profile_read_clock: the shader cycles and reference ticks accumulated between those stamps since the last reset (mean over
+ * the XCDs stamped on both sides) - cycles / ticks x the reference rate (100 MHz) is the clock the chip granted that kernel
+ * family, in the run it is read in.  The probes cost a few microseconds per scope: level 2 is for a measuring pass, not a
+ * timed one.  (Up to 8192 scopes between two reads carry stamps.) */
+ss_status ss_profile_read_clock(ss_ctx *ctx, int kind, double *shader_cycles, double *ref_ticks);
 
 /* Host-side pedersen_hash for the Fiat-Shamir coin (CairoVerifierPublicCoin::
  * reseed_with_field_elements hashes the OOD evaluations with a sequential

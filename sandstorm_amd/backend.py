@@ -396,7 +396,14 @@ class Context:
                                             out_stride, out_offset))
 
     def profile(self, on):
-        check(self.lib.ss_profile_enable(self.handle, 1 if on else 0))
+        """False / True: HIP events around every profiled launch; 2: also shader-clock stamps around them (profile_read_clock)"""
+        check(self.lib.ss_profile_enable(self.handle, 2 if on == 2 else 1 if on else 0))
+
+    def profile_read_clock(self, kind):
+        """-> (shader cycles, reference ticks) between the stamps of this kernel family's launches since the last reset (level 2)"""
+        cyc, ref = C.c_double(), C.c_double()
+        check(self.lib.ss_profile_read_clock(self.handle, kind, C.byref(cyc), C.byref(ref)))
+        return cyc.value, ref.value
 
     def profile_reset(self):
         check(self.lib.ss_profile_reset(self.handle))

@@ -78,6 +78,25 @@ Fp root_of_unity(uint32_t log_n) {
 
 }  // namespace
 
+// The shader clock of a profiled launch (ss_profile_enable(ctx, 2)): one wave per XCD reads the free-running shader-cycle counter
+// (s_memtime: a tick = one shader cycle) and the constant-rate reference counter (s_memrealtime) right before and right after the
+// launches of a scope, on the scope's stream; cycles / reference ticks between the two stamps of one XCD = the clock the chip
+// granted that kernel (it clocks to its power budget: the transforms run ~15 % below the constraint kernels).
+struct ClockStamp { uint64_t cycles, ref, xcc, pad; };
+static constexpr int CLOCK_PROBE_WGS = 8;
+__global__ void clock_probe_kernel(ClockStamp *out) {
+#if defined(HIPEMU)
+    if (threadIdx.x == 0) out[blockIdx.x] = ClockStamp{0, 0, blockIdx.x, 0};
+#else
+    if (threadIdx.x == 0) {
+        uint64_t c, r;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r) : : "memory");
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;       // hwreg(HW_REG_XCC_ID, 0, 4)
+        out[blockIdx.x] = ClockStamp{c, r, xcc, 0};
+    }
+#endif
+}
+
 struct ss_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -129,24 +148,43 @@ struct ss_ctx {
         return e;
     }
 
-    bool prof_on = false;
+    bool prof_on = false, prof_clock = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[SS_PROF_KINDS];
     double prof_ms[SS_PROF_KINDS] = {0};
     uint64_t prof_launches[SS_PROF_KINDS] = {0};
+    // clock stamps (prof_clock): scope i of the current batch wrote d_stamps[(2 i + {0, 1}) * CLOCK_PROBE_WGS ...]
+    static constexpr size_t CLOCK_SCOPES = 8192;
+    ClockStamp *d_stamps = nullptr;
+    std::vector<int> stamp_kinds;                      // kind of scope i
+    double prof_cycles[SS_PROF_KINDS] = {0}, prof_ref[SS_PROF_KINDS] = {0}, prof_clock_ms[SS_PROF_KINDS] = {0};
 
     // bracket one launch with events (only when profiling is on)
     struct Scope {
-        ss_ctx *c; int kind; hipEvent_t e1 = nullptr;
+        ss_ctx *c; int kind; hipEvent_t e1 = nullptr; long stamp = -1;
         Scope(ss_ctx *c_, int k) : c(c_), kind(k) {
             if (!c->prof_on) return;
             hipEvent_t e0;
             if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e1 = nullptr; return; }
+            if (c->prof_clock && c->d_stamps && c->stamp_kinds.size() < CLOCK_SCOPES) {
+                stamp = (long)c->stamp_kinds.size();
+                c->stamp_kinds.push_back(kind);
+                hipLaunchKernelGGL(clock_probe_kernel, dim3(CLOCK_PROBE_WGS), dim3(64), 0, c->stream, c->d_stamps + (2 * stamp) * CLOCK_PROBE_WGS);
+            }
             (void)hipEventRecord(e0, c->stream);
             c->prof_events[kind].push_back({e0, e1});
         }
-        ~Scope() { if (e1) (void)hipEventRecord(e1, c->stream); }
+        ~Scope() {
+            if (!e1) return;
+            (void)hipEventRecord(e1, c->stream);
+            if (stamp >= 0) hipLaunchKernelGGL(clock_probe_kernel, dim3(CLOCK_PROBE_WGS), dim3(64), 0, c->stream, c->d_stamps + (2 * stamp + 1) * CLOCK_PROBE_WGS);
+        }
     };
-    void prof_collect() {
+    void prof_collect() {                              // (the stream is synchronised)
+        std::vector<ClockStamp> st;
+        if (!stamp_kinds.empty()) {
+            st.resize(2 * stamp_kinds.size() * CLOCK_PROBE_WGS);
+            if (hipMemcpy(st.data(), d_stamps, st.size() * sizeof(ClockStamp), hipMemcpyDeviceToHost) != hipSuccess) st.clear();
+        }
         for (int k = 0; k < SS_PROF_KINDS; ++k) {
             for (auto &pr : prof_events[k]) {
                 float ms = 0;
@@ -155,6 +193,20 @@ struct ss_ctx {
             }
             prof_events[k].clear();
         }
+        // per scope: the XCDs stamped on both sides (a probe's workgroups land one per XCD; matched by the XCC id they read)
+        for (size_t i = 0; i < stamp_kinds.size() && !st.empty(); ++i) {
+            const ClockStamp *a = st.data() + (2 * i) * CLOCK_PROBE_WGS, *b = a + CLOCK_PROBE_WGS;
+            double cyc = 0, ref = 0;
+            int matched = 0;
+            for (int x = 0; x < CLOCK_PROBE_WGS; ++x)
+                for (int y = 0; y < CLOCK_PROBE_WGS; ++y)
+                    if (a[x].xcc == b[y].xcc && b[y].ref > a[x].ref && b[y].cycles > a[x].cycles) {
+                        cyc += (double)(b[y].cycles - a[x].cycles); ref += (double)(b[y].ref - a[x].ref); ++matched;
+                        break;
+                    }
+            if (matched) { prof_cycles[stamp_kinds[i]] += cyc / matched; prof_ref[stamp_kinds[i]] += ref / matched; }
+        }
+        stamp_kinds.clear();
     }
 
     ss_status ensure_scratch(size_t bytes) {
@@ -328,7 +380,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -361,6 +413,7 @@ void ss_ctx_destroy(ss_ctx *ctx) {
     ctx->pool_trim();
     for (auto &kv : ctx->pool_live) hipFree(kv.first);     // leaked by the caller
     pedersen_tables_destroy(ctx->ped);
+    if (ctx->d_stamps) hipFree(ctx->d_stamps);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->scratch2) hipFree(ctx->scratch2);
     if (ctx->transient_tw) hipFree(ctx->transient_tw);
@@ -595,14 +648,29 @@ ss_status ss_comm_all_gather(ss_comm *comm, const void *d_send, uint64_t bytes, 
 
 ss_status ss_profile_enable(ss_ctx *ctx, int on) {
     if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
+    if (on == 2 && !ctx->d_stamps) {
+        void *p = nullptr;
+        HIP_TRY(ctx->malloc_retry(&p, 2 * ss_ctx::CLOCK_SCOPES * CLOCK_PROBE_WGS * sizeof(ClockStamp)));
+        ctx->d_stamps = (ClockStamp *)p;
+    }
+    if (ctx->prof_clock && on != 2) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->prof_collect(); }
     ctx->prof_on = on != 0;
+    ctx->prof_clock = on == 2;
     return SS_OK;
 }
 ss_status ss_profile_reset(ss_ctx *ctx) {
     if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->prof_collect();
-    for (int k = 0; k < SS_PROF_KINDS; ++k) { ctx->prof_ms[k] = 0; ctx->prof_launches[k] = 0; }
+    for (int k = 0; k < SS_PROF_KINDS; ++k) { ctx->prof_ms[k] = 0; ctx->prof_launches[k] = 0; ctx->prof_cycles[k] = 0; ctx->prof_ref[k] = 0; }
+    return SS_OK;
+}
+ss_status ss_profile_read_clock(ss_ctx *ctx, int kind, double *shader_cycles, double *ref_ticks) {
+    if (!ctx || kind < 0 || kind >= SS_PROF_KINDS) return fail(SS_ERR_INVALID, "bad argument");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->prof_collect();
+    if (shader_cycles) *shader_cycles = ctx->prof_cycles[kind];
+    if (ref_ticks) *ref_ticks = ctx->prof_ref[kind];
     return SS_OK;
 }
 ss_status ss_profile_read(ss_ctx *ctx, int kind, double *total_ms, uint64_t *launches) {

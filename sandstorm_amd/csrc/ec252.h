@@ -80,6 +80,40 @@ SS_HD JacL jacl_add_aff(const JacL &p, const AffL &q) {
     return r;
 }
 
+// XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2): the mixed addition is 8M + 2S - one squaring fewer than the Jacobian
+// one above, which squares z1 first - and a hash only wants x = X / ZZ at its end, so nothing is owed for the fourth coordinate
+// but nine registers (round 5; the accumulate kernels of pedersen.hip: one hash per lane, 20 - 22 additions in a row).
+// Infinity is ZZ = 0.  The lazy discipline is jacl_add_aff's, value for value: u2, s2, v and the two new coordinates are plain
+// products (normalised, < 2p); h, rr < 4p go into the multiplier unreduced; x3, y3 are weakly reduced.
+struct XyzzL { Fl x, y, zz, zzz; };
+SS_HD XyzzL xyzzl_double(const XyzzL &p) {                 // dbl-2008-s-1 with a = 1
+    const Fl u = fn_dbl(p.y), v = fn_sqr(u), w = fn_mul(u, v), s = fn_mul(p.x, v);
+    const Fl xx = fn_sqr(p.x), m = fn_add(fn_add(fn_dbl(xx), xx), fn_sqr(p.zz));
+    XyzzL r;
+    r.x = fn_sub(fn_sqr(m), fn_dbl(s));
+    r.y = fn_sub(fn_mul(m, fn_sub(s, r.x)), fn_mul(w, p.y));
+    r.zz = fn_mul(v, p.zz);
+    r.zzz = fn_mul(w, p.zzz);
+    return r;
+}
+SS_HD XyzzL xyzzl_add_aff(const XyzzL &p, const AffL &q) {  // madd-2008-s
+    if (fn_is_zero(p.zz)) { XyzzL r; r.x = q.x; r.y = q.y; r.zz = fl_one(); r.zzz = fl_one(); return r; }
+    const Fl u2 = fn_mul(q.x, p.zz), s2 = fn_mul(q.y, p.zzz);
+    const Fl h = fl_sub_c<2, 1>(u2, p.x), rr = fl_sub_c<2, 1>(s2, p.y);          // lazy: < 4p
+    const Fl hh = fl_sqr(h);
+    XyzzL r;
+    r.zz = fn_mul(p.zz, hh);
+    if (fn_is_zero(r.zz)) {                                                       // zz1 != 0, so h = 0 (mod p)
+        if (fn_is_zero(fl_weak_reduce(rr))) return xyzzl_double(p);
+        XyzzL o; o.x = fl_one(); o.y = fl_one(); o.zz = fl_zero(); o.zzz = fl_zero(); return o;
+    }
+    const Fl hhh = fl_mul(h, hh), v = fn_mul(p.x, hh);
+    r.x = fl_weak_reduce(fl_sub_c<8, 2>(fl_sub_c<2, 1>(fl_sqr(rr), hhh), fl_add(v, v)));
+    r.y = fl_weak_reduce(fl_sub_c<2, 1>(fl_mul(rr, fl_sub_c<2, 1>(v, r.x)), fn_mul(p.y, hhh)));
+    r.zzz = fn_mul(p.zzz, hhh);
+    return r;
+}
+
 // p + q, both Jacobian (12M + 4S); infinity is z = 0 on either side.  Used by the lane-split
 // accumulation of small tree levels, where partial sums of one hash meet across lanes.
 SS_HD JacL jacl_add(const JacL &p, const JacL &q) {

@@ -84,6 +84,9 @@ static constexpr int LOG_TILE_MAX = SS_NTT_LOG_TILE;          // 2048 elements
 #ifndef SS_NTT_OCC_DIF
 #define SS_NTT_OCC_DIF (SS_NTT_THREADS_DIF / 128)
 #endif
+#ifndef SS_NTT_TW_LDS
+#define SS_NTT_TW_LDS 1            // a strided CTI pass's 2^r - 1 tree nodes staged in LDS once per tile (A/B: 0 = a global load per butterfly group)
+#endif
 // The wave-private phases (NTT_WAVE_SYNC; chunk ownership = threadIdx.x >> 6, log_waves = log2(blockDim.x >> 6)) are written for
 // 64-lane wavefronts and workgroups that are a power-of-two number of them: anything else would corrupt tiles silently.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(HIPEMU) && !defined(__GFX9__)
@@ -132,9 +135,24 @@ typedef lds_u32x4_t __attribute__((address_space(3))) *lds_u32x4_ptr;
 typedef u32 __attribute__((address_space(3))) *lds_u32_ptr;
 static constexpr u32 LDS_TOP_OFF = 0, LDS_LO_OFF = 4u << LOG_TILE_MAX, LDS_HI_OFF = LDS_LO_OFF + (16u << LOG_TILE_MAX),
                      LDS_TILE_BYTES = LDS_HI_OFF + (16u << LOG_TILE_MAX);
+// Behind the tile: the twiddles of a strided CTI pass.  Its 2^r rows are one subtree of the remainder tree for ALL of the tile's
+// adjacent columns q, so a tile reads 2^r - 1 <= 127 distinct plan entries (level by level contiguous in the plan) where a DIT pass
+// reads 2^r - 1 per q: staged once per tile (4.5 KB), read back with 16 lanes per address - instead of one 36-byte global load per
+// butterfly group and lane with its 64-bit address arithmetic.  Local index of node jj of the pass's stage v: (2^(r-1-v) - 1) + jj.
+static constexpr u32 LDS_TW_MAX = 128, LDS_TW_LO_OFF = LDS_TILE_BYTES, LDS_TW_HI_OFF = LDS_TW_LO_OFF + 16u * LDS_TW_MAX,
+                     LDS_TW_TOP_OFF = LDS_TW_HI_OFF + 16u * LDS_TW_MAX, LDS_TOTAL_BYTES = LDS_TW_TOP_OFF + 4u * LDS_TW_MAX;
 struct Tile {
     lds_bytes_ptr base;
+    bool tw_staged;              // this pass reads its twiddles from the LDS copy (wave-uniform)
 };
+__device__ __forceinline__ Fl lds_tw_load(const Tile &t, u32 local) {
+    const lds_u32x4_t a = *(lds_u32x4_ptr)(t.base + LDS_TW_LO_OFF + (local << 4)), b = *(lds_u32x4_ptr)(t.base + LDS_TW_HI_OFF + (local << 4));
+    Fl r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = *(lds_u32_ptr)(t.base + LDS_TW_TOP_OFF + (local << 2));
+    return r;
+}
 struct LdsAddr {          // byte offsets of one element inside the 16-byte planes / the dword plane
     u32 a16, a4;
 };
@@ -393,10 +411,19 @@ __device__ __forceinline__ void radix_group(const Tile &t, const TwPlanes &tw, c
         constexpr bool PRE = SS_NTT_PRELOAD_TW && G <= 2 && MODE != MODE_DIF;
         Fl tw0[PRE ? (1 << G) / 2 : 1], tw1[PRE ? (1 << G) / 2 : 1];
         if (PRE) {                                   // (the two trivial levels of a CTI transform's top group read theirs for nothing)
+            if (MODE == MODE_CTI && t.tw_staged) {   // wave-uniform branch: the tile's staged tree nodes (see LDS_TW_*)
+                const uint32_t jhi = (ebase >> log_t) >> (u + G);          // the group's rows are (jhi << G | m) << u | (row bits below u)
 #pragma unroll
-            for (int pr = 0; pr < (1 << G) / 2; ++pr) {
-                tw0[PRE ? pr : 0] = tw_load(tw, stage_tw_index<MODE, G, 0>(p, u, g0, pr));
-                if (G >= 2) tw1[PRE ? pr : 0] = tw_load(tw, stage_tw_index<MODE, G, 1>(p, u, g0, pr));
+                for (int pr = 0; pr < (1 << G) / 2; ++pr) {
+                    tw0[PRE ? pr : 0] = lds_tw_load(t, ((1u << (p.r - 1u - u)) - 1u) + (jhi << (G - 1)) + (uint32_t)pr);
+                    if (G >= 2) tw1[PRE ? pr : 0] = lds_tw_load(t, ((1u << (p.r - 2u - u)) - 1u) + (jhi << (G >= 2 ? G - 2 : 0)) + (uint32_t)(pr >> 1));
+                }
+            } else {
+#pragma unroll
+                for (int pr = 0; pr < (1 << G) / 2; ++pr) {
+                    tw0[PRE ? pr : 0] = tw_load(tw, stage_tw_index<MODE, G, 0>(p, u, g0, pr));
+                    if (G >= 2) tw1[PRE ? pr : 0] = tw_load(tw, stage_tw_index<MODE, G, 1>(p, u, g0, pr));
+                }
             }
         }
         Fl x[1 << G];
@@ -433,12 +460,13 @@ __device__ __forceinline__ void radix_group(const Tile &t, const TwPlanes &tw, c
 template <int MODE>
 __global__ __launch_bounds__(MODE == MODE_DIF ? SS_NTT_THREADS_DIF : SS_NTT_THREADS, MODE == MODE_DIF ? SS_NTT_OCC_DIF : SS_NTT_OCC)
 void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw_plan, PassParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(SS_NTT_TW_LDS && MODE == MODE_CTI) ? LDS_TOTAL_BYTES : LDS_TILE_BYTES];
     constexpr int NTT_GMAX = MODE == MODE_DIF ? SS_NTT_GMAX_DIF : SS_NTT_GMAX;
     constexpr int LG = LAYOUT_G(MODE);
     const uint32_t tile_elems = 1u << p.log_tile;
     Tile t;
     t.base = (lds_bytes_ptr)smem;
+    t.tw_staged = false;
     TwPlanes tw;
     {
         const uint64_t tw_total = p.tw_entries;
@@ -473,6 +501,22 @@ void ntt_pass_kernel(ColPtrs cols, const Fp *__restrict__ tw_plan, PassParams p)
     // Strided passes read/write HBM from the first/last register group directly; the
     // contiguous pass (tile = one 64 KiB block, first group of stride 1) stages through LDS.
     const bool fuse = !p.contig;
+    if (SS_NTT_TW_LDS && MODE == MODE_CTI && fuse && !p.win_log1 && p.log_tile - p.r <= p.s0 && p.r >= 2 && p.r <= 7 && p.u_first == 0) {
+        // the tile's columns q share q >> s0 (2^(log_tile - r) <= 2^s0 adjacent ones): node jj of stage v is plan entry
+        // (2^level - 1) + (qhi << (r - 1 - v)) + jj, level = log_n - 1 - s0 - v
+        t.tw_staged = true;
+        const uint32_t i = threadIdx.x;
+        if (i < (1u << p.r) - 1u) {
+            const uint32_t k = 31u - (uint32_t)__builtin_clz(i + 1u), v = p.r - 1u - k, jj = i + 1u - (1u << k);
+            const uint32_t qhi = (tile << (p.log_tile - p.r)) >> p.s0, level = p.log_n - 1u - p.s0 - v;
+            const uint32_t idx = ((1u << level) - 1u) + (qhi << k) + jj;
+            const uint4 a4 = tw.lo[idx], b4 = tw.hi[idx];
+            *(lds_u32x4_ptr)(t.base + LDS_TW_LO_OFF + (i << 4)) = lds_u32x4_t{a4.x, a4.y, a4.z, a4.w};
+            *(lds_u32x4_ptr)(t.base + LDS_TW_HI_OFF + (i << 4)) = lds_u32x4_t{b4.x, b4.y, b4.z, b4.w};
+            *(lds_u32_ptr)(t.base + LDS_TW_TOP_OFF + (i << 2)) = tw.top[idx];
+        }
+        __syncthreads();
+    }
     // A tile is 2^log_chunk elements per wave.  A phase is chunk-private when wave w touches the elements [w << log_chunk,
     // (w + 1) << log_chunk) only: the contiguous pass's load and store phases by construction, a register group when its
     // elements' stride stays inside a chunk (sh + G <= log_chunk; radix_group deals a wave the items of one chunk).  Between two

@@ -204,7 +204,8 @@ hipError_t pedersen_tables_create(hipStream_t st, PedersenTables **out) {
     uint32_t forced = 0;
     if (const char *e = getenv("SS_PED_WINDOW")) {
         forced = (uint32_t)strtoul(e, nullptr, 10);
-        if (forced != 16 && forced != 18 && forced != 20 && forced != 22 && forced != 24) return hipErrorInvalidValue;
+        // 26: ten windows per input instead of eleven for an 86 GB table - asked for, never chosen by itself (A/B: profiles/r05_pedersen_*)
+        if (forced != 16 && forced != 18 && forced != 20 && forced != 22 && forced != 24 && forced != 26) return hipErrorInvalidValue;
     }
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return hipErrorInvalidDevice;
@@ -445,28 +446,46 @@ __device__ __forceinline__ u32 ped_next_digit(Fp &c) {
     return d;
 }
 
+// One hash per lane accumulates in XYZZ coordinates (ec252.h: 8M + 2S per mixed addition, a squaring fewer than the Jacobian form;
+// the finish kernel then divides X by ZZ itself instead of squaring an inverse).  A/B: -DSS_PED_XYZZ=0 = the Jacobian form of rounds 1-4.
+#ifndef SS_PED_XYZZ
+#define SS_PED_XYZZ 1
+#endif
+#if SS_PED_XYZZ
+typedef XyzzL PedAcc;
+__device__ __forceinline__ PedAcc ped_acc_start(const Aff &shift) { return PedAcc{fl_from_fp(shift.x), fl_from_fp(shift.y), fl_one(), fl_one()}; }
+__device__ __forceinline__ PedAcc ped_acc_add(const PedAcc &acc, const AffL &q) { return xyzzl_add_aff(acc, q); }
+__device__ __forceinline__ const Fl &ped_acc_den(const PedAcc &acc) { return acc.zz; }
+#else
+typedef JacL PedAcc;
+__device__ __forceinline__ PedAcc ped_acc_start(const Aff &shift) { return PedAcc{fl_from_fp(shift.x), fl_from_fp(shift.y), fl_one()}; }
+__device__ __forceinline__ PedAcc ped_acc_add(const PedAcc &acc, const AffL &q) { return jacl_add_aff(acc, q); }
+__device__ __forceinline__ const Fl &ped_acc_den(const PedAcc &acc) { return acc.z; }
+#endif
+
 // acc += scalar (canonical integer limbs) over input slot e
 template <int W>
-__device__ __forceinline__ void ped_accumulate(JacL &acc, Fp canon, const Aff *__restrict__ table, uint64_t per_input, int e) {
+__device__ __forceinline__ void ped_accumulate(PedAcc &acc, Fp canon, const Aff *__restrict__ table, uint64_t per_input, int e) {
     constexpr uint32_t span = (1u << W) - 1u;
     constexpr int nwin = (PED_BITS + W - 1) / W;
     const Aff *tab = table + (size_t)e * per_input;
 #pragma unroll 1
     for (int w = 0; w < nwin; ++w) {
         const u32 d = ped_next_digit<W>(canon);
-        if (d) acc = jacl_add_aff(acc, load_affl(tab + (size_t)w * span + (d - 1)));
+        if (d) acc = ped_acc_add(acc, load_affl(tab + (size_t)w * span + (d - 1)));
     }
 }
 
-// both inputs canonical (< p); leaves the Jacobian (X, Z) of P0 + a-part + b-part as weakly reduced images
+// both inputs canonical (< p); leaves X and the denominator's root (XYZZ: ZZ itself, x = X / ZZ; Jacobian: Z, x = X / Z^2) of
+// P0 + a-part + b-part as weakly reduced images
 template <int W>
 __device__ __forceinline__ void ped_jacobian(const Fp &a, const Fp &b, const Aff *__restrict__ table, uint64_t per_input, const Aff &shift,
                                              Fp *__restrict__ x_out, Fp *__restrict__ z_out) {
-    JacL acc; acc.x = fl_from_fp(shift.x); acc.y = fl_from_fp(shift.y); acc.z = fl_one();
+    PedAcc acc = ped_acc_start(shift);
     ped_accumulate<W>(acc, a, table, per_input, 0);
     ped_accumulate<W>(acc, b, table, per_input, 1);
     store_felt(x_out, fl_pack(acc.x));            // fn_* results are normalised and < 2p
-    store_felt(z_out, fl_pack(acc.z));
+    store_felt(z_out, fl_pack(ped_acc_den(acc)));
 }
 
 // 32 big-endian bytes -> canonical integer mod p
@@ -717,7 +736,7 @@ __global__ __launch_bounds__(64) void pedersen_pairs_small_kernel(const Aff *__r
     if (sub == 0u) canon_to_be_bytes(fp_from_mont(x), out + 32 * k);
 }
 
-// ---- phase 2: x = X / Z^2, `chunk` hashes per lane (k = j * lanes + lane), one inversion per lane ----
+// ---- phase 2: x = X / ZZ (Jacobian build: X / Z^2), `chunk` hashes per lane (k = j * lanes + lane), one inversion per lane ----
 // Montgomery's trick with the prefix products in tmp[2 count ..).  A point at infinity (Z = 0:
 // unreachable for a hash, kept for totality) yields x = 0 as the per-hash formula did.
 template <bool BYTES>
@@ -744,7 +763,7 @@ __global__ __launch_bounds__(64) void pedersen_finish_kernel(Fp *__restrict__ tm
         if (infinity) z = fl_one();
         const Fl zi = fn_mul(inv, fl_from_fp(load_felt(P + k)));
         inv = fn_mul(inv, z);
-        Fp x = fl_to_fp(fn_mul(fl_from_fp(load_felt(X + k)), fn_sqr(zi)));
+        Fp x = fl_to_fp(fn_mul(fl_from_fp(load_felt(X + k)), SS_PED_XYZZ ? zi : fn_sqr(zi)));     // (XYZZ: the stored denominator is ZZ)
         if (infinity) x = fp_zero();
         if (BYTES) canon_to_be_bytes(fp_from_mont(x), out_bytes + 32 * k);
         else store_felt(out_felts + k, x);
@@ -769,6 +788,7 @@ static hipError_t launch_finish(hipStream_t st, Fp *tmp, uint64_t count, Fp *out
         case 18: { constexpr int W = 18; CALL; } break;                        \
         case 20: { constexpr int W = 20; CALL; } break;                        \
         case 22: { constexpr int W = 22; CALL; } break;                        \
+        case 26: { constexpr int W = 26; CALL; } break;                        \
         default: { constexpr int W = 24; CALL; } break;                        \
     }
 static hipError_t launch_acc_felts(hipStream_t st, const PedersenTables *t, const PedFeltArgs &g, uint64_t count, Fp *tmp) {

@@ -71,6 +71,45 @@ int main() {
         if (!fp_eq(fl_to_fp(back.x), t.x) || !fp_eq(fl_to_fp(back.y), t.y)) { printf("from-infinity mismatch %d\n", i); return 1; }
         checked += 3;
     }
+    // XYZZ (the accumulate kernels, round 5): chains of mixed additions against the plain Jacobian ones - x = X / ZZ, y = Y / ZZZ -,
+    // the doubling and infinity cases, and a start from infinity
+    {
+        auto affine_of = [](const XyzzL &l) {
+            const Fp zz = fl_to_fp(l.zz), zzz = fl_to_fp(l.zzz);
+            return Aff{fp_mul(fl_to_fp(l.x), fp_inv(zz)), fp_mul(fl_to_fp(l.y), fp_inv(zzz))};
+        };
+        for (int chain = 0; chain < 100; ++chain) {
+            const Aff start = pool[splitmix() % pool.size()];
+            Jac acc = lift(start);
+            XyzzL accx{fl_from_fp(start.x), fl_from_fp(start.y), fl_one(), fl_one()};
+            for (int i = 0; i < 24; ++i) {
+                const Aff &q = pool[splitmix() % pool.size()];
+                acc = jac_add_aff(acc, q);
+                accx = xyzzl_add_aff(accx, limb(q));
+                ++checked;
+            }
+            if (fp_is_zero(acc.z) != fp_is_zero(fl_to_fp(accx.zz))) { printf("xyzz: infinity disagreement, chain %d\n", chain); return 1; }
+            if (fp_is_zero(acc.z)) continue;
+            const Aff want = to_affine(acc), got = affine_of(accx);
+            if (!fp_eq(got.x, want.x) || !fp_eq(got.y, want.y)) { printf("xyzz chain mismatch %d\n", chain); return 1; }
+            // ZZ^3 = ZZZ^2 (the representation's invariant)
+            const Fp zz = fl_to_fp(accx.zz), zzz = fl_to_fp(accx.zzz);
+            if (!fp_eq(fp_mul(fp_sqr(zz), zz), fp_sqr(zzz))) { printf("xyzz invariant broken %d\n", chain); return 1; }
+        }
+        for (int i = 0; i < 50; ++i) {
+            const Aff q = pool[splitmix() % pool.size()], t = pool[splitmix() % pool.size()];
+            XyzzL pl{fl_from_fp(q.x), fl_from_fp(q.y), fl_one(), fl_one()};
+            pl = xyzzl_add_aff(pl, limb(t));
+            pl = xyzzl_add_aff(pl, limb(Aff{t.x, fp_neg(t.y)}));        // q again, with ZZ != 1
+            const Aff twice = to_affine(jac_double(lift(q))), got = affine_of(xyzzl_add_aff(pl, limb(q)));
+            if (!fp_eq(got.x, twice.x) || !fp_eq(got.y, twice.y)) { printf("xyzz doubling case mismatch %d\n", i); return 1; }
+            const XyzzL inf = xyzzl_add_aff(pl, limb(Aff{q.x, fp_neg(q.y)}));
+            if (!fp_is_zero(fl_to_fp(inf.zz))) { printf("xyzz infinity case mismatch %d\n", i); return 1; }
+            const XyzzL back = xyzzl_add_aff(inf, limb(t));
+            if (!fp_eq(fl_to_fp(back.x), t.x) || !fp_eq(fl_to_fp(back.y), t.y) || !fp_eq(fl_to_fp(back.zz), fp_one())) { printf("xyzz from-infinity mismatch %d\n", i); return 1; }
+            checked += 3;
+        }
+    }
     // affine + affine (the first round of the lane-split accumulation) against the plain mixed addition: generic pairs, q + q, q - q,
     // and the point at infinity on either or both sides
     for (int i = 0; i < 400; ++i) {

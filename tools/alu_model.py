@@ -19,15 +19,22 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "sandstorm_amd", "_build")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-DEFAULT_RATES = os.path.join(ROOT, "profiles", "r04_ubench_instruction_rates.txt")
+DEFAULT_RATES = os.path.join(ROOT, "profiles", "r05_ubench_instruction_rates.txt")
+if not os.path.exists(DEFAULT_RATES):
+    DEFAULT_RATES = os.path.join(ROOT, "profiles", "r04_ubench_instruction_rates.txt")
+
+
+OWN_CLOCK = [False]
 
 
 def rates(path):
     out = {}
     for line in open(path):
         m = re.match(r"^(v_\w+)\s+[\d.]+ ms\s+[\d.]+ T lane-ops/s\s+~\s*([\d.]+) cyc", line)
+        own = re.search(r"own clock [\d.]+ GHz\s+->\s*([\d.]+) cyc", line)          # round 5: the probe stamps its own clock
         if m and m.group(1) != "v_cndmask_b32":      # (that probe chains on VCC and measures the hazard, not the issue cost: priced as a simple op)
-            out[m.group(1)] = float(m.group(2))
+            out[m.group(1)] = float(own.group(1)) if own else float(m.group(2))
+            OWN_CLOCK[0] = OWN_CLOCK[0] or bool(own)
     return out
 
 
@@ -84,7 +91,8 @@ def main():
                 cyc = sum(n * cost_of(mn, table) for mn, n in mix.items())
                 model[name] = {"object": obj, "valu": valu, "mads": sum(n for mn, n in mix.items() if mn.startswith("v_mad_u64")),
                                "weighted_cycles_per_inst": round(cyc / valu, 4)}
-    out = {"rates_source": os.path.relpath(sys.argv[1] if len(sys.argv) > 1 else DEFAULT_RATES, ROOT), "rates": table, "clock_hz": 2.4e9, "simds": 1024,
+    out = {"rates_source": os.path.relpath(sys.argv[1] if len(sys.argv) > 1 else DEFAULT_RATES, ROOT), "rates": table, "simds": 1024,
+           "cycles_are": "cycles of the probe's own clock (s_memtime / s_memrealtime inside tools/ubench.hip)" if OWN_CLOCK[0] else "cycles at a nominal 2.4 GHz",
            "kernels": model}
     with open(os.path.join(ROOT, "profiles", "alu_model.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
