@@ -437,12 +437,13 @@ enum { SS_PROF_NTT_PASS = 0, SS_PROF_HASH_ROWS = 1, SS_PROF_MERKLE = 2, SS_PROF_
 ss_status ss_profile_enable(ss_ctx *ctx, int on);
 ss_status ss_profile_reset(ss_ctx *ctx);
 ss_status ss_profile_read(ss_ctx *ctx, int kind, double *total_ms, uint64_t *launches);
-/* ss_profile_enable(ctx, 2): besides the events, one wave per XCD stamps the shader-cycle counter (s_memtime) and the
- * constant-rate reference counter (s_memrealtime) right before and after every profiled scope, on its stream.
- * ss_profile_read_clock: the shader cycles and reference ticks accumulated between those stamps since the last reset (mean over
- * the XCDs stamped on both sides) - cycles / ticks x the reference rate (100 MHz) is the clock the chip granted that kernel
- * family, in the run it is read in.  The probes cost a few microseconds per scope: level 2 is for a measuring pass, not a
- * timed one.  (Up to 8192 scopes between two reads carry stamps.) */
+/* ss_profile_enable(ctx, 2): besides the events, every profiled scope stamps the chip's constant-rate reference counter
+ * (s_memrealtime, 100 MHz) before and after its launches, and ONE monitor wave on a stream of its own samples its shader-cycle
+ * counter (s_memtime: one per compute unit, so only a single wave's readings are comparable) against that reference every ~20 us
+ * for as long as level 2 is on (at most 3 s per read interval).  ss_profile_read_clock: the shader cycles - the monitor's count
+ * interpolated at the scopes' reference stamps - and the reference ticks accumulated over this kernel family's scopes since the
+ * last reset: cycles / ticks x 100 MHz is the clock the chip granted those kernels, in the run it is read in.  The stamps cost a
+ * few microseconds per scope: level 2 is for a measuring pass, not a timed one.  (Up to 8192 scopes between two reads.) */
 ss_status ss_profile_read_clock(ss_ctx *ctx, int kind, double *shader_cycles, double *ref_ticks);
 
 /* Host-side pedersen_hash for the Fiat-Shamir coin (CairoVerifierPublicCoin::

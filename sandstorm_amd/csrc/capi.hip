@@ -78,22 +78,50 @@ Fp root_of_unity(uint32_t log_n) {
 
 }  // namespace
 
-// The shader clock of a profiled launch (ss_profile_enable(ctx, 2)): one wave per XCD reads the free-running shader-cycle counter
-// (s_memtime: a tick = one shader cycle) and the constant-rate reference counter (s_memrealtime) right before and right after the
-// launches of a scope, on the scope's stream; cycles / reference ticks between the two stamps of one XCD = the clock the chip
-// granted that kernel (it clocks to its power budget: the transforms run ~15 % below the constraint kernels).
-struct ClockStamp { uint64_t cycles, ref, xcc, pad; };
-static constexpr int CLOCK_PROBE_WGS = 8;
-__global__ void clock_probe_kernel(ClockStamp *out) {
+// The shader clock of a profiled launch (ss_profile_enable(ctx, 2)).  s_memtime is a free-running shader-cycle counter, but one per
+// compute unit (stamps of two waves on different CUs differ by their counters' offsets - measured: a first version that paired
+// before / after stamps by XCD came out at "3.1 GHz"), while s_memrealtime is the chip's one constant-rate reference counter
+// (100 MHz).  So ONE wave - the monitor, launched on a stream of its own when level 2 is switched on - samples its own
+// (s_memtime, s_memrealtime) pair every few microseconds into a ring for as long as the measuring pass lasts, and every profiled
+// scope stamps only the reference counter before and after its launches: the monitor's cycle count interpolated at those two
+// reference times is the shader cycles that passed, cycles / reference ticks x 100 MHz the clock the chip granted the scope's
+// kernels (it clocks to its power budget: the transforms run ~10 % below the constraint kernels).  One DVFS domain is assumed:
+// the monitor's CU clocks as the others do.
+struct ClockStamp { uint64_t cycles, ref; };
+static constexpr uint32_t CLOCK_MONITOR_SLOTS = 1u << 17;          // 2 MB; a sample per ~20 us: 2.6 s of proof
+__device__ __forceinline__ void clock_read(uint64_t &cycles, uint64_t &ref) {
 #if defined(HIPEMU)
-    if (threadIdx.x == 0) out[blockIdx.x] = ClockStamp{0, 0, blockIdx.x, 0};
+    cycles = 0; ref = 0;
 #else
-    if (threadIdx.x == 0) {
-        uint64_t c, r;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r) : : "memory");
-        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;       // hwreg(HW_REG_XCC_ID, 0, 4)
-        out[blockIdx.x] = ClockStamp{c, r, xcc, 0};
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(cycles), "=s"(ref) : : "memory");
+#endif
+}
+__global__ void clock_probe_kernel(ClockStamp *out) {
+    if (threadIdx.x == 0) { ClockStamp s; clock_read(s.cycles, s.ref); *out = s; }
+}
+// one wave: samples until `*stop` is set (the host writes it through a pinned mapping), the ring is full, or max_ticks reference
+// ticks have passed - whichever comes first, so a lost stop flag ends in seconds, not never
+__global__ __launch_bounds__(64) void clock_monitor_kernel(ClockStamp *ring, uint32_t slots, volatile uint32_t *stop, uint64_t max_ticks, uint32_t *count) {
+#if defined(HIPEMU)
+    if (threadIdx.x == 0) *count = 0;
+#else
+    if (threadIdx.x != 0) return;
+    uint64_t c, r, r0, next;
+    clock_read(c, r0);
+    next = r0;
+    uint32_t n = 0;
+    while (n < slots) {
+        clock_read(c, r);
+        if (r >= next) {
+            ring[n].cycles = c; ring[n].ref = r;
+            ++n;
+            next = r + 2000;                                     // 20 us
+            if (*stop || r - r0 > max_ticks) break;
+        }
+        __builtin_amdgcn_s_sleep(32);
     }
+    __threadfence_system();
+    *count = n;
 #endif
 }
 
@@ -152,11 +180,15 @@ struct ss_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[SS_PROF_KINDS];
     double prof_ms[SS_PROF_KINDS] = {0};
     uint64_t prof_launches[SS_PROF_KINDS] = {0};
-    // clock stamps (prof_clock): scope i of the current batch wrote d_stamps[(2 i + {0, 1}) * CLOCK_PROBE_WGS ...]
+    // clock stamps (prof_clock): scope i of the current batch wrote d_stamps[2 i] before and [2 i + 1] after its launches
     static constexpr size_t CLOCK_SCOPES = 8192;
-    ClockStamp *d_stamps = nullptr;
+    ClockStamp *d_stamps = nullptr, *d_ring = nullptr;
+    uint32_t *h_stop = nullptr, *d_count = nullptr;    // pinned, mapped: the monitor's stop flag; its sample count
+    hipStream_t monitor_stream = nullptr;
+    bool monitor_running = false;
+    std::vector<ClockStamp> monitor_samples;           // of the measuring pass so far
     std::vector<int> stamp_kinds;                      // kind of scope i
-    double prof_cycles[SS_PROF_KINDS] = {0}, prof_ref[SS_PROF_KINDS] = {0}, prof_clock_ms[SS_PROF_KINDS] = {0};
+    double prof_cycles[SS_PROF_KINDS] = {0}, prof_ref[SS_PROF_KINDS] = {0};
 
     // bracket one launch with events (only when profiling is on)
     struct Scope {
@@ -165,10 +197,10 @@ struct ss_ctx {
             if (!c->prof_on) return;
             hipEvent_t e0;
             if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e1 = nullptr; return; }
-            if (c->prof_clock && c->d_stamps && c->stamp_kinds.size() < CLOCK_SCOPES) {
+            if (c->prof_clock && c->monitor_running && c->stamp_kinds.size() < CLOCK_SCOPES) {
                 stamp = (long)c->stamp_kinds.size();
                 c->stamp_kinds.push_back(kind);
-                hipLaunchKernelGGL(clock_probe_kernel, dim3(CLOCK_PROBE_WGS), dim3(64), 0, c->stream, c->d_stamps + (2 * stamp) * CLOCK_PROBE_WGS);
+                hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->stream, c->d_stamps + 2 * stamp);
             }
             (void)hipEventRecord(e0, c->stream);
             c->prof_events[kind].push_back({e0, e1});
@@ -176,15 +208,48 @@ struct ss_ctx {
         ~Scope() {
             if (!e1) return;
             (void)hipEventRecord(e1, c->stream);
-            if (stamp >= 0) hipLaunchKernelGGL(clock_probe_kernel, dim3(CLOCK_PROBE_WGS), dim3(64), 0, c->stream, c->d_stamps + (2 * stamp + 1) * CLOCK_PROBE_WGS);
+            if (stamp >= 0) hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->stream, c->d_stamps + 2 * stamp + 1);
         }
     };
-    void prof_collect() {                              // (the stream is synchronised)
-        std::vector<ClockStamp> st;
-        if (!stamp_kinds.empty()) {
-            st.resize(2 * stamp_kinds.size() * CLOCK_PROBE_WGS);
-            if (hipMemcpy(st.data(), d_stamps, st.size() * sizeof(ClockStamp), hipMemcpyDeviceToHost) != hipSuccess) st.clear();
+    hipError_t monitor_start() {
+        if (monitor_running) return hipSuccess;
+        hipError_t e = hipSuccess;
+        if (!d_stamps) {
+            void *p = nullptr;
+            if ((e = malloc_retry(&p, 2 * CLOCK_SCOPES * sizeof(ClockStamp))) != hipSuccess) return e;
+            d_stamps = (ClockStamp *)p;
+            if ((e = malloc_retry(&p, CLOCK_MONITOR_SLOTS * sizeof(ClockStamp))) != hipSuccess) return e;
+            d_ring = (ClockStamp *)p;
+            if ((e = hipHostMalloc((void **)&h_stop, 2 * sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess) return e;
+            d_count = h_stop + 1;
+            if ((e = hipStreamCreateWithFlags(&monitor_stream, hipStreamNonBlocking)) != hipSuccess) return e;
         }
+        h_stop[0] = 0; h_stop[1] = 0;
+        monitor_samples.clear();
+        hipLaunchKernelGGL(clock_monitor_kernel, dim3(1), dim3(64), 0, monitor_stream, d_ring, CLOCK_MONITOR_SLOTS, (volatile uint32_t *)h_stop, (uint64_t)300000000ull /* 3 s */, d_count);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        monitor_running = true;
+        return hipSuccess;
+    }
+    void monitor_stop() {                               // -> monitor_samples
+        if (!monitor_running) return;
+        *(volatile uint32_t *)h_stop = 1;
+        (void)hipStreamSynchronize(monitor_stream);
+        monitor_running = false;
+        const uint32_t n = ((volatile uint32_t *)h_stop)[1];
+        monitor_samples.resize(n);
+        if (n && hipMemcpy(monitor_samples.data(), d_ring, n * sizeof(ClockStamp), hipMemcpyDeviceToHost) != hipSuccess) monitor_samples.clear();
+    }
+    // the monitor's cycle count at reference time `ref`, linearly between its two samples around it (-1: outside the samples)
+    double monitor_cycles_at(uint64_t ref) const {
+        const std::vector<ClockStamp> &m = monitor_samples;
+        if (m.size() < 2 || ref < m.front().ref || ref > m.back().ref) return -1.0;
+        size_t lo = 0, hi = m.size() - 1;
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (m[mid].ref <= ref) lo = mid; else hi = mid; }
+        const double span = (double)(m[hi].ref - m[lo].ref);
+        return (double)(m[lo].cycles - m.front().cycles) + (span > 0 ? (double)(m[hi].cycles - m[lo].cycles) * (double)(ref - m[lo].ref) / span : 0.0);
+    }
+    void prof_collect() {                              // (the stream is synchronised)
         for (int k = 0; k < SS_PROF_KINDS; ++k) {
             for (auto &pr : prof_events[k]) {
                 float ms = 0;
@@ -193,20 +258,20 @@ struct ss_ctx {
             }
             prof_events[k].clear();
         }
-        // per scope: the XCDs stamped on both sides (a probe's workgroups land one per XCD; matched by the XCC id they read)
-        for (size_t i = 0; i < stamp_kinds.size() && !st.empty(); ++i) {
-            const ClockStamp *a = st.data() + (2 * i) * CLOCK_PROBE_WGS, *b = a + CLOCK_PROBE_WGS;
-            double cyc = 0, ref = 0;
-            int matched = 0;
-            for (int x = 0; x < CLOCK_PROBE_WGS; ++x)
-                for (int y = 0; y < CLOCK_PROBE_WGS; ++y)
-                    if (a[x].xcc == b[y].xcc && b[y].ref > a[x].ref && b[y].cycles > a[x].cycles) {
-                        cyc += (double)(b[y].cycles - a[x].cycles); ref += (double)(b[y].ref - a[x].ref); ++matched;
-                        break;
-                    }
-            if (matched) { prof_cycles[stamp_kinds[i]] += cyc / matched; prof_ref[stamp_kinds[i]] += ref / matched; }
-        }
+        if (stamp_kinds.empty()) return;
+        // the scopes' reference stamps against the monitor's samples: the monitor is stopped (and restarted if the pass goes on)
+        const bool again = monitor_running;
+        monitor_stop();
+        std::vector<ClockStamp> st(2 * stamp_kinds.size());
+        if (hipMemcpy(st.data(), d_stamps, st.size() * sizeof(ClockStamp), hipMemcpyDeviceToHost) == hipSuccess)
+            for (size_t i = 0; i < stamp_kinds.size(); ++i) {
+                const double c0 = monitor_cycles_at(st[2 * i].ref), c1 = monitor_cycles_at(st[2 * i + 1].ref);
+                if (c0 < 0 || c1 <= c0 || st[2 * i + 1].ref <= st[2 * i].ref) continue;
+                prof_cycles[stamp_kinds[i]] += c1 - c0;
+                prof_ref[stamp_kinds[i]] += (double)(st[2 * i + 1].ref - st[2 * i].ref);
+            }
         stamp_kinds.clear();
+        if (again) (void)monitor_start();
     }
 
     ss_status ensure_scratch(size_t bytes) {
@@ -413,7 +478,11 @@ void ss_ctx_destroy(ss_ctx *ctx) {
     ctx->pool_trim();
     for (auto &kv : ctx->pool_live) hipFree(kv.first);     // leaked by the caller
     pedersen_tables_destroy(ctx->ped);
+    ctx->monitor_stop();
     if (ctx->d_stamps) hipFree(ctx->d_stamps);
+    if (ctx->d_ring) hipFree(ctx->d_ring);
+    if (ctx->h_stop) hipHostFree(ctx->h_stop);
+    if (ctx->monitor_stream) hipStreamDestroy(ctx->monitor_stream);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->scratch2) hipFree(ctx->scratch2);
     if (ctx->transient_tw) hipFree(ctx->transient_tw);
@@ -648,12 +717,8 @@ ss_status ss_comm_all_gather(ss_comm *comm, const void *d_send, uint64_t bytes, 
 
 ss_status ss_profile_enable(ss_ctx *ctx, int on) {
     if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
-    if (on == 2 && !ctx->d_stamps) {
-        void *p = nullptr;
-        HIP_TRY(ctx->malloc_retry(&p, 2 * ss_ctx::CLOCK_SCOPES * CLOCK_PROBE_WGS * sizeof(ClockStamp)));
-        ctx->d_stamps = (ClockStamp *)p;
-    }
-    if (ctx->prof_clock && on != 2) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->prof_collect(); }
+    if (ctx->prof_clock && on != 2) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->prof_collect(); ctx->monitor_stop(); }
+    if (on == 2 && !ctx->prof_clock) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx->monitor_start()); }
     ctx->prof_on = on != 0;
     ctx->prof_clock = on == 2;
     return SS_OK;

@@ -85,7 +85,10 @@ static constexpr int LOG_TILE_MAX = SS_NTT_LOG_TILE;          // 2048 elements
 #define SS_NTT_OCC_DIF (SS_NTT_THREADS_DIF / 128)
 #endif
 #ifndef SS_NTT_TW_LDS
-#define SS_NTT_TW_LDS 1            // a strided CTI pass's 2^r - 1 tree nodes staged in LDS once per tile (A/B: 0 = a global load per butterfly group)
+// 1: a strided CTI pass's 2^r - 1 tree nodes staged in LDS once per tile instead of a global load per butterfly group (VERDICT r4
+// #2; built and MEASURED in round 5, profiles/r05_ntt_twiddles_lds.txt: batch LDE 44.0-44.4 ms from global memory, 44.2-44.6 ms from
+// LDS - the loads it replaces were L1 hits of 16 lanes per address already, and the tile pays a barrier for the staging).  Off.
+#define SS_NTT_TW_LDS 0
 #endif
 // The wave-private phases (NTT_WAVE_SYNC; chunk ownership = threadIdx.x >> 6, log_waves = log2(blockDim.x >> 6)) are written for
 // 64-lane wavefronts and workgroups that are a power-of-two number of them: anything else would corrupt tiles silently.
