@@ -98,6 +98,14 @@ ss_status ss_dev_free(ss_ctx *ctx, void *d_ptr);
 ss_status ss_ctx_trim(ss_ctx *ctx);
 ss_status ss_upload(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 ss_status ss_download(ss_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+/* Upload without the wait: the copy is enqueued on a copy stream of the context's own and returns at once (src: pinned host memory
+ * that stays untouched until the copy is done - the `GpuAllocator` seam, layouts/src/recursive/trace.rs:115-120); *ticket names it.
+ * ss_wait_upload(ctx, ticket) orders everything enqueued on the context's stream AFTERWARDS behind that copy (a stream wait: the
+ * host does not block); a ticket is waited for once.  ss_upload_async may be called from another host thread than the one that
+ * drives the context - the trace generator's, which uploads a column the moment no section will write it again, while the prover
+ * already extends the columns that have arrived (`Stark::prove` starts from the witness: src/lib.rs:94-100). */
+ss_status ss_upload_async(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes, uint64_t *ticket);
+ss_status ss_wait_upload(ss_ctx *ctx, uint64_t ticket);
 /* zero-fill on the ctx stream (`Vec::resize(trace_len, Fp::ZERO)`, layouts/src/recursive/trace.rs:741-748) */
 ss_status ss_dev_zero(ss_ctx *ctx, void *d_ptr, size_t bytes);
 

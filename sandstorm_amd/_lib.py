@@ -123,6 +123,8 @@ SIGNATURES = {
     "ss_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ss_profile_reset": (C.c_int, [C.c_void_p]),
     "ss_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), _u64p]),
+    "ss_upload_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _u64p]),
+    "ss_wait_upload": (C.c_int, [C.c_void_p, C.c_uint64]),
     "ss_profile_read_clock": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ss_fp252_mul_bench": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
 }

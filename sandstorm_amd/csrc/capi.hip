@@ -176,6 +176,12 @@ struct ss_ctx {
         return e;
     }
 
+    // ss_upload_async: copies on a stream of their own, an event per copy (ticket = slot + 1); the only context state another
+    // host thread may touch while the owner enqueues kernels (the trace generator's thread uploads a column the moment it is final)
+    hipStream_t copy_stream = nullptr;
+    std::mutex copy_mutex;
+    std::vector<hipEvent_t> copy_events;               // nullptr: slot free
+
     bool prof_on = false, prof_clock = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[SS_PROF_KINDS];
     double prof_ms[SS_PROF_KINDS] = {0};
@@ -445,7 +451,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns, ss_upload_async / ss_wait_upload (uploads on a copy stream, ordered into the context's stream by ticket)
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -479,6 +485,8 @@ void ss_ctx_destroy(ss_ctx *ctx) {
     for (auto &kv : ctx->pool_live) hipFree(kv.first);     // leaked by the caller
     pedersen_tables_destroy(ctx->ped);
     ctx->monitor_stop();
+    for (hipEvent_t ev : ctx->copy_events) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->d_stamps) hipFree(ctx->d_stamps);
     if (ctx->d_ring) hipFree(ctx->d_ring);
     if (ctx->h_stop) hipHostFree(ctx->h_stop);
@@ -555,6 +563,34 @@ ss_status ss_upload(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes) {
     if (!ctx || (!d_dst && bytes) || (!src && bytes)) return fail(SS_ERR_INVALID, "NULL argument");
     HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SS_OK;
+}
+ss_status ss_upload_async(ss_ctx *ctx, void *d_dst, const void *src, size_t bytes, uint64_t *ticket) {
+    if (!ctx || !ticket || (!d_dst && bytes) || (!src && bytes)) return fail(SS_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->copy_mutex);
+    HIP_TRY(hipSetDevice(ctx->device));                // (the caller may be a thread that has never touched the device)
+    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(ev, ctx->copy_stream);
+    if (e != hipSuccess) { (void)hipEventDestroy(ev); return fail(SS_ERR_HIP, "%s", hipGetErrorString(e)); }
+    size_t slot = 0;
+    while (slot < ctx->copy_events.size() && ctx->copy_events[slot]) ++slot;
+    if (slot == ctx->copy_events.size()) ctx->copy_events.push_back(nullptr);
+    ctx->copy_events[slot] = ev;
+    *ticket = slot + 1;
+    return SS_OK;
+}
+ss_status ss_wait_upload(ss_ctx *ctx, uint64_t ticket) {
+    if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->copy_mutex);
+    if (ticket == 0 || ticket > ctx->copy_events.size() || !ctx->copy_events[ticket - 1]) return fail(SS_ERR_INVALID, "no such upload ticket (a ticket is waited for once)");
+    hipEvent_t ev = ctx->copy_events[ticket - 1];
+    ctx->copy_events[ticket - 1] = nullptr;
+    const hipError_t e = hipStreamWaitEvent(ctx->stream, ev, 0);
+    (void)hipEventDestroy(ev);                          // (the wait keeps what it needs of the event)
+    if (e != hipSuccess) return fail(SS_ERR_HIP, "%s", hipGetErrorString(e));
     return SS_OK;
 }
 ss_status ss_dev_zero(ss_ctx *ctx, void *d_ptr, size_t bytes) {

@@ -1,6 +1,11 @@
 // host_capi.cpp — C entry points of libsandstorm_host.so: the C++ prover for callers
 // without C++ (bench.py and the tests reach it through ctypes).
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -340,6 +345,167 @@ int ssh_air_create_starknet(ss_ctx *ctx, uint32_t rc_min, uint32_t rc_max, uint6
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }
+// ---- files -> proof with generation, upload and the first transforms overlapped (cli/src/main.rs:200-202 times
+// generate_trace + prove).  A trace job is a layout's generator with its inputs parsed: layout 1 = recursive, 2 = starknet; the
+// public input as in ssh_public_coin_seed; instances / counts as ssh_starknet_base_trace takes them (the recursive layout reads
+// pedersen, range_check and bitwise: entries 0, 1, 3).
+namespace {
+struct TraceJob {
+    uint32_t ncols = 0;
+    uint64_t n = 0;
+    std::vector<uint32_t> order;                 // the order the columns become final in (the generators' column_done calls)
+    std::function<void(Felt *const *out, const std::function<void(int)> *done)> run;
+};
+TraceJob make_trace_job(int layout, const uint8_t *trace_bin, uint64_t trace_len, const uint8_t *memory_bin, uint64_t memory_len, uint32_t rc_min,
+                        uint32_t rc_max, uint64_t n_steps, const uint32_t *segments, const uint32_t *mem_addresses, const uint64_t *mem_values,
+                        uint64_t n_mem, const uint64_t *const *instances, const uint64_t *counts) {
+    if (layout != 1 && layout != 2) throw std::runtime_error("layout: 1 = recursive, 2 = starknet");
+    auto pi = std::make_shared<AirPublicInput>();
+    pi->layout = layout == 1 ? "recursive" : "starknet";
+    pi->rc_min = (uint16_t)rc_min; pi->rc_max = (uint16_t)rc_max; pi->n_steps = n_steps;
+    for (int k = 0; k < 9; ++k) { pi->segments[k].present = segments[3 * k] != 0; pi->segments[k].begin_addr = segments[3 * k + 1]; pi->segments[k].stop_ptr = segments[3 * k + 2]; }
+    pi->public_memory.resize(n_mem);
+    for (uint64_t i = 0; i < n_mem; ++i) { pi->public_memory[i].address = mem_addresses[i]; memcpy(pi->public_memory[i].value.data(), mem_values + 4 * i, 32); }
+    auto val = [](const uint64_t *rec, int k) { U256 v; memcpy(v.data(), rec + 1 + 4 * k, 32); return v; };
+    auto cnt = [&](int k) -> uint64_t { return counts && instances && instances[k] ? counts[k] : 0; };
+    auto priv = std::make_shared<StarknetPrivateInput>();
+    for (uint64_t i = 0; i < cnt(0); ++i) { const uint64_t *r = instances[0] + 9 * i; priv->pedersen.push_back(PedersenInstance{(uint32_t)r[0], val(r, 0), val(r, 1)}); }
+    for (uint64_t i = 0; i < cnt(1); ++i) { const uint64_t *r = instances[1] + 5 * i; priv->range_check.push_back(RangeCheckInstance{(uint32_t)r[0], val(r, 0)}); }
+    for (uint64_t i = 0; i < cnt(2); ++i) { const uint64_t *r = instances[2] + 17 * i; priv->ecdsa.push_back(EcdsaInstance{(uint32_t)r[0], val(r, 0), val(r, 1), val(r, 2), val(r, 3)}); }
+    for (uint64_t i = 0; i < cnt(3); ++i) { const uint64_t *r = instances[3] + 9 * i; priv->bitwise.push_back(BitwiseInstance{(uint32_t)r[0], val(r, 0), val(r, 1)}); }
+    for (uint64_t i = 0; i < cnt(4); ++i) { const uint64_t *r = instances[4] + 21 * i; priv->ec_op.push_back(EcOpInstance{(uint32_t)r[0], val(r, 0), val(r, 1), val(r, 2), val(r, 3), val(r, 4)}); }
+    for (uint64_t i = 0; i < cnt(5); ++i) { const uint64_t *r = instances[5] + 13 * i; priv->poseidon.push_back(PoseidonInstance{(uint32_t)r[0], {val(r, 0), val(r, 1), val(r, 2)}}); }
+    auto states = std::make_shared<std::vector<RegisterState>>(read_register_states(trace_bin, trace_len));
+    auto memory = std::make_shared<std::vector<U256>>();
+    auto present = std::make_shared<std::vector<uint8_t>>();
+    read_memory(memory_bin, memory_len, *memory, *present);
+    TraceJob job;
+    job.n = 16 * (uint64_t)states->size();
+    if (layout == 1) {
+        job.ncols = 7;
+        job.order = {0, 6, 5, 1, 2, 3, 4};        // flags, auxiliary, range check, the diluted pair, memory pool, sorted memory
+        job.run = [=](Felt *const *out, const std::function<void(int)> *done) {
+            PrivateInput rp;
+            rp.pedersen = priv->pedersen; rp.range_check = priv->range_check; rp.bitwise = priv->bitwise;
+            recursive_base_trace_into(out, *states, *memory, *present, *pi, rp, done);
+        };
+    } else {
+        job.ncols = 9;
+        job.order = {0, 1, 2, 3, 4, 7, 8, 5, 6};  // flags, the four Pedersen columns, range check, auxiliary, memory pool, sorted memory
+        job.run = [=](Felt *const *out, const std::function<void(int)> *done) {
+            Felt *o[9];
+            for (int c = 0; c < 9; ++c) o[c] = out[c];
+            starknet_base_trace_into(o, *states, *memory, *present, *pi, *priv, done);
+        };
+    }
+    return job;
+}
+}  // namespace
+
+// the generators with a per-column callback: column_done(user, c) is called (on the calling thread, between two sections of the
+// generator) as soon as column c of columns_out is final.  order_out (optional, room for 9): the order the callbacks come in.
+typedef void (*ssh_column_cb)(void *user, int column);
+int ssh_base_trace_cb(int layout, const uint8_t *trace_bin, uint64_t trace_len, const uint8_t *memory_bin, uint64_t memory_len, uint32_t rc_min,
+                      uint32_t rc_max, uint64_t n_steps, const uint32_t *segments, const uint32_t *mem_addresses, const uint64_t *mem_values,
+                      uint64_t n_mem, const uint64_t *const *instances, const uint64_t *counts, uint64_t *const *columns_out, ssh_column_cb column_done,
+                      void *user, uint32_t *order_out) {
+    try {
+        const TraceJob job = make_trace_job(layout, trace_bin, trace_len, memory_bin, memory_len, rc_min, rc_max, n_steps, segments, mem_addresses, mem_values,
+                                            n_mem, instances, counts);
+        if (order_out) for (uint32_t k = 0; k < job.ncols; ++k) order_out[k] = job.order[k];
+        const std::function<void(int)> done = [&](int c) { if (column_done) column_done(user, c); };
+        job.run(reinterpret_cast<Felt *const *>(columns_out), &done);
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// `sandstorm-cli prove` from the raw files to the proof bytes in ONE call: the generator runs on a thread of its own and writes the
+// caller's PINNED host columns (the GpuAllocator seam, layouts/src/recursive/trace.rs:115-120); every column leaves for the device
+// (d_cols) on the context's copy stream the moment it is final (ss_upload_async), and the prover - on the calling thread - extends
+// the columns as they land (ColumnFeed) and goes on as ssh_prove_wire does.  times_out (optional, 2 doubles): the generator's wall
+// time and the whole call's.  The proof is the one ssh_prove_wire writes from the same columns (tests/test_gpu_full_size.py).
+int ssh_prove_files(ss_ctx *ctx, int layout, const uint8_t *trace_bin, uint64_t trace_len, const uint8_t *memory_bin, uint64_t memory_len, uint32_t rc_min,
+                    uint32_t rc_max, uint64_t n_steps, const uint32_t *segments, const uint32_t *mem_addresses, const uint64_t *mem_values, uint64_t n_mem,
+                    const uint64_t *const *instances, const uint64_t *counts, uint64_t *const *pinned_cols, uint64_t *const *d_cols, ssh_air *air_h,
+                    int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32], ssh_extension_cb cb, void *user,
+                    const uint32_t options[5], double *times_out, uint8_t **proof_bytes, uint64_t *proof_len) {
+    try {
+        if (!ctx || !air_h || !seed || !pinned_cols || !d_cols) throw std::runtime_error("ssh_prove_files: NULL argument");
+        const auto t_start = std::chrono::steady_clock::now();
+        const TraceJob job = make_trace_job(layout, trace_bin, trace_len, memory_bin, memory_len, rc_min, rc_max, n_steps, segments, mem_addresses, mem_values,
+                                            n_mem, instances, counts);
+        Air *air = reinterpret_cast<Air *>(air_h);
+        if (air->num_base_columns != job.ncols) throw std::runtime_error("ssh_prove_files: the AIR is another layout's");
+        Claim claim;
+        claim.air = air; claim.tree_kind = tree_kind; claim.n_friendly_layers = n_friendly_layers; claim.coin_kind = coin_kind;
+        ProofOptions opt;
+        if (options) {
+            opt.num_queries = options[0]; opt.lde_blowup_factor = options[1]; opt.grinding_factor = options[2];
+            opt.fri_folding_factor = options[3]; opt.fri_max_remainder_coeffs = options[4];
+        }
+        std::mutex m;
+        std::condition_variable cv;
+        std::vector<uint64_t> ticket(job.ncols, 0);
+        bool failed = false;
+        std::string err;
+        double gen_s = 0.0;
+        const std::function<void(int)> done = [&](int c) {           // the generator's thread: column c is final -> its upload leaves
+            uint64_t t = 0;
+            const ss_status st = ss_upload_async(ctx, d_cols[c], pinned_cols[c], 32 * (size_t)job.n, &t);
+            std::lock_guard<std::mutex> lk(m);
+            if (st != SS_OK) { failed = true; err = ss_last_error(); } else ticket[c] = t;
+            cv.notify_all();
+        };
+        std::thread producer([&] {
+            try { job.run(reinterpret_cast<Felt *const *>(pinned_cols), &done); }
+            catch (const std::exception &e) { std::lock_guard<std::mutex> lk(m); failed = true; err = e.what(); cv.notify_all(); }
+            gen_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        });
+        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{producer};      // (also when the prover throws)
+        Matrix base;
+        base.nrows = job.n;
+        for (uint32_t c = 0; c < job.ncols; ++c) base.cols.push_back(d_cols[c]);
+        ColumnFeed feed;
+        feed.order = job.order;
+        feed.wait = [&](uint32_t c) {
+            uint64_t t;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return ticket[c] != 0 || failed; });
+                if (failed) throw std::runtime_error(err);
+                t = ticket[c];
+            }
+            if (ss_wait_upload(ctx, t) != SS_OK) throw std::runtime_error(ss_last_error());
+        };
+        Digest sd;
+        memcpy(sd.data(), seed, 32);
+        Prover prover(ctx, claim, opt);
+        prover.set_base_feed(feed);
+        uint32_t log_n = 0;
+        while ((1ull << log_n) < job.n) ++log_n;
+        Proof proof = prover.prove(sd, base, [&](const std::vector<Felt> &ch) {
+            Matrix ext;
+            ext.nrows = base.nrows;
+            std::vector<uint64_t> flat(4 * ch.size());
+            for (size_t i = 0; i < ch.size(); ++i) memcpy(flat.data() + 4 * i, ch[i].data(), 32);
+            std::vector<uint64_t *> cols(air->num_extension_columns, nullptr);
+            if (!cb || cb(user, flat.data(), (uint32_t)ch.size(), cols.data()) != 0) throw std::runtime_error("extension callback failed");
+            ext.cols = cols;
+            return ext;
+        });
+        producer.join();
+        if (ss_ctx_sync(ctx) != SS_OK) throw std::runtime_error(ss_last_error());
+        if (times_out) { times_out[0] = gen_s; times_out[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); }
+        if (proof_bytes && proof_len) {
+            const std::vector<uint8_t> b = proof.serialize_wire();
+            *proof_bytes = (uint8_t *)malloc(b.size());
+            memcpy(*proof_bytes, b.data(), b.size());
+            *proof_len = b.size();
+        }
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
 // the lowered composition program for these challenges and its table descriptions, as one u64 blob:
 // n_instr, code words..., n_consts, 4 limbs each..., n_slots, then layout_air_tables()
 int ssh_air_dump(ssh_air *air_h, uint64_t n, const uint64_t *challenges, uint32_t nchallenges, const uint64_t alpha[4], uint64_t **blob, uint64_t *blob_len) {

@@ -204,8 +204,19 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
 
     // 2. base trace: interpolate, extend, commit
     Matrix base_lde = Matrix::alloc(ctx_, base_trace.num_cols(), N), base_co = Matrix::alloc(ctx_, base_trace.num_cols(), n);
-    ok(ss_lde_fp252(ctx_, (const uint64_t *const *)base_trace.cols.data(), base_trace.num_cols(), log_n, lb, g.data(),
-                    base_lde.cols.data(), base_co.cols.data()));
+    if (feed_.wait) {                        // the columns as they land (ColumnFeed): one transform pair per column, in arrival order
+        if (feed_.order.size() != base_trace.num_cols()) throw std::runtime_error("the column feed's order must name every base column once");
+        std::vector<uint8_t> seen(base_trace.num_cols(), 0);
+        for (uint32_t c : feed_.order) {
+            if (c >= base_trace.num_cols() || seen[c]++) throw std::runtime_error("the column feed's order must name every base column once");
+            feed_.wait(c);
+            const uint64_t *in = base_trace.cols[c];
+            ok(ss_lde_fp252(ctx_, &in, 1, log_n, lb, g.data(), &base_lde.cols[c], &base_co.cols[c]));
+        }
+    } else {
+        ok(ss_lde_fp252(ctx_, (const uint64_t *const *)base_trace.cols.data(), base_trace.num_cols(), log_n, lb, g.data(),
+                        base_lde.cols.data(), base_co.cols.data()));
+    }
     mark("base lde");
     auto base_tree = commit(base_lde);
     mark("base commit");

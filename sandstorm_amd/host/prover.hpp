@@ -159,6 +159,16 @@ void fri_open(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Pro
 // extension columns, resident in HBM
 using ExtensionBuilder = std::function<Matrix(const std::vector<Felt> &challenges)>;
 
+// Base columns that arrive while the proof is already running: `wait(c)` returns once everything enqueued on the context's stream
+// from then on sees column c of the base trace (the trace generator's thread uploads a column the moment no section will write it
+// again: trace_*.hpp column_done, ss_upload_async / ss_wait_upload); `order` = the order the columns become final in.  The base
+// trace is then extended column by column as it lands instead of as one batch - `Stark::prove` starts from the witness
+// (src/lib.rs:94-100, cli/src/main.rs:200-202): generation, upload and the first transforms overlap.
+struct ColumnFeed {
+    std::function<void(uint32_t)> wait;
+    std::vector<uint32_t> order;
+};
+
 class Prover {
 public:
     Prover(ss_ctx *ctx, const Claim &claim, const ProofOptions &opt = ProofOptions(), const Conventions &conv = Conventions())
@@ -169,6 +179,7 @@ public:
     // finds first - `find_any`, crypto/src/public_coin/solidity.rs:120-141); the GPU grinder returns the smallest.
     // Supplying the reference's nonce makes the whole proof comparable byte for byte.
     void set_pow_nonce(uint64_t nonce) { have_nonce_ = true; nonce_ = nonce; }
+    void set_base_feed(ColumnFeed feed) { feed_ = std::move(feed); }
 private:
     bool have_nonce_ = false;
     uint64_t nonce_ = 0;
@@ -176,6 +187,7 @@ private:
     Claim claim_;
     ProofOptions opt_;
     Conventions conv_;
+    ColumnFeed feed_;
 };
 
 // the layouts' AIRs

@@ -70,7 +70,9 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
 // the same into the caller's columns (pinned host memory the upload reads straight from: the GpuAllocator seam of
 // layouts/src/recursive/trace.rs:115-120); every cell is written
 void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
-                               const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv) {
+                               const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv,
+                               const std::function<void(int)> *column_done) {
+    auto done = [&](std::initializer_list<int> cs) { if (column_done && *column_done) for (int c : cs) (*column_done)(c); };
     const HostThreadsScope host_threads_scope;              // OpenMP threads by the cgroup's CPU quota (trace_common.hpp)
     const bool timing = getenv("SSH_TRACE_TIMING") != nullptr;   // diagnostic: per-section wall time on stderr
     auto t_prev = std::chrono::steady_clock::now();
@@ -165,6 +167,7 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
     for (auto &part : rc_count_of) for (size_t v = 0; v < part.size(); ++v) rc_count[v] += part[v];
 
     mark("cpu cells");
+    done({COL_FLAGS});
     // ---- range-check builtin instances, ordered values and padding (trace.rs:131-160, 236-284; utils.rs:357-380)
     struct Rc128 { uint32_t index; U256 value; };
     std::vector<Rc128> rc128;
@@ -268,6 +271,7 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
         }
     }
     mark("pedersen");
+    done({COL_AUXILIARY});
     // ---- range-check builtin cells
     {
         const uint64_t step = RANGE_CHECK_BUILTIN_RATIO * CYCLE_HEIGHT;
@@ -279,6 +283,7 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
         }
     }
     mark("rc builtin");
+    done({COL_RANGE_CHECK});
     // ---- bitwise builtin and the diluted check (trace.rs:420-588)
     {
         const uint64_t step = BITWISE_RATIO * CYCLE_HEIGHT;
@@ -350,6 +355,7 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
             }
     }
     mark("bitwise + diluted");
+    done({COL_DILUTED_UNORDERED, COL_DILUTED_ORDERED});
     // ---- gap fillers (trace.rs:594-625)
     {
         const std::vector<uint64_t> gaps = memory_gaps(npc_addr, pi.public_memory, num_cycles);
@@ -357,9 +363,11 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
         for (size_t k = 0; k < gaps.size(); ++k) set_pair(k * CYCLE_HEIGHT + NPC_UNUSED_ADDR, gaps[k], zero);
     }
     mark("gap fill");
+    done({COL_NPC});
     // ---- sorted memory (get_ordered_memory_accesses, utils.rs:112-152)
     ordered_memory_into(out[COL_MEMORY], n, npc_addr, out[COL_NPC], n / PUBLIC_MEMORY_STEP, pi.public_memory, pad_value);
     mark("sorted memory");
+    done({COL_MEMORY});
 }
 
 }  // namespace ssh

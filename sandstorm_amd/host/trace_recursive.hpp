@@ -4,6 +4,7 @@
 // Mirror: sandstorm_amd/layouts/recursive.py::base_trace, against which tests/test_layout_recursive.py checks it cell
 // for cell; that module also holds the 93 constraints the trace is validated with.
 #pragma once
+#include <functional>
 #include <cstdint>
 #include <vector>
 
@@ -33,7 +34,10 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
                                                     const PrivateInput &priv);
 
 // the same into the caller's 7 columns of 16 * cycles felts each (every cell is written)
+// column_done (optional): called with c as soon as no section will write column c again (flags after the CPU cells, auxiliary after
+// Pedersen, range check after its builtin, the diluted pair after bitwise, the memory pool after the gap fillers, sorted memory last)
 void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
-                               const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv);
+                               const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv,
+                               const std::function<void(int)> *column_done = nullptr);
 
 }  // namespace ssh

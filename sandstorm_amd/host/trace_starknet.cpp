@@ -267,7 +267,9 @@ PoseidonTrace poseidon_trace(const std::array<Felt, 3> &input) {       // poseid
 }  // namespace
 
 void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
-                              const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv) {
+                              const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv,
+                              const std::function<void(int)> *column_done) {
+    auto done = [&](std::initializer_list<int> cs) { if (column_done && *column_done) for (int c : cs) (*column_done)(c); };
     const HostThreadsScope host_threads_scope;              // OpenMP threads by the cgroup's CPU quota (trace_common.hpp)
     const uint64_t num_cycles = states.size();
     if (!num_cycles || (num_cycles & (num_cycles - 1))) fail("the number of cycles must be a power of two");
@@ -395,6 +397,7 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
     parallel_for(n / DILUTED_CHECK_STEP, [&](uint64_t k) { rc_col[8 * k + DC_UNORDERED] = rc_col[8 * k + DC_ORDERED] = zero; });      // trace.rs:294-302
 
     lap("cpu cells + range-check pool");
+    done({COL_FLAGS});
     // ---- Pedersen (trace.rs:304-386)
     {
         std::map<uint32_t, const PedersenInstance *> given;
@@ -450,6 +453,7 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         });
     }
     lap("pedersen");
+    done({COL_PEDERSEN_X, COL_PEDERSEN_Y, COL_PEDERSEN_SUFFIX, COL_PEDERSEN_SLOPE});
     // ---- range-check builtin (trace.rs:388-426)
     {
         const uint64_t step = RANGE_CHECK_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[4].begin_addr;
@@ -659,6 +663,7 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         });
     }
     lap("poseidon");
+    done({COL_RANGE_CHECK, COL_AUXILIARY});
     // ---- gap fillers (trace.rs:890-925)
     {
         const std::vector<uint64_t> gaps = memory_gaps(npc_addr, pi.public_memory, num_cycles);
@@ -666,9 +671,11 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         for (size_t k = 0; k < gaps.size(); ++k) set_pair(k * CYCLE_HEIGHT + NPC_UNUSED_ADDR, gaps[k], zero);
     }
     lap("gap fillers");
+    done({COL_NPC});
     // ---- sorted memory (get_ordered_memory_accesses, utils.rs:112-152)
     ordered_memory_into(out[COL_MEMORY], n, npc_addr, out[COL_NPC], n / PUBLIC_MEMORY_STEP, pi.public_memory, pad_value);
     lap("sorted memory");
+    done({COL_MEMORY});
 }
 
 std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,

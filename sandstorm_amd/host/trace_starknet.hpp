@@ -4,6 +4,7 @@
 // Mirror: sandstorm_amd/layouts/starknet.py::base_trace, which is pinned to the reference's own proof of its bootloader
 // run; tests/test_layout_starknet.py compares the two cell for cell on that run.
 #pragma once
+#include <functional>
 #include "trace_recursive.hpp"
 
 namespace ssh {
@@ -24,8 +25,12 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
                                                    const StarknetPrivateInput &priv);
 
 // the same into caller-owned columns of 16 * states.size() felts each (every cell is written)
+// column_done (optional): called with c as soon as no section will write column c again - flags after the CPU cells, the four
+// Pedersen columns after their builtin, range check and auxiliary after Poseidon, the memory pool after the gap fillers, the
+// sorted memory last - so that an upload of c can leave while the rest is still being generated (host/prover.hpp ColumnFeed)
 void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
-                              const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv);
+                              const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv,
+                              const std::function<void(int)> *column_done = nullptr);
 
 // shared with the AIR (air_starknet.cpp): StarkWare's Hades round constants, the curve's generator and beta
 const std::vector<std::array<Felt, 3>> &poseidon_round_keys();

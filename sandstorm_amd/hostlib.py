@@ -460,6 +460,88 @@ def starknet_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=N
     return cols
 
 
+_INSTANCE_SHAPES = (("pedersen", 9), ("range_check", 5), ("ecdsa", 17), ("bitwise", 9), ("ec_op", 21), ("poseidon", 13))
+COLUMN_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+
+
+def _trace_job_args(layout, trace_bin, memory_bin, pi, private_input):
+    """the arguments ssh_base_trace_cb / ssh_prove_files share (host_capi.cpp make_trace_job); -> (args, keep-alive)"""
+    if len(trace_bin) % 24:
+        raise _lib.SandstormHipError("host: trace file is not a sequence of (ap, fp, pc) u64 triples")
+    private_input = private_input or {}
+    segs, addrs, vals = _public_input_args(pi)
+    arrays = [_instances(private_input.get(name, []), width) for name, width in _INSTANCE_SHAPES]
+    counts = np.array([len(private_input.get(name, [])) for name, _ in _INSTANCE_SHAPES], dtype=np.uint64)
+    inst = (C.c_void_p * 6)(*[a.ctypes.data for a in arrays])
+    u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    args = (1 if layout == "recursive" else 2, trace_bin, len(trace_bin), memory_bin, len(memory_bin), pi.rc_min, pi.rc_max, pi.n_steps,
+            segs.ctypes.data_as(u32p), addrs.ctypes.data_as(u32p), vals.ctypes.data_as(u64p), len(addrs), inst, counts.ctypes.data_as(u64p))
+    return args, (segs, addrs, vals, arrays, counts, inst)
+
+
+_TRACE_JOB_ARGTYPES = [C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32),
+                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+
+
+def base_trace_with_callback(layout, trace_bin: bytes, memory_bin: bytes, pi, private_input=None, out=None, column_done=None):
+    """either layout's generator (as recursive_base_trace / starknet_base_trace) calling column_done(c) as soon as no section will
+    write column c again (host/trace_*.hpp) -> (columns, the order the callbacks came in as the library announces it)"""
+    ncols = 7 if layout == "recursive" else 9
+    cols = _trace_out(out, ncols, 16 * (len(trace_bin) // 24))
+    ptrs = (C.c_void_p * ncols)(*[c.ctypes.data for c in cols])
+    args, keep = _trace_job_args(layout, trace_bin, memory_bin, pi, private_input)
+    fn = load().ssh_base_trace_cb
+    fn.argtypes = _TRACE_JOB_ARGTYPES + [C.POINTER(C.c_void_p), COLUMN_CB, C.c_void_p, C.POINTER(C.c_uint32)]
+    cb = COLUMN_CB((lambda _u, c: column_done(int(c))) if column_done else (lambda _u, c: None))
+    order = (C.c_uint32 * 9)()
+    _check(fn(*args, ptrs, cb, None, order))
+    del keep
+    return cols, [int(order[k]) for k in range(ncols)]
+
+
+def prove_files(ctx, layout, trace_bin: bytes, memory_bin: bytes, pi, private_input, pinned_cols, dev_cols, air: HostAir, tree_kind, n_friendly,
+                coin_kind, seed, build_extension, options=None, want_proof=True):
+    """`sandstorm-cli prove` in one call (host_capi.cpp ssh_prove_files): the generator on a thread of its own writes `pinned_cols`
+    (pinned host arrays [16 * cycles, 4] of 8-byte items), every column is uploaded to `dev_cols` the moment it is final, the prover
+    extends the columns as they land.  -> (proof bytes in the reference's wire format or None, {"trace_gen_s", "total_s"})"""
+    options = options or ProofOptions()
+    ncols = 7 if layout == "recursive" else 9
+    n = 16 * (len(trace_bin) // 24)
+    views = _trace_out(pinned_cols, ncols, n)
+    if len(dev_cols) != ncols:
+        raise _lib.SandstormHipError("host: %d device columns for a layout of %d" % (len(dev_cols), ncols))
+    host_ptrs = (C.c_void_p * ncols)(*[c.ctypes.data for c in views])
+    args, keep_args = _trace_job_args(layout, trace_bin, memory_bin, pi, private_input)
+    keep = []
+
+    def cb(_user, ch_ptr, nch, out_ptr):
+        try:
+            ch = [np.array([ch_ptr[4 * i + k] for k in range(4)], dtype=np.uint64) for i in range(nch)]
+            cols = build_extension(ch)
+            keep.append(cols)
+            for i, col in enumerate(cols):
+                out_ptr[i] = be._ptr_of(col)
+            return 0
+        except Exception:                       # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+    opts = (C.c_uint32 * 5)(options.num_queries, options.lde_blowup_factor, options.grinding_factor,
+                            options.fri_folding_factor, options.fri_max_remainder_coeffs)
+    fn = load().ssh_prove_files
+    fn.argtypes = [C.c_void_p] + _TRACE_JOB_ARGTYPES + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p, EXT_CB, C.c_void_p,
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
+    out, ln, times = C.POINTER(C.c_uint8)(), C.c_uint64(), (C.c_double * 2)()
+    _check(fn(ctx.handle, *args, host_ptrs, be._ptr_array(dev_cols), air.h, tree_kind, n_friendly, coin_kind, bytes(seed), EXT_CB(cb), None, opts, times,
+              C.byref(out) if want_proof else None, C.byref(ln) if want_proof else None))
+    del keep_args
+    raw = None
+    if want_proof:
+        raw = bytes(bytearray(out[:ln.value]))
+        load().ssh_free(out)
+    return raw, {"trace_gen_s": times[0], "total_s": times[1]}
+
+
 def verify(air: HostAir, tree_kind, coin_kind, seed, proof: bytes, shipped_conventions=True, fri_alpha_times_offset=True,
            required_security_bits=80, expected_options=None, n_friendly_layers=22):
     """the C++ host's verifier (sandstorm_amd/host/verifier.cpp) on a proof in the reference's wire format; raises

@@ -119,6 +119,7 @@ static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSucc
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
 enum { hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocMapped = 2 };
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }     // every "stream" of the emulation runs its work at once
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned = 0) { return hipMalloc(p, bytes); }
 static inline hipError_t hipHostFree(void *p) { return hipFree(p); }

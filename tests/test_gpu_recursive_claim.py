@@ -163,3 +163,49 @@ def test_recursive_2p20_steps_cairo_verifier_claim():
     Pedersen above, both digest variants on the wire"""
     raw = prove_and_verify(20)
     assert len(raw) > 200_000
+
+
+@pytest.mark.parametrize("log_steps", [14, 16])
+def test_files_to_proof_in_one_call_writes_the_same_bytes(log_steps, request):
+    """hostlib.prove_files (host_capi.cpp ssh_prove_files; what bench.py's end_to_end leg times): the generator on a thread of its own
+    writes pinned columns, every column is uploaded the moment it is final (ss_upload_async), the prover extends the columns as they
+    land (one transform pair per column, in arrival order) - the proof is the one the batch path writes: the committed 2^14-step
+    fixture, and this run's own 2^16-step proof"""
+    import numpy as np
+    from sandstorm_amd import backend as be, binary, hostlib, public_input
+    from sandstorm_amd.layouts import recursive as rec
+    if log_steps == 14:
+        with open(os.path.join(ROOT, "tests", "golden", "array_sum_recursive_cairo.proof"), "rb") as f:
+            want = f.read()
+    else:
+        want = request.getfixturevalue("proof_2p16")
+    states, memory, pi = recursive_example(log_steps)
+    trace_bin, memory_bin = binary.write_register_states(states), binary.write_memory(memory)
+    del states, memory
+    log_n = log_steps + 4
+    n = 1 << log_n
+    ctx = be.Context(0)
+    try:
+        import torch
+        pinned = [torch.empty((n, 4), dtype=torch.int64).pin_memory() if torch.cuda.is_available() else torch.empty((n, 4), dtype=torch.int64) for _ in range(7)]
+        views = [t.numpy().view("uint64") for t in pinned]
+    except ImportError:
+        views = [np.zeros((n, 4), dtype=np.uint64) for _ in range(7)]
+    dev = [ctx.alloc(32 * n) for _ in range(7)]
+    air = hostlib.RecursiveHostAir(ctx, pi, log_n)
+    seed = public_input.public_coin_seed(pi, be.COIN_CAIRO)
+    aux_idx = (rec.COL_NPC, rec.COL_MEMORY, rec.COL_RANGE_CHECK, rec.COL_DILUTED_UNORDERED, rec.COL_DILUTED_ORDERED)
+    keep = []
+
+    def build_extension(challenges):
+        keep.append(hostlib.build_extension_columns(ctx, "recursive", [dev[c] for c in aux_idx], n, challenges))
+        return keep[-1].cols
+    for _ in range(2):                                   # twice: tickets and events are per call
+        raw, times = hostlib.prove_files(ctx, "recursive", trace_bin, memory_bin, pi, None, views, dev, air, be.TREE_FRIENDLY, N_FRIENDLY, be.COIN_CAIRO, seed,
+                                         build_extension)
+        assert raw == want
+        assert 0 < times["trace_gen_s"] <= times["total_s"]
+    for m in keep:
+        m.close()
+    air.close()
+    ctx.close()

@@ -325,3 +325,31 @@ for addr in (0xFFFFFFF0, 1 << 24):
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), EX)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.count("REFUSED") == 2, out.stdout[-1000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("layout", ["recursive", "starknet"])
+def test_column_done_is_called_when_a_column_is_final(layout):
+    """the generators' column_done callbacks (host/trace_*.hpp; ssh_prove_files uploads a column the moment its callback comes): at
+    callback time the column already holds what it holds at the end, every column is announced once, in the announced order"""
+    import numpy as np
+    from sandstorm_amd import binary, examples, hostlib
+    if layout == "recursive":
+        states, memory, pi = examples.recursive_example(14)
+        plain = hostlib.recursive_base_trace
+    else:
+        states, memory, pi = examples.starknet_example(17)             # (the reference's own run: its diluted values need 2^17 steps)
+        plain = hostlib.starknet_base_trace
+    trace_bin, memory_bin = binary.write_register_states(states), binary.write_memory(memory)
+    ncols, n = (7, 16 << 14) if layout == "recursive" else (9, 16 << 17)
+    out = [np.full((n, 4), 0xA5A5A5A5A5A5A5A5, dtype=np.uint64) for _ in range(ncols)]          # (not zero: a cell nobody wrote would show)
+    seen, snap = [], {}
+
+    def done(c):
+        seen.append(c)
+        snap[c] = out[c].copy()
+    cols, order = hostlib.base_trace_with_callback(layout, trace_bin, memory_bin, pi, None, out, done)
+    assert seen == order and sorted(seen) == list(range(ncols))
+    want = plain(trace_bin, memory_bin, pi)
+    for c in range(ncols):
+        assert np.array_equal(cols[c], want[c]), "column %d" % c
+        assert np.array_equal(snap[c], want[c]), "column %d was announced before it was final" % c
