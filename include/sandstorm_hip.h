@@ -61,14 +61,16 @@ enum {
     SS_HASH_KECCAK = 0,       /* Keccak256HashFn           keccak.rs:13-59  */
     SS_HASH_KECCAK_M20 = 1,   /* MaskedKeccak256HashFn<20> keccak.rs:61-98  */
     SS_HASH_BLAKE2S = 2,      /* Blake2sHashFn             blake2s.rs:10-62 */
-    SS_HASH_BLAKE2S_M20 = 3   /* MaskedBlake2sHashFn<20>   blake2s.rs:64-100 */
+    SS_HASH_BLAKE2S_M20 = 3,  /* MaskedBlake2sHashFn<20>   blake2s.rs:64-100 */
+    SS_HASH_SHA256 = 4        /* ministark's Sha256HashFn (cli/src/main.rs:105,119: the 64-bit field's claim); FIPS 180-4; ss_hash_rows_gl64 only */
 };
 /* Merkle tree types chosen by src/claims.rs:12-33 */
 enum {
     SS_TREE_KECCAK = 0,       /* LeafVariantMerkleTree<Keccak256HashFn>           */
     SS_TREE_KECCAK_M20 = 1,   /* LeafVariantMerkleTree<MaskedKeccak256HashFn<20>> */
     SS_TREE_FRIENDLY = 2,     /* FriendlyMerkleTree<N, PedersenHashFn>            */
-    SS_TREE_BLAKE2S = 3       /* MatrixMerkleTree over Blake2sHashFn (blake2s.rs:10-62): the 64-bit field's trees here */
+    SS_TREE_BLAKE2S = 3,      /* MatrixMerkleTree over Blake2sHashFn (blake2s.rs:10-62): the 64-bit field's trees here */
+    SS_TREE_SHA256 = 4        /* MatrixMerkleTreeImpl<Sha256HashFn> (cli/src/main.rs:119): node = SHA-256(left || right), digests as leaves */
 };
 enum { SS_LEAF_DIGEST = 0, SS_LEAF_FELT = 1 };
 enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
@@ -344,8 +346,9 @@ ss_status ss_running_product_gl64x3(ss_ctx *ctx, const uint64_t *d_num_addr, con
 /* H1 / openings for matrices of 8-byte elements: digest i = Keccak-256 or Blake2s-256 (hash_kind) of row i's elements as little-endian bytes, segment by
  * segment (element e of segment s = d_segments[s][i * seg_len + e]): a trace matrix is nseg columns with seg_len 1, the rows of
  * an Fq3 FRI layer ([len][3] interleaved, row j = {evals[j + k rows]}) are nseg = fold segments d_evals + 3 k rows of seg_len 3.
- * The tree over the digests is ss_merkle_build's SS_TREE_KECCAK / SS_TREE_BLAKE2S.  (The reference instantiates this field with ministark's
- * SHA-256 trees, un-vendored: this is the library's own choice for it.)  ss_gather_rows_gl64: the opened rows, to HOST memory
+ * The tree over the digests is ss_merkle_build's SS_TREE_KECCAK / SS_TREE_BLAKE2S / SS_TREE_SHA256.  (The reference instantiates this
+ * field with ministark's Sha256HashFn trees, cli/src/main.rs:105,119 - SS_HASH_SHA256 / SS_TREE_SHA256 here, the hash pinned by the
+ * FIPS 180-4 vectors; how ministark lays a row out as bytes is not in the reference: little-endian elements, as for the other two.)  ss_gather_rows_gl64: the opened rows, to HOST memory
  * [nidx][nseg][seg_len]. */
 ss_status ss_hash_rows_gl64(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len,
                             uint64_t nrows, uint8_t *d_digests);

@@ -123,6 +123,49 @@ void or_blake2s256(const uint8_t *msg, size_t len, uint8_t out[32]) {
     memcpy(out, h, 32);
 }
 
+/* ------------------------------------------------------------- SHA-256
+ * FIPS 180-4 sections 4.1.2, 4.2.2, 5.1.1, 5.3.3, 6.2.  The reference names ministark's Sha256HashFn for its 64-bit-field claim
+ * (cli/src/main.rs:105,119-120; the `sha2` crate behind it is the same function): pinned by the standard's own vectors
+ * (tests/test_oracle_golden.py) - the one part of that claim a public document pins. */
+static const uint32_t SHA_K[64] = {
+    0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u,
+    0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+    0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u,
+    0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+    0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+    0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+static uint32_t sha_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+static void sha256_block(uint32_t h[8], const uint8_t blk[64]) {
+    uint32_t w[64];
+    for (int t = 0; t < 16; ++t) w[t] = ((uint32_t)blk[4 * t] << 24) | ((uint32_t)blk[4 * t + 1] << 16) | ((uint32_t)blk[4 * t + 2] << 8) | blk[4 * t + 3];
+    for (int t = 16; t < 64; ++t) {
+        const uint32_t s0 = sha_rotr(w[t - 15], 7) ^ sha_rotr(w[t - 15], 18) ^ (w[t - 15] >> 3);
+        const uint32_t s1 = sha_rotr(w[t - 2], 17) ^ sha_rotr(w[t - 2], 19) ^ (w[t - 2] >> 10);
+        w[t] = w[t - 16] + s0 + w[t - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int t = 0; t < 64; ++t) {
+        const uint32_t t1 = hh + (sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[t] + w[t];
+        const uint32_t t2 = (sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+void or_sha256(const uint8_t *msg, size_t len, uint8_t out[32]) {
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    const uint64_t bits = (uint64_t)len * 8;
+    while (len >= 64) { sha256_block(h, msg); msg += 64; len -= 64; }
+    uint8_t blk[128];
+    memset(blk, 0, sizeof blk);
+    memcpy(blk, msg, len);
+    blk[len] = 0x80;
+    const size_t total = len + 9 <= 64 ? 64 : 128;
+    for (int i = 0; i < 8; ++i) blk[total - 1 - i] = (uint8_t)(bits >> (8 * i));
+    sha256_block(h, blk);
+    if (total == 128) sha256_block(h, blk + 64);
+    for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+}
+
 /* --------------------------------------------------- reference hash rules */
 void or_apply_mask(int kind, uint8_t d[32]) {
     if (kind == OR_HASH_KECCAK_M20) memset(d + 20, 0, 12);      /* hash/mod.rs:5-13  */

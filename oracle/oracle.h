@@ -44,6 +44,7 @@ fp_t or_poly_eval(const fp_t *coeffs, size_t n, fp_t x);
 /* ---- hash.c */
 void or_keccak256(const uint8_t *msg, size_t len, uint8_t out[32]);
 void or_blake2s256(const uint8_t *msg, size_t len, uint8_t out[32]);
+void or_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);       /* FIPS 180-4 (the 64-bit field's Sha256HashFn: cli/src/main.rs:105,119) */
 void or_apply_mask(int kind, uint8_t d[32]);
 void or_hash_bytes(int kind, const uint8_t *msg, size_t len, uint8_t out[32]);
 void or_hash_elements(int kind, const fp_t *e, size_t n, uint8_t out[32]);

@@ -143,6 +143,12 @@ def keccak256(data: bytes) -> bytes:
     return bytes(out)
 
 
+def sha256(data: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    lib().or_sha256(bytes(data), C.c_size_t(len(data)), out)
+    return out.raw
+
+
 def blake2s256(data: bytes) -> bytes:
     out = (C.c_uint8 * 32)()
     lib().or_blake2s256(data, C.c_size_t(len(data)), out)

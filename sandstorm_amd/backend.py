@@ -28,8 +28,8 @@ NATURAL, BITREV = 0, 1
 FRI_BITREV_ROWS, FRI_UNNORMALISED = 1, 2
 FORWARD, INVERSE = 0, 1
 NTT_PART_LOCAL, NTT_PART_CROSS = 0, 1
-HASH_KECCAK, HASH_KECCAK_M20, HASH_BLAKE2S, HASH_BLAKE2S_M20 = 0, 1, 2, 3
-TREE_KECCAK, TREE_KECCAK_M20, TREE_FRIENDLY, TREE_BLAKE2S = 0, 1, 2, 3
+HASH_KECCAK, HASH_KECCAK_M20, HASH_BLAKE2S, HASH_BLAKE2S_M20, HASH_SHA256 = 0, 1, 2, 3, 4
+TREE_KECCAK, TREE_KECCAK_M20, TREE_FRIENDLY, TREE_BLAKE2S, TREE_SHA256 = 0, 1, 2, 3, 4
 LEAF_DIGEST, LEAF_FELT = 0, 1
 COIN_SOLIDITY, COIN_CAIRO = 0, 1
 PROF_NTT_PASS, PROF_HASH_ROWS, PROF_MERKLE, PROF_FRI, PROF_QUOTIENT, PROF_DEEP, PROF_EXT = range(7)

@@ -451,7 +451,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns, ss_upload_async / ss_wait_upload (uploads on a copy stream, ordered into the context's stream by ticket)
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns, ss_upload_async / ss_wait_upload (uploads on a copy stream, ordered into the context's stream by ticket), SS_HASH_SHA256 / SS_TREE_SHA256 for the 64-bit field's rows and trees
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -989,7 +989,8 @@ ss_status ss_merkle_build_ex(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_lay
                              uint8_t root_out[33]) {
     if (!ctx || !d_leaves || !d_nodes) return fail(SS_ERR_INVALID, "NULL argument");
     if (n < 2 || (n & (n - 1))) return fail(SS_ERR_INVALID, "n must be a power of two >= 2");
-    if (tree_kind < 0 || tree_kind > 3) return fail(SS_ERR_INVALID, "bad tree kind");
+    if (tree_kind < 0 || tree_kind > SS_TREE_SHA256) return fail(SS_ERR_INVALID, "bad tree kind");
+    if (tree_kind == SS_TREE_SHA256 && leaf_kind != SS_LEAF_DIGEST) return fail(SS_ERR_UNSUPPORTED, "SHA-256 trees take digests as leaves");
     if (leaf_kind != SS_LEAF_DIGEST && leaf_kind != SS_LEAF_FELT) return fail(SS_ERR_INVALID, "bad leaf kind %d", leaf_kind);
     if (leaf_order != SS_ORDER_NATURAL && leaf_order != SS_ORDER_BITREV) return fail(SS_ERR_INVALID, "bad leaf order %d", leaf_order);
     uint32_t log_n = 0;
@@ -1003,7 +1004,7 @@ ss_status ss_merkle_build_ex(ss_ctx *ctx, int tree_kind, uint32_t n_friendly_lay
     }
     hipStream_t s = ctx->stream;
     const int hk = tree_kind == SS_TREE_KECCAK ? SS_HASH_KECCAK : tree_kind == SS_TREE_KECCAK_M20 ? SS_HASH_KECCAK_M20
-                 : tree_kind == SS_TREE_BLAKE2S ? SS_HASH_BLAKE2S : SS_HASH_BLAKE2S_M20;
+                 : tree_kind == SS_TREE_BLAKE2S ? SS_HASH_BLAKE2S : tree_kind == SS_TREE_SHA256 ? SS_HASH_SHA256 : SS_HASH_BLAKE2S_M20;
     if (tree_kind == SS_TREE_FRIENDLY && !ctx->ped) HIP_TRY(pedersen_tables_create(s, &ctx->ped));
     Fp *ped_tmp = nullptr;
     if (tree_kind == SS_TREE_FRIENDLY) {
@@ -2245,13 +2246,14 @@ ss_status ss_running_product_gl64x3(ss_ctx *ctx, const uint64_t *d_num_addr, con
 ss_status ss_hash_rows_gl64(ss_ctx *ctx, int hash_kind, const uint64_t *const *d_segments, uint32_t nseg, uint32_t seg_len, uint64_t nrows,
                             uint8_t *d_digests) {
     if (!ctx || !d_segments || !d_digests) return fail(SS_ERR_INVALID, "NULL argument");
-    if (hash_kind != SS_HASH_KECCAK && hash_kind != SS_HASH_BLAKE2S) return fail(SS_ERR_INVALID, "hash kind %d: Keccak-256 or Blake2s-256", hash_kind);
+    if (hash_kind != SS_HASH_KECCAK && hash_kind != SS_HASH_BLAKE2S && hash_kind != SS_HASH_SHA256)
+        return fail(SS_ERR_INVALID, "hash kind %d: Keccak-256, Blake2s-256 or SHA-256", hash_kind);
     if (nseg == 0 || nseg > (uint32_t)MAX_COLS || seg_len == 0 || seg_len > 64) return fail(SS_ERR_UNSUPPORTED, "row shape %u x %u out of range", nseg, seg_len);
     ConstColPtrs segs;
     memset(&segs, 0, sizeof segs);
     for (uint32_t c = 0; c < nseg; ++c) { if (!d_segments[c]) return fail(SS_ERR_INVALID, "NULL segment"); segs.p[c] = d_segments[c]; }
     ss_ctx::Scope prof(ctx, SS_PROF_HASH_ROWS);
-    HIP_TRY(launch_hash_rows_u64(ctx->stream, hash_kind == SS_HASH_KECCAK ? 0 : 1, segs, nseg, seg_len, nrows, d_digests));
+    HIP_TRY(launch_hash_rows_u64(ctx->stream, hash_kind == SS_HASH_KECCAK ? 0 : hash_kind == SS_HASH_SHA256 ? 2 : 1, segs, nseg, seg_len, nrows, d_digests));
     return SS_OK;
 }
 

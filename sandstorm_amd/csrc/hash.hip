@@ -425,6 +425,92 @@ __global__ void gather8_kernel(const uint8_t *__restrict__ in, const uint64_t *_
 }
 
 // -------------------------------------------------------------- launchers
+// ---------------------------------------------------------------- SHA-256 (FIPS 180-4)
+// The reference instantiates its 64-bit-field claim with ministark's Sha256HashFn trees (cli/src/main.rs:105,119: un-vendored;
+// the hash itself is public: FIPS 180-4, pinned by its vectors in tests/test_goldilocks.py).  Rows of 8-byte elements as their
+// little-endian bytes, like the other two hashes of ss_hash_rows_gl64; a node is SHA-256(left || right).
+__device__ __forceinline__ uint32_t sha_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }      // -> v_alignbit_b32
+__device__ __constant__ uint32_t SHA256_K[64] = {
+    0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u,
+    0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+    0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u,
+    0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+    0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+    0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+__device__ __forceinline__ void sha256_init(uint32_t h[8]) {
+    h[0] = 0x6a09e667u; h[1] = 0xbb67ae85u; h[2] = 0x3c6ef372u; h[3] = 0xa54ff53au; h[4] = 0x510e527fu; h[5] = 0x9b05688cu; h[6] = 0x1f83d9abu; h[7] = 0x5be0cd19u;
+}
+// one 64-byte block: w[0..15] = its big-endian words (clobbered: the schedule runs in place)
+__device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16]) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+        if (t >= 16) {
+            const uint32_t w15 = w[(t + 1) & 15], w2 = w[(t + 14) & 15];
+            const uint32_t s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3), s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);
+            w[t & 15] = w[t & 15] + s0 + w[(t + 9) & 15] + s1;
+        }
+        const uint32_t S1 = sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25), ch = (e & f) ^ (~e & g);
+        const uint32_t t1 = hh + S1 + ch + SHA256_K[t] + w[t & 15];
+        const uint32_t S0 = sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22), maj = (a & b) ^ (a & c) ^ (b & c);
+        const uint32_t t2 = S0 + maj;
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+__device__ __forceinline__ void sha256_store_digest(const uint32_t h[8], uint8_t *out) {
+    uint4 *q = reinterpret_cast<uint4 *>(out);
+    q[0] = make_uint4(bswap32(h[0]), bswap32(h[1]), bswap32(h[2]), bswap32(h[3]));
+    q[1] = make_uint4(bswap32(h[4]), bswap32(h[5]), bswap32(h[6]), bswap32(h[7]));
+}
+// rows of 8-byte elements (ss_hash_rows_gl64's shape): 8 elements per block, then the padding (0x80, zeros, the bit length)
+__global__ __launch_bounds__(256) void sha256_rows_u64_kernel(ConstColPtrs segs, uint32_t nseg, uint32_t seg_len, uint64_t nrows,
+                                                              uint8_t *__restrict__ out) {
+    const uint32_t nelem = nseg * seg_len;
+    const uint32_t nblocks = (8 * nelem + 9 + 63) / 64;                  // message + 0x80 + 8 length bytes
+    for (uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; row < nrows; row += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t h[8];
+        sha256_init(h);
+        uint32_t seg = 0, e = 0;
+        for (uint32_t blk = 0; blk < nblocks; ++blk) {
+            uint32_t w[16];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t idx = 8 * blk + i;
+                uint64_t v = 0;
+                if (idx < nelem) {
+                    const uint64_t *sp = reinterpret_cast<const uint64_t *>(segs.p[0]);
+#pragma unroll
+                    for (int c = 1; c < MAX_COLS; ++c) if (seg == (uint32_t)c) sp = reinterpret_cast<const uint64_t *>(segs.p[c]);
+                    v = sp[row * seg_len + e];
+                    if (++e == seg_len) { e = 0; ++seg; }
+                } else if (idx == nelem) v = 0x80ull;                     // the byte after the message (little-endian image of the element slot)
+                // the element's little-endian bytes b0..b7 are message bytes: big-endian words (b0 b1 b2 b3), (b4 b5 b6 b7)
+                w[2 * i] = bswap32((uint32_t)v); w[2 * i + 1] = bswap32((uint32_t)(v >> 32));
+            }
+            if (blk == nblocks - 1) { w[14] = 0; w[15] = 64u * nelem; }  // bit length (< 2^32: rows of at most 16 x 64 elements)
+            sha256_compress(h, w);
+        }
+        sha256_store_digest(h, out + 32 * row);
+    }
+}
+// node = SHA-256(left || right): one data block and the constant padding block of a 64-byte message
+__global__ __launch_bounds__(256) void sha256_pairs_kernel(const uint8_t *__restrict__ in, uint64_t count, uint8_t *__restrict__ out) {
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < count; k += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t h[8], w[16];
+        const uint4 *q = reinterpret_cast<const uint4 *>(in + 64 * k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { uint4 v = q[i]; w[4 * i] = bswap32(v.x); w[4 * i + 1] = bswap32(v.y); w[4 * i + 2] = bswap32(v.z); w[4 * i + 3] = bswap32(v.w); }
+        sha256_init(h);
+        sha256_compress(h, w);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = 0;
+        w[0] = 0x80000000u; w[15] = 512u;
+        sha256_compress(h, w);
+        sha256_store_digest(h, out + 32 * k);
+    }
+}
+
 static inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t cap) {
     uint64_t g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -463,6 +549,7 @@ __global__ __launch_bounds__(256) void blake2s_rows_u64_kernel(ConstColPtrs segs
 
 hipError_t launch_hash_rows_u64(hipStream_t st, int kind, const ConstColPtrs &segs, uint32_t nseg, uint32_t seg_len, uint64_t nrows, uint8_t *digests) {
     if (kind == 0) hipLaunchKernelGGL(keccak_rows_u64_kernel, dim3(grid_for(nrows, 256, 1u << 20)), dim3(256), 0, st, segs, nseg, seg_len, nrows, digests);
+    else if (kind == 2) hipLaunchKernelGGL(sha256_rows_u64_kernel, dim3(grid_for(nrows, 256, 1u << 20)), dim3(256), 0, st, segs, nseg, seg_len, nrows, digests);
     else hipLaunchKernelGGL(blake2s_rows_u64_kernel, dim3(grid_for(nrows, 256, 1u << 20)), dim3(256), 0, st, segs, nseg, seg_len, nrows, digests);
     return hipGetLastError();
 }
@@ -499,7 +586,9 @@ hipError_t launch_bitrev_copy(hipStream_t st, const Fp *src, uint32_t log_n, Fp 
 }
 hipError_t launch_hash_pairs(hipStream_t st, int kind, const uint8_t *in, uint64_t count, uint8_t *out) {
     const uint32_t grid = grid_for(count, 256, 1u << 20);
-    if (kind == 0 || kind == 1)
+    if (kind == 4)                              // SS_HASH_SHA256 (the header's enum is not included here)
+        hipLaunchKernelGGL(sha256_pairs_kernel, dim3(grid), dim3(256), 0, st, in, count, out);
+    else if (kind == 0 || kind == 1)
         hipLaunchKernelGGL(keccak_pairs_kernel, dim3(grid), dim3(256), 0, st, in, count, out, kind == 1);
     else
         hipLaunchKernelGGL(blake2s_pairs_kernel, dim3(grid), dim3(256), 0, st, in, count, out, kind == 3);

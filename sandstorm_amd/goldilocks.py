@@ -9,7 +9,10 @@ src/lib.rs:75-125), with this library's own choices where the reference is silen
     is therefore an Fp polynomial, and the mask / out-of-domain values / DEEP terms are per coordinate column;
   * trees: Blake2s-256 (the reference's Blake2sHashFn; a quarter of Keccak's cost on this chip) over the rows' little-endian bytes
     (ss_hash_rows_gl64) and ss_merkle_build's SS_TREE_BLAKE2S, natural row order; coin: the Keccak coin of the 252-bit path
-    (coin.PublicCoin), a field element = 8 drawn bytes below p;
+    (coin.PublicCoin), a field element = 8 drawn bytes below p.  Options(hash="sha256") takes the parts the reference NAMES for
+    the claim instead (cli/src/main.rs:119-120): SHA-256 row digests and trees (SS_HASH_SHA256 / SS_TREE_SHA256: FIPS 180-4, the
+    one thing about this claim a public document pins - tests/test_oracle_golden.py, tests/test_goldilocks.py) and a coin of the
+    reference's own shape with SHA-256 inside (PublicCoinImpl's internals are ministark's: un-vendored);
   * composition H(x) = H0(x^2) + x H1(x^2) (two Fq3 columns = six coordinate columns), out-of-domain point z^2 for them;
   * FRI: fold 8, the layer's challenge as drawn, values normalised; remainder = coefficients of the last layer.
 What is checked instead of parity: each kernel against the oracle (tests/test_goldilocks.py), and that proofs of true statements
@@ -37,6 +40,12 @@ class Options:
     grinding: int = 16
     fold: int = 8
     max_remainder: int = 16
+    # "blake2s": this library's choice for the field (Blake2s-256 trees, the Keccak coin of the 252-bit path).  "sha256": the parts
+    # the reference names for the claim (cli/src/main.rs:119-120): MatrixMerkleTreeImpl<Sha256HashFn> trees (SS_HASH_SHA256 rows,
+    # SS_TREE_SHA256 nodes: FIPS 180-4) and a coin of the reference's own shape with SHA-256 inside (PublicCoinImpl<Fq3, Sha256HashFn>
+    # is ministark's, un-vendored: reseed = H(be32(digest + 1) || bytes), draw = H(digest || be32(counter)) as in
+    # crypto/src/public_coin/solidity.rs:54-118); the proof-of-work hash stays Keccak (ss_pow_grind's)
+    hash: str = "blake2s"
 
 
 @dataclass
@@ -83,9 +92,16 @@ class Proof:
     comp: Optional[Opening] = None
 
 
+def _sha256(data: bytes) -> bytes:
+    import hashlib
+    return hashlib.sha256(data).digest()
+
+
 class Coin(PublicCoin):
-    def __init__(self, seed: bytes):
+    def __init__(self, seed: bytes, hash_name: str = "blake2s"):
         super().__init__(be.COIN_SOLIDITY, seed)
+        if hash_name == "sha256":
+            self._h = _sha256
 
     def draw_felt(self):
         while True:
@@ -121,7 +137,8 @@ def transcript_seed(seed: bytes, opt: Options, trace_len: int, statement=None) -
     """the options, the trace length AND the statement are part of the transcript: every challenge depends on the public memory
     and segments being claimed (Fiat-Shamir over the whole statement), and a proof does not verify under other options"""
     return keccak256(bytes(seed) + b"".join(int(v).to_bytes(8, "big") for v in (opt.num_queries, opt.log_blowup, opt.grinding, opt.fold,
-                                                                                 opt.max_remainder, trace_len)) + statement_digest(statement))
+                                                                                 opt.max_remainder, trace_len)) + statement_digest(statement)
+                     + (b"" if opt.hash == "blake2s" else opt.hash.encode()))
 
 
 DEFAULT_REQUIRED_SECURITY_BITS = 80                # cli/src/main.rs:66-67
@@ -161,14 +178,17 @@ class Prover:
 
     def __init__(self, ctx, air: Air, options: Options = None):
         self.ctx, self.air, self.opt = ctx, air, options or Options()
+        if self.opt.hash not in ("blake2s", "sha256"):
+            raise ValueError("Options.hash: 'blake2s' or 'sha256'")
+        self._row_hash, self._tree = (be.HASH_SHA256, be.TREE_SHA256) if self.opt.hash == "sha256" else (be.HASH_BLAKE2S, be.TREE_BLAKE2S)
 
     def _commit(self, cols, n_rows):
         import torch
         dig = torch.empty((n_rows, 32), dtype=torch.uint8, device=cols[0].device)          # every byte is written by the kernels
         nodes = torch.empty((2 * n_rows, 32), dtype=torch.uint8, device=cols[0].device)
         # rows of more than 16 columns do not occur here (<= 8 trace, 6 composition coordinate columns)
-        self.ctx.hash_rows_gl64(cols, 1, n_rows, dig)
-        root, _ = self.ctx.merkle_build(be.TREE_BLAKE2S, 0, be.LEAF_DIGEST, dig, n_rows, nodes)
+        self.ctx.hash_rows_gl64(cols, 1, n_rows, dig, self._row_hash)
+        root, _ = self.ctx.merkle_build(self._tree, 0, be.LEAF_DIGEST, dig, n_rows, nodes)
         return root, nodes
 
     def _open(self, cols, nodes, n_rows, positions, seg_len=1):
@@ -188,7 +208,7 @@ class Prover:
         N = n << lb
         dev = base_cols[0].device
         new = lambda rows, width=None: torch.empty((rows,) if width is None else (rows, width), dtype=torch.int64, device=dev)   # fully written below
-        coin = Coin(transcript_seed(seed, opt, n, statement))
+        coin = Coin(transcript_seed(seed, opt, n, statement), opt.hash)
         proof = Proof(opt, n)
 
         def extend(cols):
@@ -251,8 +271,8 @@ class Prover:
             segs = [be.DeviceView(_Raw(layer), 24 * k * rows, 24 * rows) for k in range(opt.fold)]
             dig = torch.empty((rows, 32), dtype=torch.uint8, device=dev)
             nodes = torch.empty((2 * rows, 32), dtype=torch.uint8, device=dev)
-            ctx.hash_rows_gl64(segs, 3, rows, dig)
-            root_l, _ = ctx.merkle_build(be.TREE_BLAKE2S, 0, be.LEAF_DIGEST, dig, rows, nodes)
+            ctx.hash_rows_gl64(segs, 3, rows, dig, self._row_hash)
+            root_l, _ = ctx.merkle_build(self._tree, 0, be.LEAF_DIGEST, dig, rows, nodes)
             coin.reseed_with_digest(root_l)
             a = coin.draw_fq3()
             nxt = new(rows, 3)
@@ -307,6 +327,8 @@ def proof_to_arrays(p: Proof) -> dict:
          "ood_trace": p.ood_trace, "ood_comp": p.ood_comp, "remainder": p.remainder,
          "fri_roots": np.frombuffer(b"".join(fl.root for fl in p.fri_layers), dtype=np.uint8).copy(),
          "fri_log_len": np.array([fl.log_len for fl in p.fri_layers], dtype=np.uint32)}
+    if o.hash != "blake2s":                 # (absent = the default: the fixtures made before the option existed stay as they are)
+        d["hash"] = np.frombuffer(o.hash.encode(), dtype=np.uint8).copy()
     for name, op in [("base", p.base), ("ext", p.ext), ("comp", p.comp)] + [("fri%d" % k, fl.opening) for k, fl in enumerate(p.fri_layers)]:
         if op is not None:
             d[name + "_rows"], d[name + "_paths"] = op.rows, op.paths
@@ -316,7 +338,7 @@ def proof_to_arrays(p: Proof) -> dict:
 def proof_from_arrays(d) -> Proof:
     o = [int(v) for v in d["options"]]
     roots = bytes(d["roots"])
-    p = Proof(Options(*o[:5]), o[5], roots[:32], roots[32:64] if int(d["has_ext"][0]) else b"", roots[64:96], np.array(d["ood_trace"]),
+    p = Proof(Options(*o[:5], hash=bytes(d["hash"]).decode() if "hash" in d else "blake2s"), o[5], roots[:32], roots[32:64] if int(d["has_ext"][0]) else b"", roots[64:96], np.array(d["ood_trace"]),
               np.array(d["ood_comp"]), [], np.array(d["remainder"]), o[6])
     opening = lambda name: Opening(np.array(d[name + "_rows"]), np.array(d[name + "_paths"])) if name + "_rows" in d else None
     p.base, p.ext, p.comp = opening("base"), opening("ext"), opening("comp")
@@ -336,26 +358,26 @@ def _need(cond, what):
         raise VerificationError(what)
 
 
-def _tree_hash(data: bytes) -> bytes:
+def _tree_hash(data: bytes, hash_name: str = "blake2s") -> bytes:
     import hashlib
-    return hashlib.blake2s(data).digest()
+    return hashlib.sha256(data).digest() if hash_name == "sha256" else hashlib.blake2s(data).digest()
 
 
-def _climb(leaf, path, pos):
+def _climb(leaf, path, pos, hash_name="blake2s"):
     node = leaf
     for lvl in range(path.shape[0]):
         sib = bytes(path[lvl])
-        node = _tree_hash(node + sib) if ((pos >> lvl) & 1) == 0 else _tree_hash(sib + node)
+        node = _tree_hash(node + sib, hash_name) if ((pos >> lvl) & 1) == 0 else _tree_hash(sib + node, hash_name)
     return node
 
 
-def _check_opening(opening, width, positions, depth, root, what):
+def _check_opening(opening, width, positions, depth, root, what, hash_name="blake2s"):
     _need(opening is not None and isinstance(opening.rows, np.ndarray) and isinstance(opening.paths, np.ndarray) and
           opening.rows.dtype == np.uint64 and opening.paths.dtype == np.uint8, what + ": dtype")
     _need(opening.rows.shape == (len(positions), width) and opening.paths.shape == (len(positions), depth, 32), what + ": shape")
     for q, pos in enumerate(positions):
-        leaf = _tree_hash(b"".join(int(v).to_bytes(8, "little") for v in opening.rows[q]))
-        _need(_climb(leaf, opening.paths[q], pos) == root, what + ": authentication path does not reach the root")
+        leaf = _tree_hash(b"".join(int(v).to_bytes(8, "little") for v in opening.rows[q]), hash_name)
+        _need(_climb(leaf, opening.paths[q], pos, hash_name) == root, what + ": authentication path does not reach the root")
 
 
 def _verify_pow(digest, bits, nonce):
@@ -406,7 +428,8 @@ def _verify(proof, air, seed, statement, expected_options, required_security_bit
     _u64_array(proof.ood_comp, (6, 3), "out-of-domain composition values")
     _u64_array(proof.remainder, (None, 3), "FRI remainder")
     ncols = air.num_base + air.num_ext
-    coin = Coin(transcript_seed(seed, opt, n, statement))
+    _need(opt.hash in ("blake2s", "sha256"), "options: hash")
+    coin = Coin(transcript_seed(seed, opt, n, statement), opt.hash)
     coin.reseed_with_digest(proof.base_root)
     challenges = [coin.draw_fq3() for _ in range(air.num_challenges)]
     if air.num_ext:
@@ -453,10 +476,10 @@ def _verify(proof, air, seed, statement, expected_options, required_security_bit
     coin.reseed_with_int(proof.pow_nonce)
     positions = coin.draw_queries(opt.num_queries, N)
     # trace / composition openings, DEEP value at every query
-    _check_opening(proof.base, air.num_base, positions, log_n + lb, proof.base_root, "base trace")
+    _check_opening(proof.base, air.num_base, positions, log_n + lb, proof.base_root, "base trace", opt.hash)
     if air.num_ext:
-        _check_opening(proof.ext, air.num_ext, positions, log_n + lb, proof.ext_root, "extension trace")
-    _check_opening(proof.comp, 6, positions, log_n + lb, proof.comp_root, "composition trace")
+        _check_opening(proof.ext, air.num_ext, positions, log_n + lb, proof.ext_root, "extension trace", opt.hash)
+    _check_opening(proof.comp, 6, positions, log_n + lb, proof.comp_root, "composition trace", opt.hash)
     wN = F.root_of_unity(log_n + lb)
     deep_at = {}
     for q, pos in enumerate(positions):
@@ -475,7 +498,7 @@ def _verify(proof, air, seed, statement, expected_options, required_security_bit
     for li, fl in enumerate(proof.fri_layers):
         rows = (1 << ll) // opt.fold
         folded = sorted(set(p % rows for p in pos))
-        _check_opening(fl.opening, 3 * opt.fold, folded, ll - log_fold, fl.root, "FRI layer %d" % li)
+        _check_opening(fl.opening, 3 * opt.fold, folded, ll - log_fold, fl.root, "FRI layer %d" % li, opt.hash)
         wL, nxt = F.root_of_unity(ll), {}
         wf_inv = pow(F.root_of_unity(log_fold), -1, P)
         for qi, j in enumerate(folded):

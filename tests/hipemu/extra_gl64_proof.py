@@ -36,3 +36,37 @@ def test_device_code_reproduces_the_gpu_made_proof(oracle):
         gs.verify(proof, air, seed, statement=pi, expected_options=opt, required_security_bits=28)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_sha256_claim_on_the_device_code():
+    """Options(hash="sha256") - the parts cli/src/main.rs:119-120 names for the 64-bit field's claim: SHA-256 row digests and trees
+    (FIPS 180-4: the verifier recomputes them with hashlib), a coin with SHA-256 inside - proves and verifies; not the default claim's
+    proof, and neither verifies as the other"""
+    import dataclasses
+    import torch
+    from sandstorm_amd import goldilocks as gs
+    from sandstorm_amd.backend import Context
+    prog = pl.example_program(10)
+    states, memory = pl.run(prog, 64)
+    pi = pl.public_input_of(prog, states, memory)
+    cols = pl.base_trace(states, memory, pi)
+    ctx = Context(0)
+    try:
+        base = [torch.from_numpy(np.array(c, dtype=np.uint64).view(np.int64)) for c in cols]
+        air, seed = gs.plain_air(), bytes(range(32))
+        proofs = {}
+        for h in ("sha256", "blake2s"):
+            opt = gs.Options(num_queries=20, grinding=8, hash=h)
+            proofs[h] = gs.Prover(ctx, air, opt).prove(seed, base, lambda ch: gs.plain_extension_on_device(ctx, base, ch)[0], statement=pi)
+            gs.verify(proofs[h], air, seed, statement=pi, expected_options=opt, required_security_bits=28)
+        assert proofs["sha256"].base_root != proofs["blake2s"].base_root
+        again = gs.proof_from_arrays(gs.proof_to_arrays(proofs["sha256"]))
+        assert again.options.hash == "sha256"
+        gs.verify(again, air, seed, statement=pi, required_security_bits=28)
+        for h, other in (("sha256", "blake2s"), ("blake2s", "sha256")):
+            forged = dataclasses.replace(proofs[h], options=dataclasses.replace(proofs[h].options, hash=other))
+            with pytest.raises(gs.VerificationError):
+                gs.verify(forged, air, seed, statement=pi, required_security_bits=28)
+    finally:
+        ctx.close()

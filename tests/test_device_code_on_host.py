@@ -65,11 +65,11 @@ def test_sweeps_over_the_sizes_the_gpu_suite_samples(emulated_library):
 
 def test_the_64_bit_field(emulated_library):
     """tests/test_goldilocks.py below the benchmark sizes, every transform size (tests/hipemu/extra_gl64_sizes.py), and a whole proof
-    of the plain layout equal to the one the MI355X wrote (tests/hipemu/extra_gl64_proof.py)"""
+    of the plain layout equal to the one the MI355X wrote, and one under the SHA-256 claim (tests/hipemu/extra_gl64_proof.py)"""
     # (the whole proof: the Python host over the C ABI with CPU tensors as device buffers writes the MI355X-made fixture)
     out = run_gpu_tests_on_host(emulated_library, ["tests/test_goldilocks.py", "tests/hipemu/extra_gl64_sizes.py", "tests/hipemu/extra_gl64_proof.py",
                                                    "-k", "not benchmark_size"])
-    assert "54 passed" in out, out[-500:]                     # 30 + 17 sizes + folds, row shapes, running products + 1 proof
+    assert "59 passed" in out, out[-500:]                     # 34 + 17 sizes + folds, row shapes (SHA-256's padding edges too), running products + 2 proofs
 
 
 def test_extension_columns_and_compiled_constraint_kernels(emulated_library):

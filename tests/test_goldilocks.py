@@ -415,10 +415,11 @@ def test_the_kernels_compose_into_a_proof_skeleton(ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nseg,seg_len", [(1, 1), (5, 1), (8, 1), (9, 1), (16, 1), (8, 3), (2, 17), (1, 34)])
+@pytest.mark.parametrize("nseg,seg_len", [(1, 1), (5, 1), (6, 1), (7, 1), (8, 1), (9, 1), (14, 1), (15, 1), (16, 1), (8, 3), (2, 17), (1, 34)])
 def test_row_hashing_and_trees_of_8_byte_elements(ctx, nseg, seg_len):
-    """ss_hash_rows_gl64 (Keccak-256 / Blake2s-256 over the rows' little-endian bytes, block boundaries included), the Blake2s
-    tree over the digests, ss_gather_rows_gl64 - against hashlib and the library's host Keccak"""
+    """ss_hash_rows_gl64 (Keccak-256 / Blake2s-256 / SHA-256 over the rows' little-endian bytes, block and padding boundaries
+    included: 8, 9, 16 elements ... against SHA-256's 55 / 56 / 64-byte edges), the Blake2s and SHA-256 trees over the digests,
+    ss_gather_rows_gl64 - against hashlib (OpenSSL's SHA-256: the FIPS 180-4 function) and the library's host Keccak"""
     import hashlib
     from sandstorm_amd import backend as be
     from sandstorm_amd.coin import keccak256
@@ -427,11 +428,20 @@ def test_row_hashing_and_trees_of_8_byte_elements(ctx, nseg, seg_len):
     segs = [rand_fp(rng, nrows * seg_len) for _ in range(nseg)]
     d_segs = [ctx.column(s) for s in segs]
     row_bytes = lambda i: b"".join(int(s[i * seg_len + e]).to_bytes(8, "little") for s in segs for e in range(seg_len))
-    for kind, h in ((be.HASH_KECCAK, keccak256), (be.HASH_BLAKE2S, lambda d: hashlib.blake2s(d).digest())):
+    for kind, h in ((be.HASH_KECCAK, keccak256), (be.HASH_SHA256, lambda d: hashlib.sha256(d).digest()), (be.HASH_BLAKE2S, lambda d: hashlib.blake2s(d).digest())):
         out = ctx.alloc(32 * nrows)
         ctx.hash_rows_gl64(d_segs, seg_len, nrows, out, kind)
         got = out.download(np.uint8, (nrows, 32))
         assert [bytes(r) for r in got] == [h(row_bytes(i)) for i in range(nrows)]
+        if kind == be.HASH_SHA256:              # MatrixMerkleTreeImpl<Sha256HashFn> (cli/src/main.rs:119): node = SHA-256(left || right)
+            nodes = ctx.alloc(64 * nrows)
+            root, _ = ctx.merkle_build(be.TREE_SHA256, 0, be.LEAF_DIGEST, out, nrows, nodes)
+            level = [hashlib.sha256(row_bytes(i)).digest() for i in range(nrows)]
+            while len(level) > 1:
+                level = [hashlib.sha256(level[2 * k] + level[2 * k + 1]).digest() for k in range(len(level) // 2)]
+            assert root == level[0]
+            paths, _ = ctx.merkle_open(nodes, None, nrows, [3, 62])
+            assert bytes(paths[0][0]) == hashlib.sha256(row_bytes(2)).digest() and bytes(paths[1][0]) == hashlib.sha256(row_bytes(63)).digest()
     nodes = ctx.alloc(64 * nrows)
     root, _ = ctx.merkle_build(be.TREE_BLAKE2S, 0, be.LEAF_DIGEST, out, nrows, nodes)
     level = [hashlib.blake2s(row_bytes(i)).digest() for i in range(nrows)]

@@ -154,6 +154,31 @@ def test_proof_of_the_example_verifies(proved):
 
 
 @pytest.mark.gpu
+def test_the_claim_with_the_parts_the_reference_names_for_it(proved):
+    """Options(hash="sha256"): MatrixMerkleTreeImpl<Sha256HashFn> trees and a coin with SHA-256 inside (cli/src/main.rs:119-120) - the
+    proof verifies, survives its array form, is not the Blake2s claim's proof, and neither verifies as the other"""
+    import dataclasses
+    gs, air, pi, cols, prove, opt = proved
+    sha = dataclasses.replace(opt, hash="sha256")
+    seed = bytes(range(32))
+    proof = prove(cols, sha)
+    positions = gs.verify(proof, air, seed, statement=pi, expected_options=sha, required_security_bits=28)
+    assert len(positions) >= 15
+    again = gs.proof_from_arrays(gs.proof_to_arrays(proof))
+    assert again.options.hash == "sha256" and gs.verify(again, air, seed, statement=pi, required_security_bits=28) == positions
+    other = prove(cols)
+    assert other.base_root != proof.base_root and other.options.hash == "blake2s"
+    for p, h in ((proof, "blake2s"), (other, "sha256")):
+        forged = dataclasses.replace(p, options=dataclasses.replace(p.options, hash=h))
+        with pytest.raises(gs.VerificationError):
+            gs.verify(forged, air, seed, statement=pi, required_security_bits=28)
+    bad = dataclasses.replace(proof, base=gs.Opening(proof.base.rows.copy(), proof.base.paths.copy()))
+    bad.base.paths[0, 0, 0] ^= 1
+    with pytest.raises(gs.VerificationError, match="authentication path"):
+        gs.verify(bad, air, seed, statement=pi, required_security_bits=28)
+
+
+@pytest.mark.gpu
 def test_tampered_proofs_and_statements_are_rejected(proved):
     gs, air, pi, cols, prove, opt = proved
     proof = prove(cols)

@@ -369,3 +369,19 @@ def test_starknet_ood_vector_is_in_column_order(golden):
     assert ood[start[1]:start[2]] == [px] * 5 and ood[start[2]:start[3]] == [py] * 4
     assert ood[start[3]:start[4]] == [0] * 9 and ood[start[4]:start[5]] == [0] * 2
     assert ood[start[1] - 1] not in (px, py, 0) and ood[start[5]] != 0
+
+
+def test_sha256_is_the_fips_180_4_function(oracle):
+    """the oracle's SHA-256 (oracle/hash.c: the hash of the trees the reference names for its 64-bit-field claim, cli/src/main.rs:105,119)
+    against the standard's own example vectors (FIPS 180-4 / NIST CSRC "SHA-256 examples": one block, two blocks, the empty message,
+    one million 'a') and, at every length across the padding boundaries, against OpenSSL's (hashlib)"""
+    import hashlib
+    kat = {b"abc": "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad",
+           b"": "e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855",
+           b"abcdbcdecdefdefgefghfghighijhijkijkljklmklmnlmnomnopnopq": "248d6a61d20638b8e5c026930c3e6039a33ce45964ff2167f6ecedd419db06c1",
+           b"a" * 1000000: "cdc76e5c9914fb9281a1c7e284d73e67f1809a48a497200e046d39ccc7112cd0"}
+    for msg, want in kat.items():
+        assert oracle.sha256(msg).hex() == want
+    blob = bytes((i * 131 + 7) & 0xff for i in range(300))
+    for n in range(0, 200):
+        assert oracle.sha256(blob[:n]) == hashlib.sha256(blob[:n]).digest(), n
