@@ -1901,8 +1901,9 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
     const uint64_t N = npoints;
     // constants in limb form: 9 x 28-bit limbs of the interchange image (add / sub / mov) and of the R280 form (fl_mul_r280)
     const uint32_t nc = prog->n_consts ? prog->n_consts : 1u;
-    // [constants | table descriptors | one step w^(lanes of the grid) per part, 32-byte aligned]
-    const size_t wstep_at = (((size_t)nc * QG_CONST_STRIDE + 2 * (size_t)(prog->n_tables ? prog->n_tables : 1u)) + 7) / 8 * 8;
+    // [constants | table descriptors, then those of the scaled copies | one step w^(lanes of the grid) per part, 32-byte aligned]
+    const size_t n_desc = (size_t)(prog->n_tables ? prog->n_tables : 1u) + gen.n_scaled;
+    const size_t wstep_at = (((size_t)nc * QG_CONST_STRIDE + 2 * n_desc) + 7) / 8 * 8;
     std::vector<uint32_t> host(wstep_at + 8 * (size_t)QG_MAX_PARTS, 0u);
     for (uint32_t k = 0; k < prog->n_consts; ++k) {
         const Fp c = fp_from_limbs64(prog->consts + 4 * (size_t)k);
@@ -1919,6 +1920,20 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
         tdesc[2 * t] = prog->table_desc[2 * t];
         tdesc[2 * t + 1] = (uint32_t)((1ull << prog->table_desc[2 * t + 1]) - 1ull);
     }
+    // the multiplier-only tables times 2^24, one after the other behind the staged words (quotient_gen.h QG_TABLE_SCALED_RAW)
+    QgScaleArgs sc;
+    uint64_t scaled_felts = 0;
+    if (gen.n_scaled > (uint32_t)QG_MAX_SCALED) return fail(SS_ERR_UNSUPPORTED, "%u scaled tables > %d", gen.n_scaled, QG_MAX_SCALED);
+    for (uint32_t j = 0; j < gen.n_scaled; ++j) {
+        const uint32_t t = gen.scaled[j];
+        if (t >= prog->n_tables) return fail(SS_ERR_INVALID, "scaled table %u of %u", t, prog->n_tables);
+        const uint64_t len = 1ull << prog->table_desc[2 * t + 1];
+        sc.src[j] = prog->table_desc[2 * t]; sc.dst[j] = (uint32_t)scaled_felts; sc.len[j] = (uint32_t)len;
+        tdesc[2 * (prog->n_tables + j)] = (uint32_t)scaled_felts;
+        tdesc[2 * (prog->n_tables + j) + 1] = (uint32_t)(len - 1ull);
+        scaled_felts += len;
+    }
+    sc.n = gen.n_scaled;
     const Fp w_dom = root_of_unity(log_N);
     std::vector<uint64_t> part_blocks(gen.n_parts);
     for (uint32_t p = 0; p < gen.n_parts; ++p) {
@@ -1931,7 +1946,8 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
         const Fp ws = fp_pow_u64(w_dom, blocks * gen.parts[p].threads);
         for (int j = 0; j < 8; ++j) host[wstep_at + 8 * (size_t)p + j] = ws.v[j];
     }
-    ss_status st = ctx->ensure_scratch(host.size() * 4 + 256);
+    const size_t scaled_at = ((host.size() * 4 + 256 + 63) / 64) * 64;
+    ss_status st = ctx->ensure_scratch(scaled_at + scaled_felts * sizeof(Fp));
     if (st != SS_OK) return st;
     hipStream_t s = ctx->stream;
     void *pinned = nullptr;                      // no host round trip: the copy leaves from pinned memory the context owns
@@ -1942,6 +1958,11 @@ ss_status eval_quotient_compiled(ss_ctx *ctx, const QGenKernel &gen, const ss_ai
     QGenArgs a;
     for (int c = 0; c < QG_MAX_COLS; ++c) a.cols[c] = c < (int)ncols ? (const Fp *)d_lde_cols[c] : nullptr;
     a.tables = (const Fp *)prog->d_tables;
+    a.tables_scaled = (const Fp *)((char *)ctx->scratch + scaled_at);
+    if (sc.n) {
+        sc.tables = a.tables; sc.out = (Fp *)((char *)ctx->scratch + scaled_at);
+        HIP_TRY(launch_qg_scale_tables(s, sc, scaled_felts));
+    }
     a.consts = (const uint32_t *)ctx->scratch;
     a.tdesc = a.consts + (size_t)nc * QG_CONST_STRIDE;
     a.out = (Fp *)d_out;

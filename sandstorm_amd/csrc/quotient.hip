@@ -17,6 +17,7 @@
 #include "fp252.h"
 #include "fl252.h"
 #include "kernels.h"
+#include "quotient_gen.h"
 
 namespace ss {
 
@@ -242,6 +243,26 @@ hipError_t launch_quotient_vm(hipStream_t st, const uint32_t *d_code, uint32_t n
     a.code = d_code; a.slots = d_slots; a.out = out; a.offset = offset; a.w = w; a.wstep = wstep;
     a.n_entries = n_entries; a.npoints = npoints; a.xcd_split = xcd_split;
     hipLaunchKernelGGL(quotient_vm_kernel, dim3((uint32_t)(lanes / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---- the compiled kernels' copy of the multiplier-only tables times 2^24 (quotient_gen.h QgScaleArgs; one launch per evaluation:
+// a few thousand to a few hundred thousand entries) - "group sum x zerofier inverse" is then a product with the ten-step reduction
+__global__ __launch_bounds__(256) void qg_scale_tables_kernel(QgScaleArgs a, uint64_t total) {
+    Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
+    const Fp f = fp_to_mont(two24);
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t j = 0;
+        while (j + 1 < a.n && i >= a.dst[j + 1]) ++j;          // the copies lie one after the other: table j covers [dst[j], dst[j] + len[j])
+        a.out[i] = fp_mul(a.tables[a.src[j] + (i - a.dst[j])], f);
+    }
+}
+
+hipError_t launch_qg_scale_tables(hipStream_t st, const QgScaleArgs &a, uint64_t total_felts) {
+    if (a.n == 0 || total_felts == 0) return hipSuccess;
+    uint32_t blocks = (uint32_t)((total_felts + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(qg_scale_tables_kernel, dim3(blocks), dim3(256), 0, st, a, total_felts);
     return hipGetLastError();
 }
 

@@ -23,7 +23,8 @@ static constexpr int QG_CONST_STRIDE = 48;       // dwords per constant, four li
 struct QGenArgs {
     const Fp *cols[QG_MAX_COLS];
     const Fp *tables;                            // all tables, concatenated
-    const uint32_t *tdesc;                       // per table: first element, index mask (period - 1)
+    const Fp *tables_scaled;                     // the multiplier-only tables times 2^24, concatenated (QGenKernel::scaled; made per launch)
+    const uint32_t *tdesc;                       // per table: first element, index mask (period - 1); then the same per scaled copy
     const uint32_t *consts;                      // per constant QG_CONST_STRIDE dwords, limb form
     Fp *out;
     Fp *sink;                                    // 32 bytes nobody reads: where lanes past the end of the points store
@@ -52,7 +53,18 @@ struct QGenKernel {
     uint32_t variant;                            // tools/gen_quotient.py VARIANTS; ss_eval_quotient takes 0 (SS_QG_VARIANT overrides)
     uint32_t n_parts;
     QGenPart parts[QG_MAX_PARTS];
+    uint32_t n_scaled;                           // tables the kernels read from a 2^24-fold copy (multiplier-only tables): their numbers;
+    const uint32_t *scaled;                      // copy j is addressed by descriptor n_tables + j
 };
+
+// the launch's copy of the multiplier-only tables times 2^24 (csrc/quotient.hip qg_scale_tables_kernel)
+static constexpr int QG_MAX_SCALED = 48;
+struct QgScaleArgs {
+    const Fp *tables;
+    Fp *out;
+    uint32_t n, src[QG_MAX_SCALED], dst[QG_MAX_SCALED], len[QG_MAX_SCALED];      // per table: first element in `tables`, in `out`, elements
+};
+hipError_t launch_qg_scale_tables(hipStream_t st, const QgScaleArgs &a, uint64_t total_felts);
 
 #define QG_VARIANT(entry) const QGenKernel &entry();
 #include "quotient_gen_variants.inc"             // quotient_gen_starknet(), quotient_gen_recursive() [, the A/B variants]
@@ -119,6 +131,7 @@ __device__ __forceinline__ void qg_wide_tail(QgWide &w, const Fl &l) {
 // point's for the loads issued across the loop edge.
 #define QG_TRACE_RAW(col, off, idx) qg_load_raw(a.cols[col], ((idx) + ((off) << lb)) & maskN)
 #define QG_TABLE_RAW(t, idx) qg_load_raw(a.tables + tdesc[2 * (t)], ((idx) + row0) & tdesc[2 * (t) + 1])
+#define QG_TABLE_SCALED_RAW(t, idx) qg_load_raw(a.tables_scaled + tdesc[2 * (t)], ((idx) + row0) & tdesc[2 * (t) + 1])
 #define QG_CONST(k) qg_const_lds(lds_consts + QG_CONST_LDS_STRIDE * (k))
 #define QG_CONST_R280(k) qg_const_lds(lds_consts + QG_CONST_LDS_STRIDE * (k) + 9)
 #define QG_CONST_R280_UP(k) qg_const_lds(lds_consts + QG_CONST_LDS_STRIDE * (k) + 18)

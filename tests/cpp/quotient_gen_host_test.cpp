@@ -19,7 +19,7 @@ using namespace ss;
 
 struct HostArgs {
     std::vector<std::vector<Fp>> cols;
-    std::vector<Fp> tables;
+    std::vector<Fp> tables, tables_scaled;   // the multiplier-only tables times 2^24 (QG_SCALED_H: csrc/quotient_gen_<layout>_scaled.inc)
     std::vector<uint32_t> tdesc;          // per table: first element, index mask
     std::vector<Fl> consts, consts_r280, consts_up, consts_upn;
     std::vector<Fp> out;
@@ -30,6 +30,7 @@ struct HostArgs {
 
 #define QG_TRACE_RAW(col, off, idx) a.cols[col][((idx) + ((off) << lb)) & maskN]
 #define QG_TABLE_RAW(t, idx) a.tables[a.tdesc[2 * (t)] + (((idx) + row0) & a.tdesc[2 * (t) + 1])]
+#define QG_TABLE_SCALED_RAW(t, idx) a.tables_scaled[a.tdesc[2 * (t)] + (((idx) + row0) & a.tdesc[2 * (t) + 1])]
 #define QG_CONST(k) a.consts[k]
 #define QG_CONST_R280(k) a.consts_r280[k]
 #define QG_CONST_R280_UP(k) a.consts_up[k]
@@ -71,6 +72,7 @@ static inline void qg_wide_tail(QgWide &w, const Fl &l) {
     Fl x = fl_from_fp(fp_mul(a.offset, fp_pow_u64(a.w, lane)));                      \
     const Fl wstep = fl_from_fp(fp_pow_u64(a.w, lanes));
 typedef void (*part_fn)(HostArgs &, uint64_t, uint64_t);
+#include QG_SCALED_H
 #include QG_PARTS_H
 
 template <class T>
@@ -95,6 +97,17 @@ int main(int argc, char **argv) {
         const Fp up = fp_mul(c, fp_to_mont(two24));
         a.consts.push_back(fl_from_fp(c)); a.consts_r280.push_back(fl_to_r280(c));
         a.consts_up.push_back(fl_to_r280(up)); a.consts_upn.push_back(fl_to_r280(fp_neg(up)));
+    }
+    {                                            // what csrc/capi.hip eval_quotient_compiled does per launch
+        Fp f24 = fp_zero(); f24.v[0] = 1u << 24;
+        const Fp f = fp_to_mont(f24);
+        for (uint32_t j = 0; j < QG_N_SCALED; ++j) {
+            const uint32_t t = QG_SCALED_TABLES[j], first = a.tdesc[2 * t], len = a.tdesc[2 * t + 1] + 1u;
+            a.tdesc.push_back((uint32_t)a.tables_scaled.size());
+            a.tdesc.push_back(len - 1u);
+            for (uint32_t i = 0; i < len; ++i) a.tables_scaled.push_back(fp_mul(a.tables[first + i], f));
+        }
+        if (QG_N_TABLES * 2 + QG_N_SCALED * 2 != a.tdesc.size()) { fprintf(stderr, "table count\n"); return 2; }
     }
     a.npoints = hdr[5]; a.row0 = (uint32_t)hdr[6]; a.trace_mask = (uint32_t)hdr[7]; a.log_blowup = (uint32_t)hdr[8];
     a.out.assign(a.npoints, fp_zero());

@@ -38,7 +38,9 @@ def build(layout, tmp):
         for j, inc in enumerate(parts):
             f.write("static void run_lane_p%d(HostArgs &a, uint64_t lane, uint64_t lanes) {\n    QG_LANE_PRELUDE\n#include \"%s\"\n}\n" % (j, inc))
         f.write("static const part_fn PARTS[] = {%s};\n" % ", ".join("run_lane_p%d" % j for j in range(len(parts))))
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fopenmp", "-I", tmp, "-DQG_PARTS_H=\"qg_parts.h\"", "-o", exe, CPP])
+    scaled = os.path.join(ROOT, "sandstorm_amd", "csrc", "quotient_gen_%s_scaled.inc" % layout)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fopenmp", "-I", tmp, "-DQG_PARTS_H=\"qg_parts.h\"", "-DQG_SCALED_H=\"%s\"" % scaled,
+                           "-o", exe, CPP])
     return exe
 
 
