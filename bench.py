@@ -850,15 +850,16 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
     prof = {name: ctx.profile_read(k) for name, k in kinds}
     # one more proof, untimed, with shader-clock stamps around every profiled launch (ss_profile_enable level 2: s_memtime /
     # s_memrealtime read by one wave per XCD before and after each scope): the clock each stage's kernels are granted IN THIS RUN
-    ctx.profile(2)
-    ctx.profile_reset()
-    step()
     stage_clock = {}
-    for name, k in kinds:
-        cyc, ref = ctx.profile_read_clock(k)
-        ms2 = ctx.profile_read(k)[0]
-        if ref > 0 and ms2 > 0:
-            stage_clock[name] = {"ghz": cyc / ref * 0.1, "ref_ticks_per_s": ref / (ms2 * 1e-3), "stamped_ms": ms2}
+    if not args.no_stage_clocks:
+        ctx.profile(2)
+        ctx.profile_reset()
+        step()
+        for name, k in kinds:
+            cyc, ref = ctx.profile_read_clock(k)
+            ms2 = ctx.profile_read(k)[0]
+            if ref > 0 and ms2 > 0:
+                stage_clock[name] = {"ghz": cyc / ref * 0.1, "ref_ticks_per_s": ref / (ms2 * 1e-3), "stamped_ms": ms2}
     ctx.profile(False)
     out = None
     if rank == 0:
@@ -1012,6 +1013,9 @@ def main():
     ap.add_argument("--workload", default="starknet_2p20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true", help="skip the recursive_2p20 leg of the default run")
+    ap.add_argument("--no-stage-clocks", action="store_true",
+                    help="skip the one extra, untimed proof whose launches are stamped for the stages' shader clocks (the counter passes of "
+                         "tools/*.sh count kernels per run: two proofs, not three)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the files -> proof leg (trace generation + upload + proof of a real statement)")
     ap.add_argument("--sharded-host", default="cpp", choices=["python", "cpp"],
                     help="--mode shard: the driver above the C ABI - the C++ host's sharded.cpp over RCCL (ss_comm_*; default: every "

@@ -32,8 +32,9 @@ typedef int (*ssh_extension_cb)(void *user, const uint64_t *challenges, uint32_t
 const char *ssh_last_error(void) { return g_err.c_str(); }
 // bumped whenever an entry point of this file changes its signature or meaning (hostlib.py checks it at load; ss_abi_version is
 // the device library's).  2: ssh_prove_sharded takes transport handles (ssh_rccl_group_create / ssh_callback_group_create)
-// instead of the raw RCCL id; ssh_air_create left for the callers' own AIR objects.
-#define SSH_HOST_ABI_VERSION 2
+// instead of the raw RCCL id; ssh_air_create left for the callers' own AIR objects.  3: ssh_prove_files, ssh_base_trace_cb,
+// ssh_callback_group_create, ssh_group_self_check.
+#define SSH_HOST_ABI_VERSION 3
 uint32_t ssh_abi_version(void) { return SSH_HOST_ABI_VERSION; }
 
 // an `ssh_air` handle is an `Air *` (prover.hpp): the layouts' AIRs come from ssh_air_create_recursive / _starknet below; a caller

@@ -16,7 +16,7 @@ AIR_MINI = 0
 EXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p))
 ALL_TO_ALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint64))
 ALL_GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint8))
-HOST_ABI_VERSION = 2             # host_capi.cpp SSH_HOST_ABI_VERSION
+HOST_ABI_VERSION = 3             # host_capi.cpp SSH_HOST_ABI_VERSION
 SHARDED_EXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))
 
 _host = None

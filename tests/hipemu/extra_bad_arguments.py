@@ -12,7 +12,7 @@ import pytest
 FINE_WITH_NOTHING = {"ss_ctx_sync", "ss_ctx_trim", "ss_ctx_set_stream", "ss_profile_enable", "ss_profile_reset", "ss_dev_zero", "ss_dev_free",
                      "ss_upload", "ss_download", "ss_dev_copy", "ss_dev_copy_2d"}
 # ... and calls whose remaining arguments cannot be wrong: no stream / a NULL pointer to free / any flag / NULL outputs
-ALWAYS_FINE = {"ss_ctx_sync", "ss_ctx_trim", "ss_profile_reset", "ss_ctx_set_stream", "ss_dev_free", "ss_profile_enable", "ss_profile_read"}
+ALWAYS_FINE = {"ss_ctx_sync", "ss_ctx_trim", "ss_profile_reset", "ss_ctx_set_stream", "ss_dev_free", "ss_profile_enable", "ss_profile_read", "ss_profile_read_clock"}
 # the first argument of these is a communicator, not a context (a NULL one is refused; there is none to hand in without RCCL)
 COMM_FIRST = {"ss_comm_exchange", "ss_comm_all_gather"}
 NO_CTX = {"ss_last_error", "ss_abi_version", "ss_ctx_create", "ss_ctx_destroy", "ss_pedersen_hash_host", "ss_keccak256_host", "ss_comm_unique_id"}

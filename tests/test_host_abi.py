@@ -121,7 +121,7 @@ def test_host_library_document_names_what_the_library_exports():
     import ctypes as C
     from sandstorm_amd import hostlib
     lib = hostlib.load()
-    assert lib.ssh_abi_version() == hostlib.HOST_ABI_VERSION == 2
+    assert lib.ssh_abi_version() == hostlib.HOST_ABI_VERSION == 3
     with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
         doc = f.read()
     named = set(re.findall(r"\b(ssh_[a-z0-9_]+)\b", doc)) - {"ssh_air", "ssh_matrix", "ssh_coin"}          # handle types

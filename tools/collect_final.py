@@ -36,7 +36,7 @@ def parse_pmc(path, counter):
 for name in sorted(os.listdir(SRC)):
     if name.startswith("bench_") and name.endswith(".json"):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, "%s_%s" % (TAG, name)))
-for name in ("pytest_gpu.txt", "smoke.txt", "sq_counters_starknet_2p20.txt", "sq_counters_recursive_2p20.txt", "ubench.txt"):
+for name in ("pytest_gpu.txt", "smoke.txt", "sq_counters_starknet_2p20.txt", "sq_counters_recursive_2p20.txt", "ubench.txt", "mfma_mulbench.txt", "mulbench.txt"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, "%s_%s" % (TAG, name)))
 
@@ -92,7 +92,8 @@ STAGES = {"ntt_pass": ["ntt_pass_kernel"], "quotient": ["quotient_"], "deep": ["
           "hash_rows": ["keccak_rows", "blake2s_rows"], "merkle": ["_pairs_kernel", "pedersen_", "felt_pairs"], "fri_fold": ["fri_fold_kernel"],
           "extension_scans": ["scan_", "perm_", "dil_", "inverse_dense"]}
 model_path = os.path.join(DST, "alu_model.json")
-model = json.load(open(model_path))["kernels"] if os.path.exists(model_path) else {}
+model_json = json.load(open(model_path)) if os.path.exists(model_path) else {}
+model = model_json.get("kernels", {})
 
 
 def parse_all(path):
@@ -135,7 +136,8 @@ for w in ("starknet_2p20", "recursive_2p20"):
                          "wait_any_per_proof": sum(v.get("SQ_WAIT_ANY", 0.0) for v in sel.values()) / 2, "kernels": per_kernel}
     with open(os.path.join(DST, "alu_counters_%s.json" % w), "w") as f:
         json.dump({"workload": w, "commit": COMMIT, "proofs_in_run": 2, "source": "profiles/%s_sq_counters_%s.txt" % (TAG, w),
-                   "model": "profiles/alu_model.json (tools/alu_model.py: static instruction mix x profiles/r04_ubench_instruction_rates.txt)",
+                   "model": "profiles/alu_model.json (tools/alu_model.py: static instruction mix x %s)" % model_json.get("rates_source"),
+                   "cycles_are": model_json.get("cycles_are"),
                    "stages": stages}, f, indent=1)
     print(w, "alu counters:", {k: "%.3g" % v["valu_wave_insts_per_proof"] for k, v in stages.items()})
 

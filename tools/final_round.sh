@@ -13,6 +13,8 @@ done
 timeout 300 python bench.py --workload starknet_2p20 --mode shard --sharded-host python --no-cpu-baseline > $OUT/bench_starknet_2p20_shard_1gpu.json 2> $OUT/bench_shard.err
 timeout 300 python bench.py --workload starknet_2p20 --mode shard --sharded-host cpp --no-cpu-baseline > $OUT/bench_starknet_2p20_shard_cpp_1gpu.json 2> $OUT/bench_shard_cpp.err
 tools/_build/ubench > $OUT/ubench.txt 2>&1
+tools/_build/mfma_mulbench > $OUT/mfma_mulbench.txt 2>&1
+tools/_build/mulbench > $OUT/mulbench.txt 2>&1
 timeout 300 python bench.py --workload goldilocks_lde_2p20 --steps 10 --warmup 2 > $OUT/bench_goldilocks_lde_2p20.json 2> $OUT/bench_gl.err
 timeout 300 python bench.py --workload goldilocks_plain_2p20 --steps 3 --warmup 1 > $OUT/bench_goldilocks_plain_2p20.json 2> $OUT/bench_glp.err
 timeout 300 python bench.py --workload starknet_2p22 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_starknet_2p22.json 2> $OUT/bench_2p22.err
@@ -26,8 +28,8 @@ cp -r $R/gpurun_out/prof $OUT/prof_starknet_2p20
 WORKLOAD=recursive_2p20 bash tools/profile_round.sh > $OUT/profile_round_rec.log 2>&1
 cp -r $R/gpurun_out/prof $OUT/prof_recursive_2p20
 # SQ instruction / wait counters of the default workload (own pass: --pmc only)
-bash tools/pmc_run.sh sq_final "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-end-to-end > $OUT/sq_counters_starknet_2p20.txt 2>&1
-bash tools/pmc_run.sh sq_final_rec "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $R/bench.py --workload recursive_2p20 --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end > $OUT/sq_counters_recursive_2p20.txt 2>&1
+bash tools/pmc_run.sh sq_final "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-end-to-end --no-stage-clocks > $OUT/sq_counters_starknet_2p20.txt 2>&1
+bash tools/pmc_run.sh sq_final_rec "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $R/bench.py --workload recursive_2p20 --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-stage-clocks > $OUT/sq_counters_recursive_2p20.txt 2>&1
 for w in starknet_2p20 recursive_2p20; do bash tools/valu_busy.sh $w $OUT/valu_busy > $OUT/valu_busy_$w.log 2>&1; done
 bash tools/gl64_pmc.sh > $OUT/gl64_pmc.log 2>&1
 ls $OUT

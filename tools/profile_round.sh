@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-end-to-end ${WORKLOAD:+--workload $WORKLOAD}"
+CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-end-to-end --no-stage-clocks ${WORKLOAD:+--workload $WORKLOAD}"
 rm -rf /tmp/rp_stats /tmp/rp_fetch /tmp/rp_write
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -- $CMD > $OUT/stats_run.log 2>&1
 f=$(ls /tmp/rp_stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv
