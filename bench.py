@@ -972,6 +972,10 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
                        "host": "C++ prover (sandstorm_amd/host, libsandstorm_host.so) through ctypes",
                        "fri_layers": len(proof.fri_layers), "pow_nonce": proof.pow_nonce},
             "stage_ms_per_proof": {k: round(v, 3) for k, v in stage_ms.items()},
+            # every stage's shader clock in THIS run (one stamped proof after the timed ones) and its issue fraction at that clock
+            "stage_clock_ghz": {k: round(v["ghz"], 4) for k, v in stage_clock.items()},
+            "stage_alu_frac": {k: round(r["alu"]["frac"], 4) for k in stage_ms if k in algo
+                               for r in [stage_roofline(k, "", "")] if r.get("alu")},
             "roofline": dict(stage_roofline("ntt_pass", "ss::ntt_pass_kernel",
                                             "the kernel north_star names.  algorithmic bytes = 2*N*32 B per transform (SURVEY 8d), shared by "
                                             "its passes; Fp252 butterflies are integer-ALU bound before HBM bound (DESIGN.md section 3): "
@@ -1072,6 +1076,7 @@ def main():
                          cpu_leg=not args.no_cpu_baseline)
         out["north_star"] = {"workload": "recursive_2p20", "value": ns["value"], "unit": "s", "steps": ns["steps"], "warmup": ns["warmup"],
                              "claim": ns["config"]["claim"], "air": ns["config"]["air"], "stage_ms_per_proof": ns["stage_ms_per_proof"],
+                             "stage_clock_ghz": ns.get("stage_clock_ghz"), "stage_alu_frac": ns.get("stage_alu_frac"),
                              "ntt_gfield_ops_per_s": ns["ntt_gfield_ops_per_s"], "roofline": ns["roofline"],
                              "roofline_dominant": ns["roofline_dominant"], "cpu_baseline": ns.get("cpu_baseline"),
                              "end_to_end": ns.get("end_to_end"),

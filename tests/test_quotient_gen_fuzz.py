@@ -164,11 +164,24 @@ def test_random_programs_through_the_generator(oracle, knobs, tmp_path, monkeypa
     monkeypatch.setattr(gen_quotient, "OUT_DIR", tmp)
     rng = np.random.default_rng(1000 + int(os.environ.get("SS_FUZZ_SEED", "0")) * 977 + sum(int(x) << i for i, x in enumerate(knobs)))
     programs = [Builder(rng).program(j == 0) for j in range(14)]
+    # the tables that are only ever multipliers, read from their 2^24-fold copies (r280 products: tools/gen_quotient.py generate) - in
+    # every second knob set, so that both forms of "sum x table" are in the sample
+    scaled = []
+    if depth % 2 == 1:
+        uses = {}
+        for ins in programs:
+            for op, d, kind, w1 in ins:
+                if op <= OP_MUL and kind == TABLE:
+                    uses.setdefault(w1, set()).add(op)
+        scaled = sorted(t for t, ops in uses.items() if ops == {OP_MUL})
+    with open(os.path.join(tmp, "qg_scaled.h"), "w") as f:
+        f.write("static const uint32_t QG_N_TABLES = %du, QG_N_SCALED = %du;\nstatic const uint32_t QG_SCALED_TABLES[] = {%s};\n"
+                % (NTABLES, len(scaled), ", ".join("%du" % t for t in scaled) if scaled else "0u"))
     wide_terms = 0
     with open(os.path.join(tmp, "qg_parts.h"), "w") as f:
         for j, ins in enumerate(programs):
             stats = gen_quotient.generate_body("fuzz", ins, NCONSTS, NSLOTS, NTABLES, NCOLS, depth, "fuzz_p%d.inc" % j, fuse,
-                                               "QG_OUT" if j == 0 else "QG_OUT_ACC", 0, wide, lazy_sub, const_factor, min_terms)
+                                               "QG_OUT" if j == 0 else "QG_OUT_ACC", 0, wide, lazy_sub, const_factor, min_terms, scaled)
             wide_terms += stats["wide_terms"]
             f.write("static void run_lane_p%d(HostArgs &a, uint64_t lane, uint64_t lanes) {\n    QG_LANE_PRELUDE\n#include \"%s\"\n}\n"
                     % (j, os.path.join(tmp, "fuzz_p%d.inc" % j)))
@@ -176,7 +189,7 @@ def test_random_programs_through_the_generator(oracle, knobs, tmp_path, monkeypa
     if wide and fuse:
         assert wide_terms > 0, "no program of the sample got a wide sum: the sample does not test what it is meant to"
     exe = os.path.join(tmp, "qg_fuzz")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fopenmp", "-I", tmp, "-DQG_PARTS_H=\"qg_parts.h\"", "-o", exe, CPP])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fopenmp", "-I", tmp, "-DQG_PARTS_H=\"qg_parts.h\"", "-DQG_SCALED_H=\"qg_scaled.h\"", "-o", exe, CPP])
     n, N = 1 << LOG_N, 2 << LOG_N
     tabs, desc, off = [], [], 0
     for t in range(NTABLES):
