@@ -193,15 +193,11 @@ def cpu_baseline(layout, log_steps_full, gpu_ctx):
                      "(2^%d trace rows), CLI-default options, by the oracle (C + OpenMP port, untuned, not the reference binary) "
                      "through the same Python host as the GPU: %.2f s on %d threads; the GPU on the same sample %.4f s; "
                      "`value` = that CPU time x %.1f (n log n to 2^%d steps)" % (layout, sample, ls, t_cpu, threads, t_gpu, scale, log_steps_full)}
-    if layout == "recursive" and log_steps_full > sample:
-        # a second, smaller size of the same pipeline: the growth exponent MEASURED between 2^(sample-2) and 2^sample steps instead
-        # of the bare n log n factor (the starknet layout's smallest statement is already a minute of CPU: its leg cites this one)
-        t_small = python_host_proof(CpuContext(), layout, sample - 2)
-        e = math.log(t_cpu / t_small) / math.log(4.0)
-        out.update({"fit": {"steps_log2": [sample - 2, sample], "seconds": [t_small, t_cpu], "exponent": e},
-                    "value_fitted": t_cpu * float(1 << (lf - ls)) ** e,
-                    "fit_note": "t ~ n^%.3f between 2^%d and 2^%d steps; `value_fitted` = the 2^%d-step time x (2^%d)^%.3f, beside "
-                                "`value`'s n log n factor" % (e, sample - 2, sample, sample, lf - ls, e)})
+    # ONE extrapolation (n log n), and one line about what it is: the reference's own CPU prover is Rust (nightly, an un-vendored git
+    # crate) and cannot be built in this image, so north_star's ">= 10x the reference CPU prover" is not answerable here; this leg is
+    # the untuned port on the cores the box grants - a reported baseline whose ratio to the GPU says nothing about kernel quality
+    out["note"] = ("the reference CPU prover cannot be built here (Rust nightly + un-vendored ministark): this is the oracle's port, "
+                   "untuned; `value` is its measured sample x n log n - the only extrapolation made")
     return out
 
 
@@ -1083,13 +1079,6 @@ def main():
                              "target": ">= 10x the CPU prover's end-to-end time at 1 GPU (BASELINE.json north_star); cpu_baseline here "
                                        "is the oracle port, not the reference binary"}
     if rank == 0:
-        fit = ((out.get("north_star") or {}).get("cpu_baseline") or {}).get("fit") if out else None
-        if fit and out.get("cpu_baseline") and "value_fitted" not in out["cpu_baseline"]:
-            cb = out["cpu_baseline"]                 # the headline leg has one feasible CPU size: extrapolate it with the exponent the north-star leg measured
-            log_steps_full = WORKLOADS[args.workload][1]
-            sample = min(log_steps_full, 17)
-            cb["value_fitted"] = cb["measured_sample_s"] * float(1 << (log_steps_full - sample)) ** fit["exponent"]
-            cb["fit_note"] = "exponent %.3f measured on the recursive layout's pair of sizes (north_star.cpu_baseline.fit)" % fit["exponent"]
         emit(out)
     if world > 1:
         dist.destroy_process_group()
