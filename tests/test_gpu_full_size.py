@@ -113,6 +113,14 @@ def test_cpp_sharded_host_two_ranks_at_2p20_steps_real_starknet_air(proof_2p20):
     assert run_ranks(2, make(2)) == proof_2p20
 
 
+def test_cpp_sharded_host_two_PROCESSES_at_2p20_steps_real_starknet_air(proof_2p20, tmp_path):
+    """the same as processes - what `bench.py --gpus N` starts: two ranks under torch.distributed.run sharing this box's GPU, each with
+    its own context, coin and columns, the group self check first, the exchanges through the driver's CallbackTransport over gloo
+    (tests/dist_cpp_host_worker.py): BASELINE configs[2]'s statement, the layout of configs[3], the single-device proof byte for byte"""
+    from tests.hipemu.extra_sharded_host_procs import run_processes
+    assert run_processes(2, "starknet:20", tmp_path, timeout=1500) == proof_2p20
+
+
 @pytest.fixture(scope="module")
 def proof_2p22():
     import torch
