@@ -395,6 +395,17 @@ class Context:
         check(self.lib.ss_diluted_aggregate(self.handle, _ptr_of(ordered), stride, offset, count, zp, ap, _ptr_of(out),
                                             out_stride, out_offset))
 
+    def upload_async(self, dst, host_array):
+        """ss_upload_async: the copy leaves on the context's copy stream and the call returns; `host_array` (pinned, contiguous) must stay
+        untouched until the copy is done.  -> the ticket for wait_upload"""
+        t = C.c_uint64()
+        check(self.lib.ss_upload_async(self.handle, _ptr_of(dst), host_array.ctypes.data, host_array.nbytes, C.byref(t)))
+        return t.value
+
+    def wait_upload(self, ticket):
+        """ss_wait_upload: what is enqueued on the context's stream from now on sees that upload (a stream wait; once per ticket)"""
+        check(self.lib.ss_wait_upload(self.handle, int(ticket)))
+
     def profile(self, on):
         """False / True: HIP events around every profiled launch; 2: also shader-clock stamps around them (profile_read_clock)"""
         check(self.lib.ss_profile_enable(self.handle, 2 if on == 2 else 1 if on else 0))

@@ -190,6 +190,31 @@ def test_ntt_spread_over_ranks_takes_any_number_of_columns(ctx, be, oracle):
                 assert np.array_equal(ds[c].download(np.uint64, (B, 4)), one_by_one[c]), (direction, part, "in place", c)
 
 
+def test_uploads_on_the_copy_stream_are_ordered_by_their_tickets(ctx, be, oracle):
+    """ss_upload_async / ss_wait_upload (the trace generator's thread uploads a column the moment it is final, the prover's stream
+    waits for it before the column's first use): a transform enqueued after the wait sees the uploaded column; a ticket serves one
+    wait; ticket 0 and a ticket never issued are refused"""
+    from sandstorm_amd._lib import SandstormHipError
+    log_n = 12
+    cols = [random_column(1 << log_n, 900 + c) for c in range(3)]
+    bufs = [ctx.alloc(32 << log_n) for _ in cols]
+    tickets = [ctx.upload_async(b, c) for b, c in zip(bufs, cols)]
+    assert len(set(tickets)) == 3 and all(t > 0 for t in tickets)
+    for t in reversed(tickets):                              # any order
+        ctx.wait_upload(t)
+    ctx.ntt(bufs, log_n, be.FORWARD, None)
+    for b, c in zip(bufs, cols):
+        assert np.array_equal(b.download(np.uint64, (1 << log_n, 4)), oracle.ntt(c))
+    with pytest.raises(SandstormHipError, match="ticket"):
+        ctx.wait_upload(tickets[0])
+    for bad in (0, 1 << 40):
+        with pytest.raises(SandstormHipError, match="ticket"):
+            ctx.wait_upload(bad)
+    again = ctx.upload_async(bufs[0], cols[1])               # slots are reused
+    ctx.wait_upload(again)
+    assert np.array_equal(bufs[0].download(np.uint64, (1 << log_n, 4)), cols[1])
+
+
 def test_fri_fold_rows_of_a_layer(ctx, be, oracle):
     """ss_fri_fold_rows: a layer folded range by range (each range's entries column after column) is the layer folded whole"""
     log_len, fold = 12, 8
