@@ -209,3 +209,32 @@ def test_files_to_proof_in_one_call_writes_the_same_bytes(log_steps, request):
         m.close()
     air.close()
     ctx.close()
+
+
+def test_files_to_proof_reports_the_generators_error():
+    """ssh_prove_files with files the generator refuses (a trace that is not a power of two of cycles; a public memory that does not
+    fit the run): the generator's thread fails, the prover - waiting for its first column - gives up with THAT message, the thread is
+    joined, the context stays usable"""
+    import dataclasses
+    import numpy as np
+    from sandstorm_amd import backend as be, binary, hostlib, public_input
+    from sandstorm_amd._lib import SandstormHipError
+    states, memory, pi = recursive_example(14)
+    trace_bin, memory_bin = binary.write_register_states(states), binary.write_memory(memory)
+    log_n = 18
+    n = 1 << log_n
+    ctx = be.Context(0)
+    views = [np.zeros((n, 4), dtype=np.uint64) for _ in range(7)]
+    dev = [ctx.alloc(32 * n) for _ in range(7)]
+    air = hostlib.RecursiveHostAir(ctx, pi, log_n)
+    seed = public_input.public_coin_seed(pi, be.COIN_CAIRO)
+    args = (views, dev, air, be.TREE_FRIENDLY, N_FRIENDLY, be.COIN_CAIRO, seed, lambda ch: [])
+    with pytest.raises(SandstormHipError, match="power of two"):
+        hostlib.prove_files(ctx, "recursive", trace_bin[:24 * 3000], memory_bin, pi, None, [np.zeros((16 * 3000, 4), dtype=np.uint64) for _ in range(7)], *args[1:])
+    bad = dataclasses.replace(pi, public_memory=pi.public_memory + [(0xFFFFFFF0, 7)])
+    with pytest.raises(SandstormHipError, match="memory gaps"):
+        hostlib.prove_files(ctx, "recursive", trace_bin, memory_bin, bad, None, *args)
+    # and the context still serves: a transform on it
+    ctx.ntt([dev[0]], 10, be.FORWARD, None)
+    air.close()
+    ctx.close()
