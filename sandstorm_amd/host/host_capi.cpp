@@ -11,6 +11,7 @@
 #include <string>
 
 #include "extension.hpp"
+#include "goldilocks_prover.hpp"
 #include "prover.hpp"
 #include "sharded.hpp"
 #include "public_input.hpp"
@@ -503,6 +504,81 @@ int ssh_prove_files(ss_ctx *ctx, int layout, const uint8_t *trace_bin, uint64_t 
             memcpy(*proof_bytes, b.data(), b.size());
             *proof_len = b.size();
         }
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// ---- the 64-bit field's claim (goldilocks_prover.hpp; cli/src/main.rs:103-133).  options: {num_queries, log_blowup, grinding, fold,
+// max_remainder, sha256 (0 / 1)}.  mask: nmask x (column, offset).  ext_cb fills `num_ext` device pointers (the extension trace's
+// coordinate columns) for the challenges (3 u64 each); prog_cb returns the lowered composition program for challenges and alpha as a
+// blob the callee owns until the next call: [n_instr, n_consts, n_slots, n_tables, d_tables, code (2 n_instr u32 packed in u64
+// pairs: one word per u64), consts (3 n_consts), table_desc (2 n_tables)].  The proof comes back as ONE u64 blob (ssh_free):
+// [trace_len, pow_nonce, has_ext, n_layers | base_root, ext_root, comp_root (4 u64 each, the 32 bytes) | n_ood, ood_trace... |
+// 18 ood_comp | n_rem, remainder... | per layer: root (4), log_len | openings base, ext (if any), comp, then one per layer:
+// npos, width, depth, rows (npos x width), paths (npos x depth x 4 u64)].
+typedef int (*ssh_gl_extension_cb)(void *user, const uint64_t *challenges, uint32_t nchallenges, uint64_t **d_cols_out);
+typedef int (*ssh_gl_program_cb)(void *user, const uint64_t *challenges, uint32_t nchallenges, const uint64_t *alpha, const uint64_t **blob_out,
+                                 uint64_t *blob_len);
+int ssh_gl_prove(ss_ctx *ctx, const uint32_t options[6], const uint8_t seed[32], const uint8_t statement_digest[32], const uint64_t *const *d_base,
+                 uint32_t nbase, uint64_t n, const uint32_t *mask, uint32_t nmask, uint32_t num_challenges, uint32_t num_ext, ssh_gl_extension_cb ext_cb,
+                 ssh_gl_program_cb prog_cb, void *user, uint64_t **proof_blob, uint64_t *proof_len) {
+    try {
+        if (!ctx || !options || !seed || !statement_digest || !d_base || !mask || !prog_cb || !proof_blob || !proof_len) throw std::runtime_error("ssh_gl_prove: NULL argument");
+        gl::Options opt;
+        opt.num_queries = options[0]; opt.log_blowup = options[1]; opt.grinding = options[2]; opt.fold = options[3]; opt.max_remainder = options[4];
+        opt.sha256 = options[5] != 0;
+        Digest sd, st;
+        memcpy(sd.data(), seed, 32);
+        memcpy(st.data(), statement_digest, 32);
+        std::vector<const uint64_t *> base(d_base, d_base + nbase);
+        std::vector<std::pair<uint32_t, uint32_t>> cells;
+        for (uint32_t j = 0; j < nmask; ++j) cells.push_back({mask[2 * j], mask[2 * j + 1]});
+        auto flat = [](const std::vector<gl::Fq3> &v) { std::vector<uint64_t> o; for (auto &c : v) o.insert(o.end(), c.begin(), c.end()); return o; };
+        const gl::Proof p = gl::prove(ctx, opt, sd, st, base, n, cells, num_challenges, num_ext,
+            [&](const std::vector<gl::Fq3> &ch) {
+                std::vector<uint64_t *> cols(num_ext, nullptr);
+                const std::vector<uint64_t> f = flat(ch);
+                if (!ext_cb || ext_cb(user, f.data(), (uint32_t)ch.size(), cols.data()) != 0) throw std::runtime_error("extension callback failed");
+                return std::vector<const uint64_t *>(cols.begin(), cols.end());
+            },
+            [&](const std::vector<gl::Fq3> &ch, const gl::Fq3 &alpha) {
+                const uint64_t *blob = nullptr;
+                uint64_t len = 0;
+                const std::vector<uint64_t> f = flat(ch);
+                if (prog_cb(user, f.data(), (uint32_t)ch.size(), alpha.data(), &blob, &len) != 0 || !blob || len < 5) throw std::runtime_error("program callback failed");
+                gl::ProgramData pd;
+                const uint64_t n_instr = blob[0], n_consts = blob[1], n_tables = blob[3];
+                if (len != 5 + 2 * n_instr + 3 * n_consts + 2 * n_tables) throw std::runtime_error("program callback: blob length");
+                pd.n_slots = (uint32_t)blob[2];
+                pd.d_tables = reinterpret_cast<const uint64_t *>((uintptr_t)blob[4]);
+                const uint64_t *q = blob + 5;
+                for (uint64_t i = 0; i < 2 * n_instr; ++i) pd.code.push_back((uint32_t)*q++);
+                pd.consts.assign(q, q + 3 * n_consts); q += 3 * n_consts;
+                for (uint64_t i = 0; i < 2 * n_tables; ++i) pd.table_desc.push_back((uint32_t)*q++);
+                return pd;
+            });
+        std::vector<uint64_t> out{p.trace_len, p.pow_nonce, p.has_ext ? 1ull : 0ull, p.fri_layers.size()};
+        auto digest = [&](const Digest &d) { uint64_t w[4]; memcpy(w, d.data(), 32); out.insert(out.end(), w, w + 4); };
+        digest(p.base_root); digest(p.ext_root); digest(p.comp_root);
+        out.push_back(p.ood_trace.size() / 3); out.insert(out.end(), p.ood_trace.begin(), p.ood_trace.end());
+        out.insert(out.end(), p.ood_comp.begin(), p.ood_comp.end());
+        out.push_back(p.remainder.size() / 3); out.insert(out.end(), p.remainder.begin(), p.remainder.end());
+        for (auto &fl : p.fri_layers) { digest(fl.root); out.push_back(fl.log_len); }
+        auto opening = [&](const gl::Opening &o) {
+            const uint64_t npos = o.width ? o.rows.size() / o.width : 0;
+            out.push_back(npos); out.push_back(o.width); out.push_back(o.depth);
+            out.insert(out.end(), o.rows.begin(), o.rows.end());
+            const size_t at = out.size();
+            out.resize(at + o.paths.size() / 8);
+            memcpy(out.data() + at, o.paths.data(), o.paths.size());
+        };
+        opening(p.base);
+        if (p.has_ext) opening(p.ext);
+        opening(p.comp);
+        for (auto &fl : p.fri_layers) opening(fl.opening);
+        *proof_blob = (uint64_t *)malloc(out.size() * 8);
+        memcpy(*proof_blob, out.data(), out.size() * 8);
+        *proof_len = out.size();
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }

@@ -460,6 +460,101 @@ def starknet_base_trace(trace_bin: bytes, memory_bin: bytes, pi, private_input=N
     return cols
 
 
+GL_EXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p))
+GL_PROG_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64))
+
+
+def gl_prove(ctx, air, options, seed, base_cols, build_extension, tables=None, statement=None):
+    """the 64-bit field's claim by the C++ host (host/goldilocks_prover.cpp ssh_gl_prove; the mirror of goldilocks.Prover.prove, which
+    writes the same proof arrays): every stage a kernel behind the C ABI, the transcript in C++; what the LAYOUT decides comes from here
+    through two callbacks - the extension trace's coordinate columns for the drawn challenges (build_extension, as goldilocks.Prover
+    takes it) and the lowered composition program for them (air.composition + air_program.lower).  air: a goldilocks.Air; base_cols:
+    device columns of n values.  -> goldilocks.Proof"""
+    from . import air_program as ap, goldilocks as gs
+    opt = options or gs.Options()
+    n = int(base_cols[0].shape[0]) if hasattr(base_cols[0], "shape") else int(base_cols[0].nbytes // 8)
+    tables = tables or air.make_tables(n, opt.log_blowup)
+    keep = []
+
+    def ext_cb(_user, ch_ptr, nch, out_ptr):
+        try:
+            ch = [tuple(int(ch_ptr[3 * i + k]) for k in range(3)) for i in range(nch)]
+            cols = list(build_extension(ch))
+            keep.append(cols)
+            for i, col in enumerate(cols):
+                out_ptr[i] = be._ptr_of(col)
+            return 0
+        except Exception:                       # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def prog_cb(_user, ch_ptr, nch, alpha_ptr, blob_out, len_out):
+        try:
+            ch = [tuple(int(ch_ptr[3 * i + k]) for k in range(3)) for i in range(nch)]
+            alpha = tuple(int(alpha_ptr[k]) for k in range(3))
+            prog = ap.lower(air.composition(n, ch, alpha, tables, statement), gs.P, ext=True, symbols=tables.symbols)
+            tvals, tdesc = tables.device_tables()               # (the composition names the tables it reads: after it)
+            d_tables = ctx.alloc(max(8, tvals.nbytes))
+            d_tables.upload(np.ascontiguousarray(tvals))
+            keep.append(d_tables)
+            code = np.asarray(prog.code, dtype=np.uint32).astype(np.uint64)
+            consts = np.asarray(prog.consts, dtype=np.uint64).reshape(-1)
+            head = np.array([len(code) // 2, len(consts) // 3, prog.n_slots, len(tdesc) // 2, be._ptr_of(d_tables)], dtype=np.uint64)
+            blob = np.ascontiguousarray(np.concatenate([head, code, consts, np.asarray(tdesc, dtype=np.uint64)]))
+            keep.append(blob)
+            blob_out[0] = C.cast(blob.ctypes.data, C.POINTER(C.c_uint64))
+            len_out[0] = len(blob)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+    h = load()
+    h.ssh_gl_prove.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32),
+                               C.c_uint32, C.c_uint32, C.c_uint32, GL_EXT_CB, GL_PROG_CB, C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
+    opts = (C.c_uint32 * 6)(opt.num_queries, opt.log_blowup, opt.grinding, opt.fold, opt.max_remainder, 1 if opt.hash == "sha256" else 0)
+    mask = np.ascontiguousarray([v for cell in air.mask for v in cell], dtype=np.uint32)
+    out, ln = C.POINTER(C.c_uint64)(), C.c_uint64()
+    _check(h.ssh_gl_prove(ctx.handle, opts, bytes(seed), gs.statement_digest(statement), be._ptr_array(base_cols), len(base_cols), n,
+                          mask.ctypes.data_as(C.POINTER(C.c_uint32)), len(air.mask), air.num_challenges, air.num_ext, GL_EXT_CB(ext_cb), GL_PROG_CB(prog_cb), None,
+                          C.byref(out), C.byref(ln)))
+    w = np.ctypeslib.as_array(out, shape=(ln.value,)).copy()
+    h.ssh_free(out)
+    del keep[:]
+    o = 0
+
+    def take(k):
+        nonlocal o
+        v = w[o:o + k]
+        o += k
+        return v
+    trace_len, nonce, has_ext, n_layers = (int(v) for v in take(4))
+    roots = [take(4).tobytes() for _ in range(3)]
+    proof = gs.Proof(opt, trace_len, roots[0], roots[1] if has_ext else b"", roots[2])
+    proof.ood_trace = take(3 * int(take(1)[0])).reshape(-1, 3).copy()
+    proof.ood_comp = take(18).reshape(6, 3).copy()
+    proof.remainder = take(3 * int(take(1)[0])).reshape(-1, 3).copy()
+    proof.pow_nonce = nonce
+    for _ in range(n_layers):
+        root = take(4).tobytes()
+        proof.fri_layers.append(gs.FriLayer(root, int(take(1)[0])))
+
+    def opening():
+        npos, width, depth = (int(v) for v in take(3))
+        rows = take(npos * width).reshape(npos, width).copy()
+        paths = take(npos * depth * 4).copy().view(np.uint8).reshape(npos, depth, 32)
+        return gs.Opening(rows, paths)
+    proof.base = opening()
+    if has_ext:
+        proof.ext = opening()
+    proof.comp = opening()
+    for fl in proof.fri_layers:
+        fl.opening = opening()
+    assert o == len(w)
+    return proof
+
+
 _INSTANCE_SHAPES = (("pedersen", 9), ("range_check", 5), ("ecdsa", 17), ("bitwise", 9), ("ec_op", 21), ("poseidon", 13))
 COLUMN_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
 

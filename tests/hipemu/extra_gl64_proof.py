@@ -70,3 +70,32 @@ def test_sha256_claim_on_the_device_code():
                 gs.verify(forged, air, seed, statement=pi, required_security_bits=28)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hash_name", ["blake2s", "sha256"])
+def test_cpp_host_writes_the_python_hosts_proof(hash_name):
+    """hostlib.gl_prove (host/goldilocks_prover.cpp: the 64-bit field's claim in the C++ host - coin, transcript, every stage's call) against
+    goldilocks.Prover on the same statement: the same proof, array for array - and with it, for "blake2s", the MI355X-made fixture"""
+    import torch
+    from sandstorm_amd import goldilocks as gs, hostlib
+    from sandstorm_amd.backend import Context
+    prog = pl.example_program(10)
+    states, memory = pl.run(prog, 64)
+    pi = pl.public_input_of(prog, states, memory)
+    cols = pl.base_trace(states, memory, pi)
+    ctx = Context(0)
+    try:
+        base = [torch.from_numpy(np.array(c, dtype=np.uint64).view(np.int64)) for c in cols]
+        air, seed = gs.plain_air(), bytes(range(32))
+        opt = gs.Options(num_queries=20, grinding=8, hash=hash_name)
+        ext = lambda ch: gs.plain_extension_on_device(ctx, base, ch)[0]
+        want = gs.proof_to_arrays(gs.Prover(ctx, air, opt).prove(seed, base, ext, statement=pi))
+        proof = hostlib.gl_prove(ctx, air, opt, seed, base, ext, statement=pi)
+        got = gs.proof_to_arrays(proof)
+        assert set(got) == set(want)
+        for k in sorted(want):
+            assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), k
+        gs.verify(proof, air, seed, statement=pi, expected_options=opt, required_security_bits=28)
+    finally:
+        ctx.close()

@@ -69,7 +69,7 @@ def test_the_64_bit_field(emulated_library):
     # (the whole proof: the Python host over the C ABI with CPU tensors as device buffers writes the MI355X-made fixture)
     out = run_gpu_tests_on_host(emulated_library, ["tests/test_goldilocks.py", "tests/hipemu/extra_gl64_sizes.py", "tests/hipemu/extra_gl64_proof.py",
                                                    "-k", "not benchmark_size"])
-    assert "59 passed" in out, out[-500:]                     # 34 + 17 sizes + folds, row shapes (SHA-256's padding edges too), running products + 2 proofs
+    assert "61 passed" in out, out[-500:]                     # 34 + 17 sizes + folds, row shapes (SHA-256's padding edges too), running products + 2 proofs + the C++ host's two
 
 
 def test_extension_columns_and_compiled_constraint_kernels(emulated_library):

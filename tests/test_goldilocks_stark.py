@@ -179,6 +179,28 @@ def test_the_claim_with_the_parts_the_reference_names_for_it(proved):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hash_name", ["blake2s", "sha256"])
+def test_cpp_host_writes_the_python_hosts_proof(proved, hash_name):
+    """hostlib.gl_prove (host/goldilocks_prover.cpp: the claim in the C++ host) against goldilocks.Prover on the MI355X: the same proof,
+    array for array"""
+    import dataclasses
+    import torch
+    from sandstorm_amd import hostlib
+    gs, air, pi, cols, prove, opt = proved
+    o = dataclasses.replace(opt, hash=hash_name)
+    want = gs.proof_to_arrays(prove(cols, o))
+    ctx = prove.ctx
+    dev = torch.device("cuda", 0)
+    base = [torch.from_numpy(np.array(c, dtype=np.uint64).view(np.int64)).to(dev) for c in cols]
+    proof = hostlib.gl_prove(ctx, air, o, bytes(range(32)), base, lambda ch: gs.plain_extension_on_device(ctx, base, ch)[0], statement=pi)
+    got = gs.proof_to_arrays(proof)
+    assert set(got) == set(want)
+    for k in sorted(want):
+        assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), k
+    gs.verify(proof, air, bytes(range(32)), statement=pi, expected_options=o, required_security_bits=28)
+
+
+@pytest.mark.gpu
 def test_tampered_proofs_and_statements_are_rejected(proved):
     gs, air, pi, cols, prove, opt = proved
     proof = prove(cols)
