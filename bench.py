@@ -352,7 +352,13 @@ def bench_goldilocks_plain(args, log_steps, rank, local_rank, world, device):
     base = [cols[c] for c in range(5)]
     # the extension column's running products are built on the device inside the timed region (check=False: synthetic columns are
     # not permutations of each other)
-    step = lambda: prover.prove(seed, base, lambda ch: gs.plain_extension_on_device(ctx, base, ch, check=False)[0], statement=pi)
+    build_ext = lambda ch: gs.plain_extension_on_device(ctx, base, ch, check=False)[0]
+    tables = air.make_tables(n, opt.log_blowup)     # periodic columns of (n, blowup): constants like the twiddles, kept across proofs
+    if args.gl_host == "cpp":
+        from sandstorm_amd import hostlib
+        step = lambda: hostlib.gl_prove(ctx, air, opt, seed, base, build_ext, tables=tables, statement=pi)
+    else:
+        step = lambda: prover.prove(seed, base, build_ext, statement=pi, tables=tables)
 
     def barrier():
         if world > 1:
@@ -395,7 +401,8 @@ def bench_goldilocks_plain(args, log_steps, rank, local_rank, world, device):
                                           % (opt.num_queries, opt.grinding, opt.fold, opt.max_remainder),
                          "claim": "this library's own instantiation (Blake2s trees over the rows' bytes, Keccak coin, Fq3 columns as three "
                                   "coordinate columns): the reference's parts for this claim are un-vendored - PARITY UNPINNED",
-                         "host": "Python host (sandstorm_amd/goldilocks.py) over the C ABI", "fri_layers": len(proof.fri_layers),
+                         "host": ("C++ host (host/goldilocks_prover.cpp, ssh_gl_prove) over the C ABI; the layout's composition is lowered in Python per proof"
+                                  if args.gl_host == "cpp" else "Python host (sandstorm_amd/goldilocks.py) over the C ABI"), "fri_layers": len(proof.fri_layers),
                          "outside": "host trace generation: base columns resident in HBM",
                          "per_gpu": "one independent proof per rank"},
               "stage_ms_per_proof": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
@@ -1017,6 +1024,9 @@ def main():
                     help="skip the one extra, untimed proof whose launches are stamped for the stages' shader clocks (the counter passes of "
                          "tools/*.sh count kernels per run: two proofs, not three)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the files -> proof leg (trace generation + upload + proof of a real statement)")
+    ap.add_argument("--gl-host", default="cpp", choices=["python", "cpp"],
+                    help="--workload goldilocks_plain_*: the host above the C ABI - host/goldilocks_prover.cpp (ssh_gl_prove) or "
+                         "sandstorm_amd/goldilocks.py; both write the same proof")
     ap.add_argument("--sharded-host", default="cpp", choices=["python", "cpp"],
                     help="--mode shard: the driver above the C ABI - the C++ host's sharded.cpp over RCCL (ss_comm_*; default: every "
                          "single-vector transform and the large FRI layers spread over the ranks), or sandstorm_amd/sharded_prover.py "

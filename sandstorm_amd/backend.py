@@ -395,6 +395,10 @@ class Context:
         check(self.lib.ss_diluted_aggregate(self.handle, _ptr_of(ordered), stride, offset, count, zp, ap, _ptr_of(out),
                                             out_stride, out_offset))
 
+    def dev_copy_2d(self, dst, dst_pitch, src, src_pitch, width, rows, dst_offset=0, src_offset=0):
+        """ss_dev_copy_2d: `rows` runs of `width` bytes, row r from src + src_offset + r * src_pitch to dst + dst_offset + r * dst_pitch"""
+        check(self.lib.ss_dev_copy_2d(self.handle, _ptr_of(dst) + dst_offset, dst_pitch, _ptr_of(src) + src_offset, src_pitch, width, rows))
+
     def upload_async(self, dst, host_array):
         """ss_upload_async: the copy leaves on the context's copy stream and the call returns; `host_array` (pinned, contiguous) must stay
         untouched until the copy is done.  -> the ticket for wait_upload"""

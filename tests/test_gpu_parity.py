@@ -215,6 +215,26 @@ def test_uploads_on_the_copy_stream_are_ordered_by_their_tickets(ctx, be, oracle
     assert np.array_equal(bufs[0].download(np.uint64, (1 << log_n, 4)), cols[1])
 
 
+@pytest.mark.parametrize("width,src_pitch,dst_pitch", [(8, 24, 8), (8, 8, 16), (32, 96, 32), (24, 24, 40), (64, 72, 64), (72, 80, 72), (12, 16, 12), (4, 8, 4)])
+def test_rows_copied_between_pitches(ctx, width, src_pitch, dst_pitch):
+    """ss_dev_copy_2d: a coordinate out of interleaved triples, a column spread over every other slot, a leaf block's comb - rows of whole
+    64-bit words go through the library's own kernel, every other shape through the runtime's rectangular copy; both against numpy, at
+    offsets inside the buffers, with what lies between the rows of the destination left alone"""
+    rng = np.random.default_rng(width * 1000 + src_pitch)
+    for rows in (1, 257, 5000):
+        so, do = 8 * 3, 8 * 2
+        src = rng.integers(0, 256, so + rows * src_pitch, dtype=np.uint8)
+        dst0 = rng.integers(0, 256, do + rows * dst_pitch + 16, dtype=np.uint8)
+        d_src, d_dst = ctx.alloc(src.nbytes), ctx.alloc(dst0.nbytes)
+        d_src.upload(src)
+        d_dst.upload(dst0)
+        ctx.dev_copy_2d(d_dst, dst_pitch, d_src, src_pitch, width, rows, dst_offset=do, src_offset=so)
+        want = dst0.copy()
+        for r in range(rows):
+            want[do + r * dst_pitch:do + r * dst_pitch + width] = src[so + r * src_pitch:so + r * src_pitch + width]
+        assert np.array_equal(d_dst.download(np.uint8, (dst0.nbytes,)), want), (width, rows)
+
+
 def test_fri_fold_rows_of_a_layer(ctx, be, oracle):
     """ss_fri_fold_rows: a layer folded range by range (each range's entries column after column) is the layer folded whole"""
     log_len, fold = 12, 8
