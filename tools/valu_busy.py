@@ -41,9 +41,10 @@ if len(sys.argv) > 3:
     STAGES = {"ntt_pass": ["ntt_pass_kernel"], "quotient": ["quotient_"], "deep": ["deep_kernel", "deep_rational", "ood_blocks", "ood_fold", "batch_inverse", "poly_reduce"],
               "hash_rows": ["keccak_rows", "blake2s_rows"], "merkle": ["_pairs_kernel", "pedersen_", "felt_pairs"], "fri_fold": ["fri_fold_kernel"],
               "extension_scans": ["scan_", "perm_", "dil_", "inverse_dense"]}
+    ONE_TIME = ("pedersen_build_windows", "pedersen_join_halves")       # the window table's build: once per process, not a proof's work
     out = {}
     for stage, keys in STAGES.items():
-        sel = [a for k, a in agg.items() if any(key in k for key in keys) and a.get("SQ_INSTS_VALU")]
+        sel = [a for k, a in agg.items() if any(key in k for key in keys) and a.get("SQ_INSTS_VALU") and not any(o in k for o in ONE_TIME)]
         ns, gui, iv = sum(a["_ns"] for a in sel), sum(a.get("GRBM_GUI_ACTIVE", 0.0) for a in sel) / 8.0, sum(a["SQ_INSTS_VALU"] for a in sel)
         if ns and gui:
             out[stage] = {"kernel_ms_in_run": ns / 1e6, "grbm_gui_active_per_xcd": gui, "effective_clock_ghz": gui / ns,
