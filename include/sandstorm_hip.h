@@ -78,7 +78,7 @@ enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
 const char *ss_last_error(void);
 /* ABI version of this header; bump on any signature change.  ss_abi_version() of the loaded
  * library must equal SS_ABI_VERSION of the header the caller was built against. */
-#define SS_ABI_VERSION 9u
+#define SS_ABI_VERSION 10u
 uint32_t ss_abi_version(void);
 
 /* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;
@@ -216,6 +216,21 @@ ss_status ss_merkle_open(ss_ctx *ctx, const uint8_t *d_nodes, const uint8_t *d_t
 /* gather full rows `idx` of a column-major matrix to the host (query phase) */
 ss_status ss_gather_rows(ss_ctx *ctx, const uint64_t *const *d_cols, uint32_t ncols,
                          const uint64_t *idx, uint32_t nidx, uint64_t *out /* nidx*ncols felts */);
+/* The whole query phase in one round trip (ABI 10): every job gathers entries `idx` of `ncols` device arrays of `entry_bytes`-byte entries
+ * (32: field elements or digests - the opened rows of a matrix, a tree's leaf digests, or authentication paths with idx = the sibling
+ * node numbers over the node array as one "column"; 1: the tag bytes of a FriendlyMerkleTree's nodes, ncols = 1) into host memory
+ * `out`, nidx * ncols entries, row after row - what ss_gather_rows / ss_merkle_open return, but one index upload, one download and one
+ * synchronisation for all jobs (`Queries::new` + `MerkleTree::prove` over the three trace trees and every FRI layer: 27 calls of
+ * ~60 us each before).  Jobs with nidx = 0 are skipped. */
+typedef struct ss_gather_job {
+    const void *const *d_cols;
+    uint32_t ncols;
+    uint32_t entry_bytes;      /* 32 or 1 */
+    const uint64_t *idx;       /* host */
+    uint32_t nidx;
+    void *out;                 /* host: nidx * ncols * entry_bytes */
+} ss_gather_job;
+ss_status ss_gather_batch(ss_ctx *ctx, const ss_gather_job *jobs, uint32_t njobs);
 
 /* ---- Q1: AirConfig::eval_constraint over the LDE domain (ministark default
  *      body; DAG built by layouts/src/{recursive,starknet}/air.rs).

@@ -38,6 +38,12 @@ class AirProgram(C.Structure):
                 ("n_tables", C.c_uint32), ("n_slots", C.c_uint32)]
 
 
+class GatherJob(C.Structure):
+    """ss_gather_job"""
+    _fields_ = [("d_cols", C.POINTER(C.c_void_p)), ("ncols", C.c_uint32), ("entry_bytes", C.c_uint32), ("idx", C.POINTER(C.c_uint64)),
+                ("nidx", C.c_uint32), ("out", C.c_void_p)]
+
+
 class PermOperand(C.Structure):
     """ss_perm_operand"""
     _fields_ = [("d_data", C.c_void_p), ("stride", C.c_uint64), ("addr_offset", C.c_uint64), ("value_offset", C.c_int64)]
@@ -87,6 +93,7 @@ SIGNATURES = {
     "ss_merkle_open": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, _u64p, C.c_uint32,
                                  C.c_void_p, C.c_void_p]),
     "ss_gather_rows": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, _u64p, C.c_uint32, C.c_void_p]),
+    "ss_gather_batch": (C.c_int, [C.c_void_p, C.POINTER(GatherJob), C.c_uint32]),
     "ss_inverse_table": (C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p, C.c_void_p]),
     "ss_eval_quotient": (C.c_int, [C.c_void_p, C.POINTER(AirProgram), _vpp, C.c_uint32, C.c_uint32,
                                    C.c_uint32, _u64p, C.c_void_p]),

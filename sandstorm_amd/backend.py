@@ -208,6 +208,26 @@ class Context:
                                       idx.ctypes.data_as(C.POINTER(C.c_uint64)), len(idx), out.ctypes.data))
         return out
 
+    def gather_batch(self, jobs):
+        """ss_gather_batch: jobs = [(device arrays, entry_bytes (32 | 1), indices)] -> one array per job, uint64[nidx, ncols, 4] for 32-byte
+        entries / uint8[nidx] for single bytes; one upload, one download, one synchronisation for all of them"""
+        from ._lib import GatherJob
+        arr = (GatherJob * max(1, len(jobs)))()
+        keep, outs = [], []
+        for j, (cols, entry_bytes, indices) in enumerate(jobs):
+            idx = np.ascontiguousarray(indices, dtype=np.uint64)
+            out = np.zeros((len(idx), len(cols), 4), dtype=np.uint64) if entry_bytes == 32 else np.zeros(len(idx) * len(cols), dtype=np.uint8)
+            ptrs = _ptr_array(cols)
+            keep.append((idx, ptrs))
+            outs.append(out)
+            arr[j].d_cols = C.cast(ptrs, C.POINTER(C.c_void_p))
+            arr[j].ncols, arr[j].entry_bytes = len(cols), entry_bytes
+            arr[j].idx = idx.ctypes.data_as(C.POINTER(C.c_uint64))
+            arr[j].nidx = len(idx)
+            arr[j].out = out.ctypes.data
+        check(self.lib.ss_gather_batch(self.handle, arr, len(jobs)))
+        return outs
+
     def fri_fold(self, evals, log_len, fold, alpha, offset, out, flags=0):
         """flags: FRI_BITREV_ROWS | FRI_UNNORMALISED (include/sandstorm_hip.h: the conventions of the reference's proofs)"""
         _k1, a = _felt_ptr(alpha)

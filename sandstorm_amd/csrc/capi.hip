@@ -69,12 +69,20 @@ Fp fp_from_limbs64(const uint64_t v[4]) {
     return a;
 }
 
-// 3^((p-1)/2^log_n), (p-1) = (2^59+17) * 2^192
-Fp root_of_unity(uint32_t log_n) {
-    Fp c = fp_pow_u64(fp_from_u64(3), (1ull << 59) + 17ull);
-    for (uint32_t i = 0; i < 192 - log_n; ++i) c = fp_sqr(c);
-    return c;
-}
+// 3^((p-1)/2^log_n), (p-1) = (2^59+17) * 2^192, and its inverse: both from a table made once per process (the 8 x 32-bit arithmetic of
+// fp252.h is shaped for the device: on a host core the ~230 squarings of one root cost 35 us and a power-ladder inversion 67 us, and a proof
+// asked for ~60 of them between its launches - 2 ms of idle device, profiles/r05_host_gaps.txt)
+struct RootTable {
+    Fp w[193], wi[193];
+    RootTable() {
+        Fp c = fp_pow_u64(fp_from_u64(3), (1ull << 59) + 17ull);
+        for (int k = 192; k >= 0; --k) { w[k] = c; c = fp_sqr(c); }
+        for (int k = 0; k <= 192; ++k) wi[k] = fp_inv_safegcd(w[k]);
+    }
+};
+const RootTable &root_table() { static const RootTable t; return t; }
+Fp root_of_unity(uint32_t log_n) { return root_table().w[log_n <= 192 ? log_n : 192]; }
+Fp root_of_unity_inv(uint32_t log_n) { return root_table().wi[log_n <= 192 ? log_n : 192]; }
 
 }  // namespace
 
@@ -294,7 +302,7 @@ struct ss_ctx {
                          uint32_t win_stages = 0) {
         const uint64_t n = 1ull << log_n;
         Fp r = root_of_unity(log_n), h = offset;
-        if (inverse) { r = fp_inv(r); h = fp_inv(h); }
+        if (inverse) { r = root_of_unity_inv(log_n); h = fp_inv_safegcd(h); }
         const bool h_is_one = fp_eq(h, fp_one());
         const uint64_t half = n / 2 ? n / 2 : 1;
         const uint64_t n_lo = half < 4096 ? half : 4096, n_hi = half < 4096 ? 1 : half / 4096;
@@ -451,7 +459,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns, ss_upload_async / ss_wait_upload (uploads on a copy stream, ordered into the context's stream by ticket), SS_HASH_SHA256 / SS_TREE_SHA256 for the 64-bit field's rows and trees
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns, ss_upload_async / ss_wait_upload (uploads on a copy stream, ordered into the context's stream by ticket), SS_HASH_SHA256 / SS_TREE_SHA256 for the 64-bit field's rows and trees; 10: ss_gather_batch (the query phase's gathers in one round trip)
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -1125,14 +1133,58 @@ ss_status ss_gather_rows(ss_ctx *ctx, const uint64_t *const *d_cols, uint32_t nc
     uint64_t *d_idx = (uint64_t *)ctx->scratch;
     uint8_t *d_out = (uint8_t *)ctx->scratch + (size_t)nidx * 8;
     HIP_TRY(hipMemcpyAsync(d_idx, idx, (size_t)nidx * 8, hipMemcpyHostToDevice, ctx->stream));
-    for (uint32_t c = 0; c < ncols; ++c)
-        HIP_TRY(launch_gather32(ctx->stream, (const uint8_t *)d_cols[c], d_idx, nidx, d_out + (size_t)c * nidx * 32));
-    std::vector<uint64_t> tmp((size_t)nidx * ncols * 4);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), d_out, tmp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    // one launch per MAX_COLS columns, written row after row: the download is the caller's array
+    for (uint32_t c0 = 0; c0 < ncols; c0 += (uint32_t)MAX_COLS)
+        HIP_TRY(launch_gather32_cols(ctx->stream, (const void *const *)d_cols + c0, std::min<uint32_t>((uint32_t)MAX_COLS, ncols - c0), c0, ncols, d_idx, nidx, d_out));
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)nidx * ncols * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (uint32_t q = 0; q < nidx; ++q)
-        for (uint32_t c = 0; c < ncols; ++c)
-            memcpy(out + ((size_t)q * ncols + c) * 4, tmp.data() + ((size_t)c * nidx + q) * 4, 32);
+    return SS_OK;
+}
+
+ss_status ss_gather_batch(ss_ctx *ctx, const ss_gather_job *jobs, uint32_t njobs) {
+    if (!ctx || (!jobs && njobs)) return fail(SS_ERR_INVALID, "NULL argument");
+    size_t n_idx = 0, out_bytes = 0;
+    for (uint32_t j = 0; j < njobs; ++j) {
+        const ss_gather_job &g = jobs[j];
+        if (!g.nidx || !g.ncols) continue;
+        if (!g.d_cols || !g.idx || !g.out) return fail(SS_ERR_INVALID, "job %u: NULL argument", j);
+        if (g.entry_bytes != 32 && !(g.entry_bytes == 1 && g.ncols == 1)) return fail(SS_ERR_INVALID, "job %u: entries of 32 bytes, or of 1 byte from one array", j);
+        if (has_null(g.d_cols, g.ncols)) return fail(SS_ERR_INVALID, "job %u: NULL column", j);
+        n_idx += g.nidx;
+        out_bytes += (((size_t)g.nidx * g.ncols * g.entry_bytes) + 31) & ~(size_t)31;      // every job's output 32-byte aligned
+    }
+    if (!n_idx) return SS_OK;
+    ss_status st = ctx->ensure_scratch(n_idx * 8 + out_bytes);
+    if (st != SS_OK) return st;
+    std::vector<uint64_t> all_idx;
+    all_idx.reserve(n_idx);
+    for (uint32_t j = 0; j < njobs; ++j)
+        if (jobs[j].nidx && jobs[j].ncols) all_idx.insert(all_idx.end(), jobs[j].idx, jobs[j].idx + jobs[j].nidx);
+    uint64_t *d_idx = (uint64_t *)ctx->scratch;
+    uint8_t *d_out = (uint8_t *)ctx->scratch + n_idx * 8;
+    HIP_TRY(hipMemcpyAsync(d_idx, all_idx.data(), n_idx * 8, hipMemcpyHostToDevice, ctx->stream));
+    size_t io = 0, oo = 0;
+    for (uint32_t j = 0; j < njobs; ++j) {
+        const ss_gather_job &g = jobs[j];
+        if (!g.nidx || !g.ncols) continue;
+        if (g.entry_bytes == 1) HIP_TRY(launch_gather8(ctx->stream, (const uint8_t *)g.d_cols[0], d_idx + io, g.nidx, d_out + oo));
+        else
+            for (uint32_t c0 = 0; c0 < g.ncols; c0 += (uint32_t)MAX_COLS)
+                HIP_TRY(launch_gather32_cols(ctx->stream, g.d_cols + c0, std::min<uint32_t>((uint32_t)MAX_COLS, g.ncols - c0), c0, g.ncols, d_idx + io, g.nidx, d_out + oo));
+        io += g.nidx;
+        oo += (((size_t)g.nidx * g.ncols * g.entry_bytes) + 31) & ~(size_t)31;
+    }
+    std::vector<uint8_t> host(out_bytes);
+    HIP_TRY(hipMemcpyAsync(host.data(), d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    oo = 0;
+    for (uint32_t j = 0; j < njobs; ++j) {
+        const ss_gather_job &g = jobs[j];
+        if (!g.nidx || !g.ncols) continue;
+        const size_t bytes = (size_t)g.nidx * g.ncols * g.entry_bytes;
+        memcpy(g.out, host.data() + oo, bytes);
+        oo += (bytes + 31) & ~(size_t)31;
+    }
     return SS_OK;
 }
 
@@ -1157,14 +1209,14 @@ static ss_status fri_fold_impl(ss_ctx *ctx, const uint64_t *d_evals, uint32_t lo
         if (!count) return SS_OK;
     }
     const Fp off = domain_offset ? fp_from_limbs64(domain_offset) : fp_one();
-    const Fp w_inv = fp_inv(root_of_unity(log_len));
-    const Fp wf_inv = fp_inv(root_of_unity(log_fold));
+    const Fp w_inv = root_of_unity_inv(log_len);
+    const Fp wf_inv = root_of_unity_inv(log_fold);
     Fp tw[8];
     tw[0] = fp_one();
     for (int k = 1; k < 8; ++k) tw[k] = fp_mul(tw[k - 1], wf_inv);
     ss_ctx::Scope prof(ctx, SS_PROF_FRI);
     HIP_TRY(launch_fri_fold(ctx->stream, (const Fp *)d_evals, log_len, log_fold, fp_from_limbs64(alpha),
-                            fp_inv(off), w_inv, tw, flags, (Fp *)d_out, row0, count));
+                            fp_inv_safegcd(off), w_inv, tw, flags, (Fp *)d_out, row0, count));
     return SS_OK;
 }
 ss_status ss_fri_fold_ex(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
@@ -1597,7 +1649,7 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
     const uint64_t n = 1ull << log_n;
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp zf = fp_from_limbs64(z);
-    const Fp wn_inv = fp_inv(root_of_unity(log_n));
+    const Fp wn_inv = root_of_unity_inv(log_n);
     // Taps of the denominator table, column by column (deep.hip): cell (col, off) reads D at shift `off` with coefficient
     // c' = coeff * w_n^-off (R280 form: times 2^24); one more "column" of constants carries -K_off = -sum_{cells at off} c' * ood.
     Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
@@ -1760,11 +1812,11 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
         if (block) {
             // D[j] <-> sub-coset point m0 - pre + j (indices modulo n: the powers of w_n wrap by themselves)
             const Fp x_d = fp_mul(off, fp_pow_u64(wn, (m0 + n - pre % n) % n)), x_c = fp_mul(off, fp_pow_u64(wn, m0 % n));
-            HIP_TRY(launch_batch_inverse_range(s, D, d_len, x_d, wn, fp_inv(wn), zf, true));
-            if (ncomp) HIP_TRY(launch_batch_inverse_range(s, Dc, dc_len, x_c, wn, fp_inv(wn), zc, true));
+            HIP_TRY(launch_batch_inverse_range(s, D, d_len, x_d, wn, root_of_unity_inv(log_n), zf, true));
+            if (ncomp) HIP_TRY(launch_batch_inverse_range(s, Dc, dc_len, x_c, wn, root_of_unity_inv(log_n), zc, true));
         } else {
-            HIP_TRY(launch_batch_inverse(s, D, log_n, off, wn, fp_inv(wn), zf, true));
-            if (ncomp) HIP_TRY(launch_batch_inverse(s, Dc, log_n, off, wn, fp_inv(wn), zc, true));
+            HIP_TRY(launch_batch_inverse(s, D, log_n, off, wn, root_of_unity_inv(log_n), zf, true));
+            if (ncomp) HIP_TRY(launch_batch_inverse(s, Dc, log_n, off, wn, root_of_unity_inv(log_n), zc, true));
         }
         HIP_TRY(launch_deep(s, (const void *const *)d_trace_lde, ntrace_cols, (const void *const *)d_comp_lde, ncomp, D, Dc,
                             d_tap_shift, d_tap_coef, d_cdesc, ncoldesc, d_comp_coef, comp_k, count,
@@ -1887,7 +1939,7 @@ ss_status ss_inverse_table(ss_ctx *ctx, uint32_t log_N, const uint64_t offset[4]
     const Fp off = offset ? fp_from_limbs64(offset) : fp_one();
     const Fp w = root_of_unity(log_N);
     ss_ctx::Scope prof(ctx, SS_PROF_QUOTIENT);
-    HIP_TRY(launch_batch_inverse(ctx->stream, (Fp *)d_out, log_N, off, w, fp_inv(w), fp_from_limbs64(cval), false));
+    HIP_TRY(launch_batch_inverse(ctx->stream, (Fp *)d_out, log_N, off, w, root_of_unity_inv(log_N), fp_from_limbs64(cval), false));
     return SS_OK;
 }
 

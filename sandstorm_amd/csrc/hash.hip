@@ -418,6 +418,18 @@ __global__ void gather32_kernel(const uint8_t *__restrict__ in, const uint64_t *
     uint4 *o = reinterpret_cast<uint4 *>(out + 32 * i);
     o[0] = q[0]; o[1] = q[1];
 }
+// rows of a column set: out[(q * row_cols + c0 + c)] = cols[c][idx[q]] for c < ncols - the opened rows in the order the proof lists them
+// (row after row), one launch for the chunk's columns
+__global__ void gather32_cols_kernel(ConstColPtrs cols, uint32_t ncols, uint32_t c0, uint32_t row_cols, const uint64_t *__restrict__ idx, uint64_t nidx,
+                                     uint8_t *__restrict__ out) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= nidx * ncols) return;
+    const uint64_t q = i / ncols;
+    const uint32_t c = (uint32_t)(i - q * ncols);
+    const uint4 *src = reinterpret_cast<const uint4 *>((const uint8_t *)cols.p[c] + 32 * idx[q]);
+    uint4 *o = reinterpret_cast<uint4 *>(out + 32 * (q * row_cols + c0 + c));
+    o[0] = src[0]; o[1] = src[1];
+}
 __global__ void gather8_kernel(const uint8_t *__restrict__ in, const uint64_t *__restrict__ idx, uint64_t n,
                                uint8_t *__restrict__ out) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -623,6 +635,14 @@ hipError_t launch_pow_grind(hipStream_t st, int coin_kind, const uint64_t *d_pre
 hipError_t launch_gather32(hipStream_t st, const uint8_t *in, const uint64_t *d_idx, uint64_t n, uint8_t *out) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(gather32_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, in, d_idx, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_gather32_cols(hipStream_t st, const void *const *d_cols, uint32_t ncols, uint32_t c0, uint32_t row_cols, const uint64_t *d_idx,
+                                uint64_t nidx, uint8_t *out) {
+    ConstColPtrs cp;
+    for (uint32_t c = 0; c < ncols; ++c) cp.p[c] = d_cols[c];
+    const uint64_t total = nidx * ncols;
+    hipLaunchKernelGGL(gather32_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cp, ncols, c0, row_cols, d_idx, nidx, out);
     return hipGetLastError();
 }
 hipError_t launch_gather8(hipStream_t st, const uint8_t *in, const uint64_t *d_idx, uint64_t n, uint8_t *out) {

@@ -53,6 +53,8 @@ hipError_t launch_pow_prefix(hipStream_t st, int coin_kind, const uint8_t digest
 hipError_t launch_pow_grind(hipStream_t st, int coin_kind, const uint64_t *d_prefix, uint32_t bits,
                             uint64_t start, uint64_t count, unsigned long long *d_best);
 hipError_t launch_gather32(hipStream_t st, const uint8_t *in, const uint64_t *d_idx, uint64_t n, uint8_t *out);
+hipError_t launch_gather32_cols(hipStream_t st, const void *const *d_cols, uint32_t ncols, uint32_t c0, uint32_t row_cols, const uint64_t *d_idx,
+                                uint64_t nidx, uint8_t *out);            // ncols <= MAX_COLS; out[(q * row_cols + c0 + c) * 32 ..]
 hipError_t launch_gather8(hipStream_t st, const uint8_t *in, const uint64_t *d_idx, uint64_t n, uint8_t *out);
 
 // ---- pedersen.hip

@@ -69,11 +69,46 @@ std::vector<uint8_t> MerkleTree::leaf_digests(const std::vector<uint64_t> &idx) 
     return out;
 }
 
-static std::vector<uint64_t> gather(ss_ctx *ctx, const std::vector<uint64_t *> &cols, const std::vector<uint64_t> &idx) {
-    std::vector<uint64_t> out(idx.size() * cols.size() * 4);
-    ok(ss_gather_rows(ctx, (const uint64_t *const *)cols.data(), (uint32_t)cols.size(), idx.data(), (uint32_t)idx.size(), out.data()));
-    return out;
+void MerkleTree::queue_openings(GatherBatch &batch, const std::vector<uint64_t> &idx, std::vector<uint8_t> *paths, std::vector<uint8_t> *tags,
+                                std::vector<uint8_t> *leaves) const {
+    const uint32_t log_n = log2u(n_);
+    // the siblings along each path, leaf level first (ss_merkle_open): node numbers of the heap-ordered node array
+    std::vector<uint64_t> sib(idx.size() * log_n);
+    for (size_t q = 0; q < idx.size(); ++q) {
+        if (idx[q] >= n_) throw std::runtime_error("leaf index out of range");
+        uint64_t k = n_ + idx[q];
+        for (uint32_t l = 0; l < log_n; ++l) { sib[q * log_n + l] = k ^ 1ull; k >>= 1; }
+    }
+    if (tags) {
+        tags->assign(idx.size() * log_n, 0);
+        if (tags_) batch.entries(tags_->u8(), 1, sib, tags);
+    }
+    if (paths) batch.entries(nodes_->u8(), 32, std::move(sib), paths);
+    if (leaves) {
+        leaves->clear();
+        if (leaves_ && !idx.empty()) batch.entries(leaves_->u8(), 32, idx, leaves);
+    }
 }
+
+void GatherBatch::rows(const std::vector<uint64_t *> &cols, const std::vector<uint64_t> &idx, std::vector<uint64_t> *out) {
+    out->assign(idx.size() * cols.size() * 4, 0);
+    if (idx.empty() || cols.empty()) return;
+    idx_.push_back(idx);
+    cols_.emplace_back(cols.begin(), cols.end());
+    jobs_.push_back(ss_gather_job{cols_.back().data(), (uint32_t)cols.size(), 32u, idx_.back().data(), (uint32_t)idx.size(), out->data()});
+}
+void GatherBatch::entries(const void *d_array, uint32_t entry_bytes, std::vector<uint64_t> idx, std::vector<uint8_t> *out) {
+    out->assign(idx.size() * entry_bytes, 0);
+    if (idx.empty()) return;
+    idx_.push_back(std::move(idx));
+    cols_.push_back(std::vector<const void *>{d_array});
+    jobs_.push_back(ss_gather_job{cols_.back().data(), 1u, entry_bytes, idx_.back().data(), (uint32_t)idx_.back().size(), out->data()});
+}
+void GatherBatch::run() {
+    if (!jobs_.empty()) ok(ss_gather_batch(ctx_, jobs_.data(), (uint32_t)jobs_.size()));
+    jobs_.clear(); idx_.clear(); cols_.clear();
+}
+
 static std::vector<uint64_t> flat(const std::vector<Felt> &v) {
     std::vector<uint64_t> o(4 * v.size());
     for (size_t i = 0; i < v.size(); ++i) memcpy(o.data() + 4 * i, v[i].data(), 32);
@@ -151,12 +186,14 @@ uint64_t proof_of_work(ss_ctx *ctx, const Claim &claim, PublicCoin &coin, const 
 }
 
 void fri_open(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Proof &proof, std::vector<FriLayerState> &layers,
-              const std::vector<uint64_t> &positions) {
-    fri_open_from(ctx, conv, opt, proof, layers, positions, 0);
+              const std::vector<uint64_t> &positions, GatherBatch *batch) {
+    fri_open_from(ctx, conv, opt, proof, layers, positions, 0, batch);
 }
 // layers[k] is the proof's layer first + k; `positions`: the query positions as folded down to layer `first`'s index space
 void fri_open_from(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Proof &proof, std::vector<FriLayerState> &layers_from,
-                   const std::vector<uint64_t> &positions, size_t first) {
+                   const std::vector<uint64_t> &positions, size_t first, GatherBatch *batch) {
+    GatherBatch own(ctx);
+    GatherBatch &gb = batch ? *batch : own;
     const uint32_t log_fold = log2u(opt.fri_folding_factor);
     std::vector<uint64_t> p = positions;
     for (size_t li = first; li < first + layers_from.size(); ++li) {
@@ -169,10 +206,10 @@ void fri_open_from(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt
         std::vector<uint64_t> nat_rows = p;
         if (conv.bitrev_commit) for (auto &r : nat_rows) r = brev_bits(r, row_bits);
         proof.fri_layers[li].positions = p;
-        proof.fri_layers[li].rows = gather(ctx, layer.matrix.cols, nat_rows);
-        proof.fri_layers[li].paths = layer.tree->prove(p, &proof.fri_layers[li].path_tags);
-        proof.fri_layers[li].leaves = layer.tree->leaf_digests(p);
+        gb.rows(layer.matrix.cols, nat_rows, &proof.fri_layers[li].rows);
+        layer.tree->queue_openings(gb, p, &proof.fri_layers[li].paths, &proof.fri_layers[li].path_tags, &proof.fri_layers[li].leaves);
     }
+    if (!batch) own.run();
 }
 
 // ------------------------------------------------------------------------- prove
@@ -316,18 +353,17 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     // a position is an index into the COMMITTED order; the matrices themselves are in natural order
     std::vector<uint64_t> nat = pos;
     if (conv_.bitrev_commit) for (auto &q : nat) q = brev(q, log_N);
-    proof.base_rows = gather(ctx_, base_lde.cols, nat);
-    proof.base_paths = base_tree->prove(pos, &proof.base_path_tags);
-    proof.base_leaves = base_tree->leaf_digests(pos);
+    GatherBatch gb(ctx_);                       // every opening of the proof in one round trip to the device
+    gb.rows(base_lde.cols, nat, &proof.base_rows);
+    base_tree->queue_openings(gb, pos, &proof.base_paths, &proof.base_path_tags, &proof.base_leaves);
     if (ext_tree) {
-        proof.extension_rows = gather(ctx_, ext_lde.cols, nat);
-        proof.extension_paths = ext_tree->prove(pos, &proof.extension_path_tags);
-        proof.extension_leaves = ext_tree->leaf_digests(pos);
+        gb.rows(ext_lde.cols, nat, &proof.extension_rows);
+        ext_tree->queue_openings(gb, pos, &proof.extension_paths, &proof.extension_path_tags, &proof.extension_leaves);
     }
-    proof.composition_rows = gather(ctx_, comp_lde.cols, nat);
-    proof.composition_paths = comp_tree->prove(pos, &proof.composition_path_tags);
-    proof.composition_leaves = comp_tree->leaf_digests(pos);
-    fri_open(ctx_, conv_, opt_, proof, layers, pos);
+    gb.rows(comp_lde.cols, nat, &proof.composition_rows);
+    comp_tree->queue_openings(gb, pos, &proof.composition_paths, &proof.composition_path_tags, &proof.composition_leaves);
+    fri_open(ctx_, conv_, opt_, proof, layers, pos, &gb);
+    gb.run();
     mark("pow + openings");
     return proof;
 }

@@ -4,6 +4,7 @@
 // proof data is a call into libsandstorm_hip.so.
 #pragma once
 #include <cstdint>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <string>
@@ -62,6 +63,25 @@ struct Matrix {
     uint32_t num_cols() const { return (uint32_t)cols.size(); }
 };
 
+class MerkleTree;
+// The query phase's gathers - opened rows, authentication paths, leaf digests of every tree - collected and run as ONE ss_gather_batch:
+// one index upload, one download, one synchronisation (27 calls of ~60 us with an idle device before: profiles/r05_host_gaps.txt).
+// The output vectors are sized when queued and filled by run(); they must stay where they are until then.
+class GatherBatch {
+public:
+    explicit GatherBatch(ss_ctx *ctx) : ctx_(ctx) {}
+    // rows `idx` of a column-major matrix of 32-byte elements -> out[idx.size() * cols.size() * 4], row after row (ss_gather_rows)
+    void rows(const std::vector<uint64_t *> &cols, const std::vector<uint64_t> &idx, std::vector<uint64_t> *out);
+    // entries `idx` of one device array of `entry_bytes`-byte entries -> out
+    void entries(const void *d_array, uint32_t entry_bytes, std::vector<uint64_t> idx, std::vector<uint8_t> *out);
+    void run();
+private:
+    ss_ctx *ctx_;
+    std::vector<ss_gather_job> jobs_;
+    std::deque<std::vector<uint64_t>> idx_;             // (deque: the jobs point into these)
+    std::deque<std::vector<const void *>> cols_;
+};
+
 // MatrixMerkleTree::from_matrix / MerkleTree::{root, prove} (crypto/src/merkle/mod.rs:72-123, 258-304)
 class MerkleTree {
 public:
@@ -74,6 +94,9 @@ public:
     // the row digests at these leaf indices (32 bytes each); empty for a single-column tree, whose leaves are the
     // elements themselves
     std::vector<uint8_t> leaf_digests(const std::vector<uint64_t> &idx) const;
+    // prove + leaf_digests as jobs of a batch (the same bytes, after batch.run())
+    void queue_openings(GatherBatch &batch, const std::vector<uint64_t> &idx, std::vector<uint8_t> *paths, std::vector<uint8_t> *tags,
+                        std::vector<uint8_t> *leaves) const;
     uint64_t n() const { return n_; }
 private:
     ss_ctx *ctx_ = nullptr;
@@ -150,10 +173,11 @@ std::vector<FriLayerState> fri_commit_phase(ss_ctx *ctx, const Claim &claim, con
 std::vector<FriLayerState> fri_commit_phase_from(ss_ctx *ctx, const Claim &claim, const Conventions &conv, const ProofOptions &opt, PublicCoin &coin,
                                                  Proof &proof, std::shared_ptr<DeviceBuffer> evals, uint32_t log_len, Felt offset, uint64_t degree_bound);
 uint64_t proof_of_work(ss_ctx *ctx, const Claim &claim, PublicCoin &coin, const ProofOptions &opt, bool have_nonce, uint64_t nonce);
+// (batch: the openings join it and the caller runs it; NULL: a batch of their own)
 void fri_open_from(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Proof &proof, std::vector<FriLayerState> &layers_from,
-                   const std::vector<uint64_t> &positions, size_t first);
+                   const std::vector<uint64_t> &positions, size_t first, GatherBatch *batch = nullptr);
 void fri_open(ss_ctx *ctx, const Conventions &conv, const ProofOptions &opt, Proof &proof, std::vector<FriLayerState> &layers,
-              const std::vector<uint64_t> &positions);
+              const std::vector<uint64_t> &positions, GatherBatch *batch = nullptr);
 
 // build_extension_columns(&challenges) (layouts/src/recursive/trace.rs:699-814): returns the
 // extension columns, resident in HBM

@@ -10,7 +10,7 @@ import pytest
 
 # calls that legitimately succeed with nothing to do
 FINE_WITH_NOTHING = {"ss_ctx_sync", "ss_ctx_trim", "ss_ctx_set_stream", "ss_profile_enable", "ss_profile_reset", "ss_dev_zero", "ss_dev_free",
-                     "ss_upload", "ss_download", "ss_dev_copy", "ss_dev_copy_2d"}
+                     "ss_upload", "ss_download", "ss_dev_copy", "ss_dev_copy_2d", "ss_gather_batch"}
 # ... and calls whose remaining arguments cannot be wrong: no stream / a NULL pointer to free / any flag / NULL outputs
 ALWAYS_FINE = {"ss_ctx_sync", "ss_ctx_trim", "ss_profile_reset", "ss_ctx_set_stream", "ss_dev_free", "ss_profile_enable", "ss_profile_read", "ss_profile_read_clock"}
 # the first argument of these is a communicator, not a context (a NULL one is refused; there is none to hand in without RCCL)

@@ -51,7 +51,7 @@ def test_every_kernel_against_the_oracle(emulated_library):
     VM, proof of work - the 252-bit path's parity tests, all but the two that only exist for their size"""
     # (the trees of this file are small: the 32-lanes-per-hash Pedersen kernel serves their levels as it does on the device)
     out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_parity.py", "-k", "not large_impulse"], SS_PED_SMALL_MAX="1024")
-    assert "200 passed" in out, out[-500:]
+    assert "207 passed" in out, out[-500:]
 
 
 def test_sweeps_over_the_sizes_the_gpu_suite_samples(emulated_library):

@@ -4,6 +4,7 @@ oracle cannot reach in seconds — through size-independent properties.
 
 Bar: bit-exact (integer / byte work).  Run with `pytest -m gpu` on an MI355X.
 """
+import os
 import numpy as np
 import pytest
 
@@ -233,6 +234,89 @@ def test_rows_copied_between_pitches(ctx, width, src_pitch, dst_pitch):
         for r in range(rows):
             want[do + r * dst_pitch:do + r * dst_pitch + width] = src[so + r * src_pitch:so + r * src_pitch + width]
         assert np.array_equal(d_dst.download(np.uint8, (dst0.nbytes,)), want), (width, rows)
+
+
+def test_profiled_launches_are_counted_timed_and_clocked(ctx, be, oracle):
+    """ss_profile_enable / ss_profile_reset / ss_profile_read / ss_profile_read_clock (what bench.py's stage times, launch counts and
+    stage clocks are read from): launches of a family are counted and timed only while profiling is on; at level 2 the stamps around them
+    give shader cycles and reference ticks whose ratio is a clock an MI355X can run at (the reference counter ticks at 100 MHz); results do
+    not depend on the level"""
+    log_n = 14
+    col = random_column(1 << log_n, 4242)
+    want = oracle.ntt(col)
+    buf = ctx.alloc(32 << log_n)
+    emulated = os.environ.get("SS_TEST_HIPEMU") == "1"         # (no shader clock to stamp on the host: levels 0 and 1 only)
+    for level in (0, 1) if emulated else (0, 1, 2):
+        ctx.profile(level)
+        ctx.profile_reset()
+        for _ in range(3):
+            buf.upload(col)
+            ctx.ntt([buf], log_n, be.FORWARD, None)
+        assert np.array_equal(buf.download(np.uint64, (1 << log_n, 4)), want), level
+        ms, launches = ctx.profile_read(be.PROF_NTT_PASS)
+        cycles, ref = ctx.profile_read_clock(be.PROF_NTT_PASS)
+        if level == 0:
+            assert launches == 0 and ms == 0.0 and cycles == 0.0 and ref == 0.0
+            continue
+        assert launches >= 3 and launches % 3 == 0 and (ms > 0.0 or emulated), (level, launches, ms)    # (the emulated events carry no time)
+        assert ctx.profile_read(be.PROF_DEEP) == (0.0, 0)       # a family that did not run
+        if level == 1:
+            assert cycles == 0.0 and ref == 0.0
+        else:
+            ghz = cycles / (ref / 100e6) / 1e9
+            assert ref > 0 and 0.3 < ghz < 3.5, (cycles, ref, ghz)
+        ctx.profile_reset()
+        assert ctx.profile_read(be.PROF_NTT_PASS) == (0.0, 0)
+    ctx.profile(False)
+
+
+@pytest.mark.parametrize("ncols", [1, 9, 16, 17, 37])
+def test_opened_rows_of_a_column_set(ctx, ncols):
+    """ss_gather_rows: the rows at the query positions, row after row (one launch per 16 columns writes them in that order), repeated and
+    unsorted positions included"""
+    n = 1 << 10
+    cols = [random_column(n, 7000 + c) for c in range(ncols)]
+    d = _up(ctx, cols)
+    idx = np.array([5, 0, n - 1, 5, 77, 512, 513, 1], dtype=np.uint64)
+    rows = ctx.gather_rows(d, idx)
+    assert rows.shape == (len(idx), ncols, 4)
+    for qi, q in enumerate(idx):
+        for c in range(ncols):
+            assert np.array_equal(rows[qi, c], cols[c][int(q)]), (qi, c)
+    assert ctx.gather_rows(d, np.zeros(0, dtype=np.uint64)).shape[0] == 0
+
+
+def test_query_phase_gathers_in_one_round_trip(ctx, be):
+    """ss_gather_batch: every job's entries as the single calls return them - opened rows (ss_gather_rows, also past 16 columns),
+    authentication paths and tag bytes (ss_merkle_open: the siblings' node numbers over the node array), leaf digests - with empty jobs
+    skipped and outputs of odd byte counts next to each other; malformed jobs are refused"""
+    from sandstorm_amd._lib import SandstormHipError
+    n = 1 << 9
+    cols = [random_column(n, 8100 + c) for c in range(19)]
+    d = _up(ctx, cols)
+    leaves = np.random.default_rng(5).integers(0, 256, (n, 32), dtype=np.uint8)
+    d_leaves = ctx.alloc(32 * n)
+    d_leaves.upload(leaves)
+    d_nodes, d_tags = ctx.alloc(64 * n), ctx.alloc(2 * n)
+    ctx.merkle_build(be.TREE_FRIENDLY, 3, be.LEAF_DIGEST, d_leaves, n, d_nodes, tags=d_tags)
+    pos = np.array([3, 500, 3, 0, n - 1], dtype=np.uint64)
+    log_n = 9
+    sib = np.array([((n + int(q)) >> l) ^ 1 for q in pos for l in range(log_n)], dtype=np.uint64)
+    few = np.array([7, 1, 300], dtype=np.uint64)
+    outs = ctx.gather_batch([(d, 32, pos), ([d_nodes], 32, sib), ([d_tags], 1, sib), (d[:3], 32, np.zeros(0, dtype=np.uint64)),
+                             ([d_leaves], 32, pos), ([d_tags], 1, few), (d[2:4], 32, few)])
+    assert np.array_equal(outs[0], ctx.gather_rows(d, pos))
+    paths, tags = ctx.merkle_open(d_nodes, d_tags, n, pos)
+    assert outs[1].tobytes() == np.asarray(paths).tobytes() and outs[2].tobytes() == np.asarray(tags).tobytes()
+    assert outs[3].shape[0] == 0
+    assert outs[4].tobytes() == leaves[pos.astype(np.int64)].tobytes()
+    all_tags = d_tags.download(np.uint8, (2 * n,))
+    assert np.array_equal(outs[5], all_tags[few.astype(np.int64)])
+    assert np.array_equal(outs[6], ctx.gather_rows(d[2:4], few))
+    assert ctx.gather_batch([]) == []
+    for bad in ([(d[:2], 1, few)], [(d[:1], 16, few)]):
+        with pytest.raises(SandstormHipError):
+            ctx.gather_batch(bad)
 
 
 def test_fri_fold_rows_of_a_layer(ctx, be, oracle):

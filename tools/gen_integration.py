@@ -13,7 +13,7 @@ BEGIN, END = "<!-- BEGIN GENERATED: tools/gen_integration.py -->", "<!-- END GEN
 
 SCALARS = {"uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8", "int": "c_int", "size_t": "usize", "int64_t": "i64", "void": "c_void",
            "char": "c_char", "double": "f64", "float": "f32", "ss_status": "c_int", "ss_ctx": "SsCtx", "ss_comm": "SsComm", "ss_air_program": "SsAirProgram",
-           "ss_perm_operand": "SsPermOperand"}
+           "ss_perm_operand": "SsPermOperand", "ss_gather_job": "SsGatherJob"}
 
 
 def prototypes(text=None):
@@ -76,6 +76,8 @@ def rust_block():
              "    pub code: *const u32, pub n_instr: u32,", "    pub consts: *const u64, pub n_consts: u32,",
              "    pub d_tables: *const u64, pub table_desc: *const u32, pub n_tables: u32,", "    pub n_slots: u32,", "}",
              "#[repr(C)] pub struct SsPermOperand {         // ss_perm_operand", "    pub d_data: *const u64, pub stride: u64, pub addr_offset: u64, pub value_offset: i64,", "}",
+             "#[repr(C)] pub struct SsGatherJob {           // ss_gather_job",
+             "    pub d_cols: *const *const c_void, pub ncols: u32, pub entry_bytes: u32, pub idx: *const u64, pub nidx: u32, pub out: *mut c_void,", "}",
              "#[link(name = \"sandstorm_hip\")]", "extern \"C\" {"]
     for name, ret, params in prototypes():
         args = ", ".join("%s: %s" % (p if p not in ("in", "type", "ref", "mod") else p + "_", rust_type(t)) for t, p in params)

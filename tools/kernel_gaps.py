@@ -18,7 +18,7 @@ def main():
     for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         with open(path) as fh:
             for r in csv.DictReader(fh):
-                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]))
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]))
     rows.sort()
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     cut = t1 - (t1 - t0) * frac
@@ -45,6 +45,28 @@ def main():
     print("kernel time in the window by name (ms, launches):")
     for name, (t, k) in sorted(by_name.items(), key=lambda kv: -kv[1][0])[:16]:
         print("  %9.3f %6d  %s" % (t / 1e6, k, name[:90]))
+    if os.environ.get("GAPS_SEQUENCE"):
+        # the launches of the window in order, runs of one kernel folded: when, how many, their time, the idle time before each run's launches
+        print("sequence (start ms, launches, kernel ms, idle us before / inside the run, kernel):")
+        run, last_end = None, rows[0][0]
+        for s_, e_, name in rows:
+            gap = max(0, s_ - last_end) / 1e3
+            if run and run[0] == name:
+                run[2] += 1; run[3] += e_ - s_; run[5] += gap
+            else:
+                if run:
+                    print("  %9.2f %5d %9.3f %8.1f %8.1f  %s" % ((run[1] - cut) / 1e6, run[2], run[3] / 1e6, run[4], run[5], run[0][:70]))
+                run = [name, s_, 1, e_ - s_, gap, 0.0]
+            last_end = max(last_end, e_)
+        print("  %9.2f %5d %9.3f %8.1f %8.1f  %s" % ((run[1] - cut) / 1e6, run[2], run[3] / 1e6, run[4], run[5], run[0][:70]))
+    pairs = {}
+    for g in gaps:
+        t = pairs.setdefault((g[1][:40], g[2][:40]), [0.0, 0])
+        t[0] += g[0]
+        t[1] += 1
+    print("idle time by (kernel before, kernel after) (ms, gaps):")
+    for (a, b), (t, k) in sorted(pairs.items(), key=lambda kv: -kv[1][0])[:14]:
+        print("  %9.3f %6d  %-40s -> %s" % (t / 1e3, k, a, b))
     for g in gaps:
         if g[0] >= min_gap:
             print("  at %8.2f ms  %9.1f us   after %-46s before %s" % (g[3], g[0], g[1][:46], g[2][:60]))
