@@ -32,4 +32,8 @@ bash tools/pmc_run.sh sq_final "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_
 bash tools/pmc_run.sh sq_final_rec "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" python $R/bench.py --workload recursive_2p20 --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-stage-clocks > $OUT/sq_counters_recursive_2p20.txt 2>&1
 for w in starknet_2p20 recursive_2p20; do bash tools/valu_busy.sh $w $OUT/valu_busy > $OUT/valu_busy_$w.log 2>&1; done
 bash tools/gl64_pmc.sh > $OUT/gl64_pmc.log 2>&1
+# where the device sat idle inside a proof (tools/kernel_gaps.py over a kernel trace of 4 proofs)
+for w in starknet_2p20 recursive_2p20 goldilocks_plain_2p20; do
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rp_gaps_$w && timeout 250 rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_gaps_$w -- python $R/bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-north-star --no-end-to-end --no-stage-clocks > /dev/null 2>&1; python $R/tools/kernel_gaps.py /tmp/rp_gaps_$w 300 0.45 > $OUT/kernel_gaps_$w.txt 2>&1)
+done
 ls $OUT
