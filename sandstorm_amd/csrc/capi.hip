@@ -109,9 +109,10 @@ __global__ void clock_probe_kernel(ClockStamp *out) {
 }
 // one wave: samples until `*stop` is set (the host writes it through a pinned mapping), the ring is full, or max_ticks reference
 // ticks have passed - whichever comes first, so a lost stop flag ends in seconds, not never
-__global__ __launch_bounds__(64) void clock_monitor_kernel(ClockStamp *ring, uint32_t slots, volatile uint32_t *stop, uint64_t max_ticks, uint32_t *count) {
+__global__ __launch_bounds__(64) void clock_monitor_kernel(ClockStamp *ring, uint32_t slots, volatile uint32_t *stop, uint64_t max_ticks, uint32_t *count,
+                                                           volatile uint32_t *started) {
 #if defined(HIPEMU)
-    if (threadIdx.x == 0) *count = 0;
+    if (threadIdx.x == 0) { *count = 0; *started = 1; }
 #else
     if (threadIdx.x != 0) return;
     uint64_t c, r, r0, next;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(64) void clock_monitor_kernel(ClockStamp *ring, uin
         clock_read(c, r);
         if (r >= next) {
             ring[n].cycles = c; ring[n].ref = r;
+            if (n == 0) { __threadfence_system(); *started = 1; }  // the host lets scopes stamp from here on (monitor_start)
             ++n;
             next = r + 2000;                                     // 20 us
             if (*stop || r - r0 > max_ticks) break;
@@ -234,15 +236,20 @@ struct ss_ctx {
             d_stamps = (ClockStamp *)p;
             if ((e = malloc_retry(&p, CLOCK_MONITOR_SLOTS * sizeof(ClockStamp))) != hipSuccess) return e;
             d_ring = (ClockStamp *)p;
-            if ((e = hipHostMalloc((void **)&h_stop, 2 * sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess) return e;
+            if ((e = hipHostMalloc((void **)&h_stop, 4 * sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess) return e;
             d_count = h_stop + 1;
             if ((e = hipStreamCreateWithFlags(&monitor_stream, hipStreamNonBlocking)) != hipSuccess) return e;
         }
-        h_stop[0] = 0; h_stop[1] = 0;
+        h_stop[0] = 0; h_stop[1] = 0; h_stop[2] = 0;
         monitor_samples.clear();
-        hipLaunchKernelGGL(clock_monitor_kernel, dim3(1), dim3(64), 0, monitor_stream, d_ring, CLOCK_MONITOR_SLOTS, (volatile uint32_t *)h_stop, (uint64_t)300000000ull /* 3 s */, d_count);
+        hipLaunchKernelGGL(clock_monitor_kernel, dim3(1), dim3(64), 0, monitor_stream, d_ring, CLOCK_MONITOR_SLOTS, (volatile uint32_t *)h_stop, (uint64_t)300000000ull /* 3 s */, d_count,
+                           (volatile uint32_t *)(h_stop + 2));
         if ((e = hipGetLastError()) != hipSuccess) return e;
         monitor_running = true;
+        // a scope that stamps before the monitor's first sample has no cycle count to be read against (a short pass on a busy device
+        // lost all of its scopes that way): wait for the wave to be there - tens of microseconds, two seconds at most
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!((volatile uint32_t *)h_stop)[2] && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2)) {}
         return hipSuccess;
     }
     void monitor_stop() {                               // -> monitor_samples
