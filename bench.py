@@ -855,14 +855,18 @@ def bench_proof(args, workload, rank, local_rank, world, device, steps, warmup, 
     # s_memrealtime read by one wave per XCD before and after each scope): the clock each stage's kernels are granted IN THIS RUN
     stage_clock = {}
     if not args.no_stage_clocks:
-        ctx.profile(2)
-        ctx.profile_reset()
-        step()
-        for name, k in kinds:
-            cyc, ref = ctx.profile_read_clock(k)
-            ms2 = ctx.profile_read(k)[0]
-            if ref > 0 and ms2 > 0:
-                stage_clock[name] = {"ghz": cyc / ref * 0.1, "ref_ticks_per_s": ref / (ms2 * 1e-3), "stamped_ms": ms2}
+        try:
+            ctx.profile(2)
+        except Exception as e:          # noqa: BLE001 - no stream for the clock monitor that leaves the measured one alone: the line goes without clocks
+            sys.stderr.write("bench.py: stage clocks not measured (%s)\n" % e)
+        else:
+            ctx.profile_reset()
+            step()
+            for name, k in kinds:
+                cyc, ref = ctx.profile_read_clock(k)
+                ms2 = ctx.profile_read(k)[0]
+                if ref > 0 and ms2 > 0:
+                    stage_clock[name] = {"ghz": cyc / ref * 0.1, "ref_ticks_per_s": ref / (ms2 * 1e-3), "stamped_ms": ms2}
     ctx.profile(False)
     out = None
     if rank == 0:

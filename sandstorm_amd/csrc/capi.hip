@@ -227,30 +227,57 @@ struct ss_ctx {
             if (stamp >= 0) hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->stream, c->d_stamps + 2 * stamp + 1);
         }
     };
+    // The monitor wave runs until it is told to stop, so it must never sit in the hardware queue the measured stream maps to (the runtime
+    // spreads a process's streams over a few hardware queues; in a process that had made enough streams before, the monitor's landed
+    // on the context's: the measured launches waited for the monitor's ring to fill and every scope stamped outside its samples).
+    // Its stream is created at the highest priority - priority classes have queues of their own - and, belt and braces, a probe on the
+    // measured stream must complete while the monitor runs: if it does not, the monitor is stopped and started on another stream.
+    hipError_t monitor_stream_create() {
+        int least = 0, greatest = 0;
+        if (getenv("SS_CLOCK_MONITOR_NORMAL_PRIORITY") || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || greatest == least)
+            return hipStreamCreateWithFlags(&monitor_stream, hipStreamNonBlocking);
+        return hipStreamCreateWithPriority(&monitor_stream, hipStreamNonBlocking, greatest);
+    }
     hipError_t monitor_start() {
         if (monitor_running) return hipSuccess;
         hipError_t e = hipSuccess;
         if (!d_stamps) {
             void *p = nullptr;
-            if ((e = malloc_retry(&p, 2 * CLOCK_SCOPES * sizeof(ClockStamp))) != hipSuccess) return e;
+            if ((e = malloc_retry(&p, (2 * CLOCK_SCOPES + 1) * sizeof(ClockStamp))) != hipSuccess) return e;
             d_stamps = (ClockStamp *)p;
             if ((e = malloc_retry(&p, CLOCK_MONITOR_SLOTS * sizeof(ClockStamp))) != hipSuccess) return e;
             d_ring = (ClockStamp *)p;
             if ((e = hipHostMalloc((void **)&h_stop, 4 * sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess) return e;
             d_count = h_stop + 1;
+            if ((e = monitor_stream_create()) != hipSuccess) return e;
+        }
+        for (int attempt = 0; attempt < 6; ++attempt) {
+            h_stop[0] = 0; h_stop[1] = 0; h_stop[2] = 0;
+            monitor_samples.clear();
+            hipLaunchKernelGGL(clock_monitor_kernel, dim3(1), dim3(64), 0, monitor_stream, d_ring, CLOCK_MONITOR_SLOTS, (volatile uint32_t *)h_stop, (uint64_t)300000000ull /* 3 s */, d_count,
+                               (volatile uint32_t *)(h_stop + 2));
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            monitor_running = true;
+            // a scope that stamps before the monitor's first sample has no cycle count to be read against: wait for the wave to be
+            // there (tens of microseconds), then for a probe on the measured stream (idle: the callers synchronise it first)
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!((volatile uint32_t *)h_stop)[2] && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2)) {}
+            hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, d_stamps + 2 * CLOCK_SCOPES);
+            bool through = false;
+            const auto t1 = std::chrono::steady_clock::now();
+            while (std::chrono::steady_clock::now() - t1 < std::chrono::milliseconds(100))
+                if (hipStreamQuery(stream) == hipSuccess) { through = true; break; }
+            if (through && ((volatile uint32_t *)h_stop)[2]) return hipSuccess;
+            // the measured stream is stuck behind the monitor (or the monitor never started): stop it, take another stream
+            if (getenv("SS_CLOCK_MONITOR_DEBUG"))
+                fprintf(stderr, "clock monitor: attempt %d: started=%u, the measured stream %s\n", attempt, ((volatile uint32_t *)h_stop)[2], through ? "ran" : "did not run");
+            monitor_stop();
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(monitor_stream);
+            monitor_stream = nullptr;
             if ((e = hipStreamCreateWithFlags(&monitor_stream, hipStreamNonBlocking)) != hipSuccess) return e;
         }
-        h_stop[0] = 0; h_stop[1] = 0; h_stop[2] = 0;
-        monitor_samples.clear();
-        hipLaunchKernelGGL(clock_monitor_kernel, dim3(1), dim3(64), 0, monitor_stream, d_ring, CLOCK_MONITOR_SLOTS, (volatile uint32_t *)h_stop, (uint64_t)300000000ull /* 3 s */, d_count,
-                           (volatile uint32_t *)(h_stop + 2));
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        monitor_running = true;
-        // a scope that stamps before the monitor's first sample has no cycle count to be read against (a short pass on a busy device
-        // lost all of its scopes that way): wait for the wave to be there - tens of microseconds, two seconds at most
-        const auto t0 = std::chrono::steady_clock::now();
-        while (!((volatile uint32_t *)h_stop)[2] && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2)) {}
-        return hipSuccess;
+        return hipErrorNotReady;                       // no stream that leaves the measured one alone: no clocks, the caller says so
     }
     void monitor_stop() {                               // -> monitor_samples
         if (!monitor_running) return;
@@ -793,7 +820,12 @@ ss_status ss_comm_all_gather(ss_comm *comm, const void *d_send, uint64_t bytes, 
 ss_status ss_profile_enable(ss_ctx *ctx, int on) {
     if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
     if (ctx->prof_clock && on != 2) { HIP_TRY(hipStreamSynchronize(ctx->stream)); ctx->prof_collect(); ctx->monitor_stop(); }
-    if (on == 2 && !ctx->prof_clock) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx->monitor_start()); }
+    if (on == 2 && !ctx->prof_clock) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const hipError_t me = ctx->monitor_start();
+        if (me == hipErrorNotReady) return fail(SS_ERR_UNSUPPORTED, "no stream for the clock monitor that leaves the context's stream running (levels 0 and 1 are available)");
+        HIP_TRY(me);
+    }
     ctx->prof_on = on != 0;
     ctx->prof_clock = on == 2;
     return SS_OK;

@@ -77,7 +77,7 @@ static inline uint32_t hipemu_bitop3(uint32_t a, uint32_t b, uint32_t c, uint32_
 
 // ---- runtime
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101, hipErrorNotReady = 600 };
 typedef struct hipemu_stream *hipStream_t;
 typedef struct hipemu_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
@@ -112,6 +112,9 @@ static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, siz
 }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }          // launches run to completion where they are made
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned flags, int) { return hipStreamCreateWithFlags(s, flags); }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
