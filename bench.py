@@ -472,8 +472,15 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
             # ONE communicator for the whole run, made before the warm-up (an RCCL unique id serves one ncclCommInitRank per
             # rank; its set-up is not part of a proof).  A watchdog turns a bootstrap that never completes into an error.
             import threading
-            box = [hostlib.rccl_unique_id() if rank == 0 else None]
+            uid, uid_err = None, None
+            if rank == 0:
+                try:
+                    uid = hostlib.rccl_unique_id()
+                except Exception as e:              # noqa: BLE001 - librccl not loadable / ncclGetUniqueId refused: every rank must learn it, none may wait for an id
+                    uid_err = "%s: %s" % (type(e).__name__, e)
+            box = [(uid, uid_err)]
             dist.broadcast_object_list(box, src=0)
+            uid, uid_err = box[0]
             done = threading.Event()
 
             def watchdog():
@@ -485,11 +492,12 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
             # RCCL between more than one GPU has never run where this was developed (one GPU per box): if the communicator cannot be
             # made on ANY rank (library not found, ncclCommInitRank refused), every rank falls back to the Python driver over
             # torch.distributed - same proof bytes, same kernels - and the JSON line says so
-            group, group_err = None, None
-            try:
-                group = hostlib.RcclGroup(ctx, box[0], rank, world)
-            except Exception as e:                  # noqa: BLE001 - reported below, by every rank the same way
-                group_err = "%s: %s" % (type(e).__name__, e)
+            group, group_err = None, uid_err
+            if uid is not None:
+                try:
+                    group = hostlib.RcclGroup(ctx, uid, rank, world)
+                except Exception as e:              # noqa: BLE001 - reported below, by every rank the same way
+                    group_err = "%s: %s" % (type(e).__name__, e)
             bad = torch.tensor([0 if group is not None else 1], dtype=torch.int32, device=device)
             dist.all_reduce(bad)
             if not int(bad.item()):
