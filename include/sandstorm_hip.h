@@ -220,8 +220,9 @@ ss_status ss_gather_rows(ss_ctx *ctx, const uint64_t *const *d_cols, uint32_t nc
  * (32: field elements or digests - the opened rows of a matrix, a tree's leaf digests, or authentication paths with idx = the sibling
  * node numbers over the node array as one "column"; 1: the tag bytes of a FriendlyMerkleTree's nodes, ncols = 1) into host memory
  * `out`, nidx * ncols entries, row after row - what ss_gather_rows / ss_merkle_open return, but one index upload, one download and one
- * synchronisation for all jobs (`Queries::new` + `MerkleTree::prove` over the three trace trees and every FRI layer: 27 calls of
- * ~60 us each before).  Jobs with nidx = 0 are skipped. */
+ * synchronisation for all jobs (ministark's `Queries::new` - un-vendored, Cargo.lock:894-896 - with `MerkleTree::prove`,
+ * crypto/src/merkle/mod.rs:258-304, over the three trace trees and every FRI layer: 27 calls of ~60 us each before).  Jobs with
+ * nidx = 0 are skipped. */
 typedef struct ss_gather_job {
     const void *const *d_cols;
     uint32_t ncols;
