@@ -9,6 +9,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -26,6 +27,16 @@ enum { F_DST_REG, F_OP0_REG, F_OP1_IMM, F_OP1_FP, F_OP1_AP, F_RES_ADD, F_RES_MUL
 
 
 [[noreturn]] inline void fail(const std::string &m) { throw std::runtime_error("trace: " + m); }
+
+// the address half of the memory pool as integers (sorting, gap search): a vector whose elements are NOT value-initialised when it is
+// sized - the generators assign every element in their parallel first pass, and a serial fill of its 64 MB (2^20 steps) took as long as
+// a builtin's section
+template <class T> struct default_init_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_allocator<U>; };
+    template <class U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+using AddrArray = std::vector<uint64_t, default_init_allocator<uint64_t>>;
 
 inline bool felt_is_zero(const Felt &f) { return (f[0] | f[1] | f[2] | f[3]) == 0; }
 inline bool felt_eq(const Felt &a, const Felt &b) { return a == b; }
@@ -185,7 +196,7 @@ struct HostThreadsScope {
 
 // the addresses between the lowest and the highest accessed one that nothing accesses, ascending (the gap fillers of
 // trace.rs:594-625 / 890-925): a byte map of the accessed addresses instead of a sort of all n / 2 accesses
-inline std::vector<uint64_t> memory_gaps(const std::vector<uint64_t> &npc_addr, const std::vector<MemoryEntry> &public_memory, uint64_t max_gaps) {
+inline std::vector<uint64_t> memory_gaps(const AddrArray &npc_addr, const std::vector<MemoryEntry> &public_memory, uint64_t max_gaps) {
     uint64_t top = 0, low = UINT64_MAX;
 #pragma omp parallel for schedule(static) reduction(max : top) reduction(min : low)
     for (uint64_t k = 0; k < npc_addr.size(); ++k) { top = std::max(top, npc_addr[k]); low = std::min(low, npc_addr[k]); }
@@ -218,7 +229,7 @@ inline std::vector<uint64_t> memory_gaps(const std::vector<uint64_t> &npc_addr, 
 // prefix sum and a parallel fill replace the sort of ~n / 2 forty-byte records (0.8 s of the recursive layout's 2.6 s at 2^20
 // steps on 256 host threads), with the reference's checks kept: the pool's address-0 cells are exactly the public-memory
 // cells, memory starts at address 1, has no gaps and one value per address.
-inline void ordered_memory_into(Felt *mem_col, uint64_t n, const std::vector<uint64_t> &npc_addr, const Felt *npc, uint64_t cells,
+inline void ordered_memory_into(Felt *mem_col, uint64_t n, const AddrArray &npc_addr, const Felt *npc, uint64_t cells,
                                 const std::vector<MemoryEntry> &public_memory, const Felt &pad_value) {
     if (public_memory.size() > cells) fail("public memory does not fit");
     const uint64_t half = n / 2;

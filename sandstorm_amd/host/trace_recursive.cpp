@@ -91,35 +91,20 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
     struct Col { Felt *p; Felt &operator[](uint64_t i) const { return p[i]; } };
     Col cols[NUM_COLS];
     for (int c = 0; c < NUM_COLS; ++c) cols[c] = Col{out[c]};
-    {   // every cell no section writes is the field's zero: such cells exist in the two diluted-check columns and the auxiliary
-        // one; the flags, the memory pool (padding first), the ordered memory and the range-check column (its maximum first) are
-        // written whole
-        constexpr int64_t CHUNK = 1 << 16;
-        const int64_t chunks = (int64_t)((n + CHUNK - 1) / CHUNK);
-        const int sparse[3] = {COL_DILUTED_UNORDERED, COL_DILUTED_ORDERED, COL_AUXILIARY};
-#pragma omp parallel for schedule(static) if (par)
-        for (int64_t k = 0; k < chunks * 3; ++k) {
-            const int64_t c = sparse[k % 3], at = (k / 3) * CHUNK;
-            std::fill(out[c] + at, out[c] + std::min<int64_t>((int64_t)n, at + CHUNK), zero);
-        }
-    }
+    // every cell no section writes is the field's zero; no column is zeroed first - the section that owns a column writes its zeros
+    // with its values (the auxiliary column in the CPU's pass, the two diluted-check columns in the bitwise section): one pass per column
     const Col flags = cols[COL_FLAGS], un_col = cols[COL_DILUTED_UNORDERED], od_col = cols[COL_DILUTED_ORDERED], npc = cols[COL_NPC],
               rc_col = cols[COL_RANGE_CHECK], aux = cols[COL_AUXILIARY];
-    std::vector<uint64_t> npc_addr(n / 2, 0);           // the address half of the pool, as integers (sorting, gap search)
+    AddrArray npc_addr(n / 2);                          // the address half of the pool, as integers (sorting, gap search); assigned by its cycle below
 
     const MemoryEntry *padding = nullptr;
     for (auto &e : pi.public_memory) if (e.address == 1) { padding = &e; break; }
     if (!padding) fail("public memory has no entry at address 1");
     const Felt pad_value = felt_from_canonical(padding->value), pad_addr = felt_from_u64(1);
-#pragma omp parallel for schedule(static) if (par)
-    for (int64_t k = 0; k < (int64_t)(n / 2); ++k) { npc[2 * k] = pad_addr; npc[2 * k + 1] = pad_value; npc_addr[k] = 1; }
     auto set_pair = [&](uint64_t row, uint64_t address, const Felt &value) { npc[row] = felt_from_u64(address); npc[row + 1] = value; npc_addr[row / 2] = address; };
-    const Felt rc_max_f = felt_from_u64(pi.rc_max);
-#pragma omp parallel for schedule(static) if (par)
-    for (int64_t k = 0; k < (int64_t)n; ++k) rc_col[k] = rc_max_f;
 
     mark("init");
-    // ---- CPU cells (trace.rs:172-232) and the range-check pool
+    // ---- the range-check pool: the offsets of every instruction counted first, no column touched (trace.rs:131-160; utils.rs:357-380)
     std::vector<uint32_t> rc_count(1 << 16, 0);
     std::string first_error;                            // exceptions must not leave an OpenMP region
     // one histogram of the offsets per thread (an idling run has the same three offsets in every cycle: all threads would hammer
@@ -129,35 +114,7 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
     for (int64_t cyc = 0; cyc < (int64_t)num_cycles; ++cyc) try {
         std::vector<uint32_t> &my_count = rc_count_of[(size_t)omp_get_thread_num()];
         if (my_count.empty()) my_count.assign(1 << 16, 0);
-        const uint64_t cycle = (uint64_t)cyc;
-        const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
-        const U256 &iw = mem.at(pc);
-        const Word w{iw[0]};
-        if ((iw[1] | iw[2] | iw[3]) || w.flag(F_ZERO)) fail("memory cell " + std::to_string(pc) + " is not an instruction");
-        const uint64_t dst_addr = w.off_dst() + (w.flag(F_DST_REG) ? fp : ap) - HALF_OFFSET;
-        const uint64_t op0_addr = w.off_op0() + (w.flag(F_OP0_REG) ? fp : ap) - HALF_OFFSET;
-        const int src = w.op1_src();
-        if (src != 0 && src != 1 && src != 2 && src != 4) fail("invalid op1 source");
-        const uint64_t base = src == 0 ? mem.small(op0_addr) : src == 1 ? pc : src == 2 ? fp : ap;
-        const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
-        const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
-        Felt res;
-        if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : felt_inv(dst);           // get_res: dst^-1 on a jnz
-        else if (w.res_logic() == 0) res = op1;
-        else if (w.res_logic() == 1) res = felt_add(op0, op1);
-        else if (w.res_logic() == 2) res = felt_mul(op0, op1);
-        else fail("invalid res logic");
-        const Felt tmp0 = w.flag(F_PC_JNZ) ? dst : zero;
-        for (int f = 0; f < 16; ++f) flags[r + f] = felt_from_u64(w.flag_prefix(f));
-        set_pair(r + NPC_PC, pc, felt_from_canonical(iw));
-        set_pair(r + NPC_MEM_OP0_ADDR, op0_addr, op0);
-        set_pair(r + NPC_MEM_DST_ADDR, dst_addr, dst);
-        set_pair(r + NPC_MEM_OP1_ADDR, op1_addr, op1);
-        set_pair(r + NPC_PUB_MEM_ADDR, 0, zero);
-        rc_col[r + RC_OFF_DST] = felt_from_u64(w.off_dst()); rc_col[r + RC_OFF_OP1] = felt_from_u64(w.off_op1()); rc_col[r + RC_OFF_OP0] = felt_from_u64(w.off_op0());
-        aux[r + AUX_TMP0] = tmp0; aux[r + AUX_TMP1] = felt_mul(tmp0, res);
-        aux[r + AUX_AP] = felt_from_u64(ap); aux[r + AUX_FP] = felt_from_u64(fp);
-        aux[r + AUX_OP0_MUL_OP1] = felt_mul(op0, op1); aux[r + AUX_RES] = res;
+        const Word w{mem.at(states[(uint64_t)cyc].pc)[0]};
         for (uint64_t v : {w.off_dst(), w.off_op0(), w.off_op1()}) ++my_count[v];
     } catch (const std::exception &e) {
 #pragma omp critical
@@ -165,10 +122,7 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
     }
     if (!first_error.empty()) throw std::runtime_error(first_error);
     for (auto &part : rc_count_of) for (size_t v = 0; v < part.size(); ++v) rc_count[v] += part[v];
-
-    mark("cpu cells");
-    done({COL_FLAGS});
-    // ---- range-check builtin instances, ordered values and padding (trace.rs:131-160, 236-284; utils.rs:357-380)
+    // range-check builtin instances, ordered values and padding (trace.rs:236-284)
     struct Rc128 { uint32_t index; U256 value; };
     std::vector<Rc128> rc128;
     auto part_of = [](const U256 &v, unsigned k) { return (uint32_t)(shr(v, 16 * (RANGE_CHECK_BUILTIN_PARTS - 1 - k))[0] & 0xffff); };
@@ -194,26 +148,77 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
         }
         rc128.push_back(Rc128{(uint32_t)index, value});
     }
-    {   // the odd cycles take the next padding values in order, every cycle its CYCLE_HEIGHT / RANGE_CHECK_STEP ordered values: both
-        // sequences are indexed by the cycle, so the cycles go in parallel
-        const size_t pad0 = pad_i;
-        const uint64_t per = CYCLE_HEIGHT / RANGE_CHECK_STEP;
-#pragma omp parallel for schedule(static) if (par)
-        for (int64_t cyc = 0; cyc < (int64_t)num_cycles; ++cyc) {
-            const uint64_t cycle = (uint64_t)cyc, r = cycle * CYCLE_HEIGHT;
-            if (cycle % 2 == 1) {
-                const size_t at = pad0 + cycle / 2;
-                rc_col[r + RC_UNUSED] = felt_from_u64(at < padding_vals.size() ? padding_vals[at] : rc_hi);
-            }
-            for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP) {
-                const uint64_t at = cycle * per + o / RANGE_CHECK_STEP;
-                rc_col[r + o + RC_ORDERED] = felt_from_u64(at < ordered_vals.size() ? ordered_vals[at] : rc_hi);
-            }
-        }
-        if (pad0 + num_cycles / 2 < padding_vals.size() || num_cycles * per < ordered_vals.size()) fail("range-check values do not fit the trace");
-    }
+    // the odd cycles take the next padding values in order, every cycle its CYCLE_HEIGHT / RANGE_CHECK_STEP ordered values: both
+    // sequences are indexed by the cycle, so the cycles go in parallel
+    const size_t pad0 = pad_i;
+    const uint64_t per = CYCLE_HEIGHT / RANGE_CHECK_STEP;
+    if (pad0 + num_cycles / 2 < padding_vals.size() || num_cycles * per < ordered_vals.size()) fail("range-check values do not fit the trace");
+    const Felt rc_max_f = felt_from_u64(pi.rc_max);
 
     mark("range check");
+    // ---- CPU cells (trace.rs:172-232).  The generator is bound by the host's memory traffic, so the four columns this section fills are
+    // written ONCE: a cycle's 16 rows of each are made in a block on the stack - padding first, then what the cycle puts there, in the
+    // order the separate passes of the first version wrote them - and stored row after row; a builtin's cells of these columns get the
+    // padding here and their values in the builtin's section
+#pragma omp parallel for schedule(static) if (par)
+    for (int64_t cyc = 0; cyc < (int64_t)num_cycles; ++cyc) try {
+        const uint64_t cycle = (uint64_t)cyc;
+        const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
+        const U256 &iw = mem.at(pc);
+        const Word w{iw[0]};
+        if ((iw[1] | iw[2] | iw[3]) || w.flag(F_ZERO)) fail("memory cell " + std::to_string(pc) + " is not an instruction");
+        const uint64_t dst_addr = w.off_dst() + (w.flag(F_DST_REG) ? fp : ap) - HALF_OFFSET;
+        const uint64_t op0_addr = w.off_op0() + (w.flag(F_OP0_REG) ? fp : ap) - HALF_OFFSET;
+        const int src = w.op1_src();
+        if (src != 0 && src != 1 && src != 2 && src != 4) fail("invalid op1 source");
+        const uint64_t base = src == 0 ? mem.small(op0_addr) : src == 1 ? pc : src == 2 ? fp : ap;
+        const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
+        const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
+        Felt res;
+        if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : felt_inv(dst);           // get_res: dst^-1 on a jnz
+        else if (w.res_logic() == 0) res = op1;
+        else if (w.res_logic() == 1) res = felt_add(op0, op1);
+        else if (w.res_logic() == 2) res = felt_mul(op0, op1);
+        else fail("invalid res logic");
+        const Felt tmp0 = w.flag(F_PC_JNZ) ? dst : zero;
+        Felt blk[CYCLE_HEIGHT];
+        for (int f = 0; f < 16; ++f) flags[r + f] = felt_from_u64(w.flag_prefix(f));
+        // memory pool: (address, value) pairs, the padding pair where the CPU has none
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += 2) { blk[o] = pad_addr; blk[o + 1] = pad_value; npc_addr[(r + o) / 2] = 1; }
+        auto pair = [&](uint64_t o, uint64_t address, const Felt &value) { blk[o] = felt_from_u64(address); blk[o + 1] = value; npc_addr[(r + o) / 2] = address; };
+        pair(NPC_PC, pc, felt_from_canonical(iw));
+        pair(NPC_MEM_OP0_ADDR, op0_addr, op0);
+        pair(NPC_MEM_DST_ADDR, dst_addr, dst);
+        pair(NPC_MEM_OP1_ADDR, op1_addr, op1);
+        pair(NPC_PUB_MEM_ADDR, 0, zero);
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) npc[r + o] = blk[o];
+        // range-check column: the declared maximum, the instruction's offsets, the odd cycles' next padding value, the ordered values
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = rc_max_f;
+        blk[RC_OFF_DST] = felt_from_u64(w.off_dst()); blk[RC_OFF_OP1] = felt_from_u64(w.off_op1()); blk[RC_OFF_OP0] = felt_from_u64(w.off_op0());
+        if (cycle % 2 == 1) {
+            const size_t at = pad0 + cycle / 2;
+            blk[RC_UNUSED] = felt_from_u64(at < padding_vals.size() ? padding_vals[at] : rc_hi);
+        }
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP) {
+            const uint64_t at = cycle * per + o / RANGE_CHECK_STEP;
+            blk[o + RC_ORDERED] = felt_from_u64(at < ordered_vals.size() ? ordered_vals[at] : rc_hi);
+        }
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) rc_col[r + o] = blk[o];
+        // auxiliary column: zero where no section writes
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = zero;
+        blk[AUX_TMP0] = tmp0; blk[AUX_TMP1] = felt_mul(tmp0, res);
+        blk[AUX_AP] = felt_from_u64(ap); blk[AUX_FP] = felt_from_u64(fp);
+        blk[AUX_OP0_MUL_OP1] = felt_mul(op0, op1); blk[AUX_RES] = res;
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) aux[r + o] = blk[o];
+    } catch (const std::exception &e) {
+#pragma omp critical
+        if (first_error.empty()) first_error = e.what();
+    }
+    if (!first_error.empty()) throw std::runtime_error(first_error);
+
+    mark("cpu cells");
+    done({COL_FLAGS});
+
     // ---- Pedersen builtin (trace.rs:300-400; builtins/src/pedersen/mod.rs:81-163)
     const Segment &ped_seg = pi.segments[3], &rc_seg = pi.segments[4], &bw_seg = pi.segments[6];
     if (!ped_seg.present || !rc_seg.present || !bw_seg.present) fail("the layout needs the pedersen, range_check and bitwise segments");
@@ -308,19 +313,22 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
             uint64_t parts[4][4][4];
             for (int p = 0; p < 4; ++p) for (int c = 0; c < 4; ++c) partition64((*vals[p])[c], parts[p][c]);
             const uint64_t base = i * step, addr = bw_seg.begin_addr + 5 * i;
+            Felt blk[BITWISE_RATIO * CYCLE_HEIGHT];                  // the instance's rows of the unordered column: zeros, then its cells
+            for (uint64_t o = 0; o < step; ++o) blk[o] = zero;
             for (int k = 0; k < 4; ++k) {
                 const uint64_t v = parts[2][3][k] + parts[3][3][k];
                 const unsigned sh = k == 3 ? 8 : 4;
                 if ((v << sh) >> sh != v) fail("bitwise instance: top segment does not fit");
-                un_col[base + shifted_cells[k]] = felt_from_u64(v << sh);
+                blk[shifted_cells[k]] = felt_from_u64(v << sh);
                 ++my_count[undilute(v << sh)];
             }
             for (int p = 0; p < 4; ++p)
                 for (int c = 0; c < 4; ++c)
                     for (int s = 0; s < 4; ++s) {
-                        un_col[base + 32 * p + 8 * c + 2 * s] = felt_from_u64(parts[p][c][s]);
+                        blk[32 * p + 8 * c + 2 * s] = felt_from_u64(parts[p][c][s]);
                         ++my_count[undilute(parts[p][c][s])];
                     }
+            for (uint64_t o = 0; o < step; ++o) un_col[base + o] = blk[o];
             for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + k * (step / 4), addr + k, felt_from_canonical(*vals[k]));
             set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, felt_from_canonical(vor));
         } catch (const std::exception &e) {
@@ -342,6 +350,7 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
         if (pi_ < padding.size()) fail("diluted-check values do not fit the trace");
         std::vector<uint64_t> first_row((1u << DILUTED_N_BITS) + 1, n - total);
         for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) first_row[v + 1] = first_row[v] + std::max(dil_count[v], 1u);
+        first_row[0] = 0;               // the rows before the first value are zeros, and so is the first value's image: one run from row 0
 #pragma omp parallel for schedule(dynamic, 64) if (par)
         for (int64_t v = 0; v < (int64_t)(1u << DILUTED_N_BITS); ++v) {
             const Felt f = felt_from_u64(dilute((uint32_t)v));

@@ -289,58 +289,28 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
     struct Col { Felt *p; Felt &operator[](uint64_t i) const { return p[i]; } };
     Col cols[NUM_COLS];
     for (int c = 0; c < NUM_COLS; ++c) cols[c] = Col{out[c]};
-    constexpr uint64_t CHUNK = 1 << 16;
-    // every cell no section writes is zero.  Only the auxiliary column has such cells: the flags (16 per cycle), the four Pedersen
-    // columns (512 rows per instance of 512), the memory pool (padding first), the ordered memory and the range-check column
-    // (its maximum first) are written whole - 8 of the 9 columns need no first pass over them (0.5 GB each at 2^20 steps)
-    parallel_for((n + CHUNK - 1) / CHUNK, [&](uint64_t k) {
-        const uint64_t at = k * CHUNK;
-        std::fill(out[COL_AUXILIARY] + at, out[COL_AUXILIARY] + std::min(n, at + CHUNK), zero);
-    });
+    // The CPU's cells.  The generator is bound by the host's memory traffic (4.8 GB of columns at 2^20 steps), so every column this
+    // section touches is written ONCE: a cycle's 16 rows of the flags, the memory pool, the range-check column and the auxiliary column
+    // are made in a block on the stack - padding first, then what the cycle puts there, in the order the separate passes of the first
+    // version wrote them - and stored row after row.  Cells of these columns that a builtin owns get the padding here and their values
+    // in the builtin's section.  (The four Pedersen columns and the ordered memory are written whole by their own sections.)
     const Col flags = cols[COL_FLAGS], npc = cols[COL_NPC], rc_col = cols[COL_RANGE_CHECK], aux = cols[COL_AUXILIARY];
-    std::vector<uint64_t> npc_addr(n / 2, 1);
+    AddrArray npc_addr(n / 2);                          // every entry assigned by its cycle below
 
     const MemoryEntry *padding = nullptr;
     for (auto &e : pi.public_memory) if (e.address == 1) { padding = &e; break; }
     if (!padding) fail("public memory has no entry at address 1");
     const Felt pad_value = felt_from_canonical(padding->value), pad_addr = felt_from_u64(1);
-    parallel_for(n / 2, [&](uint64_t k) { npc[2 * k] = pad_addr; npc[2 * k + 1] = pad_value; });
     auto set_pair = [&](uint64_t row, uint64_t address, const Felt &value) { npc[row] = felt_from_u64(address); npc[row + 1] = value; npc_addr[row / 2] = address; };
 
-    lap("allocation + npc padding");
-    // ---- CPU cells (trace.rs:177-244) and the range-check pool (trace.rs:142-165)
+    lap("allocation");
+    // ---- the range-check pool (trace.rs:142-165): the offsets of every instruction counted first (no column is touched)
     std::vector<uint32_t> rc_count(1 << 16, 0);
     std::vector<std::vector<uint32_t>> rc_count_of((size_t)omp_get_max_threads());
     parallel_for(num_cycles, [&](uint64_t cycle) {
         std::vector<uint32_t> &my_count = rc_count_of[(size_t)omp_get_thread_num()];
         if (my_count.empty()) my_count.assign(1 << 16, 0);
-        const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
-        const U256 &iw = mem.at(pc);
-        const Word w{iw[0]};
-        if ((iw[1] | iw[2] | iw[3]) || w.flag(F_ZERO)) fail("memory cell " + std::to_string(pc) + " is not an instruction");
-        const uint64_t dst_addr = w.off_dst() + (w.flag(F_DST_REG) ? fp : ap) - HALF_OFFSET;
-        const uint64_t op0_addr = w.off_op0() + (w.flag(F_OP0_REG) ? fp : ap) - HALF_OFFSET;
-        const int src = w.op1_src();
-        if (src != 0 && src != 1 && src != 2 && src != 4) fail("invalid op1 source");
-        const uint64_t base = src == 0 ? mem.small(op0_addr) : src == 1 ? pc : src == 2 ? fp : ap;
-        const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
-        const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
-        Felt res;
-        if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : felt_inv(dst);
-        else if (w.res_logic() == 0) res = op1;
-        else if (w.res_logic() == 1) res = felt_add(op0, op1);
-        else if (w.res_logic() == 2) res = felt_mul(op0, op1);
-        else fail("invalid res logic");
-        const Felt tmp0 = w.flag(F_PC_JNZ) ? dst : zero;
-        for (int f = 0; f < 16; ++f) flags[r + f] = felt_from_u64(w.flag_prefix(f));
-        set_pair(r + NPC_PC, pc, felt_from_canonical(iw));
-        set_pair(r + NPC_MEM_OP0_ADDR, op0_addr, op0);
-        set_pair(r + NPC_MEM_DST_ADDR, dst_addr, dst);
-        set_pair(r + NPC_MEM_OP1_ADDR, op1_addr, op1);
-        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += PUBLIC_MEMORY_STEP) set_pair(r + o + NPC_PUB_MEM_ADDR, 0, zero);
-        aux[r + AUX_TMP0] = tmp0; aux[r + AUX_TMP1] = felt_mul(tmp0, res);
-        aux[r + AUX_AP] = felt_from_u64(ap); aux[r + AUX_FP] = felt_from_u64(fp);
-        aux[r + AUX_OP0_MUL_OP1] = felt_mul(op0, op1); aux[r + AUX_RES] = res;
+        const Word w{mem.at(states[cycle].pc)[0]};
         for (uint64_t v : {w.off_dst(), w.off_op0(), w.off_op1()}) ++my_count[v];
     });
     for (auto &part : rc_count_of) for (size_t v = 0; v < part.size(); ++v) rc_count[v] += part[v];
@@ -359,14 +329,6 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         if (!rc_count[v]) padding_vals.push_back(v);
         for (uint32_t c = 0; c < std::max(rc_count[v], 1u); ++c) ordered_vals.push_back(v);
     }
-    // the column starts as the padding value; the CPU's offsets go in afterwards (trace.rs:165-235)
-    const Felt rc_max_f = felt_from_u64(rc_hi);
-    parallel_for(num_cycles, [&](uint64_t cycle) {
-        const Word w{mem.at(states[cycle].pc)[0]};
-        const uint64_t r = cycle * CYCLE_HEIGHT;
-        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) rc_col[r + o] = rc_max_f;
-        rc_col[r + RC_OFF_DST] = felt_from_u64(w.off_dst()); rc_col[r + RC_OFF_OP1] = felt_from_u64(w.off_op1()); rc_col[r + RC_OFF_OP0] = felt_from_u64(w.off_op0());
-    });
     size_t pad_i = 0;
     auto next_padding = [&]() { return pad_i < padding_vals.size() ? padding_vals[pad_i++] : rc_hi; };
     for (uint64_t index = rc128.size(); index < num_cycles / RANGE_CHECK_BUILTIN_RATIO; ++index) {       // trace.rs:246-261
@@ -377,24 +339,66 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         }
         rc128.push_back(Rc128{(uint32_t)index, value});
     }
-    {   // the odd cycles take the next padding values in order, every cycle its CYCLE_HEIGHT / RANGE_CHECK_STEP ordered values: both
-        // sequences are indexed by the cycle, so the cycles go in parallel
-        const size_t pad0 = pad_i;
-        const uint64_t per = CYCLE_HEIGHT / RANGE_CHECK_STEP;
-        parallel_for(num_cycles, [&](uint64_t cycle) {
-            const uint64_t r = cycle * CYCLE_HEIGHT;
-            if (cycle % 2 == 1) {
-                const size_t at = pad0 + cycle / 2;
-                rc_col[r + RC_UNUSED] = felt_from_u64(at < padding_vals.size() ? padding_vals[at] : rc_hi);
-            }
-            for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP) {
-                const uint64_t at = cycle * per + o / RANGE_CHECK_STEP;
-                rc_col[r + o + RC_ORDERED] = felt_from_u64(at < ordered_vals.size() ? ordered_vals[at] : rc_hi);
-            }
-        });
-        if (pad0 + num_cycles / 2 < padding_vals.size() || num_cycles * per < ordered_vals.size()) fail("range-check values do not fit the trace");
-    }
-    parallel_for(n / DILUTED_CHECK_STEP, [&](uint64_t k) { rc_col[8 * k + DC_UNORDERED] = rc_col[8 * k + DC_ORDERED] = zero; });      // trace.rs:294-302
+    // the odd cycles take the next padding values in order, every cycle its CYCLE_HEIGHT / RANGE_CHECK_STEP ordered values: both
+    // sequences are indexed by the cycle, so the cycles go in parallel
+    const size_t pad0 = pad_i;
+    const uint64_t per = CYCLE_HEIGHT / RANGE_CHECK_STEP;
+    if (pad0 + num_cycles / 2 < padding_vals.size() || num_cycles * per < ordered_vals.size()) fail("range-check values do not fit the trace");
+    const Felt rc_max_f = felt_from_u64(rc_hi);
+
+    // ---- CPU cells (trace.rs:177-244), the range-check column's pool cells (trace.rs:165-235, 294-302)
+    parallel_for(num_cycles, [&](uint64_t cycle) {
+        const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
+        const U256 &iw = mem.at(pc);
+        const Word w{iw[0]};
+        if ((iw[1] | iw[2] | iw[3]) || w.flag(F_ZERO)) fail("memory cell " + std::to_string(pc) + " is not an instruction");
+        const uint64_t dst_addr = w.off_dst() + (w.flag(F_DST_REG) ? fp : ap) - HALF_OFFSET;
+        const uint64_t op0_addr = w.off_op0() + (w.flag(F_OP0_REG) ? fp : ap) - HALF_OFFSET;
+        const int src = w.op1_src();
+        if (src != 0 && src != 1 && src != 2 && src != 4) fail("invalid op1 source");
+        const uint64_t base = src == 0 ? mem.small(op0_addr) : src == 1 ? pc : src == 2 ? fp : ap;
+        const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
+        const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
+        Felt res;
+        if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : felt_inv(dst);
+        else if (w.res_logic() == 0) res = op1;
+        else if (w.res_logic() == 1) res = felt_add(op0, op1);
+        else if (w.res_logic() == 2) res = felt_mul(op0, op1);
+        else fail("invalid res logic");
+        const Felt tmp0 = w.flag(F_PC_JNZ) ? dst : zero;
+        Felt blk[CYCLE_HEIGHT];
+        // flags
+        for (int f = 0; f < 16; ++f) flags[r + f] = felt_from_u64(w.flag_prefix(f));
+        // memory pool: (address, value) pairs, the padding pair where the CPU has none (a builtin's pair comes with its section)
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += 2) { blk[o] = pad_addr; blk[o + 1] = pad_value; npc_addr[(r + o) / 2] = 1; }
+        auto pair = [&](uint64_t o, uint64_t address, const Felt &value) { blk[o] = felt_from_u64(address); blk[o + 1] = value; npc_addr[(r + o) / 2] = address; };
+        pair(NPC_PC, pc, felt_from_canonical(iw));
+        pair(NPC_MEM_OP0_ADDR, op0_addr, op0);
+        pair(NPC_MEM_DST_ADDR, dst_addr, dst);
+        pair(NPC_MEM_OP1_ADDR, op1_addr, op1);
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += PUBLIC_MEMORY_STEP) pair(o + NPC_PUB_MEM_ADDR, 0, zero);
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) npc[r + o] = blk[o];
+        // auxiliary column: zero where no section writes
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = zero;
+        blk[AUX_TMP0] = tmp0; blk[AUX_TMP1] = felt_mul(tmp0, res);
+        blk[AUX_AP] = felt_from_u64(ap); blk[AUX_FP] = felt_from_u64(fp);
+        blk[AUX_OP0_MUL_OP1] = felt_mul(op0, op1); blk[AUX_RES] = res;
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) aux[r + o] = blk[o];
+        // range-check column: the padding value, the instruction's offsets, the odd cycles' next padding value, the cycle's ordered
+        // values, zeros where the diluted check's cells are
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = rc_max_f;
+        blk[RC_OFF_DST] = felt_from_u64(w.off_dst()); blk[RC_OFF_OP1] = felt_from_u64(w.off_op1()); blk[RC_OFF_OP0] = felt_from_u64(w.off_op0());
+        if (cycle % 2 == 1) {
+            const size_t at = pad0 + cycle / 2;
+            blk[RC_UNUSED] = felt_from_u64(at < padding_vals.size() ? padding_vals[at] : rc_hi);
+        }
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP) {
+            const uint64_t at = cycle * per + o / RANGE_CHECK_STEP;
+            blk[o + RC_ORDERED] = felt_from_u64(at < ordered_vals.size() ? ordered_vals[at] : rc_hi);
+        }
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += DILUTED_CHECK_STEP) blk[o + DC_UNORDERED] = blk[o + DC_ORDERED] = zero;      // trace.rs:294-302
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) rc_col[r + o] = blk[o];
+    });
 
     lap("cpu cells + range-check pool");
     done({COL_FLAGS});
