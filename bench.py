@@ -1070,6 +1070,10 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one node, one process per GPU: RCCL's bootstrap over the loopback interface, for torch's group as for the C ABI's own
+        # communicator (csrc/capi.hip sets the same default before its first ncclCommInitRank: on a box with no other interface the
+        # probing took minutes); a deployment that wants another interface sets the variable itself
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         # a rank that fails must not leave the others in a collective for the default ten minutes
         import datetime
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=300))
