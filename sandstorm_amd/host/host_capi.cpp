@@ -377,19 +377,19 @@ TraceJob make_trace_job(int layout, const uint8_t *trace_bin, uint64_t trace_len
     for (uint64_t i = 0; i < cnt(3); ++i) { const uint64_t *r = instances[3] + 9 * i; priv->bitwise.push_back(BitwiseInstance{(uint32_t)r[0], val(r, 0), val(r, 1)}); }
     for (uint64_t i = 0; i < cnt(4); ++i) { const uint64_t *r = instances[4] + 21 * i; priv->ec_op.push_back(EcOpInstance{(uint32_t)r[0], val(r, 0), val(r, 1), val(r, 2), val(r, 3), val(r, 4)}); }
     for (uint64_t i = 0; i < cnt(5); ++i) { const uint64_t *r = instances[5] + 13 * i; priv->poseidon.push_back(PoseidonInstance{(uint32_t)r[0], {val(r, 0), val(r, 1), val(r, 2)}}); }
-    auto states = std::make_shared<std::vector<RegisterState>>(read_register_states(trace_bin, trace_len));
+    const RegisterStates states(trace_bin, trace_len);         // read in place: the caller's bytes outlive the job (both callers run it before they return)
     auto memory = std::make_shared<std::vector<U256>>();
     auto present = std::make_shared<std::vector<uint8_t>>();
     read_memory(memory_bin, memory_len, *memory, *present);
     TraceJob job;
-    job.n = 16 * (uint64_t)states->size();
+    job.n = 16 * (uint64_t)states.size();
     if (layout == 1) {
         job.ncols = 7;
         job.order = {0, 6, 5, 1, 2, 3, 4};        // flags, auxiliary, range check, the diluted pair, memory pool, sorted memory
         job.run = [=](Felt *const *out, const std::function<void(int)> *done) {
             PrivateInput rp;
             rp.pedersen = priv->pedersen; rp.range_check = priv->range_check; rp.bitwise = priv->bitwise;
-            recursive_base_trace_into(out, *states, *memory, *present, *pi, rp, done);
+            recursive_base_trace_into(out, states, *memory, *present, *pi, rp, done);
         };
     } else {
         job.ncols = 9;
@@ -397,7 +397,7 @@ TraceJob make_trace_job(int layout, const uint8_t *trace_bin, uint64_t trace_len
         job.run = [=](Felt *const *out, const std::function<void(int)> *done) {
             Felt *o[9];
             for (int c = 0; c < 9; ++c) o[c] = out[c];
-            starknet_base_trace_into(o, *states, *memory, *present, *pi, *priv, done);
+            starknet_base_trace_into(o, states, *memory, *present, *pi, *priv, done);
         };
     }
     return job;

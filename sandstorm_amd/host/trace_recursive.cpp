@@ -44,6 +44,10 @@ std::vector<RegisterState> read_register_states(const uint8_t *data, size_t len)
     return out;
 }
 
+RegisterStates::RegisterStates(const uint8_t *bytes, size_t len) : data(bytes), count(len / 24) {
+    if (len % 24) fail("trace file is not a sequence of (ap, fp, pc) u64 triples");
+}
+
 void read_memory(const uint8_t *data, size_t len, std::vector<U256> &memory, std::vector<uint8_t> &present) {
     if (len % 40) fail("memory file is not a sequence of (u64 address, 32-byte word) records");
     uint64_t max_addr = 0;
@@ -58,7 +62,7 @@ void read_memory(const uint8_t *data, size_t len, std::vector<U256> &memory, std
     }
 }
 
-std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+std::vector<std::vector<Felt>> recursive_base_trace(const RegisterStates &states, const std::vector<U256> &memory,
                                                     const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv) {
     std::vector<std::vector<Felt>> cols(NUM_COLS);
     Felt *out[NUM_COLS];
@@ -69,7 +73,7 @@ std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterSt
 
 // the same into the caller's columns (pinned host memory the upload reads straight from: the GpuAllocator seam of
 // layouts/src/recursive/trace.rs:115-120); every cell is written
-void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states, const std::vector<U256> &memory,
                                const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv,
                                const std::function<void(int)> *column_done) {
     auto done = [&](std::initializer_list<int> cs) { if (column_done && *column_done) for (int c : cs) (*column_done)(c); };
@@ -304,15 +308,24 @@ void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterSta
             std::vector<uint32_t> &my_count = dil_count_of[(size_t)omp_get_thread_num()];
             if (my_count.empty()) my_count.assign(1u << DILUTED_N_BITS, 0);
             const uint64_t i = (uint64_t)bi;
+            const uint64_t base = i * step, addr = bw_seg.begin_addr + 5 * i;
             U256 x{}, y{};
             auto it = given.find((uint32_t)i);
             if (it != given.end()) { x = it->second->x; y = it->second->y; }
+            else {
+                // the dummy instance (x = y = 0; nearly every instance of a run is one): each of its 4 + 64 diluted cells is the value 0 -
+                // nothing to partition, dilute or check (that arithmetic, not the stores, was most of this section's time)
+                for (uint64_t o = 0; o < step; ++o) un_col[base + o] = zero;
+                my_count[0] += 4 + 64;
+                for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + k * (step / 4), addr + k, zero);
+                set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, zero);
+                continue;
+            }
             U256 vand, vxor, vor;
             for (int k = 0; k < 4; ++k) { vand[k] = x[k] & y[k]; vxor[k] = x[k] ^ y[k]; vor[k] = x[k] | y[k]; }
             const U256 *vals[4] = {&x, &y, &vand, &vxor};
             uint64_t parts[4][4][4];
             for (int p = 0; p < 4; ++p) for (int c = 0; c < 4; ++c) partition64((*vals[p])[c], parts[p][c]);
-            const uint64_t base = i * step, addr = bw_seg.begin_addr + 5 * i;
             Felt blk[BITWISE_RATIO * CYCLE_HEIGHT];                  // the instance's rows of the unordered column: zeros, then its cells
             for (uint64_t o = 0; o < step; ++o) blk[o] = zero;
             for (int k = 0; k < 4; ++k) {

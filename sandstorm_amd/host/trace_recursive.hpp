@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <vector>
 
+#include <cstring>
+
 #include "public_input.hpp"
 
 namespace ssh {
@@ -15,6 +17,19 @@ namespace ssh {
 struct RegisterState { uint64_t ap, fp, pc; };                 // binary/src/lib.rs:50-56
 
 std::vector<RegisterState> read_register_states(const uint8_t *data, size_t len);        // trace.bin
+// trace.bin read where it lies: its records ARE (ap, fp, pc) as little-endian 8-byte integers, and the generators read every record
+// once or twice - a copy of the file into a vector (24 MB at 2^20 steps, fresh pages every call) cost 10-17 ms per proof before the
+// first column could be made.  Also what a vector of states converts to; the bytes must outlive the view.
+struct RegisterStates {
+    const uint8_t *data = nullptr;
+    size_t count = 0;
+    RegisterStates() = default;
+    RegisterStates(const uint8_t *bytes, size_t len);                                     // refuses a length that is not whole records
+    RegisterStates(const std::vector<RegisterState> &v) : data(reinterpret_cast<const uint8_t *>(v.data())), count(v.size()) {}
+    size_t size() const { return count; }
+    RegisterState operator[](size_t i) const { RegisterState s; memcpy(&s, data + sizeof(RegisterState) * i, sizeof s); return s; }
+};
+static_assert(sizeof(RegisterState) == 24, "a trace.bin record");
 // memory.bin -> memory[address] (canonical 256-bit words); present[address] = 0 for cells the run never touched
 void read_memory(const uint8_t *data, size_t len, std::vector<U256> &memory, std::vector<uint8_t> &present);
 
@@ -29,14 +44,14 @@ struct PrivateInput {                                           // air-private-i
 
 // -> the 7 base columns (Montgomery felts, 16 rows per cycle): flags | diluted unordered / bitwise | diluted ordered |
 // memory pool | sorted memory | range check / Pedersen partial sums | auxiliary / Pedersen suffixes, slopes
-std::vector<std::vector<Felt>> recursive_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+std::vector<std::vector<Felt>> recursive_base_trace(const RegisterStates &states, const std::vector<U256> &memory,
                                                     const std::vector<uint8_t> &present, const AirPublicInput &pi,
                                                     const PrivateInput &priv);
 
 // the same into the caller's 7 columns of 16 * cycles felts each (every cell is written)
 // column_done (optional): called with c as soon as no section will write column c again (flags after the CPU cells, auxiliary after
 // Pedersen, range check after its builtin, the diluted pair after bitwise, the memory pool after the gap fillers, sorted memory last)
-void recursive_base_trace_into(Felt *const out[7], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states, const std::vector<U256> &memory,
                                const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv,
                                const std::function<void(int)> *column_done = nullptr);
 

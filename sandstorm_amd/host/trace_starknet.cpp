@@ -266,7 +266,7 @@ PoseidonTrace poseidon_trace(const std::array<Felt, 3> &input) {       // poseid
 
 }  // namespace
 
-void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, const std::vector<U256> &memory,
                               const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv,
                               const std::function<void(int)> *column_done) {
     auto done = [&](std::initializer_list<int> cs) { if (column_done && *column_done) for (int c : cs) (*column_done)(c); };
@@ -530,12 +530,22 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
         parallel_for(n / step, [&](uint64_t i) {
             std::vector<uint32_t> &my_count = dil_count_of[(size_t)omp_get_thread_num()];
             if (my_count.empty()) my_count.assign(1u << DILUTED_N_BITS, 0);
+            const uint64_t base = i * step, addr = begin + 5 * i;
             U256 x{}, y{};
             auto it = given.find((uint32_t)i);
             if (it != given.end()) { x = it->second->x; y = it->second->y; }
+            else {
+                // the dummy instance (x = y = 0; nearly every instance of a run is one): each of its 4 + 64 diluted cells is the value 0 -
+                // nothing to partition, dilute or check
+                for (unsigned k = 0; k < 4; ++k) rc_col[base + BITWISE_SHIFTED_CELLS[k]] = zero;
+                for (uint64_t q = 0; q < 64; ++q) rc_col[base + 16 * q + 1] = zero;
+                my_count[0] += 4 + 64;
+                for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + 256 * k, addr + k, zero);
+                set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, zero);
+                return;
+            }
             U256 vand, vxor, vor;
             for (int k = 0; k < 4; ++k) { vand[k] = x[k] & y[k]; vxor[k] = x[k] ^ y[k]; vor[k] = x[k] | y[k]; }
-            const uint64_t base = i * step, addr = begin + 5 * i;
             const U256 *vals[4] = {&x, &y, &vand, &vxor};
             uint64_t parts[4][4][4];
             for (int p = 0; p < 4; ++p) for (int c = 0; c < 4; ++c) partition64((*vals[p])[c], parts[p][c]);
@@ -682,7 +692,7 @@ void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterStat
     done({COL_MEMORY});
 }
 
-std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+std::vector<std::vector<Felt>> starknet_base_trace(const RegisterStates &states, const std::vector<U256> &memory,
                                                    const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv) {
     std::vector<std::vector<Felt>> cols(NUM_COLS);
     Felt *out[NUM_COLS];

@@ -20,7 +20,7 @@ struct StarknetPrivateInput : PrivateInput {
 
 // -> the 9 base columns (Montgomery felts): flags | Pedersen partial sum x | y | suffix | slope | memory pool | sorted memory |
 // range check / diluted check / bitwise / Poseidon partial rounds | auxiliary / ECDSA / EC op / Poseidon full rounds
-std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+std::vector<std::vector<Felt>> starknet_base_trace(const RegisterStates &states, const std::vector<U256> &memory,
                                                    const std::vector<uint8_t> &present, const AirPublicInput &pi,
                                                    const StarknetPrivateInput &priv);
 
@@ -28,7 +28,7 @@ std::vector<std::vector<Felt>> starknet_base_trace(const std::vector<RegisterSta
 // column_done (optional): called with c as soon as no section will write column c again - flags after the CPU cells, the four
 // Pedersen columns after their builtin, range check and auxiliary after Poseidon, the memory pool after the gap fillers, the
 // sorted memory last - so that an upload of c can leave while the rest is still being generated (host/prover.hpp ColumnFeed)
-void starknet_base_trace_into(Felt *const out[9], const std::vector<RegisterState> &states, const std::vector<U256> &memory,
+void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, const std::vector<U256> &memory,
                               const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv,
                               const std::function<void(int)> *column_done = nullptr);
 
