@@ -105,11 +105,18 @@ Felt felt_pow(const Felt &a, uint64_t e) {
 }
 // more field helpers on transcript-sized data (host AIRs, trace generation)
 Felt felt_inv(const Felt &a) {
-    // a^(p-2): p - 2 = 2^251 + 2^196 + 2^192 - 1 ; plain square-and-multiply on the host (rare)
+    // a^(p-2): p - 2 = 2^251 + 2^196 + (2^192 - 1).  Left to right: bit 251, 55 squarings down to bit 196 (x a), 4 squarings, then the
+    // 192 one-bits six at a time (six squarings, x a^63): 251 squarings + 43 products where bit-by-bit takes 251 + 193 - the trace
+    // generators invert per elliptic-curve step of a builtin instance, by the thousand per real instance
+    const Felt a2 = felt_mul(a, a), a3 = felt_mul(a2, a), a7 = felt_mul(felt_mul(a3, a3), a);
+    const Felt a15 = felt_mul(felt_mul(a7, a7), a), a31 = felt_mul(felt_mul(a15, a15), a), a63 = felt_mul(felt_mul(a31, a31), a);
     Felt r = a;
-    for (int i = 250; i >= 0; --i) {
-        r = felt_mul(r, r);
-        if (i == 196 || i < 192) r = felt_mul(r, a);
+    for (int i = 0; i < 55; ++i) r = felt_mul(r, r);
+    r = felt_mul(r, a);
+    for (int i = 0; i < 4; ++i) r = felt_mul(r, r);
+    for (int g = 0; g < 32; ++g) {
+        for (int i = 0; i < 6; ++i) r = felt_mul(r, r);
+        r = felt_mul(r, a63);
     }
     return r;
 }

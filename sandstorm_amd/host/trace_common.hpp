@@ -9,6 +9,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -94,6 +95,53 @@ inline Pt ec_add(const Pt &a, const Pt &b) {
     const Felt x3 = felt_sub(felt_sub(felt_mul(lam, lam), a.x), b.x);
     return Pt{x3, felt_sub(felt_mul(lam, felt_sub(a.x, x3)), a.y)};
 }
+// ---- the same curve in Jacobian coordinates, for CHAINS of steps: a chain of doublings or of additions costs one inversion (the batch
+// below) instead of one per step - a signature's trace is ~3600 affine steps, a scalar multiplication's ~770
+// v[k] <- 1 / v[k] with one inversion (Montgomery's trick); an element without an inverse is the reference's inverse().unwrap() panic
+inline void batch_invert(Felt *v, size_t n) {
+    if (!n) return;
+    std::vector<Felt> prefix(n);
+    for (size_t k = 0; k < n; ++k) {
+        if (felt_is_zero(v[k])) fail("a curve step divides by zero");
+        prefix[k] = k ? felt_mul(prefix[k - 1], v[k]) : v[k];
+    }
+    Felt run = felt_inv(prefix[n - 1]);
+    for (size_t k = n; k-- > 0;) {
+        const Felt inv = k ? felt_mul(run, prefix[k - 1]) : run;
+        if (k) run = felt_mul(run, v[k]);
+        v[k] = inv;
+    }
+}
+struct Jac { Felt X, Y, Z; };                              // (X / Z^2, Y / Z^3)
+inline Jac jac_of(const Pt &p) { return Jac{p.x, p.y, felt_from_u64(1)}; }
+inline Jac jac_double(const Jac &p) {                      // a = 1: M = 3 X^2 + Z^4, S = 4 X Y^2
+    const Felt xx = felt_mul(p.X, p.X), yy = felt_mul(p.Y, p.Y), yyyy = felt_mul(yy, yy), zz = felt_mul(p.Z, p.Z);
+    const Felt t = felt_mul(p.X, yy), t2 = felt_add(t, t), s4 = felt_add(t2, t2);
+    const Felt m = felt_add(felt_add(felt_add(xx, xx), xx), felt_mul(zz, zz));
+    const Felt x3 = felt_sub(felt_mul(m, m), felt_add(s4, s4));
+    const Felt y4 = felt_add(yyyy, yyyy), y8 = felt_add(y4, y4);
+    const Felt yz = felt_mul(p.Y, p.Z);
+    return Jac{x3, felt_sub(felt_mul(m, felt_sub(s4, x3)), felt_add(y8, y8)), felt_add(yz, yz)};
+}
+// p + q for an affine q that does not share p's x (h = q.x Z^2 - X, not zero, is the caller's: it has looked at it already)
+inline Jac jac_add_affine(const Jac &p, const Pt &q, const Felt &zz, const Felt &h) {
+    const Felt r = felt_sub(felt_mul(q.y, felt_mul(p.Z, zz)), p.Y);
+    const Felt hh = felt_mul(h, h), hhh = felt_mul(h, hh), v = felt_mul(p.X, hh);
+    const Felt x3 = felt_sub(felt_sub(felt_mul(r, r), hhh), felt_add(v, v));
+    return Jac{x3, felt_sub(felt_mul(r, felt_sub(v, x3)), felt_mul(p.Y, hhh)), felt_mul(p.Z, h)};
+}
+inline std::vector<Pt> batch_normalize(const std::vector<Jac> &j) {
+    std::vector<Felt> zi(j.size());
+    for (size_t k = 0; k < j.size(); ++k) zi[k] = j[k].Z;
+    batch_invert(zi.data(), zi.size());
+    std::vector<Pt> out(j.size());
+    for (size_t k = 0; k < j.size(); ++k) {
+        const Felt zi2 = felt_mul(zi[k], zi[k]);
+        out[k] = Pt{felt_mul(j[k].X, zi2), felt_mul(j[k].Y, felt_mul(zi2, zi[k]))};
+    }
+    return out;
+}
+
 // builtins/src/pedersen/constants.rs:5-30, canonical little-endian limbs
 inline constexpr uint64_t PEDERSEN_POINTS[5][2][4] = {
     {{0x551fde4050ca6804ull, 0x716b0b1022947733ull, 0x00ee1b87eb599f16ull, 0x049ee3eba8c16007ull}, {0xd0405d266e10268aull, 0x4e621062c0e056c1ull, 0xf346d49d06ea0ed3ull, 0x03ca0cfe4b3bc6ddull}},
@@ -108,8 +156,8 @@ inline Pt pedersen_point(int k) {
     return Pt{felt_from_canonical(x), felt_from_canonical(y)};
 }
 inline const std::vector<Pt> &constant_points() {          // gen_element_steps' constant_points for both inputs (512 entries)
-    static std::vector<Pt> pts;
-    if (pts.empty()) {
+    static const std::vector<Pt> pts = [] {                 // (made once, by whichever thread comes first: instances are traced in parallel)
+        std::vector<Pt> all;
         for (int e = 0; e < 2; ++e) {
             std::vector<Pt> half;
             Pt acc = pedersen_point(1 + 2 * e);
@@ -117,14 +165,15 @@ inline const std::vector<Pt> &constant_points() {          // gen_element_steps'
             acc = pedersen_point(2 + 2 * e);
             for (int i = 0; i < 4; ++i) { half.push_back(acc); acc = ec_double(acc); }
             for (int i = 0; i < 4; ++i) half.push_back(half[251]);
-            pts.insert(pts.end(), half.begin(), half.end());
+            all.insert(all.end(), half.begin(), half.end());
         }
-    }
+        return all;
+    }();
     return pts;
 }
 struct Step { Pt point; Felt suffix, slope; };
-// gen_element_steps (builtins/src/pedersen/mod.rs:121-163)
-inline Pt element_steps(const U256 &x, Pt point, int which, std::vector<Step> &out) {
+// gen_element_steps (builtins/src/pedersen/mod.rs:121-163) as the reference writes it: affine, one inversion per set bit
+inline Pt element_steps_affine(const U256 &x, Pt point, int which, std::vector<Step> &out) {
     const std::vector<Pt> &cp = constant_points();
     for (unsigned i = 0; i < 256; ++i) {
         const U256 suffix = shr(x, i);
@@ -139,9 +188,64 @@ inline Pt element_steps(const U256 &x, Pt point, int which, std::vector<Step> &o
             } else {
                 slope = felt_mul(felt_sub(point.y, c.y), felt_inv(felt_sub(point.x, c.x)));
             }
-            next = ec_add(point, c);
+            const Felt x3 = felt_sub(felt_sub(felt_mul(slope, slope), point.x), c.x);        // the sum from the slope just made (chord or tangent)
+            next = Pt{x3, felt_sub(felt_mul(slope, felt_sub(point.x, x3)), point.y)};
         }
         out.push_back(Step{point, felt_from_canonical(suffix), slope});
+        point = next;
+    }
+    return point;
+}
+// The same cells with ONE inversion per element instead of one per set bit (a real instance cost 16 ms of host time that way - 500
+// inversions; a 2^20-step run has room for 8192 / 32768 instances).  The partial sums are accumulated in Jacobian coordinates
+// (mixed additions of the affine constant points); a sum's slope is R / Z3 of the addition that made the NEXT sum - the chord's slope
+// (y2 - y1) / (x2 - x1) with x1 = X1 / Z1^2, y1 = Y1 / Z1^3 is R / (H Z1), and Z3 = Z1 H - so one batch inversion of the Z3's gives
+// every affine sum and every slope.  The affine cells are field elements: whichever way they are computed they are the same
+// (tests/test_layout_recursive.py holds the two paths together).  A sum that meets its constant point (a tangent; never for inputs
+// that are not made for it) sends the element through the affine path.
+inline Pt element_steps(const U256 &x, Pt point, int which, std::vector<Step> &out) {
+    static const bool affine_only = getenv("SSH_TRACE_AFFINE_STEPS") != nullptr;
+    if (affine_only) return element_steps_affine(x, point, which, out);
+    const std::vector<Pt> &cp = constant_points();
+    struct Jac { Felt X, Y, Z, R; };
+    Jac acc[256];                                       // the sum after the k-th set bit, with the R of the addition that made it
+    unsigned m = 0;
+    Felt X1 = point.x, Y1 = point.y, Z1 = felt_from_u64(1);
+    for (unsigned i = 0; i < 256; ++i) {
+        if (!bit(x, i)) continue;
+        const Pt &c = cp[256 * which + i];
+        const Felt zz = felt_mul(Z1, Z1), u2 = felt_mul(c.x, zz), s2 = felt_mul(c.y, felt_mul(Z1, zz));
+        const Felt h = felt_sub(u2, X1), r = felt_sub(s2, Y1);
+        if (felt_is_zero(h)) {
+            if (!felt_is_zero(r)) fail("point at infinity in a Pedersen partial sum");
+            return element_steps_affine(x, point, which, out);
+        }
+        const Felt hh = felt_mul(h, h), hhh = felt_mul(h, hh), v = felt_mul(X1, hh);
+        const Felt x3 = felt_sub(felt_sub(felt_mul(r, r), hhh), felt_add(v, v));
+        const Felt y3 = felt_sub(felt_mul(r, felt_sub(v, x3)), felt_mul(Y1, hhh));
+        const Felt z3 = felt_mul(Z1, h);
+        acc[m++] = Jac{x3, y3, z3, r};
+        X1 = x3; Y1 = y3; Z1 = z3;
+    }
+    // Montgomery's trick over the Z3's (none is zero: every H was not)
+    Felt prefix[256], zinv[256];
+    for (unsigned k = 0; k < m; ++k) prefix[k] = k ? felt_mul(prefix[k - 1], acc[k].Z) : acc[k].Z;
+    if (m) {
+        Felt run = felt_inv(prefix[m - 1]);
+        for (unsigned k = m; k-- > 0;) { zinv[k] = k ? felt_mul(run, prefix[k - 1]) : run; if (k) run = felt_mul(run, acc[k].Z); }
+    }
+    const Felt zero = felt_from_u64(0);
+    unsigned k = 0;                                     // set bits passed
+    for (unsigned i = 0; i < 256; ++i) {
+        Felt slope = zero;
+        Pt next = point;
+        if (bit(x, i)) {
+            const Felt zi2 = felt_mul(zinv[k], zinv[k]);
+            slope = felt_mul(acc[k].R, zinv[k]);
+            next = Pt{felt_mul(acc[k].X, zi2), felt_mul(acc[k].Y, felt_mul(zi2, zinv[k]))};
+            ++k;
+        }
+        out.push_back(Step{point, felt_from_canonical(shr(x, i)), slope});
         point = next;
     }
     return point;
@@ -193,6 +297,20 @@ struct HostThreadsScope {
     HostThreadsScope() : before(omp_get_max_threads()) { omp_set_num_threads(host_threads()); }
     ~HostThreadsScope() { omp_set_num_threads(before); }
 };
+
+// body(k) for k in [0, count) on the host's threads (dynamic: the items are builtin instances of uneven cost); the first exception a
+// body throws is rethrown on the caller's thread (none may leave an OpenMP region)
+template <class Body> void parallel_items(uint64_t count, const Body &body) {
+    std::exception_ptr err;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (uint64_t k = 0; k < count; ++k) {
+        try { body(k); } catch (...) {
+#pragma omp critical(ssh_trace_item_error)
+            if (!err) err = std::current_exception();
+        }
+    }
+    if (err) std::rethrow_exception(err);
+}
 
 // the addresses between the lowest and the highest accessed one that nothing accesses, ascending (the gap fillers of
 // trace.rs:594-625 / 890-925): a byte map of the accessed addresses instead of a sort of all n / 2 accesses

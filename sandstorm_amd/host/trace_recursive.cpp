@@ -233,28 +233,28 @@ void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states,
         struct Cached { std::vector<Step> steps; Felt out; };
         std::map<std::pair<U256, U256>, Cached> cache;
         const Pt p0 = pedersen_point(0);
-        auto trace_of = [&](const U256 &a, const U256 &b) -> const Cached & {
-            auto key = std::make_pair(a, b);
-            auto cit = cache.find(key);
-            if (cit == cache.end()) {
-                Cached c;
-                const Pt mid = element_steps(a, p0, 0, c.steps);
-                element_steps(b, mid, 1, c.steps);
-                c.out = c.steps.back().point.x;
-                Felt want;
-                const Felt fa = felt_from_canonical(a), fb = felt_from_canonical(b);
-                if (ss_pedersen_hash_host(fa.data(), fb.data(), want.data()) != SS_OK || !felt_eq(want, c.out))
-                    fail("Pedersen partial sums do not end at the hash");                     // the reference's own assert
-                cit = cache.emplace(key, std::move(c)).first;
-            }
-            return cit->second;
-        };
-        // the distinct instance traces first (sequential: the map is shared), then the cells in parallel
+        // the DISTINCT instances are found first (sequential: the map is shared; nearly every instance is the dummy one), their traces
+        // are made by all threads (a real instance is 512 curve steps: a run may hold thousands of them), then the cells in parallel
         std::vector<const Cached *> of_block(n / step);
+        std::vector<std::pair<const std::pair<U256, U256> *, Cached *>> distinct;
         for (uint64_t i = 0; i < n / step; ++i) {
             auto it = given.find((uint32_t)i);
-            of_block[i] = it != given.end() ? &trace_of(it->second->a, it->second->b) : &trace_of(U256{}, U256{});
+            const auto ins = cache.emplace(it != given.end() ? std::make_pair(it->second->a, it->second->b) : std::make_pair(U256{}, U256{}), Cached{});
+            if (ins.second) distinct.emplace_back(&ins.first->first, &ins.first->second);
+            of_block[i] = &ins.first->second;
         }
+        parallel_items(distinct.size(), [&](uint64_t k) {
+            const U256 &a = distinct[k].first->first, &b = distinct[k].first->second;
+            Cached &c = *distinct[k].second;
+            c.steps.reserve(512);
+            const Pt mid = element_steps(a, p0, 0, c.steps);
+            element_steps(b, mid, 1, c.steps);
+            c.out = c.steps.back().point.x;
+            Felt want;
+            const Felt fa = felt_from_canonical(a), fb = felt_from_canonical(b);
+            if (ss_pedersen_hash_host(fa.data(), fb.data(), want.data()) != SS_OK || !felt_eq(want, c.out))
+                fail("Pedersen partial sums do not end at the hash");                     // the reference's own assert
+        });
 #pragma omp parallel for schedule(static) if (par)
         for (int64_t bi = 0; bi < (int64_t)(n / step); ++bi) {
             const uint64_t i = (uint64_t)bi;

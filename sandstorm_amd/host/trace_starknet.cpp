@@ -142,38 +142,76 @@ bool felt_sqrt(const Felt &a, Felt &root) {
 }
 
 struct Doubling { Pt point; Felt slope; };
-std::vector<Doubling> doubling_steps(Pt p) {              // ecdsa/mod.rs:192-206
-    std::vector<Doubling> out;
-    for (int i = 0; i < 256; ++i) { out.push_back(Doubling{p, slope_of(p, p)}); p = ec_double(p); }
+// ecdsa/mod.rs:192-206: p, 2 p, 4 p, ... with the tangents' slopes (3 x^2 + 1) / (2 y) - the chain in Jacobian coordinates, the
+// affine points and the slopes' denominators from two batched inversions (the reference inverts per step)
+std::vector<Doubling> doubling_steps(const Pt &p) {
+    std::vector<Jac> chain(256);
+    chain[0] = jac_of(p);
+    for (int i = 1; i < 256; ++i) chain[i] = jac_double(chain[i - 1]);
+    const std::vector<Pt> pts = batch_normalize(chain);
+    std::vector<Felt> den(256);
+    for (int i = 0; i < 256; ++i) den[i] = felt_add(pts[i].y, pts[i].y);
+    batch_invert(den.data(), den.size());
+    const Felt one = felt_from_u64(1);
+    std::vector<Doubling> out(256);
+    for (int i = 0; i < 256; ++i) {
+        const Felt xx = felt_mul(pts[i].x, pts[i].x);
+        out[i] = Doubling{pts[i], felt_mul(felt_add(felt_add(felt_add(xx, xx), xx), one), den[i])};
+    }
     return out;
 }
-struct MadStep { Pt partial; Felt suffix, slope, x_diff_inv; };
-// gen_ec_mad_steps (ecdsa/mod.rs:157-190, ec_op/mod.rs:98-130)
-std::vector<MadStep> ec_mad_steps(const U256 &x, Pt point, Pt partial, unsigned max_doublings) {
-    std::vector<MadStep> out;
-    for (unsigned i = 0; i < 256; ++i) {
-        const U256 suffix = shr(x, i);
-        Felt slope = felt_from_u64(0);
-        Pt next = partial;
-        if (suffix[0] & 1) { slope = slope_of(point, partial); next = ec_add(partial, point); }
-        if (felt_eq(partial.x, point.x)) fail("a partial sum meets the fixed point");
-        out.push_back(MadStep{partial, felt_from_canonical(suffix), slope, felt_inv(felt_sub(partial.x, point.x))});
-        partial = next;
-        if (i < max_doublings) point = ec_double(point);
+// The two chains of a multiply-add (gen_ec_mad_steps / mimic_ec_mad_air): point_i = 2^min(i, max_doublings) point and
+// partial_i = partial + the point_j of the set bits j < i of x, for i < steps; `last` = the sum after the last step.  Both chains are
+// accumulated in Jacobian coordinates and made affine by one batched inversion each.  met: the first step whose partial sum shares its
+// x with the step's point (the reference divides by that difference: a panic there, `false` in the signature check), else -1; the
+// chains are not filled in then.
+struct MadChain { std::vector<Pt> point, partial; Pt last; int met = -1; };
+MadChain mad_chain(const U256 &x, const Pt &point, const Pt &partial, unsigned max_doublings, unsigned steps) {
+    MadChain c;
+    if (!steps) { c.last = partial; return c; }
+    std::vector<Jac> dbl(steps);
+    dbl[0] = jac_of(point);
+    for (unsigned i = 1; i < steps; ++i) dbl[i] = i - 1 < max_doublings ? jac_double(dbl[i - 1]) : dbl[i - 1];
+    c.point = batch_normalize(dbl);
+    std::vector<Jac> sums(1, jac_of(partial));                // the partial sum changes at the set bits only
+    std::vector<uint32_t> which(steps);
+    for (unsigned i = 0; i < steps; ++i) {
+        const Jac &cur = sums.back();
+        which[i] = (uint32_t)sums.size() - 1;
+        const Felt zz = felt_mul(cur.Z, cur.Z), h = felt_sub(felt_mul(c.point[i].x, zz), cur.X);
+        if (felt_is_zero(h)) { c.met = (int)i; return c; }
+        if (bit(x, i)) sums.push_back(jac_add_affine(cur, c.point[i], zz, h));
     }
+    const std::vector<Pt> affine = batch_normalize(sums);
+    c.partial.resize(steps);
+    for (unsigned i = 0; i < steps; ++i) c.partial[i] = affine[which[i]];
+    c.last = affine.back();
+    return c;
+}
+struct MadStep { Pt partial; Felt suffix, slope, x_diff_inv; };
+// gen_ec_mad_steps (ecdsa/mod.rs:157-190, ec_op/mod.rs:98-130): ONE more batched inversion serves every step's three uses of
+// 1 / (partial.x - point.x) - the cell itself and the chord's slope (point.y - partial.y) / (point.x - partial.x) (the sum along the
+// chord is the chain's next partial sum)
+std::vector<MadStep> ec_mad_steps(const U256 &x, const Pt &point, const Pt &partial, unsigned max_doublings) {
+    const MadChain c = mad_chain(x, point, partial, max_doublings, 256);
+    if (c.met >= 0) fail("a partial sum meets the fixed point");
+    std::vector<Felt> x_diff_inv(256);
+    for (unsigned i = 0; i < 256; ++i) x_diff_inv[i] = felt_sub(c.partial[i].x, c.point[i].x);
+    batch_invert(x_diff_inv.data(), x_diff_inv.size());
+    const Felt zero = felt_from_u64(0);
+    std::vector<MadStep> out(256);
+    for (unsigned i = 0; i < 256; ++i)
+        out[i] = MadStep{c.partial[i], felt_from_canonical(shr(x, i)), bit(x, i) ? felt_mul(felt_sub(c.partial[i].y, c.point[i].y), x_diff_inv[i]) : zero,
+                         x_diff_inv[i]};
     return out;
 }
 // mimic_ec_mad_air (ecdsa/mod.rs:278-301)
-bool mimic_ec_mad(U256 m, Pt point, Pt partial, Pt &out) {
+bool mimic_ec_mad(const U256 &m, const Pt &point, const Pt &partial, Pt &out) {
     const unsigned bits = bit_length(m);
     if (bits < 1 || bits >= 252) return false;
-    while (!is_zero(m)) {
-        if (felt_eq(partial.x, point.x)) return false;
-        if (m[0] & 1) partial = ec_add(partial, point);
-        point = ec_double(point);
-        m = shr(m, 1);
-    }
-    out = partial;
+    const MadChain c = mad_chain(m, point, partial, 256, bits);
+    if (c.met >= 0) return false;
+    out = c.last;
     return true;
 }
 
@@ -411,31 +449,33 @@ void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, 
         const uint64_t step = PEDERSEN_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[3].begin_addr;
         const Pt p0 = pedersen_point(0);
         const Col xs = cols[COL_PEDERSEN_X], ys = cols[COL_PEDERSEN_Y], suffixes = cols[COL_PEDERSEN_SUFFIX], slopes = cols[COL_PEDERSEN_SLOPE];
-        // the distinct instance traces first (sequential: the map is shared; nearly every instance is the dummy one), then the
-        // cells of all instances in parallel
+        // the DISTINCT instances are found first (sequential: the map is shared; nearly every instance is the dummy one), their traces
+        // are made by all threads, then the cells of all instances in parallel
         auto inputs_of = [&](uint64_t i, U256 &a, U256 &b) {
             a = U256{}; b = U256{};
             auto it = given.find((uint32_t)i);
             if (it != given.end()) { a = it->second->a; b = it->second->b; }
         };
         std::vector<const Cached *> of_block(n / step);
+        std::vector<std::pair<const std::pair<U256, U256> *, Cached *>> distinct;
         for (uint64_t i = 0; i < n / step; ++i) {
             U256 a, b;
             inputs_of(i, a, b);
-            auto key = std::make_pair(a, b);
-            auto cit = cache.find(key);
-            if (cit == cache.end()) {
-                Cached c;
-                const Pt mid = element_steps(a, p0, 0, c.steps);
-                element_steps(b, mid, 1, c.steps);
-                c.out = c.steps.back().point.x;
-                Felt want;
-                const Felt fa = felt_from_canonical(a), fb = felt_from_canonical(b);
-                if (ss_pedersen_hash_host(fa.data(), fb.data(), want.data()) != SS_OK || !felt_eq(want, c.out)) fail("Pedersen partial sums do not end at the hash");
-                cit = cache.emplace(key, std::move(c)).first;
-            }
-            of_block[i] = &cit->second;
+            const auto ins = cache.emplace(std::make_pair(a, b), Cached{});
+            if (ins.second) distinct.emplace_back(&ins.first->first, &ins.first->second);
+            of_block[i] = &ins.first->second;
         }
+        parallel_items(distinct.size(), [&](uint64_t k) {               // (a real instance is 512 curve steps; a run may hold tens of thousands)
+            const U256 &a = distinct[k].first->first, &b = distinct[k].first->second;
+            Cached &c = *distinct[k].second;
+            c.steps.reserve(512);
+            const Pt mid = element_steps(a, p0, 0, c.steps);
+            element_steps(b, mid, 1, c.steps);
+            c.out = c.steps.back().point.x;
+            Felt want;
+            const Felt fa = felt_from_canonical(a), fb = felt_from_canonical(b);
+            if (ss_pedersen_hash_host(fa.data(), fb.data(), want.data()) != SS_OK || !felt_eq(want, c.out)) fail("Pedersen partial sums do not end at the hash");
+        });
         parallel_for(n / step, [&](uint64_t i) {
             U256 a, b;
             inputs_of(i, a, b);
@@ -482,16 +522,18 @@ void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, 
         if (n / step > given.size())
             std::call_once(dummy_once, [] { ecdsa_dummy_instance(dummy[0], dummy[1], dummy[2], dummy[3]); dummy_trace = ecdsa_trace(dummy[0], dummy[1], dummy[2], dummy[3]); });
         std::vector<const EcdsaTrace *> of_block(n / step);
+        std::vector<std::pair<const std::tuple<U256, U256, U256, U256> *, EcdsaTrace *>> distinct;
         for (uint64_t i = 0; i < n / step; ++i) {
-            U256 in[4];
             auto it = given.find((uint32_t)i);
             if (it == given.end()) { of_block[i] = &dummy_trace; continue; }
-            in[0] = it->second->pubkey_x; in[1] = it->second->message; in[2] = it->second->r; in[3] = it->second->w;
-            auto key = std::make_tuple(in[0], in[1], in[2], in[3]);
-            auto cit = cache.find(key);
-            if (cit == cache.end()) cit = cache.emplace(key, ecdsa_trace(in[0], in[1], in[2], in[3])).first;
-            of_block[i] = &cit->second;
+            const auto ins = cache.emplace(std::make_tuple(it->second->pubkey_x, it->second->message, it->second->r, it->second->w), EcdsaTrace{});
+            if (ins.second) distinct.emplace_back(&ins.first->first, &ins.first->second);
+            of_block[i] = &ins.first->second;
         }
+        parallel_items(distinct.size(), [&](uint64_t k) {               // (three scalar multiplications with their doubling chains per signature)
+            const auto &key = *distinct[k].first;
+            *distinct[k].second = ecdsa_trace(std::get<0>(key), std::get<1>(key), std::get<2>(key), std::get<3>(key));
+        });
         parallel_for(n / step, [&](uint64_t i) {
             const EcdsaTrace &t = *of_block[i];
             const uint64_t base = i * step;
@@ -602,6 +644,7 @@ void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, 
         std::map<std::tuple<U256, U256, U256, U256, U256>, Trace> cache;
         const uint64_t step = EC_OP_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[7].begin_addr;
         std::vector<const Trace *> of_block(n / step);
+        std::vector<std::pair<const std::tuple<U256, U256, U256, U256, U256> *, Trace *>> distinct;
         for (uint64_t i = 0; i < n / step; ++i) {
             U256 in[5];
             auto it = given.find((uint32_t)i);
@@ -610,20 +653,21 @@ void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, 
                 in[0] = canonical_of(cv.shift.x); in[1] = canonical_of(cv.shift.y); in[2] = canonical_of(cv.generator.x); in[3] = canonical_of(cv.generator.y);
                 in[4] = U256{1, 0, 0, 0};
             }
-            auto key = std::make_tuple(in[0], in[1], in[2], in[3], in[4]);
-            auto cit = cache.find(key);
-            if (cit == cache.end()) {
-                Trace t;
-                t.p = Pt{felt_from_canonical(in[0]), felt_from_canonical(in[1])}; t.q = Pt{felt_from_canonical(in[2]), felt_from_canonical(in[3])};
-                t.m = felt_from_canonical(in[4]);
-                t.q_doubling = doubling_steps(t.q);
-                t.r_steps = ec_mad_steps(in[4], t.q, t.p, 255);
-                t.r = t.r_steps.back().partial;
-                t.b251_196 = bit(in[4], 251) && bit(in[4], 196); t.b251_196_192 = t.b251_196 && bit(in[4], 192);
-                cit = cache.emplace(key, std::move(t)).first;
-            }
-            of_block[i] = &cit->second;
+            const auto ins = cache.emplace(std::make_tuple(in[0], in[1], in[2], in[3], in[4]), Trace{});
+            if (ins.second) distinct.emplace_back(&ins.first->first, &ins.first->second);
+            of_block[i] = &ins.first->second;
         }
+        parallel_items(distinct.size(), [&](uint64_t k) {               // (a scalar multiplication with its doubling chain per instance)
+            const auto &in = *distinct[k].first;
+            Trace &t = *distinct[k].second;
+            t.p = Pt{felt_from_canonical(std::get<0>(in)), felt_from_canonical(std::get<1>(in))};
+            t.q = Pt{felt_from_canonical(std::get<2>(in)), felt_from_canonical(std::get<3>(in))};
+            t.m = felt_from_canonical(std::get<4>(in));
+            t.q_doubling = doubling_steps(t.q);
+            t.r_steps = ec_mad_steps(std::get<4>(in), t.q, t.p, 255);
+            t.r = t.r_steps.back().partial;
+            t.b251_196 = bit(std::get<4>(in), 251) && bit(std::get<4>(in), 196); t.b251_196_192 = t.b251_196 && bit(std::get<4>(in), 192);
+        });
         parallel_for(n / step, [&](uint64_t i) {
             const Trace &t = *of_block[i];
             const uint64_t base = i * step, addr = begin + 7 * i;
@@ -652,14 +696,18 @@ void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, 
             if (it != given.end()) for (int k = 0; k < 3; ++k) in[k] = it->second->input[k];
         };
         std::vector<const PoseidonTrace *> of_block(n / step);
+        std::vector<std::pair<const std::tuple<U256, U256, U256> *, PoseidonTrace *>> distinct;
         for (uint64_t i = 0; i < n / step; ++i) {
             U256 in[3];
             inputs_of(i, in);
-            auto key = std::make_tuple(in[0], in[1], in[2]);
-            auto cit = cache.find(key);
-            if (cit == cache.end()) cit = cache.emplace(key, poseidon_trace(std::array<Felt, 3>{felt_from_canonical(in[0]), felt_from_canonical(in[1]), felt_from_canonical(in[2])})).first;
-            of_block[i] = &cit->second;
+            const auto ins = cache.emplace(std::make_tuple(in[0], in[1], in[2]), PoseidonTrace{});
+            if (ins.second) distinct.emplace_back(&ins.first->first, &ins.first->second);
+            of_block[i] = &ins.first->second;
         }
+        parallel_items(distinct.size(), [&](uint64_t k) {
+            const auto &in = *distinct[k].first;
+            *distinct[k].second = poseidon_trace(std::array<Felt, 3>{felt_from_canonical(std::get<0>(in)), felt_from_canonical(std::get<1>(in)), felt_from_canonical(std::get<2>(in))});
+        });
         parallel_for(n / step, [&](uint64_t i) {
             U256 in[3];
             inputs_of(i, in);

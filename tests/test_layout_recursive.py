@@ -4,6 +4,7 @@ base trace generated from the reference's own example run (tests/golden/example/
 and validate each other; a corrupted cell must trip the constraint that reads it."""
 import os
 import random
+import sys
 
 import pytest
 
@@ -353,3 +354,65 @@ def test_column_done_is_called_when_a_column_is_final(layout):
     for c in range(ncols):
         assert np.array_equal(cols[c], want[c]), "column %d" % c
         assert np.array_equal(snap[c], want[c]), "column %d was announced before it was final" % c
+
+
+_PEDERSEN_DIGEST_SCRIPT = r"""
+import hashlib, os, random, sys
+sys.path.insert(0, %(root)r)
+from sandstorm_amd import hostlib
+ex = os.path.join(%(root)r, "tests", "golden", "example")
+trace_bin, memory_bin = open(os.path.join(ex, "trace.bin"), "rb").read(), open(os.path.join(ex, "memory.bin"), "rb").read()
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from test_layout_recursive import load_run, many_pedersen_instances
+_, _, pi = load_run()
+cols = hostlib.recursive_base_trace(trace_bin, memory_bin, pi, {"pedersen": many_pedersen_instances()})
+print(" ".join(hashlib.sha256(c.tobytes()).hexdigest() for c in cols))
+"""
+
+
+def many_pedersen_instances():
+    """inputs of the Pedersen builtin that meet every branch of its curve steps: no bit set, one bit, every low bit, the top bits the
+    AIR's flags read (251, 196, 192), the largest field element, and random ones - as many as the example run has room for"""
+    p = (1 << 251) + 17 * (1 << 192) + 1
+    rng = random.Random(1906)
+    edge = [0, 1, 2, (1 << 248) - 1, 1 << 247, 1 << 248, (1 << 251) | (1 << 196) | (1 << 192), (1 << 251) | (1 << 196), 1 << 251, p - 1, p - 2, (1 << 251) - 1]
+    pairs = [(a, b) for a in edge[:6] for b in (0, edge[6])] + [(edge[i], edge[-1 - i]) for i in range(len(edge))]
+    pairs += [(rng.randrange(p), rng.randrange(p)) for _ in range(20)]
+    pairs += [pairs[3], pairs[-1]]                                   # (instances that repeat: traced once)
+    return [(i, a, b) for i, (a, b) in enumerate(pairs)]
+
+
+def test_pedersen_steps_from_one_inversion_equal_the_affine_ones(oracle):
+    """host/trace_common.hpp element_steps: the partial sums of an instance in Jacobian coordinates, ONE batched inversion per input for
+    every affine sum and every slope, the distinct instances traced by all threads - against the reference's shape (affine, an inversion
+    per set bit: SSH_TRACE_AFFINE_STEPS=1 in a process of its own; the switch is read once) on inputs that meet every branch, column
+    digest for column digest; and both against layouts/recursive.py on a few of them"""
+    import hashlib
+    import subprocess
+    import numpy as np
+    from sandstorm_amd import hostlib
+    from sandstorm_amd.layouts import recursive as rec
+    inst = many_pedersen_instances()
+    assert len(inst) <= 128                                          # the example run's 2^13... steps hold 2^18 / 2048 instances
+    script = _PEDERSEN_DIGEST_SCRIPT % {"root": ROOT}
+    digests = {}
+    for mode in ("jacobian", "affine"):
+        env = dict(os.environ)
+        env.pop("SSH_TRACE_AFFINE_STEPS", None)
+        if mode == "affine":
+            env["SSH_TRACE_AFFINE_STEPS"] = "1"
+        out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[mode] = out.stdout.split()
+    assert len(digests["jacobian"]) == 7 and digests["jacobian"] == digests["affine"]
+    # the Python mirror on a handful (pure-Python curve arithmetic: 0.2 s per instance)
+    states, memory, pi = load_run()
+    with open(os.path.join(EX, "trace.bin"), "rb") as f:
+        trace_bin = f.read()
+    with open(os.path.join(EX, "memory.bin"), "rb") as f:
+        memory_bin = f.read()
+    few = {"pedersen": [(k, a, b) for k, (_, a, b) in enumerate(inst[9:14] + inst[-4:])]}
+    want = rec.base_trace(states, memory, pi, few)
+    got = hostlib.recursive_base_trace(trace_bin, memory_bin, pi, few)
+    for c, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g, oracle.to_mont(w)), "column %d" % c
