@@ -62,15 +62,27 @@ def real_instances():
         if 0 < r < 1 << 251 and 0 < w < 1 << 251:
             break
     pub = sk._ec_mul(priv, sk.GENERATOR)
+    # a second signer over a message of one bit (a multiply-add whose chain has a single addition)
+    priv2, msg2, k2 = rng.getrandbits(240) + 2, 1 << 7, 2000
+    while True:
+        k2 += 1
+        r2 = sk._ec_mul(k2, sk.GENERATOR)[0]
+        w2 = k2 * pow(msg2 + r2 * priv2, -1, sk.CURVE_ORDER) % sk.CURVE_ORDER
+        if 0 < r2 < 1 << 251 and 0 < w2 < 1 << 251:
+            break
+    pub2 = sk._ec_mul(priv2, sk.GENERATOR)
     p5, q7, q9 = sk._ec_mul(5, sk.GENERATOR), sk._ec_mul(7, sk.GENERATOR), sk._ec_mul(9, sk.GENERATOR)
     top = (1 << 251) | (1 << 196) | (1 << 192)
     return {
         "pedersen": [(2, rng.getrandbits(250), rng.getrandbits(250)), (3, top, (1 << 251) | (1 << 196)), (7, 0, 5)],
         "range_check": [(i, sum(rng.randrange(32758, 32794) << (16 * j) for j in range(8))) for i in range(5)],
-        "ecdsa": [(1, pub[0], msg, r, w)],
+        "ecdsa": [(1, pub[0], msg, r, w), (4, pub2[0], msg2, r2, w2)],
         "bitwise": [(i, rng.getrandbits(251), rng.getrandbits(251)) for i in range(6)],
         "ec_op": [(0, p5[0], p5[1], q7[0], q7[1], rng.getrandbits(250)), (2, p5[0], p5[1], q9[0], q9[1], top),
-                  (3, q7[0], q7[1], p5[0], p5[1], (1 << 251) | (1 << 196) | rng.getrandbits(190))],
+                  (3, q7[0], q7[1], p5[0], p5[1], (1 << 251) | (1 << 196) | rng.getrandbits(190)),
+                  # scalars of one and two bits, and of every low bit (the chains of host/trace_starknet.cpp mad_chain: sums that never,
+                  # once, always change)
+                  (6, p5[0], p5[1], q9[0], q9[1], 1), (7, q9[0], q9[1], q7[0], q7[1], 3), (9, q7[0], q7[1], q9[0], q9[1], (1 << 250) - 1)],
         "poseidon": [(0, 1, 2, 3), (5, rng.getrandbits(251), rng.getrandbits(251), rng.getrandbits(251))],
     }
 
