@@ -142,6 +142,35 @@ inline std::vector<Pt> batch_normalize(const std::vector<Jac> &j) {
     return out;
 }
 
+// get_res of a conditional jump is dst^-1 (trace.rs:172-232): the reference inverts per such cycle - one cycle in ten of a real program,
+// ten microseconds each.  The jnz cycles of a BLOCK of cycles are looked up first and inverted together; the block's main pass then
+// takes them in the same order.  A cycle the main pass is going to refuse (not an instruction, a cell memory.bin does not hold) is
+// skipped here - the main pass says why.  take() checks the product, so an inverse can never land on another cycle's cell.
+struct JnzInverses {
+    std::vector<Felt> inv;
+    size_t next = 0;
+    JnzInverses(const RegisterStates &states, const Mem &mem, uint64_t first_cycle, uint64_t end_cycle) {
+        auto readable = [&](uint64_t a) { return a < mem.m.size() && mem.present[a]; };
+        for (uint64_t cycle = first_cycle; cycle < end_cycle; ++cycle) {
+            const RegisterState st = states[cycle];
+            if (!readable(st.pc)) continue;
+            const U256 &iw = mem.m[st.pc];
+            const Word w{iw[0]};
+            if ((iw[1] | iw[2] | iw[3]) || w.flag(F_ZERO) || w.pc_update() != 4) continue;
+            const uint64_t dst_addr = w.off_dst() + (w.flag(F_DST_REG) ? st.fp : st.ap) - HALF_OFFSET;
+            if (!readable(dst_addr)) continue;
+            const Felt dst = felt_from_canonical(mem.m[dst_addr]);
+            if (!felt_is_zero(dst)) inv.push_back(dst);
+        }
+        batch_invert(inv.data(), inv.size());
+    }
+    Felt take(const Felt &dst) {                           // dst is not zero
+        static const Felt one = felt_from_u64(1);
+        if (next < inv.size() && felt_eq(felt_mul(inv[next], dst), one)) return inv[next++];
+        return felt_inv(dst);
+    }
+};
+
 // builtins/src/pedersen/constants.rs:5-30, canonical little-endian limbs
 inline constexpr uint64_t PEDERSEN_POINTS[5][2][4] = {
     {{0x551fde4050ca6804ull, 0x716b0b1022947733ull, 0x00ee1b87eb599f16ull, 0x049ee3eba8c16007ull}, {0xd0405d266e10268aull, 0x4e621062c0e056c1ull, 0xf346d49d06ea0ed3ull, 0x03ca0cfe4b3bc6ddull}},

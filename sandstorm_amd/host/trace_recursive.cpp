@@ -164,9 +164,12 @@ void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states,
     // written ONCE: a cycle's 16 rows of each are made in a block on the stack - padding first, then what the cycle puts there, in the
     // order the separate passes of the first version wrote them - and stored row after row; a builtin's cells of these columns get the
     // padding here and their values in the builtin's section
+    constexpr uint64_t JNZ_BLOCK = 512;                  // cycles whose conditional jumps share one inversion (JnzInverses)
 #pragma omp parallel for schedule(static) if (par)
-    for (int64_t cyc = 0; cyc < (int64_t)num_cycles; ++cyc) try {
-        const uint64_t cycle = (uint64_t)cyc;
+    for (int64_t blk_i = 0; blk_i < (int64_t)((num_cycles + JNZ_BLOCK - 1) / JNZ_BLOCK); ++blk_i) try {
+      const uint64_t first_cycle = (uint64_t)blk_i * JNZ_BLOCK, end_cycle = std::min(num_cycles, first_cycle + JNZ_BLOCK);
+      JnzInverses jnz(states, mem, first_cycle, end_cycle);
+      for (uint64_t cycle = first_cycle; cycle < end_cycle; ++cycle) {
         const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
         const U256 &iw = mem.at(pc);
         const Word w{iw[0]};
@@ -179,7 +182,7 @@ void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states,
         const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
         const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
         Felt res;
-        if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : felt_inv(dst);           // get_res: dst^-1 on a jnz
+        if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : jnz.take(dst);           // get_res: dst^-1 on a jnz
         else if (w.res_logic() == 0) res = op1;
         else if (w.res_logic() == 1) res = felt_add(op0, op1);
         else if (w.res_logic() == 2) res = felt_mul(op0, op1);
@@ -214,6 +217,7 @@ void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states,
         blk[AUX_AP] = felt_from_u64(ap); blk[AUX_FP] = felt_from_u64(fp);
         blk[AUX_OP0_MUL_OP1] = felt_mul(op0, op1); blk[AUX_RES] = res;
         for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) aux[r + o] = blk[o];
+      }
     } catch (const std::exception &e) {
 #pragma omp critical
         if (first_error.empty()) first_error = e.what();

@@ -385,7 +385,11 @@ void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, 
     const Felt rc_max_f = felt_from_u64(rc_hi);
 
     // ---- CPU cells (trace.rs:177-244), the range-check column's pool cells (trace.rs:165-235, 294-302)
-    parallel_for(num_cycles, [&](uint64_t cycle) {
+    constexpr uint64_t JNZ_BLOCK = 512;                  // cycles whose conditional jumps share one inversion (JnzInverses)
+    parallel_for((num_cycles + JNZ_BLOCK - 1) / JNZ_BLOCK, [&](uint64_t block) {
+      const uint64_t first_cycle = block * JNZ_BLOCK, end_cycle = std::min(num_cycles, first_cycle + JNZ_BLOCK);
+      JnzInverses jnz(states, mem, first_cycle, end_cycle);
+      for (uint64_t cycle = first_cycle; cycle < end_cycle; ++cycle) {
         const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
         const U256 &iw = mem.at(pc);
         const Word w{iw[0]};
@@ -398,7 +402,7 @@ void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, 
         const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
         const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
         Felt res;
-        if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : felt_inv(dst);
+        if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : jnz.take(dst);
         else if (w.res_logic() == 0) res = op1;
         else if (w.res_logic() == 1) res = felt_add(op0, op1);
         else if (w.res_logic() == 2) res = felt_mul(op0, op1);
@@ -436,6 +440,7 @@ void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, 
         }
         for (uint64_t o = 0; o < CYCLE_HEIGHT; o += DILUTED_CHECK_STEP) blk[o + DC_UNORDERED] = blk[o + DC_ORDERED] = zero;      // trace.rs:294-302
         for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) rc_col[r + o] = blk[o];
+      }
     });
 
     lap("cpu cells + range-check pool");
