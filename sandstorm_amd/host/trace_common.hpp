@@ -236,8 +236,8 @@ inline Pt element_steps(const U256 &x, Pt point, int which, std::vector<Step> &o
     static const bool affine_only = getenv("SSH_TRACE_AFFINE_STEPS") != nullptr;
     if (affine_only) return element_steps_affine(x, point, which, out);
     const std::vector<Pt> &cp = constant_points();
-    struct Jac { Felt X, Y, Z, R; };
-    Jac acc[256];                                       // the sum after the k-th set bit, with the R of the addition that made it
+    struct Sum { Felt X, Y, Z, R; };
+    Sum acc[256];                                       // the sum after the k-th set bit, with the R of the addition that made it
     unsigned m = 0;
     Felt X1 = point.x, Y1 = point.y, Z1 = felt_from_u64(1);
     for (unsigned i = 0; i < 256; ++i) {
@@ -253,7 +253,7 @@ inline Pt element_steps(const U256 &x, Pt point, int which, std::vector<Step> &o
         const Felt x3 = felt_sub(felt_sub(felt_mul(r, r), hhh), felt_add(v, v));
         const Felt y3 = felt_sub(felt_mul(r, felt_sub(v, x3)), felt_mul(Y1, hhh));
         const Felt z3 = felt_mul(Z1, h);
-        acc[m++] = Jac{x3, y3, z3, r};
+        acc[m++] = Sum{x3, y3, z3, r};
         X1 = x3; Y1 = y3; Z1 = z3;
     }
     // Montgomery's trick over the Z3's (none is zero: every H was not)
