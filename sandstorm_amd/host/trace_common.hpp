@@ -39,6 +39,31 @@ template <class T> struct default_init_allocator : std::allocator<T> {
 };
 using AddrArray = std::vector<uint64_t, default_init_allocator<uint64_t>>;
 
+using CountArray = std::vector<uint32_t, default_init_allocator<uint32_t>>;
+// The range-check pool's ordered values (utils.rs:357-380): every v of [lo, hi] max(count[v], 1) times, ascending - RUNS, laid out by a
+// prefix sum and filled by all threads (3.3 million entries at 2^20 steps, a third of them one offset of an idling run: pushed one by one
+// on one thread they took half of the section that makes them, before any column can be written)
+inline void ordered_runs(const std::vector<uint32_t> &count, uint32_t lo, uint32_t hi, CountArray &out) {
+    out.clear();
+    if (lo > hi) return;
+    std::vector<uint64_t> first((size_t)(hi - lo) + 2, 0);
+    for (uint32_t v = lo; v <= hi; ++v) first[v - lo + 1] = first[v - lo] + std::max(count[v], 1u);
+    out.resize(first.back());
+    uint32_t *o = out.data();
+    constexpr uint64_t LONG_RUN = 1 << 14;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t v = lo; v <= (int64_t)hi; ++v) {
+        const uint64_t a = first[(size_t)v - lo], b = first[(size_t)v - lo + 1];
+        if (b - a < LONG_RUN) std::fill(o + a, o + b, (uint32_t)v);
+    }
+    for (uint32_t v = lo; v <= hi; ++v) {
+        const uint64_t a = first[v - lo], b = first[v - lo + 1];
+        if (b - a < LONG_RUN) continue;
+#pragma omp parallel for schedule(static)
+        for (int64_t k = (int64_t)a; k < (int64_t)b; ++k) o[k] = v;
+    }
+}
+
 inline bool felt_is_zero(const Felt &f) { return (f[0] | f[1] | f[2] | f[3]) == 0; }
 inline bool felt_eq(const Felt &a, const Felt &b) { return a == b; }
 inline U256 shr(const U256 &v, unsigned k) {

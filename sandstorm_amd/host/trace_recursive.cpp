@@ -137,11 +137,10 @@ void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states,
     }
     uint32_t rc_lo = 0xffff, rc_hi = 0;
     for (uint32_t v = 0; v < (1u << 16); ++v) if (rc_count[v]) { rc_lo = std::min(rc_lo, v); rc_hi = std::max(rc_hi, v); }
-    std::vector<uint32_t> padding_vals, ordered_vals;
-    for (uint32_t v = rc_lo; v <= rc_hi; ++v) {
-        if (!rc_count[v]) padding_vals.push_back(v);
-        for (uint32_t c = 0; c < std::max(rc_count[v], 1u); ++c) ordered_vals.push_back(v);
-    }
+    std::vector<uint32_t> padding_vals;
+    for (uint32_t v = rc_lo; v <= rc_hi; ++v) if (!rc_count[v]) padding_vals.push_back(v);
+    CountArray ordered_vals;
+    ordered_runs(rc_count, rc_lo, rc_hi, ordered_vals);
     size_t pad_i = 0;
     auto next_padding = [&]() { return pad_i < padding_vals.size() ? padding_vals[pad_i++] : rc_hi; };
     for (uint64_t index = rc128.size(); index < num_cycles / RANGE_CHECK_BUILTIN_RATIO; ++index) {
