@@ -1,6 +1,7 @@
 """No GPU: the C++ host library (libsandstorm_host.so) — its Fiat-Shamir coin against the
 reference KATs and the oracle coin."""
 import numpy as np
+import pytest
 
 from tests.util import random_column
 
@@ -64,3 +65,37 @@ def test_trace_generators_write_every_cell_of_the_callers_columns():
         gen(trace_bin, memory_bin, pi, priv, out=out)
         for c, (a, b) in enumerate(zip(out, want)):
             assert np.array_equal(a, b), (layout, c)
+
+
+def test_the_files_entry_takes_the_private_input_as_the_column_entries_do():
+    """host_capi.cpp make_trace_job - what ssh_prove_files and ssh_base_trace_cb build their generator call from - reads the builtin
+    instances of air-private-input.json out of six flat arrays: with real instances of every builtin its columns are the ones
+    ssh_recursive_base_trace / ssh_starknet_base_trace write (those are held against the Python mirror in tests/test_layout_*.py),
+    both layouts, and an instance list the generator refuses comes back as its message"""
+    import random
+    from sandstorm_amd import binary, examples, hostlib
+    from sandstorm_amd._lib import SandstormHipError
+    from tests.test_layout_starknet import bootloader_run, real_instances
+    states, memory, pi = examples.recursive_example(14)
+    rng = random.Random(3)
+    rec_priv = {"pedersen": [(0, rng.getrandbits(250), rng.getrandbits(250)), (5, 0, 5), (7, (1 << 251) | (1 << 196) | (1 << 192), 1)],
+                "bitwise": [(i, rng.getrandbits(251), rng.getrandbits(251)) for i in range(4)],
+                "range_check": [(i, sum(rng.randrange(32700, 32800) << (16 * k) for k in range(8))) for i in range(3)]}
+    cases = [("recursive", binary.write_register_states(states), binary.write_memory(memory), pi, rec_priv)]
+    states, memory, pi, priv = bootloader_run()
+    more = dict(real_instances())
+    more["pedersen"] = priv["pedersen"] + more["pedersen"]
+    cases.append(("starknet", binary.write_register_states(states), binary.write_memory(memory), pi, more))
+    for layout, trace_bin, memory_bin, pi, private in cases:
+        plain = hostlib.recursive_base_trace if layout == "recursive" else hostlib.starknet_base_trace
+        want = plain(trace_bin, memory_bin, pi, private)
+        got, _ = hostlib.base_trace_with_callback(layout, trace_bin, memory_bin, pi, private)
+        assert len(got) == len(want)
+        for c, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(a, b), (layout, c)
+        dummies = plain(trace_bin, memory_bin, pi, {"pedersen": private["pedersen"][:2]} if layout == "starknet" else None)
+        assert any(not np.array_equal(a, b) for a, b in zip(want, dummies))         # (the instances do reach the cells)
+    with pytest.raises(SandstormHipError, match="signature is invalid"):
+        bad = dict(more)
+        bad["ecdsa"] = [(1,) + tuple(more["ecdsa"][0][1:4]) + (more["ecdsa"][0][4] + 1,)]
+        hostlib.base_trace_with_callback("starknet", trace_bin, memory_bin, pi, bad)
