@@ -5,10 +5,12 @@ the path): `trace.bin` (register states), `memory.bin` (partial memory) and the 
   trace.bin    records of three little-endian u64: ap, fp, pc                       (RegisterStates::from_reader)
   memory.bin   records of a little-endian u64 address + a 32-byte little-endian word (Memory::from_reader)
   instruction  off_dst | off_op0 << 16 | off_op1 << 32 | flags << 48, offsets biased by 2^15 (Word)
+  air-private-input.json   where the two files are, and the builtin instances of the run          (AirPrivateInput)
 """
+import json
 import struct
-from dataclasses import dataclass
-from typing import List, Optional
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
 
 P = 2**251 + 17 * 2**192 + 1
 HALF_OFFSET = 1 << 15
@@ -50,6 +52,62 @@ def write_register_states(states) -> bytes:
 def write_memory(memory) -> bytes:
     """the inverse of read_memory: one record per touched cell, in address order"""
     return b"".join(struct.pack("<Q", a) + int(w).to_bytes(32, "little") for a, w in enumerate(memory) if w is not None)
+
+
+def _u256(text) -> int:
+    """deserialize_hex_str (binary/src/utils.rs:30-33): the string through ruint's FromStr - "0x..." as every cairo-run file writes it,
+    a bare decimal number as well"""
+    if not isinstance(text, str):
+        raise ValueError("a 256-bit value of the private input must be a string, got %r" % (text,))
+    value = int(text, 0)
+    if not 0 <= value < 1 << 256:
+        raise ValueError("%s does not fit 256 bits" % text)
+    return value
+
+
+@dataclass
+class AirPrivateInput:
+    """`air-private-input.json` (binary/src/lib.rs:522-536; the instance records :343-520): the paths of trace.bin / memory.bin and the
+    builtin instances `cairo-run` recorded.  `instances` holds them as the trace generators take them (layouts/*.py base_trace,
+    hostlib.*_base_trace, hostlib.prove_files): tuples that start with the instance's index -
+      pedersen (index, x, y) | range_check (index, value) | ecdsa (index, pubkey, msg, r, w) | bitwise (index, x, y) |
+      ec_op (index, p_x, p_y, q_x, q_y, m) | poseidon (index, input_s0, input_s1, input_s2).
+    `pedersen` and `range_check` must be there; the other four default to none (the reference's #[serde(default)])."""
+    trace_path: str
+    memory_path: str
+    instances: Dict[str, List[tuple]] = field(default_factory=dict)
+
+    _FIELDS = (("pedersen", ("x", "y"), True), ("range_check", ("value",), True), ("ecdsa", ("pubkey", "msg", ("signature_input", "r"), ("signature_input", "w")), False),
+               ("bitwise", ("x", "y"), False), ("ec_op", ("p_x", "p_y", "q_x", "q_y", "m"), False), ("poseidon", ("input_s0", "input_s1", "input_s2"), False))
+
+    @classmethod
+    def from_dict(cls, doc) -> "AirPrivateInput":
+        for key in ("trace_path", "memory_path"):
+            if not isinstance(doc.get(key), str):
+                raise ValueError("private input: `%s` is missing" % key)
+        instances = {}
+        for name, keys, required in cls._FIELDS:
+            if name not in doc:
+                if required:
+                    raise ValueError("private input: `%s` is missing" % name)
+                instances[name] = []
+                continue
+            rows = []
+            for rec in doc[name]:
+                try:
+                    index = rec["index"]
+                    if not isinstance(index, int) or isinstance(index, bool) or not 0 <= index < 1 << 32:
+                        raise ValueError("index %r is not a u32" % (index,))
+                    rows.append((index,) + tuple(_u256(rec[k[0]][k[1]] if isinstance(k, tuple) else rec[k]) for k in keys))
+                except (KeyError, TypeError) as e:
+                    raise ValueError("private input: a `%s` instance lacks %s" % (name, e))
+            instances[name] = rows
+        return cls(doc["trace_path"], doc["memory_path"], instances)
+
+    @classmethod
+    def from_json(cls, path) -> "AirPrivateInput":
+        with open(path) as f:
+            return cls.from_dict(json.load(f))
 
 
 class Word:

@@ -44,10 +44,9 @@ def bootloader_run():
     with gzip.open(os.path.join(g, "bootloader", "memory.bin.gz")) as f:
         memory = binary.read_memory(f.read())
     pi = public_input.AirPublicInput.from_json(os.path.join(g, "air_public_input_bootloader.json"))
-    with open(os.path.join(g, "bootloader", "air-private-input.json")) as f:
-        priv = json.load(f)
-    assert all(priv[k] == [] for k in ("range_check", "ecdsa", "bitwise", "ec_op", "poseidon"))
-    return states, memory, pi, {"pedersen": [(e["index"], int(e["x"], 16), int(e["y"], 16)) for e in priv["pedersen"]]}
+    priv = binary.AirPrivateInput.from_json(os.path.join(g, "bootloader", "air-private-input.json")).instances
+    assert all(priv[k] == [] for k in ("range_check", "ecdsa", "bitwise", "ec_op", "poseidon")) and len(priv["pedersen"]) == 2
+    return states, memory, pi, {"pedersen": priv["pedersen"]}
 
 
 def real_instances():
