@@ -397,13 +397,11 @@ def _public_input_args(pi):
 
 def _instances(rows, width):
     """[(index, v0[, v1])] -> uint64 array of `width` words per instance (index, then 4 little-endian limbs per value)"""
-    out = np.zeros((max(1, len(rows)), width), dtype=np.uint64)
-    for i, row in enumerate(rows):
-        out[i, 0] = int(row[0])
-        for j, v in enumerate(row[1:]):
-            for k in range(4):
-                out[i, 1 + 4 * j + k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
-    return out
+    if not rows:
+        return np.zeros((1, width), dtype=np.uint64)
+    # (a run may bring tens of thousands of instances: one to_bytes per value, not four shifts)
+    raw = b"".join(int(row[0]).to_bytes(8, "little") + b"".join(int(v).to_bytes(32, "little") for v in row[1:]).ljust(8 * (width - 1), b"\0") for row in rows)
+    return np.frombuffer(raw, dtype="<u8").reshape(len(rows), width).copy()
 
 
 def _trace_out(out, ncols, n):
