@@ -166,57 +166,57 @@ void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states,
     constexpr uint64_t JNZ_BLOCK = 512;                  // cycles whose conditional jumps share one inversion (JnzInverses)
 #pragma omp parallel for schedule(static) if (par)
     for (int64_t blk_i = 0; blk_i < (int64_t)((num_cycles + JNZ_BLOCK - 1) / JNZ_BLOCK); ++blk_i) try {
-      const uint64_t first_cycle = (uint64_t)blk_i * JNZ_BLOCK, end_cycle = std::min(num_cycles, first_cycle + JNZ_BLOCK);
-      JnzInverses jnz(states, mem, first_cycle, end_cycle);
-      for (uint64_t cycle = first_cycle; cycle < end_cycle; ++cycle) {
-        const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
-        const U256 &iw = mem.at(pc);
-        const Word w{iw[0]};
-        if ((iw[1] | iw[2] | iw[3]) || w.flag(F_ZERO)) fail("memory cell " + std::to_string(pc) + " is not an instruction");
-        const uint64_t dst_addr = w.off_dst() + (w.flag(F_DST_REG) ? fp : ap) - HALF_OFFSET;
-        const uint64_t op0_addr = w.off_op0() + (w.flag(F_OP0_REG) ? fp : ap) - HALF_OFFSET;
-        const int src = w.op1_src();
-        if (src != 0 && src != 1 && src != 2 && src != 4) fail("invalid op1 source");
-        const uint64_t base = src == 0 ? mem.small(op0_addr) : src == 1 ? pc : src == 2 ? fp : ap;
-        const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
-        const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
-        Felt res;
-        if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : jnz.take(dst);           // get_res: dst^-1 on a jnz
-        else if (w.res_logic() == 0) res = op1;
-        else if (w.res_logic() == 1) res = felt_add(op0, op1);
-        else if (w.res_logic() == 2) res = felt_mul(op0, op1);
-        else fail("invalid res logic");
-        const Felt tmp0 = w.flag(F_PC_JNZ) ? dst : zero;
-        Felt blk[CYCLE_HEIGHT];
-        for (int f = 0; f < 16; ++f) flags[r + f] = felt_from_u64(w.flag_prefix(f));
-        // memory pool: (address, value) pairs, the padding pair where the CPU has none
-        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += 2) { blk[o] = pad_addr; blk[o + 1] = pad_value; npc_addr[(r + o) / 2] = 1; }
-        auto pair = [&](uint64_t o, uint64_t address, const Felt &value) { blk[o] = felt_from_u64(address); blk[o + 1] = value; npc_addr[(r + o) / 2] = address; };
-        pair(NPC_PC, pc, felt_from_canonical(iw));
-        pair(NPC_MEM_OP0_ADDR, op0_addr, op0);
-        pair(NPC_MEM_DST_ADDR, dst_addr, dst);
-        pair(NPC_MEM_OP1_ADDR, op1_addr, op1);
-        pair(NPC_PUB_MEM_ADDR, 0, zero);
-        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) npc[r + o] = blk[o];
-        // range-check column: the declared maximum, the instruction's offsets, the odd cycles' next padding value, the ordered values
-        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = rc_max_f;
-        blk[RC_OFF_DST] = felt_from_u64(w.off_dst()); blk[RC_OFF_OP1] = felt_from_u64(w.off_op1()); blk[RC_OFF_OP0] = felt_from_u64(w.off_op0());
-        if (cycle % 2 == 1) {
-            const size_t at = pad0 + cycle / 2;
-            blk[RC_UNUSED] = felt_from_u64(at < padding_vals.size() ? padding_vals[at] : rc_hi);
+        const uint64_t first_cycle = (uint64_t)blk_i * JNZ_BLOCK, end_cycle = std::min(num_cycles, first_cycle + JNZ_BLOCK);
+        JnzInverses jnz(states, mem, first_cycle, end_cycle);
+        for (uint64_t cycle = first_cycle; cycle < end_cycle; ++cycle) {
+            const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
+            const U256 &iw = mem.at(pc);
+            const Word w{iw[0]};
+            if ((iw[1] | iw[2] | iw[3]) || w.flag(F_ZERO)) fail("memory cell " + std::to_string(pc) + " is not an instruction");
+            const uint64_t dst_addr = w.off_dst() + (w.flag(F_DST_REG) ? fp : ap) - HALF_OFFSET;
+            const uint64_t op0_addr = w.off_op0() + (w.flag(F_OP0_REG) ? fp : ap) - HALF_OFFSET;
+            const int src = w.op1_src();
+            if (src != 0 && src != 1 && src != 2 && src != 4) fail("invalid op1 source");
+            const uint64_t base = src == 0 ? mem.small(op0_addr) : src == 1 ? pc : src == 2 ? fp : ap;
+            const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
+            const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
+            Felt res;
+            if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : jnz.take(dst);           // get_res: dst^-1 on a jnz
+            else if (w.res_logic() == 0) res = op1;
+            else if (w.res_logic() == 1) res = felt_add(op0, op1);
+            else if (w.res_logic() == 2) res = felt_mul(op0, op1);
+            else fail("invalid res logic");
+            const Felt tmp0 = w.flag(F_PC_JNZ) ? dst : zero;
+            Felt blk[CYCLE_HEIGHT];
+            for (int f = 0; f < 16; ++f) flags[r + f] = felt_from_u64(w.flag_prefix(f));
+            // memory pool: (address, value) pairs, the padding pair where the CPU has none
+            for (uint64_t o = 0; o < CYCLE_HEIGHT; o += 2) { blk[o] = pad_addr; blk[o + 1] = pad_value; npc_addr[(r + o) / 2] = 1; }
+            auto pair = [&](uint64_t o, uint64_t address, const Felt &value) { blk[o] = felt_from_u64(address); blk[o + 1] = value; npc_addr[(r + o) / 2] = address; };
+            pair(NPC_PC, pc, felt_from_canonical(iw));
+            pair(NPC_MEM_OP0_ADDR, op0_addr, op0);
+            pair(NPC_MEM_DST_ADDR, dst_addr, dst);
+            pair(NPC_MEM_OP1_ADDR, op1_addr, op1);
+            pair(NPC_PUB_MEM_ADDR, 0, zero);
+            for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) npc[r + o] = blk[o];
+            // range-check column: the declared maximum, the instruction's offsets, the odd cycles' next padding value, the ordered values
+            for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = rc_max_f;
+            blk[RC_OFF_DST] = felt_from_u64(w.off_dst()); blk[RC_OFF_OP1] = felt_from_u64(w.off_op1()); blk[RC_OFF_OP0] = felt_from_u64(w.off_op0());
+            if (cycle % 2 == 1) {
+                const size_t at = pad0 + cycle / 2;
+                blk[RC_UNUSED] = felt_from_u64(at < padding_vals.size() ? padding_vals[at] : rc_hi);
+            }
+            for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP) {
+                const uint64_t at = cycle * per + o / RANGE_CHECK_STEP;
+                blk[o + RC_ORDERED] = felt_from_u64(at < ordered_vals.size() ? ordered_vals[at] : rc_hi);
+            }
+            for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) rc_col[r + o] = blk[o];
+            // auxiliary column: zero where no section writes
+            for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = zero;
+            blk[AUX_TMP0] = tmp0; blk[AUX_TMP1] = felt_mul(tmp0, res);
+            blk[AUX_AP] = felt_from_u64(ap); blk[AUX_FP] = felt_from_u64(fp);
+            blk[AUX_OP0_MUL_OP1] = felt_mul(op0, op1); blk[AUX_RES] = res;
+            for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) aux[r + o] = blk[o];
         }
-        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP) {
-            const uint64_t at = cycle * per + o / RANGE_CHECK_STEP;
-            blk[o + RC_ORDERED] = felt_from_u64(at < ordered_vals.size() ? ordered_vals[at] : rc_hi);
-        }
-        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) rc_col[r + o] = blk[o];
-        // auxiliary column: zero where no section writes
-        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = zero;
-        blk[AUX_TMP0] = tmp0; blk[AUX_TMP1] = felt_mul(tmp0, res);
-        blk[AUX_AP] = felt_from_u64(ap); blk[AUX_FP] = felt_from_u64(fp);
-        blk[AUX_OP0_MUL_OP1] = felt_mul(op0, op1); blk[AUX_RES] = res;
-        for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) aux[r + o] = blk[o];
-      }
     } catch (const std::exception &e) {
 #pragma omp critical
         if (first_error.empty()) first_error = e.what();
