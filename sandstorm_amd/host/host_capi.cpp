@@ -385,7 +385,7 @@ TraceJob make_trace_job(int layout, const uint8_t *trace_bin, uint64_t trace_len
     job.n = 16 * (uint64_t)states.size();
     if (layout == 1) {
         job.ncols = 7;
-        job.order = {0, 6, 5, 1, 2, 3, 4};        // flags, auxiliary, range check, the diluted pair, memory pool, sorted memory
+        job.order = {1, 2, 0, 6, 5, 3, 4};        // the diluted pair, flags, auxiliary, range check, memory pool, sorted memory
         job.run = [=](Felt *const *out, const std::function<void(int)> *done) {
             PrivateInput rp;
             rp.pedersen = priv->pedersen; rp.range_check = priv->range_check; rp.bitwise = priv->bitwise;

@@ -108,6 +108,92 @@ void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states,
     auto set_pair = [&](uint64_t row, uint64_t address, const Felt &value) { npc[row] = felt_from_u64(address); npc[row + 1] = value; npc_addr[row / 2] = address; };
 
     mark("init");
+    const Segment &ped_seg = pi.segments[3], &rc_seg = pi.segments[4], &bw_seg = pi.segments[6];
+    if (!ped_seg.present || !rc_seg.present || !bw_seg.present) fail("the layout needs the pedersen, range_check and bitwise segments");
+    // ---- bitwise builtin and the diluted check (trace.rs:420-588), FIRST: the two diluted-check columns need no CPU cell, and the call
+    // this generator runs inside (ssh_prove_files) is bound by the uploads of the finished columns - one copy stream, 9.5 ms a column -,
+    // which cannot begin before a column is final.  The instances' five memory cells wait for the CPU section, which writes the
+    // memory pool's rows whole (below)
+    {
+        const uint64_t step = BITWISE_RATIO * CYCLE_HEIGHT;
+        std::map<uint32_t, const BitwiseInstance *> given;
+        for (auto &inst : priv.bitwise) given[inst.index] = &inst;
+        std::vector<uint32_t> dil_count(1u << DILUTED_N_BITS, 0);
+        // one histogram per thread (nearly every instance is the dummy one: all threads would hammer the counter of value 0)
+        std::vector<std::vector<uint32_t>> dil_count_of((size_t)omp_get_max_threads());
+        const uint64_t shifted_cells[4] = {1, 65, 33, 97};
+        std::string bw_error;
+#pragma omp parallel for schedule(static) if (par)
+        for (int64_t bi = 0; bi < (int64_t)(n / step); ++bi) try {
+            std::vector<uint32_t> &my_count = dil_count_of[(size_t)omp_get_thread_num()];
+            if (my_count.empty()) my_count.assign(1u << DILUTED_N_BITS, 0);
+            const uint64_t i = (uint64_t)bi;
+            const uint64_t base = i * step;
+            U256 x{}, y{};
+            auto it = given.find((uint32_t)i);
+            if (it != given.end()) { x = it->second->x; y = it->second->y; }
+            else {
+                // the dummy instance (x = y = 0; nearly every instance of a run is one): each of its 4 + 64 diluted cells is the value 0 -
+                // nothing to partition, dilute or check (that arithmetic, not the stores, was most of this section's time)
+                for (uint64_t o = 0; o < step; ++o) un_col[base + o] = zero;
+                my_count[0] += 4 + 64;
+                continue;
+            }
+            U256 vand, vxor;
+            for (int k = 0; k < 4; ++k) { vand[k] = x[k] & y[k]; vxor[k] = x[k] ^ y[k]; }
+            const U256 *vals[4] = {&x, &y, &vand, &vxor};
+            uint64_t parts[4][4][4];
+            for (int p = 0; p < 4; ++p) for (int c = 0; c < 4; ++c) partition64((*vals[p])[c], parts[p][c]);
+            Felt blk[BITWISE_RATIO * CYCLE_HEIGHT];                  // the instance's rows of the unordered column: zeros, then its cells
+            for (uint64_t o = 0; o < step; ++o) blk[o] = zero;
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t v = parts[2][3][k] + parts[3][3][k];
+                const unsigned sh = k == 3 ? 8 : 4;
+                if ((v << sh) >> sh != v) fail("bitwise instance: top segment does not fit");
+                blk[shifted_cells[k]] = felt_from_u64(v << sh);
+                ++my_count[undilute(v << sh)];
+            }
+            for (int p = 0; p < 4; ++p)
+                for (int c = 0; c < 4; ++c)
+                    for (int s = 0; s < 4; ++s) {
+                        blk[32 * p + 8 * c + 2 * s] = felt_from_u64(parts[p][c][s]);
+                        ++my_count[undilute(parts[p][c][s])];
+                    }
+            for (uint64_t o = 0; o < step; ++o) un_col[base + o] = blk[o];
+        } catch (const std::exception &e) {
+#pragma omp critical
+            if (bw_error.empty()) bw_error = e.what();
+        }
+        if (!bw_error.empty()) throw std::runtime_error(bw_error);
+        for (auto &part : dil_count_of) for (size_t v = 0; v < part.size(); ++v) dil_count[v] += part[v];
+        std::vector<uint32_t> padding;
+        uint64_t total = 0;
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) { if (!dil_count[v]) padding.push_back(v); total += std::max(dil_count[v], 1u); }
+        if (total > n) fail("diluted-check values do not fit the trace");
+        size_t pi_ = 0;
+        for (uint64_t blk = 0; blk < n / step && pi_ < padding.size(); ++blk)
+            for (uint64_t off = 1; off < step && pi_ < padding.size(); off += 2) {
+                if (off == 1 || off == 33 || off == 65 || off == 97) continue;
+                un_col[blk * step + off] = felt_from_u64(dilute(padding[pi_++]));
+            }
+        if (pi_ < padding.size()) fail("diluted-check values do not fit the trace");
+        std::vector<uint64_t> first_row((1u << DILUTED_N_BITS) + 1, n - total);
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) first_row[v + 1] = first_row[v] + std::max(dil_count[v], 1u);
+        first_row[0] = 0;               // the rows before the first value are zeros, and so is the first value's image: one run from row 0
+#pragma omp parallel for schedule(dynamic, 64) if (par)
+        for (int64_t v = 0; v < (int64_t)(1u << DILUTED_N_BITS); ++v) {
+            const Felt f = felt_from_u64(dilute((uint32_t)v));
+            if (first_row[v + 1] - first_row[v] < 4096) { for (uint64_t r2 = first_row[v]; r2 < first_row[v + 1]; ++r2) od_col[r2] = f; }
+        }
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)             // the long runs (value 0 of the dummy instances) by all threads
+            if (first_row[v + 1] - first_row[v] >= 4096) {
+                const Felt f = felt_from_u64(dilute(v));
+#pragma omp parallel for schedule(static) if (par)
+                for (int64_t r2 = (int64_t)first_row[v]; r2 < (int64_t)first_row[v + 1]; ++r2) od_col[r2] = f;
+            }
+    }
+    mark("bitwise + diluted");
+    done({COL_DILUTED_UNORDERED, COL_DILUTED_ORDERED});
     // ---- the range-check pool: the offsets of every instruction counted first, no column touched (trace.rs:131-160; utils.rs:357-380)
     std::vector<uint32_t> rc_count(1 << 16, 0);
     std::string first_error;                            // exceptions must not leave an OpenMP region
@@ -225,10 +311,26 @@ void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states,
 
     mark("cpu cells");
     done({COL_FLAGS});
+    {   // the bitwise instances' memory cells: x, y, x & y, x ^ y in the pool cells of the instance's four quarters, x | y beside
+        const uint64_t step = BITWISE_RATIO * CYCLE_HEIGHT;
+        std::map<uint32_t, const BitwiseInstance *> given;
+        for (auto &inst : priv.bitwise) given[inst.index] = &inst;
+#pragma omp parallel for schedule(static) if (par)
+        for (int64_t bi = 0; bi < (int64_t)(n / step); ++bi) {
+            const uint64_t i = (uint64_t)bi, base = i * step, addr = bw_seg.begin_addr + 5 * i;
+            U256 x{}, y{};
+            auto it = given.find((uint32_t)i);
+            if (it != given.end()) { x = it->second->x; y = it->second->y; }
+            U256 vand, vxor, vor;
+            for (int k = 0; k < 4; ++k) { vand[k] = x[k] & y[k]; vxor[k] = x[k] ^ y[k]; vor[k] = x[k] | y[k]; }
+            const U256 *vals[4] = {&x, &y, &vand, &vxor};
+            for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + k * (step / 4), addr + k, felt_from_canonical(*vals[k]));
+            set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, felt_from_canonical(vor));
+        }
+    }
+    mark("bitwise memory cells");
 
     // ---- Pedersen builtin (trace.rs:300-400; builtins/src/pedersen/mod.rs:81-163)
-    const Segment &ped_seg = pi.segments[3], &rc_seg = pi.segments[4], &bw_seg = pi.segments[6];
-    if (!ped_seg.present || !rc_seg.present || !bw_seg.present) fail("the layout needs the pedersen, range_check and bitwise segments");
     {
         const uint64_t step = PEDERSEN_BUILTIN_RATIO * CYCLE_HEIGHT;
         std::map<uint32_t, const PedersenInstance *> given;
@@ -296,91 +398,6 @@ void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states,
     }
     mark("rc builtin");
     done({COL_RANGE_CHECK});
-    // ---- bitwise builtin and the diluted check (trace.rs:420-588)
-    {
-        const uint64_t step = BITWISE_RATIO * CYCLE_HEIGHT;
-        std::map<uint32_t, const BitwiseInstance *> given;
-        for (auto &inst : priv.bitwise) given[inst.index] = &inst;
-        std::vector<uint32_t> dil_count(1u << DILUTED_N_BITS, 0);
-        // one histogram per thread (nearly every instance is the dummy one: all threads would hammer the counter of value 0)
-        std::vector<std::vector<uint32_t>> dil_count_of((size_t)omp_get_max_threads());
-        const uint64_t shifted_cells[4] = {1, 65, 33, 97};
-        std::string bw_error;
-#pragma omp parallel for schedule(static) if (par)
-        for (int64_t bi = 0; bi < (int64_t)(n / step); ++bi) try {
-            std::vector<uint32_t> &my_count = dil_count_of[(size_t)omp_get_thread_num()];
-            if (my_count.empty()) my_count.assign(1u << DILUTED_N_BITS, 0);
-            const uint64_t i = (uint64_t)bi;
-            const uint64_t base = i * step, addr = bw_seg.begin_addr + 5 * i;
-            U256 x{}, y{};
-            auto it = given.find((uint32_t)i);
-            if (it != given.end()) { x = it->second->x; y = it->second->y; }
-            else {
-                // the dummy instance (x = y = 0; nearly every instance of a run is one): each of its 4 + 64 diluted cells is the value 0 -
-                // nothing to partition, dilute or check (that arithmetic, not the stores, was most of this section's time)
-                for (uint64_t o = 0; o < step; ++o) un_col[base + o] = zero;
-                my_count[0] += 4 + 64;
-                for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + k * (step / 4), addr + k, zero);
-                set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, zero);
-                continue;
-            }
-            U256 vand, vxor, vor;
-            for (int k = 0; k < 4; ++k) { vand[k] = x[k] & y[k]; vxor[k] = x[k] ^ y[k]; vor[k] = x[k] | y[k]; }
-            const U256 *vals[4] = {&x, &y, &vand, &vxor};
-            uint64_t parts[4][4][4];
-            for (int p = 0; p < 4; ++p) for (int c = 0; c < 4; ++c) partition64((*vals[p])[c], parts[p][c]);
-            Felt blk[BITWISE_RATIO * CYCLE_HEIGHT];                  // the instance's rows of the unordered column: zeros, then its cells
-            for (uint64_t o = 0; o < step; ++o) blk[o] = zero;
-            for (int k = 0; k < 4; ++k) {
-                const uint64_t v = parts[2][3][k] + parts[3][3][k];
-                const unsigned sh = k == 3 ? 8 : 4;
-                if ((v << sh) >> sh != v) fail("bitwise instance: top segment does not fit");
-                blk[shifted_cells[k]] = felt_from_u64(v << sh);
-                ++my_count[undilute(v << sh)];
-            }
-            for (int p = 0; p < 4; ++p)
-                for (int c = 0; c < 4; ++c)
-                    for (int s = 0; s < 4; ++s) {
-                        blk[32 * p + 8 * c + 2 * s] = felt_from_u64(parts[p][c][s]);
-                        ++my_count[undilute(parts[p][c][s])];
-                    }
-            for (uint64_t o = 0; o < step; ++o) un_col[base + o] = blk[o];
-            for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + k * (step / 4), addr + k, felt_from_canonical(*vals[k]));
-            set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, felt_from_canonical(vor));
-        } catch (const std::exception &e) {
-#pragma omp critical
-            if (bw_error.empty()) bw_error = e.what();
-        }
-        if (!bw_error.empty()) throw std::runtime_error(bw_error);
-        for (auto &part : dil_count_of) for (size_t v = 0; v < part.size(); ++v) dil_count[v] += part[v];
-        std::vector<uint32_t> padding;
-        uint64_t total = 0;
-        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) { if (!dil_count[v]) padding.push_back(v); total += std::max(dil_count[v], 1u); }
-        if (total > n) fail("diluted-check values do not fit the trace");
-        size_t pi_ = 0;
-        for (uint64_t blk = 0; blk < n / step && pi_ < padding.size(); ++blk)
-            for (uint64_t off = 1; off < step && pi_ < padding.size(); off += 2) {
-                if (off == 1 || off == 33 || off == 65 || off == 97) continue;
-                un_col[blk * step + off] = felt_from_u64(dilute(padding[pi_++]));
-            }
-        if (pi_ < padding.size()) fail("diluted-check values do not fit the trace");
-        std::vector<uint64_t> first_row((1u << DILUTED_N_BITS) + 1, n - total);
-        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) first_row[v + 1] = first_row[v] + std::max(dil_count[v], 1u);
-        first_row[0] = 0;               // the rows before the first value are zeros, and so is the first value's image: one run from row 0
-#pragma omp parallel for schedule(dynamic, 64) if (par)
-        for (int64_t v = 0; v < (int64_t)(1u << DILUTED_N_BITS); ++v) {
-            const Felt f = felt_from_u64(dilute((uint32_t)v));
-            if (first_row[v + 1] - first_row[v] < 4096) { for (uint64_t r2 = first_row[v]; r2 < first_row[v + 1]; ++r2) od_col[r2] = f; }
-        }
-        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)             // the long runs (value 0 of the dummy instances) by all threads
-            if (first_row[v + 1] - first_row[v] >= 4096) {
-                const Felt f = felt_from_u64(dilute(v));
-#pragma omp parallel for schedule(static) if (par)
-                for (int64_t r2 = (int64_t)first_row[v]; r2 < (int64_t)first_row[v + 1]; ++r2) od_col[r2] = f;
-            }
-    }
-    mark("bitwise + diluted");
-    done({COL_DILUTED_UNORDERED, COL_DILUTED_ORDERED});
     // ---- gap fillers (trace.rs:594-625)
     {
         const std::vector<uint64_t> gaps = memory_gaps(npc_addr, pi.public_memory, num_cycles);

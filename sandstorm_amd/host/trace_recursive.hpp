@@ -49,8 +49,9 @@ std::vector<std::vector<Felt>> recursive_base_trace(const RegisterStates &states
                                                     const PrivateInput &priv);
 
 // the same into the caller's 7 columns of 16 * cycles felts each (every cell is written)
-// column_done (optional): called with c as soon as no section will write column c again (flags after the CPU cells, auxiliary after
-// Pedersen, range check after its builtin, the diluted pair after bitwise, the memory pool after the gap fillers, sorted memory last)
+// column_done (optional): called with c as soon as no section will write column c again (the diluted pair after bitwise - the first
+// section: it needs no CPU cell -, flags after the CPU cells, auxiliary after Pedersen, range check after its builtin, the memory pool
+// after the gap fillers, sorted memory last)
 void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states, const std::vector<U256> &memory,
                                const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv,
                                const std::function<void(int)> *column_done = nullptr);
