@@ -283,7 +283,8 @@ void ecdsa_dummy_instance(U256 &pubkey_x, U256 &message, U256 &r, U256 &w) {
     }
 }
 
-struct PoseidonTrace { std::array<Felt, 3> full[8]; std::vector<Felt> partial; Felt out[3]; };
+// (the squares are cells of the trace too: made with the instance's trace - once per DISTINCT instance, not once per block that holds it)
+struct PoseidonTrace { std::array<Felt, 3> full[8], full_sq[8]; std::vector<Felt> partial, partial_sq; Felt out[3]; };
 Felt cube(const Felt &v) { return felt_mul(felt_mul(v, v), v); }
 PoseidonTrace poseidon_trace(const std::array<Felt, 3> &input) {       // poseidon::InstanceTrace::new (poseidon/mod.rs:45-98)
     const auto &rk = poseidon_round_keys();
@@ -299,6 +300,9 @@ PoseidonTrace poseidon_trace(const std::array<Felt, 3> &input) {       // poseid
                   felt_sub(felt_add(st[0], st[1]), felt_add(st[2], st[2]))};
         }
     for (int j = 0; j < 3; ++j) t.out[j] = st[j];
+    for (int rnd = 0; rnd < 8; ++rnd) for (int j = 0; j < 3; ++j) t.full_sq[rnd][j] = felt_mul(t.full[rnd][j], t.full[rnd][j]);
+    t.partial_sq.resize(t.partial.size());
+    for (size_t k = 0; k < t.partial.size(); ++k) t.partial_sq[k] = felt_mul(t.partial[k], t.partial[k]);
     return t;
 }
 
@@ -721,10 +725,10 @@ void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, 
             for (uint64_t rnd = 0; rnd < 8; ++rnd)
                 for (int j = 0; j < 3; ++j) {
                     aux[base + 64 * rnd + FULL[j][0]] = t.full[rnd][j];
-                    aux[base + 64 * rnd + FULL[j][1]] = felt_mul(t.full[rnd][j], t.full[rnd][j]);
+                    aux[base + 64 * rnd + FULL[j][1]] = t.full_sq[rnd][j];
                 }
-            for (uint64_t k = 0; k < 64; ++k) { rc_col[base + 8 * k + 3] = t.partial[k]; rc_col[base + 8 * k + 7] = felt_mul(t.partial[k], t.partial[k]); }
-            for (uint64_t k = 0; k + 61 < t.partial.size(); ++k) { aux[base + 16 * k + 6] = t.partial[61 + k]; aux[base + 16 * k + 14] = felt_mul(t.partial[61 + k], t.partial[61 + k]); }
+            for (uint64_t k = 0; k < 64; ++k) { rc_col[base + 8 * k + 3] = t.partial[k]; rc_col[base + 8 * k + 7] = t.partial_sq[k]; }
+            for (uint64_t k = 0; k + 61 < t.partial.size(); ++k) { aux[base + 16 * k + 6] = t.partial[61 + k]; aux[base + 16 * k + 14] = t.partial_sq[61 + k]; }
             for (int k = 0; k < 3; ++k) { set_pair(base + NPC_POSEIDON_ADDRS[k], addr + k, input[k]); set_pair(base + NPC_POSEIDON_ADDRS[3 + k], addr + 3 + k, t.out[k]); }
         });
     }
