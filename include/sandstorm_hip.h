@@ -78,7 +78,7 @@ enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
 const char *ss_last_error(void);
 /* ABI version of this header; bump on any signature change.  ss_abi_version() of the loaded
  * library must equal SS_ABI_VERSION of the header the caller was built against. */
-#define SS_ABI_VERSION 10u
+#define SS_ABI_VERSION 11u
 uint32_t ss_abi_version(void);
 
 /* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;
@@ -455,12 +455,105 @@ ss_status ss_diluted_aggregate(ss_ctx *ctx, const uint64_t *d_ordered, uint64_t 
                                const uint64_t z[4], const uint64_t alpha[4], uint64_t *d_out, uint64_t out_stride,
                                uint64_t out_offset);
 
+/* ---- the BASE trace on the device (ABI 11; SURVEY.md section 8a row A1 / "next" row X1).  ExecutionTrace::new
+ *      (layouts/src/starknet/trace.rs:99-987, layouts/src/recursive/trace.rs:89-688, layouts/src/utils.rs:112-152,
+ *      357-380) makes the 9 / 7 base columns from `cairo-run`'s trace.bin / memory.bin with rayon loops and sequential
+ *      sorts on the host; uploaded, they are 3.6 - 4.8 GB of PCIe traffic for cells that are functions of ~25 MB.  These entry
+ *      points make the cells in HBM from the raw files' bytes: the caller (host/device_trace.cpp, which knows the layouts)
+ *      uploads the files, a placement table and one template per DISTINCT builtin instance, and calls them in the order the
+ *      reference's sections run (a later section overwrites an earlier one's cells, as there).  Everything on the ctx stream,
+ *      no host sync; errors of the INPUT (a cell memory.bin does not hold, memory that is not continuous, ...) are bits of a
+ *      status block the caller reads once at the end (ss_trace_status).  Columns: n = 16 * num_cycles Montgomery felts. */
+/* where the CPU's cells sit in a cycle's 16 rows (CYCLE_HEIGHT; the Npc / RangeCheck / Auxiliary enums of
+ * layouts/src/{recursive,starknet}/air.rs): the memory pool's 8 (address, value) pairs, the range-check and the auxiliary column's 16 cells */
+enum { SS_TRACE_NPC_PAD = 0,      /* (1, the value at address 1): the padding pair (trace.rs:204-207)      */
+       SS_TRACE_NPC_PUBLIC = 1,   /* (0, 0): a public-memory slot (Npc::PubMemAddr)                       */
+       SS_TRACE_NPC_PC = 2, SS_TRACE_NPC_OP0 = 3, SS_TRACE_NPC_DST = 4, SS_TRACE_NPC_OP1 = 5 };  /* (pc, instruction), (op0 address, op0), ... */
+enum { SS_TRACE_RC_FILL = 0,      /* the column's filler (rc_max / the pool's largest value); the pool's own cells come with ss_trace_rc_pool */
+       SS_TRACE_RC_ZERO = 1, SS_TRACE_RC_OFF_DST = 2, SS_TRACE_RC_OFF_OP0 = 3, SS_TRACE_RC_OFF_OP1 = 4 };
+enum { SS_TRACE_AUX_ZERO = 0, SS_TRACE_AUX_AP = 1, SS_TRACE_AUX_FP = 2, SS_TRACE_AUX_TMP0 = 3, SS_TRACE_AUX_TMP1 = 4, SS_TRACE_AUX_OP0_MUL_OP1 = 5,
+       SS_TRACE_AUX_RES = 6 };
+typedef struct { uint8_t npc_pair[8], rc_cell[16], aux_cell[16]; } ss_trace_layout;
+/* the status block: SS_TRACE_STATUS_WORDS u32 in device memory, zeroed (ss_dev_zero) before the first call of a generation.
+ * word 0: SS_TRACE_ERR_* bits; word 1: ~(the smallest cycle or address an error names); the rest: the ordered memory's counters */
+#define SS_TRACE_STATUS_WORDS 16u
+enum { SS_TRACE_ERR_MISSING_CELL = 1,        /* the run reads a cell memory.bin does not hold                        */
+       SS_TRACE_ERR_NOT_INSTRUCTION = 2,     /* pc points at a word that is not an instruction (binary/src/lib.rs:565-721) */
+       SS_TRACE_ERR_BAD_OP1_SOURCE = 4, SS_TRACE_ERR_BAD_RES_LOGIC = 8,
+       SS_TRACE_ERR_NOT_AN_ADDRESS = 16,     /* op0 is used as an address and does not fit one                       */
+       SS_TRACE_ERR_ADDRESS_RANGE = 32,      /* an address beyond n / 2: continuous memory cannot reach it            */
+       SS_TRACE_ERR_PUBLIC_ZERO = 64,        /* a public-memory entry at address 0                                   */
+       SS_TRACE_ERR_PUBLIC_CELLS = 128,      /* the pool's address-0 pairs are not exactly the public-memory slots    */
+       SS_TRACE_ERR_NO_ONES = 256,           /* memory does not start at address 1                                   */
+       SS_TRACE_ERR_NOT_SINGLE_VALUED = 512, SS_TRACE_ERR_NOT_CONTINUOUS = 1024,      /* utils.rs:132-150            */
+       SS_TRACE_ERR_TOO_MANY_GAPS = 2048,    /* more unaccessed addresses than cycles to hold them (trace.rs:594-625) */
+       SS_TRACE_ERR_FILL = 4096 };           /* the ordered accesses do not fill the column                          */
+/* memory.bin on the device: d_records = the file's bytes (n_records x (u64 address, 32-byte little-endian word), uploaded by
+ * the caller) -> d_image[address] as 4 x u64; cells the file does not name are marked (all-ones: not a field element).
+ * cells: entries of d_image; records beyond it are dropped (no address above n / 2 can be accessed by a valid run). */
+ss_status ss_trace_memory_image(ss_ctx *ctx, const uint64_t *d_records, uint64_t n_records, uint64_t *d_image, uint64_t cells);
+/* The CPU's cells (starknet trace.rs:177-244, 294-302; recursive 172-232): one lane per cycle decodes the instruction at pc,
+ * reads dst / op0 / op1 from d_image, computes res (dst^-1 for a conditional jump), tmp0, tmp1, op0 * op1, and the workgroup
+ * writes the cycle's 16 rows of the flags, memory-pool, range-check and auxiliary columns whole (every cell: what no later
+ * call overwrites keeps the padding written here) and the pool's 8 addresses per cycle as integers (d_pool_addr, n / 2 u32).
+ * d_states: trace.bin's bytes ((ap, fp, pc) u64 triples).  pad_value: the value at address 1, Montgomery.  rc_fill: the
+ * range-check column's filler. */
+ss_status ss_trace_cpu_cells(ss_ctx *ctx, const ss_trace_layout *layout, const uint64_t *d_states, uint64_t num_cycles, const uint64_t *d_image,
+                             uint64_t cells, const uint64_t pad_value[4], uint64_t rc_fill, uint64_t *d_flags, uint64_t *d_pool, uint64_t *d_range_check,
+                             uint64_t *d_auxiliary, uint32_t *d_pool_addr, uint32_t *d_status);
+/* A builtin's instances (Pedersen trace.rs:304-386, ECDSA 428-523, bitwise 525-705, EC op 707-777, Poseidon 779-888): block i
+ * of `block_rows` rows holds one instance; cell e of the instance's template goes to column d_cells[e].col, row
+ * i * block_rows + d_cells[e].off, and is the template's value e (SS_TRACE_CELL_VALUE: d_values[template * n_cells + e],
+ * Montgomery) or the felt of the address addr_begin + addr_per_block * i + d_cells[e].arg (SS_TRACE_CELL_ADDRESS: an even row of
+ * the memory pool; d_pool_addr gets the integer).  d_template_of_block: the template of every block (NULL: template 0
+ * everywhere - a run whose instances are all the dummy one); n_templates: templates in d_values. */
+typedef struct { uint32_t col, off, kind, arg; } ss_trace_cell;
+enum { SS_TRACE_CELL_VALUE = 0, SS_TRACE_CELL_ADDRESS = 1 };
+ss_status ss_trace_builtin(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, const ss_trace_cell *d_cells, uint32_t n_cells, const uint64_t *d_values,
+                           uint32_t n_templates, const uint32_t *d_template_of_block, uint64_t n_blocks, uint64_t block_rows, uint64_t addr_begin,
+                           uint64_t addr_per_block, uint32_t *d_pool_addr);
+/* The 16-bit range-check pool (utils.rs:357-380; starknet trace.rs:142-165, 246-292, 388-426).  The caller counts the pool's
+ * values (65536 bins: the instructions' offsets, the builtin's parts) and hands over
+ *   d_first[j], j <= rc_hi - rc_lo + 1: ordered values before value rc_lo + j (every value of [rc_lo, rc_hi] max(count, 1) times),
+ *   d_padding[n_padding]: the values of [rc_lo, rc_hi] nothing uses, ascending (then rc_hi forever).
+ * ss_trace_rc_pool writes, per cycle, its 16 / ordered_step ordered values at rows ordered_step * j + ordered_off and, on odd
+ * cycles, padding value pad0 + cycle / 2 at row unused_off; ss_trace_rc_builtin slot s < n_slots of slot_rows rows: instance s of
+ * d_given (3 u64 each: index, value low, value high) or, from n_given on, a dummy instance whose 8 parts are padding values
+ * 8 (s - n_given) ...; the parts at rows part_stride * k + part_off of the range-check column, (addr_begin + index, value) at
+ * rows pair_off, pair_off + 1 of the memory pool. */
+typedef struct {
+    uint64_t n_slots, n_given, slot_rows, addr_begin, n_padding, pad0;
+    uint32_t part_stride, part_off, pair_off, rc_lo, rc_hi, ordered_step, ordered_off, unused_off;
+} ss_trace_rc_plan;
+ss_status ss_trace_rc_pool(ss_ctx *ctx, const ss_trace_rc_plan *plan, const uint32_t *d_first, const uint16_t *d_padding, uint64_t num_cycles,
+                           uint64_t *d_range_check);
+ss_status ss_trace_rc_builtin(ss_ctx *ctx, const ss_trace_rc_plan *plan, const uint64_t *d_given, const uint16_t *d_padding, uint64_t *d_range_check,
+                              uint64_t *d_pool, uint32_t *d_pool_addr);
+/* An ordered pool's column (the diluted check: starknet trace.rs:695-705, recursive 560-588): slot k < slots goes to
+ * d_col[k * stride + offset]: zero for k < d_first[0], else the value lo + j with d_first[j] <= k < d_first[j + 1]
+ * (j < n_values; d_first has n_values + 1 entries), diluted (bit i -> bit 4 i) if asked. */
+ss_status ss_trace_ordered_runs(ss_ctx *ctx, uint64_t *d_col, uint64_t stride, uint64_t offset, uint64_t slots, const uint32_t *d_first,
+                                uint32_t n_values, uint32_t lo, int diluted);
+/* d_col[d_rows[k]] = felt(d_values[k]) for k < count (rows >= col_rows are skipped): the cells that are neither per cycle
+ * nor per instance (the diluted pool's padding values: trace.rs:668-693) */
+ss_status ss_trace_patch(ss_ctx *ctx, uint64_t *d_col, uint64_t col_rows, const uint64_t *d_rows, const uint64_t *d_values, uint64_t count);
+/* get_ordered_memory_accesses (utils.rs:112-152) and the gap fillers before it (trace.rs:594-625 / 890-925), without a sort:
+ * the pool's n / 2 accesses (d_pool_addr; values in d_pool) and the public memory's entries (d_public_addr / d_public_value
+ * [n_public], the latter Montgomery; its remaining public_cells - n_public entries are (1, pad_value)) are counted per address,
+ * the unaccessed addresses between the lowest and the highest become (address, 0) pairs at row unused_off of cycles 0, 1, ...
+ * of d_pool, and d_memory receives (a, value(a)) x count(a) for a = 1, 2, ...; the reference's checks set SS_TRACE_ERR_* bits. */
+ss_status ss_trace_ordered_memory(ss_ctx *ctx, uint64_t n, uint64_t *d_pool, uint64_t *d_memory, uint32_t *d_pool_addr, const uint32_t *d_public_addr,
+                                  const uint64_t *d_public_value, uint32_t n_public, uint64_t public_cells, const uint64_t pad_value[4],
+                                  uint32_t unused_off, uint32_t *d_status);
+/* waits for the stream and reads the status block (SS_TRACE_STATUS_WORDS u32) */
+ss_status ss_trace_status(ss_ctx *ctx, const uint32_t *d_status, uint32_t *status_out);
+
 /* ---- per-kernel timing (bench.py's roofline leg): when enabled, every launch of
  *      the named kernel family on the ctx stream is bracketed by HIP events.
  *      ss_profile_read synchronises the stream and returns the accumulated device
  *      time and launch count since the last reset. */
 enum { SS_PROF_NTT_PASS = 0, SS_PROF_HASH_ROWS = 1, SS_PROF_MERKLE = 2, SS_PROF_FRI = 3, SS_PROF_QUOTIENT = 4,
-       SS_PROF_DEEP = 5, SS_PROF_EXT = 6, SS_PROF_KINDS = 7 };
+       SS_PROF_DEEP = 5, SS_PROF_EXT = 6, SS_PROF_TRACE = 7, SS_PROF_KINDS = 8 };
 ss_status ss_profile_enable(ss_ctx *ctx, int on);
 ss_status ss_profile_reset(ss_ctx *ctx);
 ss_status ss_profile_read(ss_ctx *ctx, int kind, double *total_ms, uint64_t *launches);

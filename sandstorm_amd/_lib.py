@@ -94,6 +94,19 @@ SIGNATURES = {
                                  C.c_void_p, C.c_void_p]),
     "ss_gather_rows": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, _u64p, C.c_uint32, C.c_void_p]),
     "ss_gather_batch": (C.c_int, [C.c_void_p, C.POINTER(GatherJob), C.c_uint32]),
+    # the base trace on the device (ABI 11): structs as opaque pointers (the C++ host fills them: host/device_trace.hpp)
+    "ss_trace_memory_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "ss_trace_cpu_cells": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ss_trace_builtin": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64,
+                                   C.c_uint64, C.c_uint64, C.c_void_p]),
+    "ss_trace_rc_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "ss_trace_rc_builtin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ss_trace_ordered_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
+    "ss_trace_patch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ss_trace_ordered_memory": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, _u64p,
+                                          C.c_uint32, C.c_void_p]),
+    "ss_trace_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ss_inverse_table": (C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p, C.c_void_p]),
     "ss_eval_quotient": (C.c_int, [C.c_void_p, C.POINTER(AirProgram), _vpp, C.c_uint32, C.c_uint32,
                                    C.c_uint32, _u64p, C.c_void_p]),

@@ -32,7 +32,7 @@ HASH_KECCAK, HASH_KECCAK_M20, HASH_BLAKE2S, HASH_BLAKE2S_M20, HASH_SHA256 = 0, 1
 TREE_KECCAK, TREE_KECCAK_M20, TREE_FRIENDLY, TREE_BLAKE2S, TREE_SHA256 = 0, 1, 2, 3, 4
 LEAF_DIGEST, LEAF_FELT = 0, 1
 COIN_SOLIDITY, COIN_CAIRO = 0, 1
-PROF_NTT_PASS, PROF_HASH_ROWS, PROF_MERKLE, PROF_FRI, PROF_QUOTIENT, PROF_DEEP, PROF_EXT = range(7)
+PROF_NTT_PASS, PROF_HASH_ROWS, PROF_MERKLE, PROF_FRI, PROF_QUOTIENT, PROF_DEEP, PROF_EXT, PROF_TRACE = range(8)
 
 
 def felt(v):

@@ -493,7 +493,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns, ss_upload_async / ss_wait_upload (uploads on a copy stream, ordered into the context's stream by ticket), SS_HASH_SHA256 / SS_TREE_SHA256 for the 64-bit field's rows and trees; 10: ss_gather_batch (the query phase's gathers in one round trip)
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns, ss_upload_async / ss_wait_upload (uploads on a copy stream, ordered into the context's stream by ticket), SS_HASH_SHA256 / SS_TREE_SHA256 for the 64-bit field's rows and trees; 10: ss_gather_batch (the query phase's gathers in one round trip); 11: ss_trace_* (the base trace made on the device from trace.bin / memory.bin)
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -1324,6 +1324,127 @@ ss_status ss_diluted_aggregate(ss_ctx *ctx, const uint64_t *d_ordered, uint64_t 
     ss_ctx::Scope prof(ctx, SS_PROF_EXT);
     HIP_TRY(launch_diluted_aggregate(ctx->stream, (const Fp *)d_ordered, stride, offset, count, fp_from_limbs64(z),
                                      fp_from_limbs64(alpha), (Fp *)d_out, out_stride, out_offset, (Fp *)ctx->scratch));
+    return SS_OK;
+}
+
+// -------------------------------------------------------------- the base trace on the device (ABI 11; trace.hip)
+namespace {
+static_assert(SS_TRACE_ERR_MISSING_CELL == TRACE_ERR_MISSING_CELL && SS_TRACE_ERR_FILL == TRACE_ERR_FILL && SS_TRACE_ERR_NOT_CONTINUOUS == TRACE_ERR_NOT_CONTINUOUS &&
+              SS_TRACE_ERR_PUBLIC_CELLS == TRACE_ERR_PUBLIC_CELLS && SS_TRACE_STATUS_WORDS == TRACE_ST_WORDS && SS_TRACE_NPC_OP1 == TRACE_NPC_OP1 &&
+              SS_TRACE_RC_OFF_OP1 == TRACE_RC_OFF_OP1 && SS_TRACE_AUX_RES == TRACE_AUX_RES && SS_TRACE_CELL_ADDRESS == TRACE_TILE_ADDRESS,
+              "the header's constants are the kernels'");
+bool trace_layout_ok(const ss_trace_layout *l) {
+    if (!l) return false;
+    for (int j = 0; j < 8; ++j) if (l->npc_pair[j] > SS_TRACE_NPC_OP1) return false;
+    for (int o = 0; o < 16; ++o) if (l->rc_cell[o] > SS_TRACE_RC_OFF_OP1 || l->aux_cell[o] > SS_TRACE_AUX_RES) return false;
+    return true;
+}
+TraceRcPlan rc_plan_of(const ss_trace_rc_plan *p) {
+    TraceRcPlan q;
+    q.n_slots = p->n_slots; q.n_given = p->n_given; q.slot_rows = p->slot_rows; q.addr_begin = p->addr_begin; q.n_padding = p->n_padding; q.pad0 = p->pad0;
+    q.part_stride = p->part_stride; q.part_off = p->part_off; q.pair_off = p->pair_off; q.rc_lo = p->rc_lo; q.rc_hi = p->rc_hi;
+    q.ordered_step = p->ordered_step; q.ordered_off = p->ordered_off; q.unused_off = p->unused_off;
+    return q;
+}
+}  // namespace
+ss_status ss_trace_memory_image(ss_ctx *ctx, const uint64_t *d_records, uint64_t n_records, uint64_t *d_image, uint64_t cells) {
+    if (!ctx || !d_image || (n_records && !d_records)) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!cells || cells > (1ull << 33)) return fail(SS_ERR_INVALID, "memory image of %llu cells", (unsigned long long)cells);
+    ss_ctx::Scope prof(ctx, SS_PROF_TRACE);
+    HIP_TRY(launch_trace_memory_image(ctx->stream, d_records, n_records, d_image, cells));
+    return SS_OK;
+}
+ss_status ss_trace_cpu_cells(ss_ctx *ctx, const ss_trace_layout *layout, const uint64_t *d_states, uint64_t num_cycles, const uint64_t *d_image,
+                             uint64_t cells, const uint64_t pad_value[4], uint64_t rc_fill, uint64_t *d_flags, uint64_t *d_pool, uint64_t *d_range_check,
+                             uint64_t *d_auxiliary, uint32_t *d_pool_addr, uint32_t *d_status) {
+    if (!ctx || !d_states || !d_image || !pad_value || !d_flags || !d_pool || !d_range_check || !d_auxiliary || !d_pool_addr || !d_status)
+        return fail(SS_ERR_INVALID, "NULL argument");
+    if (!trace_layout_ok(layout)) return fail(SS_ERR_INVALID, "bad trace layout (a cell kind out of range)");
+    if (!num_cycles || num_cycles > (1ull << 28)) return fail(SS_ERR_INVALID, "num_cycles out of range");
+    TraceLayout L;
+    memcpy(L.npc_pair, layout->npc_pair, 8); memcpy(L.rc_cell, layout->rc_cell, 16); memcpy(L.aux_cell, layout->aux_cell, 16);
+    ss_ctx::Scope prof(ctx, SS_PROF_TRACE);
+    HIP_TRY(launch_trace_cpu(ctx->stream, L, d_states, num_cycles, d_image, cells, fp_from_limbs64(pad_value), rc_fill, (Fp *)d_flags, (Fp *)d_pool,
+                             (Fp *)d_range_check, (Fp *)d_auxiliary, d_pool_addr, d_status));
+    return SS_OK;
+}
+ss_status ss_trace_builtin(ss_ctx *ctx, uint64_t *const *d_cols, uint32_t ncols, const ss_trace_cell *d_cells, uint32_t n_cells, const uint64_t *d_values,
+                           uint32_t n_templates, const uint32_t *d_template_of_block, uint64_t n_blocks, uint64_t block_rows, uint64_t addr_begin,
+                           uint64_t addr_per_block, uint32_t *d_pool_addr) {
+    if (!ctx || !d_cols || !d_cells || !d_values || !d_pool_addr) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!ncols || ncols > (uint32_t)MAX_COLS) return fail(SS_ERR_INVALID, "ncols out of range");
+    if (!n_templates || !block_rows) return fail(SS_ERR_INVALID, "no template / empty blocks");
+    if (n_blocks > (1ull << 32) || (double)n_blocks * n_cells > 1e12) return fail(SS_ERR_INVALID, "too many cells");
+    ColPtrs cp{};
+    for (uint32_t c = 0; c < ncols; ++c) { if (!d_cols[c]) return fail(SS_ERR_INVALID, "NULL column"); cp.dst[c] = d_cols[c]; }
+    static_assert(sizeof(ss_trace_cell) == sizeof(TraceTileEntry), "ss_trace_cell is TraceTileEntry");
+    ss_ctx::Scope prof(ctx, SS_PROF_TRACE);
+    HIP_TRY(launch_trace_tile(ctx->stream, cp, ncols, (const TraceTileEntry *)d_cells, n_cells, (const Fp *)d_values, n_templates, d_template_of_block, n_blocks,
+                              block_rows, addr_begin, addr_per_block, d_pool_addr));
+    return SS_OK;
+}
+namespace {
+bool rc_plan_ok(const ss_trace_rc_plan *p) {
+    return p && p->rc_lo <= p->rc_hi && p->rc_hi < 65536 && (p->ordered_step == 1 || p->ordered_step == 2 || p->ordered_step == 4 || p->ordered_step == 8 || p->ordered_step == 16) &&
+           p->ordered_off < p->ordered_step && p->unused_off < 16 && p->n_given <= p->n_slots && p->n_padding <= 65536 &&
+           (!p->n_slots || (p->part_off + 7ull * p->part_stride < p->slot_rows && p->pair_off + 1ull < p->slot_rows));
+}
+}  // namespace
+ss_status ss_trace_rc_pool(ss_ctx *ctx, const ss_trace_rc_plan *plan, const uint32_t *d_first, const uint16_t *d_padding, uint64_t num_cycles,
+                           uint64_t *d_range_check) {
+    if (!ctx || !d_first || !d_range_check || (plan && plan->n_padding && !d_padding)) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!rc_plan_ok(plan)) return fail(SS_ERR_INVALID, "bad range-check plan");
+    if (!num_cycles || num_cycles > (1ull << 28)) return fail(SS_ERR_INVALID, "num_cycles out of range");
+    ss_ctx::Scope prof(ctx, SS_PROF_TRACE);
+    HIP_TRY(launch_trace_rc_pool(ctx->stream, rc_plan_of(plan), d_first, d_padding, num_cycles, (Fp *)d_range_check));
+    return SS_OK;
+}
+ss_status ss_trace_rc_builtin(ss_ctx *ctx, const ss_trace_rc_plan *plan, const uint64_t *d_given, const uint16_t *d_padding, uint64_t *d_range_check,
+                              uint64_t *d_pool, uint32_t *d_pool_addr) {
+    if (!ctx || !d_range_check || !d_pool || !d_pool_addr || (plan && plan->n_given && !d_given) || (plan && plan->n_padding && !d_padding))
+        return fail(SS_ERR_INVALID, "NULL argument");
+    if (!rc_plan_ok(plan)) return fail(SS_ERR_INVALID, "bad range-check plan");
+    ss_ctx::Scope prof(ctx, SS_PROF_TRACE);
+    HIP_TRY(launch_trace_rc_builtin(ctx->stream, rc_plan_of(plan), d_given, d_padding, (Fp *)d_range_check, (Fp *)d_pool, d_pool_addr));
+    return SS_OK;
+}
+ss_status ss_trace_ordered_runs(ss_ctx *ctx, uint64_t *d_col, uint64_t stride, uint64_t offset, uint64_t slots, const uint32_t *d_first,
+                                uint32_t n_values, uint32_t lo, int diluted) {
+    if (!ctx || !d_col || !d_first) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!stride || offset >= stride || !n_values || (uint64_t)lo + n_values > (1ull << 32)) return fail(SS_ERR_INVALID, "bad stride / offset / value range");
+    if (diluted && (uint64_t)lo + n_values > 65536) return fail(SS_ERR_INVALID, "diluted values have 16 bits");
+    ss_ctx::Scope prof(ctx, SS_PROF_TRACE);
+    HIP_TRY(launch_trace_runs(ctx->stream, (Fp *)d_col, stride, offset, slots, d_first, n_values, lo, diluted != 0));
+    return SS_OK;
+}
+ss_status ss_trace_patch(ss_ctx *ctx, uint64_t *d_col, uint64_t col_rows, const uint64_t *d_rows, const uint64_t *d_values, uint64_t count) {
+    if (!ctx || !d_col || (count && (!d_rows || !d_values))) return fail(SS_ERR_INVALID, "NULL argument");
+    ss_ctx::Scope prof(ctx, SS_PROF_TRACE);
+    HIP_TRY(launch_trace_patch(ctx->stream, (Fp *)d_col, col_rows, d_rows, d_values, count));
+    return SS_OK;
+}
+ss_status ss_trace_ordered_memory(ss_ctx *ctx, uint64_t n, uint64_t *d_pool, uint64_t *d_memory, uint32_t *d_pool_addr, const uint32_t *d_public_addr,
+                                  const uint64_t *d_public_value, uint32_t n_public, uint64_t public_cells, const uint64_t pad_value[4],
+                                  uint32_t unused_off, uint32_t *d_status) {
+    if (!ctx || !d_pool || !d_memory || !d_pool_addr || !pad_value || !d_status || (n_public && (!d_public_addr || !d_public_value)))
+        return fail(SS_ERR_INVALID, "NULL argument");
+    if (n < 16 || (n & (n - 1)) || n > (1ull << 32)) return fail(SS_ERR_INVALID, "n must be a power of two in [16, 2^32]");
+    if (unused_off >= 16 || (unused_off & 1)) return fail(SS_ERR_INVALID, "the unused pair starts at an even row of a cycle");
+    if (n_public > public_cells) return fail(SS_ERR_INVALID, "public memory does not fit its cells");
+    ss_status st = ctx->ensure_scratch(trace_memory_scratch_words(n / 2) * sizeof(uint32_t));
+    if (st != SS_OK) return st;
+    TraceMemoryArgs m;
+    m.n = n; m.npc = (Fp *)d_pool; m.memory = (Fp *)d_memory; m.d_pool_addr = d_pool_addr; m.d_public_addr = d_public_addr;
+    m.d_public_value = (const Fp *)d_public_value; m.n_public = n_public; m.public_cells = public_cells; m.pad_value = fp_from_limbs64(pad_value);
+    m.unused_off = unused_off; m.d_status = d_status;
+    ss_ctx::Scope prof(ctx, SS_PROF_TRACE);
+    HIP_TRY(launch_trace_ordered_memory(ctx->stream, m, (uint32_t *)ctx->scratch));
+    return SS_OK;
+}
+ss_status ss_trace_status(ss_ctx *ctx, const uint32_t *d_status, uint32_t *status_out) {
+    if (!ctx || !d_status || !status_out) return fail(SS_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(status_out, d_status, SS_TRACE_STATUS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SS_OK;
 }
 

@@ -125,6 +125,50 @@ hipError_t launch_permutation_product(hipStream_t st, const PermOperand &num, co
 hipError_t launch_diluted_aggregate(hipStream_t st, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z,
                                     const Fp &alpha, Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch);
 
+// ---- trace.hip (the base trace on the device; ss_trace_* of the C ABI)
+// where the CPU's cells sit in a cycle's 16 rows (= ss_trace_layout): the memory pool's 8 (address, value) pairs, the range-check
+// column's and the auxiliary column's 16 cells
+struct TraceLayout { uint8_t npc_pair[8], rc_cell[16], aux_cell[16]; };
+enum { TRACE_NPC_PAD = 0, TRACE_NPC_PUBLIC = 1, TRACE_NPC_PC = 2, TRACE_NPC_OP0 = 3, TRACE_NPC_DST = 4, TRACE_NPC_OP1 = 5 };
+enum { TRACE_RC_FILL = 0, TRACE_RC_ZERO = 1, TRACE_RC_OFF_DST = 2, TRACE_RC_OFF_OP0 = 3, TRACE_RC_OFF_OP1 = 4 };
+enum { TRACE_AUX_ZERO = 0, TRACE_AUX_AP = 1, TRACE_AUX_FP = 2, TRACE_AUX_TMP0 = 3, TRACE_AUX_TMP1 = 4, TRACE_AUX_MUL = 5, TRACE_AUX_RES = 6 };
+struct TraceTileEntry { uint32_t col, off, kind, arg; };          // = ss_trace_cell
+enum { TRACE_TILE_VALUE = 0, TRACE_TILE_ADDRESS = 1 };
+struct TraceRcPlan {                                               // = ss_trace_rc_plan
+    uint64_t n_slots, n_given, slot_rows, addr_begin, n_padding, pad0;
+    uint32_t part_stride, part_off, pair_off, rc_lo, rc_hi, ordered_step, ordered_off, unused_off;
+};
+struct TraceMemoryArgs {
+    uint64_t n;                       // trace rows
+    Fp *npc, *memory;                 // the memory pool's column, the ordered column
+    uint32_t *d_pool_addr;            // n / 2: the pool's addresses as integers
+    const uint32_t *d_public_addr;    // the public memory's entries: addresses, Montgomery values
+    const Fp *d_public_value;
+    uint32_t n_public;
+    uint64_t public_cells;            // the pool's address-0 pairs (n / PUBLIC_MEMORY_STEP)
+    Fp pad_value;                     // the value at address 1
+    uint32_t unused_off;              // row offset of a cycle's unused pool pair (Npc::UnusedAddr)
+    uint32_t *d_status;
+};
+// the status words of a generation (u32, zeroed by the caller before the first kernel)
+enum { TRACE_ST_ERRORS = 0, TRACE_ST_WHERE = 1, TRACE_ST_ZEROS = 2, TRACE_ST_ONES = 3, TRACE_ST_TOP = 4, TRACE_ST_NLOW = 5, TRACE_ST_GAPS = 6, TRACE_ST_WORDS = 16 };
+enum { TRACE_ERR_MISSING_CELL = 1, TRACE_ERR_NOT_INSTRUCTION = 2, TRACE_ERR_BAD_OP1_SOURCE = 4, TRACE_ERR_BAD_RES_LOGIC = 8, TRACE_ERR_NOT_AN_ADDRESS = 16,
+       TRACE_ERR_ADDRESS_RANGE = 32, TRACE_ERR_PUBLIC_ZERO = 64, TRACE_ERR_PUBLIC_CELLS = 128, TRACE_ERR_NO_ONES = 256, TRACE_ERR_NOT_SINGLE_VALUED = 512,
+       TRACE_ERR_NOT_CONTINUOUS = 1024, TRACE_ERR_TOO_MANY_GAPS = 2048, TRACE_ERR_FILL = 4096 };
+hipError_t launch_trace_memory_image(hipStream_t st, const uint64_t *d_records, uint64_t n_records, uint64_t *d_image, uint64_t cells);
+hipError_t launch_trace_cpu(hipStream_t st, const TraceLayout &L, const uint64_t *d_states, uint64_t num_cycles, const uint64_t *d_image, uint64_t cells,
+                            const Fp &pad_value, uint64_t rc_fill, Fp *flags, Fp *npc, Fp *rc, Fp *aux, uint32_t *d_pool_addr, uint32_t *d_status);
+hipError_t launch_trace_tile(hipStream_t st, const ColPtrs &cols, uint32_t ncols, const TraceTileEntry *d_entries, uint32_t n_entries, const Fp *d_values,
+                             uint32_t n_templates, const uint32_t *d_tmpl_of_block, uint64_t nblocks, uint64_t step, uint64_t addr_begin, uint64_t addr_mult,
+                             uint32_t *d_pool_addr);
+hipError_t launch_trace_rc_builtin(hipStream_t st, const TraceRcPlan &p, const uint64_t *d_given, const uint16_t *d_padding, Fp *rc, Fp *npc, uint32_t *d_pool_addr);
+hipError_t launch_trace_rc_pool(hipStream_t st, const TraceRcPlan &p, const uint32_t *d_first, const uint16_t *d_padding, uint64_t num_cycles, Fp *rc);
+hipError_t launch_trace_runs(hipStream_t st, Fp *col, uint64_t stride, uint64_t off, uint64_t slots, const uint32_t *d_first, uint32_t n_values, uint32_t lo,
+                             bool diluted);
+hipError_t launch_trace_patch(hipStream_t st, Fp *col, uint64_t col_rows, const uint64_t *d_rows, const uint64_t *d_values, uint64_t count);
+uint64_t trace_memory_scratch_words(uint64_t half);
+hipError_t launch_trace_ordered_memory(hipStream_t st, const TraceMemoryArgs &m, uint32_t *scratch);
+
 // ---- goldilocks.hip (the 64-bit field variant)
 uint64_t gl_pow_host(uint64_t a, uint64_t e);
 uint64_t gl_root_of_unity_host(uint32_t log_n);

@@ -357,6 +357,7 @@ struct TraceJob {
     uint64_t n = 0;
     std::vector<uint32_t> order;                 // the order the columns become final in (the generators' column_done calls)
     std::function<void(Felt *const *out, const std::function<void(int)> *done)> run;
+    std::function<void(ss_ctx *ctx, uint64_t *const *d_cols)> run_device;        // the same columns made in HBM (device_trace.hpp)
 };
 TraceJob make_trace_job(int layout, const uint8_t *trace_bin, uint64_t trace_len, const uint8_t *memory_bin, uint64_t memory_len, uint32_t rc_min,
                         uint32_t rc_max, uint64_t n_steps, const uint32_t *segments, const uint32_t *mem_addresses, const uint64_t *mem_values,
@@ -391,6 +392,11 @@ TraceJob make_trace_job(int layout, const uint8_t *trace_bin, uint64_t trace_len
             rp.pedersen = priv->pedersen; rp.range_check = priv->range_check; rp.bitwise = priv->bitwise;
             recursive_base_trace_into(out, states, *memory, *present, *pi, rp, done);
         };
+        job.run_device = [=](ss_ctx *ctx, uint64_t *const *d_cols) {
+            PrivateInput rp;
+            rp.pedersen = priv->pedersen; rp.range_check = priv->range_check; rp.bitwise = priv->bitwise;
+            recursive_base_trace_device(ctx, d_cols, trace_bin, trace_len, memory_bin, memory_len, *memory, *present, *pi, rp);
+        };
     } else {
         job.ncols = 9;
         job.order = {0, 1, 2, 3, 4, 7, 8, 5, 6};  // flags, the four Pedersen columns, range check, auxiliary, memory pool, sorted memory
@@ -398,6 +404,9 @@ TraceJob make_trace_job(int layout, const uint8_t *trace_bin, uint64_t trace_len
             Felt *o[9];
             for (int c = 0; c < 9; ++c) o[c] = out[c];
             starknet_base_trace_into(o, states, *memory, *present, *pi, *priv, done);
+        };
+        job.run_device = [=](ss_ctx *ctx, uint64_t *const *d_cols) {
+            starknet_base_trace_device(ctx, d_cols, trace_bin, trace_len, memory_bin, memory_len, *memory, *present, *pi, *priv);
         };
     }
     return job;
@@ -417,6 +426,22 @@ int ssh_base_trace_cb(int layout, const uint8_t *trace_bin, uint64_t trace_len, 
         if (order_out) for (uint32_t k = 0; k < job.ncols; ++k) order_out[k] = job.order[k];
         const std::function<void(int)> done = [&](int c) { if (column_done) column_done(user, c); };
         job.run(reinterpret_cast<Felt *const *>(columns_out), &done);
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// the base columns made ON the device from the raw files (csrc/trace.hip; host/device_trace.hpp): d_cols = 7 / 9 device columns of
+// 16 * cycles felts (ss_dev_alloc'd or the caller's own device memory).  Returns when the columns are final (the input's errors -
+// a cell memory.bin does not hold, memory that is not continuous, ... - are the host generator's refusals).
+int ssh_base_trace_device(ss_ctx *ctx, int layout, const uint8_t *trace_bin, uint64_t trace_len, const uint8_t *memory_bin, uint64_t memory_len, uint32_t rc_min,
+                          uint32_t rc_max, uint64_t n_steps, const uint32_t *segments, const uint32_t *mem_addresses, const uint64_t *mem_values, uint64_t n_mem,
+                          const uint64_t *const *instances, const uint64_t *counts, uint64_t *const *d_cols) {
+    try {
+        if (!ctx || !d_cols) throw std::runtime_error("ssh_base_trace_device: NULL argument");
+        const TraceJob job = make_trace_job(layout, trace_bin, trace_len, memory_bin, memory_len, rc_min, rc_max, n_steps, segments, mem_addresses, mem_values,
+                                            n_mem, instances, counts);
+        for (uint32_t c = 0; c < job.ncols; ++c) if (!d_cols[c]) throw std::runtime_error("ssh_base_trace_device: NULL column");
+        job.run_device(ctx, d_cols);
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }
@@ -496,6 +521,61 @@ int ssh_prove_files(ss_ctx *ctx, int layout, const uint8_t *trace_bin, uint64_t 
             return ext;
         });
         producer.join();
+        if (ss_ctx_sync(ctx) != SS_OK) throw std::runtime_error(ss_last_error());
+        if (times_out) { times_out[0] = gen_s; times_out[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); }
+        if (proof_bytes && proof_len) {
+            const std::vector<uint8_t> b = proof.serialize_wire();
+            *proof_bytes = (uint8_t *)malloc(b.size());
+            memcpy(*proof_bytes, b.data(), b.size());
+            *proof_len = b.size();
+        }
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+
+// files -> proof with the base trace made ON the device: trace.bin / memory.bin go up as they are (25 MB where the host-made columns
+// are 3.6 - 4.8 GB of PCIe traffic), csrc/trace.hip makes the columns in d_cols, and the prover goes on as ssh_prove_wire does - what
+// the reference's "Proof generated in" timer wraps (cli/src/main.rs:200-202: generate_trace + prove).  times_out (optional, 2
+// doubles): until the columns were final (the device's generation, waited for: the input's errors are reported before anything is
+// proven), and the whole call.  The proof is the one ssh_prove_files / ssh_prove_wire write for the same statement.
+int ssh_prove_files_device(ss_ctx *ctx, int layout, const uint8_t *trace_bin, uint64_t trace_len, const uint8_t *memory_bin, uint64_t memory_len, uint32_t rc_min,
+                           uint32_t rc_max, uint64_t n_steps, const uint32_t *segments, const uint32_t *mem_addresses, const uint64_t *mem_values, uint64_t n_mem,
+                           const uint64_t *const *instances, const uint64_t *counts, uint64_t *const *d_cols, ssh_air *air_h, int tree_kind,
+                           uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32], ssh_extension_cb cb, void *user, const uint32_t options[5],
+                           double *times_out, uint8_t **proof_bytes, uint64_t *proof_len) {
+    try {
+        if (!ctx || !air_h || !seed || !d_cols) throw std::runtime_error("ssh_prove_files_device: NULL argument");
+        const auto t_start = std::chrono::steady_clock::now();
+        const TraceJob job = make_trace_job(layout, trace_bin, trace_len, memory_bin, memory_len, rc_min, rc_max, n_steps, segments, mem_addresses, mem_values,
+                                            n_mem, instances, counts);
+        Air *air = reinterpret_cast<Air *>(air_h);
+        if (air->num_base_columns != job.ncols) throw std::runtime_error("ssh_prove_files_device: the AIR is another layout's");
+        for (uint32_t c = 0; c < job.ncols; ++c) if (!d_cols[c]) throw std::runtime_error("ssh_prove_files_device: NULL column");
+        job.run_device(ctx, d_cols);
+        const double gen_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        Claim claim;
+        claim.air = air; claim.tree_kind = tree_kind; claim.n_friendly_layers = n_friendly_layers; claim.coin_kind = coin_kind;
+        ProofOptions opt;
+        if (options) {
+            opt.num_queries = options[0]; opt.lde_blowup_factor = options[1]; opt.grinding_factor = options[2];
+            opt.fri_folding_factor = options[3]; opt.fri_max_remainder_coeffs = options[4];
+        }
+        Matrix base;
+        base.nrows = job.n;
+        for (uint32_t c = 0; c < job.ncols; ++c) base.cols.push_back(d_cols[c]);
+        Digest sd;
+        memcpy(sd.data(), seed, 32);
+        Prover prover(ctx, claim, opt);
+        Proof proof = prover.prove(sd, base, [&](const std::vector<Felt> &ch) {
+            Matrix ext;
+            ext.nrows = base.nrows;
+            std::vector<uint64_t> flat(4 * ch.size());
+            for (size_t i = 0; i < ch.size(); ++i) memcpy(flat.data() + 4 * i, ch[i].data(), 32);
+            std::vector<uint64_t *> cols(air->num_extension_columns, nullptr);
+            if (!cb || cb(user, flat.data(), (uint32_t)ch.size(), cols.data()) != 0) throw std::runtime_error("extension callback failed");
+            ext.cols = cols;
+            return ext;
+        });
         if (ss_ctx_sync(ctx) != SS_OK) throw std::runtime_error(ss_last_error());
         if (times_out) { times_out[0] = gen_s; times_out[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); }
         if (proof_bytes && proof_len) {

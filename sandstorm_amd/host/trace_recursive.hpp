@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "public_input.hpp"
+#include "../../include/sandstorm_hip.h"
 
 namespace ssh {
 
@@ -55,5 +56,12 @@ std::vector<std::vector<Felt>> recursive_base_trace(const RegisterStates &states
 void recursive_base_trace_into(Felt *const out[7], const RegisterStates &states, const std::vector<U256> &memory,
                                const std::vector<uint8_t> &present, const AirPublicInput &pi, const PrivateInput &priv,
                                const std::function<void(int)> *column_done = nullptr);
+
+// the same 7 columns made in HBM by the device (csrc/trace.hip through the ss_trace_* entry points; host/device_trace.hpp): the raw
+// files' bytes go up as they are, the host only counts the range-check pool and traces the DISTINCT builtin instances.
+// memory / present: memory.bin as read_memory gives it (the plans read it).
+void recursive_base_trace_device(ss_ctx *ctx, uint64_t *const d_cols[7], const uint8_t *trace_bin, uint64_t trace_len, const uint8_t *memory_bin,
+                                 uint64_t memory_len, const std::vector<U256> &memory, const std::vector<uint8_t> &present, const AirPublicInput &pi,
+                                 const PrivateInput &priv);
 
 }  // namespace ssh

@@ -16,6 +16,7 @@
 
 #include "../../include/sandstorm_hip.h"
 #include "trace_common.hpp"
+#include "device_trace.hpp"
 
 namespace ssh {
 
@@ -306,446 +307,462 @@ PoseidonTrace poseidon_trace(const std::array<Felt, 3> &input) {       // poseid
     return t;
 }
 
+// an EC-op instance's trace (ec_op::InstanceTrace::new, ec_op/mod.rs:40-130)
+struct EcOpTrace { Pt p, q, r; Felt m; std::vector<Doubling> q_doubling; std::vector<MadStep> r_steps; bool b251_196, b251_196_192; };
+using U256x2 = std::pair<U256, U256>;
+using U256x3 = std::tuple<U256, U256, U256>;
+using U256x4 = std::tuple<U256, U256, U256, U256>;
+using U256x5 = std::tuple<U256, U256, U256, U256, U256>;
+
+// the dummy signature (a constant: ecdsa/mod.rs gen_dummy_instance) and its trace - three scalar multiplications with their doubling
+// chains, ~0.15 s - are made once per process
+struct EcdsaDummy { U256x4 key; std::shared_ptr<const EcdsaTrace> trace; };
+const EcdsaDummy &ecdsa_dummy() {
+    static const EcdsaDummy d = [] {
+        U256 v[4];
+        ecdsa_dummy_instance(v[0], v[1], v[2], v[3]);
+        return EcdsaDummy{U256x4{v[0], v[1], v[2], v[3]}, std::make_shared<const EcdsaTrace>(ecdsa_trace(v[0], v[1], v[2], v[3]))};
+    }();
+    return d;
+}
+
+const ss_trace_layout &cpu_layout() {                     // the CPU's cells in a cycle's 16 rows (starknet air.rs:2538-3250: Npc, RangeCheck, Auxiliary)
+    static const ss_trace_layout l = [] {
+        ss_trace_layout v;
+        for (int j = 0; j < 8; ++j) v.npc_pair[j] = SS_TRACE_NPC_PAD;
+        v.npc_pair[NPC_PC / 2] = SS_TRACE_NPC_PC; v.npc_pair[NPC_MEM_OP0_ADDR / 2] = SS_TRACE_NPC_OP0; v.npc_pair[NPC_MEM_DST_ADDR / 2] = SS_TRACE_NPC_DST;
+        v.npc_pair[NPC_MEM_OP1_ADDR / 2] = SS_TRACE_NPC_OP1;
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += PUBLIC_MEMORY_STEP) v.npc_pair[(o + NPC_PUB_MEM_ADDR) / 2] = SS_TRACE_NPC_PUBLIC;
+        for (int o = 0; o < 16; ++o) { v.rc_cell[o] = SS_TRACE_RC_FILL; v.aux_cell[o] = SS_TRACE_AUX_ZERO; }
+        v.rc_cell[RC_OFF_DST] = SS_TRACE_RC_OFF_DST; v.rc_cell[RC_OFF_OP1] = SS_TRACE_RC_OFF_OP1; v.rc_cell[RC_OFF_OP0] = SS_TRACE_RC_OFF_OP0;
+        for (uint64_t o = 0; o < CYCLE_HEIGHT; o += DILUTED_CHECK_STEP) v.rc_cell[o + DC_UNORDERED] = v.rc_cell[o + DC_ORDERED] = SS_TRACE_RC_ZERO;      // trace.rs:294-302
+        v.aux_cell[AUX_AP] = SS_TRACE_AUX_AP; v.aux_cell[AUX_FP] = SS_TRACE_AUX_FP; v.aux_cell[AUX_TMP0] = SS_TRACE_AUX_TMP0; v.aux_cell[AUX_TMP1] = SS_TRACE_AUX_TMP1;
+        v.aux_cell[AUX_OP0_MUL_OP1] = SS_TRACE_AUX_OP0_MUL_OP1; v.aux_cell[AUX_RES] = SS_TRACE_AUX_RES;
+        return v;
+    }();
+    return l;
+}
+
+struct Inputs {
+    const RegisterStates &states;
+    const Mem &mem;
+    const AirPublicInput &pi;
+    const StarknetPrivateInput &priv;
+    uint64_t num_cycles, n;
+    Felt pad_value;
+};
+
+// ---- the host backend: the sections' cells straight into the caller's columns
+struct HostBackend {
+    const Inputs &in;
+    Felt *const *out;
+    const std::function<void(int)> *column_done;
+    AddrArray npc_addr;
+    std::chrono::steady_clock::time_point t_last = std::chrono::steady_clock::now();
+    const bool timing = getenv("SSH_TRACE_TIMING") != nullptr;               // stage times on stderr
+    HostBackend(const Inputs &in_, Felt *const *out_, const std::function<void(int)> *cd) : in(in_), out(out_), column_done(cd), npc_addr(in_.n / 2) {}
+    void lap(const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[starknet trace] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    }
+    void done(std::initializer_list<int> cs) { if (column_done && *column_done) for (int c : cs) (*column_done)(c); }
+    void set_pair(uint64_t row, uint64_t address, const Felt &value) { out[COL_NPC][row] = felt_from_u64(address); out[COL_NPC][row + 1] = value; npc_addr[row / 2] = address; }
+
+    // The CPU's cells (trace.rs:177-244) and the range-check pool's (trace.rs:165-235, 294-302).  The generator is bound by the host's
+    // memory traffic (4.8 GB of columns at 2^20 steps), so every column this section touches is written ONCE: a cycle's 16 rows of the
+    // flags, the memory pool, the range-check column and the auxiliary column are made in a block on the stack - padding first, then
+    // what the cycle puts there - and stored row after row.  Cells of these columns that a builtin owns get the padding here and their
+    // values in the builtin's section.
+    void cpu_section(const RcPoolPlan &pool, const std::vector<uint32_t> &rc_count, uint64_t rc_fill) {
+        const uint64_t num_cycles = in.num_cycles;
+        const RegisterStates &states = in.states;
+        const Mem &mem = in.mem;
+        Felt *const flags = out[COL_FLAGS], *const npc = out[COL_NPC], *const rc_col = out[COL_RANGE_CHECK], *const aux = out[COL_AUXILIARY];
+        const Felt zero = felt_from_u64(0), pad_addr = felt_from_u64(1), pad_value = in.pad_value, rc_max_f = felt_from_u64(rc_fill);
+        CountArray ordered_vals;
+        ordered_runs(rc_count, pool.lo, pool.hi, ordered_vals);
+        const uint64_t per = CYCLE_HEIGHT / RANGE_CHECK_STEP;
+        constexpr uint64_t JNZ_BLOCK = 512;                  // cycles whose conditional jumps share one inversion (JnzInverses)
+        parallel_for((num_cycles + JNZ_BLOCK - 1) / JNZ_BLOCK, [&](uint64_t block) {
+            const uint64_t first_cycle = block * JNZ_BLOCK, end_cycle = std::min(num_cycles, first_cycle + JNZ_BLOCK);
+            JnzInverses jnz(states, mem, first_cycle, end_cycle);
+            for (uint64_t cycle = first_cycle; cycle < end_cycle; ++cycle) {
+                const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
+                const U256 &iw = mem.at(pc);
+                const Word w{iw[0]};
+                if ((iw[1] | iw[2] | iw[3]) || w.flag(F_ZERO)) fail("memory cell " + std::to_string(pc) + " is not an instruction");
+                const uint64_t dst_addr = w.off_dst() + (w.flag(F_DST_REG) ? fp : ap) - HALF_OFFSET;
+                const uint64_t op0_addr = w.off_op0() + (w.flag(F_OP0_REG) ? fp : ap) - HALF_OFFSET;
+                const int src = w.op1_src();
+                if (src != 0 && src != 1 && src != 2 && src != 4) fail("invalid op1 source");
+                const uint64_t base = src == 0 ? mem.small(op0_addr) : src == 1 ? pc : src == 2 ? fp : ap;
+                const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
+                const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
+                Felt res;
+                if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : jnz.take(dst);
+                else if (w.res_logic() == 0) res = op1;
+                else if (w.res_logic() == 1) res = felt_add(op0, op1);
+                else if (w.res_logic() == 2) res = felt_mul(op0, op1);
+                else fail("invalid res logic");
+                const Felt tmp0 = w.flag(F_PC_JNZ) ? dst : zero;
+                Felt blk[CYCLE_HEIGHT];
+                // flags
+                for (int f = 0; f < 16; ++f) flags[r + f] = felt_from_u64(w.flag_prefix(f));
+                // memory pool: (address, value) pairs, the padding pair where the CPU has none (a builtin's pair comes with its section)
+                for (uint64_t o = 0; o < CYCLE_HEIGHT; o += 2) { blk[o] = pad_addr; blk[o + 1] = pad_value; npc_addr[(r + o) / 2] = 1; }
+                auto pair = [&](uint64_t o, uint64_t address, const Felt &value) { blk[o] = felt_from_u64(address); blk[o + 1] = value; npc_addr[(r + o) / 2] = address; };
+                pair(NPC_PC, pc, felt_from_canonical(iw));
+                pair(NPC_MEM_OP0_ADDR, op0_addr, op0);
+                pair(NPC_MEM_DST_ADDR, dst_addr, dst);
+                pair(NPC_MEM_OP1_ADDR, op1_addr, op1);
+                for (uint64_t o = 0; o < CYCLE_HEIGHT; o += PUBLIC_MEMORY_STEP) pair(o + NPC_PUB_MEM_ADDR, 0, zero);
+                for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) npc[r + o] = blk[o];
+                // auxiliary column: zero where no section writes
+                for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = zero;
+                blk[AUX_TMP0] = tmp0; blk[AUX_TMP1] = felt_mul(tmp0, res);
+                blk[AUX_AP] = felt_from_u64(ap); blk[AUX_FP] = felt_from_u64(fp);
+                blk[AUX_OP0_MUL_OP1] = felt_mul(op0, op1); blk[AUX_RES] = res;
+                for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) aux[r + o] = blk[o];
+                // range-check column: the padding value, the instruction's offsets, the odd cycles' next padding value, the cycle's ordered
+                // values, zeros where the diluted check's cells are
+                for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = rc_max_f;
+                blk[RC_OFF_DST] = felt_from_u64(w.off_dst()); blk[RC_OFF_OP1] = felt_from_u64(w.off_op1()); blk[RC_OFF_OP0] = felt_from_u64(w.off_op0());
+                if (cycle % 2 == 1) blk[RC_UNUSED] = felt_from_u64(pool.pad(pool.pad0 + cycle / 2));
+                for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP) {
+                    const uint64_t at = cycle * per + o / RANGE_CHECK_STEP;
+                    blk[o + RC_ORDERED] = felt_from_u64(at < ordered_vals.size() ? ordered_vals[at] : pool.hi);
+                }
+                for (uint64_t o = 0; o < CYCLE_HEIGHT; o += DILUTED_CHECK_STEP) blk[o + DC_UNORDERED] = blk[o + DC_ORDERED] = zero;      // trace.rs:294-302
+                for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) rc_col[r + o] = blk[o];
+            }
+        });
+        lap("cpu cells + range-check pool");
+        done({COL_FLAGS});
+    }
+    // a builtin's blocks: block i holds template of_block[i]
+    template <class Place> void builtin(const char *what, const std::vector<uint32_t> &of_block, uint32_t, uint64_t step, uint64_t begin, uint64_t per_block, const Place &place) {
+        parallel_for(of_block.size(), [&](uint64_t i) {
+            HostSink sink{out, &npc_addr, COL_NPC, i * step, begin + per_block * i};
+            place(sink, of_block[i]);
+        });
+        lap(what);
+    }
+    // the range-check builtin's slots (trace.rs:388-426): the given instances, then dummies made of the pool's padding values
+    void rc_builtin(const ss_trace_rc_plan &plan, const RcPoolPlan &pool, const std::vector<uint64_t> &given3) {
+        Felt *const rc_col = out[COL_RANGE_CHECK];
+        parallel_for(plan.n_slots, [&](uint64_t s) {
+            uint64_t lo = 0, hi = 0, index = s;
+            if (s < plan.n_given) { index = given3[3 * s]; lo = given3[3 * s + 1]; hi = given3[3 * s + 2]; }
+            else for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) { hi = (hi << 16) | (lo >> 48); lo = (lo << 16) | pool.pad(8 * (s - plan.n_given) + k); }
+            const uint64_t base = s * plan.slot_rows;
+            for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) {
+                const unsigned sh = 16 * (RANGE_CHECK_BUILTIN_PARTS - 1 - k);
+                rc_col[base + plan.part_stride * k + plan.part_off] = felt_from_u64((sh >= 64 ? hi >> (sh - 64) : lo >> sh) & 0xffff);
+            }
+            set_pair(base + plan.pair_off, plan.addr_begin + index, felt_from_canonical(U256{lo, hi, 0, 0}));
+        });
+        lap("range-check builtin");
+    }
+    void diluted(const DilutedPlan &dp, const std::vector<uint64_t> &pad_rows, const std::vector<uint64_t> &pad_values, uint64_t slots) {
+        Felt *const rc_col = out[COL_RANGE_CHECK];
+        for (size_t k = 0; k < pad_rows.size(); ++k) rc_col[pad_rows[k]] = felt_from_u64(pad_values[k]);
+        parallel_for(1u << DILUTED_N_BITS, [&](uint64_t v) {                // the short runs value by value
+            if (dp.first[v + 1] - dp.first[v] >= 4096) return;
+            const Felt f = felt_from_u64(dilute((uint32_t)v));
+            for (uint64_t k = dp.first[v]; k < dp.first[v + 1]; ++k) rc_col[DILUTED_CHECK_STEP * k + DC_ORDERED] = f;
+        });
+        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)                 // the long ones (value 0 of the dummy instances) by all threads
+            if (dp.first[v + 1] - dp.first[v] >= 4096) {
+                const Felt f = felt_from_u64(dilute(v));
+                const uint64_t k0 = dp.first[v];
+                parallel_for(dp.first[v + 1] - k0, [&](uint64_t j) { rc_col[DILUTED_CHECK_STEP * (k0 + j) + DC_ORDERED] = f; });
+            }
+        (void)slots;
+        lap("diluted pool");
+    }
+    // gap fillers (trace.rs:890-925) and the ordered memory (get_ordered_memory_accesses, utils.rs:112-152)
+    void memory() {
+        done({COL_RANGE_CHECK, COL_AUXILIARY});
+        const std::vector<uint64_t> gaps = memory_gaps(npc_addr, in.pi.public_memory, in.num_cycles);
+        if (gaps.size() > in.num_cycles) fail("more memory gaps than cycles to hold them");
+        for (size_t k = 0; k < gaps.size(); ++k) set_pair(k * CYCLE_HEIGHT + NPC_UNUSED_ADDR, gaps[k], felt_from_u64(0));
+        lap("gap fillers");
+        done({COL_NPC});
+        ordered_memory_into(out[COL_MEMORY], in.n, npc_addr, out[COL_NPC], in.n / PUBLIC_MEMORY_STEP, in.pi.public_memory, in.pad_value);
+        lap("sorted memory");
+        done({COL_MEMORY});
+    }
+    void pedersen_done() { done({COL_PEDERSEN_X, COL_PEDERSEN_Y, COL_PEDERSEN_SUFFIX, COL_PEDERSEN_SLOPE}); }
+};
+
+// ---- the device backend: the same sections as uploads of plans / templates and kernel launches (device_trace.hpp, csrc/trace.hip)
+struct DeviceBackend {
+    const Inputs &in;
+    DeviceTrace &dt;
+    void cpu_section(const RcPoolPlan &pool, const std::vector<uint32_t> &rc_count, uint64_t rc_fill) {
+        dt.cpu_cells(cpu_layout(), COL_FLAGS, COL_NPC, COL_RANGE_CHECK, COL_AUXILIARY, in.pad_value, rc_fill);
+        ss_trace_rc_plan plan{};
+        plan.ordered_step = RANGE_CHECK_STEP; plan.ordered_off = RC_ORDERED; plan.unused_off = RC_UNUSED;
+        dt.rc_pool(plan, pool, rc_count, COL_RANGE_CHECK);
+    }
+    template <class Place> void builtin(const char *, const std::vector<uint32_t> &of_block, uint32_t n_templates, uint64_t step, uint64_t begin, uint64_t per_block,
+                                        const Place &place) {
+        dt.builtin(n_templates, of_block, step, begin, per_block, place);
+    }
+    void rc_builtin(const ss_trace_rc_plan &plan, const RcPoolPlan &, const std::vector<uint64_t> &given3) { dt.rc_builtin(plan, given3, COL_RANGE_CHECK); }
+    void diluted(const DilutedPlan &dp, const std::vector<uint64_t> &pad_rows, const std::vector<uint64_t> &pad_values, uint64_t slots) {
+        dt.patch(COL_RANGE_CHECK, pad_rows, pad_values);
+        dt.ordered_runs(COL_RANGE_CHECK, DILUTED_CHECK_STEP, DC_ORDERED, slots, dp.first, 0, true);
+    }
+    void memory() { dt.ordered_memory(COL_MEMORY, in.pi.public_memory, in.n / PUBLIC_MEMORY_STEP, in.pad_value, NPC_UNUSED_ADDR); }
+    void pedersen_done() {}
+};
+
+// ExecutionTrace::new (layouts/src/starknet/trace.rs:99-987) section by section, for either backend: where a builtin's cells go is
+// said ONCE (the `place` lambdas), the host stores them per block, the device per distinct instance
+template <class Backend> void generate(Backend &be, const Inputs &in) {
+    const uint64_t num_cycles = in.num_cycles, n = in.n;
+    const AirPublicInput &pi = in.pi;
+    const StarknetPrivateInput &priv = in.priv;
+    // ---- the range-check pool (trace.rs:142-165): the offsets of every instruction and the builtin's parts counted first
+    std::vector<uint32_t> rc_count(1 << 16, 0);
+    {
+        std::vector<std::vector<uint32_t>> rc_count_of((size_t)omp_get_max_threads());
+        parallel_for(num_cycles, [&](uint64_t cycle) {
+            std::vector<uint32_t> &my_count = rc_count_of[(size_t)omp_get_thread_num()];
+            if (my_count.empty()) my_count.assign(1 << 16, 0);
+            const Word w{in.mem.at(in.states[cycle].pc)[0]};
+            for (uint64_t v : {w.off_dst(), w.off_op0(), w.off_op1()}) ++my_count[v];
+        });
+        for (auto &part : rc_count_of) for (size_t v = 0; v < part.size(); ++v) rc_count[v] += part[v];
+    }
+    ss_trace_rc_plan rc_plan{};
+    rc_plan.n_slots = num_cycles / RANGE_CHECK_BUILTIN_RATIO; rc_plan.n_given = priv.range_check.size(); rc_plan.slot_rows = RANGE_CHECK_BUILTIN_RATIO * CYCLE_HEIGHT;
+    rc_plan.addr_begin = pi.segments[4].begin_addr; rc_plan.part_stride = 32; rc_plan.part_off = RC16_COMPONENT; rc_plan.pair_off = NPC_RANGE_CHECK128_ADDR;
+    rc_plan.ordered_step = RANGE_CHECK_STEP; rc_plan.ordered_off = RC_ORDERED; rc_plan.unused_off = RC_UNUSED;
+    if (rc_plan.n_given > rc_plan.n_slots) fail("more range-check instances than the trace has slots for");
+    std::vector<uint64_t> rc_given;                       // index, value low, value high
+    for (auto &inst : priv.range_check) {
+        if (inst.value[2] | inst.value[3]) fail("range-check value does not fit 128 bits");
+        rc_given.insert(rc_given.end(), {(uint64_t)inst.index, inst.value[0], inst.value[1]});
+        for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) ++rc_count[(uint32_t)(shr(inst.value, 16 * (RANGE_CHECK_BUILTIN_PARTS - 1 - k))[0] & 0xffff)];
+    }
+    RcPoolPlan pool;
+    pool.from_counts(rc_count, rc_plan.n_slots - rc_plan.n_given);          // the dummy instances take the first padding values (trace.rs:246-261)
+    // the odd cycles take the next padding values in order, every cycle its CYCLE_HEIGHT / RANGE_CHECK_STEP ordered values
+    if (pool.pad0 + num_cycles / 2 < pool.padding.size() || num_cycles * (CYCLE_HEIGHT / RANGE_CHECK_STEP) < pool.total) fail("range-check values do not fit the trace");
+    rc_plan.rc_lo = pool.lo; rc_plan.rc_hi = pool.hi; rc_plan.n_padding = pool.padding.size(); rc_plan.pad0 = pool.pad0;
+    be.cpu_section(pool, rc_count, pool.hi);
+
+    // ---- Pedersen (trace.rs:304-386)
+    {
+        const uint64_t step = PEDERSEN_BUILTIN_RATIO * CYCLE_HEIGHT;
+        const auto given = instances_by_index(priv.pedersen, n / step, "pedersen");
+        Instances<U256x2, PedersenTrace> inst;
+        inst.assign(n / step, [&](uint64_t i) { auto it = given.find((uint32_t)i); return it != given.end() ? U256x2{it->second->a, it->second->b} : U256x2{}; });
+        inst.trace_all([](const U256x2 &k) { return pedersen_instance_trace(k.first, k.second); });
+        be.builtin("pedersen", inst.of_block, (uint32_t)inst.keys.size(), step, pi.segments[3].begin_addr, 3, [&](auto &s, uint32_t t) {
+            const PedersenTrace &c = *inst.traces[t];
+            for (uint64_t j = 0; j < 512; ++j) {
+                s.cell(COL_PEDERSEN_X, j, c.steps[j].point.x); s.cell(COL_PEDERSEN_Y, j, c.steps[j].point.y);
+                s.cell(COL_PEDERSEN_SUFFIX, j, c.steps[j].suffix); s.cell(COL_PEDERSEN_SLOPE, j, c.steps[j].slope);
+            }
+            const U256 *in2[2] = {&inst.keys[t].first, &inst.keys[t].second};
+            for (int half = 0; half < 2; ++half) {
+                const bool b251 = bit(*in2[half], 251), b196 = bit(*in2[half], 196), b192 = bit(*in2[half], 192);
+                s.cell(COL_PEDERSEN_SLOPE, 256 * half + 255, felt_from_u64(b251 && b196));
+                s.cell(COL_AUXILIARY, 256 * half + 71, felt_from_u64(b251 && b196 && b192));
+            }
+            s.pair(NPC_PEDERSEN_INPUT0_ADDR, 0, felt_from_canonical(inst.keys[t].first));
+            s.pair(NPC_PEDERSEN_INPUT1_ADDR, 1, felt_from_canonical(inst.keys[t].second));
+            s.pair(NPC_PEDERSEN_OUTPUT_ADDR, 2, c.out);
+        });
+        be.pedersen_done();
+    }
+    // ---- range-check builtin (trace.rs:388-426)
+    be.rc_builtin(rc_plan, pool, rc_given);
+    // ---- ECDSA (trace.rs:428-523)
+    {
+        const uint64_t step = ECDSA_BUILTIN_RATIO * CYCLE_HEIGHT;
+        const auto given = instances_by_index(priv.ecdsa, n / step, "ecdsa");
+        Instances<U256x4, EcdsaTrace> inst;
+        inst.assign(n / step, [&](uint64_t i) {
+            auto it = given.find((uint32_t)i);
+            return it != given.end() ? U256x4{it->second->pubkey_x, it->second->message, it->second->r, it->second->w} : ecdsa_dummy().key;
+        });
+        inst.trace_all([](const U256x4 &k) {               // (three scalar multiplications with their doubling chains per signature)
+            if (k == ecdsa_dummy().key) return ecdsa_dummy().trace;
+            return std::make_shared<const EcdsaTrace>(ecdsa_trace(std::get<0>(k), std::get<1>(k), std::get<2>(k), std::get<3>(k)));
+        });
+        be.builtin("ecdsa", inst.of_block, (uint32_t)inst.keys.size(), step, pi.segments[5].begin_addr, 2, [&](auto &s, uint32_t ti) {
+            const EcdsaTrace &t = *inst.traces[ti];
+            for (int half = 0; half < 2; ++half) {
+                const std::vector<MadStep> &mad = half ? t.wb_steps : t.rq_steps;
+                const std::vector<Doubling> &dbl = half ? t.b_doubling : t.pubkey_doubling;
+                for (uint64_t j = 0; j < 256; ++j) {
+                    const uint64_t r = 64 * (256 * half + j);
+                    s.cell(COL_AUXILIARY, r + EC_PUBKEY_DOUBLING_X, dbl[j].point.x); s.cell(COL_AUXILIARY, r + EC_PUBKEY_DOUBLING_Y, dbl[j].point.y);
+                    s.cell(COL_AUXILIARY, r + EC_PUBKEY_DOUBLING_SLOPE, dbl[j].slope);
+                    s.cell(COL_AUXILIARY, r + EC_PUBKEY_PARTIAL_SUM_X, mad[j].partial.x); s.cell(COL_AUXILIARY, r + EC_PUBKEY_PARTIAL_SUM_Y, mad[j].partial.y);
+                    s.cell(COL_AUXILIARY, r + EC_PUBKEY_PARTIAL_SUM_SLOPE, mad[j].slope); s.cell(COL_AUXILIARY, r + EC_PUBKEY_PARTIAL_SUM_X_DIFF_INV, mad[j].x_diff_inv);
+                    s.cell(COL_AUXILIARY, r + EC_R_SUFFIX, mad[j].suffix);
+                }
+            }
+            for (uint64_t j = 0; j < 256; ++j) {
+                const uint64_t r = 128 * j;
+                const MadStep &st = t.zg_steps[j];
+                s.cell(COL_AUXILIARY, r + EC_GENERATOR_PARTIAL_SUM_X, st.partial.x); s.cell(COL_AUXILIARY, r + EC_GENERATOR_PARTIAL_SUM_Y, st.partial.y);
+                s.cell(COL_AUXILIARY, r + EC_GENERATOR_PARTIAL_SUM_SLOPE, st.slope); s.cell(COL_AUXILIARY, r + EC_GENERATOR_PARTIAL_SUM_X_DIFF_INV, st.x_diff_inv);
+                s.cell(COL_AUXILIARY, r + EC_MESSAGE_SUFFIX, st.suffix);
+            }
+            s.cell(COL_AUXILIARY, EC_B_SLOPE, t.b_slope); s.cell(COL_AUXILIARY, EC_B_X_DIFF_INV, t.b_x_diff_inv); s.cell(COL_AUXILIARY, EC_W_INV, t.w_inv);
+            s.cell(COL_AUXILIARY, EC_R_INV, t.r_inv); s.cell(COL_AUXILIARY, EC_R_POINT_SLOPE, t.r_point_slope); s.cell(COL_AUXILIARY, EC_R_POINT_X_DIFF_INV, t.r_point_x_diff_inv);
+            s.cell(COL_AUXILIARY, EC_MESSAGE_INV, t.message_inv);
+            s.cell(COL_AUXILIARY, EC_PUBKEY_X_SQUARED, felt_mul(t.pubkey.x, t.pubkey.x));
+            s.pair(NPC_ECDSA_PUBKEY_ADDR, 0, t.pubkey.x);
+            s.pair(NPC_ECDSA_MESSAGE_ADDR, 1, t.message);
+        });
+    }
+    // ---- bitwise and the diluted check (trace.rs:525-705)
+    {
+        const uint64_t step = BITWISE_RATIO * CYCLE_HEIGHT;
+        const auto given = instances_by_index(priv.bitwise, n / step, "bitwise");
+        Instances<U256x2, BitwiseTrace> inst;
+        inst.assign(n / step, [&](uint64_t i) { auto it = given.find((uint32_t)i); return it != given.end() ? U256x2{it->second->x, it->second->y} : U256x2{}; });
+        inst.trace_all([](const U256x2 &k) { return bitwise_instance_trace(k.first, k.second); });
+        be.builtin("bitwise", inst.of_block, (uint32_t)inst.keys.size(), step, pi.segments[6].begin_addr, 5, [&](auto &s, uint32_t ti) {
+            const BitwiseTrace &t = *inst.traces[ti];
+            for (unsigned k = 0; k < 4; ++k) s.cell(COL_RANGE_CHECK, BITWISE_SHIFTED_CELLS[k], t.shifted[k]);
+            for (int p = 0; p < 4; ++p) for (int c = 0; c < 4; ++c) for (int sg = 0; sg < 4; ++sg) s.cell(COL_RANGE_CHECK, 256 * p + 16 * (4 * c + sg) + 1, t.parts[p][c][sg]);
+            for (int k = 0; k < 4; ++k) s.pair(NPC_BITWISE_POOL_ADDR + 256 * k, k, t.memory[k]);
+            s.pair(NPC_BITWISE_X_OR_Y_ADDR, 4, t.memory[4]);
+        });
+        // the diluted pool: every instance's 68 diluted cells counted (by template: nearly every block holds the dummy instance)
+        std::vector<uint32_t> dil_count(1u << DILUTED_N_BITS, 0), blocks_of(inst.keys.size(), 0);
+        for (uint32_t t : inst.of_block) ++blocks_of[t];
+        for (size_t t = 0; t < inst.keys.size(); ++t) for (uint32_t v : inst.traces[t]->undiluted) dil_count[v] += blocks_of[t];
+        const uint64_t slots = n / DILUTED_CHECK_STEP;
+        DilutedPlan dp;
+        dp.from_counts(dil_count, slots);
+        std::vector<uint64_t> pad_rows, pad_values;
+        size_t pi_d = 0;
+        for (uint64_t blk = 0; blk < n / 1024 && pi_d < dp.padding.size(); ++blk)               // the free cells 8 i + 1, i odd (trace.rs:668-693)
+            for (uint64_t i = 1; i < 1024 / DILUTED_CHECK_STEP && pi_d < dp.padding.size(); i += 2) {
+                const uint64_t off = 8 * i + DC_UNORDERED;
+                if (std::find(std::begin(BITWISE_SHIFTED_CELLS), std::end(BITWISE_SHIFTED_CELLS), off) != std::end(BITWISE_SHIFTED_CELLS)) continue;
+                pad_rows.push_back(blk * 1024 + off);
+                pad_values.push_back(dilute(dp.padding[pi_d++]));
+            }
+        if (pi_d != dp.padding.size()) fail("diluted-check values do not fit the trace");
+        be.diluted(dp, pad_rows, pad_values, slots);
+    }
+    // ---- EC op (trace.rs:707-777)
+    {
+        const Curve &cv = curve();
+        const uint64_t step = EC_OP_BUILTIN_RATIO * CYCLE_HEIGHT;
+        const auto given = instances_by_index(priv.ec_op, n / step, "ec_op");
+        // gen_dummy_instance (ec_op/mod.rs:84-96): P0 + 1 * G
+        const U256x5 dummy{canonical_of(cv.shift.x), canonical_of(cv.shift.y), canonical_of(cv.generator.x), canonical_of(cv.generator.y), U256{1, 0, 0, 0}};
+        Instances<U256x5, EcOpTrace> inst;
+        inst.assign(n / step, [&](uint64_t i) {
+            auto it = given.find((uint32_t)i);
+            return it != given.end() ? U256x5{it->second->p_x, it->second->p_y, it->second->q_x, it->second->q_y, it->second->m} : dummy;
+        });
+        inst.trace_all([](const U256x5 &in5) {               // (a scalar multiplication with its doubling chain per instance)
+            auto t = std::make_shared<EcOpTrace>();
+            t->p = Pt{felt_from_canonical(std::get<0>(in5)), felt_from_canonical(std::get<1>(in5))};
+            t->q = Pt{felt_from_canonical(std::get<2>(in5)), felt_from_canonical(std::get<3>(in5))};
+            t->m = felt_from_canonical(std::get<4>(in5));
+            t->q_doubling = doubling_steps(t->q);
+            t->r_steps = ec_mad_steps(std::get<4>(in5), t->q, t->p, 255);
+            t->r = t->r_steps.back().partial;
+            t->b251_196 = bit(std::get<4>(in5), 251) && bit(std::get<4>(in5), 196); t->b251_196_192 = t->b251_196 && bit(std::get<4>(in5), 192);
+            return std::shared_ptr<const EcOpTrace>(t);
+        });
+        be.builtin("ec op", inst.of_block, (uint32_t)inst.keys.size(), step, pi.segments[7].begin_addr, 7, [&](auto &s, uint32_t ti) {
+            const EcOpTrace &t = *inst.traces[ti];
+            for (uint64_t j = 0; j < 256; ++j) {
+                const uint64_t r = 64 * j;
+                s.cell(COL_AUXILIARY, r + OP_Q_DOUBLING_X, t.q_doubling[j].point.x); s.cell(COL_AUXILIARY, r + OP_Q_DOUBLING_Y, t.q_doubling[j].point.y);
+                s.cell(COL_AUXILIARY, r + OP_Q_DOUBLING_SLOPE, t.q_doubling[j].slope);
+                s.cell(COL_AUXILIARY, r + OP_R_PARTIAL_SUM_X, t.r_steps[j].partial.x); s.cell(COL_AUXILIARY, r + OP_R_PARTIAL_SUM_Y, t.r_steps[j].partial.y);
+                s.cell(COL_AUXILIARY, r + OP_M_SUFFIX, t.r_steps[j].suffix);
+                if (j != 255) {                              // the ECDSA builtin owns the last ones
+                    s.cell(COL_AUXILIARY, r + OP_R_PARTIAL_SUM_SLOPE, t.r_steps[j].slope); s.cell(COL_AUXILIARY, r + OP_R_PARTIAL_SUM_X_DIFF_INV, t.r_steps[j].x_diff_inv);
+                }
+            }
+            s.cell(COL_AUXILIARY, OP_M_BIT251_AND_BIT196, felt_from_u64(t.b251_196)); s.cell(COL_AUXILIARY, OP_M_BIT251_AND_BIT196_AND_BIT192, felt_from_u64(t.b251_196_192));
+            const Felt values[7] = {t.p.x, t.p.y, t.q.x, t.q.y, t.m, t.r.x, t.r.y};
+            for (int k = 0; k < 7; ++k) s.pair(NPC_EC_OP_ADDRS[k], k, values[k]);
+        });
+    }
+    // ---- Poseidon (trace.rs:779-888)
+    {
+        const uint64_t step = POSEIDON_RATIO * CYCLE_HEIGHT;
+        const uint64_t FULL[3][2] = {{53, 29}, {13, 61}, {45, 3}};
+        const auto given = instances_by_index(priv.poseidon, n / step, "poseidon");
+        Instances<U256x3, PoseidonTrace> inst;
+        inst.assign(n / step, [&](uint64_t i) {
+            auto it = given.find((uint32_t)i);
+            return it != given.end() ? U256x3{it->second->input[0], it->second->input[1], it->second->input[2]} : U256x3{};
+        });
+        inst.trace_all([](const U256x3 &k) {
+            return std::make_shared<const PoseidonTrace>(poseidon_trace(std::array<Felt, 3>{felt_from_canonical(std::get<0>(k)), felt_from_canonical(std::get<1>(k)), felt_from_canonical(std::get<2>(k))}));
+        });
+        be.builtin("poseidon", inst.of_block, (uint32_t)inst.keys.size(), step, pi.segments[8].begin_addr, 6, [&](auto &s, uint32_t ti) {
+            const PoseidonTrace &t = *inst.traces[ti];
+            const U256x3 &k3 = inst.keys[ti];
+            const Felt input[3] = {felt_from_canonical(std::get<0>(k3)), felt_from_canonical(std::get<1>(k3)), felt_from_canonical(std::get<2>(k3))};
+            for (uint64_t rnd = 0; rnd < 8; ++rnd)
+                for (int j = 0; j < 3; ++j) { s.cell(COL_AUXILIARY, 64 * rnd + FULL[j][0], t.full[rnd][j]); s.cell(COL_AUXILIARY, 64 * rnd + FULL[j][1], t.full_sq[rnd][j]); }
+            for (uint64_t k = 0; k < 64; ++k) { s.cell(COL_RANGE_CHECK, 8 * k + 3, t.partial[k]); s.cell(COL_RANGE_CHECK, 8 * k + 7, t.partial_sq[k]); }
+            for (uint64_t k = 0; k + 61 < t.partial.size(); ++k) { s.cell(COL_AUXILIARY, 16 * k + 6, t.partial[61 + k]); s.cell(COL_AUXILIARY, 16 * k + 14, t.partial_sq[61 + k]); }
+            for (int k = 0; k < 3; ++k) { s.pair(NPC_POSEIDON_ADDRS[k], k, input[k]); s.pair(NPC_POSEIDON_ADDRS[3 + k], 3 + k, t.out[k]); }
+        });
+    }
+    // ---- gap fillers (trace.rs:890-925), sorted memory (get_ordered_memory_accesses, utils.rs:112-152)
+    be.memory();
+}
+
+Inputs check_inputs(const RegisterStates &states, const Mem &mem, const AirPublicInput &pi, const StarknetPrivateInput &priv) {
+    const uint64_t num_cycles = states.size();
+    if (!num_cycles || (num_cycles & (num_cycles - 1))) fail("the number of cycles must be a power of two");
+    if (num_cycles < ECDSA_BUILTIN_RATIO) fail("the starknet layout needs at least 2048 cycles");
+    for (int k : {3, 4, 5, 6, 7, 8}) if (!pi.segments[k].present) fail("the starknet layout requires every builtin segment");
+    const MemoryEntry *padding = nullptr;
+    for (auto &e : pi.public_memory) if (e.address == 1) { padding = &e; break; }
+    if (!padding) fail("public memory has no entry at address 1");
+    return Inputs{states, mem, pi, priv, num_cycles, num_cycles * CYCLE_HEIGHT, felt_from_canonical(padding->value)};
+}
+
 }  // namespace
 
 void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, const std::vector<U256> &memory,
                               const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv,
                               const std::function<void(int)> *column_done) {
-    auto done = [&](std::initializer_list<int> cs) { if (column_done && *column_done) for (int c : cs) (*column_done)(c); };
     const HostThreadsScope host_threads_scope;              // OpenMP threads by the cgroup's CPU quota (trace_common.hpp)
-    const uint64_t num_cycles = states.size();
-    if (!num_cycles || (num_cycles & (num_cycles - 1))) fail("the number of cycles must be a power of two");
-    if (num_cycles < ECDSA_BUILTIN_RATIO) fail("the starknet layout needs at least 2048 cycles");
-    for (int k : {3, 4, 5, 6, 7, 8}) if (!pi.segments[k].present) fail("the starknet layout requires every builtin segment");
-    const uint64_t n = num_cycles * CYCLE_HEIGHT;
     const Mem mem{memory, present};
-    const Felt zero = felt_from_u64(0);
-    const bool timing = getenv("SSH_TRACE_TIMING") != nullptr;               // stage times on stderr
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!timing) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[starknet trace] %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
-        t_last = now;
-    };
-    struct Col { Felt *p; Felt &operator[](uint64_t i) const { return p[i]; } };
-    Col cols[NUM_COLS];
-    for (int c = 0; c < NUM_COLS; ++c) cols[c] = Col{out[c]};
-    // The CPU's cells.  The generator is bound by the host's memory traffic (4.8 GB of columns at 2^20 steps), so every column this
-    // section touches is written ONCE: a cycle's 16 rows of the flags, the memory pool, the range-check column and the auxiliary column
-    // are made in a block on the stack - padding first, then what the cycle puts there, in the order the separate passes of the first
-    // version wrote them - and stored row after row.  Cells of these columns that a builtin owns get the padding here and their values
-    // in the builtin's section.  (The four Pedersen columns and the ordered memory are written whole by their own sections.)
-    const Col flags = cols[COL_FLAGS], npc = cols[COL_NPC], rc_col = cols[COL_RANGE_CHECK], aux = cols[COL_AUXILIARY];
-    AddrArray npc_addr(n / 2);                          // every entry assigned by its cycle below
+    const Inputs in = check_inputs(states, mem, pi, priv);
+    HostBackend be(in, out, column_done);
+    be.lap("allocation");
+    generate(be, in);
+}
 
-    const MemoryEntry *padding = nullptr;
-    for (auto &e : pi.public_memory) if (e.address == 1) { padding = &e; break; }
-    if (!padding) fail("public memory has no entry at address 1");
-    const Felt pad_value = felt_from_canonical(padding->value), pad_addr = felt_from_u64(1);
-    auto set_pair = [&](uint64_t row, uint64_t address, const Felt &value) { npc[row] = felt_from_u64(address); npc[row + 1] = value; npc_addr[row / 2] = address; };
-
-    lap("allocation");
-    // ---- the range-check pool (trace.rs:142-165): the offsets of every instruction counted first (no column is touched)
-    std::vector<uint32_t> rc_count(1 << 16, 0);
-    std::vector<std::vector<uint32_t>> rc_count_of((size_t)omp_get_max_threads());
-    parallel_for(num_cycles, [&](uint64_t cycle) {
-        std::vector<uint32_t> &my_count = rc_count_of[(size_t)omp_get_thread_num()];
-        if (my_count.empty()) my_count.assign(1 << 16, 0);
-        const Word w{mem.at(states[cycle].pc)[0]};
-        for (uint64_t v : {w.off_dst(), w.off_op0(), w.off_op1()}) ++my_count[v];
-    });
-    for (auto &part : rc_count_of) for (size_t v = 0; v < part.size(); ++v) rc_count[v] += part[v];
-    struct Rc128 { uint32_t index; U256 value; };
-    std::vector<Rc128> rc128;
-    auto part_of = [](const U256 &v, unsigned k) { return (uint32_t)(shr(v, 16 * (RANGE_CHECK_BUILTIN_PARTS - 1 - k))[0] & 0xffff); };
-    for (auto &inst : priv.range_check) {
-        if (inst.value[2] | inst.value[3]) fail("range-check value does not fit 128 bits");
-        rc128.push_back(Rc128{inst.index, inst.value});
-        for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) ++rc_count[part_of(inst.value, k)];
-    }
-    uint32_t rc_lo = 0xffff, rc_hi = 0;
-    for (uint32_t v = 0; v < (1u << 16); ++v) if (rc_count[v]) { rc_lo = std::min(rc_lo, v); rc_hi = std::max(rc_hi, v); }
-    std::vector<uint32_t> padding_vals;
-    for (uint32_t v = rc_lo; v <= rc_hi; ++v) if (!rc_count[v]) padding_vals.push_back(v);
-    CountArray ordered_vals;
-    ordered_runs(rc_count, rc_lo, rc_hi, ordered_vals);
-    size_t pad_i = 0;
-    auto next_padding = [&]() { return pad_i < padding_vals.size() ? padding_vals[pad_i++] : rc_hi; };
-    for (uint64_t index = rc128.size(); index < num_cycles / RANGE_CHECK_BUILTIN_RATIO; ++index) {       // trace.rs:246-261
-        U256 value{};
-        for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) {
-            value[3] = (value[3] << 16) | (value[2] >> 48); value[2] = (value[2] << 16) | (value[1] >> 48);
-            value[1] = (value[1] << 16) | (value[0] >> 48); value[0] = (value[0] << 16) | next_padding();
-        }
-        rc128.push_back(Rc128{(uint32_t)index, value});
-    }
-    // the odd cycles take the next padding values in order, every cycle its CYCLE_HEIGHT / RANGE_CHECK_STEP ordered values: both
-    // sequences are indexed by the cycle, so the cycles go in parallel
-    const size_t pad0 = pad_i;
-    const uint64_t per = CYCLE_HEIGHT / RANGE_CHECK_STEP;
-    if (pad0 + num_cycles / 2 < padding_vals.size() || num_cycles * per < ordered_vals.size()) fail("range-check values do not fit the trace");
-    const Felt rc_max_f = felt_from_u64(rc_hi);
-
-    // ---- CPU cells (trace.rs:177-244), the range-check column's pool cells (trace.rs:165-235, 294-302)
-    constexpr uint64_t JNZ_BLOCK = 512;                  // cycles whose conditional jumps share one inversion (JnzInverses)
-    parallel_for((num_cycles + JNZ_BLOCK - 1) / JNZ_BLOCK, [&](uint64_t block) {
-        const uint64_t first_cycle = block * JNZ_BLOCK, end_cycle = std::min(num_cycles, first_cycle + JNZ_BLOCK);
-        JnzInverses jnz(states, mem, first_cycle, end_cycle);
-        for (uint64_t cycle = first_cycle; cycle < end_cycle; ++cycle) {
-            const uint64_t r = cycle * CYCLE_HEIGHT, pc = states[cycle].pc, ap = states[cycle].ap, fp = states[cycle].fp;
-            const U256 &iw = mem.at(pc);
-            const Word w{iw[0]};
-            if ((iw[1] | iw[2] | iw[3]) || w.flag(F_ZERO)) fail("memory cell " + std::to_string(pc) + " is not an instruction");
-            const uint64_t dst_addr = w.off_dst() + (w.flag(F_DST_REG) ? fp : ap) - HALF_OFFSET;
-            const uint64_t op0_addr = w.off_op0() + (w.flag(F_OP0_REG) ? fp : ap) - HALF_OFFSET;
-            const int src = w.op1_src();
-            if (src != 0 && src != 1 && src != 2 && src != 4) fail("invalid op1 source");
-            const uint64_t base = src == 0 ? mem.small(op0_addr) : src == 1 ? pc : src == 2 ? fp : ap;
-            const uint64_t op1_addr = w.off_op1() + base - HALF_OFFSET;
-            const Felt dst = felt_from_canonical(mem.at(dst_addr)), op0 = felt_from_canonical(mem.at(op0_addr)), op1 = felt_from_canonical(mem.at(op1_addr));
-            Felt res;
-            if (w.pc_update() == 4) res = felt_is_zero(dst) ? zero : jnz.take(dst);
-            else if (w.res_logic() == 0) res = op1;
-            else if (w.res_logic() == 1) res = felt_add(op0, op1);
-            else if (w.res_logic() == 2) res = felt_mul(op0, op1);
-            else fail("invalid res logic");
-            const Felt tmp0 = w.flag(F_PC_JNZ) ? dst : zero;
-            Felt blk[CYCLE_HEIGHT];
-            // flags
-            for (int f = 0; f < 16; ++f) flags[r + f] = felt_from_u64(w.flag_prefix(f));
-            // memory pool: (address, value) pairs, the padding pair where the CPU has none (a builtin's pair comes with its section)
-            for (uint64_t o = 0; o < CYCLE_HEIGHT; o += 2) { blk[o] = pad_addr; blk[o + 1] = pad_value; npc_addr[(r + o) / 2] = 1; }
-            auto pair = [&](uint64_t o, uint64_t address, const Felt &value) { blk[o] = felt_from_u64(address); blk[o + 1] = value; npc_addr[(r + o) / 2] = address; };
-            pair(NPC_PC, pc, felt_from_canonical(iw));
-            pair(NPC_MEM_OP0_ADDR, op0_addr, op0);
-            pair(NPC_MEM_DST_ADDR, dst_addr, dst);
-            pair(NPC_MEM_OP1_ADDR, op1_addr, op1);
-            for (uint64_t o = 0; o < CYCLE_HEIGHT; o += PUBLIC_MEMORY_STEP) pair(o + NPC_PUB_MEM_ADDR, 0, zero);
-            for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) npc[r + o] = blk[o];
-            // auxiliary column: zero where no section writes
-            for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = zero;
-            blk[AUX_TMP0] = tmp0; blk[AUX_TMP1] = felt_mul(tmp0, res);
-            blk[AUX_AP] = felt_from_u64(ap); blk[AUX_FP] = felt_from_u64(fp);
-            blk[AUX_OP0_MUL_OP1] = felt_mul(op0, op1); blk[AUX_RES] = res;
-            for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) aux[r + o] = blk[o];
-            // range-check column: the padding value, the instruction's offsets, the odd cycles' next padding value, the cycle's ordered
-            // values, zeros where the diluted check's cells are
-            for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) blk[o] = rc_max_f;
-            blk[RC_OFF_DST] = felt_from_u64(w.off_dst()); blk[RC_OFF_OP1] = felt_from_u64(w.off_op1()); blk[RC_OFF_OP0] = felt_from_u64(w.off_op0());
-            if (cycle % 2 == 1) {
-                const size_t at = pad0 + cycle / 2;
-                blk[RC_UNUSED] = felt_from_u64(at < padding_vals.size() ? padding_vals[at] : rc_hi);
-            }
-            for (uint64_t o = 0; o < CYCLE_HEIGHT; o += RANGE_CHECK_STEP) {
-                const uint64_t at = cycle * per + o / RANGE_CHECK_STEP;
-                blk[o + RC_ORDERED] = felt_from_u64(at < ordered_vals.size() ? ordered_vals[at] : rc_hi);
-            }
-            for (uint64_t o = 0; o < CYCLE_HEIGHT; o += DILUTED_CHECK_STEP) blk[o + DC_UNORDERED] = blk[o + DC_ORDERED] = zero;      // trace.rs:294-302
-            for (uint64_t o = 0; o < CYCLE_HEIGHT; ++o) rc_col[r + o] = blk[o];
-        }
-    });
-
-    lap("cpu cells + range-check pool");
-    done({COL_FLAGS});
-    // ---- Pedersen (trace.rs:304-386)
-    {
-        std::map<uint32_t, const PedersenInstance *> given;
-        for (auto &p : priv.pedersen) given[p.index] = &p;
-        struct Cached { std::vector<Step> steps; Felt out; };
-        std::map<std::pair<U256, U256>, Cached> cache;
-        const uint64_t step = PEDERSEN_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[3].begin_addr;
-        const Pt p0 = pedersen_point(0);
-        const Col xs = cols[COL_PEDERSEN_X], ys = cols[COL_PEDERSEN_Y], suffixes = cols[COL_PEDERSEN_SUFFIX], slopes = cols[COL_PEDERSEN_SLOPE];
-        // the DISTINCT instances are found first (sequential: the map is shared; nearly every instance is the dummy one), their traces
-        // are made by all threads, then the cells of all instances in parallel
-        auto inputs_of = [&](uint64_t i, U256 &a, U256 &b) {
-            a = U256{}; b = U256{};
-            auto it = given.find((uint32_t)i);
-            if (it != given.end()) { a = it->second->a; b = it->second->b; }
-        };
-        std::vector<const Cached *> of_block(n / step);
-        std::vector<std::pair<const std::pair<U256, U256> *, Cached *>> distinct;
-        for (uint64_t i = 0; i < n / step; ++i) {
-            U256 a, b;
-            inputs_of(i, a, b);
-            const auto ins = cache.emplace(std::make_pair(a, b), Cached{});
-            if (ins.second) distinct.emplace_back(&ins.first->first, &ins.first->second);
-            of_block[i] = &ins.first->second;
-        }
-        parallel_items(distinct.size(), [&](uint64_t k) {               // (a real instance is 512 curve steps; a run may hold tens of thousands)
-            const U256 &a = distinct[k].first->first, &b = distinct[k].first->second;
-            Cached &c = *distinct[k].second;
-            c.steps.reserve(512);
-            const Pt mid = element_steps(a, p0, 0, c.steps);
-            element_steps(b, mid, 1, c.steps);
-            c.out = c.steps.back().point.x;
-            Felt want;
-            const Felt fa = felt_from_canonical(a), fb = felt_from_canonical(b);
-            if (ss_pedersen_hash_host(fa.data(), fb.data(), want.data()) != SS_OK || !felt_eq(want, c.out)) fail("Pedersen partial sums do not end at the hash");
-        });
-        parallel_for(n / step, [&](uint64_t i) {
-            U256 a, b;
-            inputs_of(i, a, b);
-            const Cached &c = *of_block[i];
-            const uint64_t base = i * step, addr = begin + 3 * i;
-            for (uint64_t j = 0; j < 512; ++j) {
-                xs[base + j] = c.steps[j].point.x; ys[base + j] = c.steps[j].point.y;
-                suffixes[base + j] = c.steps[j].suffix; slopes[base + j] = c.steps[j].slope;
-            }
-            const U256 *in[2] = {&a, &b};
-            for (int half = 0; half < 2; ++half) {
-                const bool b251 = bit(*in[half], 251), b196 = bit(*in[half], 196), b192 = bit(*in[half], 192);
-                slopes[base + 256 * half + 255] = felt_from_u64(b251 && b196);
-                aux[base + 256 * half + 71] = felt_from_u64(b251 && b196 && b192);
-            }
-            set_pair(base + NPC_PEDERSEN_INPUT0_ADDR, addr, felt_from_canonical(a));
-            set_pair(base + NPC_PEDERSEN_INPUT1_ADDR, addr + 1, felt_from_canonical(b));
-            set_pair(base + NPC_PEDERSEN_OUTPUT_ADDR, addr + 2, c.out);
-        });
-    }
-    lap("pedersen");
-    done({COL_PEDERSEN_X, COL_PEDERSEN_Y, COL_PEDERSEN_SUFFIX, COL_PEDERSEN_SLOPE});
-    // ---- range-check builtin (trace.rs:388-426)
-    {
-        const uint64_t step = RANGE_CHECK_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[4].begin_addr;
-        parallel_for(rc128.size(), [&](uint64_t blk) {
-            const uint64_t base = blk * step;
-            for (unsigned k = 0; k < RANGE_CHECK_BUILTIN_PARTS; ++k) rc_col[base + 32 * k + RC16_COMPONENT] = felt_from_u64(part_of(rc128[blk].value, k));
-            set_pair(base + NPC_RANGE_CHECK128_ADDR, begin + rc128[blk].index, felt_from_canonical(rc128[blk].value));
-        });
-    }
-    lap("range-check builtin");
-    // ---- ECDSA (trace.rs:428-523)
-    {
-        std::map<uint32_t, const EcdsaInstance *> given;
-        for (auto &p : priv.ecdsa) given[p.index] = &p;
-        std::map<std::tuple<U256, U256, U256, U256>, EcdsaTrace> cache;
-        const uint64_t step = ECDSA_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[5].begin_addr;
-        // the dummy instance (a constant: ecdsa/mod.rs gen_dummy_instance) and its trace - three scalar multiplications with their
-        // doubling chains, ~0.15 s - are made once per process
-        static std::once_flag dummy_once;
-        static U256 dummy[4];
-        static EcdsaTrace dummy_trace;
-        if (n / step > given.size())
-            std::call_once(dummy_once, [] { ecdsa_dummy_instance(dummy[0], dummy[1], dummy[2], dummy[3]); dummy_trace = ecdsa_trace(dummy[0], dummy[1], dummy[2], dummy[3]); });
-        std::vector<const EcdsaTrace *> of_block(n / step);
-        std::vector<std::pair<const std::tuple<U256, U256, U256, U256> *, EcdsaTrace *>> distinct;
-        for (uint64_t i = 0; i < n / step; ++i) {
-            auto it = given.find((uint32_t)i);
-            if (it == given.end()) { of_block[i] = &dummy_trace; continue; }
-            const auto ins = cache.emplace(std::make_tuple(it->second->pubkey_x, it->second->message, it->second->r, it->second->w), EcdsaTrace{});
-            if (ins.second) distinct.emplace_back(&ins.first->first, &ins.first->second);
-            of_block[i] = &ins.first->second;
-        }
-        parallel_items(distinct.size(), [&](uint64_t k) {               // (three scalar multiplications with their doubling chains per signature)
-            const auto &key = *distinct[k].first;
-            *distinct[k].second = ecdsa_trace(std::get<0>(key), std::get<1>(key), std::get<2>(key), std::get<3>(key));
-        });
-        parallel_for(n / step, [&](uint64_t i) {
-            const EcdsaTrace &t = *of_block[i];
-            const uint64_t base = i * step;
-            for (int half = 0; half < 2; ++half) {
-                const std::vector<MadStep> &mad = half ? t.wb_steps : t.rq_steps;
-                const std::vector<Doubling> &dbl = half ? t.b_doubling : t.pubkey_doubling;
-                for (uint64_t j = 0; j < 256; ++j) {
-                    const uint64_t r = base + 64 * (256 * half + j);
-                    aux[r + EC_PUBKEY_DOUBLING_X] = dbl[j].point.x; aux[r + EC_PUBKEY_DOUBLING_Y] = dbl[j].point.y; aux[r + EC_PUBKEY_DOUBLING_SLOPE] = dbl[j].slope;
-                    aux[r + EC_PUBKEY_PARTIAL_SUM_X] = mad[j].partial.x; aux[r + EC_PUBKEY_PARTIAL_SUM_Y] = mad[j].partial.y;
-                    aux[r + EC_PUBKEY_PARTIAL_SUM_SLOPE] = mad[j].slope; aux[r + EC_PUBKEY_PARTIAL_SUM_X_DIFF_INV] = mad[j].x_diff_inv; aux[r + EC_R_SUFFIX] = mad[j].suffix;
-                }
-            }
-            for (uint64_t j = 0; j < 256; ++j) {
-                const uint64_t r = base + 128 * j;
-                const MadStep &s = t.zg_steps[j];
-                aux[r + EC_GENERATOR_PARTIAL_SUM_X] = s.partial.x; aux[r + EC_GENERATOR_PARTIAL_SUM_Y] = s.partial.y;
-                aux[r + EC_GENERATOR_PARTIAL_SUM_SLOPE] = s.slope; aux[r + EC_GENERATOR_PARTIAL_SUM_X_DIFF_INV] = s.x_diff_inv; aux[r + EC_MESSAGE_SUFFIX] = s.suffix;
-            }
-            aux[base + EC_B_SLOPE] = t.b_slope; aux[base + EC_B_X_DIFF_INV] = t.b_x_diff_inv; aux[base + EC_W_INV] = t.w_inv; aux[base + EC_R_INV] = t.r_inv;
-            aux[base + EC_R_POINT_SLOPE] = t.r_point_slope; aux[base + EC_R_POINT_X_DIFF_INV] = t.r_point_x_diff_inv; aux[base + EC_MESSAGE_INV] = t.message_inv;
-            aux[base + EC_PUBKEY_X_SQUARED] = felt_mul(t.pubkey.x, t.pubkey.x);
-            set_pair(base + NPC_ECDSA_PUBKEY_ADDR, begin + 2 * i, t.pubkey.x);
-            set_pair(base + NPC_ECDSA_MESSAGE_ADDR, begin + 2 * i + 1, t.message);
-        });
-    }
-    lap("ecdsa");
-    // ---- bitwise and the diluted check (trace.rs:525-705)
-    {
-        std::map<uint32_t, const BitwiseInstance *> given;
-        for (auto &p : priv.bitwise) given[p.index] = &p;
-        const uint64_t step = BITWISE_RATIO * CYCLE_HEIGHT, begin = pi.segments[6].begin_addr;
-        std::vector<uint32_t> dil_count(1u << DILUTED_N_BITS, 0);
-        // one histogram per thread (nearly every instance is the dummy one: all threads would hammer the counter of value 0)
-        std::vector<std::vector<uint32_t>> dil_count_of((size_t)omp_get_max_threads());
-        parallel_for(n / step, [&](uint64_t i) {
-            std::vector<uint32_t> &my_count = dil_count_of[(size_t)omp_get_thread_num()];
-            if (my_count.empty()) my_count.assign(1u << DILUTED_N_BITS, 0);
-            const uint64_t base = i * step, addr = begin + 5 * i;
-            U256 x{}, y{};
-            auto it = given.find((uint32_t)i);
-            if (it != given.end()) { x = it->second->x; y = it->second->y; }
-            else {
-                // the dummy instance (x = y = 0; nearly every instance of a run is one): each of its 4 + 64 diluted cells is the value 0 -
-                // nothing to partition, dilute or check
-                for (unsigned k = 0; k < 4; ++k) rc_col[base + BITWISE_SHIFTED_CELLS[k]] = zero;
-                for (uint64_t q = 0; q < 64; ++q) rc_col[base + 16 * q + 1] = zero;
-                my_count[0] += 4 + 64;
-                for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + 256 * k, addr + k, zero);
-                set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, zero);
-                return;
-            }
-            U256 vand, vxor, vor;
-            for (int k = 0; k < 4; ++k) { vand[k] = x[k] & y[k]; vxor[k] = x[k] ^ y[k]; vor[k] = x[k] | y[k]; }
-            const U256 *vals[4] = {&x, &y, &vand, &vxor};
-            uint64_t parts[4][4][4];
-            for (int p = 0; p < 4; ++p) for (int c = 0; c < 4; ++c) partition64((*vals[p])[c], parts[p][c]);
-            for (unsigned k = 0; k < 4; ++k) {
-                const uint64_t v = parts[2][3][k] + parts[3][3][k];
-                const unsigned sh = k == 3 ? 8 : 4;
-                if (((v << sh) >> sh) != v) fail("bitwise instance " + std::to_string(i) + ": top segment does not fit");
-                rc_col[base + BITWISE_SHIFTED_CELLS[k]] = felt_from_u64(v << sh);
-                ++my_count[undilute(v << sh)];
-            }
-            for (int p = 0; p < 4; ++p)
-                for (int c = 0; c < 4; ++c)
-                    for (int s = 0; s < 4; ++s) {
-                        rc_col[base + 256 * p + 16 * (4 * c + s) + 1] = felt_from_u64(parts[p][c][s]);
-                        ++my_count[undilute(parts[p][c][s])];
-                    }
-            for (int k = 0; k < 4; ++k) set_pair(base + NPC_BITWISE_POOL_ADDR + 256 * k, addr + k, felt_from_canonical(*vals[k]));
-            set_pair(base + NPC_BITWISE_X_OR_Y_ADDR, addr + 4, felt_from_canonical(vor));
-        });
-        for (auto &part : dil_count_of) for (size_t v = 0; v < part.size(); ++v) dil_count[v] += part[v];
-        std::vector<uint32_t> padding_d;
-        uint64_t total = 0;
-        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) { if (!dil_count[v]) padding_d.push_back(v); total += std::max(dil_count[v], 1u); }
-        size_t pi_d = 0;
-        for (uint64_t blk = 0; blk < n / 1024 && pi_d < padding_d.size(); ++blk)               // the free cells 8 i + 1, i odd (trace.rs:668-693)
-            for (uint64_t i = 1; i < 1024 / DILUTED_CHECK_STEP && pi_d < padding_d.size(); i += 2) {
-                const uint64_t off = 8 * i + DC_UNORDERED;
-                if (std::find(std::begin(BITWISE_SHIFTED_CELLS), std::end(BITWISE_SHIFTED_CELLS), off) != std::end(BITWISE_SHIFTED_CELLS)) continue;
-                rc_col[blk * 1024 + off] = felt_from_u64(dilute(padding_d[pi_d++]));
-            }
-        const uint64_t slots = n / DILUTED_CHECK_STEP;
-        if (pi_d != padding_d.size() || total > slots) fail("diluted-check values do not fit the trace");
-        std::vector<uint64_t> first_slot((1u << DILUTED_N_BITS) + 1, slots - total);
-        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v) first_slot[v + 1] = first_slot[v] + std::max(dil_count[v], 1u);
-        parallel_for(1u << DILUTED_N_BITS, [&](uint64_t v) {                // the short runs value by value
-            if (first_slot[v + 1] - first_slot[v] >= 4096) return;
-            const Felt f = felt_from_u64(dilute((uint32_t)v));
-            for (uint64_t k = first_slot[v]; k < first_slot[v + 1]; ++k) rc_col[8 * k + DC_ORDERED] = f;
-        });
-        for (uint32_t v = 0; v < (1u << DILUTED_N_BITS); ++v)                 // the long ones (value 0 of the dummy instances) by all threads
-            if (first_slot[v + 1] - first_slot[v] >= 4096) {
-                const Felt f = felt_from_u64(dilute(v));
-                const uint64_t k0 = first_slot[v];
-                parallel_for(first_slot[v + 1] - k0, [&](uint64_t j) { rc_col[8 * (k0 + j) + DC_ORDERED] = f; });
-            }
-    }
-    lap("bitwise + diluted");
-    // ---- EC op (trace.rs:707-777)
-    {
-        std::map<uint32_t, const EcOpInstance *> given;
-        for (auto &p : priv.ec_op) given[p.index] = &p;
-        const Curve &cv = curve();
-        struct Trace { Pt p, q, r; Felt m; std::vector<Doubling> q_doubling; std::vector<MadStep> r_steps; bool b251_196, b251_196_192; };
-        std::map<std::tuple<U256, U256, U256, U256, U256>, Trace> cache;
-        const uint64_t step = EC_OP_BUILTIN_RATIO * CYCLE_HEIGHT, begin = pi.segments[7].begin_addr;
-        std::vector<const Trace *> of_block(n / step);
-        std::vector<std::pair<const std::tuple<U256, U256, U256, U256, U256> *, Trace *>> distinct;
-        for (uint64_t i = 0; i < n / step; ++i) {
-            U256 in[5];
-            auto it = given.find((uint32_t)i);
-            if (it != given.end()) { in[0] = it->second->p_x; in[1] = it->second->p_y; in[2] = it->second->q_x; in[3] = it->second->q_y; in[4] = it->second->m; }
-            else {                                                   // gen_dummy_instance (ec_op/mod.rs:84-96): P0 + 1 * G
-                in[0] = canonical_of(cv.shift.x); in[1] = canonical_of(cv.shift.y); in[2] = canonical_of(cv.generator.x); in[3] = canonical_of(cv.generator.y);
-                in[4] = U256{1, 0, 0, 0};
-            }
-            const auto ins = cache.emplace(std::make_tuple(in[0], in[1], in[2], in[3], in[4]), Trace{});
-            if (ins.second) distinct.emplace_back(&ins.first->first, &ins.first->second);
-            of_block[i] = &ins.first->second;
-        }
-        parallel_items(distinct.size(), [&](uint64_t k) {               // (a scalar multiplication with its doubling chain per instance)
-            const auto &in = *distinct[k].first;
-            Trace &t = *distinct[k].second;
-            t.p = Pt{felt_from_canonical(std::get<0>(in)), felt_from_canonical(std::get<1>(in))};
-            t.q = Pt{felt_from_canonical(std::get<2>(in)), felt_from_canonical(std::get<3>(in))};
-            t.m = felt_from_canonical(std::get<4>(in));
-            t.q_doubling = doubling_steps(t.q);
-            t.r_steps = ec_mad_steps(std::get<4>(in), t.q, t.p, 255);
-            t.r = t.r_steps.back().partial;
-            t.b251_196 = bit(std::get<4>(in), 251) && bit(std::get<4>(in), 196); t.b251_196_192 = t.b251_196 && bit(std::get<4>(in), 192);
-        });
-        parallel_for(n / step, [&](uint64_t i) {
-            const Trace &t = *of_block[i];
-            const uint64_t base = i * step, addr = begin + 7 * i;
-            for (uint64_t j = 0; j < 256; ++j) {
-                const uint64_t r = base + 64 * j;
-                aux[r + OP_Q_DOUBLING_X] = t.q_doubling[j].point.x; aux[r + OP_Q_DOUBLING_Y] = t.q_doubling[j].point.y; aux[r + OP_Q_DOUBLING_SLOPE] = t.q_doubling[j].slope;
-                aux[r + OP_R_PARTIAL_SUM_X] = t.r_steps[j].partial.x; aux[r + OP_R_PARTIAL_SUM_Y] = t.r_steps[j].partial.y; aux[r + OP_M_SUFFIX] = t.r_steps[j].suffix;
-                if (j != 255) { aux[r + OP_R_PARTIAL_SUM_SLOPE] = t.r_steps[j].slope; aux[r + OP_R_PARTIAL_SUM_X_DIFF_INV] = t.r_steps[j].x_diff_inv; }   // the ECDSA builtin owns the last ones
-            }
-            aux[base + OP_M_BIT251_AND_BIT196] = felt_from_u64(t.b251_196); aux[base + OP_M_BIT251_AND_BIT196_AND_BIT192] = felt_from_u64(t.b251_196_192);
-            const Felt values[7] = {t.p.x, t.p.y, t.q.x, t.q.y, t.m, t.r.x, t.r.y};
-            for (int k = 0; k < 7; ++k) set_pair(base + NPC_EC_OP_ADDRS[k], addr + k, values[k]);
-        });
-    }
-    lap("ec op");
-    // ---- Poseidon (trace.rs:779-888)
-    {
-        std::map<uint32_t, const PoseidonInstance *> given;
-        for (auto &p : priv.poseidon) given[p.index] = &p;
-        std::map<std::tuple<U256, U256, U256>, PoseidonTrace> cache;
-        const uint64_t step = POSEIDON_RATIO * CYCLE_HEIGHT, begin = pi.segments[8].begin_addr;
-        const uint64_t FULL[3][2] = {{53, 29}, {13, 61}, {45, 3}};
-        auto inputs_of = [&](uint64_t i, U256 (&in)[3]) {
-            for (int k = 0; k < 3; ++k) in[k] = U256{};
-            auto it = given.find((uint32_t)i);
-            if (it != given.end()) for (int k = 0; k < 3; ++k) in[k] = it->second->input[k];
-        };
-        std::vector<const PoseidonTrace *> of_block(n / step);
-        std::vector<std::pair<const std::tuple<U256, U256, U256> *, PoseidonTrace *>> distinct;
-        for (uint64_t i = 0; i < n / step; ++i) {
-            U256 in[3];
-            inputs_of(i, in);
-            const auto ins = cache.emplace(std::make_tuple(in[0], in[1], in[2]), PoseidonTrace{});
-            if (ins.second) distinct.emplace_back(&ins.first->first, &ins.first->second);
-            of_block[i] = &ins.first->second;
-        }
-        parallel_items(distinct.size(), [&](uint64_t k) {
-            const auto &in = *distinct[k].first;
-            *distinct[k].second = poseidon_trace(std::array<Felt, 3>{felt_from_canonical(std::get<0>(in)), felt_from_canonical(std::get<1>(in)), felt_from_canonical(std::get<2>(in))});
-        });
-        parallel_for(n / step, [&](uint64_t i) {
-            U256 in[3];
-            inputs_of(i, in);
-            const std::array<Felt, 3> input{felt_from_canonical(in[0]), felt_from_canonical(in[1]), felt_from_canonical(in[2])};
-            const PoseidonTrace &t = *of_block[i];
-            const uint64_t base = i * step, addr = begin + 6 * i;
-            for (uint64_t rnd = 0; rnd < 8; ++rnd)
-                for (int j = 0; j < 3; ++j) {
-                    aux[base + 64 * rnd + FULL[j][0]] = t.full[rnd][j];
-                    aux[base + 64 * rnd + FULL[j][1]] = t.full_sq[rnd][j];
-                }
-            for (uint64_t k = 0; k < 64; ++k) { rc_col[base + 8 * k + 3] = t.partial[k]; rc_col[base + 8 * k + 7] = t.partial_sq[k]; }
-            for (uint64_t k = 0; k + 61 < t.partial.size(); ++k) { aux[base + 16 * k + 6] = t.partial[61 + k]; aux[base + 16 * k + 14] = t.partial_sq[61 + k]; }
-            for (int k = 0; k < 3; ++k) { set_pair(base + NPC_POSEIDON_ADDRS[k], addr + k, input[k]); set_pair(base + NPC_POSEIDON_ADDRS[3 + k], addr + 3 + k, t.out[k]); }
-        });
-    }
-    lap("poseidon");
-    done({COL_RANGE_CHECK, COL_AUXILIARY});
-    // ---- gap fillers (trace.rs:890-925)
-    {
-        const std::vector<uint64_t> gaps = memory_gaps(npc_addr, pi.public_memory, num_cycles);
-        if (gaps.size() > num_cycles) fail("more memory gaps than cycles to hold them");
-        for (size_t k = 0; k < gaps.size(); ++k) set_pair(k * CYCLE_HEIGHT + NPC_UNUSED_ADDR, gaps[k], zero);
-    }
-    lap("gap fillers");
-    done({COL_NPC});
-    // ---- sorted memory (get_ordered_memory_accesses, utils.rs:112-152)
-    ordered_memory_into(out[COL_MEMORY], n, npc_addr, out[COL_NPC], n / PUBLIC_MEMORY_STEP, pi.public_memory, pad_value);
-    lap("sorted memory");
-    done({COL_MEMORY});
+// the same columns made in HBM (d_cols: 9 device columns of 16 * cycles felts): trace.bin / memory.bin go up as they are, the cells are
+// made by csrc/trace.hip; only what the host needs for the plans is read here (the instructions' offsets for the range-check pool)
+void starknet_base_trace_device(ss_ctx *ctx, uint64_t *const d_cols[9], const uint8_t *trace_bin, uint64_t trace_len, const uint8_t *memory_bin, uint64_t memory_len,
+                                const std::vector<U256> &memory, const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv) {
+    const HostThreadsScope host_threads_scope;
+    const RegisterStates states(trace_bin, trace_len);
+    const Mem mem{memory, present};
+    const Inputs in = check_inputs(states, mem, pi, priv);
+    DeviceTrace dt(ctx, in.num_cycles, d_cols, NUM_COLS);
+    dt.load_inputs(trace_bin, trace_len, memory_bin, memory_len);
+    DeviceBackend be{in, dt};
+    generate(be, in);
+    dt.finish();
 }
 
 std::vector<std::vector<Felt>> starknet_base_trace(const RegisterStates &states, const std::vector<U256> &memory,

@@ -6,6 +6,7 @@
 #pragma once
 #include <functional>
 #include "trace_recursive.hpp"
+#include "../../include/sandstorm_hip.h"
 
 namespace ssh {
 
@@ -31,6 +32,13 @@ std::vector<std::vector<Felt>> starknet_base_trace(const RegisterStates &states,
 void starknet_base_trace_into(Felt *const out[9], const RegisterStates &states, const std::vector<U256> &memory,
                               const std::vector<uint8_t> &present, const AirPublicInput &pi, const StarknetPrivateInput &priv,
                               const std::function<void(int)> *column_done = nullptr);
+
+// the same 9 columns made in HBM by the device (csrc/trace.hip through the ss_trace_* entry points; host/device_trace.hpp): the raw
+// files' bytes go up as they are - 25 MB where the host-made columns are 4.8 GB at 2^20 steps -, the host only counts the range-check
+// pool and traces the DISTINCT builtin instances.  memory / present: memory.bin as read_memory gives it (the plans read it).
+void starknet_base_trace_device(ss_ctx *ctx, uint64_t *const d_cols[9], const uint8_t *trace_bin, uint64_t trace_len, const uint8_t *memory_bin,
+                                uint64_t memory_len, const std::vector<U256> &memory, const std::vector<uint8_t> &present, const AirPublicInput &pi,
+                                const StarknetPrivateInput &priv);
 
 // shared with the AIR (air_starknet.cpp): StarkWare's Hades round constants, the curve's generator and beta
 const std::vector<std::array<Felt, 3>> &poseidon_round_keys();

@@ -635,6 +635,64 @@ def prove_files(ctx, layout, trace_bin: bytes, memory_bin: bytes, pi, private_in
     return raw, {"trace_gen_s": times[0], "total_s": times[1]}
 
 
+def device_base_trace(ctx, layout, trace_bin: bytes, memory_bin: bytes, pi, private_input=None, dev_cols=None):
+    """either layout's base columns made ON the device from the raw files (host_capi.cpp ssh_base_trace_device -> host/device_trace.hpp
+    -> csrc/trace.hip): trace.bin / memory.bin are uploaded as they are, the cells are made in HBM.  dev_cols: 7 / 9 device columns of
+    [16 * cycles, 4] 8-byte items (DeviceBuffers, torch tensors or addresses; fresh DeviceBuffers if None) -> the columns"""
+    ncols = 7 if layout == "recursive" else 9
+    n = 16 * (len(trace_bin) // 24)
+    if dev_cols is None:
+        dev_cols = [ctx.alloc(32 * n) for _ in range(ncols)]
+    if len(dev_cols) != ncols:
+        raise _lib.SandstormHipError("host: %d device columns for a layout of %d" % (len(dev_cols), ncols))
+    args, keep = _trace_job_args(layout, trace_bin, memory_bin, pi, private_input)
+    fn = load().ssh_base_trace_device
+    fn.argtypes = [C.c_void_p] + _TRACE_JOB_ARGTYPES + [C.POINTER(C.c_void_p)]
+    _check(fn(ctx.handle, *args, be._ptr_array(dev_cols)))
+    del keep
+    return dev_cols
+
+
+def prove_files_device(ctx, layout, trace_bin: bytes, memory_bin: bytes, pi, private_input, dev_cols, air: HostAir, tree_kind, n_friendly, coin_kind, seed,
+                       build_extension, options=None, want_proof=True):
+    """`sandstorm-cli prove` in one call with the base trace made on the device (host_capi.cpp ssh_prove_files_device): the files' bytes
+    go up as they are, csrc/trace.hip makes the columns in `dev_cols`, the prover goes on from there.
+    -> (proof bytes in the reference's wire format or None, {"trace_gen_s", "total_s"})"""
+    options = options or ProofOptions()
+    ncols = 7 if layout == "recursive" else 9
+    if len(dev_cols) != ncols:
+        raise _lib.SandstormHipError("host: %d device columns for a layout of %d" % (len(dev_cols), ncols))
+    args, keep_args = _trace_job_args(layout, trace_bin, memory_bin, pi, private_input)
+    keep = []
+
+    def cb(_user, ch_ptr, nch, out_ptr):
+        try:
+            ch = [np.array([ch_ptr[4 * i + k] for k in range(4)], dtype=np.uint64) for i in range(nch)]
+            cols = build_extension(ch)
+            keep.append(cols)
+            for i, col in enumerate(cols):
+                out_ptr[i] = be._ptr_of(col)
+            return 0
+        except Exception:                       # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+    opts = (C.c_uint32 * 5)(options.num_queries, options.lde_blowup_factor, options.grinding_factor,
+                            options.fri_folding_factor, options.fri_max_remainder_coeffs)
+    fn = load().ssh_prove_files_device
+    fn.argtypes = [C.c_void_p] + _TRACE_JOB_ARGTYPES + [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p, EXT_CB, C.c_void_p,
+                                                        C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
+    out, ln, times = C.POINTER(C.c_uint8)(), C.c_uint64(), (C.c_double * 2)()
+    _check(fn(ctx.handle, *args, be._ptr_array(dev_cols), air.h, tree_kind, n_friendly, coin_kind, bytes(seed), EXT_CB(cb), None, opts, times,
+              C.byref(out) if want_proof else None, C.byref(ln) if want_proof else None))
+    del keep_args
+    raw = None
+    if want_proof:
+        raw = bytes(bytearray(out[:ln.value]))
+        load().ssh_free(out)
+    return raw, {"trace_gen_s": times[0], "total_s": times[1]}
+
+
 def verify(air: HostAir, tree_kind, coin_kind, seed, proof: bytes, shipped_conventions=True, fri_alpha_times_offset=True,
            required_security_bits=80, expected_options=None, n_friendly_layers=22):
     """the C++ host's verifier (sandstorm_amd/host/verifier.cpp) on a proof in the reference's wire format; raises

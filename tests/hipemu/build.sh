@@ -11,7 +11,7 @@ SAN=${HIPEMU_SANITIZE:+-fsanitize=$HIPEMU_SANITIZE -fno-omit-frame-pointer -g1}
 FLAGS="-x c++ -std=c++17 -O2 -fPIC -w $SAN -I $HERE -I $ROOT/include -I $ROOT/sandstorm_amd/csrc"
 # the generated constraint kernels' translation units: csrc/quotient_gen_sources.mk (tools/gen_quotient.py)
 QG=$(sed -n 's/^QG_SRCS := //p' $ROOT/sandstorm_amd/csrc/quotient_gen_sources.mk | sed 's/\.hip//g')
-SRCS="capi ntt hash pedersen fri deep quotient ext goldilocks $QG"
+SRCS="capi ntt hash pedersen fri deep quotient ext trace goldilocks $QG"
 pids=()
 for f in $SRCS; do
   src=$ROOT/sandstorm_amd/csrc/$f.hip; obj=$OUT/$f.o

@@ -58,6 +58,23 @@ static inline unsigned long long atomicMin(unsigned long long *p, unsigned long 
     while (v < o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     return o;
 }
+// 32-bit atomics on "device" memory and LDS (trace.hip's histograms): workgroups may run on several OS threads
+static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline uint32_t atomicMin(uint32_t *p, uint32_t v) {
+    uint32_t o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
+static inline uint32_t atomicMax(uint32_t *p, uint32_t v) {
+    uint32_t o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
+static inline uint32_t atomicCAS(uint32_t *p, uint32_t expect, uint32_t v) {
+    __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+    return expect;                                           // the value that was there
+}
 static inline uint32_t __brev(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i); return r; }
 static inline uint64_t __brevll(uint64_t x) { uint64_t r = 0; for (int i = 0; i < 64; ++i) r |= ((x >> i) & 1ull) << (63 - i); return r; }
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
     from sandstorm_amd import _lib
-    assert lib.ss_abi_version() == _lib.header_abi_version() == 10
+    assert lib.ss_abi_version() == _lib.header_abi_version() == 11
 
 
 def test_boundary_document_and_bindings_follow_the_header():

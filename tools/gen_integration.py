@@ -13,7 +13,8 @@ BEGIN, END = "<!-- BEGIN GENERATED: tools/gen_integration.py -->", "<!-- END GEN
 
 SCALARS = {"uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8", "int": "c_int", "size_t": "usize", "int64_t": "i64", "void": "c_void",
            "char": "c_char", "double": "f64", "float": "f32", "ss_status": "c_int", "ss_ctx": "SsCtx", "ss_comm": "SsComm", "ss_air_program": "SsAirProgram",
-           "ss_perm_operand": "SsPermOperand", "ss_gather_job": "SsGatherJob"}
+           "ss_perm_operand": "SsPermOperand", "ss_gather_job": "SsGatherJob", "uint16_t": "u16", "ss_trace_layout": "SsTraceLayout",
+           "ss_trace_cell": "SsTraceCell", "ss_trace_rc_plan": "SsTraceRcPlan"}
 
 
 def prototypes(text=None):
@@ -78,6 +79,11 @@ def rust_block():
              "#[repr(C)] pub struct SsPermOperand {         // ss_perm_operand", "    pub d_data: *const u64, pub stride: u64, pub addr_offset: u64, pub value_offset: i64,", "}",
              "#[repr(C)] pub struct SsGatherJob {           // ss_gather_job",
              "    pub d_cols: *const *const c_void, pub ncols: u32, pub entry_bytes: u32, pub idx: *const u64, pub nidx: u32, pub out: *mut c_void,", "}",
+             "#[repr(C)] pub struct SsTraceLayout { pub npc_pair: [u8; 8], pub rc_cell: [u8; 16], pub aux_cell: [u8; 16] }      // ss_trace_layout",
+             "#[repr(C)] pub struct SsTraceCell { pub col: u32, pub off: u32, pub kind: u32, pub arg: u32 }                       // ss_trace_cell",
+             "#[repr(C)] pub struct SsTraceRcPlan {         // ss_trace_rc_plan",
+             "    pub n_slots: u64, pub n_given: u64, pub slot_rows: u64, pub addr_begin: u64, pub n_padding: u64, pub pad0: u64,",
+             "    pub part_stride: u32, pub part_off: u32, pub pair_off: u32, pub rc_lo: u32, pub rc_hi: u32, pub ordered_step: u32, pub ordered_off: u32, pub unused_off: u32,", "}",
              "#[link(name = \"sandstorm_hip\")]", "extern \"C\" {"]
     for name, ret, params in prototypes():
         args = ", ".join("%s: %s" % (p if p not in ("in", "type", "ref", "mod") else p + "_", rust_type(t)) for t, p in params)
