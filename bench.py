@@ -688,17 +688,19 @@ def _side_leg(name, fn, *args):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def end_to_end(ctx, layout, log_steps, device, repeats=3):
+def end_to_end(ctx, layout, log_steps, device, repeats=5):
     """`files -> proof`: what the reference's "Proof generated in" timer wraps - claim.prove(options, witness) (cli/src/main.rs:200-202)
     INCLUDES generate_trace (src/lib.rs:94-100).  A REAL statement of the layout at this step count (the reference's example run
     re-declared and padded with its final state: sandstorm_amd/examples.py; the same statements tests/test_gpu_full_size.py and
-    tests/test_gpu_recursive_claim.py prove and verify); the raw `cairo-run` bytes are the input:
-      trace_gen_s  the C++ host's ExecutionTrace::new (OpenMP over the host's cores) straight into PINNED host columns
-                   (the GpuAllocator seam, layouts/src/recursive/trace.rs:115-120), allocated once like the reference's vectors
-      h2d_s        the columns to HBM (one async copy per column, then a sync)
-      prove_s      the proof by the C++ host: every stage of bench.py's timed region plus the REAL extension columns (check on)
-    one after the other (`serial`), and then the same in ONE call with the three overlapped (`total_s`, `upload_overlapped`)
-    -> the means over `repeats` runs after one untimed run (pinned pages touched, plans and tables built)."""
+    tests/test_gpu_recursive_claim.py prove and verify); the raw `cairo-run` bytes are the input.
+      total_s      ONE call from the files to the proof with the base trace made ON the device (ssh_prove_files_device: trace.bin /
+                   memory.bin uploaded as they are, csrc/trace.hip makes the 7 / 9 columns in HBM, then the proof) - round 6
+      trace_gen_s  inside that call: until the columns were final (upload of the files, plans, kernels, the status read)
+      prove_s      the proof alone on resident columns: every stage of bench.py's timed region plus the REAL extension columns (check on)
+      host_generated  the round-5 path beside it: the C++ host's ExecutionTrace::new (OpenMP) into PINNED host columns, every column
+                   uploaded the moment it is final, the prover extending them as they land (ssh_prove_files), and the same three
+                   steps one after the other (`serial`)
+    -> the means over `repeats` runs after one untimed run (plans and tables built)."""
     from sandstorm_amd import backend as be, binary, examples, hostlib, public_input
     from sandstorm_amd.prover import ProofOptions
     log_n = log_steps + 4
@@ -720,8 +722,6 @@ def end_to_end(ctx, layout, log_steps, device, repeats=3):
     trace_bin, memory_bin = binary.write_register_states(states), binary.write_memory(memory)
     del states, memory
     seed = public_input.public_coin_seed(xpi, coin_kind)
-    pinned = [torch.empty((n, 4), dtype=torch.int64).pin_memory() for _ in range(nb)]
-    views = [t.numpy().view("uint64") for t in pinned]
     dev = [torch.empty((n, 4), dtype=torch.int64, device=device) for _ in range(nb)]
     keep = []
 
@@ -730,8 +730,31 @@ def end_to_end(ctx, layout, log_steps, device, repeats=3):
         keep.append(hostlib.build_extension_columns(ctx, layout, [dev[c] for c in aux_idx], n, challenges))
         return keep[0].cols
     options = ProofOptions()
-    acc = {"trace_gen_s": 0.0, "h2d_s": 0.0, "prove_s": 0.0}
+    # ---- the base trace made on the device: ONE call from the files to the proof; then the proof alone on the columns it left
+    total, inside, prove = 0.0, 0.0, 0.0
     for it in range(repeats + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, tm = hostlib.prove_files_device(ctx, layout, trace_bin, memory_bin, xpi, None, dev, air, tree_kind, n_friendly, coin_kind, seed, build_extension, options,
+                                           want_proof=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        hostlib.prove(ctx, air, tree_kind, n_friendly, coin_kind, seed, dev, log_n, build_extension, options, want_proof=False)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if it:
+            total += t1 - t0
+            inside += tm["trace_gen_s"]
+            prove += t2 - t1
+    total, inside, prove = total / repeats, inside / repeats, prove / repeats
+    out = {"total_s": total, "generator": "device", "trace_gen_s": inside, "prove_s": prove, "total_over_prove": total / prove if prove > 0 else None,
+           "input_bytes": len(trace_bin) + len(memory_bin), "column_bytes": 32 * n * nb}
+    # ---- the host-generated path (round 5), fewer repeats: pinned columns, the generator on the host's cores, uploads overlapped
+    host_repeats = 2
+    pinned = [torch.empty((n, 4), dtype=torch.int64).pin_memory() for _ in range(nb)]
+    views = [t.numpy().view("uint64") for t in pinned]
+    acc = {"trace_gen_s": 0.0, "h2d_s": 0.0, "prove_s": 0.0}
+    for it in range(host_repeats + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         gen(trace_bin, memory_bin, xpi, out=views)
@@ -747,12 +770,9 @@ def end_to_end(ctx, layout, log_steps, device, repeats=3):
             acc["trace_gen_s"] += t1 - t0
             acc["h2d_s"] += t2 - t1
             acc["prove_s"] += t3 - t2
-    serial = {k: v / repeats for k, v in acc.items()}
-    # ... and the same from the files in ONE call (hostlib.prove_files -> host_capi.cpp ssh_prove_files): the generator on a thread of
-    # its own, every column uploaded on the copy stream the moment no section writes it again, the prover extending the columns as
-    # they land - generation, upload and the first transforms overlap.  Wall time of the call, device idle before and after.
+    serial = {k: v / host_repeats for k, v in acc.items()}
     over = {"total_s": 0.0, "trace_gen_s": 0.0}
-    for it in range(repeats + 1):
+    for it in range(host_repeats + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         _, tm = hostlib.prove_files(ctx, layout, trace_bin, memory_bin, xpi, None, views, dev, air, tree_kind, n_friendly, coin_kind, seed, build_extension,
@@ -762,21 +782,19 @@ def end_to_end(ctx, layout, log_steps, device, repeats=3):
         if it:
             over["total_s"] += t1 - t0
             over["trace_gen_s"] += tm["trace_gen_s"]
-    over = {k: v / repeats for k, v in over.items()}
+    over = {k: v / host_repeats for k, v in over.items()}
     for m in keep:
         m.close()
     del keep[:], dev, pinned, views
     air.close()
-    out = {"total_s": over["total_s"], "upload_overlapped": True, "trace_gen_s": over["trace_gen_s"],
-           "prove_s": serial["prove_s"], "h2d_s": serial["h2d_s"],
-           "serial": dict(serial, total_s=sum(serial.values())),
-           "total_over_prove": over["total_s"] / serial["prove_s"] if serial["prove_s"] > 0 else None}
-    out["host_threads"] = int(os.environ.get("OMP_NUM_THREADS", HOST_CPUS))
-    out["host_cpus_visible"], out["host_cpu_quota"] = os.cpu_count(), HOST_CPUS
+    out["host_generated"] = {"total_s": over["total_s"], "upload_overlapped": True, "trace_gen_s": over["trace_gen_s"], "h2d_s": serial["h2d_s"],
+                             "serial": dict(serial, total_s=sum(serial.values())), "host_threads": int(os.environ.get("OMP_NUM_THREADS", HOST_CPUS)),
+                             "host_cpus_visible": os.cpu_count(), "host_cpu_quota": HOST_CPUS}
     out["statement"] = ("the reference's array-sum run re-declared for the %s layout, padded to 2^%d steps (a real, verifiable statement: "
                         "%d base columns x 2^%d rows from %.1f MB of trace.bin / memory.bin).  total_s: ONE call from the files to the proof "
-                        "(ssh_prove_files), generation / upload / first transforms overlapped, trace_gen_s the generator thread's wall time "
-                        "inside it; serial: the same three steps one after the other (generator, upload + sync, proof), prove_s / h2d_s from there"
+                        "(ssh_prove_files_device): the files' bytes uploaded as they are, the base columns made in HBM by csrc/trace.hip, then "
+                        "the proof; trace_gen_s: until the columns were final inside that call; prove_s: the proof alone on resident columns.  "
+                        "host_generated: the round-5 path (host generator into pinned columns, uploads overlapped: ssh_prove_files)"
                         % (layout, log_steps, nb, log_n, (len(trace_bin) + len(memory_bin)) / 1e6))
     return out
 

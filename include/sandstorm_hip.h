@@ -86,7 +86,7 @@ uint32_t ss_abi_version(void);
 ss_status ss_ctx_create(int device, ss_ctx **out);
 void ss_ctx_destroy(ss_ctx *ctx);
 ss_status ss_ctx_set_stream(ss_ctx *ctx, void *hip_stream); /* NULL = ctx-owned stream */
-ss_status ss_ctx_sync(ss_ctx *ctx);
+ss_status ss_ctx_sync(ss_ctx *ctx);       /* waits for the ctx stream and for the copy stream of ss_upload_async */
 /* ss_dev_alloc/ss_dev_free are pooled (the role of GpuAllocator / PageAlignedAllocator,
  * src/lib.rs:27-28): a freed block is kept for reuse by later allocations of a similar size
  * on the same context, so steady-state proving makes no hipMalloc/hipFree calls.

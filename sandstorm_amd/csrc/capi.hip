@@ -551,6 +551,10 @@ ss_status ss_ctx_set_stream(ss_ctx *ctx, void *hip_stream) {
 }
 ss_status ss_ctx_sync(ss_ctx *ctx) {
     if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
+    {   // the uploads of ss_upload_async too: a caller that gives up half way must not free pinned memory a copy still reads
+        std::lock_guard<std::mutex> lock(ctx->copy_mutex);
+        if (ctx->copy_stream) HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SS_OK;
 }
@@ -1166,11 +1170,12 @@ ss_status ss_gather_rows(ss_ctx *ctx, const uint64_t *const *d_cols, uint32_t nc
     if (!ctx || !d_cols || (!idx && nidx) || (!out && nidx)) return fail(SS_ERR_INVALID, "NULL argument");
     if (nidx == 0 || ncols == 0) return SS_OK;
     if (has_null((const void *const *)d_cols, ncols)) return fail(SS_ERR_INVALID, "NULL column");
-    const size_t need = (size_t)nidx * 8 + (size_t)nidx * ncols * 32;
+    const size_t idx_bytes = ((size_t)nidx * 8 + 31) & ~(size_t)31;      // the rows behind the indices on a 32-byte boundary (uint4 stores)
+    const size_t need = idx_bytes + (size_t)nidx * ncols * 32;
     ss_status st = ctx->ensure_scratch(need);
     if (st != SS_OK) return st;
     uint64_t *d_idx = (uint64_t *)ctx->scratch;
-    uint8_t *d_out = (uint8_t *)ctx->scratch + (size_t)nidx * 8;
+    uint8_t *d_out = (uint8_t *)ctx->scratch + idx_bytes;
     HIP_TRY(hipMemcpyAsync(d_idx, idx, (size_t)nidx * 8, hipMemcpyHostToDevice, ctx->stream));
     // one launch per MAX_COLS columns, written row after row: the download is the caller's array
     for (uint32_t c0 = 0; c0 < ncols; c0 += (uint32_t)MAX_COLS)
@@ -1193,14 +1198,15 @@ ss_status ss_gather_batch(ss_ctx *ctx, const ss_gather_job *jobs, uint32_t njobs
         out_bytes += (((size_t)g.nidx * g.ncols * g.entry_bytes) + 31) & ~(size_t)31;      // every job's output 32-byte aligned
     }
     if (!n_idx) return SS_OK;
-    ss_status st = ctx->ensure_scratch(n_idx * 8 + out_bytes);
+    const size_t idx_bytes = (n_idx * 8 + 31) & ~(size_t)31;             // the rows behind the indices on a 32-byte boundary (uint4 stores)
+    ss_status st = ctx->ensure_scratch(idx_bytes + out_bytes);
     if (st != SS_OK) return st;
     std::vector<uint64_t> all_idx;
     all_idx.reserve(n_idx);
     for (uint32_t j = 0; j < njobs; ++j)
         if (jobs[j].nidx && jobs[j].ncols) all_idx.insert(all_idx.end(), jobs[j].idx, jobs[j].idx + jobs[j].nidx);
     uint64_t *d_idx = (uint64_t *)ctx->scratch;
-    uint8_t *d_out = (uint8_t *)ctx->scratch + n_idx * 8;
+    uint8_t *d_out = (uint8_t *)ctx->scratch + idx_bytes;
     HIP_TRY(hipMemcpyAsync(d_idx, all_idx.data(), n_idx * 8, hipMemcpyHostToDevice, ctx->stream));
     size_t io = 0, oo = 0;
     for (uint32_t j = 0; j < njobs; ++j) {

@@ -363,6 +363,12 @@ TraceJob make_trace_job(int layout, const uint8_t *trace_bin, uint64_t trace_len
                         uint32_t rc_max, uint64_t n_steps, const uint32_t *segments, const uint32_t *mem_addresses, const uint64_t *mem_values,
                         uint64_t n_mem, const uint64_t *const *instances, const uint64_t *counts) {
     if (layout != 1 && layout != 2) throw std::runtime_error("layout: 1 = recursive, 2 = starknet");
+    if (!trace_bin || (!memory_bin && memory_len) || !segments || (n_mem && (!mem_addresses || !mem_values))) throw std::runtime_error("trace job: NULL argument");
+    // the public input and the files must be of the same run: the columns are sized by trace.bin, the statement by n_steps
+    if (trace_len % 24) throw std::runtime_error("trace: trace file is not a sequence of (ap, fp, pc) u64 triples");
+    if (!trace_len || ((trace_len / 24) & (trace_len / 24 - 1))) throw std::runtime_error("trace: the number of cycles must be a power of two");
+    if (n_steps != trace_len / 24) throw std::runtime_error("trace job: the public input declares " + std::to_string(n_steps) + " steps, trace.bin holds " + std::to_string(trace_len / 24));
+    if (rc_min > 0xffff || rc_max > 0xffff) throw std::runtime_error("trace job: rc_min / rc_max are 16-bit values");
     auto pi = std::make_shared<AirPublicInput>();
     pi->layout = layout == 1 ? "recursive" : "starknet";
     pi->rc_min = (uint16_t)rc_min; pi->rc_max = (uint16_t)rc_max; pi->n_steps = n_steps;
@@ -488,7 +494,17 @@ int ssh_prove_files(ss_ctx *ctx, int layout, const uint8_t *trace_bin, uint64_t 
             catch (const std::exception &e) { std::lock_guard<std::mutex> lk(m); failed = true; err = e.what(); cv.notify_all(); }
             gen_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         });
-        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{producer};      // (also when the prover throws)
+        std::vector<char> waited(job.ncols, 0);
+        // when the prover (or the generator) gives up half way: the producer is joined, every upload that left is waited for - a ticket
+        // nobody waited for is released, the copy stream is drained - before the caller gets its pinned columns back
+        struct Joiner {
+            std::thread &t; ss_ctx *ctx; std::vector<uint64_t> &ticket; std::vector<char> &waited;
+            ~Joiner() {
+                if (t.joinable()) t.join();
+                for (size_t c = 0; c < ticket.size(); ++c) if (ticket[c] && !waited[c]) (void)ss_wait_upload(ctx, ticket[c]);
+                (void)ss_ctx_sync(ctx);
+            }
+        } joiner{producer, ctx, ticket, waited};
         Matrix base;
         base.nrows = job.n;
         for (uint32_t c = 0; c < job.ncols; ++c) base.cols.push_back(d_cols[c]);
@@ -501,6 +517,7 @@ int ssh_prove_files(ss_ctx *ctx, int layout, const uint8_t *trace_bin, uint64_t 
                 cv.wait(lk, [&] { return ticket[c] != 0 || failed; });
                 if (failed) throw std::runtime_error(err);
                 t = ticket[c];
+                waited[c] = 1;
             }
             if (ss_wait_upload(ctx, t) != SS_OK) throw std::runtime_error(ss_last_error());
         };

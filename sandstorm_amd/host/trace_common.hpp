@@ -189,10 +189,16 @@ struct JnzInverses {
         }
         batch_invert(inv.data(), inv.size());
     }
+    size_t fallbacks = 0;                                   // cycles the pre-pass and the main pass disagreed about (none, unless the two decodes drift apart)
     Felt take(const Felt &dst) {                           // dst is not zero
         static const Felt one = felt_from_u64(1);
         if (next < inv.size() && felt_eq(felt_mul(inv[next], dst), one)) return inv[next++];
+        ++fallbacks;
         return felt_inv(dst);
+    }
+    ~JnzInverses() {
+        static const bool timing = getenv("SSH_TRACE_TIMING") != nullptr;
+        if (timing && (fallbacks || next != inv.size())) fprintf(stderr, "[trace timing] jnz inverses: %zu cycles took the per-cycle inversion, %zu batched inverses unused\n", fallbacks, inv.size() - next);
     }
 };
 

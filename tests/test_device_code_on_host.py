@@ -80,6 +80,18 @@ def test_extension_columns_and_compiled_constraint_kernels(emulated_library):
     assert "41 passed" in out, out[-500:]                     # 36 + 5 (the sixth queues 2^20-point evaluations back to back: hardware only)
 
 
+def test_the_base_trace_made_by_the_device_code(emulated_library):
+    """tests/test_gpu_device_trace.py: csrc/trace.hip (one lane per Cairo cycle, builtin templates, the pools and the ordered memory by
+    histogram + prefix sum + binary search) against the host generator, cell for cell - the reference's example run with and without
+    real builtin instances, the bench's statements of both layouts, the reference's bootloader run with every builtin, the input's
+    errors - and the 2^14-step files -> proof call through it (the committed proof's bytes)"""
+    out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_device_trace.py"])
+    assert "6 passed, 2 skipped" in out, out[-500:]
+    heavy()
+    out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_recursive_claim.py", "-k", "device_generator and 14"], timeout=2400)
+    assert "1 passed" in out, out[-500:]
+
+
 def test_whole_proofs(emulated_library):
     """tests/test_gpu_prove.py: prove -> serialise -> verify on the mini AIR, both hosts, every tree and coin"""
     heavy()

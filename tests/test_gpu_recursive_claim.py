@@ -211,6 +211,49 @@ def test_files_to_proof_in_one_call_writes_the_same_bytes(log_steps, request):
     ctx.close()
 
 
+@pytest.mark.parametrize("log_steps", [14, 16])
+def test_files_to_proof_through_the_device_generator_writes_the_same_bytes(log_steps, request):
+    """hostlib.prove_files_device (host_capi.cpp ssh_prove_files_device; what bench.py's end_to_end leg times since round 6): the
+    files' bytes go up as they are, the base columns are made in HBM (csrc/trace.hip), the prover goes on from there - the proof is
+    the batch path's: the committed 2^14-step fixture, and this run's own 2^16-step proof"""
+    from sandstorm_amd import backend as be, binary, hostlib, public_input
+    from sandstorm_amd.layouts import recursive as rec
+    if log_steps == 14:
+        with open(os.path.join(ROOT, "tests", "golden", "array_sum_recursive_cairo.proof"), "rb") as f:
+            want = f.read()
+    else:
+        want = request.getfixturevalue("proof_2p16")
+    states, memory, pi = recursive_example(log_steps)
+    trace_bin, memory_bin = binary.write_register_states(states), binary.write_memory(memory)
+    del states, memory
+    log_n = log_steps + 4
+    n = 1 << log_n
+    ctx = be.Context(0)
+    dev = [ctx.alloc(32 * n) for _ in range(7)]
+    air = hostlib.RecursiveHostAir(ctx, pi, log_n)
+    seed = public_input.public_coin_seed(pi, be.COIN_CAIRO)
+    aux_idx = (rec.COL_NPC, rec.COL_MEMORY, rec.COL_RANGE_CHECK, rec.COL_DILUTED_UNORDERED, rec.COL_DILUTED_ORDERED)
+    keep = []
+
+    def build_extension(challenges):
+        keep.append(hostlib.build_extension_columns(ctx, "recursive", [dev[c] for c in aux_idx], n, challenges))
+        return keep[-1].cols
+    for _ in range(2):
+        raw, times = hostlib.prove_files_device(ctx, "recursive", trace_bin, memory_bin, pi, None, dev, air, be.TREE_FRIENDLY, N_FRIENDLY, be.COIN_CAIRO, seed,
+                                                build_extension)
+        assert raw == want
+        assert 0 < times["trace_gen_s"] <= times["total_s"]
+    # files the generator refuses: nothing is proven, the message is the generator's, the context stays usable
+    from sandstorm_amd._lib import SandstormHipError
+    with pytest.raises(SandstormHipError, match="power of two"):
+        hostlib.prove_files_device(ctx, "recursive", trace_bin[:24 * 3000], memory_bin, pi, None, dev, air, be.TREE_FRIENDLY, N_FRIENDLY, be.COIN_CAIRO, seed, build_extension)
+    ctx.ntt([dev[0]], 10, be.FORWARD, None)
+    for m in keep:
+        m.close()
+    air.close()
+    ctx.close()
+
+
 def test_files_to_proof_reports_the_generators_error():
     """ssh_prove_files with files the generator refuses (a trace that is not a power of two of cycles; a public memory that does not
     fit the run): the generator's thread fails, the prover - waiting for its first column - gives up with THAT message, the thread is

@@ -3,7 +3,7 @@
 `example/array-sum.proof.saved` (tests/golden/reference_array_sum_starknet.proof) is the reference's own proof of its
 array-sum example under the starknet layout (EthVerifierClaim, 2^17 steps, 16 queries, 16 grinding bits).  The C++ host
 here proves the same statement from the same run - trace.bin / memory.bin re-declared for the layout, base trace by
-host/trace_starknet.cpp, the real 195-constraint AIR (host/air_starknet.cpp), extension column by the device scans,
+host/trace_starknet.cpp or by the device's generator (csrc/trace.hip), the real 195-constraint AIR (host/air_starknet.cpp), extension column by the device scans,
 every stage a HIP kernel behind the C ABI - and emits the SAME BYTES: the three trace roots, all six FRI layer roots,
 the 269 + 2 out-of-domain values, the remainder; and, given the reference's proof-of-work nonce (its grinder returns
 whichever valid nonce its parallel search hits first - `find_any`, crypto/src/public_coin/solidity.rs:120-141 - ours
@@ -19,16 +19,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFERENCE = os.path.join(ROOT, "tests", "golden", "reference_array_sum_starknet.proof")
 
 
-@pytest.fixture(scope="module")
-def statement():
+@pytest.fixture(scope="module", params=["host generator", "device generator"])
+def statement(request):
+    """the base trace by the host's generator (host/trace_starknet.cpp, uploaded) or made ON the device from the raw files' bytes
+    (csrc/trace.hip through host/device_trace.hpp): the same proof bytes either way"""
     from sandstorm_amd import backend as be, binary, hostlib, public_input
     from sandstorm_amd.layouts import starknet as sk
     states, memory, spi = starknet_example(17)
-    cols = hostlib.starknet_base_trace(binary.write_register_states(states), binary.write_memory(memory), spi)
-    n = cols[0].shape[0]
-    assert n == 1 << 21
+    n = 1 << 21
     ctx = be.Context(0)
-    base = be.Matrix.from_host(ctx, cols)
+    if request.param == "host generator":
+        cols = hostlib.starknet_base_trace(binary.write_register_states(states), binary.write_memory(memory), spi)
+        assert cols[0].shape[0] == n
+        base = be.Matrix.from_host(ctx, cols)
+    else:
+        import types
+        base = types.SimpleNamespace(cols=hostlib.device_base_trace(ctx, "starknet", binary.write_register_states(states), binary.write_memory(memory), spi))
     air = hostlib.StarknetHostAir(ctx, spi, 21)
     seed = public_input.public_coin_seed(spi, be.COIN_SOLIDITY)
     keep = []
