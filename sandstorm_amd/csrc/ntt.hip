@@ -364,6 +364,13 @@ __device__ __forceinline__ uint32_t tile_gindex(const PassParams &p, uint32_t ti
 template <int MODE>
 __device__ __forceinline__ Fp pass_output(const PassParams &p, const Fl &x, bool product) {
     Fp out;
+#ifdef SS_NTT_ABL_NOCONV     // timing ablation only (wrong results): a pass leaves its limbs as they are - what a 9 x 28-bit format BETWEEN passes would
+    if (!p.final_pass) {     // save at a pass's end (VERDICT r5 "next" 3a), without the ninth word's traffic such a format adds: an upper bound
+        for (int i = 0; i < 8; ++i) out.v[i] = x.l[i];
+        out.v[7] ^= x.l[8];
+        return out;
+    }
+#endif
     if (p.final_pass) {                        // leaving the transform: canonical image (< p)
         out = product ? fp_reduce_once(fl_pack(x)) : fl_to_fp(x);
         if (MODE != MODE_DIT && p.scale_pow2) out = fp_div_pow2(out, p.scale_pow2);
@@ -433,7 +440,15 @@ __device__ __forceinline__ void radix_group(const Tile &t, const TwPlanes &tw, c
         if (from_global) {
             const Fp *sp = src + (mem_index(p, g0) >> p.log_expand);
 #pragma unroll
-            for (int m = 0; m < (1 << G); ++m) x[m] = fl_from_fp(gload(sp + (size_t)m * src_step));
+            for (int m = 0; m < (1 << G); ++m) {
+#ifdef SS_NTT_ABL_NOCONV     // ... and at its start: the 8 words taken as limbs (EVERY pass, the first one too: more than the format would save)
+                const Fp raw = gload(sp + (size_t)m * src_step);
+                for (int i = 0; i < 8; ++i) x[m].l[i] = raw.v[i];
+                x[m].l[8] = raw.v[7] >> 28;
+#else
+                x[m] = fl_from_fp(gload(sp + (size_t)m * src_step));
+#endif
+            }
         } else {
 #pragma unroll
             for (int m = 0; m < (1 << G); ++m) x[m] = lds_load(t, ab ^ am[m]);
