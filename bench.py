@@ -421,13 +421,13 @@ def bench_goldilocks_plain(args, log_steps, rank, local_rank, world, device):
 
 
 def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
-    """--gpus N > 1: ONE proof over the N GPUs of the node (sandstorm_amd/sharded_prover.py): trace columns extended on
-    their owner (column c on rank c % N), point-to-point re-shards into row blocks over RCCL, row hashing / constraint
-    evaluation / DEEP on row blocks, leaf-block sub-trees + root all-gather, composition and DEEP gathers and FRI on rank 0.
-    A step = one whole proof; the time is the max over ranks between two barriers; strong scaling."""
+    """--gpus N > 1: ONE proof over the N GPUs of the node by the C++ host's sharded prover (sandstorm_amd/host/sharded.cpp): trace
+    columns extended on their owner (column c on rank c % N), point-to-point re-shards into row blocks over RCCL, row hashing /
+    constraint evaluation / DEEP on row blocks, leaf-block sub-trees + root all-gather, single-vector transforms and the large FRI
+    layers spread over the ranks.  A step = one whole proof; the time is the max over ranks between two
+    barriers; strong scaling."""
     from sandstorm_amd import backend as be, extension, hostlib
-    from sandstorm_amd.prover import Claim, ProofOptions
-    from sandstorm_amd.sharded_prover import Comm, ShardedProver
+    from sandstorm_amd.prover import ProofOptions
     L, pi = _sample_statement(layout, log_steps)
     n = 16 << log_steps
     # ONE stream for torch's tensor ops, the collectives and the C ABI's kernels (torch's default stream has handle 0, which
@@ -435,16 +435,11 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     stream = torch.cuda.Stream(device)
     torch.cuda.set_stream(stream)
     ctx = be.Context(local_rank, stream=stream.cuda_stream)
-    # the C++ host's AIR (tables on the device, program lowered in C++ per proof) behind the Python driver's Air interface
+    # the C++ host's AIR (tables on the device, program lowered in C++ per proof)
     host_air = (hostlib.StarknetHostAir if layout == "starknet" else hostlib.RecursiveHostAir)(ctx, pi, log_steps + 4, 1)
     air = hostlib.prover_air(host_air)
     nb, ne = air.num_base_columns, air.num_extension_columns
-    if layout == "recursive":
-        tree, coin = be.FriendlyMerkleTree, be.COIN_CAIRO
-    else:
-        tree, coin = be.LeafVariantMerkleTree, be.COIN_SOLIDITY
-    comm = Comm(device=device)
-    prover = ShardedProver(ctx, Claim(air, tree, coin), comm, ProofOptions())
+    coin = be.COIN_CAIRO if layout == "recursive" else be.COIN_SOLIDITY
     mine = {c: synth_columns(device, 1, log_steps + 4, seed=0x53414E44 + c)[0] for c in range(nb) if c % world == rank}
     my_ext = [c for c in range(nb, nb + ne) if c % world == rank]
     aux = synth_columns(device, 5 if layout == "recursive" else 3, log_steps + 4, seed=0x7E57) if my_ext else None
@@ -463,7 +458,8 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
         dist.barrier()
         torch.cuda.synchronize()
     comm_check = None
-    if args.sharded_host == "cpp":
+    transport = "a group of one" if world == 1 else "RCCL through ss_comm_*"
+    if True:
         # the C++ host's sharded prover (sandstorm_amd/host/sharded.cpp) over RCCL through the C ABI (ss_comm_*): rank 0 makes the
         # communicator's id, torch.distributed only hands it out
         if world == 1:                              # a group of one needs no communicator
@@ -490,8 +486,10 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
                     os._exit(3)
             threading.Thread(target=watchdog, daemon=True).start()
             # RCCL between more than one GPU has never run where this was developed (one GPU per box): if the communicator cannot be
-            # made on ANY rank (library not found, ncclCommInitRank refused), every rank falls back to the Python driver over
-            # torch.distributed - same proof bytes, same kernels - and the JSON line says so
+            # made on ANY rank (library not found, ncclCommInitRank refused) or fails its self check, every rank runs the SAME driver
+            # over the caller's own collectives instead (ssh_callback_group_create: torch.distributed's gloo group, device memory
+            # staged through the host - how the CPU suite runs it as 2 / 4 / 8 processes): same proof bytes, same kernels, slower
+            # exchanges - and the JSON line says so
             group, group_err = None, uid_err
             if uid is not None:
                 try:
@@ -520,23 +518,22 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
             if int(bad.item()):
                 if rank == 0 or group_err:
                     sys.stderr.write("bench.py: rank %d: the C++ host's RCCL group did not come up or failed its self check on %d rank(s) (%s): "
-                                     "falling back to --sharded-host python\n" % (rank, int(bad.item()), group_err))
-                args.sharded_host, args.sharded_host_fallback = "python", group_err or "another rank failed"
+                                     "the same driver over torch.distributed's gloo group (host-staged exchanges)\n" % (rank, int(bad.item()), group_err))
+                args.transport_fallback = group_err or "another rank failed"
                 if group is not None:
                     group.close()
-                group = None
-    if args.sharded_host == "cpp":
-        tree_kind, n_friendly = (be.TREE_FRIENDLY, 22) if layout == "recursive" else (be.TREE_KECCAK_M20, 0)
-        wire_proof = [None]
+                group = hostlib.torch_dist_group(dist.new_group(backend="gloo"))
+                transport = "the caller's collectives (gloo, host-staged): the RCCL group failed"
+                comm_check = dict(comm_check or {}, fallback_ok=True, fallback_exchange_gbps=hostlib.group_self_check(ctx, rank, world, group, 1 << 20))
+    tree_kind, n_friendly = (be.TREE_FRIENDLY, 22) if layout == "recursive" else (be.TREE_KECCAK_M20, 0)
+    wire_proof = [None]
 
-        def prove_once():
-            wire_proof[0] = hostlib.prove_sharded(ctx, host_air, tree_kind, n_friendly, coin, seed, rank, world, group, mine, log_steps + 4,
-                                                  build_extension, ProofOptions())
-            return wire_proof[0]
-    else:
-        prove_once = lambda: prover.prove(seed, mine, build_extension, n)
+    def prove_once():
+        wire_proof[0] = hostlib.prove_sharded(ctx, host_air, tree_kind, n_friendly, coin, seed, rank, world, group, mine, log_steps + 4,
+                                              build_extension, ProofOptions())
+        return wire_proof[0]
     proof = prove_once()
-    if args.sharded_host == "cpp" and rank == 0:
+    if rank == 0:
         from sandstorm_amd import wire as wire_format
         proof = wire_format.parse(proof, tree_kind)
 
@@ -592,17 +589,14 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
                                        "rows), leaf-block sub-trees + root all-gather, " % (world, world, max(o for _, o in air.mask) << 1))
                                       + ("extension columns / composition interpolation + extension / DEEP extension each ONE transform over "
                                          "the ranks (two equal-split all-to-alls per transform), FRI layers above 2^21 values folded and "
-                                         "committed by all ranks, the rest on rank 0" if args.sharded_host == "cpp" else
-                                         "composition interpolation / DEEP extension / FRI on rank 0"),
+                                         "committed by all ranks, the rest on rank 0"),
                        "air": "the REAL %s AIR (%d mask cells) on synthetic columns" % (layout, len(air.mask)),
                        "claim": "CairoVerifierClaim (Blake2s+Pedersen-22 tree, Cairo coin)" if layout == "recursive"
                                 else "EthVerifierClaim (Keccak-masked-20 tree, Solidity coin)",
                        "proof_options": "65 queries, blowup 2, 16 PoW bits, FRI fold 8, <=16 remainder coeffs",
-                       "host": ("C++ host (sandstorm_amd/host/sharded.cpp) over the C ABI, " + ("a group of one" if world == 1 else "RCCL through ss_comm_*"))
-                               if args.sharded_host == "cpp" else
-                               "Python host (sandstorm_amd/sharded_prover.py) over the C ABI + torch.distributed (nccl = RCCL)",
+                       "host": "C++ host (sandstorm_amd/host/sharded.cpp) over the C ABI, " + transport,
                        "fri_layers": len(proof.fri_layers) if proof is not None else None,
-                       "sharded_host_fallback": getattr(args, "sharded_host_fallback", None),
+                       "transport_fallback": getattr(args, "transport_fallback", None),
                        "comm_self_check": comm_check,
                        "note": "python bench.py --gpus N --mode replicas runs N independent proofs instead (weak scaling)"},
         })
@@ -1070,13 +1064,15 @@ def main():
                     help="--workload goldilocks_plain_*: the host above the C ABI - host/goldilocks_prover.cpp (ssh_gl_prove) or "
                          "sandstorm_amd/goldilocks.py; both write the same proof")
     ap.add_argument("--sharded-host", default="cpp", choices=["python", "cpp"],
-                    help="--mode shard: the driver above the C ABI - the C++ host's sharded.cpp over RCCL (ss_comm_*; default: every "
-                         "single-vector transform and the large FRI layers spread over the ranks), or sandstorm_amd/sharded_prover.py "
-                         "over torch.distributed (the older distribution: composition, DEEP extension and FRI on rank 0)")
+                    help="--mode shard: the driver above the C ABI is the C++ host's sharded.cpp (RCCL through ss_comm_*; every single-vector "
+                         "transform and the large FRI layers spread over the ranks).  `python` named the round-3 Python driver, retired in "
+                         "round 6 (one distribution in the tree): it is refused")
     ap.add_argument("--mode", default="auto", choices=["auto", "shard", "replicas"],
                     help="N > 1 GPUs: shard = ONE proof over the N GPUs (column-sharded LDE, row-block hashing / constraints / DEEP, "
                          "RCCL point-to-point re-shards; strong scaling) - the default; replicas = one independent proof per GPU (weak scaling)")
     args = ap.parse_args()
+    if args.sharded_host != "cpp":
+        sys.exit("--sharded-host python: the Python sharded driver was retired in round 6; the one distribution is host/sharded.cpp (the default)")
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

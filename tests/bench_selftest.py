@@ -2,8 +2,7 @@
 exercised WITHOUT a GPU (tests/test_bench_launcher.py).  The ranks are gloo processes running what the real run's ranks run by
 default - the C++ host's sharded prover (sandstorm_amd/host/sharded.cpp, `--sharded-host cpp`), group self check first - with the
 device code on the CPU (tests/hipemu: test infrastructure) and the driver's CallbackTransport over gloo where the MI355X run has
-RCCL; `--sharded-host python`: sandstorm_amd/sharded_prover.py over the CPU oracle, as tests/dist_prove_worker.py.  The line it
-prints is labelled as what it is: not a measurement of anything."""
+RCCL.  The line it prints is labelled as what it is: not a measurement of anything."""
 import os
 
 import torch
@@ -16,37 +15,24 @@ def run(args, rank, world, timed_steps, emit):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     comm_check = None
-    if args.sharded_host == "cpp":
-        os.environ.setdefault("HIPEMU_THREADS", str(max(1, (os.cpu_count() or 1) // world)))
-        os.environ.setdefault("SSH_FRI_SPREAD_MIN_LOG", "6")       # the ranks fold this small proof's first FRI layers together, as they do 2^25-value ones
-        from sandstorm_amd import _lib
-        _lib.LIB_PATH = os.environ.get("SS_TEST_HIPEMU_LIB", os.path.join(ROOT, "tests", "hipemu", "_build", "libsandstorm_hipemu.so"))
-        from sandstorm_amd import backend as be, hostlib
-        from tests import mini_air_host, sharded_host_cases as cases
-        mini_air_host.register()
-        make, _ = cases.mini_case(9, 4)
-        ctx = be.Context(0)
-        air, tree_kind, nf, coin_kind, seed, mine, log_n, ext, opt = make(world)(rank, ctx)
-        group = hostlib.torch_dist_group()
-        comm_check = {"ok": True, "exchange_gbps": hostlib.group_self_check(ctx, rank, world, group, 1 << 16)}
-        proofs = []
+    os.environ.setdefault("HIPEMU_THREADS", str(max(1, (os.cpu_count() or 1) // world)))
+    os.environ.setdefault("SSH_FRI_SPREAD_MIN_LOG", "6")       # the ranks fold this small proof's first FRI layers together, as they do 2^25-value ones
+    from sandstorm_amd import _lib
+    _lib.LIB_PATH = os.environ.get("SS_TEST_HIPEMU_LIB", os.path.join(ROOT, "tests", "hipemu", "_build", "libsandstorm_hipemu.so"))
+    from sandstorm_amd import backend as be, hostlib
+    from tests import mini_air_host, sharded_host_cases as cases
+    mini_air_host.register()
+    make, _ = cases.mini_case(9, 4)
+    ctx = be.Context(0)
+    air, tree_kind, nf, coin_kind, seed, mine, log_n, ext, opt = make(world)(rank, ctx)
+    group = hostlib.torch_dist_group()
+    comm_check = {"ok": True, "exchange_gbps": hostlib.group_self_check(ctx, rank, world, group, 1 << 16)}
+    proofs = []
 
-        def step():
-            proofs.append(hostlib.prove_sharded(ctx, air, tree_kind, nf, coin_kind, seed, rank, world, group, mine, log_n, ext, opt))
-        last = lambda: proofs[-1]
-        what = "the C++ host's sharded prover over the emulated device code, CallbackTransport over gloo"
-    else:
-        from tests import dist_prove_worker as w
-        n, cols, claim, opt, ext, seed, leaf_hash = w.mini(9, 4)
-        prover = w.ShardedProver(w.CpuContext(), claim, w.Comm(device=torch.device("cpu")), opt)
-        mine = {c: w.tensor(v) for c, v in cols.items() if c % world == rank}
-        proofs = []
-
-        def step():
-            proofs.append(prover.prove(seed, mine, lambda ch: ext(ch, lambda c: c % world == rank), n))
-        last = lambda: w.wire.serialize(w.wire.from_proof(proofs[-1], leaf_hash))
-        what = "the CPU oracle behind the Python sharded driver"
-
+    def step():
+        proofs.append(hostlib.prove_sharded(ctx, air, tree_kind, nf, coin_kind, seed, rank, world, group, mine, log_n, ext, opt))
+    last = lambda: proofs[-1]
+    what = "the C++ host's sharded prover over the emulated device code, CallbackTransport over gloo"
     def all_max(dt):
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -62,9 +48,8 @@ def run(args, rank, world, timed_steps, emit):
               "proof_is_the_single_device_proof": same,
               "config": {"workload": "selftest mini:9:4", "sharded_host": args.sharded_host, "comm_self_check": comm_check}})
     dist.barrier()
-    if args.sharded_host == "cpp":
-        group.close()
-        air.close()
-        del mine, ext
-        ctx.close()
+    group.close()
+    air.close()
+    del mine, ext
+    ctx.close()
     dist.destroy_process_group()

@@ -1,6 +1,6 @@
 """`python bench.py --gpus N` as the driver types it - no launcher around it.  bench.py starts its own N ranks
 under torch.distributed.run, rank 0 prints the ONE JSON line, the exit code is the ranks'.  Here on gloo ranks with the
-CPU oracle behind the sharded driver (SS_BENCH_SELFTEST=1: tests/bench_selftest.py), since this container has no GPU; and the
+device code on the CPU behind the C++ sharded host (SS_BENCH_SELFTEST=1: tests/bench_selftest.py), since this container has no GPU; and the
 refusals: fewer devices than ranks, a group whose size is not --gpus."""
 import json
 import os
@@ -28,11 +28,11 @@ def emulated_library():
     return out.stdout.strip().splitlines()[-1]
 
 
-@pytest.mark.parametrize("gpus,host", [(2, "cpp"), (4, "cpp"), (8, "cpp"), (2, "python")])
-def test_bench_launches_its_own_ranks(gpus, host, emulated_library):
-    """the default path of `bench.py --gpus N` - the C++ sharded host, one PROCESS per rank, group self check before the warm-up - and
-    the Python driver behind `--sharded-host python`"""
-    out = run_bench(["--gpus", str(gpus), "--steps", "2", "--warmup", "1"] + (["--sharded-host", host] if host != "cpp" else []),
+@pytest.mark.parametrize("gpus", [2, 4, 8])
+def test_bench_launches_its_own_ranks(gpus, emulated_library):
+    """the path of `bench.py --gpus N` - the C++ sharded host, one PROCESS per rank, group self check before the warm-up"""
+    host = "cpp"
+    out = run_bench(["--gpus", str(gpus), "--steps", "2", "--warmup", "1"],
                     {"SS_BENCH_SELFTEST": "1", "OMP_NUM_THREADS": "1", "SS_TEST_HIPEMU_LIB": emulated_library})
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -44,6 +44,12 @@ def test_bench_launches_its_own_ranks(gpus, host, emulated_library):
     if host == "cpp":
         assert line["config"]["comm_self_check"]["ok"] is True and line["config"]["comm_self_check"]["exchange_gbps"] > 0
     assert line["value"] > 0 and abs(line["ms_per_step"] - 1e3 * line["value"]) < 1e-6
+
+
+def test_the_retired_python_driver_is_refused():
+    """one distribution in the tree (VERDICT r5 #8): `--sharded-host python` names nothing any more"""
+    out = run_bench(["--gpus", "2", "--sharded-host", "python"], {"SS_BENCH_SELFTEST": "1"})
+    assert out.returncode != 0 and "retired" in out.stderr and out.stdout.strip() == ""
 
 
 def test_bench_refuses_more_ranks_than_devices():

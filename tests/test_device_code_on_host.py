@@ -98,12 +98,12 @@ def test_whole_proofs(emulated_library):
     run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_prove.py"])
 
 
-def test_one_proof_over_several_ranks(emulated_library):
-    """tests/hipemu/extra_sharded.py: the sharded driver (torch.distributed / gloo) with the device code on every rank writes the
-    single-device proof byte for byte - the reference's example with the real recursive AIR on 2 ranks, the mini AIR on 4"""
+def test_row_block_entry_points(emulated_library):
+    """tests/test_gpu_row_blocks.py: the row-block entry points against the whole-domain ones (halo, refusal, DEEP blocks + extension); ONE
+    proof over several ranks is test_cpp_sharded_prover_over_ranks_as_threads / _as_processes below"""
     heavy()
-    out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_sharded.py", "tests/hipemu/extra_sharded.py", "-k", "row_block_forms or (device_code_on_every_rank and (example-2 or 4-4))"])
-    assert "3 passed" in out, out[-500:]                      # + the row-block entry points against the whole-domain ones (halo, refusal, DEEP blocks + extension)
+    out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_row_blocks.py"])
+    assert "1 passed" in out, out[-500:]
 
 
 def test_entry_points_refuse_what_they_cannot_serve(emulated_library):

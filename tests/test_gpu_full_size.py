@@ -88,21 +88,6 @@ def test_starknet_2p20_steps_real_statement_proves_and_verifies(proof_2p20):
     assert len(proof_2p20) > 100_000
 
 
-def test_sharded_driver_writes_the_same_proof_at_2p20_steps(proof_2p20, tmp_path):
-    """the multi-GPU driver (sandstorm_amd/sharded_prover.py: row-block quotient / DEEP / hashing, leaf-block sub-trees) on
-    one rank over RCCL, same statement, same size: the C++ single-device host's proof, byte for byte"""
-    from tests.test_gpu_sharded import run_sharded_gpu
-    assert run_sharded_gpu(1, "starknet:20", tmp_path, "nccl", timeout=1500) == proof_2p20
-
-
-def test_sharded_driver_two_ranks_real_starknet_air(tmp_path):
-    """two ranks (sharing this box's GPU, gloo staged through the host) on the real starknet AIR at 2^18 steps: the
-    wrap-around halo of 2 * 33 158 rows crosses the rank boundary"""
-    from tests.test_gpu_sharded import run_sharded_gpu
-    want = _prove_and_verify(18, python_verifier=False)
-    assert run_sharded_gpu(2, "starknet:18", tmp_path, "gloo", timeout=1500) == want
-
-
 def test_cpp_sharded_host_two_ranks_at_2p20_steps_real_starknet_air(proof_2p20):
     """the C++ host's sharded prover (host/sharded.cpp) at BASELINE configs[2]'s size on two ranks - threads of this process, each
     with its own context on this box's GPU: column-owned base LDE and re-shard with the 66 316-row halo, the extension column, the

@@ -150,21 +150,6 @@ def test_recursive_2p16_steps_cairo_verifier_claim(proof_2p16):
     assert len(proof_2p16) > 100_000
 
 
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
-def test_sharded_driver_writes_the_same_proof_at_2p16_steps(proof_2p16, world, backend, tmp_path):
-    """the multi-GPU driver on the same statement: sub-trees with 22 - log2(ranks) Pedersen layers, the top levels merged on
-    the hosts, `MixedMerkleDigest` tags carried through the openings - the single-device proof byte for byte"""
-    from tests.test_gpu_sharded import run_sharded_gpu
-    assert run_sharded_gpu(world, "recursive:16", tmp_path, backend, timeout=1500) == proof_2p16
-
-
-def test_recursive_2p20_steps_cairo_verifier_claim():
-    """the north-star's configuration at full size: 2^24 rows x 10 columns, 2^25 leaves - Blake2s levels at depths 22-24,
-    Pedersen above, both digest variants on the wire"""
-    raw = prove_and_verify(20)
-    assert len(raw) > 200_000
-
-
 @pytest.mark.parametrize("log_steps", [14, 16])
 def test_files_to_proof_in_one_call_writes_the_same_bytes(log_steps, request):
     """hostlib.prove_files (host_capi.cpp ssh_prove_files; what bench.py's end_to_end leg times): the generator on a thread of its own

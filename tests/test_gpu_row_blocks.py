@@ -1,19 +1,12 @@
-"""The single-proof multi-GPU path with the real kernels:
-  * the row-block entry points (ss_eval_quotient_rows, ss_deep_compose_rows + ss_deep_extend) give, block by block, what
-    the whole-domain entry points give - bit for bit, on the real recursive program, wrap-around halo included;
-  * sandstorm_amd/sharded_prover.py on 1 rank (RCCL backend) and on 2 and 4 ranks that share this box's one GPU
-    (gloo, staged through the host) writes the single-device proofs under tests/golden/, byte for byte."""
-import os
-import subprocess
-import sys
-
+"""The row-block entry points of the single-proof multi-GPU path (host/sharded.cpp drives them): ss_eval_quotient_rows,
+ss_deep_compose_rows + ss_deep_extend give, block by block, what the whole-domain entry points give - bit for bit, on the real
+recursive program, wrap-around halo included."""
 import numpy as np
 import pytest
 
 from tests.test_gpu_real_quotient import _Prog, _rand
 from tests.test_layout_recursive import load_run
 from tests.test_layout_starknet import CHALLENGES, P
-from tests.test_sharded import GOLD, ROOT, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -94,23 +87,3 @@ def test_row_block_forms_are_the_whole_domain_forms(oracle):
         finally:
             os.environ.pop("SS_DEEP_RATIONAL_MIN_LOG", None)
     ctx.close()
-
-
-def run_sharded_gpu(world, case, tmp_path, backend="gloo", timeout=900):
-    out_file = str(tmp_path / "proof.bin")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_prove_worker_gpu.py"),
-           case, out_file, backend]
-    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=timeout)
-    assert out.returncode == 0 and "SHARDED_PROOF_WRITTEN" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
-    with open(out_file, "rb") as f:
-        return f.read()
-
-
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
-@pytest.mark.parametrize("name,case", [("mini_proof_eth_log9.bin", "mini:9:4"), ("mini_proof_eth_log5_nolayers.bin", "mini:5:32"),
-                                       ("array_sum_recursive_eth.proof", "example")])
-def test_sharded_prover_on_the_device(world, backend, name, case, tmp_path):
-    with open(os.path.join(GOLD, name), "rb") as f:
-        want = f.read()
-    assert run_sharded_gpu(world, case, tmp_path, backend) == want

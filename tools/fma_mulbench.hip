@@ -8,7 +8,7 @@
 // and the halves are accumulated as the doubles' BIT PATTERNS in 64-bit integer columns (the exponent patterns are subtracted once
 // per column).  p = 2^251 + 17 2^192 + 1 in this radix is (1, 0, 0, 17 2^36, 2^43) with p = 1 mod 2^52, so a Montgomery step is
 // m = -t_i mod 2^52 and t += m p 2^(52 i) with m p3 and m p4 as shifts (R = 2^260).  Needs round-toward-zero for doubles: the wave's
-// MODE register is set at kernel start (gfx9 has no per-instruction rounding).
+// MODE register is set at kernel start (gfx9 has no per-instruction rounding) and kept from the compiler (set_round_toward_zero_f64).
 //
 // Counted per product: 25 partial products x (2 FMA + 1 subtraction + 2 64-bit integer additions) + 5 reduction steps x ~12 64-bit
 // integer operations + carries + the way back to doubles ~ 210 instructions, nearly all on half-rate pipes (FMA f64 4.31 cycles,
@@ -28,10 +28,18 @@ using namespace ss;
 constexpr int ITERS = 256;
 struct F52 { double v[5]; };                 // integer limbs in [0, 2^52), value sum v[i] 2^(52 i), Montgomery form with R = 2^260
 
-__device__ __forceinline__ void set_round_toward_zero_f64() {
-    // HW_REG_MODE (id 1), FP_ROUND bits 3:2 (double / half precision) = 3: round toward zero
-    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);
+// HW_REG_MODE, FP_ROUND bits 3:2 (double / half precision) = 3: round toward zero.  The compiler's mode pass puts the register back
+// to round-to-nearest in front of every double-precision instruction IT emits (a first version, with __builtin_fma, came out of the
+// compiler with `s_setreg hwreg(HW_REG_MODE, 2, 2), 0` before the first product and failed the check on every operand pair whose
+// low half rounds up), so every double-precision operation of this file is inline assembly the pass does not see, and the lane index
+// every load depends on goes through the instruction that sets the mode.
+__device__ __forceinline__ int set_round_toward_zero_f64(int x) {
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3" : "+v"(x));
+    return x;
 }
+__device__ __forceinline__ double fma_rz(double a, double b, double c) { double r; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ double add_f64(double a, double b) { double r; asm("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double sub_f64(double a, double b) { double r; asm("v_add_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ u64 bits_of(double x) { return (u64)__double_as_longlong(x); }
 __device__ __forceinline__ double double_of(u64 b) { return __longlong_as_double((long long)b); }
 
@@ -46,8 +54,8 @@ __device__ __forceinline__ F52 f52_mul(const F52 &a, const F52 &b) {
     for (int i = 0; i < 5; ++i)
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const double h = __builtin_fma(a.v[i], b.v[j], C1);
-            const double l = __builtin_fma(a.v[i], b.v[j], C2 - h);
+            const double h = fma_rz(a.v[i], b.v[j], C1);
+            const double l = fma_rz(a.v[i], b.v[j], sub_f64(C2, h));
             t[i + j + 1] += bits_of(h);
             t[i + j] += bits_of(l);
         }
@@ -73,7 +81,7 @@ __device__ __forceinline__ F52 f52_mul(const F52 &a, const F52 &b) {
     for (int i = 0; i < 5; ++i) {
         const u64 x = t[5 + i] + c;
         c = x >> 52;
-        r.v[i] = double_of(LO_PAT | (x & MASK)) - 0x1p52;  // the integer as a double
+        r.v[i] = sub_f64(double_of(LO_PAT | (x & MASK)), 0x1p52);  // the integer as a double
     }
     // (c is zero: the result is below 2 p < 2^253)
     return r;
@@ -85,9 +93,9 @@ __device__ __forceinline__ F52 f52_add(const F52 &x, const F52 &y) {
     u64 c = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        const u64 s = (bits_of(x.v[i] + 0x1p52) & MASK) + (bits_of(y.v[i] + 0x1p52) & MASK) + c;
+        const u64 s = (bits_of(add_f64(x.v[i], 0x1p52)) & MASK) + (bits_of(add_f64(y.v[i], 0x1p52)) & MASK) + c;
         c = s >> 52;
-        r.v[i] = double_of(LO_PAT | (s & MASK)) - 0x1p52;
+        r.v[i] = sub_f64(double_of(LO_PAT | (s & MASK)), 0x1p52);
     }
     return r;
 }
@@ -98,11 +106,11 @@ __device__ __forceinline__ F52 f52_sub4p(const F52 &x, const F52 &y) {         /
     long long c = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        const long long s = (long long)(bits_of(x.v[i] + 0x1p52) & MASK) - (long long)(bits_of(y.v[i] + 0x1p52) & MASK) + (long long)P4[i] + c;
+        const long long s = (long long)(bits_of(add_f64(x.v[i], 0x1p52)) & MASK) - (long long)(bits_of(add_f64(y.v[i], 0x1p52)) & MASK) + (long long)P4[i] + c;
         c = s >> 52;
-        r.v[i] = double_of(LO_PAT | ((u64)s & MASK)) - 0x1p52;
+        r.v[i] = sub_f64(double_of(LO_PAT | ((u64)s & MASK)), 0x1p52);
     }
-    r.v[4] += (double)(c << 52);                                                // the top limb keeps what is above (values < 8 p < 2^255: < 2^47 in limb 4)
+    // (c is zero: the values are below 8 p < 2^255, limb 4 below 2^47)
     return r;
 }
 
@@ -112,41 +120,59 @@ __device__ __forceinline__ F52 f52_load(const u64 *p) {       // 4 x u64 (an int
     const u64 l[5] = {w0 & MASK, ((w0 >> 52) | (w1 << 12)) & MASK, ((w1 >> 40) | (w2 << 24)) & MASK, ((w2 >> 28) | (w3 << 36)) & MASK, w3 >> 16};
     F52 r;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) r.v[i] = double_of(LO_PAT | l[i]) - 0x1p52;
+    for (int i = 0; i < 5; ++i) r.v[i] = sub_f64(double_of(LO_PAT | l[i]), 0x1p52);
     return r;
 }
 __device__ __forceinline__ void f52_store(u64 *p, const F52 &x) {
     const u64 MASK = (1ull << 52) - 1;
     u64 l[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) l[i] = i < 4 ? bits_of(x.v[i] + 0x1p52) & MASK : (u64)x.v[4];
+    for (int i = 0; i < 5; ++i) l[i] = bits_of(add_f64(x.v[i], 0x1p52)) & MASK;
     p[0] = l[0] | (l[1] << 52); p[1] = (l[1] >> 12) | (l[2] << 40); p[2] = (l[2] >> 24) | (l[3] << 28); p[3] = (l[3] >> 36) | (l[4] << 16);
 }
 
 __global__ __launch_bounds__(256) void k_f52_check(const u64 *a, const u64 *b, u64 *out, int n) {
-    set_round_toward_zero_f64();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = set_round_toward_zero_f64(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
     f52_store(out + 4 * i, f52_mul(f52_load(a + 4 * i), f52_load(b + 4 * i)));
 }
 __global__ __launch_bounds__(256) void k_f52_mul(const u64 *in, u64 *out) {
-    set_round_toward_zero_f64();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = set_round_toward_zero_f64(blockIdx.x * blockDim.x + threadIdx.x);
     F52 x0 = f52_load(in + 16 * i), x1 = f52_load(in + 16 * i + 4), x2 = f52_load(in + 16 * i + 8), x3 = f52_load(in + 16 * i + 12);
     const F52 y = f52_load(in + 4 * ((4 * i + 5) & 1023));
     for (int it = 0; it < ITERS; ++it) { x0 = f52_mul(x0, y); x1 = f52_mul(x1, y); x2 = f52_mul(x2, y); x3 = f52_mul(x3, y); }
     f52_store(out + 4 * i, f52_add(f52_add(x0, x1), f52_add(x2, x3)));
 }
+// x - q p with q = floor(x / 2^251) - 1 (or 0): brings a lazy sum back below 3 p, limbs normalised (what fl_weak_reduce is to the 9 x 28-bit form)
+__device__ __forceinline__ F52 f52_weak(const F52 &x) {
+    const u64 LO_PAT = 0x433ull << 52, MASK = (1ull << 52) - 1;
+    u64 l[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) l[i] = bits_of(add_f64(x.v[i], 0x1p52)) & MASK;
+    u64 q = l[4] >> 43;
+    q -= q != 0;
+    const long long sub[5] = {(long long)q, 0, 0, (long long)(q * (17ull << 36)), (long long)(q << 43)};      // q p, limb by limb (q < 2^9: every term below 2^52)
+    F52 r;
+    long long c = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const long long t = (long long)l[i] - sub[i] + c;
+        c = t >> 52;
+        r.v[i] = sub_f64(double_of(LO_PAT | ((u64)t & MASK)), 0x1p52);
+    }
+    return r;
+}
+// the same radix-4 style loop as k_fl_bfly: 4 products, 4 sums, 4 differences per round, the lazy values brought back every second round
 __global__ __launch_bounds__(256) void k_f52_bfly(const u64 *in, u64 *out) {
-    set_round_toward_zero_f64();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = set_round_toward_zero_f64(blockIdx.x * blockDim.x + threadIdx.x);
     F52 x0 = f52_load(in + 16 * i), x1 = f52_load(in + 16 * i + 4), x2 = f52_load(in + 16 * i + 8), x3 = f52_load(in + 16 * i + 12);
     const F52 w = f52_load(in + 4 * ((4 * i + 5) & 1023));
-    for (int it = 0; it < ITERS; ++it) {                    // (sums are multiplied next: a product's result is below 2 p whatever its operands' size below 2^256)
+    for (int it = 0; it < ITERS; ++it) {                    // (a product is below 2 p whatever its operands below 2^260; sums grow by < 2 p, differences by < 4 p per round)
         F52 t = f52_mul(x1, w); x1 = f52_sub4p(x0, t); x0 = f52_add(x0, t);
         t = f52_mul(x3, w); x3 = f52_sub4p(x2, t); x2 = f52_add(x2, t);
-        t = f52_mul(x2, w); x2 = f52_mul(f52_sub4p(x0, t), w); x0 = f52_mul(f52_add(x0, t), w);
-        t = f52_mul(x3, w); x3 = f52_mul(f52_sub4p(x1, t), w); x1 = f52_mul(f52_add(x1, t), w);
+        t = f52_mul(x2, w); x2 = f52_sub4p(x0, t); x0 = f52_add(x0, t);
+        t = f52_mul(x3, w); x3 = f52_sub4p(x1, t); x1 = f52_add(x1, t);
+        if ((it & 1) == 1) { x0 = f52_weak(x0); x1 = f52_weak(x1); x2 = f52_weak(x2); x3 = f52_weak(x3); }
     }
     f52_store(out + 4 * i, f52_add(f52_add(x0, x1), f52_add(x2, x3)));
 }
@@ -237,8 +263,7 @@ int main() {
     const double fl_chain = time_it("fl_mul   9 x 28-bit, chain", [&] { hipLaunchKernelGGL(k_fl_mul, grid, block, 0, 0, (const Fp *)din, (Fp *)dres); }, 4.0 * ITERS, "mulmod");
     const double f52_chain = time_it("f52_mul  5 x 52-bit FMA, chain", [&] { hipLaunchKernelGGL(k_f52_mul, grid, block, 0, 0, (const u64 *)din, dres); }, 4.0 * ITERS, "mulmod");
     const double fl_bfly = time_it("fl   butterflies", [&] { hipLaunchKernelGGL(k_fl_bfly, grid, block, 0, 0, (const Fp *)din, (Fp *)dres); }, 4.0 * ITERS, "butterfly");
-    // (the FMA butterfly loop multiplies its sums once more per round to bring them back below 2 p: 8 products per 4 butterflies)
-    const double f52_bfly = time_it("f52  butterflies (8 products / 4)", [&] { hipLaunchKernelGGL(k_f52_bfly, grid, block, 0, 0, (const u64 *)din, dres); }, 4.0 * ITERS, "butterfly");
+    const double f52_bfly = time_it("f52  butterflies", [&] { hipLaunchKernelGGL(k_f52_bfly, grid, block, 0, 0, (const u64 *)din, dres); }, 4.0 * ITERS, "butterfly");
     printf("FMA form / 9 x 28-bit form: chain %.2f x, butterflies %.2f x  (the bar for a plan was 1.2 x as a butterfly)\n", f52_chain / fl_chain, f52_bfly / fl_bfly);
     return 0;
 }
