@@ -83,5 +83,12 @@ fp_t fp_from_be_bytes_reduce(const uint8_t in[32]) {
     return fp_from_canonical(c);
 }
 
+/* bench.py's cpu_baseline leg: `iters` dependent Montgomery products on the calling core -> the last value (so that nothing is
+ * optimised away); the caller times it.  What the port's products cost, to be read beside ark-ff's (the reference's field). */
+fp_t or_mulmod_chain(fp_t x, fp_t y, uint64_t iters) {
+    for (uint64_t i = 0; i < iters; ++i) x = fp_mul(x, y);
+    return x;
+}
+
 void or_pedersen_init(void);
 void or_init(void) { fp_init(); or_pedersen_init(); }

@@ -58,26 +58,32 @@ static inline fp_t fp_sub(fp_t a, fp_t b) {
 }
 static inline fp_t fp_neg(fp_t a) { fp_t z = {{0,0,0,0}}; return fp_sub(z, a); }
 
-/* Montgomery product a*b*R^-1 mod p (CIOS). */
+/* Montgomery product a*b*R^-1 mod p: the 4 x 4 schoolbook product, then four reduction steps that use the prime's shape -
+ * p = 1 + P3 2^192 and -p^-1 = -1 mod 2^64, so a step is m = -t_i, t += m (limb i becomes zero) and t += m P3 2^(64 (i + 3)):
+ * 20 64 x 64 multiplications where the generic CIOS loop (rounds 1-5) did 32.  The same function, value for value (Montgomery
+ * reduction has one canonical result): every known-answer test of oracle/README.md holds it. */
 static inline fp_t fp_mul(fp_t a, fp_t b) {
-    uint64_t t[6] = {0,0,0,0,0,0};
+    uint64_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 4; ++i) {
         u128 c = 0;
         for (int j = 0; j < 4; ++j) {
-            c += (u128)a.l[j] * b.l[i] + t[j];
-            t[j] = (uint64_t)c; c >>= 64;
+            c += (u128)a.l[j] * b.l[i] + t[i + j];
+            t[i + j] = (uint64_t)c; c >>= 64;
         }
-        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
-        uint64_t m = t[0] * FP_INV;
-        c = (u128)m * FP_P[0] + t[0]; c >>= 64;
-        for (int j = 1; j < 4; ++j) {
-            c += (u128)m * FP_P[j] + t[j];
-            t[j-1] = (uint64_t)c; c >>= 64;
-        }
-        c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+        t[i + 4] = (uint64_t)c;
     }
-    fp_t r = {{t[0], t[1], t[2], t[3]}};
-    if (t[4] || fp_geq_p(r.l)) fp_sub_p(r.l);
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t m = 0 - t[i];
+        const u128 mp = (u128)m * FP_P[3];
+        u128 c = ((u128)t[i] + m) >> 64;
+        c += t[i + 1]; t[i + 1] = (uint64_t)c; c >>= 64;
+        c += t[i + 2]; t[i + 2] = (uint64_t)c; c >>= 64;
+        c += (u128)t[i + 3] + (uint64_t)mp; t[i + 3] = (uint64_t)c; c >>= 64;
+        c += (u128)t[i + 4] + (uint64_t)(mp >> 64); t[i + 4] = (uint64_t)c; c >>= 64;
+        for (int k = i + 5; k < 9; ++k) { c += t[k]; t[k] = (uint64_t)c; c >>= 64; }
+    }
+    fp_t r = {{t[4], t[5], t[6], t[7]}};
+    if (t[8] || fp_geq_p(r.l)) fp_sub_p(r.l);
     return r;
 }
 static inline int fp_eq(fp_t a, fp_t b) { return memcmp(&a, &b, sizeof a) == 0; }

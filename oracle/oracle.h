@@ -51,9 +51,12 @@ void or_hash_elements(int kind, const fp_t *e, size_t n, uint8_t out[32]);
 void or_hash_merge(int kind, const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
 void or_hash_rows(int kind, const fp_t *const *cols, size_t ncols, size_t nrows, uint8_t *out);
 
+fp_t or_mulmod_chain(fp_t x, fp_t y, uint64_t iters);       /* fp252.c: a dependent chain of products (timing) */
+
 /* ---- pedersen.c */
 void or_pedersen_init(void);
 fp_t or_pedersen_hash(fp_t a, fp_t b);
+fp_t or_pedersen_hash_bitwise(fp_t a, fp_t b);      /* the definition the table form is held to */
 /* PedersenHashFn::hash_elements chain (crypto/src/hash/pedersen.rs:65-76) */
 fp_t or_pedersen_hash_elements(const fp_t *e, size_t n);
 /* affine doubling chain 2^i * P_k, i < count (periodic-column KAT helper) */

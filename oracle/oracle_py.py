@@ -57,6 +57,10 @@ def lib():
         _lib.or_init()
         _lib.or_pedersen_hash.restype = _FP
         _lib.or_pedersen_hash.argtypes = [_FP, _FP]
+        _lib.or_pedersen_hash_bitwise.restype = _FP
+        _lib.or_pedersen_hash_bitwise.argtypes = [_FP, _FP]
+        _lib.or_mulmod_chain.restype = _FP
+        _lib.or_mulmod_chain.argtypes = [_FP, _FP, C.c_uint64]
         _lib.or_pedersen_hash_elements.restype = _FP
         _lib.or_poly_eval.restype = _FP
         _lib.or_coin_draw.restype = _FP
@@ -167,6 +171,21 @@ def hash_rows(kind, cols):
 
 def pedersen_hash(a, b):
     return _fp_out(lib().or_pedersen_hash(_fp(a), _fp(b)))
+
+
+def pedersen_hash_bitwise(a, b):
+    """the definition (one mixed addition per set bit) the 4-bit-window form of pedersen_hash is held to"""
+    return _fp_out(lib().or_pedersen_hash_bitwise(_fp(a), _fp(b)))
+
+
+def mulmod_ns(iters=2_000_000):
+    """nanoseconds per Montgomery product of the port on ONE core (a dependent chain): bench.py's cpu_baseline reports it"""
+    import time
+    x, y = to_mont([0x1234567])[0], to_mont([0x7654321 << 180])[0]
+    lib().or_mulmod_chain(_fp(x), _fp(y), 1000)
+    t0 = time.perf_counter()
+    lib().or_mulmod_chain(_fp(x), _fp(y), iters)
+    return (time.perf_counter() - t0) / iters * 1e9
 
 
 def pedersen_hash_elements(elems):

@@ -1,6 +1,8 @@
 """The row-block entry points of the single-proof multi-GPU path (host/sharded.cpp drives them): ss_eval_quotient_rows,
 ss_deep_compose_rows + ss_deep_extend give, block by block, what the whole-domain entry points give - bit for bit, on the real
 recursive program, wrap-around halo included."""
+import os
+
 import numpy as np
 import pytest
 

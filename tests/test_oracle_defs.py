@@ -203,3 +203,18 @@ def test_fri_fold_conventions_agree(oracle):
     assert np.array_equal(got, nat[[br(i, log_len - 3) for i in range(n // fold)]])
     un = oracle.from_mont(oracle.fri_fold(ev, fold, alpha, off, oracle.FRI_UNNORMALISED))
     assert [int(x) for x in un] == [int(x) * fold % P for x in oracle.from_mont(nat)]
+
+
+def test_pedersen_window_tables_equal_the_bitwise_sum(oracle):
+    """oracle/pedersen.c computes the hash from 4-bit window tables (the shape of starknet-crypto's pedersen_hash, which the CPU leg of
+    bench.py stands in for); the bit-by-bit point sum of the published definition is kept beside it: equal on random inputs, on inputs
+    with empty and full digits, with only high bits, and on the reference's own examples (tests/test_oracle_golden.py pins those)"""
+    import random
+    rng = random.Random(66)
+    p = 2**251 + 17 * 2**192 + 1
+    cases = [(0, 0), (1, 0), (0, 1), (p - 1, p - 1), (15 << 248, 15 << 248), ((1 << 248) - 1, 1 << 251), (0xf0f0f0f0 << 100, 0x0f0f0f0f << 17)]
+    cases += [(rng.randrange(p), rng.randrange(p)) for _ in range(40)]
+    for a, b in cases:
+        am, bm = oracle.to_mont([a % p])[0], oracle.to_mont([b % p])[0]
+        assert np.array_equal(oracle.pedersen_hash(am, bm), oracle.pedersen_hash_bitwise(am, bm)), (hex(a), hex(b))
+    assert 5 < oracle.mulmod_ns(200_000) < 2000
