@@ -200,15 +200,19 @@ def cpu_baseline(layout, log_steps_full, gpu_ctx):
     python_host_proof(gpu_ctx, layout, sample)                      # warm: plans, tables, pool
     t_gpu = python_host_proof(gpu_ctx, layout, sample, proofs=3)
     ls, lf = sample + 4, log_steps_full + 4
-    scale = float(1 << (lf - ls)) * (lf + 1) / (ls + 1)
+    scale, scale_is = float(1 << (lf - ls)) * (lf + 1) / (ls + 1), "n log n"
+    full = CPU_PORT_FULL_SIZE.get("%s_2p%d" % (layout, log_steps_full))
+    if full and full.get("sample_log_steps") == sample and full.get("sample_seconds"):
+        # the port's full-size / sample ratio MEASURED once on a box of this pool (n log n is 11 % off for starknet, 2.4 x too high for
+        # the recursive layout, whose Pedersen layers stop at depth 22: profiles/r06_cpu_port_full_size.txt)
+        scale, scale_is = full["seconds"] / full["sample_seconds"], "the port's own full-size / sample ratio, measured once (profiles/cpu_port_full_size.json)"
     out = {"value": t_cpu * scale, "unit": "s", "cores": threads, "host_cpus": os.cpu_count(), "cpu_quota": HOST_CPUS, "kind": "port",
            "measured_sample_s": t_cpu, "gpu_same_sample_s": t_gpu, "sample_speedup": t_cpu / t_gpu,
            "port_mulmod_ns_per_core": mulmod_ns, "port_mulmod_per_s_per_core": 1e9 / mulmod_ns,
            "sample": "MEASURED whole proof (every stage incl. constraint program and DEEP) of the %s layout's real AIR at 2^%d steps "
                      "(2^%d trace rows), CLI-default options, by the oracle (C + OpenMP port, not the reference binary) "
                      "through the same Python host as the GPU: %.2f s on %d threads; the GPU on the same sample %.4f s; "
-                     "`value` = that CPU time x %.1f (n log n to 2^%d steps)" % (layout, sample, ls, t_cpu, threads, t_gpu, scale, log_steps_full)}
-    full = CPU_PORT_FULL_SIZE.get("%s_2p%d" % (layout, log_steps_full))
+                     "`value` = that CPU time x %.2f (%s, to 2^%d steps)" % (layout, sample, ls, t_cpu, threads, t_gpu, scale, scale_is, log_steps_full)}
     if full:
         out["full_size_measured_once"] = dict(full, note="the port's whole proof at THIS size, run once outside bench.py (tools/cpu_full_size.py) on a box of "
                                                          "this pool: what `value`'s n log n extrapolation is held against")
@@ -217,7 +221,7 @@ def cpu_baseline(layout, log_steps_full, gpu_ctx):
     # shape, Pedersen from 4-bit window tables as starknet-crypto looks its points up, twiddles precomputed by all threads) and the
     # cost of one of its field products on one core of this box
     out["note"] = ("the reference CPU prover cannot be built here (Rust nightly + un-vendored ministark): this is the oracle's port on the cores the box "
-                   "grants; `value` is its measured sample x n log n.  port_mulmod_ns_per_core is one Montgomery product of the port on one core "
+                   "grants; `value` is its measured sample scaled to the full size (see `sample`).  port_mulmod_ns_per_core is one Montgomery product of the port on one core "
                    "(a dependent chain); arkworks' own benches put ark-ff's 4-limb Montgomery product at ~20-30 ns on 3+ GHz x86 - the reference's "
                    "field-bound stages cannot be faster than this port's by more than that ratio, its hash-bound ones (Pedersen: starknet-crypto's "
                    "4-bit windows, as here) are of the same shape")

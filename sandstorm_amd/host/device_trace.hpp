@@ -10,6 +10,9 @@
 //     thrown with the host generator's messages.
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -183,6 +186,13 @@ class DeviceTrace {
         check(ss_dev_zero(ctx_, d_status_, SS_TRACE_STATUS_WORDS * 4));
         d_pool_addr_ = (uint32_t *)alloc(n_ / 2 * 4);
     }
+    // SSH_TRACE_TIMING: the HOST's time per step of a generation on stderr (uploads, plans, templates, launches; the kernels run behind)
+    void lap(const char *what) {
+        if (!timing_) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[device trace] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last_).count());
+        t_last_ = now;
+    }
     ~DeviceTrace() {
         if (!finished_) (void)ss_ctx_sync(ctx_);                  // (an exception on the way: nothing may still read what is freed here)
         for (void *p : owned_) (void)ss_dev_free(ctx_, p);
@@ -202,12 +212,14 @@ class DeviceTrace {
         uint64_t *d_records = n_records ? (uint64_t *)upload(memory_bin, memory_len) : nullptr;
         d_image_ = (uint64_t *)alloc(cells_ * 32);
         check(ss_trace_memory_image(ctx_, d_records, n_records, d_image_, cells_));
+        lap("files uploaded");
     }
     void zero_column(int col) { check(ss_dev_zero(ctx_, cols_[col], n_ * 32)); }
     void cpu_cells(const ss_trace_layout &layout, int flags_col, int npc_col, int rc_col, int aux_col, const Felt &pad_value, uint64_t rc_fill) {
         npc_col_ = npc_col;
         check(ss_trace_cpu_cells(ctx_, &layout, d_states_, num_cycles_, d_image_, cells_, pad_value.data(), rc_fill, cols_[flags_col], cols_[npc_col], cols_[rc_col],
                                  cols_[aux_col], d_pool_addr_, d_status_));
+        lap("cpu cells launched");
     }
     // a builtin's blocks from its templates: place(sink, template) records template t's cells (every template the same cells)
     template <class Place> void builtin(uint32_t n_templates, const std::vector<uint32_t> &of_block, uint64_t block_rows, uint64_t addr_begin, uint64_t addr_per_block,
@@ -231,6 +243,7 @@ class DeviceTrace {
         const uint64_t *d_values = (const uint64_t *)upload_vec(std::move(*values));
         check(ss_trace_builtin(ctx_, cols_.data(), ncols_, d_cells, n_cells, d_values, n_templates, d_of_block, n_blocks, block_rows, addr_begin, addr_per_block,
                                d_pool_addr_));
+        lap("builtin templates");
     }
     // the range-check pool: plan + histogram -> the pool's cells of every cycle; then (later, in the host sections' order) the builtin
     void rc_pool(ss_trace_rc_plan &plan, const RcPoolPlan &pool, const std::vector<uint32_t> &count, int rc_col) {
@@ -268,12 +281,14 @@ class DeviceTrace {
         const uint64_t *d_value = value.empty() ? nullptr : (const uint64_t *)upload_vec(std::move(value));
         check(ss_trace_ordered_memory(ctx_, n_, cols_[npc_col_], cols_[mem_col], d_pool_addr_, d_addr, d_value, n_public, public_cells, pad_value.data(), unused_off,
                                       d_status_));
+        lap("ordered memory launched");
     }
     // waits for the kernels and turns the status bits into the generator's refusals
     void finish() {
         uint32_t st[SS_TRACE_STATUS_WORDS];
         check(ss_trace_status(ctx_, d_status_, st));
         finished_ = true;
+        lap("kernels done (status)");
         const uint32_t err = st[0];
         if (!err) return;
         const std::string where = std::to_string((uint32_t)~st[1]);
@@ -324,6 +339,8 @@ class DeviceTrace {
     uint64_t cells_ = 0;
     int npc_col_ = 0;
     bool finished_ = false;
+    const bool timing_ = getenv("SSH_TRACE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t_last_ = std::chrono::steady_clock::now();
     const uint32_t *d_rc_first_ = nullptr;
     const uint16_t *d_rc_padding_ = nullptr;
 };

@@ -759,6 +759,7 @@ void starknet_base_trace_device(ss_ctx *ctx, uint64_t *const d_cols[9], const ui
     const Mem mem{memory, present};
     const Inputs in = check_inputs(states, mem, pi, priv);
     DeviceTrace dt(ctx, in.num_cycles, d_cols, NUM_COLS);
+    dt.lap("inputs checked");
     dt.load_inputs(trace_bin, trace_len, memory_bin, memory_len);
     DeviceBackend be{in, dt};
     generate(be, in);

@@ -11,7 +11,16 @@ import sys
 import pytest
 
 from tests.sharded_host_cases import GOLD, mini_case, single_device_mini
-from tests.test_sharded import ROOT, free_port
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 pytestmark = pytest.mark.gpu
 

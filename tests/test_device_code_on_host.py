@@ -86,7 +86,7 @@ def test_the_base_trace_made_by_the_device_code(emulated_library):
     real builtin instances, the bench's statements of both layouts, the reference's bootloader run with every builtin, the input's
     errors - and the 2^14-step files -> proof call through it (the committed proof's bytes)"""
     out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_device_trace.py"])
-    assert "6 passed, 2 skipped" in out, out[-500:]
+    assert "6 passed, 3 skipped" in out, out[-500:]
     heavy()
     out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_recursive_claim.py", "-k", "device_generator and 14"], timeout=2400)
     assert "1 passed" in out, out[-500:]

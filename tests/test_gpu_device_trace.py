@@ -160,3 +160,19 @@ def test_columns_at_2p20_steps(ctx, layout):
         got = col.download(np.uint64, (n, 4))
         assert np.array_equal(got, want[c]), "column %d" % c
         col.free()
+
+
+@pytest.mark.skipif(EMULATED, reason="BASELINE configs[3]'s size: hardware only")
+def test_starknet_columns_at_2p22_steps(ctx):
+    """BASELINE configs[3]'s statement size (starknet layout, 2^22 steps): 2^26 rows per column, 19 GB of columns from 101 MB of files -
+    every cell against the host generator (32-bit pool addresses, the u32 prefix sums and the 2^25-entry count arrays at their largest)"""
+    from sandstorm_amd import hostlib
+    trace_bin, memory_bin, pi = padded_statement("starknet", 22)
+    n = 16 << 22
+    cols = hostlib.device_base_trace(ctx, "starknet", trace_bin, memory_bin, pi, None)
+    want = hostlib.starknet_base_trace(trace_bin, memory_bin, pi)
+    for c, col in enumerate(cols):
+        got = col.download(np.uint64, (n, 4))
+        assert np.array_equal(got, want[c]), "column %d" % c
+        col.free()
+        want[c] = None

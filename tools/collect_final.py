@@ -36,7 +36,7 @@ def parse_pmc(path, counter):
 for name in sorted(os.listdir(SRC)):
     if name.startswith("bench_") and name.endswith(".json"):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, "%s_%s" % (TAG, name)))
-for name in ("pytest_gpu.txt", "smoke.txt", "sq_counters_starknet_2p20.txt", "sq_counters_recursive_2p20.txt", "ubench.txt", "mfma_mulbench.txt", "mulbench.txt",
+for name in ("pytest_gpu.txt", "smoke.txt", "sq_counters_starknet_2p20.txt", "sq_counters_recursive_2p20.txt", "ubench.txt", "mfma_mulbench.txt", "mulbench.txt", "fma_mulbench.txt", "e2e_device.txt", "device_trace_kernel_stats.csv",
              "kernel_gaps_starknet_2p20.txt", "kernel_gaps_recursive_2p20.txt", "kernel_gaps_goldilocks_plain_2p20.txt"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, "%s_%s" % (TAG, name)))

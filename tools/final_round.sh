@@ -10,17 +10,21 @@ for w in starknet_2p20 recursive_2p20 recursive_2p16 array_sum_example; do
   timeout 600 python bench.py --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err
   python -c "import json; d=json.load(open('$OUT/bench_$w.json')); print('$w', d['value'], d['stage_ms_per_proof'], d['ntt_gfield_ops_per_s'], d.get('cpu_baseline',{}).get('measured_sample_s'))"
 done
-timeout 300 python bench.py --workload starknet_2p20 --mode shard --sharded-host python --no-cpu-baseline > $OUT/bench_starknet_2p20_shard_1gpu.json 2> $OUT/bench_shard.err
 timeout 300 python bench.py --workload starknet_2p20 --mode shard --sharded-host cpp --no-cpu-baseline > $OUT/bench_starknet_2p20_shard_cpp_1gpu.json 2> $OUT/bench_shard_cpp.err
 tools/_build/ubench > $OUT/ubench.txt 2>&1
 tools/_build/mfma_mulbench > $OUT/mfma_mulbench.txt 2>&1
 tools/_build/mulbench > $OUT/mulbench.txt 2>&1
+tools/_build/fma_mulbench > $OUT/fma_mulbench.txt 2>&1
+# files -> proof through the device generator, without torch; then the generator's kernels by name
+timeout 300 python tools/e2e_device.py starknet recursive > $OUT/e2e_device.txt 2>&1; cat $OUT/e2e_device.txt
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rp_trace && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_trace -- python $R/tools/e2e_device.py starknet recursive > /dev/null 2>&1)
+f=$(find /tmp/rp_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && ( head -1 $f; grep -i "trace_\|mem_\|scan_chunks\|scan_sums\|scan_apply_kernel_u32" $f ) > $OUT/device_trace_kernel_stats.csv
 timeout 300 python bench.py --workload goldilocks_lde_2p20 --steps 10 --warmup 2 > $OUT/bench_goldilocks_lde_2p20.json 2> $OUT/bench_gl.err
 timeout 300 python bench.py --workload goldilocks_plain_2p20 --steps 3 --warmup 1 > $OUT/bench_goldilocks_plain_2p20.json 2> $OUT/bench_glp.err
 timeout 300 python bench.py --workload starknet_2p22 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_starknet_2p22.json 2> $OUT/bench_2p22.err
 python -c "
 import json
-for w in ('starknet_2p20_shard_1gpu','starknet_2p20_shard_cpp_1gpu','goldilocks_lde_2p20','goldilocks_plain_2p20','starknet_2p22'):
+for w in ('starknet_2p20_shard_cpp_1gpu','goldilocks_lde_2p20','goldilocks_plain_2p20','starknet_2p22'):
     try: d=json.load(open('$OUT/bench_%s.json'%w)); print(w, d['value'])
     except Exception as e: print(w, 'FAILED', e)"
 bash tools/profile_round.sh > $OUT/profile_round.log 2>&1
