@@ -73,11 +73,13 @@ template <class Key, class Trace> struct Instances {
     template <class KeyOf> void assign(uint64_t nblocks, const KeyOf &key_of) {
         std::map<Key, uint32_t> index;
         of_block.resize(nblocks);
+        uint32_t last = 0;
         for (uint64_t i = 0; i < nblocks; ++i) {
             const Key k = key_of(i);
+            if (i && k == keys[last]) { of_block[i] = last; continue; }       // (runs of one instance - the dummy's - cost a comparison, not a map lookup)
             auto ins = index.emplace(k, (uint32_t)keys.size());
             if (ins.second) keys.push_back(k);
-            of_block[i] = ins.first->second;
+            of_block[i] = last = ins.first->second;
         }
         traces.resize(keys.size());
     }
@@ -102,6 +104,15 @@ template <class Inst> std::map<uint32_t, const Inst *> instances_by_index(const 
 // ---- what both layouts' builtin sections share
 // a Pedersen instance's 512 curve steps and its hash (builtins/src/pedersen/mod.rs:81-163), with the reference's own assert
 struct PedersenTrace { std::vector<Step> steps; Felt out; };
+inline std::shared_ptr<const PedersenTrace> pedersen_instance_trace(const U256 &a, const U256 &b);
+// the dummy instance (a = b = 0: what nearly every block of a run holds) is traced once per process
+inline std::shared_ptr<const PedersenTrace> pedersen_instance_trace_cached(const U256 &a, const U256 &b) {
+    if ((a[0] | a[1] | a[2] | a[3] | b[0] | b[1] | b[2] | b[3]) == 0) {
+        static const std::shared_ptr<const PedersenTrace> dummy = pedersen_instance_trace(U256{}, U256{});
+        return dummy;
+    }
+    return pedersen_instance_trace(a, b);
+}
 inline std::shared_ptr<const PedersenTrace> pedersen_instance_trace(const U256 &a, const U256 &b) {
     auto c = std::make_shared<PedersenTrace>();
     c->steps.reserve(512);

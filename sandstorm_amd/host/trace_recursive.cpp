@@ -365,7 +365,7 @@ template <class Backend> void generate(Backend &be, const Inputs &in) {
         const auto given = instances_by_index(priv.pedersen, n / step, "pedersen");
         Instances<U256x2, PedersenTrace> inst;
         inst.assign(n / step, [&](uint64_t i) { auto it = given.find((uint32_t)i); return it != given.end() ? U256x2{it->second->a, it->second->b} : U256x2{}; });
-        inst.trace_all([](const U256x2 &k) { return pedersen_instance_trace(k.first, k.second); });
+        inst.trace_all([](const U256x2 &k) { return pedersen_instance_trace_cached(k.first, k.second); });
         be.builtin("pedersen", inst.of_block, (uint32_t)inst.keys.size(), step, ped_seg.begin_addr, 3, -1, [&](auto &s, uint32_t t) {
             const PedersenTrace &c = *inst.traces[t];
             for (uint64_t j = 0; j < 512; ++j) {

@@ -562,7 +562,7 @@ template <class Backend> void generate(Backend &be, const Inputs &in) {
         const auto given = instances_by_index(priv.pedersen, n / step, "pedersen");
         Instances<U256x2, PedersenTrace> inst;
         inst.assign(n / step, [&](uint64_t i) { auto it = given.find((uint32_t)i); return it != given.end() ? U256x2{it->second->a, it->second->b} : U256x2{}; });
-        inst.trace_all([](const U256x2 &k) { return pedersen_instance_trace(k.first, k.second); });
+        inst.trace_all([](const U256x2 &k) { return pedersen_instance_trace_cached(k.first, k.second); });
         be.builtin("pedersen", inst.of_block, (uint32_t)inst.keys.size(), step, pi.segments[3].begin_addr, 3, [&](auto &s, uint32_t t) {
             const PedersenTrace &c = *inst.traces[t];
             for (uint64_t j = 0; j < 512; ++j) {
@@ -670,7 +670,7 @@ template <class Backend> void generate(Backend &be, const Inputs &in) {
             auto it = given.find((uint32_t)i);
             return it != given.end() ? U256x5{it->second->p_x, it->second->p_y, it->second->q_x, it->second->q_y, it->second->m} : dummy;
         });
-        inst.trace_all([](const U256x5 &in5) {               // (a scalar multiplication with its doubling chain per instance)
+        auto trace_of = [](const U256x5 &in5) {              // (a scalar multiplication with its doubling chain per instance)
             auto t = std::make_shared<EcOpTrace>();
             t->p = Pt{felt_from_canonical(std::get<0>(in5)), felt_from_canonical(std::get<1>(in5))};
             t->q = Pt{felt_from_canonical(std::get<2>(in5)), felt_from_canonical(std::get<3>(in5))};
@@ -680,6 +680,13 @@ template <class Backend> void generate(Backend &be, const Inputs &in) {
             t->r = t->r_steps.back().partial;
             t->b251_196 = bit(std::get<4>(in5), 251) && bit(std::get<4>(in5), 196); t->b251_196_192 = t->b251_196 && bit(std::get<4>(in5), 192);
             return std::shared_ptr<const EcOpTrace>(t);
+        };
+        inst.trace_all([&](const U256x5 &in5) {
+            if (in5 == dummy) {                              // the dummy instance (a constant) is traced once per process
+                static const std::shared_ptr<const EcOpTrace> cached = trace_of(in5);
+                return cached;
+            }
+            return trace_of(in5);
         });
         be.builtin("ec op", inst.of_block, (uint32_t)inst.keys.size(), step, pi.segments[7].begin_addr, 7, [&](auto &s, uint32_t ti) {
             const EcOpTrace &t = *inst.traces[ti];
