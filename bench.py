@@ -453,7 +453,7 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     constraint evaluation / DEEP on row blocks, leaf-block sub-trees + root all-gather, single-vector transforms and the large FRI
     layers spread over the ranks.  A step = one whole proof; the time is the max over ranks between two
     barriers; strong scaling."""
-    from sandstorm_amd import backend as be, extension, hostlib
+    from sandstorm_amd import backend as be, hostlib
     from sandstorm_amd.prover import ProofOptions
     L, pi = _sample_statement(layout, log_steps)
     n = 16 << log_steps
@@ -468,17 +468,19 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
     nb, ne = air.num_base_columns, air.num_extension_columns
     coin = be.COIN_CAIRO if layout == "recursive" else be.COIN_SOLIDITY
     mine = {c: synth_columns(device, 1, log_steps + 4, seed=0x53414E44 + c)[0] for c in range(nb) if c % world == rank}
-    my_ext = [c for c in range(nb, nb + ne) if c % world == rank]
-    aux = synth_columns(device, 5 if layout == "recursive" else 3, log_steps + 4, seed=0x7E57) if my_ext else None
+    # the extension trace as ROW BLOCKS: every rank holds its n / N rows of the auxiliary columns and runs the layout's scans on them;
+    # one all-gather of the blocks' totals (7 field elements per rank) and the blocks before a block are folded in
+    # (host/extension.cpp build_extension_blocks) - no rank makes or scatters a whole extension column
+    log_block = log_steps + 4 - (world.bit_length() - 1)
+    aux = synth_columns(device, 5 if layout == "recursive" else 3, log_block, seed=0x7E57 + rank)
+    ext_keep = []
 
-    def build_extension(challenges):
-        if not my_ext:
-            return {}
-        # every owner of an extension column runs the layout's scans on the auxiliary columns (resident on it) and keeps its own
-        out = be.Matrix(ctx, [torch.zeros((n, 4), dtype=torch.int64, device=device) for _ in range(ne)], n)
-        tc = extension.TraceColumns(aux[0], aux[1], aux[2], n, *(aux[3:5] if layout == "recursive" else ()))
-        extension.build_extension_columns(layout, ctx, tc, challenges, check=False, out=out)
-        return {c: out.cols[c - nb] for c in my_ext}
+    def extension_blocks(challenges):
+        while ext_keep:
+            ext_keep.pop().close()
+        m = hostlib.build_extension_blocks(ctx, layout, aux, n, rank, world, group, challenges, check=False)      # synthetic cells: no permutation closes
+        ext_keep.append(m)
+        return m.cols
     seed = bytes((7 * i) & 0xff for i in range(32))
 
     def barrier():
@@ -557,7 +559,7 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
 
     def prove_once():
         wire_proof[0] = hostlib.prove_sharded(ctx, host_air, tree_kind, n_friendly, coin, seed, rank, world, group, mine, log_steps + 4,
-                                              build_extension, ProofOptions())
+                                              None, ProofOptions(), extension_blocks=extension_blocks)
         return wire_proof[0]
     proof = prove_once()
     if rank == 0:

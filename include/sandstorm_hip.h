@@ -78,7 +78,7 @@ enum { SS_COIN_SOLIDITY = 0, SS_COIN_CAIRO = 1 };
 const char *ss_last_error(void);
 /* ABI version of this header; bump on any signature change.  ss_abi_version() of the loaded
  * library must equal SS_ABI_VERSION of the header the caller was built against. */
-#define SS_ABI_VERSION 11u
+#define SS_ABI_VERSION 12u
 uint32_t ss_abi_version(void);
 
 /* ---- context & memory (replaces ministark-gpu's Metal planner/GpuAllocator;
@@ -454,6 +454,23 @@ ss_status ss_permutation_product(ss_ctx *ctx, const ss_perm_operand *num, const 
 ss_status ss_diluted_aggregate(ss_ctx *ctx, const uint64_t *d_ordered, uint64_t stride, uint64_t offset, uint64_t count,
                                const uint64_t z[4], const uint64_t alpha[4], uint64_t *d_out, uint64_t out_stride,
                                uint64_t out_offset);
+
+/* ---- the same loops (trace.rs:699-814 "TODO: multithread") over the ROW BLOCKS of several devices (ABI 12): device r holds
+ *      items [r count, (r + 1) count) of the operands.  A running product is the block's own ss_permutation_product (its
+ *      last_out = the block's total) times the totals of the blocks before it: d_data[offset + i*stride] *= factor, i < count. */
+ss_status ss_scale_strided(ss_ctx *ctx, uint64_t *d_data, uint64_t stride, uint64_t offset, uint64_t count,
+                           const uint64_t factor[4]);
+/* The aggregate's recurrence acc_i = acc_{i-1} * m_i + c_i (m_i = 1 + z*u_i, c_i = alpha*u_i^2) composes as affine maps:
+ * d_maps[2i], d_maps[2i+1] = (M_i, C_i) with acc_i = M_i * start + C_i, where `start` is the value before the block.
+ * starts_column != 0: item 0 is the column's first cell (acc_0 = 1, a constant map).  Otherwise item 0 is left the identity:
+ * its term needs the ordered value before the block, which another device holds; the caller composes that one map from the two
+ * boundary values.  total_out (nullable, host): (M, C) of the block's last item.  d_maps: 2*count felts, the caller's. */
+ss_status ss_diluted_aggregate_block(ss_ctx *ctx, const uint64_t *d_ordered, uint64_t stride, uint64_t offset, uint64_t count,
+                                     int starts_column, const uint64_t z[4], const uint64_t alpha[4], uint64_t *d_maps,
+                                     uint64_t total_out[8]);
+/* d_out[out_offset + i*out_stride] = d_maps[2i] * start + d_maps[2i+1] for i < count. */
+ss_status ss_affine_apply(ss_ctx *ctx, const uint64_t *d_maps, uint64_t count, const uint64_t start[4], uint64_t *d_out,
+                          uint64_t out_stride, uint64_t out_offset);
 
 /* ---- the BASE trace on the device (ABI 11; SURVEY.md section 8a row A1 / "next" row X1).  ExecutionTrace::new
  *      (layouts/src/starknet/trace.rs:99-987, layouts/src/recursive/trace.rs:89-688, layouts/src/utils.rs:112-152,

@@ -80,6 +80,10 @@ SIGNATURES = {
                                          C.c_void_p, C.c_uint64, C.c_uint64, _u64p]),
     "ss_diluted_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, _u64p, _u64p,
                                        C.c_void_p, C.c_uint64, C.c_uint64]),
+    "ss_scale_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, _u64p]),
+    "ss_diluted_aggregate_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _u64p, _u64p,
+                                             C.c_void_p, _u64p]),
+    "ss_affine_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, _u64p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "ss_ntt_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_int, _u64p, C.c_int, C.c_int]),
     "ss_lde_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _vpp, _vpp]),
     "ss_evaluate_fp252": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _vpp]),

@@ -415,6 +415,25 @@ class Context:
         check(self.lib.ss_diluted_aggregate(self.handle, _ptr_of(ordered), stride, offset, count, zp, ap, _ptr_of(out),
                                             out_stride, out_offset))
 
+    def scale_strided(self, data, stride, offset, count, factor):
+        """ss_scale_strided: data[offset + i*stride] *= factor - a block's running product times the blocks before it"""
+        _k, fp = _felt_ptr(factor)
+        check(self.lib.ss_scale_strided(self.handle, _ptr_of(data), stride, offset, count, fp))
+
+    def diluted_aggregate_block(self, ordered, stride, offset, count, starts_column, z, alpha, maps, want_total=True):
+        """ss_diluted_aggregate_block: the block's scanned affine maps (maps: 2*count felts) -> (M, C) of its last item"""
+        _kz, zp = _felt_ptr(z)
+        _ka, ap = _felt_ptr(alpha)
+        total = np.zeros(8, dtype=np.uint64)
+        check(self.lib.ss_diluted_aggregate_block(self.handle, _ptr_of(ordered), stride, offset, count, 1 if starts_column else 0, zp, ap,
+                                                  _ptr_of(maps), total.ctypes.data_as(C.POINTER(C.c_uint64)) if want_total else None))
+        return (total[:4].copy(), total[4:].copy()) if want_total else None
+
+    def affine_apply(self, maps, count, start, out, out_stride=1, out_offset=0):
+        """ss_affine_apply: out[out_offset + i*out_stride] = M_i * start + C_i"""
+        _k, sp = _felt_ptr(start)
+        check(self.lib.ss_affine_apply(self.handle, _ptr_of(maps), count, sp, _ptr_of(out), out_stride, out_offset))
+
     def dev_copy_2d(self, dst, dst_pitch, src, src_pitch, width, rows, dst_offset=0, src_offset=0):
         """ss_dev_copy_2d: `rows` runs of `width` bytes, row r from src + src_offset + r * src_pitch to dst + dst_offset + r * dst_pitch"""
         check(self.lib.ss_dev_copy_2d(self.handle, _ptr_of(dst) + dst_offset, dst_pitch, _ptr_of(src) + src_offset, src_pitch, width, rows))

@@ -493,7 +493,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns, ss_upload_async / ss_wait_upload (uploads on a copy stream, ordered into the context's stream by ticket), SS_HASH_SHA256 / SS_TREE_SHA256 for the 64-bit field's rows and trees; 10: ss_gather_batch (the query phase's gathers in one round trip); 11: ss_trace_* (the base trace made on the device from trace.bin / memory.bin)
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns, ss_upload_async / ss_wait_upload (uploads on a copy stream, ordered into the context's stream by ticket), SS_HASH_SHA256 / SS_TREE_SHA256 for the 64-bit field's rows and trees; 10: ss_gather_batch (the query phase's gathers in one round trip); 11: ss_trace_* (the base trace made on the device from trace.bin / memory.bin); 12: one extension scan over the row blocks of several devices: ss_scale_strided, ss_diluted_aggregate_block, ss_affine_apply
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -1330,6 +1330,42 @@ ss_status ss_diluted_aggregate(ss_ctx *ctx, const uint64_t *d_ordered, uint64_t 
     ss_ctx::Scope prof(ctx, SS_PROF_EXT);
     HIP_TRY(launch_diluted_aggregate(ctx->stream, (const Fp *)d_ordered, stride, offset, count, fp_from_limbs64(z),
                                      fp_from_limbs64(alpha), (Fp *)d_out, out_stride, out_offset, (Fp *)ctx->scratch));
+    return SS_OK;
+}
+
+// ---- the same scans over the row blocks of several devices (ABI 12; host/extension.cpp build_extension_blocks)
+ss_status ss_scale_strided(ss_ctx *ctx, uint64_t *d_data, uint64_t stride, uint64_t offset, uint64_t count, const uint64_t factor[4]) {
+    if (!ctx || !d_data || !factor) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!stride || offset >= stride) return fail(SS_ERR_INVALID, "bad stride/offset");
+    if (count == 0 || count > (1ull << 32)) return fail(SS_ERR_INVALID, "count out of range");
+    ss_ctx::Scope prof(ctx, SS_PROF_EXT);
+    HIP_TRY(launch_scale_strided(ctx->stream, (Fp *)d_data, stride, offset, count, fp_from_limbs64(factor)));
+    return SS_OK;
+}
+ss_status ss_diluted_aggregate_block(ss_ctx *ctx, const uint64_t *d_ordered, uint64_t stride, uint64_t offset, uint64_t count,
+                                     int starts_column, const uint64_t z[4], const uint64_t alpha[4], uint64_t *d_maps,
+                                     uint64_t total_out[8]) {
+    if (!ctx || !d_ordered || !z || !alpha || !d_maps) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!stride || offset >= stride) return fail(SS_ERR_INVALID, "bad stride/offset");
+    if (count == 0 || count > (1ull << 32)) return fail(SS_ERR_INVALID, "count out of range");
+    ss_status st = ctx->ensure_scratch(scan_agg_felts(count, 2) * sizeof(Fp));
+    if (st != SS_OK) return st;
+    ss_ctx::Scope prof(ctx, SS_PROF_EXT);
+    HIP_TRY(launch_diluted_aggregate_maps(ctx->stream, (const Fp *)d_ordered, stride, offset, count, starts_column != 0, fp_from_limbs64(z),
+                                          fp_from_limbs64(alpha), (Fp *)d_maps, (Fp *)ctx->scratch));
+    if (total_out) {
+        HIP_TRY(hipMemcpyAsync(total_out, (const Fp *)d_maps + 2 * (count - 1), 2 * sizeof(Fp), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return SS_OK;
+}
+ss_status ss_affine_apply(ss_ctx *ctx, const uint64_t *d_maps, uint64_t count, const uint64_t start[4], uint64_t *d_out,
+                          uint64_t out_stride, uint64_t out_offset) {
+    if (!ctx || !d_maps || !start || !d_out) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!out_stride || out_offset >= out_stride) return fail(SS_ERR_INVALID, "bad output stride/offset");
+    if (count == 0 || count > (1ull << 32)) return fail(SS_ERR_INVALID, "count out of range");
+    ss_ctx::Scope prof(ctx, SS_PROF_EXT);
+    HIP_TRY(launch_affine_apply(ctx->stream, (const Fp *)d_maps, count, fp_from_limbs64(start), (Fp *)d_out, out_stride, out_offset));
     return SS_OK;
 }
 

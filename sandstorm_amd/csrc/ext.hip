@@ -55,6 +55,18 @@ __global__ __launch_bounds__(256) void dil_finish_kernel(const Fp *__restrict__ 
     dil_finish_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, mc, count, out, out_stride, out_off);
 }
 
+__global__ __launch_bounds__(256) void scale_strided_kernel(Fp *data, uint64_t stride, uint64_t off, uint64_t count, Fp factor) {
+    scale_strided_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, stride, off, count, factor);
+}
+__global__ __launch_bounds__(256) void dil_terms_block_kernel(const Fp *x, uint64_t stride, uint64_t off, uint64_t count, bool starts_column,
+                                                              Fp z, Fp alpha, Fp *__restrict__ mc) {
+    dil_terms_block_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, x, stride, off, count, starts_column, z, alpha, mc);
+}
+__global__ __launch_bounds__(256) void affine_apply_kernel(const Fp *__restrict__ mc, uint64_t count, Fp start, Fp *out, uint64_t out_stride,
+                                                           uint64_t out_off) {
+    affine_apply_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, mc, count, start, out, out_stride, out_off);
+}
+
 inline dim3 grid_for(uint64_t lanes, uint32_t block) { return dim3((uint32_t)((lanes + block - 1) / block)); }
 
 // SS_SCAN_LOG_CHUNK / SS_INV_LOG_CHUNK override the chunk sizes (tuning only)
@@ -97,6 +109,10 @@ struct HipExec {                 // a lane body = a kernel launch on the context
         hipLaunchKernelGGL(dil_finish_kernel, grid_for(count, 256), dim3(256), 0, st, mc, count, out, out_stride, out_off);
         return done();
     }
+    int dil_terms_block(const Fp *x, uint64_t stride, uint64_t off, uint64_t count, bool starts_column, const Fp &z, const Fp &alpha, Fp *mc) {
+        hipLaunchKernelGGL(dil_terms_block_kernel, grid_for(count, 256), dim3(256), 0, st, x, stride, off, count, starts_column, z, alpha, mc);
+        return done();
+    }
 };
 
 }  // namespace
@@ -113,6 +129,23 @@ hipError_t launch_diluted_aggregate(hipStream_t st, const Fp *x, uint64_t stride
     static const ScanShape shape = shape_from_env();
     HipExec ex{st, shape};
     return (hipError_t)diluted_aggregate(ex, x, stride, off, count, z, alpha, out, out_stride, out_off, scratch);
+}
+
+hipError_t launch_scale_strided(hipStream_t st, Fp *data, uint64_t stride, uint64_t off, uint64_t count, const Fp &factor) {
+    hipLaunchKernelGGL(scale_strided_kernel, grid_for(count, 256), dim3(256), 0, st, data, stride, off, count, factor);
+    return hipGetLastError();
+}
+
+hipError_t launch_diluted_aggregate_maps(hipStream_t st, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, bool starts_column,
+                                         const Fp &z, const Fp &alpha, Fp *mc, Fp *scratch) {
+    static const ScanShape shape = shape_from_env();
+    HipExec ex{st, shape};
+    return (hipError_t)diluted_aggregate_maps(ex, x, stride, off, count, starts_column, z, alpha, mc, scratch);
+}
+
+hipError_t launch_affine_apply(hipStream_t st, const Fp *mc, uint64_t count, const Fp &start, Fp *out, uint64_t out_stride, uint64_t out_off) {
+    hipLaunchKernelGGL(affine_apply_kernel, grid_for(count, 256), dim3(256), 0, st, mc, count, start, out, out_stride, out_off);
+    return hipGetLastError();
 }
 
 }  // namespace ss

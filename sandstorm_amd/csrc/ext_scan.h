@@ -125,6 +125,26 @@ SS_HD void dil_finish_lane(uint64_t k, const Fp *mc, uint64_t count, Fp *out, ui
     out[k * out_stride + out_off] = mc[2 * k + 1];                           // the map is constant: its value is c
 }
 
+// ---- one scan over the row blocks of several devices (ss_scale_strided, ss_diluted_aggregate_block, ss_affine_apply) ----------
+// A running product over rows [lo, hi) is the block's own scan times the product of the blocks before it; the aggregate's maps
+// compose the same way.  A block that does not start the column leaves its item 0 the IDENTITY: the term between two blocks
+// needs the row before the block, which its owner holds - the caller composes it from the two boundary values (dil_term_map).
+SS_HD void scale_strided_lane(uint64_t k, Fp *data, uint64_t stride, uint64_t off, uint64_t count, const Fp &factor) {
+    if (k >= count) return;
+    data[k * stride + off] = fp_mul(data[k * stride + off], factor);
+}
+SS_HD void dil_terms_block_lane(uint64_t k, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, bool starts_column, const Fp &z,
+                                const Fp &alpha, Fp *mc) {
+    if (k >= count) return;
+    if (k == 0 && !starts_column) { AffineOp::store(mc, 0, AffineOp::identity()); return; }
+    dil_terms_lane(k, x, stride, off, count, z, alpha, mc);
+}
+// the block's cells from its scanned maps and the value before the block: acc_k = m_k start + c_k
+SS_HD void affine_apply_lane(uint64_t k, const Fp *mc, uint64_t count, const Fp &start, Fp *out, uint64_t out_stride, uint64_t out_off) {
+    if (k >= count) return;
+    out[k * out_stride + out_off] = fp_add(fp_mul(mc[2 * k], start), mc[2 * k + 1]);
+}
+
 inline uint64_t scan_chunks(uint64_t n, uint32_t lc) { return (n + (1ull << lc) - 1) >> lc; }
 // aggregates of every level, for any chunk size >= 2^SCAN_MIN_LOG_CHUNK: sum_l ceil(n / 4^l) < n/3 + (levels <= 32)
 inline uint64_t scan_agg_felts(uint64_t count, uint32_t felts) { return felts * (count / ((1ull << SCAN_MIN_LOG_CHUNK) - 1) + 64); }
@@ -162,6 +182,15 @@ int permutation_product(Exec &ex, const PermOperand &num, const PermOperand &den
     if ((e = ex.perm_finish((const Fp *)tn, (const Fp *)td, count, tn, 1, 0))) return e;                               // n_k / d_k
     if ((e = scan_inclusive<MulOp>(ex, tn, count, aggs))) return e;
     return ex.perm_finish((const Fp *)tn, (const Fp *)nullptr, count, out, out_stride, out_off);
+}
+// the block's scanned maps (mc: 2 count felts, kept by the caller between the two phases); aggs: scan_agg_felts(count, 2)
+template <class Exec>
+int diluted_aggregate_maps(Exec &ex, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, bool starts_column, const Fp &z,
+                           const Fp &alpha, Fp *mc, Fp *aggs) {
+    if (count == 0) return 0;
+    int e = ex.dil_terms_block(x, stride, off, count, starts_column, z, alpha, mc);
+    if (e) return e;
+    return scan_inclusive<AffineOp>(ex, mc, count, aggs);
 }
 template <class Exec>
 int diluted_aggregate(Exec &ex, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z, const Fp &alpha, Fp *out,

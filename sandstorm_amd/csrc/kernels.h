@@ -124,6 +124,11 @@ hipError_t launch_permutation_product(hipStream_t st, const PermOperand &num, co
                                       const Fp &z, const Fp &alpha, Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch);
 hipError_t launch_diluted_aggregate(hipStream_t st, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z,
                                     const Fp &alpha, Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch);
+// the scans of ONE column over the row blocks of several devices (ABI 12): a block's own scan, then the blocks before it folded in
+hipError_t launch_scale_strided(hipStream_t st, Fp *data, uint64_t stride, uint64_t off, uint64_t count, const Fp &factor);
+hipError_t launch_diluted_aggregate_maps(hipStream_t st, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, bool starts_column,
+                                         const Fp &z, const Fp &alpha, Fp *mc, Fp *scratch);
+hipError_t launch_affine_apply(hipStream_t st, const Fp *mc, uint64_t count, const Fp &start, Fp *out, uint64_t out_stride, uint64_t out_off);
 
 // ---- trace.hip (the base trace on the device; ss_trace_* of the C ABI)
 // where the CPU's cells sit in a cycle's 16 rows (= ss_trace_layout): the memory pool's 8 (address, value) pairs, the range-check

@@ -3,6 +3,7 @@
 // (layouts/src/recursive/trace.rs:699-814, layouts/src/starknet/trace.rs:997-1100); here the auxiliary columns
 // stay in HBM and the loops are ss_permutation_product / ss_diluted_aggregate calls.
 #pragma once
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -22,5 +23,16 @@ struct TraceColumns {                       // what the reference's trace object
 // check: throw where the reference asserts that a permutation product closes to one (trace.rs:734, 757-760).
 Matrix build_extension_columns(ss_ctx *ctx, const std::string &layout, const TraceColumns &cols,
                                const std::vector<Felt> &challenges, bool check = true);
+
+// The same columns as ROW BLOCKS over `world` devices (one process per GPU): `cols` points at this rank's rows
+// [rank n / world, (rank + 1) n / world) of the auxiliary columns (cols.trace_len = n, the whole trace's length), the result holds
+// the same rows of the extension columns.  Every rank calls it with the same challenges; all_gather is entered ONCE per call with
+// (number of products + 4) * 32 bytes: every rank's bytes in rank order (a Transport's all_gather, MPI_Allgather ...).
+struct BlockGather {
+    uint32_t rank = 0, world = 1;
+    std::function<std::vector<uint8_t>(const std::vector<uint8_t> &)> all_gather;
+};
+Matrix build_extension_blocks(ss_ctx *ctx, const std::string &layout, const TraceColumns &cols, const std::vector<Felt> &challenges,
+                              const BlockGather &gather, bool check = true);
 
 }  // namespace ssh

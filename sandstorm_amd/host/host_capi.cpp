@@ -34,8 +34,9 @@ const char *ssh_last_error(void) { return g_err.c_str(); }
 // bumped whenever an entry point of this file changes its signature or meaning (hostlib.py checks it at load; ss_abi_version is
 // the device library's).  2: ssh_prove_sharded takes transport handles (ssh_rccl_group_create / ssh_callback_group_create)
 // instead of the raw RCCL id; ssh_air_create left for the callers' own AIR objects.  3: ssh_prove_files, ssh_base_trace_cb,
-// ssh_callback_group_create, ssh_group_self_check.
-#define SSH_HOST_ABI_VERSION 3
+// ssh_callback_group_create, ssh_group_self_check.  4: ssh_prove_sharded_blocks, ssh_build_extension_blocks (the extension trace
+// as row blocks over the ranks).
+#define SSH_HOST_ABI_VERSION 4
 uint32_t ssh_abi_version(void) { return SSH_HOST_ABI_VERSION; }
 
 // an `ssh_air` handle is an `Air *` (prover.hpp): the layouts' AIRs come from ssh_air_create_recursive / _starknet below; a caller
@@ -164,10 +165,13 @@ int ssh_group_self_check(ss_ctx *ctx, uint32_t rank, uint32_t world, ssh_local_g
 }
 typedef int (*ssh_sharded_extension_cb)(void *user, const uint64_t *challenges, uint32_t nchallenges, uint32_t *cols_out, uint64_t **d_cols_out,
                                         uint32_t *ncols_out);
-int ssh_prove_sharded(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32], uint32_t rank,
-                      uint32_t world, ssh_local_group *group, ssh_rccl_group *rccl, const uint32_t *base_cols, uint64_t *const *d_base,
-                      uint32_t nbase_mine, uint32_t log_n, ssh_sharded_extension_cb cb, void *user, const uint32_t options[5],
-                      uint8_t **proof_bytes, uint64_t *proof_len) {
+// the extension trace as ROW BLOCKS (ssh_build_extension_blocks): d_blocks_out = one block of 2^log_n / world rows per extension column
+typedef int (*ssh_extension_blocks_cb)(void *user, const uint64_t *challenges, uint32_t nchallenges, uint64_t **d_blocks_out);
+}  // extern "C"
+static int prove_sharded_impl(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32], uint32_t rank,
+                              uint32_t world, ssh_local_group *group, ssh_rccl_group *rccl, const uint32_t *base_cols, uint64_t *const *d_base,
+                              uint32_t nbase_mine, uint32_t log_n, ssh_sharded_extension_cb cb, ssh_extension_blocks_cb blocks_cb, void *user,
+                              const uint32_t options[5], uint8_t **proof_bytes, uint64_t *proof_len) {
     std::shared_ptr<LocalGroup> *lg = reinterpret_cast<std::shared_ptr<LocalGroup> *>(group);
     try {
         if (!ctx || !air_h || !seed || (!group && !rccl)) throw std::runtime_error("ssh_prove_sharded: NULL argument");
@@ -187,6 +191,15 @@ int ssh_prove_sharded(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_fri
         Digest sd;
         memcpy(sd.data(), seed, 32);
         ShardedProver prover(ctx, claim, *comm, opt);
+        if (blocks_cb)
+            prover.set_extension_blocks([&](const std::vector<Felt> &ch) {
+                std::vector<uint64_t> flat(4 * ch.size());
+                for (size_t i = 0; i < ch.size(); ++i) memcpy(flat.data() + 4 * i, ch[i].data(), 32);
+                std::vector<uint64_t *> blks(air->num_extension_columns, nullptr);
+                if (blocks_cb(user, flat.data(), (uint32_t)ch.size(), blks.data()) != 0) throw std::runtime_error("extension callback failed");
+                for (uint64_t *b : blks) if (!b) throw std::runtime_error("extension callback: a row block is missing");
+                return blks;
+            });
         Proof proof;
         const bool have = prover.prove(sd, mine, [&](const std::vector<Felt> &ch) {
             std::vector<uint64_t> flat(4 * ch.size());
@@ -205,6 +218,54 @@ int ssh_prove_sharded(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_fri
             memcpy(*proof_bytes, b.data(), b.size());
             *proof_len = b.size();
         }
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        if (lg) local_group_fail(**lg);
+        return 1;
+    }
+}
+extern "C" {
+int ssh_prove_sharded(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32], uint32_t rank,
+                      uint32_t world, ssh_local_group *group, ssh_rccl_group *rccl, const uint32_t *base_cols, uint64_t *const *d_base,
+                      uint32_t nbase_mine, uint32_t log_n, ssh_sharded_extension_cb cb, void *user, const uint32_t options[5],
+                      uint8_t **proof_bytes, uint64_t *proof_len) {
+    return prove_sharded_impl(ctx, air_h, tree_kind, n_friendly_layers, coin_kind, seed, rank, world, group, rccl, base_cols, d_base, nbase_mine, log_n, cb, nullptr,
+                              user, options, proof_bytes, proof_len);
+}
+// The same proof with the extension trace built as row blocks on EVERY rank (the scans of Trace::build_extension_columns divided
+// over the ranks: ssh_build_extension_blocks inside the callback) - no owner, no scatter of whole extension columns.
+int ssh_prove_sharded_blocks(ss_ctx *ctx, ssh_air *air_h, int tree_kind, uint32_t n_friendly_layers, int coin_kind, const uint8_t seed[32], uint32_t rank,
+                             uint32_t world, ssh_local_group *group, ssh_rccl_group *rccl, const uint32_t *base_cols, uint64_t *const *d_base,
+                             uint32_t nbase_mine, uint32_t log_n, ssh_extension_blocks_cb cb, void *user, const uint32_t options[5],
+                             uint8_t **proof_bytes, uint64_t *proof_len) {
+    if (!cb) { g_err = "ssh_prove_sharded_blocks: NULL callback"; return 1; }
+    return prove_sharded_impl(ctx, air_h, tree_kind, n_friendly_layers, coin_kind, seed, rank, world, group, rccl, base_cols, d_base, nbase_mine, log_n, nullptr, cb,
+                              user, options, proof_bytes, proof_len);
+}
+
+// Trace::build_extension_columns as row blocks over the ranks of a group (extension.hpp build_extension_blocks).  d_aux: as
+// ssh_build_extension_columns, but pointing at THIS rank's rows [rank n / world, (rank + 1) n / world) of the auxiliary columns;
+// trace_len = n.  group / transport: as ssh_prove_sharded (every rank of the group enters, with the same challenges; callable
+// from inside ssh_prove_sharded_blocks' callback).  The matrix holds the same rows of the extension columns.
+typedef struct ssh_matrix ssh_matrix;
+int ssh_build_extension_blocks(ss_ctx *ctx, int layout, const uint64_t *const *d_aux, uint64_t trace_len, uint32_t rank, uint32_t world,
+                               ssh_local_group *group, ssh_rccl_group *transport, const uint64_t *challenges, int check, ssh_matrix **out) {
+    std::shared_ptr<LocalGroup> *lg = reinterpret_cast<std::shared_ptr<LocalGroup> *>(group);
+    try {
+        if (!ctx || !d_aux || !challenges || !out || (!group && !transport)) throw std::runtime_error("ssh_build_extension_blocks: NULL argument");
+        std::unique_ptr<Transport> local = lg ? make_local_transport(*lg, rank) : nullptr;
+        Transport *comm = lg ? local.get() : reinterpret_cast<Transport *>(transport);
+        if (comm->world != world || comm->rank != rank) throw std::runtime_error("ssh_build_extension_blocks: the group has another number of ranks, or this is another rank of it");
+        TraceColumns c;
+        c.npc = d_aux[0]; c.memory = d_aux[1]; c.range_check = d_aux[2]; c.trace_len = trace_len;
+        if (layout == 1) { c.diluted_unordered = d_aux[3]; c.diluted_ordered = d_aux[4]; }
+        std::vector<Felt> ch(6);
+        for (int i = 0; i < 6; ++i) memcpy(ch[i].data(), challenges + 4 * i, 32);
+        BlockGather g;
+        g.rank = rank; g.world = world;
+        g.all_gather = [&](const std::vector<uint8_t> &mine) { return comm->all_gather(ctx, mine); };
+        *out = reinterpret_cast<ssh_matrix *>(new Matrix(build_extension_blocks(ctx, layout == 1 ? "recursive" : "starknet", c, ch, g, check != 0)));
         return 0;
     } catch (const std::exception &e) {
         g_err = e.what();

@@ -613,6 +613,20 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
         co->insert(co->end(), cb.begin(), cb.end());
         return ev;
     };
+    // the same from columns that ARRIVE as blocks of n / R rows (the extension trace made by build_extension_blocks): no scatter
+    auto spread_lde_of_blocks = [&](const std::vector<uint64_t *> &blks, std::vector<Buf> *co) {
+        std::vector<Buf> xb;
+        for (uint64_t *p : blks) {
+            Buf blk = std::make_shared<DeviceBuffer>(ctx_, 32 * nb_rows);
+            ok(ss_dev_copy(ctx_, blk->u8(), p, 32 * nb_rows));
+            xb.push_back(blk);
+        }
+        std::vector<Buf> cb = spread_inverse(xb, log_n, nullptr);
+        xb.clear();
+        std::vector<Buf> ev = with_halo(spread_forward(cb, log_N, lb, &g), B, halo);
+        co->insert(co->end(), cb.begin(), cb.end());
+        return ev;
+    };
     // 2. base trace: R columns at a time, one per rank, extended whole on their owners and dealt out as row blocks; a few columns
     // left over (9 columns on 8 ranks: one) each as one transform over all the ranks - no rank extends two while the others wait
     for (uint32_t c = 0; c < nb; ++c)
@@ -639,10 +653,16 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
     std::vector<Buf> blocks = base_blocks, ext_blocks;
     std::unique_ptr<Commitment> ext_com;
     if (ne) {
-        const std::map<uint32_t, uint64_t *> my_ext = build_extension(proof.challenges);
-        for (uint32_t c = nb; c < nb + ne; ++c)
-            if ((owner(c) == r) != (my_ext.count(c) == 1)) throw std::runtime_error("extension column c lives on rank c % R");
-        ext_blocks = spread_lde(my_ext, nb, ne, &spread_coeff_blocks);
+        if (ext_blocks_) {
+            const std::vector<uint64_t *> blks = ext_blocks_(proof.challenges);
+            if (blks.size() != ne) throw std::runtime_error("the extension builder returns one row block per extension column");
+            ext_blocks = spread_lde_of_blocks(blks, &spread_coeff_blocks);
+        } else {
+            const std::map<uint32_t, uint64_t *> my_ext = build_extension(proof.challenges);
+            for (uint32_t c = nb; c < nb + ne; ++c)
+                if ((owner(c) == r) != (my_ext.count(c) == 1)) throw std::runtime_error("extension column c lives on rank c % R");
+            ext_blocks = spread_lde(my_ext, nb, ne, &spread_coeff_blocks);
+        }
         ext_com = commit(ext_blocks, N, order);
         proof.has_extension = true;
         proof.extension_root = ext_com->root;

@@ -60,6 +60,10 @@ void transport_self_check(ss_ctx *ctx, Transport &comm, uint64_t bandwidth_bytes
 // rank owns (column c lives on rank c % world)
 using ShardedExtensionBuilder = std::function<std::map<uint32_t, uint64_t *>(const std::vector<Felt> &challenges)>;
 
+// the same as ROW BLOCKS (extension.hpp build_extension_blocks): on EVERY rank, rows [rank n / world, (rank + 1) n / world) of all
+// the extension columns, in column order - the scans divide over the ranks and the owner's scatter falls away
+using ShardedExtensionBlocks = std::function<std::vector<uint64_t *>(const std::vector<Felt> &challenges)>;
+
 class ShardedProver {
 public:
     ShardedProver(ss_ctx *ctx, const Claim &claim, Transport &comm, const ProofOptions &opt = ProofOptions(), const Conventions &conv = Conventions())
@@ -69,6 +73,8 @@ public:
     bool prove(const Digest &coin_seed, const std::map<uint32_t, uint64_t *> &my_base, const ShardedExtensionBuilder &build_extension,
                uint64_t n, Proof *out);
     void set_pow_nonce(uint64_t nonce) { have_nonce_ = true; nonce_ = nonce; }
+    // the extension trace comes as row blocks from this builder; prove()'s build_extension is not called
+    void set_extension_blocks(ShardedExtensionBlocks b) { ext_blocks_ = std::move(b); }
 private:
     struct Commitment;
     using Buf = std::shared_ptr<DeviceBuffer>;
@@ -93,6 +99,7 @@ private:
     Conventions conv_;
     bool have_nonce_ = false;
     uint64_t nonce_ = 0;
+    ShardedExtensionBlocks ext_blocks_;
 };
 
 // MerkleTreeConfig::hash_nodes on the host for the log2(world) levels above the ranks' sub-trees (33 bytes: digest + tag)

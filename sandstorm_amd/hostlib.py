@@ -16,8 +16,9 @@ AIR_MINI = 0
 EXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p))
 ALL_TO_ALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint64))
 ALL_GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint8))
-HOST_ABI_VERSION = 3             # host_capi.cpp SSH_HOST_ABI_VERSION
+HOST_ABI_VERSION = 4             # host_capi.cpp SSH_HOST_ABI_VERSION
 SHARDED_EXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32))
+EXT_BLOCKS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p))
 
 _host = None
 
@@ -54,6 +55,9 @@ def load():
         h.ssh_prove_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, SHARDED_EXT_CB, C.c_void_p,
                                         C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
+        h.ssh_prove_sharded_blocks.argtypes = h.ssh_prove_sharded.argtypes[:14] + [EXT_BLOCKS_CB] + h.ssh_prove_sharded.argtypes[15:]
+        h.ssh_build_extension_blocks.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                 C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_void_p)]
         h.ssh_prove_wire_with_nonce.argtypes = h.ssh_prove.argtypes[:12] + [C.c_uint64] + h.ssh_prove.argtypes[12:]
         h.ssh_free.argtypes = [C.c_void_p]
         h.ssh_build_extension_columns.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_uint64, C.POINTER(C.c_uint64),
@@ -359,6 +363,19 @@ def build_extension_columns(ctx, layout, aux_cols, trace_len, challenges, check=
     _check(load().ssh_build_extension_columns(ctx.handle, 1 if layout == "recursive" else 2, be._ptr_array(aux_cols), trace_len,
                                               ch.ctypes.data_as(C.POINTER(C.c_uint64)), 1 if check else 0, C.byref(h)))
     return HostMatrix(ctx, h, trace_len)
+
+
+def build_extension_blocks(ctx, layout, aux_blocks, trace_len, rank, world, group, challenges, check=True):
+    """the same columns as ROW BLOCKS over the ranks of `group` (host/extension.cpp build_extension_blocks): aux_blocks = this rank's
+    rows [rank n / world, (rank + 1) n / world) of the auxiliary columns, trace_len = n; every rank enters (one all-gather of the
+    blocks' totals).  -> a HostMatrix of the same rows of the extension columns"""
+    ch = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint64) for c in challenges[:6]]))
+    h = C.c_void_p()
+    local = isinstance(group, LocalGroup)
+    _check(load().ssh_build_extension_blocks(ctx.handle, 1 if layout == "recursive" else 2, be._ptr_array(aux_blocks), trace_len, rank, world,
+                                             group.h if local else None, None if local else group.h, ch.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                             1 if check else 0, C.byref(h)))
+    return HostMatrix(ctx, h, trace_len // world)
 
 
 def public_coin_seed(pi, coin_kind):
@@ -828,14 +845,30 @@ def group_self_check(ctx, rank, world, group, bandwidth_bytes=0):
     return gbps.value
 
 
-def prove_sharded(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, rank, world, group, my_base, log_n, build_extension, options=None):
+def prove_sharded(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, rank, world, group, my_base, log_n, build_extension, options=None,
+                  extension_blocks=None):
     """ONE proof over `world` ranks by the C++ host (host/sharded.cpp; the Python mirror is sandstorm_amd/sharded_prover.py).  Called
     by every rank with its own context and AIR handle.  group: a LocalGroup (ranks = threads of this process), this rank's
     RcclGroup (one process per GPU) or a CallbackGroup (one process per GPU, the caller's collectives).  my_base: {column: device column} of the base columns with column % world ==
     rank; build_extension(challenges) -> {global column number: device column} of this rank's extension columns (kept alive by
-    the caller).  -> the proof in the reference's wire format on rank 0, None on the others."""
+    the caller).  extension_blocks(challenges) -> [device block of 2^log_n / world rows per extension column] on EVERY rank (the
+    scans divided over the ranks: build_extension_blocks) replaces build_extension.  -> the proof in the reference's wire format on
+    rank 0, None on the others."""
     options = options or ProofOptions()
     keep = []
+
+    def blocks_cb(_user, ch_ptr, nch, ptrs_out):
+        try:
+            ch = [np.array([ch_ptr[4 * i + k] for k in range(4)], dtype=np.uint64) for i in range(nch)]
+            blks = list(extension_blocks(ch))
+            keep.append(blks)
+            for i, b in enumerate(blks):
+                ptrs_out[i] = be._ptr_of(b)
+            return 0
+        except Exception:                       # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
 
     def cb(_user, ch_ptr, nch, cols_out, ptrs_out, ncols_out):
         try:
@@ -857,9 +890,11 @@ def prove_sharded(ctx, air: HostAir, tree_kind, n_friendly, coin_kind, seed, ran
     col_ids = (C.c_uint32 * max(1, len(cols)))(*cols)
     out, n = C.POINTER(C.c_uint8)(), C.c_uint64()
     local = isinstance(group, LocalGroup)
-    _check(load().ssh_prove_sharded(ctx.handle, air.h, tree_kind, n_friendly, coin_kind, bytes(seed), rank, world, group.h if local else None,
-                                    None if local else group.h, col_ids, be._ptr_array([my_base[c] for c in cols]), len(cols), log_n,
-                                    SHARDED_EXT_CB(cb), None, opts, C.byref(out), C.byref(n)))
+    entry, callback = ((load().ssh_prove_sharded_blocks, EXT_BLOCKS_CB(blocks_cb)) if extension_blocks is not None else
+                       (load().ssh_prove_sharded, SHARDED_EXT_CB(cb)))
+    _check(entry(ctx.handle, air.h, tree_kind, n_friendly, coin_kind, bytes(seed), rank, world, group.h if local else None,
+                 None if local else group.h, col_ids, be._ptr_array([my_base[c] for c in cols]), len(cols), log_n,
+                 callback, None, opts, C.byref(out), C.byref(n)))
     if not n.value:
         return None
     raw = bytes(bytearray(out[:n.value]))

@@ -55,6 +55,10 @@ struct LoopExec {                               // a "launch" = the lane body fo
         for (uint64_t k = count + 3; k-- > 0;) dil_finish_lane(k, mc, count, out, os, oo);
         return 0;
     }
+    int dil_terms_block(const Fp *x, uint64_t stride, uint64_t off, uint64_t count, bool starts_column, const Fp &z, const Fp &alpha, Fp *mc) {
+        for (uint64_t k = count + 3; k-- > 0;) dil_terms_block_lane(k, x, stride, off, count, starts_column, z, alpha, mc);
+        return 0;
+    }
 };
 
 static Fp term(const Fp *col, uint64_t stride, uint64_t a, int64_t v, uint64_t k, const Fp &z, const Fp &alpha) {
@@ -117,6 +121,50 @@ int main() {
             }
             for (uint64_t i = 0; i < out.size(); ++i)
                 if (!fp_eq(out[i], want[i])) { printf("diluted aggregate mismatch: count %llu dense %d index %llu\n", (unsigned long long)count, dense, (unsigned long long)i); return 1; }
+            ++cases;
+        }
+        // the same column as row blocks (one scan over several devices): every block's own maps, the term between two blocks
+        // composed from the two boundary values, the value before the block applied - the cells of the single scan (`want`)
+        for (uint64_t nblocks : {2ull, 5ull}) {
+            if (count < nblocks || count > 5000) continue;
+            const uint64_t stride = 8, off = 5, os = 8, oo = 3, per = count / nblocks, total = per * nblocks;
+            std::vector<Fp> x(total * stride);
+            for (auto &v : x) v = random_fp();
+            const Fp z = random_fp(), alpha = random_fp(), sentinel = random_fp();
+            std::vector<Fp> out(total * os, sentinel), want(total * os, sentinel), scratch(diluted_aggregate_scratch_felts(total));
+            if (diluted_aggregate(ex, x.data(), stride, off, total, z, alpha, want.data(), os, oo, scratch.data())) { printf("exec error\n"); return 1; }
+            Fp value = fp_zero();
+            for (uint64_t b = 0; b < nblocks; ++b) {
+                const Fp *xb = x.data() + b * per * stride;
+                std::vector<Fp> maps(2 * per), aggs(scan_agg_felts(per, 2));
+                if (diluted_aggregate_maps(ex, xb, stride, off, per, b == 0, z, alpha, maps.data(), aggs.data())) { printf("exec error\n"); return 1; }
+                Fp start = value;
+                if (b) {
+                    const Fp u = fp_sub(xb[off], xb[off - stride]);
+                    start = fp_add(fp_mul(value, fp_add(fp_one(), fp_mul(z, u))), fp_mul(alpha, fp_sqr(u)));
+                }
+                for (uint64_t k = per + 3; k-- > 0;) affine_apply_lane(k, maps.data(), per, start, out.data() + b * per * os, os, oo);
+                value = fp_add(fp_mul(maps[2 * (per - 1)], start), maps[2 * (per - 1) + 1]);
+            }
+            for (uint64_t i = 0; i < out.size(); ++i)
+                if (!fp_eq(out[i], want[i])) { printf("blocked aggregate mismatch: count %llu blocks %llu index %llu\n", (unsigned long long)count, (unsigned long long)nblocks, (unsigned long long)i); return 1; }
+            // a running product over the same blocks: the block's own scan, scaled by the product of the blocks before it
+            std::vector<Fp> a(total * 4);
+            for (auto &v : a) v = random_fp();
+            std::vector<Fp> pout(total * 4, sentinel), pwant(total * 4, sentinel), ps(permutation_product_scratch_felts(total));
+            const PermOperand num{a.data(), 4, 0, -1}, den{a.data(), 4, 2, -1};
+            if (permutation_product(ex, num, den, total, z, alpha, pwant.data(), 4, 1, ps.data())) { printf("exec error\n"); return 1; }
+            Fp before = fp_one();
+            for (uint64_t b = 0; b < nblocks; ++b) {
+                const PermOperand nb{a.data() + 4 * b * per, 4, 0, -1}, db{a.data() + 4 * b * per, 4, 2, -1};
+                Fp *ob = pout.data() + 4 * b * per;
+                if (permutation_product(ex, nb, db, per, z, alpha, ob, 4, 1, ps.data())) { printf("exec error\n"); return 1; }
+                const Fp last = ob[4 * (per - 1) + 1];
+                if (b) for (uint64_t k = per + 3; k-- > 0;) scale_strided_lane(k, ob, 4, 1, per, before);
+                before = fp_mul(before, last);
+            }
+            for (uint64_t i = 0; i < pout.size(); ++i)
+                if (!fp_eq(pout[i], pwant[i])) { printf("blocked product mismatch: count %llu blocks %llu index %llu\n", (unsigned long long)count, (unsigned long long)nblocks, (unsigned long long)i); return 1; }
             ++cases;
         }
     }

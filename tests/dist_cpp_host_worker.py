@@ -8,8 +8,9 @@ exchange - what eight processes on eight GPUs do.
 argv: case out_path [repeat]
   mini:<log_n>:<max_remainder>            tests/mini_air.py, masked-Keccak trees + Solidity coin
   mini-cairo:<log_n>:<max_remainder>:<N>  the same under FriendlyMerkleTree<N> + the Cairo coin
-  recursive:<log_steps>                   the reference's example padded to 2^log_steps steps, the real recursive AIR, CairoVerifierClaim
-  starknet:<log_steps>                    the same run re-declared for the starknet layout, the real starknet AIR, the Eth claim's parts
+  recursive:<log_steps>[:blocks]          the reference's example padded to 2^log_steps steps, the real recursive AIR, CairoVerifierClaim
+  starknet:<log_steps>[:blocks]           the same run re-declared for the starknet layout, the real starknet AIR, the Eth claim's parts
+                                          (blocks: the extension trace as row blocks on every rank, hostlib.build_extension_blocks)
   selfcheck[:corrupt]                     only the group's self check (hostlib.group_self_check); corrupt: rank 1's all-to-all flips one
                                           received byte - the check must fail on every rank, naming rank 1 (out_path: one verdict line per rank)
 rank 0 writes the proof (reference wire format) to out_path."""
@@ -73,20 +74,21 @@ def main():
         make, _ = cases.mini_case(int(kind[1]), int(kind[2]))
     elif kind[0] == "mini-cairo":
         make, _ = cases.mini_case(int(kind[1]), int(kind[2]), "cairo", int(kind[3]))
-    elif kind[0] == "recursive":
-        make, _ = cases.recursive_case(int(kind[1]))
-    elif kind[0] == "starknet":
-        make, _ = cases.starknet_case(int(kind[1]))
+    elif kind[0] in ("recursive", "starknet"):
+        make_case, _ = (cases.recursive_case if kind[0] == "recursive" else cases.starknet_case)(int(kind[1]))
+        make = (lambda w: make_case(w, blocks=True)) if kind[2:] == ["blocks"] else make_case
     else:
         raise SystemExit("unknown case %r" % case)
     ctx = be.Context(0)
     air, tree_kind, nf, coin_kind, seed, mine, log_n, ext, opt = make(world)(rank, ctx)
     group = hostlib.torch_dist_group()
+    ext.group = group
     hostlib.group_self_check(ctx, rank, world, group)       # as bench.py does before its warm-up
     proof = None
     try:
         for _ in range(repeat):                              # a group outlives a proof
-            proof = hostlib.prove_sharded(ctx, air, tree_kind, nf, coin_kind, seed, rank, world, group, mine, log_n, ext, opt)
+            proof = hostlib.prove_sharded(ctx, air, tree_kind, nf, coin_kind, seed, rank, world, group, mine, log_n, ext, opt,
+                                          extension_blocks=getattr(ext, "blocks", None))
             assert (proof is not None) == (rank == 0)
     finally:
         group.close()

@@ -39,15 +39,16 @@ def test_cpp_sharded_prover_friendly_tree_and_cairo_coin(world):
     assert run_ranks(world, make(world)) == want
 
 
-@pytest.mark.parametrize("world", [4, 8])
-def test_cpp_sharded_prover_real_recursive_air_cairo_claim(world):
+@pytest.mark.parametrize("world,blocks", [(4, False), (8, False), (2, True), (8, True)])
+def test_cpp_sharded_prover_real_recursive_air_cairo_claim(world, blocks):
     """the reference's example under the CLI's claim for it, 4 and 8 ranks: tests/golden/array_sum_recursive_cairo.proof (written by
     the single-device C++ host on the MI355X), wrap-around halo of 4116 rows included; three extension columns, the composition
-    and DEEP's extension each ONE transform over the ranks, two FRI layers folded by the ranks"""
+    and DEEP's extension each ONE transform over the ranks, two FRI layers folded by the ranks.  blocks: the extension trace's scans
+    divided over the ranks too (build_extension_blocks: every rank its rows, one all-gather of the blocks' totals) - the same bytes"""
     make, _ = recursive_case(14)
     with open(os.path.join(GOLD, "array_sum_recursive_cairo.proof"), "rb") as f:
         want = f.read()
-    assert run_ranks(world, make(world)) == want
+    assert run_ranks(world, make(world, blocks=blocks)) == want
 
 
 def test_too_few_rows_for_the_ranks_is_an_error():

@@ -64,13 +64,14 @@ def test_processes_friendly_tree_and_cairo_coin(world, tmp_path):
     assert run_processes(world, "mini-cairo:9:4:7", tmp_path) == want
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_processes_real_recursive_air_cairo_claim(world, tmp_path):
+@pytest.mark.parametrize("world,case", [(2, "recursive:14"), (4, "recursive:14"), (4, "recursive:14:blocks")])
+def test_processes_real_recursive_air_cairo_claim(world, case, tmp_path):
     """the reference's example under the CLI's claim for it: tests/golden/array_sum_recursive_cairo.proof (written by the single-device
-    C++ host on the MI355X).  2 ranks: base column 6 is left over and spread; 4 ranks: every base column on its owner"""
+    C++ host on the MI355X).  2 ranks: base column 6 is left over and spread; 4 ranks: every base column on its owner.  blocks: the
+    extension trace's scans divided over the processes (one all-gather of the blocks' totals over gloo)"""
     with open(os.path.join(GOLD, "array_sum_recursive_cairo.proof"), "rb") as f:
         want = f.read()
-    assert run_processes(world, "recursive:14", tmp_path) == want
+    assert run_processes(world, case, tmp_path) == want
 
 
 @pytest.mark.parametrize("world", [2, 8])

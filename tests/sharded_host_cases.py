@@ -27,9 +27,11 @@ def run_ranks(world, make_rank, group=None, repeat=1):
             ctx = be.Context(0)
             air, tree_kind, nf, coin_kind, seed, mine, log_n, ext, opt = make_rank(rank, ctx)
             grp = hostlib.RcclGroup(ctx, rccl_id, rank, world) if rccl_id is not None else group
+            ext.group = grp                      # (the block form of the extension trace exchanges its blocks' totals over it)
             try:
                 for _ in range(repeat):          # a communicator outlives a proof (an RCCL unique id serves ONE ncclCommInitRank per rank)
-                    out[rank] = hostlib.prove_sharded(ctx, air, tree_kind, nf, coin_kind, seed, rank, world, grp, mine, log_n, ext, opt)
+                    out[rank] = hostlib.prove_sharded(ctx, air, tree_kind, nf, coin_kind, seed, rank, world, grp, mine, log_n, ext, opt,
+                                                      extension_blocks=getattr(ext, "blocks", None))
             finally:
                 if rccl_id is not None:
                     grp.close()                             # everything that lives in the context's pool goes before the context does
@@ -118,12 +120,21 @@ def recursive_case(log_steps, claim="cairo"):
     opt = ProofOptions()
     aux_cols = (rec.COL_NPC, rec.COL_MEMORY, rec.COL_RANGE_CHECK, rec.COL_DILUTED_UNORDERED, rec.COL_DILUTED_ORDERED)
 
-    def make(world):
+    def make(world, blocks=False):
+        """blocks: the extension trace as row blocks on every rank (hostlib.build_extension_blocks: the scans divided over the ranks)"""
         def make_rank(rank, ctx):
             air = hostlib.RecursiveHostAir(ctx, pi, log_n, 1)
             mine = {c: ctx.column(v) for c, v in enumerate(host) if c % world == rank}
             my_ext = [c for c in (7, 8, 9) if c % world == rank]
             keep = []
+            nb = n // world
+
+            def ext_blocks(challenges):
+                aux = [ctx.column(host[c][rank * nb:(rank + 1) * nb]) for c in aux_cols]
+                m = hostlib.build_extension_blocks(ctx, "recursive", aux, n, rank, world, ext.group, challenges)
+                keep.append(aux)
+                ext.matrices.append(m)
+                return m.cols
 
             def ext(challenges):
                 if not my_ext:
@@ -134,6 +145,8 @@ def recursive_case(log_steps, claim="cairo"):
                 ext.matrices.append(m)
                 return {c: m.cols[c - 7] for c in my_ext}
             ext.matrices = []
+            if blocks:
+                ext.blocks = ext_blocks
             return air, tree, nf, coin, seed, mine, log_n, ext, opt
         return make_rank
     return make, (tree, nf, coin, opt, host, log_n, pi, seed)
@@ -158,11 +171,19 @@ def starknet_case(log_steps):
     nb = len(host)
     aux_cols = (sk.COL_NPC, sk.COL_MEMORY, sk.COL_RANGE_CHECK)
 
-    def make(world):
+    def make(world, blocks=False):
         def make_rank(rank, ctx):
             air = hostlib.StarknetHostAir(ctx, spi, log_n)
             mine = {c: ctx.column(v) for c, v in enumerate(host) if c % world == rank}
             keep = []
+            nb_rows = n // world
+
+            def ext_blocks(challenges):
+                aux = [ctx.column(host[c][rank * nb_rows:(rank + 1) * nb_rows]) for c in aux_cols]
+                m = hostlib.build_extension_blocks(ctx, "starknet", aux, n, rank, world, ext.group, challenges)
+                keep.append(aux)
+                ext.matrices.append(m)
+                return m.cols
 
             def ext(challenges):
                 if nb % world != rank:               # the one extension column is column nb
@@ -173,6 +194,8 @@ def starknet_case(log_steps):
                 ext.matrices.append(m)
                 return {nb: m.cols[0]}
             ext.matrices = []
+            if blocks:
+                ext.blocks = ext_blocks
             return air, tree, nf, coin, seed, mine, log_n, ext, opt
         return make_rank
     return make, (tree, nf, coin, opt, host, log_n, spi, seed)

@@ -77,7 +77,7 @@ def test_extension_columns_and_compiled_constraint_kernels(emulated_library):
     starknet / recursive kernels against the interpreter and the oracle over whole domains)"""
     heavy()
     out = run_gpu_tests_on_host(emulated_library, ["tests/test_gpu_extension.py", "tests/test_gpu_real_quotient.py", "-k", "not back_to_back"])
-    assert "41 passed" in out, out[-500:]                     # 36 + 5 (the sixth queues 2^20-point evaluations back to back: hardware only)
+    assert "53 passed" in out, out[-500:]                     # 48 (12 of them the scans over row blocks) + 5 (the sixth queues 2^20-point evaluations back to back: hardware only)
 
 
 def test_the_base_trace_made_by_the_device_code(emulated_library):
@@ -132,7 +132,7 @@ def test_cpp_sharded_prover_over_ranks_as_threads(emulated_library):
         out = run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_sharded_host.py"])
     finally:
         del os.environ["HIPEMU_THREADS"]
-    assert "12 passed" in out, out[-500:]                     # 7 mini + 2 friendly + 2 real AIR + the too-few-rows error
+    assert "14 passed" in out, out[-500:]                     # 7 mini + 2 friendly + 4 real AIR (2 with the extension trace as row blocks) + the too-few-rows error
 
 
 def test_cpp_sharded_prover_over_ranks_as_processes(emulated_library):
@@ -142,4 +142,4 @@ def test_cpp_sharded_prover_over_ranks_as_processes(emulated_library):
     AIR with a spread base column)"""
     heavy()
     out = run_gpu_tests_on_host(emulated_library, ["tests/hipemu/extra_sharded_host_procs.py"])
-    assert "9 passed" in out, out[-500:]                      # 3 mini + 2 friendly + 2 real AIR + the group self check on 2 and 8
+    assert "10 passed" in out, out[-500:]                     # 3 mini + 2 friendly + 3 real AIR (one with the extension trace as row blocks) + the group self check on 2 and 8

@@ -123,6 +123,108 @@ def test_cpp_host_build_extension_columns(ctx, oracle, layout):
         hostlib.build_extension_columns(ctx, layout, dev, n, ch)
 
 
+@pytest.mark.parametrize("dense", [True, False])
+@pytest.mark.parametrize("world", [2, 8])
+def test_block_scans_compose_to_the_whole_scan(ctx, oracle, world, dense):
+    """ABI 12: ss_diluted_aggregate_block + ss_affine_apply and ss_permutation_product + ss_scale_strided on `world` row blocks, the blocks
+    before a block folded in on the host as host/extension.cpp build_extension_blocks does - the single scan's cells, bit for bit"""
+    count = 512                                         # items per block
+    stride, off, os_, oo = (1, 0, 1, 0) if dense else (8, 5, 8, 3)
+    total = count * world
+    x = random_column(stride * total, 21)
+    z, alpha = random_column(2, 22)
+    want = _filled(oracle, total * os_)
+    oracle.diluted_aggregate(x, stride, off, total, z, alpha, want, os_, oo)
+    zc, ac = (int(v) for v in oracle.from_mont(np.stack([z, alpha])))
+    xs = [int(v) for v in oracle.from_mont(x[off::stride])]
+    value = None
+    got = _filled(oracle, total * os_)
+    for r in range(world):
+        dx = ctx.column(x[r * count * stride:(r + 1) * count * stride])
+        maps = ctx.alloc(64 * count)
+        m, c = (int(oracle.from_mont(t[None])[0]) for t in ctx.diluted_aggregate_block(dx, stride, off, count, r == 0, z, alpha, maps))
+        start = 0
+        if r:
+            u = (xs[r * count] - xs[r * count - 1]) % P
+            start = (value * (1 + zc * u) + ac * u * u) % P
+        dout = ctx.column(_filled(oracle, count * os_))
+        ctx.affine_apply(maps, count, oracle.to_mont([start])[0], dout, os_, oo)
+        got[r * count * os_:(r + 1) * count * os_] = dout.download(np.uint64, (count * os_, 4))
+        value = (m * start + c) % P
+    assert np.array_equal(got, want)
+    # a running product: the block's own product, then times the blocks before it
+    a = random_column(4 * total, 23)
+    want = _filled(oracle, total * 4)
+    oracle.permutation_product((a, 4, 0, -1), (a, 4, 2, -1), total, z, alpha, want, 4, 1)
+    got = _filled(oracle, total * 4)
+    before = 1
+    for r in range(world):
+        da = ctx.column(a[4 * r * count:4 * (r + 1) * count])
+        dout = ctx.column(_filled(oracle, count * 4))
+        last = ctx.permutation_product((da, 4, 0, -1), (da, 4, 2, -1), count, z, None, dout, 4, 1)
+        if r:
+            ctx.scale_strided(dout, 4, 1, count, oracle.to_mont([before])[0])
+        got[4 * r * count:4 * (r + 1) * count] = dout.download(np.uint64, (count * 4, 4))
+        before = before * int(oracle.from_mont(last[None])[0]) % P
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("layout", ["recursive", "starknet"])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_cpp_host_build_extension_blocks(oracle, layout, world):
+    """the C++ host's build_extension_blocks (the scans of Trace::build_extension_columns divided over `world` ranks, here threads
+    with a context each, one all-gather of the blocks' totals): rank r's matrix = rows [r n / world, (r + 1) n / world) of the
+    oracle's extension columns; a column that is no permutation is refused on EVERY rank"""
+    import threading
+    from sandstorm_amd import backend as be, hostlib
+    from sandstorm_amd._lib import SandstormHipError
+    n = 1 << 11
+    nb = n // world
+    host = permuted_trace(oracle, layout, n, seed=9)
+    ch = challenges(oracle)
+    want, _ = oracle.build_extension_columns(layout, host, ch, n)
+    names = ["npc", "memory", "range_check"] + (["diluted_unordered", "diluted_ordered"] if layout == "recursive" else [])
+    bad = dict(host)
+    bad["range_check"] = host["range_check"].copy()
+    bad["range_check"][2] = oracle.to_mont([4242])[0]
+
+    def run(columns, check=True):
+        group = hostlib.LocalGroup(world)
+        out, errs = [None] * world, [None] * world
+
+        def body(r):
+            c = be.Context(0)
+            try:
+                dev = [c.column(columns[k][r * nb:(r + 1) * nb]) for k in names]
+                m = hostlib.build_extension_blocks(c, layout, dev, n, r, world, group, ch, check=check)
+                out[r] = m.to_host()
+                m.close()
+            except BaseException as e:           # noqa: BLE001 - compared below
+                errs[r] = e
+            finally:
+                c.close()
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        group.close()
+        return out, errs
+    out, errs = run(host)
+    assert errs == [None] * world, errs
+    for r in range(world):
+        assert len(out[r]) == len(want)
+        for g, w in zip(out[r], want):
+            assert np.array_equal(g, w[r * nb:(r + 1) * nb]), (r, world)
+    out, errs = run(bad)
+    # (every rank computes the same closing value and throws; one that is still inside the gather's last barrier when the first
+    # failure marks the thread group learns it as "another rank failed")
+    assert all(isinstance(e, SandstormHipError) and ("range-check permutation product" in str(e) or "another rank failed" in str(e)) for e in errs), errs
+    assert any("range-check permutation product" in str(e) for e in errs), errs
+    out, errs = run(bad, check=False)
+    assert errs == [None] * world and all(o is not None for o in out)
+
+
 def test_extension_scans_at_full_size(ctx, oracle):
     """2^22 items (a 2^23-row memory column, the starknet 2^19-step shape): a true permutation closes to one, and
     sampled neighbours satisfy out_{i+1} * den_{i+1} = out_i * num_{i+1} (big integers)."""

@@ -92,10 +92,11 @@ def test_cpp_sharded_host_two_ranks_at_2p20_steps_real_starknet_air(proof_2p20):
     """the C++ host's sharded prover (host/sharded.cpp) at BASELINE configs[2]'s size on two ranks - threads of this process, each
     with its own context on this box's GPU: column-owned base LDE and re-shard with the 66 316-row halo, the extension column, the
     composition (one 2^25-point inverse, two extensions) and DEEP's extension each ONE transform over the ranks, FRI layers 0 and
-    1 (2^25 and 2^22 values) folded and committed by both ranks - the single-device proof, byte for byte"""
+    1 (2^25 and 2^22 values) folded and committed by both ranks - the single-device proof, byte for byte.  The extension column comes as
+    row blocks: each rank scans its 2^23 rows, one all-gather of the blocks' totals (hostlib.build_extension_blocks, ABI 12)"""
     from tests.sharded_host_cases import run_ranks, starknet_case
     make, _ = starknet_case(20)
-    assert run_ranks(2, make(2)) == proof_2p20
+    assert run_ranks(2, make(2, blocks=True)) == proof_2p20
 
 
 def test_cpp_sharded_host_two_PROCESSES_at_2p20_steps_real_starknet_air(proof_2p20, tmp_path):

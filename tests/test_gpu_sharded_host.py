@@ -40,14 +40,15 @@ def test_cpp_sharded_prover_friendly_tree_and_cairo_coin(world):
     assert run_ranks(world, make(world)) == want
 
 
-@pytest.mark.parametrize("world", [1, 4])
-def test_cpp_sharded_prover_real_recursive_air_cairo_claim(world):
+@pytest.mark.parametrize("world,blocks", [(1, False), (4, False), (1, True), (2, True), (8, True)])
+def test_cpp_sharded_prover_real_recursive_air_cairo_claim(world, blocks):
     """the reference's example under the CLI's claim for it: tests/golden/array_sum_recursive_cairo.proof (the single-device C++
-    host's), wrap-around halo of 4116 rows on the last rank"""
+    host's), wrap-around halo of 4116 rows on the last rank.  blocks: the extension trace's scans divided over the ranks (ABI 12:
+    hostlib.build_extension_blocks, one all-gather of the blocks' totals) - the same bytes"""
     make, _ = recursive_case(14)
     with open(os.path.join(GOLD, "array_sum_recursive_cairo.proof"), "rb") as f:
         want = f.read()
-    assert run_ranks(world, make(world)) == want
+    assert run_ranks(world, make(world, blocks=blocks)) == want
 
 
 def test_cpp_sharded_prover_at_2p16_steps_two_ranks():
@@ -82,7 +83,8 @@ def test_rccl_transport_with_a_group_of_one():
 
 
 @pytest.mark.parametrize("world,case,gold", [(2, "mini:9:4", "mini_proof_eth_log9.bin"), (4, "mini:9:4", "mini_proof_eth_log9.bin"),
-                                             (2, "recursive:14", "array_sum_recursive_cairo.proof")])
+                                             (2, "recursive:14", "array_sum_recursive_cairo.proof"),
+                                             (4, "recursive:14:blocks", "array_sum_recursive_cairo.proof")])
 def test_cpp_sharded_prover_with_ranks_as_processes(world, case, gold, tmp_path):
     """the ranks as PROCESSES under torch.distributed.run - what `bench.py --gpus N` starts - sharing this box's GPU: every process with
     its own context, coin and columns, the group self check first, the exchanges through the driver's CallbackTransport over gloo

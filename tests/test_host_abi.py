@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
     from sandstorm_amd import _lib
-    assert lib.ss_abi_version() == _lib.header_abi_version() == 11
+    assert lib.ss_abi_version() == _lib.header_abi_version() == 12
 
 
 def test_boundary_document_and_bindings_follow_the_header():
@@ -121,7 +121,7 @@ def test_host_library_document_names_what_the_library_exports():
     import ctypes as C
     from sandstorm_amd import hostlib
     lib = hostlib.load()
-    assert lib.ssh_abi_version() == hostlib.HOST_ABI_VERSION == 3
+    assert lib.ssh_abi_version() == hostlib.HOST_ABI_VERSION == 4
     with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
         doc = f.read()
     named = set(re.findall(r"\b(ssh_[a-z0-9_]+)\b", doc)) - {"ssh_air", "ssh_matrix", "ssh_coin"}          # handle types
