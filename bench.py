@@ -616,7 +616,8 @@ def bench_sharded(args, layout, log_steps, rank, local_rank, world, device):
                        "parallelism": ("ONE proof sharded over %d GPUs: base-column LDE by column (column c on rank c %% %d), row hashing / "
                                        "constraint evaluation / DEEP by row block (point-to-point re-shard over RCCL, wrap-around halo of %d "
                                        "rows), leaf-block sub-trees + root all-gather, " % (world, world, max(o for _, o in air.mask) << 1))
-                                      + ("extension columns / composition interpolation + extension / DEEP extension each ONE transform over "
+                                      + ("the extension trace's scans by row block (one all-gather of the blocks' totals), "
+                                         "extension columns / composition interpolation + extension / DEEP extension each ONE transform over "
                                          "the ranks (two equal-split all-to-alls per transform), FRI layers above 2^21 values folded and "
                                          "committed by all ranks, the rest on rank 0"),
                        "air": "the REAL %s AIR (%d mask cells) on synthetic columns" % (layout, len(air.mask)),
