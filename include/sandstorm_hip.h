@@ -300,6 +300,12 @@ ss_status ss_ood_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t nco
 /* ss_poly_eval: out[c] = P_c(x) for bit-reversed coefficient columns. */
 ss_status ss_poly_eval(ss_ctx *ctx, const uint64_t *const *d_coeffs, uint32_t ncols, uint32_t log_n,
                        const uint64_t x[4], uint64_t *out /* ncols felts, host */);
+/* Optional, ahead of ss_deep_compose (ABI 12): the composer's denominators 1 / (x - z w_n^o) and 1 / (x - z^ncomp) over
+ * offset * <w_n> depend on the out-of-domain point alone.  Queued here - the call does not wait - they are built while
+ * the host hashes the out-of-domain values into the coin (the Cairo coin: one Pedersen hash per value, crypto/src/
+ * public_coin/cairo.rs reseed_with_field_elements); the next ss_deep_compose with the same (ncomp, log_n, offset, z)
+ * uses them, any other makes its own. */
+ss_status ss_deep_prepare(ss_ctx *ctx, uint32_t ncomp, uint32_t log_n, const uint64_t offset[4], const uint64_t z[4]);
 /* d_out[i] = sum_j coeff_trace[j] (T_{col_j}(x_i) - ood_trace[j]) / (x_i - z w_n^{off_j})
  *          + sum_k coeff_comp[k]  (H_k(x_i)      - ood_comp[k])  / (x_i - z^ncomp)
  * for every x_i = offset * w_N^i of the LDE domain, natural order. */

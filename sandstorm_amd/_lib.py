@@ -123,6 +123,7 @@ SIGNATURES = {
     "ss_ood_eval": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, _u32p, _u32p, C.c_uint32, _u64p,
                               C.c_void_p]),
     "ss_poly_eval": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, C.c_uint32, _u64p, C.c_void_p]),
+    "ss_deep_prepare": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _u64p, _u64p]),
     "ss_deep_compose": (C.c_int, [C.c_void_p, _vpp, C.c_uint32, _vpp, C.c_uint32, C.c_uint32, C.c_uint32,
                                   _u64p, _u32p, _u32p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, _u64p, C.c_void_p]),

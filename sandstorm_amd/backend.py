@@ -335,6 +335,12 @@ class Context:
                                    len(mc), zp, out.ctypes.data))
         return out
 
+    def deep_prepare(self, ncomp, log_n, offset, z):
+        """ss_deep_prepare: DEEP's denominator tables for this out-of-domain point, queued (no wait) for the next deep_compose with it"""
+        _k1, op = _felt_ptr(offset)
+        _k2, zp = _felt_ptr(z)
+        check(self.lib.ss_deep_prepare(self.handle, ncomp, log_n, op, zp))
+
     def deep_compose(self, trace_cols, comp_cols, log_n, log_blowup, offset, mask_col, mask_off, ood_trace,
                      coeff_trace, ood_comp, coeff_comp, z, out):
         mc = np.ascontiguousarray(mask_col, dtype=np.uint32)

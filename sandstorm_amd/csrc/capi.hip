@@ -396,6 +396,13 @@ struct ss_ctx {
         *out = transient_tw;
         return SS_OK;
     }
+    // FRI: the powers w_len^-k a layer's rows divide by, as two small tables per layer size (launch_fri_pow_table; domain only)
+    std::map<uint32_t, Fp *> fri_pow_tabs;
+    // DEEP's two denominator tables made AHEAD of ss_deep_compose (ss_deep_prepare): they depend on the out-of-domain point only,
+    // so the device builds them while the host hashes the out-of-domain values into the coin
+    Fp *deep_tab = nullptr;
+    size_t deep_tab_elems = 0;
+    struct DeepKey { bool valid = false; uint32_t log_n = 0, ncomp = 0; Fp off, z; } deep_key;
     // second grow-only scratch (tables that must coexist with `scratch`)
     void *scratch2 = nullptr;
     size_t scratch2_bytes = 0;
@@ -493,7 +500,7 @@ bool valid_log(uint32_t log_n) { return log_n >= 1 && log_n <= 30; }
 extern "C" {
 
 const char *ss_last_error(void) { return g_err.c_str(); }
-uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns, ss_upload_async / ss_wait_upload (uploads on a copy stream, ordered into the context's stream by ticket), SS_HASH_SHA256 / SS_TREE_SHA256 for the 64-bit field's rows and trees; 10: ss_gather_batch (the query phase's gathers in one round trip); 11: ss_trace_* (the base trace made on the device from trace.bin / memory.bin); 12: one extension scan over the row blocks of several devices: ss_scale_strided, ss_diluted_aggregate_block, ss_affine_apply
+uint32_t ss_abi_version(void) { return SS_ABI_VERSION; }   // 2: ss_ctx_trim, *_ex; 3: ss_permutation_product, ss_diluted_aggregate, ss_dev_zero; 4: the row-block forms ss_eval_quotient_rows, ss_deep_compose_rows, ss_deep_extend; 5: the 64-bit field: ss_ntt_gl64, ss_lde_gl64, ss_fri_fold_gl64x3; 6: its DEEP, constraint program and row hashing: ss_ood_eval_gl64x3, ss_deep_compose_gl64x3, ss_eval_quotient_gl64x3, ss_hash_rows_gl64, ss_gather_rows_gl64, ss_running_product_gl64x3; 7: the sharded driver's data movement: ss_dev_copy, ss_dev_copy_2d, ss_bitrev_permute32, ss_comm_* (RCCL); 8: one transform / one FRI layer spread over the ranks: ss_ntt_shard_fp252, ss_fri_fold_rows; 9: ss_profile_enable(ctx, 2) + ss_profile_read_clock (shader-clock stamps around profiled launches), ss_ntt_shard_fp252 takes any number of columns, ss_upload_async / ss_wait_upload (uploads on a copy stream, ordered into the context's stream by ticket), SS_HASH_SHA256 / SS_TREE_SHA256 for the 64-bit field's rows and trees; 10: ss_gather_batch (the query phase's gathers in one round trip); 11: ss_trace_* (the base trace made on the device from trace.bin / memory.bin); 12: one extension scan over the row blocks of several devices: ss_scale_strided, ss_diluted_aggregate_block, ss_affine_apply; ss_deep_prepare (DEEP's denominator tables queued while the host hashes the out-of-domain values)
 
 ss_status ss_ctx_create(int device, ss_ctx **out) {
     if (!out) return fail(SS_ERR_INVALID, "out is NULL");
@@ -535,6 +542,8 @@ void ss_ctx_destroy(ss_ctx *ctx) {
     if (ctx->monitor_stream) hipStreamDestroy(ctx->monitor_stream);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->scratch2) hipFree(ctx->scratch2);
+    if (ctx->deep_tab) hipFree(ctx->deep_tab);
+    for (auto &kv : ctx->fri_pow_tabs) hipFree(kv.second);
     if (ctx->transient_tw) hipFree(ctx->transient_tw);
     if (ctx->d_small) hipFree(ctx->d_small);
     if (ctx->stage) hipHostFree(ctx->stage);
@@ -602,6 +611,7 @@ ss_status ss_ctx_trim(ss_ctx *ctx) {
     if (!ctx) return fail(SS_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->pool_trim();
+    if (ctx->deep_tab) { (void)hipFree(ctx->deep_tab); ctx->deep_tab = nullptr; ctx->deep_tab_elems = 0; ctx->deep_key.valid = false; }
     pedersen_tables_trim();                      // the window tables of contexts that are gone (up to 23.6 GB per device)
     return SS_OK;
 }
@@ -1259,9 +1269,24 @@ static ss_status fri_fold_impl(ss_ctx *ctx, const uint64_t *d_evals, uint32_t lo
     Fp tw[8];
     tw[0] = fp_one();
     for (int k = 1; k < 8; ++k) tw[k] = fp_mul(tw[k - 1], wf_inv);
+    // 1 / x_j = offset^-1 w_len^-e: e = (hi << lo_bits) | lo read from two tables of this layer size (kept by the context)
+    const uint32_t row_bits = log_len - log_fold, lo_bits = (row_bits + 1) / 2, hi_bits = row_bits - lo_bits;
+    const Fp *pow_tab = nullptr;
+    if (row_bits >= 8) {
+        const uint32_t key = log_len | (log_fold << 8);          // (the split of the exponent depends on the fold too)
+        auto it = ctx->fri_pow_tabs.find(key);
+        if (it == ctx->fri_pow_tabs.end()) {
+            Fp *tab = nullptr;
+            HIP_TRY(ctx->malloc_retry((void **)&tab, ((1ull << lo_bits) + (1ull << hi_bits)) * sizeof(Fp)));
+            hipError_t e = launch_fri_pow_table(ctx->stream, tab, w_inv, lo_bits, hi_bits);
+            if (e != hipSuccess) { (void)hipFree(tab); return fail(SS_ERR_HIP, "%s", hipGetErrorString(e)); }
+            it = ctx->fri_pow_tabs.emplace(key, tab).first;
+        }
+        pow_tab = it->second;
+    }
     ss_ctx::Scope prof(ctx, SS_PROF_FRI);
     HIP_TRY(launch_fri_fold(ctx->stream, (const Fp *)d_evals, log_len, log_fold, fp_from_limbs64(alpha),
-                            fp_inv_safegcd(off), w_inv, tw, flags, (Fp *)d_out, row0, count));
+                            fp_inv_safegcd(off), w_inv, tw, flags, (Fp *)d_out, row0, count, pow_tab, lo_bits));
     return SS_OK;
 }
 ss_status ss_fri_fold_ex(ss_ctx *ctx, const uint64_t *d_evals, uint32_t log_len, uint32_t fold,
@@ -1991,6 +2016,11 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
         D = (Fp *)ctx->scratch2; Dc = D + n; d_sub = D + 2 * n; poly_vals = D + 3 * n;
         if (sub_out) *sub_out = d_sub;
     }
+    // the tables ss_deep_prepare left for this very point (queued on this stream before anything this call queues)
+    const ss_ctx::DeepKey &dk = ctx->deep_key;
+    const bool prepared = !block && dk.valid && dk.log_n == log_n && dk.ncomp == ncomp && fp_eq(dk.off, off) && fp_eq(dk.z, zf);
+    ctx->deep_key.valid = false;
+    if (prepared) { D = ctx->deep_tab; Dc = D + n; }
     const size_t small = (size_t)(ntaps + 1) * (4 + 32) + (size_t)(ncoldesc + 1) * 12 + (size_t)(ncomp + 1) * 32 + 256 + poly_coef.size() * 32;
     st = ctx->ensure_scratch(small);
     if (st != SS_OK) return st;
@@ -2016,7 +2046,7 @@ ss_status deep_subcoset(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_
             const Fp x_d = fp_mul(off, fp_pow_u64(wn, (m0 + n - pre % n) % n)), x_c = fp_mul(off, fp_pow_u64(wn, m0 % n));
             HIP_TRY(launch_batch_inverse_range(s, D, d_len, x_d, wn, root_of_unity_inv(log_n), zf, true));
             if (ncomp) HIP_TRY(launch_batch_inverse_range(s, Dc, dc_len, x_c, wn, root_of_unity_inv(log_n), zc, true));
-        } else {
+        } else if (!prepared) {
             HIP_TRY(launch_batch_inverse(s, D, log_n, off, wn, root_of_unity_inv(log_n), zf, true));
             if (ncomp) HIP_TRY(launch_batch_inverse(s, Dc, log_n, off, wn, root_of_unity_inv(log_n), zc, true));
         }
@@ -2085,6 +2115,29 @@ ss_status deep_check_args(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint3
 }  // namespace
 
 extern "C" {
+
+ss_status ss_deep_prepare(ss_ctx *ctx, uint32_t ncomp, uint32_t log_n, const uint64_t offset[4], const uint64_t z[4]) {
+    if (!ctx || !z) return fail(SS_ERR_INVALID, "NULL argument");
+    if (!valid_log(log_n) || ncomp > 4) return fail(SS_ERR_INVALID, "size out of range");
+    const uint64_t n = 1ull << log_n;
+    ctx->deep_key.valid = false;
+    if (ctx->deep_tab_elems < 2 * n) {
+        if (ctx->deep_tab) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->deep_tab)); ctx->deep_tab = nullptr; ctx->deep_tab_elems = 0; }
+        HIP_TRY(ctx->malloc_retry((void **)&ctx->deep_tab, 2 * n * sizeof(Fp)));
+        ctx->deep_tab_elems = 2 * n;
+    }
+    const Fp off = offset ? fp_from_limbs64(offset) : fp_one(), zf = fp_from_limbs64(z), wn = root_of_unity(log_n);
+    Fp zc = fp_one();
+    for (uint32_t k = 0; k < ncomp; ++k) zc = fp_mul(zc, zf);
+    {
+        ss_ctx::Scope prof(ctx, SS_PROF_DEEP);
+        HIP_TRY(launch_batch_inverse(ctx->stream, ctx->deep_tab, log_n, off, wn, root_of_unity_inv(log_n), zf, true));
+        if (ncomp) HIP_TRY(launch_batch_inverse(ctx->stream, ctx->deep_tab + n, log_n, off, wn, root_of_unity_inv(log_n), zc, true));
+    }
+    ctx->deep_key.log_n = log_n; ctx->deep_key.ncomp = ncomp; ctx->deep_key.off = off; ctx->deep_key.z = zf;
+    ctx->deep_key.valid = true;
+    return SS_OK;                                // nothing waited for: the caller's host work runs beside the two kernels
+}
 
 ss_status ss_deep_compose(ss_ctx *ctx, const uint64_t *const *d_trace_lde, uint32_t ntrace_cols,
                           const uint64_t *const *d_comp_lde, uint32_t ncomp, uint32_t log_n, uint32_t log_blowup,

@@ -235,42 +235,51 @@ hipError_t launch_ood_fold(hipStream_t st, const OodFoldArray *d_arrays, uint32_
 }
 
 // ---- D[i] = 1 / (offset * w^i - z), i < 2^log_N ----------------------------------------
-// chunk c of length CH is handled by one lane: forward pass stores prefix products in D,
-// one inversion, backward pass overwrites them with the inverses.
+// One lane per chunk of CH elements: a forward pass stores the prefix products in D, one inversion, a backward pass overwrites
+// them with the inverses.  Chunk c is the elements c, c + m, c + 2 m, ... (m chunks): the lanes of a wave touch 64 neighbouring
+// elements in every step (2 KiB runs; with contiguous chunks every lane had a cache line of its own - 4 KiB apart - and the
+// kernel ran at the memory system's pace, not the multiplier's), and the lane's points are a geometric sequence of ratio w^m.
 // r280 != 0: the table is written in R280 form (fl252.h: entries times 2^24, for fl_mul_r280 consumers);
 // the factor rides on the running inverse, so it costs one multiplication per chunk.
 __global__ __launch_bounds__(128) void batch_inverse_kernel(Fp *__restrict__ D, uint64_t nchunks, uint32_t log_chunk,
-                                                            Fp offset, Fp w, Fp w_inv, Fp z, int r280) {
+                                                            Fp offset, Fp w, Fp step, Fp step_inv, Fp z, int r280) {
     const uint64_t c = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
-    const uint64_t CH = 1ull << log_chunk, i0 = c << log_chunk;
-    const Fl wl = fl_from_fp(w), wil = fl_from_fp(w_inv), zl = fl_from_fp(z);
-    Fl x = fl_from_fp(fp_mul(offset, fp_pow_u64(w, i0)));
+    const uint64_t CH = 1ull << log_chunk;
+    const Fl sl = fl_from_fp(step), sil = fl_from_fp(step_inv), zl = fl_from_fp(z);
+    Fl x = fl_from_fp(fp_mul(offset, fp_pow_u64(w, c)));
     Fl run = fl_one();
     for (uint64_t k = 0; k < CH; ++k) {
-        dstore(D + i0 + k, fl_pack(run));        // prefix product of d_0 .. d_{k-1} (weakly reduced image)
+        dstore(D + c + k * nchunks, fl_pack(run));   // prefix product of the chunk's d_0 .. d_{k-1} (weakly reduced image)
         run = fl_mul(fl_sub_c<2, 1>(x, zl), run);
-        x = fl_mul(x, wl);
+        x = fl_mul(x, sl);
     }
     Fl inv = fl_from_fp(fp_inv_safegcd(fl_to_fp(fl_weak_reduce(run))));   // 1 / (d_0 ... d_{CH-1}); 0 stays 0 if some x_i == z
     if (r280) { Fp two24 = fp_zero(); two24.v[0] = 1u << 24; inv = fl_mul(inv, fl_from_fp(fp_to_mont(two24))); }
     for (uint64_t k = CH; k-- > 0;) {
-        x = fl_mul(x, wil);                      // x_{i0+k}
-        const Fl pre = fl_from_fp(dload(D + i0 + k));
-        dstore(D + i0 + k, fl_to_fp(fl_mul(inv, pre)));
+        x = fl_mul(x, sil);                          // the chunk's point k
+        const Fl pre = fl_from_fp(dload(D + c + k * nchunks));
+        dstore(D + c + k * nchunks, fl_to_fp(fl_mul(inv, pre)));
         inv = fl_mul(fl_sub_c<2, 1>(x, zl), inv);
     }
 }
 
-hipError_t launch_batch_inverse(hipStream_t st, Fp *D, uint32_t log_N, const Fp &offset, const Fp &w,
-                                const Fp &w_inv, const Fp &z, bool r280) {
-    // enough lanes to fill the chip, chunks long enough to amortise the inversion
+static uint32_t batch_inverse_log_chunk(uint32_t log_N) {
+    // enough lanes to fill the chip, chunks long enough to amortise the inversion (SS_BATCH_INV_LOG_CHUNK: tuning only)
     uint32_t log_chunk = log_N > 17 ? log_N - 17 : 0;
     if (log_chunk < 4) log_chunk = log_N < 4 ? log_N : 4;
     if (log_chunk > 7) log_chunk = 7;
+    static const char *env = getenv("SS_BATCH_INV_LOG_CHUNK");
+    if (env) { const uint32_t v = (uint32_t)atoi(env); if (v >= 1 && v <= 10 && v <= log_N) log_chunk = v; }
+    return log_chunk;
+}
+
+hipError_t launch_batch_inverse(hipStream_t st, Fp *D, uint32_t log_N, const Fp &offset, const Fp &w,
+                                const Fp &w_inv, const Fp &z, bool r280) {
+    const uint32_t log_chunk = batch_inverse_log_chunk(log_N);
     const uint64_t nchunks = 1ull << (log_N - log_chunk);
     hipLaunchKernelGGL(batch_inverse_kernel, dim3((uint32_t)((nchunks + 127) / 128)), dim3(128), 0, st, D, nchunks,
-                       log_chunk, offset, w, w_inv, z, r280 ? 1 : 0);
+                       log_chunk, offset, w, fp_pow_u64(w, nchunks), fp_pow_u64(w_inv, nchunks), z, r280 ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -283,7 +292,7 @@ hipError_t launch_batch_inverse_range(hipStream_t st, Fp *D, uint64_t len, const
     const uint64_t nchunks = len >> log_chunk;
     if (nchunks == 0) return hipSuccess;
     hipLaunchKernelGGL(batch_inverse_kernel, dim3((uint32_t)((nchunks + 127) / 128)), dim3(128), 0, st, D, nchunks,
-                       log_chunk, x0, w, w_inv, z, r280 ? 1 : 0);
+                       log_chunk, x0, w, fp_pow_u64(w, nchunks), fp_pow_u64(w_inv, nchunks), z, r280 ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -25,8 +25,12 @@
 namespace ss {
 
 struct FriConsts {
-    Fp alpha, offset_inv, w_inv;
+    Fp alpha_over_offset, w_inv;        // alpha / offset; w_len^-1
     Fp tw_inv[8];  // w_fold^(-k), k < fold/2
+    // w_len^-e from two small tables (a lane's 1 / x_j is one product instead of a 22-bit power: 33 products, twice the fold's own):
+    // pow_lo[k] = w^-k, k < 2^lo_bits; pow_hi[k] = w^-(k << lo_bits)
+    const Fp *pow_lo, *pow_hi;
+    uint32_t lo_bits;
     uint32_t flags;
 };
 
@@ -91,7 +95,8 @@ __global__ __launch_bounds__(128) void fri_fold_kernel(const Fp *__restrict__ ev
     // t = alpha / x_j,  1/x_j = offset^-1 * w^-e,  e = j (natural) or bitrev(j) over the log2(rows) row bits
     const uint32_t row_bits = log_len - LOGF;
     const uint64_t e = bitrev_rows ? (row_bits ? (uint64_t)(__brevll(j) >> (64u - row_bits)) : 0ull) : j;
-    const Fp t = fp_mul(c.alpha, fp_mul(c.offset_inv, fp_pow_u64(c.w_inv, e)));
+    const Fp t = c.pow_lo ? fp_mul(fp_mul(c.alpha_over_offset, fri_load(c.pow_lo + (e & ((1ull << c.lo_bits) - 1ull)))), fri_load(c.pow_hi + (e >> c.lo_bits)))
+                          : fp_mul(c.alpha_over_offset, fp_pow_u64(c.w_inv, e));
     // Horner over natural-order coefficients c_m = v[bitrev(m)]
     Fp acc = v[brev_c(F - 1, LOGF)];
 #pragma unroll
@@ -100,12 +105,26 @@ __global__ __launch_bounds__(128) void fri_fold_kernel(const Fp *__restrict__ ev
     fri_store(out + i, (c.flags & SS_FRI_UNNORMALISED) ? acc : fp_div_pow2(acc, LOGF));
 }
 
+// tab[k] = w_inv^k for k < 2^lo_bits, then tab[2^lo_bits + k] = w_inv^(k << lo_bits) for k < 2^hi_bits (once per layer size and
+// context: the powers depend on the domain alone)
+__global__ __launch_bounds__(256) void fri_pow_table_kernel(Fp *__restrict__ tab, Fp w_inv, uint32_t lo_bits, uint32_t hi_bits) {
+    const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, nlo = 1ull << lo_bits, nhi = 1ull << hi_bits;
+    if (k >= nlo + nhi) return;
+    fri_store(tab + k, fp_pow_u64(w_inv, k < nlo ? k : (k - nlo) << lo_bits));
+}
+hipError_t launch_fri_pow_table(hipStream_t st, Fp *tab, const Fp &w_inv, uint32_t lo_bits, uint32_t hi_bits) {
+    const uint64_t n = (1ull << lo_bits) + (1ull << hi_bits);
+    hipLaunchKernelGGL(fri_pow_table_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, tab, w_inv, lo_bits, hi_bits);
+    return hipGetLastError();
+}
+
 hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, uint32_t log_fold,
                            const Fp &alpha, const Fp &offset_inv, const Fp &w_inv, const Fp *fold_tw_inv,
-                           uint32_t flags, Fp *out, uint64_t row0, uint64_t count) {
+                           uint32_t flags, Fp *out, uint64_t row0, uint64_t count, const Fp *pow_tab, uint32_t lo_bits) {
     FriConsts c;
     c.flags = flags;
-    c.alpha = alpha; c.offset_inv = offset_inv; c.w_inv = w_inv;
+    c.alpha_over_offset = fp_mul(alpha, offset_inv); c.w_inv = w_inv;
+    c.pow_lo = pow_tab; c.pow_hi = pow_tab ? pow_tab + (1ull << lo_bits) : nullptr; c.lo_bits = lo_bits;
     for (int k = 0; k < 8; ++k) c.tw_inv[k] = k < (1 << log_fold) / 2 ? fold_tw_inv[k] : fp_zero();
     const uint64_t rows = count;
     dim3 grid((uint32_t)((rows + 127) / 128)), block(128);

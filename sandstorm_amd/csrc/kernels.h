@@ -82,7 +82,9 @@ Fp pedersen_hash_host(const Fp &a, const Fp &b);
 // rows row0 .. row0 + count of the layer, entry k of row row0 + i at evals[i + k * count] (the whole layer: 0, len / fold)
 hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, uint32_t log_fold,
                            const Fp &alpha, const Fp &offset_inv, const Fp &w_inv, const Fp *fold_tw_inv,
-                           uint32_t flags, Fp *out, uint64_t row0, uint64_t count);
+                           uint32_t flags, Fp *out, uint64_t row0, uint64_t count, const Fp *pow_tab, uint32_t lo_bits);
+// pow_tab of launch_fri_fold: w_inv^k, k < 2^lo_bits, then w_inv^(k << lo_bits), k < 2^hi_bits (null: the power per lane)
+hipError_t launch_fri_pow_table(hipStream_t st, Fp *tab, const Fp &w_inv, uint32_t lo_bits, uint32_t hi_bits);
 
 // ---- deep.hip
 hipError_t launch_poly_reduce(hipStream_t st, const void *const *in, void *const *out, uint32_t ncols,

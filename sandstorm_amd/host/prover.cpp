@@ -321,6 +321,9 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
     ok(ss_poly_eval(ctx_, (const uint64_t *const *)comp_coeffs.data(), ncomp, log_n, zc.data(), ood_c.data()));
     for (uint32_t j = 0; j < nmask; ++j) { Felt f; memcpy(f.data(), ood_t.data() + 4 * j, 32); proof.ood_trace.push_back(f); }
     for (uint32_t k = 0; k < ncomp; ++k) { Felt f; memcpy(f.data(), ood_c.data() + 4 * k, 32); proof.ood_composition.push_back(f); }
+    // DEEP's denominator tables depend on z alone: the device builds them while this thread hashes the out-of-domain values into the
+    // coin (the Cairo coin chains one host Pedersen hash per value: ~2 ms at the recursive layout's 135 values)
+    ok(ss_deep_prepare(ctx_, ncomp, log_n, g.data(), proof.z.data()));
     {
         std::vector<Felt> all = proof.ood_trace;
         all.insert(all.end(), proof.ood_composition.begin(), proof.ood_composition.end());

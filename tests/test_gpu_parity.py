@@ -757,6 +757,13 @@ def test_deep_compose_vs_oracle(ctx, be, oracle, log_n):
     got = out.download(np.uint64, (N, 4))
     want = oracle.deep_compose(ev.to_host(), cm.to_host(), log_n, lb, g, mc, mo, ood_t, ct, ood_c, cc, zm)
     assert np.array_equal(got, want)
+    # ss_deep_prepare (ABI 12): the denominator tables queued ahead for this point are the ones the composer uses - the same values;
+    # tables prepared for ANOTHER point (or size, or offset) are not
+    for prepared_z, prepared_log in ((zm, log_n), (oracle.to_mont([z + 1])[0], log_n), (zm, log_n + 1)):
+        ctx.deep_prepare(2, prepared_log, g, prepared_z)
+        out2 = ctx.alloc(32 * N)
+        ctx.deep_compose(ev.cols, cm.cols, log_n, lb, g, mc, mo, ood_t, ct, ood_c, cc, zm, out2)
+        assert np.array_equal(out2.download(np.uint64, (N, 4)), want)
     # consistent OOD values => the DEEP quotient is a polynomial of degree < n
     ctx.ntt([out], log_n + lb, be.INVERSE, g)
     assert not np.any(out.download(np.uint64, (N, 4))[n:])
