@@ -12,12 +12,11 @@
 //   reduce : one lane folds a chunk of 2^k consecutive items into its aggregate
 //   (recurse on the aggregates until one lane holds them all)
 //   apply  : the lane replays its chunk starting from the scanned aggregate before it
-// and the denominators' prefix products are inverted by Montgomery's trick on the same
-// kind of chunks (one safegcd inversion per chunk), zero-preserving like ark-ff's
-// batch_inversion (a zero entry stays zero and does not poison its neighbours).
-// The arithmetic is exact, so the order of association does not change a single bit.
-// Cost: ~10 multiplications and ~10 x 32 B of HBM traffic per item — microseconds next
-// to the LDE; the point is that the columns never leave HBM between the two phases.
+// A running product takes TWO kinds of passes: perm_quotients (the terms n_k, d_k, the batched inversion of the d_k by Montgomery's
+// trick - one safegcd inversion per lane's chunk, zero-preserving like ark-ff's batch_inversion - and q_k = n_k / d_k, one launch),
+// then the scan of the q_k whose last level writes the strided column.  The arithmetic is exact, so the order of association
+// does not change a single bit.  Cost: ~10 multiplications and ~11 x 32 B of HBM traffic per item (17 before the passes were
+// fused: round 6) - microseconds next to the LDE; the point is that the columns never leave HBM between the two phases.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "ext_scan.h"
@@ -35,24 +34,18 @@ template <class Op>
 __global__ __launch_bounds__(128) void scan_apply_kernel(Fp *__restrict__ data, uint64_t n, const Fp *__restrict__ aggscan, uint32_t lc) {
     scan_apply_lane<Op>(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, aggscan, lc);
 }
-__global__ __launch_bounds__(128) void inverse_dense_kernel(Fp *__restrict__ data, uint64_t n, Fp *__restrict__ tmp, uint32_t lc) {
-    inverse_dense_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, tmp, lc);
+template <class Op>
+__global__ __launch_bounds__(128) void scan_apply_out_kernel(const Fp *__restrict__ data, uint64_t n, const Fp *__restrict__ aggscan, uint32_t lc,
+                                                             Fp *out, uint64_t out_stride, uint64_t out_off) {
+    scan_apply_out_lane<Op>(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, data, n, aggscan, lc, out, out_stride, out_off);
 }
-__global__ __launch_bounds__(256) void perm_terms_kernel(PermOperand num, PermOperand den, uint64_t count, Fp z, Fp alpha,
-                                                         Fp *__restrict__ tn, Fp *__restrict__ td) {
-    perm_terms_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, num, den, count, z, alpha, tn, td);
-}
-__global__ __launch_bounds__(256) void perm_finish_kernel(const Fp *pn, const Fp *__restrict__ pd_inv, uint64_t count,
-                                                          Fp *out, uint64_t out_stride, uint64_t out_off) {
-    perm_finish_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, pn, pd_inv, count, out, out_stride, out_off);
+__global__ __launch_bounds__(128) void perm_quotients_kernel(PermOperand num, PermOperand den, uint64_t count, Fp z, Fp alpha,
+                                                             Fp *__restrict__ q, Fp *__restrict__ tmp, uint32_t lc) {
+    perm_quotients_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, num, den, count, z, alpha, q, tmp, lc);
 }
 __global__ __launch_bounds__(256) void dil_terms_kernel(const Fp *x, uint64_t stride, uint64_t off, uint64_t count, Fp z, Fp alpha,
                                                         Fp *__restrict__ mc) {
     dil_terms_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, x, stride, off, count, z, alpha, mc);
-}
-__global__ __launch_bounds__(256) void dil_finish_kernel(const Fp *__restrict__ mc, uint64_t count, Fp *out, uint64_t out_stride,
-                                                         uint64_t out_off) {
-    dil_finish_lane(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, mc, count, out, out_stride, out_off);
 }
 
 __global__ __launch_bounds__(256) void scale_strided_kernel(Fp *data, uint64_t stride, uint64_t off, uint64_t count, Fp factor) {
@@ -89,24 +82,16 @@ struct HipExec {                 // a lane body = a kernel launch on the context
         hipLaunchKernelGGL(scan_apply_kernel<Op>, grid_for(lanes, 128), dim3(128), 0, st, data, n, aggscan, lc);
         return done();
     }
-    int inverse_dense(uint64_t lanes, Fp *data, uint64_t n, Fp *tmp, uint32_t lc) {
-        hipLaunchKernelGGL(inverse_dense_kernel, grid_for(lanes, 128), dim3(128), 0, st, data, n, tmp, lc);
+    template <class Op> int apply_out(uint64_t lanes, const Fp *data, uint64_t n, const Fp *aggscan, uint32_t lc, Fp *out, uint64_t out_stride, uint64_t out_off) {
+        hipLaunchKernelGGL(scan_apply_out_kernel<Op>, grid_for(lanes, 128), dim3(128), 0, st, data, n, aggscan, lc, out, out_stride, out_off);
         return done();
     }
-    int perm_terms(const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z, const Fp &alpha, Fp *tn, Fp *td) {
-        hipLaunchKernelGGL(perm_terms_kernel, grid_for(count, 256), dim3(256), 0, st, num, den, count, z, alpha, tn, td);
-        return done();
-    }
-    int perm_finish(const Fp *pn, const Fp *pd_inv, uint64_t count, Fp *out, uint64_t out_stride, uint64_t out_off) {
-        hipLaunchKernelGGL(perm_finish_kernel, grid_for(count, 256), dim3(256), 0, st, pn, pd_inv, count, out, out_stride, out_off);
+    int perm_quotients(const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z, const Fp &alpha, Fp *q, Fp *tmp, uint32_t lc) {
+        hipLaunchKernelGGL(perm_quotients_kernel, grid_for(scan_chunks(count, lc), 128), dim3(128), 0, st, num, den, count, z, alpha, q, tmp, lc);
         return done();
     }
     int dil_terms(const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z, const Fp &alpha, Fp *mc) {
         hipLaunchKernelGGL(dil_terms_kernel, grid_for(count, 256), dim3(256), 0, st, x, stride, off, count, z, alpha, mc);
-        return done();
-    }
-    int dil_finish(const Fp *mc, uint64_t count, Fp *out, uint64_t out_stride, uint64_t out_off) {
-        hipLaunchKernelGGL(dil_finish_kernel, grid_for(count, 256), dim3(256), 0, st, mc, count, out, out_stride, out_off);
         return done();
     }
     int dil_terms_block(const Fp *x, uint64_t stride, uint64_t off, uint64_t count, bool starts_column, const Fp &z, const Fp &alpha, Fp *mc) {

@@ -27,6 +27,7 @@ struct MulOp {                       // field multiplication
     static SS_HD T load(const Fp *base, uint64_t i) { return base[i]; }
     static SS_HD void store(Fp *base, uint64_t i, const T &x) { base[i] = x; }
     static SS_HD T combine(const T &acc, const T &x) { return fp_mul(acc, x); }
+    static SS_HD Fp value(const T &x) { return x; }
 };
 struct Affine { Fp m, c; };          // t -> m t + c
 struct AffineOp {                    // "then": (acc then x)(t) = x.m (acc.m t + acc.c) + x.c
@@ -36,6 +37,7 @@ struct AffineOp {                    // "then": (acc then x)(t) = x.m (acc.m t +
     static SS_HD T load(const Fp *base, uint64_t i) { return Affine{base[2 * i], base[2 * i + 1]}; }
     static SS_HD void store(Fp *base, uint64_t i, const T &x) { base[2 * i] = x.m; base[2 * i + 1] = x.c; }
     static SS_HD T combine(const T &acc, const T &x) { return Affine{fp_mul(acc.m, x.m), fp_add(fp_mul(acc.c, x.m), x.c)}; }
+    static SS_HD Fp value(const T &x) { return x.c; }          // of a constant map (the aggregate's item 0 is one, so every prefix is)
 };
 
 // ---- lane bodies (c = chunk index = global lane id) -------------------------------------------
@@ -62,27 +64,17 @@ SS_HD void scan_apply_lane(uint64_t c, Fp *data, uint64_t n, const Fp *aggscan, 
     }
 }
 
-// zero-preserving element-wise inversion (ark-ff batch_inversion semantics); tmp: n felts.
-// Prefix products of the non-zero entries of the chunk, one inversion, back-substitution.
-SS_HD void inverse_dense_lane(uint64_t c, Fp *data, uint64_t n, Fp *tmp, uint32_t lc) {
-    // chunk c = elements c, c + m, c + 2 m, ... (m chunks): neighbouring lanes touch neighbouring elements
-    const uint64_t m = (n + (1ull << lc) - 1) >> lc;
-    if (c >= m) return;
-    Fl run = fl_one();
-    for (uint64_t i = c; i < n; i += m) {
-        const Fl v = fl_from_fp(data[i]);
-        tmp[i] = fl_pack(run);                    // (a weakly reduced image: only read back below)
-        if (!fn_is_zero(v)) run = fn_mul(run, v);
-    }
-    Fl inv = fl_from_fp(fp_inv_safegcd(fl_to_fp(run)));   // run is a product of non-zero entries (or 1)
-    uint64_t last = c + ((n - 1 - c) / m) * m;            // the chunk's last element
-    for (uint64_t i = last;; i -= m) {
-        const Fl v = fl_from_fp(data[i]);
-        if (!fn_is_zero(v)) {                     // a zero stays zero
-            data[i] = fl_to_fp(fn_mul(inv, fl_from_fp(tmp[i])));
-            inv = fn_mul(inv, v);
-        }
-        if (i == c) break;
+// the last level of a scan whose cells go to a strided column: out[i * out_stride + out_off] <- value(data[0] . ... . data[i]) (data is
+// only read: one pass and one array less than scanning in place and copying)
+template <class Op>
+SS_HD void scan_apply_out_lane(uint64_t c, const Fp *data, uint64_t n, const Fp *aggscan, uint32_t lc, Fp *out, uint64_t out_stride, uint64_t out_off) {
+    const uint64_t i0 = c << lc;
+    if (i0 >= n) return;
+    const uint64_t i1 = i0 + (1ull << lc) < n ? i0 + (1ull << lc) : n;
+    typename Op::T acc = (c && aggscan) ? Op::load(aggscan, c - 1) : Op::identity();
+    for (uint64_t i = i0; i < i1; ++i) {
+        acc = Op::combine(acc, Op::load(data, i));
+        out[i * out_stride + out_off] = Op::value(acc);
     }
 }
 
@@ -92,20 +84,34 @@ SS_HD Fp perm_term(const PermOperand &o, uint64_t k, const Fp &z, const Fp &alph
     if (o.v_off < 0) return fp_sub(z, a);                                    // z - x_k           (trace.rs:727-728)
     return fp_sub(z, fp_add(fp_mul(alpha, item[o.v_off]), a));               // z - (alpha v + a)  (trace.rs:713-714)
 }
-SS_HD void perm_terms_lane(uint64_t k, const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z,
-                           const Fp &alpha, Fp *tn, Fp *td) {
-    if (k >= count) return;
-    tn[k] = perm_term(num, k, z, alpha);
-    td[k] = perm_term(den, k, z, alpha);
+// q_k = n_k / d_k for the chunk's items (chunk c = items c, c + m, c + 2 m, ...: neighbouring lanes touch neighbouring items) in ONE
+// pass: the denominators' prefix products forward (tmp: count felts), one inversion, and on the way back the terms again - they are
+// a subtraction and at most one product of cells that are still in the cache - times the inverse.  A zero denominator gives q_k = 0
+// and stays out of the chunk's product (batch_inversion's zeros).  perm_terms + inverse_dense + perm_finish in one launch and
+// 11 instead of 17 element transfers per item.
+SS_HD void perm_quotients_lane(uint64_t c, const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z, const Fp &alpha,
+                               Fp *q, Fp *tmp, uint32_t lc) {
+    const uint64_t m = (count + (1ull << lc) - 1) >> lc;
+    if (c >= m) return;
+    Fl run = fl_one();
+    for (uint64_t k = c; k < count; k += m) {
+        const Fl d = fl_from_fp(perm_term(den, k, z, alpha));
+        tmp[k] = fl_pack(run);
+        if (!fn_is_zero(d)) run = fn_mul(run, d);
+    }
+    Fl inv = fl_from_fp(fp_inv_safegcd(fl_to_fp(run)));
+    const uint64_t last = c + ((count - 1 - c) / m) * m;
+    for (uint64_t k = last;; k -= m) {
+        const Fl d = fl_from_fp(perm_term(den, k, z, alpha));
+        if (fn_is_zero(d)) q[k] = fp_zero();
+        else {
+            const Fl dinv = fn_mul(inv, fl_from_fp(tmp[k]));
+            q[k] = fl_to_fp(fn_mul(fl_from_fp(perm_term(num, k, z, alpha)), dinv));
+            inv = fn_mul(inv, d);
+        }
+        if (k == c) break;
+    }
 }
-SS_HD void perm_finish_lane(uint64_t k, const Fp *pn, const Fp *pd_inv, uint64_t count, Fp *out, uint64_t out_stride,
-                            uint64_t out_off) {
-    if (k >= count) return;
-    // n * d_inv (trace.rs:767-769); without pd_inv: the strided copy of a finished column.  (out may be pn itself when the strides
-    // are 1: a lane reads and writes the same element)
-    out[k * out_stride + out_off] = pd_inv ? fp_mul(pn[k], pd_inv[k]) : pn[k];
-}
-
 // item 0 is the constant map t -> 1 (the initial value), item k the map t -> t (1 + z u_k) + alpha u_k^2
 SS_HD void dil_terms_lane(uint64_t k, const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z,
                           const Fp &alpha, Fp *mc) {
@@ -120,11 +126,6 @@ SS_HD void dil_terms_lane(uint64_t k, const Fp *x, uint64_t stride, uint64_t off
     }
     AffineOp::store(mc, k, f);
 }
-SS_HD void dil_finish_lane(uint64_t k, const Fp *mc, uint64_t count, Fp *out, uint64_t out_stride, uint64_t out_off) {
-    if (k >= count) return;
-    out[k * out_stride + out_off] = mc[2 * k + 1];                           // the map is constant: its value is c
-}
-
 // ---- one scan over the row blocks of several devices (ss_scale_strided, ss_diluted_aggregate_block, ss_affine_apply) ----------
 // A running product over rows [lo, hi) is the block's own scan times the product of the blocks before it; the aggregate's maps
 // compose the same way.  A block that does not start the column leaves its item 0 the IDENTITY: the term between two blocks
@@ -162,6 +163,18 @@ int scan_inclusive(Exec &ex, Fp *data, uint64_t n, Fp *tmp) {
     return ex.template apply<Op>(m, data, n, (const Fp *)tmp, lc);
 }
 
+// the same scan with its cells written to a strided column (data keeps the items below the top level's prefixes: scratch)
+template <class Op, class Exec>
+int scan_inclusive_out(Exec &ex, Fp *data, uint64_t n, Fp *tmp, Fp *out, uint64_t out_stride, uint64_t out_off) {
+    const uint32_t lc = ex.shape.log_scan;
+    if (n <= (1ull << lc)) return ex.template apply_out<Op>(1, (const Fp *)data, n, (const Fp *)nullptr, lc, out, out_stride, out_off);
+    const uint64_t m = scan_chunks(n, lc);
+    int e = ex.template reduce<Op>(m, (const Fp *)data, n, tmp, lc);
+    if (e) return e;
+    if ((e = scan_inclusive<Op>(ex, tmp, m, tmp + Op::FELTS * m))) return e;
+    return ex.template apply_out<Op>(m, (const Fp *)data, n, (const Fp *)tmp, lc, out, out_stride, out_off);
+}
+
 inline uint64_t permutation_product_scratch_felts(uint64_t count) { return 3 * count + scan_agg_felts(count, 1); }
 inline uint64_t diluted_aggregate_scratch_felts(uint64_t count) { return 2 * count + scan_agg_felts(count, 2); }
 
@@ -170,18 +183,15 @@ template <class Exec>
 int permutation_product(Exec &ex, const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z, const Fp &alpha,
                         Fp *out, uint64_t out_stride, uint64_t out_off, Fp *scratch) {
     if (count == 0) return 0;
-    Fp *tn = scratch, *td = scratch + count, *tmp = scratch + 2 * count, *aggs = scratch + 3 * count;
-    int e = ex.perm_terms(num, den, count, z, alpha, tn, td);
-    if (e) return e;
+    Fp *q = scratch, *tmp = scratch + count, *aggs = scratch + 3 * count;
     // The reference scans numerators and denominators apart and divides the running products (trace.rs:752-769).  The field is
     // exact, so prod n_k / prod d_k = prod (n_k / d_k) bit for bit: invert the TERMS' denominators (the same batch inversion, the
     // same count), form the quotient terms and scan once - one scan (~ 15 launches) less per product.  A zero denominator d_k:
     // the reference's denominator_acc is zero from k on, batch_inversion leaves zeros, the column is zero from k on; here the
     // term k is zero and so is every product from k on.
-    if ((e = ex.inverse_dense(scan_chunks(count, ex.shape.log_inv), td, count, tmp, ex.shape.log_inv))) return e;     // batch_inversion
-    if ((e = ex.perm_finish((const Fp *)tn, (const Fp *)td, count, tn, 1, 0))) return e;                               // n_k / d_k
-    if ((e = scan_inclusive<MulOp>(ex, tn, count, aggs))) return e;
-    return ex.perm_finish((const Fp *)tn, (const Fp *)nullptr, count, out, out_stride, out_off);
+    int e = ex.perm_quotients(num, den, count, z, alpha, q, tmp, ex.shape.log_inv);                 // terms, batch_inversion, n_k / d_k
+    if (e) return e;
+    return scan_inclusive_out<MulOp>(ex, q, count, aggs, out, out_stride, out_off);
 }
 // the block's scanned maps (mc: 2 count felts, kept by the caller between the two phases); aggs: scan_agg_felts(count, 2)
 template <class Exec>
@@ -199,8 +209,7 @@ int diluted_aggregate(Exec &ex, const Fp *x, uint64_t stride, uint64_t off, uint
     Fp *mc = scratch, *aggs = scratch + 2 * count;
     int e = ex.dil_terms(x, stride, off, count, z, alpha, mc);
     if (e) return e;
-    if ((e = scan_inclusive<AffineOp>(ex, mc, count, aggs))) return e;
-    return ex.dil_finish((const Fp *)mc, count, out, out_stride, out_off);
+    return scan_inclusive_out<AffineOp>(ex, mc, count, aggs, out, out_stride, out_off);      // item 0 is a constant map: so is every prefix
 }
 
 }  // namespace ss

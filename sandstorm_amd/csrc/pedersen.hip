@@ -771,7 +771,10 @@ __global__ __launch_bounds__(64) void pedersen_finish_kernel(Fp *__restrict__ tm
 }
 
 static uint64_t finish_lanes(uint64_t count) {
-    const uint64_t chunk = count >= (1ull << 16) ? 8 : count >= (1ull << 13) ? 4 : 1;
+    // hashes per inversion: 5 products per hash + ~130 products' worth of safegcd per chunk, against enough lanes to fill the chip
+    // (SS_PED_FINISH_CHUNK: the chunk of levels of >= 2^18 hashes, tuning only)
+    static const uint64_t big = [] { const char *e = getenv("SS_PED_FINISH_CHUNK"); const long v = e ? atol(e) : 0; return v >= 1 && v <= 64 ? (uint64_t)v : 8ull; }();
+    const uint64_t chunk = count >= (1ull << 18) ? big : count >= (1ull << 16) ? 8 : count >= (1ull << 13) ? 4 : 1;
     return (count + chunk - 1) / chunk;
 }
 static hipError_t launch_finish(hipStream_t st, Fp *tmp, uint64_t count, Fp *out_felts, uint8_t *out_bytes) {

@@ -35,24 +35,16 @@ struct LoopExec {                               // a "launch" = the lane body fo
         for (uint64_t c = lanes + 3; c-- > 0;) scan_apply_lane<Op>(c, data, n, aggscan, lc);
         return 0;
     }
-    int inverse_dense(uint64_t lanes, Fp *data, uint64_t n, Fp *tmp, uint32_t lc) {
-        for (uint64_t c = lanes + 3; c-- > 0;) inverse_dense_lane(c, data, n, tmp, lc);
+    template <class Op> int apply_out(uint64_t lanes, const Fp *data, uint64_t n, const Fp *aggscan, uint32_t lc, Fp *out, uint64_t os, uint64_t oo) {
+        for (uint64_t c = lanes + 3; c-- > 0;) scan_apply_out_lane<Op>(c, data, n, aggscan, lc, out, os, oo);
         return 0;
     }
-    int perm_terms(const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z, const Fp &alpha, Fp *tn, Fp *td) {
-        for (uint64_t k = count + 3; k-- > 0;) perm_terms_lane(k, num, den, count, z, alpha, tn, td);
-        return 0;
-    }
-    int perm_finish(const Fp *pn, const Fp *pd, uint64_t count, Fp *out, uint64_t os, uint64_t oo) {
-        for (uint64_t k = count + 3; k-- > 0;) perm_finish_lane(k, pn, pd, count, out, os, oo);
+    int perm_quotients(const PermOperand &num, const PermOperand &den, uint64_t count, const Fp &z, const Fp &alpha, Fp *q, Fp *tmp, uint32_t lc) {
+        for (uint64_t c = scan_chunks(count, lc) + 3; c-- > 0;) perm_quotients_lane(c, num, den, count, z, alpha, q, tmp, lc);
         return 0;
     }
     int dil_terms(const Fp *x, uint64_t stride, uint64_t off, uint64_t count, const Fp &z, const Fp &alpha, Fp *mc) {
         for (uint64_t k = count + 3; k-- > 0;) dil_terms_lane(k, x, stride, off, count, z, alpha, mc);
-        return 0;
-    }
-    int dil_finish(const Fp *mc, uint64_t count, Fp *out, uint64_t os, uint64_t oo) {
-        for (uint64_t k = count + 3; k-- > 0;) dil_finish_lane(k, mc, count, out, os, oo);
         return 0;
     }
     int dil_terms_block(const Fp *x, uint64_t stride, uint64_t off, uint64_t count, bool starts_column, const Fp &z, const Fp &alpha, Fp *mc) {
