@@ -1151,7 +1151,7 @@ def main():
         # north_star's own target beside BASELINE's metric configuration: recursive layout, 2^20 steps, the CLI's claim for it
         # (cli/src/main.rs:95-99: FriendlyMerkleTree<22> + Cairo coin), the same protocol on fewer proofs, in the same run
         # (a leg beside BASELINE's metric: if it fails, the line that carries the metric still goes out and says so)
-        ns = _side_leg("north_star", bench_proof, args, "recursive_2p20", rank, local_rank, world, device, max(10, args.steps) if args.steps >= 5 else args.steps, 2,
+        ns = _side_leg("north_star", bench_proof, args, "recursive_2p20", rank, local_rank, world, device, max(10, args.steps), 2,
                        not args.no_cpu_baseline)          # >= 10 timed proofs in a driver-style run (3 were a thin sample)
         if "error" in ns and "value" not in ns:
             out["north_star"] = {"workload": "recursive_2p20", "error": ns["error"]}
