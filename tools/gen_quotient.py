@@ -317,11 +317,12 @@ depth = lambda cfg, d: (d,) + cfg[1:]
 # 512-lane workgroup with fused dot products 63.7 -> 60.1 ms (round 2's shape with the flags recomputed: 67.5).
 # (suffix, cuts inside zerofier groups, [part configurations], recompute cheap scratch values at their uses)
 VARIANTS = {
-    "starknet": [("", True, [sync(BIG_WG_FUSED, 16)] * 6, True),
-                 ("_v1", False, [ONE_WG], False),                                               # round 2's kernel
-                 ("_v2", True, [sync(ONE_WG, 16)] + [sync(BIG_WG_FUSED, 16)] * 5, False)],     # part 0 with its 17 slots
+    "starknet": [("", True, [sync(BIG_WG_FUSED, 16)] * 6, True)],      # (round 2's one kernel and round 3's 17-slot first part no longer fit the LDS beside today's constants)
     "recursive": [("", False, [sync(BIG_WG_FUSED, 16)], True),
-                  ("_v1", False, [TWO_WG_REGS], False)],                                        # round 2's kernel
+                  # round 6 A/B (profiles/r06_call_j_recursive_quotient_parts.txt): the program cut into 2 / 3 parts has the same 229
+                  # multiplications and runs 55.3 / 54.0 ms against the one part's 53.9 - 143 G products/s of the multiplier's 157
+                  ("_v2", True, [sync(BIG_WG_FUSED, 16)] * 2, True),
+                  ("_v3", True, [sync(BIG_WG_FUSED, 16)] * 3, True)],
 }
 LDS_BYTES_PER_CU = 160 * 1024
 REMAT_ABOVE_SLOTS = 8
@@ -391,7 +392,9 @@ WIDE_MAX_SPAN = int(os.environ.get("QG_WIDE_SPAN", "1000"))            # program
 # of starknet is faster as it was, with a shallower prefetch.
 PART_TUNING = {"starknet": {("", 0): (True, 3, True, True, 1), ("", 1): (True, 2, True, True, 1), ("", 2): (True, 3, False, False, 1),
                             ("", 3): (True, 3, True, True, 2), ("", 4): (True, 2, False, False, 2), ("", 5): (True, 3, True, True, 1)},
-               "recursive": {("", 0): (True, 2, True, True, 1)}}
+               "recursive": {("", 0): (True, 2, True, True, 1),
+                             ("_v2", 0): (True, 2, True, True, 1), ("_v2", 1): (True, 2, True, True, 1),
+                             ("_v3", 0): (True, 2, True, True, 1), ("_v3", 1): (True, 2, True, True, 1), ("_v3", 2): (True, 2, True, True, 1)}}
 
 
 class WideViolation(Exception):
