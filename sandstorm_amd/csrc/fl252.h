@@ -171,22 +171,21 @@ SS_HD u32 fl_opaque(u32 x) {
 // Montgomery reduction of 17 lazy 64-bit columns (weights 2^(28 k)) by R = 2^256 =
 // 2^(9*28) * 2^4; output normalised (limbs < 2^28, top limb small).
 SS_HD Fl fl_mont_reduce(u64 (&c)[18]) {
-    const u32 k24 = fl_opaque(1u << 24), k27 = fl_opaque(1u << 27), k1 = fl_opaque(1u);
-    // nine 28-bit Montgomery steps: p = 1 (mod 2^28) so m = -c[i] mod 2^28
+    const u32 k17 = fl_opaque(17u << 24), k27 = fl_opaque(1u << 27), k1 = fl_opaque(1u);
+    // nine 28-bit Montgomery steps: p = 1 (mod 2^28) so m = -c[i] mod 2^28.  The columns are lazy 64-bit sums, so m * 17 * 2^192 goes
+    // into ONE of them as m * (17 << 24) < 2^57 (limbs 6 and 7 of p at once: a multiply-add less per step; round 6)
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const u32 m = (0u - (u32)c[i]) & FL_MASK;
         c[i + 1] += ((u64)m * k1 + c[i]) >> 28;       // limb i becomes 0; its carry moves up
-        c[i + 6] += (u64)m * k24;
-        c[i + 7] += (u64)m * k1;
+        c[i + 6] += (u64)m * k17;
         c[i + 8] += (u64)m * k27;
     }
     // one 4-bit step to complete R = 2^256
     {
         const u32 m = (0u - (u32)c[9]) & 15u;
         c[9] += m;
-        c[15] += (u64)m * k24;
-        c[16] += (u64)m * k1;
+        c[15] += (u64)m * k17;
         c[17] += (u64)m * k27;
     }
     // shift right by 4 across columns and normalise
@@ -231,13 +230,12 @@ SS_HD Fl fl_mul_r280(const Fl &a, const Fl &t) {
     for (int i = 0; i < 9; ++i)
 #pragma unroll
         for (int j = 0; j < 9; ++j) c[i + j] += (u64)a.l[i] * t.l[j];
-    const u32 k24 = fl_opaque(1u << 24), k27 = fl_opaque(1u << 27), k1 = fl_opaque(1u);
+    const u32 k17 = fl_opaque(17u << 24), k27 = fl_opaque(1u << 27), k1 = fl_opaque(1u);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         const u32 m = (0u - (u32)c[i]) & FL_MASK;
         c[i + 1] += ((u64)m * k1 + c[i]) >> 28;       // limb i becomes 0; its carry moves up
-        c[i + 6] += (u64)m * k24;
-        c[i + 7] += (u64)m * k1;
+        c[i + 6] += (u64)m * k17;                     // m * 17 * 2^192: limbs 6 and 7 of p into one lazy column (fl_mont_reduce)
         c[i + 8] += (u64)m * k27;
     }
     Fl r;
@@ -269,13 +267,12 @@ SS_HD void fl_wide_mad(FlWide &w, const Fl &a, const Fl &t) {
         for (int j = 0; j < 9; ++j) w.c[i + j] += (u64)a.l[i] * t.l[j];
 }
 SS_HD Fl fl_wide_reduce(FlWide &w) {
-    const u32 k24 = fl_opaque(1u << 24), k27 = fl_opaque(1u << 27), k1 = fl_opaque(1u);
+    const u32 k17 = fl_opaque(17u << 24), k27 = fl_opaque(1u << 27), k1 = fl_opaque(1u);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         const u32 m = (0u - (u32)w.c[i]) & FL_MASK;
         w.c[i + 1] += ((u64)m * k1 + w.c[i]) >> 28;
-        w.c[i + 6] += (u64)m * k24;
-        w.c[i + 7] += (u64)m * k1;
+        w.c[i + 6] += (u64)m * k17;                   // (a column holds <= 144 products < 2^56 and this < 2^57: below 2^64)
         w.c[i + 8] += (u64)m * k27;
     }
     Fl r;
