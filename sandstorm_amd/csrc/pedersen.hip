@@ -60,7 +60,7 @@ static constexpr int PED_MAX_WINDOWS = 16;        // the lane-split kernel gives
 
 struct PedersenTables {
     Aff *d_table;   // [2][nwin * span]
-    Aff shift;      // P0
+    Aff shift;      // P0, in the R280 domain like the table's points (x 2^280: pedersen_tables_build)
     uint32_t W, nwin, span;      // window bits, windows per input, entries per window (2^W - 1)
     uint64_t per_input;          // nwin * span
     int device, users;           // the tables are constants: ONE copy per device and process, shared by its contexts
@@ -136,6 +136,7 @@ static const std::vector<Aff> &host_tables(Aff *shift) {
 
 __global__ void pedersen_build_windows_kernel(const Aff *__restrict__ bit_points, Aff *__restrict__ table, uint32_t W, uint32_t span, uint64_t per_input);
 __global__ void pedersen_join_halves_kernel(const Aff *__restrict__ half, Aff *__restrict__ table, uint32_t W, uint32_t nwin, uint32_t nhalf);
+__global__ void pedersen_table_to_r280_kernel(Fp *__restrict__ coords, uint64_t n);
 
 // the 2 x 252 bit points: bit i of input e stands for 2^i P_{1+2e} (i < 248) or 2^(i-248) P_{2+2e}
 static void build_bit_points(std::vector<Aff> &out) {
@@ -184,6 +185,16 @@ static hipError_t pedersen_tables_build(hipStream_t st, uint32_t W, int device, 
         const uint64_t lanes = 2ull * t->nwin * ((1ull << W) / 8);
         hipLaunchKernelGGL(pedersen_join_halves_kernel, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, d_half, t->d_table, W, t->nwin, nhalf);
         e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        // the accumulate kernels run in the R280 domain (ec252.h EcR280): every coordinate of the finished table times 2^24 (once per
+        // process: 7.4 10^8 products for W = 24), and the shift point P0 with them
+        const uint64_t coords = 4 * t->per_input;
+        hipLaunchKernelGGL(pedersen_table_to_r280_kernel, dim3((uint32_t)((coords + 255) / 256)), dim3(256), 0, st, (Fp *)t->d_table, coords);
+        e = hipGetLastError();
+        Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
+        const Fp k24 = fp_to_mont(two24);
+        t->shift.x = fp_mul(shift.x, k24); t->shift.y = fp_mul(shift.y, k24);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (d_bits) (void)hipFree(d_bits);
@@ -436,6 +447,14 @@ __global__ __launch_bounds__(64) void pedersen_join_halves_kernel(const Aff *__r
     }
 }
 
+// the finished table into the R280 domain: coordinate c (a Montgomery image x 2^256) -> x 2^280 = c * 2^24
+__global__ __launch_bounds__(256) void pedersen_table_to_r280_kernel(Fp *__restrict__ coords, uint64_t n) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
+    store_felt(coords + i, fp_mul(load_felt(coords + i), fp_to_mont(two24)));
+}
+
 // the canonical scalar as a shift register: its low W bits are the next window's digit (no dynamically indexed limbs)
 template <int W>
 __device__ __forceinline__ u32 ped_next_digit(Fp &c) {
@@ -447,21 +466,14 @@ __device__ __forceinline__ u32 ped_next_digit(Fp &c) {
 }
 
 // One hash per lane accumulates in XYZZ coordinates (ec252.h: 8M + 2S per mixed addition, a squaring fewer than the Jacobian form;
-// the finish kernel then divides X by ZZ itself instead of squaring an inverse).  A/B: -DSS_PED_XYZZ=0 = the Jacobian form of rounds 1-4.
-#ifndef SS_PED_XYZZ
-#define SS_PED_XYZZ 1
-#endif
-#if SS_PED_XYZZ
+// the finish kernel then divides X by ZZ itself instead of squaring an inverse), in the R280 DOMAIN (values x 2^280, the table's
+// points stored that way: every product is the ten-step reduction alone, 25 instructions fewer than the 2^256 form's - round 6).
+// X and ZZ leave as x 2^280 images; the finish kernel reads them as Montgomery images of X 2^24 and ZZ 2^24: its inverse of ZZ
+// is ZZ^-1 2^232, and the 2^256-form product with X 2^280 is (X / ZZ) 2^256 - the interchange form, no conversion anywhere.
 typedef XyzzL PedAcc;
-__device__ __forceinline__ PedAcc ped_acc_start(const Aff &shift) { return PedAcc{fl_from_fp(shift.x), fl_from_fp(shift.y), fl_one(), fl_one()}; }
-__device__ __forceinline__ PedAcc ped_acc_add(const PedAcc &acc, const AffL &q) { return xyzzl_add_aff(acc, q); }
+__device__ __forceinline__ PedAcc ped_acc_start(const Aff &shift) { return PedAcc{fl_from_fp(shift.x), fl_from_fp(shift.y), fl_one_r280(), fl_one_r280()}; }
+__device__ __forceinline__ PedAcc ped_acc_add(const PedAcc &acc, const AffL &q) { return xyzzl_add_aff_d<EcR280>(acc, q); }
 __device__ __forceinline__ const Fl &ped_acc_den(const PedAcc &acc) { return acc.zz; }
-#else
-typedef JacL PedAcc;
-__device__ __forceinline__ PedAcc ped_acc_start(const Aff &shift) { return PedAcc{fl_from_fp(shift.x), fl_from_fp(shift.y), fl_one()}; }
-__device__ __forceinline__ PedAcc ped_acc_add(const PedAcc &acc, const AffL &q) { return jacl_add_aff(acc, q); }
-__device__ __forceinline__ const Fl &ped_acc_den(const PedAcc &acc) { return acc.z; }
-#endif
 
 // acc += scalar (canonical integer limbs) over input slot e
 template <int W>
@@ -577,28 +589,28 @@ __device__ __forceinline__ Fl ped_by_role(uint32_t role, const Fl &a0, const Fl 
 // ONE multiplication per level - its role's.  Five dependent multiplications instead of sixteen; the lanes agree on (p, q) in this
 // order and all of them end with the same (x3, y3, z3).
 __device__ __forceinline__ JacL jacl_add_quad(const JacL &p, const JacL &q, uint32_t role) {
-    Fl m = fn_mul(ped_by_role(role, p.z, q.z, p.z, p.z), ped_by_role(role, p.z, q.z, q.z, p.z));
+    Fl m = fl_mul_r280(ped_by_role(role, p.z, q.z, p.z, p.z), ped_by_role(role, p.z, q.z, q.z, p.z));
     const Fl z1z1 = fl_quad<0>(m), z2z2 = fl_quad<1>(m), z1z2 = fl_quad<2>(m);
-    m = fn_mul(ped_by_role(role, p.x, q.x, q.z, p.z), ped_by_role(role, z2z2, z1z1, z2z2, z1z1));
+    m = fl_mul_r280(ped_by_role(role, p.x, q.x, q.z, p.z), ped_by_role(role, z2z2, z1z1, z2z2, z1z1));
     const Fl u1 = fl_quad<0>(m), u2 = fl_quad<1>(m), t1 = fl_quad<2>(m), t2 = fl_quad<3>(m);
     const Fl h = fn_sub(u2, u1);
-    m = fn_mul(ped_by_role(role, p.y, q.y, h, z1z2), ped_by_role(role, t1, t2, h, h));
+    m = fl_mul_r280(ped_by_role(role, p.y, q.y, h, z1z2), ped_by_role(role, t1, t2, h, h));
     const Fl s1 = fl_quad<0>(m), s2 = fl_quad<1>(m), hh = fl_quad<2>(m), z3 = fl_quad<3>(m);
     const Fl rr = fn_sub(s2, s1);
-    m = fn_mul(ped_by_role(role, h, u1, rr, rr), ped_by_role(role, hh, hh, rr, rr));
+    m = fl_mul_r280(ped_by_role(role, h, u1, rr, rr), ped_by_role(role, hh, hh, rr, rr));
     const Fl hhh = fl_quad<0>(m), v = fl_quad<1>(m), rr2 = fl_quad<2>(m);
     JacL r;
     r.x = fn_sub(fn_sub(rr2, hhh), fn_dbl(v));
     const Fl vx = fn_sub(v, r.x);
-    m = fn_mul(ped_by_role(role, rr, s1, rr, s1), ped_by_role(role, vx, hhh, vx, hhh));
+    m = fl_mul_r280(ped_by_role(role, rr, s1, rr, s1), ped_by_role(role, vx, hhh, vx, hhh));
     r.y = fn_sub(fl_quad<0>(m), fl_quad<1>(m));
     r.z = z3;
     // the exceptional cases, as jacl_add decides them (every lane of the quad sees the same p and q, so they agree)
     if (__builtin_expect(fn_is_zero(p.z) || fn_is_zero(q.z) || fn_is_zero(h), 0)) {
         if (fn_is_zero(p.z)) return q;
         if (fn_is_zero(q.z)) return p;
-        if (fn_is_zero(rr)) return jacl_double(p);
-        JacL o; o.x = fl_one(); o.y = fl_one(); o.z = fl_zero(); return o;
+        if (fn_is_zero(rr)) return jacl_double_d<EcR280>(p);
+        JacL o; o.x = fl_one_r280(); o.y = fl_one_r280(); o.z = fl_zero(); return o;
     }
     return r;
 }
@@ -689,7 +701,7 @@ __global__ __launch_bounds__(64) void pedersen_pairs_small_kernel(const Aff *__r
     u32 d = 0;                                              // this lane's digit: window w of the scalar (lanes w >= nwin have none)
 #pragma unroll 1
     for (uint32_t q = 0; q <= w && q < nwin; ++q) { const u32 dq = ped_next_digit<W>(c); if (q == w) d = dq; }
-    AffL pt; pt.x = fl_one(); pt.y = fl_one();
+    AffL pt; pt.x = fl_one_r280(); pt.y = fl_one_r280();
     int inf = 1;
     if (d) { pt = load_affl(table + (size_t)e * per_input + (size_t)w * span + (d - 1)); inf = 0; }
     if (shift_in_lane && sub == 15u) { pt.x = fl_from_fp(shift.x); pt.y = fl_from_fp(shift.y); inf = 0; }
@@ -707,7 +719,7 @@ __global__ __launch_bounds__(64) void pedersen_pairs_small_kernel(const Aff *__r
             b.x.l[i] = o.x.l[i] ^ dx; b.y.l[i] = o.y.l[i] ^ dy;
         }
         const int di = (oinf ^ inf) & (int)up;
-        acc = jacl_add_affs(a, (inf ^ di) != 0, b, (oinf ^ di) != 0);
+        acc = jacl_add_affs_d<EcR280>(a, (inf ^ di) != 0, b, (oinf ^ di) != 0);
     }
 #pragma unroll 1
     for (uint32_t m = 2; m <= 16; m <<= 1) {
@@ -724,14 +736,16 @@ __global__ __launch_bounds__(64) void pedersen_pairs_small_kernel(const Aff *__r
     }
     if (!shift_in_lane) {
         AffL sh; sh.x = fl_from_fp(shift.x); sh.y = fl_from_fp(shift.y);
-        acc = jacl_add_aff(acc, sh);
+        acc = jacl_add_aff_d<EcR280>(acc, sh);
     }
     // x = X / Z^2 on every lane of the hash (they hold the same sum); Z = 0 - a point at infinity, unreachable for a hash - inverts
     // to 0 and gives x = 0, as pedersen_finish_kernel
-    Fp r3;                                                  // (z R)^-1 -> z^-1 R: a Montgomery product with R^3 (fp_inv_safegcd)
-    r3.v[0] = 0x406df18eu; r3.v[1] = 0xcc7177d1u; r3.v[2] = 0x77ffcc06u; r3.v[3] = 0x75457066u;
-    r3.v[4] = 0x36300018u; r3.v[5] = 0xf47d84f8u; r3.v[6] = 0x873c0a6du; r3.v[7] = 0x038e5f79u;
-    const Fl zi = fl_from_fp(fp_mul(sg_inverse_quad(fl_to_fp(acc.z), role), r3));
+    // The sum is in the R280 domain: acc.z holds z 2^280, its plain inverse is z^-1 2^-280, and the 2^256-form products below want
+    // zi = z^-1 2^244 - then X 2^280 * zi^2 comes out as (X / z^2) 2^256, the interchange form: one Montgomery product with 2^780
+    Fp k780;
+    k780.v[0] = 0xdf18d8e4u; k780.v[1] = 0x177d1406u; k780.v[2] = 0xfcc06cc7u; k780.v[3] = 0x5706677fu;
+    k780.v[4] = 0x00018754u; k780.v[5] = 0xd84f8363u; k780.v[6] = 0xc0a6666bu; k780.v[7] = 0x05f79873u;
+    const Fl zi = fl_from_fp(fp_mul(sg_inverse_quad(fl_to_fp(acc.z), role), k780));
     const Fp x = fl_to_fp(fn_mul(acc.x, fn_sqr(zi)));        // acc.x: normalised and < 2p from either addition
     if (sub == 0u) canon_to_be_bytes(fp_from_mont(x), out + 32 * k);
 }
@@ -763,7 +777,7 @@ __global__ __launch_bounds__(64) void pedersen_finish_kernel(Fp *__restrict__ tm
         if (infinity) z = fl_one();
         const Fl zi = fn_mul(inv, fl_from_fp(load_felt(P + k)));
         inv = fn_mul(inv, z);
-        Fp x = fl_to_fp(fn_mul(fl_from_fp(load_felt(X + k)), SS_PED_XYZZ ? zi : fn_sqr(zi)));     // (XYZZ: the stored denominator is ZZ)
+        Fp x = fl_to_fp(fn_mul(fl_from_fp(load_felt(X + k)), zi));     // (X 2^280) (ZZ^-1 2^232) 2^-256 = (X / ZZ) 2^256 (ped_acc_start's note)
         if (infinity) x = fp_zero();
         if (BYTES) canon_to_be_bytes(fp_from_mont(x), out_bytes + 32 * k);
         else store_felt(out_felts + k, x);

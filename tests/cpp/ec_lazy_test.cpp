@@ -110,6 +110,87 @@ int main() {
             checked += 3;
         }
     }
+    // The same in the R280 DOMAIN (values x * 2^280, the ten-step reduction alone: what the Pedersen kernels run from round 6 on, their
+    // table points stored in that form): XYZZ chains with doublings and infinities, affine + affine, the Jacobian + Jacobian of the
+    // small levels - coordinates are ratios (x = X / ZZ, y = Y / ZZZ; X / Z^2, Y / Z^3 after rescaling Z), so the plain inverse reads them
+    {
+        Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
+        const Fp k24 = fp_to_mont(two24), k24inv = fp_inv(k24);
+        auto limb280 = [&](const Aff &a) { return AffL{fl_from_fp(fp_mul(a.x, k24)), fl_from_fp(fp_mul(a.y, k24))}; };
+        auto affine_of = [](const XyzzL &l) {
+            const Fp zz = fl_to_fp(l.zz), zzz = fl_to_fp(l.zzz);
+            return Aff{fp_mul(fl_to_fp(l.x), fp_inv(zz)), fp_mul(fl_to_fp(l.y), fp_inv(zzz))};
+        };
+        auto affine_of_jac = [&](const JacL &l) {          // stored X 2^280, Y 2^280, Z 2^280 -> the R256 images, then X / Z^2, Y / Z^3
+            const Jac j{fp_mul(fl_to_fp(l.x), k24inv), fp_mul(fl_to_fp(l.y), k24inv), fp_mul(fl_to_fp(l.z), k24inv)};
+            return to_affine(j);
+        };
+        if (!fp_eq(fl_to_fp(fl_one_r280()), k24)) { printf("fl_one_r280 is not 2^280\n"); return 1; }
+        for (int chain = 0; chain < 100; ++chain) {
+            const Aff start = pool[splitmix() % pool.size()];
+            Jac acc = lift(start);
+            const AffL s280 = limb280(start);
+            XyzzL accx{s280.x, s280.y, fl_one_r280(), fl_one_r280()};
+            for (int i = 0; i < 24; ++i) {
+                // every eighth step repeats or negates what the chain holds: the doubling and infinity branches inside a chain
+                Aff q = pool[splitmix() % pool.size()];
+                if (i % 8 == 5 && !fp_is_zero(acc.z)) { q = to_affine(acc); if (chain & 1) q.y = fp_neg(q.y); }
+                acc = jac_add_aff(acc, q);
+                accx = xyzzl_add_aff_d<EcR280>(accx, limb280(q));
+                ++checked;
+                if (fp_is_zero(acc.z) != fp_is_zero(fl_to_fp(accx.zz))) { printf("r280 xyzz: infinity disagreement, chain %d step %d\n", chain, i); return 1; }
+                if (fp_is_zero(acc.z)) continue;
+                const Aff want = to_affine(acc), got = affine_of(accx);
+                if (!fp_eq(got.x, want.x) || !fp_eq(got.y, want.y)) { printf("r280 xyzz chain mismatch %d step %d\n", chain, i); return 1; }
+            }
+        }
+        for (int i = 0; i < 400; ++i) {
+            const Aff a = pool[splitmix() % pool.size()], b = i % 8 == 0 ? a : i % 8 == 1 ? Aff{a.x, fp_neg(a.y)} : pool[splitmix() % pool.size()];
+            const JacL got = jacl_add_affs_d<EcR280>(limb280(a), false, limb280(b), false);
+            const Jac want = jac_add_aff(lift(a), b);
+            if (fp_is_zero(want.z) != fp_is_zero(fl_to_fp(got.z))) { printf("r280 affine + affine: infinity disagreement %d\n", i); return 1; }
+            if (!fp_is_zero(want.z)) {
+                const Aff w = to_affine(want), g2 = affine_of_jac(got);
+                if (!fp_eq(g2.x, w.x) || !fp_eq(g2.y, w.y)) { printf("r280 affine + affine mismatch %d\n", i); return 1; }
+                // Jacobian + Jacobian and Jacobian + affine on top of it
+                const Aff c = pool[splitmix() % pool.size()], d = pool[splitmix() % pool.size()];
+                const JacL cd = jacl_add_affs_d<EcR280>(limb280(c), false, limb280(d), false);
+                const Jac wcd = jac_add_aff(lift(c), d);
+                if (!fp_is_zero(wcd.z)) {
+                    const JacL sum = jacl_add_d<EcR280>(got, cd);
+                    Jac wsum = jac_add_aff(want, c);
+                    wsum = jac_add_aff(wsum, d);
+                    if (fp_is_zero(wsum.z) != fp_is_zero(fl_to_fp(sum.z))) { printf("r280 jac + jac: infinity disagreement %d\n", i); return 1; }
+                    if (!fp_is_zero(wsum.z)) {
+                        const Aff ws = to_affine(wsum), gs = affine_of_jac(sum);
+                        if (!fp_eq(gs.x, ws.x) || !fp_eq(gs.y, ws.y)) { printf("r280 jac + jac mismatch %d\n", i); return 1; }
+                        const Aff e = pool[splitmix() % pool.size()];
+                        const JacL se = jacl_add_aff_d<EcR280>(sum, limb280(e));
+                        const Jac wse = jac_add_aff(wsum, e);
+                        if (!fp_is_zero(wse.z)) {
+                            const Aff w2 = to_affine(wse), g3 = affine_of_jac(se);
+                            if (!fp_eq(g3.x, w2.x) || !fp_eq(g3.y, w2.y)) { printf("r280 jac + affine mismatch %d\n", i); return 1; }
+                        }
+                    }
+                }
+            }
+            checked += 3;
+        }
+        // the R280 product and square at the lazy bounds
+        for (int it = 0; it < 2000; ++it) {
+            Fl a, b;
+            for (int i = 0; i < 9; ++i) {
+                const u32 amax = (1u << 30) + (1u << 27), bmax = (1u << 29) + (1u << 25);
+                a.l[i] = it == 0 ? amax : amax - (u32)(splitmix() % (it & 1 ? 16u : amax));
+                b.l[i] = it == 0 ? bmax : bmax - (u32)(splitmix() % (it & 2 ? 16u : bmax));
+            }
+            a.l[8] &= (1u << 29) - 1; b.l[8] &= (1u << 29) - 1;
+            // a b 2^-280 = (a b 2^-256) 2^-24
+            const Fp want = fp_mul(fp_mul(fl_to_fp(a), fl_to_fp(b)), k24inv), wantsq = fp_mul(fp_sqr(fl_to_fp(b)), k24inv);
+            if (!fp_eq(fl_to_fp(fl_mul_r280(a, b)), want)) { printf("fl_mul_r280 at the lazy bounds: mismatch %d\n", it); return 1; }
+            if (!fp_eq(fl_to_fp(fl_sqr_r280(b)), wantsq)) { printf("fl_sqr_r280 at the lazy bounds: mismatch %d\n", it); return 1; }
+        }
+    }
     // affine + affine (the first round of the lane-split accumulation) against the plain mixed addition: generic pairs, q + q, q - q,
     // and the point at infinity on either or both sides
     for (int i = 0; i < 400; ++i) {
