@@ -129,6 +129,24 @@ template <class D> SS_HD XyzzL xyzzl_add_aff_d(const XyzzL &p, const AffL &q) { 
     return r;
 }
 
+// p + q, both affine and neither the point at infinity (mmadd-2008-s: 4M + 2S) -> XYZZ.  The first addition of a hash: its
+// accumulator is still the affine shift point, and the generic form would multiply by ZZ = ZZZ = 1 four times.
+template <class D> SS_HD XyzzL xyzzl_add_affs_d(const AffL &p, const AffL &q) {
+    const Fl h = fl_sub_c<2, 1>(q.x, p.x), rr = fl_sub_c<2, 1>(q.y, p.y);        // lazy: < 4p
+    const Fl hh = D::sqr(h);
+    if (fn_is_zero(hh)) {                                                         // p = +-q: the generic form knows what to do
+        XyzzL a; a.x = p.x; a.y = p.y; a.zz = D::one(); a.zzz = D::one();
+        return xyzzl_add_aff_d<D>(a, q);
+    }
+    const Fl hhh = D::mul(h, hh), v = D::mul(p.x, hh);
+    XyzzL r;
+    r.x = fl_weak_reduce(fl_sub_c<8, 2>(fl_sub_c<2, 1>(D::sqr(rr), hhh), fl_add(v, v)));
+    r.y = fl_weak_reduce(fl_sub_c<2, 1>(D::mul(rr, fl_sub_c<2, 1>(v, r.x)), D::mul(p.y, hhh)));
+    r.zz = hh;
+    r.zzz = hhh;
+    return r;
+}
+
 // p + q, both Jacobian (12M + 4S); infinity is z = 0 on either side.  Used by the lane-split
 // accumulation of small tree levels, where partial sums of one hash meet across lanes.
 template <class D> SS_HD JacL jacl_add_d(const JacL &p, const JacL &q) {

@@ -477,14 +477,19 @@ __device__ __forceinline__ const Fl &ped_acc_den(const PedAcc &acc) { return acc
 
 // acc += scalar (canonical integer limbs) over input slot e
 template <int W>
-__device__ __forceinline__ void ped_accumulate(PedAcc &acc, Fp canon, const Aff *__restrict__ table, uint64_t per_input, int e) {
+// (fresh: the accumulator is still the affine shift point - its first addition is affine + affine, 4M + 2S instead of 8M + 2S)
+__device__ __forceinline__ void ped_accumulate(PedAcc &acc, bool &fresh, Fp canon, const Aff *__restrict__ table, uint64_t per_input, int e) {
     constexpr uint32_t span = (1u << W) - 1u;
     constexpr int nwin = (PED_BITS + W - 1) / W;
     const Aff *tab = table + (size_t)e * per_input;
 #pragma unroll 1
     for (int w = 0; w < nwin; ++w) {
         const u32 d = ped_next_digit<W>(canon);
-        if (d) acc = ped_acc_add(acc, load_affl(tab + (size_t)w * span + (d - 1)));
+        if (d) {
+            const AffL q = load_affl(tab + (size_t)w * span + (d - 1));
+            if (fresh) { acc = xyzzl_add_affs_d<EcR280>(AffL{acc.x, acc.y}, q); fresh = false; }
+            else acc = ped_acc_add(acc, q);
+        }
     }
 }
 
@@ -494,8 +499,9 @@ template <int W>
 __device__ __forceinline__ void ped_jacobian(const Fp &a, const Fp &b, const Aff *__restrict__ table, uint64_t per_input, const Aff &shift,
                                              Fp *__restrict__ x_out, Fp *__restrict__ z_out) {
     PedAcc acc = ped_acc_start(shift);
-    ped_accumulate<W>(acc, a, table, per_input, 0);
-    ped_accumulate<W>(acc, b, table, per_input, 1);
+    bool fresh = true;
+    ped_accumulate<W>(acc, fresh, a, table, per_input, 0);
+    ped_accumulate<W>(acc, fresh, b, table, per_input, 1);
     store_felt(x_out, fl_pack(acc.x));            // fn_* results are normalised and < 2p
     store_felt(z_out, fl_pack(ped_acc_den(acc)));
 }

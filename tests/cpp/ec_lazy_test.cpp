@@ -144,6 +144,25 @@ int main() {
                 if (!fp_eq(got.x, want.x) || !fp_eq(got.y, want.y)) { printf("r280 xyzz chain mismatch %d step %d\n", chain, i); return 1; }
             }
         }
+        // affine + affine -> XYZZ (a hash's first addition), generic pairs, q + q and q - q, both domains
+        for (int i = 0; i < 300; ++i) {
+            const Aff a = pool[splitmix() % pool.size()], b = i % 8 == 0 ? a : i % 8 == 1 ? Aff{a.x, fp_neg(a.y)} : pool[splitmix() % pool.size()];
+            const Jac want = jac_add_aff(lift(a), b);
+            const XyzzL g280 = xyzzl_add_affs_d<EcR280>(limb280(a), limb280(b)), g256 = xyzzl_add_affs_d<EcR256>(limb(a), limb(b));
+            if (fp_is_zero(want.z) != fp_is_zero(fl_to_fp(g280.zz)) || fp_is_zero(want.z) != fp_is_zero(fl_to_fp(g256.zz))) { printf("xyzz affine + affine: infinity disagreement %d\n", i); return 1; }
+            if (!fp_is_zero(want.z)) {
+                const Aff w = to_affine(want), x280 = affine_of(g280), x256 = affine_of(g256);
+                if (!fp_eq(x280.x, w.x) || !fp_eq(x280.y, w.y) || !fp_eq(x256.x, w.x) || !fp_eq(x256.y, w.y)) { printf("xyzz affine + affine mismatch %d\n", i); return 1; }
+                // and the chain goes on from it
+                const Aff c = pool[splitmix() % pool.size()];
+                const Jac w2 = jac_add_aff(want, c);
+                if (!fp_is_zero(w2.z)) {
+                    const Aff ww = to_affine(w2), gg = affine_of(xyzzl_add_aff_d<EcR280>(g280, limb280(c)));
+                    if (!fp_eq(gg.x, ww.x) || !fp_eq(gg.y, ww.y)) { printf("xyzz affine + affine, then + c: mismatch %d\n", i); return 1; }
+                }
+            }
+            checked += 2;
+        }
         for (int i = 0; i < 400; ++i) {
             const Aff a = pool[splitmix() % pool.size()], b = i % 8 == 0 ? a : i % 8 == 1 ? Aff{a.x, fp_neg(a.y)} : pool[splitmix() % pool.size()];
             const JacL got = jacl_add_affs_d<EcR280>(limb280(a), false, limb280(b), false);
