@@ -1,5 +1,6 @@
 // air_layout.cpp — see air_layout.hpp
 #include "air_layout.hpp"
+#include <map>
 
 namespace ssh {
 namespace layout {
@@ -113,6 +114,16 @@ void LayoutAir::finish_construction() {
 
 AirProgramData LayoutAir::build_program(uint64_t n, const std::vector<Felt> &ch, const Felt &alpha) {
     if (n != n_) throw std::runtime_error("this " + name + " AIR was built for another trace length");
+    if (prepared_.valid && prepared_.n == n && prepared_.ch == ch) {
+        // built ahead (prepare_program): the powers of the composition coefficient are the only constants it could not know
+        AirProgramData pd = prepared_.pd;
+        Felt apow = felt_from_u64(1);
+        for (uint32_t slot : prepared_.alpha_slot) {
+            if (slot != 0xffffffffu) pd.program.consts[slot] = apow;
+            apow = felt_mul(apow, alpha);
+        }
+        return pd;
+    }
     Graph g;
     const int root = composition(g, ch, alpha);
     AirProgramData pd;
@@ -120,6 +131,31 @@ AirProgramData LayoutAir::build_program(uint64_t n, const std::vector<Felt> &ch,
     pd.d_tables = tables_ ? tables_->u64() : nullptr;
     pd.table_desc = desc_;
     return pd;
+}
+
+// The graph names every value a proof brings by SYMBOL (Graph::runtime_constant), the k-th power of the composition coefficient as
+// "alpha^" k and nothing else of it: the code and all other constants are decided by the challenges.  Lowered here with the
+// coefficient 1; build_program writes the real powers over their slots (a power that no instruction reads has none).
+void LayoutAir::prepare_program(uint64_t n, const std::vector<Felt> &ch) {
+    prepared_.valid = false;
+    if (n != n_) return;
+    Graph g;
+    const int root = composition(g, ch, felt_from_u64(1));
+    prepared_.pd.program = lower(g, root);
+    prepared_.pd.d_tables = tables_ ? tables_->u64() : nullptr;
+    prepared_.pd.table_desc = desc_;
+    std::map<uint32_t, uint32_t> slot_of;                     // graph constant -> program constant
+    const std::vector<uint32_t> &gi = prepared_.pd.program.const_graph_index;
+    for (uint32_t k = 0; k < gi.size(); ++k) slot_of[gi[k]] = k;
+    prepared_.alpha_slot.clear();
+    for (uint64_t k = 0;; ++k) {
+        const int ix = g.symbol_const_index(Graph::sym("alpha^", k));
+        if (ix < 0) break;
+        auto it = slot_of.find((uint32_t)ix);
+        prepared_.alpha_slot.push_back(it == slot_of.end() ? 0xffffffffu : it->second);
+    }
+    prepared_.n = n; prepared_.ch = ch;
+    prepared_.valid = true;
 }
 
 Felt LayoutAir::composition_at(uint64_t n, const std::vector<Felt> &ch, const Felt &alpha, const Felt &z, const std::vector<Felt> &ood) {

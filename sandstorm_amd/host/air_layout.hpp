@@ -68,10 +68,14 @@ std::vector<Felt> interpolate(std::vector<Felt> values);     // coefficients of 
 class LayoutAir : public Air {
 public:
     AirProgramData build_program(uint64_t n, const std::vector<Felt> &ch, const Felt &alpha) override;
+    void prepare_program(uint64_t n, const std::vector<Felt> &ch) override;
     Felt composition_at(uint64_t n, const std::vector<Felt> &ch, const Felt &alpha, const Felt &z, const std::vector<Felt> &ood) override;
     // flat description of the tables for host-side checks: per table kind, e, #num, (p, e)..., #den, (p, e)...
     std::vector<uint64_t> describe_tables() const;
 
+private:
+    // the program lowered for `ch` with a placeholder composition coefficient, and where its powers sit among the constants
+    struct Prepared { bool valid = false; uint64_t n = 0; std::vector<Felt> ch; AirProgramData pd; std::vector<uint32_t> alpha_slot; } prepared_;
 protected:
     LayoutAir(ss_ctx *ctx, const AirPublicInput &pi, uint32_t log_n, uint32_t lb, uint64_t lde_offset)
         : ctx_(ctx), pi_(pi), log_n_(log_n), lb_(lb), offset_(lde_offset), n_(1ull << log_n), g_(root_of_unity(log_n)) {}

@@ -64,7 +64,7 @@ struct Lowerer {
         case NodeKind::X: kind = SS_SRC_X; payload = 0; return true;
         case NodeKind::Const: {
             auto it = const_ix.find(nd.p0);
-            if (it == const_ix.end()) { payload = (uint32_t)prog.consts.size(); prog.consts.push_back(g.constants()[nd.p0]); const_ix[nd.p0] = payload; } else payload = it->second;
+            if (it == const_ix.end()) { payload = (uint32_t)prog.consts.size(); prog.consts.push_back(g.constants()[nd.p0]); prog.const_graph_index.push_back(nd.p0); const_ix[nd.p0] = payload; } else payload = it->second;
             kind = SS_SRC_CONST; return true; }
         case NodeKind::Trace: kind = SS_SRC_TRACE; payload = (nd.p0 << 24) | nd.p1; return true;
         case NodeKind::Table: kind = SS_SRC_TABLE; payload = nd.p0; return true;

@@ -47,6 +47,8 @@ public:
     int sub(int a, int b);
     int mul(int a, int b);
     int inv(int a);
+    // the index in constants() of a runtime constant's value (-1: the graph never named that symbol)
+    int symbol_const_index(uint64_t symbol) const { auto it = const_sym_.find(symbol); return it == const_sym_.end() ? -1 : it->second; }
     const std::vector<Node> &nodes() const { return nodes_; }
     const std::vector<Felt> &constants() const { return consts_; }
 private:
@@ -61,6 +63,8 @@ private:
 struct Program {
     std::vector<uint32_t> code;      // 2 words per instruction
     std::vector<Felt> consts;
+    std::vector<uint32_t> const_graph_index;     // consts[k] is the graph's constants()[const_graph_index[k]] (a program built ahead of its
+                                                 // composition coefficient has the powers of it patched in: LayoutAir::prepare_program)
     uint32_t n_slots = 0;
     uint32_t n_instr() const { return (uint32_t)(code.size() / 2); }
 };

@@ -792,6 +792,17 @@ int ssh_air_program(ssh_air *air_h, uint64_t n, const uint64_t *challenges, uint
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 1; }
 }
+// Air::prepare_program: the program for these challenges lowered ahead of its composition coefficient (the next ssh_air_program /
+// proof with the same challenges only patches the coefficient's powers in); a test hook - the provers call it themselves
+int ssh_air_prepare_program(ssh_air *air_h, uint64_t n, const uint64_t *challenges, uint32_t nchallenges) {
+    try {
+        Air *air = reinterpret_cast<Air *>(air_h);
+        std::vector<Felt> ch(nchallenges);
+        for (uint32_t i = 0; i < nchallenges; ++i) memcpy(ch[i].data(), challenges + 4 * i, 32);
+        air->prepare_program(n, ch);
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
 // the mask (trace_arguments(): sorted (column, row offset) cells): cols_out / offs_out have room for ssh_air_columns(air, 2) entries
 int ssh_air_mask(ssh_air *air_h, uint32_t *cols_out, uint32_t *offs_out) {
     Air *air = reinterpret_cast<Air *>(air_h);

@@ -271,6 +271,9 @@ Proof Prover::prove(const Digest &coin_seed, const Matrix &base_trace, const Ext
         ext_co = Matrix::alloc(ctx_, ext.num_cols(), n);
         ok(ss_lde_fp252(ctx_, (const uint64_t *const *)ext.cols.data(), ext.num_cols(), log_n, lb, g.data(), ext_lde.cols.data(),
                         ext_co.cols.data()));
+        // the transforms are queued, not waited for: the host lowers the composition program for these challenges meanwhile (all of
+        // it but the powers of the composition coefficient, drawn after the commitment below: Air::prepare_program)
+        air.prepare_program(n, proof.challenges);
         mark("extension lde");
         ext_tree = commit(ext_lde);
         mark("extension commit");

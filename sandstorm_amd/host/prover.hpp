@@ -119,6 +119,10 @@ public:
     uint32_t num_base_columns = 0, num_extension_columns = 0, num_challenges = 0;
     std::vector<std::pair<uint32_t, uint32_t>> mask;     // trace_arguments(): sorted (column, offset)
     virtual AirProgramData build_program(uint64_t n, const std::vector<Felt> &challenges, const Felt &composition_coeff) = 0;
+    // Optional, ahead of build_program: everything of the program that the challenges decide (its code, every constant but the powers
+    // of the composition coefficient), so that the host builds it while the device extends and commits the extension trace and the
+    // call above only patches the powers in.  Pure host work; a no-op for an AIR that does not take the hint.
+    virtual void prepare_program(uint64_t, const std::vector<Felt> &) {}
     // the verifier's side of the out-of-domain identity: the composition constraint at z, its trace cells read from the
     // out-of-domain vector (in `mask` order), its tables evaluated as the functions they tabulate
     virtual Felt composition_at(uint64_t n, const std::vector<Felt> &challenges, const Felt &composition_coeff, const Felt &z,

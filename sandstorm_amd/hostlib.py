@@ -139,6 +139,13 @@ class RecursiveHostAir(HostAir):
         self.num_extension_columns = load().ssh_air_columns(h, 1)
         self.mask_size = load().ssh_air_columns(h, 2)
 
+    def prepare(self, n, challenges):
+        """Air::prepare_program: lower the program for these challenges ahead of the composition coefficient"""
+        ch = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint64) for c in challenges]))
+        h = load()
+        h.ssh_air_prepare_program.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32]
+        _check(h.ssh_air_prepare_program(self.h, n, ch.ctypes.data_as(C.POINTER(C.c_uint64)), len(challenges)))
+
     def dump(self, n, challenges, alpha):
         """-> (code uint32[], consts uint64[*,4], n_slots, table specs in layouts.recursive.Tables' format)"""
         ch = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint64) for c in challenges]))

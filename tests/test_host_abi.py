@@ -129,7 +129,7 @@ def test_host_library_document_names_what_the_library_exports():
         C.cast(getattr(lib, name), C.c_void_p)              # AttributeError: the document names something the library lacks
     src = open(os.path.join(ROOT, "sandstorm_amd", "host", "host_capi.cpp")).read()
     defined = set(re.findall(r"^[a-z_0-9 \*]*?\b(ssh_[a-z0-9_]+)\(", src, flags=re.M))
-    hooks = {"ssh_last_error", "ssh_free", "ssh_air_destroy", "ssh_air_columns", "ssh_air_dump", "ssh_air_program", "ssh_air_mask",
+    hooks = {"ssh_last_error", "ssh_free", "ssh_air_destroy", "ssh_air_columns", "ssh_air_dump", "ssh_air_program", "ssh_air_prepare_program", "ssh_air_mask",
              "ssh_air_num_challenges", "ssh_coin_new", "ssh_coin_free", "ssh_coin_op", "ssh_matrix_num_cols", "ssh_matrix_col",
              "ssh_matrix_destroy", "ssh_local_group_create", "ssh_local_group_destroy", "ssh_rccl_group_destroy", "ssh_prove",
              "ssh_prove_wire_with_nonce", "ssh_build_extension_columns", "ssh_public_coin_seed"}

@@ -255,6 +255,18 @@ def test_composition_of_the_example_is_a_polynomial(example, oracle):
         cvals += v
     out_cpp = oracle.eval_program(code, consts, oracle.to_mont(cvals), cdesc, n_slots, lde, log_n, 1, g)
     assert np.array_equal(out_cpp, out)
+    # Air::prepare_program (what the prover calls while the device extends the extension trace): the program lowered ahead of the
+    # composition coefficient, its powers patched in - word for word the program built in one go, for this coefficient and another;
+    # a program prepared for OTHER challenges is not used
+    mch = [oracle.to_mont([c])[0] for c in CHALLENGES]
+    for a2 in (alpha, alpha * 7 + 3):
+        want2 = cpp.dump(n, mch, oracle.to_mont([a2])[0])
+        cpp.prepare(n, mch)
+        got2 = cpp.dump(n, mch, oracle.to_mont([a2])[0])
+        assert np.array_equal(got2[0], want2[0]) and np.array_equal(got2[1], want2[1]) and got2[2:] == want2[2:]
+        cpp.prepare(n, [oracle.to_mont([c + 1])[0] for c in CHALLENGES])
+        got3 = cpp.dump(n, mch, oracle.to_mont([a2])[0])
+        assert np.array_equal(got3[0], want2[0]) and np.array_equal(got3[1], want2[1])
     cpp.close()
     bad = [list(c) for c in cols[:1]] + cols[1:]
     bad[0][16 * 777 + 3] = (bad[0][16 * 777 + 3] + 1) % rec.P          # one flag cell of one cycle

@@ -345,6 +345,14 @@ def test_cpp_air_is_the_python_one(oracle):
     cpp = hostlib.StarknetHostAir(None, spi, log_n)
     assert cpp.mask_size == 269 and (cpp.num_base_columns, cpp.num_extension_columns) == (9, 1)
     code, consts, n_slots, specs = cpp.dump(n, [oracle.to_mont([c])[0] for c in CHALLENGES], oracle.to_mont([alpha])[0])
+    # Air::prepare_program: lowered ahead of the composition coefficient, its 195 powers patched in - the same words
+    cpp.prepare(n, [oracle.to_mont([c])[0] for c in CHALLENGES])
+    for a2 in (alpha, alpha + 12345):
+        got2 = cpp.dump(n, [oracle.to_mont([c])[0] for c in CHALLENGES], oracle.to_mont([a2])[0])
+        if a2 == alpha:
+            assert np.array_equal(got2[0], code) and np.array_equal(got2[1], consts) and got2[2] == n_slots
+        else:
+            assert np.array_equal(got2[0], code) and not np.array_equal(got2[1], consts)
     cpp.close()
     assert sorted(map(repr, specs)) == sorted(map(repr, tables.specs)) and specs[:9] == tables.specs[:9]
     rng = np.random.default_rng(11)
