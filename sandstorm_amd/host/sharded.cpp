@@ -663,6 +663,7 @@ bool ShardedProver::prove(const Digest &coin_seed, const std::map<uint32_t, uint
                 if ((owner(c) == r) != (my_ext.count(c) == 1)) throw std::runtime_error("extension column c lives on rank c % R");
             ext_blocks = spread_lde(my_ext, nb, ne, &spread_coeff_blocks);
         }
+        air.prepare_program(n, proof.challenges);        // (host work beside the queued transforms: Air::prepare_program)
         ext_com = commit(ext_blocks, N, order);
         proof.has_extension = true;
         proof.extension_root = ext_com->root;
