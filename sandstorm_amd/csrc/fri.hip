@@ -20,13 +20,14 @@
 #include <hip/hip_runtime.h>
 #include "../../include/sandstorm_hip.h"
 #include "fp252.h"
+#include "fl252.h"
 #include "kernels.h"
 
 namespace ss {
 
 struct FriConsts {
     Fp alpha_over_offset, w_inv;        // alpha / offset; w_len^-1
-    Fp tw_inv[8];  // w_fold^(-k), k < fold/2
+    Fp tw_inv[8];  // w_fold^(-k), k < fold/2, in R280 form (times 2^24)
     // w_len^-e from two small tables (a lane's 1 / x_j is one product instead of a 22-bit power: 33 products, twice the fold's own):
     // pow_lo[k] = w^-k, k < 2^lo_bits; pow_hi[k] = w^-(k << lo_bits)
     const Fp *pow_lo, *pow_hi;
@@ -54,19 +55,21 @@ __host__ __device__ constexpr int brev_c(int m, int bits) {
     return r;
 }
 
+// The fold runs in the hot-loop limb form (fl252.h: a row's 14 products at the 9 x 28-bit multiplier's rate, twice the 8 x 32
+// interchange form's - round 6); sums and differences are weakly reduced (normalised, < 2p), the stage twiddles come in R280 form.
 template <int LOGF, int ST>
-__device__ __forceinline__ void fri_stage(Fp (&v)[1 << LOGF], const FriConsts &c) {
+__device__ __forceinline__ void fri_stage(Fl (&v)[1 << LOGF], const Fl (&tw)[8]) {
     if (ST >= LOGF) return;
     constexpr int STC = ST < LOGF ? ST : 0;
     constexpr int half = 1 << STC;
 #pragma unroll
     for (int pr = 0; pr < (1 << LOGF) / 2; ++pr) {
         const int i = ((pr >> STC) << (STC + 1)) | (pr & (half - 1));
-        const int tw = (pr & (half - 1)) << (LOGF - 1 - STC);   // exponent of w_fold^-1
-        const Fp a = v[i], b = v[i | half];
-        v[i] = fp_add(a, b);
-        const Fp d = fp_sub(a, b);
-        v[i | half] = tw == 0 ? d : fp_mul(d, c.tw_inv[tw]);
+        const int t = (pr & (half - 1)) << (LOGF - 1 - STC);   // exponent of w_fold^-1
+        const Fl a = v[i], b = v[i | half];
+        v[i] = fn_add(a, b);
+        const Fl d = fl_sub_c<2, 1>(a, b);                      // lazy (< 4p): a multiplier's operand, or reduced below
+        v[i | half] = t == 0 ? fl_weak_reduce(d) : fl_mul_r280(d, tw[t]);
     }
 }
 
@@ -79,30 +82,35 @@ __global__ __launch_bounds__(128) void fri_fold_kernel(const Fp *__restrict__ ev
     if (i >= rows) return;
     const uint64_t j = row0 + i;
     const bool bitrev_rows = (c.flags & SS_FRI_BITREV_ROWS) != 0;
-    Fp v[F];                                         // v[k] = f(x_j w_fold^k)
+    Fl v[F];                                         // v[k] = f(x_j w_fold^k)
     if (bitrev_rows) {
 #pragma unroll
-        for (int k = 0; k < F; ++k) v[k] = fri_load(evals + i * F + brev_c(k, LOGF));
+        for (int k = 0; k < F; ++k) v[k] = fl_from_fp(fri_load(evals + i * F + brev_c(k, LOGF)));
     } else {
 #pragma unroll
-        for (int k = 0; k < F; ++k) v[k] = fri_load(evals + i + (uint64_t)k * rows);
+        for (int k = 0; k < F; ++k) v[k] = fl_from_fp(fri_load(evals + i + (uint64_t)k * rows));
     }
+    Fl tw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tw[k] = fl_from_fp(c.tw_inv[k]);
     // unnormalised inverse NTT, DIF: natural in, bit-reversed out
-    if (LOGF >= 4) fri_stage<LOGF, 3>(v, c);
-    if (LOGF >= 3) fri_stage<LOGF, 2>(v, c);
-    if (LOGF >= 2) fri_stage<LOGF, 1>(v, c);
-    fri_stage<LOGF, 0>(v, c);
+    if (LOGF >= 4) fri_stage<LOGF, 3>(v, tw);
+    if (LOGF >= 3) fri_stage<LOGF, 2>(v, tw);
+    if (LOGF >= 2) fri_stage<LOGF, 1>(v, tw);
+    fri_stage<LOGF, 0>(v, tw);
     // t = alpha / x_j,  1/x_j = offset^-1 * w^-e,  e = j (natural) or bitrev(j) over the log2(rows) row bits
     const uint32_t row_bits = log_len - LOGF;
     const uint64_t e = bitrev_rows ? (row_bits ? (uint64_t)(__brevll(j) >> (64u - row_bits)) : 0ull) : j;
-    const Fp t = c.pow_lo ? fp_mul(fp_mul(c.alpha_over_offset, fri_load(c.pow_lo + (e & ((1ull << c.lo_bits) - 1ull)))), fri_load(c.pow_hi + (e >> c.lo_bits)))
-                          : fp_mul(c.alpha_over_offset, fp_pow_u64(c.w_inv, e));
-    // Horner over natural-order coefficients c_m = v[bitrev(m)]
-    Fp acc = v[brev_c(F - 1, LOGF)];
+    const Fl ao = fl_from_fp(c.alpha_over_offset);
+    const Fl t = c.pow_lo ? fl_mul(fl_mul(ao, fl_from_fp(fri_load(c.pow_lo + (e & ((1ull << c.lo_bits) - 1ull))))), fl_from_fp(fri_load(c.pow_hi + (e >> c.lo_bits))))
+                          : fl_mul(ao, fl_from_fp(fp_pow_u64(c.w_inv, e)));
+    // Horner over natural-order coefficients c_m = v[bitrev(m)] (t: a product, normalised; the running sum one addition lazy)
+    Fl acc = v[brev_c(F - 1, LOGF)];
 #pragma unroll
-    for (int m = F - 2; m >= 0; --m) acc = fp_add(fp_mul(acc, t), v[brev_c(m, LOGF)]);
+    for (int m = F - 2; m >= 0; --m) acc = fl_add(fl_mul(acc, t), v[brev_c(m, LOGF)]);
     // the butterflies above are an unnormalised inverse NTT: acc = fold * interpolant(alpha)
-    fri_store(out + i, (c.flags & SS_FRI_UNNORMALISED) ? acc : fp_div_pow2(acc, LOGF));
+    const Fp r = fl_to_fp(acc);
+    fri_store(out + i, (c.flags & SS_FRI_UNNORMALISED) ? r : fp_div_pow2(r, LOGF));
 }
 
 // tab[k] = w_inv^k for k < 2^lo_bits, then tab[2^lo_bits + k] = w_inv^(k << lo_bits) for k < 2^hi_bits (once per layer size and
@@ -125,7 +133,10 @@ hipError_t launch_fri_fold(hipStream_t st, const Fp *evals, uint32_t log_len, ui
     c.flags = flags;
     c.alpha_over_offset = fp_mul(alpha, offset_inv); c.w_inv = w_inv;
     c.pow_lo = pow_tab; c.pow_hi = pow_tab ? pow_tab + (1ull << lo_bits) : nullptr; c.lo_bits = lo_bits;
-    for (int k = 0; k < 8; ++k) c.tw_inv[k] = k < (1 << log_fold) / 2 ? fold_tw_inv[k] : fp_zero();
+    // the stage twiddles in R280 form (times 2^24: the butterflies' fl_mul_r280)
+    Fp two24 = fp_zero(); two24.v[0] = 1u << 24;
+    const Fp k24 = fp_to_mont(two24);
+    for (int k = 0; k < 8; ++k) c.tw_inv[k] = k < (1 << log_fold) / 2 ? fp_mul(fold_tw_inv[k], k24) : fp_zero();
     const uint64_t rows = count;
     dim3 grid((uint32_t)((rows + 127) / 128)), block(128);
     switch (log_fold) {
